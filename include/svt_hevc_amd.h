@@ -1,0 +1,279 @@
+/*
+ * svt_hevc_amd.h - C-ABI of the MI355X-native block-analysis hot path of SVT-HEVC.
+ *
+ * Two layers:
+ *
+ *  (1) LEAF layer ("svt_amd_<ReferenceName>"): one entry point per slot of the
+ *      reference's [EB_ASM_TYPE_TOTAL] function-pointer tables, with the exact
+ *      argument list of the reference typedef it replaces, on HOST pointers,
+ *      synchronous.  A maintainer drops these into a third table slot
+ *      (INTEGRATION.md).  They exist for per-call differential parity, not speed.
+ *
+ *  (2) BATCHED layer: one call per picture for the open-loop front half
+ *      (pad + decimate + HME L0/L1/L2 + full-pel 85-PU search + AVC-style
+ *      half/quarter-pel refinement + bi-pred + candidate sort), called from
+ *      MotionEstimationKernel in place of its LCU loop
+ *      (reference: Source/Lib/Codec/EbMotionEstimationProcess.c:706-820).
+ *      Device state lives behind an opaque handle.
+ *
+ * Plain C types only.  All functions return 0 (SVT_AMD_OK) or a negative
+ * SvtAmdStatus; nothing here falls back to a CPU implementation - if the HIP
+ * device or code object is unavailable the call fails with SVT_AMD_ERR_DEVICE.
+ */
+#ifndef SVT_HEVC_AMD_H
+#define SVT_HEVC_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_AMD_API __attribute__((visibility("default")))
+
+typedef enum SvtAmdStatus {
+    SVT_AMD_OK = 0,
+    SVT_AMD_ERR_BAD_PARAM = -1,   /* maps to EB_ErrorBadParameter            (EbApi.h:114-129) */
+    SVT_AMD_ERR_RESOURCES = -2,   /* maps to EB_ErrorInsufficientResources                     */
+    SVT_AMD_ERR_DEVICE = -3       /* HIP failure; maps to EB_ErrorUndefined                    */
+} SvtAmdStatus;
+
+/* ------------------------------------------------------------------------- */
+/* Shared data model                                                         */
+/* ------------------------------------------------------------------------- */
+
+#define SVT_AMD_LCU_SIZE 64
+#define SVT_AMD_ME_PU_COUNT 85        /* MAX_ME_PU_COUNT, EbMotionEstimationLcuResults.h:14 */
+#define SVT_AMD_PAD_FULL 68           /* lcuSize + ME_FILTER_TAP, EbEncHandle.c:901-904     */
+#define SVT_AMD_PAD_QUARTER 32        /* EbEncHandle.c:911-914                              */
+#define SVT_AMD_PAD_SIXTEENTH 16      /* EbEncHandle.c:921-924                              */
+
+/* fractionalSearchMethod values, EbDefinitions.h:756-758 */
+#define SVT_AMD_SUB_SAD_SEARCH 0
+#define SVT_AMD_FULL_SAD_SEARCH 1
+#define SVT_AMD_SSD_SEARCH 2
+
+/* prediction direction, EbDefinitions.h (UNI_PRED_LIST_0/1, BI_PRED) */
+#define SVT_AMD_UNI_PRED_LIST_0 0
+#define SVT_AMD_UNI_PRED_LIST_1 1
+#define SVT_AMD_BI_PRED 2
+
+/*
+ * Per-picture ME/HME controls.  Every field is a value the reference derives
+ * on the host (out of the hot-path scope) and hands to MotionEstimateLcu:
+ *   MeContext_t fields set by SetMeHmeParamsOq / SignalDerivationMeKernelOq
+ *   (EbMotionEstimationProcess.c:54-120, 310-421) and PictureParentControlSet_t
+ *   fields set by PictureDecision (EbPictureDecisionProcess.c:334-470).
+ */
+typedef struct SvtAmdMeParams {
+    uint16_t luma_width;            /* SequenceControlSet_t.lumaWidth  (multiple of 8) */
+    uint16_t luma_height;           /* SequenceControlSet_t.lumaHeight                  */
+    uint8_t  num_lists;             /* 1: P picture (list 0 only), 2: B picture         */
+    uint8_t  temporal_layer_index;  /* pcs->temporalLayerIndex                          */
+    uint8_t  ref_pocs_equal;        /* refPicPocArray[0] == refPicPocArray[1]           */
+    uint8_t  enable_hme_flag;       /* pcs->enableHmeFlag                               */
+    uint8_t  enable_hme_level0;     /* pcs->enableHmeLevel0Flag                         */
+    uint8_t  enable_hme_level1;
+    uint8_t  enable_hme_level2;
+    uint8_t  one_quadrant_hme;      /* MeContext_t.oneQuadrantHME                       */
+    uint8_t  update_hme_search_center; /* MeContext_t.updateHmeSearchCenter             */
+    uint8_t  num_hme_regions_w;     /* numberHmeSearchRegionInWidth  (<= 2)             */
+    uint8_t  num_hme_regions_h;     /* numberHmeSearchRegionInHeight (<= 2)             */
+    uint8_t  search_area_width;     /* MeContext_t.searchAreaWidth  (full-pel)          */
+    uint8_t  search_area_height;
+    uint8_t  fractional_search_method; /* SVT_AMD_*_SEARCH                              */
+    uint8_t  fractional_search_model;  /* 0: all, 1: SuPelEnable gated, 2: off          */
+    uint8_t  fractional_search_64x64;
+    uint8_t  cu8x8_mode;            /* pcs->cu8x8Mode  (1 = no 8x8 refinement/bipred)   */
+    uint8_t  cu16x16_mode;          /* pcs->cu16x16Mode                                 */
+    uint16_t hme_l0_total_w;        /* hmeLevel0TotalSearchAreaWidth                    */
+    uint16_t hme_l0_total_h;
+    uint16_t hme_l0_w[2];           /* hmeLevel0SearchAreaInWidthArray                  */
+    uint16_t hme_l0_h[2];
+    uint16_t hme_l1_w[2];
+    uint16_t hme_l1_h[2];
+    uint16_t hme_l2_w[2];
+    uint16_t hme_l2_h[2];
+    uint16_t hme_l0_mult_x;         /* HME_LEVEL_0_SEARCH_AREA_MULTIPLIER_X[hl][tl], EbDefinitions.h:1322 */
+    uint16_t hme_l0_mult_y;
+    uint32_t lambda;                /* MeContext_t.lambda (SAD lambda, EbMotionEstimationProcess.c:690-698) */
+    uint32_t mvd_bits[12];          /* MeContext_t.mvdBitsArray (NUMBER_OF_MVD_CASES)   */
+} SvtAmdMeParams;
+
+/* One ME candidate record per PU; same content as MeCuResults_t
+ * (EbMotionEstimationLcuResults.h:58-74) with explicit widths. */
+typedef struct SvtAmdMeCuResult {
+    int16_t  x_mv_l0, y_mv_l0, x_mv_l1, y_mv_l1;   /* quarter-pel units */
+    uint32_t distortion[3];                          /* sorted candidates */
+    uint8_t  direction[3];
+    uint8_t  total_me_candidate_index;
+} SvtAmdMeCuResult;
+
+/* Full per-LCU output of the front half (what MotionEstimateLcu leaves behind). */
+typedef struct SvtAmdMeLcuResult {
+    SvtAmdMeCuResult pu[SVT_AMD_ME_PU_COUNT];        /* raster-within-tier order = meResults[lcu][pu] */
+    uint32_t best_sad[2][SVT_AMD_ME_PU_COUNT];       /* pLcuBestSad[list][0][], internal Z order      */
+    uint32_t best_mv[2][SVT_AMD_ME_PU_COUNT];        /* pLcuBestMV, (y<<16)|x quarter-pel             */
+    int16_t  hme_center_x[2], hme_center_y[2];       /* search centre fed to the full-pel search      */
+    int16_t  search_origin_x[2], search_origin_y[2]; /* x/ySearchAreaOrigin[list][0]                  */
+    uint8_t  search_w[2], search_h[2];               /* clipped search area                           */
+} SvtAmdMeLcuResult;
+
+/* ------------------------------------------------------------------------- */
+/* BATCHED layer                                                             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct SvtAmdContext SvtAmdContext;          /* opaque; owns device, stream, arenas */
+
+/* Library/device bring-up.  Replaces nothing in the reference: called from
+ * EbInitEncoder/EbDeinitEncoder (EbEncHandle.c:689,1519) by the hook overlay. */
+SVT_AMD_API int svt_amd_context_create(int device_ordinal, uint16_t max_luma_width,
+                                       uint16_t max_luma_height, int num_picture_slots,
+                                       SvtAmdContext **out_ctx);
+SVT_AMD_API void svt_amd_context_destroy(SvtAmdContext *ctx);
+SVT_AMD_API const char *svt_amd_version(void);
+SVT_AMD_API const char *svt_amd_last_error(void);
+
+/*
+ * Upload one source luma plane into picture slot `slot` and build, on the
+ * device, everything the PA reference object holds for ME:
+ *   padded full-resolution plane      (GeneratePadding,   EbMcp.c:1017)
+ *   1/4 and 1/16 point-decimated planes + their padding
+ *                                     (DecimateInputPicture, EbPictureAnalysisProcess.c:4139;
+ *                                      Decimation2D :173)
+ *   AVC-style half-pel planes b, h, j (EbHevcInterpolateSearchRegionAVC, EbMotionEstimation.c:645;
+ *                                      AvcStyleLumaInterpolationFilterHorizontal/Vertical,
+ *                                      C_DEFAULT/EbAvcStyleMcp_C.c:34,62), computed once per picture
+ *                                      instead of once per LCU per list.
+ * `luma` is a HOST pointer to width x height samples with `stride` bytes per row.
+ */
+SVT_AMD_API int svt_amd_picture_upload(SvtAmdContext *ctx, int slot, const uint8_t *luma,
+                                       uint32_t stride, uint16_t width, uint16_t height);
+
+/* Same, but the plane already lives in device memory (bench / multi-GPU path). */
+SVT_AMD_API int svt_amd_picture_upload_device(SvtAmdContext *ctx, int slot, const void *d_luma,
+                                              uint32_t stride, uint16_t width, uint16_t height);
+
+/*
+ * Motion estimation of one whole picture (all LCUs), replaces the LCU loop of
+ * MotionEstimationKernel (EbMotionEstimationProcess.c:706-820) and
+ * MotionEstimateLcu (EbMotionEstimation.c:3671-4450).
+ *   cur_slot          picture being coded
+ *   ref_slot[l]       PA reference picture of list l (ref_slot[1] ignored for P)
+ *   out               HOST array of picWidthInLcu*picHeightInLcu records, raster LCU order
+ * Blocking: returns when `out` is filled.
+ */
+SVT_AMD_API int svt_amd_me_picture(SvtAmdContext *ctx, const SvtAmdMeParams *params,
+                                   int cur_slot, const int ref_slot[2],
+                                   SvtAmdMeLcuResult *out);
+
+/* Asynchronous form: results stay in device memory (slot-owned buffer) until
+ * svt_amd_me_picture_fetch copies them out.  Used by bench.py and by a host
+ * that overlaps ME of picture n+1 with EncDec of picture n. */
+SVT_AMD_API int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params,
+                                          int cur_slot, const int ref_slot[2]);
+SVT_AMD_API int svt_amd_me_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out);
+SVT_AMD_API int svt_amd_synchronize(SvtAmdContext *ctx);
+
+/* Device-side timing of the launches issued between begin/end on the context's
+ * own stream (HIP events); used for roofline.achieved in bench.py. */
+SVT_AMD_API int svt_amd_timer_begin(SvtAmdContext *ctx);
+SVT_AMD_API int svt_amd_timer_end(SvtAmdContext *ctx, float *elapsed_ms);
+/* Average duration (ms) and launch count of the named kernel class since the
+ * last svt_amd_timer_begin; kernel_class in {"me_search","me_subpel","prep"} */
+SVT_AMD_API int svt_amd_kernel_time(SvtAmdContext *ctx, const char *kernel_class,
+                                    float *avg_ms, int *launches);
+
+/* Debug/parity access to the device-built planes of a slot (host copies).
+ * which: 0 full, 1 quarter, 2 sixteenth, 3 half-pel b, 4 half-pel h, 5 half-pel j.
+ * Copies the whole padded allocation; out_stride / out_pad describe it. */
+SVT_AMD_API int svt_amd_picture_read_plane(SvtAmdContext *ctx, int slot, int which, uint8_t *dst,
+                                           size_t dst_capacity, uint32_t *out_stride,
+                                           uint32_t *out_pad, uint32_t *out_rows);
+
+/* ------------------------------------------------------------------------- */
+/* LEAF layer (table-slot replacements; host pointers; synchronous)          */
+/* Each comment names the reference typedef/table and the C_DEFAULT symbol.  */
+/* ------------------------------------------------------------------------- */
+
+/* EB_SADKERNELNxM_TYPE, NxMSadKernel_funcPtrArray (EbComputeSAD.h:95);
+ * C peer FastLoop_NxMSadKernel (C_DEFAULT/EbComputeSAD_C.c:147). */
+SVT_AMD_API uint32_t svt_amd_NxMSadKernel(const uint8_t *src, uint32_t srcStride,
+                                          const uint8_t *ref, uint32_t refStride,
+                                          uint32_t height, uint32_t width);
+
+/* EB_SADLOOPKERNELNxM_TYPE, NxMSadLoopKernel_funcPtrArray (EbComputeSAD.h:152);
+ * C peer SadLoopKernel (C_DEFAULT/EbComputeSAD_C.c:170). */
+SVT_AMD_API void svt_amd_SadLoopKernel(const uint8_t *src, uint32_t srcStride,
+                                       const uint8_t *ref, uint32_t refStride,
+                                       uint32_t height, uint32_t width, uint64_t *bestSad,
+                                       int16_t *xSearchCenter, int16_t *ySearchCenter,
+                                       uint32_t srcStrideRaw, int16_t searchAreaWidth,
+                                       int16_t searchAreaHeight);
+
+/* EB_SADAVGKERNELNxM_TYPE, NxMSadAveragingKernel_funcPtrArray (EbComputeSAD.h:123);
+ * C peer CombinedAveragingSAD (C_DEFAULT/EbComputeSAD_C.c:14). */
+SVT_AMD_API uint32_t svt_amd_NxMSadAveragingKernel(const uint8_t *src, uint32_t srcStride,
+                                                   const uint8_t *ref1, uint32_t ref1Stride,
+                                                   const uint8_t *ref2, uint32_t ref2Stride,
+                                                   uint32_t height, uint32_t width);
+
+/* GetEightHorizontalSearchPointResults_8x8_16x16_funcPtrArray (EbComputeSAD.h);
+ * C peer GetEightHorizontalSearchPointResults_8x8_16x16_PU (EbComputeSAD_C.c:252). */
+SVT_AMD_API void svt_amd_GetEightHorizontalSearchPointResults_8x8_16x16_PU(
+    const uint8_t *src, uint32_t srcStride, const uint8_t *ref, uint32_t refStride,
+    uint32_t *pBestSad8x8, uint32_t *pBestMV8x8, uint32_t *pBestSad16x16,
+    uint32_t *pBestMV16x16, uint32_t mv, uint16_t *pSad16x16);
+
+/* GetEightHorizontalSearchPointResults_32x32_64x64_funcPtrArray;
+ * C peer GetEightHorizontalSearchPointResults_32x32_64x64 (EbComputeSAD_C.c:372). */
+SVT_AMD_API void svt_amd_GetEightHorizontalSearchPointResults_32x32_64x64(
+    const uint16_t *pSad16x16, uint32_t *pBestSad32x32, uint32_t *pBestSad64x64,
+    uint32_t *pBestMV32x32, uint32_t *pBestMV64x64, uint32_t mv);
+
+/* SadCalculation_8x8_16x16_funcPtrArray (EbMeSadCalculation.h:106);
+ * C peer SadCalculation_8x8_16x16 (C_DEFAULT/EbMeSadCalculation_C.c:14). */
+SVT_AMD_API void svt_amd_SadCalculation_8x8_16x16(
+    const uint8_t *src, uint32_t srcStride, const uint8_t *ref, uint32_t refStride,
+    uint32_t *pBestSad8x8, uint32_t *pBestSad16x16, uint32_t *pBestMV8x8,
+    uint32_t *pBestMV16x16, uint32_t mv, uint32_t *pSad16x16);
+
+/* SadCalculation_32x32_64x64_funcPtrArray; C peer EbMeSadCalculation_C.c:64. */
+SVT_AMD_API void svt_amd_SadCalculation_32x32_64x64(
+    const uint32_t *pSad16x16, uint32_t *pBestSad32x32, uint32_t *pBestSad64x64,
+    uint32_t *pBestMV32x32, uint32_t *pBestMV64x64, uint32_t mv);
+
+/* AvcStyleUniPredLumaIFFunctionPtrArray[..][1|2] (EbAvcStyleMcp.h:111);
+ * C peers AvcStyleLumaInterpolationFilterHorizontal/Vertical (EbAvcStyleMcp_C.c:34,62). */
+SVT_AMD_API void svt_amd_AvcStyleLumaInterpolationFilterHorizontal(
+    const uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+    uint32_t puWidth, uint32_t puHeight, uint8_t *tempBuf, uint32_t fracPos);
+SVT_AMD_API void svt_amd_AvcStyleLumaInterpolationFilterVertical(
+    const uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+    uint32_t puWidth, uint32_t puHeight, uint8_t *tempBuf, uint32_t fracPos);
+
+/* PictureAverageArray (EbAvcStyleMcp.h:129); C peer PictureAverageKernel
+ * (C_DEFAULT/EbPictureOperators_C.c:46). */
+SVT_AMD_API void svt_amd_PictureAverageKernel(const uint8_t *src0, uint32_t src0Stride,
+                                              const uint8_t *src1, uint32_t src1Stride,
+                                              uint8_t *dst, uint32_t dstStride,
+                                              uint32_t areaWidth, uint32_t areaHeight);
+
+/* SpatialFullDistortionKernel_funcPtrArray (EbPictureOperators.h:633);
+ * C peer SpatialFullDistortionKernel (C_DEFAULT/EbPictureOperators_C.c:643). */
+SVT_AMD_API uint64_t svt_amd_SpatialFullDistortionKernel(const uint8_t *input, uint32_t inputStride,
+                                                         const uint8_t *recon, uint32_t reconStride,
+                                                         uint32_t areaWidth, uint32_t areaHeight);
+
+/* Decimation2D (EbPictureAnalysisProcess.c:173) - not table-dispatched in the
+ * reference but the producer of the HME inputs. */
+SVT_AMD_API void svt_amd_Decimation2D(const uint8_t *inputSamples, uint32_t inputStride,
+                                      uint32_t inputAreaWidth, uint32_t inputAreaHeight,
+                                      uint8_t *decimSamples, uint32_t decimStride,
+                                      uint32_t decimStep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HEVC_AMD_H */

@@ -1,0 +1,100 @@
+/*
+ * oracle/svt_oracle.h - TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the SVT-HEVC block-analysis hot path, used as the
+ * bit-exact checker for the HIP path (tests/, __graft_entry__.smoke(),
+ * bench.py's cpu_baseline leg).  Nothing in the product (svt-hevc_amd/) may
+ * include, link or call this.  Pinning: every function here is checked against
+ * the reference itself, compiled into oracle/_ref/libsvtref.so from
+ * /root/reference (tests/test_oracle_vs_ref.py) and against golden fixtures
+ * produced by that build (tests/golden/, tests/golden/make_me_golden.py).
+ *
+ * Each function cites the reference file:line it restates
+ * (paths relative to /root/reference/Source/Lib).
+ */
+#ifndef SVT_ORACLE_H
+#define SVT_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "../include/svt_hevc_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- leaf kernels (same signatures as the reference C_DEFAULT symbols) ---- */
+uint32_t svt_oracle_NxMSadKernel(const uint8_t *src, uint32_t srcStride, const uint8_t *ref,
+                                 uint32_t refStride, uint32_t height, uint32_t width);
+void svt_oracle_SadLoopKernel(const uint8_t *src, uint32_t srcStride, const uint8_t *ref,
+                              uint32_t refStride, uint32_t height, uint32_t width,
+                              uint64_t *bestSad, int16_t *xSearchCenter, int16_t *ySearchCenter,
+                              uint32_t srcStrideRaw, int16_t searchAreaWidth,
+                              int16_t searchAreaHeight);
+uint32_t svt_oracle_NxMSadAveragingKernel(const uint8_t *src, uint32_t srcStride,
+                                          const uint8_t *ref1, uint32_t ref1Stride,
+                                          const uint8_t *ref2, uint32_t ref2Stride,
+                                          uint32_t height, uint32_t width);
+void svt_oracle_GetEightHorizontalSearchPointResults_8x8_16x16_PU(
+    const uint8_t *src, uint32_t srcStride, const uint8_t *ref, uint32_t refStride,
+    uint32_t *pBestSad8x8, uint32_t *pBestMV8x8, uint32_t *pBestSad16x16,
+    uint32_t *pBestMV16x16, uint32_t mv, uint16_t *pSad16x16);
+void svt_oracle_GetEightHorizontalSearchPointResults_32x32_64x64(
+    const uint16_t *pSad16x16, uint32_t *pBestSad32x32, uint32_t *pBestSad64x64,
+    uint32_t *pBestMV32x32, uint32_t *pBestMV64x64, uint32_t mv);
+void svt_oracle_SadCalculation_8x8_16x16(const uint8_t *src, uint32_t srcStride,
+                                         const uint8_t *ref, uint32_t refStride,
+                                         uint32_t *pBestSad8x8, uint32_t *pBestSad16x16,
+                                         uint32_t *pBestMV8x8, uint32_t *pBestMV16x16,
+                                         uint32_t mv, uint32_t *pSad16x16);
+void svt_oracle_SadCalculation_32x32_64x64(const uint32_t *pSad16x16, uint32_t *pBestSad32x32,
+                                           uint32_t *pBestSad64x64, uint32_t *pBestMV32x32,
+                                           uint32_t *pBestMV64x64, uint32_t mv);
+void svt_oracle_AvcStyleLumaInterpolationFilterHorizontal(
+    const uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+    uint32_t puWidth, uint32_t puHeight, uint8_t *tempBuf, uint32_t fracPos);
+void svt_oracle_AvcStyleLumaInterpolationFilterVertical(
+    const uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+    uint32_t puWidth, uint32_t puHeight, uint8_t *tempBuf, uint32_t fracPos);
+void svt_oracle_PictureAverageKernel(const uint8_t *src0, uint32_t src0Stride,
+                                     const uint8_t *src1, uint32_t src1Stride, uint8_t *dst,
+                                     uint32_t dstStride, uint32_t areaWidth, uint32_t areaHeight);
+uint64_t svt_oracle_SpatialFullDistortionKernel(const uint8_t *input, uint32_t inputStride,
+                                                const uint8_t *recon, uint32_t reconStride,
+                                                uint32_t areaWidth, uint32_t areaHeight);
+void svt_oracle_Decimation2D(const uint8_t *inputSamples, uint32_t inputStride,
+                             uint32_t inputAreaWidth, uint32_t inputAreaHeight,
+                             uint8_t *decimSamples, uint32_t decimStride, uint32_t decimStep);
+
+/* ---- picture-level ME (restates MotionEstimationKernel's LCU loop) -------- */
+
+/* A padded 8-bit plane: sample (x,y), x in [-pad, width+pad), is
+ * data[(y + pad) * stride + (x + pad)]. */
+typedef struct SvtOraclePlane {
+    uint8_t *data;
+    uint32_t stride;
+    uint32_t pad;
+    uint32_t width, height;
+} SvtOraclePlane;
+
+/* Everything ME reads of one picture (EbPaReferenceObject_t + derived half-pel planes). */
+typedef struct SvtOraclePicture {
+    SvtOraclePlane full, quarter, sixteenth; /* inputPadded / quarterDecimated / sixteenthDecimated */
+    SvtOraclePlane hp_b, hp_h, hp_j;         /* AVC-style half-pel planes, geometry of `full`       */
+} SvtOraclePicture;
+
+/* Build from a raw luma plane; returns NULL on allocation failure. */
+SvtOraclePicture *svt_oracle_picture_create(const uint8_t *luma, uint32_t stride,
+                                            uint32_t width, uint32_t height);
+void svt_oracle_picture_destroy(SvtOraclePicture *pic);
+
+/* ME of LCUs [lcu_begin, lcu_end) of one picture (raster LCU order);
+ * out[] is indexed by absolute LCU index. */
+int svt_oracle_me_picture(const SvtAmdMeParams *params, const SvtOraclePicture *cur,
+                          const SvtOraclePicture *ref0, const SvtOraclePicture *ref1,
+                          uint32_t lcu_begin, uint32_t lcu_end, SvtAmdMeLcuResult *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

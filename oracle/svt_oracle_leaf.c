@@ -1,0 +1,249 @@
+/*
+ * oracle/svt_oracle_leaf.c - TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
+ * CPU restatement of the SAD / interpolation / picture-operator leaf kernels
+ * of the ME front half.  Citations: /root/reference/Source/Lib/...
+ */
+#include "svt_oracle.h"
+
+static inline uint32_t absdiff(uint8_t a, uint8_t b) { return a > b ? (uint32_t)(a - b) : (uint32_t)(b - a); }
+
+/* FastLoop_NxMSadKernel, C_DEFAULT/EbComputeSAD_C.c:147-168: plain NxM SAD, all rows. */
+uint32_t svt_oracle_NxMSadKernel(const uint8_t *src, uint32_t srcStride, const uint8_t *ref,
+                                 uint32_t refStride, uint32_t height, uint32_t width)
+{
+    uint32_t sad = 0;
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++)
+            sad += absdiff(src[y * srcStride + x], ref[y * refStride + x]);
+    return sad;
+}
+
+/* SadLoopKernel, C_DEFAULT/EbComputeSAD_C.c:170-214: exhaustive raster search,
+ * best initialised to 0xffffff, strict '<' so the first minimum in raster order
+ * wins; the reference row pointer advances by srcStrideRaw per search row. */
+void svt_oracle_SadLoopKernel(const uint8_t *src, uint32_t srcStride, const uint8_t *ref,
+                              uint32_t refStride, uint32_t height, uint32_t width,
+                              uint64_t *bestSad, int16_t *xSearchCenter, int16_t *ySearchCenter,
+                              uint32_t srcStrideRaw, int16_t searchAreaWidth,
+                              int16_t searchAreaHeight)
+{
+    *bestSad = 0xffffff;
+    for (int16_t sy = 0; sy < searchAreaHeight; sy++) {
+        for (int16_t sx = 0; sx < searchAreaWidth; sx++) {
+            uint32_t sad = svt_oracle_NxMSadKernel(src, srcStride, ref + sx, refStride, height, width);
+            if (sad < *bestSad) {
+                *bestSad = sad;
+                *xSearchCenter = sx;
+                *ySearchCenter = sy;
+            }
+        }
+        ref += srcStrideRaw;
+    }
+}
+
+/* CombinedAveragingSAD, C_DEFAULT/EbComputeSAD_C.c:14-41: SAD(src, (ref1+ref2+1)>>1). */
+uint32_t svt_oracle_NxMSadAveragingKernel(const uint8_t *src, uint32_t srcStride,
+                                          const uint8_t *ref1, uint32_t ref1Stride,
+                                          const uint8_t *ref2, uint32_t ref2Stride,
+                                          uint32_t height, uint32_t width)
+{
+    uint32_t sad = 0;
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            uint8_t avg = (uint8_t)((ref1[y * ref1Stride + x] + ref2[y * ref2Stride + x] + 1) >> 1);
+            sad += absdiff(src[y * srcStride + x], avg);
+        }
+    return sad;
+}
+
+/* Subsad8x8, C_DEFAULT/EbComputeSAD_C.c:216-238: 8 wide, rows 0,2,4,6 only. */
+static uint32_t sad8x8_even_rows(const uint8_t *src, uint32_t srcStride, const uint8_t *ref, uint32_t refStride)
+{
+    uint32_t s = 0;
+    for (uint32_t y = 0; y < 8; y += 2)
+        for (uint32_t x = 0; x < 8; x++)
+            s += absdiff(src[y * srcStride + x], ref[y * refStride + x]);
+    return s;
+}
+
+static inline int16_t mvx(uint32_t mv) { return (int16_t)(mv & 0xffff); }
+static inline int16_t mvy(uint32_t mv) { return (int16_t)(mv >> 16); }
+static inline uint32_t mvpack(int16_t x, int16_t y) { return ((uint32_t)(uint16_t)y << 16) | (uint16_t)x; }
+
+/* GetEightHorizontalSearchPointResults_8x8_16x16_PU, C_DEFAULT/EbComputeSAD_C.c:252-366.
+ * For 8 consecutive x positions: four even-row 8x8 SADs, doubled, '<' update of the
+ * best 8x8s and the best 16x16; the undoubled 16x16 sum is stored truncated to u16. */
+void svt_oracle_GetEightHorizontalSearchPointResults_8x8_16x16_PU(
+    const uint8_t *src, uint32_t srcStride, const uint8_t *ref, uint32_t refStride,
+    uint32_t *pBestSad8x8, uint32_t *pBestMV8x8, uint32_t *pBestSad16x16,
+    uint32_t *pBestMV16x16, uint32_t mv, uint16_t *pSad16x16)
+{
+    for (uint32_t i = 0; i < 8; i++) {
+        uint32_t s[4];
+        uint32_t here = mvpack((int16_t)(mvx(mv) + (int16_t)i * 4), mvy(mv));
+        s[0] = sad8x8_even_rows(src, srcStride, ref + i, refStride);
+        s[1] = sad8x8_even_rows(src + 8, srcStride, ref + i + 8, refStride);
+        s[2] = sad8x8_even_rows(src + 8 * srcStride, srcStride, ref + i + 8 * refStride, refStride);
+        s[3] = sad8x8_even_rows(src + 8 + 8 * srcStride, srcStride, ref + i + 8 + 8 * refStride, refStride);
+        for (int k = 0; k < 4; k++)
+            if (2 * s[k] < pBestSad8x8[k]) {
+                pBestSad8x8[k] = 2 * s[k];
+                pBestMV8x8[k] = here;
+            }
+        uint16_t s16 = (uint16_t)(s[0] + s[1] + s[2] + s[3]);
+        pSad16x16[i] = s16;
+        if ((uint32_t)(2 * s16) < pBestSad16x16[0]) {
+            pBestSad16x16[0] = 2 * s16;
+            pBestMV16x16[0] = here;
+        }
+    }
+}
+
+/* GetEightHorizontalSearchPointResults_32x32_64x64, C_DEFAULT/EbComputeSAD_C.c:372-449.
+ * pSad16x16[k*8 + i]: k = 16x16 index in Z order, i = position.  32x32 uses '<',
+ * 64x64 uses '<=' (later position wins ties). */
+void svt_oracle_GetEightHorizontalSearchPointResults_32x32_64x64(
+    const uint16_t *pSad16x16, uint32_t *pBestSad32x32, uint32_t *pBestSad64x64,
+    uint32_t *pBestMV32x32, uint32_t *pBestMV64x64, uint32_t mv)
+{
+    for (uint32_t i = 0; i < 8; i++) {
+        uint32_t here = mvpack((int16_t)(mvx(mv) + (int16_t)i * 4), mvy(mv));
+        uint32_t s64 = 0;
+        for (int q = 0; q < 4; q++) {
+            uint32_t s32 = (uint32_t)pSad16x16[(4 * q + 0) * 8 + i] + pSad16x16[(4 * q + 1) * 8 + i] +
+                           pSad16x16[(4 * q + 2) * 8 + i] + pSad16x16[(4 * q + 3) * 8 + i];
+            if (2 * s32 < pBestSad32x32[q]) {
+                pBestSad32x32[q] = 2 * s32;
+                pBestMV32x32[q] = here;
+            }
+            s64 += s32;
+        }
+        if (2 * s64 <= pBestSad64x64[0]) {
+            pBestSad64x64[0] = 2 * s64;
+            pBestMV64x64[0] = here;
+        }
+    }
+}
+
+/* Compute8x4SAD_Kernel (EbComputeSAD_C.c:47-70) on doubled strides == even rows. */
+/* SadCalculation_8x8_16x16, C_DEFAULT/EbMeSadCalculation_C.c:14-62: single position. */
+void svt_oracle_SadCalculation_8x8_16x16(const uint8_t *src, uint32_t srcStride,
+                                         const uint8_t *ref, uint32_t refStride,
+                                         uint32_t *pBestSad8x8, uint32_t *pBestSad16x16,
+                                         uint32_t *pBestMV8x8, uint32_t *pBestMV16x16,
+                                         uint32_t mv, uint32_t *pSad16x16)
+{
+    uint64_t s[4];
+    s[0] = (uint64_t)sad8x8_even_rows(src, srcStride, ref, refStride) << 1;
+    s[1] = (uint64_t)sad8x8_even_rows(src + 8, srcStride, ref + 8, refStride) << 1;
+    s[2] = (uint64_t)sad8x8_even_rows(src + 8 * srcStride, srcStride, ref + 8 * refStride, refStride) << 1;
+    s[3] = (uint64_t)sad8x8_even_rows(src + 8 * srcStride + 8, srcStride, ref + 8 * refStride + 8, refStride) << 1;
+    for (int k = 0; k < 4; k++)
+        if (s[k] < pBestSad8x8[k]) {
+            pBestSad8x8[k] = (uint32_t)s[k];
+            pBestMV8x8[k] = mv;
+        }
+    uint64_t s16 = s[0] + s[1] + s[2] + s[3];
+    if (s16 < pBestSad16x16[0]) {
+        pBestSad16x16[0] = (uint32_t)s16;
+        pBestMV16x16[0] = mv;
+    }
+    *pSad16x16 = (uint32_t)s16;
+}
+
+/* SadCalculation_32x32_64x64, C_DEFAULT/EbMeSadCalculation_C.c:64-98: all '<'. */
+void svt_oracle_SadCalculation_32x32_64x64(const uint32_t *pSad16x16, uint32_t *pBestSad32x32,
+                                           uint32_t *pBestSad64x64, uint32_t *pBestMV32x32,
+                                           uint32_t *pBestMV64x64, uint32_t mv)
+{
+    uint32_t s64 = 0;
+    for (int q = 0; q < 4; q++) {
+        uint32_t s32 = pSad16x16[4 * q] + pSad16x16[4 * q + 1] + pSad16x16[4 * q + 2] + pSad16x16[4 * q + 3];
+        if (s32 < pBestSad32x32[q]) {
+            pBestSad32x32[q] = s32;
+            pBestMV32x32[q] = mv;
+        }
+        s64 += s32;
+    }
+    if (s64 < pBestSad64x64[0]) {
+        pBestSad64x64[0] = s64;
+        pBestMV64x64[0] = mv;
+    }
+}
+
+/* AvcStyleLumaIFCoeff, C_DEFAULT/EbAvcStyleMcp_C.c:10-15 */
+static const int8_t avc_coeff[4][4] = {{0, 0, 0, 0}, {-1, 25, 9, -1}, {-2, 18, 18, -2}, {-1, 9, 25, -1}};
+static inline uint8_t clip255(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+/* AvcStyleLumaInterpolationFilterHorizontal, C_DEFAULT/EbAvcStyleMcp_C.c:34-60:
+ * taps at x-1..x+2, (sum + 16) >> 5, clip to 8 bits. */
+void svt_oracle_AvcStyleLumaInterpolationFilterHorizontal(
+    const uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+    uint32_t puWidth, uint32_t puHeight, uint8_t *tempBuf, uint32_t fracPos)
+{
+    const int8_t *c = avc_coeff[fracPos];
+    (void)tempBuf;
+    refPic -= 1;
+    for (uint32_t y = 0; y < puHeight; y++) {
+        for (uint32_t x = 0; x < puWidth; x++)
+            dst[x] = clip255((refPic[x] * c[0] + refPic[x + 1] * c[1] + refPic[x + 2] * c[2] +
+                              refPic[x + 3] * c[3] + 16) >> 5);
+        refPic += srcStride;
+        dst += dstStride;
+    }
+}
+
+/* AvcStyleLumaInterpolationFilterVertical, C_DEFAULT/EbAvcStyleMcp_C.c:62-90. */
+void svt_oracle_AvcStyleLumaInterpolationFilterVertical(
+    const uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+    uint32_t puWidth, uint32_t puHeight, uint8_t *tempBuf, uint32_t fracPos)
+{
+    const int8_t *c = avc_coeff[fracPos];
+    const int32_t s = (int32_t)srcStride;
+    (void)tempBuf;
+    refPic -= s;
+    for (uint32_t y = 0; y < puHeight; y++) {
+        for (uint32_t x = 0; x < puWidth; x++)
+            dst[x] = clip255((refPic[x] * c[0] + refPic[x + s] * c[1] + refPic[x + 2 * s] * c[2] +
+                              refPic[x + 3 * s] * c[3] + 16) >> 5);
+        refPic += srcStride;
+        dst += dstStride;
+    }
+}
+
+/* PictureAverageKernel, C_DEFAULT/EbPictureOperators_C.c:46-66: (a + b + 1) >> 1. */
+void svt_oracle_PictureAverageKernel(const uint8_t *src0, uint32_t src0Stride,
+                                     const uint8_t *src1, uint32_t src1Stride, uint8_t *dst,
+                                     uint32_t dstStride, uint32_t areaWidth, uint32_t areaHeight)
+{
+    for (uint32_t y = 0; y < areaHeight; y++)
+        for (uint32_t x = 0; x < areaWidth; x++)
+            dst[y * dstStride + x] = (uint8_t)((src0[y * src0Stride + x] + src1[y * src1Stride + x] + 1) >> 1);
+}
+
+/* SpatialFullDistortionKernel, C_DEFAULT/EbPictureOperators_C.c:643-668: pixel SSE. */
+uint64_t svt_oracle_SpatialFullDistortionKernel(const uint8_t *input, uint32_t inputStride,
+                                                const uint8_t *recon, uint32_t reconStride,
+                                                uint32_t areaWidth, uint32_t areaHeight)
+{
+    uint64_t d = 0;
+    for (uint32_t y = 0; y < areaHeight; y++)
+        for (uint32_t x = 0; x < areaWidth; x++) {
+            int64_t e = (int64_t)input[y * inputStride + x] - recon[y * reconStride + x];
+            d += (uint64_t)(e * e);
+        }
+    return d;
+}
+
+/* Decimation2D, Codec/EbPictureAnalysisProcess.c:173-197: point sub-sampling. */
+void svt_oracle_Decimation2D(const uint8_t *inputSamples, uint32_t inputStride,
+                             uint32_t inputAreaWidth, uint32_t inputAreaHeight,
+                             uint8_t *decimSamples, uint32_t decimStride, uint32_t decimStep)
+{
+    for (uint32_t v = 0; v < inputAreaHeight; v += decimStep) {
+        for (uint32_t h = 0; h < inputAreaWidth; h += decimStep)
+            decimSamples[h >> (decimStep >> 1)] = inputSamples[h];
+        inputSamples += inputStride << (decimStep >> 1);
+        decimSamples += decimStride;
+    }
+}

@@ -1,0 +1,300 @@
+"""Shared test/bench plumbing: ctypes views of include/svt_hevc_amd.h, loaders for
+the three libraries (product HIP library, oracle restatement, reference build)
+and the seeded synthetic clips of SURVEY.md section 8d.
+
+Only tests/, bench.py and __graft_entry__.py import this module; the oracle and
+reference loaders are test infrastructure (checker / CPU baseline only).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCT_SO = os.path.join(ROOT, "svt-hevc_amd", "libsvt_hevc_amd.so")
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsvtref.so")
+REF_APP = os.path.join(ROOT, "oracle", "_ref", "SvtHevcEncApp_ref")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+ME_PU_COUNT = 85
+PAD_FULL, PAD_QUARTER, PAD_SIXTEENTH = 68, 32, 16
+
+
+class MeParams(C.Structure):
+    """SvtAmdMeParams"""
+    _fields_ = [
+        ("luma_width", C.c_uint16), ("luma_height", C.c_uint16),
+        ("num_lists", C.c_uint8), ("temporal_layer_index", C.c_uint8),
+        ("ref_pocs_equal", C.c_uint8), ("enable_hme_flag", C.c_uint8),
+        ("enable_hme_level0", C.c_uint8), ("enable_hme_level1", C.c_uint8),
+        ("enable_hme_level2", C.c_uint8), ("one_quadrant_hme", C.c_uint8),
+        ("update_hme_search_center", C.c_uint8), ("num_hme_regions_w", C.c_uint8),
+        ("num_hme_regions_h", C.c_uint8), ("search_area_width", C.c_uint8),
+        ("search_area_height", C.c_uint8), ("fractional_search_method", C.c_uint8),
+        ("fractional_search_model", C.c_uint8), ("fractional_search_64x64", C.c_uint8),
+        ("cu8x8_mode", C.c_uint8), ("cu16x16_mode", C.c_uint8),
+        ("hme_l0_total_w", C.c_uint16), ("hme_l0_total_h", C.c_uint16),
+        ("hme_l0_w", C.c_uint16 * 2), ("hme_l0_h", C.c_uint16 * 2),
+        ("hme_l1_w", C.c_uint16 * 2), ("hme_l1_h", C.c_uint16 * 2),
+        ("hme_l2_w", C.c_uint16 * 2), ("hme_l2_h", C.c_uint16 * 2),
+        ("hme_l0_mult_x", C.c_uint16), ("hme_l0_mult_y", C.c_uint16),
+        ("lambda_", C.c_uint32), ("mvd_bits", C.c_uint32 * 12),
+    ]
+
+
+class MeCuResult(C.Structure):
+    """SvtAmdMeCuResult"""
+    _fields_ = [
+        ("x_mv_l0", C.c_int16), ("y_mv_l0", C.c_int16),
+        ("x_mv_l1", C.c_int16), ("y_mv_l1", C.c_int16),
+        ("distortion", C.c_uint32 * 3), ("direction", C.c_uint8 * 3),
+        ("total_me_candidate_index", C.c_uint8),
+    ]
+
+
+class MeLcuResult(C.Structure):
+    """SvtAmdMeLcuResult"""
+    _fields_ = [
+        ("pu", MeCuResult * ME_PU_COUNT),
+        ("best_sad", (C.c_uint32 * ME_PU_COUNT) * 2),
+        ("best_mv", (C.c_uint32 * ME_PU_COUNT) * 2),
+        ("hme_center_x", C.c_int16 * 2), ("hme_center_y", C.c_int16 * 2),
+        ("search_origin_x", C.c_int16 * 2), ("search_origin_y", C.c_int16 * 2),
+        ("search_w", C.c_uint8 * 2), ("search_h", C.c_uint8 * 2),
+    ]
+
+
+# numpy dtypes with the same layout (checked in tests/test_abi.py)
+ME_CU_DTYPE = np.dtype([("mv", "<i2", (4,)), ("distortion", "<u4", (3,)),
+                        ("direction", "u1", (3,)), ("total", "u1")], align=True)
+ME_LCU_DTYPE = np.dtype([("pu", ME_CU_DTYPE, (ME_PU_COUNT,)),
+                         ("best_sad", "<u4", (2, ME_PU_COUNT)),
+                         ("best_mv", "<u4", (2, ME_PU_COUNT)),
+                         ("hme_center_x", "<i2", (2,)), ("hme_center_y", "<i2", (2,)),
+                         ("search_origin_x", "<i2", (2,)), ("search_origin_y", "<i2", (2,)),
+                         ("search_w", "u1", (2,)), ("search_h", "u1", (2,))], align=True)
+ME_PARAMS_DTYPE = np.dtype(MeParams)
+
+DUMP_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"),
+                       ("ref_poc", "<u8", (2,)), ("lcu_index", "<u4"), ("lcu_origin_x", "<u4"),
+                       ("lcu_origin_y", "<u4"), ("slice_type", "<u4"), ("enc_mode", "<u4"),
+                       ("luma_crc", "<u4"), ("ref_crc", "<u4", (2,)),
+                       ("params", ME_PARAMS_DTYPE), ("result", ME_LCU_DTYPE)], align=True)
+
+
+def params_from_record(rec):
+    """numpy record with ME_PARAMS_DTYPE -> MeParams ctypes struct"""
+    p = MeParams()
+    C.memmove(C.byref(p), rec.tobytes(), C.sizeof(p))
+    return p
+
+
+# ----------------------------------------------------------------------------
+# library loaders
+# ----------------------------------------------------------------------------
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _sig(fn, res, args):
+    fn.restype = res
+    fn.argtypes = args
+    return fn
+
+
+def _declare_leaf(lib, prefix):
+    """Leaf-kernel prototypes shared by oracle (svt_oracle_) and product (svt_amd_)."""
+    u32, u64, i16, vp = C.c_uint32, C.c_uint64, C.c_int16, C.c_void_p
+    g = lambda n: getattr(lib, prefix + n)
+    _sig(g("NxMSadKernel"), u32, [vp, u32, vp, u32, u32, u32])
+    _sig(g("SadLoopKernel"), None, [vp, u32, vp, u32, u32, u32, C.POINTER(u64), C.POINTER(i16),
+                                   C.POINTER(i16), u32, i16, i16])
+    _sig(g("NxMSadAveragingKernel"), u32, [vp, u32, vp, u32, vp, u32, u32, u32])
+    _sig(g("GetEightHorizontalSearchPointResults_8x8_16x16_PU"), None,
+         [vp, u32, vp, u32, vp, vp, vp, vp, u32, vp])
+    _sig(g("GetEightHorizontalSearchPointResults_32x32_64x64"), None, [vp, vp, vp, vp, vp, u32])
+    _sig(g("SadCalculation_8x8_16x16"), None, [vp, u32, vp, u32, vp, vp, vp, vp, u32, vp])
+    _sig(g("SadCalculation_32x32_64x64"), None, [vp, vp, vp, vp, vp, u32])
+    _sig(g("AvcStyleLumaInterpolationFilterHorizontal"), None, [vp, u32, vp, u32, u32, u32, vp, u32])
+    _sig(g("AvcStyleLumaInterpolationFilterVertical"), None, [vp, u32, vp, u32, u32, u32, vp, u32])
+    _sig(g("PictureAverageKernel"), None, [vp, u32, vp, u32, vp, u32, u32, u32])
+    _sig(g("SpatialFullDistortionKernel"), u64, [vp, u32, vp, u32, u32, u32])
+    _sig(g("Decimation2D"), None, [vp, u32, u32, u32, vp, u32, u32])
+
+
+def load_oracle():
+    """Test infrastructure: the CPU restatement (oracle/liboracle.so)."""
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    lib = C.CDLL(ORACLE_SO)
+    _declare_leaf(lib, "svt_oracle_")
+    _sig(lib.svt_oracle_picture_create, C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32])
+    _sig(lib.svt_oracle_picture_destroy, None, [C.c_void_p])
+    _sig(lib.svt_oracle_me_picture, C.c_int,
+         [C.POINTER(MeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p])
+    return lib
+
+
+def load_ref():
+    """Test infrastructure: the reference itself (oracle/_ref/libsvtref.so), or None."""
+    if not os.path.exists(REF_SO):
+        return None
+    return C.CDLL(REF_SO)
+
+
+def load_product():
+    """The HIP library.  Fails loudly when it has not been built."""
+    if not os.path.exists(PRODUCT_SO):
+        raise RuntimeError("svt-hevc_amd/libsvt_hevc_amd.so missing: run `python __graft_entry__.py build`")
+    lib = C.CDLL(PRODUCT_SO)
+    _declare_leaf(lib, "svt_amd_")
+    vp, i, u16, u32 = C.c_void_p, C.c_int, C.c_uint16, C.c_uint32
+    _sig(lib.svt_amd_context_create, i, [i, u16, u16, i, C.POINTER(vp)])
+    _sig(lib.svt_amd_context_destroy, None, [vp])
+    _sig(lib.svt_amd_version, C.c_char_p, [])
+    _sig(lib.svt_amd_last_error, C.c_char_p, [])
+    _sig(lib.svt_amd_picture_upload, i, [vp, i, vp, u32, u16, u16])
+    _sig(lib.svt_amd_picture_upload_device, i, [vp, i, vp, u32, u16, u16])
+    _sig(lib.svt_amd_me_picture, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int), vp])
+    _sig(lib.svt_amd_me_picture_launch, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int)])
+    _sig(lib.svt_amd_me_picture_fetch, i, [vp, i, vp])
+    _sig(lib.svt_amd_synchronize, i, [vp])
+    _sig(lib.svt_amd_timer_begin, i, [vp])
+    _sig(lib.svt_amd_timer_end, i, [vp, C.POINTER(C.c_float)])
+    _sig(lib.svt_amd_kernel_time, i, [vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)])
+    _sig(lib.svt_amd_picture_read_plane, i, [vp, i, i, vp, C.c_size_t, C.POINTER(u32),
+                                             C.POINTER(u32), C.POINTER(u32)])
+    return lib
+
+
+# ----------------------------------------------------------------------------
+# synthetic clips
+# ----------------------------------------------------------------------------
+
+def gen_luma(kind, w, h, t, seed):
+    """One 8-bit luma frame of clip `kind` at time t."""
+    if kind == "flat":
+        return np.full((h, w), 128, np.uint8)
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        for _ in range(t):
+            rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        return rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    # "motion": sinusoids drifting 3/2 px per frame + fixed noise field moving (-2,-1)
+    noise = rng.integers(0, 256, size=(h + 256, w + 512), dtype=np.uint8)
+    x = np.arange(w)[None, :]
+    y = np.arange(h)[:, None]
+    tt = t % 128
+    l = 128 + 50 * (np.sin((x + 3 * t) / 17.0) + np.cos((y + 2 * t) / 23.0)) + \
+        (noise[tt:tt + h, 2 * tt:2 * tt + w] >> 4)
+    return np.clip(np.floor(l), 0, 255).astype(np.uint8)
+
+
+def gen_chroma(w, h, t):
+    xc = np.arange(w // 2)[None, :]
+    yc = np.arange(h // 2)[:, None]
+    cb = 128 + 40 * np.sin((xc / 2.0 + t) / 31.0) + 0 * yc
+    cr = 128 + 40 * np.cos((yc / 2.0 - t) / 29.0) + 0 * xc
+    return (np.clip(np.floor(cb), 0, 255).astype(np.uint8),
+            np.clip(np.floor(cr), 0, 255).astype(np.uint8))
+
+
+def write_clip(path, kind, w, h, n, seed):
+    with open(path, "wb") as f:
+        for t in range(n):
+            f.write(gen_luma(kind, w, h, t, seed).tobytes())
+            cb, cr = gen_chroma(w, h, t)
+            f.write(cb.tobytes())
+            f.write(cr.tobytes())
+
+
+def plane_checksum(luma):
+    """Same polynomial as oracle/ref_harness_me_dump.c:plane_checksum (s = s*31 + v mod 2^32)."""
+    flat = luma.astype(np.uint64).ravel()
+    # Horner in blocks to stay vectorised
+    s = 0
+    p31 = 31
+    chunk = 4096
+    pw = np.ones(chunk, np.uint64)
+    for i in range(chunk - 2, -1, -1):
+        pw[i] = (pw[i + 1] * p31) & 0xFFFFFFFF
+    for off in range(0, flat.size, chunk):
+        blk = flat[off:off + chunk]
+        k = blk.size
+        acc = int((blk * pw[chunk - k:] & 0xFFFFFFFF).sum() & 0xFFFFFFFF)
+        s = (s * pow(31, k, 1 << 32) + acc) & 0xFFFFFFFF
+    return s
+
+
+# ----------------------------------------------------------------------------
+# oracle convenience wrappers
+# ----------------------------------------------------------------------------
+
+class OraclePicture:
+    def __init__(self, lib, luma):
+        self.lib = lib
+        luma = np.ascontiguousarray(luma, np.uint8)
+        h, w = luma.shape
+        self.handle = lib.svt_oracle_picture_create(luma.ctypes.data, w, w, h)
+        if not self.handle:
+            raise MemoryError("svt_oracle_picture_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.svt_oracle_picture_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+def lcu_count(w, h):
+    return ((w + 63) // 64) * ((h + 63) // 64)
+
+
+def oracle_me_picture(lib, params, cur, ref0, ref1=None, lcu_begin=0, lcu_end=None):
+    n = lcu_count(params.luma_width, params.luma_height)
+    if lcu_end is None:
+        lcu_end = n
+    out = np.zeros(n, ME_LCU_DTYPE)
+    rc = lib.svt_oracle_me_picture(C.byref(params), cur.handle, ref0.handle,
+                                   ref1.handle if ref1 is not None else None,
+                                   lcu_begin, lcu_end, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("svt_oracle_me_picture -> %d" % rc)
+    return out
+
+
+def compare_me(got, want, num_lists, what="", lcus=None):
+    """Bit-exact comparison of the fields the reference defines.  For P pictures the
+    reference leaves xMvL1/yMvL1 uninitialised (EbMotionEstimation.c:4427-4434)."""
+    errs = []
+    idx = range(len(want)) if lcus is None else lcus
+    for i in idx:
+        g, w = got[i], want[i]
+        for pu in range(ME_PU_COUNT):
+            gp, wp = g["pu"][pu], w["pu"][pu]
+            tot = int(wp["total"])
+            if int(gp["total"]) != tot:
+                errs.append((i, pu, "total", int(gp["total"]), tot))
+                continue
+            nmv = 4 if num_lists == 2 else 2
+            if not np.array_equal(gp["mv"][:nmv], wp["mv"][:nmv]):
+                errs.append((i, pu, "mv", gp["mv"][:nmv].tolist(), wp["mv"][:nmv].tolist()))
+            if not np.array_equal(gp["distortion"][:tot], wp["distortion"][:tot]):
+                errs.append((i, pu, "dist", gp["distortion"][:tot].tolist(), wp["distortion"][:tot].tolist()))
+            if not np.array_equal(gp["direction"][:tot], wp["direction"][:tot]):
+                errs.append((i, pu, "dir", gp["direction"][:tot].tolist(), wp["direction"][:tot].tolist()))
+        for l in range(num_lists):
+            if not np.array_equal(g["best_sad"][l], w["best_sad"][l]):
+                errs.append((i, -1, "best_sad[%d]" % l, None, None))
+            if not np.array_equal(g["best_mv"][l], w["best_mv"][l]):
+                errs.append((i, -1, "best_mv[%d]" % l, None, None))
+            if int(g["search_origin_x"][l]) != int(w["search_origin_x"][l]) or \
+               int(g["search_origin_y"][l]) != int(w["search_origin_y"][l]):
+                errs.append((i, -1, "origin[%d]" % l,
+                             (int(g["search_origin_x"][l]), int(g["search_origin_y"][l])),
+                             (int(w["search_origin_x"][l]), int(w["search_origin_y"][l]))))
+    assert not errs, "%s: %d mismatches, first: %s" % (what, len(errs), errs[:5])
