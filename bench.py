@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py - hot-path throughput of the MI355X-native SVT-HEVC block-analysis path.
+
+One "step" = one pass of the hot path over one batch of synthetic 1080p pictures
+(BASELINE.json configs[1]: 1920x1080 8-bit, encMode 9, low-delay P): for every picture
+of the batch, picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes) and
+open-loop motion estimation of all 510 LCUs against the previous picture (HME L0/L1,
+full-pel 85-PU search, half/quarter-pel refinement, candidate records), with the ME
+controls exactly as the reference encoder derived them for this configuration
+(tests/golden/me_p_1920x1080_m9.npz).  Inputs are resident in HBM before the timed
+region; results stay in HBM (the PCIe-inclusive rate is discussed in DESIGN.md).
+
+Prints ONE JSON line (rank 0).  `value` = pictures/s of the hot path over all GPUs,
+NOT whole-encoder fps: the closed-loop EncDec half is not on the device yet
+(DESIGN.md "scope").  N>1: pictures are sharded over ranks (independent, no collective).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import svtlib as S  # noqa: E402
+from golden_util import load_case  # noqa: E402
+
+W, H = 1920, 1080
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_frames_device(n, seed, device):
+    """Moving-texture luma frames generated on the device (uint8 [n, H, W])."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    noise = torch.randint(0, 256, (H + 2 * n + 8, W + 4 * n + 8), dtype=torch.uint8, device=device, generator=g)
+    x = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+    y = torch.arange(H, device=device, dtype=torch.float32)[:, None]
+    frames = torch.empty((n, H, W), dtype=torch.uint8, device=device)
+    for t in range(n):
+        l = 128 + 50 * (torch.sin((x + 3 * t) / 17.0) + torch.cos((y + 2 * t) / 23.0)) + \
+            (noise[t:t + H, 2 * t:2 * t + W] >> 4).float()
+        frames[t] = l.clamp(0, 255).to(torch.uint8)
+    return frames
+
+
+def cpu_baseline_port(params, budget_s=12.0):
+    """Oracle (plain C restatement, 1 thread) on a bounded sample of the same workload."""
+    oracle = S.load_oracle()
+    f0, f1 = S.gen_luma("motion", W, H, 0, 7), S.gen_luma("motion", W, H, 1, 7)
+    p0, p1 = S.OraclePicture(oracle, f0), S.OraclePicture(oracle, f1)
+    nl = S.lcu_count(W, H)
+    done, t0 = 0, time.perf_counter()
+    row = 30
+    while done < nl and time.perf_counter() - t0 < budget_s:
+        S.oracle_me_picture(oracle, params, p1, p0, None, done, min(nl, done + row))
+        done += row
+    dt = time.perf_counter() - t0
+    return {"value": round(done / nl / dt, 4), "unit": "fps", "cores": 1, "kind": "port",
+            "sample": "%d of %d LCUs of one 1080p P picture (ME only, oracle/svt_oracle_me.c, 1 thread, %.1f s)"
+                      % (min(done, nl), nl, dt)}
+
+
+def reference_encoder_fps(frames=24):
+    """Whole reference encoder (AVX2 path, all host cores) on the same configuration - context only."""
+    if not os.path.exists(S.REF_APP):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            yuv = os.path.join(td, "c.yuv")
+            S.write_clip(yuv, "motion", W, H, frames, 7)
+            out = subprocess.run([S.REF_APP, "-i", yuv, "-w", str(W), "-h", str(H), "-n", str(frames), "-encMode", "9",
+                                  "-pred-struct", "0", "-q", "32", "-asm", "1", "-b", os.path.join(td, "o.265")],
+                                 capture_output=True, text=True, timeout=300).stdout
+        for line in out.splitlines():
+            if "Average Speed" in line:
+                return {"value": float(line.split()[2]), "unit": "fps (whole encoder, -asm 1)",
+                        "cores": os.cpu_count(), "frames": frames}
+    except Exception as e:  # context only
+        return {"error": str(e)}
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="pictures per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = S.load_product()  # fails loudly when the HIP library is absent
+    B = a.batch
+    ctx = C.c_void_p()
+    rc = lib.svt_amd_context_create(local_rank, W, H + 8, B + 1, C.byref(ctx))
+    assert rc == 0, lib.svt_amd_last_error()
+
+    g = load_case("p_1920x1080_m9")
+    params = S.params_from_record(g["params"][0])
+    frames = synth_frames_device(B + 1, 1234 + rank, dev)
+    torch.cuda.synchronize()
+
+    def prep(slot, idx):
+        r = lib.svt_amd_picture_upload_device(ctx, slot, C.c_void_p(frames[idx].data_ptr()), W, W, H)
+        assert r == 0, lib.svt_amd_last_error()
+
+    refs = (C.c_int * 2)(0, 0)
+
+    def step():
+        # picture i (slot i) is searched against picture i-1; slot 0 holds the last
+        # picture of the previous step, so every picture is prepared exactly once.
+        for i in range(1, B + 1):
+            prep(i, i)
+            refs[0] = i - 1
+            r = lib.svt_amd_me_picture_launch(ctx, C.byref(params), i, refs)
+            assert r == 0, lib.svt_amd_last_error()
+        prep(0, B)  # becomes the reference of the next step's first picture
+
+    prep(0, 0)
+    for _ in range(a.warmup):
+        step()
+    lib.svt_amd_synchronize(ctx)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    lib.svt_amd_timer_begin(ctx)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    lib.svt_amd_synchronize(ctx)
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = C.c_float()
+    lib.svt_amd_timer_end(ctx, C.byref(ev_ms))
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    me_ms, me_n, prep_ms, prep_n = C.c_float(), C.c_int(), C.c_float(), C.c_int()
+    lib.svt_amd_kernel_time(ctx, b"me_search", C.byref(me_ms), C.byref(me_n))
+    lib.svt_amd_kernel_time(ctx, b"prep", C.byref(prep_ms), C.byref(prep_n))
+
+    if rank == 0:
+        pictures = world * B * a.steps
+        fps = pictures / dt
+        nlcu = S.lcu_count(W, H)
+        # algorithmic HBM bytes of one ME launch: source + 1 reference, each
+        # full + 1/4 + 1/16 planes (1.3125 bytes/pel), plus the per-LCU result records
+        algo_bytes = 2 * 1.3125 * W * H + nlcu * C.sizeof(S.MeLcuResult)
+        achieved = algo_bytes / (me_ms.value * 1e-3) / 1e9 if me_ms.value > 0 else 0.0
+        res = {
+            "metric": "encoded fps (hot path: picture prep + motion estimation)", "value": round(fps, 2),
+            "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1080p 8-bit encMode 9 low-delay P (BASELINE configs[1]): per picture pad+decimate+"
+                                   "half-pel planes and open-loop ME (HME L0/L1, full-pel 85 PU, sub-pel) of 510 LCUs "
+                                   "vs previous picture; EncDec (MD/DCT/DLF/SAO) not on device yet",
+                       "width": W, "height": H, "pictures_per_step_per_gpu": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
+                       "parallelism": "pictures sharded over ranks, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_me_picture", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms.value, 4),
+                         "launches_timed": me_n.value,
+                         "prep_avg_ms": round(prep_ms.value, 4), "prep_launches": prep_n.value,
+                         "event_ms_total": round(ev_ms.value, 3)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_port(params)
+            ref = reference_encoder_fps()
+            if ref:
+                res["reference_encoder"] = ref
+        print(json.dumps(res), flush=True)
+
+    lib.svt_amd_context_destroy(ctx)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,380 @@
+/*
+ * Context, picture slots and the batched C-ABI entry points (include/svt_hevc_amd.h).
+ * Host side only; kernels live in prep_kernels.hip / me_kernels.hip / leaf.hip.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "svt_amd_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void svt_amd_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *svt_amd_last_error(void) { return g_err; }
+extern "C" const char *svt_amd_version(void) { return "svt-hevc_amd 0.1 (gfx950)"; }
+
+static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static int plane_create(DevPlane *p, int w, int h, int pad)
+{
+    memset(p, 0, sizeof(*p));
+    p->width = w;
+    p->height = h;
+    p->pad = pad;
+    p->lead_cols = align_up(pad, 128);
+    p->pitch = align_up(w + p->lead_cols + pad + 64, 256);
+    p->lead_rows = pad + 8;
+    const size_t rows = (size_t)h + 2 * (size_t)p->lead_rows;
+    p->alloc_bytes = rows * (size_t)p->pitch;
+    HIP_TRY(hipMalloc((void **)&p->alloc, p->alloc_bytes));
+    HIP_TRY(hipMemset(p->alloc, 0, p->alloc_bytes));
+    p->origin = p->alloc + (size_t)p->lead_rows * p->pitch + p->lead_cols;
+    return SVT_AMD_OK;
+}
+
+static void plane_destroy(DevPlane *p)
+{
+    if (p->alloc)
+        (void)hipFree(p->alloc);
+    memset(p, 0, sizeof(*p));
+}
+
+extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; ctx->slots && i < ctx->num_slots; i++) {
+        DevPicture *s = &ctx->slots[i];
+        plane_destroy(&s->full);
+        plane_destroy(&s->quarter);
+        plane_destroy(&s->sixteenth);
+        plane_destroy(&s->hp_b);
+        plane_destroy(&s->hp_h);
+        plane_destroy(&s->hp_j);
+        if (s->d_me_out)
+            (void)hipFree(s->d_me_out);
+        if (s->d_staging)
+            (void)hipFree(s->d_staging);
+    }
+    free(ctx->slots);
+    for (int i = 0; i < ctx->cap_stamps; i++) {
+        (void)hipEventDestroy(ctx->stamps[i].a);
+        (void)hipEventDestroy(ctx->stamps[i].b);
+    }
+    free(ctx->stamps);
+    if (ctx->ev_begin)
+        (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end)
+        (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_width,
+                                      uint16_t max_luma_height, int num_picture_slots,
+                                      SvtAmdContext **out_ctx)
+{
+    if (!out_ctx || num_picture_slots < 1 || max_luma_width < 64 || max_luma_height < 64 ||
+        (max_luma_width & 7) || (max_luma_height & 7)) {
+        svt_amd_set_error("svt_amd_context_create: bad parameter");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    *out_ctx = NULL;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_ordinal < 0 || device_ordinal >= ndev) {
+        svt_amd_set_error("svt_amd_context_create: device %d of %d", device_ordinal, ndev);
+        return SVT_AMD_ERR_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device_ordinal));
+    SvtAmdContext *ctx = (SvtAmdContext *)calloc(1, sizeof(*ctx));
+    if (!ctx)
+        return SVT_AMD_ERR_RESOURCES;
+    ctx->device = device_ordinal;
+    ctx->max_w = max_luma_width;
+    ctx->max_h = max_luma_height;
+    ctx->num_slots = num_picture_slots;
+    ctx->slots = (DevPicture *)calloc((size_t)num_picture_slots, sizeof(DevPicture));
+    int rc = ctx->slots ? SVT_AMD_OK : SVT_AMD_ERR_RESOURCES;
+#define CHK(x) do { if (rc == SVT_AMD_OK) { hipError_t e_ = (x); if (e_ != hipSuccess) { svt_amd_set_error("%s: %s", #x, hipGetErrorString(e_)); rc = SVT_AMD_ERR_DEVICE; } } } while (0)
+    CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CHK(hipEventCreate(&ctx->ev_begin));
+    CHK(hipEventCreate(&ctx->ev_end));
+#undef CHK
+    const int nlcu = ((max_luma_width + 63) / 64) * ((max_luma_height + 63) / 64);
+    for (int i = 0; rc == SVT_AMD_OK && i < num_picture_slots; i++) {
+        DevPicture *s = &ctx->slots[i];
+        const int w = max_luma_width, h = max_luma_height;
+        if ((rc = plane_create(&s->full, w, h, SVT_AMD_PAD_FULL)) != 0) break;
+        if ((rc = plane_create(&s->quarter, w >> 1, h >> 1, SVT_AMD_PAD_QUARTER)) != 0) break;
+        if ((rc = plane_create(&s->sixteenth, w >> 2, h >> 2, SVT_AMD_PAD_SIXTEENTH)) != 0) break;
+        if ((rc = plane_create(&s->hp_b, w, h, SVT_AMD_PAD_FULL)) != 0) break;
+        if ((rc = plane_create(&s->hp_h, w, h, SVT_AMD_PAD_FULL)) != 0) break;
+        if ((rc = plane_create(&s->hp_j, w, h, SVT_AMD_PAD_FULL)) != 0) break;
+        if (hipMalloc((void **)&s->d_me_out, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess ||
+            hipMalloc((void **)&s->d_staging, (size_t)w * h) != hipSuccess) {
+            svt_amd_set_error("hipMalloc (slot %d) failed", i);
+            rc = SVT_AMD_ERR_RESOURCES;
+            break;
+        }
+        s->staging_bytes = (size_t)w * h;
+    }
+    if (rc != SVT_AMD_OK) {
+        svt_amd_context_destroy(ctx);
+        return rc;
+    }
+    *out_ctx = ctx;
+    return SVT_AMD_OK;
+}
+
+/* ---- timing ------------------------------------------------------------ */
+
+int svt_amd_stamp_begin(SvtAmdContext *ctx, int cls)
+{
+    if (!ctx->timer_armed)
+        return SVT_AMD_OK;
+    if (ctx->num_stamps == ctx->cap_stamps) {
+        int ncap = ctx->cap_stamps ? ctx->cap_stamps * 2 : 64;
+        SvtAmdContext::Stamp *ns = (SvtAmdContext::Stamp *)realloc(ctx->stamps, (size_t)ncap * sizeof(*ns));
+        if (!ns)
+            return SVT_AMD_ERR_RESOURCES;
+        ctx->stamps = ns;
+        for (int i = ctx->cap_stamps; i < ncap; i++) {
+            HIP_TRY(hipEventCreate(&ns[i].a));
+            HIP_TRY(hipEventCreate(&ns[i].b));
+        }
+        ctx->cap_stamps = ncap;
+    }
+    ctx->stamps[ctx->num_stamps].cls = cls;
+    HIP_TRY(hipEventRecord(ctx->stamps[ctx->num_stamps].a, ctx->stream));
+    return SVT_AMD_OK;
+}
+
+int svt_amd_stamp_end(SvtAmdContext *ctx)
+{
+    if (!ctx->timer_armed)
+        return SVT_AMD_OK;
+    HIP_TRY(hipEventRecord(ctx->stamps[ctx->num_stamps].b, ctx->stream));
+    ctx->num_stamps++;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_timer_begin(SvtAmdContext *ctx)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->num_stamps = 0;
+    ctx->timer_armed = 1;
+    HIP_TRY(hipEventRecord(ctx->ev_begin, ctx->stream));
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_timer_end(SvtAmdContext *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipEventRecord(ctx->ev_end, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev_end));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    ctx->timer_armed = 0;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_kernel_time(SvtAmdContext *ctx, const char *kernel_class, float *avg_ms, int *launches)
+{
+    if (!ctx || !kernel_class || !avg_ms || !launches)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int cls = !strcmp(kernel_class, "prep") ? KC_PREP : !strcmp(kernel_class, "me_search") ? KC_ME_SEARCH : -1;
+    if (cls < 0)
+        return SVT_AMD_ERR_BAD_PARAM;
+    double sum = 0;
+    int n = 0;
+    for (int i = 0; i < ctx->num_stamps; i++) {
+        if (ctx->stamps[i].cls != cls)
+            continue;
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(ctx->stamps[i].b));
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->stamps[i].a, ctx->stamps[i].b));
+        sum += ms;
+        n++;
+    }
+    *avg_ms = n ? (float)(sum / n) : 0.f;
+    *launches = n;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_synchronize(SvtAmdContext *ctx)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* ---- pictures ---------------------------------------------------------- */
+
+static int check_slot(SvtAmdContext *ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= ctx->num_slots) {
+        svt_amd_set_error("bad context/slot %d", slot);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    return SVT_AMD_OK;
+}
+
+static int set_geometry(SvtAmdContext *ctx, DevPicture *s, uint16_t width, uint16_t height)
+{
+    if (width < 64 || height < 64 || (width & 7) || (height & 7) || width > ctx->max_w || height > ctx->max_h) {
+        svt_amd_set_error("picture %ux%u not supported by context %ux%u", width, height, ctx->max_w, ctx->max_h);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    s->width = width;
+    s->height = height;
+    s->full.width = s->hp_b.width = s->hp_h.width = s->hp_j.width = width;
+    s->full.height = s->hp_b.height = s->hp_h.height = s->hp_j.height = height;
+    s->quarter.width = width >> 1, s->quarter.height = height >> 1;
+    s->sixteenth.width = width >> 2, s->sixteenth.height = height >> 2;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_picture_upload_device(SvtAmdContext *ctx, int slot, const void *d_luma,
+                                             uint32_t stride, uint16_t width, uint16_t height)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc)
+        return rc;
+    if (!d_luma || stride < width)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *s = &ctx->slots[slot];
+    if ((rc = set_geometry(ctx, s, width, height)) != 0)
+        return rc;
+    if ((rc = svt_amd_launch_prep(ctx, s, (const uint8_t *)d_luma, stride)) != 0)
+        return rc;
+    s->valid = 1;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_picture_upload(SvtAmdContext *ctx, int slot, const uint8_t *luma,
+                                      uint32_t stride, uint16_t width, uint16_t height)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc)
+        return rc;
+    if (!luma || stride < width)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *s = &ctx->slots[slot];
+    if ((size_t)width * height > s->staging_bytes)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipMemcpy2DAsync(s->d_staging, width, luma, stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    return svt_amd_picture_upload_device(ctx, slot, s->d_staging, width, width, height);
+}
+
+extern "C" int svt_amd_picture_read_plane(SvtAmdContext *ctx, int slot, int which, uint8_t *dst,
+                                          size_t dst_capacity, uint32_t *out_stride,
+                                          uint32_t *out_pad, uint32_t *out_rows)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc)
+        return rc;
+    DevPicture *s = &ctx->slots[slot];
+    DevPlane *pl[6] = {&s->full, &s->quarter, &s->sixteenth, &s->hp_b, &s->hp_h, &s->hp_j};
+    if (which < 0 || which > 5 || !dst || !out_stride || !out_pad || !out_rows)
+        return SVT_AMD_ERR_BAD_PARAM;
+    DevPlane *p = pl[which];
+    const uint32_t w = (uint32_t)(p->width + 2 * p->pad), rows = (uint32_t)(p->height + 2 * p->pad);
+    if (dst_capacity < (size_t)w * rows)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy2D(dst, w, p->origin - (size_t)p->pad * p->pitch - p->pad, (size_t)p->pitch, w, rows,
+                        hipMemcpyDeviceToHost));
+    *out_stride = w;
+    *out_pad = (uint32_t)p->pad;
+    *out_rows = rows;
+    return SVT_AMD_OK;
+}
+
+/* ---- motion estimation ------------------------------------------------- */
+
+static int validate_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, int cur_slot, const int ref_slot[2])
+{
+    if (!ctx || !p || !ref_slot)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (p->num_lists < 1 || p->num_lists > 2 || p->num_hme_regions_w > 2 || p->num_hme_regions_h > 2 ||
+        p->search_area_width < 1 || p->search_area_height < 1) {
+        svt_amd_set_error("svt_amd_me_picture: bad SvtAmdMeParams");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    int rc = check_slot(ctx, cur_slot);
+    for (int l = 0; !rc && l < p->num_lists; l++)
+        rc = check_slot(ctx, ref_slot[l]);
+    if (rc)
+        return rc;
+    const DevPicture *c = &ctx->slots[cur_slot];
+    if (!c->valid || c->width != p->luma_width || c->height != p->luma_height) {
+        svt_amd_set_error("svt_amd_me_picture: slot %d does not hold a %ux%u picture", cur_slot, p->luma_width,
+                          p->luma_height);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    for (int l = 0; l < p->num_lists; l++) {
+        const DevPicture *r = &ctx->slots[ref_slot[l]];
+        if (!r->valid || r->width != c->width || r->height != c->height) {
+            svt_amd_set_error("svt_amd_me_picture: reference slot %d invalid", ref_slot[l]);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+    }
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
+                                         const int ref_slot[2])
+{
+    int rc = validate_me(ctx, params, cur_slot, ref_slot);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const DevPicture *r0 = &ctx->slots[ref_slot[0]];
+    const DevPicture *r1 = params->num_lists == 2 ? &ctx->slots[ref_slot[1]] : r0;
+    return svt_amd_launch_me(ctx, params, c, r0, r1, c->d_me_out);
+}
+
+extern "C" int svt_amd_me_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    if (!out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    HIP_TRY(hipMemcpyAsync(out, c->d_me_out, (size_t)nlcu * sizeof(SvtAmdMeLcuResult), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_me_picture(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
+                                  const int ref_slot[2], SvtAmdMeLcuResult *out)
+{
+    int rc = svt_amd_me_picture_launch(ctx, params, cur_slot, ref_slot);
+    if (rc)
+        return rc;
+    return svt_amd_me_picture_fetch(ctx, cur_slot, out);
+}

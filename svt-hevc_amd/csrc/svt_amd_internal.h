@@ -1,0 +1,94 @@
+/*
+ * Internal declarations of the HIP library (not part of the C-ABI).
+ * Device memory layout of one picture slot (all planes 8-bit, row pitch a
+ * multiple of 256 B, sample (0,0) 128-B aligned so LCU rows are fetched as
+ * aligned 64-B segments):
+ *
+ *   full      (W   x H  ) valid x in [-68 , W+68),  y in [-68, H+68)   PA "inputPaddedPicture"
+ *   quarter   (W/2 x H/2) valid pad 32                                  "quarterDecimatedPicture"
+ *   sixteenth (W/4 x H/4) valid pad 16                                  "sixteenthDecimatedPicture"
+ *   hp_b / hp_h / hp_j    geometry of `full`; AVC-style half-pel planes
+ */
+#ifndef SVT_AMD_INTERNAL_H
+#define SVT_AMD_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svt_hevc_amd.h"
+
+struct DevPlane {
+    uint8_t *origin;   /* device pointer to sample (0,0) */
+    int32_t  pitch;    /* bytes per row */
+    int32_t  width, height, pad;
+    uint8_t *alloc;    /* base of the allocation */
+    size_t   alloc_bytes;
+    int32_t  lead_rows; /* rows above y = -pad kept as guard */
+    int32_t  lead_cols; /* bytes left of x = 0 in each row   */
+};
+
+struct DevPicture {
+    DevPlane full, quarter, sixteenth, hp_b, hp_h, hp_j;
+    SvtAmdMeLcuResult *d_me_out;   /* device buffer, one record per LCU */
+    uint8_t *d_staging;            /* device copy of the raw luma (upload path) */
+    size_t   staging_bytes;
+    uint16_t width, height;
+    int      valid;
+};
+
+/* kernel-side view */
+struct PicView {
+    const uint8_t *full, *quarter, *sixteenth, *hp_b, *hp_h, *hp_j;
+    int32_t pitch_full, pitch_quarter, pitch_sixteenth;
+};
+
+enum { KC_PREP = 0, KC_ME_SEARCH = 1, KC_COUNT = 2 };
+
+struct SvtAmdContext {
+    int device;
+    hipStream_t stream;
+    uint16_t max_w, max_h;
+    int num_slots;
+    DevPicture *slots;
+    hipEvent_t ev_begin, ev_end;
+    /* per-kernel-class event pairs recorded while the timer is armed */
+    int timer_armed;
+    struct Stamp { hipEvent_t a, b; int cls; } *stamps;
+    int num_stamps, cap_stamps;
+};
+
+void svt_amd_set_error(const char *fmt, ...);
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            svt_amd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                              __FILE__, __LINE__);                                         \
+            return SVT_AMD_ERR_DEVICE;                                                     \
+        }                                                                                  \
+    } while (0)
+
+/* stamps a kernel class duration when the timer is armed */
+int svt_amd_stamp_begin(SvtAmdContext *ctx, int cls);
+int svt_amd_stamp_end(SvtAmdContext *ctx);
+
+/* kernel launchers (prep_kernels.hip / me_kernels.hip) */
+int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_luma, uint32_t stride);
+int svt_amd_launch_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, const DevPicture *cur,
+                      const DevPicture *ref0, const DevPicture *ref1, SvtAmdMeLcuResult *d_out);
+
+static inline PicView make_view(const DevPicture *p)
+{
+    PicView v;
+    v.full = p->full.origin;
+    v.quarter = p->quarter.origin;
+    v.sixteenth = p->sixteenth.origin;
+    v.hp_b = p->hp_b.origin;
+    v.hp_h = p->hp_h.origin;
+    v.hp_j = p->hp_j.origin;
+    v.pitch_full = p->full.pitch;
+    v.pitch_quarter = p->quarter.pitch;
+    v.pitch_sixteenth = p->sixteenth.pitch;
+    return v;
+}
+
+#endif
