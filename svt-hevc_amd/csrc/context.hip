@@ -281,6 +281,9 @@ extern "C" int svt_amd_picture_upload(SvtAmdContext *ctx, int slot, const uint8_
     if ((size_t)width * height > s->staging_bytes)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipMemcpy2DAsync(s->d_staging, width, luma, stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    /* the caller owns `luma` and may release it as soon as we return (the reference
+     * copies in EbH265EncSendPicture, EbEncHandle.c:3329): wait for the H2D copy */
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return svt_amd_picture_upload_device(ctx, slot, s->d_staging, width, width, height);
 }
 

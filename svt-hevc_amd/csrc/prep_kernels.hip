@@ -16,7 +16,15 @@
 #include "svt_amd_internal.h"
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ uint32_t clip255(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+/* clip((sum + 16) >> 5) to [0,255].  Written as max(sum,0) -> logical shift -> umin on purpose:
+ * the natural form clamp(sum >> 5, 0, 255) is pattern-matched by hipcc 7.2 into
+ * v_ashr_pk_u8_i32 pairs whose upper 16 result bits are not zero on gfx950 when an input
+ * is negative, which corrupted the two neighbouring samples (found by the parity test). */
+__device__ __forceinline__ uint32_t round_shift_clip(int sum_plus_16)
+{
+    const uint32_t u = (uint32_t)(sum_plus_16 < 0 ? 0 : sum_plus_16) >> 5;
+    return u > 255u ? 255u : u;
+}
 
 /* dst(x,y) = src[clamp(y) * step][clamp(x) * step] for x in [-pad, w+pad), y in [-pad, h+pad) */
 __global__ __launch_bounds__(256) void k_build_plane(uint8_t *__restrict__ dst, int pitch, int w, int h, int pad,
@@ -55,14 +63,14 @@ __global__ __launch_bounds__(256) void k_halfpel_bh(const uint8_t *__restrict__ 
         a[i] = r[i - 2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        vb |= clip255((-2 * a[i] + 18 * a[i + 1] + 18 * a[i + 2] - 2 * a[i + 3] + 16) >> 5) << (8 * i);
+        vb |= round_shift_clip(-2 * a[i] + 18 * a[i + 1] + 18 * a[i + 2] - 2 * a[i + 3] + 16) << (8 * i);
     const uint32_t m2 = *(const uint32_t *)(r - 2 * pitch), m1 = *(const uint32_t *)(r - pitch),
                    c0 = *(const uint32_t *)r, p1 = *(const uint32_t *)(r + pitch);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int s = 8 * i;
-        vh |= clip255((-2 * (int)((m2 >> s) & 255) + 18 * (int)((m1 >> s) & 255) + 18 * (int)((c0 >> s) & 255) -
-                       2 * (int)((p1 >> s) & 255) + 16) >> 5) << s;
+        vh |= round_shift_clip(-2 * (int)((m2 >> s) & 255) + 18 * (int)((m1 >> s) & 255) + 18 * (int)((c0 >> s) & 255) -
+                               2 * (int)((p1 >> s) & 255) + 16) << s;
     }
     *(uint32_t *)(B + (ptrdiff_t)y * pitch + x0) = vb;
     *(uint32_t *)(H + (ptrdiff_t)y * pitch + x0) = vh;
@@ -83,8 +91,8 @@ __global__ __launch_bounds__(256) void k_halfpel_j(const uint8_t *__restrict__ B
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int s = 8 * i;
-        vj |= clip255((-2 * (int)((m2 >> s) & 255) + 18 * (int)((m1 >> s) & 255) + 18 * (int)((c0 >> s) & 255) -
-                       2 * (int)((p1 >> s) & 255) + 16) >> 5) << s;
+        vj |= round_shift_clip(-2 * (int)((m2 >> s) & 255) + 18 * (int)((m1 >> s) & 255) + 18 * (int)((c0 >> s) & 255) -
+                               2 * (int)((p1 >> s) & 255) + 16) << s;
     }
     *(uint32_t *)(J + (ptrdiff_t)y * pitch + x0) = vj;
 }
