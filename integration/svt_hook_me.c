@@ -1,0 +1,174 @@
+/*
+ * integration/svt_hook_me.c - the reference-side binding of the batched ME boundary.
+ *
+ * This is the code a maintainer adds to the reference: it is
+ * compiled against the reference headers and linked, with the reference's own
+ * objects and -Wl,--wrap=MotionEstimateLcu, into integration/_build/libsvthip.so /
+ * SvtHevcEncApp_hip.  Every call the reference's MotionEstimationKernel makes to
+ * MotionEstimateLcu (Codec/EbMotionEstimationProcess.c:780) is answered from the
+ * result of ONE svt_amd_me_picture() call per picture on the MI355X; the
+ * reference's CPU motion search is never executed.  There is no fallback: any
+ * error from the HIP library aborts the encoder.
+ *
+ * Contains no reference source.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbMotionEstimation.h"
+#include "EbMotionEstimationContext.h"
+#include "EbReferenceObject.h"
+
+#include "../include/svt_hevc_amd.h"
+
+#define NSLOTS 48   /* device picture slots, keyed by pictureNumber % NSLOTS */
+#define NRESULTS 32 /* host result sets in flight */
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static SvtAmdContext *g_ctx;
+static uint64_t g_slot_pic[NSLOTS];
+static struct { uint64_t pic; int valid; SvtAmdMeLcuResult *res; } g_results[NRESULTS];
+static uint32_t g_nlcu;
+static unsigned long g_pictures, g_lcus;
+static void hook_report(void);
+
+static void die(const char *what)
+{
+    fprintf(stderr, "svt_hook_me: %s: %s\n", what, svt_amd_last_error());
+    abort();
+}
+
+static int ensure_uploaded(uint64_t pic, const EbPictureBufferDesc_t *padded)
+{
+    const int slot = (int)(pic % NSLOTS);
+    if (g_slot_pic[slot] != pic + 1) {
+        const uint8_t *luma = padded->bufferY + (size_t)padded->originY * padded->strideY + padded->originX;
+        if (svt_amd_picture_upload(g_ctx, slot, luma, padded->strideY, padded->width, padded->height))
+            die("svt_amd_picture_upload");
+        g_slot_pic[slot] = pic + 1;
+    }
+    return slot;
+}
+
+static void fill_params(SvtAmdMeParams *p, const PictureParentControlSet_t *pcs, const SequenceControlSet_t *scs,
+                        const MeContext_t *ctx)
+{
+    const int nlists = (pcs->sliceType == EB_P_PICTURE) ? 1 : 2;
+    memset(p, 0, sizeof(*p));
+    p->luma_width = scs->lumaWidth;
+    p->luma_height = scs->lumaHeight;
+    p->num_lists = (uint8_t)nlists;
+    p->temporal_layer_index = pcs->temporalLayerIndex;
+    p->ref_pocs_equal = (nlists == 2 && pcs->refPicPocArray[0] == pcs->refPicPocArray[1]);
+    p->enable_hme_flag = pcs->enableHmeFlag;
+    p->enable_hme_level0 = pcs->enableHmeLevel0Flag;
+    p->enable_hme_level1 = pcs->enableHmeLevel1Flag;
+    p->enable_hme_level2 = pcs->enableHmeLevel2Flag;
+    p->one_quadrant_hme = ctx->oneQuadrantHME;
+    p->update_hme_search_center = ctx->updateHmeSearchCenter;
+    p->num_hme_regions_w = (uint8_t)ctx->numberHmeSearchRegionInWidth;
+    p->num_hme_regions_h = (uint8_t)ctx->numberHmeSearchRegionInHeight;
+    p->search_area_width = (uint8_t)ctx->searchAreaWidth;
+    p->search_area_height = (uint8_t)ctx->searchAreaHeight;
+    p->fractional_search_method = ctx->fractionalSearchMethod;
+    p->fractional_search_model = ctx->fractionalSearchModel;
+    p->fractional_search_64x64 = ctx->fractionalSearch64x64;
+    p->cu8x8_mode = pcs->cu8x8Mode;
+    p->cu16x16_mode = pcs->cu16x16Mode;
+    p->hme_l0_total_w = ctx->hmeLevel0TotalSearchAreaWidth;
+    p->hme_l0_total_h = ctx->hmeLevel0TotalSearchAreaHeight;
+    for (int k = 0; k < 2; k++) {
+        p->hme_l0_w[k] = ctx->hmeLevel0SearchAreaInWidthArray[k];
+        p->hme_l0_h[k] = ctx->hmeLevel0SearchAreaInHeightArray[k];
+        p->hme_l1_w[k] = ctx->hmeLevel1SearchAreaInWidthArray[k];
+        p->hme_l1_h[k] = ctx->hmeLevel1SearchAreaInHeightArray[k];
+        p->hme_l2_w[k] = ctx->hmeLevel2SearchAreaInWidthArray[k];
+        p->hme_l2_h[k] = ctx->hmeLevel2SearchAreaInHeightArray[k];
+    }
+    p->hme_l0_mult_x = (uint16_t)HME_LEVEL_0_SEARCH_AREA_MULTIPLIER_X[pcs->hierarchicalLevels][pcs->temporalLayerIndex];
+    p->hme_l0_mult_y = (uint16_t)HME_LEVEL_0_SEARCH_AREA_MULTIPLIER_Y[pcs->hierarchicalLevels][pcs->temporalLayerIndex];
+    p->lambda = (uint32_t)ctx->lambda;
+    for (int k = 0; k < 12; k++)
+        p->mvd_bits[k] = ctx->mvdBitsArray[k];
+}
+
+/* runs the whole picture on the GPU once; returns the cached result set */
+static const SvtAmdMeLcuResult *picture_results(PictureParentControlSet_t *pcs, MeContext_t *ctx)
+{
+    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    const uint64_t pic = pcs->pictureNumber;
+    const int e = (int)(pic % NRESULTS);
+    if (g_results[e].valid && g_results[e].pic == pic)
+        return g_results[e].res;
+    if (!g_ctx) {
+        const char *dev = getenv("SVT_AMD_DEVICE");
+        const uint16_t mh = (uint16_t)((scs->lumaHeight + 7) & ~7);
+        if (svt_amd_context_create(dev ? atoi(dev) : 0, scs->lumaWidth, mh, NSLOTS, &g_ctx))
+            die("svt_amd_context_create");
+        g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
+        fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
+        atexit(hook_report);
+    }
+    if (!g_results[e].res && !(g_results[e].res = (SvtAmdMeLcuResult *)malloc(sizeof(SvtAmdMeLcuResult) * g_nlcu)))
+        die("malloc");
+    const int nlists = (pcs->sliceType == EB_P_PICTURE) ? 1 : 2;
+    EbPaReferenceObject_t *cur = (EbPaReferenceObject_t *)pcs->paReferencePictureWrapperPtr->objectPtr;
+    const int cur_slot = ensure_uploaded(pic, cur->inputPaddedPicturePtr);
+    int ref_slot[2] = {0, 0};
+    for (int l = 0; l < nlists; l++) {
+        EbPaReferenceObject_t *ro = (EbPaReferenceObject_t *)pcs->refPaPicPtrArray[l]->objectPtr;
+        ref_slot[l] = ensure_uploaded(pcs->refPicPocArray[l], ro->inputPaddedPicturePtr);
+    }
+    SvtAmdMeParams p;
+    fill_params(&p, pcs, scs, ctx);
+    if (svt_amd_me_picture(g_ctx, &p, cur_slot, ref_slot, g_results[e].res))
+        die("svt_amd_me_picture");
+    g_results[e].pic = pic;
+    g_results[e].valid = 1;
+    g_pictures++;
+    return g_results[e].res;
+}
+
+EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX,
+                                      EB_U32 lcuOriginY, MeContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
+{
+    (void)lcuOriginX;
+    (void)lcuOriginY;
+    (void)inputPtr;
+    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    pthread_mutex_lock(&g_lock);
+    const SvtAmdMeLcuResult *r = &picture_results(pcs, ctx)[lcuIndex];
+    g_lcus++;
+    pthread_mutex_unlock(&g_lock);
+
+    for (int pu = 0; pu < SVT_AMD_ME_PU_COUNT; pu++) {
+        MeCuResults_t *m = &pcs->meResults[lcuIndex][pu];
+        const SvtAmdMeCuResult *s = &r->pu[pu];
+        m->xMvL0 = s->x_mv_l0;
+        m->yMvL0 = s->y_mv_l0;
+        m->xMvL1 = s->x_mv_l1;
+        m->yMvL1 = s->y_mv_l1;
+        m->totalMeCandidateIndex = s->total_me_candidate_index;
+        for (int k = 0; k < s->total_me_candidate_index; k++) {
+            m->distortionDirection[k].distortion = s->distortion[k];
+            m->distortionDirection[k].direction = s->direction[k];
+        }
+    }
+    if (scs->staticConfig.rateControlMode) { /* EbMotionEstimation.c:4442-4448 */
+        pcs->rcMEdistortion[lcuIndex] = 0;
+        for (int i = 0; i < 16; i++)
+            pcs->rcMEdistortion[lcuIndex] += pcs->meResults[lcuIndex][5 + i].distortionDirection[0].distortion;
+    }
+    return EB_ErrorNone;
+}
+
+static void hook_report(void)
+{
+    fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs estimated on the GPU, 0 on the CPU\n", g_pictures, g_lcus);
+    fflush(stderr);
+}
