@@ -174,6 +174,12 @@ SVT_AMD_API int svt_amd_me_picture(SvtAmdContext *ctx, const SvtAmdMeParams *par
 SVT_AMD_API int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params,
                                           int cur_slot, const int ref_slot[2]);
 SVT_AMD_API int svt_amd_me_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out);
+/* LCU-range form for multi-GPU sharding of one picture by LCU rows: only
+ * records [lcu_begin, lcu_end) of the slot's result buffer are written.  The reference's
+ * analogue is the 6x10 ME segment grid (EbEncHandle.c:1680-1681). */
+SVT_AMD_API int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params,
+                                                int cur_slot, const int ref_slot[2],
+                                                uint32_t lcu_begin, uint32_t lcu_end);
 SVT_AMD_API int svt_amd_synchronize(SvtAmdContext *ctx);
 
 /* Device-side timing of the launches issued between begin/end on the context's

@@ -344,17 +344,31 @@ static int validate_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, int cur_slot
     return SVT_AMD_OK;
 }
 
-extern "C" int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
-                                         const int ref_slot[2])
+extern "C" int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
+                                               const int ref_slot[2], uint32_t lcu_begin, uint32_t lcu_end)
 {
     int rc = validate_me(ctx, params, cur_slot, ref_slot);
     if (rc)
         return rc;
+    const uint32_t nlcu = ((params->luma_width + 63u) / 64u) * ((params->luma_height + 63u) / 64u);
+    if (lcu_begin >= lcu_end || lcu_end > nlcu) {
+        svt_amd_set_error("svt_amd_me_picture_range_launch: bad LCU range [%u,%u) of %u", lcu_begin, lcu_end, nlcu);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     DevPicture *c = &ctx->slots[cur_slot];
     const DevPicture *r0 = &ctx->slots[ref_slot[0]];
     const DevPicture *r1 = params->num_lists == 2 ? &ctx->slots[ref_slot[1]] : r0;
-    return svt_amd_launch_me(ctx, params, c, r0, r1, c->d_me_out);
+    return svt_amd_launch_me(ctx, params, c, r0, r1, c->d_me_out, (int)lcu_begin, (int)lcu_end);
+}
+
+extern "C" int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
+                                         const int ref_slot[2])
+{
+    if (!params)
+        return SVT_AMD_ERR_BAD_PARAM;
+    const uint32_t nlcu = ((params->luma_width + 63u) / 64u) * ((params->luma_height + 63u) / 64u);
+    return svt_amd_me_picture_range_launch(ctx, params, cur_slot, ref_slot, 0, nlcu);
 }
 
 extern "C" int svt_amd_me_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out)

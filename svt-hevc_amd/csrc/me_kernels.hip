@@ -262,13 +262,13 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
 }
 
 __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur, PicView ref0, PicView ref1,
-                                                   SvtAmdMeLcuResult *__restrict__ out)
+                                                   SvtAmdMeLcuResult *__restrict__ out, int lcu_begin)
 {
     __shared__ MeShared S;
     const int t = threadIdx.x;
     const int W = P.luma_width, H = P.luma_height;
     const int wl = (W + LCU - 1) / LCU;
-    const int lcu = blockIdx.x;
+    const int lcu = lcu_begin + (int)blockIdx.x;
     const int ox = (lcu % wl) * LCU, oy = (lcu / wl) * LCU;
     const int lw = imin(LCU, W - ox), lh = imin(LCU, H - oy);
     const int pf = cur.pitch_full;
@@ -924,14 +924,14 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
 }
 
 int svt_amd_launch_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, const DevPicture *cur, const DevPicture *ref0,
-                      const DevPicture *ref1, SvtAmdMeLcuResult *d_out)
+                      const DevPicture *ref1, SvtAmdMeLcuResult *d_out, int lcu_begin, int lcu_end)
 {
-    const int nlcu = ((p->luma_width + 63) / 64) * ((p->luma_height + 63) / 64);
+    const int nlcu = lcu_end - lcu_begin;
     int rc = svt_amd_stamp_begin(ctx, KC_ME_SEARCH);
     if (rc)
         return rc;
     hipLaunchKernelGGL(k_me_picture, dim3((unsigned)nlcu), dim3(NT), 0, ctx->stream, *p, make_view(cur),
-                       make_view(ref0), make_view(ref1), d_out);
+                       make_view(ref0), make_view(ref1), d_out, lcu_begin);
     HIP_TRY(hipGetLastError());
     return svt_amd_stamp_end(ctx);
 }

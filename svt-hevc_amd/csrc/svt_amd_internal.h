@@ -74,7 +74,8 @@ int svt_amd_stamp_end(SvtAmdContext *ctx);
 /* kernel launchers (prep_kernels.hip / me_kernels.hip) */
 int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_luma, uint32_t stride);
 int svt_amd_launch_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, const DevPicture *cur,
-                      const DevPicture *ref0, const DevPicture *ref1, SvtAmdMeLcuResult *d_out);
+                      const DevPicture *ref0, const DevPicture *ref1, SvtAmdMeLcuResult *d_out, int lcu_begin,
+                      int lcu_end);
 
 static inline PicView make_view(const DevPicture *p)
 {

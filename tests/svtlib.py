@@ -160,6 +160,7 @@ def load_product():
     _sig(lib.svt_amd_me_picture, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int), vp])
     _sig(lib.svt_amd_me_picture_launch, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int)])
     _sig(lib.svt_amd_me_picture_fetch, i, [vp, i, vp])
+    _sig(lib.svt_amd_me_picture_range_launch, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int), u32, u32])
     _sig(lib.svt_amd_synchronize, i, [vp])
     _sig(lib.svt_amd_timer_begin, i, [vp])
     _sig(lib.svt_amd_timer_end, i, [vp, C.POINTER(C.c_float)])
