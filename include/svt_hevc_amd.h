@@ -174,6 +174,21 @@ SVT_AMD_API int svt_amd_me_picture(SvtAmdContext *ctx, const SvtAmdMeParams *par
 SVT_AMD_API int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params,
                                           int cur_slot, const int ref_slot[2]);
 SVT_AMD_API int svt_amd_me_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out);
+/*
+ * Batched form: motion estimation of up to 256 pictures in ONE launch (grid = pictures x LCUs).
+ * The front half is open loop, so every picture whose source and reference pictures have been
+ * uploaded can be searched at once; this is what fills the 256 CUs (a single 1080p picture is
+ * only 510 workgroups).  Results land in each current slot's result buffer (svt_amd_me_picture_fetch).
+ * Reference analogue: several pictures are in flight across the 60 ME segment tasks per picture
+ * (EbEncHandle.c:1680-1681, pictureControlSetPoolInitCount :1796-1809).
+ */
+typedef struct SvtAmdMeJob {
+    SvtAmdMeParams params;
+    int32_t cur_slot;
+    int32_t ref_slot[2];
+} SvtAmdMeJob;
+SVT_AMD_API int svt_amd_me_batch_launch(SvtAmdContext *ctx, const SvtAmdMeJob *jobs, int num_jobs);
+
 /* LCU-range form for multi-GPU sharding of one picture by LCU rows: only
  * records [lcu_begin, lcu_end) of the slot's result buffer are written.  The reference's
  * analogue is the 6x10 ME segment grid (EbEncHandle.c:1680-1681). */
@@ -190,6 +205,12 @@ SVT_AMD_API int svt_amd_timer_end(SvtAmdContext *ctx, float *elapsed_ms);
  * last svt_amd_timer_begin; kernel_class in {"me_search","me_subpel","prep"} */
 SVT_AMD_API int svt_amd_kernel_time(SvtAmdContext *ctx, const char *kernel_class,
                                     float *avg_ms, int *launches);
+
+/* Development aid: per-workgroup phase clock stamps of the next batched ME launch
+ * (call with out == NULL to arm for `workgroups` = jobs x max LCUs, again with a buffer of
+ * workgroups*16 u64 to collect).  tools/me_phase_profile.py prints the breakdown. */
+SVT_AMD_API int svt_amd_debug_me_phase_profile(SvtAmdContext *ctx, size_t workgroups,
+                                               unsigned long long *out);
 
 /* Debug/parity access to the device-built planes of a slot (host copies).
  * which: 0 full, 1 quarter, 2 sixteenth, 3 half-pel b, 4 half-pel h, 5 half-pel j.

@@ -68,6 +68,10 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
             (void)hipFree(s->d_staging);
     }
     free(ctx->slots);
+    if (ctx->d_jobs)
+        (void)hipFree(ctx->d_jobs);
+    if (ctx->d_dbg)
+        (void)hipFree(ctx->d_dbg);
     for (int i = 0; i < ctx->cap_stamps; i++) {
         (void)hipEventDestroy(ctx->stamps[i].a);
         (void)hipEventDestroy(ctx->stamps[i].b);
@@ -114,6 +118,10 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
     CHK(hipEventCreate(&ctx->ev_end));
 #undef CHK
     const int nlcu = ((max_luma_width + 63) / 64) * ((max_luma_height + 63) / 64);
+    if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_jobs, sizeof(MeJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
+        svt_amd_set_error("hipMalloc(job descriptors) failed");
+        rc = SVT_AMD_ERR_RESOURCES;
+    }
     for (int i = 0; rc == SVT_AMD_OK && i < num_picture_slots; i++) {
         DevPicture *s = &ctx->slots[i];
         const int w = max_luma_width, h = max_luma_height;
@@ -344,22 +352,94 @@ static int validate_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, int cur_slot
     return SVT_AMD_OK;
 }
 
-extern "C" int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
-                                               const int ref_slot[2], uint32_t lcu_begin, uint32_t lcu_end)
+static int make_job(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot, const int ref_slot[2],
+                    uint32_t lcu_begin, uint32_t lcu_end, MeJobDev *job)
 {
     int rc = validate_me(ctx, params, cur_slot, ref_slot);
     if (rc)
         return rc;
     const uint32_t nlcu = ((params->luma_width + 63u) / 64u) * ((params->luma_height + 63u) / 64u);
     if (lcu_begin >= lcu_end || lcu_end > nlcu) {
-        svt_amd_set_error("svt_amd_me_picture_range_launch: bad LCU range [%u,%u) of %u", lcu_begin, lcu_end, nlcu);
+        svt_amd_set_error("motion estimation: bad LCU range [%u,%u) of %u", lcu_begin, lcu_end, nlcu);
         return SVT_AMD_ERR_BAD_PARAM;
     }
-    HIP_TRY(hipSetDevice(ctx->device));
     DevPicture *c = &ctx->slots[cur_slot];
     const DevPicture *r0 = &ctx->slots[ref_slot[0]];
     const DevPicture *r1 = params->num_lists == 2 ? &ctx->slots[ref_slot[1]] : r0;
-    return svt_amd_launch_me(ctx, params, c, r0, r1, c->d_me_out, (int)lcu_begin, (int)lcu_end);
+    job->P = *params;
+    job->cur = make_view(c);
+    job->ref0 = make_view(r0);
+    job->ref1 = make_view(r1);
+    job->out = c->d_me_out;
+    job->lcu_begin = (int32_t)lcu_begin;
+    job->lcu_count = (int32_t)(lcu_end - lcu_begin);
+    job->dbg_clock = NULL;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
+                                               const int ref_slot[2], uint32_t lcu_begin, uint32_t lcu_end)
+{
+    MeJobDev job;
+    int rc = make_job(ctx, params, cur_slot, ref_slot, lcu_begin, lcu_end, &job);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_amd_launch_me_batch(ctx, &job, 1, job.lcu_count);
+}
+
+extern "C" int svt_amd_me_batch_launch(SvtAmdContext *ctx, const SvtAmdMeJob *jobs, int num_jobs)
+{
+    if (!ctx || !jobs || num_jobs < 1 || num_jobs > SVT_AMD_MAX_BATCH) {
+        svt_amd_set_error("svt_amd_me_batch_launch: 1..%d jobs", SVT_AMD_MAX_BATCH);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    MeJobDev *dj = (MeJobDev *)malloc(sizeof(MeJobDev) * (size_t)num_jobs);
+    if (!dj)
+        return SVT_AMD_ERR_RESOURCES;
+    int rc = SVT_AMD_OK, max_lcus = 0;
+    for (int i = 0; i < num_jobs && rc == SVT_AMD_OK; i++) {
+        const SvtAmdMeParams *p = &jobs[i].params;
+        const uint32_t nlcu = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
+        rc = make_job(ctx, p, jobs[i].cur_slot, jobs[i].ref_slot, 0, nlcu, &dj[i]);
+        max_lcus = dj[i].lcu_count > max_lcus ? dj[i].lcu_count : max_lcus;
+    }
+    if (rc == SVT_AMD_OK) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess && ctx->d_dbg && (size_t)num_jobs * max_lcus <= ctx->dbg_slots)
+            for (int i = 0; i < num_jobs; i++)
+                dj[i].dbg_clock = ctx->d_dbg;
+        rc = e == hipSuccess ? svt_amd_launch_me_batch(ctx, dj, num_jobs, max_lcus) : SVT_AMD_ERR_DEVICE;
+    }
+    free(dj);
+    return rc;
+}
+
+/* Phase profile of the NEXT batched ME launches: arms a device buffer of 16 shader-clock stamps
+ * per workgroup; a second call with out != NULL copies the stamps of the last launch
+ * (workgroups x 16 u64) and disarms.  Development aid, not part of the reference surface. */
+extern "C" int svt_amd_debug_me_phase_profile(SvtAmdContext *ctx, size_t workgroups, unsigned long long *out)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!out) {
+        if (ctx->d_dbg)
+            (void)hipFree(ctx->d_dbg);
+        ctx->d_dbg = NULL;
+        HIP_TRY(hipMalloc((void **)&ctx->d_dbg, workgroups * 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ctx->d_dbg, 0, workgroups * 16 * sizeof(unsigned long long)));
+        ctx->dbg_slots = workgroups;
+        return SVT_AMD_OK;
+    }
+    if (!ctx->d_dbg || workgroups > ctx->dbg_slots)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, ctx->d_dbg, workgroups * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(ctx->d_dbg);
+    ctx->d_dbg = NULL;
+    ctx->dbg_slots = 0;
+    return SVT_AMD_OK;
 }
 
 extern "C" int svt_amd_me_picture_launch(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,

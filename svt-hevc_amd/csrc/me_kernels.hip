@@ -29,6 +29,9 @@
 
 #define NT 256
 #define LCU 64
+#ifndef ME_MIN_WAVES_PER_SIMD
+#define ME_MIN_WAVES_PER_SIMD 3 /* LDS (static + windows ~ 53 KB at cfg2) admits 3 workgroups per CU */
+#endif
 #define MAX_SAD_VALUE (64 * 64 * 255)
 #define COST_PRECISION 8
 #define MD_SHIFT 23
@@ -76,6 +79,48 @@ __device__ __forceinline__ uint32_t row_sad(const uint8_t *a, const uint8_t *b, 
     return s;
 }
 
+/* N consecutive dwords from an UNALIGNED LDS byte address, fetched as N+1 aligned dwords and
+ * funnel-shifted with v_alignbyte_b32.  (Unaligned ds_read_b32 works on gfx950 but stalls the
+ * LDS pipe: SQ_LDS_UNALIGNED_STALL was 75 % of all LDS cycles before this - profiles/r01.) */
+template <int N>
+__device__ __forceinline__ void lds_ld_unaligned(const uint8_t *p, uint32_t (&out)[N])
+{
+    const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;
+    const uint32_t *q = (const uint32_t *)(p - sh);
+    uint32_t prev = q[0];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t nx = q[i + 1];
+        out[i] = __builtin_amdgcn_alignbyte(nx, prev, sh);
+        prev = nx;
+    }
+}
+
+/* row SAD, a = aligned LDS source row, b = unaligned LDS window row, w samples (w even) */
+__device__ __forceinline__ uint32_t row_sad_lds(const uint8_t *a, const uint8_t *b, int w)
+{
+    uint32_t s = 0;
+    int x = 0;
+    for (; x + 16 <= w; x += 16) {
+        uint32_t r[4];
+        lds_ld_unaligned<4>(b + x, r);
+        const uint4 sv = *(const uint4 *)(a + x);
+        s = sad4(sv.x, r[0], s), s = sad4(sv.y, r[1], s), s = sad4(sv.z, r[2], s), s = sad4(sv.w, r[3], s);
+    }
+    for (; x + 4 <= w; x += 4) {
+        uint32_t r[1];
+        lds_ld_unaligned<1>(b + x, r);
+        s = sad4(*(const uint32_t *)(a + x), r[0], s);
+    }
+    if (x < w) {
+        uint32_t r[1];
+        lds_ld_unaligned<1>(b + x, r);
+        const uint32_t m = (1u << (8 * (w - x))) - 1u;
+        s = sad4(*(const uint32_t *)(a + x) & m, r[0] & m, s);
+    }
+    return s;
+}
+
 __device__ __forceinline__ uint32_t ssd4(uint32_t a, uint32_t b)
 {
     uint32_t s = 0;
@@ -85,6 +130,32 @@ __device__ __forceinline__ uint32_t ssd4(uint32_t a, uint32_t b)
         s += (uint32_t)(d * d);
     }
     return s;
+}
+
+/* A rectangle of a reference plane staged in LDS (dynamic pool).  Rows start on 16-byte
+ * boundaries of the plane so the staging loads are aligned dwordx4 and coalesced. */
+struct LWin {
+    const uint8_t *p; /* LDS address of plane sample (x0, y0) */
+    int x0, y0, stride;
+};
+extern __shared__ __attribute__((aligned(16))) uint8_t g_pool[];
+
+__device__ __forceinline__ const uint8_t *wat(const LWin &w, int x, int y)
+{
+    return w.p + (y - w.y0) * w.stride + (x - w.x0);
+}
+/* stage plane samples [x0,x1) x [y0,y1) at LDS offset `off` of the pool; returns the new offset */
+__device__ __forceinline__ int load_window(LWin &w, int off, const uint8_t *plane, int pitch, int x0, int y0, int x1,
+                                           int y1, int t)
+{
+    const int xa = x0 & ~15, wa = ((x1 - xa) + 15) & ~15, n16 = wa >> 4, rows = y1 - y0;
+    uint8_t *dst = g_pool + off;
+    w.p = dst, w.x0 = xa, w.y0 = y0, w.stride = wa;
+    for (int i = t; i < rows * n16; i += NT) {
+        const int r = i / n16, c = i - r * n16;
+        *(uint4 *)(dst + r * wa + c * 16) = *(const uint4 *)(plane + (ptrdiff_t)(y0 + r) * pitch + xa + c * 16);
+    }
+    return off + rows * wa;
 }
 
 /* Z-order <-> raster (tab32x32 / tab8x8, EbMotionEstimation.c:98-102) */
@@ -198,47 +269,84 @@ struct MeShared {
     unsigned long long hs[3][2][2];
     int cx, cy;                    /* search centre of the current list                    */
     int e32, e16, e8, eq;
+    int sums[9];                   /* SuPelEnable: per tier {sum mvx, sum mvy, sum sad} */
+    int qp[4][4];                  /* HME quadrant search areas {origin x, origin y, width, height}         */
+    int cand[6][4];                /* LCU-SAD candidates {unclamped x, y, clamped x, y}                     */
 };
 
 /* ------------------------------------------------------------------------- */
 
-template <int DUMMY>
-__device__ void lcu_sads(MeShared &S, const uint8_t *ref, int pitch, int ox, int oy, int lw, int lh, int ncand,
-                         const int *cdx, const int *cdy, int t)
+/* Sub-sampled LCU SAD against the reference at the displacements S.cand[c][2..3]:
+ * NxMSadKernel(lcuSrcPtr, stride<<1, ref, stride<<1, lcuHeight>>1, lcuWidth) per candidate.
+ * One (candidate,row) item per thread; the caller must have synchronised S.cand. */
+__device__ void lcu_sads(MeShared &S, const uint8_t *ref, int pitch, int ox, int oy, int lw, int lh, int ncand, int t)
 {
-    /* NxMSadKernel(lcuSrcPtr, stride<<1, ref, stride<<1, lcuHeight>>1, lcuWidth) per candidate */
     if (t < 8)
         S.acc[t] = 0;
     __syncthreads();
-    const int rows = lh >> 1;
-    for (int i = t; i < ncand * rows; i += NT) {
-        const int c = i / rows, r = i - c * rows;
-        const uint32_t s = row_sad(&S.src[(2 * r) * LCU], ref + (ptrdiff_t)(oy + cdy[c] + 2 * r) * pitch + ox + cdx[c], lw);
-        atomicAdd(&S.acc[c], s);
+    const int rows = lh >> 1; /* <= 32 */
+    for (int i = t; i < ncand * 32; i += NT) {
+        const int c = i >> 5, r = i & 31;
+        if (r < rows) {
+            const uint32_t s = row_sad(&S.src[(2 * r) * LCU],
+                                       ref + (ptrdiff_t)(oy + S.cand[c][3] + 2 * r) * pitch + ox + S.cand[c][2], lw);
+            atomicAdd(&S.acc[c], s);
+        }
     }
     __syncthreads();
 }
 
-/* One HME pass over up to four quadrants of one pyramid level.
+/* exact p / d for p < 40000, d < 300 with r = (1<<24)/d + 1 (checked exhaustively) */
+__device__ __forceinline__ uint32_t fastdiv_recip(uint32_t d) { return (1u << 24) / d + 1u; }
+__device__ __forceinline__ uint32_t fastdiv(uint32_t p, uint32_t r) { return (uint32_t)(((unsigned long long)p * r) >> 24); }
+
+/* One HME pass over up to four quadrants of one pyramid level.  Each quadrant's search
+ * window is first staged in LDS (coalesced 16-byte loads).  A search position is then
+ * owned by a group of `rows` adjacent lanes (8 / 16 / 32 at level 0 / 1 / 2), one block
+ * row per lane; the row SADs are summed with a butterfly over the group, so all four
+ * waves stay busy even for the 32-position level-1 searches.
  * SadLoopKernel semantics (C_DEFAULT/EbComputeSAD_C.c:170): raster scan, strict '<'. */
 __device__ void hme_pass(MeShared &S, int level, const uint8_t *refplane, int pitch, int bx0, int by0, int bw,
-                         int rows, int nq, const int *qox, const int *qoy, const int *qw, const int *qh, int t)
+                         int rows, int nq, int t)
 {
     if (t < 4)
         S.hkey[t] = ~0ull;
+    {
+        int off = 0;
+        for (int q = 0; q < nq; q++) {
+            const int qx = S.qp[q][0], qy = S.qp[q][1], qw = S.qp[q][2], qh = S.qp[q][3];
+            LWin w;
+            off = load_window(w, off, refplane, pitch, bx0 + qx, by0 + qy, bx0 + qx + qw + bw,
+                              by0 + qy + qh + 2 * (rows - 1) + 1, t);
+        }
+    }
     __syncthreads();
     const uint8_t *src = level == 0 ? S.ssrc : level == 1 ? S.qsrc : S.src;
     const int sstride = level == 0 ? 16 : level == 1 ? 32 : 2 * LCU;
+    const int lg = level == 0 ? 3 : level == 1 ? 4 : 5; /* log2(rows) */
+    const int y = t & (rows - 1);
+    const uint8_t *srow = src + y * sstride;
+    int off = 0;
     for (int q = 0; q < nq; q++) {
-        const int npos = qw[q] * qh[q];
+        const int qx = S.qp[q][0], qy = S.qp[q][1], qw = S.qp[q][2], qh = S.qp[q][3];
+        /* same geometry as load_window computed above */
+        const int x0 = bx0 + qx, xa = x0 & ~15, wstride = ((x0 + qw + bw - xa) + 15) & ~15;
+        const int wrows = qh + 2 * (rows - 1) + 1;
+        const uint8_t *wbase = g_pool + off + (x0 - xa) + y * 2 * wstride;
+        off += wrows * wstride;
+        const int npos = qw * qh, items = npos << lg;
+        const uint32_t rc = fastdiv_recip((uint32_t)(qw > 0 ? qw : 1));
         unsigned long long best = ~0ull;
-        for (int p = t; p < npos; p += NT) {
-            const int sy = p / qw[q], sx = p - sy * qw[q];
-            const uint8_t *r = refplane + (ptrdiff_t)(by0 + qoy[q] + sy) * pitch + bx0 + qox[q] + sx;
-            uint32_t s = 0;
-            for (int y = 0; y < rows; y++)
-                s += row_sad(src + y * sstride, r + (ptrdiff_t)(2 * y) * pitch, bw);
-            const unsigned long long k = ((unsigned long long)s << 32) | (uint32_t)p;
+        for (int i0 = 0; i0 < items; i0 += NT) { /* uniform trip count: every lane joins the butterfly */
+            const int p = (i0 + t) >> lg;
+            uint32_t sv = 0;
+            if (p < npos) {
+                const int sy = (int)fastdiv((uint32_t)p, rc), sx = p - sy * qw;
+                sv = row_sad_lds(srow, wbase + sy * wstride + sx, bw);
+            }
+            for (int o = rows >> 1; o > 0; o >>= 1)
+                sv += __shfl_xor(sv, o);
+            const unsigned long long k = p < npos ? (((unsigned long long)sv << 32) | (uint32_t)p) : ~0ull;
             best = k < best ? k : best;
         }
         best = wave_min64(best);
@@ -261,10 +369,25 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
     }
 }
 
-__global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur, PicView ref0, PicView ref1,
-                                                   SvtAmdMeLcuResult *__restrict__ out, int lcu_begin)
+/* optional phase profile: when the job carries a debug buffer, thread 0 of every workgroup
+ * stores the shader clock at each phase boundary (svt_amd_debug_me_phase_profile) */
+#define STAMP(i)                                                                      \
+    do {                                                                              \
+        if (J.dbg_clock && t == 0)                                                    \
+            J.dbg_clock[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+
+/* grid = (max LCUs of any job, jobs): one workgroup per (picture, LCU) */
+__global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const MeJobDev *__restrict__ jobs)
 {
     __shared__ MeShared S;
+    const MeJobDev &J = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= J.lcu_count)
+        return;
+    const SvtAmdMeParams P = J.P;
+    const PicView cur = J.cur, ref0 = J.ref0, ref1 = J.ref1;
+    SvtAmdMeLcuResult *__restrict__ out = J.out;
+    const int lcu_begin = J.lcu_begin;
     const int t = threadIdx.x;
     const int W = P.luma_width, H = P.luma_height;
     const int wl = (W + LCU - 1) / LCU;
@@ -274,6 +397,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
     const int pf = cur.pitch_full;
     const int method = P.fractional_search_method;
 
+    STAMP(0);
     /* ---- stage the source LCU (EbMotionEstimationProcess.c:714-779) ---- */
     for (int i = t; i < LCU * LCU / 4; i += NT) {
         const int y = i >> 4, x = (i & 15) << 2;
@@ -303,6 +427,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
     }
     __syncthreads();
 
+    LWin wF, wB, wH, wJ; /* LDS windows of the current list's reference planes */
     int hme_init_done = 0;
     int sa_x[2] = {0, 0}, sa_y[2] = {0, 0}, sa_w[2] = {0, 0}, sa_h[2] = {0, 0};
     int hcx[2] = {0, 0}, hcy[2] = {0, 0};
@@ -312,101 +437,94 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
         int cx = 0, cy = 0;
 
         if (P.temporal_layer_index > 0 || list == 0) {
+            if (list == 0) STAMP(1);
             /* ---- TestSearchAreaBounds (EbMotionEstimation.c:3363-3665) ---- */
             if (P.update_hme_search_center) {
-                int cdx[6], cdy[6], ux[6], uy[6];
-                ux[0] = 0, uy[0] = 0;
-                ux[1] = -(int)P.hme_l0_total_w, uy[1] = 0;
-                ux[2] = (int)P.hme_l0_total_w, uy[2] = 0;
-                ux[3] = 0, uy[3] = -(int)P.hme_l0_total_h;
-                ux[4] = 0, uy[4] = (int)P.hme_l0_total_h;
-                ux[5] = 0 - (mvx(S.best_mv[0][0]) >> 2), uy[5] = 0 - (mvy(S.best_mv[0][0]) >> 2);
                 const int nc = list == 1 ? 6 : 5;
-                for (int k = 0; k < 6; k++) {
-                    ux[k] = (int16_t)ux[k], uy[k] = (int16_t)uy[k];
-                    cdx[k] = k ? clamp_center(ox, ux[k], LCU - 1, W) : 0;
-                    cdy[k] = k ? clamp_center(oy, uy[k], LCU - 1, H) : 0;
+                if (t < 6) { /* candidate t: zero, A, B, C, D, direct (list-0 64x64 MV mirrored) */
+                    int ux = t == 1 ? -(int)P.hme_l0_total_w : t == 2 ? (int)P.hme_l0_total_w
+                             : t == 5 ? 0 - (mvx(S.best_mv[0][0]) >> 2) : 0;
+                    int uy = t == 3 ? -(int)P.hme_l0_total_h : t == 4 ? (int)P.hme_l0_total_h
+                             : t == 5 ? 0 - (mvy(S.best_mv[0][0]) >> 2) : 0;
+                    ux = (int16_t)ux, uy = (int16_t)uy;
+                    S.cand[t][0] = ux, S.cand[t][1] = uy;
+                    S.cand[t][2] = t ? clamp_center(ox, ux, LCU - 1, W) : 0;
+                    S.cand[t][3] = t ? clamp_center(oy, uy, LCU - 1, H) : 0;
                 }
-                lcu_sads<0>(S, R.full, R.pitch_full, ox, oy, lw, lh, nc, cdx, cdy, t);
-                unsigned long long cost[6], best = ~0ull;
-                for (int k = 0; k < 6; k++) {
-                    cost[k] = k < nc ? ((unsigned long long)(S.acc[k] << 1) << COST_PRECISION) : 0xFFFFFFFFFFFFFull;
-                    best = cost[k] < best ? cost[k] : best;
-                }
-                const int order[6] = {0, 1, 2, 3, 5, 4}; /* zero, A, B, C, direct, D */
-                for (int i = 5; i >= 0; i--)
-                    if (best == cost[order[i]])
-                        cx = ux[order[i]], cy = uy[order[i]];
-                __syncthreads(); /* S.acc is reused below */
+                __syncthreads();
+                lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, nc, t);
+                /* tie order: zero, A, B, C, direct, D (:3634-3658); costs are sad << 9 */
+                const uint32_t a0 = S.acc[0], a1 = S.acc[1], a2 = S.acc[2], a3 = S.acc[3], a4 = S.acc[4],
+                               a5 = nc == 6 ? S.acc[5] : 0xffffffffu;
+                uint32_t best = a0;
+                best = a1 < best ? a1 : best, best = a2 < best ? a2 : best, best = a3 < best ? a3 : best;
+                best = a4 < best ? a4 : best, best = a5 < best ? a5 : best;
+                const int pick = best == a0 ? 0 : best == a1 ? 1 : best == a2 ? 2 : best == a3 ? 3 : best == a5 ? 5 : 4;
+                cx = S.cand[pick][0], cy = S.cand[pick][1];
+                __syncthreads(); /* S.acc / S.cand are reused below */
             }
 
+            if (list == 0) STAMP(2);
             /* ---- HME (EbMotionEstimation.c:3800-4069) ---- */
             if (P.enable_hme_flag && lh == LCU) {
                 const int nw = P.num_hme_regions_w, nh = P.num_hme_regions_h;
+                const int one = (P.one_quadrant_hme && !P.enable_hme_level1 && !P.enable_hme_level2);
+                const int nq = nw * nh;
+                const int qh_ = t < 4 ? (nw == 2 ? (t >> 1) : t) : 0, qw_ = t < 4 ? (nw == 2 ? (t & 1) : 0) : 0; /* q = h*nw + w */
                 if (!hme_init_done) {
-                    if (t == 0)
-                        for (int h = 0; h < imin(nh, 2); h++)
-                            for (int w = 0; w < imin(nw, 2); w++) {
-                                const int sh0 = P.update_hme_search_center ? 2 : 0, sh1 = P.update_hme_search_center ? 1 : 0;
-                                S.hx[0][w][h] = (int16_t)(cx >> sh0), S.hy[0][w][h] = (int16_t)(cy >> sh0);
-                                S.hx[1][w][h] = (int16_t)(cx >> sh1), S.hy[1][w][h] = (int16_t)(cy >> sh1);
-                                S.hx[2][w][h] = (int16_t)cx, S.hy[2][w][h] = (int16_t)cy;
-                            }
+                    if (t < nq) {
+                        const int sh0 = P.update_hme_search_center ? 2 : 0, sh1 = P.update_hme_search_center ? 1 : 0;
+                        S.hx[0][qw_][qh_] = (int16_t)(cx >> sh0), S.hy[0][qw_][qh_] = (int16_t)(cy >> sh0);
+                        S.hx[1][qw_][qh_] = (int16_t)(cx >> sh1), S.hy[1][qw_][qh_] = (int16_t)(cy >> sh1);
+                        S.hx[2][qw_][qh_] = (int16_t)cx, S.hy[2][qw_][qh_] = (int16_t)cy;
+                    }
                     hme_init_done = 1;
                     __syncthreads();
                 }
                 const uint32_t mx = P.hme_l0_mult_x, my = P.hme_l0_mult_y;
-                int qox[4], qoy[4], qw[4], qh[4];
                 if (P.enable_hme_level0) {
                     const int px16 = ox >> 2, py16 = oy >> 2;
                     const int pw16 = W >> 2, ph16 = H >> 2, pad16 = SVT_AMD_PAD_SIXTEENTH - 1;
-                    int nq;
-                    if (P.one_quadrant_hme && !P.enable_hme_level1 && !P.enable_hme_level2) {
-                        /* EbHevcHmeOneQuadrantLevel0 (:1847-2010) */
-                        int sw = (int16_t)((P.hme_l0_total_w * mx) / 100), sh = (int16_t)((P.hme_l0_total_h * my) / 100);
-                        int so_x = -(int)(int16_t)(sw >> 1) + (cx >> 2), so_y = -(int)(int16_t)(sh >> 1) + (cy >> 2);
-                        clamp_area(px16, pad16, pw16, so_x, sw);
-                        clamp_area(py16, pad16, ph16, so_y, sh);
-                        if (sw & 15)
-                            sw = (sw >> 4) << 4;
-                        qox[0] = so_x, qoy[0] = so_y, qw[0] = sw, qh[0] = sh;
-                        nq = 1;
-                    } else {
-                        nq = 0;
-                        for (int h = 0; h < nh; h++)
-                            for (int w = 0; w < nw; w++) {
-                                int sw = (int16_t)((P.hme_l0_w[w] * mx) / 100), sh = (int16_t)((P.hme_l0_h[h] * my) / 100);
-                                int dx = cx >> 2, dy = cy >> 2;
-                                for (int k = w; k > 0; k--)
-                                    dx += (int16_t)((P.hme_l0_w[k - 1] * mx) / 100);
-                                for (int k = h; k > 0; k--)
-                                    dy += (int16_t)((P.hme_l0_h[k - 1] * my) / 100);
-                                int so_x = (int16_t)(-(int)(int16_t)(((P.hme_l0_total_w * mx) / 100) >> 1) + dx);
-                                int so_y = (int16_t)(-(int)(int16_t)(((P.hme_l0_total_h * my) / 100) >> 1) + dy);
-                                clamp_area(px16, pad16, pw16, so_x, sw);
-                                clamp_area(py16, pad16, ph16, so_y, sh);
-                                qox[nq] = so_x, qoy[nq] = so_y, qw[nq] = sw, qh[nq] = sh;
-                                nq++;
-                            }
+                    const int nq0 = one ? 1 : nq;
+                    if (t < nq0) { /* thread q derives quadrant q = (qw_, qh_) */
+                        int sw, sh, so_x, so_y;
+                        if (one) {
+                            /* EbHevcHmeOneQuadrantLevel0 (:1847-2010) */
+                            sw = (int16_t)((P.hme_l0_total_w * mx) / 100), sh = (int16_t)((P.hme_l0_total_h * my) / 100);
+                            so_x = -(int)(int16_t)(sw >> 1) + (cx >> 2), so_y = -(int)(int16_t)(sh >> 1) + (cy >> 2);
+                            clamp_area(px16, pad16, pw16, so_x, sw);
+                            clamp_area(py16, pad16, ph16, so_y, sh);
+                            if (sw & 15)
+                                sw = (sw >> 4) << 4;
+                        } else {
+                            sw = (int16_t)((P.hme_l0_w[qw_] * mx) / 100), sh = (int16_t)((P.hme_l0_h[qh_] * my) / 100);
+                            int dx = cx >> 2, dy = cy >> 2;
+                            if (qw_)
+                                dx += (int16_t)((P.hme_l0_w[0] * mx) / 100);
+                            if (qh_)
+                                dy += (int16_t)((P.hme_l0_h[0] * my) / 100);
+                            so_x = (int16_t)(-(int)(int16_t)(((P.hme_l0_total_w * mx) / 100) >> 1) + dx);
+                            so_y = (int16_t)(-(int)(int16_t)(((P.hme_l0_total_h * my) / 100) >> 1) + dy);
+                            clamp_area(px16, pad16, pw16, so_x, sw);
+                            clamp_area(py16, pad16, ph16, so_y, sh);
+                        }
+                        S.qp[t][0] = so_x, S.qp[t][1] = so_y, S.qp[t][2] = sw, S.qp[t][3] = sh;
                     }
-                    hme_pass(S, 0, R.sixteenth, R.pitch_sixteenth, px16, py16, lw >> 2, 8, nq, qox, qoy, qw, qh, t);
-                    if (t == 0) {
-                        int q = 0;
-                        const int one = (P.one_quadrant_hme && !P.enable_hme_level1 && !P.enable_hme_level2);
-                        for (int h = 0; h < (one ? 1 : nh); h++)
-                            for (int w = 0; w < (one ? 1 : nw); w++, q++) {
-                                const unsigned long long k = S.hkey[q];
-                                if (k != ~0ull) { /* an empty search leaves the centre untouched */
-                                    const int p = (int)(uint32_t)k, sy = p / qw[q], sx = p - sy * qw[q];
-                                    S.hx[0][w][h] = (int16_t)((int16_t)(sx + qox[q]) * 4);
-                                    S.hy[0][w][h] = (int16_t)((int16_t)(sy + qoy[q]) * 4);
-                                    S.hs[0][w][h] = (k >> 32) * 2;
-                                } else {
-                                    S.hs[0][w][h] = 0xffffffull * 2;
-                                    S.hx[0][w][h] = (int16_t)((int16_t)(S.hx[0][w][h] + qox[q]) * 4);
-                                    S.hy[0][w][h] = (int16_t)((int16_t)(S.hy[0][w][h] + qoy[q]) * 4);
-                                }
-                            }
+                    __syncthreads();
+                    hme_pass(S, 0, R.sixteenth, R.pitch_sixteenth, px16, py16, lw >> 2, 8, nq0, t);
+                    if (t < nq0) {
+                        const unsigned long long k = S.hkey[t];
+                        const int qx = S.qp[t][0], qy = S.qp[t][1], qwv = S.qp[t][2];
+                        if (k != ~0ull) { /* an empty search leaves the centre untouched */
+                            const int p = (int)(uint32_t)k, sy = p / qwv, sx = p - sy * qwv;
+                            S.hx[0][qw_][qh_] = (int16_t)((int16_t)(sx + qx) * 4);
+                            S.hy[0][qw_][qh_] = (int16_t)((int16_t)(sy + qy) * 4);
+                            S.hs[0][qw_][qh_] = (k >> 32) * 2;
+                        } else {
+                            S.hs[0][qw_][qh_] = 0xffffffull * 2;
+                            S.hx[0][qw_][qh_] = (int16_t)((int16_t)(S.hx[0][qw_][qh_] + qx) * 4);
+                            S.hy[0][qw_][qh_] = (int16_t)((int16_t)(S.hy[0][qw_][qh_] + qy) * 4);
+                        }
                     }
                     __syncthreads();
                 }
@@ -416,31 +534,26 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
                     const int shf = 2 - lvl;
                     const int bx0 = ox >> shf, by0 = oy >> shf, pwl = W >> shf, phl = H >> shf;
                     const int padl = lvl == 2 ? LCU - 1 : SVT_AMD_PAD_QUARTER - 1;
-                    int nq = 0;
-                    for (int h = 0; h < nh; h++)
-                        for (int w = 0; w < nw; w++) {
-                            int sw = hme_l12_width((int16_t)(lvl == 1 ? P.hme_l1_w[w] : P.hme_l2_w[w]));
-                            int sh = (int16_t)(lvl == 1 ? P.hme_l1_h[h] : P.hme_l2_h[h]);
-                            const int pcx = lvl == 1 ? (S.hx[0][w][h] >> 1) : S.hx[1][w][h];
-                            const int pcy = lvl == 1 ? (S.hy[0][w][h] >> 1) : S.hy[1][w][h];
-                            int so_x = (int16_t)(-(sw >> 1) + pcx), so_y = (int16_t)(-(sh >> 1) + pcy);
-                            clamp_area(bx0, padl, pwl, so_x, sw);
-                            clamp_area(by0, padl, phl, so_y, sh);
-                            qox[nq] = so_x, qoy[nq] = so_y, qw[nq] = sw, qh[nq] = sh;
-                            nq++;
-                        }
+                    if (t < nq) {
+                        int sw = hme_l12_width((int16_t)(lvl == 1 ? P.hme_l1_w[qw_] : P.hme_l2_w[qw_]));
+                        int sh = (int16_t)(lvl == 1 ? P.hme_l1_h[qh_] : P.hme_l2_h[qh_]);
+                        const int pcx = lvl == 1 ? (S.hx[0][qw_][qh_] >> 1) : S.hx[1][qw_][qh_];
+                        const int pcy = lvl == 1 ? (S.hy[0][qw_][qh_] >> 1) : S.hy[1][qw_][qh_];
+                        int so_x = (int16_t)(-(sw >> 1) + pcx), so_y = (int16_t)(-(sh >> 1) + pcy);
+                        clamp_area(bx0, padl, pwl, so_x, sw);
+                        clamp_area(by0, padl, phl, so_y, sh);
+                        S.qp[t][0] = so_x, S.qp[t][1] = so_y, S.qp[t][2] = sw, S.qp[t][3] = sh;
+                    }
+                    __syncthreads();
                     hme_pass(S, lvl, lvl == 1 ? R.quarter : R.full, lvl == 1 ? R.pitch_quarter : R.pitch_full, bx0, by0,
-                             lw >> shf, lvl == 1 ? 16 : 32, nq, qox, qoy, qw, qh, t);
-                    if (t == 0) {
-                        int q = 0;
-                        for (int h = 0; h < nh; h++)
-                            for (int w = 0; w < nw; w++, q++) {
-                                const unsigned long long k = S.hkey[q];
-                                const int p = (int)(uint32_t)k, sy = p / qw[q], sx = p - sy * qw[q];
-                                S.hx[lvl][w][h] = (int16_t)((int16_t)(sx + qox[q]) * (1 << shf));
-                                S.hy[lvl][w][h] = (int16_t)((int16_t)(sy + qoy[q]) * (1 << shf));
-                                S.hs[lvl][w][h] = (k >> 32) * 2;
-                            }
+                             lw >> shf, lvl == 1 ? 16 : 32, nq, t);
+                    if (t < nq) {
+                        const unsigned long long k = S.hkey[t];
+                        const int qx = S.qp[t][0], qy = S.qp[t][1], qwv = S.qp[t][2];
+                        const int p = (int)(uint32_t)k, sy = p / qwv, sx = p - sy * qwv;
+                        S.hx[lvl][qw_][qh_] = (int16_t)((int16_t)(sx + qx) * (1 << shf));
+                        S.hy[lvl][qw_][qh_] = (int16_t)((int16_t)(sy + qy) * (1 << shf));
+                        S.hs[lvl][qw_][qh_] = (k >> 32) * 2;
                     }
                     __syncthreads();
                 }
@@ -484,14 +597,19 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
         }
         hcx[list] = cx, hcy[list] = cy;
 
+        if (list == 0) STAMP(3);
         /* ---- EbHevcCheckZeroZeroCenter (:2946-3034) ---- */
         if (cx != 0 || cy != 0) {
             if (P.update_hme_search_center) {
                 cx = clamp_center(ox, cx, LCU - 1, W);
                 cy = clamp_center(oy, cy, LCU - 1, H);
             }
-            int cdx[2] = {0, cx}, cdy[2] = {0, cy};
-            lcu_sads<0>(S, R.full, R.pitch_full, ox, oy, lw, lh, 2, cdx, cdy, t);
+            if (t == 0) {
+                S.cand[0][2] = 0, S.cand[0][3] = 0;
+                S.cand[1][2] = cx, S.cand[1][3] = cy;
+            }
+            __syncthreads();
+            lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, 2, t);
             const uint32_t zeroSad = S.acc[0] << 1, hmeSad = S.acc[1] << 1;
             const unsigned long long zeroCost = (unsigned long long)zeroSad << COST_PRECISION;
             const uint32_t rate = mvd_fraction_bits(abs(cx << 2), abs(cy << 2), P.mvd_bits);
@@ -509,6 +627,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
         clamp_area(oy, LCU - 1, H, soy, sah);
         sa_x[list] = sox, sa_y[list] = soy, sa_w[list] = saw, sa_h[list] = sah;
 
+        if (list == 0) STAMP(4);
         /* ---- FullPelSearch_LCU (:586-633) ---- */
         {
             if (t < 85)
@@ -516,6 +635,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
             if (t == 0)
                 S.key64 = ~0ull;
             const int npos = saw * sah, mult8 = saw & ~7;
+            const uint32_t rcw = fastdiv_recip((uint32_t)saw);
             const int b = t & 63, sub = t >> 6;
             int bx, by, bsz;
             pu_geom_z(21 + b, bx, by, bsz);
@@ -526,19 +646,32 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
                 s1[r] = *(const uint32_t *)&S.src[(by + 2 * r) * LCU + bx + 4];
             }
             uint32_t best8 = 0xffffffffu;
-            const uint8_t *rbase = R.full + (ptrdiff_t)(oy + by + soy) * R.pitch_full + ox + bx + sox;
+            /* stage the search region of the four planes: F now, b/h/j for the sub-pel stages.
+             * x in [sox-2, sox+saw+63+2), y likewise (integer winner +-1 after half-pel, +-1 for the
+             * quarter-pel neighbours). */
+            {
+                const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
+                int off = load_window(wF, 0, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                off = load_window(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                off = load_window(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                off = load_window(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
+            }
+            const uint8_t *rbase = wat(wF, ox + bx + sox, oy + by + soy);
+            const int fstride = wF.stride;
             __syncthreads();
             for (int base = 0; base < npos; base += 64) {
                 for (int i = 0; i < 16; i++) {
                     const int pl = sub + 4 * i, p = base + pl;
                     if (p < npos) {
-                        const int sy = p / saw, sx = p - sy * saw;
-                        const uint8_t *r = rbase + (ptrdiff_t)sy * R.pitch_full + sx;
+                        const int sy = (int)fastdiv((uint32_t)p, rcw), sx = p - sy * saw;
+                        const uint8_t *r = rbase + sy * fstride + sx;
                         uint32_t s = 0;
 #pragma unroll
                         for (int rr = 0; rr < 4; rr++) {
-                            s = sad4(s0[rr], ld4(r + (ptrdiff_t)(2 * rr) * R.pitch_full), s);
-                            s = sad4(s1[rr], ld4(r + (ptrdiff_t)(2 * rr) * R.pitch_full + 4), s);
+                            uint32_t v[2];
+                            lds_ld_unaligned<2>(r + (2 * rr) * fstride, v);
+                            s = sad4(s0[rr], v[0], s);
+                            s = sad4(s1[rr], v[1], s);
                         }
                         S.sad8[pl][b] = (uint16_t)s;
                         const uint32_t k = (s << 14) | (uint32_t)p;
@@ -606,26 +739,32 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
             __syncthreads();
         }
 
+        if (list == 0) STAMP(5);
         /* ---- sub-pel (:4236-4318) ---- */
+        /* SuPelEnable (:3035-3361): tier sums of MV components and SADs, one PU per thread */
+        if (P.fractional_search_model == 1) {
+            if (t < 9)
+                S.sums[t] = 0;
+            __syncthreads();
+            if (t >= 1 && t < 85) {
+                const int tier = t < 5 ? 0 : t < 21 ? 1 : 2;
+                atomicAdd(&S.sums[tier * 3 + 0], mvx(S.best_mv[list][t]));
+                atomicAdd(&S.sums[tier * 3 + 1], mvy(S.best_mv[list][t]));
+                atomicAdd(&S.sums[tier * 3 + 2], (int)S.best_sad[list][t]);
+            }
+            __syncthreads();
+        }
         if (t == 0) {
             int e32 = 0, e16 = 0, e8 = 0, eq = 0;
             if (P.fractional_search_model == 0) {
                 e32 = e16 = e8 = eq = 1;
             } else if (P.fractional_search_model == 1) {
-                /* SuPelEnable (:3035-3361) */
-                const int first[3] = {1, 5, 21}, count[3] = {4, 16, 64}, shift[3] = {2, 4, 6};
+                const int shift[3] = {2, 4, 6};
                 uint32_t mag[3], avgsad[3];
                 for (int tt = 0; tt < 3; tt++) {
-                    int sx = 0, sy = 0;
-                    uint32_t ss = 0;
-                    for (int k = 0; k < count[tt]; k++) {
-                        sx += mvx(S.best_mv[list][first[tt] + k]);
-                        sy += mvy(S.best_mv[list][first[tt] + k]);
-                        ss += S.best_sad[list][first[tt] + k];
-                    }
-                    const uint32_t ux = (uint32_t)(sx >> shift[tt]), uy = (uint32_t)(sy >> shift[tt]);
+                    const uint32_t ux = (uint32_t)(S.sums[tt * 3 + 0] >> shift[tt]), uy = (uint32_t)(S.sums[tt * 3 + 1] >> shift[tt]);
                     mag[tt] = ux * ux + uy * uy;
-                    avgsad[tt] = ss >> shift[tt];
+                    avgsad[tt] = (uint32_t)S.sums[tt * 3 + 2] >> shift[tt];
                 }
                 const int tl = P.temporal_layer_index;
                 const uint32_t th = tl == 0 ? 48 * 48 : tl == 1 ? 32 * 32 : tl == 2 ? 80 * 80 : 48 * 48;
@@ -645,7 +784,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
             const int en[4] = {f64, S.e32, S.e16, S.e8};
             const int tier_first[4] = {0, 1, 5, 21}, tier_cnt[4] = {1, 4, 16, 64}, tier_sz[4] = {64, 32, 16, 8};
             const int rstep = (method == SVT_AMD_SUB_SAD_SEARCH) ? 2 : 1;
-            const PicView &RR = R;
+            if (list == 0) STAMP(6);
             /* ===== half-pel: EbHevcHalfPelSearch_LCU / PU_HalfPelRefinement (:733-1187) ===== */
             for (int i = t; i < 85 * 8; i += NT) {
                 (&S.dist[0][0])[i] = 0;
@@ -663,13 +802,17 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
                     const uint32_t mv = S.best_mv[list][n];
                     const int ax = ox + px_ + (mvx(mv) >> 2), ay = oy + py_ + (mvy(mv) >> 2) + row * rstep;
                     /* order L,R,T,B,TL,TR,BR,BL: planes b,b,h,h,j,j,j,j; offsets */
-                    const uint8_t *pl = (k < 2) ? RR.hp_b : (k < 4 ? RR.hp_h : RR.hp_j);
+                    const LWin &pl = (k < 2) ? wB : (k < 4 ? wH : wJ);
                     const int ddx = (k == 1 || k == 5 || k == 6) ? 1 : 0, ddy = (k == 3 || k == 6 || k == 7) ? 1 : 0;
-                    const uint8_t *r = pl + (ptrdiff_t)(ay + ddy) * RR.pitch_full + ax + ddx;
+                    const uint8_t *r = wat(pl, ax + ddx, ay + ddy);
                     const uint8_t *s = &S.src[(py_ + row * rstep) * LCU + px_];
                     uint32_t d = 0, sd = 0;
-                    for (int x = 0; x < sz; x += 4)
-                        row_metric(method, *(const uint32_t *)(s + x), ld4(r + x), d, sd);
+                    for (int x = 0; x < sz; x += 8) {
+                        uint32_t v[2];
+                        lds_ld_unaligned<2>(r + x, v);
+                        row_metric(method, *(const uint32_t *)(s + x), v[0], d, sd);
+                        row_metric(method, *(const uint32_t *)(s + x + 4), v[1], d, sd);
+                    }
                     atomicAdd(&S.dist[n][k], d);
                     if (method == SVT_AMD_SSD_SEARCH)
                         atomicAdd(&S.dsad[n][k], sd);
@@ -686,11 +829,14 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
                         int px_, py_, psz;
                         pu_geom_z(n, px_, py_, psz);
                         const uint32_t mv = S.best_mv[list][n];
-                        const uint8_t *r = RR.full + (ptrdiff_t)(oy + py_ + (mvy(mv) >> 2) + row) * RR.pitch_full + ox + px_ + (mvx(mv) >> 2);
+                        const uint8_t *r = wat(wF, ox + px_ + (mvx(mv) >> 2), oy + py_ + (mvy(mv) >> 2) + row);
                         const uint8_t *s = &S.src[(py_ + row) * LCU + px_];
                         uint32_t d = 0;
-                        for (int x = 0; x < sz; x += 4)
-                            d += ssd4(*(const uint32_t *)(s + x), ld4(r + x));
+                        for (int x = 0; x < sz; x += 8) {
+                            uint32_t v[2];
+                            lds_ld_unaligned<2>(r + x, v);
+                            d += ssd4(*(const uint32_t *)(s + x), v[0]) + ssd4(*(const uint32_t *)(s + x + 4), v[1]);
+                        }
                         atomicAdd(&S.best_ssd[list][n], d);
                     }
                 }
@@ -728,6 +874,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
             }
             __syncthreads();
 
+            if (list == 0) STAMP(7);
             /* ===== quarter-pel: QuarterPelSearch_LCU / PU_QuarterPelRefinementOnTheFly (:1226-1846) ===== */
             const int qen[4] = {f64, S.eq && S.e32, S.eq && S.e16, S.eq && S.e8};
             for (int i = t; i < 85 * 8; i += NT) {
@@ -760,16 +907,21 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
                     const int y = row * rstep;
                     const int ax = ox + px_ + ((xMv + 2) >> 2), ay = oy + py_ + ((yMv + 2) >> 2) + y;
                     const QSrc q0 = c_qtab[qm][k][0], q1 = c_qtab[qm][k][1];
-                    const uint8_t *planes[4] = {RR.full, RR.hp_b, RR.hp_h, RR.hp_j};
-                    const uint8_t *r1 = planes[q0.plane] + (ptrdiff_t)(ay + q0.dy) * RR.pitch_full + ax + q0.dx;
-                    const uint8_t *r2 = planes[q1.plane] + (ptrdiff_t)(ay + q1.dy) * RR.pitch_full + ax + q1.dx;
+                    const LWin &w1 = q0.plane == 0 ? wF : q0.plane == 1 ? wB : q0.plane == 2 ? wH : wJ;
+                    const LWin &w2 = q1.plane == 0 ? wF : q1.plane == 1 ? wB : q1.plane == 2 ? wH : wJ;
+                    const uint8_t *r1 = wat(w1, ax + q0.dx, ay + q0.dy);
+                    const uint8_t *r2 = wat(w2, ax + q1.dx, ay + q1.dy);
                     /* source = MeContext_t.lcuBuffer: zero outside the picture (trap A19) */
                     const int inside_y = (py_ + y) < lh;
                     const uint8_t *s = &S.src[(py_ + y) * LCU + px_];
                     uint32_t d = 0, sdv = 0;
-                    for (int x = 0; x < sz; x += 4) {
-                        const uint32_t sv = (inside_y && (px_ + x) < lw) ? *(const uint32_t *)(s + x) : 0u;
-                        row_metric(method, sv, avg4(ld4(r1 + x), ld4(r2 + x)), d, sdv);
+                    for (int x = 0; x < sz; x += 8) {
+                        uint32_t v1[2], v2[2];
+                        lds_ld_unaligned<2>(r1 + x, v1);
+                        lds_ld_unaligned<2>(r2 + x, v2);
+                        const int in = inside_y && (px_ + x) < lw; /* lw is a multiple of 8 */
+                        row_metric(method, in ? *(const uint32_t *)(s + x) : 0u, avg4(v1[0], v2[0]), d, sdv);
+                        row_metric(method, in ? *(const uint32_t *)(s + x + 4) : 0u, avg4(v1[1], v2[1]), d, sdv);
                     }
                     atomicAdd(&S.dist[n][k], d);
                     if (method == SVT_AMD_SSD_SEARCH)
@@ -806,6 +958,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
         }
     } /* lists */
 
+    STAMP(8);
     /* ---- bi-prediction (:2608-2917) ---- */
     if (P.num_lists == 2) {
         const int rstep = (method == SVT_AMD_SUB_SAD_SEARCH) ? 2 : 1;
@@ -867,6 +1020,7 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
         __syncthreads();
     }
 
+    STAMP(9);
     /* ---- candidate records (:4321-4440) ---- */
     SvtAmdMeLcuResult *o = &out[lcu];
     if (t < 85) {
@@ -921,17 +1075,71 @@ __global__ __launch_bounds__(NT) void k_me_picture(SvtAmdMeParams P, PicView cur
         o->search_w[t] = (uint8_t)sa_w[t];
         o->search_h[t] = (uint8_t)sa_h[t];
     }
+    STAMP(10);
 }
 
-int svt_amd_launch_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, const DevPicture *cur, const DevPicture *ref0,
-                      const DevPicture *ref1, SvtAmdMeLcuResult *d_out, int lcu_begin, int lcu_end)
+/* upper bound of the dynamic LDS pool a job needs: the largest of the per-phase window sets */
+static size_t me_pool_bytes(const SvtAmdMeParams *p)
 {
-    const int nlcu = lcu_end - lcu_begin;
+    auto win = [](int w, int rows) { return (size_t)((w + 30) & ~15) * (size_t)rows; };
+    size_t need = 0, v;
+    const int nq = p->num_hme_regions_w * p->num_hme_regions_h;
+    if (p->enable_hme_flag) {
+        if (p->enable_hme_level0) {
+            const int tw = (p->hme_l0_total_w * p->hme_l0_mult_x) / 100, th = (p->hme_l0_total_h * p->hme_l0_mult_y) / 100;
+            int mw = tw, mh = th;
+            for (int k = 0; k < 2; k++) {
+                mw = mw > (p->hme_l0_w[k] * p->hme_l0_mult_x) / 100 ? mw : (p->hme_l0_w[k] * p->hme_l0_mult_x) / 100;
+                mh = mh > (p->hme_l0_h[k] * p->hme_l0_mult_y) / 100 ? mh : (p->hme_l0_h[k] * p->hme_l0_mult_y) / 100;
+            }
+            v = (size_t)nq * win(mw + 16, mh + 15);
+            need = v > need ? v : need;
+        }
+        for (int lvl = 1; lvl <= 2; lvl++) {
+            if (!(lvl == 1 ? p->enable_hme_level1 : p->enable_hme_level2))
+                continue;
+            int mw = 8, mh = 1;
+            for (int k = 0; k < 2; k++) {
+                const int w = lvl == 1 ? p->hme_l1_w[k] : p->hme_l2_w[k], h = lvl == 1 ? p->hme_l1_h[k] : p->hme_l2_h[k];
+                const int ww = (w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w;
+                mw = ww > mw ? ww : mw;
+                mh = h > mh ? h : mh;
+            }
+            v = (size_t)nq * win(mw + (lvl == 1 ? 32 : 64), mh + (lvl == 1 ? 31 : 63));
+            need = v > need ? v : need;
+        }
+    }
+    const int saw = p->search_area_width > 127 ? 127 : p->search_area_width;
+    const int sah = p->search_area_height > 127 ? 127 : p->search_area_height;
+    v = 4 * win(saw + 67, sah + 67);
+    need = v > need ? v : need;
+    return (need + 64 + 255) & ~(size_t)255; /* +64: the aligned over-read of the last window row */
+}
+
+int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus)
+{
+    if (njobs < 1 || njobs > SVT_AMD_MAX_BATCH)
+        return SVT_AMD_ERR_BAD_PARAM;
+    size_t pool = 0;
+    for (int i = 0; i < njobs; i++) {
+        const size_t b = me_pool_bytes(&host_jobs[i].P);
+        pool = b > pool ? b : pool;
+    }
+    if (pool + sizeof(MeShared) > 160 * 1024) {
+        svt_amd_set_error("motion estimation: search windows need %zu B of LDS (> 160 KiB)", pool + sizeof(MeShared));
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    static size_t attr_set = 0;
+    if (pool > attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_me_picture, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool));
+        attr_set = pool;
+    }
+    /* pageable source: the runtime stages it before returning, so host_jobs may be reused */
+    HIP_TRY(hipMemcpyAsync(ctx->d_jobs, host_jobs, sizeof(MeJobDev) * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream));
     int rc = svt_amd_stamp_begin(ctx, KC_ME_SEARCH);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(k_me_picture, dim3((unsigned)nlcu), dim3(NT), 0, ctx->stream, *p, make_view(cur),
-                       make_view(ref0), make_view(ref1), d_out, lcu_begin);
+    hipLaunchKernelGGL(k_me_picture, dim3((unsigned)max_lcus, (unsigned)njobs), dim3(NT), pool, ctx->stream, ctx->d_jobs);
     HIP_TRY(hipGetLastError());
     return svt_amd_stamp_end(ctx);
 }

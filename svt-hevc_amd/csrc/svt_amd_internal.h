@@ -43,6 +43,17 @@ struct PicView {
 
 enum { KC_PREP = 0, KC_ME_SEARCH = 1, KC_COUNT = 2 };
 
+#define SVT_AMD_MAX_BATCH 256
+
+/* one motion-estimation job = one picture (or an LCU range of it) against its references */
+struct MeJobDev {
+    SvtAmdMeParams P;
+    PicView cur, ref0, ref1;
+    SvtAmdMeLcuResult *out;
+    int32_t lcu_begin, lcu_count;
+    unsigned long long *dbg_clock; /* optional: 16 clock stamps per workgroup (phase profile) */
+};
+
 struct SvtAmdContext {
     int device;
     hipStream_t stream;
@@ -54,6 +65,9 @@ struct SvtAmdContext {
     int timer_armed;
     struct Stamp { hipEvent_t a, b; int cls; } *stamps;
     int num_stamps, cap_stamps;
+    MeJobDev *d_jobs;              /* device array of SVT_AMD_MAX_BATCH job descriptors */
+    unsigned long long *d_dbg;     /* phase-profile buffer (svt_amd_debug_me_phase_profile) */
+    size_t dbg_slots;
 };
 
 void svt_amd_set_error(const char *fmt, ...);
@@ -73,9 +87,7 @@ int svt_amd_stamp_end(SvtAmdContext *ctx);
 
 /* kernel launchers (prep_kernels.hip / me_kernels.hip) */
 int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_luma, uint32_t stride);
-int svt_amd_launch_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, const DevPicture *cur,
-                      const DevPicture *ref0, const DevPicture *ref1, SvtAmdMeLcuResult *d_out, int lcu_begin,
-                      int lcu_end);
+int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus);
 
 static inline PicView make_view(const DevPicture *p)
 {

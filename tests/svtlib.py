@@ -44,6 +44,11 @@ class MeParams(C.Structure):
     ]
 
 
+class MeJob(C.Structure):
+    """SvtAmdMeJob"""
+    _fields_ = [("params", MeParams), ("cur_slot", C.c_int32), ("ref_slot", C.c_int32 * 2)]
+
+
 class MeCuResult(C.Structure):
     """SvtAmdMeCuResult"""
     _fields_ = [
@@ -160,6 +165,7 @@ def load_product():
     _sig(lib.svt_amd_me_picture, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int), vp])
     _sig(lib.svt_amd_me_picture_launch, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int)])
     _sig(lib.svt_amd_me_picture_fetch, i, [vp, i, vp])
+    _sig(lib.svt_amd_me_batch_launch, i, [vp, C.POINTER(MeJob), i])
     _sig(lib.svt_amd_me_picture_range_launch, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int), u32, u32])
     _sig(lib.svt_amd_synchronize, i, [vp])
     _sig(lib.svt_amd_timer_begin, i, [vp])

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-phase time breakdown of k_me_picture (shader-clock stamps taken by thread 0 of each
+workgroup).  usage: python tools/me_phase_profile.py [batch]   (needs the GPU)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import svtlib as S  # noqa: E402
+from golden_util import load_case  # noqa: E402
+
+NAMES = ["stage src", "TestSearchAreaBounds", "HME L0/L1/L2", "CheckZeroZero", "full-pel (+window load)",
+         "SuPelEnable", "half-pel", "quarter-pel", "bi-pred", "records"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    W, H = 1920, 1080
+    lib = S.load_product()
+    lib.svt_amd_debug_me_phase_profile.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    ctx = C.c_void_p()
+    assert lib.svt_amd_context_create(0, W, H + 8, B + 1, C.byref(ctx)) == 0
+    params = S.params_from_record(load_case("p_1920x1080_m9")["params"][0])
+    dev = torch.device("cuda", 0)
+    frames = torch.randint(0, 256, (B + 1, H, W), dtype=torch.uint8, device=dev)
+    for t in range(1, B + 1):  # smooth-ish motion: shifted copies + noise
+        frames[t] = torch.roll(frames[0], shifts=(t, 2 * t), dims=(0, 1))
+    torch.cuda.synchronize()
+    for i in range(B + 1):
+        assert lib.svt_amd_picture_upload_device(ctx, i, C.c_void_p(frames[i].data_ptr()), W, W, H) == 0
+    jobs = (S.MeJob * B)()
+    for i in range(B):
+        jobs[i].params, jobs[i].cur_slot = params, i + 1
+        jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = i
+    nlcu = S.lcu_count(W, H)
+    for _ in range(2):
+        assert lib.svt_amd_me_batch_launch(ctx, jobs, B) == 0
+    lib.svt_amd_synchronize(ctx)
+    n = B * nlcu
+    assert lib.svt_amd_debug_me_phase_profile(ctx, n, None) == 0
+    assert lib.svt_amd_me_batch_launch(ctx, jobs, B) == 0
+    buf = np.zeros((n, 16), np.uint64)
+    assert lib.svt_amd_debug_me_phase_profile(ctx, n, buf.ctypes.data) == 0
+    d = np.diff(buf[:, :11].astype(np.int64), axis=1)
+    tot = (buf[:, 10] - buf[:, 0]).astype(np.int64)
+    print("workgroups %d; clocks per workgroup: median %d, mean %d" % (n, np.median(tot), tot.mean()))
+    for i, nm in enumerate(NAMES):
+        print("  %-26s median %8d  mean %8d  (%4.1f%%)" % (nm, np.median(d[:, i]), d[:, i].mean(), 100.0 * d[:, i].mean() / tot.mean()))
+    span = int(buf[:, 10].max() - buf[:, 0].min())
+    print("kernel span %d clocks; sum of workgroup clocks / span = %.1f concurrent workgroups" % (span, tot.sum() / span))
+    lib.svt_amd_context_destroy(ctx)
+
+
+if __name__ == "__main__":
+    main()
