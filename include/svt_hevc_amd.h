@@ -300,6 +300,79 @@ SVT_AMD_API void svt_amd_Decimation2D(const uint8_t *inputSamples, uint32_t inpu
                                       uint8_t *decimSamples, uint32_t decimStride,
                                       uint32_t decimStep);
 
+/* ------------------------------------------------------------------------- */
+/* EncDec leaf families: residual, transforms, quantisation, distortion, SATD */
+/* ------------------------------------------------------------------------- */
+
+/* BATCHED forms (device pointers; block b of a size x size batch at base + b*size*size).
+ * kind: 0 DCT, 1 low-precision "Estimate" DCT (32/16 only), 2 DST (4x4 only).
+ * Replace the per-TU calls EstimateTransform/EncodeTransform -> Transform* (EbTransforms.c:3268,3343;
+ * tables EbTransforms.h:339-510), EstimateInvTransform/EncodeInvTransform (:3455,3502),
+ * QuantizeInvQuantize via UnifiedQuantizeInvQuantize (EbTransforms.c:2978), PictureFullDistortionLuma
+ * -> FullDistortionKernel*_32bit (EbPictureOperators.c:397; table EbPictureOperators.h:503) and
+ * Compute8x8Satd/Compute4x4Satd (EbPictureOperators.c:186-262, EbHmCode.c:41). */
+SVT_AMD_API int svt_amd_fwd_transform_batch(SvtAmdContext *ctx, int kind, int size, uint32_t bitIncrement,
+                                            const int16_t *d_residual, int16_t *d_coeff, uint32_t nblocks);
+SVT_AMD_API int svt_amd_inv_transform_batch(SvtAmdContext *ctx, int kind, int size, uint32_t bitIncrement,
+                                            const int16_t *d_coeff, int16_t *d_residual, uint32_t nblocks);
+SVT_AMD_API int svt_amd_quantize_batch(SvtAmdContext *ctx, int size, uint32_t qFunc, uint32_t q_offset,
+                                       int32_t shiftedQBits, int32_t shiftedFFunc, int32_t iq_offset,
+                                       int32_t shiftNum, const int16_t *d_coeff, int16_t *d_quant,
+                                       int16_t *d_recon, uint32_t *d_nz, uint32_t nblocks);
+/* mode: 0 FullDistortionKernel_32bit, 1 ...CbfZero_32bit, 2 ...Intra_32bit; d_result = 2 x u64 per block */
+SVT_AMD_API int svt_amd_full_distortion_batch(SvtAmdContext *ctx, int size, int mode, const int16_t *d_coeff,
+                                              const int16_t *d_recon, uint64_t *d_result, uint32_t nblocks);
+SVT_AMD_API int svt_amd_satd_batch(SvtAmdContext *ctx, int size, const int16_t *d_diff, uint64_t *d_satd,
+                                   uint32_t nblocks);
+
+/* LEAF forms: EB_TRANS_COEFF_* tables (EbTransforms.h:339-510); C peers C_DEFAULT/EbTransforms_C.c:1602-2119 */
+#define SVT_AMD_DECL_TRANSFORM(name)                                                                      \
+    SVT_AMD_API void svt_amd_##name(int16_t *src, const uint32_t srcStride, int16_t *dst,                 \
+                                    const uint32_t dstStride, int16_t *transformInnerArrayPtr,            \
+                                    uint32_t bitIncrement);
+SVT_AMD_DECL_TRANSFORM(Transform32x32)
+SVT_AMD_DECL_TRANSFORM(Transform32x32Estimate)
+SVT_AMD_DECL_TRANSFORM(Transform16x16)
+SVT_AMD_DECL_TRANSFORM(Transform16x16Estimate)
+SVT_AMD_DECL_TRANSFORM(Transform8x8)
+SVT_AMD_DECL_TRANSFORM(Transform4x4)
+SVT_AMD_DECL_TRANSFORM(DstTransform4x4)
+SVT_AMD_DECL_TRANSFORM(InvTransform32x32)
+SVT_AMD_DECL_TRANSFORM(InvTransform16x16)
+SVT_AMD_DECL_TRANSFORM(InvTransform8x8)
+SVT_AMD_DECL_TRANSFORM(InvTransform4x4)
+SVT_AMD_DECL_TRANSFORM(InvDstTransform4x4)
+
+/* QiQ_funcPtrArray (EbTransforms.h:271-296); C peer QuantizeInvQuantize (EbTransforms_C.c:89) */
+SVT_AMD_API void svt_amd_QuantizeInvQuantize(int16_t *coeff, const uint32_t coeffStride, int16_t *quantCoeff,
+                                             int16_t *reconCoeff, const uint32_t qFunc, const uint32_t q_offset,
+                                             const int32_t shiftedQBits, const int32_t shiftedFFunc,
+                                             const int32_t iq_offset, const int32_t shiftNum,
+                                             const uint32_t areaSize, uint32_t *nonzerocoeff);
+/* FullDistortionIntrinsic_funcPtrArray (EbPictureOperators.h:503); C peers EbPictureOperators_C.c:385-480 */
+SVT_AMD_API void svt_amd_FullDistortionKernel_32bit(int16_t *coeff, uint32_t coeffStride, int16_t *reconCoeff,
+                                                    uint32_t reconCoeffStride, uint64_t distortionResult[2],
+                                                    uint32_t areaWidth, uint32_t areaHeight);
+SVT_AMD_API void svt_amd_FullDistortionKernelCbfZero_32bit(int16_t *coeff, uint32_t coeffStride, int16_t *reconCoeff,
+                                                           uint32_t reconCoeffStride, uint64_t distortionResult[2],
+                                                           uint32_t areaWidth, uint32_t areaHeight);
+SVT_AMD_API void svt_amd_FullDistortionKernelIntra_32bit(int16_t *coeff, uint32_t coeffStride, int16_t *reconCoeff,
+                                                         uint32_t reconCoeffStride, uint64_t distortionResult[2],
+                                                         uint32_t areaWidth, uint32_t areaHeight);
+/* Compute8x8Satd_funcPtrArray (EbPictureOperators.h); C peers EbPictureOperators_C.c:481,563, EbHmCode.c:41,127 */
+SVT_AMD_API uint64_t svt_amd_Compute8x8Satd(int16_t *diff);
+SVT_AMD_API uint64_t svt_amd_Compute4x4Satd(int16_t *diff);
+SVT_AMD_API uint64_t svt_amd_Compute8x8Satd_U8(uint8_t *src, uint64_t *dcValue, uint32_t srcStride);
+SVT_AMD_API uint64_t svt_amd_Compute4x4Satd_U8(uint8_t *src, uint64_t *dcValue, uint32_t srcStride);
+/* ResidualKernel_funcPtrArray / AdditionKernel_funcPtrArray (EbPictureOperators.h:242-330);
+ * C peers ResidualKernel (:297), PictureAdditionKernel (:112) */
+SVT_AMD_API void svt_amd_ResidualKernel(uint8_t *input, uint32_t inputStride, uint8_t *pred, uint32_t predStride,
+                                        int16_t *residual, uint32_t residualStride, uint32_t areaWidth,
+                                        uint32_t areaHeight);
+SVT_AMD_API void svt_amd_PictureAdditionKernel(uint8_t *predPtr, uint32_t predStride, int16_t *residualPtr,
+                                               uint32_t residualStride, uint8_t *reconPtr, uint32_t reconStride,
+                                               uint32_t width, uint32_t height);
+
 #ifdef __cplusplus
 }
 #endif

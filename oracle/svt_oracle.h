@@ -66,6 +66,34 @@ void svt_oracle_Decimation2D(const uint8_t *inputSamples, uint32_t inputStride,
                              uint32_t inputAreaWidth, uint32_t inputAreaHeight,
                              uint8_t *decimSamples, uint32_t decimStride, uint32_t decimStep);
 
+/* ---- residual / transform / quantisation / distortion / SATD leaves ------- */
+/* kind: 0 DCT, 1 low-precision "Estimate" DCT (32/16), 2 DST (4x4); inner may be NULL */
+void svt_oracle_FwdTransform(int kind, int size, const int16_t *residual, uint32_t srcStride, int16_t *coeff,
+                             uint32_t dstStride, int16_t *inner, uint32_t bitIncrement);
+void svt_oracle_InvTransform(int kind, int size, const int16_t *coeff, uint32_t srcStride, int16_t *residual,
+                             uint32_t dstStride, int16_t *inner, uint32_t bitIncrement);
+void svt_oracle_QuantizeInvQuantize(const int16_t *coeff, uint32_t coeffStride, int16_t *quantCoeff,
+                                    int16_t *reconCoeff, uint32_t qFunc, uint32_t q_offset, int32_t shiftedQBits,
+                                    int32_t shiftedFFunc, int32_t iq_offset, int32_t shiftNum, uint32_t areaSize,
+                                    uint32_t *nonzerocoeff);
+void svt_oracle_UpdateQiQCoef(int16_t *quantCoeff, int16_t *reconCoeff, uint32_t coeffStride, int32_t shiftedFFunc,
+                              int32_t iq_offset, int32_t shiftNum, uint32_t areaSize, uint32_t *nonzerocoeff,
+                              uint32_t componentType, uint32_t sliceType, uint32_t temporalLayer,
+                              uint32_t enableCbflag, uint8_t enableContouringQCUpdateFlag);
+void svt_oracle_ResidualKernel(const uint8_t *input, uint32_t inputStride, const uint8_t *pred, uint32_t predStride,
+                               int16_t *residual, uint32_t residualStride, uint32_t w, uint32_t h);
+void svt_oracle_PictureAdditionKernel(const uint8_t *pred, uint32_t predStride, const int16_t *residual,
+                                      uint32_t residualStride, uint8_t *recon, uint32_t reconStride, uint32_t w,
+                                      uint32_t h);
+void svt_oracle_ZeroOutCoeffKernel(int16_t *coeff, uint32_t stride, uint32_t origin, uint32_t w, uint32_t h);
+/* mode: 0 FullDistortionKernel_32bit, 1 ...CbfZero_32bit, 2 ...Intra_32bit */
+void svt_oracle_FullDistortionKernel_32bit(const int16_t *coeff, uint32_t coeffStride, const int16_t *recon,
+                                           uint32_t reconStride, uint64_t result[2], uint32_t w, uint32_t h, int mode);
+uint64_t svt_oracle_Compute8x8Satd(const int16_t *diff);
+uint64_t svt_oracle_Compute4x4Satd(const int16_t *diff);
+uint64_t svt_oracle_Compute8x8Satd_U8(const uint8_t *src, uint64_t *dcValue, uint32_t srcStride);
+uint64_t svt_oracle_Compute4x4Satd_U8(const uint8_t *src, uint64_t *dcValue, uint32_t srcStride);
+
 /* ---- picture-level ME (restates MotionEstimationKernel's LCU loop) -------- */
 
 /* A padded 8-bit plane: sample (x,y), x in [-pad, width+pad), is

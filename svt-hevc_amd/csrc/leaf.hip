@@ -15,51 +15,7 @@
 typedef uint32_t __attribute__((aligned(1))) u32u;
 __device__ __forceinline__ uint32_t l_absd(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
 
-/* -------- device buffer helper -------- */
-struct DBuf {
-    uint8_t *d = nullptr;
-    size_t n = 0;
-    bool ok = true;
-    DBuf(const void *host, size_t bytes, bool upload = true) : n(bytes)
-    {
-        if (hipMalloc((void **)&d, bytes + 64) != hipSuccess) {
-            ok = false;
-            d = nullptr;
-            svt_amd_set_error("leaf: hipMalloc(%zu) failed", bytes);
-            return;
-        }
-        if (upload && host && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-            ok = false;
-            svt_amd_set_error("leaf: H2D copy failed");
-        }
-    }
-    bool download(void *host, size_t bytes) const
-    {
-        if (!ok || hipMemcpy(host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
-            svt_amd_set_error("leaf: D2H copy failed");
-            return false;
-        }
-        return true;
-    }
-    ~DBuf()
-    {
-        if (d)
-            (void)hipFree(d);
-    }
-};
-static inline size_t span(uint32_t stride, uint32_t w, uint32_t h) { return h ? (size_t)(h - 1) * stride + w : 0; }
-static bool finish(const char *what)
-{
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess)
-        e = hipGetLastError();
-    if (e != hipSuccess) {
-        svt_amd_set_error("leaf %s: %s", what, hipGetErrorString(e));
-        fprintf(stderr, "svt_hevc_amd: %s\n", svt_amd_last_error());
-        return false;
-    }
-    return true;
-}
+#include "leaf_util.h"
 
 /* -------- kernels (one workgroup of 256 threads) -------- */
 

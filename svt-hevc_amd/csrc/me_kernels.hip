@@ -328,7 +328,7 @@ __device__ void hme_pass(MeShared &S, int level, const uint8_t *refplane, int pi
     const uint8_t *srow = src + y * sstride;
     int off = 0;
     for (int q = 0; q < nq; q++) {
-        const int qx = S.qp[q][0], qy = S.qp[q][1], qw = S.qp[q][2], qh = S.qp[q][3];
+        const int qx = S.qp[q][0], qw = S.qp[q][2], qh = S.qp[q][3];
         /* same geometry as load_window computed above */
         const int x0 = bx0 + qx, xa = x0 & ~15, wstride = ((x0 + qw + bw - xa) + 15) & ~15;
         const int wrows = qh + 2 * (rows - 1) + 1;

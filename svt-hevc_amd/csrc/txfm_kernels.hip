@@ -1,0 +1,516 @@
+/*
+ * Residual / transform / quantisation / distortion / SATD kernels of the EncDec half
+ * (SURVEY.md 8a "EncDec" rows), batched over contiguous blocks in HBM:
+ * block b of a size x size batch starts at base + b*size*size (row stride = size).
+ *
+ * Forward DCT/DST  - Transform32x32/16x16(+Estimate)/8x8/4x4, DstTransform4x4
+ *                    (C_DEFAULT/EbTransforms_C.c:1602-1908; butterflies :269-1073)
+ * Inverse          - InvTransform32x32/16x16/8x8/4x4, InvDstTransform4x4 (:1910-2119)
+ * Quantisation     - QuantizeInvQuantize (:89-138), UpdateQiQCoef (:209-260)
+ * Distortion       - FullDistortionKernel_32bit / CbfZero / Intra (C_DEFAULT/EbPictureOperators_C.c:385-480)
+ * SATD             - Compute8x8Satd(_U8) (:481-642), Compute4x4Satd(_U8) (Codec/EbHmCode.c:41-215)
+ * Picture ops      - ResidualKernel, PictureAdditionKernel, ZeroOutCoeffKernel, PictureCopyKernel (:83-360)
+ *
+ * The forward butterfly keeps the reference's exact integer widths: the low-precision
+ * "Estimate" variants wrap the first one (16-point) / two (32-point) even/odd levels to
+ * 16 bits, every pass truncates its output to int16.  Levels are evaluated in place in LDS
+ * (one barrier per level), then every output is a short dot product with the HEVC matrix
+ * row held in LDS.  Bound: HBM (4 bytes moved per coefficient, ~40 integer ops).
+ */
+#include "svt_amd_internal.h"
+
+#define TX_THREADS 256
+
+/* HEVC core transform matrix (H.265 8.6.4.2); N-point row k = row k*32/N, first N columns */
+__constant__ int8_t c_T32[32][32] = {
+    {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64},
+    {90, 90, 88, 85, 82, 78, 73, 67, 61, 54, 46, 38, 31, 22, 13, 4, -4, -13, -22, -31, -38, -46, -54, -61, -67, -73, -78, -82, -85, -88, -90, -90},
+    {90, 87, 80, 70, 57, 43, 25, 9, -9, -25, -43, -57, -70, -80, -87, -90, -90, -87, -80, -70, -57, -43, -25, -9, 9, 25, 43, 57, 70, 80, 87, 90},
+    {90, 82, 67, 46, 22, -4, -31, -54, -73, -85, -90, -88, -78, -61, -38, -13, 13, 38, 61, 78, 88, 90, 85, 73, 54, 31, 4, -22, -46, -67, -82, -90},
+    {89, 75, 50, 18, -18, -50, -75, -89, -89, -75, -50, -18, 18, 50, 75, 89, 89, 75, 50, 18, -18, -50, -75, -89, -89, -75, -50, -18, 18, 50, 75, 89},
+    {88, 67, 31, -13, -54, -82, -90, -78, -46, -4, 38, 73, 90, 85, 61, 22, -22, -61, -85, -90, -73, -38, 4, 46, 78, 90, 82, 54, 13, -31, -67, -88},
+    {87, 57, 9, -43, -80, -90, -70, -25, 25, 70, 90, 80, 43, -9, -57, -87, -87, -57, -9, 43, 80, 90, 70, 25, -25, -70, -90, -80, -43, 9, 57, 87},
+    {85, 46, -13, -67, -90, -73, -22, 38, 82, 88, 54, -4, -61, -90, -78, -31, 31, 78, 90, 61, 4, -54, -88, -82, -38, 22, 73, 90, 67, 13, -46, -85},
+    {83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83},
+    {82, 22, -54, -90, -61, 13, 78, 85, 31, -46, -90, -67, 4, 73, 88, 38, -38, -88, -73, -4, 67, 90, 46, -31, -85, -78, -13, 61, 90, 54, -22, -82},
+    {80, 9, -70, -87, -25, 57, 90, 43, -43, -90, -57, 25, 87, 70, -9, -80, -80, -9, 70, 87, 25, -57, -90, -43, 43, 90, 57, -25, -87, -70, 9, 80},
+    {78, -4, -82, -73, 13, 85, 67, -22, -88, -61, 31, 90, 54, -38, -90, -46, 46, 90, 38, -54, -90, -31, 61, 88, 22, -67, -85, -13, 73, 82, 4, -78},
+    {75, -18, -89, -50, 50, 89, 18, -75, -75, 18, 89, 50, -50, -89, -18, 75, 75, -18, -89, -50, 50, 89, 18, -75, -75, 18, 89, 50, -50, -89, -18, 75},
+    {73, -31, -90, -22, 78, 67, -38, -90, -13, 82, 61, -46, -88, -4, 85, 54, -54, -85, 4, 88, 46, -61, -82, 13, 90, 38, -67, -78, 22, 90, 31, -73},
+    {70, -43, -87, 9, 90, 25, -80, -57, 57, 80, -25, -90, -9, 87, 43, -70, -70, 43, 87, -9, -90, -25, 80, 57, -57, -80, 25, 90, 9, -87, -43, 70},
+    {67, -54, -78, 38, 85, -22, -90, 4, 90, 13, -88, -31, 82, 46, -73, -61, 61, 73, -46, -82, 31, 88, -13, -90, -4, 90, 22, -85, -38, 78, 54, -67},
+    {64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64},
+    {61, -73, -46, 82, 31, -88, -13, 90, -4, -90, 22, 85, -38, -78, 54, 67, -67, -54, 78, 38, -85, -22, 90, 4, -90, 13, 88, -31, -82, 46, 73, -61},
+    {57, -80, -25, 90, -9, -87, 43, 70, -70, -43, 87, 9, -90, 25, 80, -57, -57, 80, 25, -90, 9, 87, -43, -70, 70, 43, -87, -9, 90, -25, -80, 57},
+    {54, -85, -4, 88, -46, -61, 82, 13, -90, 38, 67, -78, -22, 90, -31, -73, 73, 31, -90, 22, 78, -67, -38, 90, -13, -82, 61, 46, -88, 4, 85, -54},
+    {50, -89, 18, 75, -75, -18, 89, -50, -50, 89, -18, -75, 75, 18, -89, 50, 50, -89, 18, 75, -75, -18, 89, -50, -50, 89, -18, -75, 75, 18, -89, 50},
+    {46, -90, 38, 54, -90, 31, 61, -88, 22, 67, -85, 13, 73, -82, 4, 78, -78, -4, 82, -73, -13, 85, -67, -22, 88, -61, -31, 90, -54, -38, 90, -46},
+    {43, -90, 57, 25, -87, 70, 9, -80, 80, -9, -70, 87, -25, -57, 90, -43, -43, 90, -57, -25, 87, -70, -9, 80, -80, 9, 70, -87, 25, 57, -90, 43},
+    {38, -88, 73, -4, -67, 90, -46, -31, 85, -78, 13, 61, -90, 54, 22, -82, 82, -22, -54, 90, -61, -13, 78, -85, 31, 46, -90, 67, 4, -73, 88, -38},
+    {36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36},
+    {31, -78, 90, -61, 4, 54, -88, 82, -38, -22, 73, -90, 67, -13, -46, 85, -85, 46, 13, -67, 90, -73, 22, 38, -82, 88, -54, -4, 61, -90, 78, -31},
+    {25, -70, 90, -80, 43, 9, -57, 87, -87, 57, -9, -43, 80, -90, 70, -25, -25, 70, -90, 80, -43, -9, 57, -87, 87, -57, 9, 43, -80, 90, -70, 25},
+    {22, -61, 85, -90, 73, -38, -4, 46, -78, 90, -82, 54, -13, -31, 67, -88, 88, -67, 31, 13, -54, 82, -90, 78, -46, 4, 38, -73, 90, -85, 61, -22},
+    {18, -50, 75, -89, 89, -75, 50, -18, -18, 50, -75, 89, -89, 75, -50, 18, 18, -50, 75, -89, 89, -75, 50, -18, -18, 50, -75, 89, -89, 75, -50, 18},
+    {13, -38, 61, -78, 88, -90, 85, -73, 54, -31, 4, 22, -46, 67, -82, 90, -90, 82, -67, 46, -22, -4, 31, -54, 73, -85, 90, -88, 78, -61, 38, -13},
+    {9, -25, 43, -57, 70, -80, 87, -90, 90, -87, 80, -70, 57, -43, 25, -9, -9, 25, -43, 57, -70, 80, -87, 90, -90, 87, -80, 70, -57, 43, -25, 9},
+    {4, -13, 22, -31, 38, -46, 54, -61, 67, -73, 78, -82, 85, -88, 90, -90, 90, -90, 88, -85, 82, -78, 73, -67, 61, -54, 46, -38, 31, -22, 13, -4}};
+
+__device__ __forceinline__ int clip16i(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+/* ------------------------------------------------------------------------- */
+/* forward / inverse transforms: one workgroup per group of GB blocks         */
+/* ------------------------------------------------------------------------- */
+
+template <int N>
+struct TxShared {
+    static constexpr int GB = (N >= 16) ? 1 : (N == 8 ? 4 : 16); /* blocks per workgroup */
+    int8_t T[32][32];
+    int16_t io[GB][N * N];  /* input, later the transposed first-pass output */
+    int32_t E[GB][N][N];    /* running even vector, levels evaluated in place */
+    int32_t D[GB][N][N];    /* decomposed rows: [0..1] last even pair, [h..2h) odd vector of length h */
+};
+
+/* one 1-D forward pass over all rows of the GB blocks held in S.io; output transposed into dst */
+template <int N, bool TO_GLOBAL>
+__device__ void fwd_pass(TxShared<N> &S, int shift, int wrap_levels, int16_t *gdst, int nvalid, int t)
+{
+    constexpr int GB = TxShared<N>::GB;
+    constexpr int LOG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
+    for (int i = t; i < GB * N * N; i += TX_THREADS)
+        (&S.E[0][0][0])[i] = (&S.io[0][0])[i];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < LOG - 1; m++) {
+        const int half = N >> (m + 1);
+        for (int i = t; i < GB * N * half; i += TX_THREADS) {
+            const int j = i % half, r = (i / half) % N, b = i / (half * N);
+            int s = S.E[b][r][j] + S.E[b][r][2 * half - 1 - j], d = S.E[b][r][j] - S.E[b][r][2 * half - 1 - j];
+            if (m < wrap_levels)
+                s = (int16_t)s, d = (int16_t)d;
+            S.D[b][r][half + j] = d;
+            S.E[b][r][j] = s; /* indices >= half are only read in this level: no hazard */
+        }
+        __syncthreads();
+    }
+    const int offset = (int16_t)(1 << (shift - 1));
+    for (int i = t; i < GB * N * N; i += TX_THREADS) {
+        const int r = i % N, k = (i / N) % N, b = i / (N * N);
+        int acc = 0;
+        if ((k & (N / 2 - 1)) == 0) { /* k == 0 or N/2: last even pair */
+            acc = S.T[k * (32 / N)][0] * S.E[b][r][0] + S.T[k * (32 / N)][1] * S.E[b][r][1];
+        } else {
+            const int m = __ffs(k) - 1, len = N >> (m + 1);
+            const int8_t *c = S.T[k * (32 / N)];
+            const int32_t *dv = &S.D[b][r][len];
+            for (int j = 0; j < len; j++)
+                acc += c[j] * dv[j];
+        }
+        const int16_t v = (int16_t)((acc + offset) >> shift);
+        if (TO_GLOBAL) {
+            if (b < nvalid)
+                gdst[(size_t)b * N * N + k * N + r] = v;
+        } else {
+            S.io[b][k * N + r] = v;
+        }
+    }
+    __syncthreads();
+}
+
+template <int N>
+__global__ __launch_bounds__(TX_THREADS) void k_fwd_dct(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
+                                                       uint32_t nblocks, int shift1, int shift2, int wrap_levels)
+{
+    __shared__ TxShared<N> S;
+    constexpr int GB = TxShared<N>::GB;
+    const int t = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * GB;
+    const int nvalid = (int)min((uint32_t)GB, nblocks - b0);
+    for (int i = t; i < 32 * 32; i += TX_THREADS)
+        (&S.T[0][0])[i] = (&c_T32[0][0])[i];
+    for (int i = t; i < GB * N * N; i += TX_THREADS)
+        (&S.io[0][0])[i] = (i < nvalid * N * N) ? src[(size_t)b0 * N * N + i] : (int16_t)0;
+    __syncthreads();
+    fwd_pass<N, false>(S, shift1, wrap_levels, nullptr, nvalid, t);
+    fwd_pass<N, true>(S, shift2, wrap_levels, dst + (size_t)b0 * N * N, nvalid, t);
+}
+
+/* 4x4 DST (Dst4 / DstInverse4): one thread per row, 64 blocks per workgroup */
+__device__ __forceinline__ void dst4_fwd_row(const int16_t *x, int16_t *out, int ostride, int r, int shift)
+{
+    const int offset = (int16_t)(1 << (shift - 1));
+    const int e0 = x[0] + x[3], o0 = x[1] + x[3], e1 = x[0] - x[1], o1 = 74 * x[2];
+    out[0 * ostride + r] = (int16_t)((29 * e0 + 55 * o0 + o1 + offset) >> shift);
+    out[2 * ostride + r] = (int16_t)((29 * e1 + 55 * e0 - o1 + offset) >> shift);
+    out[1 * ostride + r] = (int16_t)(((74 * (x[0] + x[1] - x[3])) + offset) >> shift);
+    out[3 * ostride + r] = (int16_t)((55 * e1 - 29 * o0 + o1 + offset) >> shift);
+}
+__device__ __forceinline__ void dst4_inv_col(const int16_t *in, int istride, int r, int16_t *out, int shift)
+{
+    const int offset = (int16_t)(1 << (shift - 1));
+    const int c0 = in[r], c1 = in[istride + r], c2 = in[2 * istride + r], c3 = in[3 * istride + r];
+    const int o0 = c0 + c2, o1 = c0 - c3, e0 = c2 + c3, e1 = 74 * c1;
+    out[0] = (int16_t)clip16i((29 * o0 + 55 * e0 + e1 + offset) >> shift);
+    out[1] = (int16_t)clip16i((55 * o1 - 29 * e0 + e1 + offset) >> shift);
+    out[2] = (int16_t)clip16i(((74 * (c0 - c2 + c3)) + offset) >> shift);
+    out[3] = (int16_t)clip16i((55 * o0 + 29 * o1 - e1 + offset) >> shift);
+}
+__global__ __launch_bounds__(TX_THREADS) void k_dst4(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
+                                                    uint32_t nblocks, int shift1, int shift2, int inverse)
+{
+    __shared__ int16_t a[64][16], m[64][16];
+    const int t = threadIdx.x, lb = t >> 2, r = t & 3;
+    const uint32_t b = blockIdx.x * 64 + lb;
+    if (b < nblocks)
+        for (int j = 0; j < 4; j++)
+            a[lb][r * 4 + j] = src[(size_t)b * 16 + r * 4 + j];
+    __syncthreads();
+    if (b < nblocks) {
+        if (!inverse)
+            dst4_fwd_row(&a[lb][r * 4], m[lb], 4, r, shift1);
+        else
+            dst4_inv_col(a[lb], 4, r, &m[lb][r * 4], shift1);
+    }
+    __syncthreads();
+    if (b < nblocks) {
+        if (!inverse)
+            dst4_fwd_row(&m[lb][r * 4], a[lb], 4, r, shift2);
+        else
+            dst4_inv_col(m[lb], 4, r, &a[lb][r * 4], shift2);
+    }
+    __syncthreads();
+    if (b < nblocks)
+        for (int j = 0; j < 4; j++)
+            dst[(size_t)b * 16 + r * 4 + j] = a[lb][r * 4 + j];
+}
+
+/* inverse DCT: exact integer matrix product per pass, clip to 16 bits */
+template <int N>
+__global__ __launch_bounds__(TX_THREADS) void k_inv_dct(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
+                                                       uint32_t nblocks, int shift1, int shift2)
+{
+    constexpr int GB = TxShared<N>::GB;
+    __shared__ int8_t T[32][32];
+    __shared__ int16_t in[GB][N * N], mid[GB][N * N];
+    const int t = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * GB;
+    const int nvalid = (int)min((uint32_t)GB, nblocks - b0);
+    for (int i = t; i < 32 * 32; i += TX_THREADS)
+        (&T[0][0])[i] = (&c_T32[0][0])[i];
+    for (int i = t; i < GB * N * N; i += TX_THREADS)
+        (&in[0][0])[i] = (i < nvalid * N * N) ? src[(size_t)b0 * N * N + i] : (int16_t)0;
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int shift = pass ? shift2 : shift1, offset = (int16_t)(1 << (shift - 1));
+        for (int i = t; i < GB * N * N; i += TX_THREADS) {
+            const int j = i % N, r = (i / N) % N, b = i / (N * N);
+            const int16_t *s = pass ? mid[b] : in[b];
+            int acc = 0;
+#pragma unroll 8
+            for (int k = 0; k < N; k++)
+                acc += T[k * (32 / N)][j] * s[k * N + r];
+            const int16_t v = (int16_t)clip16i((acc + offset) >> shift);
+            if (pass == 0)
+                mid[b][r * N + j] = v;
+            else if (b < nvalid)
+                dst[(size_t)(b0 + b) * N * N + r * N + j] = v;
+        }
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* quantisation, distortion, SATD, picture operators                          */
+/* ------------------------------------------------------------------------- */
+
+/* QuantizeInvQuantize over contiguous size x size blocks; nz[b] = non-zero count */
+__global__ __launch_bounds__(TX_THREADS) void k_quant(const int16_t *__restrict__ coeff, int16_t *__restrict__ q,
+                                                     int16_t *__restrict__ rec, uint32_t *__restrict__ nz,
+                                                     uint32_t nblocks, int n2, uint32_t qFunc, uint32_t q_offset,
+                                                     int shiftedQBits, int shiftedFFunc, int iq_offset, int shiftNum)
+{
+    __shared__ uint32_t cnt;
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        if (threadIdx.x == 0)
+            cnt = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int i = threadIdx.x; i < n2; i += TX_THREADS) {
+            const int v = coeff[(size_t)b * n2 + i], sign = v < 0 ? -1 : 1;
+            int tq = abs(v);
+            tq = (int)((uint32_t)tq * qFunc);
+            tq = (int)((uint32_t)tq + q_offset);
+            tq >>= shiftedQBits;
+            const int qv = clip16i(sign * tq);
+            q[(size_t)b * n2 + i] = (int16_t)qv;
+            mine += qv != 0;
+            rec[(size_t)b * n2 + i] = (int16_t)clip16i(((qv * shiftedFFunc) + iq_offset) >> shiftNum);
+        }
+        atomicAdd(&cnt, mine);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            nz[b] = cnt;
+        __syncthreads();
+    }
+}
+
+/* FullDistortionKernel*_32bit: 32-bit modular sums of squared int16-truncated differences */
+__global__ __launch_bounds__(TX_THREADS) void k_full_distortion(const int16_t *__restrict__ coeff,
+                                                               const int16_t *__restrict__ rec,
+                                                               unsigned long long *__restrict__ out, uint32_t nblocks,
+                                                               int n2, int mode)
+{
+    __shared__ uint32_t acc[2];
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        if (threadIdx.x < 2)
+            acc[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t res = 0, pred = 0;
+        for (int i = threadIdx.x; i < n2; i += TX_THREADS) {
+            const int16_t c = coeff[(size_t)b * n2 + i], d = (int16_t)(c - rec[(size_t)b * n2 + i]);
+            res += (uint32_t)(d * d);
+            pred += (uint32_t)(c * c);
+        }
+        atomicAdd(&acc[0], res);
+        atomicAdd(&acc[1], pred);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            out[2 * b + 0] = mode == 1 ? acc[1] : acc[0];
+            out[2 * b + 1] = mode == 2 ? acc[0] : acc[1];
+        }
+        __syncthreads();
+    }
+}
+
+/* N x N Hadamard SATD, one block per group of N lanes: lane = row, row butterfly in registers,
+ * column butterfly across lanes with xor shuffles; 16-bit arithmetic as in the reference */
+template <int N>
+__global__ __launch_bounds__(TX_THREADS) void k_satd(const int16_t *__restrict__ diff, const uint8_t *__restrict__ u8,
+                                                    uint32_t u8stride, unsigned long long *__restrict__ satd,
+                                                    long long *__restrict__ dc, uint32_t nblocks)
+{
+    const int lane = threadIdx.x & (N - 1);
+    const uint32_t b = (blockIdx.x * TX_THREADS + threadIdx.x) / N;
+    const bool ok = b < nblocks;
+    int16_t v[N];
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        v[j] = !ok ? (int16_t)0 : diff ? diff[(size_t)b * N * N + lane * N + j]
+                                       : (int16_t)u8[(size_t)b * N * N * 0 + (size_t)lane * u8stride + j + (size_t)b * N];
+#pragma unroll
+    for (int len = 1; len < N; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < N; i += len << 1)
+#pragma unroll
+            for (int j = i; j < i + len; j++) {
+                const int16_t s = (int16_t)(v[j] + v[j + len]), d = (int16_t)(v[j] - v[j + len]);
+                v[j] = s, v[j + len] = d;
+            }
+#pragma unroll
+    for (int len = 1; len < N; len <<= 1)
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const int o = __shfl_xor((int)v[j], len);
+            v[j] = (lane & len) ? (int16_t)(o - v[j]) : (int16_t)(v[j] + o);
+        }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        s += (uint32_t)abs((int)v[j]);
+    const int dc0 = v[0];
+#pragma unroll
+    for (int o = 1; o < N; o <<= 1)
+        s += __shfl_xor(s, o);
+    if (ok && lane == 0) {
+        satd[b] = N == 8 ? ((unsigned long long)s + 2) >> 2 : ((unsigned long long)s + 1) >> 1;
+        if (dc)
+            dc[b] = dc0;
+    }
+}
+
+__global__ void k_residual(const uint8_t *in, uint32_t is, const uint8_t *pred, uint32_t ps, int16_t *res,
+                           uint32_t rs, uint32_t w, uint32_t h)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / w, x = i - y * w;
+        res[(size_t)y * rs + x] = (int16_t)((int16_t)in[(size_t)y * is + x] - (int16_t)pred[(size_t)y * ps + x]);
+    }
+}
+__global__ void k_addition(const uint8_t *pred, uint32_t ps, const int16_t *res, uint32_t rs, uint8_t *rec,
+                           uint32_t cs, uint32_t w, uint32_t h)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / w, x = i - y * w;
+        const int v = (int)res[(size_t)y * rs + x] + pred[(size_t)y * ps + x];
+        rec[(size_t)y * cs + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* launchers (device pointers)                                                */
+/* ------------------------------------------------------------------------- */
+
+static int fwd_shifts(int kind, int size, uint32_t inc, int *s1, int *s2, int *wrap)
+{
+    const int lg = size == 32 ? 5 : size == 16 ? 4 : size == 8 ? 3 : size == 4 ? 2 : -1;
+    if (lg < 0 || kind < 0 || kind > 2 || (kind == 2 && size != 4) || inc > 4)
+        return SVT_AMD_ERR_BAD_PARAM;
+    const int est = kind == 1 && size >= 16;
+    *s1 = est ? (size == 32 ? 6 : 4) + (int)inc : lg - 1 + (int)inc;
+    *s2 = est ? 9 : lg + 6;
+    *wrap = est ? (size == 32 ? 2 : 1) : 0;
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_fwd_transform(hipStream_t st, int kind, int size, uint32_t inc, const int16_t *d_res,
+                                 int16_t *d_coeff, uint32_t n)
+{
+    int s1, s2, wrap;
+    int rc = fwd_shifts(kind, size, inc, &s1, &s2, &wrap);
+    if (rc || !n)
+        return rc ? rc : SVT_AMD_ERR_BAD_PARAM;
+    if (kind == 2)
+        hipLaunchKernelGGL(k_dst4, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, 0);
+    else if (size == 32)
+        hipLaunchKernelGGL(k_fwd_dct<32>, dim3(n), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+    else if (size == 16)
+        hipLaunchKernelGGL(k_fwd_dct<16>, dim3(n), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+    else if (size == 8)
+        hipLaunchKernelGGL(k_fwd_dct<8>, dim3((n + 3) / 4), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+    else
+        hipLaunchKernelGGL(k_fwd_dct<4>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_inv_transform(hipStream_t st, int kind, int size, uint32_t inc, const int16_t *d_coeff,
+                                 int16_t *d_res, uint32_t n)
+{
+    if (!n || inc > 4 || !(size == 4 || size == 8 || size == 16 || size == 32) || (kind == 2 && size != 4) ||
+        (kind != 0 && kind != 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    const int s1 = 7, s2 = 12 - (int)inc; /* SHIFT_INV_1ST, SHIFT_INV_2ND - bitIncrement */
+    if (kind == 2)
+        hipLaunchKernelGGL(k_dst4, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2, 1);
+    else if (size == 32)
+        hipLaunchKernelGGL(k_inv_dct<32>, dim3(n), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+    else if (size == 16)
+        hipLaunchKernelGGL(k_inv_dct<16>, dim3(n), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+    else if (size == 8)
+        hipLaunchKernelGGL(k_inv_dct<8>, dim3((n + 3) / 4), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+    else
+        hipLaunchKernelGGL(k_inv_dct<4>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_quant(hipStream_t st, int size, uint32_t qFunc, uint32_t q_offset, int shiftedQBits,
+                         int shiftedFFunc, int iq_offset, int shiftNum, const int16_t *d_coeff, int16_t *d_q,
+                         int16_t *d_rec, uint32_t *d_nz, uint32_t n)
+{
+    if (!n || size < 4 || size > 64)
+        return SVT_AMD_ERR_BAD_PARAM;
+    hipLaunchKernelGGL(k_quant, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_q, d_rec, d_nz, n,
+                       size * size, qFunc, q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_full_distortion(hipStream_t st, int size, int mode, const int16_t *d_coeff, const int16_t *d_rec,
+                                   unsigned long long *d_out, uint32_t n)
+{
+    if (!n || mode < 0 || mode > 2)
+        return SVT_AMD_ERR_BAD_PARAM;
+    hipLaunchKernelGGL(k_full_distortion, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_rec, d_out, n,
+                       size * size, mode);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* element-count form used by the leaf wrapper (rectangular areas) */
+int svt_amd_launch_full_distortion_n(hipStream_t st, int n2, int mode, const int16_t *d_coeff, const int16_t *d_rec,
+                                     unsigned long long *d_out, uint32_t n)
+{
+    if (!n || mode < 0 || mode > 2 || n2 < 1)
+        return SVT_AMD_ERR_BAD_PARAM;
+    hipLaunchKernelGGL(k_full_distortion, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_rec, d_out, n, n2, mode);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_satd(hipStream_t st, int size, const int16_t *d_diff, const uint8_t *d_u8, uint32_t u8stride,
+                        unsigned long long *d_satd, long long *d_dc, uint32_t n)
+{
+    if (!n || (size != 4 && size != 8))
+        return SVT_AMD_ERR_BAD_PARAM;
+    const uint32_t per = TX_THREADS / (uint32_t)size;
+    if (size == 8)
+        hipLaunchKernelGGL(k_satd<8>, dim3((n + per - 1) / per), dim3(TX_THREADS), 0, st, d_diff, d_u8, u8stride, d_satd, d_dc, n);
+    else
+        hipLaunchKernelGGL(k_satd<4>, dim3((n + per - 1) / per), dim3(TX_THREADS), 0, st, d_diff, d_u8, u8stride, d_satd, d_dc, n);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_residual(hipStream_t st, const uint8_t *in, uint32_t is, const uint8_t *pred, uint32_t ps,
+                            int16_t *res, uint32_t rs, uint32_t w, uint32_t h)
+{
+    hipLaunchKernelGGL(k_residual, dim3((w * h + 255) / 256 < 2048 ? (w * h + 255) / 256 : 2048), dim3(256), 0, st, in, is,
+                       pred, ps, res, rs, w, h);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+int svt_amd_launch_addition(hipStream_t st, const uint8_t *pred, uint32_t ps, const int16_t *res, uint32_t rs,
+                            uint8_t *rec, uint32_t cs, uint32_t w, uint32_t h)
+{
+    hipLaunchKernelGGL(k_addition, dim3((w * h + 255) / 256 < 2048 ? (w * h + 255) / 256 : 2048), dim3(256), 0, st, pred,
+                       ps, res, rs, rec, cs, w, h);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* ---- batched C-ABI (device pointers, context stream) ---- */
+extern "C" int svt_amd_fwd_transform_batch(SvtAmdContext *ctx, int kind, int size, uint32_t bitIncrement,
+                                           const int16_t *d_residual, int16_t *d_coeff, uint32_t nblocks)
+{
+    if (!ctx || !d_residual || !d_coeff)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_amd_launch_fwd_transform(ctx->stream, kind, size, bitIncrement, d_residual, d_coeff, nblocks);
+}
+extern "C" int svt_amd_inv_transform_batch(SvtAmdContext *ctx, int kind, int size, uint32_t bitIncrement,
+                                           const int16_t *d_coeff, int16_t *d_residual, uint32_t nblocks)
+{
+    if (!ctx || !d_residual || !d_coeff)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_amd_launch_inv_transform(ctx->stream, kind, size, bitIncrement, d_coeff, d_residual, nblocks);
+}
+extern "C" int svt_amd_quantize_batch(SvtAmdContext *ctx, int size, uint32_t qFunc, uint32_t q_offset,
+                                      int32_t shiftedQBits, int32_t shiftedFFunc, int32_t iq_offset, int32_t shiftNum,
+                                      const int16_t *d_coeff, int16_t *d_quant, int16_t *d_recon, uint32_t *d_nz,
+                                      uint32_t nblocks)
+{
+    if (!ctx || !d_coeff || !d_quant || !d_recon || !d_nz)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_amd_launch_quant(ctx->stream, size, qFunc, q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum,
+                                d_coeff, d_quant, d_recon, d_nz, nblocks);
+}
+extern "C" int svt_amd_full_distortion_batch(SvtAmdContext *ctx, int size, int mode, const int16_t *d_coeff,
+                                             const int16_t *d_recon, uint64_t *d_result, uint32_t nblocks)
+{
+    if (!ctx || !d_coeff || !d_recon || !d_result)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_amd_launch_full_distortion(ctx->stream, size, mode, d_coeff, d_recon, (unsigned long long *)d_result, nblocks);
+}
+extern "C" int svt_amd_satd_batch(SvtAmdContext *ctx, int size, const int16_t *d_diff, uint64_t *d_satd,
+                                  uint32_t nblocks)
+{
+    if (!ctx || !d_diff || !d_satd)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_amd_launch_satd(ctx->stream, size, d_diff, nullptr, 0, (unsigned long long *)d_satd, nullptr, nblocks);
+}

@@ -153,6 +153,10 @@ def load_product():
     """The HIP library.  Fails loudly when it has not been built."""
     if not os.path.exists(PRODUCT_SO):
         raise RuntimeError("svt-hevc_amd/libsvt_hevc_amd.so missing: run `python __graft_entry__.py build`")
+    # torch bundles its own copy of the HIP runtime with the same SONAME (libamdhip64.so.7).  Import it
+    # FIRST so the loader binds our library to that copy: two HIP/HSA runtimes in one process cannot both
+    # open the GPU ("No HIP GPUs are available" from whichever initialises second).
+    import torch  # noqa: F401
     lib = C.CDLL(PRODUCT_SO)
     _declare_leaf(lib, "svt_amd_")
     vp, i, u16, u32 = C.c_void_p, C.c_int, C.c_uint16, C.c_uint32
