@@ -373,6 +373,57 @@ SVT_AMD_API void svt_amd_PictureAdditionKernel(uint8_t *predPtr, uint32_t predSt
                                                uint32_t residualStride, uint8_t *reconPtr, uint32_t reconStride,
                                                uint32_t width, uint32_t height);
 
+/* ------------------------------------------------------------------------- */
+/* Intra prediction kernels                                                   */
+/* ------------------------------------------------------------------------- */
+/* mode ids of the batched form, in the order of the reference's kernel tables
+ * (Codec/EbIntraPrediction.h:470-648) */
+enum SvtAmdIntraKernel {
+    SVT_AMD_INTRA_VERTICAL_LUMA = 0, SVT_AMD_INTRA_VERTICAL_CHROMA, SVT_AMD_INTRA_HORIZONTAL_LUMA,
+    SVT_AMD_INTRA_HORIZONTAL_CHROMA, SVT_AMD_INTRA_DC_LUMA, SVT_AMD_INTRA_DC_CHROMA, SVT_AMD_INTRA_PLANAR,
+    SVT_AMD_INTRA_ANGULAR_34, SVT_AMD_INTRA_ANGULAR_18, SVT_AMD_INTRA_ANGULAR_2,
+    SVT_AMD_INTRA_ANGULAR_VERTICAL, SVT_AMD_INTRA_ANGULAR_HORIZONTAL
+};
+/* block b: reference samples at d_refs + b*ref_pitch (samples; layout [0..2N) left, [2N] top-left,
+ * [2N+1..4N] top; refSampMain = block base + main_offset for the two generic angular kernels),
+ * prediction written to d_pred + b*size*size (stride = size). */
+SVT_AMD_API int svt_amd_intra_pred_batch(SvtAmdContext *ctx, int mode, int bytes_per_sample, int size, int skip,
+                                         int32_t intraPredAngle, const void *d_refs, uint32_t ref_pitch,
+                                         int32_t main_offset, void *d_pred, uint32_t nblocks);
+
+/* LEAF forms: EB_INTRA_NOANG_TYPE / EB_INTRA_NOANG_16bit_TYPE / EB_INTRA_ANG_TYPE (EbIntraPrediction.h:430-466);
+ * C peers C_DEFAULT/EbIntraPrediction_C.c:15-1051 */
+#define SVT_AMD_DECL_INTRA(name, T)                                                                        \
+    SVT_AMD_API void svt_amd_##name(const uint32_t size, T *refSamples, T *predictionPtr,                  \
+                                    const uint32_t predictionBufferStride, const uint8_t skip);
+#define SVT_AMD_DECL_INTRA_ANG(name, T)                                                                    \
+    SVT_AMD_API void svt_amd_##name(uint32_t size, T *refSampMain, T *predictionPtr,                       \
+                                    uint32_t predictionBufferStride, const uint8_t skip, int32_t intraPredAngle);
+SVT_AMD_DECL_INTRA(IntraModeVerticalLuma, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeVerticalLuma16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeVerticalChroma, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeVerticalChroma16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeHorizontalLuma, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeHorizontalLuma16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeHorizontalChroma, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeHorizontalChroma16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeDCLuma, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeDCLuma16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeDCChroma, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeDCChroma16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModePlanar, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModePlanar16bit, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeAngular_34, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeAngular16bit_34, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeAngular_18, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeAngular16bit_18, uint16_t)
+SVT_AMD_DECL_INTRA(IntraModeAngular_2, uint8_t)
+SVT_AMD_DECL_INTRA(IntraModeAngular16bit_2, uint16_t)
+SVT_AMD_DECL_INTRA_ANG(IntraModeAngular_Vertical_Kernel, uint8_t)
+SVT_AMD_DECL_INTRA_ANG(IntraModeAngular16bit_Vertical_Kernel, uint16_t)
+SVT_AMD_DECL_INTRA_ANG(IntraModeAngular_Horizontal_Kernel, uint8_t)
+SVT_AMD_DECL_INTRA_ANG(IntraModeAngular16bit_Horizontal_Kernel, uint16_t)
+
 #ifdef __cplusplus
 }
 #endif

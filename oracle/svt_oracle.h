@@ -94,6 +94,18 @@ uint64_t svt_oracle_Compute4x4Satd(const int16_t *diff);
 uint64_t svt_oracle_Compute8x8Satd_U8(const uint8_t *src, uint64_t *dcValue, uint32_t srcStride);
 uint64_t svt_oracle_Compute4x4Satd_U8(const uint8_t *src, uint64_t *dcValue, uint32_t srcStride);
 
+/* ---- intra prediction leaves (C_DEFAULT/EbIntraPrediction_C.c) ------------ */
+enum {
+    SVT_ORACLE_INTRA_VERTICAL_LUMA = 0, SVT_ORACLE_INTRA_VERTICAL_CHROMA, SVT_ORACLE_INTRA_HORIZONTAL_LUMA,
+    SVT_ORACLE_INTRA_HORIZONTAL_CHROMA, SVT_ORACLE_INTRA_DC_LUMA, SVT_ORACLE_INTRA_DC_CHROMA, SVT_ORACLE_INTRA_PLANAR,
+    SVT_ORACLE_INTRA_ANGULAR_34, SVT_ORACLE_INTRA_ANGULAR_18, SVT_ORACLE_INTRA_ANGULAR_2,
+    SVT_ORACLE_INTRA_ANGULAR_VERTICAL, SVT_ORACLE_INTRA_ANGULAR_HORIZONTAL
+};
+/* bps: 1 (8-bit kernels) or 2 (16-bit kernels); ref is refSamples, or refSampMain for the two generic
+ * angular kernels; stride in samples */
+void svt_oracle_IntraPred(int mode, int bps, uint32_t size, const void *ref, void *pred, uint32_t stride, int skip,
+                          int32_t intraPredAngle);
+
 /* ---- picture-level ME (restates MotionEstimationKernel's LCU loop) -------- */
 
 /* A padded 8-bit plane: sample (x,y), x in [-pad, width+pad), is
