@@ -424,6 +424,108 @@ SVT_AMD_DECL_INTRA_ANG(IntraModeAngular16bit_Vertical_Kernel, uint16_t)
 SVT_AMD_DECL_INTRA_ANG(IntraModeAngular_Horizontal_Kernel, uint8_t)
 SVT_AMD_DECL_INTRA_ANG(IntraModeAngular16bit_Horizontal_Kernel, uint16_t)
 
+/* ------------------------------------------------------------------------- */
+/* In-loop filters (deblocking, SAO) and 10-bit pack/unpack                   */
+/* ------------------------------------------------------------------------- */
+/* One 4-sample luma edge: `offset` = sample index of q0 of the first edge sample inside the plane;
+ * tc/beta as derived by the reference's LCU drivers (EbDeblockingFilter.c:2222-3600, tables :33-66). */
+typedef struct SvtAmdDlfLumaEdge { int32_t offset; int16_t tc, beta; uint8_t vertical, pad[3]; } SvtAmdDlfLumaEdge;
+typedef struct SvtAmdDlfChromaEdge { int32_t offset; uint8_t cb_tc, cr_tc, vertical, pad; } SvtAmdDlfChromaEdge;
+/* per-LCU SAO statistics, the four output arrays of GatherSaoStatisticsLcu* in one record */
+typedef struct SvtAmdSaoStats {
+    int32_t boDiff[32]; uint16_t boCount[32]; int32_t eoDiff[4][5]; uint16_t eoCount[4][5];
+} SvtAmdSaoStats;
+
+/* BATCHED (device pointers).  Edges of one launch must not overlap. */
+SVT_AMD_API int svt_amd_dlf_luma_edges_batch(SvtAmdContext *ctx, void *d_plane, uint32_t stride,
+                                             int bytes_per_sample, const SvtAmdDlfLumaEdge *d_edges, uint32_t nedges);
+SVT_AMD_API int svt_amd_dlf_chroma_edges_batch(SvtAmdContext *ctx, void *d_cb, void *d_cr, uint32_t stride,
+                                               int bytes_per_sample, const SvtAmdDlfChromaEdge *d_edges,
+                                               uint32_t nedges);
+/* statistics of every LCU of a plane (raster LCU order), replaces the per-LCU SaoGenerationDecision ->
+ * GatherSaoStatisticsLcu* calls (EbSampleAdaptiveOffsetGenerationDecision.c:647,936) */
+SVT_AMD_API int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,
+                                           uint32_t inputStride, const void *d_recon, uint32_t reconStride,
+                                           uint32_t width, uint32_t height, uint32_t lcu_size,
+                                           int only_eo_90_45_135, SvtAmdSaoStats *d_stats);
+/* plane-level 8+2 bit -> 16 bit pack (compressed = 4 two-bit samples per byte) and the inverse */
+SVT_AMD_API int svt_amd_pack_plane(SvtAmdContext *ctx, const uint8_t *d_in8, uint32_t in8Stride, const uint8_t *d_inn,
+                                   uint32_t innStride, int compressed, uint16_t *d_out16, uint32_t outStride,
+                                   uint32_t width, uint32_t height);
+SVT_AMD_API int svt_amd_unpack_plane(SvtAmdContext *ctx, const uint16_t *d_in16, uint32_t inStride, uint8_t *d_out8,
+                                     uint32_t out8Stride, uint8_t *d_outn, uint32_t outnStride, uint32_t width,
+                                     uint32_t height);
+
+/* LEAF forms.  Luma4SampleEdgeDLFCore_Table / Chroma2SampleEdgeDLFCore_Table (EbDeblockingFilter.h:245-272) */
+SVT_AMD_API void svt_amd_Luma4SampleEdgeDLFCore(uint8_t *edgeStartFilteredSamplePtr, uint32_t reconLumaPicStride,
+                                                uint8_t isVerticalEdge, int32_t tc, int32_t beta);
+SVT_AMD_API void svt_amd_Luma4SampleEdgeDLFCore16bit(uint16_t *edgeStartFilteredSamplePtr, uint32_t reconLumaPicStride,
+                                                     uint8_t isVerticalEdge, int32_t tc, int32_t beta);
+SVT_AMD_API void svt_amd_Chroma2SampleEdgeDLFCore(uint8_t *edgeStartSampleCb, uint8_t *edgeStartSampleCr,
+                                                  uint32_t reconChromaPicStride, uint8_t isVerticalEdge, uint8_t cbTc,
+                                                  uint8_t crTc);
+SVT_AMD_API void svt_amd_Chroma2SampleEdgeDLFCore16bit(uint16_t *edgeStartSampleCb, uint16_t *edgeStartSampleCr,
+                                                       uint32_t reconChromaPicStride, uint8_t isVerticalEdge,
+                                                       uint8_t cbTc, uint8_t crTc);
+/* SaoGatherFunctionTable* (EbSampleAdaptiveOffset.h:171-206); return EB_ERRORTYPE (0 = EB_ErrorNone) */
+SVT_AMD_API int svt_amd_GatherSaoStatisticsLcuLossy_62x62(uint8_t *inputSamplePtr, uint32_t inputStride,
+                                                          uint8_t *reconSamplePtr, uint32_t reconStride, uint32_t lcuWidth,
+                                                          uint32_t lcuHeight, int32_t *boDiff, uint16_t *boCount,
+                                                          int32_t eoDiff[4][5], uint16_t eoCount[4][5]);
+SVT_AMD_API int svt_amd_GatherSaoStatisticsLcu_62x62_16bit(uint16_t *inputSamplePtr, uint32_t inputStride,
+                                                           uint16_t *reconSamplePtr, uint32_t reconStride, uint32_t lcuWidth,
+                                                           uint32_t lcuHeight, int32_t *boDiff, uint16_t *boCount,
+                                                           int32_t eoDiff[4][5], uint16_t eoCount[4][5]);
+SVT_AMD_API int svt_amd_GatherSaoStatisticsLcu_OnlyEo_90_45_135_Lossy(uint8_t *inputSamplePtr, uint32_t inputStride,
+                                                                      uint8_t *reconSamplePtr, uint32_t reconStride,
+                                                                      uint32_t lcuWidth, uint32_t lcuHeight,
+                                                                      int32_t eoDiff[4][5], uint16_t eoCount[4][5]);
+SVT_AMD_API int svt_amd_GatherSaoStatisticsLcu_62x62_OnlyEo_90_45_135_16bit(uint16_t *inputSamplePtr, uint32_t inputStride,
+                                                                            uint16_t *reconSamplePtr, uint32_t reconStride,
+                                                                            uint32_t lcuWidth, uint32_t lcuHeight,
+                                                                            int32_t eoDiff[4][5], uint16_t eoCount[4][5]);
+/* SaoFunctionTableEO_* / BO tables (EbSampleAdaptiveOffset.h:209-360) */
+SVT_AMD_API int svt_amd_SAOApplyBO(uint8_t *reconSamplePtr, uint32_t reconStride, uint32_t saoBandPosition,
+                                   int8_t *saoOffsetPtr, uint32_t lcuHeight, uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_0(uint8_t *reconSamplePtr, uint32_t reconStride, uint8_t *temporalBufferLeft,
+                                     int8_t *saoOffsetPtr, uint32_t lcuHeight, uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_90(uint8_t *reconSamplePtr, uint32_t reconStride, uint8_t *temporalBufferUpper,
+                                      int8_t *saoOffsetPtr, uint32_t lcuHeight, uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_135(uint8_t *reconSamplePtr, uint32_t reconStride, uint8_t *temporalBufferLeft,
+                                       uint8_t *temporalBufferUpper, int8_t *saoOffsetPtr, uint32_t lcuHeight,
+                                       uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_45(uint8_t *reconSamplePtr, uint32_t reconStride, uint8_t *temporalBufferLeft,
+                                      uint8_t *temporalBufferUpper, int8_t *saoOffsetPtr, uint32_t lcuHeight,
+                                      uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyBO16bit(uint16_t *reconSamplePtr, uint32_t reconStride, uint32_t saoBandPosition,
+                                        int8_t *saoOffsetPtr, uint32_t lcuHeight, uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_0_16bit(uint16_t *reconSamplePtr, uint32_t reconStride, uint16_t *temporalBufferLeft,
+                                           int8_t *saoOffsetPtr, uint32_t lcuHeight, uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_90_16bit(uint16_t *reconSamplePtr, uint32_t reconStride, uint16_t *temporalBufferUpper,
+                                            int8_t *saoOffsetPtr, uint32_t lcuHeight, uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_135_16bit(uint16_t *reconSamplePtr, uint32_t reconStride, uint16_t *temporalBufferLeft,
+                                             uint16_t *temporalBufferUpper, int8_t *saoOffsetPtr, uint32_t lcuHeight,
+                                             uint32_t lcuWidth);
+SVT_AMD_API int svt_amd_SAOApplyEO_45_16bit(uint16_t *reconSamplePtr, uint32_t reconStride, uint16_t *temporalBufferLeft,
+                                            uint16_t *temporalBufferUpper, int8_t *saoOffsetPtr, uint32_t lcuHeight,
+                                            uint32_t lcuWidth);
+/* Pack2D_funcPtrArray_16Bit_SRC ... UnPackAvg_funcPtrArray (EbPackUnPack.h:27-175) */
+SVT_AMD_API void svt_amd_EB_ENC_msbPack2D(uint8_t *in8BitBuffer, uint32_t in8Stride, uint8_t *innBitBuffer,
+                                          uint16_t *out16BitBuffer, uint32_t innStride, uint32_t outStride,
+                                          uint32_t width, uint32_t height);
+SVT_AMD_API void svt_amd_CompressedPackmsb(uint8_t *in8BitBuffer, uint32_t in8Stride, uint8_t *innBitBuffer,
+                                           uint16_t *out16BitBuffer, uint32_t innStride, uint32_t outStride,
+                                           uint32_t width, uint32_t height);
+SVT_AMD_API void svt_amd_CPack_C(const uint8_t *innBitBuffer, uint32_t innStride, uint8_t *inCompnBitBuffer,
+                                 uint32_t outStride, uint8_t *localCache, uint32_t width, uint32_t height);
+SVT_AMD_API void svt_amd_EB_ENC_msbUnPack2D(uint16_t *in16BitBuffer, uint32_t inStride, uint8_t *out8BitBuffer,
+                                            uint8_t *outnBitBuffer, uint32_t out8Stride, uint32_t outnStride,
+                                            uint32_t width, uint32_t height);
+SVT_AMD_API void svt_amd_UnPack8BitData(uint16_t *in16BitBuffer, uint32_t inStride, uint8_t *out8BitBuffer,
+                                        uint32_t out8Stride, uint32_t width, uint32_t height);
+SVT_AMD_API void svt_amd_UnpackAvg(uint16_t *ref16L0, uint32_t refL0Stride, uint16_t *ref16L1, uint32_t refL1Stride,
+                                   uint8_t *dstPtr, uint32_t dstStride, uint32_t width, uint32_t height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,28 @@ enum {
 void svt_oracle_IntraPred(int mode, int bps, uint32_t size, const void *ref, void *pred, uint32_t stride, int skip,
                           int32_t intraPredAngle);
 
+/* ---- in-loop filters and bit-depth packing leaves (bps: 1 = 8-bit kernels, 2 = *16bit kernels) ---- */
+void svt_oracle_Luma4SampleEdgeDLFCore(int bps, void *edge, uint32_t stride, int isVerticalEdge, int32_t tc, int32_t beta);
+void svt_oracle_Chroma2SampleEdgeDLFCore(int bps, void *cb, void *cr, uint32_t stride, int isVerticalEdge,
+                                         uint8_t cbTc, uint8_t crTc);
+void svt_oracle_GatherSaoStatistics(int bps, int only_eo_90_45_135, const void *input, uint32_t inputStride,
+                                    const void *recon, uint32_t reconStride, uint32_t lcuWidth, uint32_t lcuHeight,
+                                    int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5], uint16_t eoCount[4][5]);
+void svt_oracle_SAOApplyBO(int bps, void *recon, uint32_t stride, uint32_t bandPosition, const int8_t *offset,
+                           uint32_t lcuHeight, uint32_t lcuWidth);
+/* eoType 0: 0 deg (left only), 1: 90 (upper only), 2: 135, 3: 45 (left + upper, upper indexed -1..W) */
+void svt_oracle_SAOApplyEO(int bps, int eoType, void *recon, uint32_t stride, const void *left, const void *upper,
+                           const int8_t *offset, uint32_t lcuHeight, uint32_t lcuWidth);
+void svt_oracle_msbPack2D(const uint8_t *in8, uint32_t in8Stride, const uint8_t *inn, uint16_t *out16, uint32_t innStride,
+                          uint32_t outStride, uint32_t w, uint32_t h);
+void svt_oracle_CompressedPackmsb(const uint8_t *in8, uint32_t in8Stride, const uint8_t *inn, uint16_t *out16,
+                                  uint32_t innStride, uint32_t outStride, uint32_t w, uint32_t h);
+void svt_oracle_CPack(const uint8_t *inn, uint32_t innStride, uint8_t *out, uint32_t outStride, uint32_t w, uint32_t h);
+void svt_oracle_msbUnPack2D(const uint16_t *in16, uint32_t inStride, uint8_t *out8, uint8_t *outn, uint32_t out8Stride,
+                            uint32_t outnStride, uint32_t w, uint32_t h);
+void svt_oracle_UnpackAvg(const uint16_t *l0, uint32_t s0, const uint16_t *l1, uint32_t s1, uint8_t *dst,
+                          uint32_t dstStride, uint32_t w, uint32_t h);
+
 /* ---- picture-level ME (restates MotionEstimationKernel's LCU loop) -------- */
 
 /* A padded 8-bit plane: sample (x,y), x in [-pad, width+pad), is

@@ -1,0 +1,220 @@
+/*
+ * oracle/svt_oracle_loopfilter.c - TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
+ * CPU restatement of the in-loop filter and bit-depth packing leaf kernels:
+ *   deblocking edge cores   C_DEFAULT/EbDeblockingFilter_C.c:39-577
+ *   SAO statistics + apply  C_DEFAULT/EbSampleAdaptiveOffset_C.c:23-861
+ *   10-bit pack / unpack    C_DEFAULT/EbPackUnPack_C.c:12-251
+ * bps = bytes per sample (1: 8-bit kernels, 2: the *16bit kernels, 10-bit ranges).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "svt_oracle.h"
+
+#define GET(p, i) (bps == 1 ? (int)((const uint8_t *)(p))[i] : (int)((const uint16_t *)(p))[i])
+#define PUT(p, i, v)                              \
+    do {                                          \
+        if (bps == 1)                             \
+            ((uint8_t *)(p))[i] = (uint8_t)(v);   \
+        else                                      \
+            ((uint16_t *)(p))[i] = (uint16_t)(v); \
+    } while (0)
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+static inline int sgn(int a, int b) { return (a - b) < 0 ? -1 : (a - b) > 0 ? 1 : 0; } /* SIGN, EbUtility.h:102 */
+
+/* Luma4SampleEdgeDLFCore(16bit), EbDeblockingFilter_C.c:39-238, 240-438.  `edge` points at q0 of the
+ * first of the 4 edge samples; p side is at negative offsets along the filter direction. */
+void svt_oracle_Luma4SampleEdgeDLFCore(int bps, void *edge, uint32_t stride, int isVerticalEdge, int32_t tc, int32_t beta)
+{
+    const int maxv = bps == 1 ? 255 : 1023;
+    const int fs = isVerticalEdge ? 1 : (int)stride, ns = isVerticalEdge ? (int)stride : 1;
+#define S(k, line) GET(edge, (k) * fs + (line) * ns) /* k >= 0: q_k, k < 0: p_{-k-1} */
+    const int dp0 = abs(S(-3, 0) - 2 * S(-2, 0) + S(-1, 0)), dp3 = abs(S(-3, 3) - 2 * S(-2, 3) + S(-1, 3));
+    const int dq0 = abs(S(2, 0) - 2 * S(1, 0) + S(0, 0)), dq3 = abs(S(2, 3) - 2 * S(1, 3) + S(0, 3));
+    const int dp = dp0 + dp3, dq = dq0 + dq3, d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+    if (d >= beta)
+        return;
+    int strong = 1;
+    for (int line = 0; line < 4; line += 3) {
+        const int dl = line ? d3 : d0;
+        strong = strong && ((dl << 1) < (beta >> 2)) &&
+                 (beta >> 3) > (abs(S(-4, line) - S(-1, line)) + abs(S(3, line) - S(0, line))) &&
+                 ((5 * tc + 1) >> 1) > abs(S(-1, line) - S(0, line));
+    }
+    for (int c = 0; c < 4; c++) {
+        const int q0 = S(0, c), q1 = S(1, c), q2 = S(2, c), q3 = S(3, c);
+        const int p0 = S(-1, c), p1 = S(-2, c), p2 = S(-3, c), p3 = S(-4, c);
+#define W(k, v) PUT(edge, (k) * fs + c * ns, v)
+        if (strong) {
+            W(0, clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
+            W(-1, clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
+            W(1, clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2));
+            W(-2, clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2));
+            W(2, clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
+            W(-3, clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
+        } else {
+            int delta = ((q0 - p0) * 9 - (q1 - p1) * 3 + 8) >> 4;
+            if (abs(delta) < tc * 10) {
+                delta = clip3(-tc, tc, delta);
+                W(0, clip3(0, maxv, q0 - delta));
+                W(-1, clip3(0, maxv, p0 + delta));
+                const int side = (beta + (beta >> 1)) >> 3, tc2 = tc >> 1;
+                if (side > dp)
+                    W(-2, clip3(0, maxv, p1 + clip3(-tc2, tc2, ((((p0 + p2 + 1) >> 1) - p1 + delta) >> 1))));
+                if (side > dq)
+                    W(1, clip3(0, maxv, q1 + clip3(-tc2, tc2, ((((q0 + q2 + 1) >> 1) - q1 - delta) >> 1))));
+            }
+        }
+#undef W
+    }
+#undef S
+}
+
+/* Chroma2SampleEdgeDLFCore(16bit), EbDeblockingFilter_C.c:469-577 */
+void svt_oracle_Chroma2SampleEdgeDLFCore(int bps, void *cb, void *cr, uint32_t stride, int isVerticalEdge,
+                                         uint8_t cbTc, uint8_t crTc)
+{
+    const int maxv = bps == 1 ? 255 : 1023;
+    const int fs = isVerticalEdge ? 1 : (int)stride, ns = isVerticalEdge ? (int)stride : 1;
+    for (int plane = 0; plane < 2; plane++) {
+        void *e = plane ? cr : cb;
+        const int tc = plane ? crTc : cbTc;
+        for (int c = 0; c < 2; c++) {
+            const int q0 = GET(e, c * ns), q1 = GET(e, c * ns + fs), p0 = GET(e, c * ns - fs), p1 = GET(e, c * ns - 2 * fs);
+            const int16_t delta = (int16_t)clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+            PUT(e, c * ns - fs, clip3(0, maxv, p0 + delta));
+            PUT(e, c * ns, clip3(0, maxv, q0 - delta));
+        }
+    }
+}
+
+/* GatherSaoStatisticsLcu_62x62_16bit (:23), GatherSaoStatisticsLcuLossy_62x62 (:125),
+ * ..._OnlyEo_90_45_135_Lossy (:227), ..._62x62_OnlyEo_90_45_135_16bit (:311).
+ * Statistics over the interior (W-2)x(H-2); eo index order 0:0deg 1:90 2:135 3:45; categories
+ * compacted (slot 2 <- 3, 3 <- 4) at the end; 8-bit variants clip diff to [-128,127]. */
+void svt_oracle_GatherSaoStatistics(int bps, int only_eo_90_45_135, const void *input, uint32_t inputStride,
+                                    const void *recon, uint32_t reconStride, uint32_t lcuWidth, uint32_t lcuHeight,
+                                    int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5], uint16_t eoCount[4][5])
+{
+    const int boShift = bps == 1 ? 3 : 5;
+    if (!only_eo_90_45_135)
+        for (int i = 0; i < 32; i++)
+            boDiff[i] = 0, boCount[i] = 0;
+    for (int t = 0; t < 4; t++)
+        for (int k = 0; k < 5; k++)
+            eoDiff[t][k] = 0, eoCount[t][k] = 0;
+    const int rs = (int)reconStride;
+    for (uint32_t j = 1; j + 1 < lcuHeight; j++)
+        for (uint32_t i = 1; i + 1 < lcuWidth; i++) {
+            const int at = (int)(j * reconStride + i), r = GET(recon, at);
+            int diff = GET(input, j * inputStride + i) - r;
+            if (bps == 1)
+                diff = clip3(-128, 127, diff);
+            if (!only_eo_90_45_135) {
+                boDiff[r >> boShift] += diff;
+                boCount[r >> boShift]++;
+            }
+            const int nb[4][2] = {{-1, 1}, {-rs, rs}, {-rs - 1, rs + 1}, {-rs + 1, rs - 1}};
+            for (int t = only_eo_90_45_135 ? 1 : 0; t < 4; t++) {
+                const int idx = sgn(r, GET(recon, at + nb[t][0])) + sgn(r, GET(recon, at + nb[t][1])) + 2;
+                eoDiff[t][idx] += diff;
+                eoCount[t][idx]++;
+            }
+        }
+    for (int t = 0; t < 4; t++) {
+        eoDiff[t][2] = eoDiff[t][3], eoDiff[t][3] = eoDiff[t][4];
+        eoCount[t][2] = eoCount[t][3], eoCount[t][3] = eoCount[t][4];
+    }
+}
+
+/* SAOApplyBO(16bit), EbSampleAdaptiveOffset_C.c:394-468 */
+void svt_oracle_SAOApplyBO(int bps, void *recon, uint32_t stride, uint32_t bandPosition, const int8_t *offset,
+                           uint32_t lcuHeight, uint32_t lcuWidth)
+{
+    const int maxv = bps == 1 ? 255 : 1023, shift = bps == 1 ? 3 : 5;
+    for (uint32_t y = 0; y < lcuHeight; y++)
+        for (uint32_t x = 0; x < lcuWidth; x++) {
+            const int v = GET(recon, y * stride + x);
+            const uint32_t bo = (uint32_t)v >> shift;
+            if (!(bo < bandPosition || bo > bandPosition + 4 - 1)) /* SAO_BO_LEN = 4 */
+                PUT(recon, y * stride + x, clip3(0, maxv, v + offset[bo - bandPosition]));
+        }
+}
+
+/* SAOApplyEO_0 / _90 / _135 / _45 (+16bit), EbSampleAdaptiveOffset_C.c:470-861.  The reference
+ * works in place and carries neighbour signs; equivalently every sample is classified against the
+ * ORIGINAL neighbours, where column -1 comes from temporalBufferLeft[y], row -1 from
+ * temporalBufferUpper[x] (x = -1..W), and row H / column W are the untouched picture samples. */
+void svt_oracle_SAOApplyEO(int bps, int eoType, void *recon, uint32_t stride, const void *left, const void *upper,
+                           const int8_t *offset, uint32_t lcuHeight, uint32_t lcuWidth)
+{
+    const int maxv = bps == 1 ? 255 : 1023;
+    const int W = (int)lcuWidth, H = (int)lcuHeight, os = W + 2;
+    int *orig = (int *)malloc(sizeof(int) * (size_t)(W + 2) * (size_t)(H + 2));
+#define O(x, y) orig[((y) + 1) * os + (x) + 1]
+    for (int y = -1; y <= H; y++)
+        for (int x = -1; x <= W; x++) {
+            int v = 0;
+            if (y == -1)
+                v = upper ? GET(upper, x) : 0;
+            else if (x == -1)
+                v = left ? GET(left, y) : 0;
+            else
+                v = GET(recon, y * (int)stride + x);
+            O(x, y) = v;
+        }
+    static const int dx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}}, dy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int c = O(x, y);
+            const int idx = sgn(c, O(x + dx[eoType][0], y + dy[eoType][0])) + sgn(c, O(x + dx[eoType][1], y + dy[eoType][1])) + 2;
+            PUT(recon, y * (int)stride + x, clip3(0, maxv, c + offset[idx]));
+        }
+#undef O
+    free(orig);
+}
+
+/* EbPackUnPack_C.c */
+void svt_oracle_msbPack2D(const uint8_t *in8, uint32_t in8Stride, const uint8_t *inn, uint16_t *out16, uint32_t innStride,
+                          uint32_t outStride, uint32_t w, uint32_t h) /* EB_ENC_msbPack2D :12 */
+{
+    for (uint32_t j = 0; j < h; j++)
+        for (uint32_t k = 0; k < w; k++)
+            out16[k + j * outStride] = (uint16_t)((in8[k + j * in8Stride] << 2) | ((inn[k + j * innStride] >> 6) & 3));
+}
+void svt_oracle_CompressedPackmsb(const uint8_t *in8, uint32_t in8Stride, const uint8_t *inn, uint16_t *out16,
+                                  uint32_t innStride, uint32_t outStride, uint32_t w, uint32_t h) /* :40 */
+{
+    for (uint32_t j = 0; j < h; j++)
+        for (uint32_t k = 0; k < w / 4; k++) {
+            const uint8_t four = inn[k + j * innStride];
+            for (int i = 0; i < 4; i++)
+                out16[k * 4 + i + j * outStride] = (uint16_t)((in8[k * 4 + i + j * in8Stride] << 2) | ((four >> (6 - 2 * i)) & 3));
+        }
+}
+void svt_oracle_CPack(const uint8_t *inn, uint32_t innStride, uint8_t *out, uint32_t outStride, uint32_t w, uint32_t h) /* CPack_C :83 */
+{
+    for (uint32_t r = 0; r < h; r++)
+        for (uint32_t c = 0; c < w; c += 4) {
+            const uint32_t i = c + r * innStride;
+            out[c / 4 + r * outStride] = (uint8_t)(((inn[i] >> 0) & 0xC0) | ((inn[i + 1] >> 2) & 0x30) |
+                                                   ((inn[i + 2] >> 4) & 0x0C) | ((inn[i + 3] >> 6) & 0x03));
+        }
+}
+void svt_oracle_msbUnPack2D(const uint16_t *in16, uint32_t inStride, uint8_t *out8, uint8_t *outn, uint32_t out8Stride,
+                            uint32_t outnStride, uint32_t w, uint32_t h) /* EB_ENC_msbUnPack2D :116; out8 only: UnPack8BitData :143 */
+{
+    for (uint32_t j = 0; j < h; j++)
+        for (uint32_t k = 0; k < w; k++) {
+            const uint16_t p = in16[k + j * inStride];
+            out8[k + j * out8Stride] = (uint8_t)(p >> 2);
+            if (outn)
+                outn[k + j * outnStride] = (uint8_t)(p << 6);
+        }
+}
+void svt_oracle_UnpackAvg(const uint16_t *l0, uint32_t s0, const uint16_t *l1, uint32_t s1, uint8_t *dst,
+                          uint32_t dstStride, uint32_t w, uint32_t h) /* UnpackAvg :165 */
+{
+    for (uint32_t j = 0; j < h; j++)
+        for (uint32_t k = 0; k < w; k++)
+            dst[k + j * dstStride] = (uint8_t)(((uint8_t)(l0[k + j * s0] >> 2) + (uint8_t)(l1[k + j * s1] >> 2) + 1) >> 1);
+}

@@ -1,0 +1,547 @@
+/*
+ * In-loop filter and bit-depth packing kernels (EncDec rows "BS / DLF", "SAO", "pack/unpack").
+ *
+ *   deblocking edge cores  Luma4SampleEdgeDLFCore(16bit), Chroma2SampleEdgeDLFCore(16bit)
+ *                          (C_DEFAULT/EbDeblockingFilter_C.c:39-577; tables Codec/EbDeblockingFilter.h:245-272)
+ *                          batched: one thread per 4-sample (luma) / 2-sample (chroma) edge of an edge list;
+ *                          the edges of one launch must not overlap (all vertical edges of a picture, then
+ *                          all horizontal ones - exactly the order the reference's LCU drivers use).
+ *   SAO statistics         GatherSaoStatisticsLcu* (C_DEFAULT/EbSampleAdaptiveOffset_C.c:23-393; tables
+ *                          Codec/EbSampleAdaptiveOffset.h:171-206): one workgroup per LCU, LDS histograms.
+ *   SAO apply              SAOApplyBO / SAOApplyEO_0/90/135/45 (+16bit) (:394-861; tables :209-360): one thread
+ *                          per sample, classified against the ORIGINAL neighbours (out of place), which is what
+ *                          the reference's in-place sign-carrying loops compute.
+ *   pack / unpack          EB_ENC_msbPack2D, CompressedPackmsb, CPack_C, EB_ENC_msbUnPack2D, UnPack8BitData,
+ *                          UnpackAvg (C_DEFAULT/EbPackUnPack_C.c:12-251; tables Codec/EbPackUnPack.h:27-175):
+ *                          pure streaming, HBM-bound.
+ */
+#include "leaf_util.h"
+#include <cstring>
+#include <cstdlib>
+
+__device__ __forceinline__ int f_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int f_sgn(int a, int b) { return (a - b) < 0 ? -1 : ((a - b) > 0 ? 1 : 0); }
+
+/* ---------------- deblocking ---------------- */
+struct DlfLumaEdge { int32_t offset; int16_t tc, beta; uint8_t vertical, pad[3]; };     /* = SvtAmdDlfLumaEdge */
+struct DlfChromaEdge { int32_t offset; uint8_t cb_tc, cr_tc, vertical, pad; };          /* = SvtAmdDlfChromaEdge */
+
+template <typename T>
+__device__ void dlf_luma_core(T *edge, int stride, int vertical, int tc, int beta)
+{
+    const int maxv = sizeof(T) == 1 ? 255 : 1023;
+    const int fs = vertical ? 1 : stride, ns = vertical ? stride : 1;
+#define S(k, line) ((int)edge[(k) * fs + (line) * ns])
+    const int dp0 = abs(S(-3, 0) - 2 * S(-2, 0) + S(-1, 0)), dp3 = abs(S(-3, 3) - 2 * S(-2, 3) + S(-1, 3));
+    const int dq0 = abs(S(2, 0) - 2 * S(1, 0) + S(0, 0)), dq3 = abs(S(2, 3) - 2 * S(1, 3) + S(0, 3));
+    const int dp = dp0 + dp3, dq = dq0 + dq3, d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+    if (d >= beta)
+        return;
+    bool strong = true;
+#pragma unroll
+    for (int line = 0; line < 4; line += 3) {
+        const int dl = line ? d3 : d0;
+        strong = strong && ((dl << 1) < (beta >> 2)) &&
+                 (beta >> 3) > (abs(S(-4, line) - S(-1, line)) + abs(S(3, line) - S(0, line))) &&
+                 ((5 * tc + 1) >> 1) > abs(S(-1, line) - S(0, line));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int q0 = S(0, c), q1 = S(1, c), q2 = S(2, c), q3 = S(3, c);
+        const int p0 = S(-1, c), p1 = S(-2, c), p2 = S(-3, c), p3 = S(-4, c);
+#define W(k, v) edge[(k) * fs + c * ns] = (T)(v)
+        if (strong) {
+            W(0, f_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
+            W(-1, f_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
+            W(1, f_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2));
+            W(-2, f_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2));
+            W(2, f_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
+            W(-3, f_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
+        } else {
+            int delta = ((q0 - p0) * 9 - (q1 - p1) * 3 + 8) >> 4;
+            if (abs(delta) < tc * 10) {
+                delta = f_clip3(-tc, tc, delta);
+                W(0, f_clip3(0, maxv, q0 - delta));
+                W(-1, f_clip3(0, maxv, p0 + delta));
+                const int side = (beta + (beta >> 1)) >> 3, tc2 = tc >> 1;
+                if (side > dp)
+                    W(-2, f_clip3(0, maxv, p1 + f_clip3(-tc2, tc2, ((((p0 + p2 + 1) >> 1) - p1 + delta) >> 1))));
+                if (side > dq)
+                    W(1, f_clip3(0, maxv, q1 + f_clip3(-tc2, tc2, ((((q0 + q2 + 1) >> 1) - q1 - delta) >> 1))));
+            }
+        }
+#undef W
+    }
+#undef S
+}
+
+template <typename T>
+__global__ void k_dlf_luma(T *plane, int stride, const DlfLumaEdge *edges, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dlf_luma_core<T>(plane + edges[i].offset, stride, edges[i].vertical, edges[i].tc, edges[i].beta);
+}
+
+template <typename T>
+__global__ void k_dlf_chroma(T *cb, T *cr, int stride, const DlfChromaEdge *edges, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int maxv = sizeof(T) == 1 ? 255 : 1023;
+    const int fs = edges[i].vertical ? 1 : stride, ns = edges[i].vertical ? stride : 1;
+#pragma unroll
+    for (int plane = 0; plane < 2; plane++) {
+        T *e = (plane ? cr : cb) + edges[i].offset;
+        const int tc = plane ? edges[i].cr_tc : edges[i].cb_tc;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int q0 = e[c * ns], q1 = e[c * ns + fs], p0 = e[c * ns - fs], p1 = e[c * ns - 2 * fs];
+            const int delta = (int16_t)f_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+            e[c * ns - fs] = (T)f_clip3(0, maxv, p0 + delta);
+            e[c * ns] = (T)f_clip3(0, maxv, q0 - delta);
+        }
+    }
+}
+
+/* ---------------- SAO statistics ---------------- */
+struct SaoStats { int32_t boDiff[32]; uint16_t boCount[32]; int32_t eoDiff[4][5]; uint16_t eoCount[4][5]; }; /* = SvtAmdSaoStats */
+
+/* one workgroup per LCU of a picture-wide grid (lcu_size x lcu_size, clipped at the right/bottom) */
+template <typename T>
+__global__ __launch_bounds__(256) void k_sao_gather(const T *__restrict__ input, int inStride,
+                                                    const T *__restrict__ recon, int reconStride, int width, int height,
+                                                    int lcu_size, int lcus_w, int only_eo, SaoStats *__restrict__ out)
+{
+    __shared__ int bo_d[32], eo_d[4][5];
+    __shared__ unsigned bo_c[32], eo_c[4][5];
+    const int t = threadIdx.x, lcu = blockIdx.x;
+    const int x0 = (lcu % lcus_w) * lcu_size, y0 = (lcu / lcus_w) * lcu_size;
+    const int lw = min(lcu_size, width - x0), lh = min(lcu_size, height - y0);
+    if (t < 32)
+        bo_d[t] = 0, bo_c[t] = 0;
+    if (t < 20)
+        (&eo_d[0][0])[t] = 0, (&eo_c[0][0])[t] = 0;
+    __syncthreads();
+    const int boShift = sizeof(T) == 1 ? 3 : 5;
+    const int iw = lw - 2, ih = lh - 2;
+    for (int i = t; i < iw * ih; i += 256) {
+        const int yy = i / iw + 1, xx = i - (yy - 1) * iw + 1;
+        const T *r = recon + (ptrdiff_t)(y0 + yy) * reconStride + x0 + xx;
+        const int c = r[0];
+        int diff = (int)input[(ptrdiff_t)(y0 + yy) * inStride + x0 + xx] - c;
+        if (sizeof(T) == 1)
+            diff = f_clip3(-128, 127, diff);
+        if (!only_eo) {
+            atomicAdd(&bo_d[c >> boShift], diff);
+            atomicAdd(&bo_c[c >> boShift], 1u);
+        }
+        const int nb[4][2] = {{-1, 1}, {-reconStride, reconStride}, {-reconStride - 1, reconStride + 1}, {-reconStride + 1, reconStride - 1}};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (only_eo && k == 0)
+                continue;
+            const int idx = f_sgn(c, r[nb[k][0]]) + f_sgn(c, r[nb[k][1]]) + 2;
+            atomicAdd(&eo_d[k][idx], diff);
+            atomicAdd(&eo_c[k][idx], 1u);
+        }
+    }
+    __syncthreads();
+    SaoStats *o = &out[lcu];
+    if (t < 32 && !only_eo)
+        o->boDiff[t] = bo_d[t], o->boCount[t] = (uint16_t)bo_c[t];
+    if (t < 4) { /* category compaction: slot 2 <- 3, 3 <- 4 (EbSampleAdaptiveOffset_C.c:113-118) */
+        o->eoDiff[t][0] = eo_d[t][0], o->eoDiff[t][1] = eo_d[t][1], o->eoDiff[t][2] = eo_d[t][3];
+        o->eoDiff[t][3] = eo_d[t][4], o->eoDiff[t][4] = eo_d[t][4];
+        o->eoCount[t][0] = (uint16_t)eo_c[t][0], o->eoCount[t][1] = (uint16_t)eo_c[t][1], o->eoCount[t][2] = (uint16_t)eo_c[t][3];
+        o->eoCount[t][3] = (uint16_t)eo_c[t][4], o->eoCount[t][4] = (uint16_t)eo_c[t][4];
+    }
+}
+
+/* ---------------- SAO apply (leaf level, out of place) ---------------- */
+/* src: original samples incl. one row below and one column right; dst: output area. */
+template <typename T>
+__global__ void k_sao_apply(int kind /* 0..3 EO type, 4 BO */, const T *__restrict__ src, T *__restrict__ dst, int stride,
+                            const T *__restrict__ left, const T *__restrict__ upper /* index -1..W */, int band,
+                            const int8_t *__restrict__ offset, int W, int H)
+{
+    const int maxv = sizeof(T) == 1 ? 255 : 1023;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * H; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const int c = src[y * stride + x];
+        if (kind == 4) {
+            const int bo = c >> (sizeof(T) == 1 ? 3 : 5);
+            dst[y * stride + x] = (bo < band || bo > band + 3) ? (T)c : (T)f_clip3(0, maxv, c + offset[bo - band]);
+            continue;
+        }
+        const int dx0 = (kind == 1) ? 0 : (kind == 3 ? 1 : -1), dy0 = (kind == 0) ? 0 : -1;
+        int n[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int xx = x + (s ? -dx0 : dx0), yy = y + (s ? -dy0 : dy0);
+            n[s] = (yy < 0) ? (int)upper[xx] : (xx < 0) ? (int)left[yy] : (int)src[yy * stride + xx];
+        }
+        dst[y * stride + x] = (T)f_clip3(0, maxv, c + offset[f_sgn(c, n[0]) + f_sgn(c, n[1]) + 2]);
+    }
+}
+
+/* ---------------- pack / unpack (streaming) ---------------- */
+__global__ void k_pack(const uint8_t *__restrict__ in8, uint32_t in8Stride, const uint8_t *__restrict__ inn,
+                       uint32_t innStride, uint16_t *__restrict__ out16, uint32_t outStride, uint32_t w, uint32_t h,
+                       int compressed)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / w, x = i - y * w;
+        const uint32_t two = compressed ? (inn[(x >> 2) + (size_t)y * innStride] >> (6 - 2 * (x & 3))) & 3u
+                                        : (inn[x + (size_t)y * innStride] >> 6) & 3u;
+        out16[x + (size_t)y * outStride] = (uint16_t)((in8[x + (size_t)y * in8Stride] << 2) | two);
+    }
+}
+__global__ void k_cpack(const uint8_t *__restrict__ inn, uint32_t innStride, uint8_t *__restrict__ out,
+                        uint32_t outStride, uint32_t w, uint32_t h)
+{
+    const uint32_t w4 = w / 4;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w4 * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / w4, x = (i - y * w4) * 4;
+        const uint8_t *p = inn + x + (size_t)y * innStride;
+        out[(x >> 2) + (size_t)y * outStride] =
+            (uint8_t)((p[0] & 0xC0) | ((p[1] >> 2) & 0x30) | ((p[2] >> 4) & 0x0C) | ((p[3] >> 6) & 0x03));
+    }
+}
+__global__ void k_unpack(const uint16_t *__restrict__ in16, uint32_t inStride, uint8_t *__restrict__ out8,
+                         uint32_t out8Stride, uint8_t *__restrict__ outn, uint32_t outnStride, uint32_t w, uint32_t h)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / w, x = i - y * w;
+        const uint16_t p = in16[x + (size_t)y * inStride];
+        out8[x + (size_t)y * out8Stride] = (uint8_t)(p >> 2);
+        if (outn)
+            outn[x + (size_t)y * outnStride] = (uint8_t)(p << 6);
+    }
+}
+__global__ void k_unpack_avg(const uint16_t *__restrict__ l0, uint32_t s0, const uint16_t *__restrict__ l1, uint32_t s1,
+                             uint8_t *__restrict__ dst, uint32_t ds, uint32_t w, uint32_t h)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / w, x = i - y * w;
+        dst[x + (size_t)y * ds] = (uint8_t)(((uint8_t)(l0[x + (size_t)y * s0] >> 2) + (uint8_t)(l1[x + (size_t)y * s1] >> 2) + 1) >> 1);
+    }
+}
+
+static inline dim3 grid1d(uint32_t n) { return dim3((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+/* ---------------- batched C-ABI (device pointers) ---------------- */
+extern "C" int svt_amd_dlf_luma_edges_batch(SvtAmdContext *ctx, void *d_plane, uint32_t stride, int bytes_per_sample,
+                                            const SvtAmdDlfLumaEdge *d_edges, uint32_t nedges)
+{
+    if (!ctx || !d_plane || !d_edges || !nedges || (bytes_per_sample != 1 && bytes_per_sample != 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes_per_sample == 1)
+        hipLaunchKernelGGL(k_dlf_luma<uint8_t>, grid1d(nedges), dim3(256), 0, ctx->stream, (uint8_t *)d_plane, (int)stride,
+                           (const DlfLumaEdge *)d_edges, nedges);
+    else
+        hipLaunchKernelGGL(k_dlf_luma<uint16_t>, grid1d(nedges), dim3(256), 0, ctx->stream, (uint16_t *)d_plane, (int)stride,
+                           (const DlfLumaEdge *)d_edges, nedges);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_dlf_chroma_edges_batch(SvtAmdContext *ctx, void *d_cb, void *d_cr, uint32_t stride,
+                                              int bytes_per_sample, const SvtAmdDlfChromaEdge *d_edges, uint32_t nedges)
+{
+    if (!ctx || !d_cb || !d_cr || !d_edges || !nedges || (bytes_per_sample != 1 && bytes_per_sample != 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes_per_sample == 1)
+        hipLaunchKernelGGL(k_dlf_chroma<uint8_t>, grid1d(nedges), dim3(256), 0, ctx->stream, (uint8_t *)d_cb, (uint8_t *)d_cr,
+                           (int)stride, (const DlfChromaEdge *)d_edges, nedges);
+    else
+        hipLaunchKernelGGL(k_dlf_chroma<uint16_t>, grid1d(nedges), dim3(256), 0, ctx->stream, (uint16_t *)d_cb, (uint16_t *)d_cr,
+                           (int)stride, (const DlfChromaEdge *)d_edges, nedges);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,
+                                          uint32_t inputStride, const void *d_recon, uint32_t reconStride,
+                                          uint32_t width, uint32_t height, uint32_t lcu_size, int only_eo_90_45_135,
+                                          SvtAmdSaoStats *d_stats)
+{
+    if (!ctx || !d_input || !d_recon || !d_stats || !width || !height || lcu_size < 8 ||
+        (bytes_per_sample != 1 && bytes_per_sample != 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int lw = (int)((width + lcu_size - 1) / lcu_size), lh = (int)((height + lcu_size - 1) / lcu_size);
+    if (bytes_per_sample == 1)
+        hipLaunchKernelGGL(k_sao_gather<uint8_t>, dim3(lw * lh), dim3(256), 0, ctx->stream, (const uint8_t *)d_input,
+                           (int)inputStride, (const uint8_t *)d_recon, (int)reconStride, (int)width, (int)height,
+                           (int)lcu_size, lw, only_eo_90_45_135, (SaoStats *)d_stats);
+    else
+        hipLaunchKernelGGL(k_sao_gather<uint16_t>, dim3(lw * lh), dim3(256), 0, ctx->stream, (const uint16_t *)d_input,
+                           (int)inputStride, (const uint16_t *)d_recon, (int)reconStride, (int)width, (int)height,
+                           (int)lcu_size, lw, only_eo_90_45_135, (SaoStats *)d_stats);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_pack_plane(SvtAmdContext *ctx, const uint8_t *d_in8, uint32_t in8Stride, const uint8_t *d_inn,
+                                  uint32_t innStride, int compressed, uint16_t *d_out16, uint32_t outStride,
+                                  uint32_t width, uint32_t height)
+{
+    if (!ctx || !d_in8 || !d_inn || !d_out16 || !width || !height)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_pack, grid1d(width * height), dim3(256), 0, ctx->stream, d_in8, in8Stride, d_inn, innStride, d_out16,
+                       outStride, width, height, compressed);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_unpack_plane(SvtAmdContext *ctx, const uint16_t *d_in16, uint32_t inStride, uint8_t *d_out8,
+                                    uint32_t out8Stride, uint8_t *d_outn, uint32_t outnStride, uint32_t width,
+                                    uint32_t height)
+{
+    if (!ctx || !d_in16 || !d_out8 || !width || !height)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_unpack, grid1d(width * height), dim3(256), 0, ctx->stream, d_in16, inStride, d_out8, out8Stride, d_outn,
+                       outnStride, width, height);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* ---------------- LEAF wrappers (host pointers, reference signatures) ---------------- */
+template <typename T>
+static void luma_dlf_leaf(T *edge, uint32_t stride, uint8_t vertical, int32_t tc, int32_t beta)
+{
+    /* stage the 8 x 4 neighbourhood: rows/cols -4..3 around the edge start */
+    const int fs = vertical ? 1 : (int)stride, ns = vertical ? (int)stride : 1;
+    const ptrdiff_t lo = -4 * fs, hi = 3 * fs + 3 * ns;
+    DBuf buf(edge + lo, (size_t)(hi - lo + 1) * sizeof(T)), e(nullptr, sizeof(DlfLumaEdge), false);
+    if (!(buf.ok && e.ok))
+        return;
+    DlfLumaEdge he = {(int32_t)(-lo), (int16_t)tc, (int16_t)beta, vertical, {0, 0, 0}};
+    if (hipMemcpy(e.d, &he, sizeof(he), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    hipLaunchKernelGGL(k_dlf_luma<T>, dim3(1), dim3(64), 0, 0, (T *)buf.d, (int)stride, (const DlfLumaEdge *)e.d, 1u);
+    if (finish("Luma4SampleEdgeDLFCore"))
+        buf.download(edge + lo, (size_t)(hi - lo + 1) * sizeof(T));
+}
+extern "C" void svt_amd_Luma4SampleEdgeDLFCore(uint8_t *edgeStartFilteredSamplePtr, uint32_t reconLumaPicStride,
+                                               uint8_t isVerticalEdge, int32_t tc, int32_t beta)
+{
+    luma_dlf_leaf<uint8_t>(edgeStartFilteredSamplePtr, reconLumaPicStride, isVerticalEdge, tc, beta);
+}
+extern "C" void svt_amd_Luma4SampleEdgeDLFCore16bit(uint16_t *edgeStartFilteredSamplePtr, uint32_t reconLumaPicStride,
+                                                    uint8_t isVerticalEdge, int32_t tc, int32_t beta)
+{
+    luma_dlf_leaf<uint16_t>(edgeStartFilteredSamplePtr, reconLumaPicStride, isVerticalEdge, tc, beta);
+}
+template <typename T>
+static void chroma_dlf_leaf(T *cb, T *cr, uint32_t stride, uint8_t vertical, uint8_t cbTc, uint8_t crTc)
+{
+    const int fs = vertical ? 1 : (int)stride, ns = vertical ? (int)stride : 1;
+    const ptrdiff_t lo = -2 * fs, hi = fs + ns;
+    DBuf b(cb + lo, (size_t)(hi - lo + 1) * sizeof(T)), r(cr + lo, (size_t)(hi - lo + 1) * sizeof(T)),
+        e(nullptr, sizeof(DlfChromaEdge), false);
+    if (!(b.ok && r.ok && e.ok))
+        return;
+    DlfChromaEdge he = {(int32_t)(-lo), cbTc, crTc, vertical, 0};
+    if (hipMemcpy(e.d, &he, sizeof(he), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    hipLaunchKernelGGL(k_dlf_chroma<T>, dim3(1), dim3(64), 0, 0, (T *)b.d, (T *)r.d, (int)stride, (const DlfChromaEdge *)e.d, 1u);
+    if (finish("Chroma2SampleEdgeDLFCore")) {
+        b.download(cb + lo, (size_t)(hi - lo + 1) * sizeof(T));
+        r.download(cr + lo, (size_t)(hi - lo + 1) * sizeof(T));
+    }
+}
+extern "C" void svt_amd_Chroma2SampleEdgeDLFCore(uint8_t *edgeStartSampleCb, uint8_t *edgeStartSampleCr,
+                                                 uint32_t reconChromaPicStride, uint8_t isVerticalEdge, uint8_t cbTc,
+                                                 uint8_t crTc)
+{
+    chroma_dlf_leaf<uint8_t>(edgeStartSampleCb, edgeStartSampleCr, reconChromaPicStride, isVerticalEdge, cbTc, crTc);
+}
+extern "C" void svt_amd_Chroma2SampleEdgeDLFCore16bit(uint16_t *edgeStartSampleCb, uint16_t *edgeStartSampleCr,
+                                                      uint32_t reconChromaPicStride, uint8_t isVerticalEdge,
+                                                      uint8_t cbTc, uint8_t crTc)
+{
+    chroma_dlf_leaf<uint16_t>(edgeStartSampleCb, edgeStartSampleCr, reconChromaPicStride, isVerticalEdge, cbTc, crTc);
+}
+
+template <typename T>
+static int sao_gather_leaf(int only_eo, T *input, uint32_t inputStride, T *recon, uint32_t reconStride, uint32_t lcuWidth,
+                           uint32_t lcuHeight, int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5], uint16_t eoCount[4][5])
+{
+    DBuf a(input, span(inputStride, lcuWidth, lcuHeight) * sizeof(T)), b(recon, span(reconStride, lcuWidth, lcuHeight) * sizeof(T)),
+        o(nullptr, sizeof(SaoStats), false);
+    if (!(a.ok && b.ok && o.ok))
+        return 1;
+    hipLaunchKernelGGL(k_sao_gather<T>, dim3(1), dim3(256), 0, 0, (const T *)a.d, (int)inputStride, (const T *)b.d,
+                       (int)reconStride, (int)lcuWidth, (int)lcuHeight, 1 << 20, 1, only_eo, (SaoStats *)o.d);
+    SaoStats st;
+    if (!finish("GatherSaoStatistics") || !o.download(&st, sizeof(st)))
+        return 1;
+    if (!only_eo) {
+        ::memcpy(boDiff, st.boDiff, sizeof(st.boDiff));
+        ::memcpy(boCount, st.boCount, sizeof(st.boCount));
+    }
+    ::memcpy(eoDiff, st.eoDiff, sizeof(st.eoDiff));
+    ::memcpy(eoCount, st.eoCount, sizeof(st.eoCount));
+    if (only_eo) /* the reference zeroes type 0 and never touches it */
+        for (int k = 0; k < 5; k++)
+            eoDiff[0][k] = 0, eoCount[0][k] = 0;
+    return 0;
+}
+extern "C" int svt_amd_GatherSaoStatisticsLcuLossy_62x62(uint8_t *inputSamplePtr, uint32_t inputStride, uint8_t *reconSamplePtr,
+                                                         uint32_t reconStride, uint32_t lcuWidth, uint32_t lcuHeight,
+                                                         int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5],
+                                                         uint16_t eoCount[4][5])
+{
+    return sao_gather_leaf<uint8_t>(0, inputSamplePtr, inputStride, reconSamplePtr, reconStride, lcuWidth, lcuHeight, boDiff, boCount, eoDiff, eoCount);
+}
+extern "C" int svt_amd_GatherSaoStatisticsLcu_62x62_16bit(uint16_t *inputSamplePtr, uint32_t inputStride, uint16_t *reconSamplePtr,
+                                                          uint32_t reconStride, uint32_t lcuWidth, uint32_t lcuHeight,
+                                                          int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5],
+                                                          uint16_t eoCount[4][5])
+{
+    return sao_gather_leaf<uint16_t>(0, inputSamplePtr, inputStride, reconSamplePtr, reconStride, lcuWidth, lcuHeight, boDiff, boCount, eoDiff, eoCount);
+}
+extern "C" int svt_amd_GatherSaoStatisticsLcu_OnlyEo_90_45_135_Lossy(uint8_t *inputSamplePtr, uint32_t inputStride,
+                                                                     uint8_t *reconSamplePtr, uint32_t reconStride,
+                                                                     uint32_t lcuWidth, uint32_t lcuHeight,
+                                                                     int32_t eoDiff[4][5], uint16_t eoCount[4][5])
+{
+    return sao_gather_leaf<uint8_t>(1, inputSamplePtr, inputStride, reconSamplePtr, reconStride, lcuWidth, lcuHeight, nullptr, nullptr, eoDiff, eoCount);
+}
+extern "C" int svt_amd_GatherSaoStatisticsLcu_62x62_OnlyEo_90_45_135_16bit(uint16_t *inputSamplePtr, uint32_t inputStride,
+                                                                           uint16_t *reconSamplePtr, uint32_t reconStride,
+                                                                           uint32_t lcuWidth, uint32_t lcuHeight,
+                                                                           int32_t eoDiff[4][5], uint16_t eoCount[4][5])
+{
+    return sao_gather_leaf<uint16_t>(1, inputSamplePtr, inputStride, reconSamplePtr, reconStride, lcuWidth, lcuHeight, nullptr, nullptr, eoDiff, eoCount);
+}
+
+template <typename T>
+static int sao_apply_leaf(int kind, T *recon, uint32_t stride, T *left, T *upper, uint32_t band, int8_t *offset,
+                          uint32_t lcuHeight, uint32_t lcuWidth)
+{
+    /* the source copy includes the right column / bottom row neighbours the EO type reads */
+    const uint32_t ex = (kind == 0 || kind == 2 || kind == 3), ey = (kind >= 1 && kind <= 3);
+    const size_t bytes = span(stride, lcuWidth + ex, lcuHeight + ey) * sizeof(T);
+    /* left[0..H-1] (+1 for EO_45), upper[-1..W] for the diagonals, upper[0..W-1] for EO_90 */
+    const uint32_t nl = lcuHeight + (kind == 3), ulo = (kind == 2 || kind == 3) ? 1 : 0,
+                   nu = lcuWidth + ((kind == 2 || kind == 3) ? 2 : 0);
+    DBuf s(recon, bytes), d(recon, bytes), l(left ? (const void *)left : (const void *)recon, (left ? nl : 1) * sizeof(T)),
+        u(upper ? (const void *)(upper - ulo) : (const void *)recon, (upper ? nu : 1) * sizeof(T)), o(offset, kind == 4 ? 4 : 5);
+    if (!(s.ok && d.ok && l.ok && u.ok && o.ok))
+        return 1;
+    hipLaunchKernelGGL(k_sao_apply<T>, dim3(16), dim3(256), 0, 0, kind, (const T *)s.d, (T *)d.d, (int)stride, (const T *)l.d,
+                       (const T *)u.d + ulo, (int)band, (const int8_t *)o.d, (int)lcuWidth, (int)lcuHeight);
+    if (!finish("SAOApply"))
+        return 1;
+    /* copy back only the LCU area */
+    T *tmp = (T *)malloc(bytes);
+    if (!tmp || !d.download(tmp, bytes)) {
+        free(tmp);
+        return 1;
+    }
+    for (uint32_t y = 0; y < lcuHeight; y++)
+        ::memcpy(recon + (size_t)y * stride, tmp + (size_t)y * stride, lcuWidth * sizeof(T));
+    free(tmp);
+    return 0;
+}
+#define SAO_LEAF(T, sfx)                                                                                                  \
+    extern "C" int svt_amd_SAOApplyBO##sfx(T *r, uint32_t st, uint32_t band, int8_t *off, uint32_t h, uint32_t w)          \
+    { return sao_apply_leaf<T>(4, r, st, nullptr, nullptr, band, off, h, w); }                                            \
+    extern "C" int svt_amd_SAOApplyEO_0##sfx(T *r, uint32_t st, T *left, int8_t *off, uint32_t h, uint32_t w)              \
+    { return sao_apply_leaf<T>(0, r, st, left, nullptr, 0, off, h, w); }                                                  \
+    extern "C" int svt_amd_SAOApplyEO_90##sfx(T *r, uint32_t st, T *upper, int8_t *off, uint32_t h, uint32_t w)            \
+    { return sao_apply_leaf<T>(1, r, st, nullptr, upper, 0, off, h, w); }                                                 \
+    extern "C" int svt_amd_SAOApplyEO_135##sfx(T *r, uint32_t st, T *left, T *upper, int8_t *off, uint32_t h, uint32_t w)  \
+    { return sao_apply_leaf<T>(2, r, st, left, upper, 0, off, h, w); }                                                    \
+    extern "C" int svt_amd_SAOApplyEO_45##sfx(T *r, uint32_t st, T *left, T *upper, int8_t *off, uint32_t h, uint32_t w)   \
+    { return sao_apply_leaf<T>(3, r, st, left, upper, 0, off, h, w); }
+SAO_LEAF(uint8_t, )
+extern "C" int svt_amd_SAOApplyBO16bit(uint16_t *r, uint32_t st, uint32_t band, int8_t *off, uint32_t h, uint32_t w)
+{ return sao_apply_leaf<uint16_t>(4, r, st, nullptr, nullptr, band, off, h, w); }
+extern "C" int svt_amd_SAOApplyEO_0_16bit(uint16_t *r, uint32_t st, uint16_t *left, int8_t *off, uint32_t h, uint32_t w)
+{ return sao_apply_leaf<uint16_t>(0, r, st, left, nullptr, 0, off, h, w); }
+extern "C" int svt_amd_SAOApplyEO_90_16bit(uint16_t *r, uint32_t st, uint16_t *upper, int8_t *off, uint32_t h, uint32_t w)
+{ return sao_apply_leaf<uint16_t>(1, r, st, nullptr, upper, 0, off, h, w); }
+extern "C" int svt_amd_SAOApplyEO_135_16bit(uint16_t *r, uint32_t st, uint16_t *left, uint16_t *upper, int8_t *off, uint32_t h, uint32_t w)
+{ return sao_apply_leaf<uint16_t>(2, r, st, left, upper, 0, off, h, w); }
+extern "C" int svt_amd_SAOApplyEO_45_16bit(uint16_t *r, uint32_t st, uint16_t *left, uint16_t *upper, int8_t *off, uint32_t h, uint32_t w)
+{ return sao_apply_leaf<uint16_t>(3, r, st, left, upper, 0, off, h, w); }
+
+/* pack / unpack leaves */
+extern "C" void svt_amd_EB_ENC_msbPack2D(uint8_t *in8BitBuffer, uint32_t in8Stride, uint8_t *innBitBuffer,
+                                         uint16_t *out16BitBuffer, uint32_t innStride, uint32_t outStride,
+                                         uint32_t width, uint32_t height)
+{
+    DBuf a(in8BitBuffer, span(in8Stride, width, height)), b(innBitBuffer, span(innStride, width, height)),
+        o(out16BitBuffer, span(outStride, width, height) * 2);
+    if (!(a.ok && b.ok && o.ok))
+        return;
+    hipLaunchKernelGGL(k_pack, grid1d(width * height), dim3(256), 0, 0, a.d, in8Stride, b.d, innStride, (uint16_t *)o.d, outStride, width, height, 0);
+    if (finish("EB_ENC_msbPack2D"))
+        o.download(out16BitBuffer, span(outStride, width, height) * 2);
+}
+extern "C" void svt_amd_CompressedPackmsb(uint8_t *in8BitBuffer, uint32_t in8Stride, uint8_t *innBitBuffer,
+                                          uint16_t *out16BitBuffer, uint32_t innStride, uint32_t outStride,
+                                          uint32_t width, uint32_t height)
+{
+    const uint32_t w4 = width & ~3u; /* the reference packs width/4 groups */
+    DBuf a(in8BitBuffer, span(in8Stride, width, height)), b(innBitBuffer, span(innStride, (width + 3) / 4, height)),
+        o(out16BitBuffer, span(outStride, width, height) * 2);
+    if (!(a.ok && b.ok && o.ok) || !w4)
+        return;
+    hipLaunchKernelGGL(k_pack, grid1d(w4 * height), dim3(256), 0, 0, a.d, in8Stride, b.d, innStride, (uint16_t *)o.d, outStride, w4, height, 1);
+    if (finish("CompressedPackmsb"))
+        o.download(out16BitBuffer, span(outStride, width, height) * 2);
+}
+extern "C" void svt_amd_CPack_C(const uint8_t *innBitBuffer, uint32_t innStride, uint8_t *inCompnBitBuffer,
+                                uint32_t outStride, uint8_t *localCache, uint32_t width, uint32_t height)
+{
+    (void)localCache;
+    DBuf a(innBitBuffer, span(innStride, width, height)), o(inCompnBitBuffer, span(outStride, width / 4, height));
+    if (!(a.ok && o.ok))
+        return;
+    hipLaunchKernelGGL(k_cpack, grid1d(width / 4 * height), dim3(256), 0, 0, a.d, innStride, o.d, outStride, width, height);
+    if (finish("CPack_C"))
+        o.download(inCompnBitBuffer, span(outStride, width / 4, height));
+}
+static void unpack_leaf(uint16_t *in16, uint32_t inStride, uint8_t *out8, uint32_t out8Stride, uint8_t *outn,
+                        uint32_t outnStride, uint32_t w, uint32_t h)
+{
+    DBuf a(in16, span(inStride, w, h) * 2), o8(out8, span(out8Stride, w, h)), on(outn ? outn : out8, outn ? span(outnStride, w, h) : 4);
+    if (!(a.ok && o8.ok && on.ok))
+        return;
+    hipLaunchKernelGGL(k_unpack, grid1d(w * h), dim3(256), 0, 0, (const uint16_t *)a.d, inStride, o8.d, out8Stride, outn ? on.d : nullptr,
+                       outnStride, w, h);
+    if (!finish("unpack"))
+        return;
+    o8.download(out8, span(out8Stride, w, h));
+    if (outn)
+        on.download(outn, span(outnStride, w, h));
+}
+extern "C" void svt_amd_EB_ENC_msbUnPack2D(uint16_t *in16BitBuffer, uint32_t inStride, uint8_t *out8BitBuffer,
+                                           uint8_t *outnBitBuffer, uint32_t out8Stride, uint32_t outnStride,
+                                           uint32_t width, uint32_t height)
+{
+    unpack_leaf(in16BitBuffer, inStride, out8BitBuffer, out8Stride, outnBitBuffer, outnStride, width, height);
+}
+extern "C" void svt_amd_UnPack8BitData(uint16_t *in16BitBuffer, uint32_t inStride, uint8_t *out8BitBuffer,
+                                       uint32_t out8Stride, uint32_t width, uint32_t height)
+{
+    unpack_leaf(in16BitBuffer, inStride, out8BitBuffer, out8Stride, nullptr, 0, width, height);
+}
+extern "C" void svt_amd_UnpackAvg(uint16_t *ref16L0, uint32_t refL0Stride, uint16_t *ref16L1, uint32_t refL1Stride,
+                                  uint8_t *dstPtr, uint32_t dstStride, uint32_t width, uint32_t height)
+{
+    DBuf a(ref16L0, span(refL0Stride, width, height) * 2), b(ref16L1, span(refL1Stride, width, height) * 2),
+        o(dstPtr, span(dstStride, width, height));
+    if (!(a.ok && b.ok && o.ok))
+        return;
+    hipLaunchKernelGGL(k_unpack_avg, grid1d(width * height), dim3(256), 0, 0, (const uint16_t *)a.d, refL0Stride, (const uint16_t *)b.d,
+                       refL1Stride, o.d, dstStride, width, height);
+    if (finish("UnpackAvg"))
+        o.download(dstPtr, span(dstStride, width, height));
+}

@@ -1,0 +1,295 @@
+"""-m gpu: deblocking cores, SAO statistics/apply and 10-bit pack/unpack through the C-ABI (leaf entry points and
+the batched device-pointer forms) vs the oracle (pinned to the reference in tests/test_oracle_loopfilter.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svtlib as S
+from test_oracle_loopfilter import P, img
+
+pytestmark = pytest.mark.gpu
+u32, i32, vp, u8 = C.c_uint32, C.c_int32, C.c_void_p, C.c_uint8
+
+
+class LumaEdge(C.Structure):
+    _fields_ = [("offset", i32), ("tc", C.c_int16), ("beta", C.c_int16), ("vertical", u8), ("pad", u8 * 3)]
+
+
+class ChromaEdge(C.Structure):
+    _fields_ = [("offset", i32), ("cb_tc", u8), ("cr_tc", u8), ("vertical", u8), ("pad", u8)]
+
+
+STATS = np.dtype([("boDiff", "<i4", 32), ("boCount", "<u2", 32), ("eoDiff", "<i4", (4, 5)), ("eoCount", "<u2", (4, 5))])
+
+
+@pytest.fixture(scope="module")
+def libs(product, oracle):
+    oracle.svt_oracle_Luma4SampleEdgeDLFCore.argtypes = [C.c_int, vp, u32, C.c_int, i32, i32]
+    oracle.svt_oracle_Chroma2SampleEdgeDLFCore.argtypes = [C.c_int, vp, vp, u32, C.c_int, u8, u8]
+    oracle.svt_oracle_GatherSaoStatistics.argtypes = [C.c_int, C.c_int, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]
+    oracle.svt_oracle_SAOApplyBO.argtypes = [C.c_int, vp, u32, u32, vp, u32, u32]
+    oracle.svt_oracle_SAOApplyEO.argtypes = [C.c_int, C.c_int, vp, u32, vp, vp, vp, u32, u32]
+    product.svt_amd_dlf_luma_edges_batch.argtypes = [vp, vp, u32, C.c_int, vp, u32]
+    product.svt_amd_dlf_chroma_edges_batch.argtypes = [vp, vp, vp, u32, C.c_int, vp, u32]
+    product.svt_amd_sao_gather_picture.argtypes = [vp, C.c_int, vp, u32, vp, u32, u32, u32, u32, C.c_int, vp]
+    product.svt_amd_pack_plane.argtypes = [vp, vp, u32, vp, u32, C.c_int, vp, u32, u32, u32]
+    product.svt_amd_unpack_plane.argtypes = [vp, vp, u32, vp, u32, vp, u32, u32, u32]
+    return product, oracle
+
+
+def test_struct_sizes():
+    assert C.sizeof(LumaEdge) == 12 and C.sizeof(ChromaEdge) == 8 and STATS.itemsize == 128 + 64 + 80 + 40
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+@pytest.mark.parametrize("vertical", [0, 1])
+def test_luma_dlf_leaf(libs, bps, vertical):
+    product, oracle = libs
+    fn = product.svt_amd_Luma4SampleEdgeDLFCore if bps == 1 else product.svt_amd_Luma4SampleEdgeDLFCore16bit
+    rng = np.random.default_rng(bps * 2 + vertical)
+    hits = 0
+    for trial in range(60):
+        a = img(rng, bps, 16, 16, smooth=trial % 4 != 0)
+        if trial % 3 == 0 and not vertical:
+            a = np.ascontiguousarray(a.T)
+        sh = 2 if bps == 2 else 0
+        tc, beta = int(rng.integers(0, 25)) << sh, int(rng.integers(0, 65)) << sh
+        w, g = a.copy(), a.copy()
+        off = (8 * 16 + 8) * bps if vertical else (8 * 16 + 6) * bps
+        fn(vp(P(w, off)), u32(16), u8(vertical), i32(tc), i32(beta))
+        oracle.svt_oracle_Luma4SampleEdgeDLFCore(bps, P(g, off), 16, vertical, tc, beta)
+        assert np.array_equal(w, g), trial
+        hits += int(not np.array_equal(w, a))
+    assert hits > 6
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+@pytest.mark.parametrize("vertical", [0, 1])
+def test_chroma_dlf_leaf(libs, bps, vertical):
+    product, oracle = libs
+    fn = product.svt_amd_Chroma2SampleEdgeDLFCore if bps == 1 else product.svt_amd_Chroma2SampleEdgeDLFCore16bit
+    rng = np.random.default_rng(bps + vertical)
+    for trial in range(40):
+        cb, cr = img(rng, bps, 8, 8, trial % 2 == 0), img(rng, bps, 8, 8, trial % 2 == 0)
+        tcb, tcr = int(rng.integers(0, 25)), int(rng.integers(0, 25))
+        wb, wr, gb, gr = cb.copy(), cr.copy(), cb.copy(), cr.copy()
+        off = (4 * 8 + 4) * bps
+        fn(vp(P(wb, off)), vp(P(wr, off)), u32(8), u8(vertical), u8(tcb), u8(tcr))
+        oracle.svt_oracle_Chroma2SampleEdgeDLFCore(bps, P(gb, off), P(gr, off), 8, vertical, tcb, tcr)
+        assert np.array_equal(wb, gb) and np.array_equal(wr, gr)
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+def test_dlf_picture_batched(libs, gpu_ctx, bps):
+    """All vertical 8x8-grid edges of a 1080p-sized plane in one launch, then all horizontal ones - the order the
+    reference's LCU drivers apply them in (EbDeblockingFilter.c:2222)."""
+    import torch
+    product, oracle = libs
+    rng = np.random.default_rng(bps)
+    w, h = 1920, 1080
+    hi = 256 if bps == 1 else 1024
+    base = (np.add.outer(np.arange(h) // 8 * 5, np.arange(w) // 8 * 3) % 64 + hi // 2 + rng.integers(-2, 3, (h, w)))
+    plane = base.clip(0, hi - 1).astype(np.uint8 if bps == 1 else np.uint16)
+    want = plane.copy()
+    dev = torch.from_numpy(plane.view(np.uint8).copy()).cuda()
+    sh = 2 if bps == 2 else 0
+    for vertical in (1, 0):
+        edges = []
+        if vertical:
+            for y in range(0, h - 3, 4):
+                for x in range(8, w, 8):
+                    edges.append((y * w + x, int(rng.integers(0, 20)) << sh, int(rng.integers(8, 65)) << sh, 1))
+        else:
+            for y in range(8, h, 8):
+                for x in range(0, w, 4):
+                    edges.append((y * w + x, int(rng.integers(0, 20)) << sh, int(rng.integers(8, 65)) << sh, 0))
+        arr = np.zeros(len(edges), dtype=np.dtype([("offset", "<i4"), ("tc", "<i2"), ("beta", "<i2"), ("v", "u1"), ("pad", "u1", 3)]))
+        e = np.array(edges, dtype=np.int64)
+        arr["offset"], arr["tc"], arr["beta"], arr["v"] = e[:, 0], e[:, 1], e[:, 2], e[:, 3]
+        d_edges = torch.from_numpy(arr.view(np.uint8).copy()).cuda()
+        rc = product.svt_amd_dlf_luma_edges_batch(gpu_ctx, dev.data_ptr(), w, bps, d_edges.data_ptr(), len(edges))
+        assert rc == 0, product.svt_amd_last_error()
+        product.svt_amd_synchronize(gpu_ctx)
+        for off, tc, beta, v in edges:
+            oracle.svt_oracle_Luma4SampleEdgeDLFCore(bps, P(want, off * bps), w, v, tc, beta)
+    got = dev.cpu().numpy().view(plane.dtype).reshape(h, w)
+    assert not np.array_equal(want, plane)
+    assert np.array_equal(got, want)
+
+
+def test_dlf_chroma_batched(libs, gpu_ctx):
+    import torch
+    product, oracle = libs
+    rng = np.random.default_rng(5)
+    w, h = 960, 540
+    cb = (128 + rng.integers(-6, 7, (h, w)) + 9 * ((np.arange(w) // 8) % 2)[None, :]).astype(np.uint8)
+    cr = (100 + rng.integers(-6, 7, (h, w)) + 9 * ((np.arange(h) // 8) % 2)[:, None]).astype(np.uint8)
+    wb, wr = cb.copy(), cr.copy()
+    db, dr = torch.from_numpy(cb.copy()).cuda(), torch.from_numpy(cr.copy()).cuda()
+    for vertical in (1, 0):
+        if vertical:
+            edges = [(y * w + x, int(rng.integers(0, 20)), int(rng.integers(0, 20)), 1) for y in range(0, h - 1, 2) for x in range(8, w, 8)]
+        else:
+            edges = [(y * w + x, int(rng.integers(0, 20)), int(rng.integers(0, 20)), 0) for y in range(8, h, 8) for x in range(0, w, 2)]
+        arr = np.zeros(len(edges), dtype=np.dtype([("offset", "<i4"), ("cb", "u1"), ("cr", "u1"), ("v", "u1"), ("pad", "u1")]))
+        e = np.array(edges, dtype=np.int64)
+        arr["offset"], arr["cb"], arr["cr"], arr["v"] = e[:, 0], e[:, 1], e[:, 2], e[:, 3]
+        d_edges = torch.from_numpy(arr.view(np.uint8).copy()).cuda()
+        rc = product.svt_amd_dlf_chroma_edges_batch(gpu_ctx, db.data_ptr(), dr.data_ptr(), w, 1, d_edges.data_ptr(), len(edges))
+        assert rc == 0, product.svt_amd_last_error()
+        product.svt_amd_synchronize(gpu_ctx)
+        for off, tcb, tcr, v in edges:
+            oracle.svt_oracle_Chroma2SampleEdgeDLFCore(1, P(wb, off), P(wr, off), w, v, tcb, tcr)
+    assert np.array_equal(db.cpu().numpy(), wb) and np.array_equal(dr.cpu().numpy(), wr)
+    assert not np.array_equal(wb, cb)
+
+
+def oracle_gather(oracle, bps, only, src, rec, stride, w, h, sp=0, rp=0):
+    bd, bc = np.zeros(32, np.int32), np.zeros(32, np.uint16)
+    ed, ec = np.zeros((4, 5), np.int32), np.zeros((4, 5), np.uint16)
+    oracle.svt_oracle_GatherSaoStatistics(bps, only, P(src, sp), stride, P(rec, rp), stride, w, h, P(bd), P(bc), P(ed), P(ec))
+    return bd, bc, ed, ec
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+@pytest.mark.parametrize("w,h", [(64, 64), (40, 56), (16, 8)])
+def test_sao_gather_leaf(libs, bps, w, h):
+    product, oracle = libs
+    rng = np.random.default_rng(bps + w)
+    src = img(rng, bps, h, 80)
+    rec = (src.astype(np.int32) + rng.integers(-9, 10, size=src.shape)).clip(0, 255 if bps == 1 else 1023).astype(src.dtype)
+    full = product.svt_amd_GatherSaoStatisticsLcuLossy_62x62 if bps == 1 else product.svt_amd_GatherSaoStatisticsLcu_62x62_16bit
+    eo = product.svt_amd_GatherSaoStatisticsLcu_OnlyEo_90_45_135_Lossy if bps == 1 else \
+        product.svt_amd_GatherSaoStatisticsLcu_62x62_OnlyEo_90_45_135_16bit
+    for only in (0, 1):
+        bd, bc = np.zeros(32, np.int32), np.zeros(32, np.uint16)
+        ed, ec = np.full((4, 5), 7, np.int32), np.full((4, 5), 7, np.uint16)
+        if only:
+            rc = eo(vp(P(src)), u32(80), vp(P(rec)), u32(80), u32(w), u32(h), vp(P(ed)), vp(P(ec)))
+        else:
+            rc = full(vp(P(src)), u32(80), vp(P(rec)), u32(80), u32(w), u32(h), vp(P(bd)), vp(P(bc)), vp(P(ed)), vp(P(ec)))
+        assert rc == 0
+        for a, b in zip((bd, bc, ed, ec), oracle_gather(oracle, bps, only, src, rec, 80, w, h)):
+            assert np.array_equal(a, b), only
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+def test_sao_gather_picture(libs, gpu_ctx, bps):
+    import torch
+    product, oracle = libs
+    rng = np.random.default_rng(bps)
+    w, h, st = 416, 240, 448  # 7 x 4 LCUs, partial right column (32) and bottom row (48)
+    src = img(rng, bps, h, st)
+    rec = (src.astype(np.int32) + rng.integers(-12, 13, size=src.shape)).clip(0, 255 if bps == 1 else 1023).astype(src.dtype)
+    ds, dr = torch.from_numpy(src.view(np.uint8).copy()).cuda(), torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    lw, lh = (w + 63) // 64, (h + 63) // 64
+    for only in (0, 1):
+        out = torch.zeros(lw * lh * STATS.itemsize, dtype=torch.uint8, device="cuda")
+        rc = product.svt_amd_sao_gather_picture(gpu_ctx, bps, ds.data_ptr(), st, dr.data_ptr(), st, w, h, 64, only, out.data_ptr())
+        assert rc == 0, product.svt_amd_last_error()
+        product.svt_amd_synchronize(gpu_ctx)
+        got = out.cpu().numpy().view(STATS)
+        for l in range(lw * lh):
+            x0, y0 = (l % lw) * 64, (l // lw) * 64
+            o = (y0 * st + x0) * bps
+            bd, bc, ed, ec = oracle_gather(oracle, bps, only, src, rec, st, min(64, w - x0), min(64, h - y0), o, o)
+            if not only:
+                assert np.array_equal(got[l]["boDiff"], bd) and np.array_equal(got[l]["boCount"], bc), l
+            k0 = 1 if only else 0
+            assert np.array_equal(got[l]["eoDiff"][k0:], ed[k0:]) and np.array_equal(got[l]["eoCount"][k0:], ec[k0:]), l
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+def test_sao_apply_leaf(libs, bps):
+    product, oracle = libs
+    rng = np.random.default_rng(bps)
+    for w, h in ((64, 64), (24, 40), (8, 8)):
+        rec = img(rng, bps, h + 2, 80)
+        off = np.array([-7, -3, 0, 4, 6], np.int8)
+        for band in (0, 5, 28):
+            a, b = rec.copy(), rec.copy()
+            rc = getattr(product, "svt_amd_SAOApplyBO" + ("" if bps == 1 else "16bit"))(
+                vp(P(a)), u32(80), u32(band), vp(P(off)), u32(h), u32(w))
+            assert rc == 0
+            oracle.svt_oracle_SAOApplyBO(bps, P(b), 80, band, P(off), h, w)
+            assert np.array_equal(a, b)
+        left = img(rng, bps, 1, h + 2)[0]
+        upper = img(rng, bps, 1, w + 3)[0]
+        for t, name in {0: "SAOApplyEO_0", 1: "SAOApplyEO_90", 2: "SAOApplyEO_135", 3: "SAOApplyEO_45"}.items():
+            a, b = rec.copy(), rec.copy()
+            fn = getattr(product, "svt_amd_" + name + ("_16bit" if bps == 2 else ""))
+            up = P(upper, bps)
+            if t == 0:
+                rc = fn(vp(P(a)), u32(80), vp(P(left)), vp(P(off)), u32(h), u32(w))
+            elif t == 1:
+                rc = fn(vp(P(a)), u32(80), vp(up), vp(P(off)), u32(h), u32(w))
+            else:
+                rc = fn(vp(P(a)), u32(80), vp(P(left)), vp(up), vp(P(off)), u32(h), u32(w))
+            assert rc == 0
+            oracle.svt_oracle_SAOApplyEO(bps, t, P(b), 80, P(left), up, P(off), h, w)
+            assert np.array_equal(a, b), name
+            assert not np.array_equal(a, rec)
+
+
+def test_pack_unpack_leaf(libs):
+    product, oracle = libs
+    rng = np.random.default_rng(0)
+    w, h = 64, 24
+    in8, inn = rng.integers(0, 256, (h, 80), np.uint8), rng.integers(0, 256, (h, 72), np.uint8)
+    o0, o1 = np.zeros((h, 96), np.uint16), np.zeros((h, 96), np.uint16)
+    product.svt_amd_EB_ENC_msbPack2D(vp(P(in8)), u32(80), vp(P(inn)), vp(P(o0)), u32(72), u32(96), u32(w), u32(h))
+    oracle.svt_oracle_msbPack2D(vp(P(in8)), u32(80), vp(P(inn)), vp(P(o1)), u32(72), u32(96), u32(w), u32(h))
+    assert np.array_equal(o0, o1) and o0.any()
+    o0[:], o1[:] = 0, 0
+    product.svt_amd_CompressedPackmsb(vp(P(in8)), u32(80), vp(P(inn)), vp(P(o0)), u32(72), u32(96), u32(w), u32(h))
+    oracle.svt_oracle_CompressedPackmsb(vp(P(in8)), u32(80), vp(P(inn)), vp(P(o1)), u32(72), u32(96), u32(w), u32(h))
+    assert np.array_equal(o0, o1) and o0.any()
+    c0, c1 = np.zeros((h, 32), np.uint8), np.zeros((h, 32), np.uint8)
+    product.svt_amd_CPack_C(vp(P(inn)), u32(72), vp(P(c0)), u32(32), None, u32(w), u32(h))
+    oracle.svt_oracle_CPack(vp(P(inn)), u32(72), vp(P(c1)), u32(32), u32(w), u32(h))
+    assert np.array_equal(c0, c1) and c0.any()
+    in16 = rng.integers(0, 1024, (h, 80)).astype(np.uint16)
+    a8, an, b8, bn = (np.zeros((h, 72), np.uint8) for _ in range(4))
+    product.svt_amd_EB_ENC_msbUnPack2D(vp(P(in16)), u32(80), vp(P(a8)), vp(P(an)), u32(72), u32(72), u32(w), u32(h))
+    oracle.svt_oracle_msbUnPack2D(vp(P(in16)), u32(80), vp(P(b8)), vp(P(bn)), u32(72), u32(72), u32(w), u32(h))
+    assert np.array_equal(a8, b8) and np.array_equal(an, bn) and a8.any()
+    a8[:], b8[:] = 0, 0
+    product.svt_amd_UnPack8BitData(vp(P(in16)), u32(80), vp(P(a8)), u32(72), u32(w), u32(h))
+    oracle.svt_oracle_msbUnPack2D(vp(P(in16)), u32(80), vp(P(b8)), None, u32(72), u32(0), u32(w), u32(h))
+    assert np.array_equal(a8, b8) and a8.any()
+    in16b = rng.integers(0, 1024, (h, 96)).astype(np.uint16)
+    product.svt_amd_UnpackAvg(vp(P(in16)), u32(80), vp(P(in16b)), u32(96), vp(P(a8)), u32(72), u32(w), u32(h))
+    oracle.svt_oracle_UnpackAvg(vp(P(in16)), u32(80), vp(P(in16b)), u32(96), vp(P(b8)), u32(72), u32(w), u32(h))
+    assert np.array_equal(a8, b8)
+
+
+@pytest.mark.parametrize("compressed", [0, 1])
+def test_pack_unpack_plane_roundtrip(libs, gpu_ctx, compressed):
+    """Full-size property: unpack(pack(8 bit, 2 bit)) returns the inputs; pack agrees with the oracle on a 1080p plane."""
+    import torch
+    product, oracle = libs
+    rng = np.random.default_rng(compressed)
+    w, h = 1920, 1080
+    in8 = rng.integers(0, 256, (h, w), np.uint8)
+    two = rng.integers(0, 4, (h, w), np.uint8)
+    if compressed:
+        inn = ((two[:, 0::4] << 6) | (two[:, 1::4] << 4) | (two[:, 2::4] << 2) | two[:, 3::4]).astype(np.uint8)
+    else:
+        inn = (two << 6).astype(np.uint8)
+    d8, dn = torch.from_numpy(in8).cuda(), torch.from_numpy(np.ascontiguousarray(inn)).cuda()
+    d16 = torch.zeros((h, w), dtype=torch.int16, device="cuda")
+    rc = product.svt_amd_pack_plane(gpu_ctx, d8.data_ptr(), w, dn.data_ptr(), inn.shape[1], compressed, d16.data_ptr(), w, w, h)
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    got = d16.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, (in8.astype(np.uint16) << 2) | two)
+    want = np.zeros((h, w), np.uint16)
+    fn = oracle.svt_oracle_CompressedPackmsb if compressed else oracle.svt_oracle_msbPack2D
+    fn(vp(P(in8)), u32(w), vp(P(inn)), vp(P(want)), u32(inn.shape[1]), u32(w), u32(w), u32(h))
+    assert np.array_equal(got, want)
+    o8, on = torch.zeros((h, w), dtype=torch.uint8, device="cuda"), torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    rc = product.svt_amd_unpack_plane(gpu_ctx, d16.data_ptr(), w, o8.data_ptr(), w, on.data_ptr(), w, w, h)
+    assert rc == 0
+    product.svt_amd_synchronize(gpu_ctx)
+    assert np.array_equal(o8.cpu().numpy(), in8) and np.array_equal(on.cpu().numpy(), two << 6)
