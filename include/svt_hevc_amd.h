@@ -197,6 +197,46 @@ SVT_AMD_API int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmd
                                                 uint32_t lcu_begin, uint32_t lcu_end);
 SVT_AMD_API int svt_amd_synchronize(SvtAmdContext *ctx);
 
+/*
+ * Open-loop intra search (OIS) of one whole picture: replaces the second LCU loop of
+ * MotionEstimationKernel (EbMotionEstimationProcess.c:786-797) and OpenLoopIntraSearchLcu
+ * (EbMotionEstimation.c:5053-5320): per 32x32 / 16x16 / 8x8 CU of every LCU, predict from SOURCE
+ * neighbours (UpdateNeighborSamplesArrayOpenLoop, EbIntraPrediction.c:5222; out-of-picture = 128, no
+ * smoothing) for the mode subset the slice type / OIS point selects, NxM SAD, candidate injection.
+ */
+typedef struct SvtAmdOisParams {
+    uint16_t luma_width, luma_height;          /* SequenceControlSet_t.lumaWidth/Height                   */
+    uint8_t  slice_is_intra;                   /* pcs->sliceType == EB_I_PICTURE                          */
+    uint8_t  temporal_layer_index;             /* pcs->temporalLayerIndex                                 */
+    uint8_t  limit_ois_to_dc_mode;             /* pcs->limitOisToDcModeFlag (EbPictureDecisionProcess.c:417) */
+    uint8_t  skip_ois_8x8;                     /* pcs->skipOis8x8 (:455)                                  */
+    uint8_t  cu8x8_mode;                       /* pcs->cu8x8Mode                                          */
+    uint8_t  ois_kernel_level;                 /* MotionEstimationContext_t.oisKernelLevel (EbMotionEstimationProcess.c:356) */
+    uint8_t  ois_th_set;                       /* .oisThSet (:371-393)                                    */
+    uint8_t  set_best_ois_distortion_to_valid; /* .setBestOisDistortionToValid (:396)                     */
+} SvtAmdOisParams;
+
+#define SVT_AMD_OIS_MAX_CAND 18                /* MAX_OIS_2, EbCodingUnit.h:61 */
+/* candidate word = OisCandidate_t.oisResults (EbCodingUnit.h:91-101): bits 0-19 distortion, 20 validDistortion,
+ * 24-31 intraMode.  The reference only touches some bitfields of some entries per call (the rest keeps whatever
+ * the PCS pool held); the three bits the reference leaves unnamed say which: */
+#define SVT_AMD_OIS_W_DIST  (1u << 21)         /* this call wrote .distortion      */
+#define SVT_AMD_OIS_W_VALID (1u << 22)         /* this call wrote .validDistortion */
+#define SVT_AMD_OIS_W_MODE  (1u << 23)         /* this call wrote .intraMode       */
+typedef struct SvtAmdOisLcuResult {
+    uint32_t candidate[SVT_AMD_ME_PU_COUNT][SVT_AMD_OIS_MAX_CAND]; /* by rasterScanCuIndex; [0] (64x64) unused  */
+    uint8_t  total_intra_luma_mode[SVT_AMD_ME_PU_COUNT];           /* 0xFF = left untouched by this call        */
+    uint8_t  pad[3];
+} SvtAmdOisLcuResult;
+/* me: HOST array of the picture's ME results (distortion[0] of PUs 1..84 is read) or NULL - then the results of the
+ * last ME launch for cur_slot, still resident on the device, are used (NULL is also right for I pictures and
+ * limit_ois_to_dc_mode).  out: HOST array, one record per LCU, raster order.  Blocking. */
+SVT_AMD_API int svt_amd_ois_picture(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot,
+                                    const SvtAmdMeLcuResult *me, SvtAmdOisLcuResult *out);
+SVT_AMD_API int svt_amd_ois_picture_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot);
+SVT_AMD_API int svt_amd_ois_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out);
+
+
 /* Device-side timing of the launches issued between begin/end on the context's
  * own stream (HIP events); used for roofline.achieved in bench.py. */
 SVT_AMD_API int svt_amd_timer_begin(SvtAmdContext *ctx);

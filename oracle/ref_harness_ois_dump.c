@@ -1,0 +1,121 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/): link-time interposer around the REFERENCE's
+ * OpenLoopIntraSearchLcu (Codec/EbMotionEstimation.c:5053), compiled only into
+ * oracle/_ref/libsvtref.so with -Wl,--wrap=OpenLoopIntraSearchLcu.
+ *
+ * With SVT_REF_OIS_DUMP=<file>, every call leaves one binary record: the controls the call
+ * read (as an SvtAmdOisParams), the ME distortions it consulted, and the OIS result arrays of
+ * the LCU BEFORE and AFTER the call (the function only touches some bitfields; the rest is
+ * whatever the PCS pool held).  tests/golden/make_ois_golden.py turns the dump into fixtures.
+ * No reference source here; reference headers are included only to read its structs.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbMotionEstimationProcess.h"
+#include "EbMotionEstimationContext.h"
+
+#include "../include/svt_hevc_amd.h"
+
+EB_ERRORTYPE __real_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex,
+                                           MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr);
+
+#define OIS_DUMP_MAGIC 0x5349444fU /* "ODIS" */
+
+typedef struct OisSnapshot {
+    uint32_t candidate[85][SVT_AMD_OIS_MAX_CAND];
+    uint8_t total[85];
+    uint8_t pad[3];
+} OisSnapshot;
+
+typedef struct OisDumpRecord {
+    uint32_t magic, record_size;
+    uint64_t picture_number;
+    uint32_t lcu_index, slice_type, enc_mode, luma_crc;
+    SvtAmdOisParams params;
+    uint32_t me_sad[85];
+    OisSnapshot before, after;
+} OisDumpRecord;
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static FILE *g_file;
+static int g_state;
+
+static void snapshot(const PictureParentControlSet_t *pcs, EB_U32 lcu, OisSnapshot *s)
+{
+    const OisCu32Cu16Results_t *a = pcs->oisCu32Cu16Results[lcu];
+    const OisCu8Results_t *b = pcs->oisCu8Results[lcu];
+    memset(s, 0, sizeof(*s));
+    for (int cu = 1; cu < 85; cu++) {
+        const OisCandidate_t *c = cu < 21 ? a->sortedOisCandidate[cu] : b->sortedOisCandidate[cu - 21];
+        s->total[cu] = cu < 21 ? a->totalIntraLumaMode[cu] : b->totalIntraLumaMode[cu - 21];
+        for (int k = 0; k < SVT_AMD_OIS_MAX_CAND; k++) /* every CU owns MAX_OIS_2 entries (EbPictureControlSet.c) */
+            s->candidate[cu][k] = c[k].oisResults & 0xFF1FFFFFu;
+    }
+}
+
+EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex,
+                                           MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
+{
+    if (g_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_state == 0) {
+            const char *path = getenv("SVT_REF_OIS_DUMP");
+            g_file = path ? fopen(path, "wb") : NULL;
+            g_state = g_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (g_state < 0)
+        return __real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
+
+    OisDumpRecord *r = (OisDumpRecord *)calloc(1, sizeof(*r));
+    if (!r)
+        return __real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
+    snapshot(pcs, lcuIndex, &r->before);
+    EB_ERRORTYPE err = __real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
+    snapshot(pcs, lcuIndex, &r->after);
+
+    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    r->magic = OIS_DUMP_MAGIC;
+    r->record_size = (uint32_t)sizeof(*r);
+    r->picture_number = pcs->pictureNumber;
+    r->lcu_index = lcuIndex;
+    r->slice_type = pcs->sliceType;
+    r->enc_mode = pcs->encMode;
+    if (lcuIndex == 0) {
+        uint32_t s = 0;
+        for (uint32_t y = 0; y < inputPtr->height; y++) {
+            const uint8_t *row = inputPtr->bufferY + (size_t)(inputPtr->originY + y) * inputPtr->strideY + inputPtr->originX;
+            for (uint32_t x = 0; x < inputPtr->width; x++)
+                s = s * 31u + row[x];
+        }
+        r->luma_crc = s;
+    }
+    SvtAmdOisParams *p = &r->params;
+    p->luma_width = scs->lumaWidth;
+    p->luma_height = scs->lumaHeight;
+    p->slice_is_intra = pcs->sliceType == EB_I_PICTURE;
+    p->temporal_layer_index = pcs->temporalLayerIndex;
+    p->limit_ois_to_dc_mode = pcs->limitOisToDcModeFlag;
+    p->skip_ois_8x8 = pcs->skipOis8x8;
+    p->cu8x8_mode = pcs->cu8x8Mode;
+    p->ois_kernel_level = ctx->oisKernelLevel;
+    p->ois_th_set = ctx->oisThSet;
+    p->set_best_ois_distortion_to_valid = ctx->setBestOisDistortionToValid;
+    if (pcs->sliceType != EB_I_PICTURE)
+        for (int cu = 0; cu < 85; cu++)
+            r->me_sad[cu] = pcs->meResults[lcuIndex][cu].distortionDirection[0].distortion;
+
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_file);
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+    return err;
+}

@@ -159,4 +159,10 @@ int svt_oracle_me_picture(const SvtAmdMeParams *params, const SvtOraclePicture *
 #ifdef __cplusplus
 }
 #endif
+/* ---- open-loop intra search (svt_oracle_ois.c) ---- */
+/* luma points at the picture origin (sample 0,0); reads never leave [0,W)x[0,H). me_sad: distortion[0] of the
+ * LCU's 85 ME records (NULL for I pictures). */
+void svt_oracle_ois_lcu(const SvtAmdOisParams *P, const uint8_t *luma, uint32_t stride, uint32_t lcu_x, uint32_t lcu_y,
+                        const uint32_t *me_sad, SvtAmdOisLcuResult *out);
+
 #endif

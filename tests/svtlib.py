@@ -89,6 +89,61 @@ DUMP_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_numbe
                        ("params", ME_PARAMS_DTYPE), ("result", ME_LCU_DTYPE)], align=True)
 
 
+class OisParams(C.Structure):
+    """SvtAmdOisParams"""
+    _fields_ = [("luma_width", C.c_uint16), ("luma_height", C.c_uint16), ("slice_is_intra", C.c_uint8),
+                ("temporal_layer_index", C.c_uint8), ("limit_ois_to_dc_mode", C.c_uint8), ("skip_ois_8x8", C.c_uint8),
+                ("cu8x8_mode", C.c_uint8), ("ois_kernel_level", C.c_uint8), ("ois_th_set", C.c_uint8),
+                ("set_best_ois_distortion_to_valid", C.c_uint8)]
+
+
+OIS_PARAMS_DTYPE = np.dtype(OisParams)
+OIS_MAX_CAND = 18
+OIS_LCU_DTYPE = np.dtype([("candidate", "<u4", (ME_PU_COUNT, OIS_MAX_CAND)), ("total", "u1", (ME_PU_COUNT,)),
+                          ("pad", "u1", (3,))])
+OIS_DUMP_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("lcu_index", "<u4"),
+                           ("slice_type", "<u4"), ("enc_mode", "<u4"), ("luma_crc", "<u4"),
+                           ("params", OIS_PARAMS_DTYPE), ("me_sad", "<u4", (ME_PU_COUNT,)),
+                           ("before", OIS_LCU_DTYPE), ("after", OIS_LCU_DTYPE)], align=True)
+OIS_W_DIST, OIS_W_VALID, OIS_W_MODE = 1 << 21, 1 << 22, 1 << 23
+
+
+def ois_params_from_record(rec):
+    p = OisParams()
+    C.memmove(C.byref(p), rec.tobytes(), C.sizeof(p))
+    return p
+
+
+def ois_apply(before, out):
+    """What the reference's arrays hold after a call that produced `out` on top of `before` (OIS_LCU_DTYPE arrays):
+    only the bitfields flagged SVT_AMD_OIS_W_* are replaced; total 0xFF = untouched."""
+    c = out["candidate"].astype(np.uint32)
+    m = (np.where(c & OIS_W_DIST, 0xFFFFF, 0) | np.where(c & OIS_W_VALID, 1 << 20, 0) |
+         np.where(c & OIS_W_MODE, 0xFF000000, 0)).astype(np.uint32)
+    after = before.copy()
+    after["candidate"] = (before["candidate"] & ~m) | (c & m)
+    after["total"] = np.where(out["total"] == 0xFF, before["total"], out["total"])
+    return after
+
+
+def oracle_ois_picture(oracle, params, luma, me_results=None):
+    """Oracle OIS of every LCU of a picture. luma: HxW uint8; me_results: ME_LCU_DTYPE array or None."""
+    h, w = luma.shape
+    oracle.svt_oracle_ois_lcu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_void_p]
+    oracle.svt_oracle_ois_lcu.restype = None
+    lw, lh = (w + 63) // 64, (h + 63) // 64
+    out = np.zeros(lw * lh, OIS_LCU_DTYPE)
+    luma = np.ascontiguousarray(luma)
+    for l in range(lw * lh):
+        sad = None
+        if me_results is not None:
+            sad = np.ascontiguousarray(me_results[l]["pu"]["distortion"][:, 0].astype(np.uint32))
+        oracle.svt_oracle_ois_lcu(C.byref(params), luma.ctypes.data, w, (l % lw) * 64, (l // lw) * 64,
+                                  sad.ctypes.data if sad is not None else None, out[l:l + 1].ctypes.data)
+    return out
+
+
 def params_from_record(rec):
     """numpy record with ME_PARAMS_DTYPE -> MeParams ctypes struct"""
     p = MeParams()
