@@ -64,12 +64,16 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
         plane_destroy(&s->hp_j);
         if (s->d_me_out)
             (void)hipFree(s->d_me_out);
+        if (s->d_ois_out)
+            (void)hipFree(s->d_ois_out);
         if (s->d_staging)
             (void)hipFree(s->d_staging);
     }
     free(ctx->slots);
     if (ctx->d_jobs)
         (void)hipFree(ctx->d_jobs);
+    if (ctx->d_me_scratch)
+        (void)hipFree(ctx->d_me_scratch);
     if (ctx->d_dbg)
         (void)hipFree(ctx->d_dbg);
     for (int i = 0; i < ctx->cap_stamps; i++) {
@@ -118,6 +122,10 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
     CHK(hipEventCreate(&ctx->ev_end));
 #undef CHK
     const int nlcu = ((max_luma_width + 63) / 64) * ((max_luma_height + 63) / 64);
+    if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_me_scratch, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess) {
+        svt_amd_set_error("hipMalloc(ME scratch) failed");
+        rc = SVT_AMD_ERR_RESOURCES;
+    }
     if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_jobs, sizeof(MeJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
         svt_amd_set_error("hipMalloc(job descriptors) failed");
         rc = SVT_AMD_ERR_RESOURCES;
@@ -132,6 +140,7 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
         if ((rc = plane_create(&s->hp_h, w, h, SVT_AMD_PAD_FULL)) != 0) break;
         if ((rc = plane_create(&s->hp_j, w, h, SVT_AMD_PAD_FULL)) != 0) break;
         if (hipMalloc((void **)&s->d_me_out, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess ||
+            hipMalloc((void **)&s->d_ois_out, (size_t)nlcu * sizeof(SvtAmdOisLcuResult)) != hipSuccess ||
             hipMalloc((void **)&s->d_staging, (size_t)w * h) != hipSuccess) {
             svt_amd_set_error("hipMalloc (slot %d) failed", i);
             rc = SVT_AMD_ERR_RESOURCES;
@@ -205,7 +214,7 @@ extern "C" int svt_amd_kernel_time(SvtAmdContext *ctx, const char *kernel_class,
 {
     if (!ctx || !kernel_class || !avg_ms || !launches)
         return SVT_AMD_ERR_BAD_PARAM;
-    int cls = !strcmp(kernel_class, "prep") ? KC_PREP : !strcmp(kernel_class, "me_search") ? KC_ME_SEARCH : -1;
+    int cls = !strcmp(kernel_class, "prep") ? KC_PREP : !strcmp(kernel_class, "me_search") ? KC_ME_SEARCH : !strcmp(kernel_class, "ois") ? KC_OIS : -1;
     if (cls < 0)
         return SVT_AMD_ERR_BAD_PARAM;
     double sum = 0;
@@ -474,4 +483,74 @@ extern "C" int svt_amd_me_picture(SvtAmdContext *ctx, const SvtAmdMeParams *para
     if (rc)
         return rc;
     return svt_amd_me_picture_fetch(ctx, cur_slot, out);
+}
+
+/* ---- open-loop intra search ------------------------------------------------ */
+static int validate_ois(SvtAmdContext *ctx, const SvtAmdOisParams *p, int cur_slot)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    const DevPicture *c = &ctx->slots[cur_slot];
+    if (!p || !c->valid || p->luma_width != c->width || p->luma_height != c->height || p->ois_th_set > 2 ||
+        p->temporal_layer_index > 5) {
+        svt_amd_set_error("svt_amd_ois_picture: bad parameter (slot %d)", cur_slot);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    return SVT_AMD_OK;
+}
+
+static int ois_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot, const SvtAmdMeLcuResult *d_me)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    svt_amd_stamp_begin(ctx, KC_OIS);
+    int rc = svt_amd_launch_ois(ctx, params, c, d_me, c->d_ois_out);
+    svt_amd_stamp_end(ctx);
+    return rc;
+}
+
+extern "C" int svt_amd_ois_picture_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot)
+{
+    int rc = validate_ois(ctx, params, cur_slot);
+    if (rc)
+        return rc;
+    return ois_launch(ctx, params, cur_slot, ctx->slots[cur_slot].d_me_out);
+}
+
+extern "C" int svt_amd_ois_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    if (!out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    HIP_TRY(hipMemcpyAsync(out, c->d_ois_out, (size_t)nlcu * sizeof(SvtAmdOisLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_ois_picture(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot,
+                                   const SvtAmdMeLcuResult *me, SvtAmdOisLcuResult *out)
+{
+    int rc = validate_ois(ctx, params, cur_slot);
+    if (rc)
+        return rc;
+    if (!out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    const SvtAmdMeLcuResult *d_me = ctx->slots[cur_slot].d_me_out;
+    if (me) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const int nlcu = ((params->luma_width + 63) / 64) * ((params->luma_height + 63) / 64);
+        HIP_TRY(hipMemcpyAsync(ctx->d_me_scratch, me, (size_t)nlcu * sizeof(SvtAmdMeLcuResult), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); /* `me` may be freed by the caller on return of a later call */
+        d_me = ctx->d_me_scratch;
+    }
+    rc = ois_launch(ctx, params, cur_slot, d_me);
+    if (rc)
+        return rc;
+    return svt_amd_ois_picture_fetch(ctx, cur_slot, out);
 }

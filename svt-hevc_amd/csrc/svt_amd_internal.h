@@ -29,6 +29,7 @@ struct DevPlane {
 struct DevPicture {
     DevPlane full, quarter, sixteenth, hp_b, hp_h, hp_j;
     SvtAmdMeLcuResult *d_me_out;   /* device buffer, one record per LCU */
+    SvtAmdOisLcuResult *d_ois_out; /* device buffer, one record per LCU */
     uint8_t *d_staging;            /* device copy of the raw luma (upload path) */
     size_t   staging_bytes;
     uint16_t width, height;
@@ -41,7 +42,7 @@ struct PicView {
     int32_t pitch_full, pitch_quarter, pitch_sixteenth;
 };
 
-enum { KC_PREP = 0, KC_ME_SEARCH = 1, KC_COUNT = 2 };
+enum { KC_PREP = 0, KC_ME_SEARCH = 1, KC_OIS = 2, KC_COUNT = 3 };
 
 #define SVT_AMD_MAX_BATCH 256
 
@@ -65,6 +66,7 @@ struct SvtAmdContext {
     int timer_armed;
     struct Stamp { hipEvent_t a, b; int cls; } *stamps;
     int num_stamps, cap_stamps;
+    SvtAmdMeLcuResult *d_me_scratch; /* host-supplied ME results for svt_amd_ois_picture */
     MeJobDev *d_jobs;              /* device array of SVT_AMD_MAX_BATCH job descriptors */
     unsigned long long *d_dbg;     /* phase-profile buffer (svt_amd_debug_me_phase_profile) */
     size_t dbg_slots;
@@ -88,6 +90,8 @@ int svt_amd_stamp_end(SvtAmdContext *ctx);
 /* kernel launchers (prep_kernels.hip / me_kernels.hip) */
 int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_luma, uint32_t stride);
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus);
+int svt_amd_launch_ois(SvtAmdContext *ctx, const SvtAmdOisParams *P, const DevPicture *pic,
+                       const SvtAmdMeLcuResult *d_me, SvtAmdOisLcuResult *d_out);
 
 static inline PicView make_view(const DevPicture *p)
 {
