@@ -1,5 +1,6 @@
 /*
- * integration/svt_hook_me.c - the reference-side binding of the batched ME boundary.
+ * integration/svt_hook_me.c - the reference-side binding of the batched front-half boundary
+ * (motion estimation + open-loop intra search).
  *
  * This is the code a maintainer adds to the reference: it is
  * compiled against the reference headers and linked, with the reference's own
@@ -7,8 +8,9 @@
  * SvtHevcEncApp_hip.  Every call the reference's MotionEstimationKernel makes to
  * MotionEstimateLcu (Codec/EbMotionEstimationProcess.c:780) is answered from the
  * result of ONE svt_amd_me_picture() call per picture on the MI355X; the
- * reference's CPU motion search is never executed.  There is no fallback: any
- * error from the HIP library aborts the encoder.
+ * reference's CPU motion search is never executed.  OpenLoopIntraSearchLcu (:793) is
+ * answered the same way from ONE svt_amd_ois_picture() per picture (--wrap=OpenLoopIntraSearchLcu).
+ * There is no fallback: any error from the HIP library aborts the encoder.
  *
  * Contains no reference source.
  */
@@ -23,6 +25,7 @@
 #include "EbMotionEstimation.h"
 #include "EbMotionEstimationContext.h"
 #include "EbReferenceObject.h"
+#include "EbMotionEstimationProcess.h"
 
 #include "../include/svt_hevc_amd.h"
 
@@ -33,9 +36,12 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static SvtAmdContext *g_ctx;
 static uint64_t g_slot_pic[NSLOTS];
 static struct { uint64_t pic; int valid; SvtAmdMeLcuResult *res; } g_results[NRESULTS];
+static struct { uint64_t pic; int valid; SvtAmdOisLcuResult *res; } g_ois[NRESULTS];
+static unsigned long g_ois_pictures, g_ois_lcus;
 static uint32_t g_nlcu;
 static unsigned long g_pictures, g_lcus;
 static void hook_report(void);
+static void ensure_context(const SequenceControlSet_t *scs);
 
 static void die(const char *what)
 {
@@ -43,6 +49,7 @@ static void die(const char *what)
     abort();
 }
 
+/* `padded`: any picture buffer whose luma is the source picture (PA padded copy or the enhanced input) */
 static int ensure_uploaded(uint64_t pic, const EbPictureBufferDesc_t *padded)
 {
     const int slot = (int)(pic % NSLOTS);
@@ -105,15 +112,7 @@ static const SvtAmdMeLcuResult *picture_results(PictureParentControlSet_t *pcs, 
     const int e = (int)(pic % NRESULTS);
     if (g_results[e].valid && g_results[e].pic == pic)
         return g_results[e].res;
-    if (!g_ctx) {
-        const char *dev = getenv("SVT_AMD_DEVICE");
-        const uint16_t mh = (uint16_t)((scs->lumaHeight + 7) & ~7);
-        if (svt_amd_context_create(dev ? atoi(dev) : 0, scs->lumaWidth, mh, NSLOTS, &g_ctx))
-            die("svt_amd_context_create");
-        g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
-        fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
-        atexit(hook_report);
-    }
+    ensure_context(scs);
     if (!g_results[e].res && !(g_results[e].res = (SvtAmdMeLcuResult *)malloc(sizeof(SvtAmdMeLcuResult) * g_nlcu)))
         die("malloc");
     const int nlists = (pcs->sliceType == EB_P_PICTURE) ? 1 : 2;
@@ -167,8 +166,90 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
     return EB_ErrorNone;
 }
 
+static void ensure_context(const SequenceControlSet_t *scs)
+{
+    if (g_ctx)
+        return;
+    const char *dev = getenv("SVT_AMD_DEVICE");
+    const uint16_t mh = (uint16_t)((scs->lumaHeight + 7) & ~7);
+    if (svt_amd_context_create(dev ? atoi(dev) : 0, scs->lumaWidth, mh, NSLOTS, &g_ctx))
+        die("svt_amd_context_create");
+    g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
+    fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
+    atexit(hook_report);
+}
+
+/*
+ * Open-loop intra search: every call of OpenLoopIntraSearchLcu (EbMotionEstimationProcess.c:793) is answered
+ * from ONE svt_amd_ois_picture() per picture.  For P/B pictures the ME results it consults are the ones the
+ * device produced for this picture (still resident: me == NULL).
+ */
+static const SvtAmdOisLcuResult *ois_results(PictureParentControlSet_t *pcs, MotionEstimationContext_t *ctx,
+                                             const EbPictureBufferDesc_t *inputPtr)
+{
+    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    const uint64_t pic = pcs->pictureNumber;
+    const int e = (int)(pic % NRESULTS);
+    if (g_ois[e].valid && g_ois[e].pic == pic)
+        return g_ois[e].res;
+    ensure_context(scs);
+    if (!g_ois[e].res && !(g_ois[e].res = (SvtAmdOisLcuResult *)malloc(sizeof(SvtAmdOisLcuResult) * g_nlcu)))
+        die("malloc");
+    const int slot = ensure_uploaded(pic, inputPtr);
+    SvtAmdOisParams p;
+    memset(&p, 0, sizeof(p));
+    p.luma_width = scs->lumaWidth;
+    p.luma_height = scs->lumaHeight;
+    p.slice_is_intra = pcs->sliceType == EB_I_PICTURE;
+    p.temporal_layer_index = pcs->temporalLayerIndex;
+    p.limit_ois_to_dc_mode = pcs->limitOisToDcModeFlag;
+    p.skip_ois_8x8 = pcs->skipOis8x8;
+    p.cu8x8_mode = pcs->cu8x8Mode;
+    p.ois_kernel_level = ctx->oisKernelLevel;
+    p.ois_th_set = ctx->oisThSet;
+    p.set_best_ois_distortion_to_valid = ctx->setBestOisDistortionToValid;
+    if (svt_amd_ois_picture(g_ctx, &p, slot, NULL, g_ois[e].res))
+        die("svt_amd_ois_picture");
+    g_ois[e].pic = pic;
+    g_ois[e].valid = 1;
+    g_ois_pictures++;
+    return g_ois[e].res;
+}
+
+EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex,
+                                           MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
+{
+    pthread_mutex_lock(&g_lock);
+    const SvtAmdOisLcuResult *r = &ois_results(pcs, ctx, inputPtr)[lcuIndex];
+    g_ois_lcus++;
+    pthread_mutex_unlock(&g_lock);
+    OisCu32Cu16Results_t *a = pcs->oisCu32Cu16Results[lcuIndex];
+    OisCu8Results_t *b = pcs->oisCu8Results[lcuIndex];
+    for (int cu = 1; cu < SVT_AMD_ME_PU_COUNT; cu++) {
+        OisCandidate_t *c = cu < 21 ? a->sortedOisCandidate[cu] : b->sortedOisCandidate[cu - 21];
+        for (int k = 0; k < SVT_AMD_OIS_MAX_CAND; k++) {
+            const uint32_t w = r->candidate[cu][k];
+            if (w & SVT_AMD_OIS_W_DIST)
+                c[k].distortion = w & 0xFFFFFu;
+            if (w & SVT_AMD_OIS_W_VALID)
+                c[k].validDistortion = (w >> 20) & 1u;
+            if (w & SVT_AMD_OIS_W_MODE)
+                c[k].intraMode = w >> 24;
+        }
+        if (r->total_intra_luma_mode[cu] != 0xFF) {
+            if (cu < 21)
+                a->totalIntraLumaMode[cu] = r->total_intra_luma_mode[cu];
+            else
+                b->totalIntraLumaMode[cu - 21] = r->total_intra_luma_mode[cu];
+        }
+    }
+    return EB_ErrorNone;
+}
+
 static void hook_report(void)
 {
+    fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,
+            g_ois_lcus);
     fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs estimated on the GPU, 0 on the CPU\n", g_pictures, g_lcus);
     fflush(stderr);
 }

@@ -1,6 +1,6 @@
 """-m gpu: end-to-end drop-in check.  The reference encoder with its MotionEstimateLcu
-replaced by ONE svt_amd_me_picture() call per picture (integration/svt_hook_me.c, linked
-with --wrap) must emit a .265 that is byte-identical to the unmodified reference's
+replaced by ONE svt_amd_me_picture() call per picture and its OpenLoopIntraSearchLcu by ONE
+svt_amd_ois_picture() call per picture (integration/svt_hook_me.c, linked with --wrap) must emit a .265 that is byte-identical to the unmodified reference's
 (oracle/_ref/SvtHevcEncApp_ref) on the same YUV - the reference's own `asm_test`
 criterion (Tests/SVT-HEVC_FunctionalTests.py:830-853) with a third leg."""
 import hashlib
@@ -21,6 +21,10 @@ CASES = [
     ("noise", 320, 256, 6, ["-encMode", "4"]),
     ("motion", 1920, 1080, 6, ["-encMode", "9", "-pred-struct", "0"]),
     ("flat", 1024, 768, 5, ["-encMode", "7", "-rc", "1", "-tbr", "2000000"]),
+    # all-intra 1080p encMode 10 (BASELINE configs[0]): OIS with 8x8 CUs on every picture, no ME at all
+    ("motion", 1920, 1080, 4, ["-encMode", "10", "-intra-period", "0"]),
+    # encMode 4 flat low-delay P: 35-mode OIS on P pictures, SSD sub-pel ME
+    ("motion", 416, 240, 5, ["-encMode", "4", "-pred-struct", "0", "-hierarchical-levels", "0"]),
 ]
 
 
@@ -41,5 +45,6 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
     hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
     # every MotionEstimateLcu call is redirected at link time (--wrap); the hook announces itself
     assert "svt_hook_me: motion estimation on svt-hevc_amd" in log, "hook inactive:\n" + log[-1000:]
+    assert "pictures / %d LCUs intra-searched (OIS) on the GPU" % (n * S.lcu_count(w, h)) in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     assert os.path.getsize(str(tmp_path / "hip.265")) > 100
