@@ -40,6 +40,7 @@ static struct { uint64_t pic; int valid; SvtAmdOisLcuResult *res; } g_ois[NRESUL
 static unsigned long g_ois_pictures, g_ois_lcus;
 static uint32_t g_nlcu;
 static unsigned long g_pictures, g_lcus;
+static int g_verbose; /* SVT_HOOK_VERBOSE=1: one stderr line per picture handled on the device */
 static void hook_report(void);
 static void ensure_context(const SequenceControlSet_t *scs);
 
@@ -130,6 +131,8 @@ static const SvtAmdMeLcuResult *picture_results(PictureParentControlSet_t *pcs, 
     g_results[e].pic = pic;
     g_results[e].valid = 1;
     g_pictures++;
+    if (g_verbose)
+        fprintf(stderr, "svt_hook_me: ME picture %llu on the GPU (%u LCUs)\n", (unsigned long long)pic, g_nlcu);
     return g_results[e].res;
 }
 
@@ -175,6 +178,7 @@ static void ensure_context(const SequenceControlSet_t *scs)
     if (svt_amd_context_create(dev ? atoi(dev) : 0, scs->lumaWidth, mh, NSLOTS, &g_ctx))
         die("svt_amd_context_create");
     g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
+    g_verbose = getenv("SVT_HOOK_VERBOSE") != NULL;
     fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
     atexit(hook_report);
 }
@@ -213,6 +217,8 @@ static const SvtAmdOisLcuResult *ois_results(PictureParentControlSet_t *pcs, Mot
     g_ois[e].pic = pic;
     g_ois[e].valid = 1;
     g_ois_pictures++;
+    if (g_verbose)
+        fprintf(stderr, "svt_hook_me: OIS picture %llu on the GPU (%u LCUs)\n", (unsigned long long)pic, g_nlcu);
     return g_ois[e].res;
 }
 
