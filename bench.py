@@ -3,11 +3,12 @@
 
 One "step" = one pass of the hot path over one batch of synthetic 1080p pictures
 (BASELINE.json configs[1]: 1920x1080 8-bit, encMode 9, low-delay P): for every picture
-of the batch, picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes) and
+of the batch, picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes),
 open-loop motion estimation of all 510 LCUs against the previous picture (HME L0/L1,
-full-pel 85-PU search, half/quarter-pel refinement, candidate records), with the ME
-controls exactly as the reference encoder derived them for this configuration
-(tests/golden/me_p_1920x1080_m9.npz).  Inputs are resident in HBM before the timed
+full-pel 85-PU search, half/quarter-pel refinement, candidate records) and open-loop
+intra search (OIS points from the ME distortions, stage-1 modes, candidate injection),
+with the controls exactly as the reference encoder derived them for this configuration
+(tests/golden/me_p_1920x1080_m9.npz, ois_ip_1920x1080_m9.npz).  Inputs are resident in HBM before the timed
 region; results stay in HBM (the PCIe-inclusive rate is discussed in DESIGN.md).
 
 Prints ONE JSON line (rank 0).  `value` = pictures/s of the hot path over all GPUs,
@@ -50,21 +51,25 @@ def synth_frames_device(n, seed, device):
     return frames
 
 
-def cpu_baseline_port(params, budget_s=12.0):
-    """Oracle (plain C restatement, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline_port(params, oparams, budget_s=12.0):
+    """Oracle (plain C restatement, 1 thread) on a bounded sample of the same workload: whole pictures
+    (prep + ME + OIS each) until the time budget is used."""
     oracle = S.load_oracle()
-    f0, f1 = S.gen_luma("motion", W, H, 0, 7), S.gen_luma("motion", W, H, 1, 7)
-    p0, p1 = S.OraclePicture(oracle, f0), S.OraclePicture(oracle, f1)
+    frames = [S.gen_luma("motion", W, H, t, 7) for t in range(4)]
     nl = S.lcu_count(W, H)
+    prev = S.OraclePicture(oracle, frames[0])
     done, t0 = 0, time.perf_counter()
-    row = 30
-    while done < nl and time.perf_counter() - t0 < budget_s:
-        S.oracle_me_picture(oracle, params, p1, p0, None, done, min(nl, done + row))
-        done += row
+    while time.perf_counter() - t0 < budget_s:
+        f = frames[(done + 1) % len(frames)]
+        cur = S.OraclePicture(oracle, f)                                  # pad + decimate + half-pel planes
+        me = S.oracle_me_picture(oracle, params, cur, prev, None, 0, nl)  # ME of all LCUs
+        S.oracle_ois_picture(oracle, oparams, f, me)                      # OIS of all LCUs
+        prev = cur
+        done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(done / nl / dt, 4), "unit": "fps", "cores": 1, "kind": "port",
-            "sample": "%d of %d LCUs of one 1080p P picture (ME only, oracle/svt_oracle_me.c, 1 thread, %.1f s)"
-                      % (min(done, nl), nl, dt)}
+    return {"value": round(done / dt, 4), "unit": "fps", "cores": 1, "kind": "port",
+            "sample": "%d whole 1080p P pictures (prep + ME + OIS of 510 LCUs each; oracle/svt_oracle_me.c, "
+                      "svt_oracle_ois.c; 1 thread; %.1f s)" % (done, dt)}
 
 
 def reference_encoder_fps(frames=24):
@@ -122,11 +127,17 @@ def main():
         assert r == 0, lib.svt_amd_last_error()
 
     jobs = (S.MeJob * B)()
+    ojobs = (S.OisJob * B)()
+    og = np.load(os.path.join(S.GOLDEN_DIR, "ois_ip_1920x1080_m9.npz"))
+    oparams = S.ois_params_from_record(og["params"][1])  # the P picture of the reference run
+    assert not oparams.slice_is_intra
     for i in range(B):
         jobs[i].params = params
         jobs[i].cur_slot = i + 1
         jobs[i].ref_slot[0] = i
         jobs[i].ref_slot[1] = i
+        ojobs[i].params = oparams
+        ojobs[i].cur_slot = i + 1
 
     def step():
         # picture i (slot i) is searched against picture i-1; slot 0 holds the last
@@ -135,6 +146,8 @@ def main():
         for i in range(1, B + 1):
             prep(i, i)
         r = lib.svt_amd_me_batch_launch(ctx, jobs, B)
+        assert r == 0, lib.svt_amd_last_error()
+        r = lib.svt_amd_ois_batch_launch(ctx, ojobs, B)  # reads the ME results left on the device
         assert r == 0, lib.svt_amd_last_error()
         prep(0, B)  # becomes the reference of the next step's first picture
 
@@ -168,6 +181,8 @@ def main():
     me_ms, me_n, prep_ms, prep_n = C.c_float(), C.c_int(), C.c_float(), C.c_int()
     lib.svt_amd_kernel_time(ctx, b"me_search", C.byref(me_ms), C.byref(me_n))
     lib.svt_amd_kernel_time(ctx, b"prep", C.byref(prep_ms), C.byref(prep_n))
+    ois_ms, ois_n = C.c_float(), C.c_int()
+    lib.svt_amd_kernel_time(ctx, b"ois", C.byref(ois_ms), C.byref(ois_n))
 
     if rank == 0:
         pictures = world * B * a.steps
@@ -178,13 +193,13 @@ def main():
         algo_bytes = B * (2 * 1.3125 * W * H + nlcu * C.sizeof(S.MeLcuResult))  # one launch = B pictures
         achieved = algo_bytes / (me_ms.value * 1e-3) / 1e9 if me_ms.value > 0 else 0.0
         res = {
-            "metric": "encoded fps (hot path: picture prep + motion estimation)", "value": round(fps, 2),
+            "metric": "encoded fps (hot path: picture prep + motion estimation + open-loop intra search)", "value": round(fps, 2),
             "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1080p 8-bit encMode 9 low-delay P (BASELINE configs[1]): per picture pad+decimate+"
-                                   "half-pel planes and open-loop ME (HME L0/L1, full-pel 85 PU, sub-pel) of 510 LCUs "
-                                   "vs previous picture; EncDec (MD/DCT/DLF/SAO) not on device yet",
+                                   "half-pel planes, open-loop ME (HME L0/L1, full-pel 85 PU, sub-pel) of 510 LCUs "
+                                   "vs previous picture and open-loop intra search; EncDec mode decision not on device yet",
                        "width": W, "height": H, "pictures_per_step_per_gpu": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
                        "parallelism": "pictures sharded over ranks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_me_picture", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -192,10 +207,11 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms.value, 4),
                          "launches_timed": me_n.value, "pictures_per_launch": B,
                          "prep_avg_ms": round(prep_ms.value, 4), "prep_launches": prep_n.value,
+                         "ois_avg_launch_ms": round(ois_ms.value, 4), "ois_launches": ois_n.value,
                          "event_ms_total": round(ev_ms.value, 3)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_port(params)
+            res["cpu_baseline"] = cpu_baseline_port(params, oparams)
             ref = reference_encoder_fps()
             if ref:
                 res["reference_encoder"] = ref

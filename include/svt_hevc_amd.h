@@ -235,6 +235,12 @@ SVT_AMD_API int svt_amd_ois_picture(SvtAmdContext *ctx, const SvtAmdOisParams *p
                                     const SvtAmdMeLcuResult *me, SvtAmdOisLcuResult *out);
 SVT_AMD_API int svt_amd_ois_picture_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot);
 SVT_AMD_API int svt_amd_ois_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out);
+/* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
+typedef struct SvtAmdOisJob {
+    SvtAmdOisParams params;
+    int32_t cur_slot;
+} SvtAmdOisJob;
+SVT_AMD_API int svt_amd_ois_batch_launch(SvtAmdContext *ctx, const SvtAmdOisJob *jobs, int num_jobs);
 
 
 /* Device-side timing of the launches issued between begin/end on the context's

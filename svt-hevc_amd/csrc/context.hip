@@ -74,6 +74,8 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
         (void)hipFree(ctx->d_jobs);
     if (ctx->d_me_scratch)
         (void)hipFree(ctx->d_me_scratch);
+    if (ctx->d_ois_jobs)
+        (void)hipFree(ctx->d_ois_jobs);
     if (ctx->d_dbg)
         (void)hipFree(ctx->d_dbg);
     for (int i = 0; i < ctx->cap_stamps; i++) {
@@ -124,6 +126,10 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
     const int nlcu = ((max_luma_width + 63) / 64) * ((max_luma_height + 63) / 64);
     if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_me_scratch, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess) {
         svt_amd_set_error("hipMalloc(ME scratch) failed");
+        rc = SVT_AMD_ERR_RESOURCES;
+    }
+    if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_ois_jobs, sizeof(OisJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
+        svt_amd_set_error("hipMalloc(OIS job descriptors) failed");
         rc = SVT_AMD_ERR_RESOURCES;
     }
     if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_jobs, sizeof(MeJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
@@ -500,12 +506,46 @@ static int validate_ois(SvtAmdContext *ctx, const SvtAmdOisParams *p, int cur_sl
     return SVT_AMD_OK;
 }
 
+static void make_ois_job(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot, const SvtAmdMeLcuResult *d_me,
+                         OisJobDev *j)
+{
+    DevPicture *c = &ctx->slots[cur_slot];
+    j->P = *params;
+    j->full = c->full.origin;
+    j->pitch = c->full.pitch;
+    j->lcus_w = (params->luma_width + 63) / 64;
+    j->nlcu = j->lcus_w * ((params->luma_height + 63) / 64);
+    j->me = d_me;
+    j->out = c->d_ois_out;
+}
+
 static int ois_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot, const SvtAmdMeLcuResult *d_me)
 {
     HIP_TRY(hipSetDevice(ctx->device));
-    DevPicture *c = &ctx->slots[cur_slot];
+    OisJobDev j;
+    make_ois_job(ctx, params, cur_slot, d_me, &j);
     svt_amd_stamp_begin(ctx, KC_OIS);
-    int rc = svt_amd_launch_ois(ctx, params, c, d_me, c->d_ois_out);
+    int rc = svt_amd_launch_ois_batch(ctx, &j, 1, j.nlcu);
+    svt_amd_stamp_end(ctx);
+    return rc;
+}
+
+extern "C" int svt_amd_ois_batch_launch(SvtAmdContext *ctx, const SvtAmdOisJob *jobs, int num_jobs)
+{
+    if (!ctx || !jobs || num_jobs < 1 || num_jobs > SVT_AMD_MAX_BATCH)
+        return SVT_AMD_ERR_BAD_PARAM;
+    static thread_local OisJobDev host[SVT_AMD_MAX_BATCH];
+    int max_lcus = 0;
+    for (int i = 0; i < num_jobs; i++) {
+        int rc = validate_ois(ctx, &jobs[i].params, jobs[i].cur_slot);
+        if (rc)
+            return rc;
+        make_ois_job(ctx, &jobs[i].params, jobs[i].cur_slot, ctx->slots[jobs[i].cur_slot].d_me_out, &host[i]);
+        max_lcus = host[i].nlcu > max_lcus ? host[i].nlcu : max_lcus;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    svt_amd_stamp_begin(ctx, KC_OIS);
+    int rc = svt_amd_launch_ois_batch(ctx, host, num_jobs, max_lcus);
     svt_amd_stamp_end(ctx);
     return rc;
 }

@@ -258,13 +258,19 @@ __device__ bool decide_cu(OisShared &S, const SvtAmdOisParams &P, int cu, bool v
     return updated;
 }
 
-__global__ __launch_bounds__(256) void k_ois_picture(SvtAmdOisParams P, const uint8_t *__restrict__ full, int pitch,
-                                                     const SvtAmdMeLcuResult *__restrict__ me,
-                                                     SvtAmdOisLcuResult *__restrict__ out, int lcus_w)
+__global__ __launch_bounds__(256) void k_ois_picture(const OisJobDev *__restrict__ jobs)
 {
     __shared__ OisShared S;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const OisJobDev &J = jobs[blockIdx.y];
     const int lcu = blockIdx.x;
+    if (lcu >= J.nlcu)
+        return;
+    const SvtAmdOisParams P = J.P;
+    const uint8_t *__restrict__ full = J.full;
+    const int pitch = J.pitch, lcus_w = J.lcus_w;
+    const SvtAmdMeLcuResult *__restrict__ me = J.me;
+    SvtAmdOisLcuResult *__restrict__ out = J.out;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lx = (lcu % lcus_w) * 64, ly = (lcu / lcus_w) * 64;
     const int W = P.luma_width, H = P.luma_height;
     const int last = P.slice_is_intra ? 84 : ((P.skip_ois_8x8 || P.cu8x8_mode == 1) ? 20 : 84);
@@ -438,12 +444,10 @@ __global__ __launch_bounds__(256) void k_ois_picture(SvtAmdOisParams P, const ui
         ot[t] = t < 85 ? S.out_total[t] : 0;
 }
 
-int svt_amd_launch_ois(SvtAmdContext *ctx, const SvtAmdOisParams *P, const DevPicture *pic,
-                       const SvtAmdMeLcuResult *d_me, SvtAmdOisLcuResult *d_out)
+int svt_amd_launch_ois_batch(SvtAmdContext *ctx, const OisJobDev *host_jobs, int njobs, int max_lcus)
 {
-    const int lw = (P->luma_width + 63) / 64, lh = (P->luma_height + 63) / 64;
-    hipLaunchKernelGGL(k_ois_picture, dim3(lw * lh), dim3(256), 0, ctx->stream, *P, (const uint8_t *)pic->full.origin,
-                       (int)pic->full.pitch, d_me, d_out, lw);
+    HIP_TRY(hipMemcpyAsync(ctx->d_ois_jobs, host_jobs, sizeof(OisJobDev) * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_ois_picture, dim3(max_lcus, njobs), dim3(256), 0, ctx->stream, (const OisJobDev *)ctx->d_ois_jobs);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }

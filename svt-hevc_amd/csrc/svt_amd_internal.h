@@ -55,6 +55,15 @@ struct MeJobDev {
     unsigned long long *dbg_clock; /* optional: 16 clock stamps per workgroup (phase profile) */
 };
 
+/* one open-loop intra search job = one picture */
+struct OisJobDev {
+    SvtAmdOisParams P;
+    const uint8_t *full;           /* padded source luma, sample (0,0) */
+    int32_t pitch, lcus_w, nlcu;
+    const SvtAmdMeLcuResult *me;   /* ME results of the picture (P/B) */
+    SvtAmdOisLcuResult *out;
+};
+
 struct SvtAmdContext {
     int device;
     hipStream_t stream;
@@ -67,6 +76,7 @@ struct SvtAmdContext {
     struct Stamp { hipEvent_t a, b; int cls; } *stamps;
     int num_stamps, cap_stamps;
     SvtAmdMeLcuResult *d_me_scratch; /* host-supplied ME results for svt_amd_ois_picture */
+    OisJobDev *d_ois_jobs;         /* device array of SVT_AMD_MAX_BATCH OIS job descriptors */
     MeJobDev *d_jobs;              /* device array of SVT_AMD_MAX_BATCH job descriptors */
     unsigned long long *d_dbg;     /* phase-profile buffer (svt_amd_debug_me_phase_profile) */
     size_t dbg_slots;
@@ -90,8 +100,7 @@ int svt_amd_stamp_end(SvtAmdContext *ctx);
 /* kernel launchers (prep_kernels.hip / me_kernels.hip) */
 int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_luma, uint32_t stride);
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus);
-int svt_amd_launch_ois(SvtAmdContext *ctx, const SvtAmdOisParams *P, const DevPicture *pic,
-                       const SvtAmdMeLcuResult *d_me, SvtAmdOisLcuResult *d_out);
+int svt_amd_launch_ois_batch(SvtAmdContext *ctx, const struct OisJobDev *host_jobs, int njobs, int max_lcus);
 
 static inline PicView make_view(const DevPicture *p)
 {

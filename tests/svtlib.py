@@ -97,6 +97,11 @@ class OisParams(C.Structure):
                 ("set_best_ois_distortion_to_valid", C.c_uint8)]
 
 
+class OisJob(C.Structure):
+    """SvtAmdOisJob"""
+    _fields_ = [("params", OisParams), ("cur_slot", C.c_int32)]
+
+
 OIS_PARAMS_DTYPE = np.dtype(OisParams)
 OIS_MAX_CAND = 18
 OIS_LCU_DTYPE = np.dtype([("candidate", "<u4", (ME_PU_COUNT, OIS_MAX_CAND)), ("total", "u1", (ME_PU_COUNT,)),
@@ -226,6 +231,10 @@ def load_product():
     _sig(lib.svt_amd_me_picture_fetch, i, [vp, i, vp])
     _sig(lib.svt_amd_me_batch_launch, i, [vp, C.POINTER(MeJob), i])
     _sig(lib.svt_amd_me_picture_range_launch, i, [vp, C.POINTER(MeParams), i, C.POINTER(C.c_int), u32, u32])
+    _sig(lib.svt_amd_ois_picture, i, [vp, C.POINTER(OisParams), i, vp, vp])
+    _sig(lib.svt_amd_ois_picture_launch, i, [vp, C.POINTER(OisParams), i])
+    _sig(lib.svt_amd_ois_picture_fetch, i, [vp, i, vp])
+    _sig(lib.svt_amd_ois_batch_launch, i, [vp, C.POINTER(OisJob), i])
     _sig(lib.svt_amd_synchronize, i, [vp])
     _sig(lib.svt_amd_timer_begin, i, [vp])
     _sig(lib.svt_amd_timer_end, i, [vp, C.POINTER(C.c_float)])

@@ -16,7 +16,6 @@ pytestmark = pytest.mark.gpu
 def ois_picture(lib, ctx, params, slot, me=None):
     n = S.lcu_count(params.luma_width, params.luma_height)
     out = np.zeros(n, S.OIS_LCU_DTYPE)
-    lib.svt_amd_ois_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     rc = lib.svt_amd_ois_picture(ctx, C.byref(params), slot, me.ctypes.data if me is not None else None, out.ctypes.data)
     assert rc == 0, lib.svt_amd_last_error()
     return out
@@ -107,3 +106,23 @@ def test_me_then_ois_on_device_1080p(product, gpu_ctx, oracle):
     want = S.oracle_ois_picture(oracle, params, f1, me)
     assert same(got, want)
     assert (want["total"][:, 1:21] != 255).all(axis=1)[:30 * 16].all()  # complete LCU rows: every 32/16 CU decided
+
+
+def test_ois_batch_matches_single(product, gpu_ctx, oracle):
+    """Several pictures in one launch (grid = pictures x LCUs) == one launch per picture."""
+    w, h = 416, 240
+    mp = default_params(w, h)
+    frames = [S.gen_luma("motion", w, h, t, 7) for t in range(4)]
+    for t, f in enumerate(frames):
+        upload(product, gpu_ctx, t, f)
+    mes = {t: me_picture(product, gpu_ctx, mp, t, [t - 1]) for t in (1, 2, 3)}
+    params = mk_params(w, h, skip_ois_8x8=1, cu8x8_mode=1)
+    jobs = (S.OisJob * 3)()
+    for i, t in enumerate((1, 2, 3)):
+        jobs[i].params, jobs[i].cur_slot = params, t
+    assert product.svt_amd_ois_batch_launch(gpu_ctx, jobs, 3) == 0, product.svt_amd_last_error()
+    n = S.lcu_count(w, h)
+    for t in (1, 2, 3):
+        got = np.zeros(n, S.OIS_LCU_DTYPE)
+        assert product.svt_amd_ois_picture_fetch(gpu_ctx, t, got.ctypes.data) == 0
+        assert same(got, S.oracle_ois_picture(oracle, params, frames[t], mes[t]))
