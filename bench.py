@@ -122,36 +122,42 @@ def main():
     frames = synth_frames_device(B + 1, 1234 + rank, dev)
     torch.cuda.synchronize()
 
-    def prep(slot, idx):
-        r = lib.svt_amd_picture_upload_device(ctx, slot, C.c_void_p(frames[idx].data_ptr()), W, W, H)
-        assert r == 0, lib.svt_amd_last_error()
-
-    jobs = (S.MeJob * B)()
-    ojobs = (S.OisJob * B)()
+    # Ring of B+1 slots: picture n lives in slot n % (B+1) and is searched against picture n-1, so every
+    # picture is prepared exactly once and the B pictures of a step are independent of each other
+    # (the front half is open loop): per step ONE prep launch, ONE ME launch, ONE OIS launch.
+    R = B + 1
     og = np.load(os.path.join(S.GOLDEN_DIR, "ois_ip_1920x1080_m9.npz"))
     oparams = S.ois_params_from_record(og["params"][1])  # the P picture of the reference run
     assert not oparams.slice_is_intra
-    for i in range(B):
-        jobs[i].params = params
-        jobs[i].cur_slot = i + 1
-        jobs[i].ref_slot[0] = i
-        jobs[i].ref_slot[1] = i
-        ojobs[i].params = oparams
-        ojobs[i].cur_slot = i + 1
+    lib.svt_amd_picture_upload_device_batch.restype = C.c_int
+    lib.svt_amd_picture_upload_device_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                                                        C.c_uint32, C.c_uint16, C.c_uint16]
+    phases = []
+    for k in range(R):  # step s starts at picture n0 = 1 + s*B; phase = n0 % R
+        slots = (C.c_int * B)()
+        ptrs = (C.c_void_p * B)()
+        jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
+        for i in range(B):
+            cur, ref = (k + i) % R, (k + i - 1) % R
+            slots[i], ptrs[i] = cur, frames[cur].data_ptr()
+            jobs[i].params, jobs[i].cur_slot = params, cur
+            jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = ref
+            ojobs[i].params, ojobs[i].cur_slot = oparams, cur
+        phases.append((slots, ptrs, jobs, ojobs))
+    state = {"n0": 1}
 
     def step():
-        # picture i (slot i) is searched against picture i-1; slot 0 holds the last
-        # picture of the previous step, so every picture is prepared exactly once.
-        # The front half is open loop: all B pictures are searched in ONE launch.
-        for i in range(1, B + 1):
-            prep(i, i)
+        slots, ptrs, jobs, ojobs = phases[state["n0"] % R]
+        r = lib.svt_amd_picture_upload_device_batch(ctx, B, slots, ptrs, W, W, H)
+        assert r == 0, lib.svt_amd_last_error()
         r = lib.svt_amd_me_batch_launch(ctx, jobs, B)
         assert r == 0, lib.svt_amd_last_error()
         r = lib.svt_amd_ois_batch_launch(ctx, ojobs, B)  # reads the ME results left on the device
         assert r == 0, lib.svt_amd_last_error()
-        prep(0, B)  # becomes the reference of the next step's first picture
+        state["n0"] += B
 
-    prep(0, 0)
+    r = lib.svt_amd_picture_upload_device(ctx, 0, C.c_void_p(frames[0].data_ptr()), W, W, H)
+    assert r == 0, lib.svt_amd_last_error()
     for _ in range(a.warmup):
         step()
     lib.svt_amd_synchronize(ctx)

@@ -154,6 +154,10 @@ SVT_AMD_API int svt_amd_picture_upload(SvtAmdContext *ctx, int slot, const uint8
 /* Same, but the plane already lives in device memory (bench / multi-GPU path). */
 SVT_AMD_API int svt_amd_picture_upload_device(SvtAmdContext *ctx, int slot, const void *d_luma,
                                               uint32_t stride, uint16_t width, uint16_t height);
+/* Up to 256 pictures of the same geometry in ONE launch (slots[i] <- d_luma[i]). */
+SVT_AMD_API int svt_amd_picture_upload_device_batch(SvtAmdContext *ctx, int num, const int *slots,
+                                                    const void *const *d_luma, uint32_t stride,
+                                                    uint16_t width, uint16_t height);
 
 /*
  * Motion estimation of one whole picture (all LCUs), replaces the LCU loop of

@@ -76,6 +76,8 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
         (void)hipFree(ctx->d_me_scratch);
     if (ctx->d_ois_jobs)
         (void)hipFree(ctx->d_ois_jobs);
+    if (ctx->d_prep_jobs)
+        (void)hipFree(ctx->d_prep_jobs);
     if (ctx->d_dbg)
         (void)hipFree(ctx->d_dbg);
     for (int i = 0; i < ctx->cap_stamps; i++) {
@@ -126,6 +128,10 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
     const int nlcu = ((max_luma_width + 63) / 64) * ((max_luma_height + 63) / 64);
     if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_me_scratch, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess) {
         svt_amd_set_error("hipMalloc(ME scratch) failed");
+        rc = SVT_AMD_ERR_RESOURCES;
+    }
+    if (rc == SVT_AMD_OK && hipMalloc(&ctx->d_prep_jobs, 128 * SVT_AMD_MAX_BATCH) != hipSuccess) {
+        svt_amd_set_error("hipMalloc(prep descriptors) failed");
         rc = SVT_AMD_ERR_RESOURCES;
     }
     if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_ois_jobs, sizeof(OisJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
@@ -288,6 +294,32 @@ extern "C" int svt_amd_picture_upload_device(SvtAmdContext *ctx, int slot, const
     if ((rc = svt_amd_launch_prep(ctx, s, (const uint8_t *)d_luma, stride)) != 0)
         return rc;
     s->valid = 1;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_picture_upload_device_batch(SvtAmdContext *ctx, int num, const int *slots,
+                                                   const void *const *d_luma, uint32_t stride, uint16_t width,
+                                                   uint16_t height)
+{
+    if (!ctx || !slots || !d_luma || num < 1 || num > SVT_AMD_MAX_BATCH || stride < width)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *pics[SVT_AMD_MAX_BATCH];
+    for (int i = 0; i < num; i++) {
+        int rc = check_slot(ctx, slots[i]);
+        if (rc)
+            return rc;
+        if (!d_luma[i])
+            return SVT_AMD_ERR_BAD_PARAM;
+        pics[i] = &ctx->slots[slots[i]];
+        if ((rc = set_geometry(ctx, pics[i], width, height)) != 0)
+            return rc;
+    }
+    int rc = svt_amd_launch_prep_batch(ctx, pics, (const uint8_t *const *)d_luma, stride, num);
+    if (rc)
+        return rc;
+    for (int i = 0; i < num; i++)
+        pics[i]->valid = 1;
     return SVT_AMD_OK;
 }
 

@@ -76,6 +76,7 @@ struct SvtAmdContext {
     struct Stamp { hipEvent_t a, b; int cls; } *stamps;
     int num_stamps, cap_stamps;
     SvtAmdMeLcuResult *d_me_scratch; /* host-supplied ME results for svt_amd_ois_picture */
+    void *d_prep_jobs;             /* device array of SVT_AMD_MAX_BATCH prep descriptors (128 B each reserved) */
     OisJobDev *d_ois_jobs;         /* device array of SVT_AMD_MAX_BATCH OIS job descriptors */
     MeJobDev *d_jobs;              /* device array of SVT_AMD_MAX_BATCH job descriptors */
     unsigned long long *d_dbg;     /* phase-profile buffer (svt_amd_debug_me_phase_profile) */
@@ -99,6 +100,8 @@ int svt_amd_stamp_end(SvtAmdContext *ctx);
 
 /* kernel launchers (prep_kernels.hip / me_kernels.hip) */
 int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_luma, uint32_t stride);
+int svt_amd_launch_prep_batch(SvtAmdContext *ctx, DevPicture *const *pics, const uint8_t *const *d_luma, uint32_t stride,
+                              int n);
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus);
 int svt_amd_launch_ois_batch(SvtAmdContext *ctx, const struct OisJobDev *host_jobs, int njobs, int max_lcus);
 

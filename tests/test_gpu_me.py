@@ -126,3 +126,28 @@ def test_bad_arguments_are_rejected(product, gpu_ctx):
     assert product.svt_amd_me_picture(gpu_ctx, C.byref(p), 0, refs, out.ctypes.data) == -1
     small = np.zeros((32, 32), np.uint8)
     assert product.svt_amd_picture_upload(gpu_ctx, 0, small.ctypes.data, 32, 32, 32) == -1
+
+
+def test_batched_prep_equals_single(product, gpu_ctx):
+    """svt_amd_picture_upload_device_batch (one fused launch for several pictures) builds the same six planes as
+    the per-picture upload, including odd source strides (slow path of the kernel)."""
+    import torch
+    w, h = 328, 264
+    frames = [S.gen_luma("motion", w, h, t, 5) for t in range(3)]
+    for stride in (w, w + 3):
+        buf = np.zeros((3, h, stride), np.uint8)
+        for i, f in enumerate(frames):
+            buf[i, :, :w] = f
+        dev = torch.from_numpy(buf).cuda()
+        slots = (C.c_int * 3)(3, 4, 5)
+        ptrs = (C.c_void_p * 3)(*[dev[i].data_ptr() for i in range(3)])
+        product.svt_amd_picture_upload_device_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                                                                C.c_uint32, C.c_uint16, C.c_uint16]
+        assert product.svt_amd_picture_upload_device_batch(gpu_ctx, 3, slots, ptrs, stride, w, h) == 0, \
+            product.svt_amd_last_error()
+        for i, f in enumerate(frames):
+            upload(product, gpu_ctx, 0, f)
+            for which in range(6):
+                a = read_plane(product, gpu_ctx, 0, which, w, h)
+                b = read_plane(product, gpu_ctx, 3 + i, which, w, h)
+                assert np.array_equal(a, b), (stride, i, which)
