@@ -356,6 +356,104 @@ __device__ void hme_pass(MeShared &S, int level, const uint8_t *refplane, int pi
     __syncthreads();
 }
 
+/* v_qsad_pk_u16_u8: four SADs of the 4 source bytes against the 4 sliding byte windows of a 64-bit reference
+ * word, accumulated into four packed u16 lanes (semantics checked on gfx950 by tools/qsad_probe.hip). */
+__device__ __forceinline__ unsigned long long qsad(uint32_t ref_lo, uint32_t ref_hi, uint32_t src, unsigned long long acc)
+{
+    return __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)ref_hi << 32) | ref_lo, src, acc);
+}
+
+/* HME pass, quad-SAD form (the fast path; hme_pass above remains for block widths that are not a multiple of 4).
+ * A work item is (search row sy, aligned window dword m) = FOUR adjacent search positions; the lane walks the
+ * block rows of its chunk, reading G+1 aligned window dwords and the G source dwords per row and issuing G
+ * v_qsad_pk_u16_u8 - no unaligned access, no funnel shifts, 4 positions per instruction.  ROWS block rows are split
+ * into C chunks on adjacent lanes (more parallelism for the small level-1/2 searches; rows-per-chunk x width <= 256
+ * keeps the packed u16 sums exact).  Wave w serves quadrant w % nq.  Tie rule as hme_pass. */
+template <int G, int ROWS, int C>
+__device__ void hme_pass_q(MeShared &S, const uint8_t *src, int sstride, const uint8_t *refplane, int pitch, int bx0,
+                           int by0, int nq, int t)
+{
+    if (t < 4)
+        S.hkey[t] = ~0ull;
+    {
+        int off = 0;
+        for (int q = 0; q < nq; q++) {
+            const int qx = S.qp[q][0], qy = S.qp[q][1], qw = S.qp[q][2], qh = S.qp[q][3];
+            LWin w;
+            off = load_window(w, off, refplane, pitch, bx0 + qx, by0 + qy, bx0 + qx + qw + 4 * G,
+                              by0 + qy + qh + 2 * (ROWS - 1) + 1, t);
+        }
+    }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63;
+    const int q = wave % nq, slot = wave / nq, nslots = (4 + nq - 1 - q) / nq; /* waves serving quadrant q */
+    int off = 0;
+    for (int k = 0; k < q; k++) {
+        const int x0k = bx0 + S.qp[k][0], xak = x0k & ~15;
+        off += (S.qp[k][3] + 2 * (ROWS - 1) + 1) * (((x0k + S.qp[k][2] + 4 * G - xak) + 15) & ~15);
+    }
+    const int qw = S.qp[q][2], qh = S.qp[q][3];
+    const int x0 = bx0 + S.qp[q][0], xa = x0 & ~15, wstride = ((x0 + qw + 4 * G - xa) + 15) & ~15;
+    const int bo0 = x0 - xa;                          /* window byte offset of search position sx = 0 */
+    const int m0 = bo0 >> 2, mcount = ((bo0 + qw - 1) >> 2) - m0 + 1;
+    const int items = qh * mcount * C;
+    const uint32_t rc = fastdiv_recip((uint32_t)(mcount > 0 ? mcount : 1));
+    constexpr int RPC = ROWS / C;                     /* block rows per chunk */
+    unsigned long long best = ~0ull;
+    for (int i0 = slot * 64; i0 < items; i0 += nslots * 64) { /* uniform per wave */
+        const int li = i0 + lane, it = li / C, ch = li - it * C;
+        const bool live = li < items;
+        uint32_t sd[4] = {0, 0, 0, 0};
+        int sy = 0, mi = 0;
+        if (live) {
+            sy = (int)fastdiv((uint32_t)it, rc), mi = it - sy * mcount;
+            const uint32_t *wr = (const uint32_t *)(g_pool + off + (sy + 2 * ch * RPC) * wstride) + m0 + mi;
+            const uint8_t *sr = src + ch * RPC * sstride;
+            unsigned long long acc = 0;
+#pragma unroll
+            for (int r = 0; r < RPC; r++) {
+                uint32_t d[G + 1];
+#pragma unroll
+                for (int g = 0; g <= G; g++)
+                    d[g] = wr[g];
+#pragma unroll
+                for (int g4 = 0; g4 < G; g4 += 4) {
+                    const uint4 sv = *(const uint4 *)(sr + 4 * g4);
+                    acc = qsad(d[g4], d[g4 + 1], sv.x, acc);
+                    acc = qsad(d[g4 + 1], d[g4 + 2], sv.y, acc);
+                    acc = qsad(d[g4 + 2], d[g4 + 3], sv.z, acc);
+                    acc = qsad(d[g4 + 3], d[g4 + 4], sv.w, acc);
+                }
+                wr += (2 * wstride) >> 2;
+                sr += sstride;
+            }
+            sd[0] = (uint32_t)(acc & 0xffff), sd[1] = (uint32_t)(acc >> 16) & 0xffff;
+            sd[2] = (uint32_t)(acc >> 32) & 0xffff, sd[3] = (uint32_t)(acc >> 48);
+        }
+        if (C > 1) {
+#pragma unroll
+            for (int o = C >> 1; o > 0; o >>= 1) {
+                sd[0] += __shfl_xor(sd[0], o), sd[1] += __shfl_xor(sd[1], o);
+                sd[2] += __shfl_xor(sd[2], o), sd[3] += __shfl_xor(sd[3], o);
+            }
+        }
+        if (live && ch == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sx = 4 * (m0 + mi) + k - bo0;
+                if (sx >= 0 && sx < qw) {
+                    const unsigned long long key = ((unsigned long long)sd[k] << 32) | (uint32_t)(sy * qw + sx);
+                    best = key < best ? key : best;
+                }
+            }
+        }
+    }
+    best = wave_min64(best);
+    if (lane == 0 && best != ~0ull)
+        atomicMin(&S.hkey[q], best);
+    __syncthreads();
+}
+
 __device__ __forceinline__ int hme_l12_width(int w) { return (w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w; }
 
 /* sub-pel row distortion: metric by fractionalSearchMethod; optional full SAD alongside */
@@ -511,7 +609,10 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                         S.qp[t][0] = so_x, S.qp[t][1] = so_y, S.qp[t][2] = sw, S.qp[t][3] = sh;
                     }
                     __syncthreads();
-                    hme_pass(S, 0, R.sixteenth, R.pitch_sixteenth, px16, py16, lw >> 2, 8, nq0, t);
+                    if ((lw >> 2) == 16)
+                        hme_pass_q<4, 8, 1>(S, S.ssrc, 16, R.sixteenth, R.pitch_sixteenth, px16, py16, nq0, t);
+                    else
+                        hme_pass(S, 0, R.sixteenth, R.pitch_sixteenth, px16, py16, lw >> 2, 8, nq0, t);
                     if (t < nq0) {
                         const unsigned long long k = S.hkey[t];
                         const int qx = S.qp[t][0], qy = S.qp[t][1], qwv = S.qp[t][2];
@@ -545,8 +646,13 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                         S.qp[t][0] = so_x, S.qp[t][1] = so_y, S.qp[t][2] = sw, S.qp[t][3] = sh;
                     }
                     __syncthreads();
-                    hme_pass(S, lvl, lvl == 1 ? R.quarter : R.full, lvl == 1 ? R.pitch_quarter : R.pitch_full, bx0, by0,
-                             lw >> shf, lvl == 1 ? 16 : 32, nq, t);
+                    if (lw == LCU && lvl == 1)
+                        hme_pass_q<8, 16, 4>(S, S.qsrc, 32, R.quarter, R.pitch_quarter, bx0, by0, nq, t);
+                    else if (lw == LCU)
+                        hme_pass_q<16, 32, 8>(S, S.src, 2 * LCU, R.full, R.pitch_full, bx0, by0, nq, t);
+                    else
+                        hme_pass(S, lvl, lvl == 1 ? R.quarter : R.full, lvl == 1 ? R.pitch_quarter : R.pitch_full, bx0, by0,
+                                 lw >> shf, lvl == 1 ? 16 : 32, nq, t);
                     if (t < nq) {
                         const unsigned long long k = S.hkey[t];
                         const int qx = S.qp[t][0], qy = S.qp[t][1], qwv = S.qp[t][2];
