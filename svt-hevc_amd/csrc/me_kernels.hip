@@ -276,21 +276,40 @@ struct MeShared {
 
 /* ------------------------------------------------------------------------- */
 
-/* Sub-sampled LCU SAD against the reference at the displacements S.cand[c][2..3]:
+/* Sub-sampled LCU SAD against the reference at the displacements S.cand[c][2..3], c in [first, ncand):
  * NxMSadKernel(lcuSrcPtr, stride<<1, ref, stride<<1, lcuHeight>>1, lcuWidth) per candidate.
- * One (candidate,row) item per thread; the caller must have synchronised S.cand. */
-__device__ void lcu_sads(MeShared &S, const uint8_t *ref, int pitch, int ox, int oy, int lw, int lh, int ncand, int t)
+ * The caller must have synchronised S.cand; S.acc[c] for c < first is left untouched. */
+typedef uint4 __attribute__((aligned(1))) u128u;
+__device__ void lcu_sads(MeShared &S, const uint8_t *ref, int pitch, int ox, int oy, int lw, int lh, int ncand, int t,
+                         int first = 0)
 {
-    if (t < 8)
+    if (t < 8 && t >= first)
         S.acc[t] = 0;
     __syncthreads();
     const int rows = lh >> 1; /* <= 32 */
-    for (int i = t; i < ncand * 32; i += NT) {
-        const int c = i >> 5, r = i & 31;
-        if (r < rows) {
-            const uint32_t s = row_sad(&S.src[(2 * r) * LCU],
-                                       ref + (ptrdiff_t)(oy + S.cand[c][3] + 2 * r) * pitch + ox + S.cand[c][2], lw);
-            atomicAdd(&S.acc[c], s);
+    if (lw == LCU) {
+        /* item = (candidate, row, 16-sample quarter): one unaligned 16-byte global load + 4 v_sad_u8; the 128 items
+         * of a candidate fill two whole waves, so the candidate sum is a wave reduction + one LDS atomic per wave */
+        for (int i = first * 128 + t; i < ncand * 128; i += NT) {
+            const int c = i >> 7, r = (i >> 2) & 31, qx = (i & 3) << 4;
+            uint32_t s = 0;
+            if (r < rows) {
+                const uint4 a = *(const uint4 *)&S.src[(2 * r) * LCU + qx];
+                const uint4 b = *(const u128u *)(ref + (ptrdiff_t)(oy + S.cand[c][3] + 2 * r) * pitch + ox + S.cand[c][2] + qx);
+                s = sad4(a.x, b.x, s), s = sad4(a.y, b.y, s), s = sad4(a.z, b.z, s), s = sad4(a.w, b.w, s);
+            }
+            s = wave_sum(s);
+            if ((t & 63) == 0)
+                atomicAdd(&S.acc[c], s);
+        }
+    } else {
+        for (int i = first * 32 + t; i < ncand * 32; i += NT) {
+            const int c = i >> 5, r = i & 31;
+            if (r < rows) {
+                const uint32_t s = row_sad(&S.src[(2 * r) * LCU],
+                                           ref + (ptrdiff_t)(oy + S.cand[c][3] + 2 * r) * pitch + ox + S.cand[c][2], lw);
+                atomicAdd(&S.acc[c], s);
+            }
         }
     }
     __syncthreads();
@@ -533,6 +552,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
     for (int list = 0; list < P.num_lists; list++) {
         const PicView &R = list ? ref1 : ref0;
         int cx = 0, cy = 0;
+        int zero_sad_valid = 0;
 
         if (P.temporal_layer_index > 0 || list == 0) {
             if (list == 0) STAMP(1);
@@ -551,6 +571,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 }
                 __syncthreads();
                 lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, nc, t);
+                zero_sad_valid = 1; /* S.acc[0] = SAD at (0,0) of this list's reference: reused by CheckZeroZeroCenter */
                 /* tie order: zero, A, B, C, direct, D (:3634-3658); costs are sad << 9 */
                 const uint32_t a0 = S.acc[0], a1 = S.acc[1], a2 = S.acc[2], a3 = S.acc[3], a4 = S.acc[4],
                                a5 = nc == 6 ? S.acc[5] : 0xffffffffu;
@@ -715,7 +736,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 S.cand[1][2] = cx, S.cand[1][3] = cy;
             }
             __syncthreads();
-            lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, 2, t);
+            lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, 2, t, zero_sad_valid);
             const uint32_t zeroSad = S.acc[0] << 1, hmeSad = S.acc[1] << 1;
             const unsigned long long zeroCost = (unsigned long long)zeroSad << COST_PRECISION;
             const uint32_t rate = mvd_fraction_bits(abs(cx << 2), abs(cy << 2), P.mvd_bits);
@@ -765,23 +786,36 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             const uint8_t *rbase = wat(wF, ox + bx + sox, oy + by + soy);
             const int fstride = wF.stride;
             __syncthreads();
+            /* 8x8 even-row SADs: an item is (search row, aligned window dword) = 4 adjacent search positions of
+             * block b, 8 v_qsad_pk_u16_u8 (4 rows x 2 dwords) on aligned LDS dwords */
+            const int a0 = (int)((uintptr_t)rbase & 3);
+            const uint32_t *rb4 = (const uint32_t *)(rbase - a0);
+            const int mcount = ((a0 + saw - 1) >> 2) + 1, fs4 = fstride >> 2;
+            const uint32_t rcm = fastdiv_recip((uint32_t)mcount);
             for (int base = 0; base < npos; base += 64) {
-                for (int i = 0; i < 16; i++) {
-                    const int pl = sub + 4 * i, p = base + pl;
-                    if (p < npos) {
-                        const int sy = (int)fastdiv((uint32_t)p, rcw), sx = p - sy * saw;
-                        const uint8_t *r = rbase + sy * fstride + sx;
-                        uint32_t s = 0;
+                const int pend = imin(npos, base + 64);
+                const int sy0 = (int)fastdiv((uint32_t)base, rcw), sy1 = (int)fastdiv((uint32_t)(pend - 1), rcw);
+                const int items = (sy1 - sy0 + 1) * mcount;
+                for (int it = sub; it < items; it += 4) {
+                    const int ry = (int)fastdiv((uint32_t)it, rcm), mi = it - ry * mcount, sy = sy0 + ry;
+                    const uint32_t *r = rb4 + sy * fs4 + mi;
+                    unsigned long long acc = 0;
 #pragma unroll
-                        for (int rr = 0; rr < 4; rr++) {
-                            uint32_t v[2];
-                            lds_ld_unaligned<2>(r + (2 * rr) * fstride, v);
-                            s = sad4(s0[rr], v[0], s);
-                            s = sad4(s1[rr], v[1], s);
+                    for (int rr = 0; rr < 4; rr++) {
+                        const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
+                        acc = qsad(d0, d1, s0[rr], acc);
+                        acc = qsad(d1, d2, s1[rr], acc);
+                        r += 2 * fs4;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int sx = 4 * mi + k - a0, p = sy * saw + sx;
+                        if (sx >= 0 && sx < saw && p >= base && p < pend) {
+                            const uint32_t sv = (uint32_t)(acc >> (16 * k)) & 0xffffu;
+                            S.sad8[p - base][b] = (uint16_t)sv;
+                            const uint32_t key = (sv << 14) | (uint32_t)p;
+                            best8 = key < best8 ? key : best8;
                         }
-                        S.sad8[pl][b] = (uint16_t)s;
-                        const uint32_t k = (s << 14) | (uint32_t)p;
-                        best8 = k < best8 ? k : best8;
                     }
                 }
                 __syncthreads();
