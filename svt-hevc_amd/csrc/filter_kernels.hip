@@ -126,27 +126,88 @@ __global__ __launch_bounds__(256) void k_sao_gather(const T *__restrict__ input,
     __syncthreads();
     const int boShift = sizeof(T) == 1 ? 3 : 5;
     const int iw = lw - 2, ih = lh - 2;
-    for (int i = t; i < iw * ih; i += 256) {
-        const int yy = i / iw + 1, xx = i - (yy - 1) * iw + 1;
-        const T *r = recon + (ptrdiff_t)(y0 + yy) * reconStride + x0 + xx;
+    /* edge-offset histograms live in registers (select-accumulate, compile-time indices): 20 LDS atomics per sample
+     * on five hot addresses serialise; band-offset bins are spread by the sample value and stay LDS atomics */
+    int ed[4][5];
+    unsigned ec[4][5];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            ed[k][c] = 0, ec[k][c] = 0;
+    /* LCU-sized areas are staged in LDS with coalesced row loads (the statistics read every sample nine times) */
+    __shared__ T tile_r[64 * 64], tile_i[64 * 64];
+    const bool staged = lw <= 64 && lh <= 64;
+    const T *rp = recon + (ptrdiff_t)y0 * reconStride + x0, *ip = input + (ptrdiff_t)y0 * inStride + x0;
+    int rs = reconStride, is = inStride;
+    if (staged) {
+        for (int i = t; i < lw * lh; i += 256) {
+            const int yy = i / lw, xx = i - yy * lw;
+            tile_r[yy * 64 + xx] = rp[(ptrdiff_t)yy * reconStride + xx];
+            tile_i[yy * 64 + xx] = ip[(ptrdiff_t)yy * inStride + xx];
+        }
+        __syncthreads();
+        rp = tile_r, ip = tile_i, rs = 64, is = 64;
+    }
+    const int total = iw * ih;
+    for (int i0 = 0; i0 < total; i0 += 256) { /* uniform trip count: whole waves take part in the shuffles below */
+        const int i = i0 + t;
+        const bool live = i < total;
+        const int yy = live ? i / iw + 1 : 1, xx = live ? i - (yy - 1) * iw + 1 : 1;
+        const T *r = rp + yy * rs + xx;
         const int c = r[0];
-        int diff = (int)input[(ptrdiff_t)(y0 + yy) * inStride + x0 + xx] - c;
+        int diff = (int)ip[yy * is + xx] - c;
         if (sizeof(T) == 1)
             diff = f_clip3(-128, 127, diff);
+        if (!live)
+            diff = 0;
         if (!only_eo) {
-            atomicAdd(&bo_d[c >> boShift], diff);
-            atomicAdd(&bo_c[c >> boShift], 1u);
+            /* smooth content puts a whole wave into one band: then one atomic per wave instead of 64 colliding ones */
+            const int bin = c >> boShift, first = __builtin_amdgcn_readfirstlane(bin);
+            if (__all(!live || bin == first)) {
+                int dsum = diff;
+                unsigned csum = live ? 1u : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    dsum += __shfl_xor(dsum, o), csum += __shfl_xor(csum, o);
+                if ((t & 63) == 0 && csum) {
+                    atomicAdd(&bo_d[first], dsum);
+                    atomicAdd(&bo_c[first], csum);
+                }
+            } else if (live) {
+                atomicAdd(&bo_d[bin], diff);
+                atomicAdd(&bo_c[bin], 1u);
+            }
         }
-        const int nb[4][2] = {{-1, 1}, {-reconStride, reconStride}, {-reconStride - 1, reconStride + 1}, {-reconStride + 1, reconStride - 1}};
+        if (!live)
+            continue;
+        const int nb[4][2] = {{-1, 1}, {-rs, rs}, {-rs - 1, rs + 1}, {-rs + 1, rs - 1}};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (only_eo && k == 0)
                 continue;
             const int idx = f_sgn(c, r[nb[k][0]]) + f_sgn(c, r[nb[k][1]]) + 2;
-            atomicAdd(&eo_d[k][idx], diff);
-            atomicAdd(&eo_c[k][idx], 1u);
+#pragma unroll
+            for (int cc = 0; cc < 5; cc++) {
+                ed[k][cc] += idx == cc ? diff : 0;
+                ec[k][cc] += idx == cc ? 1u : 0u;
+            }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int cc = 0; cc < 5; cc++) {
+            int dsum = ed[k][cc];
+            unsigned csum = ec[k][cc];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                dsum += __shfl_xor(dsum, o), csum += __shfl_xor(csum, o);
+            if ((t & 63) == 0) {
+                atomicAdd(&eo_d[k][cc], dsum);
+                atomicAdd(&eo_c[k][cc], csum);
+            }
+        }
     __syncthreads();
     SaoStats *o = &out[lcu];
     if (t < 32 && !only_eo)

@@ -67,8 +67,9 @@ struct TxShared {
     static constexpr int GB = (N >= 16) ? 1 : (N == 8 ? 4 : 16); /* blocks per workgroup */
     int8_t T[32][32];
     int16_t io[GB][N * N];  /* input, later the transposed first-pass output */
-    int32_t E[GB][N][N];    /* running even vector, levels evaluated in place */
-    int32_t D[GB][N][N];    /* decomposed rows: [0..1] last even pair, [h..2h) odd vector of length h */
+    int32_t E[GB][N][N + 1]; /* running even vector, levels evaluated in place; +1: the dot-product stage walks  */
+    int32_t D[GB][N][N + 1]; /* rows with the row index fastest, unpadded rows would all hit one LDS bank.       */
+                             /* D: [h..2h) = odd vector of length h */
 };
 
 /* one 1-D forward pass over all rows of the GB blocks held in S.io; output transposed into dst */
@@ -78,7 +79,7 @@ __device__ void fwd_pass(TxShared<N> &S, int shift, int wrap_levels, int16_t *gd
     constexpr int GB = TxShared<N>::GB;
     constexpr int LOG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
     for (int i = t; i < GB * N * N; i += TX_THREADS)
-        (&S.E[0][0][0])[i] = (&S.io[0][0])[i];
+        S.E[i / (N * N)][(i / N) % N][i % N] = (&S.io[0][0])[i];
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < LOG - 1; m++) {
@@ -223,6 +224,102 @@ __global__ __launch_bounds__(TX_THREADS) void k_inv_dct(const int16_t *__restric
 /* ------------------------------------------------------------------------- */
 /* quantisation, distortion, SATD, picture operators                          */
 /* ------------------------------------------------------------------------- */
+
+/* Wave-centric forms for power-of-two block sizes (16 .. 4096 coefficients, 16-byte aligned blocks): a lane moves
+ * 8 coefficients per 16-byte access, a block is owned by n2/8 adjacent lanes (up to a whole wave, which then
+ * iterates), per-block sums are segmented shuffles - no LDS, no barriers, several small blocks per wave. */
+__device__ __forceinline__ uint32_t seg_sum(uint32_t v, int lanes)
+{
+    for (int o = 1; o < lanes; o <<= 1)
+        v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(TX_THREADS) void k_quant_w(const int16_t *__restrict__ coeff, int16_t *__restrict__ q,
+                                                       int16_t *__restrict__ rec, uint32_t *__restrict__ nz,
+                                                       uint32_t nblocks, int n2, uint32_t qFunc, uint32_t q_offset,
+                                                       int shiftedQBits, int shiftedFFunc, int iq_offset, int shiftNum)
+{
+    const int lane = threadIdx.x & 63, lpb = n2 >= 512 ? 64 : n2 >> 3, bpw = 64 / lpb, iters = n2 / (8 * lpb);
+    const uint32_t gw = (blockIdx.x * TX_THREADS + threadIdx.x) >> 6, nw = (gridDim.x * TX_THREADS) >> 6;
+    for (uint32_t wb = gw; wb * bpw < nblocks; wb += nw) {
+        const uint32_t b = wb * bpw + lane / lpb;
+        const int sub = lane % lpb;
+        uint32_t mine = 0;
+        if (b < nblocks) {
+            for (int it = 0; it < iters; it++) {
+                const size_t at = (size_t)b * n2 + (size_t)(it * lpb + sub) * 8;
+                const uint4 cv = *(const uint4 *)(coeff + at);
+                const uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
+                uint32_t qo[4], ro[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t qq = 0, rr = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int v = (int16_t)(w[k] >> (16 * h)), sign = v < 0 ? -1 : 1;
+                        int tq = abs(v);
+                        tq = (int)((uint32_t)tq * qFunc);
+                        tq = (int)((uint32_t)tq + q_offset);
+                        tq >>= shiftedQBits;
+                        const int qv = clip16i(sign * tq);
+                        mine += qv != 0;
+                        qq |= (uint32_t)(uint16_t)qv << (16 * h);
+                        rr |= (uint32_t)(uint16_t)clip16i(((qv * shiftedFFunc) + iq_offset) >> shiftNum) << (16 * h);
+                    }
+                    qo[k] = qq, ro[k] = rr;
+                }
+                *(uint4 *)(q + at) = make_uint4(qo[0], qo[1], qo[2], qo[3]);
+                *(uint4 *)(rec + at) = make_uint4(ro[0], ro[1], ro[2], ro[3]);
+            }
+        }
+        mine = seg_sum(mine, lpb);
+        if (b < nblocks && sub == 0)
+            nz[b] = mine;
+    }
+}
+__global__ __launch_bounds__(TX_THREADS) void k_full_distortion_w(const int16_t *__restrict__ coeff,
+                                                                 const int16_t *__restrict__ rec,
+                                                                 unsigned long long *__restrict__ out, uint32_t nblocks,
+                                                                 int n2, int mode)
+{
+    const int lane = threadIdx.x & 63, lpb = n2 >= 512 ? 64 : n2 >> 3, bpw = 64 / lpb, iters = n2 / (8 * lpb);
+    const uint32_t gw = (blockIdx.x * TX_THREADS + threadIdx.x) >> 6, nw = (gridDim.x * TX_THREADS) >> 6;
+    for (uint32_t wb = gw; wb * bpw < nblocks; wb += nw) {
+        const uint32_t b = wb * bpw + lane / lpb;
+        const int sub = lane % lpb;
+        uint32_t res = 0, pred = 0;
+        if (b < nblocks) {
+            for (int it = 0; it < iters; it++) {
+                const size_t at = (size_t)b * n2 + (size_t)(it * lpb + sub) * 8;
+                const uint4 cv = *(const uint4 *)(coeff + at), rv = *(const uint4 *)(rec + at);
+                const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int16_t c = (int16_t)(cw[k] >> (16 * h)), d = (int16_t)(c - (int16_t)(rw[k] >> (16 * h)));
+                        res += (uint32_t)(d * d);
+                        pred += (uint32_t)(c * c);
+                    }
+            }
+        }
+        res = seg_sum(res, lpb), pred = seg_sum(pred, lpb);
+        if (b < nblocks && sub == 0) {
+            out[2 * b + 0] = mode == 1 ? pred : res;
+            out[2 * b + 1] = mode == 2 ? res : pred;
+        }
+    }
+}
+static inline bool wave_form_ok(int n2, const void *a, const void *b, const void *c)
+{
+    return n2 >= 16 && n2 <= 4096 && (n2 & (n2 - 1)) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+static inline unsigned wave_form_grid(uint32_t n, int n2)
+{
+    const int lpb = n2 >= 512 ? 64 : n2 >> 3, bpw = 64 / lpb;
+    const uint32_t waves = (n + bpw - 1) / bpw, wgs = (waves + 3) / 4;
+    return wgs < 8192 ? wgs : 8192;
+}
 
 /* QuantizeInvQuantize over contiguous size x size blocks; nz[b] = non-zero count */
 __global__ __launch_bounds__(TX_THREADS) void k_quant(const int16_t *__restrict__ coeff, int16_t *__restrict__ q,
@@ -411,8 +508,12 @@ int svt_amd_launch_quant(hipStream_t st, int size, uint32_t qFunc, uint32_t q_of
 {
     if (!n || size < 4 || size > 64)
         return SVT_AMD_ERR_BAD_PARAM;
-    hipLaunchKernelGGL(k_quant, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_q, d_rec, d_nz, n,
-                       size * size, qFunc, q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum);
+    if (wave_form_ok(size * size, d_coeff, d_q, d_rec))
+        hipLaunchKernelGGL(k_quant_w, dim3(wave_form_grid(n, size * size)), dim3(TX_THREADS), 0, st, d_coeff, d_q, d_rec, d_nz,
+                           n, size * size, qFunc, q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum);
+    else
+        hipLaunchKernelGGL(k_quant, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_q, d_rec, d_nz, n,
+                           size * size, qFunc, q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -422,8 +523,12 @@ int svt_amd_launch_full_distortion(hipStream_t st, int size, int mode, const int
 {
     if (!n || mode < 0 || mode > 2)
         return SVT_AMD_ERR_BAD_PARAM;
-    hipLaunchKernelGGL(k_full_distortion, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_rec, d_out, n,
-                       size * size, mode);
+    if (wave_form_ok(size * size, d_coeff, d_rec, d_rec))
+        hipLaunchKernelGGL(k_full_distortion_w, dim3(wave_form_grid(n, size * size)), dim3(TX_THREADS), 0, st, d_coeff, d_rec,
+                           d_out, n, size * size, mode);
+    else
+        hipLaunchKernelGGL(k_full_distortion, dim3(n < 4096 ? n : 4096), dim3(TX_THREADS), 0, st, d_coeff, d_rec, d_out, n,
+                           size * size, mode);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Throughput of the batched EncDec leaf-family kernels at 1080p-picture-sized batches (needs the GPU).
+For every kernel: algorithmic bytes (each operand read once, each result written once) / HIP-event time
+-> GB/s and the fraction of the 8 TB/s HBM peak.  usage: python tools/leaf_bench.py [iters]"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import svtlib as S  # noqa: E402
+
+PEAK = 8000.0
+vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    lib = S.load_product()
+    ctx = C.c_void_p()
+    assert lib.svt_amd_context_create(0, 1920, 1088, 2, C.byref(ctx)) == 0
+    dev = torch.device("cuda", 0)
+    W, H = 1920, 1080
+    npx = W * H
+    rows = []
+
+    def timed(name, nbytes, fn):
+        fn()
+        lib.svt_amd_synchronize(ctx)
+        torch.cuda.synchronize()
+        lib.svt_amd_timer_begin(ctx)
+        for _ in range(iters):
+            rc = fn()
+            assert rc == 0, lib.svt_amd_last_error()
+        ms = C.c_float()
+        lib.svt_amd_timer_end(ctx, C.byref(ms))
+        us = ms.value * 1e3 / iters
+        gbs = nbytes / (us * 1e-6) / 1e9
+        rows.append({"kernel": name, "us": round(us, 2), "MB": round(nbytes / 1e6, 2), "GB/s": round(gbs, 1),
+                     "frac_of_hbm_peak": round(gbs / PEAK, 4)})
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    res = torch.randint(-255, 256, (npx,), dtype=torch.int16, device=dev, generator=g)
+    coef, rec, q = torch.empty_like(res), torch.empty_like(res), torch.empty_like(res)
+    lib.svt_amd_fwd_transform_batch.argtypes = [vp, C.c_int, C.c_int, u32, vp, vp, u32]
+    lib.svt_amd_inv_transform_batch.argtypes = [vp, C.c_int, C.c_int, u32, vp, vp, u32]
+    lib.svt_amd_quantize_batch.argtypes = [vp, C.c_int, u32, u32, i32, i32, i32, i32, vp, vp, vp, vp, u32]
+    lib.svt_amd_full_distortion_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, u32]
+    lib.svt_amd_satd_batch.argtypes = [vp, C.c_int, vp, vp, u32]
+    for size in (32, 16, 8, 4):
+        nb = npx // (size * size)
+        kind = 1 if size >= 16 else 0
+        timed("fwd_transform %dx%d%s (%d TUs)" % (size, size, " Estimate" if kind else "", nb), 4 * nb * size * size,
+              lambda: lib.svt_amd_fwd_transform_batch(ctx, kind, size, 0, res.data_ptr(), coef.data_ptr(), nb))
+        timed("inv_transform %dx%d (%d TUs)" % (size, size, nb), 4 * nb * size * size,
+              lambda: lib.svt_amd_inv_transform_batch(ctx, 0, size, 0, coef.data_ptr(), rec.data_ptr(), nb))
+    nz = torch.zeros(npx // 16, dtype=torch.int32, device=dev)
+    for size in (32, 8):
+        nb = npx // (size * size)
+        timed("quantize+inverse %dx%d (%d TUs)" % (size, size, nb), 6 * nb * size * size + 4 * nb,
+              lambda: lib.svt_amd_quantize_batch(ctx, size, 26214, 171 << 11, 20, 40 << 2, 1 << 3, 4, coef.data_ptr(),
+                                                 q.data_ptr(), rec.data_ptr(), nz.data_ptr(), nb))
+    dist = torch.zeros(2 * (npx // 16), dtype=torch.int64, device=dev)
+    for size in (32, 8):
+        nb = npx // (size * size)
+        timed("full_distortion %dx%d (%d TUs)" % (size, size, nb), 4 * nb * size * size + 16 * nb,
+              lambda: lib.svt_amd_full_distortion_batch(ctx, size, 0, coef.data_ptr(), rec.data_ptr(), dist.data_ptr(), nb))
+    nb = npx // 64
+    timed("satd 8x8 (%d blocks)" % nb, 2 * nb * 64 + 8 * nb,
+          lambda: lib.svt_amd_satd_batch(ctx, 8, res.data_ptr(), dist.data_ptr(), nb))
+
+    # streaming picture-level kernels
+    lib.svt_amd_pack_plane.argtypes = [vp, vp, u32, vp, u32, C.c_int, vp, u32, u32, u32]
+    lib.svt_amd_unpack_plane.argtypes = [vp, vp, u32, vp, u32, vp, u32, u32, u32]
+    lib.svt_amd_sao_gather_picture.argtypes = [vp, C.c_int, vp, u32, vp, u32, u32, u32, u32, C.c_int, vp]
+    in8 = torch.randint(0, 256, (H, W), dtype=torch.uint8, device=dev, generator=g)
+    inn = torch.randint(0, 256, (H, W // 4), dtype=torch.uint8, device=dev, generator=g)
+    p16 = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    o8, on = torch.zeros_like(in8), torch.zeros_like(in8)
+    timed("pack 8+2 bit (compressed) -> 16 bit, 1080p plane", npx * (1 + 0.25 + 2),
+          lambda: lib.svt_amd_pack_plane(ctx, in8.data_ptr(), W, inn.data_ptr(), W // 4, 1, p16.data_ptr(), W, W, H))
+    timed("unpack 16 bit -> 8 + 2 bit, 1080p plane", npx * (2 + 1 + 1),
+          lambda: lib.svt_amd_unpack_plane(ctx, p16.data_ptr(), W, o8.data_ptr(), W, on.data_ptr(), W, W, H))
+    rec8 = (in8.to(torch.int16) + torch.randint(-6, 7, (H, W), dtype=torch.int16, device=dev, generator=g)).clamp(0, 255).to(torch.uint8)
+    stats = torch.zeros(510 * 312, dtype=torch.uint8, device=dev)
+    timed("SAO statistics, 510 LCUs (BO + 4 EO)", 2 * npx + 510 * 312,
+          lambda: lib.svt_amd_sao_gather_picture(ctx, 1, in8.data_ptr(), W, rec8.data_ptr(), W, W, H, 64, 0, stats.data_ptr()))
+
+    # deblocking: all vertical 8x8-grid luma edges of a 1080p plane
+    lib.svt_amd_dlf_luma_edges_batch.argtypes = [vp, vp, u32, C.c_int, vp, u32]
+    ys, xs = np.meshgrid(np.arange(0, H - 3, 4), np.arange(8, W, 8), indexing="ij")
+    e = np.zeros(ys.size, dtype=np.dtype([("offset", "<i4"), ("tc", "<i2"), ("beta", "<i2"), ("v", "u1"), ("pad", "u1", 3)]))
+    e["offset"], e["tc"], e["beta"], e["v"] = (ys * W + xs).ravel(), 6, 38, 1
+    d_e = torch.from_numpy(e.view(np.uint8)).to(dev)
+    plane = in8.clone()
+    timed("deblock luma, %d vertical 4-sample edges" % len(e), len(e) * (2 * 32 + 12),
+          lambda: lib.svt_amd_dlf_luma_edges_batch(ctx, plane.data_ptr(), W, 1, d_e.data_ptr(), len(e)))
+
+    print(json.dumps({"iters": iters, "peak_GBs": PEAK, "kernels": rows}, indent=1))
+    lib.svt_amd_context_destroy(ctx)
+
+
+if __name__ == "__main__":
+    main()
