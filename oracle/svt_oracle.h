@@ -165,4 +165,11 @@ int svt_oracle_me_picture(const SvtAmdMeParams *params, const SvtOraclePicture *
 void svt_oracle_ois_lcu(const SvtAmdOisParams *P, const uint8_t *luma, uint32_t stride, uint32_t lcu_x, uint32_t lcu_y,
                         const uint32_t *me_sad, SvtAmdOisLcuResult *out);
 
+/* ---- HEVC motion-compensation interpolation (svt_oracle_mcp.c) ---- */
+/* chroma: 0 luma (fx,fy quarter-pel 0..3), 1 chroma (eighth-pel 0..7); out_raw: int16 output with stride = w */
+void svt_oracle_mcp(int bps, int chroma, int out_raw, uint32_t fx, uint32_t fy, const void *ref, uint32_t srcStride,
+                    void *dst, uint32_t dstStride, uint32_t w, uint32_t h);
+void svt_oracle_BiPredClipping(int bps, uint32_t w, uint32_t h, const int16_t *l0, const int16_t *l1, void *dst,
+                               uint32_t dstStride, int32_t offset);
+
 #endif
