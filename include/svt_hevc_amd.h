@@ -576,6 +576,122 @@ SVT_AMD_API void svt_amd_UnPack8BitData(uint16_t *in16BitBuffer, uint32_t inStri
 SVT_AMD_API void svt_amd_UnpackAvg(uint16_t *ref16L0, uint32_t refL0Stride, uint16_t *ref16L1, uint32_t refL1Stride,
                                    uint8_t *dstPtr, uint32_t dstStride, uint32_t width, uint32_t height);
 
+/* ------------------------------------------------------------------------- */
+/* HEVC motion-compensation interpolation (closed-loop inter prediction)      */
+/* ------------------------------------------------------------------------- */
+/* One prediction block: integer position = sample index ref_off of the reference plane, fractional part (fx,fy) in
+ * quarter samples for luma (0..3), eighth samples for chroma (0..7); output at sample index dst_off.
+ * Raw (int16, bi-prediction intermediate) output is packed with stride = w at dst_off.  w, h <= 64. */
+typedef struct SvtAmdMcpBlock { int32_t ref_off, dst_off; uint16_t w, h; uint8_t fx, fy, pad[2]; } SvtAmdMcpBlock;
+typedef struct SvtAmdBiPredBlock { int32_t l0_off, l1_off, dst_off; uint16_t w, h; } SvtAmdBiPredBlock;
+/* BATCHED (device pointers): replaces the per-PU calls of UniPredHevcInterpolationMd / EncodeUniPredInterpolation
+ * (Codec/EbMcp.c:99-600) into uniPredLumaIFFunctionPtrArrayNew / uniPredChromaIFFunctionPtrArrayNew (out_raw 0) and of
+ * BiPredHevcInterpolationMd (:601-1016) into biPredLumaIFFunctionPtrArrayNew / biPredChromaIFFunctionPtrArrayNew
+ * (out_raw 1) followed by biPredClippingFuncPtrArray (Codec/EbMcpTables.c:14-745). */
+SVT_AMD_API int svt_amd_mcp_batch(SvtAmdContext *ctx, int bytes_per_sample, int chroma, int out_raw, const void *d_ref,
+                                  uint32_t refStride, void *d_dst, uint32_t dstStride,
+                                  const SvtAmdMcpBlock *d_blocks, uint32_t nblocks);
+/* offset: Offset5 (luma) / ChromaOffset5 of Codec/EbDefinitions.h:1022-1030; ignored for 16-bit */
+SVT_AMD_API int svt_amd_bipred_clip_batch(SvtAmdContext *ctx, int bytes_per_sample, const int16_t *d_l0,
+                                          const int16_t *d_l1, void *d_dst, uint32_t dstStride, int32_t offset,
+                                          const SvtAmdBiPredBlock *d_blocks, uint32_t nblocks);
+
+/* LEAF forms: the distinct C_DEFAULT symbols of uniPredLumaIFFunctionPtrArrayNew[16], biPredLumaIFFunctionPtrArrayNew[16],
+ * uniPredChromaIFFunctionPtrArrayNew[64], biPredChromaIFFunctionPtrArrayNew[64], their 16-bit twins and the two
+ * clipping tables.  firstPassIFDst is the reference's scratch buffer; it is not written. */
+#define SVT_AMD_DECL_MCP_UNI(name, T)                                                                          \
+    SVT_AMD_API void svt_amd_##name(T *refPic, uint32_t srcStride, T *dst, uint32_t dstStride, uint32_t puWidth, \
+                                    uint32_t puHeight, int16_t *firstPassIFDst);
+#define SVT_AMD_DECL_MCP_RAW(name, T)                                                                          \
+    SVT_AMD_API void svt_amd_##name(T *refPic, uint32_t srcStride, int16_t *dst, uint32_t puWidth,             \
+                                    uint32_t puHeight, int16_t *firstPassIFDst);
+#define SVT_AMD_DECL_MCP_CUNI(name, T)                                                                         \
+    SVT_AMD_API void svt_amd_##name(T *refPic, uint32_t srcStride, T *dst, uint32_t dstStride, uint32_t puWidth, \
+                                    uint32_t puHeight, int16_t *firstPassIFDst, uint32_t fracPosx, uint32_t fracPosy);
+#define SVT_AMD_DECL_MCP_CRAW(name, T)                                                                         \
+    SVT_AMD_API void svt_amd_##name(T *refPic, uint32_t srcStride, int16_t *dst, uint32_t puWidth,             \
+                                    uint32_t puHeight, int16_t *firstPassIFDst, uint32_t fracPosx, uint32_t fracPosy);
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosaNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosaNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosaOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosaOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosbNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosbNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosbOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosbOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoscNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoscNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoscOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoscOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosdNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosdNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosdOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosdOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoseNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoseNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoseOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoseOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosfNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosfNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosfOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosfOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosgNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosgNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosgOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosgOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoshNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoshNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoshOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoshOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosiNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosiNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosiOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosiOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosjNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosjNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosjOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosjOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoskNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPoskNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoskOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPoskOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosnNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosnNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosnOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosnOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPospNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPospNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPospOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPospOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosqNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosqNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosqOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosqOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosrNew, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationFilterPosrNew16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosrOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationFilterPosrOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationCopy, uint8_t)
+SVT_AMD_DECL_MCP_UNI(LumaInterpolationCopy16bit, uint16_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationCopyOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_RAW(LumaInterpolationCopyOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_CUNI(ChromaInterpolationCopy, uint8_t)
+SVT_AMD_DECL_MCP_CUNI(ChromaInterpolationFilterOneD, uint8_t)
+SVT_AMD_DECL_MCP_CUNI(ChromaInterpolationFilterTwoD, uint8_t)
+SVT_AMD_DECL_MCP_CUNI(ChromaInterpolationCopy16bit, uint16_t)
+SVT_AMD_DECL_MCP_CUNI(ChromaInterpolationFilterOneD16bit, uint16_t)
+SVT_AMD_DECL_MCP_CUNI(ChromaInterpolationFilterTwoD16bit, uint16_t)
+SVT_AMD_DECL_MCP_CRAW(ChromaInterpolationCopyOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_CRAW(ChromaInterpolationFilterOneDOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_CRAW(ChromaInterpolationFilterTwoDOutRaw, uint8_t)
+SVT_AMD_DECL_MCP_CRAW(ChromaInterpolationCopyOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_CRAW(ChromaInterpolationFilterOneDOutRaw16bit, uint16_t)
+SVT_AMD_DECL_MCP_CRAW(ChromaInterpolationFilterTwoDOutRaw16bit, uint16_t)
+SVT_AMD_API void svt_amd_BiPredClipping(uint32_t puWidth, uint32_t puHeight, int16_t *list0Src, int16_t *list1Src,
+                                        uint8_t *dst, uint32_t dstStride, int32_t offset);
+SVT_AMD_API void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight, int16_t *list0Src, int16_t *list1Src,
+                                             uint16_t *dst, uint32_t dstStride);
+
 #ifdef __cplusplus
 }
 #endif

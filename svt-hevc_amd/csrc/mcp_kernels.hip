@@ -1,0 +1,258 @@
+/*
+ * HEVC motion-compensation interpolation (EncDec row "Inter2Nx2NPuPredictionHevc ... MCP leaf set").
+ *
+ * One kernel covers the reference's ~150 leaf functions (C_DEFAULT/EbMcp_C.c; tables Codec/EbMcpTables.c:14-745):
+ * luma 8-tap at the 16 quarter-pel positions, chroma 4-tap at the 64 eighth-pel positions, clipped uni-prediction
+ * output or biased int16 raw output for bi-prediction, 8- and 10-bit samples - they are all the H.265 8.5.3.3.3
+ * separable filter with the fixed-point conventions listed in oracle/svt_oracle_mcp.c.
+ * One workgroup per prediction block; 2-D positions run the horizontal pass into LDS (int16, h + taps - 1 rows),
+ * barrier, vertical pass.  Plus BiPredClipping(16bit): average of two raw blocks.
+ * Bound: HBM for the copy / 1-D positions (1-2 bytes in, 1-2 out per sample), ALU-light otherwise.
+ */
+#include "leaf_util.h"
+
+struct McpBlock { int32_t ref_off, dst_off; uint16_t w, h; uint8_t fx, fy, pad[2]; }; /* = SvtAmdMcpBlock */
+struct BiBlock { int32_t l0_off, l1_off, dst_off; uint16_t w, h; };                     /* = SvtAmdBiPredBlock */
+
+__device__ __constant__ int8_t c_luma_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0},
+                                                    {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+__device__ __constant__ int8_t c_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
+                                                      {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mcp(const T *__restrict__ ref, int rstride, void *__restrict__ dst, int dstride,
+                                             const McpBlock *__restrict__ blocks, int chroma, int out_raw)
+{
+    __shared__ int16_t tmp[(64 + 7) * 64];
+    const McpBlock b = blocks[blockIdx.x];
+    const int w = b.w, h = b.h, fx = b.fx, fy = b.fy, t = threadIdx.x;
+    const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3;
+    const int8_t *tx = chroma ? c_chroma_taps[fx & 7] : c_luma_taps[fx & 3];
+    const int8_t *ty = chroma ? c_chroma_taps[fy & 7] : c_luma_taps[fy & 3];
+    constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
+    const int B = (sizeof(T) == 2 || !chroma) ? 8192 : 0;
+    const T *r0 = ref + b.ref_off;
+    const int ds = out_raw ? w : dstride;
+    const bool two_d = fx && fy;
+    if (two_d) {
+        const int rows = h + ntaps - 1;
+        for (int i = t; i < rows * w; i += 256) {
+            const int j = i / w, x = i - j * w;
+            const T *p = r0 + (ptrdiff_t)(j + first) * rstride + x + first;
+            int hs = 0;
+            for (int k = 0; k < ntaps; k++)
+                hs += tx[k] * (int)p[k];
+            tmp[i] = (int16_t)((hs - (B << s1)) >> s1);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < w * h; i += 256) {
+        const int y = i / w, x = i - y * w;
+        int v;
+        if (two_d) {
+            int sum = 0;
+            for (int j = 0; j < ntaps; j++)
+                sum += ty[j] * (int)tmp[(y + j) * w + x];
+            v = out_raw ? (sum >> 6) : min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
+        } else if (!fx && !fy) {
+            const int p = r0[(ptrdiff_t)y * rstride + x];
+            v = out_raw ? (int16_t)((p << (6 - s1)) - B) : p;
+        } else {
+            const ptrdiff_t step = fx ? 1 : rstride;
+            const T *p = r0 + (ptrdiff_t)y * rstride + x + first * step;
+            const int8_t *tp = fx ? tx : ty;
+            int sum = 0;
+            for (int k = 0; k < ntaps; k++)
+                sum += tp[k] * (int)p[k * step];
+            v = out_raw ? ((sum - (B << s1)) >> s1) : min(maxv, max(0, (sum + 32) >> 6));
+        }
+        if (out_raw)
+            ((int16_t *)dst)[b.dst_off + y * ds + x] = (int16_t)v;
+        else
+            ((T *)dst)[b.dst_off + (ptrdiff_t)y * ds + x] = (T)v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bipred_clip(const int16_t *__restrict__ l0, const int16_t *__restrict__ l1,
+                                                     T *__restrict__ dst, int dstride, const BiBlock *__restrict__ blocks,
+                                                     int offset)
+{
+    const BiBlock b = blocks[blockIdx.x];
+    const int w = b.w, h = b.h;
+    for (int i = threadIdx.x; i < w * h; i += 256) {
+        const int y = i / w, x = i - y * w;
+        const int s = (int)l0[b.l0_off + i] + (int)l1[b.l1_off + i];
+        dst[b.dst_off + (ptrdiff_t)y * dstride + x] =
+            sizeof(T) == 1 ? (T)min(255, max(0, (s + offset) >> 7)) : (T)min(1023, max(0, (s + 16400) >> 5));
+    }
+}
+
+static int check_blocks_args(SvtAmdContext *ctx, const void *a, const void *b, const void *c, uint32_t n, int bps)
+{
+    if (!ctx || !a || !b || !c || !n || (bps != 1 && bps != 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_mcp_batch(SvtAmdContext *ctx, int bytes_per_sample, int chroma, int out_raw, const void *d_ref,
+                                 uint32_t refStride, void *d_dst, uint32_t dstStride, const SvtAmdMcpBlock *d_blocks,
+                                 uint32_t nblocks)
+{
+    int rc = check_blocks_args(ctx, d_ref, d_dst, d_blocks, nblocks, bytes_per_sample);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes_per_sample == 1)
+        hipLaunchKernelGGL(k_mcp<uint8_t>, dim3(nblocks), dim3(256), 0, ctx->stream, (const uint8_t *)d_ref, (int)refStride,
+                           d_dst, (int)dstStride, (const McpBlock *)d_blocks, chroma, out_raw);
+    else
+        hipLaunchKernelGGL(k_mcp<uint16_t>, dim3(nblocks), dim3(256), 0, ctx->stream, (const uint16_t *)d_ref, (int)refStride,
+                           d_dst, (int)dstStride, (const McpBlock *)d_blocks, chroma, out_raw);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_bipred_clip_batch(SvtAmdContext *ctx, int bytes_per_sample, const int16_t *d_l0, const int16_t *d_l1,
+                                         void *d_dst, uint32_t dstStride, int32_t offset, const SvtAmdBiPredBlock *d_blocks,
+                                         uint32_t nblocks)
+{
+    int rc = check_blocks_args(ctx, d_l0, d_l1, d_blocks, nblocks, bytes_per_sample);
+    if (rc || !d_dst)
+        return rc ? rc : SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes_per_sample == 1)
+        hipLaunchKernelGGL(k_bipred_clip<uint8_t>, dim3(nblocks), dim3(256), 0, ctx->stream, d_l0, d_l1, (uint8_t *)d_dst,
+                           (int)dstStride, (const BiBlock *)d_blocks, offset);
+    else
+        hipLaunchKernelGGL(k_bipred_clip<uint16_t>, dim3(nblocks), dim3(256), 0, ctx->stream, d_l0, d_l1, (uint16_t *)d_dst,
+                           (int)dstStride, (const BiBlock *)d_blocks, offset);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* ---------------- LEAF wrappers (host pointers, reference signatures) ---------------- */
+/* exact extent of reference samples the (fx,fy) position reads, relative to the block */
+static void tap_extent(int chroma, int f, int *lo, int *hi)
+{
+    if (!f) {
+        *lo = 0, *hi = 0;
+    } else if (chroma) {
+        *lo = -1, *hi = 2;
+    } else {
+        *lo = f == 3 ? -2 : -3, *hi = f == 1 ? 3 : 4;
+    }
+}
+
+template <typename T>
+static void mcp_leaf(int chroma, int out_raw, int fx, int fy, const T *refPic, uint32_t srcStride, void *dst, uint32_t dstStride,
+                     uint32_t w, uint32_t h)
+{
+    if (!w || !h || w > 64 || h > 64) {
+        svt_amd_set_error("mcp leaf: block %ux%u not supported", w, h);
+        return;
+    }
+    int xlo, xhi, ylo, yhi;
+    tap_extent(chroma, fx, &xlo, &xhi);
+    tap_extent(chroma, fy, &ylo, &yhi);
+    const T *first = refPic + (ptrdiff_t)ylo * srcStride + xlo;
+    const size_t rsamples = span(srcStride, w + xhi - xlo, h + yhi - ylo);
+    const size_t dbytes = out_raw ? (size_t)w * h * 2 : span(dstStride, w, h) * sizeof(T);
+    DBuf r(first, rsamples * sizeof(T)), d(dst, dbytes), bl(nullptr, sizeof(McpBlock), false);
+    if (!(r.ok && d.ok && bl.ok))
+        return;
+    McpBlock hb = {(int32_t)(-(ptrdiff_t)ylo * srcStride - xlo), 0, (uint16_t)w, (uint16_t)h, (uint8_t)fx, (uint8_t)fy, {0, 0}};
+    if (hipMemcpy(bl.d, &hb, sizeof(hb), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    hipLaunchKernelGGL(k_mcp<T>, dim3(1), dim3(256), 0, 0, (const T *)r.d, (int)srcStride, (void *)d.d, (int)dstStride,
+                       (const McpBlock *)bl.d, chroma, out_raw);
+    if (finish("mcp"))
+        d.download(dst, dbytes);
+}
+
+#define LUMA_POS(M) M(a, 1, 0) M(b, 2, 0) M(c, 3, 0) M(d, 0, 1) M(e, 1, 1) M(f, 2, 1) M(g, 3, 1) M(h, 0, 2) M(i, 1, 2) \
+    M(j, 2, 2) M(k, 3, 2) M(n, 0, 3) M(p, 1, 3) M(q, 2, 3) M(r, 3, 3)
+
+#define UNI8(pos, fx, fy)                                                                                                   \
+    extern "C" void svt_amd_LumaInterpolationFilterPos##pos##New(uint8_t *refPic, uint32_t srcStride, uint8_t *dst,         \
+                                                                 uint32_t dstStride, uint32_t puWidth, uint32_t puHeight,   \
+                                                                 int16_t *firstPassIFDst)                                   \
+    { (void)firstPassIFDst; mcp_leaf<uint8_t>(0, 0, fx, fy, refPic, srcStride, dst, dstStride, puWidth, puHeight); }
+#define UNI16(pos, fx, fy)                                                                                                  \
+    extern "C" void svt_amd_LumaInterpolationFilterPos##pos##New16bit(uint16_t *refPic, uint32_t srcStride, uint16_t *dst,  \
+                                                                      uint32_t dstStride, uint32_t puWidth,                 \
+                                                                      uint32_t puHeight, int16_t *firstPassIFDst)           \
+    { (void)firstPassIFDst; mcp_leaf<uint16_t>(0, 0, fx, fy, refPic, srcStride, dst, dstStride, puWidth, puHeight); }
+#define RAW8(pos, fx, fy)                                                                                                   \
+    extern "C" void svt_amd_LumaInterpolationFilterPos##pos##OutRaw(uint8_t *refPic, uint32_t srcStride, int16_t *dst,      \
+                                                                    uint32_t puWidth, uint32_t puHeight,                    \
+                                                                    int16_t *firstPassIFDst)                                \
+    { (void)firstPassIFDst; mcp_leaf<uint8_t>(0, 1, fx, fy, refPic, srcStride, dst, 0, puWidth, puHeight); }
+#define RAW16(pos, fx, fy)                                                                                                  \
+    extern "C" void svt_amd_LumaInterpolationFilterPos##pos##OutRaw16bit(uint16_t *refPic, uint32_t srcStride, int16_t *dst, \
+                                                                         uint32_t puWidth, uint32_t puHeight,               \
+                                                                         int16_t *firstPassIFDst)                           \
+    { (void)firstPassIFDst; mcp_leaf<uint16_t>(0, 1, fx, fy, refPic, srcStride, dst, 0, puWidth, puHeight); }
+LUMA_POS(UNI8)
+LUMA_POS(UNI16)
+LUMA_POS(RAW8)
+LUMA_POS(RAW16)
+
+extern "C" void svt_amd_LumaInterpolationCopy(uint8_t *refPic, uint32_t srcStride, uint8_t *dst, uint32_t dstStride,
+                                              uint32_t puWidth, uint32_t puHeight, int16_t *firstPassIFDst)
+{ (void)firstPassIFDst; mcp_leaf<uint8_t>(0, 0, 0, 0, refPic, srcStride, dst, dstStride, puWidth, puHeight); }
+extern "C" void svt_amd_LumaInterpolationCopy16bit(uint16_t *refPic, uint32_t srcStride, uint16_t *dst, uint32_t dstStride,
+                                                   uint32_t puWidth, uint32_t puHeight, int16_t *firstPassIFDst)
+{ (void)firstPassIFDst; mcp_leaf<uint16_t>(0, 0, 0, 0, refPic, srcStride, dst, dstStride, puWidth, puHeight); }
+extern "C" void svt_amd_LumaInterpolationCopyOutRaw(uint8_t *refPic, uint32_t srcStride, int16_t *dst, uint32_t puWidth,
+                                                    uint32_t puHeight, int16_t *firstPassIFDst)
+{ (void)firstPassIFDst; mcp_leaf<uint8_t>(0, 1, 0, 0, refPic, srcStride, dst, 0, puWidth, puHeight); }
+extern "C" void svt_amd_LumaInterpolationCopyOutRaw16bit(uint16_t *refPic, uint32_t srcStride, int16_t *dst, uint32_t puWidth,
+                                                         uint32_t puHeight, int16_t *firstPassIFDst)
+{ (void)firstPassIFDst; mcp_leaf<uint16_t>(0, 1, 0, 0, refPic, srcStride, dst, 0, puWidth, puHeight); }
+
+/* chroma: Copy ignores the fractions, OneD filters along x when fracPosx != 0 else along y, TwoD both */
+#define CH_UNI(name, T, FX, FY)                                                                                             \
+    extern "C" void svt_amd_##name(T *refPic, uint32_t srcStride, T *dst, uint32_t dstStride, uint32_t puWidth,             \
+                                   uint32_t puHeight, int16_t *firstPassIFDst, uint32_t fracPosx, uint32_t fracPosy)        \
+    { (void)firstPassIFDst; (void)fracPosx; (void)fracPosy;                                                                 \
+      mcp_leaf<T>(1, 0, (int)(FX), (int)(FY), refPic, srcStride, dst, dstStride, puWidth, puHeight); }
+#define CH_RAW(name, T, FX, FY)                                                                                             \
+    extern "C" void svt_amd_##name(T *refPic, uint32_t srcStride, int16_t *dst, uint32_t puWidth, uint32_t puHeight,        \
+                                   int16_t *firstPassIFDst, uint32_t fracPosx, uint32_t fracPosy)                           \
+    { (void)firstPassIFDst; (void)fracPosx; (void)fracPosy;                                                                 \
+      mcp_leaf<T>(1, 1, (int)(FX), (int)(FY), refPic, srcStride, dst, 0, puWidth, puHeight); }
+CH_UNI(ChromaInterpolationCopy, uint8_t, 0, 0)
+CH_UNI(ChromaInterpolationFilterOneD, uint8_t, fracPosx & 7, fracPosx ? 0 : (fracPosy & 7))
+CH_UNI(ChromaInterpolationFilterTwoD, uint8_t, fracPosx & 7, fracPosy & 7)
+CH_UNI(ChromaInterpolationCopy16bit, uint16_t, 0, 0)
+CH_UNI(ChromaInterpolationFilterOneD16bit, uint16_t, fracPosx & 7, fracPosx ? 0 : (fracPosy & 7))
+CH_UNI(ChromaInterpolationFilterTwoD16bit, uint16_t, fracPosx & 7, fracPosy & 7)
+CH_RAW(ChromaInterpolationCopyOutRaw, uint8_t, 0, 0)
+CH_RAW(ChromaInterpolationFilterOneDOutRaw, uint8_t, fracPosx & 7, fracPosx ? 0 : (fracPosy & 7))
+CH_RAW(ChromaInterpolationFilterTwoDOutRaw, uint8_t, fracPosx & 7, fracPosy & 7)
+CH_RAW(ChromaInterpolationCopyOutRaw16bit, uint16_t, 0, 0)
+CH_RAW(ChromaInterpolationFilterOneDOutRaw16bit, uint16_t, fracPosx & 7, fracPosx ? 0 : (fracPosy & 7))
+CH_RAW(ChromaInterpolationFilterTwoDOutRaw16bit, uint16_t, fracPosx & 7, fracPosy & 7)
+
+template <typename T>
+static void bipred_leaf(uint32_t w, uint32_t h, int16_t *l0, int16_t *l1, T *dst, uint32_t dstStride, int32_t offset)
+{
+    const size_t n = (size_t)w * h, dbytes = span(dstStride, w, h) * sizeof(T);
+    DBuf a(l0, n * 2), b(l1, n * 2), d(dst, dbytes), bl(nullptr, sizeof(BiBlock), false);
+    if (!(a.ok && b.ok && d.ok && bl.ok) || !n)
+        return;
+    BiBlock hb = {0, 0, 0, (uint16_t)w, (uint16_t)h};
+    if (hipMemcpy(bl.d, &hb, sizeof(hb), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    hipLaunchKernelGGL(k_bipred_clip<T>, dim3(1), dim3(256), 0, 0, (const int16_t *)a.d, (const int16_t *)b.d, (T *)d.d,
+                       (int)dstStride, (const BiBlock *)bl.d, offset);
+    if (finish("BiPredClipping"))
+        d.download(dst, dbytes);
+}
+extern "C" void svt_amd_BiPredClipping(uint32_t puWidth, uint32_t puHeight, int16_t *list0Src, int16_t *list1Src,
+                                       uint8_t *dst, uint32_t dstStride, int32_t offset)
+{ bipred_leaf<uint8_t>(puWidth, puHeight, list0Src, list1Src, dst, dstStride, offset); }
+extern "C" void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight, int16_t *list0Src, int16_t *list1Src,
+                                            uint16_t *dst, uint32_t dstStride)
+{ bipred_leaf<uint16_t>(puWidth, puHeight, list0Src, list1Src, dst, dstStride, 0); }
