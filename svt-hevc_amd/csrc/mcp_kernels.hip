@@ -34,13 +34,16 @@ __global__ __launch_bounds__(256) void k_mcp(const T *__restrict__ ref, int rstr
     const T *r0 = ref + b.ref_off;
     const int ds = out_raw ? w : dstride;
     const bool two_d = fx && fy;
+    /* only the taps the reference's own functions read (the 7-tap quarter positions never touch the 8th sample) */
+    const int kx0 = (!chroma && fx == 3) ? 1 : 0, kx1 = (!chroma && fx == 1) ? 7 : ntaps;
+    const int ky0 = (!chroma && fy == 3) ? 1 : 0, ky1 = (!chroma && fy == 1) ? 7 : ntaps;
     if (two_d) {
-        const int rows = h + ntaps - 1;
+        const int rows = h + ky1 - ky0 - 1; /* tmp row j = reference row j + first + ky0 */
         for (int i = t; i < rows * w; i += 256) {
             const int j = i / w, x = i - j * w;
-            const T *p = r0 + (ptrdiff_t)(j + first) * rstride + x + first;
+            const T *p = r0 + (ptrdiff_t)(j + first + ky0) * rstride + x + first;
             int hs = 0;
-            for (int k = 0; k < ntaps; k++)
+            for (int k = kx0; k < kx1; k++)
                 hs += tx[k] * (int)p[k];
             tmp[i] = (int16_t)((hs - (B << s1)) >> s1);
         }
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(256) void k_mcp(const T *__restrict__ ref, int rstr
         int v;
         if (two_d) {
             int sum = 0;
-            for (int j = 0; j < ntaps; j++)
-                sum += ty[j] * (int)tmp[(y + j) * w + x];
+            for (int j = ky0; j < ky1; j++)
+                sum += ty[j] * (int)tmp[(y + j - ky0) * w + x];
             v = out_raw ? (sum >> 6) : min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
         } else if (!fx && !fy) {
             const int p = r0[(ptrdiff_t)y * rstride + x];
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void k_mcp(const T *__restrict__ ref, int rstr
             const T *p = r0 + (ptrdiff_t)y * rstride + x + first * step;
             const int8_t *tp = fx ? tx : ty;
             int sum = 0;
-            for (int k = 0; k < ntaps; k++)
+            for (int k = fx ? kx0 : ky0; k < (fx ? kx1 : ky1); k++)
                 sum += tp[k] * (int)p[k * step];
             v = out_raw ? ((sum - (B << s1)) >> s1) : min(maxv, max(0, (sum + 32) >> 6));
         }
