@@ -239,6 +239,20 @@ SVT_AMD_API int svt_amd_ois_picture(SvtAmdContext *ctx, const SvtAmdOisParams *p
                                     const SvtAmdMeLcuResult *me, SvtAmdOisLcuResult *out);
 SVT_AMD_API int svt_amd_ois_picture_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot);
 SVT_AMD_API int svt_amd_ois_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out);
+/*
+ * Collocated zero-motion SAD at 1/16 resolution and the background classes derived from it: replaces
+ * ComputeDecimatedZzSad (EbMotionEstimationProcess.c:176-300, called per ME segment at :828 when lookAheadDistance != 0
+ * and pictureNumber > 0).  prev_slot = the previous picture in display order; results are what the reference stores
+ * into the PREVIOUS picture's zzCostArray / nonMovingIndexArray.  out: HOST array, one record per LCU.  Blocking.
+ */
+typedef struct SvtAmdZzLcu {
+    uint32_t sad;              /* decimatedLcuCollocatedSad (0xFFFFFFFF for incomplete LCUs)     */
+    uint8_t  zz_cost;          /* zzCostArray[lcu]: 0 / 3 / 10 / 20 / 30, 0xFF = INVALID_ZZ_COST */
+    uint8_t  non_moving_index; /* nonMovingIndexArray[lcu]: 0 / 10 / 20 / 30                     */
+    uint8_t  pad[2];
+} SvtAmdZzLcu;
+SVT_AMD_API int svt_amd_zz_sad_picture(SvtAmdContext *ctx, int cur_slot, int prev_slot, SvtAmdZzLcu *out);
+
 /* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
 typedef struct SvtAmdOisJob {
     SvtAmdOisParams params;

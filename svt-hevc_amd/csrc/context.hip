@@ -626,3 +626,27 @@ extern "C" int svt_amd_ois_picture(SvtAmdContext *ctx, const SvtAmdOisParams *pa
         return rc;
     return svt_amd_ois_picture_fetch(ctx, cur_slot, out);
 }
+
+/* ---- collocated zero-motion SAD -------------------------------------------- */
+extern "C" int svt_amd_zz_sad_picture(SvtAmdContext *ctx, int cur_slot, int prev_slot, SvtAmdZzLcu *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (!rc)
+        rc = check_slot(ctx, prev_slot);
+    if (rc)
+        return rc;
+    DevPicture *c = &ctx->slots[cur_slot], *p = &ctx->slots[prev_slot];
+    if (!out || !c->valid || !p->valid || c->width != p->width || c->height != p->height) {
+        svt_amd_set_error("svt_amd_zz_sad_picture: bad parameter (slots %d, %d)", cur_slot, prev_slot);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    /* results are small (8 B / LCU): reuse the head of the ME scratch buffer */
+    SvtAmdZzLcu *d_out = (SvtAmdZzLcu *)ctx->d_me_scratch;
+    if ((rc = svt_amd_launch_zz_sad(ctx, c, p, d_out)) != 0)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)nlcu * sizeof(SvtAmdZzLcu), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}

@@ -451,3 +451,49 @@ int svt_amd_launch_ois_batch(SvtAmdContext *ctx, const OisJobDev *host_jobs, int
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * ComputeDecimatedZzSad (EbMotionEstimationProcess.c:176-300): one wavefront per LCU; the previous picture's
+ * 1/16 plane IS the collocated LCU decimated by 4 (Decimation2D is a point sub-sampler), so both operands
+ * come from the planes prep already built.  Lane = (row, 4-sample group): one v_sad_u8.
+ * --------------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void k_zz_sad(const uint8_t *__restrict__ cur16, const uint8_t *__restrict__ prev16,
+                                                int pitch, int width, int height, int nlcu, int lcus_w,
+                                                SvtAmdZzLcu *__restrict__ out)
+{
+    const int lcu = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (lcu >= nlcu)
+        return;
+    const int ox = (lcu % lcus_w) * 64, oy = (lcu / lcus_w) * 64;
+    const int lw = min(64, width - ox), lh = min(64, height - oy);
+    uint32_t sad = ~0u;
+    uint8_t zz = 0xFF;
+    if (lw == 64 && lh == 64) {
+        const int r = lane >> 2, g = (lane & 3) << 2;
+        const ptrdiff_t at = (ptrdiff_t)((oy >> 2) + r) * pitch + (ox >> 2) + g;
+        uint32_t s = __builtin_amdgcn_sad_u8(*(const uint32_t *)(cur16 + at), *(const uint32_t *)(prev16 + at), 0u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            s += __shfl_xor(s, o);
+        sad = s;
+        zz = sad < 256 ? 0 : sad < 512 ? 3 : sad < 1024 ? 10 : sad < 2048 ? 20 : 30;
+    }
+    if (lane == 0) {
+        const uint32_t area = (uint32_t)((lw >> 2) * (lh >> 2));
+        SvtAmdZzLcu o;
+        o.sad = sad, o.zz_cost = zz;
+        o.non_moving_index = sad < area * 2 ? 0 : sad < area * 4 ? 10 : sad < area * 8 ? 20 : 30;
+        o.pad[0] = o.pad[1] = 0;
+        out[lcu] = o;
+    }
+}
+
+int svt_amd_launch_zz_sad(SvtAmdContext *ctx, const DevPicture *cur, const DevPicture *prev, SvtAmdZzLcu *d_out)
+{
+    const int lw = (cur->width + 63) / 64, lh = (cur->height + 63) / 64;
+    hipLaunchKernelGGL(k_zz_sad, dim3((lw * lh + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t *)cur->sixteenth.origin,
+                       (const uint8_t *)prev->sixteenth.origin, (int)cur->sixteenth.pitch, (int)cur->width, (int)cur->height,
+                       lw * lh, lw, d_out);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}

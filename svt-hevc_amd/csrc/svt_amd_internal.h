@@ -103,6 +103,7 @@ int svt_amd_launch_prep(SvtAmdContext *ctx, DevPicture *pic, const uint8_t *d_lu
 int svt_amd_launch_prep_batch(SvtAmdContext *ctx, DevPicture *const *pics, const uint8_t *const *d_luma, uint32_t stride,
                               int n);
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus);
+int svt_amd_launch_zz_sad(SvtAmdContext *ctx, const DevPicture *cur, const DevPicture *prev, SvtAmdZzLcu *d_out);
 int svt_amd_launch_ois_batch(SvtAmdContext *ctx, const struct OisJobDev *host_jobs, int njobs, int max_lcus);
 
 static inline PicView make_view(const DevPicture *p)

@@ -126,3 +126,20 @@ def test_ois_batch_matches_single(product, gpu_ctx, oracle):
         got = np.zeros(n, S.OIS_LCU_DTYPE)
         assert product.svt_amd_ois_picture_fetch(gpu_ctx, t, got.ctypes.data) == 0
         assert same(got, S.oracle_ois_picture(oracle, params, frames[t], mes[t]))
+
+
+@pytest.mark.parametrize("kind,w,h", [("motion", 416, 240), ("flat", 320, 256), ("noise", 328, 264), ("motion", 1920, 1080)])
+def test_zz_sad_matches_oracle(product, gpu_ctx, oracle, kind, w, h):
+    """ComputeDecimatedZzSad on the device (1/16 planes of two slots) vs the oracle."""
+    from test_oracle_zz import ZZ, oracle_zz
+    cur, prev = S.gen_luma(kind, w, h, 3, 7), S.gen_luma(kind, w, h, 2, 7)
+    if kind == "motion":
+        cur = cur.copy()
+        cur[:, :192] = prev[:, :192]
+    upload(product, gpu_ctx, 0, prev)
+    upload(product, gpu_ctx, 1, cur)
+    got = np.zeros(S.lcu_count(w, h), ZZ)
+    product.svt_amd_zz_sad_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert product.svt_amd_zz_sad_picture(gpu_ctx, 1, 0, got.ctypes.data) == 0, product.svt_amd_last_error()
+    want = oracle_zz(oracle, cur, prev)
+    assert np.array_equal(got, want)
