@@ -931,31 +931,42 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 (&S.dsad[0][0])[i] = 0;
             }
             __syncthreads();
+            /* item = (PU, position k, row chunk): chunk counts {32, 8, 2, 1} per tier give every lane the same
+             * ~16 dword SADs; the chunks of one (PU, k) sit on adjacent lanes and are summed with a segmented
+             * shuffle, so S.dist is written once per (PU, k) - no LDS atomics. */
+            const int tier_lc[4] = {5, 3, 1, 0}; /* log2(chunks) */
             for (int tier = 0; tier < 4; tier++) {
                 if (!en[tier])
                     continue;
-                const int sz = tier_sz[tier], rows = sz / rstep, items = tier_cnt[tier] * 8 * rows;
+                const int sz = tier_sz[tier], rows = sz / rstep, lc = tier_lc[tier], rpc = rows >> lc;
+                const int items = tier_cnt[tier] * 8 << lc; /* a multiple of NT: whole waves, no tail */
                 for (int i = t; i < items; i += NT) {
-                    const int row = i % rows, k = (i / rows) & 7, n = tier_first[tier] + i / (rows * 8);
+                    const int ch = i & ((1 << lc) - 1), k = (i >> lc) & 7, n = tier_first[tier] + (i >> (lc + 3));
                     int px_, py_, psz;
                     pu_geom_z(n, px_, py_, psz);
                     const uint32_t mv = S.best_mv[list][n];
-                    const int ax = ox + px_ + (mvx(mv) >> 2), ay = oy + py_ + (mvy(mv) >> 2) + row * rstep;
                     /* order L,R,T,B,TL,TR,BR,BL: planes b,b,h,h,j,j,j,j; offsets */
                     const LWin &pl = (k < 2) ? wB : (k < 4 ? wH : wJ);
                     const int ddx = (k == 1 || k == 5 || k == 6) ? 1 : 0, ddy = (k == 3 || k == 6 || k == 7) ? 1 : 0;
-                    const uint8_t *r = wat(pl, ax + ddx, ay + ddy);
-                    const uint8_t *s = &S.src[(py_ + row * rstep) * LCU + px_];
+                    const int y0 = ch * rpc * rstep;
+                    const uint8_t *r = wat(pl, ox + px_ + (mvx(mv) >> 2) + ddx, oy + py_ + (mvy(mv) >> 2) + y0 + ddy);
+                    const uint8_t *sp = &S.src[(py_ + y0) * LCU + px_];
                     uint32_t d = 0, sd = 0;
-                    for (int x = 0; x < sz; x += 8) {
-                        uint32_t v[2];
-                        lds_ld_unaligned<2>(r + x, v);
-                        row_metric(method, *(const uint32_t *)(s + x), v[0], d, sd);
-                        row_metric(method, *(const uint32_t *)(s + x + 4), v[1], d, sd);
+                    for (int rr = 0; rr < rpc; rr++) {
+                        for (int x = 0; x < sz; x += 8) {
+                            uint32_t v[2];
+                            lds_ld_unaligned<2>(r + x, v);
+                            row_metric(method, *(const uint32_t *)(sp + x), v[0], d, sd);
+                            row_metric(method, *(const uint32_t *)(sp + x + 4), v[1], d, sd);
+                        }
+                        r += pl.stride * rstep, sp += LCU * rstep;
                     }
-                    atomicAdd(&S.dist[n][k], d);
-                    if (method == SVT_AMD_SSD_SEARCH)
-                        atomicAdd(&S.dsad[n][k], sd);
+                    for (int o = 1; o < (1 << lc); o <<= 1)
+                        d += __shfl_xor(d, o), sd += __shfl_xor(sd, o);
+                    if (ch == 0) {
+                        S.dist[n][k] = d;
+                        S.dsad[n][k] = sd;
+                    }
                 }
             }
             /* SSD search also needs the SSE of the full-pel winner (:798-806) */
@@ -1022,50 +1033,58 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 (&S.dsad[0][0])[i] = 0;
             }
             __syncthreads();
+            /* only the three positions next to the half-pel winner are evaluated (:1252-1273): item =
+             * (PU, j in 0..2, row chunk); position code = winner direction + j - 1 on the ring
+             * TL,T,TR,R,BR,B,BL,L (mirrored when the MV already sits on a half-pel position). */
             for (int tier = 0; tier < 4; tier++) {
                 if (!qen[tier])
                     continue;
                 const int sz = tier == 0 ? 32 : tier_sz[tier]; /* the 64x64 call passes 32x32 (:1677) */
-                const int rows = sz / rstep, items = tier_cnt[tier] * 8 * rows;
-                for (int i = t; i < items; i += NT) {
-                    const int row = i % rows, k = (i / rows) & 7, n = tier_first[tier] + i / (rows * 8);
+                const int lc = tier == 0 ? 3 : tier_lc[tier], rows = sz / rstep, rpc = rows >> lc;
+                const int items = tier_cnt[tier] * 3 << lc;
+                for (int i0 = 0; i0 < items; i0 += NT) { /* uniform trips: whole waves join the shuffles */
+                    const int i = i0 + t;
+                    const bool live = i < items;
+                    const int ii = live ? i : 0;
+                    const int ch = ii & ((1 << lc) - 1), pj = ii >> lc, pidx = pj / 3, j = pj - pidx * 3;
+                    const int n = tier_first[tier] + pidx;
                     int px_, py_, psz;
                     pu_geom_z(n, px_, py_, psz);
                     const uint32_t mv = S.best_mv[list][n];
                     const int xMv = mvx(mv), yMv = mvy(mv);
                     const int qm = (yMv & 2) + ((xMv & 2) >> 1);
-                    const int sd = S.dir[list][n];
-                    /* validity: position k (L,R,T,B,TL,TR,BR,BL) is tested when the half-pel
-                     * winner direction lies within +-1 step of it (mirrored when the MV is
-                     * already on a half-pel position), :1252-1273 */
-                    /* ring order of directions: TL,T,TR,R,BR,B,BL,L == codes 0..7 */
-                    const int kcode[8] = {D_L, D_R, D_T, D_B, D_TL, D_TR, D_BR, D_BL};
-                    const int target = qm ? ((kcode[k] + 4) & 7) : kcode[k];
-                    const int diff = (sd - target) & 7;
-                    if (!(diff == 0 || diff == 1 || diff == 7))
-                        continue;
-                    const int y = row * rstep;
+                    const int code = (S.dir[list][n] + j - 1 + (qm ? 4 : 0)) & 7;
+                    const int k = (int)((0x07361524u >> (4 * code)) & 7u); /* direction code -> position index */
+                    const int y = ch * rpc * rstep;
                     const int ax = ox + px_ + ((xMv + 2) >> 2), ay = oy + py_ + ((yMv + 2) >> 2) + y;
                     const QSrc q0 = c_qtab[qm][k][0], q1 = c_qtab[qm][k][1];
                     const LWin &w1 = q0.plane == 0 ? wF : q0.plane == 1 ? wB : q0.plane == 2 ? wH : wJ;
                     const LWin &w2 = q1.plane == 0 ? wF : q1.plane == 1 ? wB : q1.plane == 2 ? wH : wJ;
                     const uint8_t *r1 = wat(w1, ax + q0.dx, ay + q0.dy);
                     const uint8_t *r2 = wat(w2, ax + q1.dx, ay + q1.dy);
-                    /* source = MeContext_t.lcuBuffer: zero outside the picture (trap A19) */
-                    const int inside_y = (py_ + y) < lh;
-                    const uint8_t *s = &S.src[(py_ + y) * LCU + px_];
+                    const uint8_t *sp = &S.src[(py_ + y) * LCU + px_];
                     uint32_t d = 0, sdv = 0;
-                    for (int x = 0; x < sz; x += 8) {
-                        uint32_t v1[2], v2[2];
-                        lds_ld_unaligned<2>(r1 + x, v1);
-                        lds_ld_unaligned<2>(r2 + x, v2);
-                        const int in = inside_y && (px_ + x) < lw; /* lw is a multiple of 8 */
-                        row_metric(method, in ? *(const uint32_t *)(s + x) : 0u, avg4(v1[0], v2[0]), d, sdv);
-                        row_metric(method, in ? *(const uint32_t *)(s + x + 4) : 0u, avg4(v1[1], v2[1]), d, sdv);
+                    if (live) {
+                        for (int rr = 0; rr < rpc; rr++) {
+                            /* source = MeContext_t.lcuBuffer: zero outside the picture (trap A19) */
+                            const int inside_y = (py_ + y + rr * rstep) < lh;
+                            for (int x = 0; x < sz; x += 8) {
+                                uint32_t v1[2], v2[2];
+                                lds_ld_unaligned<2>(r1 + x, v1);
+                                lds_ld_unaligned<2>(r2 + x, v2);
+                                const int in = inside_y && (px_ + x) < lw; /* lw is a multiple of 8 */
+                                row_metric(method, in ? *(const uint32_t *)(sp + x) : 0u, avg4(v1[0], v2[0]), d, sdv);
+                                row_metric(method, in ? *(const uint32_t *)(sp + x + 4) : 0u, avg4(v1[1], v2[1]), d, sdv);
+                            }
+                            r1 += w1.stride * rstep, r2 += w2.stride * rstep, sp += LCU * rstep;
+                        }
                     }
-                    atomicAdd(&S.dist[n][k], d);
-                    if (method == SVT_AMD_SSD_SEARCH)
-                        atomicAdd(&S.dsad[n][k], sdv);
+                    for (int o = 1; o < (1 << lc); o <<= 1)
+                        d += __shfl_xor(d, o), sdv += __shfl_xor(sdv, o);
+                    if (live && ch == 0) {
+                        S.dist[n][k] = d;
+                        S.dsad[n][k] = sdv;
+                    }
                 }
             }
             __syncthreads();

@@ -64,6 +64,7 @@ def test_intra_batched(libs, gpu_ctx, bps):
         ang = KERNELS[mode][2]
         angle = -17 if ang else 0
         off = 2 * size + 4 if ang else 0
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         assert product.svt_amd_intra_pred_batch(gpu_ctx, mode, bps, size, 0, angle, d_refs.data_ptr(), pitch, off,
                                                 d_pred.data_ptr(), n) == 0
         assert product.svt_amd_synchronize(gpu_ctx) == 0

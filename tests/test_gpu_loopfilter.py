@@ -108,6 +108,7 @@ def test_dlf_picture_batched(libs, gpu_ctx, bps):
         e = np.array(edges, dtype=np.int64)
         arr["offset"], arr["tc"], arr["beta"], arr["v"] = e[:, 0], e[:, 1], e[:, 2], e[:, 3]
         d_edges = torch.from_numpy(arr.view(np.uint8).copy()).cuda()
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         rc = product.svt_amd_dlf_luma_edges_batch(gpu_ctx, dev.data_ptr(), w, bps, d_edges.data_ptr(), len(edges))
         assert rc == 0, product.svt_amd_last_error()
         product.svt_amd_synchronize(gpu_ctx)
@@ -136,6 +137,7 @@ def test_dlf_chroma_batched(libs, gpu_ctx):
         e = np.array(edges, dtype=np.int64)
         arr["offset"], arr["cb"], arr["cr"], arr["v"] = e[:, 0], e[:, 1], e[:, 2], e[:, 3]
         d_edges = torch.from_numpy(arr.view(np.uint8).copy()).cuda()
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         rc = product.svt_amd_dlf_chroma_edges_batch(gpu_ctx, db.data_ptr(), dr.data_ptr(), w, 1, d_edges.data_ptr(), len(edges))
         assert rc == 0, product.svt_amd_last_error()
         product.svt_amd_synchronize(gpu_ctx)
@@ -186,6 +188,7 @@ def test_sao_gather_picture(libs, gpu_ctx, bps):
     lw, lh = (w + 63) // 64, (h + 63) // 64
     for only in (0, 1):
         out = torch.zeros(lw * lh * STATS.itemsize, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         rc = product.svt_amd_sao_gather_picture(gpu_ctx, bps, ds.data_ptr(), st, dr.data_ptr(), st, w, h, 64, only, out.data_ptr())
         assert rc == 0, product.svt_amd_last_error()
         product.svt_amd_synchronize(gpu_ctx)
@@ -279,6 +282,7 @@ def test_pack_unpack_plane_roundtrip(libs, gpu_ctx, compressed):
         inn = (two << 6).astype(np.uint8)
     d8, dn = torch.from_numpy(in8).cuda(), torch.from_numpy(np.ascontiguousarray(inn)).cuda()
     d16 = torch.zeros((h, w), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     rc = product.svt_amd_pack_plane(gpu_ctx, d8.data_ptr(), w, dn.data_ptr(), inn.shape[1], compressed, d16.data_ptr(), w, w, h)
     assert rc == 0, product.svt_amd_last_error()
     product.svt_amd_synchronize(gpu_ctx)
@@ -289,6 +293,7 @@ def test_pack_unpack_plane_roundtrip(libs, gpu_ctx, compressed):
     fn(vp(P(in8)), u32(w), vp(P(inn)), vp(P(want)), u32(inn.shape[1]), u32(w), u32(w), u32(h))
     assert np.array_equal(got, want)
     o8, on = torch.zeros((h, w), dtype=torch.uint8, device="cuda"), torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     rc = product.svt_amd_unpack_plane(gpu_ctx, d16.data_ptr(), w, o8.data_ptr(), w, on.data_ptr(), w, w, h)
     assert rc == 0
     product.svt_amd_synchronize(gpu_ctx)

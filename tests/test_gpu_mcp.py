@@ -110,6 +110,7 @@ def test_mcp_batch_picture(product, gpu_ctx, oracle, bps):
     blocks["w"], blocks["h"], blocks["fx"], blocks["fy"] = 16, 16, mvx & 3, mvy & 3
     d_blocks = torch.from_numpy(blocks.view(np.uint8).copy()).cuda()
     d_dst = torch.zeros(W * H * bps, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     rc = product.svt_amd_mcp_batch(gpu_ctx, bps, 0, 0, d_ref.data_ptr(), st, d_dst.data_ptr(), W, d_blocks.data_ptr(), len(blocks))
     assert rc == 0, product.svt_amd_last_error()
     product.svt_amd_synchronize(gpu_ctx)
@@ -140,6 +141,7 @@ def test_mcp_batch_picture(product, gpu_ctx, oracle, bps):
     d_raw1 = torch.zeros(nx * ny * 256, dtype=torch.int16, device="cuda")
     for rb, d_raw in ((raw_blocks0, d_raw0), (raw_blocks1, d_raw1)):
         d_b = torch.from_numpy(rb.view(np.uint8).copy()).cuda()
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         assert product.svt_amd_mcp_batch(gpu_ctx, bps, 0, 1, d_ref.data_ptr(), st, d_raw.data_ptr(), 0, d_b.data_ptr(), len(rb)) == 0
         product.svt_amd_synchronize(gpu_ctx)
     bi = np.zeros(nx * ny, BI_BLOCK)
@@ -147,6 +149,7 @@ def test_mcp_batch_picture(product, gpu_ctx, oracle, bps):
     bi["dst_off"], bi["w"], bi["h"] = by * W + bx, 16, 16
     d_bi = torch.from_numpy(bi.view(np.uint8).copy()).cuda()
     d_dst.zero_()
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     assert product.svt_amd_bipred_clip_batch(gpu_ctx, bps, d_raw0.data_ptr(), d_raw1.data_ptr(), d_dst.data_ptr(), W,
                                              64 + 16384, d_bi.data_ptr(), len(bi)) == 0
     product.svt_amd_synchronize(gpu_ctx)

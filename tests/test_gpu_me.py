@@ -143,6 +143,7 @@ def test_batched_prep_equals_single(product, gpu_ctx):
         ptrs = (C.c_void_p * 3)(*[dev[i].data_ptr() for i in range(3)])
         product.svt_amd_picture_upload_device_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
                                                                 C.c_uint32, C.c_uint16, C.c_uint16]
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         assert product.svt_amd_picture_upload_device_batch(gpu_ctx, 3, slots, ptrs, stride, w, h) == 0, \
             product.svt_amd_last_error()
         for i, f in enumerate(frames):

@@ -145,12 +145,17 @@ def test_batched_pipeline_matches_oracle(libs, gpu_ctx, kind, size):
     torch.cuda.synchronize()
     qf, qo, qb, ffs, iqo, sn = qparams(size, 30)
     ikind = 2 if kind == 2 else 0
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     assert product.svt_amd_fwd_transform_batch(gpu_ctx, kind, size, 0, d_res.data_ptr(), d_coef.data_ptr(), n) == 0
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     assert product.svt_amd_quantize_batch(gpu_ctx, size, qf, qo, qb, ffs, iqo, sn, d_coef.data_ptr(), d_q.data_ptr(),
                                           d_rec.data_ptr(), d_nz.data_ptr(), n) == 0
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     assert product.svt_amd_full_distortion_batch(gpu_ctx, size, 0, d_coef.data_ptr(), d_rec.data_ptr(), d_dist.data_ptr(), n) == 0
+    torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
     assert product.svt_amd_inv_transform_batch(gpu_ctx, ikind, size, 0, d_rec.data_ptr(), d_inv.data_ptr(), n) == 0
     if size in (4, 8):
+        torch.cuda.synchronize()  # torch fills/copies run on torch's stream, the library on its own
         assert product.svt_amd_satd_batch(gpu_ctx, size, d_res.data_ptr(), d_satd.data_ptr(), n) == 0
     assert product.svt_amd_synchronize(gpu_ctx) == 0
     coef, q, rec, inv = (x.cpu().numpy() for x in (d_coef, d_q, d_rec, d_inv))
