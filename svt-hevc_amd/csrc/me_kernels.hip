@@ -491,7 +491,7 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
 #define STAMP(i)                                                                      \
     do {                                                                              \
         if (J.dbg_clock && t == 0)                                                    \
-            J.dbg_clock[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+            J.dbg_clock[((size_t)blockIdx.y * J.lcu_count + blk) * 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 
 /* grid = (max LCUs of any job, jobs): one workgroup per (picture, LCU) */
@@ -499,7 +499,12 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
 {
     __shared__ MeShared S;
     const MeJobDev &J = jobs[blockIdx.y];
-    if ((int)blockIdx.x >= J.lcu_count)
+    /* XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so
+     * XCD x gets blockIdx.x = x, x+8, ...; give it a CONTIGUOUS run of LCUs - neighbouring LCUs share most of
+     * their HME / search-window bytes and then hit in that XCD's L2 instead of refetching across XCDs. */
+    const int per_xcd = (J.lcu_count + 7) >> 3;
+    const int blk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || blk >= J.lcu_count)
         return;
     const SvtAmdMeParams P = J.P;
     const PicView cur = J.cur, ref0 = J.ref0, ref1 = J.ref1;
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
     const int t = threadIdx.x;
     const int W = P.luma_width, H = P.luma_height;
     const int wl = (W + LCU - 1) / LCU;
-    const int lcu = lcu_begin + (int)blockIdx.x;
+    const int lcu = lcu_begin + blk;
     const int ox = (lcu % wl) * LCU, oy = (lcu / wl) * LCU;
     const int lw = imin(LCU, W - ox), lh = imin(LCU, H - oy);
     const int pf = cur.pitch_full;
@@ -1298,7 +1303,7 @@ int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int n
     int rc = svt_amd_stamp_begin(ctx, KC_ME_SEARCH);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(k_me_picture, dim3((unsigned)max_lcus, (unsigned)njobs), dim3(NT), pool, ctx->stream, ctx->d_jobs);
+    hipLaunchKernelGGL(k_me_picture, dim3((unsigned)((max_lcus + 7) & ~7), (unsigned)njobs), dim3(NT), pool, ctx->stream, ctx->d_jobs);
     HIP_TRY(hipGetLastError());
     return svt_amd_stamp_end(ctx);
 }
