@@ -591,6 +591,40 @@ SVT_AMD_API void svt_amd_UnpackAvg(uint16_t *ref16L0, uint32_t refL0Stride, uint
                                    uint8_t *dstPtr, uint32_t dstStride, uint32_t width, uint32_t height);
 
 /* ------------------------------------------------------------------------- */
+/* Coefficient rate estimation (mode-decision full loop / encode pass)        */
+/* ------------------------------------------------------------------------- */
+/* Same layout as the reference's CabacCost_t (Codec/EbCabacContextModel.h:216-226), filled on the host by
+ * PrecomputeCabacCost (Codec/EbCoeffEstimation_Intrinsic.c:161) from the CABAC context state. */
+typedef struct SvtAmdCabacCost {
+    uint32_t CabacBitsLast[60 * 2 + 28 * 2];
+    uint8_t  CabacBitsSig[2 * 42];
+    uint8_t  CabacBitsG1[2 * 24];
+    uint8_t  CabacBitsG2[2 * 6];
+    uint8_t  CabacBitsSigMl[2 * 4];
+    uint16_t CabacBitsG1x[24 / 4 * 16];
+    uint8_t  CabacBitsSigV[32][16];
+} SvtAmdCabacCost;
+/* per-TU side information of the batched form */
+typedef struct SvtAmdTuInfo {
+    uint32_t num_nonzero;      /* numNonZeroCoeffs: the true count of non-zero coefficients (0 -> 0 bits) */
+    uint8_t  type;             /* INTER_MODE 1 / INTRA_MODE 2 (Codec/EbDefinitions.h:345)                 */
+    uint8_t  intra_luma_mode, intra_chroma_mode, component; /* component: 0 luma, else chroma            */
+} SvtAmdTuInfo;
+/* BATCHED: bits of nblocks contiguous size x size blocks (block b at d_coeff + b*size*size); d_bits[b] = the amount
+ * EstimateQuantizedCoefficients_Lossy (EbCoeffEstimation_Intrinsic.c:1415) adds to *coeffBitsLong for that TU.
+ * `cost` is a HOST pointer (copied to the device by the call). */
+SVT_AMD_API int svt_amd_coeff_bits_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, uint32_t size,
+                                         const int16_t *d_coeff, const SvtAmdTuInfo *d_info, uint64_t *d_bits,
+                                         uint32_t nblocks);
+/* LEAF: slot [1][*] of EstimateQuantizedCoefficients (Codec/EbEntropyCoding.h:334-347); cabacEncodeCtxPtr unused, as in
+ * the reference; returns EB_ERRORTYPE (0 = EB_ErrorNone). */
+SVT_AMD_API int svt_amd_EstimateQuantizedCoefficients_Lossy(SvtAmdCabacCost *CabacCost, void *cabacEncodeCtxPtr,
+                                                            uint32_t size, uint32_t type, uint32_t intraLumaMode,
+                                                            uint32_t intraChromaMode, int16_t *coeffBufferPtr,
+                                                            const uint32_t coeffStride, uint32_t componentType,
+                                                            uint32_t numNonZeroCoeffs, uint64_t *coeffBitsLong);
+
+/* ------------------------------------------------------------------------- */
 /* HEVC motion-compensation interpolation (closed-loop inter prediction)      */
 /* ------------------------------------------------------------------------- */
 /* One prediction block: integer position = sample index ref_off of the reference plane, fractional part (fx,fy) in

@@ -176,4 +176,9 @@ void svt_oracle_BiPredClipping(int bps, uint32_t w, uint32_t h, const int16_t *l
 void svt_oracle_zz_sad_picture(const uint8_t *cur, const uint8_t *prev, uint32_t stride, uint32_t width, uint32_t height,
                                SvtAmdZzLcu *out);
 
+/* ---- coefficient rate estimation (svt_oracle_rate.c) ---- */
+uint64_t svt_oracle_coeff_bits_lossy(const SvtAmdCabacCost *C, uint32_t size, uint32_t type, uint32_t intraLumaMode,
+                                     uint32_t intraChromaMode, const int16_t *coeff, uint32_t stride,
+                                     uint32_t componentType, uint32_t numNonZeroCoeffs);
+
 #endif
