@@ -100,6 +100,42 @@ def main():
     timed("deblock luma, %d vertical 4-sample edges" % len(e), len(e) * (2 * 32 + 12),
           lambda: lib.svt_amd_dlf_luma_edges_batch(ctx, plane.data_ptr(), W, 1, d_e.data_ptr(), len(e)))
 
+    # HEVC motion compensation: a 1080p luma plane as 16x16 PUs with random quarter-pel vectors
+    lib.svt_amd_mcp_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp, u32, vp, u32]
+    PADX = 80
+    st = W + 2 * PADX
+    refp = torch.randint(0, 256, (H + 2 * PADX, st), dtype=torch.uint8, device=dev, generator=g)
+    nx, ny = W // 16, H // 16
+    rng = np.random.default_rng(0)
+    blocks = np.zeros(nx * ny, np.dtype([("ref_off", "<i4"), ("dst_off", "<i4"), ("w", "<u2"), ("h", "<u2"), ("fx", "u1"),
+                                         ("fy", "u1"), ("pad", "u1", 2)]))
+    mvx, mvy = rng.integers(-64 * 4, 64 * 4, nx * ny), rng.integers(-64 * 4, 64 * 4, nx * ny)
+    bx, by = np.tile(np.arange(nx) * 16, ny), np.repeat(np.arange(ny) * 16, nx)
+    blocks["ref_off"] = (PADX + by + (mvy >> 2)) * st + PADX + bx + (mvx >> 2)
+    blocks["dst_off"], blocks["w"], blocks["h"] = by * W + bx, 16, 16
+    blocks["fx"], blocks["fy"] = mvx & 3, mvy & 3
+    d_b = torch.from_numpy(blocks.view(np.uint8)).to(dev)
+    pred = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+    timed("MCP luma uni-pred, %d 16x16 PUs, random 1/4-pel MVs" % len(blocks), 2 * npx,
+          lambda: lib.svt_amd_mcp_batch(ctx, 1, 0, 0, refp.data_ptr(), st, pred.data_ptr(), W, d_b.data_ptr(), len(blocks)))
+
+    # coefficient rate estimation: every 8x8 / 32x32 TU of a 1080p plane, ~10 % non-zero coefficients
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_rate import TU_INFO, synthetic_cost
+    lib.svt_amd_coeff_bits_batch.argtypes = [vp, vp, u32, vp, vp, vp, u32]
+    cost = synthetic_cost(1)
+    for size in (8, 32):
+        nb = npx // (size * size)
+        q16 = (torch.randint(-3, 4, (npx,), dtype=torch.int16, device=dev, generator=g) *
+               (torch.rand(npx, device=dev, generator=g) < 0.1)).to(torch.int16)
+        nnz = (q16.view(nb, size * size) != 0).sum(dim=1).cpu().numpy()
+        info = np.zeros(nb, TU_INFO)
+        info["num_nonzero"], info["type"] = nnz, 1
+        d_i = torch.from_numpy(info.view(np.uint8)).to(dev)
+        bits = torch.zeros(nb, dtype=torch.int64, device=dev)
+        timed("coeff rate estimation %dx%d (%d TUs)" % (size, size, nb), 2 * nb * size * size + 16 * nb,
+              lambda: lib.svt_amd_coeff_bits_batch(ctx, cost.ctypes.data, size, q16.data_ptr(), d_i.data_ptr(), bits.data_ptr(), nb))
+
     print(json.dumps({"iters": iters, "peak_GBs": PEAK, "kernels": rows}, indent=1))
     lib.svt_amd_context_destroy(ctx)
 
