@@ -494,6 +494,14 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
             J.dbg_clock[((size_t)blockIdx.y * J.lcu_count + blk) * 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 
+/* tier = 0 (64x64), 1 (32x32), 2 (16x16), 3 (8x8): closed forms instead of small private arrays, which the
+ * compiler would place in scratch memory when indexed dynamically (scratch = VMEM latency + HBM write traffic) */
+__device__ __forceinline__ int tier_first_of(int tier) { return tier == 0 ? 0 : tier == 1 ? 1 : tier == 2 ? 5 : 21; }
+__device__ __forceinline__ int tier_cnt_of(int tier) { return 1 << (2 * tier); }
+__device__ __forceinline__ int tier_sz_of(int tier) { return 64 >> tier; }
+__device__ __forceinline__ int tier_lc_of(int tier) { return tier == 0 ? 5 : tier == 1 ? 3 : tier == 2 ? 1 : 0; }
+__device__ __forceinline__ int pick4(int i, int a, int b, int c, int d) { return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
+
 /* grid = (max LCUs of any job, jobs): one workgroup per (picture, LCU) */
 __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const MeJobDev *__restrict__ jobs)
 {
@@ -506,7 +514,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
     const int blk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || blk >= J.lcu_count)
         return;
-    const SvtAmdMeParams P = J.P;
+    const SvtAmdMeParams &P = J.P; /* stays in global memory: uniform fields come in through scalar loads; a private copy
+                                     * would live in scratch because of the indexed arrays inside */
     const PicView cur = J.cur, ref0 = J.ref0, ref1 = J.ref1;
     SvtAmdMeLcuResult *__restrict__ out = J.out;
     const int lcu_begin = J.lcu_begin;
@@ -551,8 +560,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
 
     LWin wF, wB, wH, wJ; /* LDS windows of the current list's reference planes */
     int hme_init_done = 0;
-    int sa_x[2] = {0, 0}, sa_y[2] = {0, 0}, sa_w[2] = {0, 0}, sa_h[2] = {0, 0};
-    int hcx[2] = {0, 0}, hcy[2] = {0, 0};
+    int sa_x0 = 0, sa_x1 = 0, sa_y0 = 0, sa_y1 = 0, sa_w0 = 0, sa_w1 = 0, sa_h0 = 0, sa_h1 = 0;
+    int hcx0 = 0, hcx1 = 0, hcy0 = 0, hcy1 = 0;
 
     for (int list = 0; list < P.num_lists; list++) {
         const PicView &R = list ? ref1 : ref0;
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 }
             }
         }
-        hcx[list] = cx, hcy[list] = cy;
+        if (list) hcx1 = cx, hcy1 = cy; else hcx0 = cx, hcy0 = cy;
 
         if (list == 0) STAMP(3);
         /* ---- EbHevcCheckZeroZeroCenter (:2946-3034) ---- */
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
         int sox = cx - (saw >> 1), soy = cy - (sah >> 1);
         clamp_area(ox, LCU - 1, W, sox, saw);
         clamp_area(oy, LCU - 1, H, soy, sah);
-        sa_x[list] = sox, sa_y[list] = soy, sa_w[list] = saw, sa_h[list] = sah;
+        if (list) sa_x1 = sox, sa_y1 = soy, sa_w1 = saw, sa_h1 = sah; else sa_x0 = sox, sa_y0 = soy, sa_w0 = saw, sa_h0 = sah;
 
         if (list == 0) STAMP(4);
         /* ---- FullPelSearch_LCU (:586-633) ---- */
@@ -926,8 +935,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
         const int run_sub = (P.fractional_search_model != 2) && any_sub;
         if (run_sub) {
             const int f64 = P.fractional_search_64x64;
-            const int en[4] = {f64, S.e32, S.e16, S.e8};
-            const int tier_first[4] = {0, 1, 5, 21}, tier_cnt[4] = {1, 4, 16, 64}, tier_sz[4] = {64, 32, 16, 8};
+            const int en0 = f64, en1 = S.e32, en2 = S.e16, en3 = S.e8;
+#define EN(tier_) pick4(tier_, en0, en1, en2, en3)
             const int rstep = (method == SVT_AMD_SUB_SAD_SEARCH) ? 2 : 1;
             if (list == 0) STAMP(6);
             /* ===== half-pel: EbHevcHalfPelSearch_LCU / PU_HalfPelRefinement (:733-1187) ===== */
@@ -939,14 +948,13 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             /* item = (PU, position k, row chunk): chunk counts {32, 8, 2, 1} per tier give every lane the same
              * ~16 dword SADs; the chunks of one (PU, k) sit on adjacent lanes and are summed with a segmented
              * shuffle, so S.dist is written once per (PU, k) - no LDS atomics. */
-            const int tier_lc[4] = {5, 3, 1, 0}; /* log2(chunks) */
             for (int tier = 0; tier < 4; tier++) {
-                if (!en[tier])
+                if (!EN(tier))
                     continue;
-                const int sz = tier_sz[tier], rows = sz / rstep, lc = tier_lc[tier], rpc = rows >> lc;
-                const int items = tier_cnt[tier] * 8 << lc; /* a multiple of NT: whole waves, no tail */
+                const int sz = tier_sz_of(tier), rows = sz / rstep, lc = tier_lc_of(tier), rpc = rows >> lc;
+                const int items = tier_cnt_of(tier) * 8 << lc; /* a multiple of NT: whole waves, no tail */
                 for (int i = t; i < items; i += NT) {
-                    const int ch = i & ((1 << lc) - 1), k = (i >> lc) & 7, n = tier_first[tier] + (i >> (lc + 3));
+                    const int ch = i & ((1 << lc) - 1), k = (i >> lc) & 7, n = tier_first_of(tier) + (i >> (lc + 3));
                     int px_, py_, psz;
                     pu_geom_z(n, px_, py_, psz);
                     const uint32_t mv = S.best_mv[list][n];
@@ -977,11 +985,11 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             /* SSD search also needs the SSE of the full-pel winner (:798-806) */
             if (method == SVT_AMD_SSD_SEARCH) {
                 for (int tier = 0; tier < 4; tier++) {
-                    if (!en[tier])
+                    if (!EN(tier))
                         continue;
-                    const int sz = tier_sz[tier], items = tier_cnt[tier] * sz;
+                    const int sz = tier_sz_of(tier), items = tier_cnt_of(tier) * sz;
                     for (int i = t; i < items; i += NT) {
-                        const int row = i % sz, n = tier_first[tier] + i / sz;
+                        const int row = i % sz, n = tier_first_of(tier) + i / sz;
                         int px_, py_, psz;
                         pu_geom_z(n, px_, py_, psz);
                         const uint32_t mv = S.best_mv[list][n];
@@ -1000,7 +1008,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             __syncthreads();
             if (t < 85) {
                 const int tier = t == 0 ? 0 : t < 5 ? 1 : t < 21 ? 2 : 3;
-                if (en[tier]) {
+                if (EN(tier)) {
                     const int mdx[8] = {-2, 2, 0, 0, -2, 2, 2, -2}, mdy[8] = {0, 0, -2, 2, -2, -2, 2, 2};
                     const uint32_t mv0 = S.best_mv[list][t];
                     uint32_t bsad = S.best_sad[list][t], bmv = mv0, bssd = S.best_ssd[list][t];
@@ -1032,7 +1040,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
 
             if (list == 0) STAMP(7);
             /* ===== quarter-pel: QuarterPelSearch_LCU / PU_QuarterPelRefinementOnTheFly (:1226-1846) ===== */
-            const int qen[4] = {f64, S.eq && S.e32, S.eq && S.e16, S.eq && S.e8};
+            const int qen0 = f64, qen1 = S.eq && S.e32, qen2 = S.eq && S.e16, qen3 = S.eq && S.e8;
+#define QEN(tier_) pick4(tier_, qen0, qen1, qen2, qen3)
             for (int i = t; i < 85 * 8; i += NT) {
                 (&S.dist[0][0])[i] = 0;
                 (&S.dsad[0][0])[i] = 0;
@@ -1042,17 +1051,17 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
              * (PU, j in 0..2, row chunk); position code = winner direction + j - 1 on the ring
              * TL,T,TR,R,BR,B,BL,L (mirrored when the MV already sits on a half-pel position). */
             for (int tier = 0; tier < 4; tier++) {
-                if (!qen[tier])
+                if (!QEN(tier))
                     continue;
-                const int sz = tier == 0 ? 32 : tier_sz[tier]; /* the 64x64 call passes 32x32 (:1677) */
-                const int lc = tier == 0 ? 3 : tier_lc[tier], rows = sz / rstep, rpc = rows >> lc;
-                const int items = tier_cnt[tier] * 3 << lc;
+                const int sz = tier == 0 ? 32 : tier_sz_of(tier); /* the 64x64 call passes 32x32 (:1677) */
+                const int lc = tier == 0 ? 3 : tier_lc_of(tier), rows = sz / rstep, rpc = rows >> lc;
+                const int items = tier_cnt_of(tier) * 3 << lc;
                 for (int i0 = 0; i0 < items; i0 += NT) { /* uniform trips: whole waves join the shuffles */
                     const int i = i0 + t;
                     const bool live = i < items;
                     const int ii = live ? i : 0;
                     const int ch = ii & ((1 << lc) - 1), pj = ii >> lc, pidx = pj / 3, j = pj - pidx * 3;
-                    const int n = tier_first[tier] + pidx;
+                    const int n = tier_first_of(tier) + pidx;
                     int px_, py_, psz;
                     pu_geom_z(n, px_, py_, psz);
                     const uint32_t mv = S.best_mv[list][n];
@@ -1095,7 +1104,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             __syncthreads();
             if (t < 85) {
                 const int tier = t == 0 ? 0 : t < 5 ? 1 : t < 21 ? 2 : 3;
-                if (qen[tier]) {
+                if (QEN(tier)) {
                     const int mdx[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, mdy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
                     const int kcode[8] = {D_L, D_R, D_T, D_B, D_TL, D_TR, D_BR, D_BL};
                     const uint32_t mv0 = S.best_mv[list][t];
@@ -1129,14 +1138,13 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
         const int npu = (P.cu16x16_mode != 0) ? 5 : ((P.cu8x8_mode != 0) ? 21 : 85);
         /* items: (pu n, row) */
         int first = 0;
-        const int tier_first[4] = {0, 1, 5, 21}, tier_cnt[4] = {1, 4, 16, 64}, tier_sz[4] = {64, 32, 16, 8};
         (void)first;
         for (int tier = 0; tier < 4; tier++) {
-            if (tier_first[tier] >= npu)
+            if (tier_first_of(tier) >= npu)
                 break;
-            const int sz = tier_sz[tier], rows = sz / rstep, items = tier_cnt[tier] * rows;
+            const int sz = tier_sz_of(tier), rows = sz / rstep, items = tier_cnt_of(tier) * rows;
             for (int i = t; i < items; i += NT) {
-                const int row = i % rows, n = tier_first[tier] + i / rows;
+                const int row = i % rows, n = tier_first_of(tier) + i / rows;
                 int px_, py_, psz;
                 pu_geom_z(n, px_, py_, psz);
                 const int y = row * rstep;
@@ -1232,12 +1240,12 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
         o->best_mv[1][t] = S.best_mv[1][t];
     }
     if (t < 2) {
-        o->hme_center_x[t] = (int16_t)hcx[t];
-        o->hme_center_y[t] = (int16_t)hcy[t];
-        o->search_origin_x[t] = (int16_t)sa_x[t];
-        o->search_origin_y[t] = (int16_t)sa_y[t];
-        o->search_w[t] = (uint8_t)sa_w[t];
-        o->search_h[t] = (uint8_t)sa_h[t];
+        o->hme_center_x[t] = (int16_t)(t ? hcx1 : hcx0);
+        o->hme_center_y[t] = (int16_t)(t ? hcy1 : hcy0);
+        o->search_origin_x[t] = (int16_t)(t ? sa_x1 : sa_x0);
+        o->search_origin_y[t] = (int16_t)(t ? sa_y1 : sa_y0);
+        o->search_w[t] = (uint8_t)(t ? sa_w1 : sa_w0);
+        o->search_h[t] = (uint8_t)(t ? sa_h1 : sa_h0);
     }
     STAMP(10);
 }
