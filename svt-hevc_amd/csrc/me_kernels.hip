@@ -158,6 +158,30 @@ __device__ __forceinline__ int load_window(LWin &w, int off, const uint8_t *plan
     return off + rows * wa;
 }
 
+/* Same staging through the LDS-DMA path (global_load_lds_dwordx4): the data never passes through VGPRs and the
+ * issuing wave does not wait for it, so the loads overlap with whatever is computed next.  One wave instruction
+ * moves 64 consecutive 16-byte items to 1 KiB of consecutive LDS (M0 = LDS base of the chunk, lane i lands at
+ * base + 16 i), which is exactly the row-major window layout.  The caller must execute
+ * `__builtin_amdgcn_s_waitcnt(0)` + `__syncthreads()` before anybody reads the window. */
+__device__ __forceinline__ int load_window_async(LWin &w, int off, const uint8_t *plane, int pitch, int x0, int y0, int x1,
+                                                 int y1, int t)
+{
+    const int xa = x0 & ~15, wa = ((x1 - xa) + 15) & ~15, n16 = wa >> 4, rows = y1 - y0, total = rows * n16;
+    uint8_t *dst = g_pool + off;
+    w.p = dst, w.x0 = xa, w.y0 = y0, w.stride = wa;
+    const int lane = t & 63;
+    for (int c0 = (t >> 6) * 64; c0 < total; c0 += NT) { /* chunk of 64 items per wave instruction */
+        const int i = c0 + lane;
+        if (i < total) {
+            const int r = i / n16, c = i - r * n16;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(plane + (ptrdiff_t)(y0 + r) * pitch + xa + c * 16),
+                (__attribute__((address_space(3))) void *)(dst + c0 * 16), 16, 0, 0);
+        }
+    }
+    return off + rows * wa;
+}
+
 /* Z-order <-> raster (tab32x32 / tab8x8, EbMotionEstimation.c:98-102) */
 __constant__ uint8_t c_tab16[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 __constant__ uint8_t c_tab8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23,
@@ -793,9 +817,11 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             {
                 const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
                 int off = load_window(wF, 0, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t);
-                off = load_window(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t);
-                off = load_window(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t);
-                off = load_window(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                /* the half-pel planes are first read by the sub-pel stages: fetch them asynchronously under the
+                 * full-pel search (waited for at "sub-pel windows landed" below) */
+                off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                off = load_window_async(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                off = load_window_async(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
             }
             const uint8_t *rbase = wat(wF, ox + bx + sox, oy + by + soy);
             const int fstride = wF.stride;
@@ -890,6 +916,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 S.best_sad[list][t] = 2 * s;
                 S.best_mv[list][t] = mvpack((sx + sox) * 4, (sy + soy) * 4);
             }
+            __builtin_amdgcn_s_waitcnt(0); /* sub-pel windows landed (LDS-DMA issued before the search) */
             __syncthreads();
         }
 
