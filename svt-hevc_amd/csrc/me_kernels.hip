@@ -296,6 +296,7 @@ struct MeShared {
     int sums[9];                   /* SuPelEnable: per tier {sum mvx, sum mvy, sum sad} */
     int qp[4][4];                  /* HME quadrant search areas {origin x, origin y, width, height}         */
     int cand[6][4];                /* LCU-SAD candidates {unclamped x, y, clamped x, y}                     */
+    uint32_t mvd_bits[12];         /* P.mvd_bits (dynamically indexed by the rate function)                 */
 };
 
 /* ------------------------------------------------------------------------- */
@@ -423,10 +424,11 @@ __device__ void hme_pass_q(MeShared &S, const uint8_t *src, int sstride, const u
         for (int q = 0; q < nq; q++) {
             const int qx = S.qp[q][0], qy = S.qp[q][1], qw = S.qp[q][2], qh = S.qp[q][3];
             LWin w;
-            off = load_window(w, off, refplane, pitch, bx0 + qx, by0 + qy, bx0 + qx + qw + 4 * G,
-                              by0 + qy + qh + 2 * (ROWS - 1) + 1, t);
+            off = load_window_async(w, off, refplane, pitch, bx0 + qx, by0 + qy, bx0 + qx + qw + 4 * G,
+                                    by0 + qy + qh + 2 * (ROWS - 1) + 1, t);
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     const int wave = t >> 6, lane = t & 63;
     const int q = wave % nq, slot = wave / nq, nslots = (4 + nq - 1 - q) / nq; /* waves serving quadrant q */
@@ -575,6 +577,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
     }
     if (t < 85)
         S.bipred[t] = 0;
+    if (t >= 64 && t < 76)
+        S.mvd_bits[t - 64] = P.mvd_bits[t - 64];
     if (t < 12) {
         (&S.hx[0][0][0])[t] = 0;
         (&S.hy[0][0][0])[t] = 0;
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                             if (sw & 15)
                                 sw = (sw >> 4) << 4;
                         } else {
-                            sw = (int16_t)((P.hme_l0_w[qw_] * mx) / 100), sh = (int16_t)((P.hme_l0_h[qh_] * my) / 100);
+                            sw = (int16_t)(((qw_ ? P.hme_l0_w[1] : P.hme_l0_w[0]) * mx) / 100), sh = (int16_t)(((qh_ ? P.hme_l0_h[1] : P.hme_l0_h[0]) * my) / 100);
                             int dx = cx >> 2, dy = cy >> 2;
                             if (qw_)
                                 dx += (int16_t)((P.hme_l0_w[0] * mx) / 100);
@@ -686,7 +690,10 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                             S.hy[0][qw_][qh_] = (int16_t)((int16_t)(S.hy[0][qw_][qh_] + qy) * 4);
                         }
                     }
-                    __syncthreads();
+                    /* the next level's parameters are derived by the same thread from its own quadrant's result and
+                     * are published by that level's barrier: a barrier here is only needed after the last level */
+                    if (!P.enable_hme_level1 && !P.enable_hme_level2)
+                        __syncthreads();
                 }
                 for (int lvl = 1; lvl <= 2; lvl++) {
                     if (!(lvl == 1 ? P.enable_hme_level1 : P.enable_hme_level2))
@@ -695,8 +702,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     const int bx0 = ox >> shf, by0 = oy >> shf, pwl = W >> shf, phl = H >> shf;
                     const int padl = lvl == 2 ? LCU - 1 : SVT_AMD_PAD_QUARTER - 1;
                     if (t < nq) {
-                        int sw = hme_l12_width((int16_t)(lvl == 1 ? P.hme_l1_w[qw_] : P.hme_l2_w[qw_]));
-                        int sh = (int16_t)(lvl == 1 ? P.hme_l1_h[qh_] : P.hme_l2_h[qh_]);
+                        int sw = hme_l12_width((int16_t)(lvl == 1 ? (qw_ ? P.hme_l1_w[1] : P.hme_l1_w[0]) : (qw_ ? P.hme_l2_w[1] : P.hme_l2_w[0])));
+                        int sh = (int16_t)(lvl == 1 ? (qh_ ? P.hme_l1_h[1] : P.hme_l1_h[0]) : (qh_ ? P.hme_l2_h[1] : P.hme_l2_h[0]));
                         const int pcx = lvl == 1 ? (S.hx[0][qw_][qh_] >> 1) : S.hx[1][qw_][qh_];
                         const int pcy = lvl == 1 ? (S.hy[0][qw_][qh_] >> 1) : S.hy[1][qw_][qh_];
                         int so_x = (int16_t)(-(sw >> 1) + pcx), so_y = (int16_t)(-(sh >> 1) + pcy);
@@ -720,7 +727,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                         S.hy[lvl][qw_][qh_] = (int16_t)((int16_t)(sy + qy) * (1 << shf));
                         S.hs[lvl][qw_][qh_] = (k >> 32) * 2;
                     }
-                    __syncthreads();
+                    if (lvl == 2 || !P.enable_hme_level2)
+                        __syncthreads();
                 }
                 /* centre selection (:3958-4069) - every thread evaluates the same scalars */
                 {
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, 2, t, zero_sad_valid);
             const uint32_t zeroSad = S.acc[0] << 1, hmeSad = S.acc[1] << 1;
             const unsigned long long zeroCost = (unsigned long long)zeroSad << COST_PRECISION;
-            const uint32_t rate = mvd_fraction_bits(abs(cx << 2), abs(cy << 2), P.mvd_bits);
+            const uint32_t rate = mvd_fraction_bits(abs(cx << 2), abs(cy << 2), S.mvd_bits);
             const unsigned long long hmeCost = (unsigned long long)(uint32_t)(hmeSad << COST_PRECISION) +
                                                ((((unsigned long long)P.lambda * rate) + MD_OFFSET) >> MD_SHIFT);
             if (zeroCost <= hmeCost)
