@@ -16,12 +16,13 @@
  */
 #include "svt_amd_internal.h"
 
-#define WIN_W 100 /* 97 used; row pitch in bytes */
+#define WIN_W 100 /* row pitch in bytes: columns -4 .. 95 of the LCU (starts on a dword of the plane) */
+#define WIN_X0 4  /* window column of LCU column 0 */
 #define WIN_H 97
 #define MAXK 35
 
 struct OisShared {
-    uint8_t win[WIN_H * WIN_W];         /* win[(y+1)*WIN_W + (x+1)] = source sample (x,y) relative to the LCU */
+    uint8_t win[WIN_H * WIN_W];         /* win[(y+1)*WIN_W + x + WIN_X0] = source sample (x,y) relative to the LCU */
     uint8_t refs[4 * 129 + 16 * 65 + 64 * 33 + 4]; /* per CU: left[0..2N-1] top-to-bottom, top-left, top[0..2N-1] */
     uint32_t sad[85][MAXK];
     uint32_t out_cand[85][SVT_AMD_OIS_MAX_CAND];
@@ -132,7 +133,33 @@ __device__ __forceinline__ uint32_t task_sad(const OisShared &S, int cu, int mod
     for (int p = lane; p < N * N; p += 64) {
         const int y = p >> lg, x = p & (N - 1);
         const int pr = predict_sample(mode, N, lg, r, x, y, dc);
-        acc += (uint32_t)abs((int)S.win[(cy + y + 1) * WIN_W + cx + x + 1] - pr);
+        acc += (uint32_t)abs((int)S.win[(cy + y + 1) * WIN_W + cx + x + WIN_X0] - pr);
+    }
+    return wave_sum(acc);
+}
+
+/* DC prediction is a constant except for the filtered first row / column (N < 32): SAD four samples per lane-op
+ * against the replicated DC value; the DC SAD of every CU is the one task every P/B picture always runs */
+__device__ __forceinline__ uint32_t task_sad_dc(const OisShared &S, int cu, int lane)
+{
+    int cx, cy, N, lg;
+    cu_geom(cu, cx, cy, N, lg);
+    const uint8_t *r = S.refs + ref_base(cu);
+    const int dc = S.dc[cu];
+    const uint32_t dc4 = (uint32_t)dc * 0x01010101u;
+    const int qshift = lg - 2; /* dwords per row = N / 4 */
+    uint32_t acc = 0;
+    for (int q = lane; q < (N * N) >> 2; q += 64) {
+        const int y = q >> qshift, x4 = (q & ((1 << qshift) - 1)) << 2;
+        const uint32_t sv = *(const uint32_t *)&S.win[(cy + y + 1) * WIN_W + cx + x4 + WIN_X0];
+        uint32_t pv = dc4;
+        if (N < 32 && (y == 0 || x4 == 0)) {
+            pv = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pv |= (uint32_t)predict_sample(1, N, lg, r, x4 + i, y, dc) << (8 * i);
+        }
+        acc = __builtin_amdgcn_sad_u8(sv, pv, acc);
     }
     return wave_sum(acc);
 }
@@ -275,19 +302,20 @@ __global__ __launch_bounds__(256) void k_ois_picture(const OisJobDev *__restrict
     const int W = P.luma_width, H = P.luma_height;
     const int last = P.slice_is_intra ? 84 : ((P.skip_ois_8x8 || P.cu8x8_mode == 1) ? 20 : 84);
 
-    /* 1. window (the padded plane makes every address valid; out-of-picture samples are never USED) */
+    /* 1. window (the padded plane makes every address valid; out-of-picture samples are never USED); rows start at
+     * LCU column -4, a dword boundary of the plane, so every load is one aligned dword */
     for (int i = t; i < WIN_H * 25; i += 256) {
         const int row = i / 25, c4 = i - row * 25;
-        const uint8_t *src = full + (ptrdiff_t)(ly + row - 1) * pitch + lx - 1 + c4 * 4;
-        uint32_t v = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
-        *(uint32_t *)&S.win[row * WIN_W + c4 * 4] = v;
+        *(uint32_t *)&S.win[row * WIN_W + c4 * 4] =
+            *(const uint32_t *)(full + (ptrdiff_t)(ly + row - 1) * pitch + lx - WIN_X0 + c4 * 4);
     }
     if (t == 0)
         S.stale = 0;
     __syncthreads();
 
     /* 2. reference arrays of every CU */
-    for (int i = t; i < 516 + 1040 + 2112; i += 256) {
+    const int nref = last == 20 ? 516 + 1040 : 516 + 1040 + 2112; /* no 8x8 CUs when last == 20 */
+    for (int i = t; i < nref; i += 256) {
         int cu, e;
         if (i < 516)
             cu = 1 + i / 129, e = i % 129;
@@ -301,19 +329,19 @@ __global__ __launch_bounds__(256) void k_ois_picture(const OisJobDev *__restrict
         int v = 128;
         if (e < 2 * N) {
             if (ox != 0 && oy + e < H)
-                v = S.win[(cy + e + 1) * WIN_W + cx];
+                v = S.win[(cy + e + 1) * WIN_W + cx + WIN_X0 - 1];
         } else if (e == 2 * N) {
             if (ox != 0 && oy != 0)
-                v = S.win[cy * WIN_W + cx];
+                v = S.win[cy * WIN_W + cx + WIN_X0 - 1];
         } else {
             const int j = e - 2 * N - 1;
             if (oy != 0 && ox + j < W)
-                v = S.win[cy * WIN_W + cx + j + 1];
+                v = S.win[cy * WIN_W + cx + j + WIN_X0];
         }
         S.refs[i] = (uint8_t)v;
     }
     __syncthreads();
-    if (t >= 1 && t <= 84) {
+    if (t >= 1 && t <= last) {
         int cx, cy, N, lg;
         cu_geom(t, cx, cy, N, lg);
         const uint8_t *r = S.refs + ref_base(t);
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(256) void k_ois_picture(const OisJobDev *__restrict
             CU_VALID(cu, valid);
             if (!valid)
                 continue;
-            const uint32_t s = task_sad(S, cu, 1, lane);
+            const uint32_t s = task_sad_dc(S, cu, lane);
             if (lane == 0)
                 S.sad[cu][9] = s;
         }
