@@ -35,7 +35,12 @@ CASES = {
     "noise_320x256_m4": ("noise", 320, 256, 3, 11, ["-encMode", "4"], 2),
     # encMode 1: 64x64 fractional search, 64x64 search area, cu8x8 refinement
     "p_320x256_m1": ("motion", 320, 256, 3, 7, ["-encMode", "1"], 2),
+    # BASELINE config 3 (4K, encMode 7, random access, 2 hierarchical levels, 60 fps): one B picture, four LCU rows
+    # kept (top, two interior, the partial bottom row) to bound the fixture size
+    "b_3840x2160_m7": ("motion", 3840, 2160, 5, 7,
+                       ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-fps", "60"], 1),
 }
+ROWS_KEPT = {"b_3840x2160_m7": [0, 11, 22, 33]}
 
 
 def run_case(name):
@@ -64,10 +69,19 @@ def run_case(name):
         meta.append([pn, int(r0["slice_type"]), int(r0["ref_poc"][0]), int(r0["ref_poc"][1])])
         params.append(r0["params"])
         assert all(rr["params"] == r0["params"])
-        results.append(rr["result"])
+        res = rr["result"].copy()
+        if name in ROWS_KEPT:  # zero the rows that are not kept (they then compress to nothing)
+            wl = (w + 63) // 64
+            keep_mask = np.zeros(nl, bool)
+            for r in ROWS_KEPT[name]:
+                keep_mask[r * wl:(r + 1) * wl] = True
+            res[~keep_mask] = np.zeros((), res.dtype)
+        results.append(res)
     out["meta"] = np.array(meta, np.int64)           # picture, slice type, ref POC l0, ref POC l1
     out["params"] = np.array(params, S.ME_PARAMS_DTYPE)
     out["results"] = np.stack(results)                # [picture][lcu] ME_LCU_DTYPE
+    if name in ROWS_KEPT:
+        out["rows_kept"] = np.array(ROWS_KEPT[name])
     path = os.path.join(S.GOLDEN_DIR, "me_%s.npz" % name)
     np.savez_compressed(path, **out)
     print("%-20s %d pictures x %d LCUs -> %s (%.0f KiB)" % (name, len(pics), nl, os.path.basename(path),
