@@ -66,6 +66,8 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
             (void)hipFree(s->d_me_out);
         if (s->d_ois_out)
             (void)hipFree(s->d_ois_out);
+        if (s->d_me_carry)
+            (void)hipFree(s->d_me_carry);
         if (s->d_staging)
             (void)hipFree(s->d_staging);
     }
@@ -153,6 +155,7 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
         if ((rc = plane_create(&s->hp_j, w, h, SVT_AMD_PAD_FULL)) != 0) break;
         if (hipMalloc((void **)&s->d_me_out, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess ||
             hipMalloc((void **)&s->d_ois_out, (size_t)nlcu * sizeof(SvtAmdOisLcuResult)) != hipSuccess ||
+            hipMalloc(&s->d_me_carry, (size_t)nlcu * 192) != hipSuccess ||
             hipMalloc((void **)&s->d_staging, (size_t)w * h) != hipSuccess) {
             svt_amd_set_error("hipMalloc (slot %d) failed", i);
             rc = SVT_AMD_ERR_RESOURCES;
@@ -418,6 +421,7 @@ static int make_job(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_sl
     job->ref0 = make_view(r0);
     job->ref1 = make_view(r1);
     job->out = c->d_me_out;
+    job->carry = (struct MeCarry *)c->d_me_carry;
     job->lcu_begin = (int32_t)lcu_begin;
     job->lcu_count = (int32_t)(lcu_end - lcu_begin);
     job->dbg_clock = NULL;

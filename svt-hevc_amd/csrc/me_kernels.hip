@@ -273,31 +273,44 @@ __device__ uint32_t mvd_fraction_bits(int mvdX, int mvdY, const uint32_t *bits)
     return n;
 }
 
+/* LDS state shared by both kernels of the split (static allocation) */
 struct MeShared {
     uint8_t src[LCU * LCU + 16];   /* source LCU rows (padded-plane content)              */
     uint8_t qsrc[32 * 16 + 16];    /* 1/4 LCU, even rows                                   */
     uint8_t ssrc[16 * 8 + 16];     /* 1/16 LCU, even rows                                  */
+    unsigned long long hkey[4];    /* HME per-quadrant minima                              */
+    uint32_t acc[8];               /* LCU-level SAD accumulators                           */
+    int16_t hx[3][2][2], hy[3][2][2]; /* HME centres per level [w][h]                      */
+    unsigned long long hs[3][2][2];
+    int qp[4][4];                  /* HME quadrant search areas {origin x, origin y, width, height}         */
+    int cand[6][4];                /* LCU-SAD candidates {unclamped x, y, clamped x, y}                     */
+    uint32_t mvd_bits[12];         /* P.mvd_bits (dynamically indexed by the rate function)                 */
+};
+/* LDS state of the search kernel only; lives at the start of the dynamic pool (the staged windows follow), so the
+ * HME kernel does not pay for it and fits ~3x more workgroups per CU */
+struct MeSearch {
     uint16_t sad8[64][64];         /* per-position 8x8 even-row SADs of the current chunk  */
     uint16_t sad16[64][16];
     uint32_t sad32[64][4];
     uint32_t key[85];              /* packed (sad,index) minima, PUs 1..84                 */
     unsigned long long key64;      /* 64x64 */
-    unsigned long long hkey[4];    /* HME per-quadrant minima                              */
     uint32_t best_sad[2][85], best_mv[2][85], best_ssd[2][85];
     uint8_t dir[2][85];
     uint32_t dist[85][8];          /* sub-pel distortions (search metric)                  */
     uint32_t dsad[85][8];          /* full SAD at the same positions (SSD search only)     */
     uint32_t bipred[85];
-    uint32_t acc[8];               /* LCU-level SAD accumulators                           */
-    int16_t hx[3][2][2], hy[3][2][2]; /* HME centres per level [w][h]                      */
-    unsigned long long hs[3][2][2];
-    int cx, cy;                    /* search centre of the current list                    */
     int e32, e16, e8, eq;
     int sums[9];                   /* SuPelEnable: per tier {sum mvx, sum mvy, sum sad} */
-    int qp[4][4];                  /* HME quadrant search areas {origin x, origin y, width, height}         */
-    int cand[6][4];                /* LCU-SAD candidates {unclamped x, y, clamped x, y}                     */
-    uint32_t mvd_bits[12];         /* P.mvd_bits (dynamically indexed by the rate function)                 */
 };
+#define ME_SEARCH_BYTES ((int)((sizeof(MeSearch) + 15) & ~(size_t)15))
+/* what the HME kernel hands to the search kernel (and to itself for list 1: trap A21) per LCU */
+struct MeCarry {
+    int16_t hx[3][2][2], hy[3][2][2];
+    unsigned long long hs[3][2][2];
+    int32_t cx[2], cy[2];          /* search centre after EbHevcCheckZeroZeroCenter, per list */
+    int32_t hme_init_done, pad;
+};
+static_assert(sizeof(MeCarry) <= 192, "context.hip reserves 192 bytes of carry per LCU");
 
 /* ------------------------------------------------------------------------- */
 
@@ -528,8 +541,15 @@ __device__ __forceinline__ int tier_sz_of(int tier) { return 64 >> tier; }
 __device__ __forceinline__ int tier_lc_of(int tier) { return tier == 0 ? 5 : tier == 1 ? 3 : tier == 2 ? 1 : 0; }
 __device__ __forceinline__ int pick4(int i, int a, int b, int c, int d) { return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
 
-/* grid = (max LCUs of any job, jobs): one workgroup per (picture, LCU) */
-__global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const MeJobDev *__restrict__ jobs)
+/* grid = (max LCUs of any job, jobs): one workgroup per (picture, LCU).
+ * The per-LCU chain is split in two kernels per reference list (the launcher runs them back to back):
+ *   PHASE 0  "hme"     TestSearchAreaBounds + HME L0/L1/L2 + CheckZeroZeroCenter -> search centre (MeCarry)
+ *   PHASE 1  "search"  full-pel 85-PU search + sub-pel refinement of that list; after the last list also
+ *                      bi-prediction and the candidate records
+ * The HME part needs ~15 KB of LDS and few registers, the search part ~55 KB: as separate kernels the
+ * latency-bound HME phases run at ~3x the occupancy instead of inheriting the search kernel's footprint. */
+template <int PHASE>
+__global__ __launch_bounds__(NT, PHASE == 0 ? 4 : ME_MIN_WAVES_PER_SIMD) void k_me(const MeJobDev *__restrict__ jobs, int list)
 {
     __shared__ MeShared S;
     const MeJobDev &J = jobs[blockIdx.y];
@@ -542,6 +562,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
         return;
     const SvtAmdMeParams &P = J.P; /* stays in global memory: uniform fields come in through scalar loads; a private copy
                                      * would live in scratch because of the indexed arrays inside */
+    if (list >= P.num_lists)
+        return;
     const PicView cur = J.cur, ref0 = J.ref0, ref1 = J.ref1;
     SvtAmdMeLcuResult *__restrict__ out = J.out;
     const int lcu_begin = J.lcu_begin;
@@ -553,59 +575,65 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
     const int lw = imin(LCU, W - ox), lh = imin(LCU, H - oy);
     const int pf = cur.pitch_full;
     const int method = P.fractional_search_method;
+    MeCarry *__restrict__ carry = &J.carry[lcu];
+    SvtAmdMeLcuResult *o = &out[lcu];
+    MeSearch &B = *(MeSearch *)g_pool; /* PHASE 1 only */
+    const PicView &R = list ? ref1 : ref0;
+    (void)method;
 
-    STAMP(0);
+    STAMP(PHASE == 0 ? 0 : 5);
     /* ---- stage the source LCU (EbMotionEstimationProcess.c:714-779) ---- */
     for (int i = t; i < LCU * LCU / 4; i += NT) {
         const int y = i >> 4, x = (i & 15) << 2;
         *(uint32_t *)&S.src[y * LCU + x] = *(const uint32_t *)(cur.full + (ptrdiff_t)(oy + y) * pf + ox + x);
     }
-    if (t < 128) { /* 1/4: 16 even rows x 32 */
-        const int y = t >> 3, x = (t & 7) << 2;
-        *(uint32_t *)&S.qsrc[y * 32 + x] =
-            ld4(cur.quarter + (ptrdiff_t)((oy >> 1) + 2 * y) * cur.pitch_quarter + (ox >> 1) + x);
-    } else if (t < 160) { /* 1/16: 8 even rows x 16 */
-        const int u = t - 128, y = u >> 2, x = (u & 3) << 2;
-        *(uint32_t *)&S.ssrc[y * 16 + x] =
-            ld4(cur.sixteenth + (ptrdiff_t)((oy >> 2) + 2 * y) * cur.pitch_sixteenth + (ox >> 2) + x);
-    }
-    for (int i = t; i < 2 * 85; i += NT) {
-        (&S.best_sad[0][0])[i] = 0;
-        (&S.best_mv[0][0])[i] = 0;
-        (&S.best_ssd[0][0])[i] = 0;
-        (&S.dir[0][0])[i] = 0;
-    }
-    if (t < 85)
-        S.bipred[t] = 0;
-    if (t >= 64 && t < 76)
-        S.mvd_bits[t - 64] = P.mvd_bits[t - 64];
-    if (t < 12) {
-        (&S.hx[0][0][0])[t] = 0;
-        (&S.hy[0][0][0])[t] = 0;
-        (&S.hs[0][0][0])[t] = 0;
+    int cx = 0, cy = 0;
+    if (PHASE == 0) {
+        if (t < 128) { /* 1/4: 16 even rows x 32 */
+            const int y = t >> 3, x = (t & 7) << 2;
+            *(uint32_t *)&S.qsrc[y * 32 + x] =
+                ld4(cur.quarter + (ptrdiff_t)((oy >> 1) + 2 * y) * cur.pitch_quarter + (ox >> 1) + x);
+        } else if (t < 160) { /* 1/16: 8 even rows x 16 */
+            const int u = t - 128, y = u >> 2, x = (u & 3) << 2;
+            *(uint32_t *)&S.ssrc[y * 16 + x] =
+                ld4(cur.sixteenth + (ptrdiff_t)((oy >> 2) + 2 * y) * cur.pitch_sixteenth + (ox >> 2) + x);
+        }
+        if (t >= 64 && t < 76)
+            S.mvd_bits[t - 64] = P.mvd_bits[t - 64];
+        if (t < 12) { /* per-quadrant HME centres survive from list 0 to list 1 (trap A21) */
+            (&S.hx[0][0][0])[t] = list ? (&carry->hx[0][0][0])[t] : (int16_t)0;
+            (&S.hy[0][0][0])[t] = list ? (&carry->hy[0][0][0])[t] : (int16_t)0;
+            (&S.hs[0][0][0])[t] = list ? (&carry->hs[0][0][0])[t] : 0ull;
+        }
+    } else {
+        for (int i = t; i < 85; i += NT) {
+            B.best_sad[list][i] = 0, B.best_mv[list][i] = 0, B.best_ssd[list][i] = 0, B.dir[list][i] = 0;
+            /* the other list: zero for a one-list picture, list 0's final result for list 1 */
+            B.best_sad[1 - list][i] = list ? o->best_sad[0][i] : 0u;
+            B.best_mv[1 - list][i] = list ? o->best_mv[0][i] : 0u;
+            B.best_ssd[1 - list][i] = 0, B.dir[1 - list][i] = 0;
+            B.bipred[i] = 0;
+        }
+        cx = carry->cx[list], cy = carry->cy[list];
     }
     __syncthreads();
 
     LWin wF, wB, wH, wJ; /* LDS windows of the current list's reference planes */
-    int hme_init_done = 0;
-    int sa_x0 = 0, sa_x1 = 0, sa_y0 = 0, sa_y1 = 0, sa_w0 = 0, sa_w1 = 0, sa_h0 = 0, sa_h1 = 0;
-    int hcx0 = 0, hcx1 = 0, hcy0 = 0, hcy1 = 0;
 
-    for (int list = 0; list < P.num_lists; list++) {
-        const PicView &R = list ? ref1 : ref0;
-        int cx = 0, cy = 0;
+    if (PHASE == 0) {
+        int hme_init_done = list ? carry->hme_init_done : 0;
         int zero_sad_valid = 0;
-
+        const uint32_t mv64_l0 = list ? o->best_mv[0][0] : 0u; /* list 0's final 64x64 MV (direct candidate) */
         if (P.temporal_layer_index > 0 || list == 0) {
-            if (list == 0) STAMP(1);
+            STAMP(1);
             /* ---- TestSearchAreaBounds (EbMotionEstimation.c:3363-3665) ---- */
             if (P.update_hme_search_center) {
                 const int nc = list == 1 ? 6 : 5;
                 if (t < 6) { /* candidate t: zero, A, B, C, D, direct (list-0 64x64 MV mirrored) */
                     int ux = t == 1 ? -(int)P.hme_l0_total_w : t == 2 ? (int)P.hme_l0_total_w
-                             : t == 5 ? 0 - (mvx(S.best_mv[0][0]) >> 2) : 0;
+                             : t == 5 ? 0 - (mvx(mv64_l0) >> 2) : 0;
                     int uy = t == 3 ? -(int)P.hme_l0_total_h : t == 4 ? (int)P.hme_l0_total_h
-                             : t == 5 ? 0 - (mvy(S.best_mv[0][0]) >> 2) : 0;
+                             : t == 5 ? 0 - (mvy(mv64_l0) >> 2) : 0;
                     ux = (int16_t)ux, uy = (int16_t)uy;
                     S.cand[t][0] = ux, S.cand[t][1] = uy;
                     S.cand[t][2] = t ? clamp_center(ox, ux, LCU - 1, W) : 0;
@@ -625,7 +653,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 __syncthreads(); /* S.acc / S.cand are reused below */
             }
 
-            if (list == 0) STAMP(2);
+            STAMP(2);
             /* ---- HME (EbMotionEstimation.c:3800-4069) ---- */
             if (P.enable_hme_flag && lh == LCU) {
                 const int nw = P.num_hme_regions_w, nh = P.num_hme_regions_h;
@@ -768,9 +796,9 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 }
             }
         }
-        if (list) hcx1 = cx, hcy1 = cy; else hcx0 = cx, hcy0 = cy;
+        const int hcx = cx, hcy = cy; /* the HME centre before the zero-centre check: reported in the record */
 
-        if (list == 0) STAMP(3);
+        STAMP(3);
         /* ---- EbHevcCheckZeroZeroCenter (:2946-3034) ---- */
         if (cx != 0 || cy != 0) {
             if (P.update_hme_search_center) {
@@ -793,20 +821,34 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             __syncthreads();
         }
 
+        /* hand-over to the search kernel (and to the HME kernel of list 1) */
+        if (t == 0) {
+            carry->cx[list] = cx, carry->cy[list] = cy;
+            carry->hme_init_done = hme_init_done;
+            o->hme_center_x[list] = (int16_t)hcx, o->hme_center_y[list] = (int16_t)hcy;
+            if (P.num_lists == 1)
+                o->hme_center_x[1] = 0, o->hme_center_y[1] = 0;
+        }
+        if (t < 12) {
+            (&carry->hx[0][0][0])[t] = (&S.hx[0][0][0])[t];
+            (&carry->hy[0][0][0])[t] = (&S.hy[0][0][0])[t];
+            (&carry->hs[0][0][0])[t] = (&S.hs[0][0][0])[t];
+        }
+        STAMP(4);
+    } else { /* PHASE 1 */
         /* ---- search area (:4072-4200); unrestricted MVs ---- */
         int saw = imin(P.search_area_width, 127), sah = imin(P.search_area_height, 127);
         int sox = cx - (saw >> 1), soy = cy - (sah >> 1);
         clamp_area(ox, LCU - 1, W, sox, saw);
         clamp_area(oy, LCU - 1, H, soy, sah);
-        if (list) sa_x1 = sox, sa_y1 = soy, sa_w1 = saw, sa_h1 = sah; else sa_x0 = sox, sa_y0 = soy, sa_w0 = saw, sa_h0 = sah;
 
-        if (list == 0) STAMP(4);
+        STAMP(6);
         /* ---- FullPelSearch_LCU (:586-633) ---- */
         {
             if (t < 85)
-                S.key[t] = 0xffffffffu;
+                B.key[t] = 0xffffffffu;
             if (t == 0)
-                S.key64 = ~0ull;
+                B.key64 = ~0ull;
             const int npos = saw * sah, mult8 = saw & ~7;
             const uint32_t rcw = fastdiv_recip((uint32_t)saw);
             const int b = t & 63, sub = t >> 6;
@@ -824,7 +866,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
              * quarter-pel neighbours). */
             {
                 const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
-                int off = load_window(wF, 0, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                int off = load_window(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t);
                 /* the half-pel planes are first read by the sub-pel stages: fetch them asynchronously under the
                  * full-pel search (waited for at "sub-pel windows landed" below) */
                 off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t);
@@ -860,7 +902,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                         const int sx = 4 * mi + k - a0, p = sy * saw + sx;
                         if (sx >= 0 && sx < saw && p >= base && p < pend) {
                             const uint32_t sv = (uint32_t)(acc >> (16 * k)) & 0xffffu;
-                            S.sad8[p - base][b] = (uint16_t)sv;
+                            B.sad8[p - base][b] = (uint16_t)sv;
                             const uint32_t key = (sv << 14) | (uint32_t)p;
                             best8 = key < best8 ? key : best8;
                         }
@@ -873,73 +915,73 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     for (int i = 0; i < 4; i++) {
                         const int pl = (t >> 4) + 16 * i, p = base + pl;
                         if (p < npos) {
-                            const uint16_t *q = &S.sad8[pl][4 * k16];
+                            const uint16_t *q = &B.sad8[pl][4 * k16];
                             const uint32_t s = (uint32_t)q[0] + q[1] + q[2] + q[3];
-                            S.sad16[pl][k16] = (uint16_t)s;
+                            B.sad16[pl][k16] = (uint16_t)s;
                             const uint32_t k = (s << 14) | (uint32_t)p;
                             bk = k < bk ? k : bk;
                         }
                     }
                     if (bk != 0xffffffffu)
-                        atomicMin(&S.key[5 + k16], bk);
+                        atomicMin(&B.key[5 + k16], bk);
                 }
                 __syncthreads();
                 { /* 32x32: one (position, quadrant) per thread */
                     const int pl = t >> 2, k32 = t & 3, p = base + pl;
                     if (p < npos) {
-                        const uint16_t *q = &S.sad16[pl][4 * k32];
+                        const uint16_t *q = &B.sad16[pl][4 * k32];
                         const uint32_t s = (uint32_t)q[0] + q[1] + q[2] + q[3];
-                        S.sad32[pl][k32] = s;
-                        atomicMin(&S.key[1 + k32], (s << 14) | (uint32_t)p);
+                        B.sad32[pl][k32] = s;
+                        atomicMin(&B.key[1 + k32], (s << 14) | (uint32_t)p);
                     }
                 }
                 __syncthreads();
                 if (t < 64) { /* 64x64: '<=' inside complete groups of 8, '<' in the tail */
                     const int p = base + t;
                     if (p < npos) {
-                        const uint32_t s = S.sad32[t][0] + S.sad32[t][1] + S.sad32[t][2] + S.sad32[t][3];
+                        const uint32_t s = B.sad32[t][0] + B.sad32[t][1] + B.sad32[t][2] + B.sad32[t][3];
                         const int sy = p / saw, sx = p - sy * saw;
                         const uint32_t code = (sx < mult8) ? (uint32_t)(16383 - p) : (0x4000u | (uint32_t)p);
-                        atomicMin(&S.key64, ((unsigned long long)s << 15) | code);
+                        atomicMin(&B.key64, ((unsigned long long)s << 15) | code);
                     }
                 }
                 __syncthreads();
             }
-            atomicMin(&S.key[21 + b], best8);
+            atomicMin(&B.key[21 + b], best8);
             __syncthreads();
             if (t < 85) {
                 uint32_t s;
                 int p;
                 if (t == 0) {
-                    const unsigned long long k = S.key64;
+                    const unsigned long long k = B.key64;
                     const uint32_t code = (uint32_t)(k & 0x7fff);
                     s = (uint32_t)(k >> 15);
                     p = (code & 0x4000u) ? (int)(code & 0x3fff) : 16383 - (int)code;
                 } else {
-                    const uint32_t k = S.key[t];
+                    const uint32_t k = B.key[t];
                     s = k >> 14;
                     p = (int)(k & 0x3fff);
                 }
                 const int sy = p / saw, sx = p - sy * saw;
-                S.best_sad[list][t] = 2 * s;
-                S.best_mv[list][t] = mvpack((sx + sox) * 4, (sy + soy) * 4);
+                B.best_sad[list][t] = 2 * s;
+                B.best_mv[list][t] = mvpack((sx + sox) * 4, (sy + soy) * 4);
             }
             __builtin_amdgcn_s_waitcnt(0); /* sub-pel windows landed (LDS-DMA issued before the search) */
             __syncthreads();
         }
 
-        if (list == 0) STAMP(5);
+        STAMP(7);
         /* ---- sub-pel (:4236-4318) ---- */
         /* SuPelEnable (:3035-3361): tier sums of MV components and SADs, one PU per thread */
         if (P.fractional_search_model == 1) {
             if (t < 9)
-                S.sums[t] = 0;
+                B.sums[t] = 0;
             __syncthreads();
             if (t >= 1 && t < 85) {
                 const int tier = t < 5 ? 0 : t < 21 ? 1 : 2;
-                atomicAdd(&S.sums[tier * 3 + 0], mvx(S.best_mv[list][t]));
-                atomicAdd(&S.sums[tier * 3 + 1], mvy(S.best_mv[list][t]));
-                atomicAdd(&S.sums[tier * 3 + 2], (int)S.best_sad[list][t]);
+                atomicAdd(&B.sums[tier * 3 + 0], mvx(B.best_mv[list][t]));
+                atomicAdd(&B.sums[tier * 3 + 1], mvy(B.best_mv[list][t]));
+                atomicAdd(&B.sums[tier * 3 + 2], (int)B.best_sad[list][t]);
             }
             __syncthreads();
         }
@@ -951,9 +993,9 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 const int shift[3] = {2, 4, 6};
                 uint32_t mag[3], avgsad[3];
                 for (int tt = 0; tt < 3; tt++) {
-                    const uint32_t ux = (uint32_t)(S.sums[tt * 3 + 0] >> shift[tt]), uy = (uint32_t)(S.sums[tt * 3 + 1] >> shift[tt]);
+                    const uint32_t ux = (uint32_t)(B.sums[tt * 3 + 0] >> shift[tt]), uy = (uint32_t)(B.sums[tt * 3 + 1] >> shift[tt]);
                     mag[tt] = ux * ux + uy * uy;
-                    avgsad[tt] = (uint32_t)S.sums[tt * 3 + 2] >> shift[tt];
+                    avgsad[tt] = (uint32_t)B.sums[tt * 3 + 2] >> shift[tt];
                 }
                 const int tl = P.temporal_layer_index;
                 const uint32_t th = tl == 0 ? 48 * 48 : tl == 1 ? 32 * 32 : tl == 2 ? 80 * 80 : 48 * 48;
@@ -963,26 +1005,26 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 e8 = (tl <= 2) ? !(avgsad[2] < 8 * 8 * 2) : ((mag[2] < th) ? !(avgsad[2] < 8 * 8 * 2) : 0);
                 eq = 1;
             }
-            S.e32 = e32, S.e16 = e16 && P.cu16x16_mode == 0, S.e8 = e8 && P.cu8x8_mode != 1, S.eq = eq;
+            B.e32 = e32, B.e16 = e16 && P.cu16x16_mode == 0, B.e8 = e8 && P.cu8x8_mode != 1, B.eq = eq;
         }
         __syncthreads();
-        const int any_sub = S.e32 || S.e16 || S.e8 || S.eq || 0;
+        const int any_sub = B.e32 || B.e16 || B.e8 || B.eq || 0;
         const int run_sub = (P.fractional_search_model != 2) && any_sub;
         if (run_sub) {
             const int f64 = P.fractional_search_64x64;
-            const int en0 = f64, en1 = S.e32, en2 = S.e16, en3 = S.e8;
+            const int en0 = f64, en1 = B.e32, en2 = B.e16, en3 = B.e8;
 #define EN(tier_) pick4(tier_, en0, en1, en2, en3)
             const int rstep = (method == SVT_AMD_SUB_SAD_SEARCH) ? 2 : 1;
-            if (list == 0) STAMP(6);
+            STAMP(8);
             /* ===== half-pel: EbHevcHalfPelSearch_LCU / PU_HalfPelRefinement (:733-1187) ===== */
             for (int i = t; i < 85 * 8; i += NT) {
-                (&S.dist[0][0])[i] = 0;
-                (&S.dsad[0][0])[i] = 0;
+                (&B.dist[0][0])[i] = 0;
+                (&B.dsad[0][0])[i] = 0;
             }
             __syncthreads();
             /* item = (PU, position k, row chunk): chunk counts {32, 8, 2, 1} per tier give every lane the same
              * ~16 dword SADs; the chunks of one (PU, k) sit on adjacent lanes and are summed with a segmented
-             * shuffle, so S.dist is written once per (PU, k) - no LDS atomics. */
+             * shuffle, so B.dist is written once per (PU, k) - no LDS atomics. */
             for (int tier = 0; tier < 4; tier++) {
                 if (!EN(tier))
                     continue;
@@ -992,7 +1034,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     const int ch = i & ((1 << lc) - 1), k = (i >> lc) & 7, n = tier_first_of(tier) + (i >> (lc + 3));
                     int px_, py_, psz;
                     pu_geom_z(n, px_, py_, psz);
-                    const uint32_t mv = S.best_mv[list][n];
+                    const uint32_t mv = B.best_mv[list][n];
                     /* order L,R,T,B,TL,TR,BR,BL: planes b,b,h,h,j,j,j,j; offsets */
                     const LWin &pl = (k < 2) ? wB : (k < 4 ? wH : wJ);
                     const int ddx = (k == 1 || k == 5 || k == 6) ? 1 : 0, ddy = (k == 3 || k == 6 || k == 7) ? 1 : 0;
@@ -1012,8 +1054,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     for (int o = 1; o < (1 << lc); o <<= 1)
                         d += __shfl_xor(d, o), sd += __shfl_xor(sd, o);
                     if (ch == 0) {
-                        S.dist[n][k] = d;
-                        S.dsad[n][k] = sd;
+                        B.dist[n][k] = d;
+                        B.dsad[n][k] = sd;
                     }
                 }
             }
@@ -1027,7 +1069,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                         const int row = i % sz, n = tier_first_of(tier) + i / sz;
                         int px_, py_, psz;
                         pu_geom_z(n, px_, py_, psz);
-                        const uint32_t mv = S.best_mv[list][n];
+                        const uint32_t mv = B.best_mv[list][n];
                         const uint8_t *r = wat(wF, ox + px_ + (mvx(mv) >> 2), oy + py_ + (mvy(mv) >> 2) + row);
                         const uint8_t *s = &S.src[(py_ + row) * LCU + px_];
                         uint32_t d = 0;
@@ -1036,7 +1078,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                             lds_ld_unaligned<2>(r + x, v);
                             d += ssd4(*(const uint32_t *)(s + x), v[0]) + ssd4(*(const uint32_t *)(s + x + 4), v[1]);
                         }
-                        atomicAdd(&S.best_ssd[list][n], d);
+                        atomicAdd(&B.best_ssd[list][n], d);
                     }
                 }
             }
@@ -1045,15 +1087,15 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 const int tier = t == 0 ? 0 : t < 5 ? 1 : t < 21 ? 2 : 3;
                 if (EN(tier)) {
                     const int mdx[8] = {-2, 2, 0, 0, -2, 2, 2, -2}, mdy[8] = {0, 0, -2, 2, -2, -2, 2, 2};
-                    const uint32_t mv0 = S.best_mv[list][t];
-                    uint32_t bsad = S.best_sad[list][t], bmv = mv0, bssd = S.best_ssd[list][t];
+                    const uint32_t mv0 = B.best_mv[list][t];
+                    uint32_t bsad = B.best_sad[list][t], bmv = mv0, bssd = B.best_ssd[list][t];
                     uint32_t dmin = 0xffffffffu;
                     for (int k = 0; k < 8; k++) {
-                        const uint32_t d = (method == SVT_AMD_SUB_SAD_SEARCH) ? (S.dist[t][k] << 1) : S.dist[t][k];
+                        const uint32_t d = (method == SVT_AMD_SUB_SAD_SEARCH) ? (B.dist[t][k] << 1) : B.dist[t][k];
                         dmin = d < dmin ? d : dmin;
                         if (method == SVT_AMD_SSD_SEARCH) {
                             if (d < bssd)
-                                bsad = S.dsad[t][k], bmv = mvpack(mvx(mv0) + mdx[k], mvy(mv0) + mdy[k]), bssd = d;
+                                bsad = B.dsad[t][k], bmv = mvpack(mvx(mv0) + mdx[k], mvy(mv0) + mdy[k]), bssd = d;
                         } else if (d < bsad) {
                             bsad = d, bmv = mvpack(mvx(mv0) + mdx[k], mvy(mv0) + mdy[k]);
                         }
@@ -1063,23 +1105,23 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     const uint8_t code[8] = {D_L, D_R, D_T, D_B, D_TL, D_TR, D_BR, D_BL};
                     uint8_t dirv = 0;
                     for (int i = 7; i >= 0; i--) {
-                        const uint32_t d = (method == SVT_AMD_SUB_SAD_SEARCH) ? (S.dist[t][chk[i]] << 1) : S.dist[t][chk[i]];
+                        const uint32_t d = (method == SVT_AMD_SUB_SAD_SEARCH) ? (B.dist[t][chk[i]] << 1) : B.dist[t][chk[i]];
                         if (d == dmin)
                             dirv = code[chk[i]];
                     }
-                    S.best_sad[list][t] = bsad, S.best_mv[list][t] = bmv, S.best_ssd[list][t] = bssd;
-                    S.dir[list][t] = dirv;
+                    B.best_sad[list][t] = bsad, B.best_mv[list][t] = bmv, B.best_ssd[list][t] = bssd;
+                    B.dir[list][t] = dirv;
                 }
             }
             __syncthreads();
 
-            if (list == 0) STAMP(7);
+            STAMP(9);
             /* ===== quarter-pel: QuarterPelSearch_LCU / PU_QuarterPelRefinementOnTheFly (:1226-1846) ===== */
-            const int qen0 = f64, qen1 = S.eq && S.e32, qen2 = S.eq && S.e16, qen3 = S.eq && S.e8;
+            const int qen0 = f64, qen1 = B.eq && B.e32, qen2 = B.eq && B.e16, qen3 = B.eq && B.e8;
 #define QEN(tier_) pick4(tier_, qen0, qen1, qen2, qen3)
             for (int i = t; i < 85 * 8; i += NT) {
-                (&S.dist[0][0])[i] = 0;
-                (&S.dsad[0][0])[i] = 0;
+                (&B.dist[0][0])[i] = 0;
+                (&B.dsad[0][0])[i] = 0;
             }
             __syncthreads();
             /* only the three positions next to the half-pel winner are evaluated (:1252-1273): item =
@@ -1099,10 +1141,10 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     const int n = tier_first_of(tier) + pidx;
                     int px_, py_, psz;
                     pu_geom_z(n, px_, py_, psz);
-                    const uint32_t mv = S.best_mv[list][n];
+                    const uint32_t mv = B.best_mv[list][n];
                     const int xMv = mvx(mv), yMv = mvy(mv);
                     const int qm = (yMv & 2) + ((xMv & 2) >> 1);
-                    const int code = (S.dir[list][n] + j - 1 + (qm ? 4 : 0)) & 7;
+                    const int code = (B.dir[list][n] + j - 1 + (qm ? 4 : 0)) & 7;
                     const int k = (int)((0x07361524u >> (4 * code)) & 7u); /* direction code -> position index */
                     const int y = ch * rpc * rstep;
                     const int ax = ox + px_ + ((xMv + 2) >> 2), ay = oy + py_ + ((yMv + 2) >> 2) + y;
@@ -1131,8 +1173,8 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     for (int o = 1; o < (1 << lc); o <<= 1)
                         d += __shfl_xor(d, o), sdv += __shfl_xor(sdv, o);
                     if (live && ch == 0) {
-                        S.dist[n][k] = d;
-                        S.dsad[n][k] = sdv;
+                        B.dist[n][k] = d;
+                        B.dsad[n][k] = sdv;
                     }
                 }
             }
@@ -1142,31 +1184,47 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 if (QEN(tier)) {
                     const int mdx[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, mdy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
                     const int kcode[8] = {D_L, D_R, D_T, D_B, D_TL, D_TR, D_BR, D_BL};
-                    const uint32_t mv0 = S.best_mv[list][t];
+                    const uint32_t mv0 = B.best_mv[list][t];
                     const int qm = (mvy(mv0) & 2) + ((mvx(mv0) & 2) >> 1);
-                    const int sd = S.dir[list][t];
-                    uint32_t bsad = S.best_sad[list][t], bmv = mv0, bssd = S.best_ssd[list][t];
+                    const int sd = B.dir[list][t];
+                    uint32_t bsad = B.best_sad[list][t], bmv = mv0, bssd = B.best_ssd[list][t];
                     for (int k = 0; k < 8; k++) {
                         const int target = qm ? ((kcode[k] + 4) & 7) : kcode[k];
                         const int diff = (sd - target) & 7;
                         if (!(diff == 0 || diff == 1 || diff == 7))
                             continue;
-                        const uint32_t d = (method == SVT_AMD_SUB_SAD_SEARCH) ? (S.dist[t][k] << 1) : S.dist[t][k];
+                        const uint32_t d = (method == SVT_AMD_SUB_SAD_SEARCH) ? (B.dist[t][k] << 1) : B.dist[t][k];
                         if (method == SVT_AMD_SSD_SEARCH) {
                             if (d < bssd)
-                                bsad = S.dsad[t][k], bmv = mvpack(mvx(mv0) + mdx[k], mvy(mv0) + mdy[k]), bssd = d;
+                                bsad = B.dsad[t][k], bmv = mvpack(mvx(mv0) + mdx[k], mvy(mv0) + mdy[k]), bssd = d;
                         } else if (d < bsad) {
                             bsad = d, bmv = mvpack(mvx(mv0) + mdx[k], mvy(mv0) + mdy[k]);
                         }
                     }
-                    S.best_sad[list][t] = bsad, S.best_mv[list][t] = bmv, S.best_ssd[list][t] = bssd;
+                    B.best_sad[list][t] = bsad, B.best_mv[list][t] = bmv, B.best_ssd[list][t] = bssd;
                 }
             }
             __syncthreads();
         }
-    } /* lists */
+        /* ---- this list's results (read back by the kernels of list 1 and by the parity tests) ---- */
+        if (t < 85) {
+            o->best_sad[list][t] = B.best_sad[list][t];
+            o->best_mv[list][t] = B.best_mv[list][t];
+            if (P.num_lists == 1)
+                o->best_sad[1][t] = 0, o->best_mv[1][t] = 0;
+        }
+        if (t == 0) {
+            o->search_origin_x[list] = (int16_t)sox, o->search_origin_y[list] = (int16_t)soy;
+            o->search_w[list] = (uint8_t)saw, o->search_h[list] = (uint8_t)sah;
+            if (P.num_lists == 1)
+                o->search_origin_x[1] = 0, o->search_origin_y[1] = 0, o->search_w[1] = 0, o->search_h[1] = 0;
+        }
+        if (list != P.num_lists - 1) {
+            STAMP(12);
+            return;
+        }
 
-    STAMP(8);
+    STAMP(10);
     /* ---- bi-prediction (:2608-2917) ---- */
     if (P.num_lists == 2) {
         const int rstep = (method == SVT_AMD_SUB_SAD_SEARCH) ? 2 : 1;
@@ -1186,7 +1244,7 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                 const uint8_t *a[2], *b[2];
                 for (int l = 0; l < 2; l++) {
                     const PicView &RR = l ? ref1 : ref0;
-                    const uint32_t mv = S.best_mv[l][n];
+                    const uint32_t mv = B.best_mv[l][n];
                     const int xMv = mvx(mv), yMv = mvy(mv);
                     const int ax = ox + px_ + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
                     const int frac = (xMv & 3) + ((yMv & 3) << 2);
@@ -1221,26 +1279,25 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
                     const uint32_t p1 = avg4(ld4(a[1] + x), ld4(b[1] + x));
                     d = sad4(*(const uint32_t *)(s + x), avg4(p0, p1), d);
                 }
-                atomicAdd(&S.bipred[n], d);
+                atomicAdd(&B.bipred[n], d);
             }
         }
         __syncthreads();
     }
 
-    STAMP(9);
+    STAMP(11);
     /* ---- candidate records (:4321-4440) ---- */
-    SvtAmdMeLcuResult *o = &out[lcu];
     if (t < 85) {
         const int pu = t;
         const int n = pu == 0 ? 0 : pu < 5 ? pu : pu < 21 ? c_tab16[pu - 5] + 5 : c_tab8[pu - 21] + 21;
         int total = P.num_lists;
         if (P.num_lists == 2 && (P.cu8x8_mode == 0 || pu < 21) && (P.cu16x16_mode == 0 || pu < 5))
             total = 3;
-        const uint32_t bi = (method == SVT_AMD_SUB_SAD_SEARCH) ? (S.bipred[n] << 1) : S.bipred[n];
-        const uint32_t v[3] = {S.best_sad[0][n], S.best_sad[1][n], bi};
+        const uint32_t bi = (method == SVT_AMD_SUB_SAD_SEARCH) ? (B.bipred[n] << 1) : B.bipred[n];
+        const uint32_t v[3] = {B.best_sad[0][n], B.best_sad[1][n], bi};
         SvtAmdMeCuResult r;
-        r.x_mv_l0 = (int16_t)mvx(S.best_mv[0][n]), r.y_mv_l0 = (int16_t)mvy(S.best_mv[0][n]);
-        r.x_mv_l1 = (int16_t)mvx(S.best_mv[1][n]), r.y_mv_l1 = (int16_t)mvy(S.best_mv[1][n]);
+        r.x_mv_l0 = (int16_t)mvx(B.best_mv[0][n]), r.y_mv_l0 = (int16_t)mvy(B.best_mv[0][n]);
+        r.x_mv_l1 = (int16_t)mvx(B.best_mv[1][n]), r.y_mv_l1 = (int16_t)mvy(B.best_mv[1][n]);
         r.total_me_candidate_index = (uint8_t)total;
         for (int k = 0; k < 3; k++)
             r.distortion[k] = 0, r.direction[k] = 0;
@@ -1269,24 +1326,14 @@ __global__ __launch_bounds__(NT, ME_MIN_WAVES_PER_SIMD) void k_me_picture(const 
             r.distortion[0] = v[0], r.direction[0] = SVT_AMD_UNI_PRED_LIST_0;
         }
         o->pu[pu] = r;
-        o->best_sad[0][t] = S.best_sad[0][t];
-        o->best_sad[1][t] = S.best_sad[1][t];
-        o->best_mv[0][t] = S.best_mv[0][t];
-        o->best_mv[1][t] = S.best_mv[1][t];
     }
-    if (t < 2) {
-        o->hme_center_x[t] = (int16_t)(t ? hcx1 : hcx0);
-        o->hme_center_y[t] = (int16_t)(t ? hcy1 : hcy0);
-        o->search_origin_x[t] = (int16_t)(t ? sa_x1 : sa_x0);
-        o->search_origin_y[t] = (int16_t)(t ? sa_y1 : sa_y0);
-        o->search_w[t] = (uint8_t)(t ? sa_w1 : sa_w0);
-        o->search_h[t] = (uint8_t)(t ? sa_h1 : sa_h0);
-    }
-    STAMP(10);
+    STAMP(12);
+    } /* PHASE 1 */
 }
 
-/* upper bound of the dynamic LDS pool a job needs: the largest of the per-phase window sets */
-static size_t me_pool_bytes(const SvtAmdMeParams *p)
+/* upper bounds of the dynamic LDS pools a job needs: HME kernel = the largest per-level window set;
+ * search kernel = MeSearch + the four staged search windows */
+static void me_pool_bytes(const SvtAmdMeParams *p, size_t *hme_pool, size_t *search_pool)
 {
     auto win = [](int w, int rows) { return (size_t)((w + 30) & ~15) * (size_t)rows; };
     size_t need = 0, v;
@@ -1316,37 +1363,48 @@ static size_t me_pool_bytes(const SvtAmdMeParams *p)
             need = v > need ? v : need;
         }
     }
+    *hme_pool = (need + 64 + 255) & ~(size_t)255; /* +64: the aligned over-read of the last window row */
     const int saw = p->search_area_width > 127 ? 127 : p->search_area_width;
     const int sah = p->search_area_height > 127 ? 127 : p->search_area_height;
-    v = 4 * win(saw + 67, sah + 67);
-    need = v > need ? v : need;
-    return (need + 64 + 255) & ~(size_t)255; /* +64: the aligned over-read of the last window row */
+    *search_pool = ((size_t)ME_SEARCH_BYTES + 4 * win(saw + 67, sah + 67) + 64 + 255) & ~(size_t)255;
 }
 
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus)
 {
     if (njobs < 1 || njobs > SVT_AMD_MAX_BATCH)
         return SVT_AMD_ERR_BAD_PARAM;
-    size_t pool = 0;
+    size_t pool0 = 0, pool1 = 0;
+    int max_lists = 1;
     for (int i = 0; i < njobs; i++) {
-        const size_t b = me_pool_bytes(&host_jobs[i].P);
-        pool = b > pool ? b : pool;
+        size_t a, b;
+        me_pool_bytes(&host_jobs[i].P, &a, &b);
+        pool0 = a > pool0 ? a : pool0;
+        pool1 = b > pool1 ? b : pool1;
+        max_lists = host_jobs[i].P.num_lists > max_lists ? host_jobs[i].P.num_lists : max_lists;
     }
-    if (pool + sizeof(MeShared) > 160 * 1024) {
-        svt_amd_set_error("motion estimation: search windows need %zu B of LDS (> 160 KiB)", pool + sizeof(MeShared));
+    if (pool1 + sizeof(MeShared) > 160 * 1024 || pool0 + sizeof(MeShared) > 160 * 1024) {
+        svt_amd_set_error("motion estimation: search windows need %zu B of LDS (> 160 KiB)", pool1 + sizeof(MeShared));
         return SVT_AMD_ERR_BAD_PARAM;
     }
-    static size_t attr_set = 0;
-    if (pool > attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_me_picture, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool));
-        attr_set = pool;
+    static size_t attr0 = 0, attr1 = 0;
+    if (pool0 > attr0) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_me<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool0));
+        attr0 = pool0;
+    }
+    if (pool1 > attr1) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_me<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool1));
+        attr1 = pool1;
     }
     /* pageable source: the runtime stages it before returning, so host_jobs may be reused */
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs, host_jobs, sizeof(MeJobDev) * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream));
     int rc = svt_amd_stamp_begin(ctx, KC_ME_SEARCH);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(k_me_picture, dim3((unsigned)((max_lcus + 7) & ~7), (unsigned)njobs), dim3(NT), pool, ctx->stream, ctx->d_jobs);
+    const dim3 grid((unsigned)((max_lcus + 7) & ~7), (unsigned)njobs);
+    for (int list = 0; list < max_lists; list++) { /* list 1 depends on list 0's result (direct candidate, bi-pred) */
+        hipLaunchKernelGGL(k_me<0>, grid, dim3(NT), pool0, ctx->stream, ctx->d_jobs, list);
+        hipLaunchKernelGGL(k_me<1>, grid, dim3(NT), pool1, ctx->stream, ctx->d_jobs, list);
+    }
     HIP_TRY(hipGetLastError());
     return svt_amd_stamp_end(ctx);
 }

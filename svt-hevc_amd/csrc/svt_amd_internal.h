@@ -30,6 +30,7 @@ struct DevPicture {
     DevPlane full, quarter, sixteenth, hp_b, hp_h, hp_j;
     SvtAmdMeLcuResult *d_me_out;   /* device buffer, one record per LCU */
     SvtAmdOisLcuResult *d_ois_out; /* device buffer, one record per LCU */
+    void *d_me_carry;              /* MeCarry per LCU (me_kernels.hip), 192 B reserved each */
     uint8_t *d_staging;            /* device copy of the raw luma (upload path) */
     size_t   staging_bytes;
     uint16_t width, height;
@@ -51,6 +52,7 @@ struct MeJobDev {
     SvtAmdMeParams P;
     PicView cur, ref0, ref1;
     SvtAmdMeLcuResult *out;
+    struct MeCarry *carry;         /* per-LCU hand-over between the HME and the search kernel */
     int32_t lcu_begin, lcu_count;
     unsigned long long *dbg_clock; /* optional: 16 clock stamps per workgroup (phase profile) */
 };
