@@ -140,6 +140,17 @@ struct LWin {
 };
 extern __shared__ __attribute__((aligned(16))) uint8_t g_pool[];
 
+/* row pitch of a staged window covering plane columns [x0, x1): rows start on a 16-byte boundary of the plane.
+ * odd != 0 rounds the pitch to an ODD number of 16-byte units: rows then start on 8 different bank phases instead of
+ * 1-2 (a pitch of 64 B puts every other row on the same LDS banks), used for the HME windows whose work items walk
+ * down the rows. */
+__device__ __forceinline__ int win_pitch(int x0, int x1, int odd)
+{
+    int wa = ((x1 - (x0 & ~15)) + 15) & ~15;
+    if (odd && !((wa >> 4) & 1))
+        wa += 16;
+    return wa;
+}
 __device__ __forceinline__ const uint8_t *wat(const LWin &w, int x, int y)
 {
     return w.p + (y - w.y0) * w.stride + (x - w.x0);
@@ -164,9 +175,9 @@ __device__ __forceinline__ int load_window(LWin &w, int off, const uint8_t *plan
  * base + 16 i), which is exactly the row-major window layout.  The caller must execute
  * `__builtin_amdgcn_s_waitcnt(0)` + `__syncthreads()` before anybody reads the window. */
 __device__ __forceinline__ int load_window_async(LWin &w, int off, const uint8_t *plane, int pitch, int x0, int y0, int x1,
-                                                 int y1, int t)
+                                                 int y1, int t, int odd = 0)
 {
-    const int xa = x0 & ~15, wa = ((x1 - xa) + 15) & ~15, n16 = wa >> 4, rows = y1 - y0, total = rows * n16;
+    const int xa = x0 & ~15, wa = win_pitch(x0, x1, odd), n16 = wa >> 4, rows = y1 - y0, total = rows * n16;
     uint8_t *dst = g_pool + off;
     w.p = dst, w.x0 = xa, w.y0 = y0, w.stride = wa;
     const int lane = t & 63;
@@ -438,7 +449,7 @@ __device__ void hme_pass_q(MeShared &S, const uint8_t *src, int sstride, const u
             const int qx = S.qp[q][0], qy = S.qp[q][1], qw = S.qp[q][2], qh = S.qp[q][3];
             LWin w;
             off = load_window_async(w, off, refplane, pitch, bx0 + qx, by0 + qy, bx0 + qx + qw + 4 * G,
-                                    by0 + qy + qh + 2 * (ROWS - 1) + 1, t);
+                                    by0 + qy + qh + 2 * (ROWS - 1) + 1, t, 1);
         }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -447,11 +458,11 @@ __device__ void hme_pass_q(MeShared &S, const uint8_t *src, int sstride, const u
     const int q = wave % nq, slot = wave / nq, nslots = (4 + nq - 1 - q) / nq; /* waves serving quadrant q */
     int off = 0;
     for (int k = 0; k < q; k++) {
-        const int x0k = bx0 + S.qp[k][0], xak = x0k & ~15;
-        off += (S.qp[k][3] + 2 * (ROWS - 1) + 1) * (((x0k + S.qp[k][2] + 4 * G - xak) + 15) & ~15);
+        const int x0k = bx0 + S.qp[k][0];
+        off += (S.qp[k][3] + 2 * (ROWS - 1) + 1) * win_pitch(x0k, x0k + S.qp[k][2] + 4 * G, 1);
     }
     const int qw = S.qp[q][2], qh = S.qp[q][3];
-    const int x0 = bx0 + S.qp[q][0], xa = x0 & ~15, wstride = ((x0 + qw + 4 * G - xa) + 15) & ~15;
+    const int x0 = bx0 + S.qp[q][0], xa = x0 & ~15, wstride = win_pitch(x0, x0 + qw + 4 * G, 1);
     const int bo0 = x0 - xa;                          /* window byte offset of search position sx = 0 */
     const int m0 = bo0 >> 2, mcount = ((bo0 + qw - 1) >> 2) - m0 + 1;
     const int items = qh * mcount * C;
@@ -549,7 +560,7 @@ __device__ __forceinline__ int pick4(int i, int a, int b, int c, int d) { return
  * The HME part needs ~15 KB of LDS and few registers, the search part ~55 KB: as separate kernels the
  * latency-bound HME phases run at ~3x the occupancy instead of inheriting the search kernel's footprint. */
 template <int PHASE>
-__global__ __launch_bounds__(NT, PHASE == 0 ? 4 : ME_MIN_WAVES_PER_SIMD) void k_me(const MeJobDev *__restrict__ jobs, int list)
+__global__ __launch_bounds__(NT, PHASE == 0 ? 6 : ME_MIN_WAVES_PER_SIMD) void k_me(const MeJobDev *__restrict__ jobs, int list)
 {
     __shared__ MeShared S;
     const MeJobDev &J = jobs[blockIdx.y];
@@ -851,9 +862,12 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? 4 : ME_MIN_WAVES_PER_SIMD) void k_
                 B.key64 = ~0ull;
             const int npos = saw * sah, mult8 = saw & ~7;
             const uint32_t rcw = fastdiv_recip((uint32_t)saw);
-            const int b = t & 63, sub = t >> 6;
-            int bx, by, bsz;
-            pu_geom_z(21 + b, bx, by, bsz);
+            /* thread -> (8x8 block, item slot): a wave owns two rows of eight blocks, four lanes (slots) per block.
+             * Blocks in the same column are 8 window rows apart = the same LDS banks for any 16-byte-multiple pitch, so
+             * a wave must not hold all 64 blocks at one search position (that was an 8-way bank conflict). */
+            const int bxi = t & 7, byi = 2 * (t >> 6) + ((t >> 3) & 1), sub = (t >> 4) & 3;
+            const int bx = bxi << 3, by = byi << 3;
+            const int b = (bxi & 1) | ((byi & 1) << 1) | ((bxi & 2) << 1) | ((byi & 2) << 2) | ((bxi & 4) << 2) | ((byi & 4) << 3); /* Z index */
             uint32_t s0[4], s1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -1346,7 +1360,7 @@ static void me_pool_bytes(const SvtAmdMeParams *p, size_t *hme_pool, size_t *sea
                 mw = mw > (p->hme_l0_w[k] * p->hme_l0_mult_x) / 100 ? mw : (p->hme_l0_w[k] * p->hme_l0_mult_x) / 100;
                 mh = mh > (p->hme_l0_h[k] * p->hme_l0_mult_y) / 100 ? mh : (p->hme_l0_h[k] * p->hme_l0_mult_y) / 100;
             }
-            v = (size_t)nq * win(mw + 16, mh + 15);
+            v = (size_t)nq * win(mw + 16 + 16, mh + 15);
             need = v > need ? v : need;
         }
         for (int lvl = 1; lvl <= 2; lvl++) {
@@ -1359,7 +1373,7 @@ static void me_pool_bytes(const SvtAmdMeParams *p, size_t *hme_pool, size_t *sea
                 mw = ww > mw ? ww : mw;
                 mh = h > mh ? h : mh;
             }
-            v = (size_t)nq * win(mw + (lvl == 1 ? 32 : 64), mh + (lvl == 1 ? 31 : 63));
+            v = (size_t)nq * win(mw + (lvl == 1 ? 32 : 64) + 16, mh + (lvl == 1 ? 31 : 63));
             need = v > need ? v : need;
         }
     }

@@ -13,8 +13,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import svtlib as S  # noqa: E402
 from golden_util import load_case  # noqa: E402
 
-NAMES = ["stage src", "TestSearchAreaBounds", "HME L0/L1/L2", "CheckZeroZero", "full-pel (+window load)",
-         "SuPelEnable", "half-pel", "quarter-pel", "bi-pred", "records"]
+# stamp i .. i+1 (k_me<0> writes 0..4, k_me<1> writes 5..12; 4 -> 5 is the gap between the two kernels)
+NAMES = ["hme: stage src", "hme: TestSearchAreaBounds", "hme: HME L0/L1/L2", "hme: CheckZeroZero", None,
+         "search: stage + init", "search: full-pel (+windows)", "search: SuPelEnable", "search: half-pel",
+         "search: quarter-pel", "search: bi-pred", "search: records"]
 
 
 def main():
@@ -45,13 +47,16 @@ def main():
     assert lib.svt_amd_me_batch_launch(ctx, jobs, B) == 0
     buf = np.zeros((n, 16), np.uint64)
     assert lib.svt_amd_debug_me_phase_profile(ctx, n, buf.ctypes.data) == 0
-    d = np.diff(buf[:, :11].astype(np.int64), axis=1)
-    tot = (buf[:, 10] - buf[:, 0]).astype(np.int64)
-    print("workgroups %d; clocks per workgroup: median %d, mean %d" % (n, np.median(tot), tot.mean()))
-    for i, nm in enumerate(NAMES):
-        print("  %-26s median %8d  mean %8d  (%4.1f%%)" % (nm, np.median(d[:, i]), d[:, i].mean(), 100.0 * d[:, i].mean() / tot.mean()))
-    span = int(buf[:, 10].max() - buf[:, 0].min())
-    print("kernel span %d clocks; sum of workgroup clocks / span = %.1f concurrent workgroups" % (span, tot.sum() / span))
+    d = np.diff(buf[:, :13].astype(np.int64), axis=1)
+    for k0, k1, nm in ((0, 4, "k_me<0> (hme)"), (5, 12, "k_me<1> (search)")):
+        tot = (buf[:, k1] - buf[:, k0]).astype(np.int64)
+        print("%s: workgroups %d; clocks per workgroup: median %d, mean %d" % (nm, n, np.median(tot), tot.mean()))
+        for i in range(k0, k1):
+            if NAMES[i]:
+                print("  %-30s median %8d  mean %8d  (%4.1f%%)" % (NAMES[i], np.median(d[:, i]), d[:, i].mean(),
+                                                                   100.0 * d[:, i].mean() / tot.mean()))
+        span = int(buf[:, k1].max() - buf[:, k0].min())
+        print("  kernel span %d clocks; mean concurrent workgroups %.0f" % (span, tot.sum() / span))
     lib.svt_amd_context_destroy(ctx)
 
 
