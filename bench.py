@@ -208,11 +208,11 @@ def main():
                                    "vs previous picture and open-loop intra search; EncDec mode decision not on device yet",
                        "width": W, "height": H, "pictures_per_step_per_gpu": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
                        "parallelism": "pictures sharded over ranks, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_me_picture", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search), one batch = 2 launches", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of this kernel per launch at this configuration
-                         # (profiles/r01_c_pmc_fetch.csv, _write.csv; separate passes, KB -> bytes, uncorrected)
-                         "traffic": int((446737.1 + 306652.9) * 1024) if B == 16 else None,
+                         # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of the two ME kernels per batch at this configuration
+                         # (profiles/r01_e_pmc_fetch.csv, _write.csv; separate passes, KB -> bytes, uncorrected)
+                         "traffic": int((139024.2 + 85324.1 + 232041.2 + 37221.7) * 1024) if B == 16 else None,
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms.value, 4),
                          "launches_timed": me_n.value, "pictures_per_launch": B,
                          "prep_avg_ms": round(prep_ms.value, 4), "prep_launches": prep_n.value,

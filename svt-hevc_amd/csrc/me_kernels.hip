@@ -481,17 +481,16 @@ __device__ void hme_pass_q(MeShared &S, const uint8_t *src, int sstride, const u
             unsigned long long acc = 0;
 #pragma unroll
             for (int r = 0; r < RPC; r++) {
-                uint32_t d[G + 1];
-#pragma unroll
-                for (int g = 0; g <= G; g++)
-                    d[g] = wr[g];
+                uint32_t d0 = wr[0]; /* five window dwords live at a time (a whole-row array costs 17 VGPRs at level 2) */
 #pragma unroll
                 for (int g4 = 0; g4 < G; g4 += 4) {
+                    const uint32_t d1 = wr[g4 + 1], d2 = wr[g4 + 2], d3 = wr[g4 + 3], d4 = wr[g4 + 4];
                     const uint4 sv = *(const uint4 *)(sr + 4 * g4);
-                    acc = qsad(d[g4], d[g4 + 1], sv.x, acc);
-                    acc = qsad(d[g4 + 1], d[g4 + 2], sv.y, acc);
-                    acc = qsad(d[g4 + 2], d[g4 + 3], sv.z, acc);
-                    acc = qsad(d[g4 + 3], d[g4 + 4], sv.w, acc);
+                    acc = qsad(d0, d1, sv.x, acc);
+                    acc = qsad(d1, d2, sv.y, acc);
+                    acc = qsad(d2, d3, sv.z, acc);
+                    acc = qsad(d3, d4, sv.w, acc);
+                    d0 = d4;
                 }
                 wr += (2 * wstride) >> 2;
                 sr += sstride;
