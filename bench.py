@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="pictures per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent picture sequences per GPU, each on its own context/stream, stepped round-robin "
+                         "(2 overlaps the latency-bound kernels of neighbouring batches; per-kernel times then inflate)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,54 +116,68 @@ def main():
 
     lib = S.load_product()  # fails loudly when the HIP library is absent
     B = a.batch
-    ctx = C.c_void_p()
-    rc = lib.svt_amd_context_create(local_rank, W, H + 8, B + 1, C.byref(ctx))
-    assert rc == 0, lib.svt_amd_last_error()
-
     g = load_case("p_1920x1080_m9")
     params = S.params_from_record(g["params"][0])
-    frames = synth_frames_device(B + 1, 1234 + rank, dev)
-    torch.cuda.synchronize()
-
-    # Ring of B+1 slots: picture n lives in slot n % (B+1) and is searched against picture n-1, so every
-    # picture is prepared exactly once and the B pictures of a step are independent of each other
-    # (the front half is open loop): per step ONE prep launch, ONE ME launch, ONE OIS launch.
-    R = B + 1
     og = np.load(os.path.join(S.GOLDEN_DIR, "ois_ip_1920x1080_m9.npz"))
     oparams = S.ois_params_from_record(og["params"][1])  # the P picture of the reference run
     assert not oparams.slice_is_intra
     lib.svt_amd_picture_upload_device_batch.restype = C.c_int
     lib.svt_amd_picture_upload_device_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
                                                         C.c_uint32, C.c_uint16, C.c_uint16]
-    phases = []
-    for k in range(R):  # step s starts at picture n0 = 1 + s*B; phase = n0 % R
-        slots = (C.c_int * B)()
-        ptrs = (C.c_void_p * B)()
-        jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
-        for i in range(B):
-            cur, ref = (k + i) % R, (k + i - 1) % R
-            slots[i], ptrs[i] = cur, frames[cur].data_ptr()
-            jobs[i].params, jobs[i].cur_slot = params, cur
-            jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = ref
-            ojobs[i].params, ojobs[i].cur_slot = oparams, cur
-        phases.append((slots, ptrs, jobs, ojobs))
-    state = {"n0": 1}
+    # Ring of B+1 slots: picture n lives in slot n % (B+1) and is searched against picture n-1, so every
+    # picture is prepared exactly once and the B pictures of a step are independent of each other
+    # (the front half is open loop): per step ONE prep launch, ONE ME batch (2 launches), ONE OIS launch.
+    R = B + 1
+
+    def make_lane(idx):
+        ctx = C.c_void_p()
+        rc = lib.svt_amd_context_create(local_rank, W, H + 8, R, C.byref(ctx))
+        assert rc == 0, lib.svt_amd_last_error()
+        frames = synth_frames_device(R, 1234 + 17 * rank + idx, dev)
+        torch.cuda.synchronize()
+        phases = []
+        for k in range(R):  # step s starts at picture n0 = 1 + s*B; phase = n0 % R
+            slots = (C.c_int * B)()
+            ptrs = (C.c_void_p * B)()
+            jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
+            for i in range(B):
+                cur, ref = (k + i) % R, (k + i - 1) % R
+                slots[i], ptrs[i] = cur, frames[cur].data_ptr()
+                jobs[i].params, jobs[i].cur_slot = params, cur
+                jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = ref
+                ojobs[i].params, ojobs[i].cur_slot = oparams, cur
+            phases.append((slots, ptrs, jobs, ojobs))
+        state = {"n0": 1}
+
+        def step():
+            slots, ptrs, jobs, ojobs = phases[state["n0"] % R]
+            r = lib.svt_amd_picture_upload_device_batch(ctx, B, slots, ptrs, W, W, H)
+            assert r == 0, lib.svt_amd_last_error()
+            r = lib.svt_amd_me_batch_launch(ctx, jobs, B)
+            assert r == 0, lib.svt_amd_last_error()
+            r = lib.svt_amd_ois_batch_launch(ctx, ojobs, B)  # reads the ME results left on the device
+            assert r == 0, lib.svt_amd_last_error()
+            state["n0"] += B
+
+        r = lib.svt_amd_picture_upload_device(ctx, 0, C.c_void_p(frames[0].data_ptr()), W, W, H)
+        assert r == 0, lib.svt_amd_last_error()
+        return ctx, step, frames
+
+    lanes = [make_lane(i) for i in range(max(1, a.streams))]
+    ctx = lanes[0][0]
+    tick = {"i": 0}
 
     def step():
-        slots, ptrs, jobs, ojobs = phases[state["n0"] % R]
-        r = lib.svt_amd_picture_upload_device_batch(ctx, B, slots, ptrs, W, W, H)
-        assert r == 0, lib.svt_amd_last_error()
-        r = lib.svt_amd_me_batch_launch(ctx, jobs, B)
-        assert r == 0, lib.svt_amd_last_error()
-        r = lib.svt_amd_ois_batch_launch(ctx, ojobs, B)  # reads the ME results left on the device
-        assert r == 0, lib.svt_amd_last_error()
-        state["n0"] += B
+        lanes[tick["i"] % len(lanes)][1]()
+        tick["i"] += 1
 
-    r = lib.svt_amd_picture_upload_device(ctx, 0, C.c_void_p(frames[0].data_ptr()), W, W, H)
-    assert r == 0, lib.svt_amd_last_error()
+    def sync_all():
+        for c, _, _ in lanes:
+            lib.svt_amd_synchronize(c)
+
     for _ in range(a.warmup):
         step()
-    lib.svt_amd_synchronize(ctx)
+    sync_all()
 
     def barrier():
         if world > 1:
@@ -173,7 +190,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    lib.svt_amd_synchronize(ctx)
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = C.c_float()
@@ -207,7 +224,7 @@ def main():
                                    "half-pel planes, open-loop ME (HME L0/L1, full-pel 85 PU, sub-pel) of 510 LCUs "
                                    "vs previous picture and open-loop intra search; EncDec mode decision not on device yet",
                        "width": W, "height": H, "pictures_per_step_per_gpu": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
-                       "parallelism": "pictures sharded over ranks, no collective"},
+                       "parallelism": "pictures sharded over ranks, no collective", "streams_per_gpu": len(lanes)},
             "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search), one batch = 2 launches", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of the two ME kernels per batch at this configuration
@@ -226,7 +243,8 @@ def main():
                 res["reference_encoder"] = ref
         print(json.dumps(res), flush=True)
 
-    lib.svt_amd_context_destroy(ctx)
+    for c, _, _ in lanes:
+        lib.svt_amd_context_destroy(c)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -157,9 +157,9 @@ __device__ __forceinline__ const uint8_t *wat(const LWin &w, int x, int y)
 }
 /* stage plane samples [x0,x1) x [y0,y1) at LDS offset `off` of the pool; returns the new offset */
 __device__ __forceinline__ int load_window(LWin &w, int off, const uint8_t *plane, int pitch, int x0, int y0, int x1,
-                                           int y1, int t)
+                                           int y1, int t, int odd = 0)
 {
-    const int xa = x0 & ~15, wa = ((x1 - xa) + 15) & ~15, n16 = wa >> 4, rows = y1 - y0;
+    const int xa = x0 & ~15, wa = win_pitch(x0, x1, odd), n16 = wa >> 4, rows = y1 - y0;
     uint8_t *dst = g_pool + off;
     w.p = dst, w.x0 = xa, w.y0 = y0, w.stride = wa;
     for (int i = t; i < rows * n16; i += NT) {
@@ -300,15 +300,21 @@ struct MeShared {
 /* LDS state of the search kernel only; lives at the start of the dynamic pool (the staged windows follow), so the
  * HME kernel does not pay for it and fits ~3x more workgroups per CU */
 struct MeSearch {
-    uint16_t sad8[64][64];         /* per-position 8x8 even-row SADs of the current chunk  */
-    uint16_t sad16[64][16];
-    uint32_t sad32[64][4];
+    union {                        /* the full-pel SAD trees and the sub-pel accumulators are never live together */
+        struct {
+            uint16_t sad8[64][64]; /* per-position 8x8 even-row SADs of the current chunk  */
+            uint16_t sad16[64][16];
+            uint32_t sad32[64][4];
+        };
+        struct {
+            uint32_t dist[85][8];  /* sub-pel distortions (search metric)                  */
+            uint32_t dsad[85][8];  /* full SAD at the same positions (SSD search only)     */
+        };
+    };
     uint32_t key[85];              /* packed (sad,index) minima, PUs 1..84                 */
     unsigned long long key64;      /* 64x64 */
     uint32_t best_sad[2][85], best_mv[2][85], best_ssd[2][85];
     uint8_t dir[2][85];
-    uint32_t dist[85][8];          /* sub-pel distortions (search metric)                  */
-    uint32_t dsad[85][8];          /* full SAD at the same positions (SSD search only)     */
     uint32_t bipred[85];
     int e32, e16, e8, eq;
     int sums[9];                   /* SuPelEnable: per tier {sum mvx, sum mvy, sum sad} */
@@ -879,12 +885,12 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? 6 : ME_MIN_WAVES_PER_SIMD) void k_
              * quarter-pel neighbours). */
             {
                 const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
-                int off = load_window(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                int off = load_window(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
                 /* the half-pel planes are first read by the sub-pel stages: fetch them asynchronously under the
                  * full-pel search (waited for at "sub-pel windows landed" below) */
-                off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t);
-                off = load_window_async(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t);
-                off = load_window_async(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                off = load_window_async(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                off = load_window_async(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
             }
             const uint8_t *rbase = wat(wF, ox + bx + sox, oy + by + soy);
             const int fstride = wF.stride;
@@ -1379,7 +1385,7 @@ static void me_pool_bytes(const SvtAmdMeParams *p, size_t *hme_pool, size_t *sea
     *hme_pool = (need + 64 + 255) & ~(size_t)255; /* +64: the aligned over-read of the last window row */
     const int saw = p->search_area_width > 127 ? 127 : p->search_area_width;
     const int sah = p->search_area_height > 127 ? 127 : p->search_area_height;
-    *search_pool = ((size_t)ME_SEARCH_BYTES + 4 * win(saw + 67, sah + 67) + 64 + 255) & ~(size_t)255;
+    *search_pool = ((size_t)ME_SEARCH_BYTES + 4 * win(saw + 67 + 16, sah + 67) + 64 + 255) & ~(size_t)255;
 }
 
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus)
