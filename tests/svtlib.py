@@ -285,6 +285,17 @@ def write_clip(path, kind, w, h, n, seed):
             f.write(cr.tobytes())
 
 
+def write_clip10(path, kind, w, h, n, seed):
+    """10-bit clip in the reference app's unpacked format (16-bit little-endian samples): (8-bit clip << 2) | 2 noise bits."""
+    rng = np.random.default_rng(seed + 1000)
+    with open(path, "wb") as f:
+        for t in range(n):
+            cb, cr = gen_chroma(w, h, t)
+            for plane in (gen_luma(kind, w, h, t, seed), cb, cr):
+                lsb = rng.integers(0, 4, plane.shape, dtype=np.uint16)
+                f.write(((plane.astype(np.uint16) << 2) | lsb).astype("<u2").tobytes())
+
+
 def plane_checksum(luma):
     """Same polynomial as oracle/ref_harness_me_dump.c:plane_checksum (s = s*31 + v mod 2^32)."""
     flat = luma.astype(np.uint64).ravel()

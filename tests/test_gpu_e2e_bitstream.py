@@ -25,6 +25,14 @@ CASES = [
     ("motion", 1920, 1080, 4, ["-encMode", "10", "-intra-period", "0"]),
     # encMode 4 flat low-delay P: 35-mode OIS on P pictures, SSD sub-pel ME
     ("motion", 416, 240, 5, ["-encMode", "4", "-pred-struct", "0", "-hierarchical-levels", "0"]),
+    # HME switched off, user-defined search area
+    ("motion", 640, 384, 6, ["-encMode", "6", "-use-default-me-hme", "0", "-hme", "0", "-search-w", "24", "-search-h", "16"]),
+    # 2 x 2 tiles (unrestricted motion vectors: the search may cross tile borders, the default)
+    ("motion", 832, 480, 6, ["-encMode", "5", "-tile_col_cnt", "2", "-tile_row_cnt", "2"]),
+    # 10-bit input: the front half works on the 8-bit MSB planes (BASELINE configs[3]/[4] class)
+    ("motion10", 640, 384, 5, ["-encMode", "7", "-bit-depth", "10"]),
+    # BASELINE configs[2]: 4K, encMode 7, random access with 2 hierarchical levels, SAO, 60 fps
+    ("motion", 3840, 2160, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-fps", "60"]),
 ]
 
 
@@ -41,7 +49,10 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
     assert os.path.exists(HIP_APP) and os.path.exists(S.REF_APP), \
         "integration/_build and oracle/_ref must be prebuilt (python __graft_entry__.py build, needs /root/reference)"
     yuv = str(tmp_path / "clip.yuv")
-    S.write_clip(yuv, kind, w, h, n, 7)
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
     hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
     # every MotionEstimateLcu call is redirected at link time (--wrap); the hook announces itself
