@@ -625,6 +625,43 @@ SVT_AMD_API int svt_amd_EstimateQuantizedCoefficients_Lossy(SvtAmdCabacCost *Cab
                                                             uint32_t numNonZeroCoeffs, uint64_t *coeffBitsLong);
 
 /* ------------------------------------------------------------------------- */
+/* Luma full loop of one mode-decision candidate                              */
+/* ------------------------------------------------------------------------- */
+/* Replaces ProductFullLoop (Codec/EbFullLoop.c:185-446; caller PerformFullLoop, EbProductCodingLoop.c:4351-4460) for
+ * the configuration the presets >= encMode 5 use: no RDOQ / PM-core, coefficient-domain distortion, no CABAC-context
+ * update (Codec/EbEncDecProcess.c:2028-2205).  Per transform unit: EstimateTransform (EbTransforms.c:3268) ->
+ * ProductUnifiedQuantizeInvQuantizeMd (EbFullLoop.c:77) -> PictureFullDistortionLuma (EbPictureOperators.c:397) ->
+ * TuEstimateCoeffBitsLuma (EbEntropyCoding.c:7899) -> TuCalcCostLuma (EbRateDistortionCost.c:289).  A 64x64 CU is four
+ * 32x32 transform units (TU index 1..4), smaller CUs one (TU index 0). */
+typedef struct SvtAmdFullLoopIn {
+    uint32_t size;              /* CU size 8 / 16 / 32 / 64                                              */
+    uint32_t qp;
+    uint32_t slice_type;        /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR (selects the quantiser dead zone)    */
+    uint32_t pf_mode;           /* contextPtr->pfMdMode: 0 off, 1 N2, 2 N4                               */
+    uint32_t cand_type;         /* INTER_MODE 1 / INTRA_MODE 2                                           */
+    uint32_t intra_luma_mode;
+    uint32_t full_lambda;       /* contextPtr->fullLambda                                                */
+    uint32_t cbf_bits[4];       /* mdRateEstimationPtr->lumaCbfBits[0], [1], [5], [6]                    */
+    uint32_t ycbf;              /* candidatePtr->yCbf before the call                                    */
+    uint64_t coeff_bits;        /* *yCoeffBits before the call (accumulated)                             */
+    uint64_t dist[2];           /* yFullDistortion before the call (accumulated for 64x64)               */
+} SvtAmdFullLoopIn;
+typedef struct SvtAmdFullLoopOut {
+    uint32_t nz[5];             /* yCountNonZeroCoeffs[0..4] entries this call wrote (others 0)          */
+    uint32_t ycbf;              /* candidatePtr->yCbf after the call                                     */
+    uint64_t coeff_bits;        /* *yCoeffBits after the call                                            */
+    uint64_t dist[2];           /* yFullDistortion[DIST_CALC_RESIDUAL / PREDICTION] after the call       */
+    int16_t  ydc[4];            /* candidateBuffer->yDc                                                  */
+    uint16_t cand_nz[4];        /* candidateBuffer->yCountNonZeroCoeffs                                  */
+} SvtAmdFullLoopOut;
+/* BATCHED: candidate c has its size x size luma residual at d_residual + c*4096 (row pitch = size); the quantised
+ * and the reconstructed coefficients are written in the same layout.  `cost` is a HOST pointer. */
+SVT_AMD_API int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost,
+                                             const SvtAmdFullLoopIn *d_in, const int16_t *d_residual,
+                                             int16_t *d_quant, int16_t *d_recon, SvtAmdFullLoopOut *d_out,
+                                             uint32_t ncand);
+
+/* ------------------------------------------------------------------------- */
 /* HEVC motion-compensation interpolation (closed-loop inter prediction)      */
 /* ------------------------------------------------------------------------- */
 /* One prediction block: integer position = sample index ref_off of the reference plane, fractional part (fx,fy) in

@@ -181,4 +181,8 @@ uint64_t svt_oracle_coeff_bits_lossy(const SvtAmdCabacCost *C, uint32_t size, ui
                                      uint32_t intraChromaMode, const int16_t *coeff, uint32_t stride,
                                      uint32_t componentType, uint32_t numNonZeroCoeffs);
 
+/* ---- luma full loop of one candidate (svt_oracle_fullloop.c) ---- */
+void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
+                                       int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out);
+
 #endif

@@ -1,0 +1,104 @@
+/*
+ * oracle/svt_oracle_fullloop.c - TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
+ * CPU restatement of the luma full loop of one mode-decision candidate:
+ *   ProductFullLoop                       Codec/EbFullLoop.c:185-446
+ *   ProductUnifiedQuantizeInvQuantizeMd   Codec/EbFullLoop.c:77-180   (no RDOQ / PM-core)
+ *   PictureFullDistortionLuma             Codec/EbPictureOperators.c:397-424 (table EbPictureOperators.h:503-556)
+ *   TuEstimateCoeffBitsLuma               Codec/EbEntropyCoding.c:7899-7954  (coeffCabacUpdate == 0)
+ *   TuCalcCostLuma                        Codec/EbRateDistortionCost.c:289-367
+ * composed from the leaf restatements of svt_oracle_txfm.c and svt_oracle_rate.c.  Pinned by
+ * tests/test_oracle_fullloop_golden.py against records of real ProductFullLoop calls (tests/golden/fullloop_*.npz).
+ */
+#include <string.h>
+#include "svt_oracle.h"
+
+static uint32_t ilog2u(uint32_t v) { uint32_t n = 0; while (v > 1) v >>= 1, n++; return n; }
+
+/* one transform unit of size T at `origin` of pitch-`pitch` buffers */
+static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, uint32_t cuSize, uint32_t T, uint32_t tuIndex,
+                         const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch, uint32_t *nzOut,
+                         uint64_t dist[2], uint64_t *bits, uint32_t *ycbf)
+{
+    static const uint32_t QF[6] = {26214, 23302, 20560, 18396, 16384, 14564}, FF[6] = {40, 45, 51, 57, 64, 72};
+    int16_t coeff[32 * 32];
+    /* EstimateTransform: the C_DEFAULT partial-frequency tables hold the full transforms (EbTransforms.h:358-415) */
+    svt_oracle_FwdTransform(T >= 16 ? 1 : 0, (int)T, residual, pitch, coeff, T, NULL, 0);
+    /* ProductUnifiedQuantizeInvQuantizeMd */
+    const int32_t qpRem = (int32_t)(in->qp % 6), qpPer = (int32_t)(in->qp / 6);
+    const uint32_t tshift = 7 - ilog2u(T);
+    const int32_t shiftedQBits = 14 + qpPer + (int32_t)tshift;
+    const uint32_t q_offset = ((in->slice_type == 2 || in->slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int32_t shiftedFFunc = qpPer > 8 ? (int32_t)FF[qpRem] << (qpPer - 2) : (int32_t)FF[qpRem] << qpPer;
+    const int32_t shiftNum = qpPer > 8 ? 20 - 14 - (int32_t)tshift - 2 : 20 - 14 - (int32_t)tshift;
+    const int32_t iq_offset = 1 << (shiftNum - 1);
+    const uint32_t area = T >> in->pf_mode;
+    uint32_t nz = 0;
+    /* quantised / reconstructed coefficients overwrite only the area (the rest keeps the residual / old content) */
+    svt_oracle_QuantizeInvQuantize(coeff, T, quant, recon, QF[qpRem], q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum,
+                                   area, &nz);
+    /* note: quant/recon are addressed with pitch `pitch` by the caller's layout */
+    (void)pitch;
+    svt_oracle_UpdateQiQCoef(quant, recon, T, shiftedFFunc, iq_offset, shiftNum, area, &nz, 0, in->slice_type, 0, 0, 0);
+    *nzOut = nz;
+    /* PictureFullDistortionLuma: [nz != 0][intra] */
+    uint64_t d[2] = {0, 0};
+    svt_oracle_FullDistortionKernel_32bit(coeff, T, recon, T, d, area, area, nz == 0 ? 1 : (in->cand_type == 2 ? 2 : 0));
+    const uint32_t shift = cuSize == 64 ? 4 : 2 * (7 - ilog2u(T));
+    d[0] = (d[0] + ((uint64_t)1 << (shift - 1))) >> shift;
+    d[1] = (d[1] + ((uint64_t)1 << (shift - 1))) >> shift;
+    /* TuEstimateCoeffBitsLuma */
+    uint64_t tuBits = 0;
+    if (nz)
+        tuBits = svt_oracle_coeff_bits_lossy(cost, area, in->cand_type, in->intra_luma_mode, 4, quant, T, 0, nz);
+    tuBits >>= 15;
+    /* TuCalcCostLuma */
+    const uint32_t ctx = cuSize == T;
+    const uint64_t nzDist = d[0] << 8, zDist = d[1] << 8;
+    const uint64_t nzRate = (tuBits << 15) + in->cbf_bits[2 + ctx], zRate = in->cbf_bits[ctx];
+    const uint64_t zCost = in->cand_type == 2 ? ~0ull : zDist + ((((uint64_t)in->full_lambda * zRate) + (1u << 22)) >> 23);
+    const uint64_t nzCost = nzDist + ((((uint64_t)in->full_lambda * nzRate) + (1u << 22)) >> 23);
+    *ycbf |= (uint32_t)((nz != 0) && (nzCost < zCost)) << tuIndex;
+    *bits = nzCost < zCost ? tuBits : 0;
+    dist[0] = nzCost < zCost ? d[0] : d[1];
+    dist[1] = d[1];
+}
+
+/* residual / quant / recon: size x size, row pitch = size; quant and recon must be pre-filled by the caller with what the
+ * reference buffers held (quant: the residual itself - one buffer serves both; recon: anything) */
+void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
+                                       int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out)
+{
+    memset(out, 0, sizeof(*out));
+    out->ycbf = in->ycbf;
+    out->coeff_bits = in->coeff_bits;
+    const uint32_t S = in->size;
+    if (S == 64) {
+        out->dist[0] = in->dist[0], out->dist[1] = in->dist[1];
+        for (uint32_t tu = 0; tu < 4; tu++) {
+            const uint32_t off = ((tu & 1) << 5) + ((tu > 1) ? 32 * 64 : 0);
+            int16_t r[32 * 32], q[32 * 32], c[32 * 32];
+            for (int y = 0; y < 32; y++) {
+                memcpy(r + y * 32, residual + off + y * 64, 64);
+                memcpy(q + y * 32, quant + off + y * 64, 64);
+                memcpy(c + y * 32, recon + off + y * 64, 64);
+            }
+            uint64_t d[2], bits;
+            full_loop_tu(cost, in, 64, 32, tu + 1, r, q, c, 32, &out->nz[tu + 1], d, &bits, &out->ycbf);
+            for (int y = 0; y < 32; y++) {
+                memcpy(quant + off + y * 64, q + y * 32, 64);
+                memcpy(recon + off + y * 64, c + y * 32, 64);
+            }
+            out->coeff_bits += bits;
+            out->dist[0] += d[0], out->dist[1] += d[1];
+            out->ydc[tu] = (int16_t)(q[0] < 0 ? -q[0] : q[0]);
+            out->cand_nz[tu] = (uint16_t)out->nz[tu + 1];
+        }
+    } else {
+        uint64_t d[2], bits;
+        full_loop_tu(cost, in, S, S, 0, residual, quant, recon, S, &out->nz[0], d, &bits, &out->ycbf);
+        out->coeff_bits += bits;
+        out->dist[0] = d[0], out->dist[1] = d[1];
+        out->ydc[0] = (int16_t)(quant[0] < 0 ? -quant[0] : quant[0]);
+        out->cand_nz[0] = (uint16_t)out->nz[0];
+    }
+}
