@@ -18,105 +18,7 @@
  * row held in LDS.  Bound: HBM (4 bytes moved per coefficient, ~40 integer ops).
  */
 #include "svt_amd_internal.h"
-
-#define TX_THREADS 256
-
-/* HEVC core transform matrix (H.265 8.6.4.2); N-point row k = row k*32/N, first N columns */
-__constant__ int8_t c_T32[32][32] = {
-    {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64},
-    {90, 90, 88, 85, 82, 78, 73, 67, 61, 54, 46, 38, 31, 22, 13, 4, -4, -13, -22, -31, -38, -46, -54, -61, -67, -73, -78, -82, -85, -88, -90, -90},
-    {90, 87, 80, 70, 57, 43, 25, 9, -9, -25, -43, -57, -70, -80, -87, -90, -90, -87, -80, -70, -57, -43, -25, -9, 9, 25, 43, 57, 70, 80, 87, 90},
-    {90, 82, 67, 46, 22, -4, -31, -54, -73, -85, -90, -88, -78, -61, -38, -13, 13, 38, 61, 78, 88, 90, 85, 73, 54, 31, 4, -22, -46, -67, -82, -90},
-    {89, 75, 50, 18, -18, -50, -75, -89, -89, -75, -50, -18, 18, 50, 75, 89, 89, 75, 50, 18, -18, -50, -75, -89, -89, -75, -50, -18, 18, 50, 75, 89},
-    {88, 67, 31, -13, -54, -82, -90, -78, -46, -4, 38, 73, 90, 85, 61, 22, -22, -61, -85, -90, -73, -38, 4, 46, 78, 90, 82, 54, 13, -31, -67, -88},
-    {87, 57, 9, -43, -80, -90, -70, -25, 25, 70, 90, 80, 43, -9, -57, -87, -87, -57, -9, 43, 80, 90, 70, 25, -25, -70, -90, -80, -43, 9, 57, 87},
-    {85, 46, -13, -67, -90, -73, -22, 38, 82, 88, 54, -4, -61, -90, -78, -31, 31, 78, 90, 61, 4, -54, -88, -82, -38, 22, 73, 90, 67, 13, -46, -85},
-    {83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83},
-    {82, 22, -54, -90, -61, 13, 78, 85, 31, -46, -90, -67, 4, 73, 88, 38, -38, -88, -73, -4, 67, 90, 46, -31, -85, -78, -13, 61, 90, 54, -22, -82},
-    {80, 9, -70, -87, -25, 57, 90, 43, -43, -90, -57, 25, 87, 70, -9, -80, -80, -9, 70, 87, 25, -57, -90, -43, 43, 90, 57, -25, -87, -70, 9, 80},
-    {78, -4, -82, -73, 13, 85, 67, -22, -88, -61, 31, 90, 54, -38, -90, -46, 46, 90, 38, -54, -90, -31, 61, 88, 22, -67, -85, -13, 73, 82, 4, -78},
-    {75, -18, -89, -50, 50, 89, 18, -75, -75, 18, 89, 50, -50, -89, -18, 75, 75, -18, -89, -50, 50, 89, 18, -75, -75, 18, 89, 50, -50, -89, -18, 75},
-    {73, -31, -90, -22, 78, 67, -38, -90, -13, 82, 61, -46, -88, -4, 85, 54, -54, -85, 4, 88, 46, -61, -82, 13, 90, 38, -67, -78, 22, 90, 31, -73},
-    {70, -43, -87, 9, 90, 25, -80, -57, 57, 80, -25, -90, -9, 87, 43, -70, -70, 43, 87, -9, -90, -25, 80, 57, -57, -80, 25, 90, 9, -87, -43, 70},
-    {67, -54, -78, 38, 85, -22, -90, 4, 90, 13, -88, -31, 82, 46, -73, -61, 61, 73, -46, -82, 31, 88, -13, -90, -4, 90, 22, -85, -38, 78, 54, -67},
-    {64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64},
-    {61, -73, -46, 82, 31, -88, -13, 90, -4, -90, 22, 85, -38, -78, 54, 67, -67, -54, 78, 38, -85, -22, 90, 4, -90, 13, 88, -31, -82, 46, 73, -61},
-    {57, -80, -25, 90, -9, -87, 43, 70, -70, -43, 87, 9, -90, 25, 80, -57, -57, 80, 25, -90, 9, 87, -43, -70, 70, 43, -87, -9, 90, -25, -80, 57},
-    {54, -85, -4, 88, -46, -61, 82, 13, -90, 38, 67, -78, -22, 90, -31, -73, 73, 31, -90, 22, 78, -67, -38, 90, -13, -82, 61, 46, -88, 4, 85, -54},
-    {50, -89, 18, 75, -75, -18, 89, -50, -50, 89, -18, -75, 75, 18, -89, 50, 50, -89, 18, 75, -75, -18, 89, -50, -50, 89, -18, -75, 75, 18, -89, 50},
-    {46, -90, 38, 54, -90, 31, 61, -88, 22, 67, -85, 13, 73, -82, 4, 78, -78, -4, 82, -73, -13, 85, -67, -22, 88, -61, -31, 90, -54, -38, 90, -46},
-    {43, -90, 57, 25, -87, 70, 9, -80, 80, -9, -70, 87, -25, -57, 90, -43, -43, 90, -57, -25, 87, -70, -9, 80, -80, 9, 70, -87, 25, 57, -90, 43},
-    {38, -88, 73, -4, -67, 90, -46, -31, 85, -78, 13, 61, -90, 54, 22, -82, 82, -22, -54, 90, -61, -13, 78, -85, 31, 46, -90, 67, 4, -73, 88, -38},
-    {36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36},
-    {31, -78, 90, -61, 4, 54, -88, 82, -38, -22, 73, -90, 67, -13, -46, 85, -85, 46, 13, -67, 90, -73, 22, 38, -82, 88, -54, -4, 61, -90, 78, -31},
-    {25, -70, 90, -80, 43, 9, -57, 87, -87, 57, -9, -43, 80, -90, 70, -25, -25, 70, -90, 80, -43, -9, 57, -87, 87, -57, 9, 43, -80, 90, -70, 25},
-    {22, -61, 85, -90, 73, -38, -4, 46, -78, 90, -82, 54, -13, -31, 67, -88, 88, -67, 31, 13, -54, 82, -90, 78, -46, 4, 38, -73, 90, -85, 61, -22},
-    {18, -50, 75, -89, 89, -75, 50, -18, -18, 50, -75, 89, -89, 75, -50, 18, 18, -50, 75, -89, 89, -75, 50, -18, -18, 50, -75, 89, -89, 75, -50, 18},
-    {13, -38, 61, -78, 88, -90, 85, -73, 54, -31, 4, 22, -46, 67, -82, 90, -90, 82, -67, 46, -22, -4, 31, -54, 73, -85, 90, -88, 78, -61, 38, -13},
-    {9, -25, 43, -57, 70, -80, 87, -90, 90, -87, 80, -70, 57, -43, 25, -9, -9, 25, -43, 57, -70, 80, -87, 90, -90, 87, -80, 70, -57, 43, -25, 9},
-    {4, -13, 22, -31, 38, -46, 54, -61, 67, -73, 78, -82, 85, -88, 90, -90, 90, -90, 88, -85, 82, -78, 73, -67, 61, -54, 46, -38, 31, -22, 13, -4}};
-
-__device__ __forceinline__ int clip16i(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
-
-/* ------------------------------------------------------------------------- */
-/* forward / inverse transforms: one workgroup per group of GB blocks         */
-/* ------------------------------------------------------------------------- */
-
-template <int N>
-struct TxShared {
-    static constexpr int GB = (N >= 16) ? 1 : (N == 8 ? 4 : 16); /* blocks per workgroup */
-    int8_t T[32][32];
-    int16_t io[GB][N * N];  /* input, later the transposed first-pass output */
-    int32_t E[GB][N][N + 1]; /* running even vector, levels evaluated in place; +1: the dot-product stage walks  */
-    int32_t D[GB][N][N + 1]; /* rows with the row index fastest, unpadded rows would all hit one LDS bank.       */
-                             /* D: [h..2h) = odd vector of length h */
-};
-
-/* one 1-D forward pass over all rows of the GB blocks held in S.io; output transposed into dst */
-template <int N, bool TO_GLOBAL>
-__device__ void fwd_pass(TxShared<N> &S, int shift, int wrap_levels, int16_t *gdst, int nvalid, int t)
-{
-    constexpr int GB = TxShared<N>::GB;
-    constexpr int LOG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
-    for (int i = t; i < GB * N * N; i += TX_THREADS)
-        S.E[i / (N * N)][(i / N) % N][i % N] = (&S.io[0][0])[i];
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < LOG - 1; m++) {
-        const int half = N >> (m + 1);
-        for (int i = t; i < GB * N * half; i += TX_THREADS) {
-            const int j = i % half, r = (i / half) % N, b = i / (half * N);
-            int s = S.E[b][r][j] + S.E[b][r][2 * half - 1 - j], d = S.E[b][r][j] - S.E[b][r][2 * half - 1 - j];
-            if (m < wrap_levels)
-                s = (int16_t)s, d = (int16_t)d;
-            S.D[b][r][half + j] = d;
-            S.E[b][r][j] = s; /* indices >= half are only read in this level: no hazard */
-        }
-        __syncthreads();
-    }
-    const int offset = (int16_t)(1 << (shift - 1));
-    for (int i = t; i < GB * N * N; i += TX_THREADS) {
-        const int r = i % N, k = (i / N) % N, b = i / (N * N);
-        int acc = 0;
-        if ((k & (N / 2 - 1)) == 0) { /* k == 0 or N/2: last even pair */
-            acc = S.T[k * (32 / N)][0] * S.E[b][r][0] + S.T[k * (32 / N)][1] * S.E[b][r][1];
-        } else {
-            const int m = __ffs(k) - 1, len = N >> (m + 1);
-            const int8_t *c = S.T[k * (32 / N)];
-            const int32_t *dv = &S.D[b][r][len];
-            for (int j = 0; j < len; j++)
-                acc += c[j] * dv[j];
-        }
-        const int16_t v = (int16_t)((acc + offset) >> shift);
-        if (TO_GLOBAL) {
-            if (b < nvalid)
-                gdst[(size_t)b * N * N + k * N + r] = v;
-        } else {
-            S.io[b][k * N + r] = v;
-        }
-    }
-    __syncthreads();
-}
+#include "txfm_device.h"
 
 template <int N>
 __global__ __launch_bounds__(TX_THREADS) void k_fwd_dct(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
