@@ -660,6 +660,11 @@ SVT_AMD_API int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCab
                                              const SvtAmdFullLoopIn *d_in, const int16_t *d_residual,
                                              int16_t *d_quant, int16_t *d_recon, SvtAmdFullLoopOut *d_out,
                                              uint32_t ncand);
+/* Per-call form on HOST pointers (row pitch `pitch` samples, e.g. the reference's 64-sample LCU buffers); writes back
+ * only the (T >> pf) area of every transform unit, like the reference.  Blocking; used by the ProductFullLoop binding. */
+SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
+                                       const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch,
+                                       SvtAmdFullLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
 /* HEVC motion-compensation interpolation (closed-loop inter prediction)      */

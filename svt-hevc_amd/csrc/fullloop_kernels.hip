@@ -12,6 +12,7 @@
  */
 #include "txfm_device.h"
 #include "rate_device.h"
+#include <cstring>
 
 struct FlShared {
     int16_t q[32 * 32];       /* quantised coefficients of the current TU, row pitch N */
@@ -155,5 +156,46 @@ extern "C" int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCaba
     hipLaunchKernelGGL(k_full_loop_luma<8>, dim3(ncand), dim3(TX_THREADS), 0, ctx->stream, d_in, d_residual, d_quant, d_recon,
                        d_out, 2, 9, 0);
     HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* Host-pointer form for one candidate (the per-call binding of integration/svt_hook_me.c): operands are staged
+ * through scratch buffers owned by the context's device; blocking.  Row pitch of the three host arrays = `pitch`
+ * samples (the reference's 64-sample LCU buffers); only the (T >> pf) area of every TU is written back. */
+extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
+                                      const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch,
+                                      SvtAmdFullLoopOut *out)
+{
+    if (!ctx || !cost || !in || !residual || !quant || !recon || !out || pitch < in->size ||
+        (in->size != 8 && in->size != 16 && in->size != 32 && in->size != 64) || in->pf_mode > 1)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    static uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
+    const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 8192, o_r = o_q + 8192, total = o_r + 8192;
+    if (!d_scratch)
+        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    const uint32_t S = in->size;
+    int16_t packed[64 * 64];
+    for (uint32_t y = 0; y < S; y++)
+        ::memcpy(packed + y * S, residual + (size_t)y * pitch, S * sizeof(int16_t));
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_in, in, sizeof(*in), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_res, packed, (size_t)S * S * 2, hipMemcpyHostToDevice, ctx->stream));
+    int rc = svt_amd_full_loop_luma_batch(ctx, cost, (const SvtAmdFullLoopIn *)(d_scratch + o_in), (const int16_t *)(d_scratch + o_res),
+                                          (int16_t *)(d_scratch + o_q), (int16_t *)(d_scratch + o_r),
+                                          (SvtAmdFullLoopOut *)(d_scratch + o_out), 1);
+    if (rc)
+        return rc;
+    int16_t hq[64 * 64], hr[64 * 64];
+    HIP_TRY(hipMemcpyAsync(out, d_scratch + o_out, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hq, d_scratch + o_q, (size_t)S * S * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hr, d_scratch + o_r, (size_t)S * S * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t T = S == 64 ? 32 : S, area = T >> in->pf_mode;
+    for (uint32_t ty = 0; ty < S; ty += T)
+        for (uint32_t tx = 0; tx < S; tx += T)
+            for (uint32_t y = 0; y < area; y++) {
+                ::memcpy(quant + (size_t)(ty + y) * pitch + tx, hq + (ty + y) * S + tx, area * sizeof(int16_t));
+                ::memcpy(recon + (size_t)(ty + y) * pitch + tx, hr + (ty + y) * S + tx, area * sizeof(int16_t));
+            }
     return SVT_AMD_OK;
 }

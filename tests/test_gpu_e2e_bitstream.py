@@ -63,3 +63,30 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
     assert log.count("svt_hook_me: ME picture") == n - n_intra, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     assert os.path.getsize(str(tmp_path / "hip.265")) > 100
+
+
+FULLLOOP_CASES = [
+    ("motion", 416, 240, 4, ["-encMode", "9", "-pred-struct", "0"]),
+    ("motion", 416, 240, 3, ["-encMode", "10", "-intra-period", "0"]),          # encMode 10 needs the 1080p class:
+    ("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"]),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", FULLLOOP_CASES)
+def test_bitstream_identical_with_gpu_full_loop(tmp_path, kind, w, h, n, args):
+    """Same check with the mode decision's luma full loop (ProductFullLoop) also answered by the device, one fused
+    kernel call per candidate (SVT_HOOK_FULLLOOP=1): transform, quantisation, distortion, rate and cbf decision of
+    every candidate CU come from svt_amd_full_loop_luma."""
+    if "-intra-period" in args:
+        w, h = 1920, 1080
+        n = 1
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
+    os.environ["SVT_HOOK_FULLLOOP"] = "1"
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
+    finally:
+        del os.environ["SVT_HOOK_FULLLOOP"]
+    assert "svt_hook_me: luma full loop (ProductFullLoop) on the GPU" in log, log[-1000:]
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
