@@ -667,6 +667,43 @@ SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost
                                        SvtAmdFullLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
+/* Chroma full loop of one mode-decision candidate                            */
+/* ------------------------------------------------------------------------- */
+/* Replaces the pair FullLoop_R (Codec/EbFullLoop.c:579-870) + CuFullDistortionFastTuMode_R (:873-1066) as the mode
+ * decision calls them with PICTURE_BUFFER_DESC_CHROMA_MASK (EbProductCodingLoop.c:4291-4319 and :4518-4547), for the same
+ * configuration as the luma loop above (no RDOQ / PM-core, coefficient-domain distortion, no CABAC-context update).
+ * Per chroma transform unit (size/2, four 16x16 for a 64x64 CU) and plane: EstimateTransform (EbTransforms.c:3268) ->
+ * UnifiedQuantizeInvQuantize_R (EbFullLoop.c:452) -> PictureFullDistortion_R (EbPictureOperators.c:325) + the chroma
+ * scaling (EbFullLoop.c:1000-1004) -> TuEstimateCoeffBits_R (EbEntropyCoding.c:7963) -> TuCalcCost chroma branches
+ * (EbRateDistortionCost.c:273-279).  Partial-frequency correction as :647-652 (4x4 never, 8x8 at most N2). */
+typedef struct SvtAmdChromaLoopIn {
+    uint32_t size;              /* CU size 8 / 16 / 32 / 64 (chroma TU = size/2, 16 for 64)              */
+    uint32_t cb_qp, cr_qp;      /* MapChromaQp() outputs the caller derived                              */
+    uint32_t slice_type;        /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR                                      */
+    uint32_t pf_mode;           /* contextPtr->pfMdMode: 0 off, 1 N2                                     */
+    uint32_t cand_type;         /* INTER_MODE 1 / INTRA_MODE 2                                           */
+    uint32_t intra_luma_mode;   /* chroma mode is EB_INTRA_CHROMA_DM in this loop                        */
+    uint32_t pad;
+} SvtAmdChromaLoopIn;
+typedef struct SvtAmdChromaLoopOut {
+    uint32_t nz[2][5];          /* countNonZeroCoeffs[1 / 2][0..4] entries the call wrote (others 0)     */
+    uint32_t cbf[2];            /* candidatePtr->cbCbf / crCbf (zeroed by the caller between the two)    */
+    uint64_t coeff_bits[2];     /* *cbCoeffBits / *crCoeffBits (the caller passes zeros in)              */
+    uint64_t dist[2][2];        /* cb / cr FullDistortion[DIST_CALC_RESIDUAL / PREDICTION]               */
+} SvtAmdChromaLoopOut;
+/* BATCHED: candidate c has its (size/2)^2 Cb residual at d_residual + c*2048 and its Cr residual 1024 samples later
+ * (row pitch = size/2); quantised and reconstructed coefficients come back in the same layout. `cost`: HOST pointer. */
+SVT_AMD_API int svt_amd_full_loop_chroma_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost,
+                                               const SvtAmdChromaLoopIn *d_in, const int16_t *d_residual,
+                                               int16_t *d_quant, int16_t *d_recon, SvtAmdChromaLoopOut *d_out,
+                                               uint32_t ncand);
+/* Per-call form on HOST pointers ([0] = Cb, [1] = Cr; row pitch `pitch` samples, e.g. the reference's 32-sample chroma
+ * LCU buffers); writes back only the (T >> pf) area of every transform unit.  Blocking. */
+SVT_AMD_API int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
+                                         const int16_t *const residual[2], int16_t *const quant[2],
+                                         int16_t *const recon[2], uint32_t pitch, SvtAmdChromaLoopOut *out);
+
+/* ------------------------------------------------------------------------- */
 /* HEVC motion-compensation interpolation (closed-loop inter prediction)      */
 /* ------------------------------------------------------------------------- */
 /* One prediction block: integer position = sample index ref_off of the reference plane, fractional part (fx,fy) in

@@ -102,3 +102,72 @@ void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmd
         out->cand_nz[0] = (uint16_t)out->nz[0];
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Chroma full loop: FullLoop_R (Codec/EbFullLoop.c:579-870) followed by CuFullDistortionFastTuMode_R (:873-1066), both
+ * with PICTURE_BUFFER_DESC_CHROMA_MASK, as EbProductCodingLoop.c:4291-4319 / :4518-4547 call them.
+ *   UnifiedQuantizeInvQuantize_R   Codec/EbFullLoop.c:452-575  (QiQ + UpdateQiQCoef_R with both flags 0: no change)
+ *   PictureFullDistortion_R        Codec/EbPictureOperators.c:325-390
+ *   TuEstimateCoeffBits_R          Codec/EbEntropyCoding.c:7963-8076 (coeffCabacUpdate == 0)
+ *   TuCalcCost (chroma branches)   Codec/EbRateDistortionCost.c:273-279
+ * ------------------------------------------------------------------------------------------------------------------ */
+static void chroma_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, uint32_t qp, uint32_t T, uint32_t component,
+                           const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t *nzOut, uint64_t dist[2],
+                           uint64_t *bits)
+{
+    static const uint32_t QF[6] = {26214, 23302, 20560, 18396, 16384, 14564}, FF[6] = {40, 45, 51, 57, 64, 72};
+    int16_t coeff[16 * 16];
+    /* correctedPFMode (EbFullLoop.c:647-652): 4x4 off, 8x8 at most N2 */
+    const uint32_t pf = T == 4 ? 0 : (T == 8 && in->pf_mode == 2 ? 1 : in->pf_mode);
+    svt_oracle_FwdTransform(T >= 16 ? 1 : 0, (int)T, residual, T, coeff, T, NULL, 0);
+    const int32_t qpRem = (int32_t)(qp % 6), qpPer = (int32_t)(qp / 6);
+    const uint32_t tshift = 15 - 8 - ilog2u(T); /* MAX_TR_DYNAMIC_RANGE - bitDepth (mode decision works on 8 bits) - log2 */
+    const int32_t shiftedQBits = 14 + qpPer + (int32_t)tshift;
+    const uint32_t q_offset = ((in->slice_type == 2 || in->slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int32_t shiftedFFunc = qpPer > 8 ? (int32_t)FF[qpRem] << (qpPer - 2) : (int32_t)FF[qpRem] << qpPer;
+    const int32_t shiftNum = qpPer > 8 ? 20 - 14 - (int32_t)tshift - 2 : 20 - 14 - (int32_t)tshift;
+    const int32_t iq_offset = 1 << (shiftNum - 1);
+    const uint32_t area = T >> pf;
+    uint32_t nz = 0;
+    svt_oracle_QuantizeInvQuantize(coeff, T, quant, recon, QF[qpRem], q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum,
+                                   area, &nz);
+    *nzOut = nz;
+    uint64_t d[2] = {0, 0};
+    svt_oracle_FullDistortionKernel_32bit(coeff, T, recon, T, d, area, area, nz == 0 ? 1 : (in->cand_type == 2 ? 2 : 0));
+    const uint32_t shift = 2 * (7 - ilog2u(T));
+    dist[0] = (d[0] + ((uint64_t)1 << (shift - 1))) >> shift;
+    dist[1] = (d[1] + ((uint64_t)1 << (shift - 1))) >> shift;
+    uint64_t tuBits = 0;
+    if (nz)
+        tuBits = svt_oracle_coeff_bits_lossy(cost, area, in->cand_type, in->intra_luma_mode, 4, quant, T, component, nz);
+    *bits = tuBits >> 15;
+}
+
+/* residual / quant / recon: [0] Cb, [1] Cr, each (size/2)^2 with row pitch size/2; quant and recon pre-filled by the
+ * caller with what the reference buffers held (quant: the residual itself; recon: anything) */
+void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
+                                 int16_t *const quant[2], int16_t *const recon[2], SvtAmdChromaLoopOut *out)
+{
+    memset(out, 0, sizeof(*out));
+    const uint32_t C = in->size >> 1, T = in->size == 64 ? 16 : C, ntu = in->size == 64 ? 4 : 1;
+    for (uint32_t tu = 0; tu < ntu; tu++) {
+        const uint32_t off = ntu == 1 ? 0 : ((tu & 1) << 4) + ((tu > 1) ? 16 * 32 : 0), tuIndex = ntu == 1 ? 0 : tu + 1;
+        for (uint32_t p = 0; p < 2; p++) {
+            int16_t r[16 * 16], q[16 * 16], c[16 * 16];
+            for (uint32_t y = 0; y < T; y++) {
+                memcpy(r + y * T, residual[p] + off + y * C, T * 2);
+                memcpy(q + y * T, quant[p] + off + y * C, T * 2);
+                memcpy(c + y * T, recon[p] + off + y * C, T * 2);
+            }
+            uint64_t d[2], bits;
+            chroma_loop_tu(cost, in, p ? in->cr_qp : in->cb_qp, T, p + 1, r, q, c, &out->nz[p][tuIndex], d, &bits);
+            for (uint32_t y = 0; y < T; y++) {
+                memcpy(quant[p] + off + y * C, q + y * T, T * 2);
+                memcpy(recon[p] + off + y * C, c + y * T, T * 2);
+            }
+            out->cbf[p] |= (uint32_t)(out->nz[p][tuIndex] != 0) << tuIndex;
+            out->coeff_bits[p] += bits;
+            out->dist[p][0] += d[0], out->dist[p][1] += d[1];
+        }
+    }
+}
