@@ -324,6 +324,95 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     }
 }
 
+/*
+ * Mode-decision chroma full loop: the pair FullLoop_R (EbFullLoop.c:579) + CuFullDistortionFastTuMode_R (:873), called
+ * back to back with the chroma mask (EbProductCodingLoop.c:4291-4319, :4518-4547), is answered by one
+ * svt_amd_full_loop_chroma() call made from the first of the two; the second hands out the stashed results.  Same
+ * conditions and the same SVT_HOOK_FULLLOOP=1 switch as the luma binding above.
+ */
+void __real_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_t *candidateBuffer,
+                       ModeDecisionContext_t *contextPtr, const CodedUnitStats_t *cuStatsPtr,
+                       EbPictureBufferDesc_t *inputPicturePtr, PictureControlSet_t *pcs, EB_U32 componentMask, EB_U32 cbQp,
+                       EB_U32 crQp, EB_U32 *cbCountNonZeroCoeffs, EB_U32 *crCountNonZeroCoeffs);
+void __real_CuFullDistortionFastTuMode_R(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex,
+                                         LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_t *candidateBuffer,
+                                         ModeDecisionContext_t *contextPtr, ModeDecisionCandidate_t *candidatePtr,
+                                         const CodedUnitStats_t *cuStatsPtr, EB_U64 cbFullDistortion[DIST_CALC_TOTAL],
+                                         EB_U64 crFullDistortion[DIST_CALC_TOTAL],
+                                         EB_U32 countNonZeroCoeffs[3][MAX_NUM_OF_TU_PER_CU], EB_U32 componentMask,
+                                         EB_U64 *cbCoeffBits, EB_U64 *crCoeffBits);
+static unsigned long g_cl_gpu, g_cl_cpu;
+static __thread SvtAmdChromaLoopOut t_chroma_out;
+static __thread const ModeDecisionCandidateBuffer_t *t_chroma_for; /* candidate buffer the stash belongs to */
+
+void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_t *candidateBuffer,
+                       ModeDecisionContext_t *contextPtr, const CodedUnitStats_t *cuStatsPtr,
+                       EbPictureBufferDesc_t *inputPicturePtr, PictureControlSet_t *pcs, EB_U32 componentMask, EB_U32 cbQp,
+                       EB_U32 crQp, EB_U32 *cbCountNonZeroCoeffs, EB_U32 *crCountNonZeroCoeffs)
+{
+    if (g_fl_state == 0)
+        g_fl_state = getenv("SVT_HOOK_FULLLOOP") ? 1 : -1;
+    t_chroma_for = NULL;
+    if (g_fl_state < 0 || !g_ctx || contextPtr->rdoqPmCoreMethod || contextPtr->spatialSseFullLoop ||
+        contextPtr->coeffCabacUpdate || componentMask != PICTURE_BUFFER_DESC_CHROMA_MASK ||
+        candidateBuffer->residualQuantCoeffPtr->strideCb != 32 || candidateBuffer->reconCoeffPtr->strideCb != 32) {
+        if (g_fl_state > 0) {
+            pthread_mutex_lock(&g_lock);
+            g_cl_cpu++;
+            pthread_mutex_unlock(&g_lock);
+        }
+        __real_FullLoop_R(lcuPtr, candidateBuffer, contextPtr, cuStatsPtr, inputPicturePtr, pcs, componentMask, cbQp, crQp,
+                          cbCountNonZeroCoeffs, crCountNonZeroCoeffs);
+        return;
+    }
+    const ModeDecisionCandidate_t *c = candidateBuffer->candidatePtr;
+    const uint32_t size = cuStatsPtr->size;
+    const uint32_t origin = size == 64 ? 0 : (cuStatsPtr->originX + cuStatsPtr->originY * 32) >> 1;
+    SvtAmdChromaLoopIn in;
+    memset(&in, 0, sizeof(in));
+    in.size = size, in.cb_qp = cbQp, in.cr_qp = crQp, in.slice_type = pcs->sliceType, in.pf_mode = contextPtr->pfMdMode;
+    in.cand_type = c->type, in.intra_luma_mode = c->intraLumaMode;
+    int16_t *q[2] = {(int16_t *)candidateBuffer->residualQuantCoeffPtr->bufferCb + origin,
+                     (int16_t *)candidateBuffer->residualQuantCoeffPtr->bufferCr + origin}; /* residual in, quantised out */
+    int16_t *r[2] = {(int16_t *)candidateBuffer->reconCoeffPtr->bufferCb + origin,
+                     (int16_t *)candidateBuffer->reconCoeffPtr->bufferCr + origin};
+    pthread_mutex_lock(&g_lock);
+    if (svt_amd_full_loop_chroma(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, (const int16_t *const *)q, q, r, 32,
+                                 &t_chroma_out))
+        die("svt_amd_full_loop_chroma");
+    if (g_cl_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: chroma full loop (FullLoop_R + CuFullDistortionFastTuMode_R) on the GPU\n");
+    if (g_verbose && (g_cl_gpu % 2000) == 0)
+        fprintf(stderr, "svt_hook_me: %lu chroma full-loop candidates on the GPU, %lu on the CPU\n", g_cl_gpu, g_cl_cpu);
+    pthread_mutex_unlock(&g_lock);
+    for (int k = (size == 64 ? 1 : 0); k < (size == 64 ? 5 : 1); k++)
+        cbCountNonZeroCoeffs[k] = t_chroma_out.nz[0][k], crCountNonZeroCoeffs[k] = t_chroma_out.nz[1][k];
+    t_chroma_for = candidateBuffer;
+}
+
+void __wrap_CuFullDistortionFastTuMode_R(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex,
+                                         LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_t *candidateBuffer,
+                                         ModeDecisionContext_t *contextPtr, ModeDecisionCandidate_t *candidatePtr,
+                                         const CodedUnitStats_t *cuStatsPtr, EB_U64 cbFullDistortion[DIST_CALC_TOTAL],
+                                         EB_U64 crFullDistortion[DIST_CALC_TOTAL],
+                                         EB_U32 countNonZeroCoeffs[3][MAX_NUM_OF_TU_PER_CU], EB_U32 componentMask,
+                                         EB_U64 *cbCoeffBits, EB_U64 *crCoeffBits)
+{
+    if (t_chroma_for != candidateBuffer || componentMask != PICTURE_BUFFER_DESC_CHROMA_MASK) {
+        t_chroma_for = NULL;
+        __real_CuFullDistortionFastTuMode_R(inputPicturePtr, inputCbOriginIndex, lcuPtr, candidateBuffer, contextPtr,
+                                            candidatePtr, cuStatsPtr, cbFullDistortion, crFullDistortion, countNonZeroCoeffs,
+                                            componentMask, cbCoeffBits, crCoeffBits);
+        return;
+    }
+    t_chroma_for = NULL;
+    const SvtAmdChromaLoopOut *o = &t_chroma_out;
+    candidatePtr->cbCbf |= o->cbf[0], candidatePtr->crCbf |= o->cbf[1];
+    *cbCoeffBits += o->coeff_bits[0], *crCoeffBits += o->coeff_bits[1];
+    cbFullDistortion[0] += o->dist[0][0], cbFullDistortion[1] += o->dist[0][1];
+    crFullDistortion[0] += o->dist[1][0], crFullDistortion[1] += o->dist[1][1];
+}
+
 static void hook_report(void)
 {
     fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,

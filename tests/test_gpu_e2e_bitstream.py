@@ -69,14 +69,16 @@ FULLLOOP_CASES = [
     ("motion", 416, 240, 4, ["-encMode", "9", "-pred-struct", "0"]),
     ("motion", 416, 240, 3, ["-encMode", "10", "-intra-period", "0"]),          # encMode 10 needs the 1080p class:
     ("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"]),
+    ("motion", 416, 240, 3, ["-encMode", "5", "-pred-struct", "0"]),            # 8x8 CUs: 4x4 chroma transform units
 ]
 
 
 @pytest.mark.parametrize("kind,w,h,n,args", FULLLOOP_CASES)
 def test_bitstream_identical_with_gpu_full_loop(tmp_path, kind, w, h, n, args):
-    """Same check with the mode decision's luma full loop (ProductFullLoop) also answered by the device, one fused
-    kernel call per candidate (SVT_HOOK_FULLLOOP=1): transform, quantisation, distortion, rate and cbf decision of
-    every candidate CU come from svt_amd_full_loop_luma."""
+    """Same check with the mode decision's luma full loop (ProductFullLoop) and chroma full loop (FullLoop_R +
+    CuFullDistortionFastTuMode_R) also answered by the device, one fused kernel call per candidate
+    (SVT_HOOK_FULLLOOP=1): transform, quantisation, distortion, rate and cbf decision of every candidate CU come from
+    svt_amd_full_loop_luma / svt_amd_full_loop_chroma."""
     if "-intra-period" in args:
         w, h = 1920, 1080
         n = 1
@@ -89,4 +91,6 @@ def test_bitstream_identical_with_gpu_full_loop(tmp_path, kind, w, h, n, args):
     finally:
         del os.environ["SVT_HOOK_FULLLOOP"]
     assert "svt_hook_me: luma full loop (ProductFullLoop) on the GPU" in log, log[-1000:]
+    if "-intra-period" not in args:  # intra pictures of these presets leave chroma to the encode pass
+        assert "svt_hook_me: chroma full loop (FullLoop_R + CuFullDistortionFastTuMode_R) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
