@@ -110,6 +110,10 @@ void svt_oracle_IntraPred(int mode, int bps, uint32_t size, const void *ref, voi
 void svt_oracle_Luma4SampleEdgeDLFCore(int bps, void *edge, uint32_t stride, int isVerticalEdge, int32_t tc, int32_t beta);
 void svt_oracle_Chroma2SampleEdgeDLFCore(int bps, void *cb, void *cr, uint32_t stride, int isVerticalEdge,
                                          uint8_t cbTc, uint8_t crTc);
+/* whole-picture deblocking = the result of the three per-LCU drivers over all LCUs (4:2:0; tight or strided planes) */
+void svt_oracle_dlf_picture(int bps, void *y, uint32_t strideY, void *cb, void *cr, uint32_t strideC, uint32_t width,
+                            uint32_t height, const uint8_t *bs_v, const uint8_t *bs_h, const uint8_t *qp, uint32_t qpStride,
+                            int tcOffset, int betaOffset, int cbQpOffset, int crQpOffset);
 void svt_oracle_GatherSaoStatistics(int bps, int only_eo_90_45_135, const void *input, uint32_t inputStride,
                                     const void *recon, uint32_t reconStride, uint32_t lcuWidth, uint32_t lcuHeight,
                                     int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5], uint16_t eoCount[4][5]);

@@ -218,3 +218,69 @@ void svt_oracle_UnpackAvg(const uint16_t *l0, uint32_t s0, const uint16_t *l1, u
         for (uint32_t k = 0; k < w; k++)
             dst[k + j * dstStride] = (uint8_t)(((uint8_t)(l0[k + j * s0] >> 2) + (uint8_t)(l1[k + j * s1] >> 2) + 1) >> 1);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Picture-level deblocking: what the three per-LCU drivers LCUInternalAreaDLFCore / LCUBoundaryDLFCore /
+ * LCUPictureEdgeDLFCore (+16bit; Codec/EbDeblockingFilter.c:2222-4330, called per LCU from EbCodingLoop.c:4600-4631)
+ * leave in the reconstructed picture once every LCU has been through them: all vertical edges of the 8x8 grid, then all
+ * horizontal edges (H.265 8.7.2; the drivers' internal-area / boundary / picture-edge split only orders the same edge
+ * set so that this holds LCU by LCU).  Edge strength from the per-LCU arrays (index = 4x4 block raster inside the LCU,
+ * EbDeblockingFilter.h:19-22), tc / beta from the mean qp of the two sides (tables :30-38; qp per 8x8 block,
+ * :23-24), chroma edges on the 8-sample chroma grid where bS > 1 with the mapped chroma qp (:21-25), 4:2:0.
+ * Pinned by tests/test_oracle_dlf_golden.py against whole pictures of real encoder runs.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static const uint8_t kTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+static const uint8_t kBeta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                  16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+static const uint8_t kChromaQpMap[58] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+                                         29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
+
+static int chroma_tc(int qpMean, int qpOffset, int tcOffset)
+{
+    const int q = qpMean + qpOffset;
+    const uint8_t qc = (uint8_t)(q < 0 ? q : q > 57 ? q - 6 : kChromaQpMap[q]); /* convertToChromaQp into an EB_U8 */
+    return kTc[clip3(0, 53, (int)qc + 2 + tcOffset)];
+}
+
+void svt_oracle_dlf_picture(int bps, void *y, uint32_t strideY, void *cb, void *cr, uint32_t strideC, uint32_t width,
+                            uint32_t height, const uint8_t *bs_v, const uint8_t *bs_h, const uint8_t *qp, uint32_t qpStride,
+                            int tcOffset, int betaOffset, int cbQpOffset, int crQpOffset)
+{
+    const uint32_t lcuCols = (width + 63) >> 6, scale = bps == 1 ? 0 : 2;
+    uint8_t *Y = (uint8_t *)y, *CB = (uint8_t *)cb, *CR = (uint8_t *)cr;
+    for (int dir = 0; dir < 2; dir++) { /* 0: vertical edges, 1: horizontal edges */
+        const uint8_t *bs = dir ? bs_h : bs_v;
+        /* luma: 4-sample segments of the 8x8 grid */
+        for (uint32_t py = dir ? 8 : 0; py < height; py += dir ? 8 : 4)
+            for (uint32_t px = dir ? 0 : 8; px < width; px += dir ? 4 : 8) {
+                const uint32_t lcu = (py >> 6) * lcuCols + (px >> 6);
+                const int b = bs[lcu * 256 + ((px & 63) >> 2) + (((py & 63) >> 2) << 4)];
+                if (!b)
+                    continue;
+                const int qq = qp[(px >> 3) + (py >> 3) * qpStride];
+                const int qpp = dir ? qp[(px >> 3) + ((py - 1) >> 3) * qpStride] : qp[((px - 1) >> 3) + (py >> 3) * qpStride];
+                const int Q = (qq + qpp + 1) >> 1;
+                const int tc = kTc[clip3(0, 53, Q + ((b > 1) << 1) + tcOffset)] << scale;
+                const int beta = kBeta[clip3(0, 51, Q + betaOffset)] << scale;
+                svt_oracle_Luma4SampleEdgeDLFCore(bps, Y + ((size_t)py * strideY + px) * bps, strideY, !dir, tc, beta);
+            }
+        /* chroma (4:2:0): 2-sample segments of the 8x8 chroma grid, bS of the co-located luma 4x4 block */
+        const uint32_t cw = width >> 1, ch = height >> 1;
+        for (uint32_t cy = dir ? 8 : 0; cy < ch; cy += dir ? 8 : 2)
+            for (uint32_t cx = dir ? 0 : 8; cx < cw; cx += dir ? 2 : 8) {
+                const uint32_t lcu = (cy >> 5) * lcuCols + (cx >> 5);
+                const int b = bs[lcu * 256 + ((cx & 31) >> 1) + (((cy & 31) >> 1) << 4)];
+                if (b <= 1)
+                    continue;
+                const int qq = qp[((2 * cx) >> 3) + ((2 * cy) >> 3) * qpStride];
+                const int qpp = dir ? qp[((2 * cx) >> 3) + ((2 * (cy - 1)) >> 3) * qpStride]
+                                    : qp[((2 * (cx - 1)) >> 3) + ((2 * cy) >> 3) * qpStride];
+                const int Q = (qq + qpp + 1) >> 1;
+                const int cbTc = (uint8_t)(chroma_tc(Q, cbQpOffset, tcOffset) << scale);
+                const int crTc = (uint8_t)(chroma_tc(Q, crQpOffset, tcOffset) << scale);
+                const size_t off = ((size_t)cy * strideC + cx) * bps;
+                svt_oracle_Chroma2SampleEdgeDLFCore(bps, CB + off, CR + off, strideC, !dir, cbTc, crTc);
+            }
+    }
+}

@@ -1,0 +1,56 @@
+"""CPU-only: pins the picture-level deblocking of oracle/svt_oracle_loopfilter.c (svt_oracle_dlf_picture) against whole
+pictures of real encoder runs: reconstruction before the filter + boundary strengths + qp array -> reconstruction after
+the reference's three per-LCU drivers have run over every LCU (tests/golden/dlf_*.npz, made by
+tests/golden/make_dlf_golden.py)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import svtlib as S
+
+CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(S.GOLDEN_DIR, "dlf_*.npz")))
+
+
+def load_dlf_case(name):
+    """-> list of pictures: dict(hdr, pre=[y,cb,cr], post=[y,cb,cr], bsv, bsh, qp)"""
+    g = np.load(os.path.join(S.GOLDEN_DIR, "dlf_%s.npz" % name))
+    pics = []
+    for k in range(int(g["count"])):
+        pics.append(dict(hdr=g["hdr%d" % k][0], pre=[g["pre_%s%d" % (c, k)] for c in ("y", "cb", "cr")],
+                         post=[g["post_%s%d" % (c, k)] for c in ("y", "cb", "cr")], bsv=g["bsv%d" % k], bsh=g["bsh%d" % k],
+                         qp=g["qp%d" % k]))
+    return pics
+
+
+def oracle_dlf(oracle, pic):
+    h = pic["hdr"]
+    planes = [np.ascontiguousarray(p).copy() for p in pic["pre"]]
+    oracle.svt_oracle_dlf_picture.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
+                                              C.c_int, C.c_int]
+    oracle.svt_oracle_dlf_picture.restype = None
+    bsv, bsh, qp = (np.ascontiguousarray(pic[k]) for k in ("bsv", "bsh", "qp"))
+    oracle.svt_oracle_dlf_picture(int(h["bytes_per_sample"]), planes[0].ctypes.data, planes[0].shape[1], planes[1].ctypes.data,
+                                  planes[2].ctypes.data, planes[1].shape[1], int(h["width"]), int(h["height"]),
+                                  bsv.ctypes.data, bsh.ctypes.data, qp.ctypes.data, int(h["qp_stride"]), int(h["tc_offset"]),
+                                  int(h["beta_offset"]), int(h["cb_qp_offset"]), int(h["cr_qp_offset"]))
+    return planes
+
+
+def test_have_cases():
+    assert len(CASES) >= 5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_dlf_picture_oracle_matches_reference(oracle, name):
+    pics = load_dlf_case(name)
+    assert len(pics) >= 2
+    for k, pic in enumerate(pics):
+        got = oracle_dlf(oracle, pic)
+        for p in range(3):
+            bad = np.argwhere(got[p] != pic["post"][p])
+            assert len(bad) == 0, (name, k, p, len(bad), bad[:5].tolist())
+        assert sum(int((a != b).sum()) for a, b in zip(pic["pre"], pic["post"])) > 1000   # the filter did something
