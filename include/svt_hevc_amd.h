@@ -506,6 +506,17 @@ SVT_AMD_API int svt_amd_dlf_luma_edges_batch(SvtAmdContext *ctx, void *d_plane, 
 SVT_AMD_API int svt_amd_dlf_chroma_edges_batch(SvtAmdContext *ctx, void *d_cb, void *d_cr, uint32_t stride,
                                                int bytes_per_sample, const SvtAmdDlfChromaEdge *d_edges,
                                                uint32_t nedges);
+/* WHOLE PICTURE (device pointers, 4:2:0, in place): the state the per-LCU drivers LCUInternalAreaDLFCore /
+ * LCUBoundaryDLFCore / LCUPictureEdgeDLFCore (+16bit; Codec/EbDeblockingFilter.c:2222, 2828, 3518, called per LCU from
+ * EbCodingLoop.c:4600-4631) leave once every LCU has been through them.  d_y/d_cb/d_cr point at sample (0,0) of the
+ * planes (strides in samples); d_bs_v / d_bs_h = pictureControlSetPtr->verticalEdgeBSArray / horizontalEdgeBSArray laid
+ * out [lcu raster][256] (index = 4x4 block raster inside the 64x64 LCU, EbDeblockingFilter.h:19-22); d_qp = qpArray
+ * (one byte per 8x8 block, row pitch qpStride); offsets = the picture control set's tcOffset / betaOffset / cbQpOffset /
+ * crQpOffset.  width and height are multiples of 8.  Tile and picture boundaries carry strength 0 in the arrays. */
+SVT_AMD_API int svt_amd_dlf_picture(SvtAmdContext *ctx, int bytes_per_sample, void *d_y, uint32_t strideY, void *d_cb,
+                                    void *d_cr, uint32_t strideC, uint32_t width, uint32_t height,
+                                    const uint8_t *d_bs_v, const uint8_t *d_bs_h, const uint8_t *d_qp, uint32_t qpStride,
+                                    int32_t tcOffset, int32_t betaOffset, int32_t cbQpOffset, int32_t crQpOffset);
 /* statistics of every LCU of a plane (raster LCU order), replaces the per-LCU SaoGenerationDecision ->
  * GatherSaoStatisticsLcu* calls (EbSampleAdaptiveOffsetGenerationDecision.c:647,936) */
 SVT_AMD_API int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,

@@ -78,29 +78,101 @@ __device__ void dlf_luma_core(T *edge, int stride, int vertical, int tc, int bet
 template <typename T>
 __global__ void k_dlf_luma(T *plane, int stride, const DlfLumaEdge *edges, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         dlf_luma_core<T>(plane + edges[i].offset, stride, edges[i].vertical, edges[i].tc, edges[i].beta);
 }
 
 template <typename T>
 __global__ void k_dlf_chroma(T *cb, T *cr, int stride, const DlfChromaEdge *edges, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
     const int maxv = sizeof(T) == 1 ? 255 : 1023;
-    const int fs = edges[i].vertical ? 1 : stride, ns = edges[i].vertical ? stride : 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int fs = edges[i].vertical ? 1 : stride, ns = edges[i].vertical ? stride : 1;
 #pragma unroll
-    for (int plane = 0; plane < 2; plane++) {
-        T *e = (plane ? cr : cb) + edges[i].offset;
-        const int tc = plane ? edges[i].cr_tc : edges[i].cb_tc;
+        for (int plane = 0; plane < 2; plane++) {
+            T *e = (plane ? cr : cb) + edges[i].offset;
+            const int tc = plane ? edges[i].cr_tc : edges[i].cb_tc;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int q0 = e[c * ns], q1 = e[c * ns + fs], p0 = e[c * ns - fs], p1 = e[c * ns - 2 * fs];
-            const int delta = (int16_t)f_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
-            e[c * ns - fs] = (T)f_clip3(0, maxv, p0 + delta);
-            e[c * ns] = (T)f_clip3(0, maxv, q0 - delta);
+            for (int c = 0; c < 2; c++) {
+                const int q0 = e[c * ns], q1 = e[c * ns + fs], p0 = e[c * ns - fs], p1 = e[c * ns - 2 * fs];
+                const int delta = (int16_t)f_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+                e[c * ns - fs] = (T)f_clip3(0, maxv, p0 + delta);
+                e[c * ns] = (T)f_clip3(0, maxv, q0 - delta);
+            }
+        }
+    }
+}
+
+/* ---------------- deblocking, whole picture ---------------- */
+/* What LCUInternalAreaDLFCore / LCUBoundaryDLFCore / LCUPictureEdgeDLFCore (+16bit; EbDeblockingFilter.c:2222-4330) leave
+ * behind once they have run over every LCU: all vertical edges of the 8x8 grid (launch dir = 0), then all horizontal
+ * ones (dir = 1).  One thread per 4-sample luma segment or 2-sample chroma segment; strength from the per-LCU arrays,
+ * tc / beta from the mean qp of the two sides.  Within one direction the segments touch disjoint samples, so the
+ * filter runs in place; neighbouring threads own neighbouring 8-byte (vertical) / 4-byte (horizontal) groups of a row,
+ * so every row access of a wave is one contiguous run. */
+struct DlfPic {
+    void *y, *cb, *cr;
+    const uint8_t *bs_v, *bs_h, *qp;
+    int strideY, strideC, width, height, qpStride, lcuCols;
+    int tcOffset, betaOffset, cbQpOffset, crQpOffset;
+};
+__constant__ uint8_t c_dlf_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                     2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ uint8_t c_dlf_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                       16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ uint8_t c_chroma_qp_map[58] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+                                            29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
+
+__device__ __forceinline__ int dlf_chroma_tc(int qpMean, int qpOffset, int tcOffset)
+{
+    const int q = qpMean + qpOffset;
+    const uint8_t qc = (uint8_t)(q < 0 ? q : q > 57 ? q - 6 : c_chroma_qp_map[q]); /* convertToChromaQp into an EB_U8 (:21-25) */
+    return c_dlf_tc[f_clip3(0, 53, (int)qc + 2 + tcOffset)];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dlf_picture(const DlfPic P, int dir, uint32_t nLumaX, uint32_t nLuma, uint32_t nChromaX,
+                                                     uint32_t nChroma)
+{
+    const int scale = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nLuma + nChroma; i += gridDim.x * blockDim.x) {
+        if (i < nLuma) {
+            const uint32_t sy = i / nLumaX, sx = i - sy * nLumaX;
+            const int px = dir ? (int)sx * 4 : (int)(sx + 1) * 8, py = dir ? (int)(sy + 1) * 8 : (int)sy * 4;
+            const uint8_t *bs = dir ? P.bs_h : P.bs_v;
+            const int b = bs[((py >> 6) * P.lcuCols + (px >> 6)) * 256 + ((px & 63) >> 2) + (((py & 63) >> 2) << 4)];
+            if (!b)
+                continue;
+            const int qq = P.qp[(px >> 3) + (py >> 3) * P.qpStride];
+            const int qpp = dir ? P.qp[(px >> 3) + ((py - 1) >> 3) * P.qpStride] : P.qp[((px - 1) >> 3) + (py >> 3) * P.qpStride];
+            const int Q = (qq + qpp + 1) >> 1;
+            const int tc = c_dlf_tc[f_clip3(0, 53, Q + ((b > 1) << 1) + P.tcOffset)] << scale;
+            const int beta = c_dlf_beta[f_clip3(0, 51, Q + P.betaOffset)] << scale;
+            dlf_luma_core<T>((T *)P.y + (size_t)py * P.strideY + px, P.strideY, !dir, tc, beta);
+        } else {
+            const uint32_t j = i - nLuma, sy = j / nChromaX, sx = j - sy * nChromaX;
+            const int cx = dir ? (int)sx * 2 : (int)(sx + 1) * 8, cy = dir ? (int)(sy + 1) * 8 : (int)sy * 2;
+            const uint8_t *bs = dir ? P.bs_h : P.bs_v;
+            const int b = bs[((cy >> 5) * P.lcuCols + (cx >> 5)) * 256 + ((cx & 31) >> 1) + (((cy & 31) >> 1) << 4)];
+            if (b <= 1)
+                continue;
+            const int qq = P.qp[((2 * cx) >> 3) + ((2 * cy) >> 3) * P.qpStride];
+            const int qpp = dir ? P.qp[((2 * cx) >> 3) + ((2 * (cy - 1)) >> 3) * P.qpStride]
+                                : P.qp[((2 * (cx - 1)) >> 3) + ((2 * cy) >> 3) * P.qpStride];
+            const int Q = (qq + qpp + 1) >> 1;
+            const int fs = dir ? P.strideC : 1, ns = dir ? 1 : P.strideC;
+#pragma unroll
+            for (int plane = 0; plane < 2; plane++) {
+                T *e = (T *)(plane ? P.cr : P.cb) + (size_t)cy * P.strideC + cx;
+                const int tc = (uint8_t)(dlf_chroma_tc(Q, plane ? P.crQpOffset : P.cbQpOffset, P.tcOffset) << scale);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int q0 = e[c * ns], q1 = e[c * ns + fs], p0 = e[c * ns - fs], p1 = e[c * ns - 2 * fs];
+                    const int delta = (int16_t)f_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+                    e[c * ns - fs] = (T)f_clip3(0, maxv, p0 + delta);
+                    e[c * ns] = (T)f_clip3(0, maxv, q0 - delta);
+                }
+            }
         }
     }
 }
@@ -320,6 +392,35 @@ extern "C" int svt_amd_dlf_chroma_edges_batch(SvtAmdContext *ctx, void *d_cb, vo
     else
         hipLaunchKernelGGL(k_dlf_chroma<uint16_t>, grid1d(nedges), dim3(256), 0, ctx->stream, (uint16_t *)d_cb, (uint16_t *)d_cr,
                            (int)stride, (const DlfChromaEdge *)d_edges, nedges);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_dlf_picture(SvtAmdContext *ctx, int bytes_per_sample, void *d_y, uint32_t strideY, void *d_cb,
+                                   void *d_cr, uint32_t strideC, uint32_t width, uint32_t height, const uint8_t *d_bs_v,
+                                   const uint8_t *d_bs_h, const uint8_t *d_qp, uint32_t qpStride, int32_t tcOffset,
+                                   int32_t betaOffset, int32_t cbQpOffset, int32_t crQpOffset)
+{
+    if (!ctx || !d_y || !d_cb || !d_cr || !d_bs_v || !d_bs_h || !d_qp || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
+        width < 8 || height < 8 || (width & 7) || (height & 7) || strideY < width || strideC < width / 2 ||
+        qpStride < width / 8)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DlfPic P = {d_y, d_cb, d_cr, d_bs_v, d_bs_h, d_qp, (int)strideY, (int)strideC, (int)width, (int)height, (int)qpStride,
+                (int)((width + 63) >> 6), tcOffset, betaOffset, cbQpOffset, crQpOffset};
+    const uint32_t cw = width / 2, ch = height / 2;
+    for (int dir = 0; dir < 2; dir++) {
+        /* segments along x, then totals: vertical edges at x = 8, 16, .. < W in 4-row (chroma 2-row) pieces;
+         * horizontal edges at y = 8, 16, .. < H in 4-column (chroma 2-column) pieces */
+        const uint32_t lx = dir ? width / 4 : (width - 1) / 8, ly = dir ? (height - 1) / 8 : height / 4;
+        const uint32_t cx = dir ? cw / 2 : (cw - 1) / 8, cy = dir ? (ch - 1) / 8 : ch / 2;
+        const uint32_t nL = lx * ly, nC = cx * cy;
+        if (!(nL + nC))
+            continue;
+        if (bytes_per_sample == 1)
+            hipLaunchKernelGGL(k_dlf_picture<uint8_t>, grid1d(nL + nC), dim3(256), 0, ctx->stream, P, dir, lx, nL, cx ? cx : 1, nC);
+        else
+            hipLaunchKernelGGL(k_dlf_picture<uint16_t>, grid1d(nL + nC), dim3(256), 0, ctx->stream, P, dir, lx, nL, cx ? cx : 1, nC);
+    }
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }

@@ -1,0 +1,87 @@
+"""-m gpu: picture-level deblocking (svt_amd_dlf_picture) through the C-ABI against (1) whole pictures of real encoder
+runs (tests/golden/dlf_*.npz: reconstruction before / after the reference's per-LCU deblocking drivers) and (2) the
+oracle (pinned to the same pictures in tests/test_oracle_dlf_golden.py) on random pictures with random strengths / qps,
+8 and 10 bit, strided planes, up to 4K."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svtlib as S
+from test_oracle_dlf_golden import CASES, load_dlf_case, oracle_dlf
+
+pytestmark = pytest.mark.gpu
+vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+
+
+def gpu_dlf(product, gpu_ctx, pic, pad=0):
+    """pic as in load_dlf_case; planes are placed in buffers with `pad` extra samples per row -> filtered planes"""
+    import torch
+    h = pic["hdr"]
+    bps = int(h["bytes_per_sample"])
+    dev, strides = [], []
+    for p in pic["pre"]:
+        buf = np.zeros((p.shape[0], p.shape[1] + pad), p.dtype)
+        buf[:, :p.shape[1]] = p
+        t = torch.from_numpy(buf.view(np.int16) if bps == 2 else buf).cuda()
+        dev.append(t)
+        strides.append(buf.shape[1])
+    aux = [torch.from_numpy(np.ascontiguousarray(pic[k])).cuda() for k in ("bsv", "bsh", "qp")]
+    product.svt_amd_dlf_picture.argtypes = [vp, C.c_int, vp, u32, vp, vp, u32, u32, u32, vp, vp, vp, u32, i32, i32, i32, i32]
+    torch.cuda.synchronize()
+    rc = product.svt_amd_dlf_picture(gpu_ctx, bps, dev[0].data_ptr(), strides[0], dev[1].data_ptr(), dev[2].data_ptr(),
+                                     strides[1], int(h["width"]), int(h["height"]), aux[0].data_ptr(), aux[1].data_ptr(),
+                                     aux[2].data_ptr(), int(h["qp_stride"]), int(h["tc_offset"]), int(h["beta_offset"]),
+                                     int(h["cb_qp_offset"]), int(h["cr_qp_offset"]))
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    out = []
+    for t, p in zip(dev, pic["pre"]):
+        a = t.cpu().numpy()
+        a = a.view(np.uint16) if bps == 2 else a
+        out.append(a[:, :p.shape[1]])
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_dlf_picture_matches_reference_golden(product, gpu_ctx, name):
+    for k, pic in enumerate(load_dlf_case(name)):
+        got = gpu_dlf(product, gpu_ctx, pic, pad=8 * (k & 1))
+        for p in range(3):
+            bad = np.argwhere(got[p] != pic["post"][p])
+            assert len(bad) == 0, (name, k, p, len(bad), bad[:5].tolist())
+
+
+def random_picture(rng, w, h, bps, smooth):
+    hdr = np.zeros(1, dtype=[("width", "<u4"), ("height", "<u4"), ("bytes_per_sample", "<u4"), ("qp_stride", "<u4"),
+                             ("tc_offset", "<i4"), ("beta_offset", "<i4"), ("cb_qp_offset", "<i4"), ("cr_qp_offset", "<i4")])[0]
+    hdr["width"], hdr["height"], hdr["bytes_per_sample"], hdr["qp_stride"] = w, h, bps, w // 8 + 3
+    hdr["tc_offset"], hdr["beta_offset"] = int(rng.integers(-6, 7)), int(rng.integers(-6, 7))
+    hdr["cb_qp_offset"], hdr["cr_qp_offset"] = int(rng.integers(-12, 13)), int(rng.integers(-12, 13))
+    maxv = 255 if bps == 1 else 1023
+    planes = []
+    for (pw, ph) in ((w, h), (w // 2, h // 2), (w // 2, h // 2)):
+        if smooth:   # blocky but smooth content: the strong / normal filters actually fire
+            base = rng.integers(0, maxv + 1, ((ph + 7) // 8, (pw + 7) // 8))
+            a = np.kron(base, np.ones((8, 8), np.int64))[:ph, :pw] + rng.integers(-2, 3, (ph, pw))
+        else:
+            a = rng.integers(0, maxv + 1, (ph, pw))
+        planes.append(np.clip(a, 0, maxv).astype(np.uint8 if bps == 1 else np.uint16))
+    nlcu = ((w + 63) // 64) * ((h + 63) // 64)
+    bsv, bsh = (rng.integers(0, 3, (nlcu, 256)).astype(np.uint8) for _ in range(2))
+    qp = rng.integers(0, 52, (int(hdr["qp_stride"]) * (h // 8),)).astype(np.uint8)
+    return dict(hdr=hdr, pre=planes, bsv=bsv, bsh=bsh, qp=qp)
+
+
+@pytest.mark.parametrize("w,h,bps,smooth", [(64, 64, 1, 1), (8, 8, 1, 1), (72, 40, 1, 0), (416, 240, 2, 1), (1920, 1080, 1, 1),
+                                            (3840, 2160, 1, 1), (1280, 720, 2, 0)])
+def test_dlf_picture_matches_oracle_random(product, gpu_ctx, oracle, w, h, bps, smooth):
+    rng = np.random.default_rng(w * 7 + h + bps)
+    pic = random_picture(rng, w, h, bps, smooth)
+    want = oracle_dlf(oracle, pic)
+    got = gpu_dlf(product, gpu_ctx, pic, pad=4)
+    changed = 0
+    for p in range(3):
+        assert np.array_equal(got[p], want[p]), (p, np.argwhere(got[p] != want[p])[:5].tolist())
+        changed += int((want[p] != pic["pre"][p]).sum())
+    assert changed > 0 or w <= 8
