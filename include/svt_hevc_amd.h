@@ -517,6 +517,23 @@ SVT_AMD_API int svt_amd_dlf_picture(SvtAmdContext *ctx, int bytes_per_sample, vo
                                     void *d_cr, uint32_t strideC, uint32_t width, uint32_t height,
                                     const uint8_t *d_bs_v, const uint8_t *d_bs_h, const uint8_t *d_qp, uint32_t qpStride,
                                     int32_t tcOffset, int32_t betaOffset, int32_t cbQpOffset, int32_t crQpOffset);
+/* WHOLE PICTURE SAO application (device pointers, 4:2:0, OUT OF PLACE: d_dst[k] != d_src[k]): replaces
+ * ApplySaoOffsetsPicture(16bit) -> ApplySaoOffsetsLcu(16bit) (Codec/EbEncDecProcess.c:522-757, :215-517; 16-bit :762-1330).
+ * One record per LCU (raster order): SaoParameters_t (Codec/EbCodingUnit.h:137-146; type[0] luma, type[1] chroma:
+ * 0 off, 1..4 edge offset 0 / 90 / 135 / 45 degrees, 5 band offset) with the two merge flags squeezed into bytes and the
+ * tile-edge flags of lcuEdgeInfoPtr / tileInfoPtr that ApplySaoOffsetsLcu reads (:252-256) in edge_flags.
+ * luma_on / chroma_on = pictureControlSetPtr->saoFlag[0] / [1]. */
+typedef struct SvtAmdSaoLcuParams {
+    uint8_t  merge_left, merge_up;
+    uint8_t  edge_flags;        /* 1 tile left edge, 2 tile right edge, 4 tile top edge, 8 tile bottom edge */
+    uint8_t  pad;
+    uint32_t type[2];
+    int32_t  offset[3][4];
+    uint32_t band[3];
+} SvtAmdSaoLcuParams;
+SVT_AMD_API int svt_amd_sao_apply_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *const d_src[3],
+                                          void *const d_dst[3], uint32_t strideY, uint32_t strideC, uint32_t width,
+                                          uint32_t height, const SvtAmdSaoLcuParams *d_lcus, int luma_on, int chroma_on);
 /* statistics of every LCU of a plane (raster LCU order), replaces the per-LCU SaoGenerationDecision ->
  * GatherSaoStatisticsLcu* calls (EbSampleAdaptiveOffsetGenerationDecision.c:647,936) */
 SVT_AMD_API int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,

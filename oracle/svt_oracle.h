@@ -114,6 +114,16 @@ void svt_oracle_Chroma2SampleEdgeDLFCore(int bps, void *cb, void *cr, uint32_t s
 void svt_oracle_dlf_picture(int bps, void *y, uint32_t strideY, void *cb, void *cr, uint32_t strideC, uint32_t width,
                             uint32_t height, const uint8_t *bs_v, const uint8_t *bs_h, const uint8_t *qp, uint32_t qpStride,
                             int tcOffset, int betaOffset, int cbQpOffset, int crQpOffset);
+/* whole-picture SAO application (out of place); one parameter record per LCU, same field order as SaoParameters_t after
+ * the two merge flags (Codec/EbCodingUnit.h:137-146) plus the tile-edge flags ApplySaoOffsetsLcu reads */
+typedef struct SvtOracleSaoLcu {
+    uint8_t merge_left, merge_up, edge_flags /* 1 left, 2 right, 4 top, 8 bottom tile edge */, pad;
+    uint32_t type[2];
+    int32_t offset[3][4];
+    uint32_t band[3];
+} SvtOracleSaoLcu;
+void svt_oracle_sao_apply_picture(int bps, const void *const src[3], void *const dst[3], uint32_t strideY, uint32_t strideC,
+                                  uint32_t width, uint32_t height, const SvtOracleSaoLcu *lcus, int lumaOn, int chromaOn);
 void svt_oracle_GatherSaoStatistics(int bps, int only_eo_90_45_135, const void *input, uint32_t inputStride,
                                     const void *recon, uint32_t reconStride, uint32_t lcuWidth, uint32_t lcuHeight,
                                     int32_t *boDiff, uint16_t *boCount, int32_t eoDiff[4][5], uint16_t eoCount[4][5]);

@@ -284,3 +284,51 @@ void svt_oracle_dlf_picture(int bps, void *y, uint32_t strideY, void *cb, void *
             }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Picture-level SAO application: what ApplySaoOffsetsPicture(16bit) -> ApplySaoOffsetsLcu(16bit)
+ * (Codec/EbEncDecProcess.c:522-757, :215-517, 16-bit twins :762-1330) leave in the reconstructed picture.  The reference
+ * filters LCU by LCU in place, keeping the previous LCU's last column and the previous LCU row's last row aside so every
+ * sample is classified against UNFILTERED neighbours - i.e. an out-of-place filter, which is what this restates.
+ * Per LCU and component: type 1..4 = edge offset 0 / 90 / 135 / 45 degrees with offsets {o0, o1, 0, o2, o3} indexed by
+ * sign(c - a) + sign(c - b) + 2 (:263-270), type 5 = band offset for the 4 bands from saoBandPosition (:497-506);
+ * samples on a tile edge in the direction the class looks at keep their value (:283-318 etc.); clip to the bit depth.
+ * params: one record per LCU = {type[2] (luma, chroma), offset[3][4], band[3]}; edge_flags per LCU: 1 left, 2 right,
+ * 4 top, 8 bottom tile edge.  Pinned by tests/test_oracle_dlf_golden.py on whole pictures of real encoder runs.
+ * ------------------------------------------------------------------------------------------------------------------ */
+void svt_oracle_sao_apply_picture(int bps, const void *const src[3], void *const dst[3], uint32_t strideY, uint32_t strideC,
+                                  uint32_t width, uint32_t height, const SvtOracleSaoLcu *lcus, int lumaOn, int chromaOn)
+{
+    const int maxv = bps == 1 ? 255 : 1023, boShift = bps == 1 ? 3 : 5;
+    const uint32_t lcuCols = (width + 63) >> 6;
+    for (int comp = 0; comp < 3; comp++) {
+        const uint32_t sh = comp ? 1 : 0, W = width >> sh, H = height >> sh, stride = comp ? strideC : strideY, L = 64 >> sh;
+        const int on = comp ? chromaOn : lumaOn;
+        for (uint32_t y = 0; y < H; y++)
+            for (uint32_t x = 0; x < W; x++) {
+                const size_t i = (size_t)y * stride + x;
+                const int c = GET(src[comp], i);
+                const SvtOracleSaoLcu *p = &lcus[(y / L) * lcuCols + (x / L)];
+                const uint32_t type = on ? p->type[comp ? 1 : 0] : 0;
+                int v = c;
+                if (type == 5) {
+                    const int band = c >> boShift, pos = (int)p->band[comp];
+                    if (band >= pos && band <= pos + 3)
+                        v = clip3(0, maxv, c + (int8_t)p->offset[comp][band - pos]);
+                } else if (type >= 1 && type <= 4) {
+                    const uint32_t lx = x % L, ly = y % L, lw = (W - (x - lx)) < L ? (W - (x - lx)) : L, lh = (H - (y - ly)) < L ? (H - (y - ly)) : L;
+                    const int atL = lx == 0 && (p->edge_flags & 1), atR = lx == lw - 1 && (p->edge_flags & 2);
+                    const int atT = ly == 0 && (p->edge_flags & 4), atB = ly == lh - 1 && (p->edge_flags & 8);
+                    const int skip = type == 1 ? (atL || atR) : type == 2 ? (atT || atB) : (atL || atR || atT || atB);
+                    if (!skip) {
+                        const int dx = type == 2 ? 0 : (type == 4 ? 1 : -1), dy = type == 1 ? 0 : -1;
+                        const int a = GET(src[comp], i + (ptrdiff_t)dy * stride + dx), b = GET(src[comp], i - (ptrdiff_t)dy * stride - dx);
+                        const int8_t o[5] = {(int8_t)p->offset[comp][0], (int8_t)p->offset[comp][1], 0, (int8_t)p->offset[comp][2],
+                                             (int8_t)p->offset[comp][3]};
+                        v = clip3(0, maxv, c + o[sgn(c, a) + sgn(c, b) + 2]);
+                    }
+                }
+                PUT(dst[comp], i, v);
+            }
+    }
+}

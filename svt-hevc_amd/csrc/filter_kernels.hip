@@ -17,6 +17,7 @@
  */
 #include "leaf_util.h"
 #include <cstring>
+#include <type_traits>
 #include <cstdlib>
 
 __device__ __forceinline__ int f_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -319,6 +320,117 @@ __global__ void k_sao_apply(int kind /* 0..3 EO type, 4 BO */, const T *__restri
     }
 }
 
+/* ---------------- SAO apply, whole picture (out of place) ---------------- */
+/* ApplySaoOffsetsPicture(16bit) -> ApplySaoOffsetsLcu(16bit) (Codec/EbEncDecProcess.c:215-757, :762-1330): every sample is
+ * classified against the UNFILTERED neighbours (the reference keeps the previous LCU's last column / the previous LCU
+ * row's last row aside for exactly that), so src -> dst in one streaming pass.  One thread per 8 consecutive samples of
+ * a row (one 8- or 16-byte store); the three planes are three slices of one launch. */
+struct SaoLcuParams { uint8_t merge_left, merge_up, edge_flags, pad; uint32_t type[2]; int32_t offset[3][4]; uint32_t band[3]; }; /* = SvtAmdSaoLcuParams */
+struct SaoPic {
+    const void *src[3];
+    void *dst[3];
+    const SaoLcuParams *lcus;
+    int strideY, strideC, width, height, lcuCols, lumaOn, chromaOn;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void k_sao_apply_picture(const SaoPic P, uint32_t groupsY, uint32_t groupsC)
+{
+    constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, boShift = sizeof(T) == 1 ? 3 : 5;
+    typedef typename std::conditional<sizeof(T) == 1, uint2, uint4>::type V8; /* 8 samples */
+    const uint32_t total = groupsY + 2 * groupsC;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        const int comp = g < groupsY ? 0 : (g < groupsY + groupsC ? 1 : 2);
+        const uint32_t gi = comp == 0 ? g : (comp == 1 ? g - groupsY : g - groupsY - groupsC);
+        const int sh = comp ? 1 : 0, W = P.width >> sh, H = P.height >> sh, stride = comp ? P.strideC : P.strideY, L = 64 >> sh;
+        const int gpr = (W + 7) >> 3, y = (int)(gi / gpr), x0 = (int)(gi - (uint32_t)y * gpr) * 8;
+        const T *src = (const T *)P.src[comp];
+        T *dst = (T *)P.dst[comp];
+        const SaoLcuParams *p = P.lcus + (y / L) * P.lcuCols + (x0 / L);
+        const uint32_t type = (comp ? P.chromaOn : P.lumaOn) ? p->type[comp ? 1 : 0] : 0u;
+        const int n = W - x0 < 8 ? W - x0 : 8;
+        const T *row = src + (size_t)y * stride;
+        int c[10]; /* c[1..8] = the group, c[0] / c[9] = the samples left / right of it */
+        if (VEC && n == 8) {
+            const V8 v = *(const V8 *)(row + x0);
+            const uint32_t *w = (const uint32_t *)&v;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                c[k + 1] = sizeof(T) == 1 ? (int)((w[k >> 2] >> (8 * (k & 3))) & 255u) : (int)((w[k >> 1] >> (16 * (k & 1))) & 65535u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                c[k + 1] = k < n ? (int)row[x0 + k] : 0;
+        }
+        int out[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            out[k] = c[k + 1];
+        if (type == 5) {
+            const int pos = (int)p->band[comp];
+            const int o0 = (int8_t)p->offset[comp][0], o1 = (int8_t)p->offset[comp][1], o2 = (int8_t)p->offset[comp][2], o3 = (int8_t)p->offset[comp][3];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int b = (c[k + 1] >> boShift) - pos;
+                const int o = b == 0 ? o0 : b == 1 ? o1 : b == 2 ? o2 : b == 3 ? o3 : 0;
+                out[k] = f_clip3(0, maxv, c[k + 1] + o);
+            }
+        } else if (type >= 1 && type <= 4) {
+            const int lx0 = x0 % L, ly = y % L, lcuX = x0 - lx0, lcuY = y - ly;
+            const int lw = W - lcuX < L ? W - lcuX : L, lh = H - lcuY < L ? H - lcuY : L;
+            const int ef = p->edge_flags;
+            const bool rowSkip = type != 1 && ((ly == 0 && (ef & 4)) || (ly == lh - 1 && (ef & 8)));
+            const int o[5] = {(int8_t)p->offset[comp][0], (int8_t)p->offset[comp][1], 0, (int8_t)p->offset[comp][2], (int8_t)p->offset[comp][3]};
+            int a[8], b[8]; /* the two neighbours of every sample */
+            if (type == 1) {
+                c[0] = x0 > 0 ? (int)row[x0 - 1] : 0;
+                c[9] = x0 + 8 < W ? (int)row[x0 + 8] : 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    a[k] = c[k], b[k] = c[k + 2];
+            } else {
+                /* upper / lower rows at column offset -dx / +dx ... a = (y-1, x+dx), b = (y+1, x-dx) */
+                const int dx = type == 2 ? 0 : (type == 4 ? 1 : -1);
+                const T *up = y > 0 ? row - stride : row, *dn = y + 1 < H ? row + stride : row;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int xa = x0 + k + dx, xb = x0 + k - dx;
+                    a[k] = (xa >= 0 && xa < W) ? (int)up[xa] : 0;
+                    b[k] = (xb >= 0 && xb < W) ? (int)dn[xb] : 0;
+                }
+            }
+            if (!rowSkip) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int lx = lx0 + k;
+                    const bool colSkip = type != 2 && ((lx == 0 && (ef & 1)) || (lx == lw - 1 && (ef & 2)));
+                    if (!colSkip)
+                        out[k] = f_clip3(0, maxv, c[k + 1] + o[f_sgn(c[k + 1], a[k]) + f_sgn(c[k + 1], b[k]) + 2]);
+                }
+            }
+        }
+        T *drow = dst + (size_t)y * stride + x0;
+        if (VEC && n == 8) {
+            V8 v;
+            uint32_t *w = (uint32_t *)&v;
+            if (sizeof(T) == 1) {
+                w[0] = (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+                w[1] = (uint32_t)out[4] | ((uint32_t)out[5] << 8) | ((uint32_t)out[6] << 16) | ((uint32_t)out[7] << 24);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    w[k] = (uint32_t)out[2 * k] | ((uint32_t)out[2 * k + 1] << 16);
+            }
+            *(V8 *)drow = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < n)
+                    drow[k] = (T)out[k];
+        }
+    }
+}
+
 /* ---------------- pack / unpack (streaming) ---------------- */
 __global__ void k_pack(const uint8_t *__restrict__ in8, uint32_t in8Stride, const uint8_t *__restrict__ inn,
                        uint32_t innStride, uint16_t *__restrict__ out16, uint32_t outStride, uint32_t w, uint32_t h,
@@ -420,6 +532,42 @@ extern "C" int svt_amd_dlf_picture(SvtAmdContext *ctx, int bytes_per_sample, voi
             hipLaunchKernelGGL(k_dlf_picture<uint8_t>, grid1d(nL + nC), dim3(256), 0, ctx->stream, P, dir, lx, nL, cx ? cx : 1, nC);
         else
             hipLaunchKernelGGL(k_dlf_picture<uint16_t>, grid1d(nL + nC), dim3(256), 0, ctx->stream, P, dir, lx, nL, cx ? cx : 1, nC);
+    }
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_sao_apply_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *const d_src[3], void *const d_dst[3],
+                                         uint32_t strideY, uint32_t strideC, uint32_t width, uint32_t height,
+                                         const SvtAmdSaoLcuParams *d_lcus, int luma_on, int chroma_on)
+{
+    if (!ctx || !d_src || !d_dst || !d_lcus || (bytes_per_sample != 1 && bytes_per_sample != 2) || !width || !height ||
+        (width & 1) || (height & 1) || strideY < width || strideC < width / 2)
+        return SVT_AMD_ERR_BAD_PARAM;
+    for (int k = 0; k < 3; k++)
+        if (!d_src[k] || !d_dst[k] || d_src[k] == d_dst[k])
+            return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    SaoPic P;
+    bool vec = (strideY % 8) == 0 && (strideC % 8) == 0;
+    for (int k = 0; k < 3; k++) {
+        P.src[k] = d_src[k], P.dst[k] = d_dst[k];
+        vec = vec && ((uintptr_t)d_src[k] % (8 * bytes_per_sample)) == 0 && ((uintptr_t)d_dst[k] % (8 * bytes_per_sample)) == 0;
+    }
+    P.lcus = (const SaoLcuParams *)d_lcus;
+    P.strideY = (int)strideY, P.strideC = (int)strideC, P.width = (int)width, P.height = (int)height;
+    P.lcuCols = (int)((width + 63) >> 6), P.lumaOn = luma_on, P.chromaOn = chroma_on;
+    const uint32_t gy = ((width + 7) / 8) * height, gc = ((width / 2 + 7) / 8) * (height / 2);
+    const dim3 grid = grid1d(gy + 2 * gc);
+    if (bytes_per_sample == 1) {
+        if (vec)
+            hipLaunchKernelGGL((k_sao_apply_picture<uint8_t, true>), grid, dim3(256), 0, ctx->stream, P, gy, gc);
+        else
+            hipLaunchKernelGGL((k_sao_apply_picture<uint8_t, false>), grid, dim3(256), 0, ctx->stream, P, gy, gc);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((k_sao_apply_picture<uint16_t, true>), grid, dim3(256), 0, ctx->stream, P, gy, gc);
+        else
+            hipLaunchKernelGGL((k_sao_apply_picture<uint16_t, false>), grid, dim3(256), 0, ctx->stream, P, gy, gc);
     }
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
