@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Throughput of the batched EncDec leaf-family kernels at 1080p-picture-sized batches (needs the GPU).
+"""Throughput of the batched EncDec kernels at picture-sized batches (needs the GPU).
 For every kernel: algorithmic bytes (each operand read once, each result written once) / HIP-event time
--> GB/s and the fraction of the 8 TB/s HBM peak.  usage: python tools/leaf_bench.py [iters]"""
+-> GB/s and the fraction of the 8 TB/s HBM peak.  usage: python tools/leaf_bench.py [iters] [width height]"""
 import ctypes as C
 import json
 import os
@@ -22,10 +22,11 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     lib = S.load_product()
     ctx = C.c_void_p()
-    assert lib.svt_amd_context_create(0, 1920, 1088, 2, C.byref(ctx)) == 0
+    assert lib.svt_amd_context_create(0, 1920, 1088, 2, C.byref(ctx)) == 0  # the leaf kernels only need its stream
     dev = torch.device("cuda", 0)
-    W, H = 1920, 1080
+    W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
     npx = W * H
+    nlcu = ((W + 63) // 64) * ((H + 63) // 64)
     rows = []
 
     def timed(name, nbytes, fn):
@@ -81,16 +82,16 @@ def main():
     inn = torch.randint(0, 256, (H, W // 4), dtype=torch.uint8, device=dev, generator=g)
     p16 = torch.zeros((H, W), dtype=torch.int16, device=dev)
     o8, on = torch.zeros_like(in8), torch.zeros_like(in8)
-    timed("pack 8+2 bit (compressed) -> 16 bit, 1080p plane", npx * (1 + 0.25 + 2),
+    timed("pack 8+2 bit (compressed) -> 16 bit, plane", npx * (1 + 0.25 + 2),
           lambda: lib.svt_amd_pack_plane(ctx, in8.data_ptr(), W, inn.data_ptr(), W // 4, 1, p16.data_ptr(), W, W, H))
-    timed("unpack 16 bit -> 8 + 2 bit, 1080p plane", npx * (2 + 1 + 1),
+    timed("unpack 16 bit -> 8 + 2 bit, plane", npx * (2 + 1 + 1),
           lambda: lib.svt_amd_unpack_plane(ctx, p16.data_ptr(), W, o8.data_ptr(), W, on.data_ptr(), W, W, H))
     rec8 = (in8.to(torch.int16) + torch.randint(-6, 7, (H, W), dtype=torch.int16, device=dev, generator=g)).clamp(0, 255).to(torch.uint8)
-    stats = torch.zeros(510 * 312, dtype=torch.uint8, device=dev)
-    timed("SAO statistics, 510 LCUs (BO + 4 EO)", 2 * npx + 510 * 312,
+    stats = torch.zeros(nlcu * 312, dtype=torch.uint8, device=dev)
+    timed("SAO statistics, %d LCUs (BO + 4 EO)" % nlcu, 2 * npx + nlcu * 312,
           lambda: lib.svt_amd_sao_gather_picture(ctx, 1, in8.data_ptr(), W, rec8.data_ptr(), W, W, H, 64, 0, stats.data_ptr()))
 
-    # deblocking: all vertical 8x8-grid luma edges of a 1080p plane
+    # deblocking: all vertical 8x8-grid luma edges of a plane
     lib.svt_amd_dlf_luma_edges_batch.argtypes = [vp, vp, u32, C.c_int, vp, u32]
     ys, xs = np.meshgrid(np.arange(0, H - 3, 4), np.arange(8, W, 8), indexing="ij")
     e = np.zeros(ys.size, dtype=np.dtype([("offset", "<i4"), ("tc", "<i2"), ("beta", "<i2"), ("v", "u1"), ("pad", "u1", 3)]))
@@ -99,6 +100,30 @@ def main():
     plane = in8.clone()
     timed("deblock luma, %d vertical 4-sample edges" % len(e), len(e) * (2 * 32 + 12),
           lambda: lib.svt_amd_dlf_luma_edges_batch(ctx, plane.data_ptr(), W, 1, d_e.data_ptr(), len(e)))
+
+    # whole-picture deblocking (both passes, luma + chroma) and SAO application, 4:2:0
+    lib.svt_amd_dlf_picture.argtypes = [vp, C.c_int, vp, u32, vp, vp, u32, u32, u32, vp, vp, vp, u32, i32, i32, i32, i32]
+    lib.svt_amd_sao_apply_picture.argtypes = [vp, C.c_int, vp, vp, u32, u32, u32, u32, vp, C.c_int, C.c_int]
+    for bps in (1, 2):
+        tdt = torch.uint8 if bps == 1 else torch.int16
+        hi = 256 if bps == 1 else 1024
+        pl = [torch.randint(0, hi, (H >> s, W >> s), dtype=tdt, device=dev, generator=g) for s in (0, 1, 1)]
+        out = [torch.zeros_like(t) for t in pl]
+        bs = [torch.randint(0, 3, (nlcu, 256), dtype=torch.uint8, device=dev, generator=g) for _ in range(2)]
+        qpa = torch.randint(20, 45, ((H // 8) * (W // 8),), dtype=torch.uint8, device=dev, generator=g)
+        timed("deblock picture %d-bit (V + H pass, luma + chroma, random strengths)" % (8 if bps == 1 else 10),
+              2 * 2 * 1.5 * npx * bps + 2 * nlcu * 512,
+              lambda: lib.svt_amd_dlf_picture(ctx, bps, pl[0].data_ptr(), W, pl[1].data_ptr(), pl[2].data_ptr(), W // 2, W, H,
+                                              bs[0].data_ptr(), bs[1].data_ptr(), qpa.data_ptr(), W // 8, 0, 0, 0, 0))
+        ldt = np.dtype([("ml", "u1"), ("mu", "u1"), ("ef", "u1"), ("pad", "u1"), ("type", "<u4", 2), ("offset", "<i4", (3, 4)),
+                        ("band", "<u4", 3)])
+        lc = np.zeros(nlcu, ldt)
+        r2 = np.random.default_rng(3)
+        lc["type"], lc["offset"], lc["band"] = r2.integers(1, 6, (nlcu, 2)), r2.integers(-7, 8, (nlcu, 3, 4)), r2.integers(0, 29, (nlcu, 3))
+        d_lc = torch.from_numpy(lc.view(np.uint8)).to(dev)
+        ps, pd = (vp * 3)(*[t.data_ptr() for t in pl]), (vp * 3)(*[t.data_ptr() for t in out])
+        timed("SAO apply picture %d-bit (all LCUs on, random types)" % (8 if bps == 1 else 10), 2 * 1.5 * npx * bps + nlcu * 76,
+              lambda: lib.svt_amd_sao_apply_picture(ctx, bps, ps, pd, W, W // 2, W, H, d_lc.data_ptr(), 1, 1))
 
     # HEVC motion compensation: a 1080p luma plane as 16x16 PUs with random quarter-pel vectors
     lib.svt_amd_mcp_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp, u32, vp, u32]
@@ -119,7 +144,7 @@ def main():
     timed("MCP luma uni-pred, %d 16x16 PUs, random 1/4-pel MVs" % len(blocks), 2 * npx,
           lambda: lib.svt_amd_mcp_batch(ctx, 1, 0, 0, refp.data_ptr(), st, pred.data_ptr(), W, d_b.data_ptr(), len(blocks)))
 
-    # coefficient rate estimation: every 8x8 / 32x32 TU of a 1080p plane, ~10 % non-zero coefficients
+    # coefficient rate estimation: every 8x8 / 32x32 TU of a plane, ~10 % non-zero coefficients
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_rate import TU_INFO, synthetic_cost
     lib.svt_amd_coeff_bits_batch.argtypes = [vp, vp, u32, vp, vp, vp, u32]
@@ -136,7 +161,34 @@ def main():
         timed("coeff rate estimation %dx%d (%d TUs)" % (size, size, nb), 2 * nb * size * size + 16 * nb,
               lambda: lib.svt_amd_coeff_bits_batch(ctx, cost.ctypes.data, size, q16.data_ptr(), d_i.data_ptr(), bits.data_ptr(), nb))
 
-    print(json.dumps({"iters": iters, "peak_GBs": PEAK, "kernels": rows}, indent=1))
+    # fused mode-decision full loops: one candidate per 32x32 / 16x16 CU of the picture
+    from test_oracle_fullloop_golden import FullLoopIn, FullLoopOut
+    from test_oracle_chromaloop_golden import ChromaLoopIn, ChromaLoopOut
+    lib.svt_amd_full_loop_luma_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32]
+    lib.svt_amd_full_loop_chroma_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32]
+    for size in (32, 16):
+        nc = npx // (size * size)
+        fin = np.zeros(nc, np.dtype(FullLoopIn))
+        fin["size"], fin["qp"], fin["slice_type"], fin["cand_type"], fin["full_lambda"] = size, 32, 1, 1, 200000
+        fin["cbf_bits"] = (20000, 30000, 40000, 20000)
+        d_fin = torch.from_numpy(fin.view(np.uint8)).to(dev)
+        resid = torch.randint(-20, 21, (nc, 4096), dtype=torch.int16, device=dev, generator=g)
+        qo, ro = torch.zeros_like(resid), torch.zeros_like(resid)
+        fout = torch.zeros(nc * C.sizeof(FullLoopOut), dtype=torch.uint8, device=dev)
+        timed("full loop luma %dx%d (%d candidates: DCT+quant+dist+rate+cost)" % (size, size, nc), nc * (6 * size * size + 72 + 64),
+              lambda: lib.svt_amd_full_loop_luma_batch(ctx, cost.ctypes.data, d_fin.data_ptr(), resid.data_ptr(), qo.data_ptr(),
+                                                       ro.data_ptr(), fout.data_ptr(), nc))
+        cin = np.zeros(nc, np.dtype(ChromaLoopIn))
+        cin["size"], cin["cb_qp"], cin["cr_qp"], cin["slice_type"], cin["cand_type"] = size, 31, 31, 1, 1
+        d_cin = torch.from_numpy(cin.view(np.uint8)).to(dev)
+        cres = torch.randint(-20, 21, (nc, 2048), dtype=torch.int16, device=dev, generator=g)
+        cq, cr_ = torch.zeros_like(cres), torch.zeros_like(cres)
+        cout = torch.zeros(nc * C.sizeof(ChromaLoopOut), dtype=torch.uint8, device=dev)
+        timed("full loop chroma of %dx%d CUs (%d candidates, Cb + Cr)" % (size, size, nc), nc * (6 * size * size // 2 + 32 + 96),
+              lambda: lib.svt_amd_full_loop_chroma_batch(ctx, cost.ctypes.data, d_cin.data_ptr(), cres.data_ptr(), cq.data_ptr(),
+                                                         cr_.data_ptr(), cout.data_ptr(), nc))
+
+    print(json.dumps({"iters": iters, "width": W, "height": H, "peak_GBs": PEAK, "kernels": rows}, indent=1))
     lib.svt_amd_context_destroy(ctx)
 
 
