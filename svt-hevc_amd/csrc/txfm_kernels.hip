@@ -20,22 +20,45 @@
 #include "svt_amd_internal.h"
 #include "txfm_device.h"
 
+/* Forward DCT, register-resident: lane = one row of one N x N block, 64 / N blocks per wave, 4 waves per workgroup.
+ * HBM: every residual row is one contiguous N*2-byte run per lane; results leave as one 2-byte store per lane and
+ * output row (a wave covers 128 contiguous bytes).  LDS only carries the transpose between the two passes. */
 template <int N>
 __global__ __launch_bounds__(TX_THREADS) void k_fwd_dct(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
                                                        uint32_t nblocks, int shift1, int shift2, int wrap_levels)
 {
-    __shared__ TxShared<N> S;
-    constexpr int GB = TxShared<N>::GB;
-    const int t = threadIdx.x;
-    const uint32_t b0 = blockIdx.x * GB;
-    const int nvalid = (int)min((uint32_t)GB, nblocks - b0);
-    for (int i = t; i < 32 * 32; i += TX_THREADS)
-        (&S.T[0][0])[i] = (&c_T32[0][0])[i];
-    for (int i = t; i < GB * N * N; i += TX_THREADS)
-        (&S.io[0][0])[i] = (i < nvalid * N * N) ? src[(size_t)b0 * N * N + i] : (int16_t)0;
-    __syncthreads();
-    fwd_pass<N, false>(S, shift1, wrap_levels, nullptr, nvalid, t);
-    fwd_pass<N, true>(S, shift2, wrap_levels, dst + (size_t)b0 * N * N, nvalid, t);
+    constexpr int UPW = 64 / N, UPB = UPW * (TX_THREADS / 64); /* units per wave / per workgroup */
+    __shared__ int16_t tiles[UPB * TxRegTile<N>::UNIT];
+    const int t = threadIdx.x, u = t / N, r = t - u * N;
+    const uint32_t b = blockIdx.x * UPB + u;
+    int x[N];
+    if (b < nblocks) {
+        const int16_t *row = src + (size_t)b * N * N + r * N;
+        if (N >= 8) {
+#pragma unroll
+            for (int j = 0; j < N; j += 8) {
+                const uint4 v = *(const uint4 *)(row + j);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    x[j + 2 * k] = (int16_t)(w[k] & 0xffffu), x[j + 2 * k + 1] = (int16_t)(w[k] >> 16);
+            }
+        } else {
+            const uint2 v = *(const uint2 *)row;
+            x[0] = (int16_t)(v.x & 0xffffu), x[1] = (int16_t)(v.x >> 16), x[2] = (int16_t)(v.y & 0xffffu), x[3] = (int16_t)(v.y >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            x[j] = 0;
+    }
+    fwd_2d_regs<N>(x, tiles + u * TxRegTile<N>::UNIT, r, shift1, shift2, wrap_levels);
+    if (b < nblocks) {
+        int16_t *out = dst + (size_t)b * N * N + r;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            out[j * N] = (int16_t)x[j];
+    }
 }
 
 /* 4x4 DST (Dst4 / DstInverse4): one thread per row, 64 blocks per workgroup */
@@ -372,13 +395,13 @@ int svt_amd_launch_fwd_transform(hipStream_t st, int kind, int size, uint32_t in
     if (kind == 2)
         hipLaunchKernelGGL(k_dst4, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, 0);
     else if (size == 32)
-        hipLaunchKernelGGL(k_fwd_dct<32>, dim3(n), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<32>, dim3((n + 7) / 8), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
     else if (size == 16)
-        hipLaunchKernelGGL(k_fwd_dct<16>, dim3(n), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<16>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
     else if (size == 8)
-        hipLaunchKernelGGL(k_fwd_dct<8>, dim3((n + 3) / 4), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<8>, dim3((n + 31) / 32), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
     else
-        hipLaunchKernelGGL(k_fwd_dct<4>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<4>, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
