@@ -3,9 +3,10 @@
  *
  * Replaces ProductFullLoop (Codec/EbFullLoop.c:185-446) and the pair FullLoop_R + CuFullDistortionFastTuMode_R (:579-1066)
  * for the presets' common configuration (no RDOQ / PM-core, coefficient-domain distortion, no CABAC-context update).
- * A workgroup owns GB transform units at a time: one 32x32 or 16x16 (four waves), four 8x8 (one wave: four luma
- * candidates, or Cb + Cr of two), sixteen 4x4 (one wave: Cb + Cr of eight candidates); a 64x64 CU walks its four units
- * one after the other.  Everything between the residual and the cost decision
+ * One wave owns 64 / N transform units at a time, each on N lanes of its own: lane r holds row r of the residual through the
+ * first transform pass and column r of the coefficient block from the second pass on (txfm_device.h, register-resident
+ * transform: the matrix is immediates, LDS only carries the transpose); a 64x64 CU walks its four units one after the
+ * other.  Everything between the residual and the cost decision
  * stays on chip:
  *   residual -> LDS -> forward "Estimate" DCT (two passes in LDS, txfm_device.h)
  *            -> quantise / inverse-quantise the (T >> pf) area, count non-zeros, coefficient-domain distortions
@@ -17,33 +18,17 @@
 #include "rate_device.h"
 #include <cstring>
 
-/* one transform unit in flight */
-struct FlSlot {
-    int active;            /* candidate exists and has this launch's transform size */
-    uint32_t cand, plane;  /* candidate index; 0 luma / Cb, 1 Cr */
+/* Per-unit parameters, held by every lane of the unit (lane r of the unit = row r of the residual in the first transform
+ * pass, column r of the coefficient block afterwards). */
+struct FlUnit {
+    int active;            /* candidate exists, has this launch's transform size and still has units left */
     uint32_t base, pitch;  /* sample offset of the unit's (0,0) in the residual / quant / recon arrays, row pitch */
     int area, lg;          /* quantised area (T >> pf) and its log2 */
     uint32_t QF, q_offset;
     int shiftedQBits, shiftedFFunc, iq_offset, shiftNum;
-    int cand_type, intra_luma_mode;
 };
 
-template <int N, int G>
-struct FlShared {
-    static constexpr int GB = G;
-    int16_t q[GB][N * N];          /* quantised coefficients of the units in flight, row pitch N */
-    unsigned nz[GB], res[GB], pred[GB], bits[GB];
-    FlSlot slot[GB];
-    /* running results of the slot's candidate (plane), kept here rather than in registers of every thread */
-    struct Acc {
-        unsigned long long bits, d0, d1;
-        uint32_t cbf, nzs[5];
-        int16_t ydc[4];
-        uint16_t cand_nz[4];
-    } acc[GB];
-};
-
-__device__ __forceinline__ void fl_quant_params(FlSlot &S, uint32_t qp, uint32_t slice_type, int LG)
+__device__ __forceinline__ void fl_quant_params(FlUnit &S, uint32_t qp, uint32_t slice_type, int LG)
 {
     /* ProductUnifiedQuantizeInvQuantizeMd (EbFullLoop.c:98-113) = UnifiedQuantizeInvQuantize_R (:483-497) at bit depth 8 */
     const int qpRem = (int)(qp % 6), qpPer = (int)(qp / 6);
@@ -57,241 +42,210 @@ __device__ __forceinline__ void fl_quant_params(FlSlot &S, uint32_t qp, uint32_t
     S.iq_offset = 1 << (S.shiftNum - 1);
 }
 
-/* N: transform size of this launch.  CHROMA 0: SvtAmdFullLoopIn/Out, residual slab 4096 samples per candidate;
- * CHROMA 1: SvtAmdChromaLoopIn/Out, slab 2048 (Cb then Cr).  Workgroup b serves the candidates
- * [b*CPW, (b+1)*CPW) (CPW = candidates per workgroup); for the one-unit-at-a-time sizes of the chroma loop
- * blockIdx.y is the plane. */
-template <int N, bool CHROMA, int NT, int GB>
-__global__ __launch_bounds__(NT) void k_full_loop(const void *__restrict__ in_all, const int16_t *__restrict__ residual,
+/* N: transform size of this launch.  CHROMA 0: SvtAmdFullLoopIn/Out, residual slab 4096 samples per candidate, one unit
+ * sequence per candidate; CHROMA 1: SvtAmdChromaLoopIn/Out, slab 2048 (Cb then Cr), one unit sequence per (candidate,
+ * plane).  One wave per workgroup; the wave's 64 / N unit sequences run side by side, each on its own N lanes; a
+ * 64x64 CU's sequence has four units (all others one).  No workgroup barrier anywhere: a unit never leaves its wave. */
+template <int N, bool CHROMA>
+__global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_all, const int16_t *__restrict__ residual,
                                                   int16_t *__restrict__ quant, int16_t *__restrict__ recon,
                                                   void *__restrict__ out_all, uint32_t ncand, int shift1, int shift2,
                                                   int wrap_levels)
 {
+    constexpr int UPW = 64 / N; /* unit sequences per wave */
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
-    constexpr int PLANES = CHROMA ? 2 : 1;
-    constexpr int CPW = GB >= PLANES ? GB / PLANES : 1; /* candidates per workgroup */
-    __shared__ TxShared<N, GB> X;
-    __shared__ FlShared<N, GB> F;
-    const int t = threadIdx.x;
-    /* lane s owns slot s; with one unit in flight every thread mirrors slot 0 */
-    int my_size = 0, my_active = 0;
-    uint32_t my_cand = 0, my_plane = 0;
-    if (CPW == 1 || t < GB) { /* one candidate per workgroup: every thread mirrors it (slot t % GB) */
-        const int s = t % GB;
-        my_cand = blockIdx.x * CPW + (uint32_t)s / PLANES;
-        my_plane = GB >= PLANES ? (uint32_t)s % PLANES : blockIdx.y;
-        if (my_cand < ncand) {
-            if (CHROMA) {
-                const SvtAmdChromaLoopIn *in = (const SvtAmdChromaLoopIn *)in_all + my_cand;
-                my_size = (int)in->size;
-                my_active = (my_size == 64 ? 16 : my_size >> 1) == N;
-            } else {
-                const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + my_cand;
-                my_size = (int)in->size;
-                my_active = (my_size == 64 ? 32 : my_size) == N;
+    __shared__ int16_t tiles[UPW * TxRegTile<N>::UNIT];
+    __shared__ int16_t Fq[UPW][N * N]; /* quantised coefficients of the units in flight, row pitch N */
+    __shared__ uint32_t Fbits[UPW];
+    const int t = threadIdx.x, u = t / N, r = t - u * N;
+    const uint32_t seq = blockIdx.x * UPW + u;
+    const uint32_t cand = CHROMA ? seq >> 1 : seq, plane = CHROMA ? seq & 1 : 0;
+
+    int size = 0, ntu = 0, cand_type = 0, intra_luma_mode = 0;
+    uint32_t pf = 0, qp = 0, slice = 0;
+    if (cand < ncand) {
+        if (CHROMA) {
+            const SvtAmdChromaLoopIn *in = (const SvtAmdChromaLoopIn *)in_all + cand;
+            size = (int)in->size;
+            if ((size == 64 ? 16 : size >> 1) == N) {
+                ntu = size == 64 ? 4 : 1;
+                /* correctedPFMode (EbFullLoop.c:647-652): 4x4 never, 8x8 at most N2 */
+                pf = N == 4 ? 0u : (N == 8 && in->pf_mode == 2 ? 1u : in->pf_mode);
+                qp = plane ? in->cr_qp : in->cb_qp, slice = in->slice_type;
+                cand_type = (int)in->cand_type, intra_luma_mode = (int)in->intra_luma_mode;
+            }
+        } else {
+            const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + cand;
+            size = (int)in->size;
+            if ((size == 64 ? 32 : size) == N) {
+                ntu = size == 64 ? 4 : 1;
+                pf = in->pf_mode, qp = in->qp, slice = in->slice_type;
+                cand_type = (int)in->cand_type, intra_luma_mode = (int)in->intra_luma_mode;
             }
         }
     }
-    /* this launch serves one transform size: leave at once when none of the workgroup's candidates has it
-     * (uniform without a barrier: one unit -> every thread looked at the same candidate; several -> a single wave) */
-    if (CPW == 1) {
-        if (!my_active)
-            return;
-    } else if (NT == 64) {
-        if (!__ballot(my_active))
-            return;
-    } else { /* several units, several waves: agree through LDS */
-        __shared__ int s_any;
-        if (t == 0)
-            s_any = 0;
-        __syncthreads();
-        if (my_active)
-            s_any = 1;
-        __syncthreads();
-        if (!s_any)
-            return;
-    }
-    /* a 64x64 CU has four units; only the one-unit-at-a-time sizes can meet one */
-    const int ntu = (CPW == 1 && my_size == 64) ? 4 : 1;
-    for (int i = t; i < 32 * 32; i += NT)
-        (&X.T[0][0])[i] = (&c_T32[0][0])[i];
-    if (t < GB) {
-        typename FlShared<N, GB>::Acc a;
-        a.bits = 0, a.d0 = 0, a.d1 = 0, a.cbf = 0;
-        for (int k = 0; k < 5; k++)
-            a.nzs[k] = 0;
-        for (int k = 0; k < 4; k++)
-            a.ydc[k] = 0, a.cand_nz[k] = 0;
-        if (!CHROMA && my_active) {
-            const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + my_cand;
-            a.cbf = in->ycbf, a.bits = in->coeff_bits;
-            a.d0 = my_size == 64 ? in->dist[0] : 0, a.d1 = my_size == 64 ? in->dist[1] : 0;
-        }
-        F.acc[t] = a;
+    /* this launch serves one transform size: a wave none of whose candidates has it leaves at once */
+    if (!__ballot(ntu != 0))
+        return;
+    int ntu_max = ntu;
+    for (int o = 32; o > 0; o >>= 1)
+        ntu_max = max(ntu_max, __shfl_xor(ntu_max, o));
+
+    /* running results of the sequence (meaningful in lane 0 of the unit) */
+    uint32_t cbf = 0, nzs[5] = {0, 0, 0, 0, 0};
+    unsigned long long bits_acc = 0, d0_acc = 0, d1_acc = 0;
+    int16_t ydc[4] = {0, 0, 0, 0};
+    uint16_t cand_nz[4] = {0, 0, 0, 0};
+    uint32_t cbf_bits0 = 0, cbf_bits1 = 0, full_lambda = 0;
+    if (!CHROMA && ntu) {
+        const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + cand;
+        cbf = in->ycbf, bits_acc = in->coeff_bits;
+        d0_acc = size == 64 ? in->dist[0] : 0, d1_acc = size == 64 ? in->dist[1] : 0;
+        const int ctx = size == N;
+        cbf_bits0 = in->cbf_bits[ctx], cbf_bits1 = in->cbf_bits[2 + ctx], full_lambda = in->full_lambda;
     }
 
-    for (int tu = 0; tu < ntu; tu++) {
-        if (t < GB) {
-            FlSlot S;
-            S.active = my_active, S.cand = my_cand, S.plane = my_plane;
-            S.area = N, S.lg = LG, S.base = 0, S.pitch = N, S.cand_type = 0, S.intra_luma_mode = 0;
-            S.QF = 0, S.q_offset = 0, S.shiftedQBits = 0, S.shiftedFFunc = 0, S.iq_offset = 1, S.shiftNum = 1;
-            if (my_active) {
-                uint32_t pf, qp, slice;
-                if (CHROMA) {
-                    const SvtAmdChromaLoopIn *in = (const SvtAmdChromaLoopIn *)in_all + my_cand;
-                    /* correctedPFMode (EbFullLoop.c:647-652): 4x4 never, 8x8 at most N2 */
-                    pf = N == 4 ? 0u : (N == 8 && in->pf_mode == 2 ? 1u : in->pf_mode);
-                    qp = my_plane ? in->cr_qp : in->cb_qp, slice = in->slice_type;
-                    S.cand_type = (int)in->cand_type, S.intra_luma_mode = (int)in->intra_luma_mode;
-                    S.pitch = (uint32_t)my_size >> 1;
-                    S.base = my_cand * 2048u + my_plane * 1024u + (my_size == 64 ? ((tu & 1) << 4) + (tu > 1 ? 16 * 32 : 0) : 0);
-                } else {
-                    const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + my_cand;
-                    pf = in->pf_mode, qp = in->qp, slice = in->slice_type;
-                    S.cand_type = (int)in->cand_type, S.intra_luma_mode = (int)in->intra_luma_mode;
-                    S.pitch = (uint32_t)my_size;
-                    S.base = my_cand * 4096u + (my_size == 64 ? ((tu & 1) << 5) + (tu > 1 ? 32 * 64 : 0) : 0);
+    FlUnit S;
+    S.area = N >> pf, S.lg = LG - (int)pf;
+    S.pitch = CHROMA ? (uint32_t)size >> 1 : (uint32_t)size;
+    fl_quant_params(S, qp, slice, LG);
+    int16_t *tile = tiles + u * TxRegTile<N>::UNIT;
+
+    for (int tu = 0; tu < ntu_max; tu++) {
+        S.active = tu < ntu;
+        if (CHROMA)
+            S.base = cand * 2048u + plane * 1024u + (size == 64 ? ((tu & 1) << 4) + (tu > 1 ? 16 * 32 : 0) : 0);
+        else
+            S.base = cand * 4096u + (size == 64 ? ((tu & 1) << 5) + (tu > 1 ? 32 * 64 : 0) : 0);
+        /* residual row r -> registers */
+        int x[N];
+        if (S.active) {
+            const int16_t *row = residual + S.base + (size_t)r * S.pitch;
+            if (N >= 8) {
+#pragma unroll
+                for (int j = 0; j < N; j += 8) {
+                    const uint4 v = *(const uint4 *)(row + j);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        x[j + 2 * k] = (int16_t)(w[k] & 0xffffu), x[j + 2 * k + 1] = (int16_t)(w[k] >> 16);
                 }
-                S.area = N >> pf, S.lg = LG - (int)pf;
-                fl_quant_params(S, qp, slice, LG);
-            }
-            F.slot[t] = S;
-            F.nz[t] = 0, F.res[t] = 0, F.pred[t] = 0, F.bits[t] = 0;
-        }
-        __syncthreads();
-        for (int i = t; i < GB * N * N; i += NT) {
-            const int s = i / (N * N), e = i - s * (N * N);
-            const FlSlot &S = F.slot[s];
-            (&X.io[0][0])[i] = S.active ? residual[S.base + (e / N) * S.pitch + (e % N)] : (int16_t)0;
-        }
-        __syncthreads();
-        fwd_pass<N, false, NT, GB>(X, shift1, wrap_levels, nullptr, GB, t);
-        fwd_pass<N, false, NT, GB>(X, shift2, wrap_levels, nullptr, GB, t);
-        /* QuantizeInvQuantize (C_DEFAULT/EbTransforms_C.c:89) over the area + the two coefficient-domain sums */
-        unsigned nz1 = 0, res1 = 0, pred1 = 0;
-        for (int i = t; i < GB * N * N; i += NT) {
-            const int s = i / (N * N), e = i - s * (N * N), r = e / N, c = e - r * N;
-            const FlSlot &S = F.slot[s];
-            if (!S.active || r >= S.area || c >= S.area)
-                continue;
-            const int v = X.io[s][e], sign = v < 0 ? -1 : 1;
-            int tq = abs(v);
-            tq = (int)((uint32_t)tq * S.QF);
-            tq = (int)((uint32_t)tq + S.q_offset);
-            tq >>= S.shiftedQBits;
-            const int qv = clip16i(sign * tq);
-            const int rv = clip16i(((qv * S.shiftedFFunc) + S.iq_offset) >> S.shiftNum);
-            F.q[s][e] = (int16_t)qv;
-            quant[S.base + r * S.pitch + c] = (int16_t)qv;
-            recon[S.base + r * S.pitch + c] = (int16_t)rv;
-            const int16_t d = (int16_t)(v - rv);
-            if (GB == 1) {
-                nz1 += qv != 0, res1 += (unsigned)(d * d), pred1 += (unsigned)(v * v);
             } else {
-                if (qv)
-                    atomicAdd(&F.nz[s], 1u);
-                atomicAdd(&F.res[s], (unsigned)(d * d));
-                atomicAdd(&F.pred[s], (unsigned)(v * v));
+                const uint2 v = *(const uint2 *)row;
+                x[0] = (int16_t)(v.x & 0xffffu), x[1] = (int16_t)(v.x >> 16), x[2] = (int16_t)(v.y & 0xffffu), x[3] = (int16_t)(v.y >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                x[j] = 0;
+        }
+        /* EstimateTransform: both passes in registers; afterwards x[j] = coefficient (j, r) */
+        fwd_2d_regs<N>(x, tile, r, shift1, shift2, wrap_levels);
+        /* QuantizeInvQuantize (C_DEFAULT/EbTransforms_C.c:89) over the area + the two coefficient-domain sums */
+        unsigned nz = 0, res = 0, pred = 0;
+        if (S.active && r < S.area) {
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if (j < S.area) {
+                    const int v = x[j], sign = v < 0 ? -1 : 1;
+                    int tq = abs(v);
+                    tq = (int)((uint32_t)tq * S.QF);
+                    tq = (int)((uint32_t)tq + S.q_offset);
+                    tq >>= S.shiftedQBits;
+                    const int qv = clip16i(sign * tq);
+                    const int rv = clip16i(((qv * S.shiftedFFunc) + S.iq_offset) >> S.shiftNum);
+                    Fq[u][j * N + r] = (int16_t)qv;
+                    quant[S.base + j * S.pitch + r] = (int16_t)qv;
+                    recon[S.base + j * S.pitch + r] = (int16_t)rv;
+                    const int16_t d = (int16_t)(v - rv);
+                    nz += qv != 0, res += (unsigned)(d * d), pred += (unsigned)(v * v);
+                }
             }
         }
-        if (GB == 1) { /* one unit: reduce inside the wave first */
-            for (int o = 32; o > 0; o >>= 1)
-                nz1 += __shfl_xor(nz1, o), res1 += __shfl_xor(res1, o), pred1 += __shfl_xor(pred1, o);
-            if ((t & 63) == 0) {
-                atomicAdd(&F.nz[0], nz1);
-                atomicAdd(&F.res[0], res1);
-                atomicAdd(&F.pred[0], pred1);
-            }
-        }
-        __syncthreads();
-        /* TuEstimateCoeffBitsLuma / TuEstimateCoeffBits_R: one lane per 4x4 sub-block; units of equal area together */
+#pragma unroll
+        for (int o = 1; o < N; o <<= 1)
+            nz += __shfl_xor(nz, o), res += __shfl_xor(res, o), pred += __shfl_xor(pred, o);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* TuEstimateCoeffBitsLuma / TuEstimateCoeffBits_R: one lane per 4x4 sub-block; units of equal area together,
+         * as many per call as the wave holds */
+        if (r == 0)
+            Fbits[u] = 0;
 #pragma unroll 1
-        for (int pfv = 0; pfv < ((N == 4 || GB == 1) ? 1 : 3) && t < 64; pfv++) { /* wave 0 */
-            const int lg = GB == 1 ? __builtin_amdgcn_readfirstlane(F.slot[0].lg) : LG - pfv;
+        for (int pfv = 0; pfv < (N == 4 ? 1 : 3); pfv++) {
+            const int lg = LG - pfv;
             if (lg < 2)
                 break;
-            const int S4 = lg == 2 ? 1 : 1 << (2 * (lg - 2));
-            const int s = t / S4, sub = t - s * S4;
-            bool live = s < GB;
-            SvtAmdTuInfo ti = {0, 0, 0, 4 /* EB_INTRA_CHROMA_DM */, 0};
-            const int16_t *p0 = &F.q[0][0];
-            if (GB == 1) {
-                /* one unit: everything about it is wave-uniform - keep it in scalar registers */
-                const FlSlot &S = F.slot[0];
-                const int act = __builtin_amdgcn_readfirstlane(S.active && S.lg == lg && F.nz[0] != 0);
-                live = live && act;
-                ti.num_nonzero = (uint32_t)__builtin_amdgcn_readfirstlane((int)F.nz[0]);
-                ti.type = (uint8_t)__builtin_amdgcn_readfirstlane(S.cand_type);
-                ti.intra_luma_mode = (uint8_t)__builtin_amdgcn_readfirstlane(S.intra_luma_mode);
-                ti.component = CHROMA ? (uint8_t)(__builtin_amdgcn_readfirstlane((int)S.plane) + 1) : (uint8_t)0;
-            } else if (live) {
-                const FlSlot &S = F.slot[s];
-                live = S.active && S.lg == lg && F.nz[s] != 0;
-                if (live) {
-                    ti.num_nonzero = F.nz[s], ti.type = (uint8_t)S.cand_type, ti.intra_luma_mode = (uint8_t)S.intra_luma_mode;
-                    ti.component = CHROMA ? (uint8_t)(S.plane + 1) : (uint8_t)0;
-                    p0 = &F.q[s][0];
-                }
-            }
-            if (!__ballot(live))
+            if (!__ballot(S.active && S.lg == lg && nz != 0))
                 continue;
-            const uint32_t b = coeff_bits_lanes(p0, N, lg, ti, live, t, sub);
-            if (live && sub == 0)
-                F.bits[s] = b;
+            const int S4 = lg == 2 ? 1 : 1 << (2 * (lg - 2));
+            const int per_call = 64 / S4 < UPW ? 64 / S4 : UPW;
+#pragma unroll 1
+            for (int c0 = 0; c0 < UPW; c0 += per_call) {
+                const int uu = c0 + t / S4, sub = t % S4;
+                const int src_lane = (uu < UPW ? uu : 0) * N; /* lane 0 of that unit holds its facts */
+                const int u_ok = __shfl(S.active && S.lg == lg && nz != 0, src_lane);
+                const uint32_t u_nz = (uint32_t)__shfl((int)nz, src_lane);
+                const int u_type = __shfl(cand_type, src_lane), u_mode = __shfl(intra_luma_mode, src_lane);
+                const int u_plane = __shfl((int)plane, src_lane);
+                const bool live = uu < c0 + per_call && uu < UPW && u_ok;
+                if (!__ballot(live))
+                    continue;
+                SvtAmdTuInfo ti = {live ? u_nz : 0u, (uint8_t)u_type, (uint8_t)u_mode, 4 /* EB_INTRA_CHROMA_DM */,
+                                   CHROMA ? (uint8_t)(u_plane + 1) : (uint8_t)0};
+                const uint32_t b = coeff_bits_lanes(&Fq[uu < UPW ? uu : 0][0], N, lg, ti, live, t, sub);
+                if (live && sub == 0)
+                    Fbits[uu] = b;
+            }
         }
-        __syncthreads();
-        if (t < GB && my_active) {
-            const FlSlot &S = F.slot[t];
-            const unsigned tnz = F.nz[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r == 0 && S.active) {
             /* PictureFullDistortionLuma / _R table [nz != 0][intra] + the scaling of the caller */
-            const int mode = tnz == 0 ? 1 : (S.cand_type == 2 ? 2 : 0);
-            unsigned long long d0 = mode == 1 ? F.pred[t] : F.res[t], d1 = mode == 2 ? F.res[t] : F.pred[t];
-            const int dshift = (!CHROMA && my_size == 64) ? 4 : 2 * (7 - LG);
+            const int mode = nz == 0 ? 1 : (cand_type == 2 ? 2 : 0);
+            unsigned long long d0 = mode == 1 ? pred : res, d1 = mode == 2 ? res : pred;
+            const int dshift = (!CHROMA && size == 64) ? 4 : 2 * (7 - LG);
             d0 = (d0 + (1ull << (dshift - 1))) >> dshift;
             d1 = (d1 + (1ull << (dshift - 1))) >> dshift;
-            const unsigned long long tuBits = ((unsigned long long)F.bits[t] << 10) >> 15;
-            const int tuIndex = my_size == 64 ? tu + 1 : 0;
-            typename FlShared<N, GB>::Acc &A = F.acc[t];
-            A.nzs[tuIndex] = tnz;
+            const unsigned long long tuBits = ((unsigned long long)Fbits[u] << 10) >> 15;
+            const int tuIndex = size == 64 ? tu + 1 : 0;
+            nzs[tuIndex] = nz;
             if (CHROMA) {
                 /* TuCalcCost, chroma branches (EbRateDistortionCost.c:273-279) */
-                A.cbf |= (uint32_t)(tnz != 0) << tuIndex;
-                A.bits += tuBits, A.d0 += d0, A.d1 += d1;
+                cbf |= (uint32_t)(nz != 0) << tuIndex;
+                bits_acc += tuBits, d0_acc += d0, d1_acc += d1;
             } else {
                 /* TuCalcCostLuma (EbRateDistortionCost.c:289) */
-                const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + my_cand;
-                const int ctx = my_size == N;
-                const unsigned long long nzRate = (tuBits << 15) + in->cbf_bits[2 + ctx], zRate = in->cbf_bits[ctx];
-                const unsigned long long lam = in->full_lambda;
-                const unsigned long long zCost = S.cand_type == 2 ? ~0ull : (d1 << 8) + (((lam * zRate) + (1u << 22)) >> 23);
+                const unsigned long long nzRate = (tuBits << 15) + cbf_bits1, zRate = cbf_bits0, lam = full_lambda;
+                const unsigned long long zCost = cand_type == 2 ? ~0ull : (d1 << 8) + (((lam * zRate) + (1u << 22)) >> 23);
                 const unsigned long long nzCost = (d0 << 8) + (((lam * nzRate) + (1u << 22)) >> 23);
                 const bool keep = nzCost < zCost;
-                A.cbf |= (uint32_t)((tnz != 0) && keep) << tuIndex;
-                A.bits += keep ? tuBits : 0;
-                A.d0 += keep ? d0 : d1;
-                A.d1 += d1;
-                A.ydc[my_size == 64 ? tu : 0] = (int16_t)abs((int)F.q[t][0]);
-                A.cand_nz[my_size == 64 ? tu : 0] = (uint16_t)tnz;
+                cbf |= (uint32_t)((nz != 0) && keep) << tuIndex;
+                bits_acc += keep ? tuBits : 0;
+                d0_acc += keep ? d0 : d1;
+                d1_acc += d1;
+                ydc[size == 64 ? tu : 0] = (int16_t)abs((int)Fq[u][0]);
+                cand_nz[size == 64 ? tu : 0] = (uint16_t)nz;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
-    if (t < GB && my_active) {
-        const typename FlShared<N, GB>::Acc &A = F.acc[t];
+    if (r == 0 && ntu) {
         if (CHROMA) {
-            SvtAmdChromaLoopOut *o = (SvtAmdChromaLoopOut *)out_all + my_cand;
+            SvtAmdChromaLoopOut *o = (SvtAmdChromaLoopOut *)out_all + cand;
             for (int k = 0; k < 5; k++)
-                o->nz[my_plane][k] = A.nzs[k];
-            o->cbf[my_plane] = A.cbf, o->coeff_bits[my_plane] = A.bits, o->dist[my_plane][0] = A.d0, o->dist[my_plane][1] = A.d1;
+                o->nz[plane][k] = nzs[k];
+            o->cbf[plane] = cbf, o->coeff_bits[plane] = bits_acc, o->dist[plane][0] = d0_acc, o->dist[plane][1] = d1_acc;
         } else {
             SvtAmdFullLoopOut o;
             for (int k = 0; k < 5; k++)
-                o.nz[k] = A.nzs[k];
+                o.nz[k] = nzs[k];
             for (int k = 0; k < 4; k++)
-                o.ydc[k] = A.ydc[k], o.cand_nz[k] = A.cand_nz[k];
-            o.ycbf = A.cbf, o.coeff_bits = A.bits, o.dist[0] = A.d0, o.dist[1] = A.d1;
-            ((SvtAmdFullLoopOut *)out_all)[my_cand] = o;
+                o.ydc[k] = ydc[k], o.cand_nz[k] = cand_nz[k];
+            o.ycbf = cbf, o.coeff_bits = bits_acc, o.dist[0] = d0_acc, o.dist[1] = d1_acc;
+            ((SvtAmdFullLoopOut *)out_all)[cand] = o;
         }
     }
 }
@@ -300,14 +254,10 @@ template <int N, bool CHROMA>
 static void launch_full_loop(hipStream_t st, const void *d_in, const int16_t *d_res, int16_t *d_q, int16_t *d_r, void *d_out,
                              uint32_t ncand, int s1, int s2, int wrap)
 {
-    /* units in flight per workgroup and its width: four waves share one 32x32 unit, the Cb + Cr 16x16 units of one
-     * candidate (a 64x64 CU has four such pairs in a row) or four luma 16x16 units; the smaller sizes run one wave over
-     * 4 / 16 units */
-    constexpr int GB = N == 32 ? 1 : N == 16 ? (CHROMA ? 2 : 4) : N == 8 ? 4 : 16;
-    constexpr int NT = N >= 16 ? 256 : 64;
-    constexpr int PLANES = CHROMA ? 2 : 1, CPW = GB >= PLANES ? GB / PLANES : 1;
-    const dim3 grid((ncand + CPW - 1) / CPW, GB >= PLANES ? 1 : PLANES);
-    hipLaunchKernelGGL((k_full_loop<N, CHROMA, NT, GB>), grid, dim3(NT), 0, st, d_in, d_res, d_q, d_r, d_out, ncand, s1, s2, wrap);
+    constexpr int UPW = 64 / N;
+    const uint32_t nseq = CHROMA ? 2 * ncand : ncand;
+    hipLaunchKernelGGL((k_full_loop<N, CHROMA>), dim3((nseq + UPW - 1) / UPW), dim3(64), 0, st, d_in, d_res, d_q, d_r, d_out, ncand,
+                       s1, s2, wrap);
 }
 
 extern "C" int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *d_in,

@@ -149,6 +149,44 @@ __device__ __forceinline__ void fwd_1d_regs(int (&e)[N], int shift, int wrap_lev
     }
 }
 
+/* One 1-D N-point INVERSE pass (InvTransform32x32 .. 4x4, C_DEFAULT/EbTransforms_C.c:1910-2094) on coefficients held in
+ * registers: exact 32-bit even / odd recombination (equal to the plain matrix product), v[j] = sum_k T[k][j] * c[k]. */
+template <int N, int L, int S>
+struct InvBF {
+    static __device__ __forceinline__ void run(const int (&c)[N], int (&v)[L])
+    {
+        int e[L / 2];
+        InvBF<N, L / 2, 2 * S>::run(c, e);
+#pragma unroll
+        for (int k = 0; k < L / 2; k++) {
+            int o = 0;
+#pragma unroll
+            for (int i = 1; i < L; i += 2)
+                o += d_T32[(i * S) * (32 / N)][k] * c[i * S];
+            v[k] = e[k] + o;
+            v[L - 1 - k] = e[k] - o;
+        }
+    }
+};
+template <int N, int S>
+struct InvBF<N, 2, S> {
+    static __device__ __forceinline__ void run(const int (&c)[N], int (&v)[2])
+    {
+        v[0] = d_T32[0][0] * c[0] + d_T32[S * (32 / N)][0] * c[S];
+        v[1] = d_T32[0][1] * c[0] + d_T32[S * (32 / N)][1] * c[S];
+    }
+};
+template <int N, typename Emit>
+__device__ __forceinline__ void inv_1d_regs(const int (&c)[N], int shift, Emit emit)
+{
+    int v[N];
+    InvBF<N, N, 1>::run(c, v);
+    const int offset = (int16_t)(1 << (shift - 1));
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        emit(j, (int16_t)clip16i((v[j] + offset) >> shift));
+}
+
 /* LDS tile of the register transform: the intermediate of one N x N unit, rows padded by two samples so that a lane
  * per row and a lane per column both walk distinct banks; units 16 dwords apart from a bank-aligned pitch */
 template <int N>

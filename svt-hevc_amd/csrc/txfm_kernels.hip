@@ -110,39 +110,50 @@ __global__ __launch_bounds__(TX_THREADS) void k_dst4(const int16_t *__restrict__
             dst[(size_t)b * 16 + r * 4 + j] = a[lb][r * 4 + j];
 }
 
-/* inverse DCT: exact integer matrix product per pass, clip to 16 bits */
+/* inverse DCT, register-resident: lane r = column r of the coefficient block in pass 1 (2-byte loads, a wave reads 128
+ * contiguous bytes per coefficient row), row r of the result in pass 2 (one contiguous N*2-byte run per lane);
+ * exact integer arithmetic per pass, clip to 16 bits. */
 template <int N>
 __global__ __launch_bounds__(TX_THREADS) void k_inv_dct(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
                                                        uint32_t nblocks, int shift1, int shift2)
 {
-    constexpr int GB = TxShared<N>::GB;
-    __shared__ int8_t T[32][32];
-    __shared__ int16_t in[GB][N * N], mid[GB][N * N];
-    const int t = threadIdx.x;
-    const uint32_t b0 = blockIdx.x * GB;
-    const int nvalid = (int)min((uint32_t)GB, nblocks - b0);
-    for (int i = t; i < 32 * 32; i += TX_THREADS)
-        (&T[0][0])[i] = (&c_T32[0][0])[i];
-    for (int i = t; i < GB * N * N; i += TX_THREADS)
-        (&in[0][0])[i] = (i < nvalid * N * N) ? src[(size_t)b0 * N * N + i] : (int16_t)0;
-    __syncthreads();
+    constexpr int UPW = 64 / N, UPB = UPW * (TX_THREADS / 64), P = TxRegTile<N>::PITCH;
+    __shared__ int16_t tiles[UPB * TxRegTile<N>::UNIT];
+    const int t = threadIdx.x, u = t / N, r = t - u * N;
+    const uint32_t b = blockIdx.x * UPB + u;
+    int16_t *tile = tiles + u * TxRegTile<N>::UNIT;
+    int c[N];
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int shift = pass ? shift2 : shift1, offset = (int16_t)(1 << (shift - 1));
-        for (int i = t; i < GB * N * N; i += TX_THREADS) {
-            const int j = i % N, r = (i / N) % N, b = i / (N * N);
-            const int16_t *s = pass ? mid[b] : in[b];
-            int acc = 0;
-#pragma unroll 8
-            for (int k = 0; k < N; k++)
-                acc += T[k * (32 / N)][j] * s[k * N + r];
-            const int16_t v = (int16_t)clip16i((acc + offset) >> shift);
-            if (pass == 0)
-                mid[b][r * N + j] = v;
-            else if (b < nvalid)
-                dst[(size_t)(b0 + b) * N * N + r * N + j] = v;
+    for (int k = 0; k < N; k++)
+        c[k] = b < nblocks ? (int)src[(size_t)b * N * N + k * N + r] : 0;
+    /* pass 1: column r -> row r of the intermediate */
+    inv_1d_regs<N>(c, shift1, [&](int j, int16_t v) { tile[r * P + j] = v; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        c[k] = tile[k * P + r];
+    int y[N];
+    inv_1d_regs<N>(c, shift2, [&](int j, int16_t v) { y[j] = v; });
+    if (b < nblocks) {
+        int16_t *out = dst + (size_t)b * N * N + r * N;
+        if (N >= 8) {
+#pragma unroll
+            for (int j = 0; j < N; j += 8) {
+                uint4 v;
+                v.x = (uint32_t)(uint16_t)y[j] | ((uint32_t)(uint16_t)y[j + 1] << 16);
+                v.y = (uint32_t)(uint16_t)y[j + 2] | ((uint32_t)(uint16_t)y[j + 3] << 16);
+                v.z = (uint32_t)(uint16_t)y[j + 4] | ((uint32_t)(uint16_t)y[j + 5] << 16);
+                v.w = (uint32_t)(uint16_t)y[j + 6] | ((uint32_t)(uint16_t)y[j + 7] << 16);
+                *(uint4 *)(out + j) = v;
+            }
+        } else {
+            uint2 v;
+            v.x = (uint32_t)(uint16_t)y[0] | ((uint32_t)(uint16_t)y[1] << 16);
+            v.y = (uint32_t)(uint16_t)y[2] | ((uint32_t)(uint16_t)y[3] << 16);
+            *(uint2 *)out = v;
         }
-        __syncthreads();
     }
 }
 
@@ -416,13 +427,13 @@ int svt_amd_launch_inv_transform(hipStream_t st, int kind, int size, uint32_t in
     if (kind == 2)
         hipLaunchKernelGGL(k_dst4, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2, 1);
     else if (size == 32)
-        hipLaunchKernelGGL(k_inv_dct<32>, dim3(n), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+        hipLaunchKernelGGL(k_inv_dct<32>, dim3((n + 7) / 8), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
     else if (size == 16)
-        hipLaunchKernelGGL(k_inv_dct<16>, dim3(n), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+        hipLaunchKernelGGL(k_inv_dct<16>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
     else if (size == 8)
-        hipLaunchKernelGGL(k_inv_dct<8>, dim3((n + 3) / 4), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+        hipLaunchKernelGGL(k_inv_dct<8>, dim3((n + 31) / 32), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
     else
-        hipLaunchKernelGGL(k_inv_dct<4>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
+        hipLaunchKernelGGL(k_inv_dct<4>, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_coeff, d_res, n, s1, s2);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
