@@ -695,6 +695,25 @@ SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost
                                        SvtAmdFullLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
+/* Reconstruction of transform units (final encode pass)                      */
+/* ------------------------------------------------------------------------- */
+/* Replaces, per reconstructed plane of a transform unit, EncodeGenerateRecon / EncodeGenerateRecon16bit
+ * (Codec/EbCodingLoop.c:1084-1243, :1660-1797; reached through the global table EncodeGenerateReconFunctionPtr, :1807):
+ * EncodeInvTransform (Codec/EbTransforms.c:3502: DC-only shortcut, inverse DCT, inverse DST for the 4x4 luma unit) +
+ * PictureAdditionKernel(16bit).  Unit u has its size x size inverse-quantised coefficients at d_coeff + u*size*size;
+ * pred_off / recon_off = sample index of the unit's (0,0) in the prediction / reconstruction plane (the reference
+ * reconstructs in place: both planes may be the same buffer with equal offsets). */
+typedef struct SvtAmdReconUnit { int32_t pred_off, recon_off; uint8_t only_dc, dst, pad[2]; } SvtAmdReconUnit;
+SVT_AMD_API int svt_amd_recon_tu_batch(SvtAmdContext *ctx, int bytes_per_sample, int size, const int16_t *d_coeff,
+                                       const SvtAmdReconUnit *d_units, const void *d_pred, uint32_t predStride,
+                                       void *d_recon, uint32_t reconStride, uint32_t nunits);
+/* Per-call form on HOST pointers (strides in samples; coeffStride 64 / 32 for the reference's LCU scratch planes).
+ * Blocking; used by the EncodeGenerateReconFunctionPtr binding. */
+SVT_AMD_API int svt_amd_recon_tu(SvtAmdContext *ctx, int bytes_per_sample, int size, int only_dc, int dst,
+                                 const int16_t *coeff, uint32_t coeffStride, const void *pred, uint32_t predStride,
+                                 void *recon, uint32_t reconStride);
+
+/* ------------------------------------------------------------------------- */
 /* Chroma full loop of one mode-decision candidate                            */
 /* ------------------------------------------------------------------------- */
 /* Replaces the pair FullLoop_R (Codec/EbFullLoop.c:579-870) + CuFullDistortionFastTuMode_R (:873-1066) as the mode

@@ -29,6 +29,9 @@
 #include "EbModeDecisionProcess.h"
 #include "EbModeDecision.h"
 #include "EbFullLoop.h"
+#include "EbEncDecProcess.h"
+#include "EbCodingUnit.h"
+#include "EbTransformUnit.h"
 #include "EbCabacContextModel.h"
 
 #include "../include/svt_hevc_amd.h"
@@ -411,6 +414,80 @@ void __wrap_CuFullDistortionFastTuMode_R(EbPictureBufferDesc_t *inputPicturePtr,
     *cbCoeffBits += o->coeff_bits[0], *crCoeffBits += o->coeff_bits[1];
     cbFullDistortion[0] += o->dist[0][0], cbFullDistortion[1] += o->dist[0][1];
     crFullDistortion[0] += o->dist[1][0], crFullDistortion[1] += o->dist[1][1];
+}
+
+/*
+ * Final encode pass, reconstruction of a transform unit: EncodeGenerateRecon / EncodeGenerateRecon16bit
+ * (EbCodingLoop.c:1084, :1660) are static, but the encode pass only reaches them through the global table
+ * EncodeGenerateReconFunctionPtr[2] (:1807).  With SVT_HOOK_RECON=1 its slots are replaced: every plane the call
+ * reconstructs (cbf set, CU not skipped) is answered by svt_amd_recon_tu() (inverse transform / DC shortcut / DST +
+ * prediction add on the device); 4:2:0 only, anything else goes to the saved reference function.
+ */
+typedef void (*ReconFn)(EncDecContext_t *, EB_U32, EB_U32, EB_U32, EB_COLOR_FORMAT, EB_BOOL, EB_U32, EbPictureBufferDesc_t *,
+                        EbPictureBufferDesc_t *, EB_S16 *);
+extern ReconFn EncodeGenerateReconFunctionPtr[2];
+static ReconFn g_recon_real[2];
+static unsigned long g_recon_gpu;
+
+static void recon_on_device(int is16, EncDecContext_t *ctx, EB_U32 originX, EB_U32 originY, EB_U32 componentMask,
+                            EB_COLOR_FORMAT colorFormat, EB_BOOL secondChroma, EB_U32 tuSize, EbPictureBufferDesc_t *predSamples,
+                            EbPictureBufferDesc_t *residual16bit, EB_S16 *scratch)
+{
+    if (!g_ctx || colorFormat != EB_YUV420 || secondChroma) {
+        g_recon_real[is16](ctx, originX, originY, componentMask, colorFormat, secondChroma, tuSize, predSamples, residual16bit, scratch);
+        return;
+    }
+    const CodingUnit_t *cu = ctx->cuPtr;
+    const TransformUnit_t *tu = &cu->transformUnitArray[ctx->tuItr];
+    const int bps = is16 ? 2 : 1;
+    for (int p = 0; p < 3; p++) {
+        const int wanted = p == 0 ? (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) != 0 : (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
+        const int cbf = p == 0 ? tu->lumaCbf : p == 1 ? tu->cbCbf : tu->crCbf;
+        if (!wanted || !cbf || cu->skipFlag)
+            continue;
+        const uint32_t n = p == 0 ? tuSize : (tuSize == 4 ? 4 : tuSize >> 1);
+        const int dst = p == 0 && tuSize == 4;
+        const int only_dc = tuSize == 4 ? 0 : (p == 0 ? (tu->transCoeffShapeLuma == ONLY_DC_SHAPE || tu->isOnlyDc[0])
+                                                      : (tu->transCoeffShapeChroma == ONLY_DC_SHAPE || tu->isOnlyDc[p]));
+        uint32_t off, scratchOff, cstride, stride;
+        uint8_t *plane;
+        int16_t *cplane;
+        if (p == 0) {
+            stride = predSamples->strideY, plane = predSamples->bufferY, cplane = (int16_t *)residual16bit->bufferY;
+            off = (predSamples->originY + originY) * stride + (predSamples->originX + originX);
+            scratchOff = ((originY & 63) * 64) + (originX & 63), cstride = 64;
+        } else {
+            stride = p == 1 ? predSamples->strideCb : predSamples->strideCr;
+            plane = p == 1 ? predSamples->bufferCb : predSamples->bufferCr;
+            cplane = (int16_t *)(p == 1 ? residual16bit->bufferCb : residual16bit->bufferCr);
+            off = ((predSamples->originX + originX) >> 1) + (((predSamples->originY + originY) >> 1) * stride);
+            scratchOff = ((originX & 63) >> 1) + (((originY & 63) >> 1) * 32), cstride = 32;
+        }
+        pthread_mutex_lock(&g_lock);
+        if (svt_amd_recon_tu(g_ctx, bps, (int)n, only_dc, dst, cplane + scratchOff, cstride, plane + (size_t)off * bps, stride,
+                             plane + (size_t)off * bps, stride))
+            die("svt_amd_recon_tu");
+        if (g_recon_gpu++ == 0 && g_verbose)
+            fprintf(stderr, "svt_hook_me: transform-unit reconstruction (EncodeGenerateRecon) on the GPU\n");
+        pthread_mutex_unlock(&g_lock);
+    }
+}
+static void recon8(EncDecContext_t *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_COLOR_FORMAT e, EB_BOOL f, EB_U32 g, EbPictureBufferDesc_t *h,
+                   EbPictureBufferDesc_t *i, EB_S16 *j)
+{
+    recon_on_device(0, a, b, c, d, e, f, g, h, i, j);
+}
+static void recon16(EncDecContext_t *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_COLOR_FORMAT e, EB_BOOL f, EB_U32 g, EbPictureBufferDesc_t *h,
+                    EbPictureBufferDesc_t *i, EB_S16 *j)
+{
+    recon_on_device(1, a, b, c, d, e, f, g, h, i, j);
+}
+__attribute__((constructor)) static void recon_install(void)
+{
+    if (!getenv("SVT_HOOK_RECON"))
+        return;
+    g_recon_real[0] = EncodeGenerateReconFunctionPtr[0], g_recon_real[1] = EncodeGenerateReconFunctionPtr[1];
+    EncodeGenerateReconFunctionPtr[0] = recon8, EncodeGenerateReconFunctionPtr[1] = recon16;
 }
 
 static void hook_report(void)

@@ -200,5 +200,8 @@ void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmd
                                        int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out);
 void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
                                  int16_t *const quant[2], int16_t *const recon[2], SvtAmdChromaLoopOut *out);
+/* reconstruction of one transform unit of one plane (inverse transform or DC shortcut + prediction, clipped) */
+void svt_oracle_recon_tu(int bps, uint32_t size, int only_dc, int dst, const int16_t *coeff, const void *pred,
+                         uint32_t predStride, void *recon, uint32_t reconStride);
 
 #endif

@@ -171,3 +171,38 @@ void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChroma
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Reconstruction of one transform unit of one plane: EncodeGenerateRecon / EncodeGenerateRecon16bit
+ * (Codec/EbCodingLoop.c:1084-1243, :1660-1797) = EncodeInvTransform (Codec/EbTransforms.c:3502-3553; DC-only shortcut
+ * :3516-3535) + PictureAdditionKernel(16bit) (C_DEFAULT/EbPictureOperators_C.c:112-175).  coeff: size x size, pitch =
+ * size; pred / recon: bps-byte samples.  Pinned by tests/test_oracle_recon_golden.py on records of real calls.
+ * ------------------------------------------------------------------------------------------------------------------ */
+void svt_oracle_recon_tu(int bps, uint32_t size, int only_dc, int dst, const int16_t *coeff, const void *pred,
+                         uint32_t predStride, void *recon, uint32_t reconStride)
+{
+    int16_t res[32 * 32];
+    const uint32_t inc = bps == 1 ? 0 : 2; /* BIT_INCREMENT_8BIT / _10BIT */
+    if (only_dc) {
+        const int32_t s1 = 7, s2 = 12 - (int32_t)inc;
+        int32_t v = (64 * coeff[0] + (1 << (s1 - 1))) >> s1;
+        v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+        v = (64 * (int16_t)v + (1 << (s2 - 1))) >> s2;
+        v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+        for (uint32_t i = 0; i < size * size; i++)
+            res[i] = (int16_t)v;
+    } else {
+        svt_oracle_InvTransform(dst ? 2 : 0, (int)size, coeff, size, res, size, NULL, inc);
+    }
+    const int maxv = bps == 1 ? 255 : 1023;
+    for (uint32_t y = 0; y < size; y++)
+        for (uint32_t x = 0; x < size; x++) {
+            const int p = bps == 1 ? ((const uint8_t *)pred)[y * predStride + x] : ((const uint16_t *)pred)[y * predStride + x];
+            int v = p + res[y * size + x];
+            v = v < 0 ? 0 : v > maxv ? maxv : v;
+            if (bps == 1)
+                ((uint8_t *)recon)[y * reconStride + x] = (uint8_t)v;
+            else
+                ((uint16_t *)recon)[y * reconStride + x] = (uint16_t)v;
+        }
+}

@@ -19,6 +19,7 @@
  */
 #include "svt_amd_internal.h"
 #include "txfm_device.h"
+#include <cstring>
 
 /* Forward DCT, register-resident: lane = one row of one N x N block, 64 / N blocks per wave, 4 waves per workgroup.
  * HBM: every residual row is one contiguous N*2-byte run per lane; results leave as one 2-byte store per lane and
@@ -81,6 +82,17 @@ __device__ __forceinline__ void dst4_inv_col(const int16_t *in, int istride, int
     out[2] = (int16_t)clip16i(((74 * (c0 - c2 + c3)) + offset) >> shift);
     out[3] = (int16_t)clip16i((55 * o0 + 29 * o1 - e1 + offset) >> shift);
 }
+__device__ __forceinline__ void dst4_inv_col_regs(const int (&c)[4], int (&out)[4], int shift)
+{
+    const int offset = (int16_t)(1 << (shift - 1));
+    const int o0 = c[0] + c[2], o1 = c[0] - c[3], e0 = c[2] + c[3], e1 = 74 * c[1];
+    out[0] = clip16i((29 * o0 + 55 * e0 + e1 + offset) >> shift);
+    out[1] = clip16i((55 * o1 - 29 * e0 + e1 + offset) >> shift);
+    out[2] = clip16i(((74 * (c[0] - c[2] + c[3])) + offset) >> shift);
+    out[3] = clip16i((55 * o0 + 29 * o1 - e1 + offset) >> shift);
+}
+template <int N>
+__device__ __forceinline__ void dst4_inv_col_regs(const int (&)[N], int (&)[N], int) {} /* only the 4x4 unit has a DST */
 __global__ __launch_bounds__(TX_THREADS) void k_dst4(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
                                                     uint32_t nblocks, int shift1, int shift2, int inverse)
 {
@@ -153,6 +165,70 @@ __global__ __launch_bounds__(TX_THREADS) void k_inv_dct(const int16_t *__restric
             v.x = (uint32_t)(uint16_t)y[0] | ((uint32_t)(uint16_t)y[1] << 16);
             v.y = (uint32_t)(uint16_t)y[2] | ((uint32_t)(uint16_t)y[3] << 16);
             *(uint2 *)out = v;
+        }
+    }
+}
+
+/* Reconstruction of transform units, fused: EncodeGenerateRecon(16bit) (Codec/EbCodingLoop.c:1084, :1660) =
+ * EncodeInvTransform (EbTransforms.c:3502; DC-only shortcut, inverse DCT, 4x4 inverse DST) + PictureAdditionKernel(16bit).
+ * Lane r of a unit: column r of the coefficients in the first pass, row r of the residual after the second, then row r of
+ * the prediction (one contiguous run) -> clipped sum -> one contiguous store.  The residual never leaves registers. */
+struct ReconUnit { int32_t pred_off, recon_off; uint8_t only_dc, dst, pad[2]; }; /* = SvtAmdReconUnit */
+
+template <int N, typename T>
+__global__ __launch_bounds__(TX_THREADS) void k_recon_tu(const int16_t *__restrict__ coeff, const ReconUnit *__restrict__ units,
+                                                        const T *__restrict__ pred, uint32_t predStride, T *__restrict__ recon,
+                                                        uint32_t reconStride, uint32_t nunits, int shift1, int shift2)
+{
+    constexpr int UPW = 64 / N, UPB = UPW * (TX_THREADS / 64), P = TxRegTile<N>::PITCH;
+    constexpr int maxv = sizeof(T) == 1 ? 255 : 1023;
+    __shared__ int16_t tiles[UPB * TxRegTile<N>::UNIT];
+    const int t = threadIdx.x, u = t / N, r = t - u * N;
+    const uint32_t b = blockIdx.x * UPB + u;
+    const bool live = b < nunits;
+    int16_t *tile = tiles + u * TxRegTile<N>::UNIT;
+    ReconUnit U = {0, 0, 0, 0, {0, 0}};
+    if (live)
+        U = units[b];
+    int c[N], y[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        c[k] = live ? (int)coeff[(size_t)b * N * N + k * N + r] : 0;
+    if (N == 4 && U.dst) {
+        /* InvDstTransform4x4: column r -> row r, twice (dst4_inv_col above) */
+        dst4_inv_col_regs(c, y, shift1);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            tile[r * P + j] = (int16_t)y[j];
+    } else {
+        inv_1d_regs<N>(c, shift1, [&](int j, int16_t v) { tile[r * P + j] = v; });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        c[k] = tile[k * P + r];
+    if (N == 4 && U.dst)
+        dst4_inv_col_regs(c, y, shift2);
+    else
+        inv_1d_regs<N>(c, shift2, [&](int j, int16_t v) { y[j] = v; });
+    if (U.only_dc) {
+        /* EncodeInvTransform's shortcut: the twice scaled and clipped DC value everywhere */
+        int v = (int)coeff[(size_t)b * N * N];
+        v = clip16i((64 * v + (1 << (shift1 - 1))) >> shift1);
+        v = clip16i((64 * (int16_t)v + (1 << (shift2 - 1))) >> shift2);
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            y[j] = v;
+    }
+    if (live) {
+        const T *prow = pred + U.pred_off + (size_t)r * predStride;
+        T *out = recon + U.recon_off + (size_t)r * reconStride;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const int v = (int)prow[j] + y[j];
+            out[j] = (T)(v < 0 ? 0 : v > maxv ? maxv : v);
         }
     }
 }
@@ -554,4 +630,70 @@ extern "C" int svt_amd_satd_batch(SvtAmdContext *ctx, int size, const int16_t *d
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     return svt_amd_launch_satd(ctx->stream, size, d_diff, nullptr, 0, (unsigned long long *)d_satd, nullptr, nblocks);
+}
+
+extern "C" int svt_amd_recon_tu_batch(SvtAmdContext *ctx, int bytes_per_sample, int size, const int16_t *d_coeff,
+                                      const SvtAmdReconUnit *d_units, const void *d_pred, uint32_t predStride, void *d_recon,
+                                      uint32_t reconStride, uint32_t nunits)
+{
+    if (!ctx || !d_coeff || !d_units || !d_pred || !d_recon || !nunits || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
+        !(size == 4 || size == 8 || size == 16 || size == 32))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int s1 = 7, s2 = bytes_per_sample == 1 ? 12 : 10; /* SHIFT_INV_1ST, SHIFT_INV_2ND - bitIncrement (0 / 2) */
+    const ReconUnit *un = (const ReconUnit *)d_units;
+#define SVT_RECON_LAUNCH(N, T)                                                                                               \
+    hipLaunchKernelGGL((k_recon_tu<N, T>), dim3((nunits + (64 / N) * 4 - 1) / ((64 / N) * 4)), dim3(TX_THREADS), 0, ctx->stream, \
+                       d_coeff, un, (const T *)d_pred, predStride, (T *)d_recon, reconStride, nunits, s1, s2)
+    if (bytes_per_sample == 1) {
+        if (size == 32) SVT_RECON_LAUNCH(32, uint8_t);
+        else if (size == 16) SVT_RECON_LAUNCH(16, uint8_t);
+        else if (size == 8) SVT_RECON_LAUNCH(8, uint8_t);
+        else SVT_RECON_LAUNCH(4, uint8_t);
+    } else {
+        if (size == 32) SVT_RECON_LAUNCH(32, uint16_t);
+        else if (size == 16) SVT_RECON_LAUNCH(16, uint16_t);
+        else if (size == 8) SVT_RECON_LAUNCH(8, uint16_t);
+        else SVT_RECON_LAUNCH(4, uint16_t);
+    }
+#undef SVT_RECON_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* Host-pointer form for one unit (the per-call binding of integration/svt_hook_me.c): operands are staged through a
+ * scratch buffer of the context's device; blocking; callers serialise per context. */
+extern "C" int svt_amd_recon_tu(SvtAmdContext *ctx, int bytes_per_sample, int size, int only_dc, int dst, const int16_t *coeff,
+                                uint32_t coeffStride, const void *pred, uint32_t predStride, void *recon, uint32_t reconStride)
+{
+    if (!ctx || !coeff || !pred || !recon || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
+        !(size == 4 || size == 8 || size == 16 || size == 32) || coeffStride < (uint32_t)size || predStride < (uint32_t)size ||
+        reconStride < (uint32_t)size)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    static uint8_t *d_scratch = nullptr; /* unit | coeff | pred -> recon (in place) */
+    const size_t o_unit = 0, o_coeff = 64, o_pix = o_coeff + 2048, total = o_pix + 2048;
+    if (!d_scratch)
+        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    const size_t bps = (size_t)bytes_per_sample;
+    int16_t hc[32 * 32];
+    uint8_t hp[32 * 32 * 2];
+    for (int y = 0; y < size; y++) {
+        ::memcpy(hc + y * size, coeff + (size_t)y * coeffStride, (size_t)size * 2);
+        ::memcpy(hp + (size_t)y * size * bps, (const uint8_t *)pred + (size_t)y * predStride * bps, (size_t)size * bps);
+    }
+    SvtAmdReconUnit u = {0, 0, (uint8_t)(only_dc != 0), (uint8_t)(dst != 0), {0, 0}};
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_unit, &u, sizeof(u), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_coeff, hc, (size_t)size * size * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_pix, hp, (size_t)size * size * bps, hipMemcpyHostToDevice, ctx->stream));
+    int rc = svt_amd_recon_tu_batch(ctx, bytes_per_sample, size, (const int16_t *)(d_scratch + o_coeff),
+                                    (const SvtAmdReconUnit *)(d_scratch + o_unit), d_scratch + o_pix, (uint32_t)size,
+                                    d_scratch + o_pix, (uint32_t)size, 1);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(hp, d_scratch + o_pix, (size_t)size * size * bps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int y = 0; y < size; y++)
+        ::memcpy((uint8_t *)recon + (size_t)y * reconStride * bps, hp + (size_t)y * size * bps, (size_t)size * bps);
+    return SVT_AMD_OK;
 }

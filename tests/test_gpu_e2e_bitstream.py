@@ -94,3 +94,32 @@ def test_bitstream_identical_with_gpu_full_loop(tmp_path, kind, w, h, n, args):
     if "-intra-period" not in args:  # intra pictures of these presets leave chroma to the encode pass
         assert "svt_hook_me: chroma full loop (FullLoop_R + CuFullDistortionFastTuMode_R) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
+
+
+RECON_CASES = [
+    ("motion", 416, 240, 4, ["-encMode", "9", "-pred-struct", "0"]),
+    ("noise", 192, 128, 2, ["-encMode", "1", "-intra-period", "0", "-q", "25"]),   # 4x4 luma units: inverse DST
+    ("motion10", 416, 240, 3, ["-encMode", "7", "-bit-depth", "10"]),              # EncodeGenerateRecon16bit
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", RECON_CASES)
+def test_bitstream_and_recon_identical_with_gpu_reconstruction(tmp_path, kind, w, h, n, args):
+    """The final encode pass's transform-unit reconstruction (EncodeGenerateRecon / 16bit, reached through the global
+    table EncodeGenerateReconFunctionPtr) answered by svt_amd_recon_tu (SVT_HOOK_RECON=1): the reference pictures of
+    every later picture then come from the device, so both the bitstream and the reconstruction output must match."""
+    yuv = str(tmp_path / "clip.yuv")
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    os.environ["SVT_HOOK_RECON"] = "1"
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        del os.environ["SVT_HOOK_RECON"]
+    assert "svt_hook_me: transform-unit reconstruction (EncodeGenerateRecon) on the GPU" in log, log[-1000:]
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
+    a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
+    assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
