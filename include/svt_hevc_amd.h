@@ -695,6 +695,38 @@ SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost
                                        SvtAmdFullLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
+/* Encode-pass intra prediction of a prediction unit from its neighbours      */
+/* ------------------------------------------------------------------------- */
+/* Replaces the pair GenerateIntraReferenceSamplesEncodePass (Codec/EbIntraPrediction.c:212-757; 16-bit twin :760-1300)
+ * + EncodePassIntraPrediction (:4395-4673; 16-bit :4680-4960) that the encode pass reaches through the global tables
+ * GenerateIntraReferenceSamplesFuncTable / EncodePassIntraPredictionFuncTable (Codec/EbCodingLoop.c:1814, :1832):
+ * availability of every 4-sample neighbour group (array bound, z-order, slice, picture / tile edge, constrained intra),
+ * substitution of the missing ones, [1 2 1] / strong (bilinear) smoothing of the luma reference, filtered-or-not choice by
+ * mode and size (intraLumaFilterTable), and the prediction of the luma block and, with the derived chroma mode, of the
+ * two chroma blocks (4:2:0).  The job carries the slices of the reference's neighbour arrays the unit can see, already
+ * cut out by the caller: entry i of left[] / top[] = i-th sample below / right of the unit's top-left corner. */
+typedef struct SvtAmdIntraPuJob {
+    uint32_t size;                         /* 8 / 16 / 32                                                          */
+    uint8_t  constrained_intra, strong_smoothing;
+    uint8_t  pic_left, pic_top, pic_right; /* pictureLeft/Top/RightBoundary arguments (tile edges)                */
+    uint8_t  bottom_left_ok, top_right_ok; /* isBottomLeftAvailable / isUpperRightAvailable(cuDepth, cuIndex)     */
+    uint8_t  luma_mode, chroma_mode;       /* EB_INTRA_* / EB_INTRA_CHROMA_* (4 = derived from luma)              */
+    uint8_t  mode_tl;                      /* mode-type neighbour entries: 1 INTER, 2 INTRA, 0xFF invalid,        */
+    uint8_t  mode_left[16], mode_top[16];  /*   0xFE beyond the array; one per 4 luma samples                     */
+    uint8_t  pad[2];
+    uint16_t left[3][64], top[3][64];      /* [Y, Cb, Cr][i]: reconstructed neighbour samples (chroma: size used)  */
+    uint16_t tl[3], pad2;
+    int32_t  dst_off_y, dst_off_c;         /* sample offsets of the unit inside the three destination planes      */
+} SvtAmdIntraPuJob;
+/* BATCHED (device pointers): job j predicts into d_pred_y / d_pred_cb / d_pred_cr at its offsets; strides in samples. */
+SVT_AMD_API int svt_amd_intra_pu_batch(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *d_jobs,
+                                       uint32_t njobs, void *d_pred_y, uint32_t strideY, void *d_pred_cb, void *d_pred_cr,
+                                       uint32_t strideC);
+/* Per-call form on HOST pointers (one unit, blocking): the binding of the two table slots. */
+SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *job, void *pred_y,
+                                 uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC);
+
+/* ------------------------------------------------------------------------- */
 /* Reconstruction of transform units (final encode pass)                      */
 /* ------------------------------------------------------------------------- */
 /* Replaces, per reconstructed plane of a transform unit, EncodeGenerateRecon / EncodeGenerateRecon16bit

@@ -1,0 +1,157 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/): interposer on the REFERENCE's encode-pass intra prediction of a prediction unit,
+ * the pair GenerateIntraReferenceSamplesEncodePass (Codec/EbIntraPrediction.c:212; 16-bit twin
+ * GenerateIntraReference16bitSamplesEncodePass) + EncodePassIntraPrediction (:4395; 16-bit :4680), which the encode pass
+ * reaches through the global tables GenerateIntraReferenceSamplesFuncTable[2] / EncodePassIntraPredictionFuncTable[2]
+ * (Codec/EbCodingLoop.c:1814, :1832).  A constructor swaps the slots for recording wrappers.  Compiled only into
+ * oracle/_ref/libsvtref.so.
+ *
+ * With SVT_REF_INTRA_DUMP=<file>, a sample of the call pairs (every SVT_REF_INTRA_STRIDE-th, default 7) leaves one binary
+ * record: the slices of the neighbour arrays the first call may look at (mode type per 4 samples, reconstructed luma /
+ * chroma samples left, above and above-left of the unit), its flags, the two z-order availabilities it derives, and the
+ * modes and the three predicted blocks of the second call.  tests/golden/make_intra_golden.py builds the fixtures.
+ * No reference source here.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureBufferDesc.h"
+#include "EbNeighborArrays.h"
+#include "EbIntraPrediction.h"
+#include "EbAvailability.h"
+
+typedef EB_ERRORTYPE (*GenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
+                              NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_COLOR_FORMAT, EB_BOOL, EB_BOOL, EB_BOOL);
+typedef EB_ERRORTYPE (*PredFn)(void *, EB_U32, EB_U32, EB_U32, EB_U32, EbPictureBufferDesc_t *, EB_COLOR_FORMAT, EB_BOOL, EB_U32, EB_U32,
+                               EB_U32);
+extern GenFn GenerateIntraReferenceSamplesFuncTable[2];
+extern PredFn EncodePassIntraPredictionFuncTable[2];
+static GenFn g_gen[2];
+static PredFn g_pred[2];
+
+#define INTRA_DUMP_MAGIC 0x52544e49U /* "INTR" */
+typedef struct IntraRecord {
+    uint32_t magic, record_size;
+    uint32_t size, bytes_per_sample;
+    uint8_t constrained_intra, strong_smoothing, pic_left, pic_top, pic_right, bottom_left_ok, top_right_ok, pad0;
+    uint32_t luma_mode, chroma_mode, component_mask, pad1;
+    uint8_t mode_left[32], mode_top[32], mode_tl, pad2[7]; /* per 4 samples going down / right from the unit's corner; 0xFE: beyond the array */
+    uint16_t left[3][128], top[3][128], tl[3], pad3;       /* [plane][i]: i-th sample below the corner / right of it */
+    uint16_t pred_y[64 * 64], pred_cb[32 * 32], pred_cr[32 * 32]; /* size x size (chroma size/2), row pitch = that size */
+} IntraRecord;
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static FILE *g_file;
+static int g_state, g_stride = 7;
+static unsigned long g_calls;
+static __thread IntraRecord *t_pending;
+static __thread void *t_pending_ref;
+
+static uint16_t rd(const uint8_t *a, uint32_t i, int bps) { return bps == 1 ? a[i] : ((const uint16_t *)a)[i]; }
+
+static EB_ERRORTYPE gen_wrapper(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                                EB_U32 cuDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *y, NeighborArrayUnit_t *cb,
+                                NeighborArrayUnit_t *cr, void *ref, EB_COLOR_FORMAT cf, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
+{
+    if (g_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_state == 0) {
+            const char *path = getenv("SVT_REF_INTRA_DUMP"), *st = getenv("SVT_REF_INTRA_STRIDE");
+            g_file = path ? fopen(path, "wb") : NULL;
+            if (st && atoi(st) > 0)
+                g_stride = atoi(st);
+            g_state = g_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    free(t_pending);
+    t_pending = NULL;
+    int take = 0;
+    if (g_state > 0 && cf == EB_YUV420 && size >= 8 && size <= 64) {
+        pthread_mutex_lock(&g_lock);
+        take = (g_calls++ % (unsigned long)g_stride) == 0;
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (take) {
+        IntraRecord *r = (IntraRecord *)calloc(1, sizeof(*r));
+        const int bps = is16 ? 2 : 1;
+        r->magic = INTRA_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->size = size, r->bytes_per_sample = (uint32_t)bps;
+        r->constrained_intra = constrained, r->strong_smoothing = strong, r->pic_left = pl, r->pic_top = pt, r->pic_right = pr;
+        uint32_t lg = 0;
+        while ((1u << lg) < size)
+            lg++;
+        const uint32_t cuIndex = ((originY & (lcuSize - 1)) >> lg) * (1u << cuDepth) + ((originX & (lcuSize - 1)) >> lg);
+        r->bottom_left_ok = isBottomLeftAvailable(cuDepth, cuIndex), r->top_right_ok = isUpperRightAvailable(cuDepth, cuIndex);
+        for (uint32_t k = 0; k < 2 * size / 4; k++) {
+            const uint32_t li = GetNeighborArrayUnitLeftIndex(mode, originY + 4 * k), ti = GetNeighborArrayUnitTopIndex(mode, originX + 4 * k);
+            r->mode_left[k] = li >= mode->leftArraySize ? 0xFE : mode->leftArray[li];
+            r->mode_top[k] = ti >= mode->topArraySize ? 0xFE : mode->topArray[ti];
+        }
+        r->mode_tl = mode->topLeftArray[GetNeighborArrayUnitTopLeftIndex(mode, (EB_S32)originX, (EB_S32)originY)];
+        NeighborArrayUnit_t *na[3] = {y, cb, cr};
+        for (int p = 0; p < 3; p++) {
+            const uint32_t sh = p ? 1 : 0, n2 = (2 * size) >> sh, ox = originX >> sh, oy = originY >> sh;
+            for (uint32_t i = 0; i < n2; i++) {
+                /* a sample is only read when its 4-sample mode entry lies inside the mode array */
+                const uint32_t k = (i << sh) >> 2;
+                r->left[p][i] = r->mode_left[k] == 0xFE ? 0 : rd(na[p]->leftArray, oy + i, bps);
+                r->top[p][i] = r->mode_top[k] == 0xFE ? 0 : rd(na[p]->topArray, ox + i, bps);
+            }
+            r->tl[p] = p == 0 ? rd(y->topLeftArray, MAX_PICTURE_HEIGHT_SIZE + originX - originY, bps)
+                              : rd(na[p]->topLeftArray, ((MAX_PICTURE_HEIGHT_SIZE - originY) >> 1) + (originX >> 1), bps);
+        }
+        t_pending = r, t_pending_ref = ref;
+    }
+    return g_gen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, cf, pl, pt, pr);
+}
+
+static EB_ERRORTYPE pred_wrapper(int is16, void *ref, EB_U32 originX, EB_U32 originY, EB_U32 puSize, EB_U32 puChromaSize,
+                                 EbPictureBufferDesc_t *pic, EB_COLOR_FORMAT cf, EB_BOOL second, EB_U32 lumaMode, EB_U32 chromaMode,
+                                 EB_U32 mask)
+{
+    const EB_ERRORTYPE rc = g_pred[is16](ref, originX, originY, puSize, puChromaSize, pic, cf, second, lumaMode, chromaMode, mask);
+    IntraRecord *r = t_pending;
+    t_pending = NULL;
+    if (!r)
+        return rc;
+    if (ref != t_pending_ref || puSize != r->size || second || mask != PICTURE_BUFFER_DESC_FULL_MASK) {
+        free(r);
+        return rc;
+    }
+    const int bps = (int)r->bytes_per_sample;
+    r->luma_mode = lumaMode, r->chroma_mode = chromaMode, r->component_mask = mask;
+    for (uint32_t yy = 0; yy < puSize; yy++)
+        for (uint32_t xx = 0; xx < puSize; xx++)
+            r->pred_y[yy * puSize + xx] = rd(pic->bufferY, (originY + yy) * pic->strideY + originX + xx, bps);
+    const uint32_t c = puSize >> 1;
+    for (uint32_t yy = 0; yy < c; yy++)
+        for (uint32_t xx = 0; xx < c; xx++) {
+            r->pred_cb[yy * c + xx] = rd(pic->bufferCb, ((originY >> 1) + yy) * pic->strideCb + (originX >> 1) + xx, bps);
+            r->pred_cr[yy * c + xx] = rd(pic->bufferCr, ((originY >> 1) + yy) * pic->strideCr + (originX >> 1) + xx, bps);
+        }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_file);
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+    return rc;
+}
+
+#define GEN_ARGS EB_BOOL a, EB_BOOL b, EB_U32 c, EB_U32 d, EB_U32 e, EB_U32 f, EB_U32 g, NeighborArrayUnit_t *h, NeighborArrayUnit_t *i, \
+                 NeighborArrayUnit_t *j, NeighborArrayUnit_t *k, void *l, EB_COLOR_FORMAT m, EB_BOOL n, EB_BOOL o, EB_BOOL p
+static EB_ERRORTYPE gen8(GEN_ARGS) { return gen_wrapper(0, a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p); }
+static EB_ERRORTYPE gen16(GEN_ARGS) { return gen_wrapper(1, a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p); }
+#define PRED_ARGS void *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_U32 e, EbPictureBufferDesc_t *f, EB_COLOR_FORMAT g, EB_BOOL h, EB_U32 i, EB_U32 j, EB_U32 k
+static EB_ERRORTYPE pred8(PRED_ARGS) { return pred_wrapper(0, a, b, c, d, e, f, g, h, i, j, k); }
+static EB_ERRORTYPE pred16(PRED_ARGS) { return pred_wrapper(1, a, b, c, d, e, f, g, h, i, j, k); }
+
+__attribute__((constructor)) static void install(void)
+{
+    g_gen[0] = GenerateIntraReferenceSamplesFuncTable[0], g_gen[1] = GenerateIntraReferenceSamplesFuncTable[1];
+    g_pred[0] = EncodePassIntraPredictionFuncTable[0], g_pred[1] = EncodePassIntraPredictionFuncTable[1];
+    GenerateIntraReferenceSamplesFuncTable[0] = gen8, GenerateIntraReferenceSamplesFuncTable[1] = gen16;
+    EncodePassIntraPredictionFuncTable[0] = pred8, EncodePassIntraPredictionFuncTable[1] = pred16;
+}

@@ -105,6 +105,9 @@ enum {
  * angular kernels; stride in samples */
 void svt_oracle_IntraPred(int mode, int bps, uint32_t size, const void *ref, void *pred, uint32_t stride, int skip,
                           int32_t intraPredAngle);
+/* encode-pass intra prediction of one prediction unit from neighbour-array slices (composite, see svt_oracle_intra.c) */
+void svt_oracle_intra_pu(int bps, const SvtAmdIntraPuJob *job, void *pred_y, uint32_t strideY, void *pred_cb, void *pred_cr,
+                         uint32_t strideC);
 
 /* ---- in-loop filters and bit-depth packing leaves (bps: 1 = 8-bit kernels, 2 = *16bit kernels) ---- */
 void svt_oracle_Luma4SampleEdgeDLFCore(int bps, void *edge, uint32_t stride, int isVerticalEdge, int32_t tc, int32_t beta);

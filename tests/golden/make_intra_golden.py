@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generate the encode-pass intra-prediction golden fixtures from the REFERENCE itself.
+
+Runs oracle/_ref/SvtHevcEncApp_ref on seeded clips with SVT_REF_INTRA_DUMP set, so the table-slot interposers of
+oracle/ref_harness_intra_dump.c record a sample of the GenerateIntraReferenceSamplesEncodePass + EncodePassIntraPrediction
+call pairs of the real encode pass: neighbour-array slices and flags in, the three predicted blocks out.
+Stored as tests/golden/intra_<name>.npz.  Needs /root/reference (this container only).
+Usage: python tests/golden/make_intra_golden.py [name ...]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import svtlib as S  # noqa: E402
+
+REC = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("size", "<u4"), ("bytes_per_sample", "<u4"),
+                ("constrained_intra", "u1"), ("strong_smoothing", "u1"), ("pic_left", "u1"), ("pic_top", "u1"), ("pic_right", "u1"),
+                ("bottom_left_ok", "u1"), ("top_right_ok", "u1"), ("pad0", "u1"), ("luma_mode", "<u4"), ("chroma_mode", "<u4"),
+                ("component_mask", "<u4"), ("pad1", "<u4"), ("mode_left", "u1", 32), ("mode_top", "u1", 32), ("mode_tl", "u1"),
+                ("pad2", "u1", 7), ("left", "<u2", (3, 128)), ("top", "<u2", (3, 128)), ("tl", "<u2", 3), ("pad3", "<u2"),
+                ("pred_y", "<u2", 4096), ("pred_cb", "<u2", 1024), ("pred_cr", "<u2", 1024)])
+
+# name -> (clip kind, width, height, frames, seed, bit depth, encoder args, sampling stride, records kept)
+CASES = {
+    "i_416x240_m9": ("motion", 416, 240, 2, 7, 8, ["-encMode", "9", "-intra-period", "0"], 1, 260),
+    "i_noise_200x136_m5": ("noise", 200, 136, 2, 11, 8, ["-encMode", "5", "-intra-period", "0", "-q", "28"], 3, 260),
+    "p_noise_320x256_m6": ("noise", 320, 256, 3, 11, 8, ["-encMode", "6", "-pred-struct", "0", "-q", "25"], 2, 200),
+    "i10_416x240_m7": ("motion", 416, 240, 2, 7, 10, ["-encMode", "7", "-intra-period", "0", "-bit-depth", "10"], 1, 200),
+    "i_tiles_640x384_m9": ("motion", 640, 384, 2, 7, 8, ["-encMode", "9", "-intra-period", "0", "-tile_row_cnt", "2", "-tile_col_cnt", "2"], 2, 200),
+    "p_cip_noise_320x256_m6": ("noise", 320, 256, 4, 11, 8, ["-encMode", "6", "-pred-struct", "0", "-q", "25", "-constrd-intra", "1"], 2, 200),
+}
+KEEP = ("size", "bytes_per_sample", "constrained_intra", "strong_smoothing", "pic_left", "pic_top", "pic_right", "bottom_left_ok",
+        "top_right_ok", "luma_mode", "chroma_mode", "mode_left", "mode_top", "mode_tl", "left", "top", "tl")
+
+
+def run_case(name):
+    kind, w, h, n, seed, depth, args, stride, keep = CASES[name]
+    with tempfile.TemporaryDirectory() as td:
+        yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "intra.dump")
+        (S.write_clip10 if depth == 10 else S.write_clip)(yuv, kind, w, h, n, seed)
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-q", "32", "-asm", "0",
+               "-b", os.path.join(td, "out.265")] + args
+        subprocess.run(cmd, env=dict(os.environ, SVT_REF_INTRA_DUMP=dump, SVT_REF_INTRA_STRIDE=str(stride)), check=True,
+                       stdout=subprocess.DEVNULL)
+        recs = np.fromfile(dump, dtype=REC)
+    assert len(recs) and (recs["record_size"] == REC.itemsize).all(), (len(recs), REC.itemsize)
+    order = np.lexsort((recs["luma_mode"], recs["size"]))
+    sel = order[np.linspace(0, len(order) - 1, min(keep, len(order))).astype(int)]
+    recs = recs[np.sort(np.unique(sel))]
+    out = {k: recs[k] for k in KEEP}
+    out["pred_y"] = np.concatenate([r["pred_y"][: int(r["size"]) ** 2] for r in recs])
+    out["pred_cb"] = np.concatenate([r["pred_cb"][: (int(r["size"]) // 2) ** 2] for r in recs])
+    out["pred_cr"] = np.concatenate([r["pred_cr"][: (int(r["size"]) // 2) ** 2] for r in recs])
+    path = os.path.join(S.GOLDEN_DIR, "intra_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    sizes, cnt = np.unique(recs["size"], return_counts=True)
+    print("%-26s %d records (sizes %s) -> %s (%.0f KiB); %d luma modes, edges L/T/R %d/%d/%d, bl/tr ok %d/%d, inter neighbours %d, cip %d" %
+          (name, len(recs), dict(zip(sizes.tolist(), cnt.tolist())), os.path.basename(path), os.path.getsize(path) / 1024,
+           len(np.unique(recs["luma_mode"])), int(recs["pic_left"].sum()), int(recs["pic_top"].sum()), int(recs["pic_right"].sum()),
+           int(recs["bottom_left_ok"].sum()), int(recs["top_right_ok"].sum()),
+           int(((recs["mode_left"] == 1).any(axis=1) | (recs["mode_top"] == 1).any(axis=1)).sum()), int(recs["constrained_intra"].sum())))
+
+
+if __name__ == "__main__":
+    if not os.path.exists(S.REF_APP):
+        sys.exit("oracle/_ref/SvtHevcEncApp_ref missing: run `make -C oracle ref` (needs /root/reference)")
+    for nm in (sys.argv[1:] or list(CASES)):
+        run_case(nm)
