@@ -29,6 +29,9 @@
 #include "EbModeDecisionProcess.h"
 #include "EbModeDecision.h"
 #include "EbFullLoop.h"
+#include "EbNeighborArrays.h"
+#include "EbIntraPrediction.h"
+#include "EbAvailability.h"
 #include "EbEncDecProcess.h"
 #include "EbCodingUnit.h"
 #include "EbTransformUnit.h"
@@ -488,6 +491,104 @@ __attribute__((constructor)) static void recon_install(void)
         return;
     g_recon_real[0] = EncodeGenerateReconFunctionPtr[0], g_recon_real[1] = EncodeGenerateReconFunctionPtr[1];
     EncodeGenerateReconFunctionPtr[0] = recon8, EncodeGenerateReconFunctionPtr[1] = recon16;
+}
+
+/*
+ * Encode-pass intra prediction of a prediction unit: GenerateIntraReferenceSamplesEncodePass (+16bit) and
+ * EncodePassIntraPrediction (+16bit) are reached through the global tables GenerateIntraReferenceSamplesFuncTable[2] /
+ * EncodePassIntraPredictionFuncTable[2] (EbCodingLoop.c:1814, :1832).  With SVT_HOOK_INTRA=1 both slots are replaced: the
+ * first cuts the slices of the neighbour arrays the unit can see into an SvtAmdIntraPuJob (and still lets the reference
+ * build its arrays, which nothing reads afterwards), the second answers with svt_amd_intra_pu() - availability,
+ * substitution, smoothing, mode dispatch and the three predicted blocks all come from the device.  4:2:0, units of 8..32.
+ */
+typedef EB_ERRORTYPE (*IntraGenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
+                                   NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_COLOR_FORMAT, EB_BOOL, EB_BOOL, EB_BOOL);
+typedef EB_ERRORTYPE (*IntraPredFn)(void *, EB_U32, EB_U32, EB_U32, EB_U32, EbPictureBufferDesc_t *, EB_COLOR_FORMAT, EB_BOOL, EB_U32,
+                                    EB_U32, EB_U32);
+extern IntraGenFn GenerateIntraReferenceSamplesFuncTable[2];
+extern IntraPredFn EncodePassIntraPredictionFuncTable[2];
+static IntraGenFn g_intra_gen[2];
+static IntraPredFn g_intra_pred[2];
+static unsigned long g_intra_gpu;
+static __thread SvtAmdIntraPuJob t_intra_job;
+static __thread void *t_intra_for; /* reference-sample object the stashed job belongs to */
+
+static uint16_t na_rd(const uint8_t *a, uint32_t i, int bps) { return bps == 1 ? a[i] : ((const uint16_t *)a)[i]; }
+
+static EB_ERRORTYPE intra_gen(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                              EB_U32 cuDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *y, NeighborArrayUnit_t *cb,
+                              NeighborArrayUnit_t *cr, void *ref, EB_COLOR_FORMAT cf, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
+{
+    t_intra_for = NULL;
+    if (g_ctx && cf == EB_YUV420 && size >= 8 && size <= 32) {
+        SvtAmdIntraPuJob *j = &t_intra_job;
+        const int bps = is16 ? 2 : 1;
+        memset(j, 0, sizeof(*j));
+        j->size = size, j->constrained_intra = constrained, j->strong_smoothing = strong;
+        j->pic_left = pl, j->pic_top = pt, j->pic_right = pr;
+        uint32_t lg = 0;
+        while ((1u << lg) < size)
+            lg++;
+        const uint32_t cuIndex = ((originY & (lcuSize - 1)) >> lg) * (1u << cuDepth) + ((originX & (lcuSize - 1)) >> lg);
+        j->bottom_left_ok = isBottomLeftAvailable(cuDepth, cuIndex), j->top_right_ok = isUpperRightAvailable(cuDepth, cuIndex);
+        for (uint32_t k = 0; k < 2 * size / 4; k++) {
+            const uint32_t li = GetNeighborArrayUnitLeftIndex(mode, originY + 4 * k), ti = GetNeighborArrayUnitTopIndex(mode, originX + 4 * k);
+            j->mode_left[k] = li >= mode->leftArraySize ? 0xFE : mode->leftArray[li];
+            j->mode_top[k] = ti >= mode->topArraySize ? 0xFE : mode->topArray[ti];
+        }
+        j->mode_tl = mode->topLeftArray[GetNeighborArrayUnitTopLeftIndex(mode, (EB_S32)originX, (EB_S32)originY)];
+        NeighborArrayUnit_t *na[3] = {y, cb, cr};
+        for (int p = 0; p < 3; p++) {
+            const uint32_t sh = p ? 1 : 0, n2 = (2 * size) >> sh, ox = originX >> sh, oy = originY >> sh;
+            for (uint32_t i = 0; i < n2; i++) {
+                const uint32_t k = (i << sh) >> 2;
+                j->left[p][i] = j->mode_left[k] == 0xFE ? 0 : na_rd(na[p]->leftArray, oy + i, bps);
+                j->top[p][i] = j->mode_top[k] == 0xFE ? 0 : na_rd(na[p]->topArray, ox + i, bps);
+            }
+            j->tl[p] = p == 0 ? na_rd(y->topLeftArray, MAX_PICTURE_HEIGHT_SIZE + originX - originY, bps)
+                              : na_rd(na[p]->topLeftArray, ((MAX_PICTURE_HEIGHT_SIZE - originY) >> 1) + (originX >> 1), bps);
+        }
+        t_intra_for = ref;
+    }
+    return g_intra_gen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, cf, pl, pt, pr);
+}
+
+static EB_ERRORTYPE intra_pred(int is16, void *ref, EB_U32 originX, EB_U32 originY, EB_U32 puSize, EB_U32 puChromaSize,
+                               EbPictureBufferDesc_t *pic, EB_COLOR_FORMAT cf, EB_BOOL second, EB_U32 lumaMode, EB_U32 chromaMode,
+                               EB_U32 mask)
+{
+    void *stash = t_intra_for;
+    t_intra_for = NULL;
+    if (!stash || stash != ref || puSize != t_intra_job.size || second || mask != PICTURE_BUFFER_DESC_FULL_MASK || lumaMode > 34)
+        return g_intra_pred[is16](ref, originX, originY, puSize, puChromaSize, pic, cf, second, lumaMode, chromaMode, mask);
+    const size_t bps = is16 ? 2 : 1;
+    t_intra_job.luma_mode = (uint8_t)lumaMode, t_intra_job.chroma_mode = (uint8_t)chromaMode;
+    pthread_mutex_lock(&g_lock);
+    if (svt_amd_intra_pu(g_ctx, (int)bps, &t_intra_job, pic->bufferY + ((size_t)originY * pic->strideY + originX) * bps, pic->strideY,
+                         pic->bufferCb + ((size_t)(originY >> 1) * pic->strideCb + (originX >> 1)) * bps,
+                         pic->bufferCr + ((size_t)(originY >> 1) * pic->strideCr + (originX >> 1)) * bps, pic->strideCb))
+        die("svt_amd_intra_pu");
+    if (g_intra_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: encode-pass intra prediction (reference samples + prediction) on the GPU\n");
+    pthread_mutex_unlock(&g_lock);
+    return EB_ErrorNone;
+}
+
+#define IGEN_ARGS EB_BOOL a, EB_BOOL b, EB_U32 c, EB_U32 d, EB_U32 e, EB_U32 f, EB_U32 g, NeighborArrayUnit_t *h, NeighborArrayUnit_t *i, \
+                  NeighborArrayUnit_t *j, NeighborArrayUnit_t *k, void *l, EB_COLOR_FORMAT m, EB_BOOL n, EB_BOOL o, EB_BOOL p
+static EB_ERRORTYPE intra_gen8(IGEN_ARGS) { return intra_gen(0, a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p); }
+static EB_ERRORTYPE intra_gen16(IGEN_ARGS) { return intra_gen(1, a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p); }
+#define IPRED_ARGS void *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_U32 e, EbPictureBufferDesc_t *f, EB_COLOR_FORMAT g, EB_BOOL h, EB_U32 i, EB_U32 j, EB_U32 k
+static EB_ERRORTYPE intra_pred8(IPRED_ARGS) { return intra_pred(0, a, b, c, d, e, f, g, h, i, j, k); }
+static EB_ERRORTYPE intra_pred16(IPRED_ARGS) { return intra_pred(1, a, b, c, d, e, f, g, h, i, j, k); }
+__attribute__((constructor)) static void intra_install(void)
+{
+    if (!getenv("SVT_HOOK_INTRA"))
+        return;
+    g_intra_gen[0] = GenerateIntraReferenceSamplesFuncTable[0], g_intra_gen[1] = GenerateIntraReferenceSamplesFuncTable[1];
+    g_intra_pred[0] = EncodePassIntraPredictionFuncTable[0], g_intra_pred[1] = EncodePassIntraPredictionFuncTable[1];
+    GenerateIntraReferenceSamplesFuncTable[0] = intra_gen8, GenerateIntraReferenceSamplesFuncTable[1] = intra_gen16;
+    EncodePassIntraPredictionFuncTable[0] = intra_pred8, EncodePassIntraPredictionFuncTable[1] = intra_pred16;
 }
 
 static void hook_report(void)

@@ -11,6 +11,7 @@
  * for the two generic angular kernels `main_offset` selects refSampMain inside the block's array.
  */
 #include "leaf_util.h"
+#include <cstring>
 
 enum { IM_VERT_LUMA = 0, IM_VERT_CHROMA, IM_HOR_LUMA, IM_HOR_CHROMA, IM_DC_LUMA, IM_DC_CHROMA, IM_PLANAR,
        IM_ANG34, IM_ANG18, IM_ANG2, IM_ANG_VERT, IM_ANG_HOR, IM_COUNT };
@@ -168,3 +169,213 @@ INTRA_ANG_LEAF(IntraModeAngular_Vertical_Kernel, uint8_t, IM_ANG_VERT)
 INTRA_ANG_LEAF(IntraModeAngular16bit_Vertical_Kernel, uint16_t, IM_ANG_VERT)
 INTRA_ANG_LEAF(IntraModeAngular_Horizontal_Kernel, uint8_t, IM_ANG_HOR)
 INTRA_ANG_LEAF(IntraModeAngular16bit_Horizontal_Kernel, uint16_t, IM_ANG_HOR)
+
+/* ------------------------------------------------------------------------- */
+/* Encode-pass intra prediction of a prediction unit from its neighbours      */
+/* ------------------------------------------------------------------------- */
+/* GenerateIntraReferenceSamplesEncodePass (Codec/EbIntraPrediction.c:212-757, 16-bit :760) + EncodePassIntraPrediction
+ * (:4395, 16-bit :4680), fused: one workgroup per unit.  Phase 1 (one thread per neighbour sample): availability of the
+ * 4-sample groups, substitution (every missing sample takes the nearest available one before it in scan order, the
+ * leading run the first available one).  Phase 2: [1 2 1] / bilinear smoothing of the luma reference.  Phase 3 (one
+ * thread per predicted sample, all three planes): H.265 8.4.4.2 prediction from the chosen reference in LDS.
+ * Nothing but the job record is read from HBM and nothing but the prediction is written. */
+struct IntraPuJob {                       /* = SvtAmdIntraPuJob */
+    uint32_t size;
+    uint8_t constrained_intra, strong_smoothing, pic_left, pic_top, pic_right, bottom_left_ok, top_right_ok, luma_mode, chroma_mode,
+        mode_tl, mode_left[16], mode_top[16], pad[2];
+    uint16_t left[3][64], top[3][64], tl[3], pad2;
+    int32_t dst_off_y, dst_off_c;
+};
+__constant__ int8_t c_pu_ang[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+__constant__ int16_t c_pu_inv[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+
+/* r: left[0..2N-1] top to bottom, r[2N] top-left, r[2N+1+j] top[j] */
+__device__ __forceinline__ int pu_predict(int mode, int N, int lg, const int16_t *r, int x, int y, int dc, bool lumaEdge, int maxv)
+{
+    const int16_t *left = r, *top = r + 2 * N + 1;
+    const int tl = r[2 * N];
+    if (mode == 0)
+        return ((N - 1 - x) * left[y] + (x + 1) * top[N] + (N - 1 - y) * top[x] + (y + 1) * left[N] + N) >> (lg + 1);
+    if (mode == 1) {
+        if (lumaEdge && N < 32) {
+            if (x == 0 && y == 0)
+                return (left[0] + top[0] + 2 * dc + 2) >> 2;
+            if (y == 0)
+                return (top[x] + 3 * dc + 2) >> 2;
+            if (x == 0)
+                return (left[y] + 3 * dc + 2) >> 2;
+        }
+        return dc;
+    }
+    if (mode == 26)
+        return (lumaEdge && N < 32 && x == 0) ? min(maxv, max(0, top[0] + ((left[y] - tl) >> 1))) : (int)top[x];
+    if (mode == 10)
+        return (lumaEdge && N < 32 && y == 0) ? min(maxv, max(0, left[0] + ((top[x] - tl) >> 1))) : (int)left[y];
+    const bool vert = mode >= 18;
+    const int d = vert ? mode - 26 : 10 - mode;
+    const int a = d < 0 ? -c_pu_ang[-d] : c_pu_ang[d];
+    const int u = vert ? x : y, v = vert ? y : x;
+    const int16_t *mainr = vert ? top : left, *side = vert ? left : top;
+    const int pos = (v + 1) * a, i = pos >> 5, f = pos & 31;
+    int s[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int idx = u + i + 1 + k;
+        s[k] = idx > 0 ? mainr[idx - 1] : idx == 0 ? tl : side[((-idx * c_pu_inv[-d] + 128) >> 8) - 1];
+    }
+    return ((32 - f) * s[0] + f * s[1] + 16) >> 5;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_intra_pu(const IntraPuJob *__restrict__ jobs, T *__restrict__ pred_y, uint32_t strideY,
+                                                  T *__restrict__ pred_cb, T *__restrict__ pred_cr, uint32_t strideC)
+{
+    constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, mid = sizeof(T) == 1 ? 128 : 512, thr = sizeof(T) == 1 ? 8 : 32;
+    __shared__ int16_t border[3][132]; /* scan order: bottom-left ... top-left ... top-right */
+    __shared__ int16_t ref[3][132];    /* left top-to-bottom, top-left, top: what the prediction reads */
+    __shared__ uint8_t ok[36];         /* availability of the 4-sample groups in scan order */
+    __shared__ int s_first, s_dc[3], s_mode[3];
+    const IntraPuJob &J = jobs[blockIdx.x];
+    const int t = threadIdx.x, N = (int)J.size, nb = N >> 2, lgN = 31 - __clz(N);
+    if (t <= 4 * nb) {
+        bool a;
+        if (t < 2 * nb) { /* left group t covers rows [2N-4-4t, 2N-4t) */
+            const int e = J.mode_left[(2 * N - 4 - 4 * t) >> 2];
+            a = !(e == 0xFE || (!J.bottom_left_ok && t < nb) || e == 0xFF || J.pic_left || (e == 1 && J.constrained_intra));
+        } else if (t == 2 * nb) {
+            a = !(J.mode_tl == 0xFF || J.pic_left || J.pic_top || (J.mode_tl == 1 && J.constrained_intra));
+        } else {
+            const int k = t - 2 * nb - 1, e = J.mode_top[k];
+            a = !(e == 0xFE || (!J.top_right_ok && k >= nb) || e == 0xFF || J.pic_top || (J.pic_right && k >= nb) ||
+                  (e == 1 && J.constrained_intra));
+        }
+        ok[t] = a;
+    }
+    if (t == 0)
+        s_first = 1 << 30;
+    __syncthreads();
+    if (t <= 4 * nb && ok[t])
+        atomicMin(&s_first, t);
+    __syncthreads();
+    const int firstGroup = s_first;
+    /* substitution, one thread per (plane, sample in scan order) */
+    for (int i = t; i < 3 * 129; i += 256) {
+        const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N, g = p ? 2 : 4;
+        if (k > 4 * n)
+            continue;
+        int v = mid;
+        if (firstGroup < (1 << 30)) {
+            /* group of sample k in scan order: [0, 2n) left, 2n top-left, (2n, 4n] top */
+            auto group_of = [&](int kk) { return kk < 2 * n ? kk / g : kk == 2 * n ? 2 * nb : 2 * nb + 1 + (kk - 2 * n - 1) / g; };
+            int src = k;
+            while (src >= 0 && !ok[group_of(src)])
+                src--;
+            if (src < 0) { /* leading run: first sample of the first available group */
+                src = firstGroup < 2 * nb ? firstGroup * g : firstGroup == 2 * nb ? 2 * n : 2 * n + 1 + (firstGroup - 2 * nb - 1) * g;
+            }
+            v = src < 2 * n ? J.left[p][2 * n - 1 - src] : src == 2 * n ? J.tl[p] : J.top[p][src - 2 * n - 1];
+        }
+        border[p][k] = (int16_t)v;
+    }
+    __syncthreads();
+    /* reference choice per plane */
+    int lmode = J.luma_mode;
+    const int cm = J.chroma_mode;
+    const int cmode = cm == 0 ? 0 : cm == 1 ? 26 : cm == 2 ? 10 : cm == 3 ? 1 : lmode;
+    const int dA = abs(lmode - 10), dB = abs(lmode - 26), dm = dA < dB ? dA : dB;
+    const int thrTab = lgN == 2 ? 35 : lgN == 3 ? 7 : lgN == 4 ? 1 : lgN == 5 ? 0 : 10; /* intraLumaFilterTable */
+    const bool filt = dm > thrTab && lmode != 1;
+    const int bl = border[0][0], tlv = border[0][2 * N], tr = border[0][4 * N];
+    const bool strong = J.strong_smoothing && N >= 32 && abs(bl + tlv - 2 * border[0][N]) < thr &&
+                        abs(tlv + tr - 2 * border[0][3 * N]) < thr;
+    for (int i = t; i < 3 * 129; i += 256) {
+        const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N;
+        if (k > 4 * n)
+            continue;
+        int v = border[p][k];
+        if (p == 0 && filt) {
+            if (strong) {
+                if (k > 0 && k < 2 * n)
+                    v = ((2 * n - k) * bl + k * tlv + n) >> (lgN + 1);
+                else if (k > 2 * n && k < 4 * n)
+                    v = ((2 * n - (k - 2 * n)) * tlv + (k - 2 * n) * tr + n) >> (lgN + 1);
+            } else if (k > 0 && k < 4 * n) {
+                v = (border[0][k - 1] + 2 * v + border[0][k + 1] + 2) >> 2;
+            }
+        }
+        /* scan order -> left top-to-bottom | top-left | top */
+        ref[p][k < 2 * n ? 2 * n - 1 - k : k] = (int16_t)v;
+    }
+    __syncthreads();
+    if (t < 3) {
+        const int n = t ? N >> 1 : N;
+        int dc = 0;
+        for (int i = 0; i < n; i++)
+            dc += ref[t][i] + ref[t][2 * n + 1 + i];
+        s_dc[t] = (dc + n) >> ((t ? lgN - 1 : lgN) + 1);
+        s_mode[t] = t ? cmode : lmode;
+    }
+    __syncthreads();
+    const int nY = N * N, nC = nY >> 2;
+    for (int i = t; i < nY + 2 * nC; i += 256) {
+        const int p = i < nY ? 0 : (i < nY + nC ? 1 : 2), e = p == 0 ? i : (p == 1 ? i - nY : i - nY - nC);
+        const int n = p ? N >> 1 : N, lg = p ? lgN - 1 : lgN, y = e >> lg, x = e & (n - 1);
+        const int v = pu_predict(s_mode[p], n, lg, ref[p], x, y, s_dc[p], p == 0, maxv);
+        if (p == 0)
+            pred_y[J.dst_off_y + (size_t)y * strideY + x] = (T)v;
+        else
+            (p == 1 ? pred_cb : pred_cr)[J.dst_off_c + (size_t)y * strideC + x] = (T)v;
+    }
+}
+
+extern "C" int svt_amd_intra_pu_batch(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *d_jobs, uint32_t njobs,
+                                      void *d_pred_y, uint32_t strideY, void *d_pred_cb, void *d_pred_cr, uint32_t strideC)
+{
+    static_assert(sizeof(IntraPuJob) == sizeof(SvtAmdIntraPuJob), "job layout");
+    if (!ctx || !d_jobs || !njobs || !d_pred_y || !d_pred_cb || !d_pred_cr || (bytes_per_sample != 1 && bytes_per_sample != 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes_per_sample == 1)
+        hipLaunchKernelGGL(k_intra_pu<uint8_t>, dim3(njobs), dim3(256), 0, ctx->stream, (const IntraPuJob *)d_jobs, (uint8_t *)d_pred_y,
+                           strideY, (uint8_t *)d_pred_cb, (uint8_t *)d_pred_cr, strideC);
+    else
+        hipLaunchKernelGGL(k_intra_pu<uint16_t>, dim3(njobs), dim3(256), 0, ctx->stream, (const IntraPuJob *)d_jobs, (uint16_t *)d_pred_y,
+                           strideY, (uint16_t *)d_pred_cb, (uint16_t *)d_pred_cr, strideC);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* host-pointer form for one unit: job up, the three blocks back (the binding of the two table slots); blocking */
+extern "C" int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *job, void *pred_y, uint32_t strideY,
+                                void *pred_cb, void *pred_cr, uint32_t strideC)
+{
+    if (!ctx || !job || !pred_y || !pred_cb || !pred_cr || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
+        (job->size != 8 && job->size != 16 && job->size != 32) || strideY < job->size || strideC < job->size / 2)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    static uint8_t *d_scratch = nullptr; /* job | Y 32x32 | Cb 16x16 | Cr 16x16 (16-bit worst case) */
+    const size_t o_job = 0, o_y = 1024, o_cb = o_y + 2048, o_cr = o_cb + 512, total = o_cr + 512;
+    if (!d_scratch)
+        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    SvtAmdIntraPuJob j = *job;
+    j.dst_off_y = 0, j.dst_off_c = 0;
+    const uint32_t N = job->size, C = N / 2;
+    const size_t bps = (size_t)bytes_per_sample;
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_job, &j, sizeof(j), hipMemcpyHostToDevice, ctx->stream));
+    int rc = svt_amd_intra_pu_batch(ctx, bytes_per_sample, (const SvtAmdIntraPuJob *)(d_scratch + o_job), 1, d_scratch + o_y, N,
+                                    d_scratch + o_cb, d_scratch + o_cr, C);
+    if (rc)
+        return rc;
+    uint8_t hy[2048], hcb[512], hcr[512];
+    HIP_TRY(hipMemcpyAsync(hy, d_scratch + o_y, (size_t)N * N * bps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hcb, d_scratch + o_cb, (size_t)C * C * bps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hcr, d_scratch + o_cr, (size_t)C * C * bps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t y = 0; y < N; y++)
+        ::memcpy((uint8_t *)pred_y + (size_t)y * strideY * bps, hy + (size_t)y * N * bps, (size_t)N * bps);
+    for (uint32_t y = 0; y < C; y++) {
+        ::memcpy((uint8_t *)pred_cb + (size_t)y * strideC * bps, hcb + (size_t)y * C * bps, (size_t)C * bps);
+        ::memcpy((uint8_t *)pred_cr + (size_t)y * strideC * bps, hcr + (size_t)y * C * bps, (size_t)C * bps);
+    }
+    return SVT_AMD_OK;
+}

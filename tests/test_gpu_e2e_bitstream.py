@@ -123,3 +123,31 @@ def test_bitstream_and_recon_identical_with_gpu_reconstruction(tmp_path, kind, w
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
+
+
+INTRA_CASES = [
+    ("motion", 416, 240, 3, ["-encMode", "9", "-intra-period", "0"]),
+    ("noise", 320, 256, 4, ["-encMode", "6", "-pred-struct", "0", "-q", "25", "-constrd-intra", "1"]),   # intra CUs among inter ones
+    ("motion10", 416, 240, 2, ["-encMode", "7", "-intra-period", "0", "-bit-depth", "10"]),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", INTRA_CASES)
+def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind, w, h, n, args):
+    """The encode pass's intra prediction of every 8..32 prediction unit (reference-sample generation with availability,
+    substitution and smoothing + the prediction itself) answered by svt_amd_intra_pu (SVT_HOOK_INTRA=1)."""
+    yuv = str(tmp_path / "clip.yuv")
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    os.environ["SVT_HOOK_INTRA"] = "1"
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        del os.environ["SVT_HOOK_INTRA"]
+    assert "svt_hook_me: encode-pass intra prediction (reference samples + prediction) on the GPU" in log, log[-1000:]
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
+    a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
+    assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
