@@ -695,6 +695,34 @@ SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost
                                        SvtAmdFullLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
+/* Encode-pass inter prediction of prediction units                            */
+/* ------------------------------------------------------------------------- */
+/* Replaces EncodePassInterPrediction (Codec/EbInterPrediction.c:761-926, called per prediction unit from
+ * EbCodingLoop.c:3932) with its EncodeUniPredInterpolation / EncodeBiPredInterpolation (Codec/EbMcp.c:175-250, :562-760)
+ * for 8-bit 4:2:0: clamp of the quarter-sample position to the padded picture (:802-812), split into integer and
+ * fractional parts for luma (1/4) and chroma (1/8), the HEVC interpolation of the three planes and, for bi-prediction,
+ * the average of the two 14-bit intermediates.  Reference pictures are whole padded pictures resident in HBM. */
+typedef struct SvtAmdRefPicture {
+    const void *d_y, *d_cb, *d_cr;     /* device pointers to the START of the padded buffers (not to sample (0,0))  */
+    uint32_t strideY, strideC;         /* in samples                                                               */
+    uint32_t originX, originY;         /* luma padding: sample (0,0) is at originX + originY*strideY               */
+    uint32_t width, height;            /* luma                                                                     */
+} SvtAmdRefPicture;
+typedef struct SvtAmdInterPuJob {
+    int16_t  mv[2][2];                 /* [list][x, y] in quarter samples                                          */
+    uint16_t pu_x, pu_y;               /* luma position of the unit in the picture                                 */
+    uint8_t  pu_w, pu_h;               /* 8 .. 64                                                                  */
+    uint8_t  pred_dir;                 /* UNI_PRED_LIST_0 0, UNI_PRED_LIST_1 1, BI_PRED 2                          */
+    uint8_t  pad;
+    int32_t  dst_off_y, dst_off_c;     /* sample offsets of the unit inside the destination planes                 */
+} SvtAmdInterPuJob;
+/* BATCHED: `jobs` is a HOST array (the call derives the per-plane interpolation lists from it and uploads them);
+ * reference pictures and destination planes are device memory.  ref1 may be NULL when no job uses list 1. */
+SVT_AMD_API int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs,
+                                       const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint8_t *d_pred_y,
+                                       uint32_t strideY, uint8_t *d_pred_cb, uint8_t *d_pred_cr, uint32_t strideC);
+
+/* ------------------------------------------------------------------------- */
 /* Encode-pass intra prediction of a prediction unit from its neighbours      */
 /* ------------------------------------------------------------------------- */
 /* Replaces the pair GenerateIntraReferenceSamplesEncodePass (Codec/EbIntraPrediction.c:212-757; 16-bit twin :760-1300)

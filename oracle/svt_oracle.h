@@ -188,6 +188,9 @@ void svt_oracle_mcp(int bps, int chroma, int out_raw, uint32_t fx, uint32_t fy, 
                     void *dst, uint32_t dstStride, uint32_t w, uint32_t h);
 void svt_oracle_BiPredClipping(int bps, uint32_t w, uint32_t h, const int16_t *l0, const int16_t *l1, void *dst,
                                uint32_t dstStride, int32_t offset);
+/* encode-pass inter prediction of one prediction unit, 8-bit 4:2:0 (composite of the two above) */
+void svt_oracle_inter_pu(const SvtAmdInterPuJob *job, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint8_t *pred_y,
+                         uint32_t strideY, uint8_t *pred_cb, uint8_t *pred_cr, uint32_t strideC);
 
 /* ---- ComputeDecimatedZzSad (svt_oracle_zz.c); cur/prev point at sample (0,0) of the two source pictures ---- */
 void svt_oracle_zz_sad_picture(const uint8_t *cur, const uint8_t *prev, uint32_t stride, uint32_t width, uint32_t height,
