@@ -200,6 +200,11 @@ SVT_AMD_API int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmd
                                                 int cur_slot, const int ref_slot[2],
                                                 uint32_t lcu_begin, uint32_t lcu_end);
 SVT_AMD_API int svt_amd_synchronize(SvtAmdContext *ctx);
+/* plain device memory on the context's GPU for C hosts that keep reference pictures / planes resident (blocking copies) */
+SVT_AMD_API int svt_amd_device_alloc(SvtAmdContext *ctx, size_t bytes, void **d_ptr);
+SVT_AMD_API int svt_amd_device_free(SvtAmdContext *ctx, void *d_ptr);
+SVT_AMD_API int svt_amd_device_upload(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes);
+SVT_AMD_API int svt_amd_device_download(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes);
 
 /*
  * Open-loop intra search (OIS) of one whole picture: replaces the second LCU loop of

@@ -29,6 +29,7 @@
 #include "EbModeDecisionProcess.h"
 #include "EbModeDecision.h"
 #include "EbFullLoop.h"
+#include "EbInterPrediction.h"
 #include "EbNeighborArrays.h"
 #include "EbIntraPrediction.h"
 #include "EbAvailability.h"
@@ -589,6 +590,104 @@ __attribute__((constructor)) static void intra_install(void)
     g_intra_pred[0] = EncodePassIntraPredictionFuncTable[0], g_intra_pred[1] = EncodePassIntraPredictionFuncTable[1];
     GenerateIntraReferenceSamplesFuncTable[0] = intra_gen8, GenerateIntraReferenceSamplesFuncTable[1] = intra_gen16;
     EncodePassIntraPredictionFuncTable[0] = intra_pred8, EncodePassIntraPredictionFuncTable[1] = intra_pred16;
+}
+
+/*
+ * Encode-pass inter prediction: EncodePassInterPrediction (EbInterPrediction.c:761, called per prediction unit from
+ * EbCodingLoop.c:3932) is answered by svt_amd_inter_pu_batch() with SVT_HOOK_INTER=1 (8-bit 4:2:0).  Reference pictures
+ * stay resident in HBM: each (buffer, POC) pair is uploaded once, whole and padded, into a small cache of device copies.
+ */
+EB_ERRORTYPE __real_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
+                                              PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
+                                              MotionCompensationPredictionContext_t *mcpContext);
+#define REF_CACHE 8
+static struct RefSlot { const void *buf; uint64_t poc, used; void *d[3]; size_t bytes[3]; SvtAmdRefPicture pic; } g_refs[REF_CACHE];
+static uint64_t g_ref_clock;
+static void *g_inter_scratch[3]; /* device prediction planes: 64x64, 32x32, 32x32 */
+static unsigned long g_inter_gpu, g_inter_uploads;
+static int g_inter_state;
+
+/* must hold g_lock */
+static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p, uint64_t poc)
+{
+    struct RefSlot *victim = &g_refs[0];
+    for (int i = 0; i < REF_CACHE; i++) {
+        if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
+            g_refs[i].used = ++g_ref_clock;
+            return &g_refs[i].pic;
+        }
+        if (g_refs[i].used < victim->used)
+            victim = &g_refs[i];
+    }
+    const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
+    const size_t need[3] = {(size_t)rowsY * p->strideY, (size_t)rowsC * p->strideCb, (size_t)rowsC * p->strideCr};
+    const uint8_t *src[3] = {p->bufferY, p->bufferCb, p->bufferCr};
+    for (int k = 0; k < 3; k++) {
+        if (victim->bytes[k] < need[k]) {
+            if (victim->d[k] && svt_amd_device_free(g_ctx, victim->d[k]))
+                die("svt_amd_device_free");
+            if (svt_amd_device_alloc(g_ctx, need[k], &victim->d[k]))
+                die("svt_amd_device_alloc");
+            victim->bytes[k] = need[k];
+        }
+        if (svt_amd_device_upload(g_ctx, victim->d[k], src[k], need[k]))
+            die("svt_amd_device_upload");
+    }
+    victim->buf = p->bufferY, victim->poc = poc, victim->used = ++g_ref_clock;
+    victim->pic.d_y = victim->d[0], victim->pic.d_cb = victim->d[1], victim->pic.d_cr = victim->d[2];
+    victim->pic.strideY = p->strideY, victim->pic.strideC = p->strideCb, victim->pic.originX = p->originX, victim->pic.originY = p->originY;
+    victim->pic.width = p->width, victim->pic.height = p->height;
+    g_inter_uploads++;
+    return &victim->pic;
+}
+
+EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
+                                              PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
+                                              MotionCompensationPredictionContext_t *mcpContext)
+{
+    if (g_inter_state == 0)
+        g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
+    if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
+        puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr)
+        return __real_EncodePassInterPrediction(mvUnit, puOriginX, puOriginY, puWidth, puHeight, pcs, predictionPtr, mcpContext);
+    SvtAmdInterPuJob job;
+    memset(&job, 0, sizeof(job));
+    job.pu_x = puOriginX, job.pu_y = puOriginY, job.pu_w = puWidth, job.pu_h = puHeight, job.pred_dir = mvUnit->predDirection;
+    pthread_mutex_lock(&g_lock);
+    const SvtAmdRefPicture *refs[2] = {NULL, NULL};
+    SvtAmdRefPicture copy[2];
+    for (int l = 0; l < 2; l++) {
+        job.mv[l][0] = mvUnit->mv[l].x, job.mv[l][1] = mvUnit->mv[l].y;
+        if (mvUnit->predDirection == l || mvUnit->predDirection == BI_PRED) {
+            const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
+            copy[l] = *resident_reference(ro->referencePicture, ro->refPOC); /* the slot may be recycled by the other list */
+            refs[l] = &copy[l];
+        }
+    }
+    if (!g_inter_scratch[0])
+        for (int k = 0; k < 3; k++)
+            if (svt_amd_device_alloc(g_ctx, k ? 1024 : 4096, &g_inter_scratch[k]))
+                die("svt_amd_device_alloc");
+    if (svt_amd_inter_pu_batch(g_ctx, &job, 1, refs[0], refs[1], (uint8_t *)g_inter_scratch[0], puWidth, (uint8_t *)g_inter_scratch[1],
+                               (uint8_t *)g_inter_scratch[2], puWidth >> 1))
+        die("svt_amd_inter_pu_batch");
+    uint8_t hy[4096], hcb[1024], hcr[1024];
+    if (svt_amd_device_download(g_ctx, hy, g_inter_scratch[0], (size_t)puWidth * puHeight) ||
+        svt_amd_device_download(g_ctx, hcb, g_inter_scratch[1], (size_t)puWidth * puHeight / 4) ||
+        svt_amd_device_download(g_ctx, hcr, g_inter_scratch[2], (size_t)puWidth * puHeight / 4))
+        die("svt_amd_device_download");
+    if (g_inter_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU\n");
+    pthread_mutex_unlock(&g_lock);
+    const uint32_t oy = (predictionPtr->originY + puOriginY) * predictionPtr->strideY + predictionPtr->originX + puOriginX;
+    const uint32_t oc = (((predictionPtr->originY + puOriginY) * predictionPtr->strideCb) >> 1) + ((predictionPtr->originX + puOriginX) >> 1);
+    for (uint32_t y = 0; y < puHeight; y++)
+        memcpy(predictionPtr->bufferY + oy + y * predictionPtr->strideY, hy + y * puWidth, puWidth);
+    for (uint32_t y = 0; y < (uint32_t)(puHeight >> 1); y++) {
+        memcpy(predictionPtr->bufferCb + oc + y * predictionPtr->strideCb, hcb + y * (puWidth >> 1), puWidth >> 1);
+        memcpy(predictionPtr->bufferCr + oc + y * predictionPtr->strideCr, hcr + y * (puWidth >> 1), puWidth >> 1);
+    }
+    return EB_ErrorNone;
 }
 
 static void hook_report(void)

@@ -256,6 +256,43 @@ extern "C" int svt_amd_synchronize(SvtAmdContext *ctx)
     return SVT_AMD_OK;
 }
 
+/* ---- plain device memory for C hosts (reference pictures, prediction planes, job lists) ---- */
+extern "C" int svt_amd_device_alloc(SvtAmdContext *ctx, size_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr || !bytes)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_device_free(SvtAmdContext *ctx, void *d_ptr)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_device_upload(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || !d_dst || !src)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_device_download(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || !dst || !d_src)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
 /* ---- pictures ---------------------------------------------------------- */
 
 static int check_slot(SvtAmdContext *ctx, int slot)

@@ -259,3 +259,119 @@ extern "C" void svt_amd_BiPredClipping(uint32_t puWidth, uint32_t puHeight, int1
 extern "C" void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight, int16_t *list0Src, int16_t *list1Src,
                                             uint16_t *dst, uint32_t dstStride)
 { bipred_leaf<uint16_t>(puWidth, puHeight, list0Src, list1Src, dst, dstStride, 0); }
+
+/* ------------------------------------------------------------------------- */
+/* Encode-pass inter prediction of prediction units (driver over the kernels above) */
+/* ------------------------------------------------------------------------- */
+/* EncodePassInterPrediction (Codec/EbInterPrediction.c:761-926) with EncodeUniPredInterpolation /
+ * EncodeBiPredInterpolation (Codec/EbMcp.c:175-250, :562-760), 8-bit 4:2:0.  The host side only turns every unit into
+ * interpolation blocks (position clamp :802-812, integer / fractional split, chroma derivation) - a few integer
+ * operations per unit; all sample work runs in k_mcp / k_bipred_clip on lists of blocks: per reference list and plane one
+ * launch for the uni-predicted units (straight into the prediction planes), one for the 14-bit intermediates of the
+ * bi-predicted ones, then one averaging launch per plane. */
+#include <vector>
+
+static inline int clampi(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+
+extern "C" int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
+                                      const SvtAmdRefPicture *ref1, uint8_t *d_pred_y, uint32_t strideY, uint8_t *d_pred_cb,
+                                      uint8_t *d_pred_cr, uint32_t strideC)
+{
+    if (!ctx || !jobs || !njobs || !d_pred_y || !d_pred_cb || !d_pred_cr || (!ref0 && !ref1))
+        return SVT_AMD_ERR_BAD_PARAM;
+    const SvtAmdRefPicture *refs[2] = {ref0, ref1};
+    std::vector<McpBlock> uni[2][3], raw[2][3];
+    std::vector<BiBlock> bi[3];
+    size_t raw_len[3] = {0, 0, 0}; /* int16 per list and plane */
+    for (uint32_t i = 0; i < njobs; i++) {
+        const SvtAmdInterPuJob &J = jobs[i];
+        if (J.pred_dir > 2 || J.pu_w < 8 || J.pu_h < 8 || J.pu_w > 64 || J.pu_h > 64 || (J.pu_w & 1) || (J.pu_h & 1))
+            return SVT_AMD_ERR_BAD_PARAM;
+        const bool is_bi = J.pred_dir == 2;
+        for (int l = 0; l < 2; l++) {
+            if (!(is_bi || J.pred_dir == l))
+                continue;
+            const SvtAmdRefPicture *R = refs[l];
+            if (!R || !R->d_y || !R->d_cb || !R->d_cr)
+                return SVT_AMD_ERR_BAD_PARAM;
+            const int px = clampi(((int)R->originX - 71) << 2, (int)(R->width + R->originX + 7) << 2, (((int)J.pu_x + (int)R->originX) << 2) + J.mv[l][0]);
+            const int py = clampi(((int)R->originY - 71) << 2, (int)(R->height + R->originY + 7) << 2, (((int)J.pu_y + (int)R->originY) << 2) + J.mv[l][1]);
+            for (int p = 0; p < 3; p++) {
+                const int sh = p ? 1 : 0;
+                McpBlock b;
+                b.w = (uint16_t)(J.pu_w >> sh), b.h = (uint16_t)(J.pu_h >> sh), b.pad[0] = b.pad[1] = 0;
+                b.fx = (uint8_t)(p ? px & 7 : px & 3), b.fy = (uint8_t)(p ? py & 7 : py & 3);
+                b.ref_off = (int32_t)((p ? py >> 3 : py >> 2) * (int)(p ? R->strideC : R->strideY) + (p ? px >> 3 : px >> 2));
+                if (is_bi) {
+                    b.dst_off = (int32_t)raw_len[p]; /* same offset in both lists' intermediate buffers */
+                    raw[l][p].push_back(b);
+                } else {
+                    b.dst_off = p ? J.dst_off_c : J.dst_off_y;
+                    uni[l][p].push_back(b);
+                }
+            }
+        }
+        if (is_bi)
+            for (int p = 0; p < 3; p++) {
+                const int sh = p ? 1 : 0;
+                BiBlock c = {(int32_t)raw_len[p], (int32_t)raw_len[p], p ? J.dst_off_c : J.dst_off_y, (uint16_t)(J.pu_w >> sh), (uint16_t)(J.pu_h >> sh)};
+                bi[p].push_back(c);
+                raw_len[p] += (size_t)c.w * c.h;
+            }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    /* one scratch slab: block lists, then the intermediates [list][plane] */
+    size_t bytes = 0, off_uni[2][3], off_raw[2][3], off_bi[3], off_int[2][3];
+    auto take = [&](size_t n) { const size_t o = bytes; bytes += (n + 255) & ~(size_t)255; return o; };
+    for (int l = 0; l < 2; l++)
+        for (int p = 0; p < 3; p++)
+            off_uni[l][p] = take(uni[l][p].size() * sizeof(McpBlock)), off_raw[l][p] = take(raw[l][p].size() * sizeof(McpBlock));
+    for (int p = 0; p < 3; p++)
+        off_bi[p] = take(bi[p].size() * sizeof(BiBlock));
+    for (int l = 0; l < 2; l++)
+        for (int p = 0; p < 3; p++)
+            off_int[l][p] = take(raw_len[p] * sizeof(int16_t));
+    static uint8_t *d_slab = nullptr; /* grow-only; callers serialise per context */
+    static size_t slab_bytes = 0;
+    if (bytes > slab_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (d_slab)
+            HIP_TRY(hipFree(d_slab));
+        d_slab = nullptr, slab_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&d_slab, bytes));
+        slab_bytes = bytes;
+    }
+    for (int l = 0; l < 2; l++)
+        for (int p = 0; p < 3; p++) {
+            if (!uni[l][p].empty())
+                HIP_TRY(hipMemcpyAsync(d_slab + off_uni[l][p], uni[l][p].data(), uni[l][p].size() * sizeof(McpBlock), hipMemcpyHostToDevice, ctx->stream));
+            if (!raw[l][p].empty())
+                HIP_TRY(hipMemcpyAsync(d_slab + off_raw[l][p], raw[l][p].data(), raw[l][p].size() * sizeof(McpBlock), hipMemcpyHostToDevice, ctx->stream));
+        }
+    for (int p = 0; p < 3; p++)
+        if (!bi[p].empty())
+            HIP_TRY(hipMemcpyAsync(d_slab + off_bi[p], bi[p].data(), bi[p].size() * sizeof(BiBlock), hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *dst[3] = {d_pred_y, d_pred_cb, d_pred_cr};
+    for (int l = 0; l < 2; l++)
+        for (int p = 0; p < 3; p++) {
+            const SvtAmdRefPicture *R = refs[l];
+            if (!R)
+                continue;
+            const uint8_t *plane = (const uint8_t *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr);
+            const int rs = (int)(p ? R->strideC : R->strideY), ds = (int)(p ? strideC : strideY);
+            if (!uni[l][p].empty())
+                hipLaunchKernelGGL(k_mcp<uint8_t>, dim3((unsigned)uni[l][p].size()), dim3(256), 0, ctx->stream, plane, rs, (void *)dst[p], ds,
+                                   (const McpBlock *)(d_slab + off_uni[l][p]), p != 0, 0);
+            if (!raw[l][p].empty())
+                hipLaunchKernelGGL(k_mcp<uint8_t>, dim3((unsigned)raw[l][p].size()), dim3(256), 0, ctx->stream, plane, rs,
+                                   (void *)(d_slab + off_int[l][p]), 0, (const McpBlock *)(d_slab + off_raw[l][p]), p != 0, 1);
+        }
+    for (int p = 0; p < 3; p++)
+        if (!bi[p].empty()) /* Offset5 / ChromaOffset5 (Codec/EbDefinitions.h:1022-1030) */
+            hipLaunchKernelGGL(k_bipred_clip<uint8_t>, dim3((unsigned)bi[p].size()), dim3(256), 0, ctx->stream,
+                               (const int16_t *)(d_slab + off_int[0][p]), (const int16_t *)(d_slab + off_int[1][p]), dst[p],
+                               (int)(p ? strideC : strideY), (const BiBlock *)(d_slab + off_bi[p]), p ? 64 : 16448);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the host vectors back the asynchronous uploads */
+    return SVT_AMD_OK;
+}

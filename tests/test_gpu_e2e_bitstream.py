@@ -151,3 +151,27 @@ def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind,
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
+
+
+INTER_CASES = [
+    ("motion", 416, 240, 5, ["-encMode", "9", "-pred-struct", "0"]),
+    ("motion", 320, 192, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2"]),   # bi-prediction, two lists
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", INTER_CASES)
+def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind, w, h, n, args):
+    """The encode pass's inter prediction of every prediction unit (EncodePassInterPrediction) answered by
+    svt_amd_inter_pu_batch from reference pictures resident on the device (SVT_HOOK_INTER=1)."""
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    os.environ["SVT_HOOK_INTER"] = "1"
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        del os.environ["SVT_HOOK_INTER"]
+    assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU" in log, log[-1000:]
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
+    a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
+    assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
