@@ -760,6 +760,33 @@ SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const
                                  uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC);
 
 /* ------------------------------------------------------------------------- */
+/* Quantiser of the final encode pass                                          */
+/* ------------------------------------------------------------------------- */
+/* Replaces UnifiedQuantizeInvQuantize (Codec/EbTransforms.c:2978-3250, called from EncodeLoop / EncodeLoop16bit,
+ * Codec/EbCodingLoop.c:740-954, :1333-1550) on its paths without RDOQ / PM-core and without perceptual masking
+ * (pmpMaskingLevelEncDec == 0; masking needs -brr 1): scaling constants from qp / bit depth / size / slice type
+ * (:3097-3112), dead-zone override dZoffset (:3118), the DC-only shape (:3043-3090), the (size >> shape) active area,
+ * the isolated-coefficient clean-up (:3190-3232) and UpdateQiQCoef (C_DEFAULT/EbTransforms_C.c:209) with the contouring
+ * and forced-cbf flags.  Unit u: coefficients at d_coeff + u*1024 (row pitch = size); quantised / reconstructed
+ * coefficients are written in the same layout (only the active area is touched), non-zero count to d_nz[u]. */
+typedef struct SvtAmdQuantUnit {
+    uint8_t  size;              /* 4 / 8 / 16 / 32                                                         */
+    uint8_t  qp, bit_depth;     /* 8 or 10                                                                 */
+    uint8_t  slice_type;        /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR                                        */
+    uint8_t  shape;             /* transCoeffShape: 0 default, 1 N2, 2 N4, 3 only DC                       */
+    uint8_t  clean_sparse, enable_cb_flag, contouring_flag;
+    uint8_t  component;         /* COMPONENT_LUMA 0, chroma otherwise                                      */
+    uint8_t  temporal_layer;
+    uint8_t  pad[2];
+    uint32_t dz_offset;
+} SvtAmdQuantUnit;
+SVT_AMD_API int svt_amd_unified_quantize_batch(SvtAmdContext *ctx, const SvtAmdQuantUnit *d_units, const int16_t *d_coeff,
+                                               int16_t *d_quant, int16_t *d_recon, uint32_t *d_nz, uint32_t nunits);
+/* Per-call form on HOST pointers (row pitch coeffStride for all three blocks); blocking. */
+SVT_AMD_API int svt_amd_unified_quantize(SvtAmdContext *ctx, const SvtAmdQuantUnit *unit, const int16_t *coeff,
+                                         uint32_t coeffStride, int16_t *quant, int16_t *recon, uint32_t *nz);
+
+/* ------------------------------------------------------------------------- */
 /* Reconstruction of transform units (final encode pass)                      */
 /* ------------------------------------------------------------------------- */
 /* Replaces, per reconstructed plane of a transform unit, EncodeGenerateRecon / EncodeGenerateRecon16bit

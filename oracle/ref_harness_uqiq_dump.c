@@ -1,0 +1,125 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/): link-time interposer around the REFERENCE's UnifiedQuantizeInvQuantize
+ * (Codec/EbTransforms.c:2978), the quantiser of the final encode pass (called from the static EncodeLoop / EncodeLoop16bit,
+ * Codec/EbCodingLoop.c:651, :1244).  Compiled only into oracle/_ref/libsvtref.so with -Wl,--wrap=UnifiedQuantizeInvQuantize.
+ *
+ * With SVT_REF_UQIQ_DUMP=<file>, a sample of the calls without RDOQ / PM-core and without perceptual masking (every
+ * SVT_REF_UQIQ_STRIDE-th, default 23) leaves one binary record: the transform coefficients and every scalar the call reads,
+ * and the quantised / reconstructed coefficients and the non-zero count it leaves.
+ * tests/golden/make_uqiq_golden.py builds the fixtures.  No reference source here.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbEncDecProcess.h"
+#include "EbModeDecisionProcess.h"
+#include "EbTransforms.h"
+
+void __real_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureControlSet_t *pcs, EB_S16 *coeff, const EB_U32 coeffStride,
+                                       EB_S16 *quantCoeff, EB_S16 *reconCoeff, EB_U32 qp, EB_U32 bitDepth, EB_U32 areaSize,
+                                       EB_PICTURE sliceType, EB_U32 *yCountNonZeroCoeffs, EB_U8 transCoeffShape,
+                                       EB_U8 cleanSparseCeoffPfEncDec, EB_U8 pmpMaskingLevelEncDec, EB_MODETYPE type, EB_U32 enableCbflag,
+                                       EB_U8 enableContouringQCUpdateFlag, EB_U32 componentType, EB_U32 temporalLayerIndex,
+                                       EB_U32 dZoffset, CabacEncodeContext_t *cabacEncodeCtxPtr, EB_U64 lambda, EB_U32 intraLumaMode,
+                                       EB_U32 intraChromaMode, CabacCost_t *CabacCost);
+
+#define UQIQ_DUMP_MAGIC 0x51495155U /* "UQIQ" */
+typedef struct UqiqRecord {
+    uint32_t magic, record_size;
+    uint32_t size, qp, bit_depth, slice_type, shape, clean_sparse, enable_cb_flag, contouring_flag, component, temporal_layer, dz_offset;
+    uint32_t nz_out;
+    int16_t coeff[32 * 32], quant_in[32 * 32], recon_in[32 * 32], quant[32 * 32], recon[32 * 32]; /* size x size, pitch = size */
+} UqiqRecord;
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static FILE *g_file;
+static int g_state, g_stride = 23;
+static unsigned long g_calls;
+
+static void grab(int16_t *dst, const EB_S16 *src, uint32_t stride, uint32_t n)
+{
+    for (uint32_t y = 0; y < n; y++)
+        memcpy(dst + y * n, src + (size_t)y * stride, n * sizeof(int16_t));
+}
+
+void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureControlSet_t *pcs, EB_S16 *coeff, const EB_U32 coeffStride,
+                                       EB_S16 *quantCoeff, EB_S16 *reconCoeff, EB_U32 qp, EB_U32 bitDepth, EB_U32 areaSize,
+                                       EB_PICTURE sliceType, EB_U32 *yCountNonZeroCoeffs, EB_U8 transCoeffShape,
+                                       EB_U8 cleanSparseCeoffPfEncDec, EB_U8 pmpMaskingLevelEncDec, EB_MODETYPE type, EB_U32 enableCbflag,
+                                       EB_U8 enableContouringQCUpdateFlag, EB_U32 componentType, EB_U32 temporalLayerIndex,
+                                       EB_U32 dZoffset, CabacEncodeContext_t *cabacEncodeCtxPtr, EB_U64 lambda, EB_U32 intraLumaMode,
+                                       EB_U32 intraChromaMode, CabacCost_t *CabacCost)
+{
+    if (g_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_state == 0) {
+            const char *path = getenv("SVT_REF_UQIQ_DUMP"), *st = getenv("SVT_REF_UQIQ_STRIDE");
+            g_file = path ? fopen(path, "wb") : NULL;
+            if (st && atoi(st) > 0)
+                g_stride = atoi(st);
+            g_state = g_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    int take = 0;
+    if (g_state > 0 && !contextPtr->mdContext->rdoqPmCoreMethod && !pmpMaskingLevelEncDec && yCountNonZeroCoeffs && areaSize <= 32) {
+        pthread_mutex_lock(&g_lock);
+        take = (g_calls++ % (unsigned long)g_stride) == 0;
+        pthread_mutex_unlock(&g_lock);
+    }
+    UqiqRecord *r = NULL;
+    if (take) {
+        r = (UqiqRecord *)calloc(1, sizeof(*r));
+        r->magic = UQIQ_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r);
+        r->size = areaSize, r->qp = qp, r->bit_depth = bitDepth, r->slice_type = sliceType, r->shape = transCoeffShape;
+        r->clean_sparse = cleanSparseCeoffPfEncDec, r->enable_cb_flag = enableCbflag, r->contouring_flag = enableContouringQCUpdateFlag;
+        r->component = componentType, r->temporal_layer = temporalLayerIndex, r->dz_offset = dZoffset;
+        grab(r->coeff, coeff, coeffStride, areaSize);
+        grab(r->quant_in, quantCoeff, coeffStride, areaSize);
+        grab(r->recon_in, reconCoeff, coeffStride, areaSize);
+    }
+    __real_UnifiedQuantizeInvQuantize(contextPtr, pcs, coeff, coeffStride, quantCoeff, reconCoeff, qp, bitDepth, areaSize, sliceType,
+                                      yCountNonZeroCoeffs, transCoeffShape, cleanSparseCeoffPfEncDec, pmpMaskingLevelEncDec, type,
+                                      enableCbflag, enableContouringQCUpdateFlag, componentType, temporalLayerIndex, dZoffset,
+                                      cabacEncodeCtxPtr, lambda, intraLumaMode, intraChromaMode, CabacCost);
+    if (!r)
+        return;
+    r->nz_out = *yCountNonZeroCoeffs;
+    grab(r->quant, quantCoeff, coeffStride, areaSize);
+    grab(r->recon, reconCoeff, coeffStride, areaSize);
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_file);
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+}
+
+/* Direct call into the reference function with stand-in context objects (only the fields the non-RDOQ, non-masking paths
+ * read are meaningful), so tests can pin the optional branches (shapes, dead-zone override, clean-up, contouring, forced
+ * cbf) that ordinary encoder runs do not reach.  unit = SvtAmdQuantUnit of include/svt_hevc_amd.h. */
+#include "EbSequenceControlSet.h"
+#include "../include/svt_hevc_amd.h"
+void svt_ref_unified_quantize(const SvtAmdQuantUnit *u, int16_t *coeff, uint32_t stride, int16_t *quant, int16_t *recon, uint32_t *nz)
+{
+    static EncDecContext_t *ctx;
+    static ModeDecisionContext_t *md;
+    static PictureControlSet_t *pcs;
+    static PictureParentControlSet_t *ppcs;
+    static SequenceControlSet_t *scs;
+    static EbObjectWrapper_t wrapper;
+    pthread_mutex_lock(&g_lock);
+    if (!ctx) {
+        ctx = (EncDecContext_t *)calloc(1, sizeof(*ctx)), md = (ModeDecisionContext_t *)calloc(1, sizeof(*md));
+        pcs = (PictureControlSet_t *)calloc(1, sizeof(*pcs)), ppcs = (PictureParentControlSet_t *)calloc(1, sizeof(*ppcs));
+        scs = (SequenceControlSet_t *)calloc(1, sizeof(*scs));
+        ctx->mdContext = md, pcs->ParentPcsPtr = ppcs, ppcs->sequenceControlSetWrapperPtr = &wrapper, wrapper.objectPtr = scs;
+    }
+    pthread_mutex_unlock(&g_lock);
+    __real_UnifiedQuantizeInvQuantize(ctx, pcs, coeff, stride, quant, recon, u->qp, u->bit_depth, u->size, (EB_PICTURE)u->slice_type, nz,
+                                      u->shape, u->clean_sparse, 0, INTER_MODE, u->enable_cb_flag, u->contouring_flag, u->component,
+                                      u->temporal_layer, u->dz_offset, NULL, 0, 0, 0, NULL);
+}

@@ -80,6 +80,9 @@ void svt_oracle_UpdateQiQCoef(int16_t *quantCoeff, int16_t *reconCoeff, uint32_t
                               int32_t iq_offset, int32_t shiftNum, uint32_t areaSize, uint32_t *nonzerocoeff,
                               uint32_t componentType, uint32_t sliceType, uint32_t temporalLayer,
                               uint32_t enableCbflag, uint8_t enableContouringQCUpdateFlag);
+/* the encode pass's quantiser without RDOQ / masking (composite of the two above + shape / dead-zone / clean-up) */
+void svt_oracle_unified_quantize(const SvtAmdQuantUnit *unit, const int16_t *coeff, uint32_t stride, int16_t *quant, int16_t *recon,
+                                 uint32_t *nz);
 void svt_oracle_ResidualKernel(const uint8_t *input, uint32_t inputStride, const uint8_t *pred, uint32_t predStride,
                                int16_t *residual, uint32_t residualStride, uint32_t w, uint32_t h);
 void svt_oracle_PictureAdditionKernel(const uint8_t *pred, uint32_t predStride, const int16_t *residual,

@@ -313,3 +313,61 @@ uint64_t svt_oracle_Compute4x4Satd_U8(const uint8_t *src, uint64_t *dcValue, uin
     *dcValue += (uint64_t)(int64_t)dc;
     return s;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * UnifiedQuantizeInvQuantize (Codec/EbTransforms.c:2978-3250) on its paths without RDOQ / PM-core and without perceptual
+ * masking.  coeff / quant / recon: size x size blocks with row pitch `stride`.  Pinned by
+ * tests/test_oracle_uqiq_golden.py on records of real encode-pass calls.
+ * ------------------------------------------------------------------------------------------------------------------ */
+void svt_oracle_unified_quantize(const SvtAmdQuantUnit *U, const int16_t *coeff, uint32_t stride, int16_t *quant, int16_t *recon,
+                                 uint32_t *nzOut)
+{
+    static const uint32_t QF[6] = {26214, 23302, 20560, 18396, 16384, 14564}, FF[6] = {40, 45, 51, 57, 64, 72};
+    uint32_t lg = 0;
+    while ((1u << lg) < U->size)
+        lg++;
+    const int32_t qpRem = U->qp % 6, qpPer = U->qp / 6;
+    const uint32_t tshift = 15 - U->bit_depth - lg;
+    const int32_t shiftedQBits = 14 + qpPer + (int32_t)tshift;
+    const uint32_t q_offset = ((U->slice_type == 2 || U->slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int32_t shiftedFFunc = qpPer > 8 ? (int32_t)FF[qpRem] << (qpPer - 2) : (int32_t)FF[qpRem] << qpPer;
+    const int32_t shiftNum = qpPer > 8 ? 20 - 14 - (int32_t)tshift - 2 : 20 - 14 - (int32_t)tshift;
+    const int32_t iq_offset = 1 << (shiftNum - 1);
+    uint32_t nz = 0;
+    if (U->shape == 3) { /* ONLY_DC_SHAPE (:3043-3090) */
+        const int32_t c = coeff[0], sign = c < 0 ? -1 : 1;
+        int32_t t = (c < 0 ? -c : c) * (int32_t)QF[qpRem];
+        t = (int32_t)((uint32_t)t + q_offset);
+        t >>= shiftedQBits;
+        int32_t q = sign * t;
+        q = q < -32768 ? -32768 : q > 32767 ? 32767 : q;
+        quant[0] = (int16_t)q;
+        nz = q != 0;
+        int32_t r = ((q * shiftedFFunc) + iq_offset) >> shiftNum;
+        recon[0] = (int16_t)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+        *nzOut = nz;
+        return;
+    }
+    const uint32_t offs = U->dz_offset ? (uint32_t)(U->dz_offset * (1u << shiftedQBits) / 20) : q_offset;
+    const uint32_t area = (uint32_t)U->size >> U->shape;
+    svt_oracle_QuantizeInvQuantize(coeff, stride, quant, recon, QF[qpRem], offs, shiftedQBits, shiftedFFunc, iq_offset, shiftNum, area,
+                                   &nz);
+    if (U->clean_sparse && U->size >= 8 && nz && U->slice_type != 2 && area >= 4) /* :3190-3232 */
+        for (uint32_t by = 0; by < area / 4; by++)
+            for (uint32_t bx = 0; bx < area / 4; bx++) {
+                uint32_t cnt = 0;
+                for (uint32_t y = 0; y < 4; y++)
+                    for (uint32_t x = 0; x < 4; x++)
+                        cnt += quant[(4 * by + y) * stride + 4 * bx + x] != 0;
+                if (cnt == 1)
+                    for (uint32_t y = 0; y < 4; y++)
+                        for (uint32_t x = 0; x < 4; x++) {
+                            const uint32_t loc = (4 * by + y) * stride + 4 * bx + x;
+                            if (quant[loc] && loc)
+                                quant[loc] = 0, recon[loc] = 0, nz--;
+                        }
+            }
+    svt_oracle_UpdateQiQCoef(quant, recon, stride, shiftedFFunc, iq_offset, shiftNum, area, &nz, U->component, U->slice_type,
+                             U->temporal_layer, U->enable_cb_flag, U->contouring_flag);
+    *nzOut = nz;
+}
