@@ -29,6 +29,7 @@
 #include "EbModeDecisionProcess.h"
 #include "EbModeDecision.h"
 #include "EbFullLoop.h"
+#include "EbTransforms.h"
 #include "EbInterPrediction.h"
 #include "EbNeighborArrays.h"
 #include "EbIntraPrediction.h"
@@ -688,6 +689,55 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
         memcpy(predictionPtr->bufferCr + oc + y * predictionPtr->strideCr, hcr + y * (puWidth >> 1), puWidth >> 1);
     }
     return EB_ErrorNone;
+}
+
+/*
+ * Final encode pass, quantiser: UnifiedQuantizeInvQuantize (EbTransforms.c:2978, called from the static EncodeLoop /
+ * EncodeLoop16bit) is answered by svt_amd_unified_quantize() with SVT_HOOK_QUANT=1 on its paths without RDOQ / PM-core and
+ * without perceptual masking (everything the default configuration reaches); other calls go to the reference code.
+ */
+void __real_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureControlSet_t *pcs, EB_S16 *coeff, const EB_U32 coeffStride,
+                                       EB_S16 *quantCoeff, EB_S16 *reconCoeff, EB_U32 qp, EB_U32 bitDepth, EB_U32 areaSize,
+                                       EB_PICTURE sliceType, EB_U32 *yCountNonZeroCoeffs, EB_U8 transCoeffShape,
+                                       EB_U8 cleanSparseCeoffPfEncDec, EB_U8 pmpMaskingLevelEncDec, EB_MODETYPE type, EB_U32 enableCbflag,
+                                       EB_U8 enableContouringQCUpdateFlag, EB_U32 componentType, EB_U32 temporalLayerIndex,
+                                       EB_U32 dZoffset, CabacEncodeContext_t *cabacEncodeCtxPtr, EB_U64 lambda, EB_U32 intraLumaMode,
+                                       EB_U32 intraChromaMode, CabacCost_t *CabacCost);
+static unsigned long g_quant_gpu;
+static int g_quant_state;
+
+void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureControlSet_t *pcs, EB_S16 *coeff, const EB_U32 coeffStride,
+                                       EB_S16 *quantCoeff, EB_S16 *reconCoeff, EB_U32 qp, EB_U32 bitDepth, EB_U32 areaSize,
+                                       EB_PICTURE sliceType, EB_U32 *yCountNonZeroCoeffs, EB_U8 transCoeffShape,
+                                       EB_U8 cleanSparseCeoffPfEncDec, EB_U8 pmpMaskingLevelEncDec, EB_MODETYPE type, EB_U32 enableCbflag,
+                                       EB_U8 enableContouringQCUpdateFlag, EB_U32 componentType, EB_U32 temporalLayerIndex,
+                                       EB_U32 dZoffset, CabacEncodeContext_t *cabacEncodeCtxPtr, EB_U64 lambda, EB_U32 intraLumaMode,
+                                       EB_U32 intraChromaMode, CabacCost_t *CabacCost)
+{
+    if (g_quant_state == 0)
+        g_quant_state = getenv("SVT_HOOK_QUANT") ? 1 : -1;
+    if (g_quant_state < 0 || !g_ctx || contextPtr->mdContext->rdoqPmCoreMethod || pmpMaskingLevelEncDec || !yCountNonZeroCoeffs ||
+        areaSize > 32 || areaSize < 4 || qp > 51 || (bitDepth != 8 && bitDepth != 10)) {
+        __real_UnifiedQuantizeInvQuantize(contextPtr, pcs, coeff, coeffStride, quantCoeff, reconCoeff, qp, bitDepth, areaSize, sliceType,
+                                          yCountNonZeroCoeffs, transCoeffShape, cleanSparseCeoffPfEncDec, pmpMaskingLevelEncDec, type,
+                                          enableCbflag, enableContouringQCUpdateFlag, componentType, temporalLayerIndex, dZoffset,
+                                          cabacEncodeCtxPtr, lambda, intraLumaMode, intraChromaMode, CabacCost);
+        return;
+    }
+    SvtAmdQuantUnit u;
+    memset(&u, 0, sizeof(u));
+    u.size = (uint8_t)areaSize, u.qp = (uint8_t)qp, u.bit_depth = (uint8_t)bitDepth, u.slice_type = (uint8_t)sliceType;
+    u.shape = transCoeffShape, u.clean_sparse = cleanSparseCeoffPfEncDec, u.enable_cb_flag = (uint8_t)enableCbflag;
+    u.contouring_flag = enableContouringQCUpdateFlag, u.component = (uint8_t)componentType, u.temporal_layer = (uint8_t)temporalLayerIndex;
+    u.dz_offset = dZoffset;
+    pthread_mutex_lock(&g_lock);
+    uint32_t nz = 0;
+    if (svt_amd_unified_quantize(g_ctx, &u, coeff, coeffStride, quantCoeff, reconCoeff, &nz))
+        die("svt_amd_unified_quantize");
+    if (g_quant_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: encode-pass quantiser (UnifiedQuantizeInvQuantize) on the GPU\n");
+    pthread_mutex_unlock(&g_lock);
+    *yCountNonZeroCoeffs = nz;
 }
 
 static void hook_report(void)

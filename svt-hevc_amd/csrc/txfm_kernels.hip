@@ -697,3 +697,138 @@ extern "C" int svt_amd_recon_tu(SvtAmdContext *ctx, int bytes_per_sample, int si
         ::memcpy((uint8_t *)recon + (size_t)y * reconStride * bps, hp + (size_t)y * size * bps, (size_t)size * bps);
     return SVT_AMD_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Quantiser of the final encode pass: UnifiedQuantizeInvQuantize (Codec/EbTransforms.c:2978) without RDOQ / masking */
+/* ------------------------------------------------------------------------- */
+struct QuantUnit { uint8_t size, qp, bit_depth, slice_type, shape, clean_sparse, enable_cb_flag, contouring_flag, component,
+                   temporal_layer, pad[2]; uint32_t dz_offset; }; /* = SvtAmdQuantUnit */
+
+/* one workgroup per unit; the quantised block is mirrored in LDS for the two neighbourhood-dependent post-passes
+ * (isolated-coefficient clean-up per 4x4 block, UpdateQiQCoef) */
+__global__ __launch_bounds__(256) void k_unified_quant(const QuantUnit *__restrict__ units, const int16_t *__restrict__ coeff,
+                                                      int16_t *__restrict__ quant, int16_t *__restrict__ recon,
+                                                      uint32_t *__restrict__ nzOut)
+{
+    __shared__ int16_t q[32 * 32], r[32 * 32];
+    __shared__ unsigned s_nz;
+    const QuantUnit U = units[blockIdx.x];
+    const int t = threadIdx.x, N = U.size, lg = 31 - __clz(N);
+    const size_t base = (size_t)blockIdx.x * 1024;
+    const int qpRem = U.qp % 6, qpPer = U.qp / 6;
+    const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
+    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    const int tshift = 15 - U.bit_depth - lg, shiftedQBits = 14 + qpPer + tshift;
+    const uint32_t q_offset = ((U.slice_type == 2 || U.slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
+    const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
+    const bool only_dc = U.shape == 3;
+    const uint32_t offs = (!only_dc && U.dz_offset) ? (uint32_t)(U.dz_offset * (1u << shiftedQBits) / 20) : q_offset;
+    const int area = only_dc ? 1 : N >> U.shape;
+    if (t == 0)
+        s_nz = 0;
+    __syncthreads();
+    unsigned nz = 0;
+    for (int i = t; i < area * area; i += 256) {
+        const int y = i / area, x = i - y * area, v = coeff[base + y * N + x], sign = v < 0 ? -1 : 1;
+        int tq = abs(v);
+        tq = (int)((uint32_t)tq * QF);
+        tq = (int)((uint32_t)tq + offs);
+        tq >>= shiftedQBits;
+        const int qv = clip16i(sign * tq);
+        q[y * N + x] = (int16_t)qv;
+        r[y * N + x] = (int16_t)clip16i(((qv * shiftedFFunc) + iq_offset) >> shiftNum);
+        nz += qv != 0;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        nz += __shfl_xor(nz, o);
+    if ((t & 63) == 0)
+        atomicAdd(&s_nz, nz);
+    __syncthreads();
+    if (!only_dc) {
+        /* zero coefficients that are alone in their 4x4 block, except position (0,0) (:3190-3232) */
+        if (U.clean_sparse && N >= 8 && s_nz && U.slice_type != 2 && area >= 4) {
+            const int nb = area >> 2;
+            unsigned removed = 0;
+            for (int b = t; b < nb * nb; b += 256) {
+                const int by = b / nb, bx = b - by * nb;
+                int cnt = 0, loc = -1;
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++)
+                        if (q[(4 * by + y) * N + 4 * bx + x])
+                            cnt++, loc = (4 * by + y) * N + 4 * bx + x;
+                if (cnt == 1 && loc != 0)
+                    q[loc] = 0, r[loc] = 0, removed++;
+            }
+            if (removed)
+                atomicSub(&s_nz, removed);
+            __syncthreads();
+        }
+        if (t == 0) { /* UpdateQiQCoef (C_DEFAULT/EbTransforms_C.c:209-260) */
+            unsigned n = s_nz;
+            if (n < 10 && U.contouring_flag && U.slice_type == 2 && U.temporal_layer == 0 && U.component == 0) {
+                const int loc = (area - 1) + (area - 1) * N;
+                if (q[loc] == 0)
+                    n++, q[loc] = 1, r[loc] = (int16_t)((int16_t)((1 * shiftedFFunc) + iq_offset) >> shiftNum);
+            }
+            if (n == 0 && U.enable_cb_flag == 1) {
+                const int loc = (area - 2) * N + (area - 1);
+                n = 1, q[loc] = 1, r[loc] = (int16_t)((int16_t)((1 * shiftedFFunc) + iq_offset) >> shiftNum);
+            }
+            s_nz = n;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < area * area; i += 256) {
+        const int y = i / area, x = i - y * area;
+        quant[base + y * N + x] = q[y * N + x];
+        recon[base + y * N + x] = r[y * N + x];
+    }
+    if (t == 0)
+        nzOut[blockIdx.x] = s_nz;
+}
+
+extern "C" int svt_amd_unified_quantize_batch(SvtAmdContext *ctx, const SvtAmdQuantUnit *d_units, const int16_t *d_coeff,
+                                              int16_t *d_quant, int16_t *d_recon, uint32_t *d_nz, uint32_t nunits)
+{
+    static_assert(sizeof(QuantUnit) == sizeof(SvtAmdQuantUnit), "unit layout");
+    if (!ctx || !d_units || !d_coeff || !d_quant || !d_recon || !d_nz || !nunits)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_unified_quant, dim3(nunits), dim3(256), 0, ctx->stream, (const QuantUnit *)d_units, d_coeff, d_quant, d_recon, d_nz);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_unified_quantize(SvtAmdContext *ctx, const SvtAmdQuantUnit *unit, const int16_t *coeff, uint32_t coeffStride,
+                                        int16_t *quant, int16_t *recon, uint32_t *nz)
+{
+    if (!ctx || !unit || !coeff || !quant || !recon || !nz || !(unit->size == 4 || unit->size == 8 || unit->size == 16 || unit->size == 32) ||
+        coeffStride < unit->size || unit->shape > 3 || (unit->bit_depth != 8 && unit->bit_depth != 10) || unit->qp > 51 ||
+        (unit->shape != 3 && (unit->size >> unit->shape) < 2))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    static uint8_t *d_scratch = nullptr; /* unit | nz | coeff | quant | recon ; callers serialise per context */
+    const size_t o_unit = 0, o_nz = 64, o_c = 128, o_q = o_c + 2048, o_r = o_q + 2048, total = o_r + 2048;
+    if (!d_scratch)
+        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    const int N = unit->size, area = unit->shape == 3 ? 1 : N >> unit->shape;
+    int16_t hc[32 * 32], hq[32 * 32], hr[32 * 32];
+    for (int y = 0; y < N; y++)
+        ::memcpy(hc + y * N, coeff + (size_t)y * coeffStride, (size_t)N * 2);
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_unit, unit, sizeof(*unit), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_c, hc, (size_t)N * N * 2, hipMemcpyHostToDevice, ctx->stream));
+    int rc = svt_amd_unified_quantize_batch(ctx, (const SvtAmdQuantUnit *)(d_scratch + o_unit), (const int16_t *)(d_scratch + o_c),
+                                            (int16_t *)(d_scratch + o_q), (int16_t *)(d_scratch + o_r), (uint32_t *)(d_scratch + o_nz), 1);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(nz, d_scratch + o_nz, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hq, d_scratch + o_q, (size_t)N * N * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hr, d_scratch + o_r, (size_t)N * N * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int y = 0; y < area; y++) { /* like the reference, only the active area is written */
+        ::memcpy(quant + (size_t)y * coeffStride, hq + y * N, (size_t)area * 2);
+        ::memcpy(recon + (size_t)y * coeffStride, hr + y * N, (size_t)area * 2);
+    }
+    return SVT_AMD_OK;
+}

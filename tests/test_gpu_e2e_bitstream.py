@@ -177,14 +177,18 @@ def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind,
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
 
 
-@pytest.mark.parametrize("kind,w,h,n,args", [("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"])])
+@pytest.mark.parametrize("kind,w,h,n,args", [("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"]),
+                                             ("motion10", 416, 240, 3, ["-encMode", "9", "-pred-struct", "0", "-bit-depth", "10"])])
 def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n, args):
-    """All device bindings at once: ME, OIS, both MD full loops, encode-pass intra and inter prediction, transform-unit
-    reconstruction."""
+    """All device bindings at once: ME, OIS, both MD full loops, encode-pass intra and inter prediction, quantiser and
+    transform-unit reconstruction."""
     yuv = str(tmp_path / "clip.yuv")
-    S.write_clip(yuv, kind, w, h, n, 7)
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
-    flags = ("SVT_HOOK_FULLLOOP", "SVT_HOOK_RECON", "SVT_HOOK_INTRA", "SVT_HOOK_INTER")
+    flags = ("SVT_HOOK_FULLLOOP", "SVT_HOOK_RECON", "SVT_HOOK_INTRA", "SVT_HOOK_INTER", "SVT_HOOK_QUANT")
     for f in flags:
         os.environ[f] = "1"
     try:
@@ -193,7 +197,10 @@ def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n,
         for f in flags:
             del os.environ[f]
     for msg in ("motion estimation on svt-hevc_amd", "luma full loop (ProductFullLoop) on the GPU", "chroma full loop",
-                "transform-unit reconstruction", "encode-pass intra prediction", "encode-pass inter prediction"):
+                "transform-unit reconstruction", "encode-pass intra prediction", "encode-pass inter prediction",
+                "encode-pass quantiser"):
+        if kind.endswith("10") and "inter prediction" in msg:
+            continue    # the 16-bit inter driver stays on the host
         assert msg in log, (msg, log[-1500:])
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
