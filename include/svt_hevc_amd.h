@@ -760,6 +760,20 @@ SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const
                                  uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC);
 
 /* ------------------------------------------------------------------------- */
+/* One transform unit of the final encode pass, end to end                     */
+/* ------------------------------------------------------------------------- */
+/* The product form of EncodeLoop + EncodeGenerateRecon (Codec/EbCodingLoop.c:651-1083, :1084-1243; 16-bit :1244-1797) for
+ * one plane of one DCT unit with the default coefficient shape and no RDOQ / masking: PictureResidual -> EstimateTransform
+ * -> UnifiedQuantizeInvQuantize -> EncodeInvTransform -> PictureAdditionKernel in ONE kernel, residual and coefficients in
+ * registers.  Unit u: source block at d_src + src_off, prediction at d_rec + rec_off (overwritten by the reconstruction,
+ * like the reference's in-place recon buffer); its quantised coefficients go to d_quant + u*size*size (row pitch = size),
+ * the non-zero count to d_nz[u].  Bit depth 8 (1 byte per sample) or 10 (2 bytes). */
+typedef struct SvtAmdEncodeUnit { int32_t src_off, rec_off; uint8_t qp, slice_type, pad[2]; uint32_t dz_offset; } SvtAmdEncodeUnit;
+SVT_AMD_API int svt_amd_encode_tu_batch(SvtAmdContext *ctx, int bytes_per_sample, int size, const SvtAmdEncodeUnit *d_units,
+                                        const void *d_src, uint32_t srcStride, void *d_rec, uint32_t recStride,
+                                        int16_t *d_quant, uint32_t *d_nz, uint32_t nunits);
+
+/* ------------------------------------------------------------------------- */
 /* Quantiser of the final encode pass                                          */
 /* ------------------------------------------------------------------------- */
 /* Replaces UnifiedQuantizeInvQuantize (Codec/EbTransforms.c:2978-3250, called from EncodeLoop / EncodeLoop16bit,

@@ -187,6 +187,63 @@ __device__ __forceinline__ void inv_1d_regs(const int (&c)[N], int shift, Emit e
         emit(j, (int16_t)clip16i((v[j] + offset) >> shift));
 }
 
+/* A row of N samples (8- or 16-bit) <-> registers, with 16-byte (or whole-row) vector accesses when the row is aligned */
+template <int N, typename T>
+__device__ __forceinline__ void load_row(const T *p, int (&v)[N])
+{
+    constexpr int BYTES = N * (int)sizeof(T), VB = BYTES >= 16 ? 16 : BYTES; /* vector width in bytes: 16, 8 or 4 */
+    if (((uintptr_t)p & (VB - 1)) == 0) {
+#pragma unroll
+        for (int o = 0; o < BYTES; o += VB) {
+            uint32_t w[4];
+            if (VB == 16) {
+                const uint4 q = *(const uint4 *)((const uint8_t *)p + o);
+                w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+            } else if (VB == 8) {
+                const uint2 q = *(const uint2 *)((const uint8_t *)p + o);
+                w[0] = q.x, w[1] = q.y;
+            } else {
+                w[0] = *(const uint32_t *)((const uint8_t *)p + o);
+            }
+#pragma unroll
+            for (int k = 0; k < VB / (int)sizeof(T); k++) {
+                const int bit = k * 8 * (int)sizeof(T);
+                v[o / (int)sizeof(T) + k] = (int)((w[bit >> 5] >> (bit & 31)) & (sizeof(T) == 1 ? 0xffu : 0xffffu));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            v[j] = (int)p[j];
+    }
+}
+template <int N, typename T>
+__device__ __forceinline__ void store_row(T *p, const int (&v)[N])
+{
+    constexpr int BYTES = N * (int)sizeof(T), VB = BYTES >= 16 ? 16 : BYTES;
+    if (((uintptr_t)p & (VB - 1)) == 0) {
+#pragma unroll
+        for (int o = 0; o < BYTES; o += VB) {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < VB / (int)sizeof(T); k++) {
+                const int bit = k * 8 * (int)sizeof(T);
+                w[bit >> 5] |= ((uint32_t)v[o / (int)sizeof(T) + k] & (sizeof(T) == 1 ? 0xffu : 0xffffu)) << (bit & 31);
+            }
+            if (VB == 16)
+                *(uint4 *)((uint8_t *)p + o) = make_uint4(w[0], w[1], w[2], w[3]);
+            else if (VB == 8)
+                *(uint2 *)((uint8_t *)p + o) = make_uint2(w[0], w[1]);
+            else
+                *(uint32_t *)((uint8_t *)p + o) = w[0];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            p[j] = (T)v[j];
+    }
+}
+
 /* LDS tile of the register transform: the intermediate of one N x N unit, rows padded by two samples so that a lane
  * per row and a lane per column both walk distinct banks; units 16 dwords apart from a bank-aligned pitch */
 template <int N>

@@ -223,13 +223,14 @@ __global__ __launch_bounds__(TX_THREADS) void k_recon_tu(const int16_t *__restri
             y[j] = v;
     }
     if (live) {
-        const T *prow = pred + U.pred_off + (size_t)r * predStride;
-        T *out = recon + U.recon_off + (size_t)r * reconStride;
+        int pr[N];
+        load_row<N, T>(pred + U.pred_off + (size_t)r * predStride, pr);
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            const int v = (int)prow[j] + y[j];
-            out[j] = (T)(v < 0 ? 0 : v > maxv ? maxv : v);
+            const int v = pr[j] + y[j];
+            y[j] = v < 0 ? 0 : v > maxv ? maxv : v;
         }
+        store_row<N, T>(recon + U.recon_off + (size_t)r * reconStride, y);
     }
 }
 
@@ -830,5 +831,129 @@ extern "C" int svt_amd_unified_quantize(SvtAmdContext *ctx, const SvtAmdQuantUni
         ::memcpy(quant + (size_t)y * coeffStride, hq + y * N, (size_t)area * 2);
         ::memcpy(recon + (size_t)y * coeffStride, hr + y * N, (size_t)area * 2);
     }
+    return SVT_AMD_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* The whole transform unit of the final encode pass in one kernel             */
+/* ------------------------------------------------------------------------- */
+/* EncodeLoop (Codec/EbCodingLoop.c:651: PictureResidual -> EstimateTransform -> UnifiedQuantizeInvQuantize) followed by
+ * EncodeGenerateRecon (:1084: EncodeInvTransform -> PictureAdditionKernel) for one plane of one unit, default coefficient
+ * shape, no RDOQ / masking, DCT units (the 4x4 luma DST unit goes through the separate kernels).  Lane r of a unit: row r of
+ * source and prediction -> residual -> forward transform in registers -> column r of the coefficients -> quantised and
+ * inverse-quantised in registers (the quantised column is the one HBM output besides the picture) -> column r is exactly
+ * what the inverse transform's first pass wants -> row r of the residual -> + prediction, clipped -> reconstruction row r.
+ * HBM per sample: 1 B source + 1 B prediction in, 2 B coefficients + 1 B reconstruction out (8-bit). */
+struct EncodeUnit { int32_t src_off, rec_off; uint8_t qp, slice_type, pad[2]; uint32_t dz_offset; }; /* = SvtAmdEncodeUnit */
+
+template <int N, typename T>
+__global__ __launch_bounds__(TX_THREADS) void k_encode_tu(const EncodeUnit *__restrict__ units, const T *__restrict__ src,
+                                                         uint32_t srcStride, T *__restrict__ rec, uint32_t recStride,
+                                                         int16_t *__restrict__ quantOut, uint32_t *__restrict__ nzOut,
+                                                         uint32_t nunits, int fs1, int fs2, int wrap, int is1, int is2)
+{
+    constexpr int UPW = 64 / N, UPB = UPW * (TX_THREADS / 64), P = TxRegTile<N>::PITCH;
+    constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
+    constexpr int depth = sizeof(T) == 1 ? 8 : 10;
+    __shared__ int16_t tiles[UPB * TxRegTile<N>::UNIT];
+    const int t = threadIdx.x, u = t / N, r = t - u * N;
+    const uint32_t b = blockIdx.x * UPB + u;
+    const bool live = b < nunits;
+    int16_t *tile = tiles + u * TxRegTile<N>::UNIT;
+    EncodeUnit U = {0, 0, 0, 0, {0, 0}, 0};
+    if (live)
+        U = units[b];
+    int x[N], pred[N];
+    if (live) {
+        load_row<N, T>(rec + U.rec_off + (size_t)r * recStride, pred);
+        load_row<N, T>(src + U.src_off + (size_t)r * srcStride, x);
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            x[j] -= pred[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            x[j] = 0, pred[j] = 0;
+    }
+    fwd_2d_regs<N>(x, tile, r, fs1, fs2, wrap); /* x[j] = coefficient (j, r) */
+    /* UnifiedQuantizeInvQuantize, default shape (EbTransforms.c:3097-3160) */
+    const int qpRem = U.qp % 6, qpPer = U.qp / 6;
+    const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
+    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    const int tshift = 15 - depth - LG, shiftedQBits = 14 + qpPer + tshift;
+    const uint32_t q_offset = ((U.slice_type == 2 || U.slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const uint32_t offs = U.dz_offset ? (uint32_t)(U.dz_offset * (1u << shiftedQBits) / 20) : q_offset;
+    const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
+    const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
+    unsigned nz = 0;
+    int c[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const int v = x[j], sign = v < 0 ? -1 : 1;
+        int tq = abs(v);
+        tq = (int)((uint32_t)tq * QF);
+        tq = (int)((uint32_t)tq + offs);
+        tq >>= shiftedQBits;
+        const int qv = clip16i(sign * tq);
+        c[j] = clip16i(((qv * shiftedFFunc) + iq_offset) >> shiftNum);
+        nz += qv != 0;
+        if (live)
+            quantOut[(size_t)b * N * N + j * N + r] = (int16_t)qv;
+    }
+#pragma unroll
+    for (int o = 1; o < N; o <<= 1)
+        nz += __shfl_xor(nz, o);
+    if (live && r == 0)
+        nzOut[b] = nz;
+    /* EncodeInvTransform + PictureAdditionKernel; the tile is free again (both forward passes are through with it) */
+    __builtin_amdgcn_wave_barrier();
+    inv_1d_regs<N>(c, is1, [&](int j, int16_t v) { tile[r * P + j] = v; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        c[k] = tile[k * P + r];
+    int y[N];
+    inv_1d_regs<N>(c, is2, [&](int j, int16_t v) { y[j] = v; });
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const int v = pred[j] + y[j];
+            y[j] = v < 0 ? 0 : v > maxv ? maxv : v;
+        }
+        store_row<N, T>(rec + U.rec_off + (size_t)r * recStride, y);
+    }
+}
+
+extern "C" int svt_amd_encode_tu_batch(SvtAmdContext *ctx, int bytes_per_sample, int size, const SvtAmdEncodeUnit *d_units,
+                                       const void *d_src, uint32_t srcStride, void *d_rec, uint32_t recStride, int16_t *d_quant,
+                                       uint32_t *d_nz, uint32_t nunits)
+{
+    static_assert(sizeof(EncodeUnit) == sizeof(SvtAmdEncodeUnit), "unit layout");
+    if (!ctx || !d_units || !d_src || !d_rec || !d_quant || !d_nz || !nunits || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
+        !(size == 4 || size == 8 || size == 16 || size == 32))
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int inc = bytes_per_sample == 1 ? 0 : 2;
+    /* EstimateTransform (32: 6+inc / 9 wrap 2, 16: 4+inc / 9 wrap 1, 8: 2+inc / 9, 4: 1+inc / 8), EncodeInvTransform 7 / 12-inc */
+    const int fs1 = (size == 32 ? 6 : size == 16 ? 4 : size == 8 ? 2 : 1) + inc, fs2 = size == 4 ? 8 : 9, wrap = size == 32 ? 2 : size == 16 ? 1 : 0;
+    const EncodeUnit *un = (const EncodeUnit *)d_units;
+#define SVT_ENC_LAUNCH(N, T)                                                                                                  \
+    hipLaunchKernelGGL((k_encode_tu<N, T>), dim3((nunits + (64 / N) * 4 - 1) / ((64 / N) * 4)), dim3(TX_THREADS), 0, ctx->stream, un, \
+                       (const T *)d_src, srcStride, (T *)d_rec, recStride, d_quant, d_nz, nunits, fs1, fs2, wrap, 7, 12 - inc)
+    if (bytes_per_sample == 1) {
+        if (size == 32) SVT_ENC_LAUNCH(32, uint8_t);
+        else if (size == 16) SVT_ENC_LAUNCH(16, uint8_t);
+        else if (size == 8) SVT_ENC_LAUNCH(8, uint8_t);
+        else SVT_ENC_LAUNCH(4, uint8_t);
+    } else {
+        if (size == 32) SVT_ENC_LAUNCH(32, uint16_t);
+        else if (size == 16) SVT_ENC_LAUNCH(16, uint16_t);
+        else if (size == 8) SVT_ENC_LAUNCH(8, uint16_t);
+        else SVT_ENC_LAUNCH(4, uint16_t);
+    }
+#undef SVT_ENC_LAUNCH
+    HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }

@@ -188,6 +188,24 @@ def main():
               lambda: lib.svt_amd_full_loop_chroma_batch(ctx, cost.ctypes.data, d_cin.data_ptr(), cres.data_ptr(), cq.data_ptr(),
                                                          cr_.data_ptr(), cout.data_ptr(), nc))
 
+    # the whole transform unit of the final encode pass in one kernel (residual -> T -> Q -> iQ -> iT -> recon), luma plane
+    lib.svt_amd_encode_tu_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, u32, vp, u32, vp, vp, u32]
+    eudt = np.dtype([("src_off", "<i4"), ("rec_off", "<i4"), ("qp", "u1"), ("slice_type", "u1"), ("pad", "u1", 2), ("dz", "<u4")])
+    srcp = torch.randint(0, 256, (H, W), dtype=torch.uint8, device=dev, generator=g)
+    for size in (32, 16, 8):
+        xs, ys = np.meshgrid(np.arange(0, W - size + 1, size), np.arange(0, H - size + 1, size))
+        eu = np.zeros(xs.size, eudt)
+        eu["src_off"] = eu["rec_off"] = (ys * W + xs).ravel()
+        eu["qp"], eu["slice_type"] = 32, 1
+        d_eu = torch.from_numpy(eu.view(np.uint8)).to(dev)
+        recp = (srcp.to(torch.int16) + torch.randint(-12, 13, (H, W), dtype=torch.int16, device=dev, generator=g)).clamp(0, 255).to(torch.uint8)
+        qo2 = torch.zeros(len(eu) * size * size, dtype=torch.int16, device=dev)
+        nz2 = torch.zeros(len(eu), dtype=torch.int32, device=dev)
+        timed("encode TU %dx%d fused (%d units: residual+DCT+quant+iquant+iDCT+recon)" % (size, size, len(eu)),
+              len(eu) * (size * size * 5 + 16 + 4),
+              lambda: lib.svt_amd_encode_tu_batch(ctx, 1, size, d_eu.data_ptr(), srcp.data_ptr(), W, recp.data_ptr(), W, qo2.data_ptr(),
+                                                  nz2.data_ptr(), len(eu)))
+
     print(json.dumps({"iters": iters, "width": W, "height": H, "peak_GBs": PEAK, "kernels": rows}, indent=1))
     lib.svt_amd_context_destroy(ctx)
 
