@@ -871,6 +871,11 @@ typedef struct SvtAmdBiPredBlock { int32_t l0_off, l1_off, dst_off; uint16_t w, 
 SVT_AMD_API int svt_amd_mcp_batch(SvtAmdContext *ctx, int bytes_per_sample, int chroma, int out_raw, const void *d_ref,
                                   uint32_t refStride, void *d_dst, uint32_t dstStride,
                                   const SvtAmdMcpBlock *d_blocks, uint32_t nblocks);
+/* the same with a promise about the largest block width / height of the list (0 = unknown, up to 64): smaller blocks
+ * need less LDS, so more of them are in flight per CU */
+SVT_AMD_API int svt_amd_mcp_batch_sized(SvtAmdContext *ctx, int bytes_per_sample, int chroma, int out_raw, const void *d_ref,
+                                        uint32_t refStride, void *d_dst, uint32_t dstStride,
+                                        const SvtAmdMcpBlock *d_blocks, uint32_t nblocks, uint32_t max_block_dim);
 /* offset: Offset5 (luma) / ChromaOffset5 of Codec/EbDefinitions.h:1022-1030; ignored for 16-bit */
 SVT_AMD_API int svt_amd_bipred_clip_batch(SvtAmdContext *ctx, int bytes_per_sample, const int16_t *d_l0,
                                           const int16_t *d_l1, void *d_dst, uint32_t dstStride, int32_t offset,

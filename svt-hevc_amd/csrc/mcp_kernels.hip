@@ -5,8 +5,9 @@
  * luma 8-tap at the 16 quarter-pel positions, chroma 4-tap at the 64 eighth-pel positions, clipped uni-prediction
  * output or biased int16 raw output for bi-prediction, 8- and 10-bit samples - they are all the H.265 8.5.3.3.3
  * separable filter with the fixed-point conventions listed in oracle/svt_oracle_mcp.c.
- * One workgroup per prediction block; 2-D positions run the horizontal pass into LDS (int16, h + taps - 1 rows),
- * barrier, vertical pass.  Plus BiPredClipping(16bit): average of two raw blocks.
+ * One workgroup per prediction block: the reference window goes to LDS once, 2-D positions run the horizontal pass into
+ * a second LDS array (int16, h + taps - 1 rows), barrier, vertical pass; four outputs per thread and pass.
+ * Plus BiPredClipping(16bit): average of two raw blocks.
  * Bound: HBM for the copy / 1-D positions (1-2 bytes in, 1-2 out per sample), ALU-light otherwise.
  */
 #include "leaf_util.h"
@@ -19,11 +20,19 @@ __device__ __constant__ int8_t c_luma_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {
 __device__ __constant__ int8_t c_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
                                                       {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_mcp(const T *__restrict__ ref, int rstride, void *__restrict__ dst, int dstride,
+/* One workgroup per block.  The reference window is staged in LDS once (every sample of it is read from memory exactly
+ * once); each pass then produces four neighbouring outputs per thread from one run of taps+3 LDS samples (2.75 LDS
+ * reads per output instead of 8 memory reads).  Block widths and heights are multiples of 4. */
+#define MCP_NT 64 /* one wave per block: the blocks are small (16x16 is typical) and independent, barriers stay inside a wave */
+/* MAXD: largest block width / height of the launch - it sizes the two LDS arrays and with them the number of blocks a
+ * CU keeps in flight (16: 1.5 KB per block, 64: 15 KB) */
+template <typename T, int MAXD>
+__global__ __launch_bounds__(MCP_NT) void k_mcp(const T *__restrict__ ref, int rstride, void *__restrict__ dst, int dstride,
                                              const McpBlock *__restrict__ blocks, int chroma, int out_raw)
 {
-    __shared__ int16_t tmp[(64 + 7) * 64];
+    constexpr int WP = MAXD + 8;                    /* window pitch */
+    __shared__ T win[(MAXD + 7 + 4) * WP];          /* + 4 rows: the four-output groups of the last rows read past the window */
+    __shared__ int16_t tmp[(MAXD + 7 + 4) * MAXD];
     const McpBlock b = blocks[blockIdx.x];
     const int w = b.w, h = b.h, fx = b.fx, fy = b.fy, t = threadIdx.x;
     const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3;
@@ -33,46 +42,92 @@ __global__ __launch_bounds__(256) void k_mcp(const T *__restrict__ ref, int rstr
     const int B = (sizeof(T) == 2 || !chroma) ? 8192 : 0;
     const T *r0 = ref + b.ref_off;
     const int ds = out_raw ? w : dstride;
-    const bool two_d = fx && fy;
     /* only the taps the reference's own functions read (the 7-tap quarter positions never touch the 8th sample) */
-    const int kx0 = (!chroma && fx == 3) ? 1 : 0, kx1 = (!chroma && fx == 1) ? 7 : ntaps;
-    const int ky0 = (!chroma && fy == 3) ? 1 : 0, ky1 = (!chroma && fy == 1) ? 7 : ntaps;
-    if (two_d) {
-        const int rows = h + ky1 - ky0 - 1; /* tmp row j = reference row j + first + ky0 */
-        for (int i = t; i < rows * w; i += 256) {
-            const int j = i / w, x = i - j * w;
-            const T *p = r0 + (ptrdiff_t)(j + first + ky0) * rstride + x + first;
-            int hs = 0;
-            for (int k = kx0; k < kx1; k++)
-                hs += tx[k] * (int)p[k];
-            tmp[i] = (int16_t)((hs - (B << s1)) >> s1);
+    const int kx0 = fx ? ((!chroma && fx == 3) ? 1 : 0) : 0, kx1 = fx ? ((!chroma && fx == 1) ? 7 : ntaps) : 1;
+    const int ky0 = fy ? ((!chroma && fy == 3) ? 1 : 0) : 0, ky1 = fy ? ((!chroma && fy == 1) ? 7 : ntaps) : 1;
+    /* window: columns [ox, ox + cols), rows [oy, oy + rows) relative to the block */
+    const int ox = fx ? first + kx0 : 0, cols = w + (kx1 - kx0 - 1), oy = fy ? first + ky0 : 0, rows = h + (ky1 - ky0 - 1);
+    {
+        const uint32_t rc = (1u << 20) / (uint32_t)cols + 1u; /* i / cols for i < 2^13 by reciprocal multiplication */
+        for (int i = t; i < rows * cols; i += MCP_NT) {
+            const int j = (int)(((uint32_t)i * rc) >> 20), x = i - j * cols;
+            win[j * WP + x] = r0[(ptrdiff_t)(j + oy) * rstride + x + ox];
         }
-        __syncthreads();
     }
-    for (int i = t; i < w * h; i += 256) {
-        const int y = i / w, x = i - y * w;
-        int v;
-        if (two_d) {
-            int sum = 0;
-            for (int j = ky0; j < ky1; j++)
-                sum += ty[j] * (int)tmp[(y + j - ky0) * w + x];
-            v = out_raw ? (sum >> 6) : min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
-        } else if (!fx && !fy) {
-            const int p = r0[(ptrdiff_t)y * rstride + x];
-            v = out_raw ? (int16_t)((p << (6 - s1)) - B) : p;
-        } else {
-            const ptrdiff_t step = fx ? 1 : rstride;
-            const T *p = r0 + (ptrdiff_t)y * rstride + x + first * step;
-            const int8_t *tp = fx ? tx : ty;
-            int sum = 0;
-            for (int k = fx ? kx0 : ky0; k < (fx ? kx1 : ky1); k++)
-                sum += tp[k] * (int)p[k * step];
-            v = out_raw ? ((sum - (B << s1)) >> s1) : min(maxv, max(0, (sum + 32) >> 6));
-        }
+    __syncthreads();
+    auto put = [&](int x, int y, int v) {
         if (out_raw)
             ((int16_t *)dst)[b.dst_off + y * ds + x] = (int16_t)v;
         else
             ((T *)dst)[b.dst_off + (ptrdiff_t)y * ds + x] = (T)v;
+    };
+    const int wq = (w + 3) >> 2, hq = (h + 3) >> 2; /* groups of four (the last one may be partial) */
+    if (!fx && !fy) {
+        for (int i = t; i < w * h; i += MCP_NT) {
+            const int y = i / w, x = i - y * w, p = win[y * WP + x];
+            put(x, y, out_raw ? (int16_t)((p << (6 - s1)) - B) : p);
+        }
+        return;
+    }
+    if (fx) { /* horizontal pass over every window row: four outputs per thread from one run of samples */
+        const int nt = kx1 - kx0;
+        const int lgq = 31 - __clz(wq), gpr = 1 << lgq; /* wq is 1, 2, 4, 8 or 16 for the power-of-two block widths ... */
+        const bool pow2 = gpr == wq;
+        for (int i = t; i < rows * wq; i += MCP_NT) {
+            const int j = pow2 ? i >> lgq : i / wq, x0 = (i - j * wq) * 4; /* ... other widths take the division */
+            int smp[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+                smp[k] = k < nt + 3 ? (int)win[j * WP + x0 + k] : 0;
+            int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < nt) {
+                    const int c = tx[kx0 + k];
+                    acc[0] += c * smp[k], acc[1] += c * smp[k + 1], acc[2] += c * smp[k + 2], acc[3] += c * smp[k + 3];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (x0 + q >= w)
+                    break;
+                if (fy)
+                    tmp[j * w + x0 + q] = (int16_t)((acc[q] - (B << s1)) >> s1);
+                else
+                    put(x0 + q, j, out_raw ? ((acc[q] - (B << s1)) >> s1) : min(maxv, max(0, (acc[q] + 32) >> 6)));
+            }
+        }
+        if (!fy)
+            return;
+        __syncthreads();
+    }
+    /* vertical pass: four outputs of one column per thread */
+    const int nt = ky1 - ky0;
+    const int lgw = 31 - __clz(w);
+    const bool wpow2 = (1 << lgw) == w;
+    for (int i = t; i < hq * w; i += MCP_NT) {
+        const int yq = wpow2 ? i >> lgw : i / w, x = i - yq * w, y0 = yq * 4;
+        int smp[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++)
+            smp[k] = k < nt + 3 ? (fx ? (int)tmp[(y0 + k) * w + x] : (int)win[(y0 + k) * WP + x]) : 0;
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < nt) {
+                const int c = ty[ky0 + k];
+                acc[0] += c * smp[k], acc[1] += c * smp[k + 1], acc[2] += c * smp[k + 2], acc[3] += c * smp[k + 3];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (y0 + q >= h)
+                break;
+            int v;
+            if (fx)
+                v = out_raw ? (acc[q] >> 6) : min(maxv, max(0, (acc[q] + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
+            else
+                v = out_raw ? ((acc[q] - (B << s1)) >> s1) : min(maxv, max(0, (acc[q] + 32) >> 6));
+            put(x, y0 + q, v);
+        }
     }
 }
 
@@ -91,6 +146,18 @@ __global__ __launch_bounds__(256) void k_bipred_clip(const int16_t *__restrict__
     }
 }
 
+template <typename T>
+static void launch_mcp(hipStream_t st, uint32_t nblocks, uint32_t max_dim, const T *ref, int rstride, void *dst, int dstride,
+                       const McpBlock *blocks, int chroma, int out_raw)
+{
+    if (max_dim && max_dim <= 16)
+        hipLaunchKernelGGL((k_mcp<T, 16>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
+    else if (max_dim && max_dim <= 32)
+        hipLaunchKernelGGL((k_mcp<T, 32>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
+    else
+        hipLaunchKernelGGL((k_mcp<T, 64>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
+}
+
 static int check_blocks_args(SvtAmdContext *ctx, const void *a, const void *b, const void *c, uint32_t n, int bps)
 {
     if (!ctx || !a || !b || !c || !n || (bps != 1 && bps != 2))
@@ -98,22 +165,28 @@ static int check_blocks_args(SvtAmdContext *ctx, const void *a, const void *b, c
     return SVT_AMD_OK;
 }
 
+extern "C" int svt_amd_mcp_batch_sized(SvtAmdContext *ctx, int bytes_per_sample, int chroma, int out_raw, const void *d_ref,
+                                       uint32_t refStride, void *d_dst, uint32_t dstStride, const SvtAmdMcpBlock *d_blocks,
+                                       uint32_t nblocks, uint32_t max_block_dim)
+{
+    int rc = check_blocks_args(ctx, d_ref, d_dst, d_blocks, nblocks, bytes_per_sample);
+    if (rc || max_block_dim > 64)
+        return rc ? rc : SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes_per_sample == 1)
+        launch_mcp<uint8_t>(ctx->stream, nblocks, max_block_dim, (const uint8_t *)d_ref, (int)refStride, d_dst, (int)dstStride,
+                            (const McpBlock *)d_blocks, chroma, out_raw);
+    else
+        launch_mcp<uint16_t>(ctx->stream, nblocks, max_block_dim, (const uint16_t *)d_ref, (int)refStride, d_dst, (int)dstStride,
+                             (const McpBlock *)d_blocks, chroma, out_raw);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
 extern "C" int svt_amd_mcp_batch(SvtAmdContext *ctx, int bytes_per_sample, int chroma, int out_raw, const void *d_ref,
                                  uint32_t refStride, void *d_dst, uint32_t dstStride, const SvtAmdMcpBlock *d_blocks,
                                  uint32_t nblocks)
 {
-    int rc = check_blocks_args(ctx, d_ref, d_dst, d_blocks, nblocks, bytes_per_sample);
-    if (rc)
-        return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (bytes_per_sample == 1)
-        hipLaunchKernelGGL(k_mcp<uint8_t>, dim3(nblocks), dim3(256), 0, ctx->stream, (const uint8_t *)d_ref, (int)refStride,
-                           d_dst, (int)dstStride, (const McpBlock *)d_blocks, chroma, out_raw);
-    else
-        hipLaunchKernelGGL(k_mcp<uint16_t>, dim3(nblocks), dim3(256), 0, ctx->stream, (const uint16_t *)d_ref, (int)refStride,
-                           d_dst, (int)dstStride, (const McpBlock *)d_blocks, chroma, out_raw);
-    HIP_TRY(hipGetLastError());
-    return SVT_AMD_OK;
+    return svt_amd_mcp_batch_sized(ctx, bytes_per_sample, chroma, out_raw, d_ref, refStride, d_dst, dstStride, d_blocks, nblocks, 0);
 }
 
 extern "C" int svt_amd_bipred_clip_batch(SvtAmdContext *ctx, int bytes_per_sample, const int16_t *d_l0, const int16_t *d_l1,
@@ -167,7 +240,7 @@ static void mcp_leaf(int chroma, int out_raw, int fx, int fy, const T *refPic, u
     McpBlock hb = {(int32_t)(-(ptrdiff_t)ylo * srcStride - xlo), 0, (uint16_t)w, (uint16_t)h, (uint8_t)fx, (uint8_t)fy, {0, 0}};
     if (hipMemcpy(bl.d, &hb, sizeof(hb), hipMemcpyHostToDevice) != hipSuccess)
         return;
-    hipLaunchKernelGGL(k_mcp<T>, dim3(1), dim3(256), 0, 0, (const T *)r.d, (int)srcStride, (void *)d.d, (int)dstStride,
+    hipLaunchKernelGGL((k_mcp<T, 64>), dim3(1), dim3(MCP_NT), 0, 0, (const T *)r.d, (int)srcStride, (void *)d.d, (int)dstStride,
                        (const McpBlock *)bl.d, chroma, out_raw);
     if (finish("mcp"))
         d.download(dst, dbytes);
@@ -359,12 +432,18 @@ extern "C" int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob
                 continue;
             const uint8_t *plane = (const uint8_t *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr);
             const int rs = (int)(p ? R->strideC : R->strideY), ds = (int)(p ? strideC : strideY);
+            auto max_dim = [](const std::vector<McpBlock> &v) {
+                uint32_t m = 0;
+                for (const McpBlock &k : v)
+                    m = k.w > m ? k.w : m, m = k.h > m ? k.h : m;
+                return m;
+            };
             if (!uni[l][p].empty())
-                hipLaunchKernelGGL(k_mcp<uint8_t>, dim3((unsigned)uni[l][p].size()), dim3(256), 0, ctx->stream, plane, rs, (void *)dst[p], ds,
-                                   (const McpBlock *)(d_slab + off_uni[l][p]), p != 0, 0);
+                launch_mcp<uint8_t>(ctx->stream, (uint32_t)uni[l][p].size(), max_dim(uni[l][p]), plane, rs, (void *)dst[p], ds,
+                                    (const McpBlock *)(d_slab + off_uni[l][p]), p != 0, 0);
             if (!raw[l][p].empty())
-                hipLaunchKernelGGL(k_mcp<uint8_t>, dim3((unsigned)raw[l][p].size()), dim3(256), 0, ctx->stream, plane, rs,
-                                   (void *)(d_slab + off_int[l][p]), 0, (const McpBlock *)(d_slab + off_raw[l][p]), p != 0, 1);
+                launch_mcp<uint8_t>(ctx->stream, (uint32_t)raw[l][p].size(), max_dim(raw[l][p]), plane, rs, (void *)(d_slab + off_int[l][p]), 0,
+                                    (const McpBlock *)(d_slab + off_raw[l][p]), p != 0, 1);
         }
     for (int p = 0; p < 3; p++)
         if (!bi[p].empty()) /* Offset5 / ChromaOffset5 (Codec/EbDefinitions.h:1022-1030) */

@@ -126,7 +126,7 @@ def main():
               lambda: lib.svt_amd_sao_apply_picture(ctx, bps, ps, pd, W, W // 2, W, H, d_lc.data_ptr(), 1, 1))
 
     # HEVC motion compensation: a 1080p luma plane as 16x16 PUs with random quarter-pel vectors
-    lib.svt_amd_mcp_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp, u32, vp, u32]
+    lib.svt_amd_mcp_batch_sized.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp, u32, vp, u32, u32]
     PADX = 80
     st = W + 2 * PADX
     refp = torch.randint(0, 256, (H + 2 * PADX, st), dtype=torch.uint8, device=dev, generator=g)
@@ -142,7 +142,7 @@ def main():
     d_b = torch.from_numpy(blocks.view(np.uint8)).to(dev)
     pred = torch.zeros((H, W), dtype=torch.uint8, device=dev)
     timed("MCP luma uni-pred, %d 16x16 PUs, random 1/4-pel MVs" % len(blocks), 2 * npx,
-          lambda: lib.svt_amd_mcp_batch(ctx, 1, 0, 0, refp.data_ptr(), st, pred.data_ptr(), W, d_b.data_ptr(), len(blocks)))
+          lambda: lib.svt_amd_mcp_batch_sized(ctx, 1, 0, 0, refp.data_ptr(), st, pred.data_ptr(), W, d_b.data_ptr(), len(blocks), 16))
 
     # coefficient rate estimation: every 8x8 / 32x32 TU of a plane, ~10 % non-zero coefficients
     sys.path.insert(0, os.path.join(ROOT, "tests"))
