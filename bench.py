@@ -228,8 +228,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search), one batch = 2 launches", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of the two ME kernels per batch at this configuration
-                         # (profiles/r01_e_pmc_fetch.csv, _write.csv; separate passes, KB -> bytes, uncorrected)
-                         "traffic": int((139024.2 + 85324.1 + 232041.2 + 37221.7) * 1024) if B == 16 else None,
+                         # (profiles/r01_g_pmc_fetch.csv, _write.csv; separate passes, KB -> bytes, uncorrected)
+                         "traffic": int((134699.6 + 85340.2 + 224357.7 + 38430.8) * 1024) if B == 16 else None,
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms.value, 4),
                          "launches_timed": me_n.value, "pictures_per_launch": B,
                          "prep_avg_ms": round(prep_ms.value, 4), "prep_launches": prep_n.value,
