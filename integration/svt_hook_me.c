@@ -692,6 +692,70 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
 }
 
 /*
+ * Mode-decision inter prediction: Inter2Nx2NPuPredictionHevc (EbInterPrediction.c:469; entries of the prediction tables
+ * PredictionFunTableOl / Cl, EbProductCodingLoop.c:218-230) does the same clamp + interpolation as the encode-pass
+ * function, for the candidate's vectors, into the candidate's LCU-local prediction buffer (64-sample pitch) and for the
+ * planes of componentMask.  Same switch and the same resident reference pictures as above; 8-bit encoders only.
+ */
+EB_ERRORTYPE __real_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextPtr, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                               ModeDecisionCandidateBuffer_t *candidateBufferPtr);
+static unsigned long g_md_inter_gpu;
+
+EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextPtr, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                               ModeDecisionCandidateBuffer_t *candidateBufferPtr)
+{
+    if (g_inter_state == 0)
+        g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
+    const SequenceControlSet_t *scs = (const SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    const ModeDecisionCandidate_t *c = candidateBufferPtr->candidatePtr;
+    const EB_U32 size = mdContextPtr->cuStats->size, dir = c->predictionDirection[mdContextPtr->puItr];
+    EbPictureBufferDesc_t *dst = candidateBufferPtr->predictionPtr;
+    if (g_inter_state < 0 || !g_ctx || scs->staticConfig.encoderBitDepth > EB_8BIT || mdContextPtr->cuUseRefSrcFlag || size < 8 || size > 64 ||
+        dir > BI_PRED || dst->strideY != 64 || dst->strideCb != 32 || dst->strideCr != 32)
+        return __real_Inter2Nx2NPuPredictionHevc(mdContextPtr, componentMask, pcs, candidateBufferPtr);
+    SvtAmdInterPuJob job;
+    memset(&job, 0, sizeof(job));
+    job.pu_x = (uint16_t)mdContextPtr->cuOriginX, job.pu_y = (uint16_t)mdContextPtr->cuOriginY, job.pu_w = job.pu_h = (uint8_t)size;
+    job.pred_dir = (uint8_t)dir;
+    job.mv[0][0] = c->motionVector_x_L0, job.mv[0][1] = c->motionVector_y_L0, job.mv[1][0] = c->motionVector_x_L1, job.mv[1][1] = c->motionVector_y_L1;
+    pthread_mutex_lock(&g_lock);
+    const SvtAmdRefPicture *refs[2] = {NULL, NULL};
+    SvtAmdRefPicture copy[2];
+    for (int l = 0; l < 2; l++)
+        if (dir == (EB_U32)l || dir == BI_PRED) {
+            const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
+            copy[l] = *resident_reference(ro->referencePicture, ro->refPOC);
+            refs[l] = &copy[l];
+        }
+    if (!g_inter_scratch[0])
+        for (int k = 0; k < 3; k++)
+            if (svt_amd_device_alloc(g_ctx, k ? 1024 : 4096, &g_inter_scratch[k]))
+                die("svt_amd_device_alloc");
+    if (svt_amd_inter_pu_batch(g_ctx, &job, 1, refs[0], refs[1], (uint8_t *)g_inter_scratch[0], size, (uint8_t *)g_inter_scratch[1],
+                               (uint8_t *)g_inter_scratch[2], size >> 1))
+        die("svt_amd_inter_pu_batch");
+    uint8_t hy[4096], hcb[1024], hcr[1024];
+    if (((componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) && svt_amd_device_download(g_ctx, hy, g_inter_scratch[0], (size_t)size * size)) ||
+        ((componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) && (svt_amd_device_download(g_ctx, hcb, g_inter_scratch[1], (size_t)size * size / 4) ||
+                                                               svt_amd_device_download(g_ctx, hcr, g_inter_scratch[2], (size_t)size * size / 4))))
+        die("svt_amd_device_download");
+    if (g_md_inter_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU\n");
+    pthread_mutex_unlock(&g_lock);
+    const uint32_t oy = ((mdContextPtr->cuOriginY & 63) * 64) + (mdContextPtr->cuOriginX & 63);
+    const uint32_t oc = ((((mdContextPtr->cuOriginY & 63) * 32) + (mdContextPtr->cuOriginX & 63)) >> 1);
+    if (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK)
+        for (uint32_t y = 0; y < size; y++)
+            memcpy(dst->bufferY + oy + y * 64, hy + y * size, size);
+    if (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK)
+        for (uint32_t y = 0; y < size / 2; y++) {
+            memcpy(dst->bufferCb + oc + y * 32, hcb + y * (size / 2), size / 2);
+            memcpy(dst->bufferCr + oc + y * 32, hcr + y * (size / 2), size / 2);
+        }
+    return EB_ErrorNone;
+}
+
+/*
  * Final encode pass, quantiser: UnifiedQuantizeInvQuantize (EbTransforms.c:2978, called from the static EncodeLoop /
  * EncodeLoop16bit) is answered by svt_amd_unified_quantize() with SVT_HOOK_QUANT=1 on its paths without RDOQ / PM-core and
  * without perceptual masking (everything the default configuration reaches); other calls go to the reference code.

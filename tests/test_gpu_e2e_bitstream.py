@@ -161,8 +161,9 @@ INTER_CASES = [
 
 @pytest.mark.parametrize("kind,w,h,n,args", INTER_CASES)
 def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind, w, h, n, args):
-    """The encode pass's inter prediction of every prediction unit (EncodePassInterPrediction) answered by
-    svt_amd_inter_pu_batch from reference pictures resident on the device (SVT_HOOK_INTER=1)."""
+    """The encode pass's inter prediction of every prediction unit (EncodePassInterPrediction) and the mode decision's
+    inter prediction of every candidate (Inter2Nx2NPuPredictionHevc) answered by svt_amd_inter_pu_batch from reference
+    pictures resident on the device (SVT_HOOK_INTER=1)."""
     yuv = str(tmp_path / "clip.yuv")
     S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
@@ -172,6 +173,7 @@ def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind,
     finally:
         del os.environ["SVT_HOOK_INTER"]
     assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU" in log, log[-1000:]
+    assert "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
