@@ -20,6 +20,9 @@
 #include "EbPictureControlSet.h"
 #include "EbSequenceControlSet.h"
 #include "EbDeblockingFilter.h"
+#include "EbCodingUnit.h"
+#include "EbReferenceObject.h"
+#include "EbUtility.h"
 
 #define DLF_DUMP_MAGIC 0x20464c44U /* "DLF " */
 
@@ -168,6 +171,49 @@ static void last_call(EbPictureBufferDesc_t *pic, PictureControlSet_t *pcs)
         fwrite(d->bsv, 256, d->nlcu, g_file);
         fwrite(d->bsh, 256, d->nlcu, g_file);
         fwrite(pcs->qpArray, 1, pcs->qpArraySize, g_file);
+        /* inputs of the boundary-strength derivation (SetBSArrayBasedOnPUBoundary / TUBoundary, :339-530), as picture-level
+         * maps: one entry per 8x8 block from the final coding-unit tree, the luma cbf map per 4x4 block, the two reference
+         * POCs, the per-LCU tile-edge flags */
+        {
+            typedef struct CuMapEntry { uint8_t mode, dir, size_log2, pad; int16_t mv[2][2]; } CuMapEntry;
+            const uint32_t bw = scs->lumaWidth >> 3, bh = scs->lumaHeight >> 3;
+            CuMapEntry *map = (CuMapEntry *)calloc((size_t)bw * bh, sizeof(CuMapEntry));
+            uint8_t *edge = (uint8_t *)calloc(d->nlcu, 1);
+            for (uint32_t l = 0; l < d->nlcu; l++) {
+                LargestCodingUnit_t *lcu = pcs->lcuPtrArray[l];
+                edge[l] = (uint8_t)((lcu->lcuEdgeInfoPtr->tileLeftEdgeFlag ? 1 : 0) | (lcu->lcuEdgeInfoPtr->tileTopEdgeFlag ? 2 : 0));
+                uint32_t leaf = 0;
+                while (leaf < CU_MAX_COUNT) {
+                    const CodingUnit_t *cu = lcu->codedLeafArrayPtr[leaf];
+                    const CodedUnitStats_t *st = GetCodedUnitStats(leaf);
+                    if (cu->splitFlag == EB_FALSE) {
+                        const uint32_t x0 = lcu->originX + st->originX, y0 = lcu->originY + st->originY;
+                        for (uint32_t y = y0; y < y0 + st->size && y < scs->lumaHeight; y += 8)
+                            for (uint32_t x = x0; x < x0 + st->size && x < scs->lumaWidth; x += 8) {
+                                CuMapEntry *e = &map[(y >> 3) * bw + (x >> 3)];
+                                e->mode = (uint8_t)cu->predictionModeFlag, e->dir = (uint8_t)cu->predictionUnitArray[0].interPredDirectionIndex;
+                                e->size_log2 = (uint8_t)st->sizeLog2;
+                                e->mv[0][0] = cu->predictionUnitArray[0].mv[0].x, e->mv[0][1] = cu->predictionUnitArray[0].mv[0].y;
+                                e->mv[1][0] = cu->predictionUnitArray[0].mv[1].x, e->mv[1][1] = cu->predictionUnitArray[0].mv[1].y;
+                            }
+                        leaf += DepthOffset[st->depth];
+                    } else {
+                        leaf++;
+                    }
+                }
+            }
+            uint64_t poc[2] = {0, 0};
+            for (int l = 0; l < 2; l++)
+                if (pcs->sliceType != EB_I_PICTURE && pcs->refPicPtrArray[l])
+                    poc[l] = ((EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr)->refPOC;
+            const uint32_t tag[4] = {0x31585342U /* "BSX1" */, bw * bh, (scs->lumaWidth >> 2) * (scs->lumaHeight >> 2), d->nlcu};
+            fwrite(tag, sizeof(tag), 1, g_file);
+            fwrite(map, sizeof(CuMapEntry), (size_t)bw * bh, g_file);
+            fwrite(pcs->cbfMapArray, 1, tag[2], g_file);
+            fwrite(poc, sizeof(poc), 1, g_file);
+            fwrite(edge, 1, d->nlcu, g_file);
+            free(map), free(edge);
+        }
         fflush(g_file);
     }
     for (int p = 0; p < 3; p++)

@@ -120,6 +120,10 @@ void svt_oracle_Chroma2SampleEdgeDLFCore(int bps, void *cb, void *cr, uint32_t s
 void svt_oracle_dlf_picture(int bps, void *y, uint32_t strideY, void *cb, void *cr, uint32_t strideC, uint32_t width,
                             uint32_t height, const uint8_t *bs_v, const uint8_t *bs_h, const uint8_t *qp, uint32_t qpStride,
                             int tcOffset, int betaOffset, int cbQpOffset, int crQpOffset);
+/* picture-level boundary-strength derivation from coding-unit / cbf maps (see svt_oracle_loopfilter.c) */
+typedef struct SvtOracleCuMapEntry { uint8_t mode, dir, size_log2, pad; int16_t mv[2][2]; } SvtOracleCuMapEntry;
+void svt_oracle_bs_picture(const SvtOracleCuMapEntry *map, const uint8_t *cbf, uint32_t width, uint32_t height, int sliceType,
+                           const uint64_t refPoc[2], const uint8_t *lcuEdge, uint8_t *bs_v, uint8_t *bs_h);
 /* whole-picture SAO application (out of place); one parameter record per LCU, same field order as SaoParameters_t after
  * the two merge flags (Codec/EbCodingUnit.h:137-146) plus the tile-edge flags ApplySaoOffsetsLcu reads */
 typedef struct SvtOracleSaoLcu {

@@ -332,3 +332,76 @@ void svt_oracle_sao_apply_picture(int bps, const void *const src[3], void *const
             }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Picture-level boundary-strength derivation: what SetBSArrayBasedOnPUBoundary (Codec/EbDeblockingFilter.c:339-442) and
+ * SetBSArrayBasedOnTUBoundary (:472-530) with CalculateBSForPUBoundary (:109-335) / CalculateBSForTUBoundaryInsidePU
+ * (:444-468), called per coding unit from the encode pass, leave in the per-LCU arrays.  Inputs as picture-level maps: one
+ * entry per 8x8 block (prediction mode 1 inter / 2 intra, inter direction, log2 of the coding-unit size, the two motion
+ * vectors), the luma cbf per 4x4 block, slice type, the two reference POCs, per-LCU tile-edge flags (1 left, 2 top).
+ * Only 2Nx2N prediction units exist; transform-unit edges inside a coding unit occur only in 64x64 units (four 32x32).
+ * Output layout = the reference's: [lcu raster][4x4 block raster inside the LCU]; entries the reference never writes
+ * stay 0.  Pinned by tests/test_oracle_dlf_golden.py against the arrays of real encoder runs.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static int mv_far(const int16_t a[2], const int16_t b[2])
+{
+    return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; /* CHECK_MV_COMPONENT_EQUAL_OR_GREATER_THAN_4 (EbDeblockingFilter.h:25) */
+}
+
+static int bs_pu_edge(const SvtOracleCuMapEntry *cur, const SvtOracleCuMapEntry *nb, int cbfAny, int sliceType, const uint64_t poc[2])
+{
+    if (cur->mode == 2 || nb->mode == 2)
+        return 2;
+    if (sliceType == 1) /* EB_P_PICTURE: one list, one reference */
+        return mv_far(cur->mv[0], nb->mv[0]) | cbfAny;
+    int c1;
+    switch (cur->dir + nb->dir * 3) {
+    case 0: c1 = mv_far(cur->mv[0], nb->mv[0]); break;                                   /* L0 / L0: same picture */
+    case 1: c1 = poc[1] != poc[0] || mv_far(cur->mv[1], nb->mv[0]); break;
+    case 3: c1 = poc[0] != poc[1] || mv_far(cur->mv[0], nb->mv[1]); break;
+    case 4: c1 = mv_far(cur->mv[1], nb->mv[1]); break;
+    case 8:
+        if (poc[0] == poc[1]) /* all four equalities of :243-244 hold */
+            c1 = (mv_far(cur->mv[0], nb->mv[0]) || mv_far(cur->mv[1], nb->mv[1])) && (mv_far(cur->mv[0], nb->mv[1]) || mv_far(cur->mv[1], nb->mv[0]));
+        else                  /* list-wise equal (:267): the same two pictures on both sides */
+            c1 = mv_far(cur->mv[0], nb->mv[0]) || mv_far(cur->mv[1], nb->mv[1]);
+        break;
+    default: c1 = 1; break;                                                              /* one side bi, the other uni */
+    }
+    return c1 | cbfAny;
+}
+
+void svt_oracle_bs_picture(const SvtOracleCuMapEntry *map, const uint8_t *cbf, uint32_t width, uint32_t height, int sliceType,
+                           const uint64_t refPoc[2], const uint8_t *lcuEdge, uint8_t *bs_v, uint8_t *bs_h)
+{
+    const uint32_t bw = width >> 3, bh = height >> 3, cw = width >> 2, lcuCols = (width + 63) >> 6, nlcu = lcuCols * ((height + 63) >> 6);
+    memset(bs_v, 0, (size_t)nlcu * 256);
+    memset(bs_h, 0, (size_t)nlcu * 256);
+    for (int dir = 0; dir < 2; dir++) /* 0: vertical edges (left neighbour), 1: horizontal edges (upper neighbour) */
+        for (uint32_t by = 0; by < bh; by++)
+            for (uint32_t bx = 0; bx < bw; bx++) {
+                const SvtOracleCuMapEntry *cur = &map[by * bw + bx];
+                const uint32_t x = bx << 3, y = by << 3, size = 1u << cur->size_log2, pos = dir ? y : x;
+                const uint32_t lcu = (y >> 6) * lcuCols + (x >> 6);
+                const int cuEdge = (pos & (size - 1)) == 0;                 /* the block's left / top side is its coding unit's */
+                const int tuEdge = !cuEdge && size == 64 && (pos & 31) == 0; /* the 32x32 units of a 64x64 coding unit */
+                if (!cuEdge && !tuEdge)
+                    continue;
+                if (cuEdge && (pos & 63) == 0 && (lcuEdge[lcu] & (dir ? 2 : 1)))
+                    continue; /* tile (or picture) boundary: never filtered, the array keeps 0 */
+                if (pos == 0)
+                    continue;
+                const SvtOracleCuMapEntry *nb = dir ? &map[(by - 1) * bw + bx] : &map[by * bw + bx - 1];
+                for (uint32_t k = 0; k < 2; k++) { /* the two 4-sample segments of the 8-sample block side */
+                    const uint32_t sx = dir ? x + 4 * k : x, sy = dir ? y : y + 4 * k;
+                    const uint32_t nx = dir ? sx : sx - 4, ny = dir ? sy - 4 : sy;
+                    const int cbfAny = cbf[(sy >> 2) * cw + (sx >> 2)] || cbf[(ny >> 2) * cw + (nx >> 2)];
+                    int b;
+                    if (tuEdge)
+                        b = cur->mode == 2 ? 2 : cbfAny;
+                    else
+                        b = bs_pu_edge(cur, nb, cbfAny, sliceType, refPoc);
+                    (dir ? bs_h : bs_v)[lcu * 256 + ((sx & 63) >> 2) + (((sy & 63) >> 2) << 4)] = (uint8_t)b;
+                }
+            }
+}

@@ -24,6 +24,7 @@ HDR = np.dtype([("magic", "<u4"), ("header_size", "<u4"), ("picture_number", "<u
                 ("qp_stride", "<u4"), ("qp_size", "<u4"), ("tc_offset", "<i4"), ("beta_offset", "<i4"),
                 ("cb_qp_offset", "<i4"), ("cr_qp_offset", "<i4")])
 
+CUMAP = np.dtype([("mode", "u1"), ("dir", "u1"), ("size_log2", "u1"), ("pad", "u1"), ("mv", "<i2", (2, 2))])
 SAO_HDR = np.dtype([("magic", "<u4"), ("header_size", "<u4"), ("picture_number", "<u8"), ("nlcu", "<u4"),
                     ("sao_flag", "<u4", 2), ("pad", "<u4")])
 SAO_LCU = np.dtype([("merge_left", "u1"), ("merge_up", "u1"), ("edge_flags", "u1"), ("pad", "u1"), ("type", "<u4", 2),
@@ -57,7 +58,13 @@ def parse(dump):
         bsv = np.frombuffer(raw, np.uint8, nlcu * 256, pos).reshape(nlcu, 256).copy(); pos += nlcu * 256
         bsh = np.frombuffer(raw, np.uint8, nlcu * 256, pos).reshape(nlcu, 256).copy(); pos += nlcu * 256
         qp = np.frombuffer(raw, np.uint8, int(h["qp_size"]), pos).copy(); pos += int(h["qp_size"])
-        recs.append((h, planes, bsv, bsh, qp))
+        tag = np.frombuffer(raw, "<u4", 4, pos); pos += 16
+        assert tag[0] == 0x31585342, hex(int(tag[0]))
+        cumap = np.frombuffer(raw, CUMAP, int(tag[1]), pos).copy(); pos += CUMAP.itemsize * int(tag[1])
+        cbf = np.frombuffer(raw, np.uint8, int(tag[2]), pos).copy(); pos += int(tag[2])
+        refpoc = np.frombuffer(raw, "<u8", 2, pos).copy(); pos += 16
+        edge = np.frombuffer(raw, np.uint8, int(tag[3]), pos).copy(); pos += int(tag[3])
+        recs.append((h, planes, bsv, bsh, qp, cumap, cbf, refpoc, edge))
     return recs
 
 
@@ -106,7 +113,8 @@ def run_case(name):
     order = sorted(range(len(recs)), key=lambda i: -changed[i])[:keep]
     out, sao_changed = {}, {}
     for k, i in enumerate(sorted(order)):
-        h0, planes, bsv, bsh, qp = recs[i]
+        h0, planes, bsv, bsh, qp, cumap, cbf, refpoc, edge = recs[i]
+        out["cumap%d" % k], out["cbf%d" % k], out["refpoc%d" % k], out["lcu_edge%d" % k] = cumap, cbf, refpoc, edge
         out["hdr%d" % k] = np.array([h0])
         for nm, a in zip(("pre_y", "pre_cb", "pre_cr", "post_y", "post_cb", "post_cr"), planes):
             out["%s%d" % (nm, k)] = a

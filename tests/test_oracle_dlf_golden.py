@@ -22,7 +22,8 @@ def load_dlf_case(name):
         pics.append(dict(hdr=g["hdr%d" % k][0], pre=[g["pre_%s%d" % (c, k)] for c in ("y", "cb", "cr")],
                          post=[g["post_%s%d" % (c, k)] for c in ("y", "cb", "cr")], bsv=g["bsv%d" % k], bsh=g["bsh%d" % k],
                          qp=g["qp%d" % k], final=[g["final_%s%d" % (c, k)] for c in ("y", "cb", "cr")],
-                         sao_flag=g["sao_flag%d" % k], sao_lcu=g["sao_lcu%d" % k]))
+                         sao_flag=g["sao_flag%d" % k], sao_lcu=g["sao_lcu%d" % k], cumap=g["cumap%d" % k], cbf=g["cbf%d" % k],
+                         refpoc=g["refpoc%d" % k], lcu_edge=g["lcu_edge%d" % k]))
     return pics
 
 
@@ -85,3 +86,25 @@ def test_sao_apply_picture_oracle_matches_reference(oracle, name):
         seen |= set(np.unique(pic["sao_lcu"]["type"]).tolist())
     if name in ("p_416x240_m9", "tiles_640x384_m9"):
         assert seen >= {1, 2, 3, 4}, seen
+
+
+def oracle_bs(oracle, pic):
+    h = pic["hdr"]
+    oracle.svt_oracle_bs_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
+    oracle.svt_oracle_bs_picture.restype = None
+    cumap, cbf, poc, edge = (np.ascontiguousarray(pic[k]) for k in ("cumap", "cbf", "refpoc", "lcu_edge"))
+    bsv, bsh = np.zeros_like(pic["bsv"]), np.zeros_like(pic["bsh"])
+    oracle.svt_oracle_bs_picture(cumap.ctypes.data, cbf.ctypes.data, int(h["width"]), int(h["height"]), int(h["slice_type"]),
+                                 poc.ctypes.data, edge.ctypes.data, bsv.ctypes.data, bsh.ctypes.data)
+    return bsv, bsh
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bs_picture_oracle_matches_reference(oracle, name):
+    """coding-unit map + cbf map -> the boundary-strength arrays the reference's per-CU derivation left"""
+    for k, pic in enumerate(load_dlf_case(name)):
+        bsv, bsh = oracle_bs(oracle, pic)
+        for nm, got, want in (("vertical", bsv, pic["bsv"]), ("horizontal", bsh, pic["bsh"])):
+            bad = np.argwhere(got != want)
+            assert len(bad) == 0, (name, k, nm, len(bad), [(int(a), int(b), int(got[a, b]), int(want[a, b])) for a, b in bad[:8]])
