@@ -511,6 +511,17 @@ SVT_AMD_API int svt_amd_dlf_luma_edges_batch(SvtAmdContext *ctx, void *d_plane, 
 SVT_AMD_API int svt_amd_dlf_chroma_edges_batch(SvtAmdContext *ctx, void *d_cb, void *d_cr, uint32_t stride,
                                                int bytes_per_sample, const SvtAmdDlfChromaEdge *d_edges,
                                                uint32_t nedges);
+/* WHOLE PICTURE boundary-strength derivation (device pointers): replaces the per-coding-unit calls SetBSArrayBasedOnPUBoundary
+ * (Codec/EbDeblockingFilter.c:339) and SetBSArrayBasedOnTUBoundary (:472) with CalculateBSForPUBoundary (:109) that the
+ * encode pass makes against its neighbour arrays (EbCodingLoop.c:3546-4450).  d_map: one entry per 8x8 block, raster
+ * (mode: 1 INTER_MODE / 2 INTRA_MODE of the covering coding unit, dir: its interPredDirectionIndex, size_log2: log2 of the
+ * coding-unit size, mv: predictionUnitArray[0].mv); d_cbf = pictureControlSetPtr->cbfMapArray (luma cbf per 4x4 block,
+ * row pitch width / 4); ref_poc0 / 1 = refPOC of the two reference lists; d_lcu_edge: per LCU, 1 = tile left edge, 2 = tile
+ * top edge.  Output = the layout svt_amd_dlf_picture reads ([lcu raster][256]). */
+typedef struct SvtAmdCuMapEntry { uint8_t mode, dir, size_log2, pad; int16_t mv[2][2]; } SvtAmdCuMapEntry;
+SVT_AMD_API int svt_amd_bs_picture(SvtAmdContext *ctx, const SvtAmdCuMapEntry *d_map, const uint8_t *d_cbf, uint32_t width,
+                                   uint32_t height, int slice_type, uint64_t ref_poc0, uint64_t ref_poc1,
+                                   const uint8_t *d_lcu_edge, uint8_t *d_bs_v, uint8_t *d_bs_h);
 /* WHOLE PICTURE (device pointers, 4:2:0, in place): the state the per-LCU drivers LCUInternalAreaDLFCore /
  * LCUBoundaryDLFCore / LCUPictureEdgeDLFCore (+16bit; Codec/EbDeblockingFilter.c:2222, 2828, 3518, called per LCU from
  * EbCodingLoop.c:4600-4631) leave once every LCU has been through them.  d_y/d_cb/d_cr point at sample (0,0) of the

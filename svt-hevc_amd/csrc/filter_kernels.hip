@@ -178,6 +178,66 @@ __global__ __launch_bounds__(256) void k_dlf_picture(const DlfPic P, int dir, ui
     }
 }
 
+/* ---------------- boundary strengths, whole picture ---------------- */
+/* SetBSArrayBasedOnPUBoundary / SetBSArrayBasedOnTUBoundary with CalculateBSForPUBoundary (Codec/EbDeblockingFilter.c:109-530),
+ * which the encode pass runs per coding unit against its neighbour arrays, as one data-parallel pass over picture-level
+ * maps: one thread per (direction, 8x8 block) decides the two 4-sample segments of the block's left / top side. */
+struct CuMapEntry { uint8_t mode, dir, size_log2, pad; int16_t mv[2][2]; }; /* = SvtAmdCuMapEntry */
+
+__device__ __forceinline__ bool bs_mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+
+__global__ __launch_bounds__(256) void k_bs_picture(const CuMapEntry *__restrict__ map, const uint8_t *__restrict__ cbf, int width, int height,
+                                                   int sliceType, unsigned long long poc0, unsigned long long poc1,
+                                                   const uint8_t *__restrict__ lcuEdge, uint8_t *__restrict__ bs_v, uint8_t *__restrict__ bs_h)
+{
+    const int bw = width >> 3, bh = height >> 3, cw = width >> 2, lcuCols = (width + 63) >> 6;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * bw * bh; i += gridDim.x * blockDim.x) {
+        const int dir = i >= bw * bh, j = dir ? i - bw * bh : i, by = j / bw, bx = j - by * bw;
+        const CuMapEntry cur = map[by * bw + bx];
+        const int x = bx << 3, y = by << 3, size = 1 << cur.size_log2, pos = dir ? y : x;
+        const int lcu = (y >> 6) * lcuCols + (x >> 6);
+        uint8_t *out = (dir ? bs_h : bs_v) + lcu * 256;
+        const bool cuEdge = (pos & (size - 1)) == 0, tuEdge = !cuEdge && size == 64 && (pos & 31) == 0;
+        int b[2] = {0, 0};
+        if ((cuEdge || tuEdge) && pos != 0 && !(cuEdge && (pos & 63) == 0 && (lcuEdge[lcu] & (dir ? 2 : 1)))) {
+            const CuMapEntry nb = dir ? map[(by - 1) * bw + bx] : map[by * bw + bx - 1];
+            int c1 = 1;
+            if (!tuEdge && cur.mode != 2 && nb.mode != 2) {
+                if (sliceType == 1) {
+                    c1 = bs_mv_far(cur.mv[0], nb.mv[0]);
+                } else {
+                    switch (cur.dir + nb.dir * 3) {
+                    case 0: c1 = bs_mv_far(cur.mv[0], nb.mv[0]); break;
+                    case 1: c1 = poc1 != poc0 || bs_mv_far(cur.mv[1], nb.mv[0]); break;
+                    case 3: c1 = poc0 != poc1 || bs_mv_far(cur.mv[0], nb.mv[1]); break;
+                    case 4: c1 = bs_mv_far(cur.mv[1], nb.mv[1]); break;
+                    case 8:
+                        c1 = poc0 == poc1 ? (bs_mv_far(cur.mv[0], nb.mv[0]) || bs_mv_far(cur.mv[1], nb.mv[1])) &&
+                                                (bs_mv_far(cur.mv[0], nb.mv[1]) || bs_mv_far(cur.mv[1], nb.mv[0]))
+                                          : (bs_mv_far(cur.mv[0], nb.mv[0]) || bs_mv_far(cur.mv[1], nb.mv[1]));
+                        break;
+                    default: c1 = 1; break;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int sx = dir ? x + 4 * k : x, sy = dir ? y : y + 4 * k, nx = dir ? sx : sx - 4, ny = dir ? sy - 4 : sy;
+                const int cbfAny = cbf[(sy >> 2) * cw + (sx >> 2)] || cbf[(ny >> 2) * cw + (nx >> 2)];
+                if (tuEdge)
+                    b[k] = cur.mode == 2 ? 2 : cbfAny;
+                else
+                    b[k] = (cur.mode == 2 || nb.mode == 2) ? 2 : (c1 | cbfAny);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int sx = dir ? x + 4 * k : x, sy = dir ? y : y + 4 * k;
+            out[((sx & 63) >> 2) + (((sy & 63) >> 2) << 4)] = (uint8_t)b[k];
+        }
+    }
+}
+
 /* ---------------- SAO statistics ---------------- */
 struct SaoStats { int32_t boDiff[32]; uint16_t boCount[32]; int32_t eoDiff[4][5]; uint16_t eoCount[4][5]; }; /* = SvtAmdSaoStats */
 
@@ -533,6 +593,24 @@ extern "C" int svt_amd_dlf_picture(SvtAmdContext *ctx, int bytes_per_sample, voi
         else
             hipLaunchKernelGGL(k_dlf_picture<uint16_t>, grid1d(nL + nC), dim3(256), 0, ctx->stream, P, dir, lx, nL, cx ? cx : 1, nC);
     }
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_bs_picture(SvtAmdContext *ctx, const SvtAmdCuMapEntry *d_map, const uint8_t *d_cbf, uint32_t width, uint32_t height,
+                                  int slice_type, uint64_t ref_poc0, uint64_t ref_poc1, const uint8_t *d_lcu_edge, uint8_t *d_bs_v,
+                                  uint8_t *d_bs_h)
+{
+    static_assert(sizeof(CuMapEntry) == sizeof(SvtAmdCuMapEntry), "map entry layout");
+    if (!ctx || !d_map || !d_cbf || !d_lcu_edge || !d_bs_v || !d_bs_h || width < 8 || height < 8 || (width & 7) || (height & 7) ||
+        slice_type < 0 || slice_type > 3)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = 2 * (width / 8) * (height / 8), nlcu = ((width + 63) / 64) * ((height + 63) / 64);
+    /* 4x4 positions off the 8x8 grid are never written by the reference either: the arrays start as zeros */
+    HIP_TRY(hipMemsetAsync(d_bs_v, 0, (size_t)nlcu * 256, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_bs_h, 0, (size_t)nlcu * 256, ctx->stream));
+    hipLaunchKernelGGL(k_bs_picture, grid1d(n), dim3(256), 0, ctx->stream, (const CuMapEntry *)d_map, d_cbf, (int)width, (int)height,
+                       slice_type, (unsigned long long)ref_poc0, (unsigned long long)ref_poc1, d_lcu_edge, d_bs_v, d_bs_h);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }

@@ -160,3 +160,72 @@ def test_sao_apply_picture_matches_oracle_random(product, gpu_ctx, oracle, w, h,
         if w > 3000:
             break
     assert sum(int((a != b).sum()) for a, b in zip(want, src)) > 0
+
+
+# ---- picture-level boundary-strength derivation, and the chain maps -> strengths -> deblocked picture ----------------
+from test_oracle_dlf_golden import oracle_bs  # noqa: E402
+
+
+def gpu_bs(product, gpu_ctx, pic):
+    import torch
+    h = pic["hdr"]
+    t = {k: torch.from_numpy(np.ascontiguousarray(pic[k]).view(np.uint8).reshape(-1).copy()).cuda() for k in ("cumap", "cbf", "lcu_edge")}
+    d_v = torch.full((pic["bsv"].size,), 9, dtype=torch.uint8, device="cuda")
+    d_h = torch.full((pic["bsh"].size,), 9, dtype=torch.uint8, device="cuda")
+    product.svt_amd_bs_picture.argtypes = [vp, vp, vp, u32, u32, C.c_int, C.c_uint64, C.c_uint64, vp, vp, vp]
+    torch.cuda.synchronize()
+    rc = product.svt_amd_bs_picture(gpu_ctx, t["cumap"].data_ptr(), t["cbf"].data_ptr(), int(h["width"]), int(h["height"]),
+                                    int(h["slice_type"]), int(pic["refpoc"][0]), int(pic["refpoc"][1]), t["lcu_edge"].data_ptr(),
+                                    d_v.data_ptr(), d_h.data_ptr())
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    return d_v.cpu().numpy().reshape(pic["bsv"].shape), d_h.cpu().numpy().reshape(pic["bsh"].shape)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bs_picture_matches_reference_golden(product, gpu_ctx, name):
+    for k, pic in enumerate(load_dlf_case(name)):
+        bsv, bsh = gpu_bs(product, gpu_ctx, pic)
+        assert np.array_equal(bsv, pic["bsv"]) and np.array_equal(bsh, pic["bsh"]), (name, k)
+        # chained on the device results: strengths -> deblocked picture
+        got = gpu_dlf(product, gpu_ctx, dict(pic, bsv=bsv, bsh=bsh))
+        for p in range(3):
+            assert np.array_equal(got[p], pic["post"][p]), (name, k, p)
+
+
+def test_bs_picture_matches_oracle_random(product, gpu_ctx, oracle):
+    """random coding-unit trees, modes, vectors and cbf maps on B and P slices with equal and different reference POCs"""
+    rng = np.random.default_rng(8)
+    W, H = 448, 200
+    bw, bh = W // 8, H // 8
+    cu_dt = np.dtype([("mode", "u1"), ("dir", "u1"), ("size_log2", "u1"), ("pad", "u1"), ("mv", "<i2", (2, 2))])
+    for trial in range(6):
+        cumap = np.zeros((bh, bw), cu_dt)
+        for ly in range(0, bh, 8):
+            for lx in range(0, bw, 8):                       # one LCU: random quadtree
+                def fill(x0, y0, lg):
+                    n = 1 << (lg - 3)
+                    if lg > 3 and rng.random() < 0.55:
+                        for dy in (0, n // 2):
+                            for dx in (0, n // 2):
+                                fill(x0 + dx, y0 + dy, lg - 1)
+                        return
+                    e = (int(rng.choice([1, 1, 2])), int(rng.integers(0, 3)), lg, 0, rng.integers(-9, 10, (2, 2)) * int(rng.choice([1, 1, 3])))
+                    cumap[y0:y0 + n, x0:x0 + n] = np.array([e], cu_dt)[0]
+                fill(lx, ly, 6)
+        cumap = cumap[:bh, :bw]
+        cbf = (rng.random((H // 4, W // 4)) < 0.3).astype(np.uint8)
+        nlcu = ((W + 63) // 64) * ((H + 63) // 64)
+        edge = np.zeros(nlcu, np.uint8)
+        cols = (W + 63) // 64
+        for i in range(nlcu):
+            edge[i] = (1 if i % cols == 0 or rng.random() < 0.2 else 0) | (2 if i // cols == 0 or rng.random() < 0.2 else 0)
+        hdr = np.zeros(1, dtype=[("width", "<u4"), ("height", "<u4"), ("slice_type", "<u4")])[0]
+        hdr["width"], hdr["height"], hdr["slice_type"] = W, H, trial % 2
+        poc = np.array([5, 5 if trial < 3 else 9], np.uint64)
+        pic = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1), refpoc=poc, lcu_edge=edge, bsv=np.zeros((nlcu, 256), np.uint8),
+                   bsh=np.zeros((nlcu, 256), np.uint8))
+        want = oracle_bs(oracle, pic)
+        got = gpu_bs(product, gpu_ctx, pic)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), trial
+        assert set(np.unique(want[0]).tolist()) == {0, 1, 2}
