@@ -550,6 +550,24 @@ typedef struct SvtAmdSaoLcuParams {
 SVT_AMD_API int svt_amd_sao_apply_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *const d_src[3],
                                           void *const d_dst[3], uint32_t strideY, uint32_t strideC, uint32_t width,
                                           uint32_t height, const SvtAmdSaoLcuParams *d_lcus, int luma_on, int chroma_on);
+/* SAO parameter decision of a whole picture from per-LCU statistics (device pointers): replaces the part of
+ * SaoGenerationDecision / SaoGenerationDecision16bit after the statistics gathering (Codec/
+ * EbSampleAdaptiveOffsetGenerationDecision.c:647-850, :936-1140): DetermineSaoLumaModeOffsets (:44), DetermineSaoChroma
+ * ModeOffsets (:182), the reduced luma mode of temporal layers 0 / 1 (:347) and TestSaoCopyModes (:437).  Every LCU's own
+ * best parameters are independent; the merge test needs the final parameters of the left and the upper LCU and runs as a
+ * wavefront over anti-diagonals.  d_stats_y / cb / cr: [lcu raster] records as svt_amd_sao_gather_picture writes them;
+ * d_enable: per LCU, 0 = the encode pass's shut-off conditions hold (EbCodingLoop.c:4675-4697), parameters stay zero;
+ * d_params: in: edge_flags (1 / 4 = no left / upper merge candidate), out: everything else; d_costs: [lcu][2] the luma and
+ * chroma best costs the reference's call returns (also the work space between the two passes). */
+typedef struct SvtAmdSaoDecisionParams {
+    uint64_t lambda, chroma_lambda;                 /* contextPtr->fullLambda / fullChromaLambdaSao                      */
+    uint32_t type_bits[6], merge_bits[2], offset_bits[8]; /* mdRateEstimationPtr->saoTypeIndexBits / MergeFlagBits / OffsetTrunUnaryBits */
+    uint8_t  is_10bit, mm_sao, temporal_layer, pad; /* mm_sao = contextPtr->saoMode                                      */
+} SvtAmdSaoDecisionParams;
+SVT_AMD_API int svt_amd_sao_decide_picture(SvtAmdContext *ctx, const SvtAmdSaoDecisionParams *params, const SvtAmdSaoStats *d_stats_y,
+                                           const SvtAmdSaoStats *d_stats_cb, const SvtAmdSaoStats *d_stats_cr, uint32_t lcu_cols,
+                                           uint32_t lcu_rows, const uint8_t *d_enable, SvtAmdSaoLcuParams *d_params,
+                                           int64_t *d_costs);
 /* statistics of every LCU of a plane (raster LCU order), replaces the per-LCU SaoGenerationDecision ->
  * GatherSaoStatisticsLcu* calls (EbSampleAdaptiveOffsetGenerationDecision.c:647,936) */
 SVT_AMD_API int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,

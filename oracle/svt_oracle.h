@@ -21,6 +21,14 @@
 
 #ifdef __cplusplus
 extern "C" {
+
+/* ---- SAO parameter decision of one LCU (svt_oracle_saodec.c) ---- */
+void svt_oracle_sao_decide_lcu(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *const stats[3], const SvtAmdSaoLcuParams *left,
+                               const SvtAmdSaoLcuParams *up, SvtAmdSaoLcuParams *out, int64_t costs[2]);
+void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *sy, const SvtAmdSaoStats *scb,
+                                   const SvtAmdSaoStats *scr, uint32_t cols, uint32_t rows, const uint8_t *enable,
+                                   SvtAmdSaoLcuParams *params, int64_t *costs);
+
 #endif
 
 /* ---- leaf kernels (same signatures as the reference C_DEFAULT symbols) ---- */
@@ -182,6 +190,14 @@ int svt_oracle_me_picture(const SvtAmdMeParams *params, const SvtOraclePicture *
 
 #ifdef __cplusplus
 }
+
+/* ---- SAO parameter decision of one LCU (svt_oracle_saodec.c) ---- */
+void svt_oracle_sao_decide_lcu(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *const stats[3], const SvtAmdSaoLcuParams *left,
+                               const SvtAmdSaoLcuParams *up, SvtAmdSaoLcuParams *out, int64_t costs[2]);
+void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *sy, const SvtAmdSaoStats *scb,
+                                   const SvtAmdSaoStats *scr, uint32_t cols, uint32_t rows, const uint8_t *enable,
+                                   SvtAmdSaoLcuParams *params, int64_t *costs);
+
 #endif
 /* ---- open-loop intra search (svt_oracle_ois.c) ---- */
 /* luma points at the picture origin (sample 0,0); reads never leave [0,W)x[0,H). me_sad: distortion[0] of the
@@ -216,5 +232,13 @@ void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChroma
 /* reconstruction of one transform unit of one plane (inverse transform or DC shortcut + prediction, clipped) */
 void svt_oracle_recon_tu(int bps, uint32_t size, int only_dc, int dst, const int16_t *coeff, const void *pred,
                          uint32_t predStride, void *recon, uint32_t reconStride);
+
+
+/* ---- SAO parameter decision of one LCU (svt_oracle_saodec.c) ---- */
+void svt_oracle_sao_decide_lcu(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *const stats[3], const SvtAmdSaoLcuParams *left,
+                               const SvtAmdSaoLcuParams *up, SvtAmdSaoLcuParams *out, int64_t costs[2]);
+void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *sy, const SvtAmdSaoStats *scb,
+                                   const SvtAmdSaoStats *scr, uint32_t cols, uint32_t rows, const uint8_t *enable,
+                                   SvtAmdSaoLcuParams *params, int64_t *costs);
 
 #endif

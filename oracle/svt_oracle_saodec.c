@@ -1,0 +1,233 @@
+/*
+ * oracle/svt_oracle_saodec.c - TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
+ * CPU restatement of the SAO parameter decision of one LCU from its statistics:
+ *   SaoGenerationDecision / SaoGenerationDecision16bit   Codec/EbSampleAdaptiveOffsetGenerationDecision.c:647-850, :936-1140
+ *     (everything after the statistics gathering)
+ *   DetermineSaoLumaModeOffsets                          :44-175
+ *   DetermineSaoChromaModeOffsets                        :182-340  (band offset switched off for chroma, :221-223; the
+ *                                                                   per-type distortion is NOT reset between Cb and Cr)
+ *   DetermineSaoLumaModeOffsets_OnlyEo_90_45_135         :347-430  (the reduced mode of temporal layers 0 / 1)
+ *   DetermineSaoEOLumaModeOffsets                        :853-930  (the 16-bit path: four edge types, no band offset)
+ *   TestSaoCopyModes                                     :437-640
+ *   GetSaoOffsetsFractionBits                            Codec/EbMdRateEstimation.c:250-296
+ * Pinned by tests/test_oracle_saodec_golden.py on records of real calls.
+ */
+#include <string.h>
+#include "svt_oracle.h"
+
+#define MD_SHIFT 23
+#define MD_OFFSET (1 << 22)
+#define COSTP 8
+
+static int64_t rate_cost(int64_t rate, uint64_t lambda) { return (int64_t)(((uint64_t)rate * lambda + MD_OFFSET) >> MD_SHIFT); }
+
+static int64_t offsets_bits(const SvtAmdSaoDecisionParams *P, uint32_t type, const int32_t *o)
+{
+    int64_t bits = type == 5 ? 163840 : 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t a = (uint32_t)(o[k] < 0 ? -o[k] : o[k]), c = a > 7 ? 7 : a;
+        bits += P->offset_bits[c];
+        if (type == 5 && c)
+            bits += 32768;
+    }
+    return bits;
+}
+
+static int32_t est_offset(int32_t diff, uint32_t count, int lo, int hi)
+{
+    int32_t o = count == 0 ? 0 : diff / (int32_t)count; /* ROUND() of an integer quotient is the quotient */
+    return o < lo ? lo : o > hi ? hi : o;
+}
+
+static int64_t dist_of(int32_t o, int32_t diff, uint32_t count, int shift) { return (int64_t)(-(2 * o * diff) + ((int32_t)count * o * o)) >> shift; }
+
+static void eo_limits(int is10, int cat, int *lo, int *hi)
+{
+    const int m = is10 ? 31 : 7;
+    *lo = cat < 2 ? 0 : -m, *hi = cat < 2 ? m : 0;
+}
+
+/* luma: full mode (band + 4 edge types), the 16-bit one (4 edge types) or the reduced one (edge types 1..3 only) */
+static void decide_luma(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *S, int reduced, SvtAmdSaoLcuParams *out, int64_t *best)
+{
+    const int onlyEo = reduced || P->is_10bit;
+    const int is10 = P->is_10bit, sh = is10 ? 4 : 0, bm = is10 ? 31 : 7;
+    const int64_t maxc = (int64_t)(~0ull >> 1), offCost = rate_cost(P->type_bits[0], P->lambda);
+    int32_t bo[32], eo[4][4];
+    int64_t boBest = maxc, eoBest = maxc;
+    uint32_t bestBand = 0, bestEo = 0;
+    if (!onlyEo) {
+        int64_t bd[32];
+        for (int b = 0; b < 32; b++) {
+            bo[b] = est_offset(S->boDiff[b], S->boCount[b], -bm, bm);
+            bd[b] = dist_of(bo[b], S->boDiff[b], S->boCount[b], sh);
+        }
+        for (uint32_t b = 0; b < 29; b++) {
+            const int64_t c = ((bd[b] + bd[b + 1] + bd[b + 2] + bd[b + 3]) << COSTP) + rate_cost(offsets_bits(P, 5, bo + b), P->lambda);
+            if (c < boBest)
+                boBest = c, bestBand = b;
+        }
+    }
+    for (uint32_t t = reduced ? 1 : 0; t < 4; t++) {
+        int64_t d = 0;
+        for (int c = 0; c < 4; c++) {
+            int lo, hi;
+            eo_limits(is10, c, &lo, &hi);
+            eo[t][c] = est_offset(S->eoDiff[t][c], S->eoCount[t][c], lo, hi);
+            d += dist_of(eo[t][c], S->eoDiff[t][c], S->eoCount[t][c], sh);
+        }
+        const int64_t c = (d << COSTP) + rate_cost(offsets_bits(P, t + 1, eo[t]), P->lambda);
+        if (c < eoBest)
+            eoBest = c, bestEo = t;
+    }
+    if (!onlyEo)
+        boBest += rate_cost(P->type_bits[5], P->lambda);
+    eoBest += rate_cost(P->type_bits[bestEo + 1], P->lambda);
+    if ((!onlyEo && boBest < offCost) || eoBest < offCost) {
+        *best = (!onlyEo && boBest < eoBest) ? boBest : eoBest;
+        if (!onlyEo && *best == boBest) {
+            out->type[0] = 5, out->band[0] = bestBand;
+            for (int k = 0; k < 4; k++)
+                out->offset[0][k] = bo[bestBand + k];
+        } else {
+            out->type[0] = bestEo + 1;
+            for (int k = 0; k < 4; k++)
+                out->offset[0][k] = eo[bestEo][k];
+        }
+    } else {
+        out->type[0] = 0, *best = offCost;
+    }
+}
+
+static void decide_chroma(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *Scb, const SvtAmdSaoStats *Scr, SvtAmdSaoLcuParams *out,
+                          int64_t *best)
+{
+    const int is10 = P->is_10bit, sh = is10 ? 4 : 0;
+    const int64_t maxc = (int64_t)(~0ull >> 1), offCost = rate_cost(P->type_bits[0], P->chroma_lambda);
+    const SvtAmdSaoStats *S[2] = {Scb, Scr};
+    int32_t eo[2][4][4];
+    int64_t eoBest = maxc;
+    uint32_t bestEo = 1;
+    for (uint32_t t = 0; t < 4; t++) {
+        int64_t d = 0, cost = 0; /* d keeps accumulating over both components (:293-300) */
+        for (int comp = 0; comp < 2; comp++) {
+            for (int c = 0; c < 4; c++) {
+                int lo, hi;
+                eo_limits(is10, c, &lo, &hi);
+                eo[comp][t][c] = est_offset(S[comp]->eoDiff[t][c], S[comp]->eoCount[t][c], lo, hi);
+                d += dist_of(eo[comp][t][c], S[comp]->eoDiff[t][c], S[comp]->eoCount[t][c], sh);
+            }
+            cost += (d << COSTP) + rate_cost(offsets_bits(P, t + 1, eo[comp][t]), P->chroma_lambda);
+        }
+        if (cost < eoBest)
+            eoBest = cost, bestEo = t;
+    }
+    eoBest += rate_cost(P->type_bits[bestEo + 1], P->chroma_lambda);
+    if (eoBest < offCost) { /* the band-offset candidate is switched off: its cost is "infinite" */
+        *best = eoBest;
+        out->type[1] = bestEo + 1;
+        for (int comp = 0; comp < 2; comp++)
+            for (int k = 0; k < 4; k++)
+                out->offset[1 + comp][k] = eo[comp][bestEo][k];
+    } else {
+        out->type[1] = 0, *best = offCost;
+    }
+}
+
+static int64_t merge_dist(const SvtAmdSaoLcuParams *N, int comp, const SvtAmdSaoStats *S)
+{
+    const uint32_t type = N->type[comp ? 1 : 0];
+    int64_t d = 0;
+    if (type == 0)
+        return 0;
+    for (int k = 0; k < 4; k++) {
+        const int32_t o = N->offset[comp][k];
+        if (type == 5)
+            d += -(2 * o * S->boDiff[N->band[comp] + k]) + ((int32_t)S->boCount[N->band[comp] + k] * o * o);
+        else
+            d += -(2 * o * S->eoDiff[type - 1][k]) + ((int32_t)S->eoCount[type - 1][k] * o * o);
+    }
+    return d;
+}
+
+static void test_copy_modes(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *const S[3], SvtAmdSaoLcuParams *out,
+                            const SvtAmdSaoLcuParams *left, const SvtAmdSaoLcuParams *up, int64_t *lumaBest, int64_t *chromaBest)
+{
+    const int sh = P->is_10bit ? 4 : 0;
+    const int64_t maxc = (int64_t)(~0ull >> 1);
+    const uint64_t lam = P->lambda;
+    const int64_t leftFlag = left ? P->merge_bits[0] : 0, upFlag0 = up ? P->merge_bits[0] : 0;
+    const int64_t flags = rate_cost(leftFlag + upFlag0, lam);
+    int64_t bestCost = *lumaBest + *chromaBest + flags;
+    *lumaBest += flags, *chromaBest += flags;
+    int64_t lCost = maxc, uCost = maxc, lLuma = 0, lChroma = 0, uLuma = 0, uChroma = 0;
+    if (left) {
+        const int64_t dl = merge_dist(left, 0, S[0]) >> sh, dc = (merge_dist(left, 1, S[1]) + merge_dist(left, 2, S[2])) >> sh;
+        const int64_t r = rate_cost(P->merge_bits[1], lam);
+        lLuma = (dl << COSTP) + r, lChroma = (dc << COSTP) + r, lCost = (dl << COSTP) + (dc << COSTP) + r;
+    }
+    if (up) {
+        const int64_t dl = merge_dist(up, 0, S[0]) >> sh, dc = (merge_dist(up, 1, S[1]) + merge_dist(up, 2, S[2])) >> sh;
+        const int64_t r = rate_cost(leftFlag + P->merge_bits[1], lam);
+        uLuma = (dl << COSTP) + r, uChroma = (dc << COSTP) + r, uCost = (dl << COSTP) + (dc << COSTP) + r;
+    }
+    if (lCost < bestCost || uCost < bestCost) {
+        bestCost = lCost < uCost ? lCost : uCost;
+        const SvtAmdSaoLcuParams *N = NULL;
+        if (bestCost == lCost && left)
+            N = left, out->merge_left = 1, *lumaBest = lLuma, *chromaBest = lChroma;
+        else if (bestCost == uCost && up)
+            N = up, out->merge_up = 1, *lumaBest = uLuma, *chromaBest = uChroma;
+        if (N) {
+            out->type[0] = N->type[0], out->type[1] = N->type[1];
+            memcpy(out->offset, N->offset, sizeof(out->offset));
+            memcpy(out->band, N->band, sizeof(out->band));
+        }
+    }
+}
+
+/* stats[c]: the statistics of component c (Y, Cb, Cr) of this LCU; left / up: final parameters of the neighbours or NULL;
+ * out: this LCU's parameters (edge_flags left untouched); costs: luma / chroma best costs as the reference returns them */
+void svt_oracle_sao_decide_lcu(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *const stats[3], const SvtAmdSaoLcuParams *left,
+                               const SvtAmdSaoLcuParams *up, SvtAmdSaoLcuParams *out, int64_t costs[2])
+{
+    const uint8_t keep = out->edge_flags;
+    memset(out, 0, sizeof(*out));
+    out->edge_flags = keep;
+    costs[0] = costs[1] = 0;
+    if (P->mm_sao) {
+        decide_luma(P, stats[0], 0, out, &costs[0]);
+        decide_chroma(P, stats[1], stats[2], out, &costs[1]);
+        test_copy_modes(P, stats, out, left, up, &costs[0], &costs[1]);
+    } else {
+        if (P->temporal_layer < 2) {
+            decide_luma(P, stats[0], 1, out, &costs[0]);
+            test_copy_modes(P, stats, out, left, up, &costs[0], &costs[1]);
+        }
+    }
+}
+
+/* whole picture, LCUs in raster order exactly as the encode pass visits them (EbCodingLoop.c:4640-4760): the left / upper
+ * neighbour is a merge candidate unless the LCU sits on a tile's left / top edge (edge_flags 1 / 4); an LCU whose shut-off
+ * condition holds (enable[i] == 0) keeps all-zero parameters and "maximum" costs are not modelled (costs left 0). */
+void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *sy, const SvtAmdSaoStats *scb,
+                                   const SvtAmdSaoStats *scr, uint32_t cols, uint32_t rows, const uint8_t *enable,
+                                   SvtAmdSaoLcuParams *params, int64_t *costs)
+{
+    for (uint32_t y = 0; y < rows; y++)
+        for (uint32_t x = 0; x < cols; x++) {
+            const uint32_t i = y * cols + x;
+            SvtAmdSaoLcuParams *o = params + i;
+            if (enable && !enable[i]) {
+                const uint8_t keep = o->edge_flags;
+                memset(o, 0, sizeof(*o));
+                o->edge_flags = keep;
+                costs[2 * i] = costs[2 * i + 1] = 0;
+                continue;
+            }
+            const SvtAmdSaoStats *const st[3] = {sy + i, scb + i, scr + i};
+            const SvtAmdSaoLcuParams *left = (x > 0 && !(o->edge_flags & 1)) ? o - 1 : NULL;
+            const SvtAmdSaoLcuParams *up = (y > 0 && !(o->edge_flags & 4)) ? o - cols : NULL;
+            svt_oracle_sao_decide_lcu(P, st, left, up, o, costs + 2 * i);
+        }
+}

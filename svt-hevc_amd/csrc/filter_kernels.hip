@@ -534,6 +534,214 @@ __global__ void k_unpack_avg(const uint16_t *__restrict__ l0, uint32_t s0, const
     }
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * SAO parameter decision from per-LCU statistics (SaoGenerationDecision(16bit) after its gathering step,
+ * EbSampleAdaptiveOffsetGenerationDecision.c:44-640, :853-930).  Two launches:
+ *   k_sao_decide_own   one thread per LCU: the LCU's own best luma / chroma parameters and their costs (independent)
+ *   k_sao_decide_merge one workgroup: the merge-left / merge-up test needs the neighbours' FINAL parameters, so the LCUs are
+ *                      visited as a wavefront over anti-diagonals (x + y = d), one thread per LCU row
+ * ------------------------------------------------------------------------------------------------------------------------ */
+struct SaoDecide {                                  /* = SvtAmdSaoDecisionParams */
+    uint64_t lambda, chromaLambda;
+    uint32_t typeBits[6], mergeBits[2], offsetBits[8];
+    uint8_t is10, mmSao, temporalLayer, pad;
+};
+__device__ __forceinline__ int64_t sao_rate_cost(uint64_t rate, uint64_t lambda) { return (int64_t)((rate * lambda + (1u << 22)) >> 23); }
+__device__ __forceinline__ int sao_est(int diff, int count, int lo, int hi)
+{
+    const int o = count == 0 ? 0 : diff / count;
+    return o < lo ? lo : o > hi ? hi : o;
+}
+__device__ __forceinline__ int sao_dist(int o, int diff, int count) { return -(2 * o * diff) + count * o * o; }
+__device__ __forceinline__ uint32_t sao_offset_bits(const SaoDecide &P, int o)
+{
+    const int a = o < 0 ? -o : o;
+    return P.offsetBits[a > 7 ? 7 : a];
+}
+/* best edge-offset class of one component set: comps = 1 (luma) or 2 (Cb + Cr, the distortion keeps accumulating across the
+ * two components exactly as the reference's eoTypeDistortion does) */
+template <int COMPS>
+__device__ __forceinline__ int64_t sao_best_eo(const SaoDecide &P, const SaoStats *const *S, int firstType, uint64_t lambda, int sh,
+                                              int m, uint32_t &bestType)
+{
+    int64_t best = (int64_t)(~0ull >> 1);
+    bestType = 0;
+    for (int t = firstType; t < 4; t++) {
+        int64_t d = 0, cost = 0;
+        for (int c = 0; c < COMPS; c++) {
+            uint64_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int diff = S[c]->eoDiff[t][k], cnt = S[c]->eoCount[t][k];
+                const int o = sao_est(diff, cnt, k < 2 ? 0 : -m, k < 2 ? m : 0);
+                d += sao_dist(o, diff, cnt) >> sh;
+                bits += sao_offset_bits(P, o);
+            }
+            cost += (d << 8) + sao_rate_cost(bits, lambda);
+        }
+        if (cost < best)
+            best = cost, bestType = (uint32_t)t;
+    }
+    return best + sao_rate_cost(P.typeBits[bestType + 1], lambda);
+}
+__device__ __forceinline__ void sao_eo_offsets(const SaoStats *S, uint32_t t, int m, int32_t *o)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        o[k] = sao_est(S->eoDiff[t][k], S->eoCount[t][k], k < 2 ? 0 : -m, k < 2 ? m : 0);
+}
+
+__global__ void __launch_bounds__(64) k_sao_decide_own(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
+                                                       uint32_t nlcu, const uint8_t *enable, SaoLcuParams *params, int64_t *costs)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nlcu)
+        return;
+    SaoLcuParams o;
+    o.merge_left = o.merge_up = 0, o.edge_flags = params[i].edge_flags, o.pad = 0;
+    o.type[0] = o.type[1] = 0;
+    for (int c = 0; c < 3; c++) {
+        o.band[c] = 0;
+        for (int k = 0; k < 4; k++)
+            o.offset[c][k] = 0;
+    }
+    int64_t lumaBest = 0, chromaBest = 0;
+    const bool reduced = !P.mmSao;
+    if ((enable == nullptr || enable[i]) && (P.mmSao || P.temporalLayer < 2)) {
+        const int sh = P.is10 ? 4 : 0, m = P.is10 ? 31 : 7;
+        const int64_t maxc = (int64_t)(~0ull >> 1);
+        const SaoStats *Y = sy + i;
+        {   /* luma */
+            const int64_t offCost = sao_rate_cost(P.typeBits[0], P.lambda);
+            int64_t boBest = maxc;
+            uint32_t bestBand = 0;
+            if (!reduced && !P.is10) {
+                /* sliding window of four bands: distortion and rate of the last four */
+                int64_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                for (int b = 0; b < 32; b++) {
+                    const int diff = Y->boDiff[b], cnt = Y->boCount[b];
+                    const int ob = sao_est(diff, cnt, -m, m);
+                    d0 = d1, d1 = d2, d2 = d3, d3 = sao_dist(ob, diff, cnt) >> sh;
+                    r0 = r1, r1 = r2, r2 = r3, r3 = sao_offset_bits(P, ob) + (ob ? 32768u : 0u);
+                    if (b >= 3) {
+                        const int64_t c = ((d0 + d1 + d2 + d3) << 8) + sao_rate_cost(163840ull + r0 + r1 + r2 + r3, P.lambda);
+                        if (c < boBest)
+                            boBest = c, bestBand = (uint32_t)(b - 3);
+                    }
+                }
+                boBest += sao_rate_cost(P.typeBits[5], P.lambda);
+            }
+            uint32_t bestEo;
+            const SaoStats *one[1] = {Y};
+            const int64_t eoBest = sao_best_eo<1>(P, one, reduced ? 1 : 0, P.lambda, sh, m, bestEo);
+            if (boBest < offCost || eoBest < offCost) {
+                if (boBest <= eoBest) {
+                    lumaBest = boBest, o.type[0] = 5, o.band[0] = bestBand;
+                    for (int k = 0; k < 4; k++)
+                        o.offset[0][k] = sao_est(Y->boDiff[bestBand + k], Y->boCount[bestBand + k], -m, m);
+                } else {
+                    lumaBest = eoBest, o.type[0] = bestEo + 1;
+                    sao_eo_offsets(Y, bestEo, m, o.offset[0]);
+                }
+            } else {
+                lumaBest = offCost;
+            }
+        }
+        if (P.mmSao) { /* chroma: edge offset only, Cb and Cr share the class */
+            const int64_t offCost = sao_rate_cost(P.typeBits[0], P.chromaLambda);
+            const SaoStats *two[2] = {scb + i, scr + i};
+            uint32_t bestEo;
+            const int64_t eoBest = sao_best_eo<2>(P, two, 0, P.chromaLambda, sh, m, bestEo);
+            if (eoBest < offCost) {
+                chromaBest = eoBest, o.type[1] = bestEo + 1;
+                sao_eo_offsets(two[0], bestEo, m, o.offset[1]);
+                sao_eo_offsets(two[1], bestEo, m, o.offset[2]);
+            } else {
+                chromaBest = offCost;
+            }
+        }
+    }
+    params[i] = o;
+    costs[2 * i] = lumaBest, costs[2 * i + 1] = chromaBest;
+}
+
+/* distortion of applying a neighbour's parameters to this LCU's statistics (TestSaoCopyModes :487-587) */
+__device__ __forceinline__ int64_t sao_merge_dist(const SaoLcuParams &N, int comp, const SaoStats *S)
+{
+    const uint32_t type = N.type[comp ? 1 : 0];
+    int64_t d = 0;
+    if (type == 0)
+        return 0;
+    for (int k = 0; k < 4; k++) {
+        const int o = N.offset[comp][k];
+        if (type == 5) {
+            const uint32_t b = (N.band[comp] + k) & 31;
+            d += sao_dist(o, S->boDiff[b], S->boCount[b]);
+        } else {
+            d += sao_dist(o, S->eoDiff[type - 1][k], S->eoCount[type - 1][k]);
+        }
+    }
+    return d;
+}
+__global__ void __launch_bounds__(256) k_sao_decide_merge(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
+                                                          uint32_t cols, uint32_t rows, const uint8_t *enable, SaoLcuParams *params,
+                                                          int64_t *costs)
+{
+    const int sh = P.is10 ? 4 : 0;
+    const int64_t maxc = (int64_t)(~0ull >> 1);
+    for (uint32_t d = 0; d < cols + rows - 1; d++) {
+        for (uint32_t y = threadIdx.x; y < rows; y += blockDim.x) {
+            const uint32_t x = d - y;
+            if (y > d || x >= cols)
+                continue;
+            const uint32_t i = y * cols + x;
+            if (enable != nullptr && !enable[i])
+                continue;
+            SaoLcuParams o = params[i];
+            const bool hasLeft = !(o.edge_flags & 1) && x > 0, hasUp = !(o.edge_flags & 4) && y > 0;
+            const uint64_t leftFlag = hasLeft ? P.mergeBits[0] : 0, upFlag = hasUp ? P.mergeBits[0] : 0;
+            const int64_t flags = sao_rate_cost(leftFlag + upFlag, P.lambda);
+            int64_t luma = costs[2 * i] + flags, chroma = costs[2 * i + 1] + flags;
+            int64_t best = costs[2 * i] + costs[2 * i + 1] + flags;
+            int64_t lCost = maxc, uCost = maxc, lLuma = 0, lChroma = 0, uLuma = 0, uChroma = 0;
+            SaoLcuParams L, U;
+            if (hasLeft) {
+                L = params[i - 1];
+                const int64_t dl = sao_merge_dist(L, 0, sy + i) >> sh,
+                              dc = (sao_merge_dist(L, 1, scb + i) + sao_merge_dist(L, 2, scr + i)) >> sh;
+                const int64_t r = sao_rate_cost(P.mergeBits[1], P.lambda);
+                lLuma = (dl << 8) + r, lChroma = (dc << 8) + r, lCost = (dl << 8) + (dc << 8) + r;
+            }
+            if (hasUp) {
+                U = params[i - cols];
+                const int64_t dl = sao_merge_dist(U, 0, sy + i) >> sh,
+                              dc = (sao_merge_dist(U, 1, scb + i) + sao_merge_dist(U, 2, scr + i)) >> sh;
+                const int64_t r = sao_rate_cost(leftFlag + P.mergeBits[1], P.lambda);
+                uLuma = (dl << 8) + r, uChroma = (dc << 8) + r, uCost = (dl << 8) + (dc << 8) + r;
+            }
+            if (lCost < best || uCost < best) {
+                const bool left = lCost <= uCost && hasLeft;
+                const SaoLcuParams &N = left ? L : U;
+                if (left || hasUp) {
+                    o.merge_left = left, o.merge_up = !left;
+                    luma = left ? lLuma : uLuma, chroma = left ? lChroma : uChroma;
+                    o.type[0] = N.type[0], o.type[1] = N.type[1];
+                    for (int c = 0; c < 3; c++) {
+                        o.band[c] = N.band[c];
+                        for (int k = 0; k < 4; k++)
+                            o.offset[c][k] = N.offset[c][k];
+                    }
+                    params[i] = o;
+                }
+            }
+            costs[2 * i] = luma, costs[2 * i + 1] = chroma;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 static inline dim3 grid1d(uint32_t n) { return dim3((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
 /* ---------------- batched C-ABI (device pointers) ---------------- */
@@ -647,6 +855,26 @@ extern "C" int svt_amd_sao_apply_picture(SvtAmdContext *ctx, int bytes_per_sampl
         else
             hipLaunchKernelGGL((k_sao_apply_picture<uint16_t, false>), grid, dim3(256), 0, ctx->stream, P, gy, gc);
     }
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_sao_decide_picture(SvtAmdContext *ctx, const SvtAmdSaoDecisionParams *params, const SvtAmdSaoStats *d_stats_y,
+                                          const SvtAmdSaoStats *d_stats_cb, const SvtAmdSaoStats *d_stats_cr, uint32_t lcu_cols,
+                                          uint32_t lcu_rows, const uint8_t *d_enable, SvtAmdSaoLcuParams *d_params, int64_t *d_costs)
+{
+    static_assert(sizeof(SaoDecide) == sizeof(SvtAmdSaoDecisionParams), "layout");
+    if (!ctx || !params || !d_stats_y || !d_stats_cb || !d_stats_cr || !lcu_cols || !lcu_rows || !d_params || !d_costs)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    SaoDecide P;
+    ::memcpy(&P, params, sizeof(P));
+    const uint32_t nlcu = lcu_cols * lcu_rows;
+    hipLaunchKernelGGL(k_sao_decide_own, dim3((nlcu + 63) / 64), dim3(64), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+                       (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, nlcu, d_enable, (SaoLcuParams *)d_params, d_costs);
+    if (P.mmSao || P.temporalLayer < 2)
+        hipLaunchKernelGGL(k_sao_decide_merge, dim3(1), dim3(256), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+                           (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
+                           (SaoLcuParams *)d_params, d_costs);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
