@@ -556,7 +556,8 @@ SVT_AMD_API int svt_amd_sao_apply_picture(SvtAmdContext *ctx, int bytes_per_samp
  * ModeOffsets (:182), the reduced luma mode of temporal layers 0 / 1 (:347) and TestSaoCopyModes (:437).  Every LCU's own
  * best parameters are independent; the merge test needs the final parameters of the left and the upper LCU and runs as a
  * wavefront over anti-diagonals.  d_stats_y / cb / cr: [lcu raster] records as svt_amd_sao_gather_picture writes them;
- * d_enable: per LCU, 0 = the encode pass's shut-off conditions hold (EbCodingLoop.c:4675-4697), parameters stay zero;
+ * d_enable: per LCU (NULL = all 1), 0 = the encode pass's shut-off conditions hold (EbCodingLoop.c:4675-4697), parameters
+ * become zero; 1 = decide; 2 = d_params already holds this LCU's final parameters (an earlier call), a merge candidate only;
  * d_params: in: edge_flags (1 / 4 = no left / upper merge candidate), out: everything else; d_costs: [lcu][2] the luma and
  * chroma best costs the reference's call returns (also the work space between the two passes). */
 typedef struct SvtAmdSaoDecisionParams {
@@ -568,6 +569,12 @@ SVT_AMD_API int svt_amd_sao_decide_picture(SvtAmdContext *ctx, const SvtAmdSaoDe
                                            const SvtAmdSaoStats *d_stats_cb, const SvtAmdSaoStats *d_stats_cr, uint32_t lcu_cols,
                                            uint32_t lcu_rows, const uint8_t *d_enable, SvtAmdSaoLcuParams *d_params,
                                            int64_t *d_costs);
+/* ONE LCU (host pointers, synchronous): the same decision with the neighbours' final parameters handed in (NULL = no
+ * candidate), i.e. exactly the inputs SaoGenerationDecision has once its statistics are gathered. */
+SVT_AMD_API int svt_amd_sao_decide_lcu(SvtAmdContext *ctx, const SvtAmdSaoDecisionParams *params, const SvtAmdSaoStats *stats_y,
+                                       const SvtAmdSaoStats *stats_cb, const SvtAmdSaoStats *stats_cr,
+                                       const SvtAmdSaoLcuParams *left, const SvtAmdSaoLcuParams *up, SvtAmdSaoLcuParams *out,
+                                       int64_t costs[2]);
 /* statistics of every LCU of a plane (raster LCU order), replaces the per-LCU SaoGenerationDecision ->
  * GatherSaoStatisticsLcu* calls (EbSampleAdaptiveOffsetGenerationDecision.c:647,936) */
 SVT_AMD_API int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,

@@ -804,6 +804,143 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
     *yCountNonZeroCoeffs = nz;
 }
 
+/* ---- SAO statistics + parameter decision of an LCU -------------------------------------------------------------------------
+ * SaoGenerationDecision / SaoGenerationDecision16bit (Codec/EbSampleAdaptiveOffsetGenerationDecision.c:647, :936; called per
+ * LCU from EbCodingLoop.c:4711, :4732) are answered, with SVT_HOOK_SAO=1, by the device: the statistics by the library's
+ * gather entry points on the same sample windows, the decision by svt_amd_sao_decide_lcu() with the neighbours' parameters.
+ */
+EB_ERRORTYPE __real_SaoGenerationDecision(SaoStats_t *saoStats, SaoParameters_t *saoParams, MdRateEstimationContext_t *md, EB_U64 fullLambda,
+                                          EB_U64 fullChromaLambdaSao, EB_BOOL mmSao, PictureControlSet_t *pcs, EB_U32 tbOriginX,
+                                          EB_U32 tbOriginY, EB_U32 lcuWidth, EB_U32 lcuHeight, SaoParameters_t *saoPtr,
+                                          SaoParameters_t *leftSaoPtr, SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost,
+                                          EB_S64 *saoChromaBestCost);
+EB_ERRORTYPE __real_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPtr, SaoStats_t *saoStats, SaoParameters_t *saoParams,
+                                               MdRateEstimationContext_t *md, EB_U64 fullLambda, EB_U64 fullChromaLambdaSao, EB_BOOL mmSao,
+                                               PictureControlSet_t *pcs, EB_U32 tbOriginX, EB_U32 tbOriginY, EB_U32 lcuWidth,
+                                               EB_U32 lcuHeight, SaoParameters_t *saoPtr, SaoParameters_t *leftSaoPtr,
+                                               SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost, EB_S64 *saoChromaBestCost);
+static unsigned long g_sao_gpu;
+static int g_sao_state;
+
+static void sao_params_in(SvtAmdSaoLcuParams *d, const SaoParameters_t *s)
+{
+    memset(d, 0, sizeof(*d));
+    d->merge_left = s->saoMergeLeftFlag, d->merge_up = s->saoMergeUpFlag;
+    d->type[0] = s->saoTypeIndex[0], d->type[1] = s->saoTypeIndex[1];
+    memcpy(d->offset, s->saoOffset, sizeof(d->offset));
+    memcpy(d->band, s->saoBandPosition, sizeof(d->band));
+}
+
+/* in8 / in16: the three input planes' first sample of this LCU and their strides; same for the reconstruction */
+static void sao_on_device(int is16, void *const in[3], const uint32_t inStride[3], void *const rec[3], const uint32_t recStride[3],
+                          SaoStats_t *saoStats, MdRateEstimationContext_t *md, EB_U64 fullLambda, EB_U64 fullChromaLambdaSao, EB_BOOL mmSao,
+                          PictureControlSet_t *pcs, EB_U32 lcuWidth, EB_U32 lcuHeight, SaoParameters_t *saoPtr, SaoParameters_t *leftSaoPtr,
+                          SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost, EB_S64 *saoChromaBestCost)
+{
+    SvtAmdSaoStats st[3];
+    SvtAmdSaoDecisionParams P;
+    SvtAmdSaoLcuParams left, up, out;
+    int64_t costs[2] = {0, 0};
+    memset(st, 0, sizeof(st)), memset(&P, 0, sizeof(P)), memset(&out, 0, sizeof(out));
+    P.lambda = fullLambda, P.chroma_lambda = fullChromaLambdaSao;
+    for (int k = 0; k < 6; k++)
+        P.type_bits[k] = md->saoTypeIndexBits[k];
+    for (int k = 0; k < 2; k++)
+        P.merge_bits[k] = md->saoMergeFlagBits[k];
+    for (int k = 0; k < 8; k++)
+        P.offset_bits[k] = md->saoOffsetTrunUnaryBits[k];
+    P.is_10bit = (uint8_t)is16, P.mm_sao = mmSao ? 1 : 0, P.temporal_layer = pcs->temporalLayerIndex;
+    pthread_mutex_lock(&g_lock);
+    const int ncomp = mmSao ? 3 : (pcs->temporalLayerIndex < 2 ? 1 : 0);
+    for (int c = 0; c < ncomp; c++) {
+        const uint32_t w = c ? lcuWidth >> 1 : lcuWidth, h = c ? lcuHeight >> 1 : lcuHeight;
+        int rc;
+        if (mmSao)
+            rc = is16 ? svt_amd_GatherSaoStatisticsLcu_62x62_16bit((uint16_t *)in[c], inStride[c], (uint16_t *)rec[c], recStride[c], w, h,
+                                                                   st[c].boDiff, st[c].boCount, st[c].eoDiff, st[c].eoCount)
+                      : svt_amd_GatherSaoStatisticsLcuLossy_62x62((uint8_t *)in[c], inStride[c], (uint8_t *)rec[c], recStride[c], w, h,
+                                                                  st[c].boDiff, st[c].boCount, st[c].eoDiff, st[c].eoCount);
+        else
+            rc = is16 ? svt_amd_GatherSaoStatisticsLcu_62x62_OnlyEo_90_45_135_16bit((uint16_t *)in[c], inStride[c], (uint16_t *)rec[c],
+                                                                                    recStride[c], w, h, st[c].eoDiff, st[c].eoCount)
+                      : svt_amd_GatherSaoStatisticsLcu_OnlyEo_90_45_135_Lossy((uint8_t *)in[c], inStride[c], (uint8_t *)rec[c],
+                                                                              recStride[c], w, h, st[c].eoDiff, st[c].eoCount);
+        if (rc)
+            die("svt_amd_GatherSaoStatistics*");
+        memcpy(saoStats->eoDiff[c], st[c].eoDiff, sizeof(st[c].eoDiff));
+        memcpy(saoStats->eoCount[c], st[c].eoCount, sizeof(st[c].eoCount));
+        if (mmSao) {
+            memcpy(saoStats->boDiff[c], st[c].boDiff, sizeof(st[c].boDiff));
+            memcpy(saoStats->boCount[c], st[c].boCount, sizeof(st[c].boCount));
+        }
+    }
+    if (leftSaoPtr)
+        sao_params_in(&left, leftSaoPtr);
+    if (upSaoPtr)
+        sao_params_in(&up, upSaoPtr);
+    if (svt_amd_sao_decide_lcu(g_ctx, &P, &st[0], &st[1], &st[2], leftSaoPtr ? &left : NULL, upSaoPtr ? &up : NULL, &out, costs))
+        die("svt_amd_sao_decide_lcu");
+    if (g_sao_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: SAO statistics + decision (SaoGenerationDecision%s) on the GPU\n", is16 ? "16bit" : "");
+    pthread_mutex_unlock(&g_lock);
+    saoPtr->saoMergeLeftFlag = out.merge_left, saoPtr->saoMergeUpFlag = out.merge_up;
+    saoPtr->saoTypeIndex[0] = out.type[0], saoPtr->saoTypeIndex[1] = out.type[1];
+    memcpy(saoPtr->saoOffset, out.offset, sizeof(out.offset));
+    memcpy(saoPtr->saoBandPosition, out.band, sizeof(out.band));
+    *saoLumaBestCost = costs[0], *saoChromaBestCost = costs[1];
+}
+
+EB_ERRORTYPE __wrap_SaoGenerationDecision(SaoStats_t *saoStats, SaoParameters_t *saoParams, MdRateEstimationContext_t *md, EB_U64 fullLambda,
+                                          EB_U64 fullChromaLambdaSao, EB_BOOL mmSao, PictureControlSet_t *pcs, EB_U32 tbOriginX,
+                                          EB_U32 tbOriginY, EB_U32 lcuWidth, EB_U32 lcuHeight, SaoParameters_t *saoPtr,
+                                          SaoParameters_t *leftSaoPtr, SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost,
+                                          EB_S64 *saoChromaBestCost)
+{
+    if (g_sao_state == 0)
+        g_sao_state = getenv("SVT_HOOK_SAO") ? 1 : -1;
+    const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr;
+    const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
+        ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture : pcs->reconPicturePtr;
+    if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420)
+        return __real_SaoGenerationDecision(saoStats, saoParams, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, tbOriginX, tbOriginY,
+                                            lcuWidth, lcuHeight, saoPtr, leftSaoPtr, upSaoPtr, saoLumaBestCost, saoChromaBestCost);
+    void *ip[3] = {in->bufferY + (in->originY + tbOriginY) * in->strideY + in->originX + tbOriginX,
+                   in->bufferCb + (((in->originY + tbOriginY) * in->strideCb) >> 1) + ((in->originX + tbOriginX) >> 1),
+                   in->bufferCr + (((in->originY + tbOriginY) * in->strideCr) >> 1) + ((in->originX + tbOriginX) >> 1)};
+    void *rp[3] = {rec->bufferY + (rec->originY + tbOriginY) * rec->strideY + rec->originX + tbOriginX,
+                   rec->bufferCb + (((rec->originY + tbOriginY) * rec->strideCb) >> 1) + ((rec->originX + tbOriginX) >> 1),
+                   rec->bufferCr + (((rec->originY + tbOriginY) * rec->strideCr) >> 1) + ((rec->originX + tbOriginX) >> 1)};
+    const uint32_t is_[3] = {in->strideY, in->strideCb, in->strideCr}, rs[3] = {rec->strideY, rec->strideCb, rec->strideCr};
+    sao_on_device(0, ip, is_, rp, rs, saoStats, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, lcuWidth, lcuHeight, saoPtr, leftSaoPtr,
+                  upSaoPtr, saoLumaBestCost, saoChromaBestCost);
+    return EB_ErrorNone;
+}
+
+EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPtr, SaoStats_t *saoStats, SaoParameters_t *saoParams,
+                                               MdRateEstimationContext_t *md, EB_U64 fullLambda, EB_U64 fullChromaLambdaSao, EB_BOOL mmSao,
+                                               PictureControlSet_t *pcs, EB_U32 tbOriginX, EB_U32 tbOriginY, EB_U32 lcuWidth,
+                                               EB_U32 lcuHeight, SaoParameters_t *saoPtr, SaoParameters_t *leftSaoPtr,
+                                               SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost, EB_S64 *saoChromaBestCost)
+{
+    if (g_sao_state == 0)
+        g_sao_state = getenv("SVT_HOOK_SAO") ? 1 : -1;
+    const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
+        ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture16bit : pcs->reconPicture16bitPtr;
+    if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420)
+        return __real_SaoGenerationDecision16bit(inputLcuPtr, saoStats, saoParams, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, tbOriginX,
+                                                 tbOriginY, lcuWidth, lcuHeight, saoPtr, leftSaoPtr, upSaoPtr, saoLumaBestCost,
+                                                 saoChromaBestCost);
+    void *ip[3] = {inputLcuPtr->bufferY, inputLcuPtr->bufferCb, inputLcuPtr->bufferCr};
+    void *rp[3] = {(uint16_t *)rec->bufferY + (rec->originY + tbOriginY) * rec->strideY + rec->originX + tbOriginX,
+                   (uint16_t *)rec->bufferCb + (((rec->originY + tbOriginY) * rec->strideCb) >> 1) + ((rec->originX + tbOriginX) >> 1),
+                   (uint16_t *)rec->bufferCr + (((rec->originY + tbOriginY) * rec->strideCb) >> 1) + ((rec->originX + tbOriginX) >> 1)};
+    const uint32_t is_[3] = {inputLcuPtr->strideY, inputLcuPtr->strideCb, inputLcuPtr->strideCr},
+                   rs[3] = {rec->strideY, rec->strideCb, rec->strideCr};
+    sao_on_device(1, ip, is_, rp, rs, saoStats, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, lcuWidth, lcuHeight, saoPtr, leftSaoPtr,
+                  upSaoPtr, saoLumaBestCost, saoChromaBestCost);
+    return EB_ErrorNone;
+}
+
 static void hook_report(void)
 {
     fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,

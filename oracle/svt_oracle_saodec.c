@@ -218,6 +218,8 @@ void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAm
         for (uint32_t x = 0; x < cols; x++) {
             const uint32_t i = y * cols + x;
             SvtAmdSaoLcuParams *o = params + i;
+            if (enable && enable[i] == 2)
+                continue; /* given */
             if (enable && !enable[i]) {
                 const uint8_t keep = o->edge_flags;
                 memset(o, 0, sizeof(*o));

@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(64) k_sao_decide_own(SaoDecide P, const SaoSta
                                                        uint32_t nlcu, const uint8_t *enable, SaoLcuParams *params, int64_t *costs)
 {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= nlcu)
+    if (i >= nlcu || (enable != nullptr && enable[i] == 2)) /* 2: parameters given, a merge candidate only */
         return;
     SaoLcuParams o;
     o.merge_left = o.merge_up = 0, o.edge_flags = params[i].edge_flags, o.pad = 0;
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64) k_sao_decide_own(SaoDecide P, const SaoSta
     }
     int64_t lumaBest = 0, chromaBest = 0;
     const bool reduced = !P.mmSao;
-    if ((enable == nullptr || enable[i]) && (P.mmSao || P.temporalLayer < 2)) {
+    if ((enable == nullptr || enable[i] == 1) && (P.mmSao || P.temporalLayer < 2)) {
         const int sh = P.is10 ? 4 : 0, m = P.is10 ? 31 : 7;
         const int64_t maxc = (int64_t)(~0ull >> 1);
         const SaoStats *Y = sy + i;
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(256) k_sao_decide_merge(SaoDecide P, const Sao
             if (y > d || x >= cols)
                 continue;
             const uint32_t i = y * cols + x;
-            if (enable != nullptr && !enable[i])
+            if (enable != nullptr && enable[i] != 1)
                 continue;
             SaoLcuParams o = params[i];
             const bool hasLeft = !(o.edge_flags & 1) && x > 0, hasUp = !(o.edge_flags & 4) && y > 0;
@@ -876,6 +876,43 @@ extern "C" int svt_amd_sao_decide_picture(SvtAmdContext *ctx, const SvtAmdSaoDec
                            (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
                            (SaoLcuParams *)d_params, d_costs);
     HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+/* one LCU with its neighbours' final parameters given (host pointers): the call SaoGenerationDecision(16bit) makes after its
+ * gathering step.  A 2x2 grid: (1,0) = the upper LCU, (0,1) = the left one (both "given"), (1,1) = this LCU. */
+extern "C" int svt_amd_sao_decide_lcu(SvtAmdContext *ctx, const SvtAmdSaoDecisionParams *params, const SvtAmdSaoStats *stats_y,
+                                      const SvtAmdSaoStats *stats_cb, const SvtAmdSaoStats *stats_cr, const SvtAmdSaoLcuParams *left,
+                                      const SvtAmdSaoLcuParams *up, SvtAmdSaoLcuParams *out, int64_t costs[2])
+{
+    if (!ctx || !params || !stats_y || !stats_cb || !stats_cr || !out || !costs)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    struct { SaoStats st[3][4]; SaoLcuParams lcu[4]; int64_t cost[8]; uint8_t enable[8]; } h;
+    ::memset(&h, 0, sizeof(h));
+    ::memcpy(&h.st[0][3], stats_y, sizeof(SaoStats));
+    ::memcpy(&h.st[1][3], stats_cb, sizeof(SaoStats));
+    ::memcpy(&h.st[2][3], stats_cr, sizeof(SaoStats));
+    h.enable[1] = h.enable[2] = 2, h.enable[3] = 1;
+    if (up)
+        ::memcpy(&h.lcu[1], up, sizeof(SaoLcuParams));
+    if (left)
+        ::memcpy(&h.lcu[2], left, sizeof(SaoLcuParams));
+    h.lcu[3].edge_flags = (uint8_t)((left ? 0 : 1) | (up ? 0 : 4));
+    DBuf d(&h, sizeof(h));
+    if (!d.ok)
+        return SVT_AMD_ERR_DEVICE;
+    auto *dh = (decltype(h) *)d.d;
+    const int rc = svt_amd_sao_decide_picture(ctx, params, (const SvtAmdSaoStats *)dh->st[0], (const SvtAmdSaoStats *)dh->st[1],
+                                              (const SvtAmdSaoStats *)dh->st[2], 2, 2, dh->enable, (SvtAmdSaoLcuParams *)dh->lcu, dh->cost);
+    if (rc != SVT_AMD_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!d.download(&h, sizeof(h)))
+        return SVT_AMD_ERR_DEVICE;
+    const uint8_t keep = out->edge_flags;
+    ::memcpy(out, &h.lcu[3], sizeof(SaoLcuParams));
+    out->edge_flags = keep;
+    costs[0] = h.cost[6], costs[1] = h.cost[7];
     return SVT_AMD_OK;
 }
 extern "C" int svt_amd_sao_gather_picture(SvtAmdContext *ctx, int bytes_per_sample, const void *d_input,

@@ -37,8 +37,8 @@ CASES = [
 
 
 def _encode(app, yuv, w, h, n, args, out):
-    r = subprocess.run([app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-q", "32", "-asm", "1",
-                        "-b", out] + args, capture_output=True, text=True, timeout=600,
+    r = subprocess.run([app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "1", "-b", out] +
+                       ([] if "-q" in args else ["-q", "32"]) + args, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, SVT_HOOK_VERBOSE="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), r.stderr
@@ -179,18 +179,47 @@ def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind,
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
 
 
-@pytest.mark.parametrize("kind,w,h,n,args", [("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"]),
-                                             ("motion10", 416, 240, 3, ["-encMode", "9", "-pred-struct", "0", "-bit-depth", "10"])])
-def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n, args):
-    """All device bindings at once: ME, OIS, both MD full loops, encode-pass intra and inter prediction, quantiser and
-    transform-unit reconstruction."""
+SAO_CASES = [
+    ("motion", 416, 240, 5, ["-encMode", "9", "-pred-struct", "0", "-hierarchical-levels", "0", "-sao", "1"]),
+    ("motion", 416, 240, 9, ["-encMode", "5", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-q", "30"]),
+    ("motion10", 416, 240, 4, ["-encMode", "9", "-pred-struct", "0", "-hierarchical-levels", "0", "-sao", "1", "-bit-depth", "10", "-q", "20"]),
+    ("motion", 640, 384, 3, ["-encMode", "3", "-pred-struct", "0", "-hierarchical-levels", "0", "-tile_row_cnt", "2", "-tile_col_cnt", "2"]),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", SAO_CASES)
+def test_bitstream_and_recon_identical_with_gpu_sao_decision(tmp_path, kind, w, h, n, args):
+    """Every LCU's SAO statistics and parameter decision (SaoGenerationDecision / SaoGenerationDecision16bit) answered by the
+    device (SVT_HOOK_SAO=1): gather entry points + svt_amd_sao_decide_lcu."""
     yuv = str(tmp_path / "clip.yuv")
     if kind.endswith("10"):
         S.write_clip10(yuv, kind[:-2], w, h, n, 7)
     else:
         S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
-    flags = ("SVT_HOOK_FULLLOOP", "SVT_HOOK_RECON", "SVT_HOOK_INTRA", "SVT_HOOK_INTER", "SVT_HOOK_QUANT")
+    os.environ["SVT_HOOK_SAO"] = "1"
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        del os.environ["SVT_HOOK_SAO"]
+    assert "svt_hook_me: SAO statistics + decision (SaoGenerationDecision" in log, log[-1000:]
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
+    a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
+    assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", [("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"]),
+                                             ("motion10", 416, 240, 3, ["-encMode", "9", "-pred-struct", "0", "-bit-depth", "10"])])
+def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n, args):
+    """All device bindings at once: ME, OIS, both MD full loops, encode-pass intra and inter prediction, quantiser,
+    transform-unit reconstruction and the SAO statistics + decision."""
+    yuv = str(tmp_path / "clip.yuv")
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    flags = ("SVT_HOOK_FULLLOOP", "SVT_HOOK_RECON", "SVT_HOOK_INTRA", "SVT_HOOK_INTER", "SVT_HOOK_QUANT", "SVT_HOOK_SAO")
     for f in flags:
         os.environ[f] = "1"
     try:
@@ -200,7 +229,7 @@ def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n,
             del os.environ[f]
     for msg in ("motion estimation on svt-hevc_amd", "luma full loop (ProductFullLoop) on the GPU", "chroma full loop",
                 "transform-unit reconstruction", "encode-pass intra prediction", "encode-pass inter prediction",
-                "encode-pass quantiser"):
+                "encode-pass quantiser", "SAO statistics + decision"):
         if kind.endswith("10") and "inter prediction" in msg:
             continue    # the 16-bit inter driver stays on the host
         assert msg in log, (msg, log[-1500:])

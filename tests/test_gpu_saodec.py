@@ -42,6 +42,24 @@ def test_sao_decision_matches_reference_pictures(product, gpu_ctx, name):
         assert (params["type"][off] == 0).all() and (params["merge_left"][off] == 0).all() and (params["merge_up"][off] == 0).all()
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_sao_decision_lcu_form_matches_reference_records(product, gpu_ctx, name):
+    """the one-LCU host form: every record's neighbours are handed in exactly as the reference saw them"""
+    from test_oracle_saodec_golden import load_saodec_case, lcu_of, params_of, stats_of
+    recs = load_saodec_case(name)
+    recs = recs[:: max(1, len(recs) // 150)]
+    product.svt_amd_sao_decide_lcu.argtypes = [vp] * 9
+    for i, r in enumerate(recs):
+        st, d, out, costs = stats_of(r), params_of(r), np.zeros(1, LCU), np.zeros(2, np.int64)
+        left, up = lcu_of(r["left"]), lcu_of(r["up"])
+        rc = product.svt_amd_sao_decide_lcu(gpu_ctx, d.ctypes.data, st[0:1].ctypes.data, st[1:2].ctypes.data, st[2:3].ctypes.data,
+                                            left.ctypes.data if r["has_left"] else None, up.ctypes.data if r["has_up"] else None,
+                                            out.ctypes.data, costs.ctypes.data)
+        assert rc == 0, product.svt_amd_last_error()
+        assert same_decision(out[0], r["out"]), (name, i, out[0], r["out"])
+        assert costs[0] == r["luma_cost"] and costs[1] == r["chroma_cost"], (name, i, costs)
+
+
 def random_picture(rng, cols, rows, is10, mm, layer, with_enable, flat):
     n = cols * rows
     P = np.zeros(1, DEC)
@@ -68,6 +86,13 @@ def random_picture(rng, cols, rows, is10, mm, layer, with_enable, flat):
     params = np.zeros(n, LCU)
     params["edge_flags"] = rng.integers(0, 16, n) * (rng.random(n) < 0.15)
     enable = (rng.random(n) < 0.85).astype(np.uint8) if with_enable else None
+    if with_enable:     # a few LCUs with parameters "decided by an earlier call"
+        given = rng.random(n) < 0.08
+        enable[given] = 2
+        params["type"][given] = rng.integers(0, 6, (int(given.sum()), 2))
+        params["type"][:, 1][params["type"][:, 1] == 5] = 3
+        params["offset"][given] = rng.integers(0, amp + 1, (int(given.sum()), 3, 4)) * np.array([1, 1, -1, -1])
+        params["band"][given] = rng.integers(0, 29, (int(given.sum()), 3))
     return dict(P=P, stats=stats, enable=enable, params=params, cols=cols, rows=rows)
 
 
