@@ -791,7 +791,10 @@ typedef struct SvtAmdIntraPuJob {
 SVT_AMD_API int svt_amd_intra_pu_batch(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *d_jobs,
                                        uint32_t njobs, void *d_pred_y, uint32_t strideY, void *d_pred_cb, void *d_pred_cr,
                                        uint32_t strideC);
-/* Per-call form on HOST pointers (one unit, blocking): the binding of the two table slots. */
+/* Per-call form on HOST pointers (one unit, blocking): the binding of the two table slots, and of the mode decision's
+ * IntraPredictionCl (Codec/EbIntraPrediction.c:3682; generators GenerateIntraLuma/ChromaReferenceSamplesMd, EbProductCodingLoop.c:
+ * 269, :2196), which asks for the luma block and the chroma pair separately: pred_y == NULL or pred_cb == pred_cr == NULL
+ * leaves that part out. */
 SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *job, void *pred_y,
                                  uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC);
 

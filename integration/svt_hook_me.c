@@ -593,6 +593,91 @@ __attribute__((constructor)) static void intra_install(void)
     EncodePassIntraPredictionFuncTable[0] = intra_pred8, EncodePassIntraPredictionFuncTable[1] = intra_pred16;
 }
 
+/* Mode-decision side: IntraPredictionCl (EbIntraPrediction.c:3682, reached through ProductPredictionFunTableCl) predicts the
+ * luma block and / or the chroma pair of a candidate from the mode decision's own neighbour arrays into the candidate's
+ * LCU-local prediction buffer.  Same switch; the reference's generators still run (their flags and arrays are host state
+ * other paths read), the predicted samples come from the device. */
+EB_ERRORTYPE __real_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand);
+static unsigned long g_md_intra_gpu;
+static int g_md_intra_state;
+
+static void md_intra_job(SvtAmdIntraPuJob *j, ModeDecisionContext_t *md, int chroma)
+{
+    const uint32_t size = md->cuStats->size, originX = md->cuOriginX, originY = md->cuOriginY, cuDepth = md->cuStats->depth;
+    NeighborArrayUnit_t *mode = md->modeTypeNeighborArray;
+    memset(j, 0, sizeof(*j));
+    j->size = size, j->constrained_intra = 0, j->strong_smoothing = 1;
+    if (!chroma) { /* EbProductCodingLoop.c:274-276; the chroma generator is called without edge flags (:2203-2219) */
+        const uint32_t m = md->lcuPtr->size - 1;
+        j->pic_left = md->lcuPtr->lcuEdgeInfoPtr->tileLeftEdgeFlag == EB_TRUE && (originX & m) == 0;
+        j->pic_top = md->lcuPtr->lcuEdgeInfoPtr->tileTopEdgeFlag == EB_TRUE && (originY & m) == 0;
+        j->pic_right = md->lcuPtr->lcuEdgeInfoPtr->tileRightEdgeFlag == EB_TRUE && ((originX + size) & m) == 0;
+    }
+    uint32_t lg = 0;
+    while ((1u << lg) < size)
+        lg++;
+    const uint32_t cuIndex = ((originY & 63) >> lg) * (1u << cuDepth) + ((originX & 63) >> lg);
+    j->bottom_left_ok = isBottomLeftAvailable(cuDepth, cuIndex), j->top_right_ok = isUpperRightAvailable(cuDepth, cuIndex);
+    for (uint32_t k = 0; k < 2 * size / 4; k++) {
+        const uint32_t li = GetNeighborArrayUnitLeftIndex(mode, originY + 4 * k), ti = GetNeighborArrayUnitTopIndex(mode, originX + 4 * k);
+        j->mode_left[k] = li >= mode->leftArraySize ? 0xFE : mode->leftArray[li];
+        j->mode_top[k] = ti >= mode->topArraySize ? 0xFE : mode->topArray[ti];
+    }
+    j->mode_tl = mode->topLeftArray[GetNeighborArrayUnitTopLeftIndex(mode, (EB_S32)originX, (EB_S32)originY)];
+    NeighborArrayUnit_t *na[3] = {md->lumaReconNeighborArray, md->cbReconNeighborArray, md->crReconNeighborArray};
+    for (int p = chroma ? 1 : 0; p < (chroma ? 3 : 1); p++) {
+        const uint32_t sh = p ? 1 : 0, n2 = (2 * size) >> sh, ox = originX >> sh, oy = originY >> sh;
+        for (uint32_t i = 0; i < n2; i++) {
+            const uint32_t k = (i << sh) >> 2;
+            j->left[p][i] = j->mode_left[k] == 0xFE ? 0 : na[p]->leftArray[oy + i];
+            j->top[p][i] = j->mode_top[k] == 0xFE ? 0 : na[p]->topArray[ox + i];
+        }
+        j->tl[p] = p == 0 ? na[0]->topLeftArray[MAX_PICTURE_HEIGHT_SIZE + originX - originY]
+                          : na[p]->topLeftArray[((MAX_PICTURE_HEIGHT_SIZE - originY) >> 1) + (originX >> 1)];
+    }
+}
+
+EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand)
+{
+    if (g_md_intra_state == 0)
+        g_md_intra_state = getenv("SVT_HOOK_INTRA") ? 1 : -1;
+    const uint32_t size = md->cuStats->size, lumaMode = cand->candidatePtr->intraLumaMode;
+    const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
+    if (g_md_intra_state < 0 || !g_ctx || md->intraMdOpenLoopFlag || size < 8 || size > 32 || lumaMode > 34 ||
+        (chromaAsked && ((componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK ||
+                         !md->useChromaInformationInFullLoop)))
+        return __real_IntraPredictionCl(md, componentMask, pcs, cand);
+    EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr, *pred = cand->predictionPtr;
+    SvtAmdIntraPuJob j;
+    if (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) {
+        if (md->lumaIntraRefSamplesGenDone == EB_FALSE)
+            GenerateIntraLumaReferenceSamplesMd(md, in);
+        md_intra_job(&j, md, 0);
+        j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
+        pthread_mutex_lock(&g_lock);
+        if (svt_amd_intra_pu(g_ctx, 1, &j, pred->bufferY + (md->cuOriginY & 63) * 64 + (md->cuOriginX & 63), pred->strideY, NULL, NULL, 0))
+            die("svt_amd_intra_pu (mode decision, luma)");
+        if (g_md_intra_gpu++ == 0 && g_verbose)
+            fprintf(stderr, "svt_hook_me: mode-decision intra prediction (IntraPredictionCl) on the GPU\n");
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (chromaAsked) {
+        if (md->chromaIntraRefSamplesGenDone == EB_FALSE)
+            GenerateIntraChromaReferenceSamplesMd(md, in);
+        md_intra_job(&j, md, 1);
+        j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
+        const uint32_t o = (((md->cuOriginY & 63) * 32) + (md->cuOriginX & 63)) >> 1;
+        pthread_mutex_lock(&g_lock);
+        if (svt_amd_intra_pu(g_ctx, 1, &j, NULL, 0, pred->bufferCb + o, pred->bufferCr + o, pred->strideCb))
+            die("svt_amd_intra_pu (mode decision, chroma)");
+        g_md_intra_gpu++;
+        pthread_mutex_unlock(&g_lock);
+    }
+    return EB_ErrorNone;
+}
+
 /*
  * Encode-pass inter prediction: EncodePassInterPrediction (EbInterPrediction.c:761, called per prediction unit from
  * EbCodingLoop.c:3932) is answered by svt_amd_inter_pu_batch() with SVT_HOOK_INTER=1 (8-bit 4:2:0).  Reference pictures

@@ -10,6 +10,13 @@
  * record: the slices of the neighbour arrays the first call may look at (mode type per 4 samples, reconstructed luma /
  * chroma samples left, above and above-left of the unit), its flags, the two z-order availabilities it derives, and the
  * modes and the three predicted blocks of the second call.  tests/golden/make_intra_golden.py builds the fixtures.
+ *
+ * The mode decision's closed-loop intra prediction IntraPredictionCl (Codec/EbIntraPrediction.c:3682, reached through
+ * ProductPredictionFunTableCl, EbProductCodingLoop.c:223-227) is caught with -Wl,--wrap=IntraPredictionCl: with
+ * SVT_REF_INTRA_MD_DUMP=<file> every SVT_REF_INTRA_MD_STRIDE-th call (default 23) leaves records of the same layout, one for
+ * the luma block (component_mask 1, the tile-edge flags GenerateIntraLumaReferenceSamplesMd derives, EbProductCodingLoop.c:
+ * 274-276) and / or one for the two chroma blocks (component_mask 6, no edge flags, :2203-2219), cut from the mode decision's
+ * own neighbour arrays and its candidate prediction buffer.
  * No reference source here.
  */
 #include <stdio.h>
@@ -22,6 +29,9 @@
 #include "EbNeighborArrays.h"
 #include "EbIntraPrediction.h"
 #include "EbAvailability.h"
+#include "EbPictureControlSet.h"
+#include "EbModeDecisionProcess.h"
+#include "EbModeDecision.h"
 
 typedef EB_ERRORTYPE (*GenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
                               NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_COLOR_FORMAT, EB_BOOL, EB_BOOL, EB_BOOL);
@@ -154,4 +164,97 @@ __attribute__((constructor)) static void install(void)
     g_pred[0] = EncodePassIntraPredictionFuncTable[0], g_pred[1] = EncodePassIntraPredictionFuncTable[1];
     GenerateIntraReferenceSamplesFuncTable[0] = gen8, GenerateIntraReferenceSamplesFuncTable[1] = gen16;
     EncodePassIntraPredictionFuncTable[0] = pred8, EncodePassIntraPredictionFuncTable[1] = pred16;
+}
+
+/* ---- mode-decision side ---- */
+EB_ERRORTYPE __real_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand);
+static FILE *g_md_file;
+static int g_md_state, g_md_stride = 23;
+static unsigned long g_md_calls;
+
+static void md_record(ModeDecisionContext_t *md, ModeDecisionCandidateBuffer_t *cand, int chroma)
+{
+    IntraRecord *r = (IntraRecord *)calloc(1, sizeof(*r));
+    const uint32_t size = md->cuStats->size, originX = md->cuOriginX, originY = md->cuOriginY, cuDepth = md->cuStats->depth;
+    NeighborArrayUnit_t *mode = md->modeTypeNeighborArray;
+    r->magic = INTRA_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->size = size, r->bytes_per_sample = 1;
+    r->constrained_intra = 0, r->strong_smoothing = 1;
+    if (!chroma) {
+        const uint32_t m = md->lcuPtr->size - 1;
+        r->pic_left = md->lcuPtr->lcuEdgeInfoPtr->tileLeftEdgeFlag == EB_TRUE && (originX & m) == 0;
+        r->pic_top = md->lcuPtr->lcuEdgeInfoPtr->tileTopEdgeFlag == EB_TRUE && (originY & m) == 0;
+        r->pic_right = md->lcuPtr->lcuEdgeInfoPtr->tileRightEdgeFlag == EB_TRUE && ((originX + size) & m) == 0;
+    }
+    uint32_t lg = 0;
+    while ((1u << lg) < size)
+        lg++;
+    const uint32_t cuIndex = ((originY & 63) >> lg) * (1u << cuDepth) + ((originX & 63) >> lg);
+    r->bottom_left_ok = isBottomLeftAvailable(cuDepth, cuIndex), r->top_right_ok = isUpperRightAvailable(cuDepth, cuIndex);
+    for (uint32_t k = 0; k < 2 * size / 4; k++) {
+        const uint32_t li = GetNeighborArrayUnitLeftIndex(mode, originY + 4 * k), ti = GetNeighborArrayUnitTopIndex(mode, originX + 4 * k);
+        r->mode_left[k] = li >= mode->leftArraySize ? 0xFE : mode->leftArray[li];
+        r->mode_top[k] = ti >= mode->topArraySize ? 0xFE : mode->topArray[ti];
+    }
+    r->mode_tl = mode->topLeftArray[GetNeighborArrayUnitTopLeftIndex(mode, (EB_S32)originX, (EB_S32)originY)];
+    NeighborArrayUnit_t *na[3] = {md->lumaReconNeighborArray, md->cbReconNeighborArray, md->crReconNeighborArray};
+    for (int p = chroma ? 1 : 0; p < (chroma ? 3 : 1); p++) {
+        const uint32_t sh = p ? 1 : 0, n2 = (2 * size) >> sh, ox = originX >> sh, oy = originY >> sh;
+        for (uint32_t i = 0; i < n2; i++) {
+            const uint32_t k = (i << sh) >> 2;
+            r->left[p][i] = r->mode_left[k] == 0xFE ? 0 : rd(na[p]->leftArray, oy + i, 1);
+            r->top[p][i] = r->mode_top[k] == 0xFE ? 0 : rd(na[p]->topArray, ox + i, 1);
+        }
+        r->tl[p] = p == 0 ? rd(na[0]->topLeftArray, MAX_PICTURE_HEIGHT_SIZE + originX - originY, 1)
+                          : rd(na[p]->topLeftArray, ((MAX_PICTURE_HEIGHT_SIZE - originY) >> 1) + (originX >> 1), 1);
+    }
+    r->luma_mode = cand->candidatePtr->intraLumaMode, r->chroma_mode = 4 /* derived: "the chromaMode is always DM" */;
+    r->component_mask = chroma ? PICTURE_BUFFER_DESC_CHROMA_MASK : PICTURE_BUFFER_DESC_LUMA_MASK;
+    const EbPictureBufferDesc_t *pred = cand->predictionPtr;
+    if (!chroma) {
+        const uint32_t o = (originY & 63) * 64 + (originX & 63);
+        for (uint32_t yy = 0; yy < size; yy++)
+            for (uint32_t xx = 0; xx < size; xx++)
+                r->pred_y[yy * size + xx] = pred->bufferY[o + yy * pred->strideY + xx];
+    } else {
+        const uint32_t o = (((originY & 63) * 32) + (originX & 63)) >> 1, c = size >> 1;
+        for (uint32_t yy = 0; yy < c; yy++)
+            for (uint32_t xx = 0; xx < c; xx++) {
+                r->pred_cb[yy * c + xx] = pred->bufferCb[o + yy * pred->strideCb + xx];
+                r->pred_cr[yy * c + xx] = pred->bufferCr[o + yy * pred->strideCr + xx];
+            }
+    }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_md_file);
+    fflush(g_md_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+}
+
+EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand)
+{
+    if (g_md_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_md_state == 0) {
+            const char *path = getenv("SVT_REF_INTRA_MD_DUMP"), *st = getenv("SVT_REF_INTRA_MD_STRIDE");
+            g_md_file = path ? fopen(path, "wb") : NULL;
+            if (st && atoi(st) > 0)
+                g_md_stride = atoi(st);
+            g_md_state = g_md_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    const EB_ERRORTYPE rc = __real_IntraPredictionCl(md, componentMask, pcs, cand);
+    int take = 0;
+    if (g_md_state > 0 && !md->intraMdOpenLoopFlag && md->cuStats->size >= 8 && md->cuStats->size <= 32) {
+        pthread_mutex_lock(&g_lock);
+        take = (g_md_calls++ % (unsigned long)g_md_stride) == 0;
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (take && (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK))
+        md_record(md, cand, 0);
+    if (take && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) == PICTURE_BUFFER_DESC_CHROMA_MASK && md->useChromaInformationInFullLoop)
+        md_record(md, cand, 1);
+    return rc;
 }

@@ -349,8 +349,9 @@ extern "C" int svt_amd_intra_pu_batch(SvtAmdContext *ctx, int bytes_per_sample, 
 extern "C" int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *job, void *pred_y, uint32_t strideY,
                                 void *pred_cb, void *pred_cr, uint32_t strideC)
 {
-    if (!ctx || !job || !pred_y || !pred_cb || !pred_cr || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
-        (job->size != 8 && job->size != 16 && job->size != 32) || strideY < job->size || strideC < job->size / 2)
+    const bool wantY = pred_y != nullptr, wantC = pred_cb != nullptr && pred_cr != nullptr;
+    if (!ctx || !job || (!wantY && !wantC) || (!pred_cb) != (!pred_cr) || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
+        (job->size != 8 && job->size != 16 && job->size != 32) || (wantY && strideY < job->size) || (wantC && strideC < job->size / 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     static uint8_t *d_scratch = nullptr; /* job | Y 32x32 | Cb 16x16 | Cr 16x16 (16-bit worst case) */
@@ -367,13 +368,16 @@ extern "C" int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const 
     if (rc)
         return rc;
     uint8_t hy[2048], hcb[512], hcr[512];
-    HIP_TRY(hipMemcpyAsync(hy, d_scratch + o_y, (size_t)N * N * bps, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(hcb, d_scratch + o_cb, (size_t)C * C * bps, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(hcr, d_scratch + o_cr, (size_t)C * C * bps, hipMemcpyDeviceToHost, ctx->stream));
+    if (wantY)
+        HIP_TRY(hipMemcpyAsync(hy, d_scratch + o_y, (size_t)N * N * bps, hipMemcpyDeviceToHost, ctx->stream));
+    if (wantC) {
+        HIP_TRY(hipMemcpyAsync(hcb, d_scratch + o_cb, (size_t)C * C * bps, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(hcr, d_scratch + o_cr, (size_t)C * C * bps, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (uint32_t y = 0; y < N; y++)
+    for (uint32_t y = 0; wantY && y < N; y++)
         ::memcpy((uint8_t *)pred_y + (size_t)y * strideY * bps, hy + (size_t)y * N * bps, (size_t)N * bps);
-    for (uint32_t y = 0; y < C; y++) {
+    for (uint32_t y = 0; wantC && y < C; y++) {
         ::memcpy((uint8_t *)pred_cb + (size_t)y * strideC * bps, hcb + (size_t)y * C * bps, (size_t)C * bps);
         ::memcpy((uint8_t *)pred_cr + (size_t)y * strideC * bps, hcr + (size_t)y * C * bps, (size_t)C * bps);
     }

@@ -5,7 +5,9 @@ Runs oracle/_ref/SvtHevcEncApp_ref on seeded clips with SVT_REF_INTRA_DUMP set, 
 oracle/ref_harness_intra_dump.c record a sample of the GenerateIntraReferenceSamplesEncodePass + EncodePassIntraPrediction
 call pairs of the real encode pass: neighbour-array slices and flags in, the three predicted blocks out.
 Stored as tests/golden/intra_<name>.npz.  Needs /root/reference (this container only).
-Usage: python tests/golden/make_intra_golden.py [name ...]
+With SVT_REF_INTRA_MD_DUMP the same harness records the mode decision's closed-loop IntraPredictionCl calls (one record per
+luma block, one per chroma pair; component_mask says which planes are valid) -> tests/golden/intramd_<name>.npz.
+Usage: python tests/golden/make_intra_golden.py [name ...]      (names of either family)
 """
 import os
 import subprocess
@@ -32,6 +34,13 @@ CASES = {
     "i10_416x240_m7": ("motion", 416, 240, 2, 7, 10, ["-encMode", "7", "-intra-period", "0", "-bit-depth", "10"], 1, 200),
     "i_tiles_640x384_m9": ("motion", 640, 384, 2, 7, 8, ["-encMode", "9", "-intra-period", "0", "-tile_row_cnt", "2", "-tile_col_cnt", "2"], 2, 200),
     "p_cip_noise_320x256_m6": ("noise", 320, 256, 4, 11, 8, ["-encMode", "6", "-pred-struct", "0", "-q", "25", "-constrd-intra", "1"], 2, 200),
+}
+# mode-decision side: name -> (clip kind, width, height, frames, seed, encoder args, sampling stride, records kept)
+MD_CASES = {
+    "i_416x240_m9": ("motion", 416, 240, 2, 7, ["-encMode", "9", "-intra-period", "0"], 5, 260),
+    "ip_noise_320x256_m1": ("noise", 320, 256, 3, 11, ["-encMode", "1", "-pred-struct", "0", "-q", "28"], 61, 260),
+    "p_motion_416x240_m5": ("motion", 416, 240, 4, 7, ["-encMode", "5", "-pred-struct", "0"], 11, 220),
+    "i_tiles_640x384_m3": ("motion", 640, 384, 2, 7, ["-encMode", "3", "-intra-period", "0", "-tile_row_cnt", "2", "-tile_col_cnt", "2"], 23, 260),
 }
 KEEP = ("size", "bytes_per_sample", "constrained_intra", "strong_smoothing", "pic_left", "pic_top", "pic_right", "bottom_left_ok",
         "top_right_ok", "luma_mode", "chroma_mode", "mode_left", "mode_top", "mode_tl", "left", "top", "tl")
@@ -65,8 +74,44 @@ def run_case(name):
            int(((recs["mode_left"] == 1).any(axis=1) | (recs["mode_top"] == 1).any(axis=1)).sum()), int(recs["constrained_intra"].sum())))
 
 
+def run_md_case(name):
+    kind, w, h, n, seed, args, stride, keep = MD_CASES[name]
+    with tempfile.TemporaryDirectory() as td:
+        yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "intramd.dump")
+        S.write_clip(yuv, kind, w, h, n, seed)
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + \
+            ([] if "-q" in args else ["-q", "32"]) + args
+        subprocess.run(cmd, env=dict(os.environ, SVT_REF_INTRA_MD_DUMP=dump, SVT_REF_INTRA_MD_STRIDE=str(stride)), check=True,
+                       stdout=subprocess.DEVNULL)
+        recs = np.fromfile(dump, dtype=REC)
+    assert len(recs) and (recs["record_size"] == REC.itemsize).all(), (len(recs), REC.itemsize)
+    total = len(recs)
+    groups = [np.flatnonzero((recs["component_mask"] == m) & (recs["size"] == z)) for m in np.unique(recs["component_mask"])
+              for z in np.unique(recs["size"])]
+    groups = [g[np.argsort(recs["luma_mode"][g], kind="stable")] for g in groups if len(g)]
+    share = keep // len(groups)
+    sel = np.concatenate([g[np.linspace(0, len(g) - 1, min(share, len(g))).astype(int)] for g in groups])
+    recs = recs[np.sort(np.unique(sel))]
+    out = {k: recs[k] for k in KEEP + ("component_mask",)}
+    out["pred_y"] = np.concatenate([r["pred_y"][: int(r["size"]) ** 2] for r in recs])
+    out["pred_cb"] = np.concatenate([r["pred_cb"][: (int(r["size"]) // 2) ** 2] for r in recs])
+    out["pred_cr"] = np.concatenate([r["pred_cr"][: (int(r["size"]) // 2) ** 2] for r in recs])
+    path = os.path.join(S.GOLDEN_DIR, "intramd_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    sizes, cnt = np.unique(recs["size"], return_counts=True)
+    print("%-26s %d of %d records (sizes %s, luma %d / chroma %d) -> %s (%.0f KiB); %d luma modes, edges L/T/R %d/%d/%d, inter neighbours %d" %
+          (name, len(recs), total, dict(zip(sizes.tolist(), cnt.tolist())), int((recs["component_mask"] == 1).sum()),
+           int((recs["component_mask"] != 1).sum()), os.path.basename(path), os.path.getsize(path) / 1024,
+           len(np.unique(recs["luma_mode"])), int(recs["pic_left"].sum()), int(recs["pic_top"].sum()), int(recs["pic_right"].sum()),
+           int(((recs["mode_left"] == 1).any(axis=1) | (recs["mode_top"] == 1).any(axis=1)).sum())))
+
+
 if __name__ == "__main__":
     if not os.path.exists(S.REF_APP):
         sys.exit("oracle/_ref/SvtHevcEncApp_ref missing: run `make -C oracle ref` (needs /root/reference)")
-    for nm in (sys.argv[1:] or list(CASES)):
-        run_case(nm)
+    names = sys.argv[1:] or (list(CASES) + ["md:" + k for k in MD_CASES])
+    for nm in names:
+        if nm.startswith("md:"):
+            run_md_case(nm[3:])
+        else:
+            run_case(nm)

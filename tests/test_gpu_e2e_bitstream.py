@@ -129,13 +129,16 @@ INTRA_CASES = [
     ("motion", 416, 240, 3, ["-encMode", "9", "-intra-period", "0"]),
     ("noise", 320, 256, 4, ["-encMode", "6", "-pred-struct", "0", "-q", "25", "-constrd-intra", "1"]),   # intra CUs among inter ones
     ("motion10", 416, 240, 2, ["-encMode", "7", "-intra-period", "0", "-bit-depth", "10"]),
+    # encMode 1: chroma in the mode decision's full loop (IntraPredictionCl asked for the chroma pair as well), 2 x 2 tiles
+    ("noise", 320, 256, 3, ["-encMode", "1", "-pred-struct", "0", "-q", "28", "-tile_row_cnt", "2", "-tile_col_cnt", "2"]),
 ]
 
 
 @pytest.mark.parametrize("kind,w,h,n,args", INTRA_CASES)
 def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind, w, h, n, args):
     """The encode pass's intra prediction of every 8..32 prediction unit (reference-sample generation with availability,
-    substitution and smoothing + the prediction itself) answered by svt_amd_intra_pu (SVT_HOOK_INTRA=1)."""
+    substitution and smoothing + the prediction itself) and the mode decision's closed-loop intra prediction of every candidate
+    (IntraPredictionCl) answered by svt_amd_intra_pu (SVT_HOOK_INTRA=1)."""
     yuv = str(tmp_path / "clip.yuv")
     if kind.endswith("10"):
         S.write_clip10(yuv, kind[:-2], w, h, n, 7)
@@ -148,6 +151,7 @@ def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind,
     finally:
         del os.environ["SVT_HOOK_INTRA"]
     assert "svt_hook_me: encode-pass intra prediction (reference samples + prediction) on the GPU" in log, log[-1000:]
+    assert "svt_hook_me: mode-decision intra prediction (IntraPredictionCl) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"

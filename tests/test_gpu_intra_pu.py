@@ -66,6 +66,38 @@ def test_intra_pu_matches_reference_golden(product, gpu_ctx, name):
             assert np.array_equal(got[k][p], want[p]), (name, i, p, int(g["size"][i]), int(g["luma_mode"][i]))
 
 
+def test_intra_pu_matches_mode_decision_records(product, gpu_ctx):
+    """records of the mode decision's IntraPredictionCl: batched form for all of them, and the per-call host form asking for
+    the luma block or the chroma pair alone (what the binding of IntraPredictionCl does)"""
+    from test_oracle_intramd_golden import CASES as MD_CASES, load_intramd_case, planes_of
+    product.svt_amd_intra_pu.argtypes = [vp, C.c_int, vp, vp, u32, vp, vp, u32]
+    assert len(MD_CASES) == 4
+    for name in MD_CASES:
+        g = load_intramd_case(name)
+        n = len(g["size"])
+        jobs = np.concatenate([job_of(g, i) for i in range(n)])
+        got = run_jobs(product, gpu_ctx, 1, jobs)
+        for i in range(n):
+            want = want_of(g, i)
+            for p in planes_of(int(g["component_mask"][i])):
+                assert np.array_equal(got[i][p], want[p]), (name, i, p, int(g["size"][i]), int(g["luma_mode"][i]))
+        for i in range(0, n, 5):
+            want, j = want_of(g, i), job_of(g, i)
+            s_, c_ = int(g["size"][i]), int(g["size"][i]) // 2
+            if int(g["component_mask"][i]) == 1:
+                y = np.full((s_, 64), 0xAA, np.uint8)
+                rc = product.svt_amd_intra_pu(gpu_ctx, 1, j.ctypes.data, y.ctypes.data, 64, None, None, 0)
+                assert rc == 0 and np.array_equal(y[:, :s_], want[0]) and (y[:, s_:] == 0xAA).all(), (name, i)
+            else:
+                cb, cr = np.full((c_, 32), 0xAA, np.uint8), np.full((c_, 32), 0xAA, np.uint8)
+                rc = product.svt_amd_intra_pu(gpu_ctx, 1, j.ctypes.data, None, 0, cb.ctypes.data, cr.ctypes.data, 32)
+                assert rc == 0 and np.array_equal(cb[:, :c_], want[1]) and np.array_equal(cr[:, :c_], want[2]), (name, i)
+                assert (cb[:, c_:] == 0xAA).all()
+    j = job_of(load_intramd_case(MD_CASES[0]), 0)
+    assert product.svt_amd_intra_pu(gpu_ctx, 1, j.ctypes.data, None, 0, None, None, 0) != 0
+    assert product.svt_amd_intra_pu(gpu_ctx, 1, j.ctypes.data, None, 0, j.ctypes.data, None, 32) != 0
+
+
 def random_jobs(rng, n, bps):
     maxv = 255 if bps == 1 else 1023
     jobs = np.zeros(n, JOB)
