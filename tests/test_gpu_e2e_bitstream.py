@@ -130,7 +130,7 @@ INTRA_CASES = [
     ("noise", 320, 256, 4, ["-encMode", "6", "-pred-struct", "0", "-q", "25", "-constrd-intra", "1"]),   # intra CUs among inter ones
     ("motion10", 416, 240, 2, ["-encMode", "7", "-intra-period", "0", "-bit-depth", "10"]),
     # encMode 1: chroma in the mode decision's full loop (IntraPredictionCl asked for the chroma pair as well), 2 x 2 tiles
-    ("noise", 320, 256, 3, ["-encMode", "1", "-pred-struct", "0", "-q", "28", "-tile_row_cnt", "2", "-tile_col_cnt", "2"]),
+    ("noise", 640, 384, 2, ["-encMode", "1", "-pred-struct", "0", "-q", "28", "-tile_row_cnt", "2", "-tile_col_cnt", "2"]),
 ]
 
 
