@@ -762,6 +762,12 @@ typedef struct SvtAmdInterPuJob {
 SVT_AMD_API int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs,
                                        const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint8_t *d_pred_y,
                                        uint32_t strideY, uint8_t *d_pred_cb, uint8_t *d_pred_cr, uint32_t strideC);
+/* The 16-bit twin: replaces EncodePassInterPrediction16bit (Codec/EbInterPrediction.c:928-1110) with UniPredInterpolation16bit /
+ * BiPredInterpolation16bit (Codec/EbMcp.c:249, :804); reference and destination planes hold 16-bit samples (10-bit content,
+ * EbReferenceObject_t.referencePicture16bit), strides and offsets in samples. */
+SVT_AMD_API int svt_amd_inter_pu_batch16bit(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs,
+                                            const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint16_t *d_pred_y,
+                                            uint32_t strideY, uint16_t *d_pred_cb, uint16_t *d_pred_cr, uint32_t strideC);
 
 /* ------------------------------------------------------------------------- */
 /* Encode-pass intra prediction of a prediction unit from its neighbours      */

@@ -214,6 +214,8 @@ void svt_oracle_BiPredClipping(int bps, uint32_t w, uint32_t h, const int16_t *l
 /* encode-pass inter prediction of one prediction unit, 8-bit 4:2:0 (composite of the two above) */
 void svt_oracle_inter_pu(const SvtAmdInterPuJob *job, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint8_t *pred_y,
                          uint32_t strideY, uint8_t *pred_cb, uint8_t *pred_cr, uint32_t strideC);
+void svt_oracle_inter_pu16bit(const SvtAmdInterPuJob *J, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint16_t *pred_y,
+                              uint32_t strideY, uint16_t *pred_cb, uint16_t *pred_cr, uint32_t strideC);
 
 /* ---- ComputeDecimatedZzSad (svt_oracle_zz.c); cur/prev point at sample (0,0) of the two source pictures ---- */
 void svt_oracle_zz_sad_picture(const uint8_t *cur, const uint8_t *prev, uint32_t stride, uint32_t width, uint32_t height,

@@ -83,15 +83,15 @@ void svt_oracle_BiPredClipping(int bps, uint32_t w, uint32_t h, const int16_t *l
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Encode-pass inter prediction of one prediction unit (8-bit 4:2:0): EncodePassInterPrediction
+ * Encode-pass inter prediction of one prediction unit (4:2:0): EncodePassInterPrediction
  * (Codec/EbInterPrediction.c:761-926) -> EncodeUniPredInterpolation / EncodeBiPredInterpolation (Codec/EbMcp.c:175-250,
  * :562-760) composed from the leaf restatements above.  ref planes: pointers to the START of the padded buffers.
  * Pinned by tests/test_oracle_inter_golden.py on records of real calls.
  * ------------------------------------------------------------------------------------------------------------------ */
 static int clamp_i(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
 
-void svt_oracle_inter_pu(const SvtAmdInterPuJob *J, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint8_t *pred_y,
-                         uint32_t strideY, uint8_t *pred_cb, uint8_t *pred_cr, uint32_t strideC)
+static void inter_pu(int bps, const SvtAmdInterPuJob *J, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, void *pred_y,
+                     uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC)
 {
     const SvtAmdRefPicture *refs[2] = {ref0, ref1};
     const int bi = J->pred_dir == 2;
@@ -107,16 +107,31 @@ void svt_oracle_inter_pu(const SvtAmdInterPuJob *J, const SvtAmdRefPicture *ref0
             const int sh = p ? 1 : 0, w = J->pu_w >> sh, h = J->pu_h >> sh;
             const uint32_t stride = p ? R->strideC : R->strideY;
             const int ix = p ? px >> 3 : px >> 2, iy = p ? py >> 3 : py >> 2, fx = p ? px & 7 : px & 3, fy = p ? py & 7 : py & 3;
-            const uint8_t *src = (const uint8_t *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr) + (size_t)iy * stride + ix;
-            uint8_t *dst = p == 0 ? pred_y : p == 1 ? pred_cb : pred_cr;
+            const uint8_t *src = (const uint8_t *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr) + ((size_t)iy * stride + ix) * bps;
+            void *dst = p == 0 ? pred_y : p == 1 ? pred_cb : pred_cr;
             if (bi)
-                svt_oracle_mcp(1, p != 0, 1, (uint32_t)fx, (uint32_t)fy, src, stride, raw[l][p], 0, (uint32_t)w, (uint32_t)h);
+                svt_oracle_mcp(bps, p != 0, 1, (uint32_t)fx, (uint32_t)fy, src, stride, raw[l][p], 0, (uint32_t)w, (uint32_t)h);
             else
-                svt_oracle_mcp(1, p != 0, 0, (uint32_t)fx, (uint32_t)fy, src, stride, dst, p ? strideC : strideY, (uint32_t)w, (uint32_t)h);
+                svt_oracle_mcp(bps, p != 0, 0, (uint32_t)fx, (uint32_t)fy, src, stride, dst, p ? strideC : strideY, (uint32_t)w, (uint32_t)h);
         }
     }
     if (bi)
-        for (int p = 0; p < 3; p++) /* Offset5 / ChromaOffset5 (Codec/EbDefinitions.h:1022-1030) */
-            svt_oracle_BiPredClipping(1, (uint32_t)(J->pu_w >> (p ? 1 : 0)), (uint32_t)(J->pu_h >> (p ? 1 : 0)), raw[0][p], raw[1][p],
+        for (int p = 0; p < 3; p++) /* Offset5 / ChromaOffset5 (Codec/EbDefinitions.h:1022-1030); the 16-bit clip has its own constant */
+            svt_oracle_BiPredClipping(bps, (uint32_t)(J->pu_w >> (p ? 1 : 0)), (uint32_t)(J->pu_h >> (p ? 1 : 0)), raw[0][p], raw[1][p],
                                       p == 0 ? pred_y : p == 1 ? pred_cb : pred_cr, p ? strideC : strideY, p ? 64 : 16448);
+}
+
+void svt_oracle_inter_pu(const SvtAmdInterPuJob *J, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint8_t *pred_y,
+                         uint32_t strideY, uint8_t *pred_cb, uint8_t *pred_cr, uint32_t strideC)
+{
+    inter_pu(1, J, ref0, ref1, pred_y, strideY, pred_cb, pred_cr, strideC);
+}
+
+/* EncodePassInterPrediction16bit (Codec/EbInterPrediction.c:928-1110) -> UniPredInterpolation16bit / BiPredInterpolation16bit
+ * (Codec/EbMcp.c:249, :804): the same positions and split on 16-bit sample planes.  Pinned by tests/test_oracle_inter_golden.py
+ * on records of real calls of 10-bit encodes. */
+void svt_oracle_inter_pu16bit(const SvtAmdInterPuJob *J, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint16_t *pred_y,
+                              uint32_t strideY, uint16_t *pred_cb, uint16_t *pred_cr, uint32_t strideC)
+{
+    inter_pu(2, J, ref0, ref1, pred_y, strideY, pred_cb, pred_cr, strideC);
 }

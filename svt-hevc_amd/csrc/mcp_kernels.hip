@@ -346,9 +346,9 @@ extern "C" void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight,
 
 static inline int clampi(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
 
-extern "C" int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
-                                      const SvtAmdRefPicture *ref1, uint8_t *d_pred_y, uint32_t strideY, uint8_t *d_pred_cb,
-                                      uint8_t *d_pred_cr, uint32_t strideC)
+template <typename T>
+static int inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
+                          const SvtAmdRefPicture *ref1, T *d_pred_y, uint32_t strideY, T *d_pred_cb, T *d_pred_cr, uint32_t strideC)
 {
     if (!ctx || !jobs || !njobs || !d_pred_y || !d_pred_cb || !d_pred_cr || (!ref0 && !ref1))
         return SVT_AMD_ERR_BAD_PARAM;
@@ -424,13 +424,13 @@ extern "C" int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob
     for (int p = 0; p < 3; p++)
         if (!bi[p].empty())
             HIP_TRY(hipMemcpyAsync(d_slab + off_bi[p], bi[p].data(), bi[p].size() * sizeof(BiBlock), hipMemcpyHostToDevice, ctx->stream));
-    uint8_t *dst[3] = {d_pred_y, d_pred_cb, d_pred_cr};
+    T *dst[3] = {d_pred_y, d_pred_cb, d_pred_cr};
     for (int l = 0; l < 2; l++)
         for (int p = 0; p < 3; p++) {
             const SvtAmdRefPicture *R = refs[l];
             if (!R)
                 continue;
-            const uint8_t *plane = (const uint8_t *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr);
+            const T *plane = (const T *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr);
             const int rs = (int)(p ? R->strideC : R->strideY), ds = (int)(p ? strideC : strideY);
             auto max_dim = [](const std::vector<McpBlock> &v) {
                 uint32_t m = 0;
@@ -439,18 +439,32 @@ extern "C" int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob
                 return m;
             };
             if (!uni[l][p].empty())
-                launch_mcp<uint8_t>(ctx->stream, (uint32_t)uni[l][p].size(), max_dim(uni[l][p]), plane, rs, (void *)dst[p], ds,
+                launch_mcp<T>(ctx->stream, (uint32_t)uni[l][p].size(), max_dim(uni[l][p]), plane, rs, (void *)dst[p], ds,
                                     (const McpBlock *)(d_slab + off_uni[l][p]), p != 0, 0);
             if (!raw[l][p].empty())
-                launch_mcp<uint8_t>(ctx->stream, (uint32_t)raw[l][p].size(), max_dim(raw[l][p]), plane, rs, (void *)(d_slab + off_int[l][p]), 0,
+                launch_mcp<T>(ctx->stream, (uint32_t)raw[l][p].size(), max_dim(raw[l][p]), plane, rs, (void *)(d_slab + off_int[l][p]), 0,
                                     (const McpBlock *)(d_slab + off_raw[l][p]), p != 0, 1);
         }
     for (int p = 0; p < 3; p++)
         if (!bi[p].empty()) /* Offset5 / ChromaOffset5 (Codec/EbDefinitions.h:1022-1030) */
-            hipLaunchKernelGGL(k_bipred_clip<uint8_t>, dim3((unsigned)bi[p].size()), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_bipred_clip<T>, dim3((unsigned)bi[p].size()), dim3(256), 0, ctx->stream,
                                (const int16_t *)(d_slab + off_int[0][p]), (const int16_t *)(d_slab + off_int[1][p]), dst[p],
                                (int)(p ? strideC : strideY), (const BiBlock *)(d_slab + off_bi[p]), p ? 64 : 16448);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the host vectors back the asynchronous uploads */
     return SVT_AMD_OK;
+}
+extern "C" int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
+                                      const SvtAmdRefPicture *ref1, uint8_t *d_pred_y, uint32_t strideY, uint8_t *d_pred_cb,
+                                      uint8_t *d_pred_cr, uint32_t strideC)
+{
+    return inter_pu_batch<uint8_t>(ctx, jobs, njobs, ref0, ref1, d_pred_y, strideY, d_pred_cb, d_pred_cr, strideC);
+}
+/* EncodePassInterPrediction16bit (Codec/EbInterPrediction.c:928-1110) with UniPredInterpolation16bit / BiPredInterpolation16bit
+ * (Codec/EbMcp.c:249, :804): the same driver on 16-bit sample planes (10-bit content) */
+extern "C" int svt_amd_inter_pu_batch16bit(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
+                                           const SvtAmdRefPicture *ref1, uint16_t *d_pred_y, uint32_t strideY, uint16_t *d_pred_cb,
+                                           uint16_t *d_pred_cr, uint32_t strideC)
+{
+    return inter_pu_batch<uint16_t>(ctx, jobs, njobs, ref0, ref1, d_pred_y, strideY, d_pred_cb, d_pred_cr, strideC);
 }

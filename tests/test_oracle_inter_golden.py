@@ -12,6 +12,7 @@ import pytest
 import svtlib as S
 
 CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(S.GOLDEN_DIR, "inter_*.npz")))
+CASES16 = sorted(os.path.basename(p)[8:-4] for p in glob.glob(os.path.join(S.GOLDEN_DIR, "inter16_*.npz")))  # 10-bit encodes
 
 JOB = np.dtype([("mv", "<i2", (2, 2)), ("pu_x", "<u2"), ("pu_y", "<u2"), ("pu_w", "u1"), ("pu_h", "u1"), ("pred_dir", "u1"), ("pad", "u1"),
                 ("dst_off_y", "<i4"), ("dst_off_c", "<i4")])
@@ -22,8 +23,8 @@ class RefPicture(C.Structure):
                 ("originX", C.c_uint32), ("originY", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
-def load_inter_case(name):
-    g = dict(np.load(os.path.join(S.GOLDEN_DIR, "inter_%s.npz" % name)))
+def load_inter_case(name, hbd=False):
+    g = dict(np.load(os.path.join(S.GOLDEN_DIR, ("inter16_%s.npz" if hbd else "inter_%s.npz") % name)))
     n = g["pu_w"].astype(np.int64) * g["pu_h"].astype(np.int64)
     g["off_y"] = np.concatenate([[0], np.cumsum(n)])
     g["off_c"] = np.concatenate([[0], np.cumsum(n // 4)])
@@ -57,14 +58,16 @@ def test_struct_sizes():
 
 
 def test_have_cases():
-    assert len(CASES) >= 4
+    assert len(CASES) >= 4 and len(CASES16) == 2
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_inter_pu_oracle_matches_reference(oracle, name):
-    g = load_inter_case(name)
-    oracle.svt_oracle_inter_pu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
-    oracle.svt_oracle_inter_pu.restype = None
+@pytest.mark.parametrize("name,hbd", [(n, False) for n in CASES] + [(n, True) for n in CASES16])
+def test_inter_pu_oracle_matches_reference(oracle, name, hbd):
+    g = load_inter_case(name, hbd)
+    fn = oracle.svt_oracle_inter_pu16bit if hbd else oracle.svt_oracle_inter_pu
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    fn.restype = None
+    assert g["pred_y"].dtype == (np.uint16 if hbd else np.uint8) and (not hbd or int(g["pred_y"].max()) > 255)
     planes = {int(p): [np.ascontiguousarray(g["pic%d_%s" % (p, c)]) for c in ("y", "cb", "cr")] for p in g["pic_ids"]}
     refs = {p: ref_struct(g, p, [a.ctypes.data for a in planes[p]]) for p in planes}
     seen = set()
@@ -73,10 +76,10 @@ def test_inter_pu_oracle_matches_reference(oracle, name):
         got = [np.zeros_like(w) for w in want]
         j = job_of(g, i)
         r0, r1 = (refs.get(int(v)) for v in g["ref_id"][i])
-        oracle.svt_oracle_inter_pu(j.ctypes.data, C.addressof(r0) if r0 else None, C.addressof(r1) if r1 else None, got[0].ctypes.data,
-                                   got[0].shape[1], got[1].ctypes.data, got[2].ctypes.data, got[1].shape[1])
+        fn(j.ctypes.data, C.addressof(r0) if r0 else None, C.addressof(r1) if r1 else None, got[0].ctypes.data,
+           got[0].shape[1], got[1].ctypes.data, got[2].ctypes.data, got[1].shape[1])
         for p in range(3):
             assert np.array_equal(got[p], want[p]), (name, i, p, g["mv"][i].tolist(), int(g["pred_dir"][i]),
                                                      np.argwhere(got[p] != want[p])[:4].tolist())
         seen.add((int(g["pred_dir"][i]), int(g["mv"][i][0][0]) & 3, int(g["mv"][i][0][1]) & 3))
-    assert len(seen) >= 3
+    assert len(seen) >= (2 if hbd else 3)
