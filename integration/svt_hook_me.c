@@ -694,7 +694,9 @@ static unsigned long g_inter_gpu, g_inter_uploads;
 static int g_inter_state;
 
 /* must hold g_lock */
-static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p, uint64_t poc)
+static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps);
+static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p, uint64_t poc) { return resident_reference_bps(p, poc, 1); }
+static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps)
 {
     struct RefSlot *victim = &g_refs[0];
     for (int i = 0; i < REF_CACHE; i++) {
@@ -706,7 +708,7 @@ static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p
             victim = &g_refs[i];
     }
     const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
-    const size_t need[3] = {(size_t)rowsY * p->strideY, (size_t)rowsC * p->strideCb, (size_t)rowsC * p->strideCr};
+    const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
     const uint8_t *src[3] = {p->bufferY, p->bufferCb, p->bufferCr};
     for (int k = 0; k < 3; k++) {
         if (victim->bytes[k] < need[k]) {
@@ -772,6 +774,64 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
     for (uint32_t y = 0; y < (uint32_t)(puHeight >> 1); y++) {
         memcpy(predictionPtr->bufferCb + oc + y * predictionPtr->strideCb, hcb + y * (puWidth >> 1), puWidth >> 1);
         memcpy(predictionPtr->bufferCr + oc + y * predictionPtr->strideCr, hcr + y * (puWidth >> 1), puWidth >> 1);
+    }
+    return EB_ErrorNone;
+}
+
+/* The 16-bit twin (10-bit encodes): EncodePassInterPrediction16bit (EbInterPrediction.c:928) reads referencePicture16bit and
+ * writes 16-bit samples; same switch, same cache (keyed by buffer address), svt_amd_inter_pu_batch16bit. */
+EB_ERRORTYPE __real_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
+                                                   PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
+                                                   MotionCompensationPredictionContext_t *mcpContext);
+static void *g_inter16_scratch[3];
+static unsigned long g_inter16_gpu;
+
+EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
+                                                   PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
+                                                   MotionCompensationPredictionContext_t *mcpContext)
+{
+    if (g_inter_state == 0)
+        g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
+    if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
+        puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr)
+        return __real_EncodePassInterPrediction16bit(mvUnit, puOriginX, puOriginY, puWidth, puHeight, pcs, predictionPtr, mcpContext);
+    SvtAmdInterPuJob job;
+    memset(&job, 0, sizeof(job));
+    job.pu_x = puOriginX, job.pu_y = puOriginY, job.pu_w = puWidth, job.pu_h = puHeight, job.pred_dir = mvUnit->predDirection;
+    pthread_mutex_lock(&g_lock);
+    const SvtAmdRefPicture *refs[2] = {NULL, NULL};
+    SvtAmdRefPicture copy[2];
+    for (int l = 0; l < 2; l++) {
+        job.mv[l][0] = mvUnit->mv[l].x, job.mv[l][1] = mvUnit->mv[l].y;
+        if (mvUnit->predDirection == l || mvUnit->predDirection == BI_PRED) {
+            const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
+            copy[l] = *resident_reference_bps(ro->referencePicture16bit, ro->refPOC, 2);
+            refs[l] = &copy[l];
+        }
+    }
+    if (!g_inter16_scratch[0])
+        for (int k = 0; k < 3; k++)
+            if (svt_amd_device_alloc(g_ctx, k ? 2048 : 8192, &g_inter16_scratch[k]))
+                die("svt_amd_device_alloc");
+    if (svt_amd_inter_pu_batch16bit(g_ctx, &job, 1, refs[0], refs[1], (uint16_t *)g_inter16_scratch[0], puWidth,
+                                    (uint16_t *)g_inter16_scratch[1], (uint16_t *)g_inter16_scratch[2], puWidth >> 1))
+        die("svt_amd_inter_pu_batch16bit");
+    uint16_t hy[4096], hcb[1024], hcr[1024];
+    if (svt_amd_device_download(g_ctx, hy, g_inter16_scratch[0], (size_t)puWidth * puHeight * 2) ||
+        svt_amd_device_download(g_ctx, hcb, g_inter16_scratch[1], (size_t)puWidth * puHeight / 2) ||
+        svt_amd_device_download(g_ctx, hcr, g_inter16_scratch[2], (size_t)puWidth * puHeight / 2))
+        die("svt_amd_device_download");
+    if (g_inter16_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction16bit) on the GPU\n");
+    pthread_mutex_unlock(&g_lock);
+    const uint32_t oy = (predictionPtr->originY + puOriginY) * predictionPtr->strideY + predictionPtr->originX + puOriginX;
+    const uint32_t oc = (((predictionPtr->originY + puOriginY) * predictionPtr->strideCb) >> 1) + ((predictionPtr->originX + puOriginX) >> 1);
+    uint16_t *py = (uint16_t *)predictionPtr->bufferY, *pcb = (uint16_t *)predictionPtr->bufferCb, *pcr = (uint16_t *)predictionPtr->bufferCr;
+    for (uint32_t y = 0; y < puHeight; y++)
+        memcpy(py + oy + y * predictionPtr->strideY, hy + y * puWidth, 2 * (size_t)puWidth);
+    for (uint32_t y = 0; y < (uint32_t)(puHeight >> 1); y++) {
+        memcpy(pcb + oc + y * predictionPtr->strideCb, hcb + y * (puWidth >> 1), puWidth);
+        memcpy(pcr + oc + y * predictionPtr->strideCr, hcr + y * (puWidth >> 1), puWidth);
     }
     return EB_ErrorNone;
 }

@@ -160,6 +160,7 @@ def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind,
 INTER_CASES = [
     ("motion", 416, 240, 5, ["-encMode", "9", "-pred-struct", "0"]),
     ("motion", 320, 192, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2"]),   # bi-prediction, two lists
+    ("motion10", 320, 192, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-bit-depth", "10"]),  # 16-bit driver
 ]
 
 
@@ -169,15 +170,21 @@ def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind,
     inter prediction of every candidate (Inter2Nx2NPuPredictionHevc) answered by svt_amd_inter_pu_batch from reference
     pictures resident on the device (SVT_HOOK_INTER=1)."""
     yuv = str(tmp_path / "clip.yuv")
-    S.write_clip(yuv, kind, w, h, n, 7)
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
     os.environ["SVT_HOOK_INTER"] = "1"
     try:
         hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
     finally:
         del os.environ["SVT_HOOK_INTER"]
-    assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU" in log, log[-1000:]
-    assert "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU" in log, log[-1000:]
+    if kind.endswith("10"):     # the mode decision of a 10-bit encode stays on the host
+        assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction16bit) on the GPU" in log, log[-1000:]
+    else:
+        assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU" in log, log[-1000:]
+        assert "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
@@ -235,7 +242,7 @@ def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n,
                 "transform-unit reconstruction", "encode-pass intra prediction", "encode-pass inter prediction",
                 "encode-pass quantiser", "SAO statistics + decision"):
         if kind.endswith("10") and "inter prediction" in msg:
-            continue    # the 16-bit inter driver stays on the host
+            msg = "encode-pass inter prediction (EncodePassInterPrediction16bit)"
         assert msg in log, (msg, log[-1500:])
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
