@@ -706,7 +706,9 @@ typedef struct SvtAmdFullLoopIn {
     uint32_t size;              /* CU size 8 / 16 / 32 / 64                                              */
     uint32_t qp;
     uint32_t slice_type;        /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR (selects the quantiser dead zone)    */
-    uint32_t pf_mode;           /* contextPtr->pfMdMode: 0 off, 1 N2, 2 N4                               */
+    uint16_t pf_mode;           /* contextPtr->pfMdMode: 0 off, 1 N2, 2 N4                               */
+    uint16_t pm_core;           /* contextPtr->rdoqPmCoreMethod: 0 EB_NO_RDOQ, 2 EB_PMCORE (encMode 1..4: every 4x4 block
+                                 * of levels re-decided among 100 / 70 / 50 % scalings, EbTransforms.c:2807-2950)      */
     uint32_t cand_type;         /* INTER_MODE 1 / INTRA_MODE 2                                           */
     uint32_t intra_luma_mode;
     uint32_t full_lambda;       /* contextPtr->fullLambda                                                */
@@ -729,6 +731,13 @@ SVT_AMD_API int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCab
                                              const SvtAmdFullLoopIn *d_in, const int16_t *d_residual,
                                              int16_t *d_quant, int16_t *d_recon, SvtAmdFullLoopOut *d_out,
                                              uint32_t ncand);
+/* Same arguments; serves the candidates whose pm_core is EB_PMCORE (2) and leaves the others alone, as the call above leaves
+ * those alone: ProductUnifiedQuantizeInvQuantizeMd -> DecoupledQuantizeInvQuantizeLoops (Codec/EbFullLoop.c:121-148,
+ * EbTransforms.c:2605-2973) - a picture-level switch of encMode 1..4 (EbEncDecProcess.c:2201). */
+SVT_AMD_API int svt_amd_full_loop_luma_pmcore_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost,
+                                                    const SvtAmdFullLoopIn *d_in, const int16_t *d_residual,
+                                                    int16_t *d_quant, int16_t *d_recon, SvtAmdFullLoopOut *d_out,
+                                                    uint32_t ncand);
 /* Per-call form on HOST pointers (row pitch `pitch` samples, e.g. the reference's 64-sample LCU buffers); writes back
  * only the (T >> pf) area of every transform unit, like the reference.  Blocking; used by the ProductFullLoop binding. */
 SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,

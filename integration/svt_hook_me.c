@@ -286,8 +286,8 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
 {
     if (g_fl_state == 0)
         g_fl_state = getenv("SVT_HOOK_FULLLOOP") ? 1 : -1;
-    if (g_fl_state < 0 || !g_ctx || contextPtr->rdoqPmCoreMethod || contextPtr->spatialSseFullLoop ||
-        contextPtr->coeffCabacUpdate || contextPtr->pfMdMode > 1) {
+    if (g_fl_state < 0 || !g_ctx || (contextPtr->rdoqPmCoreMethod && contextPtr->rdoqPmCoreMethod != EB_PMCORE) ||
+        contextPtr->spatialSseFullLoop || contextPtr->coeffCabacUpdate || contextPtr->pfMdMode > 1) {
         if (g_fl_state > 0) {
             pthread_mutex_lock(&g_lock);
             g_fl_cpu++;
@@ -304,6 +304,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     SvtAmdFullLoopOut out;
     memset(&in, 0, sizeof(in));
     in.size = size, in.qp = qp, in.slice_type = pcs->sliceType, in.pf_mode = contextPtr->pfMdMode;
+    in.pm_core = (uint16_t)contextPtr->rdoqPmCoreMethod;
     in.cand_type = c->type, in.intra_luma_mode = c->intraLumaMode, in.full_lambda = contextPtr->fullLambda;
     in.cbf_bits[0] = c->mdRateEstimationPtr->lumaCbfBits[0], in.cbf_bits[1] = c->mdRateEstimationPtr->lumaCbfBits[1];
     in.cbf_bits[2] = c->mdRateEstimationPtr->lumaCbfBits[5], in.cbf_bits[3] = c->mdRateEstimationPtr->lumaCbfBits[6];
@@ -361,7 +362,8 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
     if (g_fl_state == 0)
         g_fl_state = getenv("SVT_HOOK_FULLLOOP") ? 1 : -1;
     t_chroma_for = NULL;
-    if (g_fl_state < 0 || !g_ctx || contextPtr->rdoqPmCoreMethod || contextPtr->spatialSseFullLoop ||
+    /* PM-core leaves chroma alone (EbTransforms.c:2808): its Decoupled... call is the plain quantiser there */
+    if (g_fl_state < 0 || !g_ctx || (contextPtr->rdoqPmCoreMethod && contextPtr->rdoqPmCoreMethod != EB_PMCORE) || contextPtr->spatialSseFullLoop ||
         contextPtr->coeffCabacUpdate || componentMask != PICTURE_BUFFER_DESC_CHROMA_MASK ||
         candidateBuffer->residualQuantCoeffPtr->strideCb != 32 || candidateBuffer->reconCoeffPtr->strideCb != 32) {
         if (g_fl_state > 0) {

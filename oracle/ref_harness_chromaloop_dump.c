@@ -8,7 +8,7 @@
  * one binary record each: the Cb / Cr residuals of the candidate CU as FullLoop_R found them, the scalars the pair read
  * (chroma qps, slice type, partial-frequency mode, candidate type / intra mode, the CabacCost_t tables) and everything
  * the pair produced (quantised and reconstructed coefficients, non-zero counts, coefficient bits, distortions, cbfs).
- * Only the configuration the BASELINE presets use is recorded: no RDOQ/PM-core, no spatial-SSE full loop, no
+ * Only the configuration the BASELINE presets use is recorded: no RDOQ (PM-core, which leaves chroma alone, is), no spatial-SSE full loop, no
  * CABAC-context update.  tests/golden/make_chromaloop_golden.py builds the fixtures.
  * No reference source here; reference headers are included only to read its structs.
  */
@@ -82,7 +82,8 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
         pthread_mutex_unlock(&g_lock);
     }
     int take = 0;
-    if (g_state > 0 && !contextPtr->rdoqPmCoreMethod && !contextPtr->spatialSseFullLoop && !contextPtr->coeffCabacUpdate &&
+    if (g_state > 0 && (!contextPtr->rdoqPmCoreMethod || contextPtr->rdoqPmCoreMethod == EB_PMCORE) && !contextPtr->spatialSseFullLoop &&
+        !contextPtr->coeffCabacUpdate &&
         componentMask == PICTURE_BUFFER_DESC_CHROMA_MASK && candidateBuffer->residualQuantCoeffPtr->strideCb == 32) {
         pthread_mutex_lock(&g_lock);
         take = (g_calls++ % (unsigned long)g_stride) == 0;

@@ -74,7 +74,8 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
         pthread_mutex_unlock(&g_lock);
     }
     int take = 0;
-    if (g_state > 0 && !contextPtr->rdoqPmCoreMethod && !contextPtr->spatialSseFullLoop && !contextPtr->coeffCabacUpdate) {
+    if (g_state > 0 && (!contextPtr->rdoqPmCoreMethod || contextPtr->rdoqPmCoreMethod == EB_PMCORE) && !contextPtr->spatialSseFullLoop &&
+        !contextPtr->coeffCabacUpdate) {
         pthread_mutex_lock(&g_lock);
         take = (g_calls++ % (unsigned long)g_stride) == 0;
         pthread_mutex_unlock(&g_lock);
@@ -92,7 +93,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     r->picture_number = pcs->pictureNumber;
     r->size = size, r->origin_x = cuStatsPtr->originX, r->origin_y = cuStatsPtr->originY, r->qp = qp;
     r->slice_type = pcs->sliceType, r->temporal_layer = pcs->temporalLayerIndex;
-    r->pf_mode = contextPtr->pfMdMode, r->cand_type = c->type, r->intra_luma_mode = c->intraLumaMode;
+    r->pf_mode = contextPtr->pfMdMode | ((uint32_t)contextPtr->rdoqPmCoreMethod << 16) /* = SvtAmdFullLoopIn.pf_mode + .pm_core */, r->cand_type = c->type, r->intra_luma_mode = c->intraLumaMode;
     r->full_lambda = contextPtr->fullLambda;
     r->cbf_bits[0] = c->mdRateEstimationPtr->lumaCbfBits[0], r->cbf_bits[1] = c->mdRateEstimationPtr->lumaCbfBits[1];
     r->cbf_bits[2] = c->mdRateEstimationPtr->lumaCbfBits[5], r->cbf_bits[3] = c->mdRateEstimationPtr->lumaCbfBits[6];

@@ -2,7 +2,9 @@
  * oracle/svt_oracle_fullloop.c - TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
  * CPU restatement of the luma full loop of one mode-decision candidate:
  *   ProductFullLoop                       Codec/EbFullLoop.c:185-446
- *   ProductUnifiedQuantizeInvQuantizeMd   Codec/EbFullLoop.c:77-180   (no RDOQ / PM-core)
+ *   ProductUnifiedQuantizeInvQuantizeMd   Codec/EbFullLoop.c:77-180   (plain, or PM-core = encMode 1..4; no RDOQ)
+ *   DecoupledQuantizeInvQuantizeLoops     Codec/EbTransforms.c:2605-2973 (its EB_PMCORE branch, :2807-2950) with
+ *                                         MatMultOut (:39-71) and the 4x4 masking matrices (:469-477, :1232-1249)
  *   PictureFullDistortionLuma             Codec/EbPictureOperators.c:397-424 (table EbPictureOperators.h:503-556)
  *   TuEstimateCoeffBitsLuma               Codec/EbEntropyCoding.c:7899-7954  (coeffCabacUpdate == 0)
  *   TuCalcCostLuma                        Codec/EbRateDistortionCost.c:289-367
@@ -13,6 +15,73 @@
 #include "svt_oracle.h"
 
 static uint32_t ilog2u(uint32_t v) { uint32_t n = 0; while (v > 1) v >>= 1, n++; return n; }
+
+/* EB_PMCORE branch of DecoupledQuantizeInvQuantizeLoops for a luma block whose regular quantisation (quant, nz) is done:
+ * every 4x4 block with a non-zero level is re-quantised from its coefficients scaled by 100 % / 70 % / 50 % (the DC of the
+ * first block passes unscaled when its regular level exceeds PM_DC_TRSHLD1), the candidate of the lowest coefficient-domain
+ * SSE + lambda * (4x4 rate estimate) replaces the block; then every level is de-quantised again.  `area` = the block the
+ * caller quantises (already reduced by the partial-frequency mode), which is also what the SSE rounding shift is derived
+ * from (:2895).  coeff / quant / recon share the row pitch. */
+static void pm_core_luma(const SvtAmdCabacCost *cost, const int16_t *coeff, int16_t *quant, int16_t *recon, uint32_t pitch, uint32_t area,
+                         uint32_t candType, uint64_t lambda, uint32_t qf, uint32_t q_offset, int32_t shiftedQBits, int32_t shiftedFFunc,
+                         int32_t iq_offset, int32_t shiftNum, uint32_t *nzInOut)
+{
+    static const uint16_t mask[3] = {100 * 256 / 100, 70 * 256 / 100, 50 * 256 / 100};
+    if (*nzInOut) {
+        uint32_t total = 0;
+        const uint32_t shift = 2 * (7 - ilog2u(area));
+        for (uint32_t by = 0; by < area / 4; by++)
+            for (uint32_t bx = 0; bx < area / 4; bx++) {
+                const uint32_t off = bx * 4 + by * 4 * pitch;
+                int any = 0;
+                for (int k = 0; k < 16; k++)
+                    any |= quant[off + (k >> 2) * pitch + (k & 3)] != 0;
+                if (!any)
+                    continue;
+                uint64_t bestCost = 0xFFFFFFFFFFFFFFull; /* MAX_CU_COST */
+                int16_t bq[16], br[16];
+                uint32_t bnz = 0;
+                int have = 0;
+                for (int c = 0; c < 3; c++) {
+                    int16_t tr[16], qu[16], iq[16];
+                    for (int k = 0; k < 16; k++) {
+                        const int v = coeff[off + (k >> 2) * pitch + (k & 3)];
+                        int t = ((v < 0 ? -v : v) * mask[c] + 128) >> 8;
+                        t = v < 0 ? -t : t;
+                        tr[k] = (int16_t)(t < -32768 ? -32768 : t > 32767 ? 32767 : t);
+                    }
+                    if (bx + by == 0 && (quant[0] < 0 ? -quant[0] : quant[0]) > 10)
+                        tr[0] = coeff[0];
+                    uint32_t nz = 0;
+                    svt_oracle_QuantizeInvQuantize(tr, 4, qu, iq, qf, q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum, 4, &nz);
+                    uint64_t sse[2] = {0, 0};
+                    int16_t cblk[16];
+                    for (int k = 0; k < 16; k++)
+                        cblk[k] = coeff[off + (k >> 2) * pitch + (k & 3)];
+                    svt_oracle_FullDistortionKernel_32bit(cblk, 4, iq, 4, sse, 4, 4, nz == 0 ? 1 : 2);
+                    sse[0] = (sse[0] + ((uint64_t)1 << (shift - 1))) >> shift;
+                    const uint64_t bits = nz ? svt_oracle_coeff_bits_lossy(cost, 4, candType, 0, 0, qu, 4, 0, nz) : 0;
+                    const uint64_t cst = (sse[0] << 8) + ((lambda * bits + (1u << 22)) >> 23);
+                    if (cst < bestCost) {
+                        bestCost = cst, bnz = nz, have = 1;
+                        memcpy(bq, qu, sizeof(bq)), memcpy(br, iq, sizeof(br));
+                    }
+                }
+                if (!have) { /* bestCand stays 0 when nothing beats MAX_CU_COST: cannot happen with these magnitudes */
+                    continue;
+                }
+                for (int k = 0; k < 16; k++)
+                    quant[off + (k >> 2) * pitch + (k & 3)] = bq[k], recon[off + (k >> 2) * pitch + (k & 3)] = br[k];
+                total += bnz;
+            }
+        *nzInOut = total;
+    }
+    for (uint32_t y = 0; y < area; y++)
+        for (uint32_t x = 0; x < area; x++) {
+            const int32_t t = ((quant[y * pitch + x] * shiftedFFunc) + iq_offset) >> shiftNum;
+            recon[y * pitch + x] = (int16_t)(t < -32768 ? -32768 : t > 32767 ? 32767 : t);
+        }
+}
 
 /* one transform unit of size T at `origin` of pitch-`pitch` buffers */
 static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, uint32_t cuSize, uint32_t T, uint32_t tuIndex,
@@ -32,13 +101,18 @@ static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in
     const int32_t shiftNum = qpPer > 8 ? 20 - 14 - (int32_t)tshift - 2 : 20 - 14 - (int32_t)tshift;
     const int32_t iq_offset = 1 << (shiftNum - 1);
     const uint32_t area = T >> in->pf_mode;
+    const uint32_t pm_core = in->pm_core; /* contextPtr->rdoqPmCoreMethod: 0 none, 2 EB_PMCORE */
     uint32_t nz = 0;
     /* quantised / reconstructed coefficients overwrite only the area (the rest keeps the residual / old content) */
     svt_oracle_QuantizeInvQuantize(coeff, T, quant, recon, QF[qpRem], q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum,
                                    area, &nz);
     /* note: quant/recon are addressed with pitch `pitch` by the caller's layout */
     (void)pitch;
-    svt_oracle_UpdateQiQCoef(quant, recon, T, shiftedFFunc, iq_offset, shiftNum, area, &nz, 0, in->slice_type, 0, 0, 0);
+    if (pm_core)
+        pm_core_luma(cost, coeff, quant, recon, T, area, in->cand_type, in->full_lambda, QF[qpRem], q_offset, shiftedQBits, shiftedFFunc,
+                     iq_offset, shiftNum, &nz);
+    else
+        svt_oracle_UpdateQiQCoef(quant, recon, T, shiftedFFunc, iq_offset, shiftNum, area, &nz, 0, in->slice_type, 0, 0, 0);
     *nzOut = nz;
     /* PictureFullDistortionLuma: [nz != 0][intra] */
     uint64_t d[2] = {0, 0};

@@ -2,7 +2,8 @@
  * Luma and chroma full loops of mode-decision candidates, fused (EncDec row "PerformFullLoop, ProductFullLoop ...").
  *
  * Replaces ProductFullLoop (Codec/EbFullLoop.c:185-446) and the pair FullLoop_R + CuFullDistortionFastTuMode_R (:579-1066)
- * for the presets' common configuration (no RDOQ / PM-core, coefficient-domain distortion, no CABAC-context update).
+ * for the presets' common configuration (plain quantiser or, for the luma loop, its PM-core variant of encMode 1..4; no RDOQ;
+ * coefficient-domain distortion, no CABAC-context update).
  * One wave owns 64 / N transform units at a time, each on N lanes of its own: lane r holds row r of the residual through the
  * first transform pass and column r of the coefficient block from the second pass on (txfm_device.h, register-resident
  * transform: the matrix is immediates, LDS only carries the transpose); a 64x64 CU walks its four units one after the
@@ -46,7 +47,7 @@ __device__ __forceinline__ void fl_quant_params(FlUnit &S, uint32_t qp, uint32_t
  * sequence per candidate; CHROMA 1: SvtAmdChromaLoopIn/Out, slab 2048 (Cb then Cr), one unit sequence per (candidate,
  * plane).  One wave per workgroup; the wave's 64 / N unit sequences run side by side, each on its own N lanes; a
  * 64x64 CU's sequence has four units (all others one).  No workgroup barrier anywhere: a unit never leaves its wave. */
-template <int N, bool CHROMA>
+template <int N, bool CHROMA, bool PM>
 __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_all, const int16_t *__restrict__ residual,
                                                   int16_t *__restrict__ quant, int16_t *__restrict__ recon,
                                                   void *__restrict__ out_all, uint32_t ncand, int shift1, int shift2,
@@ -57,11 +58,12 @@ __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_al
     __shared__ int16_t tiles[UPW * TxRegTile<N>::UNIT];
     __shared__ int16_t Fq[UPW][N * N]; /* quantised coefficients of the units in flight, row pitch N */
     __shared__ uint32_t Fbits[UPW];
+    __shared__ int16_t Pq[PM ? 64 : 1][16]; /* PM-core: the 4x4 block of levels a lane is pricing */
     const int t = threadIdx.x, u = t / N, r = t - u * N;
     const uint32_t seq = blockIdx.x * UPW + u;
     const uint32_t cand = CHROMA ? seq >> 1 : seq, plane = CHROMA ? seq & 1 : 0;
 
-    int size = 0, ntu = 0, cand_type = 0, intra_luma_mode = 0;
+    int size = 0, ntu = 0, cand_type = 0, intra_luma_mode = 0, pm_core = 0;
     uint32_t pf = 0, qp = 0, slice = 0;
     if (cand < ncand) {
         if (CHROMA) {
@@ -77,9 +79,9 @@ __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_al
         } else {
             const SvtAmdFullLoopIn *in = (const SvtAmdFullLoopIn *)in_all + cand;
             size = (int)in->size;
-            if ((size == 64 ? 32 : size) == N) {
+            if ((size == 64 ? 32 : size) == N && (in->pm_core != 0) == PM) { /* PM-core candidates have their own launch */
                 ntu = size == 64 ? 4 : 1;
-                pf = in->pf_mode, qp = in->qp, slice = in->slice_type;
+                pf = in->pf_mode, qp = in->qp, slice = in->slice_type, pm_core = in->pm_core;
                 cand_type = (int)in->cand_type, intra_luma_mode = (int)in->intra_luma_mode;
             }
         }
@@ -165,6 +167,120 @@ __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_al
 #pragma unroll
         for (int o = 1; o < N; o <<= 1)
             nz += __shfl_xor(nz, o), res += __shfl_xor(res, o), pred += __shfl_xor(pred, o);
+        if constexpr (PM) {
+            /* DecoupledQuantizeInvQuantizeLoops, EB_PMCORE branch (Codec/EbTransforms.c:2807-2950): every 4x4 block of the area
+             * that holds a level is re-quantised from its coefficients scaled by 100 / 70 / 50 % (MatMultOut :39-71; the DC of
+             * block 0 passes unscaled when its regular level exceeds PM_DC_TRSHLD1) and the cheapest of the three in
+             * coefficient-domain SSE + lambda * (4x4 rate estimate) replaces it.  One lane per 4x4 block. */
+            const bool pmu = pm_core != 0 && S.active && nz != 0;
+            if (__ballot(pmu)) {
+                if (pmu && r < S.area) {
+#pragma unroll
+                    for (int j = 0; j < N; j++)
+                        if (j < S.area)
+                            tile[j * N + r] = (int16_t)x[j];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int nb = S.area >> 2, nblk = pmu ? nb * nb : 0;
+                int nblk_max = nblk;
+                for (int o = 32; o > 0; o >>= 1)
+                    nblk_max = max(nblk_max, __shfl_xor(nblk_max, o));
+                const int sse_shift = 2 * (7 - S.lg);
+#pragma unroll 1
+                for (int b0 = 0; b0 < nblk_max; b0 += N) {
+                    const int b = b0 + r;
+                    const bool liveb = b < nblk;
+                    const int by = liveb ? b / nb : 0, bx = liveb ? b - by * nb : 0;
+                    const int off = by * 4 * N + bx * 4;
+                    int cf[16];
+                    bool any = false;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        cf[k] = liveb ? (int)tile[off + (k >> 2) * N + (k & 3)] : 0;
+                        any = any || (liveb && Fq[u][off + (k >> 2) * N + (k & 3)] != 0);
+                    }
+                    const bool dc_pass = any && b == 0 && abs((int)Fq[u][0]) > 10;
+                    unsigned long long best = 0xFFFFFFFFFFFFFFull; /* MAX_CU_COST */
+                    uint32_t bq[8]; /* the best candidate's 16 levels, packed in pairs */
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        bq[k] = 0;
+#pragma unroll 1
+                    for (int c = 0; c < 3; c++) {
+                        const int m = c == 0 ? 256 : c == 1 ? 179 : 128;
+                        unsigned nzc = 0, sres = 0, spred = 0;
+                        uint32_t pk[8];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const int v = cf[k];
+                            int tr = (abs(v) * m + 128) >> 8;
+                            tr = clip16i(v < 0 ? -tr : tr);
+                            if (k == 0 && dc_pass)
+                                tr = v;
+                            int tq = (int)((uint32_t)abs(tr) * S.QF);
+                            tq = (int)((uint32_t)tq + S.q_offset);
+                            tq >>= S.shiftedQBits;
+                            const int qv = clip16i(tr < 0 ? -tq : tq);
+                            const int rv = clip16i(((qv * S.shiftedFFunc) + S.iq_offset) >> S.shiftNum);
+                            const int16_t d = (int16_t)(v - rv);
+                            nzc += qv != 0, sres += (unsigned)(d * d), spred += (unsigned)(v * v);
+                            Pq[t][k] = (int16_t)qv;
+                            if (k & 1)
+                                pk[k >> 1] |= (uint32_t)(uint16_t)qv << 16;
+                            else
+                                pk[k >> 1] = (uint32_t)(uint16_t)qv;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const bool price = any && nzc != 0;
+                        SvtAmdTuInfo ti = {price ? nzc : 0u, (uint8_t)cand_type, 0, 0, 0};
+                        const uint32_t b32 = coeff_bits_lanes(&Pq[t][0], 4, 2, ti, price, t, 0);
+                        unsigned long long sse = nzc ? sres : spred;
+                        sse = (sse + (1ull << (sse_shift - 1))) >> sse_shift;
+                        const unsigned long long bits = price ? (unsigned long long)b32 << 10 : 0ull;
+                        const unsigned long long cst = (sse << 8) + (((unsigned long long)full_lambda * bits + (1u << 22)) >> 23);
+                        if (cst < best) {
+                            best = cst;
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                                bq[k] = pk[k];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            Fq[u][off + (k >> 2) * N + (k & 3)] = (int16_t)((k & 1) ? bq[k >> 1] >> 16 : bq[k >> 1] & 0xffffu);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                /* the levels are final now: de-quantise again, rewrite the outputs, recount */
+                unsigned nz2 = 0, res2 = 0, pred2 = 0;
+                if (pmu && r < S.area) {
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        if (j < S.area) {
+                            const int v = x[j], qv = (int)Fq[u][j * N + r];
+                            const int rv = clip16i(((qv * S.shiftedFFunc) + S.iq_offset) >> S.shiftNum);
+                            quant[S.base + j * S.pitch + r] = (int16_t)qv;
+                            recon[S.base + j * S.pitch + r] = (int16_t)rv;
+                            const int16_t d = (int16_t)(v - rv);
+                            nz2 += qv != 0, res2 += (unsigned)(d * d), pred2 += (unsigned)(v * v);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < N; o <<= 1)
+                    nz2 += __shfl_xor(nz2, o), res2 += __shfl_xor(res2, o), pred2 += __shfl_xor(pred2, o);
+                if (pmu)
+                    nz = nz2, res = res2, pred = pred2;
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -250,13 +366,13 @@ __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_al
     }
 }
 
-template <int N, bool CHROMA>
+template <int N, bool CHROMA, bool PM = false>
 static void launch_full_loop(hipStream_t st, const void *d_in, const int16_t *d_res, int16_t *d_q, int16_t *d_r, void *d_out,
                              uint32_t ncand, int s1, int s2, int wrap)
 {
     constexpr int UPW = 64 / N;
     const uint32_t nseq = CHROMA ? 2 * ncand : ncand;
-    hipLaunchKernelGGL((k_full_loop<N, CHROMA>), dim3((nseq + UPW - 1) / UPW), dim3(64), 0, st, d_in, d_res, d_q, d_r, d_out, ncand,
+    hipLaunchKernelGGL((k_full_loop<N, CHROMA, PM>), dim3((nseq + UPW - 1) / UPW), dim3(64), 0, st, d_in, d_res, d_q, d_r, d_out, ncand,
                        s1, s2, wrap);
 }
 
@@ -276,6 +392,26 @@ extern "C" int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCaba
     launch_full_loop<32, false>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2);
     launch_full_loop<16, false>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
     launch_full_loop<8, false>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* The candidates of the batch whose pm_core is set (pictures of encMode 1..4: contextPtr->rdoqPmCoreMethod == EB_PMCORE is a
+ * picture-level switch, EbEncDecProcess.c:2201); the plain entry point above serves the others.  Kept apart because the block
+ * re-decision costs registers the plain path should not pay for. */
+extern "C" int svt_amd_full_loop_luma_pmcore_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *d_in,
+                                                   const int16_t *d_residual, int16_t *d_quant, int16_t *d_recon,
+                                                   SvtAmdFullLoopOut *d_out, uint32_t ncand)
+{
+    if (!ctx || !cost || !d_in || !d_residual || !d_quant || !d_recon || !d_out || !ncand)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rate_upload_tables(cost, ctx->stream);
+    if (rc)
+        return rc;
+    launch_full_loop<32, false, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2);
+    launch_full_loop<16, false, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
+    launch_full_loop<8, false, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -306,7 +442,7 @@ extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost 
                                       SvtAmdFullLoopOut *out)
 {
     if (!ctx || !cost || !in || !residual || !quant || !recon || !out || pitch < in->size ||
-        (in->size != 8 && in->size != 16 && in->size != 32 && in->size != 64) || in->pf_mode > 1)
+        (in->size != 8 && in->size != 16 && in->size != 32 && in->size != 64) || in->pf_mode > 1 || (in->pm_core != 0 && in->pm_core != 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     static uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
@@ -319,9 +455,9 @@ extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost 
         ::memcpy(packed + y * S, residual + (size_t)y * pitch, S * sizeof(int16_t));
     HIP_TRY(hipMemcpyAsync(d_scratch + o_in, in, sizeof(*in), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_scratch + o_res, packed, (size_t)S * S * 2, hipMemcpyHostToDevice, ctx->stream));
-    int rc = svt_amd_full_loop_luma_batch(ctx, cost, (const SvtAmdFullLoopIn *)(d_scratch + o_in), (const int16_t *)(d_scratch + o_res),
-                                          (int16_t *)(d_scratch + o_q), (int16_t *)(d_scratch + o_r),
-                                          (SvtAmdFullLoopOut *)(d_scratch + o_out), 1);
+    int rc = (in->pm_core ? svt_amd_full_loop_luma_pmcore_batch : svt_amd_full_loop_luma_batch)(
+        ctx, cost, (const SvtAmdFullLoopIn *)(d_scratch + o_in), (const int16_t *)(d_scratch + o_res), (int16_t *)(d_scratch + o_q),
+        (int16_t *)(d_scratch + o_r), (SvtAmdFullLoopOut *)(d_scratch + o_out), 1);
     if (rc)
         return rc;
     int16_t hq[64 * 64], hr[64 * 64];

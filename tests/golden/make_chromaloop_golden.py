@@ -32,6 +32,8 @@ CASES = {
     "p_416x240_m9": ("motion", 416, 240, 5, 7, ["-encMode", "9", "-pred-struct", "0"], 5, 240),
     "b_416x240_m7": ("motion", 416, 240, 10, 7, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"], 17, 260),
     "noise_320x256_m6": ("noise", 320, 256, 3, 11, ["-encMode", "6", "-pred-struct", "1", "-q", "22"], 13, 240),
+    # encMode 4 P pictures: rdoqPmCoreMethod == EB_PMCORE, which re-decides luma blocks only - the chroma pair is unchanged
+    "pm_p_416x240_m4": ("motion", 416, 240, 4, 7, ["-encMode", "4", "-pred-struct", "0"], 41, 240),
 }
 
 

@@ -32,6 +32,10 @@ CASES = {
     "i_1920x1080_m10": ("motion", 1920, 1080, 1, 7, ["-encMode", "10", "-intra-period", "0"], 211, 200),
     "b_416x240_m7": ("motion", 416, 240, 6, 7, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"], 23, 260),
     "noise_320x256_m6": ("noise", 320, 256, 3, 11, ["-encMode", "6", "-pred-struct", "1", "-q", "22"], 31, 200),
+    # encMode 1..4: PM-core re-decision of every 4x4 block of levels (contextPtr->rdoqPmCoreMethod == EB_PMCORE).  Only the P / B
+    # pictures of encMode 4 run it without the CABAC-context-updating rate estimator (coeffCabacUpdate, EbEncDecProcess.c:2116)
+    "pm_b_noise_320x256_m4": ("noise", 320, 256, 5, 11, ["-encMode", "4", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "27"], 89, 260),
+    "pm_p_motion_416x240_m4": ("motion", 416, 240, 4, 7, ["-encMode", "4", "-pred-struct", "0", "-q", "30"], 61, 260),
 }
 
 
@@ -40,8 +44,8 @@ def run_case(name):
     with tempfile.TemporaryDirectory() as td:
         yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "fl.dump")
         S.write_clip(yuv, kind, w, h, n, seed)
-        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-q", "32", "-asm", "0",
-               "-b", os.path.join(td, "out.265")] + args
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + \
+            ([] if "-q" in args else ["-q", "32"]) + args
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_FULLLOOP_DUMP=dump, SVT_REF_FULLLOOP_STRIDE=str(stride)),
                        check=True, stdout=subprocess.DEVNULL)
         recs = np.fromfile(dump, dtype=REC)
@@ -51,14 +55,15 @@ def run_case(name):
     sel = order[np.linspace(0, len(order) - 1, min(keep, len(order))).astype(int)]
     recs = recs[np.sort(sel)]
     out = {k: recs[k] for k in REC.names if k not in ("residual", "quant", "recon", "magic", "record_size")}
+    out["pm_core"], out["pf_mode"] = recs["pf_mode"] >> 16, recs["pf_mode"] & 0xffff   # the harness packs both into one word
     for k in ("residual", "quant", "recon"):  # pack: only size*size samples are meaningful
         out[k] = np.concatenate([r[k][: int(r["size"]) ** 2] for r in recs])
     path = os.path.join(S.GOLDEN_DIR, "fullloop_%s.npz" % name)
     np.savez_compressed(path, **out)
     sizes, cnt = np.unique(recs["size"], return_counts=True)
-    print("%-28s %d records (sizes %s) -> %s (%.0f KiB); types %s, pf %s, slices %s" %
+    print("%-28s %d records (sizes %s) -> %s (%.0f KiB); types %s, pf %s, pm-core %s, slices %s" %
           (name, len(recs), dict(zip(sizes.tolist(), cnt.tolist())), os.path.basename(path), os.path.getsize(path) / 1024,
-           np.unique(recs["cand_type"]).tolist(), np.unique(recs["pf_mode"]).tolist(), np.unique(recs["slice_type"]).tolist()))
+           np.unique(recs["cand_type"]).tolist(), np.unique(out["pf_mode"]).tolist(), np.unique(out["pm_core"]).tolist(), np.unique(recs["slice_type"]).tolist()))
 
 
 if __name__ == "__main__":

@@ -28,11 +28,15 @@ def run_batch(product, gpu_ctx, cost, ins, residuals):
     d_res = torch.from_numpy(h_res).cuda()
     d_q, d_r = d_res.clone(), torch.zeros_like(d_res)   # the reference's quant buffer starts as the residual
     d_out = torch.zeros(n * OUT_DT.itemsize, dtype=torch.uint8, device="cuda")
-    product.svt_amd_full_loop_luma_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32]
     torch.cuda.synchronize()
-    rc = product.svt_amd_full_loop_luma_batch(gpu_ctx, cost.ctypes.data, d_in.data_ptr(), d_res.data_ptr(), d_q.data_ptr(),
-                                              d_r.data_ptr(), d_out.data_ptr(), n)
-    assert rc == 0, product.svt_amd_last_error()
+    # the plain entry point serves the candidates without PM-core, the other one those with it: a mixed batch needs both
+    for fn, wanted in ((product.svt_amd_full_loop_luma_batch, any((f.pf_mode >> 16) == 0 for f in ins)),
+                       (product.svt_amd_full_loop_luma_pmcore_batch, any((f.pf_mode >> 16) != 0 for f in ins))):
+        if not wanted:
+            continue
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32]
+        rc = fn(gpu_ctx, cost.ctypes.data, d_in.data_ptr(), d_res.data_ptr(), d_q.data_ptr(), d_r.data_ptr(), d_out.data_ptr(), n)
+        assert rc == 0, product.svt_amd_last_error()
     product.svt_amd_synchronize(gpu_ctx)
     outs = d_out.cpu().numpy().view(OUT_DT)
     return outs, d_q.cpu().numpy(), d_r.cpu().numpy()
@@ -81,6 +85,8 @@ def test_fullloop_matches_oracle_random(product, gpu_ctx, oracle):
         fin = FullLoopIn()
         fin.size, fin.qp, fin.slice_type = size, int(rng.integers(10, 52)), int(rng.integers(0, 3))
         fin.pf_mode = int(rng.integers(0, 2)) if size >= 16 else 0
+        if k % 3 == 0:      # PM-core (encMode 1..4): the upper half of the word is SvtAmdFullLoopIn.pm_core = EB_PMCORE
+            fin.pf_mode |= 2 << 16
         fin.cand_type, fin.intra_luma_mode = int(rng.integers(1, 3)), int(rng.integers(0, 35))
         fin.full_lambda = int(rng.integers(1000, 4000000))
         for j, v in enumerate(rng.integers(1000, 90000, 4)):
@@ -102,7 +108,7 @@ def test_fullloop_matches_oracle_random(product, gpu_ctx, oracle):
                                                  quant.ctypes.data, recon.ctypes.data, C.addressof(want))
         got = as_struct(outs[k])
         T = 32 if size == 64 else size
-        ar = T >> fin.pf_mode
+        ar = T >> (fin.pf_mode & 0xffff)
         gq, gr = qs[k, :size * size].reshape(size, size), rs[k, :size * size].reshape(size, size)
         for ty in range(0, size, T):
             for tx in range(0, size, T):

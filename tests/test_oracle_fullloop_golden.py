@@ -33,7 +33,7 @@ def load_fullloop_case(name):
 
 def record_in(g, i):
     fin = FullLoopIn()
-    fin.size, fin.qp, fin.slice_type, fin.pf_mode = int(g["size"][i]), int(g["qp"][i]), int(g["slice_type"][i]), int(g["pf_mode"][i])
+    fin.size, fin.qp, fin.slice_type, fin.pf_mode = int(g["size"][i]), int(g["qp"][i]), int(g["slice_type"][i]), int(g["pf_mode"][i]) | (int(g["pm_core"][i]) << 16 if "pm_core" in g else 0)
     fin.cand_type, fin.intra_luma_mode, fin.full_lambda = int(g["cand_type"][i]), int(g["intra_luma_mode"][i]), int(g["full_lambda"][i])
     for k in range(4):
         fin.cbf_bits[k] = int(g["cbf_bits"][i][k])
