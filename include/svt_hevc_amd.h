@@ -853,6 +853,24 @@ SVT_AMD_API int svt_amd_unified_quantize_batch(SvtAmdContext *ctx, const SvtAmdQ
 /* Per-call form on HOST pointers (row pitch coeffStride for all three blocks); blocking. */
 SVT_AMD_API int svt_amd_unified_quantize(SvtAmdContext *ctx, const SvtAmdQuantUnit *unit, const int16_t *coeff,
                                          uint32_t coeffStride, int16_t *quant, int16_t *recon, uint32_t *nz);
+/* The same reference function when contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE (encMode 1..4; Codec/EbTransforms.c:
+ * 3009-3052 -> DecoupledQuantizeInvQuantizeLoops :2605-2973): whole unit, no shapes / dead-zone override / clean-ups; luma units
+ * get every 4x4 block of levels re-decided among 100 / 70 / 50 % coefficient scalings by SSE + lambda * rate (rate tables =
+ * the CabacCost_t the call receives, `cost` is a HOST pointer), chroma units the plain quantiser. */
+typedef struct SvtAmdPmQuantUnit {
+    uint8_t  size;              /* 4 / 8 / 16 / 32                                                         */
+    uint8_t  qp, bit_depth;     /* 8 or 10                                                                 */
+    uint8_t  slice_type;        /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR                                        */
+    uint8_t  component;         /* COMPONENT_LUMA 0, chroma otherwise                                      */
+    uint8_t  cand_type;         /* the `type` argument: INTER_MODE 1 / INTRA_MODE 2                        */
+    uint8_t  pad[2];
+    uint32_t lambda;            /* the `lambda` argument (contextPtr->fullLambda)                          */
+} SvtAmdPmQuantUnit;
+SVT_AMD_API int svt_amd_pmcore_quantize_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *d_units,
+                                              const int16_t *d_coeff, int16_t *d_quant, int16_t *d_recon, uint32_t *d_nz,
+                                              uint32_t nunits);
+SVT_AMD_API int svt_amd_pmcore_quantize(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *unit,
+                                        const int16_t *coeff, uint32_t coeffStride, int16_t *quant, int16_t *recon, uint32_t *nz);
 
 /* ------------------------------------------------------------------------- */
 /* Reconstruction of transform units (final encode pass)                      */

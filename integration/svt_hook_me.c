@@ -914,7 +914,7 @@ void __real_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
                                        EB_U8 enableContouringQCUpdateFlag, EB_U32 componentType, EB_U32 temporalLayerIndex,
                                        EB_U32 dZoffset, CabacEncodeContext_t *cabacEncodeCtxPtr, EB_U64 lambda, EB_U32 intraLumaMode,
                                        EB_U32 intraChromaMode, CabacCost_t *CabacCost);
-static unsigned long g_quant_gpu;
+static unsigned long g_quant_gpu, g_quant_pm_gpu;
 static int g_quant_state;
 
 void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureControlSet_t *pcs, EB_S16 *coeff, const EB_U32 coeffStride,
@@ -927,6 +927,23 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
 {
     if (g_quant_state == 0)
         g_quant_state = getenv("SVT_HOOK_QUANT") ? 1 : -1;
+    if (g_quant_state > 0 && g_ctx && contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE && yCountNonZeroCoeffs && areaSize <= 32 &&
+        areaSize >= 4 && qp <= 51 && (bitDepth == 8 || bitDepth == 10) && lambda <= 0xffffffffu) {
+        /* encMode 1..4: the PM-core variant (EbTransforms.c:3009-3052) */
+        SvtAmdPmQuantUnit pu;
+        memset(&pu, 0, sizeof(pu));
+        pu.size = (uint8_t)areaSize, pu.qp = (uint8_t)qp, pu.bit_depth = (uint8_t)bitDepth, pu.slice_type = (uint8_t)sliceType;
+        pu.component = (uint8_t)componentType, pu.cand_type = (uint8_t)type, pu.lambda = (uint32_t)lambda;
+        uint32_t pnz = 0;
+        pthread_mutex_lock(&g_lock);
+        if (svt_amd_pmcore_quantize(g_ctx, (const SvtAmdCabacCost *)CabacCost, &pu, coeff, coeffStride, quantCoeff, reconCoeff, &pnz))
+            die("svt_amd_pmcore_quantize");
+        if (g_quant_pm_gpu++ == 0 && g_verbose)
+            fprintf(stderr, "svt_hook_me: encode-pass PM-core quantiser (UnifiedQuantizeInvQuantize, EB_PMCORE) on the GPU\n");
+        pthread_mutex_unlock(&g_lock);
+        *yCountNonZeroCoeffs = pnz;
+        return;
+    }
     if (g_quant_state < 0 || !g_ctx || contextPtr->mdContext->rdoqPmCoreMethod || pmpMaskingLevelEncDec || !yCountNonZeroCoeffs ||
         areaSize > 32 || areaSize < 4 || qp > 51 || (bitDepth != 8 && bitDepth != 10)) {
         __real_UnifiedQuantizeInvQuantize(contextPtr, pcs, coeff, coeffStride, quantCoeff, reconCoeff, qp, bitDepth, areaSize, sliceType,

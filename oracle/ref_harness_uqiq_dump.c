@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include "../include/svt_hevc_amd.h"
 
 #include "EbDefinitions.h"
 #include "EbPictureControlSet.h"
@@ -34,6 +35,18 @@ typedef struct UqiqRecord {
     uint32_t nz_out;
     int16_t coeff[32 * 32], quant_in[32 * 32], recon_in[32 * 32], quant[32 * 32], recon[32 * 32]; /* size x size, pitch = size */
 } UqiqRecord;
+
+/* calls with rdoqPmCoreMethod == EB_PMCORE (encMode 1..4): SVT_REF_UQIQPM_DUMP=<file>, every SVT_REF_UQIQPM_STRIDE-th (default 23) */
+#define UQIQPM_DUMP_MAGIC 0x4d504955U /* "UIPM" */
+typedef struct UqiqPmRecord {
+    uint32_t magic, record_size;
+    uint32_t size, qp, bit_depth, slice_type, component, cand_type, lambda, nz_out;
+    SvtAmdCabacCost cost;
+    int16_t coeff[32 * 32], quant[32 * 32], recon[32 * 32]; /* size x size, pitch = size */
+} UqiqPmRecord;
+static FILE *g_pm_file;
+static int g_pm_state, g_pm_stride = 23;
+static unsigned long g_pm_calls;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static FILE *g_file;
@@ -71,6 +84,44 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
         take = (g_calls++ % (unsigned long)g_stride) == 0;
         pthread_mutex_unlock(&g_lock);
     }
+    if (g_pm_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_pm_state == 0) {
+            const char *path = getenv("SVT_REF_UQIQPM_DUMP"), *st = getenv("SVT_REF_UQIQPM_STRIDE");
+            g_pm_file = path ? fopen(path, "wb") : NULL;
+            if (st && atoi(st) > 0)
+                g_pm_stride = atoi(st);
+            g_pm_state = g_pm_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (g_pm_state > 0 && contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE && yCountNonZeroCoeffs && areaSize <= 32 && lambda <= 0xffffffffu) {
+        int takePm;
+        pthread_mutex_lock(&g_lock);
+        takePm = (g_pm_calls++ % (unsigned long)g_pm_stride) == 0;
+        pthread_mutex_unlock(&g_lock);
+        if (takePm) {
+            UqiqPmRecord *p = (UqiqPmRecord *)calloc(1, sizeof(*p));
+            p->magic = UQIQPM_DUMP_MAGIC, p->record_size = (uint32_t)sizeof(*p);
+            p->size = areaSize, p->qp = qp, p->bit_depth = bitDepth, p->slice_type = sliceType, p->component = componentType;
+            p->cand_type = type, p->lambda = (uint32_t)lambda;
+            memcpy(&p->cost, CabacCost, sizeof(p->cost));
+            grab(p->coeff, coeff, coeffStride, areaSize);
+            __real_UnifiedQuantizeInvQuantize(contextPtr, pcs, coeff, coeffStride, quantCoeff, reconCoeff, qp, bitDepth, areaSize, sliceType,
+                                              yCountNonZeroCoeffs, transCoeffShape, cleanSparseCeoffPfEncDec, pmpMaskingLevelEncDec, type,
+                                              enableCbflag, enableContouringQCUpdateFlag, componentType, temporalLayerIndex, dZoffset,
+                                              cabacEncodeCtxPtr, lambda, intraLumaMode, intraChromaMode, CabacCost);
+            p->nz_out = *yCountNonZeroCoeffs;
+            grab(p->quant, quantCoeff, coeffStride, areaSize);
+            grab(p->recon, reconCoeff, coeffStride, areaSize);
+            pthread_mutex_lock(&g_lock);
+            fwrite(p, sizeof(*p), 1, g_pm_file);
+            fflush(g_pm_file);
+            pthread_mutex_unlock(&g_lock);
+            free(p);
+            return;
+        }
+    }
     UqiqRecord *r = NULL;
     if (take) {
         r = (UqiqRecord *)calloc(1, sizeof(*r));
@@ -102,7 +153,6 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
  * read are meaningful), so tests can pin the optional branches (shapes, dead-zone override, clean-up, contouring, forced
  * cbf) that ordinary encoder runs do not reach.  unit = SvtAmdQuantUnit of include/svt_hevc_amd.h. */
 #include "EbSequenceControlSet.h"
-#include "../include/svt_hevc_amd.h"
 void svt_ref_unified_quantize(const SvtAmdQuantUnit *u, int16_t *coeff, uint32_t stride, int16_t *quant, int16_t *recon, uint32_t *nz)
 {
     static EncDecContext_t *ctx;

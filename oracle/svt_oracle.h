@@ -227,6 +227,8 @@ uint64_t svt_oracle_coeff_bits_lossy(const SvtAmdCabacCost *C, uint32_t size, ui
                                      uint32_t componentType, uint32_t numNonZeroCoeffs);
 
 /* ---- luma full loop of one candidate (svt_oracle_fullloop.c) ---- */
+void svt_oracle_pmcore_quantize(const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *U, const int16_t *coeff, int16_t *quant,
+                                int16_t *recon, uint32_t *nzOut);
 void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
                                        int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out);
 void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],

@@ -83,6 +83,29 @@ static void pm_core_luma(const SvtAmdCabacCost *cost, const int16_t *coeff, int1
         }
 }
 
+/* UnifiedQuantizeInvQuantize of the encode pass with rdoqPmCoreMethod == EB_PMCORE (Codec/EbTransforms.c:3009-3052): the whole
+ * unit through DecoupledQuantizeInvQuantizeLoops.  coeff / quant / recon: size x size, row pitch = size.
+ * Pinned by tests/test_oracle_uqiq_golden.py on records of encMode-4 encodes. */
+void svt_oracle_pmcore_quantize(const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *U, const int16_t *coeff, int16_t *quant,
+                                int16_t *recon, uint32_t *nzOut)
+{
+    static const uint32_t QF[6] = {26214, 23302, 20560, 18396, 16384, 14564}, FF[6] = {40, 45, 51, 57, 64, 72};
+    const uint32_t T = U->size;
+    const int32_t qpRem = (int32_t)(U->qp % 6), qpPer = (int32_t)(U->qp / 6);
+    const int32_t tshift = 15 - (int32_t)U->bit_depth - (int32_t)ilog2u(T);
+    const int32_t shiftedQBits = 14 + qpPer + tshift;
+    const uint32_t q_offset = ((U->slice_type == 2 || U->slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int32_t shiftedFFunc = qpPer > 8 ? (int32_t)FF[qpRem] << (qpPer - 2) : (int32_t)FF[qpRem] << qpPer;
+    const int32_t shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift;
+    const int32_t iq_offset = 1 << (shiftNum - 1);
+    uint32_t nz = 0;
+    svt_oracle_QuantizeInvQuantize(coeff, T, quant, recon, QF[qpRem], q_offset, shiftedQBits, shiftedFFunc, iq_offset, shiftNum, T, &nz);
+    if (U->component == 0)
+        pm_core_luma(cost, coeff, quant, recon, T, T, U->cand_type, U->lambda, QF[qpRem], q_offset, shiftedQBits, shiftedFFunc, iq_offset,
+                     shiftNum, &nz);
+    *nzOut = nz;
+}
+
 /* one transform unit of size T at `origin` of pitch-`pitch` buffers */
 static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, uint32_t cuSize, uint32_t T, uint32_t tuIndex,
                          const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch, uint32_t *nzOut,

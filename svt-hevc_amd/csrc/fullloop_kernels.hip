@@ -43,6 +43,91 @@ __device__ __forceinline__ void fl_quant_params(FlUnit &S, uint32_t qp, uint32_t
     S.iq_offset = 1 << (S.shiftNum - 1);
 }
 
+/* The 4x4-block re-decision of DecoupledQuantizeInvQuantizeLoops' EB_PMCORE branch (Codec/EbTransforms.c:2807-2950) for one
+ * unit whose coefficients (cf_lds) and regular levels (lev_lds) lie in LDS with row pitch `pitch`: lane r of the unit's
+ * STRIDE lanes takes blocks r, r + STRIDE, ...; every block that holds a level is re-quantised from its coefficients scaled by
+ * 100 / 70 / 50 % (MatMultOut :39-71; the DC of block 0 passes unscaled when its regular level exceeds PM_DC_TRSHLD1) and the
+ * cheapest of the three in coefficient-domain SSE + lambda * (4x4 rate estimate) replaces it in lev_lds.  All lanes of the
+ * wave call together (pmu = this lane's unit takes part); Pq = 16 samples of LDS scratch per lane of the wave. */
+template <int STRIDE>
+__device__ __forceinline__ void pm_core_blocks(const int16_t *cf_lds, int16_t *lev_lds, int pitch, int area, int lg_area, int r, bool pmu,
+                                               int t, int cand_type, uint32_t full_lambda, const FlUnit &Q, int16_t (*Pq)[16])
+{
+    const int nb = area >> 2, nblk = pmu ? nb * nb : 0;
+    int nblk_max = nblk;
+    for (int o = 32; o > 0; o >>= 1)
+        nblk_max = max(nblk_max, __shfl_xor(nblk_max, o));
+    const int sse_shift = 2 * (7 - lg_area);
+#pragma unroll 1
+    for (int b0 = 0; b0 < nblk_max; b0 += STRIDE) {
+        const int b = b0 + r;
+        const bool liveb = b < nblk;
+        const int by = liveb ? b / nb : 0, bx = liveb ? b - by * nb : 0;
+        const int off = by * 4 * pitch + bx * 4;
+        int cf[16];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            cf[k] = liveb ? (int)cf_lds[off + (k >> 2) * pitch + (k & 3)] : 0;
+            any = any || (liveb && lev_lds[off + (k >> 2) * pitch + (k & 3)] != 0);
+        }
+        const bool dc_pass = any && b == 0 && abs((int)lev_lds[0]) > 10;
+        unsigned long long best = 0xFFFFFFFFFFFFFFull; /* MAX_CU_COST */
+        uint32_t bq[8]; /* the best candidate's 16 levels, packed in pairs */
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            bq[k] = 0;
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            const int m = c == 0 ? 256 : c == 1 ? 179 : 128;
+            unsigned nzc = 0, sres = 0, spred = 0;
+            uint32_t pk[8];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int v = cf[k];
+                int tr = (abs(v) * m + 128) >> 8;
+                tr = clip16i(v < 0 ? -tr : tr);
+                if (k == 0 && dc_pass)
+                    tr = v;
+                int tq = (int)((uint32_t)abs(tr) * Q.QF);
+                tq = (int)((uint32_t)tq + Q.q_offset);
+                tq >>= Q.shiftedQBits;
+                const int qv = clip16i(tr < 0 ? -tq : tq);
+                const int rv = clip16i(((qv * Q.shiftedFFunc) + Q.iq_offset) >> Q.shiftNum);
+                const int16_t d = (int16_t)(v - rv);
+                nzc += qv != 0, sres += (unsigned)(d * d), spred += (unsigned)(v * v);
+                Pq[t][k] = (int16_t)qv;
+                if (k & 1)
+                    pk[k >> 1] |= (uint32_t)(uint16_t)qv << 16;
+                else
+                    pk[k >> 1] = (uint32_t)(uint16_t)qv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool price = any && nzc != 0;
+            SvtAmdTuInfo ti = {price ? nzc : 0u, (uint8_t)cand_type, 0, 0, 0};
+            const uint32_t b32 = coeff_bits_lanes(&Pq[t][0], 4, 2, ti, price, t, 0);
+            unsigned long long sse = nzc ? sres : spred;
+            sse = (sse + (1ull << (sse_shift - 1))) >> sse_shift;
+            const unsigned long long bits = price ? (unsigned long long)b32 << 10 : 0ull;
+            const unsigned long long cst = (sse << 8) + (((unsigned long long)full_lambda * bits + (1u << 22)) >> 23);
+            if (cst < best) {
+                best = cst;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    bq[k] = pk[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                lev_lds[off + (k >> 2) * pitch + (k & 3)] = (int16_t)((k & 1) ? bq[k >> 1] >> 16 : bq[k >> 1] & 0xffffu);
+        }
+    }
+}
+
 /* N: transform size of this launch.  CHROMA 0: SvtAmdFullLoopIn/Out, residual slab 4096 samples per candidate, one unit
  * sequence per candidate; CHROMA 1: SvtAmdChromaLoopIn/Out, slab 2048 (Cb then Cr), one unit sequence per (candidate,
  * plane).  One wave per workgroup; the wave's 64 / N unit sequences run side by side, each on its own N lanes; a
@@ -183,79 +268,7 @@ __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_al
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int nb = S.area >> 2, nblk = pmu ? nb * nb : 0;
-                int nblk_max = nblk;
-                for (int o = 32; o > 0; o >>= 1)
-                    nblk_max = max(nblk_max, __shfl_xor(nblk_max, o));
-                const int sse_shift = 2 * (7 - S.lg);
-#pragma unroll 1
-                for (int b0 = 0; b0 < nblk_max; b0 += N) {
-                    const int b = b0 + r;
-                    const bool liveb = b < nblk;
-                    const int by = liveb ? b / nb : 0, bx = liveb ? b - by * nb : 0;
-                    const int off = by * 4 * N + bx * 4;
-                    int cf[16];
-                    bool any = false;
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        cf[k] = liveb ? (int)tile[off + (k >> 2) * N + (k & 3)] : 0;
-                        any = any || (liveb && Fq[u][off + (k >> 2) * N + (k & 3)] != 0);
-                    }
-                    const bool dc_pass = any && b == 0 && abs((int)Fq[u][0]) > 10;
-                    unsigned long long best = 0xFFFFFFFFFFFFFFull; /* MAX_CU_COST */
-                    uint32_t bq[8]; /* the best candidate's 16 levels, packed in pairs */
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        bq[k] = 0;
-#pragma unroll 1
-                    for (int c = 0; c < 3; c++) {
-                        const int m = c == 0 ? 256 : c == 1 ? 179 : 128;
-                        unsigned nzc = 0, sres = 0, spred = 0;
-                        uint32_t pk[8];
-#pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const int v = cf[k];
-                            int tr = (abs(v) * m + 128) >> 8;
-                            tr = clip16i(v < 0 ? -tr : tr);
-                            if (k == 0 && dc_pass)
-                                tr = v;
-                            int tq = (int)((uint32_t)abs(tr) * S.QF);
-                            tq = (int)((uint32_t)tq + S.q_offset);
-                            tq >>= S.shiftedQBits;
-                            const int qv = clip16i(tr < 0 ? -tq : tq);
-                            const int rv = clip16i(((qv * S.shiftedFFunc) + S.iq_offset) >> S.shiftNum);
-                            const int16_t d = (int16_t)(v - rv);
-                            nzc += qv != 0, sres += (unsigned)(d * d), spred += (unsigned)(v * v);
-                            Pq[t][k] = (int16_t)qv;
-                            if (k & 1)
-                                pk[k >> 1] |= (uint32_t)(uint16_t)qv << 16;
-                            else
-                                pk[k >> 1] = (uint32_t)(uint16_t)qv;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const bool price = any && nzc != 0;
-                        SvtAmdTuInfo ti = {price ? nzc : 0u, (uint8_t)cand_type, 0, 0, 0};
-                        const uint32_t b32 = coeff_bits_lanes(&Pq[t][0], 4, 2, ti, price, t, 0);
-                        unsigned long long sse = nzc ? sres : spred;
-                        sse = (sse + (1ull << (sse_shift - 1))) >> sse_shift;
-                        const unsigned long long bits = price ? (unsigned long long)b32 << 10 : 0ull;
-                        const unsigned long long cst = (sse << 8) + (((unsigned long long)full_lambda * bits + (1u << 22)) >> 23);
-                        if (cst < best) {
-                            best = cst;
-#pragma unroll
-                            for (int k = 0; k < 8; k++)
-                                bq[k] = pk[k];
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    if (any) {
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            Fq[u][off + (k >> 2) * N + (k & 3)] = (int16_t)((k & 1) ? bq[k >> 1] >> 16 : bq[k >> 1] & 0xffffu);
-                    }
-                }
+                pm_core_blocks<N>(tile, &Fq[u][0], N, S.area, S.lg, r, pmu, t, cand_type, full_lambda, S, Pq);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -514,5 +527,115 @@ extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCos
                     ::memcpy(quant[p] + (size_t)(ty + y) * pitch + tx, hq + p * 1024 + (ty + y) * C + tx, area * sizeof(int16_t));
                     ::memcpy(recon[p] + (size_t)(ty + y) * pitch + tx, hr + p * 1024 + (ty + y) * C + tx, area * sizeof(int16_t));
                 }
+    return SVT_AMD_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * The encode pass's quantiser at encMode 1..4: UnifiedQuantizeInvQuantize with contextPtr->mdContext->rdoqPmCoreMethod ==
+ * EB_PMCORE (Codec/EbTransforms.c:3009-3052) = DecoupledQuantizeInvQuantizeLoops over the whole unit (coefficient shapes,
+ * dead-zone override and the clean-ups of the plain path do not apply): regular quantisation, for luma the 4x4-block
+ * re-decision above, then every level de-quantised again.  One wave per unit; the unit lives in LDS.
+ * ------------------------------------------------------------------------------------------------------------------------ */
+struct PmQuantUnit { uint8_t size, qp, bit_depth, slice_type, component, cand_type, pad[2]; uint32_t lambda; }; /* = SvtAmdPmQuantUnit */
+
+__global__ __launch_bounds__(64) void k_pmcore_quant(const PmQuantUnit *__restrict__ units, const int16_t *__restrict__ coeff,
+                                                     int16_t *__restrict__ quant, int16_t *__restrict__ recon,
+                                                     uint32_t *__restrict__ nzOut)
+{
+    __shared__ int16_t cf[32 * 32], lev[32 * 32];
+    __shared__ int16_t Pq[64][16];
+    const PmQuantUnit U = units[blockIdx.x];
+    const int t = threadIdx.x, N = U.size, lg = 31 - __clz(N);
+    const size_t base = (size_t)blockIdx.x * 1024;
+    FlUnit Q;
+    const int qpRem = U.qp % 6, qpPer = U.qp / 6;
+    Q.QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
+    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    const int tshift = 15 - U.bit_depth - lg;
+    Q.shiftedQBits = 14 + qpPer + tshift;
+    Q.q_offset = ((U.slice_type == 2 || U.slice_type == 3) ? 171u : 85u) << (Q.shiftedQBits - 9);
+    Q.shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
+    Q.shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift;
+    Q.iq_offset = 1 << (Q.shiftNum - 1);
+    unsigned nz = 0;
+    for (int i = t; i < N * N; i += 64) {
+        const int v = coeff[base + i], sign = v < 0 ? -1 : 1;
+        int tq = abs(v);
+        tq = (int)((uint32_t)tq * Q.QF);
+        tq = (int)((uint32_t)tq + Q.q_offset);
+        tq >>= Q.shiftedQBits;
+        const int qv = clip16i(sign * tq);
+        cf[i] = (int16_t)v, lev[i] = (int16_t)qv;
+        nz += qv != 0;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        nz += __shfl_xor(nz, o);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (nz != 0 && U.component == 0) {
+        pm_core_blocks<64>(cf, lev, N, N, lg, t, true, t, (int)U.cand_type, U.lambda, Q, Pq);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    nz = 0;
+    for (int i = t; i < N * N; i += 64) {
+        const int qv = lev[i];
+        quant[base + i] = (int16_t)qv;
+        recon[base + i] = (int16_t)clip16i(((qv * Q.shiftedFFunc) + Q.iq_offset) >> Q.shiftNum);
+        nz += qv != 0;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        nz += __shfl_xor(nz, o);
+    if (t == 0)
+        nzOut[blockIdx.x] = nz;
+}
+
+extern "C" int svt_amd_pmcore_quantize_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *d_units,
+                                             const int16_t *d_coeff, int16_t *d_quant, int16_t *d_recon, uint32_t *d_nz, uint32_t nunits)
+{
+    static_assert(sizeof(PmQuantUnit) == sizeof(SvtAmdPmQuantUnit), "unit layout");
+    if (!ctx || !cost || !d_units || !d_coeff || !d_quant || !d_recon || !d_nz || !nunits)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rate_upload_tables(cost, ctx->stream);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_pmcore_quant, dim3(nunits), dim3(64), 0, ctx->stream, (const PmQuantUnit *)d_units, d_coeff, d_quant, d_recon, d_nz);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_pmcore_quantize(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *unit, const int16_t *coeff,
+                                       uint32_t coeffStride, int16_t *quant, int16_t *recon, uint32_t *nz)
+{
+    if (!ctx || !cost || !unit || !coeff || !quant || !recon || !nz ||
+        !(unit->size == 4 || unit->size == 8 || unit->size == 16 || unit->size == 32) || coeffStride < unit->size ||
+        (unit->bit_depth != 8 && unit->bit_depth != 10) || unit->qp > 51)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    static uint8_t *d_scratch = nullptr; /* unit | nz | coeff | quant | recon ; callers serialise per context */
+    const size_t o_unit = 0, o_nz = 64, o_c = 128, o_q = o_c + 2048, o_r = o_q + 2048, total = o_r + 2048;
+    if (!d_scratch)
+        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    const int N = unit->size;
+    int16_t hc[32 * 32], hq[32 * 32], hr[32 * 32];
+    for (int y = 0; y < N; y++)
+        ::memcpy(hc + y * N, coeff + (size_t)y * coeffStride, (size_t)N * 2);
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_unit, unit, sizeof(*unit), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_scratch + o_c, hc, (size_t)N * N * 2, hipMemcpyHostToDevice, ctx->stream));
+    int rc = svt_amd_pmcore_quantize_batch(ctx, cost, (const SvtAmdPmQuantUnit *)(d_scratch + o_unit), (const int16_t *)(d_scratch + o_c),
+                                           (int16_t *)(d_scratch + o_q), (int16_t *)(d_scratch + o_r), (uint32_t *)(d_scratch + o_nz), 1);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(nz, d_scratch + o_nz, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hq, d_scratch + o_q, (size_t)N * N * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hr, d_scratch + o_r, (size_t)N * N * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int y = 0; y < N; y++) {
+        ::memcpy(quant + (size_t)y * coeffStride, hq + y * N, (size_t)N * 2);
+        ::memcpy(recon + (size_t)y * coeffStride, hr + y * N, (size_t)N * 2);
+    }
     return SVT_AMD_OK;
 }

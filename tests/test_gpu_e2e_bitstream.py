@@ -222,6 +222,27 @@ def test_bitstream_and_recon_identical_with_gpu_sao_decision(tmp_path, kind, w, 
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"
 
 
+def test_bitstream_identical_with_pm_core_on_the_device(tmp_path):
+    """encMode 4 (BASELINE configs[4]'s preset): the PM-core variants of the luma full loop (P pictures) and of the encode-pass
+    quantiser (every picture) on the device, C_DEFAULT against C_DEFAULT (the reference's AVX2 helpers of this path differ
+    from its C code, EbTransforms.c:2848)."""
+    kind, w, h, n, args = "motion", 416, 240, 4, ["-encMode", "4", "-pred-struct", "0", "-asm", "0"]
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    flags = ("SVT_HOOK_FULLLOOP", "SVT_HOOK_QUANT")
+    for f in flags:
+        os.environ[f] = "1"
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        for f in flags:
+            del os.environ[f]
+    assert "luma full loop (ProductFullLoop) on the GPU" in log and "encode-pass PM-core quantiser" in log, log[-1500:]
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
+    assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
+
+
 @pytest.mark.parametrize("kind,w,h,n,args", [("motion", 416, 240, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"]),
                                              ("motion10", 416, 240, 3, ["-encMode", "9", "-pred-struct", "0", "-bit-depth", "10"])])
 def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n, args):
