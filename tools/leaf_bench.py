@@ -125,6 +125,18 @@ def main():
         timed("SAO apply picture %d-bit (all LCUs on, random types)" % (8 if bps == 1 else 10), 2 * 1.5 * npx * bps + nlcu * 76,
               lambda: lib.svt_amd_sao_apply_picture(ctx, bps, ps, pd, W, W // 2, W, H, d_lc.data_ptr(), 1, 1))
 
+    # SAO parameter decision of the picture from per-LCU statistics (own decision per LCU + merge wavefront)
+    from test_gpu_saodec import random_picture
+    lcols, lrows = (W + 63) // 64, (H + 63) // 64
+    sp = random_picture(np.random.default_rng(5), lcols, lrows, 0, 1, 0, 0, 1)
+    d_st = [torch.from_numpy(np.ascontiguousarray(sp["stats"][c]).view(np.uint8)).to(dev) for c in range(3)]
+    d_sp = torch.from_numpy(sp["params"].view(np.uint8).copy()).to(dev)
+    d_sc = torch.zeros((lcols * lrows, 2), dtype=torch.int64, device=dev)
+    lib.svt_amd_sao_decide_picture.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp]
+    timed("SAO decision picture (%d LCUs: own parameters + merge wavefront)" % (lcols * lrows), lcols * lrows * (3 * 312 + 72 + 16),
+          lambda: lib.svt_amd_sao_decide_picture(ctx, sp["P"].ctypes.data, d_st[0].data_ptr(), d_st[1].data_ptr(), d_st[2].data_ptr(), lcols,
+                                                 lrows, None, d_sp.data_ptr(), d_sc.data_ptr()))
+
     # HEVC motion compensation: a 1080p luma plane as 16x16 PUs with random quarter-pel vectors
     lib.svt_amd_mcp_batch_sized.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp, u32, vp, u32, u32]
     PADX = 80
@@ -178,6 +190,13 @@ def main():
         timed("full loop luma %dx%d (%d candidates: DCT+quant+dist+rate+cost)" % (size, size, nc), nc * (6 * size * size + 72 + 64),
               lambda: lib.svt_amd_full_loop_luma_batch(ctx, cost.ctypes.data, d_fin.data_ptr(), resid.data_ptr(), qo.data_ptr(),
                                                        ro.data_ptr(), fout.data_ptr(), nc))
+        # the PM-core variant (encMode 1..4): pm_core = 2 in the upper half of the pf_mode word
+        fin["pf_mode"] = 2 << 16
+        d_fpm = torch.from_numpy(fin.view(np.uint8)).to(dev)
+        lib.svt_amd_full_loop_luma_pmcore_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32]
+        timed("full loop luma %dx%d, PM-core quantiser (%d candidates)" % (size, size, nc), nc * (6 * size * size + 72 + 64),
+              lambda: lib.svt_amd_full_loop_luma_pmcore_batch(ctx, cost.ctypes.data, d_fpm.data_ptr(), resid.data_ptr(), qo.data_ptr(),
+                                                              ro.data_ptr(), fout.data_ptr(), nc))
         cin = np.zeros(nc, np.dtype(ChromaLoopIn))
         cin["size"], cin["cb_qp"], cin["cr_qp"], cin["slice_type"], cin["cand_type"] = size, 31, 31, 1, 1
         d_cin = torch.from_numpy(cin.view(np.uint8)).to(dev)
