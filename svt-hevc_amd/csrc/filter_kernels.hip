@@ -594,6 +594,21 @@ __device__ __forceinline__ void sao_eo_offsets(const SaoStats *S, uint32_t t, in
 __global__ void __launch_bounds__(64) k_sao_decide_own(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
                                                        uint32_t nlcu, const uint8_t *enable, SaoLcuParams *params, int64_t *costs)
 {
+    /* the three statistics records of the workgroup's 64 LCUs, fetched with coalesced loads (a thread walking its own 312-byte
+     * records would pay one memory latency per band) */
+    __shared__ SaoStats st[3][64];
+    {
+        const uint32_t first = blockIdx.x * 64, cnt = min(64u, nlcu - first);
+        const uint32_t words = cnt * (uint32_t)(sizeof(SaoStats) / 4);
+        const SaoStats *src[3] = {sy, scb, scr};
+        for (int c = 0; c < (P.mmSao ? 3 : 1); c++) {
+            const uint32_t *g = (const uint32_t *)(src[c] + first);
+            uint32_t *l = (uint32_t *)&st[c][0];
+            for (uint32_t w = threadIdx.x; w < words; w += 64)
+                l[w] = g[w];
+        }
+    }
+    __syncthreads();
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nlcu || (enable != nullptr && enable[i] == 2)) /* 2: parameters given, a merge candidate only */
         return;
@@ -610,7 +625,7 @@ __global__ void __launch_bounds__(64) k_sao_decide_own(SaoDecide P, const SaoSta
     if ((enable == nullptr || enable[i] == 1) && (P.mmSao || P.temporalLayer < 2)) {
         const int sh = P.is10 ? 4 : 0, m = P.is10 ? 31 : 7;
         const int64_t maxc = (int64_t)(~0ull >> 1);
-        const SaoStats *Y = sy + i;
+        const SaoStats *Y = &st[0][threadIdx.x];
         {   /* luma */
             const int64_t offCost = sao_rate_cost(P.typeBits[0], P.lambda);
             int64_t boBest = maxc;
@@ -650,7 +665,7 @@ __global__ void __launch_bounds__(64) k_sao_decide_own(SaoDecide P, const SaoSta
         }
         if (P.mmSao) { /* chroma: edge offset only, Cb and Cr share the class */
             const int64_t offCost = sao_rate_cost(P.typeBits[0], P.chromaLambda);
-            const SaoStats *two[2] = {scb + i, scr + i};
+            const SaoStats *two[2] = {&st[1][threadIdx.x], &st[2][threadIdx.x]};
             uint32_t bestEo;
             const int64_t eoBest = sao_best_eo<2>(P, two, 0, P.chromaLambda, sh, m, bestEo);
             if (eoBest < offCost) {
@@ -684,6 +699,130 @@ __device__ __forceinline__ int64_t sao_merge_dist(const SaoLcuParams &N, int com
     }
     return d;
 }
+/* What a neighbour hands on: 20 bytes instead of the 72-byte record */
+struct SaoMergeCand { uint8_t type[2]; uint8_t band[3]; int8_t offset[3][4]; uint8_t pad[3]; };
+/* the eight statistics a candidate needs for one component, fetched without a branch so that the loads of all components and
+ * of both candidates are in flight together (a chain of "if type ... load ... use" pays one memory latency per link) */
+struct SaoMergeFetch { int diff[4], cnt[4]; };
+__device__ __forceinline__ SaoMergeFetch sao_merge_fetch(const SaoMergeCand &N, int comp, const SaoStats *S)
+{
+    const uint32_t type = N.type[comp ? 1 : 0];
+    const uint32_t band = N.band[comp] > 28 ? 28u : N.band[comp];
+    const int32_t *dp = type == 5 ? &S->boDiff[band] : &S->eoDiff[type ? type - 1 : 0][0];
+    const uint16_t *cp = type == 5 ? &S->boCount[band] : &S->eoCount[type ? type - 1 : 0][0];
+    SaoMergeFetch f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        f.diff[k] = dp[k], f.cnt[k] = cp[k];
+    return f;
+}
+__device__ __forceinline__ int64_t sao_merge_dist_f(const SaoMergeCand &N, int comp, const SaoMergeFetch &f)
+{
+    int64_t d = 0;
+    if (N.type[comp ? 1 : 0] == 0)
+        return 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        d += sao_dist((int)N.offset[comp][k], f.diff[k], f.cnt[k]);
+    return d;
+}
+/* One workgroup, thread y walks LCU row y: at step d it finishes LCU (d - y, y).  Both merge candidates of that LCU were
+ * finished at step d - 1 - the left one by the same thread, the upper one by thread y - 1 - so the final parameters travel
+ * through two LDS lines (previous / current anti-diagonal, indexed by row) and HBM only sees each LCU's own record once
+ * in and once out.  MAXR rows fit the LDS lines; taller pictures take the generic kernel below. */
+template <int MAXR>
+__global__ void __launch_bounds__(MAXR) k_sao_decide_merge_lds(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
+                                                               uint32_t cols, uint32_t rows, const uint8_t *enable, SaoLcuParams *params,
+                                                               int64_t *costs)
+{
+    __shared__ SaoMergeCand line[2][MAXR];
+    const int sh = P.is10 ? 4 : 0;
+    const int64_t maxc = (int64_t)(~0ull >> 1);
+    const uint32_t y = threadIdx.x;
+    const int64_t rMerge = sao_rate_cost(P.mergeBits[1], P.lambda);
+    /* the next LCU's record and costs are fetched one step ahead */
+    SaoLcuParams nxt;
+    int64_t nLuma = 0, nChroma = 0;
+    uint32_t nEn = 0;
+    if (y < rows && y == 0) {
+        nxt = params[0], nLuma = costs[0], nChroma = costs[1], nEn = enable ? enable[0] : 1;
+    }
+    for (uint32_t d = 0; d < cols + rows - 1; d++) {
+        const uint32_t x = d - y;
+        const bool mine = y < rows && y <= d && x < cols;
+        const uint32_t i = mine ? y * cols + x : 0;
+        SaoLcuParams o = nxt;
+        int64_t luma = nLuma, chroma = nChroma;
+        const uint32_t en = nEn;
+        /* prefetch for step d + 1: LCU (x + 1, y), or the row's first one */
+        {
+            const uint32_t xn = d + 1 - y;
+            if (y < rows && y <= d + 1 && xn < cols) {
+                const uint32_t in = y * cols + xn;
+                nxt = params[in], nLuma = costs[2 * in], nChroma = costs[2 * in + 1], nEn = enable ? enable[in] : 1;
+            }
+        }
+        SaoMergeCand fin;
+        if (mine) {
+            if (en == 1) {
+                const bool hasLeft = !(o.edge_flags & 1) && x > 0, hasUp = !(o.edge_flags & 4) && y > 0;
+                const uint64_t leftFlag = hasLeft ? P.mergeBits[0] : 0, upFlag = hasUp ? P.mergeBits[0] : 0;
+                const int64_t flags = sao_rate_cost(leftFlag + upFlag, P.lambda);
+                const int64_t best = luma + chroma + flags;
+                luma += flags, chroma += flags;
+                int64_t lCost = maxc, uCost = maxc, lLuma = 0, lChroma = 0, uLuma = 0, uChroma = 0;
+                SaoMergeCand L = line[(d + 1) & 1][y], U = line[(d + 1) & 1][y ? y - 1 : 0];
+                if (!hasLeft)
+                    L.type[0] = L.type[1] = 0;
+                if (!hasUp)
+                    U.type[0] = U.type[1] = 0;
+                const SaoStats *S3[3] = {sy + i, scb + i, scr + i};
+                SaoMergeFetch fl[3], fu[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    fl[c] = sao_merge_fetch(L, c, S3[c]), fu[c] = sao_merge_fetch(U, c, S3[c]);
+                if (hasLeft) {
+                    const int64_t dl = sao_merge_dist_f(L, 0, fl[0]) >> sh,
+                                  dc = (sao_merge_dist_f(L, 1, fl[1]) + sao_merge_dist_f(L, 2, fl[2])) >> sh;
+                    lLuma = (dl << 8) + rMerge, lChroma = (dc << 8) + rMerge, lCost = (dl << 8) + (dc << 8) + rMerge;
+                }
+                if (hasUp) {
+                    const int64_t dl = sao_merge_dist_f(U, 0, fu[0]) >> sh,
+                                  dc = (sao_merge_dist_f(U, 1, fu[1]) + sao_merge_dist_f(U, 2, fu[2])) >> sh;
+                    const int64_t r = sao_rate_cost(leftFlag + P.mergeBits[1], P.lambda);
+                    uLuma = (dl << 8) + r, uChroma = (dc << 8) + r, uCost = (dl << 8) + (dc << 8) + r;
+                }
+                if (lCost < best || uCost < best) {
+                    const bool left = lCost <= uCost && hasLeft;
+                    if (left || hasUp) {
+                        const SaoMergeCand &N = left ? L : U;
+                        o.merge_left = left, o.merge_up = !left;
+                        luma = left ? lLuma : uLuma, chroma = left ? lChroma : uChroma;
+                        o.type[0] = N.type[0], o.type[1] = N.type[1];
+                        for (int c = 0; c < 3; c++) {
+                            o.band[c] = N.band[c];
+                            for (int k = 0; k < 4; k++)
+                                o.offset[c][k] = N.offset[c][k];
+                        }
+                        params[i] = o;
+                    }
+                }
+                costs[2 * i] = luma, costs[2 * i + 1] = chroma;
+            }
+            fin.type[0] = (uint8_t)o.type[0], fin.type[1] = (uint8_t)o.type[1];
+            for (int c = 0; c < 3; c++) {
+                fin.band[c] = (uint8_t)o.band[c];
+                for (int k = 0; k < 4; k++)
+                    fin.offset[c][k] = (int8_t)o.offset[c][k];
+            }
+            line[d & 1][y] = fin;
+        }
+        /* only the LDS lines travel between threads: wait for them, not for the HBM stores and the prefetch (a full
+         * __syncthreads() would put a store acknowledgement on every step's critical path) */
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sao_decide_merge(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
                                                           uint32_t cols, uint32_t rows, const uint8_t *enable, SaoLcuParams *params,
                                                           int64_t *costs)
@@ -871,10 +1010,20 @@ extern "C" int svt_amd_sao_decide_picture(SvtAmdContext *ctx, const SvtAmdSaoDec
     const uint32_t nlcu = lcu_cols * lcu_rows;
     hipLaunchKernelGGL(k_sao_decide_own, dim3((nlcu + 63) / 64), dim3(64), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
                        (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, nlcu, d_enable, (SaoLcuParams *)d_params, d_costs);
-    if (P.mmSao || P.temporalLayer < 2)
-        hipLaunchKernelGGL(k_sao_decide_merge, dim3(1), dim3(256), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
-                           (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
-                           (SaoLcuParams *)d_params, d_costs);
+    if (P.mmSao || P.temporalLayer < 2) {
+        if (lcu_rows <= 64)
+            hipLaunchKernelGGL(k_sao_decide_merge_lds<64>, dim3(1), dim3(64), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+                               (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
+                               (SaoLcuParams *)d_params, d_costs);
+        else if (lcu_rows <= 256)
+            hipLaunchKernelGGL(k_sao_decide_merge_lds<256>, dim3(1), dim3(256), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+                               (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
+                               (SaoLcuParams *)d_params, d_costs);
+        else
+            hipLaunchKernelGGL(k_sao_decide_merge, dim3(1), dim3(256), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+                               (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
+                               (SaoLcuParams *)d_params, d_costs);
+    }
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
