@@ -745,6 +745,30 @@ SVT_AMD_API int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost
                                        SvtAmdFullLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
+/* Distortion stage of the mode decision's fast loop                           */
+/* ------------------------------------------------------------------------- */
+/* Replaces, for a list of candidates whose predictions are already on the device (svt_amd_intra_pu_batch /
+ * svt_amd_inter_pu_batch), the measurement ProductPerformFastLoop makes after ProductMdFastPuPrediction (Codec/
+ * EbProductCodingLoop.c:2036-2078): luma SAD of the predicted block against the source block (NxMSadKernel_funcPtrArray,
+ * C_DEFAULT/EbComputeSAD_C.c:147) and, with contextPtr->useChromaInformationInFastLoop, Cb SAD + Cr SAD; most-probable-mode
+ * candidates skip it.  What stays with the caller: the candidate that reuses its open-loop distortion (:2042-2043), the
+ * ">> 2" of zero-motion 64x64 candidates in noise LCUs (:2079-2090) and the fast-cost functions themselves (scalar).
+ * 8-bit 4:2:0; offsets and strides in samples; the chroma planes may be NULL when no candidate sets flag 1. */
+typedef struct SvtAmdFastLoopCand {
+    int32_t src_off_y, src_off_c;      /* the coding unit's block inside the source planes                         */
+    int32_t pred_off_y, pred_off_c;    /* the candidate's block inside the prediction planes                       */
+    uint8_t size;                      /* 8 / 16 / 32 / 64                                                         */
+    uint8_t flags;                     /* 1: with chroma (useChromaInformationInFastLoop); 2: mpmFlag, skip        */
+    uint8_t pad[2];
+} SvtAmdFastLoopCand;
+typedef struct SvtAmdFastLoopDist { uint32_t luma, chroma; } SvtAmdFastLoopDist; /* lumaFastDistortion, chromaFastDistortion */
+SVT_AMD_API int svt_amd_fast_loop_distortion_batch(SvtAmdContext *ctx, const uint8_t *d_src_y, uint32_t srcStrideY,
+                                                   const uint8_t *d_src_cb, const uint8_t *d_src_cr, uint32_t srcStrideC,
+                                                   const uint8_t *d_pred_y, uint32_t predStrideY, const uint8_t *d_pred_cb,
+                                                   const uint8_t *d_pred_cr, uint32_t predStrideC,
+                                                   const SvtAmdFastLoopCand *d_cands, uint32_t ncand, SvtAmdFastLoopDist *d_out);
+
+/* ------------------------------------------------------------------------- */
 /* Encode-pass inter prediction of prediction units                            */
 /* ------------------------------------------------------------------------- */
 /* Replaces EncodePassInterPrediction (Codec/EbInterPrediction.c:761-926, called per prediction unit from

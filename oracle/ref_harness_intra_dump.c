@@ -169,6 +169,7 @@ __attribute__((constructor)) static void install(void)
 /* ---- mode-decision side ---- */
 EB_ERRORTYPE __real_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
                                       ModeDecisionCandidateBuffer_t *cand);
+void svt_ref_fastloop_note_prediction(const void *candidateBuffer);
 static FILE *g_md_file;
 static int g_md_state, g_md_stride = 23;
 static unsigned long g_md_calls;
@@ -246,6 +247,7 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
         pthread_mutex_unlock(&g_lock);
     }
     const EB_ERRORTYPE rc = __real_IntraPredictionCl(md, componentMask, pcs, cand);
+    svt_ref_fastloop_note_prediction(cand); /* ref_harness_fastloop_dump.c: this candidate buffer was just predicted */
     int take = 0;
     if (g_md_state > 0 && !md->intraMdOpenLoopFlag && md->cuStats->size >= 8 && md->cuStats->size <= 32) {
         pthread_mutex_lock(&g_lock);

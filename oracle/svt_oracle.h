@@ -32,6 +32,9 @@ void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAm
 #endif
 
 /* ---- leaf kernels (same signatures as the reference C_DEFAULT symbols) ---- */
+void svt_oracle_fast_loop_distortion(const SvtAmdFastLoopCand *K, const uint8_t *srcY, uint32_t srcStrideY, const uint8_t *srcCb,
+                                     const uint8_t *srcCr, uint32_t srcStrideC, const uint8_t *predY, uint32_t predStrideY,
+                                     const uint8_t *predCb, const uint8_t *predCr, uint32_t predStrideC, SvtAmdFastLoopDist *out);
 uint32_t svt_oracle_NxMSadKernel(const uint8_t *src, uint32_t srcStride, const uint8_t *ref,
                                  uint32_t refStride, uint32_t height, uint32_t width);
 void svt_oracle_SadLoopKernel(const uint8_t *src, uint32_t srcStride, const uint8_t *ref,
