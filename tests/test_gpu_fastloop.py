@@ -1,7 +1,7 @@
 """-m gpu: the distortion stage of the fast loop (svt_amd_fast_loop_distortion_batch) through the C-ABI against (1) records of
 real second-loop iterations of ProductPerformFastLoop (tests/golden/fastloop_*.npz) and (2) the oracle (pinned to the same
 records in tests/test_oracle_fastloop_golden.py) on a 1080p picture: every CU size, unaligned strides, chroma on / off,
-most-probable-mode candidates; and chained behind the device's own intra prediction (svt_amd_intra_pu_batch)."""
+most-probable-mode candidates."""
 import ctypes as C
 
 import numpy as np
