@@ -128,12 +128,35 @@ def main():
     # picture is prepared exactly once and the B pictures of a step are independent of each other
     # (the front half is open loop): per step ONE prep launch, ONE ME batch (2 launches), ONE OIS launch.
     R = B + 1
+    # Residual / DCT / quantiser / reconstruction stage (the "+ DCT" of BASELINE configs[1]): every picture's luma plane as 16x16
+    # transform units (8x8 for the last 8 rows of 1080), each predicted from the co-located block of the working reconstruction
+    # plane of its batch position, through the fused encode-pass kernel (svt_amd_encode_tu_batch: residual -> DCT -> Q -> iQ ->
+    # iDCT -> reconstruction in place).  One launch per unit size and step.
+    eudt = np.dtype([("src_off", "<i4"), ("rec_off", "<i4"), ("qp", "u1"), ("slice_type", "u1"), ("pad", "u1", 2), ("dz", "<u4")])
+    lib.svt_amd_encode_tu_batch.restype = C.c_int
+    lib.svt_amd_encode_tu_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_uint32]
+    H16 = H // 16 * 16
+    g16 = np.stack(np.meshgrid(np.arange(0, H16, 16), np.arange(0, W, 16), indexing="ij"), -1).reshape(-1, 2)
+    g8 = np.stack(np.meshgrid(np.arange(H16, H, 8), np.arange(0, W, 8), indexing="ij"), -1).reshape(-1, 2)
+
+    def unit_list(grid, cur_slots):
+        u = np.zeros(len(cur_slots) * len(grid), eudt)
+        for i, cur in enumerate(cur_slots):
+            blk = u[i * len(grid):(i + 1) * len(grid)]
+            blk["src_off"] = cur * H * W + grid[:, 0] * W + grid[:, 1]
+            blk["rec_off"] = i * H * W + grid[:, 0] * W + grid[:, 1]
+        u["qp"], u["slice_type"] = 32, 1
+        return u
 
     def make_lane(idx):
         ctx = C.c_void_p()
         rc = lib.svt_amd_context_create(local_rank, W, H + 8, R, C.byref(ctx))
         assert rc == 0, lib.svt_amd_last_error()
         frames = synth_frames_device(R, 1234 + 17 * rank + idx, dev)
+        rec = frames[:B].clone()                                     # working reconstruction planes, one per batch position
+        quant = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
+        nz = torch.zeros(B * (len(g16) + len(g8)), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         phases = []
         for k in range(R):  # step s starts at picture n0 = 1 + s*B; phase = n0 % R
@@ -146,22 +169,33 @@ def main():
                 jobs[i].params, jobs[i].cur_slot = params, cur
                 jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = ref
                 ojobs[i].params, ojobs[i].cur_slot = oparams, cur
-            phases.append((slots, ptrs, jobs, ojobs))
+            curs = [(k + i) % R for i in range(B)]
+            u16 = torch.from_numpy(unit_list(g16, curs).view(np.uint8)).to(dev)
+            u8 = torch.from_numpy(unit_list(g8, curs).view(np.uint8)).to(dev) if len(g8) else None
+            phases.append((slots, ptrs, jobs, ojobs, u16, u8))
         state = {"n0": 1}
 
         def step():
-            slots, ptrs, jobs, ojobs = phases[state["n0"] % R]
+            slots, ptrs, jobs, ojobs, u16, u8 = phases[state["n0"] % R]
             r = lib.svt_amd_picture_upload_device_batch(ctx, B, slots, ptrs, W, W, H)
             assert r == 0, lib.svt_amd_last_error()
             r = lib.svt_amd_me_batch_launch(ctx, jobs, B)
             assert r == 0, lib.svt_amd_last_error()
             r = lib.svt_amd_ois_batch_launch(ctx, ojobs, B)  # reads the ME results left on the device
             assert r == 0, lib.svt_amd_last_error()
+            r = lib.svt_amd_encode_tu_batch(ctx, 1, 16, u16.data_ptr(), frames.data_ptr(), W, rec.data_ptr(), W, quant.data_ptr(),
+                                            nz.data_ptr(), B * len(g16))
+            assert r == 0, lib.svt_amd_last_error()
+            if u8 is not None:
+                r = lib.svt_amd_encode_tu_batch(ctx, 1, 8, u8.data_ptr(), frames.data_ptr(), W, rec.data_ptr(), W,
+                                                quant.data_ptr() + 2 * 256 * B * len(g16),   # levels are stored unit after unit
+                                                nz.data_ptr() + 4 * B * len(g16), B * len(g8))
+                assert r == 0, lib.svt_amd_last_error()
             state["n0"] += B
 
         r = lib.svt_amd_picture_upload_device(ctx, 0, C.c_void_p(frames[0].data_ptr()), W, W, H)
         assert r == 0, lib.svt_amd_last_error()
-        return ctx, step, frames
+        return ctx, step, (frames, rec, quant, nz)
 
     lanes = [make_lane(i) for i in range(max(1, a.streams))]
     ctx = lanes[0][0]
@@ -216,13 +250,16 @@ def main():
         algo_bytes = B * (2 * 1.3125 * W * H + nlcu * C.sizeof(S.MeLcuResult))  # one launch = B pictures
         achieved = algo_bytes / (me_ms.value * 1e-3) / 1e9 if me_ms.value > 0 else 0.0
         res = {
-            "metric": "encoded fps (hot path: picture prep + motion estimation + open-loop intra search)", "value": round(fps, 2),
+            "metric": "encoded fps (hot path: picture prep + motion estimation + open-loop intra search + residual DCT/quantiser/"
+                      "reconstruction)", "value": round(fps, 2),
             "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1080p 8-bit encMode 9 low-delay P (BASELINE configs[1]): per picture pad+decimate+"
                                    "half-pel planes, open-loop ME (HME L0/L1, full-pel 85 PU, sub-pel) of 510 LCUs "
-                                   "vs previous picture and open-loop intra search; EncDec mode decision not on device yet",
+                                   "vs previous picture, open-loop intra search, and the fused encode-pass unit (residual, DCT, quantiser, inverse "
+                                   "quantiser, inverse DCT, reconstruction) over the luma plane as 16x16 transform units; mode decision "
+                                   "control flow stays on the host",
                        "width": W, "height": H, "pictures_per_step_per_gpu": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
                        "parallelism": "pictures sharded over ranks, no collective", "streams_per_gpu": len(lanes)},
             "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search), one batch = 2 launches", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
