@@ -230,6 +230,8 @@ uint64_t svt_oracle_coeff_bits_lossy(const SvtAmdCabacCost *C, uint32_t size, ui
                                      uint32_t componentType, uint32_t numNonZeroCoeffs);
 
 /* ---- luma full loop of one candidate (svt_oracle_fullloop.c) ---- */
+uint64_t svt_oracle_encode_plane(const uint8_t *src, uint8_t *rec, uint32_t stride, uint32_t width, uint32_t row0, uint32_t rows,
+                                 uint32_t size, uint32_t qp, uint32_t slice_type);
 void svt_oracle_pmcore_quantize(const SvtAmdCabacCost *cost, const SvtAmdPmQuantUnit *U, const int16_t *coeff, int16_t *quant,
                                 int16_t *recon, uint32_t *nzOut);
 void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,

@@ -303,3 +303,30 @@ void svt_oracle_recon_tu(int bps, uint32_t size, int only_dc, int dst, const int
                 ((uint16_t *)recon)[y * reconStride + x] = (uint16_t)v;
         }
 }
+
+/* The encode-pass unit over a whole 8-bit plane (EncodeLoop + EncodeGenerateRecon, Codec/EbCodingLoop.c:651, :1084): every
+ * `size` x `size` unit of the first `rows` rows is residual -> EstimateTransform -> UnifiedQuantizeInvQuantize (default shape) ->
+ * EncodeInvTransform -> PictureAddition against the co-located block of `rec`, which is overwritten with the reconstruction.
+ * Composition of pinned functions; serves bench.py's cpu_baseline leg and tests.  Returns the number of non-zero levels. */
+uint64_t svt_oracle_encode_plane(const uint8_t *src, uint8_t *rec, uint32_t stride, uint32_t width, uint32_t row0, uint32_t rows,
+                                 uint32_t size, uint32_t qp, uint32_t slice_type)
+{
+    uint64_t total = 0;
+    SvtAmdQuantUnit U;
+    memset(&U, 0, sizeof(U));
+    U.size = (uint8_t)size, U.qp = (uint8_t)qp, U.bit_depth = 8, U.slice_type = (uint8_t)slice_type;
+    for (uint32_t y = row0; y + size <= row0 + rows; y += size)
+        for (uint32_t x = 0; x + size <= width; x += size) {
+            int16_t res[32 * 32], coeff[32 * 32], q[32 * 32], r[32 * 32];
+            for (uint32_t j = 0; j < size; j++)
+                for (uint32_t i = 0; i < size; i++)
+                    res[j * size + i] = (int16_t)((int)src[(size_t)(y + j) * stride + x + i] - (int)rec[(size_t)(y + j) * stride + x + i]);
+            svt_oracle_FwdTransform(size >= 16 ? 1 : 0, (int)size, res, size, coeff, size, NULL, 0);
+            uint32_t nz = 0;
+            svt_oracle_unified_quantize(&U, coeff, size, q, r, &nz);
+            if (nz)
+                svt_oracle_recon_tu(1, size, 0, 0, r, rec + (size_t)y * stride + x, stride, rec + (size_t)y * stride + x, stride);
+            total += nz;
+        }
+    return total;
+}

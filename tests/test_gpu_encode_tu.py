@@ -75,3 +75,38 @@ def test_encode_tu_matches_oracle_composition(product, gpu_ctx, oracle, size, bp
         nonzero += nz.value != 0
     assert zero > 0 and nonzero > n // 3
     assert np.array_equal(got_rec[:, 256:], pred[:, 256:])
+
+
+def test_encode_plane_as_the_bench_runs_it(product, gpu_ctx, oracle):
+    """bench.py's DCT stage: a whole luma plane as 16x16 units (8x8 for the rows a multiple of 16 leaves over), reconstruction in
+    place, against oracle/svt_oracle_fullloop.c:svt_oracle_encode_plane (bench.py's cpu_baseline leg)."""
+    import torch
+    W, H = 416, 248
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    pred = np.clip(src.astype(np.int16) + rng.integers(-25, 26, (H, W)), 0, 255).astype(np.uint8)
+    eudt = np.dtype([("src_off", "<i4"), ("rec_off", "<i4"), ("qp", "u1"), ("slice_type", "u1"), ("pad", "u1", 2), ("dz", "<u4")])
+    H16 = H // 16 * 16
+    want = pred.copy()
+    oracle.svt_oracle_encode_plane.restype = C.c_uint64
+    oracle.svt_oracle_encode_plane.argtypes = [vp, vp] + [u32] * 7
+    nz_want = oracle.svt_oracle_encode_plane(src.ctypes.data, want.ctypes.data, W, W, 0, H16, 16, 32, 1)
+    nz_want += oracle.svt_oracle_encode_plane(src.ctypes.data, want.ctypes.data, W, W, H16, H - H16, 8, 32, 1)
+    d_src, d_rec = torch.from_numpy(src).cuda(), torch.from_numpy(pred.copy()).cuda()
+    d_q = torch.zeros(H * W, dtype=torch.int16, device="cuda")
+    product.svt_amd_encode_tu_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, u32, vp, u32, vp, vp, u32]
+    total = 0
+    for size, y0, y1 in ((16, 0, H16), (8, H16, H)):
+        ys, xs = np.meshgrid(np.arange(y0, y1, size), np.arange(0, W, size), indexing="ij")
+        u = np.zeros(ys.size, eudt)
+        u["src_off"] = u["rec_off"] = (ys * W + xs).ravel()
+        u["qp"], u["slice_type"] = 32, 1
+        d_u = torch.from_numpy(u.view(np.uint8)).cuda()
+        d_nz = torch.zeros(len(u), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        rc = product.svt_amd_encode_tu_batch(gpu_ctx, 1, size, d_u.data_ptr(), d_src.data_ptr(), W, d_rec.data_ptr(), W, d_q.data_ptr(),
+                                             d_nz.data_ptr(), len(u))
+        assert rc == 0, product.svt_amd_last_error()
+        product.svt_amd_synchronize(gpu_ctx)
+        total += int(d_nz.sum().item())
+    assert np.array_equal(d_rec.cpu().numpy(), want) and total == nz_want and total > 1000
