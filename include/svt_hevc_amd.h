@@ -821,7 +821,8 @@ typedef struct SvtAmdIntraPuJob {
     uint8_t  luma_mode, chroma_mode;       /* EB_INTRA_* / EB_INTRA_CHROMA_* (4 = derived from luma)              */
     uint8_t  mode_tl;                      /* mode-type neighbour entries: 1 INTER, 2 INTRA, 0xFF invalid,        */
     uint8_t  mode_left[16], mode_top[16];  /*   0xFE beyond the array; one per 4 luma samples                     */
-    uint8_t  pad[2];
+    uint8_t  no_smoothing;                 /* 1: never take the filtered reference (IntraPredictionOl, the open-loop  */
+    uint8_t  pad;                          /*    mode decision: neighbours = source samples, 128 where there are none) */
     uint16_t left[3][64], top[3][64];      /* [Y, Cb, Cr][i]: reconstructed neighbour samples (chroma: size used)  */
     uint16_t tl[3], pad2;
     int32_t  dst_off_y, dst_off_c;         /* sample offsets of the unit inside the three destination planes      */
@@ -833,7 +834,9 @@ SVT_AMD_API int svt_amd_intra_pu_batch(SvtAmdContext *ctx, int bytes_per_sample,
 /* Per-call form on HOST pointers (one unit, blocking): the binding of the two table slots, and of the mode decision's
  * IntraPredictionCl (Codec/EbIntraPrediction.c:3682; generators GenerateIntraLuma/ChromaReferenceSamplesMd, EbProductCodingLoop.c:
  * 269, :2196), which asks for the luma block and the chroma pair separately: pred_y == NULL or pred_cb == pred_cr == NULL
- * leaves that part out. */
+ * leaves that part out.  Its open-loop twin IntraPredictionOl (:5427; neighbours = source samples cut by UpdateNeighborSamples
+ * ArrayOL / UpdateChromaNeighborSamplesArrayOL, :4952, :5065: mid-grey where the picture ends, no substitution, no smoothing) is
+ * the same call with every neighbour group marked available, the literal samples in left / top / tl and no_smoothing = 1. */
 SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const SvtAmdIntraPuJob *job, void *pred_y,
                                  uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC);
 

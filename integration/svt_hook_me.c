@@ -680,6 +680,79 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
     return EB_ErrorNone;
 }
 
+/* The open-loop twin: IntraPredictionOl (EbIntraPrediction.c:5427, slot of ProductPredictionFunTableOl) predicts from SOURCE
+ * neighbours (UpdateNeighborSamplesArrayOL / UpdateChromaNeighborSamplesArrayOL, :4952, :5065: mid-grey where the picture ends,
+ * no substitution, no smoothing).  Same switch, same device call: every neighbour group marked available, the literal
+ * samples in the job, no_smoothing = 1. */
+EB_ERRORTYPE __real_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand);
+static unsigned long g_md_intra_ol_gpu;
+
+static void ol_slices(uint16_t *left, uint16_t *top, uint16_t *tl, const uint8_t *plane, uint32_t stride, uint32_t x, uint32_t y, uint32_t n,
+                      uint32_t width, uint32_t height, int picLeft, int picTop)
+{
+    const uint8_t *src = plane + (size_t)y * stride + x;
+    for (uint32_t i = 0; i < 2 * n; i++)
+        left[i] = top[i] = 128;
+    *tl = 128;
+    if (!picLeft)
+        for (uint32_t i = 0; i < 2 * n && y + i < height; i++)
+            left[i] = src[(size_t)i * stride - 1];
+    if (!picLeft && !picTop)
+        *tl = src[-(ptrdiff_t)stride - 1];
+    if (!picTop)
+        for (uint32_t i = 0; i < 2 * n && x + i < width; i++)
+            top[i] = src[i - (ptrdiff_t)stride];
+}
+
+EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand)
+{
+    if (g_md_intra_state == 0)
+        g_md_intra_state = getenv("SVT_HOOK_INTRA") ? 1 : -1;
+    const uint32_t size = md->cuStats->size, lumaMode = cand->candidatePtr->intraLumaMode, ox = md->cuOriginX, oy = md->cuOriginY;
+    const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
+    if (g_md_intra_state < 0 || !g_ctx || !md->intraMdOpenLoopFlag || size < 8 || size > 32 || lumaMode > 34 ||
+        (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK))
+        return __real_IntraPredictionOl(md, componentMask, pcs, cand);
+    EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr, *pred = cand->predictionPtr;
+    const uint32_t m = md->lcuPtr->size - 1;
+    const int picLeft = md->lcuPtr->lcuEdgeInfoPtr->pictureLeftEdgeFlag == EB_TRUE && (ox & m) == 0;
+    const int picTop = md->lcuPtr->lcuEdgeInfoPtr->pictureTopEdgeFlag == EB_TRUE && (oy & m) == 0;
+    SvtAmdIntraPuJob j;
+    memset(&j, 0, sizeof(j));
+    j.size = size, j.bottom_left_ok = j.top_right_ok = 1, j.no_smoothing = 1, j.mode_tl = 2;
+    memset(j.mode_left, 2, sizeof(j.mode_left)), memset(j.mode_top, 2, sizeof(j.mode_top));
+    j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
+    if (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) {
+        if (md->lumaIntraRefSamplesGenDone == EB_FALSE)
+            GenerateIntraLumaReferenceSamplesMd(md, in);
+        ol_slices(j.left[0], j.top[0], &j.tl[0], in->bufferY + (size_t)in->originY * in->strideY + in->originX, in->strideY, ox, oy, size,
+                  in->width, in->height, picLeft, picTop);
+        pthread_mutex_lock(&g_lock);
+        if (svt_amd_intra_pu(g_ctx, 1, &j, pred->bufferY + (oy & 63) * 64 + (ox & 63), pred->strideY, NULL, NULL, 0))
+            die("svt_amd_intra_pu (mode decision, open loop, luma)");
+        if (g_md_intra_ol_gpu++ == 0 && g_verbose)
+            fprintf(stderr, "svt_hook_me: open-loop mode-decision intra prediction (IntraPredictionOl) on the GPU\n");
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (chromaAsked) {
+        if (md->chromaIntraRefSamplesGenDone == EB_FALSE)
+            GenerateIntraChromaReferenceSamplesMd(md, in);
+        ol_slices(j.left[1], j.top[1], &j.tl[1], in->bufferCb + (size_t)(in->originY >> 1) * in->strideCb + (in->originX >> 1), in->strideCb,
+                  ox >> 1, oy >> 1, size >> 1, in->width >> 1, in->height >> 1, picLeft, picTop);
+        ol_slices(j.left[2], j.top[2], &j.tl[2], in->bufferCr + (size_t)(in->originY >> 1) * in->strideCr + (in->originX >> 1), in->strideCr,
+                  ox >> 1, oy >> 1, size >> 1, in->width >> 1, in->height >> 1, picLeft, picTop);
+        const uint32_t o = (((oy & 63) * 32) + (ox & 63)) >> 1;
+        pthread_mutex_lock(&g_lock);
+        if (svt_amd_intra_pu(g_ctx, 1, &j, NULL, 0, pred->bufferCb + o, pred->bufferCr + o, pred->strideCb))
+            die("svt_amd_intra_pu (mode decision, open loop, chroma)");
+        g_md_intra_ol_gpu++;
+        pthread_mutex_unlock(&g_lock);
+    }
+    return EB_ErrorNone;
+}
+
 /*
  * Encode-pass inter prediction: EncodePassInterPrediction (EbInterPrediction.c:761, called per prediction unit from
  * EbCodingLoop.c:3932) is answered by svt_amd_inter_pu_batch() with SVT_HOOK_INTER=1 (8-bit 4:2:0).  Reference pictures

@@ -6,8 +6,8 @@
  * and hands both to the fast-cost function of the candidate type.  Compiled only into oracle/_ref/libsvtref.so with
  * -Wl,--wrap= for the four fast-cost functions (Intra2Nx2NFastCostIsliceOpt, Intra2Nx2NFastCostPsliceOpt,
  * InterFastCostPsliceOpt, InterFastCostBsliceOpt, Codec/EbRateDistortionCost.c) and the prediction functions that are not
- * wrapped elsewhere (IntraPredictionOl, Inter2Nx2NPuPredictionHevc, Inter2Nx2NPuPredictionInterpolationFree); the
- * IntraPredictionCl interposer of ref_harness_intra_dump.c reports here through svt_ref_fastloop_note_prediction().
+ * wrapped elsewhere (Inter2Nx2NPuPredictionHevc, Inter2Nx2NPuPredictionInterpolationFree); the IntraPredictionCl / IntraPredictionOl
+ * interposers of ref_harness_intra_dump.c report here through svt_ref_fastloop_note_prediction().
  *
  * A fast-cost call that directly follows a prediction call for the same candidate buffer on the same thread is a
  * second-loop call.  With SVT_REF_FASTLOOP_DUMP=<file>, every SVT_REF_FASTLOOP_STRIDE-th of them (default 29) leaves one
@@ -120,6 +120,5 @@ WRAP_COST(InterFastCostBsliceOpt)
         t_predicted = cb;                                \
         return rc;                                       \
     }
-WRAP_PRED(IntraPredictionOl)
 WRAP_PRED(Inter2Nx2NPuPredictionHevc)
 WRAP_PRED(Inter2Nx2NPuPredictionInterpolationFree)

@@ -16,7 +16,10 @@
  * SVT_REF_INTRA_MD_DUMP=<file> every SVT_REF_INTRA_MD_STRIDE-th call (default 23) leaves records of the same layout, one for
  * the luma block (component_mask 1, the tile-edge flags GenerateIntraLumaReferenceSamplesMd derives, EbProductCodingLoop.c:
  * 274-276) and / or one for the two chroma blocks (component_mask 6, no edge flags, :2203-2219), cut from the mode decision's
- * own neighbour arrays and its candidate prediction buffer.
+ * own neighbour arrays and its candidate prediction buffer.  Its open-loop twin IntraPredictionOl (:5427,
+ * -Wl,--wrap=IntraPredictionOl) leaves records of the same layout too, with the neighbours cut from the source picture as
+ * UpdateNeighborSamplesArrayOL / UpdateChromaNeighborSamplesArrayOL do (:4952, :5065), every group marked available and
+ * pad0 = 1 ("no smoothing").
  * No reference source here.
  */
 #include <stdio.h>
@@ -174,6 +177,39 @@ static FILE *g_md_file;
 static int g_md_state, g_md_stride = 23;
 static unsigned long g_md_calls;
 
+static void md_open(void)
+{
+    if (g_md_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_md_state == 0) {
+            const char *path = getenv("SVT_REF_INTRA_MD_DUMP"), *st = getenv("SVT_REF_INTRA_MD_STRIDE");
+            g_md_file = path ? fopen(path, "wb") : NULL;
+            if (st && atoi(st) > 0)
+                g_md_stride = atoi(st);
+            g_md_state = g_md_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+}
+
+/* open loop: the 2N left / 1 / 2N top neighbours of a block of a source plane, mid-grey beyond the picture */
+static void ol_slices(uint16_t *left, uint16_t *top, uint16_t *tl, const uint8_t *plane, uint32_t stride, uint32_t x, uint32_t y, uint32_t n,
+                      uint32_t width, uint32_t height, int picLeft, int picTop)
+{
+    const uint8_t *src = plane + (size_t)y * stride + x;
+    for (uint32_t i = 0; i < 2 * n; i++)
+        left[i] = top[i] = 128;
+    *tl = 128;
+    if (!picLeft)
+        for (uint32_t i = 0; i < 2 * n && y + i < height; i++)
+            left[i] = src[(size_t)i * stride - 1];
+    if (!picLeft && !picTop)
+        *tl = src[-(ptrdiff_t)stride - 1];
+    if (!picTop)
+        for (uint32_t i = 0; i < 2 * n && x + i < width; i++)
+            top[i] = src[i - (ptrdiff_t)stride];
+}
+
 static void md_record(ModeDecisionContext_t *md, ModeDecisionCandidateBuffer_t *cand, int chroma)
 {
     IntraRecord *r = (IntraRecord *)calloc(1, sizeof(*r));
@@ -235,21 +271,11 @@ static void md_record(ModeDecisionContext_t *md, ModeDecisionCandidateBuffer_t *
 EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
                                       ModeDecisionCandidateBuffer_t *cand)
 {
-    if (g_md_state == 0) {
-        pthread_mutex_lock(&g_lock);
-        if (g_md_state == 0) {
-            const char *path = getenv("SVT_REF_INTRA_MD_DUMP"), *st = getenv("SVT_REF_INTRA_MD_STRIDE");
-            g_md_file = path ? fopen(path, "wb") : NULL;
-            if (st && atoi(st) > 0)
-                g_md_stride = atoi(st);
-            g_md_state = g_md_file ? 1 : -1;
-        }
-        pthread_mutex_unlock(&g_lock);
-    }
+    md_open();
     const EB_ERRORTYPE rc = __real_IntraPredictionCl(md, componentMask, pcs, cand);
     svt_ref_fastloop_note_prediction(cand); /* ref_harness_fastloop_dump.c: this candidate buffer was just predicted */
     int take = 0;
-    if (g_md_state > 0 && !md->intraMdOpenLoopFlag && md->cuStats->size >= 8 && md->cuStats->size <= 32) {
+    if (g_md_state > 0 && !getenv("SVT_REF_INTRA_MD_OL") && !md->intraMdOpenLoopFlag && md->cuStats->size >= 8 && md->cuStats->size <= 32) {
         pthread_mutex_lock(&g_lock);
         take = (g_md_calls++ % (unsigned long)g_md_stride) == 0;
         pthread_mutex_unlock(&g_lock);
@@ -258,5 +284,69 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
         md_record(md, cand, 0);
     if (take && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) == PICTURE_BUFFER_DESC_CHROMA_MASK && md->useChromaInformationInFullLoop)
         md_record(md, cand, 1);
+    return rc;
+}
+
+EB_ERRORTYPE __real_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand);
+static void ol_record(ModeDecisionContext_t *md, PictureControlSet_t *pcs, ModeDecisionCandidateBuffer_t *cand, int chroma)
+{
+    IntraRecord *r = (IntraRecord *)calloc(1, sizeof(*r));
+    const uint32_t size = md->cuStats->size, originX = md->cuOriginX, originY = md->cuOriginY, m = md->lcuPtr->size - 1;
+    const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr;
+    const int picLeft = md->lcuPtr->lcuEdgeInfoPtr->pictureLeftEdgeFlag == EB_TRUE && (originX & m) == 0;
+    const int picTop = md->lcuPtr->lcuEdgeInfoPtr->pictureTopEdgeFlag == EB_TRUE && (originY & m) == 0;
+    r->magic = INTRA_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->size = size, r->bytes_per_sample = 1;
+    r->pad0 = 1; /* no smoothing */
+    r->bottom_left_ok = r->top_right_ok = 1;
+    memset(r->mode_left, 2, sizeof(r->mode_left)), memset(r->mode_top, 2, sizeof(r->mode_top)), r->mode_tl = 2;
+    if (!chroma) {
+        ol_slices(r->left[0], r->top[0], &r->tl[0], in->bufferY + (size_t)in->originY * in->strideY + in->originX, in->strideY, originX, originY,
+                  size, in->width, in->height, picLeft, picTop);
+    } else {
+        ol_slices(r->left[1], r->top[1], &r->tl[1], in->bufferCb + (size_t)(in->originY >> 1) * in->strideCb + (in->originX >> 1), in->strideCb,
+                  originX >> 1, originY >> 1, size >> 1, in->width >> 1, in->height >> 1, picLeft, picTop);
+        ol_slices(r->left[2], r->top[2], &r->tl[2], in->bufferCr + (size_t)(in->originY >> 1) * in->strideCr + (in->originX >> 1), in->strideCr,
+                  originX >> 1, originY >> 1, size >> 1, in->width >> 1, in->height >> 1, picLeft, picTop);
+    }
+    r->luma_mode = cand->candidatePtr->intraLumaMode, r->chroma_mode = 4;
+    r->component_mask = chroma ? PICTURE_BUFFER_DESC_CHROMA_MASK : PICTURE_BUFFER_DESC_LUMA_MASK;
+    const EbPictureBufferDesc_t *pred = cand->predictionPtr;
+    if (!chroma) {
+        const uint32_t o = (originY & 63) * 64 + (originX & 63);
+        for (uint32_t yy = 0; yy < size; yy++)
+            for (uint32_t xx = 0; xx < size; xx++)
+                r->pred_y[yy * size + xx] = pred->bufferY[o + yy * pred->strideY + xx];
+    } else {
+        const uint32_t o = (((originY & 63) * 32) + (originX & 63)) >> 1, c = size >> 1;
+        for (uint32_t yy = 0; yy < c; yy++)
+            for (uint32_t xx = 0; xx < c; xx++) {
+                r->pred_cb[yy * c + xx] = pred->bufferCb[o + yy * pred->strideCb + xx];
+                r->pred_cr[yy * c + xx] = pred->bufferCr[o + yy * pred->strideCr + xx];
+            }
+    }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_md_file);
+    fflush(g_md_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+}
+
+EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componentMask, PictureControlSet_t *pcs,
+                                      ModeDecisionCandidateBuffer_t *cand)
+{
+    md_open();
+    const EB_ERRORTYPE rc = __real_IntraPredictionOl(md, componentMask, pcs, cand);
+    svt_ref_fastloop_note_prediction(cand);
+    const char *only = getenv("SVT_REF_INTRA_MD_OL"); /* set: record the open-loop calls instead of the closed-loop ones */
+    if (!only || g_md_state <= 0 || !md->intraMdOpenLoopFlag || md->cuStats->size < 8 || md->cuStats->size > 32)
+        return rc;
+    pthread_mutex_lock(&g_lock);
+    const int take = (g_md_calls++ % (unsigned long)g_md_stride) == 0;
+    pthread_mutex_unlock(&g_lock);
+    if (take && (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK))
+        ol_record(md, pcs, cand, 0);
+    if (take && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) == PICTURE_BUFFER_DESC_CHROMA_MASK)
+        ol_record(md, pcs, cand, 1);
     return rc;
 }

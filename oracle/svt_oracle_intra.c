@@ -230,7 +230,7 @@ void svt_oracle_intra_pu(int bps, const SvtAmdIntraPuJob *J, void *pred_y, uint3
                 rf[i] = fb[i];
             static const int thrTab[5] = {35, 7, 1, 0, 10}; /* intraLumaFilterTable (:60-66) */
             const int dA = abs(mode - 10), dB = abs(mode - 26), dm = dA < dB ? dA : dB;
-            if (dm > thrTab[ilog2((uint32_t)n) - 2] && mode != 1)
+            if (dm > thrTab[ilog2((uint32_t)n) - 2] && mode != 1 && !J->no_smoothing)
                 use = rf;
         } else {
             const int cm = J->chroma_mode; /* EB_INTRA_CHROMA_PLANAR 0, VERTICAL 1, HORIZONTAL 2, DC 3, DM 4 */

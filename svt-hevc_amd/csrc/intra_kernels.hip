@@ -182,7 +182,7 @@ INTRA_ANG_LEAF(IntraModeAngular16bit_Horizontal_Kernel, uint16_t, IM_ANG_HOR)
 struct IntraPuJob {                       /* = SvtAmdIntraPuJob */
     uint32_t size;
     uint8_t constrained_intra, strong_smoothing, pic_left, pic_top, pic_right, bottom_left_ok, top_right_ok, luma_mode, chroma_mode,
-        mode_tl, mode_left[16], mode_top[16], pad[2];
+        mode_tl, mode_left[16], mode_top[16], no_smoothing, pad;
     uint16_t left[3][64], top[3][64], tl[3], pad2;
     int32_t dst_off_y, dst_off_c;
 };
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_intra_pu(const IntraPuJob *__restrict__
     const int cmode = cm == 0 ? 0 : cm == 1 ? 26 : cm == 2 ? 10 : cm == 3 ? 1 : lmode;
     const int dA = abs(lmode - 10), dB = abs(lmode - 26), dm = dA < dB ? dA : dB;
     const int thrTab = lgN == 2 ? 35 : lgN == 3 ? 7 : lgN == 4 ? 1 : lgN == 5 ? 0 : 10; /* intraLumaFilterTable */
-    const bool filt = dm > thrTab && lmode != 1;
+    const bool filt = dm > thrTab && lmode != 1 && !J.no_smoothing;
     const int bl = border[0][0], tlv = border[0][2 * N], tr = border[0][4 * N];
     const bool strong = J.strong_smoothing && N >= 32 && abs(bl + tlv - 2 * border[0][N]) < thr &&
                         abs(tlv + tr - 2 * border[0][3 * N]) < thr;

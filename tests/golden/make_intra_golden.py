@@ -42,6 +42,12 @@ MD_CASES = {
     "p_motion_416x240_m5": ("motion", 416, 240, 4, 7, ["-encMode", "5", "-pred-struct", "0"], 11, 220),
     "i_tiles_640x384_m3": ("motion", 640, 384, 2, 7, ["-encMode", "3", "-intra-period", "0", "-tile_row_cnt", "2", "-tile_col_cnt", "2"], 23, 260),
 }
+# open-loop mode decision (IntraPredictionOl: non-reference / upper-layer pictures): same fields, neighbours = source samples
+OL_CASES = {
+    "b_416x240_m7": ("motion", 416, 240, 9, 7, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2"], 7, 240),
+    "p_noise_200x136_m9": ("noise", 200, 136, 5, 11, ["-encMode", "9", "-pred-struct", "0", "-hierarchical-levels", "1", "-q", "28"], 1, 240),
+    "b_noise_200x136_m4": ("noise", 200, 136, 9, 11, ["-encMode", "4", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "26"], 13, 300),
+}
 KEEP = ("size", "bytes_per_sample", "constrained_intra", "strong_smoothing", "pic_left", "pic_top", "pic_right", "bottom_left_ok",
         "top_right_ok", "luma_mode", "chroma_mode", "mode_left", "mode_top", "mode_tl", "left", "top", "tl")
 
@@ -74,15 +80,17 @@ def run_case(name):
            int(((recs["mode_left"] == 1).any(axis=1) | (recs["mode_top"] == 1).any(axis=1)).sum()), int(recs["constrained_intra"].sum())))
 
 
-def run_md_case(name):
-    kind, w, h, n, seed, args, stride, keep = MD_CASES[name]
+def run_md_case(name, ol=False):
+    kind, w, h, n, seed, args, stride, keep = (OL_CASES if ol else MD_CASES)[name]
     with tempfile.TemporaryDirectory() as td:
         yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "intramd.dump")
         S.write_clip(yuv, kind, w, h, n, seed)
         cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + \
             ([] if "-q" in args else ["-q", "32"]) + args
-        subprocess.run(cmd, env=dict(os.environ, SVT_REF_INTRA_MD_DUMP=dump, SVT_REF_INTRA_MD_STRIDE=str(stride)), check=True,
-                       stdout=subprocess.DEVNULL)
+        env = dict(os.environ, SVT_REF_INTRA_MD_DUMP=dump, SVT_REF_INTRA_MD_STRIDE=str(stride))
+        if ol:
+            env["SVT_REF_INTRA_MD_OL"] = "1"
+        subprocess.run(cmd, env=env, check=True, stdout=subprocess.DEVNULL)
         recs = np.fromfile(dump, dtype=REC)
     assert len(recs) and (recs["record_size"] == REC.itemsize).all(), (len(recs), REC.itemsize)
     total = len(recs)
@@ -93,10 +101,11 @@ def run_md_case(name):
     sel = np.concatenate([g[np.linspace(0, len(g) - 1, min(share, len(g))).astype(int)] for g in groups])
     recs = recs[np.sort(np.unique(sel))]
     out = {k: recs[k] for k in KEEP + ("component_mask",)}
+    out["no_smoothing"] = recs["pad0"]
     out["pred_y"] = np.concatenate([r["pred_y"][: int(r["size"]) ** 2] for r in recs])
     out["pred_cb"] = np.concatenate([r["pred_cb"][: (int(r["size"]) // 2) ** 2] for r in recs])
     out["pred_cr"] = np.concatenate([r["pred_cr"][: (int(r["size"]) // 2) ** 2] for r in recs])
-    path = os.path.join(S.GOLDEN_DIR, "intramd_%s.npz" % name)
+    path = os.path.join(S.GOLDEN_DIR, ("intraol_%s.npz" if ol else "intramd_%s.npz") % name)
     np.savez_compressed(path, **out)
     sizes, cnt = np.unique(recs["size"], return_counts=True)
     print("%-26s %d of %d records (sizes %s, luma %d / chroma %d) -> %s (%.0f KiB); %d luma modes, edges L/T/R %d/%d/%d, inter neighbours %d" %
@@ -109,9 +118,11 @@ def run_md_case(name):
 if __name__ == "__main__":
     if not os.path.exists(S.REF_APP):
         sys.exit("oracle/_ref/SvtHevcEncApp_ref missing: run `make -C oracle ref` (needs /root/reference)")
-    names = sys.argv[1:] or (list(CASES) + ["md:" + k for k in MD_CASES])
+    names = sys.argv[1:] or (list(CASES) + ["md:" + k for k in MD_CASES] + ["ol:" + k for k in OL_CASES])
     for nm in names:
         if nm.startswith("md:"):
             run_md_case(nm[3:])
+        elif nm.startswith("ol:"):
+            run_md_case(nm[3:], ol=True)
         else:
             run_case(nm)

@@ -132,6 +132,8 @@ INTRA_CASES = [
     ("motion", 416, 240, 3, ["-encMode", "9", "-intra-period", "0"]),
     ("noise", 320, 256, 4, ["-encMode", "6", "-pred-struct", "0", "-q", "25", "-constrd-intra", "1"]),   # intra CUs among inter ones
     ("motion10", 416, 240, 2, ["-encMode", "7", "-intra-period", "0", "-bit-depth", "10"]),
+    # B pictures above the base layer decide with the open-loop twin (IntraPredictionOl: source neighbours)
+    ("noise", 200, 136, 9, ["-encMode", "4", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "26", "-asm", "0"]),
     # encMode 1: chroma in the mode decision's full loop (IntraPredictionCl asked for the chroma pair as well), 2 x 2 tiles
     ("noise", 640, 384, 2, ["-encMode", "1", "-pred-struct", "0", "-q", "28", "-tile_row_cnt", "2", "-tile_col_cnt", "2"]),
 ]
@@ -155,6 +157,8 @@ def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind,
         del os.environ["SVT_HOOK_INTRA"]
     assert "svt_hook_me: encode-pass intra prediction (reference samples + prediction) on the GPU" in log, log[-1000:]
     assert "svt_hook_me: mode-decision intra prediction (IntraPredictionCl) on the GPU" in log, log[-1000:]
+    if "-hierarchical-levels" in args:
+        assert "svt_hook_me: open-loop mode-decision intra prediction (IntraPredictionOl) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"

@@ -69,20 +69,20 @@ def test_intra_pu_matches_reference_golden(product, gpu_ctx, name):
 def test_intra_pu_matches_mode_decision_records(product, gpu_ctx):
     """records of the mode decision's IntraPredictionCl: batched form for all of them, and the per-call host form asking for
     the luma block or the chroma pair alone (what the binding of IntraPredictionCl does)"""
-    from test_oracle_intramd_golden import CASES as MD_CASES, load_intramd_case, planes_of
+    from test_oracle_intramd_golden import CASES as MD_CASES, OL_CASES, load_intramd_case, md_job_of, planes_of
     product.svt_amd_intra_pu.argtypes = [vp, C.c_int, vp, vp, u32, vp, vp, u32]
-    assert len(MD_CASES) == 4
-    for name in MD_CASES:
-        g = load_intramd_case(name)
+    assert len(MD_CASES) == 4 and len(OL_CASES) == 3
+    for name, ol in [(n, False) for n in MD_CASES] + [(n, True) for n in OL_CASES]:     # closed loop, then the open-loop twin
+        g = load_intramd_case(name, ol)
         n = len(g["size"])
-        jobs = np.concatenate([job_of(g, i) for i in range(n)])
+        jobs = np.concatenate([md_job_of(g, i) for i in range(n)])
         got = run_jobs(product, gpu_ctx, 1, jobs)
         for i in range(n):
             want = want_of(g, i)
             for p in planes_of(int(g["component_mask"][i])):
                 assert np.array_equal(got[i][p], want[p]), (name, i, p, int(g["size"][i]), int(g["luma_mode"][i]))
         for i in range(0, n, 5):
-            want, j = want_of(g, i), job_of(g, i)
+            want, j = want_of(g, i), md_job_of(g, i)
             s_, c_ = int(g["size"][i]), int(g["size"][i]) // 2
             if int(g["component_mask"][i]) == 1:
                 y = np.full((s_, 64), 0xAA, np.uint8)

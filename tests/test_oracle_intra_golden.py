@@ -15,7 +15,7 @@ CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(S.GOLDE
 
 JOB = np.dtype([("size", "<u4"), ("constrained_intra", "u1"), ("strong_smoothing", "u1"), ("pic_left", "u1"), ("pic_top", "u1"),
                 ("pic_right", "u1"), ("bottom_left_ok", "u1"), ("top_right_ok", "u1"), ("luma_mode", "u1"), ("chroma_mode", "u1"),
-                ("mode_tl", "u1"), ("mode_left", "u1", 16), ("mode_top", "u1", 16), ("pad", "u1", 2), ("left", "<u2", (3, 64)),
+                ("mode_tl", "u1"), ("mode_left", "u1", 16), ("mode_top", "u1", 16), ("no_smoothing", "u1"), ("pad", "u1"), ("left", "<u2", (3, 64)),
                 ("top", "<u2", (3, 64)), ("tl", "<u2", 3), ("pad2", "<u2"), ("dst_off_y", "<i4"), ("dst_off_c", "<i4")])
 
 
