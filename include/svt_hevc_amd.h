@@ -814,7 +814,8 @@ SVT_AMD_API int svt_amd_inter_pu_batch16bit(SvtAmdContext *ctx, const SvtAmdInte
  * two chroma blocks (4:2:0).  The job carries the slices of the reference's neighbour arrays the unit can see, already
  * cut out by the caller: entry i of left[] / top[] = i-th sample below / right of the unit's top-left corner. */
 typedef struct SvtAmdIntraPuJob {
-    uint32_t size;                         /* 8 / 16 / 32                                                          */
+    uint32_t size;                         /* 8 / 16 / 32; 4 = a luma partition of an intra 4x4 coding unit (luma only; */
+                                           /* its chroma pair is the chroma part of a size-8 job at the coding unit)  */
     uint8_t  constrained_intra, strong_smoothing;
     uint8_t  pic_left, pic_top, pic_right; /* pictureLeft/Top/RightBoundary arguments (tile edges)                */
     uint8_t  bottom_left_ok, top_right_ok; /* isBottomLeftAvailable / isUpperRightAvailable(cuDepth, cuIndex)     */

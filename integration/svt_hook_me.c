@@ -557,10 +557,107 @@ static EB_ERRORTYPE intra_gen(int is16, EB_BOOL constrained, EB_BOOL strong, EB_
     return g_intra_gen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, cf, pl, pt, pr);
 }
 
+/* intra 4x4 coding units (EbCodingLoop.c:3594-3690): the luma generator per 4x4 partition and the chroma generator once per 8x8
+ * coding unit are reached through two more global tables; their slots stash a size-4 luma job / a size-8 chroma job, and the
+ * prediction slot answers the luma-mask and the chroma-mask calls from them. */
+typedef EB_ERRORTYPE (*LumaGenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
+                                  NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_BOOL, EB_BOOL, EB_BOOL);
+typedef EB_ERRORTYPE (*ChromaGenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
+                                    NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_COLOR_FORMAT, EB_BOOL, EB_BOOL, EB_BOOL, EB_BOOL);
+extern LumaGenFn GenerateLumaIntraReferenceSamplesFuncTable[2];
+extern ChromaGenFn GenerateChromaIntraReferenceSamplesFuncTable[2];
+static LumaGenFn g_intra_lgen[2];
+static ChromaGenFn g_intra_cgen[2];
+static __thread SvtAmdIntraPuJob t_intra4_job[2]; /* [0] luma partition, [1] chroma pair */
+static __thread void *t_intra4_for[2];
+static unsigned long g_intra4_gpu;
+
+static void intra_slices(SvtAmdIntraPuJob *j, int bps, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size,
+                         EB_U32 lcuSize, EB_U32 partitionDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *na[3], int p0, int p1, EB_BOOL pl,
+                         EB_BOOL pt, EB_BOOL pr)
+{
+    memset(j, 0, sizeof(*j));
+    j->size = size, j->constrained_intra = constrained, j->strong_smoothing = strong;
+    j->pic_left = pl, j->pic_top = pt, j->pic_right = pr;
+    uint32_t lg = 0;
+    while ((1u << lg) < size)
+        lg++;
+    const uint32_t cuIndex = ((originY & (lcuSize - 1)) >> lg) * (1u << partitionDepth) + ((originX & (lcuSize - 1)) >> lg);
+    j->bottom_left_ok = isBottomLeftAvailable(partitionDepth, cuIndex), j->top_right_ok = isUpperRightAvailable(partitionDepth, cuIndex);
+    for (uint32_t k = 0; k < 2 * size / 4; k++) {
+        const uint32_t li = GetNeighborArrayUnitLeftIndex(mode, originY + 4 * k), ti = GetNeighborArrayUnitTopIndex(mode, originX + 4 * k);
+        j->mode_left[k] = li >= mode->leftArraySize ? 0xFE : mode->leftArray[li];
+        j->mode_top[k] = ti >= mode->topArraySize ? 0xFE : mode->topArray[ti];
+    }
+    j->mode_tl = mode->topLeftArray[GetNeighborArrayUnitTopLeftIndex(mode, (EB_S32)originX, (EB_S32)originY)];
+    for (int p = p0; p < p1; p++) {
+        const uint32_t sh = p ? 1 : 0, n2 = (2 * size) >> sh, ox = originX >> sh, oy = originY >> sh;
+        for (uint32_t i = 0; i < n2; i++) {
+            const uint32_t k = (i << sh) >> 2;
+            j->left[p][i] = j->mode_left[k] == 0xFE ? 0 : na_rd(na[p]->leftArray, oy + i, bps);
+            j->top[p][i] = j->mode_top[k] == 0xFE ? 0 : na_rd(na[p]->topArray, ox + i, bps);
+        }
+        j->tl[p] = p == 0 ? na_rd(na[0]->topLeftArray, MAX_PICTURE_HEIGHT_SIZE + originX - originY, bps)
+                          : na_rd(na[p]->topLeftArray, ((MAX_PICTURE_HEIGHT_SIZE - originY) >> 1) + (originX >> 1), bps);
+    }
+}
+
+static EB_ERRORTYPE intra_lgen(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                               EB_U32 cuDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *y, NeighborArrayUnit_t *cb, NeighborArrayUnit_t *cr,
+                               void *ref, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
+{
+    t_intra4_for[0] = NULL;
+    if (g_ctx && size == 4) {
+        NeighborArrayUnit_t *na[3] = {y, cb, cr};
+        intra_slices(&t_intra4_job[0], is16 ? 2 : 1, constrained, strong, originX, originY, 4, lcuSize, cuDepth + 1, mode, na, 0, 1, pl, pt, pr);
+        t_intra4_for[0] = ref;
+    }
+    return g_intra_lgen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, pl, pt, pr);
+}
+
+static EB_ERRORTYPE intra_cgen(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                               EB_U32 cuDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *y, NeighborArrayUnit_t *cb, NeighborArrayUnit_t *cr,
+                               void *ref, EB_COLOR_FORMAT cf, EB_BOOL second, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
+{
+    t_intra4_for[1] = NULL;
+    if (g_ctx && size == 8 && cf == EB_YUV420 && !second) {
+        NeighborArrayUnit_t *na[3] = {y, cb, cr};
+        intra_slices(&t_intra4_job[1], is16 ? 2 : 1, constrained, strong, originX, originY, 8, lcuSize, cuDepth, mode, na, 1, 3, pl, pt, pr);
+        t_intra4_for[1] = ref;
+    }
+    return g_intra_cgen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, cf, second, pl, pt, pr);
+}
+
 static EB_ERRORTYPE intra_pred(int is16, void *ref, EB_U32 originX, EB_U32 originY, EB_U32 puSize, EB_U32 puChromaSize,
                                EbPictureBufferDesc_t *pic, EB_COLOR_FORMAT cf, EB_BOOL second, EB_U32 lumaMode, EB_U32 chromaMode,
                                EB_U32 mask)
 {
+    if (puSize == 4 && cf == EB_YUV420 && !second && lumaMode <= 34 &&
+        (mask == PICTURE_BUFFER_DESC_LUMA_MASK || mask == PICTURE_BUFFER_DESC_CHROMA_MASK)) { /* intra 4x4 coding unit */
+        const int c = mask == PICTURE_BUFFER_DESC_CHROMA_MASK;
+        void *stash4 = t_intra4_for[c];
+        t_intra4_for[c] = NULL;
+        if (stash4 && stash4 == ref) {
+            const size_t bps4 = is16 ? 2 : 1;
+            SvtAmdIntraPuJob *j4 = &t_intra4_job[c];
+            j4->luma_mode = (uint8_t)lumaMode, j4->chroma_mode = (uint8_t)chromaMode;
+            pthread_mutex_lock(&g_lock);
+            int rc4;
+            if (!c)
+                rc4 = svt_amd_intra_pu(g_ctx, (int)bps4, j4, pic->bufferY + ((size_t)originY * pic->strideY + originX) * bps4, pic->strideY, NULL,
+                                       NULL, 0);
+            else
+                rc4 = svt_amd_intra_pu(g_ctx, (int)bps4, j4, NULL, 0,
+                                       pic->bufferCb + ((size_t)(originY >> 1) * pic->strideCb + (originX >> 1)) * bps4,
+                                       pic->bufferCr + ((size_t)(originY >> 1) * pic->strideCr + (originX >> 1)) * bps4, pic->strideCb);
+            if (rc4)
+                die("svt_amd_intra_pu (intra 4x4)");
+            if (g_intra4_gpu++ == 0 && g_verbose)
+                fprintf(stderr, "svt_hook_me: encode-pass intra 4x4 prediction on the GPU\n");
+            pthread_mutex_unlock(&g_lock);
+            return EB_ErrorNone;
+        }
+    }
     void *stash = t_intra_for;
     t_intra_for = NULL;
     if (!stash || stash != ref || puSize != t_intra_job.size || second || mask != PICTURE_BUFFER_DESC_FULL_MASK || lumaMode > 34)
@@ -585,6 +682,14 @@ static EB_ERRORTYPE intra_gen16(IGEN_ARGS) { return intra_gen(1, a, b, c, d, e, 
 #define IPRED_ARGS void *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_U32 e, EbPictureBufferDesc_t *f, EB_COLOR_FORMAT g, EB_BOOL h, EB_U32 i, EB_U32 j, EB_U32 k
 static EB_ERRORTYPE intra_pred8(IPRED_ARGS) { return intra_pred(0, a, b, c, d, e, f, g, h, i, j, k); }
 static EB_ERRORTYPE intra_pred16(IPRED_ARGS) { return intra_pred(1, a, b, c, d, e, f, g, h, i, j, k); }
+#define ILGEN_ARGS EB_BOOL a, EB_BOOL b, EB_U32 c, EB_U32 d, EB_U32 e, EB_U32 f, EB_U32 g, NeighborArrayUnit_t *h, NeighborArrayUnit_t *i, \
+                   NeighborArrayUnit_t *j, NeighborArrayUnit_t *k, void *l, EB_BOOL n, EB_BOOL o, EB_BOOL p
+static EB_ERRORTYPE intra_lgen8(ILGEN_ARGS) { return intra_lgen(0, a, b, c, d, e, f, g, h, i, j, k, l, n, o, p); }
+static EB_ERRORTYPE intra_lgen16(ILGEN_ARGS) { return intra_lgen(1, a, b, c, d, e, f, g, h, i, j, k, l, n, o, p); }
+#define ICGEN_ARGS EB_BOOL a, EB_BOOL b, EB_U32 c, EB_U32 d, EB_U32 e, EB_U32 f, EB_U32 g, NeighborArrayUnit_t *h, NeighborArrayUnit_t *i, \
+                   NeighborArrayUnit_t *j, NeighborArrayUnit_t *k, void *l, EB_COLOR_FORMAT m, EB_BOOL q, EB_BOOL n, EB_BOOL o, EB_BOOL p
+static EB_ERRORTYPE intra_cgen8(ICGEN_ARGS) { return intra_cgen(0, a, b, c, d, e, f, g, h, i, j, k, l, m, q, n, o, p); }
+static EB_ERRORTYPE intra_cgen16(ICGEN_ARGS) { return intra_cgen(1, a, b, c, d, e, f, g, h, i, j, k, l, m, q, n, o, p); }
 __attribute__((constructor)) static void intra_install(void)
 {
     if (!getenv("SVT_HOOK_INTRA"))
@@ -593,6 +698,10 @@ __attribute__((constructor)) static void intra_install(void)
     g_intra_pred[0] = EncodePassIntraPredictionFuncTable[0], g_intra_pred[1] = EncodePassIntraPredictionFuncTable[1];
     GenerateIntraReferenceSamplesFuncTable[0] = intra_gen8, GenerateIntraReferenceSamplesFuncTable[1] = intra_gen16;
     EncodePassIntraPredictionFuncTable[0] = intra_pred8, EncodePassIntraPredictionFuncTable[1] = intra_pred16;
+    g_intra_lgen[0] = GenerateLumaIntraReferenceSamplesFuncTable[0], g_intra_lgen[1] = GenerateLumaIntraReferenceSamplesFuncTable[1];
+    g_intra_cgen[0] = GenerateChromaIntraReferenceSamplesFuncTable[0], g_intra_cgen[1] = GenerateChromaIntraReferenceSamplesFuncTable[1];
+    GenerateLumaIntraReferenceSamplesFuncTable[0] = intra_lgen8, GenerateLumaIntraReferenceSamplesFuncTable[1] = intra_lgen16;
+    GenerateChromaIntraReferenceSamplesFuncTable[0] = intra_cgen8, GenerateChromaIntraReferenceSamplesFuncTable[1] = intra_cgen16;
 }
 
 /* Mode-decision side: IntraPredictionCl (EbIntraPrediction.c:3682, reached through ProductPredictionFunTableCl) predicts the

@@ -40,6 +40,15 @@ typedef EB_ERRORTYPE (*GenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, 
                               NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_COLOR_FORMAT, EB_BOOL, EB_BOOL, EB_BOOL);
 typedef EB_ERRORTYPE (*PredFn)(void *, EB_U32, EB_U32, EB_U32, EB_U32, EbPictureBufferDesc_t *, EB_COLOR_FORMAT, EB_BOOL, EB_U32, EB_U32,
                                EB_U32);
+typedef EB_ERRORTYPE (*LumaGenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
+                                  NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_BOOL, EB_BOOL, EB_BOOL);
+typedef EB_ERRORTYPE (*ChromaGenFn)(EB_BOOL, EB_BOOL, EB_U32, EB_U32, EB_U32, EB_U32, EB_U32, NeighborArrayUnit_t *, NeighborArrayUnit_t *,
+                                    NeighborArrayUnit_t *, NeighborArrayUnit_t *, void *, EB_COLOR_FORMAT, EB_BOOL, EB_BOOL, EB_BOOL, EB_BOOL);
+/* the intra 4x4 path of the encode pass (EbCodingLoop.c:3594-3690): luma per 4x4 partition, chroma once per 8x8 coding unit */
+extern LumaGenFn GenerateLumaIntraReferenceSamplesFuncTable[2];
+extern ChromaGenFn GenerateChromaIntraReferenceSamplesFuncTable[2];
+static LumaGenFn g_lgen[2];
+static ChromaGenFn g_cgen[2];
 extern GenFn GenerateIntraReferenceSamplesFuncTable[2];
 extern PredFn EncodePassIntraPredictionFuncTable[2];
 static GenFn g_gen[2];
@@ -62,6 +71,11 @@ static int g_state, g_stride = 7;
 static unsigned long g_calls;
 static __thread IntraRecord *t_pending;
 static __thread void *t_pending_ref;
+static __thread IntraRecord *t_pending4[2]; /* intra 4x4: [0] a 4x4 luma partition, [1] the chroma pair of its 8x8 coding unit */
+static __thread void *t_pending4_ref[2];
+static FILE *g_file4;                        /* SVT_REF_INTRA4_DUMP, every SVT_REF_INTRA4_STRIDE-th generator call (default 5) */
+static int g_state4, g_stride4 = 5;
+static unsigned long g_calls4;
 
 static uint16_t rd(const uint8_t *a, uint32_t i, int bps) { return bps == 1 ? a[i] : ((const uint16_t *)a)[i]; }
 
@@ -121,11 +135,117 @@ static EB_ERRORTYPE gen_wrapper(int is16, EB_BOOL constrained, EB_BOOL strong, E
     return g_gen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, cf, pl, pt, pr);
 }
 
+/* neighbour-array slices of a unit of `size` at (originX, originY) for the planes [p0, p1) */
+static IntraRecord *slices_record(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                                  EB_U32 partitionDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *na[3], int p0, int p1, EB_BOOL pl,
+                                  EB_BOOL pt, EB_BOOL pr)
+{
+    IntraRecord *r = (IntraRecord *)calloc(1, sizeof(*r));
+    const int bps = is16 ? 2 : 1;
+    r->magic = INTRA_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->size = size, r->bytes_per_sample = (uint32_t)bps;
+    r->constrained_intra = constrained, r->strong_smoothing = strong, r->pic_left = pl, r->pic_top = pt, r->pic_right = pr;
+    uint32_t lg = 0;
+    while ((1u << lg) < size)
+        lg++;
+    const uint32_t cuIndex = ((originY & (lcuSize - 1)) >> lg) * (1 << partitionDepth) + ((originX & (lcuSize - 1)) >> lg);
+    r->bottom_left_ok = isBottomLeftAvailable(partitionDepth, cuIndex), r->top_right_ok = isUpperRightAvailable(partitionDepth, cuIndex);
+    for (uint32_t k = 0; k < 2 * size / 4; k++) {
+        const uint32_t li = GetNeighborArrayUnitLeftIndex(mode, originY + 4 * k), ti = GetNeighborArrayUnitTopIndex(mode, originX + 4 * k);
+        r->mode_left[k] = li >= mode->leftArraySize ? 0xFE : mode->leftArray[li];
+        r->mode_top[k] = ti >= mode->topArraySize ? 0xFE : mode->topArray[ti];
+    }
+    r->mode_tl = mode->topLeftArray[GetNeighborArrayUnitTopLeftIndex(mode, (EB_S32)originX, (EB_S32)originY)];
+    for (int p = p0; p < p1; p++) {
+        const uint32_t sh = p ? 1 : 0, n2 = (2 * size) >> sh, ox = originX >> sh, oy = originY >> sh;
+        for (uint32_t i = 0; i < n2; i++) {
+            const uint32_t k = (i << sh) >> 2;
+            r->left[p][i] = r->mode_left[k] == 0xFE ? 0 : rd(na[p]->leftArray, oy + i, bps);
+            r->top[p][i] = r->mode_top[k] == 0xFE ? 0 : rd(na[p]->topArray, ox + i, bps);
+        }
+        r->tl[p] = p == 0 ? rd(na[0]->topLeftArray, MAX_PICTURE_HEIGHT_SIZE + originX - originY, bps)
+                          : rd(na[p]->topLeftArray, ((MAX_PICTURE_HEIGHT_SIZE - originY) >> 1) + (originX >> 1), bps);
+    }
+    return r;
+}
+
+static int take4(void)
+{
+    if (g_state4 == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_state4 == 0) {
+            const char *path = getenv("SVT_REF_INTRA4_DUMP"), *st = getenv("SVT_REF_INTRA4_STRIDE");
+            g_file4 = path ? fopen(path, "wb") : NULL;
+            if (st && atoi(st) > 0)
+                g_stride4 = atoi(st);
+            g_state4 = g_file4 ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (g_state4 < 0)
+        return 0;
+    pthread_mutex_lock(&g_lock);
+    const int take = (g_calls4++ % (unsigned long)g_stride4) == 0;
+    pthread_mutex_unlock(&g_lock);
+    return take;
+}
+
+static EB_ERRORTYPE lgen_wrapper(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                                 EB_U32 cuDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *y, NeighborArrayUnit_t *cb, NeighborArrayUnit_t *cr,
+                                 void *ref, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
+{
+    free(t_pending4[0]);
+    t_pending4[0] = NULL;
+    if (size == 4 && take4()) {
+        NeighborArrayUnit_t *na[3] = {y, cb, cr};
+        t_pending4[0] = slices_record(is16, constrained, strong, originX, originY, 4, lcuSize, cuDepth + 1, mode, na, 0, 1, pl, pt, pr);
+        t_pending4_ref[0] = ref;
+    }
+    return g_lgen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, pl, pt, pr);
+}
+
+static EB_ERRORTYPE cgen_wrapper(int is16, EB_BOOL constrained, EB_BOOL strong, EB_U32 originX, EB_U32 originY, EB_U32 size, EB_U32 lcuSize,
+                                 EB_U32 cuDepth, NeighborArrayUnit_t *mode, NeighborArrayUnit_t *y, NeighborArrayUnit_t *cb, NeighborArrayUnit_t *cr,
+                                 void *ref, EB_COLOR_FORMAT cf, EB_BOOL second, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
+{
+    free(t_pending4[1]);
+    t_pending4[1] = NULL;
+    if (size == 8 && cf == EB_YUV420 && !second && take4()) {
+        NeighborArrayUnit_t *na[3] = {y, cb, cr};
+        t_pending4[1] = slices_record(is16, constrained, strong, originX, originY, 8, lcuSize, cuDepth, mode, na, 1, 3, pl, pt, pr);
+        t_pending4_ref[1] = ref;
+    }
+    return g_cgen[is16](constrained, strong, originX, originY, size, lcuSize, cuDepth, mode, y, cb, cr, ref, cf, second, pl, pt, pr);
+}
+
 static EB_ERRORTYPE pred_wrapper(int is16, void *ref, EB_U32 originX, EB_U32 originY, EB_U32 puSize, EB_U32 puChromaSize,
                                  EbPictureBufferDesc_t *pic, EB_COLOR_FORMAT cf, EB_BOOL second, EB_U32 lumaMode, EB_U32 chromaMode,
                                  EB_U32 mask)
 {
     const EB_ERRORTYPE rc = g_pred[is16](ref, originX, originY, puSize, puChromaSize, pic, cf, second, lumaMode, chromaMode, mask);
+    if (puSize == 4 && cf == EB_YUV420 && (mask == PICTURE_BUFFER_DESC_LUMA_MASK || mask == PICTURE_BUFFER_DESC_CHROMA_MASK)) {
+        const int c = mask == PICTURE_BUFFER_DESC_CHROMA_MASK;
+        IntraRecord *q = t_pending4[c];
+        t_pending4[c] = NULL;
+        if (q && t_pending4_ref[c] == ref && !second) {
+            const int bps = (int)q->bytes_per_sample;
+            q->luma_mode = lumaMode, q->chroma_mode = chromaMode, q->component_mask = mask;
+            for (uint32_t yy = 0; yy < 4; yy++)
+                for (uint32_t xx = 0; xx < 4; xx++) {
+                    if (!c) {
+                        q->pred_y[yy * 4 + xx] = rd(pic->bufferY, (originY + yy) * pic->strideY + originX + xx, bps);
+                    } else {
+                        q->pred_cb[yy * 4 + xx] = rd(pic->bufferCb, ((originY >> 1) + yy) * pic->strideCb + (originX >> 1) + xx, bps);
+                        q->pred_cr[yy * 4 + xx] = rd(pic->bufferCr, ((originY >> 1) + yy) * pic->strideCr + (originX >> 1) + xx, bps);
+                    }
+                }
+            pthread_mutex_lock(&g_lock);
+            fwrite(q, sizeof(*q), 1, g_file4);
+            fflush(g_file4);
+            pthread_mutex_unlock(&g_lock);
+        }
+        free(q);
+        return rc;
+    }
     IntraRecord *r = t_pending;
     t_pending = NULL;
     if (!r)
@@ -161,11 +281,24 @@ static EB_ERRORTYPE gen16(GEN_ARGS) { return gen_wrapper(1, a, b, c, d, e, f, g,
 static EB_ERRORTYPE pred8(PRED_ARGS) { return pred_wrapper(0, a, b, c, d, e, f, g, h, i, j, k); }
 static EB_ERRORTYPE pred16(PRED_ARGS) { return pred_wrapper(1, a, b, c, d, e, f, g, h, i, j, k); }
 
+#define LGEN_ARGS EB_BOOL a, EB_BOOL b, EB_U32 c, EB_U32 d, EB_U32 e, EB_U32 f, EB_U32 g, NeighborArrayUnit_t *h, NeighborArrayUnit_t *i, \
+                  NeighborArrayUnit_t *j, NeighborArrayUnit_t *k, void *l, EB_BOOL n, EB_BOOL o, EB_BOOL p
+static EB_ERRORTYPE lgen8(LGEN_ARGS) { return lgen_wrapper(0, a, b, c, d, e, f, g, h, i, j, k, l, n, o, p); }
+static EB_ERRORTYPE lgen16(LGEN_ARGS) { return lgen_wrapper(1, a, b, c, d, e, f, g, h, i, j, k, l, n, o, p); }
+#define CGEN_ARGS EB_BOOL a, EB_BOOL b, EB_U32 c, EB_U32 d, EB_U32 e, EB_U32 f, EB_U32 g, NeighborArrayUnit_t *h, NeighborArrayUnit_t *i, \
+                  NeighborArrayUnit_t *j, NeighborArrayUnit_t *k, void *l, EB_COLOR_FORMAT m, EB_BOOL q, EB_BOOL n, EB_BOOL o, EB_BOOL p
+static EB_ERRORTYPE cgen8(CGEN_ARGS) { return cgen_wrapper(0, a, b, c, d, e, f, g, h, i, j, k, l, m, q, n, o, p); }
+static EB_ERRORTYPE cgen16(CGEN_ARGS) { return cgen_wrapper(1, a, b, c, d, e, f, g, h, i, j, k, l, m, q, n, o, p); }
+
 __attribute__((constructor)) static void install(void)
 {
     g_gen[0] = GenerateIntraReferenceSamplesFuncTable[0], g_gen[1] = GenerateIntraReferenceSamplesFuncTable[1];
     g_pred[0] = EncodePassIntraPredictionFuncTable[0], g_pred[1] = EncodePassIntraPredictionFuncTable[1];
     GenerateIntraReferenceSamplesFuncTable[0] = gen8, GenerateIntraReferenceSamplesFuncTable[1] = gen16;
+    g_lgen[0] = GenerateLumaIntraReferenceSamplesFuncTable[0], g_lgen[1] = GenerateLumaIntraReferenceSamplesFuncTable[1];
+    g_cgen[0] = GenerateChromaIntraReferenceSamplesFuncTable[0], g_cgen[1] = GenerateChromaIntraReferenceSamplesFuncTable[1];
+    GenerateLumaIntraReferenceSamplesFuncTable[0] = lgen8, GenerateLumaIntraReferenceSamplesFuncTable[1] = lgen16;
+    GenerateChromaIntraReferenceSamplesFuncTable[0] = cgen8, GenerateChromaIntraReferenceSamplesFuncTable[1] = cgen16;
     EncodePassIntraPredictionFuncTable[0] = pred8, EncodePassIntraPredictionFuncTable[1] = pred16;
 }
 

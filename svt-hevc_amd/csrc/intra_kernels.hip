@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256) void k_intra_pu(const IntraPuJob *__restrict__
     for (int i = t; i < nY + 2 * nC; i += 256) {
         const int p = i < nY ? 0 : (i < nY + nC ? 1 : 2), e = p == 0 ? i : (p == 1 ? i - nY : i - nY - nC);
         const int n = p ? N >> 1 : N, lg = p ? lgN - 1 : lgN, y = e >> lg, x = e & (n - 1);
+        if (N == 4 && p != 0)
+            continue; /* a 4x4 luma partition has no chroma of its own: the pair belongs to the 8x8 coding unit (a size-8 job) */
         const int v = pu_predict(s_mode[p], n, lg, ref[p], x, y, s_dc[p], p == 0, maxv);
         if (p == 0)
             pred_y[J.dst_off_y + (size_t)y * strideY + x] = (T)v;
@@ -351,7 +353,8 @@ extern "C" int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const 
 {
     const bool wantY = pred_y != nullptr, wantC = pred_cb != nullptr && pred_cr != nullptr;
     if (!ctx || !job || (!wantY && !wantC) || (!pred_cb) != (!pred_cr) || (bytes_per_sample != 1 && bytes_per_sample != 2) ||
-        (job->size != 8 && job->size != 16 && job->size != 32) || (wantY && strideY < job->size) || (wantC && strideC < job->size / 2))
+        (job->size != 4 && job->size != 8 && job->size != 16 && job->size != 32) || (job->size == 4 && wantC) ||
+        (wantY && strideY < job->size) || (wantC && strideC < job->size / 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     static uint8_t *d_scratch = nullptr; /* job | Y 32x32 | Cb 16x16 | Cr 16x16 (16-bit worst case) */

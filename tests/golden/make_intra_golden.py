@@ -48,6 +48,12 @@ OL_CASES = {
     "p_noise_200x136_m9": ("noise", 200, 136, 5, 11, ["-encMode", "9", "-pred-struct", "0", "-hierarchical-levels", "1", "-q", "28"], 1, 240),
     "b_noise_200x136_m4": ("noise", 200, 136, 9, 11, ["-encMode", "4", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "26"], 13, 300),
 }
+# intra 4x4 coding units of the encode pass (encMode <= 2): a 4x4 luma partition (size 4, component_mask 1) or the chroma pair of
+# its 8x8 coding unit (size 8, component_mask 6; the predicted chroma blocks are 4x4)
+I4_CASES = {
+    "i_noise_200x136_m1": ("noise", 200, 136, 2, 11, 8, ["-encMode", "1", "-intra-period", "0", "-q", "24"], 3, 300),
+    "i10_motion_416x240_m2": ("motion", 416, 240, 1, 7, 10, ["-encMode", "2", "-intra-period", "0", "-q", "22", "-bit-depth", "10"], 3, 240),
+}
 KEEP = ("size", "bytes_per_sample", "constrained_intra", "strong_smoothing", "pic_left", "pic_top", "pic_right", "bottom_left_ok",
         "top_right_ok", "luma_mode", "chroma_mode", "mode_left", "mode_top", "mode_tl", "left", "top", "tl")
 
@@ -78,6 +84,34 @@ def run_case(name):
            len(np.unique(recs["luma_mode"])), int(recs["pic_left"].sum()), int(recs["pic_top"].sum()), int(recs["pic_right"].sum()),
            int(recs["bottom_left_ok"].sum()), int(recs["top_right_ok"].sum()),
            int(((recs["mode_left"] == 1).any(axis=1) | (recs["mode_top"] == 1).any(axis=1)).sum()), int(recs["constrained_intra"].sum())))
+
+
+def run_i4_case(name):
+    kind, w, h, n, seed, depth, args, stride, keep = I4_CASES[name]
+    with tempfile.TemporaryDirectory() as td:
+        yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "intra4.dump")
+        (S.write_clip10 if depth == 10 else S.write_clip)(yuv, kind, w, h, n, seed)
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + args
+        subprocess.run(cmd, env=dict(os.environ, SVT_REF_INTRA4_DUMP=dump, SVT_REF_INTRA4_STRIDE=str(stride)), check=True,
+                       stdout=subprocess.DEVNULL)
+        recs = np.fromfile(dump, dtype=REC)
+    assert len(recs) and (recs["record_size"] == REC.itemsize).all(), (len(recs), REC.itemsize)
+    total = len(recs)
+    groups = [np.flatnonzero(recs["component_mask"] == m) for m in np.unique(recs["component_mask"])]
+    groups = [g[np.argsort(recs["luma_mode"][g], kind="stable")] for g in groups if len(g)]
+    share = keep // len(groups)
+    sel = np.concatenate([g[np.linspace(0, len(g) - 1, min(share, len(g))).astype(int)] for g in groups])
+    recs = recs[np.sort(np.unique(sel))]
+    out = {k: recs[k] for k in KEEP + ("component_mask",)}
+    out["pred_y"] = np.concatenate([r["pred_y"][: int(r["size"]) ** 2] for r in recs])
+    out["pred_cb"] = np.concatenate([r["pred_cb"][: (int(r["size"]) // 2) ** 2] for r in recs])
+    out["pred_cr"] = np.concatenate([r["pred_cr"][: (int(r["size"]) // 2) ** 2] for r in recs])
+    path = os.path.join(S.GOLDEN_DIR, "intra4_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-26s %d of %d records (luma 4x4 %d / chroma pairs %d) -> %s (%.0f KiB); %d luma modes, edges L/T/R %d/%d/%d, bl/tr ok %d/%d" %
+          (name, len(recs), total, int((recs["component_mask"] == 1).sum()), int((recs["component_mask"] != 1).sum()),
+           os.path.basename(path), os.path.getsize(path) / 1024, len(np.unique(recs["luma_mode"])), int(recs["pic_left"].sum()),
+           int(recs["pic_top"].sum()), int(recs["pic_right"].sum()), int(recs["bottom_left_ok"].sum()), int(recs["top_right_ok"].sum())))
 
 
 def run_md_case(name, ol=False):
@@ -118,11 +152,13 @@ def run_md_case(name, ol=False):
 if __name__ == "__main__":
     if not os.path.exists(S.REF_APP):
         sys.exit("oracle/_ref/SvtHevcEncApp_ref missing: run `make -C oracle ref` (needs /root/reference)")
-    names = sys.argv[1:] or (list(CASES) + ["md:" + k for k in MD_CASES] + ["ol:" + k for k in OL_CASES])
+    names = sys.argv[1:] or (list(CASES) + ["md:" + k for k in MD_CASES] + ["ol:" + k for k in OL_CASES] + ["i4:" + k for k in I4_CASES])
     for nm in names:
         if nm.startswith("md:"):
             run_md_case(nm[3:])
         elif nm.startswith("ol:"):
             run_md_case(nm[3:], ol=True)
+        elif nm.startswith("i4:"):
+            run_i4_case(nm[3:])
         else:
             run_case(nm)

@@ -98,6 +98,32 @@ def test_intra_pu_matches_mode_decision_records(product, gpu_ctx):
     assert product.svt_amd_intra_pu(gpu_ctx, 1, j.ctypes.data, None, 0, j.ctypes.data, None, 32) != 0
 
 
+def test_intra_pu_matches_intra4x4_records(product, gpu_ctx):
+    """intra 4x4 coding units of the encode pass: size-4 jobs (luma partition) and size-8 jobs (the coding unit's chroma pair),
+    through the per-call host form the binding uses"""
+    from test_oracle_intra4_golden import CASES as I4_CASES, load_intra4_case
+    product.svt_amd_intra_pu.argtypes = [vp, C.c_int, vp, vp, u32, vp, vp, u32]
+    assert len(I4_CASES) == 2
+    for name in I4_CASES:
+        g = load_intra4_case(name)
+        for i in range(len(g["size"])):
+            bps, mask = int(g["bytes_per_sample"][i]), int(g["component_mask"][i])
+            dt = np.uint8 if bps == 1 else np.uint16
+            want, j = want_of(g, i), job_of(g, i)
+            if mask == 1:
+                y = np.full((4, 16), 0xAA, dt)
+                rc = product.svt_amd_intra_pu(gpu_ctx, bps, j.ctypes.data, y.ctypes.data, 16, None, None, 0)
+                assert rc == 0 and np.array_equal(y[:, :4], want[0]) and (y[:, 4:] == 0xAA).all(), (name, i, int(g["luma_mode"][i]))
+            else:
+                cb, cr = np.full((4, 8), 0xAA, dt), np.full((4, 8), 0xAA, dt)
+                rc = product.svt_amd_intra_pu(gpu_ctx, bps, j.ctypes.data, None, 0, cb.ctypes.data, cr.ctypes.data, 8)
+                assert rc == 0 and np.array_equal(cb[:, :4], want[1]) and np.array_equal(cr[:, :4], want[2]), (name, i)
+    j = job_of(load_intra4_case(I4_CASES[0]), 0)
+    j["size"] = 4
+    buf = np.zeros((8, 8), np.uint8)
+    assert product.svt_amd_intra_pu(gpu_ctx, 1, j.ctypes.data, buf.ctypes.data, 8, buf.ctypes.data, buf.ctypes.data, 8) != 0   # 4x4: luma only
+
+
 def random_jobs(rng, n, bps):
     maxv = 255 if bps == 1 else 1023
     jobs = np.zeros(n, JOB)
