@@ -133,7 +133,7 @@ __device__ __forceinline__ void pm_core_blocks(const int16_t *cf_lds, int16_t *l
  * plane).  One wave per workgroup; the wave's 64 / N unit sequences run side by side, each on its own N lanes; a
  * 64x64 CU's sequence has four units (all others one).  No workgroup barrier anywhere: a unit never leaves its wave. */
 template <int N, bool CHROMA, bool PM>
-__global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_all, const int16_t *__restrict__ residual,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))) void k_full_loop(const void *__restrict__ in_all, const int16_t *__restrict__ residual,
                                                   int16_t *__restrict__ quant, int16_t *__restrict__ recon,
                                                   void *__restrict__ out_all, uint32_t ncand, int shift1, int shift2,
                                                   int wrap_levels)
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(64) void k_full_loop(const void *__restrict__ in_al
 #pragma unroll
                     for (int j = 0; j < N; j++) {
                         if (j < S.area) {
-                            const int v = x[j], qv = (int)Fq[u][j * N + r];
+                            /* the coefficient comes back from the tile: x[] need not stay in registers across the re-decision */
+                            const int v = (int)tile[j * N + r], qv = (int)Fq[u][j * N + r];
                             const int rv = clip16i(((qv * S.shiftedFFunc) + S.iq_offset) >> S.shiftNum);
                             quant[S.base + j * S.pitch + r] = (int16_t)qv;
                             recon[S.base + j * S.pitch + r] = (int16_t)rv;
