@@ -726,89 +726,99 @@ __device__ __forceinline__ int64_t sao_merge_dist_f(const SaoMergeCand &N, int c
         d += sao_dist((int)N.offset[comp][k], f.diff[k], f.cnt[k]);
     return d;
 }
-/* One workgroup, thread y walks LCU row y: at step d it finishes LCU (d - y, y).  Both merge candidates of that LCU were
- * finished at step d - 1 - the left one by the same thread, the upper one by thread y - 1 - so the final parameters travel
- * through two LDS lines (previous / current anti-diagonal, indexed by row) and HBM only sees each LCU's own record once
- * in and once out.  MAXR rows fit the LDS lines; taller pictures take the generic kernel below. */
+/* One workgroup; eight lanes walk LCU row y together: at step d they finish LCU (d - y, y).  Both merge candidates of that LCU
+ * were finished at step d - 1 - the left one by the same lanes, the upper one by the lanes of row y - 1 - so the final
+ * parameters travel through two LDS lines (previous / current anti-diagonal, indexed by row) and HBM only sees each LCU's own
+ * record once in and once out.  Lanes 0..2 of a row price the left candidate's three components, lanes 3..5 the upper one's
+ * (their eight statistics come from wherever the candidate's type and band point: one HBM round trip per step, which is what
+ * a step costs - about 2 us, profiles/r01_m_leaf_kernel_stats.txt), lane 0 decides; it also fetches the next LCU's record
+ * one step ahead.  MAXR rows fit the LDS lines; taller pictures take the generic kernel below. */
 template <int MAXR>
-__global__ void __launch_bounds__(MAXR) k_sao_decide_merge_lds(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
-                                                               uint32_t cols, uint32_t rows, const uint8_t *enable, SaoLcuParams *params,
-                                                               int64_t *costs)
+__global__ void __launch_bounds__(MAXR * 8) k_sao_decide_merge_lds(SaoDecide P, const SaoStats *sy, const SaoStats *scb, const SaoStats *scr,
+                                                                   uint32_t cols, uint32_t rows, const uint8_t *enable, SaoLcuParams *params,
+                                                                   int64_t *costs)
 {
     __shared__ SaoMergeCand line[2][MAXR];
     const int sh = P.is10 ? 4 : 0;
     const int64_t maxc = (int64_t)(~0ull >> 1);
-    const uint32_t y = threadIdx.x;
+    const uint32_t y = threadIdx.x >> 3, l = threadIdx.x & 7, lead = (threadIdx.x & 63) & ~7u; /* lane of the row's lane 0 inside the wave */
     const int64_t rMerge = sao_rate_cost(P.mergeBits[1], P.lambda);
-    /* the next LCU's record and costs are fetched one step ahead */
     SaoLcuParams nxt;
     int64_t nLuma = 0, nChroma = 0;
     uint32_t nEn = 0;
-    if (y < rows && y == 0) {
+    if (l == 0 && y == 0 && rows)
         nxt = params[0], nLuma = costs[0], nChroma = costs[1], nEn = enable ? enable[0] : 1;
-    }
     for (uint32_t d = 0; d < cols + rows - 1; d++) {
         const uint32_t x = d - y;
         const bool mine = y < rows && y <= d && x < cols;
         const uint32_t i = mine ? y * cols + x : 0;
-        SaoLcuParams o = nxt;
-        int64_t luma = nLuma, chroma = nChroma;
-        const uint32_t en = nEn;
-        /* prefetch for step d + 1: LCU (x + 1, y), or the row's first one */
-        {
-            const uint32_t xn = d + 1 - y;
+        SaoLcuParams o;
+        int64_t luma = 0, chroma = 0;
+        uint32_t en = 0;
+        if (l == 0) {
+            o = nxt, luma = nLuma, chroma = nChroma, en = nEn;
+            const uint32_t xn = d + 1 - y; /* prefetch for step d + 1: LCU (x + 1, y), or the row's first one */
             if (y < rows && y <= d + 1 && xn < cols) {
                 const uint32_t in = y * cols + xn;
                 nxt = params[in], nLuma = costs[2 * in], nChroma = costs[2 * in + 1], nEn = enable ? enable[in] : 1;
             }
         }
-        SaoMergeCand fin;
-        if (mine) {
-            if (en == 1) {
-                const bool hasLeft = !(o.edge_flags & 1) && x > 0, hasUp = !(o.edge_flags & 4) && y > 0;
+        const uint32_t flagsEn = (uint32_t)__shfl((int)(l == 0 ? (en | ((uint32_t)o.edge_flags << 8)) : 0u), (int)lead);
+        const bool active = mine && (flagsEn & 0xff) == 1;
+        const uint32_t edge = flagsEn >> 8;
+        const bool hasLeft = !(edge & 1) && x > 0, hasUp = !(edge & 4) && y > 0;
+        /* lanes 0..5: one (candidate, component) each */
+        int64_t dist = 0;
+        SaoMergeCand N;
+        {
+            const bool up = l >= 3;
+            N = line[(d + 1) & 1][up ? (y ? y - 1 : 0) : y];
+            if (!(up ? hasUp : hasLeft))
+                N.type[0] = N.type[1] = 0;
+            const int comp = up ? (int)l - 3 : (int)l;
+            if (active && l < 6) {
+                const SaoStats *S = (comp == 0 ? sy : comp == 1 ? scb : scr) + i;
+                const SaoMergeFetch f = sao_merge_fetch(N, comp, S);
+                dist = sao_merge_dist_f(N, comp, f);
+            }
+        }
+        /* gather the six distortions in lane 0 of the row */
+        const int64_t d1 = __shfl_down(dist, 1), d2 = __shfl_down(dist, 2), d3 = __shfl_down(dist, 3), d4 = __shfl_down(dist, 4),
+                      d5 = __shfl_down(dist, 5);
+        if (mine && l == 0) {
+            if (active) {
                 const uint64_t leftFlag = hasLeft ? P.mergeBits[0] : 0, upFlag = hasUp ? P.mergeBits[0] : 0;
                 const int64_t flags = sao_rate_cost(leftFlag + upFlag, P.lambda);
                 const int64_t best = luma + chroma + flags;
                 luma += flags, chroma += flags;
                 int64_t lCost = maxc, uCost = maxc, lLuma = 0, lChroma = 0, uLuma = 0, uChroma = 0;
-                SaoMergeCand L = line[(d + 1) & 1][y], U = line[(d + 1) & 1][y ? y - 1 : 0];
-                if (!hasLeft)
-                    L.type[0] = L.type[1] = 0;
-                if (!hasUp)
-                    U.type[0] = U.type[1] = 0;
-                const SaoStats *S3[3] = {sy + i, scb + i, scr + i};
-                SaoMergeFetch fl[3], fu[3];
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    fl[c] = sao_merge_fetch(L, c, S3[c]), fu[c] = sao_merge_fetch(U, c, S3[c]);
                 if (hasLeft) {
-                    const int64_t dl = sao_merge_dist_f(L, 0, fl[0]) >> sh,
-                                  dc = (sao_merge_dist_f(L, 1, fl[1]) + sao_merge_dist_f(L, 2, fl[2])) >> sh;
+                    const int64_t dl = dist >> sh, dc = (d1 + d2) >> sh;
                     lLuma = (dl << 8) + rMerge, lChroma = (dc << 8) + rMerge, lCost = (dl << 8) + (dc << 8) + rMerge;
                 }
                 if (hasUp) {
-                    const int64_t dl = sao_merge_dist_f(U, 0, fu[0]) >> sh,
-                                  dc = (sao_merge_dist_f(U, 1, fu[1]) + sao_merge_dist_f(U, 2, fu[2])) >> sh;
+                    const int64_t dl = d3 >> sh, dc = (d4 + d5) >> sh;
                     const int64_t r = sao_rate_cost(leftFlag + P.mergeBits[1], P.lambda);
                     uLuma = (dl << 8) + r, uChroma = (dc << 8) + r, uCost = (dl << 8) + (dc << 8) + r;
                 }
                 if (lCost < best || uCost < best) {
                     const bool left = lCost <= uCost && hasLeft;
                     if (left || hasUp) {
-                        const SaoMergeCand &N = left ? L : U;
+                        const SaoMergeCand M = line[(d + 1) & 1][left ? y : y - 1];
                         o.merge_left = left, o.merge_up = !left;
                         luma = left ? lLuma : uLuma, chroma = left ? lChroma : uChroma;
-                        o.type[0] = N.type[0], o.type[1] = N.type[1];
+                        o.type[0] = M.type[0], o.type[1] = M.type[1];
                         for (int c = 0; c < 3; c++) {
-                            o.band[c] = N.band[c];
+                            o.band[c] = M.band[c];
                             for (int k = 0; k < 4; k++)
-                                o.offset[c][k] = N.offset[c][k];
+                                o.offset[c][k] = M.offset[c][k];
                         }
                         params[i] = o;
                     }
                 }
                 costs[2 * i] = luma, costs[2 * i + 1] = chroma;
             }
+            SaoMergeCand fin;
             fin.type[0] = (uint8_t)o.type[0], fin.type[1] = (uint8_t)o.type[1];
             for (int c = 0; c < 3; c++) {
                 fin.band[c] = (uint8_t)o.band[c];
@@ -1012,11 +1022,11 @@ extern "C" int svt_amd_sao_decide_picture(SvtAmdContext *ctx, const SvtAmdSaoDec
                        (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, nlcu, d_enable, (SaoLcuParams *)d_params, d_costs);
     if (P.mmSao || P.temporalLayer < 2) {
         if (lcu_rows <= 64)
-            hipLaunchKernelGGL(k_sao_decide_merge_lds<64>, dim3(1), dim3(64), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+            hipLaunchKernelGGL(k_sao_decide_merge_lds<64>, dim3(1), dim3(512), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
                                (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
                                (SaoLcuParams *)d_params, d_costs);
-        else if (lcu_rows <= 256)
-            hipLaunchKernelGGL(k_sao_decide_merge_lds<256>, dim3(1), dim3(256), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
+        else if (lcu_rows <= 128)
+            hipLaunchKernelGGL(k_sao_decide_merge_lds<128>, dim3(1), dim3(1024), 0, ctx->stream, P, (const SaoStats *)d_stats_y,
                                (const SaoStats *)d_stats_cb, (const SaoStats *)d_stats_cr, lcu_cols, lcu_rows, d_enable,
                                (SaoLcuParams *)d_params, d_costs);
         else
