@@ -862,6 +862,48 @@ EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componen
     return EB_ErrorNone;
 }
 
+/* The mode decision's intra 4x4 search: Intra4x4IntraPredictionCl (EbIntraPrediction.c:3993, called per candidate from
+ * PerformIntra4x4Search, EbProductCodingLoop.c:2836) predicts a 4x4 luma partition and, with chroma in the loop, the coding unit's
+ * chroma pair from the references Intra4x4InitFastLoop (:2543) built: luma size 4 at depth 3, no edge flags; chroma at the coding
+ * unit.  Same switch, same jobs as the encode-pass 4x4 path. */
+EB_ERRORTYPE __real_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, EB_U32 puOriginY, EB_U32 puWidth, EB_U32 puHeight, EB_U32 lcuSize,
+                                              EB_U32 componentMask, PictureControlSet_t *pcs, ModeDecisionCandidateBuffer_t *cand, EB_PTR ctx);
+static unsigned long g_md_intra4_gpu;
+
+EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, EB_U32 puOriginY, EB_U32 puWidth, EB_U32 puHeight, EB_U32 lcuSize,
+                                              EB_U32 componentMask, PictureControlSet_t *pcs, ModeDecisionCandidateBuffer_t *cand, EB_PTR ctx)
+{
+    ModeDecisionContext_t *md = (ModeDecisionContext_t *)ctx;
+    if (g_md_intra_state == 0)
+        g_md_intra_state = getenv("SVT_HOOK_INTRA") ? 1 : -1;
+    const uint32_t lumaMode = cand->candidatePtr->intraLumaMode;
+    const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
+    if (g_md_intra_state < 0 || !g_ctx || puWidth != 4 || puHeight != 4 || lcuSize != 64 || md->intraMdOpenLoopFlag || lumaMode > 34 ||
+        !(componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) ||
+        (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK))
+        return __real_Intra4x4IntraPredictionCl(puIndex, puOriginX, puOriginY, puWidth, puHeight, lcuSize, componentMask, pcs, cand, ctx);
+    NeighborArrayUnit_t *na[3] = {md->lumaReconNeighborArray, md->cbReconNeighborArray, md->crReconNeighborArray};
+    EbPictureBufferDesc_t *pred = cand->predictionPtr;
+    SvtAmdIntraPuJob j;
+    intra_slices(&j, 1, EB_FALSE, EB_TRUE, puOriginX, puOriginY, 4, 64, 3 + 1, md->modeTypeNeighborArray, na, 0, 1, EB_FALSE, EB_FALSE, EB_FALSE);
+    j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
+    pthread_mutex_lock(&g_lock);
+    if (svt_amd_intra_pu(g_ctx, 1, &j, pred->bufferY + ((puOriginY & 63) * pred->strideY) + (puOriginX & 63), pred->strideY, NULL, NULL, 0))
+        die("svt_amd_intra_pu (mode decision, 4x4 luma)");
+    if (chromaAsked) {
+        intra_slices(&j, 1, EB_FALSE, EB_TRUE, md->cuOriginX, md->cuOriginY, 8, 64, md->cuDepth, md->modeTypeNeighborArray, na, 1, 3, EB_FALSE,
+                     EB_FALSE, EB_FALSE);
+        j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
+        const uint32_t oc = (((puOriginY & 63) * pred->strideCb) + (puOriginX & 63)) >> 1;
+        if (svt_amd_intra_pu(g_ctx, 1, &j, NULL, 0, pred->bufferCb + oc, pred->bufferCr + oc, pred->strideCb))
+            die("svt_amd_intra_pu (mode decision, 4x4 chroma)");
+    }
+    if (g_md_intra4_gpu++ == 0 && g_verbose)
+        fprintf(stderr, "svt_hook_me: mode-decision intra 4x4 search prediction (Intra4x4IntraPredictionCl) on the GPU\n");
+    pthread_mutex_unlock(&g_lock);
+    return EB_ErrorNone;
+}
+
 /*
  * Encode-pass inter prediction: EncodePassInterPrediction (EbInterPrediction.c:761, called per prediction unit from
  * EbCodingLoop.c:3932) is answered by svt_amd_inter_pu_batch() with SVT_HOOK_INTER=1 (8-bit 4:2:0).  Reference pictures

@@ -195,7 +195,7 @@ static EB_ERRORTYPE lgen_wrapper(int is16, EB_BOOL constrained, EB_BOOL strong, 
 {
     free(t_pending4[0]);
     t_pending4[0] = NULL;
-    if (size == 4 && take4()) {
+    if (size == 4 && !getenv("SVT_REF_INTRA4_MD") && take4()) {
         NeighborArrayUnit_t *na[3] = {y, cb, cr};
         t_pending4[0] = slices_record(is16, constrained, strong, originX, originY, 4, lcuSize, cuDepth + 1, mode, na, 0, 1, pl, pt, pr);
         t_pending4_ref[0] = ref;
@@ -209,7 +209,7 @@ static EB_ERRORTYPE cgen_wrapper(int is16, EB_BOOL constrained, EB_BOOL strong, 
 {
     free(t_pending4[1]);
     t_pending4[1] = NULL;
-    if (size == 8 && cf == EB_YUV420 && !second && take4()) {
+    if (size == 8 && cf == EB_YUV420 && !second && !getenv("SVT_REF_INTRA4_MD") && take4()) {
         NeighborArrayUnit_t *na[3] = {y, cb, cr};
         t_pending4[1] = slices_record(is16, constrained, strong, originX, originY, 8, lcuSize, cuDepth, mode, na, 1, 3, pl, pt, pr);
         t_pending4_ref[1] = ref;
@@ -481,5 +481,48 @@ EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componen
         ol_record(md, pcs, cand, 0);
     if (take && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) == PICTURE_BUFFER_DESC_CHROMA_MASK)
         ol_record(md, pcs, cand, 1);
+    return rc;
+}
+
+/* The mode decision's intra 4x4 search (PerformIntra4x4Search, EbProductCodingLoop.c:2642-2960): Intra4x4InitFastLoop (:2543) builds
+ * the partition's luma reference (size 4, depth 3, no edge flags) and the coding unit's chroma reference from the mode decision's
+ * neighbour arrays, Intra4x4IntraPredictionCl (EbIntraPrediction.c:3993, -Wl,--wrap) predicts every candidate.  Records go to the
+ * SVT_REF_INTRA4_DUMP stream with pad1 = 1. */
+EB_ERRORTYPE __real_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, EB_U32 puOriginY, EB_U32 puWidth, EB_U32 puHeight, EB_U32 lcuSize,
+                                              EB_U32 componentMask, PictureControlSet_t *pcs, ModeDecisionCandidateBuffer_t *cand, EB_PTR ctx);
+EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, EB_U32 puOriginY, EB_U32 puWidth, EB_U32 puHeight, EB_U32 lcuSize,
+                                              EB_U32 componentMask, PictureControlSet_t *pcs, ModeDecisionCandidateBuffer_t *cand, EB_PTR ctx)
+{
+    const EB_ERRORTYPE rc = __real_Intra4x4IntraPredictionCl(puIndex, puOriginX, puOriginY, puWidth, puHeight, lcuSize, componentMask, pcs, cand, ctx);
+    ModeDecisionContext_t *md = (ModeDecisionContext_t *)ctx;
+    if (puWidth != 4 || lcuSize != 64 || md->intraMdOpenLoopFlag || !getenv("SVT_REF_INTRA4_MD") || !take4())
+        return rc;
+    NeighborArrayUnit_t *na[3] = {md->lumaReconNeighborArray, md->cbReconNeighborArray, md->crReconNeighborArray};
+    const EbPictureBufferDesc_t *pred = cand->predictionPtr;
+    for (int c = 0; c < 2; c++) {
+        if (c && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK)
+            break;
+        IntraRecord *q = c ? slices_record(0, EB_FALSE, EB_TRUE, md->cuOriginX, md->cuOriginY, 8, 64, md->cuDepth, md->modeTypeNeighborArray, na, 1, 3,
+                                           EB_FALSE, EB_FALSE, EB_FALSE)
+                           : slices_record(0, EB_FALSE, EB_TRUE, puOriginX, puOriginY, 4, 64, 3 + 1, md->modeTypeNeighborArray, na, 0, 1, EB_FALSE,
+                                           EB_FALSE, EB_FALSE);
+        q->luma_mode = cand->candidatePtr->intraLumaMode, q->chroma_mode = 4, q->pad1 = 1;
+        q->component_mask = c ? PICTURE_BUFFER_DESC_CHROMA_MASK : PICTURE_BUFFER_DESC_LUMA_MASK;
+        const uint32_t oy_ = ((puOriginY & 63) * pred->strideY) + (puOriginX & 63), oc_ = (((puOriginY & 63) * pred->strideCb) + (puOriginX & 63)) >> 1;
+        for (uint32_t yy = 0; yy < 4; yy++)
+            for (uint32_t xx = 0; xx < 4; xx++) {
+                if (!c) {
+                    q->pred_y[yy * 4 + xx] = pred->bufferY[oy_ + yy * pred->strideY + xx];
+                } else {
+                    q->pred_cb[yy * 4 + xx] = pred->bufferCb[oc_ + yy * pred->strideCb + xx];
+                    q->pred_cr[yy * 4 + xx] = pred->bufferCr[oc_ + yy * pred->strideCr + xx];
+                }
+            }
+        pthread_mutex_lock(&g_lock);
+        fwrite(q, sizeof(*q), 1, g_file4);
+        fflush(g_file4);
+        pthread_mutex_unlock(&g_lock);
+        free(q);
+    }
     return rc;
 }

@@ -53,6 +53,8 @@ OL_CASES = {
 I4_CASES = {
     "i_noise_200x136_m1": ("noise", 200, 136, 2, 11, 8, ["-encMode", "1", "-intra-period", "0", "-q", "24"], 3, 300),
     "i10_motion_416x240_m2": ("motion", 416, 240, 1, 7, 10, ["-encMode", "2", "-intra-period", "0", "-q", "22", "-bit-depth", "10"], 3, 240),
+    # the mode decision's 4x4 search (Intra4x4IntraPredictionCl): names starting with "md_"
+    "md_i_noise_200x136_m1": ("noise", 200, 136, 1, 11, 8, ["-encMode", "1", "-intra-period", "0", "-q", "24"], 97, 300),
 }
 KEEP = ("size", "bytes_per_sample", "constrained_intra", "strong_smoothing", "pic_left", "pic_top", "pic_right", "bottom_left_ok",
         "top_right_ok", "luma_mode", "chroma_mode", "mode_left", "mode_top", "mode_tl", "left", "top", "tl")
@@ -92,8 +94,10 @@ def run_i4_case(name):
         yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "intra4.dump")
         (S.write_clip10 if depth == 10 else S.write_clip)(yuv, kind, w, h, n, seed)
         cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + args
-        subprocess.run(cmd, env=dict(os.environ, SVT_REF_INTRA4_DUMP=dump, SVT_REF_INTRA4_STRIDE=str(stride)), check=True,
-                       stdout=subprocess.DEVNULL)
+        env = dict(os.environ, SVT_REF_INTRA4_DUMP=dump, SVT_REF_INTRA4_STRIDE=str(stride))
+        if name.startswith("md_"):
+            env["SVT_REF_INTRA4_MD"] = "1"
+        subprocess.run(cmd, env=env, check=True, stdout=subprocess.DEVNULL)
         recs = np.fromfile(dump, dtype=REC)
     assert len(recs) and (recs["record_size"] == REC.itemsize).all(), (len(recs), REC.itemsize)
     total = len(recs)

@@ -161,6 +161,7 @@ def test_bitstream_and_recon_identical_with_gpu_intra_prediction(tmp_path, kind,
         assert "svt_hook_me: open-loop mode-decision intra prediction (IntraPredictionOl) on the GPU" in log, log[-1000:]
     if args[:2] == ["-encMode", "1"]:   # encMode <= 2: intra 4x4 coding units
         assert "svt_hook_me: encode-pass intra 4x4 prediction on the GPU" in log, log[-1000:]
+        assert "svt_hook_me: mode-decision intra 4x4 search prediction (Intra4x4IntraPredictionCl) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"

@@ -103,7 +103,7 @@ def test_intra_pu_matches_intra4x4_records(product, gpu_ctx):
     through the per-call host form the binding uses"""
     from test_oracle_intra4_golden import CASES as I4_CASES, load_intra4_case
     product.svt_amd_intra_pu.argtypes = [vp, C.c_int, vp, vp, u32, vp, vp, u32]
-    assert len(I4_CASES) == 2
+    assert len(I4_CASES) == 3
     for name in I4_CASES:
         g = load_intra4_case(name)
         for i in range(len(g["size"])):

@@ -24,7 +24,7 @@ def load_intra4_case(name):
 
 
 def test_have_cases():
-    assert len(CASES) == 2
+    assert len(CASES) == 3
 
 
 @pytest.mark.parametrize("name", CASES)
