@@ -87,3 +87,51 @@ def test_fast_loop_distortion_rejects_bad_arguments(product, gpu_ctx):
     assert product.svt_amd_fast_loop_distortion_batch(gpu_ctx, None, 64, None, None, 0, 8, 64, None, None, 0, 8, 1, 8) != 0
     assert product.svt_amd_fast_loop_distortion_batch(gpu_ctx, 8, 64, 8, None, 32, 8, 64, None, None, 0, 8, 1, 8) != 0
     assert product.svt_amd_fast_loop_distortion_batch(gpu_ctx, 8, 64, None, None, 0, 8, 64, None, None, 0, 8, 0, 8) != 0
+
+
+def test_predict_all_then_measure_all_on_the_device(product, gpu_ctx, oracle):
+    """The fast loop's data-parallel part as two launches with nothing crossing PCIe in between: svt_amd_intra_pu_batch predicts every
+    candidate (neighbour slices of real mode-decision records) into device planes, svt_amd_fast_loop_distortion_batch measures them
+    against a source picture; checked against the oracle's prediction + SADs."""
+    import torch
+    from test_oracle_intra_golden import JOB
+    from test_oracle_intramd_golden import CASES as MD_CASES, load_intramd_case, md_job_of
+    g = load_intramd_case(MD_CASES[0])
+    idx = [i for i in range(len(g["size"])) if int(g["component_mask"][i]) == 1][:120]
+    n = len(idx)
+    jobs = np.concatenate([md_job_of(g, i) for i in idx])
+    jobs["dst_off_y"] = np.arange(n) * 32            # candidate k owns columns [32k, 32k + size) of a 32-row prediction plane
+    jobs["dst_off_c"] = np.arange(n) * 16
+    rng = np.random.default_rng(8)
+    srcY = rng.integers(0, 256, (32, 32 * n), dtype=np.uint8)
+    srcC = [rng.integers(0, 256, (16, 16 * n), dtype=np.uint8) for _ in range(2)]
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).copy()).cuda()
+    d_py = torch.zeros((32, 32 * n), dtype=torch.uint8, device="cuda")
+    d_pc = [torch.zeros((16, 16 * n), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_src = [torch.from_numpy(a).cuda() for a in [srcY] + srcC]
+    cands = np.zeros(n, CAND)
+    cands["size"], cands["flags"] = jobs["size"], 1
+    cands["src_off_y"] = cands["pred_off_y"] = jobs["dst_off_y"]
+    cands["src_off_c"] = cands["pred_off_c"] = jobs["dst_off_c"]
+    d_c = torch.from_numpy(cands.view(np.uint8).copy()).cuda()
+    d_o = torch.zeros(n * 8, dtype=torch.uint8, device="cuda")
+    product.svt_amd_intra_pu_batch.argtypes = [vp, C.c_int, vp, u32, vp, u32, vp, vp, u32]
+    product.svt_amd_fast_loop_distortion_batch.argtypes = ARGS
+    torch.cuda.synchronize()
+    # the kernel takes one row pitch per launch: all candidates share the 32 * n wide planes
+    assert product.svt_amd_intra_pu_batch(gpu_ctx, 1, d_jobs.data_ptr(), n, d_py.data_ptr(), 32 * n, d_pc[0].data_ptr(), d_pc[1].data_ptr(),
+                                          16 * n) == 0, product.svt_amd_last_error()
+    assert product.svt_amd_fast_loop_distortion_batch(gpu_ctx, d_src[0].data_ptr(), 32 * n, d_src[1].data_ptr(), d_src[2].data_ptr(), 16 * n,
+                                                      d_py.data_ptr(), 32 * n, d_pc[0].data_ptr(), d_pc[1].data_ptr(), 16 * n, d_c.data_ptr(),
+                                                      n, d_o.data_ptr()) == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    out = d_o.cpu().numpy().view(DIST)
+    oracle.svt_oracle_intra_pu.argtypes = [C.c_int, vp, vp, u32, vp, vp, u32]
+    oracle.svt_oracle_intra_pu.restype = None
+    for k in range(n):
+        z = int(jobs["size"][k])
+        p = [np.zeros((z, z), np.uint8), np.zeros((z // 2, z // 2), np.uint8), np.zeros((z // 2, z // 2), np.uint8)]
+        oracle.svt_oracle_intra_pu(1, jobs[k:k + 1].ctypes.data, p[0].ctypes.data, z, p[1].ctypes.data, p[2].ctypes.data, z // 2)
+        luma = int(np.abs(srcY[:z, 32 * k:32 * k + z].astype(int) - p[0]).sum())
+        chroma = sum(int(np.abs(srcC[c][:z // 2, 16 * k:16 * k + z // 2].astype(int) - p[1 + c]).sum()) for c in range(2))
+        assert (int(out[k]["luma"]), int(out[k]["chroma"])) == (luma, chroma), (k, z, out[k], luma, chroma)
