@@ -53,6 +53,15 @@ static unsigned long g_ois_pictures, g_ois_lcus;
 static uint32_t g_nlcu;
 static unsigned long g_pictures, g_lcus;
 static int g_verbose; /* SVT_HOOK_VERBOSE=1: one stderr line per picture handled on the device */
+/* calls a binding handed back to the reference function (switch off, or outside what the binding covers) */
+static unsigned long g_cpu_EncodePassInterPrediction;
+static unsigned long g_cpu_EncodePassInterPrediction16bit;
+static unsigned long g_cpu_Inter2Nx2NPuPredictionHevc;
+static unsigned long g_cpu_Intra4x4IntraPredictionCl;
+static unsigned long g_cpu_IntraPredictionCl;
+static unsigned long g_cpu_IntraPredictionOl;
+static unsigned long g_cpu_SaoGenerationDecision;
+static unsigned long g_cpu_SaoGenerationDecision16bit;
 static void hook_report(void);
 static void ensure_context(const SequenceControlSet_t *scs);
 
@@ -758,8 +767,10 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
     const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
     if (g_md_intra_state < 0 || !g_ctx || md->intraMdOpenLoopFlag || size < 8 || size > 32 || lumaMode > 34 ||
         (chromaAsked && ((componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK ||
-                         !md->useChromaInformationInFullLoop)))
+                         !md->useChromaInformationInFullLoop))) {
+        __sync_fetch_and_add(&g_cpu_IntraPredictionCl, 1ul);
         return __real_IntraPredictionCl(md, componentMask, pcs, cand);
+    }
     EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr, *pred = cand->predictionPtr;
     SvtAmdIntraPuJob j;
     if (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) {
@@ -822,8 +833,10 @@ EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componen
     const uint32_t size = md->cuStats->size, lumaMode = cand->candidatePtr->intraLumaMode, ox = md->cuOriginX, oy = md->cuOriginY;
     const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
     if (g_md_intra_state < 0 || !g_ctx || !md->intraMdOpenLoopFlag || size < 8 || size > 32 || lumaMode > 34 ||
-        (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK))
+        (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK)) {
+        __sync_fetch_and_add(&g_cpu_IntraPredictionOl, 1ul);
         return __real_IntraPredictionOl(md, componentMask, pcs, cand);
+    }
     EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr, *pred = cand->predictionPtr;
     const uint32_t m = md->lcuPtr->size - 1;
     const int picLeft = md->lcuPtr->lcuEdgeInfoPtr->pictureLeftEdgeFlag == EB_TRUE && (ox & m) == 0;
@@ -880,8 +893,10 @@ EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, 
     const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
     if (g_md_intra_state < 0 || !g_ctx || puWidth != 4 || puHeight != 4 || lcuSize != 64 || md->intraMdOpenLoopFlag || lumaMode > 34 ||
         !(componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) ||
-        (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK))
+        (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK)) {
+        __sync_fetch_and_add(&g_cpu_Intra4x4IntraPredictionCl, 1ul);
         return __real_Intra4x4IntraPredictionCl(puIndex, puOriginX, puOriginY, puWidth, puHeight, lcuSize, componentMask, pcs, cand, ctx);
+    }
     NeighborArrayUnit_t *na[3] = {md->lumaReconNeighborArray, md->cbReconNeighborArray, md->crReconNeighborArray};
     EbPictureBufferDesc_t *pred = cand->predictionPtr;
     SvtAmdIntraPuJob j;
@@ -962,8 +977,10 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
     if (g_inter_state == 0)
         g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
     if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
-        puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr)
+        puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr) {
+        __sync_fetch_and_add(&g_cpu_EncodePassInterPrediction, 1ul);
         return __real_EncodePassInterPrediction(mvUnit, puOriginX, puOriginY, puWidth, puHeight, pcs, predictionPtr, mcpContext);
+    }
     SvtAmdInterPuJob job;
     memset(&job, 0, sizeof(job));
     job.pu_x = puOriginX, job.pu_y = puOriginY, job.pu_w = puWidth, job.pu_h = puHeight, job.pred_dir = mvUnit->predDirection;
@@ -1019,8 +1036,10 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
     if (g_inter_state == 0)
         g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
     if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
-        puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr)
+        puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr) {
+        __sync_fetch_and_add(&g_cpu_EncodePassInterPrediction16bit, 1ul);
         return __real_EncodePassInterPrediction16bit(mvUnit, puOriginX, puOriginY, puWidth, puHeight, pcs, predictionPtr, mcpContext);
+    }
     SvtAmdInterPuJob job;
     memset(&job, 0, sizeof(job));
     job.pu_x = puOriginX, job.pu_y = puOriginY, job.pu_w = puWidth, job.pu_h = puHeight, job.pred_dir = mvUnit->predDirection;
@@ -1082,8 +1101,10 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
     const EB_U32 size = mdContextPtr->cuStats->size, dir = c->predictionDirection[mdContextPtr->puItr];
     EbPictureBufferDesc_t *dst = candidateBufferPtr->predictionPtr;
     if (g_inter_state < 0 || !g_ctx || scs->staticConfig.encoderBitDepth > EB_8BIT || mdContextPtr->cuUseRefSrcFlag || size < 8 || size > 64 ||
-        dir > BI_PRED || dst->strideY != 64 || dst->strideCb != 32 || dst->strideCr != 32)
+        dir > BI_PRED || dst->strideY != 64 || dst->strideCb != 32 || dst->strideCr != 32) {
+        __sync_fetch_and_add(&g_cpu_Inter2Nx2NPuPredictionHevc, 1ul);
         return __real_Inter2Nx2NPuPredictionHevc(mdContextPtr, componentMask, pcs, candidateBufferPtr);
+    }
     SvtAmdInterPuJob job;
     memset(&job, 0, sizeof(job));
     job.pu_x = (uint16_t)mdContextPtr->cuOriginX, job.pu_y = (uint16_t)mdContextPtr->cuOriginY, job.pu_w = job.pu_h = (uint8_t)size;
@@ -1289,9 +1310,11 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision(SaoStats_t *saoStats, SaoParameters_t 
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr;
     const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
         ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture : pcs->reconPicturePtr;
-    if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420)
+    if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420) {
+        __sync_fetch_and_add(&g_cpu_SaoGenerationDecision, 1ul);
         return __real_SaoGenerationDecision(saoStats, saoParams, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, tbOriginX, tbOriginY,
                                             lcuWidth, lcuHeight, saoPtr, leftSaoPtr, upSaoPtr, saoLumaBestCost, saoChromaBestCost);
+    }
     void *ip[3] = {in->bufferY + (in->originY + tbOriginY) * in->strideY + in->originX + tbOriginX,
                    in->bufferCb + (((in->originY + tbOriginY) * in->strideCb) >> 1) + ((in->originX + tbOriginX) >> 1),
                    in->bufferCr + (((in->originY + tbOriginY) * in->strideCr) >> 1) + ((in->originX + tbOriginX) >> 1)};
@@ -1314,10 +1337,12 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
         g_sao_state = getenv("SVT_HOOK_SAO") ? 1 : -1;
     const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
         ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture16bit : pcs->reconPicture16bitPtr;
-    if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420)
+    if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420) {
+        __sync_fetch_and_add(&g_cpu_SaoGenerationDecision16bit, 1ul);
         return __real_SaoGenerationDecision16bit(inputLcuPtr, saoStats, saoParams, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, tbOriginX,
                                                  tbOriginY, lcuWidth, lcuHeight, saoPtr, leftSaoPtr, upSaoPtr, saoLumaBestCost,
                                                  saoChromaBestCost);
+    }
     void *ip[3] = {inputLcuPtr->bufferY, inputLcuPtr->bufferCb, inputLcuPtr->bufferCr};
     void *rp[3] = {(uint16_t *)rec->bufferY + (rec->originY + tbOriginY) * rec->strideY + rec->originX + tbOriginX,
                    (uint16_t *)rec->bufferCb + (((rec->originY + tbOriginY) * rec->strideCb) >> 1) + ((rec->originX + tbOriginX) >> 1),
@@ -1331,6 +1356,20 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
 
 static void hook_report(void)
 {
+    if (g_verbose) {
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", g_cpu_EncodePassInterPrediction);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", g_cpu_EncodePassInterPrediction16bit);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Inter2Nx2NPuPredictionHevc", g_cpu_Inter2Nx2NPuPredictionHevc);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Intra4x4IntraPredictionCl", g_cpu_Intra4x4IntraPredictionCl);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionCl", g_cpu_IntraPredictionCl);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionOl", g_cpu_IntraPredictionOl);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision", g_cpu_SaoGenerationDecision);
+        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision16bit", g_cpu_SaoGenerationDecision16bit);
+        fprintf(stderr, "svt_hook_me: on the GPU: full loop luma %lu (left to the reference code %lu) chroma %lu (%lu), recon %lu, intra encode pass %lu + 4x4 %lu, "
+                        "intra MD closed %lu open %lu 4x4 %lu, inter encode pass %lu + 16-bit %lu, inter MD %lu, quantiser %lu + PM-core %lu, SAO %lu\n",
+                g_fl_gpu, g_fl_cpu, g_cl_gpu, g_cl_cpu, g_recon_gpu, g_intra_gpu, g_intra4_gpu, g_md_intra_gpu, g_md_intra_ol_gpu, g_md_intra4_gpu,
+                g_inter_gpu, g_inter16_gpu, g_md_inter_gpu, g_quant_gpu, g_quant_pm_gpu, g_sao_gpu);
+    }
     fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,
             g_ois_lcus);
     fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs estimated on the GPU, 0 on the CPU\n", g_pictures, g_lcus);
