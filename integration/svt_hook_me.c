@@ -1356,22 +1356,30 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
 
 static void hook_report(void)
 {
+    /* the sample application closes stderr before it returns (EbAppConfig.c:648): the report goes to the file SVT_HOOK_REPORT
+     * names, or to stdout */
+    const char *rp = getenv("SVT_HOOK_REPORT");
+    FILE *out = rp ? fopen(rp, "w") : stdout;
+    if (!out)
+        return;
     if (g_verbose) {
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", g_cpu_EncodePassInterPrediction);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", g_cpu_EncodePassInterPrediction16bit);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Inter2Nx2NPuPredictionHevc", g_cpu_Inter2Nx2NPuPredictionHevc);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Intra4x4IntraPredictionCl", g_cpu_Intra4x4IntraPredictionCl);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionCl", g_cpu_IntraPredictionCl);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionOl", g_cpu_IntraPredictionOl);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision", g_cpu_SaoGenerationDecision);
-        fprintf(stderr, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision16bit", g_cpu_SaoGenerationDecision16bit);
-        fprintf(stderr, "svt_hook_me: on the GPU: full loop luma %lu (left to the reference code %lu) chroma %lu (%lu), recon %lu, intra encode pass %lu + 4x4 %lu, "
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", g_cpu_EncodePassInterPrediction);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", g_cpu_EncodePassInterPrediction16bit);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Inter2Nx2NPuPredictionHevc", g_cpu_Inter2Nx2NPuPredictionHevc);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Intra4x4IntraPredictionCl", g_cpu_Intra4x4IntraPredictionCl);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionCl", g_cpu_IntraPredictionCl);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionOl", g_cpu_IntraPredictionOl);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision", g_cpu_SaoGenerationDecision);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision16bit", g_cpu_SaoGenerationDecision16bit);
+        fprintf(out, "svt_hook_me: on the GPU: full loop luma %lu (left to the reference code %lu) chroma %lu (%lu), recon %lu, intra encode pass %lu + 4x4 %lu, "
                         "intra MD closed %lu open %lu 4x4 %lu, inter encode pass %lu + 16-bit %lu, inter MD %lu, quantiser %lu + PM-core %lu, SAO %lu\n",
                 g_fl_gpu, g_fl_cpu, g_cl_gpu, g_cl_cpu, g_recon_gpu, g_intra_gpu, g_intra4_gpu, g_md_intra_gpu, g_md_intra_ol_gpu, g_md_intra4_gpu,
                 g_inter_gpu, g_inter16_gpu, g_md_inter_gpu, g_quant_gpu, g_quant_pm_gpu, g_sao_gpu);
     }
-    fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,
+    fprintf(out, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,
             g_ois_lcus);
-    fprintf(stderr, "svt_hook_me: %lu pictures / %lu LCUs estimated on the GPU, 0 on the CPU\n", g_pictures, g_lcus);
-    fflush(stderr);
+    fprintf(out, "svt_hook_me: %lu pictures / %lu LCUs estimated on the GPU, 0 on the CPU\n", g_pictures, g_lcus);
+    fflush(out);
+    if (rp)
+        fclose(out);
 }

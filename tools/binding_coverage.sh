@@ -14,9 +14,9 @@ PY
 export SVT_HOOK_VERBOSE=1 SVT_HOOK_FULLLOOP=1 SVT_HOOK_RECON=1 SVT_HOOK_INTRA=1 SVT_HOOK_INTER=1 SVT_HOOK_QUANT=1 SVT_HOOK_SAO=1
 run() { # tag yuv frames args...
   tag=$1; yuv=$2; n=$3; shift 3
-  timeout 200 integration/_build/SvtHevcEncApp_hip -i $yuv -w 416 -h 240 -n $n -q 32 -asm 0 -b /tmp/cov.265 "$@" > /dev/null 2> $O/$tag.err < /dev/null
+  SVT_HOOK_REPORT=$O/$tag.report timeout 200 integration/_build/SvtHevcEncApp_hip -i $yuv -w 416 -h 240 -n $n -q 32 -asm 0 -b /tmp/cov.265 "$@" > /dev/null 2> $O/$tag.err < /dev/null
   echo "== $tag: $*" >> $O/coverage.txt
-  grep -E "on the GPU:|calls left to the reference|pictures /" $O/$tag.err >> $O/coverage.txt
+  cat $O/$tag.report >> $O/coverage.txt
 }
 : > $O/coverage.txt
 run m9_ldp /tmp/cov8.yuv 9 -encMode 9 -pred-struct 0
