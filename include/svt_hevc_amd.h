@@ -258,6 +258,37 @@ typedef struct SvtAmdZzLcu {
 } SvtAmdZzLcu;
 SVT_AMD_API int svt_amd_zz_sad_picture(SvtAmdContext *ctx, int cur_slot, int prev_slot, SvtAmdZzLcu *out);
 
+/*
+ * Front-end pipeline (the asynchronous product path of the batched boundary `hip_me_picture`): replaces, per
+ * picture, the LCU loops of MotionEstimationKernel (Codec/EbMotionEstimationProcess.c:706-820) with
+ *     upload (pinned staging, asynchronous H2D) -> plane building -> ME of both lists -> OIS -> results into pinned host
+ *     memory (asynchronous D2H)
+ * queued on ONE stream ("lane") and overlapped with the other lanes' copies and kernels.  A lane is a context forked from
+ * the one that owns the picture slots (svt_amd_context_fork): all lanes see the same slots, each has its own stream,
+ * descriptors, timers and pinned result buffers.  The owning context is itself a lane.  Calls on one lane are serialised by
+ * the caller; different lanes may be driven from different threads.
+ *   svt_amd_picture_upload_async  copies `luma` into pinned staging before returning (caller may reuse it), queues the rest
+ *   svt_amd_frontend_submit       queues ME (has_me) and/or OIS (has_ois) of cur_slot + the result copies; never blocks
+ *   svt_amd_frontend_wait         blocks until the lane's job is complete; *me / *ois point at the lane's pinned buffers
+ *                                 (one record per LCU, raster order), valid until svt_amd_frontend_release
+ */
+typedef struct SvtAmdFrontendJob {
+    int32_t cur_slot;
+    int32_t ref_slot[2];
+    uint8_t has_me;            /* P / B pictures */
+    uint8_t has_ois;
+    uint8_t pad[2];
+    SvtAmdMeParams me;
+    SvtAmdOisParams ois;
+} SvtAmdFrontendJob;
+SVT_AMD_API int svt_amd_context_fork(SvtAmdContext *parent, SvtAmdContext **out_lane);
+SVT_AMD_API int svt_amd_picture_upload_async(SvtAmdContext *lane, int slot, const uint8_t *luma, uint32_t stride,
+                                             uint16_t width, uint16_t height);
+SVT_AMD_API int svt_amd_picture_publish(SvtAmdContext *lane, int slot);
+SVT_AMD_API int svt_amd_frontend_submit(SvtAmdContext *lane, const SvtAmdFrontendJob *job);
+SVT_AMD_API int svt_amd_frontend_wait(SvtAmdContext *lane, const SvtAmdMeLcuResult **me, const SvtAmdOisLcuResult **ois);
+SVT_AMD_API int svt_amd_frontend_release(SvtAmdContext *lane);
+
 /* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
 typedef struct SvtAmdOisJob {
     SvtAmdOisParams params;

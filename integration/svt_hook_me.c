@@ -15,6 +15,7 @@
  * Contains no reference source.
  */
 #include <pthread.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,13 +43,32 @@
 #include "../include/svt_hevc_amd.h"
 
 #define NSLOTS 48   /* device picture slots, keyed by pictureNumber % NSLOTS */
-#define NRESULTS 32 /* host result sets in flight */
+#define NLANES 8    /* front-end lanes = pictures whose ME / OIS results are in flight or being served */
+
+/*
+ * Front half, pipelined: a picture's first MotionEstimateLcu / OpenLoopIntraSearchLcu call claims a LANE (its own HIP stream
+ * and pinned result buffers, include/svt_hevc_amd.h "Front-end pipeline"), queues upload -> planes -> ME -> OIS -> result copies
+ * on it and only then waits for that lane's completion event; threads of other pictures run their own lanes meanwhile, so copies
+ * and kernels of neighbouring pictures overlap and nobody waits under the table lock.  A lane is released when every LCU of its
+ * picture has been served (both loops of EbMotionEstimationProcess.c:706-820), which is what sizes the table safely.
+ */
+typedef struct {
+    SvtAmdContext *lane;
+    uint64_t pic;
+    int state;                       /* 0 free, 1 submitted */
+    unsigned gen;                    /* claims so far: tells a thread's cached entry from a re-used lane */
+    const SvtAmdMeLcuResult *me;     /* pinned, valid while state == 1 */
+    const SvtAmdOisLcuResult *ois;
+    unsigned me_left, ois_left;      /* LCUs still to serve (atomics) */
+    SvtAmdOisParams oisp;
+} FrontEntry;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_front_lock = PTHREAD_MUTEX_INITIALIZER; /* entry table + slot table */
+static pthread_cond_t g_front_cv = PTHREAD_COND_INITIALIZER;
 static SvtAmdContext *g_ctx;
+static FrontEntry g_front[NLANES];
 static uint64_t g_slot_pic[NSLOTS];
-static struct { uint64_t pic; int valid; SvtAmdMeLcuResult *res; } g_results[NRESULTS];
-static struct { uint64_t pic; int valid; SvtAmdOisLcuResult *res; } g_ois[NRESULTS];
 static unsigned long g_ois_pictures, g_ois_lcus;
 static uint32_t g_nlcu;
 static unsigned long g_pictures, g_lcus;
@@ -63,7 +83,7 @@ static unsigned long g_cpu_IntraPredictionOl;
 static unsigned long g_cpu_SaoGenerationDecision;
 static unsigned long g_cpu_SaoGenerationDecision16bit;
 static void hook_report(void);
-static void ensure_context(const SequenceControlSet_t *scs);
+static void ensure_context(uint16_t lumaWidth, uint16_t lumaHeight);
 
 static void die(const char *what)
 {
@@ -71,14 +91,25 @@ static void die(const char *what)
     abort();
 }
 
-/* `padded`: any picture buffer whose luma is the source picture (PA padded copy or the enhanced input) */
-static int ensure_uploaded(uint64_t pic, const EbPictureBufferDesc_t *padded)
+/* The rate tables handed to the device are the reference's CabacCost_t, field for field */
+_Static_assert(sizeof(CabacCost_t) == sizeof(SvtAmdCabacCost), "CabacCost_t layout");
+_Static_assert(offsetof(CabacCost_t, CabacBitsLast) == offsetof(SvtAmdCabacCost, CabacBitsLast), "CabacBitsLast");
+_Static_assert(offsetof(CabacCost_t, CabacBitsSig) == offsetof(SvtAmdCabacCost, CabacBitsSig), "CabacBitsSig");
+_Static_assert(offsetof(CabacCost_t, CabacBitsG1) == offsetof(SvtAmdCabacCost, CabacBitsG1), "CabacBitsG1");
+_Static_assert(offsetof(CabacCost_t, CabacBitsG2) == offsetof(SvtAmdCabacCost, CabacBitsG2), "CabacBitsG2");
+_Static_assert(offsetof(CabacCost_t, CabacBitsSigMl) == offsetof(SvtAmdCabacCost, CabacBitsSigMl), "CabacBitsSigMl");
+_Static_assert(offsetof(CabacCost_t, CabacBitsG1x) == offsetof(SvtAmdCabacCost, CabacBitsG1x), "CabacBitsG1x");
+_Static_assert(offsetof(CabacCost_t, CabacBitsSigV) == offsetof(SvtAmdCabacCost, CabacBitsSigV), "CabacBitsSigV");
+
+/* `padded`: any picture buffer whose luma is the source picture (PA padded copy or the enhanced input).  Called under
+ * g_front_lock; queues the upload on `lane` unless the slot already holds (or is already being filled with) the picture. */
+static int ensure_uploaded(SvtAmdContext *lane, uint64_t pic, const EbPictureBufferDesc_t *padded)
 {
     const int slot = (int)(pic % NSLOTS);
     if (g_slot_pic[slot] != pic + 1) {
         const uint8_t *luma = padded->bufferY + (size_t)padded->originY * padded->strideY + padded->originX;
-        if (svt_amd_picture_upload(g_ctx, slot, luma, padded->strideY, padded->width, padded->height))
-            die("svt_amd_picture_upload");
+        if (svt_amd_picture_upload_async(lane, slot, luma, padded->strideY, padded->width, padded->height))
+            die("svt_amd_picture_upload_async");
         g_slot_pic[slot] = pic + 1;
     }
     return slot;
@@ -126,35 +157,118 @@ static void fill_params(SvtAmdMeParams *p, const PictureParentControlSet_t *pcs,
         p->mvd_bits[k] = ctx->mvdBitsArray[k];
 }
 
-/* runs the whole picture on the GPU once; returns the cached result set */
-static const SvtAmdMeLcuResult *picture_results(PictureParentControlSet_t *pcs, MeContext_t *ctx)
+/* The open-loop intra search controls of a picture.  At the picture's first MotionEstimateLcu call only MeContext_t is at hand,
+ * so the three MotionEstimationContext_t values are derived as SignalDerivationMeKernelOq does
+ * (Codec/EbMotionEstimationProcess.c:356-396); every OpenLoopIntraSearchLcu call checks them against the context it is given. */
+static void fill_ois_params(SvtAmdOisParams *p, const PictureParentControlSet_t *pcs, const SequenceControlSet_t *scs)
 {
-    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    memset(p, 0, sizeof(*p));
+    p->luma_width = scs->lumaWidth;
+    p->luma_height = scs->lumaHeight;
+    p->slice_is_intra = pcs->sliceType == EB_I_PICTURE;
+    p->temporal_layer_index = pcs->temporalLayerIndex;
+    p->limit_ois_to_dc_mode = pcs->limitOisToDcModeFlag;
+    p->skip_ois_8x8 = pcs->skipOis8x8;
+    p->cu8x8_mode = pcs->cu8x8Mode;
+    p->ois_kernel_level = pcs->encMode <= ENC_MODE_4 && scs->inputResolution < INPUT_SIZE_4K_RANGE && pcs->temporalLayerIndex == 0;
+    if (scs->inputResolution == INPUT_SIZE_4K_RANGE)
+        p->ois_th_set = (pcs->encMode <= ENC_MODE_5 && pcs->isUsedAsReferenceFlag == EB_TRUE) ? 2 : 1;
+    else
+        p->ois_th_set = pcs->encMode <= ENC_MODE_6 ? 2 : 1;
+    p->set_best_ois_distortion_to_valid = 0;
+}
+
+/* The picture's lane entry: claims a lane and queues the whole front half on first touch; returns with the results complete.
+ * `me_ctx` is NULL when the first touch is an OIS call (I pictures never reach MotionEstimateLcu). */
+static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t *me_ctx, const EbPictureBufferDesc_t *inputPtr)
+{
+    static __thread FrontEntry *cached;
+    static __thread unsigned cached_gen;
     const uint64_t pic = pcs->pictureNumber;
-    const int e = (int)(pic % NRESULTS);
-    if (g_results[e].valid && g_results[e].pic == pic)
-        return g_results[e].res;
-    ensure_context(scs);
-    if (!g_results[e].res && !(g_results[e].res = (SvtAmdMeLcuResult *)malloc(sizeof(SvtAmdMeLcuResult) * g_nlcu)))
-        die("malloc");
-    const int nlists = (pcs->sliceType == EB_P_PICTURE) ? 1 : 2;
-    EbPaReferenceObject_t *cur = (EbPaReferenceObject_t *)pcs->paReferencePictureWrapperPtr->objectPtr;
-    const int cur_slot = ensure_uploaded(pic, cur->inputPaddedPicturePtr);
-    int ref_slot[2] = {0, 0};
-    for (int l = 0; l < nlists; l++) {
-        EbPaReferenceObject_t *ro = (EbPaReferenceObject_t *)pcs->refPaPicPtrArray[l]->objectPtr;
-        ref_slot[l] = ensure_uploaded(pcs->refPicPocArray[l], ro->inputPaddedPicturePtr);
+    FrontEntry *e = cached;
+    if (e && __atomic_load_n(&e->state, __ATOMIC_ACQUIRE) == 1 && e->pic == pic && e->gen == cached_gen)
+        return e; /* this thread already waited for it */
+    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    pthread_mutex_lock(&g_front_lock);
+    ensure_context(scs->lumaWidth, scs->lumaHeight);
+    g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
+    for (;;) {
+        e = NULL;
+        FrontEntry *fr = NULL;
+        for (int i = 0; i < NLANES; i++) {
+            if (g_front[i].state == 1 && g_front[i].pic == pic)
+                e = &g_front[i];
+            else if (g_front[i].state == 0 && !fr)
+                fr = &g_front[i];
+        }
+        if (e)
+            break;
+        if (fr) {
+            e = fr;
+            const int intra = pcs->sliceType == EB_I_PICTURE;
+            if (!intra && !me_ctx)
+                die("front_entry: OIS before ME on a non-intra picture (unexpected call order)");
+            SvtAmdFrontendJob job;
+            memset(&job, 0, sizeof(job));
+            if (intra) {
+                job.cur_slot = ensure_uploaded(e->lane, pic, inputPtr);
+            } else {
+                const int nlists = (pcs->sliceType == EB_P_PICTURE) ? 1 : 2;
+                EbPaReferenceObject_t *cur = (EbPaReferenceObject_t *)pcs->paReferencePictureWrapperPtr->objectPtr;
+                job.cur_slot = ensure_uploaded(e->lane, pic, cur->inputPaddedPicturePtr);
+                for (int l = 0; l < nlists; l++) {
+                    EbPaReferenceObject_t *ro = (EbPaReferenceObject_t *)pcs->refPaPicPtrArray[l]->objectPtr;
+                    job.ref_slot[l] = ensure_uploaded(e->lane, pcs->refPicPocArray[l], ro->inputPaddedPicturePtr);
+                }
+                job.has_me = 1;
+                fill_params(&job.me, pcs, scs, me_ctx);
+            }
+            job.has_ois = 1;
+            fill_ois_params(&job.ois, pcs, scs);
+            if (svt_amd_frontend_submit(e->lane, &job))
+                die("svt_amd_frontend_submit");
+            e->oisp = job.ois;
+            e->pic = pic;
+            e->me_left = intra ? 0 : g_nlcu;
+            e->ois_left = g_nlcu;
+            e->me = NULL, e->ois = NULL;
+            e->gen++;
+            if (!intra)
+                g_pictures++;
+            g_ois_pictures++;
+            if (g_verbose) {
+                if (!intra)
+                    fprintf(stderr, "svt_hook_me: ME picture %llu on the GPU (%u LCUs)\n", (unsigned long long)pic, g_nlcu);
+                fprintf(stderr, "svt_hook_me: OIS picture %llu on the GPU (%u LCUs)\n", (unsigned long long)pic, g_nlcu);
+            }
+            __atomic_store_n(&e->state, 1, __ATOMIC_RELEASE);
+            break;
+        }
+        pthread_cond_wait(&g_front_cv, &g_front_lock); /* every lane is serving an earlier picture */
     }
-    SvtAmdMeParams p;
-    fill_params(&p, pcs, scs, ctx);
-    if (svt_amd_me_picture(g_ctx, &p, cur_slot, ref_slot, g_results[e].res))
-        die("svt_amd_me_picture");
-    g_results[e].pic = pic;
-    g_results[e].valid = 1;
-    g_pictures++;
-    if (g_verbose)
-        fprintf(stderr, "svt_hook_me: ME picture %llu on the GPU (%u LCUs)\n", (unsigned long long)pic, g_nlcu);
-    return g_results[e].res;
+    pthread_mutex_unlock(&g_front_lock);
+    /* outside the lock: wait for this lane's completion event (idempotent; any number of threads may wait) */
+    const SvtAmdMeLcuResult *me;
+    const SvtAmdOisLcuResult *ois;
+    if (svt_amd_frontend_wait(e->lane, &me, &ois))
+        die("svt_amd_frontend_wait");
+    e->me = me, e->ois = ois;
+    cached = e;
+    cached_gen = e->gen;
+    return e;
+}
+
+static void front_served(FrontEntry *e, unsigned *counter)
+{
+    if (__atomic_sub_fetch(counter, 1, __ATOMIC_ACQ_REL) != 0)
+        return;
+    if (__atomic_load_n(&e->me_left, __ATOMIC_ACQUIRE) || __atomic_load_n(&e->ois_left, __ATOMIC_ACQUIRE))
+        return;
+    pthread_mutex_lock(&g_front_lock);
+    svt_amd_frontend_release(e->lane);
+    __atomic_store_n(&e->state, 0, __ATOMIC_RELEASE);
+    pthread_cond_broadcast(&g_front_cv);
+    pthread_mutex_unlock(&g_front_lock);
 }
 
 EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX,
@@ -162,13 +276,9 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
 {
     (void)lcuOriginX;
     (void)lcuOriginY;
-    (void)inputPtr;
     SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
-    pthread_mutex_lock(&g_lock);
-    const SvtAmdMeLcuResult *r = &picture_results(pcs, ctx)[lcuIndex];
-    g_lcus++;
-    pthread_mutex_unlock(&g_lock);
-
+    FrontEntry *e = front_entry(pcs, ctx, inputPtr);
+    const SvtAmdMeLcuResult *r = &e->me[lcuIndex];
     for (int pu = 0; pu < SVT_AMD_ME_PU_COUNT; pu++) {
         MeCuResults_t *m = &pcs->meResults[lcuIndex][pu];
         const SvtAmdMeCuResult *s = &r->pu[pu];
@@ -187,69 +297,57 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
         for (int i = 0; i < 16; i++)
             pcs->rcMEdistortion[lcuIndex] += pcs->meResults[lcuIndex][5 + i].distortionDirection[0].distortion;
     }
+    __atomic_add_fetch(&g_lcus, 1, __ATOMIC_RELAXED);
+    front_served(e, &e->me_left);
     return EB_ErrorNone;
 }
 
-static void ensure_context(const SequenceControlSet_t *scs)
+static void ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
 {
     if (g_ctx)
         return;
     const char *dev = getenv("SVT_AMD_DEVICE");
-    const uint16_t mh = (uint16_t)((scs->lumaHeight + 7) & ~7);
-    if (svt_amd_context_create(dev ? atoi(dev) : 0, scs->lumaWidth, mh, NSLOTS, &g_ctx))
+    const uint16_t mh = (uint16_t)((lumaHeight + 7) & ~7);
+    if (svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &g_ctx))
         die("svt_amd_context_create");
-    g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
+    for (int i = 0; i < NLANES; i++)
+        if (svt_amd_context_fork(g_ctx, &g_front[i].lane))
+            die("svt_amd_context_fork");
+    g_nlcu = ((lumaWidth + 63u) / 64u) * ((lumaHeight + 63u) / 64u);
     g_verbose = getenv("SVT_HOOK_VERBOSE") != NULL;
     fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
     atexit(hook_report);
 }
 
-/*
- * Open-loop intra search: every call of OpenLoopIntraSearchLcu (EbMotionEstimationProcess.c:793) is answered
- * from ONE svt_amd_ois_picture() per picture.  For P/B pictures the ME results it consults are the ones the
- * device produced for this picture (still resident: me == NULL).
- */
-static const SvtAmdOisLcuResult *ois_results(PictureParentControlSet_t *pcs, MotionEstimationContext_t *ctx,
-                                             const EbPictureBufferDesc_t *inputPtr)
+/* Device start-up belongs to EbInitEncoder, not to the first picture: the picture-analysis reference objects are built there
+ * (EbEncHandle.c, EbSystemResourceCtor with this creator), and their descriptor carries the luma size. */
+EB_ERRORTYPE __real_EbPaReferenceObjectCtor(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr);
+EB_ERRORTYPE __wrap_EbPaReferenceObjectCtor(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr)
 {
-    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
-    const uint64_t pic = pcs->pictureNumber;
-    const int e = (int)(pic % NRESULTS);
-    if (g_ois[e].valid && g_ois[e].pic == pic)
-        return g_ois[e].res;
-    ensure_context(scs);
-    if (!g_ois[e].res && !(g_ois[e].res = (SvtAmdOisLcuResult *)malloc(sizeof(SvtAmdOisLcuResult) * g_nlcu)))
-        die("malloc");
-    const int slot = ensure_uploaded(pic, inputPtr);
-    SvtAmdOisParams p;
-    memset(&p, 0, sizeof(p));
-    p.luma_width = scs->lumaWidth;
-    p.luma_height = scs->lumaHeight;
-    p.slice_is_intra = pcs->sliceType == EB_I_PICTURE;
-    p.temporal_layer_index = pcs->temporalLayerIndex;
-    p.limit_ois_to_dc_mode = pcs->limitOisToDcModeFlag;
-    p.skip_ois_8x8 = pcs->skipOis8x8;
-    p.cu8x8_mode = pcs->cu8x8Mode;
-    p.ois_kernel_level = ctx->oisKernelLevel;
-    p.ois_th_set = ctx->oisThSet;
-    p.set_best_ois_distortion_to_valid = ctx->setBestOisDistortionToValid;
-    if (svt_amd_ois_picture(g_ctx, &p, slot, NULL, g_ois[e].res))
-        die("svt_amd_ois_picture");
-    g_ois[e].pic = pic;
-    g_ois[e].valid = 1;
-    g_ois_pictures++;
-    if (g_verbose)
-        fprintf(stderr, "svt_hook_me: OIS picture %llu on the GPU (%u LCUs)\n", (unsigned long long)pic, g_nlcu);
-    return g_ois[e].res;
+    const EbPaReferenceObjectDescInitData_t *d = (const EbPaReferenceObjectDescInitData_t *)objectInitDataPtr;
+    if (d && !getenv("SVT_HOOK_LAZY_INIT")) {
+        pthread_mutex_lock(&g_front_lock);
+        ensure_context(d->referencePictureDescInitData.maxWidth, d->referencePictureDescInitData.maxHeight);
+        pthread_mutex_unlock(&g_front_lock);
+    }
+    return __real_EbPaReferenceObjectCtor(objectDblPtr, objectInitDataPtr);
 }
 
+/*
+ * Open-loop intra search: every call of OpenLoopIntraSearchLcu (EbMotionEstimationProcess.c:793) is answered from the
+ * picture's lane.  For P/B pictures the ME results the search consults are the ones the device produced for this picture
+ * (queued on the same stream right before it).
+ */
 EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex,
                                            MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
 {
-    pthread_mutex_lock(&g_lock);
-    const SvtAmdOisLcuResult *r = &ois_results(pcs, ctx, inputPtr)[lcuIndex];
-    g_ois_lcus++;
-    pthread_mutex_unlock(&g_lock);
+    FrontEntry *e = front_entry(pcs, NULL, inputPtr);
+    if (e->oisp.ois_kernel_level != ctx->oisKernelLevel || e->oisp.ois_th_set != ctx->oisThSet ||
+        e->oisp.set_best_ois_distortion_to_valid != ctx->setBestOisDistortionToValid) {
+        fprintf(stderr, "svt_hook_me: open-loop intra search controls differ from SignalDerivationMeKernelOq's\n");
+        abort();
+    }
+    const SvtAmdOisLcuResult *r = &e->ois[lcuIndex];
     OisCu32Cu16Results_t *a = pcs->oisCu32Cu16Results[lcuIndex];
     OisCu8Results_t *b = pcs->oisCu8Results[lcuIndex];
     for (int cu = 1; cu < SVT_AMD_ME_PU_COUNT; cu++) {
@@ -270,6 +368,8 @@ EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U3
                 b->totalIntraLumaMode[cu - 21] = r->total_intra_luma_mode[cu];
         }
     }
+    __atomic_add_fetch(&g_ois_lcus, 1, __ATOMIC_RELAXED);
+    front_served(e, &e->ois_left);
     return EB_ErrorNone;
 }
 

@@ -54,7 +54,7 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; ctx->slots && i < ctx->num_slots; i++) {
+    for (int i = 0; !ctx->parent && ctx->slots && i < ctx->num_slots; i++) {
         DevPicture *s = &ctx->slots[i];
         plane_destroy(&s->full);
         plane_destroy(&s->quarter);
@@ -70,8 +70,23 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
             (void)hipFree(s->d_me_carry);
         if (s->d_staging)
             (void)hipFree(s->d_staging);
+        if (s->h_staging)
+            (void)hipHostFree(s->h_staging);
+        if (s->ev_ready)
+            (void)hipEventDestroy(s->ev_ready);
     }
-    free(ctx->slots);
+    if (!ctx->parent)
+        free(ctx->slots);
+    if (ctx->d_cabac_cost)
+        (void)hipFree(ctx->d_cabac_cost);
+    if (ctx->d_leaf_scratch)
+        (void)hipFree(ctx->d_leaf_scratch);
+    if (ctx->h_me)
+        (void)hipHostFree(ctx->h_me);
+    if (ctx->h_ois)
+        (void)hipHostFree(ctx->h_ois);
+    if (ctx->ev_done)
+        (void)hipEventDestroy(ctx->ev_done);
     if (ctx->d_jobs)
         (void)hipFree(ctx->d_jobs);
     if (ctx->d_me_scratch)
@@ -94,6 +109,70 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     free(ctx);
+}
+
+/* stream, events, descriptor / cost buffers: everything a context or a lane owns besides the picture slots */
+static int context_common_create(SvtAmdContext *ctx)
+{
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev_begin));
+    HIP_TRY(hipEventCreate(&ctx->ev_end));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+    const int nlcu = ((ctx->max_w + 63) / 64) * ((ctx->max_h + 63) / 64);
+    if (hipMalloc((void **)&ctx->d_me_scratch, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess ||
+        hipMalloc(&ctx->d_prep_jobs, 128 * SVT_AMD_MAX_BATCH) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_ois_jobs, sizeof(OisJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_jobs, sizeof(MeJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess ||
+        hipMalloc(&ctx->d_cabac_cost, sizeof(SvtAmdCabacCost)) != hipSuccess) {
+        svt_amd_set_error("hipMalloc (context buffers) failed");
+        return SVT_AMD_ERR_RESOURCES;
+    }
+    return SVT_AMD_OK;
+}
+
+int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out)
+{
+    if (bytes > ctx->leaf_scratch_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_leaf_scratch)
+            (void)hipFree(ctx->d_leaf_scratch);
+        ctx->d_leaf_scratch = nullptr;
+        ctx->leaf_scratch_bytes = 0;
+        const size_t n = bytes < 65536 ? 65536 : bytes;
+        HIP_TRY(hipMalloc((void **)&ctx->d_leaf_scratch, n));
+        ctx->leaf_scratch_bytes = n;
+    }
+    *out = ctx->d_leaf_scratch;
+    return SVT_AMD_OK;
+}
+
+/* A lane: a second (third, ...) stream over the SAME picture slots.  Pictures uploaded through any lane are visible to all
+ * (cross-stream ordering through the slot's ev_ready event); descriptors, timers, scratch and the cost table are per lane.
+ * Destroy lanes before their parent. */
+extern "C" int svt_amd_context_fork(SvtAmdContext *parent, SvtAmdContext **out_lane)
+{
+    if (!parent || !out_lane || parent->parent) {
+        svt_amd_set_error("svt_amd_context_fork: bad parameter");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    *out_lane = NULL;
+    HIP_TRY(hipSetDevice(parent->device));
+    SvtAmdContext *ctx = (SvtAmdContext *)calloc(1, sizeof(*ctx));
+    if (!ctx)
+        return SVT_AMD_ERR_RESOURCES;
+    ctx->device = parent->device;
+    ctx->parent = parent;
+    ctx->max_w = parent->max_w;
+    ctx->max_h = parent->max_h;
+    ctx->num_slots = parent->num_slots;
+    ctx->slots = parent->slots;
+    int rc = context_common_create(ctx);
+    if (rc != SVT_AMD_OK) {
+        svt_amd_context_destroy(ctx);
+        return rc;
+    }
+    *out_lane = ctx;
+    return SVT_AMD_OK;
 }
 
 extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_width,
@@ -122,28 +201,9 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
     ctx->num_slots = num_picture_slots;
     ctx->slots = (DevPicture *)calloc((size_t)num_picture_slots, sizeof(DevPicture));
     int rc = ctx->slots ? SVT_AMD_OK : SVT_AMD_ERR_RESOURCES;
-#define CHK(x) do { if (rc == SVT_AMD_OK) { hipError_t e_ = (x); if (e_ != hipSuccess) { svt_amd_set_error("%s: %s", #x, hipGetErrorString(e_)); rc = SVT_AMD_ERR_DEVICE; } } } while (0)
-    CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    CHK(hipEventCreate(&ctx->ev_begin));
-    CHK(hipEventCreate(&ctx->ev_end));
-#undef CHK
     const int nlcu = ((max_luma_width + 63) / 64) * ((max_luma_height + 63) / 64);
-    if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_me_scratch, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess) {
-        svt_amd_set_error("hipMalloc(ME scratch) failed");
-        rc = SVT_AMD_ERR_RESOURCES;
-    }
-    if (rc == SVT_AMD_OK && hipMalloc(&ctx->d_prep_jobs, 128 * SVT_AMD_MAX_BATCH) != hipSuccess) {
-        svt_amd_set_error("hipMalloc(prep descriptors) failed");
-        rc = SVT_AMD_ERR_RESOURCES;
-    }
-    if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_ois_jobs, sizeof(OisJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
-        svt_amd_set_error("hipMalloc(OIS job descriptors) failed");
-        rc = SVT_AMD_ERR_RESOURCES;
-    }
-    if (rc == SVT_AMD_OK && hipMalloc((void **)&ctx->d_jobs, sizeof(MeJobDev) * SVT_AMD_MAX_BATCH) != hipSuccess) {
-        svt_amd_set_error("hipMalloc(job descriptors) failed");
-        rc = SVT_AMD_ERR_RESOURCES;
-    }
+    if (rc == SVT_AMD_OK)
+        rc = context_common_create(ctx);
     for (int i = 0; rc == SVT_AMD_OK && i < num_picture_slots; i++) {
         DevPicture *s = &ctx->slots[i];
         const int w = max_luma_width, h = max_luma_height;
@@ -162,6 +222,11 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
             break;
         }
         s->staging_bytes = (size_t)w * h;
+        if (hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess) {
+            svt_amd_set_error("hipEventCreate (slot %d) failed", i);
+            rc = SVT_AMD_ERR_DEVICE;
+            break;
+        }
     }
     if (rc != SVT_AMD_OK) {
         svt_amd_context_destroy(ctx);
@@ -183,11 +248,15 @@ int svt_amd_stamp_begin(SvtAmdContext *ctx, int cls)
         if (!ns)
             return SVT_AMD_ERR_RESOURCES;
         ctx->stamps = ns;
-        for (int i = ctx->cap_stamps; i < ncap; i++) {
+        for (int i = ctx->cap_stamps; i < ncap; i++) { /* cap_stamps follows every pair that exists, so none leaks on failure */
             HIP_TRY(hipEventCreate(&ns[i].a));
-            HIP_TRY(hipEventCreate(&ns[i].b));
+            if (hipEventCreate(&ns[i].b) != hipSuccess) {
+                (void)hipEventDestroy(ns[i].a);
+                svt_amd_set_error("hipEventCreate failed (kernel stamps)");
+                return SVT_AMD_ERR_DEVICE;
+            }
+            ctx->cap_stamps = i + 1;
         }
-        ctx->cap_stamps = ncap;
     }
     ctx->stamps[ctx->num_stamps].cls = cls;
     HIP_TRY(hipEventRecord(ctx->stamps[ctx->num_stamps].a, ctx->stream));
@@ -208,6 +277,7 @@ extern "C" int svt_amd_timer_begin(SvtAmdContext *ctx)
     if (!ctx)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* stamps of a previous window may still be pending */
     ctx->num_stamps = 0;
     ctx->timer_armed = 1;
     HIP_TRY(hipEventRecord(ctx->ev_begin, ctx->stream));
@@ -490,7 +560,8 @@ extern "C" int svt_amd_me_batch_launch(SvtAmdContext *ctx, const SvtAmdMeJob *jo
         const SvtAmdMeParams *p = &jobs[i].params;
         const uint32_t nlcu = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
         rc = make_job(ctx, p, jobs[i].cur_slot, jobs[i].ref_slot, 0, nlcu, &dj[i]);
-        max_lcus = dj[i].lcu_count > max_lcus ? dj[i].lcu_count : max_lcus;
+        if (rc == SVT_AMD_OK)
+            max_lcus = dj[i].lcu_count > max_lcus ? dj[i].lcu_count : max_lcus;
     }
     if (rc == SVT_AMD_OK) {
         hipError_t e = hipSetDevice(ctx->device);
@@ -512,6 +583,7 @@ extern "C" int svt_amd_debug_me_phase_profile(SvtAmdContext *ctx, size_t workgro
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!out) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); /* a launch armed earlier may still write its stamps */
         if (ctx->d_dbg)
             (void)hipFree(ctx->d_dbg);
         ctx->d_dbg = NULL;
@@ -597,10 +669,12 @@ static int ois_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur
     HIP_TRY(hipSetDevice(ctx->device));
     OisJobDev j;
     make_ois_job(ctx, params, cur_slot, d_me, &j);
-    svt_amd_stamp_begin(ctx, KC_OIS);
-    int rc = svt_amd_launch_ois_batch(ctx, &j, 1, j.nlcu);
-    svt_amd_stamp_end(ctx);
-    return rc;
+    int rc = svt_amd_stamp_begin(ctx, KC_OIS);
+    if (rc)
+        return rc;
+    rc = svt_amd_launch_ois_batch(ctx, &j, 1, j.nlcu);
+    const int rc2 = svt_amd_stamp_end(ctx);
+    return rc ? rc : rc2;
 }
 
 extern "C" int svt_amd_ois_batch_launch(SvtAmdContext *ctx, const SvtAmdOisJob *jobs, int num_jobs)
@@ -617,10 +691,12 @@ extern "C" int svt_amd_ois_batch_launch(SvtAmdContext *ctx, const SvtAmdOisJob *
         max_lcus = host[i].nlcu > max_lcus ? host[i].nlcu : max_lcus;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    svt_amd_stamp_begin(ctx, KC_OIS);
-    int rc = svt_amd_launch_ois_batch(ctx, host, num_jobs, max_lcus);
-    svt_amd_stamp_end(ctx);
-    return rc;
+    int rc = svt_amd_stamp_begin(ctx, KC_OIS);
+    if (rc)
+        return rc;
+    rc = svt_amd_launch_ois_batch(ctx, host, num_jobs, max_lcus);
+    const int rc2 = svt_amd_stamp_end(ctx);
+    return rc ? rc : rc2;
 }
 
 extern "C" int svt_amd_ois_picture_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur_slot)
@@ -666,6 +742,118 @@ extern "C" int svt_amd_ois_picture(SvtAmdContext *ctx, const SvtAmdOisParams *pa
     if (rc)
         return rc;
     return svt_amd_ois_picture_fetch(ctx, cur_slot, out);
+}
+
+/* ---- front-end pipeline: asynchronous upload -> planes -> ME -> OIS -> results in pinned host memory ---------------- */
+
+/* Copies the caller's luma into the slot's pinned staging buffer (the caller may release `luma` on return, as with
+ * svt_amd_picture_upload), then queues H2D copy + plane building on this lane's stream and records the slot's ready event.
+ * Nothing blocks on the device. */
+extern "C" int svt_amd_picture_upload_async(SvtAmdContext *ctx, int slot, const uint8_t *luma, uint32_t stride,
+                                            uint16_t width, uint16_t height)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc)
+        return rc;
+    if (!luma || stride < width)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *s = &ctx->slots[slot];
+    if ((size_t)width * height > s->staging_bytes)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if ((rc = set_geometry(ctx, s, width, height)) != 0)
+        return rc;
+    if (!s->h_staging)
+        HIP_TRY(hipHostMalloc((void **)&s->h_staging, s->staging_bytes, hipHostMallocDefault));
+    if (stride == width)
+        memcpy(s->h_staging, luma, (size_t)width * height);
+    else
+        for (uint32_t y = 0; y < height; y++)
+            memcpy(s->h_staging + (size_t)y * width, luma + (size_t)y * stride, width);
+    HIP_TRY(hipMemcpyAsync(s->d_staging, s->h_staging, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = svt_amd_launch_prep(ctx, s, s->d_staging, width)) != 0)
+        return rc;
+    HIP_TRY(hipEventRecord(s->ev_ready, ctx->stream));
+    s->valid = 1;
+    return SVT_AMD_OK;
+}
+
+/* Marks a slot filled through svt_amd_picture_upload_device[_batch] on this lane as ready for other lanes. */
+extern "C" int svt_amd_picture_publish(SvtAmdContext *ctx, int slot)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->slots[slot].ev_ready, ctx->stream));
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_frontend_submit(SvtAmdContext *ctx, const SvtAmdFrontendJob *job)
+{
+    if (!ctx || !job || (!job->has_me && !job->has_ois)) {
+        svt_amd_set_error("svt_amd_frontend_submit: bad parameter");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    if (ctx->frontend_busy) {
+        svt_amd_set_error("svt_amd_frontend_submit: the lane still holds an unfetched job (svt_amd_frontend_wait first)");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    int rc = check_slot(ctx, job->cur_slot);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[job->cur_slot];
+    const int nlcu = ((ctx->max_w + 63) / 64) * ((ctx->max_h + 63) / 64);
+    if (!ctx->h_me)
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_me, (size_t)nlcu * sizeof(SvtAmdMeLcuResult), hipHostMallocDefault));
+    if (!ctx->h_ois)
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_ois, (size_t)nlcu * sizeof(SvtAmdOisLcuResult), hipHostMallocDefault));
+    /* pictures may have been prepared on another lane's stream */
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, c->ev_ready, 0));
+    const int pn = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    if (job->has_me) {
+        for (int l = 0; l < job->me.num_lists && l < 2; l++) {
+            if ((rc = check_slot(ctx, job->ref_slot[l])) != 0)
+                return rc;
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slots[job->ref_slot[l]].ev_ready, 0));
+        }
+        if ((rc = svt_amd_me_picture_launch(ctx, &job->me, job->cur_slot, job->ref_slot)) != 0)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->h_me, c->d_me_out, (size_t)pn * sizeof(SvtAmdMeLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (job->has_ois) {
+        if ((rc = svt_amd_ois_picture_launch(ctx, &job->ois, job->cur_slot)) != 0)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->h_ois, c->d_ois_out, (size_t)pn * sizeof(SvtAmdOisLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_done, ctx->stream));
+    ctx->frontend_busy = 1;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_frontend_wait(SvtAmdContext *ctx, const SvtAmdMeLcuResult **me, const SvtAmdOisLcuResult **ois)
+{
+    if (!ctx || !ctx->frontend_busy) {
+        svt_amd_set_error("svt_amd_frontend_wait: nothing submitted on this lane");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev_done));
+    if (me)
+        *me = ctx->h_me;
+    if (ois)
+        *ois = ctx->h_ois;
+    return SVT_AMD_OK;
+}
+
+/* The lane's pinned result buffers may be overwritten by the next submit from now on. */
+extern "C" int svt_amd_frontend_release(SvtAmdContext *ctx)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    ctx->frontend_busy = 0;
+    return SVT_AMD_OK;
 }
 
 /* ---- collocated zero-motion SAD -------------------------------------------- */

@@ -50,7 +50,7 @@ __device__ __forceinline__ void fl_quant_params(FlUnit &S, uint32_t qp, uint32_t
  * cheapest of the three in coefficient-domain SSE + lambda * (4x4 rate estimate) replaces it in lev_lds.  All lanes of the
  * wave call together (pmu = this lane's unit takes part); Pq = 16 samples of LDS scratch per lane of the wave. */
 template <int STRIDE>
-__device__ __forceinline__ void pm_core_blocks(const int16_t *cf_lds, int16_t *lev_lds, int pitch, int area, int lg_area, int r, bool pmu,
+__device__ __forceinline__ void pm_core_blocks(const SvtAmdCabacCost &c_cost, const int16_t *cf_lds, int16_t *lev_lds, int pitch, int area, int lg_area, int r, bool pmu,
                                                int t, int cand_type, uint32_t full_lambda, const FlUnit &Q, int16_t (*Pq)[16])
 {
     const int nb = area >> 2, nblk = pmu ? nb * nb : 0;
@@ -107,7 +107,7 @@ __device__ __forceinline__ void pm_core_blocks(const int16_t *cf_lds, int16_t *l
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const bool price = any && nzc != 0;
             SvtAmdTuInfo ti = {price ? nzc : 0u, (uint8_t)cand_type, 0, 0, 0};
-            const uint32_t b32 = coeff_bits_lanes(&Pq[t][0], 4, 2, ti, price, t, 0);
+            const uint32_t b32 = coeff_bits_lanes(c_cost, &Pq[t][0], 4, 2, ti, price, t, 0);
             unsigned long long sse = nzc ? sres : spred;
             sse = (sse + (1ull << (sse_shift - 1))) >> sse_shift;
             const unsigned long long bits = price ? (unsigned long long)b32 << 10 : 0ull;
@@ -133,11 +133,12 @@ __device__ __forceinline__ void pm_core_blocks(const int16_t *cf_lds, int16_t *l
  * plane).  One wave per workgroup; the wave's 64 / N unit sequences run side by side, each on its own N lanes; a
  * 64x64 CU's sequence has four units (all others one).  No workgroup barrier anywhere: a unit never leaves its wave. */
 template <int N, bool CHROMA, bool PM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))) void k_full_loop(const void *__restrict__ in_all, const int16_t *__restrict__ residual,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))) void k_full_loop(const SvtAmdCabacCost *__restrict__ cost_p, const void *__restrict__ in_all, const int16_t *__restrict__ residual,
                                                   int16_t *__restrict__ quant, int16_t *__restrict__ recon,
                                                   void *__restrict__ out_all, uint32_t ncand, int shift1, int shift2,
                                                   int wrap_levels)
 {
+    const SvtAmdCabacCost &c_cost = *cost_p;
     constexpr int UPW = 64 / N; /* unit sequences per wave */
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
     __shared__ int16_t tiles[UPW * TxRegTile<N>::UNIT];
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                pm_core_blocks<N>(tile, &Fq[u][0], N, S.area, S.lg, r, pmu, t, cand_type, full_lambda, S, Pq);
+                pm_core_blocks<N>(c_cost, tile, &Fq[u][0], N, S.area, S.lg, r, pmu, t, cand_type, full_lambda, S, Pq);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
                     continue;
                 SvtAmdTuInfo ti = {live ? u_nz : 0u, (uint8_t)u_type, (uint8_t)u_mode, 4 /* EB_INTRA_CHROMA_DM */,
                                    CHROMA ? (uint8_t)(u_plane + 1) : (uint8_t)0};
-                const uint32_t b = coeff_bits_lanes(&Fq[uu < UPW ? uu : 0][0], N, lg, ti, live, t, sub);
+                const uint32_t b = coeff_bits_lanes(c_cost, &Fq[uu < UPW ? uu : 0][0], N, lg, ti, live, t, sub);
                 if (live && sub == 0)
                     Fbits[uu] = b;
             }
@@ -381,12 +382,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
 }
 
 template <int N, bool CHROMA, bool PM = false>
-static void launch_full_loop(hipStream_t st, const void *d_in, const int16_t *d_res, int16_t *d_q, int16_t *d_r, void *d_out,
+static void launch_full_loop(SvtAmdContext *ctx, const void *d_in, const int16_t *d_res, int16_t *d_q, int16_t *d_r, void *d_out,
                              uint32_t ncand, int s1, int s2, int wrap)
 {
     constexpr int UPW = 64 / N;
     const uint32_t nseq = CHROMA ? 2 * ncand : ncand;
-    hipLaunchKernelGGL((k_full_loop<N, CHROMA, PM>), dim3((nseq + UPW - 1) / UPW), dim3(64), 0, st, d_in, d_res, d_q, d_r, d_out, ncand,
+    hipLaunchKernelGGL((k_full_loop<N, CHROMA, PM>), dim3((nseq + UPW - 1) / UPW), dim3(64), 0, ctx->stream, (const SvtAmdCabacCost *)ctx->d_cabac_cost, d_in, d_res, d_q, d_r, d_out, ncand,
                        s1, s2, wrap);
 }
 
@@ -397,15 +398,15 @@ extern "C" int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCaba
     if (!ctx || !cost || !d_in || !d_residual || !d_quant || !d_recon || !d_out || !ncand)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = rate_upload_tables(cost, ctx->stream);
+    int rc = rate_upload_tables(ctx, cost);
     if (rc)
         return rc;
     /* one launch per transform size; a workgroup none of whose candidates has that size returns at once (sorting the
      * batch by CU size keeps the 8x8 workgroups full).
      * EstimateTransform shifts: Transform32x32Estimate 6/9 wrap 2, Transform16x16Estimate 4/9 wrap 1, Transform8x8 2/9 */
-    launch_full_loop<32, false>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2);
-    launch_full_loop<16, false>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
-    launch_full_loop<8, false>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
+    launch_full_loop<32, false>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2);
+    launch_full_loop<16, false>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
+    launch_full_loop<8, false>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -420,12 +421,12 @@ extern "C" int svt_amd_full_loop_luma_pmcore_batch(SvtAmdContext *ctx, const Svt
     if (!ctx || !cost || !d_in || !d_residual || !d_quant || !d_recon || !d_out || !ncand)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = rate_upload_tables(cost, ctx->stream);
+    int rc = rate_upload_tables(ctx, cost);
     if (rc)
         return rc;
-    launch_full_loop<32, false, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2);
-    launch_full_loop<16, false, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
-    launch_full_loop<8, false, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
+    launch_full_loop<32, false, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2);
+    launch_full_loop<16, false, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
+    launch_full_loop<8, false, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -437,13 +438,13 @@ extern "C" int svt_amd_full_loop_chroma_batch(SvtAmdContext *ctx, const SvtAmdCa
     if (!ctx || !cost || !d_in || !d_residual || !d_quant || !d_recon || !d_out || !ncand)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = rate_upload_tables(cost, ctx->stream);
+    int rc = rate_upload_tables(ctx, cost);
     if (rc)
         return rc;
     /* EstimateTransform shifts: Transform16x16Estimate 4/9 wrap 1, Transform8x8 2/9, Transform4x4 1/8 */
-    launch_full_loop<16, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
-    launch_full_loop<8, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
-    launch_full_loop<4, true>(ctx->stream, d_in, d_residual, d_quant, d_recon, d_out, ncand, 1, 8, 0);
+    launch_full_loop<16, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1);
+    launch_full_loop<8, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0);
+    launch_full_loop<4, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 1, 8, 0);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -459,10 +460,13 @@ extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost 
         (in->size != 8 && in->size != 16 && in->size != 32 && in->size != 64) || in->pf_mode > 1 || (in->pm_core != 0 && in->pm_core != 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    static uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
+    uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
     const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 8192, o_r = o_q + 8192, total = o_r + 8192;
-    if (!d_scratch)
-        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
+        if (rc_s)
+            return rc_s;
+    }
     const uint32_t S = in->size;
     int16_t packed[64 * 64];
     for (uint32_t y = 0; y < S; y++)
@@ -498,10 +502,13 @@ extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCos
         (in->size != 8 && in->size != 16 && in->size != 32 && in->size != 64) || in->pf_mode > 2)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    static uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
+    uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
     const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 4096, o_r = o_q + 4096, total = o_r + 4096;
-    if (!d_scratch)
-        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
+        if (rc_s)
+            return rc_s;
+    }
     const uint32_t C = in->size / 2;
     int16_t packed[2048];
     for (int p = 0; p < 2; p++)
@@ -539,12 +546,13 @@ extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCos
  * ------------------------------------------------------------------------------------------------------------------------ */
 struct PmQuantUnit { uint8_t size, qp, bit_depth, slice_type, component, cand_type, pad[2]; uint32_t lambda; }; /* = SvtAmdPmQuantUnit */
 
-__global__ __launch_bounds__(64) void k_pmcore_quant(const PmQuantUnit *__restrict__ units, const int16_t *__restrict__ coeff,
+__global__ __launch_bounds__(64) void k_pmcore_quant(const SvtAmdCabacCost *__restrict__ cost_p, const PmQuantUnit *__restrict__ units, const int16_t *__restrict__ coeff,
                                                      int16_t *__restrict__ quant, int16_t *__restrict__ recon,
                                                      uint32_t *__restrict__ nzOut)
 {
     __shared__ int16_t cf[32 * 32], lev[32 * 32];
     __shared__ int16_t Pq[64][16];
+    const SvtAmdCabacCost &c_cost = *cost_p;
     const PmQuantUnit U = units[blockIdx.x];
     const int t = threadIdx.x, N = U.size, lg = 31 - __clz(N);
     const size_t base = (size_t)blockIdx.x * 1024;
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(64) void k_pmcore_quant(const PmQuantUnit *__restri
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (nz != 0 && U.component == 0) {
-        pm_core_blocks<64>(cf, lev, N, N, lg, t, true, t, (int)U.cand_type, U.lambda, Q, Pq);
+        pm_core_blocks<64>(c_cost, cf, lev, N, N, lg, t, true, t, (int)U.cand_type, U.lambda, Q, Pq);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -600,10 +608,10 @@ extern "C" int svt_amd_pmcore_quantize_batch(SvtAmdContext *ctx, const SvtAmdCab
     if (!ctx || !cost || !d_units || !d_coeff || !d_quant || !d_recon || !d_nz || !nunits)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = rate_upload_tables(cost, ctx->stream);
+    int rc = rate_upload_tables(ctx, cost);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(k_pmcore_quant, dim3(nunits), dim3(64), 0, ctx->stream, (const PmQuantUnit *)d_units, d_coeff, d_quant, d_recon, d_nz);
+    hipLaunchKernelGGL(k_pmcore_quant, dim3(nunits), dim3(64), 0, ctx->stream, (const SvtAmdCabacCost *)ctx->d_cabac_cost, (const PmQuantUnit *)d_units, d_coeff, d_quant, d_recon, d_nz);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -616,10 +624,13 @@ extern "C" int svt_amd_pmcore_quantize(SvtAmdContext *ctx, const SvtAmdCabacCost
         (unit->bit_depth != 8 && unit->bit_depth != 10) || unit->qp > 51)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    static uint8_t *d_scratch = nullptr; /* unit | nz | coeff | quant | recon ; callers serialise per context */
+    uint8_t *d_scratch = nullptr; /* unit | nz | coeff | quant | recon ; callers serialise per context */
     const size_t o_unit = 0, o_nz = 64, o_c = 128, o_q = o_c + 2048, o_r = o_q + 2048, total = o_r + 2048;
-    if (!d_scratch)
-        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
+        if (rc_s)
+            return rc_s;
+    }
     const int N = unit->size;
     int16_t hc[32 * 32], hq[32 * 32], hr[32 * 32];
     for (int y = 0; y < N; y++)

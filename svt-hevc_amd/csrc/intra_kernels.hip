@@ -357,10 +357,13 @@ extern "C" int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const 
         (wantY && strideY < job->size) || (wantC && strideC < job->size / 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    static uint8_t *d_scratch = nullptr; /* job | Y 32x32 | Cb 16x16 | Cr 16x16 (16-bit worst case) */
+    uint8_t *d_scratch = nullptr; /* job | Y 32x32 | Cb 16x16 | Cr 16x16 (16-bit worst case) */
     const size_t o_job = 0, o_y = 1024, o_cb = o_y + 2048, o_cr = o_cb + 512, total = o_cr + 512;
-    if (!d_scratch)
-        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
+        if (rc_s)
+            return rc_s;
+    }
     SvtAmdIntraPuJob j = *job;
     j.dst_off_y = 0, j.dst_off_c = 0;
     const uint32_t N = job->size, C = N / 2;

@@ -25,6 +25,7 @@
  *     instead of being re-interpolated per LCU and list.
  * All arithmetic is integer; results are bit-exact with the C_DEFAULT path.
  */
+#include <mutex>
 #include "svt_amd_internal.h"
 
 #define NT 256
@@ -1405,14 +1406,19 @@ int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int n
         svt_amd_set_error("motion estimation: search windows need %zu B of LDS (> 160 KiB)", pool1 + sizeof(MeShared));
         return SVT_AMD_ERR_BAD_PARAM;
     }
-    static size_t attr0 = 0, attr1 = 0;
-    if (pool0 > attr0) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_me<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool0));
-        attr0 = pool0;
-    }
-    if (pool1 > attr1) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_me<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool1));
-        attr1 = pool1;
+    {   /* dynamic-LDS limits of the two kernels: high-water marks PER DEVICE (function attributes are per device) */
+        static std::mutex mu;
+        static size_t attr0[64], attr1[64];
+        std::lock_guard<std::mutex> g(mu);
+        const int dv = ctx->device & 63;
+        if (pool0 > attr0[dv]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_me<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool0));
+            attr0[dv] = pool0;
+        }
+        if (pool1 > attr1[dv]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_me<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool1));
+            attr1[dv] = pool1;
+        }
     }
     /* pageable source: the runtime stages it before returning, so host_jobs may be reused */
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs, host_jobs, sizeof(MeJobDev) * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream));

@@ -1,8 +1,10 @@
-/* Device code of the coefficient rate estimator shared by rate_kernels.hip and fullloop_kernels.hip.  The scan /
- * context tables and the CabacCost_t copy live in per-translation-unit constant memory: every TU that includes this
- * header uploads them through its own rate_upload_tables(). */
+/* Device code of the coefficient rate estimator shared by rate_kernels.hip and fullloop_kernels.hip.  The immutable scan /
+ * context tables live in per-translation-unit constant memory (uploaded once per device, rate_upload_tables()); the
+ * CabacCost_t copy is a device buffer OWNED BY THE CONTEXT (ctx->d_cabac_cost, written stream-ordered on the context's
+ * stream) and reaches the device functions as a pointer, so contexts on one device never share it. */
 #ifndef SVT_AMD_RATE_DEVICE_H
 #define SVT_AMD_RATE_DEVICE_H
+#include <mutex>
 #include "leaf_util.h"
 
 #define ONE_BIT 32u
@@ -12,7 +14,6 @@ struct RateTables {
     uint8_t sb[4][64]; /* sub-block scans by log2(size) - 2; (y << 4) | x */
 };
 static __constant__ RateTables c_rt;
-static __constant__ SvtAmdCabacCost c_cost;
 
 static void build_tables(RateTables *t)
 {
@@ -49,7 +50,7 @@ __device__ __forceinline__ uint32_t golomb_bits0(uint32_t symbol) /* rice parame
         bins += 2 * (31 - __clz((int)(symbol - 2))) + 3;
     return ONE_BIT * bins;
 }
-__device__ __forceinline__ uint32_t last_xy_bits(uint32_t x, uint32_t y, uint32_t size, int isChroma)
+__device__ __forceinline__ uint32_t last_xy_bits(const SvtAmdCabacCost &c_cost, uint32_t x, uint32_t y, uint32_t size, int isChroma)
 {
     const int off = (isChroma ? 120 : 0) - 8;
     if (size == 1)
@@ -61,7 +62,7 @@ __device__ __forceinline__ uint32_t last_xy_bits(uint32_t x, uint32_t y, uint32_
 /* Bits of one TU, computed by the S = (size/4)^2 adjacent lanes that own its sub-blocks (sub = lane & (S-1)); every lane
  * of the wave must call (ballot / shuffles inside).  p: coefficient (0,0) of the TU (global or LDS), row pitch `stride`;
  * live = this lane's TU exists.  The sum lands in all S lanes; the caller shifts it by 10 like the reference. */
-__device__ __forceinline__ uint32_t coeff_bits_lanes(const int16_t *p0, uint32_t stride, int lg, const SvtAmdTuInfo ti, bool live,
+__device__ __forceinline__ uint32_t coeff_bits_lanes(const SvtAmdCabacCost &c_cost, const int16_t *p0, uint32_t stride, int lg, const SvtAmdTuInfo ti, bool live,
                                                      int lane, int sub)
 {
     const int S = lg == 2 ? 1 : 1 << (2 * (lg - 2));
@@ -103,7 +104,7 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const int16_t *p0, uint32_t
         if (ti.num_nonzero == 1 && first != 0) { /* DC-only fast track */
             if (sub == 0) {
                 const uint32_t a = first, o1 = isChroma * 16, o2 = isChroma * 4;
-                bits = last_xy_bits(0, 0, size, isChroma) + c_cost.CabacBitsG1[2 * (o1 + 1) + (a > 1)];
+                bits = last_xy_bits(c_cost, 0, 0, size, isChroma) + c_cost.CabacBitsG1[2 * (o1 + 1) + (a > 1)];
                 if (a > 1) {
                     bits += c_cost.CabacBitsG2[2 * o2 + (a > 2)];
                     if (a > 2)
@@ -119,7 +120,7 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const int16_t *p0, uint32_t
                 const uint32_t pl = scan ? c_rt.col4[posLast] : c_rt.diag4[posLast];
                 ly += pl >> 2, lx += pl & 3;
                 if (scan) { const uint32_t tmp = lx; lx = ly; ly = tmp; }
-                bits += last_xy_bits(lx, ly, size, isChroma);
+                bits += last_xy_bits(c_cost, lx, ly, size, isChroma);
             }
             bool coded = true;
             if (sub != 0 && !isLast) { /* coded_sub_block_flag */
@@ -192,16 +193,30 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const int16_t *p0, uint32_t
 }
 
 
-static int rate_upload_tables(const SvtAmdCabacCost *cost, hipStream_t st)
+/* once per device: the immutable scan / context tables */
+static int rate_tables_once(int device)
 {
-    static bool tables_done = false;
-    if (!tables_done) {
+    static std::mutex mu;
+    static bool tables_done[64];
+    std::lock_guard<std::mutex> g(mu);
+    if (device < 0 || device >= 64)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (!tables_done[device]) {
         RateTables t;
         build_tables(&t);
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_rt), &t, sizeof(t)));
-        tables_done = true;
+        tables_done[device] = true;
     }
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_cost), cost, sizeof(*cost), 0, hipMemcpyHostToDevice, st));
+    return SVT_AMD_OK;
+}
+/* per call: the caller's CabacCost_t into the context's own buffer, stream-ordered before the kernels that read it */
+static int rate_upload_tables(SvtAmdContext *ctx, const SvtAmdCabacCost *cost)
+{
+    int rc = rate_tables_once(ctx->device);
+    if (rc)
+        return rc;
+    /* pageable source: staged by the runtime before the call returns */
+    HIP_TRY(hipMemcpyAsync(ctx->d_cabac_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, ctx->stream));
     return SVT_AMD_OK;
 }
 #endif

@@ -15,7 +15,7 @@
 #include "rate_device.h"
 
 /* lg = log2(size) in 2..5, S = sub-blocks per TU = lanes per TU */
-__global__ __launch_bounds__(256) void k_coeff_bits(const int16_t *__restrict__ coeff, uint32_t stride, size_t block_pitch,
+__global__ __launch_bounds__(256) void k_coeff_bits(const SvtAmdCabacCost *__restrict__ cost_p, const int16_t *__restrict__ coeff, uint32_t stride, size_t block_pitch,
                                                     const SvtAmdTuInfo *__restrict__ info, unsigned long long *__restrict__ out,
                                                     uint32_t nblocks, int lg)
 {
@@ -27,12 +27,12 @@ __global__ __launch_bounds__(256) void k_coeff_bits(const int16_t *__restrict__ 
     SvtAmdTuInfo ti = {0, 1, 0, 0, 0};
     if (live)
         ti = info[b];
-    const uint32_t bits = coeff_bits_lanes(coeff + (size_t)(live ? b : 0) * block_pitch, stride, lg, ti, live, lane, sub);
+    const uint32_t bits = coeff_bits_lanes(*cost_p, coeff + (size_t)(live ? b : 0) * block_pitch, stride, lg, ti, live, lane, sub);
     if (live && sub == 0)
         out[b] = (unsigned long long)bits << 10;
 }
 
-static int launch_rate(hipStream_t st, uint32_t size, const int16_t *d_coeff, uint32_t stride, size_t pitch,
+static int launch_rate(hipStream_t st, const SvtAmdCabacCost *d_cost, uint32_t size, const int16_t *d_coeff, uint32_t stride, size_t pitch,
                        const SvtAmdTuInfo *d_info, unsigned long long *d_bits, uint32_t n)
 {
     const int lg = size == 4 ? 2 : size == 8 ? 3 : size == 16 ? 4 : size == 32 ? 5 : 0;
@@ -40,7 +40,7 @@ static int launch_rate(hipStream_t st, uint32_t size, const int16_t *d_coeff, ui
         return SVT_AMD_ERR_BAD_PARAM;
     const int S = lg == 2 ? 1 : 1 << (2 * (lg - 2)), tpw = 64 / S;
     const uint32_t waves = (n + tpw - 1) / tpw;
-    hipLaunchKernelGGL(k_coeff_bits, dim3((waves + 3) / 4), dim3(256), 0, st, d_coeff, stride, pitch, d_info, d_bits, n, lg);
+    hipLaunchKernelGGL(k_coeff_bits, dim3((waves + 3) / 4), dim3(256), 0, st, d_cost, d_coeff, stride, pitch, d_info, d_bits, n, lg);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
@@ -52,10 +52,10 @@ extern "C" int svt_amd_coeff_bits_batch(SvtAmdContext *ctx, const SvtAmdCabacCos
     if (!ctx || !cost || !d_coeff || !d_info || !d_bits)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = rate_upload_tables(cost, ctx->stream);
+    int rc = rate_upload_tables(ctx, cost);
     if (rc)
         return rc;
-    return launch_rate(ctx->stream, size, d_coeff, size, (size_t)size * size, d_info, (unsigned long long *)d_bits, nblocks);
+    return launch_rate(ctx->stream, (const SvtAmdCabacCost *)ctx->d_cabac_cost, size, d_coeff, size, (size_t)size * size, d_info, (unsigned long long *)d_bits, nblocks);
 }
 
 extern "C" int svt_amd_EstimateQuantizedCoefficients_Lossy(SvtAmdCabacCost *CabacCost, void *cabacEncodeCtxPtr, uint32_t size,
@@ -67,13 +67,14 @@ extern "C" int svt_amd_EstimateQuantizedCoefficients_Lossy(SvtAmdCabacCost *Caba
     (void)cabacEncodeCtxPtr;
     if (!CabacCost || !coeffBufferPtr || !coeffBitsLong || !numNonZeroCoeffs)
         return 1;
-    if (rate_upload_tables(CabacCost, 0))
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || rate_tables_once(dev))
         return 1;
     SvtAmdTuInfo hi = {numNonZeroCoeffs, (uint8_t)type, (uint8_t)intraLumaMode, (uint8_t)intraChromaMode, (uint8_t)componentType};
-    DBuf c(coeffBufferPtr, span(coeffStride, size, size) * 2), i(&hi, sizeof(hi)), o(nullptr, 8, false);
-    if (!(c.ok && i.ok && o.ok))
+    DBuf c(coeffBufferPtr, span(coeffStride, size, size) * 2), i(&hi, sizeof(hi)), o(nullptr, 8, false), k(CabacCost, sizeof(*CabacCost));
+    if (!(c.ok && i.ok && o.ok && k.ok))
         return 1;
-    if (launch_rate(0, size, (const int16_t *)c.d, coeffStride, 0, (const SvtAmdTuInfo *)i.d, (unsigned long long *)o.d, 1))
+    if (launch_rate(0, (const SvtAmdCabacCost *)k.d, size, (const int16_t *)c.d, coeffStride, 0, (const SvtAmdTuInfo *)i.d, (unsigned long long *)o.d, 1))
         return 1;
     unsigned long long v = 0;
     if (!finish("EstimateQuantizedCoefficients_Lossy") || !o.download(&v, 8))

@@ -33,6 +33,8 @@ struct DevPicture {
     void *d_me_carry;              /* MeCarry per LCU (me_kernels.hip), 192 B reserved each */
     uint8_t *d_staging;            /* device copy of the raw luma (upload path) */
     size_t   staging_bytes;
+    uint8_t *h_staging;            /* pinned host copy of the raw luma (asynchronous upload path), allocated on first use */
+    hipEvent_t ev_ready;           /* recorded after the planes of this slot were built: lanes on other streams wait on it */
     uint16_t width, height;
     int      valid;
 };
@@ -68,6 +70,7 @@ struct OisJobDev {
 
 struct SvtAmdContext {
     int device;
+    SvtAmdContext *parent;         /* lane (svt_amd_context_fork): shares the parent's picture slots, owns everything else */
     hipStream_t stream;
     uint16_t max_w, max_h;
     int num_slots;
@@ -83,7 +86,19 @@ struct SvtAmdContext {
     MeJobDev *d_jobs;              /* device array of SVT_AMD_MAX_BATCH job descriptors */
     unsigned long long *d_dbg;     /* phase-profile buffer (svt_amd_debug_me_phase_profile) */
     size_t dbg_slots;
+    void *d_cabac_cost;            /* this context's copy of the caller's CabacCost_t (rate_device.h) */
+    uint8_t *d_leaf_scratch;       /* staging of the one-unit host-pointer forms (svt_amd_ctx_scratch) */
+    size_t leaf_scratch_bytes;
+    /* front-end pipeline (svt_amd_frontend_submit / _wait): pinned result buffers + completion event of this lane */
+    SvtAmdMeLcuResult *h_me;
+    SvtAmdOisLcuResult *h_ois;
+    hipEvent_t ev_done;
+    int frontend_busy;
 };
+
+/* device scratch of at least `bytes` owned by the context (grown on demand, freed by svt_amd_context_destroy);
+ * callers serialise per context, as for every other call on one context */
+int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out);
 
 void svt_amd_set_error(const char *fmt, ...);
 #define HIP_TRY(expr)                                                                      \

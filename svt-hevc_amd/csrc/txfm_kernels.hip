@@ -672,10 +672,13 @@ extern "C" int svt_amd_recon_tu(SvtAmdContext *ctx, int bytes_per_sample, int si
         reconStride < (uint32_t)size)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    static uint8_t *d_scratch = nullptr; /* unit | coeff | pred -> recon (in place) */
+    uint8_t *d_scratch = nullptr; /* unit | coeff | pred -> recon (in place) */
     const size_t o_unit = 0, o_coeff = 64, o_pix = o_coeff + 2048, total = o_pix + 2048;
-    if (!d_scratch)
-        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
+        if (rc_s)
+            return rc_s;
+    }
     const size_t bps = (size_t)bytes_per_sample;
     int16_t hc[32 * 32];
     uint8_t hp[32 * 32 * 2];
@@ -809,10 +812,13 @@ extern "C" int svt_amd_unified_quantize(SvtAmdContext *ctx, const SvtAmdQuantUni
         (unit->shape != 3 && (unit->size >> unit->shape) < 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    static uint8_t *d_scratch = nullptr; /* unit | nz | coeff | quant | recon ; callers serialise per context */
+    uint8_t *d_scratch = nullptr; /* unit | nz | coeff | quant | recon ; callers serialise per context */
     const size_t o_unit = 0, o_nz = 64, o_c = 128, o_q = o_c + 2048, o_r = o_q + 2048, total = o_r + 2048;
-    if (!d_scratch)
-        HIP_TRY(hipMalloc((void **)&d_scratch, total));
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
+        if (rc_s)
+            return rc_s;
+    }
     const int N = unit->size, area = unit->shape == 3 ? 1 : N >> unit->shape;
     int16_t hc[32 * 32], hq[32 * 32], hr[32 * 32];
     for (int y = 0; y < N; y++)

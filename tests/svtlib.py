@@ -296,6 +296,21 @@ def write_clip10(path, kind, w, h, n, seed):
                 f.write(((plane.astype(np.uint16) << 2) | lsb).astype("<u2").tobytes())
 
 
+def write_clip10_compressed(path, kind, w, h, n, seed):
+    """10-bit clip in the reference's compressed format (-compressed-ten-bit-format 1; Docs/svt-hevc_encoder_user_guide.md
+    "Compressed 10-bit format", read by Source/App/EbAppProcessCmd.c:881-900): per frame the three 8-bit MSB planes, then the
+    three 2-bit planes packed four samples to a byte (luma W*H/4 bytes in the 64x64-unrolled order, then Cb, Cr).  Every byte
+    value is a legal quadruple of 2-bit samples, so the LSB planes are seeded random bytes."""
+    rng = np.random.default_rng(seed + 2000)
+    with open(path, "wb") as f:
+        for t in range(n):
+            cb, cr = gen_chroma(w, h, t)
+            for plane in (gen_luma(kind, w, h, t, seed), cb, cr):
+                f.write(plane.tobytes())
+            for size in (w * h // 4, w * h // 16, w * h // 16):
+                f.write(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+
+
 def plane_checksum(luma):
     """Same polynomial as oracle/ref_harness_me_dump.c:plane_checksum (s = s*31 + v mod 2^32)."""
     flat = luma.astype(np.uint64).ravel()
