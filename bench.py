@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py - hot-path throughput of the MI355X-native SVT-HEVC block-analysis path.
+"""bench.py - throughput of the MI355X-native SVT-HEVC block-analysis hot path on BASELINE.json's headline configuration.
 
-One "step" = one pass of the hot path over one batch of synthetic 1080p pictures
-(BASELINE.json configs[1]: 1920x1080 8-bit, encMode 9, low-delay P): for every picture
-of the batch, picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes),
-open-loop motion estimation of all 510 LCUs against the previous picture (HME L0/L1,
-full-pel 85-PU search, half/quarter-pel refinement, candidate records) and open-loop
-intra search (OIS points from the ME distortions, stage-1 modes, candidate injection),
-with the controls exactly as the reference encoder derived them for this configuration
-(tests/golden/me_p_1920x1080_m9.npz, ois_ip_1920x1080_m9.npz).  Inputs are resident in HBM before the timed
-region; results stay in HBM (the PCIe-inclusive rate is discussed in DESIGN.md).
+Workload (default, `--config 2`): BASELINE configs[2] = 3840x2160 8-bit, encMode 7, random access with 2 hierarchical levels
+(B pictures, two reference lists, HME level-0 64x32 + level 1, full-pel 16x9, selective sub-pel), controls exactly as the
+reference encoder derived them for this configuration (tests/golden/me_b_3840x2160_m7.npz, ois_ib_3840x2160_m7.npz).
+`--config 1` = BASELINE configs[1] (1920x1080 encMode 9 low-delay P, one list).
 
-Prints ONE JSON line (rank 0).  `value` = pictures/s of the hot path over all GPUs,
-NOT whole-encoder fps: the closed-loop EncDec half is not on the device yet
-(DESIGN.md "scope").  N>1: pictures are sharded over ranks (independent, no collective).
+One "step" = one pass of the front half of the hot path over one batch of B pictures PER LANE (2 lanes), THROUGH THE HOST BOUNDARY:
+    pinned host luma --H2D--> picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes, one launch)
+    -> open-loop motion estimation of every LCU against both references (HME, full-pel 85-PU search, half/quarter-pel,
+       bi-prediction, candidate records: 2 kernels per list, one batched launch each)
+    -> open-loop intra search (one batched launch, reads the ME results left in HBM)
+    --D2H--> ME records (3,420 B/LCU) + OIS records (6,208 B/LCU) in pinned host memory.
+Two lanes (streams over the same picture slots, svt_amd_context_fork) alternate steps, so the copies of one step overlap the
+kernels of the other.  Both PCIe directions are INSIDE the timed region; `hbm_resident_fps` is the same loop without them.
+
+Prints ONE JSON line (rank 0).  `value` = front-half pictures/s over all GPUs, NOT whole-encoder fps: the closed-loop EncDec
+half still runs on the host in the hooked encoder, whose md5-gated whole-encoder fps is reported beside it as `encoder_fps`
+(hooked encoder vs the unmodified reference on the same clip).  N>1: every rank runs its own pictures (no collective).
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -29,86 +36,111 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import svtlib as S  # noqa: E402
 from golden_util import load_case  # noqa: E402
 
-W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
+CONFIGS = {
+    2: dict(w=3840, h=2160, me="b_3840x2160_m7", me_pic=0, ois="ib_3840x2160_m7", ois_pic=4, enc="cfg3",
+            name="4K 8-bit encMode 7 random-access B pictures (BASELINE configs[2])"),
+    1: dict(w=1920, h=1080, me="p_1920x1080_m9", me_pic=0, ois="ip_1920x1080_m9", ois_pic=1, enc="cfg2",
+            name="1080p 8-bit encMode 9 low-delay P pictures (BASELINE configs[1])"),
+}
 
-def synth_frames_device(n, seed, device):
-    """Moving-texture luma frames generated on the device (uint8 [n, H, W])."""
+
+def synth_frames(n, w, h, seed, device):
+    """Moving-texture luma frames generated on the device (uint8 [n, h, w]) - SURVEY 8d's clip."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    noise = torch.randint(0, 256, (H + 2 * n + 8, W + 4 * n + 8), dtype=torch.uint8, device=device, generator=g)
-    x = torch.arange(W, device=device, dtype=torch.float32)[None, :]
-    y = torch.arange(H, device=device, dtype=torch.float32)[:, None]
-    frames = torch.empty((n, H, W), dtype=torch.uint8, device=device)
+    noise = torch.randint(0, 256, (h + 2 * n + 8, w + 4 * n + 8), dtype=torch.uint8, device=device, generator=g)
+    x = torch.arange(w, device=device, dtype=torch.float32)[None, :]
+    y = torch.arange(h, device=device, dtype=torch.float32)[:, None]
+    frames = torch.empty((n, h, w), dtype=torch.uint8, device=device)
     for t in range(n):
-        l = 128 + 50 * (torch.sin((x + 3 * t) / 17.0) + torch.cos((y + 2 * t) / 23.0)) + \
-            (noise[t:t + H, 2 * t:2 * t + W] >> 4).float()
+        l = 128 + 50 * (torch.sin((x + 3 * t) / 17.0) + torch.cos((y + 2 * t) / 23.0)) + (noise[t:t + h, 2 * t:2 * t + w] >> 4).float()
         frames[t] = l.clamp(0, 255).to(torch.uint8)
     return frames
 
 
-def cpu_baseline_port(params, oparams, budget_s=12.0):
-    """Oracle (plain C restatement, 1 thread) on a bounded sample of the same workload: whole pictures
-    (prep + ME + OIS + the residual / DCT / quantiser / reconstruction stage each) until the time budget is used."""
-    oracle = S.load_oracle()
-    oracle.svt_oracle_encode_plane.restype = C.c_uint64
-    oracle.svt_oracle_encode_plane.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7
-    H16 = H // 16 * 16
-    frames = [S.gen_luma("motion", W, H, t, 7) for t in range(4)]
-    nl = S.lcu_count(W, H)
-    prev = S.OraclePicture(oracle, frames[0])
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        f = frames[(done + 1) % len(frames)]
-        cur = S.OraclePicture(oracle, f)                                  # pad + decimate + half-pel planes
-        me = S.oracle_me_picture(oracle, params, cur, prev, None, 0, nl)  # ME of all LCUs
-        S.oracle_ois_picture(oracle, oparams, f, me)                      # OIS of all LCUs
-        src, rec = np.ascontiguousarray(f), np.ascontiguousarray(frames[done % len(frames)]).copy()
-        oracle.svt_oracle_encode_plane(src.ctypes.data, rec.ctypes.data, W, W, 0, H16, 16, 32, 1)          # 16x16 units
-        oracle.svt_oracle_encode_plane(src.ctypes.data, rec.ctypes.data, W, W, H16, H - H16, 8, 32, 1)     # last 8 rows: 8x8
-        prev = cur
-        done += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 4), "unit": "fps", "cores": 1, "kind": "port",
-            "sample": "%d whole 1080p P pictures (prep + ME + OIS of 510 LCUs + residual/DCT/quantiser/reconstruction of the luma plane "
-                      "each; oracle/svt_oracle_me.c, svt_oracle_ois.c, svt_oracle_fullloop.c:svt_oracle_encode_plane; 1 thread; "
-                      "%.1f s)" % (done, dt)}
+def cpu_baseline_reference(cfg, unique=8, frames=48):
+    """The REFERENCE's own front half on this host: oracle/_ref/SvtHevcEncApp_ref (-asm 1 = AVX2 tables) encodes a bounded clip
+    of the same configuration while oracle/ref_harness_front_time.c sums the thread CPU time spent inside MotionEstimateLcu and
+    OpenLoopIntraSearchLcu.  value = pictures per CPU-second of those two functions = the one-core rate of the same stages."""
+    import encoder_fps as E
+    w, h, depth, args = E.CONFIGS[cfg["enc"]]
+    with tempfile.TemporaryDirectory() as td:
+        yuv, rep = os.path.join(td, "c.yuv"), os.path.join(td, "front.json")
+        S.write_clip(yuv, "motion", w, h, unique, 7)
+        t0 = time.perf_counter()
+        E.run_app(S.REF_APP, yuv, w, h, frames, args + ["-asm", "1"], os.path.join(td, "o.265"), env={"SVT_REF_FRONT_TIME": rep},
+                  nb=unique)
+        wall = time.perf_counter() - t0
+        r = json.load(open(rep))
+    nl = S.lcu_count(w, h)
+    cpu_s = (r["me_ns"] + r["ois_ns"]) * 1e-9
+    pictures = r["ois_calls"] / nl
+    return {"value": round(pictures / cpu_s, 3), "unit": "fps", "cores": 1, "kind": "reference",
+            "sample": "%d %dx%d pictures of the same configuration (%d unique, looped) through oracle/_ref/SvtHevcEncApp_ref -asm 1 "
+                      "(reference compiled in place, AVX2 tables); thread CPU time inside MotionEstimateLcu (%d LCU calls, %.2f s) + "
+                      "OpenLoopIntraSearchLcu (%d LCU calls, %.2f s) summed over all threads = %.2f CPU-s; picture preparation "
+                      "(decimation / padding) is outside those two functions and not counted; encoder wall %.1f s" %
+                      (int(pictures), w, h, unique, r["me_calls"], r["me_ns"] * 1e-9, r["ois_calls"], r["ois_ns"] * 1e-9, cpu_s, wall),
+            "host_threads": os.cpu_count(),
+            "all_cores_upper_bound": round(pictures / cpu_s * (os.cpu_count() or 1), 1)}
 
 
-def reference_encoder_fps(frames=24):
-    """Whole reference encoder (AVX2 path, all host cores) on the same configuration - context only."""
-    if not os.path.exists(S.REF_APP):
-        return None
-    try:
-        with tempfile.TemporaryDirectory() as td:
-            yuv = os.path.join(td, "c.yuv")
-            S.write_clip(yuv, "motion", W, H, frames, 7)
-            out = subprocess.run([S.REF_APP, "-i", yuv, "-w", str(W), "-h", str(H), "-n", str(frames), "-encMode", "9",
-                                  "-pred-struct", "0", "-q", "32", "-asm", "1", "-b", os.path.join(td, "o.265")],
-                                 capture_output=True, text=True, timeout=300).stdout
-        for line in out.splitlines():
-            if "Average Speed" in line:
-                return {"value": float(line.split()[2]), "unit": "fps (whole encoder, -asm 1)",
-                        "cores": os.cpu_count(), "frames": frames}
-    except Exception as e:  # context only
-        return {"error": str(e)}
-    return None
+def pmc_traffic(argv_inner, kernel_tag="k_me"):
+    """HBM traffic of the dominant kernels, measured: re-runs this command (2 steps) under rocprofv3 --pmc FETCH_SIZE and, in a
+    separate pass, --pmc WRITE_SIZE (the TCC block cannot hold both, MI355X_MICROARCH.md "rocprofv3 PMC slots"), sums the
+    counters over the dispatches of the two ME kernels and divides by the ME batches launched.  Counter unit is KiB; on gfx950
+    FETCH_SIZE tallies 128-B requests at 64 B, so the corrected figure doubles it (same guide, "HBM")."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = {}
+    batches = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="svtpmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", td, "--", sys.executable,
+                                os.path.abspath(__file__)] + argv_inner, capture_output=True, text=True, timeout=600, env=env,
+                               cwd="/tmp")
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+            total, n = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        total += float(row["Counter_Value"])
+                        n += 1
+            inner = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            info = json.loads(inner[-1])
+            batches = info["me_batches"]
+            out[counter] = total * 1024.0 / batches
+            out[counter + "_dispatches"] = n
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return {"fetch_bytes_raw": int(out["FETCH_SIZE"]), "write_bytes_raw": int(out["WRITE_SIZE"]),
+            "fetch_bytes_corrected": int(2 * out["FETCH_SIZE"]),
+            "per": "ME batch (all dispatches of k_me<0> + k_me<1> of one svt_amd_me_batch_launch)",
+            "dispatches_counted": out["FETCH_SIZE_dispatches"], "batches": batches}, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="pictures per step per GPU")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="pictures per step per GPU (default: 64 at 4K, 128 at 1080p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent picture sequences per GPU, each on its own context/stream, stepped round-robin "
-                         "(2 overlaps the latency-bound kernels of neighbouring batches; per-kernel times then inflate)")
+    ap.add_argument("--no-encoder-fps", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true")
+    ap.add_argument("--inner", action="store_true", help="(internal) counter pass: GPU loop only, prints the batch count")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,104 +153,69 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    cfg = CONFIGS[a.config]
+    W, H = cfg["w"], cfg["h"]
     lib = S.load_product()  # fails loudly when the HIP library is absent
-    B = a.batch
-    g = load_case("p_1920x1080_m9")
-    params = S.params_from_record(g["params"][0])
-    og = np.load(os.path.join(S.GOLDEN_DIR, "ois_ip_1920x1080_m9.npz"))
-    oparams = S.ois_params_from_record(og["params"][1])  # the P picture of the reference run
-    assert not oparams.slice_is_intra
-    lib.svt_amd_picture_upload_device_batch.restype = C.c_int
-    lib.svt_amd_picture_upload_device_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
-                                                        C.c_uint32, C.c_uint16, C.c_uint16]
-    # Ring of B+1 slots: picture n lives in slot n % (B+1) and is searched against picture n-1, so every
-    # picture is prepared exactly once and the B pictures of a step are independent of each other
-    # (the front half is open loop): per step ONE prep launch, ONE ME batch (2 launches), ONE OIS launch.
-    R = B + 1
-    # Residual / DCT / quantiser / reconstruction stage (the "+ DCT" of BASELINE configs[1]): every picture's luma plane as 16x16
-    # transform units (8x8 for the last 8 rows of 1080), each predicted from the co-located block of the working reconstruction
-    # plane of its batch position, through the fused encode-pass kernel (svt_amd_encode_tu_batch: residual -> DCT -> Q -> iQ ->
-    # iDCT -> reconstruction in place).  One launch per unit size and step.
-    eudt = np.dtype([("src_off", "<i4"), ("rec_off", "<i4"), ("qp", "u1"), ("slice_type", "u1"), ("pad", "u1", 2), ("dz", "<u4")])
-    lib.svt_amd_encode_tu_batch.restype = C.c_int
-    lib.svt_amd_encode_tu_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
-                                            C.c_void_p, C.c_void_p, C.c_uint32]
-    H16 = H // 16 * 16
-    g16 = np.stack(np.meshgrid(np.arange(0, H16, 16), np.arange(0, W, 16), indexing="ij"), -1).reshape(-1, 2)
-    g8 = np.stack(np.meshgrid(np.arange(H16, H, 8), np.arange(0, W, 8), indexing="ij"), -1).reshape(-1, 2)
+    vp, i32 = C.c_void_p, C.c_int
 
-    def unit_list(grid, cur_slots):
-        u = np.zeros(len(cur_slots) * len(grid), eudt)
-        for i, cur in enumerate(cur_slots):
-            blk = u[i * len(grid):(i + 1) * len(grid)]
-            blk["src_off"] = cur * H * W + grid[:, 0] * W + grid[:, 1]
-            blk["rec_off"] = i * H * W + grid[:, 0] * W + grid[:, 1]
-        u["qp"], u["slice_type"] = 32, 1
-        return u
-
-    def make_lane(idx):
-        ctx = C.c_void_p()
-        rc = lib.svt_amd_context_create(local_rank, W, H + 8, R, C.byref(ctx))
+    def ok(rc):
         assert rc == 0, lib.svt_amd_last_error()
-        frames = synth_frames_device(R, 1234 + 17 * rank + idx, dev)
-        rec = frames[:B].clone()                                     # working reconstruction planes, one per batch position
-        quant = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
-        nz = torch.zeros(B * (len(g16) + len(g8)), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        phases = []
-        for k in range(R):  # step s starts at picture n0 = 1 + s*B; phase = n0 % R
-            slots = (C.c_int * B)()
-            ptrs = (C.c_void_p * B)()
-            jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
+
+    B = a.batch or (64 if a.config == 2 else 128)
+    g = load_case(cfg["me"])
+    params = S.params_from_record(g["params"][cfg["me_pic"]])
+    og = np.load(os.path.join(S.GOLDEN_DIR, "ois_%s.npz" % cfg["ois"]))
+    oparams = S.ois_params_from_record(og["params"][cfg["ois_pic"]])
+    assert not oparams.slice_is_intra and params.luma_width == W and oparams.luma_width == W
+    nlists = params.num_lists
+    nlcu = S.lcu_count(W, H)
+    me_b, ois_b = C.sizeof(S.MeLcuResult), S.OIS_LCU_DTYPE.itemsize
+    NL = 2  # lanes
+    root = vp()
+    ok(lib.svt_amd_context_create(local_rank, W, (H + 7) & ~7, NL * B, C.byref(root)))
+    # pinned host input: B distinct frames of the moving-texture clip (shared by both lanes)
+    h_in = vp()
+    ok(lib.svt_amd_host_alloc(root, B * W * H, C.byref(h_in)))
+    frames = synth_frames(B, W, H, 1234 + 17 * rank, dev)
+    torch.cuda.synchronize()
+    ok(lib.svt_amd_device_download(root, h_in, vp(frames.data_ptr()), B * W * H))
+    del frames
+    lanes = []
+    for li in range(NL):
+        lane = vp()
+        ok(lib.svt_amd_context_fork(root, C.byref(lane)))
+        d_stage, h_me, h_ois = vp(), vp(), vp()
+        ok(lib.svt_amd_device_alloc(lane, B * W * H, C.byref(d_stage)))
+        ok(lib.svt_amd_host_alloc(lane, B * nlcu * me_b, C.byref(h_me)))
+        ok(lib.svt_amd_host_alloc(lane, B * nlcu * ois_b, C.byref(h_ois)))
+        slots = (i32 * B)(*[li * B + i for i in range(B)])
+        ptrs = (vp * B)(*[d_stage.value + i * W * H for i in range(B)])
+        jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
+        for i in range(B):  # picture i against its neighbours in the batch (list 0 = previous, list 1 = next)
+            jobs[i].params, jobs[i].cur_slot = params, slots[i]
+            jobs[i].ref_slot[0] = slots[(i - 1) % B]
+            jobs[i].ref_slot[1] = slots[(i + 1) % B]
+            ojobs[i].params, ojobs[i].cur_slot = oparams, slots[i]
+        lanes.append(dict(ctx=lane, d_stage=d_stage, h_me=h_me, h_ois=h_ois, slots=slots, ptrs=ptrs, jobs=jobs, ojobs=ojobs))
+
+    counts = {"batches": 0}
+
+    def step(L, copies=True):
+        ok(lib.svt_amd_synchronize(L["ctx"]))  # this lane's previous step is complete: its buffers are free again
+        if copies:
+            ok(lib.svt_amd_device_upload_async(L["ctx"], L["d_stage"], h_in, B * W * H))
+        ok(lib.svt_amd_picture_upload_device_batch(L["ctx"], B, L["slots"], L["ptrs"], W, W, H))
+        ok(lib.svt_amd_me_batch_launch(L["ctx"], L["jobs"], B))
+        ok(lib.svt_amd_ois_batch_launch(L["ctx"], L["ojobs"], B))
+        if copies:
             for i in range(B):
-                cur, ref = (k + i) % R, (k + i - 1) % R
-                slots[i], ptrs[i] = cur, frames[cur].data_ptr()
-                jobs[i].params, jobs[i].cur_slot = params, cur
-                jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = ref
-                ojobs[i].params, ojobs[i].cur_slot = oparams, cur
-            curs = [(k + i) % R for i in range(B)]
-            u16 = torch.from_numpy(unit_list(g16, curs).view(np.uint8)).to(dev)
-            u8 = torch.from_numpy(unit_list(g8, curs).view(np.uint8)).to(dev) if len(g8) else None
-            phases.append((slots, ptrs, jobs, ojobs, u16, u8))
-        state = {"n0": 1}
-
-        def step():
-            slots, ptrs, jobs, ojobs, u16, u8 = phases[state["n0"] % R]
-            r = lib.svt_amd_picture_upload_device_batch(ctx, B, slots, ptrs, W, W, H)
-            assert r == 0, lib.svt_amd_last_error()
-            r = lib.svt_amd_me_batch_launch(ctx, jobs, B)
-            assert r == 0, lib.svt_amd_last_error()
-            r = lib.svt_amd_ois_batch_launch(ctx, ojobs, B)  # reads the ME results left on the device
-            assert r == 0, lib.svt_amd_last_error()
-            r = lib.svt_amd_encode_tu_batch(ctx, 1, 16, u16.data_ptr(), frames.data_ptr(), W, rec.data_ptr(), W, quant.data_ptr(),
-                                            nz.data_ptr(), B * len(g16))
-            assert r == 0, lib.svt_amd_last_error()
-            if u8 is not None:
-                r = lib.svt_amd_encode_tu_batch(ctx, 1, 8, u8.data_ptr(), frames.data_ptr(), W, rec.data_ptr(), W,
-                                                quant.data_ptr() + 2 * 256 * B * len(g16),   # levels are stored unit after unit
-                                                nz.data_ptr() + 4 * B * len(g16), B * len(g8))
-                assert r == 0, lib.svt_amd_last_error()
-            state["n0"] += B
-
-        r = lib.svt_amd_picture_upload_device(ctx, 0, C.c_void_p(frames[0].data_ptr()), W, W, H)
-        assert r == 0, lib.svt_amd_last_error()
-        return ctx, step, (frames, rec, quant, nz)
-
-    lanes = [make_lane(i) for i in range(max(1, a.streams))]
-    ctx = lanes[0][0]
-    tick = {"i": 0}
-
-    def step():
-        lanes[tick["i"] % len(lanes)][1]()
-        tick["i"] += 1
+                ok(lib.svt_amd_me_picture_fetch_async(L["ctx"], L["slots"][i], vp(L["h_me"].value + i * nlcu * me_b)))
+                ok(lib.svt_amd_ois_picture_fetch_async(L["ctx"], L["slots"][i], vp(L["h_ois"].value + i * nlcu * ois_b)))
+        counts["batches"] += 1
 
     def sync_all():
-        for c, _, _ in lanes:
-            lib.svt_amd_synchronize(c)
-
-    for _ in range(a.warmup):
-        step()
-    sync_all()
+        for L in lanes:
+            ok(lib.svt_amd_synchronize(L["ctx"]))
 
     def barrier():
         if world > 1:
@@ -226,69 +223,109 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    lib.svt_amd_timer_begin(ctx)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    def timed(nsteps, copies):
+        barrier()
+        for L in lanes:
+            lib.svt_amd_timer_begin(L["ctx"])
+        t0 = time.perf_counter()
+        for s in range(nsteps):
+            for L in lanes:  # one batch per lane per step: lane 1's copies run under lane 0's kernels and vice versa
+                step(L, copies)
+        sync_all()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        kt = {}
+        for cls in (b"me_search", b"prep", b"ois"):
+            tot, n = 0.0, 0
+            for L in lanes:
+                ms, k, ev = C.c_float(), C.c_int(), C.c_float()
+                lib.svt_amd_kernel_time(L["ctx"], cls, C.byref(ms), C.byref(k))
+                tot += ms.value * k.value
+                n += k.value
+            kt[cls.decode()] = (tot / n if n else 0.0, n)
+        for L in lanes:
+            ev = C.c_float()
+            lib.svt_amd_timer_end(L["ctx"], C.byref(ev))
+        return dt, kt
+
+    for s in range(a.warmup):
+        for L in lanes:
+            step(L)
     sync_all()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = C.c_float()
-    lib.svt_amd_timer_end(ctx, C.byref(ev_ms))
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, kt = timed(a.steps, True)
 
-    me_ms, me_n, prep_ms, prep_n = C.c_float(), C.c_int(), C.c_float(), C.c_int()
-    lib.svt_amd_kernel_time(ctx, b"me_search", C.byref(me_ms), C.byref(me_n))
-    lib.svt_amd_kernel_time(ctx, b"prep", C.byref(prep_ms), C.byref(prep_n))
-    ois_ms, ois_n = C.c_float(), C.c_int()
-    lib.svt_amd_kernel_time(ctx, b"ois", C.byref(ois_ms), C.byref(ois_n))
+    if a.inner:
+        if rank == 0:
+            print(json.dumps({"me_batches": counts["batches"], "pictures_per_batch": B}), flush=True)
+    else:
+        dt_res, kt_res = timed(max(2, a.steps // 2), False)
+        res_steps = max(2, a.steps // 2)
 
-    if rank == 0:
-        pictures = world * B * a.steps
-        fps = pictures / dt
-        nlcu = S.lcu_count(W, H)
-        # algorithmic HBM bytes of one ME launch: source + 1 reference, each
+    if rank == 0 and not a.inner:
+        fps = world * NL * B * a.steps / dt
+        me_ms, me_n = kt["me_search"]
+        # algorithmic HBM bytes of one ME batch: per picture the source + `nlists` references, each
         # full + 1/4 + 1/16 planes (1.3125 bytes/pel), plus the per-LCU result records
-        algo_bytes = B * (2 * 1.3125 * W * H + nlcu * C.sizeof(S.MeLcuResult))  # one launch = B pictures
-        achieved = algo_bytes / (me_ms.value * 1e-3) / 1e9 if me_ms.value > 0 else 0.0
+        algo_bytes = B * ((1 + nlists) * 1.3125 * W * H + nlcu * me_b)
+        achieved = algo_bytes / (me_ms * 1e-3) / 1e9 if me_ms > 0 else 0.0
         res = {
-            "metric": "encoded fps (hot path: picture prep + motion estimation + open-loop intra search + residual DCT/quantiser/"
-                      "reconstruction)", "value": round(fps, 2),
-            "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1080p 8-bit encMode 9 low-delay P (BASELINE configs[1]): per picture pad+decimate+"
-                                   "half-pel planes, open-loop ME (HME L0/L1, full-pel 85 PU, sub-pel) of 510 LCUs "
-                                   "vs previous picture, open-loop intra search, and the fused encode-pass unit (residual, DCT, quantiser, inverse "
-                                   "quantiser, inverse DCT, reconstruction) over the luma plane as 16x16 transform units; mode decision "
-                                   "control flow stays on the host",
-                       "width": W, "height": H, "pictures_per_step_per_gpu": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
-                       "parallelism": "pictures sharded over ranks, no collective", "streams_per_gpu": len(lanes)},
-            "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search), one batch = 2 launches", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of the two ME kernels per batch at this configuration
-                         # (profiles/r01_g_pmc_fetch.csv, _write.csv; separate passes, KB -> bytes, uncorrected)
-                         "traffic": int((134699.6 + 85340.2 + 224357.7 + 38430.8) * 1024) if B == 16 else None,
-                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms.value, 4),
-                         "launches_timed": me_n.value, "pictures_per_launch": B,
-                         "prep_avg_ms": round(prep_ms.value, 4), "prep_launches": prep_n.value,
-                         "ois_avg_launch_ms": round(ois_ms.value, 4), "ois_launches": ois_n.value,
-                         "event_ms_total": round(ev_ms.value, 3)},
+            "metric": "encoded fps (front half of the hot path through the host boundary: upload + picture preparation + motion "
+                      "estimation + open-loop intra search + result download); md5-gated whole-encoder fps in `encoder_fps`",
+            "value": round(fps, 2), "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": cfg["name"] + ": per picture H2D of the luma, pad + decimate + half-pel planes, open-loop ME of %d "
+                                   "LCUs against %d reference list(s) (HME L0 %dx%d + L1, full-pel %dx%d 85-PU search, sub-pel, "
+                                   "bi-prediction), open-loop intra search, D2H of the ME + OIS records; mode decision / encode "
+                                   "pass stay on the host (see encoder_fps)" %
+                                   (nlcu, nlists, params.hme_l0_total_w, params.hme_l0_total_h, params.search_area_width,
+                                    params.search_area_height),
+                       "width": W, "height": H, "pictures_per_step_per_gpu": NL * B, "pictures_per_launch": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
+                       "timed_region_s": round(dt, 3), "pcie_in_timed_region": True, "lanes_per_gpu": NL,
+                       "h2d_bytes_per_picture": W * H, "d2h_bytes_per_picture": nlcu * (me_b + ois_b),
+                       "parallelism": "pictures sharded over ranks, no collective"},
+            "hbm_resident_fps": round(world * NL * B * res_steps / dt_res, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search): one ME batch = %d dispatches (2 per list)" % (2 * nlists),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": None, "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms, 4),
+                         "launches_timed": me_n, "pictures_per_launch": B,
+                         "prep_avg_ms": round(kt["prep"][0], 4), "prep_launches": kt["prep"][1],
+                         "ois_avg_launch_ms": round(kt["ois"][0], 4), "ois_launches": kt["ois"][1],
+                         "avg_launch_ms_hbm_resident_loop": round(kt_res["me_search"][0], 4)},
         }
+        if world == 1 and not a.no_pmc:
+            tr, err = pmc_traffic(["--inner", "--steps", "2", "--warmup", "1", "--config", str(a.config), "--batch", str(B),
+                                   "--no-cpu-baseline", "--no-encoder-fps", "--no-pmc"])
+            if tr:
+                res["roofline"]["traffic"] = tr["fetch_bytes_corrected"] + tr["write_bytes_raw"]
+                res["roofline"]["traffic_detail"] = tr
+            else:
+                res["roofline"]["traffic_error"] = err
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_port(params, oparams)
-            ref = reference_encoder_fps()
-            if ref:
-                res["reference_encoder"] = ref
+            try:
+                res["cpu_baseline"] = cpu_baseline_reference(cfg)
+            except Exception as e:  # the reference build is absent: say so, do not substitute
+                res["cpu_baseline"] = {"error": str(e)[-300:]}
+        if world == 1 and not a.no_encoder_fps:
+            try:
+                import encoder_fps as E
+                res["encoder_fps"] = E.measure(cfg["enc"], frames=64, unique=16)
+            except Exception as e:
+                res["encoder_fps"] = {"error": str(e)[-300:]}
         print(json.dumps(res), flush=True)
 
-    for c, _, _ in lanes:
-        lib.svt_amd_context_destroy(c)
+    for L in lanes:
+        lib.svt_amd_device_free(L["ctx"], L["d_stage"])
+        lib.svt_amd_host_free(L["ctx"], L["h_me"])
+        lib.svt_amd_host_free(L["ctx"], L["h_ois"])
+        lib.svt_amd_context_destroy(L["ctx"])
+    lib.svt_amd_host_free(root, h_in)
+    lib.svt_amd_context_destroy(root)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

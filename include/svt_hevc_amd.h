@@ -288,6 +288,14 @@ SVT_AMD_API int svt_amd_picture_publish(SvtAmdContext *lane, int slot);
 SVT_AMD_API int svt_amd_frontend_submit(SvtAmdContext *lane, const SvtAmdFrontendJob *job);
 SVT_AMD_API int svt_amd_frontend_wait(SvtAmdContext *lane, const SvtAmdMeLcuResult **me, const SvtAmdOisLcuResult **ois);
 SVT_AMD_API int svt_amd_frontend_release(SvtAmdContext *lane);
+/* building blocks of the same pipeline for batched hosts (bench.py): stream-ordered copies that do not wait, pinned host
+ * memory to copy from / into, and the per-slot result copies; svt_amd_synchronize(lane) completes them */
+SVT_AMD_API int svt_amd_device_upload_async(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes);
+SVT_AMD_API int svt_amd_device_download_async(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes);
+SVT_AMD_API int svt_amd_host_alloc(SvtAmdContext *ctx, size_t bytes, void **h_ptr);
+SVT_AMD_API int svt_amd_host_free(SvtAmdContext *ctx, void *h_ptr);
+SVT_AMD_API int svt_amd_me_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out);
+SVT_AMD_API int svt_amd_ois_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out);
 
 /* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
 typedef struct SvtAmdOisJob {
@@ -716,6 +724,21 @@ typedef struct SvtAmdTuInfo {
 SVT_AMD_API int svt_amd_coeff_bits_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, uint32_t size,
                                          const int16_t *d_coeff, const SvtAmdTuInfo *d_info, uint64_t *d_bits,
                                          uint32_t nblocks);
+/* The CABAC-context-UPDATING estimator: EstimateQuantizedCoefficients_generic_Update / _Update_SSE2 (Codec/EbEntropyCoding.c:2986,
+ * 9355; table EstimateQuantizedCoefficientsUpdate, EbEntropyCoding.h:387), used by the mode decision's full loops when
+ * coeffCabacUpdate is on (EbEncDecProcess.c:2115-2123).  Context models are SVT_AMD_COEFF_CTX_WORDS 32-bit words in
+ * CoeffCtxtMdl_t's order (EbCabacContextModel.h:204-214): lastSigX[30] lastSigY[30] sig[42] coeffGroupSig[4] greater1[24]
+ * greater2[6]; every call leaves the updated states in place.
+ * BATCHED: nblocks contiguous size x size blocks; consecutive runs of chain_len blocks share model d_ctx_models[run] and are
+ * walked in order (the units of one candidate).  d_bits[b] = the amount added to *coeffBitsLong (15 fractional bits). */
+#define SVT_AMD_COEFF_CTX_WORDS 136
+SVT_AMD_API int svt_amd_coeff_bits_update_batch(SvtAmdContext *ctx, uint32_t size, const int16_t *d_coeff, const SvtAmdTuInfo *d_info,
+                                                uint32_t *d_ctx_models, uint64_t *d_bits, uint32_t nblocks, uint32_t chain_len);
+/* LEAF, reference signature (CoeffCtxtMdl_t * as uint32_t *) */
+SVT_AMD_API int svt_amd_EstimateQuantizedCoefficients_Update(uint32_t *updatedCoeffCtxModel, SvtAmdCabacCost *CabacCost, void *cabacEncodeCtxPtr,
+                                                             uint32_t size, uint32_t type, uint32_t intraLumaMode, uint32_t intraChromaMode,
+                                                             int16_t *coeffBufferPtr, const uint32_t coeffStride, uint32_t componentType,
+                                                             uint32_t numNonZeroCoeffs, uint64_t *coeffBitsLong);
 /* LEAF: slot [1][*] of EstimateQuantizedCoefficients (Codec/EbEntropyCoding.h:334-347); cabacEncodeCtxPtr unused, as in
  * the reference; returns EB_ERRORTYPE (0 = EB_ErrorNone). */
 SVT_AMD_API int svt_amd_EstimateQuantizedCoefficients_Lossy(SvtAmdCabacCost *CabacCost, void *cabacEncodeCtxPtr,
@@ -986,6 +1009,22 @@ SVT_AMD_API int svt_amd_full_loop_chroma_batch(SvtAmdContext *ctx, const SvtAmdC
 SVT_AMD_API int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
                                          const int16_t *const residual[2], int16_t *const quant[2],
                                          int16_t *const recon[2], uint32_t pitch, SvtAmdChromaLoopOut *out);
+/* coeffCabacUpdate forms (the mode decision of full-depth pictures: EbEncDecProcess.c:2115-2123; call sites EbFullLoop.c:265-280,
+ * 417-432, 1014-1035): the coefficient bits of every unit come from the context-updating estimator and the candidate's
+ * CoeffCtxtMdl_t (candidateBuffer->candBuffCoeffCtxModel; SVT_AMD_COEFF_CTX_WORDS words, see svt_amd_coeff_bits_update_batch) is
+ * updated in place, unit after unit (chroma: Cb then Cr of every unit). */
+SVT_AMD_API int svt_amd_full_loop_luma_cabac_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *d_in,
+                                                   const int16_t *d_residual, int16_t *d_quant, int16_t *d_recon,
+                                                   SvtAmdFullLoopOut *d_out, uint32_t *d_ctx_models, uint32_t ncand);
+SVT_AMD_API int svt_amd_full_loop_chroma_cabac_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *d_in,
+                                                     const int16_t *d_residual, int16_t *d_quant, int16_t *d_recon,
+                                                     SvtAmdChromaLoopOut *d_out, uint32_t *d_ctx_models, uint32_t ncand);
+SVT_AMD_API int svt_amd_full_loop_luma_cabac(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
+                                             const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch,
+                                             uint32_t *ctx_model, SvtAmdFullLoopOut *out);
+SVT_AMD_API int svt_amd_full_loop_chroma_cabac(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
+                                               const int16_t *const residual[2], int16_t *const quant[2], int16_t *const recon[2],
+                                               uint32_t pitch, uint32_t *ctx_model, SvtAmdChromaLoopOut *out);
 
 /* ------------------------------------------------------------------------- */
 /* HEVC motion-compensation interpolation (closed-loop inter prediction)      */

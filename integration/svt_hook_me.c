@@ -385,7 +385,8 @@ void __real_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
                             ModeDecisionCandidateBuffer_t *candidateBuffer, ModeDecisionContext_t *contextPtr,
                             const CodedUnitStats_t *cuStatsPtr, PictureControlSet_t *pcs, EB_U32 qp,
                             EB_U32 *yCountNonZeroCoeffs, EB_U64 *yCoeffBits, EB_U64 *yFullDistortion);
-static unsigned long g_fl_gpu, g_fl_cpu;
+static unsigned long g_fl_gpu, g_fl_cpu, g_fl_cabac_gpu, g_cl_cabac_gpu;
+_Static_assert(sizeof(CoeffCtxtMdl_t) == SVT_AMD_COEFF_CTX_WORDS * 4, "CoeffCtxtMdl_t layout");
 static int g_fl_state; /* 0 unknown, 1 on, -1 off */
 
 void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputOriginIndex,
@@ -396,7 +397,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     if (g_fl_state == 0)
         g_fl_state = getenv("SVT_HOOK_FULLLOOP") ? 1 : -1;
     if (g_fl_state < 0 || !g_ctx || (contextPtr->rdoqPmCoreMethod && contextPtr->rdoqPmCoreMethod != EB_PMCORE) ||
-        contextPtr->spatialSseFullLoop || contextPtr->coeffCabacUpdate || contextPtr->pfMdMode > 1) {
+        contextPtr->spatialSseFullLoop || contextPtr->pfMdMode > 1) {
         if (g_fl_state > 0) {
             pthread_mutex_lock(&g_lock);
             g_fl_cpu++;
@@ -421,8 +422,15 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     int16_t *q = (int16_t *)candidateBuffer->residualQuantCoeffPtr->bufferY + origin; /* residual in, quantised out */
     int16_t *r = (int16_t *)candidateBuffer->reconCoeffPtr->bufferY + origin;
     pthread_mutex_lock(&g_lock);
-    if (svt_amd_full_loop_luma(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, q, q, r, 64, &out))
+    /* coeffCabacUpdate (full-depth pictures, EbEncDecProcess.c:2115): the candidate's context model goes with the call and comes
+     * back updated (EbFullLoop.c:265-280; the mode decision copies it from / to latestValidCoeffCtxModel around the loop) */
+    if (contextPtr->coeffCabacUpdate
+            ? svt_amd_full_loop_luma_cabac(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, q, q, r, 64,
+                                           (uint32_t *)&candidateBuffer->candBuffCoeffCtxModel, &out)
+            : svt_amd_full_loop_luma(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, q, q, r, 64, &out))
         die("svt_amd_full_loop_luma");
+    if (contextPtr->coeffCabacUpdate)
+        g_fl_cabac_gpu++;
     if (g_fl_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: luma full loop (ProductFullLoop) on the GPU\n");
     if (g_verbose && (g_fl_gpu % 2000) == 0)
@@ -473,7 +481,7 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
     t_chroma_for = NULL;
     /* PM-core leaves chroma alone (EbTransforms.c:2808): its Decoupled... call is the plain quantiser there */
     if (g_fl_state < 0 || !g_ctx || (contextPtr->rdoqPmCoreMethod && contextPtr->rdoqPmCoreMethod != EB_PMCORE) || contextPtr->spatialSseFullLoop ||
-        contextPtr->coeffCabacUpdate || componentMask != PICTURE_BUFFER_DESC_CHROMA_MASK ||
+        componentMask != PICTURE_BUFFER_DESC_CHROMA_MASK ||
         candidateBuffer->residualQuantCoeffPtr->strideCb != 32 || candidateBuffer->reconCoeffPtr->strideCb != 32) {
         if (g_fl_state > 0) {
             pthread_mutex_lock(&g_lock);
@@ -496,9 +504,16 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
     int16_t *r[2] = {(int16_t *)candidateBuffer->reconCoeffPtr->bufferCb + origin,
                      (int16_t *)candidateBuffer->reconCoeffPtr->bufferCr + origin};
     pthread_mutex_lock(&g_lock);
-    if (svt_amd_full_loop_chroma(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, (const int16_t *const *)q, q, r, 32,
-                                 &t_chroma_out))
+    /* coeffCabacUpdate: the model is moved by the rate estimation of the SECOND reference call (TuEstimateCoeffBits_R inside
+     * CuFullDistortionFastTuMode_R); nothing touches it between the two, so updating it here is equivalent */
+    if (contextPtr->coeffCabacUpdate
+            ? svt_amd_full_loop_chroma_cabac(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, (const int16_t *const *)q, q, r, 32,
+                                             (uint32_t *)&candidateBuffer->candBuffCoeffCtxModel, &t_chroma_out)
+            : svt_amd_full_loop_chroma(g_ctx, (const SvtAmdCabacCost *)contextPtr->CabacCost, &in, (const int16_t *const *)q, q, r, 32,
+                                       &t_chroma_out))
         die("svt_amd_full_loop_chroma");
+    if (contextPtr->coeffCabacUpdate)
+        g_cl_cabac_gpu++;
     if (g_cl_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: chroma full loop (FullLoop_R + CuFullDistortionFastTuMode_R) on the GPU\n");
     if (g_verbose && (g_cl_gpu % 2000) == 0)
@@ -1471,6 +1486,7 @@ static void hook_report(void)
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionOl", g_cpu_IntraPredictionOl);
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision", g_cpu_SaoGenerationDecision);
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision16bit", g_cpu_SaoGenerationDecision16bit);
+        fprintf(out, "svt_hook_me: with the CABAC-context-updating estimator on the GPU: full loop luma %lu chroma %lu\n", g_fl_cabac_gpu, g_cl_cabac_gpu);
         fprintf(out, "svt_hook_me: on the GPU: full loop luma %lu (left to the reference code %lu) chroma %lu (%lu), recon %lu, intra encode pass %lu + 4x4 %lu, "
                         "intra MD closed %lu open %lu 4x4 %lu, inter encode pass %lu + 16-bit %lu, inter MD %lu, quantiser %lu + PM-core %lu, SAO %lu\n",
                 g_fl_gpu, g_fl_cpu, g_cl_gpu, g_cl_cpu, g_recon_gpu, g_intra_gpu, g_intra4_gpu, g_md_intra_gpu, g_md_intra_ol_gpu, g_md_intra4_gpu,

@@ -43,7 +43,10 @@ typedef struct FullLoopRecord {
     uint16_t cand_nz[4];
     SvtAmdCabacCost cost;
     int16_t residual[64 * 64], quant[64 * 64], recon[64 * 64]; /* size x size used, row pitch = size */
+    uint32_t cabac_update, pad;  /* contextPtr->coeffCabacUpdate */
+    uint32_t ctx_in[136], ctx_out[136]; /* candidateBuffer->candBuffCoeffCtxModel before / after (CoeffCtxtMdl_t) */
 } FullLoopRecord;
+_Static_assert(sizeof(CoeffCtxtMdl_t) == 136 * 4, "CoeffCtxtMdl_t");
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static FILE *g_file;
@@ -74,8 +77,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
         pthread_mutex_unlock(&g_lock);
     }
     int take = 0;
-    if (g_state > 0 && (!contextPtr->rdoqPmCoreMethod || contextPtr->rdoqPmCoreMethod == EB_PMCORE) && !contextPtr->spatialSseFullLoop &&
-        !contextPtr->coeffCabacUpdate) {
+    if (g_state > 0 && (!contextPtr->rdoqPmCoreMethod || contextPtr->rdoqPmCoreMethod == EB_PMCORE) && !contextPtr->spatialSseFullLoop) {
         pthread_mutex_lock(&g_lock);
         take = (g_calls++ % (unsigned long)g_stride) == 0;
         pthread_mutex_unlock(&g_lock);
@@ -102,6 +104,8 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     r->bits_in = *yCoeffBits, r->dist_in[0] = yFullDistortion[0], r->dist_in[1] = yFullDistortion[1];
     memcpy(&r->cost, contextPtr->CabacCost, sizeof(r->cost));
     grab(r->residual, candidateBuffer->residualQuantCoeffPtr, origin, size);
+    r->cabac_update = contextPtr->coeffCabacUpdate;
+    memcpy(r->ctx_in, &candidateBuffer->candBuffCoeffCtxModel, sizeof(r->ctx_in));
 
     __real_ProductFullLoop(inputPicturePtr, inputOriginIndex, candidateBuffer, contextPtr, cuStatsPtr, pcs, qp,
                            yCountNonZeroCoeffs, yCoeffBits, yFullDistortion);
@@ -111,6 +115,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     r->bits_out = *yCoeffBits, r->dist_out[0] = yFullDistortion[0], r->dist_out[1] = yFullDistortion[1];
     memcpy(r->ydc, candidateBuffer->yDc, sizeof(r->ydc));
     memcpy(r->cand_nz, candidateBuffer->yCountNonZeroCoeffs, sizeof(r->cand_nz));
+    memcpy(r->ctx_out, &candidateBuffer->candBuffCoeffCtxModel, sizeof(r->ctx_out));
     grab(r->quant, candidateBuffer->residualQuantCoeffPtr, origin, size);
     grab(r->recon, candidateBuffer->reconCoeffPtr, origin, size);
     pthread_mutex_lock(&g_lock);

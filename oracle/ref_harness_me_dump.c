@@ -33,6 +33,9 @@
 EB_ERRORTYPE __real_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX,
                                       EB_U32 lcuOriginY, MeContext_t *ctx, EbPictureBufferDesc_t *inputPtr);
 
+uint64_t svt_ref_front_time_begin(void);          /* ref_harness_front_time.c */
+void svt_ref_front_time_end(int which, uint64_t t0);
+
 #define DUMP_MAGIC 0x4d45444dU /* "MDEM" */
 
 typedef struct MeDumpRecord {
@@ -68,7 +71,9 @@ static uint32_t plane_checksum(const EbPictureBufferDesc_t *p)
 EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX,
                                       EB_U32 lcuOriginY, MeContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
 {
+    const uint64_t t0 = svt_ref_front_time_begin();
     EB_ERRORTYPE err = __real_MotionEstimateLcu(pcs, lcuIndex, lcuOriginX, lcuOriginY, ctx, inputPtr);
+    svt_ref_front_time_end(0, t0);
     if (g_state == 0) {
         pthread_mutex_lock(&g_lock);
         if (g_state == 0) {

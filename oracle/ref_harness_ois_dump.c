@@ -59,6 +59,9 @@ static void snapshot(const PictureParentControlSet_t *pcs, EB_U32 lcu, OisSnapsh
     }
 }
 
+uint64_t svt_ref_front_time_begin(void);          /* ref_harness_front_time.c */
+void svt_ref_front_time_end(int which, uint64_t t0);
+
 EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex,
                                            MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
 {
@@ -71,8 +74,12 @@ EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U3
         }
         pthread_mutex_unlock(&g_lock);
     }
-    if (g_state < 0)
-        return __real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
+    if (g_state < 0) {
+        const uint64_t t0 = svt_ref_front_time_begin();
+        EB_ERRORTYPE e0 = __real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
+        svt_ref_front_time_end(1, t0);
+        return e0;
+    }
 
     OisDumpRecord *r = (OisDumpRecord *)calloc(1, sizeof(*r));
     if (!r)

@@ -228,6 +228,15 @@ void svt_oracle_zz_sad_picture(const uint8_t *cur, const uint8_t *prev, uint32_t
 uint64_t svt_oracle_coeff_bits_lossy(const SvtAmdCabacCost *C, uint32_t size, uint32_t type, uint32_t intraLumaMode,
                                      uint32_t intraChromaMode, const int16_t *coeff, uint32_t stride,
                                      uint32_t componentType, uint32_t numNonZeroCoeffs);
+/* EstimateQuantizedCoefficients_generic_Update (Codec/EbEntropyCoding.c:2986): same pricing with real context states that
+ * every context-coded bin updates.  ctx = CoeffCtxtMdl_t as SVT_ORACLE_COEFF_CTX_WORDS words (updated in place); returns
+ * the amount added to *coeffBitsLong (15 fractional bits; the callers shift right by 15). */
+#define SVT_ORACLE_COEFF_CTX_WORDS 136
+uint64_t svt_oracle_coeff_bits_update(uint32_t *ctx, uint32_t size, uint32_t type, uint32_t intraLumaMode,
+                                      uint32_t intraChromaMode, const int16_t *coeff, uint32_t stride,
+                                      uint32_t componentType, uint32_t numNonZeroCoeffs);
+extern const uint32_t svt_oracle_cabac_estimated_bits[128];
+extern uint32_t svt_oracle_next_state_mps_lps[256];
 
 /* ---- luma full loop of one candidate (svt_oracle_fullloop.c) ---- */
 uint64_t svt_oracle_encode_plane(const uint8_t *src, uint8_t *rec, uint32_t stride, uint32_t width, uint32_t row0, uint32_t rows,
@@ -249,5 +258,11 @@ void svt_oracle_sao_decide_lcu(const SvtAmdSaoDecisionParams *P, const SvtAmdSao
 void svt_oracle_sao_decide_picture(const SvtAmdSaoDecisionParams *P, const SvtAmdSaoStats *sy, const SvtAmdSaoStats *scb,
                                    const SvtAmdSaoStats *scr, uint32_t cols, uint32_t rows, const uint8_t *enable,
                                    SvtAmdSaoLcuParams *params, int64_t *costs);
+
+/* coeffCabacUpdate forms of the two full loops: model = candBuffCoeffCtxModel, SVT_ORACLE_COEFF_CTX_WORDS words, in / out */
+void svt_oracle_product_full_loop_luma_cabac(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
+                                             int16_t *quant, int16_t *recon, uint32_t *model, SvtAmdFullLoopOut *out);
+void svt_oracle_full_loop_chroma_cabac(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
+                                       int16_t *const quant[2], int16_t *const recon[2], uint32_t *model, SvtAmdChromaLoopOut *out);
 
 #endif

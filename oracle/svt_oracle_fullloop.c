@@ -109,7 +109,7 @@ void svt_oracle_pmcore_quantize(const SvtAmdCabacCost *cost, const SvtAmdPmQuant
 /* one transform unit of size T at `origin` of pitch-`pitch` buffers */
 static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, uint32_t cuSize, uint32_t T, uint32_t tuIndex,
                          const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch, uint32_t *nzOut,
-                         uint64_t dist[2], uint64_t *bits, uint32_t *ycbf)
+                         uint64_t dist[2], uint64_t *bits, uint32_t *ycbf, uint32_t *model)
 {
     static const uint32_t QF[6] = {26214, 23302, 20560, 18396, 16384, 14564}, FF[6] = {40, 45, 51, 57, 64, 72};
     int16_t coeff[32 * 32];
@@ -145,8 +145,9 @@ static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in
     d[1] = (d[1] + ((uint64_t)1 << (shift - 1))) >> shift;
     /* TuEstimateCoeffBitsLuma */
     uint64_t tuBits = 0;
-    if (nz)
-        tuBits = svt_oracle_coeff_bits_lossy(cost, area, in->cand_type, in->intra_luma_mode, 4, quant, T, 0, nz);
+    if (nz) /* coeffCabacUpdate: the context-updating estimator moves the candidate's model (EbFullLoop.c:265-280) */
+        tuBits = model ? svt_oracle_coeff_bits_update(model, area, in->cand_type, in->intra_luma_mode, 4, quant, T, 0, nz)
+                       : svt_oracle_coeff_bits_lossy(cost, area, in->cand_type, in->intra_luma_mode, 4, quant, T, 0, nz);
     tuBits >>= 15;
     /* TuCalcCostLuma */
     const uint32_t ctx = cuSize == T;
@@ -162,8 +163,8 @@ static void full_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in
 
 /* residual / quant / recon: size x size, row pitch = size; quant and recon must be pre-filled by the caller with what the
  * reference buffers held (quant: the residual itself - one buffer serves both; recon: anything) */
-void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
-                                       int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out)
+static void product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
+                                   int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out, uint32_t *model)
 {
     memset(out, 0, sizeof(*out));
     out->ycbf = in->ycbf;
@@ -180,7 +181,7 @@ void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmd
                 memcpy(c + y * 32, recon + off + y * 64, 64);
             }
             uint64_t d[2], bits;
-            full_loop_tu(cost, in, 64, 32, tu + 1, r, q, c, 32, &out->nz[tu + 1], d, &bits, &out->ycbf);
+            full_loop_tu(cost, in, 64, 32, tu + 1, r, q, c, 32, &out->nz[tu + 1], d, &bits, &out->ycbf, model);
             for (int y = 0; y < 32; y++) {
                 memcpy(quant + off + y * 64, q + y * 32, 64);
                 memcpy(recon + off + y * 64, c + y * 32, 64);
@@ -192,12 +193,24 @@ void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmd
         }
     } else {
         uint64_t d[2], bits;
-        full_loop_tu(cost, in, S, S, 0, residual, quant, recon, S, &out->nz[0], d, &bits, &out->ycbf);
+        full_loop_tu(cost, in, S, S, 0, residual, quant, recon, S, &out->nz[0], d, &bits, &out->ycbf, model);
         out->coeff_bits += bits;
         out->dist[0] = d[0], out->dist[1] = d[1];
         out->ydc[0] = (int16_t)(quant[0] < 0 ? -quant[0] : quant[0]);
         out->cand_nz[0] = (uint16_t)out->nz[0];
     }
+}
+
+void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
+                                       int16_t *quant, int16_t *recon, SvtAmdFullLoopOut *out)
+{
+    product_full_loop_luma(cost, in, residual, quant, recon, out, NULL);
+}
+/* the same call with coeffCabacUpdate: model = candidateBuffer->candBuffCoeffCtxModel (SVT_ORACLE_COEFF_CTX_WORDS words), in / out */
+void svt_oracle_product_full_loop_luma_cabac(const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in, const int16_t *residual,
+                                             int16_t *quant, int16_t *recon, uint32_t *model, SvtAmdFullLoopOut *out)
+{
+    product_full_loop_luma(cost, in, residual, quant, recon, out, model);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -210,7 +223,7 @@ void svt_oracle_product_full_loop_luma(const SvtAmdCabacCost *cost, const SvtAmd
  * ------------------------------------------------------------------------------------------------------------------ */
 static void chroma_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, uint32_t qp, uint32_t T, uint32_t component,
                            const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t *nzOut, uint64_t dist[2],
-                           uint64_t *bits)
+                           uint64_t *bits, uint32_t *model)
 {
     static const uint32_t QF[6] = {26214, 23302, 20560, 18396, 16384, 14564}, FF[6] = {40, 45, 51, 57, 64, 72};
     int16_t coeff[16 * 16];
@@ -236,14 +249,15 @@ static void chroma_loop_tu(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn
     dist[1] = (d[1] + ((uint64_t)1 << (shift - 1))) >> shift;
     uint64_t tuBits = 0;
     if (nz)
-        tuBits = svt_oracle_coeff_bits_lossy(cost, area, in->cand_type, in->intra_luma_mode, 4, quant, T, component, nz);
+        tuBits = model ? svt_oracle_coeff_bits_update(model, area, in->cand_type, in->intra_luma_mode, 4, quant, T, component, nz)
+                       : svt_oracle_coeff_bits_lossy(cost, area, in->cand_type, in->intra_luma_mode, 4, quant, T, component, nz);
     *bits = tuBits >> 15;
 }
 
 /* residual / quant / recon: [0] Cb, [1] Cr, each (size/2)^2 with row pitch size/2; quant and recon pre-filled by the
  * caller with what the reference buffers held (quant: the residual itself; recon: anything) */
-void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
-                                 int16_t *const quant[2], int16_t *const recon[2], SvtAmdChromaLoopOut *out)
+static void full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
+                             int16_t *const quant[2], int16_t *const recon[2], SvtAmdChromaLoopOut *out, uint32_t *model)
 {
     memset(out, 0, sizeof(*out));
     const uint32_t C = in->size >> 1, T = in->size == 64 ? 16 : C, ntu = in->size == 64 ? 4 : 1;
@@ -257,7 +271,7 @@ void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChroma
                 memcpy(c + y * T, recon[p] + off + y * C, T * 2);
             }
             uint64_t d[2], bits;
-            chroma_loop_tu(cost, in, p ? in->cr_qp : in->cb_qp, T, p + 1, r, q, c, &out->nz[p][tuIndex], d, &bits);
+            chroma_loop_tu(cost, in, p ? in->cr_qp : in->cb_qp, T, p + 1, r, q, c, &out->nz[p][tuIndex], d, &bits, model);
             for (uint32_t y = 0; y < T; y++) {
                 memcpy(quant[p] + off + y * C, q + y * T, T * 2);
                 memcpy(recon[p] + off + y * C, c + y * T, T * 2);
@@ -267,6 +281,18 @@ void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChroma
             out->dist[p][0] += d[0], out->dist[p][1] += d[1];
         }
     }
+}
+
+void svt_oracle_full_loop_chroma(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
+                                 int16_t *const quant[2], int16_t *const recon[2], SvtAmdChromaLoopOut *out)
+{
+    full_loop_chroma(cost, in, residual, quant, recon, out, NULL);
+}
+/* coeffCabacUpdate: Cb then Cr of every unit move the candidate's model (TuEstimateCoeffBits_R, EbEntropyCoding.c:8032-8100) */
+void svt_oracle_full_loop_chroma_cabac(const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in, const int16_t *const residual[2],
+                                       int16_t *const quant[2], int16_t *const recon[2], uint32_t *model, SvtAmdChromaLoopOut *out)
+{
+    full_loop_chroma(cost, in, residual, quant, recon, out, model);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------

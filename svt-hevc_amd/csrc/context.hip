@@ -363,6 +363,40 @@ extern "C" int svt_amd_device_download(SvtAmdContext *ctx, void *dst, const void
     return SVT_AMD_OK;
 }
 
+/* asynchronous forms (stream-ordered on the context's stream, no host wait) and pinned host memory for them */
+extern "C" int svt_amd_device_upload_async(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || !d_dst || !src)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_device_download_async(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || !dst || !d_src)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_host_alloc(SvtAmdContext *ctx, size_t bytes, void **h_ptr)
+{
+    if (!ctx || !h_ptr || !bytes)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_host_free(SvtAmdContext *ctx, void *h_ptr)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostFree(h_ptr));
+    return SVT_AMD_OK;
+}
+
 /* ---- pictures ---------------------------------------------------------- */
 
 static int check_slot(SvtAmdContext *ctx, int slot)
@@ -624,6 +658,34 @@ extern "C" int svt_amd_me_picture_fetch(SvtAmdContext *ctx, int cur_slot, SvtAmd
     HIP_TRY(hipMemcpyAsync(out, c->d_me_out, (size_t)nlcu * sizeof(SvtAmdMeLcuResult), hipMemcpyDeviceToHost,
                            ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* stream-ordered copy of the slot's ME / OIS records into (pinned) host memory; complete after svt_amd_synchronize */
+extern "C" int svt_amd_me_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    if (!out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    HIP_TRY(hipMemcpyAsync(out, c->d_me_out, (size_t)nlcu * sizeof(SvtAmdMeLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_ois_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    if (!out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    HIP_TRY(hipMemcpyAsync(out, c->d_ois_out, (size_t)nlcu * sizeof(SvtAmdOisLcuResult), hipMemcpyDeviceToHost, ctx->stream));
     return SVT_AMD_OK;
 }
 

@@ -136,7 +136,7 @@ template <int N, bool CHROMA, bool PM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))) void k_full_loop(const SvtAmdCabacCost *__restrict__ cost_p, const void *__restrict__ in_all, const int16_t *__restrict__ residual,
                                                   int16_t *__restrict__ quant, int16_t *__restrict__ recon,
                                                   void *__restrict__ out_all, uint32_t ncand, int shift1, int shift2,
-                                                  int wrap_levels)
+                                                  int wrap_levels, uint32_t *__restrict__ ctx_models)
 {
     const SvtAmdCabacCost &c_cost = *cost_p;
     constexpr int UPW = 64 / N; /* unit sequences per wave */
@@ -145,7 +145,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
     __shared__ int16_t Fq[UPW][N * N]; /* quantised coefficients of the units in flight, row pitch N */
     __shared__ uint32_t Fbits[UPW];
     __shared__ int16_t Pq[PM ? 64 : 1][16]; /* PM-core: the 4x4 block of levels a lane is pricing */
+    /* coeffCabacUpdate (ctx_models != NULL): the candidate's CoeffCtxtMdl_t, threaded through its units in the reference's order
+     * (luma: unit after unit; chroma: Cb then Cr of every unit - the two planes of a candidate are neighbouring sequences) */
+    __shared__ uint8_t Mctx[UPW][RATE_CTX_WORDS];
+    __shared__ uint16_t Msig[UPW][64], MabsC[UPW][16];
     const int t = threadIdx.x, u = t / N, r = t - u * N;
+    const int mu = CHROMA ? (u & ~1) : u; /* the sequence whose Mctx slot holds this candidate's model */
     const uint32_t seq = blockIdx.x * UPW + u;
     const uint32_t cand = CHROMA ? seq >> 1 : seq, plane = CHROMA ? seq & 1 : 0;
 
@@ -179,6 +184,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
     for (int o = 32; o > 0; o >>= 1)
         ntu_max = max(ntu_max, __shfl_xor(ntu_max, o));
 
+    if (ctx_models && ntu && (!CHROMA || plane == 0))
+        for (int i = r; i < RATE_CTX_WORDS; i += N)
+            Mctx[u][i] = (uint8_t)ctx_models[(size_t)cand * RATE_CTX_WORDS + i];
     /* running results of the sequence (meaningful in lane 0 of the unit) */
     uint32_t cbf = 0, nzs[5] = {0, 0, 0, 0, 0};
     unsigned long long bits_acc = 0, d0_acc = 0, d1_acc = 0;
@@ -299,35 +307,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        /* TuEstimateCoeffBitsLuma / TuEstimateCoeffBits_R: one lane per 4x4 sub-block; units of equal area together,
-         * as many per call as the wave holds */
-        if (r == 0)
-            Fbits[u] = 0;
+        if (ctx_models) {
+            /* context-updating estimator: the unit's lanes build its significance maps, lane 0 walks (rate_device.h) */
+            const SvtAmdTuInfo ti = {nz, (uint8_t)cand_type, (uint8_t)intra_luma_mode, 4 /* EB_INTRA_CHROMA_DM */,
+                                     CHROMA ? (uint8_t)(plane + 1) : (uint8_t)0};
+            if (S.active && nz != 0)
+                rate_update_sigmaps(Msig[u], &Fq[u][0], N, S.lg, ti, r, N);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
-        for (int pfv = 0; pfv < (N == 4 ? 1 : 3); pfv++) {
-            const int lg = LG - pfv;
-            if (lg < 2)
-                break;
-            if (!__ballot(S.active && S.lg == lg && nz != 0))
-                continue;
-            const int S4 = lg == 2 ? 1 : 1 << (2 * (lg - 2));
-            const int per_call = 64 / S4 < UPW ? 64 / S4 : UPW;
-#pragma unroll 1
-            for (int c0 = 0; c0 < UPW; c0 += per_call) {
-                const int uu = c0 + t / S4, sub = t % S4;
-                const int src_lane = (uu < UPW ? uu : 0) * N; /* lane 0 of that unit holds its facts */
-                const int u_ok = __shfl(S.active && S.lg == lg && nz != 0, src_lane);
-                const uint32_t u_nz = (uint32_t)__shfl((int)nz, src_lane);
-                const int u_type = __shfl(cand_type, src_lane), u_mode = __shfl(intra_luma_mode, src_lane);
-                const int u_plane = __shfl((int)plane, src_lane);
-                const bool live = uu < c0 + per_call && uu < UPW && u_ok;
-                if (!__ballot(live))
+            for (uint32_t ph = 0; ph < (CHROMA ? 2u : 1u); ph++) {
+                if (r == 0 && S.active && (!CHROMA || plane == ph))
+                    Fbits[u] = nz ? coeff_bits_update_walk(Mctx[mu], Msig[u], MabsC[u], &Fq[u][0], N, S.lg, ti) : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        } else {
+            /* TuEstimateCoeffBitsLuma / TuEstimateCoeffBits_R: one lane per 4x4 sub-block; units of equal area together,
+             * as many per call as the wave holds */
+            if (r == 0)
+                Fbits[u] = 0;
+    #pragma unroll 1
+            for (int pfv = 0; pfv < (N == 4 ? 1 : 3); pfv++) {
+                const int lg = LG - pfv;
+                if (lg < 2)
+                    break;
+                if (!__ballot(S.active && S.lg == lg && nz != 0))
                     continue;
-                SvtAmdTuInfo ti = {live ? u_nz : 0u, (uint8_t)u_type, (uint8_t)u_mode, 4 /* EB_INTRA_CHROMA_DM */,
-                                   CHROMA ? (uint8_t)(u_plane + 1) : (uint8_t)0};
-                const uint32_t b = coeff_bits_lanes(c_cost, &Fq[uu < UPW ? uu : 0][0], N, lg, ti, live, t, sub);
-                if (live && sub == 0)
-                    Fbits[uu] = b;
+                const int S4 = lg == 2 ? 1 : 1 << (2 * (lg - 2));
+                const int per_call = 64 / S4 < UPW ? 64 / S4 : UPW;
+    #pragma unroll 1
+                for (int c0 = 0; c0 < UPW; c0 += per_call) {
+                    const int uu = c0 + t / S4, sub = t % S4;
+                    const int src_lane = (uu < UPW ? uu : 0) * N; /* lane 0 of that unit holds its facts */
+                    const int u_ok = __shfl(S.active && S.lg == lg && nz != 0, src_lane);
+                    const uint32_t u_nz = (uint32_t)__shfl((int)nz, src_lane);
+                    const int u_type = __shfl(cand_type, src_lane), u_mode = __shfl(intra_luma_mode, src_lane);
+                    const int u_plane = __shfl((int)plane, src_lane);
+                    const bool live = uu < c0 + per_call && uu < UPW && u_ok;
+                    if (!__ballot(live))
+                        continue;
+                    SvtAmdTuInfo ti = {live ? u_nz : 0u, (uint8_t)u_type, (uint8_t)u_mode, 4 /* EB_INTRA_CHROMA_DM */,
+                                       CHROMA ? (uint8_t)(u_plane + 1) : (uint8_t)0};
+                    const uint32_t b = coeff_bits_lanes(c_cost, &Fq[uu < UPW ? uu : 0][0], N, lg, ti, live, t, sub);
+                    if (live && sub == 0)
+                        Fbits[uu] = b;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
             const int dshift = (!CHROMA && size == 64) ? 4 : 2 * (7 - LG);
             d0 = (d0 + (1ull << (dshift - 1))) >> dshift;
             d1 = (d1 + (1ull << (dshift - 1))) >> dshift;
-            const unsigned long long tuBits = ((unsigned long long)Fbits[u] << 10) >> 15;
+            const unsigned long long tuBits = ctx_models ? (unsigned long long)(Fbits[u] >> 15) : ((unsigned long long)Fbits[u] << 10) >> 15;
             const int tuIndex = size == 64 ? tu + 1 : 0;
             nzs[tuIndex] = nz;
             if (CHROMA) {
@@ -363,6 +390,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (ctx_models && ntu && (!CHROMA || plane == 0)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = r; i < RATE_CTX_WORDS; i += N)
+            ctx_models[(size_t)cand * RATE_CTX_WORDS + i] = Mctx[u][i];
+    }
     if (r == 0 && ntu) {
         if (CHROMA) {
             SvtAmdChromaLoopOut *o = (SvtAmdChromaLoopOut *)out_all + cand;
@@ -383,12 +417,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM ? 2 : 1))
 
 template <int N, bool CHROMA, bool PM = false>
 static void launch_full_loop(SvtAmdContext *ctx, const void *d_in, const int16_t *d_res, int16_t *d_q, int16_t *d_r, void *d_out,
-                             uint32_t ncand, int s1, int s2, int wrap)
+                             uint32_t ncand, int s1, int s2, int wrap, uint32_t *d_models = nullptr)
 {
     constexpr int UPW = 64 / N;
     const uint32_t nseq = CHROMA ? 2 * ncand : ncand;
     hipLaunchKernelGGL((k_full_loop<N, CHROMA, PM>), dim3((nseq + UPW - 1) / UPW), dim3(64), 0, ctx->stream, (const SvtAmdCabacCost *)ctx->d_cabac_cost, d_in, d_res, d_q, d_r, d_out, ncand,
-                       s1, s2, wrap);
+                       s1, s2, wrap, d_models);
 }
 
 extern "C" int svt_amd_full_loop_luma_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *d_in,
@@ -449,19 +483,59 @@ extern "C" int svt_amd_full_loop_chroma_batch(SvtAmdContext *ctx, const SvtAmdCa
     return SVT_AMD_OK;
 }
 
+/* coeffCabacUpdate forms (EbEncDecProcess.c:2115-2123; EbFullLoop.c:265-280, 417-432, 1014-1035): the units' coefficient bits come
+ * from the context-updating estimator and every candidate's CoeffCtxtMdl_t (d_ctx_models[cand], SVT_AMD_COEFF_CTX_WORDS words,
+ * = candidateBuffer->candBuffCoeffCtxModel) is updated in place.  Plain and PM-core candidates may be mixed. */
+extern "C" int svt_amd_full_loop_luma_cabac_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *d_in,
+                                                  const int16_t *d_residual, int16_t *d_quant, int16_t *d_recon,
+                                                  SvtAmdFullLoopOut *d_out, uint32_t *d_ctx_models, uint32_t ncand)
+{
+    if (!ctx || !cost || !d_in || !d_residual || !d_quant || !d_recon || !d_out || !d_ctx_models || !ncand)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rate_upload_tables(ctx, cost);
+    if (rc)
+        return rc;
+    launch_full_loop<32, false>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2, d_ctx_models);
+    launch_full_loop<16, false>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1, d_ctx_models);
+    launch_full_loop<8, false>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0, d_ctx_models);
+    launch_full_loop<32, false, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 6, 9, 2, d_ctx_models);
+    launch_full_loop<16, false, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1, d_ctx_models);
+    launch_full_loop<8, false, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0, d_ctx_models);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_full_loop_chroma_cabac_batch(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *d_in,
+                                                    const int16_t *d_residual, int16_t *d_quant, int16_t *d_recon,
+                                                    SvtAmdChromaLoopOut *d_out, uint32_t *d_ctx_models, uint32_t ncand)
+{
+    if (!ctx || !cost || !d_in || !d_residual || !d_quant || !d_recon || !d_out || !d_ctx_models || !ncand)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rate_upload_tables(ctx, cost);
+    if (rc)
+        return rc;
+    launch_full_loop<16, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 4, 9, 1, d_ctx_models);
+    launch_full_loop<8, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 2, 9, 0, d_ctx_models);
+    launch_full_loop<4, true>(ctx, d_in, d_residual, d_quant, d_recon, d_out, ncand, 1, 8, 0, d_ctx_models);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
 /* Host-pointer form for one candidate (the per-call binding of integration/svt_hook_me.c): operands are staged
  * through scratch buffers owned by the context's device; blocking.  Row pitch of the three host arrays = `pitch`
  * samples (the reference's 64-sample LCU buffers); only the (T >> pf) area of every TU is written back. */
-extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
-                                      const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch,
-                                      SvtAmdFullLoopOut *out)
+static int full_loop_luma_host(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
+                               const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch, uint32_t *model,
+                               SvtAmdFullLoopOut *out)
 {
     if (!ctx || !cost || !in || !residual || !quant || !recon || !out || pitch < in->size ||
         (in->size != 8 && in->size != 16 && in->size != 32 && in->size != 64) || in->pf_mode > 1 || (in->pm_core != 0 && in->pm_core != 2))
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
-    const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 8192, o_r = o_q + 8192, total = o_r + 8192;
+    const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 8192, o_r = o_q + 8192, o_m = o_r + 8192, total = o_m + 1024;
     {
         int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
         if (rc_s)
@@ -473,11 +547,20 @@ extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost 
         ::memcpy(packed + y * S, residual + (size_t)y * pitch, S * sizeof(int16_t));
     HIP_TRY(hipMemcpyAsync(d_scratch + o_in, in, sizeof(*in), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_scratch + o_res, packed, (size_t)S * S * 2, hipMemcpyHostToDevice, ctx->stream));
-    int rc = (in->pm_core ? svt_amd_full_loop_luma_pmcore_batch : svt_amd_full_loop_luma_batch)(
-        ctx, cost, (const SvtAmdFullLoopIn *)(d_scratch + o_in), (const int16_t *)(d_scratch + o_res), (int16_t *)(d_scratch + o_q),
-        (int16_t *)(d_scratch + o_r), (SvtAmdFullLoopOut *)(d_scratch + o_out), 1);
+    int rc;
+    if (model) {
+        HIP_TRY(hipMemcpyAsync(d_scratch + o_m, model, RATE_CTX_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+        rc = svt_amd_full_loop_luma_cabac_batch(ctx, cost, (const SvtAmdFullLoopIn *)(d_scratch + o_in), (const int16_t *)(d_scratch + o_res),
+                                                (int16_t *)(d_scratch + o_q), (int16_t *)(d_scratch + o_r),
+                                                (SvtAmdFullLoopOut *)(d_scratch + o_out), (uint32_t *)(d_scratch + o_m), 1);
+    } else
+        rc = (in->pm_core ? svt_amd_full_loop_luma_pmcore_batch : svt_amd_full_loop_luma_batch)(
+            ctx, cost, (const SvtAmdFullLoopIn *)(d_scratch + o_in), (const int16_t *)(d_scratch + o_res), (int16_t *)(d_scratch + o_q),
+            (int16_t *)(d_scratch + o_r), (SvtAmdFullLoopOut *)(d_scratch + o_out), 1);
     if (rc)
         return rc;
+    if (model)
+        HIP_TRY(hipMemcpyAsync(model, d_scratch + o_m, RATE_CTX_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
     int16_t hq[64 * 64], hr[64 * 64];
     HIP_TRY(hipMemcpyAsync(out, d_scratch + o_out, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(hq, d_scratch + o_q, (size_t)S * S * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -493,9 +576,25 @@ extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost 
     return SVT_AMD_OK;
 }
 
-extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
-                                        const int16_t *const residual[2], int16_t *const quant[2], int16_t *const recon[2],
-                                        uint32_t pitch, SvtAmdChromaLoopOut *out)
+extern "C" int svt_amd_full_loop_luma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
+                                      const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch,
+                                      SvtAmdFullLoopOut *out)
+{
+    return full_loop_luma_host(ctx, cost, in, residual, quant, recon, pitch, nullptr, out);
+}
+/* coeffCabacUpdate: ctx_model = the candidate's CoeffCtxtMdl_t (SVT_AMD_COEFF_CTX_WORDS words), updated in place */
+extern "C" int svt_amd_full_loop_luma_cabac(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdFullLoopIn *in,
+                                            const int16_t *residual, int16_t *quant, int16_t *recon, uint32_t pitch,
+                                            uint32_t *ctx_model, SvtAmdFullLoopOut *out)
+{
+    if (!ctx_model)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return full_loop_luma_host(ctx, cost, in, residual, quant, recon, pitch, ctx_model, out);
+}
+
+static int full_loop_chroma_host(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
+                                 const int16_t *const residual[2], int16_t *const quant[2], int16_t *const recon[2],
+                                 uint32_t pitch, uint32_t *model, SvtAmdChromaLoopOut *out)
 {
     if (!ctx || !cost || !in || !residual || !quant || !recon || !out || !residual[0] || !residual[1] || !quant[0] ||
         !quant[1] || !recon[0] || !recon[1] || pitch < in->size / 2 ||
@@ -503,7 +602,7 @@ extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCos
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t *d_scratch = nullptr; /* in | out | residual | quant | recon ; callers serialise per context */
-    const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 4096, o_r = o_q + 4096, total = o_r + 4096;
+    const size_t o_in = 0, o_out = 256, o_res = 512, o_q = o_res + 4096, o_r = o_q + 4096, o_m = o_r + 4096, total = o_m + 1024;
     {
         int rc_s = svt_amd_ctx_scratch(ctx, total, &d_scratch);
         if (rc_s)
@@ -516,11 +615,21 @@ extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCos
             ::memcpy(packed + p * 1024 + y * C, residual[p] + (size_t)y * pitch, C * sizeof(int16_t));
     HIP_TRY(hipMemcpyAsync(d_scratch + o_in, in, sizeof(*in), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_scratch + o_res, packed, sizeof(packed), hipMemcpyHostToDevice, ctx->stream));
-    int rc = svt_amd_full_loop_chroma_batch(ctx, cost, (const SvtAmdChromaLoopIn *)(d_scratch + o_in),
+    int rc;
+    if (model) {
+        HIP_TRY(hipMemcpyAsync(d_scratch + o_m, model, RATE_CTX_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+        rc = svt_amd_full_loop_chroma_cabac_batch(ctx, cost, (const SvtAmdChromaLoopIn *)(d_scratch + o_in),
+                                                  (const int16_t *)(d_scratch + o_res), (int16_t *)(d_scratch + o_q),
+                                                  (int16_t *)(d_scratch + o_r), (SvtAmdChromaLoopOut *)(d_scratch + o_out),
+                                                  (uint32_t *)(d_scratch + o_m), 1);
+    } else
+        rc = svt_amd_full_loop_chroma_batch(ctx, cost, (const SvtAmdChromaLoopIn *)(d_scratch + o_in),
                                             (const int16_t *)(d_scratch + o_res), (int16_t *)(d_scratch + o_q),
                                             (int16_t *)(d_scratch + o_r), (SvtAmdChromaLoopOut *)(d_scratch + o_out), 1);
     if (rc)
         return rc;
+    if (model)
+        HIP_TRY(hipMemcpyAsync(model, d_scratch + o_m, RATE_CTX_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
     int16_t hq[2048], hr[2048];
     HIP_TRY(hipMemcpyAsync(out, d_scratch + o_out, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(hq, d_scratch + o_q, sizeof(hq), hipMemcpyDeviceToHost, ctx->stream));
@@ -536,6 +645,21 @@ extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCos
                     ::memcpy(recon[p] + (size_t)(ty + y) * pitch + tx, hr + p * 1024 + (ty + y) * C + tx, area * sizeof(int16_t));
                 }
     return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_full_loop_chroma(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
+                                        const int16_t *const residual[2], int16_t *const quant[2], int16_t *const recon[2],
+                                        uint32_t pitch, SvtAmdChromaLoopOut *out)
+{
+    return full_loop_chroma_host(ctx, cost, in, residual, quant, recon, pitch, nullptr, out);
+}
+extern "C" int svt_amd_full_loop_chroma_cabac(SvtAmdContext *ctx, const SvtAmdCabacCost *cost, const SvtAmdChromaLoopIn *in,
+                                              const int16_t *const residual[2], int16_t *const quant[2], int16_t *const recon[2],
+                                              uint32_t pitch, uint32_t *ctx_model, SvtAmdChromaLoopOut *out)
+{
+    if (!ctx_model)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return full_loop_chroma_host(ctx, cost, in, residual, quant, recon, pitch, ctx_model, out);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------------

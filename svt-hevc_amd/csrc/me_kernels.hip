@@ -33,6 +33,12 @@
 #ifndef ME_MIN_WAVES_PER_SIMD
 #define ME_MIN_WAVES_PER_SIMD 3 /* LDS (static + windows ~ 53 KB at cfg2) admits 3 workgroups per CU */
 #endif
+#ifndef ME_HME_WAVES_PER_SIMD
+/* 4 workgroups per CU = a 128-VGPR budget: the HME kernel needs 119 and then has NO private segment.  At 6 (80 VGPRs) it spilled
+ * 6 VGPRs + 11 SGPRs into a 128 B/lane scratch frame, and the PMC pass showed the whole frame going to memory and back:
+ * 8.4 GB written + 8.4 GB fetched per 64-picture 4K batch = 2/3 of the kernels' HBM traffic (profiles/r02_c). */
+#define ME_HME_WAVES_PER_SIMD 4
+#endif
 #define MAX_SAD_VALUE (64 * 64 * 255)
 #define COST_PRECISION 8
 #define MD_SHIFT 23
@@ -534,12 +540,13 @@ __device__ __forceinline__ int hme_l12_width(int w) { return (w < 8) ? 8 : (w & 
 /* sub-pel row distortion: metric by fractionalSearchMethod; optional full SAD alongside */
 __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, uint32_t &d, uint32_t &sad)
 {
-    if (method == SVT_AMD_SSD_SEARCH) {
-        d += ssd4(a, b);
-        sad = sad4(a, b, sad);
-    } else {
-        d = sad4(a, b, d);
-    }
+    /* written with value selects: the two-branch form (sad = sad4(a, b, sad) / d = sad4(a, b, d)) was merged by the compiler into ONE
+     * v_sad_u8 through a selected POINTER, which kept d and sad in scratch memory (12 B/lane private segment, profiles/r02_c) */
+    const bool ssd = method == SVT_AMD_SSD_SEARCH;
+    const uint32_t r = sad4(a, b, ssd ? sad : d);
+    const uint32_t q = ssd ? ssd4(a, b) : 0u;
+    sad = ssd ? r : sad;
+    d = ssd ? d + q : r;
 }
 
 /* optional phase profile: when the job carries a debug buffer, thread 0 of every workgroup
@@ -566,7 +573,7 @@ __device__ __forceinline__ int pick4(int i, int a, int b, int c, int d) { return
  * The HME part needs ~15 KB of LDS and few registers, the search part ~55 KB: as separate kernels the
  * latency-bound HME phases run at ~3x the occupancy instead of inheriting the search kernel's footprint. */
 template <int PHASE>
-__global__ __launch_bounds__(NT, PHASE == 0 ? 6 : ME_MIN_WAVES_PER_SIMD) void k_me(const MeJobDev *__restrict__ jobs, int list)
+__global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAVES_PER_SIMD) void k_me(const MeJobDev *__restrict__ jobs, int list)
 {
     __shared__ MeShared S;
     const MeJobDev &J = jobs[blockIdx.y];
@@ -1012,6 +1019,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? 6 : ME_MIN_WAVES_PER_SIMD) void k_
             } else if (P.fractional_search_model == 1) {
                 const int shift[3] = {2, 4, 6};
                 uint32_t mag[3], avgsad[3];
+#pragma unroll
                 for (int tt = 0; tt < 3; tt++) {
                     const uint32_t ux = (uint32_t)(B.sums[tt * 3 + 0] >> shift[tt]), uy = (uint32_t)(B.sums[tt * 3 + 1] >> shift[tt]);
                     mag[tt] = ux * ux + uy * uy;
@@ -1262,6 +1270,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? 6 : ME_MIN_WAVES_PER_SIMD) void k_
                 pu_geom_z(n, px_, py_, psz);
                 const int y = row * rstep;
                 const uint8_t *a[2], *b[2];
+#pragma unroll
                 for (int l = 0; l < 2; l++) {
                     const PicView &RR = l ? ref1 : ref0;
                     const uint32_t mv = B.best_mv[l][n];
@@ -1321,29 +1330,31 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? 6 : ME_MIN_WAVES_PER_SIMD) void k_
         r.total_me_candidate_index = (uint8_t)total;
         for (int k = 0; k < 3; k++)
             r.distortion[k] = 0, r.direction[k] = 0;
+        /* (selects instead of v[o3[k]]: a dynamically indexed private array lives in scratch memory) */
+        const uint32_t a = v[0], b = v[1], c = v[2];
         if (total == 3) {
             /* Sort3Elements (:2919-2944) */
-            int o3[3];
-            const uint32_t a = v[0], b = v[1], c = v[2];
+            int o0, o1, o2;
             if (a <= b && a <= c) {
-                o3[0] = 0;
-                if (b <= c) o3[1] = 1, o3[2] = 2; else o3[1] = 2, o3[2] = 1;
+                o0 = 0;
+                if (b <= c) o1 = 1, o2 = 2; else o1 = 2, o2 = 1;
             } else if (b <= a && b <= c) {
-                o3[0] = 1;
-                if (a <= c) o3[1] = 0, o3[2] = 2; else o3[1] = 2, o3[2] = 0;
+                o0 = 1;
+                if (a <= c) o1 = 0, o2 = 2; else o1 = 2, o2 = 0;
             } else if (a <= b) {
-                o3[0] = 2, o3[1] = 0, o3[2] = 1;
+                o0 = 2, o1 = 0, o2 = 1;
             } else {
-                o3[0] = 2, o3[1] = 1, o3[2] = 0;
+                o0 = 2, o1 = 1, o2 = 0;
             }
-            for (int k = 0; k < 3; k++)
-                r.distortion[k] = v[o3[k]], r.direction[k] = (uint8_t)o3[k];
+            r.distortion[0] = o0 == 0 ? a : o0 == 1 ? b : c, r.direction[0] = (uint8_t)o0;
+            r.distortion[1] = o1 == 0 ? a : o1 == 1 ? b : c, r.direction[1] = (uint8_t)o1;
+            r.distortion[2] = o2 == 0 ? a : o2 == 1 ? b : c, r.direction[2] = (uint8_t)o2;
         } else if (total == 2) {
-            const int f = v[0] <= v[1] ? 0 : 1;
-            r.distortion[0] = v[f], r.direction[0] = (uint8_t)f;
-            r.distortion[1] = v[1 - f], r.direction[1] = (uint8_t)(1 - f);
+            const int f = a <= b ? 0 : 1;
+            r.distortion[0] = f ? b : a, r.direction[0] = (uint8_t)f;
+            r.distortion[1] = f ? a : b, r.direction[1] = (uint8_t)(1 - f);
         } else {
-            r.distortion[0] = v[0], r.direction[0] = SVT_AMD_UNI_PRED_LIST_0;
+            r.distortion[0] = a, r.direction[0] = SVT_AMD_UNI_PRED_LIST_0;
         }
         o->pu[pu] = r;
     }

@@ -24,7 +24,8 @@ REC = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u
                 ("ycbf_before", "<u4"), ("ycbf_after", "<u4"), ("nz_in", "<u4", 5), ("nz_out", "<u4", 5),
                 ("bits_in", "<u8"), ("bits_out", "<u8"), ("dist_in", "<u8", 2), ("dist_out", "<u8", 2),
                 ("ydc", "<i2", 4), ("cand_nz", "<u2", 4), ("cost", COST), ("residual", "<i2", 4096),
-                ("quant", "<i2", 4096), ("recon", "<i2", 4096)], align=True)
+                ("quant", "<i2", 4096), ("recon", "<i2", 4096), ("cabac_update", "<u4"), ("pad", "<u4"), ("ctx_in", "<u4", 136),
+                ("ctx_out", "<u4", 136)], align=True)
 
 # name -> (clip kind, width, height, frames, seed, encoder args, sampling stride, records kept)
 CASES = {
@@ -36,6 +37,12 @@ CASES = {
     # pictures of encMode 4 run it without the CABAC-context-updating rate estimator (coeffCabacUpdate, EbEncDecProcess.c:2116)
     "pm_b_noise_320x256_m4": ("noise", 320, 256, 5, 11, ["-encMode", "4", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "27"], 89, 260),
     "pm_p_motion_416x240_m4": ("motion", 416, 240, 4, 7, ["-encMode", "4", "-pred-struct", "0", "-q", "30"], 61, 260),
+    # coeffCabacUpdate (EbEncDecProcess.c:2115-2123): the I picture of every clip below 4K at encMode <= 9 decides over the full depth
+    # range with chroma in the loop, and prices coefficients with the CABAC-context-UPDATING estimator; the records carry the
+    # candidate's context model before and after the call.  encMode 7: plain quantiser; encMode 3: PM-core on every picture
+    "cabac_i_motion_416x240_m7": ("motion", 416, 240, 1, 7, ["-encMode", "7", "-q", "30"], 37, 300),
+    "cabac_i_noise_320x256_m7": ("noise", 320, 256, 1, 11, ["-encMode", "7", "-q", "36"], 41, 220),
+    "cabac_pm_ib_motion_416x240_m3": ("motion", 416, 240, 5, 7, ["-encMode", "3", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "30"], 211, 300),
 }
 
 
@@ -54,7 +61,12 @@ def run_case(name):
     order = np.lexsort((recs["picture_number"], recs["size"]))
     sel = order[np.linspace(0, len(order) - 1, min(keep, len(order))).astype(int)]
     recs = recs[np.sort(sel)]
-    out = {k: recs[k] for k in REC.names if k not in ("residual", "quant", "recon", "magic", "record_size")}
+    out = {k: recs[k] for k in REC.names if k not in ("residual", "quant", "recon", "magic", "record_size", "pad", "ctx_in", "ctx_out")}
+    if recs["cabac_update"].any():
+        assert recs["cabac_update"].all() or name.startswith("cabac_pm"), "mixed fixture"
+        out["ctx_in"], out["ctx_out"] = recs["ctx_in"], recs["ctx_out"]
+    else:
+        del out["cabac_update"]
     out["pm_core"], out["pf_mode"] = recs["pf_mode"] >> 16, recs["pf_mode"] & 0xffff   # the harness packs both into one word
     for k in ("residual", "quant", "recon"):  # pack: only size*size samples are meaningful
         out[k] = np.concatenate([r[k][: int(r["size"]) ** 2] for r in recs])

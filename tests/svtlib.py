@@ -102,6 +102,12 @@ class OisJob(C.Structure):
     _fields_ = [("params", OisParams), ("cur_slot", C.c_int32)]
 
 
+class FrontendJob(C.Structure):
+    """SvtAmdFrontendJob"""
+    _fields_ = [("cur_slot", C.c_int32), ("ref_slot", C.c_int32 * 2), ("has_me", C.c_uint8), ("has_ois", C.c_uint8),
+                ("pad", C.c_uint8 * 2), ("me", MeParams), ("ois", OisParams)]
+
+
 OIS_PARAMS_DTYPE = np.dtype(OisParams)
 OIS_MAX_CAND = 18
 OIS_LCU_DTYPE = np.dtype([("candidate", "<u4", (ME_PU_COUNT, OIS_MAX_CAND)), ("total", "u1", (ME_PU_COUNT,)),
@@ -241,6 +247,24 @@ def load_product():
     _sig(lib.svt_amd_kernel_time, i, [vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)])
     _sig(lib.svt_amd_picture_read_plane, i, [vp, i, i, vp, C.c_size_t, C.POINTER(u32),
                                              C.POINTER(u32), C.POINTER(u32)])
+    # lanes + asynchronous front-end pipeline
+    _sig(lib.svt_amd_context_fork, i, [vp, C.POINTER(vp)])
+    _sig(lib.svt_amd_picture_upload_async, i, [vp, i, vp, u32, u16, u16])
+    _sig(lib.svt_amd_picture_publish, i, [vp, i])
+    _sig(lib.svt_amd_frontend_submit, i, [vp, C.POINTER(FrontendJob)])
+    _sig(lib.svt_amd_frontend_wait, i, [vp, C.POINTER(vp), C.POINTER(vp)])
+    _sig(lib.svt_amd_frontend_release, i, [vp])
+    _sig(lib.svt_amd_device_alloc, i, [vp, C.c_size_t, C.POINTER(vp)])
+    _sig(lib.svt_amd_device_free, i, [vp, vp])
+    _sig(lib.svt_amd_device_upload, i, [vp, vp, vp, C.c_size_t])
+    _sig(lib.svt_amd_device_download, i, [vp, vp, vp, C.c_size_t])
+    _sig(lib.svt_amd_device_upload_async, i, [vp, vp, vp, C.c_size_t])
+    _sig(lib.svt_amd_device_download_async, i, [vp, vp, vp, C.c_size_t])
+    _sig(lib.svt_amd_host_alloc, i, [vp, C.c_size_t, C.POINTER(vp)])
+    _sig(lib.svt_amd_host_free, i, [vp, vp])
+    _sig(lib.svt_amd_me_picture_fetch_async, i, [vp, i, vp])
+    _sig(lib.svt_amd_ois_picture_fetch_async, i, [vp, i, vp])
+    _sig(lib.svt_amd_picture_upload_device_batch, i, [vp, i, C.POINTER(C.c_int), C.POINTER(vp), u32, u16, u16])
     return lib
 
 

@@ -156,3 +156,42 @@ def test_chromaloop_host_pointer_form(product, gpu_ctx, oracle):
             assert np.array_equal(hq[p][:c, :c][mask[:c, :c]], quant[p][mask[:c, :c]]), k
             assert np.array_equal(hr[p][:c, :c][mask[:c, :c]], recon[p][mask[:c, :c]]), k
             assert np.array_equal(hq[p][~mask], before_q[p][~mask]) and np.array_equal(hr[p][~mask], before_r[p][~mask]), k
+
+
+def test_chromaloop_cabac_matches_oracle_random(product, gpu_ctx, oracle):
+    """coeffCabacUpdate: Cb then Cr of every unit move the candidate's context model (TuEstimateCoeffBits_R,
+    EbEntropyCoding.c:8032-8100); outputs and the updated models against the oracle composite."""
+    import torch
+    oracle.svt_oracle_full_loop_chroma_cabac.argtypes = [C.c_void_p] * 7
+    oracle.svt_oracle_full_loop_chroma_cabac.restype = None
+    rng = np.random.default_rng(12)
+    cost = synthetic_cost(8)
+    ins, ress = random_candidates(rng, 400)
+    n = len(ins)
+    models0 = rng.integers(0, 126, (n, 136)).astype(np.uint32)
+    h_in = np.zeros(n, IN_DT)
+    h_res = np.zeros((n, 2, 1024), np.int16)
+    for i, (fin, r) in enumerate(zip(ins, ress)):
+        C.memmove(h_in[i:i + 1].ctypes.data, C.addressof(fin), C.sizeof(fin))
+        h_res[i, :, :r[0].size] = r.reshape(2, -1)
+    d_in = torch.from_numpy(h_in.view(np.uint8).copy()).cuda()
+    d_res = torch.from_numpy(h_res).cuda()
+    d_q, d_r = d_res.clone(), torch.zeros_like(d_res)
+    d_out = torch.zeros(n * OUT_DT.itemsize, dtype=torch.uint8, device="cuda")
+    d_m = torch.from_numpy(models0.view(np.int32).copy()).cuda()
+    fn = product.svt_amd_full_loop_chroma_cabac_batch
+    fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32]
+    torch.cuda.synchronize()
+    rc = fn(gpu_ctx, cost.ctypes.data, d_in.data_ptr(), d_res.data_ptr(), d_q.data_ptr(), d_r.data_ptr(), d_out.data_ptr(), d_m.data_ptr(), n)
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    outs = d_out.cpu().numpy().view(OUT_DT)
+    models = d_m.cpu().numpy().view(np.uint32)
+    for k, (fin, res) in enumerate(zip(ins, ress)):
+        res = np.ascontiguousarray(res)
+        quant, recon, want, m = res.copy(), np.zeros_like(res), ChromaLoopOut(), models0[k].copy()
+        ptrs = [(C.c_void_p * 2)(a[0].ctypes.data, a[1].ctypes.data) for a in (res, quant, recon)]
+        oracle.svt_oracle_full_loop_chroma_cabac(cost.ctypes.data, C.addressof(fin), ptrs[0], ptrs[1], ptrs[2], m.ctypes.data, C.addressof(want))
+        got = as_struct(outs[k])
+        assert bytes(got) == bytes(want), (k, fin.size, list(got.coeff_bits), list(want.coeff_bits))
+        assert np.array_equal(models[k], m), (k, fin.size, "model")

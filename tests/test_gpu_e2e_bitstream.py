@@ -33,6 +33,17 @@ CASES = [
     ("motion10", 640, 384, 5, ["-encMode", "7", "-bit-depth", "10"]),
     # BASELINE configs[2]: 4K, encMode 7, random access with 2 hierarchical levels, SAO, 60 fps
     ("motion", 3840, 2160, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-fps", "60"]),
+    # BASELINE configs[3]: the same with 10-bit input in the COMPRESSED format (8-bit planes + 2-bit planes packed four to a
+    # byte, -compressed-ten-bit-format 1: EbEncHandle.c:3329-3601 copies them as they are, EncodePassPackLcu unpacks per LCU)
+    ("motion10c", 3840, 2160, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-fps", "60",
+                                  "-bit-depth", "10", "-compressed-ten-bit-format", "1"]),
+    ("motion10c", 640, 384, 6, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1",
+                                "-bit-depth", "10", "-compressed-ten-bit-format", "1"]),
+    # BASELINE configs[4] class: 10-bit, encMode 4 (SSD sub-pel search on all 85 PUs, 8x8 refinement on reference pictures,
+    # PM-core), 4 tile columns.  At 7680x4320 the REFERENCE itself needs more than ten minutes for three pictures on the GPU
+    # box's 256 host threads (measured, profiles/r02_c), so the whole-encoder comparison runs the same switches at 1280x768;
+    # the 8K size is covered through the C-ABI in tests/test_gpu_me.py::test_me_8k_m4_rows_match_oracle
+    ("motion10", 1280, 768, 5, ["-encMode", "4", "-bit-depth", "10", "-tile_col_cnt", "4", "-fps", "60"]),
 ]
 
 
@@ -49,7 +60,9 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
     assert os.path.exists(HIP_APP) and os.path.exists(S.REF_APP), \
         "integration/_build and oracle/_ref must be prebuilt (python __graft_entry__.py build, needs /root/reference)"
     yuv = str(tmp_path / "clip.yuv")
-    if kind.endswith("10"):
+    if kind.endswith("10c"):
+        S.write_clip10_compressed(yuv, kind[:-3], w, h, n, 7)
+    elif kind.endswith("10"):
         S.write_clip10(yuv, kind[:-2], w, h, n, 7)
     else:
         S.write_clip(yuv, kind, w, h, n, 7)
@@ -73,6 +86,9 @@ FULLLOOP_CASES = [
     # encMode 4: the P pictures' luma loop runs the PM-core quantiser.  The reference's AVX2 / SSE2 helpers of that path differ
     # from its C code ("There is Mismatch between ASM vs C !", EbTransforms.c:2848), so this one compares C_DEFAULT against C_DEFAULT
     ("motion", 416, 240, 4, ["-encMode", "4", "-pred-struct", "0", "-asm", "0"]),
+    # encMode 3 random access: EVERY picture prices coefficients with the CABAC-context-updating estimator (coeffCabacUpdate:
+    # full-depth pictures with chroma in the loop, EbEncDecProcess.c:2115-2123) on top of PM-core, luma and chroma
+    ("motion", 416, 240, 5, ["-encMode", "3", "-pred-struct", "2", "-hierarchical-levels", "2", "-asm", "0"]),
 ]
 
 
@@ -89,14 +105,25 @@ def test_bitstream_identical_with_gpu_full_loop(tmp_path, kind, w, h, n, args):
     S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
     os.environ["SVT_HOOK_FULLLOOP"] = "1"
+    os.environ["SVT_HOOK_REPORT"] = str(tmp_path / "report.txt")
     try:
         hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
     finally:
         del os.environ["SVT_HOOK_FULLLOOP"]
+        del os.environ["SVT_HOOK_REPORT"]
     assert "svt_hook_me: luma full loop (ProductFullLoop) on the GPU" in log, log[-1000:]
     if "-intra-period" not in args:  # intra pictures of these presets leave chroma to the encode pass
         assert "svt_hook_me: chroma full loop (FullLoop_R + CuFullDistortionFastTuMode_R) on the GPU" in log, log[-1000:]
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
+    # no full-loop call is left to the reference code any more: the I picture of every sub-4K clip runs the
+    # CABAC-context-updating estimator, which the device now does too
+    import re
+    rep = open(str(tmp_path / "report.txt")).read()
+    m = re.search(r"full loop luma (\d+) \(left to the reference code (\d+)\) chroma (\d+) \((\d+)\)", rep)
+    assert m, rep
+    assert int(m.group(1)) > 0 and int(m.group(2)) == 0 and int(m.group(4)) == 0, rep
+    c = re.search(r"CABAC-context-updating estimator on the GPU: full loop luma (\d+) chroma (\d+)", rep)
+    assert c and (int(c.group(1)) > 0 or "-intra-period" in args), rep   # encMode 10 has the update switched off
 
 
 RECON_CASES = [

@@ -1,0 +1,110 @@
+"""-m gpu: the asynchronous front-end pipeline (lanes = streams over shared picture slots, pinned staging, ME + OIS + result
+copies queued without a host wait) gives exactly the records of the blocking per-picture calls and of the oracle; and the
+LCU-row-band form of the ME launch (the multi-GPU shard) stitches to the full picture."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svtlib as S
+from gpu_util import default_params, me_picture, upload
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(ptr, n, dtype):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * dtype.itemsize,)).view(dtype).copy()
+
+
+def test_lanes_pipeline_matches_blocking_calls_and_oracle(product, oracle):
+    lib = product
+    w, h, npic = 448, 328, 6
+    nl = S.lcu_count(w, h)
+    root = C.c_void_p()
+    assert lib.svt_amd_context_create(0, 640, 384, npic, C.byref(root)) == 0, lib.svt_amd_last_error()
+    lanes = []
+    try:
+        for _ in range(3):
+            lane = C.c_void_p()
+            assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
+            lanes.append(lane)
+        frames = [S.gen_luma("motion", w, h, t, 7) for t in range(npic)]
+        # pictures uploaded through DIFFERENT lanes than the ones that search them: cross-stream ordering via the slot events
+        for s, f in enumerate(frames):
+            f = np.ascontiguousarray(f)
+            assert lib.svt_amd_picture_upload_async(lanes[(s + 1) % 3], s, f.ctypes.data, w, w, h) == 0, lib.svt_amd_last_error()
+        p = default_params(w, h, num_lists=2, temporal_layer_index=1, cu8x8_mode=0)
+        op = S.OisParams()
+        op.luma_width, op.luma_height, op.ois_th_set, op.temporal_layer_index = w, h, 1, 1
+        jobs = []
+        for k, cur in enumerate((1, 2, 3)):  # three B pictures in flight at once, one per lane
+            j = S.FrontendJob()
+            j.cur_slot, j.has_me, j.has_ois, j.me, j.ois = cur, 1, 1, p, op
+            j.ref_slot[0], j.ref_slot[1] = cur - 1, cur + 1
+            assert lib.svt_amd_frontend_submit(lanes[k], C.byref(j)) == 0, lib.svt_amd_last_error()
+            jobs.append(j)
+        # a second submit on a busy lane is refused, not queued over the pinned buffers
+        assert lib.svt_amd_frontend_submit(lanes[0], C.byref(jobs[0])) != 0
+        pics = [S.OraclePicture(oracle, f) for f in frames]
+        for k, cur in enumerate((1, 2, 3)):
+            me_p, ois_p = C.c_void_p(), C.c_void_p()
+            assert lib.svt_amd_frontend_wait(lanes[k], C.byref(me_p), C.byref(ois_p)) == 0, lib.svt_amd_last_error()
+            me = _records(me_p, nl, S.ME_LCU_DTYPE)
+            ois = _records(ois_p, nl, S.OIS_LCU_DTYPE)
+            assert lib.svt_amd_frontend_release(lanes[k]) == 0
+            want = S.oracle_me_picture(oracle, p, pics[cur], pics[cur - 1], pics[cur + 1])
+            S.compare_me(me, want, 2, "lane %d" % k)
+            want_ois = S.oracle_ois_picture(oracle, op, frames[cur], want)
+            assert np.array_equal(ois["candidate"], want_ois["candidate"]) and np.array_equal(ois["total"], want_ois["total"])
+            # and the blocking form on the owning context gives the same bytes
+            again = me_picture(lib, root, p, cur, [cur - 1, cur + 1])
+            assert np.array_equal(again["pu"], me["pu"])
+        # an intra picture: OIS only
+        oi = S.OisParams()
+        oi.luma_width, oi.luma_height, oi.ois_th_set, oi.slice_is_intra = w, h, 1, 1
+        j = S.FrontendJob()
+        j.cur_slot, j.has_me, j.has_ois, j.ois = 0, 0, 1, oi
+        assert lib.svt_amd_frontend_submit(lanes[1], C.byref(j)) == 0, lib.svt_amd_last_error()
+        ois_p = C.c_void_p()
+        assert lib.svt_amd_frontend_wait(lanes[1], None, C.byref(ois_p)) == 0
+        ois = _records(ois_p, nl, S.OIS_LCU_DTYPE)
+        want_ois = S.oracle_ois_picture(oracle, oi, frames[0], None)
+        assert np.array_equal(ois["candidate"], want_ois["candidate"]) and np.array_equal(ois["total"], want_ois["total"])
+        lib.svt_amd_frontend_release(lanes[1])
+    finally:
+        for lane in lanes:
+            lib.svt_amd_context_destroy(lane)
+        lib.svt_amd_context_destroy(root)
+
+
+@pytest.mark.parametrize("w,h,bands", [(1920, 1080, 8), (704, 520, 3)])
+def test_me_row_bands_equal_full_picture(product, gpu_ctx, w, h, bands):
+    """svt_amd_me_picture_range_launch over contiguous LCU-row bands (what each GPU of an LCU-row shard runs) leaves,
+    band by band, exactly the records of the one-launch picture."""
+    lib = product
+    frames = [S.gen_luma("motion", w, h, t, 7) for t in range(3)]
+    for s, f in enumerate(frames):
+        upload(lib, gpu_ctx, s, f)
+    p = default_params(w, h, num_lists=2, temporal_layer_index=1)
+    full = me_picture(lib, gpu_ctx, p, 1, [0, 2])
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    nl = wl * hl
+    refs = (C.c_int * 2)(0, 2)
+    edges = [round(i * hl / bands) for i in range(bands + 1)]
+    for b in reversed(range(bands)):  # any order: bands are independent
+        if edges[b] == edges[b + 1]:
+            continue
+        rc = lib.svt_amd_me_picture_range_launch(gpu_ctx, C.byref(p), 1, refs, edges[b] * wl, edges[b + 1] * wl)
+        assert rc == 0, lib.svt_amd_last_error()
+    out = np.zeros(nl, S.ME_LCU_DTYPE)
+    assert lib.svt_amd_me_picture_fetch(gpu_ctx, 1, out.ctypes.data) == 0, lib.svt_amd_last_error()
+    assert np.array_equal(out["pu"], full["pu"])
+    assert np.array_equal(out["best_sad"], full["best_sad"]) and np.array_equal(out["best_mv"], full["best_mv"])
+    # a single band on its own, against the same rows of the full picture
+    lo, hi = edges[1] * wl, edges[2] * wl
+    upload(lib, gpu_ctx, 3, frames[1])
+    rc = lib.svt_amd_me_picture_range_launch(gpu_ctx, C.byref(p), 3, refs, lo, hi)
+    assert rc == 0, lib.svt_amd_last_error()
+    one = np.zeros(nl, S.ME_LCU_DTYPE)
+    assert lib.svt_amd_me_picture_fetch(gpu_ctx, 3, one.ctypes.data) == 0
+    assert np.array_equal(one["pu"][lo:hi], full["pu"][lo:hi])

@@ -93,6 +93,33 @@ def test_me_matches_oracle(product, gpu_ctx, oracle, kind, w, h, vi):
         assert np.array_equal(got[k][:, :p.num_lists], want[k][:, :p.num_lists]), k
 
 
+def test_me_8k_m4_rows_match_oracle(product, oracle):
+    """BASELINE configs[4] size through the C-ABI: a 7680x4320 B picture (8,160 LCUs, ~150 MB per device picture slot) with the
+    encMode-4 controls of SURVEY Appendix B (SSD sub-pel search on all 85 PUs, 8x8 refinement, HME L0 64x32 + L1, full-pel 16x9:
+    the 4K-class table row the reference uses for 8K, taken from the 4K fixture and switched to SSD / model 0 / cu8x8Mode 0).
+    The whole picture runs on the device; the oracle (pinned on the same paths by the encMode-4 fixture) checks four LCU rows:
+    top, two interior, and the partial bottom row."""
+    w, h = 7680, 4320
+    g = load_case("b_3840x2160_m7")
+    p = S.params_from_record(g["params"][0])
+    p.luma_width, p.luma_height = w, h
+    p.fractional_search_method, p.fractional_search_model, p.cu8x8_mode = 2, 0, 0
+    ctx = C.c_void_p()
+    assert product.svt_amd_context_create(0, w, h, 3, C.byref(ctx)) == 0, product.svt_amd_last_error()
+    try:
+        frames = [S.gen_luma("motion", w, h, t, 7) for t in range(3)]
+        for s_, f in enumerate(frames):
+            upload(product, ctx, s_, f)
+        got = me_picture(product, ctx, p, 1, [0, 2])
+        pics = [S.OraclePicture(oracle, f) for f in frames]
+        wl = (w + 63) // 64
+        for row in (0, 29, 47, 67):
+            want = S.oracle_me_picture(oracle, p, pics[1], pics[0], pics[2], row * wl, (row + 1) * wl)
+            S.compare_me(got, want, 2, "8K row %d" % row, range(row * wl, (row + 1) * wl))
+    finally:
+        product.svt_amd_context_destroy(ctx)
+
+
 def test_me_full_size_properties(product, gpu_ctx):
     """BASELINE config 2 size (1920x1080): properties that need no CPU oracle."""
     w, h = 1920, 1080

@@ -8,7 +8,7 @@ import pytest
 
 import svtlib as S
 from gpu_util import default_params, me_picture, upload
-from test_oracle_ois_golden import CASES, load_ois_case, me_like
+from test_oracle_ois_golden import CASES, kept_lcus, load_ois_case, me_like
 
 pytestmark = pytest.mark.gpu
 
@@ -32,13 +32,22 @@ def test_struct_sizes():
 @pytest.mark.parametrize("name", CASES)
 def test_ois_matches_reference_golden(product, gpu_ctx, name):
     g, kind, w, h, seed = load_ois_case(name)
-    for i, (pn, slice_type, enc_mode) in enumerate(g["meta"]):
-        upload(product, gpu_ctx, 0, S.gen_luma(kind, w, h, int(pn), seed))
-        params = S.ois_params_from_record(g["params"][i])
-        me = me_like(g["me_sad"][i]) if slice_type != 2 else None
-        out = ois_picture(product, gpu_ctx, params, 0, me)
-        got = S.ois_apply(g["before"][i], out)
-        assert same(got, g["after"][i]), (name, int(pn))
+    ctx = gpu_ctx
+    if w > 1920:  # BASELINE configs[2] size: its own context
+        ctx = C.c_void_p()
+        assert product.svt_amd_context_create(0, w, (h + 7) & ~7, 1, C.byref(ctx)) == 0, product.svt_amd_last_error()
+    try:
+        kept = kept_lcus(g, w, h)
+        for i, (pn, slice_type, enc_mode) in enumerate(g["meta"]):
+            upload(product, ctx, 0, S.gen_luma(kind, w, h, int(pn), seed))
+            params = S.ois_params_from_record(g["params"][i])
+            me = me_like(g["me_sad"][i], kept, S.lcu_count(w, h)) if slice_type != 2 else None
+            out = ois_picture(product, ctx, params, 0, me)[kept]
+            got = S.ois_apply(g["before"][i], out)
+            assert same(got, g["after"][i]), (name, int(pn))
+    finally:
+        if ctx is not gpu_ctx:
+            product.svt_amd_context_destroy(ctx)
 
 
 def mk_params(w, h, **kw):

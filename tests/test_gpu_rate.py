@@ -85,3 +85,62 @@ def test_rate_leaf(product, oracle):
             assert rc == 0, product.svt_amd_last_error()
             want = oracle.svt_oracle_coeff_bits_lossy(cost.ctypes.data, size, typ, lm, cm, buf.ctypes.data, 40, 0, nnz)
             assert acc.value - 777 == want, (size, trial)
+
+
+# ---- the CABAC-context-updating estimator (coeffCabacUpdate) ------------------------------------------------------------
+from test_oracle_rate import CTX_WORDS, decl_update  # noqa: E402
+
+
+@pytest.mark.parametrize("size,chain", [(4, 4), (8, 3), (16, 4), (32, 2), (32, 4)])
+def test_update_rate_batch_matches_oracle(product, gpu_ctx, oracle, size, chain):
+    """Bits of every block and the final states of every chain (units of one candidate share a model and are walked in order)."""
+    import torch
+    decl_update(oracle)
+    product.svt_amd_coeff_bits_update_batch.restype = C.c_int
+    product.svt_amd_coeff_bits_update_batch.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32]
+    rng = np.random.default_rng(40 + size + chain)
+    n = 602  # last chain is short
+    tus, info = make_batch(rng, size, n)
+    nch = (n + chain - 1) // chain
+    ctx0 = rng.integers(0, 126, (nch, CTX_WORDS)).astype(np.uint32)
+    d_c, d_i = torch.from_numpy(tus).cuda(), torch.from_numpy(info.view(np.uint8).copy()).cuda()
+    d_m = torch.from_numpy(ctx0.view(np.int32).copy()).cuda()
+    d_o = torch.zeros(n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rc = product.svt_amd_coeff_bits_update_batch(gpu_ctx, size, d_c.data_ptr(), d_i.data_ptr(), d_m.data_ptr(), d_o.data_ptr(), n, chain)
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    got = d_o.cpu().numpy().astype(np.uint64)
+    got_m = d_m.cpu().numpy().view(np.uint32)
+    for c in range(nch):
+        m = ctx0[c].copy()
+        for i in range(c * chain, min(n, (c + 1) * chain)):
+            nz = int(info[i]["num_nonzero"])
+            want = 0 if nz == 0 else oracle.svt_oracle_coeff_bits_update(
+                m.ctypes.data, size, int(info[i]["type"]), int(info[i]["luma"]), int(info[i]["chroma"]), tus[i].ctypes.data, size,
+                int(info[i]["component"]), nz)
+            assert int(got[i]) == want, (size, chain, i, info[i])
+        assert np.array_equal(got_m[c], m), (size, chain, c)
+
+
+def test_update_rate_leaf(product, oracle):
+    decl_update(oracle)
+    product.svt_amd_EstimateQuantizedCoefficients_Update.restype = C.c_int
+    rng = np.random.default_rng(19)
+    for size in (4, 8, 16, 32):
+        m_dev = rng.integers(0, 126, CTX_WORDS).astype(np.uint32)
+        m_ora = m_dev.copy()
+        for trial in range(6):
+            tu = random_tu(rng, size, rng.choice([0.05, 0.5]), trial % 2 == 0)
+            buf = np.zeros((size, 40), np.int16)
+            buf[:, :size] = tu
+            nnz = int(np.count_nonzero(tu))
+            typ, lm, cm = 2 if trial % 2 else 1, int(rng.integers(0, 35)), int(rng.integers(0, 5))
+            comp = int(rng.integers(0, 3)) if size < 32 else 0
+            acc = u64(555)
+            rc = product.svt_amd_EstimateQuantizedCoefficients_Update(vp(m_dev.ctypes.data), None, None, u32(size), u32(typ), u32(lm), u32(cm),
+                                                                      vp(buf.ctypes.data), u32(40), u32(comp), u32(nnz), C.byref(acc))
+            assert rc == 0, product.svt_amd_last_error()
+            want = oracle.svt_oracle_coeff_bits_update(m_ora.ctypes.data, size, typ, lm, cm, buf.ctypes.data, 40, comp, nnz)
+            assert acc.value - 555 == want, (size, trial)
+            assert np.array_equal(m_dev, m_ora), (size, trial)

@@ -73,7 +73,10 @@ def test_fullloop_oracle_matches_reference(oracle, name):
     g = load_fullloop_case(name)
     oracle.svt_oracle_product_full_loop_luma.argtypes = [C.c_void_p] * 6
     oracle.svt_oracle_product_full_loop_luma.restype = None
+    oracle.svt_oracle_product_full_loop_luma_cabac.argtypes = [C.c_void_p] * 7
+    oracle.svt_oracle_product_full_loop_luma_cabac.restype = None
     seen = set()
+    n_cabac = 0
     for i in range(len(g["size"])):
         a, b = int(g["offsets"][i]), int(g["offsets"][i + 1])
         size = int(g["size"][i])
@@ -81,8 +84,17 @@ def test_fullloop_oracle_matches_reference(oracle, name):
         quant, recon = res.copy(), np.zeros_like(res)
         fin, out = record_in(g, i), FullLoopOut()
         cost = np.ascontiguousarray(g["cost"][i:i + 1])
-        oracle.svt_oracle_product_full_loop_luma(cost.ctypes.data, C.addressof(fin), res.ctypes.data, quant.ctypes.data,
-                                                 recon.ctypes.data, C.addressof(out))
+        if "cabac_update" in g and g["cabac_update"][i]:
+            # coeffCabacUpdate: the candidate's context model goes in and comes out (bits AND states are pinned)
+            model = np.ascontiguousarray(g["ctx_in"][i]).copy()
+            oracle.svt_oracle_product_full_loop_luma_cabac(cost.ctypes.data, C.addressof(fin), res.ctypes.data, quant.ctypes.data,
+                                                           recon.ctypes.data, model.ctypes.data, C.addressof(out))
+            assert np.array_equal(model, g["ctx_out"][i]), (name, i, "context model")
+            n_cabac += 1
+        else:
+            oracle.svt_oracle_product_full_loop_luma(cost.ctypes.data, C.addressof(fin), res.ctypes.data, quant.ctypes.data,
+                                                     recon.ctypes.data, C.addressof(out))
         check_out(g, i, out, quant, recon, name)
         seen.add((size, int(g["cand_type"][i]), int(g["pf_mode"][i]), int(g["nz_out"][i].sum() > 0)))
     assert len(seen) >= 3
+    assert (n_cabac > 0) == name.startswith("cabac")

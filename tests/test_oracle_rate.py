@@ -80,3 +80,61 @@ def test_rate_matches_reference(oracle, size):
         assert got == want.value - 12345, (size, trial, typ, luma_mode, comp, nnz)
         checked += 1
     assert checked == 300
+
+
+# ---- the CABAC-context-updating estimator (coeffCabacUpdate) ------------------------------------------------------------
+CTX_WORDS = 136  # CoeffCtxtMdl_t: lastSigX[30] lastSigY[30] sig[42] coeffGroupSig[4] greater1[24] greater2[6]
+
+
+def decl_update(oracle):
+    oracle.svt_oracle_coeff_bits_update.restype = u64
+    oracle.svt_oracle_coeff_bits_update.argtypes = [vp, u32, u32, u32, u32, vp, u32, u32, u32]
+
+
+def test_update_tables_are_the_reference_tables(oracle):
+    """The generated state-transition table (H.265 Table 9-41) and the embedded entropy-bit constants equal the arrays the
+    reference exports (Codec/EbHmCode.c:216-246)."""
+    decl_update(oracle)
+    buf = np.zeros((4, 4), np.int16)
+    buf[0, 0] = 1
+    ctx = np.zeros(CTX_WORDS, np.uint32)
+    oracle.svt_oracle_coeff_bits_update(ctx.ctypes.data, 4, 1, 0, 0, buf.ctypes.data, 4, 0, 1)  # builds the tables
+    mine_next = np.ctypeslib.as_array((u32 * 256).in_dll(oracle, "svt_oracle_next_state_mps_lps"))
+    mine_bits = np.ctypeslib.as_array((u32 * 128).in_dll(oracle, "svt_oracle_cabac_estimated_bits"))
+    ref_next = np.ctypeslib.as_array((u32 * 256).in_dll(ref, "NextStateMpsLps"))
+    ref_bits = np.ctypeslib.as_array((u32 * 128).in_dll(ref, "CabacEstimatedBits"))
+    assert np.array_equal(mine_next, ref_next)
+    assert np.array_equal(mine_bits, ref_bits)
+
+
+@pytest.mark.parametrize("fn", ["EstimateQuantizedCoefficients_generic_Update", "EstimateQuantizedCoefficients_Update_SSE2"])
+@pytest.mark.parametrize("size", [4, 8, 16, 32])
+def test_update_rate_and_states_match_reference(oracle, size, fn):
+    """Bits AND the updated context states, from random starting states, chained over several TUs like the mode decision
+    chains them (the states one call leaves are the next call's input)."""
+    decl_update(oracle)
+    rng = np.random.default_rng(100 + size)
+    f = getattr(ref, fn)
+    f.restype = C.c_int
+    for chain in range(60):
+        ctx_ref = rng.integers(0, 126, CTX_WORDS).astype(np.uint32)
+        ctx_mine = ctx_ref.copy()
+        for trial in range(5):
+            tu = random_tu(rng, size, rng.choice([0.02, 0.1, 0.4, 0.9]), (chain + trial) % 3 == 0)
+            if (chain + trial) % 7 == 0:  # DC-only fast track
+                tu[:] = 0
+                tu[0, 0] = rng.integers(1, 9) * rng.choice([-1, 1])
+            buf = np.zeros((size, 40), np.int16)
+            buf[:, :size] = tu
+            nnz = int(np.count_nonzero(tu))
+            typ = 2 if (chain + trial) % 2 else 1
+            luma_mode, chroma_mode, comp = int(rng.integers(0, 35)), int(rng.integers(0, 5)), int(rng.integers(0, 3))
+            if comp and size == 32:
+                comp = 0
+            want = u64(777)
+            rc = f(vp(ctx_ref.ctypes.data), None, None, u32(size), u32(typ), u32(luma_mode), u32(chroma_mode), vp(buf.ctypes.data),
+                   u32(40), u32(comp), u32(nnz), C.byref(want))
+            assert rc == 0
+            got = oracle.svt_oracle_coeff_bits_update(ctx_mine.ctypes.data, size, typ, luma_mode, chroma_mode, buf.ctypes.data, 40, comp, nnz)
+            assert got == want.value - 777, (fn, size, chain, trial, typ, luma_mode, comp, nnz)
+            assert np.array_equal(ctx_mine, ctx_ref), (fn, size, chain, trial)

@@ -31,8 +31,10 @@ CONFIGS = {
 }
 
 
-def run_app(app, yuv, w, h, n, args, out, env=None, timeout=900):
-    cmd = [app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-nb", str(n), "-b", out] + args
+def run_app(app, yuv, w, h, n, args, out, env=None, timeout=900, nb=None):
+    """nb: frames preloaded into memory before the clock starts (-nb, Source/App/EbAppContext.c:420); the application cycles
+    through them, so n may exceed the frames the file holds."""
+    cmd = [app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-nb", str(nb or n), "-b", out] + args
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
     wall = time.perf_counter() - t0
@@ -46,7 +48,8 @@ def run_app(app, yuv, w, h, n, args, out, env=None, timeout=900):
     return {"fps": fps, "wall_s": round(wall, 2), "md5": md5, "bytes": os.path.getsize(out)}
 
 
-def measure(cfg="cfg3", frames=32, extra=(), asm="1", tmpdir=None, hip_env=None):
+def measure(cfg="cfg3", frames=32, extra=(), asm="1", tmpdir=None, hip_env=None, unique=None):
+    """unique: distinct frames written to the clip (default: all); the encoders cycle through them for `frames` pictures."""
     if cfg in CONFIGS:
         w, h, depth, args = CONFIGS[cfg]
     else:
@@ -57,15 +60,16 @@ def measure(cfg="cfg3", frames=32, extra=(), asm="1", tmpdir=None, hip_env=None)
         args += ["-asm", asm]
     with tempfile.TemporaryDirectory(dir=tmpdir) as td:
         yuv = os.path.join(td, "clip.yuv")
+        nu = min(unique or frames, frames)
         if depth == 10 and "-compressed-ten-bit-format" in args:
-            S.write_clip10_compressed(yuv, "motion", w, h, frames, 7)
+            S.write_clip10_compressed(yuv, "motion", w, h, nu, 7)
         elif depth == 10:
-            S.write_clip10(yuv, "motion", w, h, frames, 7)
+            S.write_clip10(yuv, "motion", w, h, nu, 7)
         else:
-            S.write_clip(yuv, "motion", w, h, frames, 7)
-        ref = run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"))
-        hip = run_app(HIP_APP, yuv, w, h, frames, args, os.path.join(td, "hip.265"), env=hip_env)
-    return {"config": cfg, "width": w, "height": h, "frames": frames, "args": " ".join(args), "host_threads": os.cpu_count(),
+            S.write_clip(yuv, "motion", w, h, nu, 7)
+        ref = run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"), nb=nu)
+        hip = run_app(HIP_APP, yuv, w, h, frames, args, os.path.join(td, "hip.265"), env=hip_env, nb=nu)
+    return {"config": cfg, "width": w, "height": h, "frames": frames, "unique_frames": nu, "args": " ".join(args), "host_threads": os.cpu_count(),
             "reference": ref, "hip": hip, "bitstream_identical": ref["md5"] == hip["md5"],
             "hip_over_reference": round(hip["fps"] / ref["fps"], 3) if ref["fps"] and hip["fps"] else None}
 
