@@ -130,6 +130,71 @@ def pmc_traffic(argv_inner, kernel_tag="k_me"):
             "dispatches_counted": out["FETCH_SIZE_dispatches"], "batches": batches}, None
 
 
+def recon_exchange_leg(lib, root, rank, world, dev, reps=10, limit_s=120.0):
+    """N > 1 only: the one data-path collective of the closed-loop design (svt-hevc_amd/csrc/comm.hip) - every rank owns a
+    rectangle of tiles of a finished 8K 10-bit reference picture (BASELINE configs[4]: 4 tile columns) and all-gathers it over RCCL.
+    Runs in a helper thread with a time limit so that a collective that does not come up can never take the bench line with it."""
+    import threading
+    import torch.distributed as dist
+    out = {}
+
+    def work():
+        try:
+            W8, H8, bps = 7680, 4320, 2
+            cols, rows = 4, (2 if world == 8 else 1)
+
+            class Rect(C.Structure):
+                _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("w", C.c_uint16), ("h", C.c_uint16)]
+            lib.svt_amd_tile_partition.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(C.c_int)]
+            rects = (Rect * world)()
+            if lib.svt_amd_tile_partition(W8, H8, cols, rows, world, rects, None) != 0:
+                out["error"] = "no tile partition for %d ranks: %s" % (world, lib.svt_amd_last_error().decode())
+                return
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                lib.svt_amd_comm_unique_id.argtypes = [C.c_void_p]
+                assert lib.svt_amd_comm_unique_id(buf) == 0, lib.svt_amd_last_error()
+                ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            ident = ident.to(dev)
+            dist.broadcast(ident, 0)
+            idb = (C.c_char * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+            lib.svt_amd_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            assert lib.svt_amd_comm_init(root, world, rank, idb) == 0, lib.svt_amd_last_error()
+            planes = [torch.full((hh, ww), rank + 1, dtype=torch.int16, device=dev) for hh, ww in ((H8, W8), (H8 // 2, W8 // 2), (H8 // 2, W8 // 2))]
+            ptrs = (C.c_void_p * 3)(*[p.data_ptr() for p in planes])
+            pitch = (C.c_uint32 * 3)(W8 * bps, W8 // 2 * bps, W8 // 2 * bps)
+            lib.svt_amd_recon_exchange.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int, C.POINTER(Rect), C.c_int, C.c_int]
+            torch.cuda.synchronize()
+            for _ in range(2):
+                assert lib.svt_amd_recon_exchange(root, ptrs, pitch, bps, rects, world, rank) == 0, lib.svt_amd_last_error()
+            lib.svt_amd_synchronize(root)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                assert lib.svt_amd_recon_exchange(root, ptrs, pitch, bps, rects, world, rank) == 0, lib.svt_amd_last_error()
+            lib.svt_amd_synchronize(root)
+            dist.barrier()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            # every rank must now hold every rank's fill value in that rank's rectangle
+            ok = all(int(planes[0][r.y + r.h // 2, r.x + r.w // 2]) == i + 1 for i, r in enumerate(rects))
+            total = W8 * H8 * bps * 3 // 2
+            out.update({"picture": "7680x4320 10-bit 4:2:0 (BASELINE configs[4]), %d x %d tiles over %d ranks" % (cols, rows, world),
+                        "bytes_per_picture": total, "ms_per_exchange": round(ms, 3), "correct": bool(ok),
+                        "received_GBps_per_gpu": round(total * (world - 1) / world / (ms * 1e-3) / 1e9, 2)})
+            lib.svt_amd_comm_destroy.argtypes = [C.c_void_p]
+            lib.svt_amd_comm_destroy(root)
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the bench line
+            out["error"] = str(e)[-300:]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(limit_s)
+    if th.is_alive():
+        return {"error": "timed out after %.0f s" % limit_s, "hung": True}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +331,7 @@ def main():
         dt_res, kt_res = timed(max(2, a.steps // 2), False)
         res_steps = max(2, a.steps // 2)
 
+    xchg = recon_exchange_leg(lib, root, rank, world, dev) if (world > 1 and not a.inner) else None
     if rank == 0 and not a.inner:
         fps = world * NL * B * a.steps / dt
         me_ms, me_n = kt["me_search"]
@@ -298,6 +364,8 @@ def main():
                          "ois_avg_launch_ms": round(kt["ois"][0], 4), "ois_launches": kt["ois"][1],
                          "avg_launch_ms_hbm_resident_loop": round(kt_res["me_search"][0], 4)},
         }
+        if xchg is not None:
+            res["recon_exchange"] = xchg
         if world == 1 and not a.no_pmc:
             tr, err = pmc_traffic(["--inner", "--steps", "2", "--warmup", "1", "--config", str(a.config), "--batch", str(B),
                                    "--no-cpu-baseline", "--no-encoder-fps", "--no-pmc"])
@@ -319,6 +387,8 @@ def main():
                 res["encoder_fps"] = {"error": str(e)[-300:]}
         print(json.dumps(res), flush=True)
 
+    if xchg and xchg.get("hung"):
+        os._exit(0)  # a helper thread is still inside the collective library: do not wait for it at teardown
     for L in lanes:
         lib.svt_amd_device_free(L["ctx"], L["d_stage"])
         lib.svt_amd_host_free(L["ctx"], L["h_me"])

@@ -297,6 +297,32 @@ SVT_AMD_API int svt_amd_host_free(SvtAmdContext *ctx, void *h_ptr);
 SVT_AMD_API int svt_amd_me_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out);
 SVT_AMD_API int svt_amd_ois_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out);
 
+/*
+ * Multi-GPU exchange of the closed-loop half (SURVEY 8e "EncDec with tiles").  Tiles are independent inside a picture
+ * (Codec/EbEntropyCoding.c:6346-6351, EbEncDecProcess.c:2743-2760), so rank r encodes a rectangle of whole tiles; motion vectors
+ * of later pictures may cross tile borders (EbEncHandle.c:2757), so every FINISHED reference picture is all-gathered once
+ * (after DLF / SAO, before it is padded and referenced: EbEncDecProcess.c:1806) - the only data-path collective.
+ *   svt_amd_tile_partition: the reference's uniform tile grid (tileColStartLcu[c] = c * widthInLcu / cols,
+ *     Codec/EbPictureControlSet.c:743-750) -> rank_rect[world] (luma samples; every rank a rectangle of whole tiles) and,
+ *     optionally, tile_rank[tile_rows * tile_cols].  Host code, no device needed.
+ *   svt_amd_comm_*: RCCL communicator of a context (one process per GPU; rank 0 makes the id, the host passes it round -
+ *     torch.distributed / MPI / a file).  librccl is opened at run time.
+ *   svt_amd_recon_exchange: pack own rectangle of Y / Cb / Cr (4:2:0) -> ncclAllGather -> unpack the others into the local planes;
+ *     stream-ordered on the context's stream.  d_planes: device pointers to sample (0,0); pitches in bytes.
+ *   svt_amd_recon_pack: the local halves alone (planes <-> slot r of a caller-owned buffer), for hosts with their own transport.
+ */
+typedef struct SvtAmdRect { uint16_t x, y, w, h; } SvtAmdRect;
+typedef struct SvtAmdCommId { char bytes[128]; } SvtAmdCommId;
+SVT_AMD_API int svt_amd_tile_partition(uint16_t luma_width, uint16_t luma_height, int tile_cols, int tile_rows, int world,
+                                       SvtAmdRect *rank_rect, int *tile_rank);
+SVT_AMD_API int svt_amd_comm_unique_id(SvtAmdCommId *out);
+SVT_AMD_API int svt_amd_comm_init(SvtAmdContext *ctx, int world, int rank, const SvtAmdCommId *id);
+SVT_AMD_API int svt_amd_comm_destroy(SvtAmdContext *ctx);
+SVT_AMD_API int svt_amd_recon_exchange(SvtAmdContext *ctx, void *const d_planes[3], const uint32_t pitch_bytes[3], int bytes_per_sample,
+                                       const SvtAmdRect *rects, int world, int rank);
+SVT_AMD_API int svt_amd_recon_pack(SvtAmdContext *ctx, void *const d_planes[3], const uint32_t pitch_bytes[3], int bytes_per_sample,
+                                   const SvtAmdRect *rects, int world, int r, void *d_slots, size_t slot_bytes, int to_slot);
+
 /* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
 typedef struct SvtAmdOisJob {
     SvtAmdOisParams params;
@@ -423,6 +449,13 @@ SVT_AMD_API int svt_amd_fwd_transform_batch(SvtAmdContext *ctx, int kind, int si
                                             const int16_t *d_residual, int16_t *d_coeff, uint32_t nblocks);
 SVT_AMD_API int svt_amd_inv_transform_batch(SvtAmdContext *ctx, int kind, int size, uint32_t bitIncrement,
                                             const int16_t *d_coeff, int16_t *d_residual, uint32_t nblocks);
+/* The 32x32 transforms as integer-MFMA products (v_mfma_i32_32x32x32_i8; txfm_mfma.hip): same results as the two calls above for
+ * size 32 (kind 0 DCT / 1 "Estimate" DCT forward; inverse DCT), every int16 input - blocks of the Estimate form whose 16-bit
+ * butterfly levels would wrap (C_DEFAULT/EbTransforms_C.c:492-520; impossible for 8-bit residuals) are redone by the VALU kernel. */
+SVT_AMD_API int svt_amd_fwd_transform_mfma_batch(SvtAmdContext *ctx, int kind, int size, uint32_t bitIncrement,
+                                                 const int16_t *d_residual, int16_t *d_coeff, uint32_t nblocks);
+SVT_AMD_API int svt_amd_inv_transform_mfma_batch(SvtAmdContext *ctx, int size, uint32_t bitIncrement, const int16_t *d_coeff,
+                                                 int16_t *d_residual, uint32_t nblocks);
 SVT_AMD_API int svt_amd_quantize_batch(SvtAmdContext *ctx, int size, uint32_t qFunc, uint32_t q_offset,
                                        int32_t shiftedQBits, int32_t shiftedFFunc, int32_t iq_offset,
                                        int32_t shiftNum, const int16_t *d_coeff, int16_t *d_quant,
@@ -855,6 +888,12 @@ SVT_AMD_API int svt_amd_inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJo
 SVT_AMD_API int svt_amd_inter_pu_batch16bit(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs,
                                             const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, uint16_t *d_pred_y,
                                             uint32_t strideY, uint16_t *d_pred_cb, uint16_t *d_pred_cr, uint32_t strideC);
+/* The mode decision of a 10-bit encode predicts in 8 bits from the 8 MSBs of the 16-bit reference pictures (Inter2Nx2NPuPredictionHevc
+ * with is16bit: UnPackReferenceBlock, Codec/EbInterPrediction.c:414-457, 589-760): ref0 / ref1 hold 16-bit planes, the prediction is
+ * 8-bit; otherwise as svt_amd_inter_pu_batch. */
+SVT_AMD_API int svt_amd_inter_pu_batch_msb(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
+                                           const SvtAmdRefPicture *ref1, uint8_t *d_pred_y, uint32_t strideY, uint8_t *d_pred_cb,
+                                           uint8_t *d_pred_cr, uint32_t strideC);
 
 /* ------------------------------------------------------------------------- */
 /* Encode-pass intra prediction of a prediction unit from its neighbours      */

@@ -1215,7 +1215,8 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
     const ModeDecisionCandidate_t *c = candidateBufferPtr->candidatePtr;
     const EB_U32 size = mdContextPtr->cuStats->size, dir = c->predictionDirection[mdContextPtr->puItr];
     EbPictureBufferDesc_t *dst = candidateBufferPtr->predictionPtr;
-    if (g_inter_state < 0 || !g_ctx || scs->staticConfig.encoderBitDepth > EB_8BIT || mdContextPtr->cuUseRefSrcFlag || size < 8 || size > 64 ||
+    const int msb = scs->staticConfig.encoderBitDepth > EB_8BIT; /* 10-bit encode: 8-bit prediction from the MSBs of the 16-bit references */
+    if (g_inter_state < 0 || !g_ctx || mdContextPtr->cuUseRefSrcFlag || size < 8 || size > 64 ||
         dir > BI_PRED || dst->strideY != 64 || dst->strideCb != 32 || dst->strideCr != 32) {
         __sync_fetch_and_add(&g_cpu_Inter2Nx2NPuPredictionHevc, 1ul);
         return __real_Inter2Nx2NPuPredictionHevc(mdContextPtr, componentMask, pcs, candidateBufferPtr);
@@ -1231,15 +1232,15 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
     for (int l = 0; l < 2; l++)
         if (dir == (EB_U32)l || dir == BI_PRED) {
             const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
-            copy[l] = *resident_reference(ro->referencePicture, ro->refPOC);
+            copy[l] = msb ? *resident_reference_bps(ro->referencePicture16bit, ro->refPOC, 2) : *resident_reference(ro->referencePicture, ro->refPOC);
             refs[l] = &copy[l];
         }
     if (!g_inter_scratch[0])
         for (int k = 0; k < 3; k++)
             if (svt_amd_device_alloc(g_ctx, k ? 1024 : 4096, &g_inter_scratch[k]))
                 die("svt_amd_device_alloc");
-    if (svt_amd_inter_pu_batch(g_ctx, &job, 1, refs[0], refs[1], (uint8_t *)g_inter_scratch[0], size, (uint8_t *)g_inter_scratch[1],
-                               (uint8_t *)g_inter_scratch[2], size >> 1))
+    if ((msb ? svt_amd_inter_pu_batch_msb : svt_amd_inter_pu_batch)(g_ctx, &job, 1, refs[0], refs[1], (uint8_t *)g_inter_scratch[0], size,
+                                                                   (uint8_t *)g_inter_scratch[1], (uint8_t *)g_inter_scratch[2], size >> 1))
         die("svt_amd_inter_pu_batch");
     uint8_t hy[4096], hcb[1024], hcr[1024];
     if (((componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) && svt_amd_device_download(g_ctx, hy, g_inter_scratch[0], (size_t)size * size)) ||

@@ -54,6 +54,7 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    (void)svt_amd_comm_destroy(ctx);
     for (int i = 0; !ctx->parent && ctx->slots && i < ctx->num_slots; i++) {
         DevPicture *s = &ctx->slots[i];
         plane_destroy(&s->full);

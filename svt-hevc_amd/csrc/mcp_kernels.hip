@@ -26,10 +26,14 @@ __device__ __constant__ int8_t c_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10
 #define MCP_NT 64 /* one wave per block: the blocks are small (16x16 is typical) and independent, barriers stay inside a wave */
 /* MAXD: largest block width / height of the launch - it sizes the two LDS arrays and with them the number of blocks a
  * CU keeps in flight (16: 1.5 KB per block, 64: 15 KB) */
-template <typename T, int MAXD>
-__global__ __launch_bounds__(MCP_NT) void k_mcp(const T *__restrict__ ref, int rstride, void *__restrict__ dst, int dstride,
+/* TS: sample type of the reference plane.  TS = uint16_t with T = uint8_t is the mode decision of a 10-bit encode: it predicts from
+ * the 8 most significant bits of the 16-bit reference pictures (UnPackReferenceBlock -> Extract8BitdataSafeSub = sample >> 2,
+ * Codec/EbInterPrediction.c:414-457, C_DEFAULT/EbPackUnPack_C.c:203-225), so the window is narrowed while it is staged. */
+template <typename T, int MAXD, typename TS = T>
+__global__ __launch_bounds__(MCP_NT) void k_mcp(const TS *__restrict__ ref, int rstride, void *__restrict__ dst, int dstride,
                                              const McpBlock *__restrict__ blocks, int chroma, int out_raw)
 {
+    constexpr int MSB_SHIFT = sizeof(TS) > sizeof(T) ? 2 : 0;
     constexpr int WP = MAXD + 8;                    /* window pitch */
     __shared__ T win[(MAXD + 7 + 4) * WP];          /* + 4 rows: the four-output groups of the last rows read past the window */
     __shared__ int16_t tmp[(MAXD + 7 + 4) * MAXD];
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(MCP_NT) void k_mcp(const T *__restrict__ ref, int r
     const int8_t *ty = chroma ? c_chroma_taps[fy & 7] : c_luma_taps[fy & 3];
     constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
     const int B = (sizeof(T) == 2 || !chroma) ? 8192 : 0;
-    const T *r0 = ref + b.ref_off;
+    const TS *r0 = ref + b.ref_off;
     const int ds = out_raw ? w : dstride;
     /* only the taps the reference's own functions read (the 7-tap quarter positions never touch the 8th sample) */
     const int kx0 = fx ? ((!chroma && fx == 3) ? 1 : 0) : 0, kx1 = fx ? ((!chroma && fx == 1) ? 7 : ntaps) : 1;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(MCP_NT) void k_mcp(const T *__restrict__ ref, int r
         const uint32_t rc = (1u << 20) / (uint32_t)cols + 1u; /* i / cols for i < 2^13 by reciprocal multiplication */
         for (int i = t; i < rows * cols; i += MCP_NT) {
             const int j = (int)(((uint32_t)i * rc) >> 20), x = i - j * cols;
-            win[j * WP + x] = r0[(ptrdiff_t)(j + oy) * rstride + x + ox];
+            win[j * WP + x] = (T)(r0[(ptrdiff_t)(j + oy) * rstride + x + ox] >> MSB_SHIFT);
         }
     }
     __syncthreads();
@@ -146,16 +150,16 @@ __global__ __launch_bounds__(256) void k_bipred_clip(const int16_t *__restrict__
     }
 }
 
-template <typename T>
-static void launch_mcp(hipStream_t st, uint32_t nblocks, uint32_t max_dim, const T *ref, int rstride, void *dst, int dstride,
+template <typename T, typename TS = T>
+static void launch_mcp(hipStream_t st, uint32_t nblocks, uint32_t max_dim, const TS *ref, int rstride, void *dst, int dstride,
                        const McpBlock *blocks, int chroma, int out_raw)
 {
     if (max_dim && max_dim <= 16)
-        hipLaunchKernelGGL((k_mcp<T, 16>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
+        hipLaunchKernelGGL((k_mcp<T, 16, TS>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
     else if (max_dim && max_dim <= 32)
-        hipLaunchKernelGGL((k_mcp<T, 32>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
+        hipLaunchKernelGGL((k_mcp<T, 32, TS>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
     else
-        hipLaunchKernelGGL((k_mcp<T, 64>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
+        hipLaunchKernelGGL((k_mcp<T, 64, TS>), dim3(nblocks), dim3(MCP_NT), 0, st, ref, rstride, dst, dstride, blocks, chroma, out_raw);
 }
 
 static int check_blocks_args(SvtAmdContext *ctx, const void *a, const void *b, const void *c, uint32_t n, int bps)
@@ -346,7 +350,7 @@ extern "C" void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight,
 
 static inline int clampi(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
 
-template <typename T>
+template <typename T, typename TS = T>
 static int inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
                           const SvtAmdRefPicture *ref1, T *d_pred_y, uint32_t strideY, T *d_pred_cb, T *d_pred_cr, uint32_t strideC)
 {
@@ -404,15 +408,11 @@ static int inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint
     for (int l = 0; l < 2; l++)
         for (int p = 0; p < 3; p++)
             off_int[l][p] = take(raw_len[p] * sizeof(int16_t));
-    static uint8_t *d_slab = nullptr; /* grow-only; callers serialise per context */
-    static size_t slab_bytes = 0;
-    if (bytes > slab_bytes) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (d_slab)
-            HIP_TRY(hipFree(d_slab));
-        d_slab = nullptr, slab_bytes = 0;
-        HIP_TRY(hipMalloc((void **)&d_slab, bytes));
-        slab_bytes = bytes;
+    uint8_t *d_slab = nullptr; /* the context's own scratch (grow-only; callers serialise per context) */
+    {
+        int rc_s = svt_amd_ctx_scratch(ctx, bytes, &d_slab);
+        if (rc_s)
+            return rc_s;
     }
     for (int l = 0; l < 2; l++)
         for (int p = 0; p < 3; p++) {
@@ -430,7 +430,7 @@ static int inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint
             const SvtAmdRefPicture *R = refs[l];
             if (!R)
                 continue;
-            const T *plane = (const T *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr);
+            const TS *plane = (const TS *)(p == 0 ? R->d_y : p == 1 ? R->d_cb : R->d_cr);
             const int rs = (int)(p ? R->strideC : R->strideY), ds = (int)(p ? strideC : strideY);
             auto max_dim = [](const std::vector<McpBlock> &v) {
                 uint32_t m = 0;
@@ -439,10 +439,10 @@ static int inter_pu_batch(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint
                 return m;
             };
             if (!uni[l][p].empty())
-                launch_mcp<T>(ctx->stream, (uint32_t)uni[l][p].size(), max_dim(uni[l][p]), plane, rs, (void *)dst[p], ds,
+                launch_mcp<T, TS>(ctx->stream, (uint32_t)uni[l][p].size(), max_dim(uni[l][p]), plane, rs, (void *)dst[p], ds,
                                     (const McpBlock *)(d_slab + off_uni[l][p]), p != 0, 0);
             if (!raw[l][p].empty())
-                launch_mcp<T>(ctx->stream, (uint32_t)raw[l][p].size(), max_dim(raw[l][p]), plane, rs, (void *)(d_slab + off_int[l][p]), 0,
+                launch_mcp<T, TS>(ctx->stream, (uint32_t)raw[l][p].size(), max_dim(raw[l][p]), plane, rs, (void *)(d_slab + off_int[l][p]), 0,
                                     (const McpBlock *)(d_slab + off_raw[l][p]), p != 0, 1);
         }
     for (int p = 0; p < 3; p++)
@@ -467,4 +467,13 @@ extern "C" int svt_amd_inter_pu_batch16bit(SvtAmdContext *ctx, const SvtAmdInter
                                            uint16_t *d_pred_cr, uint32_t strideC)
 {
     return inter_pu_batch<uint16_t>(ctx, jobs, njobs, ref0, ref1, d_pred_y, strideY, d_pred_cb, d_pred_cr, strideC);
+}
+/* The mode decision of a 10-bit encode (Inter2Nx2NPuPredictionHevc with is16bit, Codec/EbInterPrediction.c:589-760): 8-bit
+ * prediction from the 8 most significant bits of the 16-bit reference pictures (UnPackReferenceBlock :414-457 narrows a
+ * (w + 8) x (h + 8) window per unit; here the window is narrowed while it is staged into LDS).  ref0 / ref1: 16-bit planes. */
+extern "C" int svt_amd_inter_pu_batch_msb(SvtAmdContext *ctx, const SvtAmdInterPuJob *jobs, uint32_t njobs, const SvtAmdRefPicture *ref0,
+                                          const SvtAmdRefPicture *ref1, uint8_t *d_pred_y, uint32_t strideY, uint8_t *d_pred_cb,
+                                          uint8_t *d_pred_cr, uint32_t strideC)
+{
+    return inter_pu_batch<uint8_t, uint16_t>(ctx, jobs, njobs, ref0, ref1, d_pred_y, strideY, d_pred_cb, d_pred_cr, strideC);
 }

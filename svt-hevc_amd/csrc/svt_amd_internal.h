@@ -94,6 +94,11 @@ struct SvtAmdContext {
     SvtAmdOisLcuResult *h_ois;
     hipEvent_t ev_done;
     int frontend_busy;
+    /* multi-GPU exchange (comm.hip): RCCL communicator + the all-gather buffer (one slot per rank) */
+    void *comm;
+    int comm_world, comm_rank;
+    uint8_t *d_xchg;
+    size_t xchg_bytes;
 };
 
 /* device scratch of at least `bytes` owned by the context (grown on demand, freed by svt_amd_context_destroy);

@@ -26,12 +26,15 @@
  * output row (a wave covers 128 contiguous bytes).  LDS only carries the transpose between the two passes. */
 template <int N>
 __global__ __launch_bounds__(TX_THREADS) void k_fwd_dct(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
-                                                       uint32_t nblocks, int shift1, int shift2, int wrap_levels)
+                                                       uint32_t nblocks, int shift1, int shift2, int wrap_levels,
+                                                       const uint8_t *__restrict__ only = nullptr)
 {
     constexpr int UPW = 64 / N, UPB = UPW * (TX_THREADS / 64); /* units per wave / per workgroup */
     __shared__ int16_t tiles[UPB * TxRegTile<N>::UNIT];
     const int t = threadIdx.x, u = t / N, r = t - u * N;
-    const uint32_t b = blockIdx.x * UPB + u;
+    uint32_t b = blockIdx.x * UPB + u;
+    if (only && b < nblocks && !only[b])
+        b = nblocks; /* fix-up pass of the MFMA path: only the flagged blocks are transformed (and stored) */
     int x[N];
     if (b < nblocks) {
         const int16_t *row = src + (size_t)b * N * N + r * N;
@@ -483,13 +486,25 @@ int svt_amd_launch_fwd_transform(hipStream_t st, int kind, int size, uint32_t in
     if (kind == 2)
         hipLaunchKernelGGL(k_dst4, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, 0);
     else if (size == 32)
-        hipLaunchKernelGGL(k_fwd_dct<32>, dim3((n + 7) / 8), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<32>, dim3((n + 7) / 8), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap, (const uint8_t *)nullptr);
     else if (size == 16)
-        hipLaunchKernelGGL(k_fwd_dct<16>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<16>, dim3((n + 15) / 16), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap, (const uint8_t *)nullptr);
     else if (size == 8)
-        hipLaunchKernelGGL(k_fwd_dct<8>, dim3((n + 31) / 32), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<8>, dim3((n + 31) / 32), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap, (const uint8_t *)nullptr);
     else
-        hipLaunchKernelGGL(k_fwd_dct<4>, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap);
+        hipLaunchKernelGGL(k_fwd_dct<4>, dim3((n + 63) / 64), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap, (const uint8_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+int svt_amd_launch_fwd_transform_flagged(hipStream_t st, int kind, int size, uint32_t inc, const int16_t *d_res, int16_t *d_coeff, uint32_t n,
+                                         const uint8_t *d_only)
+{
+    int s1, s2, wrap;
+    int rc = fwd_shifts(kind, size, inc, &s1, &s2, &wrap);
+    if (rc || !n || size != 32)
+        return rc ? rc : SVT_AMD_ERR_BAD_PARAM;
+    hipLaunchKernelGGL(k_fwd_dct<32>, dim3((n + 7) / 8), dim3(TX_THREADS), 0, st, d_res, d_coeff, n, s1, s2, wrap, d_only);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }

@@ -123,7 +123,9 @@ def test_bitstream_identical_with_gpu_full_loop(tmp_path, kind, w, h, n, args):
     assert m, rep
     assert int(m.group(1)) > 0 and int(m.group(2)) == 0 and int(m.group(4)) == 0, rep
     c = re.search(r"CABAC-context-updating estimator on the GPU: full loop luma (\d+) chroma (\d+)", rep)
-    assert c and (int(c.group(1)) > 0 or "-intra-period" in args), rep   # encMode 10 has the update switched off
+    assert c, rep
+    if "3" == args[args.index("-encMode") + 1]:   # full-depth pictures with chroma in the loop: every picture of encMode 3
+        assert int(c.group(1)) > 0 and int(c.group(2)) > 0, rep
 
 
 RECON_CASES = [
@@ -213,15 +215,23 @@ def test_bitstream_and_recon_identical_with_gpu_inter_prediction(tmp_path, kind,
         S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
     os.environ["SVT_HOOK_INTER"] = "1"
+    os.environ["SVT_HOOK_REPORT"] = str(tmp_path / "report.txt")
     try:
         hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
     finally:
         del os.environ["SVT_HOOK_INTER"]
-    if kind.endswith("10"):     # the mode decision of a 10-bit encode stays on the host
+        del os.environ["SVT_HOOK_REPORT"]
+    if kind.endswith("10"):
         assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction16bit) on the GPU" in log, log[-1000:]
     else:
         assert "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU" in log, log[-1000:]
-        assert "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU" in log, log[-1000:]
+    # the mode decision's inter prediction too - for a 10-bit encode from the 8 MSBs of the 16-bit reference pictures
+    # (UnPackReferenceBlock path, svt_amd_inter_pu_batch_msb): no call is left to the reference code
+    assert "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU" in log, log[-1000:]
+    import re
+    rep = open(str(tmp_path / "report.txt")).read()
+    m = re.search(r"Inter2Nx2NPuPredictionHevc\s+(\d+) calls left to the reference code", rep)
+    assert m and int(m.group(1)) == 0, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     a, b = open(str(tmp_path / "ref.yuv"), "rb").read(), open(str(tmp_path / "hip.yuv"), "rb").read()
     assert len(a) > 1000 and a == b, "reconstruction output differs from the reference"

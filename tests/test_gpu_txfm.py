@@ -175,3 +175,62 @@ def test_batched_pipeline_matches_oracle(libs, gpu_ctx, kind, size):
             assert int(satd[b]) == oracle.svt_oracle_Compute8x8Satd(vp(P(src))), b
         if size == 4:
             assert int(satd[b]) == oracle.svt_oracle_Compute4x4Satd(vp(P(src))), b
+
+
+# ---- 32x32 transforms on the matrix cores (v_mfma_i32_32x32x32_i8, txfm_mfma.hip) ------------------------------------------
+@pytest.mark.parametrize("kind,inc,scale", [(0, 0, 255), (0, 2, 1023), (0, 0, 32767), (1, 0, 255), (1, 0, 8191), (1, 0, 32767), (1, 2, 1023)])
+def test_forward_32x32_mfma_matches_oracle(libs, gpu_ctx, kind, inc, scale):
+    """Full-precision and Estimate forward DCT as integer-MFMA products, all of int16's range: 8-bit / 10-bit residuals (the encoder's
+    inputs), the edge of the Estimate form's wrap-free domain, and +-32767 (where its 16-bit butterfly levels wrap in the reference:
+    the kernel flags those blocks and the VALU butterfly redoes them)."""
+    import torch
+    product, oracle = libs
+    product.svt_amd_fwd_transform_mfma_batch.argtypes = [vp, C.c_int, C.c_int, u32, vp, vp, u32]
+    rng = np.random.default_rng(kind * 100 + scale)
+    n = 301
+    blocks = rng.integers(-scale, scale + 1, size=(n, 32, 32)).astype(np.int16)
+    blocks[0] = scale            # flat extremes
+    blocks[1] = -scale
+    blocks[2, :, ::2] = scale    # alternating columns: large odd-part sums
+    blocks[2, :, 1::2] = -scale
+    blocks[3] = 0
+    blocks[4, 5, 7] = scale      # a single sample
+    if scale == 32767:           # mixed batch: most blocks stay inside the wrap-free domain
+        blocks[10:200] = rng.integers(-255, 256, size=(190, 32, 32))
+    d_in = torch.from_numpy(blocks).cuda()
+    d_out = torch.full((n, 32, 32), 12345, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    rc = product.svt_amd_fwd_transform_mfma_batch(gpu_ctx, kind, 32, inc, d_in.data_ptr(), d_out.data_ptr(), n)
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    got = d_out.cpu().numpy()
+    for b in range(n):
+        want = np.zeros((32, 32), np.int16)
+        oracle.svt_oracle_FwdTransform(kind, 32, P(np.ascontiguousarray(blocks[b])), 32, P(want), 32, None, inc)
+        assert np.array_equal(got[b], want), (kind, inc, scale, b)
+
+
+@pytest.mark.parametrize("inc,scale", [(0, 400), (2, 4000), (0, 32767)])
+def test_inverse_32x32_mfma_matches_oracle(libs, gpu_ctx, inc, scale):
+    import torch
+    product, oracle = libs
+    product.svt_amd_inv_transform_mfma_batch.argtypes = [vp, C.c_int, u32, vp, vp, u32]
+    rng = np.random.default_rng(scale + inc)
+    n = 203
+    blocks = rng.integers(-scale, scale + 1, size=(n, 32, 32)).astype(np.int16)
+    blocks[0] = scale
+    blocks[1] = -scale
+    blocks[2] = 0
+    blocks[2, 0, 0] = scale      # DC only
+    blocks[3, 1::2, :] = 0       # even rows only
+    d_in = torch.from_numpy(blocks).cuda()
+    d_out = torch.full((n, 32, 32), 12345, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    rc = product.svt_amd_inv_transform_mfma_batch(gpu_ctx, 32, inc, d_in.data_ptr(), d_out.data_ptr(), n)
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    got = d_out.cpu().numpy()
+    for b in range(n):
+        want = np.zeros((32, 32), np.int16)
+        oracle.svt_oracle_InvTransform(0, 32, P(np.ascontiguousarray(blocks[b])), 32, P(want), 32, None, inc)
+        assert np.array_equal(got[b], want), (inc, scale, b)

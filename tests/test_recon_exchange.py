@@ -1,0 +1,180 @@
+"""Multi-GPU exchange of finished reference pictures (SURVEY 8e "EncDec with tiles"; svt-hevc_amd/csrc/comm.hip).
+CPU part: the tile -> rank partition (host code of the product library, no device) and, with gloo at world size 2 and 4, the
+exchange protocol itself (own rectangle -> slot -> all-gather -> unpack) in numpy with the slot layout the device kernels use.
+GPU part (-m gpu): the device pack / unpack kernels against that numpy layout, and RCCL start-up on the box."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import svtlib as S
+
+
+class Rect(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("w", C.c_uint16), ("h", C.c_uint16)]
+
+
+def partition(lib, w, h, cols, rows, world):
+    lib.svt_amd_tile_partition.restype = C.c_int
+    lib.svt_amd_tile_partition.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(C.c_int)]
+    rects = (Rect * world)()
+    tr = (C.c_int * (cols * rows))()
+    rc = lib.svt_amd_tile_partition(w, h, cols, rows, world, rects, tr)
+    return rc, rects, list(tr)
+
+
+def slot_of(planes, r, bps):
+    """numpy twin of k_xchg_copy's slot layout: Y rows, then Cb, then Cr of rectangle r, tightly packed"""
+    y, cb, cr = planes
+    return np.concatenate([np.ascontiguousarray(y[r.y:r.y + r.h, r.x:r.x + r.w]).reshape(-1),
+                           np.ascontiguousarray(cb[r.y // 2:(r.y + r.h) // 2, r.x // 2:(r.x + r.w) // 2]).reshape(-1),
+                           np.ascontiguousarray(cr[r.y // 2:(r.y + r.h) // 2, r.x // 2:(r.x + r.w) // 2]).reshape(-1)]).view(np.uint8)
+
+
+def unslot(planes, r, buf, dtype):
+    y, cb, cr = planes
+    v = np.ascontiguousarray(buf).view(dtype)
+    n = r.w * r.h
+    y[r.y:r.y + r.h, r.x:r.x + r.w] = v[:n].reshape(r.h, r.w)
+    cb[r.y // 2:(r.y + r.h) // 2, r.x // 2:(r.x + r.w) // 2] = v[n:n + n // 4].reshape(r.h // 2, r.w // 2)
+    cr[r.y // 2:(r.y + r.h) // 2, r.x // 2:(r.x + r.w) // 2] = v[n + n // 4:n + n // 2].reshape(r.h // 2, r.w // 2)
+
+
+@pytest.mark.parametrize("w,h,cols,rows,world", [(7680, 4320, 4, 1, 4), (7680, 4320, 4, 2, 8), (7680, 4320, 4, 1, 2), (3840, 2160, 4, 1, 1),
+                                                 (1280, 768, 4, 1, 4), (832, 480, 2, 2, 4), (1920, 1080, 3, 2, 6), (1920, 1080, 3, 2, 2)])
+def test_partition_covers_picture_on_the_reference_tile_grid(w, h, cols, rows, world):
+    lib = C.CDLL(S.PRODUCT_SO)
+    rc, rects, tile_rank = partition(lib, w, h, cols, rows, world)
+    assert rc == 0
+    cover = np.zeros((h, w), np.int32)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    col_starts = {c * wl // cols * 64 for c in range(cols)} | {w}     # EbPictureControlSet.c:743
+    row_starts = {r * hl // rows * 64 for r in range(rows)} | {h}
+    for r in rects:
+        assert r.w > 0 and r.h > 0 and r.x in col_starts and r.x + r.w in col_starts and r.y in row_starts and r.y + r.h in row_starts
+        cover[r.y:r.y + r.h, r.x:r.x + r.w] += 1
+    assert (cover == 1).all()
+    # every tile lies inside the rectangle of the rank it is mapped to
+    for ty in range(rows):
+        for tx in range(cols):
+            r = rects[tile_rank[ty * cols + tx]]
+            x0, y0 = tx * wl // cols * 64, ty * hl // rows * 64
+            assert r.x <= x0 < r.x + r.w and r.y <= y0 < r.y + r.h
+    assert sorted(set(tile_rank)) == list(range(world))
+
+
+def test_partition_rejects_what_it_cannot_tile():
+    lib = C.CDLL(S.PRODUCT_SO)
+    assert partition(lib, 7680, 4320, 4, 1, 8)[0] != 0      # 8 ranks need 2 tile rows with 4 tile columns
+    assert partition(lib, 7680, 4320, 4, 1, 3)[0] != 0
+    assert partition(lib, 640, 384, 20, 1, 2)[0] != 0       # more tile columns than LCU columns
+
+
+def _worker(rank, world, port, w, h, cols, rows, bps, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+        lib = C.CDLL(S.PRODUCT_SO)
+        rc, rects, _ = partition(lib, w, h, cols, rows, world)
+        assert rc == 0
+        dt = np.uint8 if bps == 1 else np.uint16
+        rng = np.random.default_rng(5)   # the same "finished picture" on every rank; each rank may only read its own rectangle
+        full = [rng.integers(0, 256 if bps == 1 else 1024, s, dtype=dt) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2))]
+        mine = [np.zeros_like(p) for p in full]
+        unslot(mine, rects[rank], slot_of(full, rects[rank], bps), dt)          # what this rank reconstructed
+        slot_bytes = max(r.w * r.h * bps * 3 // 2 for r in rects)
+        send = np.zeros(slot_bytes, np.uint8)
+        s = slot_of(mine, rects[rank], bps)
+        send[:s.size] = s
+        recv = [torch.zeros(slot_bytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(recv, torch.from_numpy(send))
+        for r in range(world):
+            if r != rank:
+                unslot(mine, rects[r], recv[r].numpy()[:rects[r].w * rects[r].h * bps * 3 // 2], dt)
+        q.put((rank, all(np.array_equal(a, b) for a, b in zip(mine, full)), slot_bytes * (world - 1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,cols,rows,bps", [(2, 1280, 768, 4, 1, 2), (4, 832, 480, 2, 2, 1)])
+def test_exchange_protocol_gloo(world, w, h, cols, rows, bps):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300 + world
+    ps = [ctx.Process(target=_worker, args=(r, world, port, w, h, cols, rows, bps, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,cols,rows,world,bps", [(1280, 768, 4, 1, 4, 2), (1920, 1080, 3, 2, 6, 1), (7680, 4320, 4, 2, 8, 2)])
+def test_device_pack_unpack_matches_slot_layout(product, gpu_ctx, w, h, cols, rows, world, bps):
+    import torch
+    lib = product
+    rc, rects, _ = partition(lib, w, h, cols, rows, world)
+    assert rc == 0
+    dt = np.uint8 if bps == 1 else np.uint16
+    rng = np.random.default_rng(3)
+    pitches = [w + 96, w // 2 + 40, w // 2 + 40]        # padded planes, like the reference pictures
+    host = [rng.integers(0, 256 if bps == 1 else 1024, (hh, p), dtype=dt) for hh, p in zip((h, h // 2, h // 2), pitches)]
+    dev = [torch.from_numpy(a.view(np.int16) if bps == 2 else a).cuda() for a in host]
+    out = [torch.zeros_like(d) for d in dev]
+    slot_bytes = (max(r.w * r.h * bps * 3 // 2 for r in rects) + 255) & ~255
+    slots = torch.zeros(world * slot_bytes, dtype=torch.uint8, device="cuda")
+    lib.svt_amd_recon_pack.restype = C.c_int
+    lib.svt_amd_recon_pack.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int, C.POINTER(Rect), C.c_int, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_int]
+    pb = (C.c_uint32 * 3)(*[p * bps for p in pitches])
+    src = (C.c_void_p * 3)(*[d.data_ptr() for d in dev])
+    dst = (C.c_void_p * 3)(*[d.data_ptr() for d in out])
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert lib.svt_amd_recon_pack(gpu_ctx, src, pb, bps, rects, world, r, slots.data_ptr(), slot_bytes, 1) == 0, lib.svt_amd_last_error()
+    for r in range(world):
+        assert lib.svt_amd_recon_pack(gpu_ctx, dst, pb, bps, rects, world, r, slots.data_ptr(), slot_bytes, 0) == 0, lib.svt_amd_last_error()
+    lib.svt_amd_synchronize(gpu_ctx)
+    hs = slots.cpu().numpy()
+    views = [a[:, :ww] for a, ww in zip(host, (w, w // 2, w // 2))]
+    for r in range(world):
+        want = slot_of(views, rects[r], bps)
+        assert np.array_equal(hs[r * slot_bytes:r * slot_bytes + want.size], want), r
+    for a, o, ww in zip(host, out, (w, w // 2, w // 2)):
+        got = o.cpu().numpy().view(dt)
+        assert np.array_equal(got[:, :ww], a[:, :ww])
+        assert not got[:, ww:].any()         # nothing outside the picture is touched
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_starts_on_the_box():
+    """RCCL is opened at run time; a one-rank communicator must come up.  In a child process with a time limit: a wedged
+    collective library must not take the test session with it."""
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import svtlib as S
+lib = S.load_product()
+ctx = C.c_void_p()
+assert lib.svt_amd_context_create(0, 640, 384, 1, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+ident = (C.c_char * 128)()
+lib.svt_amd_comm_unique_id.argtypes = [C.c_void_p]
+lib.svt_amd_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+assert lib.svt_amd_comm_unique_id(ident) == 0, lib.svt_amd_last_error()
+assert lib.svt_amd_comm_init(ctx, 1, 0, ident) == 0, lib.svt_amd_last_error()
+lib.svt_amd_comm_destroy.argtypes = [C.c_void_p]
+assert lib.svt_amd_comm_destroy(ctx) == 0
+lib.svt_amd_context_destroy(ctx)
+print("RCCL_OK")
+''' % os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
+    assert "RCCL_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]

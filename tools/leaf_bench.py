@@ -52,6 +52,16 @@ def main():
     lib.svt_amd_quantize_batch.argtypes = [vp, C.c_int, u32, u32, i32, i32, i32, i32, vp, vp, vp, vp, u32]
     lib.svt_amd_full_distortion_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, u32]
     lib.svt_amd_satd_batch.argtypes = [vp, C.c_int, vp, vp, u32]
+    # the same 32x32 transforms on the matrix cores (v_mfma_i32_32x32x32_i8, txfm_mfma.hip): north_star's "integer MFMA ... DCT"
+    lib.svt_amd_fwd_transform_mfma_batch.argtypes = [vp, C.c_int, C.c_int, u32, vp, vp, u32]
+    lib.svt_amd_inv_transform_mfma_batch.argtypes = [vp, C.c_int, u32, vp, vp, u32]
+    nb32 = npx // 1024
+    timed("fwd_transform 32x32 Estimate, integer MFMA (%d TUs)" % nb32, 4 * nb32 * 1024,
+          lambda: lib.svt_amd_fwd_transform_mfma_batch(ctx, 1, 32, 0, res.data_ptr(), coef.data_ptr(), nb32))
+    timed("fwd_transform 32x32 full precision, integer MFMA (%d TUs)" % nb32, 4 * nb32 * 1024,
+          lambda: lib.svt_amd_fwd_transform_mfma_batch(ctx, 0, 32, 0, res.data_ptr(), coef.data_ptr(), nb32))
+    timed("inv_transform 32x32, integer MFMA (%d TUs)" % nb32, 4 * nb32 * 1024,
+          lambda: lib.svt_amd_inv_transform_mfma_batch(ctx, 32, 0, coef.data_ptr(), rec.data_ptr(), nb32))
     for size in (32, 16, 8, 4):
         nb = npx // (size * size)
         kind = 1 if size >= 16 else 0
