@@ -935,6 +935,63 @@ SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const
                                  uint32_t strideY, void *pred_cb, void *pred_cr, uint32_t strideC);
 
 /* ------------------------------------------------------------------------- */
+/* Device-resident encode pass: hip_encdec_segment                             */
+/* ------------------------------------------------------------------------- */
+/* The batched boundary of the closed-loop half (SURVEY 8b `hip_encdec_segment`) for the final encode pass: ONE call runs the
+ * coding-unit loop of EncodePass (Codec/EbCodingLoop.c:2989, :3180-4594) for every LCU the host declares ready - the LCUs of
+ * one wavefront step (AssignEncDecSegments, Codec/EbEncDecProcess.c:1540) - one workgroup per LCU, the units of an LCU in order
+ * on the device: intra reference + prediction (GenerateIntraReferenceSamplesEncodePass, EncodePassIntraPrediction), EncodeLoop
+ * (residual, Estimate transform, UnifiedQuantizeInvQuantize) and EncodeGenerateRecon of the three planes, neighbour update.
+ * The picture's un-deblocked reconstruction and its mode-type map stay on the device between calls (SvtAmdEncDecPicture) and
+ * stand in for the reference's ep*NeighborArray set (EbPictureControlSet.h:238-246).
+ *
+ * EncDec INPUT contract (what the mode decision hands over per LCU: the final coding-unit tree of LargestCodingUnit_t.
+ * codedLeafArrayPtr, Codec/EbCodingUnit.h:63-88, 186-222): */
+#define SVT_AMD_LCU_MAX_CUS 64
+typedef struct SvtAmdLcuCu {
+    uint8_t x, y, size;            /* origin inside the LCU and size in luma samples (GetCodedUnitStats): 8 / 16 / 32      */
+    uint8_t pred_mode;             /* CodingUnit_t.predictionModeFlag: 1 INTER_MODE, 2 INTRA_MODE (this revision: 2 only)  */
+    uint8_t intra_luma_mode;       /* PredictionUnit_t.intraLumaMode, EB_INTRA_PLANAR .. EB_INTRA_MODE_34                  */
+    uint8_t bottom_left_ok, top_right_ok; /* isBottomLeftAvailable / isUpperRightAvailable(depth, index), EbAvailability.c */
+    uint8_t qp, chroma_qp;         /* cuPtr->qp; MapChromaQp(clip(qp + cbQpOffset + sliceCbQpOffset)) (EbCodingLoop.c:3255) */
+    uint8_t leaf_index;            /* index of the unit in codedLeafArrayPtr (0..84)                                       */
+    uint8_t pad[2];
+    uint32_t dz_offset;            /* dead-zone override of the luma quantiser (EbCodingLoop.c:3092-3133; 0 = none)        */
+} SvtAmdLcuCu;
+typedef struct SvtAmdLcuWork {
+    uint16_t lcu_x, lcu_y;         /* luma origin of the LCU in the picture                                              */
+    uint8_t num_cus;               /* coded leaves (splitFlag == 0) in Z order                                           */
+    uint8_t slice_type;            /* EB_PICTURE: 0 B, 1 P, 2 I                                                           */
+    uint8_t temporal_layer, constrained_intra, strong_smoothing;
+    uint8_t tile_left, tile_top, tile_right; /* lcuEdgeInfoPtr->tileLeft/Top/RightEdgeFlag                              */
+    uint8_t pad[4];
+    SvtAmdLcuCu cu[SVT_AMD_LCU_MAX_CUS];
+    uint8_t src_y[64 * 64], src_cb[32 * 32], src_cr[32 * 32]; /* source samples of the LCU (enhancedPicturePtr), pitch 64 / 32 */
+} SvtAmdLcuWork;
+/* EncDec OUTPUT contract (what entropy coding and the loop filters need back per LCU): the TransformUnit_t fields the encode
+ * loop sets (Codec/EbTransformUnit.h:18-37), LargestCodingUnit_t.quantizedCoeff (s16, 64-pitch Y + two 32-pitch chroma planes at
+ * LCU-local positions) and the un-deblocked reconstruction of the LCU. */
+typedef struct SvtAmdLcuCuResult {
+    uint8_t cbf[3];                /* lumaCbf, cbCbf, crCbf                       */
+    uint8_t only_dc[3];            /* isOnlyDc[0..2]                              */
+    uint16_t nz[3];                /* nzCoefCount[0..2]                           */
+} SvtAmdLcuCuResult;
+typedef struct SvtAmdLcuResult {
+    SvtAmdLcuCuResult cu[SVT_AMD_LCU_MAX_CUS];           /* by position in SvtAmdLcuWork.cu */
+    int16_t coeff_y[64 * 64], coeff_cb[32 * 32], coeff_cr[32 * 32];
+    uint8_t rec_y[64 * 64], rec_cb[32 * 32], rec_cr[32 * 32]; /* inside the picture only */
+} SvtAmdLcuResult;
+typedef struct SvtAmdEncDecPicture SvtAmdEncDecPicture;
+SVT_AMD_API int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t luma_width, uint16_t luma_height, int bytes_per_sample,
+                                              SvtAmdEncDecPicture **out);
+SVT_AMD_API int svt_amd_encdec_picture_begin(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic); /* new picture: nothing coded yet */
+SVT_AMD_API int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic);
+/* works / results: HOST arrays of n LCUs that do not depend on each other (left, top and top-right LCUs of each were encoded by
+ * earlier calls); blocking.  Lanes of one context family may call concurrently for different LCUs of one picture. */
+SVT_AMD_API int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n,
+                                    SvtAmdLcuResult *results);
+
+/* ------------------------------------------------------------------------- */
 /* One transform unit of the final encode pass, end to end                     */
 /* ------------------------------------------------------------------------- */
 /* The product form of EncodeLoop + EncodeGenerateRecon (Codec/EbCodingLoop.c:651-1083, :1084-1243; 16-bit :1244-1797) for

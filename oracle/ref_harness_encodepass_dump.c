@@ -1,0 +1,151 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/): link-time interposer around the REFERENCE's EncodePass (Codec/EbCodingLoop.c:2989),
+ * compiled only into oracle/_ref/libsvtref.so with -Wl,--wrap=EncodePass.
+ *
+ * When SVT_REF_ENCODEPASS_DUMP names a file, every call on an LCU whose coding units are all intra 2Nx2N units of 8..32 (8-bit,
+ * 4:2:0) is recorded: BEFORE the call the final coding-unit list of the LCU and its source samples, in the layout of the product's
+ * encode-pass input contract (SvtAmdLcuWork, include/svt_hevc_amd.h); AFTER it what the reference produced, in the layout of the
+ * output contract (SvtAmdLcuResult): TransformUnit_t cbf / isOnlyDc / nzCoefCount, LargestCodingUnit_t.quantizedCoeff and the
+ * LCU of the reconstruction buffer (run the encoder with the loop filters off, `-dlf 1 -sao 0`, so that the buffer still holds
+ * the un-deblocked samples when the call returns).  tests/golden/make_encodepass_golden.py turns the dump into fixtures.
+ *
+ * Contains no reference source; includes the reference headers only to read its structs.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbEncDecProcess.h"
+#include "EbReferenceObject.h"
+#include "EbCodingUnit.h"
+#include "EbTransformUnit.h"
+#include "EbTransforms.h"
+#include "EbUtility.h"
+#include "EbAvailability.h"
+
+#include "../include/svt_hevc_amd.h"
+
+void __real_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
+                       EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr);
+
+#define EP_DUMP_MAGIC 0x53415045U /* "EPAS" */
+typedef struct EpRecord {
+    uint32_t magic, record_size;
+    uint64_t picture_number;
+    uint32_t width, height, lcu_index, dlf_off;
+    SvtAmdLcuWork work;
+    SvtAmdLcuResult result;
+} EpRecord;
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static FILE *g_file;
+static int g_state;
+
+/* the coded leaves of the LCU in order; returns 0 when a unit is outside what the record (and the product path) covers */
+static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr,
+                     EB_U32 lcuOriginX, EB_U32 lcuOriginY)
+{
+    memset(w, 0, sizeof(*w));
+    w->lcu_x = (uint16_t)lcuOriginX, w->lcu_y = (uint16_t)lcuOriginY;
+    w->slice_type = (uint8_t)pcs->sliceType, w->temporal_layer = pcs->temporalLayerIndex;
+    w->constrained_intra = pcs->constrainedIntraFlag, w->strong_smoothing = scs->enableStrongIntraSmoothing;
+    w->tile_left = lcuPtr->lcuEdgeInfoPtr->tileLeftEdgeFlag, w->tile_top = lcuPtr->lcuEdgeInfoPtr->tileTopEdgeFlag;
+    w->tile_right = lcuPtr->lcuEdgeInfoPtr->tileRightEdgeFlag;
+    EB_U32 cuItr = 0, n = 0;
+    while (cuItr < CU_MAX_COUNT) {
+        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[cuItr];
+        if (cu->splitFlag) {
+            cuItr++;
+            continue;
+        }
+        const CodedUnitStats_t *st = GetCodedUnitStats(cuItr);
+        if (cu->predictionModeFlag != INTRA_MODE || cu->predictionUnitArray->intraLumaMode == EB_INTRA_MODE_4x4 || st->size > 32 || n >= SVT_AMD_LCU_MAX_CUS)
+            return 0;
+        SvtAmdLcuCu *u = &w->cu[n++];
+        u->x = st->originX, u->y = st->originY, u->size = st->size, u->pred_mode = (uint8_t)cu->predictionModeFlag;
+        u->intra_luma_mode = (uint8_t)cu->predictionUnitArray->intraLumaMode;
+        uint32_t lg = 0;
+        while ((1u << lg) < st->size)
+            lg++;
+        const uint32_t cuIndex = (st->originY >> lg) * (1u << st->depth) + (st->originX >> lg);
+        u->bottom_left_ok = isBottomLeftAvailable(st->depth, cuIndex), u->top_right_ok = isUpperRightAvailable(st->depth, cuIndex);
+        u->leaf_index = (uint8_t)cuItr;
+        cuItr += DepthOffset[st->depth];
+    }
+    w->num_cus = (uint8_t)n;
+    return 1;
+}
+
+void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
+                       EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
+{
+    if (g_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_state == 0) {
+            const char *path = getenv("SVT_REF_ENCODEPASS_DUMP");
+            g_file = path ? fopen(path, "wb") : NULL;
+            g_state = g_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    EpRecord *r = NULL;
+    if (g_state > 0 && !contextPtr->is16bit && contextPtr->colorFormat == EB_YUV420 && (r = (EpRecord *)calloc(1, sizeof(*r))) != NULL) {
+        if (!fill_work(&r->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY)) {
+            free(r);
+            r = NULL;
+        }
+    }
+    const EbPictureBufferDesc_t *in = (const EbPictureBufferDesc_t *)pcs->ParentPcsPtr->enhancedPicturePtr;
+    const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
+    if (r) {
+        for (EB_U32 y = 0; y < lh; y++)
+            memcpy(r->work.src_y + y * 64, in->bufferY + (size_t)(in->originY + lcuOriginY + y) * in->strideY + in->originX + lcuOriginX, lw);
+        for (EB_U32 y = 0; y < lh / 2; y++) {
+            memcpy(r->work.src_cb + y * 32, in->bufferCb + (size_t)((in->originY + lcuOriginY) / 2 + y) * in->strideCb + (in->originX + lcuOriginX) / 2, lw / 2);
+            memcpy(r->work.src_cr + y * 32, in->bufferCr + (size_t)((in->originY + lcuOriginY) / 2 + y) * in->strideCr + (in->originX + lcuOriginX) / 2, lw / 2);
+        }
+    }
+    __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+    if (!r)
+        return;
+    r->magic = EP_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->picture_number = pcs->pictureNumber;
+    r->width = scs->lumaWidth, r->height = scs->lumaHeight, r->lcu_index = tbAddr;
+    r->dlf_off = scs->staticConfig.disableDlfFlag;
+    for (int i = 0; i < r->work.num_cus; i++) {
+        SvtAmdLcuCu *u = &r->work.cu[i];
+        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[u->leaf_index];
+        const TransformUnit_t *tu = &cu->transformUnitArray[0];
+        u->qp = (uint8_t)cu->qp;
+        const EB_S8 qs = (EB_S8)CLIP3((EB_S8)MIN_QP_VALUE, (EB_S8)MAX_CHROMA_MAP_QP_VALUE, (EB_S8)(cu->qp + pcs->cbQpOffset + pcs->sliceCbQpOffset));
+        u->chroma_qp = MapChromaQp((EB_U8)qs);
+        SvtAmdLcuCuResult *o = &r->result.cu[i];
+        o->cbf[0] = tu->lumaCbf, o->cbf[1] = tu->cbCbf, o->cbf[2] = tu->crCbf;
+        for (int p = 0; p < 3; p++)
+            o->only_dc[p] = tu->isOnlyDc[p], o->nz[p] = tu->nzCoefCount[p];
+    }
+    const EbPictureBufferDesc_t *q = lcuPtr->quantizedCoeff;
+    for (int y = 0; y < 64; y++)
+        memcpy(r->result.coeff_y + y * 64, (const int16_t *)q->bufferY + (size_t)y * q->strideY, 128);
+    for (int y = 0; y < 32; y++) {
+        memcpy(r->result.coeff_cb + y * 32, (const int16_t *)q->bufferCb + (size_t)y * q->strideCb, 64);
+        memcpy(r->result.coeff_cr + y * 32, (const int16_t *)q->bufferCr + (size_t)y * q->strideCr, 64);
+    }
+    const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag
+                                           ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture
+                                           : pcs->reconPicturePtr;
+    for (EB_U32 y = 0; y < lh; y++)
+        memcpy(r->result.rec_y + y * 64, rec->bufferY + (size_t)(rec->originY + lcuOriginY + y) * rec->strideY + rec->originX + lcuOriginX, lw);
+    for (EB_U32 y = 0; y < lh / 2; y++) {
+        memcpy(r->result.rec_cb + y * 32, rec->bufferCb + (size_t)((rec->originY + lcuOriginY) / 2 + y) * rec->strideCb + (rec->originX + lcuOriginX) / 2, lw / 2);
+        memcpy(r->result.rec_cr + y * 32, rec->bufferCr + (size_t)((rec->originY + lcuOriginY) / 2 + y) * rec->strideCr + (rec->originX + lcuOriginX) / 2, lw / 2);
+    }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_file);
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+}

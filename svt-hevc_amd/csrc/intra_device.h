@@ -1,0 +1,48 @@
+/* H.265 8.4.4.2 sample prediction shared by the prediction-unit kernel (intra_kernels.hip) and the device-resident encode pass
+ * (encdec_kernels.hip): one predicted sample from the reference array of its unit. */
+#ifndef SVT_AMD_INTRA_DEVICE_H
+#define SVT_AMD_INTRA_DEVICE_H
+#include "svt_amd_internal.h"
+
+static __constant__ int8_t c_pu_ang[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+static __constant__ int16_t c_pu_inv[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+
+/* r: left[0..2N-1] top to bottom, r[2N] top-left, r[2N+1+j] top[j] */
+__device__ __forceinline__ int pu_predict(int mode, int N, int lg, const int16_t *r, int x, int y, int dc, bool lumaEdge, int maxv)
+{
+    const int16_t *left = r, *top = r + 2 * N + 1;
+    const int tl = r[2 * N];
+    if (mode == 0)
+        return ((N - 1 - x) * left[y] + (x + 1) * top[N] + (N - 1 - y) * top[x] + (y + 1) * left[N] + N) >> (lg + 1);
+    if (mode == 1) {
+        if (lumaEdge && N < 32) {
+            if (x == 0 && y == 0)
+                return (left[0] + top[0] + 2 * dc + 2) >> 2;
+            if (y == 0)
+                return (top[x] + 3 * dc + 2) >> 2;
+            if (x == 0)
+                return (left[y] + 3 * dc + 2) >> 2;
+        }
+        return dc;
+    }
+    if (mode == 26)
+        return (lumaEdge && N < 32 && x == 0) ? min(maxv, max(0, top[0] + ((left[y] - tl) >> 1))) : (int)top[x];
+    if (mode == 10)
+        return (lumaEdge && N < 32 && y == 0) ? min(maxv, max(0, left[0] + ((top[x] - tl) >> 1))) : (int)left[y];
+    const bool vert = mode >= 18;
+    const int d = vert ? mode - 26 : 10 - mode;
+    const int a = d < 0 ? -c_pu_ang[-d] : c_pu_ang[d];
+    const int u = vert ? x : y, v = vert ? y : x;
+    const int16_t *mainr = vert ? top : left, *side = vert ? left : top;
+    const int pos = (v + 1) * a, i = pos >> 5, f = pos & 31;
+    int s[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int idx = u + i + 1 + k;
+        s[k] = idx > 0 ? mainr[idx - 1] : idx == 0 ? tl : side[((-idx * c_pu_inv[-d] + 128) >> 8) - 1];
+    }
+    return ((32 - f) * s[0] + f * s[1] + 16) >> 5;
+}
+
+
+#endif

@@ -335,6 +335,19 @@ def write_clip10_compressed(path, kind, w, h, n, seed):
                 f.write(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
 
 
+# ---- encode-pass contracts (SvtAmdLcuWork / SvtAmdLcuResult, include/svt_hevc_amd.h) ----
+LCU_CU_DTYPE = np.dtype([("x", "u1"), ("y", "u1"), ("size", "u1"), ("pred_mode", "u1"), ("intra_luma_mode", "u1"), ("bottom_left_ok", "u1"),
+                         ("top_right_ok", "u1"), ("qp", "u1"), ("chroma_qp", "u1"), ("leaf_index", "u1"), ("pad", "u1", 2), ("dz_offset", "<u4")])
+LCU_WORK_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("num_cus", "u1"), ("slice_type", "u1"), ("temporal_layer", "u1"),
+                           ("constrained_intra", "u1"), ("strong_smoothing", "u1"), ("tile_left", "u1"), ("tile_top", "u1"), ("tile_right", "u1"),
+                           ("pad", "u1", 4), ("cu", LCU_CU_DTYPE, 64), ("src_y", "u1", 4096), ("src_cb", "u1", 1024), ("src_cr", "u1", 1024)])
+LCU_CU_RESULT_DTYPE = np.dtype([("cbf", "u1", 3), ("only_dc", "u1", 3), ("nz", "<u2", 3)])
+LCU_RESULT_DTYPE = np.dtype([("cu", LCU_CU_RESULT_DTYPE, 64), ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024),
+                             ("rec_y", "u1", 4096), ("rec_cb", "u1", 1024), ("rec_cr", "u1", 1024)])
+EP_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
+                            ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("work", LCU_WORK_DTYPE), ("result", LCU_RESULT_DTYPE)])
+
+
 def plane_checksum(luma):
     """Same polynomial as oracle/ref_harness_me_dump.c:plane_checksum (s = s*31 + v mod 2^32)."""
     flat = luma.astype(np.uint64).ravel()

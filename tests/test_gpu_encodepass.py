@@ -1,0 +1,172 @@
+"""GPU: the device-resident encode pass svt_amd_encode_lcus (svt-hevc_amd/csrc/encdec_kernels.hip) through the C ABI against
+(a) records of the reference's own EncodePass calls (tests/golden/encodepass_*.npz), LCU by LCU in raster order and in the
+wavefront batches the host would submit, and (b) the CPU oracle on seeded random coding-unit trees over a larger picture."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svtlib as S
+from test_oracle_encodepass_golden import CASES, compare_lcu, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def sig(lib):
+    lib.svt_amd_encdec_picture_create.restype = C.c_int
+    lib.svt_amd_encdec_picture_create.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_int, C.POINTER(C.c_void_p)]
+    for f in (lib.svt_amd_encdec_picture_begin, lib.svt_amd_encdec_picture_destroy):
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+    lib.svt_amd_encode_lcus.restype = C.c_int
+    lib.svt_amd_encode_lcus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+
+
+def encode(lib, ctx, pic, works):
+    works = np.ascontiguousarray(works)
+    out = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+    assert lib.svt_amd_encode_lcus(ctx, pic, works.ctypes.data, len(works), out.ctypes.data) == 0, lib.svt_amd_last_error()
+    return out
+
+
+def wavefront_batches(wl, hl):
+    """LCUs whose left, top and top-right neighbours are done: step s holds the LCUs with x + 2*y == s"""
+    for s in range(wl + 2 * (hl - 1)):
+        b = [y * wl + (s - 2 * y) for y in range(hl) if 0 <= s - 2 * y < wl]
+        if b:
+            yield b
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("order", ["raster", "wavefront"])
+def test_encode_lcus_matches_reference_records(product, gpu_ctx, name, order):
+    lib = product
+    sig(lib)
+    g, w, h = load_case(name)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    nl = wl * hl
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        for first in range(0, len(g["work"]), nl):
+            assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
+            batches = [[i] for i in range(nl)] if order == "raster" else list(wavefront_batches(wl, hl))
+            assert sorted(i for b in batches for i in b) == list(range(nl))
+            for b in batches:
+                idx = [first + i for i in b]
+                got = encode(lib, gpu_ctx, pic, g["work"][idx])
+                for k, r in zip(idx, got):
+                    compare_lcu(g["work"][k], g["result"][k], r, w, h, (name, order, int(g["picture_number"][k]), int(g["lcu_index"][k])))
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+def random_tree(rng, lw, lh):
+    """a random quadtree of 32 / 16 / 8 units over the part of the LCU inside the picture, in Z order"""
+    out = []
+
+    def rec(x, y, s):
+        if x >= lw or y >= lh:
+            return
+        if s == 64 or x + s > lw or y + s > lh or (s > 8 and rng.random() < 0.45):
+            h = s // 2
+            for dy, dx in ((0, 0), (0, h), (h, 0), (h, h)):
+                rec(x + dx, y + dy, h)
+        else:
+            out.append((x, y, s))
+    rec(0, 0, 64)
+    return out
+
+
+def z_available(x, y, s):
+    """isBottomLeftAvailable / isUpperRightAvailable of a unit inside its LCU (Z-order decoding availability)"""
+    def zidx(px, py):
+        z = 0
+        for b in range(4):
+            z |= ((px >> (b + 2)) & 1) << (2 * b) | ((py >> (b + 2)) & 1) << (2 * b + 1)
+        return z
+    me = zidx(x, y)
+    bl = x > 0 and y + s < 64 and zidx(x - 4, y + s) < me
+    if x == 0:
+        bl = y + s < 64      # the LCU to the left is complete
+    tr = y > 0 and x + s < 64 and zidx(x + s, y - 4) < me
+    if y == 0:
+        tr = True            # the LCU row above is complete (its top-right LCU is a precondition of the call)
+    return int(bl), int(tr)
+
+
+@pytest.mark.parametrize("w,h,qp,seed", [(832, 480, 27, 1), (456, 264, 38, 2)])
+def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, qp, seed):
+    lib = product
+    sig(lib)
+    oracle.svt_oracle_encode_lcu.restype = None
+    oracle.svt_oracle_encode_lcu.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(seed)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    yy, xx = np.mgrid[0:h, 0:w]
+    src = [np.clip(128 + 60 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + rng.normal(0, 9, (h, w)), 0, 255).astype(np.uint8)]
+    src += [np.clip(128 + 30 * np.sin(xx[::2, ::2] / (31.0 + 9 * k)) + rng.normal(0, 4, (h // 2, w // 2)), 0, 255).astype(np.uint8) for k in range(2)]
+    works = np.zeros(wl * hl, S.LCU_WORK_DTYPE)
+    for ly in range(hl):
+        for lx in range(wl):
+            wk = works[ly * wl + lx]
+            lw, lh = min(64, w - 64 * lx), min(64, h - 64 * ly)
+            wk["lcu_x"], wk["lcu_y"], wk["slice_type"], wk["strong_smoothing"] = 64 * lx, 64 * ly, 2, 1
+            wk["constrained_intra"] = 0
+            wk["tile_left"], wk["tile_top"], wk["tile_right"] = lx == 0, ly == 0, lx == wl - 1
+            tree = random_tree(rng, lw, lh)
+            wk["num_cus"] = len(tree)
+            for i, (x, y, s) in enumerate(tree):
+                cu = wk["cu"][i]
+                cu["x"], cu["y"], cu["size"], cu["pred_mode"], cu["intra_luma_mode"] = x, y, s, 2, rng.integers(0, 35)
+                cu["bottom_left_ok"], cu["top_right_ok"] = z_available(x, y, s)
+                cu["qp"] = np.clip(qp + rng.integers(-3, 4), 0, 51)
+                cu["chroma_qp"] = min(int(cu["qp"]), 29 + (int(cu["qp"]) - 29) // 2) if cu["qp"] > 29 else cu["qp"]
+                cu["dz_offset"] = rng.choice([0, 0, 9, 12])
+            sy = np.zeros((64, 64), np.uint8)
+            sy[:lh, :lw] = src[0][64 * ly:64 * ly + lh, 64 * lx:64 * lx + lw]
+            wk["src_y"] = sy.reshape(-1)
+            for p, nm in ((1, "src_cb"), (2, "src_cr")):
+                sc = np.zeros((32, 32), np.uint8)
+                sc[:lh // 2, :lw // 2] = src[p][32 * ly:32 * ly + lh // 2, 32 * lx:32 * lx + lw // 2]
+                wk[nm] = sc.reshape(-1)
+    # oracle, raster order
+    pitches = (w + 32, w // 2 + 16, w // 2 + 16)
+    pb = (C.c_uint32 * 3)(*pitches)
+    rec = [np.full((hh, p), 0xA5, np.uint8) for hh, p in zip((h, h // 2, h // 2), pitches)]
+    mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+    rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+    want = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+    for k in range(len(works)):
+        oracle.svt_oracle_encode_lcu(rp, pb, mp.ctypes.data, mp.shape[1], w, h, works[k:k + 1].ctypes.data, want[k:k + 1].ctypes.data)
+    # device, wavefront batches
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        for rep in range(2):      # the second picture reuses the device picture after _begin
+            assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
+            for b in wavefront_batches(wl, hl):
+                got = encode(lib, gpu_ctx, pic, works[b])
+                for k, r in zip(b, got):
+                    compare_lcu(works[k], want[k], r, w, h, ("random", rep, k))
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+    assert int(sum(want["cu"]["only_dc"][k][:works[k]["num_cus"]].sum() for k in range(len(works)))) >= 0
+
+
+def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):
+    lib = product
+    sig(lib)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, 128, 64, 2, C.byref(pic)) != 0      # 10-bit: not in this revision
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, 128, 64, 1, C.byref(pic)) == 0
+    try:
+        wk = np.zeros(1, S.LCU_WORK_DTYPE)
+        wk[0]["num_cus"] = 1
+        wk[0]["cu"][0]["size"], wk[0]["cu"][0]["pred_mode"] = 32, 1                        # an inter unit
+        out = np.zeros(1, S.LCU_RESULT_DTYPE)
+        assert lib.svt_amd_encode_lcus(gpu_ctx, pic, wk.ctypes.data, 1, out.ctypes.data) != 0
+        wk[0]["cu"][0]["size"], wk[0]["cu"][0]["pred_mode"] = 64, 2                        # a 64x64 unit
+        assert lib.svt_amd_encode_lcus(gpu_ctx, pic, wk.ctypes.data, 1, out.ctypes.data) != 0
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
