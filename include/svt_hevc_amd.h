@@ -991,6 +991,18 @@ SVT_AMD_API int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecP
 SVT_AMD_API int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n,
                                     SvtAmdLcuResult *results);
 
+/* LCUs the HOST encoded itself (units outside this revision: inter, intra 4x4, 64x64, delta-QP / masking configurations) are
+ * handed to the device picture afterwards so that later LCUs find their neighbours: the un-deblocked last row and last column of
+ * the LCU and the mode type of the 4x4 cells along them - what the reference's ep*ReconNeighborArray / epModeTypeNeighborArray
+ * top and left entries hold when EncodePass returns (EncodePassUpdateReconSampleNeighborArrays, EbCodingLoop.c:1913). */
+typedef struct SvtAmdLcuBorder {
+    uint16_t lcu_x, lcu_y;
+    uint8_t mode_bottom[16], mode_right[16];   /* 1 INTER_MODE / 2 INTRA_MODE per 4 luma samples, left to right / top to bottom */
+    uint8_t bottom_y[64], right_y[64];         /* row lcu_y + h - 1 and column lcu_x + w - 1 (w, h = LCU size inside the picture) */
+    uint8_t bottom_cb[32], right_cb[32], bottom_cr[32], right_cr[32];
+} SvtAmdLcuBorder;
+SVT_AMD_API int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder *borders, int n);
+
 /* ------------------------------------------------------------------------- */
 /* One transform unit of the final encode pass, end to end                     */
 /* ------------------------------------------------------------------------- */

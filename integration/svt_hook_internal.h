@@ -1,0 +1,26 @@
+/*
+ * integration/svt_hook_internal.h - shared between the binding files (svt_hook_me.c: front half and per-call EncDec bindings;
+ * svt_hook_encdec.c: the device-resident encode pass).  Part of the code a maintainer adds to the reference; no reference source.
+ */
+#ifndef SVT_HOOK_INTERNAL_H
+#define SVT_HOOK_INTERNAL_H
+#include <stdio.h>
+#include "EbDefinitions.h"
+#include "EbPictureBufferDesc.h"
+#include "EbEncDecProcess.h"
+#include "../include/svt_hevc_amd.h"
+
+/* the root device context (created with the encoder, or here on first use) and the loud exit every binding shares */
+SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight);
+void svt_hook_die(const char *what);
+
+/* Non-zero while the reference's EncodePass runs on this thread for an LCU the device has already encoded (svt_hook_encdec.c):
+ * the leaves it reaches answer from the device's result instead of computing. */
+extern __thread int svt_hook_ep_active;
+/* UnifiedQuantizeInvQuantize of the served LCU: quantised coefficients, count and the DC marker of the unit / plane the call is for */
+void svt_hook_ep_quantize(EncDecContext_t *contextPtr, EB_S16 *quantCoeff, EB_S16 *reconCoeff, EB_U32 coeffStride, EB_U32 qp, EB_U32 areaSize,
+                          EB_U32 *nz, EB_U32 shape, EB_U32 cleanSparse, EB_U32 masking, EB_U32 enableCbflag, EB_U32 contouring, EB_U32 dZoffset);
+/* EncodeGenerateRecon of the served LCU: the unit's reconstruction into the picture buffer */
+void svt_hook_ep_recon(EncDecContext_t *contextPtr, EB_U32 originX, EB_U32 originY, EB_U32 tuSize, EbPictureBufferDesc_t *recon);
+void svt_hook_encdec_report(FILE *out);
+#endif

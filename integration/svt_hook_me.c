@@ -41,6 +41,7 @@
 #include "EbCabacContextModel.h"
 
 #include "../include/svt_hevc_amd.h"
+#include "svt_hook_internal.h"
 
 #define NSLOTS 48   /* device picture slots, keyed by pictureNumber % NSLOTS */
 #define NLANES 8    /* front-end lanes = pictures whose ME / OIS results are in flight or being served */
@@ -89,6 +90,14 @@ static void die(const char *what)
 {
     fprintf(stderr, "svt_hook_me: %s: %s\n", what, svt_amd_last_error());
     abort();
+}
+void svt_hook_die(const char *what) { die(what); }
+SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight)
+{
+    pthread_mutex_lock(&g_front_lock);
+    ensure_context(lumaWidth, lumaHeight);
+    pthread_mutex_unlock(&g_front_lock);
+    return g_ctx;
 }
 
 /* The rate tables handed to the device are the reference's CabacCost_t, field for field */
@@ -559,12 +568,17 @@ typedef void (*ReconFn)(EncDecContext_t *, EB_U32, EB_U32, EB_U32, EB_COLOR_FORM
 extern ReconFn EncodeGenerateReconFunctionPtr[2];
 static ReconFn g_recon_real[2];
 static unsigned long g_recon_gpu;
+static int g_recon_on;
 
 static void recon_on_device(int is16, EncDecContext_t *ctx, EB_U32 originX, EB_U32 originY, EB_U32 componentMask,
                             EB_COLOR_FORMAT colorFormat, EB_BOOL secondChroma, EB_U32 tuSize, EbPictureBufferDesc_t *predSamples,
                             EbPictureBufferDesc_t *residual16bit, EB_S16 *scratch)
 {
-    if (!g_ctx || colorFormat != EB_YUV420 || secondChroma) {
+    if (svt_hook_ep_active) { /* the device encoded this LCU: its reconstruction is already here */
+        svt_hook_ep_recon(ctx, originX, originY, tuSize, predSamples);
+        return;
+    }
+    if (!g_recon_on || !g_ctx || colorFormat != EB_YUV420 || secondChroma) {
         g_recon_real[is16](ctx, originX, originY, componentMask, colorFormat, secondChroma, tuSize, predSamples, residual16bit, scratch);
         return;
     }
@@ -615,7 +629,8 @@ static void recon16(EncDecContext_t *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_COLOR_F
 }
 __attribute__((constructor)) static void recon_install(void)
 {
-    if (!getenv("SVT_HOOK_RECON"))
+    g_recon_on = getenv("SVT_HOOK_RECON") != NULL;
+    if (!g_recon_on && !getenv("SVT_HOOK_ENCODEPASS"))
         return;
     g_recon_real[0] = EncodeGenerateReconFunctionPtr[0], g_recon_real[1] = EncodeGenerateReconFunctionPtr[1];
     EncodeGenerateReconFunctionPtr[0] = recon8, EncodeGenerateReconFunctionPtr[1] = recon16;
@@ -638,6 +653,7 @@ extern IntraPredFn EncodePassIntraPredictionFuncTable[2];
 static IntraGenFn g_intra_gen[2];
 static IntraPredFn g_intra_pred[2];
 static unsigned long g_intra_gpu;
+static int g_intra_on;
 static __thread SvtAmdIntraPuJob t_intra_job;
 static __thread void *t_intra_for; /* reference-sample object the stashed job belongs to */
 
@@ -648,7 +664,9 @@ static EB_ERRORTYPE intra_gen(int is16, EB_BOOL constrained, EB_BOOL strong, EB_
                               NeighborArrayUnit_t *cr, void *ref, EB_COLOR_FORMAT cf, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
 {
     t_intra_for = NULL;
-    if (g_ctx && cf == EB_YUV420 && size >= 8 && size <= 32) {
+    if (svt_hook_ep_active)
+        return EB_ErrorNone; /* the device encoded this LCU: nothing reads the reference-sample arrays */
+    if (g_intra_on && g_ctx && cf == EB_YUV420 && size >= 8 && size <= 32) {
         SvtAmdIntraPuJob *j = &t_intra_job;
         const int bps = is16 ? 2 : 1;
         memset(j, 0, sizeof(*j));
@@ -731,7 +749,7 @@ static EB_ERRORTYPE intra_lgen(int is16, EB_BOOL constrained, EB_BOOL strong, EB
                                void *ref, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
 {
     t_intra4_for[0] = NULL;
-    if (g_ctx && size == 4) {
+    if (g_intra_on && g_ctx && size == 4) {
         NeighborArrayUnit_t *na[3] = {y, cb, cr};
         intra_slices(&t_intra4_job[0], is16 ? 2 : 1, constrained, strong, originX, originY, 4, lcuSize, cuDepth + 1, mode, na, 0, 1, pl, pt, pr);
         t_intra4_for[0] = ref;
@@ -744,7 +762,7 @@ static EB_ERRORTYPE intra_cgen(int is16, EB_BOOL constrained, EB_BOOL strong, EB
                                void *ref, EB_COLOR_FORMAT cf, EB_BOOL second, EB_BOOL pl, EB_BOOL pt, EB_BOOL pr)
 {
     t_intra4_for[1] = NULL;
-    if (g_ctx && size == 8 && cf == EB_YUV420 && !second) {
+    if (g_intra_on && g_ctx && size == 8 && cf == EB_YUV420 && !second) {
         NeighborArrayUnit_t *na[3] = {y, cb, cr};
         intra_slices(&t_intra4_job[1], is16 ? 2 : 1, constrained, strong, originX, originY, 8, lcuSize, cuDepth, mode, na, 1, 3, pl, pt, pr);
         t_intra4_for[1] = ref;
@@ -756,6 +774,8 @@ static EB_ERRORTYPE intra_pred(int is16, void *ref, EB_U32 originX, EB_U32 origi
                                EbPictureBufferDesc_t *pic, EB_COLOR_FORMAT cf, EB_BOOL second, EB_U32 lumaMode, EB_U32 chromaMode,
                                EB_U32 mask)
 {
+    if (svt_hook_ep_active)
+        return EB_ErrorNone;
     if (puSize == 4 && cf == EB_YUV420 && !second && lumaMode <= 34 &&
         (mask == PICTURE_BUFFER_DESC_LUMA_MASK || mask == PICTURE_BUFFER_DESC_CHROMA_MASK)) { /* intra 4x4 coding unit */
         const int c = mask == PICTURE_BUFFER_DESC_CHROMA_MASK;
@@ -816,7 +836,8 @@ static EB_ERRORTYPE intra_cgen8(ICGEN_ARGS) { return intra_cgen(0, a, b, c, d, e
 static EB_ERRORTYPE intra_cgen16(ICGEN_ARGS) { return intra_cgen(1, a, b, c, d, e, f, g, h, i, j, k, l, m, q, n, o, p); }
 __attribute__((constructor)) static void intra_install(void)
 {
-    if (!getenv("SVT_HOOK_INTRA"))
+    g_intra_on = getenv("SVT_HOOK_INTRA") != NULL;
+    if (!g_intra_on && !getenv("SVT_HOOK_ENCODEPASS"))
         return;
     g_intra_gen[0] = GenerateIntraReferenceSamplesFuncTable[0], g_intra_gen[1] = GenerateIntraReferenceSamplesFuncTable[1];
     g_intra_pred[0] = EncodePassIntraPredictionFuncTable[0], g_intra_pred[1] = EncodePassIntraPredictionFuncTable[1];
@@ -1286,6 +1307,11 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
                                        EB_U32 dZoffset, CabacEncodeContext_t *cabacEncodeCtxPtr, EB_U64 lambda, EB_U32 intraLumaMode,
                                        EB_U32 intraChromaMode, CabacCost_t *CabacCost)
 {
+    if (svt_hook_ep_active) {
+        svt_hook_ep_quantize(contextPtr, quantCoeff, reconCoeff, coeffStride, qp, areaSize, yCountNonZeroCoeffs, transCoeffShape,
+                             cleanSparseCeoffPfEncDec, pmpMaskingLevelEncDec, enableCbflag, enableContouringQCUpdateFlag, dZoffset);
+        return;
+    }
     if (g_quant_state == 0)
         g_quant_state = getenv("SVT_HOOK_QUANT") ? 1 : -1;
     if (g_quant_state > 0 && g_ctx && contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE && yCountNonZeroCoeffs && areaSize <= 32 &&
@@ -1478,6 +1504,7 @@ static void hook_report(void)
     FILE *out = rp ? fopen(rp, "w") : stdout;
     if (!out)
         return;
+    svt_hook_encdec_report(out);
     if (g_verbose) {
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", g_cpu_EncodePassInterPrediction);
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", g_cpu_EncodePassInterPrediction16bit);

@@ -387,3 +387,44 @@ extern "C" int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic,
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
 }
+
+/* ---- LCUs encoded by the host: their last row / column and edge mode types enter the device picture --------------------------- */
+__global__ __launch_bounds__(256) void k_put_borders(EpPicture P, const SvtAmdLcuBorder *B)
+{
+    const SvtAmdLcuBorder &b = B[blockIdx.x];
+    const int t = threadIdx.x;
+    const int lw = min(64, (int)P.width - (int)b.lcu_x), lh = min(64, (int)P.height - (int)b.lcu_y);
+    /* 0..63 bottom Y, 64..127 right Y, 128..159 / 160..191 bottom / right Cb, 192..223 / 224..255 Cr */
+    const int p = t < 128 ? 0 : (t < 192 ? 1 : 2), e = p == 0 ? t : (p == 1 ? t - 128 : t - 192), n = p ? 32 : 64;
+    const bool right = e >= n;
+    const int i = right ? e - n : e, w = p ? lw >> 1 : lw, h = p ? lh >> 1 : lh;
+    const int x0 = p ? b.lcu_x >> 1 : b.lcu_x, y0 = p ? b.lcu_y >> 1 : b.lcu_y;
+    const uint8_t *src = p == 0 ? (right ? b.right_y : b.bottom_y) : p == 1 ? (right ? b.right_cb : b.bottom_cb) : (right ? b.right_cr : b.bottom_cr);
+    if (i < (right ? h : w))
+        P.rec[p][right ? (size_t)(y0 + i) * P.pitch[p] + x0 + w - 1 : (size_t)(y0 + h - 1) * P.pitch[p] + x0 + i] = src[i];
+    if (t < 16 && t < (lw >> 2))
+        P.mode_map[(size_t)((b.lcu_y + lh - 1) >> 2) * P.map_pitch + (b.lcu_x >> 2) + t] = b.mode_bottom[t];
+    if (t >= 16 && t < 32 && t - 16 < (lh >> 2))
+        P.mode_map[(size_t)((b.lcu_y >> 2) + t - 16) * P.map_pitch + ((b.lcu_x + lw - 1) >> 2)] = b.mode_right[t - 16];
+}
+
+extern "C" int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder *borders, int n)
+{
+    if (!ctx || !pic || !borders || n < 1 || n > 4096)
+        return SVT_AMD_ERR_BAD_PARAM;
+    for (int i = 0; i < n; i++)
+        if (borders[i].lcu_x >= pic->d.width || borders[i].lcu_y >= pic->d.height || ((borders[i].lcu_x | borders[i].lcu_y) & 63)) {
+            svt_amd_set_error("svt_amd_encdec_picture_put_borders: bad LCU %d", i);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t *d = nullptr;
+    int rc = svt_amd_ctx_scratch(ctx, sizeof(SvtAmdLcuBorder) * (size_t)n, &d);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(d, borders, sizeof(SvtAmdLcuBorder) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_put_borders, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const SvtAmdLcuBorder *)d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}

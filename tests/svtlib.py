@@ -344,6 +344,8 @@ LCU_WORK_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("num_cus", "u1")
 LCU_CU_RESULT_DTYPE = np.dtype([("cbf", "u1", 3), ("only_dc", "u1", 3), ("nz", "<u2", 3)])
 LCU_RESULT_DTYPE = np.dtype([("cu", LCU_CU_RESULT_DTYPE, 64), ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024),
                              ("rec_y", "u1", 4096), ("rec_cb", "u1", 1024), ("rec_cr", "u1", 1024)])
+LCU_BORDER_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("mode_bottom", "u1", 16), ("mode_right", "u1", 16), ("bottom_y", "u1", 64),
+                             ("right_y", "u1", 64), ("bottom_cb", "u1", 32), ("right_cb", "u1", 32), ("bottom_cr", "u1", 32), ("right_cr", "u1", 32)])
 EP_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
                             ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("work", LCU_WORK_DTYPE), ("result", LCU_RESULT_DTYPE)])
 

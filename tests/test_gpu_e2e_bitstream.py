@@ -314,3 +314,55 @@ def test_bitstream_identical_with_every_binding_enabled(tmp_path, kind, w, h, n,
         assert msg in log, (msg, log[-1500:])
     assert hip_md5 == ref_md5, "bitstream differs from the reference"
     assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
+
+
+ENCODEPASS_CASES = [
+    # all-intra, default loop filters (deblocking + SAO run in the reference code on the device's reconstruction); partial LCUs
+    ("motion", 416, 240, 3, ["-encMode", "9", "-intra-period", "0"], "all"),
+    ("noise", 200, 136, 2, ["-encMode", "6", "-intra-period", "0", "-q", "22"], "all"),
+    # BASELINE configs[0]: all-intra 1080p encMode 10
+    ("motion", 1920, 1080, 2, ["-encMode", "10", "-intra-period", "0"], "all"),
+    # random access: the I picture and the all-intra LCUs of P / B pictures on the device, LCUs with inter units on the host, their
+    # borders handed over
+    ("motion", 640, 384, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], "some"),
+    # low-delay P with constrained intra prediction: inter neighbours are unavailable to intra units
+    ("noise", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40"], "some"),
+    # 2 x 2 tiles: tile edges cut the intra neighbourhood, four wavefronts share the picture
+    ("motion", 832, 480, 3, ["-encMode", "7", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
+    # encMode 4: the encode pass quantises with PM-core, outside the device call - every LCU must be left to the reference code
+    ("motion", 416, 240, 2, ["-encMode", "4", "-intra-period", "0"], "none"),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args,expect", ENCODEPASS_CASES)
+def test_bitstream_and_recon_identical_with_device_resident_encode_pass(tmp_path, kind, w, h, n, args, expect):
+    """SVT_HOOK_ENCODEPASS=1: EncodePass of every LCU inside the device call's coverage is ONE svt_amd_encode_lcus() call (prediction,
+    transform, quantiser, reconstruction of all its units against the picture's reconstruction in HBM); the reference's own
+    EncodePass then only keeps its books from the output contract (integration/svt_hook_encdec.c).  Bitstream and reconstruction
+    must be byte-identical to the unmodified reference's."""
+    import re
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    os.environ["SVT_HOOK_ENCODEPASS"] = "1"
+    os.environ["SVT_HOOK_REPORT"] = str(tmp_path / "report.txt")
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        del os.environ["SVT_HOOK_ENCODEPASS"]
+        del os.environ["SVT_HOOK_REPORT"]
+    rep = open(str(tmp_path / "report.txt")).read()
+    m = re.search(r"encode pass: (\d+) LCUs encoded on the GPU \(one call each\); left to the reference code: (\d+) LCUs with units outside "
+                  r"the device call, (\d+) under tools outside it, (\d+) in another sample format; (\d+) host LCU borders handed over in (\d+) calls", rep)
+    assert m, rep
+    gpu, units, tools, fmt, borders, puts = (int(x) for x in m.groups())
+    nl = S.lcu_count(w, h) * n
+    assert gpu + units + tools + fmt == nl, rep
+    if expect == "all":
+        assert gpu == nl, rep
+    elif expect == "some":
+        assert gpu >= S.lcu_count(w, h) and units > 0 and borders == units and 0 < puts <= units, rep
+    else:
+        assert gpu == 0 and tools == nl, rep
+    assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
+    assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()

@@ -60,6 +60,50 @@ def test_encode_lcus_matches_reference_records(product, gpu_ctx, name, order):
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
 
 
+def border_of(work, res, w, h):
+    """what the host hands over after encoding an LCU itself: last row / column of the un-deblocked LCU and the edge mode types"""
+    b = np.zeros(1, S.LCU_BORDER_DTYPE)
+    lw, lh = min(64, w - int(work["lcu_x"])), min(64, h - int(work["lcu_y"]))
+    b[0]["lcu_x"], b[0]["lcu_y"] = work["lcu_x"], work["lcu_y"]
+    b[0]["mode_bottom"][:lw // 4] = 2
+    b[0]["mode_right"][:lh // 4] = 2
+    ry = res["rec_y"].reshape(64, 64)
+    b[0]["bottom_y"][:lw], b[0]["right_y"][:lh] = ry[lh - 1, :lw], ry[:lh, lw - 1]
+    for p in ("cb", "cr"):
+        rc = res["rec_" + p].reshape(32, 32)
+        b[0]["bottom_" + p][:lw // 2], b[0]["right_" + p][:lh // 2] = rc[lh // 2 - 1, :lw // 2], rc[:lh // 2, lw // 2 - 1]
+    return b
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("host_lcus", ["odd", "even"])
+def test_host_encoded_lcus_enter_the_device_picture(product, gpu_ctx, name, host_lcus):
+    """mixed pictures: every second LCU is "encoded by the host" (its recorded reconstruction stands in) and only its last row / column
+    and edge mode types are handed to the device; the LCUs the device encodes must still match the records"""
+    lib = product
+    sig(lib)
+    lib.svt_amd_encdec_picture_put_borders.restype = C.c_int
+    lib.svt_amd_encdec_picture_put_borders.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    g, w, h = load_case(name)
+    nl = S.lcu_count(w, h)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
+        ndev = 0
+        for k in range(nl):
+            if (k & 1) == (host_lcus == "odd"):
+                b = border_of(g["work"][k], g["result"][k], w, h)
+                assert lib.svt_amd_encdec_picture_put_borders(gpu_ctx, pic, b.ctypes.data, 1) == 0, lib.svt_amd_last_error()
+            else:
+                got = encode(lib, gpu_ctx, pic, g["work"][k:k + 1])
+                compare_lcu(g["work"][k], g["result"][k], got[0], w, h, (name, host_lcus, k))
+                ndev += 1
+        assert ndev >= nl // 2
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
 def random_tree(rng, lw, lh):
     """a random quadtree of 32 / 16 / 8 units over the part of the LCU inside the picture, in Z order"""
     out = []
