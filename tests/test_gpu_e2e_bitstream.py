@@ -326,7 +326,7 @@ ENCODEPASS_CASES = [
     # borders handed over
     ("motion", 640, 384, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], "some"),
     # low-delay P with constrained intra prediction: inter neighbours are unavailable to intra units
-    ("noise", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40"], "some"),
+    ("noise", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40"], "mixed"),
     # 2 x 2 tiles: tile edges cut the intra neighbourhood, four wavefronts share the picture
     ("motion", 832, 480, 3, ["-encMode", "7", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
     # encMode 4: the encode pass quantises with PM-core, outside the device call - every LCU must be left to the reference code
@@ -360,8 +360,10 @@ def test_bitstream_and_recon_identical_with_device_resident_encode_pass(tmp_path
     assert gpu + units + tools + fmt == nl, rep
     if expect == "all":
         assert gpu == nl, rep
-    elif expect == "some":
-        assert gpu >= S.lcu_count(w, h) and units > 0 and borders == units and 0 < puts <= units, rep
+    elif expect == "some":     # at least the I picture
+        assert gpu >= S.lcu_count(w, h) and units > 0 and borders == units, rep
+    elif expect == "mixed":    # device-encoded LCUs after host-encoded ones inside P pictures
+        assert gpu > S.lcu_count(w, h) and units > 0 and borders == units and 0 < puts <= units, rep
     else:
         assert gpu == 0 and tools == nl, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
