@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "EbDefinitions.h"
 #include "EbPictureControlSet.h"
@@ -62,7 +63,19 @@ typedef struct {
     const SvtAmdOisLcuResult *ois;
     unsigned me_left, ois_left;      /* LCUs still to serve (atomics) */
     SvtAmdOisParams oisp;
+    double t_submit;                 /* timeline of the lane (report only) */
+    int timed;
 } FrontEntry;
+
+/* front-half timeline, printed by the report: where a picture's time on a lane goes */
+static double g_t_submit_call, g_t_device, g_t_lane_held, g_t_lane_wait;
+static unsigned long g_n_lane_wait, g_n_timed;
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_mutex_t g_front_lock = PTHREAD_MUTEX_INITIALIZER; /* entry table + slot table */
@@ -75,14 +88,37 @@ static uint32_t g_nlcu;
 static unsigned long g_pictures, g_lcus;
 static int g_verbose; /* SVT_HOOK_VERBOSE=1: one stderr line per picture handled on the device */
 /* calls a binding handed back to the reference function (switch off, or outside what the binding covers) */
-static unsigned long g_cpu_EncodePassInterPrediction;
-static unsigned long g_cpu_EncodePassInterPrediction16bit;
-static unsigned long g_cpu_Inter2Nx2NPuPredictionHevc;
-static unsigned long g_cpu_Intra4x4IntraPredictionCl;
-static unsigned long g_cpu_IntraPredictionCl;
-static unsigned long g_cpu_IntraPredictionOl;
-static unsigned long g_cpu_SaoGenerationDecision;
-static unsigned long g_cpu_SaoGenerationDecision16bit;
+/* The counters sit on the mode decision's hottest calls (millions per second over all EncDec threads): one block per thread,
+ * summed by the report - a shared counter would bounce its cache line between the sockets on every call. */
+enum { CPU_EncodePassInterPrediction, CPU_EncodePassInterPrediction16bit, CPU_Inter2Nx2NPuPredictionHevc, CPU_Intra4x4IntraPredictionCl, CPU_IntraPredictionCl, CPU_IntraPredictionOl, CPU_SaoGenerationDecision, CPU_SaoGenerationDecision16bit, CPU_COUNTERS };
+typedef struct HookCounters {
+    unsigned long v[CPU_COUNTERS];
+    struct HookCounters *next;
+    char pad[64];
+} HookCounters;
+static __thread HookCounters *t_counters;
+static HookCounters *g_counters;
+static pthread_mutex_t g_counters_lock = PTHREAD_MUTEX_INITIALIZER;
+static HookCounters *counters_of_thread(void)
+{
+    HookCounters *c = (HookCounters *)calloc(1, sizeof(*c)); /* lives until exit: the report reads it after the thread is gone */
+    if (!c)
+        abort();
+    pthread_mutex_lock(&g_counters_lock);
+    c->next = g_counters, g_counters = c;
+    pthread_mutex_unlock(&g_counters_lock);
+    return t_counters = c;
+}
+#define COUNT_CPU(name) (++(t_counters ? t_counters : counters_of_thread())->v[CPU_##name])
+static unsigned long counter_sum(int i)
+{
+    unsigned long n = 0;
+    pthread_mutex_lock(&g_counters_lock);
+    for (const HookCounters *c = g_counters; c; c = c->next)
+        n += c->v[i];
+    pthread_mutex_unlock(&g_counters_lock);
+    return n;
+}
 static void hook_report(void);
 static void ensure_context(uint16_t lumaWidth, uint16_t lumaHeight);
 
@@ -214,6 +250,7 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
             break;
         if (fr) {
             e = fr;
+            const double t0 = now_s();
             const int intra = pcs->sliceType == EB_I_PICTURE;
             if (!intra && !me_ctx)
                 die("front_entry: OIS before ME on a non-intra picture (unexpected call order)");
@@ -242,6 +279,8 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
             e->ois_left = g_nlcu;
             e->me = NULL, e->ois = NULL;
             e->gen++;
+            e->t_submit = now_s(), e->timed = 0;
+            g_t_submit_call += e->t_submit - t0;
             if (!intra)
                 g_pictures++;
             g_ois_pictures++;
@@ -253,7 +292,11 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
             __atomic_store_n(&e->state, 1, __ATOMIC_RELEASE);
             break;
         }
-        pthread_cond_wait(&g_front_cv, &g_front_lock); /* every lane is serving an earlier picture */
+        {
+            const double tw = now_s();
+            pthread_cond_wait(&g_front_cv, &g_front_lock); /* every lane is serving an earlier picture */
+            g_t_lane_wait += now_s() - tw, g_n_lane_wait++;
+        }
     }
     pthread_mutex_unlock(&g_front_lock);
     /* outside the lock: wait for this lane's completion event (idempotent; any number of threads may wait) */
@@ -262,6 +305,11 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
     if (svt_amd_frontend_wait(e->lane, &me, &ois))
         die("svt_amd_frontend_wait");
     e->me = me, e->ois = ois;
+    if (!__atomic_exchange_n(&e->timed, 1, __ATOMIC_ACQ_REL)) { /* first thread back: submit -> results on the host */
+        pthread_mutex_lock(&g_front_lock);
+        g_t_device += now_s() - e->t_submit, g_n_timed++;
+        pthread_mutex_unlock(&g_front_lock);
+    }
     cached = e;
     cached_gen = e->gen;
     return e;
@@ -274,6 +322,7 @@ static void front_served(FrontEntry *e, unsigned *counter)
     if (__atomic_load_n(&e->me_left, __ATOMIC_ACQUIRE) || __atomic_load_n(&e->ois_left, __ATOMIC_ACQUIRE))
         return;
     pthread_mutex_lock(&g_front_lock);
+    g_t_lane_held += now_s() - e->t_submit;
     svt_amd_frontend_release(e->lane);
     __atomic_store_n(&e->state, 0, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_front_cv);
@@ -904,7 +953,7 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
     if (g_md_intra_state < 0 || !g_ctx || md->intraMdOpenLoopFlag || size < 8 || size > 32 || lumaMode > 34 ||
         (chromaAsked && ((componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK ||
                          !md->useChromaInformationInFullLoop))) {
-        __sync_fetch_and_add(&g_cpu_IntraPredictionCl, 1ul);
+        COUNT_CPU(IntraPredictionCl);
         return __real_IntraPredictionCl(md, componentMask, pcs, cand);
     }
     EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr, *pred = cand->predictionPtr;
@@ -970,7 +1019,7 @@ EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componen
     const int chromaAsked = (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != 0;
     if (g_md_intra_state < 0 || !g_ctx || !md->intraMdOpenLoopFlag || size < 8 || size > 32 || lumaMode > 34 ||
         (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK)) {
-        __sync_fetch_and_add(&g_cpu_IntraPredictionOl, 1ul);
+        COUNT_CPU(IntraPredictionOl);
         return __real_IntraPredictionOl(md, componentMask, pcs, cand);
     }
     EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr, *pred = cand->predictionPtr;
@@ -1030,7 +1079,7 @@ EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, 
     if (g_md_intra_state < 0 || !g_ctx || puWidth != 4 || puHeight != 4 || lcuSize != 64 || md->intraMdOpenLoopFlag || lumaMode > 34 ||
         !(componentMask & PICTURE_BUFFER_DESC_LUMA_MASK) ||
         (chromaAsked && (componentMask & PICTURE_BUFFER_DESC_CHROMA_MASK) != PICTURE_BUFFER_DESC_CHROMA_MASK)) {
-        __sync_fetch_and_add(&g_cpu_Intra4x4IntraPredictionCl, 1ul);
+        COUNT_CPU(Intra4x4IntraPredictionCl);
         return __real_Intra4x4IntraPredictionCl(puIndex, puOriginX, puOriginY, puWidth, puHeight, lcuSize, componentMask, pcs, cand, ctx);
     }
     NeighborArrayUnit_t *na[3] = {md->lumaReconNeighborArray, md->cbReconNeighborArray, md->crReconNeighborArray};
@@ -1114,7 +1163,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
         g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
     if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
         puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr) {
-        __sync_fetch_and_add(&g_cpu_EncodePassInterPrediction, 1ul);
+        COUNT_CPU(EncodePassInterPrediction);
         return __real_EncodePassInterPrediction(mvUnit, puOriginX, puOriginY, puWidth, puHeight, pcs, predictionPtr, mcpContext);
     }
     SvtAmdInterPuJob job;
@@ -1173,7 +1222,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
         g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
     if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
         puHeight > 64 || mvUnit->predDirection > BI_PRED || predictionPtr->strideCb != predictionPtr->strideCr) {
-        __sync_fetch_and_add(&g_cpu_EncodePassInterPrediction16bit, 1ul);
+        COUNT_CPU(EncodePassInterPrediction16bit);
         return __real_EncodePassInterPrediction16bit(mvUnit, puOriginX, puOriginY, puWidth, puHeight, pcs, predictionPtr, mcpContext);
     }
     SvtAmdInterPuJob job;
@@ -1239,7 +1288,7 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
     const int msb = scs->staticConfig.encoderBitDepth > EB_8BIT; /* 10-bit encode: 8-bit prediction from the MSBs of the 16-bit references */
     if (g_inter_state < 0 || !g_ctx || mdContextPtr->cuUseRefSrcFlag || size < 8 || size > 64 ||
         dir > BI_PRED || dst->strideY != 64 || dst->strideCb != 32 || dst->strideCr != 32) {
-        __sync_fetch_and_add(&g_cpu_Inter2Nx2NPuPredictionHevc, 1ul);
+        COUNT_CPU(Inter2Nx2NPuPredictionHevc);
         return __real_Inter2Nx2NPuPredictionHevc(mdContextPtr, componentMask, pcs, candidateBufferPtr);
     }
     SvtAmdInterPuJob job;
@@ -1453,7 +1502,7 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision(SaoStats_t *saoStats, SaoParameters_t 
     const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
         ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture : pcs->reconPicturePtr;
     if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420) {
-        __sync_fetch_and_add(&g_cpu_SaoGenerationDecision, 1ul);
+        COUNT_CPU(SaoGenerationDecision);
         return __real_SaoGenerationDecision(saoStats, saoParams, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, tbOriginX, tbOriginY,
                                             lcuWidth, lcuHeight, saoPtr, leftSaoPtr, upSaoPtr, saoLumaBestCost, saoChromaBestCost);
     }
@@ -1480,7 +1529,7 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
     const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
         ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture16bit : pcs->reconPicture16bitPtr;
     if (g_sao_state < 0 || !g_ctx || saoParams != saoPtr || rec->colorFormat != EB_YUV420) {
-        __sync_fetch_and_add(&g_cpu_SaoGenerationDecision16bit, 1ul);
+        COUNT_CPU(SaoGenerationDecision16bit);
         return __real_SaoGenerationDecision16bit(inputLcuPtr, saoStats, saoParams, md, fullLambda, fullChromaLambdaSao, mmSao, pcs, tbOriginX,
                                                  tbOriginY, lcuWidth, lcuHeight, saoPtr, leftSaoPtr, upSaoPtr, saoLumaBestCost,
                                                  saoChromaBestCost);
@@ -1505,15 +1554,19 @@ static void hook_report(void)
     if (!out)
         return;
     svt_hook_encdec_report(out);
+    if (g_n_timed)
+        fprintf(out, "svt_hook_me: front-half timeline over %lu pictures: submit call %.3f ms, submit -> results on the host %.3f ms, lane held %.3f ms "
+                     "(means); %lu waits for a free lane, %.1f ms in total\n", g_n_timed, 1e3 * g_t_submit_call / g_n_timed, 1e3 * g_t_device / g_n_timed,
+                1e3 * g_t_lane_held / g_n_timed, g_n_lane_wait, 1e3 * g_t_lane_wait);
     if (g_verbose) {
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", g_cpu_EncodePassInterPrediction);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", g_cpu_EncodePassInterPrediction16bit);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Inter2Nx2NPuPredictionHevc", g_cpu_Inter2Nx2NPuPredictionHevc);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Intra4x4IntraPredictionCl", g_cpu_Intra4x4IntraPredictionCl);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionCl", g_cpu_IntraPredictionCl);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionOl", g_cpu_IntraPredictionOl);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision", g_cpu_SaoGenerationDecision);
-        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision16bit", g_cpu_SaoGenerationDecision16bit);
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", counter_sum(CPU_EncodePassInterPrediction));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", counter_sum(CPU_EncodePassInterPrediction16bit));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Inter2Nx2NPuPredictionHevc", counter_sum(CPU_Inter2Nx2NPuPredictionHevc));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "Intra4x4IntraPredictionCl", counter_sum(CPU_Intra4x4IntraPredictionCl));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionCl", counter_sum(CPU_IntraPredictionCl));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "IntraPredictionOl", counter_sum(CPU_IntraPredictionOl));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision", counter_sum(CPU_SaoGenerationDecision));
+        fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "SaoGenerationDecision16bit", counter_sum(CPU_SaoGenerationDecision16bit));
         fprintf(out, "svt_hook_me: with the CABAC-context-updating estimator on the GPU: full loop luma %lu chroma %lu\n", g_fl_cabac_gpu, g_cl_cabac_gpu);
         fprintf(out, "svt_hook_me: on the GPU: full loop luma %lu (left to the reference code %lu) chroma %lu (%lu), recon %lu, intra encode pass %lu + 4x4 %lu, "
                         "intra MD closed %lu open %lu 4x4 %lu, inter encode pass %lu + 16-bit %lu, inter MD %lu, quantiser %lu + PM-core %lu, SAO %lu\n",

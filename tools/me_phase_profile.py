@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase time breakdown of k_me_picture (shader-clock stamps taken by thread 0 of each
-workgroup).  usage: python tools/me_phase_profile.py [batch]   (needs the GPU)"""
+workgroup).  usage: python tools/me_phase_profile.py [batch] [fixture, e.g. b_3840x2160_m7]   (needs the GPU)"""
+import re
 import ctypes as C
 import os
 import sys
@@ -21,23 +22,26 @@ NAMES = ["hme: stage src", "hme: TestSearchAreaBounds", "hme: HME L0/L1/L2", "hm
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    W, H = 1920, 1080
+    case = sys.argv[2] if len(sys.argv) > 2 else "p_1920x1080_m9"
+    W, H = (int(v) for v in re.search(r"_(\d+)x(\d+)_", case).groups())
     lib = S.load_product()
     lib.svt_amd_debug_me_phase_profile.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     ctx = C.c_void_p()
-    assert lib.svt_amd_context_create(0, W, H + 8, B + 1, C.byref(ctx)) == 0
-    params = S.params_from_record(load_case("p_1920x1080_m9")["params"][0])
+    assert lib.svt_amd_context_create(0, W, (H + 7) & ~7, B + 2, C.byref(ctx)) == 0
+    g = load_case(case)
+    params = S.params_from_record(g["params"][len(g["params"]) // 2])
+    print("%s: %dx%d, %d list(s), batch %d" % (case, W, H, params.num_lists, B))
     dev = torch.device("cuda", 0)
-    frames = torch.randint(0, 256, (B + 1, H, W), dtype=torch.uint8, device=dev)
-    for t in range(1, B + 1):  # smooth-ish motion: shifted copies + noise
+    frames = torch.randint(0, 256, (B + 2, H, W), dtype=torch.uint8, device=dev)
+    for t in range(1, B + 2):  # smooth-ish motion: shifted copies + noise
         frames[t] = torch.roll(frames[0], shifts=(t, 2 * t), dims=(0, 1))
     torch.cuda.synchronize()
-    for i in range(B + 1):
+    for i in range(B + 2):
         assert lib.svt_amd_picture_upload_device(ctx, i, C.c_void_p(frames[i].data_ptr()), W, W, H) == 0
     jobs = (S.MeJob * B)()
     for i in range(B):
         jobs[i].params, jobs[i].cur_slot = params, i + 1
-        jobs[i].ref_slot[0] = jobs[i].ref_slot[1] = i
+        jobs[i].ref_slot[0], jobs[i].ref_slot[1] = i, i + 2
     nlcu = S.lcu_count(W, H)
     for _ in range(2):
         assert lib.svt_amd_me_batch_launch(ctx, jobs, B) == 0
