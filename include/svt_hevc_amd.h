@@ -991,6 +991,20 @@ SVT_AMD_API int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecP
 SVT_AMD_API int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n,
                                     SvtAmdLcuResult *results);
 
+/* The whole picture in ONE call: works / results are HOST arrays of every LCU of the picture in raster order.  The wavefront of
+ * AssignEncDecSegments (Codec/EbEncDecProcess.c:1540; an LCU starts when its left and top-right LCUs of the same tile are done) runs
+ * on the device - workgroups draw LCUs in raster order and wait for their neighbours' completion flags - so the host makes no
+ * scheduling decision and the picture costs one launch.  Implies svt_amd_encdec_picture_begin.  Blocking. */
+SVT_AMD_API int svt_amd_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results);
+/* The same on DEVICE arrays (the unit lists are not validated); asynchronous on the context's stream.  tiles: tiles of the picture
+ * (they run side by side; sizes the persistent grid). */
+SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
+                                              SvtAmdLcuResult *d_results, int tiles);
+
+/* debug: out == NULL arms per-LCU shader-clock sums in the encode-pass kernels (8 x u64 per LCU: prediction, encode, copy-out, units,
+ * wait for neighbours, start, end, -), a later call with a HOST buffer of 8 * LCUs u64 fetches them (tools/encodepass_bench.py) */
+SVT_AMD_API int svt_amd_debug_encdec_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
+
 /* LCUs the HOST encoded itself (units outside this revision: inter, intra 4x4, 64x64, delta-QP / masking configurations) are
  * handed to the device picture afterwards so that later LCUs find their neighbours: the un-deblocked last row and last column of
  * the LCU and the mode type of the 4x4 cells along them - what the reference's ep*ReconNeighborArray / epModeTypeNeighborArray

@@ -27,6 +27,7 @@
  * residual -> forward "Estimate" DCT in registers -> column r quantised / de-quantised in registers -> inverse DCT -> + prediction.
  */
 #include "txfm_device.h"
+#include <vector>
 #include "intra_device.h"
 
 struct EpPicture {                 /* = SvtAmdEncDecPicture's device part */
@@ -34,6 +35,7 @@ struct EpPicture {                 /* = SvtAmdEncDecPicture's device part */
     uint32_t pitch[3];             /* samples */
     uint8_t *mode_map;             /* (height / 4) rows of map_pitch bytes */
     uint32_t map_pitch;
+    unsigned long long *prof;      /* debug (svt_amd_debug_encdec_profile): 8 shader-clock sums per LCU, or null */
     uint16_t width, height;        /* luma */
     uint32_t bps;
 };
@@ -41,6 +43,9 @@ struct SvtAmdEncDecPicture {
     EpPicture d;
     size_t plane_bytes[3], map_bytes;
     int device;
+    unsigned *d_sync; /* [0] ticket counter, [1 + lcu] epoch of the picture-level call that finished the LCU, then the ticket order */
+    unsigned epoch;
+    int nlcu;
 };
 
 typedef SvtAmdLcuCu LcuCu;
@@ -54,57 +59,78 @@ __device__ __forceinline__ int ep_mode_at(const EpPicture &P, int px, int py)
     return P.mode_map[(size_t)(py >> 2) * P.map_pitch + (px >> 2)];
 }
 
-/* The intra reference of the unit (availability, substitution, smoothing) and the three predicted blocks, written into the
- * reconstruction planes at the unit's position - k_intra_pu (intra_kernels.hip) with the neighbours read from the picture. */
+/* The LCU a workgroup encodes lives in LDS: its three reconstruction planes with a ring of neighbour samples (row -1 from x = -1 to
+ * 2n - 1: top-left, top and top-right LCUs; column -1: the left LCU), the mode types of its 4x4 cells with the same ring, and its
+ * source samples.  Every per-unit access (neighbour fetch, prediction, residual, reconstruction) is an LDS access; the picture in
+ * HBM is read once (ring) and written once (finished LCU) per LCU. */
 template <typename T>
-__device__ void ep_intra_predict(const EpPicture &P, const LcuWork &W, const LcuCu &cu, int t, int16_t (*border)[132], int16_t (*ref)[132],
-                                 uint8_t *ok, int *s_small /* [0] first group, [1..3] dc, [4..6] mode */)
+struct EpLocal {
+    static constexpr int PY = 144, PC = 80, X0 = 16; /* row pitches; column of x = 0 (rows of units start 16-byte aligned) */
+    T y[65 * PY];
+    T c[2][33 * PC];
+    uint8_t mode[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
+    uint8_t src_y[64 * 64], src_c[2][32 * 32];
+    __device__ __forceinline__ T *at(int p, int x, int y_) { return p == 0 ? &y[(y_ + 1) * PY + X0 + x] : &c[p - 1][(y_ + 1) * PC + X0 + x]; }
+    __device__ __forceinline__ int pitch(int p) const { return p == 0 ? PY : PC; }
+    /* mode type at luma sample (x, y) relative to the LCU: what lies below the LCU, right of it (from its first row on) or right of
+     * the top-right LCU is never coded before this LCU */
+    __device__ __forceinline__ int mode_at(int x, int y_) const
+    {
+        const int cx = x >> 2, cy = y_ >> 2;
+        if (cy >= 16 || cx >= 32 || (cy >= 0 && cx >= 16))
+            return 0xFF;
+        return mode[(cy + 1) * 36 + cx + 1];
+    }
+};
+
+/* The intra reference of the unit (availability, substitution, smoothing) and the three predicted blocks, written into the local
+ * reconstruction planes at the unit's position - k_intra_pu (intra_kernels.hip) with the neighbours read from the LCU in LDS. */
+template <typename T>
+__device__ void ep_intra_predict(EpLocal<T> &L, const LcuWork &W, const LcuCu &cu, int t, int16_t (*border)[132], int16_t (*ref)[132], uint8_t *ok,
+                                 int *s_small /* [0] first group, [1..3] dc */)
 {
     constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, mid = sizeof(T) == 1 ? 128 : 512, thr = sizeof(T) == 1 ? 8 : 32;
     const int N = cu.size, nb = N >> 2, lgN = 31 - __clz(N);
-    const int x0 = W.lcu_x + cu.x, y0 = W.lcu_y + cu.y;
     const bool pic_left = W.tile_left && cu.x == 0, pic_top = W.tile_top && cu.y == 0;
     const bool pic_right = W.tile_right && ((cu.x + N) & 63) == 0;
-    const T *rp[3] = {(const T *)P.rec[0], (const T *)P.rec[1], (const T *)P.rec[2]};
-    if (t <= 4 * nb) {
-        bool a;
-        if (t < 2 * nb) { /* left group t covers rows [2N-4-4t, 2N-4t) */
-            const int e = ep_mode_at(P, x0 - 1, y0 + 2 * N - 4 - 4 * t);
+    if (t < 64) { /* the 4 nb + 1 <= 33 neighbour groups, all on the first wave: availability flags and the first available group */
+        bool a = false;
+        if (t > 4 * nb) {
+        } else if (t < 2 * nb) { /* left group t covers rows [2N-4-4t, 2N-4t) */
+            const int e = L.mode_at(cu.x - 1, cu.y + 2 * N - 4 - 4 * t);
             a = !(e == 0xFE || (!cu.bottom_left_ok && t < nb) || e == 0xFF || pic_left || (e == 1 && W.constrained_intra));
         } else if (t == 2 * nb) {
-            const int e = ep_mode_at(P, x0 - 1, y0 - 1);
+            const int e = L.mode_at(cu.x - 1, cu.y - 1);
             a = !(e == 0xFE || e == 0xFF || pic_left || pic_top || (e == 1 && W.constrained_intra));
         } else {
-            const int k = t - 2 * nb - 1, e = ep_mode_at(P, x0 + 4 * k, y0 - 1);
+            const int k = t - 2 * nb - 1, e = L.mode_at(cu.x + 4 * k, cu.y - 1);
             a = !(e == 0xFE || (!cu.top_right_ok && k >= nb) || e == 0xFF || pic_top || (pic_right && k >= nb) ||
                   (e == 1 && W.constrained_intra));
         }
-        ok[t] = a;
+        if (t <= 4 * nb)
+            ok[t] = a;
+        const unsigned long long m = __ballot(a);
+        if (t == 0)
+            s_small[0] = m ? __ffsll((long long)m) - 1 : 1 << 30;
     }
-    if (t == 0)
-        s_small[0] = 1 << 30;
-    __syncthreads();
-    if (t <= 4 * nb && ok[t])
-        atomicMin(&s_small[0], t);
     __syncthreads();
     const int firstGroup = s_small[0];
     for (int i = t; i < 3 * 129; i += 256) { /* substitution, one thread per (plane, sample in scan order) */
-        const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N, g = p ? 2 : 4;
+        const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N, lgG = p ? 1 : 2, g = 1 << lgG; /* samples per group */
         if (k > 4 * n)
             continue;
         int v = mid;
         if (firstGroup < (1 << 30)) {
-            auto group_of = [&](int kk) { return kk < 2 * n ? kk / g : kk == 2 * n ? 2 * nb : 2 * nb + 1 + (kk - 2 * n - 1) / g; };
+            auto group_of = [&](int kk) { return kk < 2 * n ? kk >> lgG : kk == 2 * n ? 2 * nb : 2 * nb + 1 + ((kk - 2 * n - 1) >> lgG); };
             int src = k;
             while (src >= 0 && !ok[group_of(src)])
                 src--;
             if (src < 0)
                 src = firstGroup < 2 * nb ? firstGroup * g : firstGroup == 2 * nb ? 2 * n : 2 * n + 1 + (firstGroup - 2 * nb - 1) * g;
-            const int xp = p ? x0 >> 1 : x0, yp = p ? y0 >> 1 : y0;
-            const size_t pitch = P.pitch[p];
+            const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
             /* scan order: [0, 2n) = left column bottom to top (sample 2n-1-src from the top), 2n = top-left, then the top row */
-            v = src < 2 * n ? (int)rp[p][(size_t)(yp + 2 * n - 1 - src) * pitch + xp - 1]
-                : src == 2 * n ? (int)rp[p][(size_t)(yp - 1) * pitch + xp - 1] : (int)rp[p][(size_t)(yp - 1) * pitch + xp + (src - 2 * n - 1)];
+            v = src < 2 * n ? (int)*L.at(p, lx - 1, ly + 2 * n - 1 - src) : src == 2 * n ? (int)*L.at(p, lx - 1, ly - 1)
+                                                                                          : (int)*L.at(p, lx + (src - 2 * n - 1), ly - 1);
         }
         border[p][k] = (int16_t)v;
     }
@@ -133,22 +159,25 @@ __device__ void ep_intra_predict(const EpPicture &P, const LcuWork &W, const Lcu
         ref[p][k < 2 * n ? 2 * n - 1 - k : k] = (int16_t)v;
     }
     __syncthreads();
-    if (t < 3) {
-        const int n = t ? N >> 1 : N;
-        int dc = 0;
-        for (int i = 0; i < n; i++)
-            dc += ref[t][i] + ref[t][2 * n + 1 + i];
-        s_small[1 + t] = (dc + n) >> ((t ? lgN - 1 : lgN) + 1);
+    if (lmode == 1) { /* DC: wave p sums plane p's left column and top row */
+        const int p = t >> 6, l = t & 63;
+        if (p < 3) {
+            const int n = p ? N >> 1 : N;
+            int dc = l < n ? ref[p][l] + ref[p][2 * n + 1 + l] : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                dc += __shfl_xor(dc, o);
+            if (l == 0)
+                s_small[1 + p] = (dc + n) >> ((p ? lgN - 1 : lgN) + 1);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    T *wp[3] = {(T *)P.rec[0], (T *)P.rec[1], (T *)P.rec[2]};
     const int nY = N * N, nC = nY >> 2;
     for (int i = t; i < nY + 2 * nC; i += 256) {
         const int p = i < nY ? 0 : (i < nY + nC ? 1 : 2), e = p == 0 ? i : (p == 1 ? i - nY : i - nY - nC);
         const int n = p ? N >> 1 : N, lg = p ? lgN - 1 : lgN, y = e >> lg, x = e & (n - 1);
         const int v = pu_predict(lmode /* chroma: EB_INTRA_CHROMA_DM */, n, lg, ref[p], x, y, s_small[1 + p], p == 0, maxv);
-        const int xp = p ? x0 >> 1 : x0, yp = p ? y0 >> 1 : y0;
-        wp[p][(size_t)(yp + y) * P.pitch[p] + xp + x] = (T)v;
+        *L.at(p, (p ? cu.x >> 1 : cu.x) + x, (p ? cu.y >> 1 : cu.y) + y) = (T)v;
     }
 }
 
@@ -249,30 +278,68 @@ __device__ __forceinline__ uint32_t ep_encode_plane(int n, int lane, const uint8
     return __shfl(o, 0); /* lane 0 belongs to the live unit */
 }
 
+struct EpShared {
+    int16_t border[3][132], ref[3][132];
+    uint8_t ok[36];
+    int s_small[8];
+    int16_t tiles[3][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N */
+};
+
+/* the coding-unit loop of one LCU, by one workgroup of 256 threads */
 template <typename T>
-__global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const LcuWork *__restrict__ works, LcuResult *__restrict__ results)
+__device__ void ep_encode_lcu(const EpPicture &P, const LcuWork &W, LcuResult &R, EpShared &S, EpLocal<T> &L)
 {
-    __shared__ int16_t border[3][132], ref[3][132];
-    __shared__ uint8_t ok[36];
-    __shared__ int s_small[8];
-    __shared__ int16_t tiles[3][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N */
-    const LcuWork &W = works[blockIdx.x];
-    LcuResult &R = results[blockIdx.x];
+    int16_t (*border)[132] = S.border, (*ref)[132] = S.ref;
+    uint8_t *ok = S.ok;
+    int *s_small = S.s_small;
+    int16_t (*tiles)[2 * TxRegTile<32>::UNIT] = S.tiles;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    T *rp[3] = {(T *)P.rec[0], (T *)P.rec[1], (T *)P.rec[2]};
+    const T *rp[3] = {(const T *)P.rec[0], (const T *)P.rec[1], (const T *)P.rec[2]};
+    T *wp[3] = {(T *)P.rec[0], (T *)P.rec[1], (T *)P.rec[2]};
+    unsigned long long c_pred = 0, c_enc = 0, c0 = P.prof ? __builtin_readcyclecounter() : 0, c1 = 0;
+    const int lw = min(64, (int)P.width - (int)W.lcu_x), lh = min(64, (int)P.height - (int)W.lcu_y);
+    /* ---- the LCU's surroundings and source into LDS ---- */
+    for (int i = t; i < 17 * 36; i += 256) {
+        const int cy = i / 36 - 1, cx = i - (cy + 1) * 36 - 1;
+        L.mode[i] = (uint8_t)((cy < 0 || cx < 0) ? ep_mode_at(P, (int)W.lcu_x + 4 * cx, (int)W.lcu_y + 4 * cy) : 0xFF);
+    }
+    for (int i = t; i < 130 + 2 * 66 + 64 + 2 * 32; i += 256) { /* ring samples: top rows (x = -1 .. 2n-1), then left columns */
+        int p, x, y;
+        if (i < 130 + 2 * 66) {
+            p = i < 130 ? 0 : (i < 196 ? 1 : 2);
+            x = (p == 0 ? i : p == 1 ? i - 130 : i - 196) - 1, y = -1;
+        } else {
+            const int e = i - (130 + 2 * 66);
+            p = e < 64 ? 0 : (e < 96 ? 1 : 2);
+            x = -1, y = p == 0 ? e : p == 1 ? e - 64 : e - 96;
+        }
+        if (x >= (p ? 64 : 128))
+            continue;
+        const int gx = (p ? W.lcu_x >> 1 : W.lcu_x) + x, gy = (p ? W.lcu_y >> 1 : W.lcu_y) + y;
+        const int pw = p ? P.width >> 1 : P.width, ph = p ? P.height >> 1 : P.height;
+        if (gx >= 0 && gy >= 0 && gx < pw && gy < ph) /* what is not there is never marked available */
+            *L.at(p, x, y) = rp[p][(size_t)gy * P.pitch[p] + gx];
+    }
+    for (int i = t; i < (64 * 64 + 2 * 32 * 32) / 4; i += 256) {
+        const uint32_t v = ((const uint32_t *)W.src_y)[i]; /* src_y, src_cb, src_cr are contiguous in the contract */
+        ((uint32_t *)L.src_y)[i] = v;
+    }
+    __syncthreads();
     for (int ci = 0; ci < W.num_cus; ci++) {
         const LcuCu cu = W.cu[ci];
-        const int N = cu.size, x0 = W.lcu_x + cu.x, y0 = W.lcu_y + cu.y;
+        const int N = cu.size;
         if (cu.pred_mode == 2 && N <= 32) {
-            ep_intra_predict<T>(P, W, cu, t, border, ref, ok, s_small);
-            __syncthreads(); /* the prediction is in the picture; the unit's lanes read it back row-wise */
+            ep_intra_predict<T>(L, W, cu, t, border, ref, ok, s_small);
+            __syncthreads(); /* the prediction is in the local planes; the unit's lanes read it back row-wise */
+            if (P.prof)
+                c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
             if (wave < 3) {
                 const int p = wave, n = p ? N >> 1 : N;
-                const int xp = p ? x0 >> 1 : x0, yp = p ? y0 >> 1 : y0, lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
-                const uint8_t *src = p == 0 ? W.src_y + ly * 64 + lx : (p == 1 ? W.src_cb : W.src_cr) + ly * 32 + lx;
+                const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
+                const uint8_t *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
                 int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
-                const uint32_t o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, rp[p] + (size_t)yp * P.pitch[p] + xp, P.pitch[p], coeff,
-                                                      p ? 32 : 64, tiles[p], p ? cu.chroma_qp : cu.qp, W.slice_type, p ? 0u : cu.dz_offset, p == 0);
+                const uint32_t o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[p],
+                                                      p ? cu.chroma_qp : cu.qp, W.slice_type, p ? 0u : cu.dz_offset, p == 0);
                 if (lane == 0) {
                     R.cu[ci].nz[p] = (uint16_t)(o & 0xffff);
                     R.cu[ci].cbf[p] = (o & 0xffff) != 0;
@@ -281,19 +348,94 @@ __global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const LcuWork *
             }
         }
         /* EncodePassUpdate...ModeNeighborArrays: the unit is coded now */
-        const int cells = N >> 2;
+        const int lgc = 29 - __clz(N), cells = 1 << lgc; /* N / 4 */
         for (int i = t; i < cells * cells; i += 256)
-            P.mode_map[(size_t)((y0 >> 2) + i / cells) * P.map_pitch + (x0 >> 2) + i % cells] = cu.pred_mode;
-        __syncthreads(); /* reconstruction and map of this unit are visible to the next one */
+            L.mode[((cu.y >> 2) + (i >> lgc) + 1) * 36 + (cu.x >> 2) + (i & (cells - 1)) + 1] = cu.pred_mode;
+        __syncthreads(); /* reconstruction and mode cells of this unit are visible to the next one */
+        if (P.prof)
+            c0 = __builtin_readcyclecounter(), c_enc += c0 - c1;
     }
-    /* the LCU's un-deblocked reconstruction for the host (deblocking / SAO input, reference picture) */
-    const int lw = min(64, (int)P.width - (int)W.lcu_x), lh = min(64, (int)P.height - (int)W.lcu_y);
-    for (int i = t; i < 64 * 64 + 2 * 32 * 32; i += 256) {
-        const int p = i < 4096 ? 0 : (i < 5120 ? 1 : 2), e = p == 0 ? i : (p == 1 ? i - 4096 : i - 5120);
-        const int n = p ? 32 : 64, y = e / n, x = e - y * n;
-        if (x < (p ? lw >> 1 : lw) && y < (p ? lh >> 1 : lh)) {
-            const T v = rp[p][(size_t)((p ? W.lcu_y >> 1 : W.lcu_y) + y) * P.pitch[p] + (p ? W.lcu_x >> 1 : W.lcu_x) + x];
-            (p == 0 ? R.rec_y : p == 1 ? R.rec_cb : R.rec_cr)[e] = (uint8_t)v;
+    /* ---- the finished LCU leaves LDS: picture planes + mode map (neighbours of later LCUs, the host's deblocking / SAO input and
+     * reference picture) and the result record ---- */
+    for (int i = t; i < (64 * 64 + 2 * 32 * 32) / 4; i += 256) {
+        const int p = i < 1024 ? 0 : (i < 1280 ? 1 : 2), e = p == 0 ? i : (p == 1 ? i - 1024 : i - 1280);
+        const int n4 = p ? 8 : 16, y = e / n4, x = (e - y * n4) * 4;
+        if (x < (p ? lw >> 1 : lw) && y < (p ? lh >> 1 : lh)) { /* widths are multiples of 8 luma samples: whole groups of 4 */
+            const T *q = L.at(p, x, y);
+            const int gx = (p ? W.lcu_x >> 1 : W.lcu_x) + x, gy = (p ? W.lcu_y >> 1 : W.lcu_y) + y;
+            T *g = wp[p] + (size_t)gy * P.pitch[p] + gx;
+            uint8_t *r = (p == 0 ? R.rec_y : p == 1 ? R.rec_cb : R.rec_cr) + y * (p ? 32 : 64) + x;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                g[k] = q[k], r[k] = (uint8_t)q[k];
+        }
+    }
+    for (int i = t; i < 16 * 16; i += 256) {
+        const int cy = i >> 4, cx = i & 15;
+        if (4 * cx < lw && 4 * cy < lh)
+            P.mode_map[(size_t)((W.lcu_y >> 2) + cy) * P.map_pitch + (W.lcu_x >> 2) + cx] = L.mode[(cy + 1) * 36 + cx + 1];
+    }
+    if (P.prof && t == 0) {
+        unsigned long long *q = P.prof + 8 * (size_t)((W.lcu_y >> 6) * ((P.width + 63) >> 6) + (W.lcu_x >> 6));
+        q[0] = c_pred, q[1] = c_enc, q[2] = __builtin_readcyclecounter() - c0, q[3] = W.num_cus;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const LcuWork *__restrict__ works, LcuResult *__restrict__ results)
+{
+    __shared__ EpShared S;
+    __shared__ EpLocal<T> L;
+    ep_encode_lcu<T>(P, works[blockIdx.x], results[blockIdx.x], S, L);
+}
+
+/* AssignEncDecSegments on the device (Codec/EbEncDecProcess.c:1540: an LCU may start when its left and its top-right LCUs are done):
+ * ONE launch encodes a whole picture.  A small persistent grid of workgroups draws LCUs as tickets in raster order - every LCU an
+ * LCU waits for has a lower ticket, so it is finished or held by a workgroup that is running, and the wait cannot deadlock.  An LCU
+ * publishes itself with a device-scope release (its samples, mode map cells and results are then visible to every XCD's L2); a
+ * (tickets follow the wavefront's anti-diagonals, so a grid as wide as the wavefront stays busy).  A
+ * waiting workgroup polls the flags with RELAXED loads (an acquire per poll would drop the XCD's L2 contents every few hundred
+ * cycles and starve the workgroups that do the work - measured: 20x slower) and acquires ONCE before it reads its neighbours.
+ * done[] holds the epoch of the call that finished the LCU. */
+template <typename T>
+__global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const LcuWork *__restrict__ works, LcuResult *__restrict__ results, int nlcu,
+                                                        int wl, unsigned *ticket, unsigned *done, const unsigned *__restrict__ order, unsigned epoch)
+{
+    __shared__ EpShared S;
+    __shared__ EpLocal<T> L;
+    __shared__ unsigned s_ticket;
+    for (;;) {
+        __syncthreads(); /* the previous LCU's readers of s_ticket are through */
+        if (threadIdx.x == 0)
+            s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        if ((int)s_ticket >= nlcu)
+            return;
+        const int lcu = (int)order[s_ticket];
+        const LcuWork &W = works[lcu];
+        const unsigned long long w0 = P.prof ? __builtin_readcyclecounter() : 0;
+        if (threadIdx.x == 0) {
+            const int x = W.lcu_x >> 6;
+            /* left: (x-1, y); top-right: (x+1, y-1), or the top LCU in the last column of a tile / picture (EbEncDecProcess.c:1585-1640) */
+            const int dep0 = W.tile_left ? -1 : lcu - 1;
+            const int dep1 = W.tile_top ? -1 : (W.tile_right || x + 1 >= wl) ? lcu - wl : lcu - wl + 1;
+            if (dep0 >= 0)
+                while (__hip_atomic_load(&done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(16);
+            if (dep1 >= 0)
+                while (__hip_atomic_load(&done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* this CU's / XCD's caches drop what they held of the neighbours' samples */
+        }
+        __syncthreads();
+        const unsigned long long w1 = P.prof ? __builtin_readcyclecounter() : 0;
+        ep_encode_lcu<T>(P, W, results[lcu], S, L);
+        __syncthreads(); /* every thread's stores of this LCU are issued */
+        if (P.prof && threadIdx.x == 0)
+            P.prof[8 * (size_t)lcu + 4] = w1 - w0, P.prof[8 * (size_t)lcu + 5] = w0, P.prof[8 * (size_t)lcu + 6] = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -324,6 +466,23 @@ extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width,
     p->map_bytes = (size_t)p->d.map_pitch * (height >> 2);
     if (hipMalloc((void **)&p->d.mode_map, p->map_bytes) != hipSuccess)
         return SVT_AMD_ERR_RESOURCES;
+    p->nlcu = ((width + 63) / 64) * ((height + 63) / 64);
+    if (hipMalloc((void **)&p->d_sync, sizeof(unsigned) * (size_t)(1 + 2 * p->nlcu)) != hipSuccess)
+        return SVT_AMD_ERR_RESOURCES;
+    HIP_TRY(hipMemset(p->d_sync, 0, sizeof(unsigned) * (size_t)(1 + p->nlcu)));
+    {   /* ticket -> LCU in wavefront order: anti-diagonals x + 2y (the left and the top-right neighbour lie on the diagonal before),
+         * so that a grid no wider than the wavefront keeps every workgroup busy */
+        const int wl = (width + 63) / 64, hl = (height + 63) / 64;
+        std::vector<unsigned> order;
+        order.reserve((size_t)p->nlcu);
+        for (int d = 0; d <= (wl - 1) + 2 * (hl - 1); d++)
+            for (int y = 0; y < hl; y++) {
+                const int x = d - 2 * y;
+                if (x >= 0 && x < wl)
+                    order.push_back((unsigned)(y * wl + x));
+            }
+        HIP_TRY(hipMemcpy(p->d_sync + 1 + p->nlcu, order.data(), sizeof(unsigned) * order.size(), hipMemcpyHostToDevice));
+    }
     *out = p;
     return SVT_AMD_OK;
 }
@@ -349,31 +508,43 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
             (void)hipFree(pic->d.rec[k]);
     if (pic->d.mode_map)
         (void)hipFree(pic->d.mode_map);
+    if (pic->d_sync)
+        (void)hipFree(pic->d_sync);
+    if (pic->d.prof)
+        (void)hipFree(pic->d.prof);
     free(pic);
     return SVT_AMD_OK;
 }
 
 /* hip_encdec_segment: works / results are HOST arrays of n LCUs that do not depend on each other (one wavefront step); blocking.
  * Contexts (lanes) may call concurrently for different LCUs of the same picture as long as the wavefront order holds between calls. */
-extern "C" int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n, SvtAmdLcuResult *results)
+static int ep_validate(const SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n, const char *who)
 {
-    if (!ctx || !pic || !works || !results || n < 1 || n > 1024)
-        return SVT_AMD_ERR_BAD_PARAM;
     for (int i = 0; i < n; i++) {
         if (works[i].num_cus > SVT_AMD_LCU_MAX_CUS || works[i].lcu_x >= pic->d.width || works[i].lcu_y >= pic->d.height || (works[i].lcu_x & 63) ||
             (works[i].lcu_y & 63)) {
-            svt_amd_set_error("svt_amd_encode_lcus: bad LCU %d", i);
+            svt_amd_set_error("%s: bad LCU %d", who, i);
             return SVT_AMD_ERR_BAD_PARAM;
         }
         for (int c = 0; c < works[i].num_cus; c++) {
             const SvtAmdLcuCu &u = works[i].cu[c];
             if (u.pred_mode != 2 || !(u.size == 8 || u.size == 16 || u.size == 32) || u.intra_luma_mode > 34 || (u.x & (u.size - 1)) || (u.y & (u.size - 1)) ||
                 u.x + u.size > 64 || u.y + u.size > 64 || works[i].lcu_x + u.x + u.size > pic->d.width || works[i].lcu_y + u.y + u.size > pic->d.height) {
-                svt_amd_set_error("svt_amd_encode_lcus: LCU %d unit %d is not an intra 2Nx2N unit of 8..32 inside the picture", i, c);
+                svt_amd_set_error("%s: LCU %d unit %d is not an intra 2Nx2N unit of 8..32 inside the picture", who, i, c);
                 return SVT_AMD_ERR_BAD_PARAM;
             }
         }
     }
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n, SvtAmdLcuResult *results)
+{
+    if (!ctx || !pic || !works || !results || n < 1 || n > 1024)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int rv = ep_validate(pic, works, n, "svt_amd_encode_lcus");
+    if (rv)
+        return rv;
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t *d = nullptr;
     const size_t wb = sizeof(SvtAmdLcuWork) * (size_t)n, rb = sizeof(SvtAmdLcuResult) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
@@ -386,6 +557,70 @@ extern "C" int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic,
     HIP_TRY(hipMemcpyAsync(results, d + wba, rb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
+}
+
+/* One call per picture: works / results are HOST arrays of ALL LCUs of the picture in raster order; the wavefront runs on the
+ * device (k_encode_picture).  d_works / d_results (optional, device) replace the host arrays: nothing crosses PCIe then. */
+static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results,
+                          const SvtAmdLcuWork *d_works, SvtAmdLcuResult *d_results, int parallel_tiles)
+{
+    const int n = pic->nlcu, wl = (pic->d.width + 63) / 64;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!d_works) {
+        for (int i = 0; i < n; i++)
+            if (works[i].lcu_x != (i % wl) * 64 || works[i].lcu_y != (i / wl) * 64) {
+                svt_amd_set_error("svt_amd_encode_picture: LCU %d is not at raster position %d", i, i);
+                return SVT_AMD_ERR_BAD_PARAM;
+            }
+        int rv = ep_validate(pic, works, n, "svt_amd_encode_picture");
+        if (rv)
+            return rv;
+        parallel_tiles = 0; /* tiles = LCUs that wait for nobody (top-left corners) */
+        for (int i = 0; i < n; i++)
+            parallel_tiles += works[i].tile_left && works[i].tile_top;
+        uint8_t *d = nullptr;
+        const size_t wb = sizeof(SvtAmdLcuWork) * (size_t)n, rb = sizeof(SvtAmdLcuResult) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
+        int rc = svt_amd_ctx_scratch(ctx, wba + rb, &d);
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(d, works, wb, hipMemcpyHostToDevice, ctx->stream));
+        d_works = (const SvtAmdLcuWork *)d, d_results = (SvtAmdLcuResult *)(d + wba);
+    }
+    pic->epoch++;
+    HIP_TRY(hipMemsetAsync(pic->d_sync, 0, sizeof(unsigned), ctx->stream));              /* ticket counter */
+    HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, ctx->stream));          /* nothing coded yet */
+    /* persistent grid = the widest wavefront (an LCU row advances two LCUs behind the row above) of every tile that can run on its
+     * own: more workgroups would only poll, and they would hold the CUs other pictures' launches could use */
+    const int hl = (pic->d.height + 63) / 64;
+    int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (parallel_tiles > 0 ? parallel_tiles : 1) + 1;
+    grid = grid > n ? n : grid > 512 ? 512 : grid;
+    hipLaunchKernelGGL(k_encode_picture<uint8_t>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, (const LcuWork *)d_works,
+                       (LcuResult *)d_results, n, wl, pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+    HIP_TRY(hipGetLastError());
+    if (results)
+        HIP_TRY(hipMemcpyAsync(results, d_results, sizeof(SvtAmdLcuResult) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results)
+{
+    if (!ctx || !pic || !works || !results)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int rc = encode_picture(ctx, pic, works, results, nullptr, nullptr, 0);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* Device-resident form: work and result arrays already in HBM (what a device-side mode decision would leave there); asynchronous on
+ * the context's stream.  The caller vouches for the unit lists (no host copy to validate). */
+extern "C" int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works, SvtAmdLcuResult *d_results,
+                                             int tiles)
+{
+    if (!ctx || !pic || !d_works || !d_results || tiles < 1)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return encode_picture(ctx, pic, nullptr, nullptr, d_works, d_results, tiles);
 }
 
 /* ---- LCUs encoded by the host: their last row / column and edge mode types enter the device picture --------------------------- */
@@ -426,5 +661,24 @@ extern "C" int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncD
     hipLaunchKernelGGL(k_put_borders, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const SvtAmdLcuBorder *)d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* debug: out == NULL arms the per-LCU clock sums (8 x u64 per LCU: prediction, encode, copy-out, units, wait, start, end, -),
+ * a later call with a HOST buffer fetches them */
+extern "C" int svt_amd_debug_encdec_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out)
+{
+    if (!ctx || !pic)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pic->nlcu;
+    if (!pic->d.prof) {
+        HIP_TRY(hipMalloc((void **)&pic->d.prof, bytes));
+        HIP_TRY(hipMemset(pic->d.prof, 0, bytes));
+    }
+    if (out) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(out, pic->d.prof, bytes, hipMemcpyDeviceToHost));
+    }
     return SVT_AMD_OK;
 }

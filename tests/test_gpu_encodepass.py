@@ -138,15 +138,15 @@ def z_available(x, y, s):
     return int(bl), int(tr)
 
 
-@pytest.mark.parametrize("w,h,qp,seed", [(832, 480, 27, 1), (456, 264, 38, 2)])
-def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, qp, seed):
-    lib = product
-    sig(lib)
+def random_picture(oracle, w, h, qp, seed, tile_cols=1, tile_rows=1, constrained=0):
+    """seeded works of a whole picture (random unit trees, modes, QPs, dead zones) and what the CPU oracle makes of them in raster order"""
     oracle.svt_oracle_encode_lcu.restype = None
     oracle.svt_oracle_encode_lcu.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(seed)
     wl, hl = (w + 63) // 64, (h + 63) // 64
+    col0 = [c * wl // tile_cols for c in range(tile_cols)] + [wl]      # EbPictureControlSet.c:743 uniform spacing
+    row0 = [r * hl // tile_rows for r in range(tile_rows)] + [hl]
     yy, xx = np.mgrid[0:h, 0:w]
     src = [np.clip(128 + 60 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + rng.normal(0, 9, (h, w)), 0, 255).astype(np.uint8)]
     src += [np.clip(128 + 30 * np.sin(xx[::2, ::2] / (31.0 + 9 * k)) + rng.normal(0, 4, (h // 2, w // 2)), 0, 255).astype(np.uint8) for k in range(2)]
@@ -157,7 +157,7 @@ def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, q
             lw, lh = min(64, w - 64 * lx), min(64, h - 64 * ly)
             wk["lcu_x"], wk["lcu_y"], wk["slice_type"], wk["strong_smoothing"] = 64 * lx, 64 * ly, 2, 1
             wk["constrained_intra"] = 0
-            wk["tile_left"], wk["tile_top"], wk["tile_right"] = lx == 0, ly == 0, lx == wl - 1
+            wk["tile_left"], wk["tile_top"], wk["tile_right"] = lx in col0, ly in row0, (lx + 1) in col0
             tree = random_tree(rng, lw, lh)
             wk["num_cus"] = len(tree)
             for i, (x, y, s) in enumerate(tree):
@@ -183,6 +183,15 @@ def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, q
     want = np.zeros(len(works), S.LCU_RESULT_DTYPE)
     for k in range(len(works)):
         oracle.svt_oracle_encode_lcu(rp, pb, mp.ctypes.data, mp.shape[1], w, h, works[k:k + 1].ctypes.data, want[k:k + 1].ctypes.data)
+    return works, want
+
+
+@pytest.mark.parametrize("w,h,qp,seed", [(832, 480, 27, 1), (456, 264, 38, 2)])
+def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, qp, seed):
+    lib = product
+    sig(lib)
+    works, want = random_picture(oracle, w, h, qp, seed)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
     # device, wavefront batches
     pic = C.c_void_p()
     assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
@@ -195,7 +204,54 @@ def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, q
                     compare_lcu(works[k], want[k], r, w, h, ("random", rep, k))
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
-    assert int(sum(want["cu"]["only_dc"][k][:works[k]["num_cus"]].sum() for k in range(len(works)))) >= 0
+
+
+def sig_picture(lib):
+    sig(lib)
+    lib.svt_amd_encode_picture.restype = C.c_int
+    lib.svt_amd_encode_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encode_picture_one_call_matches_reference_records(product, gpu_ctx, name):
+    """the whole picture in ONE call, wavefront on the device"""
+    lib = product
+    sig_picture(lib)
+    g, w, h = load_case(name)
+    nl = S.lcu_count(w, h)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        for first in range(0, len(g["work"]), nl):
+            works = np.ascontiguousarray(g["work"][first:first + nl])
+            got = np.zeros(nl, S.LCU_RESULT_DTYPE)
+            for rep in range(2):    # twice: the completion flags of the first call must not satisfy the second
+                got[:] = 0
+                assert lib.svt_amd_encode_picture(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+                for k in range(nl):
+                    compare_lcu(works[k], g["result"][first + k], got[k], w, h, (name, "picture", rep, k))
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+@pytest.mark.parametrize("w,h,qp,seed,tc,tr", [(1920, 1080, 30, 3, 1, 1), (832, 480, 24, 4, 2, 2), (1280, 768, 35, 5, 4, 1), (3840, 2160, 32, 6, 1, 1)])
+def test_encode_picture_random_trees_match_oracle(product, oracle, w, h, qp, seed, tc, tr):
+    """full-size pictures (510 / 2040 LCUs >> the resident workgroups) and tile grids: the device wavefront against the oracle in raster order"""
+    lib = product
+    sig_picture(lib)
+    ctx = C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 1, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    works, want = random_picture(oracle, w, h, qp, seed, tc, tr)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        got = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+        assert lib.svt_amd_encode_picture(ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+        for k in range(len(works)):
+            compare_lcu(works[k], want[k], got[k], w, h, ("picture", w, h, k))
+    finally:
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+        lib.svt_amd_context_destroy(ctx)
 
 
 def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):

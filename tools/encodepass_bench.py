@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Device-resident encode pass at picture level (needs the GPU): svt_amd_encode_picture_device - ONE launch per picture, wavefront on
+the device, work / result arrays in HBM - on seeded all-intra pictures with random unit trees (tests/test_gpu_encodepass.py's
+generator).  Reports ms per picture, LCUs/s and pictures/s for 1..P pictures in flight on as many lanes.
+usage: python tools/encodepass_bench.py [width height] [iters]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import svtlib as S  # noqa: E402
+from test_gpu_encodepass import random_tree, z_available  # noqa: E402
+
+
+def works_of(w, h, qp, seed, only=None):
+    rng = np.random.default_rng(seed)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    works = np.zeros(wl * hl, S.LCU_WORK_DTYPE)
+    src = rng.integers(0, 256, (3, 64, 64), dtype=np.uint8)
+    for ly in range(hl):
+        for lx in range(wl):
+            wk = works[ly * wl + lx]
+            lw, lh = min(64, w - 64 * lx), min(64, h - 64 * ly)
+            wk["lcu_x"], wk["lcu_y"], wk["slice_type"], wk["strong_smoothing"] = 64 * lx, 64 * ly, 2, 1
+            wk["tile_left"], wk["tile_top"], wk["tile_right"] = lx == 0, ly == 0, lx == wl - 1
+            if only is None:
+                tree = random_tree(rng, lw, lh)
+            else:  # units of `only` where they fit, 8x8 units in what is left of a partial LCU
+                tree = [(x, y, only) for y in range(0, lh - only + 1, only) for x in range(0, lw - only + 1, only)]
+                tree += [(x, y, 8) for y in range(0, lh, 8) for x in range(0, lw, 8) if x >= lw // only * only or y >= lh // only * only]
+            if only is not None:   # Z order inside the LCU
+                tree.sort(key=lambda u: sum((((u[0] >> (3 + b)) & 1) << (2 * b)) | (((u[1] >> (3 + b)) & 1) << (2 * b + 1)) for b in range(3)))
+            wk["num_cus"] = len(tree)
+            for i, (x, y, s) in enumerate(tree):
+                cu = wk["cu"][i]
+                cu["x"], cu["y"], cu["size"], cu["pred_mode"], cu["intra_luma_mode"] = x, y, s, 2, rng.integers(0, 35)
+                cu["bottom_left_ok"], cu["top_right_ok"] = z_available(x, y, s)
+                cu["qp"], cu["chroma_qp"] = qp, min(qp, 29 + (qp - 29) // 2) if qp > 29 else qp
+            wk["src_y"] = np.roll(src[0], (lx, ly), (0, 1)).reshape(-1)
+            wk["src_cb"], wk["src_cr"] = src[1, :32, :32].reshape(-1), src[2, :32, :32].reshape(-1)
+    return works
+
+
+def main():
+    W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    lib = S.load_product()
+    vp = C.c_void_p
+    lib.svt_amd_encdec_picture_create.argtypes = [vp, C.c_uint16, C.c_uint16, C.c_int, C.POINTER(vp)]
+    lib.svt_amd_encode_picture_device.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.svt_amd_context_fork.argtypes = [vp, C.POINTER(vp)]
+    root = vp()
+    assert lib.svt_amd_context_create(0, W, (H + 7) & ~7, 1, C.byref(root)) == 0, lib.svt_amd_last_error()
+    nl = S.lcu_count(W, H)
+    rows = []
+    lib.svt_amd_debug_encdec_profile.argtypes = [vp, vp, vp]
+    for label, only in (("random trees 8..32", None), ("all 32x32", 32), ("all 8x8", 8)):
+        works = works_of(W, H, 32, 9, only)
+        units = int(works["num_cus"].sum())
+        for P in (1, 4, 16):
+            lanes, pics, dws, drs = [], [], [], []
+            for i in range(P):
+                lane, pic = vp(), vp()
+                assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
+                assert lib.svt_amd_encdec_picture_create(lane, W, H, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+                dws.append(torch.from_numpy(works.view(np.uint8).reshape(-1)).cuda())
+                drs.append(torch.empty(nl * S.LCU_RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda"))
+                lanes.append(lane), pics.append(pic)
+            torch.cuda.synchronize()
+
+            def go():
+                for i in range(P):
+                    assert lib.svt_amd_encode_picture_device(lanes[i], pics[i], dws[i].data_ptr(), drs[i].data_ptr(), 1) == 0, lib.svt_amd_last_error()
+            go()
+            for lane in lanes:
+                lib.svt_amd_synchronize(lane)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                go()
+            for lane in lanes:
+                lib.svt_amd_synchronize(lane)
+            dt = (time.perf_counter() - t0) / iters
+            alg = nl * (6144 + 12288 + 6144 + 6144)   # source read, coefficients + LCU reconstruction + picture written
+            if P == 1:   # where an LCU's time goes (shader clocks of thread 0)
+                assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], None) == 0
+                go()
+                prof = np.zeros((nl, 8), np.uint64)
+                assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], prof.ctypes.data) == 0
+                span = int(prof[:, 6].max() - prof[:, 5].min())
+                print("   clocks per LCU (mean): predict %d encode %d copy-out %d wait %d; per unit predict %d encode %d; kernel span %d clocks" %
+                      (prof[:, 0].mean(), prof[:, 1].mean(), prof[:, 2].mean(), prof[:, 4].mean(), prof[:, 0].sum() / prof[:, 3].sum(),
+                       prof[:, 1].sum() / prof[:, 3].sum(), span), flush=True)
+            rows.append({"content": label, "pictures_in_flight": P, "lcus": nl, "units": units, "ms_per_round": round(dt * 1e3, 3),
+                         "pictures_per_s": round(P / dt, 1), "lcus_per_s": round(P * nl / dt), "algorithmic_GBps": round(P * alg / dt / 1e9, 2)})
+            print(rows[-1], flush=True)
+            for lane, pic in zip(lanes, pics):
+                lib.svt_amd_encdec_picture_destroy(lane, pic)
+                lib.svt_amd_context_destroy(lane)
+    print(json.dumps({"width": W, "height": H, "iters": iters, "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()
