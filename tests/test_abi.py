@@ -63,3 +63,48 @@ def test_no_gpu_means_loud_failure():
     rc = lib.svt_amd_context_create(0, 640, 384, 2, C.byref(ctx))
     assert rc != 0 and not ctx.value
     assert lib.svt_amd_last_error()
+
+
+# the reference's public API, Source/API/EbApi.h:682-783
+EB_API = {"EbInitHandle", "EbH265EncSetParameter", "EbInitEncoder", "EbH265EncStreamHeader", "EbH265EncReleaseStreamHeader", "EbH265EncEosNal",
+          "EbH265EncReleaseEosNal", "EbH265EncSendPicture", "EbH265GetPacket", "EbH265ReleaseOutBuffer", "EbH265GetRecon", "EbDeinitEncoder",
+          "EbDeinitHandle"}
+DROP_IN = os.path.join(S.ROOT, "integration", "_build", "libSvtHevcEnc.so.1")
+
+
+def test_drop_in_library_is_the_reference_outer_abi():
+    """integration/_build/libSvtHevcEnc.so.1 (reference objects + the bindings) is what ffmpeg / gstreamer / the sample application
+    load in place of the reference's library: SONAME libSvtHevcEnc.so.1, version node SVT_HEVC_1, exactly the 13 Eb* entry points
+    (SURVEY 8b outer ABI).  The library is prebuilt by __graft_entry__.build() (needs /root/reference), so it is present wherever
+    the tests run."""
+    assert os.path.exists(DROP_IN), "run `python __graft_entry__.py build` first (needs /root/reference)"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", DROP_IN], text=True)
+    names = [line.split()[-1] for line in out.splitlines() if " T " in line or " A " in line]
+    funcs = {n.split("@")[0] for n in names if " A " not in n and not n.startswith("SVT_HEVC_1")}
+    assert funcs == EB_API, (sorted(funcs - EB_API), sorted(EB_API - funcs))
+    assert all(n.endswith("@@SVT_HEVC_1") for n in names if n.split("@")[0] in EB_API), names
+    dyn = subprocess.check_output(["readelf", "-d", DROP_IN], text=True)
+    assert "Library soname: [libSvtHevcEnc.so.1]" in dyn
+    assert "libsvt_hevc_amd.so" in dyn                      # the HIP hot path is a NEEDED library of the drop-in
+    assert os.path.islink(os.path.join(os.path.dirname(DROP_IN), "libSvtHevcEnc.so"))
+
+
+def test_drop_in_library_answers_the_api_without_the_sample_app():
+    """dlopen + EbInitHandle / EbH265EncSetParameter / EbDeinitHandle through the exported names only (no GPU needed: the device
+    context is created by EbInitEncoder, which this test does not reach)."""
+    code = r'''
+import ctypes as C, sys
+lib = C.CDLL(%r)
+h = C.c_void_p()
+cfg = C.create_string_buffer(4096)          # EB_H265_ENC_CONFIGURATION is ~600 bytes; EbInitHandle fills in the defaults
+lib.EbInitHandle.restype = C.c_uint32
+lib.EbInitHandle.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
+rc = lib.EbInitHandle(C.byref(h), None, cfg)
+assert rc == 0 and h.value, hex(rc)
+lib.EbDeinitHandle.restype = C.c_uint32
+lib.EbDeinitHandle.argtypes = [C.c_void_p]
+assert lib.EbDeinitHandle(h) == 0
+print("OUTER_ABI_OK", any(cfg.raw))
+''' % DROP_IN
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "OUTER_ABI_OK True" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]

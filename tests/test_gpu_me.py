@@ -120,6 +120,36 @@ def test_me_8k_m4_rows_match_oracle(product, oracle):
         product.svt_amd_context_destroy(ctx)
 
 
+@pytest.mark.parametrize("case,bands", [("b_1024x768_m7", (0, 3, 4, 9, 12)), ("p_1920x1080_m9", (0, 1, 8, 16, 17))])
+def test_me_row_bands_equal_the_full_picture(product, case, bands):
+    """svt_amd_me_picture_range_launch (the multi-GPU cut of one picture by LCU rows): the records of every band, taken
+    right after that band's launch, are together byte-identical to the one-launch picture - B pictures included, where list 1 reads
+    list 0's result of the same LCU."""
+    g = load_case(case)
+    p = S.params_from_record(g["params"][0])
+    w, h = p.luma_width, p.luma_height
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    ctx = C.c_void_p()
+    assert product.svt_amd_context_create(0, w, (h + 7) & ~7, 3, C.byref(ctx)) == 0, product.svt_amd_last_error()
+    try:
+        for s_ in range(3):
+            upload(product, ctx, s_, S.gen_luma("motion", w, h, s_, 11))
+        full = me_picture(product, ctx, p, 1, [0, 2])
+        refs = (C.c_int * 2)(0, 2)
+        nl = wl * hl
+        poison = np.full(nl, 0xA5, np.uint8).repeat(S.ME_LCU_DTYPE.itemsize).view(S.ME_LCU_DTYPE)
+        rows = sorted(set(r for r in bands if r < hl) | {0, hl})
+        got = poison.copy()
+        for a, b in zip(rows[:-1], rows[1:]):
+            assert product.svt_amd_me_picture_range_launch(ctx, C.byref(p), 1, refs, a * wl, b * wl) == 0, product.svt_amd_last_error()
+            band = np.zeros(nl, S.ME_LCU_DTYPE)
+            assert product.svt_amd_me_picture_fetch(ctx, 1, band.ctypes.data) == 0, product.svt_amd_last_error()
+            got[a * wl:b * wl] = band[a * wl:b * wl]
+        assert got.tobytes() == full.tobytes()
+    finally:
+        product.svt_amd_context_destroy(ctx)
+
+
 def test_me_full_size_properties(product, gpu_ctx):
     """BASELINE config 2 size (1920x1080): properties that need no CPU oracle."""
     w, h = 1920, 1080
