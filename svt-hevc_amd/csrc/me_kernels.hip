@@ -1397,7 +1397,16 @@ static void me_pool_bytes(const SvtAmdMeParams *p, size_t *hme_pool, size_t *sea
     *hme_pool = (need + 64 + 255) & ~(size_t)255; /* +64: the aligned over-read of the last window row */
     const int saw = p->search_area_width > 127 ? 127 : p->search_area_width;
     const int sah = p->search_area_height > 127 ? 127 : p->search_area_height;
-    *search_pool = ((size_t)ME_SEARCH_BYTES + 4 * win(saw + 67 + 16, sah + 67) + 64 + 255) & ~(size_t)255;
+    /* the four search windows are staged with an odd 16-byte pitch (win_pitch(.., 1)): the widest a window of w columns gets is
+     * w + 15 (alignment of its first column) rounded up to 16 and then to an odd multiple.  The bound is exact on purpose: at
+     * BASELINE configs[2] (16 x 9 search) it is what lets a third workgroup share a CU's 160 KiB. */
+    auto win_odd = [](int w, int rows) {
+        int wa = (w + 15 + 15) & ~15;
+        if (!((wa >> 4) & 1))
+            wa += 16;
+        return (size_t)wa * (size_t)rows;
+    };
+    *search_pool = ((size_t)ME_SEARCH_BYTES + 4 * win_odd(saw + 67, sah + 67) + 64 + 255) & ~(size_t)255;
 }
 
 int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int njobs, int max_lcus)
