@@ -382,7 +382,7 @@ def main():
         if world == 1 and not a.no_encoder_fps:
             try:
                 import encoder_fps as E
-                res["encoder_fps"] = E.measure(cfg["enc"], frames=64, unique=16)
+                res["encoder_fps"] = E.measure(cfg["enc"], frames=128, unique=16)  # 128: past the pipelines' fill (DESIGN 5b has 64 and 256)
             except Exception as e:
                 res["encoder_fps"] = {"error": str(e)[-300:]}
         print(json.dumps(res), flush=True)

@@ -288,6 +288,9 @@ SVT_AMD_API int svt_amd_picture_publish(SvtAmdContext *lane, int slot);
 SVT_AMD_API int svt_amd_frontend_submit(SvtAmdContext *lane, const SvtAmdFrontendJob *job);
 SVT_AMD_API int svt_amd_frontend_wait(SvtAmdContext *lane, const SvtAmdMeLcuResult **me, const SvtAmdOisLcuResult **ois);
 SVT_AMD_API int svt_amd_frontend_release(SvtAmdContext *lane);
+/* Start-up, outside any timed run: pins the staging buffers of every picture slot (root) and the lane's result buffers, and sends
+ * one dummy picture through upload -> planes -> ME -> OIS so that the kernels' code objects are loaded.  Once per lane (and root). */
+SVT_AMD_API int svt_amd_frontend_warmup(SvtAmdContext *ctx);
 /* building blocks of the same pipeline for batched hosts (bench.py): stream-ordered copies that do not wait, pinned host
  * memory to copy from / into, and the per-slot result copies; svt_amd_synchronize(lane) completes them */
 SVT_AMD_API int svt_amd_device_upload_async(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes);

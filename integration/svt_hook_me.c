@@ -69,6 +69,8 @@ typedef struct {
 
 /* front-half timeline, printed by the report: where a picture's time on a lane goes */
 static double g_t_submit_call, g_t_device, g_t_lane_held, g_t_lane_wait;
+#define TL_N 24
+static double g_tl0, g_tl_submit[TL_N], g_tl_ready[TL_N], g_tl_released[TL_N]; /* first pictures, seconds since the first call */
 static unsigned long g_n_lane_wait, g_n_timed;
 static double now_s(void)
 {
@@ -280,6 +282,10 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
             e->me = NULL, e->ois = NULL;
             e->gen++;
             e->t_submit = now_s(), e->timed = 0;
+            if (g_tl0 == 0)
+                g_tl0 = t0;
+            if (pic < TL_N)
+                g_tl_submit[pic] = e->t_submit - g_tl0;
             g_t_submit_call += e->t_submit - t0;
             if (!intra)
                 g_pictures++;
@@ -308,6 +314,8 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
     if (!__atomic_exchange_n(&e->timed, 1, __ATOMIC_ACQ_REL)) { /* first thread back: submit -> results on the host */
         pthread_mutex_lock(&g_front_lock);
         g_t_device += now_s() - e->t_submit, g_n_timed++;
+        if (e->pic < TL_N)
+            g_tl_ready[e->pic] = now_s() - g_tl0;
         pthread_mutex_unlock(&g_front_lock);
     }
     cached = e;
@@ -323,6 +331,8 @@ static void front_served(FrontEntry *e, unsigned *counter)
         return;
     pthread_mutex_lock(&g_front_lock);
     g_t_lane_held += now_s() - e->t_submit;
+    if (e->pic < TL_N)
+        g_tl_released[e->pic] = now_s() - g_tl0;
     svt_amd_frontend_release(e->lane);
     __atomic_store_n(&e->state, 0, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_front_cv);
@@ -371,6 +381,14 @@ static void ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
     for (int i = 0; i < NLANES; i++)
         if (svt_amd_context_fork(g_ctx, &g_front[i].lane))
             die("svt_amd_context_fork");
+    /* pinned buffers and kernel code objects now, not inside the first pictures (EbInitEncoder is outside the encode clock) */
+    if (!getenv("SVT_HOOK_NO_WARMUP")) {
+        if (svt_amd_frontend_warmup(g_ctx))
+            die("svt_amd_frontend_warmup");
+        for (int i = 0; i < NLANES; i++)
+            if (svt_amd_frontend_warmup(g_front[i].lane))
+                die("svt_amd_frontend_warmup (lane)");
+    }
     g_nlcu = ((lumaWidth + 63u) / 64u) * ((lumaHeight + 63u) / 64u);
     g_verbose = getenv("SVT_HOOK_VERBOSE") != NULL;
     fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
@@ -1558,6 +1576,12 @@ static void hook_report(void)
         fprintf(out, "svt_hook_me: front-half timeline over %lu pictures: submit call %.3f ms, submit -> results on the host %.3f ms, lane held %.3f ms "
                      "(means); %lu waits for a free lane, %.1f ms in total\n", g_n_timed, 1e3 * g_t_submit_call / g_n_timed, 1e3 * g_t_device / g_n_timed,
                 1e3 * g_t_lane_held / g_n_timed, g_n_lane_wait, 1e3 * g_t_lane_wait);
+    if (g_n_timed && g_verbose) {
+        fprintf(out, "svt_hook_me: first pictures (ms since the first front-half call: submitted / results on the host / all LCUs served):");
+        for (int i = 0; i < TL_N; i++)
+            fprintf(out, " %d: %.1f/%.1f/%.1f", i, 1e3 * g_tl_submit[i], 1e3 * g_tl_ready[i], 1e3 * g_tl_released[i]);
+        fprintf(out, "\n");
+    }
     if (g_verbose) {
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction", counter_sum(CPU_EncodePassInterPrediction));
         fprintf(out, "svt_hook_me: %-40s %lu calls left to the reference code\n", "EncodePassInterPrediction16bit", counter_sum(CPU_EncodePassInterPrediction16bit));

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "svt_amd_internal.h"
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -916,6 +917,68 @@ extern "C" int svt_amd_frontend_release(SvtAmdContext *ctx)
     if (!ctx)
         return SVT_AMD_ERR_BAD_PARAM;
     ctx->frontend_busy = 0;
+    return SVT_AMD_OK;
+}
+
+/* Everything a first picture would otherwise pay for inside the encoder's timed run: the pinned staging buffer of every picture
+ * slot, the lane's pinned result buffers, and the code objects of the front-half kernels (loaded on first launch) - one dummy
+ * picture goes through upload -> planes -> ME -> OIS on this lane and is dropped again.  Called per lane at encoder start-up. */
+extern "C" int svt_amd_frontend_warmup(SvtAmdContext *ctx)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int nlcu = ((ctx->max_w + 63) / 64) * ((ctx->max_h + 63) / 64);
+    if (!ctx->h_me)
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_me, (size_t)nlcu * sizeof(SvtAmdMeLcuResult), hipHostMallocDefault));
+    if (!ctx->h_ois)
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_ois, (size_t)nlcu * sizeof(SvtAmdOisLcuResult), hipHostMallocDefault));
+    if (!ctx->parent) { /* the root owns the slots */
+        for (int i = 0; i < ctx->num_slots; i++) {
+            DevPicture *s = &ctx->slots[i];
+            if (!s->h_staging)
+                HIP_TRY(hipHostMalloc((void **)&s->h_staging, s->staging_bytes, hipHostMallocDefault));
+        }
+    }
+    if (ctx->frontend_busy || ctx->num_slots < 1)
+        return SVT_AMD_OK;
+    /* a mid-grey picture against itself */
+    const uint16_t w = ctx->max_w, h = ctx->max_h;
+    DevPicture *s0 = &ctx->slots[0];
+    if (s0->valid)
+        return SVT_AMD_OK; /* slot 0 is in use: the device is warm already */
+    if (!s0->h_staging)
+        HIP_TRY(hipHostMalloc((void **)&s0->h_staging, s0->staging_bytes, hipHostMallocDefault));
+    std::vector<uint8_t> grey((size_t)w * h, 128);
+    int rc = svt_amd_picture_upload_async(ctx, 0, grey.data(), w, w, h);
+    if (rc)
+        return rc;
+    SvtAmdFrontendJob job;
+    memset(&job, 0, sizeof(job));
+    job.cur_slot = 0, job.ref_slot[0] = job.ref_slot[1] = 0;
+    job.has_me = 1, job.has_ois = 1;
+    SvtAmdMeParams &p = job.me;
+    p.luma_width = w, p.luma_height = h, p.num_lists = 2;
+    p.enable_hme_flag = p.enable_hme_level0 = p.enable_hme_level1 = 1;
+    p.update_hme_search_center = 1, p.num_hme_regions_w = p.num_hme_regions_h = 2;
+    p.search_area_width = 16, p.search_area_height = 9, p.fractional_search_model = 1, p.cu8x8_mode = 1;
+    p.hme_l0_total_w = 64, p.hme_l0_total_h = 32;
+    for (int k = 0; k < 2; k++) {
+        p.hme_l0_w[k] = 32, p.hme_l0_h[k] = 16, p.hme_l1_w[k] = 8, p.hme_l1_h[k] = 8, p.hme_l2_w[k] = 4, p.hme_l2_h[k] = 4;
+    }
+    p.hme_l0_mult_x = p.hme_l0_mult_y = 100, p.lambda = 200;
+    for (int k = 0; k < 10; k++)
+        p.mvd_bits[k] = 16384u + 4096u * (uint32_t)k;
+    SvtAmdOisParams &o = job.ois;
+    o.luma_width = w, o.luma_height = h, o.ois_th_set = 1, o.cu8x8_mode = 1;
+    if ((rc = svt_amd_frontend_submit(ctx, &job)) != 0)
+        return rc;
+    const SvtAmdMeLcuResult *me;
+    const SvtAmdOisLcuResult *ois;
+    if ((rc = svt_amd_frontend_wait(ctx, &me, &ois)) != 0)
+        return rc;
+    svt_amd_frontend_release(ctx);
+    s0->valid = 0;
     return SVT_AMD_OK;
 }
 

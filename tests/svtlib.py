@@ -254,6 +254,7 @@ def load_product():
     _sig(lib.svt_amd_frontend_submit, i, [vp, C.POINTER(FrontendJob)])
     _sig(lib.svt_amd_frontend_wait, i, [vp, C.POINTER(vp), C.POINTER(vp)])
     _sig(lib.svt_amd_frontend_release, i, [vp])
+    _sig(lib.svt_amd_frontend_warmup, i, [vp])
     _sig(lib.svt_amd_device_alloc, i, [vp, C.c_size_t, C.POINTER(vp)])
     _sig(lib.svt_amd_device_free, i, [vp, vp])
     _sig(lib.svt_amd_device_upload, i, [vp, vp, vp, C.c_size_t])

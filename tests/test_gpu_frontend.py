@@ -28,6 +28,10 @@ def test_lanes_pipeline_matches_blocking_calls_and_oracle(product, oracle):
             lane = C.c_void_p()
             assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
             lanes.append(lane)
+        # start-up warm-up (pinned buffers, code objects, one dummy picture through slot 0) must leave no trace
+        assert lib.svt_amd_frontend_warmup(root) == 0, lib.svt_amd_last_error()
+        for lane in lanes:
+            assert lib.svt_amd_frontend_warmup(lane) == 0, lib.svt_amd_last_error()
         frames = [S.gen_luma("motion", w, h, t, 7) for t in range(npic)]
         # pictures uploaded through DIFFERENT lanes than the ones that search them: cross-stream ordering via the slot events
         for s, f in enumerate(frames):

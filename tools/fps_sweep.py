@@ -12,9 +12,9 @@ for spec in specs:
     for n in (int(v) for v in ns.split(",")):
         with tempfile.TemporaryDirectory() as td:
             rp = os.path.join(td, "report.txt")
-            r = E.measure(cfg, frames=n, unique=16, hip_env={"SVT_HOOK_REPORT": rp})
+            r = E.measure(cfg, frames=n, unique=16, hip_env={"SVT_HOOK_REPORT": rp, "SVT_HOOK_VERBOSE": "1"})
             print(cfg, n, "ref fps %.1f wall %.2f | hip fps %.1f wall %.2f | identical %s" % (r["reference"]["fps"], r["reference"]["wall_s"], r["hip"]["fps"],
                                                                                              r["hip"]["wall_s"], r["bitstream_identical"]), flush=True)
             for line in open(rp):
-                if "timeline" in line or "encode pass" in line:
+                if "timeline" in line or "encode pass" in line or "first pictures" in line:
                     print("   ", line.strip(), flush=True)
