@@ -6,13 +6,15 @@ Workload (default, `--config 2`): BASELINE configs[2] = 3840x2160 8-bit, encMode
 reference encoder derived them for this configuration (tests/golden/me_b_3840x2160_m7.npz, ois_ib_3840x2160_m7.npz).
 `--config 1` = BASELINE configs[1] (1920x1080 encMode 9 low-delay P, one list).
 
-One "step" = one pass of the front half of the hot path over one batch of B pictures PER LANE (2 lanes), THROUGH THE HOST BOUNDARY:
+One "step" = one pass of the front half of the hot path over one batch of B pictures PER LANE (--lanes, default 2), THROUGH THE HOST BOUNDARY:
     pinned host luma --H2D--> picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes, one launch)
     -> open-loop motion estimation of every LCU against both references (HME, full-pel 85-PU search, half/quarter-pel,
        bi-prediction, candidate records: 2 kernels per list, one batched launch each)
     -> open-loop intra search (one batched launch, reads the ME results left in HBM)
-    --D2H--> ME records (3,420 B/LCU) + OIS records (6,208 B/LCU) in pinned host memory.
-Two lanes (streams over the same picture slots, svt_amd_context_fork) alternate steps, so the copies of one step overlap the
+    --device pack--> the compact wire records the reference side reads (MeCuResults x 85 = 2,040 B/LCU; the <= 9 OIS candidates a
+       P / B picture writes per CU = 3,148 B/LCU; the full 3,420 + 6,208 B records stay in HBM for parity tests)
+    --D2H--> into pinned host memory.
+The lanes (streams over the same picture slots, svt_amd_context_fork) take turns, so the copies of one lane overlap the
 kernels of the other.  Both PCIe directions are INSIDE the timed region; `hbm_resident_fps` is the same loop without them.
 
 Prints ONE JSON line (rank 0).  `value` = front-half pictures/s over all GPUs, NOT whole-encoder fps: the closed-loop EncDec
@@ -202,6 +204,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="pictures per step per GPU (default: 64 at 4K, 128 at 1080p)")
+    ap.add_argument("--lanes", type=int, default=2, help="lanes (streams) per GPU; each runs its own batch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoder-fps", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
@@ -234,8 +237,10 @@ def main():
     assert not oparams.slice_is_intra and params.luma_width == W and oparams.luma_width == W
     nlists = params.num_lists
     nlcu = S.lcu_count(W, H)
-    me_b, ois_b = C.sizeof(S.MeLcuResult), S.OIS_LCU_DTYPE.itemsize
-    NL = 2  # lanes
+    me_rec_b = C.sizeof(S.MeLcuResult)                       # full record in HBM (what the ME kernels write: algorithmic bytes)
+    ois_nc = lib.svt_amd_ois_compact_candidates(C.byref(oparams))
+    me_b, ois_b = S.ME_PU_COUNT * 24, S.ME_PU_COUNT * ois_nc * 4 + 88   # compact wire records that cross PCIe
+    NL = a.lanes
     root = vp()
     ok(lib.svt_amd_context_create(local_rank, W, (H + 7) & ~7, NL * B, C.byref(root)))
     # pinned host input: B distinct frames of the moving-texture clip (shared by both lanes)
@@ -274,8 +279,9 @@ def main():
         ok(lib.svt_amd_ois_batch_launch(L["ctx"], L["ojobs"], B))
         if copies:
             for i in range(B):
-                ok(lib.svt_amd_me_picture_fetch_async(L["ctx"], L["slots"][i], vp(L["h_me"].value + i * nlcu * me_b)))
-                ok(lib.svt_amd_ois_picture_fetch_async(L["ctx"], L["slots"][i], vp(L["h_ois"].value + i * nlcu * ois_b)))
+                # the compact wire records (what the reference side of the boundary reads, include/svt_hevc_amd.h): packed on the device
+                ok(lib.svt_amd_me_picture_fetch_compact_async(L["ctx"], L["slots"][i], vp(L["h_me"].value + i * nlcu * me_b)))
+                ok(lib.svt_amd_ois_picture_fetch_compact_async(L["ctx"], L["slots"][i], ois_nc, vp(L["h_ois"].value + i * nlcu * ois_b)))
         counts["batches"] += 1
 
     def sync_all():
@@ -337,7 +343,7 @@ def main():
         me_ms, me_n = kt["me_search"]
         # algorithmic HBM bytes of one ME batch: per picture the source + `nlists` references, each
         # full + 1/4 + 1/16 planes (1.3125 bytes/pel), plus the per-LCU result records
-        algo_bytes = B * ((1 + nlists) * 1.3125 * W * H + nlcu * me_b)
+        algo_bytes = B * ((1 + nlists) * 1.3125 * W * H + nlcu * me_rec_b)
         achieved = algo_bytes / (me_ms * 1e-3) / 1e9 if me_ms > 0 else 0.0
         res = {
             "metric": "encoded fps (front half of the hot path through the host boundary: upload + picture preparation + motion "

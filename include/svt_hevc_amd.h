@@ -277,7 +277,8 @@ typedef struct SvtAmdFrontendJob {
     int32_t ref_slot[2];
     uint8_t has_me;            /* P / B pictures */
     uint8_t has_ois;
-    uint8_t pad[2];
+    uint8_t compact;           /* 1: the lane's pinned buffers receive the COMPACT records (below) instead of the full ones */
+    uint8_t pad;
     SvtAmdMeParams me;
     SvtAmdOisParams ois;
 } SvtAmdFrontendJob;
@@ -288,6 +289,16 @@ SVT_AMD_API int svt_amd_picture_publish(SvtAmdContext *lane, int slot);
 SVT_AMD_API int svt_amd_frontend_submit(SvtAmdContext *lane, const SvtAmdFrontendJob *job);
 SVT_AMD_API int svt_amd_frontend_wait(SvtAmdContext *lane, const SvtAmdMeLcuResult **me, const SvtAmdOisLcuResult **ois);
 SVT_AMD_API int svt_amd_frontend_release(SvtAmdContext *lane);
+/* Compact wire format of the records (what the reference side of the boundary consumes; the full records also carry the internal
+ * best-SAD / MV arrays and 18 candidate slots per CU for parity tests): per LCU
+ *   ME :  SvtAmdMeCuResult[85]                                                        (2,040 B instead of 3,420)
+ *   OIS:  uint32_t candidate[85][nc] + uint8_t total_intra_luma_mode[85] + 3 pad      (85 * nc * 4 + 88 B instead of 6,208)
+ * nc = svt_amd_ois_compact_candidates(params) = the most candidates the picture's path writes per CU: 7 on I pictures, 9 on P / B
+ * pictures, 18 with ois_kernel_level (MAX_OIS_0 / _1 / _2, Codec/EbCodingUnit.h:59-61).  The device packs, then copies. */
+#define SVT_AMD_OIS_COMPACT_BYTES(nc) (SVT_AMD_ME_PU_COUNT * (nc) * 4 + 88)
+SVT_AMD_API int svt_amd_ois_compact_candidates(const SvtAmdOisParams *params);
+SVT_AMD_API int svt_amd_me_picture_fetch_compact_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeCuResult *out);
+SVT_AMD_API int svt_amd_ois_picture_fetch_compact_async(SvtAmdContext *ctx, int cur_slot, int candidates, void *out);
 /* Start-up, outside any timed run: pins the staging buffers of every picture slot (root) and the lane's result buffers, and sends
  * one dummy picture through upload -> planes -> ME -> OIS so that the kernels' code objects are loaded.  Once per lane (and root). */
 SVT_AMD_API int svt_amd_frontend_warmup(SvtAmdContext *ctx);

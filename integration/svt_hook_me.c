@@ -59,8 +59,9 @@ typedef struct {
     uint64_t pic;
     int state;                       /* 0 free, 1 submitted */
     unsigned gen;                    /* claims so far: tells a thread's cached entry from a re-used lane */
-    const SvtAmdMeLcuResult *me;     /* pinned, valid while state == 1 */
-    const SvtAmdOisLcuResult *ois;
+    const SvtAmdMeCuResult *me;      /* pinned, COMPACT records (include/svt_hevc_amd.h), valid while state == 1 */
+    const uint8_t *ois;
+    int ois_nc;                      /* candidates per CU in the compact OIS records */
     unsigned me_left, ois_left;      /* LCUs still to serve (atomics) */
     SvtAmdOisParams oisp;
     double t_submit;                 /* timeline of the lane (report only) */
@@ -272,10 +273,12 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
                 fill_params(&job.me, pcs, scs, me_ctx);
             }
             job.has_ois = 1;
+            job.compact = 1; /* the D2H copy is the longest stage of a lane: fetch only what is read below */
             fill_ois_params(&job.ois, pcs, scs);
             if (svt_amd_frontend_submit(e->lane, &job))
                 die("svt_amd_frontend_submit");
             e->oisp = job.ois;
+            e->ois_nc = svt_amd_ois_compact_candidates(&job.ois);
             e->pic = pic;
             e->me_left = intra ? 0 : g_nlcu;
             e->ois_left = g_nlcu;
@@ -310,7 +313,7 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
     const SvtAmdOisLcuResult *ois;
     if (svt_amd_frontend_wait(e->lane, &me, &ois))
         die("svt_amd_frontend_wait");
-    e->me = me, e->ois = ois;
+    e->me = (const SvtAmdMeCuResult *)me, e->ois = (const uint8_t *)ois;
     if (!__atomic_exchange_n(&e->timed, 1, __ATOMIC_ACQ_REL)) { /* first thread back: submit -> results on the host */
         pthread_mutex_lock(&g_front_lock);
         g_t_device += now_s() - e->t_submit, g_n_timed++;
@@ -346,10 +349,10 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
     (void)lcuOriginY;
     SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
     FrontEntry *e = front_entry(pcs, ctx, inputPtr);
-    const SvtAmdMeLcuResult *r = &e->me[lcuIndex];
+    const SvtAmdMeCuResult *r = &e->me[(size_t)lcuIndex * SVT_AMD_ME_PU_COUNT];
     for (int pu = 0; pu < SVT_AMD_ME_PU_COUNT; pu++) {
         MeCuResults_t *m = &pcs->meResults[lcuIndex][pu];
-        const SvtAmdMeCuResult *s = &r->pu[pu];
+        const SvtAmdMeCuResult *s = &r[pu];
         m->xMvL0 = s->x_mv_l0;
         m->yMvL0 = s->y_mv_l0;
         m->xMvL1 = s->x_mv_l1;
@@ -423,13 +426,15 @@ EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U3
         fprintf(stderr, "svt_hook_me: open-loop intra search controls differ from SignalDerivationMeKernelOq's\n");
         abort();
     }
-    const SvtAmdOisLcuResult *r = &e->ois[lcuIndex];
+    const int nc = e->ois_nc;
+    const uint32_t *cand = (const uint32_t *)(e->ois + (size_t)lcuIndex * SVT_AMD_OIS_COMPACT_BYTES(nc));
+    const uint8_t *total = (const uint8_t *)(cand + SVT_AMD_ME_PU_COUNT * nc);
     OisCu32Cu16Results_t *a = pcs->oisCu32Cu16Results[lcuIndex];
     OisCu8Results_t *b = pcs->oisCu8Results[lcuIndex];
     for (int cu = 1; cu < SVT_AMD_ME_PU_COUNT; cu++) {
         OisCandidate_t *c = cu < 21 ? a->sortedOisCandidate[cu] : b->sortedOisCandidate[cu - 21];
-        for (int k = 0; k < SVT_AMD_OIS_MAX_CAND; k++) {
-            const uint32_t w = r->candidate[cu][k];
+        for (int k = 0; k < nc; k++) {
+            const uint32_t w = cand[cu * nc + k];
             if (w & SVT_AMD_OIS_W_DIST)
                 c[k].distortion = w & 0xFFFFFu;
             if (w & SVT_AMD_OIS_W_VALID)
@@ -437,11 +442,11 @@ EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U3
             if (w & SVT_AMD_OIS_W_MODE)
                 c[k].intraMode = w >> 24;
         }
-        if (r->total_intra_luma_mode[cu] != 0xFF) {
+        if (total[cu] != 0xFF) {
             if (cu < 21)
-                a->totalIntraLumaMode[cu] = r->total_intra_luma_mode[cu];
+                a->totalIntraLumaMode[cu] = total[cu];
             else
-                b->totalIntraLumaMode[cu - 21] = r->total_intra_luma_mode[cu];
+                b->totalIntraLumaMode[cu - 21] = total[cu];
         }
     }
     __atomic_add_fetch(&g_ois_lcus, 1, __ATOMIC_RELAXED);

@@ -72,6 +72,8 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
             (void)hipFree(s->d_me_carry);
         if (s->d_staging)
             (void)hipFree(s->d_staging);
+        if (s->d_pack)
+            (void)hipFree(s->d_pack);
         if (s->h_staging)
             (void)hipHostFree(s->h_staging);
         if (s->ev_ready)
@@ -691,6 +693,94 @@ extern "C" int svt_amd_ois_picture_fetch_async(SvtAmdContext *ctx, int cur_slot,
     return SVT_AMD_OK;
 }
 
+/* ---- compact wire format of the front-half records -------------------------------------------------------------------------
+ * What the host side of the boundary reads (MeCuResults_t x 85; the OIS candidates the picture's path can write: MAX_OIS_0 / _1 /
+ * _2 of EbCodingUnit.h:59-61) is 5,188 of the 9,628 bytes per LCU at BASELINE configs[2]; the device packs it (one pass over the
+ * records, ~10 us per 4K picture) so that the D2H copy - the longest stage of the pipelined front half - moves only that. */
+__global__ void __launch_bounds__(256) k_pack_me(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int nlcu)
+{
+    constexpr int IN = sizeof(SvtAmdMeLcuResult) / 4, OUT = SVT_AMD_ME_PU_COUNT * sizeof(SvtAmdMeCuResult) / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x, lcu = i / OUT, k = i - lcu * OUT;
+    if (lcu < nlcu)
+        out[(size_t)lcu * OUT + k] = in[(size_t)lcu * IN + k];
+}
+__global__ void __launch_bounds__(256) k_pack_ois(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int nlcu, int nc)
+{
+    constexpr int IN = sizeof(SvtAmdOisLcuResult) / 4, TAIL = 22; /* total_intra_luma_mode[85] + pad = 88 bytes */
+    const int per = SVT_AMD_ME_PU_COUNT * nc + TAIL;
+    const int i = blockIdx.x * 256 + threadIdx.x, lcu = i / per, e = i - lcu * per;
+    if (lcu >= nlcu)
+        return;
+    const int cu = e / nc, k = e - cu * nc;
+    out[(size_t)lcu * per + e] =
+        e < SVT_AMD_ME_PU_COUNT * nc ? in[(size_t)lcu * IN + cu * SVT_AMD_OIS_MAX_CAND + k] : in[(size_t)lcu * IN + SVT_AMD_ME_PU_COUNT * SVT_AMD_OIS_MAX_CAND + (e - SVT_AMD_ME_PU_COUNT * nc)];
+}
+static_assert(sizeof(SvtAmdOisLcuResult) == (SVT_AMD_ME_PU_COUNT * SVT_AMD_OIS_MAX_CAND + 22) * 4, "OIS record layout");
+static_assert(sizeof(SvtAmdMeCuResult) == 24 && offsetof(SvtAmdMeLcuResult, pu) == 0, "ME record layout");
+
+extern "C" int svt_amd_ois_compact_candidates(const SvtAmdOisParams *p)
+{
+    return !p ? SVT_AMD_OIS_MAX_CAND : p->slice_is_intra ? 7 : p->ois_kernel_level ? 18 : 9; /* MAX_OIS_0 / _2 / _1 */
+}
+
+static int slot_pack_buffer(SvtAmdContext *ctx, DevPicture *c, size_t bytes, uint8_t **out)
+{
+    if (bytes > c->pack_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (c->d_pack)
+            (void)hipFree(c->d_pack);
+        c->d_pack = nullptr, c->pack_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_pack, bytes));
+        c->pack_bytes = bytes;
+    }
+    *out = c->d_pack;
+    return SVT_AMD_OK;
+}
+
+/* the slot's pack buffer holds the ME part first, the OIS part after it (sized for the widest OIS form) */
+static size_t pack_me_bytes(int nlcu) { return ((size_t)nlcu * SVT_AMD_ME_PU_COUNT * sizeof(SvtAmdMeCuResult) + 255) & ~(size_t)255; }
+
+extern "C" int svt_amd_me_picture_fetch_compact_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeCuResult *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    if (!out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    uint8_t *d = nullptr;
+    if ((rc = slot_pack_buffer(ctx, c, pack_me_bytes(nlcu) + (size_t)nlcu * sizeof(SvtAmdOisLcuResult), &d)) != 0)
+        return rc;
+    const int n = nlcu * (int)(SVT_AMD_ME_PU_COUNT * sizeof(SvtAmdMeCuResult) / 4);
+    hipLaunchKernelGGL(k_pack_me, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_me_out, (uint32_t *)d, nlcu);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_ois_picture_fetch_compact_async(SvtAmdContext *ctx, int cur_slot, int candidates, void *out)
+{
+    int rc = check_slot(ctx, cur_slot);
+    if (rc)
+        return rc;
+    if (!out || candidates < 1 || candidates > SVT_AMD_OIS_MAX_CAND)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevPicture *c = &ctx->slots[cur_slot];
+    const int nlcu = ((c->width + 63) / 64) * ((c->height + 63) / 64);
+    uint8_t *d = nullptr;
+    if ((rc = slot_pack_buffer(ctx, c, pack_me_bytes(nlcu) + (size_t)nlcu * sizeof(SvtAmdOisLcuResult), &d)) != 0)
+        return rc;
+    d += pack_me_bytes(nlcu);
+    const int n = nlcu * (SVT_AMD_ME_PU_COUNT * candidates + 22);
+    hipLaunchKernelGGL(k_pack_ois, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_ois_out, (uint32_t *)d, nlcu, candidates);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_AMD_OK;
+}
+
 extern "C" int svt_amd_me_picture(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot,
                                   const int ref_slot[2], SvtAmdMeLcuResult *out)
 {
@@ -884,12 +974,22 @@ extern "C" int svt_amd_frontend_submit(SvtAmdContext *ctx, const SvtAmdFrontendJ
         }
         if ((rc = svt_amd_me_picture_launch(ctx, &job->me, job->cur_slot, job->ref_slot)) != 0)
             return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->h_me, c->d_me_out, (size_t)pn * sizeof(SvtAmdMeLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+        if (job->compact)
+            rc = svt_amd_me_picture_fetch_compact_async(ctx, job->cur_slot, (SvtAmdMeCuResult *)ctx->h_me);
+        else
+            HIP_TRY(hipMemcpyAsync(ctx->h_me, c->d_me_out, (size_t)pn * sizeof(SvtAmdMeLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+        if (rc)
+            return rc;
     }
     if (job->has_ois) {
         if ((rc = svt_amd_ois_picture_launch(ctx, &job->ois, job->cur_slot)) != 0)
             return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->h_ois, c->d_ois_out, (size_t)pn * sizeof(SvtAmdOisLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+        if (job->compact)
+            rc = svt_amd_ois_picture_fetch_compact_async(ctx, job->cur_slot, svt_amd_ois_compact_candidates(&job->ois), ctx->h_ois);
+        else
+            HIP_TRY(hipMemcpyAsync(ctx->h_ois, c->d_ois_out, (size_t)pn * sizeof(SvtAmdOisLcuResult), hipMemcpyDeviceToHost, ctx->stream));
+        if (rc)
+            return rc;
     }
     HIP_TRY(hipEventRecord(ctx->ev_done, ctx->stream));
     ctx->frontend_busy = 1;
@@ -938,6 +1038,10 @@ extern "C" int svt_amd_frontend_warmup(SvtAmdContext *ctx)
             DevPicture *s = &ctx->slots[i];
             if (!s->h_staging)
                 HIP_TRY(hipHostMalloc((void **)&s->h_staging, s->staging_bytes, hipHostMallocDefault));
+            uint8_t *d = nullptr;
+            int rcp = slot_pack_buffer(ctx, s, pack_me_bytes(nlcu) + (size_t)nlcu * sizeof(SvtAmdOisLcuResult), &d);
+            if (rcp)
+                return rcp;
         }
     }
     if (ctx->frontend_busy || ctx->num_slots < 1)

@@ -34,6 +34,8 @@ struct DevPicture {
     uint8_t *d_staging;            /* device copy of the raw luma (upload path) */
     size_t   staging_bytes;
     uint8_t *h_staging;            /* pinned host copy of the raw luma (asynchronous upload path), allocated on first use */
+    uint8_t *d_pack;               /* compact wire form of this slot's ME + OIS records (svt_amd_*_fetch_compact_async) */
+    size_t pack_bytes;
     hipEvent_t ev_ready;           /* recorded after the planes of this slot were built: lanes on other streams wait on it */
     uint16_t width, height;
     int      valid;

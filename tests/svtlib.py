@@ -105,7 +105,7 @@ class OisJob(C.Structure):
 class FrontendJob(C.Structure):
     """SvtAmdFrontendJob"""
     _fields_ = [("cur_slot", C.c_int32), ("ref_slot", C.c_int32 * 2), ("has_me", C.c_uint8), ("has_ois", C.c_uint8),
-                ("pad", C.c_uint8 * 2), ("me", MeParams), ("ois", OisParams)]
+                ("compact", C.c_uint8), ("pad", C.c_uint8), ("me", MeParams), ("ois", OisParams)]
 
 
 OIS_PARAMS_DTYPE = np.dtype(OisParams)
@@ -255,6 +255,9 @@ def load_product():
     _sig(lib.svt_amd_frontend_wait, i, [vp, C.POINTER(vp), C.POINTER(vp)])
     _sig(lib.svt_amd_frontend_release, i, [vp])
     _sig(lib.svt_amd_frontend_warmup, i, [vp])
+    _sig(lib.svt_amd_ois_compact_candidates, i, [C.POINTER(OisParams)])
+    _sig(lib.svt_amd_me_picture_fetch_compact_async, i, [vp, i, vp])
+    _sig(lib.svt_amd_ois_picture_fetch_compact_async, i, [vp, i, i, vp])
     _sig(lib.svt_amd_device_alloc, i, [vp, C.c_size_t, C.POINTER(vp)])
     _sig(lib.svt_amd_device_free, i, [vp, vp])
     _sig(lib.svt_amd_device_upload, i, [vp, vp, vp, C.c_size_t])

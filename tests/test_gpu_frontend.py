@@ -75,6 +75,26 @@ def test_lanes_pipeline_matches_blocking_calls_and_oracle(product, oracle):
         want_ois = S.oracle_ois_picture(oracle, oi, frames[0], None)
         assert np.array_equal(ois["candidate"], want_ois["candidate"]) and np.array_equal(ois["total"], want_ois["total"])
         lib.svt_amd_frontend_release(lanes[1])
+        # COMPACT wire format: the same two jobs again with job.compact = 1 - MeCuResult[85] per LCU and nc candidates per CU
+        # (nc = 9 on a B picture, 7 on an I picture) must be exactly the corresponding parts of the full records
+        for k, (job, slot, full_ois) in enumerate(((jobs[1], 2, None), (j, 0, ois))):
+            job.compact = 1
+            nc = lib.svt_amd_ois_compact_candidates(C.byref(job.ois))
+            assert nc == (7 if job.ois.slice_is_intra else 9)
+            assert lib.svt_amd_frontend_submit(lanes[k], C.byref(job)) == 0, lib.svt_amd_last_error()
+            me_p, ois_p = C.c_void_p(), C.c_void_p()
+            assert lib.svt_amd_frontend_wait(lanes[k], C.byref(me_p), C.byref(ois_p)) == 0, lib.svt_amd_last_error()
+            cdt = np.dtype([("candidate", "<u4", (S.ME_PU_COUNT, nc)), ("total", "u1", (S.ME_PU_COUNT,)), ("pad", "u1", (3,))])
+            assert cdt.itemsize == S.ME_PU_COUNT * nc * 4 + 88
+            cois = _records(ois_p, nl, cdt)
+            if job.has_me:
+                cme = _records(me_p, nl * S.ME_PU_COUNT, S.ME_LCU_DTYPE["pu"].base)
+                full = me_picture(lib, root, p, slot, [slot - 1, slot + 1])
+                assert cme.tobytes() == np.ascontiguousarray(full["pu"]).tobytes()
+                full_ois = S.oracle_ois_picture(oracle, op, frames[slot], S.oracle_me_picture(oracle, p, pics[slot], pics[slot - 1], pics[slot + 1]))
+            assert np.array_equal(cois["candidate"], full_ois["candidate"][:, :, :nc]) and np.array_equal(cois["total"], full_ois["total"])
+            assert not (full_ois["candidate"][:, :, nc:] & (S.OIS_W_DIST | S.OIS_W_VALID | S.OIS_W_MODE)).any()   # nothing written beyond nc
+            lib.svt_amd_frontend_release(lanes[k])
     finally:
         for lane in lanes:
             lib.svt_amd_context_destroy(lane)
