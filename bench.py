@@ -6,7 +6,7 @@ Workload (default, `--config 2`): BASELINE configs[2] = 3840x2160 8-bit, encMode
 reference encoder derived them for this configuration (tests/golden/me_b_3840x2160_m7.npz, ois_ib_3840x2160_m7.npz).
 `--config 1` = BASELINE configs[1] (1920x1080 encMode 9 low-delay P, one list).
 
-One "step" = one pass of the front half of the hot path over one batch of B pictures PER LANE (--lanes, default 2), THROUGH THE HOST BOUNDARY:
+One "step" = one pass of the front half of the hot path over --lanes (default 2) batches of B pictures, THROUGH THE HOST BOUNDARY:
     pinned host luma --H2D--> picture preparation (pad + 1/4 + 1/16 decimation + half-pel planes, one launch)
     -> open-loop motion estimation of every LCU against both references (HME, full-pel 85-PU search, half/quarter-pel,
        bi-prediction, candidate records: 2 kernels per list, one batched launch each)
@@ -14,8 +14,10 @@ One "step" = one pass of the front half of the hot path over one batch of B pict
     --device pack--> the compact wire records the reference side reads (MeCuResults x 85 = 2,040 B/LCU; the <= 9 OIS candidates a
        P / B picture writes per CU = 3,148 B/LCU; the full 3,420 + 6,208 B records stay in HBM for parity tests)
     --D2H--> into pinned host memory.
-The lanes (streams over the same picture slots, svt_amd_context_fork) take turns, so the copies of one lane overlap the
-kernels of the other.  Both PCIe directions are INSIDE the timed region; `hbm_resident_fps` is the same loop without them.
+Three lanes (streams over the same picture slots, svt_amd_context_fork) form the pipeline: copy-in, compute, copy-out; the batches'
+buffer sets rotate through them under lane events, so the copies of batches s-1 / s+1 run under the kernels of batch s and kernels
+of different batches never share the GPU (the per-kernel times are stand-alone durations).  Both PCIe directions are INSIDE the
+timed region; `hbm_resident_fps` is the compute lane alone.
 
 Prints ONE JSON line (rank 0).  `value` = front-half pictures/s over all GPUs, NOT whole-encoder fps: the closed-loop EncDec
 half still runs on the host in the hooked encoder, whose md5-gated whole-encoder fps is reported beside it as `encoder_fps`
@@ -33,8 +35,13 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
+# one hardware queue per lane: with HIP's default of 4 the copy-out lane shares a queue with the compute lane and its stream
+# markers serialise the result copies with the next batch's kernels (profiles/r02_k_timeline.txt; the library sets the same
+# default for C hosts, svt-hevc_amd/csrc/context.hip).  Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -204,7 +211,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="pictures per step per GPU (default: 64 at 4K, 128 at 1080p)")
-    ap.add_argument("--lanes", type=int, default=2, help="lanes (streams) per GPU; each runs its own batch per step")
+    ap.add_argument("--lanes", type=int, default=2, help="buffer sets in flight per GPU (each holds one batch); 2 <= n <= 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoder-fps", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
@@ -250,14 +257,21 @@ def main():
     torch.cuda.synchronize()
     ok(lib.svt_amd_device_download(root, h_in, vp(frames.data_ptr()), B * W * H))
     del frames
-    lanes = []
+    # three lanes = three streams over the same picture slots: copy-in (H2D), compute (every kernel), copy-out (device pack + D2H).
+    # NL buffer sets (staging, B picture slots, pinned result buffers) rotate through them; lane events order the stages, the host
+    # never waits inside the loop.  Kernels of different batches therefore never share the GPU: the per-kernel times below are
+    # stand-alone durations, and the copies of batch s-1 / s+1 run under the kernels of batch s.
+    lane_in, lane_k, lane_out = vp(), vp(), vp()
+    for l in (lane_in, lane_k, lane_out):
+        ok(lib.svt_amd_context_fork(root, C.byref(l)))
+    sets = []
     for li in range(NL):
-        lane = vp()
-        ok(lib.svt_amd_context_fork(root, C.byref(lane)))
-        d_stage, h_me, h_ois = vp(), vp(), vp()
-        ok(lib.svt_amd_device_alloc(lane, B * W * H, C.byref(d_stage)))
-        ok(lib.svt_amd_host_alloc(lane, B * nlcu * me_b, C.byref(h_me)))
-        ok(lib.svt_amd_host_alloc(lane, B * nlcu * ois_b, C.byref(h_ois)))
+        d_stage, h_me, h_ois, d_me, d_ois = vp(), vp(), vp(), vp(), vp()
+        ok(lib.svt_amd_device_alloc(lane_in, B * W * H, C.byref(d_stage)))
+        ok(lib.svt_amd_device_alloc(lane_k, B * nlcu * me_b, C.byref(d_me)))      # packed wire records of the batch, device side
+        ok(lib.svt_amd_device_alloc(lane_k, B * nlcu * ois_b, C.byref(d_ois)))
+        ok(lib.svt_amd_host_alloc(lane_out, B * nlcu * me_b, C.byref(h_me)))
+        ok(lib.svt_amd_host_alloc(lane_out, B * nlcu * ois_b, C.byref(h_ois)))
         slots = (i32 * B)(*[li * B + i for i in range(B)])
         ptrs = (vp * B)(*[d_stage.value + i * W * H for i in range(B)])
         jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
@@ -266,22 +280,67 @@ def main():
             jobs[i].ref_slot[0] = slots[(i - 1) % B]
             jobs[i].ref_slot[1] = slots[(i + 1) % B]
             ojobs[i].params, ojobs[i].cur_slot = oparams, slots[i]
-        lanes.append(dict(ctx=lane, d_stage=d_stage, h_me=h_me, h_ois=h_ois, slots=slots, ptrs=ptrs, jobs=jobs, ojobs=ojobs))
+        sets.append(dict(d_stage=d_stage, h_me=h_me, h_ois=h_ois, d_me=d_me, d_ois=d_ois, slots=slots, ptrs=ptrs, jobs=jobs, ojobs=ojobs))
+    lanes = [dict(ctx=lane_in), dict(ctx=lane_k), dict(ctx=lane_out)]
 
     counts = {"batches": 0}
+    EV_STAGE, EV_READY = 0, NL   # event indices per set: [k] stage / slots handed over, [NL + k] results ready
 
-    def step(L, copies=True):
-        ok(lib.svt_amd_synchronize(L["ctx"]))  # this lane's previous step is complete: its buffers are free again
+    direct = os.environ.get("SVT_BENCH_D2H", "sdma") == "direct"   # diagnosis: pack kernels write the pinned host arrays themselves
+    skip = os.environ.get("SVT_BENCH_SKIP")   # diagnosis only: "in" / "out" drops that copy stage from the pipeline
+    trace = os.environ.get("SVT_BENCH_TRACE")
+    if trace:  # host time inside every library call of a step (which call makes the host wait?)
+        import functools
+        acc = {}
+
+        rawlib = lib
+
+        class _Timed:
+            def __getattr__(self, name):
+                f = getattr(rawlib, name)
+
+                @functools.wraps(f)
+                def g(*aa):
+                    t0 = time.perf_counter()
+                    r = f(*aa)
+                    acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+                    return r
+                return g
+        lib = _Timed()
+
+    def step(k, copies=True):
+        """one batch through the pipeline on buffer set k"""
+        L = sets[k]
         if copies:
-            ok(lib.svt_amd_device_upload_async(L["ctx"], L["d_stage"], h_in, B * W * H))
-        ok(lib.svt_amd_picture_upload_device_batch(L["ctx"], B, L["slots"], L["ptrs"], W, W, H))
-        ok(lib.svt_amd_me_batch_launch(L["ctx"], L["jobs"], B))
-        ok(lib.svt_amd_ois_batch_launch(L["ctx"], L["ojobs"], B))
+            ok(lib.svt_amd_lane_event_wait(lane_in, lane_k, EV_STAGE + k))     # the planes of the set's previous batch are built
+            if skip != "in":
+                ok(lib.svt_amd_device_upload_async(lane_in, L["d_stage"], h_in, B * W * H))
+            ok(lib.svt_amd_lane_event_record(lane_in, EV_STAGE + k))
+            ok(lib.svt_amd_lane_event_wait(lane_k, lane_in, EV_STAGE + k))
+            ok(lib.svt_amd_lane_event_wait(lane_k, lane_out, EV_STAGE + k))    # the set's previous records have left the device
+        ok(lib.svt_amd_picture_upload_device_batch(lane_k, B, L["slots"], L["ptrs"], W, W, H))
         if copies:
-            for i in range(B):
-                # the compact wire records (what the reference side of the boundary reads, include/svt_hevc_amd.h): packed on the device
-                ok(lib.svt_amd_me_picture_fetch_compact_async(L["ctx"], L["slots"][i], vp(L["h_me"].value + i * nlcu * me_b)))
-                ok(lib.svt_amd_ois_picture_fetch_compact_async(L["ctx"], L["slots"][i], ois_nc, vp(L["h_ois"].value + i * nlcu * ois_b)))
+            ok(lib.svt_amd_lane_event_record(lane_k, EV_STAGE + k))
+        ok(lib.svt_amd_me_batch_launch(lane_k, L["jobs"], B))
+        ok(lib.svt_amd_ois_batch_launch(lane_k, L["ojobs"], B))
+        if copies and direct:
+            # diagnosis: the pack kernels of the copy-out lane write straight into the pinned host arrays (no copy engine; their
+            # PCIe-bound waves hold CUs the searches want, so this is slower than the default below)
+            ok(lib.svt_amd_lane_event_record(lane_k, EV_READY + k))
+            ok(lib.svt_amd_lane_event_wait(lane_out, lane_k, EV_READY + k))
+            if skip != "out":
+                ok(lib.svt_amd_records_pack_batch_async(lane_out, L["slots"], B, ois_nc, L["h_me"], L["h_ois"]))
+            ok(lib.svt_amd_lane_event_record(lane_out, EV_STAGE + k))
+        elif copies:
+            # the compact wire records (what the reference side of the boundary reads, include/svt_hevc_amd.h): packed on the compute
+            # lane into device arrays, moved by the copy engines on the copy-out lane with two copies per batch
+            ok(lib.svt_amd_records_pack_batch_async(lane_k, L["slots"], B, ois_nc, L["d_me"], L["d_ois"]))
+            ok(lib.svt_amd_lane_event_record(lane_k, EV_READY + k))
+            ok(lib.svt_amd_lane_event_wait(lane_out, lane_k, EV_READY + k))
+            if skip != "out":  # two copies for the whole batch
+                ok(lib.svt_amd_device_download_async(lane_out, L["h_me"], L["d_me"], B * nlcu * me_b))
+                ok(lib.svt_amd_device_download_async(lane_out, L["h_ois"], L["d_ois"], B * nlcu * ois_b))
+            ok(lib.svt_amd_lane_event_record(lane_out, EV_STAGE + k))
         counts["batches"] += 1
 
     def sync_all():
@@ -300,8 +359,8 @@ def main():
             lib.svt_amd_timer_begin(L["ctx"])
         t0 = time.perf_counter()
         for s in range(nsteps):
-            for L in lanes:  # one batch per lane per step: lane 1's copies run under lane 0's kernels and vice versa
-                step(L, copies)
+            for k in range(NL):  # NL batches per step, one per buffer set
+                step(k, copies)
         sync_all()
         barrier()
         dt = time.perf_counter() - t0
@@ -325,11 +384,14 @@ def main():
         return dt, kt
 
     for s in range(a.warmup):
-        for L in lanes:
-            step(L)
+        for k in range(NL):
+            step(k)
     sync_all()
     dt, kt = timed(a.steps, True)
 
+    if trace and rank == 0:
+        print("host seconds per library call over %d batches: %s" % (counts["batches"], {k: round(v, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}),
+              file=sys.stderr, flush=True)
     if a.inner:
         if rank == 0:
             print(json.dumps({"me_batches": counts["batches"], "pictures_per_batch": B}), flush=True)
@@ -395,10 +457,13 @@ def main():
 
     if xchg and xchg.get("hung"):
         os._exit(0)  # a helper thread is still inside the collective library: do not wait for it at teardown
+    for L in sets:
+        lib.svt_amd_device_free(lane_in, L["d_stage"])
+        lib.svt_amd_device_free(lane_k, L["d_me"])
+        lib.svt_amd_device_free(lane_k, L["d_ois"])
+        lib.svt_amd_host_free(lane_out, L["h_me"])
+        lib.svt_amd_host_free(lane_out, L["h_ois"])
     for L in lanes:
-        lib.svt_amd_device_free(L["ctx"], L["d_stage"])
-        lib.svt_amd_host_free(L["ctx"], L["h_me"])
-        lib.svt_amd_host_free(L["ctx"], L["h_ois"])
         lib.svt_amd_context_destroy(L["ctx"])
     lib.svt_amd_host_free(root, h_in)
     lib.svt_amd_context_destroy(root)

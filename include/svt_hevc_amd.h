@@ -289,6 +289,10 @@ SVT_AMD_API int svt_amd_picture_publish(SvtAmdContext *lane, int slot);
 SVT_AMD_API int svt_amd_frontend_submit(SvtAmdContext *lane, const SvtAmdFrontendJob *job);
 SVT_AMD_API int svt_amd_frontend_wait(SvtAmdContext *lane, const SvtAmdMeLcuResult **me, const SvtAmdOisLcuResult **ois);
 SVT_AMD_API int svt_amd_frontend_release(SvtAmdContext *lane);
+/* Cross-lane ordering without host waits (for hosts that build their own copy-in -> compute -> copy-out pipelines): a lane records
+ * its event `index` (0..7) at the current end of its stream; another lane's stream waits for the latest record of it. */
+SVT_AMD_API int svt_amd_lane_event_record(SvtAmdContext *lane, int index);
+SVT_AMD_API int svt_amd_lane_event_wait(SvtAmdContext *lane, SvtAmdContext *source, int index);
 /* Compact wire format of the records (what the reference side of the boundary consumes; the full records also carry the internal
  * best-SAD / MV arrays and 18 candidate slots per CU for parity tests): per LCU
  *   ME :  SvtAmdMeCuResult[85]                                                        (2,040 B instead of 3,420)
@@ -299,6 +303,11 @@ SVT_AMD_API int svt_amd_frontend_release(SvtAmdContext *lane);
 SVT_AMD_API int svt_amd_ois_compact_candidates(const SvtAmdOisParams *params);
 SVT_AMD_API int svt_amd_me_picture_fetch_compact_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeCuResult *out);
 SVT_AMD_API int svt_amd_ois_picture_fetch_compact_async(SvtAmdContext *ctx, int cur_slot, int candidates, void *out);
+/* n pictures at once (batched hosts): the slots' records packed into contiguous DEVICE arrays, picture i of the batch at index i of
+ * d_me (LCUs x 85 records each) / d_ois (LCUs x SVT_AMD_OIS_COMPACT_BYTES(candidates) bytes each); either may be NULL.  Run it on
+ * the lane that ran the searches and move the arrays with one copy each on any lane (svt_amd_device_download_async). */
+SVT_AMD_API int svt_amd_records_pack_batch_async(SvtAmdContext *ctx, const int *slots, int n, int candidates, SvtAmdMeCuResult *d_me,
+                                                 void *d_ois);
 /* Start-up, outside any timed run: pins the staging buffers of every picture slot (root) and the lane's result buffers, and sends
  * one dummy picture through upload -> planes -> ME -> OIS so that the kernels' code objects are loaded.  Once per lane (and root). */
 SVT_AMD_API int svt_amd_frontend_warmup(SvtAmdContext *ctx);

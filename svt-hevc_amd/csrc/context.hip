@@ -89,6 +89,14 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
         (void)hipHostFree(ctx->h_me);
     if (ctx->h_ois)
         (void)hipHostFree(ctx->h_ois);
+    if (ctx->h_desc_ring) {
+        (void)hipHostFree(ctx->h_desc_ring);
+        for (int i = 0; i < 8; i++)
+            (void)hipEventDestroy(ctx->ev_desc[i]);
+    }
+    for (int i = 0; i < 8; i++)
+        if (ctx->ev_user[i])
+            (void)hipEventDestroy(ctx->ev_user[i]);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
     if (ctx->d_jobs)
@@ -147,6 +155,46 @@ int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out)
         ctx->leaf_scratch_bytes = n;
     }
     *out = ctx->d_leaf_scratch;
+    return SVT_AMD_OK;
+}
+
+/* Lanes are streams, and streams only run side by side when each has a hardware queue of its own: with the HIP runtime's default
+ * of four, a fifth stream shares a queue and its markers serialise with whatever that queue holds (a result copy of one lane then
+ * waits for another lane's kernels and vice versa; measured in bench.py, 1,680 -> 2,450 pictures/s).  The variable is read when the
+ * runtime starts, so it is set when this library is loaded - a C host (the encoder) loads it before any HIP call; a user's own
+ * setting wins. */
+__attribute__((constructor)) static void svt_amd_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+
+/* Job descriptors of a launch (a few KB) go host -> device through a pinned ring the GPU reads itself: a copy kernel on the
+ * lane's stream, in order with the launch that consumes them.  A hipMemcpyAsync would put them on a copy engine's queue, where they
+ * wait behind whatever picture-sized copy another lane has in flight - and the lane's kernels with them (measured: every batch's
+ * first kernel started only when the previous batch's 680 MB result copy had finished; profiles/r02_k_timeline.txt). */
+#define DESC_SLOT_BYTES (128 * 1024)
+__global__ void __launch_bounds__(256) k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        dst[i] = src[i];
+}
+int svt_amd_upload_descriptors(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (bytes > DESC_SLOT_BYTES || (bytes & 3)) {
+        HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SVT_AMD_OK;
+    }
+    if (!ctx->h_desc_ring) {
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_desc_ring, (size_t)8 * DESC_SLOT_BYTES, hipHostMallocDefault));
+        for (int i = 0; i < 8; i++)
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_desc[i], hipEventDisableTiming));
+    }
+    const int i = ctx->desc_next;
+    ctx->desc_next = (i + 1) & 7;
+    HIP_TRY(hipEventSynchronize(ctx->ev_desc[i])); /* the copy that last used this slot is done (8 launches ago) */
+    uint8_t *slot = ctx->h_desc_ring + (size_t)i * DESC_SLOT_BYTES;
+    memcpy(slot, src, bytes);
+    const uint32_t n = (uint32_t)(bytes >> 2);
+    hipLaunchKernelGGL(k_copy_words, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t *)d_dst, (const uint32_t *)slot, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_desc[i], ctx->stream));
     return SVT_AMD_OK;
 }
 
@@ -693,6 +741,29 @@ extern "C" int svt_amd_ois_picture_fetch_async(SvtAmdContext *ctx, int cur_slot,
     return SVT_AMD_OK;
 }
 
+/* Cross-lane ordering for hosts that build their own pipelines (bench.py: copy-in lane -> compute lane -> copy-out lane): lane
+ * `lane` records its event `index` at the current end of its stream; svt_amd_lane_event_wait makes another lane's stream wait for
+ * the most recent record of it (a wait on an event that was never recorded does not wait).  Nothing blocks the host. */
+extern "C" int svt_amd_lane_event_record(SvtAmdContext *lane, int index)
+{
+    if (!lane || index < 0 || index >= 8)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(lane->device));
+    if (!lane->ev_user[index])
+        HIP_TRY(hipEventCreateWithFlags(&lane->ev_user[index], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(lane->ev_user[index], lane->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_lane_event_wait(SvtAmdContext *lane, SvtAmdContext *source, int index)
+{
+    if (!lane || !source || index < 0 || index >= 8 || lane->device != source->device)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(lane->device));
+    if (source->ev_user[index])
+        HIP_TRY(hipStreamWaitEvent(lane->stream, source->ev_user[index], 0));
+    return SVT_AMD_OK;
+}
+
 /* ---- compact wire format of the front-half records -------------------------------------------------------------------------
  * What the host side of the boundary reads (MeCuResults_t x 85; the OIS candidates the picture's path can write: MAX_OIS_0 / _1 /
  * _2 of EbCodingUnit.h:59-61) is 5,188 of the 9,628 bytes per LCU at BASELINE configs[2]; the device packs it (one pass over the
@@ -778,6 +849,44 @@ extern "C" int svt_amd_ois_picture_fetch_compact_async(SvtAmdContext *ctx, int c
     hipLaunchKernelGGL(k_pack_ois, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_ois_out, (uint32_t *)d, nlcu, candidates);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* A batch of pictures at once: every slot's records are packed into contiguous DEVICE arrays (picture i of the batch at index i:
+ * LCUs x 85 ME records / LCUs x SVT_AMD_OIS_COMPACT_BYTES(candidates) OIS bytes).  The pack kernels belong on the lane that ran
+ * the searches - small kernels on another stream starve behind its picture-sized launches - and the caller then moves each array
+ * with ONE copy on whatever lane it likes (svt_amd_device_download_async).  Either destination may be NULL. */
+extern "C" int svt_amd_records_pack_batch_async(SvtAmdContext *ctx, const int *slots, int n, int candidates, SvtAmdMeCuResult *d_me, void *d_ois)
+{
+    if (!ctx || !slots || n < 1 || n > SVT_AMD_MAX_BATCH || (!d_me && !d_ois) || candidates < 1 || candidates > SVT_AMD_OIS_MAX_CAND)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int rc = check_slot(ctx, slots[0]);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const DevPicture *c0 = &ctx->slots[slots[0]];
+    const int nlcu = ((c0->width + 63) / 64) * ((c0->height + 63) / 64);
+    const size_t meb = (size_t)nlcu * SVT_AMD_ME_PU_COUNT * sizeof(SvtAmdMeCuResult), oisb = (size_t)nlcu * SVT_AMD_OIS_COMPACT_BYTES(candidates);
+    for (int i = 0; i < n; i++) {
+        if ((rc = check_slot(ctx, slots[i])) != 0)
+            return rc;
+        const DevPicture *c = &ctx->slots[slots[i]];
+        if (c->width != c0->width || c->height != c0->height) {
+            svt_amd_set_error("svt_amd_records_pack_batch_async: pictures of different sizes in one batch");
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        if (d_me) {
+            const int k = nlcu * (int)(SVT_AMD_ME_PU_COUNT * sizeof(SvtAmdMeCuResult) / 4);
+            hipLaunchKernelGGL(k_pack_me, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_me_out,
+                               (uint32_t *)((uint8_t *)d_me + meb * (size_t)i), nlcu);
+        }
+        if (d_ois) {
+            const int k = nlcu * (SVT_AMD_ME_PU_COUNT * candidates + 22);
+            hipLaunchKernelGGL(k_pack_ois, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_ois_out,
+                               (uint32_t *)((uint8_t *)d_ois + oisb * (size_t)i), nlcu, candidates);
+        }
+    }
+    HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;
 }
 

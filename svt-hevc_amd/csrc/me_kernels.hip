@@ -1440,8 +1440,12 @@ int svt_amd_launch_me_batch(SvtAmdContext *ctx, const MeJobDev *host_jobs, int n
             attr1[dv] = pool1;
         }
     }
-    /* pageable source: the runtime stages it before returning, so host_jobs may be reused */
-    HIP_TRY(hipMemcpyAsync(ctx->d_jobs, host_jobs, sizeof(MeJobDev) * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream));
+    /* copied into a pinned ring before returning, so host_jobs may be reused */
+    {
+        const int rcd = svt_amd_upload_descriptors(ctx, ctx->d_jobs, host_jobs, sizeof(MeJobDev) * (size_t)njobs);
+        if (rcd)
+            return rcd;
+    }
     int rc = svt_amd_stamp_begin(ctx, KC_ME_SEARCH);
     if (rc)
         return rc;

@@ -474,7 +474,11 @@ __global__ __launch_bounds__(256) void k_ois_picture(const OisJobDev *__restrict
 
 int svt_amd_launch_ois_batch(SvtAmdContext *ctx, const OisJobDev *host_jobs, int njobs, int max_lcus)
 {
-    HIP_TRY(hipMemcpyAsync(ctx->d_ois_jobs, host_jobs, sizeof(OisJobDev) * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int rcd = svt_amd_upload_descriptors(ctx, ctx->d_ois_jobs, host_jobs, sizeof(OisJobDev) * (size_t)njobs);
+        if (rcd)
+            return rcd;
+    }
     hipLaunchKernelGGL(k_ois_picture, dim3(max_lcus, njobs), dim3(256), 0, ctx->stream, (const OisJobDev *)ctx->d_ois_jobs);
     HIP_TRY(hipGetLastError());
     return SVT_AMD_OK;

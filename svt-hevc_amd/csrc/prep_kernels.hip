@@ -169,7 +169,11 @@ int svt_amd_launch_prep_batch(SvtAmdContext *ctx, DevPicture *const *pics, const
     int rc = svt_amd_stamp_begin(ctx, KC_PREP);
     if (rc)
         return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->d_prep_jobs, host, sizeof(PrepJobDev) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int rcd = svt_amd_upload_descriptors(ctx, ctx->d_prep_jobs, host, sizeof(PrepJobDev) * (size_t)n);
+        if (rcd)
+            return rcd;
+    }
     hipLaunchKernelGGL(k_prep_fused, dim3(b0 + b1 + b2, n), dim3(256), 0, ctx->stream, (const PrepJobDev *)ctx->d_prep_jobs, b0, b1);
     HIP_TRY(hipGetLastError());
     return svt_amd_stamp_end(ctx);

@@ -96,6 +96,10 @@ struct SvtAmdContext {
     SvtAmdOisLcuResult *h_ois;
     hipEvent_t ev_done;
     int frontend_busy;
+    hipEvent_t ev_user[8];
+    uint8_t *h_desc_ring;          /* pinned ring of launch descriptors (svt_amd_upload_descriptors) */
+    hipEvent_t ev_desc[8];
+    int desc_next;         /* svt_amd_lane_event_record / _wait */
     /* multi-GPU exchange (comm.hip): RCCL communicator + the all-gather buffer (one slot per rank) */
     void *comm;
     int comm_world, comm_rank;
@@ -105,6 +109,8 @@ struct SvtAmdContext {
 
 /* device scratch of at least `bytes` owned by the context (grown on demand, freed by svt_amd_context_destroy);
  * callers serialise per context, as for every other call on one context */
+/* launch descriptors (job arrays) reach the device without the copy engines: see context.hip */
+int svt_amd_upload_descriptors(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes);
 int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out);
 
 void svt_amd_set_error(const char *fmt, ...);

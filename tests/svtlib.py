@@ -255,6 +255,9 @@ def load_product():
     _sig(lib.svt_amd_frontend_wait, i, [vp, C.POINTER(vp), C.POINTER(vp)])
     _sig(lib.svt_amd_frontend_release, i, [vp])
     _sig(lib.svt_amd_frontend_warmup, i, [vp])
+    _sig(lib.svt_amd_lane_event_record, i, [vp, i])
+    _sig(lib.svt_amd_records_pack_batch_async, i, [vp, C.POINTER(C.c_int), i, i, vp, vp])
+    _sig(lib.svt_amd_lane_event_wait, i, [vp, vp, i])
     _sig(lib.svt_amd_ois_compact_candidates, i, [C.POINTER(OisParams)])
     _sig(lib.svt_amd_me_picture_fetch_compact_async, i, [vp, i, vp])
     _sig(lib.svt_amd_ois_picture_fetch_compact_async, i, [vp, i, i, vp])
