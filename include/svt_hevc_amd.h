@@ -1004,6 +1004,21 @@ typedef struct SvtAmdLcuResult {
     int16_t coeff_y[64 * 64], coeff_cb[32 * 32], coeff_cr[32 * 32];
     uint8_t rec_y[64 * 64], rec_cb[32 * 32], rec_cr[32 * 32]; /* inside the picture only */
 } SvtAmdLcuResult;
+/* 16-bit twins (EncodePass with is16bit: 10-bit samples in uint16_t; the source of an LCU is contextPtr->inputSample16bitBuffer as
+ * EncodePassPackLcu, EbCodingLoop.c:2867, leaves it; the quantiser runs at qp + QP_BD_OFFSET, :1307) */
+typedef struct SvtAmdLcuWork16 {
+    uint16_t lcu_x, lcu_y;
+    uint8_t num_cus, slice_type, temporal_layer, constrained_intra, strong_smoothing;
+    uint8_t tile_left, tile_top, tile_right;
+    uint8_t pad[4];
+    SvtAmdLcuCu cu[SVT_AMD_LCU_MAX_CUS];
+    uint16_t src_y[64 * 64], src_cb[32 * 32], src_cr[32 * 32];
+} SvtAmdLcuWork16;
+typedef struct SvtAmdLcuResult16 {
+    SvtAmdLcuCuResult cu[SVT_AMD_LCU_MAX_CUS];
+    int16_t coeff_y[64 * 64], coeff_cb[32 * 32], coeff_cr[32 * 32];
+    uint16_t rec_y[64 * 64], rec_cb[32 * 32], rec_cr[32 * 32];
+} SvtAmdLcuResult16;
 typedef struct SvtAmdEncDecPicture SvtAmdEncDecPicture;
 SVT_AMD_API int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t luma_width, uint16_t luma_height, int bytes_per_sample,
                                               SvtAmdEncDecPicture **out);
@@ -1014,11 +1029,16 @@ SVT_AMD_API int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecP
 SVT_AMD_API int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n,
                                     SvtAmdLcuResult *results);
 
+/* the same for a picture created with bytes_per_sample = 2 */
+SVT_AMD_API int svt_amd_encode_lcus16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, int n,
+                                      SvtAmdLcuResult16 *results);
+
 /* The whole picture in ONE call: works / results are HOST arrays of every LCU of the picture in raster order.  The wavefront of
  * AssignEncDecSegments (Codec/EbEncDecProcess.c:1540; an LCU starts when its left and top-right LCUs of the same tile are done) runs
  * on the device - workgroups draw LCUs in raster order and wait for their neighbours' completion flags - so the host makes no
  * scheduling decision and the picture costs one launch.  Implies svt_amd_encdec_picture_begin.  Blocking. */
 SVT_AMD_API int svt_amd_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results);
+SVT_AMD_API int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results);
 /* The same on DEVICE arrays (the unit lists are not validated); asynchronous on the context's stream.  tiles: tiles of the picture
  * (they run side by side; sizes the persistent grid). */
 SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
@@ -1039,6 +1059,12 @@ typedef struct SvtAmdLcuBorder {
     uint8_t bottom_cb[32], right_cb[32], bottom_cr[32], right_cr[32];
 } SvtAmdLcuBorder;
 SVT_AMD_API int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder *borders, int n);
+typedef struct SvtAmdLcuBorder16 {
+    uint16_t lcu_x, lcu_y;
+    uint8_t mode_bottom[16], mode_right[16];
+    uint16_t bottom_y[64], right_y[64], bottom_cb[32], right_cb[32], bottom_cr[32], right_cr[32];
+} SvtAmdLcuBorder16;
+SVT_AMD_API int svt_amd_encdec_picture_put_borders16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder16 *borders, int n);
 
 /* ------------------------------------------------------------------------- */
 /* One transform unit of the final encode pass, end to end                     */

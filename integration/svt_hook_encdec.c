@@ -220,7 +220,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         if (e->npending >= e->cap)
             svt_hook_die("encode pass: border list overflow");
         border_from_neighbour_arrays(&e->pending[e->npending++], pcs, contextPtr->encDecTileIndex, lcuOriginX, lcuOriginY, lw, lh);
-        g_ep_borders++;
+        __atomic_add_fetch(&g_ep_borders, 1, __ATOMIC_RELAXED);
         pthread_mutex_unlock(&e->lock);
         return;
     }
@@ -240,7 +240,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         if (svt_amd_encdec_picture_put_borders(lane, e->pic, e->pending, e->npending))
             svt_hook_die("svt_amd_encdec_picture_put_borders");
         e->npending = 0;
-        g_ep_puts++;
+        __atomic_add_fetch(&g_ep_puts, 1, __ATOMIC_RELAXED);
     }
     pthread_mutex_unlock(&e->lock);
     if (svt_amd_encode_lcus(lane, e->pic, w, 1, &t_serve->res))

@@ -2,8 +2,9 @@
  * TEST INFRASTRUCTURE ONLY (oracle/): link-time interposer around the REFERENCE's EncodePass (Codec/EbCodingLoop.c:2989),
  * compiled only into oracle/_ref/libsvtref.so with -Wl,--wrap=EncodePass.
  *
- * When SVT_REF_ENCODEPASS_DUMP names a file, every call on an LCU whose coding units are all intra 2Nx2N units of 8..32 (8-bit,
- * 4:2:0) is recorded: BEFORE the call the final coding-unit list of the LCU and its source samples, in the layout of the product's
+ * When SVT_REF_ENCODEPASS_DUMP names a file, every call on an LCU whose coding units are all intra 2Nx2N units of 8..32 (4:2:0;
+ * 8-bit encodes in EpRecord, 10-bit encodes - EncodePass with is16bit - in EpRecord16 with 16-bit source and reconstruction) is
+ * recorded: BEFORE the call the final coding-unit list of the LCU and its source samples, in the layout of the product's
  * encode-pass input contract (SvtAmdLcuWork, include/svt_hevc_amd.h); AFTER it what the reference produced, in the layout of the
  * output contract (SvtAmdLcuResult): TransformUnit_t cbf / isOnlyDc / nzCoefCount, LargestCodingUnit_t.quantizedCoeff and the
  * LCU of the reconstruction buffer (run the encoder with the loop filters off, `-dlf 1 -sao 0`, so that the buffer still holds
@@ -40,6 +41,13 @@ typedef struct EpRecord {
     SvtAmdLcuWork work;
     SvtAmdLcuResult result;
 } EpRecord;
+typedef struct EpRecord16 { /* same head; record_size tells them apart */
+    uint32_t magic, record_size;
+    uint64_t picture_number;
+    uint32_t width, height, lcu_index, dlf_off;
+    SvtAmdLcuWork16 work;
+    SvtAmdLcuResult16 result;
+} EpRecord16;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static FILE *g_file;
@@ -80,6 +88,71 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
     return 1;
 }
 
+/* units' QPs and what the reference left in the TransformUnit_t records, after the call */
+static void fill_after(SvtAmdLcuCu *cus, int n, SvtAmdLcuCuResult *out, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr)
+{
+    for (int i = 0; i < n; i++) {
+        SvtAmdLcuCu *u = &cus[i];
+        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[u->leaf_index];
+        const TransformUnit_t *tu = &cu->transformUnitArray[0];
+        u->qp = (uint8_t)cu->qp;
+        const EB_S8 qs = (EB_S8)CLIP3((EB_S8)MIN_QP_VALUE, (EB_S8)MAX_CHROMA_MAP_QP_VALUE, (EB_S8)(cu->qp + pcs->cbQpOffset + pcs->sliceCbQpOffset));
+        u->chroma_qp = MapChromaQp((EB_U8)qs);
+        SvtAmdLcuCuResult *o = &out[i];
+        o->cbf[0] = tu->lumaCbf, o->cbf[1] = tu->cbCbf, o->cbf[2] = tu->crCbf;
+        for (int p = 0; p < 3; p++)
+            o->only_dc[p] = tu->isOnlyDc[p], o->nz[p] = tu->nzCoefCount[p];
+    }
+}
+
+/* 10-bit encodes: the source of the LCU is what EncodePassPackLcu left in contextPtr->inputSample16bitBuffer (64-pitch luma, 32-pitch
+ * chroma), the reconstruction lives in the 16-bit picture buffers */
+static void encode_pass_16bit(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
+                              EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
+{
+    EpRecord16 *r = (EpRecord16 *)calloc(1, sizeof(*r));
+    if (r && !fill_work((SvtAmdLcuWork *)&r->work /* same head */, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY)) {
+        free(r);
+        r = NULL;
+    }
+    __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+    if (!r)
+        return;
+    const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
+    r->magic = EP_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->picture_number = pcs->pictureNumber;
+    r->width = scs->lumaWidth, r->height = scs->lumaHeight, r->lcu_index = tbAddr;
+    r->dlf_off = scs->staticConfig.disableDlfFlag;
+    fill_after(r->work.cu, r->work.num_cus, r->result.cu, pcs, lcuPtr);
+    const EbPictureBufferDesc_t *in = contextPtr->inputSample16bitBuffer;
+    for (EB_U32 y = 0; y < lh; y++)
+        memcpy(r->work.src_y + y * 64, (const uint16_t *)in->bufferY + (size_t)y * in->strideY, lw * 2);
+    for (EB_U32 y = 0; y < lh / 2; y++) {
+        memcpy(r->work.src_cb + y * 32, (const uint16_t *)in->bufferCb + (size_t)y * in->strideCb, lw);
+        memcpy(r->work.src_cr + y * 32, (const uint16_t *)in->bufferCr + (size_t)y * in->strideCr, lw);
+    }
+    const EbPictureBufferDesc_t *q = lcuPtr->quantizedCoeff;
+    for (int y = 0; y < 64; y++)
+        memcpy(r->result.coeff_y + y * 64, (const int16_t *)q->bufferY + (size_t)y * q->strideY, 128);
+    for (int y = 0; y < 32; y++) {
+        memcpy(r->result.coeff_cb + y * 32, (const int16_t *)q->bufferCb + (size_t)y * q->strideCb, 64);
+        memcpy(r->result.coeff_cr + y * 32, (const int16_t *)q->bufferCr + (size_t)y * q->strideCr, 64);
+    }
+    const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag
+                                           ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture16bit
+                                           : pcs->reconPicture16bitPtr;
+    for (EB_U32 y = 0; y < lh; y++)
+        memcpy(r->result.rec_y + y * 64, (const uint16_t *)rec->bufferY + (size_t)(rec->originY + lcuOriginY + y) * rec->strideY + rec->originX + lcuOriginX, lw * 2);
+    for (EB_U32 y = 0; y < lh / 2; y++) {
+        memcpy(r->result.rec_cb + y * 32, (const uint16_t *)rec->bufferCb + (size_t)((rec->originY + lcuOriginY) / 2 + y) * rec->strideCb + (rec->originX + lcuOriginX) / 2, lw);
+        memcpy(r->result.rec_cr + y * 32, (const uint16_t *)rec->bufferCr + (size_t)((rec->originY + lcuOriginY) / 2 + y) * rec->strideCr + (rec->originX + lcuOriginX) / 2, lw);
+    }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_file);
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+}
+
 void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
                        EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
 {
@@ -93,6 +166,10 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         pthread_mutex_unlock(&g_lock);
     }
     EpRecord *r = NULL;
+    if (g_state > 0 && contextPtr->is16bit && contextPtr->colorFormat == EB_YUV420) {
+        encode_pass_16bit(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+        return;
+    }
     if (g_state > 0 && !contextPtr->is16bit && contextPtr->colorFormat == EB_YUV420 && (r = (EpRecord *)calloc(1, sizeof(*r))) != NULL) {
         if (!fill_work(&r->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY)) {
             free(r);

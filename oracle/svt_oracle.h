@@ -268,5 +268,7 @@ void svt_oracle_full_loop_chroma_cabac(const SvtAmdCabacCost *cost, const SvtAmd
 /* The coding-unit loop of EncodePass for an LCU of intra 2Nx2N units (svt_oracle_encodepass.c): picture state in / out */
 void svt_oracle_encode_lcu(uint8_t *const rec[3], const uint32_t pitch[3], uint8_t *map, uint32_t mapPitch, uint32_t width, uint32_t height,
                            const SvtAmdLcuWork *W, SvtAmdLcuResult *R);
+void svt_oracle_encode_lcu16(uint16_t *const rec[3], const uint32_t pitch[3], uint8_t *map, uint32_t mapPitch, uint32_t width, uint32_t height,
+                             const SvtAmdLcuWork16 *W, SvtAmdLcuResult16 *R);
 
 #endif

@@ -49,8 +49,12 @@ struct SvtAmdEncDecPicture {
 };
 
 typedef SvtAmdLcuCu LcuCu;
-typedef SvtAmdLcuWork LcuWork;
-typedef SvtAmdLcuResult LcuResult;
+/* the contract structs of a sample type */
+template <typename T> struct EpTypes;
+template <> struct EpTypes<uint8_t> { typedef SvtAmdLcuWork Work; typedef SvtAmdLcuResult Result; typedef SvtAmdLcuBorder Border; };
+template <> struct EpTypes<uint16_t> { typedef SvtAmdLcuWork16 Work; typedef SvtAmdLcuResult16 Result; typedef SvtAmdLcuBorder16 Border; };
+static_assert(offsetof(SvtAmdLcuWork, src_y) == offsetof(SvtAmdLcuWork16, src_y) && offsetof(SvtAmdLcuResult, rec_y) == offsetof(SvtAmdLcuResult16, rec_y),
+              "the 8- and 16-bit contracts share their heads");
 
 __device__ __forceinline__ int ep_mode_at(const EpPicture &P, int px, int py)
 {
@@ -69,7 +73,7 @@ struct EpLocal {
     T y[65 * PY];
     T c[2][33 * PC];
     uint8_t mode[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
-    uint8_t src_y[64 * 64], src_c[2][32 * 32];
+    T src_y[64 * 64], src_c[2][32 * 32];
     __device__ __forceinline__ T *at(int p, int x, int y_) { return p == 0 ? &y[(y_ + 1) * PY + X0 + x] : &c[p - 1][(y_ + 1) * PC + X0 + x]; }
     __device__ __forceinline__ int pitch(int p) const { return p == 0 ? PY : PC; }
     /* mode type at luma sample (x, y) relative to the LCU: what lies below the LCU, right of it (from its first row on) or right of
@@ -86,7 +90,7 @@ struct EpLocal {
 /* The intra reference of the unit (availability, substitution, smoothing) and the three predicted blocks, written into the local
  * reconstruction planes at the unit's position - k_intra_pu (intra_kernels.hip) with the neighbours read from the LCU in LDS. */
 template <typename T>
-__device__ void ep_intra_predict(EpLocal<T> &L, const LcuWork &W, const LcuCu &cu, int t, int16_t (*border)[132], int16_t (*ref)[132], uint8_t *ok,
+__device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work &W, const LcuCu &cu, int t, int16_t (*border)[132], int16_t (*ref)[132], uint8_t *ok,
                                  int *s_small /* [0] first group, [1..3] dc */)
 {
     constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, mid = sizeof(T) == 1 ? 128 : 512, thr = sizeof(T) == 1 ? 8 : 32;
@@ -185,7 +189,7 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const LcuWork &W, const LcuCu &c
  * src: source block (pitch srcPitch); rec: prediction in, reconstruction out; coeff: LargestCodingUnit_t.quantizedCoeff position.
  * Returns (lane 0) nz | only_dc << 16. */
 template <int N, typename T>
-__device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const uint8_t *src, int srcPitch, T *rec, size_t recPitch, int16_t *coeff,
+__device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const T *src, int srcPitch, T *rec, size_t recPitch, int16_t *coeff,
                                                    int coeffPitch, int16_t *tile, int qp, int slice_type, uint32_t dz_offset, bool luma)
 {
     constexpr int P = TxRegTile<N>::PITCH;
@@ -265,7 +269,7 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const uin
 /* lane = lane of the wave; the unit lives on lanes 0..n-1, the rest of the wave are idle virtual units with tiles of their own (the
  * register transform exchanges rows through the unit's LDS tile and every lane takes part in the wave barriers) */
 template <typename T>
-__device__ __forceinline__ uint32_t ep_encode_plane(int n, int lane, const uint8_t *src, int srcPitch, T *rec, size_t recPitch,
+__device__ __forceinline__ uint32_t ep_encode_plane(int n, int lane, const T *src, int srcPitch, T *rec, size_t recPitch,
                                                     int16_t *coeff, int coeffPitch, int16_t *tiles, int qp, int slice_type, uint32_t dz, bool luma)
 {
     uint32_t o;
@@ -287,7 +291,7 @@ struct EpShared {
 
 /* the coding-unit loop of one LCU, by one workgroup of 256 threads */
 template <typename T>
-__device__ void ep_encode_lcu(const EpPicture &P, const LcuWork &W, LcuResult &R, EpShared &S, EpLocal<T> &L)
+__device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Work &W, typename EpTypes<T>::Result &R, EpShared &S, EpLocal<T> &L)
 {
     int16_t (*border)[132] = S.border, (*ref)[132] = S.ref;
     uint8_t *ok = S.ok;
@@ -320,7 +324,7 @@ __device__ void ep_encode_lcu(const EpPicture &P, const LcuWork &W, LcuResult &R
         if (gx >= 0 && gy >= 0 && gx < pw && gy < ph) /* what is not there is never marked available */
             *L.at(p, x, y) = rp[p][(size_t)gy * P.pitch[p] + gx];
     }
-    for (int i = t; i < (64 * 64 + 2 * 32 * 32) / 4; i += 256) {
+    for (int i = t; i < (64 * 64 + 2 * 32 * 32) * (int)sizeof(T) / 4; i += 256) {
         const uint32_t v = ((const uint32_t *)W.src_y)[i]; /* src_y, src_cb, src_cr are contiguous in the contract */
         ((uint32_t *)L.src_y)[i] = v;
     }
@@ -336,10 +340,11 @@ __device__ void ep_encode_lcu(const EpPicture &P, const LcuWork &W, LcuResult &R
             if (wave < 3) {
                 const int p = wave, n = p ? N >> 1 : N;
                 const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
-                const uint8_t *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
+                const T *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
                 int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
                 const uint32_t o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[p],
-                                                      p ? cu.chroma_qp : cu.qp, W.slice_type, p ? 0u : cu.dz_offset, p == 0);
+                                                      (p ? cu.chroma_qp : cu.qp) + (sizeof(T) == 2 ? 12 : 0) /* QP_BD_OFFSET, EbCodingLoop.c:1307 */,
+                                                      W.slice_type, p ? 0u : cu.dz_offset, p == 0);
                 if (lane == 0) {
                     R.cu[ci].nz[p] = (uint16_t)(o & 0xffff);
                     R.cu[ci].cbf[p] = (o & 0xffff) != 0;
@@ -364,10 +369,10 @@ __device__ void ep_encode_lcu(const EpPicture &P, const LcuWork &W, LcuResult &R
             const T *q = L.at(p, x, y);
             const int gx = (p ? W.lcu_x >> 1 : W.lcu_x) + x, gy = (p ? W.lcu_y >> 1 : W.lcu_y) + y;
             T *g = wp[p] + (size_t)gy * P.pitch[p] + gx;
-            uint8_t *r = (p == 0 ? R.rec_y : p == 1 ? R.rec_cb : R.rec_cr) + y * (p ? 32 : 64) + x;
+            T *r = (p == 0 ? R.rec_y : p == 1 ? R.rec_cb : R.rec_cr) + y * (p ? 32 : 64) + x;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                g[k] = q[k], r[k] = (uint8_t)q[k];
+                g[k] = q[k], r[k] = q[k];
         }
     }
     for (int i = t; i < 16 * 16; i += 256) {
@@ -382,7 +387,8 @@ __device__ void ep_encode_lcu(const EpPicture &P, const LcuWork &W, LcuResult &R
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const LcuWork *__restrict__ works, LcuResult *__restrict__ results)
+__global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const typename EpTypes<T>::Work *__restrict__ works,
+                                                    typename EpTypes<T>::Result *__restrict__ results)
 {
     __shared__ EpShared S;
     __shared__ EpLocal<T> L;
@@ -398,7 +404,8 @@ __global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const LcuWork *
  * cycles and starve the workgroups that do the work - measured: 20x slower) and acquires ONCE before it reads its neighbours.
  * done[] holds the epoch of the call that finished the LCU. */
 template <typename T>
-__global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const LcuWork *__restrict__ works, LcuResult *__restrict__ results, int nlcu,
+__global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typename EpTypes<T>::Work *__restrict__ works,
+                                                        typename EpTypes<T>::Result *__restrict__ results, int nlcu,
                                                         int wl, unsigned *ticket, unsigned *done, const unsigned *__restrict__ order, unsigned epoch)
 {
     __shared__ EpShared S;
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const LcuWo
         if ((int)s_ticket >= nlcu)
             return;
         const int lcu = (int)order[s_ticket];
-        const LcuWork &W = works[lcu];
+        const typename EpTypes<T>::Work &W = works[lcu];
         const unsigned long long w0 = P.prof ? __builtin_readcyclecounter() : 0;
         if (threadIdx.x == 0) {
             const int x = W.lcu_x >> 6;
@@ -443,8 +450,8 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const LcuWo
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
 extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width, uint16_t height, int bytes_per_sample, SvtAmdEncDecPicture **out)
 {
-    if (!ctx || !out || width < 8 || height < 8 || (width & 7) || (height & 7) || bytes_per_sample != 1) {
-        svt_amd_set_error("svt_amd_encdec_picture_create: bad parameter (8-bit pictures, dimensions multiples of 8)");
+    if (!ctx || !out || width < 8 || height < 8 || (width & 7) || (height & 7) || (bytes_per_sample != 1 && bytes_per_sample != 2)) {
+        svt_amd_set_error("svt_amd_encdec_picture_create: bad parameter (1 or 2 bytes per sample, dimensions multiples of 8)");
         return SVT_AMD_ERR_BAD_PARAM;
     }
     HIP_TRY(hipSetDevice(ctx->device));
@@ -518,7 +525,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
 
 /* hip_encdec_segment: works / results are HOST arrays of n LCUs that do not depend on each other (one wavefront step); blocking.
  * Contexts (lanes) may call concurrently for different LCUs of the same picture as long as the wavefront order holds between calls. */
-static int ep_validate(const SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n, const char *who)
+template <typename WorkT>
+static int ep_validate(const SvtAmdEncDecPicture *pic, const WorkT *works, int n, const char *who)
 {
     for (int i = 0; i < n; i++) {
         if (works[i].num_cus > SVT_AMD_LCU_MAX_CUS || works[i].lcu_x >= pic->d.width || works[i].lcu_y >= pic->d.height || (works[i].lcu_x & 63) ||
@@ -538,32 +546,55 @@ static int ep_validate(const SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *work
     return SVT_AMD_OK;
 }
 
-extern "C" int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n, SvtAmdLcuResult *results)
+template <typename T>
+static int encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, int n, typename EpTypes<T>::Result *results,
+                       const char *who)
 {
+    typedef typename EpTypes<T>::Work WorkT;
+    typedef typename EpTypes<T>::Result ResultT;
     if (!ctx || !pic || !works || !results || n < 1 || n > 1024)
         return SVT_AMD_ERR_BAD_PARAM;
-    int rv = ep_validate(pic, works, n, "svt_amd_encode_lcus");
+    if (pic->d.bps != sizeof(T)) {
+        svt_amd_set_error("%s: the picture holds %u-byte samples", who, pic->d.bps);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    int rv = ep_validate(pic, works, n, who);
     if (rv)
         return rv;
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t *d = nullptr;
-    const size_t wb = sizeof(SvtAmdLcuWork) * (size_t)n, rb = sizeof(SvtAmdLcuResult) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
+    const size_t wb = sizeof(WorkT) * (size_t)n, rb = sizeof(ResultT) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
     int rc = svt_amd_ctx_scratch(ctx, wba + rb, &d);
     if (rc)
         return rc;
     HIP_TRY(hipMemcpyAsync(d, works, wb, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_encode_lcu<uint8_t>, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const LcuWork *)d, (LcuResult *)(d + wba));
+    hipLaunchKernelGGL(k_encode_lcu<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const WorkT *)d, (ResultT *)(d + wba));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d + wba, rb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
 }
+extern "C" int svt_amd_encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, int n, SvtAmdLcuResult *results)
+{
+    return encode_lcus<uint8_t>(ctx, pic, works, n, results, "svt_amd_encode_lcus");
+}
+extern "C" int svt_amd_encode_lcus16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, int n, SvtAmdLcuResult16 *results)
+{
+    return encode_lcus<uint16_t>(ctx, pic, works, n, results, "svt_amd_encode_lcus16");
+}
 
 /* One call per picture: works / results are HOST arrays of ALL LCUs of the picture in raster order; the wavefront runs on the
  * device (k_encode_picture).  d_works / d_results (optional, device) replace the host arrays: nothing crosses PCIe then. */
-static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results,
-                          const SvtAmdLcuWork *d_works, SvtAmdLcuResult *d_results, int parallel_tiles)
+template <typename T>
+static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, typename EpTypes<T>::Result *results,
+                          const typename EpTypes<T>::Work *d_works, typename EpTypes<T>::Result *d_results, int parallel_tiles)
 {
+    typedef typename EpTypes<T>::Work WorkT;
+    typedef typename EpTypes<T>::Result ResultT;
+    if (pic->d.bps != sizeof(T)) {
+        svt_amd_set_error("svt_amd_encode_picture: the picture holds %u-byte samples", pic->d.bps);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
     const int n = pic->nlcu, wl = (pic->d.width + 63) / 64;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!d_works) {
@@ -579,12 +610,12 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const Sv
         for (int i = 0; i < n; i++)
             parallel_tiles += works[i].tile_left && works[i].tile_top;
         uint8_t *d = nullptr;
-        const size_t wb = sizeof(SvtAmdLcuWork) * (size_t)n, rb = sizeof(SvtAmdLcuResult) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
+        const size_t wb = sizeof(WorkT) * (size_t)n, rb = sizeof(ResultT) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
         int rc = svt_amd_ctx_scratch(ctx, wba + rb, &d);
         if (rc)
             return rc;
         HIP_TRY(hipMemcpyAsync(d, works, wb, hipMemcpyHostToDevice, ctx->stream));
-        d_works = (const SvtAmdLcuWork *)d, d_results = (SvtAmdLcuResult *)(d + wba);
+        d_works = (const WorkT *)d, d_results = (ResultT *)(d + wba);
     }
     pic->epoch++;
     HIP_TRY(hipMemsetAsync(pic->d_sync, 0, sizeof(unsigned), ctx->stream));              /* ticket counter */
@@ -594,11 +625,10 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const Sv
     const int hl = (pic->d.height + 63) / 64;
     int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (parallel_tiles > 0 ? parallel_tiles : 1) + 1;
     grid = grid > n ? n : grid > 512 ? 512 : grid;
-    hipLaunchKernelGGL(k_encode_picture<uint8_t>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, (const LcuWork *)d_works,
-                       (LcuResult *)d_results, n, wl, pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+    hipLaunchKernelGGL(k_encode_picture<T>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, d_works, d_results, n, wl, pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
     HIP_TRY(hipGetLastError());
     if (results)
-        HIP_TRY(hipMemcpyAsync(results, d_results, sizeof(SvtAmdLcuResult) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(results, d_results, sizeof(ResultT) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     return SVT_AMD_OK;
 }
 
@@ -606,7 +636,17 @@ extern "C" int svt_amd_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *p
 {
     if (!ctx || !pic || !works || !results)
         return SVT_AMD_ERR_BAD_PARAM;
-    int rc = encode_picture(ctx, pic, works, results, nullptr, nullptr, 0);
+    int rc = encode_picture<uint8_t>(ctx, pic, works, results, nullptr, nullptr, 0);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results)
+{
+    if (!ctx || !pic || !works || !results)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int rc = encode_picture<uint16_t>(ctx, pic, works, results, nullptr, nullptr, 0);
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -620,13 +660,14 @@ extern "C" int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPic
 {
     if (!ctx || !pic || !d_works || !d_results || tiles < 1)
         return SVT_AMD_ERR_BAD_PARAM;
-    return encode_picture(ctx, pic, nullptr, nullptr, d_works, d_results, tiles);
+    return encode_picture<uint8_t>(ctx, pic, nullptr, nullptr, d_works, d_results, tiles);
 }
 
 /* ---- LCUs encoded by the host: their last row / column and edge mode types enter the device picture --------------------------- */
-__global__ __launch_bounds__(256) void k_put_borders(EpPicture P, const SvtAmdLcuBorder *B)
+template <typename T>
+__global__ __launch_bounds__(256) void k_put_borders(EpPicture P, const typename EpTypes<T>::Border *B)
 {
-    const SvtAmdLcuBorder &b = B[blockIdx.x];
+    const typename EpTypes<T>::Border &b = B[blockIdx.x];
     const int t = threadIdx.x;
     const int lw = min(64, (int)P.width - (int)b.lcu_x), lh = min(64, (int)P.height - (int)b.lcu_y);
     /* 0..63 bottom Y, 64..127 right Y, 128..159 / 160..191 bottom / right Cb, 192..223 / 224..255 Cr */
@@ -634,18 +675,20 @@ __global__ __launch_bounds__(256) void k_put_borders(EpPicture P, const SvtAmdLc
     const bool right = e >= n;
     const int i = right ? e - n : e, w = p ? lw >> 1 : lw, h = p ? lh >> 1 : lh;
     const int x0 = p ? b.lcu_x >> 1 : b.lcu_x, y0 = p ? b.lcu_y >> 1 : b.lcu_y;
-    const uint8_t *src = p == 0 ? (right ? b.right_y : b.bottom_y) : p == 1 ? (right ? b.right_cb : b.bottom_cb) : (right ? b.right_cr : b.bottom_cr);
+    const T *src = p == 0 ? (right ? b.right_y : b.bottom_y) : p == 1 ? (right ? b.right_cb : b.bottom_cb) : (right ? b.right_cr : b.bottom_cr);
     if (i < (right ? h : w))
-        P.rec[p][right ? (size_t)(y0 + i) * P.pitch[p] + x0 + w - 1 : (size_t)(y0 + h - 1) * P.pitch[p] + x0 + i] = src[i];
+        ((T *)P.rec[p])[right ? (size_t)(y0 + i) * P.pitch[p] + x0 + w - 1 : (size_t)(y0 + h - 1) * P.pitch[p] + x0 + i] = src[i];
     if (t < 16 && t < (lw >> 2))
         P.mode_map[(size_t)((b.lcu_y + lh - 1) >> 2) * P.map_pitch + (b.lcu_x >> 2) + t] = b.mode_bottom[t];
     if (t >= 16 && t < 32 && t - 16 < (lh >> 2))
         P.mode_map[(size_t)((b.lcu_y >> 2) + t - 16) * P.map_pitch + ((b.lcu_x + lw - 1) >> 2)] = b.mode_right[t - 16];
 }
 
-extern "C" int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder *borders, int n)
+template <typename T>
+static int put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Border *borders, int n)
 {
-    if (!ctx || !pic || !borders || n < 1 || n > 4096)
+    typedef typename EpTypes<T>::Border BorderT;
+    if (!ctx || !pic || !borders || n < 1 || n > 4096 || pic->d.bps != sizeof(T))
         return SVT_AMD_ERR_BAD_PARAM;
     for (int i = 0; i < n; i++)
         if (borders[i].lcu_x >= pic->d.width || borders[i].lcu_y >= pic->d.height || ((borders[i].lcu_x | borders[i].lcu_y) & 63)) {
@@ -654,14 +697,22 @@ extern "C" int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncD
         }
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t *d = nullptr;
-    int rc = svt_amd_ctx_scratch(ctx, sizeof(SvtAmdLcuBorder) * (size_t)n, &d);
+    int rc = svt_amd_ctx_scratch(ctx, sizeof(BorderT) * (size_t)n, &d);
     if (rc)
         return rc;
-    HIP_TRY(hipMemcpyAsync(d, borders, sizeof(SvtAmdLcuBorder) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_put_borders, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const SvtAmdLcuBorder *)d);
+    HIP_TRY(hipMemcpyAsync(d, borders, sizeof(BorderT) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_put_borders<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const BorderT *)d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
+}
+extern "C" int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder *borders, int n)
+{
+    return put_borders<uint8_t>(ctx, pic, borders, n);
+}
+extern "C" int svt_amd_encdec_picture_put_borders16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder16 *borders, int n)
+{
+    return put_borders<uint16_t>(ctx, pic, borders, n);
 }
 
 /* debug: out == NULL arms the per-LCU clock sums (8 x u64 per LCU: prediction, encode, copy-out, units, wait, start, end, -),

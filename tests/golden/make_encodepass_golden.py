@@ -24,6 +24,10 @@ CASES = {
     "i_noise_200x136_m6": ("noise", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "22"]),
     # smooth content at a high qp: many units without coefficients and many DC-only units (EncodeInvTransform's shortcut)
     "i_motion_320x192_m7_q44": ("motion", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "44"]),
+    # 10-bit encodes (EncodePass with is16bit: EncodeLoop16bit, 16-bit intra prediction, quantiser at qp + 12): "10" in the clip kind
+    "i10_motion_416x240_m9": ("motion10", 416, 240, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "30", "-bit-depth", "10"]),
+    "i10_noise_200x136_m6": ("noise10", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "24", "-bit-depth", "10"]),
+    "i10_motion_320x192_m7_q45": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "45", "-bit-depth", "10"]),
 }
 
 
@@ -31,12 +35,16 @@ def run_case(name):
     kind, w, h, n, seed, args = CASES[name]
     with tempfile.TemporaryDirectory() as td:
         yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "ep.dump")
-        S.write_clip(yuv, kind, w, h, n, seed)
+        if kind.endswith("10"):
+            S.write_clip10(yuv, kind[:-2], w, h, n, seed)
+        else:
+            S.write_clip(yuv, kind, w, h, n, seed)
         cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-dlf", "1", "-sao", "0",
                "-b", os.path.join(td, "out.265")] + args
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_ENCODEPASS_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
-        recs = np.fromfile(dump, dtype=S.EP_RECORD_DTYPE)
-    assert len(recs) and (recs["record_size"] == S.EP_RECORD_DTYPE.itemsize).all(), (len(recs), S.EP_RECORD_DTYPE.itemsize)
+        rdt = S.EP_RECORD16_DTYPE if kind.endswith("10") else S.EP_RECORD_DTYPE
+        recs = np.fromfile(dump, dtype=rdt)
+    assert len(recs) and (recs["record_size"] == rdt.itemsize).all(), (len(recs), rdt.itemsize)
     assert (recs["dlf_off"] == 1).all()
     nl = S.lcu_count(w, h)
     order = np.lexsort((recs["lcu_index"], recs["picture_number"]))

@@ -355,6 +355,14 @@ LCU_BORDER_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("mode_bottom",
                              ("right_y", "u1", 64), ("bottom_cb", "u1", 32), ("right_cb", "u1", 32), ("bottom_cr", "u1", 32), ("right_cr", "u1", 32)])
 EP_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
                             ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("work", LCU_WORK_DTYPE), ("result", LCU_RESULT_DTYPE)])
+LCU_WORK16_DTYPE = np.dtype([(n, LCU_WORK_DTYPE.fields[n][0]) if not n.startswith("src_") else (n, "<u2", LCU_WORK_DTYPE.fields[n][0].shape)
+                             for n in LCU_WORK_DTYPE.names])
+LCU_RESULT16_DTYPE = np.dtype([(n, LCU_RESULT_DTYPE.fields[n][0]) if not n.startswith("rec_") else (n, "<u2", LCU_RESULT_DTYPE.fields[n][0].shape)
+                               for n in LCU_RESULT_DTYPE.names])
+EP_RECORD16_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
+                              ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("work", LCU_WORK16_DTYPE), ("result", LCU_RESULT16_DTYPE)])
+LCU_BORDER16_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("mode_bottom", "u1", 16), ("mode_right", "u1", 16), ("bottom_y", "<u2", 64),
+                               ("right_y", "<u2", 64), ("bottom_cb", "<u2", 32), ("right_cb", "<u2", 32), ("bottom_cr", "<u2", 32), ("right_cr", "<u2", 32)])
 
 
 def plane_checksum(luma):

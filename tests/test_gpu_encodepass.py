@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import svtlib as S
-from test_oracle_encodepass_golden import CASES, compare_lcu, load_case
+from test_oracle_encodepass_golden import CASES, compare_lcu, is16, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -17,14 +17,19 @@ def sig(lib):
     lib.svt_amd_encdec_picture_create.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_int, C.POINTER(C.c_void_p)]
     for f in (lib.svt_amd_encdec_picture_begin, lib.svt_amd_encdec_picture_destroy):
         f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
-    lib.svt_amd_encode_lcus.restype = C.c_int
-    lib.svt_amd_encode_lcus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    for f in (lib.svt_amd_encode_lcus, lib.svt_amd_encode_lcus16):
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    for f in (lib.svt_amd_encdec_picture_put_borders, lib.svt_amd_encdec_picture_put_borders16):
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
 
 def encode(lib, ctx, pic, works):
+    """8-bit or 16-bit contract by the dtype of the work records"""
     works = np.ascontiguousarray(works)
-    out = np.zeros(len(works), S.LCU_RESULT_DTYPE)
-    assert lib.svt_amd_encode_lcus(ctx, pic, works.ctypes.data, len(works), out.ctypes.data) == 0, lib.svt_amd_last_error()
+    wide = works.dtype.itemsize == S.LCU_WORK16_DTYPE.itemsize
+    out = np.zeros(len(works), S.LCU_RESULT16_DTYPE if wide else S.LCU_RESULT_DTYPE)
+    fn = lib.svt_amd_encode_lcus16 if wide else lib.svt_amd_encode_lcus
+    assert fn(ctx, pic, works.ctypes.data, len(works), out.ctypes.data) == 0, lib.svt_amd_last_error()
     return out
 
 
@@ -45,7 +50,7 @@ def test_encode_lcus_matches_reference_records(product, gpu_ctx, name, order):
     wl, hl = (w + 63) // 64, (h + 63) // 64
     nl = wl * hl
     pic = C.c_void_p()
-    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if is16(g) else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
         for first in range(0, len(g["work"]), nl):
             assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
@@ -62,7 +67,7 @@ def test_encode_lcus_matches_reference_records(product, gpu_ctx, name, order):
 
 def border_of(work, res, w, h):
     """what the host hands over after encoding an LCU itself: last row / column of the un-deblocked LCU and the edge mode types"""
-    b = np.zeros(1, S.LCU_BORDER_DTYPE)
+    b = np.zeros(1, S.LCU_BORDER16_DTYPE if res["rec_y"].dtype.itemsize == 2 else S.LCU_BORDER_DTYPE)
     lw, lh = min(64, w - int(work["lcu_x"])), min(64, h - int(work["lcu_y"]))
     b[0]["lcu_x"], b[0]["lcu_y"] = work["lcu_x"], work["lcu_y"]
     b[0]["mode_bottom"][:lw // 4] = 2
@@ -82,19 +87,18 @@ def test_host_encoded_lcus_enter_the_device_picture(product, gpu_ctx, name, host
     and edge mode types are handed to the device; the LCUs the device encodes must still match the records"""
     lib = product
     sig(lib)
-    lib.svt_amd_encdec_picture_put_borders.restype = C.c_int
-    lib.svt_amd_encdec_picture_put_borders.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     g, w, h = load_case(name)
+    put = lib.svt_amd_encdec_picture_put_borders16 if is16(g) else lib.svt_amd_encdec_picture_put_borders
     nl = S.lcu_count(w, h)
     pic = C.c_void_p()
-    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if is16(g) else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
         assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
         ndev = 0
         for k in range(nl):
             if (k & 1) == (host_lcus == "odd"):
                 b = border_of(g["work"][k], g["result"][k], w, h)
-                assert lib.svt_amd_encdec_picture_put_borders(gpu_ctx, pic, b.ctypes.data, 1) == 0, lib.svt_amd_last_error()
+                assert put(gpu_ctx, pic, b.ctypes.data, 1) == 0, lib.svt_amd_last_error()
             else:
                 got = encode(lib, gpu_ctx, pic, g["work"][k:k + 1])
                 compare_lcu(g["work"][k], g["result"][k], got[0], w, h, (name, host_lcus, k))
@@ -208,8 +212,8 @@ def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, q
 
 def sig_picture(lib):
     sig(lib)
-    lib.svt_amd_encode_picture.restype = C.c_int
-    lib.svt_amd_encode_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for f in (lib.svt_amd_encode_picture, lib.svt_amd_encode_picture16):
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -220,14 +224,16 @@ def test_encode_picture_one_call_matches_reference_records(product, gpu_ctx, nam
     g, w, h = load_case(name)
     nl = S.lcu_count(w, h)
     pic = C.c_void_p()
-    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    wide = is16(g)
+    fn = lib.svt_amd_encode_picture16 if wide else lib.svt_amd_encode_picture
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
         for first in range(0, len(g["work"]), nl):
             works = np.ascontiguousarray(g["work"][first:first + nl])
-            got = np.zeros(nl, S.LCU_RESULT_DTYPE)
+            got = np.zeros(nl, S.LCU_RESULT16_DTYPE if wide else S.LCU_RESULT_DTYPE)
             for rep in range(2):    # twice: the completion flags of the first call must not satisfy the second
                 got[:] = 0
-                assert lib.svt_amd_encode_picture(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+                assert fn(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
                 for k in range(nl):
                     compare_lcu(works[k], g["result"][first + k], got[k], w, h, (name, "picture", rep, k))
     finally:
@@ -258,7 +264,7 @@ def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):
     lib = product
     sig(lib)
     pic = C.c_void_p()
-    assert lib.svt_amd_encdec_picture_create(gpu_ctx, 128, 64, 2, C.byref(pic)) != 0      # 10-bit: not in this revision
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, 128, 64, 4, C.byref(pic)) != 0      # 1 or 2 bytes per sample
     assert lib.svt_amd_encdec_picture_create(gpu_ctx, 128, 64, 1, C.byref(pic)) == 0
     try:
         wk = np.zeros(1, S.LCU_WORK_DTYPE)
@@ -268,5 +274,9 @@ def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):
         assert lib.svt_amd_encode_lcus(gpu_ctx, pic, wk.ctypes.data, 1, out.ctypes.data) != 0
         wk[0]["cu"][0]["size"], wk[0]["cu"][0]["pred_mode"] = 64, 2                        # a 64x64 unit
         assert lib.svt_amd_encode_lcus(gpu_ctx, pic, wk.ctypes.data, 1, out.ctypes.data) != 0
+        wk16, out16 = np.zeros(1, S.LCU_WORK16_DTYPE), np.zeros(1, S.LCU_RESULT16_DTYPE)   # the 16-bit contract on an 8-bit picture
+        wk16[0]["num_cus"] = 1
+        wk16[0]["cu"][0]["size"], wk16[0]["cu"][0]["pred_mode"] = 32, 2
+        assert lib.svt_amd_encode_lcus16(gpu_ctx, pic, wk16.ctypes.data, 1, out16.ctypes.data) != 0
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)

@@ -19,6 +19,11 @@ def load_case(name):
     return g, w, h
 
 
+def is16(g):
+    """10-bit encodes (EncodePass with is16bit) are recorded with 16-bit source / reconstruction samples"""
+    return g["work"].dtype.itemsize == S.LCU_WORK16_DTYPE.itemsize
+
+
 def compare_lcu(work, want, got, w, h, tag):
     """cbf / DC-only / counts of the units, the quantised coefficients of every unit area and the LCU's reconstruction inside the picture"""
     n = int(work["num_cus"])
@@ -39,13 +44,17 @@ def compare_lcu(work, want, got, w, h, tag):
 
 
 def test_have_cases():
-    assert len(CASES) >= 3
+    assert len(CASES) >= 6 and sum("i10_" in c for c in CASES) >= 3
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_fixture_is_what_the_contract_says(name):
     g, w, h = load_case(name)
-    assert g["work"].dtype.itemsize == S.LCU_WORK_DTYPE.itemsize == 7184 and g["result"].dtype.itemsize == S.LCU_RESULT_DTYPE.itemsize == 19200
+    if is16(g):
+        assert g["work"].dtype.itemsize == S.LCU_WORK16_DTYPE.itemsize == 13328 and g["result"].dtype.itemsize == S.LCU_RESULT16_DTYPE.itemsize == 25344
+        assert int(g["work"]["src_y"].max()) > 255      # really 10-bit samples
+    else:
+        assert g["work"].dtype.itemsize == S.LCU_WORK_DTYPE.itemsize == 7184 and g["result"].dtype.itemsize == S.LCU_RESULT_DTYPE.itemsize == 19200
     nl = S.lcu_count(w, h)
     assert len(g["work"]) % nl == 0
     for wk in g["work"]:
@@ -63,19 +72,20 @@ def test_fixture_is_what_the_contract_says(name):
 @pytest.mark.parametrize("name", CASES)
 def test_encode_lcu_oracle_matches_reference(oracle, name):
     g, w, h = load_case(name)
-    oracle.svt_oracle_encode_lcu.restype = None
-    oracle.svt_oracle_encode_lcu.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
-                                             C.c_void_p, C.c_void_p]
+    fn = oracle.svt_oracle_encode_lcu16 if is16(g) else oracle.svt_oracle_encode_lcu
+    fn.restype = None
+    fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if is16(g) else (np.uint8, S.LCU_RESULT_DTYPE)
     nl = S.lcu_count(w, h)
     pitches = (w + 32, w // 2 + 16, w // 2 + 16)
     pb = (C.c_uint32 * 3)(*pitches)
     for first in range(0, len(g["work"]), nl):
         # poisoned picture: a sample the restatement may not read yet shows up as a mismatch
-        rec = [np.full((hh, p), 0xA5, np.uint8) for hh, p in zip((h, h // 2, h // 2), pitches)]
+        rec = [np.full((hh, p), 0xA5, sdt) for hh, p in zip((h, h // 2, h // 2), pitches)]
         mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
         rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
         for k in range(first, first + nl):
             work = np.ascontiguousarray(g["work"][k:k + 1])
-            got = np.zeros(1, S.LCU_RESULT_DTYPE)
-            oracle.svt_oracle_encode_lcu(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got.ctypes.data)
+            got = np.zeros(1, rdt)
+            fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got.ctypes.data)
             compare_lcu(work[0], g["result"][k], got[0], w, h, (name, int(g["picture_number"][k]), int(g["lcu_index"][k])))
