@@ -3,8 +3,8 @@
  * include/svt_hevc_amd.h "Device-resident encode pass"), enabled with SVT_HOOK_ENCODEPASS=1.
  *
  * EncodePass (Codec/EbCodingLoop.c:2989) is interposed with -Wl,--wrap=EncodePass.  For an LCU inside what this revision of
- * svt_amd_encode_lcus() covers - 8-bit 4:2:0, every coding unit an intra 2Nx2N unit of 8..32, no delta-QP / masking tools, plain
- * quantiser - the binding
+ * svt_amd_encode_lcus() / svt_amd_encode_lcus16() covers - 4:2:0, 8-bit or 10-bit (EncodePass with is16bit), every coding unit an
+ * intra 2Nx2N unit of 8..32, no delta-QP / masking tools, plain quantiser - the binding
  *   1. converts the LCU's final coding-unit tree (LargestCodingUnit_t.codedLeafArrayPtr) and its source samples into the input
  *      contract SvtAmdLcuWork,
  *   2. makes ONE device call: intra reference + prediction, residual, transform, quantiser, inverse transform and reconstruction of
@@ -55,15 +55,26 @@ typedef struct {
     uint64_t picture_plus1;      /* picture the device picture was begun for */
     SvtAmdEncDecPicture *pic;
     pthread_mutex_t lock;        /* pending list + the device put of it */
-    SvtAmdLcuBorder *pending;    /* host-encoded LCUs not handed to the device yet */
-    int npending, cap;
+    void *pending;               /* host-encoded LCUs not handed to the device yet: SvtAmdLcuBorder[] or SvtAmdLcuBorder16[] */
+    int npending, cap, wide;
 } EpPictureEntry;
 
 typedef struct {
-    SvtAmdLcuWork work;
-    SvtAmdLcuResult res;
+    union { /* the heads of the 8- and the 16-bit contract are the same */
+        SvtAmdLcuWork work;
+        SvtAmdLcuWork16 work16;
+    };
+    union {
+        SvtAmdLcuResult res;
+        SvtAmdLcuResult16 res16;
+    };
     const LargestCodingUnit_t *lcu;
+    int wide; /* 10-bit encode: the 16-bit members are live */
 } EpServe;
+_Static_assert(offsetof(SvtAmdLcuWork, src_y) == offsetof(SvtAmdLcuWork16, src_y) && offsetof(SvtAmdLcuResult, rec_y) == offsetof(SvtAmdLcuResult16, rec_y),
+               "contract heads");
+void EncodePassPackLcu(SequenceControlSet_t *sequenceControlSetPtr, EbPictureBufferDesc_t *inputPicture, EncDecContext_t *contextPtr,
+                       EB_U32 lcuOriginX, EB_U32 lcuOriginY, EB_U32 lcuWidth, EB_U32 lcuHeight); /* EbCodingLoop.c:2867 */
 
 __thread int svt_hook_ep_active;
 static __thread EpServe *t_serve;
@@ -103,7 +114,7 @@ static void lane_release(SvtAmdContext *lane)
 }
 
 /* the device picture of this PictureControlSet_t, begun for its current picture */
-static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs)
+static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide)
 {
     EpPictureEntry *e = NULL;
     pthread_mutex_lock(&g_ep_lock);
@@ -115,10 +126,11 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
             e = &g_ep_pic[i];
             e->pcs = pcs;
             pthread_mutex_init(&e->lock, NULL);
-            if (svt_amd_encdec_picture_create(lane, (uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight, 1, &e->pic))
+            e->wide = wide;
+            if (svt_amd_encdec_picture_create(lane, (uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight, wide ? 2 : 1, &e->pic))
                 svt_hook_die("svt_amd_encdec_picture_create");
             e->cap = (int)(((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u));
-            e->pending = (SvtAmdLcuBorder *)malloc(sizeof(SvtAmdLcuBorder) * (size_t)e->cap);
+            e->pending = malloc((wide ? sizeof(SvtAmdLcuBorder16) : sizeof(SvtAmdLcuBorder)) * (size_t)e->cap);
             if (!e->pending)
                 svt_hook_die("out of memory (encode-pass border list)");
         }
@@ -172,23 +184,36 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
 }
 
 /* what a host-encoded LCU leaves for its neighbours: the top / left entries of the ep* neighbour arrays over its extent */
-static void border_from_neighbour_arrays(SvtAmdLcuBorder *b, const PictureControlSet_t *pcs, EB_U32 tileIdx, EB_U32 x0, EB_U32 y0, EB_U32 lw,
+static void border_from_neighbour_arrays(void *out, int wide, const PictureControlSet_t *pcs, EB_U32 tileIdx, EB_U32 x0, EB_U32 y0, EB_U32 lw,
                                          EB_U32 lh)
 {
     NeighborArrayUnit_t *mode = pcs->epModeTypeNeighborArray[tileIdx];
-    NeighborArrayUnit_t *na[3] = {pcs->epLumaReconNeighborArray[tileIdx], pcs->epCbReconNeighborArray[tileIdx], pcs->epCrReconNeighborArray[tileIdx]};
-    memset(b, 0, sizeof(*b));
-    b->lcu_x = (uint16_t)x0, b->lcu_y = (uint16_t)y0;
+    NeighborArrayUnit_t *na[3] = {wide ? pcs->epLumaReconNeighborArray16bit[tileIdx] : pcs->epLumaReconNeighborArray[tileIdx],
+                                  wide ? pcs->epCbReconNeighborArray16bit[tileIdx] : pcs->epCbReconNeighborArray[tileIdx],
+                                  wide ? pcs->epCrReconNeighborArray16bit[tileIdx] : pcs->epCrReconNeighborArray[tileIdx]};
+    uint8_t *mb, *mr;
+    void *dst[6]; /* bottom / right of Y, Cb, Cr */
+    if (wide) {
+        SvtAmdLcuBorder16 *b = (SvtAmdLcuBorder16 *)out;
+        memset(b, 0, sizeof(*b));
+        b->lcu_x = (uint16_t)x0, b->lcu_y = (uint16_t)y0, mb = b->mode_bottom, mr = b->mode_right;
+        dst[0] = b->bottom_y, dst[1] = b->right_y, dst[2] = b->bottom_cb, dst[3] = b->right_cb, dst[4] = b->bottom_cr, dst[5] = b->right_cr;
+    } else {
+        SvtAmdLcuBorder *b = (SvtAmdLcuBorder *)out;
+        memset(b, 0, sizeof(*b));
+        b->lcu_x = (uint16_t)x0, b->lcu_y = (uint16_t)y0, mb = b->mode_bottom, mr = b->mode_right;
+        dst[0] = b->bottom_y, dst[1] = b->right_y, dst[2] = b->bottom_cb, dst[3] = b->right_cb, dst[4] = b->bottom_cr, dst[5] = b->right_cr;
+    }
     for (EB_U32 k = 0; k < lw / 4; k++)
-        b->mode_bottom[k] = mode->topArray[GetNeighborArrayUnitTopIndex(mode, x0 + 4 * k)];
+        mb[k] = mode->topArray[GetNeighborArrayUnitTopIndex(mode, x0 + 4 * k)];
     for (EB_U32 k = 0; k < lh / 4; k++)
-        b->mode_right[k] = mode->leftArray[GetNeighborArrayUnitLeftIndex(mode, y0 + 4 * k)];
-    memcpy(b->bottom_y, na[0]->topArray + x0, lw);
-    memcpy(b->right_y, na[0]->leftArray + y0, lh);
-    memcpy(b->bottom_cb, na[1]->topArray + x0 / 2, lw / 2);
-    memcpy(b->right_cb, na[1]->leftArray + y0 / 2, lh / 2);
-    memcpy(b->bottom_cr, na[2]->topArray + x0 / 2, lw / 2);
-    memcpy(b->right_cr, na[2]->leftArray + y0 / 2, lh / 2);
+        mr[k] = mode->leftArray[GetNeighborArrayUnitLeftIndex(mode, y0 + 4 * k)];
+    const size_t bps = wide ? 2 : 1;
+    for (int p = 0; p < 3; p++) {
+        const EB_U32 sh = p ? 1 : 0;
+        memcpy(dst[2 * p], na[p]->topArray + (size_t)(x0 >> sh) * bps, (size_t)(lw >> sh) * bps);
+        memcpy(dst[2 * p + 1], na[p]->leftArray + (size_t)(y0 >> sh) * bps, (size_t)(lh >> sh) * bps);
+    }
 }
 
 void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
@@ -196,7 +221,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
 {
     if (g_ep_state == 0)
         g_ep_state = getenv("SVT_HOOK_ENCODEPASS") ? 1 : -1;
-    if (g_ep_state < 0 || contextPtr->is16bit || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
+    if (g_ep_state < 0 || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
         if (g_ep_state > 0)
             __atomic_add_fetch(&g_ep_cpu_format, 1, __ATOMIC_RELAXED);
         __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
@@ -204,7 +229,8 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     }
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
-    EpPictureEntry *e = picture_entry(lane, scs, pcs);
+    const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
+    EpPictureEntry *e = picture_entry(lane, scs, pcs, wide);
     const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
     if (!t_serve && !(t_serve = (EpServe *)malloc(sizeof(EpServe))))
         svt_hook_die("out of memory (encode-pass staging)");
@@ -219,31 +245,46 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         pthread_mutex_lock(&e->lock);
         if (e->npending >= e->cap)
             svt_hook_die("encode pass: border list overflow");
-        border_from_neighbour_arrays(&e->pending[e->npending++], pcs, contextPtr->encDecTileIndex, lcuOriginX, lcuOriginY, lw, lh);
+        border_from_neighbour_arrays((uint8_t *)e->pending + (size_t)e->npending++ * (wide ? sizeof(SvtAmdLcuBorder16) : sizeof(SvtAmdLcuBorder)), wide,
+                                     pcs, contextPtr->encDecTileIndex, lcuOriginX, lcuOriginY, lw, lh);
         __atomic_add_fetch(&g_ep_borders, 1, __ATOMIC_RELAXED);
         pthread_mutex_unlock(&e->lock);
         return;
     }
     /* source samples of the LCU */
-    const EbPictureBufferDesc_t *in = (const EbPictureBufferDesc_t *)pcs->ParentPcsPtr->enhancedPicturePtr;
+    EbPictureBufferDesc_t *in = (EbPictureBufferDesc_t *)pcs->ParentPcsPtr->enhancedPicturePtr;
     SvtAmdLcuWork *w = &t_serve->work;
-    for (EB_U32 y = 0; y < lh; y++)
-        memcpy(w->src_y + y * 64, in->bufferY + (size_t)(in->originY + lcuOriginY + y) * in->strideY + in->originX + lcuOriginX, lw);
-    for (EB_U32 y = 0; y < lh / 2; y++) {
-        memcpy(w->src_cb + y * 32, in->bufferCb + (size_t)((in->originY + lcuOriginY) / 2 + y) * in->strideCb + (in->originX + lcuOriginX) / 2, lw / 2);
-        memcpy(w->src_cr + y * 32, in->bufferCr + (size_t)((in->originY + lcuOriginY) / 2 + y) * in->strideCr + (in->originX + lcuOriginX) / 2, lw / 2);
+    t_serve->wide = wide;
+    if (wide) { /* the reference packs the 8 + 2 bit planes of the LCU into its 16-bit LCU buffer at the top of EncodePass; do it now */
+        EncodePassPackLcu(scs, in, contextPtr, lcuOriginX, lcuOriginY, lw, lh);
+        const EbPictureBufferDesc_t *s16 = contextPtr->inputSample16bitBuffer;
+        SvtAmdLcuWork16 *w16 = &t_serve->work16;
+        for (EB_U32 y = 0; y < lh; y++)
+            memcpy(w16->src_y + y * 64, (const uint16_t *)s16->bufferY + (size_t)y * s16->strideY, lw * 2);
+        for (EB_U32 y = 0; y < lh / 2; y++) {
+            memcpy(w16->src_cb + y * 32, (const uint16_t *)s16->bufferCb + (size_t)y * s16->strideCb, lw);
+            memcpy(w16->src_cr + y * 32, (const uint16_t *)s16->bufferCr + (size_t)y * s16->strideCr, lw);
+        }
+    } else {
+        for (EB_U32 y = 0; y < lh; y++)
+            memcpy(w->src_y + y * 64, in->bufferY + (size_t)(in->originY + lcuOriginY + y) * in->strideY + in->originX + lcuOriginX, lw);
+        for (EB_U32 y = 0; y < lh / 2; y++) {
+            memcpy(w->src_cb + y * 32, in->bufferCb + (size_t)((in->originY + lcuOriginY) / 2 + y) * in->strideCb + (in->originX + lcuOriginX) / 2, lw / 2);
+            memcpy(w->src_cr + y * 32, in->bufferCr + (size_t)((in->originY + lcuOriginY) / 2 + y) * in->strideCr + (in->originX + lcuOriginX) / 2, lw / 2);
+        }
     }
     /* LCUs the host encoded since the last device call enter the device picture first (under the picture's lock, so that a second
      * thread's LCU cannot overtake a put it depends on) */
     pthread_mutex_lock(&e->lock);
     if (e->npending) {
-        if (svt_amd_encdec_picture_put_borders(lane, e->pic, e->pending, e->npending))
+        if (wide ? svt_amd_encdec_picture_put_borders16(lane, e->pic, (const SvtAmdLcuBorder16 *)e->pending, e->npending)
+                 : svt_amd_encdec_picture_put_borders(lane, e->pic, (const SvtAmdLcuBorder *)e->pending, e->npending))
             svt_hook_die("svt_amd_encdec_picture_put_borders");
         e->npending = 0;
         __atomic_add_fetch(&g_ep_puts, 1, __ATOMIC_RELAXED);
     }
     pthread_mutex_unlock(&e->lock);
-    if (svt_amd_encode_lcus(lane, e->pic, w, 1, &t_serve->res))
+    if (wide ? svt_amd_encode_lcus16(lane, e->pic, &t_serve->work16, 1, &t_serve->res16) : svt_amd_encode_lcus(lane, e->pic, w, 1, &t_serve->res))
         svt_hook_die("svt_amd_encode_lcus");
     lane_release(lane);
     __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
@@ -258,6 +299,27 @@ void __wrap_PictureResidual(EB_U8 *input, EB_U32 inputStride, EB_U8 *pred, EB_U3
 {
     if (!svt_hook_ep_active)
         __real_PictureResidual(input, inputStride, pred, predStride, residual, residualStride, areaWidth, areaHeight);
+}
+
+void __real_PictureResidual16bit(EB_U16 *input, EB_U32 inputStride, EB_U16 *pred, EB_U32 predStride, EB_S16 *residual, EB_U32 residualStride,
+                                 EB_U32 areaWidth, EB_U32 areaHeight);
+void __wrap_PictureResidual16bit(EB_U16 *input, EB_U32 inputStride, EB_U16 *pred, EB_U32 predStride, EB_S16 *residual, EB_U32 residualStride,
+                                 EB_U32 areaWidth, EB_U32 areaHeight)
+{
+    if (!svt_hook_ep_active)
+        __real_PictureResidual16bit(input, inputStride, pred, predStride, residual, residualStride, areaWidth, areaHeight);
+}
+
+/* EncodeLoop16bit's transform (EbCodingLoop.c:1321; the C table of EncodeTransform holds the same Estimate forms for 10-bit) */
+EB_ERRORTYPE __real_EncodeTransform(EB_S16 *residualBuffer, EB_U32 residualStride, EB_S16 *coeffBuffer, EB_U32 coeffStride, EB_U32 transformSize,
+                                    EB_S16 *transformInnerArrayPtr, EB_U32 bitIncrement, EB_BOOL dstTransformFlag, EB_TRANS_COEFF_SHAPE transCoeffShape);
+EB_ERRORTYPE __wrap_EncodeTransform(EB_S16 *residualBuffer, EB_U32 residualStride, EB_S16 *coeffBuffer, EB_U32 coeffStride, EB_U32 transformSize,
+                                    EB_S16 *transformInnerArrayPtr, EB_U32 bitIncrement, EB_BOOL dstTransformFlag, EB_TRANS_COEFF_SHAPE transCoeffShape)
+{
+    if (svt_hook_ep_active)
+        return EB_ErrorNone;
+    return __real_EncodeTransform(residualBuffer, residualStride, coeffBuffer, coeffStride, transformSize, transformInnerArrayPtr, bitIncrement,
+                                  dstTransformFlag, transCoeffShape);
 }
 
 EB_ERRORTYPE __wrap_EstimateTransform(EB_S16 *residualBuffer, EB_U32 residualStride, EB_S16 *coeffBuffer, EB_U32 coeffStride, EB_U32 transformSize,
@@ -297,7 +359,8 @@ void svt_hook_ep_quantize(EncDecContext_t *contextPtr, EB_S16 *quantCoeff, EB_S1
             p = k;
     }
     const EB_U32 n = p > 0 ? u->size / 2u : u->size;
-    if (p < 0 || areaSize != n || coeffStride != (p ? 32u : 64u) || qp != (p ? u->chroma_qp : u->qp) || shape || cleanSparse || masking ||
+    if (p < 0 || areaSize != n || coeffStride != (p ? 32u : 64u) || qp != (EB_U32)(p ? u->chroma_qp : u->qp) + (t_serve->wide ? 12u : 0u) || shape ||
+        cleanSparse || masking ||
         enableCbflag || contouring || dZoffset || !nz)
         svt_hook_die("encode pass: the reference's quantiser call differs from what the device encoded (unit, plane, QP or tool flags)");
     const int16_t *src = (p == 0 ? t_serve->res.coeff_y : p == 1 ? t_serve->res.coeff_cb : t_serve->res.coeff_cr) + (quantCoeff - base[p]);
@@ -313,14 +376,20 @@ void svt_hook_ep_recon(EncDecContext_t *contextPtr, EB_U32 originX, EB_U32 origi
     const SvtAmdLcuCu *u = &t_serve->work.cu[i];
     if (tuSize != u->size || (originX & 63) != u->x || (originY & 63) != u->y)
         svt_hook_die("encode pass: reconstruction call for another unit");
-    EB_U8 *y = recon->bufferY + (size_t)(recon->originY + originY) * recon->strideY + recon->originX + originX;
+    const size_t bps = t_serve->wide ? 2 : 1;
+    const uint8_t *ry = (const uint8_t *)t_serve->res.rec_y, *rcb, *rcr; /* rec_y sits at the same offset in both contracts */
+    if (t_serve->wide)
+        rcb = (const uint8_t *)t_serve->res16.rec_cb, rcr = (const uint8_t *)t_serve->res16.rec_cr;
+    else
+        rcb = t_serve->res.rec_cb, rcr = t_serve->res.rec_cr;
+    EB_U8 *y = recon->bufferY + ((size_t)(recon->originY + originY) * recon->strideY + recon->originX + originX) * bps;
     for (EB_U32 r = 0; r < tuSize; r++)
-        memcpy(y + (size_t)r * recon->strideY, t_serve->res.rec_y + (u->y + r) * 64 + u->x, tuSize);
-    EB_U8 *cb = recon->bufferCb + (size_t)((recon->originY + originY) / 2) * recon->strideCb + (recon->originX + originX) / 2;
-    EB_U8 *cr = recon->bufferCr + (size_t)((recon->originY + originY) / 2) * recon->strideCr + (recon->originX + originX) / 2;
+        memcpy(y + (size_t)r * recon->strideY * bps, ry + ((size_t)(u->y + r) * 64 + u->x) * bps, tuSize * bps);
+    EB_U8 *cb = recon->bufferCb + ((size_t)((recon->originY + originY) / 2) * recon->strideCb + (recon->originX + originX) / 2) * bps;
+    EB_U8 *cr = recon->bufferCr + ((size_t)((recon->originY + originY) / 2) * recon->strideCr + (recon->originX + originX) / 2) * bps;
     for (EB_U32 r = 0; r < tuSize / 2; r++) {
-        memcpy(cb + (size_t)r * recon->strideCb, t_serve->res.rec_cb + (u->y / 2 + r) * 32 + u->x / 2, tuSize / 2);
-        memcpy(cr + (size_t)r * recon->strideCr, t_serve->res.rec_cr + (u->y / 2 + r) * 32 + u->x / 2, tuSize / 2);
+        memcpy(cb + (size_t)r * recon->strideCb * bps, rcb + ((size_t)(u->y / 2 + r) * 32 + u->x / 2) * bps, tuSize / 2 * bps);
+        memcpy(cr + (size_t)r * recon->strideCr * bps, rcr + ((size_t)(u->y / 2 + r) * 32 + u->x / 2) * bps, tuSize / 2 * bps);
     }
 }
 

@@ -331,6 +331,11 @@ ENCODEPASS_CASES = [
     ("motion", 832, 480, 3, ["-encMode", "7", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
     # encMode 4: the encode pass quantises with PM-core, outside the device call - every LCU must be left to the reference code
     ("motion", 416, 240, 2, ["-encMode", "4", "-intra-period", "0"], "none"),
+    # 10-bit encodes: EncodePass with is16bit through the 16-bit contract (all-intra, and random access with host-encoded LCUs)
+    ("motion10", 416, 240, 3, ["-encMode", "9", "-intra-period", "0", "-bit-depth", "10"], "all"),
+    ("noise10", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40", "-bit-depth", "10"], "mixed"),
+    ("motion10c", 640, 384, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-bit-depth", "10",
+                                "-compressed-ten-bit-format", "1"], "some"),
 ]
 
 
@@ -342,7 +347,12 @@ def test_bitstream_and_recon_identical_with_device_resident_encode_pass(tmp_path
     must be byte-identical to the unmodified reference's."""
     import re
     yuv = str(tmp_path / "clip.yuv")
-    S.write_clip(yuv, kind, w, h, n, 7)
+    if kind.endswith("10c"):
+        S.write_clip10_compressed(yuv, kind[:-3], w, h, n, 7)
+    elif kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
     os.environ["SVT_HOOK_ENCODEPASS"] = "1"
     os.environ["SVT_HOOK_REPORT"] = str(tmp_path / "report.txt")
