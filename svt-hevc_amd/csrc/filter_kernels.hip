@@ -274,19 +274,36 @@ __global__ __launch_bounds__(256) void k_sao_gather(const T *__restrict__ input,
     const T *rp = recon + (ptrdiff_t)y0 * reconStride + x0, *ip = input + (ptrdiff_t)y0 * inStride + x0;
     int rs = reconStride, is = inStride;
     if (staged) {
-        for (int i = t; i < lw * lh; i += 256) {
-            const int yy = i / lw, xx = i - yy * lw;
-            tile_r[yy * 64 + xx] = rp[(ptrdiff_t)yy * reconStride + xx];
-            tile_i[yy * 64 + xx] = ip[(ptrdiff_t)yy * inStride + xx];
+        /* dword loads where rows are dword-aligned (LCU origins are; picture strides almost always): a quarter (8-bit) or half
+         * (16-bit) of the load instructions of the per-sample form */
+        constexpr int PER = 4 / (int)sizeof(T);
+        const bool vec = (((uintptr_t)rp | (uintptr_t)ip) & 3) == 0 && ((reconStride * (int)sizeof(T)) & 3) == 0 &&
+                         ((inStride * (int)sizeof(T)) & 3) == 0 && (lw % PER) == 0;
+        if (vec) {
+            const int wq = lw / PER;
+            for (int i = t; i < wq * lh; i += 256) {
+                const int yy = i / wq, xq = i - yy * wq;
+                *(uint32_t *)&tile_r[yy * 64 + xq * PER] = *(const uint32_t *)&rp[(ptrdiff_t)yy * reconStride + xq * PER];
+                *(uint32_t *)&tile_i[yy * 64 + xq * PER] = *(const uint32_t *)&ip[(ptrdiff_t)yy * inStride + xq * PER];
+            }
+        } else {
+            for (int i = t; i < lw * lh; i += 256) {
+                const int yy = i / lw, xx = i - yy * lw;
+                tile_r[yy * 64 + xx] = rp[(ptrdiff_t)yy * reconStride + xx];
+                tile_i[yy * 64 + xx] = ip[(ptrdiff_t)yy * inStride + xx];
+            }
         }
         __syncthreads();
         rp = tile_r, ip = tile_i, rs = 64, is = 64;
     }
     const int total = iw * ih;
+    const bool small = iw >= 1 && iw <= 64 && total <= 64 * 64;
+    const uint32_t rcw = small ? (1u << 20) / (uint32_t)iw + 1u : 0u; /* i / iw == (i * rcw) >> 20 for i < 4352, iw <= 64 (checked exhaustively) */
     for (int i0 = 0; i0 < total; i0 += 256) { /* uniform trip count: whole waves take part in the shuffles below */
         const int i = i0 + t;
         const bool live = i < total;
-        const int yy = live ? i / iw + 1 : 1, xx = live ? i - (yy - 1) * iw + 1 : 1;
+        const int q = small ? (int)(((uint32_t)i * rcw) >> 20) : i / iw;
+        const int yy = live ? q + 1 : 1, xx = live ? i - q * iw + 1 : 1;
         const T *r = rp + yy * rs + xx;
         const int c = r[0];
         int diff = (int)ip[yy * is + xx] - c;

@@ -132,3 +132,83 @@ def test_me_row_bands_equal_full_picture(product, gpu_ctx, w, h, bands):
     one = np.zeros(nl, S.ME_LCU_DTYPE)
     assert lib.svt_amd_me_picture_fetch(gpu_ctx, 3, one.ctypes.data) == 0
     assert np.array_equal(one["pu"][lo:hi], full["pu"][lo:hi])
+
+
+def test_three_lane_pipeline_batch_pack_and_lane_events(product, oracle):
+    """the batched host pipeline bench.py runs (copy-in lane -> compute lane -> copy-out lane under lane events, records packed per
+    batch into device arrays and moved with one copy each): the compact records that arrive in pinned host memory must be the
+    corresponding parts of the blocking per-picture results, for two batches rotating through two buffer sets"""
+    lib = product
+    w, h, B = 448, 328, 3
+    nl = S.lcu_count(w, h)
+    vp = C.c_void_p
+    root = vp()
+    assert lib.svt_amd_context_create(0, 640, 384, 2 * B, C.byref(root)) == 0, lib.svt_amd_last_error()
+    lanes = [vp(), vp(), vp()]
+    try:
+        for lane in lanes:
+            assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
+        lane_in, lane_k, lane_out = lanes
+        p = default_params(w, h, num_lists=2, temporal_layer_index=1, cu8x8_mode=0)
+        op = S.OisParams()
+        op.luma_width, op.luma_height, op.ois_th_set, op.temporal_layer_index = w, h, 1, 1
+        nc = lib.svt_amd_ois_compact_candidates(C.byref(op))
+        me_b, ois_b = S.ME_PU_COUNT * 24, S.ME_PU_COUNT * nc * 4 + 88
+        h_in = vp()
+        assert lib.svt_amd_host_alloc(root, 2 * B * w * h, C.byref(h_in)) == 0
+        frames = [S.gen_luma("motion", w, h, t, 9) for t in range(2 * B)]
+        np.ctypeslib.as_array(C.cast(h_in, C.POINTER(C.c_uint8)), shape=(2 * B * w * h,))[:] = np.concatenate([f.reshape(-1) for f in frames])
+        sets = []
+        for k in range(2):
+            d_stage, d_me, d_ois, h_me, h_ois = vp(), vp(), vp(), vp(), vp()
+            assert lib.svt_amd_device_alloc(lane_in, B * w * h, C.byref(d_stage)) == 0
+            assert lib.svt_amd_device_alloc(lane_k, B * nl * me_b, C.byref(d_me)) == 0 and lib.svt_amd_device_alloc(lane_k, B * nl * ois_b, C.byref(d_ois)) == 0
+            assert lib.svt_amd_host_alloc(lane_out, B * nl * me_b, C.byref(h_me)) == 0 and lib.svt_amd_host_alloc(lane_out, B * nl * ois_b, C.byref(h_ois)) == 0
+            slots = (C.c_int * B)(*[k * B + i for i in range(B)])
+            ptrs = (vp * B)(*[d_stage.value + i * w * h for i in range(B)])
+            jobs, ojobs = (S.MeJob * B)(), (S.OisJob * B)()
+            for i in range(B):
+                jobs[i].params, jobs[i].cur_slot = p, slots[i]
+                jobs[i].ref_slot[0], jobs[i].ref_slot[1] = slots[(i - 1) % B], slots[(i + 1) % B]
+                ojobs[i].params, ojobs[i].cur_slot = op, slots[i]
+            sets.append(dict(d_stage=d_stage, d_me=d_me, d_ois=d_ois, h_me=h_me, h_ois=h_ois, slots=slots, ptrs=ptrs, jobs=jobs, ojobs=ojobs))
+        for rnd in range(2):          # the second round reuses both sets: the lane events must keep the stages apart
+            for k, L in enumerate(sets):
+                assert lib.svt_amd_lane_event_wait(lane_in, lane_k, k) == 0
+                assert lib.svt_amd_device_upload_async(lane_in, L["d_stage"], vp(h_in.value + k * B * w * h), B * w * h) == 0
+                assert lib.svt_amd_lane_event_record(lane_in, k) == 0
+                assert lib.svt_amd_lane_event_wait(lane_k, lane_in, k) == 0 and lib.svt_amd_lane_event_wait(lane_k, lane_out, k) == 0
+                assert lib.svt_amd_picture_upload_device_batch(lane_k, B, L["slots"], L["ptrs"], w, w, h) == 0, lib.svt_amd_last_error()
+                assert lib.svt_amd_lane_event_record(lane_k, k) == 0
+                assert lib.svt_amd_me_batch_launch(lane_k, L["jobs"], B) == 0, lib.svt_amd_last_error()
+                assert lib.svt_amd_ois_batch_launch(lane_k, L["ojobs"], B) == 0, lib.svt_amd_last_error()
+                assert lib.svt_amd_records_pack_batch_async(lane_k, L["slots"], B, nc, L["d_me"], L["d_ois"]) == 0, lib.svt_amd_last_error()
+                assert lib.svt_amd_lane_event_record(lane_k, 2 + k) == 0 and lib.svt_amd_lane_event_wait(lane_out, lane_k, 2 + k) == 0
+                assert lib.svt_amd_device_download_async(lane_out, L["h_me"], L["d_me"], B * nl * me_b) == 0
+                assert lib.svt_amd_device_download_async(lane_out, L["h_ois"], L["d_ois"], B * nl * ois_b) == 0
+                assert lib.svt_amd_lane_event_record(lane_out, k) == 0
+        for lane in lanes:
+            assert lib.svt_amd_synchronize(lane) == 0
+        cdt = np.dtype([("candidate", "<u4", (S.ME_PU_COUNT, nc)), ("total", "u1", (S.ME_PU_COUNT,)), ("pad", "u1", (3,))])
+        for k, L in enumerate(sets):
+            cme = _records(L["h_me"], B * nl * S.ME_PU_COUNT, S.ME_LCU_DTYPE["pu"].base).reshape(B, nl, S.ME_PU_COUNT)
+            cois = _records(L["h_ois"], B * nl, cdt).reshape(B, nl)
+            for i in range(B):
+                cur = k * B + i
+                refs = [k * B + (i - 1) % B, k * B + (i + 1) % B]
+                full = me_picture(lib, root, p, cur, refs)
+                assert cme[i].tobytes() == np.ascontiguousarray(full["pu"]).tobytes(), (k, i)
+                ois = np.zeros(nl, S.OIS_LCU_DTYPE)
+                assert lib.svt_amd_ois_picture(root, C.byref(op), cur, None, ois.ctypes.data) == 0, lib.svt_amd_last_error()
+                assert np.array_equal(cois[i]["candidate"], ois["candidate"][:, :, :nc]) and np.array_equal(cois[i]["total"], ois["total"]), (k, i)
+        # and one picture against the oracle, so that "equal to the blocking calls" is not equal garbage
+        pics = [S.OraclePicture(oracle, f) for f in frames[:B]]
+        want = S.oracle_me_picture(oracle, p, pics[1], pics[0], pics[2])
+        got = np.zeros(nl, S.ME_LCU_DTYPE)
+        got["pu"] = _records(sets[0]["h_me"], B * nl * S.ME_PU_COUNT, S.ME_LCU_DTYPE["pu"].base).reshape(B, nl, S.ME_PU_COUNT)[1]
+        assert np.array_equal(got["pu"], want["pu"])
+    finally:
+        for lane in lanes:
+            if lane:
+                lib.svt_amd_context_destroy(lane)
+        lib.svt_amd_context_destroy(root)
