@@ -176,6 +176,25 @@ __device__ __forceinline__ int load_window(LWin &w, int off, const uint8_t *plan
     return off + rows * wa;
 }
 
+/* Window whose first column is the plane column x0 ITSELF (any alignment): unaligned 16-byte global loads, 16-byte LDS stores */
+typedef uint4 __attribute__((aligned(1))) u128u_w;
+__device__ __forceinline__ int load_window_at(LWin &w, int off, const uint8_t *plane, int pitch, int x0, int y0, int x1, int y1, int t,
+                                              int odd = 0)
+{
+    int wa = ((x1 - x0) + 15) & ~15;
+    if (odd && !((wa >> 4) & 1))
+        wa += 16;
+    const int n16 = wa >> 4, rows = y1 - y0;
+    uint8_t *dst = g_pool + off;
+    w.p = dst, w.x0 = x0, w.y0 = y0, w.stride = wa;
+    for (int i = t; i < rows * n16; i += NT) {
+        const int r = i / n16, c = i - r * n16;
+        *(uint4 *)(dst + r * wa + c * 16) = *(const u128u_w *)(plane + (ptrdiff_t)(y0 + r) * pitch + x0 + c * 16);
+    }
+    return off + rows * wa;
+}
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 /* Same staging through the LDS-DMA path (global_load_lds_dwordx4): the data never passes through VGPRs and the
  * issuing wave does not wait for it, so the loads overlap with whatever is computed next.  One wave instruction
  * moves 64 consecutive 16-byte items to 1 KiB of consecutive LDS (M0 = LDS base of the chunk, lane i lands at
@@ -309,9 +328,7 @@ struct MeShared {
 struct MeSearch {
     union {                        /* the full-pel SAD trees and the sub-pel accumulators are never live together */
         struct {
-            uint16_t sad8[64][64]; /* per-position 8x8 even-row SADs of the current chunk  */
-            uint16_t sad16[64][16];
-            uint32_t sad32[64][4];
+            uint32_t sad32[256][4]; /* 32x32 SADs of a chunk of search rows, [position][quadrant]: the 64x64 sums */
         };
         struct {
             uint32_t dist[85][8];  /* sub-pel distortions (search metric)                  */
@@ -874,47 +891,49 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             if (t == 0)
                 B.key64 = ~0ull;
             const int npos = saw * sah, mult8 = saw & ~7;
-            const uint32_t rcw = fastdiv_recip((uint32_t)saw);
-            /* thread -> (8x8 block, item slot): a wave owns two rows of eight blocks, four lanes (slots) per block.
-             * Blocks in the same column are 8 window rows apart = the same LDS banks for any 16-byte-multiple pitch, so
-             * a wave must not hold all 64 blocks at one search position (that was an 8-way bank conflict). */
-            const int bxi = t & 7, byi = 2 * (t >> 6) + ((t >> 3) & 1), sub = (t >> 4) & 3;
-            const int bx = bxi << 3, by = byi << 3;
-            const int b = (bxi & 1) | ((byi & 1) << 1) | ((bxi & 2) << 1) | ((byi & 2) << 2) | ((bxi & 4) << 2) | ((byi & 4) << 3); /* Z index */
+            /* A WAVE owns one 32x32 quadrant; lane = (position group g = lane >> 4, 8x8 block blk = lane & 15 in Z order inside the
+             * quadrant).  The whole SAD tree of the quadrant then lives in the wave: the four 8x8 blocks of a 16x16 are the four
+             * lanes of a quad, the four 16x16 of the 32x32 are the four quads of a 16-lane row, so 16x16 and 32x32 sums are DPP
+             * adds on the packed quad-SAD accumulators and the running minima stay in registers - no per-position SADs in LDS, no
+             * atomics, no barrier inside the search.  Only the 64x64 SAD needs the other three waves: every wave leaves its 32x32
+             * SADs of a chunk of search rows in LDS (<= 256 positions) and one pass sums them. */
+            const int q = t >> 6, lane = t & 63, grp = lane >> 4, blk = lane & 15;
+            const int bx = ((q & 1) << 5) + (((blk & 1) | (((blk >> 2) & 1) << 1)) << 3);
+            const int by = ((q >> 1) << 5) + ((((blk >> 1) & 1) | (((blk >> 3) & 1) << 1)) << 3);
             uint32_t s0[4], s1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 s0[r] = *(const uint32_t *)&S.src[(by + 2 * r) * LCU + bx];
                 s1[r] = *(const uint32_t *)&S.src[(by + 2 * r) * LCU + bx + 4];
             }
-            uint32_t best8 = 0xffffffffu;
             /* stage the search region of the four planes: F now, b/h/j for the sub-pel stages.
              * x in [sox-2, sox+saw+63+2), y likewise (integer winner +-1 after half-pel, +-1 for the
-             * quarter-pel neighbours). */
+             * quarter-pel neighbours).  The F window starts FOUR columns left of search position 0, not at a 16-byte boundary of
+             * the plane (unaligned 16-byte global loads): every block's position 0 then sits on an LDS dword and a search row of
+             * saw positions is exactly saw / 4 quad-SAD items (a fifth, mostly masked item per row otherwise). */
             {
                 const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
-                int off = load_window(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                int off = load_window_at(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0 - 2, wy0, wx1, wy1, t, 1);
                 /* the half-pel planes are first read by the sub-pel stages: fetch them asynchronously under the
                  * full-pel search (waited for at "sub-pel windows landed" below) */
                 off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
                 off = load_window_async(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
                 off = load_window_async(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
             }
-            const uint8_t *rbase = wat(wF, ox + bx + sox, oy + by + soy);
-            const int fstride = wF.stride;
+            const uint32_t *rb4 = (const uint32_t *)wat(wF, ox + bx + sox, oy + by + soy); /* dword-aligned by construction */
+            const int fs4 = wF.stride >> 2;
             __syncthreads();
-            /* 8x8 even-row SADs: an item is (search row, aligned window dword) = 4 adjacent search positions of
-             * block b, 8 v_qsad_pk_u16_u8 (4 rows x 2 dwords) on aligned LDS dwords */
-            const int a0 = (int)((uintptr_t)rbase & 3);
-            const uint32_t *rb4 = (const uint32_t *)(rbase - a0);
-            const int mcount = ((a0 + saw - 1) >> 2) + 1, fs4 = fstride >> 2;
+            const int mcount = (saw + 3) >> 2;                          /* quad-SAD items per search row */
+            const int rows_per_chunk = imax(1, imin(sah, 256 / saw));   /* <= 256 positions of 32x32 SADs in LDS at a time */
             const uint32_t rcm = fastdiv_recip((uint32_t)mcount);
-            for (int base = 0; base < npos; base += 64) {
-                const int pend = imin(npos, base + 64);
-                const int sy0 = (int)fastdiv((uint32_t)base, rcw), sy1 = (int)fastdiv((uint32_t)(pend - 1), rcw);
-                const int items = (sy1 - sy0 + 1) * mcount;
-                for (int it = sub; it < items; it += 4) {
-                    const int ry = (int)fastdiv((uint32_t)it, rcm), mi = it - ry * mcount, sy = sy0 + ry;
+            uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu;
+            const int slot = blk & 3; /* the position of an item this lane speaks for in the 16x16 / 32x32 sums */
+            for (int row0 = 0; row0 < sah; row0 += rows_per_chunk) {
+                const int nrows = imin(rows_per_chunk, sah - row0), items = nrows * mcount, pbase = row0 * saw;
+                for (int it0 = 0; it0 < items; it0 += 4) { /* uniform trip count: the DPP sums need whole rows of lanes */
+                    const int it = it0 + grp;
+                    const bool live = it < items;
+                    const int ry = live ? (int)fastdiv((uint32_t)it, rcm) : 0, mi = live ? it - ry * mcount : 0, sy = row0 + ry;
                     const uint32_t *r = rb4 + sy * fs4 + mi;
                     unsigned long long acc = 0;
 #pragma unroll
@@ -924,48 +943,41 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                         acc = qsad(d1, d2, s1[rr], acc);
                         r += 2 * fs4;
                     }
+                    const int p0 = sy * saw + 4 * mi; /* raster index of the item's first position */
+                    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+                    /* 8x8: this lane's block, four positions */
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const int sx = 4 * mi + k - a0, p = sy * saw + sx;
-                        if (sx >= 0 && sx < saw && p >= base && p < pend) {
-                            const uint32_t sv = (uint32_t)(acc >> (16 * k)) & 0xffffu;
-                            B.sad8[p - base][b] = (uint16_t)sv;
-                            const uint32_t key = (sv << 14) | (uint32_t)p;
-                            best8 = key < best8 ? key : best8;
-                        }
+                        const uint32_t sv = ((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0xffffu;
+                        const uint32_t key = (live && 4 * mi + k < saw) ? ((sv << 14) | (uint32_t)(p0 + k)) : 0xffffffffu;
+                        best8 = key < best8 ? key : best8;
                     }
+                    /* 16x16: packed sums over the quad (4 x 16320 fits a u16 lane, no carry between the halves) */
+                    lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true); /* quad_perm [1,0,3,2] */
+                    hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true);
+                    lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, true); /* quad_perm [2,3,0,1] */
+                    hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, true);
+                    uint32_t v = ((slot < 2 ? lo : hi) >> (16 * (slot & 1))) & 0xffffu; /* 16x16 SAD at position p0 + slot */
+                    const bool valid = live && 4 * mi + slot < saw;
+                    const uint32_t pk = (uint32_t)(p0 + slot);
+                    {
+                        const uint32_t key = valid ? ((v << 14) | pk) : 0xffffffffu;
+                        best16 = key < best16 ? key : best16;
+                    }
+                    /* 32x32: the same position's 16x16 SADs of the four quads of the row */
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true); /* row_ror:4 */
+                    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); /* row_ror:8 */
+                    {
+                        const uint32_t key = valid ? ((v << 14) | pk) : 0xffffffffu;
+                        best32 = key < best32 ? key : best32;
+                    }
+                    if (valid && blk < 4)
+                        B.sad32[(int)pk - pbase][q] = v;
                 }
                 __syncthreads();
-                { /* 16x16: thread owns k16 = t&15, positions (t>>4) + 16*i */
-                    const int k16 = t & 15;
-                    uint32_t bk = 0xffffffffu;
-                    for (int i = 0; i < 4; i++) {
-                        const int pl = (t >> 4) + 16 * i, p = base + pl;
-                        if (p < npos) {
-                            const uint16_t *q = &B.sad8[pl][4 * k16];
-                            const uint32_t s = (uint32_t)q[0] + q[1] + q[2] + q[3];
-                            B.sad16[pl][k16] = (uint16_t)s;
-                            const uint32_t k = (s << 14) | (uint32_t)p;
-                            bk = k < bk ? k : bk;
-                        }
-                    }
-                    if (bk != 0xffffffffu)
-                        atomicMin(&B.key[5 + k16], bk);
-                }
-                __syncthreads();
-                { /* 32x32: one (position, quadrant) per thread */
-                    const int pl = t >> 2, k32 = t & 3, p = base + pl;
-                    if (p < npos) {
-                        const uint16_t *q = &B.sad16[pl][4 * k32];
-                        const uint32_t s = (uint32_t)q[0] + q[1] + q[2] + q[3];
-                        B.sad32[pl][k32] = s;
-                        atomicMin(&B.key[1 + k32], (s << 14) | (uint32_t)p);
-                    }
-                }
-                __syncthreads();
-                if (t < 64) { /* 64x64: '<=' inside complete groups of 8, '<' in the tail */
-                    const int p = base + t;
-                    if (p < npos) {
+                { /* 64x64: '<=' inside complete groups of 8, '<' in the tail */
+                    const int p = pbase + t;
+                    if (t < nrows * saw) {
                         const uint32_t s = B.sad32[t][0] + B.sad32[t][1] + B.sad32[t][2] + B.sad32[t][3];
                         const int sy = p / saw, sx = p - sy * saw;
                         const uint32_t code = (sx < mult8) ? (uint32_t)(16383 - p) : (0x4000u | (uint32_t)p);
@@ -974,7 +986,23 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 }
                 __syncthreads();
             }
-            atomicMin(&B.key[21 + b], best8);
+            /* minima of the position groups (and, for 16x16 / 32x32, of the lanes that spoke for different positions) */
+            best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 16));
+            best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 32));
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1)
+                best16 = umin32(best16, (uint32_t)__shfl_xor((int)best16, o));
+            best16 = umin32(best16, (uint32_t)__shfl_xor((int)best16, 16));
+            best16 = umin32(best16, (uint32_t)__shfl_xor((int)best16, 32));
+#pragma unroll
+            for (int o = 1; o <= 32; o <<= 1)
+                best32 = umin32(best32, (uint32_t)__shfl_xor((int)best32, o));
+            if (grp == 0)
+                B.key[21 + ((q << 4) | blk)] = best8;
+            if (grp == 0 && (blk & 3) == 0)
+                B.key[5 + ((q << 2) | (blk >> 2))] = best16;
+            if (lane == 0)
+                B.key[1 + q] = best32;
             __syncthreads();
             if (t < 85) {
                 uint32_t s;
