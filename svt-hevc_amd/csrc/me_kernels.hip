@@ -1285,59 +1285,64 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
     if (P.num_lists == 2) {
         const int rstep = (method == SVT_AMD_SUB_SAD_SEARCH) ? 2 : 1;
         const int npu = (P.cu16x16_mode != 0) ? 5 : ((P.cu8x8_mode != 0) ? 21 : 85);
-        /* items: (pu n, row) */
-        int first = 0;
-        (void)first;
-        for (int tier = 0; tier < 4; tier++) {
-            if (tier_first_of(tier) >= npu)
-                break;
-            const int sz = tier_sz_of(tier), rows = sz / rstep, items = tier_cnt_of(tier) * rows;
-            for (int i = t; i < items; i += NT) {
-                const int row = i % rows, n = tier_first_of(tier) + i / rows;
-                int px_, py_, psz;
-                pu_geom_z(n, px_, py_, psz);
-                const int y = row * rstep;
-                const uint8_t *a[2], *b[2];
+        /* items: (pu n, row, 16-sample segment), all tiers in ONE index space: 128 items each for the 64 / 32 / 16 tiers and 256
+         * half-width ones for the 8x8 tier, so every thread gets two or three short items (a tier at a time left 32 threads
+         * walking 64-sample rows of the 64x64 PU while 224 waited) */
+        int cum[5];
+        cum[0] = 0;
 #pragma unroll
-                for (int l = 0; l < 2; l++) {
-                    const PicView &RR = l ? ref1 : ref0;
-                    const uint32_t mv = B.best_mv[l][n];
-                    const int xMv = mvx(mv), yMv = mvy(mv);
-                    const int ax = ox + px_ + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
-                    const int frac = (xMv & 3) + ((yMv & 3) << 2);
-                    const ptrdiff_t pz = RR.pitch_full;
-                    const uint8_t *F = RR.full + ay * pz + ax, *B = RR.hp_b + ay * pz + ax + 1;
-                    const uint8_t *Hh = RR.hp_h + (ay + 1) * pz + ax, *J = RR.hp_j + (ay + 1) * pz + ax + 1;
-                    /* SelectBuffer / QuarterPelCompensation (:2440-2600) */
-                    switch (frac) {
-                    case 0: a[l] = F, b[l] = F; break;
-                    case 2: a[l] = B, b[l] = B; break;
-                    case 8: a[l] = Hh, b[l] = Hh; break;
-                    case 10: a[l] = J, b[l] = J; break;
-                    case 1: a[l] = F, b[l] = B; break;
-                    case 3: a[l] = B, b[l] = F + 1; break;
-                    case 4: a[l] = F, b[l] = Hh; break;
-                    case 5: a[l] = B, b[l] = Hh; break;
-                    case 6: a[l] = B, b[l] = J; break;
-                    case 7: a[l] = B, b[l] = Hh + 1; break;
-                    case 9: a[l] = Hh, b[l] = J; break;
-                    case 11: a[l] = J, b[l] = Hh + 1; break;
-                    case 12: a[l] = Hh, b[l] = F + pz; break;
-                    case 13: a[l] = Hh, b[l] = B + pz; break;
-                    case 14: a[l] = J, b[l] = B + pz; break;
-                    default: a[l] = Hh + 1, b[l] = B + pz; break;
-                    }
+        for (int tier = 0; tier < 4; tier++) {
+            const int sz = tier_sz_of(tier), rows = sz / rstep, segs = sz >= 16 ? sz >> 4 : 1;
+            cum[tier + 1] = cum[tier] + (tier_first_of(tier) < npu ? tier_cnt_of(tier) * rows * segs : 0);
+        }
+        for (int i = t; i < cum[4]; i += NT) {
+            const int tier = i < cum[1] ? 0 : i < cum[2] ? 1 : i < cum[3] ? 2 : 3;
+            const int sz = tier_sz_of(tier), rows = sz / rstep, lgsegs = tier == 0 ? 2 : tier == 1 ? 1 : 0, wseg = sz >= 16 ? 16 : sz;
+            const int j = i - pick4(tier, cum[0], cum[1], cum[2], cum[3]);
+            const int seg = j & ((1 << lgsegs) - 1), jr = j >> lgsegs, row = jr % rows, n = tier_first_of(tier) + jr / rows;
+            int px_, py_, psz;
+            pu_geom_z(n, px_, py_, psz);
+            const int y = row * rstep, xs = seg << 4;
+            const uint8_t *a[2], *b[2];
+#pragma unroll
+            for (int l = 0; l < 2; l++) {
+                const PicView &RR = l ? ref1 : ref0;
+                const uint32_t mv = B.best_mv[l][n];
+                const int xMv = mvx(mv), yMv = mvy(mv);
+                const int ax = ox + px_ + xs + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
+                const int frac = (xMv & 3) + ((yMv & 3) << 2);
+                const ptrdiff_t pz = RR.pitch_full;
+                const uint8_t *F = RR.full + ay * pz + ax, *B = RR.hp_b + ay * pz + ax + 1;
+                const uint8_t *Hh = RR.hp_h + (ay + 1) * pz + ax, *J = RR.hp_j + (ay + 1) * pz + ax + 1;
+                /* SelectBuffer / QuarterPelCompensation (:2440-2600) */
+                switch (frac) {
+                case 0: a[l] = F, b[l] = F; break;
+                case 2: a[l] = B, b[l] = B; break;
+                case 8: a[l] = Hh, b[l] = Hh; break;
+                case 10: a[l] = J, b[l] = J; break;
+                case 1: a[l] = F, b[l] = B; break;
+                case 3: a[l] = B, b[l] = F + 1; break;
+                case 4: a[l] = F, b[l] = Hh; break;
+                case 5: a[l] = B, b[l] = Hh; break;
+                case 6: a[l] = B, b[l] = J; break;
+                case 7: a[l] = B, b[l] = Hh + 1; break;
+                case 9: a[l] = Hh, b[l] = J; break;
+                case 11: a[l] = J, b[l] = Hh + 1; break;
+                case 12: a[l] = Hh, b[l] = F + pz; break;
+                case 13: a[l] = Hh, b[l] = B + pz; break;
+                case 14: a[l] = J, b[l] = B + pz; break;
+                default: a[l] = Hh + 1, b[l] = B + pz; break;
                 }
-                const uint8_t *s = &S.src[(py_ + y) * LCU + px_];
-                uint32_t d = 0;
-                for (int x = 0; x < sz; x += 4) {
-                    /* avg of identical pointers is the identity: (v+v+1)>>1 == v */
-                    const uint32_t p0 = avg4(ld4(a[0] + x), ld4(b[0] + x));
-                    const uint32_t p1 = avg4(ld4(a[1] + x), ld4(b[1] + x));
-                    d = sad4(*(const uint32_t *)(s + x), avg4(p0, p1), d);
-                }
-                atomicAdd(&B.bipred[n], d);
             }
+            const uint8_t *s = &S.src[(py_ + y) * LCU + px_ + xs];
+            uint32_t d = 0;
+            for (int x = 0; x < wseg; x += 4) {
+                /* avg of identical pointers is the identity: (v+v+1)>>1 == v */
+                const uint32_t p0 = avg4(ld4(a[0] + x), ld4(b[0] + x));
+                const uint32_t p1 = avg4(ld4(a[1] + x), ld4(b[1] + x));
+                d = sad4(*(const uint32_t *)(s + x), avg4(p0, p1), d);
+            }
+            atomicAdd(&B.bipred[n], d);
         }
         __syncthreads();
     }
