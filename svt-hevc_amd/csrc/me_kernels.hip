@@ -566,6 +566,10 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
     d = ssd ? d + q : r;
 }
 
+/* workgroup barrier that orders LDS traffic only (ds reads / writes / atomics): unlike __syncthreads() it does not wait for
+ * outstanding vector-memory operations, so LDS-DMA loads issued earlier stay in flight across it */
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 /* optional phase profile: when the job carries a debug buffer, thread 0 of every workgroup
  * stores the shader clock at each phase boundary (svt_amd_debug_me_phase_profile) */
 #define STAMP(i)                                                                      \
@@ -914,15 +918,17 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             {
                 const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
                 int off = load_window_at(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0 - 2, wy0, wx1, wy1, t, 1);
-                /* the half-pel planes are first read by the sub-pel stages: fetch them asynchronously under the
-                 * full-pel search (waited for at "sub-pel windows landed" below) */
+                LDS_BARRIER(); /* F is in LDS (its global loads are waited for by the stores that carry them) */
+                /* the half-pel planes are first read by the sub-pel stages: fetch them by LDS-DMA UNDER the full-pel search
+                 * (waited for at "sub-pel windows landed" below).  Every barrier between here and there must be LDS_BARRIER: a
+                 * __syncthreads() carries a vmcnt(0) and would park the workgroup until the three windows have landed, which is
+                 * what the first version of this stage did */
                 off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
                 off = load_window_async(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
                 off = load_window_async(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
             }
             const uint32_t *rb4 = (const uint32_t *)wat(wF, ox + bx + sox, oy + by + soy); /* dword-aligned by construction */
             const int fs4 = wF.stride >> 2;
-            __syncthreads();
             const int mcount = (saw + 3) >> 2;                          /* quad-SAD items per search row */
             const int rows_per_chunk = imax(1, imin(sah, 256 / saw));   /* <= 256 positions of 32x32 SADs in LDS at a time */
             const uint32_t rcm = fastdiv_recip((uint32_t)mcount);
@@ -974,7 +980,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                     if (valid && blk < 4)
                         B.sad32[(int)pk - pbase][q] = v;
                 }
-                __syncthreads();
+                LDS_BARRIER();
                 { /* 64x64: '<=' inside complete groups of 8, '<' in the tail */
                     const int p = pbase + t;
                     if (t < nrows * saw) {
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                         atomicMin(&B.key64, ((unsigned long long)s << 15) | code);
                     }
                 }
-                __syncthreads();
+                LDS_BARRIER();
             }
             /* minima of the position groups (and, for 16x16 / 32x32, of the lanes that spoke for different positions) */
             best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 16));
@@ -1003,7 +1009,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 B.key[5 + ((q << 2) | (blk >> 2))] = best16;
             if (lane == 0)
                 B.key[1 + q] = best32;
-            __syncthreads();
+            LDS_BARRIER();
             if (t < 85) {
                 uint32_t s;
                 int p;
