@@ -207,7 +207,7 @@ def recon_exchange_leg(lib, root, rank, world, dev, reps=10, limit_s=120.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="pictures per step per GPU (default: 64 at 4K, 128 at 1080p)")
