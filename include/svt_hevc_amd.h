@@ -1044,8 +1044,9 @@ SVT_AMD_API int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture
 SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
                                               SvtAmdLcuResult *d_results, int tiles);
 
-/* debug: out == NULL arms per-LCU shader-clock sums in the encode-pass kernels (8 x u64 per LCU: prediction, encode, copy-out, units,
- * wait for neighbours, start, end, -), a later call with a HOST buffer of 8 * LCUs u64 fetches them (tools/encodepass_bench.py) */
+/* debug: out == NULL arms per-LCU shader-clock sums in the encode-pass kernels (16 x u64 per LCU: prediction, encode, copy-out, units,
+ * wait for neighbours, start, end, -, the prediction's four sub-phases, 4 unused), a later call with a HOST buffer of 16 * LCUs u64
+ * fetches them (tools/encodepass_bench.py) */
 SVT_AMD_API int svt_amd_debug_encdec_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
 
 /* LCUs the HOST encoded itself (units outside this revision: inter, intra 4x4, 64x64, delta-QP / masking configurations) are

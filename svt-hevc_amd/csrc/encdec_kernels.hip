@@ -35,7 +35,7 @@ struct EpPicture {                 /* = SvtAmdEncDecPicture's device part */
     uint32_t pitch[3];             /* samples */
     uint8_t *mode_map;             /* (height / 4) rows of map_pitch bytes */
     uint32_t map_pitch;
-    unsigned long long *prof;      /* debug (svt_amd_debug_encdec_profile): 8 shader-clock sums per LCU, or null */
+    unsigned long long *prof;      /* debug (svt_amd_debug_encdec_profile): 16 shader-clock sums per LCU, or null */
     uint16_t width, height;        /* luma */
     uint32_t bps;
 };
@@ -74,6 +74,7 @@ struct EpLocal {
     T c[2][33 * PC];
     uint8_t mode[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
     T src_y[64 * 64], src_c[2][32 * 32];
+    SvtAmdLcuCu cus[SVT_AMD_LCU_MAX_CUS]; /* the unit list: a unit's descriptor is an LDS read, not a trip to HBM in front of every unit */
     __device__ __forceinline__ T *at(int p, int x, int y_) { return p == 0 ? &y[(y_ + 1) * PY + X0 + x] : &c[p - 1][(y_ + 1) * PC + X0 + x]; }
     __device__ __forceinline__ int pitch(int p) const { return p == 0 ? PY : PC; }
     /* mode type at luma sample (x, y) relative to the LCU: what lies below the LCU, right of it (from its first row on) or right of
@@ -91,8 +92,16 @@ struct EpLocal {
  * reconstruction planes at the unit's position - k_intra_pu (intra_kernels.hip) with the neighbours read from the LCU in LDS. */
 template <typename T>
 __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work &W, const LcuCu &cu, int t, int16_t (*border)[132], int16_t (*ref)[132], uint8_t *ok,
-                                 int *s_small /* [0] first group, [1..3] dc */)
+                                 int *s_small /* [0] first group, [1..3] dc */, unsigned long long *ph /* debug: clocks of 4 sub-phases, or null */)
 {
+    unsigned long long pc = ph ? __builtin_readcyclecounter() : 0;
+#define EP_PH(i)                                                  \
+    do {                                                          \
+        if (ph) {                                                 \
+            const unsigned long long now = __builtin_readcyclecounter(); \
+            ph[i] += now - pc, pc = now;                          \
+        }                                                         \
+    } while (0)
     constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, mid = sizeof(T) == 1 ? 128 : 512, thr = sizeof(T) == 1 ? 8 : 32;
     const int N = cu.size, nb = N >> 2, lgN = 31 - __clz(N);
     const bool pic_left = W.tile_left && cu.x == 0, pic_top = W.tile_top && cu.y == 0;
@@ -114,10 +123,13 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
         if (t <= 4 * nb)
             ok[t] = a;
         const unsigned long long m = __ballot(a);
-        if (t == 0)
+        if (t == 0) {
             s_small[0] = m ? __ffsll((long long)m) - 1 : 1 << 30;
+            s_small[4] = (int)(uint32_t)m, s_small[5] = (int)(uint32_t)(m >> 32); /* availability of the <= 33 groups, bit per group */
+        }
     }
     __syncthreads();
+    EP_PH(0);
     const int firstGroup = s_small[0];
     for (int i = t; i < 3 * 129; i += 256) { /* substitution, one thread per (plane, sample in scan order) */
         const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N, lgG = p ? 1 : 2, g = 1 << lgG; /* samples per group */
@@ -125,12 +137,21 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
             continue;
         int v = mid;
         if (firstGroup < (1 << 30)) {
-            auto group_of = [&](int kk) { return kk < 2 * n ? kk >> lgG : kk == 2 * n ? 2 * nb : 2 * nb + 1 + ((kk - 2 * n - 1) >> lgG); };
-            int src = k;
-            while (src >= 0 && !ok[group_of(src)])
-                src--;
-            if (src < 0)
+            /* the nearest available sample at or below k in scan order (the reference walks down sample by sample): k itself when
+             * its group is there, otherwise the LAST sample of the nearest available group below - found with bit operations on
+             * the availability mask - and, with nothing below, the first sample of the first available group */
+            const unsigned long long m = ((unsigned long long)(uint32_t)s_small[5] << 32) | (uint32_t)s_small[4];
+            const int gk = k < 2 * n ? k >> lgG : k == 2 * n ? 2 * nb : 2 * nb + 1 + ((k - 2 * n - 1) >> lgG);
+            const unsigned long long below = m & ((2ull << gk) - 1ull); /* groups 0..gk */
+            int src;
+            if ((below >> gk) & 1ull) {
+                src = k;
+            } else if (below) {
+                const int sg = 63 - __clzll((long long)below);
+                src = sg < 2 * nb ? sg * g + g - 1 : sg == 2 * nb ? 2 * n : 2 * n + 1 + (sg - 2 * nb - 1) * g + g - 1;
+            } else {
                 src = firstGroup < 2 * nb ? firstGroup * g : firstGroup == 2 * nb ? 2 * n : 2 * n + 1 + (firstGroup - 2 * nb - 1) * g;
+            }
             const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
             /* scan order: [0, 2n) = left column bottom to top (sample 2n-1-src from the top), 2n = top-left, then the top row */
             v = src < 2 * n ? (int)*L.at(p, lx - 1, ly + 2 * n - 1 - src) : src == 2 * n ? (int)*L.at(p, lx - 1, ly - 1)
@@ -139,6 +160,7 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
         border[p][k] = (int16_t)v;
     }
     __syncthreads();
+    EP_PH(1);
     const int lmode = cu.intra_luma_mode;
     const int dA = abs(lmode - 10), dB = abs(lmode - 26), dm = dA < dB ? dA : dB;
     const int thrTab = lgN == 2 ? 35 : lgN == 3 ? 7 : lgN == 4 ? 1 : lgN == 5 ? 0 : 10; /* intraLumaFilterTable */
@@ -163,6 +185,7 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
         ref[p][k < 2 * n ? 2 * n - 1 - k : k] = (int16_t)v;
     }
     __syncthreads();
+    EP_PH(2);
     if (lmode == 1) { /* DC: wave p sums plane p's left column and top row */
         const int p = t >> 6, l = t & 63;
         if (p < 3) {
@@ -183,6 +206,8 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
         const int v = pu_predict(lmode /* chroma: EB_INTRA_CHROMA_DM */, n, lg, ref[p], x, y, s_small[1 + p], p == 0, maxv);
         *L.at(p, (p ? cu.x >> 1 : cu.x) + x, (p ? cu.y >> 1 : cu.y) + y) = (T)v;
     }
+    EP_PH(3);
+#undef EP_PH
 }
 
 /* One transform unit of one plane on lanes r = 0..N-1 of the calling wave (the other lanes idle): EncodeLoop + EncodeGenerateRecon.
@@ -301,6 +326,7 @@ __device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Wor
     const T *rp[3] = {(const T *)P.rec[0], (const T *)P.rec[1], (const T *)P.rec[2]};
     T *wp[3] = {(T *)P.rec[0], (T *)P.rec[1], (T *)P.rec[2]};
     unsigned long long c_pred = 0, c_enc = 0, c0 = P.prof ? __builtin_readcyclecounter() : 0, c1 = 0;
+    unsigned long long c_ph[4] = {0, 0, 0, 0};
     const int lw = min(64, (int)P.width - (int)W.lcu_x), lh = min(64, (int)P.height - (int)W.lcu_y);
     /* ---- the LCU's surroundings and source into LDS ---- */
     for (int i = t; i < 17 * 36; i += 256) {
@@ -328,12 +354,15 @@ __device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Wor
         const uint32_t v = ((const uint32_t *)W.src_y)[i]; /* src_y, src_cb, src_cr are contiguous in the contract */
         ((uint32_t *)L.src_y)[i] = v;
     }
+    for (int i = t; i < (int)(sizeof(L.cus) / 4); i += 256)
+        ((uint32_t *)L.cus)[i] = ((const uint32_t *)W.cu)[i];
+    const int num_cus = W.num_cus;
     __syncthreads();
-    for (int ci = 0; ci < W.num_cus; ci++) {
-        const LcuCu cu = W.cu[ci];
+    for (int ci = 0; ci < num_cus; ci++) {
+        const LcuCu cu = L.cus[ci];
         const int N = cu.size;
         if (cu.pred_mode == 2 && N <= 32) {
-            ep_intra_predict<T>(L, W, cu, t, border, ref, ok, s_small);
+            ep_intra_predict<T>(L, W, cu, t, border, ref, ok, s_small, P.prof ? c_ph : nullptr);
             __syncthreads(); /* the prediction is in the local planes; the unit's lanes read it back row-wise */
             if (P.prof)
                 c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
@@ -381,8 +410,9 @@ __device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Wor
             P.mode_map[(size_t)((W.lcu_y >> 2) + cy) * P.map_pitch + (W.lcu_x >> 2) + cx] = L.mode[(cy + 1) * 36 + cx + 1];
     }
     if (P.prof && t == 0) {
-        unsigned long long *q = P.prof + 8 * (size_t)((W.lcu_y >> 6) * ((P.width + 63) >> 6) + (W.lcu_x >> 6));
+        unsigned long long *q = P.prof + 16 * (size_t)((W.lcu_y >> 6) * ((P.width + 63) >> 6) + (W.lcu_x >> 6));
         q[0] = c_pred, q[1] = c_enc, q[2] = __builtin_readcyclecounter() - c0, q[3] = W.num_cus;
+        q[8] = c_ph[0], q[9] = c_ph[1], q[10] = c_ph[2], q[11] = c_ph[3]; /* prediction: availability, substitution, smoothing, samples */
     }
 }
 
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typen
         ep_encode_lcu<T>(P, W, results[lcu], S, L);
         __syncthreads(); /* every thread's stores of this LCU are issued */
         if (P.prof && threadIdx.x == 0)
-            P.prof[8 * (size_t)lcu + 4] = w1 - w0, P.prof[8 * (size_t)lcu + 5] = w0, P.prof[8 * (size_t)lcu + 6] = __builtin_readcyclecounter();
+            P.prof[16 * (size_t)lcu + 4] = w1 - w0, P.prof[16 * (size_t)lcu + 5] = w0, P.prof[16 * (size_t)lcu + 6] = __builtin_readcyclecounter();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_store(&done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -715,14 +745,15 @@ extern "C" int svt_amd_encdec_picture_put_borders16(SvtAmdContext *ctx, SvtAmdEn
     return put_borders<uint16_t>(ctx, pic, borders, n);
 }
 
-/* debug: out == NULL arms the per-LCU clock sums (8 x u64 per LCU: prediction, encode, copy-out, units, wait, start, end, -),
+/* debug: out == NULL arms the per-LCU clock sums (16 x u64 per LCU: prediction, encode, copy-out, units, wait, start, end, -, then the
+ * prediction's four sub-phases),
  * a later call with a HOST buffer fetches them */
 extern "C" int svt_amd_debug_encdec_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out)
 {
     if (!ctx || !pic)
         return SVT_AMD_ERR_BAD_PARAM;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pic->nlcu;
+    const size_t bytes = sizeof(unsigned long long) * 16 * (size_t)pic->nlcu;
     if (!pic->d.prof) {
         HIP_TRY(hipMalloc((void **)&pic->d.prof, bytes));
         HIP_TRY(hipMemset(pic->d.prof, 0, bytes));

@@ -90,12 +90,14 @@ def main():
             if P == 1:   # where an LCU's time goes (shader clocks of thread 0)
                 assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], None) == 0
                 go()
-                prof = np.zeros((nl, 8), np.uint64)
+                prof = np.zeros((nl, 16), np.uint64)
                 assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], prof.ctypes.data) == 0
                 span = int(prof[:, 6].max() - prof[:, 5].min())
                 print("   clocks per LCU (mean): predict %d encode %d copy-out %d wait %d; per unit predict %d encode %d; kernel span %d clocks" %
                       (prof[:, 0].mean(), prof[:, 1].mean(), prof[:, 2].mean(), prof[:, 4].mean(), prof[:, 0].sum() / prof[:, 3].sum(),
                        prof[:, 1].sum() / prof[:, 3].sum(), span), flush=True)
+                print("   prediction per unit: availability %d substitution %d smoothing %d samples %d" %
+                      tuple(prof[:, 8 + i].sum() / prof[:, 3].sum() for i in range(4)), flush=True)
             rows.append({"content": label, "pictures_in_flight": P, "lcus": nl, "units": units, "ms_per_round": round(dt * 1e3, 3),
                          "pictures_per_s": round(P / dt, 1), "lcus_per_s": round(P * nl / dt), "algorithmic_GBps": round(P * alg / dt / 1e9, 2)})
             print(rows[-1], flush=True)
