@@ -1044,6 +1044,25 @@ SVT_AMD_API int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture
 SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
                                               SvtAmdLcuResult *d_results, int tiles);
 
+/* Deblocking behind the encode pass: when every LCU of the picture is encoded, the device picture goes IN PLACE through the
+ * picture-level boundary-strength and deblocking kernels (svt_amd_bs_picture + svt_amd_dlf_picture: the state the reference's
+ * per-LCU drivers LCUInternalAreaDLFCore / LCUBoundaryDLFCore / LCUPictureEdgeDLFCore leave, Codec/EbCodingLoop.c:4600-4631) -
+ * the finished reconstruction / reference picture when SAO is off.  works / results: the HOST records of all LCUs in raster
+ * order (unit lists, QPs, tile edges; luma cbf of every unit).  out_*: optional HOST planes (tight pitch) that receive the
+ * deblocked picture.  Blocking.  Afterwards the device picture is no longer an encode-pass neighbour source (begin a new one). */
+typedef struct SvtAmdDeblockParams {
+    int8_t tc_offset, beta_offset, cb_qp_offset, cr_qp_offset;   /* pictureControlSetPtr->tcOffset / betaOffset / cbQpOffset / crQpOffset */
+    uint8_t slice_type;                                           /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR */
+    uint8_t pad[3];
+    uint64_t ref_poc[2];                                          /* refPOC of the two lists (inter units; 0 for intra pictures) */
+} SvtAmdDeblockParams;
+SVT_AMD_API int svt_amd_encdec_picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works,
+                                               const SvtAmdLcuResult *results, const SvtAmdDeblockParams *params, uint8_t *out_y,
+                                               uint8_t *out_cb, uint8_t *out_cr);
+SVT_AMD_API int svt_amd_encdec_picture_deblock16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works,
+                                                 const SvtAmdLcuResult16 *results, const SvtAmdDeblockParams *params, uint16_t *out_y,
+                                                 uint16_t *out_cb, uint16_t *out_cr);
+
 /* debug: out == NULL arms per-LCU shader-clock sums in the encode-pass kernels (16 x u64 per LCU: prediction, encode, copy-out, units,
  * wait for neighbours, start, end, -, the prediction's four sub-phases, 4 unused), a later call with a HOST buffer of 16 * LCUs u64
  * fetches them (tools/encodepass_bench.py) */

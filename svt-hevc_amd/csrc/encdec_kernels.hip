@@ -27,6 +27,7 @@
  * residual -> forward "Estimate" DCT in registers -> column r quantised / de-quantised in registers -> inverse DCT -> + prediction.
  */
 #include "txfm_device.h"
+#include <string.h>
 #include <vector>
 #include "intra_device.h"
 
@@ -691,6 +692,87 @@ extern "C" int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPic
     if (!ctx || !pic || !d_works || !d_results || tiles < 1)
         return SVT_AMD_ERR_BAD_PARAM;
     return encode_picture<uint8_t>(ctx, pic, nullptr, nullptr, d_works, d_results, tiles);
+}
+
+/* ---- deblocking behind the encode pass ------------------------------------------------------------------------------------------ */
+/* Once every LCU of the picture is encoded (svt_amd_encode_picture, or LCU by LCU), the device picture goes through the
+ * picture-level boundary-strength and deblocking kernels (filter_kernels.hip, proven on recorded pictures) IN PLACE: what the
+ * reference's reconstruction holds after its per-LCU drivers - the finished picture when SAO is off.  The two maps those kernels
+ * read (coding unit per 8x8 block, luma cbf per 4x4 block) and the QP array come from the contract records the host already has. */
+template <typename T>
+static int picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, const typename EpTypes<T>::Result *results,
+                           const SvtAmdDeblockParams *prm, void *out_y, void *out_cb, void *out_cr)
+{
+    if (!ctx || !pic || !works || !results || !prm || pic->d.bps != sizeof(T))
+        return SVT_AMD_ERR_BAD_PARAM;
+    const uint32_t w = pic->d.width, h = pic->d.height, wl = (w + 63) / 64, nlcu = (uint32_t)pic->nlcu;
+    const uint32_t w8 = w / 8, h8 = h / 8, w4 = w / 4, h4 = h / 4;
+    std::vector<SvtAmdCuMapEntry> map((size_t)w8 * h8);
+    std::vector<uint8_t> cbf((size_t)w4 * h4), qp((size_t)w8 * h8), edge(nlcu);
+    ::memset(map.data(), 0, map.size() * sizeof(SvtAmdCuMapEntry));
+    for (uint32_t i = 0; i < nlcu; i++) {
+        const auto &W = works[i];
+        if (W.lcu_x != (i % wl) * 64 || W.lcu_y != (i / wl) * 64) {
+            svt_amd_set_error("svt_amd_encdec_picture_deblock: LCU %u is not at raster position %u", i, i);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        edge[i] = (uint8_t)((W.tile_left ? 1 : 0) | (W.tile_top ? 2 : 0));
+        for (int c = 0; c < W.num_cus; c++) {
+            const SvtAmdLcuCu &u = W.cu[c];
+            const uint32_t x0 = W.lcu_x + u.x, y0 = W.lcu_y + u.y;
+            if (x0 + u.size > w || y0 + u.size > h || u.size < 8)
+                return SVT_AMD_ERR_BAD_PARAM;
+            SvtAmdCuMapEntry e;
+            ::memset(&e, 0, sizeof(e));
+            e.mode = u.pred_mode, e.size_log2 = (uint8_t)(u.size == 8 ? 3 : u.size == 16 ? 4 : u.size == 32 ? 5 : 6);
+            for (uint32_t y = y0 / 8; y < (y0 + u.size) / 8; y++)
+                for (uint32_t x = x0 / 8; x < (x0 + u.size) / 8; x++)
+                    map[(size_t)y * w8 + x] = e, qp[(size_t)y * w8 + x] = u.qp;
+            for (uint32_t y = y0 / 4; y < (y0 + u.size) / 4; y++)
+                ::memset(&cbf[(size_t)y * w4 + x0 / 4], results[i].cu[c].cbf[0], u.size / 4);
+        }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t b_map = (map.size() * sizeof(SvtAmdCuMapEntry) + 255) & ~(size_t)255, b_cbf = (cbf.size() + 255) & ~(size_t)255,
+                 b_qp = (qp.size() + 255) & ~(size_t)255, b_edge = ((size_t)nlcu + 255) & ~(size_t)255, b_bs = (size_t)nlcu * 256;
+    uint8_t *d = nullptr;
+    int rc = svt_amd_ctx_scratch(ctx, b_map + b_cbf + b_qp + b_edge + 2 * b_bs, &d);
+    if (rc)
+        return rc;
+    uint8_t *d_map = d, *d_cbf = d_map + b_map, *d_qp = d_cbf + b_cbf, *d_edge = d_qp + b_qp, *d_bsv = d_edge + b_edge, *d_bsh = d_bsv + b_bs;
+    HIP_TRY(hipMemcpyAsync(d_map, map.data(), map.size() * sizeof(SvtAmdCuMapEntry), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_cbf, cbf.data(), cbf.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_qp, qp.data(), qp.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_edge, edge.data(), edge.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the host vectors back the copies */
+    if ((rc = svt_amd_bs_picture(ctx, (const SvtAmdCuMapEntry *)d_map, d_cbf, w, h, prm->slice_type, prm->ref_poc[0], prm->ref_poc[1], d_edge, d_bsv,
+                                 d_bsh)) != 0)
+        return rc;
+    if (pic->d.pitch[1] != pic->d.pitch[2])
+        return SVT_AMD_ERR_BAD_PARAM;
+    if ((rc = svt_amd_dlf_picture(ctx, (int)sizeof(T), pic->d.rec[0], pic->d.pitch[0], pic->d.rec[1], pic->d.rec[2], pic->d.pitch[1], w, h, d_bsv, d_bsh,
+                                  d_qp, w8, prm->tc_offset, prm->beta_offset, prm->cb_qp_offset, prm->cr_qp_offset)) != 0)
+        return rc;
+    void *outs[3] = {out_y, out_cb, out_cr};
+    for (int k = 0; k < 3; k++)
+        if (outs[k]) {
+            const uint32_t pw = k ? w / 2 : w, ph = k ? h / 2 : h;
+            HIP_TRY(hipMemcpy2DAsync(outs[k], (size_t)pw * sizeof(T), pic->d.rec[k], (size_t)pic->d.pitch[k] * sizeof(T), (size_t)pw * sizeof(T), ph,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_encdec_picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, const SvtAmdLcuResult *results,
+                                              const SvtAmdDeblockParams *params, uint8_t *out_y, uint8_t *out_cb, uint8_t *out_cr)
+{
+    return picture_deblock<uint8_t>(ctx, pic, works, results, params, out_y, out_cb, out_cr);
+}
+extern "C" int svt_amd_encdec_picture_deblock16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works,
+                                                const SvtAmdLcuResult16 *results, const SvtAmdDeblockParams *params, uint16_t *out_y, uint16_t *out_cb,
+                                                uint16_t *out_cr)
+{
+    return picture_deblock<uint16_t>(ctx, pic, works, results, params, out_y, out_cb, out_cr);
 }
 
 /* ---- LCUs encoded by the host: their last row / column and edge mode types enter the device picture --------------------------- */

@@ -28,6 +28,12 @@ CASES = {
     "i10_motion_416x240_m9": ("motion10", 416, 240, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "30", "-bit-depth", "10"]),
     "i10_noise_200x136_m6": ("noise10", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "24", "-bit-depth", "10"]),
     "i10_motion_320x192_m7_q45": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "45", "-bit-depth", "10"]),
+    # deblocking ON (the encoder's default), SAO off: the encoder's reconstruction output is then the deblocked picture, the
+    # fixture for encode pass -> boundary strengths -> deblocking chained on the device ("dlf_" prefix: `recon_*` planes are kept,
+    # the per-LCU `rec_*` of the records are partly deblocked and not compared)
+    "dlf_i_motion_416x240_m9": ("motion", 416, 240, 2, 7, ["-encMode", "9", "-intra-period", "0", "-q", "34"]),
+    "dlf_i_noise_200x136_m6": ("noise", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "38"]),
+    "dlf_i10_motion_320x192_m7": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "36", "-bit-depth", "10"]),
 }
 
 
@@ -39,20 +45,32 @@ def run_case(name):
             S.write_clip10(yuv, kind[:-2], w, h, n, seed)
         else:
             S.write_clip(yuv, kind, w, h, n, seed)
-        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-dlf", "1", "-sao", "0",
-               "-b", os.path.join(td, "out.265")] + args
+        dlf = name.startswith("dlf_")
+        rec_out = os.path.join(td, "rec.yuv")
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-sao", "0",
+               "-b", os.path.join(td, "out.265")] + ([] if dlf else ["-dlf", "1"]) + (["-o", rec_out] if dlf else []) + args
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_ENCODEPASS_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
         rdt = S.EP_RECORD16_DTYPE if kind.endswith("10") else S.EP_RECORD_DTYPE
         recs = np.fromfile(dump, dtype=rdt)
+        rec_raw = open(rec_out, "rb").read() if dlf else b""
     assert len(recs) and (recs["record_size"] == rdt.itemsize).all(), (len(recs), rdt.itemsize)
-    assert (recs["dlf_off"] == 1).all()
+    assert (recs["dlf_off"] == (0 if dlf else 1)).all()
+    extra = {}
+    if dlf:   # the encoder's reconstruction output: n frames, 4:2:0, 8-bit samples or 16-bit little-endian for 10-bit encodes
+        sdt = np.dtype("<u2") if kind.endswith("10") else np.uint8
+        raw = np.frombuffer(rec_raw, sdt)
+        fs = w * h * 3 // 2
+        assert raw.size == n * fs, (raw.size, n, fs)
+        extra = {"recon_y": np.stack([raw[i * fs:i * fs + w * h].reshape(h, w) for i in range(n)]),
+                 "recon_cb": np.stack([raw[i * fs + w * h:i * fs + w * h * 5 // 4].reshape(h // 2, w // 2) for i in range(n)]),
+                 "recon_cr": np.stack([raw[i * fs + w * h * 5 // 4:(i + 1) * fs].reshape(h // 2, w // 2) for i in range(n)])}
     nl = S.lcu_count(w, h)
     order = np.lexsort((recs["lcu_index"], recs["picture_number"]))
     recs = recs[order]
     assert len(recs) == nl * n, "every LCU of an all-intra clip must be recorded (%d of %d)" % (len(recs), nl * n)
     path = os.path.join(S.GOLDEN_DIR, "encodepass_%s.npz" % name)
     np.savez_compressed(path, clip=np.array([kind, str(w), str(h), str(n), str(seed)]), enc_args=np.array(args),
-                        picture_number=recs["picture_number"], lcu_index=recs["lcu_index"], work=recs["work"], result=recs["result"])
+                        picture_number=recs["picture_number"], lcu_index=recs["lcu_index"], work=recs["work"], result=recs["result"], **extra)
     sizes, cnt = np.unique(np.concatenate([r["work"]["cu"]["size"][:r["work"]["num_cus"]] for r in recs]), return_counts=True)
     cbf = np.concatenate([r["result"]["cu"]["cbf"][:r["work"]["num_cus"]] for r in recs])
     odc = np.concatenate([r["result"]["cu"]["only_dc"][:r["work"]["num_cus"]] for r in recs])

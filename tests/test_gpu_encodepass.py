@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import svtlib as S
-from test_oracle_encodepass_golden import CASES, compare_lcu, is16, load_case
+from test_oracle_encodepass_golden import CASES, DLF_CASES, compare_lcu, is16, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -278,5 +278,46 @@ def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):
         wk16[0]["num_cus"] = 1
         wk16[0]["cu"][0]["size"], wk16[0]["cu"][0]["pred_mode"] = 32, 2
         assert lib.svt_amd_encode_lcus16(gpu_ctx, pic, wk16.ctypes.data, 1, out16.ctypes.data) != 0
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+class DeblockParams(C.Structure):
+    """SvtAmdDeblockParams"""
+    _fields_ = [("tc_offset", C.c_int8), ("beta_offset", C.c_int8), ("cb_qp_offset", C.c_int8), ("cr_qp_offset", C.c_int8),
+                ("slice_type", C.c_uint8), ("pad", C.c_uint8 * 3), ("ref_poc", C.c_uint64 * 2)]
+
+
+@pytest.mark.parametrize("name", DLF_CASES)
+def test_encode_picture_then_deblock_matches_the_encoders_output(product, gpu_ctx, name):
+    """two calls per picture - svt_amd_encode_picture (wavefront on the device) and svt_amd_encdec_picture_deblock (boundary strengths
+    + deblocking in place on the device picture) - give the reference encoder's own reconstruction output (deblocking on, SAO off),
+    8- and 10-bit"""
+    lib = product
+    sig_picture(lib)
+    g, w, h = load_case(name)
+    wide = is16(g)
+    enc = lib.svt_amd_encode_picture16 if wide else lib.svt_amd_encode_picture
+    dbk = lib.svt_amd_encdec_picture_deblock16 if wide else lib.svt_amd_encdec_picture_deblock
+    dbk.restype, dbk.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DeblockParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if wide else (np.uint8, S.LCU_RESULT_DTYPE)
+    nl = S.lcu_count(w, h)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        for f, first in enumerate(range(0, len(g["work"]), nl)):
+            works = np.ascontiguousarray(g["work"][first:first + nl])
+            got = np.zeros(nl, rdt)
+            assert enc(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+            for k in range(nl):
+                compare_lcu(works[k], g["result"][first + k], got[k], w, h, (name, f, k), rec=False)
+            prm = DeblockParams()
+            prm.slice_type = 2
+            out = [np.zeros((h, w), sdt), np.zeros((h // 2, w // 2), sdt), np.zeros((h // 2, w // 2), sdt)]
+            assert dbk(gpu_ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(prm), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data) == 0, \
+                lib.svt_amd_last_error()
+            for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
+                bad = np.argwhere(out[p] != g[nm][f])
+                assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)

@@ -10,7 +10,9 @@ import pytest
 
 import svtlib as S
 
-CASES = sorted(os.path.basename(p)[11:-4] for p in glob.glob(os.path.join(S.GOLDEN_DIR, "encodepass_*.npz")))
+ALL = sorted(os.path.basename(p)[11:-4] for p in glob.glob(os.path.join(S.GOLDEN_DIR, "encodepass_*.npz")))
+CASES = [c for c in ALL if not c.startswith("dlf_")]        # recorded with the loop filters off: per-LCU reconstruction comparable
+DLF_CASES = [c for c in ALL if c.startswith("dlf_")]        # deblocking on, SAO off: the encoder's output picture is the reference
 
 
 def load_case(name):
@@ -24,7 +26,7 @@ def is16(g):
     return g["work"].dtype.itemsize == S.LCU_WORK16_DTYPE.itemsize
 
 
-def compare_lcu(work, want, got, w, h, tag):
+def compare_lcu(work, want, got, w, h, tag, rec=True):
     """cbf / DC-only / counts of the units, the quantised coefficients of every unit area and the LCU's reconstruction inside the picture"""
     n = int(work["num_cus"])
     for f in ("cbf", "only_dc", "nz"):
@@ -37,6 +39,8 @@ def compare_lcu(work, want, got, w, h, tag):
         for p in ("coeff_cb", "coeff_cr"):
             a, b = got[p].reshape(32, 32), want[p].reshape(32, 32)
             assert np.array_equal(a[y // 2:(y + s) // 2, x // 2:(x + s) // 2], b[y // 2:(y + s) // 2, x // 2:(x + s) // 2]), (tag, p, i)
+    if not rec:
+        return
     lw, lh = min(64, w - int(work["lcu_x"])), min(64, h - int(work["lcu_y"]))
     assert np.array_equal(got["rec_y"].reshape(64, 64)[:lh, :lw], want["rec_y"].reshape(64, 64)[:lh, :lw]), (tag, "rec_y")
     for p in ("rec_cb", "rec_cr"):
@@ -89,3 +93,63 @@ def test_encode_lcu_oracle_matches_reference(oracle, name):
             got = np.zeros(1, rdt)
             fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got.ctypes.data)
             compare_lcu(work[0], g["result"][k], got[0], w, h, (name, int(g["picture_number"][k]), int(g["lcu_index"][k])))
+
+
+def deblock_maps(works, results, w, h):
+    """the three picture-level inputs of the deblocking kernels from the contract records: coding-unit map per 8x8 block, luma cbf
+    per 4x4 block, QP per 8x8 block, tile-edge flags per LCU (svt-hevc_amd/csrc/encdec_kernels.hip:picture_deblock does the same)"""
+    cu_dt = np.dtype([("mode", "u1"), ("dir", "u1"), ("size_log2", "u1"), ("pad", "u1"), ("mv", "<i2", (2, 2))])
+    cumap = np.zeros((h // 8, w // 8), cu_dt)
+    cbf = np.zeros((h // 4, w // 4), np.uint8)
+    qp = np.zeros((h // 8, w // 8), np.uint8)
+    edge = np.zeros(len(works), np.uint8)
+    for i, (wk, rs) in enumerate(zip(works, results)):
+        edge[i] = (1 if wk["tile_left"] else 0) | (2 if wk["tile_top"] else 0)
+        for c in range(int(wk["num_cus"])):
+            u = wk["cu"][c]
+            x0, y0, n = int(wk["lcu_x"]) + int(u["x"]), int(wk["lcu_y"]) + int(u["y"]), int(u["size"])
+            cumap["mode"][y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = u["pred_mode"]
+            cumap["size_log2"][y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = n.bit_length() - 1
+            qp[y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = u["qp"]
+            cbf[y0 // 4:(y0 + n) // 4, x0 // 4:(x0 + n) // 4] = rs["cu"]["cbf"][c][0]
+    return cumap, cbf, qp, edge
+
+
+def test_have_dlf_cases():
+    assert len(DLF_CASES) >= 3
+
+
+@pytest.mark.parametrize("name", DLF_CASES)
+def test_encode_then_deblock_oracle_matches_the_encoders_output(oracle, name):
+    """the chain the device runs - encode pass of every LCU, boundary strengths from the unit lists, picture deblocking - restated
+    on the CPU from the three pinned oracle pieces, against the reference encoder's own reconstruction output (SAO off)"""
+    from test_oracle_dlf_golden import oracle_bs, oracle_dlf
+    g, w, h = load_case(name)
+    wide = is16(g)
+    fn = oracle.svt_oracle_encode_lcu16 if wide else oracle.svt_oracle_encode_lcu
+    fn.restype = None
+    fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if wide else (np.uint8, S.LCU_RESULT_DTYPE)
+    nl = S.lcu_count(w, h)
+    pitches = (w, w // 2, w // 2)
+    pb = (C.c_uint32 * 3)(*pitches)
+    for f, first in enumerate(range(0, len(g["work"]), nl)):
+        rec = [np.zeros((hh, p), sdt) for hh, p in zip((h, h // 2, h // 2), pitches)]
+        mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+        rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+        got = np.zeros(nl, rdt)
+        for k in range(nl):
+            work = np.ascontiguousarray(g["work"][first + k:first + k + 1])
+            fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got[k:k + 1].ctypes.data)
+            compare_lcu(work[0], g["result"][first + k], got[k], w, h, (name, f, k), rec=False)
+        cumap, cbf, qp, edge = deblock_maps(g["work"][first:first + nl], got, w, h)
+        hdr = dict(width=w, height=h, bytes_per_sample=2 if wide else 1, qp_stride=w // 8, tc_offset=0, beta_offset=0, cb_qp_offset=0,
+                   cr_qp_offset=0, slice_type=2)
+        pic = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1), refpoc=np.zeros(2, np.uint64), lcu_edge=edge,
+                   bsv=np.zeros((nl, 256), np.uint8), bsh=np.zeros((nl, 256), np.uint8))
+        pic["bsv"], pic["bsh"] = oracle_bs(oracle, pic)
+        pic["pre"], pic["qp"] = rec, qp.reshape(-1)
+        out = oracle_dlf(oracle, pic)
+        for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
+            bad = np.argwhere(out[p] != g[nm][f])
+            assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
