@@ -971,15 +971,24 @@ SVT_AMD_API int svt_amd_intra_pu(SvtAmdContext *ctx, int bytes_per_sample, const
  * EncDec INPUT contract (what the mode decision hands over per LCU: the final coding-unit tree of LargestCodingUnit_t.
  * codedLeafArrayPtr, Codec/EbCodingUnit.h:63-88, 186-222): */
 #define SVT_AMD_LCU_MAX_CUS 64
+/* what the inter branch of EncodePass does with a unit (EbCodingLoop.c:3817-4400), decided by the host from the mode decision's
+ * outputs before the call (mergeFlag, and for merge units skipCost <= mergeCost, :3838-3882): */
+#define SVT_AMD_EP_INTER_AMVP  0   /* mergeFlag == 0: EncodeLoop of every transform unit + the luma cbf decision (PictureFullDistortionLuma,
+                                    * TuEstimateCoeffBitsEncDec, EncodeTuCalcCost: coded vs. zeroed luma by distortion + lambda * rate)  */
+#define SVT_AMD_EP_INTER_MERGE 1   /* merge, not skipped: EncodeLoop of every transform unit, cbf = "has coefficients" (:4164-4253)        */
+#define SVT_AMD_EP_INTER_SKIP  2   /* merge decided skip: no residual, the prediction is the reconstruction (:4165-4171)                  */
 typedef struct SvtAmdLcuCu {
-    uint8_t x, y, size;            /* origin inside the LCU and size in luma samples (GetCodedUnitStats): 8 / 16 / 32      */
-    uint8_t pred_mode;             /* CodingUnit_t.predictionModeFlag: 1 INTER_MODE, 2 INTRA_MODE (this revision: 2 only)  */
+    uint8_t x, y, size;            /* origin inside the LCU and size in luma samples (GetCodedUnitStats): 8 / 16 / 32; inter units
+                                    * also 64 (four 32x32 transform units, tuItr 1..4, EbCodingLoop.c:3944-3970)                 */
+    uint8_t pred_mode;             /* CodingUnit_t.predictionModeFlag: 1 INTER_MODE (2Nx2N), 2 INTRA_MODE (2Nx2N)               */
     uint8_t intra_luma_mode;       /* PredictionUnit_t.intraLumaMode, EB_INTRA_PLANAR .. EB_INTRA_MODE_34                  */
     uint8_t bottom_left_ok, top_right_ok; /* isBottomLeftAvailable / isUpperRightAvailable(depth, index), EbAvailability.c */
     uint8_t qp, chroma_qp;         /* cuPtr->qp; MapChromaQp(clip(qp + cbQpOffset + sliceCbQpOffset)) (EbCodingLoop.c:3255) */
     uint8_t leaf_index;            /* index of the unit in codedLeafArrayPtr (0..84)                                       */
-    uint8_t pad[2];
+    uint8_t inter_dir;             /* PredictionUnit_t.interPredDirectionIndex: UNI_PRED_LIST_0 0, UNI_PRED_LIST_1 1, BI_PRED 2 */
+    uint8_t inter_kind;            /* SVT_AMD_EP_INTER_*                                                                   */
     uint32_t dz_offset;            /* dead-zone override of the luma quantiser (EbCodingLoop.c:3092-3133; 0 = none)        */
+    int16_t mv[2][2];              /* PredictionUnit_t.mv[list].{x, y}, quarter samples                                    */
 } SvtAmdLcuCu;
 typedef struct SvtAmdLcuWork {
     uint16_t lcu_x, lcu_y;         /* luma origin of the LCU in the picture                                              */
@@ -988,6 +997,10 @@ typedef struct SvtAmdLcuWork {
     uint8_t temporal_layer, constrained_intra, strong_smoothing;
     uint8_t tile_left, tile_top, tile_right; /* lcuEdgeInfoPtr->tileLeft/Top/RightEdgeFlag                              */
     uint8_t pad[4];
+    uint32_t full_lambda;          /* contextPtr->fullLambda of the LCU (EncDecConfigureLcu, EbEncDecProcess.c:1448): inter units  */
+    uint32_t luma_cbf_bits[4];     /* mdRateEstimationPtr->lumaCbfBits[ctx], [ctx + (NUMBER_OF_CBF_CASES >> 1)] for ctx 0, 1:
+                                    * {zero cbf ctx 0, zero cbf ctx 1, non-zero ctx 0, non-zero ctx 1} (EncodeTuCalcCost)         */
+    uint8_t pad2[12];
     SvtAmdLcuCu cu[SVT_AMD_LCU_MAX_CUS];
     uint8_t src_y[64 * 64], src_cb[32 * 32], src_cr[32 * 32]; /* source samples of the LCU (enhancedPicturePtr), pitch 64 / 32 */
 } SvtAmdLcuWork;
@@ -1011,6 +1024,9 @@ typedef struct SvtAmdLcuWork16 {
     uint8_t num_cus, slice_type, temporal_layer, constrained_intra, strong_smoothing;
     uint8_t tile_left, tile_top, tile_right;
     uint8_t pad[4];
+    uint32_t full_lambda;
+    uint32_t luma_cbf_bits[4];
+    uint8_t pad2[12];
     SvtAmdLcuCu cu[SVT_AMD_LCU_MAX_CUS];
     uint16_t src_y[64 * 64], src_cb[32 * 32], src_cr[32 * 32];
 } SvtAmdLcuWork16;
@@ -1023,6 +1039,13 @@ typedef struct SvtAmdEncDecPicture SvtAmdEncDecPicture;
 SVT_AMD_API int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t luma_width, uint16_t luma_height, int bytes_per_sample,
                                               SvtAmdEncDecPicture **out);
 SVT_AMD_API int svt_amd_encdec_picture_begin(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic); /* new picture: nothing coded yet */
+/* P / B pictures: the picture-level inputs of the inter units (EncodePassInterPrediction reads pictureControlSetPtr->refPicPtrArray[list],
+ * Codec/EbInterPrediction.c:761; TuEstimateCoeffBitsEncDec reads pictureControlSetPtr->cabacCost, EbCodingLoop.c:4103) - reference
+ * pictures of list 0 / 1 (DEVICE planes, whole padded buffers of the picture's size and sample width; either may be NULL) and the
+ * coefficient-rate tables (HOST pointer, copied on the context's stream).  Call before the first LCU with inter units; holds until the
+ * next call for this picture object. */
+SVT_AMD_API int svt_amd_encdec_picture_set_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRefPicture *ref0,
+                                                 const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost);
 SVT_AMD_API int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic);
 /* works / results: HOST arrays of n LCUs that do not depend on each other (left, top and top-right LCUs of each were encoded by
  * earlier calls); blocking.  Lanes of one context family may call concurrently for different LCUs of one picture. */

@@ -2,9 +2,11 @@
  * TEST INFRASTRUCTURE ONLY (oracle/): link-time interposer around the REFERENCE's EncodePass (Codec/EbCodingLoop.c:2989),
  * compiled only into oracle/_ref/libsvtref.so with -Wl,--wrap=EncodePass.
  *
- * When SVT_REF_ENCODEPASS_DUMP names a file, every call on an LCU whose coding units are all intra 2Nx2N units of 8..32 (4:2:0;
- * 8-bit encodes in EpRecord, 10-bit encodes - EncodePass with is16bit - in EpRecord16 with 16-bit source and reconstruction) is
- * recorded: BEFORE the call the final coding-unit list of the LCU and its source samples, in the layout of the product's
+ * When SVT_REF_ENCODEPASS_DUMP names a file, every call on an LCU whose coding units are all intra 2Nx2N units of 8..32 or inter
+ * 2Nx2N units of 8..64 with the plain encode loop (4:2:0; 8-bit encodes in EpRecord, 10-bit encodes - EncodePass with is16bit - in
+ * EpRecord16 with 16-bit source and reconstruction) is recorded, and before the first such LCU of a P / B picture the picture-level
+ * inputs of the inter branch: the reference pictures it predicts from (whole padded buffers, EpRefRecord, once per reference
+ * picture) and the coefficient-rate tables (pictureControlSetPtr->cabacCost, EpCostRecord).  Per LCU: BEFORE the call the final coding-unit list of the LCU and its source samples, in the layout of the product's
  * encode-pass input contract (SvtAmdLcuWork, include/svt_hevc_amd.h); AFTER it what the reference produced, in the layout of the
  * output contract (SvtAmdLcuResult): TransformUnit_t cbf / isOnlyDc / nzCoefCount, LargestCodingUnit_t.quantizedCoeff and the
  * LCU of the reconstruction buffer (run the encoder with the loop filters off, `-dlf 1 -sao 0`, so that the buffer still holds
@@ -34,10 +36,13 @@ void __real_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
                        EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr);
 
 #define EP_DUMP_MAGIC 0x53415045U /* "EPAS" */
+#define EP_REF_MAGIC 0x46525045U  /* "EPRF" */
+#define EP_COST_MAGIC 0x43435045U /* "EPCC" */
 typedef struct EpRecord {
     uint32_t magic, record_size;
     uint64_t picture_number;
     uint32_t width, height, lcu_index, dlf_off;
+    uint64_t ref_poc[2]; /* reference pictures of list 0 / 1 (EpRefRecord.poc), ~0 = none */
     SvtAmdLcuWork work;
     SvtAmdLcuResult result;
 } EpRecord;
@@ -45,18 +50,78 @@ typedef struct EpRecord16 { /* same head; record_size tells them apart */
     uint32_t magic, record_size;
     uint64_t picture_number;
     uint32_t width, height, lcu_index, dlf_off;
+    uint64_t ref_poc[2];
     SvtAmdLcuWork16 work;
     SvtAmdLcuResult16 result;
 } EpRecord16;
+typedef struct EpRefRecord { /* followed by the three padded planes: strideY * (height + 2 originY) luma samples, then Cb, Cr */
+    uint32_t magic, record_size;
+    uint64_t poc;
+    uint32_t bps, strideY, strideC, originX, originY, width, height, pad;
+} EpRefRecord;
+typedef struct EpCostRecord {
+    uint32_t magic, record_size;
+    uint64_t picture_number;
+    SvtAmdCabacCost cost;
+} EpCostRecord;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static FILE *g_file;
 static int g_state;
+static uint64_t g_ref_done[64], g_cost_done[64];
+static int g_nref, g_ncost;
+
+_Static_assert(sizeof(SvtAmdCabacCost) == sizeof(CabacCost_t), "CabacCost_t layout");
+
+/* once per reference picture / per picture: the picture-level inputs of the inter branch */
+static void dump_inter_inputs(const PictureControlSet_t *pcs, int is16bit, uint64_t ref_poc[2])
+{
+    ref_poc[0] = ref_poc[1] = ~0ull;
+    if (pcs->sliceType == EB_I_PICTURE)
+        return;
+    pthread_mutex_lock(&g_lock);
+    for (int l = 0; l < (pcs->sliceType == EB_B_PICTURE ? 2 : 1); l++) {
+        const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
+        const EbPictureBufferDesc_t *b = is16bit ? ro->referencePicture16bit : ro->referencePicture;
+        ref_poc[l] = ro->refPOC;
+        int seen = 0;
+        for (int i = 0; i < g_nref; i++)
+            seen |= g_ref_done[i] == ro->refPOC;
+        if (seen || g_nref >= 64)
+            continue;
+        g_ref_done[g_nref++] = ro->refPOC;
+        const size_t bps = is16bit ? 2 : 1, rowsY = b->height + 2u * b->originY, rowsC = rowsY / 2;
+        EpRefRecord h = {EP_REF_MAGIC, 0, ro->refPOC, (uint32_t)bps, b->strideY, b->strideCb, b->originX, b->originY, b->width, b->height, 0};
+        h.record_size = (uint32_t)(sizeof(h) + bps * ((size_t)b->strideY * rowsY + 2u * (size_t)b->strideCb * rowsC));
+        fwrite(&h, sizeof(h), 1, g_file);
+        fwrite(b->bufferY, bps, (size_t)b->strideY * rowsY, g_file);
+        fwrite(b->bufferCb, bps, (size_t)b->strideCb * rowsC, g_file);
+        fwrite(b->bufferCr, bps, (size_t)b->strideCr * rowsC, g_file);
+    }
+    int seen = 0;
+    for (int i = 0; i < g_ncost; i++)
+        seen |= g_cost_done[i] == pcs->pictureNumber;
+    if (!seen && g_ncost < 64) {
+        g_cost_done[g_ncost++] = pcs->pictureNumber;
+        EpCostRecord c;
+        c.magic = EP_COST_MAGIC, c.record_size = (uint32_t)sizeof(c), c.picture_number = pcs->pictureNumber;
+        memcpy(&c.cost, pcs->cabacCost, sizeof(c.cost));
+        fwrite(&c, sizeof(c), 1, g_file);
+    }
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+}
 
 /* the coded leaves of the LCU in order; returns 0 when a unit is outside what the record (and the product path) covers */
 static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr,
-                     EB_U32 lcuOriginX, EB_U32 lcuOriginY)
+                     EB_U32 lcuOriginX, EB_U32 lcuOriginY, const EncDecContext_t *contextPtr)
 {
+    /* the encode loop this record (and the product path) covers: no delta-QP segments, no forced cbf, no coefficient shaping
+     * (EbCodingLoop.c:3161, :2377, EbEncDecProcess.c:2211) */
+    const EB_BOOL useDeltaQp = (EB_BOOL)(scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled);
+    const int inter_ok = !useDeltaQp && !contextPtr->fastEl && lcuPtr->chromaEncodeMode != CHROMA_MODE_BEST;
+    if (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ)
+        return 0; /* encMode <= 4: the quantiser is DecoupledQuantizeInvQuantizeLoops (EbTransforms.c:3009-3052) */
     memset(w, 0, sizeof(*w));
     w->lcu_x = (uint16_t)lcuOriginX, w->lcu_y = (uint16_t)lcuOriginY;
     w->slice_type = (uint8_t)pcs->sliceType, w->temporal_layer = pcs->temporalLayerIndex;
@@ -71,11 +136,33 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
             continue;
         }
         const CodedUnitStats_t *st = GetCodedUnitStats(cuItr);
-        if (cu->predictionModeFlag != INTRA_MODE || cu->predictionUnitArray->intraLumaMode == EB_INTRA_MODE_4x4 || st->size > 32 || n >= SVT_AMD_LCU_MAX_CUS)
+        const int intra = cu->predictionModeFlag == INTRA_MODE;
+        if (n >= SVT_AMD_LCU_MAX_CUS || (intra && (cu->predictionUnitArray->intraLumaMode == EB_INTRA_MODE_4x4 || st->size > 32)) || (!intra && !inter_ok))
             return 0;
         SvtAmdLcuCu *u = &w->cu[n++];
         u->x = st->originX, u->y = st->originY, u->size = st->size, u->pred_mode = (uint8_t)cu->predictionModeFlag;
         u->intra_luma_mode = (uint8_t)cu->predictionUnitArray->intraLumaMode;
+        if (!intra) {
+            const PredictionUnit_t *pu = cu->predictionUnitArray;
+            u->intra_luma_mode = 0;
+            u->inter_dir = (uint8_t)pu->interPredDirectionIndex;
+            for (int l = 0; l < 2; l++)
+                u->mv[l][0] = pu->mv[l].x, u->mv[l][1] = pu->mv[l].y;
+            /* merge / skip decision of the unit (EbCodingLoop.c:3838-3882) */
+            u->inter_kind = SVT_AMD_EP_INTER_AMVP;
+            if (pu->mergeFlag) {
+                EB_U64 skipCost = contextPtr->mdContext->mdEpPipeLcu[cu->leafIndex].skipCost;
+                if (pcs->sliceType == EB_B_PICTURE && pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_FALSE) {
+                    static const EB_U8 INTRA_AREA_TH[MAX_TEMPORAL_LAYERS] = {40, 30, 30, 0, 0, 0};
+                    const EbReferenceObject_t *r0 = (const EbReferenceObject_t *)pcs->refPicPtrArray[REF_LIST_0]->objectPtr;
+                    const EbReferenceObject_t *r1 = (const EbReferenceObject_t *)pcs->refPicPtrArray[REF_LIST_1]->objectPtr;
+                    if (pcs->ParentPcsPtr->variance[lcuPtr->index][0] < 200 &&
+                        (r0->intraCodedArea > INTRA_AREA_TH[r0->tmpLayerIdx] || r1->intraCodedArea > INTRA_AREA_TH[r1->tmpLayerIdx]))
+                        skipCost += (skipCost * 70) / 100;
+                }
+                u->inter_kind = skipCost <= contextPtr->mdContext->mdEpPipeLcu[cu->leafIndex].mergeCost ? SVT_AMD_EP_INTER_SKIP : SVT_AMD_EP_INTER_MERGE;
+            }
+        }
         uint32_t lg = 0;
         while ((1u << lg) < st->size)
             lg++;
@@ -85,7 +172,23 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
         cuItr += DepthOffset[st->depth];
     }
     w->num_cus = (uint8_t)n;
-    return 1;
+    /* doRecon (:3083-3087): in non-reference pictures of the limitIntra presets an LCU without intra units is not reconstructed (and a
+     * skipped unit of it not even predicted); the record then carries flags and coefficients only (bit 1 of dlf_off) */
+    int any_intra = 0;
+    for (EB_U32 i = 0; i < n; i++)
+        any_intra |= w->cu[i].pred_mode == INTRA_MODE;
+    const int do_recon = !contextPtr->mdContext->limitIntra || any_intra || pcs->ParentPcsPtr->isUsedAsReferenceFlag || scs->staticConfig.reconEnabled;
+    return do_recon ? 1 : 2;
+}
+
+/* what EncDecConfigureLcu has set when EncodePass returns (the harness cannot see it before the call only when the process reuses the
+ * context for another LCU: it does not, the context is the caller's for the whole call) */
+static void fill_rate_inputs(SvtAmdLcuWork *w, const EncDecContext_t *contextPtr)
+{
+    w->full_lambda = contextPtr->fullLambda;
+    w->luma_cbf_bits[0] = contextPtr->mdRateEstimationPtr->lumaCbfBits[0], w->luma_cbf_bits[1] = contextPtr->mdRateEstimationPtr->lumaCbfBits[1];
+    w->luma_cbf_bits[2] = contextPtr->mdRateEstimationPtr->lumaCbfBits[(NUMBER_OF_CBF_CASES >> 1)];
+    w->luma_cbf_bits[3] = contextPtr->mdRateEstimationPtr->lumaCbfBits[(NUMBER_OF_CBF_CASES >> 1) + 1];
 }
 
 /* units' QPs and what the reference left in the TransformUnit_t records, after the call */
@@ -98,10 +201,14 @@ static void fill_after(SvtAmdLcuCu *cus, int n, SvtAmdLcuCuResult *out, const Pi
         u->qp = (uint8_t)cu->qp;
         const EB_S8 qs = (EB_S8)CLIP3((EB_S8)MIN_QP_VALUE, (EB_S8)MAX_CHROMA_MAP_QP_VALUE, (EB_S8)(cu->qp + pcs->cbQpOffset + pcs->sliceCbQpOffset));
         u->chroma_qp = MapChromaQp((EB_U8)qs);
-        SvtAmdLcuCuResult *o = &out[i];
-        o->cbf[0] = tu->lumaCbf, o->cbf[1] = tu->cbCbf, o->cbf[2] = tu->crCbf;
-        for (int p = 0; p < 3; p++)
-            o->only_dc[p] = tu->isOnlyDc[p], o->nz[p] = tu->nzCoefCount[p];
+        /* a 64x64 unit is alone in its LCU: entry 0 = transformUnitArray[0] (the flags of the four units OR-ed), entries 1..4 = its four
+         * 32x32 transform units (tuItr 1..4) */
+        for (int k = 0; k < (u->size == 64 ? 5 : 1); k++) {
+            SvtAmdLcuCuResult *o = &out[i + k];
+            o->cbf[0] = tu[k].lumaCbf, o->cbf[1] = tu[k].cbCbf, o->cbf[2] = tu[k].crCbf;
+            for (int p = 0; p < 3; p++)
+                o->only_dc[p] = tu[k].isOnlyDc[p], o->nz[p] = tu[k].nzCoefCount[p];
+        }
     }
 }
 
@@ -111,17 +218,21 @@ static void encode_pass_16bit(SequenceControlSet_t *scs, PictureControlSet_t *pc
                               EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
 {
     EpRecord16 *r = (EpRecord16 *)calloc(1, sizeof(*r));
-    if (r && !fill_work((SvtAmdLcuWork *)&r->work /* same head */, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY)) {
+    int kind = 0;
+    if (r && !(kind = fill_work((SvtAmdLcuWork *)&r->work /* same head */, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr))) {
         free(r);
         r = NULL;
     }
+    if (r)
+        dump_inter_inputs(pcs, 1, r->ref_poc);
     __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
     if (!r)
         return;
+    fill_rate_inputs((SvtAmdLcuWork *)&r->work, contextPtr);
     const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
     r->magic = EP_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->picture_number = pcs->pictureNumber;
     r->width = scs->lumaWidth, r->height = scs->lumaHeight, r->lcu_index = tbAddr;
-    r->dlf_off = scs->staticConfig.disableDlfFlag;
+    r->dlf_off = scs->staticConfig.disableDlfFlag | (kind == 2 ? 2u : 0u);
     fill_after(r->work.cu, r->work.num_cus, r->result.cu, pcs, lcuPtr);
     const EbPictureBufferDesc_t *in = contextPtr->inputSample16bitBuffer;
     for (EB_U32 y = 0; y < lh; y++)
@@ -166,16 +277,19 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         pthread_mutex_unlock(&g_lock);
     }
     EpRecord *r = NULL;
+    int kind = 0;
     if (g_state > 0 && contextPtr->is16bit && contextPtr->colorFormat == EB_YUV420) {
         encode_pass_16bit(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
         return;
     }
     if (g_state > 0 && !contextPtr->is16bit && contextPtr->colorFormat == EB_YUV420 && (r = (EpRecord *)calloc(1, sizeof(*r))) != NULL) {
-        if (!fill_work(&r->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY)) {
+        if (!(kind = fill_work(&r->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr))) {
             free(r);
             r = NULL;
         }
     }
+    if (r)
+        dump_inter_inputs(pcs, 0, r->ref_poc);
     const EbPictureBufferDesc_t *in = (const EbPictureBufferDesc_t *)pcs->ParentPcsPtr->enhancedPicturePtr;
     const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
     if (r) {
@@ -191,19 +305,9 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         return;
     r->magic = EP_DUMP_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->picture_number = pcs->pictureNumber;
     r->width = scs->lumaWidth, r->height = scs->lumaHeight, r->lcu_index = tbAddr;
-    r->dlf_off = scs->staticConfig.disableDlfFlag;
-    for (int i = 0; i < r->work.num_cus; i++) {
-        SvtAmdLcuCu *u = &r->work.cu[i];
-        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[u->leaf_index];
-        const TransformUnit_t *tu = &cu->transformUnitArray[0];
-        u->qp = (uint8_t)cu->qp;
-        const EB_S8 qs = (EB_S8)CLIP3((EB_S8)MIN_QP_VALUE, (EB_S8)MAX_CHROMA_MAP_QP_VALUE, (EB_S8)(cu->qp + pcs->cbQpOffset + pcs->sliceCbQpOffset));
-        u->chroma_qp = MapChromaQp((EB_U8)qs);
-        SvtAmdLcuCuResult *o = &r->result.cu[i];
-        o->cbf[0] = tu->lumaCbf, o->cbf[1] = tu->cbCbf, o->cbf[2] = tu->crCbf;
-        for (int p = 0; p < 3; p++)
-            o->only_dc[p] = tu->isOnlyDc[p], o->nz[p] = tu->nzCoefCount[p];
-    }
+    r->dlf_off = scs->staticConfig.disableDlfFlag | (kind == 2 ? 2u : 0u);
+    fill_after(r->work.cu, r->work.num_cus, r->result.cu, pcs, lcuPtr);
+    fill_rate_inputs(&r->work, contextPtr);
     const EbPictureBufferDesc_t *q = lcuPtr->quantizedCoeff;
     for (int y = 0; y < 64; y++)
         memcpy(r->result.coeff_y + y * 64, (const int16_t *)q->bufferY + (size_t)y * q->strideY, 128);

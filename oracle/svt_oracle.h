@@ -270,5 +270,11 @@ void svt_oracle_encode_lcu(uint8_t *const rec[3], const uint32_t pitch[3], uint8
                            const SvtAmdLcuWork *W, SvtAmdLcuResult *R);
 void svt_oracle_encode_lcu16(uint16_t *const rec[3], const uint32_t pitch[3], uint8_t *map, uint32_t mapPitch, uint32_t width, uint32_t height,
                              const SvtAmdLcuWork16 *W, SvtAmdLcuResult16 *R);
+void svt_oracle_encode_lcu_inter(uint8_t *const rec[3], const uint32_t pitch[3], uint8_t *map, uint32_t mapPitch, uint32_t width, uint32_t height,
+                                 const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost, const SvtAmdLcuWork *W,
+                                 SvtAmdLcuResult *R);
+void svt_oracle_encode_lcu_inter16(uint16_t *const rec[3], const uint32_t pitch[3], uint8_t *map, uint32_t mapPitch, uint32_t width, uint32_t height,
+                                   const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost, const SvtAmdLcuWork16 *W,
+                                   SvtAmdLcuResult16 *R);
 
 #endif

@@ -29,7 +29,16 @@
 #include "txfm_device.h"
 #include <string.h>
 #include <vector>
+#include <mutex>
 #include "intra_device.h"
+#include "rate_device.h"
+
+struct EpRefPlanes {               /* one reference picture (SvtAmdRefPicture): device pointers to the START of the padded planes */
+    const void *plane[3];
+    uint32_t stride[2];            /* luma, chroma; samples */
+    int32_t originX, originY, width, height; /* luma */
+    int32_t size[2];               /* samples of a luma / chroma plane: the bound of the window loads */
+};
 
 struct EpPicture {                 /* = SvtAmdEncDecPicture's device part */
     uint8_t *rec[3];               /* un-deblocked reconstruction, sample (0,0); bytes_per_sample bytes per sample */
@@ -39,6 +48,9 @@ struct EpPicture {                 /* = SvtAmdEncDecPicture's device part */
     unsigned long long *prof;      /* debug (svt_amd_debug_encdec_profile): 16 shader-clock sums per LCU, or null */
     uint16_t width, height;        /* luma */
     uint32_t bps;
+    /* P / B pictures (svt_amd_encdec_picture_set_inter): the reference pictures of list 0 / 1 and the picture's coefficient-rate tables */
+    EpRefPlanes ref[2];
+    const SvtAmdCabacCost *cost;
 };
 struct SvtAmdEncDecPicture {
     EpPicture d;
@@ -47,6 +59,8 @@ struct SvtAmdEncDecPicture {
     unsigned *d_sync; /* [0] ticket counter, [1 + lcu] epoch of the picture-level call that finished the LCU, then the ticket order */
     unsigned epoch;
     int nlcu;
+    SvtAmdCabacCost *d_cost;
+    bool has_ref[2];
 };
 
 typedef SvtAmdLcuCu LcuCu;
@@ -73,75 +87,174 @@ struct EpLocal {
     static constexpr int PY = 144, PC = 80, X0 = 16; /* row pitches; column of x = 0 (rows of units start 16-byte aligned) */
     T y[65 * PY];
     T c[2][33 * PC];
-    uint8_t mode[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
+    uint8_t mode[3][17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33]; one copy per plane pipeline (each marks the
+                               * units IT has finished: the three waves run apart) */
     T src_y[64 * 64], src_c[2][32 * 32];
     SvtAmdLcuCu cus[SVT_AMD_LCU_MAX_CUS]; /* the unit list: a unit's descriptor is an LDS read, not a trip to HBM in front of every unit */
     __device__ __forceinline__ T *at(int p, int x, int y_) { return p == 0 ? &y[(y_ + 1) * PY + X0 + x] : &c[p - 1][(y_ + 1) * PC + X0 + x]; }
     __device__ __forceinline__ int pitch(int p) const { return p == 0 ? PY : PC; }
     /* mode type at luma sample (x, y) relative to the LCU: what lies below the LCU, right of it (from its first row on) or right of
      * the top-right LCU is never coded before this LCU */
-    __device__ __forceinline__ int mode_at(int x, int y_) const
+    __device__ __forceinline__ int mode_at(int p, int x, int y_) const
     {
         const int cx = x >> 2, cy = y_ >> 2;
         if (cy >= 16 || cx >= 32 || (cy >= 0 && cx >= 16))
             return 0xFF;
-        return mode[(cy + 1) * 36 + cx + 1];
+        return mode[p][(cy + 1) * 36 + cx + 1];
     }
 };
 
-/* The intra reference of the unit (availability, substitution, smoothing) and the three predicted blocks, written into the local
- * reconstruction planes at the unit's position - k_intra_pu (intra_kernels.hip) with the neighbours read from the LCU in LDS. */
+/* wave-level ordering of LDS traffic: what the lanes of this wave wrote is visible to its other lanes */
+#define EP_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+/* The intra reference (availability, substitution, smoothing) and the predicted block of ONE plane of the unit, by ONE wave, written
+ * into the local reconstruction plane at the unit's position - k_intra_pu (intra_kernels.hip) with the neighbours read from the
+ * LCU in LDS.  A plane only ever reads its own samples and the (input-determined) mode types, so the three planes of an LCU are three
+ * independent pipelines over the unit list: no workgroup barrier inside the LCU. */
+/* the LCU's flags in registers: read from the work record ONCE (the record is in HBM, a load per unit is a round trip per unit) */
+struct EpFlags {
+    bool tile_left, tile_top, tile_right, constrained_intra, strong_smoothing;
+    int slice_type, lcu_x, lcu_y;
+    uint32_t full_lambda, cbf_bits[4];
+};
+
+/* scratch of one plane pipeline's motion compensation: a tile of up to 32x32 samples at a time */
 template <typename T>
-__device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work &W, const LcuCu &cu, int t, int16_t (*border)[132], int16_t (*ref)[132], uint8_t *ok,
-                                 int *s_small /* [0] first group, [1..3] dc */, unsigned long long *ph /* debug: clocks of 4 sub-phases, or null */)
+struct EpMcScratch {
+    static constexpr int WP = 40;
+    T win[39 * WP];        /* reference window: (32 + 7) rows x columns */
+    int16_t tmp[39 * 32];  /* horizontally filtered rows */
+    int16_t raw[32 * 32];  /* list-0 intermediate of a bi-predicted tile */
+};
+
+static __constant__ int8_t c_ep_luma_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1},
+                                                   {0, 1, -5, 17, 58, -10, 4, -1}};
+static __constant__ int8_t c_ep_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
+                                                     {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+
+/* EncodePassInterPrediction[16bit] of ONE plane of a 2Nx2N unit by ONE wave, straight into the LCU's reconstruction plane in LDS
+ * (the prediction buffer of EncodePass IS the reconstruction buffer): position clamp (Codec/EbInterPrediction.c:802-812), then per
+ * tile of <= 32x32 samples and per reference list the H.265 8.5.3.3.3 separable filter in the reference's fixed-point conventions
+ * (mcp_kernels.hip:k_mcp, oracle/svt_oracle_mcp.c).  ONE generic path: the 8- (4-) tap filter in both directions also at integer
+ * positions - with the identity taps {64} its two-pass arithmetic reduces exactly to the one-pass and copy forms of the reference
+ * ((64 h' + 64 B + 2^(11-s)) >> (12-s) == (h + 32) >> 6 with h' = (h - B 2^s) >> s; raw: 64 h' >> 6 == h').  Samples the
+ * reference's own functions never touch (zero taps) are loaded from clamped addresses. */
+template <typename T>
+__device__ __forceinline__ void ep_inter_predict_plane(const EpPicture &P, EpLocal<T> &L, const EpFlags &F, const LcuCu &cu, int p, int lane, EpMcScratch<T> &M)
 {
-    unsigned long long pc = ph ? __builtin_readcyclecounter() : 0;
+    constexpr int WP = EpMcScratch<T>::WP;
+    constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
+    const bool chroma = p != 0;
+    const int B = (sizeof(T) == 2 || !chroma) ? 8192 : 0;
+    const int N = cu.size, n = chroma ? N >> 1 : N, tn = n > 32 ? 32 : n, lgt = 31 - __clz(tn);
+    const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3, rows = tn + ntaps - 1;
+    const int lx = chroma ? cu.x >> 1 : cu.x, ly = chroma ? cu.y >> 1 : cu.y;
+    const bool bi = cu.inter_dir == 2;
+    for (int ty0 = 0; ty0 < n; ty0 += 32)
+        for (int tx0 = 0; tx0 < n; tx0 += 32) {
+            bool second = false;
+            for (int l = 0; l < 2; l++) {
+                if (!(bi || cu.inter_dir == l))
+                    continue;
+                const EpRefPlanes &R = P.ref[l];
+                const int qx = min(max(((F.lcu_x + cu.x + R.originX) << 2) + cu.mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
+                const int qy = min(max(((F.lcu_y + cu.y + R.originY) << 2) + cu.mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
+                const int ix = (chroma ? qx >> 3 : qx >> 2) + tx0, iy = (chroma ? qy >> 3 : qy >> 2) + ty0;
+                const int fx = __builtin_amdgcn_readfirstlane(chroma ? qx & 7 : qx & 3), fy = __builtin_amdgcn_readfirstlane(chroma ? qy & 7 : qy & 3);
+                const int stride = (int)R.stride[chroma], last = R.size[chroma] - 1;
+                const T *plane = (const T *)R.plane[p];
+                int tx[8], tv[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    tx[k] = chroma ? (k < 4 ? (int)c_ep_chroma_taps[fx][k & 3] : 0) : (int)c_ep_luma_taps[fx][k];
+                    tv[k] = chroma ? (k < 4 ? (int)c_ep_chroma_taps[fy][k & 3] : 0) : (int)c_ep_luma_taps[fy][k];
+                }
+                /* window: lane = column, one row per step */
+                if (lane < rows) {
+                    const int base = (iy + first) * stride + ix + first + lane;
+#pragma unroll 4
+                    for (int j = 0; j < rows; j++)
+                        M.win[j * WP + lane] = plane[min(max(base + j * stride, 0), last)];
+                }
+                EP_WAVE_SYNC();
+                for (int i = lane; i < rows << lgt; i += 64) { /* horizontal pass of every window row */
+                    const int j = i >> lgt, x = i & (tn - 1);
+                    int hs = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k < ntaps)
+                            hs += tx[k] * (int)M.win[j * WP + x + k];
+                    M.tmp[j * 32 + x] = (int16_t)((hs - (B << s1)) >> s1);
+                }
+                EP_WAVE_SYNC();
+                for (int i = lane; i < tn << lgt; i += 64) { /* vertical pass */
+                    const int y = i >> lgt, x = i & (tn - 1);
+                    int sum = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k < ntaps)
+                            sum += tv[k] * (int)M.tmp[(y + k) * 32 + x];
+                    T *dst = L.at(p, lx + tx0 + x, ly + ty0 + y);
+                    if (!bi) {
+                        *dst = (T)min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
+                    } else if (!second) {
+                        M.raw[i] = (int16_t)(sum >> 6);
+                    } else { /* BiPredClipping / BiPredClipping16bit (Offset5 / ChromaOffset5, Codec/EbDefinitions.h:1022-1030) */
+                        const int a = (int)M.raw[i] + (int)(int16_t)(sum >> 6);
+                        *dst = (T)(sizeof(T) == 1 ? min(255, max(0, (a + (chroma ? 64 : 16448)) >> 7)) : min(1023, max(0, (a + 16400) >> 5)));
+                    }
+                }
+                EP_WAVE_SYNC();
+                second = true;
+            }
+        }
+}
+
+template <typename T>
+__device__ __forceinline__ void ep_intra_predict_plane(EpLocal<T> &L, const EpFlags &W, const LcuCu &cu, int p, int lane, int16_t *border,
+                                       int16_t *ref, bool prof, unsigned long long (&ph)[4] /* debug: clocks of 4 sub-phases */)
+{
+    unsigned long long pc = prof ? __builtin_readcyclecounter() : 0;
 #define EP_PH(i)                                                  \
     do {                                                          \
-        if (ph) {                                                 \
+        if (prof) {                                               \
             const unsigned long long now = __builtin_readcyclecounter(); \
             ph[i] += now - pc, pc = now;                          \
         }                                                         \
     } while (0)
     constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, mid = sizeof(T) == 1 ? 128 : 512, thr = sizeof(T) == 1 ? 8 : 32;
     const int N = cu.size, nb = N >> 2, lgN = 31 - __clz(N);
+    const int n = p ? N >> 1 : N, lgn = p ? lgN - 1 : lgN, lgG = p ? 1 : 2, g = 1 << lgG; /* plane size; samples per neighbour group */
+    const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
     const bool pic_left = W.tile_left && cu.x == 0, pic_top = W.tile_top && cu.y == 0;
     const bool pic_right = W.tile_right && ((cu.x + N) & 63) == 0;
-    if (t < 64) { /* the 4 nb + 1 <= 33 neighbour groups, all on the first wave: availability flags and the first available group */
-        bool a = false;
-        if (t > 4 * nb) {
-        } else if (t < 2 * nb) { /* left group t covers rows [2N-4-4t, 2N-4t) */
-            const int e = L.mode_at(cu.x - 1, cu.y + 2 * N - 4 - 4 * t);
-            a = !(e == 0xFE || (!cu.bottom_left_ok && t < nb) || e == 0xFF || pic_left || (e == 1 && W.constrained_intra));
-        } else if (t == 2 * nb) {
-            const int e = L.mode_at(cu.x - 1, cu.y - 1);
-            a = !(e == 0xFE || e == 0xFF || pic_left || pic_top || (e == 1 && W.constrained_intra));
-        } else {
-            const int k = t - 2 * nb - 1, e = L.mode_at(cu.x + 4 * k, cu.y - 1);
-            a = !(e == 0xFE || (!cu.top_right_ok && k >= nb) || e == 0xFF || pic_top || (pic_right && k >= nb) ||
-                  (e == 1 && W.constrained_intra));
-        }
-        if (t <= 4 * nb)
-            ok[t] = a;
-        const unsigned long long m = __ballot(a);
-        if (t == 0) {
-            s_small[0] = m ? __ffsll((long long)m) - 1 : 1 << 30;
-            s_small[4] = (int)(uint32_t)m, s_small[5] = (int)(uint32_t)(m >> 32); /* availability of the <= 33 groups, bit per group */
-        }
+    /* the 4 nb + 1 <= 33 neighbour groups: availability by ballot */
+    bool a = false;
+    if (lane > 4 * nb) {
+    } else if (lane < 2 * nb) { /* left group covers luma rows [2N-4-4 lane, 2N-4 lane) */
+        const int e = L.mode_at(p, cu.x - 1, cu.y + 2 * N - 4 - 4 * lane);
+        a = !(e == 0xFE || (!cu.bottom_left_ok && lane < nb) || e == 0xFF || pic_left || (e == 1 && W.constrained_intra));
+    } else if (lane == 2 * nb) {
+        const int e = L.mode_at(p, cu.x - 1, cu.y - 1);
+        a = !(e == 0xFE || e == 0xFF || pic_left || pic_top || (e == 1 && W.constrained_intra));
+    } else {
+        const int k = lane - 2 * nb - 1, e = L.mode_at(p, cu.x + 4 * k, cu.y - 1);
+        a = !(e == 0xFE || (!cu.top_right_ok && k >= nb) || e == 0xFF || pic_top || (pic_right && k >= nb) || (e == 1 && W.constrained_intra));
     }
-    __syncthreads();
+    const unsigned long long m = __ballot(a);
+    const int firstGroup = m ? __ffsll((long long)m) - 1 : 1 << 30;
     EP_PH(0);
-    const int firstGroup = s_small[0];
-    for (int i = t; i < 3 * 129; i += 256) { /* substitution, one thread per (plane, sample in scan order) */
-        const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N, lgG = p ? 1 : 2, g = 1 << lgG; /* samples per group */
-        if (k > 4 * n)
-            continue;
+    for (int k = lane; k <= 4 * n; k += 64) { /* substitution, one lane per sample in scan order */
         int v = mid;
         if (firstGroup < (1 << 30)) {
             /* the nearest available sample at or below k in scan order (the reference walks down sample by sample): k itself when
-             * its group is there, otherwise the LAST sample of the nearest available group below - found with bit operations on
-             * the availability mask - and, with nothing below, the first sample of the first available group */
-            const unsigned long long m = ((unsigned long long)(uint32_t)s_small[5] << 32) | (uint32_t)s_small[4];
+             * its group is there, otherwise the LAST sample of the nearest available group below - bit operations on the
+             * availability mask - and, with nothing below, the first sample of the first available group */
             const int gk = k < 2 * n ? k >> lgG : k == 2 * n ? 2 * nb : 2 * nb + 1 + ((k - 2 * n - 1) >> lgG);
             const unsigned long long below = m & ((2ull << gk) - 1ull); /* groups 0..gk */
             int src;
@@ -153,60 +266,50 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
             } else {
                 src = firstGroup < 2 * nb ? firstGroup * g : firstGroup == 2 * nb ? 2 * n : 2 * n + 1 + (firstGroup - 2 * nb - 1) * g;
             }
-            const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
             /* scan order: [0, 2n) = left column bottom to top (sample 2n-1-src from the top), 2n = top-left, then the top row */
             v = src < 2 * n ? (int)*L.at(p, lx - 1, ly + 2 * n - 1 - src) : src == 2 * n ? (int)*L.at(p, lx - 1, ly - 1)
                                                                                           : (int)*L.at(p, lx + (src - 2 * n - 1), ly - 1);
         }
-        border[p][k] = (int16_t)v;
+        border[k] = (int16_t)v;
     }
-    __syncthreads();
+    EP_WAVE_SYNC();
     EP_PH(1);
     const int lmode = cu.intra_luma_mode;
     const int dA = abs(lmode - 10), dB = abs(lmode - 26), dm = dA < dB ? dA : dB;
     const int thrTab = lgN == 2 ? 35 : lgN == 3 ? 7 : lgN == 4 ? 1 : lgN == 5 ? 0 : 10; /* intraLumaFilterTable */
-    const bool filt = dm > thrTab && lmode != 1;
-    const int bl = border[0][0], tlv = border[0][2 * N], tr = border[0][4 * N];
-    const bool strong = W.strong_smoothing && N >= 32 && abs(bl + tlv - 2 * border[0][N]) < thr && abs(tlv + tr - 2 * border[0][3 * N]) < thr;
-    for (int i = t; i < 3 * 129; i += 256) {
-        const int p = i / 129, k = i - p * 129, n = p ? N >> 1 : N;
-        if (k > 4 * n)
-            continue;
-        int v = border[p][k];
-        if (p == 0 && filt) {
+    const bool filt = p == 0 && dm > thrTab && lmode != 1;
+    const int bl = border[0], tlv = border[2 * n], tr = border[4 * n];
+    const bool strong = p == 0 && W.strong_smoothing && N >= 32 && abs(bl + tlv - 2 * border[n]) < thr && abs(tlv + tr - 2 * border[3 * n]) < thr;
+    for (int k = lane; k <= 4 * n; k += 64) {
+        int v = border[k];
+        if (filt) {
             if (strong) {
                 if (k > 0 && k < 2 * n)
                     v = ((2 * n - k) * bl + k * tlv + n) >> (lgN + 1);
                 else if (k > 2 * n && k < 4 * n)
                     v = ((2 * n - (k - 2 * n)) * tlv + (k - 2 * n) * tr + n) >> (lgN + 1);
             } else if (k > 0 && k < 4 * n) {
-                v = (border[0][k - 1] + 2 * v + border[0][k + 1] + 2) >> 2;
+                v = (border[k - 1] + 2 * v + border[k + 1] + 2) >> 2;
             }
         }
-        ref[p][k < 2 * n ? 2 * n - 1 - k : k] = (int16_t)v;
+        ref[k < 2 * n ? 2 * n - 1 - k : k] = (int16_t)v;
     }
-    __syncthreads();
+    EP_WAVE_SYNC();
     EP_PH(2);
-    if (lmode == 1) { /* DC: wave p sums plane p's left column and top row */
-        const int p = t >> 6, l = t & 63;
-        if (p < 3) {
-            const int n = p ? N >> 1 : N;
-            int dc = l < n ? ref[p][l] + ref[p][2 * n + 1 + l] : 0;
+    int dcv = 0;
+    if (lmode == 1) { /* DC: left column + top row of the plane */
+        int dc = lane < n ? ref[lane] + ref[2 * n + 1 + lane] : 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-                dc += __shfl_xor(dc, o);
-            if (l == 0)
-                s_small[1 + p] = (dc + n) >> ((p ? lgN - 1 : lgN) + 1);
-        }
-        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1)
+            dc += __shfl_xor(dc, o);
+        dcv = (dc + n) >> (lgn + 1);
     }
-    const int nY = N * N, nC = nY >> 2;
-    for (int i = t; i < nY + 2 * nC; i += 256) {
-        const int p = i < nY ? 0 : (i < nY + nC ? 1 : 2), e = p == 0 ? i : (p == 1 ? i - nY : i - nY - nC);
-        const int n = p ? N >> 1 : N, lg = p ? lgN - 1 : lgN, y = e >> lg, x = e & (n - 1);
-        const int v = pu_predict(lmode /* chroma: EB_INTRA_CHROMA_DM */, n, lg, ref[p], x, y, s_small[1 + p], p == 0, maxv);
-        *L.at(p, (p ? cu.x >> 1 : cu.x) + x, (p ? cu.y >> 1 : cu.y) + y) = (T)v;
+    for (int e = lane; e < n * n; e += 64) {
+        const int y = e >> lgn, x = e & (n - 1);
+        const int v = pu_predict(lmode /* chroma: EB_INTRA_CHROMA_DM */, n, lgn, ref, x, y, dcv, p == 0, maxv);
+        *L.at(p, lx + x, ly + y) = (T)v;
     }
+    EP_WAVE_SYNC();
     EP_PH(3);
 #undef EP_PH
 }
@@ -214,9 +317,19 @@ __device__ void ep_intra_predict(EpLocal<T> &L, const typename EpTypes<T>::Work 
 /* One transform unit of one plane on lanes r = 0..N-1 of the calling wave (the other lanes idle): EncodeLoop + EncodeGenerateRecon.
  * src: source block (pitch srcPitch); rec: prediction in, reconstruction out; coeff: LargestCodingUnit_t.quantizedCoeff position.
  * Returns (lane 0) nz | only_dc << 16. */
+/* the luma cbf decision of an AMVP unit (EbCodingLoop.c:4075-4124): PictureFullDistortionLuma on the coefficients, TuEstimateCoeffBitsEncDec,
+ * EncodeTuCalcCost (EbRateDistortionCost.c:2578) */
+struct EpDecide {
+    const SvtAmdCabacCost *cost;
+    int16_t *qbuf;                 /* LDS, N x N: the quantised coefficients of the unit for the rate estimator */
+    uint32_t lambda, zero_bits, nonzero_bits; /* fullLambda, lumaCbfBits[ctx], lumaCbfBits[ctx + 5] */
+};
+
+/* Returns (every lane) nz | only_dc << 16 | cbf << 17. */
 template <int N, typename T>
-__device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const T *src, int srcPitch, T *rec, size_t recPitch, int16_t *coeff,
-                                                   int coeffPitch, int16_t *tile, int qp, int slice_type, uint32_t dz_offset, bool luma)
+__device__ __forceinline__ uint32_t ep_encode_unit(int lane, int r, bool active, const T *src, int srcPitch, T *rec, size_t recPitch, int16_t *coeff,
+                                                   int coeffPitch, int16_t *tile, int qp, int slice_type, uint32_t dz_offset, bool luma,
+                                                   bool decide, const EpDecide &dec)
 {
     constexpr int P = TxRegTile<N>::PITCH;
     constexpr int maxv = sizeof(T) == 1 ? 255 : 1023, LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
@@ -257,6 +370,8 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const T *
         nz += (active && qv != 0);
         if (active)
             coeff[j * coeffPitch + r] = (int16_t)qv;
+        if (N >= 8 && decide && active)
+            dec.qbuf[j * N + r] = (int16_t)qv;
     }
 #pragma unroll
     for (int o = 1; o < N; o <<= 1)
@@ -264,6 +379,37 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const T *
     const int dc_rec = __shfl(c[0], 0); /* the de-quantised coefficient (0,0): lane 0 holds column 0 */
     /* tuPtr->isOnlyDc (EbCodingLoop.c:792, 879, 1000): one coefficient, at DC, and no 32x32 luma unit */
     const bool only_dc = nz == 1 && dc_rec != 0 && !(luma && N == 32);
+    bool cbf = nz != 0;
+    if constexpr (N >= 8) {
+        if (decide) { /* wave-uniform */
+            /* FullDistortionKernel_32bit / ...CbfZero_32bit (EbPictureOperators_C.c:385-480): 16-bit difference, 32-bit sums; a DC-only
+             * unit is measured on its DC alone */
+            uint32_t d0 = 0, d1 = 0;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < N; j++)
+                    if (!only_dc || (j == 0 && r == 0)) {
+                        const int df = (int16_t)(x[j] - c[j]), cf = (int16_t)x[j];
+                        d0 += (uint32_t)(df * df), d1 += (uint32_t)(cf * cf);
+                    }
+            }
+#pragma unroll
+            for (int o = 1; o < N; o <<= 1)
+                d0 += __shfl_xor(d0, o), d1 += __shfl_xor(d1, o);
+            constexpr int dshift = 2 * (7 - LG);
+            const unsigned long long dz = ((unsigned long long)d1 + (1ull << (dshift - 1))) >> dshift;
+            const unsigned long long dn = nz ? ((unsigned long long)d0 + (1ull << (dshift - 1))) >> dshift : dz;
+            EP_WAVE_SYNC(); /* qbuf is written */
+            constexpr int S = (N / 4) * (N / 4);
+            const SvtAmdTuInfo ti = {nz, 1 /* INTER_MODE */, 0xFF, 0xFF, 0};
+            const uint32_t b32 = coeff_bits_lanes(*dec.cost, dec.qbuf, N, LG, ti, lane < S, lane, lane & (S - 1));
+            const unsigned long long tuBits = (((unsigned long long)__shfl(b32, 0)) << 10) >> 15;
+            const unsigned long long nzRate = (tuBits << 15) + dec.nonzero_bits, zRate = dec.zero_bits, lam = dec.lambda;
+            const unsigned long long zCost = (dz << 8) + (((lam * zRate) + (1u << 22)) >> 23);
+            const unsigned long long nzCost = (dn << 8) + (((lam * nzRate) + (1u << 22)) >> 23);
+            cbf = nz != 0 && nzCost < zCost;
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     inv_1d_regs<N>(c, is1, [&](int j, int16_t v) { tile[r * P + j] = v; });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -281,7 +427,7 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const T *
         for (int j = 0; j < N; j++)
             y[j] = v;
     }
-    if (active && nz) { /* cbf == 0: the prediction stays (EbCodingLoop.c:1126) */
+    if (active && cbf) { /* cbf == 0: the prediction stays (EbCodingLoop.c:1126) */
 #pragma unroll
         for (int j = 0; j < N; j++) {
             const int v = pred[j] + y[j];
@@ -289,39 +435,39 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int r, bool active, const T *
         }
         store_row<N, T>(rec + (size_t)r * recPitch, y);
     }
-    return nz | ((uint32_t)only_dc << 16);
+    return nz | ((uint32_t)only_dc << 16) | ((uint32_t)cbf << 17);
 }
 
 /* lane = lane of the wave; the unit lives on lanes 0..n-1, the rest of the wave are idle virtual units with tiles of their own (the
  * register transform exchanges rows through the unit's LDS tile and every lane takes part in the wave barriers) */
 template <typename T>
 __device__ __forceinline__ uint32_t ep_encode_plane(int n, int lane, const T *src, int srcPitch, T *rec, size_t recPitch,
-                                                    int16_t *coeff, int coeffPitch, int16_t *tiles, int qp, int slice_type, uint32_t dz, bool luma)
+                                                    int16_t *coeff, int coeffPitch, int16_t *tiles, int qp, int slice_type, uint32_t dz, bool luma,
+                                                    bool decide = false, const EpDecide &dec = EpDecide())
 {
     uint32_t o;
     switch (n) {
-    case 32: o = ep_encode_unit<32, T>(lane & 31, lane < 32, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 5) * TxRegTile<32>::UNIT, qp, slice_type, dz, luma); break;
-    case 16: o = ep_encode_unit<16, T>(lane & 15, lane < 16, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 4) * TxRegTile<16>::UNIT, qp, slice_type, dz, luma); break;
-    case 8: o = ep_encode_unit<8, T>(lane & 7, lane < 8, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 3) * TxRegTile<8>::UNIT, qp, slice_type, dz, luma); break;
-    default: o = ep_encode_unit<4, T>(lane & 3, lane < 4, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 2) * TxRegTile<4>::UNIT, qp, slice_type, dz, luma); break;
+    case 32: o = ep_encode_unit<32, T>(lane, lane & 31, lane < 32, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 5) * TxRegTile<32>::UNIT, qp, slice_type, dz, luma, decide, dec); break;
+    case 16: o = ep_encode_unit<16, T>(lane, lane & 15, lane < 16, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 4) * TxRegTile<16>::UNIT, qp, slice_type, dz, luma, decide, dec); break;
+    case 8: o = ep_encode_unit<8, T>(lane, lane & 7, lane < 8, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 3) * TxRegTile<8>::UNIT, qp, slice_type, dz, luma, decide, dec); break;
+    default: o = ep_encode_unit<4, T>(lane, lane & 3, lane < 4, src, srcPitch, rec, recPitch, coeff, coeffPitch, tiles + (lane >> 2) * TxRegTile<4>::UNIT, qp, slice_type, dz, luma, false, dec); break;
     }
     return __shfl(o, 0); /* lane 0 belongs to the live unit */
 }
 
+template <typename T>
 struct EpShared {
-    int16_t border[3][132], ref[3][132];
-    uint8_t ok[36];
-    int s_small[8];
+    int16_t border[3][132], ref[3][132];       /* per plane pipeline */
     int16_t tiles[3][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N */
+    EpMcScratch<T> mc[3];                      /* inter units */
+    int16_t qbuf[32 * 32];                     /* luma cbf decision of AMVP units */
 };
 
 /* the coding-unit loop of one LCU, by one workgroup of 256 threads */
 template <typename T>
-__device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Work &W, typename EpTypes<T>::Result &R, EpShared &S, EpLocal<T> &L)
+__device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Work &W, typename EpTypes<T>::Result &R, EpShared<T> &S, EpLocal<T> &L)
 {
     int16_t (*border)[132] = S.border, (*ref)[132] = S.ref;
-    uint8_t *ok = S.ok;
-    int *s_small = S.s_small;
     int16_t (*tiles)[2 * TxRegTile<32>::UNIT] = S.tiles;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const T *rp[3] = {(const T *)P.rec[0], (const T *)P.rec[1], (const T *)P.rec[2]};
@@ -332,7 +478,8 @@ __device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Wor
     /* ---- the LCU's surroundings and source into LDS ---- */
     for (int i = t; i < 17 * 36; i += 256) {
         const int cy = i / 36 - 1, cx = i - (cy + 1) * 36 - 1;
-        L.mode[i] = (uint8_t)((cy < 0 || cx < 0) ? ep_mode_at(P, (int)W.lcu_x + 4 * cx, (int)W.lcu_y + 4 * cy) : 0xFF);
+        const uint8_t v = (uint8_t)((cy < 0 || cx < 0) ? ep_mode_at(P, (int)W.lcu_x + 4 * cx, (int)W.lcu_y + 4 * cy) : 0xFF);
+        L.mode[0][i] = v, L.mode[1][i] = v, L.mode[2][i] = v;
     }
     for (int i = t; i < 130 + 2 * 66 + 64 + 2 * 32; i += 256) { /* ring samples: top rows (x = -1 .. 2n-1), then left columns */
         int p, x, y;
@@ -358,38 +505,68 @@ __device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Wor
     for (int i = t; i < (int)(sizeof(L.cus) / 4); i += 256)
         ((uint32_t *)L.cus)[i] = ((const uint32_t *)W.cu)[i];
     const int num_cus = W.num_cus;
+    const EpFlags F = {W.tile_left != 0, W.tile_top != 0, W.tile_right != 0, W.constrained_intra != 0, W.strong_smoothing != 0, (int)W.slice_type,
+                       (int)W.lcu_x,     (int)W.lcu_y,    W.full_lambda,     {W.luma_cbf_bits[0], W.luma_cbf_bits[1], W.luma_cbf_bits[2], W.luma_cbf_bits[3]}};
     __syncthreads();
-    for (int ci = 0; ci < num_cus; ci++) {
-        const LcuCu cu = L.cus[ci];
-        const int N = cu.size;
-        if (cu.pred_mode == 2 && N <= 32) {
-            ep_intra_predict<T>(L, W, cu, t, border, ref, ok, s_small, P.prof ? c_ph : nullptr);
-            __syncthreads(); /* the prediction is in the local planes; the unit's lanes read it back row-wise */
-            if (P.prof)
-                c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
-            if (wave < 3) {
-                const int p = wave, n = p ? N >> 1 : N;
+    if (wave < 3) { /* wave p = plane p: its own pipeline over the unit list (luma is the long one) */
+        const int p = wave;
+        for (int ci = 0; ci < num_cus; ci++) {
+            const LcuCu cu = L.cus[ci];
+            const int N = cu.size;
+            if (cu.pred_mode == 1) { /* INTER_MODE, 2Nx2N (EbCodingLoop.c:3817-4400) */
+                ep_inter_predict_plane<T>(P, L, F, cu, p, lane, S.mc[p]);
+                if (P.prof)
+                    c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
+                const int ntu = N == 64 ? 4 : 1, TS = N == 64 ? 32 : N, n = p ? TS >> 1 : TS;
+                const bool amvp = cu.inter_kind == SVT_AMD_EP_INTER_AMVP;
+                const EpDecide D = {P.cost, S.qbuf, F.full_lambda, N == TS ? F.cbf_bits[1] : F.cbf_bits[0], N == TS ? F.cbf_bits[3] : F.cbf_bits[2]};
+                uint32_t any = 0;
+                for (int tu = 0; tu < ntu; tu++) {
+                    const int tx = cu.x + ((tu & 1) << 5), ty = cu.y + ((tu >> 1) << 5);
+                    const int lx = p ? tx >> 1 : tx, ly = p ? ty >> 1 : ty;
+                    uint32_t o = 0;
+                    if (cu.inter_kind != SVT_AMD_EP_INTER_SKIP) {
+                        const T *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
+                        int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
+                        o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[p],
+                                               (p ? cu.chroma_qp : cu.qp) + (sizeof(T) == 2 ? 12 : 0), F.slice_type, p ? 0u : cu.dz_offset, p == 0,
+                                               p == 0 && amvp, D);
+                    }
+                    if (lane == 0) { /* a 64x64 unit: entries 1..4 = its four transform units */
+                        SvtAmdLcuCuResult &E = R.cu[ci + (N == 64 ? 1 + tu : 0)];
+                        E.nz[p] = (uint16_t)(o & 0xffff), E.cbf[p] = (uint8_t)((o >> 17) & 1), E.only_dc[p] = (uint8_t)((o >> 16) & 1);
+                    }
+                    any |= (o >> 17) & 1;
+                }
+                if (N == 64 && lane == 0) /* transformUnitArray[0]: chroma flags OR-ed (:4263-4281), luma only by EncodeTuCalcCost */
+                    R.cu[ci].nz[p] = 0, R.cu[ci].only_dc[p] = 0, R.cu[ci].cbf[p] = (uint8_t)(any && (p != 0 || amvp));
+            } else if (cu.pred_mode == 2 && N <= 32) {
+                ep_intra_predict_plane<T>(L, F, cu, p, lane, border[p], ref[p], P.prof && p == 0, c_ph);
+                if (P.prof)
+                    c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
+                const int n = p ? N >> 1 : N;
                 const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
                 const T *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
                 int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
                 const uint32_t o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[p],
                                                       (p ? cu.chroma_qp : cu.qp) + (sizeof(T) == 2 ? 12 : 0) /* QP_BD_OFFSET, EbCodingLoop.c:1307 */,
-                                                      W.slice_type, p ? 0u : cu.dz_offset, p == 0);
+                                                      F.slice_type, p ? 0u : cu.dz_offset, p == 0);
                 if (lane == 0) {
                     R.cu[ci].nz[p] = (uint16_t)(o & 0xffff);
                     R.cu[ci].cbf[p] = (o & 0xffff) != 0;
-                    R.cu[ci].only_dc[p] = (uint8_t)(o >> 16);
+                    R.cu[ci].only_dc[p] = (uint8_t)((o >> 16) & 1);
                 }
             }
+            /* EncodePassUpdate...ModeNeighborArrays: this pipeline has coded the unit */
+            const int lgc = 29 - __clz(N), cells = 1 << lgc; /* N / 4 */
+            for (int i = lane; i < cells * cells; i += 64)
+                L.mode[p][((cu.y >> 2) + (i >> lgc) + 1) * 36 + (cu.x >> 2) + (i & (cells - 1)) + 1] = cu.pred_mode;
+            EP_WAVE_SYNC(); /* reconstruction and mode cells of this unit are visible to the next one (same wave) */
+            if (P.prof)
+                c0 = __builtin_readcyclecounter(), c_enc += c0 - c1;
         }
-        /* EncodePassUpdate...ModeNeighborArrays: the unit is coded now */
-        const int lgc = 29 - __clz(N), cells = 1 << lgc; /* N / 4 */
-        for (int i = t; i < cells * cells; i += 256)
-            L.mode[((cu.y >> 2) + (i >> lgc) + 1) * 36 + (cu.x >> 2) + (i & (cells - 1)) + 1] = cu.pred_mode;
-        __syncthreads(); /* reconstruction and mode cells of this unit are visible to the next one */
-        if (P.prof)
-            c0 = __builtin_readcyclecounter(), c_enc += c0 - c1;
     }
+    __syncthreads(); /* the three planes are done */
     /* ---- the finished LCU leaves LDS: picture planes + mode map (neighbours of later LCUs, the host's deblocking / SAO input and
      * reference picture) and the result record ---- */
     for (int i = t; i < (64 * 64 + 2 * 32 * 32) / 4; i += 256) {
@@ -408,7 +585,7 @@ __device__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Wor
     for (int i = t; i < 16 * 16; i += 256) {
         const int cy = i >> 4, cx = i & 15;
         if (4 * cx < lw && 4 * cy < lh)
-            P.mode_map[(size_t)((W.lcu_y >> 2) + cy) * P.map_pitch + (W.lcu_x >> 2) + cx] = L.mode[(cy + 1) * 36 + cx + 1];
+            P.mode_map[(size_t)((W.lcu_y >> 2) + cy) * P.map_pitch + (W.lcu_x >> 2) + cx] = L.mode[0][(cy + 1) * 36 + cx + 1];
     }
     if (P.prof && t == 0) {
         unsigned long long *q = P.prof + 16 * (size_t)((W.lcu_y >> 6) * ((P.width + 63) >> 6) + (W.lcu_x >> 6));
@@ -421,7 +598,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const typename EpTypes<T>::Work *__restrict__ works,
                                                     typename EpTypes<T>::Result *__restrict__ results)
 {
-    __shared__ EpShared S;
+    __shared__ EpShared<T> S;
     __shared__ EpLocal<T> L;
     ep_encode_lcu<T>(P, works[blockIdx.x], results[blockIdx.x], S, L);
 }
@@ -439,7 +616,7 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typen
                                                         typename EpTypes<T>::Result *__restrict__ results, int nlcu,
                                                         int wl, unsigned *ticket, unsigned *done, const unsigned *__restrict__ order, unsigned epoch)
 {
-    __shared__ EpShared S;
+    __shared__ EpShared<T> S;
     __shared__ EpLocal<T> L;
     __shared__ unsigned s_ticket;
     for (;;) {
@@ -505,6 +682,9 @@ extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width,
     if (hipMalloc((void **)&p->d.mode_map, p->map_bytes) != hipSuccess)
         return SVT_AMD_ERR_RESOURCES;
     p->nlcu = ((width + 63) / 64) * ((height + 63) / 64);
+    if (hipMalloc((void **)&p->d_cost, sizeof(SvtAmdCabacCost)) != hipSuccess || rate_tables_once(ctx->device))
+        return SVT_AMD_ERR_RESOURCES;
+    p->d.cost = p->d_cost;
     if (hipMalloc((void **)&p->d_sync, sizeof(unsigned) * (size_t)(1 + 2 * p->nlcu)) != hipSuccess)
         return SVT_AMD_ERR_RESOURCES;
     HIP_TRY(hipMemset(p->d_sync, 0, sizeof(unsigned) * (size_t)(1 + p->nlcu)));
@@ -550,7 +730,40 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
         (void)hipFree(pic->d_sync);
     if (pic->d.prof)
         (void)hipFree(pic->d.prof);
+    if (pic->d_cost)
+        (void)hipFree(pic->d_cost);
     free(pic);
+    return SVT_AMD_OK;
+}
+
+/* P / B pictures: what the inter units of the picture read besides the LCU records - the reference pictures of list 0 / 1 (device
+ * memory, whole padded planes; either may be NULL) and pictureControlSetPtr->cabacCost (HOST pointer, copied on the context's stream).
+ * Holds until the next call for this picture object. */
+extern "C" int svt_amd_encdec_picture_set_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRefPicture *ref0,
+                                                const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost)
+{
+    if (!ctx || !pic || (!ref0 && !ref1) || !cost)
+        return SVT_AMD_ERR_BAD_PARAM;
+    const SvtAmdRefPicture *refs[2] = {ref0, ref1};
+    for (int l = 0; l < 2; l++) {
+        const SvtAmdRefPicture *r = refs[l];
+        pic->has_ref[l] = r != nullptr;
+        memset(&pic->d.ref[l], 0, sizeof(pic->d.ref[l]));
+        if (!r)
+            continue;
+        if (!r->d_y || !r->d_cb || !r->d_cr || r->width != pic->d.width || r->height != pic->d.height || r->originX < 8 || r->originY < 8 ||
+            r->strideY < r->width + 2 * r->originX || r->strideC < (r->width + 2 * r->originX) / 2) {
+            svt_amd_set_error("svt_amd_encdec_picture_set_inter: reference picture %d does not fit the picture", l);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        EpRefPlanes &E = pic->d.ref[l];
+        E.plane[0] = r->d_y, E.plane[1] = r->d_cb, E.plane[2] = r->d_cr;
+        E.stride[0] = r->strideY, E.stride[1] = r->strideC;
+        E.originX = (int32_t)r->originX, E.originY = (int32_t)r->originY, E.width = (int32_t)r->width, E.height = (int32_t)r->height;
+        E.size[0] = (int32_t)(r->strideY * (r->height + 2 * r->originY)), E.size[1] = (int32_t)(r->strideC * ((r->height + 2 * r->originY) / 2));
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, ctx->stream)); /* pageable source: staged before the call returns */
     return SVT_AMD_OK;
 }
 
@@ -567,9 +780,16 @@ static int ep_validate(const SvtAmdEncDecPicture *pic, const WorkT *works, int n
         }
         for (int c = 0; c < works[i].num_cus; c++) {
             const SvtAmdLcuCu &u = works[i].cu[c];
-            if (u.pred_mode != 2 || !(u.size == 8 || u.size == 16 || u.size == 32) || u.intra_luma_mode > 34 || (u.x & (u.size - 1)) || (u.y & (u.size - 1)) ||
-                u.x + u.size > 64 || u.y + u.size > 64 || works[i].lcu_x + u.x + u.size > pic->d.width || works[i].lcu_y + u.y + u.size > pic->d.height) {
-                svt_amd_set_error("%s: LCU %d unit %d is not an intra 2Nx2N unit of 8..32 inside the picture", who, i, c);
+            const bool inter = u.pred_mode == 1;
+            if ((u.pred_mode != 2 && !inter) || !(u.size == 8 || u.size == 16 || u.size == 32 || (inter && u.size == 64)) || u.intra_luma_mode > 34 ||
+                (u.x & (u.size - 1)) || (u.y & (u.size - 1)) || u.x + u.size > 64 || u.y + u.size > 64 || works[i].lcu_x + u.x + u.size > pic->d.width ||
+                works[i].lcu_y + u.y + u.size > pic->d.height) {
+                svt_amd_set_error("%s: LCU %d unit %d is not an intra 2Nx2N unit of 8..32 or an inter 2Nx2N unit of 8..64 inside the picture", who, i, c);
+                return SVT_AMD_ERR_BAD_PARAM;
+            }
+            if (inter && (u.inter_dir > 2 || u.inter_kind > SVT_AMD_EP_INTER_SKIP || (u.inter_dir != 1 && !pic->has_ref[0]) || (u.inter_dir != 0 && !pic->has_ref[1]))) {
+                svt_amd_set_error("%s: LCU %d unit %d: inter unit without its reference picture (svt_amd_encdec_picture_set_inter) or with a bad direction / kind",
+                                  who, i, c);
                 return SVT_AMD_ERR_BAD_PARAM;
             }
         }

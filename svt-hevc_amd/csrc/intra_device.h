@@ -4,8 +4,19 @@
 #define SVT_AMD_INTRA_DEVICE_H
 #include "svt_amd_internal.h"
 
-static __constant__ int8_t c_pu_ang[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
-static __constant__ int16_t c_pu_inv[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+/* intraPredAngle {0, 2, 5, 9, 13, 17, 21, 26, 32} and invAngle {-, 4096, 1638, 910, 630, 482, 390, 315, 256} by |distance| from the
+ * horizontal / vertical mode, as packed immediates: a table in memory is a dependent HBM / L2 round trip per unit on the encode
+ * pass's critical path */
+__device__ __forceinline__ int pu_ang(int d)
+{
+    const unsigned long long k = 0ull | (2ull << 6) | (5ull << 12) | (9ull << 18) | (13ull << 24) | (17ull << 30) | (21ull << 36) | (26ull << 42) | (32ull << 48);
+    return (int)((k >> (6 * d)) & 63);
+}
+__device__ __forceinline__ int pu_inv(int d) /* d in 1..8 */
+{
+    const unsigned long long lo = 4096ull | (1638ull << 16) | (910ull << 32) | (630ull << 48), hi = 482ull | (390ull << 16) | (315ull << 32) | (256ull << 48);
+    return (int)(((d <= 4 ? lo : hi) >> (16 * ((d - 1) & 3))) & 0xffff);
+}
 
 /* r: left[0..2N-1] top to bottom, r[2N] top-left, r[2N+1+j] top[j] */
 __device__ __forceinline__ int pu_predict(int mode, int N, int lg, const int16_t *r, int x, int y, int dc, bool lumaEdge, int maxv)
@@ -31,7 +42,8 @@ __device__ __forceinline__ int pu_predict(int mode, int N, int lg, const int16_t
         return (lumaEdge && N < 32 && y == 0) ? min(maxv, max(0, left[0] + ((top[x] - tl) >> 1))) : (int)left[y];
     const bool vert = mode >= 18;
     const int d = vert ? mode - 26 : 10 - mode;
-    const int a = d < 0 ? -c_pu_ang[-d] : c_pu_ang[d];
+    const int a = d < 0 ? -pu_ang(-d) : pu_ang(d);
+    const int inv = d < 0 ? pu_inv(-d) : 0;
     const int u = vert ? x : y, v = vert ? y : x;
     const int16_t *mainr = vert ? top : left, *side = vert ? left : top;
     const int pos = (v + 1) * a, i = pos >> 5, f = pos & 31;
@@ -39,7 +51,7 @@ __device__ __forceinline__ int pu_predict(int mode, int N, int lg, const int16_t
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int idx = u + i + 1 + k;
-        s[k] = idx > 0 ? mainr[idx - 1] : idx == 0 ? tl : side[((-idx * c_pu_inv[-d] + 128) >> 8) - 1];
+        s[k] = idx > 0 ? mainr[idx - 1] : idx == 0 ? tl : side[((-idx * inv + 128) >> 8) - 1];
     }
     return ((32 - f) * s[0] + f * s[1] + 16) >> 5;
 }

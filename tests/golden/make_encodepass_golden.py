@@ -34,7 +34,41 @@ CASES = {
     "dlf_i_motion_416x240_m9": ("motion", 416, 240, 2, 7, ["-encMode", "9", "-intra-period", "0", "-q", "34"]),
     "dlf_i_noise_200x136_m6": ("noise", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "38"]),
     "dlf_i10_motion_320x192_m7": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "36", "-bit-depth", "10"]),
+    # P / B pictures ("p_" / "b_" / "p10_" prefix: LCUs with inter units are recorded too, with the reference pictures they predict from and
+    # the pictures' coefficient-rate tables; loop filters off as above).  Low delay P: uni-prediction, AMVP / merge / skip units, 64x64 units
+    "p_motion_416x240_m7": ("motion", 416, 240, 4, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "30"]),
+    # noise at a high qp: most AMVP units lose their luma coefficients in the cbf decision (EncodeTuCalcCost)
+    "p_noise_200x136_m5_q48": ("noise", 200, 136, 4, 13, ["-encMode", "5", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "48"]),
+    # random access: bi-prediction, non-reference B pictures (the skip-cost bias of :3865-3878)
+    "b_motion_320x192_m5": ("motion", 320, 192, 5, 9, ["-encMode", "5", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "28"]),
+    # noise: every unit carries coefficients, the luma cbf decision sees large rates
+    "p_noise_200x136_m6": ("noise", 200, 136, 3, 11, ["-encMode", "6", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "34"]),
+    "p10_motion_320x192_m7": ("motion10", 320, 192, 3, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "32", "-bit-depth", "10"]),
 }
+
+
+def parse_dump(raw, rdt):
+    """the dump of a P / B encode is a sequence of LCU records, reference-picture records and rate-table records"""
+    recs, refs, costs, off = [], {}, {}, 0
+    while off < len(raw):
+        magic, size = np.frombuffer(raw, "<u4", 2, off)
+        if magic == S.EP_MAGIC:
+            assert size == rdt.itemsize, (size, rdt.itemsize)
+            recs.append(np.frombuffer(raw, rdt, 1, off)[0])
+        elif magic == S.EP_REF_MAGIC:
+            h = np.frombuffer(raw, S.EP_REF_HEAD_DTYPE, 1, off)[0]
+            sdt = np.dtype(np.uint8) if h["bps"] == 1 else np.dtype("<u2")
+            rows_y = int(h["height"] + 2 * h["originY"])
+            ny, nc = int(h["strideY"]) * rows_y, int(h["strideC"]) * (rows_y // 2)
+            o = off + S.EP_REF_HEAD_DTYPE.itemsize
+            planes = [np.frombuffer(raw, sdt, n, o + k * sdt.itemsize) for n, k in ((ny, 0), (nc, ny), (nc, ny + nc))]
+            refs[int(h["poc"])] = (h, planes)
+        elif magic == S.EP_COST_MAGIC:
+            costs[int(np.frombuffer(raw, "<u8", 1, off + 8)[0])] = np.frombuffer(raw, np.uint8, int(size) - 16, off + 16)
+        else:
+            raise AssertionError("bad record magic %x at %d" % (magic, off))
+        off += int(size)
+    return np.array(recs, dtype=rdt), refs, costs
 
 
 def run_case(name):
@@ -51,10 +85,11 @@ def run_case(name):
                "-b", os.path.join(td, "out.265")] + ([] if dlf else ["-dlf", "1"]) + (["-o", rec_out] if dlf else []) + args
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_ENCODEPASS_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
         rdt = S.EP_RECORD16_DTYPE if kind.endswith("10") else S.EP_RECORD_DTYPE
-        recs = np.fromfile(dump, dtype=rdt)
+        recs, refs, costs = parse_dump(open(dump, "rb").read(), rdt)
         rec_raw = open(rec_out, "rb").read() if dlf else b""
+    inter = name.split("_")[0] in ("p", "b", "p10", "b10")
     assert len(recs) and (recs["record_size"] == rdt.itemsize).all(), (len(recs), rdt.itemsize)
-    assert (recs["dlf_off"] == (0 if dlf else 1)).all()
+    assert ((recs["dlf_off"] & 1) == (0 if dlf else 1)).all()   # bit 1: the LCU was not reconstructed (doRecon == 0)
     extra = {}
     if dlf:   # the encoder's reconstruction output: n frames, 4:2:0, 8-bit samples or 16-bit little-endian for 10-bit encodes
         sdt = np.dtype("<u2") if kind.endswith("10") else np.uint8
@@ -67,16 +102,35 @@ def run_case(name):
     nl = S.lcu_count(w, h)
     order = np.lexsort((recs["lcu_index"], recs["picture_number"]))
     recs = recs[order]
-    assert len(recs) == nl * n, "every LCU of an all-intra clip must be recorded (%d of %d)" % (len(recs), nl * n)
+    if inter:   # keep the P / B pictures only (the I picture is what the other fixtures hold) and what they read
+        recs = recs[recs["work"]["slice_type"] != 2]
+        pocs = sorted(set(int(v) for v in recs["ref_poc"].reshape(-1) if v != 0xFFFFFFFFFFFFFFFF))
+        assert pocs and all(k in refs for k in pocs), (pocs, sorted(refs))
+        h0 = refs[pocs[0]][0]
+        extra.update(ref_poc=recs["ref_poc"], ref_pocs=np.array(pocs, np.uint64),
+                     ref_geom=np.array([int(h0[k]) for k in ("strideY", "strideC", "originX", "originY", "width", "height")], np.uint32),
+                     ref_y=np.stack([refs[k][1][0] for k in pocs]), ref_cb=np.stack([refs[k][1][1] for k in pocs]),
+                     ref_cr=np.stack([refs[k][1][2] for k in pocs]),
+                     cost_pictures=np.array(sorted(costs), np.uint64), cost=np.stack([costs[k] for k in sorted(costs)]))
+        assert all(int(k) in costs for k in set(recs["picture_number"].tolist()))
+    else:
+        assert len(recs) == nl * n, "every LCU of an all-intra clip must be recorded (%d of %d)" % (len(recs), nl * n)
     path = os.path.join(S.GOLDEN_DIR, "encodepass_%s.npz" % name)
     np.savez_compressed(path, clip=np.array([kind, str(w), str(h), str(n), str(seed)]), enc_args=np.array(args),
-                        picture_number=recs["picture_number"], lcu_index=recs["lcu_index"], work=recs["work"], result=recs["result"], **extra)
+                        picture_number=recs["picture_number"], lcu_index=recs["lcu_index"], dlf_off=recs["dlf_off"], work=recs["work"],
+                        result=recs["result"], **extra)
     sizes, cnt = np.unique(np.concatenate([r["work"]["cu"]["size"][:r["work"]["num_cus"]] for r in recs]), return_counts=True)
     cbf = np.concatenate([r["result"]["cu"]["cbf"][:r["work"]["num_cus"]] for r in recs])
     odc = np.concatenate([r["result"]["cu"]["only_dc"][:r["work"]["num_cus"]] for r in recs])
     print("%-28s %d LCUs -> %s (%.0f KiB); unit sizes %s; cbf set %s of %d; DC-only %s" %
           (name, len(recs), os.path.basename(path), os.path.getsize(path) / 1024, dict(zip(sizes.tolist(), cnt.tolist())),
            cbf.sum(axis=0).tolist(), len(cbf), odc.sum(axis=0).tolist()))
+    if inter:
+        cus = np.concatenate([r["work"]["cu"][:r["work"]["num_cus"]] for r in recs])
+        it = cus[cus["pred_mode"] == 1]
+        print("    pictures %s; inter units %d of %d: AMVP %d merge %d skip %d; L0 %d L1 %d bi %d; reference pictures %s" %
+              (sorted(set(recs["picture_number"].tolist())), len(it), len(cus), (it["inter_kind"] == 0).sum(), (it["inter_kind"] == 1).sum(),
+               (it["inter_kind"] == 2).sum(), (it["inter_dir"] == 0).sum(), (it["inter_dir"] == 1).sum(), (it["inter_dir"] == 2).sum(), pocs))
 
 
 if __name__ == "__main__":

@@ -344,23 +344,38 @@ def write_clip10_compressed(path, kind, w, h, n, seed):
 
 # ---- encode-pass contracts (SvtAmdLcuWork / SvtAmdLcuResult, include/svt_hevc_amd.h) ----
 LCU_CU_DTYPE = np.dtype([("x", "u1"), ("y", "u1"), ("size", "u1"), ("pred_mode", "u1"), ("intra_luma_mode", "u1"), ("bottom_left_ok", "u1"),
-                         ("top_right_ok", "u1"), ("qp", "u1"), ("chroma_qp", "u1"), ("leaf_index", "u1"), ("pad", "u1", 2), ("dz_offset", "<u4")])
+                         ("top_right_ok", "u1"), ("qp", "u1"), ("chroma_qp", "u1"), ("leaf_index", "u1"), ("inter_dir", "u1"), ("inter_kind", "u1"), ("dz_offset", "<u4"),
+                         ("mv", "<i2", (2, 2))])
 LCU_WORK_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("num_cus", "u1"), ("slice_type", "u1"), ("temporal_layer", "u1"),
                            ("constrained_intra", "u1"), ("strong_smoothing", "u1"), ("tile_left", "u1"), ("tile_top", "u1"), ("tile_right", "u1"),
-                           ("pad", "u1", 4), ("cu", LCU_CU_DTYPE, 64), ("src_y", "u1", 4096), ("src_cb", "u1", 1024), ("src_cr", "u1", 1024)])
+                           ("pad", "u1", 4), ("full_lambda", "<u4"), ("luma_cbf_bits", "<u4", 4), ("pad2", "u1", 12), ("cu", LCU_CU_DTYPE, 64),
+                           ("src_y", "u1", 4096), ("src_cb", "u1", 1024), ("src_cr", "u1", 1024)])
 LCU_CU_RESULT_DTYPE = np.dtype([("cbf", "u1", 3), ("only_dc", "u1", 3), ("nz", "<u2", 3)])
 LCU_RESULT_DTYPE = np.dtype([("cu", LCU_CU_RESULT_DTYPE, 64), ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024),
                              ("rec_y", "u1", 4096), ("rec_cb", "u1", 1024), ("rec_cr", "u1", 1024)])
 LCU_BORDER_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("mode_bottom", "u1", 16), ("mode_right", "u1", 16), ("bottom_y", "u1", 64),
                              ("right_y", "u1", 64), ("bottom_cb", "u1", 32), ("right_cb", "u1", 32), ("bottom_cr", "u1", 32), ("right_cr", "u1", 32)])
 EP_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
-                            ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("work", LCU_WORK_DTYPE), ("result", LCU_RESULT_DTYPE)])
+                            ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("ref_poc", "<u8", 2), ("work", LCU_WORK_DTYPE), ("result", LCU_RESULT_DTYPE)])
 LCU_WORK16_DTYPE = np.dtype([(n, LCU_WORK_DTYPE.fields[n][0]) if not n.startswith("src_") else (n, "<u2", LCU_WORK_DTYPE.fields[n][0].shape)
                              for n in LCU_WORK_DTYPE.names])
 LCU_RESULT16_DTYPE = np.dtype([(n, LCU_RESULT_DTYPE.fields[n][0]) if not n.startswith("rec_") else (n, "<u2", LCU_RESULT_DTYPE.fields[n][0].shape)
                                for n in LCU_RESULT_DTYPE.names])
 EP_RECORD16_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
-                              ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("work", LCU_WORK16_DTYPE), ("result", LCU_RESULT16_DTYPE)])
+                              ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("ref_poc", "<u8", 2), ("work", LCU_WORK16_DTYPE), ("result", LCU_RESULT16_DTYPE)])
+# picture-level records of the encode-pass dump (oracle/ref_harness_encodepass_dump.c)
+EP_REF_HEAD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("poc", "<u8"), ("bps", "<u4"), ("strideY", "<u4"), ("strideC", "<u4"),
+                              ("originX", "<u4"), ("originY", "<u4"), ("width", "<u4"), ("height", "<u4"), ("pad", "<u4")])
+EP_MAGIC, EP_REF_MAGIC, EP_COST_MAGIC = 0x53415045, 0x46525045, 0x43435045
+
+
+class RefPicture(C.Structure):
+    """SvtAmdRefPicture (include/svt_hevc_amd.h)"""
+    _fields_ = [("d_y", C.c_void_p), ("d_cb", C.c_void_p), ("d_cr", C.c_void_p), ("strideY", C.c_uint32), ("strideC", C.c_uint32),
+                ("originX", C.c_uint32), ("originY", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+INTER_AMVP, INTER_MERGE, INTER_SKIP = 0, 1, 2
 LCU_BORDER16_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("mode_bottom", "u1", 16), ("mode_right", "u1", 16), ("bottom_y", "<u2", 64),
                                ("right_y", "<u2", 64), ("bottom_cb", "<u2", 32), ("right_cb", "<u2", 32), ("bottom_cr", "<u2", 32), ("right_cr", "<u2", 32)])
 

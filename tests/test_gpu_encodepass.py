@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import svtlib as S
-from test_oracle_encodepass_golden import CASES, DLF_CASES, compare_lcu, is16, load_case
+from test_oracle_encodepass_golden import CASES, DLF_CASES, INTER_CASES, compare_lcu, is16, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -269,7 +269,7 @@ def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):
     try:
         wk = np.zeros(1, S.LCU_WORK_DTYPE)
         wk[0]["num_cus"] = 1
-        wk[0]["cu"][0]["size"], wk[0]["cu"][0]["pred_mode"] = 32, 1                        # an inter unit
+        wk[0]["cu"][0]["size"], wk[0]["cu"][0]["pred_mode"] = 32, 1                        # an inter unit without reference pictures
         out = np.zeros(1, S.LCU_RESULT_DTYPE)
         assert lib.svt_amd_encode_lcus(gpu_ctx, pic, wk.ctypes.data, 1, out.ctypes.data) != 0
         wk[0]["cu"][0]["size"], wk[0]["cu"][0]["pred_mode"] = 64, 2                        # a 64x64 unit
@@ -278,6 +278,63 @@ def test_encode_lcus_rejects_what_it_does_not_cover(product, gpu_ctx):
         wk16[0]["num_cus"] = 1
         wk16[0]["cu"][0]["size"], wk16[0]["cu"][0]["pred_mode"] = 32, 2
         assert lib.svt_amd_encode_lcus16(gpu_ctx, pic, wk16.ctypes.data, 1, out16.ctypes.data) != 0
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+def device_refs(g, wide):
+    """the fixture's reference pictures in HBM: SvtAmdRefPicture records by POC (and the tensors that back them)"""
+    import torch
+    sy, sc, ox, oy, rw, rh = (int(v) for v in g["ref_geom"])
+    keep, out = [], {}
+    for i, poc in enumerate(g["ref_pocs"].tolist()):
+        planes = [torch.from_numpy(np.ascontiguousarray(g[k][i]).view(np.int16 if wide else np.uint8)).cuda() for k in ("ref_y", "ref_cb", "ref_cr")]
+        keep.append(planes)
+        out[poc] = S.RefPicture(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), sy, sc, ox, oy, rw, rh)
+    torch.cuda.synchronize()
+    return out, keep
+
+
+def set_inter(lib, ctx, pic, g, refs, k):
+    lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    r0, r1 = (refs.get(int(v)) for v in g["ref_poc"][k])
+    cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(int(g["picture_number"][k]))])
+    assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None, cost.ctypes.data) == 0, \
+        lib.svt_amd_last_error()
+
+
+@pytest.mark.parametrize("name", INTER_CASES)
+@pytest.mark.parametrize("how", ["lcus", "picture"])
+def test_p_and_b_pictures_match_reference_records(product, gpu_ctx, name, how):
+    """P / B pictures of the reference encoder: inter units (uni / bi-prediction from reference pictures resident in HBM, encode loop,
+    luma cbf decision of AMVP units, merge and skip units, 64x64 units) between intra units, LCU by LCU in wavefront batches and as ONE
+    launch per picture"""
+    lib = product
+    sig_picture(lib)
+    g, w, h = load_case(name)
+    wide = is16(g)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    nl = wl * hl
+    refs, keep = device_refs(g, wide)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        for first in range(0, len(g["work"]), nl):
+            set_inter(lib, gpu_ctx, pic, g, refs, first)
+            if how == "lcus":
+                assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
+                got = np.zeros(nl, S.LCU_RESULT16_DTYPE if wide else S.LCU_RESULT_DTYPE)
+                for b in wavefront_batches(wl, hl):
+                    got[b] = encode(lib, gpu_ctx, pic, g["work"][[first + i for i in b]])
+            else:
+                works = np.ascontiguousarray(g["work"][first:first + nl])
+                got = np.zeros(nl, S.LCU_RESULT16_DTYPE if wide else S.LCU_RESULT_DTYPE)
+                fn = lib.svt_amd_encode_picture16 if wide else lib.svt_amd_encode_picture
+                assert fn(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+            for k in range(nl):
+                compare_lcu(g["work"][first + k], g["result"][first + k], got[k], w, h, (name, how, int(g["picture_number"][first]), k),
+                            rec=not (int(g["dlf_off"][first + k]) & 2))
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
 
