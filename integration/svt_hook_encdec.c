@@ -4,16 +4,21 @@
  *
  * EncodePass (Codec/EbCodingLoop.c:2989) is interposed with -Wl,--wrap=EncodePass.  For an LCU inside what this revision of
  * svt_amd_encode_lcus() / svt_amd_encode_lcus16() covers - 4:2:0, 8-bit or 10-bit (EncodePass with is16bit), every coding unit an
- * intra 2Nx2N unit of 8..32, no delta-QP / masking tools, plain quantiser - the binding
+ * intra 2Nx2N unit of 8..32 or an inter 2Nx2N unit of 8..64 (the merge / skip decision of :3838-3882 is made here, from the mode
+ * decision's costs, before the call; the reference pictures are device copies kept by svt_hook_me.c), no delta-QP / masking tools,
+ * plain quantiser - the binding
  *   1. converts the LCU's final coding-unit tree (LargestCodingUnit_t.codedLeafArrayPtr) and its source samples into the input
  *      contract SvtAmdLcuWork,
  *   2. makes ONE device call: intra reference + prediction, residual, transform, quantiser, inverse transform and reconstruction of
  *      all units and planes of the LCU run on the MI355X against the picture's un-deblocked reconstruction, which stays in HBM,
  *   3. lets the reference's EncodePass run for its bookkeeping (cbf / DC flags, neighbour arrays, boundary strengths, deblocking,
  *      SAO, coefficient buffer for entropy coding) with every compute leaf it reaches answered from the output contract
- *      SvtAmdLcuResult: the intra generator / predictor table slots and PictureResidual / EstimateTransform return at once,
- *      UnifiedQuantizeInvQuantize hands back the device's coefficients, the EncodeGenerateRecon table slot the device's samples.
- * LCUs outside that (inter units, intra 4x4, PM-core quantiser at encMode <= 4, ...) are encoded by the reference code; their last
+ *      SvtAmdLcuResult: the intra generator / predictor table slots, EncodePassInterPrediction, PictureResidual / EstimateTransform
+ *      return at once, UnifiedQuantizeInvQuantize hands back the device's coefficients, the EncodeGenerateRecon table slot the
+ *      device's samples; for AMVP units PictureFullDistortionLuma / TuEstimateCoeffBitsEncDec return at once and EncodeTuCalcCost is
+ *      given costs that reproduce the device's luma cbf decision.
+ * LCUs outside that (intra 4x4, PM-core quantiser at encMode <= 4, chroma re-decision of CHROMA_MODE_BEST, ...) are encoded by the
+ * reference code; their last
  * row / column and edge mode types (the ep* neighbour arrays after the call) are handed to the device picture before the next
  * device-encoded LCU of the picture needs them.  No fallback on errors: any failure of the HIP library aborts the encoder.
  *
@@ -50,6 +55,18 @@ EB_ERRORTYPE __real_EstimateTransform(EB_S16 *residualBuffer, EB_U32 residualStr
                                       EB_S16 *transformInnerArrayPtr, EB_U32 bitIncrement, EB_BOOL dstTansformFlag,
                                       EB_TRANS_COEFF_SHAPE transCoeffShape);
 
+/* svt_hook_me.c: device copies of the picture's reference pictures (uploaded once per reference picture) */
+void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2]);
+EB_ERRORTYPE __real_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countNonZeroCoeffs, EB_U64 yTuDistortion[DIST_CALC_TOTAL], EB_U64 *yTuCoeffBits,
+                                     EB_U32 componentMask);
+EB_ERRORTYPE __real_PictureFullDistortionLuma(EbPictureBufferDesc_t *coeff, EB_U32 coeffLumaOriginIndex, EbPictureBufferDesc_t *reconCoeff,
+                                              EB_U32 reconCoeffLumaOriginIndex, EB_U32 areaSize, EB_U64 lumaDistortion[DIST_CALC_TOTAL],
+                                              EB_U32 countNonZeroCoeffsY, EB_MODETYPE mode);
+EB_ERRORTYPE __real_TuEstimateCoeffBitsEncDec(EB_U32 tuOriginIndex, EB_U32 tuChromaOriginIndex, EntropyCoder_t *entropyCoderPtr,
+                                              EbPictureBufferDesc_t *coeffBufferTB, EB_U32 countNonZeroCoeffs[3], EB_U64 *yTuCoeffBits,
+                                              EB_U64 *cbTuCoeffBits, EB_U64 *crTuCoeffBits, EB_U32 transformSize, EB_U32 transformChromaSize,
+                                              EB_MODETYPE type, CabacCost_t *CabacCost);
+
 typedef struct {
     const PictureControlSet_t *pcs;
     uint64_t picture_plus1;      /* picture the device picture was begun for */
@@ -70,6 +87,7 @@ typedef struct {
     };
     const LargestCodingUnit_t *lcu;
     int wide; /* 10-bit encode: the 16-bit members are live */
+    int last_luma_cbf; /* the device's luma cbf of the transform unit the reference quantised last (EncodeTuCalcCost follows it) */
 } EpServe;
 _Static_assert(offsetof(SvtAmdLcuWork, src_y) == offsetof(SvtAmdLcuWork16, src_y) && offsetof(SvtAmdLcuResult, rec_y) == offsetof(SvtAmdLcuResult16, rec_y),
                "contract heads");
@@ -85,7 +103,9 @@ static EpPictureEntry g_ep_pic[EP_PICTURES];
 static SvtAmdContext *g_ep_lane[EP_LANES];
 static int g_ep_lane_busy[EP_LANES];
 static int g_ep_state; /* 0 unknown, 1 on, -1 off */
-static unsigned long g_ep_gpu, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts;
+static int g_ep_verify;  /* SVT_HOOK_ENCODEPASS_VERIFY: the reference encodes the LCU itself after the device call and the two outcomes are compared */
+static unsigned long g_ep_verified, g_ep_mismatch;
+static unsigned long g_ep_gpu, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts, g_ep_inter_units, g_ep_inter_lcus;
 
 static SvtAmdContext *lane_claim(SvtAmdContext *root)
 {
@@ -137,6 +157,14 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
     if (!e)
         svt_hook_die("encode pass: more PictureControlSet_t objects than EP_PICTURES");
     if (e->picture_plus1 != pcs->pictureNumber + 1) { /* first LCU of a new picture in this object: nothing coded yet */
+        if (pcs->sliceType != EB_I_PICTURE) { /* what the inter units of the picture read: reference pictures + rate tables (complete
+                                               * before other lanes launch: the begin below waits for this lane's stream) */
+            SvtAmdRefPicture refs[2];
+            int have[2];
+            svt_hook_resident_references(pcs, wide, refs, have);
+            if (svt_amd_encdec_picture_set_inter(lane, e->pic, have[0] ? &refs[0] : NULL, have[1] ? &refs[1] : NULL, (const SvtAmdCabacCost *)pcs->cabacCost))
+                svt_hook_die("svt_amd_encdec_picture_set_inter");
+        }
         if (svt_amd_encdec_picture_begin(lane, e->pic))
             svt_hook_die("svt_amd_encdec_picture_begin");
         e->picture_plus1 = pcs->pictureNumber + 1;
@@ -148,9 +176,16 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
 
 /* EncDec input contract: the coded leaves of the LCU in Z order.  Returns 0 when a unit is outside what the device call covers. */
 static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr,
-                     EB_U32 lcuOriginX, EB_U32 lcuOriginY)
+                     EB_U32 lcuOriginX, EB_U32 lcuOriginY, const EncDecContext_t *contextPtr)
 {
     memset(w, 0, offsetof(SvtAmdLcuWork, src_y));
+    /* inter units: no coefficient shaping (encMode >= 11, EbEncDecProcess.c:2211), no chroma re-decision inside EncodePass (:3840) */
+    const int inter_ok = !contextPtr->fastEl && lcuPtr->chromaEncodeMode != CHROMA_MODE_BEST;
+    int inter_units = 0;
+    w->full_lambda = contextPtr->fullLambda; /* EncDecConfigureLcu ran before EncodePass (EbEncDecProcess.c:3004) */
+    w->luma_cbf_bits[0] = contextPtr->mdRateEstimationPtr->lumaCbfBits[0], w->luma_cbf_bits[1] = contextPtr->mdRateEstimationPtr->lumaCbfBits[1];
+    w->luma_cbf_bits[2] = contextPtr->mdRateEstimationPtr->lumaCbfBits[NUMBER_OF_CBF_CASES >> 1];
+    w->luma_cbf_bits[3] = contextPtr->mdRateEstimationPtr->lumaCbfBits[(NUMBER_OF_CBF_CASES >> 1) + 1];
     w->lcu_x = (uint16_t)lcuOriginX, w->lcu_y = (uint16_t)lcuOriginY;
     w->slice_type = (uint8_t)pcs->sliceType, w->temporal_layer = pcs->temporalLayerIndex;
     w->constrained_intra = pcs->constrainedIntraFlag, w->strong_smoothing = scs->enableStrongIntraSmoothing;
@@ -167,12 +202,35 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
             continue;
         }
         const CodedUnitStats_t *st = GetCodedUnitStats(cuItr);
-        if (cu->predictionModeFlag != INTRA_MODE || cu->predictionUnitArray->intraLumaMode == EB_INTRA_MODE_4x4 || st->size > 32 || st->size < 8 ||
-            n >= SVT_AMD_LCU_MAX_CUS)
+        const int intra = cu->predictionModeFlag == INTRA_MODE;
+        if (st->size < 8 || n >= SVT_AMD_LCU_MAX_CUS || (intra && (cu->predictionUnitArray->intraLumaMode == EB_INTRA_MODE_4x4 || st->size > 32)) ||
+            (!intra && (!inter_ok || cu->predictionModeFlag != INTER_MODE)))
             return 0;
         SvtAmdLcuCu *u = &w->cu[n++];
         u->x = st->originX, u->y = st->originY, u->size = st->size, u->pred_mode = (uint8_t)cu->predictionModeFlag;
-        u->intra_luma_mode = (uint8_t)cu->predictionUnitArray->intraLumaMode;
+        u->intra_luma_mode = intra ? (uint8_t)cu->predictionUnitArray->intraLumaMode : 0;
+        if (!intra) {
+            const PredictionUnit_t *pu = cu->predictionUnitArray;
+            u->inter_dir = (uint8_t)pu->interPredDirectionIndex;
+            for (int l = 0; l < 2; l++)
+                u->mv[l][0] = pu->mv[l].x, u->mv[l][1] = pu->mv[l].y;
+            /* the merge / skip decision EncodePass is about to make (EbCodingLoop.c:3838-3882; isFirstCUinRow is false without the delta-QP
+             * tools), on a copy of the cost it biases */
+            u->inter_kind = SVT_AMD_EP_INTER_AMVP;
+            if (pu->mergeFlag) {
+                EB_U64 skipCost = contextPtr->mdContext->mdEpPipeLcu[cu->leafIndex].skipCost;
+                if (pcs->sliceType == EB_B_PICTURE && pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_FALSE) {
+                    static const EB_U8 INTRA_AREA_TH[MAX_TEMPORAL_LAYERS] = {40, 30, 30, 0, 0, 0};
+                    const EbReferenceObject_t *r0 = (const EbReferenceObject_t *)pcs->refPicPtrArray[REF_LIST_0]->objectPtr;
+                    const EbReferenceObject_t *r1 = (const EbReferenceObject_t *)pcs->refPicPtrArray[REF_LIST_1]->objectPtr;
+                    if (pcs->ParentPcsPtr->variance[lcuPtr->index][0] < 200 &&
+                        (r0->intraCodedArea > INTRA_AREA_TH[r0->tmpLayerIdx] || r1->intraCodedArea > INTRA_AREA_TH[r1->tmpLayerIdx]))
+                        skipCost += (skipCost * 70) / 100;
+                }
+                u->inter_kind = skipCost <= contextPtr->mdContext->mdEpPipeLcu[cu->leafIndex].mergeCost ? SVT_AMD_EP_INTER_SKIP : SVT_AMD_EP_INTER_MERGE;
+            }
+            inter_units++;
+        }
         const uint32_t lg = (uint32_t)Log2f(st->size);
         const uint32_t cuIndex = (st->originY >> lg) * (1u << st->depth) + (st->originX >> lg);
         u->bottom_left_ok = isBottomLeftAvailable(st->depth, cuIndex), u->top_right_ok = isUpperRightAvailable(st->depth, cuIndex);
@@ -180,6 +238,10 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
         cuItr += DepthOffset[st->depth];
     }
     w->num_cus = (uint8_t)n;
+    if (n > 0 && inter_units) {
+        __atomic_add_fetch(&g_ep_inter_units, (unsigned long)inter_units, __ATOMIC_RELAXED);
+        __atomic_add_fetch(&g_ep_inter_lcus, 1, __ATOMIC_RELAXED);
+    }
     return n > 0;
 }
 
@@ -216,11 +278,73 @@ static void border_from_neighbour_arrays(void *out, int wide, const PictureContr
     }
 }
 
+/* Verification mode: the outcome of the reference's own EncodePass of the LCU (flags, coefficients and - with the loop filters off - the
+ * reconstruction) against what the device returned for it */
+static void verify_lcu(const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr, EB_U32 x0, EB_U32 y0)
+{
+    const SvtAmdLcuWork *w = &t_serve->work;
+    const int wide = t_serve->wide;
+    const EbPictureBufferDesc_t *q = lcuPtr->quantizedCoeff;
+    const int16_t *dq[3] = {t_serve->res.coeff_y, t_serve->res.coeff_cb, t_serve->res.coeff_cr};
+    const EB_S16 *rq[3] = {(const EB_S16 *)q->bufferY, (const EB_S16 *)q->bufferCb, (const EB_S16 *)q->bufferCr};
+    const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag
+                                           ? (wide ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture16bit
+                                                   : ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture)
+                                           : (wide ? pcs->reconPicture16bitPtr : pcs->reconPicturePtr);
+    const int rec_ok = scs->staticConfig.disableDlfFlag && !scs->staticConfig.enableSaoFlag;
+    const size_t bps = wide ? 2 : 1;
+    const uint8_t *dr[3] = {(const uint8_t *)t_serve->res.rec_y, wide ? (const uint8_t *)t_serve->res16.rec_cb : t_serve->res.rec_cb,
+                            wide ? (const uint8_t *)t_serve->res16.rec_cr : t_serve->res.rec_cr};
+    const EB_U8 *rr[3] = {rec->bufferY, rec->bufferCb, rec->bufferCr};
+    const EB_U32 rs[3] = {rec->strideY, rec->strideCb, rec->strideCr};
+    int bad = 0;
+    for (int i = 0; i < w->num_cus; i++) {
+        const SvtAmdLcuCu *u = &w->cu[i];
+        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[u->leaf_index];
+        const int skip = u->pred_mode == INTER_MODE && u->inter_kind == SVT_AMD_EP_INTER_SKIP;
+        const int ntu = u->size == 64 ? 4 : 1, T = u->size == 64 ? 32 : u->size;
+        for (int tu = 0; tu < ntu; tu++) {
+            const TransformUnit_t *t = &cu->transformUnitArray[u->size == 64 ? 1 + tu : 0];
+            const SvtAmdLcuCuResult *d = &t_serve->res.cu[i + (u->size == 64 ? 1 + tu : 0)];
+            const int tx = u->x + ((tu & 1) << 5), ty = u->y + ((tu >> 1) << 5);
+            const int rcbf[3] = {t->lumaCbf, t->cbCbf, t->crCbf};
+            for (int p = 0; p < 3; p++) {
+                const int sh = p ? 1 : 0, n = T >> sh, pitch = p ? 32 : 64, lx = tx >> sh, ly = ty >> sh;
+                int what = 0;
+                if (d->cbf[p] != rcbf[p])
+                    what |= 1;
+                if (!skip && (d->nz[p] != t->nzCoefCount[p] || d->only_dc[p] != t->isOnlyDc[p]))
+                    what |= 2;
+                for (int r = 0; r < n && !skip && !(what & 4); r++)
+                    if (memcmp(dq[p] + (ly + r) * pitch + lx, rq[p] + (ly + r) * pitch + lx, (size_t)n * 2))
+                        what |= 4;
+                for (int r = 0; r < n && rec_ok && !(what & 8); r++)
+                    if (memcmp(dr[p] + ((size_t)(ly + r) * pitch + lx) * bps,
+                               rr[p] + ((size_t)(((rec->originY + y0) >> sh) + ly + r) * rs[p] + ((rec->originX + x0) >> sh) + lx) * bps, (size_t)n * bps))
+                        what |= 8;
+                if (what && bad++ < 4)
+                    fprintf(stderr,
+                            "svt_hook_encdec: VERIFY picture %llu slice %d lcu (%u,%u) unit %d (%d,%d) size %d mode %d kind %d dir %d mv (%d,%d)(%d,%d) tu %d plane %d: "
+                            "%s%s%s%s cbf dev %d ref %d nz dev %d ref %d dc dev %d ref %d skipFlag %d mergeFlag %d\n",
+                            (unsigned long long)pcs->pictureNumber, (int)pcs->sliceType, x0, y0, i, u->x, u->y, u->size, u->pred_mode, u->inter_kind, u->inter_dir,
+                            u->mv[0][0], u->mv[0][1], u->mv[1][0], u->mv[1][1], tu, p, what & 1 ? "CBF " : "", what & 2 ? "COUNT " : "", what & 4 ? "COEFF " : "",
+                            what & 8 ? "REC " : "", d->cbf[p], rcbf[p], d->nz[p], t->nzCoefCount[p], d->only_dc[p], t->isOnlyDc[p], (int)cu->skipFlag,
+                            (int)cu->predictionUnitArray->mergeFlag);
+            }
+        }
+    }
+    __atomic_add_fetch(&g_ep_verified, 1, __ATOMIC_RELAXED);
+    if (bad)
+        __atomic_add_fetch(&g_ep_mismatch, 1, __ATOMIC_RELAXED);
+}
+
 void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
                        EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
 {
-    if (g_ep_state == 0)
+    if (g_ep_state == 0) {
+        g_ep_verify = getenv("SVT_HOOK_ENCODEPASS_VERIFY") != NULL;
         g_ep_state = getenv("SVT_HOOK_ENCODEPASS") ? 1 : -1;
+    }
     if (g_ep_state < 0 || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
         if (g_ep_state > 0)
             __atomic_add_fetch(&g_ep_cpu_format, 1, __ATOMIC_RELAXED);
@@ -237,7 +361,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     /* tools that change a unit's QP, dead zone, coefficient shape or quantiser are outside this revision */
     const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
                       contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ;
-    const int units = !tools && fill_work(&t_serve->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY);
+    const int units = !tools && fill_work(&t_serve->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr);
     if (!units) {
         lane_release(lane);
         __atomic_add_fetch(tools ? &g_ep_cpu_tools : &g_ep_cpu_units, 1, __ATOMIC_RELAXED);
@@ -289,6 +413,11 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     lane_release(lane);
     __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
     t_serve->lcu = lcuPtr;
+    if (g_ep_verify) { /* the reference encodes the LCU itself; the device's outcome is only compared */
+        __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+        verify_lcu(scs, pcs, lcuPtr, lcuOriginX, lcuOriginY);
+        return;
+    }
     svt_hook_ep_active = 1;
     __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
     svt_hook_ep_active = 0;
@@ -350,31 +479,41 @@ void svt_hook_ep_quantize(EncDecContext_t *contextPtr, EB_S16 *quantCoeff, EB_S1
     const int i = serve_unit(contextPtr);
     const SvtAmdLcuCu *u = &t_serve->work.cu[i];
     const EbPictureBufferDesc_t *q = t_serve->lcu->quantizedCoeff;
-    /* which plane: the destination lies in one of the LCU's three coefficient planes, at the unit's position */
+    /* which plane and which transform unit of the unit: the destination lies in one of the LCU's three coefficient planes (64x64 units
+     * have four 32x32 transform units, result entries i + 1 .. i + 4) */
     int p = -1;
     const EB_S16 *base[3] = {(const EB_S16 *)q->bufferY, (const EB_S16 *)q->bufferCb, (const EB_S16 *)q->bufferCr};
+    EB_U32 tx = 0, ty = 0;
     for (int k = 0; k < 3; k++) {
-        const EB_U32 pitch = k ? 32 : 64, off = k ? (u->y / 2u) * pitch + u->x / 2u : u->y * pitch + u->x;
-        if (quantCoeff == base[k] + off)
-            p = k;
+        const EB_U32 pitch = k ? 32 : 64;
+        const ptrdiff_t d = quantCoeff - base[k];
+        if (d >= 0 && d < (ptrdiff_t)(pitch * pitch))
+            p = k, tx = (EB_U32)d % pitch, ty = (EB_U32)d / pitch;
     }
-    const EB_U32 n = p > 0 ? u->size / 2u : u->size;
-    if (p < 0 || areaSize != n || coeffStride != (p ? 32u : 64u) || qp != (EB_U32)(p ? u->chroma_qp : u->qp) + (t_serve->wide ? 12u : 0u) || shape ||
-        cleanSparse || masking ||
-        enableCbflag || contouring || dZoffset || !nz)
-        svt_hook_die("encode pass: the reference's quantiser call differs from what the device encoded (unit, plane, QP or tool flags)");
+    const EB_U32 sh = p > 0 ? 1 : 0, T = u->size == 64 ? 32u : u->size, n = T >> sh;
+    if (p >= 0) /* luma coordinates inside the LCU */
+        tx <<= sh, ty <<= sh;
+    const int inside = p >= 0 && tx >= u->x && ty >= u->y && tx < (EB_U32)u->x + u->size && ty < (EB_U32)u->y + u->size && !((tx - u->x) & (T - 1)) &&
+                       !((ty - u->y) & (T - 1));
+    if (!inside || areaSize != n || coeffStride != (p ? 32u : 64u) || qp != (EB_U32)(p ? u->chroma_qp : u->qp) + (t_serve->wide ? 12u : 0u) || shape ||
+        cleanSparse || masking || enableCbflag || contouring || dZoffset || !nz ||
+        (u->pred_mode == INTER_MODE && u->inter_kind == SVT_AMD_EP_INTER_SKIP))
+        svt_hook_die("encode pass: the reference's quantiser call differs from what the device encoded (unit, plane, QP, skip decision or tool flags)");
+    const int e = i + (u->size == 64 ? 1 + (int)(((ty - u->y) >> 5) * 2 + ((tx - u->x) >> 5)) : 0);
     const int16_t *src = (p == 0 ? t_serve->res.coeff_y : p == 1 ? t_serve->res.coeff_cb : t_serve->res.coeff_cr) + (quantCoeff - base[p]);
     for (EB_U32 r = 0; r < n; r++)
         memcpy(quantCoeff + r * coeffStride, src + r * coeffStride, n * sizeof(int16_t));
-    *nz = t_serve->res.cu[i].nz[p];
-    reconCoeff[0] = t_serve->res.cu[i].only_dc[p]; /* the caller's isOnlyDc test (EbCodingLoop.c:792, 879, 1000) reads the DC term */
+    *nz = t_serve->res.cu[e].nz[p];
+    t_serve->last_luma_cbf = p == 0 ? t_serve->res.cu[e].cbf[0] : t_serve->last_luma_cbf;
+    reconCoeff[0] = t_serve->res.cu[e].only_dc[p]; /* the caller's isOnlyDc test (EbCodingLoop.c:792, 879, 1000) reads the DC term */
 }
 
 void svt_hook_ep_recon(EncDecContext_t *contextPtr, EB_U32 originX, EB_U32 originY, EB_U32 tuSize, EbPictureBufferDesc_t *recon)
 {
     const int i = serve_unit(contextPtr);
     const SvtAmdLcuCu *u = &t_serve->work.cu[i];
-    if (tuSize != u->size || (originX & 63) != u->x || (originY & 63) != u->y)
+    const EB_U32 ux = originX & 63, uy = originY & 63; /* the transform unit inside the LCU (64x64 units: four of 32) */
+    if (tuSize != (u->size == 64 ? 32u : u->size) || ux < u->x || uy < u->y || ux + tuSize > (EB_U32)u->x + u->size || uy + tuSize > (EB_U32)u->y + u->size)
         svt_hook_die("encode pass: reconstruction call for another unit");
     const size_t bps = t_serve->wide ? 2 : 1;
     const uint8_t *ry = (const uint8_t *)t_serve->res.rec_y, *rcb, *rcr; /* rec_y sits at the same offset in both contracts */
@@ -384,20 +523,61 @@ void svt_hook_ep_recon(EncDecContext_t *contextPtr, EB_U32 originX, EB_U32 origi
         rcb = t_serve->res.rec_cb, rcr = t_serve->res.rec_cr;
     EB_U8 *y = recon->bufferY + ((size_t)(recon->originY + originY) * recon->strideY + recon->originX + originX) * bps;
     for (EB_U32 r = 0; r < tuSize; r++)
-        memcpy(y + (size_t)r * recon->strideY * bps, ry + ((size_t)(u->y + r) * 64 + u->x) * bps, tuSize * bps);
+        memcpy(y + (size_t)r * recon->strideY * bps, ry + ((size_t)(uy + r) * 64 + ux) * bps, tuSize * bps);
     EB_U8 *cb = recon->bufferCb + ((size_t)((recon->originY + originY) / 2) * recon->strideCb + (recon->originX + originX) / 2) * bps;
     EB_U8 *cr = recon->bufferCr + ((size_t)((recon->originY + originY) / 2) * recon->strideCr + (recon->originX + originX) / 2) * bps;
     for (EB_U32 r = 0; r < tuSize / 2; r++) {
-        memcpy(cb + (size_t)r * recon->strideCb * bps, rcb + ((size_t)(u->y / 2 + r) * 32 + u->x / 2) * bps, tuSize / 2 * bps);
-        memcpy(cr + (size_t)r * recon->strideCr * bps, rcr + ((size_t)(u->y / 2 + r) * 32 + u->x / 2) * bps, tuSize / 2 * bps);
+        memcpy(cb + (size_t)r * recon->strideCb * bps, rcb + ((size_t)(uy / 2 + r) * 32 + ux / 2) * bps, tuSize / 2 * bps);
+        memcpy(cr + (size_t)r * recon->strideCr * bps, rcr + ((size_t)(uy / 2 + r) * 32 + ux / 2) * bps, tuSize / 2 * bps);
     }
+}
+
+/* The luma cbf decision of an AMVP unit (EbCodingLoop.c:4075-4124) was made on the device: the two measuring leaves return at once, and
+ * EncodeTuCalcCost - which also writes the TransformUnit_t flags - is given distortions that reproduce the device's decision. */
+EB_ERRORTYPE __wrap_PictureFullDistortionLuma(EbPictureBufferDesc_t *coeff, EB_U32 coeffLumaOriginIndex, EbPictureBufferDesc_t *reconCoeff,
+                                              EB_U32 reconCoeffLumaOriginIndex, EB_U32 areaSize, EB_U64 lumaDistortion[DIST_CALC_TOTAL],
+                                              EB_U32 countNonZeroCoeffsY, EB_MODETYPE mode)
+{
+    if (svt_hook_ep_active) {
+        lumaDistortion[0] = lumaDistortion[1] = 0;
+        return EB_ErrorNone;
+    }
+    return __real_PictureFullDistortionLuma(coeff, coeffLumaOriginIndex, reconCoeff, reconCoeffLumaOriginIndex, areaSize, lumaDistortion, countNonZeroCoeffsY,
+                                            mode);
+}
+
+EB_ERRORTYPE __wrap_TuEstimateCoeffBitsEncDec(EB_U32 tuOriginIndex, EB_U32 tuChromaOriginIndex, EntropyCoder_t *entropyCoderPtr,
+                                              EbPictureBufferDesc_t *coeffBufferTB, EB_U32 countNonZeroCoeffs[3], EB_U64 *yTuCoeffBits,
+                                              EB_U64 *cbTuCoeffBits, EB_U64 *crTuCoeffBits, EB_U32 transformSize, EB_U32 transformChromaSize,
+                                              EB_MODETYPE type, CabacCost_t *CabacCost)
+{
+    if (svt_hook_ep_active)
+        return EB_ErrorNone; /* the caller zeroed the three counters (:4097-4099) */
+    return __real_TuEstimateCoeffBitsEncDec(tuOriginIndex, tuChromaOriginIndex, entropyCoderPtr, coeffBufferTB, countNonZeroCoeffs, yTuCoeffBits,
+                                            cbTuCoeffBits, crTuCoeffBits, transformSize, transformChromaSize, type, CabacCost);
+}
+
+EB_ERRORTYPE __wrap_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countNonZeroCoeffs, EB_U64 yTuDistortion[DIST_CALC_TOTAL], EB_U64 *yTuCoeffBits,
+                                     EB_U32 componentMask)
+{
+    if (svt_hook_ep_active) { /* keep: coded cost 0 < zeroed cost; drop: the other way round (the rates only add to both) */
+        const int keep = t_serve->last_luma_cbf;
+        yTuDistortion[DIST_CALC_RESIDUAL] = keep ? 0 : (EB_U64)1 << 40;
+        yTuDistortion[DIST_CALC_PREDICTION] = keep ? (EB_U64)1 << 40 : 0;
+        *yTuCoeffBits = 0;
+    }
+    return __real_EncodeTuCalcCost(contextPtr, countNonZeroCoeffs, yTuDistortion, yTuCoeffBits, componentMask);
 }
 
 void svt_hook_encdec_report(FILE *out)
 {
     if (g_ep_state <= 0)
         return;
-    fprintf(out, "svt_hook_me: encode pass: %lu LCUs encoded on the GPU (one call each); left to the reference code: %lu LCUs with units outside "
-                 "the device call, %lu under tools outside it, %lu in another sample format; %lu host LCU borders handed over in %lu calls\n",
-            g_ep_gpu, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts);
+    fprintf(out, "svt_hook_me: encode pass: %lu LCUs encoded on the GPU (one call each; %lu of them with inter units, %lu inter units); left to the "
+                 "reference code: %lu LCUs with units outside the device call, %lu under tools outside it, %lu in another sample format; %lu host LCU "
+                 "borders handed over in %lu calls\n",
+            g_ep_gpu, g_ep_inter_lcus, g_ep_inter_units, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts);
+    if (g_ep_verify)
+        fprintf(out, "svt_hook_me: encode pass verification: %lu device-encoded LCUs compared with the reference's own EncodePass, %lu differ\n", g_ep_verified,
+                g_ep_mismatch);
 }

@@ -1135,7 +1135,7 @@ EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, 
 EB_ERRORTYPE __real_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
                                               PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
                                               MotionCompensationPredictionContext_t *mcpContext);
-#define REF_CACHE 8
+#define REF_CACHE 16
 static struct RefSlot { const void *buf; uint64_t poc, used; void *d[3]; size_t bytes[3]; SvtAmdRefPicture pic; } g_refs[REF_CACHE];
 static uint64_t g_ref_clock;
 static void *g_inter_scratch[3]; /* device prediction planes: 64x64, 32x32, 32x32 */
@@ -1178,10 +1178,26 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
     return &victim->pic;
 }
 
+/* for the device-resident encode pass (svt_hook_encdec.c): the reference pictures of both lists as device copies */
+void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2])
+{
+    pthread_mutex_lock(&g_lock);
+    for (int l = 0; l < 2; l++) {
+        have[l] = l == 0 ? pcs->sliceType != EB_I_PICTURE : pcs->sliceType == EB_B_PICTURE;
+        if (!have[l])
+            continue;
+        const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
+        out[l] = *resident_reference_bps(wide ? ro->referencePicture16bit : ro->referencePicture, ro->refPOC, wide ? 2 : 1);
+    }
+    pthread_mutex_unlock(&g_lock);
+}
+
 EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
                                               PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
                                               MotionCompensationPredictionContext_t *mcpContext)
 {
+    if (svt_hook_ep_active) /* the device encoded this LCU: the reconstruction table slot brings the samples */
+        return EB_ErrorNone;
     if (g_inter_state == 0)
         g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
     if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||
@@ -1241,6 +1257,8 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
                                                    PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
                                                    MotionCompensationPredictionContext_t *mcpContext)
 {
+    if (svt_hook_ep_active)
+        return EB_ErrorNone;
     if (g_inter_state == 0)
         g_inter_state = getenv("SVT_HOOK_INTER") ? 1 : -1;
     if (g_inter_state < 0 || !g_ctx || predictionPtr->colorFormat != EB_YUV420 || puWidth < 8 || puHeight < 8 || puWidth > 64 ||

@@ -19,6 +19,8 @@
  * and the luma cbf decision EncodeTuCalcCost (EbRateDistortionCost.c:2578-2675) restated below; the glue is pinned on recorded EncodePass
  * calls of P / B pictures (tests/golden/encodepass_p_*.npz, _b_*).
  */
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "svt_oracle.h"
 
@@ -99,6 +101,10 @@ static void encode_inter_cu(int bps, void *const rec[3], const uint32_t pitch[3]
                 const uint64_t zCost = (dd[1] << 8) + ((((uint64_t)W->full_lambda * zRate) + (1u << 22)) >> 23);
                 const uint64_t nzCost = (dd[0] << 8) + ((((uint64_t)W->full_lambda * nzRate) + (1u << 22)) >> 23);
                 cbf = nz != 0 && nzCost < zCost;
+                if (getenv("SVT_ORACLE_EP_DEBUG"))
+                    fprintf(stderr, "oracle AMVP unit (%d,%d) n %d nz %u only_dc %d d0 %llu d1 %llu bits %llu lambda %u cbfbits %u %u zCost %llu nzCost %llu -> cbf %d\n",
+                            cu->x, cu->y, n, nz, only_dc, (unsigned long long)dd[0], (unsigned long long)dd[1], (unsigned long long)bits, W->full_lambda,
+                            W->luma_cbf_bits[ctx], W->luma_cbf_bits[2 + ctx], (unsigned long long)zCost, (unsigned long long)nzCost, cbf);
             }
             if (cbf)
                 svt_oracle_recon_tu(bps, (uint32_t)n, only_dc, 0, r, dp, pitch[p], dp, pitch[p]);

@@ -396,18 +396,22 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int lane, int r, bool active,
 #pragma unroll
             for (int o = 1; o < N; o <<= 1)
                 d0 += __shfl_xor(d0, o), d1 += __shfl_xor(d1, o);
+            /* the unit's lanes hold the sums; the rate estimator below runs on (N / 4)^2 lanes - all 64 for a 32x32 unit, whose upper
+             * half are not lanes of the unit: everything the decision uses comes from lane 0 */
+            const uint32_t nzu = (uint32_t)__shfl((int)nz, 0);
+            d0 = (uint32_t)__shfl((int)d0, 0), d1 = (uint32_t)__shfl((int)d1, 0);
             constexpr int dshift = 2 * (7 - LG);
             const unsigned long long dz = ((unsigned long long)d1 + (1ull << (dshift - 1))) >> dshift;
-            const unsigned long long dn = nz ? ((unsigned long long)d0 + (1ull << (dshift - 1))) >> dshift : dz;
+            const unsigned long long dn = nzu ? ((unsigned long long)d0 + (1ull << (dshift - 1))) >> dshift : dz;
             EP_WAVE_SYNC(); /* qbuf is written */
             constexpr int S = (N / 4) * (N / 4);
-            const SvtAmdTuInfo ti = {nz, 1 /* INTER_MODE */, 0xFF, 0xFF, 0};
+            const SvtAmdTuInfo ti = {nzu, 1 /* INTER_MODE */, 0xFF, 0xFF, 0};
             const uint32_t b32 = coeff_bits_lanes(*dec.cost, dec.qbuf, N, LG, ti, lane < S, lane, lane & (S - 1));
             const unsigned long long tuBits = (((unsigned long long)__shfl(b32, 0)) << 10) >> 15;
             const unsigned long long nzRate = (tuBits << 15) + dec.nonzero_bits, zRate = dec.zero_bits, lam = dec.lambda;
             const unsigned long long zCost = (dz << 8) + (((lam * zRate) + (1u << 22)) >> 23);
             const unsigned long long nzCost = (dn << 8) + (((lam * nzRate) + (1u << 22)) >> 23);
-            cbf = nz != 0 && nzCost < zCost;
+            cbf = nzu != 0 && nzCost < zCost;
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -43,6 +43,8 @@ CASES = {
     "b_motion_320x192_m5": ("motion", 320, 192, 5, 9, ["-encMode", "5", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "28"]),
     # noise: every unit carries coefficients, the luma cbf decision sees large rates
     "p_noise_200x136_m6": ("noise", 200, 136, 3, 11, ["-encMode", "6", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "34"]),
+    # constrained intra prediction, encMode 8: 32x32 and 64x64 AMVP units with ~200 coefficients that the luma cbf decision zeroes
+    "p_noise_320x256_m8_ci": ("noise", 320, 256, 4, 7, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40"]),
     "p10_motion_320x192_m7": ("motion10", 320, 192, 3, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "32", "-bit-depth", "10"]),
 }
 

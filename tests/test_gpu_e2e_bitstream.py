@@ -322,11 +322,15 @@ ENCODEPASS_CASES = [
     ("noise", 200, 136, 2, ["-encMode", "6", "-intra-period", "0", "-q", "22"], "all"),
     # BASELINE configs[0]: all-intra 1080p encMode 10
     ("motion", 1920, 1080, 2, ["-encMode", "10", "-intra-period", "0"], "all"),
-    # random access: the I picture and the all-intra LCUs of P / B pictures on the device, LCUs with inter units on the host, their
-    # borders handed over
-    ("motion", 640, 384, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], "some"),
-    # low-delay P with constrained intra prediction: inter neighbours are unavailable to intra units
+    # random access: I, P and B pictures on the device - inter units (uni / bi-prediction from device copies of the reference pictures,
+    # merge / skip / AMVP) and the intra units between them
+    ("motion", 640, 384, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], "inter"),
+    # low-delay P with constrained intra prediction: inter neighbours are unavailable to intra units; at encMode 8 the top-layer
+    # pictures re-decide merge / skip with chroma inside EncodePass (CHROMA_MODE_BEST): those LCUs stay on the host, borders handed over
     ("noise", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40"], "mixed"),
+    # low-delay P, flat prediction structure, 64x64 units at a high QP, AMVP units on noise
+    ("motion", 416, 240, 6, ["-encMode", "6", "-pred-struct", "0", "-hierarchical-levels", "0", "-q", "40"], "inter"),
+    ("noise", 200, 136, 5, ["-encMode", "5", "-pred-struct", "1", "-hierarchical-levels", "0", "-q", "46"], "inter"),
     # 2 x 2 tiles: tile edges cut the intra neighbourhood, four wavefronts share the picture
     ("motion", 832, 480, 3, ["-encMode", "7", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
     # encMode 4: the encode pass quantises with PM-core, outside the device call - every LCU must be left to the reference code
@@ -335,7 +339,7 @@ ENCODEPASS_CASES = [
     ("motion10", 416, 240, 3, ["-encMode", "9", "-intra-period", "0", "-bit-depth", "10"], "all"),
     ("noise10", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40", "-bit-depth", "10"], "mixed"),
     ("motion10c", 640, 384, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-bit-depth", "10",
-                                "-compressed-ten-bit-format", "1"], "some"),
+                                "-compressed-ten-bit-format", "1"], "inter"),
 ]
 
 
@@ -362,18 +366,19 @@ def test_bitstream_and_recon_identical_with_device_resident_encode_pass(tmp_path
         del os.environ["SVT_HOOK_ENCODEPASS"]
         del os.environ["SVT_HOOK_REPORT"]
     rep = open(str(tmp_path / "report.txt")).read()
-    m = re.search(r"encode pass: (\d+) LCUs encoded on the GPU \(one call each\); left to the reference code: (\d+) LCUs with units outside "
-                  r"the device call, (\d+) under tools outside it, (\d+) in another sample format; (\d+) host LCU borders handed over in (\d+) calls", rep)
+    m = re.search(r"encode pass: (\d+) LCUs encoded on the GPU \(one call each; (\d+) of them with inter units, (\d+) inter units\); left to the "
+                  r"reference code: (\d+) LCUs with units outside the device call, (\d+) under tools outside it, (\d+) in another sample format; "
+                  r"(\d+) host LCU borders handed over in (\d+) calls", rep)
     assert m, rep
-    gpu, units, tools, fmt, borders, puts = (int(x) for x in m.groups())
+    gpu, inter_lcus, inter_units, units, tools, fmt, borders, puts = (int(x) for x in m.groups())
     nl = S.lcu_count(w, h) * n
     assert gpu + units + tools + fmt == nl, rep
     if expect == "all":
         assert gpu == nl, rep
-    elif expect == "some":     # at least the I picture
-        assert gpu >= S.lcu_count(w, h) and units > 0 and borders == units, rep
-    elif expect == "mixed":    # device-encoded LCUs after host-encoded ones inside P pictures
-        assert gpu > S.lcu_count(w, h) and units > 0 and borders == units and 0 < puts <= units, rep
+    elif expect == "inter":    # every LCU of every picture, most of them with inter units
+        assert gpu == nl and inter_lcus > nl // 3 and inter_units >= inter_lcus, rep
+    elif expect == "mixed":    # device-encoded LCUs (with inter units too) after host-encoded ones inside P pictures
+        assert gpu > S.lcu_count(w, h) and inter_lcus > 0 and units > 0 and borders == units and puts <= units, rep
     else:
         assert gpu == 0 and tools == nl, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
