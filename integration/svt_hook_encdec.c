@@ -17,7 +17,7 @@
  *      return at once, UnifiedQuantizeInvQuantize hands back the device's coefficients, the EncodeGenerateRecon table slot the
  *      device's samples; for AMVP units PictureFullDistortionLuma / TuEstimateCoeffBitsEncDec return at once and EncodeTuCalcCost is
  *      given costs that reproduce the device's luma cbf decision.
- * LCUs outside that (intra 4x4, PM-core quantiser at encMode <= 4, chroma re-decision of CHROMA_MODE_BEST, ...) are encoded by the
+ * LCUs outside that (intra 4x4, PM-core quantiser at encMode <= 4, coefficient shaping at encMode >= 11, ...) are encoded by the
  * reference code; their last
  * row / column and edge mode types (the ep* neighbour arrays after the call) are handed to the device picture before the next
  * device-encoded LCU of the picture needs them.  No fallback on errors: any failure of the HIP library aborts the encoder.
@@ -55,6 +55,9 @@ EB_ERRORTYPE __real_EstimateTransform(EB_S16 *residualBuffer, EB_U32 residualStr
                                       EB_S16 *transformInnerArrayPtr, EB_U32 bitIncrement, EB_BOOL dstTansformFlag,
                                       EB_TRANS_COEFF_SHAPE transCoeffShape);
 
+void AddChromaEncDec(PictureControlSet_t *pictureControlSetPtr, LargestCodingUnit_t *lcuPtr, CodingUnit_t *cuPtr, ModeDecisionContext_t *contextPtr,
+                     EncDecContext_t *contextPtrED, EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex, EB_U32 cuChromaOriginIndex,
+                     EB_U32 candIdxInput); /* EbProductCodingLoop.c:4158 */
 /* svt_hook_me.c: device copies of the picture's reference pictures (uploaded once per reference picture) */
 void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2]);
 EB_ERRORTYPE __real_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countNonZeroCoeffs, EB_U64 yTuDistortion[DIST_CALC_TOTAL], EB_U64 *yTuCoeffBits,
@@ -179,8 +182,8 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
                      EB_U32 lcuOriginX, EB_U32 lcuOriginY, const EncDecContext_t *contextPtr)
 {
     memset(w, 0, offsetof(SvtAmdLcuWork, src_y));
-    /* inter units: no coefficient shaping (encMode >= 11, EbEncDecProcess.c:2211), no chroma re-decision inside EncodePass (:3840) */
-    const int inter_ok = !contextPtr->fastEl && lcuPtr->chromaEncodeMode != CHROMA_MODE_BEST;
+    /* inter units: no coefficient shaping (encMode >= 11, EbEncDecProcess.c:2211) */
+    const int inter_ok = !contextPtr->fastEl;
     int inter_units = 0;
     w->full_lambda = contextPtr->fullLambda; /* EncDecConfigureLcu ran before EncodePass (EbEncDecProcess.c:3004) */
     w->luma_cbf_bits[0] = contextPtr->mdRateEstimationPtr->lumaCbfBits[0], w->luma_cbf_bits[1] = contextPtr->mdRateEstimationPtr->lumaCbfBits[1];
@@ -218,6 +221,19 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
              * tools), on a copy of the cost it biases */
             u->inter_kind = SVT_AMD_EP_INTER_AMVP;
             if (pu->mergeFlag) {
+                if (lcuPtr->chromaEncodeMode == CHROMA_MODE_BEST) {
+                    /* the mode decision left chroma out of the merge / skip costs: EncodePass adds it first (:3840-3863, host code: chroma
+                     * prediction + the chroma full loop of the merge candidate).  Done here with the same arguments, so that the decision
+                     * is known before the device call; the call EncodePass makes later recomputes the same two costs. */
+                    EbPictureBufferDesc_t *cin = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
+                    const EB_U32 cuX = lcuOriginX + st->originX, cuY = lcuOriginY + st->originY;
+                    ModeDecisionContext_t *md = contextPtr->mdContext;
+                    md->cuOriginX = cuX, md->cuOriginY = cuY, md->puItr = 0, md->cuSize = st->size, md->cuSizeLog2 = st->sizeLog2, md->cuStats = st;
+                    ((EncDecContext_t *)contextPtr)->cuStats = st;
+                    AddChromaEncDec((PictureControlSet_t *)pcs, (LargestCodingUnit_t *)lcuPtr, (CodingUnit_t *)cu, md, (EncDecContext_t *)contextPtr, cin,
+                                    ((cuY >> 1) + (cin->originY >> 1)) * cin->strideCb + ((cuX >> 1) + (cin->originX >> 1)),
+                                    (((cuY & 63) * 32) + (cuX & 63)) >> 1, 0);
+                }
                 EB_U64 skipCost = contextPtr->mdContext->mdEpPipeLcu[cu->leafIndex].skipCost;
                 if (pcs->sliceType == EB_B_PICTURE && pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_FALSE) {
                     static const EB_U8 INTRA_AREA_TH[MAX_TEMPORAL_LAYERS] = {40, 30, 30, 0, 0, 0};

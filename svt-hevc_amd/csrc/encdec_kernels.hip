@@ -949,11 +949,19 @@ static int picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const t
             SvtAmdCuMapEntry e;
             ::memset(&e, 0, sizeof(e));
             e.mode = u.pred_mode, e.size_log2 = (uint8_t)(u.size == 8 ? 3 : u.size == 16 ? 4 : u.size == 32 ? 5 : 6);
+            if (u.pred_mode == 1) /* inter: the prediction unit's direction and motion vectors decide the strength of its edges */
+                e.dir = u.inter_dir, ::memcpy(e.mv, u.mv, sizeof(e.mv));
             for (uint32_t y = y0 / 8; y < (y0 + u.size) / 8; y++)
                 for (uint32_t x = x0 / 8; x < (x0 + u.size) / 8; x++)
                     map[(size_t)y * w8 + x] = e, qp[(size_t)y * w8 + x] = u.qp;
-            for (uint32_t y = y0 / 4; y < (y0 + u.size) / 4; y++)
-                ::memset(&cbf[(size_t)y * w4 + x0 / 4], results[i].cu[c].cbf[0], u.size / 4);
+            if (u.size == 64) { /* four 32x32 transform units: result entries c + 1 .. c + 4 */
+                for (uint32_t y = 0; y < 16; y++)
+                    for (uint32_t t = 0; t < 2; t++)
+                        ::memset(&cbf[(size_t)(y0 / 4 + y) * w4 + x0 / 4 + 8 * t], results[i].cu[c + 1 + 2 * (y >> 3) + t].cbf[0], 8);
+            } else {
+                for (uint32_t y = y0 / 4; y < (y0 + u.size) / 4; y++)
+                    ::memset(&cbf[(size_t)y * w4 + x0 / 4], results[i].cu[c].cbf[0], u.size / 4);
+            }
         }
     }
     HIP_TRY(hipSetDevice(ctx->device));

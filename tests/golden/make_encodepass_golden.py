@@ -34,6 +34,9 @@ CASES = {
     "dlf_i_motion_416x240_m9": ("motion", 416, 240, 2, 7, ["-encMode", "9", "-intra-period", "0", "-q", "34"]),
     "dlf_i_noise_200x136_m6": ("noise", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "38"]),
     "dlf_i10_motion_320x192_m7": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "36", "-bit-depth", "10"]),
+    # ... of P / B pictures: boundary strengths from motion vectors, reference pictures and transform-unit cbf (64x64 units: four units)
+    "dlf_p_motion_416x240_m7": ("motion", 416, 240, 4, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "36"]),
+    "dlf_b_motion_320x192_m6": ("motion", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),
     # P / B pictures ("p_" / "b_" / "p10_" prefix: LCUs with inter units are recorded too, with the reference pictures they predict from and
     # the pictures' coefficient-rate tables; loop filters off as above).  Low delay P: uni-prediction, AMVP / merge / skip units, 64x64 units
     "p_motion_416x240_m7": ("motion", 416, 240, 4, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "30"]),
@@ -89,7 +92,7 @@ def run_case(name):
         rdt = S.EP_RECORD16_DTYPE if kind.endswith("10") else S.EP_RECORD_DTYPE
         recs, refs, costs = parse_dump(open(dump, "rb").read(), rdt)
         rec_raw = open(rec_out, "rb").read() if dlf else b""
-    inter = name.split("_")[0] in ("p", "b", "p10", "b10")
+    inter = any(t in ("p", "b", "p10", "b10") for t in name.split("_")[:2])
     assert len(recs) and (recs["record_size"] == rdt.itemsize).all(), (len(recs), rdt.itemsize)
     assert ((recs["dlf_off"] & 1) == (0 if dlf else 1)).all()   # bit 1: the LCU was not reconstructed (doRecon == 0)
     extra = {}

@@ -359,17 +359,24 @@ def test_encode_picture_then_deblock_matches_the_encoders_output(product, gpu_ct
     dbk.restype, dbk.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DeblockParams), C.c_void_p, C.c_void_p, C.c_void_p]
     sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if wide else (np.uint8, S.LCU_RESULT_DTYPE)
     nl = S.lcu_count(w, h)
+    inter = "ref_pocs" in g          # P / B pictures: prediction from the (deblocked) reference pictures of the fixture, resident in HBM
+    refs, keep = device_refs(g, wide) if inter else ({}, None)
     pic = C.c_void_p()
     assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
-        for f, first in enumerate(range(0, len(g["work"]), nl)):
+        for first in range(0, len(g["work"]), nl):
+            f = int(g["picture_number"][first])      # the encoder's output is in display order
             works = np.ascontiguousarray(g["work"][first:first + nl])
             got = np.zeros(nl, rdt)
+            if inter:
+                set_inter(lib, gpu_ctx, pic, g, refs, first)
             assert enc(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
             for k in range(nl):
                 compare_lcu(works[k], g["result"][first + k], got[k], w, h, (name, f, k), rec=False)
             prm = DeblockParams()
-            prm.slice_type = 2
+            prm.slice_type = int(works[0]["slice_type"])
+            if inter:
+                prm.ref_poc[0], prm.ref_poc[1] = int(g["ref_poc"][first][0]), int(g["ref_poc"][first][1])
             out = [np.zeros((h, w), sdt), np.zeros((h // 2, w // 2), sdt), np.zeros((h // 2, w // 2), sdt)]
             assert dbk(gpu_ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(prm), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data) == 0, \
                 lib.svt_amd_last_error()

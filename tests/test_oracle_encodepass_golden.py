@@ -191,13 +191,21 @@ def deblock_maps(works, results, w, h):
             x0, y0, n = int(wk["lcu_x"]) + int(u["x"]), int(wk["lcu_y"]) + int(u["y"]), int(u["size"])
             cumap["mode"][y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = u["pred_mode"]
             cumap["size_log2"][y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = n.bit_length() - 1
+            if int(u["pred_mode"]) == 1:
+                cumap["dir"][y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = u["inter_dir"]
+                cumap["mv"][y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = u["mv"]
             qp[y0 // 8:(y0 + n) // 8, x0 // 8:(x0 + n) // 8] = u["qp"]
-            cbf[y0 // 4:(y0 + n) // 4, x0 // 4:(x0 + n) // 4] = rs["cu"]["cbf"][c][0]
+            if n == 64:      # four 32x32 transform units, result entries 1..4
+                for t in range(4):
+                    tx, ty = x0 + 32 * (t & 1), y0 + 32 * (t >> 1)
+                    cbf[ty // 4:ty // 4 + 8, tx // 4:tx // 4 + 8] = rs["cu"]["cbf"][c + 1 + t][0]
+            else:
+                cbf[y0 // 4:(y0 + n) // 4, x0 // 4:(x0 + n) // 4] = rs["cu"]["cbf"][c][0]
     return cumap, cbf, qp, edge
 
 
 def test_have_dlf_cases():
-    assert len(DLF_CASES) >= 3
+    assert len(DLF_CASES) >= 5 and sum("ref_pocs" in load_case(c)[0] for c in DLF_CASES) >= 2
 
 
 @pytest.mark.parametrize("name", DLF_CASES)
@@ -207,26 +215,31 @@ def test_encode_then_deblock_oracle_matches_the_encoders_output(oracle, name):
     from test_oracle_dlf_golden import oracle_bs, oracle_dlf
     g, w, h = load_case(name)
     wide = is16(g)
-    fn = oracle.svt_oracle_encode_lcu16 if wide else oracle.svt_oracle_encode_lcu
-    fn.restype = None
-    fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    inter = "ref_pocs" in g       # P / B pictures: the (deblocked) reference pictures and rate tables come with the fixture
+    fn = inter_oracle_fn(oracle, wide)
+    refs, keep = ref_pictures(g, wide) if inter else ({}, None)
     sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if wide else (np.uint8, S.LCU_RESULT_DTYPE)
     nl = S.lcu_count(w, h)
     pitches = (w, w // 2, w // 2)
     pb = (C.c_uint32 * 3)(*pitches)
-    for f, first in enumerate(range(0, len(g["work"]), nl)):
+    for first in range(0, len(g["work"]), nl):
+        f = int(g["picture_number"][first])     # the encoder's output is in display order
         rec = [np.zeros((hh, p), sdt) for hh, p in zip((h, h // 2, h // 2), pitches)]
         mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
         rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
         got = np.zeros(nl, rdt)
+        r0, r1 = (refs.get(int(v)) for v in g["ref_poc"][first]) if inter else (None, None)
+        cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(f)]) if inter else None
         for k in range(nl):
             work = np.ascontiguousarray(g["work"][first + k:first + k + 1])
-            fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got[k:k + 1].ctypes.data)
+            fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None,
+               cost.ctypes.data if inter else None, work.ctypes.data, got[k:k + 1].ctypes.data)
             compare_lcu(work[0], g["result"][first + k], got[k], w, h, (name, f, k), rec=False)
         cumap, cbf, qp, edge = deblock_maps(g["work"][first:first + nl], got, w, h)
         hdr = dict(width=w, height=h, bytes_per_sample=2 if wide else 1, qp_stride=w // 8, tc_offset=0, beta_offset=0, cb_qp_offset=0,
-                   cr_qp_offset=0, slice_type=2)
-        pic = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1), refpoc=np.zeros(2, np.uint64), lcu_edge=edge,
+                   cr_qp_offset=0, slice_type=int(g["work"][first]["slice_type"]))
+        pic = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1),
+                   refpoc=np.ascontiguousarray(g["ref_poc"][first]) if inter else np.zeros(2, np.uint64), lcu_edge=edge,
                    bsv=np.zeros((nl, 256), np.uint8), bsh=np.zeros((nl, 256), np.uint8))
         pic["bsv"], pic["bsh"] = oracle_bs(oracle, pic)
         pic["pre"], pic["qp"] = rec, qp.reshape(-1)
