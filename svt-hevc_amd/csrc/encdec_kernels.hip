@@ -174,39 +174,69 @@ __device__ __forceinline__ void ep_inter_predict_plane(const EpPicture &P, EpLoc
                     tx[k] = chroma ? (k < 4 ? (int)c_ep_chroma_taps[fx][k & 3] : 0) : (int)c_ep_luma_taps[fx][k];
                     tv[k] = chroma ? (k < 4 ? (int)c_ep_chroma_taps[fy][k & 3] : 0) : (int)c_ep_luma_taps[fy][k];
                 }
-                /* window: lane = column, one row per step */
+                /* window: lane = column; every row's load is issued before the first is stored (one memory latency per window, not one
+                 * per row) */
                 if (lane < rows) {
                     const int base = (iy + first) * stride + ix + first + lane;
-#pragma unroll 4
-                    for (int j = 0; j < rows; j++)
-                        M.win[j * WP + lane] = plane[min(max(base + j * stride, 0), last)];
+                    T v[39];
+#pragma unroll
+                    for (int j = 0; j < 39; j++)
+                        if (j < rows)
+                            v[j] = plane[min(max(base + j * stride, 0), last)];
+#pragma unroll
+                    for (int j = 0; j < 39; j++)
+                        if (j < rows)
+                            M.win[j * WP + lane] = v[j];
                 }
                 EP_WAVE_SYNC();
-                for (int i = lane; i < rows << lgt; i += 64) { /* horizontal pass of every window row */
-                    const int j = i >> lgt, x = i & (tn - 1);
-                    int hs = 0;
+                /* horizontal pass of every window row: a lane slides the taps over a run of seg outputs (seg + taps - 1 reads) */
+                const int seg = tn < 8 ? tn : 8, lgs = tn < 8 ? lgt : 3, spr = tn >> lgs; /* runs per row */
+                for (int i = lane; i < rows * spr; i += 64) {
+                    const int j = i >> (lgt - lgs), x0 = (i & (spr - 1)) << lgs;
+                    int in[15];
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        if (k < ntaps)
-                            hs += tx[k] * (int)M.win[j * WP + x + k];
-                    M.tmp[j * 32 + x] = (int16_t)((hs - (B << s1)) >> s1);
+                    for (int k = 0; k < 15; k++)
+                        in[k] = k < seg + ntaps - 1 ? (int)M.win[j * WP + x0 + k] : 0;
+#pragma unroll
+                    for (int o = 0; o < 8; o++)
+                        if (o < seg) {
+                            int hs = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                                if (k < ntaps)
+                                    hs += tx[k] * in[o + k];
+                            M.tmp[j * 32 + x0 + o] = (int16_t)((hs - (B << s1)) >> s1);
+                        }
                 }
                 EP_WAVE_SYNC();
-                for (int i = lane; i < tn << lgt; i += 64) { /* vertical pass */
-                    const int y = i >> lgt, x = i & (tn - 1);
-                    int sum = 0;
+                /* vertical pass: a lane owns a column and a run of rpl rows (rpl + taps - 1 reads) */
+                const int rpl = tn >= 8 ? (tn * tn) >> 6 : 1, run = rpl < 1 ? 1 : rpl; /* 32: 16, 16: 4, 8: 1, 4: 1 */
+                {
+                    const int x = lane & (tn - 1), y0 = (lane >> lgt) * run;
+                    if (y0 < tn) {
+                        int in[23];
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        if (k < ntaps)
-                            sum += tv[k] * (int)M.tmp[(y + k) * 32 + x];
-                    T *dst = L.at(p, lx + tx0 + x, ly + ty0 + y);
-                    if (!bi) {
-                        *dst = (T)min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
-                    } else if (!second) {
-                        M.raw[i] = (int16_t)(sum >> 6);
-                    } else { /* BiPredClipping / BiPredClipping16bit (Offset5 / ChromaOffset5, Codec/EbDefinitions.h:1022-1030) */
-                        const int a = (int)M.raw[i] + (int)(int16_t)(sum >> 6);
-                        *dst = (T)(sizeof(T) == 1 ? min(255, max(0, (a + (chroma ? 64 : 16448)) >> 7)) : min(1023, max(0, (a + 16400) >> 5)));
+                        for (int k = 0; k < 23; k++)
+                            in[k] = k < run + ntaps - 1 ? (int)M.tmp[(y0 + k) * 32 + x] : 0;
+#pragma unroll
+                        for (int o = 0; o < 16; o++)
+                            if (o < run) {
+                                int sum = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; k++)
+                                    if (k < ntaps)
+                                        sum += tv[k] * in[o + k];
+                                const int y = y0 + o, i = (y << lgt) + x;
+                                T *dst = L.at(p, lx + tx0 + x, ly + ty0 + y);
+                                if (!bi) {
+                                    *dst = (T)min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
+                                } else if (!second) {
+                                    M.raw[i] = (int16_t)(sum >> 6);
+                                } else { /* BiPredClipping / BiPredClipping16bit (Offset5 / ChromaOffset5, Codec/EbDefinitions.h:1022-1030) */
+                                    const int a = (int)M.raw[i] + (int)(int16_t)(sum >> 6);
+                                    *dst = (T)(sizeof(T) == 1 ? min(255, max(0, (a + (chroma ? 64 : 16448)) >> 7)) : min(1023, max(0, (a + 16400) >> 5)));
+                                }
+                            }
                     }
                 }
                 EP_WAVE_SYNC();

@@ -18,7 +18,7 @@ import svtlib as S  # noqa: E402
 from test_gpu_encodepass import random_tree, z_available  # noqa: E402
 
 
-def works_of(w, h, qp, seed, only=None):
+def works_of(w, h, qp, seed, only=None, inter=0.0):
     rng = np.random.default_rng(seed)
     wl, hl = (w + 63) // 64, (h + 63) // 64
     works = np.zeros(wl * hl, S.LCU_WORK_DTYPE)
@@ -42,6 +42,12 @@ def works_of(w, h, qp, seed, only=None):
                 cu["x"], cu["y"], cu["size"], cu["pred_mode"], cu["intra_luma_mode"] = x, y, s, 2, rng.integers(0, 35)
                 cu["bottom_left_ok"], cu["top_right_ok"] = z_available(x, y, s)
                 cu["qp"], cu["chroma_qp"] = qp, min(qp, 29 + (qp - 29) // 2) if qp > 29 else qp
+                if rng.random() < inter:   # an inter unit: B-picture mix of directions and kinds, motion within +-24 samples (quarter units)
+                    cu["pred_mode"], cu["intra_luma_mode"] = 1, 0
+                    cu["inter_dir"], cu["inter_kind"] = rng.choice([0, 1, 2], p=[0.4, 0.2, 0.4]), rng.choice([0, 1, 2], p=[0.15, 0.55, 0.3])
+                    cu["mv"] = rng.integers(-96, 97, (2, 2))
+            if inter:
+                wk["slice_type"], wk["full_lambda"], wk["luma_cbf_bits"] = 0, 60000000, (20000, 28000, 50000, 38000)
             wk["src_y"] = np.roll(src[0], (lx, ly), (0, 1)).reshape(-1)
             wk["src_cb"], wk["src_cr"] = src[1, :32, :32].reshape(-1), src[2, :32, :32].reshape(-1)
     return works
@@ -60,8 +66,16 @@ def main():
     nl = S.lcu_count(W, H)
     rows = []
     lib.svt_amd_debug_encdec_profile.argtypes = [vp, vp, vp]
-    for label, only in (("random trees 8..32", None), ("all 32x32", 32), ("all 8x8", 8)):
-        works = works_of(W, H, 32, 9, only)
+    # a B picture's inputs: two reference pictures resident in HBM (padded planes) and the coefficient-rate tables
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [vp, vp, vp, vp, vp]
+    pad = 72
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    ref_planes = [[torch.randint(0, 256, ((H + 2 * pad) >> sh, (W + 2 * pad) >> sh), dtype=torch.uint8, device="cuda", generator=gen) for sh in (0, 1, 1)]
+                  for _ in range(2)]
+    refs = [S.RefPicture(pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), W + 2 * pad, (W + 2 * pad) >> 1, pad, pad, W, H) for pl in ref_planes]
+    cost = np.random.default_rng(3).integers(0, 200, 1560, dtype=np.uint8)
+    for label, only, inter in (("random trees 8..32", None, 0.0), ("all 32x32", 32, 0.0), ("all 8x8", 8, 0.0), ("B picture: random trees, 85 % inter units", None, 0.85)):
+        works = works_of(W, H, 32, 9, only, inter)
         units = int(works["num_cus"].sum())
         for P in (1, 4, 16):
             lanes, pics, dws, drs = [], [], [], []
@@ -69,6 +83,8 @@ def main():
                 lane, pic = vp(), vp()
                 assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
                 assert lib.svt_amd_encdec_picture_create(lane, W, H, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+                if inter:
+                    assert lib.svt_amd_encdec_picture_set_inter(lane, pic, C.byref(refs[0]), C.byref(refs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
                 dws.append(torch.from_numpy(works.view(np.uint8).reshape(-1)).cuda())
                 drs.append(torch.empty(nl * S.LCU_RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda"))
                 lanes.append(lane), pics.append(pic)
