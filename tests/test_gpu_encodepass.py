@@ -190,6 +190,99 @@ def random_picture(oracle, w, h, qp, seed, tile_cols=1, tile_rows=1, constrained
     return works, want
 
 
+def random_inter_picture(oracle, w, h, qp, seed, pad=80):    # pad > 75: a window at a clamped position stays inside the plane
+    """a seeded B picture: random unit trees with ~80 % inter units (L0 / L1 / bi, AMVP / merge / skip, whole-LCU 64x64 units, motion vectors
+    that reach far outside the picture now and then), two reference pictures, rate tables and per-LCU lambdas spread over three decades -
+    and what the CPU oracle makes of it in raster order.  Returns works, want, (reference planes, geometry), cost."""
+    from test_oracle_encodepass_golden import inter_oracle_fn
+    fn = inter_oracle_fn(oracle, False)
+    rng = np.random.default_rng(seed)
+    works, _ = random_picture(oracle, w, h, qp, seed)           # trees, intra modes, QPs, source
+    yy, xx = np.mgrid[0:h + 2 * pad, 0:w + 2 * pad]
+    refs = []
+    for r in range(2):
+        y = np.clip(128 + 60 * np.sin((xx - pad + 3 * r) / 23.0) * np.cos((yy - pad - 2 * r) / 17.0) + rng.normal(0, 6, yy.shape), 0, 255).astype(np.uint8)
+        c = [np.clip(128 + 30 * np.sin((xx[::2, ::2] - pad) / (31.0 + 9 * k)) + rng.normal(0, 3, (yy.shape[0] // 2, yy.shape[1] // 2)), 0, 255).astype(np.uint8)
+             for k in range(2)]
+        refs.append([np.ascontiguousarray(a) for a in (y, c[0], c[1])])
+    geom = (w + 2 * pad, (w + 2 * pad) // 2, pad, pad, w, h)
+    cost = np.zeros(1, np.dtype([("last", "<u4", 176), ("sig", "u1", 84), ("g1", "u1", 48), ("g2", "u1", 12), ("sigml", "u1", 8), ("g1x", "<u2", 96),
+                                 ("sigv", "u1", (32, 16))]))
+    assert cost.itemsize == 1560
+    cost["last"] = rng.integers(20, 400, 176)
+    for k in ("sig", "g1", "g2", "sigml", "sigv"):
+        cost[k] = rng.integers(5, 120, cost[k].shape)
+    cost["g1x"] = rng.integers(20, 900, 96)
+    for wk in works:
+        wk["slice_type"], wk["temporal_layer"] = 0, 1
+        wk["full_lambda"] = int(10 ** rng.uniform(5.5, 8.4))
+        wk["luma_cbf_bits"] = rng.integers(8000, 60000, 4)
+        lw, lh = min(64, w - int(wk["lcu_x"])), min(64, h - int(wk["lcu_y"]))
+        if lw == 64 and lh == 64 and rng.random() < 0.15:        # one 64x64 unit
+            wk["num_cus"] = 1
+            cu = wk["cu"][0]
+            cu["x"], cu["y"], cu["size"], cu["bottom_left_ok"], cu["top_right_ok"] = 0, 0, 64, 0, 1
+        for i in range(int(wk["num_cus"])):
+            cu = wk["cu"][i]
+            if int(cu["size"]) == 64 or rng.random() < 0.8:
+                cu["pred_mode"], cu["intra_luma_mode"], cu["dz_offset"] = 1, 0, 0
+                cu["inter_dir"], cu["inter_kind"] = rng.choice([0, 1, 2], p=[0.35, 0.25, 0.4]), rng.choice([0, 1, 2], p=[0.4, 0.4, 0.2])
+                far = rng.random() < 0.06
+                cu["mv"] = rng.integers(-4 * max(w, h), 4 * max(w, h), (2, 2)) if far else rng.integers(-70, 71, (2, 2))
+    rs = [S.RefPicture(r[0].ctypes.data, r[1].ctypes.data, r[2].ctypes.data, *geom) for r in refs]
+    pitches = (w + 32, w // 2 + 16, w // 2 + 16)
+    pb = (C.c_uint32 * 3)(*pitches)
+    rec = [np.full((hh, p), 0xA5, np.uint8) for hh, p in zip((h, h // 2, h // 2), pitches)]
+    mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+    rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+    want = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+    for k in range(len(works)):
+        fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, C.byref(rs[0]), C.byref(rs[1]), cost.ctypes.data, works[k:k + 1].ctypes.data, want[k:k + 1].ctypes.data)
+    return works, want, (refs, geom), cost
+
+
+def set_inter_random(lib, ctx, pic, refs_geom, cost):
+    """the reference pictures of random_inter_picture into HBM + svt_amd_encdec_picture_set_inter; returns what must stay alive"""
+    import torch
+    refs, geom = refs_geom
+    keep = [[torch.from_numpy(a).cuda() for a in r] for r in refs]
+    torch.cuda.synchronize()
+    rs = [S.RefPicture(k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(), *geom) for k in keep]
+    lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, C.byref(rs[0]), C.byref(rs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
+    return keep
+
+
+@pytest.mark.parametrize("w,h,qp,seed", [(832, 480, 30, 11), (1920, 1080, 34, 12)])
+def test_encode_picture_random_b_pictures_match_oracle(product, oracle, w, h, qp, seed):
+    """full-size B pictures of random inter / intra units against the oracle in raster order: every fractional position of both filters,
+    clamped positions far outside the picture, bi-prediction, 64x64 units, the luma cbf decision over three decades of lambda"""
+    lib = product
+    sig_picture(lib)
+    ctx = C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 1, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    works, want, refs_geom, cost = random_inter_picture(oracle, w, h, qp, seed)
+    cus = np.concatenate([wk["cu"][:int(wk["num_cus"])] for wk in works])
+    amvp = (cus["pred_mode"] == 1) & (cus["inter_kind"] == 0) & (cus["size"] < 64)
+    res = np.concatenate([r["cu"][:int(wk["num_cus"])] for wk, r in zip(works, want)])
+    dropped = int(((res["nz"][:, 0] != 0) & (res["cbf"][:, 0] == 0) & amvp).sum())
+    kept = int(((res["nz"][:, 0] != 0) & (res["cbf"][:, 0] == 1) & amvp).sum())
+    assert dropped > 20 and kept > 20, (dropped, kept)          # the decision goes both ways
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        keep = set_inter_random(lib, ctx, pic, refs_geom, cost)
+        got = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+        assert lib.svt_amd_encode_picture(ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+        for k in range(len(works)):
+            compare_lcu(works[k], want[k], got[k], w, h, ("B picture", w, h, k))
+        del keep
+    finally:
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+        lib.svt_amd_context_destroy(ctx)
+
+
 @pytest.mark.parametrize("w,h,qp,seed", [(832, 480, 27, 1), (456, 264, 38, 2)])
 def test_encode_lcus_random_trees_match_oracle(product, oracle, gpu_ctx, w, h, qp, seed):
     lib = product
