@@ -296,7 +296,8 @@ static void border_from_neighbour_arrays(void *out, int wide, const PictureContr
 
 /* Verification mode: the outcome of the reference's own EncodePass of the LCU (flags, coefficients and - with the loop filters off - the
  * reconstruction) against what the device returned for it */
-static void verify_lcu(const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr, EB_U32 x0, EB_U32 y0)
+static void verify_lcu(const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr, EB_U32 x0, EB_U32 y0,
+                       int limit_intra)
 {
     const SvtAmdLcuWork *w = &t_serve->work;
     const int wide = t_serve->wide;
@@ -307,7 +308,12 @@ static void verify_lcu(const SequenceControlSet_t *scs, const PictureControlSet_
                                            ? (wide ? ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture16bit
                                                    : ((EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr)->referencePicture)
                                            : (wide ? pcs->reconPicture16bitPtr : pcs->reconPicturePtr);
-    const int rec_ok = scs->staticConfig.disableDlfFlag && !scs->staticConfig.enableSaoFlag;
+    /* the reconstruction is comparable with the loop filters off, where the reference produced one (doRecon, EbCodingLoop.c:3083-3087) */
+    int any_intra = 0;
+    for (int i = 0; i < w->num_cus; i++)
+        any_intra |= w->cu[i].pred_mode == INTRA_MODE;
+    const int rec_ok = scs->staticConfig.disableDlfFlag && !scs->staticConfig.enableSaoFlag &&
+                       (!limit_intra || any_intra || pcs->ParentPcsPtr->isUsedAsReferenceFlag || scs->staticConfig.reconEnabled);
     const size_t bps = wide ? 2 : 1;
     const uint8_t *dr[3] = {(const uint8_t *)t_serve->res.rec_y, wide ? (const uint8_t *)t_serve->res16.rec_cb : t_serve->res.rec_cb,
                             wide ? (const uint8_t *)t_serve->res16.rec_cr : t_serve->res.rec_cr};
@@ -431,7 +437,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     t_serve->lcu = lcuPtr;
     if (g_ep_verify) { /* the reference encodes the LCU itself; the device's outcome is only compared */
         __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
-        verify_lcu(scs, pcs, lcuPtr, lcuOriginX, lcuOriginY);
+        verify_lcu(scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr->mdContext->limitIntra);
         return;
     }
     svt_hook_ep_active = 1;

@@ -387,3 +387,37 @@ def test_bitstream_and_recon_identical_with_device_resident_encode_pass(tmp_path
         assert gpu == 0 and tools == nl, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
     assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
+
+
+VERIFY_CASES = [
+    ("motion", 1920, 1080, 13, ["-encMode", "7"]),
+    ("noise", 832, 480, 9, ["-encMode", "5", "-pred-struct", "1", "-q", "38"]),
+    ("motion10", 1280, 720, 9, ["-encMode", "8", "-bit-depth", "10"]),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", VERIFY_CASES)
+def test_encode_pass_verification_mode_finds_no_difference(tmp_path, kind, w, h, n, args):
+    """SVT_HOOK_ENCODEPASS_VERIFY=1: every LCU is encoded on the device AND by the reference's own EncodePass inside the running encoder;
+    flags, coefficients and (loop filters off) the un-deblocked reconstruction of every unit are compared there
+    (integration/svt_hook_encdec.c:verify_lcu) - thousands of LCUs of real P / B pictures per case"""
+    import re
+    yuv = str(tmp_path / "clip.yuv")
+    if kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
+    os.environ["SVT_HOOK_ENCODEPASS"] = "1"
+    os.environ["SVT_HOOK_ENCODEPASS_VERIFY"] = "1"
+    os.environ["SVT_HOOK_REPORT"] = str(tmp_path / "report.txt")
+    try:
+        _, log = _encode(HIP_APP, yuv, w, h, n, args + ["-dlf", "1", "-sao", "0"], str(tmp_path / "hip.265"))
+    finally:
+        for k in ("SVT_HOOK_ENCODEPASS", "SVT_HOOK_ENCODEPASS_VERIFY", "SVT_HOOK_REPORT"):
+            del os.environ[k]
+    rep = open(str(tmp_path / "report.txt")).read()
+    m = re.search(r"encode pass verification: (\d+) device-encoded LCUs compared with the reference's own EncodePass, (\d+) differ", rep)
+    assert m, rep
+    compared, differ = int(m.group(1)), int(m.group(2))
+    assert compared == S.lcu_count(w, h) * n and differ == 0, rep + "\n".join(ln for ln in log.splitlines() if "VERIFY" in ln)[:3000]
+    assert re.search(r"one call each; (\d+) of them with inter units", rep) and int(re.search(r"one call each; (\d+) of them", rep).group(1)) > compared // 4, rep

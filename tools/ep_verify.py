@@ -33,6 +33,8 @@ def main():
         lines = [ln for ln in r.stderr.splitlines() if "VERIFY" in ln]
         print("\n".join(lines[:40]))
         print("exit code", r.returncode, "; mismatch lines", len(lines))
+        if r.returncode:
+            print(r.stdout[-1500:], r.stderr[-1500:])
         if os.path.exists(rep):
             print("\n".join(ln for ln in open(rep).read().splitlines() if "encode pass" in ln))
         return 1 if (r.returncode or lines) else 0
