@@ -335,6 +335,8 @@ ENCODEPASS_CASES = [
     ("noise", 200, 136, 5, ["-encMode", "5", "-pred-struct", "1", "-hierarchical-levels", "0", "-q", "46"], "inter"),
     # 2 x 2 tiles: tile edges cut the intra neighbourhood, four wavefronts share the picture
     ("motion", 832, 480, 3, ["-encMode", "7", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
+    # 2 x 2 tiles with P / B pictures: four wavefronts, inter units next to tile edges
+    ("motion", 832, 480, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "inter"),
     # encMode 4: the encode pass quantises with PM-core, outside the device call - every LCU must be left to the reference code
     ("motion", 416, 240, 2, ["-encMode", "4", "-intra-period", "0"], "none"),
     # 10-bit encodes: EncodePass with is16bit through the 16-bit contract (all-intra, and random access with host-encoded LCUs)
