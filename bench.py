@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="buffer sets in flight per GPU (each holds one batch); 2 <= n <= 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoder-fps", action="store_true")
+    ap.add_argument("--no-encode-pass", action="store_true")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--inner", action="store_true", help="(internal) counter pass: GPU loop only, prints the batch count")
     a = ap.parse_args()
@@ -436,7 +437,7 @@ def main():
             res["recon_exchange"] = xchg
         if world == 1 and not a.no_pmc:
             tr, err = pmc_traffic(["--inner", "--steps", "2", "--warmup", "1", "--config", str(a.config), "--batch", str(B),
-                                   "--no-cpu-baseline", "--no-encoder-fps", "--no-pmc"])
+                                   "--no-cpu-baseline", "--no-encoder-fps", "--no-pmc", "--no-encode-pass"])
             if tr:
                 res["roofline"]["traffic"] = tr["fetch_bytes_corrected"] + tr["write_bytes_raw"]
                 res["roofline"]["traffic_detail"] = tr
@@ -447,6 +448,13 @@ def main():
                 res["cpu_baseline"] = cpu_baseline_reference(cfg)
             except Exception as e:  # the reference build is absent: say so, do not substitute
                 res["cpu_baseline"] = {"error": str(e)[-300:]}
+        if world == 1 and not a.no_encode_pass:
+            # the device-resident encode pass, measured beside the front half: it is not part of `value`
+            try:
+                import encodepass_bench as EPB
+                res["encode_pass"] = EPB.measure_b_picture(S.load_product(), root)
+            except Exception as e:
+                res["encode_pass"] = {"error": str(e)[-300:]}
         if world == 1 and not a.no_encoder_fps:
             try:
                 import encoder_fps as E

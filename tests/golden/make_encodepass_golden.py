@@ -48,6 +48,9 @@ CASES = {
     "p_noise_200x136_m6": ("noise", 200, 136, 3, 11, ["-encMode", "6", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "34"]),
     # constrained intra prediction, encMode 8: 32x32 and 64x64 AMVP units with ~200 coefficients that the luma cbf decision zeroes
     "p_noise_320x256_m8_ci": ("noise", 320, 256, 4, 7, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40"]),
+    # 10-bit random access: 16-bit bi-prediction (BiPredClipping16bit), non-reference B pictures
+    "b10_motion_320x192_m6": ("motion10", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "30",
+                                                          "-bit-depth", "10"]),
     "p10_motion_320x192_m7": ("motion10", 320, 192, 3, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "32", "-bit-depth", "10"]),
 }
 

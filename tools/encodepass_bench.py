@@ -53,61 +53,97 @@ def works_of(w, h, qp, seed, only=None, inter=0.0):
     return works
 
 
-def main():
-    W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
-    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-    lib = S.load_product()
+def setup(lib):
     vp = C.c_void_p
     lib.svt_amd_encdec_picture_create.argtypes = [vp, C.c_uint16, C.c_uint16, C.c_int, C.POINTER(vp)]
     lib.svt_amd_encode_picture_device.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.svt_amd_context_fork.argtypes = [vp, C.POINTER(vp)]
-    root = vp()
+    lib.svt_amd_debug_encdec_profile.argtypes = [vp, vp, vp]
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [vp, vp, vp, vp, vp]
+
+
+def b_picture_inputs(W, H, pad=80):
+    """a B picture's picture-level inputs: two reference pictures resident in HBM (padded planes) and coefficient-rate tables"""
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    planes = [[torch.randint(0, 256, ((H + 2 * pad) >> sh, (W + 2 * pad) >> sh), dtype=torch.uint8, device="cuda", generator=gen) for sh in (0, 1, 1)]
+              for _ in range(2)]
+    refs = [S.RefPicture(pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), W + 2 * pad, (W + 2 * pad) >> 1, pad, pad, W, H) for pl in planes]
+    cost = np.random.default_rng(3).integers(0, 200, 1560, dtype=np.uint8)
+    return planes, refs, cost
+
+
+def run_content(lib, root, W, H, works, flights, iters, inter_inputs=None, profile=False):
+    """`flights` pictures in flight on as many lanes, `iters` rounds: seconds per round (+ the per-LCU clock sums of one picture)"""
+    vp = C.c_void_p
+    nl = S.lcu_count(W, H)
+    lanes, pics, dws, drs = [], [], [], []
+    for i in range(flights):
+        lane, pic = vp(), vp()
+        assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_encdec_picture_create(lane, W, H, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        if inter_inputs:
+            _, refs, cost = inter_inputs
+            assert lib.svt_amd_encdec_picture_set_inter(lane, pic, C.byref(refs[0]), C.byref(refs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
+        dws.append(torch.from_numpy(works.view(np.uint8).reshape(-1)).cuda())
+        drs.append(torch.empty(nl * S.LCU_RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda"))
+        lanes.append(lane), pics.append(pic)
+    torch.cuda.synchronize()
+
+    def go():
+        for i in range(flights):
+            assert lib.svt_amd_encode_picture_device(lanes[i], pics[i], dws[i].data_ptr(), drs[i].data_ptr(), 1) == 0, lib.svt_amd_last_error()
+    go()
+    for lane in lanes:
+        lib.svt_amd_synchronize(lane)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        go()
+    for lane in lanes:
+        lib.svt_amd_synchronize(lane)
+    dt = (time.perf_counter() - t0) / iters
+    prof = None
+    if profile:   # where an LCU's time goes (shader clocks of thread 0)
+        assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], None) == 0
+        go()
+        prof = np.zeros((nl, 16), np.uint64)
+        assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], prof.ctypes.data) == 0
+    for lane, pic in zip(lanes, pics):
+        lib.svt_amd_encdec_picture_destroy(lane, pic)
+        lib.svt_amd_context_destroy(lane)
+    return dt, prof
+
+
+def measure_b_picture(lib, root, W=3840, H=2160, iters=5):
+    """bench.py's `encode_pass` leg: a 4K B picture of random unit trees, 85 % inter units, alone and 16 in flight"""
+    setup(lib)
+    works = works_of(W, H, 32, 9, None, 0.85)
+    inputs = b_picture_inputs(W, H)
+    nl, units = S.lcu_count(W, H), int(works["num_cus"].sum())
+    alone, _ = run_content(lib, root, W, H, works, 1, iters, inputs)
+    many, _ = run_content(lib, root, W, H, works, 16, iters, inputs)
+    return {"content": "%dx%d B picture, random unit trees 8..32, 85 %% inter units (40 %% bi-predicted, random motion within +-24 samples), two "
+                       "reference pictures and the work / result arrays resident in HBM: svt_amd_encode_picture_device, ONE launch per picture" % (W, H),
+            "lcus": nl, "units": units, "ms_per_picture_alone": round(alone * 1e3, 2), "pictures_per_s_16_in_flight": round(16 / many, 1),
+            "lcus_per_s_16_in_flight": round(16 * nl / many)}
+
+
+def main():
+    W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    lib = S.load_product()
+    setup(lib)
+    root = C.c_void_p()
     assert lib.svt_amd_context_create(0, W, (H + 7) & ~7, 1, C.byref(root)) == 0, lib.svt_amd_last_error()
     nl = S.lcu_count(W, H)
     rows = []
-    lib.svt_amd_debug_encdec_profile.argtypes = [vp, vp, vp]
-    # a B picture's inputs: two reference pictures resident in HBM (padded planes) and the coefficient-rate tables
-    lib.svt_amd_encdec_picture_set_inter.argtypes = [vp, vp, vp, vp, vp]
-    pad = 72
-    gen = torch.Generator(device="cuda").manual_seed(5)
-    ref_planes = [[torch.randint(0, 256, ((H + 2 * pad) >> sh, (W + 2 * pad) >> sh), dtype=torch.uint8, device="cuda", generator=gen) for sh in (0, 1, 1)]
-                  for _ in range(2)]
-    refs = [S.RefPicture(pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), W + 2 * pad, (W + 2 * pad) >> 1, pad, pad, W, H) for pl in ref_planes]
-    cost = np.random.default_rng(3).integers(0, 200, 1560, dtype=np.uint8)
+    inputs = b_picture_inputs(W, H)
     for label, only, inter in (("random trees 8..32", None, 0.0), ("all 32x32", 32, 0.0), ("all 8x8", 8, 0.0), ("B picture: random trees, 85 % inter units", None, 0.85)):
         works = works_of(W, H, 32, 9, only, inter)
         units = int(works["num_cus"].sum())
         for P in (1, 4, 16):
-            lanes, pics, dws, drs = [], [], [], []
-            for i in range(P):
-                lane, pic = vp(), vp()
-                assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
-                assert lib.svt_amd_encdec_picture_create(lane, W, H, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
-                if inter:
-                    assert lib.svt_amd_encdec_picture_set_inter(lane, pic, C.byref(refs[0]), C.byref(refs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
-                dws.append(torch.from_numpy(works.view(np.uint8).reshape(-1)).cuda())
-                drs.append(torch.empty(nl * S.LCU_RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda"))
-                lanes.append(lane), pics.append(pic)
-            torch.cuda.synchronize()
-
-            def go():
-                for i in range(P):
-                    assert lib.svt_amd_encode_picture_device(lanes[i], pics[i], dws[i].data_ptr(), drs[i].data_ptr(), 1) == 0, lib.svt_amd_last_error()
-            go()
-            for lane in lanes:
-                lib.svt_amd_synchronize(lane)
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                go()
-            for lane in lanes:
-                lib.svt_amd_synchronize(lane)
-            dt = (time.perf_counter() - t0) / iters
+            dt, prof = run_content(lib, root, W, H, works, P, iters, inputs if inter else None, profile=P == 1)
             alg = nl * (6144 + 12288 + 6144 + 6144)   # source read, coefficients + LCU reconstruction + picture written
-            if P == 1:   # where an LCU's time goes (shader clocks of thread 0)
-                assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], None) == 0
-                go()
-                prof = np.zeros((nl, 16), np.uint64)
-                assert lib.svt_amd_debug_encdec_profile(lanes[0], pics[0], prof.ctypes.data) == 0
+            if prof is not None:
                 span = int(prof[:, 6].max() - prof[:, 5].min())
                 print("   clocks per LCU (mean): predict %d encode %d copy-out %d wait %d; per unit predict %d encode %d; kernel span %d clocks" %
                       (prof[:, 0].mean(), prof[:, 1].mean(), prof[:, 2].mean(), prof[:, 4].mean(), prof[:, 0].sum() / prof[:, 3].sum(),
@@ -117,9 +153,6 @@ def main():
             rows.append({"content": label, "pictures_in_flight": P, "lcus": nl, "units": units, "ms_per_round": round(dt * 1e3, 3),
                          "pictures_per_s": round(P / dt, 1), "lcus_per_s": round(P * nl / dt), "algorithmic_GBps": round(P * alg / dt / 1e9, 2)})
             print(rows[-1], flush=True)
-            for lane, pic in zip(lanes, pics):
-                lib.svt_amd_encdec_picture_destroy(lane, pic)
-                lib.svt_amd_context_destroy(lane)
     print(json.dumps({"width": W, "height": H, "iters": iters, "rows": rows}))
 
 
