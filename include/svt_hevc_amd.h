@@ -1067,12 +1067,13 @@ SVT_AMD_API int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture
 SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
                                               SvtAmdLcuResult *d_results, int tiles);
 
-/* Deblocking behind the encode pass: when every LCU of the picture is encoded, the device picture goes IN PLACE through the
+/* Deblocking behind the encode pass: when every LCU of the picture is encoded, a copy of the device picture (a second set of planes of
+ * the picture object; the un-deblocked planes stay as they are) goes through the
  * picture-level boundary-strength and deblocking kernels (svt_amd_bs_picture + svt_amd_dlf_picture: the state the reference's
  * per-LCU drivers LCUInternalAreaDLFCore / LCUBoundaryDLFCore / LCUPictureEdgeDLFCore leave, Codec/EbCodingLoop.c:4600-4631) -
  * the finished reconstruction / reference picture when SAO is off.  works / results: the HOST records of all LCUs in raster
  * order (unit lists, QPs, tile edges; luma cbf of every unit).  out_*: optional HOST planes (tight pitch) that receive the
- * deblocked picture.  Blocking.  Afterwards the device picture is no longer an encode-pass neighbour source (begin a new one). */
+ * deblocked picture.  Blocking. */
 typedef struct SvtAmdDeblockParams {
     int8_t tc_offset, beta_offset, cb_qp_offset, cr_qp_offset;   /* pictureControlSetPtr->tcOffset / betaOffset / cbQpOffset / crQpOffset */
     uint8_t slice_type;                                           /* EB_PICTURE: 0 B, 1 P, 2 I, 3 IDR */
@@ -1085,6 +1086,20 @@ SVT_AMD_API int svt_amd_encdec_picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecP
 SVT_AMD_API int svt_amd_encdec_picture_deblock16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works,
                                                  const SvtAmdLcuResult16 *results, const SvtAmdDeblockParams *params, uint16_t *out_y,
                                                  uint16_t *out_cb, uint16_t *out_cr);
+/* SAO behind the deblocked device picture (after svt_amd_encdec_picture_deblock[16]): statistics of every LCU as the reference's
+ * SaoGenerationDecision(16bit) gathers them inside EncodePass (Codec/EbCodingLoop.c:4640-4750, on the picture as it stands when the LCU is
+ * done: deblocked, except the last 4 columns / rows of the LCU where a neighbour follows - taken from the un-deblocked picture the object
+ * keeps), the parameter decision of the whole picture (svt_amd_sao_decide_picture) and ApplySaoOffsetsPicture (svt_amd_sao_apply_picture)
+ * on the deblocked picture.  What is left in the picture object - and copied to out_* (HOST, tightly packed, NULL = not wanted) - is the
+ * encoder's finished reconstruction: a reference picture is completed without leaving HBM.  params: the picture's rate inputs; enable:
+ * HOST, one byte per LCU (NULL = all 1), 0 where the encode pass shuts SAO off (:4678-4707); lcu_params (HOST, optional): the decided
+ * parameters of every LCU (what entropy coding needs).  Blocking. */
+SVT_AMD_API int svt_amd_encdec_picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works,
+                                           const SvtAmdSaoDecisionParams *params, const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params,
+                                           uint8_t *out_y, uint8_t *out_cb, uint8_t *out_cr);
+SVT_AMD_API int svt_amd_encdec_picture_sao16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works,
+                                             const SvtAmdSaoDecisionParams *params, const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params,
+                                             uint16_t *out_y, uint16_t *out_cb, uint16_t *out_cr);
 
 /* debug: out == NULL arms per-LCU shader-clock sums in the encode-pass kernels (16 x u64 per LCU: prediction, encode, copy-out, units,
  * wait for neighbours, start, end, -, the prediction's four sub-phases, 4 unused), a later call with a HOST buffer of 16 * LCUs u64

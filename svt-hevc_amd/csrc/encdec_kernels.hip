@@ -61,6 +61,10 @@ struct SvtAmdEncDecPicture {
     int nlcu;
     SvtAmdCabacCost *d_cost;
     bool has_ref[2];
+    /* the in-loop filters behind the encode pass: the deblocked picture and the picture after SAO live beside the un-deblocked one (the SAO
+     * statistics need both, svt_amd_encdec_picture_sao); same pitches as rec[] */
+    uint8_t *dbk[3], *fin[3];
+    bool deblocked;
 };
 
 typedef SvtAmdLcuCu LcuCu;
@@ -746,6 +750,7 @@ extern "C" int svt_amd_encdec_picture_begin(SvtAmdContext *ctx, SvtAmdEncDecPict
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, ctx->stream)); /* nothing coded yet */
     HIP_TRY(hipStreamSynchronize(ctx->stream));                                   /* other lanes may encode the first LCU */
+    pic->deblocked = false;
     return SVT_AMD_OK;
 }
 
@@ -766,6 +771,12 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
         (void)hipFree(pic->d.prof);
     if (pic->d_cost)
         (void)hipFree(pic->d_cost);
+    for (int k = 0; k < 3; k++) {
+        if (pic->dbk[k])
+            (void)hipFree(pic->dbk[k]);
+        if (pic->fin[k])
+            (void)hipFree(pic->fin[k]);
+    }
     free(pic);
     return SVT_AMD_OK;
 }
@@ -903,6 +914,7 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
         d_works = (const WorkT *)d, d_results = (ResultT *)(d + wba);
     }
     pic->epoch++;
+    pic->deblocked = false;
     HIP_TRY(hipMemsetAsync(pic->d_sync, 0, sizeof(unsigned), ctx->stream));              /* ticket counter */
     HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, ctx->stream));          /* nothing coded yet */
     /* persistent grid = the widest wavefront (an LCU row advances two LCUs behind the row above) of every tile that can run on its
@@ -1012,18 +1024,163 @@ static int picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const t
         return rc;
     if (pic->d.pitch[1] != pic->d.pitch[2])
         return SVT_AMD_ERR_BAD_PARAM;
-    if ((rc = svt_amd_dlf_picture(ctx, (int)sizeof(T), pic->d.rec[0], pic->d.pitch[0], pic->d.rec[1], pic->d.rec[2], pic->d.pitch[1], w, h, d_bsv, d_bsh,
+    /* the deblocked picture is a second set of planes: the un-deblocked one stays (the neighbours of LCUs still to come, and the part of
+     * the SAO statistics that the reference gathers before an LCU's right / bottom edges are filtered) */
+    for (int k = 0; k < 3; k++) {
+        if (!pic->dbk[k] && hipMalloc((void **)&pic->dbk[k], pic->plane_bytes[k]) != hipSuccess) {
+            svt_amd_set_error("hipMalloc (deblocked picture) failed");
+            return SVT_AMD_ERR_RESOURCES;
+        }
+        HIP_TRY(hipMemcpyAsync(pic->dbk[k], pic->d.rec[k], pic->plane_bytes[k], hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if ((rc = svt_amd_dlf_picture(ctx, (int)sizeof(T), pic->dbk[0], pic->d.pitch[0], pic->dbk[1], pic->dbk[2], pic->d.pitch[1], w, h, d_bsv, d_bsh,
                                   d_qp, w8, prm->tc_offset, prm->beta_offset, prm->cb_qp_offset, prm->cr_qp_offset)) != 0)
         return rc;
+    pic->deblocked = true;
     void *outs[3] = {out_y, out_cb, out_cr};
     for (int k = 0; k < 3; k++)
         if (outs[k]) {
             const uint32_t pw = k ? w / 2 : w, ph = k ? h / 2 : h;
-            HIP_TRY(hipMemcpy2DAsync(outs[k], (size_t)pw * sizeof(T), pic->d.rec[k], (size_t)pic->d.pitch[k] * sizeof(T), (size_t)pw * sizeof(T), ph,
+            HIP_TRY(hipMemcpy2DAsync(outs[k], (size_t)pw * sizeof(T), pic->dbk[k], (size_t)pic->d.pitch[k] * sizeof(T), (size_t)pw * sizeof(T), ph,
                                      hipMemcpyDeviceToHost, ctx->stream));
         }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
+}
+
+/* ---- SAO behind the deblocked device picture ------------------------------------------------------------------------------------ */
+/* the LCUs' source samples as planes (the statistics kernels read planes) */
+template <typename T>
+__global__ __launch_bounds__(256) void k_ep_source_planes(const typename EpTypes<T>::Work *__restrict__ works, T *sy, T *scb, T *scr, int pitchY, int pitchC,
+                                                          int width, int height)
+{
+    const typename EpTypes<T>::Work &W = works[blockIdx.x];
+    const int lw = min(64, width - (int)W.lcu_x), lh = min(64, height - (int)W.lcu_y);
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int y = i >> 6, x = i & 63;
+        if (x < lw && y < lh)
+            sy[(size_t)(W.lcu_y + y) * pitchY + W.lcu_x + x] = W.src_y[i];
+    }
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int y = i >> 5, x = i & 31;
+        if (x < lw / 2 && y < lh / 2) {
+            scb[(size_t)(W.lcu_y / 2 + y) * pitchC + W.lcu_x / 2 + x] = W.src_cb[i];
+            scr[(size_t)(W.lcu_y / 2 + y) * pitchC + W.lcu_x / 2 + x] = W.src_cr[i];
+        }
+    }
+}
+
+/* The picture as the reference's SaoGenerationDecision sees each LCU (EbCodingLoop.c:4600-4750): the LCU's own deblocking drivers have run,
+ * those of the LCUs to its right and below have not.  Those later drivers own the 8x8 filter blocks centred on the LCU boundary
+ * (LCUBoundaryDLFCore, EbDeblockingFilter.c:2828), i.e. every edge segment inside the last 4 columns / rows of the LCU (in the plane's own
+ * samples) and nothing else inside it: the LCU is the deblocked picture with those strips still un-deblocked, where a neighbour follows.
+ * (tests/test_oracle_encodepass_golden.py::test_encoder_order_sao_statistics_from_two_pictures proves it on the encoder's own records.) */
+template <typename T>
+__global__ __launch_bounds__(256) void k_ep_sao_composite(const T *__restrict__ dbk, const T *__restrict__ rec, T *__restrict__ out, int pitch, int w, int h,
+                                                          int lcu)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const bool right = (x & (lcu - 1)) >= lcu - 4 && (x | (lcu - 1)) + 1 < w, bottom = (y & (lcu - 1)) >= lcu - 4 && (y | (lcu - 1)) + 1 < h;
+    const size_t o = (size_t)y * pitch + x;
+    out[o] = (right || bottom) ? rec[o] : dbk[o];
+}
+
+/* Statistics of every LCU in the encoder's order, the parameter decision of the whole picture (merge wavefront) and the application, behind
+ * svt_amd_encdec_picture_deblock: what is left in the picture object (and copied out) is the encoder's finished reconstruction. */
+template <typename T>
+static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, const SvtAmdSaoDecisionParams *prm,
+                       const uint8_t *enable, SvtAmdSaoLcuParams *lcu_out, void *out_y, void *out_cb, void *out_cr)
+{
+    typedef typename EpTypes<T>::Work WorkT;
+    if (!ctx || !pic || !works || !prm || pic->d.bps != sizeof(T))
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (!pic->deblocked) {
+        svt_amd_set_error("svt_amd_encdec_picture_sao: svt_amd_encdec_picture_deblock comes first");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    const uint32_t w = pic->d.width, h = pic->d.height, wl = (w + 63) / 64, hl = (h + 63) / 64, nlcu = (uint32_t)pic->nlcu;
+    std::vector<SvtAmdSaoLcuParams> lp(nlcu);
+    ::memset(lp.data(), 0, nlcu * sizeof(SvtAmdSaoLcuParams));
+    for (uint32_t i = 0; i < nlcu; i++) {
+        if (works[i].lcu_x != (i % wl) * 64 || works[i].lcu_y != (i / wl) * 64)
+            return SVT_AMD_ERR_BAD_PARAM;
+        const bool bottom_edge = i + wl >= nlcu || works[i + wl].tile_top;
+        lp[i].edge_flags = (uint8_t)((works[i].tile_left ? 1 : 0) | (works[i].tile_right ? 2 : 0) | (works[i].tile_top ? 4 : 0) | (bottom_edge ? 8 : 0));
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int k = 0; k < 3; k++)
+        if (!pic->fin[k] && hipMalloc((void **)&pic->fin[k], pic->plane_bytes[k]) != hipSuccess)
+            return SVT_AMD_ERR_RESOURCES;
+    auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t b_works = up(sizeof(WorkT) * nlcu), b_pl[3] = {up(pic->plane_bytes[0]), up(pic->plane_bytes[1]), up(pic->plane_bytes[2])};
+    const size_t b_stats = up(sizeof(SvtAmdSaoStats) * nlcu), b_par = up(sizeof(SvtAmdSaoLcuParams) * nlcu), b_cost = up(16 * (size_t)nlcu), b_en = up(nlcu);
+    uint8_t *d = nullptr;
+    int rc = svt_amd_ctx_scratch(ctx, b_works + 2 * (b_pl[0] + b_pl[1] + b_pl[2]) + 3 * b_stats + b_par + b_cost + b_en, &d);
+    if (rc)
+        return rc;
+    uint8_t *d_works = d, *d_src[3], *d_cmp[3], *q = d + b_works;
+    for (int k = 0; k < 3; k++)
+        d_src[k] = q, q += b_pl[k];
+    for (int k = 0; k < 3; k++)
+        d_cmp[k] = q, q += b_pl[k];
+    SvtAmdSaoStats *d_stats[3];
+    for (int k = 0; k < 3; k++)
+        d_stats[k] = (SvtAmdSaoStats *)q, q += b_stats;
+    SvtAmdSaoLcuParams *d_par = (SvtAmdSaoLcuParams *)q;
+    q += b_par;
+    int64_t *d_cost = (int64_t *)q;
+    q += b_cost;
+    uint8_t *d_en = q;
+    HIP_TRY(hipMemcpyAsync(d_works, works, sizeof(WorkT) * nlcu, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_par, lp.data(), sizeof(SvtAmdSaoLcuParams) * nlcu, hipMemcpyHostToDevice, ctx->stream));
+    if (enable)
+        HIP_TRY(hipMemcpyAsync(d_en, enable, nlcu, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_stats[0], 0, 3 * b_stats, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* lp backs its copy */
+    const int pY = (int)pic->d.pitch[0], pC = (int)pic->d.pitch[1];
+    hipLaunchKernelGGL(k_ep_source_planes<T>, dim3(nlcu), dim3(256), 0, ctx->stream, (const WorkT *)d_works, (T *)d_src[0], (T *)d_src[1], (T *)d_src[2], pY, pC,
+                       (int)w, (int)h);
+    for (int k = 0; k < 3; k++) {
+        const int pw = k ? w / 2 : w, ph = k ? h / 2 : h;
+        hipLaunchKernelGGL(k_ep_sao_composite<T>, dim3((pw + 255) / 256, ph), dim3(256), 0, ctx->stream, (const T *)pic->dbk[k], (const T *)pic->d.rec[k],
+                           (T *)d_cmp[k], k ? pC : pY, pw, ph, k ? 32 : 64);
+    }
+    HIP_TRY(hipGetLastError());
+    /* GatherSaoStatisticsLcu* of the components the mode looks at (EbSampleAdaptiveOffsetGenerationDecision.c:647-760) */
+    const int ncomp = prm->mm_sao ? 3 : (prm->temporal_layer < 2 ? 1 : 0);
+    for (int k = 0; k < ncomp; k++)
+        if ((rc = svt_amd_sao_gather_picture(ctx, (int)sizeof(T), d_src[k], k ? pC : pY, d_cmp[k], k ? pC : pY, k ? w / 2 : w, k ? h / 2 : h, k ? 32 : 64,
+                                             prm->mm_sao ? 0 : 1, d_stats[k])) != 0)
+            return rc;
+    if ((rc = svt_amd_sao_decide_picture(ctx, prm, d_stats[0], d_stats[1], d_stats[2], wl, hl, enable ? d_en : nullptr, d_par, d_cost)) != 0)
+        return rc;
+    const void *srcs[3] = {pic->dbk[0], pic->dbk[1], pic->dbk[2]};
+    void *dsts[3] = {pic->fin[0], pic->fin[1], pic->fin[2]};
+    if ((rc = svt_amd_sao_apply_picture(ctx, (int)sizeof(T), srcs, dsts, pic->d.pitch[0], pic->d.pitch[1], w, h, d_par, 1, 1)) != 0)
+        return rc;
+    if (lcu_out)
+        HIP_TRY(hipMemcpyAsync(lcu_out, d_par, sizeof(SvtAmdSaoLcuParams) * nlcu, hipMemcpyDeviceToHost, ctx->stream));
+    void *outs[3] = {out_y, out_cb, out_cr};
+    for (int k = 0; k < 3; k++)
+        if (outs[k]) {
+            const uint32_t pw = k ? w / 2 : w, ph = k ? h / 2 : h;
+            HIP_TRY(hipMemcpy2DAsync(outs[k], (size_t)pw * sizeof(T), pic->fin[k], (size_t)pic->d.pitch[k] * sizeof(T), (size_t)pw * sizeof(T), ph,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_encdec_picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, const SvtAmdSaoDecisionParams *params,
+                                          const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params, uint8_t *out_y, uint8_t *out_cb, uint8_t *out_cr)
+{
+    return picture_sao<uint8_t>(ctx, pic, works, params, enable, lcu_params, out_y, out_cb, out_cr);
+}
+extern "C" int svt_amd_encdec_picture_sao16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, const SvtAmdSaoDecisionParams *params,
+                                            const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params, uint16_t *out_y, uint16_t *out_cb, uint16_t *out_cr)
+{
+    return picture_sao<uint16_t>(ctx, pic, works, params, enable, lcu_params, out_y, out_cb, out_cr);
 }
 extern "C" int svt_amd_encdec_picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, const SvtAmdLcuResult *results,
                                               const SvtAmdDeblockParams *params, uint8_t *out_y, uint8_t *out_cb, uint8_t *out_cr)

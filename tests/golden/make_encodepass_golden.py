@@ -37,6 +37,13 @@ CASES = {
     # ... of P / B pictures: boundary strengths from motion vectors, reference pictures and transform-unit cbf (64x64 units: four units)
     "dlf_p_motion_416x240_m7": ("motion", 416, 240, 4, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "36"]),
     "dlf_b_motion_320x192_m6": ("motion", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),
+    # deblocking AND SAO on ("sao_" prefix): additionally every SaoGenerationDecision call of the encode (oracle/ref_harness_saodec_dump.c:
+    # the statistics the reference gathered on the picture as it stood when the LCU was done, rate inputs, decided parameters); the
+    # encoder's output is then the finished reconstruction - the fixture of encode pass -> deblocking -> SAO chained on the device
+    "sao_i_motion_416x240_m9": ("motion", 416, 240, 2, 7, ["-encMode", "9", "-intra-period", "0", "-q", "34"]),
+    "sao_i_noise_200x136_m6": ("noise", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "38"]),
+    "sao_b_motion_320x192_m6": ("motion", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),
+    "sao_i10_motion_320x192_m7": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "36", "-bit-depth", "10"]),
     # P / B pictures ("p_" / "b_" / "p10_" prefix: LCUs with inter units are recorded too, with the reference pictures they predict from and
     # the pictures' coefficient-rate tables; loop filters off as above).  Low delay P: uni-prediction, AMVP / merge / skip units, 64x64 units
     "p_motion_416x240_m7": ("motion", 416, 240, 4, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "30"]),
@@ -87,11 +94,19 @@ def run_case(name):
             S.write_clip10(yuv, kind[:-2], w, h, n, seed)
         else:
             S.write_clip(yuv, kind, w, h, n, seed)
-        dlf = name.startswith("dlf_")
-        rec_out = os.path.join(td, "rec.yuv")
-        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-sao", "0",
+        sao = name.startswith("sao_")
+        dlf = name.startswith("dlf_") or sao
+        rec_out, sao_dump = os.path.join(td, "rec.yuv"), os.path.join(td, "saodec.dump")
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-sao", "1" if sao else "0",
                "-b", os.path.join(td, "out.265")] + ([] if dlf else ["-dlf", "1"]) + (["-o", rec_out] if dlf else []) + args
-        subprocess.run(cmd, env=dict(os.environ, SVT_REF_ENCODEPASS_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
+        env = dict(os.environ, SVT_REF_ENCODEPASS_DUMP=dump)
+        if sao:
+            env.update(SVT_REF_SAODEC_DUMP=sao_dump, SVT_REF_SAODEC_STRIDE="1")
+        subprocess.run(cmd, env=env, check=True, stdout=subprocess.DEVNULL)
+        sao_recs = None
+        if sao:
+            from make_saodec_golden import REC as SAO_REC
+            sao_recs = np.fromfile(sao_dump, SAO_REC)
         rdt = S.EP_RECORD16_DTYPE if kind.endswith("10") else S.EP_RECORD_DTYPE
         recs, refs, costs = parse_dump(open(dump, "rb").read(), rdt)
         rec_raw = open(rec_out, "rb").read() if dlf else b""
@@ -107,6 +122,9 @@ def run_case(name):
         extra = {"recon_y": np.stack([raw[i * fs:i * fs + w * h].reshape(h, w) for i in range(n)]),
                  "recon_cb": np.stack([raw[i * fs + w * h:i * fs + w * h * 5 // 4].reshape(h // 2, w // 2) for i in range(n)]),
                  "recon_cr": np.stack([raw[i * fs + w * h * 5 // 4:(i + 1) * fs].reshape(h // 2, w // 2) for i in range(n)])}
+    if sao:   # one decision record per LCU the encode pass ran the decision for (LCUs it shut SAO off for have none)
+        assert (sao_recs["magic"] == 0x44414f53).all()
+        extra["sao"] = sao_recs[np.lexsort((sao_recs["origin_x"], sao_recs["origin_y"], sao_recs["picture_number"]))]
     nl = S.lcu_count(w, h)
     order = np.lexsort((recs["lcu_index"], recs["picture_number"]))
     recs = recs[order]

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import svtlib as S
-from test_oracle_encodepass_golden import CASES, DLF_CASES, INTER_CASES, compare_lcu, is16, load_case
+from test_oracle_encodepass_golden import CASES, DLF_CASES, INTER_CASES, SAO_CASES, compare_lcu, is16, load_case, sao_inputs_of_picture
 
 pytestmark = pytest.mark.gpu
 
@@ -476,5 +476,74 @@ def test_encode_picture_then_deblock_matches_the_encoders_output(product, gpu_ct
             for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
                 bad = np.argwhere(out[p] != g[nm][f])
                 assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+@pytest.mark.parametrize("name", SAO_CASES)
+def test_encode_deblock_sao_on_the_device_matches_the_encoders_output(product, gpu_ctx, name):
+    """three calls per picture - svt_amd_encode_picture, svt_amd_encdec_picture_deblock, svt_amd_encdec_picture_sao - and what is in HBM
+    (and copied out) is the reference encoder's finished reconstruction with every in-loop filter on; the SAO parameters the device
+    decides are the encoder's own, LCU by LCU (I and B pictures, 8- and 10-bit)"""
+    from test_oracle_saodec_golden import LCU, same_decision
+    lib = product
+    sig_picture(lib)
+    g, w, h = load_case(name)
+    wide = is16(g)
+    enc = lib.svt_amd_encode_picture16 if wide else lib.svt_amd_encode_picture
+    dbk = lib.svt_amd_encdec_picture_deblock16 if wide else lib.svt_amd_encdec_picture_deblock
+    dbk.restype, dbk.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DeblockParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    sao = lib.svt_amd_encdec_picture_sao16 if wide else lib.svt_amd_encdec_picture_sao
+    sao.restype, sao.argtypes = C.c_int, [C.c_void_p] * 9
+    sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if wide else (np.uint8, S.LCU_RESULT_DTYPE)
+    nl = S.lcu_count(w, h)
+    inter = "ref_pocs" in g
+    refs, keep = device_refs(g, wide) if inter else ({}, None)
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    decided = 0
+    try:
+        for first in range(0, len(g["work"]), nl):
+            f = int(g["picture_number"][first])
+            works = np.ascontiguousarray(g["work"][first:first + nl])
+            got = np.zeros(nl, rdt)
+            if inter:
+                set_inter(lib, gpu_ctx, pic, g, refs, first)
+            assert enc(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+            prm = DeblockParams()
+            prm.slice_type = int(works[0]["slice_type"])
+            if inter:
+                prm.ref_poc[0], prm.ref_poc[1] = int(g["ref_poc"][first][0]), int(g["ref_poc"][first][1])
+            assert dbk(gpu_ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(prm), None, None, None) == 0, lib.svt_amd_last_error()
+            P, enable, params, want, idx = sao_inputs_of_picture(g, f, works, w, h)
+            out = [np.zeros((h, w), sdt), np.zeros((h // 2, w // 2), sdt), np.zeros((h // 2, w // 2), sdt)]
+            if P is None:      # the encode pass shut SAO off for the whole picture: the deblocked picture is the output
+                assert dbk(gpu_ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(prm), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data) == 0
+            else:
+                dec = np.zeros(nl, LCU)
+                assert sao(gpu_ctx, pic, works.ctypes.data, P.ctypes.data, enable.ctypes.data, dec.ctypes.data, out[0].ctypes.data, out[1].ctypes.data,
+                           out[2].ctypes.data) == 0, lib.svt_amd_last_error()
+                for i in idx:
+                    assert same_decision(dec[i], want[i]), (name, f, int(i), dec[i], want[i])
+                decided += len(idx)
+            for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
+                bad = np.argwhere(out[p] != g[nm][f])
+                assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
+        assert decided >= len(g["work"]) // 2
+    finally:
+        lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+def test_picture_sao_needs_the_deblocked_picture(product, gpu_ctx):
+    lib = product
+    sig_picture(lib)
+    lib.svt_amd_encdec_picture_sao.restype, lib.svt_amd_encdec_picture_sao.argtypes = C.c_int, [C.c_void_p] * 9
+    pic = C.c_void_p()
+    assert lib.svt_amd_encdec_picture_create(gpu_ctx, 128, 64, 1, C.byref(pic)) == 0
+    try:
+        works = np.zeros(2, S.LCU_WORK_DTYPE)
+        works[1]["lcu_x"] = 64
+        P = np.zeros(88, np.uint8)
+        assert lib.svt_amd_encdec_picture_sao(gpu_ctx, pic, works.ctypes.data, P.ctypes.data, None, None, None, None, None) != 0
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)

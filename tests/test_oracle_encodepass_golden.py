@@ -12,7 +12,8 @@ import svtlib as S
 
 ALL = sorted(os.path.basename(p)[11:-4] for p in glob.glob(os.path.join(S.GOLDEN_DIR, "encodepass_*.npz")))
 INTER_CASES = [c for c in ALL if c.split("_")[0] in ("p", "b", "p10", "b10")]   # P / B pictures: inter units, reference pictures, rate tables
-CASES = [c for c in ALL if not c.startswith("dlf_") and c not in INTER_CASES]  # all-intra, loop filters off: per-LCU reconstruction comparable
+SAO_CASES = [c for c in ALL if c.startswith("sao_")]        # deblocking and SAO on: decision records of every LCU + the encoder's finished output
+CASES = [c for c in ALL if not c.startswith(("dlf_", "sao_")) and c not in INTER_CASES]  # all-intra, loop filters off: per-LCU reconstruction comparable
 DLF_CASES = [c for c in ALL if c.startswith("dlf_")]        # deblocking on, SAO off: the encoder's output picture is the reference
 
 
@@ -208,12 +209,10 @@ def test_have_dlf_cases():
     assert len(DLF_CASES) >= 5 and sum("ref_pocs" in load_case(c)[0] for c in DLF_CASES) >= 2
 
 
-@pytest.mark.parametrize("name", DLF_CASES)
-def test_encode_then_deblock_oracle_matches_the_encoders_output(oracle, name):
-    """the chain the device runs - encode pass of every LCU, boundary strengths from the unit lists, picture deblocking - restated
-    on the CPU from the three pinned oracle pieces, against the reference encoder's own reconstruction output (SAO off)"""
+def encode_and_deblock_pictures(oracle, name, g, w, h):
+    """the chain on the CPU, picture by picture: encode pass of every LCU (checked against the records), boundary strengths from the unit
+    lists, picture deblocking.  Yields (picture number, first record, works, results, un-deblocked planes, deblocked planes)."""
     from test_oracle_dlf_golden import oracle_bs, oracle_dlf
-    g, w, h = load_case(name)
     wide = is16(g)
     inter = "ref_pocs" in g       # P / B pictures: the (deblocked) reference pictures and rate tables come with the fixture
     fn = inter_oracle_fn(oracle, wide)
@@ -243,7 +242,131 @@ def test_encode_then_deblock_oracle_matches_the_encoders_output(oracle, name):
                    bsv=np.zeros((nl, 256), np.uint8), bsh=np.zeros((nl, 256), np.uint8))
         pic["bsv"], pic["bsh"] = oracle_bs(oracle, pic)
         pic["pre"], pic["qp"] = rec, qp.reshape(-1)
-        out = oracle_dlf(oracle, pic)
+        yield f, first, g["work"][first:first + nl], got, rec, oracle_dlf(oracle, pic)
+
+
+@pytest.mark.parametrize("name", DLF_CASES)
+def test_encode_then_deblock_oracle_matches_the_encoders_output(oracle, name):
+    """the chain the device runs - encode pass of every LCU, boundary strengths from the unit lists, picture deblocking - restated
+    on the CPU from the three pinned oracle pieces, against the reference encoder's own reconstruction output (SAO off)"""
+    g, w, h = load_case(name)
+    for f, first, works, got, pre, out in encode_and_deblock_pictures(oracle, name, g, w, h):
+        for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
+            bad = np.argwhere(out[p] != g[nm][f])
+            assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
+
+
+def encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h):
+    """The samples of an LCU as the reference's SAO decision sees them (Codec/EbCodingLoop.c:4600-4750: the LCU's own three deblocking
+    drivers have run, those of the LCUs to its right and below have not): the deblocked picture, except the last 4 columns / rows of
+    the LCU (in the plane's own samples) where a neighbour still follows - those belong to 8x8 filter blocks centred on the LCU
+    boundary (LCUBoundaryDLFCore of the NEXT LCU, EbDeblockingFilter.c:2828) and still hold un-deblocked samples."""
+    sh = 1 if p else 0
+    bx, by, bw, bh = x0 >> sh, y0 >> sh, lw >> sh, lh >> sh
+    blk = fin[p][by:by + bh, bx:bx + bw].copy()
+    if x0 + lw < w:
+        blk[:, bw - 4:] = pre[p][by:by + bh, bx + bw - 4:bx + bw]
+    if y0 + lh < h:
+        blk[bh - 4:, :] = pre[p][by + bh - 4:by + bh, bx:bx + bw]
+    return blk
+
+
+def test_have_sao_cases():
+    assert len(SAO_CASES) >= 4
+
+
+@pytest.mark.parametrize("name", SAO_CASES)
+def test_encoder_order_sao_statistics_from_two_pictures(oracle, name):
+    """what the reference's SaoGenerationDecision gathered for every LCU (recorded inside the encoder) = statistics of the composite of the
+    un-deblocked and the finished deblocked picture: no LCU-by-LCU deblocking order is needed to reproduce them"""
+    g, w, h = load_case(name)
+    wide = is16(g)
+    vp, u32 = C.c_void_p, C.c_uint32
+    oracle.svt_oracle_GatherSaoStatistics.argtypes = [C.c_int, C.c_int, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]
+    oracle.svt_oracle_GatherSaoStatistics.restype = None
+    sao = g["sao"]
+    checked = 0
+    for f, first, works, got, pre, fin in encode_and_deblock_pictures(oracle, name, g, w, h):
+        for k, wk in enumerate(works):
+            x0, y0 = int(wk["lcu_x"]), int(wk["lcu_y"])
+            sel = sao[(sao["picture_number"] == f) & (sao["origin_x"] == x0) & (sao["origin_y"] == y0)]
+            if not len(sel):
+                continue          # the encode pass shut SAO off for this LCU (EbCodingLoop.c:4678-4707)
+            r = sel[0]
+            lw, lh = min(64, w - x0), min(64, h - y0)
+            ncomp = 3 if r["mm_sao"] else (1 if r["temporal_layer"] < 2 else 0)
+            for p in range(ncomp):
+                sh = 1 if p else 0
+                blk = np.ascontiguousarray(encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h))
+                src = np.ascontiguousarray(wk[("src_y", "src_cb", "src_cr")[p]].reshape(64 >> sh, 64 >> sh))
+                bd, bc = np.zeros(32, np.int32), np.zeros(32, np.uint16)
+                ed, ec = np.zeros((4, 5), np.int32), np.zeros((4, 5), np.uint16)
+                oracle.svt_oracle_GatherSaoStatistics(2 if wide else 1, 0 if r["mm_sao"] else 1, src.ctypes.data, 64 >> sh, blk.ctypes.data, blk.shape[1],
+                                                      lw >> sh, lh >> sh, bd.ctypes.data, bc.ctypes.data, ed.ctypes.data, ec.ctypes.data)
+                tag = (name, f, k, p)
+                assert np.array_equal(ed, r["eo_diff"][p]) and np.array_equal(ec, r["eo_count"][p]), (tag, "eo", ed.tolist(), r["eo_diff"][p].tolist())
+                if r["mm_sao"]:
+                    assert np.array_equal(bd, r["bo_diff"][p]) and np.array_equal(bc, r["bo_count"][p]), (tag, "bo")
+            checked += 1
+    assert checked >= len(g["work"]) // 2, checked
+
+
+
+def sao_inputs_of_picture(g, f, works, w, h):
+    """decision inputs of one picture from the fixture's records: rate parameters, enable map (0 = the encode pass shut SAO off there),
+    edge flags (1 / 4: no left / upper merge candidate; 2 / 8: right / bottom tile edge for the application) and the reference's decisions"""
+    from test_oracle_saodec_golden import LCU, params_of
+    sao = g["sao"]
+    rr = sao[sao["picture_number"] == f]
+    cols, rows = (w + 63) // 64, (h + 63) // 64
+    enable, params, want = np.zeros(cols * rows, np.uint8), np.zeros(cols * rows, LCU), np.zeros(cols * rows, LCU)
+    idx = (rr["origin_y"] // 64) * cols + rr["origin_x"] // 64
+    enable[idx] = 1
+    for k, wk in enumerate(works):
+        below = k + cols
+        params["edge_flags"][k] = (1 if wk["tile_left"] else 0) | (2 if wk["tile_right"] else 0) | (4 if wk["tile_top"] else 0) | \
+                                  (8 if (below >= len(works) or works[below]["tile_top"]) else 0)
+    for k in ("merge_left", "merge_up", "type", "offset", "band"):
+        want[k][idx] = rr["out"][k]
+    return (params_of(rr[0]) if len(rr) else None), enable, params, want, idx
+
+
+@pytest.mark.parametrize("name", SAO_CASES)
+def test_encode_deblock_sao_oracle_matches_the_encoders_output(oracle, name):
+    """the whole closed-loop tail restated from pinned pieces and two pictures in memory: encode pass -> deblocking -> SAO statistics of the
+    encoder-order composite -> parameter decision (merge wavefront) -> SAO application = the reference encoder's reconstruction output
+    with every in-loop filter on; the decided parameters equal the encoder's own, LCU by LCU"""
+    from test_oracle_dlf_golden import oracle_sao
+    from test_oracle_saodec_golden import STATS, oracle_decide_picture, same_decision
+    g, w, h = load_case(name)
+    wide = is16(g)
+    vp, u32 = C.c_void_p, C.c_uint32
+    oracle.svt_oracle_GatherSaoStatistics.argtypes = [C.c_int, C.c_int, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]
+    oracle.svt_oracle_GatherSaoStatistics.restype = None
+    cols, rows = (w + 63) // 64, (h + 63) // 64
+    for f, first, works, got, pre, fin in encode_and_deblock_pictures(oracle, name, g, w, h):
+        P, enable, params, want, idx = sao_inputs_of_picture(g, f, works, w, h)
+        if P is None:
+            out = fin
+        else:
+            stats = np.zeros((3, cols * rows), STATS)
+            ncomp = 3 if P["mm_sao"][0] else (1 if P["temporal_layer"][0] < 2 else 0)
+            for k, wk in enumerate(works):
+                x0, y0 = int(wk["lcu_x"]), int(wk["lcu_y"])
+                lw, lh = min(64, w - x0), min(64, h - y0)
+                for p in range(ncomp):
+                    sh = 1 if p else 0
+                    blk = np.ascontiguousarray(encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h))
+                    src = np.ascontiguousarray(wk[("src_y", "src_cb", "src_cr")[p]].reshape(64 >> sh, 64 >> sh))
+                    st = stats[p][k:k + 1]
+                    oracle.svt_oracle_GatherSaoStatistics(2 if wide else 1, 0 if P["mm_sao"][0] else 1, src.ctypes.data, 64 >> sh, blk.ctypes.data,
+                                                          blk.shape[1], lw >> sh, lh >> sh, st["boDiff"].ctypes.data, st["boCount"].ctypes.data,
+                                                          st["eoDiff"].ctypes.data, st["eoCount"].ctypes.data)
+            dec, _ = oracle_decide_picture(oracle, dict(P=P, stats=stats, enable=enable, params=params, cols=cols, rows=rows))
+            for i in idx:
+                assert same_decision(dec[i], want[i]), (name, f, int(i), dec[i], want[i])
+            dec["edge_flags"] = params["edge_flags"]
+            out = oracle_sao(oracle, fin, 2 if wide else 1, w, h, dec, 1, 1)
         for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
             bad = np.argwhere(out[p] != g[nm][f])
             assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
