@@ -1073,16 +1073,18 @@ __global__ __launch_bounds__(256) void k_ep_source_planes(const typename EpTypes
 /* The picture as the reference's SaoGenerationDecision sees each LCU (EbCodingLoop.c:4600-4750): the LCU's own deblocking drivers have run,
  * those of the LCUs to its right and below have not.  Those later drivers own the 8x8 filter blocks centred on the LCU boundary
  * (LCUBoundaryDLFCore, EbDeblockingFilter.c:2828), i.e. every edge segment inside the last 4 columns / rows of the LCU (in the plane's own
- * samples) and nothing else inside it: the LCU is the deblocked picture with those strips still un-deblocked, where a neighbour follows.
+ * samples) and nothing else inside it: the LCU is the deblocked picture with those strips still un-deblocked, where a neighbour OF THE SAME
+ * TILE follows (at picture and tile edges the LCU's own LCUPictureEdgeDLFCore has finished them; follow: bit 0 right, bit 1 below).
  * (tests/test_oracle_encodepass_golden.py::test_encoder_order_sao_statistics_from_two_pictures proves it on the encoder's own records.) */
 template <typename T>
 __global__ __launch_bounds__(256) void k_ep_sao_composite(const T *__restrict__ dbk, const T *__restrict__ rec, T *__restrict__ out, int pitch, int w, int h,
-                                                          int lcu)
+                                                          int lg_lcu, int wl, const uint8_t *__restrict__ follow)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lcu = 1 << lg_lcu;
     if (x >= w)
         return;
-    const bool right = (x & (lcu - 1)) >= lcu - 4 && (x | (lcu - 1)) + 1 < w, bottom = (y & (lcu - 1)) >= lcu - 4 && (y | (lcu - 1)) + 1 < h;
+    const int f = follow[(y >> lg_lcu) * wl + (x >> lg_lcu)];
+    const bool right = (x & (lcu - 1)) >= lcu - 4 && (f & 1), bottom = (y & (lcu - 1)) >= lcu - 4 && (f & 2);
     const size_t o = (size_t)y * pitch + x;
     out[o] = (right || bottom) ? rec[o] : dbk[o];
 }
@@ -1102,12 +1104,14 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     }
     const uint32_t w = pic->d.width, h = pic->d.height, wl = (w + 63) / 64, hl = (h + 63) / 64, nlcu = (uint32_t)pic->nlcu;
     std::vector<SvtAmdSaoLcuParams> lp(nlcu);
+    std::vector<uint8_t> follow(nlcu);
     ::memset(lp.data(), 0, nlcu * sizeof(SvtAmdSaoLcuParams));
     for (uint32_t i = 0; i < nlcu; i++) {
         if (works[i].lcu_x != (i % wl) * 64 || works[i].lcu_y != (i / wl) * 64)
             return SVT_AMD_ERR_BAD_PARAM;
         const bool bottom_edge = i + wl >= nlcu || works[i + wl].tile_top;
         lp[i].edge_flags = (uint8_t)((works[i].tile_left ? 1 : 0) | (works[i].tile_right ? 2 : 0) | (works[i].tile_top ? 4 : 0) | (bottom_edge ? 8 : 0));
+        follow[i] = (uint8_t)(((i % wl) + 1 < wl && !works[i].tile_right ? 1 : 0) | (!bottom_edge ? 2 : 0));
     }
     HIP_TRY(hipSetDevice(ctx->device));
     for (int k = 0; k < 3; k++)
@@ -1117,7 +1121,7 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     const size_t b_works = up(sizeof(WorkT) * nlcu), b_pl[3] = {up(pic->plane_bytes[0]), up(pic->plane_bytes[1]), up(pic->plane_bytes[2])};
     const size_t b_stats = up(sizeof(SvtAmdSaoStats) * nlcu), b_par = up(sizeof(SvtAmdSaoLcuParams) * nlcu), b_cost = up(16 * (size_t)nlcu), b_en = up(nlcu);
     uint8_t *d = nullptr;
-    int rc = svt_amd_ctx_scratch(ctx, b_works + 2 * (b_pl[0] + b_pl[1] + b_pl[2]) + 3 * b_stats + b_par + b_cost + b_en, &d);
+    int rc = svt_amd_ctx_scratch(ctx, b_works + 2 * (b_pl[0] + b_pl[1] + b_pl[2]) + 3 * b_stats + b_par + b_cost + 2 * b_en, &d);
     if (rc)
         return rc;
     uint8_t *d_works = d, *d_src[3], *d_cmp[3], *q = d + b_works;
@@ -1132,8 +1136,9 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     q += b_par;
     int64_t *d_cost = (int64_t *)q;
     q += b_cost;
-    uint8_t *d_en = q;
+    uint8_t *d_en = q, *d_follow = q + b_en;
     HIP_TRY(hipMemcpyAsync(d_works, works, sizeof(WorkT) * nlcu, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_follow, follow.data(), nlcu, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_par, lp.data(), sizeof(SvtAmdSaoLcuParams) * nlcu, hipMemcpyHostToDevice, ctx->stream));
     if (enable)
         HIP_TRY(hipMemcpyAsync(d_en, enable, nlcu, hipMemcpyHostToDevice, ctx->stream));
@@ -1145,7 +1150,7 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     for (int k = 0; k < 3; k++) {
         const int pw = k ? w / 2 : w, ph = k ? h / 2 : h;
         hipLaunchKernelGGL(k_ep_sao_composite<T>, dim3((pw + 255) / 256, ph), dim3(256), 0, ctx->stream, (const T *)pic->dbk[k], (const T *)pic->d.rec[k],
-                           (T *)d_cmp[k], k ? pC : pY, pw, ph, k ? 32 : 64);
+                           (T *)d_cmp[k], k ? pC : pY, pw, ph, k ? 5 : 6, (int)wl, (const uint8_t *)d_follow);
     }
     HIP_TRY(hipGetLastError());
     /* GatherSaoStatisticsLcu* of the components the mode looks at (EbSampleAdaptiveOffsetGenerationDecision.c:647-760) */

@@ -256,7 +256,7 @@ def test_encode_then_deblock_oracle_matches_the_encoders_output(oracle, name):
             assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
 
 
-def encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h):
+def encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h, right_follows=True, below_follows=True):
     """The samples of an LCU as the reference's SAO decision sees them (Codec/EbCodingLoop.c:4600-4750: the LCU's own three deblocking
     drivers have run, those of the LCUs to its right and below have not): the deblocked picture, except the last 4 columns / rows of
     the LCU (in the plane's own samples) where a neighbour still follows - those belong to 8x8 filter blocks centred on the LCU
@@ -264,9 +264,9 @@ def encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h):
     sh = 1 if p else 0
     bx, by, bw, bh = x0 >> sh, y0 >> sh, lw >> sh, lh >> sh
     blk = fin[p][by:by + bh, bx:bx + bw].copy()
-    if x0 + lw < w:
+    if x0 + lw < w and right_follows:
         blk[:, bw - 4:] = pre[p][by:by + bh, bx + bw - 4:bx + bw]
-    if y0 + lh < h:
+    if y0 + lh < h and below_follows:
         blk[bh - 4:, :] = pre[p][by + bh - 4:by + bh, bx:bx + bw]
     return blk
 
@@ -297,7 +297,9 @@ def test_encoder_order_sao_statistics_from_two_pictures(oracle, name):
             ncomp = 3 if r["mm_sao"] else (1 if r["temporal_layer"] < 2 else 0)
             for p in range(ncomp):
                 sh = 1 if p else 0
-                blk = np.ascontiguousarray(encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h))
+                cols_ = (w + 63) // 64
+                blk = np.ascontiguousarray(encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h, not wk["tile_right"],
+                                                             k + cols_ >= len(works) or not works[k + cols_]["tile_top"]))
                 src = np.ascontiguousarray(wk[("src_y", "src_cb", "src_cr")[p]].reshape(64 >> sh, 64 >> sh))
                 bd, bc = np.zeros(32, np.int32), np.zeros(32, np.uint16)
                 ed, ec = np.zeros((4, 5), np.int32), np.zeros((4, 5), np.uint16)
@@ -356,7 +358,8 @@ def test_encode_deblock_sao_oracle_matches_the_encoders_output(oracle, name):
                 lw, lh = min(64, w - x0), min(64, h - y0)
                 for p in range(ncomp):
                     sh = 1 if p else 0
-                    blk = np.ascontiguousarray(encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h))
+                    blk = np.ascontiguousarray(encoder_order_lcu(pre, fin, p, x0, y0, lw, lh, w, h, not wk["tile_right"],
+                                                                 k + cols >= len(works) or not works[k + cols]["tile_top"]))
                     src = np.ascontiguousarray(wk[("src_y", "src_cb", "src_cr")[p]].reshape(64 >> sh, 64 >> sh))
                     st = stats[p][k:k + 1]
                     oracle.svt_oracle_GatherSaoStatistics(2 if wide else 1, 0 if P["mm_sao"][0] else 1, src.ctypes.data, 64 >> sh, blk.ctypes.data,
