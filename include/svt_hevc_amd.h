@@ -1100,6 +1100,13 @@ SVT_AMD_API int svt_amd_encdec_picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPictu
 SVT_AMD_API int svt_amd_encdec_picture_sao16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works,
                                              const SvtAmdSaoDecisionParams *params, const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params,
                                              uint16_t *out_y, uint16_t *out_cb, uint16_t *out_cr);
+/* The picture object's latest stage (after SAO, else deblocked, else as encoded) as a padded reference picture in HBM - PadRefAndSetFlags
+ * (Codec/EbEncDecProcess.c:1805: GeneratePadding[16Bit], edge replication) - in the form svt_amd_encdec_picture_set_inter of a LATER picture
+ * object takes: reference pictures never leave the device.  origin_x / origin_y: luma padding (the reference: LCU size + 16 = 80; even);
+ * planes are (width + 2 origin_x) samples wide, chroma half of everything.  out_*: optional HOST copies of the padded planes.  *ref stays
+ * valid until the picture object is destroyed or the call is repeated on it. */
+SVT_AMD_API int svt_amd_encdec_picture_reference(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, uint32_t origin_x, uint32_t origin_y,
+                                                 SvtAmdRefPicture *ref, void *out_y, void *out_cb, void *out_cr);
 
 /* debug: out == NULL arms per-LCU shader-clock sums in the encode-pass kernels (16 x u64 per LCU: prediction, encode, copy-out, units,
  * wait for neighbours, start, end, -, the prediction's four sub-phases, 4 unused), a later call with a HOST buffer of 16 * LCUs u64

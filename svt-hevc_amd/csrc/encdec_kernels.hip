@@ -64,7 +64,10 @@ struct SvtAmdEncDecPicture {
     /* the in-loop filters behind the encode pass: the deblocked picture and the picture after SAO live beside the un-deblocked one (the SAO
      * statistics need both, svt_amd_encdec_picture_sao); same pitches as rec[] */
     uint8_t *dbk[3], *fin[3];
-    bool deblocked;
+    bool deblocked, sao_done;
+    /* the finished picture with its padding: a reference picture of later pictures (svt_amd_encdec_picture_reference) */
+    uint8_t *refp[3];
+    size_t refp_bytes[3];
 };
 
 typedef SvtAmdLcuCu LcuCu;
@@ -750,7 +753,7 @@ extern "C" int svt_amd_encdec_picture_begin(SvtAmdContext *ctx, SvtAmdEncDecPict
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, ctx->stream)); /* nothing coded yet */
     HIP_TRY(hipStreamSynchronize(ctx->stream));                                   /* other lanes may encode the first LCU */
-    pic->deblocked = false;
+    pic->deblocked = pic->sao_done = false;
     return SVT_AMD_OK;
 }
 
@@ -776,6 +779,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
             (void)hipFree(pic->dbk[k]);
         if (pic->fin[k])
             (void)hipFree(pic->fin[k]);
+        if (pic->refp[k])
+            (void)hipFree(pic->refp[k]);
     }
     free(pic);
     return SVT_AMD_OK;
@@ -914,7 +919,7 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
         d_works = (const WorkT *)d, d_results = (ResultT *)(d + wba);
     }
     pic->epoch++;
-    pic->deblocked = false;
+    pic->deblocked = pic->sao_done = false;
     HIP_TRY(hipMemsetAsync(pic->d_sync, 0, sizeof(unsigned), ctx->stream));              /* ticket counter */
     HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, ctx->stream));          /* nothing coded yet */
     /* persistent grid = the widest wavefront (an LCU row advances two LCUs behind the row above) of every tile that can run on its
@@ -1175,6 +1180,59 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
                                      hipMemcpyDeviceToHost, ctx->stream));
         }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    pic->sao_done = true;
+    return SVT_AMD_OK;
+}
+
+/* PadRefAndSetFlags (Codec/EbEncDecProcess.c:1805; GeneratePadding / GeneratePadding16Bit): the finished picture inside a frame of
+ * replicated edge samples */
+template <typename T>
+__global__ __launch_bounds__(256) void k_ep_pad(const T *__restrict__ src, int spitch, int w, int h, T *__restrict__ dst, int dstride, int ox, int oy)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w + 2 * ox)
+        return;
+    dst[(size_t)y * dstride + x] = src[(size_t)min(max(y - oy, 0), h - 1) * spitch + min(max(x - ox, 0), w - 1)];
+}
+
+/* The picture object's latest stage (after SAO, else deblocked, else as encoded) as a padded reference picture in HBM: what
+ * svt_amd_encdec_picture_set_inter of a later picture takes - reference pictures never leave the device.  origin_x / origin_y: luma padding
+ * (the reference uses LCU size + 16 = 80); the planes are (width + 2 origin_x) samples wide, chroma half of everything.  out_*: optional
+ * HOST copies of the padded planes.  The planes live until the picture object is destroyed or the call is repeated. */
+extern "C" int svt_amd_encdec_picture_reference(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, uint32_t origin_x, uint32_t origin_y, SvtAmdRefPicture *ref,
+                                                void *out_y, void *out_cb, void *out_cr)
+{
+    if (!ctx || !pic || !ref || origin_x < 8 || origin_y < 8 || (origin_x & 1) || (origin_y & 1) || origin_x > 256 || origin_y > 256)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t w = pic->d.width, h = pic->d.height, bps = pic->d.bps;
+    uint8_t *const *stage = pic->sao_done ? pic->fin : pic->deblocked ? pic->dbk : pic->d.rec;
+    void *outs[3] = {out_y, out_cb, out_cr};
+    for (int k = 0; k < 3; k++) {
+        const int sh = k ? 1 : 0, pw = (int)(w >> sh), ph = (int)(h >> sh), ox = (int)(origin_x >> sh), oy = (int)(origin_y >> sh), stride = pw + 2 * ox, rows = ph + 2 * oy;
+        const size_t need = (size_t)stride * rows * bps;
+        if (pic->refp_bytes[k] < need) {
+            if (pic->refp[k])
+                HIP_TRY(hipFree(pic->refp[k]));
+            pic->refp[k] = nullptr, pic->refp_bytes[k] = 0;
+            if (hipMalloc((void **)&pic->refp[k], need) != hipSuccess)
+                return SVT_AMD_ERR_RESOURCES;
+            pic->refp_bytes[k] = need;
+        }
+        if (bps == 1)
+            hipLaunchKernelGGL(k_ep_pad<uint8_t>, dim3((stride + 255) / 256, rows), dim3(256), 0, ctx->stream, (const uint8_t *)stage[k], (int)pic->d.pitch[k], pw, ph,
+                               (uint8_t *)pic->refp[k], stride, ox, oy);
+        else
+            hipLaunchKernelGGL(k_ep_pad<uint16_t>, dim3((stride + 255) / 256, rows), dim3(256), 0, ctx->stream, (const uint16_t *)stage[k], (int)pic->d.pitch[k], pw,
+                               ph, (uint16_t *)pic->refp[k], stride, ox, oy);
+        if (outs[k])
+            HIP_TRY(hipMemcpyAsync(outs[k], pic->refp[k], need, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* other lanes' pictures may read the planes right away */
+    ref->d_y = pic->refp[0], ref->d_cb = pic->refp[1], ref->d_cr = pic->refp[2];
+    ref->strideY = w + 2 * origin_x, ref->strideC = (w >> 1) + 2 * (origin_x >> 1), ref->originX = origin_x, ref->originY = origin_y;
+    ref->width = w, ref->height = h;
     return SVT_AMD_OK;
 }
 extern "C" int svt_amd_encdec_picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, const SvtAmdSaoDecisionParams *params,

@@ -547,3 +547,74 @@ def test_picture_sao_needs_the_deblocked_picture(product, gpu_ctx):
         assert lib.svt_amd_encdec_picture_sao(gpu_ctx, pic, works.ctypes.data, P.ctypes.data, None, None, None, None, None) != 0
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+@pytest.mark.parametrize("name", [c for c in SAO_CASES if "_p_" in c or "_b_" in c])
+def test_sequence_stays_on_the_device_from_picture_to_picture(product, gpu_ctx, name):
+    """a whole sequence (I then P, or random-access B in coding order) with one picture object per picture: encode pass -> deblocking -> SAO ->
+    padding, and the result is the NEXT pictures' reference picture through svt_amd_encdec_picture_set_inter - no reconstructed sample comes
+    from the host.  Every picture's output equals the encoder's, every padded reference equals the reference picture the encoder used."""
+    from test_oracle_saodec_golden import LCU
+    lib = product
+    sig_picture(lib)
+    g, w, h = load_case(name)
+    wide = is16(g)
+    enc = lib.svt_amd_encode_picture16 if wide else lib.svt_amd_encode_picture
+    dbk = lib.svt_amd_encdec_picture_deblock16 if wide else lib.svt_amd_encdec_picture_deblock
+    dbk.restype, dbk.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DeblockParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    sao = lib.svt_amd_encdec_picture_sao16 if wide else lib.svt_amd_encdec_picture_sao
+    sao.restype, sao.argtypes = C.c_int, [C.c_void_p] * 9
+    lib.svt_amd_encdec_picture_reference.restype = C.c_int
+    lib.svt_amd_encdec_picture_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if wide else (np.uint8, S.LCU_RESULT_DTYPE)
+    nl = S.lcu_count(w, h)
+    sy, sc, ox, oy, rw, rh = (int(v) for v in g["ref_geom"])
+    firsts = {int(g["picture_number"][k]): k for k in range(0, len(g["work"]), nl)}
+    NONE = 0xFFFFFFFFFFFFFFFF
+    done, pics, checked_refs = {}, {}, 0
+    try:
+        while len(done) < len(firsts):
+            ready = [f for f, k in firsts.items() if f not in done and all(int(v) == NONE or int(v) in done for v in g["ref_poc"][k])]
+            assert ready, (sorted(done), sorted(firsts))
+            f = min(ready)
+            first = firsts[f]
+            works = np.ascontiguousarray(g["work"][first:first + nl])
+            pic = C.c_void_p()
+            assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+            pics[f] = pic
+            r0, r1 = (done.get(int(v)) for v in g["ref_poc"][first])
+            if r0 or r1:
+                cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(f)])
+                assert lib.svt_amd_encdec_picture_set_inter(gpu_ctx, pic, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None, cost.ctypes.data) == 0, \
+                    lib.svt_amd_last_error()
+            got = np.zeros(nl, rdt)
+            assert enc(gpu_ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+            for k in range(nl):
+                compare_lcu(works[k], g["result"][first + k], got[k], w, h, (name, f, k), rec=False)
+            prm = DeblockParams()
+            prm.slice_type = int(works[0]["slice_type"])
+            prm.ref_poc[0], prm.ref_poc[1] = int(g["ref_poc"][first][0]), int(g["ref_poc"][first][1])
+            out = [np.zeros((h, w), sdt), np.zeros((h // 2, w // 2), sdt), np.zeros((h // 2, w // 2), sdt)]
+            P, enable, params, want, idx = sao_inputs_of_picture(g, f, works, w, h)
+            o = [a.ctypes.data for a in out]
+            assert dbk(gpu_ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(prm), *(o if P is None else [None] * 3)) == 0, lib.svt_amd_last_error()
+            if P is not None:
+                assert sao(gpu_ctx, pic, works.ctypes.data, P.ctypes.data, enable.ctypes.data, None, *o) == 0, lib.svt_amd_last_error()
+            for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
+                assert np.array_equal(out[p], g[nm][f]), (name, f, nm)
+            ref = S.RefPicture()
+            padded = [np.zeros(((rh + 2 * oy) >> s_, sy >> s_), sdt) for s_ in (0, 1, 1)]
+            assert lib.svt_amd_encdec_picture_reference(gpu_ctx, pic, ox, oy, C.byref(ref), *[a.ctypes.data for a in padded]) == 0, lib.svt_amd_last_error()
+            assert (ref.strideY, ref.strideC, ref.originX, ref.originY, ref.width, ref.height) == (sy, sc, ox, oy, rw, rh)
+            if f in g["ref_pocs"].tolist():
+                i = g["ref_pocs"].tolist().index(f)
+                for p, nm in enumerate(("ref_y", "ref_cb", "ref_cr")):
+                    assert np.array_equal(padded[p].reshape(-1), g[nm][i]), (name, f, nm)
+                checked_refs += 1
+            done[f] = ref
+        assert checked_refs == len(g["ref_pocs"])
+    finally:
+        for pic in pics.values():
+            lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)

@@ -228,11 +228,11 @@ def encode_and_deblock_pictures(oracle, name, g, w, h):
         rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
         got = np.zeros(nl, rdt)
         r0, r1 = (refs.get(int(v)) for v in g["ref_poc"][first]) if inter else (None, None)
-        cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(f)]) if inter else None
+        cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(f)]) if inter and f in g["cost_pictures"].tolist() else None
         for k in range(nl):
             work = np.ascontiguousarray(g["work"][first + k:first + k + 1])
             fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None,
-               cost.ctypes.data if inter else None, work.ctypes.data, got[k:k + 1].ctypes.data)
+               cost.ctypes.data if cost is not None else None, work.ctypes.data, got[k:k + 1].ctypes.data)
             compare_lcu(work[0], g["result"][first + k], got[k], w, h, (name, f, k), rec=False)
         cumap, cbf, qp, edge = deblock_maps(g["work"][first:first + nl], got, w, h)
         hdr = dict(width=w, height=h, bytes_per_sample=2 if wide else 1, qp_stride=w // 8, tc_offset=0, beta_offset=0, cb_qp_offset=0,
@@ -373,3 +373,13 @@ def test_encode_deblock_sao_oracle_matches_the_encoders_output(oracle, name):
         for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
             bad = np.argwhere(out[p] != g[nm][f])
             assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())
+        # ... and, padded as PadRefAndSetFlags does (EbEncDecProcess.c:1805: edge replication), it IS the reference picture the later
+        # pictures of the sequence predicted from
+        if "ref_pocs" in g and f in g["ref_pocs"].tolist():
+            sy, sc, ox, oy, rw, rh = (int(v) for v in g["ref_geom"])
+            i = g["ref_pocs"].tolist().index(f)
+            for p, nm in enumerate(("ref_y", "ref_cb", "ref_cr")):
+                px, py = (ox >> 1, oy >> 1) if p else (ox, oy)
+                padded = np.pad(out[p], ((py, py), (px, px)), mode="edge")
+                assert padded.shape[1] == (sc if p else sy)
+                assert np.array_equal(padded.reshape(-1), g[nm][i]), (name, f, nm)
