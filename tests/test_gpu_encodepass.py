@@ -392,6 +392,8 @@ def set_inter(lib, ctx, pic, g, refs, k):
     lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
     lib.svt_amd_encdec_picture_set_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     r0, r1 = (refs.get(int(v)) for v in g["ref_poc"][k])
+    if not r0 and not r1:
+        return            # an I picture of a whole-sequence fixture
     cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(int(g["picture_number"][k]))])
     assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None, cost.ctypes.data) == 0, \
         lib.svt_amd_last_error()
