@@ -203,6 +203,7 @@ SVT_AMD_API int svt_amd_synchronize(SvtAmdContext *ctx);
 /* plain device memory on the context's GPU for C hosts that keep reference pictures / planes resident (blocking copies) */
 SVT_AMD_API int svt_amd_device_alloc(SvtAmdContext *ctx, size_t bytes, void **d_ptr);
 SVT_AMD_API int svt_amd_device_free(SvtAmdContext *ctx, void *d_ptr);
+SVT_AMD_API int svt_amd_device_copy(SvtAmdContext *ctx, void *d_dst, const void *d_src, size_t bytes); /* device to device, blocking */
 SVT_AMD_API int svt_amd_device_upload(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes);
 SVT_AMD_API int svt_amd_device_download(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes);
 

@@ -77,6 +77,11 @@ typedef struct {
     pthread_mutex_t lock;        /* pending list + the device put of it */
     void *pending;               /* host-encoded LCUs not handed to the device yet: SvtAmdLcuBorder[] or SvtAmdLcuBorder16[] */
     int npending, cap, wide;
+    /* SVT_HOOK_ENCODEPASS_REFS: everything the device needs to finish the picture itself when its last LCU is through */
+    void *works_all, *res_all;   /* contract records of every LCU, raster order (8- or 16-bit contract) */
+    uint8_t *sao_enable;         /* LCUs the reference ran SaoGenerationDecision for */
+    SvtAmdSaoDecisionParams sao_P;
+    int sao_any, sao_varies, on_device, done;
 } EpPictureEntry;
 
 typedef struct {
@@ -107,6 +112,8 @@ static SvtAmdContext *g_ep_lane[EP_LANES];
 static int g_ep_lane_busy[EP_LANES];
 static int g_ep_state; /* 0 unknown, 1 on, -1 off */
 static int g_ep_verify;  /* SVT_HOOK_ENCODEPASS_VERIFY: the reference encodes the LCU itself after the device call and the two outcomes are compared */
+static int g_ep_refs;    /* SVT_HOOK_ENCODEPASS_REFS: pictures encoded entirely on the device are finished there and become reference pictures */
+static unsigned long g_ep_refs_done, g_ep_refs_skipped;
 static unsigned long g_ep_verified, g_ep_mismatch;
 static unsigned long g_ep_gpu, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts, g_ep_inter_units, g_ep_inter_lcus;
 
@@ -172,6 +179,16 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
             svt_hook_die("svt_amd_encdec_picture_begin");
         e->picture_plus1 = pcs->pictureNumber + 1;
         e->npending = 0;
+        e->sao_any = e->sao_varies = e->on_device = e->done = 0;
+        if (g_ep_refs) {
+            const size_t wb = wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+            if (!e->works_all) {
+                e->works_all = malloc(wb * (size_t)e->cap), e->res_all = malloc(rb * (size_t)e->cap), e->sao_enable = (uint8_t *)malloc((size_t)e->cap);
+                if (!e->works_all || !e->res_all || !e->sao_enable)
+                    svt_hook_die("out of memory (encode-pass picture records)");
+            }
+            memset(e->sao_enable, 0, (size_t)e->cap);
+        }
     }
     pthread_mutex_unlock(&g_ep_lock);
     return e;
@@ -294,6 +311,98 @@ static void border_from_neighbour_arrays(void *out, int wide, const PictureContr
     }
 }
 
+/* the SAO wraps (svt_hook_me.c) report every decision call made while an LCU is being served */
+void svt_hook_ep_note_sao(const PictureControlSet_t *pcs, EB_U32 x, EB_U32 y, const MdRateEstimationContext_t *md, EB_U64 lambda, EB_U64 chromaLambda,
+                          int mmSao, int is16)
+{
+    if (!g_ep_refs)
+        return;
+    EpPictureEntry *e = NULL;
+    pthread_mutex_lock(&g_ep_lock);
+    for (int i = 0; i < EP_PICTURES && !e; i++)
+        if (g_ep_pic[i].pcs == pcs)
+            e = &g_ep_pic[i];
+    pthread_mutex_unlock(&g_ep_lock);
+    if (!e || !e->sao_enable)
+        return;
+    SvtAmdSaoDecisionParams P;
+    memset(&P, 0, sizeof(P));
+    P.lambda = lambda, P.chroma_lambda = chromaLambda;
+    for (int k = 0; k < 6; k++)
+        P.type_bits[k] = md->saoTypeIndexBits[k];
+    for (int k = 0; k < 2; k++)
+        P.merge_bits[k] = md->saoMergeFlagBits[k];
+    for (int k = 0; k < 8; k++)
+        P.offset_bits[k] = md->saoOffsetTrunUnaryBits[k];
+    P.is_10bit = (uint8_t)is16, P.mm_sao = mmSao ? 1 : 0, P.temporal_layer = pcs->temporalLayerIndex;
+    const SequenceControlSet_t *scs = (const SequenceControlSet_t *)pcs->ParentPcsPtr->sequenceControlSetWrapperPtr->objectPtr;
+    const EB_U32 wl = (scs->lumaWidth + 63u) / 64u;
+    pthread_mutex_lock(&e->lock);
+    if (!e->sao_any)
+        e->sao_P = P, e->sao_any = 1;
+    else if (memcmp(&e->sao_P, &P, sizeof(P)))
+        e->sao_varies = 1; /* per-LCU lambdas (QP modulation): the picture-level decision call does not cover it */
+    e->sao_enable[(y / 64u) * wl + x / 64u] = 1;
+    pthread_mutex_unlock(&e->lock);
+}
+
+/* the last LCU of a picture is through and every LCU went through the device: finish the picture there (what EncDecKernel does on the host
+ * afterwards, EbEncDecProcess.c:3040-3200: remaining deblocking, ApplySaoOffsetsPicture, PadRefAndSetFlags) and hand it to the reference cache */
+static void finish_picture_on_device(SvtAmdContext *lane, EpPictureEntry *e, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs)
+{
+    const int wide = e->wide;
+    if (!pcs->ParentPcsPtr->isUsedAsReferenceFlag)
+        return;
+    if (e->on_device != e->cap || e->sao_varies || (scs->staticConfig.disableDlfFlag && scs->staticConfig.enableSaoFlag)) {
+        __atomic_add_fetch(&g_ep_refs_skipped, 1, __ATOMIC_RELAXED);
+        return;
+    }
+    const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr;
+    const EbPictureBufferDesc_t *rp = wide ? ro->referencePicture16bit : ro->referencePicture;
+    if (!scs->staticConfig.disableDlfFlag) {
+        SvtAmdDeblockParams prm;
+        memset(&prm, 0, sizeof(prm));
+        prm.tc_offset = pcs->tcOffset, prm.beta_offset = pcs->betaOffset, prm.cb_qp_offset = pcs->cbQpOffset, prm.cr_qp_offset = pcs->crQpOffset;
+        prm.slice_type = (uint8_t)pcs->sliceType;
+        prm.ref_poc[0] = prm.ref_poc[1] = ~0ull;
+        for (int l = 0; l < (pcs->sliceType == EB_B_PICTURE ? 2 : pcs->sliceType == EB_P_PICTURE ? 1 : 0); l++)
+            prm.ref_poc[l] = ((const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr)->refPOC;
+        if (wide ? svt_amd_encdec_picture_deblock16(lane, e->pic, (const SvtAmdLcuWork16 *)e->works_all, (const SvtAmdLcuResult16 *)e->res_all, &prm, NULL, NULL, NULL)
+                 : svt_amd_encdec_picture_deblock(lane, e->pic, (const SvtAmdLcuWork *)e->works_all, (const SvtAmdLcuResult *)e->res_all, &prm, NULL, NULL, NULL))
+            svt_hook_die("svt_amd_encdec_picture_deblock");
+        if (scs->staticConfig.enableSaoFlag && e->sao_any &&
+            (wide ? svt_amd_encdec_picture_sao16(lane, e->pic, (const SvtAmdLcuWork16 *)e->works_all, &e->sao_P, e->sao_enable, NULL, NULL, NULL, NULL)
+                  : svt_amd_encdec_picture_sao(lane, e->pic, (const SvtAmdLcuWork *)e->works_all, &e->sao_P, e->sao_enable, NULL, NULL, NULL, NULL)))
+            svt_hook_die("svt_amd_encdec_picture_sao");
+    }
+    SvtAmdRefPicture dev;
+    if (svt_amd_encdec_picture_reference(lane, e->pic, rp->originX, rp->originY, &dev, NULL, NULL, NULL))
+        svt_hook_die("svt_amd_encdec_picture_reference");
+    svt_hook_register_device_reference(rp, pcs->pictureNumber, wide ? 2 : 1, &dev);
+    __atomic_add_fetch(&g_ep_refs_done, 1, __ATOMIC_RELAXED);
+}
+
+/* one more LCU of the picture is through EncodePass (served from the device or not); the thread that brings the last one finishes the picture */
+static void picture_lcu_done(SvtAmdContext *root, EpPictureEntry *e, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, EB_U32 tbAddr, int served)
+{
+    if (!g_ep_refs)
+        return;
+    pthread_mutex_lock(&e->lock);
+    if (served) {
+        const size_t wb = e->wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = e->wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+        memcpy((uint8_t *)e->works_all + wb * tbAddr, &t_serve->work, wb);
+        memcpy((uint8_t *)e->res_all + rb * tbAddr, &t_serve->res, rb);
+        e->on_device++;
+    }
+    const int last = ++e->done == e->cap;
+    pthread_mutex_unlock(&e->lock);
+    if (last) {
+        SvtAmdContext *lane = lane_claim(root);
+        finish_picture_on_device(lane, e, scs, pcs);
+        lane_release(lane);
+    }
+}
+
 /* Verification mode: the outcome of the reference's own EncodePass of the LCU (flags, coefficients and - with the loop filters off - the
  * reconstruction) against what the device returned for it */
 static void verify_lcu(const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const LargestCodingUnit_t *lcuPtr, EB_U32 x0, EB_U32 y0,
@@ -365,6 +474,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
 {
     if (g_ep_state == 0) {
         g_ep_verify = getenv("SVT_HOOK_ENCODEPASS_VERIFY") != NULL;
+        g_ep_refs = getenv("SVT_HOOK_ENCODEPASS_REFS") != NULL;
         g_ep_state = getenv("SVT_HOOK_ENCODEPASS") ? 1 : -1;
     }
     if (g_ep_state < 0 || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
@@ -395,6 +505,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
                                      pcs, contextPtr->encDecTileIndex, lcuOriginX, lcuOriginY, lw, lh);
         __atomic_add_fetch(&g_ep_borders, 1, __ATOMIC_RELAXED);
         pthread_mutex_unlock(&e->lock);
+        picture_lcu_done(root, e, scs, pcs, tbAddr, 0);
         return;
     }
     /* source samples of the LCU */
@@ -443,6 +554,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     svt_hook_ep_active = 1;
     __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
     svt_hook_ep_active = 0;
+    picture_lcu_done(root, e, scs, pcs, tbAddr, 1);
 }
 
 void __wrap_PictureResidual(EB_U8 *input, EB_U32 inputStride, EB_U8 *pred, EB_U32 predStride, EB_S16 *residual, EB_U32 residualStride,
@@ -599,6 +711,9 @@ void svt_hook_encdec_report(FILE *out)
                  "reference code: %lu LCUs with units outside the device call, %lu under tools outside it, %lu in another sample format; %lu host LCU "
                  "borders handed over in %lu calls\n",
             g_ep_gpu, g_ep_inter_lcus, g_ep_inter_units, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts);
+    if (g_ep_refs)
+        fprintf(out, "svt_hook_me: encode pass: %lu reference pictures finished on the device, %lu left to the upload path (an LCU outside the device "
+                     "call, per-LCU SAO lambdas, or SAO without deblocking)\n", g_ep_refs_done, g_ep_refs_skipped);
     if (g_ep_verify)
         fprintf(out, "svt_hook_me: encode pass verification: %lu device-encoded LCUs compared with the reference's own EncodePass, %lu differ\n", g_ep_verified,
                 g_ep_mismatch);

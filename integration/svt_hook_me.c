@@ -1136,7 +1136,9 @@ EB_ERRORTYPE __real_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
                                               PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
                                               MotionCompensationPredictionContext_t *mcpContext);
 #define REF_CACHE 16
-static struct RefSlot { const void *buf; uint64_t poc, used; void *d[3]; size_t bytes[3]; SvtAmdRefPicture pic; } g_refs[REF_CACHE];
+static struct RefSlot { const void *buf; uint64_t poc, used; void *d[3]; size_t bytes[3]; SvtAmdRefPicture pic; int from_device; } g_refs[REF_CACHE];
+static unsigned long g_ref_from_device, g_ref_dev_checked, g_ref_dev_mismatch;
+static int g_ref_dev_verify = -1;
 static uint64_t g_ref_clock;
 static void *g_inter_scratch[3]; /* device prediction planes: 64x64, 32x32, 32x32 */
 static unsigned long g_inter_gpu, g_inter_uploads;
@@ -1151,6 +1153,28 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
     for (int i = 0; i < REF_CACHE; i++) {
         if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
             g_refs[i].used = ++g_ref_clock;
+            if (g_refs[i].from_device == 1) { /* produced on the device (svt_hook_register_device_reference): never uploaded.  The encoder has
+                                               * finished its own copy by now; SVT_HOOK_ENCODEPASS_REFS=verify compares the two once */
+                if (g_ref_dev_verify < 0) {
+                    const char *v = getenv("SVT_HOOK_ENCODEPASS_REFS");
+                    g_ref_dev_verify = v && !strcmp(v, "verify");
+                }
+                if (g_ref_dev_verify) {
+                    const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
+                    const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
+                    const uint8_t *src[3] = {p->bufferY, p->bufferCb, p->bufferCr};
+                    int bad = 0;
+                    for (int k = 0; k < 3; k++) {
+                        uint8_t *tmp = (uint8_t *)malloc(need[k]);
+                        if (!tmp || svt_amd_device_download(g_ctx, tmp, g_refs[i].d[k], need[k]))
+                            die("svt_amd_device_download (reference verification)");
+                        bad |= memcmp(tmp, src[k], need[k]) != 0;
+                        free(tmp);
+                    }
+                    g_ref_dev_checked++, g_ref_dev_mismatch += bad;
+                }
+                g_refs[i].from_device = 2;
+            }
             return &g_refs[i].pic;
         }
         if (g_refs[i].used < victim->used)
@@ -1170,12 +1194,56 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
         if (svt_amd_device_upload(g_ctx, victim->d[k], src[k], need[k]))
             die("svt_amd_device_upload");
     }
-    victim->buf = p->bufferY, victim->poc = poc, victim->used = ++g_ref_clock;
+    victim->buf = p->bufferY, victim->poc = poc, victim->used = ++g_ref_clock, victim->from_device = 0;
     victim->pic.d_y = victim->d[0], victim->pic.d_cb = victim->d[1], victim->pic.d_cr = victim->d[2];
     victim->pic.strideY = p->strideY, victim->pic.strideC = p->strideCb, victim->pic.originX = p->originX, victim->pic.originY = p->originY;
     victim->pic.width = p->width, victim->pic.height = p->height;
     g_inter_uploads++;
     return &victim->pic;
+}
+
+/* for the device-resident encode pass (svt_hook_encdec.c): a reference picture the DEVICE finished (encode pass -> deblocking -> SAO ->
+ * padding) enters the cache by a device-to-device copy; the encoder's own copy of it is never uploaded */
+void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, const SvtAmdRefPicture *dev)
+{
+    if (dev->strideY != p->strideY || dev->strideC != p->strideCb || dev->originX != p->originX || dev->originY != p->originY)
+        return; /* another padding geometry: the upload path serves it */
+    pthread_mutex_lock(&g_lock);
+    struct RefSlot *victim = &g_refs[0];
+    for (int i = 0; i < REF_CACHE; i++) {
+        if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
+            victim = &g_refs[i];
+            break;
+        }
+        if (g_refs[i].used < victim->used)
+            victim = &g_refs[i];
+    }
+    const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
+    const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
+    const void *src[3] = {dev->d_y, dev->d_cb, dev->d_cr};
+    for (int k = 0; k < 3; k++) {
+        if (victim->bytes[k] < need[k]) {
+            if (victim->d[k] && svt_amd_device_free(g_ctx, victim->d[k]))
+                die("svt_amd_device_free");
+            if (svt_amd_device_alloc(g_ctx, need[k], &victim->d[k]))
+                die("svt_amd_device_alloc");
+            victim->bytes[k] = need[k];
+        }
+        if (svt_amd_device_copy(g_ctx, victim->d[k], src[k], need[k]))
+            die("svt_amd_device_copy");
+    }
+    victim->buf = p->bufferY, victim->poc = poc, victim->used = ++g_ref_clock, victim->from_device = 1;
+    victim->pic.d_y = victim->d[0], victim->pic.d_cb = victim->d[1], victim->pic.d_cr = victim->d[2];
+    victim->pic.strideY = p->strideY, victim->pic.strideC = p->strideCb, victim->pic.originX = p->originX, victim->pic.originY = p->originY;
+    victim->pic.width = p->width, victim->pic.height = p->height;
+    g_ref_from_device++;
+    pthread_mutex_unlock(&g_lock);
+}
+void svt_hook_reference_report(FILE *out)
+{
+    if (g_ref_from_device)
+        fprintf(out, "svt_hook_me: %lu reference pictures finished on the device (encode pass -> deblocking -> SAO -> padding) and never uploaded; %lu "
+                     "compared with the encoder's own, %lu differ\n", g_ref_from_device, g_ref_dev_checked, g_ref_dev_mismatch);
 }
 
 /* for the device-resident encode pass (svt_hook_encdec.c): the reference pictures of both lists as device copies */
@@ -1537,6 +1605,8 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision(SaoStats_t *saoStats, SaoParameters_t 
                                           SaoParameters_t *leftSaoPtr, SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost,
                                           EB_S64 *saoChromaBestCost)
 {
+    if (svt_hook_ep_active)
+        svt_hook_ep_note_sao(pcs, tbOriginX, tbOriginY, md, fullLambda, fullChromaLambdaSao, mmSao, 0);
     if (g_sao_state == 0)
         g_sao_state = getenv("SVT_HOOK_SAO") ? 1 : -1;
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->enhancedPicturePtr;
@@ -1565,6 +1635,8 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
                                                EB_U32 lcuHeight, SaoParameters_t *saoPtr, SaoParameters_t *leftSaoPtr,
                                                SaoParameters_t *upSaoPtr, EB_S64 *saoLumaBestCost, EB_S64 *saoChromaBestCost)
 {
+    if (svt_hook_ep_active)
+        svt_hook_ep_note_sao(pcs, tbOriginX, tbOriginY, md, fullLambda, fullChromaLambdaSao, mmSao, 1);
     if (g_sao_state == 0)
         g_sao_state = getenv("SVT_HOOK_SAO") ? 1 : -1;
     const EbPictureBufferDesc_t *rec = pcs->ParentPcsPtr->isUsedAsReferenceFlag == EB_TRUE
@@ -1595,6 +1667,7 @@ static void hook_report(void)
     if (!out)
         return;
     svt_hook_encdec_report(out);
+    svt_hook_reference_report(out);
     if (g_n_timed)
         fprintf(out, "svt_hook_me: front-half timeline over %lu pictures: submit call %.3f ms, submit -> results on the host %.3f ms, lane held %.3f ms "
                      "(means); %lu waits for a free lane, %.1f ms in total\n", g_n_timed, 1e3 * g_t_submit_call / g_n_timed, 1e3 * g_t_device / g_n_timed,

@@ -405,6 +405,15 @@ extern "C" int svt_amd_device_upload(SvtAmdContext *ctx, void *d_dst, const void
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
 }
+extern "C" int svt_amd_device_copy(SvtAmdContext *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || !d_dst || !d_src)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
 extern "C" int svt_amd_device_download(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes)
 {
     if (!ctx || !dst || !d_src)

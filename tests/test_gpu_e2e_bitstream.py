@@ -423,3 +423,37 @@ def test_encode_pass_verification_mode_finds_no_difference(tmp_path, kind, w, h,
     compared, differ = int(m.group(1)), int(m.group(2))
     assert compared == S.lcu_count(w, h) * n and differ == 0, rep + "\n".join(ln for ln in log.splitlines() if "VERIFY" in ln)[:3000]
     assert re.search(r"one call each; (\d+) of them with inter units", rep) and int(re.search(r"one call each; (\d+) of them", rep).group(1)) > compared // 4, rep
+
+
+DEVICE_REF_CASES = [
+    ("motion", 640, 384, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"]),
+    ("motion", 416, 240, 8, ["-encMode", "6", "-pred-struct", "0", "-hierarchical-levels", "0", "-q", "36"]),
+    ("motion10", 640, 384, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-bit-depth", "10"]),
+    ("motion", 832, 480, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-tile_col_cnt", "2", "-tile_row_cnt", "2"]),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", DEVICE_REF_CASES)
+def test_reference_pictures_finished_on_the_device_inside_the_encoder(tmp_path, kind, w, h, n, args):
+    """SVT_HOOK_ENCODEPASS=1 SVT_HOOK_ENCODEPASS_REFS=verify: when the last LCU of a reference picture has been encoded on the device, the
+    device finishes the picture itself - deblocking, SAO (statistics in the encoder's order, decision, application), padding - and the
+    result IS the reference picture later pictures predict from (device-to-device into the reference cache, never uploaded).  Each one is
+    compared once with the reference picture the encoder finished on the host; the bitstream must stay byte-identical."""
+    import re
+    yuv = str(tmp_path / "clip.yuv")
+    (S.write_clip10 if kind.endswith("10") else S.write_clip)(yuv, kind[:-2] if kind.endswith("10") else kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
+    env = {"SVT_HOOK_ENCODEPASS": "1", "SVT_HOOK_ENCODEPASS_REFS": "verify", "SVT_HOOK_REPORT": str(tmp_path / "report.txt")}
+    os.environ.update(env)
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
+    finally:
+        for k in env:
+            del os.environ[k]
+    rep = open(str(tmp_path / "report.txt")).read()
+    m = re.search(r"(\d+) reference pictures finished on the device \(encode pass -> deblocking -> SAO -> padding\) and never uploaded; (\d+) compared "
+                  r"with the encoder's own, (\d+) differ", rep)
+    assert m, rep
+    made, compared, differ = (int(v) for v in m.groups())
+    assert made >= 2 and compared >= 1 and differ == 0, rep
+    assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
