@@ -348,7 +348,7 @@ void svt_hook_ep_note_sao(const PictureControlSet_t *pcs, EB_U32 x, EB_U32 y, co
 
 /* the last LCU of a picture is through and every LCU went through the device: finish the picture there (what EncDecKernel does on the host
  * afterwards, EbEncDecProcess.c:3040-3200: remaining deblocking, ApplySaoOffsetsPicture, PadRefAndSetFlags) and hand it to the reference cache */
-static void finish_picture_on_device(SvtAmdContext *lane, EpPictureEntry *e, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs)
+static void finish_picture_on_device(SvtAmdContext *lane, EpPictureEntry *e, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int mismatch)
 {
     const int wide = e->wide;
     if (!pcs->ParentPcsPtr->isUsedAsReferenceFlag)
@@ -359,7 +359,10 @@ static void finish_picture_on_device(SvtAmdContext *lane, EpPictureEntry *e, con
     }
     const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->ParentPcsPtr->referencePictureWrapperPtr->objectPtr;
     const EbPictureBufferDesc_t *rp = wide ? ro->referencePicture16bit : ro->referencePicture;
-    if (!scs->staticConfig.disableDlfFlag) {
+    /* allowEncDecMismatch (EbEncDecProcess.c:2036-2054: temporal layers > 0 at encMode >= 8, and at encMode 7 in 4K): the encoder neither
+     * deblocks (EbCodingLoop.c:3081) nor applies SAO (EbEncDecProcess.c:3085) on its side - its reference picture is the padded
+     * reconstruction as encoded */
+    if (!scs->staticConfig.disableDlfFlag && !mismatch) {
         SvtAmdDeblockParams prm;
         memset(&prm, 0, sizeof(prm));
         prm.tc_offset = pcs->tcOffset, prm.beta_offset = pcs->betaOffset, prm.cb_qp_offset = pcs->cbQpOffset, prm.cr_qp_offset = pcs->crQpOffset;
@@ -383,7 +386,8 @@ static void finish_picture_on_device(SvtAmdContext *lane, EpPictureEntry *e, con
 }
 
 /* one more LCU of the picture is through EncodePass (served from the device or not); the thread that brings the last one finishes the picture */
-static void picture_lcu_done(SvtAmdContext *root, EpPictureEntry *e, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, EB_U32 tbAddr, int served)
+static void picture_lcu_done(SvtAmdContext *root, EpPictureEntry *e, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, EB_U32 tbAddr, int served,
+                             int mismatch)
 {
     if (!g_ep_refs)
         return;
@@ -398,7 +402,7 @@ static void picture_lcu_done(SvtAmdContext *root, EpPictureEntry *e, const Seque
     pthread_mutex_unlock(&e->lock);
     if (last) {
         SvtAmdContext *lane = lane_claim(root);
-        finish_picture_on_device(lane, e, scs, pcs);
+        finish_picture_on_device(lane, e, scs, pcs, mismatch);
         lane_release(lane);
     }
 }
@@ -505,7 +509,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
                                      pcs, contextPtr->encDecTileIndex, lcuOriginX, lcuOriginY, lw, lh);
         __atomic_add_fetch(&g_ep_borders, 1, __ATOMIC_RELAXED);
         pthread_mutex_unlock(&e->lock);
-        picture_lcu_done(root, e, scs, pcs, tbAddr, 0);
+        picture_lcu_done(root, e, scs, pcs, tbAddr, 0, contextPtr->allowEncDecMismatch);
         return;
     }
     /* source samples of the LCU */
@@ -554,7 +558,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     svt_hook_ep_active = 1;
     __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
     svt_hook_ep_active = 0;
-    picture_lcu_done(root, e, scs, pcs, tbAddr, 1);
+    picture_lcu_done(root, e, scs, pcs, tbAddr, 1, contextPtr->allowEncDecMismatch);
 }
 
 void __wrap_PictureResidual(EB_U8 *input, EB_U32 inputStride, EB_U8 *pred, EB_U32 predStride, EB_S16 *residual, EB_U32 residualStride,

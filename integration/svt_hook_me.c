@@ -1168,7 +1168,22 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
                         uint8_t *tmp = (uint8_t *)malloc(need[k]);
                         if (!tmp || svt_amd_device_download(g_ctx, tmp, g_refs[i].d[k], need[k]))
                             die("svt_amd_device_download (reference verification)");
-                        bad |= memcmp(tmp, src[k], need[k]) != 0;
+                        if (memcmp(tmp, src[k], need[k])) {
+                            const uint32_t stride = k ? p->strideCb : p->strideY;
+                            size_t first = 0, count = 0;
+                            uint32_t x0 = ~0u, x1 = 0, y0 = ~0u, y1 = 0;
+                            for (size_t o = 0; o < need[k] / bps; o++)
+                                if (memcmp(tmp + o * bps, src[k] + o * bps, bps)) {
+                                    const uint32_t x = (uint32_t)(o % stride), y = (uint32_t)(o / stride);
+                                    if (!count++)
+                                        first = o;
+                                    x0 = x < x0 ? x : x0, x1 = x > x1 ? x : x1, y0 = y < y0 ? y : y0, y1 = y > y1 ? y : y1;
+                                }
+                            fprintf(stderr, "svt_hook_me: REFVERIFY poc %llu plane %d: %zu samples differ, first at (%zu,%zu), box x %u..%u y %u..%u (padded "
+                                            "coordinates, origin %u,%u)\n", (unsigned long long)poc, k, count, first % stride, first / stride, x0, x1, y0, y1,
+                                    k ? p->originX >> 1 : p->originX, k ? p->originY >> 1 : p->originY);
+                            bad = 1;
+                        }
                         free(tmp);
                     }
                     g_ref_dev_checked++, g_ref_dev_mismatch += bad;

@@ -45,6 +45,8 @@ CASES = {
     "sao_b_motion_320x192_m6": ("motion", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),
     "sao_tiles_motion_640x384_m7": ("motion", 640, 384, 2, 7, ["-encMode", "7", "-intra-period", "0", "-q", "33", "-tile_col_cnt", "2", "-tile_row_cnt", "2"]),
     "sao_p_noise_320x256_m8": ("noise", 320, 256, 3, 7, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "36"]),
+    # encMode 8: allowEncDecMismatch in temporal layers > 0 - those pictures are neither deblocked nor SAO-filtered on the encoder side
+    "sao_b_motion_320x192_m8": ("motion", 320, 192, 5, 9, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),
     "sao_i10_motion_320x192_m7": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "36", "-bit-depth", "10"]),
     # P / B pictures ("p_" / "b_" / "p10_" prefix: LCUs with inter units are recorded too, with the reference pictures they predict from and
     # the pictures' coefficient-rate tables; loop filters off as above).  Low delay P: uni-prediction, AMVP / merge / skip units, 64x64 units

@@ -430,6 +430,9 @@ DEVICE_REF_CASES = [
     ("motion", 416, 240, 8, ["-encMode", "6", "-pred-struct", "0", "-hierarchical-levels", "0", "-q", "36"]),
     ("motion10", 640, 384, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-bit-depth", "10"]),
     ("motion", 832, 480, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-tile_col_cnt", "2", "-tile_row_cnt", "2"]),
+    # encMode 9, 4 temporal layers: the reference pictures of layers 1 and 2 are "encoder / decoder mismatch" pictures (no deblocking, no
+    # SAO on the encoder side): the device finishes them as the encoder does
+    ("motion", 640, 384, 9, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "3"]),
 ]
 
 

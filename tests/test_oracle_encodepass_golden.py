@@ -209,6 +209,15 @@ def test_have_dlf_cases():
     assert len(DLF_CASES) >= 5 and sum("ref_pocs" in load_case(c)[0] for c in DLF_CASES) >= 2
 
 
+def allows_mismatch(g, w, h, work0):
+    """contextPtr->allowEncDecMismatch (Codec/EbEncDecProcess.c:2036-2054): in temporal layers > 0 at encMode >= 8 - and at encMode 7 in 4K - the
+    encoder neither deblocks (EbCodingLoop.c:3081) nor applies SAO (EbEncDecProcess.c:3085) on its side: its reconstruction / reference
+    picture is the picture as encoded (the SAO parameters are still decided, on that picture, and signalled)"""
+    args = g["enc_args"].tolist()
+    mode = int(args[args.index("-encMode") + 1])
+    return int(work0["temporal_layer"]) > 0 and (mode >= 8 or (mode == 7 and w * h > 1920 * 1080 * 2))
+
+
 def encode_and_deblock_pictures(oracle, name, g, w, h):
     """the chain on the CPU, picture by picture: encode pass of every LCU (checked against the records), boundary strengths from the unit
     lists, picture deblocking.  Yields (picture number, first record, works, results, un-deblocked planes, deblocked planes)."""
@@ -242,7 +251,8 @@ def encode_and_deblock_pictures(oracle, name, g, w, h):
                    bsv=np.zeros((nl, 256), np.uint8), bsh=np.zeros((nl, 256), np.uint8))
         pic["bsv"], pic["bsh"] = oracle_bs(oracle, pic)
         pic["pre"], pic["qp"] = rec, qp.reshape(-1)
-        yield f, first, g["work"][first:first + nl], got, rec, oracle_dlf(oracle, pic)
+        fin = [r.copy() for r in rec] if allows_mismatch(g, w, h, g["work"][first]) else oracle_dlf(oracle, pic)
+        yield f, first, g["work"][first:first + nl], got, rec, fin
 
 
 @pytest.mark.parametrize("name", DLF_CASES)
@@ -369,7 +379,7 @@ def test_encode_deblock_sao_oracle_matches_the_encoders_output(oracle, name):
             for i in idx:
                 assert same_decision(dec[i], want[i]), (name, f, int(i), dec[i], want[i])
             dec["edge_flags"] = params["edge_flags"]
-            out = oracle_sao(oracle, fin, 2 if wide else 1, w, h, dec, 1, 1)
+            out = fin if allows_mismatch(g, w, h, works[0]) else oracle_sao(oracle, fin, 2 if wide else 1, w, h, dec, 1, 1)
         for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
             bad = np.argwhere(out[p] != g[nm][f])
             assert len(bad) == 0, (name, f, nm, len(bad), bad[:4].tolist())

@@ -40,6 +40,8 @@ def run_app(app, yuv, w, h, n, args, out, env=None, timeout=900, nb=None):
     wall = time.perf_counter() - t0
     if r.returncode != 0:
         raise RuntimeError("encoder failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout[-1500:], r.stderr[-1500:]))
+    if os.environ.get("SVT_TOOLS_STDERR_TO") and app == HIP_APP:   # diagnosis: keep what the bindings wrote to stderr
+        open(os.environ["SVT_TOOLS_STDERR_TO"], "w").write(r.stderr)
     fps = None
     for line in r.stdout.splitlines():
         if "Average Speed" in line:
