@@ -1101,6 +1101,12 @@ SVT_AMD_API int svt_amd_encdec_picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPictu
 SVT_AMD_API int svt_amd_encdec_picture_sao16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works,
                                              const SvtAmdSaoDecisionParams *params, const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params,
                                              uint16_t *out_y, uint16_t *out_cb, uint16_t *out_cr);
+/* The parameter decision alone, on the picture object as it stands: after svt_amd_encdec_picture_deblock the encoder-order view as above;
+ * without it the picture as encoded - contextPtr->allowEncDecMismatch pictures (Codec/EbEncDecProcess.c:2036-2054: temporal layers > 0 at
+ * encMode >= 8, and at encMode 7 in 4K), which the reference neither deblocks nor SAO-filters on its side while it still decides (on the
+ * un-deblocked reconstruction) and signals the parameters.  works: SvtAmdLcuWork[] or SvtAmdLcuWork16[] by the picture's sample width. */
+SVT_AMD_API int svt_amd_encdec_picture_sao_decide(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const void *works,
+                                                  const SvtAmdSaoDecisionParams *params, const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params);
 /* The picture object's latest stage (after SAO, else deblocked, else as encoded) as a padded reference picture in HBM - PadRefAndSetFlags
  * (Codec/EbEncDecProcess.c:1805: GeneratePadding[16Bit], edge replication) - in the form svt_amd_encdec_picture_set_inter of a LATER picture
  * object takes: reference pictures never leave the device.  origin_x / origin_y: luma padding (the reference: LCU size + 16 = 80; even);

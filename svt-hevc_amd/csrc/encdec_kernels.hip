@@ -1098,12 +1098,12 @@ __global__ __launch_bounds__(256) void k_ep_sao_composite(const T *__restrict__ 
  * svt_amd_encdec_picture_deblock: what is left in the picture object (and copied out) is the encoder's finished reconstruction. */
 template <typename T>
 static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, const SvtAmdSaoDecisionParams *prm,
-                       const uint8_t *enable, SvtAmdSaoLcuParams *lcu_out, void *out_y, void *out_cb, void *out_cr)
+                       const uint8_t *enable, SvtAmdSaoLcuParams *lcu_out, void *out_y, void *out_cb, void *out_cr, bool apply)
 {
     typedef typename EpTypes<T>::Work WorkT;
     if (!ctx || !pic || !works || !prm || pic->d.bps != sizeof(T))
         return SVT_AMD_ERR_BAD_PARAM;
-    if (!pic->deblocked) {
+    if (!pic->deblocked && apply) {
         svt_amd_set_error("svt_amd_encdec_picture_sao: svt_amd_encdec_picture_deblock comes first");
         return SVT_AMD_ERR_BAD_PARAM;
     }
@@ -1119,7 +1119,7 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
         follow[i] = (uint8_t)(((i % wl) + 1 < wl && !works[i].tile_right ? 1 : 0) | (!bottom_edge ? 2 : 0));
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 3 && apply; k++)
         if (!pic->fin[k] && hipMalloc((void **)&pic->fin[k], pic->plane_bytes[k]) != hipSuccess)
             return SVT_AMD_ERR_RESOURCES;
     auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
@@ -1152,7 +1152,7 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     const int pY = (int)pic->d.pitch[0], pC = (int)pic->d.pitch[1];
     hipLaunchKernelGGL(k_ep_source_planes<T>, dim3(nlcu), dim3(256), 0, ctx->stream, (const WorkT *)d_works, (T *)d_src[0], (T *)d_src[1], (T *)d_src[2], pY, pC,
                        (int)w, (int)h);
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 3 && pic->deblocked; k++) {
         const int pw = k ? w / 2 : w, ph = k ? h / 2 : h;
         hipLaunchKernelGGL(k_ep_sao_composite<T>, dim3((pw + 255) / 256, ph), dim3(256), 0, ctx->stream, (const T *)pic->dbk[k], (const T *)pic->d.rec[k],
                            (T *)d_cmp[k], k ? pC : pY, pw, ph, k ? 5 : 6, (int)wl, (const uint8_t *)d_follow);
@@ -1161,26 +1161,26 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     /* GatherSaoStatisticsLcu* of the components the mode looks at (EbSampleAdaptiveOffsetGenerationDecision.c:647-760) */
     const int ncomp = prm->mm_sao ? 3 : (prm->temporal_layer < 2 ? 1 : 0);
     for (int k = 0; k < ncomp; k++)
-        if ((rc = svt_amd_sao_gather_picture(ctx, (int)sizeof(T), d_src[k], k ? pC : pY, d_cmp[k], k ? pC : pY, k ? w / 2 : w, k ? h / 2 : h, k ? 32 : 64,
-                                             prm->mm_sao ? 0 : 1, d_stats[k])) != 0)
-            return rc;
+        if ((rc = svt_amd_sao_gather_picture(ctx, (int)sizeof(T), d_src[k], k ? pC : pY, pic->deblocked ? (const void *)d_cmp[k] : (const void *)pic->d.rec[k],
+                                             k ? pC : pY, k ? w / 2 : w, k ? h / 2 : h, k ? 32 : 64, prm->mm_sao ? 0 : 1, d_stats[k])) != 0)
+            return rc; /* a picture that is never deblocked (decide-only call) is its own encoder-order view */
     if ((rc = svt_amd_sao_decide_picture(ctx, prm, d_stats[0], d_stats[1], d_stats[2], wl, hl, enable ? d_en : nullptr, d_par, d_cost)) != 0)
         return rc;
     const void *srcs[3] = {pic->dbk[0], pic->dbk[1], pic->dbk[2]};
     void *dsts[3] = {pic->fin[0], pic->fin[1], pic->fin[2]};
-    if ((rc = svt_amd_sao_apply_picture(ctx, (int)sizeof(T), srcs, dsts, pic->d.pitch[0], pic->d.pitch[1], w, h, d_par, 1, 1)) != 0)
+    if (apply && (rc = svt_amd_sao_apply_picture(ctx, (int)sizeof(T), srcs, dsts, pic->d.pitch[0], pic->d.pitch[1], w, h, d_par, 1, 1)) != 0)
         return rc;
     if (lcu_out)
         HIP_TRY(hipMemcpyAsync(lcu_out, d_par, sizeof(SvtAmdSaoLcuParams) * nlcu, hipMemcpyDeviceToHost, ctx->stream));
     void *outs[3] = {out_y, out_cb, out_cr};
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 3 && apply; k++)
         if (outs[k]) {
             const uint32_t pw = k ? w / 2 : w, ph = k ? h / 2 : h;
             HIP_TRY(hipMemcpy2DAsync(outs[k], (size_t)pw * sizeof(T), pic->fin[k], (size_t)pic->d.pitch[k] * sizeof(T), (size_t)pw * sizeof(T), ph,
                                      hipMemcpyDeviceToHost, ctx->stream));
         }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    pic->sao_done = true;
+    pic->sao_done = pic->sao_done || apply;
     return SVT_AMD_OK;
 }
 
@@ -1238,12 +1238,22 @@ extern "C" int svt_amd_encdec_picture_reference(SvtAmdContext *ctx, SvtAmdEncDec
 extern "C" int svt_amd_encdec_picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, const SvtAmdSaoDecisionParams *params,
                                           const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params, uint8_t *out_y, uint8_t *out_cb, uint8_t *out_cr)
 {
-    return picture_sao<uint8_t>(ctx, pic, works, params, enable, lcu_params, out_y, out_cb, out_cr);
+    return picture_sao<uint8_t>(ctx, pic, works, params, enable, lcu_params, out_y, out_cb, out_cr, true);
+}
+/* the parameter decision alone, on the picture object as it stands (deblocked: the encoder-order view; not deblocked: the picture as encoded -
+ * allowEncDecMismatch pictures, whose parameters the reference decides on its un-deblocked reconstruction and signals without applying them) */
+extern "C" int svt_amd_encdec_picture_sao_decide(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const void *works, const SvtAmdSaoDecisionParams *params,
+                                                 const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params)
+{
+    if (!pic || !lcu_params)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return pic->d.bps == 1 ? picture_sao<uint8_t>(ctx, pic, (const SvtAmdLcuWork *)works, params, enable, lcu_params, nullptr, nullptr, nullptr, false)
+                           : picture_sao<uint16_t>(ctx, pic, (const SvtAmdLcuWork16 *)works, params, enable, lcu_params, nullptr, nullptr, nullptr, false);
 }
 extern "C" int svt_amd_encdec_picture_sao16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, const SvtAmdSaoDecisionParams *params,
                                             const uint8_t *enable, SvtAmdSaoLcuParams *lcu_params, uint16_t *out_y, uint16_t *out_cb, uint16_t *out_cr)
 {
-    return picture_sao<uint16_t>(ctx, pic, works, params, enable, lcu_params, out_y, out_cb, out_cr);
+    return picture_sao<uint16_t>(ctx, pic, works, params, enable, lcu_params, out_y, out_cb, out_cr, true);
 }
 extern "C" int svt_amd_encdec_picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, const SvtAmdLcuResult *results,
                                               const SvtAmdDeblockParams *params, uint8_t *out_y, uint8_t *out_cb, uint8_t *out_cr)

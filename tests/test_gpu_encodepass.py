@@ -528,6 +528,15 @@ def test_encode_deblock_sao_on_the_device_matches_the_encoders_output(product, g
                 prm.ref_poc[0], prm.ref_poc[1] = int(g["ref_poc"][first][0]), int(g["ref_poc"][first][1])
             out = [np.zeros((h, w), sdt), np.zeros((h // 2, w // 2), sdt), np.zeros((h // 2, w // 2), sdt)]
             if allows_mismatch(g, w, h, works[0]):   # neither deblocked nor SAO-filtered on the encoder side: the output is the picture as encoded
+                P, enable, params, want, idx = sao_inputs_of_picture(g, f, works, w, h)
+                if P is not None:                   # ... but its SAO parameters are decided (on that picture) and signalled
+                    lib.svt_amd_encdec_picture_sao_decide.restype, lib.svt_amd_encdec_picture_sao_decide.argtypes = C.c_int, [C.c_void_p] * 6
+                    dec = np.zeros(nl, LCU)
+                    assert lib.svt_amd_encdec_picture_sao_decide(gpu_ctx, pic, works.ctypes.data, P.ctypes.data, enable.ctypes.data, dec.ctypes.data) == 0, \
+                        lib.svt_amd_last_error()
+                    for i in idx:
+                        assert same_decision(dec[i], want[i]), (name, f, int(i), dec[i], want[i])
+                    decided += len(idx)
                 out = encoded_picture(lib, gpu_ctx, pic, w, h, sdt)
                 for p, nm in enumerate(("recon_y", "recon_cb", "recon_cr")):
                     assert np.array_equal(out[p], g[nm][f]), (name, f, nm)
