@@ -1001,7 +1001,10 @@ typedef struct SvtAmdLcuWork {
     uint32_t full_lambda;          /* contextPtr->fullLambda of the LCU (EncDecConfigureLcu, EbEncDecProcess.c:1448): inter units  */
     uint32_t luma_cbf_bits[4];     /* mdRateEstimationPtr->lumaCbfBits[ctx], [ctx + (NUMBER_OF_CBF_CASES >> 1)] for ctx 0, 1:
                                     * {zero cbf ctx 0, zero cbf ctx 1, non-zero ctx 0, non-zero ctx 1} (EncodeTuCalcCost)         */
-    uint8_t pad2[12];
+    uint8_t pm_core;               /* contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE (encMode 1..4): the quantiser of every unit is
+                                    * DecoupledQuantizeInvQuantizeLoops (Codec/EbTransforms.c:3009-3052): no dead-zone override, luma levels
+                                    * re-decided per 4x4 block by SSE + full_lambda * rate (needs the picture's rate tables)           */
+    uint8_t pad2[11];
     SvtAmdLcuCu cu[SVT_AMD_LCU_MAX_CUS];
     uint8_t src_y[64 * 64], src_cb[32 * 32], src_cr[32 * 32]; /* source samples of the LCU (enhancedPicturePtr), pitch 64 / 32 */
 } SvtAmdLcuWork;
@@ -1027,7 +1030,8 @@ typedef struct SvtAmdLcuWork16 {
     uint8_t pad[4];
     uint32_t full_lambda;
     uint32_t luma_cbf_bits[4];
-    uint8_t pad2[12];
+    uint8_t pm_core;
+    uint8_t pad2[11];
     SvtAmdLcuCu cu[SVT_AMD_LCU_MAX_CUS];
     uint16_t src_y[64 * 64], src_cb[32 * 32], src_cr[32 * 32];
 } SvtAmdLcuWork16;
@@ -1042,7 +1046,8 @@ SVT_AMD_API int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t luma_
 SVT_AMD_API int svt_amd_encdec_picture_begin(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic); /* new picture: nothing coded yet */
 /* P / B pictures: the picture-level inputs of the inter units (EncodePassInterPrediction reads pictureControlSetPtr->refPicPtrArray[list],
  * Codec/EbInterPrediction.c:761; TuEstimateCoeffBitsEncDec reads pictureControlSetPtr->cabacCost, EbCodingLoop.c:4103) - reference
- * pictures of list 0 / 1 (DEVICE planes, whole padded buffers of the picture's size and sample width; either may be NULL) and the
+ * pictures of list 0 / 1 (DEVICE planes, whole padded buffers of the picture's size and sample width; either or - for an I picture that only
+ * needs the rate tables, SvtAmdLcuWork.pm_core - both may be NULL) and the
  * coefficient-rate tables (HOST pointer, copied on the context's stream).  Call before the first LCU with inter units; holds until the
  * next call for this picture object. */
 SVT_AMD_API int svt_amd_encdec_picture_set_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRefPicture *ref0,

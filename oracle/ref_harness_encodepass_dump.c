@@ -77,10 +77,8 @@ _Static_assert(sizeof(SvtAmdCabacCost) == sizeof(CabacCost_t), "CabacCost_t layo
 static void dump_inter_inputs(const PictureControlSet_t *pcs, int is16bit, uint64_t ref_poc[2])
 {
     ref_poc[0] = ref_poc[1] = ~0ull;
-    if (pcs->sliceType == EB_I_PICTURE)
-        return;
     pthread_mutex_lock(&g_lock);
-    for (int l = 0; l < (pcs->sliceType == EB_B_PICTURE ? 2 : 1); l++) {
+    for (int l = 0; l < (pcs->sliceType == EB_B_PICTURE ? 2 : pcs->sliceType == EB_P_PICTURE ? 1 : 0); l++) {
         const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
         const EbPictureBufferDesc_t *b = is16bit ? ro->referencePicture16bit : ro->referencePicture;
         ref_poc[l] = ro->refPOC;
@@ -120,14 +118,15 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
      * (EbCodingLoop.c:3161, :2377, EbEncDecProcess.c:2211) */
     const EB_BOOL useDeltaQp = (EB_BOOL)(scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled);
     const int inter_ok = !useDeltaQp && !contextPtr->fastEl && lcuPtr->chromaEncodeMode != CHROMA_MODE_BEST;
-    if (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ)
-        return 0; /* encMode <= 4: the quantiser is DecoupledQuantizeInvQuantizeLoops (EbTransforms.c:3009-3052) */
+    if (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE)
+        return 0; /* RDOQ (encMode 0) */
     memset(w, 0, sizeof(*w));
     w->lcu_x = (uint16_t)lcuOriginX, w->lcu_y = (uint16_t)lcuOriginY;
     w->slice_type = (uint8_t)pcs->sliceType, w->temporal_layer = pcs->temporalLayerIndex;
     w->constrained_intra = pcs->constrainedIntraFlag, w->strong_smoothing = scs->enableStrongIntraSmoothing;
     w->tile_left = lcuPtr->lcuEdgeInfoPtr->tileLeftEdgeFlag, w->tile_top = lcuPtr->lcuEdgeInfoPtr->tileTopEdgeFlag;
     w->tile_right = lcuPtr->lcuEdgeInfoPtr->tileRightEdgeFlag;
+    w->pm_core = contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE; /* encMode 1..4: DecoupledQuantizeInvQuantizeLoops (EbTransforms.c:3009-3052) */
     EB_U32 cuItr = 0, n = 0;
     while (cuItr < CU_MAX_COUNT) {
         const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[cuItr];

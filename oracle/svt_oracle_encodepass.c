@@ -36,6 +36,27 @@ static int rd(const void *p, size_t i, int bps) { return bps == 1 ? ((const uint
 /* rec[3]: un-deblocked reconstruction planes of the picture (pitch in samples, bps bytes per sample), updated in place; map: one byte
  * per 4x4 luma block (0xFF = not coded yet), updated in place.  bps 1: W / R are SvtAmdLcuWork / SvtAmdLcuResult; bps 2 (EncodePass
  * with is16bit, EncodeLoop16bit :1244: 10-bit samples, quantiser at qp + QP_BD_OFFSET :1307): SvtAmdLcuWork16 / SvtAmdLcuResult16. */
+/* the encode pass's quantiser of one unit: UnifiedQuantizeInvQuantize, or with SvtAmdLcuWork.pm_core its EB_PMCORE branch
+ * (DecoupledQuantizeInvQuantizeLoops, Codec/EbTransforms.c:3009-3052; svt_oracle_pmcore_quantize, pinned by tests/test_oracle_uqiq_golden.py) */
+static void ep_quantize(int bps, const SvtAmdLcuWork *W, const SvtAmdLcuCu *cu, int p, int n, const SvtAmdCabacCost *cost, const int16_t *coeff, int16_t *q,
+                        int16_t *r, uint32_t *nz)
+{
+    const uint8_t qp = (uint8_t)((p ? cu->chroma_qp : cu->qp) + (bps == 2 ? 12 : 0));
+    if (W->pm_core) {
+        SvtAmdPmQuantUnit U;
+        memset(&U, 0, sizeof(U));
+        U.size = (uint8_t)n, U.qp = qp, U.bit_depth = bps == 1 ? 8 : 10, U.slice_type = W->slice_type, U.component = p ? 1 : 0;
+        U.cand_type = cu->pred_mode, U.lambda = W->full_lambda;
+        svt_oracle_pmcore_quantize(cost, &U, coeff, q, r, nz);
+        return;
+    }
+    SvtAmdQuantUnit U;
+    memset(&U, 0, sizeof(U));
+    U.size = (uint8_t)n, U.qp = qp, U.bit_depth = bps == 1 ? 8 : 10;
+    U.slice_type = W->slice_type, U.component = p ? 1 : 0, U.temporal_layer = W->temporal_layer, U.dz_offset = p ? 0 : cu->dz_offset;
+    svt_oracle_unified_quantize(&U, coeff, (uint32_t)n, q, r, nz);
+}
+
 static int ilog2i(int v)
 {
     int l = 0;
@@ -78,12 +99,8 @@ static void encode_inter_cu(int bps, void *const rec[3], const uint32_t pitch[3]
                 for (int i = 0; i < n; i++)
                     res[j * n + i] = (int16_t)(rd(srcp[p], (size_t)(ly + j) * sp + lx + i, bps) - rd(dp, (size_t)j * pitch[p] + i, bps));
             svt_oracle_FwdTransform(n >= 16 ? 1 : 0, n, res, (uint32_t)n, coeff, (uint32_t)n, NULL, bps == 1 ? 0 : 2);
-            SvtAmdQuantUnit U;
-            memset(&U, 0, sizeof(U));
-            U.size = (uint8_t)n, U.qp = (uint8_t)((p ? cu->chroma_qp : cu->qp) + (bps == 2 ? 12 : 0)), U.bit_depth = bps == 1 ? 8 : 10;
-            U.slice_type = W->slice_type, U.component = p ? 1 : 0, U.temporal_layer = W->temporal_layer, U.dz_offset = p ? 0 : cu->dz_offset;
             uint32_t nz = 0;
-            svt_oracle_unified_quantize(&U, coeff, (uint32_t)n, q, r, &nz);
+            ep_quantize(bps, W, cu, p, n, cost, coeff, q, r, &nz);
             const int only_dc = nz == 1 && r[0] != 0 && !(p == 0 && n == 32);
             int cbf = nz != 0;
             if (p == 0 && cu->inter_kind == SVT_AMD_EP_INTER_AMVP) {
@@ -123,6 +140,8 @@ static void encode_lcu(int bps, void *const rec[3], const uint32_t pitch[3], uin
                        const SvtAmdLcuWork *W, const void *const srcp[3], SvtAmdLcuCuResult *Rcu, int16_t *const coeffp[3], void *const recout[3],
                        const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost)
 {
+    if (W->pm_core && !cost)
+        return;
     for (int ci = 0; ci < W->num_cus; ci++) {
         const SvtAmdLcuCu *cu = &W->cu[ci];
         const int N = cu->size, x0 = W->lcu_x + cu->x, y0 = W->lcu_y + cu->y;
@@ -169,12 +188,8 @@ static void encode_lcu(int bps, void *const rec[3], const uint32_t pitch[3], uin
                 for (int i = 0; i < n; i++)
                     res[j * n + i] = (int16_t)(rd(srcp[p], (size_t)(ly + j) * sp + lx + i, bps) - rd(d[p], (size_t)j * pitch[p] + i, bps));
             svt_oracle_FwdTransform(n >= 16 ? 1 : 0, n, res, (uint32_t)n, coeff, (uint32_t)n, NULL, bps == 1 ? 0 : 2);
-            SvtAmdQuantUnit U;
-            memset(&U, 0, sizeof(U));
-            U.size = (uint8_t)n, U.qp = (uint8_t)((p ? cu->chroma_qp : cu->qp) + (bps == 2 ? 12 : 0)), U.bit_depth = bps == 1 ? 8 : 10;
-            U.slice_type = W->slice_type, U.component = p ? 1 : 0, U.temporal_layer = W->temporal_layer, U.dz_offset = p ? 0 : cu->dz_offset;
             uint32_t nz = 0;
-            svt_oracle_unified_quantize(&U, coeff, (uint32_t)n, q, r, &nz);
+            ep_quantize(bps, W, cu, p, n, cost, coeff, q, r, &nz);
             /* tuPtr->isOnlyDc (EbCodingLoop.c:792, 879, 1000) */
             const int only_dc = nz == 1 && r[0] != 0 && !(p == 0 && n == 32);
             if (nz)

@@ -32,6 +32,7 @@
 #include <mutex>
 #include "intra_device.h"
 #include "rate_device.h"
+#include "pmcore_device.h"
 
 struct EpRefPlanes {               /* one reference picture (SvtAmdRefPicture): device pointers to the START of the padded planes */
     const void *plane[3];
@@ -60,7 +61,7 @@ struct SvtAmdEncDecPicture {
     unsigned epoch;
     int nlcu;
     SvtAmdCabacCost *d_cost;
-    bool has_ref[2];
+    bool has_ref[2], has_cost;
     /* the in-loop filters behind the encode pass: the deblocked picture and the picture after SAO live beside the un-deblocked one (the SAO
      * statistics need both, svt_amd_encdec_picture_sao); same pitches as rec[] */
     uint8_t *dbk[3], *fin[3];
@@ -128,6 +129,7 @@ struct EpFlags {
     bool tile_left, tile_top, tile_right, constrained_intra, strong_smoothing;
     int slice_type, lcu_x, lcu_y;
     uint32_t full_lambda, cbf_bits[4];
+    bool pm_core;
 };
 
 /* scratch of one plane pipeline's motion compensation: a tile of up to 32x32 samples at a time */
@@ -360,6 +362,12 @@ struct EpDecide {
     const SvtAmdCabacCost *cost;
     int16_t *qbuf;                 /* LDS, N x N: the quantised coefficients of the unit for the rate estimator */
     uint32_t lambda, zero_bits, nonzero_bits; /* fullLambda, lumaCbfBits[ctx], lumaCbfBits[ctx + 5] */
+    /* the PM-core quantiser of encMode 1..4 (UnifiedQuantizeInvQuantize with rdoqPmCoreMethod == EB_PMCORE -> DecoupledQuantizeInvQuantizeLoops,
+     * Codec/EbTransforms.c:3009-3052, :2605-2973): no dead-zone override; luma levels re-decided per 4x4 block (pmcore_device.h) */
+    bool pm_core;
+    int cand_type;                 /* predictionModeFlag of the unit */
+    int16_t *cfbuf;                /* LDS, N x N: the unit's coefficients for the re-decision */
+    int16_t (*Pq)[16];             /* LDS, 64 x 16: its per-lane scratch */
 };
 
 /* Returns (every lane) nz | only_dc << 16 | cbf << 17. */
@@ -390,11 +398,11 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int lane, int r, bool active,
     const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
     const int tshift = 15 - depth - LG, shiftedQBits = 14 + qpPer + tshift;
     const uint32_t q_offset = ((slice_type == 2 || slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
-    const uint32_t offs = dz_offset ? (uint32_t)(dz_offset * (1u << shiftedQBits) / 20) : q_offset;
+    const uint32_t offs = (dz_offset && !dec.pm_core) ? (uint32_t)(dz_offset * (1u << shiftedQBits) / 20) : q_offset;
     const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
     const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
     unsigned nz = 0;
-    int c[N];
+    int c[N], q[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
         const int v = x[j], sign = v < 0 ? -1 : 1;
@@ -402,17 +410,46 @@ __device__ __forceinline__ uint32_t ep_encode_unit(int lane, int r, bool active,
         tq = (int)((uint32_t)tq * QF);
         tq = (int)((uint32_t)tq + offs);
         tq >>= shiftedQBits;
-        const int qv = clip16i(sign * tq);
-        c[j] = clip16i(((qv * shiftedFFunc) + iq_offset) >> shiftNum);
-        nz += (active && qv != 0);
-        if (active)
-            coeff[j * coeffPitch + r] = (int16_t)qv;
-        if (N >= 8 && decide && active)
-            dec.qbuf[j * N + r] = (int16_t)qv;
+        q[j] = clip16i(sign * tq);
+        nz += (active && q[j] != 0);
     }
 #pragma unroll
     for (int o = 1; o < N; o <<= 1)
         nz += __shfl_xor(nz, o);
+    if constexpr (N >= 8) {
+        if (dec.pm_core && luma) { /* wave-uniform: the 4x4 blocks of the unit on all 64 lanes (a 32x32 unit has 64 of them) */
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < N; j++)
+                    dec.cfbuf[j * N + r] = (int16_t)x[j], dec.qbuf[j * N + r] = (int16_t)q[j];
+            }
+            EP_WAVE_SYNC();
+            if (__shfl((int)nz, 0) != 0) {
+                FlUnit Q;
+                Q.active = 1, Q.base = 0, Q.pitch = N, Q.area = N, Q.lg = LG;
+                Q.QF = QF, Q.q_offset = q_offset, Q.shiftedQBits = shiftedQBits, Q.shiftedFFunc = shiftedFFunc, Q.iq_offset = iq_offset, Q.shiftNum = shiftNum;
+                pm_core_blocks<64>(*dec.cost, dec.cfbuf, dec.qbuf, N, N, LG, lane, true, lane, dec.cand_type, dec.lambda, Q, dec.Pq);
+                EP_WAVE_SYNC();
+                nz = 0;
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < N; j++)
+                        q[j] = dec.qbuf[j * N + r], nz += q[j] != 0;
+                }
+#pragma unroll
+                for (int o = 1; o < N; o <<= 1)
+                    nz += __shfl_xor(nz, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        c[j] = clip16i(((q[j] * shiftedFFunc) + iq_offset) >> shiftNum);
+        if (active)
+            coeff[j * coeffPitch + r] = (int16_t)q[j];
+        if (N >= 8 && decide && active)
+            dec.qbuf[j * N + r] = (int16_t)q[j];
+    }
     const int dc_rec = __shfl(c[0], 0); /* the de-quantised coefficient (0,0): lane 0 holds column 0 */
     /* tuPtr->isOnlyDc (EbCodingLoop.c:792, 879, 1000): one coefficient, at DC, and no 32x32 luma unit */
     const bool only_dc = nz == 1 && dc_rec != 0 && !(luma && N == 32);
@@ -501,7 +538,9 @@ struct EpShared {
     int16_t border[3][132], ref[3][132];       /* per plane pipeline */
     int16_t tiles[3][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N */
     EpMcScratch<T> mc[3];                      /* inter units */
-    int16_t qbuf[32 * 32];                     /* luma cbf decision of AMVP units */
+    int16_t qbuf[32 * 32];                     /* luma cbf decision of AMVP units; levels of the PM-core re-decision */
+    int16_t cfbuf[32 * 32];                    /* PM-core: the luma unit's coefficients */
+    int16_t Pq[64][16];                        /* PM-core: per-lane scratch of the 4x4 rate estimate */
 };
 
 /* the coding-unit loop of one LCU, by one workgroup of 256 threads */
@@ -547,7 +586,8 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
         ((uint32_t *)L.cus)[i] = ((const uint32_t *)W.cu)[i];
     const int num_cus = W.num_cus;
     const EpFlags F = {W.tile_left != 0, W.tile_top != 0, W.tile_right != 0, W.constrained_intra != 0, W.strong_smoothing != 0, (int)W.slice_type,
-                       (int)W.lcu_x,     (int)W.lcu_y,    W.full_lambda,     {W.luma_cbf_bits[0], W.luma_cbf_bits[1], W.luma_cbf_bits[2], W.luma_cbf_bits[3]}};
+                       (int)W.lcu_x,     (int)W.lcu_y,    W.full_lambda,     {W.luma_cbf_bits[0], W.luma_cbf_bits[1], W.luma_cbf_bits[2], W.luma_cbf_bits[3]},
+                       W.pm_core != 0};
     __syncthreads();
     if (wave < 3) { /* wave p = plane p: its own pipeline over the unit list (luma is the long one) */
         const int p = wave;
@@ -560,7 +600,8 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
                     c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
                 const int ntu = N == 64 ? 4 : 1, TS = N == 64 ? 32 : N, n = p ? TS >> 1 : TS;
                 const bool amvp = cu.inter_kind == SVT_AMD_EP_INTER_AMVP;
-                const EpDecide D = {P.cost, S.qbuf, F.full_lambda, N == TS ? F.cbf_bits[1] : F.cbf_bits[0], N == TS ? F.cbf_bits[3] : F.cbf_bits[2]};
+                const EpDecide D = {P.cost, S.qbuf, F.full_lambda, N == TS ? F.cbf_bits[1] : F.cbf_bits[0], N == TS ? F.cbf_bits[3] : F.cbf_bits[2],
+                                    F.pm_core,      1,      S.cfbuf,       S.Pq};
                 uint32_t any = 0;
                 for (int tu = 0; tu < ntu; tu++) {
                     const int tx = cu.x + ((tu & 1) << 5), ty = cu.y + ((tu >> 1) << 5);
@@ -591,7 +632,8 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
                 int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
                 const uint32_t o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[p],
                                                       (p ? cu.chroma_qp : cu.qp) + (sizeof(T) == 2 ? 12 : 0) /* QP_BD_OFFSET, EbCodingLoop.c:1307 */,
-                                                      F.slice_type, p ? 0u : cu.dz_offset, p == 0);
+                                                      F.slice_type, p ? 0u : cu.dz_offset, p == 0, false,
+                                                      EpDecide{P.cost, S.qbuf, F.full_lambda, 0u, 0u, F.pm_core, 2, S.cfbuf, S.Pq});
                 if (lane == 0) {
                     R.cu[ci].nz[p] = (uint16_t)(o & 0xffff);
                     R.cu[ci].cbf[p] = (o & 0xffff) != 0;
@@ -792,8 +834,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
 extern "C" int svt_amd_encdec_picture_set_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRefPicture *ref0,
                                                 const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost)
 {
-    if (!ctx || !pic || (!ref0 && !ref1) || !cost)
-        return SVT_AMD_ERR_BAD_PARAM;
+    if (!ctx || !pic || !cost)
+        return SVT_AMD_ERR_BAD_PARAM; /* no reference picture at all: an I picture that needs the rate tables (PM-core quantiser) */
     const SvtAmdRefPicture *refs[2] = {ref0, ref1};
     for (int l = 0; l < 2; l++) {
         const SvtAmdRefPicture *r = refs[l];
@@ -814,6 +856,7 @@ extern "C" int svt_amd_encdec_picture_set_inter(SvtAmdContext *ctx, SvtAmdEncDec
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, ctx->stream)); /* pageable source: staged before the call returns */
+    pic->has_cost = true;
     return SVT_AMD_OK;
 }
 
@@ -826,6 +869,10 @@ static int ep_validate(const SvtAmdEncDecPicture *pic, const WorkT *works, int n
         if (works[i].num_cus > SVT_AMD_LCU_MAX_CUS || works[i].lcu_x >= pic->d.width || works[i].lcu_y >= pic->d.height || (works[i].lcu_x & 63) ||
             (works[i].lcu_y & 63)) {
             svt_amd_set_error("%s: bad LCU %d", who, i);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        if (works[i].pm_core && !pic->has_cost) {
+            svt_amd_set_error("%s: LCU %d asks for the PM-core quantiser without the picture's rate tables (svt_amd_encdec_picture_set_inter)", who, i);
             return SVT_AMD_ERR_BAD_PARAM;
         }
         for (int c = 0; c < works[i].num_cus; c++) {

@@ -27,6 +27,10 @@ CASES = {
     # 10-bit encodes (EncodePass with is16bit: EncodeLoop16bit, 16-bit intra prediction, quantiser at qp + 12): "10" in the clip kind
     "i10_motion_416x240_m9": ("motion10", 416, 240, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "30", "-bit-depth", "10"]),
     "i10_noise_200x136_m6": ("noise10", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "24", "-bit-depth", "10"]),
+    # encMode 3 / 4: the encode pass quantises with PM-core (DecoupledQuantizeInvQuantizeLoops: luma levels re-decided per 4x4 block by SSE +
+    # lambda * rate; "cost" = the picture's rate tables)
+    "i_motion_416x240_m4": ("motion", 416, 240, 1, 7, ["-encMode", "4", "-intra-period", "0", "-q", "30"]),
+    "i10_noise_200x136_m3": ("noise10", 200, 136, 1, 11, ["-encMode", "3", "-intra-period", "0", "-q", "28", "-bit-depth", "10"]),
     "i10_motion_320x192_m7_q45": ("motion10", 320, 192, 1, 7, ["-encMode", "7", "-intra-period", "0", "-q", "45", "-bit-depth", "10"]),
     # deblocking ON (the encoder's default), SAO off: the encoder's reconstruction output is then the deblocked picture, the
     # fixture for encode pass -> boundary strengths -> deblocking chained on the device ("dlf_" prefix: `recon_*` planes are kept,
@@ -62,6 +66,8 @@ CASES = {
     # 10-bit random access: 16-bit bi-prediction (BiPredClipping16bit), non-reference B pictures
     "b10_motion_320x192_m6": ("motion10", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "30",
                                                           "-bit-depth", "10"]),
+    "p_motion_416x240_m3": ("motion", 416, 240, 3, 7, ["-encMode", "3", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "28"]),
+    "b_noise_320x192_m4": ("noise", 320, 192, 5, 13, ["-encMode", "4", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "40"]),
     "p10_motion_320x192_m7": ("motion10", 320, 192, 3, 7, ["-encMode", "7", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "32", "-bit-depth", "10"]),
 }
 
@@ -129,6 +135,8 @@ def run_case(name):
     if sao:   # one decision record per LCU the encode pass ran the decision for (LCUs it shut SAO off for have none)
         assert (sao_recs["magic"] == 0x44414f53).all()
         extra["sao"] = sao_recs[np.lexsort((sao_recs["origin_x"], sao_recs["origin_y"], sao_recs["picture_number"]))]
+    if costs and not inter:   # intra fixtures of the PM-core presets carry the pictures' rate tables too
+        extra.update(cost_pictures=np.array(sorted(costs), np.uint64), cost=np.stack([costs[k] for k in sorted(costs)]))
     nl = S.lcu_count(w, h)
     order = np.lexsort((recs["lcu_index"], recs["picture_number"]))
     recs = recs[order]

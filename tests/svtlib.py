@@ -348,7 +348,7 @@ LCU_CU_DTYPE = np.dtype([("x", "u1"), ("y", "u1"), ("size", "u1"), ("pred_mode",
                          ("mv", "<i2", (2, 2))])
 LCU_WORK_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("num_cus", "u1"), ("slice_type", "u1"), ("temporal_layer", "u1"),
                            ("constrained_intra", "u1"), ("strong_smoothing", "u1"), ("tile_left", "u1"), ("tile_top", "u1"), ("tile_right", "u1"),
-                           ("pad", "u1", 4), ("full_lambda", "<u4"), ("luma_cbf_bits", "<u4", 4), ("pad2", "u1", 12), ("cu", LCU_CU_DTYPE, 64),
+                           ("pad", "u1", 4), ("full_lambda", "<u4"), ("luma_cbf_bits", "<u4", 4), ("pm_core", "u1"), ("pad2", "u1", 11), ("cu", LCU_CU_DTYPE, 64),
                            ("src_y", "u1", 4096), ("src_cb", "u1", 1024), ("src_cr", "u1", 1024)])
 LCU_CU_RESULT_DTYPE = np.dtype([("cbf", "u1", 3), ("only_dc", "u1", 3), ("nz", "<u2", 3)])
 LCU_RESULT_DTYPE = np.dtype([("cu", LCU_CU_RESULT_DTYPE, 64), ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024),

@@ -53,6 +53,7 @@ def test_encode_lcus_matches_reference_records(product, gpu_ctx, name, order):
     assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if is16(g) else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
         for first in range(0, len(g["work"]), nl):
+            set_inter(lib, gpu_ctx, pic, g, {}, first)      # PM-core presets: the picture's rate tables
             assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
             batches = [[i] for i in range(nl)] if order == "raster" else list(wavefront_batches(wl, hl))
             assert sorted(i for b in batches for i in b) == list(range(nl))
@@ -93,6 +94,7 @@ def test_host_encoded_lcus_enter_the_device_picture(product, gpu_ctx, name, host
     pic = C.c_void_p()
     assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if is16(g) else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
+        set_inter(lib, gpu_ctx, pic, g, {}, 0)      # PM-core presets: the picture's rate tables
         assert lib.svt_amd_encdec_picture_begin(gpu_ctx, pic) == 0
         ndev = 0
         for k in range(nl):
@@ -322,6 +324,7 @@ def test_encode_picture_one_call_matches_reference_records(product, gpu_ctx, nam
     assert lib.svt_amd_encdec_picture_create(gpu_ctx, w, h, 2 if wide else 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
     try:
         for first in range(0, len(g["work"]), nl):
+            set_inter(lib, gpu_ctx, pic, g, {}, first)      # PM-core presets: the picture's rate tables
             works = np.ascontiguousarray(g["work"][first:first + nl])
             got = np.zeros(nl, S.LCU_RESULT16_DTYPE if wide else S.LCU_RESULT_DTYPE)
             for rep in range(2):    # twice: the completion flags of the first call must not satisfy the second
@@ -391,9 +394,10 @@ def device_refs(g, wide):
 def set_inter(lib, ctx, pic, g, refs, k):
     lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
     lib.svt_amd_encdec_picture_set_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    r0, r1 = (refs.get(int(v)) for v in g["ref_poc"][k])
-    if not r0 and not r1:
-        return            # an I picture of a whole-sequence fixture
+    r0, r1 = (refs.get(int(v)) for v in g["ref_poc"][k]) if "ref_poc" in g else (None, None)
+    if "cost" not in g or int(g["picture_number"][k]) not in g["cost_pictures"].tolist():
+        assert not r0 and not r1
+        return            # an I picture without rate tables (only the PM-core presets record them for I pictures)
     cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(int(g["picture_number"][k]))])
     assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None, cost.ctypes.data) == 0, \
         lib.svt_amd_last_error()

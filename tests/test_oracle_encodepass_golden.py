@@ -18,7 +18,11 @@ DLF_CASES = [c for c in ALL if c.startswith("dlf_")]        # deblocking on, SAO
 
 
 def load_case(name):
-    g = np.load(os.path.join(S.GOLDEN_DIR, "encodepass_%s.npz" % name))
+    z = np.load(os.path.join(S.GOLDEN_DIR, "encodepass_%s.npz" % name))
+    g = {k: z[k] for k in z.files}
+    # the records in the CURRENT field names of the contract (fixtures written before a pad byte got a name have the same bytes)
+    wide = g["work"].dtype.itemsize == S.LCU_WORK16_DTYPE.itemsize
+    g["work"] = np.ascontiguousarray(g["work"]).view(S.LCU_WORK16_DTYPE if wide else S.LCU_WORK_DTYPE)
     w, h = int(g["clip"][1]), int(g["clip"][2])
     return g, w, h
 
@@ -90,9 +94,13 @@ def test_fixture_is_what_the_contract_says(name):
 @pytest.mark.parametrize("name", CASES)
 def test_encode_lcu_oracle_matches_reference(oracle, name):
     g, w, h = load_case(name)
-    fn = oracle.svt_oracle_encode_lcu16 if is16(g) else oracle.svt_oracle_encode_lcu
-    fn.restype = None
-    fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    pm = bool(g["work"]["pm_core"].any())        # PM-core presets: the quantiser reads the picture's rate tables
+    if pm:
+        fn = inter_oracle_fn(oracle, is16(g))
+    else:
+        fn = oracle.svt_oracle_encode_lcu16 if is16(g) else oracle.svt_oracle_encode_lcu
+        fn.restype = None
+        fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     sdt, rdt = (np.uint16, S.LCU_RESULT16_DTYPE) if is16(g) else (np.uint8, S.LCU_RESULT_DTYPE)
     nl = S.lcu_count(w, h)
     pitches = (w + 32, w // 2 + 16, w // 2 + 16)
@@ -105,7 +113,11 @@ def test_encode_lcu_oracle_matches_reference(oracle, name):
         for k in range(first, first + nl):
             work = np.ascontiguousarray(g["work"][k:k + 1])
             got = np.zeros(1, rdt)
-            fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got.ctypes.data)
+            if pm:
+                cost = np.ascontiguousarray(g["cost"][g["cost_pictures"].tolist().index(int(g["picture_number"][k]))])
+                fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, None, None, cost.ctypes.data, work.ctypes.data, got.ctypes.data)
+            else:
+                fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, work.ctypes.data, got.ctypes.data)
             compare_lcu(work[0], g["result"][k], got[0], w, h, (name, int(g["picture_number"][k]), int(g["lcu_index"][k])))
 
 
