@@ -17,7 +17,7 @@
  *      return at once, UnifiedQuantizeInvQuantize hands back the device's coefficients, the EncodeGenerateRecon table slot the
  *      device's samples; for AMVP units PictureFullDistortionLuma / TuEstimateCoeffBitsEncDec return at once and EncodeTuCalcCost is
  *      given costs that reproduce the device's luma cbf decision.
- * LCUs outside that (intra 4x4, PM-core quantiser at encMode <= 4, coefficient shaping at encMode >= 11, ...) are encoded by the
+ * LCUs outside that (intra 4x4 at encMode <= 2, RDOQ at encMode 0, coefficient shaping at encMode >= 11, ...) are encoded by the
  * reference code; their last
  * row / column and edge mode types (the ep* neighbour arrays after the call) are handed to the device picture before the next
  * device-encoded LCU of the picture needs them.  No fallback on errors: any failure of the HIP library aborts the encoder.
@@ -167,11 +167,12 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
     if (!e)
         svt_hook_die("encode pass: more PictureControlSet_t objects than EP_PICTURES");
     if (e->picture_plus1 != pcs->pictureNumber + 1) { /* first LCU of a new picture in this object: nothing coded yet */
-        if (pcs->sliceType != EB_I_PICTURE) { /* what the inter units of the picture read: reference pictures + rate tables (complete
-                                               * before other lanes launch: the begin below waits for this lane's stream) */
+        {   /* what the inter units of the picture read: reference pictures + rate tables (also what the PM-core quantiser of an I picture
+             * prices its levels with); complete before other lanes launch: the begin below waits for this lane's stream */
             SvtAmdRefPicture refs[2];
-            int have[2];
-            svt_hook_resident_references(pcs, wide, refs, have);
+            int have[2] = {0, 0};
+            if (pcs->sliceType != EB_I_PICTURE)
+                svt_hook_resident_references(pcs, wide, refs, have);
             if (svt_amd_encdec_picture_set_inter(lane, e->pic, have[0] ? &refs[0] : NULL, have[1] ? &refs[1] : NULL, (const SvtAmdCabacCost *)pcs->cabacCost))
                 svt_hook_die("svt_amd_encdec_picture_set_inter");
         }
@@ -211,6 +212,7 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
     w->constrained_intra = pcs->constrainedIntraFlag, w->strong_smoothing = scs->enableStrongIntraSmoothing;
     w->tile_left = lcuPtr->lcuEdgeInfoPtr->tileLeftEdgeFlag, w->tile_top = lcuPtr->lcuEdgeInfoPtr->tileTopEdgeFlag;
     w->tile_right = lcuPtr->lcuEdgeInfoPtr->tileRightEdgeFlag;
+    w->pm_core = contextPtr->mdContext->rdoqPmCoreMethod == EB_PMCORE; /* encMode 1..4: the PM-core quantiser, on the device too */
     /* without the delta-QP tools every unit is coded at the picture's QP (EbCodingLoop.c:3214, :3238-3246) */
     const EB_U8 qp = pcs->pictureQp;
     const EB_U8 chromaQp = MapChromaQp((EB_U8)CLIP3((EB_S8)MIN_QP_VALUE, (EB_S8)MAX_CHROMA_MAP_QP_VALUE, (EB_S8)(qp + pcs->cbQpOffset + pcs->sliceCbQpOffset)));
@@ -496,7 +498,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         svt_hook_die("out of memory (encode-pass staging)");
     /* tools that change a unit's QP, dead zone, coefficient shape or quantiser are outside this revision */
     const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
-                      contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ;
+                      (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE); /* RDOQ: encMode 0 */
     const int units = !tools && fill_work(&t_serve->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr);
     if (!units) {
         lane_release(lane);

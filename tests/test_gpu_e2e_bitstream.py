@@ -337,8 +337,11 @@ ENCODEPASS_CASES = [
     ("motion", 832, 480, 3, ["-encMode", "7", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
     # 2 x 2 tiles with P / B pictures: four wavefronts, inter units next to tile edges
     ("motion", 832, 480, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "inter"),
-    # encMode 4: the encode pass quantises with PM-core, outside the device call - every LCU must be left to the reference code
-    ("motion", 416, 240, 2, ["-encMode", "4", "-intra-period", "0"], "none"),
+    # encMode 4 / 3: the encode pass quantises with PM-core (luma levels re-decided per 4x4 block), on the device too
+    ("motion", 416, 240, 2, ["-encMode", "4", "-intra-period", "0"], "all"),
+    ("motion", 416, 240, 6, ["-encMode", "3", "-pred-struct", "2", "-hierarchical-levels", "2"], "inter"),
+    # encMode 2: LCUs with intra 4x4 units stay on the host between device-encoded ones
+    ("noise", 200, 136, 3, ["-encMode", "2", "-pred-struct", "0", "-hierarchical-levels", "0", "-q", "26"], "mixed"),
     # 10-bit encodes: EncodePass with is16bit through the 16-bit contract (all-intra, and random access with host-encoded LCUs)
     ("motion10", 416, 240, 3, ["-encMode", "9", "-intra-period", "0", "-bit-depth", "10"], "all"),
     ("noise10", 320, 256, 4, ["-encMode", "8", "-pred-struct", "0", "-constrd-intra", "1", "-q", "40", "-bit-depth", "10"], "full"),
