@@ -13,6 +13,9 @@
 /* the root device context (created with the encoder, or here on first use) and the loud exit every binding shares */
 SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight);
 void svt_hook_die(const char *what);
+/* the running pipeline's application callback (error reporting): noted by the first bound call that sees the sequence control set */
+struct SequenceControlSet_s;
+void svt_hook_note_callback(const struct SequenceControlSet_s *scs);
 
 /* Non-zero while the reference's EncodePass runs on this thread for an LCU the device has already encoded (svt_hook_encdec.c):
  * the leaves it reaches answer from the device's result instead of computing. */

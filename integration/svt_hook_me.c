@@ -20,6 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
+#include "EbErrorCodes.h"
+#include "EbEncodeContext.h"
 
 #include "EbDefinitions.h"
 #include "EbPictureControlSet.h"
@@ -123,19 +126,40 @@ static unsigned long counter_sum(int i)
     return n;
 }
 static void hook_report(void);
-static void ensure_context(uint16_t lumaWidth, uint16_t lumaHeight);
+static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight);
 
+/* The reference's error model (SURVEY 8b "Errors"): failures at EbInitEncoder time come back as EB_ERRORTYPE
+ * (EB_ErrorInsufficientResources from the object constructors, Codec/EbEncHandle.c:689 ff.); failures inside the running pipeline go
+ * to the application through appCallbackPtr->ErrorHandler (Codec/EbErrorHandling.h:15 CHECK_REPORT_ERROR: the handler posts an output
+ * packet whose nFlags is the error code, EbH265GetPacket hands it over as EB_ErrorMax, and the reporting thread stops for good).  A HIP
+ * failure follows the same two routes: never abort() in a host that loaded the library (ffmpeg, gstreamer). */
+static EbCallback_t *g_app_cb; /* encodeContextPtr->appCallbackPtr, noted by the first bound call of the running pipeline */
+void svt_hook_note_callback(const SequenceControlSet_t *scs)
+{
+    if (!__atomic_load_n(&g_app_cb, __ATOMIC_RELAXED) && scs && scs->encodeContextPtr)
+        __atomic_store_n(&g_app_cb, scs->encodeContextPtr->appCallbackPtr, __ATOMIC_RELEASE);
+}
 static void die(const char *what)
 {
     fprintf(stderr, "svt_hook_me: %s: %s\n", what, svt_amd_last_error());
-    abort();
+    EbCallback_t *cb = __atomic_load_n(&g_app_cb, __ATOMIC_ACQUIRE);
+    if (cb && cb->ErrorHandler && !getenv("SVT_HOOK_ABORT_ON_ERROR")) {
+        static int reported;
+        if (!__atomic_exchange_n(&reported, 1, __ATOMIC_ACQ_REL)) /* one error packet; every failing thread stops */
+            cb->ErrorHandler(cb->handle, EB_ENC_ME_ERROR1 + 0x80); /* no message of the application's table: it prints "Error: Others!" */
+        pthread_exit(NULL); /* the reference spins in `while(1);` after the handler (and EbDeinitEncoder then never joins that thread); leaving
+                             * the thread instead lets the application shut the encoder down after it has seen the error packet */
+    }
+    abort(); /* no pipeline to report to (stand-alone harness use) */
 }
 void svt_hook_die(const char *what) { die(what); }
 SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight)
 {
     pthread_mutex_lock(&g_front_lock);
-    ensure_context(lumaWidth, lumaHeight);
+    const int rc = ensure_context(lumaWidth, lumaHeight);
     pthread_mutex_unlock(&g_front_lock);
+    if (rc)
+        die("device start-up");
     return g_ctx;
 }
 
@@ -237,8 +261,12 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
     if (e && __atomic_load_n(&e->state, __ATOMIC_ACQUIRE) == 1 && e->pic == pic && e->gen == cached_gen)
         return e; /* this thread already waited for it */
     SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    svt_hook_note_callback(scs);
     pthread_mutex_lock(&g_front_lock);
-    ensure_context(scs->lumaWidth, scs->lumaHeight);
+    if (ensure_context(scs->lumaWidth, scs->lumaHeight)) {
+        pthread_mutex_unlock(&g_front_lock);
+        die("device start-up");
+    }
     g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
     for (;;) {
         e = NULL;
@@ -373,43 +401,62 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
     return EB_ErrorNone;
 }
 
-static void ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
+/* Under g_front_lock.  Returns non-zero (with the library's message on stderr) when the device cannot be brought up; the caller maps it
+ * to the reference's error model (see die()). */
+static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
 {
     if (g_ctx)
-        return;
+        return 0;
+    static int failed;
+    if (failed)
+        return 1;
     const char *dev = getenv("SVT_AMD_DEVICE");
     const uint16_t mh = (uint16_t)((lumaHeight + 7) & ~7);
-    if (svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &g_ctx))
-        die("svt_amd_context_create");
-    for (int i = 0; i < NLANES; i++)
-        if (svt_amd_context_fork(g_ctx, &g_front[i].lane))
-            die("svt_amd_context_fork");
+    SvtAmdContext *ctx = NULL;
+    const char *step = "svt_amd_context_create";
+    int rc = svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &ctx);
+    for (int i = 0; i < NLANES && !rc; i++)
+        step = "svt_amd_context_fork", rc = svt_amd_context_fork(ctx, &g_front[i].lane);
     /* pinned buffers and kernel code objects now, not inside the first pictures (EbInitEncoder is outside the encode clock) */
-    if (!getenv("SVT_HOOK_NO_WARMUP")) {
-        if (svt_amd_frontend_warmup(g_ctx))
-            die("svt_amd_frontend_warmup");
-        for (int i = 0; i < NLANES; i++)
-            if (svt_amd_frontend_warmup(g_front[i].lane))
-                die("svt_amd_frontend_warmup (lane)");
+    if (!rc && !getenv("SVT_HOOK_NO_WARMUP")) {
+        step = "svt_amd_frontend_warmup", rc = svt_amd_frontend_warmup(ctx);
+        for (int i = 0; i < NLANES && !rc; i++)
+            rc = svt_amd_frontend_warmup(g_front[i].lane);
     }
+    if (rc) {
+        fprintf(stderr, "svt_hook_me: %s (device %s): %s\n", step, dev ? dev : "0", svt_amd_last_error());
+        for (int i = 0; i < NLANES; i++)
+            if (g_front[i].lane)
+                svt_amd_context_destroy(g_front[i].lane), g_front[i].lane = NULL;
+        if (ctx)
+            svt_amd_context_destroy(ctx);
+        failed = 1;
+        return 1;
+    }
+    g_ctx = ctx;
     g_nlcu = ((lumaWidth + 63u) / 64u) * ((lumaHeight + 63u) / 64u);
     g_verbose = getenv("SVT_HOOK_VERBOSE") != NULL;
     fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
     atexit(hook_report);
+    return 0;
 }
 
 /* Device start-up belongs to EbInitEncoder, not to the first picture: the picture-analysis reference objects are built there
  * (EbEncHandle.c, EbSystemResourceCtor with this creator), and their descriptor carries the luma size. */
-EB_ERRORTYPE __real_EbPaReferenceObjectCtor(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr);
-EB_ERRORTYPE __wrap_EbPaReferenceObjectCtor(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr)
+/* (the creator, not EbPaReferenceObjectCtor: the reference calls the constructor from the same translation unit, Codec/EbReferenceObject.c:270,
+ * where --wrap cannot reach; the creator is taken by address in EbEncHandle.c:944) */
+EB_ERRORTYPE __real_EbPaReferenceObjectCreator(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr);
+EB_ERRORTYPE __wrap_EbPaReferenceObjectCreator(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr)
 {
     const EbPaReferenceObjectDescInitData_t *d = (const EbPaReferenceObjectDescInitData_t *)objectInitDataPtr;
     if (d && !getenv("SVT_HOOK_LAZY_INIT")) {
         pthread_mutex_lock(&g_front_lock);
-        ensure_context(d->referencePictureDescInitData.maxWidth, d->referencePictureDescInitData.maxHeight);
+        const int rc = ensure_context(d->referencePictureDescInitData.maxWidth, d->referencePictureDescInitData.maxHeight);
         pthread_mutex_unlock(&g_front_lock);
+        if (rc) /* no usable MI355X: EbInitEncoder fails like any other resource the encoder cannot get (EbEncHandle.c EB_NEW chain) */
+            return EB_ErrorInsufficientResources;
     }
-    return __real_EbPaReferenceObjectCtor(objectDblPtr, objectInitDataPtr);
+    return __real_EbPaReferenceObjectCreator(objectDblPtr, objectInitDataPtr);
 }
 
 /*
@@ -423,8 +470,7 @@ EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U3
     FrontEntry *e = front_entry(pcs, NULL, inputPtr);
     if (e->oisp.ois_kernel_level != ctx->oisKernelLevel || e->oisp.ois_th_set != ctx->oisThSet ||
         e->oisp.set_best_ois_distortion_to_valid != ctx->setBestOisDistortionToValid) {
-        fprintf(stderr, "svt_hook_me: open-loop intra search controls differ from SignalDerivationMeKernelOq's\n");
-        abort();
+        die("open-loop intra search controls differ from SignalDerivationMeKernelOq's");
     }
     const int nc = e->ois_nc;
     const uint32_t *cand = (const uint32_t *)(e->ois + (size_t)lcuIndex * SVT_AMD_OIS_COMPACT_BYTES(nc));

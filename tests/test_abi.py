@@ -108,3 +108,33 @@ print("OUTER_ABI_OK", any(cfg.raw))
 ''' % DROP_IN
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "OUTER_ABI_OK True" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+HIP_APP = os.path.join(S.ROOT, "integration", "_build", "SvtHevcEncApp_hip")
+
+
+def _run_hooked(tmp_path, env):
+    yuv = str(tmp_path / "c.yuv")
+    S.write_clip(yuv, "motion", 128, 64, 3, 7)
+    return subprocess.run([HIP_APP, "-i", yuv, "-w", "128", "-h", "64", "-n", "3", "-b", str(tmp_path / "o.265"), "-encMode", "9"],
+                          capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+
+
+def test_device_failure_at_init_is_an_error_code_not_a_core_dump(tmp_path):
+    """SURVEY 8b "Errors": a device that cannot be brought up fails EbInitEncoder with EB_ErrorInsufficientResources (the sample
+    application prints its out-of-memory line and exits 1) - the host process is not aborted.  Device 99 exists nowhere, so the test
+    means the same with and without a GPU."""
+    assert os.path.exists(HIP_APP), "run `python __graft_entry__.py build` first (needs /root/reference)"
+    r = _run_hooked(tmp_path, {"SVT_AMD_DEVICE": "99"})
+    assert r.returncode == 1, (r.returncode, r.stderr[-800:])                   # a signal would be negative
+    assert "Could not allocate enough memory for channel 1" in r.stdout       # EB_ErrorInsufficientResources (App/EbAppMain.c)
+    assert "svt_amd_context_create (device 99)" in r.stderr
+
+
+def test_device_failure_inside_the_pipeline_reaches_the_error_handler(tmp_path):
+    """A failure after start-up (here: the lazily created context) goes to appCallbackPtr->ErrorHandler: the application receives an
+    error packet (EbH265GetPacket -> EB_ErrorMax), reports it and shuts the encoder down itself."""
+    assert os.path.exists(HIP_APP)
+    r = _run_hooked(tmp_path, {"SVT_AMD_DEVICE": "99", "SVT_HOOK_LAZY_INIT": "1"})
+    assert r.returncode >= 0, (r.returncode, r.stderr[-800:])
+    assert "Error encoding at channel 1" in r.stdout and "Encoder finished" in r.stdout
