@@ -19,9 +19,20 @@ buffer sets rotate through them under lane events, so the copies of batches s-1 
 of different batches never share the GPU (the per-kernel times are stand-alone durations).  Both PCIe directions are INSIDE the
 timed region; `hbm_resident_fps` is the compute lane alone.
 
-Prints ONE JSON line (rank 0).  `value` = front-half pictures/s over all GPUs, NOT whole-encoder fps: the closed-loop EncDec
-half still runs on the host in the hooked encoder, whose md5-gated whole-encoder fps is reported beside it as `encoder_fps`
-(hooked encoder vs the unmodified reference on the same clip).  N>1: every rank runs its own pictures (no collective).
+Prints ONE JSON line (rank 0).
+
+`metric` / `value` = BASELINE.json's metric: ENCODED fps of the whole encoder with the HIP path bound in (integration/_build/
+SvtHevcEncApp_hip = the drop-in libSvtHevcEnc.so.1 + the reference's sample application) on BASELINE configs[2]'s command line, the
+application's own "Average Speed" (SURVEY 8d), GATED on the bitstream being md5-identical to the unmodified reference's
+(oracle/_ref/SvtHevcEncApp_ref) on the same clip: a differing bitstream reports value 0.  A "step" of that number = 8 encoded pictures
+(two mini-GOPs of the 3-layer random-access structure): --steps K encodes 8 K pictures (K = 20: 160 >= the 150 SURVEY 8d asks for);
+start-up is outside the clock (the application preloads the clip, -nb, and starts its clock after EbInitEncoder).  Which SVT_HOOK_*
+bindings were on is stated in `config.switches`.  `cpu_baseline` = the unmodified reference encoder (AVX2 tables, all host threads)
+on the same clip, plus a bounded `-lp 1` run for the per-core figure.
+`front_half` keeps the hot-path throughput of the device front half (what `value` was in rounds 1-2) and `roofline` its dominant
+kernels; both are measured with --steps K batches-pairs of the loop described above, bracketed by barrier + synchronize.
+N > 1: one hooked encoder per rank on its own GPU (SVT_AMD_DEVICE = local rank, host threads divided), all started behind a barrier;
+value = all ranks' pictures / the slowest rank's encode time ("replicas", SURVEY 8e picture-level row; no data-path collective).
 """
 import argparse
 import csv
@@ -98,6 +109,85 @@ def cpu_baseline_reference(cfg, unique=8, frames=48):
                       (int(pictures), w, h, unique, r["me_calls"], r["me_ns"] * 1e-9, r["ois_calls"], r["ois_ns"] * 1e-9, cpu_s, wall),
             "host_threads": os.cpu_count(),
             "all_cores_upper_bound": round(pictures / cpu_s * (os.cpu_count() or 1), 1)}
+
+
+def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
+    """The BASELINE metric.  Rank 0 first encodes the clip with the unmodified reference (its md5 is the gate, its fps the CPU
+    baseline); then every rank runs the hooked encoder on its own GPU behind a barrier.  Returns (rank 0) the record of the JSON
+    line's `encoder_fps` with `value` = pictures of all ranks / slowest rank's encode time, 0 when any bitstream differs."""
+    import encoder_fps as E
+    frames, unique = 8 * max(1, steps), 16
+    w, h, depth, args = E.CONFIGS[enc_cfg]
+    args = list(args) + ["-asm", "1"]
+    switches = {k: v for k, v in os.environ.items() if k.startswith("SVT_HOOK_")}
+    out = {"config": enc_cfg, "frames": frames, "unique_frames": unique, "args": " ".join(args), "host_threads": os.cpu_count(),
+           "switches": switches or "none set: motion estimation + open-loop intra search on the device (the bindings' default); the "
+                                   "EncDec bindings (SVT_HOOK_ENCODEPASS / _FULLLOOP / _INTRA / _INTER / _SAO / _MD) are off"}
+    td = tempfile.mkdtemp(prefix="svtenc_r%d_" % rank, dir="/tmp")
+    try:
+        yuv = os.path.join(td, "clip.yuv")
+        if depth == 10:
+            S.write_clip10_compressed(yuv, "motion", w, h, unique, 7)
+        else:
+            S.write_clip(yuv, "motion", w, h, unique, 7)
+        ref_md5 = ""
+        if rank == 0:
+            try:
+                ref = E.run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"), nb=unique)
+                out["reference"], ref_md5 = ref, ref["md5"]
+            except Exception as e:
+                out["reference"] = {"error": str(e)[-300:]}
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.zeros(32, dtype=torch.uint8, device=dev)
+            if rank == 0 and ref_md5:
+                t = torch.tensor(list(ref_md5.encode()), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            ref_md5 = bytes(t.cpu().tolist()).decode() if int(t.sum()) else ""
+            dist.barrier()
+        env = {"SVT_AMD_DEVICE": str(local_rank)}
+        hargs = list(args)
+        if world > 1:
+            hargs += ["-lp", str(max(1, (os.cpu_count() or 1) // world))]
+        try:
+            hip = E.run_app(E.HIP_APP, yuv, w, h, frames, hargs, os.path.join(td, "hip.265"), env=env, nb=unique)
+        except Exception as e:
+            hip = {"error": str(e)[-300:], "fps": None, "md5": None}
+        ok = bool(hip.get("md5")) and hip["md5"] == ref_md5
+        secs = frames / hip["fps"] if hip.get("fps") else float("inf")
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([secs if ok else float("inf")], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            secs = float(t.item())
+        out["hip"] = hip
+        out["bitstream_identical"] = secs != float("inf")
+        out["value"] = round(world * frames / secs, 2) if secs != float("inf") else 0.0
+        if out.get("reference", {}).get("fps") and hip.get("fps"):
+            out["hip_over_reference"] = round(hip["fps"] / out["reference"]["fps"], 3)
+        return out
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def cpu_baseline_encoder(cfg, enc):
+    """The reference encoder itself on this host's cores (AVX2 tables): the same clip and command line as `value` (timed by
+    encoded_fps_leg), plus a bounded single-thread run (-lp 1) for the per-core figure SURVEY 8d asks for."""
+    import encoder_fps as E
+    if not enc or "reference" not in enc or not enc["reference"].get("fps"):
+        raise RuntimeError("reference encoder run missing")
+    w, h, depth, args = E.CONFIGS[cfg["enc"]]
+    out = {"value": enc["reference"]["fps"], "unit": "fps", "cores": os.cpu_count(), "kind": "reference",
+           "sample": "%d %dx%d pictures (%d unique, looped), oracle/_ref/SvtHevcEncApp_ref -asm 1 (the reference compiled in place, AVX2 "
+                     "tables), default threading on all %d host threads, same command line as `value`: %s" %
+                     (enc["frames"], w, h, enc["unique_frames"], os.cpu_count(), enc["args"])}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        yuv = os.path.join(td, "c.yuv")
+        (S.write_clip10_compressed if depth == 10 else S.write_clip)(yuv, "motion", w, h, 5, 7)
+        t0 = time.perf_counter()
+        r = E.run_app(S.REF_APP, yuv, w, h, 5, list(args) + ["-asm", "1", "-lp", "1"], os.path.join(td, "o.265"), nb=5)
+        out["lp1"] = {"fps": r["fps"], "pictures": 5, "wall_s": round(time.perf_counter() - t0, 1), "args": "-lp 1"}
+    return out
 
 
 def pmc_traffic(argv_inner, kernel_tag="k_me"):
@@ -207,7 +297,7 @@ def recon_exchange_leg(lib, root, rank, world, dev, reps=10, limit_s=120.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="pictures per step per GPU (default: 64 at 4K, 128 at 1080p)")
@@ -401,6 +491,12 @@ def main():
         res_steps = max(2, a.steps // 2)
 
     xchg = recon_exchange_leg(lib, root, rank, world, dev) if (world > 1 and not a.inner) else None
+
+    # ---- the headline: md5-gated encoded fps of the whole encoder with the HIP path bound in -------------------------------------
+    enc = None
+    if not a.inner and not a.no_encoder_fps:
+        enc = encoded_fps_leg(cfg["enc"], a.steps, rank, local_rank, world, dev)
+
     if rank == 0 and not a.inner:
         fps = world * NL * B * a.steps / dt
         me_ms, me_n = kt["me_search"]
@@ -408,29 +504,49 @@ def main():
         # full + 1/4 + 1/16 planes (1.3125 bytes/pel), plus the per-LCU result records
         algo_bytes = B * ((1 + nlists) * 1.3125 * W * H + nlcu * me_rec_b)
         achieved = algo_bytes / (me_ms * 1e-3) / 1e9 if me_ms > 0 else 0.0
+        # integer view: absolute differences of the three exhaustive stages per LCU and list against the v_sad_u8 peak
+        # (4 px x 64 lanes x 4 SIMDs x 256 CUs x 2.4 GHz)
+        absdiff_lcu_list = (params.hme_l0_total_w * params.hme_l0_total_h * 16 * 8 + 4 * 8 * 4 * 32 * 16 +
+                            params.search_area_width * params.search_area_height * 64 * 32)
+        absdiff_s = B * nlcu * nlists * absdiff_lcu_list / (me_ms * 1e-3) if me_ms > 0 else 0.0
+        sad_peak = 4 * 64 * 4 * 256 * 2.4e9
+        # per-kernel algorithmic rates of the other two launches of a batch
+        prep_bytes = B * (W * H + 4 * (W + 136) * (H + 136) + (W // 2 + 64) * (H // 2 + 64) + (W // 4 + 32) * (H // 4 + 32))
+        ois_bytes = B * (W * H + nlcu * 6208)
+        value = enc["value"] if enc and "value" in enc else None
         res = {
-            "metric": "encoded fps (front half of the hot path through the host boundary: upload + picture preparation + motion "
-                      "estimation + open-loop intra search + result download); md5-gated whole-encoder fps in `encoder_fps`",
-            "value": round(fps, 2), "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "encoded fps, %s, bitstream md5-identical to the unmodified reference (BASELINE.json metric; whole encoder with the "
+                      "HIP path bound in, application's Average Speed)" % cfg["name"],
+            "value": value if value is not None else 0.0, "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(8e3 / value, 4) if value else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": cfg["name"] + ": per picture H2D of the luma, pad + decimate + half-pel planes, open-loop ME of %d "
-                                   "LCUs against %d reference list(s) (HME L0 %dx%d + L1, full-pel %dx%d 85-PU search, sub-pel, "
-                                   "bi-prediction), open-loop intra search, D2H of the ME + OIS records; mode decision / encode "
-                                   "pass stay on the host (see encoder_fps)" %
+            "config": {"workload": cfg["name"] + ": whole encode of %s pictures (one step = 8 pictures), command line of BASELINE.md section 2" %
+                                   (enc["frames"] if enc and "frames" in enc else "n/a"),
+                       "width": W, "height": H, "mpix_per_s": round(value * W * H / 1e6, 1) if value else None,
+                       "switches": enc.get("switches") if enc else None,
+                       "on_device": enc.get("on_device") if enc else None,
+                       "parallelism": "one encoder per rank on its own GPU, no data-path collective" if world > 1 else "1 GPU"},
+            "encoder_fps": enc,
+            "front_half": {"what": "upload + picture preparation + open-loop motion estimation of %d LCUs against %d list(s) (HME L0 %dx%d + L1, "
+                                   "full-pel %dx%d 85-PU search, sub-pel, bi-prediction) + open-loop intra search + result download, through the "
+                                   "host boundary (PCIe inside the timed region), %d pictures per launch, %d lanes" %
                                    (nlcu, nlists, params.hme_l0_total_w, params.hme_l0_total_h, params.search_area_width,
-                                    params.search_area_height),
-                       "width": W, "height": H, "pictures_per_step_per_gpu": NL * B, "pictures_per_launch": B, "mpix_per_s": round(fps * W * H / 1e6, 1),
-                       "timed_region_s": round(dt, 3), "pcie_in_timed_region": True, "lanes_per_gpu": NL,
-                       "h2d_bytes_per_picture": W * H, "d2h_bytes_per_picture": nlcu * (me_b + ois_b),
-                       "parallelism": "pictures sharded over ranks, no collective"},
-            "hbm_resident_fps": round(world * NL * B * res_steps / dt_res, 2),
+                                    params.search_area_height, B, NL),
+                           "fps": round(fps, 2), "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 4), "timed_region_s": round(dt, 3),
+                           "pictures_per_step_per_gpu": NL * B, "hbm_resident_fps": round(world * NL * B * res_steps / dt_res, 2),
+                           "h2d_bytes_per_picture": W * H, "d2h_bytes_per_picture": nlcu * (me_b + ois_b)},
             "roofline": {"bound": "hbm", "kernel": "k_me<0> (hme) + k_me<1> (search): one ME batch = %d dispatches (2 per list)" % (2 * nlists),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": None, "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_ms, 4),
                          "launches_timed": me_n, "pictures_per_launch": B,
-                         "prep_avg_ms": round(kt["prep"][0], 4), "prep_launches": kt["prep"][1],
-                         "ois_avg_launch_ms": round(kt["ois"][0], 4), "ois_launches": kt["ois"][1],
+                         "sad_throughput": {"abs_diff_per_s": float("%.4g" % absdiff_s), "v_sad_u8_peak_per_s": sad_peak,
+                                            "frac": round(absdiff_s / sad_peak, 5),
+                                            "abs_diff_per_lcu_per_list": absdiff_lcu_list},
+                         "other_kernels": {
+                             "k_prep_fused": {"avg_ms": round(kt["prep"][0], 4), "launches": kt["prep"][1], "algorithmic_bytes": int(prep_bytes),
+                                              "GBps": round(prep_bytes / (kt["prep"][0] * 1e-3) / 1e9, 1) if kt["prep"][0] > 0 else None},
+                             "k_ois_picture": {"avg_ms": round(kt["ois"][0], 4), "launches": kt["ois"][1], "algorithmic_bytes": int(ois_bytes),
+                                               "GBps": round(ois_bytes / (kt["ois"][0] * 1e-3) / 1e9, 1) if kt["ois"][0] > 0 else None}},
                          "avg_launch_ms_hbm_resident_loop": round(kt_res["me_search"][0], 4)},
         }
         if xchg is not None:
@@ -445,7 +561,8 @@ def main():
                 res["roofline"]["traffic_error"] = err
         if world == 1 and not a.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline_reference(cfg)
+                res["cpu_baseline"] = cpu_baseline_encoder(cfg, enc)
+                res["cpu_baseline"]["front_half_one_core"] = cpu_baseline_reference(cfg)
             except Exception as e:  # the reference build is absent: say so, do not substitute
                 res["cpu_baseline"] = {"error": str(e)[-300:]}
         if world == 1 and not a.no_encode_pass:
@@ -455,12 +572,6 @@ def main():
                 res["encode_pass"] = EPB.measure_b_picture(S.load_product(), root)
             except Exception as e:
                 res["encode_pass"] = {"error": str(e)[-300:]}
-        if world == 1 and not a.no_encoder_fps:
-            try:
-                import encoder_fps as E
-                res["encoder_fps"] = E.measure(cfg["enc"], frames=128, unique=16)  # 128: past the pipelines' fill (DESIGN 5b has 64 and 256)
-            except Exception as e:
-                res["encoder_fps"] = {"error": str(e)[-300:]}
         print(json.dumps(res), flush=True)
 
     if xchg and xchg.get("hung"):
