@@ -1395,6 +1395,94 @@ SVT_AMD_API void svt_amd_BiPredClipping(uint32_t puWidth, uint32_t puHeight, int
 SVT_AMD_API void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight, int16_t *list0Src, int16_t *list1Src,
                                              uint16_t *dst, uint32_t dstStride);
 
+
+/* ------------------------------------------------------------------------- */
+/* Device-resident mode decision: ModeDecisionLcu + EncodePass of whole pictures */
+/* ------------------------------------------------------------------------- */
+/* The closed loop of an LCU on the device (SURVEY 8a rows ModeDecisionLcu / ProductPerformFastLoop / PerformFullLoop / inter-depth
+ * decision + the EncDec input contract): ONE call per picture replaces, for every LCU, what EncDecKernel's LCU loop does between
+ * ModeDecisionConfigureLcu and the end of EncodePass (Codec/EbEncDecProcess.c:2893-3023):
+ *   ModeDecisionLcu (Codec/EbProductCodingLoop.c:4691-5114): the coding-unit loop over the LCU's MdcLcuData_t leaf list - context
+ *   generation, candidate injection (Codec/EbModeDecision.c:1795), the two fast loops (:1911; prediction + NxM SAD + fast cost,
+ *   Codec/EbRateDistortionCost.c:440), PreModeDecision (EbModeDecision.c:300), the full loop of the surviving candidates (:4351;
+ *   ProductFullLoop, Codec/EbFullLoop.c:185, + the full-cost function, EbRateDistortionCost.c:963), ProductFullModeDecision
+ *   (EbModeDecision.c:1995), the candidate's reconstruction (PerformInverseTransformRecon, :1334), the inter-depth decision
+ *   (EbFullLoop.c:1461) and the neighbour-array updates (:371) - followed by the LCU's EncodePass (the encode unit above) on the tree
+ *   it decided, and the wavefront of AssignEncDecSegments over the picture, all in one launch.
+ * The mode decision's neighbour arrays (pcs->md*NeighborArray[MD_NEIGHBOR_ARRAY_INDEX], EbPictureControlSet.h) live in HBM as
+ * picture-sized maps of the SvtAmdEncDecPicture (candidate reconstruction, mode type, intra luma mode, depth, skip flag), the
+ * ME / OIS results are read where the front half left them.
+ *
+ * THIS REVISION covers the pictures whose LCUs all take the ModeDecisionLcu path with luma-only candidates:
+ *   I pictures (PICT_FULL84_DEPTH_MODE), closed-loop intra (intraMdOpenLoopFlag == 0), chroma level 1 (CHROMA_MODE_BEST: no chroma
+ *   in the mode decision, EbEncDecProcess.c:2056-2113), no CABAC-context update, intra 4x4 off, plain quantiser, no delta-QP tools =
+ *   the I pictures of encMode 8..10 at every resolution and of encMode 7 in 4K (BASELINE configs[0], and the I pictures of
+ *   configs[1] / [2] / [3]), 8-bit.  svt_amd_md_picture_supported() says so; everything else stays with the reference code.
+ * The controls below are DERIVED BY THE REFERENCE'S HOST CODE (SignalDerivationEncDecKernelOq, ProductResetModeDecision,
+ * ModeDecisionConfigureLcu, the picture-analysis detectors) and are inputs here, like SvtAmdMeParams. */
+typedef struct SvtAmdMdRates {             /* MdRateEstimationContext_t, field for field (Codec/EbMdRateEstimation.h:113-161)      */
+    uint32_t splitFlagBits[6], skipFlagBits[6], mvpIndexBits[2], intraPartSizeBits[2], interPartSizeBits[8], predModeBits[2];
+    uint32_t intraLumaBits[4], intraChromaBits[5], refPicBits[3], mvdBits[12], lumaCbfBits[10], chromaCbfBits[10], rootCbfBits[2];
+    uint32_t transSubDivFlagBits[6], mergeFlagBits[2], mergeIndexBits[5], saoMergeFlagBits[2], saoTypeIndexBits[6];
+    uint32_t saoOffsetTrunUnaryBits[8], interBiDirBits[8], interUniDirBits[2], pad[17];
+} SvtAmdMdRates;
+typedef struct SvtAmdMdPicture {
+    uint16_t width, height;                /* luma                                                                               */
+    uint8_t slice_type;                    /* EB_PICTURE: 0 B, 1 P, 2 I                                                          */
+    uint8_t temporal_layer, is_reference, enc_mode;
+    uint8_t depth_mode;                    /* ppcs->depthMode (PICT_FULL85 1, PICT_FULL84 2, ... EbDefinitions.h)                */
+    uint8_t intra_md_open_loop;            /* ModeDecisionContext_t.intraMdOpenLoopFlag                                          */
+    uint8_t intra_injection_method;        /* .intraInjectionMethod (EbEncDecProcess.c:2014-2026)                                */
+    uint8_t limit_intra;                   /* .limitIntra                                                                        */
+    uint8_t mpm_search, mpm_search_candidate; /* ConfigureMpm (Codec/EbModeDecisionProcess.c:560)                                */
+    uint8_t pf_md_level, nfl_level_md, nmm_level_md;
+    uint8_t full_loop_escape, single_fast_loop, coeff_cabac_update, spatial_sse_full_loop;
+    uint8_t chroma_level;                  /* .chromaLevel                                                                       */
+    uint8_t intra4x4_level;                /* .intra4x4Level (2 = off)                                                           */
+    uint8_t rdoq_pmcore_method;            /* .rdoqPmCoreMethod (0 = plain quantiser)                                            */
+    uint8_t skip_ois_8x8, cu8x8_mode, cu16x16_mode, limit_ois_to_dc_mode; /* PictureParentControlSet_t                            */
+    uint8_t constrained_intra, strong_smoothing; /* encode pass: pcs->constrainedIntraFlag, scs->enableStrongIntraSmoothing      */
+    uint8_t qp, chroma_qp;                 /* contextPtr->qp, ->chromaQp of every LCU (no delta-QP tools)                        */
+    uint8_t pad[2];
+    uint32_t fast_lambda, full_lambda, fast_chroma_lambda, full_chroma_lambda; /* ModeDecisionConfigureLcu's assignment           */
+    SvtAmdMdRates rates;                   /* contextPtr->mdRateEstimationPtr (slice type + QP row of mdRateEstimationArray)     */
+} SvtAmdMdPicture;
+#define SVT_AMD_MD_LEAVES 85               /* CU_MAX_COUNT                                                                       */
+typedef struct SvtAmdMdLcu {
+    uint8_t leaf_count;                    /* MdcLcuData_t.leafCount, .leafDataArray[] (EbPictureControlSet.h:82-102)            */
+    uint8_t leaf_index[SVT_AMD_MD_LEAVES], leaf_split[SVT_AMD_MD_LEAVES];
+    uint8_t tile_left, tile_top, tile_right; /* lcuEdgeInfoPtr                                                                   */
+    uint8_t is_complete;                   /* scs->lcuParamsArray[lcu].isCompleteLcu                                             */
+    uint8_t complexity_status_2;           /* ppcs->complexLcuArray[lcu] == LCU_COMPLEXITY_STATUS_2                              */
+    uint8_t contouring_class[4];           /* DeriveContouringClass of the four 32x32 quadrants (EbModeDecisionConfiguration.c:395) */
+    uint8_t chroma_encode_mode;            /* lcuPtr->chromaEncodeMode after ConfigureChroma (1 = CHROMA_MODE_BEST)              */
+    uint8_t restrict_intra_global_motion;  /* contextPtr->restrictIntraGlobalMotion                                              */
+    uint8_t lcu_md_mode;                   /* ppcs->lcuMdModeArray[lcu] (PICT_LCU_SWITCH pictures)                               */
+} SvtAmdMdLcu;
+/* what the mode decision leaves per LCU: the decision of every leaf it tested (the final tree = leaves with split == 0 walked in
+ * Z order) and the costs the inter-depth decisions compared (mdLocalCuUnit[].cost) */
+typedef struct SvtAmdMdLcuOut {
+    uint8_t split[SVT_AMD_MD_LEAVES];      /* CodingUnit_t.splitFlag after the call                                              */
+    uint8_t tested[SVT_AMD_MD_LEAVES];     /* mdLocalCuUnit[].testedCuFlag                                                       */
+    uint8_t pred_mode[SVT_AMD_MD_LEAVES];  /* predictionModeFlag of tested leaves                                                */
+    uint8_t intra_luma_mode[SVT_AMD_MD_LEAVES];
+    uint8_t ycbf[SVT_AMD_MD_LEAVES];       /* transformUnitArray[0].lumaCbf as ProductFullModeDecision left it                  */
+    uint8_t pad[7];
+    uint64_t cost[SVT_AMD_MD_LEAVES];      /* mdLocalCuUnit[].cost                                                               */
+} SvtAmdMdLcuOut;
+/* 1 when this revision's device call covers the picture (see above) */
+SVT_AMD_API int svt_amd_md_picture_supported(const SvtAmdMdPicture *P);
+/* The whole picture: mode decision + encode pass of every LCU, one launch, wavefront on the device.  HOST arrays of every LCU in
+ * raster order: lcus (controls) in; md_out (decisions), works (the EncDec input contract the decisions amount to, source samples
+ * included) and results (the encode pass's output contract) out - any of the three may be NULL.  src_y / src_cb / src_cr: HOST
+ * planes of the picture's source (enhancedPicturePtr), sample (0,0), strides in samples.  ois: HOST array of the picture's
+ * open-loop intra search results, or NULL - then the records svt_amd_ois_picture* left in HBM for `ois_slot` are read.  cost: the
+ * picture's coefficient-rate tables (pcs->cabacCost).  Blocking. */
+SVT_AMD_API int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus,
+                                          const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr,
+                                          uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot, const SvtAmdCabacCost *cost,
+                                          SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results);
+
 #ifdef __cplusplus
 }
 #endif

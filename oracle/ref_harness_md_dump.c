@@ -1,0 +1,131 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/): link-time interposer around the REFERENCE's ModeDecisionLcu (Codec/EbProductCodingLoop.c:4691),
+ * compiled only into oracle/_ref/libsvtref.so with -Wl,--wrap=ModeDecisionLcu.
+ *
+ * When SVT_REF_MD_DUMP names a file, every picture whose LCUs go through ModeDecisionLcu is recorded:
+ *   - once per picture (at its first call): the picture-level controls (SvtAmdMdPicture, filled by integration/svt_md_fill.h - the very
+ *     code the binding uses), the coefficient-rate tables, the source picture (three planes) and the open-loop intra search results
+ *     of every LCU in the contract's layout;
+ *   - per call: the LCU's controls (SvtAmdMdLcu) BEFORE the call and what the reference decided AFTER it (SvtAmdMdLcuOut: split flag,
+ *     prediction mode, intra luma mode, luma cbf of every leaf, the tested flags and the costs of mdLocalCuUnit[]).
+ * tests/golden/make_md_golden.py turns the dump into fixtures (tests/golden/md_*.npz).
+ *
+ * Contains no reference source; includes the reference headers only to read its structs.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbEncDecProcess.h"
+#include "EbModeDecisionProcess.h"
+#include "EbCodingUnit.h"
+#include "EbUtility.h"
+
+#include "../integration/svt_md_fill.h"
+
+EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
+                                    LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr);
+
+#define MD_PIC_MAGIC 0x4350444DU /* "MDPC" */
+#define MD_LCU_MAGIC 0x434C444DU /* "MDLC" */
+typedef struct MdPicRecord { /* followed by: luma (width x height), cb, cr (width/2 x height/2), then nlcu SvtAmdOisLcuResult */
+    uint32_t magic, record_size;
+    uint64_t picture_number;
+    uint32_t nlcu, pad;
+    SvtAmdMdPicture pic;
+    SvtAmdCabacCost cost;
+} MdPicRecord;
+typedef struct MdLcuRecord {
+    uint32_t magic, record_size;
+    uint64_t picture_number;
+    uint32_t lcu_index, pad;
+    SvtAmdMdLcu lcu;
+    SvtAmdMdLcuOut out;
+} MdLcuRecord;
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static FILE *g_file;
+static int g_state;
+static uint64_t g_pic_done[256];
+static int g_npic;
+
+_Static_assert(sizeof(SvtAmdCabacCost) == sizeof(CabacCost_t), "CabacCost_t layout");
+
+static void dump_picture(const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const ModeDecisionContext_t *md)
+{
+    for (int i = 0; i < g_npic; i++)
+        if (g_pic_done[i] == pcs->pictureNumber)
+            return;
+    if (g_npic >= 256)
+        return;
+    g_pic_done[g_npic++] = pcs->pictureNumber;
+    const PictureParentControlSet_t *pp = pcs->ParentPcsPtr;
+    const EbPictureBufferDesc_t *in = pp->chromaDownSamplePicturePtr;
+    const uint32_t w = scs->lumaWidth, h = scs->lumaHeight, nlcu = ((w + 63) / 64) * ((h + 63) / 64);
+    MdPicRecord r;
+    memset(&r, 0, sizeof(r));
+    r.magic = MD_PIC_MAGIC;
+    r.record_size = (uint32_t)(sizeof(r) + (size_t)w * h * 3 / 2 + (size_t)nlcu * sizeof(SvtAmdOisLcuResult));
+    r.picture_number = pcs->pictureNumber, r.nlcu = nlcu;
+    svt_md_fill_picture(&r.pic, scs, pcs, md);
+    memcpy(&r.cost, pcs->cabacCost, sizeof(r.cost));
+    fwrite(&r, sizeof(r), 1, g_file);
+    for (uint32_t y = 0; y < h; y++)
+        fwrite(in->bufferY + (size_t)(in->originY + y) * in->strideY + in->originX, 1, w, g_file);
+    for (uint32_t y = 0; y < h / 2; y++)
+        fwrite(in->bufferCb + (size_t)(in->originY / 2 + y) * in->strideCb + in->originX / 2, 1, w / 2, g_file);
+    for (uint32_t y = 0; y < h / 2; y++)
+        fwrite(in->bufferCr + (size_t)(in->originY / 2 + y) * in->strideCr + in->originX / 2, 1, w / 2, g_file);
+    SvtAmdOisLcuResult o;
+    for (uint32_t l = 0; l < nlcu; l++) {
+        svt_md_fill_ois(&o, pp, l);
+        fwrite(&o, sizeof(o), 1, g_file);
+    }
+}
+
+EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
+                                    LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr)
+{
+    if (g_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_state == 0) {
+            const char *path = getenv("SVT_REF_MD_DUMP");
+            g_file = path ? fopen(path, "wb") : NULL;
+            g_state = g_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (g_state < 0)
+        return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
+    MdLcuRecord *r = (MdLcuRecord *)calloc(1, sizeof(*r));
+    r->magic = MD_LCU_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->picture_number = pcs->pictureNumber, r->lcu_index = lcuAddr;
+    svt_md_fill_lcu(&r->lcu, scs, pcs, lcuPtr, contextPtr);
+    pthread_mutex_lock(&g_lock);
+    dump_picture(scs, pcs, contextPtr);
+    pthread_mutex_unlock(&g_lock);
+    /* ConstructMdCuArray (EbProductCodingLoop.c:1290) leaves the tested flag of the LCU's highest leaf index as the thread's previous LCU
+     * set it (its loop stops one short); nothing reads that flag before the leaf's own test sets it, so clearing all flags here changes no
+     * decision - it makes "tested" in the record mean "tested in THIS call" (a partition exit can skip the last leaf) */
+    for (int i = 0; i < SVT_AMD_MD_LEAVES; i++)
+        contextPtr->mdLocalCuUnit[i].testedCuFlag = EB_FALSE;
+    const EB_ERRORTYPE rc = __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
+    for (int i = 0; i < SVT_AMD_MD_LEAVES; i++) {
+        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[i];
+        r->out.split[i] = (uint8_t)cu->splitFlag;
+        r->out.tested[i] = (uint8_t)contextPtr->mdLocalCuUnit[i].testedCuFlag;
+        r->out.pred_mode[i] = (uint8_t)cu->predictionModeFlag;
+        r->out.intra_luma_mode[i] = (uint8_t)cu->predictionUnitArray[0].intraLumaMode;
+        r->out.ycbf[i] = (uint8_t)cu->transformUnitArray[0].lumaCbf;
+        r->out.cost[i] = contextPtr->mdLocalCuUnit[i].cost;
+    }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_file);
+    fflush(g_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+    return rc;
+}

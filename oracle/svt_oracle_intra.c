@@ -177,6 +177,8 @@ void svt_oracle_intra_pu(int bps, const SvtAmdIntraPuJob *J, void *pred_y, uint3
     for (int k = 0; k < 4 * nb + 1; k++)
         any |= avail[k];
     for (int p = 0; p < 3; p++) {
+        if (!(p == 0 ? pred_y : p == 1 ? pred_cb : pred_cr))
+            continue; /* plane not asked for (the mode decision predicts luma and the chroma pair separately) */
         const int n = p ? N / 2 : N, g = p ? 2 : 4; /* samples per group in this plane */
         int border[4 * 64 + 1];                      /* scan order: bottom-left ... top-left ... top-right */
         if (!any) {

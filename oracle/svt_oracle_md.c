@@ -1,0 +1,261 @@
+/*
+ * oracle/svt_oracle_md.c - TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
+ * CPU checker of the device-resident mode decision (include/svt_hevc_amd.h "Device-resident mode decision"): ModeDecisionLcu
+ * (Codec/EbProductCodingLoop.c:4691-5114) for the pictures that revision covers (I pictures, PICT_FULL84, closed-loop intra, luma-only
+ * candidates), as a composite of
+ *   - svt-hevc_amd/csrc/md_logic.h: the scalar decisions (context generation, candidate lists, fast cost, candidate buffers, pre-mode
+ *     decision, full cost, full mode decision, partition exit, inter-depth decision) - ONE text shared with the HIP kernel, so that the
+ *     control code the GPU executes is the code this file runs on the CPU against the reference's own records;
+ *   - the pinned oracle leaves for everything that touches samples: svt_oracle_intra_pu (GenerateIntraLumaReferenceSamplesMd +
+ *     IntraPredictionCl, tests/test_oracle_intramd_golden.py), svt_oracle_NxMSadKernel (tests/test_oracle_leaf.py),
+ *     svt_oracle_product_full_loop_luma (ProductFullLoop, tests/test_oracle_fullloop_golden.py), svt_oracle_recon_tu
+ *     (PerformInverseTransformRecon: EstimateInvTransform + addition; the C tables hold the same inverse transforms as the encode
+ *     pass, Codec/EbTransforms.h:474-510).
+ * The mode decision's neighbour arrays (pcs->md*NeighborArray[MD_NEIGHBOR_ARRAY_INDEX]: candidate reconstruction, mode type, intra luma
+ * mode, depth, skip flag) are kept as picture-sized maps written with the same values in the same order
+ * (ModeDecisionUpdateNeighborArrays, :371): an array entry's last writer is the unit that holds the neighbouring position, as for the
+ * encode pass (svt_oracle_encodepass.c).
+ * PINNED by tests/test_oracle_md_golden.py on recorded ModeDecisionLcu calls of whole pictures (tests/golden/md_*.npz: split flags,
+ * modes, luma cbf and the costs of every tested leaf, oracle/ref_harness_md_dump.c).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "svt_oracle.h"
+#include "../svt-hevc_amd/csrc/md_logic.h"
+
+typedef struct MdPic {
+    uint8_t *rec;      /* the mode decision's luma reconstruction of the units decided so far (mdLumaReconNeighborArray) */
+    uint32_t pitch;
+    uint32_t *info;    /* per 4x4 luma block: mode type | intra luma mode << 8 | depth << 16 | skip flag << 24; ~0 = never written */
+    uint32_t infoPitch;
+    uint32_t w, h;
+} MdPic;
+
+static uint32_t info_at(const MdPic *M, int px, int py)
+{
+    if (px < 0 || py < 0 || px >= (int)M->w || py >= (int)M->h)
+        return 0xFFFFFFFEu;
+    return M->info[(size_t)(py >> 2) * M->infoPitch + (px >> 2)];
+}
+
+/* the luma prediction of one candidate: the job svt_oracle_intra_pu takes, cut from the maps as the reference cuts it from its arrays */
+static void md_predict(const MdPic *M, const SvtAmdMdLcu *L, int lcu_x, int lcu_y, const MdStats *st, int mode, uint8_t *pred /* N x N */)
+{
+    const int N = st->size, x0 = lcu_x + st->x, y0 = lcu_y + st->y;
+    SvtAmdIntraPuJob J;
+    memset(&J, 0, sizeof(J));
+    J.size = (uint32_t)N, J.constrained_intra = 0, J.strong_smoothing = 1; /* GenerateIntraLumaReferenceSamplesMd, EbProductCodingLoop.c:280-295 */
+    J.pic_left = L->tile_left && st->x == 0, J.pic_top = L->tile_top && st->y == 0, J.pic_right = L->tile_right && ((st->x + N) & 63) == 0;
+    J.bottom_left_ok = (uint8_t)md_bottom_left_ok(st), J.top_right_ok = (uint8_t)md_top_right_ok(st);
+    J.luma_mode = (uint8_t)mode, J.chroma_mode = 4;
+    for (int k = 0; k < 2 * N / 4; k++) {
+        const uint32_t le = info_at(M, x0 - 1, y0 + 4 * k) & 0xFF, te = info_at(M, x0 + 4 * k, y0 - 1) & 0xFF;
+        J.mode_left[k] = (uint8_t)le, J.mode_top[k] = (uint8_t)te;
+    }
+    const uint32_t tl = info_at(M, x0 - 1, y0 - 1) & 0xFF;
+    J.mode_tl = (uint8_t)(tl == 0xFE ? 0xFF : tl);
+    for (int i = 0; i < 2 * N; i++) {
+        const int le = J.mode_left[i >> 2], te = J.mode_top[i >> 2];
+        J.left[0][i] = (uint16_t)((le == 0xFE || le == 0xFF) ? 0 : M->rec[(size_t)(y0 + i) * M->pitch + x0 - 1]);
+        J.top[0][i] = (uint16_t)((te == 0xFE || te == 0xFF) ? 0 : M->rec[(size_t)(y0 - 1) * M->pitch + x0 + i]);
+    }
+    J.tl[0] = (uint16_t)((tl == 0xFE || tl == 0xFF) ? 0 : M->rec[(size_t)(y0 - 1) * M->pitch + x0 - 1]);
+    svt_oracle_intra_pu(1, &J, pred, (uint32_t)N, NULL, NULL, 0);
+}
+
+static void md_neighbors(const MdPic *M, const SvtAmdMdLcu *L, int lcu_x, int lcu_y, const MdStats *st, MdNeighbors *Nb)
+{
+    const int x0 = lcu_x + st->x, y0 = lcu_y + st->y;
+    uint32_t l = info_at(M, x0 - 1, y0), t = info_at(M, x0, y0 - 1);
+    if ((L->tile_left && st->x == 0) || (l & 0xFF) == 0xFE)
+        l = 0xFFFFFFFFu;
+    if ((L->tile_top && st->y == 0) || (t & 0xFF) == 0xFE)
+        t = 0xFFFFFFFFu;
+    Nb->left_mode = (uint8_t)l, Nb->left_intra = (uint8_t)(l >> 8), Nb->left_depth = (uint8_t)(l >> 16), Nb->left_skip = (uint8_t)(l >> 24);
+    Nb->top_mode = (uint8_t)t, Nb->top_intra = (uint8_t)(t >> 8), Nb->top_depth = (uint8_t)(t >> 16), Nb->top_skip = (uint8_t)(t >> 24);
+}
+
+static int g_md_debug;
+
+/* ModeDecisionLcu of one LCU against the picture state M (updated).  src: luma source of the PICTURE. */
+static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdCabacCost *cost, const uint8_t *src, uint32_t srcStride,
+                   const SvtAmdOisLcuResult *ois, int lcu_x, int lcu_y, MdPic *M, MdLcuState *S, SvtAmdMdLcuOut *out)
+{
+    /* per depth: the candidate buffers (prediction, reconstructed coefficients) of the unit tested last, and the best candidate's
+     * reconstruction (bestCandidateBuffers[depth]->reconPtr), at the unit's position inside the LCU */
+    static __thread uint8_t bestRec[4][64 * 64];
+    const int lcuH = (int)P->height - lcu_y < 64 ? (int)P->height - lcu_y : 64;
+    md_construct_cu_array(S, L);
+    int cuIdx = 0;
+    do {
+        int leaf = L->leaf_index[cuIdx];
+        MdStats st = md_stats(leaf);
+        S->local[leaf].tested = 1;
+        S->cu[leaf].split = (uint8_t)((P->slice_type == 2 && st.depth == 0) ? 1 : L->leaf_split[cuIdx]);
+        MdNeighbors Nb;
+        md_neighbors(M, L, lcu_x, lcu_y, &st, &Nb);
+        md_context_generation(S, leaf, st.y, &Nb);
+        uint32_t mpm[3] = {0, 0, 0};
+        if (P->mpm_search && !L->restrict_intra_global_motion)
+            md_mpm_modes(S->cu[leaf].left_intra_mode, S->cu[leaf].top_intra_mode, mpm);
+        const int fullReconSearchCount = md_nfl(P, L, st.size);
+        /* ProductGenerateAmvpMergeInterIntraMdCandidatesCU (EbModeDecision.c:1795) */
+        MdCand cand[MD_MAX_CAND];
+        int ncand = 0;
+        if (st.depth != 0 && (P->slice_type == 2 || st.depth == 3 || !L->restrict_intra_global_motion))
+            if (!(P->limit_intra && st.x == 0 && st.y == 0))
+                ncand = md_intra_candidates(P, L, ois, leaf, &st, cand);
+        int bufferTotal = fullReconSearchCount;
+        ncand = md_mpm_injection(P, L, &st, cand, ncand, &bufferTotal, mpm);
+        bufferTotal = ncand < bufferTotal ? ncand : bufferTotal;
+        static const int width[4] = {5, 8, 8, 8};
+        const int maxBuffers = bufferTotal + 1 < width[st.depth] ? bufferTotal + 1 : width[st.depth];
+        /* ProductPerformFastLoop (:1911): every candidate of an I picture is evaluated in the second loop */
+        const int N = st.size, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
+        uint64_t costs[MD_MAX_CAND], fastLumaRate[MD_MAX_CAND];
+        uint8_t evaluated[MD_MAX_CAND];
+        uint8_t pred[32 * 32];
+        for (int i = 0; i < ncand; i++) {
+            uint64_t dist = 0;
+            evaluated[i] = 1;
+            if (!cand[i].mpm) {
+                md_predict(M, L, lcu_x, lcu_y, &st, cand[i].intra_mode, pred);
+                dist = svt_oracle_NxMSadKernel(src + (size_t)y0 * srcStride + x0, srcStride, pred, (uint32_t)N, (uint32_t)N, (uint32_t)N);
+            }
+            costs[i] = md_intra_fast_cost_islice(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, &fastLumaRate[i]);
+            if (cand[i].mpm)
+                costs[i] = 0;
+        }
+        MdBuffers B;
+        md_fast_loop_buffers(&B, width[st.depth], maxBuffers, ncand, costs, evaluated);
+        bufferTotal = B.evaluated_count < bufferTotal ? B.evaluated_count : bufferTotal;
+        uint8_t types[MD_MAX_BUF], best[MD_MAX_BUF];
+        for (int b = 0; b < MD_MAX_BUF; b++)
+            types[b] = B.cand[b] >= 0 ? cand[B.cand[b]].type : 0;
+        const int same = B.evaluated_count == bufferTotal;
+        const int fullCount = md_pre_mode_decision(&B, types, same ? bufferTotal : maxBuffers, same, best);
+        /* PerformFullLoop (:4351) */
+        const int nfull = fullCount < bufferTotal ? fullCount : bufferTotal;
+        uint32_t ycbf[MD_MAX_BUF] = {0};
+        static __thread int16_t reconCoeff[MD_MAX_BUF][32 * 32];
+        static __thread uint8_t predBuf[MD_MAX_BUF][32 * 32];
+        for (int f = 0; f < nfull; f++) {
+            const int b = best[f];
+            const MdCand *c = &cand[B.cand[b]];
+            md_predict(M, L, lcu_x, lcu_y, &st, c->intra_mode, predBuf[b]);
+            int16_t residual[32 * 32], quant[32 * 32];
+            for (int j = 0; j < N; j++)
+                for (int i = 0; i < N; i++)
+                    residual[j * N + i] = (int16_t)(src[(size_t)(y0 + j) * srcStride + x0 + i] - predBuf[b][j * N + i]);
+            memcpy(quant, residual, sizeof(int16_t) * (size_t)(N * N));
+            SvtAmdFullLoopIn in;
+            SvtAmdFullLoopOut o;
+            memset(&in, 0, sizeof(in));
+            in.size = (uint32_t)N, in.qp = P->qp, in.slice_type = P->slice_type, in.pf_mode = 0, in.pm_core = 0, in.cand_type = MD_INTRA;
+            in.intra_luma_mode = c->intra_mode, in.full_lambda = P->full_lambda;
+            in.cbf_bits[0] = P->rates.lumaCbfBits[0], in.cbf_bits[1] = P->rates.lumaCbfBits[1];
+            in.cbf_bits[2] = P->rates.lumaCbfBits[5], in.cbf_bits[3] = P->rates.lumaCbfBits[6];
+            svt_oracle_product_full_loop_luma(cost, &in, residual, quant, reconCoeff[b], &o);
+            ycbf[b] = o.ycbf;
+            B.full_cost[b] = md_intra_full_luma_cost_islice(P, st.lg, o.ycbf, fastLumaRate[B.cand[b]], o.dist[0], o.coeff_bits);
+            if (g_md_debug)
+                fprintf(stderr, "  leaf %d cand mode %d buf %d: fast %llu ycbf %u dist %llu bits %llu full %llu\n", leaf, c->intra_mode, b,
+                        (unsigned long long)B.fast_cost[b], o.ycbf, (unsigned long long)o.dist[0], (unsigned long long)o.coeff_bits,
+                        (unsigned long long)B.full_cost[b]);
+        }
+        /* ProductFullModeDecision (EbModeDecision.c:1995) */
+        int lowest = best[0];
+        uint64_t lowestCost = ~0ull;
+        for (int f = 0; f < fullCount; f++)
+            if (B.full_cost[best[f]] < lowestCost)
+                lowest = best[f], lowestCost = B.full_cost[best[f]];
+        if (ncand > 0) {
+            const MdCand *c = &cand[B.cand[lowest]];
+            S->local[leaf].cost = B.full_cost[lowest];
+            S->cu[leaf].pred_mode = c->type, S->cu[leaf].skip_flag = 0, S->cu[leaf].intra_luma_mode = c->intra_mode;
+            S->cu[leaf].ycbf = (uint8_t)(ycbf[lowest] & 1);
+        }
+        if (g_md_debug)
+            fprintf(stderr, "leaf %d (%d,%d) size %d: %d candidates, %d buffers, full %d -> mode %d cost %llu\n", leaf, st.x, st.y, st.size, ncand, maxBuffers,
+                    nfull, S->cu[leaf].intra_luma_mode, (unsigned long long)S->local[leaf].cost);
+        S->local[leaf].mdc_index = (uint8_t)cuIdx;
+        int last;
+        const int exitParent = md_check_high_cost_partition(P, L, S, leaf);
+        if (exitParent >= 0) {
+            leaf = exitParent, st = md_stats(leaf), cuIdx = S->local[leaf].mdc_index;
+            S->cu[leaf].split = 0;
+            last = md_inter_depth_decision(P, S, leaf, lcu_x, lcu_y, 1);
+        } else {
+            /* PerformInverseTransformRecon (:1334): the best candidate's reconstruction, kept per depth */
+            if (ncand > 0) {
+                uint8_t *dst = bestRec[st.depth] + st.y * 64 + st.x;
+                if (S->cu[leaf].ycbf) {
+                    svt_oracle_recon_tu(1, (uint32_t)N, 0, 0, reconCoeff[lowest], predBuf[lowest], (uint32_t)N, dst, 64);
+                } else {
+                    for (int j = 0; j < N; j++)
+                        memcpy(dst + j * 64, predBuf[lowest] + j * N, (size_t)N);
+                }
+            }
+            last = md_inter_depth_decision(P, S, leaf, lcu_x, lcu_y, 0);
+        }
+        if (S->cu[last].split == 0) { /* ModeDecisionUpdateNeighborArrays (:371) */
+            const MdStats ls = md_stats(last);
+            const int lx = lcu_x + ls.x, ly = lcu_y + ls.y;
+            const uint32_t w = (uint32_t)S->cu[last].pred_mode | ((uint32_t)S->cu[last].intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) |
+                               ((uint32_t)S->cu[last].skip_flag << 24);
+            for (int j = 0; j < ls.size && ly + j < (int)M->h; j++) {
+                if (lx < (int)M->w)
+                    memcpy(M->rec + (size_t)(ly + j) * M->pitch + lx, bestRec[ls.depth] + (ls.y + j) * 64 + ls.x,
+                           (size_t)(lx + ls.size <= (int)M->w ? ls.size : (int)M->w - lx));
+                if ((j & 3) == 0)
+                    for (int i = 0; i < ls.size && lx + i < (int)M->w; i += 4)
+                        M->info[(size_t)((ly + j) >> 2) * M->infoPitch + ((lx + i) >> 2)] = w;
+            }
+        }
+        if (S->cu[leaf].split)
+            cuIdx++;
+        else if (lcuH < 64)
+            cuIdx++;
+        else
+            cuIdx += md_next_cu_step(L, cuIdx, st.depth);
+    } while (cuIdx < L->leaf_count);
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        for (int i = 0; i < SVT_AMD_MD_LEAVES; i++) {
+            out->split[i] = S->cu[i].split, out->tested[i] = S->local[i].tested, out->pred_mode[i] = S->cu[i].pred_mode;
+            out->intra_luma_mode[i] = S->cu[i].intra_luma_mode, out->ycbf[i] = S->cu[i].ycbf, out->cost[i] = S->local[i].cost;
+        }
+    }
+}
+
+/* The mode decision of a whole picture, LCUs in raster order.  src_y: source luma at sample (0,0); lcus / ois / out: one record per LCU.
+ * md_rec (optional, width x height, pitch = width): the mode decision's luma reconstruction at the end.  Returns 0, or -1 when the
+ * picture is outside the covered set. */
+int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost, const uint8_t *src_y, uint32_t stride,
+                          const SvtAmdOisLcuResult *ois, SvtAmdMdLcuOut *out, uint8_t *md_rec)
+{
+    if (!md_picture_supported(P))
+        return -1;
+    g_md_debug = getenv("SVT_ORACLE_MD_DEBUG") != NULL;
+    MdPic M;
+    M.w = P->width, M.h = P->height, M.pitch = P->width, M.infoPitch = (uint32_t)(P->width + 3) / 4;
+    M.rec = (uint8_t *)calloc((size_t)M.w * M.h, 1);
+    M.info = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)M.infoPitch * ((M.h + 3) / 4));
+    MdLcuState *S = (MdLcuState *)calloc(1, sizeof(MdLcuState));
+    if (!M.rec || !M.info || !S)
+        return -2;
+    memset(M.info, 0xFF, sizeof(uint32_t) * (size_t)M.infoPitch * ((M.h + 3) / 4));
+    const int wl = (P->width + 63) / 64, hl = (P->height + 63) / 64;
+    for (int ly = 0; ly < hl; ly++)
+        for (int lx = 0; lx < wl; lx++) {
+            const int i = ly * wl + lx;
+            if (g_md_debug)
+                fprintf(stderr, "LCU %d (%d,%d)\n", i, lx * 64, ly * 64);
+            md_lcu(P, &lcus[i], cost, src_y, stride, &ois[i], lx * 64, ly * 64, &M, S, out ? &out[i] : NULL);
+        }
+    if (md_rec)
+        memcpy(md_rec, M.rec, (size_t)M.w * M.h);
+    free(M.rec), free(M.info), free(S);
+    return 0;
+}

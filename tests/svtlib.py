@@ -357,6 +357,33 @@ LCU_BORDER_DTYPE = np.dtype([("lcu_x", "<u2"), ("lcu_y", "<u2"), ("mode_bottom",
                              ("right_y", "u1", 64), ("bottom_cb", "u1", 32), ("right_cb", "u1", 32), ("bottom_cr", "u1", 32), ("right_cr", "u1", 32)])
 EP_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("width", "<u4"), ("height", "<u4"),
                             ("lcu_index", "<u4"), ("dlf_off", "<u4"), ("ref_poc", "<u8", 2), ("work", LCU_WORK_DTYPE), ("result", LCU_RESULT_DTYPE)])
+# ---- device-resident mode decision (include/svt_hevc_amd.h "Device-resident mode decision") ----
+CABAC_COST_BYTES = 4 * (60 * 2 + 28 * 2) + 2 * 42 + 2 * 24 + 2 * 6 + 2 * 4 + 2 * (24 // 4 * 16) + 32 * 16
+MD_RATES_DTYPE = np.dtype([("splitFlagBits", "<u4", 6), ("skipFlagBits", "<u4", 6), ("mvpIndexBits", "<u4", 2), ("intraPartSizeBits", "<u4", 2),
+                           ("interPartSizeBits", "<u4", 8), ("predModeBits", "<u4", 2), ("intraLumaBits", "<u4", 4), ("intraChromaBits", "<u4", 5),
+                           ("refPicBits", "<u4", 3), ("mvdBits", "<u4", 12), ("lumaCbfBits", "<u4", 10), ("chromaCbfBits", "<u4", 10),
+                           ("rootCbfBits", "<u4", 2), ("transSubDivFlagBits", "<u4", 6), ("mergeFlagBits", "<u4", 2), ("mergeIndexBits", "<u4", 5),
+                           ("saoMergeFlagBits", "<u4", 2), ("saoTypeIndexBits", "<u4", 6), ("saoOffsetTrunUnaryBits", "<u4", 8),
+                           ("interBiDirBits", "<u4", 8), ("interUniDirBits", "<u4", 2), ("pad", "<u4", 17)])
+assert MD_RATES_DTYPE.itemsize == 512
+MD_PICTURE_DTYPE = np.dtype([("width", "<u2"), ("height", "<u2")] + [(n, "u1") for n in (
+    "slice_type", "temporal_layer", "is_reference", "enc_mode", "depth_mode", "intra_md_open_loop", "intra_injection_method", "limit_intra",
+    "mpm_search", "mpm_search_candidate", "pf_md_level", "nfl_level_md", "nmm_level_md", "full_loop_escape", "single_fast_loop",
+    "coeff_cabac_update", "spatial_sse_full_loop", "chroma_level", "intra4x4_level", "rdoq_pmcore_method", "skip_ois_8x8", "cu8x8_mode",
+    "cu16x16_mode", "limit_ois_to_dc_mode", "constrained_intra", "strong_smoothing", "qp", "chroma_qp")] + [("pad", "u1", 4)] +
+    [(n, "<u4") for n in ("fast_lambda", "full_lambda", "fast_chroma_lambda", "full_chroma_lambda")] + [("rates", MD_RATES_DTYPE)])
+MD_LCU_DTYPE = np.dtype([("leaf_count", "u1"), ("leaf_index", "u1", 85), ("leaf_split", "u1", 85), ("tile_left", "u1"), ("tile_top", "u1"),
+                         ("tile_right", "u1"), ("is_complete", "u1"), ("complexity_status_2", "u1"), ("contouring_class", "u1", 4),
+                         ("chroma_encode_mode", "u1"), ("restrict_intra_global_motion", "u1"), ("lcu_md_mode", "u1")])
+MD_LCU_OUT_DTYPE = np.dtype([("split", "u1", 85), ("tested", "u1", 85), ("pred_mode", "u1", 85), ("intra_luma_mode", "u1", 85), ("ycbf", "u1", 85),
+                             ("pad", "u1", 7), ("cost", "<u8", 85)])
+MD_PIC_MAGIC, MD_LCU_MAGIC = 0x4350444D, 0x434C444D
+MD_PIC_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("nlcu", "<u4"), ("pad", "<u4"),
+                                ("pic", MD_PICTURE_DTYPE), ("cost", "u1", CABAC_COST_BYTES), ("pad2", "u1", 4)])
+assert MD_PIC_RECORD_DTYPE.itemsize == 2152 and MD_PICTURE_DTYPE.itemsize == 564
+MD_LCU_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("lcu_index", "<u4"), ("pad", "<u4"),
+                                ("lcu", MD_LCU_DTYPE), ("pad1", "u1"), ("out", MD_LCU_OUT_DTYPE)])
+assert MD_LCU_RECORD_DTYPE.itemsize == 1320 and MD_LCU_RECORD_DTYPE.fields["out"][1] == 208
 LCU_WORK16_DTYPE = np.dtype([(n, LCU_WORK_DTYPE.fields[n][0]) if not n.startswith("src_") else (n, "<u2", LCU_WORK_DTYPE.fields[n][0].shape)
                              for n in LCU_WORK_DTYPE.names])
 LCU_RESULT16_DTYPE = np.dtype([(n, LCU_RESULT_DTYPE.fields[n][0]) if not n.startswith("rec_") else (n, "<u2", LCU_RESULT_DTYPE.fields[n][0].shape)
