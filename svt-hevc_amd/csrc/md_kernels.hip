@@ -1,0 +1,738 @@
+/*
+ * Device-resident mode decision + encode pass of whole pictures (include/svt_hevc_amd.h "Device-resident mode decision").
+ *
+ * Replaces, per LCU, what EncDecKernel's LCU loop runs between ModeDecisionConfigureLcu and the end of EncodePass
+ * (Codec/EbEncDecProcess.c:2893-3023): ModeDecisionLcu (Codec/EbProductCodingLoop.c:4691-5114) followed by the LCU's EncodePass
+ * (Codec/EbCodingLoop.c:2989; encdec_device.h) on the tree it decided, with the wavefront of AssignEncDecSegments
+ * (Codec/EbEncDecProcess.c:1540) over the picture - ONE launch per picture.
+ *
+ * One 256-thread workgroup per LCU.  The LCU's mode-decision state lives in LDS: the mode decision's own luma reconstruction
+ * (mdLumaReconNeighborArray as a picture plane: candidate reconstructions of the units decided so far) with a ring of neighbour samples,
+ * the neighbour-array entries of the 4x4 cells (mode type | intra luma mode | depth | skip flag) with the same ring, the source block.
+ * Per coding unit of the MdcLcuData_t leaf list:
+ *   lane 0        context generation, candidate list, MPM injection                       (md_logic.h - the text the CPU checker runs)
+ *   wave 0        intra reference of the unit: availability by ballot, substitution, [1 2 1] / strong smoothing   (8.4.4.2.2-3)
+ *   4 waves       fast loop: a wave per candidate, lanes over the samples - prediction evaluated per sample in closed form
+ *                 (intra_device.h), SAD by wave reduction; nothing is stored
+ *   lane 0        fast costs, the candidate-buffer replay, PreModeDecision
+ *   4 waves       full loop: a wave per surviving candidate - prediction, residual row per lane, Estimate DCT in registers, quantiser,
+ *                 coefficient-domain distortion, coefficient bits (a lane per 4x4 sub-block): the fused unit of the encode pass
+ *   lane 0        TuCalcCostLuma, full cost, ProductFullModeDecision, CheckHighCostPartition
+ *   wave 0        the winner's reconstruction (inverse transform + prediction)
+ *   lane 0        inter-depth decision;  all lanes: neighbour update
+ * then the LCU's final tree becomes an SvtAmdLcuWork record and the encode pass of the LCU runs in the same workgroup.
+ * Bounded by latency (an LCU's units are sequential, a picture's wavefront is <= (W/64+1)/2 LCUs wide), not by bytes: algorithmic HBM
+ * traffic per LCU = 6 KB source + 6 KB OIS record in, 1.1 KB decisions + the encode pass's 24 KB out.
+ */
+#include "encdec_device.h"
+#include <string.h>
+#include <vector>
+#include <mutex>
+#define MD_FN __host__ __device__ __forceinline__
+#include "md_logic.h"
+
+struct MdPictureDev {
+    uint8_t *md_rec;              /* the mode decision's luma reconstruction, sample (0,0) */
+    uint32_t md_pitch;
+    uint32_t *md_info;            /* per 4x4 luma block: mode type | intra luma mode << 8 | depth << 16 | skip flag << 24; ~0 = never written */
+    uint32_t info_pitch;
+    const uint8_t *src[3];        /* source planes on the device, sample (0,0) */
+    uint32_t src_pitch[2];
+    const SvtAmdOisLcuResult *ois;
+    const SvtAmdMdLcu *lcus;
+    const SvtAmdMdPicture *P;
+    SvtAmdMdLcuOut *out;
+};
+
+struct MdLocal8 {
+    static constexpr int PY = 144, X0 = 16;
+    uint8_t y[65 * PY];
+    uint32_t info[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
+    uint8_t src[64 * 64];
+    __device__ __forceinline__ uint8_t *at(int x, int y_) { return &y[(y_ + 1) * PY + X0 + x]; }
+    /* neighbour-array entry of the 4x4 cell at luma sample (x, y) relative to the LCU: what lies below the LCU, right of it (from its
+     * first row on) or right of the top-right LCU is never written before this LCU */
+    __device__ __forceinline__ uint32_t info_at(int x, int y_) const
+    {
+        const int cx = x >> 2, cy = y_ >> 2;
+        if (cy >= 16 || cx >= 32 || (cy >= 0 && cx >= 16))
+            return 0xFFFFFFFFu;
+        return info[(cy + 1) * 36 + cx + 1];
+    }
+};
+
+struct MdFl {
+    uint32_t nz, d0, bits;
+};
+
+struct MdShared {
+    MdLocal8 L;
+    MdLcuState S;
+    SvtAmdMdLcu lcu;
+    MdCand cand[MD_MAX_CAND];
+    unsigned long long costs[MD_MAX_CAND], fast_rate[MD_MAX_CAND];
+    uint32_t sad[MD_MAX_CAND];
+    uint8_t evaluated[MD_MAX_CAND];
+    MdBuffers B;
+    uint8_t types[MD_MAX_BUF], best[MD_MAX_BUF];
+    uint32_t ycbf[MD_MAX_BUF];
+    MdFl fl[MD_MAX_BUF];
+    int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done;
+    int16_t ref[132], reff[132], border[132];
+    uint8_t pred[MD_MAX_BUF][32 * 32];
+    int16_t recon_coeff[MD_MAX_BUF][32 * 32];
+    uint8_t best_rec[4][64 * 64];
+    int16_t tiles[4][2 * TxRegTile<32>::UNIT];
+    int16_t qbuf[4][32 * 32];
+};
+
+union MdEpShared {
+    MdShared md;
+    struct {
+        EpShared<uint8_t> S;
+        EpLocal<uint8_t> L;
+    } ep;
+};
+
+/* the unit's intra reference, unfiltered (ref) and filtered (reff), by ONE wave: GenerateLumaIntraReferenceSamplesEncodePass with
+ * constrainedIntraFlag 0 / strongIntraSmoothingFlag 1 as GenerateIntraLumaReferenceSamplesMd calls it (Codec/EbProductCodingLoop.c:280-295;
+ * Codec/EbIntraPrediction.c:750).  Same scheme as ep_intra_predict_plane (encdec_device.h). */
+__device__ __forceinline__ void md_build_refs(MdShared &M, const MdStats &st, int lane)
+{
+    MdLocal8 &L = M.L;
+    const int N = st.size, nb = N >> 2, lgN = st.lg, n = N;
+    const bool pic_left = M.lcu.tile_left && st.x == 0, pic_top = M.lcu.tile_top && st.y == 0;
+    const bool pic_right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
+    const bool bl_ok = md_bottom_left_ok(&st), tr_ok = md_top_right_ok(&st);
+    bool a = false;
+    if (lane > 4 * nb) {
+    } else if (lane < 2 * nb) {
+        const int e = (int)(L.info_at(st.x - 1, st.y + 2 * N - 4 - 4 * lane) & 0xFF);
+        a = !(e == 0xFE || (!bl_ok && lane < nb) || e == 0xFF || pic_left);
+    } else if (lane == 2 * nb) {
+        const int e = (int)(L.info_at(st.x - 1, st.y - 1) & 0xFF);
+        a = !(e == 0xFE || e == 0xFF || pic_left || pic_top);
+    } else {
+        const int k = lane - 2 * nb - 1, e = (int)(L.info_at(st.x + 4 * k, st.y - 1) & 0xFF);
+        a = !(e == 0xFE || (!tr_ok && k >= nb) || e == 0xFF || pic_top || (pic_right && k >= nb));
+    }
+    const unsigned long long m = __ballot(a);
+    const int firstGroup = m ? __ffsll((long long)m) - 1 : 1 << 30;
+    for (int k = lane; k <= 4 * n; k += 64) {
+        int v = 128;
+        if (firstGroup < (1 << 30)) {
+            const int gk = k < 2 * n ? k >> 2 : k == 2 * n ? 2 * nb : 2 * nb + 1 + ((k - 2 * n - 1) >> 2);
+            const unsigned long long below = m & ((2ull << gk) - 1ull);
+            int src;
+            if ((below >> gk) & 1ull) {
+                src = k;
+            } else if (below) {
+                const int sg = 63 - __clzll((long long)below);
+                src = sg < 2 * nb ? sg * 4 + 3 : sg == 2 * nb ? 2 * n : 2 * n + 1 + (sg - 2 * nb - 1) * 4 + 3;
+            } else {
+                src = firstGroup < 2 * nb ? firstGroup * 4 : firstGroup == 2 * nb ? 2 * n : 2 * n + 1 + (firstGroup - 2 * nb - 1) * 4;
+            }
+            v = src < 2 * n ? (int)*L.at(st.x - 1, st.y + 2 * n - 1 - src) : src == 2 * n ? (int)*L.at(st.x - 1, st.y - 1) : (int)*L.at(st.x + (src - 2 * n - 1), st.y - 1);
+        }
+        M.border[k] = (int16_t)v;
+    }
+    EP_WAVE_SYNC();
+    const int bl = M.border[0], tlv = M.border[2 * n], tr = M.border[4 * n];
+    const bool strong = N >= 32 && abs(bl + tlv - 2 * M.border[n]) < 8 && abs(tlv + tr - 2 * M.border[3 * n]) < 8;
+    for (int k = lane; k <= 4 * n; k += 64) {
+        const int v = M.border[k];
+        int f = v;
+        if (strong) {
+            if (k > 0 && k < 2 * n)
+                f = ((2 * n - k) * bl + k * tlv + n) >> (lgN + 1);
+            else if (k > 2 * n && k < 4 * n)
+                f = ((2 * n - (k - 2 * n)) * tlv + (k - 2 * n) * tr + n) >> (lgN + 1);
+        } else if (k > 0 && k < 4 * n) {
+            f = (M.border[k - 1] + 2 * v + M.border[k + 1] + 2) >> 2;
+        }
+        const int o = k < 2 * n ? 2 * n - 1 - k : k;
+        M.ref[o] = (int16_t)v, M.reff[o] = (int16_t)f;
+    }
+    EP_WAVE_SYNC();
+}
+
+/* which reference a luma mode predicts from (intraLumaFilterTable, Codec/EbIntraPrediction.c:60-66) */
+__device__ __forceinline__ bool md_mode_filtered(int mode, int lgN)
+{
+    const int dA = abs(mode - 10), dB = abs(mode - 26), dm = dA < dB ? dA : dB;
+    const int thrTab = lgN == 2 ? 35 : lgN == 3 ? 7 : lgN == 4 ? 1 : lgN == 5 ? 0 : 10;
+    return dm > thrTab && mode != 1;
+}
+
+__device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, int lane)
+{
+    int dc = lane < n ? ref[lane] + ref[2 * n + 1 + lane] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        dc += __shfl_xor(dc, o);
+    return (dc + n) >> (lgn + 1);
+}
+
+/* ProductFullLoop of one intra luma candidate on lanes r = 0..N-1 of the calling wave (EbFullLoop.c:185-446 for a unit with one transform
+ * unit, PF off): residual -> EstimateTransform -> ProductUnifiedQuantizeInvQuantizeMd -> PictureFullDistortionLuma ->
+ * TuEstimateCoeffBitsLuma.  pred: the candidate's prediction (pitch N); recon_coeff: the de-quantised coefficients (N x N, pitch N) for
+ * PerformInverseTransformRecon.  Returns (every lane) nz, the raw 32-bit distortion sum and the estimator's bit count. */
+template <int N>
+__device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, const uint8_t *pred, int16_t *recon_coeff, int16_t *tile, int16_t *qbuf, int qp,
+                                                  int slice_type, const SvtAmdCabacCost &cost, int intra_mode)
+{
+    constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
+    constexpr int fs1 = N == 32 ? 6 : N == 16 ? 4 : N == 8 ? 2 : 1, fs2 = N == 4 ? 8 : 9, wrap = N == 32 ? 2 : N == 16 ? 1 : 0;
+    const int r = lane & (N - 1);
+    const bool active = lane < N;
+    int x[N];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            x[j] = (int)src[r * 64 + j] - (int)pred[r * N + j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            x[j] = 0;
+    }
+    fwd_2d_regs<N>(x, tile + (lane / N) * TxRegTile<N>::UNIT, r, fs1, fs2, wrap); /* x[j] = coefficient (j, r) */
+    const int qpRem = qp % 6, qpPer = qp / 6;
+    const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
+    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    const int tshift = 7 - LG, shiftedQBits = 14 + qpPer + tshift;
+    const uint32_t offs = ((slice_type == 2 || slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
+    const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
+    unsigned nz = 0, d0 = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const int v = x[j], sign = v < 0 ? -1 : 1;
+        int tq = abs(v);
+        tq = (int)((uint32_t)tq * QF);
+        tq = (int)((uint32_t)tq + offs);
+        tq >>= shiftedQBits;
+        const int q = clip16i(sign * tq);
+        const int c = clip16i(((q * shiftedFFunc) + iq_offset) >> shiftNum);
+        if (active) {
+            qbuf[j * N + r] = (int16_t)q, recon_coeff[j * N + r] = (int16_t)c;
+            const int df = (int16_t)(v - c);
+            nz += q != 0, d0 += (uint32_t)(df * df);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < N; o <<= 1)
+        nz += __shfl_xor(nz, o), d0 += __shfl_xor(d0, o);
+    nz = (unsigned)__shfl((int)nz, 0), d0 = (unsigned)__shfl((int)d0, 0);
+    EP_WAVE_SYNC(); /* qbuf is written */
+    constexpr int S4 = (N / 4) * (N / 4);
+    const SvtAmdTuInfo ti = {nz, 2 /* INTRA_MODE */, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, 0};
+    const uint32_t b32 = coeff_bits_lanes(cost, qbuf, N, LG, ti, lane < S4, lane, lane & (S4 - 1));
+    MdFl o;
+    o.nz = nz, o.d0 = d0, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
+    return o;
+}
+
+/* PerformInverseTransformRecon of the winner (Codec/EbProductCodingLoop.c:1334-1414): EstimateInvTransform of the de-quantised
+ * coefficients + the prediction, clipped, into the per-depth reconstruction at the unit's position (pitch 64) */
+template <int N>
+__device__ __forceinline__ void md_recon_unit(int lane, const int16_t *recon_coeff, const uint8_t *pred, uint8_t *dst, int16_t *tile)
+{
+    constexpr int P = TxRegTile<N>::PITCH;
+    const int r = lane & (N - 1);
+    const bool active = lane < N;
+    int16_t *t = tile + (lane / N) * TxRegTile<N>::UNIT;
+    int c[N];
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        c[j] = active ? (int)recon_coeff[j * N + r] : 0;
+    inv_1d_regs<N>(c, 7, [&](int j, int16_t v) { t[r * P + j] = v; });
+    EP_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        c[k] = t[k * P + r];
+    int y[N];
+    inv_1d_regs<N>(c, 12, [&](int j, int16_t v) { y[j] = v; });
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const int v = (int)pred[r * N + j] + y[j];
+            dst[r * 64 + j] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+}
+
+/* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
+__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared &M)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    MdLocal8 &L = M.L;
+    const int W = (int)P.width, H = (int)P.height;
+    const int lw = min(64, W - lcu_x), lh = min(64, H - lcu_y);
+    /* ---- the LCU's surroundings into LDS ---- */
+    for (int i = t; i < (int)sizeof(SvtAmdMdLcu); i += 256)
+        ((uint8_t *)&M.lcu)[i] = ((const uint8_t *)&D.lcus[lcu])[i];
+    for (int i = t; i < 17 * 36; i += 256) {
+        const int cy = i / 36 - 1, cx = i - (cy + 1) * 36 - 1;
+        uint32_t v = 0xFFFFFFFFu;
+        if (cy < 0 || cx < 0) {
+            const int px = lcu_x + 4 * cx, py = lcu_y + 4 * cy;
+            v = (px < 0 || py < 0 || px >= W || py >= H) ? 0xFFFFFFFEu : D.md_info[(size_t)(py >> 2) * D.info_pitch + (px >> 2)];
+        }
+        L.info[i] = v;
+    }
+    for (int i = t; i < 130 + 64; i += 256) { /* ring samples: row -1 (x = -1 .. 128), column -1 */
+        const int x = i < 130 ? i - 1 : -1, y = i < 130 ? -1 : i - 130;
+        const int gx = lcu_x + x, gy = lcu_y + y;
+        if (x < 128 && gx >= 0 && gy >= 0 && gx < W && gy < H)
+            *L.at(x, y) = D.md_rec[(size_t)gy * D.md_pitch + gx];
+    }
+    for (int i = t; i < 64 * 64 / 4; i += 256) {
+        const int y = i >> 4, x = (i & 15) * 4;
+        uint32_t v = 0;
+        if (x < lw && y < lh)
+            v = *(const uint32_t *)(D.src[0] + (size_t)(lcu_y + y) * D.src_pitch[0] + lcu_x + x);
+        *(uint32_t *)&L.src[y * 64 + x] = v;
+    }
+    __syncthreads();
+    if (t == 0) {
+        md_construct_cu_array(&M.S, &M.lcu);
+        M.cu_idx = 0, M.done = 0;
+    }
+    __syncthreads();
+    const SvtAmdOisLcuResult *ois = &D.ois[lcu];
+    for (;;) {
+        /* ---- lane 0: the unit, its contexts and its candidates ---- */
+        if (t == 0) {
+            const int cuIdx = M.cu_idx, leaf = M.lcu.leaf_index[cuIdx];
+            const MdStats st = md_stats(leaf);
+            M.leaf = leaf;
+            M.S.local[leaf].tested = 1;
+            M.S.cu[leaf].split = (uint8_t)((P.slice_type == 2 && st.depth == 0) ? 1 : M.lcu.leaf_split[cuIdx]);
+            uint32_t l = L.info_at(st.x - 1, st.y), tp = L.info_at(st.x, st.y - 1);
+            if ((M.lcu.tile_left && st.x == 0) || (l & 0xFF) == 0xFE)
+                l = 0xFFFFFFFFu;
+            if ((M.lcu.tile_top && st.y == 0) || (tp & 0xFF) == 0xFE)
+                tp = 0xFFFFFFFFu;
+            MdNeighbors Nb;
+            Nb.left_mode = (uint8_t)l, Nb.left_intra = (uint8_t)(l >> 8), Nb.left_depth = (uint8_t)(l >> 16), Nb.left_skip = (uint8_t)(l >> 24);
+            Nb.top_mode = (uint8_t)tp, Nb.top_intra = (uint8_t)(tp >> 8), Nb.top_depth = (uint8_t)(tp >> 16), Nb.top_skip = (uint8_t)(tp >> 24);
+            md_context_generation(&M.S, leaf, st.y, &Nb);
+            uint32_t mpm[3] = {0, 0, 0};
+            if (P.mpm_search && !M.lcu.restrict_intra_global_motion)
+                md_mpm_modes(M.S.cu[leaf].left_intra_mode, M.S.cu[leaf].top_intra_mode, mpm);
+            int ncand = 0;
+            if (st.depth != 0 && (P.slice_type == 2 || st.depth == 3 || !M.lcu.restrict_intra_global_motion))
+                if (!(P.limit_intra && st.x == 0 && st.y == 0))
+                    ncand = md_intra_candidates(&P, &M.lcu, ois, leaf, &st, M.cand);
+            int bufferTotal = md_nfl(&P, &M.lcu, st.size);
+            ncand = md_mpm_injection(&P, &M.lcu, &st, M.cand, ncand, &bufferTotal, mpm);
+            bufferTotal = ncand < bufferTotal ? ncand : bufferTotal;
+            const int width = st.depth == 0 ? 5 : 8;
+            M.ncand = ncand, M.buffer_total = bufferTotal, M.max_buffers = bufferTotal + 1 < width ? bufferTotal + 1 : width;
+        }
+        __syncthreads();
+        const int leaf = M.leaf, ncand = M.ncand;
+        const MdStats st = md_stats(leaf);
+        const int N = st.size, lgN = st.lg;
+        /* ---- wave 0: the unit's intra reference ---- */
+        if (wave == 0 && ncand > 0)
+            md_build_refs(M, st, lane);
+        __syncthreads();
+        /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop; an I picture has no candidate of the first) ---- */
+        for (int c = wave; c < ncand; c += 4) {
+            uint32_t sad = 0;
+            if (!M.cand[c].mpm) {
+                const int mode = M.cand[c].intra_mode;
+                const int16_t *use = md_mode_filtered(mode, lgN) ? M.reff : M.ref;
+                const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
+                for (int e = lane; e < N * N; e += 64) {
+                    const int y = e >> lgN, x = e & (N - 1);
+                    const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
+                    sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    sad += __shfl_xor(sad, o);
+            }
+            if (lane == 0)
+                M.sad[c] = sad;
+        }
+        __syncthreads();
+        /* ---- lane 0: fast costs, candidate buffers, PreModeDecision ---- */
+        if (t == 0) {
+            int bufferTotal = M.buffer_total;
+            for (int i = 0; i < ncand; i++) {
+                unsigned long long rate = 0;
+                uint64_t cst = md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, M.cand[i].mpm ? 0 : M.sad[i], (uint64_t *)&rate);
+                M.costs[i] = M.cand[i].mpm ? 0 : cst, M.fast_rate[i] = rate, M.evaluated[i] = 1;
+            }
+            md_fast_loop_buffers(&M.B, 8, M.max_buffers, ncand, (const uint64_t *)M.costs, M.evaluated);
+            bufferTotal = M.B.evaluated_count < bufferTotal ? M.B.evaluated_count : bufferTotal;
+            for (int b = 0; b < MD_MAX_BUF; b++)
+                M.types[b] = M.B.cand[b] >= 0 ? M.cand[M.B.cand[b]].type : 0, M.ycbf[b] = 0;
+            const int same = M.B.evaluated_count == bufferTotal;
+            M.full_count = md_pre_mode_decision(&M.B, M.types, same ? bufferTotal : M.max_buffers, same, M.best);
+            M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
+        }
+        __syncthreads();
+        /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
+        const int nfull = M.nfull;
+        for (int f = wave; f < nfull; f += 4) {
+            const int b = M.best[f], mode = M.cand[M.B.cand[b]].intra_mode;
+            const int16_t *use = md_mode_filtered(mode, lgN) ? M.reff : M.ref;
+            const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
+            uint8_t *pred = M.pred[b];
+            for (int e = lane; e < N * N; e += 64)
+                pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
+            EP_WAVE_SYNC();
+            const uint8_t *src = &L.src[st.y * 64 + st.x];
+            MdFl o;
+            switch (N) {
+            case 32: o = md_full_loop_unit<32>(lane, src, pred, M.recon_coeff[b], M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost, mode); break;
+            case 16: o = md_full_loop_unit<16>(lane, src, pred, M.recon_coeff[b], M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost, mode); break;
+            default: o = md_full_loop_unit<8>(lane, src, pred, M.recon_coeff[b], M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost, mode); break;
+            }
+            if (lane == 0)
+                M.fl[b] = o;
+        }
+        __syncthreads();
+        /* ---- lane 0: TuCalcCostLuma, full cost, ProductFullModeDecision, CheckHighCostPartition ---- */
+        if (t == 0) {
+            for (int f = 0; f < nfull; f++) {
+                const int b = M.best[f];
+                const MdFl o = M.fl[b];
+                const int dshift = 2 * (7 - lgN);
+                const unsigned long long d0 = ((unsigned long long)o.d0 + (1ull << (dshift - 1))) >> dshift; /* intra: both sums of the kernel = the residual sum */
+                const unsigned long long tuBits = (((unsigned long long)o.bits) << 10) >> 15;
+                const uint32_t ycbf = o.nz != 0; /* an intra candidate's zero-cbf cost is infinite (EbRateDistortionCost.c:348-352) */
+                M.ycbf[b] = ycbf;
+                M.B.full_cost[b] = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[M.B.cand[b]], d0, tuBits);
+            }
+            int lowest = M.best[0];
+            unsigned long long lowestCost = ~0ull;
+            for (int f = 0; f < M.full_count; f++)
+                if (M.B.full_cost[M.best[f]] < lowestCost)
+                    lowest = M.best[f], lowestCost = M.B.full_cost[M.best[f]];
+            if (ncand > 0) {
+                const MdCand c = M.cand[M.B.cand[lowest]];
+                M.S.local[leaf].cost = M.B.full_cost[lowest];
+                M.S.cu[leaf].pred_mode = c.type, M.S.cu[leaf].skip_flag = 0, M.S.cu[leaf].intra_luma_mode = c.intra_mode;
+                M.S.cu[leaf].ycbf = (uint8_t)(M.ycbf[lowest] & 1);
+            }
+            M.lowest = lowest;
+            M.S.local[leaf].mdc_index = (uint8_t)M.cu_idx;
+            const int exitParent = md_check_high_cost_partition(&P, &M.lcu, &M.S, leaf);
+            M.do_recon = exitParent < 0 && ncand > 0, M.exited = exitParent >= 0;
+            if (exitParent >= 0) {
+                M.leaf = exitParent, M.cu_idx = M.S.local[exitParent].mdc_index;
+                M.S.cu[exitParent].split = 0;
+                M.last = md_inter_depth_decision(&P, &M.S, exitParent, lcu_x, lcu_y, 1);
+            }
+        }
+        __syncthreads();
+        /* ---- wave 0: the winner's reconstruction ---- */
+        if (M.do_recon && wave == 0) {
+            const int b = M.lowest;
+            uint8_t *dst = M.best_rec[st.depth] + st.y * 64 + st.x;
+            if (M.S.cu[leaf].ycbf) {
+                switch (N) {
+                case 32: md_recon_unit<32>(lane, M.recon_coeff[b], M.pred[b], dst, M.tiles[0]); break;
+                case 16: md_recon_unit<16>(lane, M.recon_coeff[b], M.pred[b], dst, M.tiles[0]); break;
+                default: md_recon_unit<8>(lane, M.recon_coeff[b], M.pred[b], dst, M.tiles[0]); break;
+                }
+            } else {
+                for (int e = lane; e < N * N; e += 64)
+                    dst[(e >> lgN) * 64 + (e & (N - 1))] = M.pred[b][e];
+            }
+        }
+        __syncthreads();
+        /* ---- lane 0: inter-depth decision ---- */
+        if (t == 0) {
+            if (!M.exited)
+                M.last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0);
+            M.update = M.S.cu[M.last].split == 0;
+        }
+        __syncthreads();
+        /* ---- all lanes: ModeDecisionUpdateNeighborArrays of the unit the decision ended on ---- */
+        if (M.update) {
+            const int last = M.last;
+            const MdStats ls = md_stats(last);
+            const uint32_t w = (uint32_t)M.S.cu[last].pred_mode | ((uint32_t)M.S.cu[last].intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) |
+                               ((uint32_t)M.S.cu[last].skip_flag << 24);
+            const uint8_t *srcp = M.best_rec[ls.depth];
+            for (int e = t; e < ls.size * ls.size; e += 256) {
+                const int y = e >> ls.lg, x = e & (ls.size - 1);
+                *L.at(ls.x + x, ls.y + y) = srcp[(ls.y + y) * 64 + ls.x + x];
+            }
+            const int cells = ls.size >> 2;
+            for (int e = t; e < cells * cells; e += 256)
+                L.info[((ls.y >> 2) + e / cells + 1) * 36 + (ls.x >> 2) + e % cells + 1] = w;
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int cur = M.leaf; /* the unit the loop stands on: the tested one, or the parent a partition exit fell back to */
+            const MdStats cs = md_stats(cur);
+            int cuIdx = M.cu_idx;
+            if (M.S.cu[cur].split)
+                cuIdx++;
+            else if (lh < 64)
+                cuIdx++;
+            else
+                cuIdx += md_next_cu_step(&M.lcu, cuIdx, cs.depth);
+            M.cu_idx = cuIdx;
+            M.done = cuIdx >= M.lcu.leaf_count;
+        }
+        __syncthreads();
+        if (M.done)
+            break;
+    }
+    /* ---- the LCU's state leaves LDS: neighbour maps of the picture + the decision record ---- */
+    for (int i = t; i < 64 * 64 / 4; i += 256) {
+        const int y = i >> 4, x = (i & 15) * 4;
+        if (x < lw && y < lh)
+            *(uint32_t *)(D.md_rec + (size_t)(lcu_y + y) * D.md_pitch + lcu_x + x) = *(const uint32_t *)L.at(x, y);
+    }
+    for (int i = t; i < 16 * 16; i += 256) {
+        const int cy = i >> 4, cx = i & 15;
+        if (4 * cx < lw && 4 * cy < lh)
+            D.md_info[(size_t)((lcu_y >> 2) + cy) * D.info_pitch + (lcu_x >> 2) + cx] = L.info[(cy + 1) * 36 + cx + 1];
+    }
+    if (D.out) {
+        SvtAmdMdLcuOut &O = D.out[lcu];
+        for (int i = t; i < SVT_AMD_MD_LEAVES; i += 256) {
+            O.split[i] = M.S.cu[i].split, O.tested[i] = M.S.local[i].tested, O.pred_mode[i] = M.S.cu[i].pred_mode;
+            O.intra_luma_mode[i] = M.S.cu[i].intra_luma_mode, O.ycbf[i] = M.S.cu[i].ycbf, O.cost[i] = M.S.local[i].cost;
+        }
+    }
+}
+
+/* the EncDec input contract the decisions amount to (what svt_hook_encdec.c:fill_work builds on the host): the final tree in Z order */
+__device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmdMdPicture &P, const MdShared &M, int lcu_x, int lcu_y, SvtAmdLcuWork &Wk)
+{
+    const int t = threadIdx.x;
+    const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
+    if (t == 0) {
+        Wk.lcu_x = (uint16_t)lcu_x, Wk.lcu_y = (uint16_t)lcu_y;
+        Wk.slice_type = P.slice_type, Wk.temporal_layer = P.temporal_layer, Wk.constrained_intra = P.constrained_intra, Wk.strong_smoothing = P.strong_smoothing;
+        Wk.tile_left = M.lcu.tile_left, Wk.tile_top = M.lcu.tile_top, Wk.tile_right = M.lcu.tile_right;
+        Wk.full_lambda = P.full_lambda;
+        Wk.luma_cbf_bits[0] = P.rates.lumaCbfBits[0], Wk.luma_cbf_bits[1] = P.rates.lumaCbfBits[1];
+        Wk.luma_cbf_bits[2] = P.rates.lumaCbfBits[5], Wk.luma_cbf_bits[3] = P.rates.lumaCbfBits[6];
+        Wk.pm_core = 0;
+        int n = 0, it = 0;
+        while (it < SVT_AMD_MD_LEAVES) {
+            if (M.S.cu[it].split) {
+                it++;
+                continue;
+            }
+            const MdStats st = md_stats(it);
+            if (lcu_x + st.x < (int)P.width && lcu_y + st.y < (int)P.height && n < SVT_AMD_LCU_MAX_CUS) {
+                SvtAmdLcuCu &u = Wk.cu[n++];
+                u.x = st.x, u.y = st.y, u.size = st.size, u.pred_mode = M.S.cu[it].pred_mode, u.intra_luma_mode = M.S.cu[it].intra_luma_mode;
+                u.bottom_left_ok = (uint8_t)md_bottom_left_ok(&st), u.top_right_ok = (uint8_t)md_top_right_ok(&st);
+                u.qp = P.qp, u.chroma_qp = P.chroma_qp, u.leaf_index = (uint8_t)it, u.inter_dir = 0, u.inter_kind = 0, u.dz_offset = 0;
+                u.mv[0][0] = u.mv[0][1] = u.mv[1][0] = u.mv[1][1] = 0;
+            }
+            it += md_depth_offset(st.depth);
+        }
+        Wk.num_cus = (uint8_t)n;
+    }
+    for (int i = t; i < 64 * 64 / 4; i += 256)
+        ((uint32_t *)Wk.src_y)[i] = ((const uint32_t *)M.L.src)[i];
+    for (int i = t; i < 2 * 32 * 32; i += 256) {
+        const int p = i >> 10, e = i & 1023, y = e >> 5, x = e & 31;
+        uint8_t v = 0;
+        if (x < lw / 2 && y < lh / 2)
+            v = D.src[1 + p][(size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x];
+        (p ? Wk.src_cr : Wk.src_cb)[e] = v;
+    }
+}
+
+/* ONE launch per picture: persistent workgroups draw LCUs as tickets in wavefront order (k_encode_picture's scheme, encdec_kernels.hip) */
+__global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPicture E, SvtAmdLcuWork *__restrict__ works, SvtAmdLcuResult *__restrict__ results,
+                                                           int nlcu, int wl, unsigned *ticket, unsigned *done, const unsigned *__restrict__ order, unsigned epoch)
+{
+    extern __shared__ __align__(16) unsigned char md_lds[];
+    MdEpShared &U = *reinterpret_cast<MdEpShared *>(md_lds);
+    __shared__ unsigned s_ticket;
+    const SvtAmdMdPicture &P = *D.P;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        if ((int)s_ticket >= nlcu)
+            return;
+        const int lcu = (int)order[s_ticket];
+        const int lx = lcu % wl, ly = lcu / wl;
+        const SvtAmdMdLcu &Lc = D.lcus[lcu];
+        if (threadIdx.x == 0) {
+            const int dep0 = Lc.tile_left ? -1 : lcu - 1;
+            const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
+            if (dep0 >= 0)
+                while (__hip_atomic_load(&done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(16);
+            if (dep1 >= 0)
+                while (__hip_atomic_load(&done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        md_lcu(D, E, P, lcu, lx * 64, ly * 64, U.md);
+        __syncthreads();
+        md_make_work(D, P, U.md, lx * 64, ly * 64, works[lcu]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ep_encode_lcu<uint8_t>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+/* ---- host side ------------------------------------------------------------------------------------------------------------- */
+extern "C" int svt_amd_md_picture_supported(const SvtAmdMdPicture *P) { return P ? md_picture_supported(P) : 0; }
+
+/* the mode decision's part of a picture object: neighbour maps, the picture's source and the per-LCU arrays, all in HBM */
+struct SvtAmdMdState {
+    MdPictureDev d;
+    uint8_t *d_src[3];
+    SvtAmdOisLcuResult *d_ois;
+    SvtAmdMdLcu *d_lcus;
+    SvtAmdMdPicture *d_P;
+    SvtAmdMdLcuOut *d_out;
+    SvtAmdLcuWork *d_works;
+    SvtAmdLcuResult *d_results;
+    size_t info_bytes;
+};
+
+void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
+{
+    SvtAmdMdState *m = pic->md;
+    if (!m)
+        return;
+    void *ptrs[] = {m->d.md_rec, m->d.md_info, m->d_src[0], m->d_src[1], m->d_src[2], m->d_ois, m->d_lcus, m->d_P, m->d_out, m->d_works, m->d_results};
+    for (void *q : ptrs)
+        if (q)
+            (void)hipFree(q);
+    free(m);
+    pic->md = nullptr;
+}
+
+static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
+{
+    if (pic->md) {
+        *out = pic->md;
+        return SVT_AMD_OK;
+    }
+    SvtAmdMdState *m = (SvtAmdMdState *)calloc(1, sizeof(*m));
+    if (!m)
+        return SVT_AMD_ERR_RESOURCES;
+    pic->md = m;
+    const size_t n = (size_t)pic->nlcu;
+    m->d.md_pitch = pic->d.pitch[0];
+    m->d.info_pitch = ((uint32_t)(pic->d.width >> 2) + 63) & ~63u;
+    m->info_bytes = sizeof(uint32_t) * (size_t)m->d.info_pitch * (pic->d.height >> 2);
+    bool ok = hipMalloc((void **)&m->d.md_rec, pic->plane_bytes[0]) == hipSuccess && hipMalloc((void **)&m->d.md_info, m->info_bytes) == hipSuccess;
+    for (int k = 0; k < 3 && ok; k++)
+        ok = hipMalloc((void **)&m->d_src[k], pic->plane_bytes[k]) == hipSuccess;
+    ok = ok && hipMalloc((void **)&m->d_ois, sizeof(SvtAmdOisLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_lcus, sizeof(SvtAmdMdLcu) * n) == hipSuccess &&
+         hipMalloc((void **)&m->d_P, sizeof(SvtAmdMdPicture)) == hipSuccess && hipMalloc((void **)&m->d_out, sizeof(SvtAmdMdLcuOut) * n) == hipSuccess &&
+         hipMalloc((void **)&m->d_works, sizeof(SvtAmdLcuWork) * n) == hipSuccess && hipMalloc((void **)&m->d_results, sizeof(SvtAmdLcuResult) * n) == hipSuccess;
+    if (!ok) {
+        svt_amd_set_error("hipMalloc (mode-decision picture state) failed");
+        svt_amd_md_state_free(pic);
+        return SVT_AMD_ERR_RESOURCES;
+    }
+    *out = m;
+    return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const uint8_t *src_y,
+                                         uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
+                                         int ois_slot, const SvtAmdCabacCost *cost, SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results)
+{
+    if (!ctx || !pic || !P || !lcus || !src_y || !src_cb || !src_cr || !cost)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (!md_picture_supported(P) || P->width != pic->d.width || P->height != pic->d.height || pic->d.bps != 1) {
+        svt_amd_set_error("svt_amd_md_encode_picture: picture outside what this revision covers (svt_amd_md_picture_supported), or not the picture object's size / 8-bit");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    const int n = pic->nlcu, wl = (pic->d.width + 63) / 64, hl = (pic->d.height + 63) / 64;
+    int tiles = 0;
+    for (int i = 0; i < n; i++) {
+        if (lcus[i].leaf_count < 1 || lcus[i].leaf_count > SVT_AMD_MD_LEAVES) {
+            svt_amd_set_error("svt_amd_md_encode_picture: LCU %d has no leaf list", i);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        for (int k = 0; k < lcus[i].leaf_count; k++)
+            if (lcus[i].leaf_index[k] >= SVT_AMD_MD_LEAVES || (k && lcus[i].leaf_index[k] <= lcus[i].leaf_index[k - 1])) {
+                svt_amd_set_error("svt_amd_md_encode_picture: LCU %d: leaf list not ascending", i);
+                return SVT_AMD_ERR_BAD_PARAM;
+            }
+        tiles += lcus[i].tile_left && lcus[i].tile_top;
+    }
+    const SvtAmdOisLcuResult *d_ois_slot = nullptr;
+    if (!ois) {
+        SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
+        if (ois_slot < 0 || ois_slot >= root->num_slots || !root->slots[ois_slot].d_ois_out) {
+            svt_amd_set_error("svt_amd_md_encode_picture: no open-loop intra search records in slot %d", ois_slot);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        d_ois_slot = root->slots[ois_slot].d_ois_out;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rate_tables_once(ctx->device);
+    if (rc)
+        return rc;
+    SvtAmdMdState *m = nullptr;
+    if ((rc = md_state(pic, &m)) != 0)
+        return rc;
+    hipStream_t st = ctx->stream;
+    const uint8_t *hs[3] = {src_y, src_cb, src_cr};
+    for (int k = 0; k < 3; k++) {
+        const uint32_t pw = k ? pic->d.width / 2 : pic->d.width, ph = k ? pic->d.height / 2 : pic->d.height;
+        HIP_TRY(hipMemcpy2DAsync(m->d_src[k], pic->d.pitch[k], hs[k], k ? stride_c : stride_y, pw, ph, hipMemcpyHostToDevice, st));
+        m->d.src[k] = m->d_src[k];
+    }
+    m->d.src_pitch[0] = pic->d.pitch[0], m->d.src_pitch[1] = pic->d.pitch[1];
+    HIP_TRY(hipMemcpyAsync(m->d_lcus, lcus, sizeof(SvtAmdMdLcu) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_P, P, sizeof(*P), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, st));
+    pic->has_cost = true;
+    if (ois)
+        HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
+    m->d.ois = ois ? m->d_ois : d_ois_slot, m->d.lcus = m->d_lcus, m->d.P = m->d_P, m->d.out = m->d_out;
+    pic->epoch++;
+    pic->deblocked = pic->sao_done = false;
+    HIP_TRY(hipMemsetAsync(pic->d_sync, 0, sizeof(unsigned), st));
+    HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, st));
+    HIP_TRY(hipMemsetAsync(m->d.md_info, 0xFF, m->info_bytes, st));
+    HIP_TRY(hipMemsetAsync(m->d_results, 0, sizeof(SvtAmdLcuResult) * (size_t)n, st));
+    HIP_TRY(hipMemsetAsync(m->d_works, 0, sizeof(SvtAmdLcuWork) * (size_t)n, st));
+    {
+        static std::mutex mu;
+        static bool attr[64];
+        std::lock_guard<std::mutex> g(mu);
+        if (!attr[ctx->device & 63]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared)));
+            attr[ctx->device & 63] = true;
+        }
+    }
+    int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 1;
+    grid = grid > n ? n : grid > 512 ? 512 : grid;
+    hipLaunchKernelGGL(k_md_encode_picture, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared), st, m->d, pic->d, m->d_works, m->d_results, n, wl, pic->d_sync,
+                       pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+    HIP_TRY(hipGetLastError());
+    if (md_out)
+        HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (works)
+        HIP_TRY(hipMemcpyAsync(works, m->d_works, sizeof(SvtAmdLcuWork) * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (results)
+        HIP_TRY(hipMemcpyAsync(results, m->d_results, sizeof(SvtAmdLcuResult) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SVT_AMD_OK;
+}

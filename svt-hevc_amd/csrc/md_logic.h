@@ -181,7 +181,7 @@ MD_FN int md_anti_contouring_valid(int mode) { return mode < 2 || ((mode - 2) & 
  * are not offered to this revision.  ois: the LCU's open-loop intra search record.  Returns the candidate count. */
 MD_FN int md_intra_candidates(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdOisLcuResult *ois, int leaf, const MdStats *st, MdCand *cand)
 {
-    static const uint8_t antiContouringMode[4] = {MD_PLANAR, MD_DC, MD_HOR, MD_VER}; /* first 4 of AntiContouringIntraMode */
+    const uint8_t antiContouringMode[4] = {MD_PLANAR, MD_DC, MD_HOR, MD_VER}; /* first 4 of AntiContouringIntraMode */
     int n = 0;
     const int cuSize = st->size;
     if (P->intra_injection_method == 2) {

@@ -1,0 +1,128 @@
+"""GPU: the device-resident mode decision + encode pass of whole pictures (svt_amd_md_encode_picture, through the C ABI) against
+ (i) the reference's own ModeDecisionLcu records of whole pictures (tests/golden/md_*.npz: split flag, mode, luma cbf and cost of every
+     leaf the reference tested),
+ (ii) the EncDec input contract those decisions amount to, and
+ (iii) the pinned CPU oracle of the encode pass run on that contract in raster order (coefficients, flags, reconstruction)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import svtlib as S
+from test_oracle_md_golden import CASES, compare_md, works_from_md, oracle_md_picture
+from test_oracle_encodepass_golden import compare_lcu
+
+pytestmark = pytest.mark.gpu
+
+
+def sig(lib):
+    vp = C.c_void_p
+    lib.svt_amd_md_encode_picture.restype = C.c_int
+    lib.svt_amd_md_encode_picture.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_int, vp, vp, vp, vp]
+    lib.svt_amd_md_picture_supported.restype = C.c_int
+    lib.svt_amd_md_picture_supported.argtypes = [vp]
+    lib.svt_amd_encdec_picture_create.restype = C.c_int
+    lib.svt_amd_encdec_picture_create.argtypes = [vp, C.c_uint16, C.c_uint16, C.c_int, C.POINTER(vp)]
+    lib.svt_amd_encdec_picture_destroy.argtypes = [vp, vp]
+
+
+def oracle_encode_picture(oracle, works, w, h):
+    oracle.svt_oracle_encode_lcu.restype = None
+    oracle.svt_oracle_encode_lcu.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p]
+    pitches = (w + 32, w // 2 + 16, w // 2 + 16)
+    pb = (C.c_uint32 * 3)(*pitches)
+    rec = [np.full((hh, p), 0xA5, np.uint8) for hh, p in zip((h, h // 2, h // 2), pitches)]
+    mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+    rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+    want = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+    for k in range(len(works)):
+        oracle.svt_oracle_encode_lcu(rp, pb, mp.ctypes.data, mp.shape[1], w, h, works[k:k + 1].ctypes.data, want[k:k + 1].ctypes.data)
+    return want
+
+
+def md_encode(lib, ctx, pic, g, k, ois=True):
+    P = np.ascontiguousarray(g["pic"][k:k + 1])
+    lcus = np.ascontiguousarray(g["lcu"][k])
+    cost = np.ascontiguousarray(g["cost"][k])
+    src = [np.ascontiguousarray(g[n][k]) for n in ("src_y", "src_cb", "src_cr")]
+    o = np.ascontiguousarray(g["ois"][k])
+    n = len(lcus)
+    out, works, res = np.zeros(n, S.MD_LCU_OUT_DTYPE), np.zeros(n, S.LCU_WORK_DTYPE), np.zeros(n, S.LCU_RESULT_DTYPE)
+    rc = lib.svt_amd_md_encode_picture(ctx, pic, P.ctypes.data, lcus.ctypes.data, src[0].ctypes.data, src[0].shape[1], src[1].ctypes.data,
+                                       src[2].ctypes.data, src[1].shape[1], o.ctypes.data if ois else None, 0, cost.ctypes.data, out.ctypes.data,
+                                       works.ctypes.data, res.ctypes.data)
+    assert rc == 0, lib.svt_amd_last_error()
+    return out, works, res
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_md_encode_picture_matches_the_reference_and_the_oracle(product, oracle, name):
+    lib = product
+    sig(lib)
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        for k in range(len(g["picture_number"])):
+            assert lib.svt_amd_md_picture_supported(np.ascontiguousarray(g["pic"][k:k + 1]).ctypes.data) == 1
+            for rep in range(2):   # twice: the picture object's maps and completion flags of the first call must not leak into the second
+                out, works, res = md_encode(lib, ctx, pic, g, k)
+                tag = "%s picture %d call %d" % (name, int(g["picture_number"][k]), rep)
+                compare_md(out, g["out"][k], tag)                                  # (i) the reference's decisions
+                want_works = works_from_md(g["pic"][k], g["lcu"][k], out, (g["src_y"][k], g["src_cb"][k], g["src_cr"][k]))
+                for i in range(len(works)):                                          # (ii) the contract record
+                    n = int(want_works[i]["num_cus"])
+                    assert int(works[i]["num_cus"]) == n, (tag, i)
+                    for f in ("x", "y", "size", "pred_mode", "intra_luma_mode", "bottom_left_ok", "top_right_ok", "qp", "chroma_qp", "leaf_index"):
+                        assert np.array_equal(works[i]["cu"][f][:n], want_works[i]["cu"][f][:n]), (tag, i, f)
+                    for f in ("src_y", "src_cb", "src_cr", "lcu_x", "lcu_y", "tile_left", "tile_top", "tile_right", "slice_type", "strong_smoothing",
+                              "constrained_intra", "full_lambda", "luma_cbf_bits", "pm_core"):
+                        assert np.array_equal(works[i][f], want_works[i][f]), (tag, i, f)
+                want = oracle_encode_picture(oracle, works, w, h)                    # (iii) the encode pass behind it
+                for i in range(len(works)):
+                    compare_lcu(works[i], want[i], res[i], w, h, (tag, i))
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
+
+
+def test_md_encode_picture_reads_the_ois_records_the_front_half_left_in_hbm(product, oracle):
+    """ois == NULL: the open-loop intra search of the picture ran on the device (svt_amd_ois_picture) and its records are read where they are"""
+    lib = product
+    sig(lib)
+    name = "i_motion_1920x1080_m10" if "i_motion_1920x1080_m10" in CASES else CASES[0]   # encMode 10: the candidate lists come from the OIS records
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    from gpu_util import upload
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        upload(lib, ctx, 0, np.ascontiguousarray(g["src_y"][0]))
+        op = S.OisParams()
+        op.luma_width, op.luma_height, op.slice_is_intra, op.temporal_layer_index = w, h, 1, 0
+        op.skip_ois_8x8, op.cu8x8_mode = int(g["pic"][0]["skip_ois_8x8"]), int(g["pic"][0]["cu8x8_mode"])
+        op.limit_ois_to_dc_mode, op.ois_th_set = int(g["pic"][0]["limit_ois_to_dc_mode"]), 1
+        ois = np.zeros(S.lcu_count(w, h), S.OIS_LCU_DTYPE)
+        assert lib.svt_amd_ois_picture(ctx, C.byref(op), 0, None, ois.ctypes.data) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        out, works, res = md_encode(lib, ctx, pic, g, 0, ois=False)
+        compare_md(out, g["out"][0], name + " (device OIS records)")
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
+
+
+def test_md_encode_picture_rejects_what_it_does_not_cover(product):
+    lib = product
+    sig(lib)
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % CASES[0]))
+    P = np.ascontiguousarray(g["pic"][0:1]).copy()
+    for field, value in (("slice_type", 1), ("chroma_level", 0), ("coeff_cabac_update", 1), ("intra_md_open_loop", 1), ("depth_mode", 0)):
+        Q = P.copy()
+        Q[0][field] = value
+        assert lib.svt_amd_md_picture_supported(Q.ctypes.data) == 0, field

@@ -54,3 +54,85 @@ def test_oracle_md_matches_recorded_mode_decisions(name):
     for k in range(len(g["picture_number"])):
         out, _ = oracle_md_picture(lib, g, k)
         compare_md(out, g["out"][k], "%s picture %d" % (name, int(g["picture_number"][k])))
+
+
+# ---- the EncDec input contract the decisions amount to (what the device builds behind its mode decision; test-side restatement) ----
+def md_stats(leaf):
+    """GetCodedUnitStats: (depth, size, x, y) of a leaf of the depth-first scan"""
+    if leaf == 0:
+        return 0, 64, 0, 0
+    r = leaf - 1
+    q, r32 = divmod(r, 21)
+    x, y = (q & 1) * 32, (q >> 1) * 32
+    if r32 == 0:
+        return 1, 32, x, y
+    s, r16 = divmod(r32 - 1, 5)
+    x, y = x + (s & 1) * 16, y + (s >> 1) * 16
+    if r16 == 0:
+        return 2, 16, x, y
+    e = r16 - 1
+    return 3, 8, x + (e & 1) * 8, y + (e >> 1) * 8
+
+
+def final_tree(out_lcu, lw=64, lh=64):
+    """the leaves with split == 0 in Z order, as EncodePass walks them (EbCodingLoop.c:3180, :4586-4592)"""
+    units, it = [], 0
+    while it < 85:
+        if out_lcu["split"][it]:
+            it += 1
+            continue
+        d, s, x, y = md_stats(it)
+        if x < lw and y < lh:
+            units.append((it, x, y, s))
+        it += (85, 21, 5, 1)[d]
+    return units
+
+
+def works_from_md(pic, lcus, out, src):
+    from test_gpu_encodepass import z_available
+    w, h = int(pic["width"]), int(pic["height"])
+    wl = (w + 63) // 64
+    works = np.zeros(len(lcus), S.LCU_WORK_DTYPE)
+    for k in range(len(lcus)):
+        lx, ly = 64 * (k % wl), 64 * (k // wl)
+        lw, lh = min(64, w - lx), min(64, h - ly)
+        wk = works[k]
+        wk["lcu_x"], wk["lcu_y"], wk["slice_type"], wk["temporal_layer"] = lx, ly, pic["slice_type"], pic["temporal_layer"]
+        wk["constrained_intra"], wk["strong_smoothing"] = pic["constrained_intra"], pic["strong_smoothing"]
+        wk["tile_left"], wk["tile_top"], wk["tile_right"] = lcus[k]["tile_left"], lcus[k]["tile_top"], lcus[k]["tile_right"]
+        wk["full_lambda"] = pic["full_lambda"]
+        wk["luma_cbf_bits"] = [pic["rates"]["lumaCbfBits"][i] for i in (0, 1, 5, 6)]
+        units = final_tree(out[k], lw, lh)
+        wk["num_cus"] = len(units)
+        for i, (leaf, x, y, s) in enumerate(units):
+            cu = wk["cu"][i]
+            cu["x"], cu["y"], cu["size"], cu["pred_mode"], cu["intra_luma_mode"] = x, y, s, out[k]["pred_mode"][leaf], out[k]["intra_luma_mode"][leaf]
+            cu["bottom_left_ok"], cu["top_right_ok"] = z_available(x, y, s)
+            cu["qp"], cu["chroma_qp"], cu["leaf_index"] = pic["qp"], pic["chroma_qp"], leaf
+        sy = np.zeros((64, 64), np.uint8)
+        sy[:lh, :lw] = src[0][ly:ly + lh, lx:lx + lw]
+        wk["src_y"] = sy.reshape(-1)
+        for p, nm in ((1, "src_cb"), (2, "src_cr")):
+            sc = np.zeros((32, 32), np.uint8)
+            sc[:lh // 2, :lw // 2] = src[p][ly // 2:(ly + lh) // 2, lx // 2:(lx + lw) // 2]
+            wk[nm] = sc.reshape(-1)
+    return works
+
+
+def test_recorded_decisions_are_the_trees_the_encode_pass_fixture_holds():
+    """cross-check of two independent recordings of the same encode: the final trees of md_i_motion_416x240_m9 (ModeDecisionLcu records) are the
+    coding-unit lists of encodepass_i_motion_416x240_m9 (EncodePass records)"""
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_i_motion_416x240_m9.npz"))
+    e = np.load(os.path.join(S.GOLDEN_DIR, "encodepass_i_motion_416x240_m9.npz"))
+    assert list(g["enc_args"]) == list(e["enc_args"])
+    nl = g["lcu"].shape[1]
+    for k in range(len(g["picture_number"])):
+        works = works_from_md(g["pic"][k], g["lcu"][k], g["out"][k], (g["src_y"][k], g["src_cb"][k], g["src_cr"][k]))
+        ew = e["work"][k * nl:(k + 1) * nl]
+        for i in range(nl):
+            n = int(ew[i]["num_cus"])
+            assert int(works[i]["num_cus"]) == n, (k, i)
+            for f in ("x", "y", "size", "pred_mode", "intra_luma_mode", "bottom_left_ok", "top_right_ok", "qp", "chroma_qp", "leaf_index"):
+                assert np.array_equal(works[i]["cu"][f][:n], ew[i]["cu"][f][:n]), (k, i, f)
+            for f in ("src_y", "src_cb", "src_cr", "lcu_x", "lcu_y", "tile_left", "tile_top", "tile_right", "slice_type", "strong_smoothing", "constrained_intra"):
+                assert np.array_equal(works[i][f], ew[i][f]), (k, i, f)
