@@ -43,6 +43,7 @@
 #include "EbPictureOperators.h"
 
 #include "svt_hook_internal.h"
+#include "svt_md_fill.h"
 
 #define EP_LANES 8     /* device contexts (stream + staging) EncDec threads share */
 #define EP_PICTURES 64 /* pictures in flight (PictureControlSet_t objects of the EncDec pool) */
@@ -82,6 +83,13 @@ typedef struct {
     uint8_t *sao_enable;         /* LCUs the reference ran SaoGenerationDecision for */
     SvtAmdSaoDecisionParams sao_P;
     int sao_any, sao_varies, on_device, done;
+    /* SVT_HOOK_MD: the mode decision AND the encode pass of every LCU of the picture in ONE device call, made by the picture's first
+     * ModeDecisionLcu call; the later calls (and the EncodePass calls) of the picture are answered from these arrays */
+    uint64_t md_picture_plus1;   /* picture the arrays below were filled for */
+    int md_ok;                   /* 1: served by the device; 0: outside what svt_amd_md_encode_picture covers - the reference code runs */
+    SvtAmdMdLcuOut *md_out;
+    SvtAmdLcuWork *md_works;
+    SvtAmdLcuResult *md_res;
 } EpPictureEntry;
 
 typedef struct {
@@ -481,7 +489,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     if (g_ep_state == 0) {
         g_ep_verify = getenv("SVT_HOOK_ENCODEPASS_VERIFY") != NULL;
         g_ep_refs = getenv("SVT_HOOK_ENCODEPASS_REFS") != NULL;
-        g_ep_state = getenv("SVT_HOOK_ENCODEPASS") ? 1 : -1;
+        g_ep_state = (getenv("SVT_HOOK_ENCODEPASS") || getenv("SVT_HOOK_MD")) ? 1 : -1;
     }
     if (g_ep_state < 0 || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
         if (g_ep_state > 0)
@@ -500,6 +508,20 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     /* tools that change a unit's QP, dead zone, coefficient shape or quantiser are outside this revision */
     const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
                       (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE); /* RDOQ: encMode 0 */
+    const int md_served = !tools && !wide && e->md_ok && e->md_picture_plus1 == pcs->pictureNumber + 1;
+    if (md_served) { /* the picture's device call (svt_hook_md_lcu) encoded this LCU already: no work record to build, no device call to make */
+        memcpy(&t_serve->work, &e->md_works[tbAddr], sizeof(SvtAmdLcuWork));
+        memcpy(&t_serve->res, &e->md_res[tbAddr], sizeof(SvtAmdLcuResult));
+        t_serve->wide = 0;
+        lane_release(lane);
+        __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
+        t_serve->lcu = lcuPtr;
+        svt_hook_ep_active = 1;
+        __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+        svt_hook_ep_active = 0;
+        picture_lcu_done(root, e, scs, pcs, tbAddr, 1, contextPtr->allowEncDecMismatch);
+        return;
+    }
     const int units = !tools && fill_work(&t_serve->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr);
     if (!units) {
         lane_release(lane);
@@ -710,8 +732,132 @@ EB_ERRORTYPE __wrap_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countN
     return __real_EncodeTuCalcCost(contextPtr, countNonZeroCoeffs, yTuDistortion, yTuCoeffBits, componentMask);
 }
 
+
+/* ---- SVT_HOOK_MD: ModeDecisionLcu (Codec/EbProductCodingLoop.c:4691) answered from ONE device call per picture -------------------- */
+EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
+                                    LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr);
+static int g_md_state; /* 0 unknown, 1 on, -1 off */
+static int g_md_verify; /* SVT_HOOK_MD_VERIFY: the reference decides the LCU itself as well and the two trees are compared */
+static unsigned long g_md_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch;
+
+/* what ProductFullModeDecision (Codec/EbModeDecision.c:1995-2183) and the loop around it leave in the LCU's coding-unit array, from the
+ * device's decision record */
+static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8 qp)
+{
+    for (int i = 0; i < SVT_AMD_MD_LEAVES; i++) {
+        CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[i];
+        cu->splitFlag = o->split[i];
+        if (!o->tested[i])
+            continue;
+        cu->leafIndex = (EB_U8)i, cu->qp = qp;
+        cu->predictionModeFlag = o->pred_mode[i], cu->skipFlag = EB_FALSE, cu->rootCbf = o->ycbf[i] ? EB_TRUE : EB_FALSE;
+        PredictionUnit_t *pu = cu->predictionUnitArray;
+        pu->intraLumaMode = o->pred_mode[i] == INTRA_MODE ? o->intra_luma_mode[i] : 0x1F;
+        pu->interPredDirectionIndex = 0x03, pu->mergeFlag = EB_FALSE, pu->mergeIndex = 0;
+        pu->mv[REF_LIST_0].x = pu->mv[REF_LIST_0].y = pu->mv[REF_LIST_1].x = pu->mv[REF_LIST_1].y = 0;
+        pu->mvd[REF_LIST_0].predIdx = pu->mvd[REF_LIST_1].predIdx = 0;
+        TransformUnit_t *tu = &cu->transformUnitArray[0];
+        tu->splitFlag = EB_FALSE, tu->lumaCbf = o->ycbf[i] ? EB_TRUE : EB_FALSE;
+        tu->cbCbf = tu->crCbf = EB_TRUE; /* "exclude chroma from cost calculation" (EbProductCodingLoop.c:4460): candidatePtr->cbCbf = crCbf = 1 */
+        tu->cbCbf2 = tu->crCbf2 = EB_FALSE, tu->chromaCbfContext = 0, tu->lumaCbfContext = 1;
+    }
+}
+
+/* the picture's ONE device call; under e->lock */
+static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSet_t *scs, PictureControlSet_t *pcs, ModeDecisionContext_t *md)
+{
+    e->md_picture_plus1 = pcs->pictureNumber + 1, e->md_ok = 0;
+    const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
+                      scs->staticConfig.rateControlMode != 0; /* per-LCU QP / lambda: not in SvtAmdMdPicture */
+    SvtAmdMdPicture P;
+    svt_md_fill_picture(&P, scs, pcs, md);
+    if (tools || !svt_amd_md_picture_supported(&P)) {
+        __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
+        return;
+    }
+    const size_t n = (size_t)e->cap;
+    if (!e->md_out) {
+        e->md_out = (SvtAmdMdLcuOut *)malloc(sizeof(SvtAmdMdLcuOut) * n), e->md_works = (SvtAmdLcuWork *)malloc(sizeof(SvtAmdLcuWork) * n);
+        e->md_res = (SvtAmdLcuResult *)malloc(sizeof(SvtAmdLcuResult) * n);
+        if (!e->md_out || !e->md_works || !e->md_res)
+            svt_hook_die("out of memory (mode-decision picture records)");
+    }
+    SvtAmdMdLcu *lcus = (SvtAmdMdLcu *)malloc(sizeof(SvtAmdMdLcu) * n);
+    SvtAmdOisLcuResult *ois = (SvtAmdOisLcuResult *)malloc(sizeof(SvtAmdOisLcuResult) * n);
+    if (!lcus || !ois)
+        svt_hook_die("out of memory (mode-decision picture inputs)");
+    for (size_t i = 0; i < n; i++) {
+        svt_md_fill_lcu(&lcus[i], scs, pcs, pcs->lcuPtrArray[i], md);
+        svt_md_fill_ois(&ois[i], pcs->ParentPcsPtr, (EB_U32)i);
+    }
+    const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
+    if (svt_amd_md_encode_picture(lane, e->pic, &P, lcus, in->bufferY + (size_t)in->originY * in->strideY + in->originX, in->strideY,
+                                  in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2,
+                                  in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2, in->strideCb, ois, 0,
+                                  (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out, e->md_works, e->md_res))
+        svt_hook_die("svt_amd_md_encode_picture");
+    free(lcus), free(ois);
+    e->md_ok = 1;
+    __atomic_add_fetch(&g_md_pictures, 1, __ATOMIC_RELAXED);
+}
+
+EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
+                                    LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr)
+{
+    if (g_md_state == 0) {
+        g_md_verify = getenv("SVT_HOOK_MD_VERIFY") != NULL;
+        g_md_state = getenv("SVT_HOOK_MD") ? 1 : -1;
+    }
+    if (g_md_state < 0 || scs->staticConfig.encoderBitDepth != EB_8BIT || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
+        return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
+    svt_hook_note_callback(scs);
+    SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
+    SvtAmdContext *lane = lane_claim(root);
+    EpPictureEntry *e = picture_entry(lane, scs, pcs, 0);
+    pthread_mutex_lock(&e->lock);
+    if (e->md_picture_plus1 != pcs->pictureNumber + 1)
+        md_picture(lane, e, scs, pcs, contextPtr);
+    const int ok = e->md_ok;
+    pthread_mutex_unlock(&e->lock);
+    lane_release(lane);
+    if (!ok)
+        return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
+    const SvtAmdMdLcuOut *o = &e->md_out[lcuAddr];
+    if (g_md_verify) {
+        const EB_ERRORTYPE rc = __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
+        int bad = 0;
+        for (EB_U32 i = 0; i < CU_MAX_COUNT;) { /* the final tree, as EncodePass walks it */
+            const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[i];
+            if (cu->splitFlag != o->split[i]) {
+                bad++;
+                break;
+            }
+            if (cu->splitFlag) {
+                i++;
+                continue;
+            }
+            bad += cu->predictionModeFlag != o->pred_mode[i] || cu->predictionUnitArray->intraLumaMode != o->intra_luma_mode[i];
+            i += DepthOffset[GetCodedUnitStats(i)->depth];
+        }
+        __atomic_add_fetch(&g_md_verified, 1, __ATOMIC_RELAXED);
+        if (bad) {
+            __atomic_add_fetch(&g_md_mismatch, 1, __ATOMIC_RELAXED);
+            fprintf(stderr, "svt_hook_encdec: MD VERIFY picture %llu lcu %u: the device's tree differs from the reference's\n",
+                    (unsigned long long)pcs->pictureNumber, lcuAddr);
+        }
+        return rc;
+    }
+    md_apply(lcuPtr, o, contextPtr->qp);
+    __atomic_add_fetch(&g_md_lcus, 1, __ATOMIC_RELAXED);
+    return EB_ErrorNone;
+}
+
 void svt_hook_encdec_report(FILE *out)
 {
+    if (g_md_state > 0)
+        fprintf(out, "svt_hook_me: mode decision: %lu pictures (%lu LCUs) decided AND encoded by ONE device call each (ModeDecisionLcu + EncodePass, no per-candidate "
+                     "call); %lu pictures outside the device call left to the reference code; verification: %lu LCUs compared, %lu differ\n",
+                g_md_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch);
     if (g_ep_state <= 0)
         return;
     fprintf(out, "svt_hook_me: encode pass: %lu LCUs encoded on the GPU (one call each; %lu of them with inter units, %lu inter units); left to the "

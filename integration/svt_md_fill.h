@@ -5,8 +5,9 @@
  * so that fixtures hold exactly what the binding hands to the device.  Part of the code a maintainer adds to the reference; contains
  * no reference source.
  *
- * Call after ModeDecisionConfigureLcu (Codec/EbEncDecProcess.c:2893) has run for the LCU on `md` (picture-level fields are the same
- * for every LCU of the picture without the delta-QP tools).
+ * svt_md_fill_picture: call after ModeDecisionConfigureLcu (Codec/EbEncDecProcess.c:2893) has run for ANY LCU of the picture on `md` (the
+ * fields it reads are the same for every LCU of a picture without the delta-QP tools).  svt_md_fill_lcu reads only picture-level state,
+ * so the binding can fill every LCU of a picture at the picture's first ModeDecisionLcu call.
  */
 #ifndef SVT_MD_FILL_H
 #define SVT_MD_FILL_H
@@ -63,8 +64,11 @@ static void svt_md_fill_lcu(SvtAmdMdLcu *L, const SequenceControlSet_t *scs, con
     L->complexity_status_2 = pp->complexLcuArray[lcu] == LCU_COMPLEXITY_STATUS_2;
     for (int q = 0; q < 4; q++)
         L->contouring_class[q] = DeriveContouringClass(pp, (EB_U16)lcu, (EB_U8)(1 + 21 * q));
-    L->chroma_encode_mode = lcuPtr->chromaEncodeMode;
-    L->restrict_intra_global_motion = md->restrictIntraGlobalMotion;
+    /* ConfigureChroma (Codec/EbModeDecisionProcess.c:408-471) for the two levels that need no per-LCU detector; 0 = a switch level (2..5) */
+    L->chroma_encode_mode = md->chromaLevel == 0 && pcs->colorFormat < EB_YUV422 ? CHROMA_MODE_FULL : md->chromaLevel <= 1 ? CHROMA_MODE_BEST : 0;
+    /* contextPtr->mdContext->restrictIntraGlobalMotion (Codec/EbEncDecProcess.c:2890) */
+    L->restrict_intra_global_motion = (pp->isPan || pp->isTilt) && pp->nonMovingIndexArray[lcu] < INTRA_GLOBAL_MOTION_NON_MOVING_INDEX_TH &&
+                                      pp->yMean[lcu][RASTER_SCAN_CU_INDEX_64x64] < INTRA_GLOBAL_MOTION_DARK_LCU_TH;
     L->lcu_md_mode = pp->depthMode == PICT_LCU_SWITCH_DEPTH_MODE ? pp->lcuMdModeArray[lcu] : 0;
 }
 

@@ -463,3 +463,50 @@ def test_reference_pictures_finished_on_the_device_inside_the_encoder(tmp_path, 
     made, compared, differ = (int(v) for v in m.groups())
     assert made >= 2 and compared >= 1 and differ == 0, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
+
+
+MD_CASES = [
+    # all-intra: EVERY picture's mode decision + encode pass is one device call
+    ("motion", 416, 240, 3, ["-encMode", "9", "-intra-period", "0"], "all"),
+    ("noise", 320, 256, 2, ["-encMode", "8", "-intra-period", "0", "-q", "26"], "all"),
+    # BASELINE configs[0]: 1080p encMode 10 all-intra
+    ("motion", 1920, 1080, 3, ["-encMode", "10", "-intra-period", "0"], "all"),
+    # 2 x 2 tiles
+    ("motion", 640, 384, 2, ["-encMode", "9", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
+    # random access: the I picture on the device, the B pictures' mode decision stays with the reference code (their encode pass on the device)
+    ("motion", 640, 384, 6, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], "first"),
+    # encMode 6 (chroma in the mode decision, CABAC-context update): outside this revision, every picture left to the reference code
+    ("motion", 416, 240, 2, ["-encMode", "6", "-intra-period", "0"], "none"),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,n,args,expect", MD_CASES)
+def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_path, kind, w, h, n, args, expect):
+    """SVT_HOOK_MD=1: ModeDecisionLcu AND EncodePass of every LCU of a covered picture are ONE svt_amd_md_encode_picture() call made by the
+    picture's first ModeDecisionLcu call (candidate lists, fast loop, full loop, inter-depth decision, neighbour state and the encode pass all
+    on the device, wavefront included); the reference's per-LCU calls then only copy decisions and keep books.  Bitstream and reconstruction
+    must be byte-identical to the unmodified reference's."""
+    import re
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
+    env = {"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": str(tmp_path / "report.txt")}
+    os.environ.update(env)
+    try:
+        hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "hip.yuv")], str(tmp_path / "hip.265"))
+    finally:
+        for k in env:
+            del os.environ[k]
+    rep = open(str(tmp_path / "report.txt")).read()
+    m = re.search(r"mode decision: (\d+) pictures \((\d+) LCUs\) decided AND encoded by ONE device call each .*?; (\d+) pictures outside the device call", rep)
+    assert m, rep
+    pics, lcus, left = (int(v) for v in m.groups())
+    nl = S.lcu_count(w, h)
+    if expect == "all":
+        assert pics == n and lcus == n * nl and left == 0, rep
+    elif expect == "first":
+        assert pics == 1 and lcus == nl and left == 0, rep      # P / B pictures of these presets go through LCU_SWITCH: ModeDecisionLcu is only reached per LCU
+    else:
+        assert pics == 0 and left >= 1, rep
+    assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
+    assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
