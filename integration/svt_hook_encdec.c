@@ -844,6 +844,17 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
             __atomic_add_fetch(&g_md_mismatch, 1, __ATOMIC_RELAXED);
             fprintf(stderr, "svt_hook_encdec: MD VERIFY picture %llu lcu %u: the device's tree differs from the reference's\n",
                     (unsigned long long)pcs->pictureNumber, lcuAddr);
+            for (EB_U32 i = 0, shown = 0; i < CU_MAX_COUNT && shown < 6; i++) {
+                const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[i];
+                if (cu->splitFlag != o->split[i] || (contextPtr->mdLocalCuUnit[i].testedCuFlag && (cu->predictionModeFlag != o->pred_mode[i] ||
+                    cu->predictionUnitArray->intraLumaMode != o->intra_luma_mode[i] || contextPtr->mdLocalCuUnit[i].cost != o->cost[i]))) {
+                    fprintf(stderr, "    leaf %u: split ref %d dev %d, tested ref %d dev %d, mode ref %d/%d dev %d/%d, cost ref %llu dev %llu\n", i, (int)cu->splitFlag,
+                            o->split[i], (int)contextPtr->mdLocalCuUnit[i].testedCuFlag, o->tested[i], (int)cu->predictionModeFlag,
+                            (int)cu->predictionUnitArray->intraLumaMode, o->pred_mode[i], o->intra_luma_mode[i],
+                            (unsigned long long)contextPtr->mdLocalCuUnit[i].cost, (unsigned long long)o->cost[i]);
+                    shown++;
+                }
+            }
         }
         return rc;
     }
