@@ -748,7 +748,7 @@ static void recon16(EncDecContext_t *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_COLOR_F
 __attribute__((constructor)) static void recon_install(void)
 {
     g_recon_on = getenv("SVT_HOOK_RECON") != NULL;
-    if (!g_recon_on && !getenv("SVT_HOOK_ENCODEPASS"))
+    if (!g_recon_on && !getenv("SVT_HOOK_ENCODEPASS") && !getenv("SVT_HOOK_MD"))
         return;
     g_recon_real[0] = EncodeGenerateReconFunctionPtr[0], g_recon_real[1] = EncodeGenerateReconFunctionPtr[1];
     EncodeGenerateReconFunctionPtr[0] = recon8, EncodeGenerateReconFunctionPtr[1] = recon16;
@@ -955,7 +955,7 @@ static EB_ERRORTYPE intra_cgen16(ICGEN_ARGS) { return intra_cgen(1, a, b, c, d, 
 __attribute__((constructor)) static void intra_install(void)
 {
     g_intra_on = getenv("SVT_HOOK_INTRA") != NULL;
-    if (!g_intra_on && !getenv("SVT_HOOK_ENCODEPASS"))
+    if (!g_intra_on && !getenv("SVT_HOOK_ENCODEPASS") && !getenv("SVT_HOOK_MD"))
         return;
     g_intra_gen[0] = GenerateIntraReferenceSamplesFuncTable[0], g_intra_gen[1] = GenerateIntraReferenceSamplesFuncTable[1];
     g_intra_pred[0] = EncodePassIntraPredictionFuncTable[0], g_intra_pred[1] = EncodePassIntraPredictionFuncTable[1];

@@ -126,3 +126,17 @@ def test_md_encode_picture_rejects_what_it_does_not_cover(product):
         Q = P.copy()
         Q[0][field] = value
         assert lib.svt_amd_md_picture_supported(Q.ctypes.data) == 0, field
+
+
+@pytest.mark.parametrize("w,h,enc_mode", [(3840, 2160, 7), (1920, 1080, 9)])
+def test_md_encode_picture_at_baseline_sizes_matches_the_reference_run_on_the_box(product, w, h, enc_mode):
+    """BASELINE configs[2]'s I picture (4K, encMode 7) and configs[1]'s (1080p, encMode 9): the prebuilt reference (oracle/_ref) encodes the picture
+    on this box with the recording harness on; the device's decisions for the recorded inputs must be the reference's, leaf for leaf"""
+    import sys
+    sys.path.insert(0, os.path.join(S.ROOT, "tools"))
+    import md_bench
+    if not os.path.exists(S.REF_APP):
+        pytest.skip("oracle/_ref not built")
+    g = md_bench.record(w, h, enc_mode)
+    r = md_bench.run(product, g, reps=1)
+    assert r["lcus"] == S.lcu_count(w, h) and r["final_units"] > r["lcus"]
