@@ -78,6 +78,7 @@ typedef struct {
     pthread_mutex_t lock;        /* pending list + the device put of it */
     void *pending;               /* host-encoded LCUs not handed to the device yet: SvtAmdLcuBorder[] or SvtAmdLcuBorder16[] */
     int npending, cap, wide;
+    uint32_t width, height;      /* the picture format the entry's buffers were sized for */
     /* SVT_HOOK_ENCODEPASS_REFS: everything the device needs to finish the picture itself when its last LCU is through */
     void *works_all, *res_all;   /* contract records of every LCU, raster order (8- or 16-bit contract) */
     uint8_t *sao_enable;         /* LCUs the reference ran SaoGenerationDecision for */
@@ -151,6 +152,34 @@ static void lane_release(SvtAmdContext *lane)
     pthread_mutex_unlock(&g_ep_lock);
 }
 
+/* everything an entry owns (under g_ep_lock) */
+static void entry_release(SvtAmdContext *lane, EpPictureEntry *e)
+{
+    if (e->pic)
+        svt_amd_encdec_picture_destroy(lane, e->pic);
+    free(e->pending), free(e->works_all), free(e->res_all), free(e->sao_enable), free(e->md_out), free(e->md_works), free(e->md_res);
+    pthread_mutex_destroy(&e->lock);
+    memset(e, 0, sizeof(*e));
+}
+
+/* the last kernel thread of the encoder has returned (svt_hook_me.c:hook_teardown): picture objects and lanes go */
+void svt_hook_encdec_teardown(void)
+{
+    pthread_mutex_lock(&g_ep_lock);
+    SvtAmdContext *any = NULL;
+    for (int i = 0; i < EP_LANES && !any; i++)
+        any = g_ep_lane[i];
+    for (int i = 0; i < EP_PICTURES; i++)
+        if (g_ep_pic[i].pcs && any)
+            entry_release(any, &g_ep_pic[i]);
+    for (int i = 0; i < EP_LANES; i++) {
+        if (g_ep_lane[i])
+            svt_amd_context_destroy(g_ep_lane[i]);
+        g_ep_lane[i] = NULL, g_ep_lane_busy[i] = 0;
+    }
+    pthread_mutex_unlock(&g_ep_lock);
+}
+
 /* the device picture of this PictureControlSet_t, begun for its current picture */
 static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide)
 {
@@ -159,12 +188,18 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
     for (int i = 0; i < EP_PICTURES && !e; i++)
         if (g_ep_pic[i].pcs == pcs)
             e = &g_ep_pic[i];
+    const int ncap = (int)(((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u));
+    if (e && (e->cap != ncap || e->wide != wide || e->width != scs->lumaWidth || e->height != scs->lumaHeight)) {
+        /* a PictureControlSet_t address of an earlier encoder instance with another picture format: nothing of the entry fits */
+        entry_release(lane, e);
+        e = NULL;
+    }
     for (int i = 0; i < EP_PICTURES && !e; i++)
         if (!g_ep_pic[i].pcs) {
             e = &g_ep_pic[i];
             e->pcs = pcs;
             pthread_mutex_init(&e->lock, NULL);
-            e->wide = wide;
+            e->wide = wide, e->width = scs->lumaWidth, e->height = scs->lumaHeight;
             if (svt_amd_encdec_picture_create(lane, (uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight, wide ? 2 : 1, &e->pic))
                 svt_hook_die("svt_amd_encdec_picture_create");
             e->cap = (int)(((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u));
@@ -483,6 +518,28 @@ static void verify_lcu(const SequenceControlSet_t *scs, const PictureControlSet_
         __atomic_add_fetch(&g_ep_mismatch, 1, __ATOMIC_RELAXED);
 }
 
+/* the served pass re-derives the merge / skip decision of every inter unit (EbCodingLoop.c:3838-3882, :4139, :4347-4352) from the
+ * same costs fill_work read.  Should the two ever disagree the bitstream would signal one thing and the reconstruction hold another: check
+ * the flags EncodePass left against what the device encoded, and stop loudly instead of drifting. */
+static void check_inter_kinds(const LargestCodingUnit_t *lcuPtr)
+{
+    const SvtAmdLcuWork *w = &t_serve->work;
+    for (int i = 0; i < w->num_cus; i++) {
+        const SvtAmdLcuCu *u = &w->cu[i];
+        if (u->pred_mode != INTER_MODE)
+            continue;
+        const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[u->leaf_index];
+        const int merge = cu->predictionUnitArray->mergeFlag, skip = cu->skipFlag;
+        int coded = 0;
+        for (int k = 0; k < (u->size == 64 ? 5 : 1); k++)
+            coded |= t_serve->res.cu[i + k].cbf[0] | t_serve->res.cu[i + k].cbf[1] | t_serve->res.cu[i + k].cbf[2];
+        const int ok = u->inter_kind == SVT_AMD_EP_INTER_SKIP ? (merge && skip)
+                     : u->inter_kind == SVT_AMD_EP_INTER_MERGE ? (merge && (!skip || !coded)) : !merge;
+        if (!ok)
+            svt_hook_die("encode pass: the reference's merge / skip decision of an inter unit differs from what the device encoded");
+    }
+}
+
 void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
                        EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
 {
@@ -583,6 +640,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     svt_hook_ep_active = 1;
     __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
     svt_hook_ep_active = 0;
+    check_inter_kinds(lcuPtr);
     picture_lcu_done(root, e, scs, pcs, tbAddr, 1, contextPtr->allowEncDecMismatch);
 }
 

@@ -1719,6 +1719,60 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
     return EB_ErrorNone;
 }
 
+/* ---- life cycle: the bindings' device state belongs to an encoder instance, not to the process ------------------------- */
+/* The reference's worker threads are created by EbInitEncoder and return when EbDeinitEncoder's end objects reach them
+ * (EB_CHECK_END_OBJ, Codec/EbDefinitions.h:584).  The two kernels that call into the bindings are interposed as thread entry points
+ * (--wrap=MotionEstimationKernel / EncDecKernel; EbEncHandle.c:1466, :1493 take them by address): when the last of them has returned,
+ * nothing can call a binding any more, and everything the bindings hold on the device - EncDec picture objects, lanes, reference cache,
+ * front-half lanes, the root context - is released, so that a later EbInitEncoder in the same process (another resolution, ffmpeg's next
+ * output) starts from nothing.  Two encoders alive at once share the state until both are gone (sizes are validated on reuse). */
+void *__real_MotionEstimationKernel(void *inputPtr);
+void *__real_EncDecKernel(void *inputPtr);
+void svt_hook_encdec_teardown(void);
+static int g_live_threads;
+static void hook_teardown(void)
+{
+    svt_hook_encdec_teardown();
+    pthread_mutex_lock(&g_front_lock);
+    pthread_mutex_lock(&g_lock);
+    if (g_ctx) {
+        svt_amd_synchronize(g_ctx);
+        for (int i = 0; i < REF_CACHE; i++) {
+            for (int k = 0; k < 3; k++)
+                if (g_refs[i].d[k])
+                    svt_amd_device_free(g_ctx, g_refs[i].d[k]);
+            memset(&g_refs[i], 0, sizeof(g_refs[i]));
+        }
+        for (int k = 0; k < 3; k++) {
+            if (g_inter_scratch[k])
+                svt_amd_device_free(g_ctx, g_inter_scratch[k]), g_inter_scratch[k] = NULL;
+            if (g_inter16_scratch[k])
+                svt_amd_device_free(g_ctx, g_inter16_scratch[k]), g_inter16_scratch[k] = NULL;
+        }
+        for (int i = 0; i < NLANES; i++) {
+            if (g_front[i].lane)
+                svt_amd_context_destroy(g_front[i].lane);
+            memset(&g_front[i], 0, sizeof(g_front[i]));
+        }
+        svt_amd_context_destroy(g_ctx);
+        g_ctx = NULL;
+        memset(g_slot_pic, 0, sizeof(g_slot_pic));
+    }
+    __atomic_store_n(&g_app_cb, NULL, __ATOMIC_RELEASE);
+    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&g_front_lock);
+}
+static void *kernel_thread(void *(*real)(void *), void *arg)
+{
+    __atomic_add_fetch(&g_live_threads, 1, __ATOMIC_ACQ_REL);
+    void *r = real(arg);
+    if (__atomic_sub_fetch(&g_live_threads, 1, __ATOMIC_ACQ_REL) == 0)
+        hook_teardown();
+    return r;
+}
+void *__wrap_MotionEstimationKernel(void *inputPtr) { return kernel_thread(__real_MotionEstimationKernel, inputPtr); }
+void *__wrap_EncDecKernel(void *inputPtr) { return kernel_thread(__real_EncDecKernel, inputPtr); }
+
 static void hook_report(void)
 {
     /* the sample application closes stderr before it returns (EbAppConfig.c:648): the report goes to the file SVT_HOOK_REPORT
