@@ -533,8 +533,10 @@ static void check_inter_kinds(const LargestCodingUnit_t *lcuPtr)
         int coded = 0;
         for (int k = 0; k < (u->size == 64 ? 5 : 1); k++)
             coded |= t_serve->res.cu[i + k].cbf[0] | t_serve->res.cu[i + k].cbf[1] | t_serve->res.cu[i + k].cbf[2];
-        const int ok = u->inter_kind == SVT_AMD_EP_INTER_SKIP ? (merge && skip)
-                     : u->inter_kind == SVT_AMD_EP_INTER_MERGE ? (merge && (!skip || !coded)) : !merge;
+        /* a unit decided skip leaves EncodePass with skipFlag set and mergeFlag CLEARED (:4139-4140); a merge unit keeps mergeFlag and is
+         * forced to skip only when nothing was coded (:4348-4352); an AMVP unit has neither */
+        const int ok = u->inter_kind == SVT_AMD_EP_INTER_SKIP ? (skip && !merge)
+                     : u->inter_kind == SVT_AMD_EP_INTER_MERGE ? (merge && (!skip || !coded)) : (!merge && !skip);
         if (!ok)
             svt_hook_die("encode pass: the reference's merge / skip decision of an inter unit differs from what the device encoded");
     }
