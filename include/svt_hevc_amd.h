@@ -1413,11 +1413,15 @@ SVT_AMD_API void svt_amd_BiPredClipping16bit(uint32_t puWidth, uint32_t puHeight
  * picture-sized maps of the SvtAmdEncDecPicture (candidate reconstruction, mode type, intra luma mode, depth, skip flag), the
  * ME / OIS results are read where the front half left them.
  *
- * THIS REVISION covers the pictures whose LCUs all take the ModeDecisionLcu path with luma-only candidates:
- *   I pictures (PICT_FULL84_DEPTH_MODE), closed-loop intra (intraMdOpenLoopFlag == 0), chroma level 1 (CHROMA_MODE_BEST: no chroma
- *   in the mode decision, EbEncDecProcess.c:2056-2113), no CABAC-context update, intra 4x4 off, plain quantiser, no delta-QP tools =
- *   the I pictures of encMode 8..10 at every resolution and of encMode 7 in 4K (BASELINE configs[0], and the I pictures of
- *   configs[1] / [2] / [3]), 8-bit.  svt_amd_md_picture_supported() says so; everything else stays with the reference code.
+ * THIS REVISION covers the pictures whose LCUs all take the ModeDecisionLcu path with luma-only candidates (chroma level 1,
+ * CHROMA_MODE_BEST: no chroma in the mode decision, EbEncDecProcess.c:2056-2113), no CABAC-context update, intra 4x4 off, plain
+ * quantiser, no delta-QP tools, 8-bit:
+ *   I pictures (PICT_FULL84_DEPTH_MODE), closed-loop intra (intraMdOpenLoopFlag == 0) = the I pictures of encMode 8..10 at every
+ *   resolution and of encMode 7 in 4K (BASELINE configs[0], and the I pictures of configs[1] / [2] / [3]);
+ *   P / B pictures (SvtAmdMdInter below) with open-loop intra candidates, sub-sample motion, unrestricted motion vectors, the AMVP
+ *   table generated in the mode decision and partial-frequency level 0 / 1 whose LCUs are all decided by ModeDecisionLcu (no
+ *   branch-and-depth-pillar LCUs) = the non-reference B pictures of encMode 7..8 (half the pictures of a random-access encode).
+ * svt_amd_md_picture_supported() says so; everything else stays with the reference code.
  * The controls below are DERIVED BY THE REFERENCE'S HOST CODE (SignalDerivationEncDecKernelOq, ProductResetModeDecision,
  * ModeDecisionConfigureLcu, the picture-analysis detectors) and are inputs here, like SvtAmdMeParams. */
 typedef struct SvtAmdMdRates {             /* MdRateEstimationContext_t, field for field (Codec/EbMdRateEstimation.h:113-161)      */
@@ -1443,7 +1447,8 @@ typedef struct SvtAmdMdPicture {
     uint8_t skip_ois_8x8, cu8x8_mode, cu16x16_mode, limit_ois_to_dc_mode; /* PictureParentControlSet_t                            */
     uint8_t constrained_intra, strong_smoothing; /* encode pass: pcs->constrainedIntraFlag, scs->enableStrongIntraSmoothing      */
     uint8_t qp, chroma_qp;                 /* contextPtr->qp, ->chromaQp of every LCU (no delta-QP tools)                        */
-    uint8_t pad[2];
+    uint8_t intra8x8_restriction_inter_slice; /* .intra8x8RestrictionInterSlice (EbEncDecProcess.c:2125-2151)                    */
+    uint8_t pad;
     uint32_t fast_lambda, full_lambda, fast_chroma_lambda, full_chroma_lambda; /* ModeDecisionConfigureLcu's assignment           */
     SvtAmdMdRates rates;                   /* contextPtr->mdRateEstimationPtr (slice type + QP row of mdRateEstimationArray)     */
 } SvtAmdMdPicture;
@@ -1455,10 +1460,40 @@ typedef struct SvtAmdMdLcu {
     uint8_t is_complete;                   /* scs->lcuParamsArray[lcu].isCompleteLcu                                             */
     uint8_t complexity_status_2;           /* ppcs->complexLcuArray[lcu] == LCU_COMPLEXITY_STATUS_2                              */
     uint8_t contouring_class[4];           /* DeriveContouringClass of the four 32x32 quadrants (EbModeDecisionConfiguration.c:395) */
-    uint8_t chroma_encode_mode;            /* lcuPtr->chromaEncodeMode after ConfigureChroma (1 = CHROMA_MODE_BEST)              */
+    uint8_t chroma_encode_mode;            /* lcuPtr->chromaEncodeMode after ConfigureChroma (1 = CHROMA_MODE_FULL, 2 = CHROMA_MODE_BEST)             */
     uint8_t restrict_intra_global_motion;  /* contextPtr->restrictIntraGlobalMotion                                              */
     uint8_t lcu_md_mode;                   /* ppcs->lcuMdModeArray[lcu] (PICT_LCU_SWITCH pictures)                               */
+    uint8_t skip_small_cu;                 /* SkipSmallCu's LCU condition (EbProductCodingLoop.c:2301): auraStatus == AURA_STATUS_0 and no
+                                            * stationary edge over time                                                          */
+    uint8_t cmplx_noise;                   /* ppcs->cmplxStatusLcu[lcu] == CMPLX_NOISE (:2079)                                   */
+    uint8_t variance_below_200;            /* ppcs->variance[lcu][0] < 200: the encode pass's skip-cost bias (EbCodingLoop.c:3866) */
+    uint8_t edge_block;                    /* ppcs->edgeResultsPtr[lcu].edgeBlockNum != 0                                        */
+    uint8_t no_stop_split;                 /* StopSplitCondition's LCU exemptions (Codec/EbFullLoop.c:1445-1450): isolated non-homogeneous
+                                            * area, or aura status 1 below 4K                                                    */
+    uint8_t pad[3];
 } SvtAmdMdLcu;
+/* P / B pictures: what the inter candidates need beyond the above.  Reference pictures and coefficient-rate tables are those of
+ * svt_amd_encdec_picture_set_inter (the mode decision predicts from the same reference pictures as the encode pass). */
+typedef struct SvtAmdTmvpLcu {             /* TmvpUnit_t of one LCU (Codec/EbAdaptiveMotionVectorPrediction.h:28): 16 units of 16x16 */
+    int16_t mv[2][16][2];                  /* [list][unit]{x, y}                                                                 */
+    uint64_t ref_poc[2][16];
+    uint8_t pred_dir[16], available[16];
+} SvtAmdTmvpLcu;
+typedef struct SvtAmdMdInter {
+    uint64_t picture_number;               /* pcs->pictureNumber                                                                 */
+    uint64_t ref_poc[2];                   /* ((EbReferenceObject_t *)pcs->refPicPtrArray[list]->objectPtr)->refPOC              */
+    uint64_t colocated_poc;                /* refPOC of the co-located picture (list pcs->colocatedPuRefList; list 0 in P pictures) */
+    uint8_t colocated_pu_ref_list, is_low_delay; /* pcs->colocatedPuRefList, ->isLowDelay                                        */
+    uint8_t tmvp_enable;                   /* !ppcs->disableTmvpFlag && the co-located reference object's tmvpEnableFlag         */
+    uint8_t use_subpel;                    /* ppcs->useSubpelFlag                                                                */
+    uint8_t unrestricted_mv;               /* scs->staticConfig.unrestrictedMotionVector                                         */
+    uint8_t generate_amvp_table_md;        /* ModeDecisionContext_t.generateAmvpTableMd                                          */
+    uint8_t extra_injection;               /* .amvpInjection | .unipred3x3Injection | .bipred3x3Injection (encMode 0..1)         */
+    uint8_t improve_sharpness;             /* scs->staticConfig.improveSharpness (cost biases)                                   */
+    uint8_t skip_cost_bias;                /* encode pass (EbCodingLoop.c:3861-3871): non-reference B picture with a reference picture whose
+                                            * intraCodedArea is above INTRA_AREA_TH[its temporal layer]                          */
+    uint8_t pad[7];
+} SvtAmdMdInter;
 /* what the mode decision leaves per LCU: the decision of every leaf it tested (the final tree = leaves with split == 0 walked in
  * Z order) and the costs the inter-depth decisions compared (mdLocalCuUnit[].cost) */
 typedef struct SvtAmdMdLcuOut {
@@ -1466,9 +1501,14 @@ typedef struct SvtAmdMdLcuOut {
     uint8_t tested[SVT_AMD_MD_LEAVES];     /* mdLocalCuUnit[].testedCuFlag                                                       */
     uint8_t pred_mode[SVT_AMD_MD_LEAVES];  /* predictionModeFlag of tested leaves                                                */
     uint8_t intra_luma_mode[SVT_AMD_MD_LEAVES];
-    uint8_t ycbf[SVT_AMD_MD_LEAVES];       /* transformUnitArray[0].lumaCbf as ProductFullModeDecision left it                  */
-    uint8_t pad[7];
+    uint8_t ycbf[SVT_AMD_MD_LEAVES];       /* luma cbf as ProductFullModeDecision left it: bit 0 = transformUnitArray[0].lumaCbf (units below
+                                            * 64x64), bits 1..4 = transform units 1..4 of a 64x64 unit                           */
+    uint8_t inter_dir[SVT_AMD_MD_LEAVES];  /* PredictionUnit_t.interPredDirectionIndex (3 in intra units)                        */
+    uint8_t merge_flag[SVT_AMD_MD_LEAVES], merge_index[SVT_AMD_MD_LEAVES];
+    uint8_t pad[8];
+    int16_t mv[SVT_AMD_MD_LEAVES][2][2];   /* PredictionUnit_t.mv[list].{x, y}                                                   */
     uint64_t cost[SVT_AMD_MD_LEAVES];      /* mdLocalCuUnit[].cost                                                               */
+    uint64_t merge_cost[SVT_AMD_MD_LEAVES], skip_cost[SVT_AMD_MD_LEAVES]; /* mdEpPipeLcu[].mergeCost / .skipCost (merge units)   */
 } SvtAmdMdLcuOut;
 /* 1 when this revision's device call covers the picture (see above) */
 SVT_AMD_API int svt_amd_md_picture_supported(const SvtAmdMdPicture *P);
@@ -1482,6 +1522,16 @@ SVT_AMD_API int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPictur
                                           const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr,
                                           uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot, const SvtAmdCabacCost *cost,
                                           SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results);
+/* P / B pictures: the same call with the inter inputs - X (above), me: HOST array of the picture's motion-estimation results (one
+ * record per LCU; NULL = the records svt_amd_me_picture* left in HBM for `me_slot`), tmvp: HOST array of the co-located picture's
+ * motion field (one record per LCU; may be NULL when !X->tmvp_enable).  The reference pictures and rate tables are those of the
+ * last svt_amd_encdec_picture_set_inter on `pic`.  X == NULL: an I picture, as above. */
+SVT_AMD_API int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X,
+                                                const SvtAmdMdLcu *lcus, const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb,
+                                                const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot,
+                                                const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp,
+                                                SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results);
+SVT_AMD_API int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,9 @@
 #include "EbModeDecisionProcess.h"
 #include "EbModeDecisionConfiguration.h"
 #include "EbMdRateEstimation.h"
+#include "EbReferenceObject.h"
+#include "EbAdaptiveMotionVectorPrediction.h"
+#include "EbMotionEstimationLcuResults.h"
 #include "../include/svt_hevc_amd.h"
 
 _Static_assert(sizeof(MdRateEstimationContext_t) == sizeof(SvtAmdMdRates), "MdRateEstimationContext_t layout");
@@ -43,7 +46,7 @@ static void svt_md_fill_picture(SvtAmdMdPicture *P, const SequenceControlSet_t *
     P->rdoq_pmcore_method = (uint8_t)md->rdoqPmCoreMethod;
     P->skip_ois_8x8 = pp->skipOis8x8, P->cu8x8_mode = pp->cu8x8Mode, P->cu16x16_mode = pp->cu16x16Mode, P->limit_ois_to_dc_mode = pp->limitOisToDcModeFlag;
     P->constrained_intra = pcs->constrainedIntraFlag, P->strong_smoothing = scs->enableStrongIntraSmoothing;
-    P->qp = md->qp, P->chroma_qp = md->chromaQp;
+    P->qp = md->qp, P->chroma_qp = md->chromaQp, P->intra8x8_restriction_inter_slice = md->intra8x8RestrictionInterSlice;
     P->fast_lambda = md->fastLambda, P->full_lambda = md->fullLambda, P->fast_chroma_lambda = md->fastChromaLambda, P->full_chroma_lambda = md->fullChromaLambda;
     memcpy(&P->rates, md->mdRateEstimationPtr, sizeof(P->rates));
 }
@@ -64,12 +67,73 @@ static void svt_md_fill_lcu(SvtAmdMdLcu *L, const SequenceControlSet_t *scs, con
     L->complexity_status_2 = pp->complexLcuArray[lcu] == LCU_COMPLEXITY_STATUS_2;
     for (int q = 0; q < 4; q++)
         L->contouring_class[q] = DeriveContouringClass(pp, (EB_U16)lcu, (EB_U8)(1 + 21 * q));
-    /* ConfigureChroma (Codec/EbModeDecisionProcess.c:408-471) for the two levels that need no per-LCU detector; 0 = a switch level (2..5) */
-    L->chroma_encode_mode = md->chromaLevel == 0 && pcs->colorFormat < EB_YUV422 ? CHROMA_MODE_FULL : md->chromaLevel <= 1 ? CHROMA_MODE_BEST : 0;
+    /* ConfigureChroma (Codec/EbModeDecisionProcess.c:408-471): picture-analysis detectors only, so every LCU's mode is known up front */
+    {
+        const LcuStat_t *ls = &pp->lcuStatArray[lcu];
+        const int c0 = ls->stationaryEdgeOverTimeFlag, c1 = pp->lcuHomogeneousAreaArray[lcu] && ls->cuStatArray[0].highChroma;
+        const int c2 = !ls->cuStatArray[0].highLuma, c3 = pp->grassPercentageInPicture > 60 || lcuPtr->auraStatus == AURA_STATUS_1 || pp->isPan;
+        const int full = md->chromaLevel == 0 ? 1 : md->chromaLevel == 1 ? 0 : md->chromaLevel == 2 ? (c0 || c1 || c2) : md->chromaLevel == 3 ? (c0 || c1)
+                       : md->chromaLevel == 4 ? (c2 || c3) : c0;
+        L->chroma_encode_mode = full && pcs->colorFormat < EB_YUV422 ? CHROMA_MODE_FULL : CHROMA_MODE_BEST;
+    }
     /* contextPtr->mdContext->restrictIntraGlobalMotion (Codec/EbEncDecProcess.c:2890) */
     L->restrict_intra_global_motion = (pp->isPan || pp->isTilt) && pp->nonMovingIndexArray[lcu] < INTRA_GLOBAL_MOTION_NON_MOVING_INDEX_TH &&
                                       pp->yMean[lcu][RASTER_SCAN_CU_INDEX_64x64] < INTRA_GLOBAL_MOTION_DARK_LCU_TH;
     L->lcu_md_mode = pp->depthMode == PICT_LCU_SWITCH_DEPTH_MODE ? pp->lcuMdModeArray[lcu] : 0;
+    L->skip_small_cu = lcuPtr->auraStatus == AURA_STATUS_0 && pp->lcuStatArray[lcu].stationaryEdgeOverTimeFlag == 0;
+    L->cmplx_noise = pp->cmplxStatusLcu[lcu] == CMPLX_NOISE;
+    L->variance_below_200 = pp->variance[lcu][0] < 200;
+    L->edge_block = pp->edgeResultsPtr[lcu].edgeBlockNum != 0;
+    L->no_stop_split = pp->lcuIsolatedNonHomogeneousAreaArray[lcu] || (scs->inputResolution < INPUT_SIZE_4K_RANGE && lcuPtr->auraStatus == AURA_STATUS_1);
+}
+
+/* P / B pictures */
+static void svt_md_fill_inter(SvtAmdMdInter *X, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, const ModeDecisionContext_t *md)
+{
+    const PictureParentControlSet_t *pp = pcs->ParentPcsPtr;
+    memset(X, 0, sizeof(*X));
+    X->picture_number = pcs->pictureNumber;
+    const EbReferenceObject_t *r[2] = {NULL, NULL};
+    for (int l = 0; l < (pcs->sliceType == EB_B_PICTURE ? 2 : 1); l++) {
+        r[l] = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
+        X->ref_poc[l] = r[l]->refPOC;
+    }
+    const int col = pcs->sliceType == EB_B_PICTURE ? pcs->colocatedPuRefList : REF_LIST_0;
+    X->colocated_pu_ref_list = (uint8_t)pcs->colocatedPuRefList, X->is_low_delay = pcs->isLowDelay;
+    X->colocated_poc = r[col]->refPOC;
+    X->tmvp_enable = !pp->disableTmvpFlag && r[col]->tmvpEnableFlag;
+    X->use_subpel = pp->useSubpelFlag, X->unrestricted_mv = scs->staticConfig.unrestrictedMotionVector;
+    X->generate_amvp_table_md = md->generateAmvpTableMd;
+    X->extra_injection = md->amvpInjection || md->unipred3x3Injection || md->bipred3x3Injection;
+    X->improve_sharpness = scs->staticConfig.improveSharpness;
+    if (pcs->sliceType == EB_B_PICTURE && pp->isUsedAsReferenceFlag == EB_FALSE) {
+        static const EB_U8 th[MAX_TEMPORAL_LAYERS] = {40, 30, 30, 0, 0, 0}; /* INTRA_AREA_TH, EbCodingLoop.c:3864 */
+        X->skip_cost_bias = r[0]->intraCodedArea > th[r[0]->tmpLayerIdx] || r[1]->intraCodedArea > th[r[1]->tmpLayerIdx];
+    }
+}
+
+/* the co-located picture's motion field of one LCU */
+static void svt_md_fill_tmvp(SvtAmdTmvpLcu *t, const TmvpUnit_t *u)
+{
+    for (int i = 0; i < 16; i++) {
+        for (int l = 0; l < 2; l++)
+            t->mv[l][i][0] = u->mv[l][i].x, t->mv[l][i][1] = u->mv[l][i].y, t->ref_poc[l][i] = u->refPicPOC[l][i];
+        t->pred_dir[i] = (uint8_t)u->predictionDirection[i], t->available[i] = (uint8_t)u->availabilityFlag[i];
+    }
+}
+
+/* the motion-estimation results of one LCU in the contract's layout (MeCuResults_t, Codec/EbMotionEstimationLcuResults.h:58) */
+static void svt_md_fill_me(SvtAmdMeLcuResult *m, const PictureParentControlSet_t *pp, EB_U32 lcu)
+{
+    memset(m, 0, sizeof(*m));
+    for (int pu = 0; pu < SVT_AMD_ME_PU_COUNT; pu++) {
+        const MeCuResults_t *r = &pp->meResults[lcu][pu];
+        SvtAmdMeCuResult *o = &m->pu[pu];
+        o->x_mv_l0 = r->xMvL0, o->y_mv_l0 = r->yMvL0, o->x_mv_l1 = r->xMvL1, o->y_mv_l1 = r->yMvL1;
+        o->total_me_candidate_index = r->totalMeCandidateIndex;
+        for (int k = 0; k < 3; k++)
+            o->distortion[k] = r->distortionDirection[k].distortion, o->direction[k] = r->distortionDirection[k].direction;
+    }
 }
 
 /* the picture's open-loop intra search results in the contract's layout (SvtAmdOisLcuResult: by raster-scan CU index) */

@@ -32,12 +32,18 @@ EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
 
 #define MD_PIC_MAGIC 0x4350444DU /* "MDPC" */
 #define MD_LCU_MAGIC 0x434C444DU /* "MDLC" */
-typedef struct MdPicRecord { /* followed by: luma (width x height), cb, cr (width/2 x height/2), then nlcu SvtAmdOisLcuResult */
+typedef struct MdPicRecord { /* followed by: luma (width x height), cb, cr (width/2 x height/2), then nlcu SvtAmdOisLcuResult; P / B pictures
+                              * (has_inter): nlcu SvtAmdMeLcuResult, nlcu SvtAmdTmvpLcu when tmvp_present, then per reference list (nref) the
+                              * three whole padded planes: ref_stride_y * (ref_height + 2 ref_origin_y) luma samples, then Cb, Cr at
+                              * ref_stride_c * (ref_height / 2 + ref_origin_y) */
     uint32_t magic, record_size;
     uint64_t picture_number;
-    uint32_t nlcu, pad;
+    uint32_t nlcu, has_inter;
     SvtAmdMdPicture pic;
     SvtAmdCabacCost cost;
+    uint32_t pad;
+    SvtAmdMdInter inter;
+    uint32_t ref_stride_y, ref_stride_c, ref_origin_x, ref_origin_y, ref_width, ref_height, nref, tmvp_present;
 } MdPicRecord;
 typedef struct MdLcuRecord {
     uint32_t magic, record_size;
@@ -69,10 +75,26 @@ static void dump_picture(const SequenceControlSet_t *scs, const PictureControlSe
     MdPicRecord r;
     memset(&r, 0, sizeof(r));
     r.magic = MD_PIC_MAGIC;
-    r.record_size = (uint32_t)(sizeof(r) + (size_t)w * h * 3 / 2 + (size_t)nlcu * sizeof(SvtAmdOisLcuResult));
+    size_t total = sizeof(r) + (size_t)w * h * 3 / 2 + (size_t)nlcu * sizeof(SvtAmdOisLcuResult);
     r.picture_number = pcs->pictureNumber, r.nlcu = nlcu;
     svt_md_fill_picture(&r.pic, scs, pcs, md);
     memcpy(&r.cost, pcs->cabacCost, sizeof(r.cost));
+    const EbReferenceObject_t *col = NULL;
+    const EbPictureBufferDesc_t *rb[2] = {NULL, NULL};
+    if (pcs->sliceType != EB_I_PICTURE) {
+        r.has_inter = 1;
+        svt_md_fill_inter(&r.inter, scs, pcs, md);
+        r.nref = pcs->sliceType == EB_B_PICTURE ? 2 : 1;
+        for (uint32_t l = 0; l < r.nref; l++)
+            rb[l] = ((const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr)->referencePicture;
+        r.ref_stride_y = rb[0]->strideY, r.ref_stride_c = rb[0]->strideCb, r.ref_origin_x = rb[0]->originX, r.ref_origin_y = rb[0]->originY;
+        r.ref_width = rb[0]->width, r.ref_height = rb[0]->height;
+        col = (const EbReferenceObject_t *)pcs->refPicPtrArray[pcs->sliceType == EB_B_PICTURE ? pcs->colocatedPuRefList : REF_LIST_0]->objectPtr;
+        r.tmvp_present = r.inter.tmvp_enable;
+        total += (size_t)nlcu * sizeof(SvtAmdMeLcuResult) + (r.tmvp_present ? (size_t)nlcu * sizeof(SvtAmdTmvpLcu) : 0);
+        total += (size_t)r.nref * ((size_t)r.ref_stride_y * (r.ref_height + 2 * r.ref_origin_y) + 2 * (size_t)r.ref_stride_c * (r.ref_height / 2 + r.ref_origin_y));
+    }
+    r.record_size = (uint32_t)total;
     fwrite(&r, sizeof(r), 1, g_file);
     for (uint32_t y = 0; y < h; y++)
         fwrite(in->bufferY + (size_t)(in->originY + y) * in->strideY + in->originX, 1, w, g_file);
@@ -84,6 +106,26 @@ static void dump_picture(const SequenceControlSet_t *scs, const PictureControlSe
     for (uint32_t l = 0; l < nlcu; l++) {
         svt_md_fill_ois(&o, pp, l);
         fwrite(&o, sizeof(o), 1, g_file);
+    }
+    if (!r.has_inter)
+        return;
+    SvtAmdMeLcuResult *m = (SvtAmdMeLcuResult *)malloc(sizeof(*m));
+    for (uint32_t l = 0; l < nlcu; l++) {
+        svt_md_fill_me(m, pp, l);
+        fwrite(m, sizeof(*m), 1, g_file);
+    }
+    free(m);
+    if (r.tmvp_present) {
+        SvtAmdTmvpLcu t;
+        for (uint32_t l = 0; l < nlcu; l++) {
+            svt_md_fill_tmvp(&t, &col->tmvpMap[l]);
+            fwrite(&t, sizeof(t), 1, g_file);
+        }
+    }
+    for (uint32_t l = 0; l < r.nref; l++) {
+        fwrite(rb[l]->bufferY, 1, (size_t)r.ref_stride_y * (r.ref_height + 2 * r.ref_origin_y), g_file);
+        fwrite(rb[l]->bufferCb, 1, (size_t)r.ref_stride_c * (r.ref_height / 2 + r.ref_origin_y), g_file);
+        fwrite(rb[l]->bufferCr, 1, (size_t)r.ref_stride_c * (r.ref_height / 2 + r.ref_origin_y), g_file);
     }
 }
 
@@ -120,6 +162,14 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
         r->out.pred_mode[i] = (uint8_t)cu->predictionModeFlag;
         r->out.intra_luma_mode[i] = (uint8_t)cu->predictionUnitArray[0].intraLumaMode;
         r->out.ycbf[i] = (uint8_t)cu->transformUnitArray[0].lumaCbf;
+        if (i == 0) /* a 64x64 unit: four 32x32 transform units */
+            r->out.ycbf[i] = (uint8_t)(cu->transformUnitArray[1].lumaCbf << 1 | cu->transformUnitArray[2].lumaCbf << 2 | cu->transformUnitArray[3].lumaCbf << 3 |
+                                       cu->transformUnitArray[4].lumaCbf << 4);
+        const PredictionUnit_t *pu = cu->predictionUnitArray;
+        r->out.inter_dir[i] = (uint8_t)pu->interPredDirectionIndex, r->out.merge_flag[i] = (uint8_t)pu->mergeFlag, r->out.merge_index[i] = (uint8_t)pu->mergeIndex;
+        for (int l = 0; l < 2; l++)
+            r->out.mv[i][l][0] = pu->mv[l].x, r->out.mv[i][l][1] = pu->mv[l].y;
+        r->out.merge_cost[i] = contextPtr->mdEpPipeLcu[i].mergeCost, r->out.skip_cost[i] = contextPtr->mdEpPipeLcu[i].skipCost;
         r->out.cost[i] = contextPtr->mdLocalCuUnit[i].cost;
     }
     pthread_mutex_lock(&g_lock);

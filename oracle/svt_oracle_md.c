@@ -30,6 +30,15 @@ typedef struct MdPic {
     uint32_t *info;    /* per 4x4 luma block: mode type | intra luma mode << 8 | depth << 16 | skip flag << 24; ~0 = never written */
     uint32_t infoPitch;
     uint32_t w, h;
+    MdMvUnit *mv;      /* per 8x8 luma block: the unit's MvUnit_t (mdMvNeighborArray) */
+    uint32_t mvPitch;
+    /* P / B pictures */
+    const SvtAmdMdInter *X;
+    const SvtAmdMeLcuResult *me;
+    const SvtAmdTmvpLcu *tmvp;
+    const SvtAmdRefPicture *ref[2];
+    const uint8_t *src;
+    uint32_t srcStride;
 } MdPic;
 
 static uint32_t info_at(const MdPic *M, int px, int py)
@@ -78,54 +87,166 @@ static void md_neighbors(const MdPic *M, const SvtAmdMdLcu *L, int lcu_x, int lc
 
 static int g_md_debug;
 
+/* IntraPredictionOl (Codec/EbIntraPrediction.c:5427) of the luma block: neighbours = SOURCE samples (UpdateNeighborSamplesArrayOL, :4952:
+ * mid-grey beyond the picture, no substitution, no smoothing) */
+static void md_predict_ol(const MdPic *M, const MdStats *st, int lcu_x, int lcu_y, int mode, uint8_t *pred)
+{
+    const int N = st->size, x0 = lcu_x + st->x, y0 = lcu_y + st->y;
+    SvtAmdIntraPuJob J;
+    memset(&J, 0, sizeof(J));
+    J.size = (uint32_t)N, J.bottom_left_ok = J.top_right_ok = 1, J.no_smoothing = 1, J.mode_tl = 2;
+    memset(J.mode_left, 2, sizeof(J.mode_left)), memset(J.mode_top, 2, sizeof(J.mode_top));
+    J.luma_mode = (uint8_t)mode, J.chroma_mode = 4;
+    const uint8_t *src = M->src + (size_t)y0 * M->srcStride + x0;
+    for (int i = 0; i < 2 * N; i++)
+        J.left[0][i] = J.top[0][i] = 128;
+    J.tl[0] = 128;
+    if (x0 != 0)
+        for (int i = 0; i < 2 * N && y0 + i < (int)M->h; i++)
+            J.left[0][i] = src[(ptrdiff_t)i * M->srcStride - 1];
+    if (x0 != 0 && y0 != 0)
+        J.tl[0] = src[-(ptrdiff_t)M->srcStride - 1];
+    if (y0 != 0)
+        for (int i = 0; i < 2 * N && x0 + i < (int)M->w; i++)
+            J.top[0][i] = src[i - (ptrdiff_t)M->srcStride];
+    svt_oracle_intra_pu(1, &J, pred, (uint32_t)N, NULL, NULL, 0);
+}
+
+/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468), luma */
+static void md_predict_inter(const MdPic *M, const MdStats *st, int lcu_x, int lcu_y, const MdCand *c, uint8_t *pred /* N x N */)
+{
+    static __thread uint8_t cb[32 * 32], cr[32 * 32];
+    SvtAmdInterPuJob J;
+    memset(&J, 0, sizeof(J));
+    for (int l = 0; l < 2; l++)
+        J.mv[l][0] = c->mv[l].x, J.mv[l][1] = c->mv[l].y;
+    J.pu_x = (uint16_t)(lcu_x + st->x), J.pu_y = (uint16_t)(lcu_y + st->y), J.pu_w = J.pu_h = st->size, J.pred_dir = c->dir;
+    svt_oracle_inter_pu(&J, M->ref[0], M->ref[1], pred, st->size, cb, cr, st->size / 2);
+}
+
+/* the spatial neighbours of the candidate lists with the availability GenerateL0L1AmvpMergeLists derives (:2256-2340) */
+static void md_inter_neighbors(const MdPic *M, const SvtAmdMdLcu *L, int lcu_x, int lcu_y, const MdStats *st, MdMvUnit nb[5])
+{
+    const int x0 = lcu_x + st->x, y0 = lcu_y + st->y, N = st->size;
+    const int left = L->tile_left && st->x == 0, top = L->tile_top && st->y == 0, right = L->tile_right && ((st->x + N) & 63) == 0;
+    const int px[5] = {x0 - 1, x0 - 1, x0 + N, x0 + N - 1, x0 - 1}, py[5] = {y0 + N, y0 + N - 1, y0 - 1, y0 - 1, y0 - 1};
+    int ok[5];
+    ok[MD_A0] = md_bottom_left_ok(st) && !left;
+    ok[MD_A1] = !left;
+    ok[MD_B0] = md_top_right_ok(st) && !top && !right;
+    ok[MD_B1] = !top;
+    ok[MD_B2] = !left && !top;
+    for (int k = 0; k < 5; k++) {
+        memset(&nb[k], 0, sizeof(nb[k]));
+        if (ok[k] && (info_at(M, px[k], py[k]) & 0xFF) == MD_INTER) {
+            nb[k] = M->mv[(size_t)(py[k] >> 3) * M->mvPitch + (px[k] >> 3)];
+            nb[k].avail = 1;
+        }
+    }
+}
+
 /* ModeDecisionLcu of one LCU against the picture state M (updated).  src: luma source of the PICTURE. */
 static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdCabacCost *cost, const uint8_t *src, uint32_t srcStride,
-                   const SvtAmdOisLcuResult *ois, int lcu_x, int lcu_y, MdPic *M, MdLcuState *S, SvtAmdMdLcuOut *out)
+                   const SvtAmdOisLcuResult *ois, int lcu_x, int lcu_y, int lcu_index, MdPic *M, MdLcuState *S, SvtAmdMdLcuOut *out)
 {
     /* per depth: the candidate buffers (prediction, reconstructed coefficients) of the unit tested last, and the best candidate's
      * reconstruction (bestCandidateBuffers[depth]->reconPtr), at the unit's position inside the LCU */
     static __thread uint8_t bestRec[4][64 * 64];
     const int lcuH = (int)P->height - lcu_y < 64 ? (int)P->height - lcu_y : 64;
+    const int islice = P->slice_type == 2;
     md_construct_cu_array(S, L);
     int cuIdx = 0;
     do {
         int leaf = L->leaf_index[cuIdx];
         MdStats st = md_stats(leaf);
         S->local[leaf].tested = 1;
-        S->cu[leaf].split = (uint8_t)((P->slice_type == 2 && st.depth == 0) ? 1 : L->leaf_split[cuIdx]);
+        S->cu[leaf].split = (uint8_t)((islice && st.depth == 0) ? 1 : L->leaf_split[cuIdx]);
         MdNeighbors Nb;
         md_neighbors(M, L, lcu_x, lcu_y, &st, &Nb);
         md_context_generation(S, leaf, st.y, &Nb);
+        S->cu[leaf].split = (uint8_t)md_skip_small_cu(P, L, S, leaf, st.depth);
         uint32_t mpm[3] = {0, 0, 0};
         if (P->mpm_search && !L->restrict_intra_global_motion)
             md_mpm_modes(S->cu[leaf].left_intra_mode, S->cu[leaf].top_intra_mode, mpm);
         const int fullReconSearchCount = md_nfl(P, L, st.size);
+        const int N = st.size, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
         /* ProductGenerateAmvpMergeInterIntraMdCandidatesCU (EbModeDecision.c:1795) */
         MdCand cand[MD_MAX_CAND];
+        memset(cand, 0, sizeof(cand));
         int ncand = 0;
-        if (st.depth != 0 && (P->slice_type == 2 || st.depth == 3 || !L->restrict_intra_global_motion))
+        if (st.depth != 0 && (islice || st.depth == 3 || !L->restrict_intra_global_motion))
             if (!(P->limit_intra && st.x == 0 && st.y == 0))
                 ncand = md_intra_candidates(P, L, ois, leaf, &st, cand);
+        if (!islice) {
+            MdMvUnit nb[5];
+            MdInterLists T;
+            memset(&T, 0, sizeof(T));
+            md_inter_neighbors(M, L, lcu_x, lcu_y, &st, nb);
+            const int totalMerge = md_nmm(P, N);
+            md_amvp_merge_lists(P, M->X, nb, M->X->tmvp_enable ? &M->tmvp[lcu_index] : NULL, x0, y0, N, totalMerge, &T);
+            ncand = md_inter_candidates(P, L, &M->me[lcu_index].pu[md_raster_index(&st)], &T, (uint32_t)x0, (uint32_t)y0, totalMerge, cand, ncand);
+            if (g_md_debug) {
+                fprintf(stderr, "  leaf %d amvp L0 %d:(%d,%d)(%d,%d) L1 %d:(%d,%d)(%d,%d) merge %d:", leaf, T.amvp_count[0], T.amvp[0][0].x, T.amvp[0][0].y,
+                        T.amvp[0][1].x, T.amvp[0][1].y, T.amvp_count[1], T.amvp[1][0].x, T.amvp[1][0].y, T.amvp[1][1].x, T.amvp[1][1].y, T.merge_count);
+                for (int k = 0; k < T.merge_count; k++)
+                    fprintf(stderr, " [%d (%d,%d) (%d,%d)]", T.merge[k].dir, T.merge[k].mv[0].x, T.merge[k].mv[0].y, T.merge[k].mv[1].x, T.merge[k].mv[1].y);
+                fprintf(stderr, "\n");
+            }
+        }
         int bufferTotal = fullReconSearchCount;
         ncand = md_mpm_injection(P, L, &st, cand, ncand, &bufferTotal, mpm);
         bufferTotal = ncand < bufferTotal ? ncand : bufferTotal;
         static const int width[4] = {5, 8, 8, 8};
         const int maxBuffers = bufferTotal + 1 < width[st.depth] ? bufferTotal + 1 : width[st.depth];
-        /* ProductPerformFastLoop (:1911): every candidate of an I picture is evaluated in the second loop */
-        const int N = st.size, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
+        /* ProductPerformFastLoop (:1911) */
         uint64_t costs[MD_MAX_CAND], fastLumaRate[MD_MAX_CAND];
         uint8_t evaluated[MD_MAX_CAND];
-        uint8_t pred[32 * 32];
+        static __thread uint8_t pred[64 * 64];
+        int bestFirst = -1;
+        if (!P->single_fast_loop) { /* first loop: the candidates whose distortion the open-loop stages left (:1948-1988) */
+            uint64_t bestCost = ~0ull;
+            for (int i = ncand - 1; i >= 0; i--) {
+                if (!cand[i].dist_ready)
+                    continue;
+                uint64_t r;
+                const uint64_t c = cand[i].type == MD_INTER ? md_inter_fast_cost(P, &st, &S->cu[leaf], &cand[i], cand[i].me_dist, &r)
+                                 : islice               ? md_intra_fast_cost_islice(P, &st, &S->cu[leaf], cand[i].intra_mode, cand[i].me_dist, &r)
+                                                        : md_intra_fast_cost_pslice(P, &st, &S->cu[leaf], cand[i].intra_mode, cand[i].me_dist, &r);
+                if (c <= bestCost)
+                    bestFirst = i, bestCost = c;
+            }
+        }
         for (int i = 0; i < ncand; i++) {
             uint64_t dist = 0;
-            evaluated[i] = 1;
+            evaluated[i] = (uint8_t)(!cand[i].dist_ready || i == bestFirst || P->single_fast_loop);
+            costs[i] = ~0ull, fastLumaRate[i] = 0;
+            if (!evaluated[i])
+                continue;
+            const int reuse = i == bestFirst && cand[i].type == MD_INTRA; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
+            if (reuse && P->intra_md_open_loop)
+                evaluated[i] = 3;
             if (!cand[i].mpm) {
-                md_predict(M, L, lcu_x, lcu_y, &st, cand[i].intra_mode, pred);
-                dist = svt_oracle_NxMSadKernel(src + (size_t)y0 * srcStride + x0, srcStride, pred, (uint32_t)N, (uint32_t)N, (uint32_t)N);
+                if (reuse) {
+                    dist = cand[i].me_dist;
+                } else {
+                    if (cand[i].type == MD_INTER)
+                        md_predict_inter(M, &st, lcu_x, lcu_y, &cand[i], pred);
+                    else if (P->intra_md_open_loop)
+                        md_predict_ol(M, &st, lcu_x, lcu_y, cand[i].intra_mode, pred);
+                    else
+                        md_predict(M, L, lcu_x, lcu_y, &st, cand[i].intra_mode, pred);
+                    dist = svt_oracle_NxMSadKernel(src + (size_t)y0 * srcStride + x0, srcStride, pred, (uint32_t)N, (uint32_t)N, (uint32_t)N);
+                }
             }
-            costs[i] = md_intra_fast_cost_islice(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, &fastLumaRate[i]);
+            costs[i] = cand[i].type == MD_INTER ? md_inter_fast_cost(P, &st, &S->cu[leaf], &cand[i], dist, &fastLumaRate[i])
+                     : islice                 ? md_intra_fast_cost_islice(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, &fastLumaRate[i])
+                                              : md_intra_fast_cost_pslice(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, &fastLumaRate[i]);
             if (cand[i].mpm)
                 costs[i] = 0;
+            if (g_md_debug)
+                fprintf(stderr, "  leaf %d cand %d type %d mode %d dir %d merge %d/%d mv (%d,%d) (%d,%d) dist %llu fast %llu\n", leaf, i, cand[i].type,
+                        cand[i].intra_mode, cand[i].dir, cand[i].merge_flag, cand[i].merge_index, cand[i].mv[0].x, cand[i].mv[0].y, cand[i].mv[1].x,
+                        cand[i].mv[1].y, (unsigned long long)dist, (unsigned long long)costs[i]);
         }
         MdBuffers B;
         md_fast_loop_buffers(&B, width[st.depth], maxBuffers, ncand, costs, evaluated);
@@ -137,14 +258,28 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
         const int fullCount = md_pre_mode_decision(&B, types, same ? bufferTotal : maxBuffers, same, best);
         /* PerformFullLoop (:4351) */
         const int nfull = fullCount < bufferTotal ? fullCount : bufferTotal;
-        uint32_t ycbf[MD_MAX_BUF] = {0};
-        static __thread int16_t reconCoeff[MD_MAX_BUF][32 * 32];
-        static __thread uint8_t predBuf[MD_MAX_BUF][32 * 32];
+        const int pf = md_pf_mode(P);
+        uint32_t ycbf[MD_MAX_BUF] = {0}, fullDist[MD_MAX_BUF] = {0};
+        uint64_t mergeCost[MD_MAX_BUF] = {0}, skipCost[MD_MAX_BUF] = {0};
+        static __thread int16_t reconCoeff[MD_MAX_BUF][64 * 64];
+        static __thread uint8_t predBuf[MD_MAX_BUF][64 * 64];
+        uint32_t prevRootCbf = 1;
+        uint64_t bestFullCost = 0xFFFFFFFFull;
         for (int f = 0; f < nfull; f++) {
             const int b = best[f];
             const MdCand *c = &cand[B.cand[b]];
-            md_predict(M, L, lcu_x, lcu_y, &st, c->intra_mode, predBuf[b]);
-            int16_t residual[32 * 32], quant[32 * 32];
+            if (!islice && c->type == MD_INTRA && prevRootCbf == 0)
+                continue;
+            /* the buffer's luma prediction: the candidate the fast loop predicted there, or - predictionIsReadyLuma == 0 - a fresh one */
+            const int fresh = B.cand[b] == bestFirst && c->type == MD_INTRA && P->intra_md_open_loop && evaluated[B.cand[b]];
+            const MdCand *pc = fresh || B.pred[b] < 0 ? c : &cand[B.pred[b]];
+            if (pc->type == MD_INTER)
+                md_predict_inter(M, &st, lcu_x, lcu_y, pc, predBuf[b]);
+            else if (P->intra_md_open_loop)
+                md_predict_ol(M, &st, lcu_x, lcu_y, pc->intra_mode, predBuf[b]);
+            else
+                md_predict(M, L, lcu_x, lcu_y, &st, pc->intra_mode, predBuf[b]);
+            static __thread int16_t residual[64 * 64], quant[64 * 64];
             for (int j = 0; j < N; j++)
                 for (int i = 0; i < N; i++)
                     residual[j * N + i] = (int16_t)(src[(size_t)(y0 + j) * srcStride + x0 + i] - predBuf[b][j * N + i]);
@@ -152,17 +287,25 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
             SvtAmdFullLoopIn in;
             SvtAmdFullLoopOut o;
             memset(&in, 0, sizeof(in));
-            in.size = (uint32_t)N, in.qp = P->qp, in.slice_type = P->slice_type, in.pf_mode = 0, in.pm_core = 0, in.cand_type = MD_INTRA;
+            in.size = (uint32_t)N, in.qp = P->qp, in.slice_type = P->slice_type, in.pf_mode = (uint16_t)pf, in.pm_core = 0, in.cand_type = c->type;
             in.intra_luma_mode = c->intra_mode, in.full_lambda = P->full_lambda;
             in.cbf_bits[0] = P->rates.lumaCbfBits[0], in.cbf_bits[1] = P->rates.lumaCbfBits[1];
             in.cbf_bits[2] = P->rates.lumaCbfBits[5], in.cbf_bits[3] = P->rates.lumaCbfBits[6];
             svt_oracle_product_full_loop_luma(cost, &in, residual, quant, reconCoeff[b], &o);
-            ycbf[b] = o.ycbf;
-            B.full_cost[b] = md_intra_full_luma_cost_islice(P, st.lg, o.ycbf, fastLumaRate[B.cand[b]], o.dist[0], o.coeff_bits);
+            ycbf[b] = o.ycbf, fullDist[b] = (uint32_t)o.dist[0];
+            const uint64_t bits = L->chroma_encode_mode == 2 /* CHROMA_MODE_BEST */ ? md_pf_coeff_bits(pf, P->qp, o.coeff_bits) : o.coeff_bits;
+            if (c->type == MD_INTER)
+                B.full_cost[b] = md_inter_full_luma_cost(P, &S->cu[leaf], c, N, o.ycbf, fastLumaRate[B.cand[b]], o.dist, bits, &mergeCost[b], &skipCost[b]);
+            else if (islice)
+                B.full_cost[b] = md_intra_full_luma_cost_islice(P, st.lg, o.ycbf, fastLumaRate[B.cand[b]], o.dist[0], bits);
+            else
+                B.full_cost[b] = md_intra_full_luma_cost_pslice(P, N, o.ycbf, fastLumaRate[B.cand[b]], o.dist[0], bits);
+            if (P->full_loop_escape && !islice && c->type == MD_INTER && B.full_cost[b] < bestFullCost)
+                prevRootCbf = o.ycbf, bestFullCost = B.full_cost[b];
             if (g_md_debug)
-                fprintf(stderr, "  leaf %d cand mode %d buf %d: fast %llu ycbf %u dist %llu bits %llu full %llu\n", leaf, c->intra_mode, b,
-                        (unsigned long long)B.fast_cost[b], o.ycbf, (unsigned long long)o.dist[0], (unsigned long long)o.coeff_bits,
-                        (unsigned long long)B.full_cost[b]);
+                fprintf(stderr, "  leaf %d full cand %d (type %d mode %d) buf %d: fast %llu ycbf %u dist %llu/%llu bits %llu full %llu\n", leaf, B.cand[b], c->type,
+                        c->intra_mode, b, (unsigned long long)B.fast_cost[b], o.ycbf, (unsigned long long)o.dist[0], (unsigned long long)o.dist[1],
+                        (unsigned long long)o.coeff_bits, (unsigned long long)B.full_cost[b]);
         }
         /* ProductFullModeDecision (EbModeDecision.c:1995) */
         int lowest = best[0];
@@ -172,23 +315,34 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
                 lowest = best[f], lowestCost = B.full_cost[best[f]];
         if (ncand > 0) {
             const MdCand *c = &cand[B.cand[lowest]];
-            S->local[leaf].cost = B.full_cost[lowest];
-            S->cu[leaf].pred_mode = c->type, S->cu[leaf].skip_flag = 0, S->cu[leaf].intra_luma_mode = c->intra_mode;
-            S->cu[leaf].ycbf = (uint8_t)(ycbf[lowest] & 1);
+            MdCu *u = &S->cu[leaf];
+            S->local[leaf].cost = B.full_cost[lowest], S->local[leaf].full_distortion = fullDist[lowest];
+            u->pred_mode = c->type, u->skip_flag = 0, u->intra_luma_mode = (uint8_t)(c->type == MD_INTRA ? c->intra_mode : 0x1F);
+            u->ycbf = (uint8_t)(N == 64 ? (ycbf[lowest] & 0x1E) : (ycbf[lowest] & 1));
+            u->inter_dir = (uint8_t)(c->type == MD_INTER ? c->dir : 3), u->merge_flag = (uint8_t)(c->type == MD_INTER ? c->merge_flag : 0);
+            u->merge_index = c->merge_index;
+            u->mv[0].x = u->mv[0].y = u->mv[1].x = u->mv[1].y = 0;
+            if (c->type == MD_INTER) {
+                if (c->dir != MD_L1)
+                    u->mv[0] = c->mv[0];
+                if (c->dir != MD_L0)
+                    u->mv[1] = c->mv[1];
+            }
+            u->merge_cost = mergeCost[lowest], u->skip_cost = skipCost[lowest];
         }
         if (g_md_debug)
-            fprintf(stderr, "leaf %d (%d,%d) size %d: %d candidates, %d buffers, full %d -> mode %d cost %llu\n", leaf, st.x, st.y, st.size, ncand, maxBuffers,
-                    nfull, S->cu[leaf].intra_luma_mode, (unsigned long long)S->local[leaf].cost);
+            fprintf(stderr, "leaf %d (%d,%d) size %d: %d candidates, %d buffers, full %d -> type %d mode %d cost %llu\n", leaf, st.x, st.y, st.size, ncand,
+                    maxBuffers, nfull, S->cu[leaf].pred_mode, S->cu[leaf].intra_luma_mode, (unsigned long long)S->local[leaf].cost);
         S->local[leaf].mdc_index = (uint8_t)cuIdx;
         int last;
         const int exitParent = md_check_high_cost_partition(P, L, S, leaf);
         if (exitParent >= 0) {
             leaf = exitParent, st = md_stats(leaf), cuIdx = S->local[leaf].mdc_index;
             S->cu[leaf].split = 0;
-            last = md_inter_depth_decision(P, S, leaf, lcu_x, lcu_y, 1);
+            last = md_inter_depth_decision(P, S, leaf, lcu_x, lcu_y, 1, 0);
         } else {
-            /* PerformInverseTransformRecon (:1334): the best candidate's reconstruction, kept per depth */
-            if (ncand > 0) {
+            /* PerformInverseTransformRecon (:1334): the best candidate's reconstruction, kept per depth (closed-loop intra only) */
+            if (ncand > 0 && !P->intra_md_open_loop && N <= 32) {
                 uint8_t *dst = bestRec[st.depth] + st.y * 64 + st.x;
                 if (S->cu[leaf].ycbf) {
                     svt_oracle_recon_tu(1, (uint32_t)N, 0, 0, reconCoeff[lowest], predBuf[lowest], (uint32_t)N, dst, 64);
@@ -197,20 +351,26 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
                         memcpy(dst + j * 64, predBuf[lowest] + j * N, (size_t)N);
                 }
             }
-            last = md_inter_depth_decision(P, S, leaf, lcu_x, lcu_y, 0);
+            last = md_inter_depth_decision(P, S, leaf, lcu_x, lcu_y, 0, md_stop_split(P, L, st.depth, S->local[leaf].full_distortion));
         }
         if (S->cu[last].split == 0) { /* ModeDecisionUpdateNeighborArrays (:371) */
             const MdStats ls = md_stats(last);
             const int lx = lcu_x + ls.x, ly = lcu_y + ls.y;
-            const uint32_t w = (uint32_t)S->cu[last].pred_mode | ((uint32_t)S->cu[last].intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) |
-                               ((uint32_t)S->cu[last].skip_flag << 24);
+            const MdCu *u = &S->cu[last];
+            const uint32_t w = (uint32_t)u->pred_mode | ((uint32_t)u->intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) | ((uint32_t)u->skip_flag << 24);
+            MdMvUnit mu;
+            memset(&mu, 0, sizeof(mu));
+            mu.mv[0] = u->mv[0], mu.mv[1] = u->mv[1], mu.dir = u->inter_dir;
             for (int j = 0; j < ls.size && ly + j < (int)M->h; j++) {
-                if (lx < (int)M->w)
+                if (lx < (int)M->w && !P->intra_md_open_loop)
                     memcpy(M->rec + (size_t)(ly + j) * M->pitch + lx, bestRec[ls.depth] + (ls.y + j) * 64 + ls.x,
                            (size_t)(lx + ls.size <= (int)M->w ? ls.size : (int)M->w - lx));
                 if ((j & 3) == 0)
                     for (int i = 0; i < ls.size && lx + i < (int)M->w; i += 4)
                         M->info[(size_t)((ly + j) >> 2) * M->infoPitch + ((lx + i) >> 2)] = w;
+                if ((j & 7) == 0)
+                    for (int i = 0; i < ls.size && lx + i < (int)M->w; i += 8)
+                        M->mv[(size_t)((ly + j) >> 3) * M->mvPitch + ((lx + i) >> 3)] = mu;
             }
         }
         if (S->cu[leaf].split)
@@ -223,39 +383,60 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
     if (out) {
         memset(out, 0, sizeof(*out));
         for (int i = 0; i < SVT_AMD_MD_LEAVES; i++) {
-            out->split[i] = S->cu[i].split, out->tested[i] = S->local[i].tested, out->pred_mode[i] = S->cu[i].pred_mode;
-            out->intra_luma_mode[i] = S->cu[i].intra_luma_mode, out->ycbf[i] = S->cu[i].ycbf, out->cost[i] = S->local[i].cost;
+            const MdCu *u = &S->cu[i];
+            out->split[i] = u->split, out->tested[i] = S->local[i].tested, out->pred_mode[i] = u->pred_mode;
+            out->intra_luma_mode[i] = u->intra_luma_mode, out->ycbf[i] = u->ycbf, out->cost[i] = S->local[i].cost;
+            out->inter_dir[i] = u->inter_dir, out->merge_flag[i] = u->merge_flag, out->merge_index[i] = u->merge_index;
+            for (int l = 0; l < 2; l++)
+                out->mv[i][l][0] = u->mv[l].x, out->mv[i][l][1] = u->mv[l].y;
+            out->merge_cost[i] = u->merge_cost, out->skip_cost[i] = u->skip_cost;
         }
     }
 }
 
 /* The mode decision of a whole picture, LCUs in raster order.  src_y: source luma at sample (0,0); lcus / ois / out: one record per LCU.
- * md_rec (optional, width x height, pitch = width): the mode decision's luma reconstruction at the end.  Returns 0, or -1 when the
- * picture is outside the covered set. */
-int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost, const uint8_t *src_y, uint32_t stride,
-                          const SvtAmdOisLcuResult *ois, SvtAmdMdLcuOut *out, uint8_t *md_rec)
+ * md_rec (optional, width x height, pitch = width): the mode decision's luma reconstruction at the end.  P / B pictures: X, me (one record
+ * per LCU), tmvp (the co-located picture's motion field, one record per LCU, or NULL), ref0 / ref1 (HOST planes in the layout of
+ * SvtAmdRefPicture).  Returns 0, or -1 when the picture is outside the covered set. */
+int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost,
+                                const uint8_t *src_y, uint32_t stride, const SvtAmdOisLcuResult *ois, const SvtAmdMeLcuResult *me,
+                                const SvtAmdTmvpLcu *tmvp, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, SvtAmdMdLcuOut *out,
+                                uint8_t *md_rec)
 {
-    if (!md_picture_supported(P))
+    const int wl = (P->width + 63) / 64, hl = (P->height + 63) / 64;
+    if (X ? !md_picture_supported_inter(P, X) : !md_picture_supported(P))
         return -1;
+    if (X)
+        for (int i = 0; i < wl * hl; i++)
+            if (!md_lcu_supported(P, &lcus[i]))
+                return -1;
     g_md_debug = getenv("SVT_ORACLE_MD_DEBUG") != NULL;
     MdPic M;
-    M.w = P->width, M.h = P->height, M.pitch = P->width, M.infoPitch = (uint32_t)(P->width + 3) / 4;
+    memset(&M, 0, sizeof(M));
+    M.w = P->width, M.h = P->height, M.pitch = P->width, M.infoPitch = (uint32_t)(P->width + 3) / 4, M.mvPitch = (uint32_t)(P->width + 7) / 8;
     M.rec = (uint8_t *)calloc((size_t)M.w * M.h, 1);
     M.info = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)M.infoPitch * ((M.h + 3) / 4));
+    M.mv = (MdMvUnit *)calloc((size_t)M.mvPitch * ((M.h + 7) / 8), sizeof(MdMvUnit));
+    M.X = X, M.me = me, M.tmvp = tmvp, M.ref[0] = ref0, M.ref[1] = ref1, M.src = src_y, M.srcStride = stride;
     MdLcuState *S = (MdLcuState *)calloc(1, sizeof(MdLcuState));
-    if (!M.rec || !M.info || !S)
+    if (!M.rec || !M.info || !M.mv || !S)
         return -2;
     memset(M.info, 0xFF, sizeof(uint32_t) * (size_t)M.infoPitch * ((M.h + 3) / 4));
-    const int wl = (P->width + 63) / 64, hl = (P->height + 63) / 64;
     for (int ly = 0; ly < hl; ly++)
         for (int lx = 0; lx < wl; lx++) {
             const int i = ly * wl + lx;
             if (g_md_debug)
                 fprintf(stderr, "LCU %d (%d,%d)\n", i, lx * 64, ly * 64);
-            md_lcu(P, &lcus[i], cost, src_y, stride, &ois[i], lx * 64, ly * 64, &M, S, out ? &out[i] : NULL);
+            md_lcu(P, &lcus[i], cost, src_y, stride, &ois[i], lx * 64, ly * 64, i, &M, S, out ? &out[i] : NULL);
         }
     if (md_rec)
         memcpy(md_rec, M.rec, (size_t)M.w * M.h);
-    free(M.rec), free(M.info), free(S);
+    free(M.rec), free(M.info), free(M.mv), free(S);
     return 0;
+}
+
+int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost, const uint8_t *src_y, uint32_t stride,
+                          const SvtAmdOisLcuResult *ois, SvtAmdMdLcuOut *out, uint8_t *md_rec)
+{
+    return svt_oracle_md_picture_inter(P, NULL, lcus, cost, src_y, stride, ois, NULL, NULL, NULL, NULL, out, md_rec);
 }

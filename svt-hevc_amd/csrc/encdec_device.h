@@ -130,26 +130,28 @@ static __constant__ int8_t c_ep_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10,
  * positions - with the identity taps {64} its two-pass arithmetic reduces exactly to the one-pass and copy forms of the reference
  * ((64 h' + 64 B + 2^(11-s)) >> (12-s) == (h + 32) >> 6 with h' = (h - B 2^s) >> s; raw: 64 h' >> 6 == h').  Samples the
  * reference's own functions never touch (zero taps) are loaded from clamped addresses. */
-template <typename T>
-__device__ __forceinline__ void ep_inter_predict_plane(const EpPicture &P, EpLocal<T> &L, const EpFlags &F, const LcuCu &cu, int p, int lane, EpMcScratch<T> &M)
+/* the core: the 2Nx2N unit at luma position (abs_x, abs_y) of the picture, size N, direction / vectors as given; store(x, y) = where sample
+ * (x, y) of the unit's plane-p block goes */
+template <typename T, typename Store>
+__device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int abs_x, int abs_y, int N, int inter_dir, const int16_t (*mv)[2], int p, int lane,
+                                                      EpMcScratch<T> &M, Store store)
 {
     constexpr int WP = EpMcScratch<T>::WP;
     constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
     const bool chroma = p != 0;
     const int B = (sizeof(T) == 2 || !chroma) ? 8192 : 0;
-    const int N = cu.size, n = chroma ? N >> 1 : N, tn = n > 32 ? 32 : n, lgt = 31 - __clz(tn);
+    const int n = chroma ? N >> 1 : N, tn = n > 32 ? 32 : n, lgt = 31 - __clz(tn);
     const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3, rows = tn + ntaps - 1;
-    const int lx = chroma ? cu.x >> 1 : cu.x, ly = chroma ? cu.y >> 1 : cu.y;
-    const bool bi = cu.inter_dir == 2;
+    const bool bi = inter_dir == 2;
     for (int ty0 = 0; ty0 < n; ty0 += 32)
         for (int tx0 = 0; tx0 < n; tx0 += 32) {
             bool second = false;
             for (int l = 0; l < 2; l++) {
-                if (!(bi || cu.inter_dir == l))
+                if (!(bi || inter_dir == l))
                     continue;
                 const EpRefPlanes &R = P.ref[l];
-                const int qx = min(max(((F.lcu_x + cu.x + R.originX) << 2) + cu.mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
-                const int qy = min(max(((F.lcu_y + cu.y + R.originY) << 2) + cu.mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
+                const int qx = min(max(((abs_x + R.originX) << 2) + mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
+                const int qy = min(max(((abs_y + R.originY) << 2) + mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
                 const int ix = (chroma ? qx >> 3 : qx >> 2) + tx0, iy = (chroma ? qy >> 3 : qy >> 2) + ty0;
                 const int fx = __builtin_amdgcn_readfirstlane(chroma ? qx & 7 : qx & 3), fy = __builtin_amdgcn_readfirstlane(chroma ? qy & 7 : qy & 3);
                 const int stride = (int)R.stride[chroma], last = R.size[chroma] - 1;
@@ -213,7 +215,7 @@ __device__ __forceinline__ void ep_inter_predict_plane(const EpPicture &P, EpLoc
                                     if (k < ntaps)
                                         sum += tv[k] * in[o + k];
                                 const int y = y0 + o, i = (y << lgt) + x;
-                                T *dst = L.at(p, lx + tx0 + x, ly + ty0 + y);
+                                T *dst = store(tx0 + x, ty0 + y);
                                 if (!bi) {
                                     *dst = (T)min(maxv, max(0, (sum + (B << 6) + (1 << (11 - s1))) >> (12 - s1)));
                                 } else if (!second) {
@@ -229,6 +231,13 @@ __device__ __forceinline__ void ep_inter_predict_plane(const EpPicture &P, EpLoc
                 second = true;
             }
         }
+}
+
+template <typename T>
+__device__ __forceinline__ void ep_inter_predict_plane(const EpPicture &P, EpLocal<T> &L, const EpFlags &F, const LcuCu &cu, int p, int lane, EpMcScratch<T> &M)
+{
+    const int lx = p ? cu.x >> 1 : cu.x, ly = p ? cu.y >> 1 : cu.y;
+    ep_inter_predict_core<T>(P, F.lcu_x + cu.x, F.lcu_y + cu.y, cu.size, cu.inter_dir, cu.mv, p, lane, M, [&](int x, int y) { return L.at(p, lx + x, ly + y); });
 }
 
 template <typename T>

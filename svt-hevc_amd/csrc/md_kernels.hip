@@ -42,6 +42,13 @@ struct MdPictureDev {
     const SvtAmdMdLcu *lcus;
     const SvtAmdMdPicture *P;
     SvtAmdMdLcuOut *out;
+    /* P / B pictures */
+    uint4 *md_mv;                 /* per 8x8 luma block: the unit's MvUnit_t {mv[0], mv[1], direction} (mdMvNeighborArray) */
+    uint32_t mv_pitch;
+    const SvtAmdMdInter *X;
+    const SvtAmdMeLcuResult *me;
+    const SvtAmdTmvpLcu *tmvp;
+    int encode;                   /* 0: mode decision only (no work record, no encode pass) */
 };
 
 struct MdLocal8 {
@@ -62,9 +69,29 @@ struct MdLocal8 {
 };
 
 struct MdFl {
-    uint32_t nz, d0, bits;
+    uint32_t nz, d0, d1, bits; /* non-zero levels, sum (coeff - recon)^2, sum coeff^2 over the quantised area, the estimator's bits */
 };
 
+/* what only the closed-loop (I picture) / only the inter kernel keeps in LDS */
+struct MdClosedLoop {
+    uint8_t pred[MD_MAX_BUF][32 * 32];
+    int16_t recon_coeff[MD_MAX_BUF][32 * 32];
+    uint8_t best_rec[4][64 * 64];
+};
+struct MdInterShared {
+    MdMvUnit mvu[9 * 18];          /* (cy + 1) * 18 + cx + 1: 8x8 cells, cy in [-1, 8), cx in [-1, 16] */
+    MdMvUnit nb[5];
+    MdInterLists T;
+    uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
+    EpMcScratch<uint8_t> mc[4];
+    uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (merge / skip decision of the encode pass) */
+    unsigned long long ep_merge_cost[SVT_AMD_LCU_MAX_CUS], ep_skip_cost[SVT_AMD_LCU_MAX_CUS];
+    __device__ __forceinline__ MdMvUnit *mv_at(int x, int y) { return &mvu[((y >> 3) + 1) * 18 + (x >> 3) + 1]; }
+};
+template <bool INTER> struct MdVariant { typedef MdClosedLoop type; };
+template <> struct MdVariant<true> { typedef MdInterShared type; };
+
+template <bool INTER>
 struct MdShared {
     MdLocal8 L;
     MdLcuState S;
@@ -76,18 +103,19 @@ struct MdShared {
     MdBuffers B;
     uint8_t types[MD_MAX_BUF], best[MD_MAX_BUF];
     uint32_t ycbf[MD_MAX_BUF];
-    MdFl fl[MD_MAX_BUF];
-    int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done;
+    MdFl fl[MD_MAX_BUF][4];
+    unsigned long long merge_cost[MD_MAX_BUF], skip_cost[MD_MAX_BUF];
+    uint32_t full_dist[MD_MAX_BUF];
+    int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done, best_first, any_intra;
     int16_t ref[132], reff[132], border[132];
-    uint8_t pred[MD_MAX_BUF][32 * 32];
-    int16_t recon_coeff[MD_MAX_BUF][32 * 32];
-    uint8_t best_rec[4][64 * 64];
+    typename MdVariant<INTER>::type V;
     int16_t tiles[4][2 * TxRegTile<32>::UNIT];
     int16_t qbuf[4][32 * 32];
 };
 
+template <bool INTER>
 union MdEpShared {
-    MdShared md;
+    MdShared<INTER> md;
     struct {
         EpShared<uint8_t> S;
         EpLocal<uint8_t> L;
@@ -97,7 +125,8 @@ union MdEpShared {
 /* the unit's intra reference, unfiltered (ref) and filtered (reff), by ONE wave: GenerateLumaIntraReferenceSamplesEncodePass with
  * constrainedIntraFlag 0 / strongIntraSmoothingFlag 1 as GenerateIntraLumaReferenceSamplesMd calls it (Codec/EbProductCodingLoop.c:280-295;
  * Codec/EbIntraPrediction.c:750).  Same scheme as ep_intra_predict_plane (encdec_device.h). */
-__device__ __forceinline__ void md_build_refs(MdShared &M, const MdStats &st, int lane)
+template <bool INTER>
+__device__ __forceinline__ void md_build_refs(MdShared<INTER> &M, const MdStats &st, int lane)
 {
     MdLocal8 &L = M.L;
     const int N = st.size, nb = N >> 2, lgN = st.lg, n = N;
@@ -173,13 +202,14 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
     return (dc + n) >> (lgn + 1);
 }
 
-/* ProductFullLoop of one intra luma candidate on lanes r = 0..N-1 of the calling wave (EbFullLoop.c:185-446 for a unit with one transform
- * unit, PF off): residual -> EstimateTransform -> ProductUnifiedQuantizeInvQuantizeMd -> PictureFullDistortionLuma ->
- * TuEstimateCoeffBitsLuma.  pred: the candidate's prediction (pitch N); recon_coeff: the de-quantised coefficients (N x N, pitch N) for
- * PerformInverseTransformRecon.  Returns (every lane) nz, the raw 32-bit distortion sum and the estimator's bit count. */
+/* One transform unit of ProductFullLoop (EbFullLoop.c:185-446) / FullLoop_R + CuFullDistortionFastTuMode_R (:579-1066) on lanes r = 0..N-1 of
+ * the calling wave: residual -> EstimateTransform -> quantiser -> coefficient-domain distortion -> coefficient bits.  src / pred: the unit's
+ * source and prediction (pitches in samples); recon_coeff: the de-quantised coefficients (N x N, pitch N) for PerformInverseTransformRecon, or
+ * null; pf: partial-frequency mode (1 = N2: only the low (N/2)^2 coefficients are quantised, measured and priced); type / component: of the
+ * candidate and the plane (rate tables).  Returns (every lane) the unit's sums. */
 template <int N>
-__device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, const uint8_t *pred, int16_t *recon_coeff, int16_t *tile, int16_t *qbuf, int qp,
-                                                  int slice_type, const SvtAmdCabacCost &cost, int intra_mode)
+__device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, int srcPitch, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile,
+                                                  int16_t *qbuf, int qp, int slice_type, const SvtAmdCabacCost &cost, int type, int intra_mode, int component, int pf)
 {
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
     constexpr int fs1 = N == 32 ? 6 : N == 16 ? 4 : N == 8 ? 2 : 1, fs2 = N == 4 ? 8 : 9, wrap = N == 32 ? 2 : N == 16 ? 1 : 0;
@@ -189,7 +219,7 @@ __device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, 
     if (active) {
 #pragma unroll
         for (int j = 0; j < N; j++)
-            x[j] = (int)src[r * 64 + j] - (int)pred[r * N + j];
+            x[j] = (int)src[r * srcPitch + j] - (int)pred[r * predPitch + j];
     } else {
 #pragma unroll
         for (int j = 0; j < N; j++)
@@ -203,7 +233,9 @@ __device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, 
     const uint32_t offs = ((slice_type == 2 || slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
     const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
     const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
-    unsigned nz = 0, d0 = 0;
+    const int area = N >> pf;
+    const bool in_area = active && r < area;
+    unsigned nz = 0, d0 = 0, d1 = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
         const int v = x[j], sign = v < 0 ? -1 : 1;
@@ -213,22 +245,24 @@ __device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, 
         tq >>= shiftedQBits;
         const int q = clip16i(sign * tq);
         const int c = clip16i(((q * shiftedFFunc) + iq_offset) >> shiftNum);
-        if (active) {
-            qbuf[j * N + r] = (int16_t)q, recon_coeff[j * N + r] = (int16_t)c;
+        if (in_area && j < area) {
+            qbuf[j * N + r] = (int16_t)q;
+            if (recon_coeff)
+                recon_coeff[j * N + r] = (int16_t)c;
             const int df = (int16_t)(v - c);
-            nz += q != 0, d0 += (uint32_t)(df * df);
+            nz += q != 0, d0 += (uint32_t)(df * df), d1 += (uint32_t)(v * v);
         }
     }
 #pragma unroll
     for (int o = 1; o < N; o <<= 1)
-        nz += __shfl_xor(nz, o), d0 += __shfl_xor(d0, o);
-    nz = (unsigned)__shfl((int)nz, 0), d0 = (unsigned)__shfl((int)d0, 0);
+        nz += __shfl_xor(nz, o), d0 += __shfl_xor(d0, o), d1 += __shfl_xor(d1, o);
+    nz = (unsigned)__shfl((int)nz, 0), d0 = (unsigned)__shfl((int)d0, 0), d1 = (unsigned)__shfl((int)d1, 0);
     EP_WAVE_SYNC(); /* qbuf is written */
-    constexpr int S4 = (N / 4) * (N / 4);
-    const SvtAmdTuInfo ti = {nz, 2 /* INTRA_MODE */, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, 0};
-    const uint32_t b32 = coeff_bits_lanes(cost, qbuf, N, LG, ti, lane < S4, lane, lane & (S4 - 1));
+    const int lga = LG - pf, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
+    const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
+    const uint32_t b32 = coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1));
     MdFl o;
-    o.nz = nz, o.d0 = d0, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
+    o.nz = nz, o.d0 = nz ? d0 : d1, o.d1 = d1, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
     return o;
 }
 
@@ -261,13 +295,91 @@ __device__ __forceinline__ void md_recon_unit(int lane, const int16_t *recon_coe
     }
 }
 
+/* IntraPredictionOl's reference of the unit (Codec/EbIntraPrediction.c:4952 UpdateNeighborSamplesArrayOL): SOURCE samples around the unit,
+ * mid-grey beyond the picture; no substitution, no smoothing.  By one wave; M.ref in pu_predict's layout. */
+template <bool INTER>
+__device__ __forceinline__ void md_build_refs_ol(const MdPictureDev &D, MdShared<INTER> &M, const MdStats &st, int x0, int y0, int W, int H, int lane)
+{
+    const int N = st.size;
+    const uint8_t *src = D.src[0] + (size_t)y0 * D.src_pitch[0] + x0;
+    for (int k = lane; k <= 4 * N; k += 64) {
+        int v = 128;
+        if (k < 2 * N) {
+            if (x0 != 0 && y0 + k < H)
+                v = src[(ptrdiff_t)k * D.src_pitch[0] - 1];
+        } else if (k == 2 * N) {
+            if (x0 != 0 && y0 != 0)
+                v = src[-(ptrdiff_t)D.src_pitch[0] - 1];
+        } else {
+            const int j = k - 2 * N - 1;
+            if (y0 != 0 && x0 + j < W)
+                v = src[j - (ptrdiff_t)D.src_pitch[0]];
+        }
+        M.ref[k] = (int16_t)v;
+    }
+    EP_WAVE_SYNC();
+}
+
+/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of the luma block of a candidate, by one wave, into dst (pitch = unit size) */
+__device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst)
+{
+    int16_t mv[2][2];
+    mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
+    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, 0, lane, mc, [&](int x, int y) { return dst + y * N + x; });
+    EP_WAVE_SYNC();
+}
+
+/* the luma full loop of the unit's candidate on one wave: every transform unit (four 32x32 of a 64x64 unit) -> out[tu] */
+__device__ __forceinline__ void md_full_loop_cand(int lane, int N, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile, int16_t *qbuf,
+                                                  const SvtAmdMdPicture &P, const SvtAmdCabacCost &cost, int type, int mode, int pf, MdFl *out)
+{
+    if (N == 64) {
+        for (int tu = 0; tu < 4; tu++) {
+            const int off = ((tu & 1) << 5) + ((tu >> 1) << 5) * 64, poff = ((tu & 1) << 5) + ((tu >> 1) << 5) * predPitch;
+            const MdFl o = md_full_loop_unit<32>(lane, src + off, 64, pred + poff, predPitch, nullptr, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf);
+            if (lane == 0)
+                out[tu] = o;
+            EP_WAVE_SYNC();
+        }
+        return;
+    }
+    MdFl o;
+    switch (N) {
+    case 32: o = md_full_loop_unit<32>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf); break;
+    case 16: o = md_full_loop_unit<16>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf); break;
+    default: o = md_full_loop_unit<8>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf); break;
+    }
+    if (lane == 0)
+        out[0] = o;
+}
+
+/* TuCalcCostLuma (Codec/EbRateDistortionCost.c:289-375) of one transform unit + the accumulation ProductFullLoop does: *ycbf, *bits, dist[2] */
+__device__ __forceinline__ void md_tu_calc_cost(const SvtAmdMdPicture &P, const MdFl &o, int type, int cuSize, int T, int tuIndex, uint32_t *ycbf, unsigned long long *bits,
+                                                unsigned long long dist[2])
+{
+    const int lgT = T == 32 ? 5 : T == 16 ? 4 : 3, dshift = cuSize == 64 ? 4 : 2 * (7 - lgT);
+    const unsigned long long d0 = ((unsigned long long)o.d0 + (1ull << (dshift - 1))) >> dshift, d1 = ((unsigned long long)o.d1 + (1ull << (dshift - 1))) >> dshift;
+    const unsigned long long tuBits = (((unsigned long long)o.bits) << 10) >> 15;
+    const int ctx = cuSize == T;
+    const unsigned long long lambda = P.full_lambda;
+    const unsigned long long nzRate = (tuBits << 15) + P.rates.lumaCbfBits[5 + ctx], zRate = P.rates.lumaCbfBits[ctx];
+    const unsigned long long zCost = type == MD_INTRA ? ~0ull : (d1 << 8) + ((lambda * zRate + (1u << 22)) >> 23);
+    const unsigned long long nzCost = (d0 << 8) + ((lambda * nzRate + (1u << 22)) >> 23);
+    const bool coded = o.nz != 0 && nzCost < zCost;
+    *ycbf |= (uint32_t)coded << tuIndex;
+    *bits += nzCost < zCost ? tuBits : 0;
+    dist[0] += nzCost < zCost ? d0 : d1, dist[1] += d1;
+}
+
 /* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
-__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared &M)
+template <bool INTER>
+__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     MdLocal8 &L = M.L;
     const int W = (int)P.width, H = (int)P.height;
     const int lw = min(64, W - lcu_x), lh = min(64, H - lcu_y);
+    const bool islice = P.slice_type == 2, open_loop = P.intra_md_open_loop != 0;
     /* ---- the LCU's surroundings into LDS ---- */
     for (int i = t; i < (int)sizeof(SvtAmdMdLcu); i += 256)
         ((uint8_t *)&M.lcu)[i] = ((const uint8_t *)&D.lcus[lcu])[i];
@@ -280,11 +392,27 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
         L.info[i] = v;
     }
-    for (int i = t; i < 130 + 64; i += 256) { /* ring samples: row -1 (x = -1 .. 128), column -1 */
-        const int x = i < 130 ? i - 1 : -1, y = i < 130 ? -1 : i - 130;
-        const int gx = lcu_x + x, gy = lcu_y + y;
-        if (x < 128 && gx >= 0 && gy >= 0 && gx < W && gy < H)
-            *L.at(x, y) = D.md_rec[(size_t)gy * D.md_pitch + gx];
+    if (!INTER) {
+        for (int i = t; i < 130 + 64; i += 256) { /* ring samples: row -1 (x = -1 .. 128), column -1 */
+            const int x = i < 130 ? i - 1 : -1, y = i < 130 ? -1 : i - 130;
+            const int gx = lcu_x + x, gy = lcu_y + y;
+            if (x < 128 && gx >= 0 && gy >= 0 && gx < W && gy < H)
+                *L.at(x, y) = D.md_rec[(size_t)gy * D.md_pitch + gx];
+        }
+    }
+    if constexpr (INTER) {
+        for (int i = t; i < 9 * 18; i += 256) { /* the ring of motion-vector units: row -1 and column -1 */
+            const int cy = i / 18 - 1, cx = i - (cy + 1) * 18 - 1;
+            MdMvUnit u;
+            u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
+            const int px = lcu_x + 8 * cx, py = lcu_y + 8 * cy;
+            if ((cy < 0 || cx < 0) && px >= 0 && py >= 0 && px < W && py < H) {
+                const uint4 w = D.md_mv[(size_t)(py >> 3) * D.mv_pitch + (px >> 3)];
+                u.mv[0].x = (int16_t)(w.x & 0xFFFF), u.mv[0].y = (int16_t)(w.x >> 16), u.mv[1].x = (int16_t)(w.y & 0xFFFF), u.mv[1].y = (int16_t)(w.y >> 16);
+                u.dir = (uint8_t)w.z;
+            }
+            M.V.mvu[i] = u;
+        }
     }
     for (int i = t; i < 64 * 64 / 4; i += 256) {
         const int y = i >> 4, x = (i & 15) * 4;
@@ -300,6 +428,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
     }
     __syncthreads();
     const SvtAmdOisLcuResult *ois = &D.ois[lcu];
+    const int pf = md_pf_mode(&P);
     for (;;) {
         /* ---- lane 0: the unit, its contexts and its candidates ---- */
         if (t == 0) {
@@ -307,7 +436,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             const MdStats st = md_stats(leaf);
             M.leaf = leaf;
             M.S.local[leaf].tested = 1;
-            M.S.cu[leaf].split = (uint8_t)((P.slice_type == 2 && st.depth == 0) ? 1 : M.lcu.leaf_split[cuIdx]);
+            M.S.cu[leaf].split = (uint8_t)((islice && st.depth == 0) ? 1 : M.lcu.leaf_split[cuIdx]);
             uint32_t l = L.info_at(st.x - 1, st.y), tp = L.info_at(st.x, st.y - 1);
             if ((M.lcu.tile_left && st.x == 0) || (l & 0xFF) == 0xFE)
                 l = 0xFFFFFFFFu;
@@ -317,38 +446,103 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             Nb.left_mode = (uint8_t)l, Nb.left_intra = (uint8_t)(l >> 8), Nb.left_depth = (uint8_t)(l >> 16), Nb.left_skip = (uint8_t)(l >> 24);
             Nb.top_mode = (uint8_t)tp, Nb.top_intra = (uint8_t)(tp >> 8), Nb.top_depth = (uint8_t)(tp >> 16), Nb.top_skip = (uint8_t)(tp >> 24);
             md_context_generation(&M.S, leaf, st.y, &Nb);
+            M.S.cu[leaf].split = (uint8_t)md_skip_small_cu(&P, &M.lcu, &M.S, leaf, st.depth);
             uint32_t mpm[3] = {0, 0, 0};
             if (P.mpm_search && !M.lcu.restrict_intra_global_motion)
                 md_mpm_modes(M.S.cu[leaf].left_intra_mode, M.S.cu[leaf].top_intra_mode, mpm);
             int ncand = 0;
-            if (st.depth != 0 && (P.slice_type == 2 || st.depth == 3 || !M.lcu.restrict_intra_global_motion))
+            if (st.depth != 0 && (islice || st.depth == 3 || !M.lcu.restrict_intra_global_motion))
                 if (!(P.limit_intra && st.x == 0 && st.y == 0))
                     ncand = md_intra_candidates(&P, &M.lcu, ois, leaf, &st, M.cand);
+            if constexpr (INTER) {
+                /* the spatial neighbours with the availability GenerateL0L1AmvpMergeLists derives (EbAdaptiveMotionVectorPrediction.c:2256-2340) */
+                const int N = st.size;
+                const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
+                const int px[5] = {st.x - 1, st.x - 1, st.x + N, st.x + N - 1, st.x - 1}, py[5] = {st.y + N, st.y + N - 1, st.y - 1, st.y - 1, st.y - 1};
+                const bool ok[5] = {md_bottom_left_ok(&st) && !left, !left, md_top_right_ok(&st) && !top && !right, !top, !left && !top};
+                for (int k = 0; k < 5; k++) {
+                    MdMvUnit u;
+                    u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
+                    if (ok[k] && (L.info_at(px[k], py[k]) & 0xFF) == MD_INTER) {
+                        u = *M.V.mv_at(px[k], py[k]);
+                        u.avail = 1;
+                    }
+                    M.V.nb[k] = u;
+                }
+                const int totalMerge = md_nmm(&P, N);
+                md_amvp_merge_lists(&P, D.X, M.V.nb, D.X->tmvp_enable ? &D.tmvp[lcu] : nullptr, lcu_x + st.x, lcu_y + st.y, N, totalMerge, &M.V.T);
+                ncand = md_inter_candidates(&P, &M.lcu, &D.me[lcu].pu[md_raster_index(&st)], &M.V.T, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), totalMerge,
+                                            M.cand, ncand);
+            }
             int bufferTotal = md_nfl(&P, &M.lcu, st.size);
             ncand = md_mpm_injection(&P, &M.lcu, &st, M.cand, ncand, &bufferTotal, mpm);
             bufferTotal = ncand < bufferTotal ? ncand : bufferTotal;
             const int width = st.depth == 0 ? 5 : 8;
             M.ncand = ncand, M.buffer_total = bufferTotal, M.max_buffers = bufferTotal + 1 < width ? bufferTotal + 1 : width;
+            int anyIntra = 0;
+            for (int i = 0; i < ncand; i++)
+                anyIntra |= M.cand[i].type == MD_INTRA;
+            M.any_intra = anyIntra;
+            /* the first fast loop (EbProductCodingLoop.c:1948-1988): the best of the candidates whose distortion the open-loop stages left */
+            int bestFirst = -1;
+            if (!P.single_fast_loop) {
+                unsigned long long bestCost = ~0ull;
+                for (int i = ncand - 1; i >= 0; i--) {
+                    if (!M.cand[i].dist_ready)
+                        continue;
+                    uint64_t r;
+                    const uint64_t c = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], M.cand[i].me_dist, &r)
+                                       : islice                 ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, M.cand[i].me_dist, &r)
+                                                                : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, M.cand[i].me_dist, &r);
+                    if (c <= bestCost)
+                        bestFirst = i, bestCost = c;
+                }
+            }
+            M.best_first = bestFirst;
+            for (int i = 0; i < ncand; i++) {
+                uint8_t e = (uint8_t)(!M.cand[i].dist_ready || i == bestFirst || P.single_fast_loop);
+                if (e && i == bestFirst && M.cand[i].type == MD_INTRA && open_loop)
+                    e = 3; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
+                M.evaluated[i] = e;
+            }
         }
         __syncthreads();
         const int leaf = M.leaf, ncand = M.ncand;
         const MdStats st = md_stats(leaf);
-        const int N = st.size, lgN = st.lg;
+        const int N = st.size, lgN = st.lg, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
         /* ---- wave 0: the unit's intra reference ---- */
-        if (wave == 0 && ncand > 0)
-            md_build_refs(M, st, lane);
+        if (wave == 0 && M.any_intra) {
+            if (open_loop)
+                md_build_refs_ol(D, M, st, x0, y0, W, H, lane);
+            else
+                md_build_refs(M, st, lane);
+        }
         __syncthreads();
-        /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop; an I picture has no candidate of the first) ---- */
+        /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop) ---- */
         for (int c = wave; c < ncand; c += 4) {
             uint32_t sad = 0;
-            if (!M.cand[c].mpm) {
-                const int mode = M.cand[c].intra_mode;
-                const int16_t *use = md_mode_filtered(mode, lgN) ? M.reff : M.ref;
-                const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
-                for (int e = lane; e < N * N; e += 64) {
-                    const int y = e >> lgN, x = e & (N - 1);
-                    const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
-                    sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
+            const MdCand cd = M.cand[c];
+            const int ev = M.evaluated[c];
+            const bool reuse = c == M.best_first && cd.type == MD_INTRA; /* the open-loop distortion stands (:2042) */
+            if (ev && !cd.mpm && reuse) {
+                sad = cd.me_dist;
+            } else if (ev && !cd.mpm) {
+                if (cd.type == MD_INTER) {
+                    if constexpr (INTER) {
+                        uint8_t *pr = M.V.wpred[wave];
+                        md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
+                        for (int e = lane; e < N * N; e += 64)
+                            sad += (uint32_t)abs((int)pr[e] - (int)L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]);
+                    }
+                } else {
+                    const int mode = cd.intra_mode;
+                    const int16_t *use = (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref;
+                    const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
+                    for (int e = lane; e < N * N; e += 64) {
+                        const int y = e >> lgN, x = e & (N - 1);
+                        const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
+                        sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
+                    }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1)
@@ -363,13 +557,21 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             int bufferTotal = M.buffer_total;
             for (int i = 0; i < ncand; i++) {
                 unsigned long long rate = 0;
-                uint64_t cst = md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, M.cand[i].mpm ? 0 : M.sad[i], (uint64_t *)&rate);
-                M.costs[i] = M.cand[i].mpm ? 0 : cst, M.fast_rate[i] = rate, M.evaluated[i] = 1;
+                uint64_t cst = ~0ull;
+                if (M.evaluated[i]) {
+                    const uint64_t dist = M.cand[i].mpm ? 0 : M.sad[i];
+                    cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, (uint64_t *)&rate)
+                          : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
+                                                    : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate);
+                    if (M.cand[i].mpm)
+                        cst = 0;
+                }
+                M.costs[i] = cst, M.fast_rate[i] = rate;
             }
             md_fast_loop_buffers(&M.B, 8, M.max_buffers, ncand, (const uint64_t *)M.costs, M.evaluated);
             bufferTotal = M.B.evaluated_count < bufferTotal ? M.B.evaluated_count : bufferTotal;
             for (int b = 0; b < MD_MAX_BUF; b++)
-                M.types[b] = M.B.cand[b] >= 0 ? M.cand[M.B.cand[b]].type : 0, M.ycbf[b] = 0;
+                M.types[b] = M.B.cand[b] >= 0 ? M.cand[M.B.cand[b]].type : 0, M.ycbf[b] = 0, M.full_dist[b] = 0, M.merge_cost[b] = M.skip_cost[b] = 0;
             const int same = M.B.evaluated_count == bufferTotal;
             M.full_count = md_pre_mode_decision(&M.B, M.types, same ? bufferTotal : M.max_buffers, same, M.best);
             M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
@@ -378,35 +580,62 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
         const int nfull = M.nfull;
         for (int f = wave; f < nfull; f += 4) {
-            const int b = M.best[f], mode = M.cand[M.B.cand[b]].intra_mode;
-            const int16_t *use = md_mode_filtered(mode, lgN) ? M.reff : M.ref;
-            const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
-            uint8_t *pred = M.pred[b];
-            for (int e = lane; e < N * N; e += 64)
-                pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
-            EP_WAVE_SYNC();
-            const uint8_t *src = &L.src[st.y * 64 + st.x];
-            MdFl o;
-            switch (N) {
-            case 32: o = md_full_loop_unit<32>(lane, src, pred, M.recon_coeff[b], M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost, mode); break;
-            case 16: o = md_full_loop_unit<16>(lane, src, pred, M.recon_coeff[b], M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost, mode); break;
-            default: o = md_full_loop_unit<8>(lane, src, pred, M.recon_coeff[b], M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost, mode); break;
+            const int b = M.best[f], ci = M.B.cand[b];
+            const MdCand cd = M.cand[ci];
+            /* the buffer's luma prediction: the candidate the fast loop predicted there, or - predictionIsReadyLuma == 0 - a fresh one */
+            const bool fresh = ci == M.best_first && cd.type == MD_INTRA && open_loop && M.evaluated[ci];
+            const MdCand pc = (fresh || M.B.pred[b] < 0) ? cd : M.cand[M.B.pred[b]];
+            uint8_t *pred;
+            int16_t *rc = nullptr;
+            if constexpr (INTER) {
+                pred = M.V.wpred[wave];
+            } else {
+                pred = M.V.pred[b], rc = M.V.recon_coeff[b];
             }
-            if (lane == 0)
-                M.fl[b] = o;
+            if (pc.type == MD_INTER) {
+                if constexpr (INTER)
+                    md_predict_inter(E, pc, x0, y0, N, lane, M.V.mc[wave], pred);
+            } else {
+                const int mode = pc.intra_mode;
+                const int16_t *use = (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref;
+                const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
+                for (int e = lane; e < N * N; e += 64)
+                    pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
+                EP_WAVE_SYNC();
+            }
+            md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, *E.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
         }
         __syncthreads();
         /* ---- lane 0: TuCalcCostLuma, full cost, ProductFullModeDecision, CheckHighCostPartition ---- */
         if (t == 0) {
+            uint32_t prevRootCbf = 1;
+            unsigned long long bestFullCost = 0xFFFFFFFFull;
             for (int f = 0; f < nfull; f++) {
-                const int b = M.best[f];
-                const MdFl o = M.fl[b];
-                const int dshift = 2 * (7 - lgN);
-                const unsigned long long d0 = ((unsigned long long)o.d0 + (1ull << (dshift - 1))) >> dshift; /* intra: both sums of the kernel = the residual sum */
-                const unsigned long long tuBits = (((unsigned long long)o.bits) << 10) >> 15;
-                const uint32_t ycbf = o.nz != 0; /* an intra candidate's zero-cbf cost is infinite (EbRateDistortionCost.c:348-352) */
-                M.ycbf[b] = ycbf;
-                M.B.full_cost[b] = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[M.B.cand[b]], d0, tuBits);
+                const int b = M.best[f], ci = M.B.cand[b];
+                const MdCand c = M.cand[ci];
+                if (!islice && c.type == MD_INTRA && prevRootCbf == 0)
+                    continue;
+                uint32_t ycbf = 0;
+                unsigned long long bits = 0, dist[2] = {0, 0};
+                if (N == 64) {
+                    for (int tu = 0; tu < 4; tu++)
+                        md_tu_calc_cost(P, M.fl[b][tu], c.type, 64, 32, tu + 1, &ycbf, &bits, dist);
+                } else {
+                    md_tu_calc_cost(P, M.fl[b][0], c.type, N, N, 0, &ycbf, &bits, dist);
+                }
+                M.ycbf[b] = ycbf, M.full_dist[b] = (uint32_t)dist[0];
+                if (M.lcu.chroma_encode_mode == 2 /* CHROMA_MODE_BEST */)
+                    bits = md_pf_coeff_bits(pf, P.qp, bits);
+                uint64_t mc = 0, sc = 0;
+                if (c.type == MD_INTER)
+                    M.B.full_cost[b] = md_inter_full_luma_cost(&P, &M.S.cu[leaf], &c, N, ycbf, M.fast_rate[ci], (const uint64_t *)dist, bits, &mc, &sc);
+                else if (islice)
+                    M.B.full_cost[b] = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
+                else
+                    M.B.full_cost[b] = md_intra_full_luma_cost_pslice(&P, N, ycbf, M.fast_rate[ci], dist[0], bits);
+                M.merge_cost[b] = mc, M.skip_cost[b] = sc;
+                if (P.full_loop_escape && !islice && c.type == MD_INTER && M.B.full_cost[b] < bestFullCost)
+                    prevRootCbf = ycbf, bestFullCost = M.B.full_cost[b];
             }
             int lowest = M.best[0];
             unsigned long long lowestCost = ~0ull;
@@ -415,58 +644,85 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     lowest = M.best[f], lowestCost = M.B.full_cost[M.best[f]];
             if (ncand > 0) {
                 const MdCand c = M.cand[M.B.cand[lowest]];
-                M.S.local[leaf].cost = M.B.full_cost[lowest];
-                M.S.cu[leaf].pred_mode = c.type, M.S.cu[leaf].skip_flag = 0, M.S.cu[leaf].intra_luma_mode = c.intra_mode;
-                M.S.cu[leaf].ycbf = (uint8_t)(M.ycbf[lowest] & 1);
+                MdCu &u = M.S.cu[leaf];
+                M.S.local[leaf].cost = M.B.full_cost[lowest], M.S.local[leaf].full_distortion = M.full_dist[lowest];
+                u.pred_mode = c.type, u.skip_flag = 0, u.intra_luma_mode = (uint8_t)(c.type == MD_INTRA ? c.intra_mode : 0x1F);
+                u.ycbf = (uint8_t)(N == 64 ? (M.ycbf[lowest] & 0x1E) : (M.ycbf[lowest] & 1));
+                u.inter_dir = (uint8_t)(c.type == MD_INTER ? c.dir : 3), u.merge_flag = (uint8_t)(c.type == MD_INTER ? c.merge_flag : 0), u.merge_index = c.merge_index;
+                u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0;
+                if (c.type == MD_INTER) {
+                    if (c.dir != MD_L1)
+                        u.mv[0] = c.mv[0];
+                    if (c.dir != MD_L0)
+                        u.mv[1] = c.mv[1];
+                }
+                u.merge_cost = M.merge_cost[lowest], u.skip_cost = M.skip_cost[lowest];
             }
             M.lowest = lowest;
             M.S.local[leaf].mdc_index = (uint8_t)M.cu_idx;
             const int exitParent = md_check_high_cost_partition(&P, &M.lcu, &M.S, leaf);
-            M.do_recon = exitParent < 0 && ncand > 0, M.exited = exitParent >= 0;
+            M.do_recon = exitParent < 0 && ncand > 0 && !open_loop, M.exited = exitParent >= 0;
             if (exitParent >= 0) {
                 M.leaf = exitParent, M.cu_idx = M.S.local[exitParent].mdc_index;
                 M.S.cu[exitParent].split = 0;
-                M.last = md_inter_depth_decision(&P, &M.S, exitParent, lcu_x, lcu_y, 1);
+                M.last = md_inter_depth_decision(&P, &M.S, exitParent, lcu_x, lcu_y, 1, 0);
+            } else if (open_loop) { /* no reconstruction to wait for: the inter-depth decision follows at once */
+                M.last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, md_stop_split(&P, &M.lcu, st.depth, M.S.local[leaf].full_distortion));
             }
+            if (exitParent >= 0 || open_loop)
+                M.update = M.S.cu[M.last].split == 0;
         }
         __syncthreads();
-        /* ---- wave 0: the winner's reconstruction ---- */
-        if (M.do_recon && wave == 0) {
-            const int b = M.lowest;
-            uint8_t *dst = M.best_rec[st.depth] + st.y * 64 + st.x;
-            if (M.S.cu[leaf].ycbf) {
-                switch (N) {
-                case 32: md_recon_unit<32>(lane, M.recon_coeff[b], M.pred[b], dst, M.tiles[0]); break;
-                case 16: md_recon_unit<16>(lane, M.recon_coeff[b], M.pred[b], dst, M.tiles[0]); break;
-                default: md_recon_unit<8>(lane, M.recon_coeff[b], M.pred[b], dst, M.tiles[0]); break;
+        if constexpr (!INTER) {
+            /* ---- wave 0: the winner's reconstruction ---- */
+            if (M.do_recon && wave == 0) {
+                const int b = M.lowest;
+                uint8_t *dst = M.V.best_rec[st.depth] + st.y * 64 + st.x;
+                if (M.S.cu[leaf].ycbf) {
+                    switch (N) {
+                    case 32: md_recon_unit<32>(lane, M.V.recon_coeff[b], M.V.pred[b], dst, M.tiles[0]); break;
+                    case 16: md_recon_unit<16>(lane, M.V.recon_coeff[b], M.V.pred[b], dst, M.tiles[0]); break;
+                    default: md_recon_unit<8>(lane, M.V.recon_coeff[b], M.V.pred[b], dst, M.tiles[0]); break;
+                    }
+                } else {
+                    for (int e = lane; e < N * N; e += 64)
+                        dst[(e >> lgN) * 64 + (e & (N - 1))] = M.V.pred[b][e];
                 }
-            } else {
-                for (int e = lane; e < N * N; e += 64)
-                    dst[(e >> lgN) * 64 + (e & (N - 1))] = M.pred[b][e];
             }
+            __syncthreads();
+            /* ---- lane 0: inter-depth decision ---- */
+            if (t == 0 && !open_loop) {
+                if (!M.exited)
+                    M.last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, md_stop_split(&P, &M.lcu, st.depth, M.S.local[leaf].full_distortion));
+                M.update = M.S.cu[M.last].split == 0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        /* ---- lane 0: inter-depth decision ---- */
-        if (t == 0) {
-            if (!M.exited)
-                M.last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0);
-            M.update = M.S.cu[M.last].split == 0;
-        }
-        __syncthreads();
         /* ---- all lanes: ModeDecisionUpdateNeighborArrays of the unit the decision ended on ---- */
         if (M.update) {
             const int last = M.last;
             const MdStats ls = md_stats(last);
-            const uint32_t w = (uint32_t)M.S.cu[last].pred_mode | ((uint32_t)M.S.cu[last].intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) |
-                               ((uint32_t)M.S.cu[last].skip_flag << 24);
-            const uint8_t *srcp = M.best_rec[ls.depth];
-            for (int e = t; e < ls.size * ls.size; e += 256) {
-                const int y = e >> ls.lg, x = e & (ls.size - 1);
-                *L.at(ls.x + x, ls.y + y) = srcp[(ls.y + y) * 64 + ls.x + x];
+            const MdCu u = M.S.cu[last];
+            const uint32_t w = (uint32_t)u.pred_mode | ((uint32_t)u.intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) | ((uint32_t)u.skip_flag << 24);
+            if constexpr (!INTER) {
+                if (!open_loop) {
+                    const uint8_t *srcp = M.V.best_rec[ls.depth];
+                    for (int e = t; e < ls.size * ls.size; e += 256) {
+                        const int y = e >> ls.lg, x = e & (ls.size - 1);
+                        *L.at(ls.x + x, ls.y + y) = srcp[(ls.y + y) * 64 + ls.x + x];
+                    }
+                }
             }
             const int cells = ls.size >> 2;
             for (int e = t; e < cells * cells; e += 256)
                 L.info[((ls.y >> 2) + e / cells + 1) * 36 + (ls.x >> 2) + e % cells + 1] = w;
+            if constexpr (INTER) {
+                const int c8 = ls.size >> 3;
+                MdMvUnit mu;
+                mu.mv[0] = u.mv[0], mu.mv[1] = u.mv[1], mu.dir = u.inter_dir, mu.avail = 0, mu.pad[0] = mu.pad[1] = 0;
+                for (int e = t; e < c8 * c8; e += 256)
+                    M.V.mvu[((ls.y >> 3) + e / c8 + 1) * 18 + (ls.x >> 3) + e % c8 + 1] = mu;
+            }
         }
         __syncthreads();
         if (t == 0) {
@@ -487,27 +743,46 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             break;
     }
     /* ---- the LCU's state leaves LDS: neighbour maps of the picture + the decision record ---- */
-    for (int i = t; i < 64 * 64 / 4; i += 256) {
-        const int y = i >> 4, x = (i & 15) * 4;
-        if (x < lw && y < lh)
-            *(uint32_t *)(D.md_rec + (size_t)(lcu_y + y) * D.md_pitch + lcu_x + x) = *(const uint32_t *)L.at(x, y);
+    if (!INTER) {
+        for (int i = t; i < 64 * 64 / 4; i += 256) {
+            const int y = i >> 4, x = (i & 15) * 4;
+            if (x < lw && y < lh)
+                *(uint32_t *)(D.md_rec + (size_t)(lcu_y + y) * D.md_pitch + lcu_x + x) = *(const uint32_t *)L.at(x, y);
+        }
     }
     for (int i = t; i < 16 * 16; i += 256) {
         const int cy = i >> 4, cx = i & 15;
         if (4 * cx < lw && 4 * cy < lh)
             D.md_info[(size_t)((lcu_y >> 2) + cy) * D.info_pitch + (lcu_x >> 2) + cx] = L.info[(cy + 1) * 36 + cx + 1];
     }
+    if constexpr (INTER) {
+        for (int i = t; i < 8 * 8; i += 256) {
+            const int cy = i >> 3, cx = i & 7;
+            if (8 * cx < lw && 8 * cy < lh) {
+                const MdMvUnit u = M.V.mvu[(cy + 1) * 18 + cx + 1];
+                uint4 w;
+                w.x = (uint32_t)(uint16_t)u.mv[0].x | ((uint32_t)(uint16_t)u.mv[0].y << 16), w.y = (uint32_t)(uint16_t)u.mv[1].x | ((uint32_t)(uint16_t)u.mv[1].y << 16);
+                w.z = u.dir, w.w = 0;
+                D.md_mv[(size_t)((lcu_y >> 3) + cy) * D.mv_pitch + (lcu_x >> 3) + cx] = w;
+            }
+        }
+    }
     if (D.out) {
         SvtAmdMdLcuOut &O = D.out[lcu];
         for (int i = t; i < SVT_AMD_MD_LEAVES; i += 256) {
-            O.split[i] = M.S.cu[i].split, O.tested[i] = M.S.local[i].tested, O.pred_mode[i] = M.S.cu[i].pred_mode;
-            O.intra_luma_mode[i] = M.S.cu[i].intra_luma_mode, O.ycbf[i] = M.S.cu[i].ycbf, O.cost[i] = M.S.local[i].cost;
+            const MdCu u = M.S.cu[i];
+            O.split[i] = u.split, O.tested[i] = M.S.local[i].tested, O.pred_mode[i] = u.pred_mode;
+            O.intra_luma_mode[i] = u.intra_luma_mode, O.ycbf[i] = u.ycbf, O.cost[i] = M.S.local[i].cost;
+            O.inter_dir[i] = u.inter_dir, O.merge_flag[i] = u.merge_flag, O.merge_index[i] = u.merge_index;
+            O.mv[i][0][0] = u.mv[0].x, O.mv[i][0][1] = u.mv[0].y, O.mv[i][1][0] = u.mv[1].x, O.mv[i][1][1] = u.mv[1].y;
+            O.merge_cost[i] = u.merge_cost, O.skip_cost[i] = u.skip_cost;
         }
     }
 }
 
 /* the EncDec input contract the decisions amount to (what svt_hook_encdec.c:fill_work builds on the host): the final tree in Z order */
-__device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmdMdPicture &P, const MdShared &M, int lcu_x, int lcu_y, SvtAmdLcuWork &Wk)
+template <bool INTER>
+__device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmdMdPicture &P, const MdShared<INTER> &M, int lcu_x, int lcu_y, SvtAmdLcuWork &Wk)
 {
     const int t = threadIdx.x;
     const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
@@ -528,10 +803,15 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
             const MdStats st = md_stats(it);
             if (lcu_x + st.x < (int)P.width && lcu_y + st.y < (int)P.height && n < SVT_AMD_LCU_MAX_CUS) {
                 SvtAmdLcuCu &u = Wk.cu[n++];
-                u.x = st.x, u.y = st.y, u.size = st.size, u.pred_mode = M.S.cu[it].pred_mode, u.intra_luma_mode = M.S.cu[it].intra_luma_mode;
+                const MdCu &c = M.S.cu[it];
+                u.x = st.x, u.y = st.y, u.size = st.size, u.pred_mode = c.pred_mode, u.intra_luma_mode = c.pred_mode == MD_INTRA ? c.intra_luma_mode : 0;
                 u.bottom_left_ok = (uint8_t)md_bottom_left_ok(&st), u.top_right_ok = (uint8_t)md_top_right_ok(&st);
                 u.qp = P.qp, u.chroma_qp = P.chroma_qp, u.leaf_index = (uint8_t)it, u.inter_dir = 0, u.inter_kind = 0, u.dz_offset = 0;
                 u.mv[0][0] = u.mv[0][1] = u.mv[1][0] = u.mv[1][1] = 0;
+                if (c.pred_mode == MD_INTER) {
+                    u.inter_dir = c.inter_dir, u.inter_kind = c.merge_flag ? SVT_AMD_EP_INTER_MERGE : SVT_AMD_EP_INTER_AMVP;
+                    u.mv[0][0] = c.mv[0].x, u.mv[0][1] = c.mv[0].y, u.mv[1][0] = c.mv[1].x, u.mv[1][1] = c.mv[1].y;
+                }
             }
             it += md_depth_offset(st.depth);
         }
@@ -549,11 +829,12 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
 }
 
 /* ONE launch per picture: persistent workgroups draw LCUs as tickets in wavefront order (k_encode_picture's scheme, encdec_kernels.hip) */
+template <bool INTER>
 __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPicture E, SvtAmdLcuWork *__restrict__ works, SvtAmdLcuResult *__restrict__ results,
                                                            int nlcu, int wl, unsigned *ticket, unsigned *done, const unsigned *__restrict__ order, unsigned epoch)
 {
     extern __shared__ __align__(16) unsigned char md_lds[];
-    MdEpShared &U = *reinterpret_cast<MdEpShared *>(md_lds);
+    MdEpShared<INTER> &U = *reinterpret_cast<MdEpShared<INTER> *>(md_lds);
     __shared__ unsigned s_ticket;
     const SvtAmdMdPicture &P = *D.P;
     for (;;) {
@@ -578,14 +859,16 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        md_lcu(D, E, P, lcu, lx * 64, ly * 64, U.md);
+        md_lcu<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
         __syncthreads();
-        md_make_work(D, P, U.md, lx * 64, ly * 64, works[lcu]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        ep_encode_lcu<uint8_t>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
-        __syncthreads();
+        if (D.encode) {
+            md_make_work<INTER>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ep_encode_lcu<uint8_t>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_store(&done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -595,6 +878,7 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
 
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
 extern "C" int svt_amd_md_picture_supported(const SvtAmdMdPicture *P) { return P ? md_picture_supported(P) : 0; }
+extern "C" int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X) { return P && X ? md_picture_supported_inter(P, X) : 0; }
 
 /* the mode decision's part of a picture object: neighbour maps, the picture's source and the per-LCU arrays, all in HBM */
 struct SvtAmdMdState {
@@ -606,7 +890,11 @@ struct SvtAmdMdState {
     SvtAmdMdLcuOut *d_out;
     SvtAmdLcuWork *d_works;
     SvtAmdLcuResult *d_results;
-    size_t info_bytes;
+    size_t info_bytes, mv_bytes;
+    /* P / B pictures */
+    SvtAmdMdInter *d_X;
+    SvtAmdMeLcuResult *d_me;
+    SvtAmdTmvpLcu *d_tmvp;
 };
 
 void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
@@ -614,7 +902,8 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
     SvtAmdMdState *m = pic->md;
     if (!m)
         return;
-    void *ptrs[] = {m->d.md_rec, m->d.md_info, m->d_src[0], m->d_src[1], m->d_src[2], m->d_ois, m->d_lcus, m->d_P, m->d_out, m->d_works, m->d_results};
+    void *ptrs[] = {m->d.md_rec, m->d.md_info, m->d_src[0], m->d_src[1], m->d_src[2], m->d_ois, m->d_lcus, m->d_P, m->d_out, m->d_works, m->d_results,
+                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp};
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
@@ -642,6 +931,10 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     ok = ok && hipMalloc((void **)&m->d_ois, sizeof(SvtAmdOisLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_lcus, sizeof(SvtAmdMdLcu) * n) == hipSuccess &&
          hipMalloc((void **)&m->d_P, sizeof(SvtAmdMdPicture)) == hipSuccess && hipMalloc((void **)&m->d_out, sizeof(SvtAmdMdLcuOut) * n) == hipSuccess &&
          hipMalloc((void **)&m->d_works, sizeof(SvtAmdLcuWork) * n) == hipSuccess && hipMalloc((void **)&m->d_results, sizeof(SvtAmdLcuResult) * n) == hipSuccess;
+    m->d.mv_pitch = ((uint32_t)(pic->d.width >> 3) + 15) & ~15u;
+    m->mv_bytes = sizeof(uint4) * (size_t)m->d.mv_pitch * ((pic->d.height + 7) >> 3);
+    ok = ok && hipMalloc((void **)&m->d.md_mv, m->mv_bytes) == hipSuccess && hipMalloc((void **)&m->d_X, sizeof(SvtAmdMdInter)) == hipSuccess &&
+         hipMalloc((void **)&m->d_me, sizeof(SvtAmdMeLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_tmvp, sizeof(SvtAmdTmvpLcu) * (n + 1)) == hipSuccess;
     if (!ok) {
         svt_amd_set_error("hipMalloc (mode-decision picture state) failed");
         svt_amd_md_state_free(pic);
@@ -651,14 +944,19 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     return SVT_AMD_OK;
 }
 
-extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const uint8_t *src_y,
-                                         uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
-                                         int ois_slot, const SvtAmdCabacCost *cost, SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results)
+static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus,
+                             const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
+                             int ois_slot, const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp, const SvtAmdCabacCost *cost, SvtAmdMdLcuOut *md_out,
+                             SvtAmdLcuWork *works, SvtAmdLcuResult *results)
 {
-    if (!ctx || !pic || !P || !lcus || !src_y || !src_cb || !src_cr || !cost)
+    if (!ctx || !pic || !P || !lcus || !src_y || !src_cb || !src_cr || (!X && !cost))
         return SVT_AMD_ERR_BAD_PARAM;
-    if (!md_picture_supported(P) || P->width != pic->d.width || P->height != pic->d.height || pic->d.bps != 1) {
-        svt_amd_set_error("svt_amd_md_encode_picture: picture outside what this revision covers (svt_amd_md_picture_supported), or not the picture object's size / 8-bit");
+    if ((X ? !md_picture_supported_inter(P, X) : !md_picture_supported(P)) || P->width != pic->d.width || P->height != pic->d.height || pic->d.bps != 1) {
+        svt_amd_set_error("svt_amd_md_encode_picture: picture outside what this revision covers (svt_amd_md_picture_supported[_inter]), or not the picture object's size / 8-bit");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    if (X && (!pic->has_cost || !pic->has_ref[0] || (P->slice_type == 0 && !pic->has_ref[1]) || (X->tmvp_enable && !tmvp))) {
+        svt_amd_set_error("svt_amd_md_encode_picture_inter: reference pictures / rate tables not set (svt_amd_encdec_picture_set_inter), or no co-located motion field");
         return SVT_AMD_ERR_BAD_PARAM;
     }
     const int n = pic->nlcu, wl = (pic->d.width + 63) / 64, hl = (pic->d.height + 63) / 64;
@@ -674,6 +972,19 @@ extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture
                 return SVT_AMD_ERR_BAD_PARAM;
             }
         tiles += lcus[i].tile_left && lcus[i].tile_top;
+        if (X && !md_lcu_supported(P, &lcus[i])) {
+            svt_amd_set_error("svt_amd_md_encode_picture_inter: LCU %d is not decided by ModeDecisionLcu with luma-only candidates", i);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+    }
+    const SvtAmdMeLcuResult *d_me_slot = nullptr;
+    if (X && !me) {
+        SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
+        if (me_slot < 0 || me_slot >= root->num_slots || !root->slots[me_slot].d_me_out) {
+            svt_amd_set_error("svt_amd_md_encode_picture_inter: no motion-estimation records in slot %d", me_slot);
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        d_me_slot = root->slots[me_slot].d_me_out;
     }
     const SvtAmdOisLcuResult *d_ois_slot = nullptr;
     if (!ois) {
@@ -701,8 +1012,23 @@ extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture
     m->d.src_pitch[0] = pic->d.pitch[0], m->d.src_pitch[1] = pic->d.pitch[1];
     HIP_TRY(hipMemcpyAsync(m->d_lcus, lcus, sizeof(SvtAmdMdLcu) * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->d_P, P, sizeof(*P), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, st));
-    pic->has_cost = true;
+    if (cost) {
+        HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, st));
+        pic->has_cost = true;
+    }
+    m->d.X = nullptr, m->d.me = nullptr, m->d.tmvp = nullptr;
+    if (X) {
+        HIP_TRY(hipMemcpyAsync(m->d_X, X, sizeof(*X), hipMemcpyHostToDevice, st));
+        if (me)
+            HIP_TRY(hipMemcpyAsync(m->d_me, me, sizeof(SvtAmdMeLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
+        if (X->tmvp_enable) {
+            HIP_TRY(hipMemcpyAsync(m->d_tmvp, tmvp, sizeof(SvtAmdTmvpLcu) * (size_t)n, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(m->d_tmvp + n, 0, sizeof(SvtAmdTmvpLcu), st));
+        }
+        m->d.X = m->d_X, m->d.me = me ? m->d_me : d_me_slot, m->d.tmvp = m->d_tmvp;
+        HIP_TRY(hipMemsetAsync(m->d.md_mv, 0, m->mv_bytes, st));
+    }
+    m->d.encode = X ? 0 : 1; /* P / B pictures: this revision returns the decisions; their encode pass follows in its own call */
     if (ois)
         HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
     m->d.ois = ois ? m->d_ois : d_ois_slot, m->d.lcus = m->d_lcus, m->d.P = m->d_P, m->d.out = m->d_out;
@@ -718,14 +1044,19 @@ extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture
         static bool attr[64];
         std::lock_guard<std::mutex> g(mu);
         if (!attr[ctx->device & 63]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false>)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true>)));
             attr[ctx->device & 63] = true;
         }
     }
     int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 1;
     grid = grid > n ? n : grid > 512 ? 512 : grid;
-    hipLaunchKernelGGL(k_md_encode_picture, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared), st, m->d, pic->d, m->d_works, m->d_results, n, wl, pic->d_sync,
-                       pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+    if (X)
+        hipLaunchKernelGGL(k_md_encode_picture<true>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true>), st, m->d, pic->d, m->d_works, m->d_results, n, wl,
+                           pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+    else
+        hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n, wl,
+                           pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
     HIP_TRY(hipGetLastError());
     if (md_out)
         HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -735,4 +1066,23 @@ extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture
         HIP_TRY(hipMemcpyAsync(results, m->d_results, sizeof(SvtAmdLcuResult) * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return SVT_AMD_OK;
+}
+
+extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const uint8_t *src_y,
+                                         uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
+                                         int ois_slot, const SvtAmdCabacCost *cost, SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results)
+{
+    if (!cost)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return md_encode_picture(ctx, pic, P, nullptr, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, nullptr, -1, nullptr, cost, md_out, works, results);
+}
+
+extern "C" int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus,
+                                               const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c,
+                                               const SvtAmdOisLcuResult *ois, int ois_slot, const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp,
+                                               SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results)
+{
+    if (!X)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return md_encode_picture(ctx, pic, P, X, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, me, me_slot, tmvp, nullptr, md_out, works, results);
 }

@@ -86,12 +86,17 @@ typedef struct MdLocal {
     uint8_t tested, mdc_index;
     uint8_t top_depth, left_depth, top_mode, left_mode; /* 2-bit fields in the reference: 0xFF is stored as 3 */
     uint8_t pad[2];
+    uint32_t full_distortion, pad2;                     /* mdLocalCuUnit[].fullDistortion (StopSplitCondition) */
     uint64_t cost;
 } MdLocal;
+typedef struct MdMv { int16_t x, y; } MdMv;
 typedef struct MdCu {
     uint8_t split, pred_mode, intra_luma_mode, ycbf, skip_flag;
     uint8_t left_intra_mode, top_intra_mode; /* PredictionUnit_t.intraLumaLeftMode / TopMode */
     uint8_t skip_ctx;
+    uint8_t inter_dir, merge_flag, merge_index, pad; /* PredictionUnit_t.interPredDirectionIndex (3 = intra), .mergeFlag, .mergeIndex */
+    MdMv mv[2];                                       /* PredictionUnit_t.mv */
+    uint64_t merge_cost, skip_cost;                   /* mdEpPipeLcu[].mergeCost / .skipCost */
 } MdCu;
 typedef struct MdLcuState {
     MdLocal local[SVT_AMD_MD_LEAVES];
@@ -108,6 +113,8 @@ typedef struct MdNeighbors {
 typedef struct MdCand {
     uint8_t type, intra_mode, mpm, dist_ready;
     uint32_t me_dist;
+    uint8_t dir, merge_flag, merge_index, mvp_idx[2], pad[3]; /* predictionDirection[0], mergeFlag, mergeIndex, motionVectorPredIdx */
+    MdMv mv[2], mvp[2];                                       /* motionVector_{x,y}_L0 / L1, motionVectorPred_{x,y} */
 } MdCand;
 
 /* ConstructMdCuArray (Codec/EbProductCodingLoop.c:1290) */
@@ -220,8 +227,59 @@ MD_FN int md_intra_candidates(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, co
     }
     if (st->depth == 0)
         return 0;
-    if (P->slice_type != 2)
-        return 0; /* P / B pictures: not in this revision */
+    if (P->slice_type != 2) { /* P / B pictures (:1311-1526); limitOisToDcModeFlag (encMode >= 10) is not offered to this revision */
+        if (cuSize == 32 || (cuSize >= 16 && P->cu16x16_mode == 0 && P->enc_mode < 11)) {
+            const int total = ois->total_intra_luma_mode[ri];
+            for (int k = 0; k < total; k++) {
+                const uint32_t w = ois->candidate[ri][k];
+                const int mode = (int)(w >> 24);
+                if (md_anti_contouring_valid(mode)) {
+                    cand[n].type = MD_INTRA, cand[n].intra_mode = (uint8_t)mode, cand[n].dist_ready = (uint8_t)((w >> 20) & 1), cand[n].me_dist = w & 0xFFFFFu;
+                    n++;
+                    if (limitIntra && ((isLeftCu && mode != (cuSize < 32 ? 27 : MD_VER)) || (isTopCu && mode != (cuSize < 32 ? 9 : MD_HOR))))
+                        n--;
+                }
+            }
+        } else if (cuSize == 16) {
+            if (limitIntra == 0 || (isLeftCu == 0 && isTopCu == 0)) {
+                cand[n].type = MD_INTRA, cand[n].intra_mode = MD_DC, cand[n].dist_ready = 0, cand[n].me_dist = 0, n++;
+                cand[n].type = MD_INTRA, cand[n].intra_mode = MD_PLANAR, cand[n].dist_ready = 0, cand[n].me_dist = 0, n++;
+            }
+        } else if (skipOis8x8) { /* both 8x8 modes */
+            if (limitIntra == 0 || (isLeftCu == 0 && isTopCu == 0))
+                cand[n].type = MD_INTRA, cand[n].intra_mode = MD_PLANAR, cand[n].dist_ready = 0, cand[n].me_dist = 0, n++;
+        } else if (P->cu8x8_mode == 1) {
+            if (L->is_complete) { /* the parent 16x16 unit's open-loop candidates */
+                const MdStats ps = md_stats(st->parent);
+                const int pri = md_raster_index(&ps), total = ois->total_intra_luma_mode[pri];
+                for (int k = 0; k < total; k++) {
+                    const uint32_t w = ois->candidate[pri][k];
+                    const int mode = (int)(w >> 24);
+                    if (md_anti_contouring_valid(mode)) {
+                        cand[n].type = MD_INTRA, cand[n].intra_mode = (uint8_t)mode, cand[n].dist_ready = 0, cand[n].me_dist = w & 0xFFFFFu;
+                        n++;
+                        if (limitIntra && ((isLeftCu && mode != 27) || (isTopCu && mode != 9)))
+                            n--;
+                    }
+                }
+            } else if (limitIntra == 0 || (isLeftCu == 0 && isTopCu == 0)) {
+                cand[n].type = MD_INTRA, cand[n].intra_mode = MD_DC, cand[n].dist_ready = 0, cand[n].me_dist = 0, n++;
+            }
+        } else {
+            const int total = ois->total_intra_luma_mode[ri];
+            for (int k = 0; k < total; k++) {
+                const uint32_t w = ois->candidate[ri][k];
+                const int mode = (int)(w >> 24);
+                if (!P->intra8x8_restriction_inter_slice || md_anti_contouring_valid(mode)) {
+                    cand[n].type = MD_INTRA, cand[n].intra_mode = (uint8_t)mode, cand[n].dist_ready = (uint8_t)((w >> 20) & 1), cand[n].me_dist = w & 0xFFFFFu;
+                    n++;
+                    if (limitIntra && ((isLeftCu && mode != 27) || (isTopCu && mode != 9)))
+                        n--;
+                }
+            }
+        }
+        return n;
+    }
     const int contouring = L->contouring_class[(leaf - 1) / 21];
     if (cuSize == 32) {
         if (P->intra_injection_method == 1 && contouring == 0) {
@@ -306,12 +364,15 @@ MD_FN uint64_t md_intra_fast_cost_islice(const SvtAmdMdPicture *P, const MdStats
 typedef struct MdBuffers {
     uint64_t fast_cost[MD_MAX_BUF], full_cost[MD_MAX_BUF];
     int16_t cand[MD_MAX_BUF]; /* candidatePtr of the buffer: index into the candidate array, -1 = never assigned */
+    int16_t pred[MD_MAX_BUF]; /* the candidate whose luma prediction the buffer holds (the last one the loop evaluated there; a candidate
+                               * the loop does not evaluate takes the buffer's candidatePtr, not its samples), -1 = none of this unit */
     int evaluated_count;      /* secondFastCostSearchCandidateTotalCount */
 } MdBuffers;
+/* evaluated[i]: 1 = evaluated, 3 = evaluated without a luma prediction (the open-loop intra candidate that won the first loop) */
 MD_FN void md_fast_loop_buffers(MdBuffers *B, int width, int maxBuffers, int ncand, const uint64_t *costs, const uint8_t *evaluated)
 {
     for (int i = 0; i < MD_MAX_BUF; i++)
-        B->fast_cost[i] = B->full_cost[i] = ~0ull, B->cand[i] = -1; /* EbHevcProductCodingLoopInitFastLoop :1586-1596 (i < width) */
+        B->fast_cost[i] = B->full_cost[i] = ~0ull, B->cand[i] = -1, B->pred[i] = -1; /* EbHevcProductCodingLoopInitFastLoop :1586-1596 (i < width) */
     (void)width;
     B->evaluated_count = 0;
     int highest = 0;
@@ -320,6 +381,8 @@ MD_FN void md_fast_loop_buffers(MdBuffers *B, int width, int maxBuffers, int nca
         if (evaluated[idx]) {
             B->fast_cost[highest] = costs[idx];
             B->evaluated_count++;
+            if (!(evaluated[idx] & 2))
+                B->pred[highest] = (int16_t)idx;
         }
         if (idx) { /* the buffer with the highest cost (an unused one first) takes the next candidate */
             highest = 0;
@@ -399,9 +462,9 @@ MD_FN int md_check_high_cost_partition(const SvtAmdMdPicture *P, const SvtAmdMdL
     return children > parentCost ? parent : -1;
 }
 
-/* ProductPerformInterDepthDecision (Codec/EbFullLoop.c:1461-1776; StopSplitCondition :1382 is false in the depth modes of this revision)
+/* ProductPerformInterDepthDecision (Codec/EbFullLoop.c:1461-1776; stop_split: StopSplitCondition, md_stop_split below)
  * and, with exit_parent != 0, ExitInterDepthDecision (:1070-1378).  Returns lastCuIndex. */
-MD_FN int md_inter_depth_decision(const SvtAmdMdPicture *P, MdLcuState *S, int leaf, int lcu_x, int lcu_y, int exit_parent)
+MD_FN int md_inter_depth_decision(const SvtAmdMdPicture *P, MdLcuState *S, int leaf, int lcu_x, int lcu_y, int exit_parent, int stop_split)
 {
     int last = leaf;
     const MdStats cur = md_stats(leaf);
@@ -415,7 +478,8 @@ MD_FN int md_inter_depth_decision(const SvtAmdMdPicture *P, MdLcuState *S, int l
             S->g16++, S->g8 = 0;
         else if (cur.depth == 2)
             S->g8++;
-    } else if (S->cu[leaf].split == 0) { /* lastDepthFlag */
+    } else if (S->cu[leaf].split == 0 || stop_split) { /* lastDepthFlag || stopSplitFlag */
+        S->cu[leaf].split = 0;
         if (cur.depth == 1)
             S->g16++;
         else if (cur.depth == 2)
@@ -497,11 +561,447 @@ MD_FN int md_next_cu_step(const SvtAmdMdLcu *L, int cuIdx, int depth)
     return step;
 }
 
+/* ================================================ P / B pictures ================================================ */
+#define MD_L0 0
+#define MD_L1 1
+#define MD_BI 2
+/* MvUnit_t (Codec/EbDefinitions.h) of a neighbouring position + whether the candidate derivation may use it */
+typedef struct MdMvUnit {
+    MdMv mv[2];
+    uint8_t dir, avail, pad[2];
+} MdMvUnit;
+/* the five spatial neighbours of a unit, in the order the reference names them */
+enum { MD_A0 = 0, MD_A1, MD_B0, MD_B1, MD_B2 };
+typedef struct MdMergeCand {
+    MdMv mv[2];
+    uint8_t dir, pad[3];
+} MdMergeCand;
+typedef struct MdInterLists {
+    MdMv amvp[2][2];       /* firstPuAMVPCandArray_{x,y}[list][idx] */
+    uint8_t amvp_count[2]; /* firstPuNumAvailableAMVPCand */
+    uint8_t merge_count, pad;
+    MdMergeCand merge[5];  /* interPredictionPtr->mvMergeCandidateArray */
+} MdInterLists;
+
+MD_FN int md_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ScaleMV (Codec/EbAdaptiveMotionVectorPrediction.c:28-52) */
+MD_FN void md_scale_mv(uint64_t curPoc, uint64_t targetRefPoc, uint64_t colPoc, uint64_t colRefPoc, MdMv *mv)
+{
+    int16_t td = (int16_t)(colPoc - colRefPoc), tb = (int16_t)(curPoc - targetRefPoc);
+    if (td != tb) {
+        tb = (int16_t)md_clip3(-128, 127, tb), td = (int16_t)md_clip3(-128, 127, td);
+        const int16_t temp = (int16_t)((0x4000 + ((td >> 1) < 0 ? -(td >> 1) : (td >> 1))) / td);
+        const int16_t scale = (int16_t)md_clip3(-4096, 4095, (tb * temp + 32) >> 6);
+        mv->x = (int16_t)md_clip3(-32768, 32767, (scale * mv->x + 127 + (scale * mv->x < 0)) >> 8);
+        mv->y = (int16_t)md_clip3(-32768, 32767, (scale * mv->y + 127 + (scale * mv->y < 0)) >> 8);
+    }
+}
+
+/* GetNonScalingSpatialAMVP_V2 (:172-243): the neighbour's vector that points to the target reference picture, if any */
+MD_FN int md_amvp_non_scaling(const MdMvUnit *u, int targetList, uint64_t targetPoc, const uint64_t refPoc[2], MdMv *out)
+{
+    int avail;
+    if (u->dir == MD_L0 || u->dir == MD_L1) {
+        avail = targetPoc == refPoc[u->dir];
+        if (avail)
+            *out = u->mv[u->dir];
+    } else {
+        avail = targetPoc == refPoc[targetList];
+        if (avail)
+            *out = u->mv[targetList];
+        else {
+            avail = targetPoc == refPoc[1 - targetList];
+            *out = u->mv[1 - targetList]; /* written either way, as the reference does */
+        }
+    }
+    return avail;
+}
+/* GetScalingSpatialAMVP_V2 (:247-288): always available */
+MD_FN void md_amvp_scaling(const MdMvUnit *u, int targetList, uint64_t targetPoc, uint64_t curPoc, const uint64_t refPoc[2], MdMv *out)
+{
+    const int list = u->dir == MD_BI ? targetList : u->dir;
+    *out = u->mv[list];
+    md_scale_mv(curPoc, targetPoc, curPoc, refPoc[list], out);
+}
+
+/* position of the temporal candidate in the co-located picture's motion field (GenerateL0L1AmvpMergeLists :2416-2450, repeated :2573, :2868) */
+typedef struct MdTmvpPos { uint8_t bottom_right, lcu_offset, unit, pad; } MdTmvpPos;
+MD_FN MdTmvpPos md_tmvp_position(const SvtAmdMdPicture *P, const SvtAmdTmvpLcu *map, int ox, int oy, int size)
+{
+    MdTmvpPos t;
+    t.bottom_right = 0, t.lcu_offset = 0, t.unit = 0, t.pad = 0;
+    if (!(ox + size >= P->width || oy + size >= P->height || ((oy & 63) + size) >= 64)) {
+        const int brx = (ox & 63) + size;
+        const int off = brx >> 6, bx = (brx & 63) >> 4, by = ((oy & 63) + size) >> 4;
+        const int unit = by * 4 + bx;
+        if (map[off].available[unit] == 1)
+            t.bottom_right = 1, t.lcu_offset = (uint8_t)off, t.unit = (uint8_t)unit;
+    }
+    if (!t.bottom_right)
+        t.unit = (uint8_t)(((((oy & 63) + (size >> 1)) >> 4) * 4) + (((ox & 63) + (size >> 1)) >> 4));
+    return t;
+}
+/* GetTemporalMVP_V2 (:1394-1450) / one list of GetTemporalMVPBPicture_V2 (:1592-1745) / GetTemporalMVP (:1275-1389) */
+MD_FN int md_temporal_mvp(const SvtAmdMdInter *X, const SvtAmdTmvpLcu *map, MdTmvpPos t, int targetList, uint64_t targetPoc, MdMv *out)
+{
+    int colList = X->is_low_delay ? targetList : 1 - X->colocated_pu_ref_list;
+    const SvtAmdTmvpLcu *m = &map[t.bottom_right ? t.lcu_offset : 0];
+    if (!t.bottom_right && !m->available[t.unit])
+        return 0;
+    colList = m->pred_dir[t.unit] == MD_BI ? colList : m->pred_dir[t.unit];
+    out->x = m->mv[colList][t.unit][0], out->y = m->mv[colList][t.unit][1];
+    md_scale_mv(X->picture_number, targetPoc, X->colocated_poc, m->ref_poc[colList][t.unit], out);
+    return 1;
+}
+
+MD_FN int md_mv_differs(const MdMvUnit *a, const MdMvUnit *b, int bslice)
+{
+    if (!bslice)
+        return a->mv[0].x != b->mv[0].x || a->mv[0].y != b->mv[0].y;
+    return a->dir != b->dir || a->mv[0].x != b->mv[0].x || a->mv[0].y != b->mv[0].y || a->mv[1].x != b->mv[1].x || a->mv[1].y != b->mv[1].y;
+}
+
+/* SetNmm, MDC_STAGE (Codec/EbProductCodingLoop.c:1110-1123): mvMergeSkipModeCount */
+MD_FN int md_nmm(const SvtAmdMdPicture *P, int cuSize) { return P->nmm_level_md == 0 ? 5 : (P->nmm_level_md == 1 ? (cuSize == 32 ? 3 : 2) : 2); }
+
+/* GenerateL0L1AmvpMergeLists (Codec/EbAdaptiveMotionVectorPrediction.c:2117-3005), generateAmvpTableMd on.  nb[]: the spatial
+ * neighbours with the availability the reference derives (:2256-2340: scan order, array bound, inter mode, tile edges); map: the
+ * co-located picture's motion field at this LCU (entry 1 = the LCU to the right), NULL when the temporal candidate is off. */
+MD_FN void md_amvp_merge_lists(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const MdMvUnit nb[5], const SvtAmdTmvpLcu *map, int ox, int oy,
+                               int size, int totalMerge, MdInterLists *o)
+{
+    const int bslice = P->slice_type == 0;
+    const MdMvUnit *A0 = &nb[MD_A0], *A1 = &nb[MD_A1], *B0 = &nb[MD_B0], *B1 = &nb[MD_B1], *B2 = &nb[MD_B2];
+    MdTmvpPos tp;
+    tp.bottom_right = 0, tp.lcu_offset = 0, tp.unit = 0, tp.pad = 0;
+    if (map)
+        tp = md_tmvp_position(P, map, ox, oy, size);
+    for (int list = 0; list < (bslice ? 2 : 1); list++) {
+        const uint64_t targetPoc = X->ref_poc[list];
+        MdMv *c = o->amvp[list];
+        int num = 0, ax = 0;
+        /* GetSpatialMVPPosAx_V3 (:470-572) */
+        if (A0->avail)
+            ax = md_amvp_non_scaling(A0, list, targetPoc, X->ref_poc, &c[num]);
+        if (!ax && A1->avail)
+            ax = md_amvp_non_scaling(A1, list, targetPoc, X->ref_poc, &c[num]);
+        if (!ax && (A0->avail || A1->avail)) {
+            md_amvp_scaling(A0->avail ? A0 : A1, list, targetPoc, X->picture_number, X->ref_poc, &c[num]);
+            ax = 1;
+        }
+        num += ax;
+        /* GetNonScalingSpatialMVPPosBx_V3 (:926-1094) */
+        int bx = 0;
+        if (B0->avail)
+            bx = md_amvp_non_scaling(B0, list, targetPoc, X->ref_poc, &c[num]);
+        if (!bx && B1->avail)
+            bx = md_amvp_non_scaling(B1, list, targetPoc, X->ref_poc, &c[num]);
+        if (!bx && B2->avail)
+            bx = md_amvp_non_scaling(B2, list, targetPoc, X->ref_poc, &c[num]);
+        num += bx;
+        /* GetScalingSpatialMVPPosBx_V3 (:1099-1270): the first available of B0, B1, B2 */
+        if (!ax && (B0->avail || B1->avail || B2->avail)) {
+            md_amvp_scaling(B0->avail ? B0 : (B1->avail ? B1 : B2), list, targetPoc, X->picture_number, X->ref_poc, &c[num]);
+            num++;
+        }
+        if (num == 2 && c[0].x == c[1].x && c[0].y == c[1].y)
+            num = 1;
+        if (map && num < 2)
+            num += md_temporal_mvp(X, map, tp, list, targetPoc, &c[num]);
+        if (num < 1 || (num == 1 && c[0].x != 0 && c[0].y != 0)) {
+            c[num].x = 0, c[num].y = 0;
+            num++;
+        }
+        o->amvp_count[list] = (uint8_t)num;
+    }
+    /* merge candidates (:2649-2990) */
+    MdMergeCand *m = o->merge;
+    int idx = 0;
+    do {
+        if (A1->avail)
+            m[idx].dir = bslice ? A1->dir : MD_L0, m[idx].mv[0] = A1->mv[0], m[idx].mv[1] = A1->mv[1], idx++;
+        if (idx == totalMerge)
+            break;
+        if (B1->avail && (!A1->avail || md_mv_differs(B1, A1, bslice)))
+            m[idx].dir = bslice ? B1->dir : MD_L0, m[idx].mv[0] = B1->mv[0], m[idx].mv[1] = B1->mv[1], idx++;
+        if (idx == totalMerge)
+            break;
+        if (B0->avail && (!B1->avail || md_mv_differs(B0, B1, bslice)))
+            m[idx].dir = bslice ? B0->dir : MD_L0, m[idx].mv[0] = B0->mv[0], m[idx].mv[1] = B0->mv[1], idx++;
+        if (idx == totalMerge)
+            break;
+        if (A0->avail && (!A1->avail || md_mv_differs(A0, A1, bslice)))
+            m[idx].dir = bslice ? A0->dir : MD_L0, m[idx].mv[0] = A0->mv[0], m[idx].mv[1] = A0->mv[1], idx++;
+        if (idx == totalMerge)
+            break;
+        if (idx < 4 && B2->avail && (!A1->avail || md_mv_differs(B2, A1, bslice)) && (!B1->avail || md_mv_differs(B2, B1, bslice)))
+            m[idx].dir = bslice ? B2->dir : MD_L0, m[idx].mv[0] = B2->mv[0], m[idx].mv[1] = B2->mv[1], idx++;
+        if (idx == totalMerge)
+            break;
+        if (map) { /* temporal candidate */
+            MdMv t0, t1;
+            t1.x = t1.y = 0;
+            if (bslice) {
+                if (md_temporal_mvp(X, map, tp, 0, X->ref_poc[0], &t0)) {
+                    md_temporal_mvp(X, map, tp, 1, X->ref_poc[1], &t1);
+                    m[idx].dir = MD_BI, m[idx].mv[0] = t0, m[idx].mv[1] = t1, idx++;
+                }
+            } else if (md_temporal_mvp(X, map, tp, 0, X->ref_poc[0], &t0) && idx < 5) {
+                m[idx].dir = MD_L0, m[idx].mv[0] = t0, m[idx].mv[1] = t1, idx++;
+            }
+        }
+        if (idx == totalMerge)
+            break;
+        if (bslice) { /* combined bi-predictive candidates: mvMergeCandIndexArrayForFillingUp (:20-23) */
+            const uint8_t l0c[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1c[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+            const int loopEnd = idx * (idx - 1);
+            for (int f = 0; idx < totalMerge && f < loopEnd; f++) {
+                const MdMergeCand *c0 = &m[l0c[f]], *c1 = &m[l1c[f]];
+                if (((c0->dir + 1) & 1) && ((c1->dir + 1) & 2) &&
+                    (X->ref_poc[0] != X->ref_poc[1] || c0->mv[0].x != c1->mv[1].x || c0->mv[0].y != c1->mv[1].y)) {
+                    const MdMv v0 = c0->mv[0], v1 = c1->mv[1];
+                    m[idx].dir = MD_BI, m[idx].mv[0] = v0, m[idx].mv[1] = v1, idx++;
+                }
+            }
+            if (idx == totalMerge)
+                break;
+        }
+        for (int r = 0; r < 5 && idx < totalMerge; r++) { /* zero vectors */
+            m[idx].dir = bslice ? MD_BI : MD_L0, m[idx].mv[0].x = m[idx].mv[0].y = m[idx].mv[1].x = m[idx].mv[1].y = 0;
+            idx++;
+        }
+    } while (0);
+    o->merge_count = (uint8_t)idx;
+}
+
+/* ClipMV (:54-72): the bounds are computed in 32-bit unsigned arithmetic and narrowed to 16 bits, as written */
+MD_FN void md_clip_mv(const SvtAmdMdPicture *P, uint32_t ox, uint32_t oy, MdMv *mv)
+{
+    const int16_t xlo = (int16_t)((1u - ox - 8u - 64u) << 2), xhi = (int16_t)(((uint32_t)P->width + 8u - ox - 1u) << 2);
+    const int16_t ylo = (int16_t)((1u - oy - 8u - 64u) << 2), yhi = (int16_t)(((uint32_t)P->height + 8u - oy - 1u) << 2);
+    mv->x = (int16_t)md_clip3(xlo, xhi, mv->x), mv->y = (int16_t)md_clip3(ylo, yhi, mv->y);
+}
+/* ChooseMVPIdx_V2 (Codec/EbInterPrediction.c:1126-1327) for the lists the candidate uses */
+MD_FN void md_choose_mvp(const SvtAmdMdPicture *P, uint32_t ox, uint32_t oy, const MdInterLists *T, MdCand *c)
+{
+    for (int list = 0; list < 2; list++) {
+        if (!(c->dir == MD_BI || c->dir == list))
+            continue;
+        md_clip_mv(P, ox, oy, &c->mv[list]);
+        const MdMv *a = T->amvp[list];
+        int idx = 0;
+        if (T->amvp_count[list] == 2) {
+            const uint32_t d0 = (uint32_t)(a[0].x > c->mv[list].x ? a[0].x - c->mv[list].x : c->mv[list].x - a[0].x) +
+                                (uint32_t)(a[0].y > c->mv[list].y ? a[0].y - c->mv[list].y : c->mv[list].y - a[0].y);
+            const uint32_t d1 = (uint32_t)(a[1].x > c->mv[list].x ? a[1].x - c->mv[list].x : c->mv[list].x - a[1].x) +
+                                (uint32_t)(a[1].y > c->mv[list].y ? a[1].y - c->mv[list].y : c->mv[list].y - a[1].y);
+            idx = d0 <= d1 ? 0 : 1;
+        } else if (T->amvp_count[list] > 2) {
+            continue;
+        }
+        c->mvp_idx[list] = (uint8_t)idx, c->mvp[list] = a[idx];
+    }
+}
+
+/* Me2Nx2NCandidatesInjection (Codec/EbModeDecision.c:446-566) with sub-sample motion and unrestricted motion vectors (neither RoundMv
+ * nor LimitMvOverBound), then ProductMergeSkip2Nx2NCandidatesInjection (:1608-1700).  Returns the new candidate count. */
+MD_FN int md_inter_candidates(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdMeCuResult *me, const MdInterLists *T, uint32_t ox,
+                              uint32_t oy, int totalMerge, MdCand *cand, int n)
+{
+    for (int i = 0; i < me->total_me_candidate_index; i++) {
+        const int dir = me->direction[i];
+        if (dir == MD_BI && P->depth_mode == 0 && L->lcu_md_mode == 10)
+            continue;
+        MdCand *c = &cand[n];
+        c->type = MD_INTER, c->intra_mode = 0, c->mpm = 0, c->dist_ready = 1, c->me_dist = me->distortion[i];
+        c->dir = (uint8_t)dir, c->merge_flag = 0, c->merge_index = 0;
+        c->mv[0].x = me->x_mv_l0, c->mv[0].y = me->y_mv_l0, c->mv[1].x = me->x_mv_l1, c->mv[1].y = me->y_mv_l1;
+        c->mvp_idx[0] = c->mvp_idx[1] = 0, c->mvp[0].x = c->mvp[0].y = c->mvp[1].x = c->mvp[1].y = 0;
+        md_choose_mvp(P, ox, oy, T, c);
+        n++;
+    }
+    for (int k = 0; k < totalMerge; k++) {
+        if (k >= T->merge_count)
+            continue;
+        const MdMergeCand *mc = &T->merge[k];
+        int dup = 0;
+        for (int j = k; j > 0 && !dup;) {
+            const MdMergeCand *d = &T->merge[--j];
+            const int f0 = mc->mv[0].x == d->mv[0].x && mc->mv[0].y == d->mv[0].y;
+            const int f1 = mc->dir != MD_L0 && mc->mv[1].x == d->mv[1].x && mc->mv[1].y == d->mv[1].y;
+            const int same = mc->dir == MD_L0 ? f0 : (mc->dir == MD_L1 ? f1 : (f0 && f1));
+            dup = mc->dir == d->dir && same;
+        }
+        if (dup)
+            continue;
+        MdCand *c = &cand[n];
+        c->type = MD_INTER, c->intra_mode = 0, c->mpm = 0, c->dist_ready = 0, c->me_dist = 0;
+        c->dir = mc->dir, c->merge_flag = 1, c->merge_index = (uint8_t)k;
+        c->mv[0] = mc->mv[0], c->mv[1] = mc->mv[1];
+        c->mvp_idx[0] = c->mvp_idx[1] = 0, c->mvp[0].x = c->mvp[0].y = c->mvp[1].x = c->mvp[1].y = 0;
+        n++;
+    }
+    return n;
+}
+
+/* mvBitTable (Codec/EbModeDecisionConfiguration.h:108): the 500 x 500 table is a 3 x 3 core plus 2 bits (1 << 16) per doubling of
+ * either component beyond 2 (checked entry by entry against the header by tests/golden/make_md_golden.py) */
+MD_FN uint32_t md_mv_bits(int mvdX, int mvdY)
+{
+    const uint32_t core[3][3] = {{73744, 128728, 203592}, {130975, 178780, 253644}, {202683, 253623, 321933}};
+    int lx = 0, ly = 0;
+    for (int v = mvdX; v >= 4; v >>= 1)
+        lx++;
+    for (int v = mvdY; v >= 4; v >>= 1)
+        ly++;
+    return core[mvdX > 2 ? 2 : mvdX][mvdY > 2 ? 2 : mvdY] + 65536u * (uint32_t)(lx + ly);
+}
+MD_FN uint32_t md_mvd_rate(const MdCand *c, int list)
+{
+    int dx = c->mvp[list].x > c->mv[list].x ? c->mvp[list].x - c->mv[list].x : c->mv[list].x - c->mvp[list].x;
+    int dy = c->mvp[list].y > c->mv[list].y ? c->mvp[list].y - c->mv[list].y : c->mv[list].y - c->mvp[list].y;
+    dx = dx > 499 ? 499 : dx, dy = dy > 499 ? 499 : dy;
+    return md_mv_bits(dx, dy) + (c->mvp_idx[list] ? 44891u : 23196u); /* mvpIndexBits, EbRateDistortionCost.c:18 */
+}
+/* InterFastCostPsliceOpt / InterFastCostBsliceOpt (Codec/EbRateDistortionCost.c:1157-1465) without chroma in the fast loop */
+MD_FN uint64_t md_inter_fast_cost(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *cu, const MdCand *c, uint64_t lumaDistortion,
+                                  uint64_t *fastLumaRate)
+{
+    const uint32_t skipFlagBits[6] = {17878, 62157, 86651, 54723, 14816, 8254}, mergeIndexBits[5] = {10350, 109741, 142509, 175277, 175277};
+    const uint32_t interBiDirBits[8] = {29856, 36028, 15752, 59703, 8692, 84420, 2742, 136034}, interUniDirBits[2] = {2742, 136034};
+    uint64_t rate;
+    if (c->merge_flag) {
+        rate = (uint64_t)skipFlagBits[3 + cu->skip_ctx] + mergeIndexBits[c->merge_index];
+    } else {
+        rate = 86440;
+        if (P->slice_type == 0) {
+            rate += interBiDirBits[(st->depth << 1) + (c->dir == MD_BI)];
+            if (c->dir != MD_BI)
+                rate += interUniDirBits[c->dir] + md_mvd_rate(c, c->dir);
+            else
+                rate += (uint64_t)md_mvd_rate(c, 0) + md_mvd_rate(c, 1);
+        } else {
+            rate += md_mvd_rate(c, 0);
+        }
+    }
+    *fastLumaRate = rate;
+    return (lumaDistortion << 8) + (((uint64_t)P->fast_lambda * rate + (1u << 22)) >> 23);
+}
+/* Intra2Nx2NFastCostPsliceOpt (:580-660) without chroma in the fast loop */
+MD_FN uint64_t md_intra_fast_cost_pslice(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *c, int lumaMode, uint64_t lumaDistortion,
+                                         uint64_t *fastLumaRate)
+{
+    const uint64_t chromaRate = 12368;
+    uint64_t lumaRate = st->depth == 3 ? 31523 : 0;
+    lumaRate += 136034;
+    lumaRate += (lumaMode == c->left_intra_mode || lumaMode == c->top_intra_mode) ? 72731 : 192228;
+    *fastLumaRate = lumaRate;
+    return (lumaDistortion << 8) + (((uint64_t)P->fast_lambda * (lumaRate + chromaRate) + (1u << 22)) >> 23);
+}
+
+/* the rate of the transform-tree flags of a unit's luma (shared tail of InterFullLumaCost / MergeSkipFullLumaCost / IntraFullLumaCostPslice):
+ * one split flag + one cbf per transform unit (four 32x32 units, ycbf bits 1..4, in a 64x64 unit) */
+MD_FN uint64_t md_tu_flags_rate(const SvtAmdMdPicture *P, int cuSize, uint32_t ycbf)
+{
+    if (cuSize == 64) {
+        uint64_t r = 0;
+        for (int tu = 1; tu <= 4; tu++)
+            r += (uint64_t)P->rates.transSubDivFlagBits[0] + P->rates.lumaCbfBits[((ycbf >> tu) & 1) * 5 + 0];
+        return r;
+    }
+    const int lg = cuSize == 32 ? 5 : (cuSize == 16 ? 4 : 3);
+    return (uint64_t)P->rates.transSubDivFlagBits[5 - lg] + P->rates.lumaCbfBits[(ycbf > 0) * 5 + 1];
+}
+/* InterFullLumaCost (:1968-2075) incl. MergeSkipFullLumaCost (:2370-2520).  dist[0] / dist[1]: yFullDistortion[DIST_CALC_RESIDUAL /
+ * PREDICTION]; merge units also get their merge and skip costs. */
+MD_FN uint64_t md_inter_full_luma_cost(const SvtAmdMdPicture *P, const MdCu *cu, const MdCand *c, int cuSize, uint32_t ycbf, uint64_t fastLumaRate,
+                                       const uint64_t dist[2], uint64_t yCoeffBits, uint64_t *mergeCost, uint64_t *skipCost)
+{
+    const uint64_t lambda = P->full_lambda, coeffRate = yCoeffBits << 15;
+    const int rootCbf = ycbf != 0;
+    if (c->merge_flag) {
+        uint64_t rate = (uint64_t)P->rates.skipFlagBits[cu->skip_ctx] + P->rates.mergeFlagBits[1] + P->rates.predModeBits[0] + P->rates.interPartSizeBits[0] +
+                        P->rates.mergeIndexBits[c->merge_index];
+        if (rootCbf)
+            rate += md_tu_flags_rate(P, cuSize, ycbf);
+        const uint64_t mc = (dist[0] << 8) + (((lambda * coeffRate + lambda * rate) + (1u << 22)) >> 23);
+        const uint64_t sc = (dist[1] << 8) + (((lambda * fastLumaRate) + (1u << 22)) >> 23);
+        *mergeCost = mc, *skipCost = sc;
+        return sc <= mc ? sc : mc;
+    }
+    uint64_t rate = P->rates.rootCbfBits[rootCbf];
+    if (rootCbf)
+        rate += md_tu_flags_rate(P, cuSize, ycbf);
+    rate += fastLumaRate;
+    return (dist[0] << 8) + (((lambda * coeffRate + lambda * rate) + (1u << 22)) >> 23);
+}
+/* IntraFullLumaCostPslice (:1060-1140): units up to 32x32, one transform unit */
+MD_FN uint64_t md_intra_full_luma_cost_pslice(const SvtAmdMdPicture *P, int cuSize, uint32_t ycbf, uint64_t fastLumaRate, uint64_t yDistortion0,
+                                              uint64_t yCoeffBits)
+{
+    const uint64_t lambda = P->full_lambda, coeffRate = yCoeffBits << 15;
+    const int lg = cuSize == 32 ? 5 : (cuSize == 16 ? 4 : 3);
+    const uint64_t rate = (uint64_t)P->rates.transSubDivFlagBits[5 - lg] + P->rates.lumaCbfBits[(ycbf & 1) * 5 + 1] + fastLumaRate;
+    return (yDistortion0 << 8) + (((lambda * coeffRate + lambda * rate) + (1u << 22)) >> 23);
+}
+/* the scaling PerformFullLoop applies to the luma coefficient bits of partial-frequency units (:4575-4590; N2_TH by QP) */
+MD_FN uint64_t md_pf_coeff_bits(int pfMode, int qp, uint64_t yCoeffBits)
+{
+    if (pfMode == 1)
+        return yCoeffBits * (uint64_t)(qp < 10 ? 3 : (qp < 29 ? 2 : 1));
+    return yCoeffBits;
+}
+/* DerivePartialFrequencyN2Flag (:2243-2260), levels 0 / 1 */
+MD_FN int md_pf_mode(const SvtAmdMdPicture *P) { return P->pf_md_level == 1 ? 1 : 0; }
+
+/* SkipSmallCu (:2292-2306) and its caller's condition (:4826-4836): returns the unit's split flag */
+MD_FN int md_skip_small_cu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const MdLcuState *S, int leaf, int depth)
+{
+    const int applies = (P->depth_mode >= 5 || (P->depth_mode == 0 && (L->lcu_md_mode == 5 || L->lcu_md_mode == 6 || L->lcu_md_mode == 7))) && L->is_complete;
+    if (applies && L->skip_small_cu && S->local[leaf].left_depth == depth && S->local[leaf].top_depth == depth && S->cu[leaf].split)
+        return 0;
+    return S->cu[leaf].split;
+}
+
+/* StopSplitCondition (Codec/EbFullLoop.c:1392-1455): depth thresholds on the unit's luma distortion; the tables (:14-70) depend on the
+ * temporal layer only (layer <= hierarchical levels) */
+MD_FN int md_stop_split(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int depth, uint32_t fullDistortion)
+{
+    const uint16_t d0[2][6] = {{1000, 4000, 9500, 3000, 3000, 3000}, {0, 1000, 7000, 9500, 9500, 9500}};
+    const uint16_t d1[2][6] = {{0, 2000, 5500, 9500, 9500, 9500}, {0, 1500, 1500, 1500, 1500, 1500}};
+    const uint16_t d2[2][6] = {{0, 500, 2000, 2500, 2500, 2500}, {0, 1500, 1000, 4500, 4500, 4500}};
+    if (P->depth_mode == 1 || P->depth_mode == 2 || (P->depth_mode == 0 && (L->lcu_md_mode == 1 || L->lcu_md_mode == 2 || L->lcu_md_mode == 7)))
+        return 0;
+    if (P->temporal_layer == 0 || P->slice_type == 2)
+        return 0;
+    if (!L->is_complete || L->no_stop_split)
+        return 0;
+    const int e = L->edge_block != 0, t = P->temporal_layer > 5 ? 5 : P->temporal_layer;
+    return (depth == 0 && fullDistortion < d0[e][t]) || (depth == 1 && fullDistortion < d1[e][t]) || (depth == 2 && fullDistortion < d2[e][t]);
+}
+
 /* what this revision of the device call covers (include/svt_hevc_amd.h) */
 MD_FN int md_picture_supported(const SvtAmdMdPicture *P)
 {
     return P->slice_type == 2 && P->depth_mode == 2 /* PICT_FULL84 */ && !P->intra_md_open_loop && P->chroma_level == 1 && !P->coeff_cabac_update &&
            P->intra4x4_level == 2 && !P->rdoq_pmcore_method && !P->single_fast_loop && !P->spatial_sse_full_loop && P->pf_md_level == 0 &&
            P->nfl_level_md != 3 && P->intra_injection_method <= 2 && !(P->width & 7) && !(P->height & 7);
+}
+/* P / B pictures; the LCUs must in addition all be decided by ModeDecisionLcu (md_lcu_supported) */
+MD_FN int md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X)
+{
+    return P->slice_type != 2 && P->intra_md_open_loop && P->chroma_level == 1 && !P->coeff_cabac_update && P->intra4x4_level == 2 &&
+           !P->rdoq_pmcore_method && !P->single_fast_loop && !P->spatial_sse_full_loop && P->pf_md_level <= 1 && P->nfl_level_md != 3 &&
+           P->intra_injection_method <= 1 && !P->limit_ois_to_dc_mode && !P->mpm_search && P->enc_mode < 10 && !(P->width & 7) && !(P->height & 7) &&
+           X->use_subpel && X->unrestricted_mv && X->generate_amvp_table_md && !X->extra_injection && !X->improve_sharpness;
+}
+MD_FN int md_lcu_supported(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L)
+{
+    if (L->chroma_encode_mode != 2 /* CHROMA_MODE_BEST */)
+        return 0;
+    if (P->depth_mode == 0) /* PICT_LCU_SWITCH: branch-and-depth-pillar LCUs (3, 4) stay with the reference */
+        return L->lcu_md_mode != 3 && L->lcu_md_mode != 4 && L->lcu_md_mode != 0;
+    return P->depth_mode == 1 || P->depth_mode == 2 || P->depth_mode == 5;
 }
 #endif

@@ -27,6 +27,15 @@ CASES = {
     # flat + high qp: 32x32 units without coefficients, anti-contouring classes
     "i_flat_320x192_m9_q44": ("flat", 320, 192, 1, 5, ["-encMode", "9", "-intra-period", "0", "-q", "44"], None),
     # 2x2 tiles: neighbour arrays per tile
+    # P / B pictures: the non-reference B pictures of random-access encodes (open-loop intra, luma-only candidates, partial frequency N2)
+    "b_motion_416x240_m8": ("motion", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "nonref"),
+    "b_noise_320x256_m9_q24": ("noise", 320, 256, 9, 11, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "24"], "nonref"),
+    "b_tiles_motion_640x384_m8": ("motion", 640, 384, 5, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "34", "-tile_col_cnt", "2",
+                                                               "-tile_row_cnt", "2"], "nonref"),
+    "b_objects_416x240_m8": ("objects", 416, 240, 9, 3, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "28"], "nonref"),
+    "b_objects_640x360_m9_q36": ("objects", 640, 360, 5, 5, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "36"], "nonref"),
+    "p_objects_320x192_m8_ld": ("objects", 320, 192, 6, 4, ["-encMode", "8", "-pred-struct", "1", "-hierarchical-levels", "2", "-q", "26"], "nonref"),
+    "p_motion_416x240_m8_ld": ("motion", 416, 240, 6, 9, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "2", "-q", "32"], "nonref"),
     "i_tiles_motion_640x384_m9": ("motion", 640, 384, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "33", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], None),
 }
 
@@ -43,8 +52,24 @@ def parse_dump(raw):
             cb = np.frombuffer(raw, np.uint8, w * hh // 4, o + w * hh).reshape(hh // 2, w // 2)
             cr = np.frombuffer(raw, np.uint8, w * hh // 4, o + w * hh * 5 // 4).reshape(hh // 2, w // 2)
             ois = np.frombuffer(raw, S.OIS_LCU_DTYPE, nl, o + w * hh * 3 // 2)
-            assert S.MD_PIC_RECORD_DTYPE.itemsize + w * hh * 3 // 2 + nl * S.OIS_LCU_DTYPE.itemsize == size
-            pics[int(h["picture_number"])] = (h, y, cb, cr, ois)
+            o += w * hh * 3 // 2 + nl * S.OIS_LCU_DTYPE.itemsize
+            inter = None
+            if h["has_inter"]:
+                me = np.frombuffer(raw, S.ME_LCU_DTYPE, nl, o)
+                o += nl * S.ME_LCU_DTYPE.itemsize
+                tmvp = None
+                if h["tmvp_present"]:
+                    tmvp = np.frombuffer(raw, S.MD_TMVP_LCU_DTYPE, nl, o)
+                    o += nl * S.MD_TMVP_LCU_DTYPE.itemsize
+                sy, sc, oy, rh = int(h["ref_stride_y"]), int(h["ref_stride_c"]), int(h["ref_origin_y"]), int(h["ref_height"])
+                refs = []
+                for _ in range(int(h["nref"])):
+                    ny, nc = sy * (rh + 2 * oy), sc * (rh // 2 + oy)
+                    refs.append((np.frombuffer(raw, np.uint8, ny, o), np.frombuffer(raw, np.uint8, nc, o + ny), np.frombuffer(raw, np.uint8, nc, o + ny + nc)))
+                    o += ny + 2 * nc
+                inter = (me, tmvp, refs)
+            assert o - off == size, (o - off, size)
+            pics[int(h["picture_number"])] = (h, y, cb, cr, ois, inter)
         elif magic == S.MD_LCU_MAGIC:
             assert size == S.MD_LCU_RECORD_DTYPE.itemsize, (size, S.MD_LCU_RECORD_DTYPE.itemsize)
             lcus.append(np.frombuffer(raw, S.MD_LCU_RECORD_DTYPE, 1, off)[0])
@@ -63,6 +88,19 @@ def run_case(name):
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
         pics, lcus = parse_dump(open(dump, "rb").read())
     nl = S.lcu_count(w, h)
+    if os.environ.get("MD_GOLDEN_LIST"):  # survey: what the reference derived for every recorded picture
+        for p in sorted(pics):
+            h = pics[p][0]
+            pc = h["pic"]
+            r = lcus[lcus["picture_number"] == p]
+            print("  poc %d: slice %d tl %d ref %d depth_mode %d open_loop %d chroma %d pf %d nfl %d nmm %d cabac_upd %d i4x4 %d mpm %d limit_intra %d cu8x8 %d "
+                  "subpel %d tmvp %d lcus via MD %d/%d modes %s chroma modes %s" %
+                  (p, pc["slice_type"], pc["temporal_layer"], pc["is_reference"], pc["depth_mode"], pc["intra_md_open_loop"], pc["chroma_level"], pc["pf_md_level"],
+                   pc["nfl_level_md"], pc["nmm_level_md"], pc["coeff_cabac_update"], pc["intra4x4_level"], pc["mpm_search"], pc["limit_intra"], pc["cu8x8_mode"],
+                   h["inter"]["use_subpel"], h["inter"]["tmvp_enable"], len(r), nl, sorted(set(r["lcu"]["lcu_md_mode"].tolist())),
+                   sorted(set(r["lcu"]["chroma_encode_mode"].tolist()))))
+    if keep == "nonref":
+        keep = [p for p in sorted(pics) if pics[p][0]["pic"]["slice_type"] != 2 and not pics[p][0]["pic"]["is_reference"]]
     numbers = sorted(pics) if keep is None else [p for p in sorted(pics) if p in keep]
     # only pictures every LCU of which went through ModeDecisionLcu (PICT_LCU_SWITCH pictures mix it with the BDP path)
     numbers = [p for p in numbers if (lcus["picture_number"] == p).sum() == nl]
@@ -82,6 +120,17 @@ def run_case(name):
     out["ois"] = np.stack([pics[p][4] for p in numbers])
     out["lcu"] = np.stack([r["lcu"] for r in recs])
     out["out"] = np.stack([r["out"] for r in recs])
+    if any(pics[p][5] is not None for p in numbers):  # P / B pictures: the inter inputs (every kept picture must be one)
+        assert all(pics[p][5] is not None for p in numbers)
+        out["inter"] = np.stack([pics[p][0]["inter"] for p in numbers])
+        out["me"] = np.stack([pics[p][5][0] for p in numbers])["pu"]  # only the candidate records matter to the mode decision
+        out["tmvp_present"] = np.array([pics[p][5][1] is not None for p in numbers])
+        out["tmvp"] = np.stack([pics[p][5][1] if pics[p][5][1] is not None else np.zeros(nl, S.MD_TMVP_LCU_DTYPE) for p in numbers])
+        out["ref_geom"] = np.stack([np.array([pics[p][0][k] for k in ("ref_stride_y", "ref_stride_c", "ref_origin_x", "ref_origin_y", "ref_width",
+                                                                       "ref_height", "nref")], np.uint32) for p in numbers])
+        for l in range(2):
+            for k, nm in enumerate(("y", "cb", "cr")):
+                out["ref%d_%s" % (l, nm)] = np.stack([pics[p][5][2][min(l, len(pics[p][5][2]) - 1)][k] for p in numbers])
     path = os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name)
     np.savez_compressed(path, **out)
     o = out["out"]

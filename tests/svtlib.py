@@ -288,6 +288,27 @@ def gen_luma(kind, w, h, t, seed):
         for _ in range(t):
             rng.integers(0, 256, size=(h, w), dtype=np.uint8)
         return rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    if kind == "objects":
+        # textured rectangles moving at different (fractional) speeds over a textured background that itself pans slowly, plus mild per-frame
+        # noise: neighbouring units get different motion vectors, uncovered areas have no match (AMVP, uni-prediction and intra candidates win)
+        tex = rng.integers(0, 256, size=(h + 64, w + 64), dtype=np.uint8)
+        x = np.arange(w)[None, :]
+        y = np.arange(h)[:, None]
+        bx, by = (t * 3) // 4, t // 2
+        l = 96 + 40 * np.sin((x + bx) / 29.0) * np.cos((y + by) / 37.0) + (tex[by:by + h, bx:bx + w] >> 3).astype(np.float64)
+        nobj = 6 + (w * h) // (320 * 240)
+        for k in range(nobj):
+            ow, oh = int(rng.integers(24, 97)), int(rng.integers(24, 97))
+            px, py = float(rng.integers(0, w)), float(rng.integers(0, h))
+            vx, vy = float(rng.integers(-14, 15)) / 4.0, float(rng.integers(-10, 11)) / 4.0
+            base, amp = int(rng.integers(40, 200)), int(rng.integers(2, 6))
+            otex = rng.integers(0, 256, size=(oh, ow), dtype=np.uint8) >> amp
+            x0, y0 = int(np.floor(px + vx * t)) % w, int(np.floor(py + vy * t)) % h
+            x1, y1 = min(w, x0 + ow), min(h, y0 + oh)
+            l[y0:y1, x0:x1] = base + otex[:y1 - y0, :x1 - x0]
+        frame_rng = np.random.default_rng(seed * 1000 + t)
+        l = l + frame_rng.integers(-3, 4, size=(h, w))
+        return np.clip(np.floor(l), 0, 255).astype(np.uint8)
     # "motion": sinusoids drifting 3/2 px per frame + fixed noise field moving (-2,-1)
     noise = rng.integers(0, 256, size=(h + 256, w + 512), dtype=np.uint8)
     x = np.arange(w)[None, :]
@@ -370,20 +391,30 @@ MD_PICTURE_DTYPE = np.dtype([("width", "<u2"), ("height", "<u2")] + [(n, "u1") f
     "slice_type", "temporal_layer", "is_reference", "enc_mode", "depth_mode", "intra_md_open_loop", "intra_injection_method", "limit_intra",
     "mpm_search", "mpm_search_candidate", "pf_md_level", "nfl_level_md", "nmm_level_md", "full_loop_escape", "single_fast_loop",
     "coeff_cabac_update", "spatial_sse_full_loop", "chroma_level", "intra4x4_level", "rdoq_pmcore_method", "skip_ois_8x8", "cu8x8_mode",
-    "cu16x16_mode", "limit_ois_to_dc_mode", "constrained_intra", "strong_smoothing", "qp", "chroma_qp")] + [("pad", "u1", 4)] +
+    "cu16x16_mode", "limit_ois_to_dc_mode", "constrained_intra", "strong_smoothing", "qp", "chroma_qp", "intra8x8_restriction_inter_slice")] +
+    [("pad", "u1", 3)] +
     [(n, "<u4") for n in ("fast_lambda", "full_lambda", "fast_chroma_lambda", "full_chroma_lambda")] + [("rates", MD_RATES_DTYPE)])
 MD_LCU_DTYPE = np.dtype([("leaf_count", "u1"), ("leaf_index", "u1", 85), ("leaf_split", "u1", 85), ("tile_left", "u1"), ("tile_top", "u1"),
                          ("tile_right", "u1"), ("is_complete", "u1"), ("complexity_status_2", "u1"), ("contouring_class", "u1", 4),
-                         ("chroma_encode_mode", "u1"), ("restrict_intra_global_motion", "u1"), ("lcu_md_mode", "u1")])
+                         ("chroma_encode_mode", "u1"), ("restrict_intra_global_motion", "u1"), ("lcu_md_mode", "u1"), ("skip_small_cu", "u1"),
+                         ("cmplx_noise", "u1"), ("variance_below_200", "u1"), ("edge_block", "u1"), ("no_stop_split", "u1"), ("pad", "u1", 3)])
 MD_LCU_OUT_DTYPE = np.dtype([("split", "u1", 85), ("tested", "u1", 85), ("pred_mode", "u1", 85), ("intra_luma_mode", "u1", 85), ("ycbf", "u1", 85),
-                             ("pad", "u1", 7), ("cost", "<u8", 85)])
+                             ("inter_dir", "u1", 85), ("merge_flag", "u1", 85), ("merge_index", "u1", 85), ("pad", "u1", 8), ("mv", "<i2", (85, 2, 2)),
+                             ("cost", "<u8", 85), ("merge_cost", "<u8", 85), ("skip_cost", "<u8", 85)])
+MD_TMVP_LCU_DTYPE = np.dtype([("mv", "<i2", (2, 16, 2)), ("ref_poc", "<u8", (2, 16)), ("pred_dir", "u1", 16), ("available", "u1", 16)])
+MD_INTER_DTYPE = np.dtype([("picture_number", "<u8"), ("ref_poc", "<u8", 2), ("colocated_poc", "<u8")] + [(n, "u1") for n in (
+    "colocated_pu_ref_list", "is_low_delay", "tmvp_enable", "use_subpel", "unrestricted_mv", "generate_amvp_table_md", "extra_injection",
+    "improve_sharpness", "skip_cost_bias")] + [("pad", "u1", 7)])
+assert MD_LCU_DTYPE.itemsize == 191 and MD_LCU_OUT_DTYPE.itemsize == 3408 and MD_TMVP_LCU_DTYPE.itemsize == 416 and MD_INTER_DTYPE.itemsize == 48
 MD_PIC_MAGIC, MD_LCU_MAGIC = 0x4350444D, 0x434C444D
-MD_PIC_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("nlcu", "<u4"), ("pad", "<u4"),
-                                ("pic", MD_PICTURE_DTYPE), ("cost", "u1", CABAC_COST_BYTES), ("pad2", "u1", 4)])
-assert MD_PIC_RECORD_DTYPE.itemsize == 2152 and MD_PICTURE_DTYPE.itemsize == 564
+MD_PIC_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("nlcu", "<u4"), ("has_inter", "<u4"),
+                                ("pic", MD_PICTURE_DTYPE), ("cost", "u1", CABAC_COST_BYTES), ("pad2", "u1", 4), ("inter", MD_INTER_DTYPE)] +
+                               [(n, "<u4") for n in ("ref_stride_y", "ref_stride_c", "ref_origin_x", "ref_origin_y", "ref_width", "ref_height", "nref",
+                                                     "tmvp_present")])
+assert MD_PIC_RECORD_DTYPE.itemsize == 2232 and MD_PICTURE_DTYPE.itemsize == 564
 MD_LCU_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("lcu_index", "<u4"), ("pad", "<u4"),
                                 ("lcu", MD_LCU_DTYPE), ("pad1", "u1"), ("out", MD_LCU_OUT_DTYPE)])
-assert MD_LCU_RECORD_DTYPE.itemsize == 1320 and MD_LCU_RECORD_DTYPE.fields["out"][1] == 208
+assert MD_LCU_RECORD_DTYPE.itemsize == 3624 and MD_LCU_RECORD_DTYPE.fields["out"][1] == 216
 LCU_WORK16_DTYPE = np.dtype([(n, LCU_WORK_DTYPE.fields[n][0]) if not n.startswith("src_") else (n, "<u2", LCU_WORK_DTYPE.fields[n][0].shape)
                              for n in LCU_WORK_DTYPE.names])
 LCU_RESULT16_DTYPE = np.dtype([(n, LCU_RESULT_DTYPE.fields[n][0]) if not n.startswith("rec_") else (n, "<u2", LCU_RESULT_DTYPE.fields[n][0].shape)

@@ -22,12 +22,38 @@ def oracle_md_picture(lib, g, k):
     ois = np.ascontiguousarray(g["ois"][k])
     out = np.zeros(len(lcus), S.MD_LCU_OUT_DTYPE)
     rec = np.zeros_like(src)
+    if "inter" in g.files:
+        X, me, tmvp, refs, keep = inter_inputs(g, k)
+        lib.svt_oracle_md_picture_inter.restype = C.c_int
+        lib.svt_oracle_md_picture_inter.argtypes = [C.c_void_p] * 5 + [C.c_uint32] + [C.c_void_p] * 7
+        rc = lib.svt_oracle_md_picture_inter(pic.ctypes.data, X.ctypes.data, lcus.ctypes.data, cost.ctypes.data, src.ctypes.data, src.shape[1],
+                                             ois.ctypes.data, me.ctypes.data, tmvp.ctypes.data if tmvp is not None else None, C.addressof(refs[0]),
+                                             C.addressof(refs[1]), out.ctypes.data, rec.ctypes.data)
+        assert rc == 0, rc
+        return out, rec
     lib.svt_oracle_md_picture.restype = C.c_int
     lib.svt_oracle_md_picture.argtypes = [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 3
     rc = lib.svt_oracle_md_picture(pic.ctypes.data, lcus.ctypes.data, cost.ctypes.data, src.ctypes.data, src.shape[1], ois.ctypes.data,
                                    out.ctypes.data, rec.ctypes.data)
     assert rc == 0, rc
     return out, rec
+
+
+def inter_inputs(g, k):
+    """the inter inputs of picture k of a P / B fixture: SvtAmdMdInter, the ME records in the contract's layout, the co-located motion field and
+    the two reference pictures (host planes) as SvtAmdRefPicture"""
+    X = np.ascontiguousarray(g["inter"][k:k + 1])
+    nl = g["lcu"].shape[1]
+    me = np.zeros(nl, S.ME_LCU_DTYPE)
+    me["pu"] = g["me"][k]
+    tmvp = np.ascontiguousarray(g["tmvp"][k]) if g["tmvp_present"][k] else None
+    sy, sc, ox, oy, rw, rh, _ = (int(v) for v in g["ref_geom"][k])
+    keep, refs = [], []
+    for l in range(2):
+        planes = [np.ascontiguousarray(g["ref%d_%s" % (l, nm)][k]) for nm in ("y", "cb", "cr")]
+        keep.append(planes)
+        refs.append(S.RefPicture(planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, sy, sc, ox, oy, rw, rh))
+    return X, me, tmvp, refs, keep
 
 
 def compare_md(got, want, what):
@@ -39,9 +65,13 @@ def compare_md(got, want, what):
             errs.append((i, "tested", np.nonzero(g["tested"] != w["tested"])[0][:6].tolist()))
             continue
         t = w["tested"] == 1
-        for f in ("split", "pred_mode", "intra_luma_mode", "ycbf", "cost"):
-            if not np.array_equal(g[f][t], w[f][t]):
-                bad = np.nonzero((g[f] != w[f]) & t)[0]
+        inter = t & (w["pred_mode"] == 1)
+        merge = inter & (w["merge_flag"] == 1)
+        for f, m in (("split", t), ("pred_mode", t), ("intra_luma_mode", t), ("ycbf", t), ("cost", t), ("inter_dir", t), ("merge_flag", t),
+                     ("merge_index", merge), ("mv", inter), ("merge_cost", merge), ("skip_cost", merge)):
+            if not np.array_equal(g[f][m], w[f][m]):
+                ne = g[f] != w[f]
+                bad = np.nonzero((ne.reshape(85, -1).any(axis=1)) & m)[0]
                 errs.append((i, f, bad[:6].tolist(), g[f][bad[:3]].tolist(), w[f][bad[:3]].tolist()))
     assert not errs, "%s: %d LCU fields differ, first: %s" % (what, len(errs), errs[:4])
 
