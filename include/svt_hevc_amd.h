@@ -1492,7 +1492,9 @@ typedef struct SvtAmdMdInter {
     uint8_t improve_sharpness;             /* scs->staticConfig.improveSharpness (cost biases)                                   */
     uint8_t skip_cost_bias;                /* encode pass (EbCodingLoop.c:3861-3871): non-reference B picture with a reference picture whose
                                             * intraCodedArea is above INTRA_AREA_TH[its temporal layer]                          */
-    uint8_t pad[7];
+    uint8_t pad[3];
+    uint32_t chroma_weight;                /* ChromaWeightFactor*[qp] of the picture's class (Codec/EbRateDistortionCost.c:35-65, EbLambdaRateTables.h): the weight
+                                            * of chroma distortion in the merge / skip costs                                       */
 } SvtAmdMdInter;
 /* what the mode decision leaves per LCU: the decision of every leaf it tested (the final tree = leaves with split == 0 walked in
  * Z order) and the costs the inter-depth decisions compared (mdLocalCuUnit[].cost) */

@@ -21,6 +21,7 @@
 #include "EbReferenceObject.h"
 #include "EbAdaptiveMotionVectorPrediction.h"
 #include "EbMotionEstimationLcuResults.h"
+#include "EbLambdaRateTables.h"
 #include "../include/svt_hevc_amd.h"
 
 _Static_assert(sizeof(MdRateEstimationContext_t) == sizeof(SvtAmdMdRates), "MdRateEstimationContext_t layout");
@@ -106,6 +107,10 @@ static void svt_md_fill_inter(SvtAmdMdInter *X, const SequenceControlSet_t *scs,
     X->generate_amvp_table_md = md->generateAmvpTableMd;
     X->extra_injection = md->amvpInjection || md->unipred3x3Injection || md->bipred3x3Injection;
     X->improve_sharpness = scs->staticConfig.improveSharpness;
+    X->chroma_weight = pp->predStructure == EB_PRED_RANDOM_ACCESS
+                           ? (pcs->temporalLayerIndex == 0 ? ChromaWeightFactorRaBase[md->qp] : pp->isUsedAsReferenceFlag ? ChromaWeightFactorRaRefNonBase[md->qp]
+                                                                                                                        : ChromaWeightFactorRaNonRef[md->qp])
+                           : (pcs->temporalLayerIndex == 0 ? ChromaWeightFactorLd[md->qp] : ChromaWeightFactorLdQpScaling[md->qp]);
     if (pcs->sliceType == EB_B_PICTURE && pp->isUsedAsReferenceFlag == EB_FALSE) {
         static const EB_U8 th[MAX_TEMPORAL_LAYERS] = {40, 30, 30, 0, 0, 0}; /* INTRA_AREA_TH, EbCodingLoop.c:3864 */
         X->skip_cost_bias = r[0]->intraCodedArea > th[r[0]->tmpLayerIdx] || r[1]->intraCodedArea > th[r[1]->tmpLayerIdx];

@@ -117,7 +117,9 @@ static int fill_work(SvtAmdLcuWork *w, const SequenceControlSet_t *scs, const Pi
     /* the encode loop this record (and the product path) covers: no delta-QP segments, no forced cbf, no coefficient shaping
      * (EbCodingLoop.c:3161, :2377, EbEncDecProcess.c:2211) */
     const EB_BOOL useDeltaQp = (EB_BOOL)(scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled);
-    const int inter_ok = !useDeltaQp && !contextPtr->fastEl && lcuPtr->chromaEncodeMode != CHROMA_MODE_BEST;
+    /* CHROMA_MODE_BEST LCUs: EncodePass itself completes the merge / skip costs of their merge units with chroma (AddChromaEncDec, :3840-3863); their
+     * inter_kind is read from the flags the pass leaves (fill_after) */
+    const int inter_ok = !useDeltaQp && !contextPtr->fastEl;
     if (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE)
         return 0; /* RDOQ (encMode 0) */
     memset(w, 0, sizeof(*w));
@@ -198,6 +200,12 @@ static void fill_after(SvtAmdLcuCu *cus, int n, SvtAmdLcuCuResult *out, const Pi
         const CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[u->leaf_index];
         const TransformUnit_t *tu = &cu->transformUnitArray[0];
         u->qp = (uint8_t)cu->qp;
+        if (u->pred_mode == INTER_MODE && lcuPtr->chromaEncodeMode == CHROMA_MODE_BEST) {
+            /* what the pass decided (:4138-4140): a skipped merge unit leaves with skipFlag set and mergeFlag cleared; a merge unit keeps mergeFlag (and is
+             * marked skipped only when nothing was coded, :4348-4352) */
+            const int merge = cu->predictionUnitArray->mergeFlag, skip = cu->skipFlag;
+            u->inter_kind = skip && !merge ? SVT_AMD_EP_INTER_SKIP : merge ? SVT_AMD_EP_INTER_MERGE : SVT_AMD_EP_INTER_AMVP;
+        }
         const EB_S8 qs = (EB_S8)CLIP3((EB_S8)MIN_QP_VALUE, (EB_S8)MAX_CHROMA_MAP_QP_VALUE, (EB_S8)(cu->qp + pcs->cbQpOffset + pcs->sliceCbQpOffset));
         u->chroma_qp = MapChromaQp((EB_U8)qs);
         /* a 64x64 unit is alone in its LCU: entry 0 = transformUnitArray[0] (the flags of the four units OR-ed), entries 1..4 = its four

@@ -269,9 +269,9 @@ void svt_oracle_full_loop_chroma_cabac(const SvtAmdCabacCost *cost, const SvtAmd
 int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost, const uint8_t *src_y, uint32_t stride,
                           const SvtAmdOisLcuResult *ois, SvtAmdMdLcuOut *out, uint8_t *md_rec);
 int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost,
-                                const uint8_t *src_y, uint32_t stride, const SvtAmdOisLcuResult *ois, const SvtAmdMeLcuResult *me,
-                                const SvtAmdTmvpLcu *tmvp, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, SvtAmdMdLcuOut *out,
-                                uint8_t *md_rec);
+                                const uint8_t *src_y, uint32_t stride, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c,
+                                const SvtAmdOisLcuResult *ois, const SvtAmdMeLcuResult *me, const SvtAmdTmvpLcu *tmvp, const SvtAmdRefPicture *ref0,
+                                const SvtAmdRefPicture *ref1, SvtAmdMdLcuOut *out, uint8_t *md_rec, uint8_t *ep_kind);
 
 /* The coding-unit loop of EncodePass for an LCU of intra 2Nx2N units (svt_oracle_encodepass.c): picture state in / out */
 void svt_oracle_encode_lcu(uint8_t *const rec[3], const uint32_t pitch[3], uint8_t *map, uint32_t mapPitch, uint32_t width, uint32_t height,

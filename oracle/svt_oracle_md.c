@@ -37,8 +37,8 @@ typedef struct MdPic {
     const SvtAmdMeLcuResult *me;
     const SvtAmdTmvpLcu *tmvp;
     const SvtAmdRefPicture *ref[2];
-    const uint8_t *src;
-    uint32_t srcStride;
+    const uint8_t *src, *src_c[2];
+    uint32_t srcStride, srcStrideC;
 } MdPic;
 
 static uint32_t info_at(const MdPic *M, int px, int py)
@@ -146,8 +146,43 @@ static void md_inter_neighbors(const MdPic *M, const SvtAmdMdLcu *L, int lcu_x, 
 }
 
 /* ModeDecisionLcu of one LCU against the picture state M (updated).  src: luma source of the PICTURE. */
+/* AddChromaEncDec (Codec/EbProductCodingLoop.c:4158-4349) + the merge / skip decision of EncodePass (Codec/EbCodingLoop.c:3838-3882) for a merge unit
+ * of the final tree in a CHROMA_MODE_BEST LCU: chroma prediction, chroma full loop, MergeSkipFullCost with the luma terms the mode decision kept */
+static int md_ep_unit_kind(const MdPic *M, const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdCabacCost *cost, const MdCu *u, const MdStats *st,
+                           int lcu_x, int lcu_y)
+{
+    const int N = st->size, Cn = N / 2, x0 = lcu_x + st->x, y0 = lcu_y + st->y;
+    static __thread uint8_t py[64 * 64], pc[2][32 * 32];
+    static __thread int16_t res[2][32 * 32], q[2][32 * 32], rc[2][32 * 32];
+    SvtAmdInterPuJob J;
+    memset(&J, 0, sizeof(J));
+    for (int l = 0; l < 2; l++)
+        J.mv[l][0] = u->mv[l].x, J.mv[l][1] = u->mv[l].y;
+    J.pu_x = (uint16_t)x0, J.pu_y = (uint16_t)y0, J.pu_w = J.pu_h = (uint8_t)N, J.pred_dir = u->inter_dir;
+    svt_oracle_inter_pu(&J, M->ref[0], M->ref[1], py, (uint32_t)N, pc[0], pc[1], (uint32_t)Cn);
+    for (int p = 0; p < 2; p++)
+        for (int j = 0; j < Cn; j++)
+            for (int i = 0; i < Cn; i++)
+                res[p][j * Cn + i] = q[p][j * Cn + i] = (int16_t)(M->src_c[p][(size_t)(y0 / 2 + j) * M->srcStrideC + x0 / 2 + i] - pc[p][j * Cn + i]);
+    SvtAmdChromaLoopIn in;
+    SvtAmdChromaLoopOut o;
+    memset(&in, 0, sizeof(in));
+    in.size = (uint32_t)N, in.cb_qp = in.cr_qp = P->chroma_qp, in.slice_type = P->slice_type, in.pf_mode = (uint32_t)md_pf_mode(P), in.cand_type = MD_INTER;
+    const int16_t *const rp[2] = {res[0], res[1]};
+    int16_t *const qp2[2] = {q[0], q[1]}, *const rcp[2] = {rc[0], rc[1]};
+    svt_oracle_full_loop_chroma(cost, &in, rp, qp2, rcp, &o);
+    const uint64_t bits[2] = {o.coeff_bits[0], o.coeff_bits[1]}, dist[2][2] = {{o.dist[0][0], o.dist[0][1]}, {o.dist[1][0], o.dist[1][1]}};
+    uint64_t mc, sc;
+    md_merge_skip_full_cost(P, M->X, u, N, o.cbf, bits, dist, &mc, &sc);
+    if (g_md_debug)
+        fprintf(stderr, "  ep unit (%d,%d) size %d: cb cbf %u bits %llu dist %llu/%llu cr cbf %u bits %llu dist %llu/%llu -> merge %llu skip %llu\n", st->x, st->y, N, o.cbf[0],
+                (unsigned long long)bits[0], (unsigned long long)dist[0][0], (unsigned long long)dist[0][1], o.cbf[1], (unsigned long long)bits[1],
+                (unsigned long long)dist[1][0], (unsigned long long)dist[1][1], (unsigned long long)mc, (unsigned long long)sc);
+    return md_ep_merge_kind(M->X, L, mc, sc);
+}
+
 static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdCabacCost *cost, const uint8_t *src, uint32_t srcStride,
-                   const SvtAmdOisLcuResult *ois, int lcu_x, int lcu_y, int lcu_index, MdPic *M, MdLcuState *S, SvtAmdMdLcuOut *out)
+                   const SvtAmdOisLcuResult *ois, int lcu_x, int lcu_y, int lcu_index, MdPic *M, MdLcuState *S, SvtAmdMdLcuOut *out, uint8_t *ep_kind)
 {
     /* per depth: the candidate buffers (prediction, reconstructed coefficients) of the unit tested last, and the best candidate's
      * reconstruction (bestCandidateBuffers[depth]->reconPtr), at the unit's position inside the LCU */
@@ -260,7 +295,7 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
         const int nfull = fullCount < bufferTotal ? fullCount : bufferTotal;
         const int pf = md_pf_mode(P);
         uint32_t ycbf[MD_MAX_BUF] = {0}, fullDist[MD_MAX_BUF] = {0};
-        uint64_t mergeCost[MD_MAX_BUF] = {0}, skipCost[MD_MAX_BUF] = {0};
+        uint64_t mergeCost[MD_MAX_BUF] = {0}, skipCost[MD_MAX_BUF] = {0}, yBits[MD_MAX_BUF] = {0}, yDist[MD_MAX_BUF][2] = {{0, 0}};
         static __thread int16_t reconCoeff[MD_MAX_BUF][64 * 64];
         static __thread uint8_t predBuf[MD_MAX_BUF][64 * 64];
         uint32_t prevRootCbf = 1;
@@ -294,6 +329,7 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
             svt_oracle_product_full_loop_luma(cost, &in, residual, quant, reconCoeff[b], &o);
             ycbf[b] = o.ycbf, fullDist[b] = (uint32_t)o.dist[0];
             const uint64_t bits = L->chroma_encode_mode == 2 /* CHROMA_MODE_BEST */ ? md_pf_coeff_bits(pf, P->qp, o.coeff_bits) : o.coeff_bits;
+            yBits[b] = bits, yDist[b][0] = o.dist[0], yDist[b][1] = o.dist[1];
             if (c->type == MD_INTER)
                 B.full_cost[b] = md_inter_full_luma_cost(P, &S->cu[leaf], c, N, o.ycbf, fastLumaRate[B.cand[b]], o.dist, bits, &mergeCost[b], &skipCost[b]);
             else if (islice)
@@ -329,6 +365,8 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
                     u->mv[1] = c->mv[1];
             }
             u->merge_cost = mergeCost[lowest], u->skip_cost = skipCost[lowest];
+            u->y_coeff_bits = yBits[lowest], u->y_dist[0] = yDist[lowest][0], u->y_dist[1] = yDist[lowest][1];
+            u->fast_luma_rate = fastLumaRate[B.cand[lowest]], u->ycbf_mask = ycbf[lowest];
         }
         if (g_md_debug)
             fprintf(stderr, "leaf %d (%d,%d) size %d: %d candidates, %d buffers, full %d -> type %d mode %d cost %llu\n", leaf, st.x, st.y, st.size, ncand,
@@ -380,6 +418,19 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
         else
             cuIdx += md_next_cu_step(L, cuIdx, st.depth);
     } while (cuIdx < L->leaf_count);
+    if (ep_kind) { /* what EncodePass will do with the inter units of the final tree (SVT_AMD_EP_INTER_*; 0xFF: not a final inter unit) */
+        memset(ep_kind, 0xFF, SVT_AMD_MD_LEAVES);
+        for (int it = 0; it < SVT_AMD_MD_LEAVES;) {
+            if (S->cu[it].split) {
+                it++;
+                continue;
+            }
+            const MdStats fs = md_stats(it);
+            if (lcu_x + fs.x < (int)P->width && lcu_y + fs.y < (int)P->height && S->cu[it].pred_mode == MD_INTER)
+                ep_kind[it] = (uint8_t)(S->cu[it].merge_flag ? md_ep_unit_kind(M, P, L, cost, &S->cu[it], &fs, lcu_x, lcu_y) : 0);
+            it += md_depth_offset(fs.depth);
+        }
+    }
     if (out) {
         memset(out, 0, sizeof(*out));
         for (int i = 0; i < SVT_AMD_MD_LEAVES; i++) {
@@ -399,9 +450,9 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
  * per LCU), tmvp (the co-located picture's motion field, one record per LCU, or NULL), ref0 / ref1 (HOST planes in the layout of
  * SvtAmdRefPicture).  Returns 0, or -1 when the picture is outside the covered set. */
 int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost,
-                                const uint8_t *src_y, uint32_t stride, const SvtAmdOisLcuResult *ois, const SvtAmdMeLcuResult *me,
-                                const SvtAmdTmvpLcu *tmvp, const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, SvtAmdMdLcuOut *out,
-                                uint8_t *md_rec)
+                                const uint8_t *src_y, uint32_t stride, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c,
+                                const SvtAmdOisLcuResult *ois, const SvtAmdMeLcuResult *me, const SvtAmdTmvpLcu *tmvp, const SvtAmdRefPicture *ref0,
+                                const SvtAmdRefPicture *ref1, SvtAmdMdLcuOut *out, uint8_t *md_rec, uint8_t *ep_kind)
 {
     const int wl = (P->width + 63) / 64, hl = (P->height + 63) / 64;
     if (X ? !md_picture_supported_inter(P, X) : !md_picture_supported(P))
@@ -418,6 +469,7 @@ int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X
     M.info = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)M.infoPitch * ((M.h + 3) / 4));
     M.mv = (MdMvUnit *)calloc((size_t)M.mvPitch * ((M.h + 7) / 8), sizeof(MdMvUnit));
     M.X = X, M.me = me, M.tmvp = tmvp, M.ref[0] = ref0, M.ref[1] = ref1, M.src = src_y, M.srcStride = stride;
+    M.src_c[0] = src_cb, M.src_c[1] = src_cr, M.srcStrideC = stride_c;
     MdLcuState *S = (MdLcuState *)calloc(1, sizeof(MdLcuState));
     if (!M.rec || !M.info || !M.mv || !S)
         return -2;
@@ -427,7 +479,8 @@ int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X
             const int i = ly * wl + lx;
             if (g_md_debug)
                 fprintf(stderr, "LCU %d (%d,%d)\n", i, lx * 64, ly * 64);
-            md_lcu(P, &lcus[i], cost, src_y, stride, &ois[i], lx * 64, ly * 64, i, &M, S, out ? &out[i] : NULL);
+            md_lcu(P, &lcus[i], cost, src_y, stride, &ois[i], lx * 64, ly * 64, i, &M, S, out ? &out[i] : NULL,
+                   ep_kind && X && src_cb && src_cr ? ep_kind + (size_t)i * SVT_AMD_MD_LEAVES : NULL);
         }
     if (md_rec)
         memcpy(md_rec, M.rec, (size_t)M.w * M.h);
@@ -438,5 +491,5 @@ int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X
 int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost, const uint8_t *src_y, uint32_t stride,
                           const SvtAmdOisLcuResult *ois, SvtAmdMdLcuOut *out, uint8_t *md_rec)
 {
-    return svt_oracle_md_picture_inter(P, NULL, lcus, cost, src_y, stride, ois, NULL, NULL, NULL, NULL, out, md_rec);
+    return svt_oracle_md_picture_inter(P, NULL, lcus, cost, src_y, stride, NULL, NULL, 0, ois, NULL, NULL, NULL, NULL, out, md_rec, NULL);
 }

@@ -85,7 +85,9 @@ struct MdInterShared {
     uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
     EpMcScratch<uint8_t> mc[4];
     uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (merge / skip decision of the encode pass) */
-    unsigned long long ep_merge_cost[SVT_AMD_LCU_MAX_CUS], ep_skip_cost[SVT_AMD_LCU_MAX_CUS];
+    uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
+    uint8_t fin_leaf[SVT_AMD_LCU_MAX_CUS];
+    int nfin;
     __device__ __forceinline__ MdMvUnit *mv_at(int x, int y) { return &mvu[((y >> 3) + 1) * 18 + (x >> 3) + 1]; }
 };
 template <bool INTER> struct MdVariant { typedef MdClosedLoop type; };
@@ -104,7 +106,7 @@ struct MdShared {
     uint8_t types[MD_MAX_BUF], best[MD_MAX_BUF];
     uint32_t ycbf[MD_MAX_BUF];
     MdFl fl[MD_MAX_BUF][4];
-    unsigned long long merge_cost[MD_MAX_BUF], skip_cost[MD_MAX_BUF];
+    unsigned long long merge_cost[MD_MAX_BUF], skip_cost[MD_MAX_BUF], y_bits[MD_MAX_BUF], y_dist[MD_MAX_BUF][2];
     uint32_t full_dist[MD_MAX_BUF];
     int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done, best_first, any_intra;
     int16_t ref[132], reff[132], border[132];
@@ -571,7 +573,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             md_fast_loop_buffers(&M.B, 8, M.max_buffers, ncand, (const uint64_t *)M.costs, M.evaluated);
             bufferTotal = M.B.evaluated_count < bufferTotal ? M.B.evaluated_count : bufferTotal;
             for (int b = 0; b < MD_MAX_BUF; b++)
-                M.types[b] = M.B.cand[b] >= 0 ? M.cand[M.B.cand[b]].type : 0, M.ycbf[b] = 0, M.full_dist[b] = 0, M.merge_cost[b] = M.skip_cost[b] = 0;
+                M.types[b] = M.B.cand[b] >= 0 ? M.cand[M.B.cand[b]].type : 0, M.ycbf[b] = 0, M.full_dist[b] = 0, M.merge_cost[b] = M.skip_cost[b] = 0,
+                M.y_bits[b] = M.y_dist[b][0] = M.y_dist[b][1] = 0;
             const int same = M.B.evaluated_count == bufferTotal;
             M.full_count = md_pre_mode_decision(&M.B, M.types, same ? bufferTotal : M.max_buffers, same, M.best);
             M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
@@ -633,7 +636,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     M.B.full_cost[b] = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
                 else
                     M.B.full_cost[b] = md_intra_full_luma_cost_pslice(&P, N, ycbf, M.fast_rate[ci], dist[0], bits);
-                M.merge_cost[b] = mc, M.skip_cost[b] = sc;
+                M.merge_cost[b] = mc, M.skip_cost[b] = sc, M.y_bits[b] = bits, M.y_dist[b][0] = dist[0], M.y_dist[b][1] = dist[1];
                 if (P.full_loop_escape && !islice && c.type == MD_INTER && M.B.full_cost[b] < bestFullCost)
                     prevRootCbf = ycbf, bestFullCost = M.B.full_cost[b];
             }
@@ -657,6 +660,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         u.mv[1] = c.mv[1];
                 }
                 u.merge_cost = M.merge_cost[lowest], u.skip_cost = M.skip_cost[lowest];
+                u.y_coeff_bits = M.y_bits[lowest], u.y_dist[0] = M.y_dist[lowest][0], u.y_dist[1] = M.y_dist[lowest][1];
+                u.fast_luma_rate = M.fast_rate[M.B.cand[lowest]], u.ycbf_mask = M.ycbf[lowest];
             }
             M.lowest = lowest;
             M.S.local[leaf].mdc_index = (uint8_t)M.cu_idx;
@@ -780,6 +785,89 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
     }
 }
 
+/* one chroma transform unit of FullLoop_R + CuFullDistortionFastTuMode_R on the calling wave -> nz, the two scaled distortions, the bits */
+__device__ __forceinline__ void md_chroma_tu(int lane, int T, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *tile, int16_t *qbuf, const SvtAmdMdPicture &P,
+                                             const SvtAmdCabacCost &cost, int component, int pf, uint32_t *nz, unsigned long long dist[2], unsigned long long *bits)
+{
+    const int pfc = T == 4 ? 0 : (T == 8 && pf == 2 ? 1 : pf); /* correctedPFMode (EbFullLoop.c:647-652) */
+    MdFl o;
+    switch (T) {
+    case 16: o = md_full_loop_unit<16>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, MD_INTER, 0, component, pfc); break;
+    case 8: o = md_full_loop_unit<8>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, MD_INTER, 0, component, pfc); break;
+    default: o = md_full_loop_unit<4>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, MD_INTER, 0, component, pfc); break;
+    }
+    const int lgT = T == 16 ? 4 : T == 8 ? 3 : 2, sh = 2 * (7 - lgT);
+    *nz = o.nz;
+    dist[0] = ((unsigned long long)o.d0 + (1ull << (sh - 1))) >> sh, dist[1] = ((unsigned long long)o.d1 + (1ull << (sh - 1))) >> sh;
+    *bits = (((unsigned long long)o.bits) << 10) >> 15;
+    EP_WAVE_SYNC();
+}
+
+/* what EncodePass will do with the inter units of the LCU's final tree (Codec/EbCodingLoop.c:3838-3882): AMVP units as they are; merge units by the
+ * merge / skip costs completed with chroma (AddChromaEncDec, Codec/EbProductCodingLoop.c:4158-4349: chroma prediction + chroma full loop +
+ * MergeSkipFullCost), a wave per unit.  -> M.V.ep_kind[leaf] */
+__device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, MdShared<true> &M, int lcu_x, int lcu_y)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
+    if (t == 0) {
+        int n = 0, it = 0;
+        while (it < SVT_AMD_MD_LEAVES) {
+            if (M.S.cu[it].split) {
+                it++;
+                continue;
+            }
+            const MdStats st = md_stats(it);
+            if (lcu_x + st.x < (int)P.width && lcu_y + st.y < (int)P.height && M.S.cu[it].pred_mode == MD_INTER) {
+                M.V.ep_kind[it] = M.S.cu[it].merge_flag ? SVT_AMD_EP_INTER_MERGE : SVT_AMD_EP_INTER_AMVP;
+                if (M.S.cu[it].merge_flag && n < SVT_AMD_LCU_MAX_CUS)
+                    M.V.fin_leaf[n++] = (uint8_t)it;
+            }
+            it += md_depth_offset(st.depth);
+        }
+        M.V.nfin = n;
+    }
+    for (int i = t; i < 2 * 32 * 32; i += 256) {
+        const int p = i >> 10, e = i & 1023, y = e >> 5, x = e & 31;
+        uint8_t v = 0;
+        if (x < lw / 2 && y < lh / 2)
+            v = D.src[1 + p][(size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x];
+        M.V.src_c[p][e] = v;
+    }
+    __syncthreads();
+    const int pf = md_pf_mode(&P);
+    for (int i = wave; i < M.V.nfin; i += 4) {
+        const int leaf = M.V.fin_leaf[i];
+        const MdStats st = md_stats(leaf);
+        const MdCu u = M.S.cu[leaf];
+        const int N = st.size, Cn = N >> 1, T = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
+        int16_t mv[2][2];
+        mv[0][0] = u.mv[0].x, mv[0][1] = u.mv[0].y, mv[1][0] = u.mv[1].x, mv[1][1] = u.mv[1].y;
+        uint32_t cbf[2] = {0, 0};
+        uint64_t bits[2] = {0, 0}, dist[2][2] = {{0, 0}, {0, 0}};
+        for (int p = 0; p < 2; p++) {
+            uint8_t *pred = M.V.wpred[wave] + p * 1024;
+            ep_inter_predict_core<uint8_t>(E, lcu_x + st.x, lcu_y + st.y, N, u.inter_dir, mv, 1 + p, lane, M.V.mc[wave], [&](int x, int y) { return pred + y * Cn + x; });
+            EP_WAVE_SYNC();
+            for (int tu = 0; tu < ntu; tu++) {
+                const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
+                uint32_t nz;
+                unsigned long long d[2], b;
+                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, *E.cost, 1 + p, pf,
+                             &nz, d, &b);
+                cbf[p] |= (uint32_t)(nz != 0) << (ntu == 1 ? 0 : tu + 1);
+                bits[p] += b, dist[p][0] += d[0], dist[p][1] += d[1];
+            }
+        }
+        if (lane == 0) {
+            uint64_t mc, sc;
+            md_merge_skip_full_cost(&P, D.X, &u, N, cbf, bits, dist, &mc, &sc);
+            M.V.ep_kind[leaf] = (uint8_t)md_ep_merge_kind(D.X, &M.lcu, mc, sc);
+        }
+    }
+    __syncthreads();
+}
+
 /* the EncDec input contract the decisions amount to (what svt_hook_encdec.c:fill_work builds on the host): the final tree in Z order */
 template <bool INTER>
 __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmdMdPicture &P, const MdShared<INTER> &M, int lcu_x, int lcu_y, SvtAmdLcuWork &Wk)
@@ -809,7 +897,9 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
                 u.qp = P.qp, u.chroma_qp = P.chroma_qp, u.leaf_index = (uint8_t)it, u.inter_dir = 0, u.inter_kind = 0, u.dz_offset = 0;
                 u.mv[0][0] = u.mv[0][1] = u.mv[1][0] = u.mv[1][1] = 0;
                 if (c.pred_mode == MD_INTER) {
-                    u.inter_dir = c.inter_dir, u.inter_kind = c.merge_flag ? SVT_AMD_EP_INTER_MERGE : SVT_AMD_EP_INTER_AMVP;
+                    u.inter_dir = c.inter_dir;
+                    if constexpr (INTER)
+                        u.inter_kind = M.V.ep_kind[it];
                     u.mv[0][0] = c.mv[0].x, u.mv[0][1] = c.mv[0].y, u.mv[1][0] = c.mv[1].x, u.mv[1][1] = c.mv[1].y;
                 }
             }
@@ -862,6 +952,8 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         md_lcu<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
         __syncthreads();
         if (D.encode) {
+            if constexpr (INTER)
+                md_ep_kinds(D, E, P, U.md, lx * 64, ly * 64);
             md_make_work<INTER>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
@@ -1028,7 +1120,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         m->d.X = m->d_X, m->d.me = me ? m->d_me : d_me_slot, m->d.tmvp = m->d_tmvp;
         HIP_TRY(hipMemsetAsync(m->d.md_mv, 0, m->mv_bytes, st));
     }
-    m->d.encode = X ? 0 : 1; /* P / B pictures: this revision returns the decisions; their encode pass follows in its own call */
+    m->d.encode = !X || works || results; /* P / B pictures: without a place for the work / result records, the mode decision alone */
     if (ois)
         HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
     m->d.ois = ois ? m->d_ois : d_ois_slot, m->d.lcus = m->d_lcus, m->d.P = m->d_P, m->d.out = m->d_out;

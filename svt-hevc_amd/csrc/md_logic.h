@@ -97,6 +97,8 @@ typedef struct MdCu {
     uint8_t inter_dir, merge_flag, merge_index, pad; /* PredictionUnit_t.interPredDirectionIndex (3 = intra), .mergeFlag, .mergeIndex */
     MdMv mv[2];                                       /* PredictionUnit_t.mv */
     uint64_t merge_cost, skip_cost;                   /* mdEpPipeLcu[].mergeCost / .skipCost */
+    uint64_t y_coeff_bits, y_dist[2], fast_luma_rate; /* mdEpPipeLcu[].yCoeffBits / .yFullDistortion / .fastLumaRate of a merge winner */
+    uint32_t ycbf_mask, pad2;                         /* mdEpPipeLcu[].yCbf (candidatePtr->yCbf) */
 } MdCu;
 typedef struct MdLcuState {
     MdLocal local[SVT_AMD_MD_LEAVES];
@@ -979,6 +981,47 @@ MD_FN int md_stop_split(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int dept
         return 0;
     const int e = L->edge_block != 0, t = P->temporal_layer > 5 ? 5 : P->temporal_layer;
     return (depth == 0 && fullDistortion < d0[e][t]) || (depth == 1 && fullDistortion < d1[e][t]) || (depth == 2 && fullDistortion < d2[e][t]);
+}
+
+/* MergeSkipFullCost (Codec/EbRateDistortionCost.c:2107-2355) as AddChromaEncDec calls it for the merge unit the mode decision chose in a
+ * CHROMA_MODE_BEST LCU (Codec/EbProductCodingLoop.c:4158-4349): the luma terms the mode decision kept (MdCu) + the chroma loop's sums.
+ * cbf[p] / bits[p] / dist[p][2]: candidatePtr->cbCbf / crCbf, *cbCoeffBits / *crCoeffBits, cb / crFullDistortion. */
+MD_FN void md_merge_skip_full_cost(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const MdCu *cu, int cuSize, const uint32_t cbf[2], const uint64_t bits[2],
+                                   const uint64_t dist[2][2], uint64_t *mergeCost, uint64_t *skipCost)
+{
+    const uint32_t yCbf = cu->ycbf_mask, cbCbf = cbf[0], crCbf = cbf[1];
+    const int rootCbf = yCbf || cbCbf || crCbf;
+    const int lgT = cuSize == 64 ? 5 : (cuSize == 32 ? 5 : (cuSize == 16 ? 4 : 3));
+    uint64_t lumaFlags = 0, chromaFlags = 0;
+    if (rootCbf) {
+        if (cuSize == 64) {
+            chromaFlags += (uint64_t)P->rates.chromaCbfBits[(crCbf > 0) * 5 + 0] + P->rates.chromaCbfBits[(cbCbf > 0) * 5 + 0];
+            for (int tu = 1; tu <= 4; tu++) {
+                lumaFlags += (uint64_t)P->rates.transSubDivFlagBits[5 - lgT] + P->rates.lumaCbfBits[((yCbf >> tu) & 1) * 5 + 0];
+                chromaFlags += crCbf > 0 ? P->rates.chromaCbfBits[((crCbf >> tu) & 1) * 5 + 1] : 0;
+                chromaFlags += cbCbf > 0 ? P->rates.chromaCbfBits[((cbCbf >> tu) & 1) * 5 + 1] : 0;
+            }
+        } else {
+            lumaFlags += P->rates.transSubDivFlagBits[5 - lgT];
+            if (cbCbf > 0 || crCbf > 0)
+                lumaFlags += P->rates.lumaCbfBits[(yCbf > 0) * 5 + 1];
+            chromaFlags += (uint64_t)P->rates.chromaCbfBits[(cbCbf > 0) * 5 + 0] + P->rates.chromaCbfBits[(crCbf > 0) * 5 + 0];
+        }
+    }
+    const uint64_t mergeLumaRate = (uint64_t)P->rates.skipFlagBits[cu->skip_ctx] + P->rates.mergeFlagBits[1] + P->rates.predModeBits[0] +
+                                   P->rates.interPartSizeBits[0] + P->rates.mergeIndexBits[cu->merge_index] + lumaFlags;
+    const uint64_t coeffRate = (cu->y_coeff_bits + bits[0] + bits[1]) << 15;
+    const uint64_t lambda = P->full_lambda, lambdaChroma = P->full_chroma_lambda, w = X->chroma_weight;
+    const uint64_t mergeChroma = ((dist[0][0] + dist[1][0]) * w + 128) >> 8, skipChroma = ((dist[0][1] + dist[1][1]) * w + 128) >> 8;
+    *mergeCost = (cu->y_dist[0] << 8) + mergeChroma + (((lambda * coeffRate + lambda * mergeLumaRate + lambdaChroma * chromaFlags) + (1u << 22)) >> 23);
+    *skipCost = (cu->y_dist[1] << 8) + skipChroma + (((lambda * cu->fast_luma_rate) + (1u << 22)) >> 23);
+}
+/* the merge / skip decision of EncodePass for a merge unit (Codec/EbCodingLoop.c:3838-3882): 2 = SVT_AMD_EP_INTER_SKIP, 1 = _MERGE */
+MD_FN int md_ep_merge_kind(const SvtAmdMdInter *X, const SvtAmdMdLcu *L, uint64_t mergeCost, uint64_t skipCost)
+{
+    if (X->skip_cost_bias && L->variance_below_200)
+        skipCost += (skipCost * 70) / 100;
+    return skipCost <= mergeCost ? 2 : 1;
 }
 
 /* what this revision of the device call covers (include/svt_hevc_amd.h) */

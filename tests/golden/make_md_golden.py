@@ -14,6 +14,7 @@ import tempfile
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import svtlib as S  # noqa: E402
 
 CASES = {
@@ -85,8 +86,11 @@ def run_case(name):
         yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "md.dump")
         S.write_clip(yuv, kind, w, h, n, seed)
         cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + args
-        subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
+        epdump = os.path.join(td, "ep.dump")
+        subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump, SVT_REF_ENCODEPASS_DUMP=epdump), check=True, stdout=subprocess.DEVNULL)
         pics, lcus = parse_dump(open(dump, "rb").read())
+        import make_encodepass_golden as EPG
+        ep_recs, _, _ = EPG.parse_dump(open(epdump, "rb").read(), S.EP_RECORD_DTYPE)
     nl = S.lcu_count(w, h)
     if os.environ.get("MD_GOLDEN_LIST"):  # survey: what the reference derived for every recorded picture
         for p in sorted(pics):
@@ -120,6 +124,18 @@ def run_case(name):
     out["ois"] = np.stack([pics[p][4] for p in numbers])
     out["lcu"] = np.stack([r["lcu"] for r in recs])
     out["out"] = np.stack([r["out"] for r in recs])
+    # what EncodePass did with the inter units of the final trees (EncodePass records of the same run): per leaf SVT_AMD_EP_INTER_*, 0xFF = not an
+    # inter unit of the final tree, 0xFE = the LCU has no EncodePass record
+    epk = np.full((len(numbers), nl, 85), 0xFE, np.uint8)
+    for k, p in enumerate(numbers):
+        for r in ep_recs[ep_recs["picture_number"] == p]:
+            row = epk[k, int(r["lcu_index"])]
+            row[:] = 0xFF
+            n = int(r["work"]["num_cus"])
+            cu = r["work"]["cu"][:n]
+            inter = cu["pred_mode"] == 1
+            row[cu["leaf_index"][inter]] = cu["inter_kind"][inter]
+    out["ep_kind"] = epk
     if any(pics[p][5] is not None for p in numbers):  # P / B pictures: the inter inputs (every kept picture must be one)
         assert all(pics[p][5] is not None for p in numbers)
         out["inter"] = np.stack([pics[p][0]["inter"] for p in numbers])

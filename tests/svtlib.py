@@ -404,7 +404,7 @@ MD_LCU_OUT_DTYPE = np.dtype([("split", "u1", 85), ("tested", "u1", 85), ("pred_m
 MD_TMVP_LCU_DTYPE = np.dtype([("mv", "<i2", (2, 16, 2)), ("ref_poc", "<u8", (2, 16)), ("pred_dir", "u1", 16), ("available", "u1", 16)])
 MD_INTER_DTYPE = np.dtype([("picture_number", "<u8"), ("ref_poc", "<u8", 2), ("colocated_poc", "<u8")] + [(n, "u1") for n in (
     "colocated_pu_ref_list", "is_low_delay", "tmvp_enable", "use_subpel", "unrestricted_mv", "generate_amvp_table_md", "extra_injection",
-    "improve_sharpness", "skip_cost_bias")] + [("pad", "u1", 7)])
+    "improve_sharpness", "skip_cost_bias")] + [("pad", "u1", 3), ("chroma_weight", "<u4")])
 assert MD_LCU_DTYPE.itemsize == 191 and MD_LCU_OUT_DTYPE.itemsize == 3408 and MD_TMVP_LCU_DTYPE.itemsize == 416 and MD_INTER_DTYPE.itemsize == 48
 MD_PIC_MAGIC, MD_LCU_MAGIC = 0x4350444D, 0x434C444D
 MD_PIC_RECORD_DTYPE = np.dtype([("magic", "<u4"), ("record_size", "<u4"), ("picture_number", "<u8"), ("nlcu", "<u4"), ("has_inter", "<u4"),

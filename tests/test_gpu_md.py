@@ -148,6 +148,53 @@ def test_md_of_p_and_b_pictures_matches_the_reference(product, name):
         lib.svt_amd_context_destroy(ctx)
 
 
+@pytest.mark.parametrize("name", INTER_CASES)
+def test_md_and_encode_pass_of_p_and_b_pictures_in_one_call(product, oracle, name):
+    """the same call with the encode pass behind the decisions: the work records (final tree, vectors, and for merge units the merge / skip decision
+    EncodePass makes from the chroma-completed costs - AddChromaEncDec on the device) against the reference's EncodePass records of the same encode,
+    and the encode pass's output against the pinned CPU oracle run on those records in raster order"""
+    from test_oracle_encodepass_golden import inter_oracle_fn
+    from test_oracle_md_golden import inter_inputs, compare_kinds
+    lib = product
+    sig(lib)
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    fn = inter_oracle_fn(oracle, False)
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        for k in range(len(g["picture_number"])):
+            tag = "%s picture %d" % (name, int(g["picture_number"][k]))
+            out, works, res = md_encode_inter(lib, ctx, pic, g, k, encode=True)
+            compare_md(out, g["out"][k], tag)
+            kinds = np.full((len(works), 85), 0xFF, np.uint8)
+            for i in range(len(works)):
+                n = int(works[i]["num_cus"])
+                cu = works[i]["cu"][:n]
+                inter = cu["pred_mode"] == 1
+                kinds[i, cu["leaf_index"][inter]] = cu["inter_kind"][inter]
+                assert np.array_equal(cu["mv"][inter], g["out"][k][i]["mv"][cu["leaf_index"][inter]]), (tag, i)
+                assert np.array_equal(cu["inter_dir"][inter], g["out"][k][i]["inter_dir"][cu["leaf_index"][inter]]), (tag, i)
+            compare_kinds(kinds, g["ep_kind"][k], tag)
+            # the encode pass behind it: the oracle on the device's own work records, raster order
+            X, me, tmvp, refs, planes = inter_inputs(g, k)
+            cost = np.ascontiguousarray(g["cost"][k])
+            pitches = (w + 32, w // 2 + 16, w // 2 + 16)
+            pb = (C.c_uint32 * 3)(*pitches)
+            rec = [np.full((hh, p), 0xA5, np.uint8) for hh, p in zip((h, h // 2, h // 2), pitches)]
+            mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+            rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+            want = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+            for i in range(len(works)):
+                fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, C.byref(refs[0]), C.byref(refs[1]), cost.ctypes.data, works[i:i + 1].ctypes.data,
+                   want[i:i + 1].ctypes.data)
+                compare_lcu(works[i], want[i], res[i], w, h, (tag, i))
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
+
+
 def test_md_encode_picture_reads_the_ois_records_the_front_half_left_in_hbm(product, oracle):
     """ois == NULL: the open-loop intra search of the picture ran on the device (svt_amd_ois_picture) and its records are read where they are"""
     lib = product

@@ -24,12 +24,16 @@ def oracle_md_picture(lib, g, k):
     rec = np.zeros_like(src)
     if "inter" in g.files:
         X, me, tmvp, refs, keep = inter_inputs(g, k)
+        cb, cr = np.ascontiguousarray(g["src_cb"][k]), np.ascontiguousarray(g["src_cr"][k])
+        kinds = np.zeros((len(lcus), 85), np.uint8)
         lib.svt_oracle_md_picture_inter.restype = C.c_int
-        lib.svt_oracle_md_picture_inter.argtypes = [C.c_void_p] * 5 + [C.c_uint32] + [C.c_void_p] * 7
+        lib.svt_oracle_md_picture_inter.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 8
         rc = lib.svt_oracle_md_picture_inter(pic.ctypes.data, X.ctypes.data, lcus.ctypes.data, cost.ctypes.data, src.ctypes.data, src.shape[1],
-                                             ois.ctypes.data, me.ctypes.data, tmvp.ctypes.data if tmvp is not None else None, C.addressof(refs[0]),
-                                             C.addressof(refs[1]), out.ctypes.data, rec.ctypes.data)
+                                             cb.ctypes.data, cr.ctypes.data, cb.shape[1], ois.ctypes.data, me.ctypes.data,
+                                             tmvp.ctypes.data if tmvp is not None else None, C.addressof(refs[0]), C.addressof(refs[1]), out.ctypes.data,
+                                             rec.ctypes.data, kinds.ctypes.data)
         assert rc == 0, rc
+        oracle_md_picture.kinds = kinds
         return out, rec
     lib.svt_oracle_md_picture.restype = C.c_int
     lib.svt_oracle_md_picture.argtypes = [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 3
@@ -76,6 +80,14 @@ def compare_md(got, want, what):
     assert not errs, "%s: %d LCU fields differ, first: %s" % (what, len(errs), errs[:4])
 
 
+def compare_kinds(got, want, what):
+    known = want != 0xFE
+    assert known.any(), what
+    bad = np.argwhere((got != want) & known)
+    assert len(bad) == 0, "%s: %d inter units with another merge / skip decision, first (lcu, leaf): %s got %s want %s" % (
+        what, len(bad), bad[:5].tolist(), [int(got[i, j]) for i, j in bad[:5]], [int(want[i, j]) for i, j in bad[:5]])
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_md_matches_recorded_mode_decisions(name):
     g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
@@ -84,6 +96,8 @@ def test_oracle_md_matches_recorded_mode_decisions(name):
     for k in range(len(g["picture_number"])):
         out, _ = oracle_md_picture(lib, g, k)
         compare_md(out, g["out"][k], "%s picture %d" % (name, int(g["picture_number"][k])))
+        if "inter" in g.files:   # what EncodePass does with the inter units of the final trees: AMVP / merge / skip (its chroma-completed costs)
+            compare_kinds(oracle_md_picture.kinds, g["ep_kind"][k], "%s picture %d" % (name, int(g["picture_number"][k])))
 
 
 # ---- the EncDec input contract the decisions amount to (what the device builds behind its mode decision; test-side restatement) ----
