@@ -1534,6 +1534,8 @@ SVT_AMD_API int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDec
                                                 const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp,
                                                 SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results);
 SVT_AMD_API int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X);
+/* 1 when every one of the n LCUs is decided by ModeDecisionLcu with luma-only candidates (the per-LCU half of the two checks above) */
+SVT_AMD_API int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, int n);
 
 #ifdef __cplusplus
 }

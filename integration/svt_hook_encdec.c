@@ -113,6 +113,7 @@ void EncodePassPackLcu(SequenceControlSet_t *sequenceControlSetPtr, EbPictureBuf
 
 __thread int svt_hook_ep_active;
 static __thread EpServe *t_serve;
+static __thread int t_md_kinds; /* the served LCU's work record comes from the device's mode decision: its inter_kind fields are decisions, not predictions */
 
 static pthread_mutex_t g_ep_lock = PTHREAD_MUTEX_INITIALIZER; /* picture table + lane pool */
 static pthread_cond_t g_ep_cv = PTHREAD_COND_INITIALIZER;
@@ -542,6 +543,30 @@ static void check_inter_kinds(const LargestCodingUnit_t *lcuPtr)
     }
 }
 
+/* AddChromaEncDec (Codec/EbProductCodingLoop.c:4158): EncodePass completes the merge / skip costs of a merge unit of a CHROMA_MODE_BEST LCU with
+ * chroma before it decides (EbCodingLoop.c:3840-3880).  When the LCU was decided AND encoded by the device (svt_amd_md_encode_picture_inter) that
+ * decision is part of the work record: the two costs are set so that the pass reaches it (the 70 % skip-cost bias that may follow keeps the order). */
+void __real_AddChromaEncDec(PictureControlSet_t *pictureControlSetPtr, LargestCodingUnit_t *lcuPtr, CodingUnit_t *cuPtr, ModeDecisionContext_t *contextPtr,
+                            EncDecContext_t *contextPtrED, EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex, EB_U32 cuChromaOriginIndex,
+                            EB_U32 candIdxInput);
+void __wrap_AddChromaEncDec(PictureControlSet_t *pictureControlSetPtr, LargestCodingUnit_t *lcuPtr, CodingUnit_t *cuPtr, ModeDecisionContext_t *contextPtr,
+                            EncDecContext_t *contextPtrED, EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex, EB_U32 cuChromaOriginIndex,
+                            EB_U32 candIdxInput)
+{
+    if (!(svt_hook_ep_active && t_md_kinds)) {
+        __real_AddChromaEncDec(pictureControlSetPtr, lcuPtr, cuPtr, contextPtr, contextPtrED, inputPicturePtr, inputCbOriginIndex, cuChromaOriginIndex, candIdxInput);
+        return;
+    }
+    const SvtAmdLcuWork *w = &t_serve->work;
+    for (int i = 0; i < w->num_cus; i++)
+        if (w->cu[i].leaf_index == cuPtr->leafIndex) {
+            const int skip = w->cu[i].inter_kind == SVT_AMD_EP_INTER_SKIP;
+            contextPtr->mdEpPipeLcu[cuPtr->leafIndex].skipCost = skip ? 0 : 1, contextPtr->mdEpPipeLcu[cuPtr->leafIndex].mergeCost = skip ? 1 : 0;
+            return;
+        }
+    svt_hook_die("mode decision: EncodePass asks for the merge / skip costs of a unit the device did not decide");
+}
+
 void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
                        EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
 {
@@ -575,9 +600,10 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         lane_release(lane);
         __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
         t_serve->lcu = lcuPtr;
-        svt_hook_ep_active = 1;
+        svt_hook_ep_active = 1, t_md_kinds = 1; /* the device made the merge / skip decisions too: AddChromaEncDec is answered from the work record */
         __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
-        svt_hook_ep_active = 0;
+        svt_hook_ep_active = 0, t_md_kinds = 0;
+        check_inter_kinds(lcuPtr);
         picture_lcu_done(root, e, scs, pcs, tbAddr, 1, contextPtr->allowEncDecMismatch);
         return;
     }
@@ -798,7 +824,7 @@ EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
                                     LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr);
 static int g_md_state; /* 0 unknown, 1 on, -1 off */
 static int g_md_verify; /* SVT_HOOK_MD_VERIFY: the reference decides the LCU itself as well and the two trees are compared */
-static unsigned long g_md_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch;
+static unsigned long g_md_pictures, g_md_inter_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch;
 
 /* what ProductFullModeDecision (Codec/EbModeDecision.c:1995-2183) and the loop around it leave in the LCU's coding-unit array, from the
  * device's decision record */
@@ -813,12 +839,23 @@ static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8
         cu->predictionModeFlag = o->pred_mode[i], cu->skipFlag = EB_FALSE, cu->rootCbf = o->ycbf[i] ? EB_TRUE : EB_FALSE;
         PredictionUnit_t *pu = cu->predictionUnitArray;
         pu->intraLumaMode = o->pred_mode[i] == INTRA_MODE ? o->intra_luma_mode[i] : 0x1F;
-        pu->interPredDirectionIndex = 0x03, pu->mergeFlag = EB_FALSE, pu->mergeIndex = 0;
-        pu->mv[REF_LIST_0].x = pu->mv[REF_LIST_0].y = pu->mv[REF_LIST_1].x = pu->mv[REF_LIST_1].y = 0;
+        pu->interPredDirectionIndex = o->inter_dir[i], pu->mergeFlag = o->merge_flag[i] ? EB_TRUE : EB_FALSE, pu->mergeIndex = o->merge_index[i];
+        for (int l = 0; l < 2; l++)
+            pu->mv[l].x = o->mv[i][l][0], pu->mv[l].y = o->mv[i][l][1];
         pu->mvd[REF_LIST_0].predIdx = pu->mvd[REF_LIST_1].predIdx = 0;
         TransformUnit_t *tu = &cu->transformUnitArray[0];
+        if (i == 0) { /* a 64x64 unit: four 32x32 transform units; "exclude chroma from cost calculation" (EbProductCodingLoop.c:4460) leaves the
+                       * candidate's chroma cbf at bit 0 only */
+            tu->splitFlag = EB_TRUE, tu->cbCbf = tu->crCbf = EB_FALSE, tu->cbCbf2 = tu->crCbf2 = EB_FALSE, tu->chromaCbfContext = 0;
+            for (int k = 1; k <= 4; k++) {
+                TransformUnit_t *t4 = &cu->transformUnitArray[k];
+                t4->splitFlag = EB_FALSE, t4->lumaCbf = (o->ycbf[i] >> k) & 1 ? EB_TRUE : EB_FALSE;
+                t4->cbCbf = t4->crCbf = t4->cbCbf2 = t4->crCbf2 = EB_FALSE, t4->chromaCbfContext = 1, t4->lumaCbfContext = 0;
+            }
+            continue;
+        }
         tu->splitFlag = EB_FALSE, tu->lumaCbf = o->ycbf[i] ? EB_TRUE : EB_FALSE;
-        tu->cbCbf = tu->crCbf = EB_TRUE; /* "exclude chroma from cost calculation" (EbProductCodingLoop.c:4460): candidatePtr->cbCbf = crCbf = 1 */
+        tu->cbCbf = tu->crCbf = EB_TRUE; /* candidatePtr->cbCbf = crCbf = 1 */
         tu->cbCbf2 = tu->crCbf2 = EB_FALSE, tu->chromaCbfContext = 0, tu->lumaCbfContext = 1;
     }
 }
@@ -830,8 +867,12 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
                       scs->staticConfig.rateControlMode != 0; /* per-LCU QP / lambda: not in SvtAmdMdPicture */
     SvtAmdMdPicture P;
+    SvtAmdMdInter X;
     svt_md_fill_picture(&P, scs, pcs, md);
-    if (tools || !svt_amd_md_picture_supported(&P)) {
+    const int inter = pcs->sliceType != EB_I_PICTURE;
+    if (inter)
+        svt_md_fill_inter(&X, scs, pcs, md);
+    if (tools || !(inter ? svt_amd_md_picture_supported_inter(&P, &X) : svt_amd_md_picture_supported(&P))) {
         __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
         return;
     }
@@ -851,11 +892,37 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
         svt_md_fill_ois(&ois[i], pcs->ParentPcsPtr, (EB_U32)i);
     }
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
-    if (svt_amd_md_encode_picture(lane, e->pic, &P, lcus, in->bufferY + (size_t)in->originY * in->strideY + in->originX, in->strideY,
-                                  in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2,
-                                  in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2, in->strideCb, ois, 0,
-                                  (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out, e->md_works, e->md_res))
-        svt_hook_die("svt_amd_md_encode_picture");
+    const uint8_t *sy = in->bufferY + (size_t)in->originY * in->strideY + in->originX;
+    const uint8_t *scb = in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2, *scr = in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2;
+    if (!inter) {
+        if (svt_amd_md_encode_picture(lane, e->pic, &P, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out,
+                                      e->md_works, e->md_res))
+            svt_hook_die("svt_amd_md_encode_picture");
+    } else {
+        /* a P / B picture: every LCU must be one ModeDecisionLcu decides with luma-only candidates; the motion-estimation results and the
+         * co-located picture's motion field go up with the call, the reference pictures are resident (picture_entry) */
+        if (!svt_amd_md_lcus_supported(&P, lcus, (int)n)) {
+            free(lcus), free(ois);
+            __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
+            return;
+        }
+        SvtAmdMeLcuResult *me = (SvtAmdMeLcuResult *)malloc(sizeof(SvtAmdMeLcuResult) * n);
+        SvtAmdTmvpLcu *tmvp = X.tmvp_enable ? (SvtAmdTmvpLcu *)malloc(sizeof(SvtAmdTmvpLcu) * n) : NULL;
+        if (!me || (X.tmvp_enable && !tmvp))
+            svt_hook_die("out of memory (mode-decision inter inputs)");
+        const EbReferenceObject_t *col =
+            (const EbReferenceObject_t *)pcs->refPicPtrArray[pcs->sliceType == EB_B_PICTURE ? pcs->colocatedPuRefList : REF_LIST_0]->objectPtr;
+        for (size_t i = 0; i < n; i++) {
+            svt_md_fill_me(&me[i], pcs->ParentPcsPtr, (EB_U32)i);
+            if (tmvp)
+                svt_md_fill_tmvp(&tmvp[i], &col->tmvpMap[i]);
+        }
+        if (svt_amd_md_encode_picture_inter(lane, e->pic, &P, &X, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, me, 0, tmvp, e->md_out, e->md_works,
+                                            e->md_res))
+            svt_hook_die("svt_amd_md_encode_picture_inter");
+        free(me), free(tmvp);
+        __atomic_add_fetch(&g_md_inter_pictures, 1, __ATOMIC_RELAXED);
+    }
     free(lcus), free(ois);
     e->md_ok = 1;
     __atomic_add_fetch(&g_md_pictures, 1, __ATOMIC_RELAXED);
@@ -897,6 +964,11 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
                 continue;
             }
             bad += cu->predictionModeFlag != o->pred_mode[i] || cu->predictionUnitArray->intraLumaMode != o->intra_luma_mode[i];
+            if (cu->predictionModeFlag == INTER_MODE) {
+                const PredictionUnit_t *pu = cu->predictionUnitArray;
+                bad += pu->interPredDirectionIndex != o->inter_dir[i] || pu->mergeFlag != o->merge_flag[i] || pu->mv[0].x != o->mv[i][0][0] ||
+                       pu->mv[0].y != o->mv[i][0][1] || pu->mv[1].x != o->mv[i][1][0] || pu->mv[1].y != o->mv[i][1][1];
+            }
             i += DepthOffset[GetCodedUnitStats(i)->depth];
         }
         __atomic_add_fetch(&g_md_verified, 1, __ATOMIC_RELAXED);
@@ -926,9 +998,9 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
 void svt_hook_encdec_report(FILE *out)
 {
     if (g_md_state > 0)
-        fprintf(out, "svt_hook_me: mode decision: %lu pictures (%lu LCUs) decided AND encoded by ONE device call each (ModeDecisionLcu + EncodePass, no per-candidate "
-                     "call); %lu pictures outside the device call left to the reference code; verification: %lu LCUs compared, %lu differ\n",
-                g_md_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch);
+        fprintf(out, "svt_hook_me: mode decision: %lu pictures (%lu of them P / B; %lu LCUs) decided AND encoded by ONE device call each (ModeDecisionLcu + EncodePass, "
+                     "no per-candidate call); %lu pictures outside the device call left to the reference code; verification: %lu LCUs compared, %lu differ\n",
+                g_md_pictures, g_md_inter_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch);
     if (g_ep_state <= 0)
         return;
     fprintf(out, "svt_hook_me: encode pass: %lu LCUs encoded on the GPU (one call each; %lu of them with inter units, %lu inter units); left to the "

@@ -971,6 +971,15 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
 extern "C" int svt_amd_md_picture_supported(const SvtAmdMdPicture *P) { return P ? md_picture_supported(P) : 0; }
 extern "C" int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X) { return P && X ? md_picture_supported_inter(P, X) : 0; }
+extern "C" int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, int n)
+{
+    if (!P || !lcus)
+        return 0;
+    for (int i = 0; i < n; i++)
+        if (!md_lcu_supported(P, &lcus[i]))
+            return 0;
+    return 1;
+}
 
 /* the mode decision's part of a picture object: neighbour maps, the picture's source and the per-LCU arrays, all in HBM */
 struct SvtAmdMdState {

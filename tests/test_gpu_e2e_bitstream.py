@@ -473,8 +473,15 @@ MD_CASES = [
     ("motion", 1920, 1080, 3, ["-encMode", "10", "-intra-period", "0"], "all"),
     # 2 x 2 tiles
     ("motion", 640, 384, 2, ["-encMode", "9", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
-    # random access: the I picture on the device, the B pictures' mode decision stays with the reference code (their encode pass on the device)
-    ("motion", 640, 384, 6, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], "first"),
+    # random access, encMode 9: the I picture and the non-reference B pictures (open-loop intra, luma-only candidates) on the device - here pictures
+    # 0, 1, 3, 5; the reference B pictures' mode decision (chroma in the loop) stays with the reference code, their encode pass on the device
+    ("motion", 640, 384, 6, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], ("inter", 4, 3)),
+    # encMode 8, three hierarchical levels, moving objects (AMVP, uni- and bi-prediction, merge / skip decisions with chroma): I + 4 of 8 B pictures
+    ("objects", 416, 240, 9, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "28"], ("inter", 5, 4)),
+    # low delay P
+    ("objects", 320, 192, 6, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "2", "-q", "30"], ("inter", None, None)),
+    # noise: intra units inside B pictures
+    ("noise", 320, 256, 5, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "24"], ("inter", None, None)),
     # encMode 6 (chroma in the mode decision, CABAC-context update): outside this revision, every picture left to the reference code
     ("motion", 416, 240, 2, ["-encMode", "6", "-intra-period", "0"], "none"),
 ]
@@ -498,14 +505,17 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
         for k in env:
             del os.environ[k]
     rep = open(str(tmp_path / "report.txt")).read()
-    m = re.search(r"mode decision: (\d+) pictures \((\d+) LCUs\) decided AND encoded by ONE device call each .*?; (\d+) pictures outside the device call", rep)
+    m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\) decided AND encoded by ONE device call each .*?; (\d+) pictures outside the "
+                  r"device call", rep)
     assert m, rep
-    pics, lcus, left = (int(v) for v in m.groups())
+    pics, inter, lcus, left = (int(v) for v in m.groups())
     nl = S.lcu_count(w, h)
     if expect == "all":
         assert pics == n and lcus == n * nl and left == 0, rep
-    elif expect == "first":
-        assert pics == 1 and lcus == nl and left == n - 1, rep  # the P / B pictures' LCUs that reach ModeDecisionLcu (PICT_LCU_SWITCH) stay with the reference code
+    elif isinstance(expect, tuple):
+        assert inter >= 1 and pics == inter + 1 and lcus == pics * nl, rep   # the I picture + the P / B pictures inside the device call
+        if expect[1] is not None:
+            assert pics == expect[1] and inter == expect[2], rep
     else:
         assert pics == 0 and left >= 1, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
