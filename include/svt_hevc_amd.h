@@ -1536,6 +1536,9 @@ SVT_AMD_API int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDec
 SVT_AMD_API int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X);
 /* 1 when every one of the n LCUs is decided by ModeDecisionLcu with luma-only candidates (the per-LCU half of the two checks above) */
 SVT_AMD_API int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, int n);
+/* debug: stage clocks of the mode-decision kernel (16 shader-clock sums per LCU, accumulated over the picture object's later calls; the first call
+ * switches the collection on) - see svt-hevc_amd/csrc/md_kernels.hip */
+SVT_AMD_API int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@
  * Contains no reference source.
  */
 #include <pthread.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -88,9 +89,13 @@ typedef struct {
      * ModeDecisionLcu call; the later calls (and the EncodePass calls) of the picture are answered from these arrays */
     uint64_t md_picture_plus1;   /* picture the arrays below were filled for */
     int md_ok;                   /* 1: served by the device; 0: outside what svt_amd_md_encode_picture covers - the reference code runs */
-    SvtAmdMdLcuOut *md_out;
+    SvtAmdMdLcuOut *md_out;      /* pinned host memory (svt_amd_host_alloc), like the staging arrays below: the picture's records move by DMA */
     SvtAmdLcuWork *md_works;
     SvtAmdLcuResult *md_res;
+    SvtAmdMdLcu *md_lcus;
+    SvtAmdOisLcuResult *md_ois;
+    SvtAmdMeLcuResult *md_me;
+    SvtAmdTmvpLcu *md_tmvp;
 } EpPictureEntry;
 
 typedef struct {
@@ -121,6 +126,8 @@ static EpPictureEntry g_ep_pic[EP_PICTURES];
 static SvtAmdContext *g_ep_lane[EP_LANES];
 static int g_ep_lane_busy[EP_LANES];
 static int g_ep_state; /* 0 unknown, 1 on, -1 off */
+static int g_ep_own;   /* SVT_HOOK_ENCODEPASS itself is set: LCUs of pictures the device's mode decision does not cover are encoded by per-LCU device calls;
+                        * with SVT_HOOK_MD alone those pictures stay with the reference's own EncodePass */
 static int g_ep_verify;  /* SVT_HOOK_ENCODEPASS_VERIFY: the reference encodes the LCU itself after the device call and the two outcomes are compared */
 static int g_ep_refs;    /* SVT_HOOK_ENCODEPASS_REFS: pictures encoded entirely on the device are finished there and become reference pictures */
 static unsigned long g_ep_refs_done, g_ep_refs_skipped;
@@ -158,7 +165,11 @@ static void entry_release(SvtAmdContext *lane, EpPictureEntry *e)
 {
     if (e->pic)
         svt_amd_encdec_picture_destroy(lane, e->pic);
-    free(e->pending), free(e->works_all), free(e->res_all), free(e->sao_enable), free(e->md_out), free(e->md_works), free(e->md_res);
+    free(e->pending), free(e->works_all), free(e->res_all), free(e->sao_enable);
+    void *pinned[] = {e->md_out, e->md_works, e->md_res, e->md_lcus, e->md_ois, e->md_me, e->md_tmvp};
+    for (size_t i = 0; i < sizeof(pinned) / sizeof(pinned[0]); i++)
+        if (pinned[i])
+            svt_amd_host_free(lane, pinned[i]);
     pthread_mutex_destroy(&e->lock);
     memset(e, 0, sizeof(*e));
 }
@@ -182,7 +193,10 @@ void svt_hook_encdec_teardown(void)
 }
 
 /* the device picture of this PictureControlSet_t, begun for its current picture */
-static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide)
+static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide);
+/* prepare == 0: only find (or create) the object; the caller decides whether the picture needs the device at all (SVT_HOOK_MD alone) and calls
+ * picture_prepare itself under the entry's lock */
+static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide, int prepare)
 {
     EpPictureEntry *e = NULL;
     pthread_mutex_lock(&g_ep_lock);
@@ -210,33 +224,40 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
         }
     if (!e)
         svt_hook_die("encode pass: more PictureControlSet_t objects than EP_PICTURES");
-    if (e->picture_plus1 != pcs->pictureNumber + 1) { /* first LCU of a new picture in this object: nothing coded yet */
-        {   /* what the inter units of the picture read: reference pictures + rate tables (also what the PM-core quantiser of an I picture
-             * prices its levels with); complete before other lanes launch: the begin below waits for this lane's stream */
-            SvtAmdRefPicture refs[2];
-            int have[2] = {0, 0};
-            if (pcs->sliceType != EB_I_PICTURE)
-                svt_hook_resident_references(pcs, wide, refs, have);
-            if (svt_amd_encdec_picture_set_inter(lane, e->pic, have[0] ? &refs[0] : NULL, have[1] ? &refs[1] : NULL, (const SvtAmdCabacCost *)pcs->cabacCost))
-                svt_hook_die("svt_amd_encdec_picture_set_inter");
-        }
-        if (svt_amd_encdec_picture_begin(lane, e->pic))
-            svt_hook_die("svt_amd_encdec_picture_begin");
-        e->picture_plus1 = pcs->pictureNumber + 1;
-        e->npending = 0;
-        e->sao_any = e->sao_varies = e->on_device = e->done = 0;
-        if (g_ep_refs) {
-            const size_t wb = wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
-            if (!e->works_all) {
-                e->works_all = malloc(wb * (size_t)e->cap), e->res_all = malloc(rb * (size_t)e->cap), e->sao_enable = (uint8_t *)malloc((size_t)e->cap);
-                if (!e->works_all || !e->res_all || !e->sao_enable)
-                    svt_hook_die("out of memory (encode-pass picture records)");
-            }
-            memset(e->sao_enable, 0, (size_t)e->cap);
-        }
-    }
+    if (prepare)
+        picture_prepare(lane, e, pcs, wide);
     pthread_mutex_unlock(&g_ep_lock);
     return e;
+}
+
+/* first LCU of a new picture in this object: nothing coded yet (under g_ep_lock, or under the entry's lock when the caller holds that) */
+static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide)
+{
+    if (e->picture_plus1 == pcs->pictureNumber + 1)
+        return;
+    {   /* what the inter units of the picture read: reference pictures + rate tables (also what the PM-core quantiser of an I picture
+         * prices its levels with); complete before other lanes launch: the begin below waits for this lane's stream */
+        SvtAmdRefPicture refs[2];
+        int have[2] = {0, 0};
+        if (pcs->sliceType != EB_I_PICTURE)
+            svt_hook_resident_references(pcs, wide, refs, have);
+        if (svt_amd_encdec_picture_set_inter(lane, e->pic, have[0] ? &refs[0] : NULL, have[1] ? &refs[1] : NULL, (const SvtAmdCabacCost *)pcs->cabacCost))
+            svt_hook_die("svt_amd_encdec_picture_set_inter");
+    }
+    if (svt_amd_encdec_picture_begin(lane, e->pic))
+        svt_hook_die("svt_amd_encdec_picture_begin");
+    e->picture_plus1 = pcs->pictureNumber + 1;
+    e->npending = 0;
+    e->sao_any = e->sao_varies = e->on_device = e->done = 0;
+    if (g_ep_refs) {
+        const size_t wb = wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+        if (!e->works_all) {
+            e->works_all = malloc(wb * (size_t)e->cap), e->res_all = malloc(rb * (size_t)e->cap), e->sao_enable = (uint8_t *)malloc((size_t)e->cap);
+            if (!e->works_all || !e->res_all || !e->sao_enable)
+                svt_hook_die("out of memory (encode-pass picture records)");
+        }
+        memset(e->sao_enable, 0, (size_t)e->cap);
+    }
 }
 
 /* EncDec input contract: the coded leaves of the LCU in Z order.  Returns 0 when a unit is outside what the device call covers. */
@@ -574,6 +595,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         g_ep_verify = getenv("SVT_HOOK_ENCODEPASS_VERIFY") != NULL;
         g_ep_refs = getenv("SVT_HOOK_ENCODEPASS_REFS") != NULL;
         g_ep_state = (getenv("SVT_HOOK_ENCODEPASS") || getenv("SVT_HOOK_MD")) ? 1 : -1;
+        g_ep_own = getenv("SVT_HOOK_ENCODEPASS") != NULL;
     }
     if (g_ep_state < 0 || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
         if (g_ep_state > 0)
@@ -585,7 +607,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
     const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
-    EpPictureEntry *e = picture_entry(lane, scs, pcs, wide);
+    EpPictureEntry *e = picture_entry(lane, scs, pcs, wide, g_ep_own);
     const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
     if (!t_serve && !(t_serve = (EpServe *)malloc(sizeof(EpServe))))
         svt_hook_die("out of memory (encode-pass staging)");
@@ -605,6 +627,12 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         svt_hook_ep_active = 0, t_md_kinds = 0;
         check_inter_kinds(lcuPtr);
         picture_lcu_done(root, e, scs, pcs, tbAddr, 1, contextPtr->allowEncDecMismatch);
+        return;
+    }
+    if (!g_ep_own) { /* SVT_HOOK_MD alone: a picture outside the device's mode decision is the reference code's, EncodePass included */
+        lane_release(lane);
+        __atomic_add_fetch(&g_ep_cpu_units, 1, __ATOMIC_RELAXED);
+        __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
         return;
     }
     const int units = !tools && fill_work(&t_serve->work, scs, pcs, lcuPtr, lcuOriginX, lcuOriginY, contextPtr);
@@ -823,6 +851,7 @@ EB_ERRORTYPE __wrap_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countN
 EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
                                     LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr);
 static int g_md_state; /* 0 unknown, 1 on, -1 off */
+static int g_md_skip_intra;
 static int g_md_verify; /* SVT_HOOK_MD_VERIFY: the reference decides the LCU itself as well and the two trees are compared */
 static unsigned long g_md_pictures, g_md_inter_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch;
 
@@ -861,8 +890,17 @@ static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8
 }
 
 /* the picture's ONE device call; under e->lock */
+static double g_md_t_fill, g_md_t_call; /* seconds of host work / of device calls inside md_picture, summed (under the entries' locks: racy sums, a report only) */
+static double md_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSet_t *scs, PictureControlSet_t *pcs, ModeDecisionContext_t *md)
 {
+    const double t_in = md_now();
+    double t_dev = 0;
     e->md_picture_plus1 = pcs->pictureNumber + 1, e->md_ok = 0;
     const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
                       scs->staticConfig.rateControlMode != 0; /* per-LCU QP / lambda: not in SvtAmdMdPicture */
@@ -872,21 +910,19 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     const int inter = pcs->sliceType != EB_I_PICTURE;
     if (inter)
         svt_md_fill_inter(&X, scs, pcs, md);
-    if (tools || !(inter ? svt_amd_md_picture_supported_inter(&P, &X) : svt_amd_md_picture_supported(&P))) {
+    if (tools || (!inter && g_md_skip_intra) || !(inter ? svt_amd_md_picture_supported_inter(&P, &X) : svt_amd_md_picture_supported(&P))) {
         __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
         return;
     }
     const size_t n = (size_t)e->cap;
     if (!e->md_out) {
-        e->md_out = (SvtAmdMdLcuOut *)malloc(sizeof(SvtAmdMdLcuOut) * n), e->md_works = (SvtAmdLcuWork *)malloc(sizeof(SvtAmdLcuWork) * n);
-        e->md_res = (SvtAmdLcuResult *)malloc(sizeof(SvtAmdLcuResult) * n);
-        if (!e->md_out || !e->md_works || !e->md_res)
+        if (svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcuOut) * n, (void **)&e->md_out) || svt_amd_host_alloc(lane, sizeof(SvtAmdLcuWork) * n, (void **)&e->md_works) ||
+            svt_amd_host_alloc(lane, sizeof(SvtAmdLcuResult) * n, (void **)&e->md_res) || svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcu) * n, (void **)&e->md_lcus) ||
+            svt_amd_host_alloc(lane, sizeof(SvtAmdOisLcuResult) * n, (void **)&e->md_ois))
             svt_hook_die("out of memory (mode-decision picture records)");
     }
-    SvtAmdMdLcu *lcus = (SvtAmdMdLcu *)malloc(sizeof(SvtAmdMdLcu) * n);
-    SvtAmdOisLcuResult *ois = (SvtAmdOisLcuResult *)malloc(sizeof(SvtAmdOisLcuResult) * n);
-    if (!lcus || !ois)
-        svt_hook_die("out of memory (mode-decision picture inputs)");
+    SvtAmdMdLcu *lcus = e->md_lcus;
+    SvtAmdOisLcuResult *ois = e->md_ois;
     for (size_t i = 0; i < n; i++) {
         svt_md_fill_lcu(&lcus[i], scs, pcs, pcs->lcuPtrArray[i], md);
         svt_md_fill_ois(&ois[i], pcs->ParentPcsPtr, (EB_U32)i);
@@ -894,6 +930,9 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
     const uint8_t *sy = in->bufferY + (size_t)in->originY * in->strideY + in->originX;
     const uint8_t *scb = in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2, *scr = in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2;
+    if (!inter || svt_amd_md_lcus_supported(&P, lcus, (int)n))
+        picture_prepare(lane, e, pcs, 0); /* the picture is the device's: reference pictures resident, rate tables, a fresh picture object */
+    const double t_c0 = md_now();
     if (!inter) {
         if (svt_amd_md_encode_picture(lane, e->pic, &P, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out,
                                       e->md_works, e->md_res))
@@ -902,14 +941,14 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
         /* a P / B picture: every LCU must be one ModeDecisionLcu decides with luma-only candidates; the motion-estimation results and the
          * co-located picture's motion field go up with the call, the reference pictures are resident (picture_entry) */
         if (!svt_amd_md_lcus_supported(&P, lcus, (int)n)) {
-            free(lcus), free(ois);
             __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
             return;
         }
-        SvtAmdMeLcuResult *me = (SvtAmdMeLcuResult *)malloc(sizeof(SvtAmdMeLcuResult) * n);
-        SvtAmdTmvpLcu *tmvp = X.tmvp_enable ? (SvtAmdTmvpLcu *)malloc(sizeof(SvtAmdTmvpLcu) * n) : NULL;
-        if (!me || (X.tmvp_enable && !tmvp))
+        if (!e->md_me && (svt_amd_host_alloc(lane, sizeof(SvtAmdMeLcuResult) * n, (void **)&e->md_me) ||
+                          svt_amd_host_alloc(lane, sizeof(SvtAmdTmvpLcu) * n, (void **)&e->md_tmvp)))
             svt_hook_die("out of memory (mode-decision inter inputs)");
+        SvtAmdMeLcuResult *me = e->md_me;
+        SvtAmdTmvpLcu *tmvp = X.tmvp_enable ? e->md_tmvp : NULL;
         const EbReferenceObject_t *col =
             (const EbReferenceObject_t *)pcs->refPicPtrArray[pcs->sliceType == EB_B_PICTURE ? pcs->colocatedPuRefList : REF_LIST_0]->objectPtr;
         for (size_t i = 0; i < n; i++) {
@@ -917,14 +956,17 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
             if (tmvp)
                 svt_md_fill_tmvp(&tmvp[i], &col->tmvpMap[i]);
         }
+        const double t_c1 = md_now();
         if (svt_amd_md_encode_picture_inter(lane, e->pic, &P, &X, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, me, 0, tmvp, e->md_out, e->md_works,
                                             e->md_res))
             svt_hook_die("svt_amd_md_encode_picture_inter");
-        free(me), free(tmvp);
+        t_dev = md_now() - t_c1;
         __atomic_add_fetch(&g_md_inter_pictures, 1, __ATOMIC_RELAXED);
     }
-    free(lcus), free(ois);
     e->md_ok = 1;
+    if (!inter)
+        t_dev = md_now() - t_c0;
+    g_md_t_call += t_dev, g_md_t_fill += md_now() - t_in - t_dev;
     __atomic_add_fetch(&g_md_pictures, 1, __ATOMIC_RELAXED);
 }
 
@@ -934,13 +976,14 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
     if (g_md_state == 0) {
         g_md_verify = getenv("SVT_HOOK_MD_VERIFY") != NULL;
         g_md_state = getenv("SVT_HOOK_MD") ? 1 : -1;
+        g_md_skip_intra = getenv("SVT_HOOK_MD") && !strcmp(getenv("SVT_HOOK_MD"), "pb"); /* SVT_HOOK_MD=pb: only P / B pictures go to the device */
     }
     if (g_md_state < 0 || scs->staticConfig.encoderBitDepth != EB_8BIT || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
     svt_hook_note_callback(scs);
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
-    EpPictureEntry *e = picture_entry(lane, scs, pcs, 0);
+    EpPictureEntry *e = picture_entry(lane, scs, pcs, 0, 0);
     pthread_mutex_lock(&e->lock);
     if (e->md_picture_plus1 != pcs->pictureNumber + 1)
         md_picture(lane, e, scs, pcs, contextPtr);
@@ -1001,6 +1044,10 @@ void svt_hook_encdec_report(FILE *out)
         fprintf(out, "svt_hook_me: mode decision: %lu pictures (%lu of them P / B; %lu LCUs) decided AND encoded by ONE device call each (ModeDecisionLcu + EncodePass, "
                      "no per-candidate call); %lu pictures outside the device call left to the reference code; verification: %lu LCUs compared, %lu differ\n",
                 g_md_pictures, g_md_inter_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch);
+    if (g_md_state > 0 && g_md_pictures)
+        fprintf(out, "svt_hook_me: mode decision: per device-decided picture %.1f ms inside the device call (uploads, kernel, downloads), %.1f ms of host work around it "
+                     "(controls, open-loop intra / motion-estimation / motion-field records, reference pictures)\n", 1e3 * g_md_t_call / g_md_pictures,
+                1e3 * g_md_t_fill / g_md_pictures);
     if (g_ep_state <= 0)
         return;
     fprintf(out, "svt_hook_me: encode pass: %lu LCUs encoded on the GPU (one call each; %lu of them with inter units, %lu inter units); left to the "

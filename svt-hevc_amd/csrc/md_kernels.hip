@@ -49,7 +49,16 @@ struct MdPictureDev {
     const SvtAmdMeLcuResult *me;
     const SvtAmdTmvpLcu *tmvp;
     int encode;                   /* 0: mode decision only (no work record, no encode pass) */
+    unsigned long long *prof;     /* debug (svt_amd_debug_md_profile): 16 shader-clock sums per LCU, or null */
 };
+/* stage clocks of the mode decision of one LCU, taken by lane 0 behind the barrier that ends the stage */
+#define MD_PROF(k)                                                          \
+    do {                                                                    \
+        if (D.prof && threadIdx.x == 0) {                                   \
+            const unsigned long long c_ = __builtin_readcyclecounter();    \
+            M.prof[k] += c_ - M.prof_t, M.prof_t = c_;                      \
+        }                                                                   \
+    } while (0)
 
 struct MdLocal8 {
     static constexpr int PY = 144, X0 = 16;
@@ -80,9 +89,13 @@ struct MdClosedLoop {
 };
 struct MdInterShared {
     MdMvUnit mvu[9 * 18];          /* (cy + 1) * 18 + cx + 1: 8x8 cells, cy in [-1, 8), cx in [-1, 16] */
+    SvtAmdMeCuResult me[SVT_AMD_ME_PU_COUNT]; /* the LCU's motion-estimation candidates */
+    SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
     MdMvUnit nb[5];
     MdInterLists T;
     uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
+    uint8_t cpred[8][64 * 64];     /* the fast loop's predictions of the first 8 motion-compensated candidates, kept for the full loop */
+    int8_t slot[MD_MAX_CAND];      /* candidate -> cpred slot, -1 = none */
     EpMcScratch<uint8_t> mc[4];
     uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (merge / skip decision of the encode pass) */
     uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
@@ -98,6 +111,7 @@ struct MdShared {
     MdLocal8 L;
     MdLcuState S;
     SvtAmdMdLcu lcu;
+    SvtAmdOisLcuResult ois;        /* the LCU's open-loop intra search record */
     MdCand cand[MD_MAX_CAND];
     unsigned long long costs[MD_MAX_CAND], fast_rate[MD_MAX_CAND];
     uint32_t sad[MD_MAX_CAND];
@@ -109,6 +123,7 @@ struct MdShared {
     unsigned long long merge_cost[MD_MAX_BUF], skip_cost[MD_MAX_BUF], y_bits[MD_MAX_BUF], y_dist[MD_MAX_BUF][2];
     uint32_t full_dist[MD_MAX_BUF];
     int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done, best_first, any_intra;
+    unsigned long long prof[16], prof_t;
     int16_t ref[132], reff[132], border[132];
     typename MdVariant<INTER>::type V;
     int16_t tiles[4][2 * TxRegTile<32>::UNIT];
@@ -385,6 +400,16 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
     /* ---- the LCU's surroundings into LDS ---- */
     for (int i = t; i < (int)sizeof(SvtAmdMdLcu); i += 256)
         ((uint8_t *)&M.lcu)[i] = ((const uint8_t *)&D.lcus[lcu])[i];
+    static_assert(sizeof(SvtAmdOisLcuResult) % 4 == 0 && sizeof(SvtAmdMeLcuResult) % 4 == 0 && sizeof(SvtAmdMeCuResult) % 4 == 0 && sizeof(SvtAmdTmvpLcu) % 8 == 0, "record sizes");
+    for (int i = t; i < (int)(sizeof(SvtAmdOisLcuResult) / 4); i += 256)
+        ((uint32_t *)&M.ois)[i] = ((const uint32_t *)&D.ois[lcu])[i];
+    if constexpr (INTER) {
+        for (int i = t; i < (int)(sizeof(M.V.me) / 4); i += 256)
+            ((uint32_t *)M.V.me)[i] = ((const uint32_t *)D.me[lcu].pu)[i];
+        if (D.X->tmvp_enable)
+            for (int i = t; i < (int)(2 * sizeof(SvtAmdTmvpLcu) / 4); i += 256)
+                ((uint32_t *)M.V.tmvp)[i] = ((const uint32_t *)&D.tmvp[lcu])[i];
+    }
     for (int i = t; i < 17 * 36; i += 256) {
         const int cy = i / 36 - 1, cx = i - (cy + 1) * 36 - 1;
         uint32_t v = 0xFFFFFFFFu;
@@ -429,7 +454,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         M.cu_idx = 0, M.done = 0;
     }
     __syncthreads();
-    const SvtAmdOisLcuResult *ois = &D.ois[lcu];
+    MD_PROF(0);
+    const SvtAmdOisLcuResult *ois = &M.ois;
     const int pf = md_pf_mode(&P);
     for (;;) {
         /* ---- lane 0: the unit, its contexts and its candidates ---- */
@@ -472,8 +498,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     M.V.nb[k] = u;
                 }
                 const int totalMerge = md_nmm(&P, N);
-                md_amvp_merge_lists(&P, D.X, M.V.nb, D.X->tmvp_enable ? &D.tmvp[lcu] : nullptr, lcu_x + st.x, lcu_y + st.y, N, totalMerge, &M.V.T);
-                ncand = md_inter_candidates(&P, &M.lcu, &D.me[lcu].pu[md_raster_index(&st)], &M.V.T, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), totalMerge,
+                md_amvp_merge_lists(&P, D.X, M.V.nb, D.X->tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, N, totalMerge, &M.V.T);
+                ncand = md_inter_candidates(&P, &M.lcu, &M.V.me[md_raster_index(&st)], &M.V.T, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), totalMerge,
                                             M.cand, ncand);
             }
             int bufferTotal = md_nfl(&P, &M.lcu, st.size);
@@ -501,14 +527,18 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 }
             }
             M.best_first = bestFirst;
+            int slots = 0;
             for (int i = 0; i < ncand; i++) {
                 uint8_t e = (uint8_t)(!M.cand[i].dist_ready || i == bestFirst || P.single_fast_loop);
                 if (e && i == bestFirst && M.cand[i].type == MD_INTRA && open_loop)
                     e = 3; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
                 M.evaluated[i] = e;
+                if constexpr (INTER)
+                    M.V.slot[i] = (int8_t)((e && M.cand[i].type == MD_INTER && slots < 8) ? slots++ : -1);
             }
         }
         __syncthreads();
+        MD_PROF(1);
         const int leaf = M.leaf, ncand = M.ncand;
         const MdStats st = md_stats(leaf);
         const int N = st.size, lgN = st.lg, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
@@ -520,6 +550,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 md_build_refs(M, st, lane);
         }
         __syncthreads();
+        MD_PROF(2);
         /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop) ---- */
         for (int c = wave; c < ncand; c += 4) {
             uint32_t sad = 0;
@@ -531,7 +562,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             } else if (ev && !cd.mpm) {
                 if (cd.type == MD_INTER) {
                     if constexpr (INTER) {
-                        uint8_t *pr = M.V.wpred[wave];
+                        uint8_t *pr = M.V.slot[c] >= 0 ? M.V.cpred[M.V.slot[c]] : M.V.wpred[wave];
                         md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
                         for (int e = lane; e < N * N; e += 64)
                             sad += (uint32_t)abs((int)pr[e] - (int)L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]);
@@ -554,22 +585,25 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 M.sad[c] = sad;
         }
         __syncthreads();
+        MD_PROF(3);
         /* ---- lane 0: fast costs, candidate buffers, PreModeDecision ---- */
+        if (t < ncand) { /* a lane per candidate */
+            const int i = t;
+            unsigned long long rate = 0;
+            uint64_t cst = ~0ull;
+            if (M.evaluated[i]) {
+                const uint64_t dist = M.cand[i].mpm ? 0 : M.sad[i];
+                cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, (uint64_t *)&rate)
+                      : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
+                                                : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate);
+                if (M.cand[i].mpm)
+                    cst = 0;
+            }
+            M.costs[i] = cst, M.fast_rate[i] = rate;
+        }
+        __syncthreads();
         if (t == 0) {
             int bufferTotal = M.buffer_total;
-            for (int i = 0; i < ncand; i++) {
-                unsigned long long rate = 0;
-                uint64_t cst = ~0ull;
-                if (M.evaluated[i]) {
-                    const uint64_t dist = M.cand[i].mpm ? 0 : M.sad[i];
-                    cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, (uint64_t *)&rate)
-                          : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
-                                                    : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate);
-                    if (M.cand[i].mpm)
-                        cst = 0;
-                }
-                M.costs[i] = cst, M.fast_rate[i] = rate;
-            }
             md_fast_loop_buffers(&M.B, 8, M.max_buffers, ncand, (const uint64_t *)M.costs, M.evaluated);
             bufferTotal = M.B.evaluated_count < bufferTotal ? M.B.evaluated_count : bufferTotal;
             for (int b = 0; b < MD_MAX_BUF; b++)
@@ -580,6 +614,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
         }
         __syncthreads();
+        MD_PROF(4);
         /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
         const int nfull = M.nfull;
         for (int f = wave; f < nfull; f += 4) {
@@ -587,7 +622,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             const MdCand cd = M.cand[ci];
             /* the buffer's luma prediction: the candidate the fast loop predicted there, or - predictionIsReadyLuma == 0 - a fresh one */
             const bool fresh = ci == M.best_first && cd.type == MD_INTRA && open_loop && M.evaluated[ci];
-            const MdCand pc = (fresh || M.B.pred[b] < 0) ? cd : M.cand[M.B.pred[b]];
+            const int pci = (fresh || M.B.pred[b] < 0) ? ci : M.B.pred[b];
+            const MdCand pc = M.cand[pci];
             uint8_t *pred;
             int16_t *rc = nullptr;
             if constexpr (INTER) {
@@ -596,8 +632,12 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 pred = M.V.pred[b], rc = M.V.recon_coeff[b];
             }
             if (pc.type == MD_INTER) {
-                if constexpr (INTER)
-                    md_predict_inter(E, pc, x0, y0, N, lane, M.V.mc[wave], pred);
+                if constexpr (INTER) {
+                    if (M.V.slot[pci] >= 0 && M.evaluated[pci])
+                        pred = M.V.cpred[M.V.slot[pci]]; /* the fast loop's prediction of this candidate is still there */
+                    else
+                        md_predict_inter(E, pc, x0, y0, N, lane, M.V.mc[wave], pred);
+                }
             } else {
                 const int mode = pc.intra_mode;
                 const int16_t *use = (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref;
@@ -609,6 +649,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, *E.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
         }
         __syncthreads();
+        MD_PROF(5);
         /* ---- lane 0: TuCalcCostLuma, full cost, ProductFullModeDecision, CheckHighCostPartition ---- */
         if (t == 0) {
             uint32_t prevRootCbf = 1;
@@ -678,6 +719,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 M.update = M.S.cu[M.last].split == 0;
         }
         __syncthreads();
+        MD_PROF(6);
         if constexpr (!INTER) {
             /* ---- wave 0: the winner's reconstruction ---- */
             if (M.do_recon && wave == 0) {
@@ -702,6 +744,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 M.update = M.S.cu[M.last].split == 0;
             }
             __syncthreads();
+            MD_PROF(7);
         }
         /* ---- all lanes: ModeDecisionUpdateNeighborArrays of the unit the decision ended on ---- */
         if (M.update) {
@@ -744,6 +787,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             M.done = cuIdx >= M.lcu.leaf_count;
         }
         __syncthreads();
+        MD_PROF(8);
         if (M.done)
             break;
     }
@@ -919,9 +963,13 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
 }
 
 /* ONE launch per picture: persistent workgroups draw LCUs as tickets in wavefront order (k_encode_picture's scheme, encdec_kernels.hip) */
+/* Two completion flags per LCU: md_done = the LCU's mode-decision state is in the picture's maps (what the mode decision of the right and the lower-left
+ * LCU waits for), done = its encode pass is finished (what their encode pass waits for).  The mode decision of the picture therefore runs ahead of its
+ * encode pass along the wavefront: the critical path of a picture is the mode-decision chain alone. */
 template <bool INTER>
 __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPicture E, SvtAmdLcuWork *__restrict__ works, SvtAmdLcuResult *__restrict__ results,
-                                                           int nlcu, int wl, unsigned *ticket, unsigned *done, const unsigned *__restrict__ order, unsigned epoch)
+                                                           int nlcu, int wl, unsigned *ticket, unsigned *done, unsigned *md_done, const unsigned *__restrict__ order,
+                                                           unsigned epoch)
 {
     extern __shared__ __align__(16) unsigned char md_lds[];
     MdEpShared<INTER> &U = *reinterpret_cast<MdEpShared<INTER> *>(md_lds);
@@ -937,29 +985,65 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         const int lcu = (int)order[s_ticket];
         const int lx = lcu % wl, ly = lcu / wl;
         const SvtAmdMdLcu &Lc = D.lcus[lcu];
+        unsigned long long c_ticket = 0;
+        const int dep0 = Lc.tile_left ? -1 : lcu - 1;
+        const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
         if (threadIdx.x == 0) {
-            const int dep0 = Lc.tile_left ? -1 : lcu - 1;
-            const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
+            c_ticket = D.prof ? __builtin_readcyclecounter() : 0;
             if (dep0 >= 0)
-                while (__hip_atomic_load(&done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(16);
+                while (__hip_atomic_load(&md_done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(8);
             if (dep1 >= 0)
-                while (__hip_atomic_load(&done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(16);
+                while (__hip_atomic_load(&md_done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(8);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        unsigned long long c_wait = 0, c_md = 0, c_work = 0;
+        if (D.prof && threadIdx.x == 0) {
+            c_wait = __builtin_readcyclecounter();
+            for (int k = 0; k < 16; k++)
+                U.md.prof[k] = 0;
+            U.md.prof_t = c_wait;
+        }
         md_lcu<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
         __syncthreads();
+        if (threadIdx.x == 0) { /* the LCU's neighbour state is in the maps: the next LCUs' mode decisions may start */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&md_done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (D.prof && threadIdx.x == 0) {
+            c_md = __builtin_readcyclecounter();
+            unsigned long long *q = D.prof + 16 * (size_t)lcu;
+            for (int k = 0; k < 9; k++)
+                q[k] += U.md.prof[k];
+            q[9] += c_md - U.md.prof_t;      /* the LCU's state leaving LDS */
+            q[12] += c_wait - c_ticket;       /* waiting for the LCU's neighbours */
+            q[15] += 1;
+        }
         if (D.encode) {
             if constexpr (INTER)
                 md_ep_kinds(D, E, P, U.md, lx * 64, ly * 64);
             md_make_work<INTER>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
+            if (threadIdx.x == 0) { /* the encode pass reads the neighbours' reconstruction and mode types */
+                if (dep0 >= 0)
+                    while (__hip_atomic_load(&done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                        __builtin_amdgcn_s_sleep(8);
+                if (dep1 >= 0)
+                    while (__hip_atomic_load(&done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                        __builtin_amdgcn_s_sleep(8);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (D.prof && threadIdx.x == 0)
+                c_work = __builtin_readcyclecounter();
             ep_encode_lcu<uint8_t>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
             __syncthreads();
+            if (D.prof && threadIdx.x == 0) {
+                unsigned long long *q = D.prof + 16 * (size_t)lcu;
+                q[10] += c_work - c_md, q[11] += __builtin_readcyclecounter() - c_work;
+            }
         }
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -992,6 +1076,8 @@ struct SvtAmdMdState {
     SvtAmdLcuWork *d_works;
     SvtAmdLcuResult *d_results;
     size_t info_bytes, mv_bytes;
+    unsigned long long *d_prof;
+    unsigned *d_md_done;           /* epoch of the call whose mode decision finished the LCU */
     /* P / B pictures */
     SvtAmdMdInter *d_X;
     SvtAmdMeLcuResult *d_me;
@@ -1004,7 +1090,7 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
     if (!m)
         return;
     void *ptrs[] = {m->d.md_rec, m->d.md_info, m->d_src[0], m->d_src[1], m->d_src[2], m->d_ois, m->d_lcus, m->d_P, m->d_out, m->d_works, m->d_results,
-                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp};
+                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp, m->d_prof, m->d_md_done};
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
@@ -1036,6 +1122,7 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     m->mv_bytes = sizeof(uint4) * (size_t)m->d.mv_pitch * ((pic->d.height + 7) >> 3);
     ok = ok && hipMalloc((void **)&m->d.md_mv, m->mv_bytes) == hipSuccess && hipMalloc((void **)&m->d_X, sizeof(SvtAmdMdInter)) == hipSuccess &&
          hipMalloc((void **)&m->d_me, sizeof(SvtAmdMeLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_tmvp, sizeof(SvtAmdTmvpLcu) * (n + 1)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&m->d_md_done, sizeof(unsigned) * n) == hipSuccess && hipMemset(m->d_md_done, 0, sizeof(unsigned) * n) == hipSuccess;
     if (!ok) {
         svt_amd_set_error("hipMalloc (mode-decision picture state) failed");
         svt_amd_md_state_free(pic);
@@ -1129,6 +1216,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         m->d.X = m->d_X, m->d.me = me ? m->d_me : d_me_slot, m->d.tmvp = m->d_tmvp;
         HIP_TRY(hipMemsetAsync(m->d.md_mv, 0, m->mv_bytes, st));
     }
+    m->d.prof = m->d_prof;
     m->d.encode = !X || works || results; /* P / B pictures: without a place for the work / result records, the mode decision alone */
     if (ois)
         HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1150,14 +1238,16 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
             attr[ctx->device & 63] = true;
         }
     }
-    int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 1;
-    grid = grid > n ? n : grid > 512 ? 512 : grid;
+    /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
+     * find work (all of them resident: a workgroup that waits holds its CU) */
+    int grid = 2 * ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2;
+    grid = grid > n ? n : grid > 224 ? 224 : grid;
     if (X)
         hipLaunchKernelGGL(k_md_encode_picture<true>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true>), st, m->d, pic->d, m->d_works, m->d_results, n, wl,
-                           pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+                           pic->d_sync, pic->d_sync + 1, m->d_md_done, pic->d_sync + 1 + n, pic->epoch);
     else
         hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n, wl,
-                           pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+                           pic->d_sync, pic->d_sync + 1, m->d_md_done, pic->d_sync + 1 + n, pic->epoch);
     HIP_TRY(hipGetLastError());
     if (md_out)
         HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -1186,4 +1276,29 @@ extern "C" int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDecP
     if (!X)
         return SVT_AMD_ERR_BAD_PARAM;
     return md_encode_picture(ctx, pic, P, X, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, me, me_slot, tmvp, nullptr, md_out, works, results);
+}
+
+/* debug: stage clocks of the mode-decision kernel.  First call (out == NULL or not): switches the collection on for the picture object's later
+ * calls; with out: 16 sums per LCU - [0] the LCU's surroundings into LDS, [1] lane 0: contexts + candidates, [2] the intra reference, [3] fast loop,
+ * [4] lane 0: fast costs + candidate buffers, [5] full loop, [6] lane 0: costs + decision, [7] reconstruction + inter-depth decision, [8] neighbour
+ * update + next unit, [9] state leaving LDS, [10] work record (+ merge / skip decisions), [11] encode pass, [12] waiting for neighbours, [15] calls */
+extern "C" int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out)
+{
+    if (!ctx || !pic)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    SvtAmdMdState *m = nullptr;
+    const int rc = md_state(pic, &m);
+    if (rc)
+        return rc;
+    const size_t bytes = sizeof(unsigned long long) * 16 * (size_t)pic->nlcu;
+    if (!m->d_prof) {
+        HIP_TRY(hipMalloc((void **)&m->d_prof, bytes));
+        HIP_TRY(hipMemset(m->d_prof, 0, bytes));
+    }
+    if (out) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(out, m->d_prof, bytes, hipMemcpyDeviceToHost));
+    }
+    return SVT_AMD_OK;
 }

@@ -28,7 +28,7 @@ def record(w, h, enc_mode, kind="motion", extra=()):
                "-intra-period", "0", "-q", "32"] + list(extra)
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
         pics, lcus = parse_dump(open(dump, "rb").read())
-    h0, y, cb, cr, ois = pics[0]
+    h0, y, cb, cr, ois = pics[0][:5]
     r = lcus[lcus["picture_number"] == 0]
     r = r[np.argsort(r["lcu_index"])]
     return dict(pic=np.array([h0["pic"]]), cost=np.ascontiguousarray(h0["cost"]), y=np.ascontiguousarray(y), cb=np.ascontiguousarray(cb),
@@ -45,26 +45,124 @@ def run(lib, g, reps=5, check=True):
     n = len(g["lcu"])
     out, works, res = np.zeros(n, S.MD_LCU_OUT_DTYPE), np.zeros(n, S.LCU_WORK_DTYPE), np.zeros(n, S.LCU_RESULT_DTYPE)
     ts = []
+    prof = os.environ.get("MD_BENCH_PROFILE")
+    if prof:
+        lib.svt_amd_debug_md_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert lib.svt_amd_debug_md_profile(ctx, pic, None) == 0
     for rep in range(reps + 1):
         t0 = time.perf_counter()
         rc = lib.svt_amd_md_encode_picture(ctx, pic, g["pic"].ctypes.data, g["lcu"].ctypes.data, g["y"].ctypes.data, w, g["cb"].ctypes.data, g["cr"].ctypes.data,
                                            w // 2, g["ois"].ctypes.data, 0, g["cost"].ctypes.data, out.ctypes.data, works.ctypes.data, res.ctypes.data)
         assert rc == 0, lib.svt_amd_last_error()
         ts.append((time.perf_counter() - t0) * 1e3)
+    stages = None
+    if prof:
+        pr = np.zeros((n, 16), np.uint64)
+        assert lib.svt_amd_debug_md_profile(ctx, pic, pr.ctypes.data) == 0
+        names = ["load", "lane0_candidates", "intra_ref", "fast_loop", "lane0_fast_costs", "full_loop", "lane0_decision", "recon_interdepth", "update_next",
+                 "store", "work_record", "encode_pass", "wait_neighbours"]
+        tot = pr[:, :13].sum(axis=0).astype(np.float64)
+        calls = float(pr[:, 15].sum()) / n
+        stages = {nm: round(float(tot[i]) / n / calls, 0) for i, nm in enumerate(names)}   # shader clocks per LCU per call
+        stages["sum_without_wait"] = round(float(tot[:12].sum()) / n / calls, 0)
     if check:
         compare_md(out, g["out"], "%dx%d" % (w, h))
     lib.svt_amd_encdec_picture_destroy(ctx, pic)
     lib.svt_amd_context_destroy(ctx)
     units = int(works["num_cus"].sum())
     tested = int(g["out"]["tested"].sum())
-    return {"width": w, "height": h, "lcus": n, "leaves_tested": tested, "final_units": units, "ms_first_call": round(ts[0], 2),
+    return {"stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "leaves_tested": tested, "final_units": units, "ms_first_call": round(ts[0], 2),
             "ms_per_picture": round(float(np.median(ts[1:])), 2), "pictures_per_s_one_in_flight": round(1e3 / float(np.median(ts[1:])), 2),
             "what": "svt_amd_md_encode_picture through the host-array ABI (source planes, OIS and LCU controls up, decisions + work + result records down), "
                     "decisions identical to the reference's ModeDecisionLcu records of the same picture"}
 
 
+def record_inter(w, h, enc_mode, frames=9, kind="objects", levels=3, extra=()):
+    """a random-access encode of `frames` pictures by the prebuilt reference with the recording harness on; returns the fixture-shaped records of the
+    non-reference B pictures (the pictures svt_amd_md_encode_picture_inter covers)"""
+    with tempfile.TemporaryDirectory() as td:
+        yuv, dump = os.path.join(td, "c.yuv"), os.path.join(td, "md.dump")
+        S.write_clip(yuv, kind, w, h, frames, 7)
+        cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(frames), "-asm", "1", "-b", os.path.join(td, "o.265"), "-encMode", str(enc_mode),
+               "-pred-struct", "2", "-hierarchical-levels", str(levels), "-q", "32"] + list(extra)
+        subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
+        pics, lcus = parse_dump(open(dump, "rb").read())
+    nl = S.lcu_count(w, h)
+    keep = [p for p in sorted(pics) if pics[p][0]["pic"]["slice_type"] != 2 and not pics[p][0]["pic"]["is_reference"] and (lcus["picture_number"] == p).sum() == nl]
+    g = {"picture_number": np.array(keep, np.uint64)}
+    recs = []
+    for p in keep:
+        r = lcus[lcus["picture_number"] == p]
+        recs.append(r[np.argsort(r["lcu_index"])])
+    g["pic"] = np.stack([pics[p][0]["pic"] for p in keep])
+    g["cost"] = np.stack([pics[p][0]["cost"] for p in keep])
+    for i, nm in enumerate(("src_y", "src_cb", "src_cr", "ois")):
+        g[nm] = np.stack([pics[p][1 + i] for p in keep])
+    g["lcu"] = np.stack([r["lcu"] for r in recs])
+    g["out"] = np.stack([r["out"] for r in recs])
+    g["inter"] = np.stack([pics[p][0]["inter"] for p in keep])
+    g["me"] = np.stack([pics[p][5][0] for p in keep])["pu"]
+    g["tmvp_present"] = np.array([pics[p][5][1] is not None for p in keep])
+    g["tmvp"] = np.stack([pics[p][5][1] if pics[p][5][1] is not None else np.zeros(nl, S.MD_TMVP_LCU_DTYPE) for p in keep])
+    g["ref_geom"] = np.stack([np.array([pics[p][0][k] for k in ("ref_stride_y", "ref_stride_c", "ref_origin_x", "ref_origin_y", "ref_width", "ref_height", "nref")],
+                                       np.uint32) for p in keep])
+    for l in range(2):
+        for k, nm in enumerate(("y", "cb", "cr")):
+            g["ref%d_%s" % (l, nm)] = np.stack([pics[p][5][2][min(l, len(pics[p][5][2]) - 1)][k] for p in keep])
+
+    class G(dict):
+        files = property(lambda self: list(self.keys()))
+    return G(g)
+
+
+def run_inter(lib, g, reps=3, encode=True, check=True):
+    """svt_amd_md_encode_picture_inter on every recorded picture: decisions vs the reference's, time per call"""
+    from test_gpu_md import sig, md_encode_inter
+    sig(lib)
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    prof = os.environ.get("MD_BENCH_PROFILE")
+    if prof:
+        lib.svt_amd_debug_md_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert lib.svt_amd_debug_md_profile(ctx, pic, None) == 0
+    ts, tested, units = [], 0, 0
+    for k in range(len(g["picture_number"])):
+        for rep in range(reps):
+            t0 = time.perf_counter()
+            out, works, _ = md_encode_inter(lib, ctx, pic, g, k, encode=encode)
+            if rep:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        if check:
+            compare_md(out, g["out"][k], "%dx%d picture %d" % (w, h, int(g["picture_number"][k])))
+        tested += int(g["out"][k]["tested"].sum())
+        units += int(works["num_cus"].sum())
+    n = g["lcu"].shape[1]
+    stages = None
+    if prof:
+        pr = np.zeros((n, 16), np.uint64)
+        assert lib.svt_amd_debug_md_profile(ctx, pic, pr.ctypes.data) == 0
+        names = ["load", "lane0_candidates", "intra_ref", "fast_loop", "lane0_fast_costs", "full_loop", "lane0_decision", "recon_interdepth", "update_next",
+                 "store", "work_record", "encode_pass", "wait_neighbours"]
+        tot = pr[:, :13].sum(axis=0).astype(np.float64)
+        calls = float(pr[:, 15].sum()) / n
+        stages = {nm: round(float(tot[i]) / n / calls, 0) for i, nm in enumerate(names)}
+        stages["sum_without_wait"] = round(float(tot[:12].sum()) / n / calls, 0)
+    lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    lib.svt_amd_context_destroy(ctx)
+    return {"stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "pictures": [int(p) for p in g["picture_number"]], "leaves_tested_per_picture": tested // len(ts) * (reps - 1) if ts else 0,
+            "final_units": units, "ms_per_picture_incl_host_copies": round(float(np.median(ts)), 2),
+            "what": "svt_amd_md_encode_picture_inter (mode decision%s) of the non-reference B pictures through the host-array ABI incl. reference-picture upload by the test; "
+                    "decisions identical to the reference's ModeDecisionLcu records" % (" + merge / skip decision + encode pass" if encode else " only")}
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
     w, h, m, reps = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (3840, 2160, 7, 5)
-    g = record(w, h, m)
-    print(json.dumps(run(S.load_product(), g, reps)))
+    if len(a) >= 5 and a[4] == "inter":
+        g = record_inter(w, h, m, frames=int(a[5]) if len(a) > 5 else 9)
+        print(json.dumps(run_inter(S.load_product(), g, reps)))
+    else:
+        g = record(w, h, m)
+        print(json.dumps(run(S.load_product(), g, reps)))
