@@ -1072,6 +1072,12 @@ SVT_AMD_API int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture
  * (they run side by side; sizes the persistent grid). */
 SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
                                               SvtAmdLcuResult *d_results, int tiles);
+/* An LCU waits only for what its units read across its border: intra units read the left / top-left / top / top-right LCU's reconstruction
+ * and mode types, inter units nothing (they predict from the reference pictures).  LCUs without an intra unit - most LCUs of a P / B picture -
+ * therefore start at once, on as many workgroups as the device holds.  The host-array calls above count such LCUs themselves; this device-array
+ * form is told: free_lcus = number of LCUs without an intra unit. */
+SVT_AMD_API int svt_amd_encode_picture_device_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
+                                                    SvtAmdLcuResult *d_results, int tiles, int free_lcus);
 
 /* Deblocking behind the encode pass: when every LCU of the picture is encoded, a copy of the device picture (a second set of planes of
  * the picture object; the un-deblocked planes stay as they are) goes through the

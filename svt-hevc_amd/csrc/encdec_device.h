@@ -530,6 +530,27 @@ struct EpShared {
 };
 
 /* the coding-unit loop of one LCU, by one workgroup of 256 threads */
+/* one lane: wait until the LCUs this LCU's units read from are finished (see k_encode_picture), then acquire */
+template <typename WorkT>
+__device__ __forceinline__ void ep_wait_neighbours(const WorkT &W, int lcu, int wl, const unsigned *done, unsigned epoch)
+{
+    bool intra = false;
+    for (int i = 0; i < W.num_cus; i++)
+        intra |= W.cu[i].pred_mode == 2;
+    if (intra) {
+        const int x = W.lcu_x >> 6;
+        const bool right_edge = W.tile_right || x + 1 >= wl;
+        const int dep[4] = {W.tile_left ? -1 : lcu - 1, W.tile_top ? -1 : lcu - wl, (W.tile_top || W.tile_left) ? -1 : lcu - wl - 1,
+                            (W.tile_top || right_edge) ? -1 : lcu - wl + 1};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (dep[k] >= 0)
+                while (__hip_atomic_load(&done[dep[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                    __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* this CU's / XCD's caches drop what they held of the neighbours' samples */
+}
+
 template <typename T>
 __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename EpTypes<T>::Work &W, typename EpTypes<T>::Result &R, EpShared<T> &S, EpLocal<T> &L)
 {

@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void k_encode_lcu(EpPicture P, const typename 
  * (tickets follow the wavefront's anti-diagonals, so a grid as wide as the wavefront stays busy).  A
  * waiting workgroup polls the flags with RELAXED loads (an acquire per poll would drop the XCD's L2 contents every few hundred
  * cycles and starve the workgroups that do the work - measured: 20x slower) and acquires ONCE before it reads its neighbours.
- * done[] holds the epoch of the call that finished the LCU. */
+ * done[] holds the epoch of the call that finished the LCU.
+ * WHAT an LCU waits for is what its units read of their neighbours: only intra units read reconstructed samples and mode types across the LCU
+ * border (left, top-left, top and top-right LCU of the same tile); inter units predict from the reference pictures.  An LCU without intra units
+ * therefore starts at once - in a P / B picture most do, and the wavefront of AssignEncDecSegments (which the reference needs for its
+ * neighbour ARRAYS) degenerates into nearly independent LCUs. */
 template <typename T>
 __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typename EpTypes<T>::Work *__restrict__ works,
                                                         typename EpTypes<T>::Result *__restrict__ results, int nlcu,
@@ -71,19 +75,8 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typen
         const int lcu = (int)order[s_ticket];
         const typename EpTypes<T>::Work &W = works[lcu];
         const unsigned long long w0 = P.prof ? __builtin_readcyclecounter() : 0;
-        if (threadIdx.x == 0) {
-            const int x = W.lcu_x >> 6;
-            /* left: (x-1, y); top-right: (x+1, y-1), or the top LCU in the last column of a tile / picture (EbEncDecProcess.c:1585-1640) */
-            const int dep0 = W.tile_left ? -1 : lcu - 1;
-            const int dep1 = W.tile_top ? -1 : (W.tile_right || x + 1 >= wl) ? lcu - wl : lcu - wl + 1;
-            if (dep0 >= 0)
-                while (__hip_atomic_load(&done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(16);
-            if (dep1 >= 0)
-                while (__hip_atomic_load(&done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(16);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* this CU's / XCD's caches drop what they held of the neighbours' samples */
-        }
+        if (threadIdx.x == 0)
+            ep_wait_neighbours(W, lcu, wl, done, epoch);
         __syncthreads();
         const unsigned long long w1 = P.prof ? __builtin_readcyclecounter() : 0;
         ep_encode_lcu<T>(P, W, results[lcu], S, L);
@@ -295,7 +288,7 @@ extern "C" int svt_amd_encode_lcus16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pi
  * device (k_encode_picture).  d_works / d_results (optional, device) replace the host arrays: nothing crosses PCIe then. */
 template <typename T>
 static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, typename EpTypes<T>::Result *results,
-                          const typename EpTypes<T>::Work *d_works, typename EpTypes<T>::Result *d_results, int parallel_tiles)
+                          const typename EpTypes<T>::Work *d_works, typename EpTypes<T>::Result *d_results, int parallel_tiles, int free_lcus = 0)
 {
     typedef typename EpTypes<T>::Work WorkT;
     typedef typename EpTypes<T>::Result ResultT;
@@ -315,8 +308,13 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
         if (rv)
             return rv;
         parallel_tiles = 0; /* tiles = LCUs that wait for nobody (top-left corners) */
-        for (int i = 0; i < n; i++)
+        for (int i = 0; i < n; i++) {
             parallel_tiles += works[i].tile_left && works[i].tile_top;
+            bool intra = false;
+            for (int k = 0; k < works[i].num_cus; k++)
+                intra |= works[i].cu[k].pred_mode == 2;
+            free_lcus += !intra;
+        }
         uint8_t *d = nullptr;
         const size_t wb = sizeof(WorkT) * (size_t)n, rb = sizeof(ResultT) * (size_t)n, wba = (wb + 255) & ~(size_t)255;
         int rc = svt_amd_ctx_scratch(ctx, wba + rb, &d);
@@ -333,6 +331,8 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
      * own: more workgroups would only poll, and they would hold the CUs other pictures' launches could use */
     const int hl = (pic->d.height + 63) / 64;
     int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (parallel_tiles > 0 ? parallel_tiles : 1) + 1;
+    if (free_lcus * 2 > n) /* a P / B picture: most LCUs have no intra unit and wait for nobody - as many workgroups as the device holds */
+        grid = 512;
     grid = grid > n ? n : grid > 512 ? 512 : grid;
     hipLaunchKernelGGL(k_encode_picture<T>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, d_works, d_results, n, wl, pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
     HIP_TRY(hipGetLastError());
@@ -370,6 +370,14 @@ extern "C" int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPic
     if (!ctx || !pic || !d_works || !d_results || tiles < 1)
         return SVT_AMD_ERR_BAD_PARAM;
     return encode_picture<uint8_t>(ctx, pic, nullptr, nullptr, d_works, d_results, tiles);
+}
+/* the same with the caller's knowledge of the picture: free_lcus = LCUs without an intra unit (they wait for no neighbour; sizes the grid) */
+extern "C" int svt_amd_encode_picture_device_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works, SvtAmdLcuResult *d_results,
+                                                   int tiles, int free_lcus)
+{
+    if (!ctx || !pic || !d_works || !d_results || tiles < 1 || free_lcus < 0)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return encode_picture<uint8_t>(ctx, pic, nullptr, nullptr, d_works, d_results, tiles, free_lcus);
 }
 
 /* ---- deblocking behind the encode pass ------------------------------------------------------------------------------------------ */

@@ -1025,17 +1025,12 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
             if constexpr (INTER)
                 md_ep_kinds(D, E, P, U.md, lx * 64, ly * 64);
             md_make_work<INTER>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
-            if (threadIdx.x == 0) { /* the encode pass reads the neighbours' reconstruction and mode types */
-                if (dep0 >= 0)
-                    while (__hip_atomic_load(&done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                        __builtin_amdgcn_s_sleep(8);
-                if (dep1 >= 0)
-                    while (__hip_atomic_load(&done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                        __builtin_amdgcn_s_sleep(8);
-            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (threadIdx.x == 0) /* the intra units of the encode pass read the neighbours' reconstruction and mode types */
+                ep_wait_neighbours(works[lcu], lcu, wl, done, epoch);
+            __syncthreads();
             if (D.prof && threadIdx.x == 0)
                 c_work = __builtin_readcyclecounter();
             ep_encode_lcu<uint8_t>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);

@@ -520,3 +520,21 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
         assert pics == 0 and left >= 1, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
     assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
+
+
+def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(tmp_path):
+    """BASELINE configs[2] itself (4K, encMode 7, random access, SAO on), 17 pictures: motion estimation + open-loop intra search on the device and,
+    with SVT_HOOK_MD=1, mode decision + encode pass of the I picture and of every non-reference B picture as ONE device call each - the bitstream
+    must be the unmodified reference's"""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(S.ROOT, "tools"))
+    import encoder_fps as E
+    rp = str(tmp_path / "report.txt")
+    r = E.measure("cfg3", frames=17, hip_env={"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": rp}, tmpdir=str(tmp_path))
+    rep = open(rp).read()
+    m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\)", rep)
+    assert m, rep
+    pics, inter, lcus = (int(v) for v in m.groups())
+    assert pics >= 9 and inter >= 8 and lcus == pics * S.lcu_count(3840, 2160), rep
+    assert r["bitstream_identical"], rep

@@ -192,7 +192,7 @@ def random_picture(oracle, w, h, qp, seed, tile_cols=1, tile_rows=1, constrained
     return works, want
 
 
-def random_inter_picture(oracle, w, h, qp, seed, pad=80):    # pad > 75: a window at a clamped position stays inside the plane
+def random_inter_picture(oracle, w, h, qp, seed, pad=80, intra_lcus=1.0):    # pad > 75: a window at a clamped position stays inside the plane
     """a seeded B picture: random unit trees with ~80 % inter units (L0 / L1 / bi, AMVP / merge / skip, whole-LCU 64x64 units, motion vectors
     that reach far outside the picture now and then), two reference pictures, rate tables and per-LCU lambdas spread over three decades -
     and what the CPU oracle makes of it in raster order.  Returns works, want, (reference planes, geometry), cost."""
@@ -224,9 +224,10 @@ def random_inter_picture(oracle, w, h, qp, seed, pad=80):    # pad > 75: a windo
             wk["num_cus"] = 1
             cu = wk["cu"][0]
             cu["x"], cu["y"], cu["size"], cu["bottom_left_ok"], cu["top_right_ok"] = 0, 0, 64, 0, 1
+        p_inter = 0.8 if rng.random() < intra_lcus else 1.1    # intra_lcus < 1: the other LCUs hold inter units only (they wait for no neighbour)
         for i in range(int(wk["num_cus"])):
             cu = wk["cu"][i]
-            if int(cu["size"]) == 64 or rng.random() < 0.8:
+            if int(cu["size"]) == 64 or rng.random() < p_inter:
                 cu["pred_mode"], cu["intra_luma_mode"], cu["dz_offset"] = 1, 0, 0
                 cu["inter_dir"], cu["inter_kind"] = rng.choice([0, 1, 2], p=[0.35, 0.25, 0.4]), rng.choice([0, 1, 2], p=[0.4, 0.4, 0.2])
                 far = rng.random() < 0.06
@@ -256,15 +257,17 @@ def set_inter_random(lib, ctx, pic, refs_geom, cost):
     return keep
 
 
-@pytest.mark.parametrize("w,h,qp,seed", [(832, 480, 30, 11), (1920, 1080, 34, 12)])
-def test_encode_picture_random_b_pictures_match_oracle(product, oracle, w, h, qp, seed):
+@pytest.mark.parametrize("w,h,qp,seed,intra_lcus", [(832, 480, 30, 11, 1.0), (1920, 1080, 34, 12, 1.0), (1920, 1080, 31, 13, 0.12), (3840, 2160, 33, 14, 0.08)])
+def test_encode_picture_random_b_pictures_match_oracle(product, oracle, w, h, qp, seed, intra_lcus):
     """full-size B pictures of random inter / intra units against the oracle in raster order: every fractional position of both filters,
-    clamped positions far outside the picture, bi-prediction, 64x64 units, the luma cbf decision over three decades of lambda"""
+    clamped positions far outside the picture, bi-prediction, 64x64 units, the luma cbf decision over three decades of lambda.  intra_lcus < 1:
+    intra units in few LCUs only, as in the P / B pictures of an encode - the other LCUs wait for no neighbour and the picture is encoded by as
+    many workgroups as the device holds, in no particular order (BASELINE configs[2] size included)"""
     lib = product
     sig_picture(lib)
     ctx = C.c_void_p()
     assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 1, C.byref(ctx)) == 0, lib.svt_amd_last_error()
-    works, want, refs_geom, cost = random_inter_picture(oracle, w, h, qp, seed)
+    works, want, refs_geom, cost = random_inter_picture(oracle, w, h, qp, seed, intra_lcus=intra_lcus)
     cus = np.concatenate([wk["cu"][:int(wk["num_cus"])] for wk in works])
     amvp = (cus["pred_mode"] == 1) & (cus["inter_kind"] == 0) & (cus["size"] < 64)
     res = np.concatenate([r["cu"][:int(wk["num_cus"])] for wk, r in zip(works, want)])

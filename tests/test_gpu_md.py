@@ -244,3 +244,19 @@ def test_md_encode_picture_at_baseline_sizes_matches_the_reference_run_on_the_bo
     g = md_bench.record(w, h, enc_mode)
     r = md_bench.run(product, g, reps=1)
     assert r["lcus"] == S.lcu_count(w, h) and r["final_units"] > r["lcus"]
+
+
+@pytest.mark.parametrize("w,h,enc_mode,frames", [(3840, 2160, 7, 5), (1920, 1080, 8, 5)])
+def test_md_of_b_pictures_at_baseline_sizes_matches_the_reference_run_on_the_box(product, w, h, enc_mode, frames):
+    """BASELINE configs[2] (4K encMode 7 random access) and a 1080p twin: the prebuilt reference encodes `frames` pictures on this box with the
+    recording harness on; mode decision + merge / skip decisions + encode pass of its non-reference B pictures in ONE device call each, the
+    decisions (every tested leaf: split, mode, vectors, merge index, costs) the reference's"""
+    import sys
+    sys.path.insert(0, os.path.join(S.ROOT, "tools"))
+    import md_bench
+    if not os.path.exists(S.REF_APP):
+        pytest.skip("oracle/_ref not built")
+    g = md_bench.record_inter(w, h, enc_mode, frames=frames, levels=2)
+    assert len(g["picture_number"]) >= 2
+    r = md_bench.run_inter(product, g, reps=1, encode=True)
+    assert r["lcus"] == S.lcu_count(w, h) and r["final_units"] >= r["lcus"]

@@ -18,7 +18,8 @@ import svtlib as S  # noqa: E402
 from test_gpu_encodepass import random_tree, z_available  # noqa: E402
 
 
-def works_of(w, h, qp, seed, only=None, inter=0.0):
+def works_of(w, h, qp, seed, only=None, inter=0.0, intra_lcus=1.0):
+    """intra_lcus: fraction of the LCUs that may hold intra units (the others are inter units only, as most LCUs of a real P / B picture)"""
     rng = np.random.default_rng(seed)
     wl, hl = (w + 63) // 64, (h + 63) // 64
     works = np.zeros(wl * hl, S.LCU_WORK_DTYPE)
@@ -37,12 +38,13 @@ def works_of(w, h, qp, seed, only=None, inter=0.0):
             if only is not None:   # Z order inside the LCU
                 tree.sort(key=lambda u: sum((((u[0] >> (3 + b)) & 1) << (2 * b)) | (((u[1] >> (3 + b)) & 1) << (2 * b + 1)) for b in range(3)))
             wk["num_cus"] = len(tree)
+            inter_lcu = inter if rng.random() < intra_lcus else 1.1
             for i, (x, y, s) in enumerate(tree):
                 cu = wk["cu"][i]
                 cu["x"], cu["y"], cu["size"], cu["pred_mode"], cu["intra_luma_mode"] = x, y, s, 2, rng.integers(0, 35)
                 cu["bottom_left_ok"], cu["top_right_ok"] = z_available(x, y, s)
                 cu["qp"], cu["chroma_qp"] = qp, min(qp, 29 + (qp - 29) // 2) if qp > 29 else qp
-                if rng.random() < inter:   # an inter unit: B-picture mix of directions and kinds, motion within +-24 samples (quarter units)
+                if rng.random() < inter_lcu:   # an inter unit: B-picture mix of directions and kinds, motion within +-24 samples (quarter units)
                     cu["pred_mode"], cu["intra_luma_mode"] = 1, 0
                     cu["inter_dir"], cu["inter_kind"] = rng.choice([0, 1, 2], p=[0.4, 0.2, 0.4]), rng.choice([0, 1, 2], p=[0.15, 0.55, 0.3])
                     cu["mv"] = rng.integers(-96, 97, (2, 2))
@@ -57,6 +59,7 @@ def setup(lib):
     vp = C.c_void_p
     lib.svt_amd_encdec_picture_create.argtypes = [vp, C.c_uint16, C.c_uint16, C.c_int, C.POINTER(vp)]
     lib.svt_amd_encode_picture_device.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.svt_amd_encode_picture_device_inter.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
     lib.svt_amd_context_fork.argtypes = [vp, C.POINTER(vp)]
     lib.svt_amd_debug_encdec_profile.argtypes = [vp, vp, vp]
     lib.svt_amd_encdec_picture_set_inter.argtypes = [vp, vp, vp, vp, vp]
@@ -89,9 +92,11 @@ def run_content(lib, root, W, H, works, flights, iters, inter_inputs=None, profi
         lanes.append(lane), pics.append(pic)
     torch.cuda.synchronize()
 
+    free = int(sum(1 for wk in works if not (wk["cu"]["pred_mode"][:int(wk["num_cus"])] == 2).any()))
+
     def go():
         for i in range(flights):
-            assert lib.svt_amd_encode_picture_device(lanes[i], pics[i], dws[i].data_ptr(), drs[i].data_ptr(), 1) == 0, lib.svt_amd_last_error()
+            assert lib.svt_amd_encode_picture_device_inter(lanes[i], pics[i], dws[i].data_ptr(), drs[i].data_ptr(), 1, free) == 0, lib.svt_amd_last_error()
     go()
     for lane in lanes:
         lib.svt_amd_synchronize(lane)
@@ -169,6 +174,9 @@ def measure_b_picture(lib, root, W=3840, H=2160, iters=5):
     nl, units = S.lcu_count(W, H), int(works["num_cus"].sum())
     alone, _ = run_content(lib, root, W, H, works, 1, iters, inputs)
     many, _ = run_content(lib, root, W, H, works, 16, iters, inputs)
+    works_t = works_of(W, H, 32, 9, None, 0.85, 0.1)   # what a B picture of an encode looks like: intra units in few LCUs
+    alone_t, _ = run_content(lib, root, W, H, works_t, 1, iters, inputs)
+    many_t, _ = run_content(lib, root, W, H, works_t, 4, iters, inputs)
     chain = None
     try:
         chain = finish_chain_ms(lib, root, W, H, works, inputs)
@@ -177,7 +185,10 @@ def measure_b_picture(lib, root, W=3840, H=2160, iters=5):
     return {"finished_reference_picture": chain,"content": "%dx%d B picture, random unit trees 8..32, 85 %% inter units (40 %% bi-predicted, random motion within +-24 samples), two "
                        "reference pictures and the work / result arrays resident in HBM: svt_amd_encode_picture_device, ONE launch per picture" % (W, H),
             "lcus": nl, "units": units, "ms_per_picture_alone": round(alone * 1e3, 2), "pictures_per_s_16_in_flight": round(16 / many, 1),
-            "lcus_per_s_16_in_flight": round(16 * nl / many)}
+            "lcus_per_s_16_in_flight": round(16 * nl / many),
+            "intra_units_in_10_percent_of_the_lcus": {"ms_per_picture_alone": round(alone_t * 1e3, 2), "pictures_per_s_4_in_flight": round(4 / many_t, 1),
+                                                      "what": "the same picture with the intra units confined to 10 % of the LCUs: an LCU without intra units waits for no "
+                                                              "neighbour (svt_amd_encode_picture_device_inter)"}}
 
 
 def main():
@@ -190,8 +201,10 @@ def main():
     nl = S.lcu_count(W, H)
     rows = []
     inputs = b_picture_inputs(W, H)
-    for label, only, inter in (("random trees 8..32", None, 0.0), ("all 32x32", 32, 0.0), ("all 8x8", 8, 0.0), ("B picture: random trees, 85 % inter units", None, 0.85)):
-        works = works_of(W, H, 32, 9, only, inter)
+    for label, only, inter, il in (("random trees 8..32", None, 0.0, 1.0), ("all 32x32", 32, 0.0, 1.0), ("all 8x8", 8, 0.0, 1.0),
+                                   ("B picture: random trees, 85 % inter units", None, 0.85, 1.0),
+                                   ("B picture: random trees, inter units; 10 % of the LCUs hold intra units (15 % of theirs)", None, 0.85, 0.1)):
+        works = works_of(W, H, 32, 9, only, inter, il)
         units = int(works["num_cus"].sum())
         for P in (1, 4, 16):
             dt, prof = run_content(lib, root, W, H, works, P, iters, inputs if inter else None, profile=P == 1)
