@@ -170,6 +170,29 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
         shutil.rmtree(td, ignore_errors=True)
 
 
+def closed_loop_leg(enc_cfg, enc, frames=48):
+    """the hooked encoder with SVT_HOOK_MD=pb on the clip of `value` (fewer pictures): fps, md5 against the reference's bitstream of the same
+    `frames` pictures, and the binding's own report of what ran where"""
+    import encoder_fps as E
+    w, h, depth, args = E.CONFIGS[enc_cfg]
+    args = list(args) + ["-asm", "1"]
+    unique = 16
+    td = tempfile.mkdtemp(prefix="svtenc_md_", dir="/tmp")
+    try:
+        yuv = os.path.join(td, "clip.yuv")
+        (S.write_clip10_compressed if depth == 10 else S.write_clip)(yuv, "motion", w, h, unique, 7)
+        ref = E.run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"), nb=unique)
+        rp = os.path.join(td, "report.txt")
+        hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args, os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "pb", "SVT_HOOK_REPORT": rp}, nb=unique)
+        lines = [l.strip() for l in open(rp) if "mode decision" in l] if os.path.exists(rp) else []
+        return {"switches": {"SVT_HOOK_MD": "pb"}, "frames": frames, "fps": hip["fps"], "reference_fps": ref["fps"], "bitstream_identical": hip["md5"] == ref["md5"],
+                "report": lines,
+                "what": "mode decision + merge / skip decisions + encode pass of every non-reference P / B picture on the device, one call per picture; "
+                        "the other pictures' closed loop is the reference code.  Not part of `value`: slower than `value`'s configuration (DESIGN 3.11)"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def cpu_baseline_encoder(cfg, enc):
     """The reference encoder itself on this host's cores (AVX2 tables): the same clip and command line as `value` (timed by
     encoded_fps_leg), plus a bounded single-thread run (-lp 1) for the per-core figure SURVEY 8d asks for."""
@@ -565,6 +588,13 @@ def main():
                 res["cpu_baseline"]["front_half_one_core"] = cpu_baseline_reference(cfg)
             except Exception as e:  # the reference build is absent: say so, do not substitute
                 res["cpu_baseline"] = {"error": str(e)[-300:]}
+        if world == 1 and not a.no_encoder_fps and enc and enc.get("reference", {}).get("md5"):
+            # the closed loop on the device, measured beside `value` (not part of it): the same encode with SVT_HOOK_MD=pb - mode decision + encode pass of
+            # every non-reference P / B picture as ONE device call each, everything else as in `value`
+            try:
+                res["closed_loop_on_device"] = closed_loop_leg(cfg["enc"], enc)
+            except Exception as e:
+                res["closed_loop_on_device"] = {"error": str(e)[-300:]}
         if world == 1 and not a.no_encode_pass:
             # the device-resident encode pass, measured beside the front half: it is not part of `value`
             try:

@@ -157,12 +157,53 @@ def run_inter(lib, g, reps=3, encode=True, check=True):
                     "decisions identical to the reference's ModeDecisionLcu records" % (" + merge / skip decision + encode pass" if encode else " only")}
 
 
+def run_inter_flights(lib, g, flights=2, reps=4):
+    """`flights` pictures in flight: one thread, context and picture object per flight, every thread repeating the device call of picture 0"""
+    import threading
+    from test_gpu_md import sig, md_encode_inter
+    sig(lib)
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    root = C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(root)) == 0, lib.svt_amd_last_error()
+    lib.svt_amd_context_fork.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lanes, pics = [], []
+    for i in range(flights):
+        lane, pic = C.c_void_p(), C.c_void_p()
+        assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_encdec_picture_create(lane, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        lanes.append(lane), pics.append(pic)
+        md_encode_inter(lib, lane, pic, g, 0, encode=True)   # warm-up: allocations
+    times = [[] for _ in range(flights)]
+
+    def work(i):
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            md_encode_inter(lib, lanes[i], pics[i], g, 0, encode=True)
+            times[i].append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(flights)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    for lane, pic in zip(lanes, pics):
+        lib.svt_amd_encdec_picture_destroy(lane, pic)
+        lib.svt_amd_context_destroy(lane)
+    lib.svt_amd_context_destroy(root)
+    return {"flights": flights, "ms_per_call_median": round(float(np.median(np.concatenate(times))), 2), "pictures_per_s": round(flights * reps / wall, 2)}
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
     w, h, m, reps = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (3840, 2160, 7, 5)
     if len(a) >= 5 and a[4] == "inter":
-        g = record_inter(w, h, m, frames=int(a[5]) if len(a) > 5 else 9)
-        print(json.dumps(run_inter(S.load_product(), g, reps)))
+        g = record_inter(w, h, m, frames=int(a[5]) if len(a) > 5 else 9, kind=os.environ.get("MD_BENCH_CLIP", "objects"), levels=2)
+        lib = S.load_product()
+        out = run_inter(lib, g, reps)
+        if os.environ.get("MD_BENCH_FLIGHTS"):
+            out["in_flight"] = [run_inter_flights(lib, g, f) for f in (1, 2, 4)]
+        print(json.dumps(out))
     else:
         g = record(w, h, m)
         print(json.dumps(run(S.load_product(), g, reps)))
