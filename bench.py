@@ -304,6 +304,18 @@ def recon_exchange_leg(lib, root, rank, world, dev, reps=10, limit_s=120.0):
             out.update({"picture": "7680x4320 10-bit 4:2:0 (BASELINE configs[4]), %d x %d tiles over %d ranks" % (cols, rows, world),
                         "bytes_per_picture": total, "ms_per_exchange": round(ms, 3), "correct": bool(ok),
                         "received_GBps_per_gpu": round(total * (world - 1) / world / (ms * 1e-3) / 1e9, 2)})
+            # the closed loop composed across ranks: one 4K B picture in `world` tile columns, a rank per rectangle - encode pass of
+            # the rank's LCUs, all-gather of the finished planes, padding: the next pictures' reference picture is complete on every rank
+            try:
+                import encodepass_bench as EPB
+                tr = EPB.tile_ranks_leg(lib, root, rank, world, barrier=dist.barrier)
+                secs = torch.tensor([tr.pop("seconds_per_picture")], dtype=torch.float64, device=dev)
+                dist.all_reduce(secs, op=dist.ReduceOp.MAX)
+                tr["ms_per_picture_slowest_rank"] = round(float(secs.item()) * 1e3, 2)
+                tr["pictures_per_s"] = round(1.0 / float(secs.item()), 1)
+                out["tile_ranks"] = tr
+            except Exception as e:  # noqa: BLE001
+                out["tile_ranks"] = {"error": str(e)[-300:]}
             lib.svt_amd_comm_destroy.argtypes = [C.c_void_p]
             lib.svt_amd_comm_destroy(root)
         except Exception as e:  # noqa: BLE001 - reported, never fatal for the bench line
@@ -600,8 +612,12 @@ def main():
             try:
                 import encodepass_bench as EPB
                 res["encode_pass"] = EPB.measure_b_picture(S.load_product(), root)
+                # the chain `--gpus N` runs with a rank per tile rectangle (recon_exchange.tile_ranks), here with one rank owning the whole picture
+                tr = EPB.tile_ranks_leg(S.load_product(), root, 0, 1)
+                tr["pictures_per_s"] = round(1.0 / tr.pop("seconds_per_picture"), 1)
+                res["encode_pass"]["tile_ranks_one_rank"] = tr
             except Exception as e:
-                res["encode_pass"] = {"error": str(e)[-300:]}
+                res["encode_pass"] = dict(res.get("encode_pass") or {}, error=str(e)[-300:])
         print(json.dumps(res), flush=True)
 
     if xchg and xchg.get("hung"):

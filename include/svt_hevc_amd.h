@@ -1079,6 +1079,23 @@ SVT_AMD_API int svt_amd_encode_picture_device(SvtAmdContext *ctx, SvtAmdEncDecPi
 SVT_AMD_API int svt_amd_encode_picture_device_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *d_works,
                                                     SvtAmdLcuResult *d_results, int tiles, int free_lcus);
 
+/* Multi-GPU over tiles (tiles are independent inside a picture: EncDec never reads across a tile edge, Codec/EbEncDecProcess.c:2743-2760,
+ * and the in-loop filters do not cross one either - loop_filter_across_tiles_enabled_flag is written 0, Codec/EbEntropyCoding.c:6346-6351).  A rank's
+ * picture:   svt_amd_encode_picture_rect[16]  - works / results as in svt_amd_encode_picture (every LCU's unit list; tile-edge flags), only the LCUs
+ *              inside `rect` (the rank's rectangle of whole tiles, svt_amd_tile_partition) are encoded, on the same device wavefront; the other
+ *              LCUs' results come back zeroed;
+ *            svt_amd_encdec_picture_deblock / _sao as on one GPU (the rank's rectangle comes out finished, the rest is not meaningful);
+ *            svt_amd_encdec_picture_exchange   - the object's latest stage completed across ranks: own rectangle out, the others' in (one
+ *              ncclAllGather, svt_amd_recon_exchange); _pack is its local half for hosts with their own transport (svt_amd_recon_pack);
+ *            svt_amd_encdec_picture_reference  - the now complete picture padded: the next pictures' reference on every rank. */
+SVT_AMD_API int svt_amd_encode_picture_rect(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results,
+                                            const SvtAmdRect *rect);
+SVT_AMD_API int svt_amd_encode_picture_rect16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results,
+                                              const SvtAmdRect *rect);
+SVT_AMD_API int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int rank);
+SVT_AMD_API int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
+                                            size_t slot_bytes, int to_slot);
+
 /* Deblocking behind the encode pass: when every LCU of the picture is encoded, a copy of the device picture (a second set of planes of
  * the picture object; the un-deblocked planes stay as they are) goes through the
  * picture-level boundary-strength and deblocking kernels (svt_amd_bs_picture + svt_amd_dlf_picture: the state the reference's

@@ -32,6 +32,7 @@ struct SvtAmdEncDecPicture {
     size_t plane_bytes[3], map_bytes;
     int device;
     unsigned *d_sync; /* [0] ticket counter, [1 + lcu] epoch of the picture-level call that finished the LCU, then the ticket order */
+    unsigned *d_order_rect; /* ticket order of a rank's rectangle (svt_amd_encode_picture_rect), allocated on first use */
     unsigned epoch;
     int nlcu;
     SvtAmdCabacCost *d_cost;

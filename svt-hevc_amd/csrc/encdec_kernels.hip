@@ -164,6 +164,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
         (void)hipFree(pic->d.mode_map);
     if (pic->d_sync)
         (void)hipFree(pic->d_sync);
+    if (pic->d_order_rect)
+        (void)hipFree(pic->d_order_rect);
     if (pic->d.prof)
         (void)hipFree(pic->d.prof);
     if (pic->d_cost)
@@ -288,7 +290,8 @@ extern "C" int svt_amd_encode_lcus16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pi
  * device (k_encode_picture).  d_works / d_results (optional, device) replace the host arrays: nothing crosses PCIe then. */
 template <typename T>
 static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typename EpTypes<T>::Work *works, typename EpTypes<T>::Result *results,
-                          const typename EpTypes<T>::Work *d_works, typename EpTypes<T>::Result *d_results, int parallel_tiles, int free_lcus = 0)
+                          const typename EpTypes<T>::Work *d_works, typename EpTypes<T>::Result *d_results, int parallel_tiles, int free_lcus = 0,
+                          const SvtAmdRect *rect = nullptr)
 {
     typedef typename EpTypes<T>::Work WorkT;
     typedef typename EpTypes<T>::Result ResultT;
@@ -298,6 +301,39 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
     }
     const int n = pic->nlcu, wl = (pic->d.width + 63) / 64;
     HIP_TRY(hipSetDevice(ctx->device));
+    int n_active = n;
+    const unsigned *d_order = pic->d_sync + 1 + n;
+    if (rect) {
+        /* a rank's share (multi-GPU): only the LCUs of a rectangle of whole tiles are drawn, in the same anti-diagonal order */
+        const int x0 = rect->x / 64, y0 = rect->y / 64, x1 = (rect->x + rect->w + 63) / 64, y1 = (rect->y + rect->h + 63) / 64, hl0 = (pic->d.height + 63) / 64;
+        if ((rect->x & 63) || (rect->y & 63) || !rect->w || !rect->h || x1 > wl || y1 > hl0 || !works) {
+            svt_amd_set_error("svt_amd_encode_picture_rect: the rectangle is not a set of whole LCUs of the picture");
+            return SVT_AMD_ERR_BAD_PARAM;
+        }
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const auto &W = works[y * wl + x];
+                const bool below_own = y + 1 < y1, below_any = y + 1 < hl0;
+                if ((x == x0 && !W.tile_left) || (y == y0 && !W.tile_top) || (x == x1 - 1 && x1 < wl && !W.tile_right) ||
+                    (!below_own && below_any && !works[(y + 1) * wl + x].tile_top)) {
+                    svt_amd_set_error("svt_amd_encode_picture_rect: the rectangle's border at LCU (%d, %d) is not a tile border", x, y);
+                    return SVT_AMD_ERR_BAD_PARAM;
+                }
+            }
+        std::vector<unsigned> order;
+        for (int d = 0; d <= (x1 - x0 - 1) + 2 * (y1 - y0 - 1); d++)
+            for (int y = y0; y < y1; y++) {
+                const int x = x0 + d - 2 * (y - y0);
+                if (x >= x0 && x < x1)
+                    order.push_back((unsigned)(y * wl + x));
+            }
+        n_active = (int)order.size();
+        if (!pic->d_order_rect && hipMalloc((void **)&pic->d_order_rect, sizeof(unsigned) * (size_t)n) != hipSuccess)
+            return SVT_AMD_ERR_RESOURCES;
+        HIP_TRY(hipMemcpyAsync(pic->d_order_rect, order.data(), sizeof(unsigned) * order.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the list is a local */
+        d_order = pic->d_order_rect;
+    }
     if (!d_works) {
         for (int i = 0; i < n; i++)
             if (works[i].lcu_x != (i % wl) * 64 || works[i].lcu_y != (i / wl) * 64) {
@@ -322,6 +358,8 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
             return rc;
         HIP_TRY(hipMemcpyAsync(d, works, wb, hipMemcpyHostToDevice, ctx->stream));
         d_works = (const WorkT *)d, d_results = (ResultT *)(d + wba);
+        if (rect) /* the other ranks' LCUs: nothing coded here (the filters behind the encode pass read every LCU's flags) */
+            HIP_TRY(hipMemsetAsync(d + wba, 0, rb, ctx->stream));
     }
     pic->epoch++;
     pic->deblocked = pic->sao_done = false;
@@ -333,8 +371,8 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
     int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (parallel_tiles > 0 ? parallel_tiles : 1) + 1;
     if (free_lcus * 2 > n) /* a P / B picture: most LCUs have no intra unit and wait for nobody - as many workgroups as the device holds */
         grid = 512;
-    grid = grid > n ? n : grid > 512 ? 512 : grid;
-    hipLaunchKernelGGL(k_encode_picture<T>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, d_works, d_results, n, wl, pic->d_sync, pic->d_sync + 1, pic->d_sync + 1 + n, pic->epoch);
+    grid = grid > n_active ? n_active : grid > 512 ? 512 : grid;
+    hipLaunchKernelGGL(k_encode_picture<T>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, d_works, d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
     if (results)
         HIP_TRY(hipMemcpyAsync(results, d_results, sizeof(ResultT) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -360,6 +398,55 @@ extern "C" int svt_amd_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture 
         return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
+}
+
+/* A rank's share of the picture (multi-GPU over tiles; Codec/EbEncDecProcess.c:2743-2760: EncDec never reads across a tile edge): works /
+ * results as in svt_amd_encode_picture, only the LCUs inside `rect` (a rectangle of whole tiles, svt_amd_tile_partition) are encoded; the
+ * other LCUs' results come back zeroed and their part of the device picture is whatever it was. */
+extern "C" int svt_amd_encode_picture_rect(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork *works, SvtAmdLcuResult *results,
+                                           const SvtAmdRect *rect)
+{
+    if (!ctx || !pic || !works || !results || !rect)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int rc = encode_picture<uint8_t>(ctx, pic, works, results, nullptr, nullptr, 0, 0, rect);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_encode_picture_rect16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results,
+                                             const SvtAmdRect *rect)
+{
+    if (!ctx || !pic || !works || !results || !rect)
+        return SVT_AMD_ERR_BAD_PARAM;
+    int rc = encode_picture<uint16_t>(ctx, pic, works, results, nullptr, nullptr, 0, 0, rect);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* The picture object's latest stage (after SAO, else deblocked, else as encoded) completed across ranks: own rectangle out, everybody else's in
+ * (svt_amd_recon_exchange on the object's planes; call it before svt_amd_encdec_picture_reference pads the picture).  The _pack form is the local
+ * half for hosts with their own transport (svt_amd_recon_pack). */
+extern "C" int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int rank)
+{
+    if (!ctx || !pic || !rects)
+        return SVT_AMD_ERR_BAD_PARAM;
+    uint8_t *const *stage = pic->sao_done ? pic->fin : pic->deblocked ? pic->dbk : pic->d.rec;
+    void *planes[3] = {stage[0], stage[1], stage[2]};
+    const uint32_t pitch[3] = {pic->d.pitch[0] * pic->d.bps, pic->d.pitch[1] * pic->d.bps, pic->d.pitch[2] * pic->d.bps};
+    return svt_amd_recon_exchange(ctx, planes, pitch, (int)pic->d.bps, rects, world, rank);
+}
+extern "C" int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
+                                           size_t slot_bytes, int to_slot)
+{
+    if (!ctx || !pic || !rects)
+        return SVT_AMD_ERR_BAD_PARAM;
+    uint8_t *const *stage = pic->sao_done ? pic->fin : pic->deblocked ? pic->dbk : pic->d.rec;
+    void *planes[3] = {stage[0], stage[1], stage[2]};
+    const uint32_t pitch[3] = {pic->d.pitch[0] * pic->d.bps, pic->d.pitch[1] * pic->d.bps, pic->d.pitch[2] * pic->d.bps};
+    return svt_amd_recon_pack(ctx, planes, pitch, (int)pic->d.bps, rects, world, r, d_slots, slot_bytes, to_slot);
 }
 
 /* Device-resident form: work and result arrays already in HBM (what a device-side mode decision would leave there); asynchronous on

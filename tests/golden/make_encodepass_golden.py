@@ -48,6 +48,9 @@ CASES = {
     "sao_i_noise_200x136_m6": ("noise", 200, 136, 1, 11, ["-encMode", "6", "-intra-period", "0", "-q", "38"]),
     "sao_b_motion_320x192_m6": ("motion", 320, 192, 5, 9, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),
     "sao_tiles_motion_640x384_m7": ("motion", 640, 384, 2, 7, ["-encMode", "7", "-intra-period", "0", "-q", "33", "-tile_col_cnt", "2", "-tile_row_cnt", "2"]),
+    # two tile columns in a random-access encode: the multi-GPU composition (a rank per tile rectangle, tests/test_tile_ranks.py) chains on it
+    "sao_b_tiles_motion_512x320_m6": ("motion", 512, 320, 5, 7, ["-encMode", "6", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "33",
+                                                                 "-tile_col_cnt", "2", "-tile_row_cnt", "1"]),
     "sao_p_noise_320x256_m8": ("noise", 320, 256, 3, 7, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "0", "-intra-period", "-1", "-q", "36"]),
     # encMode 8: allowEncDecMismatch in temporal layers > 0 - those pictures are neither deblocked nor SAO-filtered on the encoder side
     "sao_b_motion_320x192_m8": ("motion", 320, 192, 5, 9, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "2", "-intra-period", "-1", "-q", "34"]),

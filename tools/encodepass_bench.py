@@ -166,6 +166,58 @@ def finish_chain_ms(lib, root, W, H, works, inputs, iters=3):
     return out
 
 
+def tile_ranks_leg(lib, ctx, rank, world, barrier=None, W=3840, H=2160, iters=5):
+    """bench.py --gpus N: ONE 4K B picture cut into `world` tile columns, rank r encoding its rectangle (svt_amd_encode_picture_rect, host-array ABI:
+    every rank uploads the unit lists, downloads its results), then the finished planes all-gathered (svt_amd_encdec_picture_exchange; needs the
+    context's communicator at world > 1) and padded into a reference picture.  Seconds per picture on this rank (the caller takes the max)."""
+    vp = C.c_void_p
+    setup(lib)
+
+    class Rect(C.Structure):
+        _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("w", C.c_uint16), ("h", C.c_uint16)]
+    lib.svt_amd_tile_partition.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(C.c_int)]
+    lib.svt_amd_encode_picture_rect.argtypes = [vp, vp, vp, vp, C.POINTER(Rect)]
+    lib.svt_amd_encdec_picture_exchange.argtypes = [vp, vp, C.POINTER(Rect), C.c_int, C.c_int]
+    lib.svt_amd_encdec_picture_reference.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    rects = (Rect * world)()
+    assert lib.svt_amd_tile_partition(W, H, world, 1, world, rects, None) == 0, lib.svt_amd_last_error()
+    works = works_of(W, H, 32, 9, None, 0.85, 0.1)
+    wl = (W + 63) // 64
+    starts = {c * wl // world for c in range(world)}     # the reference's uniform tile grid (EbPictureControlSet.c:743)
+    for wk in works:
+        lx = int(wk["lcu_x"]) // 64
+        wk["tile_left"], wk["tile_right"] = lx in starts, (lx + 1 in starts) or lx == wl - 1
+    inputs = b_picture_inputs(W, H)
+    nl = S.lcu_count(W, H)
+    pic = vp()
+    assert lib.svt_amd_encdec_picture_create(ctx, W, H, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    _, refs, cost = inputs
+    assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, C.byref(refs[0]), C.byref(refs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
+    res = np.zeros(nl, S.LCU_RESULT_DTYPE)
+    ref = S.RefPicture()
+    t = {"encode": 0.0, "exchange": 0.0, "pad": 0.0}
+    for it in range(iters + 1):
+        if barrier:
+            barrier()
+        t0 = time.perf_counter()
+        assert lib.svt_amd_encode_picture_rect(ctx, pic, works.ctypes.data, res.ctypes.data, C.byref(rects[rank])) == 0, lib.svt_amd_last_error()
+        t1 = time.perf_counter()
+        assert lib.svt_amd_encdec_picture_exchange(ctx, pic, rects, world, rank) == 0, lib.svt_amd_last_error()
+        lib.svt_amd_synchronize(ctx)
+        t2 = time.perf_counter()
+        assert lib.svt_amd_encdec_picture_reference(ctx, pic, 80, 80, C.byref(ref), None, None, None) == 0, lib.svt_amd_last_error()
+        t3 = time.perf_counter()
+        if it:
+            t["encode"] += t1 - t0
+            t["exchange"] += t2 - t1
+            t["pad"] += t3 - t2
+    lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    mine = sum(1 for wk in works if rects[rank].x <= int(wk["lcu_x"]) < rects[rank].x + rects[rank].w)
+    return {"picture": "%dx%d B picture, %d tile columns over %d ranks" % (W, H, world, world), "lcus_of_this_rank": mine, "lcus": nl,
+            "encode_ms": round(t["encode"] / iters * 1e3, 2), "exchange_ms": round(t["exchange"] / iters * 1e3, 2), "pad_ms": round(t["pad"] / iters * 1e3, 2),
+            "seconds_per_picture": sum(t.values()) / iters}
+
+
 def measure_b_picture(lib, root, W=3840, H=2160, iters=5):
     """bench.py's `encode_pass` leg: a 4K B picture of random unit trees, 85 % inter units, alone and 16 in flight"""
     setup(lib)
