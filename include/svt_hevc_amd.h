@@ -1096,6 +1096,51 @@ SVT_AMD_API int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDec
 SVT_AMD_API int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
                                             size_t slot_bytes, int to_slot);
 
+/*
+ * Entropy hand-off pre-scan.  What EncodeQuantizedCoefficients (Codec/EbEntropyCoding.c:1172; callers EncodeCoeff :4069,
+ * EncodeTuCoeff :4210) does with a transform block BEFORE it codes a single bin is data parallel and needs nothing but the block: the mode-dependent
+ * scan (:1347-1372), the coefficients re-ordered by sub-block and scan with a significance map per 4x4 sub-block (:1378-1430), the last
+ * significant position (:1432-1461) - and the sign / greater-than-1 patterns its level loop derives from the same values (:1532-1600).  The device
+ * holds every quantizedCoeff after the encode pass, so it hands the entropy coder these instead of 3 * W * H / 2 bytes of s16 planes:
+ *   per transform block  SvtAmdCoeffScanTu (8 B): scan, last sub-block, last position, DC-only fast track (:1308), where its sub-blocks start;
+ *   per 4x4 sub-block    SvtAmdCoeffScanGroup (8 B), sub-blocks lastScanSet .. 0 in CODING order (empty ones too: their coded_sub_block_flag is
+ *                        coded): significance map in forward scan order, sign bits and |level| > 1 flags of the coded coefficients (CODING
+ *                        order = set bits of the map from the highest position down; first coded coefficient in the top bit of `sign`, in bit 0
+ *                        of `gt1`), index of its first level;
+ *   per coefficient      its absolute level (u16), non-zero coefficients only, CODING order.
+ * The CABAC loop that consumes them codes exactly the reference's bins: integration/svt_coeff_scan_consumer.h.
+ * Blocks: slot c of component p = the unit at position c of SvtAmdLcuWork.cu (luma: the unit's size; chroma: half of it, 4x4 for an 8x8
+ * unit); a 64x64 unit's four transform units are slots 1..4 (as in SvtAmdLcuResult.cu).  last_scan_set = -1: nothing to code (cbf 0).
+ */
+typedef struct SvtAmdCoeffScanTu {
+    uint8_t scan_index;            /* SCAN_DIAG2 0 / SCAN_HOR2 1 / SCAN_VER2 2 (Codec/EbEntropyCodingUtil.h:43)                   */
+    int8_t last_scan_set;          /* lastScanSet; -1 = no non-zero coefficient                                                   */
+    uint8_t pos_last;              /* posLast: scan position of the last significant coefficient inside that sub-block            */
+    uint8_t last_x, last_y;        /* lastSigXPos / lastSigYPos as EncodeLastSignificantXY takes them (swapped for SCAN_HOR2 / _VER2) */
+    uint8_t dc_only;               /* numNonZeroCoeffs == 1 && coeff[0] != 0: the fast track of :1308-1344 (one group, one level)  */
+    uint16_t first_group;          /* index of the block's first group in the LCU's group list                                    */
+} SvtAmdCoeffScanTu;
+typedef struct SvtAmdCoeffScanGroup {
+    uint16_t sigmap;               /* bit k: the k-th coefficient of the sub-block in forward scan order is non-zero               */
+    uint16_t sign;                 /* signFlags of :1547-1600: one bit per coded coefficient, the first coded one highest          */
+    uint16_t gt1;                  /* bit i: the i-th coded coefficient has |level| > 1                                           */
+    uint16_t first_level;          /* index of the sub-block's first level in the LCU's level list                                */
+} SvtAmdCoeffScanGroup;
+typedef struct SvtAmdCoeffScanLcu {
+    uint32_t group_base, level_base; /* where the LCU's groups / levels start in the picture's lists                              */
+    uint16_t groups, levels;         /* how many it has (<= 384 / <= 6144)                                                         */
+    uint8_t pad[4];
+    SvtAmdCoeffScanTu tu[3][SVT_AMD_LCU_MAX_CUS];       /* [Y, Cb, Cr][slot]                                                       */
+} SvtAmdCoeffScanLcu;
+/* One call per picture.  works / results: the encode pass's records of n_lcus LCUs - HOST arrays (device_arrays 0; uploaded) or DEVICE arrays
+ * (device_arrays 1: what svt_amd_encode_picture_device / svt_amd_md_encode_picture left in HBM); work_stride / result_stride: sizeof the record
+ * type (the 8- and 16-bit records share their heads, coefficients are s16 in both).  Outputs (HOST): lcus[n_lcus]; groups / levels: the
+ * picture's lists, compacted in LCU order - capacities in elements (worst case 384 / 6144 per LCU); totals[2] = {groups, levels} written.
+ * SVT_AMD_ERR_RESOURCES when a capacity is too small (totals then tell what is needed).  Blocking. */
+SVT_AMD_API int svt_amd_coeff_scan_picture(SvtAmdContext *ctx, const void *works, size_t work_stride, const void *results, size_t result_stride,
+                                           int device_arrays, int n_lcus, SvtAmdCoeffScanLcu *lcus, SvtAmdCoeffScanGroup *groups,
+                                           uint32_t group_capacity, uint16_t *levels, uint32_t level_capacity, uint32_t totals[2]);
+
 /* Deblocking behind the encode pass: when every LCU of the picture is encoded, a copy of the device picture (a second set of planes of
  * the picture object; the un-deblocked planes stay as they are) goes through the
  * picture-level boundary-strength and deblocking kernels (svt_amd_bs_picture + svt_amd_dlf_picture: the state the reference's

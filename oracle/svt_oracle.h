@@ -285,4 +285,9 @@ void svt_oracle_encode_lcu_inter16(uint16_t *const rec[3], const uint32_t pitch[
                                    const SvtAmdRefPicture *ref0, const SvtAmdRefPicture *ref1, const SvtAmdCabacCost *cost, const SvtAmdLcuWork16 *W,
                                    SvtAmdLcuResult16 *R);
 
+/* ---- entropy hand-off pre-scan (svt_oracle_coeffscan.c): the part of EncodeQuantizedCoefficients before the first bin ---- */
+void svt_oracle_coeff_scan_tu(const int16_t *coeff, uint32_t stride, uint32_t size, uint32_t type, uint32_t intra_luma_mode, int is_chroma,
+                              uint32_t nz, SvtAmdCoeffScanTu *tu, SvtAmdCoeffScanGroup *groups, uint32_t *ng, uint16_t *levels, uint32_t *nl);
+int svt_oracle_coeff_scan_lcu(const SvtAmdLcuWork *W, const SvtAmdLcuResult *R, SvtAmdCoeffScanLcu *out, SvtAmdCoeffScanGroup *groups, uint16_t *levels);
+
 #endif

@@ -526,3 +526,12 @@ def compare_me(got, want, num_lists, what="", lcus=None):
                              (int(g["search_origin_x"][l]), int(g["search_origin_y"][l])),
                              (int(w["search_origin_x"][l]), int(w["search_origin_y"][l]))))
     assert not errs, "%s: %d mismatches, first: %s" % (what, len(errs), errs[:5])
+
+
+# ---- entropy hand-off pre-scan (include/svt_hevc_amd.h: SvtAmdCoeffScanTu / Group / Lcu) ----
+COEFF_SCAN_TU_DTYPE = np.dtype([("scan_index", "u1"), ("last_scan_set", "i1"), ("pos_last", "u1"), ("last_x", "u1"), ("last_y", "u1"), ("dc_only", "u1"),
+                                ("first_group", "<u2")])
+COEFF_SCAN_GROUP_DTYPE = np.dtype([("sigmap", "<u2"), ("sign", "<u2"), ("gt1", "<u2"), ("first_level", "<u2")])
+COEFF_SCAN_LCU_DTYPE = np.dtype([("group_base", "<u4"), ("level_base", "<u4"), ("groups", "<u2"), ("levels", "<u2"), ("pad", "u1", 4),
+                                 ("tu", COEFF_SCAN_TU_DTYPE, (3, 64))])
+assert COEFF_SCAN_TU_DTYPE.itemsize == 8 and COEFF_SCAN_GROUP_DTYPE.itemsize == 8 and COEFF_SCAN_LCU_DTYPE.itemsize == 16 + 3 * 64 * 8
