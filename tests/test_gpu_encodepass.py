@@ -654,3 +654,94 @@ def test_sequence_stays_on_the_device_from_picture_to_picture(product, gpu_ctx, 
     finally:
         for pic in pics.values():
             lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+def test_8k_10bit_picture_in_four_tile_columns_encode_and_deblock(product, oracle):
+    """BASELINE configs[4] class (7680x4320, 10-bit, encMode 4 = PM-core quantiser, -tile_col_cnt 4) through the picture-level calls: a seeded I picture of
+    8,160 LCUs in four tile columns - svt_amd_encode_picture16 against the checker on the first three LCU rows of every tile (the rows below
+    depend on them through the intra neighbours, so the whole wavefront is exercised; the checker runs them in raster order) - then
+    svt_amd_encdec_picture_deblock16 of the WHOLE picture against the checker's boundary strengths + deblocking of the same un-deblocked samples."""
+    from test_oracle_dlf_golden import oracle_bs, oracle_dlf
+    from test_oracle_encodepass_golden import deblock_maps
+    lib = product
+    sig_picture(lib)
+    w, h, qp, tiles, rows_checked = 7680, 4320, 34, 4, 3
+    rng = np.random.default_rng(41)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    col0 = [c * wl // tiles for c in range(tiles)] + [wl]
+    yy, xx = np.mgrid[0:h:8, 0:w:8]
+    base = (512 + 240 * np.sin(xx / 23.0) * np.cos(yy / 17.0)).astype(np.float32)
+    src = [np.clip(np.kron(base, np.ones((8, 8), np.float32)) + rng.normal(0, 30, (h, w)).astype(np.float32), 0, 1023).astype(np.uint16)]
+    src += [np.clip(512 + rng.normal(0, 20, (h // 2, w // 2)).astype(np.float32), 0, 1023).astype(np.uint16) for _ in range(2)]
+    works = np.zeros(wl * hl, S.LCU_WORK16_DTYPE)
+    for ly in range(hl):
+        for lx in range(wl):
+            wk = works[ly * wl + lx]
+            lw, lh = min(64, w - 64 * lx), min(64, h - 64 * ly)
+            wk["lcu_x"], wk["lcu_y"], wk["slice_type"], wk["strong_smoothing"], wk["pm_core"], wk["full_lambda"] = 64 * lx, 64 * ly, 2, 1, 1, 30000000
+            wk["tile_left"], wk["tile_top"], wk["tile_right"] = lx in col0, ly == 0, (lx + 1) in col0
+            tree = random_tree(rng, lw, lh)
+            wk["num_cus"] = len(tree)
+            for i, (x, y, s) in enumerate(tree):
+                cu = wk["cu"][i]
+                cu["x"], cu["y"], cu["size"], cu["pred_mode"], cu["intra_luma_mode"] = x, y, s, 2, rng.integers(0, 35)
+                cu["bottom_left_ok"], cu["top_right_ok"] = z_available(x, y, s)
+                cu["qp"] = qp
+                cu["chroma_qp"] = 29 + (qp - 29) // 2
+            sy = np.zeros((64, 64), np.uint16)
+            sy[:lh, :lw] = src[0][64 * ly:64 * ly + lh, 64 * lx:64 * lx + lw]
+            wk["src_y"] = sy.reshape(-1)
+            for p, nm in ((1, "src_cb"), (2, "src_cr")):
+                sc = np.zeros((32, 32), np.uint16)
+                sc[:lh // 2, :lw // 2] = src[p][32 * ly:32 * ly + lh // 2, 32 * lx:32 * lx + lw // 2]
+                wk[nm] = sc.reshape(-1)
+    cost = np.random.default_rng(3).integers(0, 200, 1560, dtype=np.uint8)
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, 640, 384, 1, C.byref(ctx)) == 0, lib.svt_amd_last_error()   # the front half's slots are not needed here
+    assert lib.svt_amd_encdec_picture_create(ctx, w, h, 2, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        lib.svt_amd_encdec_picture_set_inter.restype, lib.svt_amd_encdec_picture_set_inter.argtypes = C.c_int, [C.c_void_p] * 5
+        assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, None, None, cost.ctypes.data) == 0, lib.svt_amd_last_error()
+        got = np.zeros(len(works), S.LCU_RESULT16_DTYPE)
+        assert lib.svt_amd_encode_picture16(ctx, pic, works.ctypes.data, got.ctypes.data) == 0, lib.svt_amd_last_error()
+        # the checker on the first rows, raster order, into its own picture
+        from test_oracle_encodepass_golden import inter_oracle_fn
+        fn = inter_oracle_fn(oracle, True)
+        pitches = (w, w // 2, w // 2)
+        pb = (C.c_uint32 * 3)(*pitches)
+        rec = [np.zeros((h >> s_, p), np.uint16) for s_, p in zip((0, 1, 1), pitches)]
+        mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+        rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+        for k in range(rows_checked * wl):
+            want = np.zeros(1, S.LCU_RESULT16_DTYPE)
+            fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, None, None, cost.ctypes.data, works[k:k + 1].ctypes.data, want.ctypes.data)
+            compare_lcu(works[k], want[0], got[k], w, h, ("8k", k))
+        assert int(got["cu"]["cbf"].sum()) > 10000
+        # deblocking of the whole picture: the device's own un-deblocked samples through the checker
+        pre = [np.zeros((h, w), np.uint16), np.zeros((h // 2, w // 2), np.uint16), np.zeros((h // 2, w // 2), np.uint16)]
+        for k, rs in enumerate(got):
+            lx, ly = k % wl, k // wl
+            lw, lh = min(64, w - 64 * lx), min(64, h - 64 * ly)
+            pre[0][64 * ly:64 * ly + lh, 64 * lx:64 * lx + lw] = rs["rec_y"].reshape(64, 64)[:lh, :lw]
+            pre[1][32 * ly:32 * ly + lh // 2, 32 * lx:32 * lx + lw // 2] = rs["rec_cb"].reshape(32, 32)[:lh // 2, :lw // 2]
+            pre[2][32 * ly:32 * ly + lh // 2, 32 * lx:32 * lx + lw // 2] = rs["rec_cr"].reshape(32, 32)[:lh // 2, :lw // 2]
+        cumap, cbf, qpm, edge = deblock_maps(works, got, w, h)
+        hdr = dict(width=w, height=h, bytes_per_sample=2, qp_stride=w // 8, tc_offset=0, beta_offset=0, cb_qp_offset=0, cr_qp_offset=0, slice_type=2)
+        dp = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1), refpoc=np.zeros(2, np.uint64), lcu_edge=edge,
+                  bsv=np.zeros((len(works), 256), np.uint8), bsh=np.zeros((len(works), 256), np.uint8))
+        dp["bsv"], dp["bsh"] = oracle_bs(oracle, dp)
+        dp["pre"], dp["qp"] = pre, qpm.reshape(-1)
+        fin = oracle_dlf(oracle, dp)
+        dbk = lib.svt_amd_encdec_picture_deblock16
+        dbk.restype, dbk.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DeblockParams), C.c_void_p, C.c_void_p, C.c_void_p]
+        prm = DeblockParams()
+        prm.slice_type = 2
+        out = [np.zeros_like(p) for p in pre]
+        assert dbk(ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(prm), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data) == 0, lib.svt_amd_last_error()
+        for p in range(3):
+            bad = np.argwhere(out[p] != fin[p])
+            assert len(bad) == 0, ("8k deblock", p, len(bad), bad[:4].tolist())
+        assert sum(int((a != b).sum()) for a, b in zip(pre, fin)) > 100000      # the filter did something
+    finally:
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+        lib.svt_amd_context_destroy(ctx)
