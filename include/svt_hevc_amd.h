@@ -347,6 +347,25 @@ SVT_AMD_API int svt_amd_recon_exchange(SvtAmdContext *ctx, void *const d_planes[
 SVT_AMD_API int svt_amd_recon_pack(SvtAmdContext *ctx, void *const d_planes[3], const uint32_t pitch_bytes[3], int bytes_per_sample,
                                    const SvtAmdRect *rects, int world, int r, void *d_slots, size_t slot_bytes, int to_slot);
 
+/*
+ * Picture-analysis statistics: what GatheringPictureStatistics (Codec/EbPictureAnalysisProcess.c:3995) computes from the planes the
+ * front half already holds in HBM, one call per picture slot (after svt_amd_picture_upload*):
+ *   per LCU  variance[85] / y_mean[85] of the 64x64, 32x32, 16x16 and 8x8 blocks in the order of the motion-estimation units
+ *            (ME_TIER_ZERO_PU_*: 64x64, four 32x32, sixteen 16x16, sixty-four 8x8, each raster) - ComputeBlockMeanComputeVariance (:1646): sums and
+ *            sums of squares over the EVEN rows of each 8x8 block, means in 8 / 16 fractional bits averaged up the tree with >> 2;
+ *   per picture  the luma histograms of the regions_w x regions_h regions of the 1/16 picture (bins start at 1 and end << 4,
+ *            SubSampleLumaGeneratePixelIntensityHistogramBins :3384), the regions' average intensity and the picture's luma sum (<< 4 per region).
+ * out: HOST, LCUs of the picture in raster order; histogram: HOST [regions_w][regions_h][256] or NULL; region_average: HOST [regions_w][regions_h]
+ * or NULL; sum_luma: HOST or NULL.  Blocking.
+ */
+typedef struct SvtAmdPaLcuStats {
+    uint16_t variance[SVT_AMD_ME_PU_COUNT];  /* pictureControlSetPtr->variance[lcu]  */
+    uint8_t y_mean[SVT_AMD_ME_PU_COUNT];     /* pictureControlSetPtr->yMean[lcu]     */
+    uint8_t pad;
+} SvtAmdPaLcuStats;
+SVT_AMD_API int svt_amd_picture_stats(SvtAmdContext *ctx, int slot, SvtAmdPaLcuStats *out, int regions_w, int regions_h, uint32_t *histogram,
+                                      uint8_t *region_average, uint64_t *sum_luma);
+
 /* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
 typedef struct SvtAmdOisJob {
     SvtAmdOisParams params;

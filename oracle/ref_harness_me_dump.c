@@ -68,6 +68,59 @@ static uint32_t plane_checksum(const EbPictureBufferDesc_t *p)
     return s;
 }
 
+/* SVT_REF_PA_DUMP: what the picture-analysis process left for this LCU / picture before motion estimation (GatheringPictureStatistics,
+ * Codec/EbPictureAnalysisProcess.c:3995): variance[lcu][85] / yMean[lcu][85] (ComputeBlockMeanComputeVariance :1646) per call, and with LCU 0 the
+ * luma histograms of the regions (SubSampleLumaGeneratePixelIntensityHistogramBins :3384).  tests/golden/make_pa_golden.py */
+#define PA_MAGIC 0x50414453U
+typedef struct PaDumpRecord {
+    uint32_t magic, kind;        /* kind 0: LCU record, 1: picture record */
+    uint64_t picture_number;
+    uint32_t lcu_index, regions_w, regions_h, pad;
+    uint16_t variance[85];
+    uint8_t y_mean[85];
+    uint8_t average_intensity;
+    uint32_t histogram[4][4][256];
+    uint8_t region_average[4][4];
+} PaDumpRecord;
+static FILE *g_pa_file;
+static int g_pa_state;
+static void pa_dump(PictureParentControlSet_t *pcs, EB_U32 lcuIndex)
+{
+    if (g_pa_state == 0) {
+        pthread_mutex_lock(&g_lock);
+        if (g_pa_state == 0) {
+            const char *path = getenv("SVT_REF_PA_DUMP");
+            g_pa_file = path ? fopen(path, "wb") : NULL;
+            g_pa_state = g_pa_file ? 1 : -1;
+        }
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (g_pa_state < 0)
+        return;
+    SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
+    PaDumpRecord *r = (PaDumpRecord *)calloc(1, sizeof(*r));
+    if (!r)
+        return;
+    r->magic = PA_MAGIC, r->picture_number = pcs->pictureNumber, r->lcu_index = lcuIndex;
+    memcpy(r->variance, pcs->variance[lcuIndex], sizeof(r->variance));
+    memcpy(r->y_mean, pcs->yMean[lcuIndex], sizeof(r->y_mean));
+    if (lcuIndex == 0) {
+        r->kind = 1;
+        r->regions_w = scs->pictureAnalysisNumberOfRegionsPerWidth, r->regions_h = scs->pictureAnalysisNumberOfRegionsPerHeight;
+        r->average_intensity = pcs->averageIntensity[0];
+        for (uint32_t a = 0; a < r->regions_w && a < 4; a++)
+            for (uint32_t b = 0; b < r->regions_h && b < 4; b++) {
+                memcpy(r->histogram[a][b], pcs->pictureHistogram[a][b][0], sizeof(r->histogram[a][b]));
+                r->region_average[a][b] = (uint8_t)pcs->averageIntensityPerRegion[a][b][0];
+            }
+    }
+    pthread_mutex_lock(&g_lock);
+    fwrite(r, sizeof(*r), 1, g_pa_file);
+    fflush(g_pa_file);
+    pthread_mutex_unlock(&g_lock);
+    free(r);
+}
+
 EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX,
                                       EB_U32 lcuOriginY, MeContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
 {
@@ -83,6 +136,7 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
         }
         pthread_mutex_unlock(&g_lock);
     }
+    pa_dump(pcs, lcuIndex);
     if (g_state < 0)
         return err;
 

@@ -535,3 +535,11 @@ COEFF_SCAN_GROUP_DTYPE = np.dtype([("sigmap", "<u2"), ("sign", "<u2"), ("gt1", "
 COEFF_SCAN_LCU_DTYPE = np.dtype([("group_base", "<u4"), ("level_base", "<u4"), ("groups", "<u2"), ("levels", "<u2"), ("pad", "u1", 4),
                                  ("tu", COEFF_SCAN_TU_DTYPE, (3, 64))])
 assert COEFF_SCAN_TU_DTYPE.itemsize == 8 and COEFF_SCAN_GROUP_DTYPE.itemsize == 8 and COEFF_SCAN_LCU_DTYPE.itemsize == 16 + 3 * 64 * 8
+
+
+# ---- picture-analysis statistics: SvtAmdPaLcuStats, and the record of oracle/ref_harness_me_dump.c (SVT_REF_PA_DUMP) ----
+PA_LCU_STATS_DTYPE = np.dtype([("variance", "<u2", 85), ("y_mean", "u1", 85), ("pad", "u1")])
+PA_DUMP_DTYPE = np.dtype([("magic", "<u4"), ("kind", "<u4"), ("picture_number", "<u8"), ("lcu_index", "<u4"), ("regions_w", "<u4"), ("regions_h", "<u4"),
+                          ("pad", "<u4"), ("variance", "<u2", 85), ("y_mean", "u1", 85), ("average_intensity", "u1"), ("histogram", "<u4", (4, 4, 256)),
+                          ("region_average", "u1", (4, 4))], align=True)
+assert PA_LCU_STATS_DTYPE.itemsize == 256
