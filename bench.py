@@ -111,6 +111,9 @@ def cpu_baseline_reference(cfg, unique=8, frames=48):
             "all_cores_upper_bound": round(pictures / cpu_s * (os.cpu_count() or 1), 1)}
 
 
+HIP_LP = 32   # logical processors the hooked encoder is run with (see encoded_fps_leg)
+
+
 def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
     """The BASELINE metric.  Rank 0 first encodes the clip with the unmodified reference (its md5 is the gate, its fps the CPU
     baseline); then every rank runs the hooked encoder on its own GPU behind a barrier.  Returns (rank 0) the record of the JSON
@@ -147,12 +150,29 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
             dist.barrier()
         env = {"SVT_AMD_DEVICE": str(local_rank)}
         hargs = list(args)
-        if world > 1:
-            hargs += ["-lp", str(max(1, (os.cpu_count() or 1) // world))]
+        # host threads of the encoder with the HIP path bound in (-lp, the application's own switch; the bitstream does not depend on it).  With motion
+        # estimation and the open-loop intra search on the device the host pipeline is fastest with about 32 logical processors - beyond that the
+        # reference's pipeline loses to its own thread count (profiles/r03_ab_fps_threads.txt: reference 46 / 70 / 78 / 71 / 61 / 55 / 51 fps at
+        # 8 / 16 / 32 / 48 / 64 / 128 / 256, hooked 65 / 86 / 100 / 94 / 69 / 72 / 63) - and N ranks share the host's threads anyway.
+        ncpu = os.cpu_count() or 1
+        lp = max(1, ncpu // world) if world > 1 else ncpu
+        lp = min(lp, HIP_LP)
+        if lp < ncpu:
+            hargs += ["-lp", str(lp)]
+        out["hip_threads"] = lp
         try:
             hip = E.run_app(E.HIP_APP, yuv, w, h, frames, hargs, os.path.join(td, "hip.265"), env=env, nb=unique)
         except Exception as e:
             hip = {"error": str(e)[-300:], "fps": None, "md5": None}
+        if rank == 0 and world == 1 and lp < ncpu:
+            # for the record: the reference at the same thread count (its best), and the hooked encoder at the default thread count
+            try:
+                r2 = E.run_app(S.REF_APP, yuv, w, h, frames, hargs, os.path.join(td, "ref_lp.265"), nb=unique)
+                out["reference_same_threads"] = dict(r2, args="-lp %d" % lp, same_bitstream_as_default_threading=r2["md5"] == ref_md5)
+                h2 = E.run_app(E.HIP_APP, yuv, w, h, frames, list(args), os.path.join(td, "hip_all.265"), env=env, nb=unique)
+                out["hip_default_threads"] = dict(h2, threads=ncpu, bitstream_identical=h2["md5"] == ref_md5)
+            except Exception as e:
+                out["reference_same_threads"] = {"error": str(e)[-300:]}
         ok = bool(hip.get("md5")) and hip["md5"] == ref_md5
         secs = frames / hip["fps"] if hip.get("fps") else float("inf")
         if world > 1:
@@ -164,7 +184,9 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
         out["bitstream_identical"] = secs != float("inf")
         out["value"] = round(world * frames / secs, 2) if secs != float("inf") else 0.0
         if out.get("reference", {}).get("fps") and hip.get("fps"):
-            out["hip_over_reference"] = round(hip["fps"] / out["reference"]["fps"], 3)
+            out["hip_over_reference"] = round(hip["fps"] / out["reference"]["fps"], 3)               # reference: default threading
+            if out.get("reference_same_threads", {}).get("fps"):
+                out["hip_over_reference_same_threads"] = round(hip["fps"] / out["reference_same_threads"]["fps"], 3)
         return out
     finally:
         shutil.rmtree(td, ignore_errors=True)
@@ -183,7 +205,8 @@ def closed_loop_leg(enc_cfg, enc, frames=48):
         (S.write_clip10_compressed if depth == 10 else S.write_clip)(yuv, "motion", w, h, unique, 7)
         ref = E.run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"), nb=unique)
         rp = os.path.join(td, "report.txt")
-        hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args, os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "pb", "SVT_HOOK_REPORT": rp}, nb=unique)
+        lp = min(HIP_LP, os.cpu_count() or 1)
+        hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "pb", "SVT_HOOK_REPORT": rp}, nb=unique)
         lines = [l.strip() for l in open(rp) if "mode decision" in l] if os.path.exists(rp) else []
         return {"switches": {"SVT_HOOK_MD": "pb"}, "frames": frames, "fps": hip["fps"], "reference_fps": ref["fps"], "bitstream_identical": hip["md5"] == ref["md5"],
                 "report": lines,
@@ -201,6 +224,9 @@ def cpu_baseline_encoder(cfg, enc):
         raise RuntimeError("reference encoder run missing")
     w, h, depth, args = E.CONFIGS[cfg["enc"]]
     out = {"value": enc["reference"]["fps"], "unit": "fps", "cores": os.cpu_count(), "kind": "reference",
+           "best_threading": ({"fps": enc["reference_same_threads"]["fps"], "args": enc["reference_same_threads"]["args"],
+                               "what": "the same reference run with the -lp the hooked encoder uses: the reference is faster with fewer threads than this "
+                                       "host has (profiles/r03_ab_fps_threads.txt)"} if enc.get("reference_same_threads", {}).get("fps") else None),
            "sample": "%d %dx%d pictures (%d unique, looped), oracle/_ref/SvtHevcEncApp_ref -asm 1 (the reference compiled in place, AVX2 "
                      "tables), default threading on all %d host threads, same command line as `value`: %s" %
                      (enc["frames"], w, h, enc["unique_frames"], os.cpu_count(), enc["args"])}
@@ -559,6 +585,8 @@ def main():
                                    (enc["frames"] if enc and "frames" in enc else "n/a"),
                        "width": W, "height": H, "mpix_per_s": round(value * W * H / 1e6, 1) if value else None,
                        "switches": enc.get("switches") if enc else None,
+                       "host_threads_of_the_encoder": ("-lp %d (of %d on this host); the reference's fps at default threading and at the same -lp are in "
+                                                       "encoder_fps / cpu_baseline" % (enc["hip_threads"], os.cpu_count())) if enc and enc.get("hip_threads") else None,
                        "on_device": enc.get("on_device") if enc else None,
                        "parallelism": "one encoder per rank on its own GPU, no data-path collective" if world > 1 else "1 GPU"},
             "encoder_fps": enc,
