@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typen
 }
 
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
-extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width, uint16_t height, int bytes_per_sample, SvtAmdEncDecPicture **out)
+static int picture_create(SvtAmdContext *ctx, uint16_t width, uint16_t height, int bytes_per_sample, SvtAmdEncDecPicture **out)
 {
     if (!ctx || !out || width < 8 || height < 8 || (width & 7) || (height & 7) || (bytes_per_sample != 1 && bytes_per_sample != 2)) {
         svt_amd_set_error("svt_amd_encdec_picture_create: bad parameter (1 or 2 bytes per sample, dimensions multiples of 8)");
@@ -101,6 +101,7 @@ extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width,
     SvtAmdEncDecPicture *p = (SvtAmdEncDecPicture *)calloc(1, sizeof(*p));
     if (!p)
         return SVT_AMD_ERR_RESOURCES;
+    *out = p; /* published at once: the caller releases it when a later step fails */
     p->device = ctx->device;
     p->d.width = width, p->d.height = height, p->d.bps = (uint32_t)bytes_per_sample;
     for (int k = 0; k < 3; k++) {
@@ -138,6 +139,19 @@ extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width,
     }
     *out = p;
     return SVT_AMD_OK;
+}
+
+/* every failure after the object exists releases what was allocated (svt_amd_encdec_picture_destroy tolerates missing members) */
+extern "C" int svt_amd_encdec_picture_create(SvtAmdContext *ctx, uint16_t width, uint16_t height, int bytes_per_sample, SvtAmdEncDecPicture **out)
+{
+    if (out)
+        *out = nullptr;
+    const int rc = picture_create(ctx, width, height, bytes_per_sample, out);
+    if (rc && out && *out) {
+        svt_amd_encdec_picture_destroy(ctx, *out);
+        *out = nullptr;
+    }
+    return rc;
 }
 
 extern "C" int svt_amd_encdec_picture_begin(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic)

@@ -507,35 +507,49 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             bufferTotal = ncand < bufferTotal ? ncand : bufferTotal;
             const int width = st.depth == 0 ? 5 : 8;
             M.ncand = ncand, M.buffer_total = bufferTotal, M.max_buffers = bufferTotal + 1 < width ? bufferTotal + 1 : width;
-            int anyIntra = 0;
-            for (int i = 0; i < ncand; i++)
-                anyIntra |= M.cand[i].type == MD_INTRA;
-            M.any_intra = anyIntra;
-            /* the first fast loop (EbProductCodingLoop.c:1948-1988): the best of the candidates whose distortion the open-loop stages left */
+        }
+        if (wave == 0) { /* a lane per candidate (MD_MAX_CAND <= 64): what the candidate list implies for the loops below */
+            EP_WAVE_SYNC();
+            const int nc = M.ncand, lf = M.leaf;
+            const MdStats s1 = md_stats(lf);
+            const bool in = lane < nc;
+            MdCand c = M.cand[in ? lane : 0];
+            M.any_intra = __ballot(in && c.type == MD_INTRA) != 0;
+            /* the first fast loop (EbProductCodingLoop.c:1948-1988): the best of the candidates whose distortion the open-loop stages left; the reference
+             * walks from the last candidate down with <=: the LOWEST index among equal costs */
             int bestFirst = -1;
             if (!P.single_fast_loop) {
-                unsigned long long bestCost = ~0ull;
-                for (int i = ncand - 1; i >= 0; i--) {
-                    if (!M.cand[i].dist_ready)
-                        continue;
+                const bool ready = in && c.dist_ready;
+                unsigned long long cost = ~0ull;
+                if (ready) {
                     uint64_t r;
-                    const uint64_t c = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], M.cand[i].me_dist, &r)
-                                       : islice                 ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, M.cand[i].me_dist, &r)
-                                                                : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, M.cand[i].me_dist, &r);
-                    if (c <= bestCost)
-                        bestFirst = i, bestCost = c;
+                    cost = c.type == MD_INTER ? md_inter_fast_cost(&P, &s1, &M.S.cu[lf], &c, c.me_dist, &r)
+                           : islice          ? md_intra_fast_cost_islice(&P, &s1, &M.S.cu[lf], c.intra_mode, c.me_dist, &r)
+                                             : md_intra_fast_cost_pslice(&P, &s1, &M.S.cu[lf], c.intra_mode, c.me_dist, &r);
                 }
+                unsigned long long m = cost;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned long long v = __shfl_xor(m, o);
+                    m = v < m ? v : m;
+                }
+                const unsigned long long mask = __ballot(ready && cost == m);
+                bestFirst = mask ? __ffsll((long long)mask) - 1 : -1;
             }
-            M.best_first = bestFirst;
-            int slots = 0;
-            for (int i = 0; i < ncand; i++) {
-                uint8_t e = (uint8_t)(!M.cand[i].dist_ready || i == bestFirst || P.single_fast_loop);
-                if (e && i == bestFirst && M.cand[i].type == MD_INTRA && open_loop)
-                    e = 3; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
-                M.evaluated[i] = e;
-                if constexpr (INTER)
-                    M.V.slot[i] = (int8_t)((e && M.cand[i].type == MD_INTER && slots < 8) ? slots++ : -1);
+            uint8_t e = (uint8_t)(in && (!c.dist_ready || lane == bestFirst || P.single_fast_loop));
+            if (e && lane == bestFirst && c.type == MD_INTRA && open_loop)
+                e = 3; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
+            if (in)
+                M.evaluated[lane] = e;
+            if constexpr (INTER) { /* the first eight inter candidates the loop evaluates keep their prediction for the full loop */
+                const bool q = e && c.type == MD_INTER;
+                const unsigned long long qm = __ballot(q);
+                const int rank = __popcll(qm & ((1ull << lane) - 1ull));
+                if (in)
+                    M.V.slot[lane] = (int8_t)((q && rank < 8) ? rank : -1);
             }
+            if (lane == 0)
+                M.best_first = bestFirst;
         }
         __syncthreads();
         MD_PROF(1);
@@ -586,32 +600,68 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
         __syncthreads();
         MD_PROF(3);
-        /* ---- lane 0: fast costs, candidate buffers, PreModeDecision ---- */
-        if (t < ncand) { /* a lane per candidate */
-            const int i = t;
-            unsigned long long rate = 0;
-            uint64_t cst = ~0ull;
-            if (M.evaluated[i]) {
-                const uint64_t dist = M.cand[i].mpm ? 0 : M.sad[i];
-                cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, (uint64_t *)&rate)
-                      : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
-                                                : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate);
-                if (M.cand[i].mpm)
-                    cst = 0;
+        /* ---- wave 0: fast costs (a lane per candidate: MD_MAX_CAND <= 64), candidate buffers (a lane per buffer), PreModeDecision ---- */
+        if (wave == 0) {
+            const int i = lane;
+            unsigned long long rate = 0, cst = ~0ull;
+            int evl = 0;
+            if (i < ncand) {
+                evl = M.evaluated[i];
+                if (evl) {
+                    const uint64_t dist = M.cand[i].mpm ? 0 : M.sad[i];
+                    cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, (uint64_t *)&rate)
+                          : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
+                                                    : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate);
+                    if (M.cand[i].mpm)
+                        cst = 0;
+                }
+                M.costs[i] = cst, M.fast_rate[i] = rate;
             }
-            M.costs[i] = cst, M.fast_rate[i] = rate;
-        }
-        __syncthreads();
-        if (t == 0) {
-            int bufferTotal = M.buffer_total;
-            md_fast_loop_buffers(&M.B, 8, M.max_buffers, ncand, (const uint64_t *)M.costs, M.evaluated);
-            bufferTotal = M.B.evaluated_count < bufferTotal ? M.B.evaluated_count : bufferTotal;
-            for (int b = 0; b < MD_MAX_BUF; b++)
-                M.types[b] = M.B.cand[b] >= 0 ? M.cand[M.B.cand[b]].type : 0, M.ycbf[b] = 0, M.full_dist[b] = 0, M.merge_cost[b] = M.skip_cost[b] = 0,
-                M.y_bits[b] = M.y_dist[b][0] = M.y_dist[b][1] = 0;
-            const int same = M.B.evaluated_count == bufferTotal;
-            M.full_count = md_pre_mode_decision(&M.B, M.types, same ? bufferTotal : M.max_buffers, same, M.best);
-            M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
+            /* md_fast_loop_buffers (md_logic.h; ProductPerformFastLoop's second loop, :1990-2179) with the buffers in lanes 0..7 instead of LDS: the candidates
+             * arrive from the last to the first, each goes into the buffer with the highest cost (an unused one first) = the FIRST buffer holding the maximum
+             * over [0, maxBuffers) - the reference's scan starts at buffer 0, moves on a strictly greater cost and stops at an unused (all-ones) one; its
+             * do-while looks at buffer 1 even when maxBuffers is 1.  Scalar, the replay of 35 intra candidates was a third of an I picture's time. */
+            unsigned long long bcost = ~0ull;
+            int bcand = -1, bpred = -1, evcount = 0, highest = 0;
+            const int maxb = M.max_buffers < 2 ? 2 : M.max_buffers;
+            for (int idx = ncand - 1; idx >= 0; idx--) {
+                const unsigned long long c = __shfl(cst, idx);
+                const int ev = __shfl(evl, idx);
+                if (lane == highest) {
+                    bcand = idx;
+                    if (ev) {
+                        bcost = c;
+                        if (!(ev & 2))
+                            bpred = idx;
+                    }
+                }
+                evcount += ev != 0;
+                if (idx) {
+                    unsigned long long m = lane < maxb ? bcost : 0ull;
+#pragma unroll
+                    for (int o = 1; o < MD_MAX_BUF; o <<= 1) {
+                        const unsigned long long v = __shfl_xor(m, o);
+                        m = v > m ? v : m;
+                    }
+                    m = __shfl(m, 0);
+                    highest = __ffsll((long long)__ballot(lane < maxb && bcost == m)) - 1;
+                }
+            }
+            if (lane < MD_MAX_BUF) {
+                M.B.fast_cost[lane] = bcost, M.B.full_cost[lane] = ~0ull, M.B.cand[lane] = (int16_t)bcand, M.B.pred[lane] = (int16_t)bpred;
+                M.types[lane] = bcand >= 0 ? M.cand[bcand].type : 0, M.ycbf[lane] = 0, M.full_dist[lane] = 0, M.merge_cost[lane] = M.skip_cost[lane] = 0;
+                M.y_bits[lane] = M.y_dist[lane][0] = M.y_dist[lane][1] = 0;
+            }
+            if (lane == 0)
+                M.B.evaluated_count = evcount;
+            EP_WAVE_SYNC();
+            if (lane == 0) {
+                int bufferTotal = M.buffer_total;
+                bufferTotal = evcount < bufferTotal ? evcount : bufferTotal;
+                const int same = evcount == bufferTotal;
+                M.full_count = md_pre_mode_decision(&M.B, M.types, same ? bufferTotal : M.max_buffers, same, M.best);
+                M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
+            }
         }
         __syncthreads();
         MD_PROF(4);
