@@ -1111,6 +1111,9 @@ SVT_AMD_API int svt_amd_encode_picture_rect(SvtAmdContext *ctx, SvtAmdEncDecPict
                                             const SvtAmdRect *rect);
 SVT_AMD_API int svt_amd_encode_picture_rect16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results,
                                               const SvtAmdRect *rect);
+/* the same restriction for the object's MODE-DECISION calls (svt_amd_md_encode_picture / _inter: mode decision + encode pass of the rank's rectangle in one call;
+ * the rectangle's borders must be tile borders of the SvtAmdMdLcu records; the other LCUs' records come back zeroed); rect NULL = the whole picture */
+SVT_AMD_API int svt_amd_encdec_picture_set_rect(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rect);
 SVT_AMD_API int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int rank);
 SVT_AMD_API int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
                                             size_t slot_bytes, int to_slot);

@@ -33,6 +33,9 @@ struct SvtAmdEncDecPicture {
     int device;
     unsigned *d_sync; /* [0] ticket counter, [1 + lcu] epoch of the picture-level call that finished the LCU, then the ticket order */
     unsigned *d_order_rect; /* ticket order of a rank's rectangle (svt_amd_encode_picture_rect), allocated on first use */
+    unsigned *d_order_md;   /* the same for the rectangle set with svt_amd_encdec_picture_set_rect (mode-decision calls) */
+    int md_rect_n;          /* LCUs of that rectangle, 0 = the whole picture */
+    SvtAmdRect md_rect;
     unsigned epoch;
     int nlcu;
     SvtAmdCabacCost *d_cost;

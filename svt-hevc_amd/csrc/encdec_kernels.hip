@@ -180,6 +180,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
         (void)hipFree(pic->d_sync);
     if (pic->d_order_rect)
         (void)hipFree(pic->d_order_rect);
+    if (pic->d_order_md)
+        (void)hipFree(pic->d_order_md);
     if (pic->d.prof)
         (void)hipFree(pic->d.prof);
     if (pic->d_cost)
@@ -437,6 +439,37 @@ extern "C" int svt_amd_encode_picture_rect16(SvtAmdContext *ctx, SvtAmdEncDecPic
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* The rectangle (whole tiles, svt_amd_tile_partition) the object's MODE-DECISION calls work on: svt_amd_md_encode_picture[_inter] then draws the tickets of its
+ * LCUs only (the same anti-diagonal order), decides and encodes them, and leaves the other LCUs' records zeroed.  NULL = the whole picture again. */
+extern "C" int svt_amd_encdec_picture_set_rect(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rect)
+{
+    if (!ctx || !pic)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (!rect) {
+        pic->md_rect_n = 0;
+        return SVT_AMD_OK;
+    }
+    const int wl = (pic->d.width + 63) / 64, hl = (pic->d.height + 63) / 64;
+    const int x0 = rect->x / 64, y0 = rect->y / 64, x1 = (rect->x + rect->w + 63) / 64, y1 = (rect->y + rect->h + 63) / 64;
+    if ((rect->x & 63) || (rect->y & 63) || !rect->w || !rect->h || x1 > wl || y1 > hl) {
+        svt_amd_set_error("svt_amd_encdec_picture_set_rect: the rectangle is not a set of whole LCUs of the picture");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<unsigned> order;
+    for (int d = 0; d <= (x1 - x0 - 1) + 2 * (y1 - y0 - 1); d++)
+        for (int y = y0; y < y1; y++) {
+            const int x = x0 + d - 2 * (y - y0);
+            if (x >= x0 && x < x1)
+                order.push_back((unsigned)(y * wl + x));
+        }
+    if (!pic->d_order_md && hipMalloc((void **)&pic->d_order_md, sizeof(unsigned) * (size_t)pic->nlcu) != hipSuccess)
+        return SVT_AMD_ERR_RESOURCES;
+    HIP_TRY(hipMemcpy(pic->d_order_md, order.data(), sizeof(unsigned) * order.size(), hipMemcpyHostToDevice));
+    pic->md_rect_n = (int)order.size(), pic->md_rect = *rect;
     return SVT_AMD_OK;
 }
 

@@ -1261,6 +1261,23 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         m->d.X = m->d_X, m->d.me = me ? m->d_me : d_me_slot, m->d.tmvp = m->d_tmvp;
         HIP_TRY(hipMemsetAsync(m->d.md_mv, 0, m->mv_bytes, st));
     }
+    int n_active = n;
+    const unsigned *d_order = pic->d_sync + 1 + n;
+    if (pic->md_rect_n) { /* a rank's rectangle (svt_amd_encdec_picture_set_rect): its borders must be tile borders - an LCU never waits for one outside */
+        const SvtAmdRect &r = pic->md_rect;
+        const int x0 = r.x / 64, y0 = r.y / 64, x1 = (r.x + r.w + 63) / 64, y1 = (r.y + r.h + 63) / 64;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const SvtAmdMdLcu &Lc = lcus[y * wl + x];
+                if ((x == x0 && !Lc.tile_left) || (y == y0 && !Lc.tile_top) || (x == x1 - 1 && x1 < wl && !Lc.tile_right) ||
+                    (y == y1 - 1 && y1 < hl && !lcus[(y + 1) * wl + x].tile_top)) {
+                    svt_amd_set_error("svt_amd_md_encode_picture: the rectangle's border at LCU (%d, %d) is not a tile border", x, y);
+                    return SVT_AMD_ERR_BAD_PARAM;
+                }
+            }
+        n_active = pic->md_rect_n, d_order = pic->d_order_md;
+        HIP_TRY(hipMemsetAsync(m->d_out, 0, sizeof(SvtAmdMdLcuOut) * (size_t)n, st));
+    }
     m->d.prof = m->d_prof;
     m->d.encode = !X || works || results; /* P / B pictures: without a place for the work / result records, the mode decision alone */
     if (ois)
@@ -1286,13 +1303,13 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
      * find work (all of them resident: a workgroup that waits holds its CU) */
     int grid = 2 * ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2;
-    grid = grid > n ? n : grid > 224 ? 224 : grid;
+    grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
     if (X)
-        hipLaunchKernelGGL(k_md_encode_picture<true>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true>), st, m->d, pic->d, m->d_works, m->d_results, n, wl,
-                           pic->d_sync, pic->d_sync + 1, m->d_md_done, pic->d_sync + 1 + n, pic->epoch);
+        hipLaunchKernelGGL(k_md_encode_picture<true>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
+                           pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     else
-        hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n, wl,
-                           pic->d_sync, pic->d_sync + 1, m->d_md_done, pic->d_sync + 1 + n, pic->epoch);
+        hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
+                           pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
     if (md_out)
         HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));

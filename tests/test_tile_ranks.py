@@ -298,3 +298,50 @@ def test_encode_picture_rect_rejects_a_rectangle_that_cuts_a_tile(product, gpu_c
             assert lib.svt_amd_encode_picture_rect(gpu_ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(bad)) != 0
     finally:
         lib.svt_amd_encdec_picture_destroy(gpu_ctx, pic)
+
+
+@pytest.mark.gpu
+def test_mode_decision_and_encode_pass_of_a_ranks_rectangle(product):
+    """the picture-level mode-decision call restricted to a rank's tile rectangle (svt_amd_encdec_picture_set_rect): on a recorded random-access encode with
+    2 x 2 tiles every one of 2 and of 4 ranks decides and encodes ITS LCUs exactly as the reference did - split, modes, vectors, costs of every tested leaf
+    (tests/golden/md_b_tiles_*.npz: the reference's ModeDecisionLcu records) - and leaves the other LCUs' records zeroed"""
+    from test_gpu_md import md_encode_inter, sig
+    from test_oracle_md_golden import compare_md
+    lib = product
+    sig(lib)
+    vp = C.c_void_p
+    lib.svt_amd_encdec_picture_set_rect.restype, lib.svt_amd_encdec_picture_set_rect.argtypes = C.c_int, [vp, vp, C.POINTER(Rect)]
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_b_tiles_motion_640x384_m8.npz"))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    ctx, pic = vp(), vp()
+    assert lib.svt_amd_context_create(0, w, h, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+    try:
+        for world in (2, 4):
+            rc, rects, _ = partition(lib, w, h, 2, 2, world)
+            assert rc == 0
+            for k in range(len(g["picture_number"])):
+                seen = np.zeros(S.lcu_count(w, h), bool)
+                for r in range(world):
+                    assert lib.svt_amd_encdec_picture_set_rect(ctx, pic, C.byref(rects[r])) == 0, lib.svt_amd_last_error()
+                    out, works, res = md_encode_inter(lib, ctx, pic, g, k, encode=True)
+                    mine = np.zeros(len(out), bool)
+                    mine[lcus_of(rects[r], w, h)] = True
+                    assert not seen[mine].any()
+                    seen |= mine
+                    want = g["out"][k].copy()
+                    compare_md(out[mine], want[mine], "rank %d of %d, picture %d" % (r, world, int(g["picture_number"][k])))
+                    assert not out[~mine]["tested"].any() and not works[~mine]["num_cus"].any() and works[mine]["num_cus"].all()
+                assert seen.all()
+        # a rectangle that cuts a tile is refused by the call that sees the LCUs' tile flags
+        bad = Rect(0, 0, 128, h)
+        assert lib.svt_amd_encdec_picture_set_rect(ctx, pic, C.byref(bad)) == 0
+        lib.svt_amd_md_encode_picture_inter.restype = C.c_int
+        with pytest.raises(AssertionError):
+            md_encode_inter(lib, ctx, pic, g, 0, encode=True)
+        assert lib.svt_amd_encdec_picture_set_rect(ctx, pic, None) == 0
+        out, _, _ = md_encode_inter(lib, ctx, pic, g, 0, encode=True)
+        compare_md(out, g["out"][0], "whole picture again")
+    finally:
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+        lib.svt_amd_context_destroy(ctx)
