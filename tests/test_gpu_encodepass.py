@@ -192,14 +192,14 @@ def random_picture(oracle, w, h, qp, seed, tile_cols=1, tile_rows=1, constrained
     return works, want
 
 
-def random_inter_picture(oracle, w, h, qp, seed, pad=80, intra_lcus=1.0):    # pad > 75: a window at a clamped position stays inside the plane
+def random_inter_picture(oracle, w, h, qp, seed, pad=80, intra_lcus=1.0, tile_cols=1):    # pad > 75: a window at a clamped position stays inside the plane
     """a seeded B picture: random unit trees with ~80 % inter units (L0 / L1 / bi, AMVP / merge / skip, whole-LCU 64x64 units, motion vectors
     that reach far outside the picture now and then), two reference pictures, rate tables and per-LCU lambdas spread over three decades -
     and what the CPU oracle makes of it in raster order.  Returns works, want, (reference planes, geometry), cost."""
     from test_oracle_encodepass_golden import inter_oracle_fn
     fn = inter_oracle_fn(oracle, False)
     rng = np.random.default_rng(seed)
-    works, _ = random_picture(oracle, w, h, qp, seed)           # trees, intra modes, QPs, source
+    works, _ = random_picture(oracle, w, h, qp, seed, tile_cols)           # trees, intra modes, QPs, source, tile edges
     yy, xx = np.mgrid[0:h + 2 * pad, 0:w + 2 * pad]
     refs = []
     for r in range(2):
@@ -744,4 +744,44 @@ def test_8k_10bit_picture_in_four_tile_columns_encode_and_deblock(product, oracl
         assert sum(int((a != b).sum()) for a, b in zip(pre, fin)) > 100000      # the filter did something
     finally:
         lib.svt_amd_encdec_picture_destroy(ctx, pic)
+        lib.svt_amd_context_destroy(ctx)
+
+
+def test_4k_b_picture_in_four_tile_columns_by_four_ranks_matches_the_checker(product, oracle):
+    """BASELINE configs[2]'s picture size cut the way configs[4] is (tile columns -> ranks): a seeded 4K B picture with four tile columns, each of four logical
+    ranks encoding its rectangle with svt_amd_encode_picture_rect - every LCU of every rank against the checker's raster-order encode of the whole picture
+    (tiles make the ranks independent: no rank sees another's reconstruction), nothing outside a rank's rectangle touched"""
+    from test_recon_exchange import Rect, partition
+    lib = product
+    sig_picture(lib)
+    w, h, world = 3840, 2160, 4
+    lib.svt_amd_encode_picture_rect.restype, lib.svt_amd_encode_picture_rect.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Rect)]
+    rc, rects, _ = partition(lib, w, h, world, 1, world)
+    assert rc == 0
+    works, want, refs_geom, cost = random_inter_picture(oracle, w, h, 32, 27, intra_lcus=0.3, tile_cols=world)
+    wl = (w + 63) // 64
+    ctx = C.c_void_p()
+    assert lib.svt_amd_context_create(0, 640, 384, 1, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    pics = []
+    try:
+        for r in range(world):
+            pic = C.c_void_p()
+            assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+            pics.append(pic)
+            keep = set_inter_random(lib, ctx, pic, refs_geom, cost)
+            got = np.zeros(len(works), S.LCU_RESULT_DTYPE)
+            assert lib.svt_amd_encode_picture_rect(ctx, pic, works.ctypes.data, got.ctypes.data, C.byref(rects[r])) == 0, lib.svt_amd_last_error()
+            x0, x1 = rects[r].x // 64, (rects[r].x + rects[r].w + 63) // 64
+            mine = 0
+            for k in range(len(works)):
+                if x0 <= k % wl < x1:
+                    compare_lcu(works[k], want[k], got[k], w, h, ("rank", r, k))
+                    mine += 1
+                else:
+                    assert not got[k]["cu"]["cbf"].any() and not got[k]["rec_y"].any()
+            assert mine == (x1 - x0) * ((h + 63) // 64)
+            del keep
+    finally:
+        for pic in pics:
+            lib.svt_amd_encdec_picture_destroy(ctx, pic)
         lib.svt_amd_context_destroy(ctx)
