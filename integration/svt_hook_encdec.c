@@ -193,7 +193,9 @@ void svt_hook_encdec_teardown(void)
 }
 
 /* the device picture of this PictureControlSet_t, begun for its current picture */
-static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide);
+static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide, int begin);
+static double g_prep_t[3]; /* seconds inside picture_prepare: reference pictures resident, svt_amd_encdec_picture_set_inter, _begin (racy sums, a report only) */
+static unsigned long g_prep_n;
 /* prepare == 0: only find (or create) the object; the caller decides whether the picture needs the device at all (SVT_HOOK_MD alone) and calls
  * picture_prepare itself under the entry's lock */
 static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide, int prepare)
@@ -225,13 +227,13 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
     if (!e)
         svt_hook_die("encode pass: more PictureControlSet_t objects than EP_PICTURES");
     if (prepare)
-        picture_prepare(lane, e, pcs, wide);
+        picture_prepare(lane, e, pcs, wide, 1);
     pthread_mutex_unlock(&g_ep_lock);
     return e;
 }
 
 /* first LCU of a new picture in this object: nothing coded yet (under g_ep_lock, or under the entry's lock when the caller holds that) */
-static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide)
+static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide, int begin)
 {
     if (e->picture_plus1 == pcs->pictureNumber + 1)
         return;
@@ -239,13 +241,24 @@ static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const Pictur
          * prices its levels with); complete before other lanes launch: the begin below waits for this lane's stream */
         SvtAmdRefPicture refs[2];
         int have[2] = {0, 0};
+        struct timespec t0, t1, t2, t3;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         if (pcs->sliceType != EB_I_PICTURE)
             svt_hook_resident_references(pcs, wide, refs, have);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
         if (svt_amd_encdec_picture_set_inter(lane, e->pic, have[0] ? &refs[0] : NULL, have[1] ? &refs[1] : NULL, (const SvtAmdCabacCost *)pcs->cabacCost))
             svt_hook_die("svt_amd_encdec_picture_set_inter");
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        /* the picture-level mode-decision call resets the object itself (begin = 0): a second reset here costs a stream synchronisation behind whatever the
+         * device is running - 12 ms per picture at BASELINE configs[2] with two pictures' kernels in flight */
+        if (begin && svt_amd_encdec_picture_begin(lane, e->pic))
+            svt_hook_die("svt_amd_encdec_picture_begin");
+        clock_gettime(CLOCK_MONOTONIC, &t3);
+        g_prep_t[0] += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        g_prep_t[1] += (double)(t2.tv_sec - t1.tv_sec) + 1e-9 * (double)(t2.tv_nsec - t1.tv_nsec);
+        g_prep_t[2] += (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec);
+        g_prep_n++;
     }
-    if (svt_amd_encdec_picture_begin(lane, e->pic))
-        svt_hook_die("svt_amd_encdec_picture_begin");
     e->picture_plus1 = pcs->pictureNumber + 1;
     e->npending = 0;
     e->sao_any = e->sao_varies = e->on_device = e->done = 0;
@@ -890,7 +903,7 @@ static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8
 }
 
 /* the picture's ONE device call; under e->lock */
-static double g_md_t_fill, g_md_t_call; /* seconds of host work / of device calls inside md_picture, summed (under the entries' locks: racy sums, a report only) */
+static double g_md_t_fill, g_md_t_call, g_md_t_prepare; /* seconds of host work / of device calls / of picture_prepare inside md_picture, summed (under the entries' locks: racy sums, a report only) */
 static double md_now(void)
 {
     struct timespec ts;
@@ -930,9 +943,11 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
     const uint8_t *sy = in->bufferY + (size_t)in->originY * in->strideY + in->originX;
     const uint8_t *scb = in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2, *scr = in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2;
+    const double t_p0 = md_now();
     if (!inter || svt_amd_md_lcus_supported(&P, lcus, (int)n))
-        picture_prepare(lane, e, pcs, 0); /* the picture is the device's: reference pictures resident, rate tables, a fresh picture object */
+        picture_prepare(lane, e, pcs, 0, 0); /* the picture is the device's: reference pictures resident, rate tables (the call below resets the object) */
     const double t_c0 = md_now();
+    g_md_t_prepare += t_c0 - t_p0;
     if (!inter) {
         if (svt_amd_md_encode_picture(lane, e->pic, &P, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out,
                                       e->md_works, e->md_res))
@@ -1046,8 +1061,11 @@ void svt_hook_encdec_report(FILE *out)
                 g_md_pictures, g_md_inter_pictures, g_md_lcus, g_md_left_pictures, g_md_verified, g_md_mismatch);
     if (g_md_state > 0 && g_md_pictures)
         fprintf(out, "svt_hook_me: mode decision: per device-decided picture %.1f ms inside the device call (uploads, kernel, downloads), %.1f ms of host work around it "
-                     "(controls, open-loop intra / motion-estimation / motion-field records, reference pictures)\n", 1e3 * g_md_t_call / g_md_pictures,
-                1e3 * g_md_t_fill / g_md_pictures);
+                     "(controls, open-loop intra / motion-estimation / motion-field records, reference pictures: %.1f ms of it making the reference pictures and rate "
+                     "tables resident)\n", 1e3 * g_md_t_call / g_md_pictures, 1e3 * g_md_t_fill / g_md_pictures, 1e3 * g_md_t_prepare / g_md_pictures);
+    if (g_prep_n)
+        fprintf(out, "svt_hook_me: picture objects prepared %lu times: %.2f ms reference pictures resident, %.2f ms rate tables + references set, %.2f ms begin (means)\n", g_prep_n,
+                1e3 * g_prep_t[0] / g_prep_n, 1e3 * g_prep_t[1] / g_prep_n, 1e3 * g_prep_t[2] / g_prep_n);
     if (g_ep_state <= 0)
         return;
     fprintf(out, "svt_hook_me: encode pass: %lu LCUs encoded on the GPU (one call each; %lu of them with inter units, %lu inter units); left to the "

@@ -163,7 +163,7 @@ int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out)
  * waits for another lane's kernels and vice versa; measured in bench.py, 1,680 -> 2,450 pictures/s).  The variable is read when the
  * runtime starts, so it is set when this library is loaded - a C host (the encoder) loads it before any HIP call; a user's own
  * setting wins. */
-__attribute__((constructor)) static void svt_amd_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+__attribute__((constructor)) static void svt_amd_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 /* Job descriptors of a launch (a few KB) go host -> device through a pinned ring the GPU reads itself: a copy kernel on the
  * lane's stream, in order with the launch that consumes them.  A hipMemcpyAsync would put them on a copy engine's queue, where they

@@ -29,6 +29,9 @@
 #include <vector>
 #include <mutex>
 #define MD_FN __host__ __device__ __forceinline__
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "md_logic.h"
 
 struct MdPictureDev {
@@ -1236,6 +1239,10 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     if ((rc = md_state(pic, &m)) != 0)
         return rc;
     hipStream_t st = ctx->stream;
+    /* debug (SVT_AMD_MD_TIMING): host clock around the call's three parts, with a stream synchronisation after each - one line per call on stderr */
+    static const bool timing = getenv("SVT_AMD_MD_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_up = t_begin, t_kernel = t_begin;
     const uint8_t *hs[3] = {src_y, src_cb, src_cr};
     for (int k = 0; k < 3; k++) {
         const uint32_t pw = k ? pic->d.width / 2 : pic->d.width, ph = k ? pic->d.height / 2 : pic->d.height;
@@ -1300,6 +1307,10 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
             attr[ctx->device & 63] = true;
         }
     }
+    if (timing) {
+        HIP_TRY(hipStreamSynchronize(st));
+        t_up = std::chrono::steady_clock::now();
+    }
     /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
      * find work (all of them resident: a workgroup that waits holds its CU) */
     int grid = 2 * ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2;
@@ -1311,6 +1322,10 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
                            pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
+    if (timing) {
+        HIP_TRY(hipStreamSynchronize(st));
+        t_kernel = std::chrono::steady_clock::now();
+    }
     if (md_out)
         HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));
     if (works)
@@ -1318,6 +1333,12 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     if (results)
         HIP_TRY(hipMemcpyAsync(results, m->d_results, sizeof(SvtAmdLcuResult) * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (timing) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "svt_amd_md_encode_picture%s: %d LCUs, inputs up %.2f ms, kernel %.2f ms, records down %.2f ms\n", X ? "_inter" : "", n_active, ms(t_begin, t_up),
+                ms(t_up, t_kernel), ms(t_kernel, t_end));
+    }
     return SVT_AMD_OK;
 }
 

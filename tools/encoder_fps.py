@@ -36,7 +36,10 @@ def run_app(app, yuv, w, h, n, args, out, env=None, timeout=900, nb=None):
     through them, so n may exceed the frames the file holds."""
     cmd = [app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-nb", str(nb or n), "-b", out] + args
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    child_env = dict(os.environ, **(env or {}))
+    if not (env and "GPU_MAX_HW_QUEUES" in env):
+        child_env.pop("GPU_MAX_HW_QUEUES", None)   # the encoder process takes the library's own default (bench.py sets a smaller one for its in-process loops)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=child_env)
     wall = time.perf_counter() - t0
     if r.returncode != 0:
         raise RuntimeError("encoder failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout[-1500:], r.stderr[-1500:]))
