@@ -178,3 +178,31 @@ print("RCCL_OK")
 ''' % os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
     assert "RCCL_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_the_pictures_of_the_multi_gpu_bench_leg_fit_the_partition(world):
+    """`bench.py --gpus N` (recon_exchange.tile_ranks) cannot be run here: what CAN be checked without GPUs is that the picture it builds for N ranks
+    passes the rectangle validation of svt_amd_encode_picture_rect for every rank - the rectangle of svt_amd_tile_partition starts and ends on the
+    tile-edge flags of the unit lists (restated here from svt-hevc_amd/csrc/encdec_kernels.hip:encode_picture)"""
+    import sys
+    sys.path.insert(0, os.path.join(S.ROOT, "tools"))
+    import encodepass_bench as EPB
+    w, h = 3840, 2160
+    lib = C.CDLL(S.PRODUCT_SO)
+    rc, rects, _ = partition(lib, w, h, world, 1, world)
+    assert rc == 0
+    works = EPB.tile_column_works(w, h, world)
+    wl, hl = (w + 63) // 64, (h + 63) // 64
+    seen = np.zeros(wl * hl, int)
+    for r in rects:
+        x0, y0, x1, y1 = r.x // 64, r.y // 64, (r.x + r.w + 63) // 64, (r.y + r.h + 63) // 64
+        assert r.x % 64 == 0 and r.y % 64 == 0 and x1 <= wl and y1 <= hl
+        for y in range(y0, y1):
+            for x in range(x0, x1):
+                wk = works[y * wl + x]
+                assert not (x == x0 and not wk["tile_left"]) and not (y == y0 and not wk["tile_top"]), (world, x, y)
+                assert not (x == x1 - 1 and x1 < wl and not wk["tile_right"]), (world, x, y)
+                assert not (y == y1 - 1 and y1 < hl and not works[(y + 1) * wl + x]["tile_top"]), (world, x, y)
+                seen[y * wl + x] += 1
+    assert (seen == 1).all()

@@ -166,6 +166,17 @@ def finish_chain_ms(lib, root, W, H, works, inputs, iters=3):
     return out
 
 
+def tile_column_works(W, H, cols):
+    """the B picture of tile_ranks_leg: `cols` tile columns on the reference's uniform tile grid (EbPictureControlSet.c:743); the same on every rank (seeded)"""
+    works = works_of(W, H, 32, 9, None, 0.85, 0.1)
+    wl = (W + 63) // 64
+    starts = {c * wl // cols for c in range(cols)}
+    for wk in works:
+        lx = int(wk["lcu_x"]) // 64
+        wk["tile_left"], wk["tile_right"] = lx in starts, (lx + 1 in starts) or lx == wl - 1
+    return works
+
+
 def tile_ranks_leg(lib, ctx, rank, world, barrier=None, W=3840, H=2160, iters=5):
     """bench.py --gpus N: ONE 4K B picture cut into `world` tile columns, rank r encoding its rectangle (svt_amd_encode_picture_rect, host-array ABI:
     every rank uploads the unit lists, downloads its results), then the finished planes all-gathered (svt_amd_encdec_picture_exchange; needs the
@@ -181,12 +192,7 @@ def tile_ranks_leg(lib, ctx, rank, world, barrier=None, W=3840, H=2160, iters=5)
     lib.svt_amd_encdec_picture_reference.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     rects = (Rect * world)()
     assert lib.svt_amd_tile_partition(W, H, world, 1, world, rects, None) == 0, lib.svt_amd_last_error()
-    works = works_of(W, H, 32, 9, None, 0.85, 0.1)
-    wl = (W + 63) // 64
-    starts = {c * wl // world for c in range(world)}     # the reference's uniform tile grid (EbPictureControlSet.c:743)
-    for wk in works:
-        lx = int(wk["lcu_x"]) // 64
-        wk["tile_left"], wk["tile_right"] = lx in starts, (lx + 1 in starts) or lx == wl - 1
+    works = tile_column_works(W, H, world)
     inputs = b_picture_inputs(W, H)
     nl = S.lcu_count(W, H)
     pic = vp()
