@@ -527,7 +527,8 @@ template <typename T>
 struct EpShared {
     int16_t border[3][132], ref[3][132];       /* per plane pipeline */
     int16_t tiles[3][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N */
-    EpMcScratch<T> mc[3];                      /* inter units */
+    EpMcScratch<T> mc[4];                      /* inter units: one per wave (the predictions of an LCU's inter units are made by all four waves) */
+    unsigned next_task;                        /* the waves' draw from the LCU's list of (inter unit, plane) predictions */
     int16_t qbuf[32 * 32];                     /* luma cbf decision of AMVP units; levels of the PM-core re-decision */
     int16_t cfbuf[32 * 32];                    /* PM-core: the luma unit's coefficients */
     int16_t Pq[64][16];                        /* PM-core: per-lane scratch of the 4x4 rate estimate */
@@ -599,14 +600,36 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
     const EpFlags F = {W.tile_left != 0, W.tile_top != 0, W.tile_right != 0, W.constrained_intra != 0, W.strong_smoothing != 0, (int)W.slice_type,
                        (int)W.lcu_x,     (int)W.lcu_y,    W.full_lambda,     {W.luma_cbf_bits[0], W.luma_cbf_bits[1], W.luma_cbf_bits[2], W.luma_cbf_bits[3]},
                        W.pm_core != 0};
+    if (t == 0)
+        S.next_task = 0;
     __syncthreads();
+    /* ---- the predictions of the LCU's inter units first, by all four waves (round 3): an inter unit predicts from the reference pictures alone, so its three
+     * planes are tasks nothing in the LCU has to wait for; the waves draw them - luma planes first, they are the long ones - and leave the predicted samples at
+     * the units' positions.  The unit loop below then only transforms them, in order (an intra unit in between reads the reconstruction of the units before it). ---- */
+    {
+        const int ntasks = 3 * num_cus;
+        for (;;) {
+            int k = 0;
+            if (lane == 0)
+                k = (int)atomicAdd(&S.next_task, 1u);
+            k = __shfl(k, 0);
+            if (k >= ntasks)
+                break;
+            const int ci = k < num_cus ? k : (k - num_cus) >> 1, p = k < num_cus ? 0 : 1 + ((k - num_cus) & 1);
+            const LcuCu cu = L.cus[ci];
+            if (cu.pred_mode == 1)
+                ep_inter_predict_plane<T>(P, L, F, cu, p, lane, S.mc[wave]);
+        }
+    }
+    __syncthreads();
+    if (P.prof)
+        c1 = __builtin_readcyclecounter(), c_pred += c1 - c0, c0 = c1;
     if (wave < 3) { /* wave p = plane p: its own pipeline over the unit list (luma is the long one) */
         const int p = wave;
         for (int ci = 0; ci < num_cus; ci++) {
             const LcuCu cu = L.cus[ci];
             const int N = cu.size;
-            if (cu.pred_mode == 1) { /* INTER_MODE, 2Nx2N (EbCodingLoop.c:3817-4400) */
-                ep_inter_predict_plane<T>(P, L, F, cu, p, lane, S.mc[p]);
+            if (cu.pred_mode == 1) { /* INTER_MODE, 2Nx2N (EbCodingLoop.c:3817-4400): predicted above */
                 if (P.prof)
                     c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
                 const int ntu = N == 64 ? 4 : 1, TS = N == 64 ? 32 : N, n = p ? TS >> 1 : TS;
