@@ -526,9 +526,10 @@ __device__ __forceinline__ uint32_t ep_encode_plane(int n, int lane, const T *sr
 template <typename T>
 struct EpShared {
     int16_t border[3][132], ref[3][132];       /* per plane pipeline */
-    int16_t tiles[3][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N */
+    int16_t tiles[4][2 * TxRegTile<32>::UNIT]; /* 64 / N units of TxRegTile<N>::UNIT each fit for every N; one per wave */
     EpMcScratch<T> mc[4];                      /* inter units: one per wave (the predictions of an LCU's inter units are made by all four waves) */
-    unsigned next_task;                        /* the waves' draw from the LCU's list of (inter unit, plane) predictions */
+    unsigned next_task;                        /* the waves' draw from the LCU's list of (inter unit, plane) tasks */
+    unsigned decide_lock;                      /* qbuf / cfbuf / Pq below exist once: luma planes that decide their cbf or re-decide levels take turns */
     int16_t qbuf[32 * 32];                     /* luma cbf decision of AMVP units; levels of the PM-core re-decision */
     int16_t cfbuf[32 * 32];                    /* PM-core: the luma unit's coefficients */
     int16_t Pq[64][16];                        /* PM-core: per-lane scratch of the 4x4 rate estimate */
@@ -601,7 +602,7 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
                        (int)W.lcu_x,     (int)W.lcu_y,    W.full_lambda,     {W.luma_cbf_bits[0], W.luma_cbf_bits[1], W.luma_cbf_bits[2], W.luma_cbf_bits[3]},
                        W.pm_core != 0};
     if (t == 0)
-        S.next_task = 0;
+        S.next_task = 0, S.decide_lock = 0;
     __syncthreads();
     /* ---- the predictions of the LCU's inter units first, by all four waves (round 3): an inter unit predicts from the reference pictures alone, so its three
      * planes are tasks nothing in the LCU has to wait for; the waves draw them - luma planes first, they are the long ones - and leave the predicted samples at
@@ -617,8 +618,47 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
                 break;
             const int ci = k < num_cus ? k : (k - num_cus) >> 1, p = k < num_cus ? 0 : 1 + ((k - num_cus) & 1);
             const LcuCu cu = L.cus[ci];
-            if (cu.pred_mode == 1)
-                ep_inter_predict_plane<T>(P, L, F, cu, p, lane, S.mc[wave]);
+            if (cu.pred_mode != 1)
+                continue;
+            ep_inter_predict_plane<T>(P, L, F, cu, p, lane, S.mc[wave]);
+            /* ... and its transform units (EbCodingLoop.c:3817-4400): residual of the prediction just made, nothing else of the LCU */
+            const int N = cu.size;
+            const int ntu = N == 64 ? 4 : 1, TS = N == 64 ? 32 : N, n = p ? TS >> 1 : TS;
+            const bool amvp = cu.inter_kind == SVT_AMD_EP_INTER_AMVP;
+            const EpDecide D = {P.cost, S.qbuf, F.full_lambda, N == TS ? F.cbf_bits[1] : F.cbf_bits[0], N == TS ? F.cbf_bits[3] : F.cbf_bits[2],
+                                F.pm_core,      1,      S.cfbuf,       S.Pq};
+            const bool shared_scratch = p == 0 && (amvp || F.pm_core) && cu.inter_kind != SVT_AMD_EP_INTER_SKIP;
+            if (shared_scratch) {
+                if (lane == 0)
+                    while (atomicCAS(&S.decide_lock, 0u, 1u) != 0u)
+                        __builtin_amdgcn_s_sleep(1);
+                EP_WAVE_SYNC();
+            }
+            uint32_t any = 0;
+            for (int tu = 0; tu < ntu; tu++) {
+                const int tx = cu.x + ((tu & 1) << 5), ty = cu.y + ((tu >> 1) << 5);
+                const int lx = p ? tx >> 1 : tx, ly = p ? ty >> 1 : ty;
+                uint32_t o = 0;
+                if (cu.inter_kind != SVT_AMD_EP_INTER_SKIP) {
+                    const T *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
+                    int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
+                    o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[wave],
+                                           (p ? cu.chroma_qp : cu.qp) + (sizeof(T) == 2 ? 12 : 0), F.slice_type, p ? 0u : cu.dz_offset, p == 0,
+                                           p == 0 && amvp, D);
+                }
+                if (lane == 0) { /* a 64x64 unit: entries 1..4 = its four transform units */
+                    SvtAmdLcuCuResult &E = R.cu[ci + (N == 64 ? 1 + tu : 0)];
+                    E.nz[p] = (uint16_t)(o & 0xffff), E.cbf[p] = (uint8_t)((o >> 17) & 1), E.only_dc[p] = (uint8_t)((o >> 16) & 1);
+                }
+                any |= (o >> 17) & 1;
+            }
+            if (N == 64 && lane == 0) /* transformUnitArray[0]: chroma flags OR-ed (:4263-4281), luma only by EncodeTuCalcCost */
+                R.cu[ci].nz[p] = 0, R.cu[ci].only_dc[p] = 0, R.cu[ci].cbf[p] = (uint8_t)(any && (p != 0 || amvp));
+            if (shared_scratch) {
+                EP_WAVE_SYNC();
+                if (lane == 0)
+                    atomicExch(&S.decide_lock, 0u);
+            }
         }
     }
     __syncthreads();
@@ -629,33 +669,9 @@ __device__ __forceinline__ void ep_encode_lcu(const EpPicture &P, const typename
         for (int ci = 0; ci < num_cus; ci++) {
             const LcuCu cu = L.cus[ci];
             const int N = cu.size;
-            if (cu.pred_mode == 1) { /* INTER_MODE, 2Nx2N (EbCodingLoop.c:3817-4400): predicted above */
+            if (cu.pred_mode == 1) { /* INTER_MODE: predicted and transformed above; here the unit only takes its place in the coding order */
                 if (P.prof)
-                    c1 = __builtin_readcyclecounter(), c_pred += c1 - c0;
-                const int ntu = N == 64 ? 4 : 1, TS = N == 64 ? 32 : N, n = p ? TS >> 1 : TS;
-                const bool amvp = cu.inter_kind == SVT_AMD_EP_INTER_AMVP;
-                const EpDecide D = {P.cost, S.qbuf, F.full_lambda, N == TS ? F.cbf_bits[1] : F.cbf_bits[0], N == TS ? F.cbf_bits[3] : F.cbf_bits[2],
-                                    F.pm_core,      1,      S.cfbuf,       S.Pq};
-                uint32_t any = 0;
-                for (int tu = 0; tu < ntu; tu++) {
-                    const int tx = cu.x + ((tu & 1) << 5), ty = cu.y + ((tu >> 1) << 5);
-                    const int lx = p ? tx >> 1 : tx, ly = p ? ty >> 1 : ty;
-                    uint32_t o = 0;
-                    if (cu.inter_kind != SVT_AMD_EP_INTER_SKIP) {
-                        const T *src = p == 0 ? L.src_y + ly * 64 + lx : L.src_c[p - 1] + ly * 32 + lx;
-                        int16_t *coeff = p == 0 ? R.coeff_y + ly * 64 + lx : (p == 1 ? R.coeff_cb : R.coeff_cr) + ly * 32 + lx;
-                        o = ep_encode_plane<T>(n, lane, src, p ? 32 : 64, L.at(p, lx, ly), (size_t)L.pitch(p), coeff, p ? 32 : 64, tiles[p],
-                                               (p ? cu.chroma_qp : cu.qp) + (sizeof(T) == 2 ? 12 : 0), F.slice_type, p ? 0u : cu.dz_offset, p == 0,
-                                               p == 0 && amvp, D);
-                    }
-                    if (lane == 0) { /* a 64x64 unit: entries 1..4 = its four transform units */
-                        SvtAmdLcuCuResult &E = R.cu[ci + (N == 64 ? 1 + tu : 0)];
-                        E.nz[p] = (uint16_t)(o & 0xffff), E.cbf[p] = (uint8_t)((o >> 17) & 1), E.only_dc[p] = (uint8_t)((o >> 16) & 1);
-                    }
-                    any |= (o >> 17) & 1;
-                }
-                if (N == 64 && lane == 0) /* transformUnitArray[0]: chroma flags OR-ed (:4263-4281), luma only by EncodeTuCalcCost */
-                    R.cu[ci].nz[p] = 0, R.cu[ci].only_dc[p] = 0, R.cu[ci].cbf[p] = (uint8_t)(any && (p != 0 || amvp));
+                    c1 = __builtin_readcyclecounter();
             } else if (cu.pred_mode == 2 && N <= 32) {
                 ep_intra_predict_plane<T>(L, F, cu, p, lane, border[p], ref[p], P.prof && p == 0, c_ph);
                 if (P.prof)
