@@ -478,9 +478,6 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             Nb.top_mode = (uint8_t)tp, Nb.top_intra = (uint8_t)(tp >> 8), Nb.top_depth = (uint8_t)(tp >> 16), Nb.top_skip = (uint8_t)(tp >> 24);
             md_context_generation(&M.S, leaf, st.y, &Nb);
             M.S.cu[leaf].split = (uint8_t)md_skip_small_cu(&P, &M.lcu, &M.S, leaf, st.depth);
-            uint32_t mpm[3] = {0, 0, 0};
-            if (P.mpm_search && !M.lcu.restrict_intra_global_motion)
-                md_mpm_modes(M.S.cu[leaf].left_intra_mode, M.S.cu[leaf].top_intra_mode, mpm);
             int ncand = 0;
             if (st.depth != 0 && (islice || st.depth == 3 || !M.lcu.restrict_intra_global_motion))
                 if (!(P.limit_intra && st.x == 0 && st.y == 0))
@@ -500,8 +497,28 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     }
                     M.V.nb[k] = u;
                 }
-                const int totalMerge = md_nmm(&P, N);
-                md_amvp_merge_lists(&P, D.X, M.V.nb, D.X->tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, N, totalMerge, &M.V.T);
+            }
+            M.ncand = ncand; /* the intra candidates so far (P / B pictures: the lists below are made by three waves) */
+        }
+        if constexpr (INTER) {
+            /* GenerateL0L1AmvpMergeLists: the AMVP candidates of list 0, of list 1 and the merge candidates share their inputs and nothing else - lane 0 of waves
+             * 0, 1 and 2 makes one each (three chains of LDS round trips side by side instead of one after the other) */
+            __syncthreads();
+            if (lane == 0 && wave < 3) {
+                const MdStats st = md_stats(M.leaf);
+                md_amvp_merge_lists_parts(&P, D.X, M.V.nb, D.X->tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T, 1 << wave);
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            const int leaf = M.leaf;
+            const MdStats st = md_stats(leaf);
+            int ncand = M.ncand;
+            uint32_t mpm[3] = {0, 0, 0};
+            if (P.mpm_search && !M.lcu.restrict_intra_global_motion)
+                md_mpm_modes(M.S.cu[leaf].left_intra_mode, M.S.cu[leaf].top_intra_mode, mpm);
+            if constexpr (INTER) {
+                const int totalMerge = md_nmm(&P, st.size);
                 ncand = md_inter_candidates(&P, &M.lcu, &M.V.me[md_raster_index(&st)], &M.V.T, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), totalMerge,
                                             M.cand, ncand);
             }

@@ -670,8 +670,10 @@ MD_FN int md_nmm(const SvtAmdMdPicture *P, int cuSize) { return P->nmm_level_md 
 /* GenerateL0L1AmvpMergeLists (Codec/EbAdaptiveMotionVectorPrediction.c:2117-3005), generateAmvpTableMd on.  nb[]: the spatial
  * neighbours with the availability the reference derives (:2256-2340: scan order, array bound, inter mode, tile edges); map: the
  * co-located picture's motion field at this LCU (entry 1 = the LCU to the right), NULL when the temporal candidate is off. */
-MD_FN void md_amvp_merge_lists(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const MdMvUnit nb[5], const SvtAmdTmvpLcu *map, int ox, int oy,
-                               int size, int totalMerge, MdInterLists *o)
+/* parts: 1 = the AMVP candidates of list 0, 2 = of list 1, 4 = the merge candidates - three computations that share their inputs and nothing else (the kernel
+ * runs them on three waves); 7 = all */
+MD_FN void md_amvp_merge_lists_parts(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const MdMvUnit nb[5], const SvtAmdTmvpLcu *map, int ox, int oy,
+                                     int size, int totalMerge, MdInterLists *o, int parts)
 {
     const int bslice = P->slice_type == 0;
     const MdMvUnit *A0 = &nb[MD_A0], *A1 = &nb[MD_A1], *B0 = &nb[MD_B0], *B1 = &nb[MD_B1], *B2 = &nb[MD_B2];
@@ -680,6 +682,8 @@ MD_FN void md_amvp_merge_lists(const SvtAmdMdPicture *P, const SvtAmdMdInter *X,
     if (map)
         tp = md_tmvp_position(P, map, ox, oy, size);
     for (int list = 0; list < (bslice ? 2 : 1); list++) {
+        if (!(parts & (1 << list)))
+            continue;
         const uint64_t targetPoc = X->ref_poc[list];
         MdMv *c = o->amvp[list];
         int num = 0, ax = 0;
@@ -717,6 +721,8 @@ MD_FN void md_amvp_merge_lists(const SvtAmdMdPicture *P, const SvtAmdMdInter *X,
         }
         o->amvp_count[list] = (uint8_t)num;
     }
+    if (!(parts & 4))
+        return;
     /* merge candidates (:2649-2990) */
     MdMergeCand *m = o->merge;
     int idx = 0;
@@ -775,6 +781,11 @@ MD_FN void md_amvp_merge_lists(const SvtAmdMdPicture *P, const SvtAmdMdInter *X,
         }
     } while (0);
     o->merge_count = (uint8_t)idx;
+}
+MD_FN void md_amvp_merge_lists(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const MdMvUnit nb[5], const SvtAmdTmvpLcu *map, int ox, int oy,
+                               int size, int totalMerge, MdInterLists *o)
+{
+    md_amvp_merge_lists_parts(P, X, nb, map, ox, oy, size, totalMerge, o, 7);
 }
 
 /* ClipMV (:54-72): the bounds are computed in 32-bit unsigned arithmetic and narrowed to 16 bits, as written */
