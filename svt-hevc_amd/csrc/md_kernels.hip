@@ -585,6 +585,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
         __syncthreads();
         MD_PROF(2);
+        if (D.prof && t == 0)
+            M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1;
         /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop) ---- */
         for (int c = wave; c < ncand; c += 4) {
             uint32_t sad = 0;
@@ -1089,6 +1091,7 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
                 q[k] += U.md.prof[k];
             q[9] += c_md - U.md.prof_t;      /* the LCU's state leaving LDS */
             q[12] += c_wait - c_ticket;       /* waiting for the LCU's neighbours */
+            q[13] += U.md.prof[13], q[14] += U.md.prof[14]; /* candidates of the fast loops / units tested */
             q[15] += 1;
         }
         if (D.encode) {
