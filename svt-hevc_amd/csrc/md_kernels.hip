@@ -119,6 +119,8 @@ struct MdShared {
     unsigned long long costs[MD_MAX_CAND], fast_rate[MD_MAX_CAND];
     uint32_t sad[MD_MAX_CAND];
     uint8_t evaluated[MD_MAX_CAND];
+    uint8_t heavy[MD_MAX_CAND];    /* the candidates the fast loop has to predict and measure, packed: the waves take them in turn */
+    int nheavy;
     MdBuffers B;
     uint8_t types[MD_MAX_BUF], best[MD_MAX_BUF];
     uint32_t ycbf[MD_MAX_BUF];
@@ -561,6 +563,18 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 e = 3; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
             if (in)
                 M.evaluated[lane] = e;
+            {   /* what the fast loop really has to do: predict + measure the evaluated candidates that are neither most-probable-mode placeholders nor the open-loop
+                 * intra candidate whose distortion stands (:2042).  Most P / B candidates are not among them (the motion-estimation candidates bring their distortion:
+                 * only the best of them is evaluated), so the list is packed - a wave per LIST entry keeps all four waves on real work */
+                const bool heavy = in && e && !c.mpm && !(lane == bestFirst && c.type == MD_INTRA);
+                const unsigned long long hm = __ballot(heavy);
+                if (heavy)
+                    M.heavy[__popcll(hm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                if (in && !heavy)
+                    M.sad[lane] = (e && !c.mpm) ? c.me_dist : 0u;
+                if (lane == 0)
+                    M.nheavy = __popcll(hm);
+            }
             if constexpr (INTER) { /* the first eight inter candidates the loop evaluates keep their prediction for the full loop */
                 const bool q = e && c.type == MD_INTER;
                 const unsigned long long qm = __ballot(q);
@@ -588,14 +602,11 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         if (D.prof && t == 0)
             M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1;
         /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop) ---- */
-        for (int c = wave; c < ncand; c += 4) {
+        for (int k = wave; k < M.nheavy; k += 4) {
+            const int c = M.heavy[k];
             uint32_t sad = 0;
             const MdCand cd = M.cand[c];
-            const int ev = M.evaluated[c];
-            const bool reuse = c == M.best_first && cd.type == MD_INTRA; /* the open-loop distortion stands (:2042) */
-            if (ev && !cd.mpm && reuse) {
-                sad = cd.me_dist;
-            } else if (ev && !cd.mpm) {
+            {
                 if (cd.type == MD_INTER) {
                     if constexpr (INTER) {
                         uint8_t *pr = M.V.slot[c] >= 0 ? M.V.cpred[M.V.slot[c]] : M.V.wpred[wave];
