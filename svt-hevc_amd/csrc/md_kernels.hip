@@ -512,6 +512,55 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             }
             __syncthreads();
         }
+        if constexpr (INTER) {
+            /* the inter candidates (md_inter_candidates, md_logic.h): the motion-estimation candidates and the merge candidates are independent of one another - lanes
+             * 0..2 and 3..7 of wave 0 make one each (md_choose_mvp / the duplicate check side by side) and a ballot puts the survivors in the scalar order */
+            if (wave == 0) {
+                const MdStats st = md_stats(M.leaf);
+                const int n0 = M.ncand, totalMerge = md_nmm(&P, st.size);
+                const SvtAmdMeCuResult *me = &M.V.me[md_raster_index(&st)];
+                bool keep = false;
+                MdCand c;
+                c.type = MD_INTER, c.intra_mode = 0, c.mpm = 0, c.dist_ready = 0, c.me_dist = 0, c.dir = 0, c.merge_flag = 0, c.merge_index = 0;
+                c.mvp_idx[0] = c.mvp_idx[1] = 0, c.pad[0] = c.pad[1] = c.pad[2] = 0;
+                c.mv[0].x = c.mv[0].y = c.mv[1].x = c.mv[1].y = 0, c.mvp[0].x = c.mvp[0].y = c.mvp[1].x = c.mvp[1].y = 0;
+                if (lane < 3) {
+                    if (lane < me->total_me_candidate_index) {
+                        const int dir = me->direction[lane];
+                        if (!(dir == MD_BI && P.depth_mode == 0 && M.lcu.lcu_md_mode == 10)) {
+                            keep = true;
+                            c.dist_ready = 1, c.me_dist = me->distortion[lane], c.dir = (uint8_t)dir;
+                            c.mv[0].x = me->x_mv_l0, c.mv[0].y = me->y_mv_l0, c.mv[1].x = me->x_mv_l1, c.mv[1].y = me->y_mv_l1;
+                            md_choose_mvp(&P, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), &M.V.T, &c);
+                        }
+                    }
+                } else if (lane < 8) {
+                    const int k = lane - 3;
+                    if (k < totalMerge && k < M.V.T.merge_count) {
+                        const MdMergeCand mc = M.V.T.merge[k];
+                        bool dup = false;
+                        for (int j = 0; j < k; j++) {
+                            const MdMergeCand d = M.V.T.merge[j];
+                            const bool f0 = mc.mv[0].x == d.mv[0].x && mc.mv[0].y == d.mv[0].y;
+                            const bool f1 = mc.dir != MD_L0 && mc.mv[1].x == d.mv[1].x && mc.mv[1].y == d.mv[1].y;
+                            const bool same = mc.dir == MD_L0 ? f0 : (mc.dir == MD_L1 ? f1 : (f0 && f1));
+                            dup = dup || (mc.dir == d.dir && same);
+                        }
+                        if (!dup) {
+                            keep = true;
+                            c.dir = mc.dir, c.merge_flag = 1, c.merge_index = (uint8_t)k, c.mv[0] = mc.mv[0], c.mv[1] = mc.mv[1];
+                        }
+                    }
+                }
+                const unsigned long long km = __ballot(keep);
+                if (keep)
+                    M.cand[n0 + __popcll(km & ((1ull << lane) - 1ull))] = c;
+                EP_WAVE_SYNC();
+                if (lane == 0)
+                    M.ncand = n0 + __popcll(km);
+                EP_WAVE_SYNC();
+            }
+        }
         if (t == 0) {
             const int leaf = M.leaf;
             const MdStats st = md_stats(leaf);
@@ -519,11 +568,6 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             uint32_t mpm[3] = {0, 0, 0};
             if (P.mpm_search && !M.lcu.restrict_intra_global_motion)
                 md_mpm_modes(M.S.cu[leaf].left_intra_mode, M.S.cu[leaf].top_intra_mode, mpm);
-            if constexpr (INTER) {
-                const int totalMerge = md_nmm(&P, st.size);
-                ncand = md_inter_candidates(&P, &M.lcu, &M.V.me[md_raster_index(&st)], &M.V.T, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), totalMerge,
-                                            M.cand, ncand);
-            }
             int bufferTotal = md_nfl(&P, &M.lcu, st.size);
             ncand = md_mpm_injection(&P, &M.lcu, &st, M.cand, ncand, &bufferTotal, mpm);
             bufferTotal = ncand < bufferTotal ? ncand : bufferTotal;
