@@ -138,7 +138,7 @@ static __constant__ int8_t c_ep_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10,
  * (x, y) of the unit's plane-p block goes */
 template <typename T, typename Store>
 __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int abs_x, int abs_y, int N, int inter_dir, const int16_t (*mv)[2], int p, int lane,
-                                                      EpMcScratch<T> &M, Store store)
+                                                      EpMcScratch<T> &M, Store store, int tile_first = 0, int tile_step = 1)
 {
     constexpr int WP = EpMcScratch<T>::WP;
     constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
@@ -147,8 +147,11 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
     const int n = chroma ? N >> 1 : N, tn = n > 32 ? 32 : n, lgt = 31 - __clz(tn);
     const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3, rows = tn + ntaps - 1;
     const bool bi = inter_dir == 2;
-    for (int ty0 = 0; ty0 < n; ty0 += 32)
-        for (int tx0 = 0; tx0 < n; tx0 += 32) {
+    /* the block goes in 32x32 tiles (one for blocks up to 32x32); tile_first / tile_step let several waves share the tiles of a 64x64 block */
+    const int ntile = n > 32 ? 4 : 1;
+    for (int ti = tile_first; ti < ntile; ti += tile_step) {
+        {
+            const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
             bool second = false;
             for (int l = 0; l < 2; l++) {
                 if (!(bi || inter_dir == l))
@@ -235,6 +238,7 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                 second = true;
             }
         }
+    }
 }
 
 template <typename T>

@@ -343,11 +343,12 @@ __device__ __forceinline__ void md_build_refs_ol(const MdPictureDev &D, MdShared
 }
 
 /* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of the luma block of a candidate, by one wave, into dst (pitch = unit size) */
-__device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst)
+__device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
+                                                 int tile_first = 0, int tile_step = 1)
 {
     int16_t mv[2][2];
     mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
-    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, 0, lane, mc, [&](int x, int y) { return dst + y * N + x; });
+    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, 0, lane, mc, [&](int x, int y) { return dst + y * N + x; }, tile_first, tile_step);
     EP_WAVE_SYNC();
 }
 
@@ -614,8 +615,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 const unsigned long long hm = __ballot(heavy);
                 if (heavy)
                     M.heavy[__popcll(hm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-                if (in && !heavy)
-                    M.sad[lane] = (e && !c.mpm) ? c.me_dist : 0u;
+                if (in) /* the heavy candidates' distortion is summed up by the fast loop (several waves may add to it) */
+                    M.sad[lane] = (!heavy && e && !c.mpm) ? c.me_dist : 0u;
                 if (lane == 0)
                     M.nheavy = __popcll(hm);
             }
@@ -646,7 +647,40 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         if (D.prof && t == 0)
             M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1;
         /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop) ---- */
-        for (int k = wave; k < M.nheavy; k += 4) {
+        bool tiled64 = false;
+        if constexpr (INTER) {
+            /* a 64x64 unit's candidates are motion-compensated in four 32x32 tiles: wave w takes tile w of EVERY candidate (all four waves work whatever the number of
+             * candidates) and adds its part of the distortion */
+            tiled64 = N == 64 && !M.any_intra;
+            if (tiled64) {
+                const int nh = M.nheavy;
+                for (int k = 0; k < nh; k++) {
+                    const int c = M.heavy[k], sl = M.V.slot[c];
+                    const MdCand cd = M.cand[c];
+                    uint32_t sad = 0;
+                    if (sl >= 0) {
+                        uint8_t *pr = M.V.cpred[sl];
+                        md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr, wave, 4);
+                        const int ty0 = (wave >> 1) << 5, tx0 = (wave & 1) << 5;
+                        for (int e = lane; e < 32 * 32; e += 64) {
+                            const int y = ty0 + (e >> 5), x = tx0 + (e & 31);
+                            sad += (uint32_t)abs((int)pr[y * 64 + x] - (int)L.src[(st.y + y) * 64 + st.x + x]);
+                        }
+                    } else if (wave == (k & 3)) { /* no slot left to keep the prediction in: the whole candidate on one wave */
+                        uint8_t *pr = M.V.wpred[wave];
+                        md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
+                        for (int e = lane; e < N * N; e += 64)
+                            sad += (uint32_t)abs((int)pr[e] - (int)L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]);
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1)
+                        sad += __shfl_xor(sad, o);
+                    if (lane == 0 && sad)
+                        atomicAdd(&M.sad[c], sad);
+                }
+            }
+        }
+        for (int k = wave; k < M.nheavy && !tiled64; k += 4) {
             const int c = M.heavy[k];
             uint32_t sad = 0;
             const MdCand cd = M.cand[c];
@@ -744,7 +778,36 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         MD_PROF(4);
         /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
         const int nfull = M.nfull;
-        for (int f = wave; f < nfull; f += 4) {
+        bool split64 = false;
+        if constexpr (INTER) {
+            /* a 64x64 unit has four 32x32 transform units per candidate: a wave per (candidate, transform unit) instead of a wave per candidate - with the usual one or
+             * two survivors all four waves work.  The candidates of a 64x64 unit are motion-compensated (no intra candidate at depth 0). */
+            split64 = N == 64 && nfull <= 4 && !M.any_intra;
+            if (split64) {
+                bool sync = false;
+                for (int f = 0; f < nfull; f++) {
+                    const int ci = M.B.cand[M.best[f]], pci = M.B.pred[M.best[f]] < 0 ? ci : M.B.pred[M.best[f]];
+                    if (!(M.V.slot[pci] >= 0 && M.evaluated[pci])) {
+                        sync = true;
+                        if (wave == f)
+                            md_predict_inter(E, M.cand[pci], x0, y0, N, lane, M.V.mc[wave], M.V.wpred[f]);
+                    }
+                }
+                if (sync)
+                    __syncthreads();
+                for (int f = 0; f < nfull; f++) {
+                    const int b = M.best[f], ci = M.B.cand[b], pci = M.B.pred[b] < 0 ? ci : M.B.pred[b];
+                    const uint8_t *pred = (M.V.slot[pci] >= 0 && M.evaluated[pci]) ? M.V.cpred[M.V.slot[pci]] : M.V.wpred[f];
+                    const int tu = wave, off = ((tu & 1) << 5) + ((tu >> 1) << 5) * 64;
+                    const MdFl o = md_full_loop_unit<32>(lane, &L.src[st.y * 64 + st.x] + off, 64, pred + off, 64, nullptr, M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost,
+                                                         M.cand[ci].type, M.cand[ci].intra_mode, 0, pf);
+                    if (lane == 0)
+                        M.fl[b][tu] = o;
+                    EP_WAVE_SYNC();
+                }
+            }
+        }
+        for (int f = wave; f < nfull && !split64; f += 4) {
             const int b = M.best[f], ci = M.B.cand[b];
             const MdCand cd = M.cand[ci];
             /* the buffer's luma prediction: the candidate the fast loop predicted there, or - predictionIsReadyLuma == 0 - a fresh one */
@@ -777,37 +840,54 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
         __syncthreads();
         MD_PROF(5);
-        /* ---- lane 0: TuCalcCostLuma, full cost, ProductFullModeDecision, CheckHighCostPartition ---- */
-        if (t == 0) {
-            uint32_t prevRootCbf = 1;
-            unsigned long long bestFullCost = 0xFFFFFFFFull;
-            for (int f = 0; f < nfull; f++) {
-                const int b = M.best[f], ci = M.B.cand[b];
+        /* ---- wave 0: TuCalcCostLuma + the full cost of every surviving candidate (a lane each), then lane 0: ProductFullModeDecision, CheckHighCostPartition ---- */
+        if (wave == 0) {
+            const bool have = lane < nfull;
+            int b = 0, ctype = 0;
+            uint32_t ycbf = 0;
+            unsigned long long bits = 0, dist[2] = {0, 0}, full = 0;
+            uint64_t mc = 0, sc = 0;
+            if (have) {
+                b = M.best[lane];
+                const int ci = M.B.cand[b];
                 const MdCand c = M.cand[ci];
-                if (!islice && c.type == MD_INTRA && prevRootCbf == 0)
-                    continue;
-                uint32_t ycbf = 0;
-                unsigned long long bits = 0, dist[2] = {0, 0};
+                ctype = c.type;
                 if (N == 64) {
                     for (int tu = 0; tu < 4; tu++)
                         md_tu_calc_cost(P, M.fl[b][tu], c.type, 64, 32, tu + 1, &ycbf, &bits, dist);
                 } else {
                     md_tu_calc_cost(P, M.fl[b][0], c.type, N, N, 0, &ycbf, &bits, dist);
                 }
-                M.ycbf[b] = ycbf, M.full_dist[b] = (uint32_t)dist[0];
                 if (M.lcu.chroma_encode_mode == 2 /* CHROMA_MODE_BEST */)
                     bits = md_pf_coeff_bits(pf, P.qp, bits);
-                uint64_t mc = 0, sc = 0;
                 if (c.type == MD_INTER)
-                    M.B.full_cost[b] = md_inter_full_luma_cost(&P, &M.S.cu[leaf], &c, N, ycbf, M.fast_rate[ci], (const uint64_t *)dist, bits, &mc, &sc);
+                    full = md_inter_full_luma_cost(&P, &M.S.cu[leaf], &c, N, ycbf, M.fast_rate[ci], (const uint64_t *)dist, bits, &mc, &sc);
                 else if (islice)
-                    M.B.full_cost[b] = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
+                    full = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
                 else
-                    M.B.full_cost[b] = md_intra_full_luma_cost_pslice(&P, N, ycbf, M.fast_rate[ci], dist[0], bits);
-                M.merge_cost[b] = mc, M.skip_cost[b] = sc, M.y_bits[b] = bits, M.y_dist[b][0] = dist[0], M.y_dist[b][1] = dist[1];
-                if (P.full_loop_escape && !islice && c.type == MD_INTER && M.B.full_cost[b] < bestFullCost)
-                    prevRootCbf = ycbf, bestFullCost = M.B.full_cost[b];
+                    full = md_intra_full_luma_cost_pslice(&P, N, ycbf, M.fast_rate[ci], dist[0], bits);
             }
+            /* the reference walks the candidates in order: an intra candidate after an inter one whose root cbf is 0 is not costed at all (full-loop escape, :4450-4460) and
+             * keeps whatever its buffer held */
+            uint32_t prevRootCbf = 1;
+            unsigned long long bestFullCost = 0xFFFFFFFFull, kept = 0;
+            for (int g = 0; g < nfull; g++) {
+                const int ty = __shfl(ctype, g);
+                const uint32_t yc = __shfl(ycbf, g);
+                const unsigned long long cs = __shfl(full, g);
+                if (!islice && ty == MD_INTRA && prevRootCbf == 0)
+                    continue;
+                kept |= 1ull << g;
+                if (P.full_loop_escape && !islice && ty == MD_INTER && cs < bestFullCost)
+                    prevRootCbf = yc, bestFullCost = cs;
+            }
+            if (have && ((kept >> lane) & 1ull)) {
+                M.ycbf[b] = ycbf, M.full_dist[b] = (uint32_t)dist[0], M.B.full_cost[b] = full;
+                M.merge_cost[b] = mc, M.skip_cost[b] = sc, M.y_bits[b] = bits, M.y_dist[b][0] = dist[0], M.y_dist[b][1] = dist[1];
+            }
+            EP_WAVE_SYNC();
+        }
+        if (t == 0) {
             int lowest = M.best[0];
             unsigned long long lowestCost = ~0ull;
             for (int f = 0; f < M.full_count; f++)

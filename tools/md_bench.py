@@ -151,6 +151,8 @@ def run_inter(lib, g, reps=3, encode=True, check=True):
         stages["sum_without_wait"] = round(float(tot[:12].sum()) / n / calls, 0)
         stages["fast_loop_candidates_per_unit"] = round(float(pr[:, 13].sum()) / max(1.0, float(pr[:, 14].sum())), 2)
         stages["units_tested_per_lcu"] = round(float(pr[:, 14].sum()) / n / calls, 2)
+        if os.environ.get("MD_BENCH_RAW"):
+            stages["raw_sums"] = [int(v) for v in pr.sum(axis=0)]
     lib.svt_amd_encdec_picture_destroy(ctx, pic)
     lib.svt_amd_context_destroy(ctx)
     return {"stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "pictures": [int(p) for p in g["picture_number"]], "leaves_tested_per_picture": tested // len(ts) * (reps - 1) if ts else 0,
