@@ -116,10 +116,10 @@ struct EpFlags {
 /* scratch of one plane pipeline's motion compensation: a tile of up to 32x32 samples at a time */
 template <typename T>
 struct EpMcScratch {
-    static constexpr int WP = 40;
-    T win[39 * WP];        /* reference window: (32 + 7) rows x columns */
-    int16_t tmp[39 * 32];  /* horizontally filtered rows */
-    int16_t raw[32 * 32];  /* list-0 intermediate of a bi-predicted tile */
+    static constexpr int WP = 40, TP = 44;
+    alignas(16) T win[39 * WP];        /* reference window: (32 + 7) rows x columns, rows 8-byte chunks */
+    alignas(16) int16_t tmp[32 * TP];  /* horizontally filtered rows, TRANSPOSED: column x at tmp + x * TP (a lane of the vertical pass reads one run of it) */
+    int16_t raw[32 * 32];              /* list-0 intermediate of a bi-predicted tile */
 };
 
 static __constant__ int8_t c_ep_luma_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1},
@@ -140,7 +140,7 @@ template <typename T, typename Store>
 __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int abs_x, int abs_y, int N, int inter_dir, const int16_t (*mv)[2], int p, int lane,
                                                       EpMcScratch<T> &M, Store store, int tile_first = 0, int tile_step = 1)
 {
-    constexpr int WP = EpMcScratch<T>::WP;
+    constexpr int WP = EpMcScratch<T>::WP, TP = EpMcScratch<T>::TP;
     constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
     const bool chroma = p != 0;
     const int B = (sizeof(T) == 2 || !chroma) ? 8192 : 0;
@@ -169,29 +169,55 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                     tx[k] = chroma ? (k < 4 ? (int)c_ep_chroma_taps[fx][k & 3] : 0) : (int)c_ep_luma_taps[fx][k];
                     tv[k] = chroma ? (k < 4 ? (int)c_ep_chroma_taps[fy][k & 3] : 0) : (int)c_ep_luma_taps[fy][k];
                 }
-                /* window: lane = column; every row's load is issued before the first is stored (one memory latency per window, not one
-                 * per row) */
-                if (lane < rows) {
-                    const int base = (iy + first) * stride + ix + first + lane;
-                    T v[39];
+                /* window: 8-byte chunks of the rows, a lane per chunk, every load issued before the first store (one memory latency per window, not one per row).
+                 * The chunks are not aligned (global memory takes that); one that leaves the plane is read sample by sample from clamped addresses. */
+                {
+                    constexpr int SPC = 8 / (int)sizeof(T); /* samples per chunk */
+                    const int cpr = (rows + SPC - 1) / SPC, nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
+                    const int base0 = (iy + first) * stride + ix + first;
+                    for (int i0 = 0; i0 < nchunk; i0 += 256) {
+                        uint2 v[4];
 #pragma unroll
-                    for (int j = 0; j < 39; j++)
-                        if (j < rows)
-                            v[j] = plane[min(max(base + j * stride, 0), last)];
+                        for (int u = 0; u < 4; u++) {
+                            const int i = i0 + u * 64 + lane;
+                            if (i < nchunk) {
+                                const int j = (i * inv) >> 16, m = i - j * cpr, idx = base0 + j * stride + m * SPC;
+                                if (idx >= 0 && idx + SPC <= last + 1) {
+                                    __builtin_memcpy(&v[u], plane + idx, 8);
+                                } else {
+                                    T e[SPC];
 #pragma unroll
-                    for (int j = 0; j < 39; j++)
-                        if (j < rows)
-                            M.win[j * WP + lane] = v[j];
+                                    for (int q = 0; q < SPC; q++)
+                                        e[q] = plane[min(max(idx + q, 0), last)];
+                                    __builtin_memcpy(&v[u], e, 8);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int i = i0 + u * 64 + lane;
+                            if (i < nchunk) {
+                                const int j = (i * inv) >> 16, m = i - j * cpr;
+                                *reinterpret_cast<uint2 *>(&M.win[j * WP + m * SPC]) = v[u];
+                            }
+                        }
+                    }
                 }
                 EP_WAVE_SYNC();
-                /* horizontal pass of every window row: a lane slides the taps over a run of seg outputs (seg + taps - 1 reads) */
+                /* horizontal pass of every window row: a lane slides the taps over a run of seg outputs (seg + taps - 1 samples, read as whole words) */
                 const int seg = tn < 8 ? tn : 8, lgs = tn < 8 ? lgt : 3, spr = tn >> lgs; /* runs per row */
                 for (int i = lane; i < rows * spr; i += 64) {
                     const int j = i >> (lgt - lgs), x0 = (i & (spr - 1)) << lgs;
+                    constexpr int NW = 4 * (int)sizeof(T); /* words holding 16 samples */
+                    uint32_t w[NW];
+                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(&M.win[j * WP + x0]);
+#pragma unroll
+                    for (int k = 0; k < NW; k++)
+                        w[k] = wp[k];
                     int in[15];
 #pragma unroll
                     for (int k = 0; k < 15; k++)
-                        in[k] = k < seg + ntaps - 1 ? (int)M.win[j * WP + x0 + k] : 0;
+                        in[k] = sizeof(T) == 1 ? (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) : (int)((w[(k >> 1) % NW] >> (16 * (k & 1))) & 0xFFFFu);
 #pragma unroll
                     for (int o = 0; o < 8; o++)
                         if (o < seg) {
@@ -200,19 +226,37 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                             for (int k = 0; k < 8; k++)
                                 if (k < ntaps)
                                     hs += tx[k] * in[o + k];
-                            M.tmp[j * 32 + x0 + o] = (int16_t)((hs - (B << s1)) >> s1);
+                            M.tmp[(x0 + o) * TP + j] = (int16_t)((hs - (B << s1)) >> s1);
                         }
                 }
                 EP_WAVE_SYNC();
-                /* vertical pass: a lane owns a column and a run of rpl rows (rpl + taps - 1 reads) */
+                /* vertical pass: a lane owns a column and a run of rpl rows (rpl + taps - 1 reads: one stretch of the transposed rows) */
                 const int rpl = tn >= 8 ? (tn * tn) >> 6 : 1, run = rpl < 1 ? 1 : rpl; /* 32: 16, 16: 4, 8: 1, 4: 1 */
                 {
                     const int x = lane & (tn - 1), y0 = (lane >> lgt) * run;
                     if (y0 < tn) {
                         int in[23];
+                        const int16_t *col = &M.tmp[x * TP + y0];
+                        if (run >= 4) { /* y0 is a multiple of 4 and TP of 4: 8-byte words */
+                            const uint2 *cp = reinterpret_cast<const uint2 *>(col);
 #pragma unroll
-                        for (int k = 0; k < 23; k++)
-                            in[k] = k < run + ntaps - 1 ? (int)M.tmp[(y0 + k) * 32 + x] : 0;
+                            for (int k = 0; k < 6; k++)
+                                if (4 * k < run + ntaps - 1) {
+                                    const uint2 d = cp[k];
+                                    in[4 * k] = (int)(int16_t)(d.x & 0xFFFFu), in[4 * k + 1] = (int)(int16_t)(d.x >> 16);
+                                    in[4 * k + 2] = (int)(int16_t)(d.y & 0xFFFFu);
+                                    if (4 * k + 3 < 23)
+                                        in[4 * k + 3] = (int)(int16_t)(d.y >> 16);
+                                } else {
+                                    in[4 * k] = in[4 * k + 1] = in[4 * k + 2] = 0;
+                                    if (4 * k + 3 < 23)
+                                        in[4 * k + 3] = 0;
+                                }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 23; k++)
+                                in[k] = k < run + ntaps - 1 ? (int)col[k] : 0;
+                        }
 #pragma unroll
                         for (int o = 0; o < 16; o++)
                             if (o < run) {

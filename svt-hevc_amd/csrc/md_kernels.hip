@@ -1255,6 +1255,8 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
     }
 }
 
+static_assert(sizeof(MdEpShared<true>) <= 160 * 1024 && sizeof(MdEpShared<false>) <= 160 * 1024, "the LCU state has to fit the 160 KB of LDS of a CU");
+
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
 extern "C" int svt_amd_md_picture_supported(const SvtAmdMdPicture *P) { return P ? md_picture_supported(P) : 0; }
 extern "C" int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X) { return P && X ? md_picture_supported_inter(P, X) : 0; }

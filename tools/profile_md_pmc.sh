@@ -10,8 +10,10 @@ i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS" \
+           "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ SQ_INSTS_BRANCH" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  if [ -n "$MD_PMC_ONLY" ] && [ "$MD_PMC_ONLY" != "$i" ]; then continue; fi
   timeout 300 rocprofv3 --pmc $set -d $O/p$i -o pmc --output-format csv -- python tools/md_bench.py 3840 2160 7 2 inter 5 > $O/p$i.log 2>&1 < /dev/null
 done
 python - "$O" <<'PY'
@@ -44,6 +46,9 @@ with open(O + "/md_pmc.txt", "w") as out:
                 a.get(c, 0) / wc for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA")), file=out)
         if a.get("SQ_LDS_IDX_ACTIVE"):
             print("  LDS bank conflict cycles / active %.2f" % (a["SQ_LDS_BANK_CONFLICT"] / a["SQ_LDS_IDX_ACTIVE"]), file=out)
+        if a.get("SQC_ICACHE_REQ"):
+            print("  instruction cache: hit rate %.3f, misses per wave %.0f, fetch latency %.0f cycles (SQ_IFETCH_LEVEL / SQ_IFETCH)" % (
+                a.get("SQC_ICACHE_HITS", 0) / a["SQC_ICACHE_REQ"], a.get("SQC_ICACHE_MISSES", 0) / 992.0, a.get("SQ_IFETCH_LEVEL", 0) / max(1.0, a.get("SQ_IFETCH", 0))), file=out)
         if "FETCH_SIZE" in a:
             print("  FETCH_SIZE %.1f MB raw (x2 gfx950 correction: %.1f MB)  WRITE_SIZE %.1f MB" % (a["FETCH_SIZE"] / 1024, a["FETCH_SIZE"] / 512, a.get("WRITE_SIZE", 0) / 1024), file=out)
 print(open(O + "/md_pmc.txt").read())
