@@ -67,7 +67,7 @@ struct MdLocal8 {
     static constexpr int PY = 144, X0 = 16;
     uint8_t y[65 * PY];
     uint32_t info[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
-    uint8_t src[64 * 64];
+    alignas(16) uint8_t src[64 * 64]; /* rows of words: the distortion and residual loops read four samples at a time */
     __device__ __forceinline__ uint8_t *at(int x, int y_) { return &y[(y_ + 1) * PY + X0 + x]; }
     /* neighbour-array entry of the 4x4 cell at luma sample (x, y) relative to the LCU: what lies below the LCU, right of it (from its
      * first row on) or right of the top-right LCU is never written before this LCU */
@@ -86,7 +86,7 @@ struct MdFl {
 
 /* what only the closed-loop (I picture) / only the inter kernel keeps in LDS */
 struct MdClosedLoop {
-    uint8_t pred[MD_MAX_BUF][32 * 32];
+    alignas(16) uint8_t pred[MD_MAX_BUF][32 * 32];
     int16_t recon_coeff[MD_MAX_BUF][32 * 32];
     uint8_t best_rec[4][64 * 64];
 };
@@ -96,11 +96,11 @@ struct MdInterShared {
     SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
     MdMvUnit nb[5];
     MdInterLists T;
-    uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
+    alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
     uint8_t cpred[8][64 * 64];     /* the fast loop's predictions of the first 8 motion-compensated candidates, kept for the full loop */
     int8_t slot[MD_MAX_CAND];      /* candidate -> cpred slot, -1 = none */
     EpMcScratch<uint8_t> mc[4];
-    uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (merge / skip decision of the encode pass) */
+    alignas(16) uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (merge / skip decision of the encode pass) */
     uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
     uint8_t fin_leaf[SVT_AMD_LCU_MAX_CUS];
     int nfin;
@@ -238,10 +238,15 @@ __device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, 
     const int r = lane & (N - 1);
     const bool active = lane < N;
     int x[N];
-    if (active) {
+    if (active) { /* rows start on word boundaries (units sit on 4-sample grids of word-aligned planes) */
+        const uint32_t *sw = reinterpret_cast<const uint32_t *>(src + r * srcPitch), *pw = reinterpret_cast<const uint32_t *>(pred + r * predPitch);
 #pragma unroll
-        for (int j = 0; j < N; j++)
-            x[j] = (int)src[r * srcPitch + j] - (int)pred[r * predPitch + j];
+        for (int j = 0; j < N; j += 4) {
+            const uint32_t a = sw[j >> 2], b = pw[j >> 2];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                x[j + k] = (int)((a >> (8 * k)) & 0xFFu) - (int)((b >> (8 * k)) & 0xFFu);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < N; j++)
@@ -395,15 +400,13 @@ __device__ __forceinline__ void md_tu_calc_cost(const SvtAmdMdPicture &P, const 
 }
 
 /* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
+/* what the LCU's mode decision reads that no other LCU of the picture writes (its records, its source): into LDS BEFORE the workgroup waits for the LCU's neighbours */
 template <bool INTER>
-__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
+__device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int t = threadIdx.x;
     MdLocal8 &L = M.L;
-    const int W = (int)P.width, H = (int)P.height;
-    const int lw = min(64, W - lcu_x), lh = min(64, H - lcu_y);
-    const bool islice = P.slice_type == 2, open_loop = P.intra_md_open_loop != 0;
-    /* ---- the LCU's surroundings into LDS ---- */
+    const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
     for (int i = t; i < (int)sizeof(SvtAmdMdLcu); i += 256)
         ((uint8_t *)&M.lcu)[i] = ((const uint8_t *)&D.lcus[lcu])[i];
     static_assert(sizeof(SvtAmdOisLcuResult) % 4 == 0 && sizeof(SvtAmdMeLcuResult) % 4 == 0 && sizeof(SvtAmdMeCuResult) % 4 == 0 && sizeof(SvtAmdTmvpLcu) % 8 == 0, "record sizes");
@@ -416,6 +419,30 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             for (int i = t; i < (int)(2 * sizeof(SvtAmdTmvpLcu) / 4); i += 256)
                 ((uint32_t *)M.V.tmvp)[i] = ((const uint32_t *)&D.tmvp[lcu])[i];
     }
+    for (int i = t; i < 64 * 64 / 4; i += 256) {
+        const int y = i >> 4, x = (i & 15) * 4;
+        uint32_t v = 0;
+        if (x < lw && y < lh)
+            v = *(const uint32_t *)(D.src[0] + (size_t)(lcu_y + y) * D.src_pitch[0] + lcu_x + x);
+        *(uint32_t *)&L.src[y * 64 + x] = v;
+    }
+    __syncthreads();
+    if (t == 0) {
+        md_construct_cu_array(&M.S, &M.lcu);
+        M.cu_idx = 0, M.done = 0;
+    }
+}
+
+/* ModeDecisionLcu of one LCU (its inputs are in LDS: md_lcu_inputs): on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
+template <bool INTER>
+__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    MdLocal8 &L = M.L;
+    const int W = (int)P.width, H = (int)P.height;
+    const int lw = min(64, W - lcu_x), lh = min(64, H - lcu_y);
+    const bool islice = P.slice_type == 2, open_loop = P.intra_md_open_loop != 0;
+    /* ---- the LCU's surroundings (what its neighbours left in the picture's maps) into LDS ---- */
     for (int i = t; i < 17 * 36; i += 256) {
         const int cy = i / 36 - 1, cx = i - (cy + 1) * 36 - 1;
         uint32_t v = 0xFFFFFFFFu;
@@ -447,18 +474,6 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             M.V.mvu[i] = u;
         }
     }
-    for (int i = t; i < 64 * 64 / 4; i += 256) {
-        const int y = i >> 4, x = (i & 15) * 4;
-        uint32_t v = 0;
-        if (x < lw && y < lh)
-            v = *(const uint32_t *)(D.src[0] + (size_t)(lcu_y + y) * D.src_pitch[0] + lcu_x + x);
-        *(uint32_t *)&L.src[y * 64 + x] = v;
-    }
-    __syncthreads();
-    if (t == 0) {
-        md_construct_cu_array(&M.S, &M.lcu);
-        M.cu_idx = 0, M.done = 0;
-    }
     __syncthreads();
     MD_PROF(0);
     const SvtAmdOisLcuResult *ois = &M.ois;
@@ -485,31 +500,39 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             if (st.depth != 0 && (islice || st.depth == 3 || !M.lcu.restrict_intra_global_motion))
                 if (!(P.limit_intra && st.x == 0 && st.y == 0))
                     ncand = md_intra_candidates(&P, &M.lcu, ois, leaf, &st, M.cand);
-            if constexpr (INTER) {
-                /* the spatial neighbours with the availability GenerateL0L1AmvpMergeLists derives (EbAdaptiveMotionVectorPrediction.c:2256-2340) */
-                const int N = st.size;
-                const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
-                const int px[5] = {st.x - 1, st.x - 1, st.x + N, st.x + N - 1, st.x - 1}, py[5] = {st.y + N, st.y + N - 1, st.y - 1, st.y - 1, st.y - 1};
-                const bool ok[5] = {md_bottom_left_ok(&st) && !left, !left, md_top_right_ok(&st) && !top && !right, !top, !left && !top};
-                for (int k = 0; k < 5; k++) {
-                    MdMvUnit u;
-                    u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
-                    if (ok[k] && (L.info_at(px[k], py[k]) & 0xFF) == MD_INTER) {
-                        u = *M.V.mv_at(px[k], py[k]);
-                        u.avail = 1;
-                    }
-                    M.V.nb[k] = u;
-                }
-            }
             M.ncand = ncand; /* the intra candidates so far (P / B pictures: the lists below are made by three waves) */
         }
         if constexpr (INTER) {
+            /* the spatial neighbours with the availability GenerateL0L1AmvpMergeLists derives (EbAdaptiveMotionVectorPrediction.c:2256-2340): a lane of the second wave
+             * each, beside lane 0's contexts and intra candidates */
+            if (wave == 1 && lane < 5) {
+                const MdStats st = md_stats(M.lcu.leaf_index[M.cu_idx]);
+                const int N = st.size, k = lane;
+                const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
+                const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
+                const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
+                MdMvUnit u;
+                u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
+                if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
+                    u = *M.V.mv_at(px, py);
+                    u.avail = 1;
+                }
+                M.V.nb[k] = u;
+            }
             /* GenerateL0L1AmvpMergeLists: the AMVP candidates of list 0, of list 1 and the merge candidates share their inputs and nothing else - lane 0 of waves
              * 0, 1 and 2 makes one each (three chains of LDS round trips side by side instead of one after the other) */
             __syncthreads();
             if (lane == 0 && wave < 3) {
                 const MdStats st = md_stats(M.leaf);
                 md_amvp_merge_lists_parts(&P, D.X, M.V.nb, D.X->tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T, 1 << wave);
+            } else if (wave == 3) { /* meanwhile the fourth wave: the unit's intra reference (only units below 64x64 have intra candidates) */
+                const MdStats st = md_stats(M.leaf);
+                if (st.depth != 0) {
+                    if (open_loop)
+                        md_build_refs_ol(D, M, st, lcu_x + st.x, lcu_y + st.y, W, H, lane);
+                    else
+                        md_build_refs(M, st, lane);
+                }
             }
             __syncthreads();
         }
@@ -635,14 +658,16 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         const int leaf = M.leaf, ncand = M.ncand;
         const MdStats st = md_stats(leaf);
         const int N = st.size, lgN = st.lg, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
-        /* ---- wave 0: the unit's intra reference ---- */
-        if (wave == 0 && M.any_intra) {
-            if (open_loop)
-                md_build_refs_ol(D, M, st, x0, y0, W, H, lane);
-            else
-                md_build_refs(M, st, lane);
+        /* ---- wave 0: the unit's intra reference (P / B pictures: made beside the motion-vector lists above) ---- */
+        if constexpr (!INTER) {
+            if (wave == 0 && M.any_intra) {
+                if (open_loop)
+                    md_build_refs_ol(D, M, st, x0, y0, W, H, lane);
+                else
+                    md_build_refs(M, st, lane);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         MD_PROF(2);
         if (D.prof && t == 0)
             M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1;
@@ -662,15 +687,15 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         uint8_t *pr = M.V.cpred[sl];
                         md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr, wave, 4);
                         const int ty0 = (wave >> 1) << 5, tx0 = (wave & 1) << 5;
-                        for (int e = lane; e < 32 * 32; e += 64) {
+                        for (int e = 4 * lane; e < 32 * 32; e += 256) { /* v_sad_u8: four samples a word */
                             const int y = ty0 + (e >> 5), x = tx0 + (e & 31);
-                            sad += (uint32_t)abs((int)pr[y * 64 + x] - (int)L.src[(st.y + y) * 64 + st.x + x]);
+                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[y * 64 + x]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + y) * 64 + st.x + x]), sad);
                         }
                     } else if (wave == (k & 3)) { /* no slot left to keep the prediction in: the whole candidate on one wave */
                         uint8_t *pr = M.V.wpred[wave];
                         md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
-                        for (int e = lane; e < N * N; e += 64)
-                            sad += (uint32_t)abs((int)pr[e] - (int)L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]);
+                        for (int e = 4 * lane; e < N * N; e += 256)
+                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1)
@@ -689,8 +714,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if constexpr (INTER) {
                         uint8_t *pr = M.V.slot[c] >= 0 ? M.V.cpred[M.V.slot[c]] : M.V.wpred[wave];
                         md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
-                        for (int e = lane; e < N * N; e += 64)
-                            sad += (uint32_t)abs((int)pr[e] - (int)L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]);
+                        for (int e = 4 * lane; e < N * N; e += 256)
+                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
                     }
                 } else {
                     const int mode = cd.intra_mode;
@@ -1193,6 +1218,7 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         const int lx = lcu % wl, ly = lcu / wl;
         const SvtAmdMdLcu &Lc = D.lcus[lcu];
         unsigned long long c_ticket = 0;
+        md_lcu_inputs<INTER>(D, P, lcu, lx * 64, ly * 64, U.md);
         const int dep0 = Lc.tile_left ? -1 : lcu - 1;
         const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
         if (threadIdx.x == 0) {
