@@ -347,6 +347,13 @@ __device__ __forceinline__ void md_build_refs_ol(const MdPictureDev &D, MdShared
     EP_WAVE_SYNC();
 }
 
+/* a 64-bit value of lane l (wave-uniform l): two v_readlane instead of two trips through the LDS crossbar */
+__device__ __forceinline__ unsigned long long md_readlane64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 /* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of the luma block of a candidate, by one wave, into dst (pitch = unit size) */
 __device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
                                                  int tile_first = 0, int tile_step = 1)
@@ -617,14 +624,15 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                            : islice          ? md_intra_fast_cost_islice(&P, &s1, &M.S.cu[lf], c.intra_mode, c.me_dist, &r)
                                              : md_intra_fast_cost_pslice(&P, &s1, &M.S.cu[lf], c.intra_mode, c.me_dist, &r);
                 }
-                unsigned long long m = cost;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned long long v = __shfl_xor(m, o);
-                    m = v < m ? v : m;
+                /* few candidates are ready: a scalar walk over them instead of a 64-lane reduction */
+                unsigned long long m = ~0ull, rm = __ballot(ready);
+                while (rm) {
+                    const int l = __ffsll((long long)rm) - 1;
+                    rm &= rm - 1;
+                    const unsigned long long v = md_readlane64(cost, l);
+                    if (bestFirst < 0 || v < m)
+                        m = v, bestFirst = l;
                 }
-                const unsigned long long mask = __ballot(ready && cost == m);
-                bestFirst = mask ? __ffsll((long long)mask) - 1 : -1;
             }
             uint8_t e = (uint8_t)(in && (!c.dist_ready || lane == bestFirst || P.single_fast_loop));
             if (e && lane == bestFirst && c.type == MD_INTRA && open_loop)
@@ -759,10 +767,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
              * do-while looks at buffer 1 even when maxBuffers is 1.  Scalar, the replay of 35 intra candidates was a third of an I picture's time. */
             unsigned long long bcost = ~0ull;
             int bcand = -1, bpred = -1, evcount = 0, highest = 0;
-            const int maxb = M.max_buffers < 2 ? 2 : M.max_buffers;
-            for (int idx = ncand - 1; idx >= 0; idx--) {
-                const unsigned long long c = __shfl(cst, idx);
-                const int ev = __shfl(evl, idx);
+            const int maxb = __builtin_amdgcn_readfirstlane(M.max_buffers < 2 ? 2 : M.max_buffers);
+            for (int idx = __builtin_amdgcn_readfirstlane(ncand) - 1; idx >= 0; idx--) {
+                const unsigned long long c = md_readlane64(cst, idx);
+                const int ev = __builtin_amdgcn_readlane(evl, idx);
                 if (lane == highest) {
                     bcand = idx;
                     if (ev) {
@@ -772,15 +780,17 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     }
                 }
                 evcount += ev != 0;
-                if (idx) {
-                    unsigned long long m = lane < maxb ? bcost : 0ull;
+                if (idx) { /* the first buffer holding the maximum: the buffers' costs read lane by lane (scalar) */
+                    unsigned long long m = 0;
+                    int h = 0;
 #pragma unroll
-                    for (int o = 1; o < MD_MAX_BUF; o <<= 1) {
-                        const unsigned long long v = __shfl_xor(m, o);
-                        m = v > m ? v : m;
-                    }
-                    m = __shfl(m, 0);
-                    highest = __ffsll((long long)__ballot(lane < maxb && bcost == m)) - 1;
+                    for (int b = 0; b < MD_MAX_BUF; b++)
+                        if (b < maxb) {
+                            const unsigned long long v = md_readlane64(bcost, b);
+                            if (b == 0 || v > m)
+                                m = v, h = b;
+                        }
+                    highest = h;
                 }
             }
             if (lane < MD_MAX_BUF) {
