@@ -115,6 +115,8 @@ struct MdShared {
     MdLcuState S;
     SvtAmdMdLcu lcu;
     SvtAmdOisLcuResult ois;        /* the LCU's open-loop intra search record */
+    SvtAmdMdPicture pic;           /* the picture's controls and rate tables: the full costs index the tables by lane-dependent contexts (a load from HBM each otherwise) */
+    SvtAmdCabacCost cost;          /* the picture's coefficient-rate tables: read per coefficient in the full loops, so kept beside the LCU instead of in HBM */
     MdCand cand[MD_MAX_CAND];
     unsigned long long costs[MD_MAX_CAND], fast_rate[MD_MAX_CAND];
     uint32_t sad[MD_MAX_CAND];
@@ -215,6 +217,19 @@ __device__ __forceinline__ bool md_mode_filtered(int mode, int lgN)
     return dm > thrTab && mode != 1;
 }
 
+/* the sum of v over the 64 lanes of a fully active wave, in every lane: data-parallel-primitive adds inside the rows of 16 (quad permutes, half-row and row mirror), the two
+ * row broadcasts of gfx9 across them, one v_readlane - no trip through the LDS crossbar (a butterfly of __shfl_xor is six of them in a row) */
+__device__ __forceinline__ uint32_t md_wave_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  /* quad_perm [1,0,3,2] */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  /* quad_perm [2,3,0,1] */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); /* row_half_mirror */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); /* row_mirror: every lane holds its row's sum */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast15 into rows 1 and 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast31 into rows 2 and 3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, int lane)
 {
     int dc = lane < n ? ref[lane] + ref[2 * n + 1 + lane] : 0;
@@ -280,10 +295,7 @@ __device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, 
             nz += q != 0, d0 += (uint32_t)(df * df), d1 += (uint32_t)(v * v);
         }
     }
-#pragma unroll
-    for (int o = 1; o < N; o <<= 1)
-        nz += __shfl_xor(nz, o), d0 += __shfl_xor(d0, o), d1 += __shfl_xor(d1, o);
-    nz = (unsigned)__shfl((int)nz, 0), d0 = (unsigned)__shfl((int)d0, 0), d1 = (unsigned)__shfl((int)d1, 0);
+    nz = md_wave_sum(nz), d0 = md_wave_sum(d0), d1 = md_wave_sum(d1); /* the lanes beyond the unit's rows hold zeros */
     EP_WAVE_SYNC(); /* qbuf is written */
     const int lga = LG - pf, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
     const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
@@ -409,13 +421,19 @@ __device__ __forceinline__ void md_tu_calc_cost(const SvtAmdMdPicture &P, const 
 /* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
 /* what the LCU's mode decision reads that no other LCU of the picture writes (its records, its source): into LDS BEFORE the workgroup waits for the LCU's neighbours */
 template <bool INTER>
-__device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
+__device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     const int t = threadIdx.x;
     MdLocal8 &L = M.L;
     const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
     for (int i = t; i < (int)sizeof(SvtAmdMdLcu); i += 256)
         ((uint8_t *)&M.lcu)[i] = ((const uint8_t *)&D.lcus[lcu])[i];
+    static_assert(sizeof(SvtAmdCabacCost) % 4 == 0 && sizeof(SvtAmdMdPicture) % 4 == 0, "record sizes");
+    for (int i = t; i < (int)(sizeof(SvtAmdMdPicture) / 4); i += 256)
+        ((uint32_t *)&M.pic)[i] = ((const uint32_t *)D.P)[i];
+    if (E.cost)
+        for (int i = t; i < (int)(sizeof(SvtAmdCabacCost) / 4); i += 256)
+            ((uint32_t *)&M.cost)[i] = ((const uint32_t *)E.cost)[i];
     static_assert(sizeof(SvtAmdOisLcuResult) % 4 == 0 && sizeof(SvtAmdMeLcuResult) % 4 == 0 && sizeof(SvtAmdMeCuResult) % 4 == 0 && sizeof(SvtAmdTmvpLcu) % 8 == 0, "record sizes");
     for (int i = t; i < (int)(sizeof(SvtAmdOisLcuResult) / 4); i += 256)
         ((uint32_t *)&M.ois)[i] = ((const uint32_t *)&D.ois[lcu])[i];
@@ -705,9 +723,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         for (int e = 4 * lane; e < N * N; e += 256)
                             sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
                     }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1)
-                        sad += __shfl_xor(sad, o);
+                    sad = md_wave_sum(sad);
                     if (lane == 0 && sad)
                         atomicAdd(&M.sad[c], sad);
                 }
@@ -735,9 +751,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-                    sad += __shfl_xor(sad, o);
+                sad = md_wave_sum(sad);
             }
             if (lane == 0)
                 M.sad[c] = sad;
@@ -834,7 +848,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     const int b = M.best[f], ci = M.B.cand[b], pci = M.B.pred[b] < 0 ? ci : M.B.pred[b];
                     const uint8_t *pred = (M.V.slot[pci] >= 0 && M.evaluated[pci]) ? M.V.cpred[M.V.slot[pci]] : M.V.wpred[f];
                     const int tu = wave, off = ((tu & 1) << 5) + ((tu >> 1) << 5) * 64;
-                    const MdFl o = md_full_loop_unit<32>(lane, &L.src[st.y * 64 + st.x] + off, 64, pred + off, 64, nullptr, M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, *E.cost,
+                    const MdFl o = md_full_loop_unit<32>(lane, &L.src[st.y * 64 + st.x] + off, 64, pred + off, 64, nullptr, M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, M.cost,
                                                          M.cand[ci].type, M.cand[ci].intra_mode, 0, pf);
                     if (lane == 0)
                         M.fl[b][tu] = o;
@@ -871,7 +885,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
                 EP_WAVE_SYNC();
             }
-            md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, *E.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
+            md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, M.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
         }
         __syncthreads();
         MD_PROF(5);
@@ -883,24 +897,25 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             unsigned long long bits = 0, dist[2] = {0, 0}, full = 0;
             uint64_t mc = 0, sc = 0;
             if (have) {
+                const SvtAmdMdPicture &PL = M.pic; /* the rate tables beside the LCU */
                 b = M.best[lane];
                 const int ci = M.B.cand[b];
                 const MdCand c = M.cand[ci];
                 ctype = c.type;
                 if (N == 64) {
                     for (int tu = 0; tu < 4; tu++)
-                        md_tu_calc_cost(P, M.fl[b][tu], c.type, 64, 32, tu + 1, &ycbf, &bits, dist);
+                        md_tu_calc_cost(PL, M.fl[b][tu], c.type, 64, 32, tu + 1, &ycbf, &bits, dist);
                 } else {
-                    md_tu_calc_cost(P, M.fl[b][0], c.type, N, N, 0, &ycbf, &bits, dist);
+                    md_tu_calc_cost(PL, M.fl[b][0], c.type, N, N, 0, &ycbf, &bits, dist);
                 }
                 if (M.lcu.chroma_encode_mode == 2 /* CHROMA_MODE_BEST */)
                     bits = md_pf_coeff_bits(pf, P.qp, bits);
                 if (c.type == MD_INTER)
-                    full = md_inter_full_luma_cost(&P, &M.S.cu[leaf], &c, N, ycbf, M.fast_rate[ci], (const uint64_t *)dist, bits, &mc, &sc);
+                    full = md_inter_full_luma_cost(&PL, &M.S.cu[leaf], &c, N, ycbf, M.fast_rate[ci], (const uint64_t *)dist, bits, &mc, &sc);
                 else if (islice)
-                    full = md_intra_full_luma_cost_islice(&P, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
+                    full = md_intra_full_luma_cost_islice(&PL, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
                 else
-                    full = md_intra_full_luma_cost_pslice(&P, N, ycbf, M.fast_rate[ci], dist[0], bits);
+                    full = md_intra_full_luma_cost_pslice(&PL, N, ycbf, M.fast_rate[ci], dist[0], bits);
             }
             /* the reference walks the candidates in order: an intra candidate after an inter one whose root cbf is 0 is not costed at all (full-loop escape, :4450-4460) and
              * keeps whatever its buffer held */
@@ -1139,7 +1154,7 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
                 const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                 uint32_t nz;
                 unsigned long long d[2], b;
-                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, *E.cost, 1 + p, pf,
+                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, 1 + p, pf,
                              &nz, d, &b);
                 cbf[p] |= (uint32_t)(nz != 0) << (ntu == 1 ? 0 : tu + 1);
                 bits[p] += b, dist[p][0] += d[0], dist[p][1] += d[1];
@@ -1228,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         const int lx = lcu % wl, ly = lcu / wl;
         const SvtAmdMdLcu &Lc = D.lcus[lcu];
         unsigned long long c_ticket = 0;
-        md_lcu_inputs<INTER>(D, P, lcu, lx * 64, ly * 64, U.md);
+        md_lcu_inputs<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
         const int dep0 = Lc.tile_left ? -1 : lcu - 1;
         const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
         if (threadIdx.x == 0) {

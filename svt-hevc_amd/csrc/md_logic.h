@@ -860,15 +860,15 @@ MD_FN int md_inter_candidates(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, co
 
 /* mvBitTable (Codec/EbModeDecisionConfiguration.h:108): the 500 x 500 table is a 3 x 3 core plus 2 bits (1 << 16) per doubling of
  * either component beyond 2 (checked entry by entry against the header by tests/golden/make_md_golden.py) */
+/* entry i of a table of three constants: selects, not a load (on the device a table in memory is a round trip on the decision chain of every unit) */
+MD_FN uint32_t md_sel3(int i, uint32_t a, uint32_t b, uint32_t c) { return i <= 0 ? a : (i == 1 ? b : c); }
 MD_FN uint32_t md_mv_bits(int mvdX, int mvdY)
 {
-    const uint32_t core[3][3] = {{73744, 128728, 203592}, {130975, 178780, 253644}, {202683, 253623, 321933}};
-    int lx = 0, ly = 0;
-    for (int v = mvdX; v >= 4; v >>= 1)
-        lx++;
-    for (int v = mvdY; v >= 4; v >>= 1)
-        ly++;
-    return core[mvdX > 2 ? 2 : mvdX][mvdY > 2 ? 2 : mvdY] + 65536u * (uint32_t)(lx + ly);
+    const int row = mvdX > 2 ? 2 : mvdX, col = mvdY > 2 ? 2 : mvdY;
+    const uint32_t core = md_sel3(row, md_sel3(col, 73744, 128728, 203592), md_sel3(col, 130975, 178780, 253644), md_sel3(col, 202683, 253623, 321933));
+    /* doublings beyond 2: floor(log2 v) - 1 for v >= 4 */
+    const int lx = mvdX >= 4 ? 30 - __builtin_clz((unsigned)mvdX) : 0, ly = mvdY >= 4 ? 30 - __builtin_clz((unsigned)mvdY) : 0;
+    return core + 65536u * (uint32_t)(lx + ly);
 }
 MD_FN uint32_t md_mvd_rate(const MdCand *c, int list)
 {
@@ -881,17 +881,18 @@ MD_FN uint32_t md_mvd_rate(const MdCand *c, int list)
 MD_FN uint64_t md_inter_fast_cost(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *cu, const MdCand *c, uint64_t lumaDistortion,
                                   uint64_t *fastLumaRate)
 {
-    const uint32_t skipFlagBits[6] = {17878, 62157, 86651, 54723, 14816, 8254}, mergeIndexBits[5] = {10350, 109741, 142509, 175277, 175277};
-    const uint32_t interBiDirBits[8] = {29856, 36028, 15752, 59703, 8692, 84420, 2742, 136034}, interUniDirBits[2] = {2742, 136034};
+    /* skipFlagBits[3 + skip context] = {54723, 14816, 8254}; mergeIndexBits = {10350, 109741, 142509, 175277, 175277};
+     * interBiDirBits[2 depth + bi] = {29856, 36028, 15752, 59703, 8692, 84420, 2742, 136034}; interUniDirBits = {2742, 136034} */
     uint64_t rate;
     if (c->merge_flag) {
-        rate = (uint64_t)skipFlagBits[3 + cu->skip_ctx] + mergeIndexBits[c->merge_index];
+        rate = (uint64_t)md_sel3(cu->skip_ctx, 54723, 14816, 8254) + (c->merge_index >= 3 ? 175277u : md_sel3(c->merge_index, 10350, 109741, 142509));
     } else {
         rate = 86440;
         if (P->slice_type == 0) {
-            rate += interBiDirBits[(st->depth << 1) + (c->dir == MD_BI)];
+            const int bi = c->dir == MD_BI;
+            rate += st->depth >= 3 ? (bi ? 136034u : 2742u) : md_sel3(st->depth, bi ? 36028u : 29856u, bi ? 59703u : 15752u, bi ? 84420u : 8692u);
             if (c->dir != MD_BI)
-                rate += interUniDirBits[c->dir] + md_mvd_rate(c, c->dir);
+                rate += (c->dir ? 136034u : 2742u) + md_mvd_rate(c, c->dir);
             else
                 rate += (uint64_t)md_mvd_rate(c, 0) + md_mvd_rate(c, 1);
         } else {
