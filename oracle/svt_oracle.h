@@ -266,6 +266,7 @@ void svt_oracle_full_loop_chroma_cabac(const SvtAmdCabacCost *cost, const SvtAmd
                                        int16_t *const quant[2], int16_t *const recon[2], uint32_t *model, SvtAmdChromaLoopOut *out);
 
 /* The mode decision of a whole picture (svt_oracle_md.c): ModeDecisionLcu of every LCU in raster order */
+uint32_t svt_oracle_md_mv_bits(int dx, int dy); /* mvBitTable[dx][dy] in closed form (md_logic.h:md_mv_bits) */
 int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost, const uint8_t *src_y, uint32_t stride,
                           const SvtAmdOisLcuResult *ois, SvtAmdMdLcuOut *out, uint8_t *md_rec);
 int svt_oracle_md_picture_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus, const SvtAmdCabacCost *cost,

@@ -493,3 +493,6 @@ int svt_oracle_md_picture(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, con
 {
     return svt_oracle_md_picture_inter(P, NULL, lcus, cost, src_y, stride, NULL, NULL, 0, ois, NULL, NULL, NULL, NULL, out, md_rec, NULL);
 }
+
+/* md_mv_bits (md_logic.h) for the table test (tests/test_oracle_md.py::test_mv_bit_table) */
+uint32_t svt_oracle_md_mv_bits(int dx, int dy) { return md_mv_bits(dx, dy); }

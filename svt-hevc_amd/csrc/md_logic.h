@@ -859,7 +859,7 @@ MD_FN int md_inter_candidates(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, co
 }
 
 /* mvBitTable (Codec/EbModeDecisionConfiguration.h:108): the 500 x 500 table is a 3 x 3 core plus 2 bits (1 << 16) per doubling of
- * either component beyond 2 (checked entry by entry against the header by tests/golden/make_md_golden.py) */
+ * either component beyond 2 (checked entry by entry against the header by tests/test_oracle_md_golden.py::test_mv_bit_table) */
 /* entry i of a table of three constants: selects, not a load (on the device a table in memory is a round trip on the decision chain of every unit) */
 MD_FN uint32_t md_sel3(int i, uint32_t a, uint32_t b, uint32_t c) { return i <= 0 ? a : (i == 1 ? b : c); }
 MD_FN uint32_t md_mv_bits(int mvdX, int mvdY)

@@ -180,3 +180,30 @@ def test_recorded_decisions_are_the_trees_the_encode_pass_fixture_holds():
                 assert np.array_equal(works[i]["cu"][f][:n], ew[i]["cu"][f][:n]), (k, i, f)
             for f in ("src_y", "src_cb", "src_cr", "lcu_x", "lcu_y", "tile_left", "tile_top", "tile_right", "slice_type", "strong_smoothing", "constrained_intra"):
                 assert np.array_equal(works[i][f], ew[i][f]), (k, i, f)
+
+
+MV_BITS_DIGEST = os.path.join(S.GOLDEN_DIR, "mv_bit_table.sha256")
+
+
+def test_mv_bit_table():
+    """md_mv_bits (md_logic.h: a 3 x 3 core + 2 bits per doubling, selects instead of a table in memory) against the reference's
+    mvBitTable[500][500] (Codec/EbModeDecisionConfiguration.h:108): entry by entry when the reference is built here
+    (oracle/_ref, svt_ref_mv_bits), and by the digest of the whole table committed from such a run (tests/golden/mv_bit_table.sha256)."""
+    import hashlib
+    lib = S.load_oracle()
+    lib.svt_oracle_md_mv_bits.restype = C.c_uint32
+    lib.svt_oracle_md_mv_bits.argtypes = [C.c_int, C.c_int]
+    ours = np.array([[lib.svt_oracle_md_mv_bits(x, y) for y in range(500)] for x in range(500)], np.uint32)
+    ref = S.load_ref()
+    if ref is not None and hasattr(ref, "svt_ref_mv_bits"):
+        ref.svt_ref_mv_bits.restype = C.c_uint32
+        ref.svt_ref_mv_bits.argtypes = [C.c_int, C.c_int]
+        theirs = np.array([[ref.svt_ref_mv_bits(x, y) for y in range(500)] for x in range(500)], np.uint32)
+        bad = np.argwhere(ours != theirs)
+        assert len(bad) == 0, "mvBitTable differs at %s: %d vs %d" % (bad[0], ours[tuple(bad[0])], theirs[tuple(bad[0])])
+        digest = hashlib.sha256(theirs.astype("<u4").tobytes()).hexdigest()
+        if not os.path.exists(MV_BITS_DIGEST):
+            open(MV_BITS_DIGEST, "w").write(digest + "\n")
+        assert open(MV_BITS_DIGEST).read().strip() == digest
+    assert os.path.exists(MV_BITS_DIGEST), "no reference here and no committed digest"
+    assert hashlib.sha256(ours.astype("<u4").tobytes()).hexdigest() == open(MV_BITS_DIGEST).read().strip()
