@@ -9,17 +9,24 @@
  * One 256-thread workgroup per LCU.  The LCU's mode-decision state lives in LDS: the mode decision's own luma reconstruction
  * (mdLumaReconNeighborArray as a picture plane: candidate reconstructions of the units decided so far) with a ring of neighbour samples,
  * the neighbour-array entries of the 4x4 cells (mode type | intra luma mode | depth | skip flag) with the same ring, the source block.
- * Per coding unit of the MdcLcuData_t leaf list:
- *   lane 0        context generation, candidate list, MPM injection                       (md_logic.h - the text the CPU checker runs)
- *   wave 0        intra reference of the unit: availability by ballot, substitution, [1 2 1] / strong smoothing   (8.4.4.2.2-3)
- *   4 waves       fast loop: a wave per candidate, lanes over the samples - prediction evaluated per sample in closed form
- *                 (intra_device.h), SAD by wave reduction; nothing is stored
- *   lane 0        fast costs, the candidate-buffer replay, PreModeDecision
- *   4 waves       full loop: a wave per surviving candidate - prediction, residual row per lane, Estimate DCT in registers, quantiser,
- *                 coefficient-domain distortion, coefficient bits (a lane per 4x4 sub-block): the fused unit of the encode pass
- *   lane 0        TuCalcCostLuma, full cost, ProductFullModeDecision, CheckHighCostPartition
- *   wave 0        the winner's reconstruction (inverse transform + prediction)
- *   lane 0        inter-depth decision;  all lanes: neighbour update
+ * The LCU's own inputs (its records, the source block, the picture's controls and rate tables) are loaded BEFORE the workgroup waits for the LCU's neighbours;
+ * what the neighbours left in the picture's maps follows the wait.  Per coding unit of the MdcLcuData_t leaf list (I pictures: waves 1..3 idle where P / B pictures
+ * use them):
+ *   lane 0        context generation, intra candidates                                       (md_logic.h - the text the CPU checker runs)
+ *   P / B         five lanes of wave 1: the spatial neighbours' motion vectors; then lane 0 of waves 0 / 1 / 2: AMVP list 0, AMVP list 1, merge list
+ *                 (three chains side by side) while wave 3 builds the unit's intra reference; then a lane per motion-estimation / merge candidate
+ *                 (md_choose_mvp, duplicate check), survivors in the scalar order by ballot
+ *   lane 0        MPM injection, buffer count;  wave 0: a lane per candidate - first fast loop (best distortion-ready candidate), evaluated flags,
+ *                 the packed list of candidates that really need a prediction, prediction slots
+ *   wave 0        (I pictures) intra reference of the unit: availability by ballot, substitution, [1 2 1] / strong smoothing   (8.4.4.2.2-3)
+ *   4 waves       fast loop: a wave per listed candidate (64x64 units: wave w takes 32x32 tile w of every candidate) - inter prediction through
+ *                 ep_inter_predict_core (encdec_device.h), intra prediction evaluated per sample in closed form (intra_device.h), SAD by v_sad_u8 on words
+ *   wave 0        fast costs a lane per candidate, the candidate-buffer replay with the buffers in lanes (v_readlane), PreModeDecision
+ *   4 waves       full loop: a wave per surviving candidate (64x64 units: a wave per 32x32 transform unit) - residual row per lane, Estimate DCT in
+ *                 registers, quantiser, coefficient-domain distortion, coefficient bits (a lane per 4x4 sub-block): the fused unit of the encode pass
+ *   wave 0        TuCalcCostLuma + full cost a lane per candidate; lane 0: ProductFullModeDecision, CheckHighCostPartition, (open loop) inter-depth decision
+ *   wave 0        (closed loop) the winner's reconstruction (inverse transform + prediction);  lane 0: inter-depth decision
+ *   all lanes     neighbour update
  * then the LCU's final tree becomes an SvtAmdLcuWork record and the encode pass of the LCU runs in the same workgroup.
  * Bounded by latency (an LCU's units are sequential, a picture's wavefront is <= (W/64+1)/2 LCUs wide), not by bytes: algorithmic HBM
  * traffic per LCU = 6 KB source + 6 KB OIS record in, 1.1 KB decisions + the encode pass's 24 KB out.
