@@ -112,16 +112,46 @@ static void md_predict_ol(const MdPic *M, const MdStats *st, int lcu_x, int lcu_
     svt_oracle_intra_pu(1, &J, pred, (uint32_t)N, NULL, NULL, 0);
 }
 
-/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468), luma */
-static void md_predict_inter(const MdPic *M, const MdStats *st, int lcu_x, int lcu_y, const MdCand *c, uint8_t *pred /* N x N */)
+/* IntraPredictionOl of the chroma pair (the chroma mode is always DM, :5530): neighbours = SOURCE chroma samples (UpdateChromaNeighborSamplesArrayOL, :5065) */
+static void md_predict_ol_chroma(const MdPic *M, const MdStats *st, int lcu_x, int lcu_y, int mode, uint8_t *cb, uint8_t *cr /* N/2 x N/2 each */)
 {
-    static __thread uint8_t cb[32 * 32], cr[32 * 32];
+    const int N = st->size, n = N / 2, x0 = (lcu_x + st->x) / 2, y0 = (lcu_y + st->y) / 2, w = (int)M->w / 2, h = (int)M->h / 2;
+    SvtAmdIntraPuJob J;
+    memset(&J, 0, sizeof(J));
+    J.size = (uint32_t)N, J.bottom_left_ok = J.top_right_ok = 1, J.no_smoothing = 1, J.mode_tl = 2;
+    memset(J.mode_left, 2, sizeof(J.mode_left)), memset(J.mode_top, 2, sizeof(J.mode_top));
+    J.luma_mode = (uint8_t)mode, J.chroma_mode = 4;
+    for (int p = 1; p < 3; p++) {
+        const uint8_t *src = M->src_c[p - 1] + (size_t)y0 * M->srcStrideC + x0;
+        for (int i = 0; i < 2 * n; i++)
+            J.left[p][i] = J.top[p][i] = 128;
+        J.tl[p] = 128;
+        if (x0 != 0)
+            for (int i = 0; i < 2 * n && y0 + i < h; i++)
+                J.left[p][i] = src[(ptrdiff_t)i * M->srcStrideC - 1];
+        if (x0 != 0 && y0 != 0)
+            J.tl[p] = src[-(ptrdiff_t)M->srcStrideC - 1];
+        if (y0 != 0)
+            for (int i = 0; i < 2 * n && x0 + i < w; i++)
+                J.top[p][i] = src[i - (ptrdiff_t)M->srcStrideC];
+    }
+    svt_oracle_intra_pu(1, &J, NULL, 0, cb, cr, (uint32_t)n);
+}
+
+/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468): luma (N x N) and, with cb / cr, the chroma pair (N/2 x N/2 each) */
+static void md_predict_inter_c(const MdPic *M, const MdStats *st, int lcu_x, int lcu_y, const MdCand *c, uint8_t *pred, uint8_t *cb, uint8_t *cr)
+{
+    static __thread uint8_t tcb[32 * 32], tcr[32 * 32], ty[64 * 64];
     SvtAmdInterPuJob J;
     memset(&J, 0, sizeof(J));
     for (int l = 0; l < 2; l++)
         J.mv[l][0] = c->mv[l].x, J.mv[l][1] = c->mv[l].y;
     J.pu_x = (uint16_t)(lcu_x + st->x), J.pu_y = (uint16_t)(lcu_y + st->y), J.pu_w = J.pu_h = st->size, J.pred_dir = c->dir;
-    svt_oracle_inter_pu(&J, M->ref[0], M->ref[1], pred, st->size, cb, cr, st->size / 2);
+    svt_oracle_inter_pu(&J, M->ref[0], M->ref[1], pred ? pred : ty, st->size, cb ? cb : tcb, cr ? cr : tcr, st->size / 2);
+}
+static void md_predict_inter(const MdPic *M, const MdStats *st, int lcu_x, int lcu_y, const MdCand *c, uint8_t *pred /* N x N */)
+{
+    md_predict_inter_c(M, st, lcu_x, lcu_y, c, pred, NULL, NULL);
 }
 
 /* the spatial neighbours of the candidate lists with the availability GenerateL0L1AmvpMergeLists derives (:2256-2340) */
@@ -251,8 +281,12 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
                     bestFirst = i, bestCost = c;
             }
         }
+        const int chromaFull = L->chroma_encode_mode == 1; /* CHROMA_MODE_FULL: useChromaInformationInFastLoop / InFullLoop (EbModeDecisionProcess.c:439-441) */
+        const uint32_t cw = M->X ? M->X->chroma_weight : 0;
+        const int Cn = N / 2;
+        static __thread uint8_t predC[2][32 * 32];
         for (int i = 0; i < ncand; i++) {
-            uint64_t dist = 0;
+            uint64_t dist = 0, distC = 0;
             evaluated[i] = (uint8_t)(!cand[i].dist_ready || i == bestFirst || P->single_fast_loop);
             costs[i] = ~0ull, fastLumaRate[i] = 0;
             if (!evaluated[i])
@@ -272,10 +306,20 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
                         md_predict(M, L, lcu_x, lcu_y, &st, cand[i].intra_mode, pred);
                     dist = svt_oracle_NxMSadKernel(src + (size_t)y0 * srcStride + x0, srcStride, pred, (uint32_t)N, (uint32_t)N, (uint32_t)N);
                 }
+                if (chromaFull) { /* Cb + Cr SAD of the candidate's chroma prediction (:2053-2077) */
+                    if (cand[i].type == MD_INTER)
+                        md_predict_inter_c(M, &st, lcu_x, lcu_y, &cand[i], NULL, predC[0], predC[1]);
+                    else
+                        md_predict_ol_chroma(M, &st, lcu_x, lcu_y, cand[i].intra_mode, predC[0], predC[1]);
+                    for (int p = 0; p < 2; p++)
+                        distC += svt_oracle_NxMSadKernel(M->src_c[p] + (size_t)(y0 / 2) * M->srcStrideC + x0 / 2, M->srcStrideC, predC[p], (uint32_t)Cn, (uint32_t)Cn, (uint32_t)Cn);
+                }
             }
-            costs[i] = cand[i].type == MD_INTER ? md_inter_fast_cost(P, &st, &S->cu[leaf], &cand[i], dist, &fastLumaRate[i])
+            if (chromaFull)
+                distC = md_fast_chroma_noise_rule(L, N, &cand[i], distC);
+            costs[i] = cand[i].type == MD_INTER ? md_inter_fast_cost_c(P, &st, &S->cu[leaf], &cand[i], dist, distC, cw, !L->cmplx_noise, &fastLumaRate[i])
                      : islice                 ? md_intra_fast_cost_islice(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, &fastLumaRate[i])
-                                              : md_intra_fast_cost_pslice(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, &fastLumaRate[i]);
+                                              : md_intra_fast_cost_pslice_c(P, &st, &S->cu[leaf], cand[i].intra_mode, dist, distC, cw, &fastLumaRate[i]);
             if (cand[i].mpm)
                 costs[i] = 0;
             if (g_md_debug)
@@ -328,9 +372,37 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
             in.cbf_bits[2] = P->rates.lumaCbfBits[5], in.cbf_bits[3] = P->rates.lumaCbfBits[6];
             svt_oracle_product_full_loop_luma(cost, &in, residual, quant, reconCoeff[b], &o);
             ycbf[b] = o.ycbf, fullDist[b] = (uint32_t)o.dist[0];
-            const uint64_t bits = L->chroma_encode_mode == 2 /* CHROMA_MODE_BEST */ ? md_pf_coeff_bits(pf, P->qp, o.coeff_bits) : o.coeff_bits;
+            const uint64_t bits = L->chroma_encode_mode == 2 /* CHROMA_MODE_BEST */ || chromaFull ? md_pf_coeff_bits(pf, P->qp, o.coeff_bits) : o.coeff_bits;
             yBits[b] = bits, yDist[b][0] = o.dist[0], yDist[b][1] = o.dist[1];
-            if (c->type == MD_INTER)
+            if (chromaFull) { /* :4443-4560: the candidate's OWN chroma prediction (ChromaPrediction runs when the fast loop did not evaluate it), FullLoop_R +
+                               * CuFullDistortionFastTuMode_R, the full cost with chroma */
+                static __thread int16_t resC[2][32 * 32], qC[2][32 * 32], rcC[2][32 * 32];
+                if (c->type == MD_INTER)
+                    md_predict_inter_c(M, &st, lcu_x, lcu_y, c, NULL, predC[0], predC[1]);
+                else
+                    md_predict_ol_chroma(M, &st, lcu_x, lcu_y, c->intra_mode, predC[0], predC[1]);
+                for (int p = 0; p < 2; p++)
+                    for (int j = 0; j < Cn; j++)
+                        for (int i = 0; i < Cn; i++)
+                            resC[p][j * Cn + i] = qC[p][j * Cn + i] = (int16_t)(M->src_c[p][(size_t)(y0 / 2 + j) * M->srcStrideC + x0 / 2 + i] - predC[p][j * Cn + i]);
+                SvtAmdChromaLoopIn cin;
+                SvtAmdChromaLoopOut co;
+                memset(&cin, 0, sizeof(cin));
+                cin.size = (uint32_t)N, cin.cb_qp = cin.cr_qp = P->chroma_qp, cin.slice_type = P->slice_type, cin.pf_mode = (uint32_t)pf, cin.cand_type = c->type;
+                cin.intra_luma_mode = c->intra_mode;
+                const int16_t *const rp[2] = {resC[0], resC[1]};
+                int16_t *const qp2[2] = {qC[0], qC[1]}, *const rcp[2] = {rcC[0], rcC[1]};
+                svt_oracle_full_loop_chroma(cost, &cin, rp, qp2, rcp, &co);
+                const uint64_t cbits[2] = {co.coeff_bits[0], co.coeff_bits[1]}, cdist[2][2] = {{co.dist[0][0], co.dist[0][1]}, {co.dist[1][0], co.dist[1][1]}};
+                if (c->type == MD_INTER)
+                    B.full_cost[b] = md_inter_full_cost(P, cw, &S->cu[leaf], c, N, o.ycbf, co.cbf, fastLumaRate[B.cand[b]], o.dist, cdist, bits, cbits, &mergeCost[b], &skipCost[b]);
+                else
+                    B.full_cost[b] = md_intra_full_cost_pslice(P, cw, N, o.ycbf, co.cbf, fastLumaRate[B.cand[b]], o.dist[0], cdist, bits, cbits);
+                if (g_md_debug)
+                    fprintf(stderr, "    chroma: cb cbf %u bits %llu dist %llu/%llu cr cbf %u bits %llu dist %llu/%llu\n", co.cbf[0], (unsigned long long)cbits[0],
+                            (unsigned long long)cdist[0][0], (unsigned long long)cdist[0][1], co.cbf[1], (unsigned long long)cbits[1], (unsigned long long)cdist[1][0],
+                            (unsigned long long)cdist[1][1]);
+            } else if (c->type == MD_INTER)
                 B.full_cost[b] = md_inter_full_luma_cost(P, &S->cu[leaf], c, N, o.ycbf, fastLumaRate[B.cand[b]], o.dist, bits, &mergeCost[b], &skipCost[b]);
             else if (islice)
                 B.full_cost[b] = md_intra_full_luma_cost_islice(P, st.lg, o.ycbf, fastLumaRate[B.cand[b]], o.dist[0], bits);
@@ -427,7 +499,9 @@ static void md_lcu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const SvtAmdC
             }
             const MdStats fs = md_stats(it);
             if (lcu_x + fs.x < (int)P->width && lcu_y + fs.y < (int)P->height && S->cu[it].pred_mode == MD_INTER)
-                ep_kind[it] = (uint8_t)(S->cu[it].merge_flag ? md_ep_unit_kind(M, P, L, cost, &S->cu[it], &fs, lcu_x, lcu_y) : 0);
+                ep_kind[it] = (uint8_t)(!S->cu[it].merge_flag          ? 0
+                                        : L->chroma_encode_mode == 1 ? md_ep_merge_kind(M->X, L, S->cu[it].merge_cost, S->cu[it].skip_cost) /* the mode decision's costs hold chroma */
+                                                                     : md_ep_unit_kind(M, P, L, cost, &S->cu[it], &fs, lcu_x, lcu_y));
             it += md_depth_offset(fs.depth);
         }
     }

@@ -1423,7 +1423,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
                 return SVT_AMD_ERR_BAD_PARAM;
             }
         tiles += lcus[i].tile_left && lcus[i].tile_top;
-        if (X && !md_lcu_supported(P, &lcus[i])) {
+        if (X && (!md_lcu_supported(P, &lcus[i]) || lcus[i].chroma_encode_mode == 1 /* CHROMA_MODE_FULL: the checker has it, the kernel not yet */)) {
             svt_amd_set_error("svt_amd_md_encode_picture_inter: LCU %d is not decided by ModeDecisionLcu with luma-only candidates", i);
             return SVT_AMD_ERR_BAD_PARAM;
         }

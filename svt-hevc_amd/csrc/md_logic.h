@@ -877,41 +877,67 @@ MD_FN uint32_t md_mvd_rate(const MdCand *c, int list)
     dx = dx > 499 ? 499 : dx, dy = dy > 499 ? 499 : dy;
     return md_mv_bits(dx, dy) + (c->mvp_idx[list] ? 44891u : 23196u); /* mvpIndexBits, EbRateDistortionCost.c:18 */
 }
-/* InterFastCostPsliceOpt / InterFastCostBsliceOpt (Codec/EbRateDistortionCost.c:1157-1465) without chroma in the fast loop */
-MD_FN uint64_t md_inter_fast_cost(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *cu, const MdCand *c, uint64_t lumaDistortion,
-                                  uint64_t *fastLumaRate)
+/* getWeightedChromaDistortion (Codec/EbRateDistortionCost.c:35-65): chromaWeight = ChromaWeightFactor*[qp] of the picture's class (SvtAmdMdInter.chroma_weight) */
+MD_FN uint64_t md_weighted_chroma(uint64_t chromaDistortion, uint32_t chromaWeight) { return (chromaDistortion * chromaWeight + 128) >> 8; }
+/* InterFastCostPsliceOpt / InterFastCostBsliceOpt (Codec/EbRateDistortionCost.c:1157-1465).  chromaDistortion: the Cb + Cr SAD of a candidate of a
+ * CHROMA_MODE_FULL LCU (0 otherwise); weightChroma: candidateBuffer->weightChromaDistortion (0 in LCUs of noise class CMPLX_NOISE,
+ * Codec/EbProductCodingLoop.c:2079-2094: a merge candidate's chroma SAD is then added unweighted) */
+MD_FN uint64_t md_inter_fast_cost_c(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *cu, const MdCand *c, uint64_t lumaDistortion,
+                                    uint64_t chromaDistortion, uint32_t chromaWeight, int weightChroma, uint64_t *fastLumaRate)
 {
     /* skipFlagBits[3 + skip context] = {54723, 14816, 8254}; mergeIndexBits = {10350, 109741, 142509, 175277, 175277};
      * interBiDirBits[2 depth + bi] = {29856, 36028, 15752, 59703, 8692, 84420, 2742, 136034}; interUniDirBits = {2742, 136034} */
     uint64_t rate;
     if (c->merge_flag) {
         rate = (uint64_t)md_sel3(cu->skip_ctx, 54723, 14816, 8254) + (c->merge_index >= 3 ? 175277u : md_sel3(c->merge_index, 10350, 109741, 142509));
+        *fastLumaRate = rate;
+        const uint64_t distortion = weightChroma ? (lumaDistortion << 8) + md_weighted_chroma(chromaDistortion, chromaWeight) : (lumaDistortion + chromaDistortion) << 8;
+        return distortion + (((uint64_t)P->fast_lambda * rate + (1u << 22)) >> 23);
+    }
+    rate = 86440;
+    if (P->slice_type == 0) {
+        const int bi = c->dir == MD_BI;
+        rate += st->depth >= 3 ? (bi ? 136034u : 2742u) : md_sel3(st->depth, bi ? 36028u : 29856u, bi ? 59703u : 15752u, bi ? 84420u : 8692u);
+        if (c->dir != MD_BI)
+            rate += (c->dir ? 136034u : 2742u) + md_mvd_rate(c, c->dir);
+        else
+            rate += (uint64_t)md_mvd_rate(c, 0) + md_mvd_rate(c, 1);
     } else {
-        rate = 86440;
-        if (P->slice_type == 0) {
-            const int bi = c->dir == MD_BI;
-            rate += st->depth >= 3 ? (bi ? 136034u : 2742u) : md_sel3(st->depth, bi ? 36028u : 29856u, bi ? 59703u : 15752u, bi ? 84420u : 8692u);
-            if (c->dir != MD_BI)
-                rate += (c->dir ? 136034u : 2742u) + md_mvd_rate(c, c->dir);
-            else
-                rate += (uint64_t)md_mvd_rate(c, 0) + md_mvd_rate(c, 1);
-        } else {
-            rate += md_mvd_rate(c, 0);
-        }
+        rate += md_mvd_rate(c, 0);
     }
     *fastLumaRate = rate;
-    return (lumaDistortion << 8) + (((uint64_t)P->fast_lambda * rate + (1u << 22)) >> 23);
+    return (lumaDistortion << 8) + md_weighted_chroma(chromaDistortion, chromaWeight) + (((uint64_t)P->fast_lambda * rate + (1u << 22)) >> 23);
 }
-/* Intra2Nx2NFastCostPsliceOpt (:580-660) without chroma in the fast loop */
-MD_FN uint64_t md_intra_fast_cost_pslice(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *c, int lumaMode, uint64_t lumaDistortion,
-                                         uint64_t *fastLumaRate)
+MD_FN uint64_t md_inter_fast_cost(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *cu, const MdCand *c, uint64_t lumaDistortion,
+                                  uint64_t *fastLumaRate)
+{
+    return md_inter_fast_cost_c(P, st, cu, c, lumaDistortion, 0, 0, 1, fastLumaRate);
+}
+/* Intra2Nx2NFastCostPsliceOpt (:580-660) */
+MD_FN uint64_t md_intra_fast_cost_pslice_c(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *c, int lumaMode, uint64_t lumaDistortion,
+                                           uint64_t chromaDistortion, uint32_t chromaWeight, uint64_t *fastLumaRate)
 {
     const uint64_t chromaRate = 12368;
     uint64_t lumaRate = st->depth == 3 ? 31523 : 0;
     lumaRate += 136034;
     lumaRate += (lumaMode == c->left_intra_mode || lumaMode == c->top_intra_mode) ? 72731 : 192228;
     *fastLumaRate = lumaRate;
-    return (lumaDistortion << 8) + (((uint64_t)P->fast_lambda * (lumaRate + chromaRate) + (1u << 22)) >> 23);
+    return (lumaDistortion << 8) + md_weighted_chroma(chromaDistortion, chromaWeight) + (((uint64_t)P->fast_lambda * (lumaRate + chromaRate) + (1u << 22)) >> 23);
+}
+MD_FN uint64_t md_intra_fast_cost_pslice(const SvtAmdMdPicture *P, const MdStats *st, const MdCu *c, int lumaMode, uint64_t lumaDistortion,
+                                         uint64_t *fastLumaRate)
+{
+    return md_intra_fast_cost_pslice_c(P, st, c, lumaMode, lumaDistortion, 0, 0, fastLumaRate);
+}
+/* the noise-class rule of the fast loop's chroma distortion (Codec/EbProductCodingLoop.c:2079-2094): in an LCU of class CMPLX_NOISE the chroma SAD of a 64x64
+ * candidate that does not move (intra candidates count: their vectors are zero) is quartered */
+MD_FN uint64_t md_fast_chroma_noise_rule(const SvtAmdMdLcu *L, int cuSize, const MdCand *c, uint64_t chromaDistortion)
+{
+    if (!L->cmplx_noise || cuSize != 64)
+        return chromaDistortion;
+    const int l0zz = (c->dir & 1) ? 1 : (c->mv[0].x == 0 && c->mv[0].y == 0);
+    const int l1zz = c->dir > 0 ? (c->mv[1].x == 0 && c->mv[1].y == 0) : 1;
+    return (l0zz && l1zz) ? chromaDistortion >> 2 : chromaDistortion;
 }
 
 /* the rate of the transform-tree flags of a unit's luma (shared tail of InterFullLumaCost / MergeSkipFullLumaCost / IntraFullLumaCostPslice):
@@ -995,38 +1021,80 @@ MD_FN int md_stop_split(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int dept
     return (depth == 0 && fullDistortion < d0[e][t]) || (depth == 1 && fullDistortion < d1[e][t]) || (depth == 2 && fullDistortion < d2[e][t]);
 }
 
-/* MergeSkipFullCost (Codec/EbRateDistortionCost.c:2107-2355) as AddChromaEncDec calls it for the merge unit the mode decision chose in a
- * CHROMA_MODE_BEST LCU (Codec/EbProductCodingLoop.c:4158-4349): the luma terms the mode decision kept (MdCu) + the chroma loop's sums.
+/* the transform-tree flag rates of a unit with chroma (shared by InterFullCost :1753-1950 and MergeSkipFullCost :2107-2355; rootCbf != 0): the luma part
+ * (split flags + luma cbf flags) and the chroma cbf flags.  yCbf / cbCbf / crCbf: bit 0 of a unit below 64x64, bits 1..4 of the four 32x32 transform units of a 64x64 unit */
+MD_FN void md_tu_flags_rate_c(const SvtAmdMdPicture *P, int cuSize, uint32_t yCbf, uint32_t cbCbf, uint32_t crCbf, uint64_t *lumaFlags, uint64_t *chromaFlags)
+{
+    const int lgT = cuSize == 64 ? 5 : (cuSize == 32 ? 5 : (cuSize == 16 ? 4 : 3));
+    uint64_t lf = 0, cf = 0;
+    if (cuSize == 64) {
+        cf += (uint64_t)P->rates.chromaCbfBits[(crCbf > 0) * 5 + 0] + P->rates.chromaCbfBits[(cbCbf > 0) * 5 + 0];
+        for (int tu = 1; tu <= 4; tu++) {
+            lf += (uint64_t)P->rates.transSubDivFlagBits[5 - lgT] + P->rates.lumaCbfBits[((yCbf >> tu) & 1) * 5 + 0];
+            cf += crCbf > 0 ? P->rates.chromaCbfBits[((crCbf >> tu) & 1) * 5 + 1] : 0;
+            cf += cbCbf > 0 ? P->rates.chromaCbfBits[((cbCbf >> tu) & 1) * 5 + 1] : 0;
+        }
+    } else {
+        lf += P->rates.transSubDivFlagBits[5 - lgT];
+        if (cbCbf > 0 || crCbf > 0)
+            lf += P->rates.lumaCbfBits[(yCbf > 0) * 5 + 1];
+        cf += (uint64_t)P->rates.chromaCbfBits[(cbCbf > 0) * 5 + 0] + P->rates.chromaCbfBits[(crCbf > 0) * 5 + 0];
+    }
+    *lumaFlags = lf, *chromaFlags = cf;
+}
+/* MergeSkipFullCost (Codec/EbRateDistortionCost.c:2107-2355): the merge and the skip cost of a merge candidate from the sums of its luma and chroma full loops.
  * cbf[p] / bits[p] / dist[p][2]: candidatePtr->cbCbf / crCbf, *cbCoeffBits / *crCoeffBits, cb / crFullDistortion. */
+MD_FN void md_merge_skip_full_cost_v(const SvtAmdMdPicture *P, uint32_t chromaWeight, int skipCtx, int mergeIndex, int cuSize, uint32_t yCbf, const uint32_t cbf[2],
+                                     uint64_t yCoeffBits, const uint64_t bits[2], const uint64_t yDist[2], const uint64_t dist[2][2], uint64_t fastLumaRate,
+                                     uint64_t *mergeCost, uint64_t *skipCost)
+{
+    const uint32_t cbCbf = cbf[0], crCbf = cbf[1];
+    const int rootCbf = yCbf || cbCbf || crCbf;
+    uint64_t lumaFlags = 0, chromaFlags = 0;
+    if (rootCbf)
+        md_tu_flags_rate_c(P, cuSize, yCbf, cbCbf, crCbf, &lumaFlags, &chromaFlags);
+    const uint64_t mergeLumaRate = (uint64_t)P->rates.skipFlagBits[skipCtx] + P->rates.mergeFlagBits[1] + P->rates.predModeBits[0] +
+                                   P->rates.interPartSizeBits[0] + P->rates.mergeIndexBits[mergeIndex] + lumaFlags;
+    const uint64_t coeffRate = (yCoeffBits + bits[0] + bits[1]) << 15;
+    const uint64_t lambda = P->full_lambda, lambdaChroma = P->full_chroma_lambda;
+    const uint64_t mergeChroma = md_weighted_chroma(dist[0][0] + dist[1][0], chromaWeight), skipChroma = md_weighted_chroma(dist[0][1] + dist[1][1], chromaWeight);
+    *mergeCost = (yDist[0] << 8) + mergeChroma + (((lambda * coeffRate + lambda * mergeLumaRate + lambdaChroma * chromaFlags) + (1u << 22)) >> 23);
+    *skipCost = (yDist[1] << 8) + skipChroma + (((lambda * fastLumaRate) + (1u << 22)) >> 23);
+}
+/* ... as AddChromaEncDec calls it for the merge unit the mode decision chose in a CHROMA_MODE_BEST LCU (Codec/EbProductCodingLoop.c:4158-4349): the luma terms
+ * the mode decision kept (MdCu) + the chroma loop's sums */
 MD_FN void md_merge_skip_full_cost(const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const MdCu *cu, int cuSize, const uint32_t cbf[2], const uint64_t bits[2],
                                    const uint64_t dist[2][2], uint64_t *mergeCost, uint64_t *skipCost)
 {
-    const uint32_t yCbf = cu->ycbf_mask, cbCbf = cbf[0], crCbf = cbf[1];
-    const int rootCbf = yCbf || cbCbf || crCbf;
-    const int lgT = cuSize == 64 ? 5 : (cuSize == 32 ? 5 : (cuSize == 16 ? 4 : 3));
-    uint64_t lumaFlags = 0, chromaFlags = 0;
-    if (rootCbf) {
-        if (cuSize == 64) {
-            chromaFlags += (uint64_t)P->rates.chromaCbfBits[(crCbf > 0) * 5 + 0] + P->rates.chromaCbfBits[(cbCbf > 0) * 5 + 0];
-            for (int tu = 1; tu <= 4; tu++) {
-                lumaFlags += (uint64_t)P->rates.transSubDivFlagBits[5 - lgT] + P->rates.lumaCbfBits[((yCbf >> tu) & 1) * 5 + 0];
-                chromaFlags += crCbf > 0 ? P->rates.chromaCbfBits[((crCbf >> tu) & 1) * 5 + 1] : 0;
-                chromaFlags += cbCbf > 0 ? P->rates.chromaCbfBits[((cbCbf >> tu) & 1) * 5 + 1] : 0;
-            }
-        } else {
-            lumaFlags += P->rates.transSubDivFlagBits[5 - lgT];
-            if (cbCbf > 0 || crCbf > 0)
-                lumaFlags += P->rates.lumaCbfBits[(yCbf > 0) * 5 + 1];
-            chromaFlags += (uint64_t)P->rates.chromaCbfBits[(cbCbf > 0) * 5 + 0] + P->rates.chromaCbfBits[(crCbf > 0) * 5 + 0];
-        }
+    md_merge_skip_full_cost_v(P, X->chroma_weight, cu->skip_ctx, cu->merge_index, cuSize, cu->ycbf_mask, cbf, cu->y_coeff_bits, bits, cu->y_dist, dist, cu->fast_luma_rate,
+                              mergeCost, skipCost);
+}
+/* InterFullCost (:1753-1950) of a candidate of a CHROMA_MODE_FULL LCU; merge candidates: MergeSkipFullCost (full cost = the smaller of the two) */
+MD_FN uint64_t md_inter_full_cost(const SvtAmdMdPicture *P, uint32_t chromaWeight, const MdCu *cu, const MdCand *c, int cuSize, uint32_t yCbf, const uint32_t cbf[2],
+                                  uint64_t fastLumaRate, const uint64_t yDist[2], const uint64_t dist[2][2], uint64_t yCoeffBits, const uint64_t bits[2],
+                                  uint64_t *mergeCost, uint64_t *skipCost)
+{
+    if (c->merge_flag) {
+        md_merge_skip_full_cost_v(P, chromaWeight, cu->skip_ctx, c->merge_index, cuSize, yCbf, cbf, yCoeffBits, bits, yDist, dist, fastLumaRate, mergeCost, skipCost);
+        return *skipCost <= *mergeCost ? *skipCost : *mergeCost;
     }
-    const uint64_t mergeLumaRate = (uint64_t)P->rates.skipFlagBits[cu->skip_ctx] + P->rates.mergeFlagBits[1] + P->rates.predModeBits[0] +
-                                   P->rates.interPartSizeBits[0] + P->rates.mergeIndexBits[cu->merge_index] + lumaFlags;
-    const uint64_t coeffRate = (cu->y_coeff_bits + bits[0] + bits[1]) << 15;
-    const uint64_t lambda = P->full_lambda, lambdaChroma = P->full_chroma_lambda, w = X->chroma_weight;
-    const uint64_t mergeChroma = ((dist[0][0] + dist[1][0]) * w + 128) >> 8, skipChroma = ((dist[0][1] + dist[1][1]) * w + 128) >> 8;
-    *mergeCost = (cu->y_dist[0] << 8) + mergeChroma + (((lambda * coeffRate + lambda * mergeLumaRate + lambdaChroma * chromaFlags) + (1u << 22)) >> 23);
-    *skipCost = (cu->y_dist[1] << 8) + skipChroma + (((lambda * cu->fast_luma_rate) + (1u << 22)) >> 23);
+    const int rootCbf = yCbf || cbf[0] || cbf[1];
+    uint64_t lumaFlags = 0, chromaFlags = 0;
+    if (rootCbf)
+        md_tu_flags_rate_c(P, cuSize, yCbf, cbf[0], cbf[1], &lumaFlags, &chromaFlags);
+    const uint64_t lumaRate = (uint64_t)P->rates.rootCbfBits[rootCbf] + lumaFlags + fastLumaRate;
+    const uint64_t coeffRate = (yCoeffBits + bits[0] + bits[1]) << 15, lambda = P->full_lambda, lambdaChroma = P->full_chroma_lambda;
+    return (yDist[0] << 8) + md_weighted_chroma(dist[0][0] + dist[1][0], chromaWeight) + (((lambda * coeffRate + lambda * lumaRate + lambdaChroma * chromaFlags) + (1u << 22)) >> 23);
+}
+/* IntraFullCostPslice (:807-950) of a candidate of a CHROMA_MODE_FULL LCU: units up to 32x32, one transform unit; fastChromaRate = 12368 */
+MD_FN uint64_t md_intra_full_cost_pslice(const SvtAmdMdPicture *P, uint32_t chromaWeight, int cuSize, uint32_t yCbf, const uint32_t cbf[2], uint64_t fastLumaRate,
+                                         uint64_t yDistortion0, const uint64_t dist[2][2], uint64_t yCoeffBits, const uint64_t bits[2])
+{
+    const int lg = cuSize == 32 ? 5 : (cuSize == 16 ? 4 : 3);
+    const uint64_t lumaRate = (uint64_t)P->rates.transSubDivFlagBits[5 - lg] + P->rates.lumaCbfBits[(yCbf & 1) * 5 + 1] + fastLumaRate;
+    const uint64_t chromaRate = (uint64_t)P->rates.chromaCbfBits[(cbf[1] & 1) * 5 + 0] + P->rates.chromaCbfBits[(cbf[0] & 1) * 5 + 0] + 12368;
+    const uint64_t coeffRate = (yCoeffBits + bits[0] + bits[1]) << 15, lambda = P->full_lambda, lambdaChroma = P->full_chroma_lambda;
+    return (yDistortion0 << 8) + md_weighted_chroma(dist[0][0] + dist[1][0], chromaWeight) + (((lambda * coeffRate + lambda * lumaRate + lambdaChroma * chromaRate) + (1u << 22)) >> 23);
 }
 /* the merge / skip decision of EncodePass for a merge unit (Codec/EbCodingLoop.c:3838-3882): 2 = SVT_AMD_EP_INTER_SKIP, 1 = _MERGE */
 MD_FN int md_ep_merge_kind(const SvtAmdMdInter *X, const SvtAmdMdLcu *L, uint64_t mergeCost, uint64_t skipCost)
@@ -1046,14 +1114,14 @@ MD_FN int md_picture_supported(const SvtAmdMdPicture *P)
 /* P / B pictures; the LCUs must in addition all be decided by ModeDecisionLcu (md_lcu_supported) */
 MD_FN int md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X)
 {
-    return P->slice_type != 2 && P->intra_md_open_loop && P->chroma_level == 1 && !P->coeff_cabac_update && P->intra4x4_level == 2 &&
+    return P->slice_type != 2 && P->intra_md_open_loop && !P->coeff_cabac_update && P->intra4x4_level == 2 &&
            !P->rdoq_pmcore_method && !P->single_fast_loop && !P->spatial_sse_full_loop && P->pf_md_level <= 1 && P->nfl_level_md != 3 &&
            P->intra_injection_method <= 1 && !P->limit_ois_to_dc_mode && !P->mpm_search && P->enc_mode < 10 && !(P->width & 7) && !(P->height & 7) &&
            X->use_subpel && X->unrestricted_mv && X->generate_amvp_table_md && !X->extra_injection && !X->improve_sharpness;
 }
 MD_FN int md_lcu_supported(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L)
 {
-    if (L->chroma_encode_mode != 2 /* CHROMA_MODE_BEST */)
+    if (L->chroma_encode_mode != 2 /* CHROMA_MODE_BEST */ && L->chroma_encode_mode != 1 /* CHROMA_MODE_FULL: chroma in both loops of every candidate */)
         return 0;
     if (P->depth_mode == 0) /* PICT_LCU_SWITCH: branch-and-depth-pillar LCUs (3, 4) stay with the reference */
         return L->lcu_md_mode != 3 && L->lcu_md_mode != 4 && L->lcu_md_mode != 0;

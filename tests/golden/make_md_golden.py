@@ -37,6 +37,14 @@ CASES = {
     "b_objects_640x360_m9_q36": ("objects", 640, 360, 5, 5, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "36"], "nonref"),
     "p_objects_320x192_m8_ld": ("objects", 320, 192, 6, 4, ["-encMode", "8", "-pred-struct", "1", "-hierarchical-levels", "2", "-q", "26"], "nonref"),
     "p_motion_416x240_m8_ld": ("motion", 416, 240, 6, 9, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "2", "-q", "32"], "nonref"),
+    # reference P / B pictures with open-loop intra candidates: chroma level 4 = per-LCU switch between CHROMA_MODE_FULL (chroma prediction + SAD in the fast loop, chroma
+    # full loop and chroma terms in the full costs of every candidate) and CHROMA_MODE_BEST (EbEncDecProcess.c:2066-2113, EbModeDecisionProcess.c:395-447)
+    "bref_motion_416x240_m8": ("motion", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "ref"),
+    "bref_objects_640x360_m9_q36": ("objects", 640, 360, 5, 5, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "36"], "ref"),
+    "bref_noise_320x256_m9_q24": ("noise", 320, 256, 9, 11, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "24"], "ref"),
+    "pref_motion_416x240_m8_ld": ("motion", 416, 240, 6, 9, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "2", "-q", "32"], "ref"),
+    "bref_tiles_motion_640x384_m8": ("motion", 640, 384, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "34", "-tile_col_cnt", "2",
+                                                                  "-tile_row_cnt", "2"], "ref"),
     "i_tiles_motion_640x384_m9": ("motion", 640, 384, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "33", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], None),
 }
 
@@ -105,6 +113,8 @@ def run_case(name):
                    sorted(set(r["lcu"]["chroma_encode_mode"].tolist()))))
     if keep == "nonref":
         keep = [p for p in sorted(pics) if pics[p][0]["pic"]["slice_type"] != 2 and not pics[p][0]["pic"]["is_reference"]]
+    if keep == "ref":
+        keep = [p for p in sorted(pics) if pics[p][0]["pic"]["slice_type"] != 2 and pics[p][0]["pic"]["is_reference"] and pics[p][0]["pic"]["intra_md_open_loop"]]
     numbers = sorted(pics) if keep is None else [p for p in sorted(pics) if p in keep]
     # only pictures every LCU of which went through ModeDecisionLcu (PICT_LCU_SWITCH pictures mix it with the BDP path)
     numbers = [p for p in numbers if (lcus["picture_number"] == p).sum() == nl]
