@@ -97,17 +97,27 @@ struct MdClosedLoop {
     int16_t recon_coeff[MD_MAX_BUF][32 * 32];
     uint8_t best_rec[4][64 * 64];
 };
+#define MD_PRED_SLOTS 6 /* one motion-estimation candidate + up to five merge candidates are evaluated per unit */
 struct MdInterShared {
+    /* a wave's chroma prediction of the candidate it works on: the first half of its luma scratch (a wave's tasks follow one another, the luma block is spent by then) */
+    __device__ __forceinline__ uint8_t *wpred_c(int wave, int pl) { return wpred[wave] + pl * 1024; }
     MdMvUnit mvu[9 * 18];          /* (cy + 1) * 18 + cx + 1: 8x8 cells, cy in [-1, 8), cx in [-1, 16] */
     SvtAmdMeCuResult me[SVT_AMD_ME_PU_COUNT]; /* the LCU's motion-estimation candidates */
     SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
     MdMvUnit nb[5];
     MdInterLists T;
     alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
-    uint8_t cpred[8][64 * 64];     /* the fast loop's predictions of the first 8 motion-compensated candidates, kept for the full loop */
+    uint8_t cpred[MD_PRED_SLOTS][64 * 64]; /* the fast loop's predictions of the first motion-compensated candidates, kept for the full loop */
     int8_t slot[MD_MAX_CAND];      /* candidate -> cpred slot, -1 = none */
     EpMcScratch<uint8_t> mc[4];
-    alignas(16) uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (merge / skip decision of the encode pass) */
+    alignas(16) uint8_t src_c[2][32 * 32];     /* the LCU's chroma source (CHROMA_MODE_FULL candidates; merge / skip decision of the encode pass) */
+    /* CHROMA_MODE_FULL LCUs (chroma in both loops of every candidate, EbModeDecisionProcess.c:439-441) */
+    alignas(16) uint8_t cpred_c[MD_PRED_SLOTS][2][32 * 32]; /* the chroma predictions beside cpred, pitch = unit size / 2 */
+    int16_t refc[2][132];          /* the unit's open-loop chroma intra references (Cb, Cr) in pu_predict's layout */
+    uint32_t sadc[MD_MAX_CAND];    /* Cb + Cr SAD of the fast loop */
+    uint8_t heavyc[MD_MAX_CAND];   /* the candidates whose chroma the fast loop predicts and measures, packed */
+    int nheavyc;
+    MdFl flc[MD_MAX_BUF][2][4];    /* the chroma full loop's sums per buffer, plane and transform unit */
     uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
     uint8_t fin_leaf[SVT_AMD_LCU_MAX_CUS];
     int nfin;
@@ -382,6 +392,40 @@ __device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCan
     ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, 0, lane, mc, [&](int x, int y) { return dst + y * N + x; }, tile_first, tile_step);
     EP_WAVE_SYNC();
 }
+/* ... of plane p (0 luma: N x N, 1 / 2 chroma: N/2 x N/2) into dst with pitch = the block's width */
+__device__ __forceinline__ void md_predict_inter_plane(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
+                                                       int tile_first, int tile_step)
+{
+    int16_t mv[2][2];
+    mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
+    const int pitch = p ? N >> 1 : N;
+    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, p, lane, mc, [&](int x, int y) { return dst + y * pitch + x; }, tile_first, tile_step);
+    EP_WAVE_SYNC();
+}
+/* IntraPredictionOl's chroma references of the unit (Codec/EbIntraPrediction.c:5065 UpdateChromaNeighborSamplesArrayOL): SOURCE chroma samples around the
+ * unit, mid-grey beyond the picture.  By one wave; ref[p] in pu_predict's layout (n = N/2). */
+__device__ __forceinline__ void md_build_refs_ol_chroma(const MdPictureDev &D, int16_t (*ref)[132], int N, int x0, int y0, int W, int H, int lane)
+{
+    const int n = N >> 1, cx = x0 >> 1, cy = y0 >> 1, w = W >> 1, h = H >> 1;
+    for (int i = lane; i < 2 * (4 * n + 1); i += 64) {
+        const int p = i >= 4 * n + 1, k = p ? i - (4 * n + 1) : i;
+        const uint8_t *src = D.src[1 + p] + (size_t)cy * D.src_pitch[1] + cx;
+        int v = 128;
+        if (k < 2 * n) {
+            if (cx != 0 && cy + k < h)
+                v = src[(ptrdiff_t)k * D.src_pitch[1] - 1];
+        } else if (k == 2 * n) {
+            if (cx != 0 && cy != 0)
+                v = src[-(ptrdiff_t)D.src_pitch[1] - 1];
+        } else {
+            const int j = k - 2 * n - 1;
+            if (cy != 0 && cx + j < w)
+                v = src[j - (ptrdiff_t)D.src_pitch[1]];
+        }
+        ref[p][k] = (int16_t)v;
+    }
+    EP_WAVE_SYNC();
+}
 
 /* the luma full loop of the unit's candidate on one wave: every transform unit (four 32x32 of a 64x64 unit) -> out[tu] */
 __device__ __forceinline__ void md_full_loop_cand(int lane, int N, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile, int16_t *qbuf,
@@ -425,6 +469,24 @@ __device__ __forceinline__ void md_tu_calc_cost(const SvtAmdMdPicture &P, const 
     dist[0] += nzCost < zCost ? d0 : d1, dist[1] += d1;
 }
 
+/* one chroma transform unit of FullLoop_R + CuFullDistortionFastTuMode_R on the calling wave -> nz, the two scaled distortions, the bits */
+__device__ __forceinline__ void md_chroma_tu(int lane, int T, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *tile, int16_t *qbuf, const SvtAmdMdPicture &P,
+                                             const SvtAmdCabacCost &cost, int type, int mode, int component, int pf, uint32_t *nz, unsigned long long dist[2], unsigned long long *bits)
+{
+    const int pfc = T == 4 ? 0 : (T == 8 && pf == 2 ? 1 : pf); /* correctedPFMode (EbFullLoop.c:647-652) */
+    MdFl o;
+    switch (T) {
+    case 16: o = md_full_loop_unit<16>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc); break;
+    case 8: o = md_full_loop_unit<8>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc); break;
+    default: o = md_full_loop_unit<4>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc); break;
+    }
+    const int lgT = T == 16 ? 4 : T == 8 ? 3 : 2, sh = 2 * (7 - lgT);
+    *nz = o.nz;
+    dist[0] = ((unsigned long long)o.d0 + (1ull << (sh - 1))) >> sh, dist[1] = ((unsigned long long)o.d1 + (1ull << (sh - 1))) >> sh;
+    *bits = (((unsigned long long)o.bits) << 10) >> 15;
+    EP_WAVE_SYNC();
+}
+
 /* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
 /* what the LCU's mode decision reads that no other LCU of the picture writes (its records, its source): into LDS BEFORE the workgroup waits for the LCU's neighbours */
 template <bool INTER>
@@ -457,6 +519,15 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
         if (x < lw && y < lh)
             v = *(const uint32_t *)(D.src[0] + (size_t)(lcu_y + y) * D.src_pitch[0] + lcu_x + x);
         *(uint32_t *)&L.src[y * 64 + x] = v;
+    }
+    if constexpr (INTER) { /* the chroma source: CHROMA_MODE_FULL candidates, and the merge / skip decisions behind the mode decision */
+        for (int i = t; i < 2 * 32 * 32 / 4; i += 256) {
+            const int p = i >> 8, e = i & 255, y = e >> 3, x = (e & 7) * 4;
+            uint32_t v = 0;
+            if (x < lw / 2 && y < lh / 2)
+                v = *(const uint32_t *)(D.src[1 + p] + (size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x);
+            *(uint32_t *)&M.V.src_c[p][y * 32 + x] = v;
+        }
     }
     __syncthreads();
     if (t == 0) {
@@ -564,6 +635,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         md_build_refs_ol(D, M, st, lcu_x + st.x, lcu_y + st.y, W, H, lane);
                     else
                         md_build_refs(M, st, lane);
+                    if (M.lcu.chroma_encode_mode == 1 && open_loop)
+                        md_build_refs_ol_chroma(D, M.V.refc, st.size, lcu_x + st.x, lcu_y + st.y, W, H, lane);
                 }
             }
             __syncthreads();
@@ -675,13 +748,24 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     M.sad[lane] = (!heavy && e && !c.mpm) ? c.me_dist : 0u;
                 if (lane == 0)
                     M.nheavy = __popcll(hm);
+                if constexpr (INTER) { /* CHROMA_MODE_FULL: the chroma pair of EVERY evaluated candidate is predicted and measured - the open-loop intra candidate that won
+                                        * the first loop included (only its luma distortion stands, :1651-1654) */
+                    const bool hc = in && e && !c.mpm && M.lcu.chroma_encode_mode == 1;
+                    const unsigned long long cm = __ballot(hc);
+                    if (hc)
+                        M.V.heavyc[__popcll(cm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                    if (in)
+                        M.V.sadc[lane] = 0u;
+                    if (lane == 0)
+                        M.V.nheavyc = __popcll(cm);
+                }
             }
             if constexpr (INTER) { /* the first eight inter candidates the loop evaluates keep their prediction for the full loop */
                 const bool q = e && c.type == MD_INTER;
                 const unsigned long long qm = __ballot(q);
                 const int rank = __popcll(qm & ((1ull << lane) - 1ull));
                 if (in)
-                    M.V.slot[lane] = (int8_t)((q && rank < 8) ? rank : -1);
+                    M.V.slot[lane] = (int8_t)((q && rank < MD_PRED_SLOTS) ? rank : -1);
             }
             if (lane == 0)
                 M.best_first = bestFirst;
@@ -704,51 +788,50 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         MD_PROF(2);
         if (D.prof && t == 0)
             M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1;
-        /* ---- fast loop: a wave per candidate (ProductPerformFastLoop's second loop) ---- */
-        bool tiled64 = false;
-        if constexpr (INTER) {
-            /* a 64x64 unit's candidates are motion-compensated in four 32x32 tiles: wave w takes tile w of EVERY candidate (all four waves work whatever the number of
-             * candidates) and adds its part of the distortion */
-            tiled64 = N == 64 && !M.any_intra;
-            if (tiled64) {
-                const int nh = M.nheavy;
-                for (int k = 0; k < nh; k++) {
-                    const int c = M.heavy[k], sl = M.V.slot[c];
-                    const MdCand cd = M.cand[c];
-                    uint32_t sad = 0;
-                    if (sl >= 0) {
-                        uint8_t *pr = M.V.cpred[sl];
-                        md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr, wave, 4);
-                        const int ty0 = (wave >> 1) << 5, tx0 = (wave & 1) << 5;
-                        for (int e = 4 * lane; e < 32 * 32; e += 256) { /* v_sad_u8: four samples a word */
-                            const int y = ty0 + (e >> 5), x = tx0 + (e & 31);
-                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[y * 64 + x]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + y) * 64 + st.x + x]), sad);
-                        }
-                    } else if (wave == (k & 3)) { /* no slot left to keep the prediction in: the whole candidate on one wave */
-                        uint8_t *pr = M.V.wpred[wave];
-                        md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
-                        for (int e = 4 * lane; e < N * N; e += 256)
-                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
-                    }
-                    sad = md_wave_sum(sad);
-                    if (lane == 0 && sad)
-                        atomicAdd(&M.sad[c], sad);
-                }
+        /* ---- fast loop (ProductPerformFastLoop's second loop): ONE list of tasks = (candidate, plane, tile) dealt to the four waves ----
+         * luma tasks first - a candidate of a 64x64 unit is motion-compensated in four 32x32 tiles, a task each (wave w takes tile w of EVERY candidate: all four waves work
+         * whatever the number of candidates) -, then, in CHROMA_MODE_FULL LCUs, the Cb and the Cr block of every evaluated candidate.  A task predicts its block (inter:
+         * ep_inter_predict_core into the candidate's slot - kept for the full loop - or the wave's scratch; intra: per sample in closed form), measures it against the source
+         * (v_sad_u8 on words) and adds its part to the candidate's distortion. */
+        {
+            bool tiled64 = false;
+            int nhc = 0;
+            if constexpr (INTER) {
+                tiled64 = N == 64 && !M.any_intra;
+                nhc = M.V.nheavyc;
             }
-        }
-        for (int k = wave; k < M.nheavy && !tiled64; k += 4) {
-            const int c = M.heavy[k];
-            uint32_t sad = 0;
-            const MdCand cd = M.cand[c];
-            {
+            const int T = tiled64 ? 4 : 1, nl = M.nheavy * T, ntask = nl + 2 * nhc;
+            for (int tk = wave; tk < ntask; tk += 4) {
+                const bool luma = tk < nl;
+                const int k = luma ? tk / T : (tk - nl) >> 1, ti = luma ? tk - k * T : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
+                int c;
+                if constexpr (INTER)
+                    c = luma ? M.heavy[k] : M.V.heavyc[k];
+                else
+                    c = M.heavy[k];
+                const MdCand cd = M.cand[c];
+                uint32_t sad = 0;
                 if (cd.type == MD_INTER) {
                     if constexpr (INTER) {
-                        uint8_t *pr = M.V.slot[c] >= 0 ? M.V.cpred[M.V.slot[c]] : M.V.wpred[wave];
-                        md_predict_inter(E, cd, x0, y0, N, lane, M.V.mc[wave], pr);
-                        for (int e = 4 * lane; e < N * N; e += 256)
-                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
+                        const int sl = M.V.slot[c], n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
+                        uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
+                        md_predict_inter_plane(E, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1);
+                        if (luma && tiled64) {
+                            const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
+                            for (int e = 4 * lane; e < 32 * 32; e += 256) { /* v_sad_u8: four samples a word */
+                                const int y = ty0 + (e >> 5), x = tx0 + (e & 31);
+                                sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[y * 64 + x]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + y) * 64 + st.x + x]), sad);
+                            }
+                        } else if (luma) {
+                            for (int e = 4 * lane; e < N * N; e += 256)
+                                sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
+                        } else { /* chroma blocks are 4 .. 32 samples wide: rows of words */
+                            const uint8_t *sc = &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)];
+                            for (int e = 4 * lane; e < n * n; e += 256)
+                                sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&sc[(e >> lgn) * 32 + (e & (n - 1))]), sad);
+                        }
                     }
-                } else {
+                } else if (luma) {
                     const int mode = cd.intra_mode;
                     const int16_t *use = (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref;
                     const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
@@ -757,11 +840,27 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
                         sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
                     }
+                } else {
+                    if constexpr (INTER) { /* IntraPredictionOl's chroma pair: the chroma mode is always DM (Codec/EbIntraPrediction.c:5530); kept for the full loop like the inter ones */
+                        const int mode = cd.intra_mode, n = N >> 1, lgn = lgN - 1;
+                        const int16_t *use = M.V.refc[pl - 1];
+                        const int dcv = mode == 1 ? md_dc_value(use, n, lgn, lane) : 0;
+                        const uint8_t *sc = &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)];
+                        for (int e = lane; e < n * n; e += 64) {
+                            const int y = e >> lgn, x = e & (n - 1);
+                            const int v = pu_predict(mode, n, lgn, use, x, y, dcv, false, 255);
+                            sad += (uint32_t)abs(v - (int)sc[y * 32 + x]);
+                        }
+                    }
                 }
                 sad = md_wave_sum(sad);
+                if (lane == 0 && sad) {
+                    if (luma)
+                        atomicAdd(&M.sad[c], sad);
+                    else if constexpr (INTER)
+                        atomicAdd(&M.V.sadc[c], sad);
+                }
             }
-            if (lane == 0)
-                M.sad[c] = sad;
         }
         __syncthreads();
         MD_PROF(3);
@@ -774,9 +873,15 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 evl = M.evaluated[i];
                 if (evl) {
                     const uint64_t dist = M.cand[i].mpm ? 0 : M.sad[i];
-                    cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, (uint64_t *)&rate)
+                    uint64_t distc = 0;
+                    uint32_t cw = 0;
+                    if constexpr (INTER) {
+                        if (M.lcu.chroma_encode_mode == 1) /* the chroma pair's SAD with the noise-class rule (:2079-2094) */
+                            distc = M.cand[i].mpm ? 0 : md_fast_chroma_noise_rule(&M.lcu, N, &M.cand[i], M.V.sadc[i]), cw = D.X->chroma_weight;
+                    }
+                    cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost_c(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, distc, cw, !M.lcu.cmplx_noise, (uint64_t *)&rate)
                           : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
-                                                    : md_intra_fast_cost_pslice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate);
+                                                    : md_intra_fast_cost_pslice_c(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, distc, cw, (uint64_t *)&rate);
                     if (M.cand[i].mpm)
                         cst = 0;
                 }
@@ -834,7 +939,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         MD_PROF(4);
         /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
         const int nfull = M.nfull;
-        bool split64 = false;
+        bool split64 = false, fresh64 = false;
         if constexpr (INTER) {
             /* a 64x64 unit has four 32x32 transform units per candidate: a wave per (candidate, transform unit) instead of a wave per candidate - with the usual one or
              * two survivors all four waves work.  The candidates of a 64x64 unit are motion-compensated (no intra candidate at depth 0). */
@@ -851,6 +956,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 }
                 if (sync)
                     __syncthreads();
+                fresh64 = sync;
                 for (int f = 0; f < nfull; f++) {
                     const int b = M.best[f], ci = M.B.cand[b], pci = M.B.pred[b] < 0 ? ci : M.B.pred[b];
                     const uint8_t *pred = (M.V.slot[pci] >= 0 && M.evaluated[pci]) ? M.V.cpred[M.V.slot[pci]] : M.V.wpred[f];
@@ -894,6 +1000,49 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             }
             md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, M.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
         }
+        if constexpr (INTER) {
+            /* CHROMA_MODE_FULL (PerformFullLoop :4443-4560): the chroma pair of every survivor - ChromaPrediction (the candidate's OWN prediction: the fast loop's when it
+             * evaluated the candidate, a fresh one otherwise), FullLoop_R + CuFullDistortionFastTuMode_R - as tasks (survivor, plane) on the waves the luma units left idle */
+            if (M.lcu.chroma_encode_mode == 1) {
+                if (fresh64) /* every wave is done with the fresh luma predictions in the waves' scratch before a chroma block lands there */
+                    __syncthreads();
+                const int Cn = N >> 1, lgc = lgN - 1, Tc = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
+                const int off = split64 ? 0 : nfull & 3;
+                for (int tk = (wave - off) & 3; tk < 2 * nfull; tk += 4) {
+                    const int f = tk >> 1, pl = tk & 1, b = M.best[f], ci = M.B.cand[b];
+                    const MdCand cd = M.cand[ci];
+                    const uint8_t *pred;
+                    if (cd.type == MD_INTER && M.V.slot[ci] >= 0 && M.evaluated[ci]) {
+                        pred = M.V.cpred_c[M.V.slot[ci]][pl];
+                    } else {
+                        uint8_t *pw = M.V.wpred_c(wave, pl);
+                        if (cd.type == MD_INTER) {
+                            md_predict_inter_plane(E, cd, x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1);
+                        } else {
+                            const int mode = cd.intra_mode;
+                            const int16_t *use = M.V.refc[pl];
+                            const int dcv = mode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
+                            for (int e = lane; e < Cn * Cn; e += 64)
+                                pw[e] = (uint8_t)pu_predict(mode, Cn, lgc, use, e & (Cn - 1), e >> lgc, dcv, false, 255);
+                            EP_WAVE_SYNC();
+                        }
+                        pred = pw;
+                    }
+                    for (int tu = 0; tu < ntu; tu++) {
+                        const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
+                        uint32_t nz;
+                        unsigned long long d[2], bt;
+                        md_chroma_tu(lane, Tc, &M.V.src_c[pl][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, cd.type,
+                                     cd.intra_mode, 1 + pl, pf, &nz, d, &bt);
+                        if (lane == 0) {
+                            MdFl o;
+                            o.nz = nz, o.d0 = (uint32_t)d[0], o.d1 = (uint32_t)d[1], o.bits = (uint32_t)bt;
+                            M.V.flc[b][pl][tu] = o;
+                        }
+                    }
+                }
+            }
+        }
         __syncthreads();
         MD_PROF(5);
         /* ---- wave 0: TuCalcCostLuma + the full cost of every surviving candidate (a lane each), then lane 0: ProductFullModeDecision, CheckHighCostPartition ---- */
@@ -915,9 +1064,31 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 } else {
                     md_tu_calc_cost(PL, M.fl[b][0], c.type, N, N, 0, &ycbf, &bits, dist);
                 }
-                if (M.lcu.chroma_encode_mode == 2 /* CHROMA_MODE_BEST */)
+                if (M.lcu.chroma_encode_mode == 2 /* CHROMA_MODE_BEST */ || M.lcu.chroma_encode_mode == 1)
                     bits = md_pf_coeff_bits(pf, P.qp, bits);
-                if (c.type == MD_INTER)
+                bool with_chroma = false;
+                if constexpr (INTER) {
+                    if (M.lcu.chroma_encode_mode == 1) { /* InterFullCost / MergeSkipFullCost / IntraFullCostPslice: the chroma loop's sums join the luma ones */
+                        with_chroma = true;
+                        const int ntu = N == 64 ? 4 : 1;
+                        uint32_t cbf[2] = {0, 0};
+                        uint64_t cbits[2] = {0, 0}, cdist[2][2] = {{0, 0}, {0, 0}};
+                        for (int pl = 0; pl < 2; pl++)
+                            for (int tu = 0; tu < ntu; tu++) {
+                                const MdFl o = M.V.flc[b][pl][tu];
+                                cbf[pl] |= (uint32_t)(o.nz != 0) << (ntu == 1 ? 0 : tu + 1);
+                                cbits[pl] += o.bits, cdist[pl][0] += o.d0, cdist[pl][1] += o.d1;
+                            }
+                        const uint64_t yd[2] = {dist[0], dist[1]};
+                        if (c.type == MD_INTER)
+                            full = md_inter_full_cost(&PL, D.X->chroma_weight, &M.S.cu[leaf], &c, N, ycbf, cbf, M.fast_rate[ci], yd, cdist, bits, cbits, &mc, &sc);
+                        else
+                            full = md_intra_full_cost_pslice(&PL, D.X->chroma_weight, N, ycbf, cbf, M.fast_rate[ci], dist[0], cdist, bits, cbits);
+                    }
+                }
+                if (with_chroma)
+                    ;
+                else if (c.type == MD_INTER)
                     full = md_inter_full_luma_cost(&PL, &M.S.cu[leaf], &c, N, ycbf, M.fast_rate[ci], (const uint64_t *)dist, bits, &mc, &sc);
                 else if (islice)
                     full = md_intra_full_luma_cost_islice(&PL, lgN, ycbf, M.fast_rate[ci], dist[0], bits);
@@ -1093,24 +1264,6 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
     }
 }
 
-/* one chroma transform unit of FullLoop_R + CuFullDistortionFastTuMode_R on the calling wave -> nz, the two scaled distortions, the bits */
-__device__ __forceinline__ void md_chroma_tu(int lane, int T, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *tile, int16_t *qbuf, const SvtAmdMdPicture &P,
-                                             const SvtAmdCabacCost &cost, int component, int pf, uint32_t *nz, unsigned long long dist[2], unsigned long long *bits)
-{
-    const int pfc = T == 4 ? 0 : (T == 8 && pf == 2 ? 1 : pf); /* correctedPFMode (EbFullLoop.c:647-652) */
-    MdFl o;
-    switch (T) {
-    case 16: o = md_full_loop_unit<16>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, MD_INTER, 0, component, pfc); break;
-    case 8: o = md_full_loop_unit<8>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, MD_INTER, 0, component, pfc); break;
-    default: o = md_full_loop_unit<4>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, MD_INTER, 0, component, pfc); break;
-    }
-    const int lgT = T == 16 ? 4 : T == 8 ? 3 : 2, sh = 2 * (7 - lgT);
-    *nz = o.nz;
-    dist[0] = ((unsigned long long)o.d0 + (1ull << (sh - 1))) >> sh, dist[1] = ((unsigned long long)o.d1 + (1ull << (sh - 1))) >> sh;
-    *bits = (((unsigned long long)o.bits) << 10) >> 15;
-    EP_WAVE_SYNC();
-}
-
 /* what EncodePass will do with the inter units of the LCU's final tree (Codec/EbCodingLoop.c:3838-3882): AMVP units as they are; merge units by the
  * merge / skip costs completed with chroma (AddChromaEncDec, Codec/EbProductCodingLoop.c:4158-4349: chroma prediction + chroma full loop +
  * MergeSkipFullCost), a wave per unit.  -> M.V.ep_kind[leaf] */
@@ -1128,21 +1281,16 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
             const MdStats st = md_stats(it);
             if (lcu_x + st.x < (int)P.width && lcu_y + st.y < (int)P.height && M.S.cu[it].pred_mode == MD_INTER) {
                 M.V.ep_kind[it] = M.S.cu[it].merge_flag ? SVT_AMD_EP_INTER_MERGE : SVT_AMD_EP_INTER_AMVP;
-                if (M.S.cu[it].merge_flag && n < SVT_AMD_LCU_MAX_CUS)
+                if (M.S.cu[it].merge_flag && M.lcu.chroma_encode_mode == 1) /* CHROMA_MODE_FULL: the mode decision's merge / skip costs hold chroma already (EbCodingLoop.c:3840) */
+                    M.V.ep_kind[it] = (uint8_t)md_ep_merge_kind(D.X, &M.lcu, M.S.cu[it].merge_cost, M.S.cu[it].skip_cost);
+                else if (M.S.cu[it].merge_flag && n < SVT_AMD_LCU_MAX_CUS)
                     M.V.fin_leaf[n++] = (uint8_t)it;
             }
             it += md_depth_offset(st.depth);
         }
         M.V.nfin = n;
     }
-    for (int i = t; i < 2 * 32 * 32; i += 256) {
-        const int p = i >> 10, e = i & 1023, y = e >> 5, x = e & 31;
-        uint8_t v = 0;
-        if (x < lw / 2 && y < lh / 2)
-            v = D.src[1 + p][(size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x];
-        M.V.src_c[p][e] = v;
-    }
-    __syncthreads();
+    __syncthreads(); /* (the LCU's chroma source is in LDS since md_lcu_inputs) */
     const int pf = md_pf_mode(&P);
     for (int i = wave; i < M.V.nfin; i += 4) {
         const int leaf = M.V.fin_leaf[i];
@@ -1161,8 +1309,8 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
                 const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                 uint32_t nz;
                 unsigned long long d[2], b;
-                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, 1 + p, pf,
-                             &nz, d, &b);
+                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, MD_INTER, 0,
+                             1 + p, pf, &nz, d, &b);
                 cbf[p] |= (uint32_t)(nz != 0) << (ntu == 1 ? 0 : tu + 1);
                 bits[p] += b, dist[p][0] += d[0], dist[p][1] += d[1];
             }
@@ -1423,7 +1571,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
                 return SVT_AMD_ERR_BAD_PARAM;
             }
         tiles += lcus[i].tile_left && lcus[i].tile_top;
-        if (X && (!md_lcu_supported(P, &lcus[i]) || lcus[i].chroma_encode_mode == 1 /* CHROMA_MODE_FULL: the checker has it, the kernel not yet */)) {
+        if (X && !md_lcu_supported(P, &lcus[i])) {
             svt_amd_set_error("svt_amd_md_encode_picture_inter: LCU %d is not decided by ModeDecisionLcu with luma-only candidates", i);
             return SVT_AMD_ERR_BAD_PARAM;
         }

@@ -123,7 +123,7 @@ def md_encode_inter(lib, ctx, pic, g, k, encode=False):
     return out, works, res
 
 
-INTER_CASES = [c for c in CASES if c.startswith(("b_", "p_"))]
+INTER_CASES = [c for c in CASES if c.startswith(("b_", "p_", "bref_", "pref_"))]   # bref_ / pref_: reference pictures, chroma level 4 (CHROMA_MODE_FULL LCUs)
 
 
 @pytest.mark.parametrize("name", INTER_CASES)
@@ -256,7 +256,7 @@ def test_md_of_b_pictures_at_baseline_sizes_matches_the_reference_run_on_the_box
     import md_bench
     if not os.path.exists(S.REF_APP):
         pytest.skip("oracle/_ref not built")
-    g = md_bench.record_inter(w, h, enc_mode, frames=frames, levels=2)
-    assert len(g["picture_number"]) >= 2
+    g = md_bench.record_inter(w, h, enc_mode, frames=frames, levels=2, ref=None)   # temporal layer 2 (luma-only candidates) and layer 1 (CHROMA_MODE_FULL)
+    assert len(g["picture_number"]) >= 3 and g["pic"]["is_reference"].any() and not g["pic"]["is_reference"].all()
     r = md_bench.run_inter(product, g, reps=1, encode=True)
     assert r["lcus"] == S.lcu_count(w, h) and r["final_units"] >= r["lcus"]

@@ -77,9 +77,10 @@ def run(lib, g, reps=5, check=True):
                     "decisions identical to the reference's ModeDecisionLcu records of the same picture"}
 
 
-def record_inter(w, h, enc_mode, frames=9, kind="objects", levels=3, extra=()):
-    """a random-access encode of `frames` pictures by the prebuilt reference with the recording harness on; returns the fixture-shaped records of the
-    non-reference B pictures (the pictures svt_amd_md_encode_picture_inter covers)"""
+def record_inter(w, h, enc_mode, frames=9, kind="objects", levels=3, extra=(), ref=False):
+    """a random-access encode of `frames` pictures by the prebuilt reference with the recording harness on; returns the fixture-shaped records of its
+    open-loop P / B pictures whose LCUs all went through ModeDecisionLcu (the pictures svt_amd_md_encode_picture_inter covers): ref = False the
+    non-reference ones (luma-only candidates), True the reference ones (chroma level 4: CHROMA_MODE_FULL LCUs), None both"""
     with tempfile.TemporaryDirectory() as td:
         yuv, dump = os.path.join(td, "c.yuv"), os.path.join(td, "md.dump")
         S.write_clip(yuv, kind, w, h, frames, 7)
@@ -88,7 +89,8 @@ def record_inter(w, h, enc_mode, frames=9, kind="objects", levels=3, extra=()):
         subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump), check=True, stdout=subprocess.DEVNULL)
         pics, lcus = parse_dump(open(dump, "rb").read())
     nl = S.lcu_count(w, h)
-    keep = [p for p in sorted(pics) if pics[p][0]["pic"]["slice_type"] != 2 and not pics[p][0]["pic"]["is_reference"] and (lcus["picture_number"] == p).sum() == nl]
+    keep = [p for p in sorted(pics) if pics[p][0]["pic"]["slice_type"] != 2 and pics[p][0]["pic"]["intra_md_open_loop"] and (lcus["picture_number"] == p).sum() == nl and
+            (ref is None or bool(pics[p][0]["pic"]["is_reference"]) == bool(ref))]
     g = {"picture_number": np.array(keep, np.uint64)}
     recs = []
     for p in keep:
@@ -157,7 +159,7 @@ def run_inter(lib, g, reps=3, encode=True, check=True):
     lib.svt_amd_context_destroy(ctx)
     return {"stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "pictures": [int(p) for p in g["picture_number"]], "leaves_tested_per_picture": tested // len(ts) * (reps - 1) if ts else 0,
             "final_units": units, "ms_per_picture_incl_host_copies": round(float(np.median(ts)), 2),
-            "what": "svt_amd_md_encode_picture_inter (mode decision%s) of the non-reference B pictures through the host-array ABI incl. reference-picture upload by the test; "
+            "what": "svt_amd_md_encode_picture_inter (mode decision%s) of the recorded B pictures through the host-array ABI incl. reference-picture upload by the test; "
                     "decisions identical to the reference's ModeDecisionLcu records" % (" + merge / skip decision + encode pass" if encode else " only")}
 
 
@@ -202,7 +204,8 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     w, h, m, reps = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (3840, 2160, 7, 5)
     if len(a) >= 5 and a[4] == "inter":
-        g = record_inter(w, h, m, frames=int(a[5]) if len(a) > 5 else 9, kind=os.environ.get("MD_BENCH_CLIP", "objects"), levels=2)
+        g = record_inter(w, h, m, frames=int(a[5]) if len(a) > 5 else 9, kind=os.environ.get("MD_BENCH_CLIP", "objects"), levels=2,
+                         ref={"ref": True, "all": None}.get(os.environ.get("MD_BENCH_PICTURES", ""), False))
         lib = S.load_product()
         out = run_inter(lib, g, reps)
         if os.environ.get("MD_BENCH_FLIGHTS"):
