@@ -133,6 +133,10 @@ SVT_AMD_API int svt_amd_context_create(int device_ordinal, uint16_t max_luma_wid
                                        SvtAmdContext **out_ctx);
 SVT_AMD_API void svt_amd_context_destroy(SvtAmdContext *ctx);
 SVT_AMD_API const char *svt_amd_version(void);
+/* OPT-IN process setting for hosts that keep several pictures in flight (lanes = HIP streams): asks the HIP runtime for 24 hardware queues
+ * (GPU_MAX_HW_QUEUES, unless the user set it) so that every lane's stream has a queue of its own.  Only has an effect BEFORE the process's first
+ * HIP call; the library never changes the environment on its own. */
+SVT_AMD_API int svt_amd_runtime_env_defaults(void);
 SVT_AMD_API const char *svt_amd_last_error(void);
 
 /*
@@ -1127,8 +1131,8 @@ SVT_AMD_API int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPict
  *   per transform block  SvtAmdCoeffScanTu (8 B): scan, last sub-block, last position, DC-only fast track (:1308), where its sub-blocks start;
  *   per 4x4 sub-block    SvtAmdCoeffScanGroup (8 B), sub-blocks lastScanSet .. 0 in CODING order (empty ones too: their coded_sub_block_flag is
  *                        coded): significance map in forward scan order, sign bits and |level| > 1 flags of the coded coefficients (CODING
- *                        order = set bits of the map from the highest position down; first coded coefficient in the top bit of `sign`, in bit 0
- *                        of `gt1`), index of its first level;
+ *                        order = set bits of the map from the highest position down; `sign` holds popcount(sigmap) bits right-aligned, the first
+ *                        coded coefficient at bit popcount - 1; the first coded coefficient sits in bit 0 of `gt1`), index of its first level;
  *   per coefficient      its absolute level (u16), non-zero coefficients only, CODING order.
  * The CABAC loop that consumes them codes exactly the reference's bins: integration/svt_coeff_scan_consumer.h.
  * Blocks: slot c of component p = the unit at position c of SvtAmdLcuWork.cu (luma: the unit's size; chroma: half of it, 4x4 for an 8x8
@@ -1144,7 +1148,8 @@ typedef struct SvtAmdCoeffScanTu {
 } SvtAmdCoeffScanTu;
 typedef struct SvtAmdCoeffScanGroup {
     uint16_t sigmap;               /* bit k: the k-th coefficient of the sub-block in forward scan order is non-zero               */
-    uint16_t sign;                 /* signFlags of :1547-1600: one bit per coded coefficient, the first coded one highest          */
+    uint16_t sign;                 /* signFlags of :1547-1600: n = popcount(sigmap) sign bits, RIGHT-aligned: the first coded coefficient  */
+                                   /* at bit n - 1, the last at bit 0 (what EncodeBypassBins(sign, n) writes first / last)                 */
     uint16_t gt1;                  /* bit i: the i-th coded coefficient has |level| > 1                                           */
     uint16_t first_level;          /* index of the sub-block's first level in the LCU's level list                                */
 } SvtAmdCoeffScanGroup;

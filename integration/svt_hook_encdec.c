@@ -134,17 +134,24 @@ static unsigned long g_ep_refs_done, g_ep_refs_skipped;
 static unsigned long g_ep_verified, g_ep_mismatch;
 static unsigned long g_ep_gpu, g_ep_cpu_units, g_ep_cpu_tools, g_ep_cpu_format, g_ep_borders, g_ep_puts, g_ep_inter_units, g_ep_inter_lcus;
 
+static __thread SvtAmdContext *t_lane; /* the lane this thread holds (svt_hook_die gives it back) */
+static void lane_release(SvtAmdContext *lane);
+void svt_hook_encdec_thread_exit(void)
+{
+    if (t_lane)
+        lane_release(t_lane);
+}
 static SvtAmdContext *lane_claim(SvtAmdContext *root)
 {
-    pthread_mutex_lock(&g_ep_lock);
+    svt_hook_lock(&g_ep_lock);
     for (;;) {
         for (int i = 0; i < EP_LANES; i++)
             if (!g_ep_lane_busy[i]) {
                 if (!g_ep_lane[i] && svt_amd_context_fork(root, &g_ep_lane[i]))
                     svt_hook_die("svt_amd_context_fork (encode pass)");
                 g_ep_lane_busy[i] = 1;
-                pthread_mutex_unlock(&g_ep_lock);
-                return g_ep_lane[i];
+                svt_hook_unlock(&g_ep_lock);
+                return t_lane = g_ep_lane[i];
             }
         pthread_cond_wait(&g_ep_cv, &g_ep_lock);
     }
@@ -152,12 +159,13 @@ static SvtAmdContext *lane_claim(SvtAmdContext *root)
 
 static void lane_release(SvtAmdContext *lane)
 {
-    pthread_mutex_lock(&g_ep_lock);
+    t_lane = NULL;
+    svt_hook_lock(&g_ep_lock);
     for (int i = 0; i < EP_LANES; i++)
         if (g_ep_lane[i] == lane)
             g_ep_lane_busy[i] = 0;
     pthread_cond_signal(&g_ep_cv);
-    pthread_mutex_unlock(&g_ep_lock);
+    svt_hook_unlock(&g_ep_lock);
 }
 
 /* everything an entry owns (under g_ep_lock) */
@@ -177,7 +185,7 @@ static void entry_release(SvtAmdContext *lane, EpPictureEntry *e)
 /* the last kernel thread of the encoder has returned (svt_hook_me.c:hook_teardown): picture objects and lanes go */
 void svt_hook_encdec_teardown(void)
 {
-    pthread_mutex_lock(&g_ep_lock);
+    svt_hook_lock(&g_ep_lock);
     SvtAmdContext *any = NULL;
     for (int i = 0; i < EP_LANES && !any; i++)
         any = g_ep_lane[i];
@@ -189,7 +197,7 @@ void svt_hook_encdec_teardown(void)
             svt_amd_context_destroy(g_ep_lane[i]);
         g_ep_lane[i] = NULL, g_ep_lane_busy[i] = 0;
     }
-    pthread_mutex_unlock(&g_ep_lock);
+    svt_hook_unlock(&g_ep_lock);
 }
 
 /* the device picture of this PictureControlSet_t, begun for its current picture */
@@ -201,7 +209,7 @@ static unsigned long g_prep_n;
 static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide, int prepare)
 {
     EpPictureEntry *e = NULL;
-    pthread_mutex_lock(&g_ep_lock);
+    svt_hook_lock(&g_ep_lock);
     for (int i = 0; i < EP_PICTURES && !e; i++)
         if (g_ep_pic[i].pcs == pcs)
             e = &g_ep_pic[i];
@@ -228,7 +236,7 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
         svt_hook_die("encode pass: more PictureControlSet_t objects than EP_PICTURES");
     if (prepare)
         picture_prepare(lane, e, pcs, wide, 1);
-    pthread_mutex_unlock(&g_ep_lock);
+    svt_hook_unlock(&g_ep_lock);
     return e;
 }
 
@@ -398,11 +406,11 @@ void svt_hook_ep_note_sao(const PictureControlSet_t *pcs, EB_U32 x, EB_U32 y, co
     if (!g_ep_refs)
         return;
     EpPictureEntry *e = NULL;
-    pthread_mutex_lock(&g_ep_lock);
+    svt_hook_lock(&g_ep_lock);
     for (int i = 0; i < EP_PICTURES && !e; i++)
         if (g_ep_pic[i].pcs == pcs)
             e = &g_ep_pic[i];
-    pthread_mutex_unlock(&g_ep_lock);
+    svt_hook_unlock(&g_ep_lock);
     if (!e || !e->sao_enable)
         return;
     SvtAmdSaoDecisionParams P;
@@ -417,13 +425,13 @@ void svt_hook_ep_note_sao(const PictureControlSet_t *pcs, EB_U32 x, EB_U32 y, co
     P.is_10bit = (uint8_t)is16, P.mm_sao = mmSao ? 1 : 0, P.temporal_layer = pcs->temporalLayerIndex;
     const SequenceControlSet_t *scs = (const SequenceControlSet_t *)pcs->ParentPcsPtr->sequenceControlSetWrapperPtr->objectPtr;
     const EB_U32 wl = (scs->lumaWidth + 63u) / 64u;
-    pthread_mutex_lock(&e->lock);
+    svt_hook_lock(&e->lock);
     if (!e->sao_any)
         e->sao_P = P, e->sao_any = 1;
     else if (memcmp(&e->sao_P, &P, sizeof(P)))
         e->sao_varies = 1; /* per-LCU lambdas (QP modulation): the picture-level decision call does not cover it */
     e->sao_enable[(y / 64u) * wl + x / 64u] = 1;
-    pthread_mutex_unlock(&e->lock);
+    svt_hook_unlock(&e->lock);
 }
 
 /* the last LCU of a picture is through and every LCU went through the device: finish the picture there (what EncDecKernel does on the host
@@ -471,7 +479,7 @@ static void picture_lcu_done(SvtAmdContext *root, EpPictureEntry *e, const Seque
 {
     if (!g_ep_refs)
         return;
-    pthread_mutex_lock(&e->lock);
+    svt_hook_lock(&e->lock);
     if (served) {
         const size_t wb = e->wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = e->wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
         memcpy((uint8_t *)e->works_all + wb * tbAddr, &t_serve->work, wb);
@@ -479,7 +487,7 @@ static void picture_lcu_done(SvtAmdContext *root, EpPictureEntry *e, const Seque
         e->on_device++;
     }
     const int last = ++e->done == e->cap;
-    pthread_mutex_unlock(&e->lock);
+    svt_hook_unlock(&e->lock);
     if (last) {
         SvtAmdContext *lane = lane_claim(root);
         finish_picture_on_device(lane, e, scs, pcs, mismatch);
@@ -610,7 +618,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         g_ep_state = (getenv("SVT_HOOK_ENCODEPASS") || getenv("SVT_HOOK_MD")) ? 1 : -1;
         g_ep_own = getenv("SVT_HOOK_ENCODEPASS") != NULL;
     }
-    if (g_ep_state < 0 || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
+    if (g_ep_state < 0 || svt_hook_failed() || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
         if (g_ep_state > 0)
             __atomic_add_fetch(&g_ep_cpu_format, 1, __ATOMIC_RELAXED);
         __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
@@ -653,13 +661,13 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         lane_release(lane);
         __atomic_add_fetch(tools ? &g_ep_cpu_tools : &g_ep_cpu_units, 1, __ATOMIC_RELAXED);
         __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
-        pthread_mutex_lock(&e->lock);
+        svt_hook_lock(&e->lock);
         if (e->npending >= e->cap)
             svt_hook_die("encode pass: border list overflow");
         border_from_neighbour_arrays((uint8_t *)e->pending + (size_t)e->npending++ * (wide ? sizeof(SvtAmdLcuBorder16) : sizeof(SvtAmdLcuBorder)), wide,
                                      pcs, contextPtr->encDecTileIndex, lcuOriginX, lcuOriginY, lw, lh);
         __atomic_add_fetch(&g_ep_borders, 1, __ATOMIC_RELAXED);
-        pthread_mutex_unlock(&e->lock);
+        svt_hook_unlock(&e->lock);
         picture_lcu_done(root, e, scs, pcs, tbAddr, 0, contextPtr->allowEncDecMismatch);
         return;
     }
@@ -687,7 +695,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     }
     /* LCUs the host encoded since the last device call enter the device picture first (under the picture's lock, so that a second
      * thread's LCU cannot overtake a put it depends on) */
-    pthread_mutex_lock(&e->lock);
+    svt_hook_lock(&e->lock);
     if (e->npending) {
         if (wide ? svt_amd_encdec_picture_put_borders16(lane, e->pic, (const SvtAmdLcuBorder16 *)e->pending, e->npending)
                  : svt_amd_encdec_picture_put_borders(lane, e->pic, (const SvtAmdLcuBorder *)e->pending, e->npending))
@@ -695,7 +703,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         e->npending = 0;
         __atomic_add_fetch(&g_ep_puts, 1, __ATOMIC_RELAXED);
     }
-    pthread_mutex_unlock(&e->lock);
+    svt_hook_unlock(&e->lock);
     if (wide ? svt_amd_encode_lcus16(lane, e->pic, &t_serve->work16, 1, &t_serve->res16) : svt_amd_encode_lcus(lane, e->pic, w, 1, &t_serve->res))
         svt_hook_die("svt_amd_encode_lcus");
     lane_release(lane);
@@ -870,13 +878,16 @@ static unsigned long g_md_pictures, g_md_inter_pictures, g_md_lcus, g_md_left_pi
 
 /* what ProductFullModeDecision (Codec/EbModeDecision.c:1995-2183) and the loop around it leave in the LCU's coding-unit array, from the
  * device's decision record */
-static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8 qp)
+static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8 qp, ModeDecisionContext_t *md)
 {
     for (int i = 0; i < SVT_AMD_MD_LEAVES; i++) {
         CodingUnit_t *cu = lcuPtr->codedLeafArrayPtr[i];
         cu->splitFlag = o->split[i];
         if (!o->tested[i])
             continue;
+        /* mdEpPipeLcu[].mergeCost / .skipCost (EbModeDecision.c:2043-2044): in a CHROMA_MODE_FULL LCU EncodePass takes its merge / skip decision straight from these
+         * (EbCodingLoop.c:3840-3873; in a CHROMA_MODE_BEST LCU AddChromaEncDec - wrapped above - completes them first) */
+        md->mdEpPipeLcu[i].mergeCost = o->merge_cost[i], md->mdEpPipeLcu[i].skipCost = o->skip_cost[i];
         cu->leafIndex = (EB_U8)i, cu->qp = qp;
         cu->predictionModeFlag = o->pred_mode[i], cu->skipFlag = EB_FALSE, cu->rootCbf = o->ycbf[i] ? EB_TRUE : EB_FALSE;
         PredictionUnit_t *pu = cu->predictionUnitArray;
@@ -993,17 +1004,17 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
         g_md_state = getenv("SVT_HOOK_MD") ? 1 : -1;
         g_md_skip_intra = getenv("SVT_HOOK_MD") && !strcmp(getenv("SVT_HOOK_MD"), "pb"); /* SVT_HOOK_MD=pb: only P / B pictures go to the device */
     }
-    if (g_md_state < 0 || scs->staticConfig.encoderBitDepth != EB_8BIT || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
+    if (g_md_state < 0 || svt_hook_failed() || scs->staticConfig.encoderBitDepth != EB_8BIT || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
     svt_hook_note_callback(scs);
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
     EpPictureEntry *e = picture_entry(lane, scs, pcs, 0, 0);
-    pthread_mutex_lock(&e->lock);
+    svt_hook_lock(&e->lock);
     if (e->md_picture_plus1 != pcs->pictureNumber + 1)
         md_picture(lane, e, scs, pcs, contextPtr);
     const int ok = e->md_ok;
-    pthread_mutex_unlock(&e->lock);
+    svt_hook_unlock(&e->lock);
     lane_release(lane);
     if (!ok)
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
@@ -1048,7 +1059,7 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
         }
         return rc;
     }
-    md_apply(lcuPtr, o, contextPtr->qp);
+    md_apply(lcuPtr, o, contextPtr->qp, contextPtr);
     __atomic_add_fetch(&g_md_lcus, 1, __ATOMIC_RELAXED);
     return EB_ErrorNone;
 }

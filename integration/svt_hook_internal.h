@@ -13,6 +13,14 @@
 /* the root device context (created with the encoder, or here on first use) and the loud exit every binding shares */
 SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight);
 void svt_hook_die(const char *what);
+/* Every mutex a binding takes goes through these two, so that the loud exit knows what the failing thread holds: svt_hook_die unlocks them (and gives the thread's
+ * device lane back, svt_hook_encdec_thread_exit) BEFORE it reports and leaves the thread - the other kernel threads must not block for ever on a lock or a lane whose
+ * owner is gone, or EbDeinitEncoder's pthread_join never returns.  After a failure svt_hook_failed() is non-zero and every binding falls through to the reference code. */
+#include <pthread.h>
+void svt_hook_lock(pthread_mutex_t *m);
+void svt_hook_unlock(pthread_mutex_t *m);
+int svt_hook_failed(void);
+void svt_hook_encdec_thread_exit(void);
 /* the running pipeline's application callback (error reporting): noted by the first bound call that sees the sequence control set */
 struct SequenceControlSet_s;
 void svt_hook_note_callback(const struct SequenceControlSet_s *scs);

@@ -110,19 +110,19 @@ static HookCounters *counters_of_thread(void)
     HookCounters *c = (HookCounters *)calloc(1, sizeof(*c)); /* lives until exit: the report reads it after the thread is gone */
     if (!c)
         abort();
-    pthread_mutex_lock(&g_counters_lock);
+    svt_hook_lock(&g_counters_lock);
     c->next = g_counters, g_counters = c;
-    pthread_mutex_unlock(&g_counters_lock);
+    svt_hook_unlock(&g_counters_lock);
     return t_counters = c;
 }
 #define COUNT_CPU(name) (++(t_counters ? t_counters : counters_of_thread())->v[CPU_##name])
 static unsigned long counter_sum(int i)
 {
     unsigned long n = 0;
-    pthread_mutex_lock(&g_counters_lock);
+    svt_hook_lock(&g_counters_lock);
     for (const HookCounters *c = g_counters; c; c = c->next)
         n += c->v[i];
-    pthread_mutex_unlock(&g_counters_lock);
+    svt_hook_unlock(&g_counters_lock);
     return n;
 }
 static void hook_report(void);
@@ -139,14 +139,48 @@ void svt_hook_note_callback(const SequenceControlSet_t *scs)
     if (!__atomic_load_n(&g_app_cb, __ATOMIC_RELAXED) && scs && scs->encodeContextPtr)
         __atomic_store_n(&g_app_cb, scs->encodeContextPtr->appCallbackPtr, __ATOMIC_RELEASE);
 }
+/* what the calling thread holds (see svt_hook_internal.h) */
+#define HELD_MAX 8
+static __thread pthread_mutex_t *t_held[HELD_MAX];
+static __thread int t_nheld;
+static __thread int t_kernel_thread; /* the thread runs inside kernel_thread() below: counted in g_live_threads */
+void svt_hook_lock(pthread_mutex_t *m)
+{
+    pthread_mutex_lock(m);
+    if (t_nheld < HELD_MAX)
+        t_held[t_nheld++] = m;
+}
+void svt_hook_unlock(pthread_mutex_t *m)
+{
+    for (int i = t_nheld - 1; i >= 0; i--)
+        if (t_held[i] == m) {
+            for (int k = i; k + 1 < t_nheld; k++)
+                t_held[k] = t_held[k + 1];
+            t_nheld--;
+            break;
+        }
+    pthread_mutex_unlock(m);
+}
+static int g_failed, g_reported, g_context_failed; /* reset when the last kernel thread has gone (hook_teardown): the next encoder of the process starts clean */
+int svt_hook_failed(void) { return __atomic_load_n(&g_failed, __ATOMIC_ACQUIRE); }
+static void hook_teardown(void);
+static int g_live_threads;
 static void die(const char *what)
 {
     fprintf(stderr, "svt_hook_me: %s: %s\n", what, svt_amd_last_error());
     EbCallback_t *cb = __atomic_load_n(&g_app_cb, __ATOMIC_ACQUIRE);
     if (cb && cb->ErrorHandler && !getenv("SVT_HOOK_ABORT_ON_ERROR")) {
-        static int reported;
-        if (!__atomic_exchange_n(&reported, 1, __ATOMIC_ACQ_REL)) /* one error packet; every failing thread stops */
+        __atomic_store_n(&g_failed, 1, __ATOMIC_RELEASE); /* from here on every binding hands its call to the reference code */
+        while (t_nheld > 0) /* nothing this thread holds may outlive it: locks (innermost first) ... */
+            pthread_mutex_unlock(t_held[--t_nheld]);
+        svt_hook_encdec_thread_exit(); /* ... and its device lane */
+        if (!__atomic_exchange_n(&g_reported, 1, __ATOMIC_ACQ_REL)) /* one error packet; every failing thread stops */
             cb->ErrorHandler(cb->handle, EB_ENC_ME_ERROR1 + 0x80); /* no message of the application's table: it prints "Error: Others!" */
+        if (t_kernel_thread) { /* the thread leaves without returning through kernel_thread(): its count goes here */
+            t_kernel_thread = 0;
+            if (__atomic_sub_fetch(&g_live_threads, 1, __ATOMIC_ACQ_REL) == 0)
+                hook_teardown();
+        }
         pthread_exit(NULL); /* the reference spins in `while(1);` after the handler (and EbDeinitEncoder then never joins that thread); leaving
                              * the thread instead lets the application shut the encoder down after it has seen the error packet */
     }
@@ -155,9 +189,9 @@ static void die(const char *what)
 void svt_hook_die(const char *what) { die(what); }
 SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight)
 {
-    pthread_mutex_lock(&g_front_lock);
+    svt_hook_lock(&g_front_lock);
     const int rc = ensure_context(lumaWidth, lumaHeight);
-    pthread_mutex_unlock(&g_front_lock);
+    svt_hook_unlock(&g_front_lock);
     if (rc)
         die("device start-up");
     return g_ctx;
@@ -262,9 +296,9 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
         return e; /* this thread already waited for it */
     SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
     svt_hook_note_callback(scs);
-    pthread_mutex_lock(&g_front_lock);
+    svt_hook_lock(&g_front_lock);
     if (ensure_context(scs->lumaWidth, scs->lumaHeight)) {
-        pthread_mutex_unlock(&g_front_lock);
+        svt_hook_unlock(&g_front_lock);
         die("device start-up");
     }
     g_nlcu = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
@@ -335,7 +369,7 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
             g_t_lane_wait += now_s() - tw, g_n_lane_wait++;
         }
     }
-    pthread_mutex_unlock(&g_front_lock);
+    svt_hook_unlock(&g_front_lock);
     /* outside the lock: wait for this lane's completion event (idempotent; any number of threads may wait) */
     const SvtAmdMeLcuResult *me;
     const SvtAmdOisLcuResult *ois;
@@ -343,11 +377,11 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
         die("svt_amd_frontend_wait");
     e->me = (const SvtAmdMeCuResult *)me, e->ois = (const uint8_t *)ois;
     if (!__atomic_exchange_n(&e->timed, 1, __ATOMIC_ACQ_REL)) { /* first thread back: submit -> results on the host */
-        pthread_mutex_lock(&g_front_lock);
+        svt_hook_lock(&g_front_lock);
         g_t_device += now_s() - e->t_submit, g_n_timed++;
         if (e->pic < TL_N)
             g_tl_ready[e->pic] = now_s() - g_tl0;
-        pthread_mutex_unlock(&g_front_lock);
+        svt_hook_unlock(&g_front_lock);
     }
     cached = e;
     cached_gen = e->gen;
@@ -360,21 +394,24 @@ static void front_served(FrontEntry *e, unsigned *counter)
         return;
     if (__atomic_load_n(&e->me_left, __ATOMIC_ACQUIRE) || __atomic_load_n(&e->ois_left, __ATOMIC_ACQUIRE))
         return;
-    pthread_mutex_lock(&g_front_lock);
+    svt_hook_lock(&g_front_lock);
     g_t_lane_held += now_s() - e->t_submit;
     if (e->pic < TL_N)
         g_tl_released[e->pic] = now_s() - g_tl0;
     svt_amd_frontend_release(e->lane);
     __atomic_store_n(&e->state, 0, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_front_cv);
-    pthread_mutex_unlock(&g_front_lock);
+    svt_hook_unlock(&g_front_lock);
 }
 
+EB_ERRORTYPE __real_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX, EB_U32 lcuOriginY, MeContext_t *ctx,
+                                      EbPictureBufferDesc_t *inputPtr);
+EB_ERRORTYPE __real_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr);
 EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX,
                                       EB_U32 lcuOriginY, MeContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
 {
-    (void)lcuOriginX;
-    (void)lcuOriginY;
+    if (svt_hook_failed()) /* a binding has reported a device failure: the pipeline drains on the reference's own code */
+        return __real_MotionEstimateLcu(pcs, lcuIndex, lcuOriginX, lcuOriginY, ctx, inputPtr);
     SequenceControlSet_t *scs = (SequenceControlSet_t *)pcs->sequenceControlSetWrapperPtr->objectPtr;
     FrontEntry *e = front_entry(pcs, ctx, inputPtr);
     const SvtAmdMeCuResult *r = &e->me[(size_t)lcuIndex * SVT_AMD_ME_PU_COUNT];
@@ -407,13 +444,14 @@ static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
 {
     if (g_ctx)
         return 0;
-    static int failed;
-    if (failed)
+    if (g_context_failed)
         return 1;
     const char *dev = getenv("SVT_AMD_DEVICE");
     const uint16_t mh = (uint16_t)((lumaHeight + 7) & ~7);
     SvtAmdContext *ctx = NULL;
     const char *step = "svt_amd_context_create";
+    if (!getenv("SVT_HOOK_KEEP_RUNTIME_ENV")) /* the encoder keeps up to NLANES + EP_LANES streams busy: a hardware queue each (the library's opt-in) */
+        (void)svt_amd_runtime_env_defaults();
     int rc = svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &ctx);
     for (int i = 0; i < NLANES && !rc; i++)
         step = "svt_amd_context_fork", rc = svt_amd_context_fork(ctx, &g_front[i].lane);
@@ -430,7 +468,7 @@ static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
                 svt_amd_context_destroy(g_front[i].lane), g_front[i].lane = NULL;
         if (ctx)
             svt_amd_context_destroy(ctx);
-        failed = 1;
+        g_context_failed = 1;
         return 1;
     }
     g_ctx = ctx;
@@ -450,9 +488,9 @@ EB_ERRORTYPE __wrap_EbPaReferenceObjectCreator(EB_PTR *objectDblPtr, EB_PTR obje
 {
     const EbPaReferenceObjectDescInitData_t *d = (const EbPaReferenceObjectDescInitData_t *)objectInitDataPtr;
     if (d && !getenv("SVT_HOOK_LAZY_INIT")) {
-        pthread_mutex_lock(&g_front_lock);
+        svt_hook_lock(&g_front_lock);
         const int rc = ensure_context(d->referencePictureDescInitData.maxWidth, d->referencePictureDescInitData.maxHeight);
-        pthread_mutex_unlock(&g_front_lock);
+        svt_hook_unlock(&g_front_lock);
         if (rc) /* no usable MI355X: EbInitEncoder fails like any other resource the encoder cannot get (EbEncHandle.c EB_NEW chain) */
             return EB_ErrorInsufficientResources;
     }
@@ -467,6 +505,8 @@ EB_ERRORTYPE __wrap_EbPaReferenceObjectCreator(EB_PTR *objectDblPtr, EB_PTR obje
 EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex,
                                            MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr)
 {
+    if (svt_hook_failed())
+        return __real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
     FrontEntry *e = front_entry(pcs, NULL, inputPtr);
     if (e->oisp.ois_kernel_level != ctx->oisKernelLevel || e->oisp.ois_th_set != ctx->oisThSet ||
         e->oisp.set_best_ois_distortion_to_valid != ctx->setBestOisDistortionToValid) {
@@ -526,9 +566,9 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     if (g_fl_state < 0 || !g_ctx || (contextPtr->rdoqPmCoreMethod && contextPtr->rdoqPmCoreMethod != EB_PMCORE) ||
         contextPtr->spatialSseFullLoop || contextPtr->pfMdMode > 1) {
         if (g_fl_state > 0) {
-            pthread_mutex_lock(&g_lock);
+            svt_hook_lock(&g_lock);
             g_fl_cpu++;
-            pthread_mutex_unlock(&g_lock);
+            svt_hook_unlock(&g_lock);
         }
         __real_ProductFullLoop(inputPicturePtr, inputOriginIndex, candidateBuffer, contextPtr, cuStatsPtr, pcs, qp,
                                yCountNonZeroCoeffs, yCoeffBits, yFullDistortion);
@@ -548,7 +588,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
     in.ycbf = c->yCbf, in.coeff_bits = *yCoeffBits, in.dist[0] = yFullDistortion[0], in.dist[1] = yFullDistortion[1];
     int16_t *q = (int16_t *)candidateBuffer->residualQuantCoeffPtr->bufferY + origin; /* residual in, quantised out */
     int16_t *r = (int16_t *)candidateBuffer->reconCoeffPtr->bufferY + origin;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     /* coeffCabacUpdate (full-depth pictures, EbEncDecProcess.c:2115): the candidate's context model goes with the call and comes
      * back updated (EbFullLoop.c:265-280; the mode decision copies it from / to latestValidCoeffCtxModel around the loop) */
     if (contextPtr->coeffCabacUpdate
@@ -562,7 +602,7 @@ void __wrap_ProductFullLoop(EbPictureBufferDesc_t *inputPicturePtr, EB_U32 input
         fprintf(stderr, "svt_hook_me: luma full loop (ProductFullLoop) on the GPU\n");
     if (g_verbose && (g_fl_gpu % 2000) == 0)
         fprintf(stderr, "svt_hook_me: %lu full-loop candidates on the GPU, %lu on the CPU\n", g_fl_gpu, g_fl_cpu);
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     if (size == 64)
         for (int k = 1; k < 5; k++)
             yCountNonZeroCoeffs[k] = out.nz[k];
@@ -611,9 +651,9 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
         componentMask != PICTURE_BUFFER_DESC_CHROMA_MASK ||
         candidateBuffer->residualQuantCoeffPtr->strideCb != 32 || candidateBuffer->reconCoeffPtr->strideCb != 32) {
         if (g_fl_state > 0) {
-            pthread_mutex_lock(&g_lock);
+            svt_hook_lock(&g_lock);
             g_cl_cpu++;
-            pthread_mutex_unlock(&g_lock);
+            svt_hook_unlock(&g_lock);
         }
         __real_FullLoop_R(lcuPtr, candidateBuffer, contextPtr, cuStatsPtr, inputPicturePtr, pcs, componentMask, cbQp, crQp,
                           cbCountNonZeroCoeffs, crCountNonZeroCoeffs);
@@ -630,7 +670,7 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
                      (int16_t *)candidateBuffer->residualQuantCoeffPtr->bufferCr + origin}; /* residual in, quantised out */
     int16_t *r[2] = {(int16_t *)candidateBuffer->reconCoeffPtr->bufferCb + origin,
                      (int16_t *)candidateBuffer->reconCoeffPtr->bufferCr + origin};
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     /* coeffCabacUpdate: the model is moved by the rate estimation of the SECOND reference call (TuEstimateCoeffBits_R inside
      * CuFullDistortionFastTuMode_R); nothing touches it between the two, so updating it here is equivalent */
     if (contextPtr->coeffCabacUpdate
@@ -645,7 +685,7 @@ void __wrap_FullLoop_R(LargestCodingUnit_t *lcuPtr, ModeDecisionCandidateBuffer_
         fprintf(stderr, "svt_hook_me: chroma full loop (FullLoop_R + CuFullDistortionFastTuMode_R) on the GPU\n");
     if (g_verbose && (g_cl_gpu % 2000) == 0)
         fprintf(stderr, "svt_hook_me: %lu chroma full-loop candidates on the GPU, %lu on the CPU\n", g_cl_gpu, g_cl_cpu);
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     for (int k = (size == 64 ? 1 : 0); k < (size == 64 ? 5 : 1); k++)
         cbCountNonZeroCoeffs[k] = t_chroma_out.nz[0][k], crCountNonZeroCoeffs[k] = t_chroma_out.nz[1][k];
     t_chroma_for = candidateBuffer;
@@ -726,13 +766,13 @@ static void recon_on_device(int is16, EncDecContext_t *ctx, EB_U32 originX, EB_U
             off = ((predSamples->originX + originX) >> 1) + (((predSamples->originY + originY) >> 1) * stride);
             scratchOff = ((originX & 63) >> 1) + (((originY & 63) >> 1) * 32), cstride = 32;
         }
-        pthread_mutex_lock(&g_lock);
+        svt_hook_lock(&g_lock);
         if (svt_amd_recon_tu(g_ctx, bps, (int)n, only_dc, dst, cplane + scratchOff, cstride, plane + (size_t)off * bps, stride,
                              plane + (size_t)off * bps, stride))
             die("svt_amd_recon_tu");
         if (g_recon_gpu++ == 0 && g_verbose)
             fprintf(stderr, "svt_hook_me: transform-unit reconstruction (EncodeGenerateRecon) on the GPU\n");
-        pthread_mutex_unlock(&g_lock);
+        svt_hook_unlock(&g_lock);
     }
 }
 static void recon8(EncDecContext_t *a, EB_U32 b, EB_U32 c, EB_U32 d, EB_COLOR_FORMAT e, EB_BOOL f, EB_U32 g, EbPictureBufferDesc_t *h,
@@ -903,7 +943,7 @@ static EB_ERRORTYPE intra_pred(int is16, void *ref, EB_U32 originX, EB_U32 origi
             const size_t bps4 = is16 ? 2 : 1;
             SvtAmdIntraPuJob *j4 = &t_intra4_job[c];
             j4->luma_mode = (uint8_t)lumaMode, j4->chroma_mode = (uint8_t)chromaMode;
-            pthread_mutex_lock(&g_lock);
+            svt_hook_lock(&g_lock);
             int rc4;
             if (!c)
                 rc4 = svt_amd_intra_pu(g_ctx, (int)bps4, j4, pic->bufferY + ((size_t)originY * pic->strideY + originX) * bps4, pic->strideY, NULL,
@@ -916,7 +956,7 @@ static EB_ERRORTYPE intra_pred(int is16, void *ref, EB_U32 originX, EB_U32 origi
                 die("svt_amd_intra_pu (intra 4x4)");
             if (g_intra4_gpu++ == 0 && g_verbose)
                 fprintf(stderr, "svt_hook_me: encode-pass intra 4x4 prediction on the GPU\n");
-            pthread_mutex_unlock(&g_lock);
+            svt_hook_unlock(&g_lock);
             return EB_ErrorNone;
         }
     }
@@ -926,14 +966,14 @@ static EB_ERRORTYPE intra_pred(int is16, void *ref, EB_U32 originX, EB_U32 origi
         return g_intra_pred[is16](ref, originX, originY, puSize, puChromaSize, pic, cf, second, lumaMode, chromaMode, mask);
     const size_t bps = is16 ? 2 : 1;
     t_intra_job.luma_mode = (uint8_t)lumaMode, t_intra_job.chroma_mode = (uint8_t)chromaMode;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     if (svt_amd_intra_pu(g_ctx, (int)bps, &t_intra_job, pic->bufferY + ((size_t)originY * pic->strideY + originX) * bps, pic->strideY,
                          pic->bufferCb + ((size_t)(originY >> 1) * pic->strideCb + (originX >> 1)) * bps,
                          pic->bufferCr + ((size_t)(originY >> 1) * pic->strideCr + (originX >> 1)) * bps, pic->strideCb))
         die("svt_amd_intra_pu");
     if (g_intra_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: encode-pass intra prediction (reference samples + prediction) on the GPU\n");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     return EB_ErrorNone;
 }
 
@@ -1032,12 +1072,12 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
             GenerateIntraLumaReferenceSamplesMd(md, in);
         md_intra_job(&j, md, 0);
         j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
-        pthread_mutex_lock(&g_lock);
+        svt_hook_lock(&g_lock);
         if (svt_amd_intra_pu(g_ctx, 1, &j, pred->bufferY + (md->cuOriginY & 63) * 64 + (md->cuOriginX & 63), pred->strideY, NULL, NULL, 0))
             die("svt_amd_intra_pu (mode decision, luma)");
         if (g_md_intra_gpu++ == 0 && g_verbose)
             fprintf(stderr, "svt_hook_me: mode-decision intra prediction (IntraPredictionCl) on the GPU\n");
-        pthread_mutex_unlock(&g_lock);
+        svt_hook_unlock(&g_lock);
     }
     if (chromaAsked) {
         if (md->chromaIntraRefSamplesGenDone == EB_FALSE)
@@ -1045,11 +1085,11 @@ EB_ERRORTYPE __wrap_IntraPredictionCl(ModeDecisionContext_t *md, EB_U32 componen
         md_intra_job(&j, md, 1);
         j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
         const uint32_t o = (((md->cuOriginY & 63) * 32) + (md->cuOriginX & 63)) >> 1;
-        pthread_mutex_lock(&g_lock);
+        svt_hook_lock(&g_lock);
         if (svt_amd_intra_pu(g_ctx, 1, &j, NULL, 0, pred->bufferCb + o, pred->bufferCr + o, pred->strideCb))
             die("svt_amd_intra_pu (mode decision, chroma)");
         g_md_intra_gpu++;
-        pthread_mutex_unlock(&g_lock);
+        svt_hook_unlock(&g_lock);
     }
     return EB_ErrorNone;
 }
@@ -1105,12 +1145,12 @@ EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componen
             GenerateIntraLumaReferenceSamplesMd(md, in);
         ol_slices(j.left[0], j.top[0], &j.tl[0], in->bufferY + (size_t)in->originY * in->strideY + in->originX, in->strideY, ox, oy, size,
                   in->width, in->height, picLeft, picTop);
-        pthread_mutex_lock(&g_lock);
+        svt_hook_lock(&g_lock);
         if (svt_amd_intra_pu(g_ctx, 1, &j, pred->bufferY + (oy & 63) * 64 + (ox & 63), pred->strideY, NULL, NULL, 0))
             die("svt_amd_intra_pu (mode decision, open loop, luma)");
         if (g_md_intra_ol_gpu++ == 0 && g_verbose)
             fprintf(stderr, "svt_hook_me: open-loop mode-decision intra prediction (IntraPredictionOl) on the GPU\n");
-        pthread_mutex_unlock(&g_lock);
+        svt_hook_unlock(&g_lock);
     }
     if (chromaAsked) {
         if (md->chromaIntraRefSamplesGenDone == EB_FALSE)
@@ -1120,11 +1160,11 @@ EB_ERRORTYPE __wrap_IntraPredictionOl(ModeDecisionContext_t *md, EB_U32 componen
         ol_slices(j.left[2], j.top[2], &j.tl[2], in->bufferCr + (size_t)(in->originY >> 1) * in->strideCr + (in->originX >> 1), in->strideCr,
                   ox >> 1, oy >> 1, size >> 1, in->width >> 1, in->height >> 1, picLeft, picTop);
         const uint32_t o = (((oy & 63) * 32) + (ox & 63)) >> 1;
-        pthread_mutex_lock(&g_lock);
+        svt_hook_lock(&g_lock);
         if (svt_amd_intra_pu(g_ctx, 1, &j, NULL, 0, pred->bufferCb + o, pred->bufferCr + o, pred->strideCb))
             die("svt_amd_intra_pu (mode decision, open loop, chroma)");
         g_md_intra_ol_gpu++;
-        pthread_mutex_unlock(&g_lock);
+        svt_hook_unlock(&g_lock);
     }
     return EB_ErrorNone;
 }
@@ -1156,7 +1196,7 @@ EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, 
     SvtAmdIntraPuJob j;
     intra_slices(&j, 1, EB_FALSE, EB_TRUE, puOriginX, puOriginY, 4, 64, 3 + 1, md->modeTypeNeighborArray, na, 0, 1, EB_FALSE, EB_FALSE, EB_FALSE);
     j.luma_mode = (uint8_t)lumaMode, j.chroma_mode = 4;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     if (svt_amd_intra_pu(g_ctx, 1, &j, pred->bufferY + ((puOriginY & 63) * pred->strideY) + (puOriginX & 63), pred->strideY, NULL, NULL, 0))
         die("svt_amd_intra_pu (mode decision, 4x4 luma)");
     if (chromaAsked) {
@@ -1169,7 +1209,7 @@ EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, 
     }
     if (g_md_intra4_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: mode-decision intra 4x4 search prediction (Intra4x4IntraPredictionCl) on the GPU\n");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     return EB_ErrorNone;
 }
 
@@ -1269,7 +1309,7 @@ void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t
 {
     if (dev->strideY != p->strideY || dev->strideC != p->strideCb || dev->originX != p->originX || dev->originY != p->originY)
         return; /* another padding geometry: the upload path serves it */
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     struct RefSlot *victim = &g_refs[0];
     for (int i = 0; i < REF_CACHE; i++) {
         if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
@@ -1298,7 +1338,7 @@ void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t
     victim->pic.strideY = p->strideY, victim->pic.strideC = p->strideCb, victim->pic.originX = p->originX, victim->pic.originY = p->originY;
     victim->pic.width = p->width, victim->pic.height = p->height;
     g_ref_from_device++;
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
 }
 void svt_hook_reference_report(FILE *out)
 {
@@ -1310,7 +1350,7 @@ void svt_hook_reference_report(FILE *out)
 /* for the device-resident encode pass (svt_hook_encdec.c): the reference pictures of both lists as device copies */
 void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2])
 {
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     for (int l = 0; l < 2; l++) {
         have[l] = l == 0 ? pcs->sliceType != EB_I_PICTURE : pcs->sliceType == EB_B_PICTURE;
         if (!have[l])
@@ -1318,7 +1358,7 @@ void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtA
         const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
         out[l] = *resident_reference_bps(wide ? ro->referencePicture16bit : ro->referencePicture, ro->refPOC, wide ? 2 : 1);
     }
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
 }
 
 EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
@@ -1337,7 +1377,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
     SvtAmdInterPuJob job;
     memset(&job, 0, sizeof(job));
     job.pu_x = puOriginX, job.pu_y = puOriginY, job.pu_w = puWidth, job.pu_h = puHeight, job.pred_dir = mvUnit->predDirection;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     const SvtAmdRefPicture *refs[2] = {NULL, NULL};
     SvtAmdRefPicture copy[2];
     for (int l = 0; l < 2; l++) {
@@ -1362,7 +1402,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
         die("svt_amd_device_download");
     if (g_inter_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU\n");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     const uint32_t oy = (predictionPtr->originY + puOriginY) * predictionPtr->strideY + predictionPtr->originX + puOriginX;
     const uint32_t oc = (((predictionPtr->originY + puOriginY) * predictionPtr->strideCb) >> 1) + ((predictionPtr->originX + puOriginX) >> 1);
     for (uint32_t y = 0; y < puHeight; y++)
@@ -1398,7 +1438,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
     SvtAmdInterPuJob job;
     memset(&job, 0, sizeof(job));
     job.pu_x = puOriginX, job.pu_y = puOriginY, job.pu_w = puWidth, job.pu_h = puHeight, job.pred_dir = mvUnit->predDirection;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     const SvtAmdRefPicture *refs[2] = {NULL, NULL};
     SvtAmdRefPicture copy[2];
     for (int l = 0; l < 2; l++) {
@@ -1423,7 +1463,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
         die("svt_amd_device_download");
     if (g_inter16_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction16bit) on the GPU\n");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     const uint32_t oy = (predictionPtr->originY + puOriginY) * predictionPtr->strideY + predictionPtr->originX + puOriginX;
     const uint32_t oc = (((predictionPtr->originY + puOriginY) * predictionPtr->strideCb) >> 1) + ((predictionPtr->originX + puOriginX) >> 1);
     uint16_t *py = (uint16_t *)predictionPtr->bufferY, *pcb = (uint16_t *)predictionPtr->bufferCb, *pcr = (uint16_t *)predictionPtr->bufferCr;
@@ -1466,7 +1506,7 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
     job.pu_x = (uint16_t)mdContextPtr->cuOriginX, job.pu_y = (uint16_t)mdContextPtr->cuOriginY, job.pu_w = job.pu_h = (uint8_t)size;
     job.pred_dir = (uint8_t)dir;
     job.mv[0][0] = c->motionVector_x_L0, job.mv[0][1] = c->motionVector_y_L0, job.mv[1][0] = c->motionVector_x_L1, job.mv[1][1] = c->motionVector_y_L1;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     const SvtAmdRefPicture *refs[2] = {NULL, NULL};
     SvtAmdRefPicture copy[2];
     for (int l = 0; l < 2; l++)
@@ -1489,7 +1529,7 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
         die("svt_amd_device_download");
     if (g_md_inter_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU\n");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     const uint32_t oy = ((mdContextPtr->cuOriginY & 63) * 64) + (mdContextPtr->cuOriginX & 63);
     const uint32_t oc = ((((mdContextPtr->cuOriginY & 63) * 32) + (mdContextPtr->cuOriginX & 63)) >> 1);
     if (componentMask & PICTURE_BUFFER_DESC_LUMA_MASK)
@@ -1541,12 +1581,12 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
         pu.size = (uint8_t)areaSize, pu.qp = (uint8_t)qp, pu.bit_depth = (uint8_t)bitDepth, pu.slice_type = (uint8_t)sliceType;
         pu.component = (uint8_t)componentType, pu.cand_type = (uint8_t)type, pu.lambda = (uint32_t)lambda;
         uint32_t pnz = 0;
-        pthread_mutex_lock(&g_lock);
+        svt_hook_lock(&g_lock);
         if (svt_amd_pmcore_quantize(g_ctx, (const SvtAmdCabacCost *)CabacCost, &pu, coeff, coeffStride, quantCoeff, reconCoeff, &pnz))
             die("svt_amd_pmcore_quantize");
         if (g_quant_pm_gpu++ == 0 && g_verbose)
             fprintf(stderr, "svt_hook_me: encode-pass PM-core quantiser (UnifiedQuantizeInvQuantize, EB_PMCORE) on the GPU\n");
-        pthread_mutex_unlock(&g_lock);
+        svt_hook_unlock(&g_lock);
         *yCountNonZeroCoeffs = pnz;
         return;
     }
@@ -1564,13 +1604,13 @@ void __wrap_UnifiedQuantizeInvQuantize(EncDecContext_t *contextPtr, PictureContr
     u.shape = transCoeffShape, u.clean_sparse = cleanSparseCeoffPfEncDec, u.enable_cb_flag = (uint8_t)enableCbflag;
     u.contouring_flag = enableContouringQCUpdateFlag, u.component = (uint8_t)componentType, u.temporal_layer = (uint8_t)temporalLayerIndex;
     u.dz_offset = dZoffset;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     uint32_t nz = 0;
     if (svt_amd_unified_quantize(g_ctx, &u, coeff, coeffStride, quantCoeff, reconCoeff, &nz))
         die("svt_amd_unified_quantize");
     if (g_quant_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: encode-pass quantiser (UnifiedQuantizeInvQuantize) on the GPU\n");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     *yCountNonZeroCoeffs = nz;
 }
 
@@ -1620,7 +1660,7 @@ static void sao_on_device(int is16, void *const in[3], const uint32_t inStride[3
     for (int k = 0; k < 8; k++)
         P.offset_bits[k] = md->saoOffsetTrunUnaryBits[k];
     P.is_10bit = (uint8_t)is16, P.mm_sao = mmSao ? 1 : 0, P.temporal_layer = pcs->temporalLayerIndex;
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_lock);
     const int ncomp = mmSao ? 3 : (pcs->temporalLayerIndex < 2 ? 1 : 0);
     for (int c = 0; c < ncomp; c++) {
         const uint32_t w = c ? lcuWidth >> 1 : lcuWidth, h = c ? lcuHeight >> 1 : lcuHeight;
@@ -1652,7 +1692,7 @@ static void sao_on_device(int is16, void *const in[3], const uint32_t inStride[3
         die("svt_amd_sao_decide_lcu");
     if (g_sao_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: SAO statistics + decision (SaoGenerationDecision%s) on the GPU\n", is16 ? "16bit" : "");
-    pthread_mutex_unlock(&g_lock);
+    svt_hook_unlock(&g_lock);
     saoPtr->saoMergeLeftFlag = out.merge_left, saoPtr->saoMergeUpFlag = out.merge_up;
     saoPtr->saoTypeIndex[0] = out.type[0], saoPtr->saoTypeIndex[1] = out.type[1];
     memcpy(saoPtr->saoOffset, out.offset, sizeof(out.offset));
@@ -1729,12 +1769,11 @@ EB_ERRORTYPE __wrap_SaoGenerationDecision16bit(EbPictureBufferDesc_t *inputLcuPt
 void *__real_MotionEstimationKernel(void *inputPtr);
 void *__real_EncDecKernel(void *inputPtr);
 void svt_hook_encdec_teardown(void);
-static int g_live_threads;
 static void hook_teardown(void)
 {
     svt_hook_encdec_teardown();
-    pthread_mutex_lock(&g_front_lock);
-    pthread_mutex_lock(&g_lock);
+    svt_hook_lock(&g_front_lock);
+    svt_hook_lock(&g_lock);
     if (g_ctx) {
         svt_amd_synchronize(g_ctx);
         for (int i = 0; i < REF_CACHE; i++) {
@@ -1759,13 +1798,17 @@ static void hook_teardown(void)
         memset(g_slot_pic, 0, sizeof(g_slot_pic));
     }
     __atomic_store_n(&g_app_cb, NULL, __ATOMIC_RELEASE);
-    pthread_mutex_unlock(&g_lock);
-    pthread_mutex_unlock(&g_front_lock);
+    g_context_failed = 0;
+    __atomic_store_n(&g_reported, 0, __ATOMIC_RELEASE), __atomic_store_n(&g_failed, 0, __ATOMIC_RELEASE);
+    svt_hook_unlock(&g_lock);
+    svt_hook_unlock(&g_front_lock);
 }
 static void *kernel_thread(void *(*real)(void *), void *arg)
 {
     __atomic_add_fetch(&g_live_threads, 1, __ATOMIC_ACQ_REL);
+    t_kernel_thread = 1;
     void *r = real(arg);
+    t_kernel_thread = 0;
     if (__atomic_sub_fetch(&g_live_threads, 1, __ATOMIC_ACQ_REL) == 0)
         hook_teardown();
     return r;

@@ -78,6 +78,10 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
             (void)hipHostFree(s->h_staging);
         if (s->ev_ready)
             (void)hipEventDestroy(s->ev_ready);
+        if (s->ev_me)
+            (void)hipEventDestroy(s->ev_me);
+        if (s->ev_ois)
+            (void)hipEventDestroy(s->ev_ois);
     }
     if (!ctx->parent)
         free(ctx->slots);
@@ -160,10 +164,11 @@ int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out)
 
 /* Lanes are streams, and streams only run side by side when each has a hardware queue of its own: with the HIP runtime's default
  * of four, a fifth stream shares a queue and its markers serialise with whatever that queue holds (a result copy of one lane then
- * waits for another lane's kernels and vice versa; measured in bench.py, 1,680 -> 2,450 pictures/s).  The variable is read when the
- * runtime starts, so it is set when this library is loaded - a C host (the encoder) loads it before any HIP call; a user's own
- * setting wins. */
-__attribute__((constructor)) static void svt_amd_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+ * waits for another lane's kernels and vice versa; measured in bench.py, 1,680 -> 2,450 pictures/s).  The runtime reads the variable when it
+ * starts, i.e. at the process's first HIP call - so this is a call the HOST makes, knowingly, before that (the encoder binding does, at
+ * EbInitEncoder time: integration/svt_hook_me.c).  The library itself never touches the environment of the process that
+ * loaded it; a setting the user made wins. */
+extern "C" int svt_amd_runtime_env_defaults(void) { return setenv("GPU_MAX_HW_QUEUES", "24", 0) == 0 ? SVT_AMD_OK : SVT_AMD_ERR_RESOURCES; }
 
 /* Job descriptors of a launch (a few KB) go host -> device through a pinned ring the GPU reads itself: a copy kernel on the
  * lane's stream, in order with the launch that consumes them.  A hipMemcpyAsync would put them on a copy engine's queue, where they
@@ -274,7 +279,8 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
             break;
         }
         s->staging_bytes = (size_t)w * h;
-        if (hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_me, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_ois, hipEventDisableTiming) != hipSuccess) {
             svt_amd_set_error("hipEventCreate (slot %d) failed", i);
             rc = SVT_AMD_ERR_DEVICE;
             break;
@@ -604,6 +610,22 @@ static int validate_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, int cur_slot
     return SVT_AMD_OK;
 }
 
+/* the slot's motion-estimation / open-loop intra search records are (being) written by kernels on this lane's stream: consumers on other lanes order themselves behind */
+static int me_records_written(SvtAmdContext *ctx, int slot, const SvtAmdMeParams *p)
+{
+    DevPicture *s = &ctx->slots[slot];
+    s->me_lcus = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
+    HIP_TRY(hipEventRecord(s->ev_me, ctx->stream));
+    return SVT_AMD_OK;
+}
+static int ois_records_written(SvtAmdContext *ctx, int slot, const SvtAmdOisParams *p)
+{
+    DevPicture *s = &ctx->slots[slot];
+    s->ois_lcus = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
+    HIP_TRY(hipEventRecord(s->ev_ois, ctx->stream));
+    return SVT_AMD_OK;
+}
+
 static int make_job(SvtAmdContext *ctx, const SvtAmdMeParams *params, int cur_slot, const int ref_slot[2],
                     uint32_t lcu_begin, uint32_t lcu_end, MeJobDev *job)
 {
@@ -638,7 +660,10 @@ extern "C" int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmdM
     if (rc)
         return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    return svt_amd_launch_me_batch(ctx, &job, 1, job.lcu_count);
+    rc = svt_amd_launch_me_batch(ctx, &job, 1, job.lcu_count);
+    if (rc == SVT_AMD_OK)
+        rc = me_records_written(ctx, cur_slot, params);
+    return rc;
 }
 
 extern "C" int svt_amd_me_batch_launch(SvtAmdContext *ctx, const SvtAmdMeJob *jobs, int num_jobs)
@@ -664,6 +689,8 @@ extern "C" int svt_amd_me_batch_launch(SvtAmdContext *ctx, const SvtAmdMeJob *jo
             for (int i = 0; i < num_jobs; i++)
                 dj[i].dbg_clock = ctx->d_dbg;
         rc = e == hipSuccess ? svt_amd_launch_me_batch(ctx, dj, num_jobs, max_lcus) : SVT_AMD_ERR_DEVICE;
+        for (int i = 0; i < num_jobs && rc == SVT_AMD_OK; i++)
+            rc = me_records_written(ctx, jobs[i].cur_slot, &jobs[i].params);
     }
     free(dj);
     return rc;
@@ -946,6 +973,8 @@ static int ois_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur
         return rc;
     rc = svt_amd_launch_ois_batch(ctx, &j, 1, j.nlcu);
     const int rc2 = svt_amd_stamp_end(ctx);
+    if (!rc && !rc2)
+        return ois_records_written(ctx, cur_slot, params);
     return rc ? rc : rc2;
 }
 
@@ -968,6 +997,8 @@ extern "C" int svt_amd_ois_batch_launch(SvtAmdContext *ctx, const SvtAmdOisJob *
         return rc;
     rc = svt_amd_launch_ois_batch(ctx, host, num_jobs, max_lcus);
     const int rc2 = svt_amd_stamp_end(ctx);
+    for (int i = 0; i < num_jobs && !rc && !rc2; i++)
+        rc = ois_records_written(ctx, jobs[i].cur_slot, &jobs[i].params);
     return rc ? rc : rc2;
 }
 

@@ -1576,23 +1576,41 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
             return SVT_AMD_ERR_BAD_PARAM;
         }
     }
+    hipEvent_t ev_wait[2] = {nullptr, nullptr}; /* records read where another lane's kernels leave them: this lane's stream orders itself behind those kernels */
     const SvtAmdMeLcuResult *d_me_slot = nullptr;
     if (X && !me) {
         SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
-        if (me_slot < 0 || me_slot >= root->num_slots || !root->slots[me_slot].d_me_out) {
-            svt_amd_set_error("svt_amd_md_encode_picture_inter: no motion-estimation records in slot %d", me_slot);
+        if (me_slot < 0 || me_slot >= root->num_slots || !root->slots[me_slot].d_me_out || !root->slots[me_slot].valid || root->slots[me_slot].me_lcus != (uint32_t)n ||
+            root->slots[me_slot].width != pic->d.width || root->slots[me_slot].height != pic->d.height) {
+            svt_amd_set_error("svt_amd_md_encode_picture_inter: slot %d does not hold the motion-estimation records of a %u x %u picture", me_slot, pic->d.width, pic->d.height);
             return SVT_AMD_ERR_BAD_PARAM;
         }
         d_me_slot = root->slots[me_slot].d_me_out;
+        ev_wait[0] = root->slots[me_slot].ev_me;
     }
     const SvtAmdOisLcuResult *d_ois_slot = nullptr;
     if (!ois) {
         SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
-        if (ois_slot < 0 || ois_slot >= root->num_slots || !root->slots[ois_slot].d_ois_out) {
-            svt_amd_set_error("svt_amd_md_encode_picture: no open-loop intra search records in slot %d", ois_slot);
+        if (ois_slot < 0 || ois_slot >= root->num_slots || !root->slots[ois_slot].d_ois_out || !root->slots[ois_slot].valid || root->slots[ois_slot].ois_lcus != (uint32_t)n ||
+            root->slots[ois_slot].width != pic->d.width || root->slots[ois_slot].height != pic->d.height) {
+            svt_amd_set_error("svt_amd_md_encode_picture: slot %d does not hold the open-loop intra search records of a %u x %u picture", ois_slot, pic->d.width, pic->d.height);
             return SVT_AMD_ERR_BAD_PARAM;
         }
         d_ois_slot = root->slots[ois_slot].d_ois_out;
+        ev_wait[1] = root->slots[ois_slot].ev_ois;
+    }
+    if (pic->md_rect_n) { /* a rank's rectangle (svt_amd_encdec_picture_set_rect): its borders must be tile borders - an LCU never waits for one outside */
+        const SvtAmdRect &r = pic->md_rect;
+        const int x0 = r.x / 64, y0 = r.y / 64, x1 = (r.x + r.w + 63) / 64, y1 = (r.y + r.h + 63) / 64;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const SvtAmdMdLcu &Lc = lcus[y * wl + x];
+                if ((x == x0 && !Lc.tile_left) || (y == y0 && !Lc.tile_top) || (x == x1 - 1 && x1 < wl && !Lc.tile_right) ||
+                    (y == y1 - 1 && y1 < hl && !lcus[(y + 1) * wl + x].tile_top)) {
+                    svt_amd_set_error("svt_amd_md_encode_picture: the rectangle's border at LCU (%d, %d) is not a tile border", x, y);
+                    return SVT_AMD_ERR_BAD_PARAM;
+                }
+            }
     }
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = rate_tables_once(ctx->device);
@@ -1602,6 +1620,9 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     if ((rc = md_state(pic, &m)) != 0)
         return rc;
     hipStream_t st = ctx->stream;
+    for (hipEvent_t ev : ev_wait)
+        if (ev)
+            HIP_TRY(hipStreamWaitEvent(st, ev, 0));
     /* debug (SVT_AMD_MD_TIMING): host clock around the call's three parts, with a stream synchronisation after each - one line per call on stderr */
     static const bool timing = getenv("SVT_AMD_MD_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -1633,18 +1654,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     }
     int n_active = n;
     const unsigned *d_order = pic->d_sync + 1 + n;
-    if (pic->md_rect_n) { /* a rank's rectangle (svt_amd_encdec_picture_set_rect): its borders must be tile borders - an LCU never waits for one outside */
-        const SvtAmdRect &r = pic->md_rect;
-        const int x0 = r.x / 64, y0 = r.y / 64, x1 = (r.x + r.w + 63) / 64, y1 = (r.y + r.h + 63) / 64;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
-                const SvtAmdMdLcu &Lc = lcus[y * wl + x];
-                if ((x == x0 && !Lc.tile_left) || (y == y0 && !Lc.tile_top) || (x == x1 - 1 && x1 < wl && !Lc.tile_right) ||
-                    (y == y1 - 1 && y1 < hl && !lcus[(y + 1) * wl + x].tile_top)) {
-                    svt_amd_set_error("svt_amd_md_encode_picture: the rectangle's border at LCU (%d, %d) is not a tile border", x, y);
-                    return SVT_AMD_ERR_BAD_PARAM;
-                }
-            }
+    if (pic->md_rect_n) {
         n_active = pic->md_rect_n, d_order = pic->d_order_md;
         HIP_TRY(hipMemsetAsync(m->d_out, 0, sizeof(SvtAmdMdLcuOut) * (size_t)n, st));
     }

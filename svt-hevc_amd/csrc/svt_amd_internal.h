@@ -37,6 +37,9 @@ struct DevPicture {
     uint8_t *d_pack;               /* compact wire form of this slot's ME + OIS records (svt_amd_*_fetch_compact_async) */
     size_t pack_bytes;
     hipEvent_t ev_ready;           /* recorded after the planes of this slot were built: lanes on other streams wait on it */
+    hipEvent_t ev_me, ev_ois;      /* recorded behind the kernels that wrote d_me_out / d_ois_out: a consumer on another lane's stream (the mode decision reading the
+                                    * records where they are) waits on them */
+    uint32_t me_lcus, ois_lcus;    /* LCUs of the picture whose records the buffers hold (0: none yet) */
     uint16_t width, height;
     int      valid;
 };

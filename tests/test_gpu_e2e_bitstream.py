@@ -473,11 +473,13 @@ MD_CASES = [
     ("motion", 1920, 1080, 3, ["-encMode", "10", "-intra-period", "0"], "all"),
     # 2 x 2 tiles
     ("motion", 640, 384, 2, ["-encMode", "9", "-intra-period", "0", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], "all"),
-    # random access, encMode 9: the I picture and the non-reference B pictures (open-loop intra, luma-only candidates) on the device - here pictures
-    # 0, 1, 3, 5; the reference B pictures' mode decision (chroma in the loop) stays with the reference code, their encode pass on the device
-    ("motion", 640, 384, 6, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], ("inter", 4, 3)),
-    # encMode 8, three hierarchical levels, moving objects (AMVP, uni- and bi-prediction, merge / skip decisions with chroma): I + 4 of 8 B pictures
-    ("objects", 416, 240, 9, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "28"], ("inter", 5, 4)),
+    # random access, encMode 9: the I picture, the non-reference B pictures (open-loop intra, luma-only candidates) and the reference B picture of temporal layer 1
+    # (chroma level 4: CHROMA_MODE_FULL LCUs, chroma in both loops) on the device - here pictures 0, 1, 3, 5 and 2; the base-layer B picture (closed-loop intra,
+    # branch-and-depth-pillar LCUs) stays with the reference code
+    ("motion", 640, 384, 6, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1"], ("inter", 5, 4)),
+    # encMode 8, three hierarchical levels, moving objects (AMVP, uni- and bi-prediction, merge / skip decisions with chroma): I + the 4 non-reference B pictures + the
+    # reference B pictures of layers 1 and 2 whose LCUs all take the ModeDecisionLcu path
+    ("objects", 416, 240, 9, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "28"], ("inter", 6, 5)),
     # low delay P
     ("objects", 320, 192, 6, ["-encMode", "8", "-pred-struct", "0", "-hierarchical-levels", "2", "-q", "30"], ("inter", None, None)),
     # noise: intra units inside B pictures
@@ -514,8 +516,8 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
         assert pics == n and lcus == n * nl and left == 0, rep
     elif isinstance(expect, tuple):
         assert inter >= 1 and pics == inter + 1 and lcus == pics * nl, rep   # the I picture + the P / B pictures inside the device call
-        if expect[1] is not None:
-            assert pics == expect[1] and inter == expect[2], rep
+        if expect[1] is not None:   # at least these many (which reference pictures qualify depends on the LCU depth modes the reference derives)
+            assert pics >= expect[1] and inter >= expect[2], rep
     else:
         assert pics == 0 and left >= 1, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
@@ -524,8 +526,8 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
 
 def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(tmp_path):
     """BASELINE configs[2] itself (4K, encMode 7, random access, SAO on), 17 pictures: motion estimation + open-loop intra search on the device and,
-    with SVT_HOOK_MD=1, mode decision + encode pass of the I picture and of every non-reference B picture as ONE device call each - the bitstream
-    must be the unmodified reference's"""
+    with SVT_HOOK_MD=1, mode decision + encode pass of the I picture, of every non-reference B picture (temporal layer 2) and of every layer-1 reference B picture
+    (CHROMA_MODE_FULL) as ONE device call each - the bitstream must be the unmodified reference's"""
     import re
     import sys
     sys.path.insert(0, os.path.join(S.ROOT, "tools"))
@@ -536,5 +538,5 @@ def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(
     m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\)", rep)
     assert m, rep
     pics, inter, lcus = (int(v) for v in m.groups())
-    assert pics >= 9 and inter >= 8 and lcus == pics * S.lcu_count(3840, 2160), rep
+    assert pics >= 13 and inter >= 12 and lcus == pics * S.lcu_count(3840, 2160), rep   # I + 8 layer-2 + 4 layer-1 pictures; the 4 base-layer B pictures: reference code
     assert r["bitstream_identical"], rep

@@ -221,6 +221,77 @@ def test_md_encode_picture_reads_the_ois_records_the_front_half_left_in_hbm(prod
         lib.svt_amd_context_destroy(ctx)
 
 
+def test_md_of_a_b_picture_reads_me_and_ois_records_another_lane_left_in_hbm(product):
+    """me == NULL and ois == NULL: motion estimation and open-loop intra search of the picture were LAUNCHED (not fetched) on another lane's stream; the mode decision
+    reads their records where they are, ordered behind those kernels by the slot's events (ADVICE r3).  Same decisions as with the records passed as host arrays;
+    a slot that holds no such records is refused."""
+    import torch
+    from gpu_util import upload, default_params
+    from test_oracle_md_golden import inter_inputs
+    lib = product
+    sig(lib)
+    vp = C.c_void_p
+    lib.svt_amd_md_encode_picture_inter.restype = C.c_int
+    lib.svt_amd_md_encode_picture_inter.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [vp] * 5
+    lib.svt_amd_context_fork.argtypes = [vp, C.POINTER(vp)]
+    lib.svt_amd_me_picture_range_launch.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.c_uint32]
+    lib.svt_amd_ois_picture_launch.argtypes = [vp, vp, C.c_int]
+    lib.svt_amd_me_picture_fetch.argtypes = [vp, C.c_int, vp]
+    lib.svt_amd_ois_picture_fetch.argtypes = [vp, C.c_int, vp]
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_bref_motion_416x240_m8.npz"))   # a reference B picture: CHROMA_MODE_FULL LCUs
+    k = 0
+    w, h = int(g["pic"][k]["width"]), int(g["pic"][k]["height"])
+    nl = S.lcu_count(w, h)
+    root, lane_a, lane_b, pic = vp(), vp(), vp(), vp()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 4, C.byref(root)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_context_fork(root, C.byref(lane_a)) == 0 and lib.svt_amd_context_fork(root, C.byref(lane_b)) == 0, lib.svt_amd_last_error()
+        frames = [S.gen_luma("motion", w, h, t, 7) for t in range(3)]
+        for sl, f in enumerate(frames):
+            upload(lib, lane_a, sl, f)
+        mp = default_params(w, h, num_lists=2, temporal_layer_index=1, cu8x8_mode=0)
+        refs = (C.c_int * 2)(0, 2)
+        op = S.OisParams()
+        op.luma_width, op.luma_height, op.ois_th_set, op.temporal_layer_index = w, h, 1, 1
+        # lane A: launches only - its kernels may still run when lane B's call arrives
+        assert lib.svt_amd_me_picture_range_launch(lane_a, C.byref(mp), 1, refs, 0, nl) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_ois_picture_launch(lane_a, C.byref(op), 1) == 0, lib.svt_amd_last_error()
+        P, lcus, cost = np.ascontiguousarray(g["pic"][k:k + 1]), np.ascontiguousarray(g["lcu"][k]), np.ascontiguousarray(g["cost"][k])
+        src = [np.ascontiguousarray(g[n][k]) for n in ("src_y", "src_cb", "src_cr")]
+        X, _, tmvp, rr, planes = inter_inputs(g, k)
+        dev = [[torch.from_numpy(a).cuda() for a in pl] for pl in planes]
+        torch.cuda.synchronize()
+        rs = [S.RefPicture(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), r.strideY, r.strideC, r.originX, r.originY, r.width, r.height) for d, r in zip(dev, rr)]
+        assert lib.svt_amd_encdec_picture_create(lane_b, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_encdec_picture_set_inter(lane_b, pic, C.byref(rs[0]), C.byref(rs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
+
+        def call(me, ois, slot):
+            out = np.zeros(nl, S.MD_LCU_OUT_DTYPE)
+            rc = lib.svt_amd_md_encode_picture_inter(lane_b, pic, P.ctypes.data, X.ctypes.data, lcus.ctypes.data, src[0].ctypes.data, src[0].shape[1], src[1].ctypes.data,
+                                                     src[2].ctypes.data, src[1].shape[1], ois, slot, me, slot, tmvp.ctypes.data if tmvp is not None else None, out.ctypes.data,
+                                                     None, None)
+            return rc, out
+        rc, in_place = call(None, None, 1)                  # lane B: records of slot 1 read where lane A's kernels leave them
+        assert rc == 0, lib.svt_amd_last_error()
+        me_h, ois_h = np.zeros(nl, S.ME_LCU_DTYPE), np.zeros(nl, S.OIS_LCU_DTYPE)
+        assert lib.svt_amd_me_picture_fetch(lane_a, 1, me_h.ctypes.data) == 0 and lib.svt_amd_ois_picture_fetch(lane_a, 1, ois_h.ctypes.data) == 0, lib.svt_amd_last_error()
+        rc, from_host = call(me_h.ctypes.data, ois_h.ctypes.data, 0)
+        assert rc == 0, lib.svt_amd_last_error()
+        for f in in_place.dtype.names:
+            assert np.array_equal(in_place[f], from_host[f]), f
+        assert int(in_place["tested"].sum()) >= nl
+        rc, _ = call(None, None, 3)                         # a slot no motion estimation / intra search has written
+        assert rc != 0
+        del dev
+        lib.svt_amd_encdec_picture_destroy(lane_b, pic)
+    finally:
+        for c in (lane_a, lane_b, root):
+            if c:
+                lib.svt_amd_context_destroy(c)
+
+
 def test_md_encode_picture_rejects_what_it_does_not_cover(product):
     lib = product
     sig(lib)
