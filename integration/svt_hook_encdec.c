@@ -61,7 +61,8 @@ void AddChromaEncDec(PictureControlSet_t *pictureControlSetPtr, LargestCodingUni
                      EncDecContext_t *contextPtrED, EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex, EB_U32 cuChromaOriginIndex,
                      EB_U32 candIdxInput); /* EbProductCodingLoop.c:4158 */
 /* svt_hook_me.c: device copies of the picture's reference pictures (uploaded once per reference picture) */
-void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2]);
+void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2], int slot[2]);
+void svt_hook_release_references(const int slot[2]);
 EB_ERRORTYPE __real_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countNonZeroCoeffs, EB_U64 yTuDistortion[DIST_CALC_TOTAL], EB_U64 *yTuCoeffBits,
                                      EB_U32 componentMask);
 EB_ERRORTYPE __real_PictureFullDistortionLuma(EbPictureBufferDesc_t *coeff, EB_U32 coeffLumaOriginIndex, EbPictureBufferDesc_t *reconCoeff,
@@ -75,6 +76,7 @@ EB_ERRORTYPE __real_TuEstimateCoeffBitsEncDec(EB_U32 tuOriginIndex, EB_U32 tuChr
 typedef struct {
     const PictureControlSet_t *pcs;
     uint64_t picture_plus1;      /* picture the device picture was begun for */
+    int ref_pins_plus1[2];       /* reference-cache slots (+ 1; 0 = none) pinned for that picture: released when the object moves on to its next picture / is released */
     SvtAmdEncDecPicture *pic;
     pthread_mutex_t lock;        /* pending list + the device put of it */
     void *pending;               /* host-encoded LCUs not handed to the device yet: SvtAmdLcuBorder[] or SvtAmdLcuBorder16[] */
@@ -171,6 +173,8 @@ static void lane_release(SvtAmdContext *lane)
 /* everything an entry owns (under g_ep_lock) */
 static void entry_release(SvtAmdContext *lane, EpPictureEntry *e)
 {
+    const int pins[2] = {e->ref_pins_plus1[0] - 1, e->ref_pins_plus1[1] - 1};
+    svt_hook_release_references(pins);
     if (e->pic)
         svt_amd_encdec_picture_destroy(lane, e->pic);
     free(e->pending), free(e->works_all), free(e->res_all), free(e->sao_enable);
@@ -251,8 +255,16 @@ static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const Pictur
         int have[2] = {0, 0};
         struct timespec t0, t1, t2, t3;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        if (pcs->sliceType != EB_I_PICTURE)
-            svt_hook_resident_references(pcs, wide, refs, have);
+        {   /* the previous picture of this object no longer reads its reference pictures (its device work was waited for before its LCUs were served) */
+            const int old[2] = {e->ref_pins_plus1[0] - 1, e->ref_pins_plus1[1] - 1};
+            svt_hook_release_references(old);
+            e->ref_pins_plus1[0] = e->ref_pins_plus1[1] = 0;
+        }
+        if (pcs->sliceType != EB_I_PICTURE) {
+            int slot[2];
+            svt_hook_resident_references(pcs, wide, refs, have, slot); /* pinned in the cache for as long as this picture is in the object */
+            e->ref_pins_plus1[0] = slot[0] + 1, e->ref_pins_plus1[1] = slot[1] + 1;
+        }
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if (svt_amd_encdec_picture_set_inter(lane, e->pic, have[0] ? &refs[0] : NULL, have[1] ? &refs[1] : NULL, (const SvtAmdCabacCost *)pcs->cabacCost))
             svt_hook_die("svt_amd_encdec_picture_set_inter");

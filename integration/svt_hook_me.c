@@ -1221,8 +1221,41 @@ EB_ERRORTYPE __wrap_Intra4x4IntraPredictionCl(EB_U32 puIndex, EB_U32 puOriginX, 
 EB_ERRORTYPE __real_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX, EB_U16 puOriginY, EB_U8 puWidth, EB_U8 puHeight,
                                               PictureControlSet_t *pcs, EbPictureBufferDesc_t *predictionPtr,
                                               MotionCompensationPredictionContext_t *mcpContext);
-#define REF_CACHE 16
-static struct RefSlot { const void *buf; uint64_t poc, used; void *d[3]; size_t bytes[3]; SvtAmdRefPicture pic; int from_device; } g_refs[REF_CACHE];
+/* The cache grows instead of recycling a slot somebody still reads: a slot is PINNED from the lookup that hands it out until its user lets go (a per-unit binding: until
+ * its device call has returned; a picture object of the device-resident encode pass: until the object moves on to another picture), and only unpinned slots are
+ * candidates for eviction (least recently used first).  ADVICE r2 / VERDICT r3: with a fixed table of 16 the live reference set of deep hierarchies + several
+ * pictures in flight could outgrow it, and the victim's device memory was freed or overwritten under kernels still reading it. */
+#define REF_CACHE_STEP 16
+struct RefSlot { const void *buf; uint64_t poc, used; void *d[3]; size_t bytes[3]; SvtAmdRefPicture pic; int from_device, pins; };
+static struct RefSlot *g_refs;
+static int REF_CACHE; /* slots allocated */
+static struct RefSlot *ref_victim(void) /* under g_lock: the least recently used unpinned slot; a new one when every slot is in use */
+{
+    struct RefSlot *victim = NULL;
+    for (int i = 0; i < REF_CACHE; i++)
+        if (!g_refs[i].pins && (!victim || g_refs[i].used < victim->used))
+            victim = &g_refs[i];
+    if (victim)
+        return victim;
+    struct RefSlot *n = (struct RefSlot *)realloc(g_refs, sizeof(*g_refs) * (size_t)(REF_CACHE + REF_CACHE_STEP));
+    if (!n)
+        die("out of memory (reference cache)");
+    memset(n + REF_CACHE, 0, sizeof(*n) * REF_CACHE_STEP);
+    g_refs = n, REF_CACHE += REF_CACHE_STEP;
+    return &g_refs[REF_CACHE - REF_CACHE_STEP];
+}
+/* under g_lock */
+static void ref_unpin(int slot)
+{
+    if (slot >= 0 && slot < REF_CACHE && g_refs[slot].pins > 0)
+        g_refs[slot].pins--;
+}
+void svt_hook_release_references(const int slot[2])
+{
+    svt_hook_lock(&g_lock);
+    ref_unpin(slot[0]), ref_unpin(slot[1]);
+    svt_hook_unlock(&g_lock);
+}
 static unsigned long g_ref_from_device, g_ref_dev_checked, g_ref_dev_mismatch;
 static int g_ref_dev_verify = -1;
 static uint64_t g_ref_clock;
@@ -1230,15 +1263,15 @@ static void *g_inter_scratch[3]; /* device prediction planes: 64x64, 32x32, 32x3
 static unsigned long g_inter_gpu, g_inter_uploads;
 static int g_inter_state;
 
-/* must hold g_lock */
-static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps);
-static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p, uint64_t poc) { return resident_reference_bps(p, poc, 1); }
-static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps)
+/* must hold g_lock.  *slot = the cache slot, PINNED: the caller unpins it (ref_unpin / svt_hook_release_references) when it no longer reads the device copy */
+static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot);
+static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p, uint64_t poc, int *slot) { return resident_reference_bps(p, poc, 1, slot); }
+static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot)
 {
-    struct RefSlot *victim = &g_refs[0];
     for (int i = 0; i < REF_CACHE; i++) {
         if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
             g_refs[i].used = ++g_ref_clock;
+            g_refs[i].pins++, *slot = i;
             if (g_refs[i].from_device == 1) { /* produced on the device (svt_hook_register_device_reference): never uploaded.  The encoder has
                                                * finished its own copy by now; SVT_HOOK_ENCODEPASS_REFS=verify compares the two once */
                 if (g_ref_dev_verify < 0) {
@@ -1278,9 +1311,8 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
             }
             return &g_refs[i].pic;
         }
-        if (g_refs[i].used < victim->used)
-            victim = &g_refs[i];
     }
+    struct RefSlot *victim = ref_victim();
     const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
     const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
     const uint8_t *src[3] = {p->bufferY, p->bufferCb, p->bufferCr};
@@ -1299,6 +1331,7 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
     victim->pic.d_y = victim->d[0], victim->pic.d_cb = victim->d[1], victim->pic.d_cr = victim->d[2];
     victim->pic.strideY = p->strideY, victim->pic.strideC = p->strideCb, victim->pic.originX = p->originX, victim->pic.originY = p->originY;
     victim->pic.width = p->width, victim->pic.height = p->height;
+    victim->pins = 1, *slot = (int)(victim - g_refs);
     g_inter_uploads++;
     return &victim->pic;
 }
@@ -1310,15 +1343,12 @@ void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t
     if (dev->strideY != p->strideY || dev->strideC != p->strideCb || dev->originX != p->originX || dev->originY != p->originY)
         return; /* another padding geometry: the upload path serves it */
     svt_hook_lock(&g_lock);
-    struct RefSlot *victim = &g_refs[0];
-    for (int i = 0; i < REF_CACHE; i++) {
-        if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
+    struct RefSlot *victim = NULL;
+    for (int i = 0; i < REF_CACHE && !victim; i++)
+        if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0] && !g_refs[i].pins) /* (a pinned copy of this very buffer + POC is what it was: keep it) */
             victim = &g_refs[i];
-            break;
-        }
-        if (g_refs[i].used < victim->used)
-            victim = &g_refs[i];
-    }
+    if (!victim)
+        victim = ref_victim();
     const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
     const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
     const void *src[3] = {dev->d_y, dev->d_cb, dev->d_cr};
@@ -1348,15 +1378,16 @@ void svt_hook_reference_report(FILE *out)
 }
 
 /* for the device-resident encode pass (svt_hook_encdec.c): the reference pictures of both lists as device copies */
-void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2])
+void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2], int slot[2])
 {
     svt_hook_lock(&g_lock);
     for (int l = 0; l < 2; l++) {
         have[l] = l == 0 ? pcs->sliceType != EB_I_PICTURE : pcs->sliceType == EB_B_PICTURE;
+        slot[l] = -1;
         if (!have[l])
             continue;
         const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
-        out[l] = *resident_reference_bps(wide ? ro->referencePicture16bit : ro->referencePicture, ro->refPOC, wide ? 2 : 1);
+        out[l] = *resident_reference_bps(wide ? ro->referencePicture16bit : ro->referencePicture, ro->refPOC, wide ? 2 : 1, &slot[l]); /* pinned: svt_hook_release_references */
     }
     svt_hook_unlock(&g_lock);
 }
@@ -1380,11 +1411,12 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
     svt_hook_lock(&g_lock);
     const SvtAmdRefPicture *refs[2] = {NULL, NULL};
     SvtAmdRefPicture copy[2];
+    int pin[2] = {-1, -1};
     for (int l = 0; l < 2; l++) {
         job.mv[l][0] = mvUnit->mv[l].x, job.mv[l][1] = mvUnit->mv[l].y;
         if (mvUnit->predDirection == l || mvUnit->predDirection == BI_PRED) {
             const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
-            copy[l] = *resident_reference(ro->referencePicture, ro->refPOC); /* the slot may be recycled by the other list */
+            copy[l] = *resident_reference(ro->referencePicture, ro->refPOC, &pin[l]); /* pinned until the unit's samples are back: the other list's lookup cannot recycle it */
             refs[l] = &copy[l];
         }
     }
@@ -1402,6 +1434,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction(MvUnit_t *mvUnit, EB_U16 puOriginX
         die("svt_amd_device_download");
     if (g_inter_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction) on the GPU\n");
+    ref_unpin(pin[0]), ref_unpin(pin[1]); /* the samples are back (the downloads above are blocking) */
     svt_hook_unlock(&g_lock);
     const uint32_t oy = (predictionPtr->originY + puOriginY) * predictionPtr->strideY + predictionPtr->originX + puOriginX;
     const uint32_t oc = (((predictionPtr->originY + puOriginY) * predictionPtr->strideCb) >> 1) + ((predictionPtr->originX + puOriginX) >> 1);
@@ -1441,11 +1474,12 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
     svt_hook_lock(&g_lock);
     const SvtAmdRefPicture *refs[2] = {NULL, NULL};
     SvtAmdRefPicture copy[2];
+    int pin[2] = {-1, -1};
     for (int l = 0; l < 2; l++) {
         job.mv[l][0] = mvUnit->mv[l].x, job.mv[l][1] = mvUnit->mv[l].y;
         if (mvUnit->predDirection == l || mvUnit->predDirection == BI_PRED) {
             const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
-            copy[l] = *resident_reference_bps(ro->referencePicture16bit, ro->refPOC, 2);
+            copy[l] = *resident_reference_bps(ro->referencePicture16bit, ro->refPOC, 2, &pin[l]);
             refs[l] = &copy[l];
         }
     }
@@ -1463,6 +1497,7 @@ EB_ERRORTYPE __wrap_EncodePassInterPrediction16bit(MvUnit_t *mvUnit, EB_U16 puOr
         die("svt_amd_device_download");
     if (g_inter16_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: encode-pass inter prediction (EncodePassInterPrediction16bit) on the GPU\n");
+    ref_unpin(pin[0]), ref_unpin(pin[1]); /* the samples are back (the downloads above are blocking) */
     svt_hook_unlock(&g_lock);
     const uint32_t oy = (predictionPtr->originY + puOriginY) * predictionPtr->strideY + predictionPtr->originX + puOriginX;
     const uint32_t oc = (((predictionPtr->originY + puOriginY) * predictionPtr->strideCb) >> 1) + ((predictionPtr->originX + puOriginX) >> 1);
@@ -1509,10 +1544,11 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
     svt_hook_lock(&g_lock);
     const SvtAmdRefPicture *refs[2] = {NULL, NULL};
     SvtAmdRefPicture copy[2];
+    int pin[2] = {-1, -1};
     for (int l = 0; l < 2; l++)
         if (dir == (EB_U32)l || dir == BI_PRED) {
             const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
-            copy[l] = msb ? *resident_reference_bps(ro->referencePicture16bit, ro->refPOC, 2) : *resident_reference(ro->referencePicture, ro->refPOC);
+            copy[l] = msb ? *resident_reference_bps(ro->referencePicture16bit, ro->refPOC, 2, &pin[l]) : *resident_reference(ro->referencePicture, ro->refPOC, &pin[l]);
             refs[l] = &copy[l];
         }
     if (!g_inter_scratch[0])
@@ -1529,6 +1565,7 @@ EB_ERRORTYPE __wrap_Inter2Nx2NPuPredictionHevc(ModeDecisionContext_t *mdContextP
         die("svt_amd_device_download");
     if (g_md_inter_gpu++ == 0 && g_verbose)
         fprintf(stderr, "svt_hook_me: mode-decision inter prediction (Inter2Nx2NPuPredictionHevc) on the GPU\n");
+    ref_unpin(pin[0]), ref_unpin(pin[1]); /* the samples are back (the downloads above are blocking) */
     svt_hook_unlock(&g_lock);
     const uint32_t oy = ((mdContextPtr->cuOriginY & 63) * 64) + (mdContextPtr->cuOriginX & 63);
     const uint32_t oc = ((((mdContextPtr->cuOriginY & 63) * 32) + (mdContextPtr->cuOriginX & 63)) >> 1);
@@ -1776,12 +1813,11 @@ static void hook_teardown(void)
     svt_hook_lock(&g_lock);
     if (g_ctx) {
         svt_amd_synchronize(g_ctx);
-        for (int i = 0; i < REF_CACHE; i++) {
+        for (int i = 0; i < REF_CACHE; i++)
             for (int k = 0; k < 3; k++)
                 if (g_refs[i].d[k])
                     svt_amd_device_free(g_ctx, g_refs[i].d[k]);
-            memset(&g_refs[i], 0, sizeof(g_refs[i]));
-        }
+        free(g_refs), g_refs = NULL, REF_CACHE = 0;
         for (int k = 0; k < 3; k++) {
             if (g_inter_scratch[k])
                 svt_amd_device_free(g_ctx, g_inter_scratch[k]), g_inter_scratch[k] = NULL;

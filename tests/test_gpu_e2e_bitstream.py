@@ -49,7 +49,8 @@ CASES = [
 
 def _encode(app, yuv, w, h, n, args, out):
     r = subprocess.run([app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-b", out] +
-                       ([] if "-asm" in args else ["-asm", "1"]) + ([] if "-q" in args else ["-q", "32"]) + args, capture_output=True, text=True, timeout=600,
+                       ([] if "-asm" in args else ["-asm", "1"]) + ([] if "-q" in args else ["-q", "32"]) + args, capture_output=True, text=True,
+                       timeout=120 if w * h * n <= 1920 * 1080 * 8 else 400,   # seconds: a wedged encoder must not eat the GPU session (the largest cases take < 60 s)
                        env=dict(os.environ, SVT_HOOK_VERBOSE="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), r.stderr

@@ -279,8 +279,7 @@ def test_md_of_a_b_picture_reads_me_and_ois_records_another_lane_left_in_hbm(pro
         assert lib.svt_amd_me_picture_fetch(lane_a, 1, me_h.ctypes.data) == 0 and lib.svt_amd_ois_picture_fetch(lane_a, 1, ois_h.ctypes.data) == 0, lib.svt_amd_last_error()
         rc, from_host = call(me_h.ctypes.data, ois_h.ctypes.data, 0)
         assert rc == 0, lib.svt_amd_last_error()
-        for f in in_place.dtype.names:
-            assert np.array_equal(in_place[f], from_host[f]), f
+        compare_md(in_place, from_host, "records read in place vs the same records as host arrays")   # (every tested leaf; untested leaves hold no decision)
         assert int(in_place["tested"].sum()) >= nl
         rc, _ = call(None, None, 3)                         # a slot no motion estimation / intra search has written
         assert rc != 0

@@ -31,7 +31,7 @@ CONFIGS = {
 }
 
 
-def run_app(app, yuv, w, h, n, args, out, env=None, timeout=900, nb=None):
+def run_app(app, yuv, w, h, n, args, out, env=None, timeout=300, nb=None):
     """nb: frames preloaded into memory before the clock starts (-nb, Source/App/EbAppContext.c:420); the application cycles
     through them, so n may exceed the frames the file holds."""
     cmd = [app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-nb", str(nb or n), "-b", out] + args
