@@ -192,8 +192,8 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def closed_loop_leg(enc_cfg, enc, frames=48):
-    """the hooked encoder with SVT_HOOK_MD=pb on the clip of `value` (fewer pictures): fps, md5 against the reference's bitstream of the same
+def closed_loop_leg(enc_cfg, enc, frames=64):
+    """the hooked encoder with SVT_HOOK_MD=1 on the clip of `value` (fewer pictures): fps, md5 against the reference's bitstream of the same
     `frames` pictures, and the binding's own report of what ran where"""
     import encoder_fps as E
     w, h, depth, args = E.CONFIGS[enc_cfg]
@@ -206,14 +206,47 @@ def closed_loop_leg(enc_cfg, enc, frames=48):
         ref = E.run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"), nb=unique)
         rp = os.path.join(td, "report.txt")
         lp = min(HIP_LP, os.cpu_count() or 1)
-        hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "pb", "SVT_HOOK_REPORT": rp}, nb=unique)
+        ref_lp = E.run_app(S.REF_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "ref_lp.265"), nb=unique)
+        hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": rp}, nb=unique)
         lines = [l.strip() for l in open(rp) if "mode decision" in l] if os.path.exists(rp) else []
-        return {"switches": {"SVT_HOOK_MD": "pb"}, "frames": frames, "fps": hip["fps"], "reference_fps": ref["fps"], "bitstream_identical": hip["md5"] == ref["md5"],
-                "report": lines,
-                "what": "mode decision + merge / skip decisions + encode pass of every non-reference P / B picture on the device, one call per picture; "
-                        "the other pictures' closed loop is the reference code.  Not part of `value`: slower than `value`'s configuration (DESIGN 3.11)"}
+        import re
+        m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\).*?; (\d+) pictures outside", " ".join(lines))
+        cover = {"pictures_on_device": int(m.group(1)), "p_b_pictures_on_device": int(m.group(2)), "pictures_left_to_the_reference_code": int(m.group(4))} if m else None
+        return {"switches": {"SVT_HOOK_MD": "1"}, "frames": frames, "fps": hip["fps"], "reference_fps": ref["fps"], "reference_fps_same_threads": ref_lp["fps"],
+                "threads": "-lp %d" % lp, "bitstream_identical": hip["md5"] == ref["md5"], "coverage": cover, "report": lines,
+                "what": "motion estimation + open-loop intra search + mode decision + merge / skip decisions + encode pass of the I picture and of every open-loop P / B picture "
+                        "(temporal layers 1 and 2 of BASELINE configs[2]: CHROMA_MODE_FULL reference B pictures and non-reference B pictures) on the device, ONE call per "
+                        "picture; the base-layer B pictures (closed-loop intra, branch-and-depth-pillar LCUs) are the reference code's.  Not `value`: the encoder keeps "
+                        "max(4, lp / 6) pictures in its EncDec pool and a device picture stays 90 - 150 ms in it (DESIGN 3.11 / 5d: fps = pool / residence)"}
     finally:
         shutil.rmtree(td, ignore_errors=True)
+
+
+def md_kernel_leg(w, h):
+    """`roofline_md`: the mode-decision + encode-pass kernel (k_md_encode_picture) on recorded pictures of BASELINE configs[2] - the unmodified reference (oracle/_ref, prebuilt)
+    encodes 5 pictures here with the recording harness on; the device decides + encodes its three open-loop B pictures from the recorded inputs (decisions compared with the
+    reference's, leaf for leaf), timed by HIP events on the call's stream; a second pass collects the stage clocks of the LCU chain."""
+    import md_bench
+    g = md_bench.record_inter(w, h, 7, frames=5, kind="motion", levels=2, ref=None)
+    lib = S.load_product()
+    r = md_bench.run_inter(lib, g, reps=4, encode=True, check=True, profile=False)
+    st = md_bench.run_inter(lib, g, reps=2, encode=True, check=False, profile=True)
+    per = r["kernel"]["ms_by_hip_events"]
+    nlcu = r["lcus"]
+    # SURVEY 8d, EncDec: source 1.5 B/pel + two reference pictures 2 x 1.5 + reconstruction written 1.5 + mode / vector / coefficient records ~ 3 B/pel = 9 B/pel
+    algo = 9.0 * w * h
+    worst = max(p["kernel_ms"] for p in per)
+    out = {"bound": "hbm", "kernel": "k_md_encode_picture<true>: ModeDecisionLcu + EncodePass of every LCU of a picture, ONE launch, wavefront on the device",
+           "workgroups": r["kernel"]["workgroups"], "lds_bytes_per_workgroup": None, "waves_per_cu": 4,
+           "pictures": per, "algorithmic_bytes_per_launch": int(algo),
+           "avg_launch_ms": round(sum(p["kernel_ms"] for p in per) / len(per), 3),
+           "achieved": round(algo / (sum(p["kernel_ms"] for p in per) / len(per) * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "traffic": None, "latency_bound": "a picture's critical path = %d wavefront steps (W/64 + 2 (H/64 - 1)) x the mode-decision time of one LCU" %
+                                             ((w + 63) // 64 + 2 * ((h + 63) // 64 - 1)),
+           "stage_clocks_per_lcu_on_the_chain": st["stage_clocks_per_lcu"], "decisions": "identical to the reference's ModeDecisionLcu records (checked in this run)",
+           "worst_picture_ms": worst, "lcus": nlcu}
+    out["frac"] = round(out["achieved"] / HBM_PEAK_GBS, 7)
+    return out
 
 
 def cpu_baseline_encoder(cfg, enc):
@@ -587,7 +620,12 @@ def main():
                        "switches": enc.get("switches") if enc else None,
                        "host_threads_of_the_encoder": ("-lp %d (of %d on this host); the reference's fps at default threading and at the same -lp are in "
                                                        "encoder_fps / cpu_baseline" % (enc["hip_threads"], os.cpu_count())) if enc and enc.get("hip_threads") else None,
-                       "on_device": enc.get("on_device") if enc else None,
+                       "on_device": (["Decimation2D / GeneratePadding / half-pel planes (k_prep_fused)", "HME level 0 / 1, full-pel 85-PU search, sub-pel refinement, "
+                                      "bi-prediction search, MeCuResults (k_me<0>, k_me<1>)", "OpenLoopIntraSearchLcu (k_ois_picture)"] +
+                                     (["ModeDecisionLcu + EncodePass of the I picture and every open-loop P / B picture (k_md_encode_picture)"]
+                                      if os.environ.get("SVT_HOOK_MD") else [])) if enc else None,
+                       "on_host_in_this_run": ("EncDec (mode decision, encode pass, in-loop filters): the reference's own code; `closed_loop_on_device` is the same encode "
+                                               "with it on the device") if enc and not os.environ.get("SVT_HOOK_MD") else None,
                        "parallelism": "one encoder per rank on its own GPU, no data-path collective" if world > 1 else "1 GPU"},
             "encoder_fps": enc,
             "front_half": {"what": "upload + picture preparation + open-loop motion estimation of %d LCUs against %d list(s) (HME L0 %dx%d + L1, "
@@ -635,6 +673,11 @@ def main():
                 res["closed_loop_on_device"] = closed_loop_leg(cfg["enc"], enc)
             except Exception as e:
                 res["closed_loop_on_device"] = {"error": str(e)[-300:]}
+        if world == 1 and not a.no_encode_pass and os.path.exists(S.REF_APP):
+            try:
+                res["roofline_md"] = md_kernel_leg(W, H)
+            except Exception as e:
+                res["roofline_md"] = {"error": str(e)[-300:]}
         if world == 1 and not a.no_encode_pass:
             # the device-resident encode pass, measured beside the front half: it is not part of `value`
             try:

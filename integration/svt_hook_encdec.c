@@ -76,6 +76,8 @@ EB_ERRORTYPE __real_TuEstimateCoeffBitsEncDec(EB_U32 tuOriginIndex, EB_U32 tuChr
 typedef struct {
     const PictureControlSet_t *pcs;
     uint64_t picture_plus1;      /* picture the device picture was begun for */
+    int tl_lcus;                 /* SVT_HOOK_TIMELINE: LCUs of the current picture through EncodePass so far */
+    double tl_first;
     int ref_pins_plus1[2];       /* reference-cache slots (+ 1; 0 = none) pinned for that picture: released when the object moves on to its next picture / is released */
     SvtAmdEncDecPicture *pic;
     pthread_mutex_t lock;        /* pending list + the device put of it */
@@ -642,6 +644,18 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
     EpPictureEntry *e = picture_entry(lane, scs, pcs, wide, g_ep_own);
     const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
+    if (svt_hook_timeline_enabled()) { /* SVT_HOOK_TIMELINE: first / last LCU of the picture through EncodePass */
+        svt_hook_lock(&e->lock);
+        if (e->tl_lcus == 0)
+            e->tl_first = svt_hook_now();
+        const int all = ++e->tl_lcus == e->cap;
+        const double first = e->tl_first;
+        if (all)
+            e->tl_lcus = 0;
+        svt_hook_unlock(&e->lock);
+        if (all)
+            svt_hook_timeline("encodepass", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, first, svt_hook_now());
+    }
     if (!t_serve && !(t_serve = (EpServe *)malloc(sizeof(EpServe))))
         svt_hook_die("out of memory (encode-pass staging)");
     /* tools that change a unit's QP, dead zone, coefficient shape or quantiser are outside this revision */
@@ -948,6 +962,7 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
         svt_md_fill_inter(&X, scs, pcs, md);
     if (tools || (!inter && g_md_skip_intra) || !(inter ? svt_amd_md_picture_supported_inter(&P, &X) : svt_amd_md_picture_supported(&P))) {
         __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
+        svt_hook_timeline("md_host", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_in, md_now());
         return;
     }
     const size_t n = (size_t)e->cap;
@@ -980,6 +995,7 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
          * co-located picture's motion field go up with the call, the reference pictures are resident (picture_entry) */
         if (!svt_amd_md_lcus_supported(&P, lcus, (int)n)) {
             __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
+            svt_hook_timeline("md_host", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_in, md_now());
             return;
         }
         if (!e->md_me && (svt_amd_host_alloc(lane, sizeof(SvtAmdMeLcuResult) * n, (void **)&e->md_me) ||
@@ -1004,6 +1020,9 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     e->md_ok = 1;
     if (!inter)
         t_dev = md_now() - t_c0;
+    svt_hook_timeline("md_fill", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_in, t_p0);
+    svt_hook_timeline("md_refs", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_p0, t_c0);
+    svt_hook_timeline("md_call", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, md_now() - t_dev, md_now());
     g_md_t_call += t_dev, g_md_t_fill += md_now() - t_in - t_dev;
     __atomic_add_fetch(&g_md_pictures, 1, __ATOMIC_RELAXED);
 }

@@ -21,6 +21,11 @@ void svt_hook_lock(pthread_mutex_t *m);
 void svt_hook_unlock(pthread_mutex_t *m);
 int svt_hook_failed(void);
 void svt_hook_encdec_thread_exit(void);
+/* SVT_HOOK_TIMELINE=<file>: a time line of the bindings' picture-level events (device calls, reference uploads, first / last LCU of a picture through EncodePass), one
+ * line each, written with the report - what keeps how many pictures in flight.  kind: a short tag; a, b: event-specific numbers. */
+void svt_hook_timeline(const char *kind, unsigned long long picture, int a, int b, double t_begin, double t_end);
+double svt_hook_now(void);
+int svt_hook_timeline_enabled(void);
 /* the running pipeline's application callback (error reporting): noted by the first bound call that sees the sequence control set */
 struct SequenceControlSet_s;
 void svt_hook_note_callback(const struct SequenceControlSet_s *scs);

@@ -128,6 +128,61 @@ static unsigned long counter_sum(int i)
 static void hook_report(void);
 static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight);
 
+/* SVT_HOOK_TIMELINE (svt_hook_internal.h) */
+#define TL_MAX 65536
+static struct TlEvent { char kind[12]; unsigned long long picture; int a, b; double t0, t1; } *g_tl;
+static int g_tl_n, g_tl_state;
+double svt_hook_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void svt_hook_timeline(const char *kind, unsigned long long picture, int a, int b, double t_begin, double t_end)
+{
+    if (g_tl_state == 0) {
+        int on = getenv("SVT_HOOK_TIMELINE") != NULL, expect = 0;
+        struct TlEvent *buf = on ? (struct TlEvent *)calloc(TL_MAX, sizeof(*buf)) : NULL;
+        if (buf && __atomic_compare_exchange_n(&g_tl, &(struct TlEvent *){NULL}, buf, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+            __atomic_store_n(&g_tl_state, 1, __ATOMIC_RELEASE);
+        else {
+            free(buf);
+            __atomic_compare_exchange_n(&g_tl_state, &expect, on ? 1 : -1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+        }
+    }
+    if (g_tl_state < 0 || !g_tl)
+        return;
+    const int i = __atomic_fetch_add(&g_tl_n, 1, __ATOMIC_RELAXED);
+    if (i >= TL_MAX)
+        return;
+    struct TlEvent *e = &g_tl[i];
+    strncpy(e->kind, kind, sizeof(e->kind) - 1);
+    e->picture = picture, e->a = a, e->b = b, e->t0 = t_begin, e->t1 = t_end;
+}
+int svt_hook_timeline_enabled(void)
+{
+    static int on = -1;
+    if (on < 0)
+        on = getenv("SVT_HOOK_TIMELINE") != NULL;
+    return on;
+}
+static void timeline_write(void)
+{
+    const char *path = getenv("SVT_HOOK_TIMELINE");
+    if (!path || !g_tl)
+        return;
+    FILE *f = fopen(path, "w");
+    if (!f)
+        return;
+    const int n = g_tl_n < TL_MAX ? g_tl_n : TL_MAX;
+    double t0 = 1e300;
+    for (int i = 0; i < n; i++)
+        t0 = g_tl[i].t0 < t0 ? g_tl[i].t0 : t0;
+    for (int i = 0; i < n; i++)
+        fprintf(f, "%s %llu %d %d %.3f %.3f\n", g_tl[i].kind, g_tl[i].picture, g_tl[i].a, g_tl[i].b, 1e3 * (g_tl[i].t0 - t0), 1e3 * (g_tl[i].t1 - t0));
+    fclose(f);
+}
+
 /* The reference's error model (SURVEY 8b "Errors"): failures at EbInitEncoder time come back as EB_ERRORTYPE
  * (EB_ErrorInsufficientResources from the object constructors, Codec/EbEncHandle.c:689 ff.); failures inside the running pipeline go
  * to the application through appCallbackPtr->ErrorHandler (Codec/EbErrorHandling.h:15 CHECK_REPORT_ERROR: the handler posts an output
@@ -1316,6 +1371,7 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
     const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
     const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
     const uint8_t *src[3] = {p->bufferY, p->bufferCb, p->bufferCr};
+    const double t_up = svt_hook_now();
     for (int k = 0; k < 3; k++) {
         if (victim->bytes[k] < need[k]) {
             if (victim->d[k] && svt_amd_device_free(g_ctx, victim->d[k]))
@@ -1332,6 +1388,7 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
     victim->pic.strideY = p->strideY, victim->pic.strideC = p->strideCb, victim->pic.originX = p->originX, victim->pic.originY = p->originY;
     victim->pic.width = p->width, victim->pic.height = p->height;
     victim->pins = 1, *slot = (int)(victim - g_refs);
+    svt_hook_timeline("refupload", poc, (int)((need[0] + need[1] + need[2]) >> 20), 0, t_up, svt_hook_now());
     g_inter_uploads++;
     return &victim->pic;
 }
@@ -1854,6 +1911,7 @@ void *__wrap_EncDecKernel(void *inputPtr) { return kernel_thread(__real_EncDecKe
 
 static void hook_report(void)
 {
+    timeline_write();
     /* the sample application closes stderr before it returns (EbAppConfig.c:648): the report goes to the file SVT_HOOK_REPORT
      * names, or to stdout */
     const char *rp = getenv("SVT_HOOK_REPORT");

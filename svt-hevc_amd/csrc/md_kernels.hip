@@ -1489,6 +1489,8 @@ struct SvtAmdMdState {
     size_t info_bytes, mv_bytes;
     unsigned long long *d_prof;
     unsigned *d_md_done;           /* epoch of the call whose mode decision finished the LCU */
+    hipEvent_t ev_k0, ev_k1;       /* around the last launch of k_md_encode_picture on the call's stream (svt_amd_debug_md_kernel_ms) */
+    int grid;                      /* its workgroups */
     /* P / B pictures */
     SvtAmdMdInter *d_X;
     SvtAmdMeLcuResult *d_me;
@@ -1505,6 +1507,10 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
+    if (m->ev_k0)
+        (void)hipEventDestroy(m->ev_k0);
+    if (m->ev_k1)
+        (void)hipEventDestroy(m->ev_k1);
     free(m);
     pic->md = nullptr;
 }
@@ -1534,6 +1540,7 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     ok = ok && hipMalloc((void **)&m->d.md_mv, m->mv_bytes) == hipSuccess && hipMalloc((void **)&m->d_X, sizeof(SvtAmdMdInter)) == hipSuccess &&
          hipMalloc((void **)&m->d_me, sizeof(SvtAmdMeLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_tmvp, sizeof(SvtAmdTmvpLcu) * (n + 1)) == hipSuccess;
     ok = ok && hipMalloc((void **)&m->d_md_done, sizeof(unsigned) * n) == hipSuccess && hipMemset(m->d_md_done, 0, sizeof(unsigned) * n) == hipSuccess;
+    ok = ok && hipEventCreate(&m->ev_k0) == hipSuccess && hipEventCreate(&m->ev_k1) == hipSuccess;
     if (!ok) {
         svt_amd_set_error("hipMalloc (mode-decision picture state) failed");
         svt_amd_md_state_free(pic);
@@ -1687,7 +1694,15 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
      * find work (all of them resident: a workgroup that waits holds its CU) */
     int grid = 2 * ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2;
+    {   /* debug (SVT_AMD_MD_GRID): workgroups of the launch - how many a picture really needs decides how many pictures share the GPU */
+        const char *fg = getenv("SVT_AMD_MD_GRID");
+        const int forced = fg ? atoi(fg) : 0;
+        if (forced > 0)
+            grid = forced;
+    }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
+    m->grid = grid;
+    HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X)
         hipLaunchKernelGGL(k_md_encode_picture<true>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
                            pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
@@ -1695,6 +1710,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
                            pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev_k1, st));
     if (timing) {
         HIP_TRY(hipStreamSynchronize(st));
         t_kernel = std::chrono::steady_clock::now();
@@ -1756,5 +1772,18 @@ extern "C" int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture 
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpy(out, m->d_prof, bytes, hipMemcpyDeviceToHost));
     }
+    return SVT_AMD_OK;
+}
+
+/* measurement: duration (HIP events on the call's stream) and launch width of the picture object's last k_md_encode_picture launch */
+extern "C" int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms, int *workgroups)
+{
+    if (!ctx || !pic || !pic->md || !ms)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(pic->md->ev_k1));
+    HIP_TRY(hipEventElapsedTime(ms, pic->md->ev_k0, pic->md->ev_k1));
+    if (workgroups)
+        *workgroups = pic->md->grid;
     return SVT_AMD_OK;
 }

@@ -199,7 +199,7 @@ def load_oracle():
     """Test infrastructure: the CPU restatement (oracle/liboracle.so)."""
     if not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
-    lib = C.CDLL(ORACLE_SO)
+    lib = C.CDLL(os.environ.get("SVT_ORACLE_LIB") or ORACLE_SO)   # SVT_ORACLE_LIB: an instrumented build of the same sources (tools/md_logic_coverage.sh)
     _declare_leaf(lib, "svt_oracle_")
     _sig(lib.svt_oracle_picture_create, C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32])
     _sig(lib.svt_oracle_picture_destroy, None, [C.c_void_p])

@@ -117,7 +117,7 @@ def record_inter(w, h, enc_mode, frames=9, kind="objects", levels=3, extra=(), r
     return G(g)
 
 
-def run_inter(lib, g, reps=3, encode=True, check=True):
+def run_inter(lib, g, reps=3, encode=True, check=True, profile=None):
     """svt_amd_md_encode_picture_inter on every recorded picture: decisions vs the reference's, time per call"""
     from test_gpu_md import sig, md_encode_inter
     sig(lib)
@@ -125,17 +125,22 @@ def run_inter(lib, g, reps=3, encode=True, check=True):
     ctx, pic = C.c_void_p(), C.c_void_p()
     assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
     assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
-    prof = os.environ.get("MD_BENCH_PROFILE")
+    prof = os.environ.get("MD_BENCH_PROFILE") if profile is None else profile
     if prof:
         lib.svt_amd_debug_md_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         assert lib.svt_amd_debug_md_profile(ctx, pic, None) == 0
-    ts, tested, units = [], 0, 0
+    lib.svt_amd_debug_md_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    ts, tested, units, kms = [], 0, 0, [[] for _ in g["picture_number"]]
+    wgs = C.c_int(0)
     for k in range(len(g["picture_number"])):
         for rep in range(reps):
             t0 = time.perf_counter()
             out, works, _ = md_encode_inter(lib, ctx, pic, g, k, encode=encode)
             if rep:
                 ts.append((time.perf_counter() - t0) * 1e3)
+                ms = C.c_float(0)
+                assert lib.svt_amd_debug_md_kernel_ms(ctx, pic, C.byref(ms), C.byref(wgs)) == 0, lib.svt_amd_last_error()
+                kms[k].append(float(ms.value))
         if check:
             compare_md(out, g["out"][k], "%dx%d picture %d" % (w, h, int(g["picture_number"][k])))
         tested += int(g["out"][k]["tested"].sum())
@@ -157,7 +162,11 @@ def run_inter(lib, g, reps=3, encode=True, check=True):
             stages["raw_sums"] = [int(v) for v in pr.sum(axis=0)]
     lib.svt_amd_encdec_picture_destroy(ctx, pic)
     lib.svt_amd_context_destroy(ctx)
-    return {"stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "pictures": [int(p) for p in g["picture_number"]], "leaves_tested_per_picture": tested // len(ts) * (reps - 1) if ts else 0,
+    per_pic = [{"picture": int(p), "temporal_layer": int(g["pic"][k]["temporal_layer"]), "is_reference": int(g["pic"][k]["is_reference"]),
+                "chroma_level": int(g["pic"][k]["chroma_level"]), "kernel_ms": round(float(np.median(kms[k])), 3) if kms[k] else None,
+                "leaves_tested": int(g["out"][k]["tested"].sum())} for k, p in enumerate(g["picture_number"])]
+    return {"kernel": {"name": "k_md_encode_picture<true>", "workgroups": int(wgs.value), "ms_by_hip_events": per_pic},
+            "stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "pictures": [int(p) for p in g["picture_number"]], "leaves_tested_per_picture": tested // len(ts) * (reps - 1) if ts else 0,
             "final_units": units, "ms_per_picture_incl_host_copies": round(float(np.median(ts)), 2),
             "what": "svt_amd_md_encode_picture_inter (mode decision%s) of the recorded B pictures through the host-array ABI incl. reference-picture upload by the test; "
                     "decisions identical to the reference's ModeDecisionLcu records" % (" + merge / skip decision + encode pass" if encode else " only")}
@@ -209,7 +218,7 @@ if __name__ == "__main__":
         lib = S.load_product()
         out = run_inter(lib, g, reps)
         if os.environ.get("MD_BENCH_FLIGHTS"):
-            out["in_flight"] = [run_inter_flights(lib, g, f) for f in (1, 2, 4)]
+            out["in_flight"] = [run_inter_flights(lib, g, f) for f in (int(v) for v in os.environ["MD_BENCH_FLIGHTS"].split(","))]
         print(json.dumps(out))
     else:
         g = record(w, h, m)
