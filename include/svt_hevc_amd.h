@@ -1634,6 +1634,7 @@ SVT_AMD_API int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmd
 /* debug: stage clocks of the mode-decision kernel (16 shader-clock sums per LCU, accumulated over the picture object's later calls; the first call
  * switches the collection on) - see svt-hevc_amd/csrc/md_kernels.hip */
 SVT_AMD_API int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
+SVT_AMD_API int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
 /* measurement: duration in ms (HIP events on the call's stream) and launch width (workgroups) of the picture object's last mode-decision kernel launch */
 SVT_AMD_API int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms, int *workgroups);
 

@@ -61,7 +61,7 @@ void AddChromaEncDec(PictureControlSet_t *pictureControlSetPtr, LargestCodingUni
                      EncDecContext_t *contextPtrED, EbPictureBufferDesc_t *inputPicturePtr, EB_U32 inputCbOriginIndex, EB_U32 cuChromaOriginIndex,
                      EB_U32 candIdxInput); /* EbProductCodingLoop.c:4158 */
 /* svt_hook_me.c: device copies of the picture's reference pictures (uploaded once per reference picture) */
-void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2], int slot[2]);
+void svt_hook_resident_references(SvtAmdContext *lane, const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2], int slot[2]);
 void svt_hook_release_references(const int slot[2]);
 EB_ERRORTYPE __real_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countNonZeroCoeffs, EB_U64 yTuDistortion[DIST_CALC_TOTAL], EB_U64 *yTuCoeffBits,
                                      EB_U32 componentMask);
@@ -92,6 +92,7 @@ typedef struct {
     /* SVT_HOOK_MD: the mode decision AND the encode pass of every LCU of the picture in ONE device call, made by the picture's first
      * ModeDecisionLcu call; the later calls (and the EncodePass calls) of the picture are answered from these arrays */
     uint64_t md_picture_plus1;   /* picture the arrays below were filled for */
+    uint64_t md_done_plus1;      /* ... and the device call for it has RETURNED (release store): what the lock-free fast path of the per-LCU wraps looks at */
     int md_ok;                   /* 1: served by the device; 0: outside what svt_amd_md_encode_picture covers - the reference code runs */
     SvtAmdMdLcuOut *md_out;      /* pinned host memory (svt_amd_host_alloc), like the staging arrays below: the picture's records move by DMA */
     SvtAmdLcuWork *md_works;
@@ -210,6 +211,18 @@ void svt_hook_encdec_teardown(void)
 static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const PictureControlSet_t *pcs, int wide, int begin);
 static double g_prep_t[3]; /* seconds inside picture_prepare: reference pictures resident, svt_amd_encdec_picture_set_inter, _begin (racy sums, a report only) */
 static unsigned long g_prep_n;
+/* The per-LCU wraps run 2 x 2,040 times per 4K picture on ~30 threads: the common case - the picture's ONE device call has returned, the LCU is answered from its records -
+ * must not touch a global lock or hold a device lane (profiles/r04_q: with a lane claimed per call, eight pictures inside their device calls held every lane and all other
+ * pictures' bookkeeping stood still; the global mutex alone cost ~36 ms per picture).  Entries are created once per PictureControlSet_t under g_ep_lock and never move. */
+static EpPictureEntry *entry_lookup(const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide)
+{
+    for (int i = 0; i < EP_PICTURES; i++) {
+        EpPictureEntry *e = &g_ep_pic[i];
+        if (__atomic_load_n(&e->pcs, __ATOMIC_ACQUIRE) == pcs)
+            return (e->wide == wide && e->width == scs->lumaWidth && e->height == scs->lumaHeight) ? e : NULL;
+    }
+    return NULL;
+}
 /* prepare == 0: only find (or create) the object; the caller decides whether the picture needs the device at all (SVT_HOOK_MD alone) and calls
  * picture_prepare itself under the entry's lock */
 static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide, int prepare)
@@ -228,7 +241,6 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
     for (int i = 0; i < EP_PICTURES && !e; i++)
         if (!g_ep_pic[i].pcs) {
             e = &g_ep_pic[i];
-            e->pcs = pcs;
             pthread_mutex_init(&e->lock, NULL);
             e->wide = wide, e->width = scs->lumaWidth, e->height = scs->lumaHeight;
             if (svt_amd_encdec_picture_create(lane, (uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight, wide ? 2 : 1, &e->pic))
@@ -237,6 +249,7 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
             e->pending = malloc((wide ? sizeof(SvtAmdLcuBorder16) : sizeof(SvtAmdLcuBorder)) * (size_t)e->cap);
             if (!e->pending)
                 svt_hook_die("out of memory (encode-pass border list)");
+            __atomic_store_n(&e->pcs, pcs, __ATOMIC_RELEASE); /* published last: entry_lookup reads without the lock */
         }
     if (!e)
         svt_hook_die("encode pass: more PictureControlSet_t objects than EP_PICTURES");
@@ -264,7 +277,7 @@ static void picture_prepare(SvtAmdContext *lane, EpPictureEntry *e, const Pictur
         }
         if (pcs->sliceType != EB_I_PICTURE) {
             int slot[2];
-            svt_hook_resident_references(pcs, wide, refs, have, slot); /* pinned in the cache for as long as this picture is in the object */
+            svt_hook_resident_references(lane, pcs, wide, refs, have, slot); /* pinned in the cache for as long as this picture is in the object */
             e->ref_pins_plus1[0] = slot[0] + 1, e->ref_pins_plus1[1] = slot[1] + 1;
         }
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -639,9 +652,49 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         return;
     }
     svt_hook_note_callback(scs);
+    const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
+    {   /* the common case of SVT_HOOK_MD: the picture's device call has returned - answered from its records without a global lock or a device lane (see entry_lookup) */
+        EpPictureEntry *f = entry_lookup(scs, pcs, wide);
+        if (f && !wide && __atomic_load_n(&f->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1 && f->md_picture_plus1 == pcs->pictureNumber + 1) {
+            const int tools0 = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
+                               (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE);
+            if (f->md_ok && !tools0) {
+                if (!t_serve && !(t_serve = (EpServe *)malloc(sizeof(EpServe))))
+                    svt_hook_die("out of memory (encode-pass staging)");
+                if (svt_hook_timeline_enabled()) {
+                    svt_hook_lock(&f->lock);
+                    if (f->tl_lcus == 0)
+                        f->tl_first = svt_hook_now();
+                    const int all = ++f->tl_lcus == f->cap;
+                    const double first = f->tl_first;
+                    if (all)
+                        f->tl_lcus = 0;
+                    svt_hook_unlock(&f->lock);
+                    if (all)
+                        svt_hook_timeline("encodepass", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, first, svt_hook_now());
+                }
+                memcpy(&t_serve->work, &f->md_works[tbAddr], sizeof(SvtAmdLcuWork));
+                memcpy(&t_serve->res, &f->md_res[tbAddr], sizeof(SvtAmdLcuResult));
+                t_serve->wide = 0;
+                __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
+                t_serve->lcu = lcuPtr;
+                svt_hook_ep_active = 1, t_md_kinds = 1;
+                __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+                svt_hook_ep_active = 0, t_md_kinds = 0;
+                check_inter_kinds(lcuPtr);
+                if (g_ep_refs)
+                    picture_lcu_done(svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight), f, scs, pcs, tbAddr, 1, contextPtr->allowEncDecMismatch);
+                return;
+            }
+            if (!f->md_ok && !g_ep_own) { /* SVT_HOOK_MD alone, a picture outside the device's mode decision: the reference code's, EncodePass included */
+                __atomic_add_fetch(&g_ep_cpu_units, 1, __ATOMIC_RELAXED);
+                __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+                return;
+            }
+        }
+    }
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
-    const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
     EpPictureEntry *e = picture_entry(lane, scs, pcs, wide, g_ep_own);
     const EB_U32 lw = MIN(64u, scs->lumaWidth - lcuOriginX), lh = MIN(64u, scs->lumaHeight - lcuOriginY);
     if (svt_hook_timeline_enabled()) { /* SVT_HOOK_TIMELINE: first / last LCU of the picture through EncodePass */
@@ -1038,15 +1091,23 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
     if (g_md_state < 0 || svt_hook_failed() || scs->staticConfig.encoderBitDepth != EB_8BIT || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
     svt_hook_note_callback(scs);
+    EpPictureEntry *e = entry_lookup(scs, pcs, 0);
+    int ok = 0;
+    if (e && __atomic_load_n(&e->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1) { /* the picture's device call has returned: no lock, no lane */
+        ok = e->md_ok;
+        goto decided;
+    }
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
-    EpPictureEntry *e = picture_entry(lane, scs, pcs, 0, 0);
+    e = picture_entry(lane, scs, pcs, 0, 0);
     svt_hook_lock(&e->lock);
     if (e->md_picture_plus1 != pcs->pictureNumber + 1)
         md_picture(lane, e, scs, pcs, contextPtr);
-    const int ok = e->md_ok;
+    ok = e->md_ok;
+    __atomic_store_n(&e->md_done_plus1, pcs->pictureNumber + 1, __ATOMIC_RELEASE);
     svt_hook_unlock(&e->lock);
     lane_release(lane);
+decided:;
     if (!ok)
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
     const SvtAmdMdLcuOut *o = &e->md_out[lcuAddr];

@@ -244,6 +244,9 @@ static void die(const char *what)
 void svt_hook_die(const char *what) { die(what); }
 SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight)
 {
+    SvtAmdContext *have = __atomic_load_n(&g_ctx, __ATOMIC_ACQUIRE); /* (created once per encoder instance; the per-LCU callers must not queue on a global lock) */
+    if (have)
+        return have;
     svt_hook_lock(&g_front_lock);
     const int rc = ensure_context(lumaWidth, lumaHeight);
     svt_hook_unlock(&g_front_lock);
@@ -1319,9 +1322,13 @@ static unsigned long g_inter_gpu, g_inter_uploads;
 static int g_inter_state;
 
 /* must hold g_lock.  *slot = the cache slot, PINNED: the caller unpins it (ref_unpin / svt_hook_release_references) when it no longer reads the device copy */
-static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot);
+static const SvtAmdRefPicture *resident_reference_via(SvtAmdContext *via, const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot);
+static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot) { return resident_reference_via(g_ctx, p, poc, bps, slot); }
 static const SvtAmdRefPicture *resident_reference(const EbPictureBufferDesc_t *p, uint64_t poc, int *slot) { return resident_reference_bps(p, poc, 1, slot); }
-static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot)
+/* via: the context whose stream carries an upload.  The root context's stream shares its hardware queue with whatever lane the runtime mapped there - an upload
+ * behind another picture's 60 - 100 ms persistent kernel waits that long (profiles/r04_g_timeline_*.txt: 25 - 45 ms per device picture on average); a picture's own lane
+ * is idle at this point. */
+static const SvtAmdRefPicture *resident_reference_via(SvtAmdContext *via, const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot)
 {
     for (int i = 0; i < REF_CACHE; i++) {
         if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0]) {
@@ -1380,7 +1387,7 @@ static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_
                 die("svt_amd_device_alloc");
             victim->bytes[k] = need[k];
         }
-        if (svt_amd_device_upload(g_ctx, victim->d[k], src[k], need[k]))
+        if (svt_amd_device_upload(via, victim->d[k], src[k], need[k]))
             die("svt_amd_device_upload");
     }
     victim->buf = p->bufferY, victim->poc = poc, victim->used = ++g_ref_clock, victim->from_device = 0;
@@ -1435,7 +1442,7 @@ void svt_hook_reference_report(FILE *out)
 }
 
 /* for the device-resident encode pass (svt_hook_encdec.c): the reference pictures of both lists as device copies */
-void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2], int slot[2])
+void svt_hook_resident_references(SvtAmdContext *lane, const PictureControlSet_t *pcs, int wide, SvtAmdRefPicture out[2], int have[2], int slot[2])
 {
     svt_hook_lock(&g_lock);
     for (int l = 0; l < 2; l++) {
@@ -1444,7 +1451,7 @@ void svt_hook_resident_references(const PictureControlSet_t *pcs, int wide, SvtA
         if (!have[l])
             continue;
         const EbReferenceObject_t *ro = (const EbReferenceObject_t *)pcs->refPicPtrArray[l]->objectPtr;
-        out[l] = *resident_reference_bps(wide ? ro->referencePicture16bit : ro->referencePicture, ro->refPOC, wide ? 2 : 1, &slot[l]); /* pinned: svt_hook_release_references */
+        out[l] = *resident_reference_via(lane ? lane : g_ctx, wide ? ro->referencePicture16bit : ro->referencePicture, ro->refPOC, wide ? 2 : 1, &slot[l]); /* pinned: svt_hook_release_references */
     }
     svt_hook_unlock(&g_lock);
 }

@@ -122,6 +122,32 @@ struct EpMcScratch {
     int16_t raw[32 * 32];              /* list-0 intermediate of a bi-predicted tile */
 };
 
+/* The LUMA reference samples an LCU's motion-compensated candidates are likely to read, staged ONCE per LCU and list: the (64 + 2 R + 7)^2 samples of the padded reference
+ * plane around the LCU displaced by a centre vector (the mode decision: the 64x64 unit's motion-estimation vector).  A candidate whose window lies inside takes it from
+ * here (an LDS copy, ~0.3 K clocks) instead of from HBM (a round trip of ~5 K clocks on the unit chain, two for a bi-predicted candidate); any other candidate reads
+ * global memory as before.  Filled by ep_ref_windows_fill with the core's own clamped addressing, so the samples are the ones the core would have loaded. */
+#ifdef EP_DEBUG_WINDOW_COUNTS
+static __device__ unsigned g_ep_dbg_counts[8]; /* development aid: lookups with a valid window / an invalid one / none, and hits; [4..7]: clocks / 16 of set-up, window, horizontal, vertical */
+#define EP_DBG_CLK(k)                                                                              \
+    do {                                                                                           \
+        if (lane == 0 && !chroma) {                                                                \
+            const unsigned long long c_ = __builtin_readcyclecounter();                            \
+            atomicAdd(&g_ep_dbg_counts[k], (unsigned)((c_ - dbg_t_) >> 4));                         \
+            dbg_t_ = c_;                                                                           \
+        }                                                                                          \
+    } while (0)
+#else
+#define EP_DBG_CLK(k)
+#endif
+struct EpRefWindows {
+    static constexpr int R = 8, W = 64 + 2 * R + 7, P = 88, H = W;
+    int x0[2], y0[2]; /* padded-plane coordinates of the window's first sample, per list */
+    int valid[2];
+    alignas(16) uint8_t pix[2][H * P + 16];
+};
+/* by all 256 threads of the workgroup; mv[l] = the centre vector of list l in quarter samples */
+__device__ __forceinline__ void ep_ref_windows_fill(const EpPicture &P, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t);
+
 static __constant__ int8_t c_ep_luma_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1},
                                                    {0, 1, -5, 17, 58, -10, 4, -1}};
 static __constant__ int8_t c_ep_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
@@ -138,7 +164,7 @@ static __constant__ int8_t c_ep_chroma_taps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10,
  * (x, y) of the unit's plane-p block goes */
 template <typename T, typename Store>
 __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int abs_x, int abs_y, int N, int inter_dir, const int16_t (*mv)[2], int p, int lane,
-                                                      EpMcScratch<T> &M, Store store, int tile_first = 0, int tile_step = 1)
+                                                      EpMcScratch<T> &M, Store store, int tile_first = 0, int tile_step = 1, const EpRefWindows *RW = nullptr)
 {
     constexpr int WP = EpMcScratch<T>::WP, TP = EpMcScratch<T>::TP;
     constexpr int s1 = sizeof(T) == 1 ? 0 : 2, maxv = sizeof(T) == 1 ? 255 : 1023;
@@ -147,6 +173,9 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
     const int n = chroma ? N >> 1 : N, tn = n > 32 ? 32 : n, lgt = 31 - __clz(tn);
     const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3, rows = tn + ntaps - 1;
     const bool bi = inter_dir == 2;
+#ifdef EP_DEBUG_WINDOW_COUNTS
+    unsigned long long dbg_t_ = __builtin_readcyclecounter();
+#endif
     /* the block goes in 32x32 tiles (one for blocks up to 32x32); tile_first / tile_step let several waves share the tiles of a 64x64 block */
     const int ntile = n > 32 ? 4 : 1;
     for (int ti = tile_first; ti < ntile; ti += tile_step) {
@@ -171,7 +200,36 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                 }
                 /* window: 8-byte chunks of the rows, a lane per chunk, every load issued before the first store (one memory latency per window, not one per row).
                  * The chunks are not aligned (global memory takes that); one that leaves the plane is read sample by sample from clamped addresses. */
-                {
+                EP_DBG_CLK(4);
+                bool staged = false;
+#ifdef EP_DEBUG_WINDOW_COUNTS
+                if (lane == 0 && !chroma)
+                    atomicAdd(&g_ep_dbg_counts[RW ? (RW->valid[l] ? 0 : 1) : 2], 1u);
+#endif
+                if constexpr (sizeof(T) == 1) {
+                    /* the LCU's staged reference samples (EpRefWindows), when the tile's window lies inside: chunks of 8 bytes at any byte offset - three aligned words
+                     * and two v_alignbyte each */
+                    if (RW && !chroma && RW->valid[l]) {
+                        const int cpr = (rows + 7) >> 3, rx = ix + first - RW->x0[l], ry = iy + first - RW->y0[l];
+                        if (rx >= 0 && ry >= 0 && rx + cpr * 8 <= EpRefWindows::P && ry + rows <= EpRefWindows::H) {
+                            staged = true;
+#ifdef EP_DEBUG_WINDOW_COUNTS
+                            if (lane == 0)
+                                atomicAdd(&g_ep_dbg_counts[3], 1u);
+#endif
+                            const int nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
+                            for (int i = lane; i < nchunk; i += 64) {
+                                const int j = (i * inv) >> 16, m = i - j * cpr, o = (ry + j) * EpRefWindows::P + rx + m * 8, sh = o & 3;
+                                const uint32_t *wp = reinterpret_cast<const uint32_t *>(&RW->pix[l][o & ~3]);
+                                const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                                uint2 v;
+                                v.x = __builtin_amdgcn_alignbyte(w1, w0, sh), v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                                *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v;
+                            }
+                        }
+                    }
+                }
+                if (!staged) {
                     constexpr int SPC = 8 / (int)sizeof(T); /* samples per chunk */
                     const int cpr = (rows + SPC - 1) / SPC, nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
                     const int base0 = (iy + first) * stride + ix + first;
@@ -204,6 +262,7 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                     }
                 }
                 EP_WAVE_SYNC();
+                EP_DBG_CLK(5);
                 /* horizontal pass of every window row: a lane slides the taps over a run of seg outputs (seg + taps - 1 samples, read as whole words) */
                 const int seg = tn < 8 ? tn : 8, lgs = tn < 8 ? lgt : 3, spr = tn >> lgs; /* runs per row */
                 for (int i = lane; i < rows * spr; i += 64) {
@@ -230,6 +289,7 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                         }
                 }
                 EP_WAVE_SYNC();
+                EP_DBG_CLK(6);
                 /* vertical pass: a lane owns a column and a run of rpl rows (rpl + taps - 1 reads: one stretch of the transposed rows) */
                 const int rpl = tn >= 8 ? (tn * tn) >> 6 : 1, run = rpl < 1 ? 1 : rpl; /* 32: 16, 16: 4, 8: 1, 4: 1 */
                 {
@@ -279,9 +339,45 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
                     }
                 }
                 EP_WAVE_SYNC();
+                EP_DBG_CLK(7);
                 second = true;
             }
         }
+    }
+}
+
+__device__ __forceinline__ void ep_ref_windows_fill(const EpPicture &P, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t)
+{
+    for (int l = 0; l < 2; l++) {
+        if (!use[l]) {
+            if (t == 0)
+                RW.valid[l] = 0;
+            continue;
+        }
+        const EpRefPlanes &R = P.ref[l];
+        /* the position clamp of the core (Codec/EbInterPrediction.c:802-812) applied to the LCU's origin displaced by the centre vector */
+        const int qx = min(max(((lcu_x + R.originX) << 2) + mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
+        const int qy = min(max(((lcu_y + R.originY) << 2) + mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
+        const int x0 = (qx >> 2) - 3 - EpRefWindows::R, y0 = (qy >> 2) - 3 - EpRefWindows::R;
+        const int stride = (int)R.stride[0], last = R.size[0] - 1;
+        const uint8_t *plane = (const uint8_t *)R.plane[0];
+        constexpr int CPR = EpRefWindows::P / 8, NCH = EpRefWindows::H * CPR;
+        for (int i = t; i < NCH; i += 256) {
+            const int j = i / CPR, m = i - j * CPR, idx = (y0 + j) * stride + x0 + m * 8;
+            uint2 v;
+            if (idx >= 0 && idx + 8 <= last + 1) {
+                __builtin_memcpy(&v, plane + idx, 8);
+            } else {
+                uint8_t e[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    e[q] = plane[min(max(idx + q, 0), last)];
+                __builtin_memcpy(&v, e, 8);
+            }
+            *reinterpret_cast<uint2 *>(&RW.pix[l][j * EpRefWindows::P + m * 8]) = v;
+        }
+        if (t == 0)
+            RW.x0[l] = x0, RW.y0[l] = y0, RW.valid[l] = 1;
     }
 }
 

@@ -36,6 +36,9 @@
 #include <vector>
 #include <mutex>
 #define MD_FN __host__ __device__ __forceinline__
+#ifndef MD_LEAF_CALL
+#define MD_LEAF_CALL __noinline__ /* the heavy leaves of the unit chain (interpolation, transform unit) as functions: one copy of their code and registers of their own */
+#endif
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -60,19 +63,30 @@ struct MdPictureDev {
     const SvtAmdTmvpLcu *tmvp;
     int encode;                   /* 0: mode decision only (no work record, no encode pass) */
     unsigned long long *prof;     /* debug (svt_amd_debug_md_profile): 16 shader-clock sums per LCU, or null */
+    int prof_lcus;                /* LCUs of the picture: the sub-stage sums start behind the stage sums of all of them */
 };
 /* stage clocks of the mode decision of one LCU, taken by lane 0 behind the barrier that ends the stage */
 #define MD_PROF(k)                                                          \
     do {                                                                    \
         if (D.prof && threadIdx.x == 0) {                                   \
             const unsigned long long c_ = __builtin_readcyclecounter();    \
-            M.prof[k] += c_ - M.prof_t, M.prof_t = c_;                      \
+            M.prof[k] += c_ - M.prof_t, M.prof_t = c_, M.prof_s = c_;       \
+        }                                                                   \
+    } while (0)
+/* ... and finer marks inside a stage (svt_amd_debug_md_profile_sub): slot k of 16 gets the clocks since the previous mark of either kind */
+#define MD_SUB(k)                                                           \
+    do {                                                                    \
+        if (D.prof && threadIdx.x == 0) {                                   \
+            const unsigned long long c_ = __builtin_readcyclecounter();    \
+            M.prof[16 + (k)] += c_ - M.prof_s, M.prof_s = c_;               \
         }                                                                   \
     } while (0)
 
-struct MdLocal8 {
+/* HASY: the closed-loop decision keeps the mode decision's luma reconstruction of the LCU (+ ring) here; the open-loop one (P / B pictures of this revision) never reads it */
+template <bool HASY>
+struct MdLocal8T {
     static constexpr int PY = 144, X0 = 16;
-    uint8_t y[65 * PY];
+    uint8_t y[HASY ? 65 * PY : 16];
     uint32_t info[17 * 36]; /* (cy + 1) * 36 + cx + 1: cy in [-1, 16), cx in [-1, 33] */
     alignas(16) uint8_t src[64 * 64]; /* rows of words: the distortion and residual loops read four samples at a time */
     __device__ __forceinline__ uint8_t *at(int x, int y_) { return &y[(y_ + 1) * PY + X0 + x]; }
@@ -97,7 +111,7 @@ struct MdClosedLoop {
     int16_t recon_coeff[MD_MAX_BUF][32 * 32];
     uint8_t best_rec[4][64 * 64];
 };
-#define MD_PRED_SLOTS 6 /* one motion-estimation candidate + up to five merge candidates are evaluated per unit */
+#define MD_PRED_SLOTS 5 /* one motion-estimation candidate + the merge candidates (two or three at the presets' mvMergeSkipModeCount) are evaluated per unit */
 struct MdInterShared {
     /* a wave's chroma prediction of the candidate it works on: the first half of its luma scratch (a wave's tasks follow one another, the luma block is spent by then) */
     __device__ __forceinline__ uint8_t *wpred_c(int wave, int pl) { return wpred[wave] + pl * 1024; }
@@ -118,6 +132,7 @@ struct MdInterShared {
     uint8_t heavyc[MD_MAX_CAND];   /* the candidates whose chroma the fast loop predicts and measures, packed */
     int nheavyc;
     MdFl flc[MD_MAX_BUF][2][4];    /* the chroma full loop's sums per buffer, plane and transform unit */
+    EpRefWindows rw;               /* the luma reference samples around the LCU displaced by the 64x64 unit's motion-estimation vectors, per list (encdec_device.h) */
     uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
     uint8_t fin_leaf[SVT_AMD_LCU_MAX_CUS];
     int nfin;
@@ -128,7 +143,7 @@ template <> struct MdVariant<true> { typedef MdInterShared type; };
 
 template <bool INTER>
 struct MdShared {
-    MdLocal8 L;
+    MdLocal8T<!INTER> L;
     MdLcuState S;
     SvtAmdMdLcu lcu;
     SvtAmdOisLcuResult ois;        /* the LCU's open-loop intra search record */
@@ -147,7 +162,7 @@ struct MdShared {
     unsigned long long merge_cost[MD_MAX_BUF], skip_cost[MD_MAX_BUF], y_bits[MD_MAX_BUF], y_dist[MD_MAX_BUF][2];
     uint32_t full_dist[MD_MAX_BUF];
     int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done, best_first, any_intra;
-    unsigned long long prof[16], prof_t;
+    unsigned long long prof[32], prof_t, prof_s;
     int16_t ref[132], reff[132], border[132];
     typename MdVariant<INTER>::type V;
     int16_t tiles[4][2 * TxRegTile<32>::UNIT];
@@ -169,7 +184,7 @@ union MdEpShared {
 template <bool INTER>
 __device__ __forceinline__ void md_build_refs(MdShared<INTER> &M, const MdStats &st, int lane)
 {
-    MdLocal8 &L = M.L;
+    auto &L = M.L;
     const int N = st.size, nb = N >> 2, lgN = st.lg, n = N;
     const bool pic_left = M.lcu.tile_left && st.x == 0, pic_top = M.lcu.tile_top && st.y == 0;
     const bool pic_right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
@@ -262,7 +277,7 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
  * null; pf: partial-frequency mode (1 = N2: only the low (N/2)^2 coefficients are quantised, measured and priced); type / component: of the
  * candidate and the plane (rate tables).  Returns (every lane) the unit's sums. */
 template <int N>
-__device__ __forceinline__ MdFl md_full_loop_unit(int lane, const uint8_t *src, int srcPitch, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile,
+__device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int srcPitch, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile,
                                                   int16_t *qbuf, int qp, int slice_type, const SvtAmdCabacCost &cost, int type, int intra_mode, int component, int pf)
 {
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
@@ -393,13 +408,13 @@ __device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCan
     EP_WAVE_SYNC();
 }
 /* ... of plane p (0 luma: N x N, 1 / 2 chroma: N/2 x N/2) into dst with pitch = the block's width */
-__device__ __forceinline__ void md_predict_inter_plane(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
-                                                       int tile_first, int tile_step)
+__device__ MD_LEAF_CALL void md_predict_inter_plane(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
+                                                    int tile_first, int tile_step, const EpRefWindows *rw = nullptr)
 {
     int16_t mv[2][2];
     mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
     const int pitch = p ? N >> 1 : N;
-    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, p, lane, mc, [&](int x, int y) { return dst + y * pitch + x; }, tile_first, tile_step);
+    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, p, lane, mc, [&](int x, int y) { return dst + y * pitch + x; }, tile_first, tile_step, rw);
     EP_WAVE_SYNC();
 }
 /* IntraPredictionOl's chroma references of the unit (Codec/EbIntraPrediction.c:5065 UpdateChromaNeighborSamplesArrayOL): SOURCE chroma samples around the
@@ -493,7 +508,7 @@ template <bool INTER>
 __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     const int t = threadIdx.x;
-    MdLocal8 &L = M.L;
+    auto &L = M.L;
     const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
     for (int i = t; i < (int)sizeof(SvtAmdMdLcu); i += 256)
         ((uint8_t *)&M.lcu)[i] = ((const uint8_t *)&D.lcus[lcu])[i];
@@ -534,6 +549,13 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
         md_construct_cu_array(&M.S, &M.lcu);
         M.cu_idx = 0, M.done = 0;
     }
+    if constexpr (INTER) { /* still before the wait for the LCU's neighbours: the reference samples its candidates will most likely read */
+        const SvtAmdMeCuResult me0 = M.V.me[0];
+        int16_t cmv[2][2];
+        cmv[0][0] = me0.x_mv_l0, cmv[0][1] = me0.y_mv_l0, cmv[1][0] = me0.x_mv_l1, cmv[1][1] = me0.y_mv_l1;
+        const bool use[2] = {true, P.slice_type == 0};
+        ep_ref_windows_fill(E, lcu_x, lcu_y, use, cmv, M.V.rw, t);
+    }
 }
 
 /* ModeDecisionLcu of one LCU (its inputs are in LDS: md_lcu_inputs): on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
@@ -541,7 +563,7 @@ template <bool INTER>
 __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    MdLocal8 &L = M.L;
+    auto &L = M.L;
     const int W = (int)P.width, H = (int)P.height;
     const int lw = min(64, W - lcu_x), lh = min(64, H - lcu_y);
     const bool islice = P.slice_type == 2, open_loop = P.intra_md_open_loop != 0;
@@ -578,6 +600,36 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
     }
     __syncthreads();
+    if constexpr (INTER) {
+        /* The staged reference samples were centred on the 64x64 unit's motion-estimation vector before the wait.  The candidates the chain really predicts are mostly merge
+         * candidates = the neighbours' vectors; where those lie elsewhere (periodic or low-texture content: the open-loop search and the decisions disagree) the window of
+         * that list is staged again around the vector of the LCU's left / top neighbour - once per LCU instead of a round trip to HBM per candidate of every unit. */
+        MdMvUnit nbu = M.V.mvu[1 * 18 + 0]; /* (x = -1, y = 0) */
+        int have = (L.info_at(-1, 0) & 0xFF) == MD_INTER && !M.lcu.tile_left;
+        if (!have) {
+            nbu = M.V.mvu[0 * 18 + 1]; /* (x = 0, y = -1) */
+            have = (L.info_at(0, -1) & 0xFF) == MD_INTER && !M.lcu.tile_top;
+        }
+        bool use[2] = {false, false};
+        int16_t cmv[2][2] = {{0, 0}, {0, 0}};
+        if (have) {
+            const SvtAmdMeCuResult me0 = M.V.me[0];
+            const int mex[2] = {me0.x_mv_l0, me0.x_mv_l1}, mey[2] = {me0.y_mv_l0, me0.y_mv_l1};
+            for (int l = 0; l < (P.slice_type == 0 ? 2 : 1); l++)
+                if ((nbu.dir == MD_BI || nbu.dir == l) && (abs(nbu.mv[l].x - mex[l]) > 16 || abs(nbu.mv[l].y - mey[l]) > 16))
+                    use[l] = true, cmv[l][0] = nbu.mv[l].x, cmv[l][1] = nbu.mv[l].y;
+        }
+        if (use[0] || use[1]) { /* (uniform: every thread read the same LDS words) */
+            const int x0k[2] = {M.V.rw.x0[0], M.V.rw.x0[1]}, y0k[2] = {M.V.rw.y0[0], M.V.rw.y0[1]}, vk[2] = {M.V.rw.valid[0], M.V.rw.valid[1]};
+            __syncthreads();
+            ep_ref_windows_fill(E, lcu_x, lcu_y, use, cmv, M.V.rw, t);
+            if (t == 0)
+                for (int l = 0; l < 2; l++)
+                    if (!use[l]) /* the list that keeps its window (the fill marks an unused list invalid) */
+                        M.V.rw.x0[l] = x0k[l], M.V.rw.y0[l] = y0k[l], M.V.rw.valid[l] = vk[l];
+            __syncthreads();
+        }
+    }
     MD_PROF(0);
     const SvtAmdOisLcuResult *ois = &M.ois;
     const int pf = md_pf_mode(&P);
@@ -605,7 +657,21 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     ncand = md_intra_candidates(&P, &M.lcu, ois, leaf, &st, M.cand);
             M.ncand = ncand; /* the intra candidates so far (P / B pictures: the lists below are made by three waves) */
         }
+        MD_SUB(0);
         if constexpr (INTER) {
+            /* the fourth wave, from the unit's first moment: its intra reference (only units below 64x64 have intra candidates) - source samples from HBM in the open-loop
+             * decision, a round trip that now runs under the contexts, the neighbours' vectors and the candidate lists of the other waves instead of holding their barrier */
+            if (wave == 3) {
+                const MdStats st = md_stats(M.lcu.leaf_index[M.cu_idx]);
+                if (st.depth != 0) {
+                    if (open_loop)
+                        md_build_refs_ol(D, M, st, lcu_x + st.x, lcu_y + st.y, W, H, lane);
+                    else
+                        md_build_refs(M, st, lane);
+                    if (M.lcu.chroma_encode_mode == 1 && open_loop)
+                        md_build_refs_ol_chroma(D, M.V.refc, st.size, lcu_x + st.x, lcu_y + st.y, W, H, lane);
+                }
+            }
             /* the spatial neighbours with the availability GenerateL0L1AmvpMergeLists derives (EbAdaptiveMotionVectorPrediction.c:2256-2340): a lane of the second wave
              * each, beside lane 0's contexts and intra candidates */
             if (wave == 1 && lane < 5) {
@@ -625,21 +691,14 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             /* GenerateL0L1AmvpMergeLists: the AMVP candidates of list 0, of list 1 and the merge candidates share their inputs and nothing else - lane 0 of waves
              * 0, 1 and 2 makes one each (three chains of LDS round trips side by side instead of one after the other) */
             __syncthreads();
+            MD_SUB(1);
             if (lane == 0 && wave < 3) {
                 const MdStats st = md_stats(M.leaf);
                 md_amvp_merge_lists_parts(&P, D.X, M.V.nb, D.X->tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T, 1 << wave);
-            } else if (wave == 3) { /* meanwhile the fourth wave: the unit's intra reference (only units below 64x64 have intra candidates) */
-                const MdStats st = md_stats(M.leaf);
-                if (st.depth != 0) {
-                    if (open_loop)
-                        md_build_refs_ol(D, M, st, lcu_x + st.x, lcu_y + st.y, W, H, lane);
-                    else
-                        md_build_refs(M, st, lane);
-                    if (M.lcu.chroma_encode_mode == 1 && open_loop)
-                        md_build_refs_ol_chroma(D, M.V.refc, st.size, lcu_x + st.x, lcu_y + st.y, W, H, lane);
-                }
             }
+            MD_SUB(2);
             __syncthreads();
+            MD_SUB(3);
         }
         if constexpr (INTER) {
             /* the inter candidates (md_inter_candidates, md_logic.h): the motion-estimation candidates and the merge candidates are independent of one another - lanes
@@ -690,6 +749,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 EP_WAVE_SYNC();
             }
         }
+        MD_SUB(4);
         if (t == 0) {
             const int leaf = M.leaf;
             const MdStats st = md_stats(leaf);
@@ -703,6 +763,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             const int width = st.depth == 0 ? 5 : 8;
             M.ncand = ncand, M.buffer_total = bufferTotal, M.max_buffers = bufferTotal + 1 < width ? bufferTotal + 1 : width;
         }
+        MD_SUB(5);
         if (wave == 0) { /* a lane per candidate (MD_MAX_CAND <= 64): what the candidate list implies for the loops below */
             EP_WAVE_SYNC();
             const int nc = M.ncand, lf = M.leaf;
@@ -770,6 +831,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             if (lane == 0)
                 M.best_first = bestFirst;
         }
+        MD_SUB(6);
         __syncthreads();
         MD_PROF(1);
         const int leaf = M.leaf, ncand = M.ncand;
@@ -815,7 +877,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if constexpr (INTER) {
                         const int sl = M.V.slot[c], n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
                         uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
-                        md_predict_inter_plane(E, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1);
+                        md_predict_inter_plane(E, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1, &M.V.rw);
+                        MD_SUB(7);
                         if (luma && tiled64) {
                             const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
                             for (int e = 4 * lane; e < 32 * 32; e += 256) { /* v_sad_u8: four samples a word */
@@ -854,6 +917,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     }
                 }
                 sad = md_wave_sum(sad);
+                MD_SUB(8);
                 if (lane == 0 && sad) {
                     if (luma)
                         atomicAdd(&M.sad[c], sad);
@@ -887,6 +951,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 }
                 M.costs[i] = cst, M.fast_rate[i] = rate;
             }
+            MD_SUB(9);
             /* md_fast_loop_buffers (md_logic.h; ProductPerformFastLoop's second loop, :1990-2179) with the buffers in lanes 0..7 instead of LDS: the candidates
              * arrive from the last to the first, each goes into the buffer with the highest cost (an unused one first) = the FIRST buffer holding the maximum
              * over [0, maxBuffers) - the reference's scan starts at buffer 0, moves on a strictly greater cost and stops at an unused (all-ones) one; its
@@ -919,6 +984,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     highest = h;
                 }
             }
+            MD_SUB(10);
             if (lane < MD_MAX_BUF) {
                 M.B.fast_cost[lane] = bcost, M.B.full_cost[lane] = ~0ull, M.B.cand[lane] = (int16_t)bcand, M.B.pred[lane] = (int16_t)bpred;
                 M.types[lane] = bcand >= 0 ? M.cand[bcand].type : 0, M.ycbf[lane] = 0, M.full_dist[lane] = 0, M.merge_cost[lane] = M.skip_cost[lane] = 0;
@@ -951,7 +1017,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if (!(M.V.slot[pci] >= 0 && M.evaluated[pci])) {
                         sync = true;
                         if (wave == f)
-                            md_predict_inter(E, M.cand[pci], x0, y0, N, lane, M.V.mc[wave], M.V.wpred[f]);
+                            md_predict_inter_plane(E, M.cand[pci], x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1, &M.V.rw);
                     }
                 }
                 if (sync)
@@ -988,7 +1054,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if (M.V.slot[pci] >= 0 && M.evaluated[pci])
                         pred = M.V.cpred[M.V.slot[pci]]; /* the fast loop's prediction of this candidate is still there */
                     else
-                        md_predict_inter(E, pc, x0, y0, N, lane, M.V.mc[wave], pred);
+                        md_predict_inter_plane(E, pc, x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
                 }
             } else {
                 const int mode = pc.intra_mode;
@@ -998,7 +1064,9 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
                 EP_WAVE_SYNC();
             }
+            MD_SUB(12);
             md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, M.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
+            MD_SUB(13);
         }
         if constexpr (INTER) {
             /* CHROMA_MODE_FULL (PerformFullLoop :4443-4560): the chroma pair of every survivor - ChromaPrediction (the candidate's OWN prediction: the fast loop's when it
@@ -1109,6 +1177,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 if (P.full_loop_escape && !islice && ty == MD_INTER && cs < bestFullCost)
                     prevRootCbf = yc, bestFullCost = cs;
             }
+            MD_SUB(14);
             if (have && ((kept >> lane) & 1ull)) {
                 M.ycbf[b] = ycbf, M.full_dist[b] = (uint32_t)dist[0], M.B.full_cost[b] = full;
                 M.merge_cost[b] = mc, M.skip_cost[b] = sc, M.y_bits[b] = bits, M.y_dist[b][0] = dist[0], M.y_dist[b][1] = dist[1];
@@ -1415,9 +1484,9 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         unsigned long long c_wait = 0, c_md = 0, c_work = 0;
         if (D.prof && threadIdx.x == 0) {
             c_wait = __builtin_readcyclecounter();
-            for (int k = 0; k < 16; k++)
+            for (int k = 0; k < 32; k++)
                 U.md.prof[k] = 0;
-            U.md.prof_t = c_wait;
+            U.md.prof_t = U.md.prof_s = c_wait;
         }
         md_lcu<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
         __syncthreads();
@@ -1433,6 +1502,9 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
             q[9] += c_md - U.md.prof_t;      /* the LCU's state leaving LDS */
             q[12] += c_wait - c_ticket;       /* waiting for the LCU's neighbours */
             q[13] += U.md.prof[13], q[14] += U.md.prof[14]; /* candidates of the fast loops / units tested */
+            unsigned long long *q2 = D.prof + 16 * (size_t)D.prof_lcus + 16 * (size_t)lcu; /* the sub-stage sums follow the stage sums of all LCUs */
+            for (int k = 0; k < 16; k++)
+                q2[k] += U.md.prof[16 + k];
             q[15] += 1;
         }
         if (D.encode) {
@@ -1665,7 +1737,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         n_active = pic->md_rect_n, d_order = pic->d_order_md;
         HIP_TRY(hipMemsetAsync(m->d_out, 0, sizeof(SvtAmdMdLcuOut) * (size_t)n, st));
     }
-    m->d.prof = m->d_prof;
+    m->d.prof = m->d_prof, m->d.prof_lcus = n;
     m->d.encode = !X || works || results; /* P / B pictures: without a place for the work / result records, the mode decision alone */
     if (ois)
         HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1693,7 +1765,12 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     }
     /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
      * find work (all of them resident: a workgroup that waits holds its CU) */
-    int grid = 2 * ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2;
+    /* ... but a workgroup holds a whole CU (its LDS) while it waits, and the encoder keeps several pictures in flight: five 62-workgroup launches do not fit the 256 CUs and
+     * slow one another down (profiles/r04_m_timeline_*.txt: 100 - 270 ms per call with six pictures on the device).  The wavefront of a picture is (W/64 + 1) / 2 LCUs wide at
+     * its widest and 16 on average at 4K; one workgroup per LCU of the widest front plus a few for the encode passes behind it costs a lone picture 3 - 4 % and lets eight
+     * pictures share the GPU (profiles/r04_e_md_flights.txt). */
+    int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2 + (wl + 7) / 8;
+    (void)0;
     {   /* debug (SVT_AMD_MD_GRID): workgroups of the launch - how many a picture really needs decides how many pictures share the GPU */
         const char *fg = getenv("SVT_AMD_MD_GRID");
         const int forced = fg ? atoi(fg) : 0;
@@ -1765,8 +1842,8 @@ extern "C" int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture 
         return rc;
     const size_t bytes = sizeof(unsigned long long) * 16 * (size_t)pic->nlcu;
     if (!m->d_prof) {
-        HIP_TRY(hipMalloc((void **)&m->d_prof, bytes));
-        HIP_TRY(hipMemset(m->d_prof, 0, bytes));
+        HIP_TRY(hipMalloc((void **)&m->d_prof, 2 * bytes)); /* stage sums of every LCU, then sub-stage sums of every LCU */
+        HIP_TRY(hipMemset(m->d_prof, 0, 2 * bytes));
     }
     if (out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1787,3 +1864,24 @@ extern "C" int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPictur
         *workgroups = pic->md->grid;
     return SVT_AMD_OK;
 }
+
+/* debug: the finer marks of the mode-decision kernel (MD_SUB): 16 sums per LCU, collected together with svt_amd_debug_md_profile's (which switches the collection on) */
+extern "C" int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out)
+{
+    if (!ctx || !pic || !pic->md || !pic->md->d_prof || !out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t bytes = sizeof(unsigned long long) * 16 * (size_t)pic->nlcu;
+    HIP_TRY(hipMemcpy(out, pic->md->d_prof + 16 * (size_t)pic->nlcu, bytes, hipMemcpyDeviceToHost));
+    return SVT_AMD_OK;
+}
+
+#ifdef EP_DEBUG_WINDOW_COUNTS
+extern "C" __attribute__((visibility("default"))) int svt_amd_debug_window_counts(unsigned *out)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ep_dbg_counts), sizeof(unsigned) * 8));
+    return SVT_AMD_OK;
+}
+#endif
