@@ -346,6 +346,214 @@ __device__ __forceinline__ void ep_inter_predict_core(const EpPicture &P, int ab
     }
 }
 
+/* ---- the same interpolation for 8-bit planes with everything a wave repeats per call decided at compile time (tile size, tap count) and the multiply-adds on the dot-product
+ * units: v_dot4c_i32_i8 for the horizontal pass - the window's samples as SIGNED bytes s - 128 (one v_xor per word), so that sum t_k s_k - 8192 = sum t_k (s_k - 128): exactly the
+ * offset the reference subtracts from the luma intermediate (the taps of a position sum to 64) -, v_dot2c_i32_i16 for the vertical pass on the transposed intermediate's
+ * packed pairs.  Same values as ep_inter_predict_core<uint8_t> sample for sample (the mode decision's tests compare decisions that hinge on them); 2 - 3x fewer instructions
+ * on the unit chain of the mode decision, where a wave has nobody to hide them behind. */
+constexpr uint32_t ep_pack4(int a, int b, int c, int d) { return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24); }
+constexpr uint32_t ep_pack2(int a, int b) { return (uint32_t)(a & 0xFFFF) | ((uint32_t)(b & 0xFFFF) << 16); }
+/* taps of fractional position f (wave-uniform) as SELECTS BETWEEN IMMEDIATES - a table, in whatever memory, is a load (and its latency) on every call: bytes k = 0..3 / 4..7 for
+ * the horizontal pass (h), pairs of 16-bit values for the vertical one (v).  Luma: the 8-tap filters of quarter positions 0..3; chroma: the 4-tap filters of eighth positions 0..7
+ * (H.265 tables 8-11 / 8-12 = c_ep_luma_taps / c_ep_chroma_taps above). */
+#define EP_SEL4(f, a, b, c, d) ((f) == 0 ? (a) : (f) == 1 ? (b) : (f) == 2 ? (c) : (d))
+#define EP_SEL8(f, a, b, c, d, e, g, h, i) ((f) < 4 ? EP_SEL4(f, a, b, c, d) : EP_SEL4((f) - 4, e, g, h, i))
+template <bool CHROMA>
+__device__ __forceinline__ void ep_taps8(int f, uint32_t h[2], uint32_t v[4])
+{
+    if (!CHROMA) {
+        h[0] = EP_SEL4(f, ep_pack4(0, 0, 0, 64), ep_pack4(-1, 4, -10, 58), ep_pack4(-1, 4, -11, 40), ep_pack4(0, 1, -5, 17));
+        h[1] = EP_SEL4(f, ep_pack4(0, 0, 0, 0), ep_pack4(17, -5, 1, 0), ep_pack4(40, -11, 4, -1), ep_pack4(58, -10, 4, -1));
+        v[0] = EP_SEL4(f, ep_pack2(0, 0), ep_pack2(-1, 4), ep_pack2(-1, 4), ep_pack2(0, 1));
+        v[1] = EP_SEL4(f, ep_pack2(0, 64), ep_pack2(-10, 58), ep_pack2(-11, 40), ep_pack2(-5, 17));
+        v[2] = EP_SEL4(f, ep_pack2(0, 0), ep_pack2(17, -5), ep_pack2(40, -11), ep_pack2(58, -10));
+        v[3] = EP_SEL4(f, ep_pack2(0, 0), ep_pack2(1, 0), ep_pack2(4, -1), ep_pack2(4, -1));
+    } else {
+        h[0] = EP_SEL8(f, ep_pack4(0, 64, 0, 0), ep_pack4(-2, 58, 10, -2), ep_pack4(-4, 54, 16, -2), ep_pack4(-6, 46, 28, -4), ep_pack4(-4, 36, 36, -4), ep_pack4(-4, 28, 46, -6),
+                       ep_pack4(-2, 16, 54, -4), ep_pack4(-2, 10, 58, -2));
+        h[1] = 0;
+        v[0] = EP_SEL8(f, ep_pack2(0, 64), ep_pack2(-2, 58), ep_pack2(-4, 54), ep_pack2(-6, 46), ep_pack2(-4, 36), ep_pack2(-4, 28), ep_pack2(-2, 16), ep_pack2(-2, 10));
+        v[1] = EP_SEL8(f, ep_pack2(0, 0), ep_pack2(10, -2), ep_pack2(16, -2), ep_pack2(28, -4), ep_pack2(36, -4), ep_pack2(46, -6), ep_pack2(54, -4), ep_pack2(58, -2));
+        v[2] = v[3] = 0;
+    }
+}
+__device__ __forceinline__ int ep_sdot2(uint32_t a, uint32_t b, int c)
+{
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    v2s x, y;
+    __builtin_memcpy(&x, &a, 4), __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_sdot2(x, y, c, false);
+}
+/* both passes of one tile of TN x TN samples of one list: window in M.win -> dst / M.raw.  mode: 0 uni-prediction, 1 first list of a bi-predicted tile, 2 its second list */
+template <int TN, bool CHROMA>
+__device__ __forceinline__ void ep_mc8_tile(EpMcScratch<uint8_t> &M, int lane, int fx, int fy, int mode, uint8_t *dst, int pitch)
+{
+    constexpr int WP = EpMcScratch<uint8_t>::WP, TP = EpMcScratch<uint8_t>::TP;
+    constexpr int NT = CHROMA ? 4 : 8, ROWS = TN + NT - 1, SEG = TN < 8 ? TN : 8, SPR = TN / SEG, ITEMS = ROWS * SPR;
+    constexpr int LGT = TN == 32 ? 5 : TN == 16 ? 4 : TN == 8 ? 3 : 2;
+    uint32_t hx[2], vx[4], hy[2], vy[4];
+    ep_taps8<CHROMA>(fx, hx, vx);
+    ep_taps8<CHROMA>(fy, hy, vy);
+    /* horizontal pass: an item = a run of SEG outputs of one window row, 16 bytes of the row as four words */
+#pragma unroll
+    for (int i0 = 0; i0 < ITEMS; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < ITEMS) {
+            const int j = SPR == 1 ? i : i / SPR, x0 = SPR == 1 ? 0 : (i - j * SPR) * SEG;
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(&M.win[j * WP + x0]);
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                w[k] = (k * 4 < SEG + NT - 1 ? wp[k] : 0u) ^ 0x80808080u;
+#pragma unroll
+            for (int o = 0; o < SEG; o++) {
+                const uint32_t lo = (o & 3) ? __builtin_amdgcn_alignbyte(w[(o >> 2) + 1], w[o >> 2], o & 3) : w[o >> 2];
+                int hs;
+                if (CHROMA) {
+                    hs = __builtin_amdgcn_sdot4((int)hx[0], (int)lo, 8192, false); /* no offset is subtracted from an 8-bit chroma intermediate: + 128 * 64 */
+                } else {
+                    const uint32_t hi = (o & 3) ? __builtin_amdgcn_alignbyte(w[((o >> 2) + 2) & 3], w[(o >> 2) + 1], o & 3) : w[(o >> 2) + 1];
+                    hs = __builtin_amdgcn_sdot4((int)hx[1], (int)hi, __builtin_amdgcn_sdot4((int)hx[0], (int)lo, 0, false), false);
+                }
+                M.tmp[(x0 + o) * TP + j] = (int16_t)hs;
+            }
+        }
+    }
+    EP_WAVE_SYNC();
+    /* vertical pass: a lane owns a column and RUN rows; the column of the transposed intermediate as packed pairs */
+    constexpr int RUN = TN >= 8 ? (TN * TN) / 64 : 1, NIN = RUN + NT - 1, NW = (NIN + 2) / 2 + 1;
+    const int x = lane & (TN - 1), y0 = (lane >> LGT) * RUN;
+    if (y0 < TN) {
+        const int base = y0 & ~1, odd = (y0 & 1) * 16; /* RUN >= 4: y0 is a multiple of 4 */
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(&M.tmp[x * TP + base]);
+        uint32_t d[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+            d[k] = cp[k];
+#pragma unroll
+        for (int o = 0; o < RUN; o++) {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < NT / 2; k++) {
+                const int m = (o >> 1) + k;
+                const uint32_t pr = RUN >= 4 ? ((o & 1) ? __builtin_amdgcn_alignbit(d[m + 1], d[m], 16) : d[m]) : __builtin_amdgcn_alignbit(d[m + 1], d[m], odd);
+                sum = ep_sdot2(vy[k], pr, sum);
+            }
+            const int y = y0 + o, idx = (y << LGT) + x;
+            if (mode == 0) {
+                dst[y * pitch + x] = (uint8_t)min(255, max(0, (sum + ((CHROMA ? 0 : 8192) << 6) + (1 << 11)) >> 12));
+            } else if (mode == 1) {
+                M.raw[idx] = (int16_t)(sum >> 6);
+            } else { /* BiPredClipping (Offset5 / ChromaOffset5, Codec/EbDefinitions.h:1022-1030) */
+                const int a = (int)M.raw[idx] + (int)(int16_t)(sum >> 6);
+                dst[y * pitch + x] = (uint8_t)min(255, max(0, (a + (CHROMA ? 64 : 16448)) >> 7));
+            }
+        }
+    }
+    EP_WAVE_SYNC();
+}
+/* the core for 8-bit planes: dst = the block's first sample, pitch in samples (plane p of the 2Nx2N unit at (abs_x, abs_y)) */
+__device__ __forceinline__ void ep_inter_predict_core8(const EpRefPlanes *refs /* [2]: P.ref, or the caller's copy of it in LDS */, int abs_x, int abs_y, int N, int inter_dir,
+                                                       const int16_t (*mv)[2], int p, int lane, EpMcScratch<uint8_t> &M, uint8_t *dst, int pitch, int tile_first, int tile_step,
+                                                       const EpRefWindows *RW)
+{
+    constexpr int WP = EpMcScratch<uint8_t>::WP;
+    const bool chroma = p != 0;
+    const int n = chroma ? N >> 1 : N, tn = n > 32 ? 32 : n;
+    const int ntaps = chroma ? 4 : 8, first = chroma ? -1 : -3, rows = tn + ntaps - 1;
+    const bool bi = inter_dir == 2;
+    const int ntile = n > 32 ? 4 : 1;
+#ifdef EP_DEBUG_WINDOW_COUNTS
+    unsigned long long dbg_t_ = __builtin_readcyclecounter();
+#endif
+    for (int ti = tile_first; ti < ntile; ti += tile_step) {
+        const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
+        bool second = false;
+        for (int l = 0; l < 2; l++) {
+            if (!(bi || inter_dir == l))
+                continue;
+            const EpRefPlanes R = refs[l]; /* one read of the whole record */
+            const int qx = min(max(((abs_x + R.originX) << 2) + mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
+            const int qy = min(max(((abs_y + R.originY) << 2) + mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
+            const int ix = (chroma ? qx >> 3 : qx >> 2) + tx0, iy = (chroma ? qy >> 3 : qy >> 2) + ty0;
+            const int fx = __builtin_amdgcn_readfirstlane(chroma ? qx & 7 : qx & 3), fy = __builtin_amdgcn_readfirstlane(chroma ? qy & 7 : qy & 3);
+            const int cpr = (rows + 7) >> 3, nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
+            bool staged = false;
+            EP_DBG_CLK(4);
+#ifdef EP_DEBUG_WINDOW_COUNTS
+            if (lane == 0 && !chroma)
+                atomicAdd(&g_ep_dbg_counts[0], 1u);
+#endif
+            if (RW && !chroma && RW->valid[l]) {
+                const int rx = ix + first - RW->x0[l], ry = iy + first - RW->y0[l];
+                if (rx >= 0 && ry >= 0 && rx + cpr * 8 <= EpRefWindows::P && ry + rows <= EpRefWindows::H) {
+                    staged = true;
+                    for (int i = lane; i < nchunk; i += 64) {
+                        const int j = (i * inv) >> 16, m = i - j * cpr, o = (ry + j) * EpRefWindows::P + rx + m * 8, sh = o & 3;
+                        const uint32_t *wp = reinterpret_cast<const uint32_t *>(&RW->pix[l][o & ~3]);
+                        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        uint2 v;
+                        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh), v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                        *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v;
+                    }
+                }
+            }
+            if (!staged) {
+                const int stride = (int)R.stride[chroma], last = R.size[chroma] - 1;
+                const uint8_t *plane = (const uint8_t *)R.plane[p];
+                const int base0 = (iy + first) * stride + ix + first;
+                for (int i0 = 0; i0 < nchunk; i0 += 256) {
+                    uint2 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i < nchunk) {
+                            const int j = (i * inv) >> 16, m = i - j * cpr, idx = base0 + j * stride + m * 8;
+                            if (idx >= 0 && idx + 8 <= last + 1) {
+                                __builtin_memcpy(&v[u], plane + idx, 8);
+                            } else {
+                                uint8_t e[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++)
+                                    e[q] = plane[min(max(idx + q, 0), last)];
+                                __builtin_memcpy(&v[u], e, 8);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i < nchunk) {
+                            const int j = (i * inv) >> 16, m = i - j * cpr;
+                            *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v[u];
+                        }
+                    }
+                }
+            }
+            EP_WAVE_SYNC();
+            EP_DBG_CLK(5);
+            const int mode = !bi ? 0 : (second ? 2 : 1);
+            uint8_t *td = dst + ty0 * pitch + tx0;
+            if (!chroma) {
+                switch (tn) {
+                case 32: ep_mc8_tile<32, false>(M, lane, fx, fy, mode, td, pitch); break;
+                case 16: ep_mc8_tile<16, false>(M, lane, fx, fy, mode, td, pitch); break;
+                default: ep_mc8_tile<8, false>(M, lane, fx, fy, mode, td, pitch); break;
+                }
+            } else {
+                switch (tn) {
+                case 32: ep_mc8_tile<32, true>(M, lane, fx, fy, mode, td, pitch); break;
+                case 16: ep_mc8_tile<16, true>(M, lane, fx, fy, mode, td, pitch); break;
+                case 8: ep_mc8_tile<8, true>(M, lane, fx, fy, mode, td, pitch); break;
+                default: ep_mc8_tile<4, true>(M, lane, fx, fy, mode, td, pitch); break;
+                }
+            }
+            EP_DBG_CLK(6);
+            second = true;
+        }
+    }
+}
+
 __device__ __forceinline__ void ep_ref_windows_fill(const EpPicture &P, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t)
 {
     for (int l = 0; l < 2; l++) {

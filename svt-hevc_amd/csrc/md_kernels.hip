@@ -36,6 +36,11 @@
 #include <vector>
 #include <mutex>
 #define MD_FN __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MD_LDS(ptr) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)(ptr)))
+#else
+#define MD_LDS(ptr) ((void)0)
+#endif
 #ifndef MD_LEAF_CALL
 #define MD_LEAF_CALL __noinline__ /* the heavy leaves of the unit chain (interpolation, transform unit) as functions: one copy of their code and registers of their own */
 #endif
@@ -132,6 +137,9 @@ struct MdInterShared {
     uint8_t heavyc[MD_MAX_CAND];   /* the candidates whose chroma the fast loop predicts and measures, packed */
     int nheavyc;
     MdFl flc[MD_MAX_BUF][2][4];    /* the chroma full loop's sums per buffer, plane and transform unit */
+    EpRefPlanes refs[2];           /* the reference pictures' plane pointers and geometry beside the LCU (the kernel argument they come from lives in memory as soon as a
+                                    * function takes it by reference: a chain of loads per interpolation otherwise) */
+    SvtAmdMdInter X;               /* the picture's inter controls beside the LCU: read per unit (a load from HBM each otherwise) */
     EpRefWindows rw;               /* the luma reference samples around the LCU displaced by the 64x64 unit's motion-estimation vectors, per list (encdec_device.h) */
     uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
     uint8_t fin_leaf[SVT_AMD_LCU_MAX_CUS];
@@ -282,6 +290,9 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
 {
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
     constexpr int fs1 = N == 32 ? 6 : N == 16 ? 4 : N == 8 ? 2 : 1, fs2 = N == 4 ? 8 : 9, wrap = N == 32 ? 2 : N == 16 ? 1 : 0;
+    MD_LDS(src), MD_LDS(pred), MD_LDS(tile), MD_LDS(qbuf), MD_LDS(&cost);
+    if (recon_coeff)
+        MD_LDS(recon_coeff);
     const int r = lane & (N - 1);
     const bool active = lane < N;
     int x[N];
@@ -331,7 +342,8 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     EP_WAVE_SYNC(); /* qbuf is written */
     const int lga = LG - pf, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
     const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
-    const uint32_t b32 = coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1));
+    /* nz is the whole unit's count and the same in every lane: a unit without levels (most merge candidates of a B picture at these QPs) has no bits to estimate */
+    const uint32_t b32 = nz ? coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1)) : 0u;
     MdFl o;
     o.nz = nz, o.d0 = nz ? d0 : d1, o.d1 = d1, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
     return o;
@@ -408,13 +420,16 @@ __device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCan
     EP_WAVE_SYNC();
 }
 /* ... of plane p (0 luma: N x N, 1 / 2 chroma: N/2 x N/2) into dst with pitch = the block's width */
-__device__ MD_LEAF_CALL void md_predict_inter_plane(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
-                                                    int tile_first, int tile_step, const EpRefWindows *rw = nullptr)
+__device__ MD_LEAF_CALL void md_predict_inter_plane(const EpRefPlanes *refs, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
+                                                    int tile_first, int tile_step, const EpRefWindows *rw)
 {
     int16_t mv[2][2];
     mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
     const int pitch = p ? N >> 1 : N;
-    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, p, lane, mc, [&](int x, int y) { return dst + y * pitch + x; }, tile_first, tile_step, rw);
+    /* a function's pointer arguments are generic: tell the compiler which of them point into LDS, or every access becomes a FLAT instruction (slower than ds_*, and it
+     * waits on both memory counters) */
+    MD_LDS(&mc), MD_LDS(dst), MD_LDS(rw), MD_LDS(refs); /* (the candidate is the caller's copy in registers / private memory) */
+    ep_inter_predict_core8(refs, x0, y0, N, c.dir, mv, p, lane, mc, dst, pitch, tile_first, tile_step, rw);
     EP_WAVE_SYNC();
 }
 /* IntraPredictionOl's chroma references of the unit (Codec/EbIntraPrediction.c:5065 UpdateChromaNeighborSamplesArrayOL): SOURCE chroma samples around the
@@ -524,6 +539,12 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
     if constexpr (INTER) {
         for (int i = t; i < (int)(sizeof(M.V.me) / 4); i += 256)
             ((uint32_t *)M.V.me)[i] = ((const uint32_t *)D.me[lcu].pu)[i];
+        static_assert(sizeof(EpRefPlanes) % 4 == 0, "record sizes");
+        for (int i = t; i < (int)(2 * sizeof(EpRefPlanes) / 4); i += 256)
+            ((uint32_t *)M.V.refs)[i] = ((const uint32_t *)E.ref)[i];
+        static_assert(sizeof(SvtAmdMdInter) % 4 == 0, "record sizes");
+        for (int i = t; i < (int)(sizeof(SvtAmdMdInter) / 4); i += 256)
+            ((uint32_t *)&M.V.X)[i] = ((const uint32_t *)D.X)[i];
         if (D.X->tmvp_enable)
             for (int i = t; i < (int)(2 * sizeof(SvtAmdTmvpLcu) / 4); i += 256)
                 ((uint32_t *)M.V.tmvp)[i] = ((const uint32_t *)&D.tmvp[lcu])[i];
@@ -560,8 +581,12 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
 
 /* ModeDecisionLcu of one LCU (its inputs are in LDS: md_lcu_inputs): on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
 template <bool INTER>
-__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
+__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &Pg, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
+    /* the picture's controls as the unit loop reads them: the copies md_lcu_inputs left beside the LCU in LDS, not the records in HBM (a unit's scalar stages read dozens
+     * of these fields one after the other - each a round trip of its own from global memory) */
+    const SvtAmdMdPicture &P = M.pic;
+    (void)Pg;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     auto &L = M.L;
     const int W = (int)P.width, H = (int)P.height;
@@ -694,7 +719,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             MD_SUB(1);
             if (lane == 0 && wave < 3) {
                 const MdStats st = md_stats(M.leaf);
-                md_amvp_merge_lists_parts(&P, D.X, M.V.nb, D.X->tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T, 1 << wave);
+                md_amvp_merge_lists_parts(&P, &M.V.X, M.V.nb, M.V.X.tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T, 1 << wave);
             }
             MD_SUB(2);
             __syncthreads();
@@ -877,7 +902,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if constexpr (INTER) {
                         const int sl = M.V.slot[c], n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
                         uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
-                        md_predict_inter_plane(E, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1, &M.V.rw);
+                        md_predict_inter_plane(M.V.refs, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1, &M.V.rw);
                         MD_SUB(7);
                         if (luma && tiled64) {
                             const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
@@ -941,7 +966,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     uint32_t cw = 0;
                     if constexpr (INTER) {
                         if (M.lcu.chroma_encode_mode == 1) /* the chroma pair's SAD with the noise-class rule (:2079-2094) */
-                            distc = M.cand[i].mpm ? 0 : md_fast_chroma_noise_rule(&M.lcu, N, &M.cand[i], M.V.sadc[i]), cw = D.X->chroma_weight;
+                            distc = M.cand[i].mpm ? 0 : md_fast_chroma_noise_rule(&M.lcu, N, &M.cand[i], M.V.sadc[i]), cw = M.V.X.chroma_weight;
                     }
                     cst = M.cand[i].type == MD_INTER ? md_inter_fast_cost_c(&P, &st, &M.S.cu[leaf], &M.cand[i], dist, distc, cw, !M.lcu.cmplx_noise, (uint64_t *)&rate)
                           : islice                  ? md_intra_fast_cost_islice(&P, &st, &M.S.cu[leaf], M.cand[i].intra_mode, dist, (uint64_t *)&rate)
@@ -1017,7 +1042,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if (!(M.V.slot[pci] >= 0 && M.evaluated[pci])) {
                         sync = true;
                         if (wave == f)
-                            md_predict_inter_plane(E, M.cand[pci], x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1, &M.V.rw);
+                            md_predict_inter_plane(M.V.refs, M.cand[pci], x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1, &M.V.rw);
                     }
                 }
                 if (sync)
@@ -1054,7 +1079,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if (M.V.slot[pci] >= 0 && M.evaluated[pci])
                         pred = M.V.cpred[M.V.slot[pci]]; /* the fast loop's prediction of this candidate is still there */
                     else
-                        md_predict_inter_plane(E, pc, x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
+                        md_predict_inter_plane(M.V.refs, pc, x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
                 }
             } else {
                 const int mode = pc.intra_mode;
@@ -1085,7 +1110,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     } else {
                         uint8_t *pw = M.V.wpred_c(wave, pl);
                         if (cd.type == MD_INTER) {
-                            md_predict_inter_plane(E, cd, x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1);
+                            md_predict_inter_plane(M.V.refs, cd, x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw);
                         } else {
                             const int mode = cd.intra_mode;
                             const int16_t *use = M.V.refc[pl];
@@ -1149,9 +1174,9 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                             }
                         const uint64_t yd[2] = {dist[0], dist[1]};
                         if (c.type == MD_INTER)
-                            full = md_inter_full_cost(&PL, D.X->chroma_weight, &M.S.cu[leaf], &c, N, ycbf, cbf, M.fast_rate[ci], yd, cdist, bits, cbits, &mc, &sc);
+                            full = md_inter_full_cost(&PL, M.V.X.chroma_weight, &M.S.cu[leaf], &c, N, ycbf, cbf, M.fast_rate[ci], yd, cdist, bits, cbits, &mc, &sc);
                         else
-                            full = md_intra_full_cost_pslice(&PL, D.X->chroma_weight, N, ycbf, cbf, M.fast_rate[ci], dist[0], cdist, bits, cbits);
+                            full = md_intra_full_cost_pslice(&PL, M.V.X.chroma_weight, N, ycbf, cbf, M.fast_rate[ci], dist[0], cdist, bits, cbits);
                     }
                 }
                 if (with_chroma)
@@ -1336,8 +1361,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
 /* what EncodePass will do with the inter units of the LCU's final tree (Codec/EbCodingLoop.c:3838-3882): AMVP units as they are; merge units by the
  * merge / skip costs completed with chroma (AddChromaEncDec, Codec/EbProductCodingLoop.c:4158-4349: chroma prediction + chroma full loop +
  * MergeSkipFullCost), a wave per unit.  -> M.V.ep_kind[leaf] */
-__device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, MdShared<true> &M, int lcu_x, int lcu_y)
+__device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &Pg, MdShared<true> &M, int lcu_x, int lcu_y)
 {
+    const SvtAmdMdPicture &P = M.pic;
+    (void)Pg;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
     if (t == 0) {
@@ -1351,7 +1378,7 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
             if (lcu_x + st.x < (int)P.width && lcu_y + st.y < (int)P.height && M.S.cu[it].pred_mode == MD_INTER) {
                 M.V.ep_kind[it] = M.S.cu[it].merge_flag ? SVT_AMD_EP_INTER_MERGE : SVT_AMD_EP_INTER_AMVP;
                 if (M.S.cu[it].merge_flag && M.lcu.chroma_encode_mode == 1) /* CHROMA_MODE_FULL: the mode decision's merge / skip costs hold chroma already (EbCodingLoop.c:3840) */
-                    M.V.ep_kind[it] = (uint8_t)md_ep_merge_kind(D.X, &M.lcu, M.S.cu[it].merge_cost, M.S.cu[it].skip_cost);
+                    M.V.ep_kind[it] = (uint8_t)md_ep_merge_kind(&M.V.X, &M.lcu, M.S.cu[it].merge_cost, M.S.cu[it].skip_cost);
                 else if (M.S.cu[it].merge_flag && n < SVT_AMD_LCU_MAX_CUS)
                     M.V.fin_leaf[n++] = (uint8_t)it;
             }
@@ -1386,8 +1413,8 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
         }
         if (lane == 0) {
             uint64_t mc, sc;
-            md_merge_skip_full_cost(&P, D.X, &u, N, cbf, bits, dist, &mc, &sc);
-            M.V.ep_kind[leaf] = (uint8_t)md_ep_merge_kind(D.X, &M.lcu, mc, sc);
+            md_merge_skip_full_cost(&P, &M.V.X, &u, N, cbf, bits, dist, &mc, &sc);
+            M.V.ep_kind[leaf] = (uint8_t)md_ep_merge_kind(&M.V.X, &M.lcu, mc, sc);
         }
     }
     __syncthreads();
