@@ -156,6 +156,7 @@ struct MdShared {
     SvtAmdMdLcu lcu;
     SvtAmdOisLcuResult ois;        /* the LCU's open-loop intra search record */
     SvtAmdMdPicture pic;           /* the picture's controls and rate tables: the full costs index the tables by lane-dependent contexts (a load from HBM each otherwise) */
+    RateTables rt;                 /* the estimator's scan / context tables (rate_device.h c_rt: 624 B of constant memory read per coefficient position) beside them */
     SvtAmdCabacCost cost;          /* the picture's coefficient-rate tables: read per coefficient in the full loops, so kept beside the LCU instead of in HBM */
     MdCand cand[MD_MAX_CAND];
     unsigned long long costs[MD_MAX_CAND], fast_rate[MD_MAX_CAND];
@@ -286,11 +287,11 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
  * candidate and the plane (rate tables).  Returns (every lane) the unit's sums. */
 template <int N>
 __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int srcPitch, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile,
-                                                  int16_t *qbuf, int qp, int slice_type, const SvtAmdCabacCost &cost, int type, int intra_mode, int component, int pf)
+                                                  int16_t *qbuf, int qp, int slice_type, const SvtAmdCabacCost &cost, int type, int intra_mode, int component, int pf, const RateTables &rt)
 {
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : N == 8 ? 3 : 2;
     constexpr int fs1 = N == 32 ? 6 : N == 16 ? 4 : N == 8 ? 2 : 1, fs2 = N == 4 ? 8 : 9, wrap = N == 32 ? 2 : N == 16 ? 1 : 0;
-    MD_LDS(src), MD_LDS(pred), MD_LDS(tile), MD_LDS(qbuf), MD_LDS(&cost);
+    MD_LDS(src), MD_LDS(pred), MD_LDS(tile), MD_LDS(qbuf), MD_LDS(&cost), MD_LDS(&rt);
     if (recon_coeff)
         MD_LDS(recon_coeff);
     const int r = lane & (N - 1);
@@ -343,7 +344,7 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     const int lga = LG - pf, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
     const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
     /* nz is the whole unit's count and the same in every lane: a unit without levels (most merge candidates of a B picture at these QPs) has no bits to estimate */
-    const uint32_t b32 = nz ? coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1)) : 0u;
+    const uint32_t b32 = nz ? coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1), rt) : 0u;
     MdFl o;
     o.nz = nz, o.d0 = nz ? d0 : d1, o.d1 = d1, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
     return o;
@@ -459,12 +460,12 @@ __device__ __forceinline__ void md_build_refs_ol_chroma(const MdPictureDev &D, i
 
 /* the luma full loop of the unit's candidate on one wave: every transform unit (four 32x32 of a 64x64 unit) -> out[tu] */
 __device__ __forceinline__ void md_full_loop_cand(int lane, int N, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *recon_coeff, int16_t *tile, int16_t *qbuf,
-                                                  const SvtAmdMdPicture &P, const SvtAmdCabacCost &cost, int type, int mode, int pf, MdFl *out)
+                                                  const SvtAmdMdPicture &P, const SvtAmdCabacCost &cost, const RateTables &rt, int type, int mode, int pf, MdFl *out)
 {
     if (N == 64) {
         for (int tu = 0; tu < 4; tu++) {
             const int off = ((tu & 1) << 5) + ((tu >> 1) << 5) * 64, poff = ((tu & 1) << 5) + ((tu >> 1) << 5) * predPitch;
-            const MdFl o = md_full_loop_unit<32>(lane, src + off, 64, pred + poff, predPitch, nullptr, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf);
+            const MdFl o = md_full_loop_unit<32>(lane, src + off, 64, pred + poff, predPitch, nullptr, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf, rt);
             if (lane == 0)
                 out[tu] = o;
             EP_WAVE_SYNC();
@@ -473,9 +474,9 @@ __device__ __forceinline__ void md_full_loop_cand(int lane, int N, const uint8_t
     }
     MdFl o;
     switch (N) {
-    case 32: o = md_full_loop_unit<32>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf); break;
-    case 16: o = md_full_loop_unit<16>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf); break;
-    default: o = md_full_loop_unit<8>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf); break;
+    case 32: o = md_full_loop_unit<32>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf, rt); break;
+    case 16: o = md_full_loop_unit<16>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf, rt); break;
+    default: o = md_full_loop_unit<8>(lane, src, 64, pred, predPitch, recon_coeff, tile, qbuf, P.qp, P.slice_type, cost, type, mode, 0, pf, rt); break;
     }
     if (lane == 0)
         out[0] = o;
@@ -501,14 +502,14 @@ __device__ __forceinline__ void md_tu_calc_cost(const SvtAmdMdPicture &P, const 
 
 /* one chroma transform unit of FullLoop_R + CuFullDistortionFastTuMode_R on the calling wave -> nz, the two scaled distortions, the bits */
 __device__ __forceinline__ void md_chroma_tu(int lane, int T, const uint8_t *src, const uint8_t *pred, int predPitch, int16_t *tile, int16_t *qbuf, const SvtAmdMdPicture &P,
-                                             const SvtAmdCabacCost &cost, int type, int mode, int component, int pf, uint32_t *nz, unsigned long long dist[2], unsigned long long *bits)
+                                             const SvtAmdCabacCost &cost, const RateTables &rt, int type, int mode, int component, int pf, uint32_t *nz, unsigned long long dist[2], unsigned long long *bits)
 {
     const int pfc = T == 4 ? 0 : (T == 8 && pf == 2 ? 1 : pf); /* correctedPFMode (EbFullLoop.c:647-652) */
     MdFl o;
     switch (T) {
-    case 16: o = md_full_loop_unit<16>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc); break;
-    case 8: o = md_full_loop_unit<8>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc); break;
-    default: o = md_full_loop_unit<4>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc); break;
+    case 16: o = md_full_loop_unit<16>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc, rt); break;
+    case 8: o = md_full_loop_unit<8>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc, rt); break;
+    default: o = md_full_loop_unit<4>(lane, src, 32, pred, predPitch, nullptr, tile, qbuf, P.chroma_qp, P.slice_type, cost, type, mode, component, pfc, rt); break;
     }
     const int lgT = T == 16 ? 4 : T == 8 ? 3 : 2, sh = 2 * (7 - lgT);
     *nz = o.nz;
@@ -533,6 +534,9 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
     if (E.cost)
         for (int i = t; i < (int)(sizeof(SvtAmdCabacCost) / 4); i += 256)
             ((uint32_t *)&M.cost)[i] = ((const uint32_t *)E.cost)[i];
+    static_assert(sizeof(RateTables) % 4 == 0, "record sizes");
+    for (int i = t; i < (int)(sizeof(RateTables) / 4); i += 256)
+        ((uint32_t *)&M.rt)[i] = ((const uint32_t *)&c_rt)[i];
     static_assert(sizeof(SvtAmdOisLcuResult) % 4 == 0 && sizeof(SvtAmdMeLcuResult) % 4 == 0 && sizeof(SvtAmdMeCuResult) % 4 == 0 && sizeof(SvtAmdTmvpLcu) % 8 == 0, "record sizes");
     for (int i = t; i < (int)(sizeof(SvtAmdOisLcuResult) / 4); i += 256)
         ((uint32_t *)&M.ois)[i] = ((const uint32_t *)&D.ois[lcu])[i];
@@ -1053,7 +1057,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     const uint8_t *pred = (M.V.slot[pci] >= 0 && M.evaluated[pci]) ? M.V.cpred[M.V.slot[pci]] : M.V.wpred[f];
                     const int tu = wave, off = ((tu & 1) << 5) + ((tu >> 1) << 5) * 64;
                     const MdFl o = md_full_loop_unit<32>(lane, &L.src[st.y * 64 + st.x] + off, 64, pred + off, 64, nullptr, M.tiles[wave], M.qbuf[wave], P.qp, P.slice_type, M.cost,
-                                                         M.cand[ci].type, M.cand[ci].intra_mode, 0, pf);
+                                                         M.cand[ci].type, M.cand[ci].intra_mode, 0, pf, M.rt);
                     if (lane == 0)
                         M.fl[b][tu] = o;
                     EP_WAVE_SYNC();
@@ -1090,7 +1094,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 EP_WAVE_SYNC();
             }
             MD_SUB(12);
-            md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, M.cost, cd.type, cd.intra_mode, pf, M.fl[b]);
+            md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, cd.type, cd.intra_mode, pf, M.fl[b]);
             MD_SUB(13);
         }
         if constexpr (INTER) {
@@ -1125,7 +1129,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                         uint32_t nz;
                         unsigned long long d[2], bt;
-                        md_chroma_tu(lane, Tc, &M.V.src_c[pl][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, cd.type,
+                        md_chroma_tu(lane, Tc, &M.V.src_c[pl][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, cd.type,
                                      cd.intra_mode, 1 + pl, pf, &nz, d, &bt);
                         if (lane == 0) {
                             MdFl o;
@@ -1405,7 +1409,7 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
                 const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                 uint32_t nz;
                 unsigned long long d[2], b;
-                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, MD_INTER, 0,
+                md_chroma_tu(lane, T, &M.V.src_c[p][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, MD_INTER, 0,
                              1 + p, pf, &nz, d, &b);
                 cbf[p] |= (uint32_t)(nz != 0) << (ntu == 1 ? 0 : tu + 1);
                 bits[p] += b, dist[p][0] += d[0], dist[p][1] += d[1];

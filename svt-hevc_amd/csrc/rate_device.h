@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t last_xy_bits(const SvtAmdCabacCost &c_cost, 
  * of the wave must call (ballot / shuffles inside).  p: coefficient (0,0) of the TU (global or LDS), row pitch `stride`;
  * live = this lane's TU exists.  The sum lands in all S lanes; the caller shifts it by 10 like the reference. */
 __device__ __forceinline__ uint32_t coeff_bits_lanes(const SvtAmdCabacCost &c_cost, const int16_t *p0, uint32_t stride, int lg, const SvtAmdTuInfo ti, bool live,
-                                                     int lane, int sub)
+                                                     int lane, int sub, const RateTables &rt = c_rt /* the scan / context tables: the constant-memory copy, or the caller's in LDS */)
 {
     const int S = lg == 2 ? 1 : 1 << (2 * (lg - 2));
     const uint32_t size = 1u << lg;
@@ -88,12 +88,12 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const SvtAmdCabacCost &c_co
     /* 1. this lane's sub-block in scan order */
     uint32_t lin[16], sig = 0, g1 = 0;
     {
-        uint32_t gy = c_rt.sb[lg - 2][sub] >> 4, gx = c_rt.sb[lg - 2][sub] & 15;
+        uint32_t gy = rt.sb[lg - 2][sub] >> 4, gx = rt.sb[lg - 2][sub] & 15;
         if (scan == 1) { const uint32_t tmp = gx; gx = gy; gy = tmp; }
         const int16_t *p = p0 + 4 * gy * stride + 4 * gx;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const uint32_t pos = scan ? c_rt.col4[k] : c_rt.diag4[k];
+            const uint32_t pos = scan ? rt.col4[k] : rt.diag4[k];
             uint32_t py = pos >> 2, px = pos & 3;
             if (scan == 1) { const uint32_t tmp = px; px = py; py = tmp; }
             const int v = live && ti.num_nonzero ? (int)p[stride * py + px] : 0;
@@ -125,8 +125,8 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const SvtAmdCabacCost &c_co
             const bool isLast = sub == lastSet;
             const int posLast = 31 - __clz((int)(sig | 1));
             if (isLast) { /* position of the last significant coefficient */
-                uint32_t ly = 4 * (c_rt.sb[lg - 2][sub] >> 4), lx = 4 * (c_rt.sb[lg - 2][sub] & 15);
-                const uint32_t pl = scan ? c_rt.col4[posLast] : c_rt.diag4[posLast];
+                uint32_t ly = 4 * (rt.sb[lg - 2][sub] >> 4), lx = 4 * (rt.sb[lg - 2][sub] & 15);
+                const uint32_t pl = scan ? rt.col4[posLast] : rt.diag4[posLast];
                 ly += pl >> 2, lx += pl & 3;
                 if (scan) { const uint32_t tmp = lx; lx = ly; ly = tmp; }
                 bits += last_xy_bits(c_cost, lx, ly, size, isChroma);
@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const SvtAmdCabacCost &c_co
                     const uint32_t f = (sig >> k) & 1u;
                     bool take = (k == inferred);
                     if (k <= k_start && k >= k_low) {
-                        const uint32_t ci = lg == 2 ? c_rt.ctx4[scan][k] : c_rt.ctx8[scan != 0][k];
+                        const uint32_t ci = lg == 2 ? rt.ctx4[scan][k] : rt.ctx8[scan != 0][k];
                         bits += bp[2 * ci + f];
                         take = take || f;
                     } else if (k == 0 && sub == 0 && !(isLast && lone)) { /* the DC flag has its own context */
