@@ -1,10 +1,11 @@
 /*
- * TEST INFRASTRUCTURE ONLY (oracle/): C stand-ins for the yasm routines of the
- * reference so that /root/reference can be linked without yasm/nasm.
+ * integration/svt_yasm_shim.c - C stand-ins for the yasm routines of the reference, so that
+ * /root/reference links on a machine without yasm / nasm (this image).  A maintainer with yasm
+ * drops this file and assembles the reference's own .asm files instead.
  *
- * This file is compiled ONLY into oracle/_ref/ (the reference build used as
- * the parity checker and the CPU baseline).  It contains no reference source;
- * every symbol forwards to the reference's own C_DEFAULT peer.
+ * Compiled into integration/_build/ (the drop-in library) and, by oracle/Makefile, into
+ * oracle/_ref/ (the reference build used as parity checker and CPU baseline).  It contains no
+ * reference source; every symbol forwards to the reference's own C_DEFAULT peer.
  *
  * Symbols replaced (definitions in the reference):
  *   EbHevcLog2f_SSE2                    ASM_SSE2/EbPictureOperators_SSE2.asm:622 (bsr)
