@@ -219,6 +219,29 @@ __device__ __forceinline__ int load_window_async(LWin &w, int off, const uint8_t
     return off + rows * wa;
 }
 
+/* The three half-pel windows of the search kernel share their geometry: one pass derives (row, 16-byte column) of an item once and issues the three LDS-DMA loads */
+__device__ __forceinline__ int load_windows3_async(LWin &wa_, LWin &wb_, LWin &wc_, int off, const uint8_t *pa, const uint8_t *pb, const uint8_t *pc, int pitch, int x0, int y0,
+                                                   int x1, int y1, int t)
+{
+    const int xa = x0 & ~15, wa = win_pitch(x0, x1, 1), n16 = wa >> 4, rows = y1 - y0, total = rows * n16, bytes = rows * wa;
+    uint8_t *dst = g_pool + off;
+    wa_.p = dst, wb_.p = dst + bytes, wc_.p = dst + 2 * bytes;
+    wa_.x0 = wb_.x0 = wc_.x0 = xa, wa_.y0 = wb_.y0 = wc_.y0 = y0, wa_.stride = wb_.stride = wc_.stride = wa;
+    const int lane = t & 63;
+    const uint32_t rc = (1u << 20) / (uint32_t)n16 + 1u; /* items < 2^12, n16 <= 16: (i * rc) >> 20 == i / n16 */
+    for (int c0 = (t >> 6) * 64; c0 < total; c0 += NT) {
+        const int i = c0 + lane;
+        if (i < total) {
+            const int r = (int)(((uint32_t)i * rc) >> 20), c = i - r * n16;
+            const ptrdiff_t o = (ptrdiff_t)(y0 + r) * pitch + xa + c * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + o), (__attribute__((address_space(3))) void *)(dst + c0 * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb + o), (__attribute__((address_space(3))) void *)(dst + bytes + c0 * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pc + o), (__attribute__((address_space(3))) void *)(dst + 2 * bytes + c0 * 16), 16, 0, 0);
+        }
+    }
+    return off + 3 * bytes;
+}
+
 /* Z-order <-> raster (tab32x32 / tab8x8, EbMotionEstimation.c:98-102) */
 __constant__ uint8_t c_tab16[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 __constant__ uint8_t c_tab8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23,
@@ -568,6 +591,9 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
 
 /* workgroup barrier that orders LDS traffic only (ds reads / writes / atomics): unlike __syncthreads() it does not wait for
  * outstanding vector-memory operations, so LDS-DMA loads issued earlier stay in flight across it */
+#ifndef ME_EXP
+#define ME_EXP 0
+#endif
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 /* optional phase profile: when the job carries a debug buffer, thread 0 of every workgroup
@@ -575,7 +601,7 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
 #define STAMP(i)                                                                      \
     do {                                                                              \
         if (J.dbg_clock && t == 0)                                                    \
-            J.dbg_clock[((size_t)blockIdx.y * J.lcu_count + blk) * 16 + (i)] = __builtin_readcyclecounter(); \
+            J.dbg_clock[((size_t)blockIdx.y * J.lcu_count + (lcu - lcu_begin)) * 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 
 /* tier = 0 (64x64), 1 (32x32), 2 (16x16), 3 (8x8): closed forms instead of small private arrays, which the
@@ -917,21 +943,36 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
              * saw positions is exactly saw / 4 quad-SAD items (a fifth, mostly masked item per row otherwise). */
             {
                 const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
+#if ME_EXP == 2
+                int off0 = ME_SEARCH_BYTES + ((((wx1 - (wx0 - 2)) + 15) & ~15) | 16) * (wy1 - wy0);
+                {
+                    int o2 = load_window_async(wB, off0, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                    o2 = load_window_async(wH, o2, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                    o2 = load_window_async(wJ, o2, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                }
+#endif
                 int off = load_window_at(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0 - 2, wy0, wx1, wy1, t, 1);
                 LDS_BARRIER(); /* F is in LDS (its global loads are waited for by the stores that carry them) */
+                STAMP(13);
+#if ME_EXP == 1 || ME_EXP == 2
+                if (t > 9999)
+#endif
+                {
                 /* the half-pel planes are first read by the sub-pel stages: fetch them by LDS-DMA UNDER the full-pel search
                  * (waited for at "sub-pel windows landed" below).  Every barrier between here and there must be LDS_BARRIER: a
                  * __syncthreads() carries a vmcnt(0) and would park the workgroup until the three windows have landed, which is
                  * what the first version of this stage did */
-                off = load_window_async(wB, off, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
-                off = load_window_async(wH, off, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
-                off = load_window_async(wJ, off, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
+                off = load_windows3_async(wB, wH, wJ, off, R.hp_b, R.hp_h, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
+                }
             }
+#if ME_EXP >= 10
+            STAMP(15);
+#endif
             const uint32_t *rb4 = (const uint32_t *)wat(wF, ox + bx + sox, oy + by + soy); /* dword-aligned by construction */
             const int fs4 = wF.stride >> 2;
             const int mcount = (saw + 3) >> 2;                          /* quad-SAD items per search row */
             const int rows_per_chunk = imax(1, imin(sah, 256 / saw));   /* <= 256 positions of 32x32 SADs in LDS at a time */
-            const uint32_t rcm = fastdiv_recip((uint32_t)mcount);
+            const uint32_t rcm = fastdiv_recip((uint32_t)mcount), rcs = fastdiv_recip((uint32_t)saw);
             uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu;
             const int slot = blk & 3; /* the position of an item this lane speaks for in the 16x16 / 32x32 sums */
             for (int row0 = 0; row0 < sah; row0 += rows_per_chunk) {
@@ -980,18 +1021,31 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                     if (valid && blk < 4)
                         B.sad32[(int)pk - pbase][q] = v;
                 }
+#if ME_EXP >= 10
+                STAMP(0);
+#endif
                 LDS_BARRIER();
                 { /* 64x64: '<=' inside complete groups of 8, '<' in the tail */
                     const int p = pbase + t;
+                    unsigned long long k64 = ~0ull;
                     if (t < nrows * saw) {
-                        const uint32_t s = B.sad32[t][0] + B.sad32[t][1] + B.sad32[t][2] + B.sad32[t][3];
-                        const int sy = p / saw, sx = p - sy * saw;
+                        const uint4 sq = *(const uint4 *)&B.sad32[t][0];
+                        const uint32_t s = sq.x + sq.y + sq.z + sq.w;
+                        const int sy = (int)fastdiv((uint32_t)p, rcs), sx = p - sy * saw;
                         const uint32_t code = (sx < mult8) ? (uint32_t)(16383 - p) : (0x4000u | (uint32_t)p);
-                        atomicMin(&B.key64, ((unsigned long long)s << 15) | code);
+                        k64 = ((unsigned long long)s << 15) | code;
+                    }
+                    if (q * 64 < nrows * saw) { /* the wave's minimum, then ONE LDS atomic per wave (64 lanes on one address serialise) */
+                        k64 = wave_min64(k64);
+                        if (lane == 0)
+                            atomicMin(&B.key64, k64);
                     }
                 }
                 LDS_BARRIER();
             }
+#if ME_EXP >= 10
+            STAMP(1);
+#endif
             /* minima of the position groups (and, for 16x16 / 32x32, of the lanes that spoke for different positions) */
             best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 16));
             best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 32));
@@ -1010,6 +1064,9 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             if (lane == 0)
                 B.key[1 + q] = best32;
             LDS_BARRIER();
+#if ME_EXP >= 10
+            STAMP(2);
+#endif
             if (t < 85) {
                 uint32_t s;
                 int p;
@@ -1023,10 +1080,11 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                     s = k >> 14;
                     p = (int)(k & 0x3fff);
                 }
-                const int sy = p / saw, sx = p - sy * saw;
+                const int sy = (int)fastdiv((uint32_t)p, rcs), sx = p - sy * saw;
                 B.best_sad[list][t] = 2 * s;
                 B.best_mv[list][t] = mvpack((sx + sox) * 4, (sy + soy) * 4);
             }
+            STAMP(14);
             __builtin_amdgcn_s_waitcnt(0); /* sub-pel windows landed (LDS-DMA issued before the search) */
             __syncthreads();
         }
@@ -1035,14 +1093,24 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
         /* ---- sub-pel (:4236-4318) ---- */
         /* SuPelEnable (:3035-3361): tier sums of MV components and SADs, one PU per thread */
         if (P.fractional_search_model == 1) {
-            if (t < 9)
-                B.sums[t] = 0;
-            __syncthreads();
-            if (t >= 1 && t < 85) {
-                const int tier = t < 5 ? 0 : t < 21 ? 1 : 2;
-                atomicAdd(&B.sums[tier * 3 + 0], mvx(B.best_mv[list][t]));
-                atomicAdd(&B.sums[tier * 3 + 1], mvy(B.best_mv[list][t]));
-                atomicAdd(&B.sums[tier * 3 + 2], (int)B.best_sad[list][t]);
+            /* wave 0 speaks for the 64 8x8 PUs (21..84); wave 1: lanes 0..15 the 16x16 PUs (5..20), lanes 16..19 the 32x32 PUs (1..4), the rest of its first 32 lanes
+             * zeros - xor-shuffle sums (steps 1, 2, 4, 8 inside 16 lanes; 16, 32 as well in wave 0) instead of 252 LDS atomics on 9 addresses */
+            if (t < 128) {
+                const int lane = t & 63, n = t < 64 ? 21 + lane : lane < 16 ? 5 + lane : lane < 20 ? lane - 15 : -1;
+                int vx = 0, vy = 0, vs = 0;
+                if (n >= 0)
+                    vx = mvx(B.best_mv[list][n]), vy = mvy(B.best_mv[list][n]), vs = (int)B.best_sad[list][n];
+#pragma unroll
+                for (int o = 1; o <= 8; o <<= 1)
+                    vx += __shfl_xor(vx, o), vy += __shfl_xor(vy, o), vs += __shfl_xor(vs, o);
+                if (t < 64) {
+                    vx += __shfl_xor(vx, 16), vy += __shfl_xor(vy, 16), vs += __shfl_xor(vs, 16);
+                    vx += __shfl_xor(vx, 32), vy += __shfl_xor(vy, 32), vs += __shfl_xor(vs, 32);
+                }
+                if (t == 0 || t == 64 || t == 80) {
+                    const int tier = t == 0 ? 2 : t == 64 ? 1 : 0;
+                    B.sums[tier * 3 + 0] = vx, B.sums[tier * 3 + 1] = vy, B.sums[tier * 3 + 2] = vs;
+                }
             }
             __syncthreads();
         }
@@ -1090,7 +1158,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             for (int tier = 0; tier < 4; tier++) {
                 if (!EN(tier))
                     continue;
-                const int sz = tier_sz_of(tier), rows = sz / rstep, lc = tier_lc_of(tier), rpc = rows >> lc;
+                const int sz = tier_sz_of(tier), rows = sz >> (rstep - 1), lc = tier_lc_of(tier), rpc = rows >> lc;
                 const int items = tier_cnt_of(tier) * 8 << lc; /* a multiple of NT: whole waves, no tail */
                 for (int i = t; i < items; i += NT) {
                     const int ch = i & ((1 << lc) - 1), k = (i >> lc) & 7, n = tier_first_of(tier) + (i >> (lc + 3));
@@ -1193,7 +1261,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 if (!QEN(tier))
                     continue;
                 const int sz = tier == 0 ? 32 : tier_sz_of(tier); /* the 64x64 call passes 32x32 (:1677) */
-                const int lc = tier == 0 ? 3 : tier_lc_of(tier), rows = sz / rstep, rpc = rows >> lc;
+                const int lc = tier == 0 ? 3 : tier_lc_of(tier), rows = sz >> (rstep - 1), rpc = rows >> lc;
                 const int items = tier_cnt_of(tier) * 3 << lc;
                 for (int i0 = 0; i0 < items; i0 += NT) { /* uniform trips: whole waves join the shuffles */
                     const int i = i0 + t;
@@ -1298,14 +1366,15 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
         cum[0] = 0;
 #pragma unroll
         for (int tier = 0; tier < 4; tier++) {
-            const int sz = tier_sz_of(tier), rows = sz / rstep, segs = sz >= 16 ? sz >> 4 : 1;
+            const int sz = tier_sz_of(tier), rows = sz >> (rstep - 1), segs = sz >= 16 ? sz >> 4 : 1;
             cum[tier + 1] = cum[tier] + (tier_first_of(tier) < npu ? tier_cnt_of(tier) * rows * segs : 0);
         }
         for (int i = t; i < cum[4]; i += NT) {
             const int tier = i < cum[1] ? 0 : i < cum[2] ? 1 : i < cum[3] ? 2 : 3;
-            const int sz = tier_sz_of(tier), rows = sz / rstep, lgsegs = tier == 0 ? 2 : tier == 1 ? 1 : 0, wseg = sz >= 16 ? 16 : sz;
+            const int sz = tier_sz_of(tier), rows = sz >> (rstep - 1), lgsegs = tier == 0 ? 2 : tier == 1 ? 1 : 0, wseg = sz >= 16 ? 16 : sz;
             const int j = i - pick4(tier, cum[0], cum[1], cum[2], cum[3]);
-            const int seg = j & ((1 << lgsegs) - 1), jr = j >> lgsegs, row = jr % rows, n = tier_first_of(tier) + jr / rows;
+            const int lgrows = 6 - tier - (rstep == 2 ? 1 : 0); /* rows = 1 << lgrows */
+            const int seg = j & ((1 << lgsegs) - 1), jr = j >> lgsegs, row = jr & (rows - 1), n = tier_first_of(tier) + (jr >> lgrows);
             int px_, py_, psz;
             pu_geom_z(n, px_, py_, psz);
             const int y = row * rstep, xs = seg << 4;
@@ -1316,39 +1385,53 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 const uint32_t mv = B.best_mv[l][n];
                 const int xMv = mvx(mv), yMv = mvy(mv);
                 const int ax = ox + px_ + xs + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
-                const int frac = (xMv & 3) + ((yMv & 3) << 2);
+                const uint32_t frac = (uint32_t)((xMv & 3) + ((yMv & 3) << 2));
                 const ptrdiff_t pz = RR.pitch_full;
-                const uint8_t *F = RR.full + ay * pz + ax, *B = RR.hp_b + ay * pz + ax + 1;
-                const uint8_t *Hh = RR.hp_h + (ay + 1) * pz + ax, *J = RR.hp_j + (ay + 1) * pz + ax + 1;
-                /* SelectBuffer / QuarterPelCompensation (:2440-2600) */
-                switch (frac) {
-                case 0: a[l] = F, b[l] = F; break;
-                case 2: a[l] = B, b[l] = B; break;
-                case 8: a[l] = Hh, b[l] = Hh; break;
-                case 10: a[l] = J, b[l] = J; break;
-                case 1: a[l] = F, b[l] = B; break;
-                case 3: a[l] = B, b[l] = F + 1; break;
-                case 4: a[l] = F, b[l] = Hh; break;
-                case 5: a[l] = B, b[l] = Hh; break;
-                case 6: a[l] = B, b[l] = J; break;
-                case 7: a[l] = B, b[l] = Hh + 1; break;
-                case 9: a[l] = Hh, b[l] = J; break;
-                case 11: a[l] = J, b[l] = Hh + 1; break;
-                case 12: a[l] = Hh, b[l] = F + pz; break;
-                case 13: a[l] = Hh, b[l] = B + pz; break;
-                case 14: a[l] = J, b[l] = B + pz; break;
-                default: a[l] = Hh + 1, b[l] = B + pz; break;
-                }
+                /* SelectBuffer / QuarterPelCompensation (:2440-2600) as bit tables over the 16 fractional positions (a 16-way switch on pointers diverges per lane):
+                 * planes 0 F, 1 b (+1 column), 2 h (+1 row), 3 j (+1 row, +1 column); the first source of position 15 and the second of 3, 7, 11 sit one column
+                 * further right, the second source of 12 .. 15 one row further down */
+                const uint32_t pa = (0xBAFA5450u >> (2 * frac)) & 3u, pb = (0x54BEBA14u >> (2 * frac)) & 3u;
+                const ptrdiff_t at = (ptrdiff_t)ay * pz + ax;
+                const uint8_t *ba = pa == 0 ? RR.full : pa == 1 ? RR.hp_b : pa == 2 ? RR.hp_h : RR.hp_j;
+                const uint8_t *bb = pb == 0 ? RR.full : pb == 1 ? RR.hp_b : pb == 2 ? RR.hp_h : RR.hp_j;
+                a[l] = ba + at + (pa & 1u) + ((pa >> 1) ? pz : 0) + ((0x8000u >> frac) & 1u);
+                b[l] = bb + at + (pb & 1u) + ((pb >> 1) ? pz : 0) + ((0x0888u >> frac) & 1u) + (((0xF000u >> frac) & 1u) ? pz : 0);
             }
             const uint8_t *s = &S.src[(py_ + y) * LCU + px_ + xs];
             uint32_t d = 0;
-            for (int x = 0; x < wseg; x += 4) {
-                /* avg of identical pointers is the identity: (v+v+1)>>1 == v */
-                const uint32_t p0 = avg4(ld4(a[0] + x), ld4(b[0] + x));
-                const uint32_t p1 = avg4(ld4(a[1] + x), ld4(b[1] + x));
-                d = sad4(*(const uint32_t *)(s + x), avg4(p0, p1), d);
+            /* one unaligned 16-byte (8x8 PUs: 8-byte) global load per plane instead of four dword loads: the address units take a wave's 64 scattered rows once per
+             * plane.  avg of identical pointers is the identity ((v+v+1)>>1 == v): the second plane of a full / half-pel position is not fetched */
+            if (wseg == 16) {
+                const uint4 a0 = *(const u128u_w *)a[0], a1 = *(const u128u_w *)a[1];
+                uint4 b0 = a0, b1 = a1;
+                if (b[0] != a[0])
+                    b0 = *(const u128u_w *)b[0];
+                if (b[1] != a[1])
+                    b1 = *(const u128u_w *)b[1];
+                const uint4 sv = *(const uint4 *)s;
+                d = sad4(sv.x, avg4(avg4(a0.x, b0.x), avg4(a1.x, b1.x)), d);
+                d = sad4(sv.y, avg4(avg4(a0.y, b0.y), avg4(a1.y, b1.y)), d);
+                d = sad4(sv.z, avg4(avg4(a0.z, b0.z), avg4(a1.z, b1.z)), d);
+                d = sad4(sv.w, avg4(avg4(a0.w, b0.w), avg4(a1.w, b1.w)), d);
+            } else {
+                typedef uint2 __attribute__((aligned(1))) u64u_w;
+                const uint2 a0 = *(const u64u_w *)a[0], a1 = *(const u64u_w *)a[1];
+                uint2 b0 = a0, b1 = a1;
+                if (b[0] != a[0])
+                    b0 = *(const u64u_w *)b[0];
+                if (b[1] != a[1])
+                    b1 = *(const u64u_w *)b[1];
+                const uint2 sv = *(const uint2 *)s;
+                d = sad4(sv.x, avg4(avg4(a0.x, b0.x), avg4(a1.x, b1.x)), d);
+                d = sad4(sv.y, avg4(avg4(a0.y, b0.y), avg4(a1.y, b1.y)), d);
             }
-            atomicAdd(&B.bipred[n], d);
+            /* the items of a PU sit on adjacent lanes (groups of 4 .. 64, aligned: every tier's share of the index space is a multiple of 64): summed by shuffles,
+             * one LDS atomic per group instead of one per item (64 lanes on one address serialise) */
+            const int per_pu = rows << lgsegs, G = per_pu < 64 ? per_pu : 64;
+            for (int o = 1; o < G; o <<= 1)
+                d += __shfl_xor(d, o);
+            if ((j & (G - 1)) == 0)
+                atomicAdd(&B.bipred[n], d);
         }
         __syncthreads();
     }

@@ -223,7 +223,7 @@ def load_product():
     # FIRST so the loader binds our library to that copy: two HIP/HSA runtimes in one process cannot both
     # open the GPU ("No HIP GPUs are available" from whichever initialises second).
     import torch  # noqa: F401
-    lib = C.CDLL(PRODUCT_SO)
+    lib = C.CDLL(os.environ.get("SVT_PRODUCT_LIB", PRODUCT_SO))  # the override: A/B runs of an experimental build (tools/)
     _declare_leaf(lib, "svt_amd_")
     vp, i, u16, u32 = C.c_void_p, C.c_int, C.c_uint16, C.c_uint32
     _sig(lib.svt_amd_context_create, i, [i, u16, u16, i, C.POINTER(vp)])

@@ -59,6 +59,18 @@ def main():
             if NAMES[i]:
                 print("  %-30s median %8d  mean %8d  (%4.1f%%)" % (NAMES[i], np.median(d[:, i]), d[:, i].mean(),
                                                                    100.0 * d[:, i].mean() / tot.mean()))
+        if k0 == 5 and buf[:, 13].any():  # finer marks inside the full-pel stage
+            b = buf.astype(np.int64)
+            print("      stamps 13 / 14 present in %d / %d of %d workgroups; first rows %s" % ((b[:, 13] != 0).sum(), (b[:, 14] != 0).sum(), n, np.nonzero(b[:, 13])[0][:12]))
+            ok = (b[:, 13] != 0) & (b[:, 14] != 0)
+            b = b[ok]
+            marks = ((6, 13, "F window in LDS"), (13, 14, "search proper + minima"), (14, 7, "wait for the b / h / j windows"))
+            if os.environ.get("ME_EXP_STAMPS"):  # an experimental build (-DME_EXP >= 10) reuses the HME kernel's slots for finer marks
+                marks = ((6, 13, "F window in LDS"), (13, 15, "issue the b / h / j LDS-DMA"), (15, 0, "search loop"), (0, 1, "64x64 pass"),
+                         (1, 2, "minima across lanes"), (2, 14, "winners to LDS"), (14, 7, "wait for the b / h / j windows"))
+            for a0, a1, nm2 in marks:
+                v = b[:, a1] - b[:, a0]
+                print("      %-32s median %8d  mean %8d" % (nm2, np.median(v), v.mean()))
         span = int(buf[:, k1].max() - buf[:, k0].min())
         print("  kernel span %d clocks; mean concurrent workgroups %.0f" % (span, tot.sum() / span))
     lib.svt_amd_context_destroy(ctx)
