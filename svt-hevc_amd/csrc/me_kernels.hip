@@ -194,6 +194,11 @@ __device__ __forceinline__ int load_window_at(LWin &w, int off, const uint8_t *p
     return off + rows * wa;
 }
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint4 ldu16(const uint8_t *p) /* one unaligned 16-byte global load */
+{
+    const uint4 v = *(const u128u_w *)p;
+    return v;
+}
 
 /* Same staging through the LDS-DMA path (global_load_lds_dwordx4): the data never passes through VGPRs and the
  * issuing wave does not wait for it, so the loads overlap with whatever is computed next.  One wave instruction
@@ -594,6 +599,7 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
 #ifndef ME_EXP
 #define ME_EXP 0
 #endif
+#define ME_F_ITEMS 3 /* 16-byte items of the F window a thread requests in the first round trip: 3 x 256 covers search areas up to 48 x 48 (+67) */
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 /* optional phase profile: when the job carries a debug buffer, thread 0 of every workgroup
@@ -653,13 +659,13 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
     (void)method;
 
     STAMP(PHASE == 0 ? 0 : 5);
-    /* ---- stage the source LCU (EbMotionEstimationProcess.c:714-779) ---- */
-    for (int i = t; i < LCU * LCU / 4; i += NT) {
-        const int y = i >> 4, x = (i & 15) << 2;
-        *(uint32_t *)&S.src[y * LCU + x] = *(const uint32_t *)(cur.full + (ptrdiff_t)(oy + y) * pf + ox + x);
-    }
+    /* ---- stage the source LCU (EbMotionEstimationProcess.c:714-779); the search kernel does it together with its first reference window below ---- */
     int cx = 0, cy = 0;
     if (PHASE == 0) {
+        for (int i = t; i < LCU * LCU / 4; i += NT) {
+            const int y = i >> 4, x = (i & 15) << 2;
+            *(uint32_t *)&S.src[y * LCU + x] = *(const uint32_t *)(cur.full + (ptrdiff_t)(oy + y) * pf + ox + x);
+        }
         if (t < 128) { /* 1/4: 16 even rows x 32 */
             const int y = t >> 3, x = (t & 7) << 2;
             *(uint32_t *)&S.qsrc[y * 32 + x] =
@@ -676,18 +682,8 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             (&S.hy[0][0][0])[t] = list ? (&carry->hy[0][0][0])[t] : (int16_t)0;
             (&S.hs[0][0][0])[t] = list ? (&carry->hs[0][0][0])[t] : 0ull;
         }
-    } else {
-        for (int i = t; i < 85; i += NT) {
-            B.best_sad[list][i] = 0, B.best_mv[list][i] = 0, B.best_ssd[list][i] = 0, B.dir[list][i] = 0;
-            /* the other list: zero for a one-list picture, list 0's final result for list 1 */
-            B.best_sad[1 - list][i] = list ? o->best_sad[0][i] : 0u;
-            B.best_mv[1 - list][i] = list ? o->best_mv[0][i] : 0u;
-            B.best_ssd[1 - list][i] = 0, B.dir[1 - list][i] = 0;
-            B.bipred[i] = 0;
-        }
-        cx = carry->cx[list], cy = carry->cy[list];
+        __syncthreads();
     }
-    __syncthreads();
 
     LWin wF, wB, wH, wJ; /* LDS windows of the current list's reference planes */
 
@@ -908,19 +904,68 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
         STAMP(4);
     } else { /* PHASE 1 */
         /* ---- search area (:4072-4200); unrestricted MVs ---- */
+        cx = carry->cx[list], cy = carry->cy[list];
         int saw = imin(P.search_area_width, 127), sah = imin(P.search_area_height, 127);
         int sox = cx - (saw >> 1), soy = cy - (sah >> 1);
         clamp_area(ox, LCU - 1, W, sox, saw);
         clamp_area(oy, LCU - 1, H, soy, sah);
+        /* ONE round trip to memory for everything the search starts from: the source LCU (16 bytes a thread), list 0's results (list 1 only) and the F window
+         * (x in [sox-4, sox+saw+63+2), y in [soy-2, soy+sah+63+2): the search region plus what the sub-pel stages reach; its first column FOUR samples left of search
+         * position 0, not at a 16-byte boundary of the plane: every block's position 0 then sits on an LDS dword and a search row of saw positions is exactly
+         * saw / 4 quad-SAD items) are requested back to back and land in LDS together.  (Staged one after the other - the window needs the search centre of the
+         * carry record, which is a scalar load - they cost two.) */
+        const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
+        int win_off;
+        {
+            const uint4 sv = *(const u128u_w *)(cur.full + (ptrdiff_t)(oy + (t >> 2)) * pf + ox + ((t & 3) << 4));
+            uint32_t i_sad = 0, i_mv = 0;
+            if (list && t < 85)
+                i_sad = o->best_sad[0][t], i_mv = o->best_mv[0][t];
+            int wa = ((wx1 - (wx0 - 2)) + 15) & ~15;
+            if (!((wa >> 4) & 1))
+                wa += 16;
+            const int n16 = wa >> 4, rows = wy1 - wy0, total = rows * n16;
+            const uint32_t rc = (1u << 20) / (uint32_t)n16 + 1u;
+            uint8_t *dst = g_pool + ME_SEARCH_BYTES;
+            wF.p = dst, wF.x0 = wx0 - 2, wF.y0 = wy0, wF.stride = wa;
+            uint4 fw[ME_F_ITEMS];
+#pragma unroll
+            for (int k = 0; k < ME_F_ITEMS; k++) {
+                const int i = t + k * NT;
+                if (i < total) {
+                    const int r = (int)(((uint32_t)i * rc) >> 20), c = i - r * n16;
+                    fw[k] = ldu16(R.full + (ptrdiff_t)(wy0 + r) * R.pitch_full + (wx0 - 2) + c * 16);
+                }
+            }
+            *(uint4 *)&S.src[(t >> 2) * LCU + ((t & 3) << 4)] = sv;
+            if (t < 85) {
+                B.best_sad[list][t] = 0, B.best_mv[list][t] = 0, B.best_ssd[list][t] = 0, B.dir[list][t] = 0;
+                /* the other list: zero for a one-list picture, list 0's final result for list 1 */
+                B.best_sad[1 - list][t] = i_sad, B.best_mv[1 - list][t] = i_mv;
+                B.best_ssd[1 - list][t] = 0, B.dir[1 - list][t] = 0;
+                B.bipred[t] = 0;
+                B.key[t] = 0xffffffffu;
+            }
+            if (t == 0)
+                B.key64 = ~0ull;
+#pragma unroll
+            for (int k = 0; k < ME_F_ITEMS; k++) {
+                const int i = t + k * NT;
+                if (i < total)
+                    *(uint4 *)(dst + i * 16) = fw[k];
+            }
+            for (int i = t + ME_F_ITEMS * NT; i < total; i += NT) { /* search areas beyond 48 x 48: the rest of the window the plain way */
+                const int r = (int)(((uint32_t)i * rc) >> 20), c = i - r * n16;
+                *(uint4 *)(dst + i * 16) = ldu16(R.full + (ptrdiff_t)(wy0 + r) * R.pitch_full + (wx0 - 2) + c * 16);
+            }
+            win_off = ME_SEARCH_BYTES + rows * wa;
+        }
+        LDS_BARRIER(); /* source, F window, search state are in LDS (their global loads are waited for by the stores that carry them) */
 
         STAMP(6);
         /* ---- FullPelSearch_LCU (:586-633) ---- */
         {
-            if (t < 85)
-                B.key[t] = 0xffffffffu;
-            if (t == 0)
-                B.key64 = ~0ull;
-            const int npos = saw * sah, mult8 = saw & ~7;
+            const int mult8 = saw & ~7;
             /* A WAVE owns one 32x32 quadrant; lane = (position group g = lane >> 4, 8x8 block blk = lane & 15 in Z order inside the
              * quadrant).  The whole SAD tree of the quadrant then lives in the wave: the four 8x8 blocks of a 16x16 are the four
              * lanes of a quad, the four 16x16 of the 32x32 are the four quads of a 16-lane row, so 16x16 and 32x32 sums are DPP
@@ -936,35 +981,11 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 s0[r] = *(const uint32_t *)&S.src[(by + 2 * r) * LCU + bx];
                 s1[r] = *(const uint32_t *)&S.src[(by + 2 * r) * LCU + bx + 4];
             }
-            /* stage the search region of the four planes: F now, b/h/j for the sub-pel stages.
-             * x in [sox-2, sox+saw+63+2), y likewise (integer winner +-1 after half-pel, +-1 for the
-             * quarter-pel neighbours).  The F window starts FOUR columns left of search position 0, not at a 16-byte boundary of
-             * the plane (unaligned 16-byte global loads): every block's position 0 then sits on an LDS dword and a search row of
-             * saw positions is exactly saw / 4 quad-SAD items (a fifth, mostly masked item per row otherwise). */
-            {
-                const int wx0 = ox + sox - 2, wy0 = oy + soy - 2, wx1 = ox + sox + saw + 65, wy1 = oy + soy + sah + 65;
-#if ME_EXP == 2
-                int off0 = ME_SEARCH_BYTES + ((((wx1 - (wx0 - 2)) + 15) & ~15) | 16) * (wy1 - wy0);
-                {
-                    int o2 = load_window_async(wB, off0, R.hp_b, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
-                    o2 = load_window_async(wH, o2, R.hp_h, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
-                    o2 = load_window_async(wJ, o2, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t, 1);
-                }
-#endif
-                int off = load_window_at(wF, ME_SEARCH_BYTES, R.full, R.pitch_full, wx0 - 2, wy0, wx1, wy1, t, 1);
-                LDS_BARRIER(); /* F is in LDS (its global loads are waited for by the stores that carry them) */
-                STAMP(13);
-#if ME_EXP == 1 || ME_EXP == 2
-                if (t > 9999)
-#endif
-                {
-                /* the half-pel planes are first read by the sub-pel stages: fetch them by LDS-DMA UNDER the full-pel search
-                 * (waited for at "sub-pel windows landed" below).  Every barrier between here and there must be LDS_BARRIER: a
-                 * __syncthreads() carries a vmcnt(0) and would park the workgroup until the three windows have landed, which is
-                 * what the first version of this stage did */
-                off = load_windows3_async(wB, wH, wJ, off, R.hp_b, R.hp_h, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
-                }
-            }
+            STAMP(13);
+            /* the half-pel planes (same region less the two extra columns) are first read by the sub-pel stages: fetch them by LDS-DMA UNDER the full-pel search
+             * (waited for at "sub-pel windows landed" below).  Every barrier between here and there must be LDS_BARRIER: a __syncthreads() carries a vmcnt(0)
+             * and would park the workgroup until the three windows have landed, which is what the first version of this stage did */
+            load_windows3_async(wB, wH, wJ, win_off, R.hp_b, R.hp_h, R.hp_j, R.pitch_full, wx0, wy0, wx1, wy1, t);
 #if ME_EXP >= 10
             STAMP(15);
 #endif
@@ -975,8 +996,71 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             const uint32_t rcm = fastdiv_recip((uint32_t)mcount), rcs = fastdiv_recip((uint32_t)saw);
             uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu;
             const int slot = blk & 3; /* the position of an item this lane speaks for in the 16x16 / 32x32 sums */
+            const bool fast = (saw & 3) == 0;
+            const int sh16 = (slot & 1) ? 0 : 16;
+            const int q4 = 4 / mcount, r4 = 4 - q4 * mcount;
+            uint32_t b8[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, b16 = 0xffffffffu;
             for (int row0 = 0; row0 < sah; row0 += rows_per_chunk) {
                 const int nrows = imin(rows_per_chunk, sah - row0), items = nrows * mcount, pbase = row0 * saw;
+                if (fast) {
+                    /* search rows of a multiple of four positions (every row exactly mcount items, raster index of an item's first position = 4 x its index): the
+                     * running minima keep (sad << 16 | item index) PER POSITION of the item - built from the packed halves of the quad-SAD result with one v_lshl_or /
+                     * v_and_or each, no unpacking, no per-position validity test - and are turned into (sad, raster index) keys once after the search.  A dead
+                     * lane group (item index past the end) carries all-ones halves: its keys lose against every real one. */
+                    /* Item addresses advance incrementally (four items further = q4 rows and r4 columns, one wrap at most): no multiplication inside the loop.  The
+                     * twelve window dwords of the NEXT item are fetched before the current one is evaluated - one LDS round trip per iteration, overlapped, instead of
+                     * one per block row. */
+                    int mi = (int)grp, ry = 0;
+                    while (mi >= mcount)
+                        mi -= mcount, ry++;
+                    int ro = (row0 + ry) * fs4 + mi; /* dword offset of the item's first window dword from rb4 */
+                    uint32_t itg = (uint32_t)(row0 * mcount) + (uint32_t)grp;
+                    uint32_t cur[12], nxt[12];
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+                        cur[3 * rr] = rb4[ro + 2 * rr * fs4], cur[3 * rr + 1] = rb4[ro + 2 * rr * fs4 + 1], cur[3 * rr + 2] = rb4[ro + 2 * rr * fs4 + 2];
+                    for (int it0 = 0; it0 < items; it0 += 4) {
+                        const bool live = it0 + (int)grp < items;
+                        { /* the next item of this lane group (its own again when there is none: a valid address) */
+                            int nmi = mi + r4, nro = ro + q4 * fs4 + r4;
+                            if (nmi >= mcount)
+                                nmi -= mcount, nro += fs4 - mcount;
+                            const bool more = it0 + 4 + (int)grp < items;
+                            mi = more ? nmi : mi, ro = more ? nro : ro;
+#pragma unroll
+                            for (int rr = 0; rr < 4; rr++)
+                                nxt[3 * rr] = rb4[ro + 2 * rr * fs4], nxt[3 * rr + 1] = rb4[ro + 2 * rr * fs4 + 1], nxt[3 * rr + 2] = rb4[ro + 2 * rr * fs4 + 2];
+                        }
+                        unsigned long long acc = 0;
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            acc = qsad(cur[3 * rr], cur[3 * rr + 1], s0[rr], acc);
+                            acc = qsad(cur[3 * rr + 1], cur[3 * rr + 2], s1[rr], acc);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 12; k++)
+                            cur[k] = nxt[k];
+                        uint32_t lo = live ? (uint32_t)acc : 0xffffffffu, hi = live ? (uint32_t)(acc >> 32) : 0xffffffffu;
+                        b8[0] = umin32(b8[0], (lo << 16) | itg), b8[1] = umin32(b8[1], (lo & 0xffff0000u) | itg);
+                        b8[2] = umin32(b8[2], (hi << 16) | itg), b8[3] = umin32(b8[3], (hi & 0xffff0000u) | itg);
+                        lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true); /* quad_perm [1,0,3,2] */
+                        hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true);
+                        lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, true); /* quad_perm [2,3,0,1] */
+                        hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, true);
+                        const uint32_t sel = slot < 2 ? lo : hi;
+                        const uint32_t k16 = live ? (((sel << sh16) & 0xffff0000u) | itg) : 0xffffffffu;
+                        b16 = umin32(b16, k16);
+                        uint32_t v = (sel >> (16 - sh16)) & 0xffffu;
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true); /* row_ror:4 */
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); /* row_ror:8 */
+                        const uint32_t pk = 4u * itg + (uint32_t)slot;
+                        const uint32_t k32 = live ? ((v << 14) | pk) : 0xffffffffu;
+                        best32 = umin32(best32, k32);
+                        if (live && blk < 4)
+                            B.sad32[(int)pk - pbase][q] = v;
+                        itg += 4;
+                    }
+                } else
                 for (int it0 = 0; it0 < items; it0 += 4) { /* uniform trip count: the DPP sums need whole rows of lanes */
                     const int it = it0 + grp;
                     const bool live = it < items;
@@ -1046,6 +1130,14 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
 #if ME_EXP >= 10
             STAMP(1);
 #endif
+            if (fast) { /* (sad << 16 | item index) -> (sad << 14 | raster index): the order the reference's strict '<' scan keeps */
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (b8[k] != 0xffffffffu)
+                        best8 = umin32(best8, ((b8[k] >> 16) << 14) | (4u * (b8[k] & 0xffffu) + (uint32_t)k));
+                if (b16 != 0xffffffffu)
+                    best16 = ((b16 >> 16) << 14) | (4u * (b16 & 0xffffu) + (uint32_t)slot);
+            }
             /* minima of the position groups (and, for 16x16 / 32x32, of the lanes that spoke for different positions) */
             best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 16));
             best8 = umin32(best8, (uint32_t)__shfl_xor((int)best8, 32));
