@@ -599,6 +599,7 @@ __device__ __forceinline__ void row_metric(int method, uint32_t a, uint32_t b, u
 #ifndef ME_EXP
 #define ME_EXP 0
 #endif
+#define ME_BI_ITEMS 3 /* bi-prediction items a thread has in flight */
 #define ME_F_ITEMS 3 /* 16-byte items of the F window a thread requests in the first round trip: 3 x 256 covers search areas up to 48 x 48 (+67) */
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -1461,69 +1462,98 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
             const int sz = tier_sz_of(tier), rows = sz >> (rstep - 1), segs = sz >= 16 ? sz >> 4 : 1;
             cum[tier + 1] = cum[tier] + (tier_first_of(tier) < npu ? tier_cnt_of(tier) * rows * segs : 0);
         }
-        for (int i = t; i < cum[4]; i += NT) {
-            const int tier = i < cum[1] ? 0 : i < cum[2] ? 1 : i < cum[3] ? 2 : 3;
-            const int sz = tier_sz_of(tier), rows = sz >> (rstep - 1), lgsegs = tier == 0 ? 2 : tier == 1 ? 1 : 0, wseg = sz >= 16 ? 16 : sz;
-            const int j = i - pick4(tier, cum[0], cum[1], cum[2], cum[3]);
-            const int lgrows = 6 - tier - (rstep == 2 ? 1 : 0); /* rows = 1 << lgrows */
-            const int seg = j & ((1 << lgsegs) - 1), jr = j >> lgsegs, row = jr & (rows - 1), n = tier_first_of(tier) + (jr >> lgrows);
-            int px_, py_, psz;
-            pu_geom_z(n, px_, py_, psz);
-            const int y = row * rstep, xs = seg << 4;
-            const uint8_t *a[2], *b[2];
+        /* A thread's items are taken three at a time: first the plane reads of all three are requested (one unaligned 16-byte load per plane: the address units take
+         * a wave's 64 scattered rows once per plane; avg of identical pointers is the identity ((v+v+1)>>1 == v), so the second plane of a full / half-pel position is
+         * not fetched), then they are evaluated - one trip to memory per three items instead of one per item. */
+        for (int base = 0; base < cum[4]; base += ME_BI_ITEMS * NT) {
+            uint4 va0[ME_BI_ITEMS], vb0[ME_BI_ITEMS], va1[ME_BI_ITEMS], vb1[ME_BI_ITEMS];
+            int in_[ME_BI_ITEMS], ij[ME_BI_ITEMS], iG[ME_BI_ITEMS], iw[ME_BI_ITEMS];
+            const uint8_t *is[ME_BI_ITEMS];
 #pragma unroll
-            for (int l = 0; l < 2; l++) {
-                const PicView &RR = l ? ref1 : ref0;
-                const uint32_t mv = B.best_mv[l][n];
-                const int xMv = mvx(mv), yMv = mvy(mv);
-                const int ax = ox + px_ + xs + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
-                const uint32_t frac = (uint32_t)((xMv & 3) + ((yMv & 3) << 2));
-                const ptrdiff_t pz = RR.pitch_full;
-                /* SelectBuffer / QuarterPelCompensation (:2440-2600) as bit tables over the 16 fractional positions (a 16-way switch on pointers diverges per lane):
-                 * planes 0 F, 1 b (+1 column), 2 h (+1 row), 3 j (+1 row, +1 column); the first source of position 15 and the second of 3, 7, 11 sit one column
-                 * further right, the second source of 12 .. 15 one row further down */
-                const uint32_t pa = (0xBAFA5450u >> (2 * frac)) & 3u, pb = (0x54BEBA14u >> (2 * frac)) & 3u;
-                const ptrdiff_t at = (ptrdiff_t)ay * pz + ax;
-                const uint8_t *ba = pa == 0 ? RR.full : pa == 1 ? RR.hp_b : pa == 2 ? RR.hp_h : RR.hp_j;
-                const uint8_t *bb = pb == 0 ? RR.full : pb == 1 ? RR.hp_b : pb == 2 ? RR.hp_h : RR.hp_j;
-                a[l] = ba + at + (pa & 1u) + ((pa >> 1) ? pz : 0) + ((0x8000u >> frac) & 1u);
-                b[l] = bb + at + (pb & 1u) + ((pb >> 1) ? pz : 0) + ((0x0888u >> frac) & 1u) + (((0xF000u >> frac) & 1u) ? pz : 0);
+            for (int u = 0; u < ME_BI_ITEMS; u++) {
+                const int i = base + u * NT + t;
+                iG[u] = 0;
+                if (i < cum[4]) {
+            const int tier = i < cum[1] ? 0 : i < cum[2] ? 1 : i < cum[3] ? 2 : 3;
+                    const int sz = tier_sz_of(tier), rows = sz >> (rstep - 1), lgsegs = tier == 0 ? 2 : tier == 1 ? 1 : 0, wseg = sz >= 16 ? 16 : sz;
+                    const int j = i - pick4(tier, cum[0], cum[1], cum[2], cum[3]);
+                    const int lgrows = 6 - tier - (rstep == 2 ? 1 : 0); /* rows = 1 << lgrows */
+                    const int seg = j & ((1 << lgsegs) - 1), jr = j >> lgsegs, row = jr & (rows - 1), n = tier_first_of(tier) + (jr >> lgrows);
+                    int px_, py_, psz;
+                    pu_geom_z(n, px_, py_, psz);
+                    const int y = row * rstep, xs = seg << 4;
+                    /* SelectBuffer / QuarterPelCompensation (:2440-2600) as bit tables over the 16 fractional positions (a 16-way switch on pointers diverges per lane):
+                     * planes 0 F, 1 b (+1 column), 2 h (+1 row), 3 j (+1 row, +1 column); the first source of position 15 and the second of 3, 7, 11 sit one column
+                     * further right, the second source of 12 .. 15 one row further down.  List 0's samples come from memory (its windows left with its kernel);
+                     * THIS list's are in the LDS windows of the search (the sub-pel stages read the same positions) - half of the scattered row fetches, which bound
+                     * this stage in the texture path (64 lanes = 64 rows = 64+ cache lines per load instruction), never leave the CU. */
+                    {
+                        const uint32_t mv = B.best_mv[0][n];
+                        const int xMv = mvx(mv), yMv = mvy(mv);
+                        const int ax = ox + px_ + xs + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
+                        const uint32_t frac = (uint32_t)((xMv & 3) + ((yMv & 3) << 2));
+                        const ptrdiff_t pz = ref0.pitch_full;
+                        const uint32_t pa = (0xBAFA5450u >> (2 * frac)) & 3u, pb = (0x54BEBA14u >> (2 * frac)) & 3u;
+                        const ptrdiff_t at = (ptrdiff_t)ay * pz + ax;
+                        const uint8_t *ba = pa == 0 ? ref0.full : pa == 1 ? ref0.hp_b : pa == 2 ? ref0.hp_h : ref0.hp_j;
+                        const uint8_t *bb = pb == 0 ? ref0.full : pb == 1 ? ref0.hp_b : pb == 2 ? ref0.hp_h : ref0.hp_j;
+                        const uint8_t *a0p = ba + at + (pa & 1u) + ((pa >> 1) ? pz : 0) + ((0x8000u >> frac) & 1u);
+                        const uint8_t *b0p = bb + at + (pb & 1u) + ((pb >> 1) ? pz : 0) + ((0x0888u >> frac) & 1u) + (((0xF000u >> frac) & 1u) ? pz : 0);
+                        va0[u] = ldu16(a0p);
+                        vb0[u] = va0[u];
+                        if (b0p != a0p)
+                            vb0[u] = ldu16(b0p);
+                    }
+                    {
+                        const uint32_t mv = B.best_mv[1][n];
+                        const int xMv = mvx(mv), yMv = mvy(mv);
+                        const int ax = ox + px_ + xs + (xMv >> 2), ay = oy + py_ + (yMv >> 2) + y;
+                        const uint32_t frac = (uint32_t)((xMv & 3) + ((yMv & 3) << 2));
+                        const uint32_t pa = (0xBAFA5450u >> (2 * frac)) & 3u, pb = (0x54BEBA14u >> (2 * frac)) & 3u;
+                        const uint8_t *wpa = pa == 0 ? wF.p : pa == 1 ? wB.p : pa == 2 ? wH.p : wJ.p, *wpb = pb == 0 ? wF.p : pb == 1 ? wB.p : pb == 2 ? wH.p : wJ.p;
+                        const int sa = pa == 0 ? wF.stride : wB.stride, sb = pb == 0 ? wF.stride : wB.stride; /* the three half-pel windows share their geometry */
+                        const int xa0 = pa == 0 ? wF.x0 : wB.x0, xb0 = pb == 0 ? wF.x0 : wB.x0;
+                        const uint8_t *a1p = wpa + (ay + (int)(pa >> 1) - wF.y0) * sa + (ax + (int)(pa & 1u) + (int)((0x8000u >> frac) & 1u) - xa0);
+                        const uint8_t *b1p = wpb + (ay + (int)(pb >> 1) + (int)((0xF000u >> frac) & 1u) - wF.y0) * sb + (ax + (int)(pb & 1u) + (int)((0x0888u >> frac) & 1u) - xb0);
+                        uint32_t w4[4];
+                        lds_ld_unaligned<4>(a1p, w4);
+                        va1[u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        vb1[u] = va1[u];
+                        if (b1p != a1p) {
+                            lds_ld_unaligned<4>(b1p, w4);
+                            vb1[u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        }
+                    }
+                    const int per_pu = rows << lgsegs;
+                    in_[u] = n, ij[u] = j, iG[u] = per_pu < 64 ? per_pu : 64, iw[u] = wseg;
+                    is[u] = &S.src[(py_ + y) * LCU + px_ + xs];
+                }
             }
-            const uint8_t *s = &S.src[(py_ + y) * LCU + px_ + xs];
-            uint32_t d = 0;
-            /* one unaligned 16-byte (8x8 PUs: 8-byte) global load per plane instead of four dword loads: the address units take a wave's 64 scattered rows once per
-             * plane.  avg of identical pointers is the identity ((v+v+1)>>1 == v): the second plane of a full / half-pel position is not fetched */
-            if (wseg == 16) {
-                const uint4 a0 = *(const u128u_w *)a[0], a1 = *(const u128u_w *)a[1];
-                uint4 b0 = a0, b1 = a1;
-                if (b[0] != a[0])
-                    b0 = *(const u128u_w *)b[0];
-                if (b[1] != a[1])
-                    b1 = *(const u128u_w *)b[1];
-                const uint4 sv = *(const uint4 *)s;
-                d = sad4(sv.x, avg4(avg4(a0.x, b0.x), avg4(a1.x, b1.x)), d);
-                d = sad4(sv.y, avg4(avg4(a0.y, b0.y), avg4(a1.y, b1.y)), d);
-                d = sad4(sv.z, avg4(avg4(a0.z, b0.z), avg4(a1.z, b1.z)), d);
-                d = sad4(sv.w, avg4(avg4(a0.w, b0.w), avg4(a1.w, b1.w)), d);
-            } else {
-                typedef uint2 __attribute__((aligned(1))) u64u_w;
-                const uint2 a0 = *(const u64u_w *)a[0], a1 = *(const u64u_w *)a[1];
-                uint2 b0 = a0, b1 = a1;
-                if (b[0] != a[0])
-                    b0 = *(const u64u_w *)b[0];
-                if (b[1] != a[1])
-                    b1 = *(const u64u_w *)b[1];
-                const uint2 sv = *(const uint2 *)s;
-                d = sad4(sv.x, avg4(avg4(a0.x, b0.x), avg4(a1.x, b1.x)), d);
-                d = sad4(sv.y, avg4(avg4(a0.y, b0.y), avg4(a1.y, b1.y)), d);
+#pragma unroll
+            for (int u = 0; u < ME_BI_ITEMS; u++) {
+                if (!iG[u]) /* past the end: whole waves (every tier's share of the index space is a multiple of 64) */
+                    continue;
+                const uint4 a0 = va0[u], b0 = vb0[u], a1 = va1[u], b1 = vb1[u];
+                uint32_t d = 0;
+                if (iw[u] == 16) {
+                    const uint4 sv = *(const uint4 *)is[u];
+                    d = sad4(sv.x, avg4(avg4(a0.x, b0.x), avg4(a1.x, b1.x)), d);
+                    d = sad4(sv.y, avg4(avg4(a0.y, b0.y), avg4(a1.y, b1.y)), d);
+                    d = sad4(sv.z, avg4(avg4(a0.z, b0.z), avg4(a1.z, b1.z)), d);
+                    d = sad4(sv.w, avg4(avg4(a0.w, b0.w), avg4(a1.w, b1.w)), d);
+                } else { /* 8x8 PUs: the first eight of the sixteen bytes */
+                    const uint2 sv = *(const uint2 *)is[u];
+                    d = sad4(sv.x, avg4(avg4(a0.x, b0.x), avg4(a1.x, b1.x)), d);
+                    d = sad4(sv.y, avg4(avg4(a0.y, b0.y), avg4(a1.y, b1.y)), d);
+                }
+                /* the items of a PU sit on adjacent lanes (groups of 4 .. 64, aligned): summed by shuffles, one LDS atomic per group instead of one per item
+                 * (64 lanes on one address serialise) */
+                const int G = iG[u];
+                for (int o = 1; o < G; o <<= 1)
+                    d += __shfl_xor(d, o);
+                if ((ij[u] & (G - 1)) == 0)
+                    atomicAdd(&B.bipred[in_[u]], d);
             }
-            /* the items of a PU sit on adjacent lanes (groups of 4 .. 64, aligned: every tier's share of the index space is a multiple of 64): summed by shuffles,
-             * one LDS atomic per group instead of one per item (64 lanes on one address serialise) */
-            const int per_pu = rows << lgsegs, G = per_pu < 64 ? per_pu : 64;
-            for (int o = 1; o < G; o <<= 1)
-                d += __shfl_xor(d, o);
-            if ((j & (G - 1)) == 0)
-                atomicAdd(&B.bipred[n], d);
         }
         __syncthreads();
     }
