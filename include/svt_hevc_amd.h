@@ -1628,6 +1628,21 @@ SVT_AMD_API int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDec
                                                 const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot,
                                                 const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp,
                                                 SvtAmdMdLcuOut *md_out, SvtAmdLcuWork *works, SvtAmdLcuResult *results);
+/* The same two calls for a 10-bit picture (a picture object created with bytes_per_sample = 2; encoderBitDepth 10, BASELINE configs[3]).  The reference's mode decision
+ * stays an 8-bit process there - its source is the input picture's 8-bit plane, its inter candidates are predicted from the 8 most significant bits of the 16-bit reference
+ * pictures (Inter2Nx2NPuPredictionHevc with is16bit: UnPackReferenceBlock, Codec/EbInterPrediction.c:414-457, :589-760; AddChromaEncDec likewise, EbCodingLoop.c:3841) - and
+ * only EncodePass codes the 10-bit samples (EncodePassPackLcu, EbCodingLoop.c:2867).  src_*: HOST planes of the 10-bit source in 16-bit words (8-bit plane << 2 | the two
+ * extra bits), strides in samples; the call derives the 8-MSB views of the source and of the picture object's 16-bit reference pictures on the device and decides on
+ * those, then encodes on the 10-bit samples: works / results are the 16-bit records of svt_amd_encode_picture16.  Decisions (md_out) as in the 8-bit calls. */
+SVT_AMD_API int svt_amd_md_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus,
+                                            const uint16_t *src_y, uint32_t stride_y, const uint16_t *src_cb, const uint16_t *src_cr,
+                                            uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot, const SvtAmdCabacCost *cost,
+                                            SvtAmdMdLcuOut *md_out, SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results);
+SVT_AMD_API int svt_amd_md_encode_picture_inter16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X,
+                                                  const SvtAmdMdLcu *lcus, const uint16_t *src_y, uint32_t stride_y, const uint16_t *src_cb,
+                                                  const uint16_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot,
+                                                  const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp, SvtAmdMdLcuOut *md_out,
+                                                  SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results);
 SVT_AMD_API int svt_amd_md_picture_supported_inter(const SvtAmdMdPicture *P, const SvtAmdMdInter *X);
 /* 1 when every one of the n LCUs is decided by ModeDecisionLcu with luma-only candidates (the per-LCU half of the two checks above) */
 SVT_AMD_API int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, int n);

@@ -146,7 +146,7 @@ struct EpRefWindows {
     alignas(16) uint8_t pix[2][H * P + 16];
 };
 /* by all 256 threads of the workgroup; mv[l] = the centre vector of list l in quarter samples */
-__device__ __forceinline__ void ep_ref_windows_fill(const EpPicture &P, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t);
+__device__ __forceinline__ void ep_ref_windows_fill(const EpRefPlanes *refs, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t);
 
 static __constant__ int8_t c_ep_luma_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1},
                                                    {0, 1, -5, 17, 58, -10, 4, -1}};
@@ -554,7 +554,7 @@ __device__ __forceinline__ void ep_inter_predict_core8(const EpRefPlanes *refs /
     }
 }
 
-__device__ __forceinline__ void ep_ref_windows_fill(const EpPicture &P, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t)
+__device__ __forceinline__ void ep_ref_windows_fill(const EpRefPlanes *refs, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t)
 {
     for (int l = 0; l < 2; l++) {
         if (!use[l]) {
@@ -562,7 +562,7 @@ __device__ __forceinline__ void ep_ref_windows_fill(const EpPicture &P, int lcu_
                 RW.valid[l] = 0;
             continue;
         }
-        const EpRefPlanes &R = P.ref[l];
+        const EpRefPlanes &R = refs[l];
         /* the position clamp of the core (Codec/EbInterPrediction.c:802-812) applied to the LCU's origin displaced by the centre vector */
         const int qx = min(max(((lcu_x + R.originX) << 2) + mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
         const int qy = min(max(((lcu_y + R.originY) << 2) + mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);

@@ -67,6 +67,11 @@ struct MdPictureDev {
     const SvtAmdMeLcuResult *me;
     const SvtAmdTmvpLcu *tmvp;
     int encode;                   /* 0: mode decision only (no work record, no encode pass) */
+    /* The mode decision works on 8-bit samples whatever the encoder's bit depth (Inter2Nx2NPuPredictionHevc narrows the 16-bit reference block it reads,
+     * UnPackReferenceBlock, Codec/EbInterPrediction.c:414-457; the source is the picture's 8-bit plane): mref = the reference pictures as the mode decision reads them -
+     * the picture object's own of an 8-bit picture, their 8-MSB views of a 10-bit one -, src16 = the 10-bit source the encode pass behind it codes (null: 8-bit). */
+    EpRefPlanes mref[2];
+    const uint16_t *src16[3];
     unsigned long long *prof;     /* debug (svt_amd_debug_md_profile): 16 shader-clock sums per LCU, or null */
     int prof_lcus;                /* LCUs of the picture: the sub-stage sums start behind the stage sums of all of them */
 };
@@ -178,12 +183,12 @@ struct MdShared {
     int16_t qbuf[4][32 * 32];
 };
 
-template <bool INTER>
+template <bool INTER, typename T>
 union MdEpShared {
     MdShared<INTER> md;
     struct {
-        EpShared<uint8_t> S;
-        EpLocal<uint8_t> L;
+        EpShared<T> S;
+        EpLocal<T> L;
     } ep;
 };
 
@@ -411,16 +416,7 @@ __device__ __forceinline__ unsigned long long md_readlane64(unsigned long long v
     return ((unsigned long long)hi << 32) | lo;
 }
 
-/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of the luma block of a candidate, by one wave, into dst (pitch = unit size) */
-__device__ __forceinline__ void md_predict_inter(const EpPicture &E, const MdCand &c, int x0, int y0, int N, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
-                                                 int tile_first = 0, int tile_step = 1)
-{
-    int16_t mv[2][2];
-    mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
-    ep_inter_predict_core<uint8_t>(E, x0, y0, N, c.dir, mv, 0, lane, mc, [&](int x, int y) { return dst + y * N + x; }, tile_first, tile_step);
-    EP_WAVE_SYNC();
-}
-/* ... of plane p (0 luma: N x N, 1 / 2 chroma: N/2 x N/2) into dst with pitch = the block's width */
+/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of plane p of a candidate (0 luma: N x N, 1 / 2 chroma: N/2 x N/2), by one wave, into dst with pitch = the block's width */
 __device__ MD_LEAF_CALL void md_predict_inter_plane(const EpRefPlanes *refs, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
                                                     int tile_first, int tile_step, const EpRefWindows *rw)
 {
@@ -545,7 +541,7 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
             ((uint32_t *)M.V.me)[i] = ((const uint32_t *)D.me[lcu].pu)[i];
         static_assert(sizeof(EpRefPlanes) % 4 == 0, "record sizes");
         for (int i = t; i < (int)(2 * sizeof(EpRefPlanes) / 4); i += 256)
-            ((uint32_t *)M.V.refs)[i] = ((const uint32_t *)E.ref)[i];
+            ((uint32_t *)M.V.refs)[i] = ((const uint32_t *)D.mref)[i];
         static_assert(sizeof(SvtAmdMdInter) % 4 == 0, "record sizes");
         for (int i = t; i < (int)(sizeof(SvtAmdMdInter) / 4); i += 256)
             ((uint32_t *)&M.V.X)[i] = ((const uint32_t *)D.X)[i];
@@ -579,7 +575,7 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
         int16_t cmv[2][2];
         cmv[0][0] = me0.x_mv_l0, cmv[0][1] = me0.y_mv_l0, cmv[1][0] = me0.x_mv_l1, cmv[1][1] = me0.y_mv_l1;
         const bool use[2] = {true, P.slice_type == 0};
-        ep_ref_windows_fill(E, lcu_x, lcu_y, use, cmv, M.V.rw, t);
+        ep_ref_windows_fill(D.mref, lcu_x, lcu_y, use, cmv, M.V.rw, t);
     }
 }
 
@@ -651,7 +647,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         if (use[0] || use[1]) { /* (uniform: every thread read the same LDS words) */
             const int x0k[2] = {M.V.rw.x0[0], M.V.rw.x0[1]}, y0k[2] = {M.V.rw.y0[0], M.V.rw.y0[1]}, vk[2] = {M.V.rw.valid[0], M.V.rw.valid[1]};
             __syncthreads();
-            ep_ref_windows_fill(E, lcu_x, lcu_y, use, cmv, M.V.rw, t);
+            ep_ref_windows_fill(D.mref, lcu_x, lcu_y, use, cmv, M.V.rw, t);
             if (t == 0)
                 for (int l = 0; l < 2; l++)
                     if (!use[l]) /* the list that keeps its window (the fill marks an unused list invalid) */
@@ -1397,14 +1393,13 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
         const MdStats st = md_stats(leaf);
         const MdCu u = M.S.cu[leaf];
         const int N = st.size, Cn = N >> 1, T = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
-        int16_t mv[2][2];
-        mv[0][0] = u.mv[0].x, mv[0][1] = u.mv[0].y, mv[1][0] = u.mv[1].x, mv[1][1] = u.mv[1].y;
         uint32_t cbf[2] = {0, 0};
         uint64_t bits[2] = {0, 0}, dist[2][2] = {{0, 0}, {0, 0}};
+        MdCand cd; /* the unit's final prediction as a candidate: from the reference pictures as the mode decision reads them (their 8-MSB views of a 10-bit picture) */
+        cd.type = MD_INTER, cd.dir = u.inter_dir, cd.mv[0] = u.mv[0], cd.mv[1] = u.mv[1];
         for (int p = 0; p < 2; p++) {
             uint8_t *pred = M.V.wpred[wave] + p * 1024;
-            ep_inter_predict_core<uint8_t>(E, lcu_x + st.x, lcu_y + st.y, N, u.inter_dir, mv, 1 + p, lane, M.V.mc[wave], [&](int x, int y) { return pred + y * Cn + x; });
-            EP_WAVE_SYNC();
+            md_predict_inter_plane(M.V.refs, cd, lcu_x + st.x, lcu_y + st.y, N, 1 + p, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
             for (int tu = 0; tu < ntu; tu++) {
                 const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                 uint32_t nz;
@@ -1425,8 +1420,8 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPictu
 }
 
 /* the EncDec input contract the decisions amount to (what svt_hook_encdec.c:fill_work builds on the host): the final tree in Z order */
-template <bool INTER>
-__device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmdMdPicture &P, const MdShared<INTER> &M, int lcu_x, int lcu_y, SvtAmdLcuWork &Wk)
+template <bool INTER, typename T>
+__device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmdMdPicture &P, const MdShared<INTER> &M, int lcu_x, int lcu_y, typename EpTypes<T>::Work &Wk)
 {
     const int t = threadIdx.x;
     const int lw = min(64, (int)P.width - lcu_x), lh = min(64, (int)P.height - lcu_y);
@@ -1463,14 +1458,28 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
         }
         Wk.num_cus = (uint8_t)n;
     }
-    for (int i = t; i < 64 * 64 / 4; i += 256)
-        ((uint32_t *)Wk.src_y)[i] = ((const uint32_t *)M.L.src)[i];
-    for (int i = t; i < 2 * 32 * 32; i += 256) {
-        const int p = i >> 10, e = i & 1023, y = e >> 5, x = e & 31;
-        uint8_t v = 0;
-        if (x < lw / 2 && y < lh / 2)
-            v = D.src[1 + p][(size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x];
-        (p ? Wk.src_cr : Wk.src_cb)[e] = v;
+    if constexpr (sizeof(T) == 1) {
+        for (int i = t; i < 64 * 64 / 4; i += 256)
+            ((uint32_t *)Wk.src_y)[i] = ((const uint32_t *)M.L.src)[i];
+        for (int i = t; i < 2 * 32 * 32; i += 256) {
+            const int p = i >> 10, e = i & 1023, y = e >> 5, x = e & 31;
+            uint8_t v = 0;
+            if (x < lw / 2 && y < lh / 2)
+                v = D.src[1 + p][(size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x];
+            (p ? Wk.src_cr : Wk.src_cb)[e] = v;
+        }
+    } else { /* the encode pass of a 10-bit picture codes the 10-bit source (EncodePassPackLcu's inputSample16bitBuffer, EbCodingLoop.c:2867); zero outside the picture */
+        for (int i = t; i < 64 * 64; i += 256) {
+            const int y = i >> 6, x = i & 63;
+            Wk.src_y[i] = (x < lw && y < lh) ? D.src16[0][(size_t)(lcu_y + y) * D.src_pitch[0] + lcu_x + x] : (uint16_t)0;
+        }
+        for (int i = t; i < 2 * 32 * 32; i += 256) {
+            const int p = i >> 10, e = i & 1023, y = e >> 5, x = e & 31;
+            uint16_t v = 0;
+            if (x < lw / 2 && y < lh / 2)
+                v = D.src16[1 + p][(size_t)(lcu_y / 2 + y) * D.src_pitch[1] + lcu_x / 2 + x];
+            (p ? Wk.src_cr : Wk.src_cb)[e] = v;
+        }
     }
 }
 
@@ -1478,13 +1487,13 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
 /* Two completion flags per LCU: md_done = the LCU's mode-decision state is in the picture's maps (what the mode decision of the right and the lower-left
  * LCU waits for), done = its encode pass is finished (what their encode pass waits for).  The mode decision of the picture therefore runs ahead of its
  * encode pass along the wavefront: the critical path of a picture is the mode-decision chain alone. */
-template <bool INTER>
-__global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPicture E, SvtAmdLcuWork *__restrict__ works, SvtAmdLcuResult *__restrict__ results,
+template <bool INTER, typename T>
+__global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPicture E, typename EpTypes<T>::Work *__restrict__ works, typename EpTypes<T>::Result *__restrict__ results,
                                                            int nlcu, int wl, unsigned *ticket, unsigned *done, unsigned *md_done, const unsigned *__restrict__ order,
                                                            unsigned epoch)
 {
     extern __shared__ __align__(16) unsigned char md_lds[];
-    MdEpShared<INTER> &U = *reinterpret_cast<MdEpShared<INTER> *>(md_lds);
+    MdEpShared<INTER, T> &U = *reinterpret_cast<MdEpShared<INTER, T> *>(md_lds);
     __shared__ unsigned s_ticket;
     const SvtAmdMdPicture &P = *D.P;
     for (;;) {
@@ -1541,7 +1550,7 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         if (D.encode) {
             if constexpr (INTER)
                 md_ep_kinds(D, E, P, U.md, lx * 64, ly * 64);
-            md_make_work<INTER>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
+            md_make_work<INTER, T>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1550,7 +1559,7 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
             __syncthreads();
             if (D.prof && threadIdx.x == 0)
                 c_work = __builtin_readcyclecounter();
-            ep_encode_lcu<uint8_t>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
+            ep_encode_lcu<T>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
             __syncthreads();
             if (D.prof && threadIdx.x == 0) {
                 unsigned long long *q = D.prof + 16 * (size_t)lcu;
@@ -1564,7 +1573,9 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
     }
 }
 
-static_assert(sizeof(MdEpShared<true>) <= 160 * 1024 && sizeof(MdEpShared<false>) <= 160 * 1024, "the LCU state has to fit the 160 KB of LDS of a CU");
+static_assert(sizeof(MdEpShared<true, uint8_t>) <= 160 * 1024 && sizeof(MdEpShared<false, uint8_t>) <= 160 * 1024 && sizeof(MdEpShared<true, uint16_t>) <= 160 * 1024 &&
+                  sizeof(MdEpShared<false, uint16_t>) <= 160 * 1024,
+              "the LCU state has to fit the 160 KB of LDS of a CU");
 
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
 extern "C" int svt_amd_md_picture_supported(const SvtAmdMdPicture *P) { return P ? md_picture_supported(P) : 0; }
@@ -1587,8 +1598,11 @@ struct SvtAmdMdState {
     SvtAmdMdLcu *d_lcus;
     SvtAmdMdPicture *d_P;
     SvtAmdMdLcuOut *d_out;
-    SvtAmdLcuWork *d_works;
-    SvtAmdLcuResult *d_results;
+    void *d_works, *d_results;    /* SvtAmdLcuWork / SvtAmdLcuResult of the picture object's sample width */
+    size_t work_bytes, result_bytes;
+    uint16_t *d_src16[3];          /* 10-bit pictures: the source as the encode pass codes it (d_src = its 8 MSBs, what the mode decision reads) */
+    uint8_t *d_ref8[2][3];         /* ... and the 8-MSB views of the two reference pictures (UnPackReferenceBlock) */
+    size_t ref8_bytes[2][3];
     size_t info_bytes, mv_bytes;
     unsigned long long *d_prof;
     unsigned *d_md_done;           /* epoch of the call whose mode decision finished the LCU */
@@ -1606,7 +1620,8 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
     if (!m)
         return;
     void *ptrs[] = {m->d.md_rec, m->d.md_info, m->d_src[0], m->d_src[1], m->d_src[2], m->d_ois, m->d_lcus, m->d_P, m->d_out, m->d_works, m->d_results,
-                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp, m->d_prof, m->d_md_done};
+                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp, m->d_prof, m->d_md_done, m->d_src16[0], m->d_src16[1], m->d_src16[2],
+                    m->d_ref8[0][0], m->d_ref8[0][1], m->d_ref8[0][2], m->d_ref8[1][0], m->d_ref8[1][1], m->d_ref8[1][2]};
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
@@ -1632,12 +1647,17 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     m->d.md_pitch = pic->d.pitch[0];
     m->d.info_pitch = ((uint32_t)(pic->d.width >> 2) + 63) & ~63u;
     m->info_bytes = sizeof(uint32_t) * (size_t)m->d.info_pitch * (pic->d.height >> 2);
-    bool ok = hipMalloc((void **)&m->d.md_rec, pic->plane_bytes[0]) == hipSuccess && hipMalloc((void **)&m->d.md_info, m->info_bytes) == hipSuccess;
-    for (int k = 0; k < 3 && ok; k++)
-        ok = hipMalloc((void **)&m->d_src[k], pic->plane_bytes[k]) == hipSuccess;
+    const size_t bps = pic->d.bps;
+    m->work_bytes = bps == 2 ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), m->result_bytes = bps == 2 ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+    bool ok = hipMalloc((void **)&m->d.md_rec, pic->plane_bytes[0] / bps) == hipSuccess && hipMalloc((void **)&m->d.md_info, m->info_bytes) == hipSuccess;
+    for (int k = 0; k < 3 && ok; k++) {
+        ok = hipMalloc((void **)&m->d_src[k], pic->plane_bytes[k] / bps) == hipSuccess;
+        if (bps == 2)
+            ok = ok && hipMalloc((void **)&m->d_src16[k], pic->plane_bytes[k]) == hipSuccess;
+    }
     ok = ok && hipMalloc((void **)&m->d_ois, sizeof(SvtAmdOisLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_lcus, sizeof(SvtAmdMdLcu) * n) == hipSuccess &&
          hipMalloc((void **)&m->d_P, sizeof(SvtAmdMdPicture)) == hipSuccess && hipMalloc((void **)&m->d_out, sizeof(SvtAmdMdLcuOut) * n) == hipSuccess &&
-         hipMalloc((void **)&m->d_works, sizeof(SvtAmdLcuWork) * n) == hipSuccess && hipMalloc((void **)&m->d_results, sizeof(SvtAmdLcuResult) * n) == hipSuccess;
+         hipMalloc((void **)&m->d_works, m->work_bytes * n) == hipSuccess && hipMalloc((void **)&m->d_results, m->result_bytes * n) == hipSuccess;
     m->d.mv_pitch = ((uint32_t)(pic->d.width >> 3) + 15) & ~15u;
     m->mv_bytes = sizeof(uint4) * (size_t)m->d.mv_pitch * ((pic->d.height + 7) >> 3);
     ok = ok && hipMalloc((void **)&m->d.md_mv, m->mv_bytes) == hipSuccess && hipMalloc((void **)&m->d_X, sizeof(SvtAmdMdInter)) == hipSuccess &&
@@ -1653,15 +1673,41 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     return SVT_AMD_OK;
 }
 
+/* the 8 most significant bits of 10-bit samples in 16-bit words (UnPack8BitDataSafeSub, C_DEFAULT/EbPackUnPack_C.c:203: sample >> 2): eight samples a thread */
+__global__ __launch_bounds__(256) void k_msb_view(const uint16_t *__restrict__ in, uint8_t *__restrict__ out, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const uint4 v = *(const uint4 *)(in + i);
+        uint2 o;
+        o.x = ((v.x >> 2) & 0xffu) | ((v.x >> 10) & 0xff00u) | (((v.y >> 2) & 0xffu) << 16) | (((v.y >> 18) & 0xffu) << 24);
+        o.y = ((v.z >> 2) & 0xffu) | ((v.z >> 10) & 0xff00u) | (((v.w >> 2) & 0xffu) << 16) | (((v.w >> 18) & 0xffu) << 24);
+        *(uint2 *)(out + i) = o;
+    } else {
+        for (size_t k = i; k < n; k++)
+            out[k] = (uint8_t)(in[k] >> 2);
+    }
+}
+static int msb_view(hipStream_t st, const void *in16, uint8_t *out8, size_t samples)
+{
+    if (!samples)
+        return SVT_AMD_OK;
+    hipLaunchKernelGGL(k_msb_view, dim3((unsigned)((samples + 2047) / 2048)), dim3(256), 0, st, (const uint16_t *)in16, out8, samples);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* bps: bytes per sample of the source planes, the work / result records and the picture object (1, or 2 = a 10-bit picture: the mode decision on the 8 MSBs of source
+ * and reference pictures, the encode pass on the 10-bit samples) */
 static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus,
-                             const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
+                             const void *src_y, uint32_t stride_y, const void *src_cb, const void *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
                              int ois_slot, const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp, const SvtAmdCabacCost *cost, SvtAmdMdLcuOut *md_out,
-                             SvtAmdLcuWork *works, SvtAmdLcuResult *results)
+                             void *works, void *results, uint32_t bps)
 {
     if (!ctx || !pic || !P || !lcus || !src_y || !src_cb || !src_cr || (!X && !cost))
         return SVT_AMD_ERR_BAD_PARAM;
-    if ((X ? !md_picture_supported_inter(P, X) : !md_picture_supported(P)) || P->width != pic->d.width || P->height != pic->d.height || pic->d.bps != 1) {
-        svt_amd_set_error("svt_amd_md_encode_picture: picture outside what this revision covers (svt_amd_md_picture_supported[_inter]), or not the picture object's size / 8-bit");
+    if ((X ? !md_picture_supported_inter(P, X) : !md_picture_supported(P)) || P->width != pic->d.width || P->height != pic->d.height || pic->d.bps != bps) {
+        svt_amd_set_error("svt_amd_md_encode_picture: picture outside what this revision covers (svt_amd_md_picture_supported[_inter]), or not the picture object's size / sample width");
         return SVT_AMD_ERR_BAD_PARAM;
     }
     if (X && (!pic->has_cost || !pic->has_ref[0] || (P->slice_type == 0 && !pic->has_ref[1]) || (X->tmvp_enable && !tmvp))) {
@@ -1737,13 +1783,36 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     static const bool timing = getenv("SVT_AMD_MD_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_up = t_begin, t_kernel = t_begin;
-    const uint8_t *hs[3] = {src_y, src_cb, src_cr};
+    const void *hs[3] = {src_y, src_cb, src_cr};
     for (int k = 0; k < 3; k++) {
         const uint32_t pw = k ? pic->d.width / 2 : pic->d.width, ph = k ? pic->d.height / 2 : pic->d.height;
-        HIP_TRY(hipMemcpy2DAsync(m->d_src[k], pic->d.pitch[k], hs[k], k ? stride_c : stride_y, pw, ph, hipMemcpyHostToDevice, st));
-        m->d.src[k] = m->d_src[k];
+        if (bps == 1) {
+            HIP_TRY(hipMemcpy2DAsync(m->d_src[k], pic->d.pitch[k], hs[k], k ? stride_c : stride_y, pw, ph, hipMemcpyHostToDevice, st));
+        } else { /* strides in samples */
+            HIP_TRY(hipMemcpy2DAsync(m->d_src16[k], (size_t)pic->d.pitch[k] * 2, hs[k], (size_t)(k ? stride_c : stride_y) * 2, (size_t)pw * 2, ph, hipMemcpyHostToDevice, st));
+            if ((rc = msb_view(st, m->d_src16[k], m->d_src[k], pic->plane_bytes[k] / 2)) != 0)
+                return rc;
+        }
+        m->d.src[k] = m->d_src[k], m->d.src16[k] = bps == 2 ? m->d_src16[k] : nullptr;
     }
     m->d.src_pitch[0] = pic->d.pitch[0], m->d.src_pitch[1] = pic->d.pitch[1];
+    for (int l = 0; l < 2; l++) { /* the reference pictures as the mode decision reads them */
+        m->d.mref[l] = pic->d.ref[l];
+        if (bps == 2 && X && pic->has_ref[l])
+            for (int p = 0; p < 3; p++) {
+                const size_t need = (size_t)pic->d.ref[l].size[p ? 1 : 0];
+                if (m->ref8_bytes[l][p] < need) {
+                    if (m->d_ref8[l][p])
+                        (void)hipFree(m->d_ref8[l][p]);
+                    m->d_ref8[l][p] = nullptr, m->ref8_bytes[l][p] = 0;
+                    HIP_TRY(hipMalloc((void **)&m->d_ref8[l][p], need + 16));
+                    m->ref8_bytes[l][p] = need;
+                }
+                if ((rc = msb_view(st, pic->d.ref[l].plane[p], m->d_ref8[l][p], need)) != 0)
+                    return rc;
+                m->d.mref[l].plane[p] = m->d_ref8[l][p];
+            }
+    }
     HIP_TRY(hipMemcpyAsync(m->d_lcus, lcus, sizeof(SvtAmdMdLcu) * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->d_P, P, sizeof(*P), hipMemcpyHostToDevice, st));
     if (cost) {
@@ -1778,15 +1847,17 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     HIP_TRY(hipMemsetAsync(pic->d_sync, 0, sizeof(unsigned), st));
     HIP_TRY(hipMemsetAsync(pic->d.mode_map, 0xFF, pic->map_bytes, st));
     HIP_TRY(hipMemsetAsync(m->d.md_info, 0xFF, m->info_bytes, st));
-    HIP_TRY(hipMemsetAsync(m->d_results, 0, sizeof(SvtAmdLcuResult) * (size_t)n, st));
-    HIP_TRY(hipMemsetAsync(m->d_works, 0, sizeof(SvtAmdLcuWork) * (size_t)n, st));
+    HIP_TRY(hipMemsetAsync(m->d_results, 0, m->result_bytes * (size_t)n, st));
+    HIP_TRY(hipMemsetAsync(m->d_works, 0, m->work_bytes * (size_t)n, st));
     {
         static std::mutex mu;
         static bool attr[64];
         std::lock_guard<std::mutex> g(mu);
         if (!attr[ctx->device & 63]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false>)));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true>)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint8_t>)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint8_t>)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint16_t>)));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint16_t>)));
             attr[ctx->device & 63] = true;
         }
     }
@@ -1811,12 +1882,18 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
     m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
-    if (X)
-        hipLaunchKernelGGL(k_md_encode_picture<true>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
-                           pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
+    if (X && bps == 1)
+        hipLaunchKernelGGL((k_md_encode_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true, uint8_t>), st, m->d, pic->d, (SvtAmdLcuWork *)m->d_works,
+                           (SvtAmdLcuResult *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
+    else if (bps == 1)
+        hipLaunchKernelGGL((k_md_encode_picture<false, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false, uint8_t>), st, m->d, pic->d, (SvtAmdLcuWork *)m->d_works,
+                           (SvtAmdLcuResult *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
+    else if (X)
+        hipLaunchKernelGGL((k_md_encode_picture<true, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true, uint16_t>), st, m->d, pic->d, (SvtAmdLcuWork16 *)m->d_works,
+                           (SvtAmdLcuResult16 *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     else
-        hipLaunchKernelGGL(k_md_encode_picture<false>, dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false>), st, m->d, pic->d, m->d_works, m->d_results, n_active, wl,
-                           pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
+        hipLaunchKernelGGL((k_md_encode_picture<false, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false, uint16_t>), st, m->d, pic->d, (SvtAmdLcuWork16 *)m->d_works,
+                           (SvtAmdLcuResult16 *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev_k1, st));
     if (timing) {
@@ -1826,9 +1903,9 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     if (md_out)
         HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));
     if (works)
-        HIP_TRY(hipMemcpyAsync(works, m->d_works, sizeof(SvtAmdLcuWork) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(works, m->d_works, m->work_bytes * (size_t)n, hipMemcpyDeviceToHost, st));
     if (results)
-        HIP_TRY(hipMemcpyAsync(results, m->d_results, sizeof(SvtAmdLcuResult) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(results, m->d_results, m->result_bytes * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -1845,7 +1922,15 @@ extern "C" int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture
 {
     if (!cost)
         return SVT_AMD_ERR_BAD_PARAM;
-    return md_encode_picture(ctx, pic, P, nullptr, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, nullptr, -1, nullptr, cost, md_out, works, results);
+    return md_encode_picture(ctx, pic, P, nullptr, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, nullptr, -1, nullptr, cost, md_out, works, results, 1);
+}
+extern "C" int svt_amd_md_encode_picture16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus, const uint16_t *src_y,
+                                           uint32_t stride_y, const uint16_t *src_cb, const uint16_t *src_cr, uint32_t stride_c, const SvtAmdOisLcuResult *ois,
+                                           int ois_slot, const SvtAmdCabacCost *cost, SvtAmdMdLcuOut *md_out, SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results)
+{
+    if (!cost)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return md_encode_picture(ctx, pic, P, nullptr, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, nullptr, -1, nullptr, cost, md_out, works, results, 2);
 }
 
 extern "C" int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus,
@@ -1855,7 +1940,16 @@ extern "C" int svt_amd_md_encode_picture_inter(SvtAmdContext *ctx, SvtAmdEncDecP
 {
     if (!X)
         return SVT_AMD_ERR_BAD_PARAM;
-    return md_encode_picture(ctx, pic, P, X, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, me, me_slot, tmvp, nullptr, md_out, works, results);
+    return md_encode_picture(ctx, pic, P, X, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, me, me_slot, tmvp, nullptr, md_out, works, results, 1);
+}
+extern "C" int svt_amd_md_encode_picture_inter16(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus,
+                                                 const uint16_t *src_y, uint32_t stride_y, const uint16_t *src_cb, const uint16_t *src_cr, uint32_t stride_c,
+                                                 const SvtAmdOisLcuResult *ois, int ois_slot, const SvtAmdMeLcuResult *me, int me_slot, const SvtAmdTmvpLcu *tmvp,
+                                                 SvtAmdMdLcuOut *md_out, SvtAmdLcuWork16 *works, SvtAmdLcuResult16 *results)
+{
+    if (!X)
+        return SVT_AMD_ERR_BAD_PARAM;
+    return md_encode_picture(ctx, pic, P, X, lcus, src_y, stride_y, src_cb, src_cr, stride_c, ois, ois_slot, me, me_slot, tmvp, nullptr, md_out, works, results, 2);
 }
 
 /* debug: stage clocks of the mode-decision kernel.  First call (out == NULL or not): switches the collection on for the picture object's later

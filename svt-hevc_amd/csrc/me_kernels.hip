@@ -1265,14 +1265,35 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                     const uint8_t *r = wat(pl, ox + px_ + (mvx(mv) >> 2) + ddx, oy + py_ + (mvy(mv) >> 2) + y0 + ddy);
                     const uint8_t *sp = &S.src[(py_ + y0) * LCU + px_];
                     uint32_t d = 0, sd = 0;
-                    for (int rr = 0; rr < rpc; rr++) {
-                        for (int x = 0; x < sz; x += 8) {
-                            uint32_t v[2];
-                            lds_ld_unaligned<2>(r + x, v);
-                            row_metric(method, *(const uint32_t *)(sp + x), v[0], d, sd);
-                            row_metric(method, *(const uint32_t *)(sp + x + 4), v[1], d, sd);
+                    /* the item's rows as 16-byte segments (8x8 PUs: 8-byte), four at a time: ALL their LDS reads first (source: one aligned read; window:
+                     * aligned dwords + v_alignbyte), then the metric - one LDS round trip per four segments instead of one per eight samples */
+                    const int lgspr = tier == 0 ? 2 : tier == 1 ? 1 : 0, nseg = rpc << lgspr, rs = pl.stride * rstep;
+                    for (int s0_ = 0; s0_ < nseg; s0_ += 4) {
+                        uint32_t sv[4][4], rv[4][4];
+#pragma unroll
+                        for (int q_ = 0; q_ < 4; q_++) {
+                            const int sg = s0_ + q_, rr = sg >> lgspr, x = (sg & ((1 << lgspr) - 1)) << 4;
+                            if (sz >= 16) {
+                                const uint4 v4 = *(const uint4 *)(sp + rr * (LCU * rstep) + x);
+                                sv[q_][0] = v4.x, sv[q_][1] = v4.y, sv[q_][2] = v4.z, sv[q_][3] = v4.w;
+                                lds_ld_unaligned<4>(r + rr * rs + x, rv[q_]);
+                            } else {
+                                const uint2 v2 = *(const uint2 *)(sp + rr * (LCU * rstep));
+                                uint32_t w2[2];
+                                lds_ld_unaligned<2>(r + rr * rs, w2);
+                                sv[q_][0] = v2.x, sv[q_][1] = v2.y, rv[q_][0] = w2[0], rv[q_][1] = w2[1];
+                                sv[q_][2] = sv[q_][3] = rv[q_][2] = rv[q_][3] = 0; /* metric of equal words: nothing */
+                            }
                         }
-                        r += pl.stride * rstep, sp += LCU * rstep;
+#pragma unroll
+                        for (int q_ = 0; q_ < 4; q_++) {
+                            row_metric(method, sv[q_][0], rv[q_][0], d, sd);
+                            row_metric(method, sv[q_][1], rv[q_][1], d, sd);
+                            if (sz >= 16) {
+                                row_metric(method, sv[q_][2], rv[q_][2], d, sd);
+                                row_metric(method, sv[q_][3], rv[q_][3], d, sd);
+                            }
+                        }
                     }
                     for (int o = 1; o < (1 << lc); o <<= 1)
                         d += __shfl_xor(d, o), sd += __shfl_xor(sd, o);
@@ -1379,18 +1400,38 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                     const uint8_t *sp = &S.src[(py_ + y) * LCU + px_];
                     uint32_t d = 0, sdv = 0;
                     if (live) {
-                        for (int rr = 0; rr < rpc; rr++) {
-                            /* source = MeContext_t.lcuBuffer: zero outside the picture (trap A19) */
-                            const int inside_y = (py_ + y + rr * rstep) < lh;
-                            for (int x = 0; x < sz; x += 8) {
-                                uint32_t v1[2], v2[2];
-                                lds_ld_unaligned<2>(r1 + x, v1);
-                                lds_ld_unaligned<2>(r2 + x, v2);
-                                const int in = inside_y && (px_ + x) < lw; /* lw is a multiple of 8 */
-                                row_metric(method, in ? *(const uint32_t *)(sp + x) : 0u, avg4(v1[0], v2[0]), d, sdv);
-                                row_metric(method, in ? *(const uint32_t *)(sp + x + 4) : 0u, avg4(v1[1], v2[1]), d, sdv);
+                        /* as in the half-pel stage: 16-byte segments, four at a time, every LDS read (source and the two planes) before the metric */
+                        const int lgspr = sz == 32 ? 1 : 0, nseg = rpc << lgspr, rs1 = w1.stride * rstep, rs2 = w2.stride * rstep;
+                        for (int s0_ = 0; s0_ < nseg; s0_ += 4) {
+                            uint32_t sv[4][4], v1[4][4], v2[4][4];
+#pragma unroll
+                            for (int q_ = 0; q_ < 4; q_++) {
+                                const int sg = s0_ + q_, rr = sg >> lgspr, x = (sg & ((1 << lgspr) - 1)) << 4;
+                                /* source = MeContext_t.lcuBuffer: zero outside the picture (trap A19); lw is a multiple of 8 */
+                                const bool inside_y = (py_ + y + rr * rstep) < lh, in0 = inside_y && (px_ + x) < lw, in1 = inside_y && (px_ + x + 8) < lw;
+                                if (sz >= 16) {
+                                    const uint4 v4 = *(const uint4 *)(sp + rr * (LCU * rstep) + x);
+                                    sv[q_][0] = in0 ? v4.x : 0u, sv[q_][1] = in0 ? v4.y : 0u, sv[q_][2] = in1 ? v4.z : 0u, sv[q_][3] = in1 ? v4.w : 0u;
+                                    lds_ld_unaligned<4>(r1 + rr * rs1 + x, v1[q_]);
+                                    lds_ld_unaligned<4>(r2 + rr * rs2 + x, v2[q_]);
+                                } else {
+                                    const uint2 s2 = *(const uint2 *)(sp + rr * (LCU * rstep));
+                                    uint32_t a2[2], b2[2];
+                                    lds_ld_unaligned<2>(r1 + rr * rs1, a2);
+                                    lds_ld_unaligned<2>(r2 + rr * rs2, b2);
+                                    sv[q_][0] = in0 ? s2.x : 0u, sv[q_][1] = in0 ? s2.y : 0u, v1[q_][0] = a2[0], v1[q_][1] = a2[1], v2[q_][0] = b2[0], v2[q_][1] = b2[1];
+                                    sv[q_][2] = sv[q_][3] = v1[q_][2] = v1[q_][3] = v2[q_][2] = v2[q_][3] = 0;
+                                }
                             }
-                            r1 += w1.stride * rstep, r2 += w2.stride * rstep, sp += LCU * rstep;
+#pragma unroll
+                            for (int q_ = 0; q_ < 4; q_++) {
+                                row_metric(method, sv[q_][0], avg4(v1[q_][0], v2[q_][0]), d, sdv);
+                                row_metric(method, sv[q_][1], avg4(v1[q_][1], v2[q_][1]), d, sdv);
+                                if (sz >= 16) {
+                                    row_metric(method, sv[q_][2], avg4(v1[q_][2], v2[q_][2]), d, sdv);
+                                    row_metric(method, sv[q_][3], avg4(v1[q_][3], v2[q_][3]), d, sdv);
+                                }
+                            }
                         }
                     }
                     for (int o = 1; o < (1 << lc); o <<= 1)

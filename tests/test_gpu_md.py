@@ -330,3 +330,132 @@ def test_md_of_b_pictures_at_baseline_sizes_matches_the_reference_run_on_the_box
     assert len(g["picture_number"]) >= 3 and g["pic"]["is_reference"].any() and not g["pic"]["is_reference"].all()
     r = md_bench.run_inter(product, g, reps=1, encode=True)
     assert r["lcus"] == S.lcu_count(w, h) and r["final_units"] >= r["lcus"]
+
+
+# ---- 10-bit pictures (BASELINE configs[3]) -------------------------------------------------------------------------------------------------
+# The reference's mode decision of a 10-bit encode is an 8-bit process: its source is the input picture's 8-bit plane and its inter candidates are
+# predicted from the 8 most significant bits of the 16-bit reference pictures (Inter2Nx2NPuPredictionHevc with is16bit: UnPackReferenceBlock,
+# Codec/EbInterPrediction.c:414-457, sample >> 2); only EncodePass codes the 10-bit samples.  A 10-bit picture whose samples are the fixture's 8-bit
+# ones with two arbitrary extra bits therefore has to be DECIDED exactly as the reference decided the fixture's picture - its records are the
+# expectation - and ENCODED as the pinned 16-bit oracle encodes the device's work records.
+def _widen(a, rng):
+    return ((a.astype(np.uint16) << 2) | rng.integers(0, 4, a.shape, dtype=np.uint16)).astype(np.uint16)
+
+
+def _sig16(lib):
+    vp = C.c_void_p
+    lib.svt_amd_md_encode_picture16.restype = C.c_int
+    lib.svt_amd_md_encode_picture16.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_int, vp, vp, vp, vp]
+    lib.svt_amd_md_encode_picture_inter16.restype = C.c_int
+    lib.svt_amd_md_encode_picture_inter16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [vp] * 5
+
+
+def _check_source16(works, src16, w, h, tag):
+    for i in range(len(works)):
+        x0, y0 = int(works[i]["lcu_x"]), int(works[i]["lcu_y"])
+        lw, lh = min(64, w - x0), min(64, h - y0)
+        assert np.array_equal(works[i]["src_y"].reshape(64, 64)[:lh, :lw], src16[0][y0:y0 + lh, x0:x0 + lw]), (tag, i, "src_y")
+        for p, nm in ((1, "src_cb"), (2, "src_cr")):
+            assert np.array_equal(works[i][nm].reshape(32, 32)[:lh // 2, :lw // 2], src16[p][y0 // 2:(y0 + lh) // 2, x0 // 2:(x0 + lw) // 2]), (tag, i, nm)
+
+
+@pytest.mark.parametrize("name", ["i_motion_416x240_m9", "i_tiles_motion_640x384_m9"])
+def test_md_encode_picture16_decides_on_the_8_msbs_and_encodes_the_10_bit_samples(product, oracle, name):
+    lib = product
+    sig(lib)
+    _sig16(lib)
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    rng = np.random.default_rng(10)
+    oracle.svt_oracle_encode_lcu16.restype = None
+    oracle.svt_oracle_encode_lcu16.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 2, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        for k in range(len(g["picture_number"])):
+            tag = "%s picture %d (10-bit)" % (name, int(g["picture_number"][k]))
+            P, lcus, cost, o = (np.ascontiguousarray(v) for v in (g["pic"][k:k + 1], g["lcu"][k], g["cost"][k], g["ois"][k]))
+            src16 = [_widen(g[n][k], rng) for n in ("src_y", "src_cb", "src_cr")]
+            n = len(lcus)
+            out, works, res = np.zeros(n, S.MD_LCU_OUT_DTYPE), np.zeros(n, S.LCU_WORK16_DTYPE), np.zeros(n, S.LCU_RESULT16_DTYPE)
+            rc = lib.svt_amd_md_encode_picture16(ctx, pic, P.ctypes.data, lcus.ctypes.data, src16[0].ctypes.data, src16[0].shape[1], src16[1].ctypes.data,
+                                                 src16[2].ctypes.data, src16[1].shape[1], o.ctypes.data, 0, cost.ctypes.data, out.ctypes.data, works.ctypes.data,
+                                                 res.ctypes.data)
+            assert rc == 0, lib.svt_amd_last_error()
+            compare_md(out, g["out"][k], tag)                                   # the reference's decisions
+            _check_source16(works, src16, w, h, tag)
+            pitches = (w + 32, w // 2 + 16, w // 2 + 16)                        # the encode pass behind them: the pinned 16-bit oracle, raster order
+            pb = (C.c_uint32 * 3)(*pitches)
+            rec = [np.full((hh, p), 0xA5A5, np.uint16) for hh, p in zip((h, h // 2, h // 2), pitches)]
+            mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+            rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+            want = np.zeros(n, S.LCU_RESULT16_DTYPE)
+            for i in range(n):
+                oracle.svt_oracle_encode_lcu16(rp, pb, mp.ctypes.data, mp.shape[1], w, h, works[i:i + 1].ctypes.data, want[i:i + 1].ctypes.data)
+                compare_lcu(works[i], want[i], res[i], w, h, (tag, i))
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
+
+
+@pytest.mark.parametrize("name", [c for c in INTER_CASES if c in ("b_motion_416x240_m8", "bref_motion_416x240_m8", "pref_motion_416x240_m8_ld", "bref_tiles_motion_640x384_m8")])
+def test_md_encode_picture_inter16_decides_on_the_8_msbs_and_encodes_the_10_bit_samples(product, oracle, name):
+    import torch
+    from test_oracle_encodepass_golden import inter_oracle_fn
+    from test_oracle_md_golden import inter_inputs, compare_kinds
+    lib = product
+    sig(lib)
+    _sig16(lib)
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    rng = np.random.default_rng(11)
+    fn = inter_oracle_fn(oracle, True)
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 2, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        for k in range(len(g["picture_number"])):
+            tag = "%s picture %d (10-bit)" % (name, int(g["picture_number"][k]))
+            P, lcus, cost, o = (np.ascontiguousarray(v) for v in (g["pic"][k:k + 1], g["lcu"][k], g["cost"][k], g["ois"][k]))
+            X, me, tmvp, refs8, planes8 = inter_inputs(g, k)
+            src16 = [_widen(g[n][k], rng) for n in ("src_y", "src_cb", "src_cr")]
+            planes16 = [[_widen(a, rng) for a in pl] for pl in planes8]
+            refs16 = [S.RefPicture(pl[0].ctypes.data, pl[1].ctypes.data, pl[2].ctypes.data, r.strideY, r.strideC, r.originX, r.originY, r.width, r.height)
+                      for pl, r in zip(planes16, refs8)]
+            dev = [[torch.from_numpy(a.view(np.int16)).cuda() for a in pl] for pl in planes16]
+            torch.cuda.synchronize()
+            rs = [S.RefPicture(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), r.strideY, r.strideC, r.originX, r.originY, r.width, r.height) for d, r in zip(dev, refs8)]
+            assert lib.svt_amd_encdec_picture_set_inter(ctx, pic, C.byref(rs[0]), C.byref(rs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
+            n = len(lcus)
+            out, works, res = np.zeros(n, S.MD_LCU_OUT_DTYPE), np.zeros(n, S.LCU_WORK16_DTYPE), np.zeros(n, S.LCU_RESULT16_DTYPE)
+            rc = lib.svt_amd_md_encode_picture_inter16(ctx, pic, P.ctypes.data, X.ctypes.data, lcus.ctypes.data, src16[0].ctypes.data, src16[0].shape[1],
+                                                       src16[1].ctypes.data, src16[2].ctypes.data, src16[1].shape[1], o.ctypes.data, 0, me.ctypes.data, 0,
+                                                       tmvp.ctypes.data if tmvp is not None else None, out.ctypes.data, works.ctypes.data, res.ctypes.data)
+            assert rc == 0, lib.svt_amd_last_error()
+            compare_md(out, g["out"][k], tag)                                   # the reference's decisions
+            kinds = np.full((n, 85), 0xFF, np.uint8)
+            for i in range(n):
+                m = int(works[i]["num_cus"])
+                cu = works[i]["cu"][:m]
+                inter = cu["pred_mode"] == 1
+                kinds[i, cu["leaf_index"][inter]] = cu["inter_kind"][inter]
+                assert np.array_equal(cu["mv"][inter], g["out"][k][i]["mv"][cu["leaf_index"][inter]]), (tag, i)
+            compare_kinds(kinds, g["ep_kind"][k], tag)                          # ... and its merge / skip decisions (AddChromaEncDec is an 8-bit process too)
+            _check_source16(works, src16, w, h, tag)
+            pitches = (w + 32, w // 2 + 16, w // 2 + 16)
+            pb = (C.c_uint32 * 3)(*pitches)
+            rec = [np.full((hh, p), 0xA5A5, np.uint16) for hh, p in zip((h, h // 2, h // 2), pitches)]
+            mp = np.full(((h + 3) // 4, (w + 3) // 4 + 3), 0xFF, np.uint8)
+            rp = (C.c_void_p * 3)(*[r.ctypes.data for r in rec])
+            want = np.zeros(n, S.LCU_RESULT16_DTYPE)
+            for i in range(n):
+                fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, C.byref(refs16[0]), C.byref(refs16[1]), cost.ctypes.data, works[i:i + 1].ctypes.data,
+                   want[i:i + 1].ctypes.data)
+                compare_lcu(works[i], want[i], res[i], w, h, (tag, i))
+            del dev
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
