@@ -95,8 +95,8 @@ typedef struct {
     uint64_t md_done_plus1;      /* ... and the device call for it has RETURNED (release store): what the lock-free fast path of the per-LCU wraps looks at */
     int md_ok;                   /* 1: served by the device; 0: outside what svt_amd_md_encode_picture covers - the reference code runs */
     SvtAmdMdLcuOut *md_out;      /* pinned host memory (svt_amd_host_alloc), like the staging arrays below: the picture's records move by DMA */
-    SvtAmdLcuWork *md_works;
-    SvtAmdLcuResult *md_res;
+    void *md_works, *md_res;     /* SvtAmdLcuWork / SvtAmdLcuResult of the entry's sample width (wide: the 16-bit twins) */
+    uint16_t *md_src16[3];       /* a 10-bit picture's source in 16-bit words (EncodePassPackLcu's packing, whole picture), pinned */
     SvtAmdMdLcu *md_lcus;
     SvtAmdOisLcuResult *md_ois;
     SvtAmdMeLcuResult *md_me;
@@ -123,6 +123,14 @@ void EncodePassPackLcu(SequenceControlSet_t *sequenceControlSetPtr, EbPictureBuf
 
 __thread int svt_hook_ep_active;
 static __thread EpServe *t_serve;
+/* the LCU's records of the picture's device call (SVT_HOOK_MD) into the thread's staging */
+static void serve_from_md(const EpPictureEntry *e, EB_U32 lcu)
+{
+    const size_t wb = e->wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = e->wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+    memcpy(&t_serve->work, (const uint8_t *)e->md_works + wb * lcu, wb);
+    memcpy(&t_serve->res, (const uint8_t *)e->md_res + rb * lcu, rb);
+    t_serve->wide = e->wide;
+}
 static __thread int t_md_kinds; /* the served LCU's work record comes from the device's mode decision: its inter_kind fields are decisions, not predictions */
 
 static pthread_mutex_t g_ep_lock = PTHREAD_MUTEX_INITIALIZER; /* picture table + lane pool */
@@ -181,7 +189,7 @@ static void entry_release(SvtAmdContext *lane, EpPictureEntry *e)
     if (e->pic)
         svt_amd_encdec_picture_destroy(lane, e->pic);
     free(e->pending), free(e->works_all), free(e->res_all), free(e->sao_enable);
-    void *pinned[] = {e->md_out, e->md_works, e->md_res, e->md_lcus, e->md_ois, e->md_me, e->md_tmvp};
+    void *pinned[] = {e->md_out, e->md_works, e->md_res, e->md_lcus, e->md_ois, e->md_me, e->md_tmvp, e->md_src16[0], e->md_src16[1], e->md_src16[2]};
     for (size_t i = 0; i < sizeof(pinned) / sizeof(pinned[0]); i++)
         if (pinned[i])
             svt_amd_host_free(lane, pinned[i]);
@@ -655,7 +663,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
     {   /* the common case of SVT_HOOK_MD: the picture's device call has returned - answered from its records without a global lock or a device lane (see entry_lookup) */
         EpPictureEntry *f = entry_lookup(scs, pcs, wide);
-        if (f && !wide && __atomic_load_n(&f->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1 && f->md_picture_plus1 == pcs->pictureNumber + 1) {
+        if (f && __atomic_load_n(&f->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1 && f->md_picture_plus1 == pcs->pictureNumber + 1) {
             const int tools0 = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
                                (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE);
             if (f->md_ok && !tools0) {
@@ -673,9 +681,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
                     if (all)
                         svt_hook_timeline("encodepass", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, first, svt_hook_now());
                 }
-                memcpy(&t_serve->work, &f->md_works[tbAddr], sizeof(SvtAmdLcuWork));
-                memcpy(&t_serve->res, &f->md_res[tbAddr], sizeof(SvtAmdLcuResult));
-                t_serve->wide = 0;
+                serve_from_md(f, tbAddr);
                 __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
                 t_serve->lcu = lcuPtr;
                 svt_hook_ep_active = 1, t_md_kinds = 1;
@@ -714,11 +720,9 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     /* tools that change a unit's QP, dead zone, coefficient shape or quantiser are outside this revision */
     const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
                       (contextPtr->mdContext->rdoqPmCoreMethod != EB_NO_RDOQ && contextPtr->mdContext->rdoqPmCoreMethod != EB_PMCORE); /* RDOQ: encMode 0 */
-    const int md_served = !tools && !wide && e->md_ok && e->md_picture_plus1 == pcs->pictureNumber + 1;
+    const int md_served = !tools && e->md_ok && e->md_picture_plus1 == pcs->pictureNumber + 1;
     if (md_served) { /* the picture's device call (svt_hook_md_lcu) encoded this LCU already: no work record to build, no device call to make */
-        memcpy(&t_serve->work, &e->md_works[tbAddr], sizeof(SvtAmdLcuWork));
-        memcpy(&t_serve->res, &e->md_res[tbAddr], sizeof(SvtAmdLcuResult));
-        t_serve->wide = 0;
+        serve_from_md(e, tbAddr);
         lane_release(lane);
         __atomic_add_fetch(&g_ep_gpu, 1, __ATOMIC_RELAXED);
         t_serve->lcu = lcuPtr;
@@ -1020,10 +1024,15 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     }
     const size_t n = (size_t)e->cap;
     if (!e->md_out) {
-        if (svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcuOut) * n, (void **)&e->md_out) || svt_amd_host_alloc(lane, sizeof(SvtAmdLcuWork) * n, (void **)&e->md_works) ||
-            svt_amd_host_alloc(lane, sizeof(SvtAmdLcuResult) * n, (void **)&e->md_res) || svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcu) * n, (void **)&e->md_lcus) ||
+        const size_t wb = e->wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = e->wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+        if (svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcuOut) * n, (void **)&e->md_out) || svt_amd_host_alloc(lane, wb * n, &e->md_works) ||
+            svt_amd_host_alloc(lane, rb * n, &e->md_res) || svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcu) * n, (void **)&e->md_lcus) ||
             svt_amd_host_alloc(lane, sizeof(SvtAmdOisLcuResult) * n, (void **)&e->md_ois))
             svt_hook_die("out of memory (mode-decision picture records)");
+        if (e->wide)
+            for (int k = 0; k < 3; k++)
+                if (svt_amd_host_alloc(lane, sizeof(uint16_t) * (size_t)(scs->lumaWidth >> (k ? 1 : 0)) * (scs->lumaHeight >> (k ? 1 : 0)), (void **)&e->md_src16[k]))
+                    svt_hook_die("out of memory (10-bit source picture)");
     }
     SvtAmdMdLcu *lcus = e->md_lcus;
     SvtAmdOisLcuResult *ois = e->md_ois;
@@ -1034,14 +1043,43 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
     const uint8_t *sy = in->bufferY + (size_t)in->originY * in->strideY + in->originX;
     const uint8_t *scb = in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2, *scr = in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2;
+    if (e->wide && (!inter || svt_amd_md_lcus_supported(&P, lcus, (int)n))) {
+        /* a 10-bit picture: the source EncodePass codes is the 8-bit planes plus the two extra bits, packed LCU by LCU at the top of EncodePass (EncodePassPackLcu,
+         * EbCodingLoop.c:2867) - here the reference's own packers (CompressedPackLcu / Pack2D_SRC, Codec/EbPictureOperators.h:160, :170) fill the whole picture at once;
+         * the device derives the mode decision's 8-bit view from it */
+        EbPictureBufferDesc_t *ip = (EbPictureBufferDesc_t *)pcs->ParentPcsPtr->enhancedPicturePtr;
+        const EB_U32 W = scs->lumaWidth, H = scs->lumaHeight;
+        for (EB_U32 y0 = 0; y0 < H; y0 += 64)
+            for (EB_U32 x0 = 0; x0 < W; x0 += 64) {
+                const EB_U32 lw = MIN(64u, W - x0), lh = MIN(64u, H - y0);
+                uint16_t *dy = e->md_src16[0] + (size_t)y0 * W + x0, *dcb = e->md_src16[1] + (size_t)(y0 / 2) * (W / 2) + x0 / 2, *dcr = e->md_src16[2] + (size_t)(y0 / 2) * (W / 2) + x0 / 2;
+                const EB_U32 oy = (y0 + ip->originY) * ip->strideY + x0 + ip->originX, ocb = ((y0 + ip->originY) >> 1) * ip->strideCb + ((x0 + ip->originX) >> 1),
+                             ocr = ((y0 + ip->originY) >> 1) * ip->strideCr + ((x0 + ip->originX) >> 1);
+                if (scs->staticConfig.compressedTenBitFormat == 1) {
+                    const EB_U16 l2 = ip->width / 4, c2 = (ip->width / 4) >> 1;
+                    CompressedPackLcu(ip->bufferY + oy, ip->strideY, ip->bufferBitIncY + y0 * l2 + (x0 / 4) * lh, lw / 4, dy, W, lw, lh);
+                    CompressedPackLcu(ip->bufferCb + ocb, ip->strideCb, ip->bufferBitIncCb + (y0 >> 1) * c2 + ((x0 >> 1) / 4) * (lh >> 1), (lw >> 1) / 4, dcb, W / 2, lw >> 1, lh >> 1);
+                    CompressedPackLcu(ip->bufferCr + ocr, ip->strideCr, ip->bufferBitIncCr + (y0 >> 1) * c2 + ((x0 >> 1) / 4) * (lh >> 1), (lw >> 1) / 4, dcr, W / 2, lw >> 1, lh >> 1);
+                } else {
+                    Pack2D_SRC(ip->bufferY + oy, ip->strideY, ip->bufferBitIncY + (y0 + ip->originY) * ip->strideBitIncY + x0 + ip->originX, ip->strideBitIncY, dy, W, lw, lh);
+                    Pack2D_SRC(ip->bufferCb + ocb, ip->strideCr, ip->bufferBitIncCb + ((y0 + ip->originY) >> 1) * ip->strideBitIncCb + ((x0 + ip->originX) >> 1),
+                               ip->strideBitIncCr, dcb, W / 2, lw >> 1, lh >> 1);
+                    Pack2D_SRC(ip->bufferCr + ocr, ip->strideCr, ip->bufferBitIncCr + ((y0 + ip->originY) >> 1) * ip->strideBitIncCr + ((x0 + ip->originX) >> 1),
+                               ip->strideBitIncCr, dcr, W / 2, lw >> 1, lh >> 1);
+                }
+            }
+    }
     const double t_p0 = md_now();
     if (!inter || svt_amd_md_lcus_supported(&P, lcus, (int)n))
-        picture_prepare(lane, e, pcs, 0, 0); /* the picture is the device's: reference pictures resident, rate tables (the call below resets the object) */
+        picture_prepare(lane, e, pcs, e->wide, 0); /* the picture is the device's: reference pictures resident, rate tables (the call below resets the object) */
     const double t_c0 = md_now();
     g_md_t_prepare += t_c0 - t_p0;
+    const EB_U32 W2 = scs->lumaWidth;
     if (!inter) {
-        if (svt_amd_md_encode_picture(lane, e->pic, &P, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out,
-                                      e->md_works, e->md_res))
+        if (e->wide ? svt_amd_md_encode_picture16(lane, e->pic, &P, lcus, e->md_src16[0], W2, e->md_src16[1], e->md_src16[2], W2 / 2, ois, 0,
+                                                  (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out, (SvtAmdLcuWork16 *)e->md_works, (SvtAmdLcuResult16 *)e->md_res)
+                    : svt_amd_md_encode_picture(lane, e->pic, &P, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, (const SvtAmdCabacCost *)pcs->cabacCost, e->md_out,
+                                                (SvtAmdLcuWork *)e->md_works, (SvtAmdLcuResult *)e->md_res))
             svt_hook_die("svt_amd_md_encode_picture");
     } else {
         /* a P / B picture: every LCU must be one ModeDecisionLcu decides with luma-only candidates; the motion-estimation results and the
@@ -1064,8 +1102,10 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
                 svt_md_fill_tmvp(&tmvp[i], &col->tmvpMap[i]);
         }
         const double t_c1 = md_now();
-        if (svt_amd_md_encode_picture_inter(lane, e->pic, &P, &X, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, me, 0, tmvp, e->md_out, e->md_works,
-                                            e->md_res))
+        if (e->wide ? svt_amd_md_encode_picture_inter16(lane, e->pic, &P, &X, lcus, e->md_src16[0], W2, e->md_src16[1], e->md_src16[2], W2 / 2, ois, 0, me, 0, tmvp, e->md_out,
+                                                        (SvtAmdLcuWork16 *)e->md_works, (SvtAmdLcuResult16 *)e->md_res)
+                    : svt_amd_md_encode_picture_inter(lane, e->pic, &P, &X, lcus, sy, in->strideY, scb, scr, in->strideCb, ois, 0, me, 0, tmvp, e->md_out,
+                                                      (SvtAmdLcuWork *)e->md_works, (SvtAmdLcuResult *)e->md_res))
             svt_hook_die("svt_amd_md_encode_picture_inter");
         t_dev = md_now() - t_c1;
         __atomic_add_fetch(&g_md_inter_pictures, 1, __ATOMIC_RELAXED);
@@ -1088,10 +1128,11 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
         g_md_state = getenv("SVT_HOOK_MD") ? 1 : -1;
         g_md_skip_intra = getenv("SVT_HOOK_MD") && !strcmp(getenv("SVT_HOOK_MD"), "pb"); /* SVT_HOOK_MD=pb: only P / B pictures go to the device */
     }
-    if (g_md_state < 0 || svt_hook_failed() || scs->staticConfig.encoderBitDepth != EB_8BIT || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
+    if (g_md_state < 0 || svt_hook_failed() || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
     svt_hook_note_callback(scs);
-    EpPictureEntry *e = entry_lookup(scs, pcs, 0);
+    const int wide = scs->staticConfig.encoderBitDepth > EB_8BIT; /* = EncDecContext_t.is16bit (EbEncDecProcess.c): the picture object holds 16-bit samples */
+    EpPictureEntry *e = entry_lookup(scs, pcs, wide);
     int ok = 0;
     if (e && __atomic_load_n(&e->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1) { /* the picture's device call has returned: no lock, no lane */
         ok = e->md_ok;
@@ -1099,7 +1140,7 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
     }
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);
-    e = picture_entry(lane, scs, pcs, 0, 0);
+    e = picture_entry(lane, scs, pcs, wide, 0);
     svt_hook_lock(&e->lock);
     if (e->md_picture_plus1 != pcs->pictureNumber + 1)
         md_picture(lane, e, scs, pcs, contextPtr);

@@ -487,6 +487,12 @@ MD_CASES = [
     ("noise", 320, 256, 5, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-q", "24"], ("inter", None, None)),
     # encMode 6 (chroma in the mode decision, CABAC-context update): outside this revision, every picture left to the reference code
     ("motion", 416, 240, 2, ["-encMode", "6", "-intra-period", "0"], "none"),
+    # 10-bit (BASELINE configs[3]'s bit depth and format at a small size): the mode decision on the 8 MSBs of source and reference pictures, the encode pass on the
+    # 10-bit samples, one svt_amd_md_encode_picture[_inter]16 call per picture; unpacked and compressed ("packed") 2-bit planes
+    ("motion10", 416, 240, 3, ["-encMode", "9", "-intra-period", "0", "-bit-depth", "10"], "all"),
+    ("motion10c", 640, 384, 6, ["-encMode", "9", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-bit-depth", "10", "-compressed-ten-bit-format", "1"],
+     ("inter", 5, 4)),
+    ("objects10", 416, 240, 9, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "28", "-bit-depth", "10"], ("inter", 6, 5)),
 ]
 
 
@@ -498,7 +504,12 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
     must be byte-identical to the unmodified reference's."""
     import re
     yuv = str(tmp_path / "clip.yuv")
-    S.write_clip(yuv, kind, w, h, n, 7)
+    if kind.endswith("10c"):
+        S.write_clip10_compressed(yuv, kind[:-3], w, h, n, 7)
+    elif kind.endswith("10"):
+        S.write_clip10(yuv, kind[:-2], w, h, n, 7)
+    else:
+        S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args + ["-o", str(tmp_path / "ref.yuv")], str(tmp_path / "ref.265"))
     env = {"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": str(tmp_path / "report.txt")}
     os.environ.update(env)
@@ -525,16 +536,18 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
     assert open(str(tmp_path / "ref.yuv"), "rb").read() == open(str(tmp_path / "hip.yuv"), "rb").read()
 
 
-def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(tmp_path):
-    """BASELINE configs[2] itself (4K, encMode 7, random access, SAO on), 17 pictures: motion estimation + open-loop intra search on the device and,
-    with SVT_HOOK_MD=1, mode decision + encode pass of the I picture, of every non-reference B picture (temporal layer 2) and of every layer-1 reference B picture
-    (CHROMA_MODE_FULL) as ONE device call each - the bitstream must be the unmodified reference's"""
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(tmp_path, cfg):
+    """BASELINE configs[2] itself (4K, encMode 7, random access, SAO on; tools/encoder_fps.py "cfg3") and configs[3] (the same in 10-bit, packed 2-bit planes; "cfg4"),
+    17 pictures: motion estimation + open-loop intra search on the device and, with SVT_HOOK_MD=1, mode decision + encode pass of the I picture, of every non-reference
+    B picture (temporal layer 2) and of every layer-1 reference B picture (CHROMA_MODE_FULL) as ONE device call each (10-bit: the mode decision on the 8 MSBs, the encode
+    pass on the 10-bit samples) - the bitstream must be the unmodified reference's"""
     import re
     import sys
     sys.path.insert(0, os.path.join(S.ROOT, "tools"))
     import encoder_fps as E
     rp = str(tmp_path / "report.txt")
-    r = E.measure("cfg3", frames=17, hip_env={"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": rp}, tmpdir=str(tmp_path))
+    r = E.measure(cfg, frames=17, hip_env={"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": rp}, tmpdir=str(tmp_path))
     rep = open(rp).read()
     m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\)", rep)
     assert m, rep
