@@ -1119,6 +1119,17 @@ SVT_AMD_API int svt_amd_encode_picture_rect16(SvtAmdContext *ctx, SvtAmdEncDecPi
  * the rectangle's borders must be tile borders of the SvtAmdMdLcu records; the other LCUs' records come back zeroed); rect NULL = the whole picture */
 SVT_AMD_API int svt_amd_encdec_picture_set_rect(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rect);
 SVT_AMD_API int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int rank);
+/* Multi-GPU over PICTURES (SURVEY 8e last row): the pictures of a mini-GOP are owned by different ranks - the two non-reference B pictures of temporal layer 2 run at
+ * the same time on two ranks - and a rank encodes the whole of its picture (svt_amd_encode_picture* / svt_amd_md_encode_picture*, deblocking, SAO); the only traffic is
+ * the finished REFERENCE picture, sent by its owner once:
+ *   svt_amd_encdec_picture_broadcast - ncclBroadcast of the object's latest stage from rank `root` (communicator of svt_amd_comm_init); on the other ranks the planes
+ *     land in the object's final stage, svt_amd_encdec_picture_reference then pads the picture there as on its owner;
+ *   svt_amd_encdec_picture_import    - the same hand-over between two picture objects of one process (logical ranks on one device, a host with its own transport):
+ *     a copy on ctx's stream; the owner's work on `from` must have completed (svt_amd_synchronize on its context);
+ *   svt_amd_recon_broadcast          - the collective on caller-owned planes (whole allocations of bytes[p] bytes, equal on every rank). */
+SVT_AMD_API int svt_amd_recon_broadcast(SvtAmdContext *ctx, void *const d_planes[3], const size_t bytes[3], int world, int rank, int root);
+SVT_AMD_API int svt_amd_encdec_picture_broadcast(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int world, int rank, int root);
+SVT_AMD_API int svt_amd_encdec_picture_import(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdEncDecPicture *from);
 SVT_AMD_API int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
                                             size_t slot_bytes, int to_slot);
 

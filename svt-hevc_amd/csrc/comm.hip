@@ -70,6 +70,7 @@ struct Rccl {
     int (*CommInitRank)(RcclComm *, int, RcclUniqueId, int);
     int (*CommDestroy)(RcclComm);
     int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t);
+    int (*Broadcast)(const void *, void *, size_t, int, int, RcclComm, hipStream_t);
     const char *(*GetErrorString)(int);
 };
 static Rccl g_rccl;
@@ -95,8 +96,9 @@ static int rccl_open(void)
     *(void **)&r.CommInitRank = dlsym(so, "ncclCommInitRank");
     *(void **)&r.CommDestroy = dlsym(so, "ncclCommDestroy");
     *(void **)&r.AllGather = dlsym(so, "ncclAllGather");
+    *(void **)&r.Broadcast = dlsym(so, "ncclBroadcast");
     *(void **)&r.GetErrorString = dlsym(so, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Broadcast) {
         svt_amd_set_error("RCCL: missing symbols");
         return SVT_AMD_ERR_DEVICE;
     }
@@ -259,6 +261,24 @@ extern "C" int svt_amd_recon_exchange(SvtAmdContext *ctx, void *const d_planes[3
     hipLaunchKernelGGL(k_xchg_copy, dim3(gx, (unsigned)world), dim3(256), 0, ctx->stream, P, ctx->d_xchg, slot, d_rects, bytes_per_sample, 0, world,
                        rank, 0);
     HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
+/* Picture-level parallelism (SURVEY 8e last row): a picture is encoded WHOLE by the rank that owns it; the only traffic is the finished reference picture, sent by its
+ * owner once - ncclBroadcast of the three planes (whole allocations of `bytes[p]` bytes, the same on every rank), stream-ordered on the context's stream. */
+extern "C" int svt_amd_recon_broadcast(SvtAmdContext *ctx, void *const d_planes[3], const size_t bytes[3], int world, int rank, int root)
+{
+    if (!ctx || !d_planes || !bytes || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (world == 1)
+        return SVT_AMD_OK;
+    if (!ctx->comm || ctx->comm_world != world || ctx->comm_rank != rank) {
+        svt_amd_set_error("svt_amd_recon_broadcast: no communicator of %d ranks on this context (svt_amd_comm_init)", world);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int p = 0; p < 3; p++)
+        RCCL_TRY(g_rccl.Broadcast(d_planes[p], d_planes[p], bytes[p], 0 /* ncclInt8 */, root, (RcclComm)ctx->comm, ctx->stream));
     return SVT_AMD_OK;
 }
 

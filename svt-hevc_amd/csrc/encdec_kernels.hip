@@ -485,6 +485,51 @@ extern "C" int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDecP
     const uint32_t pitch[3] = {pic->d.pitch[0] * pic->d.bps, pic->d.pitch[1] * pic->d.bps, pic->d.pitch[2] * pic->d.bps};
     return svt_amd_recon_exchange(ctx, planes, pitch, (int)pic->d.bps, rects, world, rank);
 }
+/* Picture-level parallelism: the rank that owns a picture encodes all of it; its finished picture (latest stage) goes to every rank ONCE, before
+ * svt_amd_encdec_picture_reference pads it there.  On the receiving ranks the planes land in the object's final stage (the object then counts as deblocked and
+ * SAO-filtered: nothing else of the picture exists on them).  _broadcast: ncclBroadcast on the context's communicator; _import: the same hand-over between two
+ * picture objects of one process (logical ranks on one device, peers with direct access, or a host with its own transport), a device-to-device copy. */
+extern "C" int svt_amd_recon_broadcast(SvtAmdContext *ctx, void *const d_planes[3], const size_t bytes[3], int world, int rank, int root);
+static int final_stage_planes(SvtAmdEncDecPicture *pic) /* the final stage's planes exist from the first SAO call, or from here */
+{
+    for (int k = 0; k < 3; k++)
+        if (!pic->fin[k] && hipMalloc((void **)&pic->fin[k], pic->plane_bytes[k]) != hipSuccess) {
+            svt_amd_set_error("hipMalloc (finished picture) failed");
+            return SVT_AMD_ERR_RESOURCES;
+        }
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_encdec_picture_broadcast(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int world, int rank, int root)
+{
+    if (!ctx || !pic || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return SVT_AMD_ERR_BAD_PARAM;
+    if (world == 1)
+        return SVT_AMD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rank != root ? final_stage_planes(pic) : SVT_AMD_OK;
+    if (rc)
+        return rc;
+    uint8_t *const *stage = rank != root ? pic->fin : pic->sao_done ? pic->fin : pic->deblocked ? pic->dbk : pic->d.rec;
+    void *planes[3] = {stage[0], stage[1], stage[2]};
+    rc = svt_amd_recon_broadcast(ctx, planes, pic->plane_bytes, world, rank, root);
+    if (rc == SVT_AMD_OK && rank != root)
+        pic->deblocked = pic->sao_done = true;
+    return rc;
+}
+extern "C" int svt_amd_encdec_picture_import(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdEncDecPicture *from)
+{
+    if (!ctx || !pic || !from || pic == from || pic->d.width != from->d.width || pic->d.height != from->d.height || pic->d.bps != from->d.bps)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = final_stage_planes(pic);
+    if (rc)
+        return rc;
+    uint8_t *const *stage = from->sao_done ? from->fin : from->deblocked ? from->dbk : from->d.rec;
+    for (int p = 0; p < 3; p++)
+        HIP_TRY(hipMemcpyAsync(pic->fin[p], stage[p], pic->plane_bytes[p], hipMemcpyDeviceToDevice, ctx->stream));
+    pic->deblocked = pic->sao_done = true;
+    return SVT_AMD_OK;
+}
 extern "C" int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
                                            size_t slot_bytes, int to_slot)
 {

@@ -43,6 +43,55 @@ def lcus_of(rect, w, h):
     return [y * wl + x for y in range(rect.y // 64, (rect.y + rect.h + 63) // 64) for x in range(rect.x // 64, (rect.x + rect.w + 63) // 64)]
 
 
+def finish_picture(oracle, g, w, h, f, first, works, rec, got, mine):
+    """deblocking and SAO of picture f behind its encode pass (rec: the planes as encoded, got: the LCUs' results), statistics and decisions of the LCUs in `mine`;
+    returns the finished planes"""
+    from test_oracle_dlf_golden import oracle_bs, oracle_dlf, oracle_sao
+    from test_oracle_encodepass_golden import allows_mismatch, deblock_maps, encoder_order_lcu, is16, sao_inputs_of_picture
+    from test_oracle_saodec_golden import STATS, oracle_decide_picture, same_decision
+    vp, u32 = C.c_void_p, C.c_uint32
+    oracle.svt_oracle_GatherSaoStatistics.argtypes = [C.c_int, C.c_int, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]
+    oracle.svt_oracle_GatherSaoStatistics.restype = None
+    bps = 2 if is16(g) else 1
+    nl = S.lcu_count(w, h)
+    cols, rows = (w + 63) // 64, (h + 63) // 64
+    cumap, cbf, qp, edge = deblock_maps(works, got, w, h)
+    hdr = dict(width=w, height=h, bytes_per_sample=bps, qp_stride=w // 8, tc_offset=0, beta_offset=0, cb_qp_offset=0, cr_qp_offset=0,
+               slice_type=int(works[0]["slice_type"]))
+    pic = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1), refpoc=np.ascontiguousarray(g["ref_poc"][first]), lcu_edge=edge,
+               bsv=np.zeros((nl, 256), np.uint8), bsh=np.zeros((nl, 256), np.uint8))
+    pic["bsv"], pic["bsh"] = oracle_bs(oracle, pic)
+    pic["pre"], pic["qp"] = rec, qp.reshape(-1)
+    mismatch = allows_mismatch(g, w, h, works[0])
+    fin = [r.copy() for r in rec] if mismatch else oracle_dlf(oracle, pic)
+    P, enable, params, want, idx = sao_inputs_of_picture(g, f, works, w, h)
+    out = fin
+    if P is not None:
+        stats = np.zeros((3, nl), STATS)
+        ncomp = 3 if P["mm_sao"][0] else (1 if P["temporal_layer"][0] < 2 else 0)
+        for k in mine:
+            wk = works[k]
+            x0, y0 = int(wk["lcu_x"]), int(wk["lcu_y"])
+            lw, lh = min(64, w - x0), min(64, h - y0)
+            for p in range(ncomp):
+                sh = 1 if p else 0
+                blk = np.ascontiguousarray(encoder_order_lcu(rec, fin, p, x0, y0, lw, lh, w, h, not wk["tile_right"],
+                                                             k + cols >= nl or not works[k + cols]["tile_top"]))
+                src = np.ascontiguousarray(wk[("src_y", "src_cb", "src_cr")[p]].reshape(64 >> sh, 64 >> sh))
+                st = stats[p][k:k + 1]
+                oracle.svt_oracle_GatherSaoStatistics(bps, 0 if P["mm_sao"][0] else 1, src.ctypes.data, 64 >> sh, blk.ctypes.data, blk.shape[1],
+                                                      lw >> sh, lh >> sh, st["boDiff"].ctypes.data, st["boCount"].ctypes.data,
+                                                      st["eoDiff"].ctypes.data, st["eoCount"].ctypes.data)
+        dec, _ = oracle_decide_picture(oracle, dict(P=P, stats=stats, enable=enable, params=params, cols=cols, rows=rows))
+        for i in idx:
+            if i in mine:
+                assert same_decision(dec[i], want[i]), (f, int(i), dec[i], want[i])
+        dec["edge_flags"] = params["edge_flags"]
+        if not mismatch:
+            out = oracle_sao(oracle, fin, bps, w, h, dec, 1, 1)
+    return out
+
+
 def oracle_rank_sequence(oracle, g, w, h, rects, rank, gather):
     """one rank's whole sequence with the CPU checker; gather(slot bytes) -> every rank's slot.  Returns the number of pictures checked."""
     from test_oracle_dlf_golden import oracle_bs, oracle_dlf, oracle_sao
@@ -75,40 +124,7 @@ def oracle_rank_sequence(oracle, g, w, h, rects, rank, gather):
             fn(rp, pb, mp.ctypes.data, mp.shape[1], w, h, C.byref(r0) if r0 else None, C.byref(r1) if r1 else None,
                cost.ctypes.data if cost is not None else None, works[k:k + 1].ctypes.data, got[k:k + 1].ctypes.data)
             compare_lcu(works[k], g["result"][first + k], got[k], w, h, (CASE, f, k), rec=False)
-        cumap, cbf, qp, edge = deblock_maps(works, got, w, h)
-        hdr = dict(width=w, height=h, bytes_per_sample=bps, qp_stride=w // 8, tc_offset=0, beta_offset=0, cb_qp_offset=0, cr_qp_offset=0,
-                   slice_type=int(works[0]["slice_type"]))
-        pic = dict(hdr=hdr, cumap=cumap.reshape(-1), cbf=cbf.reshape(-1), refpoc=np.ascontiguousarray(g["ref_poc"][first]), lcu_edge=edge,
-                   bsv=np.zeros((nl, 256), np.uint8), bsh=np.zeros((nl, 256), np.uint8))
-        pic["bsv"], pic["bsh"] = oracle_bs(oracle, pic)
-        pic["pre"], pic["qp"] = rec, qp.reshape(-1)
-        mismatch = allows_mismatch(g, w, h, works[0])
-        fin = [r.copy() for r in rec] if mismatch else oracle_dlf(oracle, pic)
-        P, enable, params, want, idx = sao_inputs_of_picture(g, f, works, w, h)
-        out = fin
-        if P is not None:
-            stats = np.zeros((3, nl), STATS)
-            ncomp = 3 if P["mm_sao"][0] else (1 if P["temporal_layer"][0] < 2 else 0)
-            for k in mine:
-                wk = works[k]
-                x0, y0 = int(wk["lcu_x"]), int(wk["lcu_y"])
-                lw, lh = min(64, w - x0), min(64, h - y0)
-                for p in range(ncomp):
-                    sh = 1 if p else 0
-                    blk = np.ascontiguousarray(encoder_order_lcu(rec, fin, p, x0, y0, lw, lh, w, h, not wk["tile_right"],
-                                                                 k + cols >= nl or not works[k + cols]["tile_top"]))
-                    src = np.ascontiguousarray(wk[("src_y", "src_cb", "src_cr")[p]].reshape(64 >> sh, 64 >> sh))
-                    st = stats[p][k:k + 1]
-                    oracle.svt_oracle_GatherSaoStatistics(bps, 0 if P["mm_sao"][0] else 1, src.ctypes.data, 64 >> sh, blk.ctypes.data, blk.shape[1],
-                                                          lw >> sh, lh >> sh, st["boDiff"].ctypes.data, st["boCount"].ctypes.data,
-                                                          st["eoDiff"].ctypes.data, st["eoCount"].ctypes.data)
-            dec, _ = oracle_decide_picture(oracle, dict(P=P, stats=stats, enable=enable, params=params, cols=cols, rows=rows))
-            for i in idx:
-                if i in mine:
-                    assert same_decision(dec[i], want[i]), (f, int(i), dec[i], want[i])
-            dec["edge_flags"] = params["edge_flags"]
-            if not mismatch:
-                out = oracle_sao(oracle, fin, bps, w, h, dec, 1, 1)
+        out = finish_picture(oracle, g, w, h, f, first, works, rec, got, mine)
         # before the exchange a rank holds its own rectangle of the finished picture and nothing else of value
         full = [np.zeros_like(p) for p in out]
         unslot(full, rects[rank], slot_of(out, rects[rank], bps), sdt)
