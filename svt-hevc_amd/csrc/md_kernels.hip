@@ -128,7 +128,7 @@ struct MdInterShared {
     MdMvUnit mvu[9 * 18];          /* (cy + 1) * 18 + cx + 1: 8x8 cells, cy in [-1, 8), cx in [-1, 16] */
     SvtAmdMeCuResult me[SVT_AMD_ME_PU_COUNT]; /* the LCU's motion-estimation candidates */
     SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
-    MdMvUnit nb[5];
+    MdMvUnit nb[2][5]; /* the spatial neighbours' motion, a copy per list-building wave */
     MdInterLists T;
     alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
     uint8_t cpred[MD_PRED_SLOTS][64 * 64]; /* the fast loop's predictions of the first motion-compensated candidates, kept for the full loop */
@@ -684,11 +684,32 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
         MD_SUB(0);
         if constexpr (INTER) {
-            /* the fourth wave, from the unit's first moment: its intra reference (only units below 64x64 have intra candidates) - source samples from HBM in the open-loop
-             * decision, a round trip that now runs under the contexts, the neighbours' vectors and the candidate lists of the other waves instead of holding their barrier */
-            if (wave == 3) {
+            /* GenerateL0L1AmvpMergeLists: the AMVP candidates of list 0, of list 1 and the merge candidates share their inputs and nothing else - and none of them needs
+             * what lane 0 of the first wave derives meanwhile (contexts, intra candidates).  Waves 1 and 2 therefore start at the unit's first moment: five lanes of each
+             * fetch the spatial neighbours with the availability GenerateL0L1AmvpMergeLists derives (EbAdaptiveMotionVectorPrediction.c:2256-2340) into the wave's OWN copy
+             * (no workgroup barrier between the fetch and the list), lane 0 then makes the wave's lists - four chains side by side instead of a barrier after the first. */
+            if (wave >= 1) {
                 const MdStats st = md_stats(M.lcu.leaf_index[M.cu_idx]);
-                if (st.depth != 0) {
+                if (lane < 5 && wave < 3) {
+                    const int N = st.size, k = lane;
+                    const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
+                    const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
+                    const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
+                    MdMvUnit u;
+                    u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
+                    if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
+                        u = *M.V.mv_at(px, py);
+                        u.avail = 1;
+                    }
+                    M.V.nb[wave - 1][k] = u;
+                }
+                EP_WAVE_SYNC();
+                if (lane == 0 && wave < 3) /* wave 1: both AMVP lists, wave 2: the merge candidates (the longest of the three) */
+                    md_amvp_merge_lists_parts(&P, &M.V.X, M.V.nb[wave - 1], M.V.X.tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T,
+                                              wave == 1 ? 3 : 4);
+                /* ... and the fourth wave the unit's intra reference (only units below 64x64 have intra candidates) - source samples from HBM in the open-loop decision, a
+                 * round trip under the other waves' chains */
+                if (wave == 3 && st.depth != 0) {
                     if (open_loop)
                         md_build_refs_ol(D, M, st, lcu_x + st.x, lcu_y + st.y, W, H, lane);
                     else
@@ -696,30 +717,6 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if (M.lcu.chroma_encode_mode == 1 && open_loop)
                         md_build_refs_ol_chroma(D, M.V.refc, st.size, lcu_x + st.x, lcu_y + st.y, W, H, lane);
                 }
-            }
-            /* the spatial neighbours with the availability GenerateL0L1AmvpMergeLists derives (EbAdaptiveMotionVectorPrediction.c:2256-2340): a lane of the second wave
-             * each, beside lane 0's contexts and intra candidates */
-            if (wave == 1 && lane < 5) {
-                const MdStats st = md_stats(M.lcu.leaf_index[M.cu_idx]);
-                const int N = st.size, k = lane;
-                const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
-                const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
-                const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
-                MdMvUnit u;
-                u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
-                if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
-                    u = *M.V.mv_at(px, py);
-                    u.avail = 1;
-                }
-                M.V.nb[k] = u;
-            }
-            /* GenerateL0L1AmvpMergeLists: the AMVP candidates of list 0, of list 1 and the merge candidates share their inputs and nothing else - lane 0 of waves
-             * 0, 1 and 2 makes one each (three chains of LDS round trips side by side instead of one after the other) */
-            __syncthreads();
-            MD_SUB(1);
-            if (lane == 0 && wave < 3) {
-                const MdStats st = md_stats(M.leaf);
-                md_amvp_merge_lists_parts(&P, &M.V.X, M.V.nb, M.V.X.tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T, 1 << wave);
             }
             MD_SUB(2);
             __syncthreads();
