@@ -55,21 +55,73 @@ __device__ __forceinline__ int mvx(uint32_t mv) { return (int)(int16_t)(mv & 0xf
 __device__ __forceinline__ int mvy(uint32_t mv) { return (int)(int16_t)(mv >> 16); }
 __device__ __forceinline__ uint32_t mvpack(int x, int y) { return ((uint32_t)(uint16_t)y << 16) | (uint16_t)x; }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+/* Cross-lane sums and minima on the DPP path (a modifier of a VALU instruction, a few cycles) instead of __shfl_xor, which the compiler turns into ds_bpermute_b32 - an LDS
+ * crossbar round trip of ~100 cycles per step, six dependent steps per wave reduction.  quad_perm [1,0,3,2] / [2,3,0,1] = the xor-1 / xor-2 partners; row_half_mirror pairs
+ * lane i with 7 - i of its group of eight, row_mirror with 15 - i of its row of sixteen: after the quad steps every lane of a quad holds the quad's value, so a mirror step
+ * completes the next power of two; the four rows of a wave are combined through v_readlane. */
+#define ME_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true))
+template <int GROUP> /* sum over aligned groups of GROUP lanes (1, 2, 4, 8, 16), the total in every lane of the group */
+__device__ __forceinline__ uint32_t group_sum(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o);
+    if (GROUP >= 2)
+        v += ME_DPP(v, 0xB1);
+    if (GROUP >= 4)
+        v += ME_DPP(v, 0x4E);
+    if (GROUP >= 8)
+        v += ME_DPP(v, 0x141); /* row_half_mirror */
+    if (GROUP >= 16)
+        v += ME_DPP(v, 0x140); /* row_mirror */
     return v;
 }
-__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v)
+/* the same for a group size known at run time (wave-uniform): 1 << lg lanes, lg in 0 .. 6; beyond a row of sixteen one crossbar step each */
+__device__ __forceinline__ uint32_t group_sum_rt(uint32_t v, int lg)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long w = __shfl_xor(v, o);
-        v = w < v ? w : v;
-    }
+    if (lg >= 1)
+        v += ME_DPP(v, 0xB1);
+    if (lg >= 2)
+        v += ME_DPP(v, 0x4E);
+    if (lg >= 3)
+        v += ME_DPP(v, 0x141);
+    if (lg >= 4)
+        v += ME_DPP(v, 0x140);
+    if (lg >= 5)
+        v += __shfl_xor(v, 16);
+    if (lg >= 6)
+        v += __shfl_xor(v, 32);
     return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) /* wave-uniform result */
+{
+    v = group_sum<16>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) /* wave-uniform result */
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const int ctrl = st == 0 ? 0xB1 : st == 1 ? 0x4E : st == 2 ? 0x141 : 0x140;
+        uint32_t plo, phi;
+        if (st == 0)
+            plo = ME_DPP(lo, 0xB1), phi = ME_DPP(hi, 0xB1);
+        else if (st == 1)
+            plo = ME_DPP(lo, 0x4E), phi = ME_DPP(hi, 0x4E);
+        else if (st == 2)
+            plo = ME_DPP(lo, 0x141), phi = ME_DPP(hi, 0x141);
+        else
+            plo = ME_DPP(lo, 0x140), phi = ME_DPP(hi, 0x140);
+        (void)ctrl;
+        const bool less = phi < hi || (phi == hi && plo < lo);
+        lo = less ? plo : lo, hi = less ? phi : hi;
+    }
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int r = 0; r < 64; r += 16) {
+        const unsigned long long w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, r);
+        m = w < m ? w : m;
+    }
+    return m;
 }
 
 /* SAD of one row of w samples (w even; the tail dword is masked) */
@@ -556,13 +608,8 @@ __device__ void hme_pass_q(MeShared &S, const uint8_t *src, int sstride, const u
             sd[0] = (uint32_t)(acc & 0xffff), sd[1] = (uint32_t)(acc >> 16) & 0xffff;
             sd[2] = (uint32_t)(acc >> 32) & 0xffff, sd[3] = (uint32_t)(acc >> 48);
         }
-        if (C > 1) {
-#pragma unroll
-            for (int o = C >> 1; o > 0; o >>= 1) {
-                sd[0] += __shfl_xor(sd[0], o), sd[1] += __shfl_xor(sd[1], o);
-                sd[2] += __shfl_xor(sd[2], o), sd[3] += __shfl_xor(sd[3], o);
-            }
-        }
+        if (C > 1) /* the chunks of a position sit on C adjacent lanes */
+            sd[0] = group_sum<C>(sd[0]), sd[1] = group_sum<C>(sd[1]), sd[2] = group_sum<C>(sd[2]), sd[3] = group_sum<C>(sd[3]);
         if (live && ch == 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -662,11 +709,45 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
     STAMP(PHASE == 0 ? 0 : 5);
     /* ---- stage the source LCU (EbMotionEstimationProcess.c:714-779); the search kernel does it together with its first reference window below ---- */
     int cx = 0, cy = 0;
+    /* TestSearchAreaBounds' candidate c (zero, A, B, C, D, direct = list 0's 64x64 vector mirrored): unclamped and clamped displacement (EbMotionEstimation.c:3363-3665) */
+    const uint32_t mv64_l0 = (PHASE == 0 && list) ? o->best_mv[0][0] : 0u; /* list 0's final 64x64 MV (direct candidate) */
+    auto tsab_cand = [&](int c, int &ux, int &uy, int &kx, int &ky) {
+        ux = c == 1 ? -(int)P.hme_l0_total_w : c == 2 ? (int)P.hme_l0_total_w : c == 5 ? 0 - (mvx(mv64_l0) >> 2) : 0;
+        uy = c == 3 ? -(int)P.hme_l0_total_h : c == 4 ? (int)P.hme_l0_total_h : c == 5 ? 0 - (mvy(mv64_l0) >> 2) : 0;
+        ux = (int16_t)ux, uy = (int16_t)uy;
+        kx = c ? clamp_center(ox, ux, LCU - 1, W) : 0, ky = c ? clamp_center(oy, uy, LCU - 1, H) : 0;
+    };
+    /* whole-width LCUs: the candidates' sub-sampled LCU SADs need 16-byte reference rows that depend on nothing but the picture's controls (and, for the direct candidate,
+     * one scalar load): requested TOGETHER with the source LCU - one trip to memory instead of two */
+    const bool tsab_early = PHASE == 0 && (P.temporal_layer_index > 0 || list == 0) && P.update_hme_search_center && lw == LCU;
+    const int tsab_nc = list == 1 ? 6 : 5;
+    uint4 tsab_b[3];
     if (PHASE == 0) {
-        for (int i = t; i < LCU * LCU / 4; i += NT) {
-            const int y = i >> 4, x = (i & 15) << 2;
-            *(uint32_t *)&S.src[y * LCU + x] = *(const uint32_t *)(cur.full + (ptrdiff_t)(oy + y) * pf + ox + x);
+        uint32_t sv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = t + k * NT, y = i >> 4, x = (i & 15) << 2;
+            sv[k] = *(const uint32_t *)(cur.full + (ptrdiff_t)(oy + y) * pf + ox + x);
         }
+        if (tsab_early) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { /* item = (candidate, row, 16-sample quarter), as lcu_sads deals them: candidate (t >> 7) + 2 k */
+                const int i = t + k * NT, c = i >> 7, r = (i >> 2) & 31, qx = (i & 3) << 4;
+                tsab_b[k] = make_uint4(0, 0, 0, 0);
+                if (c < tsab_nc && r < (lh >> 1)) {
+                    int ux, uy, kx, ky;
+                    tsab_cand(c, ux, uy, kx, ky);
+                    tsab_b[k] = ldu16(R.full + (ptrdiff_t)(oy + ky + 2 * r) * R.pitch_full + ox + kx + qx);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = t + k * NT, y = i >> 4, x = (i & 15) << 2;
+            *(uint32_t *)&S.src[y * LCU + x] = sv[k];
+        }
+        if (t < 8)
+            S.acc[t] = 0;
         if (t < 128) { /* 1/4: 16 even rows x 32 */
             const int y = t >> 3, x = (t & 7) << 2;
             *(uint32_t *)&S.qsrc[y * 32 + x] =
@@ -691,24 +772,37 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
     if (PHASE == 0) {
         int hme_init_done = list ? carry->hme_init_done : 0;
         int zero_sad_valid = 0;
-        const uint32_t mv64_l0 = list ? o->best_mv[0][0] : 0u; /* list 0's final 64x64 MV (direct candidate) */
         if (P.temporal_layer_index > 0 || list == 0) {
             STAMP(1);
             /* ---- TestSearchAreaBounds (EbMotionEstimation.c:3363-3665) ---- */
             if (P.update_hme_search_center) {
-                const int nc = list == 1 ? 6 : 5;
+                const int nc = tsab_nc;
                 if (t < 6) { /* candidate t: zero, A, B, C, D, direct (list-0 64x64 MV mirrored) */
-                    int ux = t == 1 ? -(int)P.hme_l0_total_w : t == 2 ? (int)P.hme_l0_total_w
-                             : t == 5 ? 0 - (mvx(mv64_l0) >> 2) : 0;
-                    int uy = t == 3 ? -(int)P.hme_l0_total_h : t == 4 ? (int)P.hme_l0_total_h
-                             : t == 5 ? 0 - (mvy(mv64_l0) >> 2) : 0;
-                    ux = (int16_t)ux, uy = (int16_t)uy;
+                    int ux, uy, kx, ky;
+                    tsab_cand(t, ux, uy, kx, ky);
                     S.cand[t][0] = ux, S.cand[t][1] = uy;
-                    S.cand[t][2] = t ? clamp_center(ox, ux, LCU - 1, W) : 0;
-                    S.cand[t][3] = t ? clamp_center(oy, uy, LCU - 1, H) : 0;
+                    S.cand[t][2] = kx, S.cand[t][3] = ky;
                 }
-                __syncthreads();
-                lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, nc, t);
+                if (tsab_early) { /* the reference rows came with the source LCU */
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const int i = t + k * NT, c = i >> 7, r = (i >> 2) & 31, qx = (i & 3) << 4;
+                        if (i < nc * 128) { /* whole waves: 128 items a candidate */
+                            uint32_t sd = 0;
+                            if (r < (lh >> 1)) {
+                                const uint4 a = *(const uint4 *)&S.src[(2 * r) * LCU + qx], b = tsab_b[k];
+                                sd = sad4(a.x, b.x, sd), sd = sad4(a.y, b.y, sd), sd = sad4(a.z, b.z, sd), sd = sad4(a.w, b.w, sd);
+                            }
+                            sd = wave_sum(sd);
+                            if ((t & 63) == 0)
+                                atomicAdd(&S.acc[c], sd);
+                        }
+                    }
+                    __syncthreads();
+                } else {
+                    __syncthreads();
+                    lcu_sads(S, R.full, R.pitch_full, ox, oy, lw, lh, nc, t);
+                }
                 zero_sad_valid = 1; /* S.acc[0] = SAD at (0,0) of this list's reference: reused by CheckZeroZeroCenter */
                 /* tie order: zero, A, B, C, direct, D (:3634-3658); costs are sad << 9 */
                 const uint32_t a0 = S.acc[0], a1 = S.acc[1], a2 = S.acc[2], a3 = S.acc[3], a4 = S.acc[4],
@@ -1193,12 +1287,10 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 int vx = 0, vy = 0, vs = 0;
                 if (n >= 0)
                     vx = mvx(B.best_mv[list][n]), vy = mvy(B.best_mv[list][n]), vs = (int)B.best_sad[list][n];
-#pragma unroll
-                for (int o = 1; o <= 8; o <<= 1)
-                    vx += __shfl_xor(vx, o), vy += __shfl_xor(vy, o), vs += __shfl_xor(vs, o);
                 if (t < 64) {
-                    vx += __shfl_xor(vx, 16), vy += __shfl_xor(vy, 16), vs += __shfl_xor(vs, 16);
-                    vx += __shfl_xor(vx, 32), vy += __shfl_xor(vy, 32), vs += __shfl_xor(vs, 32);
+                    vx = (int)wave_sum((uint32_t)vx), vy = (int)wave_sum((uint32_t)vy), vs = (int)wave_sum((uint32_t)vs);
+                } else {
+                    vx = (int)group_sum<16>((uint32_t)vx), vy = (int)group_sum<16>((uint32_t)vy), vs = (int)group_sum<16>((uint32_t)vs);
                 }
                 if (t == 0 || t == 64 || t == 80) {
                     const int tier = t == 0 ? 2 : t == 64 ? 1 : 0;
@@ -1295,8 +1387,9 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                             }
                         }
                     }
-                    for (int o = 1; o < (1 << lc); o <<= 1)
-                        d += __shfl_xor(d, o), sd += __shfl_xor(sd, o);
+                    d = group_sum_rt(d, lc);
+                    if (method == SVT_AMD_SSD_SEARCH)
+                        sd = group_sum_rt(sd, lc);
                     if (ch == 0) {
                         B.dist[n][k] = d;
                         B.dsad[n][k] = sd;
@@ -1434,8 +1527,9 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                             }
                         }
                     }
-                    for (int o = 1; o < (1 << lc); o <<= 1)
-                        d += __shfl_xor(d, o), sdv += __shfl_xor(sdv, o);
+                    d = group_sum_rt(d, lc);
+                    if (method == SVT_AMD_SSD_SEARCH)
+                        sdv = group_sum_rt(sdv, lc);
                     if (live && ch == 0) {
                         B.dist[n][k] = d;
                         B.dsad[n][k] = sdv;
@@ -1590,8 +1684,7 @@ __global__ __launch_bounds__(NT, PHASE == 0 ? ME_HME_WAVES_PER_SIMD : ME_MIN_WAV
                 /* the items of a PU sit on adjacent lanes (groups of 4 .. 64, aligned): summed by shuffles, one LDS atomic per group instead of one per item
                  * (64 lanes on one address serialise) */
                 const int G = iG[u];
-                for (int o = 1; o < G; o <<= 1)
-                    d += __shfl_xor(d, o);
+                d = group_sum_rt(d, 31 - __builtin_clz((unsigned)G));
                 if ((ij[u] & (G - 1)) == 0)
                     atomicAdd(&B.bipred[in_[u]], d);
             }
