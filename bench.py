@@ -192,7 +192,7 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def closed_loop_leg(enc_cfg, enc, frames=64):
+def closed_loop_leg(enc_cfg, enc, frames=160):
     """the hooked encoder with SVT_HOOK_MD=1 on the clip of `value` (fewer pictures): fps, md5 against the reference's bitstream of the same
     `frames` pictures, and the binding's own report of what ran where"""
     import encoder_fps as E
@@ -208,16 +208,20 @@ def closed_loop_leg(enc_cfg, enc, frames=64):
         lp = min(HIP_LP, os.cpu_count() or 1)
         ref_lp = E.run_app(S.REF_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "ref_lp.265"), nb=unique)
         hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": rp}, nb=unique)
+        # ... and with the I pictures left to the reference code: a 4K I picture's closed-loop decision (85 leaves x 35 candidates per LCU along the same wavefront) takes the
+        # device 0.45 s and every other picture waits for it
+        hip_pb = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip_pb.265"), env={"SVT_HOOK_MD": "pb"}, nb=unique)
         lines = [l.strip() for l in open(rp) if "mode decision" in l] if os.path.exists(rp) else []
         import re
         m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\).*?; (\d+) pictures outside", " ".join(lines))
         cover = {"pictures_on_device": int(m.group(1)), "p_b_pictures_on_device": int(m.group(2)), "pictures_left_to_the_reference_code": int(m.group(4))} if m else None
         return {"switches": {"SVT_HOOK_MD": "1"}, "frames": frames, "fps": hip["fps"], "reference_fps": ref["fps"], "reference_fps_same_threads": ref_lp["fps"],
                 "threads": "-lp %d" % lp, "bitstream_identical": hip["md5"] == ref["md5"], "coverage": cover, "report": lines,
+                "fps_p_b_pictures_only": hip_pb["fps"], "p_b_only_bitstream_identical": hip_pb["md5"] == ref["md5"],
                 "what": "motion estimation + open-loop intra search + mode decision + merge / skip decisions + encode pass of the I picture and of every open-loop P / B picture "
                         "(temporal layers 1 and 2 of BASELINE configs[2]: CHROMA_MODE_FULL reference B pictures and non-reference B pictures) on the device, ONE call per "
-                        "picture; the base-layer B pictures (closed-loop intra, branch-and-depth-pillar LCUs) are the reference code's.  Not `value`: the encoder keeps "
-                        "max(4, lp / 6) pictures in its EncDec pool and a device picture stays 90 - 150 ms in it (DESIGN 3.11 / 5d: fps = pool / residence)"}
+                        "picture; the base-layer B pictures (closed-loop intra, branch-and-depth-pillar LCUs) are the reference code's.  Not `value`: a device-decided "
+                        "picture stays 55 - 105 ms in the encoder's EncDec pool of max(4, lp / 6) pictures, longer than a host-decided one (DESIGN 3.11 / 5d)"}
     finally:
         shutil.rmtree(td, ignore_errors=True)
 

@@ -1864,12 +1864,11 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     }
     /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
      * find work (all of them resident: a workgroup that waits holds its CU) */
-    /* ... but a workgroup holds a whole CU (its LDS) while it waits, and the encoder keeps several pictures in flight: five 62-workgroup launches do not fit the 256 CUs and
-     * slow one another down (profiles/r04_m_timeline_*.txt: 100 - 270 ms per call with six pictures on the device).  The wavefront of a picture is (W/64 + 1) / 2 LCUs wide at
-     * its widest and 16 on average at 4K; one workgroup per LCU of the widest front plus a few for the encode passes behind it costs a lone picture 3 - 4 % and lets eight
-     * pictures share the GPU (profiles/r04_e_md_flights.txt). */
+    /* ... but a workgroup holds a whole CU (its LDS) while it waits, and the encoder keeps several pictures in flight: five 62-workgroup launches do not fit the 256 CUs.
+     * The wavefront of a picture is (W/64 + 1) / 2 LCUs wide at its widest and 16 on average at 4K; one workgroup per LCU of the widest front plus a few for the encode
+     * passes behind it costs a lone picture 3 - 4 % and lets six pictures' launches run side by side (profiles/r04_w_md_flights_*: the kernel keeps its 51 ms with
+     * twelve calls in flight, 100 pictures/s - given enough hardware queues, svt_amd_runtime_env_defaults). */
     int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2 + (wl + 7) / 8;
-    (void)0;
     {   /* debug (SVT_AMD_MD_GRID): workgroups of the launch - how many a picture really needs decides how many pictures share the GPU */
         const char *fg = getenv("SVT_AMD_MD_GRID");
         const int forced = fg ? atoi(fg) : 0;

@@ -8,7 +8,7 @@ sys.path.insert(0, "tests")
 import svtlib as S
 S.write_clip("/tmp/md_clip.yuv", "motion", 3840, 2160, 16, 7)
 PY
-SVT_HOOK_MD=pb SVT_AMD_MD_TIMING=1 SVT_HOOK_REPORT=$O/report.txt integration/_build/SvtHevcEncApp_hip -i /tmp/md_clip.yuv -w 3840 -h 2160 -n 64 -nb 16 -b /tmp/md.265 -encMode 7 -pred-struct 2 -hierarchical-levels 2 -sao 1 -fps 60 -q 32 -asm 1 -lp 32 > $O/app.txt 2> $O/stderr.txt < /dev/null
+SVT_HOOK_MD=${MD_MODE:-1} SVT_AMD_MD_TIMING=1 SVT_HOOK_REPORT=$O/report.txt integration/_build/SvtHevcEncApp_hip -i /tmp/md_clip.yuv -w 3840 -h 2160 -n 64 -nb 16 -b /tmp/md.265 -encMode 7 -pred-struct 2 -hierarchical-levels 2 -sao 1 -fps 60 -q 32 -asm 1 -lp 32 > $O/app.txt 2> $O/stderr.txt < /dev/null
 grep "Average Speed" $O/app.txt
 grep "mode decision\|picture objects" $O/report.txt | cut -c1-420
 grep "svt_amd_md_encode_picture" $O/stderr.txt | awk '{u+=$6; k+=$10; d+=$14; n++} END {printf "calls %d: inputs up %.2f ms, kernel %.2f ms, records down %.2f ms (means)\n", n, u/n, k/n, d/n}'

@@ -173,28 +173,64 @@ def run_inter(lib, g, reps=3, encode=True, check=True, profile=None):
 
 
 def run_inter_flights(lib, g, flights=2, reps=4):
-    """`flights` pictures in flight: one thread, context and picture object per flight, every thread repeating the device call of picture 0"""
+    """`flights` pictures in flight: one thread, lane (forked context) and picture object per flight, every thread repeating the device call of picture 0.  Everything
+    a call needs is staged ONCE per flight (reference pictures resident and set, records and output arrays allocated): inside the timed loop a thread only makes the
+    C call - ctypes releases the interpreter lock for its duration, so the threads really overlap (with the test helper in the loop, which re-uploads the reference
+    pictures through torch and allocates 55 MB of numpy output per call under the lock, eight threads measure the interpreter, not the device)."""
     import threading
-    from test_gpu_md import sig, md_encode_inter
+    import torch
+    from test_gpu_md import sig
+    from test_oracle_md_golden import inter_inputs
     sig(lib)
+    vp = C.c_void_p
+    lib.svt_amd_md_encode_picture_inter.restype = C.c_int
+    lib.svt_amd_md_encode_picture_inter.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    lib.svt_amd_encdec_picture_set_inter.restype = C.c_int
+    lib.svt_amd_encdec_picture_set_inter.argtypes = [vp] * 5
+    lib.svt_amd_debug_md_kernel_ms.restype = C.c_int
+    lib.svt_amd_debug_md_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
     root = C.c_void_p()
     assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(root)) == 0, lib.svt_amd_last_error()
     lib.svt_amd_context_fork.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    lanes, pics = [], []
+    k = 0
+    P = np.ascontiguousarray(g["pic"][k:k + 1])
+    lcus = np.ascontiguousarray(g["lcu"][k])
+    cost = np.ascontiguousarray(g["cost"][k])
+    src = [np.ascontiguousarray(g[n][k]) for n in ("src_y", "src_cb", "src_cr")]
+    o = np.ascontiguousarray(g["ois"][k])
+    X, me, tmvp, refs, planes = inter_inputs(g, k)
+    dev = [[torch.from_numpy(a).cuda() for a in pl] for pl in planes]
+    torch.cuda.synchronize()
+    rs = [S.RefPicture(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), r.strideY, r.strideC, r.originX, r.originY, r.width, r.height) for d, r in zip(dev, refs)]
+    n = len(lcus)
+    lanes, pics, outs = [], [], []
     for i in range(flights):
         lane, pic = C.c_void_p(), C.c_void_p()
         assert lib.svt_amd_context_fork(root, C.byref(lane)) == 0, lib.svt_amd_last_error()
         assert lib.svt_amd_encdec_picture_create(lane, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_encdec_picture_set_inter(lane, pic, C.byref(rs[0]), C.byref(rs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
         lanes.append(lane), pics.append(pic)
-        md_encode_inter(lib, lane, pic, g, 0, encode=True)   # warm-up: allocations
-    times = [[] for _ in range(flights)]
+        outs.append((np.zeros(n, S.MD_LCU_OUT_DTYPE), np.zeros(n, S.LCU_WORK_DTYPE), np.zeros(n, S.LCU_RESULT_DTYPE)))
+
+    def call(i):
+        out, works, res = outs[i]
+        rc = lib.svt_amd_md_encode_picture_inter(lanes[i], pics[i], P.ctypes.data, X.ctypes.data, lcus.ctypes.data, src[0].ctypes.data, src[0].shape[1], src[1].ctypes.data,
+                                                 src[2].ctypes.data, src[1].shape[1], o.ctypes.data, 0, me.ctypes.data, 0, tmvp.ctypes.data if tmvp is not None else None,
+                                                 out.ctypes.data, works.ctypes.data, res.ctypes.data)
+        assert rc == 0, lib.svt_amd_last_error()
+    for i in range(flights):
+        call(i)   # warm-up: allocations
+    times, kms = [[] for _ in range(flights)], [[] for _ in range(flights)]
 
     def work(i):
         for _ in range(reps):
             t0 = time.perf_counter()
-            md_encode_inter(lib, lanes[i], pics[i], g, 0, encode=True)
+            call(i)
             times[i].append((time.perf_counter() - t0) * 1e3)
+            ms = C.c_float()
+            if lib.svt_amd_debug_md_kernel_ms(lanes[i], pics[i], C.byref(ms), None) == 0:
+                kms[i].append(ms.value)
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(i,)) for i in range(flights)]
     for t in th:
@@ -206,7 +242,9 @@ def run_inter_flights(lib, g, flights=2, reps=4):
         lib.svt_amd_encdec_picture_destroy(lane, pic)
         lib.svt_amd_context_destroy(lane)
     lib.svt_amd_context_destroy(root)
-    return {"flights": flights, "ms_per_call_median": round(float(np.median(np.concatenate(times))), 2), "pictures_per_s": round(flights * reps / wall, 2)}
+    del dev
+    return {"flights": flights, "ms_per_call_median": round(float(np.median(np.concatenate(times))), 2), "kernel_ms_median": round(float(np.median(np.concatenate(kms))), 2),
+            "pictures_per_s": round(flights * reps / wall, 2)}
 
 
 if __name__ == "__main__":
