@@ -116,6 +116,73 @@ def test_one_rank_owns_every_picture(oracle):
     assert picture_rank_sequence(oracle, g, w, h, 1, 0, lambda planes, owner, shapes, sdt: planes) == (5, 0)
 
 
+# ---- the mode decision across ranks: the layer-2 pair of a mini-GOP decided on different ranks from broadcast references ---------------------------------------
+MD_CASE = "b_motion_416x240_m8"   # pictures 1, 3, 5, 7 of a random-access encode: the layer-2 B pictures of two mini-GOPs, references (0,2) (2,4) (4,6) (6,8)
+
+
+class _Fixture(dict):
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+def _md_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_oracle_md_golden import compare_md, oracle_md_picture
+        g0 = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % MD_CASE))
+        g = _Fixture({k: g0[k] for k in g0.files})
+        npic = len(g["picture_number"])
+        # the reference pictures exist on rank 0 only (it stands for their owners); every other rank starts with blank planes and gets each reference picture ONCE
+        pocs = g["inter"]["ref_poc"]
+        have = {}
+        for k in range(npic):
+            for l in range(2):
+                poc = int(pocs[k][l])
+                if poc in have:
+                    continue
+                planes = []
+                for nm in ("y", "cb", "cr"):
+                    a = np.ascontiguousarray(g0["ref%d_%s" % (l, nm)][k])
+                    t = torch.from_numpy(a.copy() if rank == 0 else np.zeros_like(a))
+                    dist.broadcast(t, src=0)
+                    planes.append(t.numpy())
+                have[poc] = planes
+        for l in range(2):
+            for p, nm in enumerate(("y", "cb", "cr")):
+                g["ref%d_%s" % (l, nm)] = np.stack([have[int(pocs[k][l])][p] for k in range(npic)])
+        mine = [k for k in range(npic) if k % world == rank]     # the pair of a mini-GOP (pictures 1 / 3, 5 / 7) is split over the ranks
+        oracle = S.load_oracle()
+        for k in mine:
+            out, _ = oracle_md_picture(oracle, g, k)
+            compare_md(out, g0["out"][k], "%s picture %d on rank %d" % (MD_CASE, int(g0["picture_number"][k]), rank))
+        q.put((rank, [int(g0["picture_number"][k]) for k in mine], ""))
+    except Exception as e:   # noqa: BLE001 - reported to the parent
+        import traceback
+        q.put((rank, None, traceback.format_exc()[-1500:] + str(e)[-500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layer2_pair_of_a_mini_gop_decided_on_different_ranks_from_broadcast_references_gloo_world2():
+    """ModeDecisionLcu of whole pictures (the CPU checker of the device's decision kernel) on two ranks: the two non-reference B pictures of a mini-GOP on different
+    ranks, each from reference pictures it received by broadcast; decisions = the reference's records, leaf for leaf"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29840 + os.getpid() % 40
+    ps = [ctx.Process(target=_md_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res[0][1] == [1, 5] and res[1][1] == [3, 7], res
+
+
 import pytest  # noqa: E402
 
 
