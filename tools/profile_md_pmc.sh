@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ SQ_INSTS_BRANCH" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  if [ -n "$MD_PMC_ONLY" ] && [ "$MD_PMC_ONLY" != "$i" ]; then continue; fi
+  if [ -n "$MD_PMC_ONLY" ]; then case " $MD_PMC_ONLY " in *" $i "*) ;; *) continue;; esac; fi   # MD_PMC_ONLY="1 2 5": only these passes
   timeout 300 rocprofv3 --pmc $set -d $O/p$i -o pmc --output-format csv -- python tools/md_bench.py 3840 2160 7 2 inter 5 > $O/p$i.log 2>&1 < /dev/null
 done
 python - "$O" <<'PY'
@@ -27,7 +27,7 @@ for f in glob.glob(O + "/p*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         if "k_md_encode_picture" not in k:
             continue
-        k = "k_md_encode_picture<inter>" if "Lb1" in k or "<true>" in k else "k_md_encode_picture<intra>"
+        k = "k_md_encode_picture<inter>" if "Lb1" in k or "<true" in k else "k_md_encode_picture<intra>"
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         meta[k] = (r["VGPR_Count"], r.get("Accum_VGPR_Count"), r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
 with open(O + "/md_pmc.txt", "w") as out:
