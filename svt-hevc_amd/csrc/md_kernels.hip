@@ -1097,8 +1097,32 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 if (fresh64) /* every wave is done with the fresh luma predictions in the waves' scratch before a chroma block lands there */
                     __syncthreads();
                 const int Cn = N >> 1, lgc = lgN - 1, Tc = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
-                const int off = split64 ? 0 : nfull & 3;
-                for (int tk = (wave - off) & 3; tk < 2 * nfull; tk += 4) {
+                /* which wave takes which (survivor, plane) task: the waves that carried a luma unit start with 3 units of load, a chroma pair member costs 2 - each task
+                 * goes to the least loaded wave (every wave derives the same table; two survivors: both chroma pairs on the two waves the luma units left idle instead
+                 * of one member behind each luma unit) */
+                unsigned mine = 0;
+                {
+                    int load[4];
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; w_++)
+                        load[w_] = (!split64 && w_ < nfull) ? 3 : 0;
+                    for (int tk = 0; tk < 2 * nfull; tk++) {
+                        int best_w = 0;
+#pragma unroll
+                        for (int w_ = 1; w_ < 4; w_++)
+                            if (load[w_] < load[best_w])
+                                best_w = w_;
+#pragma unroll
+                        for (int w_ = 0; w_ < 4; w_++)
+                            if (w_ == best_w)
+                                load[w_] += 2;
+                        if (best_w == wave)
+                            mine |= 1u << tk;
+                    }
+                }
+                for (int tk = 0; tk < 2 * nfull; tk++) {
+                    if (!((mine >> tk) & 1u))
+                        continue;
                     const int f = tk >> 1, pl = tk & 1, b = M.best[f], ci = M.B.cand[b];
                     const MdCand cd = M.cand[ci];
                     const uint8_t *pred;

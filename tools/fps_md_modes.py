@@ -11,7 +11,10 @@ import encoder_fps as E
 lp = sys.argv[1] if len(sys.argv) > 1 else "32"
 for frames in (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "64,160").split(",")):
     row = {"lp": int(lp), "frames": frames}
+    only = os.environ.get("FPS_MODES", "front_half_only,md_all,md_pb").split(",")
     for tag, env in (("front_half_only", {}), ("md_all", {"SVT_HOOK_MD": "1"}), ("md_pb", {"SVT_HOOK_MD": "pb"})):
+        if tag not in only:
+            continue
         r = E.measure("cfg3", frames=frames, extra=["-lp", lp], hip_env=env, unique=16)
         row["reference_fps"] = r["reference"]["fps"]
         row[tag + "_fps"] = r["hip"]["fps"]
