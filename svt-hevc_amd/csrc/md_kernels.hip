@@ -13,20 +13,28 @@
  * what the neighbours left in the picture's maps follows the wait.  Per coding unit of the MdcLcuData_t leaf list (I pictures: waves 1..3 idle where P / B pictures
  * use them):
  *   lane 0        context generation, intra candidates                                       (md_logic.h - the text the CPU checker runs)
- *   P / B         five lanes of wave 1: the spatial neighbours' motion vectors; then lane 0 of waves 0 / 1 / 2: AMVP list 0, AMVP list 1, merge list
- *                 (three chains side by side) while wave 3 builds the unit's intra reference; then a lane per motion-estimation / merge candidate
- *                 (md_choose_mvp, duplicate check), survivors in the scalar order by ballot
+ *   P / B         beside it, from the unit's first moment: waves 1 and 2 fetch the spatial neighbours' motion (five lanes, a copy per wave) and lane 0 of each makes its
+ *                 lists - wave 1 the AMVP candidates of both lists, wave 2 the merge candidates - while wave 3 builds the unit's intra reference (luma, and the chroma
+ *                 pair of a CHROMA_MODE_FULL LCU, from SOURCE samples); then a lane per motion-estimation / merge candidate (md_choose_mvp, duplicate check),
+ *                 survivors in the scalar order by ballot
  *   lane 0        MPM injection, buffer count;  wave 0: a lane per candidate - first fast loop (best distortion-ready candidate), evaluated flags,
  *                 the packed list of candidates that really need a prediction, prediction slots
  *   wave 0        (I pictures) intra reference of the unit: availability by ballot, substitution, [1 2 1] / strong smoothing   (8.4.4.2.2-3)
- *   4 waves       fast loop: a wave per listed candidate (64x64 units: wave w takes 32x32 tile w of every candidate) - inter prediction through
- *                 ep_inter_predict_core (encdec_device.h), intra prediction evaluated per sample in closed form (intra_device.h), SAD by v_sad_u8 on words
- *   wave 0        fast costs a lane per candidate, the candidate-buffer replay with the buffers in lanes (v_readlane), PreModeDecision
+ *   4 waves       fast loop: ONE list of tasks (candidate, plane, tile) dealt to the waves - luma blocks (64x64 units: four 32x32 tiles), then, in CHROMA_MODE_FULL LCUs,
+ *                 the Cb and Cr blocks of every evaluated candidate; inter prediction through ep_inter_predict_core8 (encdec_device.h: LDS-staged reference windows,
+ *                 v_dot4 / v_dot2 filters), intra prediction evaluated per sample in closed form (intra_device.h), SAD by v_sad_u8 on words, added to the candidate's
+ *                 LDS accumulator
+ *   wave 0        fast costs a lane per candidate (with the chroma distortion and the noise-class rule where the LCU has it), the candidate-buffer replay with the
+ *                 buffers in lanes (v_readlane), PreModeDecision
  *   4 waves       full loop: a wave per surviving candidate (64x64 units: a wave per 32x32 transform unit) - residual row per lane, Estimate DCT in
- *                 registers, quantiser, coefficient-domain distortion, coefficient bits (a lane per 4x4 sub-block): the fused unit of the encode pass
- *   wave 0        TuCalcCostLuma + full cost a lane per candidate; lane 0: ProductFullModeDecision, CheckHighCostPartition, (open loop) inter-depth decision
+ *                 registers, quantiser, coefficient-domain distortion, coefficient bits (a lane per 4x4 sub-block): the fused unit of the encode pass; CHROMA_MODE_FULL:
+ *                 the survivors' chroma pairs (FullLoop_R + CuFullDistortionFastTuMode_R) as tasks on the least loaded waves
+ *   wave 0        TuCalcCostLuma + full cost a lane per candidate (InterFullCost / MergeSkipFullCost / IntraFullCostPslice with the chroma terms where the LCU has
+ *                 them); lane 0: ProductFullModeDecision, CheckHighCostPartition, (open loop) inter-depth decision
  *   wave 0        (closed loop) the winner's reconstruction (inverse transform + prediction);  lane 0: inter-depth decision
  *   all lanes     neighbour update
+ * A 10-bit picture (k_md_encode_picture<INTER, uint16_t>) is decided on the 8-MSB views of its source and reference pictures (MdPictureDev.src / .mref) and encoded
+ * on the 10-bit samples (.src16, the picture object's 16-bit planes).
  * then the LCU's final tree becomes an SvtAmdLcuWork record and the encode pass of the LCU runs in the same workgroup.
  * Bounded by latency (an LCU's units are sequential, a picture's wavefront is <= (W/64+1)/2 LCUs wide), not by bytes: algorithmic HBM
  * traffic per LCU = 6 KB source + 6 KB OIS record in, 1.1 KB decisions + the encode pass's 24 KB out.
