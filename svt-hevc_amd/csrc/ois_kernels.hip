@@ -114,12 +114,18 @@ __device__ __forceinline__ int predict_sample(int mode, int N, int lg, const uin
     return ((32 - f) * s0 + f * s1 + 16) >> 5;
 }
 
+/* wave sum on the DPP path (quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror: after the quad steps a mirror step completes the next power of two) and
+ * v_readlane across the four rows: __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar round trip per step, and every (coding unit, mode) task of this kernel - a whole
+ * wave for as few as 64 samples - ends in one.  Wave-uniform result. */
+#define OIS_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true))
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o);
-    return v;
+    v += OIS_DPP(v, 0xB1);
+    v += OIS_DPP(v, 0x4E);
+    v += OIS_DPP(v, 0x141);
+    v += OIS_DPP(v, 0x140);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 /* SAD of CU `cu` predicted with `mode`; executed by one whole wavefront */
@@ -503,11 +509,8 @@ __global__ __launch_bounds__(256) void k_zz_sad(const uint8_t *__restrict__ cur1
     if (lw == 64 && lh == 64) {
         const int r = lane >> 2, g = (lane & 3) << 2;
         const ptrdiff_t at = (ptrdiff_t)((oy >> 2) + r) * pitch + (ox >> 2) + g;
-        uint32_t s = __builtin_amdgcn_sad_u8(*(const uint32_t *)(cur16 + at), *(const uint32_t *)(prev16 + at), 0u);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            s += __shfl_xor(s, o);
-        sad = s;
+        const uint32_t s = __builtin_amdgcn_sad_u8(*(const uint32_t *)(cur16 + at), *(const uint32_t *)(prev16 + at), 0u);
+        sad = wave_sum(s);
         zz = sad < 256 ? 0 : sad < 512 ? 3 : sad < 1024 ? 10 : sad < 2048 ? 20 : 30;
     }
     if (lane == 0) {
