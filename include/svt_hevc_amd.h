@@ -322,6 +322,13 @@ SVT_AMD_API int svt_amd_device_upload_async(SvtAmdContext *ctx, void *d_dst, con
 SVT_AMD_API int svt_amd_device_download_async(SvtAmdContext *ctx, void *dst, const void *d_src, size_t bytes);
 SVT_AMD_API int svt_amd_host_alloc(SvtAmdContext *ctx, size_t bytes, void **h_ptr);
 SVT_AMD_API int svt_amd_host_free(SvtAmdContext *ctx, void *h_ptr);
+/* Page-locks a buffer the CALLER owns (hipHostRegister) so that copies from / into it go through the DMA engines instead of the runtime's staged copy of pageable
+ * memory - which is a shader (blit) kernel on this runtime and competes for compute units with the persistent mode-decision kernels.  For host buffers that live as long
+ * as the encoder (the reference's input-picture and reference-picture pools, Codec/EbEncHandle.c:1794-1813): a process-wide table remembers (pointer, size), a second
+ * call for the same range costs a lookup.  Returns SVT_AMD_OK also when the runtime refuses the range (the copies then take the pageable path as before).
+ * svt_amd_host_unregister_all() releases every registration (before the caller frees the buffers). */
+SVT_AMD_API int svt_amd_host_register(SvtAmdContext *ctx, const void *h_ptr, size_t bytes);
+SVT_AMD_API int svt_amd_host_unregister_all(SvtAmdContext *ctx);
 SVT_AMD_API int svt_amd_me_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdMeLcuResult *out);
 SVT_AMD_API int svt_amd_ois_picture_fetch_async(SvtAmdContext *ctx, int cur_slot, SvtAmdOisLcuResult *out);
 

@@ -46,7 +46,7 @@
 #include "svt_hook_internal.h"
 #include "svt_md_fill.h"
 
-#define EP_LANES 8     /* device contexts (stream + staging) EncDec threads share */
+#define EP_LANES 16    /* device contexts (stream + staging) EncDec threads share: one per picture whose device call is in flight */
 #define EP_PICTURES 64 /* pictures in flight (PictureControlSet_t objects of the EncDec pool) */
 
 void __real_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
@@ -952,6 +952,32 @@ EB_ERRORTYPE __wrap_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countN
 
 
 /* ---- SVT_HOOK_MD: ModeDecisionLcu (Codec/EbProductCodingLoop.c:4691) answered from ONE device call per picture -------------------- */
+/* The EncDec picture pool.  The reference sizes it for host latencies: pictureControlSetPoolInitCountChild = MAX(4, coreCount / 6) PictureControlSet_t objects
+ * between the picture manager and packetization (Codec/EbEncHandle.c:1801, built at :818-829) - five at -lp 32.  A picture the device decides and encodes stays there
+ * for its device call (50 - 120 ms at 4K where the host's wavefront takes 25 - 40), so the closed loop's rate is (objects in the pool) / (residence) and the pool, not the
+ * device, sets it.  SVT_HOOK_PCS_POOL=<n> raises the count of THAT pool (recognised by its creator) to n without touching the thread counts -lp also sets;
+ * the bitstream does not depend on it (pictures are still released in decode order with their references complete).  The one-line change a maintainer makes in
+ * LoadDefaultBufferConfigurationSettings is shown in INTEGRATION.md 1h. */
+#include "EbSystemResourceManager.h"
+EB_ERRORTYPE __real_EbSystemResourceCtor(EbSystemResource_t *resourcePtr, EB_U32 objectTotalCount, EB_U32 producerProcessTotalCount, EB_U32 consumerProcessTotalCount,
+                                         EbFifo_t ***producerFifoPtrArrayPtr, EbFifo_t ***consumerFifoPtrArrayPtr, EB_BOOL fullFifoEnabled, EB_CREATOR objectCreator,
+                                         EB_PTR objectInitDataPtr, EbDctor objectDestroyer);
+EB_ERRORTYPE __wrap_EbSystemResourceCtor(EbSystemResource_t *resourcePtr, EB_U32 objectTotalCount, EB_U32 producerProcessTotalCount, EB_U32 consumerProcessTotalCount,
+                                         EbFifo_t ***producerFifoPtrArrayPtr, EbFifo_t ***consumerFifoPtrArrayPtr, EB_BOOL fullFifoEnabled, EB_CREATOR objectCreator,
+                                         EB_PTR objectInitDataPtr, EbDctor objectDestroyer)
+{
+    if (objectCreator == PictureControlSetCreator) {
+        const char *v = getenv("SVT_HOOK_PCS_POOL");
+        const int want = v ? atoi(v) : 0;
+        if (want > (int)objectTotalCount && want <= EP_PICTURES) {
+            fprintf(stderr, "svt_hook_encdec: EncDec picture pool %u -> %d PictureControlSet_t objects (SVT_HOOK_PCS_POOL)\n", objectTotalCount, want);
+            objectTotalCount = (EB_U32)want;
+        }
+    }
+    return __real_EbSystemResourceCtor(resourcePtr, objectTotalCount, producerProcessTotalCount, consumerProcessTotalCount, producerFifoPtrArrayPtr, consumerFifoPtrArrayPtr,
+                                       fullFifoEnabled, objectCreator, objectInitDataPtr, objectDestroyer);
+}
+
 EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
                                     LargestCodingUnit_t *lcuPtr, EB_U16 lcuOriginX, EB_U16 lcuOriginY, EB_U32 lcuAddr, ModeDecisionContext_t *contextPtr);
 static int g_md_state; /* 0 unknown, 1 on, -1 off */
@@ -1041,6 +1067,7 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
         svt_md_fill_ois(&ois[i], pcs->ParentPcsPtr, (EB_U32)i);
     }
     const EbPictureBufferDesc_t *in = pcs->ParentPcsPtr->chromaDownSamplePicturePtr;
+    svt_hook_pin_picture(in, 1); /* the source planes go up by DMA from where the encoder keeps them */
     const uint8_t *sy = in->bufferY + (size_t)in->originY * in->strideY + in->originX;
     const uint8_t *scb = in->bufferCb + (size_t)(in->originY / 2) * in->strideCb + in->originX / 2, *scr = in->bufferCr + (size_t)(in->originY / 2) * in->strideCr + in->originX / 2;
     if (e->wide && (!inter || svt_amd_md_lcus_supported(&P, lcus, (int)n))) {

@@ -45,5 +45,7 @@ void svt_hook_encdec_report(FILE *out);
 #include "EbMdRateEstimation.h"
 void svt_hook_ep_note_sao(const PictureControlSet_t *pcs, EB_U32 x, EB_U32 y, const MdRateEstimationContext_t *md, EB_U64 lambda, EB_U64 chromaLambda,
                           int mmSao, int is16);
+/* page-locks the planes of a pooled picture buffer of the encoder once (svt_hook_me.c) */
+void svt_hook_pin_picture(const EbPictureBufferDesc_t *p, size_t bps);
 void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, const SvtAmdRefPicture *dev);
 #endif

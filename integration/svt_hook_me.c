@@ -1321,6 +1321,26 @@ static void *g_inter_scratch[3]; /* device prediction planes: 64x64, 32x32, 32x3
 static unsigned long g_inter_gpu, g_inter_uploads;
 static int g_inter_state;
 
+/* Page-locks the planes of one of the encoder's pooled picture buffers (EbPictureBufferDescCtor / EbReconPictureBufferDescCtor allocate lumaSize / chromaSize
+ * samples per plane, Codec/EbPictureBufferDesc.c:59-94, :149-166) for the life of the encoder: svt_amd_host_register remembers the range, a second call is a
+ * lookup; hook_teardown releases them before EbDeinitEncoder frees the buffers.  SVT_HOOK_PIN_HOST=0 leaves the buffers pageable. */
+void svt_hook_pin_picture(const EbPictureBufferDesc_t *p, size_t bps)
+{
+    static int state; /* 0 unknown, 1 on, -1 off */
+    if (!state) {
+        const char *v = getenv("SVT_HOOK_PIN_HOST");
+        state = (v && !strcmp(v, "0")) ? -1 : 1;
+    }
+    if (state < 0 || !g_ctx || !p)
+        return;
+    if (p->bufferY)
+        (void)svt_amd_host_register(g_ctx, p->bufferY, (size_t)p->lumaSize * bps);
+    if (p->bufferCb)
+        (void)svt_amd_host_register(g_ctx, p->bufferCb, (size_t)p->chromaSize * bps);
+    if (p->bufferCr)
+        (void)svt_amd_host_register(g_ctx, p->bufferCr, (size_t)p->chromaSize * bps);
+}
+
 /* must hold g_lock.  *slot = the cache slot, PINNED: the caller unpins it (ref_unpin / svt_hook_release_references) when it no longer reads the device copy */
 static const SvtAmdRefPicture *resident_reference_via(SvtAmdContext *via, const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot);
 static const SvtAmdRefPicture *resident_reference_bps(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, int *slot) { return resident_reference_via(g_ctx, p, poc, bps, slot); }
@@ -1378,6 +1398,7 @@ static const SvtAmdRefPicture *resident_reference_via(SvtAmdContext *via, const 
     const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
     const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
     const uint8_t *src[3] = {p->bufferY, p->bufferCb, p->bufferCr};
+    svt_hook_pin_picture(p, bps); /* the encoder's reference-picture pool is page-locked once: the upload is a DMA transfer, not a copy kernel */
     const double t_up = svt_hook_now();
     for (int k = 0; k < 3; k++) {
         if (victim->bytes[k] < need[k]) {
@@ -1893,6 +1914,7 @@ static void hook_teardown(void)
                 svt_amd_context_destroy(g_front[i].lane);
             memset(&g_front[i], 0, sizeof(g_front[i]));
         }
+        (void)svt_amd_host_unregister_all(g_ctx); /* svt_hook_pin_picture: before EbDeinitEncoder frees the picture pools */
         svt_amd_context_destroy(g_ctx);
         g_ctx = NULL;
         memset(g_slot_pic, 0, sizeof(g_slot_pic));

@@ -8,6 +8,7 @@
 #include <string.h>
 #include "svt_amd_internal.h"
 #include <vector>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -82,6 +83,8 @@ extern "C" void svt_amd_context_destroy(SvtAmdContext *ctx)
             (void)hipEventDestroy(s->ev_me);
         if (s->ev_ois)
             (void)hipEventDestroy(s->ev_ois);
+        if (s->ev_md_read)
+            (void)hipEventDestroy(s->ev_md_read);
     }
     if (!ctx->parent)
         free(ctx->slots);
@@ -280,7 +283,7 @@ extern "C" int svt_amd_context_create(int device_ordinal, uint16_t max_luma_widt
         }
         s->staging_bytes = (size_t)w * h;
         if (hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_me, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s->ev_ois, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s->ev_ois, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_md_read, hipEventDisableTiming) != hipSuccess) {
             svt_amd_set_error("hipEventCreate (slot %d) failed", i);
             rc = SVT_AMD_ERR_DEVICE;
             break;
@@ -455,6 +458,44 @@ extern "C" int svt_amd_host_alloc(SvtAmdContext *ctx, size_t bytes, void **h_ptr
     HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
     return SVT_AMD_OK;
 }
+/* svt_amd_host_register: the process-wide table of page-locked caller buffers (include/svt_hevc_amd.h) */
+namespace {
+struct HostReg { const void *p; size_t bytes; bool ok; };
+std::mutex g_reg_mu;
+std::vector<HostReg> g_reg;
+}
+extern "C" int svt_amd_host_register(SvtAmdContext *ctx, const void *h_ptr, size_t bytes)
+{
+    if (!ctx || !h_ptr || !bytes)
+        return SVT_AMD_ERR_BAD_PARAM;
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    for (HostReg &r : g_reg)
+        if (r.p == h_ptr && r.bytes >= bytes)
+            return SVT_AMD_OK;
+    for (HostReg &r : g_reg) /* the same base with a larger extent, or a range overlapping an earlier one: the runtime refuses overlaps - leave it pageable */
+        if ((const uint8_t *)h_ptr < (const uint8_t *)r.p + r.bytes && (const uint8_t *)r.p < (const uint8_t *)h_ptr + bytes) {
+            g_reg.push_back({h_ptr, bytes, false});
+            return SVT_AMD_OK;
+        }
+    (void)hipSetDevice(ctx->device);
+    const hipError_t e = hipHostRegister(const_cast<void *>(h_ptr), bytes, hipHostRegisterDefault);
+    if (e != hipSuccess)
+        (void)hipGetLastError();
+    g_reg.push_back({h_ptr, bytes, e == hipSuccess});
+    return SVT_AMD_OK;
+}
+extern "C" int svt_amd_host_unregister_all(SvtAmdContext *ctx)
+{
+    if (!ctx)
+        return SVT_AMD_ERR_BAD_PARAM;
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    (void)hipSetDevice(ctx->device);
+    for (HostReg &r : g_reg)
+        if (r.ok && hipHostUnregister(const_cast<void *>(r.p)) != hipSuccess)
+            (void)hipGetLastError();
+    g_reg.clear();
+    return SVT_AMD_OK;
+}
 extern "C" int svt_amd_host_free(SvtAmdContext *ctx, void *h_ptr)
 {
     if (!ctx)
@@ -466,6 +507,7 @@ extern "C" int svt_amd_host_free(SvtAmdContext *ctx, void *h_ptr)
 
 /* ---- pictures ---------------------------------------------------------- */
 
+static void slot_records_reset(DevPicture *s);
 static int check_slot(SvtAmdContext *ctx, int slot)
 {
     if (!ctx || slot < 0 || slot >= ctx->num_slots) {
@@ -504,6 +546,7 @@ extern "C" int svt_amd_picture_upload_device(SvtAmdContext *ctx, int slot, const
         return rc;
     if ((rc = svt_amd_launch_prep(ctx, s, (const uint8_t *)d_luma, stride)) != 0)
         return rc;
+    slot_records_reset(s); /* the records in the slot's buffers are the previous picture's */
     s->valid = 1;
     return SVT_AMD_OK;
 }
@@ -530,7 +573,7 @@ extern "C" int svt_amd_picture_upload_device_batch(SvtAmdContext *ctx, int num, 
     if (rc)
         return rc;
     for (int i = 0; i < num; i++)
-        pics[i]->valid = 1;
+        slot_records_reset(pics[i]), pics[i]->valid = 1;
     return SVT_AMD_OK;
 }
 
@@ -611,18 +654,43 @@ static int validate_me(SvtAmdContext *ctx, const SvtAmdMeParams *p, int cur_slot
 }
 
 /* the slot's motion-estimation / open-loop intra search records are (being) written by kernels on this lane's stream: consumers on other lanes order themselves behind */
-static int me_records_written(SvtAmdContext *ctx, int slot, const SvtAmdMeParams *p)
+/* A new picture enters the slot: whatever records the buffers hold belong to the previous one (every upload path calls this where it sets `valid`). */
+static void slot_records_reset(DevPicture *s)
+{
+    __atomic_store_n(&s->me_lcus, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&s->ois_lcus, 0u, __ATOMIC_RELEASE);
+    s->me_lo = s->me_hi = 0;
+}
+/* Before a kernel of this lane writes the slot's record buffers: a mode-decision kernel of another lane may still be reading the previous picture's records in place
+ * (svt_amd_md_encode_picture_inter with me == NULL / ois == NULL records ev_md_read behind its launch). */
+static int slot_records_before_write(SvtAmdContext *ctx, DevPicture *s)
+{
+    if (__atomic_load_n(&s->md_read_pending, __ATOMIC_ACQUIRE)) {
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, s->ev_md_read, 0));
+        __atomic_store_n(&s->md_read_pending, 0, __ATOMIC_RELEASE);
+    }
+    return SVT_AMD_OK;
+}
+/* [lcu_begin, lcu_end): the LCUs the launch wrote.  The slot counts as holding the picture's records only when the launches since the last upload cover all of it. */
+static int me_records_written(SvtAmdContext *ctx, int slot, const SvtAmdMeParams *p, uint32_t lcu_begin, uint32_t lcu_end)
 {
     DevPicture *s = &ctx->slots[slot];
-    s->me_lcus = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
+    const uint32_t n = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
+    if (s->me_hi > s->me_lo && lcu_begin <= s->me_hi && lcu_end >= s->me_lo) { /* touches what is covered: one range */
+        s->me_lo = lcu_begin < s->me_lo ? lcu_begin : s->me_lo;
+        s->me_hi = lcu_end > s->me_hi ? lcu_end : s->me_hi;
+    } else {
+        s->me_lo = lcu_begin, s->me_hi = lcu_end;
+    }
     HIP_TRY(hipEventRecord(s->ev_me, ctx->stream));
+    __atomic_store_n(&s->me_lcus, (s->me_lo == 0 && s->me_hi >= n) ? n : 0u, __ATOMIC_RELEASE);
     return SVT_AMD_OK;
 }
 static int ois_records_written(SvtAmdContext *ctx, int slot, const SvtAmdOisParams *p)
 {
     DevPicture *s = &ctx->slots[slot];
-    s->ois_lcus = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
     HIP_TRY(hipEventRecord(s->ev_ois, ctx->stream));
+    __atomic_store_n(&s->ois_lcus, ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u), __ATOMIC_RELEASE);
     return SVT_AMD_OK;
 }
 
@@ -660,9 +728,11 @@ extern "C" int svt_amd_me_picture_range_launch(SvtAmdContext *ctx, const SvtAmdM
     if (rc)
         return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = slot_records_before_write(ctx, &ctx->slots[cur_slot])) != 0)
+        return rc;
     rc = svt_amd_launch_me_batch(ctx, &job, 1, job.lcu_count);
     if (rc == SVT_AMD_OK)
-        rc = me_records_written(ctx, cur_slot, params);
+        rc = me_records_written(ctx, cur_slot, params, lcu_begin, lcu_end);
     return rc;
 }
 
@@ -688,9 +758,12 @@ extern "C" int svt_amd_me_batch_launch(SvtAmdContext *ctx, const SvtAmdMeJob *jo
         if (e == hipSuccess && ctx->d_dbg && (size_t)num_jobs * max_lcus <= ctx->dbg_slots)
             for (int i = 0; i < num_jobs; i++)
                 dj[i].dbg_clock = ctx->d_dbg;
-        rc = e == hipSuccess ? svt_amd_launch_me_batch(ctx, dj, num_jobs, max_lcus) : SVT_AMD_ERR_DEVICE;
+        for (int i = 0; i < num_jobs && e == hipSuccess && rc == SVT_AMD_OK; i++)
+            rc = slot_records_before_write(ctx, &ctx->slots[jobs[i].cur_slot]);
+        if (rc == SVT_AMD_OK)
+            rc = e == hipSuccess ? svt_amd_launch_me_batch(ctx, dj, num_jobs, max_lcus) : SVT_AMD_ERR_DEVICE;
         for (int i = 0; i < num_jobs && rc == SVT_AMD_OK; i++)
-            rc = me_records_written(ctx, jobs[i].cur_slot, &jobs[i].params);
+            rc = me_records_written(ctx, jobs[i].cur_slot, &jobs[i].params, 0, (uint32_t)dj[i].lcu_count);
     }
     free(dj);
     return rc;
@@ -968,8 +1041,8 @@ static int ois_launch(SvtAmdContext *ctx, const SvtAmdOisParams *params, int cur
     HIP_TRY(hipSetDevice(ctx->device));
     OisJobDev j;
     make_ois_job(ctx, params, cur_slot, d_me, &j);
-    int rc = svt_amd_stamp_begin(ctx, KC_OIS);
-    if (rc)
+    int rc = slot_records_before_write(ctx, &ctx->slots[cur_slot]);
+    if (rc || (rc = svt_amd_stamp_begin(ctx, KC_OIS)) != 0)
         return rc;
     rc = svt_amd_launch_ois_batch(ctx, &j, 1, j.nlcu);
     const int rc2 = svt_amd_stamp_end(ctx);
@@ -992,8 +1065,10 @@ extern "C" int svt_amd_ois_batch_launch(SvtAmdContext *ctx, const SvtAmdOisJob *
         max_lcus = host[i].nlcu > max_lcus ? host[i].nlcu : max_lcus;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = svt_amd_stamp_begin(ctx, KC_OIS);
-    if (rc)
+    int rc = SVT_AMD_OK;
+    for (int i = 0; i < num_jobs && !rc; i++)
+        rc = slot_records_before_write(ctx, &ctx->slots[jobs[i].cur_slot]);
+    if (rc || (rc = svt_amd_stamp_begin(ctx, KC_OIS)) != 0)
         return rc;
     rc = svt_amd_launch_ois_batch(ctx, host, num_jobs, max_lcus);
     const int rc2 = svt_amd_stamp_end(ctx);
@@ -1077,6 +1152,7 @@ extern "C" int svt_amd_picture_upload_async(SvtAmdContext *ctx, int slot, const 
     if ((rc = svt_amd_launch_prep(ctx, s, s->d_staging, width)) != 0)
         return rc;
     HIP_TRY(hipEventRecord(s->ev_ready, ctx->stream));
+    slot_records_reset(s); /* the records in the slot's buffers are the previous picture's */
     s->valid = 1;
     return SVT_AMD_OK;
 }

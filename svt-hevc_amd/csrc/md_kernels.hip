@@ -43,6 +43,7 @@
 #include <string.h>
 #include <vector>
 #include <mutex>
+#include <condition_variable>
 #define MD_FN __host__ __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MD_LDS(ptr) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)(ptr)))
@@ -1726,6 +1727,52 @@ static int msb_view(hipStream_t st, const void *in16, uint8_t *out8, size_t samp
     return SVT_AMD_OK;
 }
 
+/* How many k_md_encode_picture launches may be on the device at a time.  A workgroup of this kernel holds a whole CU (its LDS) for the life of the launch, most of it
+ * waiting for neighbours: six pictures' launches of 40 workgroups fill a 256-CU part, and whatever else the encoder needs meanwhile - the next pictures' motion
+ * estimation and open-loop intra search, picture preparation, the runtime's copy kernels - then waits for a mode-decision launch to END (profiles/r05_a: with 12 - 16
+ * pictures in the encoder's pool the closed loop fell from 57 to 25 fps, launches starting in bursts exactly when others finished).  The limit keeps about a fifth of the
+ * CUs free: (CUs - CUs / 5) / workgroups per launch, 5 at 4K on an MI355X; SVT_AMD_MD_MAX_KERNELS overrides it.  A call waits for a free place AFTER its inputs are
+ * on the device and gives it back when its kernel has finished, before its records travel back. */
+namespace {
+std::mutex g_flight_mu;
+std::condition_variable g_flight_cv;
+int g_flights;
+int md_flight_limit(int device, int grid)
+{
+    static const int forced = getenv("SVT_AMD_MD_MAX_KERNELS") ? atoi(getenv("SVT_AMD_MD_MAX_KERNELS")) : 0;
+    if (forced > 0)
+        return forced;
+    static int cus[64];
+    if (!cus[device & 63]) {
+        hipDeviceProp_t pr;
+        cus[device & 63] = hipGetDeviceProperties(&pr, device) == hipSuccess ? pr.multiProcessorCount : 256;
+    }
+    const int c = cus[device & 63], n = (c - c / 5) / (grid > 0 ? grid : 1);
+    return n < 1 ? 1 : n;
+}
+struct MdFlight {
+    bool held = false;
+    void acquire(int limit)
+    {
+        std::unique_lock<std::mutex> l(g_flight_mu);
+        g_flight_cv.wait(l, [&] { return g_flights < limit; });
+        g_flights++, held = true;
+    }
+    void release()
+    {
+        if (!held)
+            return;
+        {
+            std::lock_guard<std::mutex> l(g_flight_mu);
+            g_flights--;
+        }
+        held = false;
+        g_flight_cv.notify_one();
+    }
+    ~MdFlight() { release(); }
+};
+}
+
 /* bps: bytes per sample of the source planes, the work / result records and the picture object (1, or 2 = a 10-bit picture: the mode decision on the 8 MSBs of source
  * and reference pictures, the encode pass on the 10-bit samples) */
 static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdInter *X, const SvtAmdMdLcu *lcus,
@@ -1765,9 +1812,9 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     const SvtAmdMeLcuResult *d_me_slot = nullptr;
     if (X && !me) {
         SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
-        if (me_slot < 0 || me_slot >= root->num_slots || !root->slots[me_slot].d_me_out || !root->slots[me_slot].valid || root->slots[me_slot].me_lcus != (uint32_t)n ||
+        if (me_slot < 0 || me_slot >= root->num_slots || !root->slots[me_slot].d_me_out || !root->slots[me_slot].valid || __atomic_load_n(&root->slots[me_slot].me_lcus, __ATOMIC_ACQUIRE) != (uint32_t)n ||
             root->slots[me_slot].width != pic->d.width || root->slots[me_slot].height != pic->d.height) {
-            svt_amd_set_error("svt_amd_md_encode_picture_inter: slot %d does not hold the motion-estimation records of a %u x %u picture", me_slot, pic->d.width, pic->d.height);
+            svt_amd_set_error("svt_amd_md_encode_picture_inter: slot %d does not hold the motion-estimation records of a %u x %u picture (none launched for the slot's current picture, or only a part of it)", me_slot, pic->d.width, pic->d.height);
             return SVT_AMD_ERR_BAD_PARAM;
         }
         d_me_slot = root->slots[me_slot].d_me_out;
@@ -1776,7 +1823,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     const SvtAmdOisLcuResult *d_ois_slot = nullptr;
     if (!ois) {
         SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
-        if (ois_slot < 0 || ois_slot >= root->num_slots || !root->slots[ois_slot].d_ois_out || !root->slots[ois_slot].valid || root->slots[ois_slot].ois_lcus != (uint32_t)n ||
+        if (ois_slot < 0 || ois_slot >= root->num_slots || !root->slots[ois_slot].d_ois_out || !root->slots[ois_slot].valid || __atomic_load_n(&root->slots[ois_slot].ois_lcus, __ATOMIC_ACQUIRE) != (uint32_t)n ||
             root->slots[ois_slot].width != pic->d.width || root->slots[ois_slot].height != pic->d.height) {
             svt_amd_set_error("svt_amd_md_encode_picture: slot %d does not hold the open-loop intra search records of a %u x %u picture", ois_slot, pic->d.width, pic->d.height);
             return SVT_AMD_ERR_BAD_PARAM;
@@ -1909,6 +1956,14 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
     m->grid = grid;
+    MdFlight flight;
+    {
+        const int limit = md_flight_limit(ctx->device, grid);
+        if (limit < 64) { /* the inputs first (a call that waits for a place holds no CU and no copy engine meanwhile) */
+            HIP_TRY(hipStreamSynchronize(st));
+            flight.acquire(limit);
+        }
+    }
     HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X && bps == 1)
         hipLaunchKernelGGL((k_md_encode_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true, uint8_t>), st, m->d, pic->d, (SvtAmdLcuWork *)m->d_works,
@@ -1924,9 +1979,22 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
                            (SvtAmdLcuResult16 *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev_k1, st));
+    {   /* records read in place: the next motion-estimation / open-loop intra launch INTO those slots orders itself behind this kernel (context.hip slot_records_before_write) */
+        SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
+        const int rs[2] = {d_me_slot ? me_slot : -1, d_ois_slot ? ois_slot : -1};
+        for (int k = 0; k < 2; k++)
+            if (rs[k] >= 0 && !(k == 1 && rs[1] == rs[0])) {
+                HIP_TRY(hipEventRecord(root->slots[rs[k]].ev_md_read, st));
+                __atomic_store_n(&root->slots[rs[k]].md_read_pending, 1, __ATOMIC_RELEASE);
+            }
+    }
     if (timing) {
         HIP_TRY(hipStreamSynchronize(st));
         t_kernel = std::chrono::steady_clock::now();
+    }
+    if (flight.held) { /* the place is free as soon as the kernel has finished: the records' way back needs no CU */
+        HIP_TRY(hipEventSynchronize(m->ev_k1));
+        flight.release();
     }
     if (md_out)
         HIP_TRY(hipMemcpyAsync(md_out, m->d_out, sizeof(SvtAmdMdLcuOut) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -39,7 +39,11 @@ struct DevPicture {
     hipEvent_t ev_ready;           /* recorded after the planes of this slot were built: lanes on other streams wait on it */
     hipEvent_t ev_me, ev_ois;      /* recorded behind the kernels that wrote d_me_out / d_ois_out: a consumer on another lane's stream (the mode decision reading the
                                     * records where they are) waits on them */
-    uint32_t me_lcus, ois_lcus;    /* LCUs of the picture whose records the buffers hold (0: none yet) */
+    uint32_t me_lcus, ois_lcus;    /* LCUs of the picture whose records the buffers hold (0: none yet, or only a part of the picture: every upload into the slot resets
+                                    * them; read / written across host threads with acquire / release) */
+    uint32_t me_lo, me_hi;         /* LCU range [lo, hi) of the slot's CURRENT picture that range launches have covered so far: me_lcus is set when it is the whole picture */
+    hipEvent_t ev_md_read;         /* recorded behind a mode-decision kernel that reads d_me_out / d_ois_out in place: the next ME / OIS launch INTO the slot waits for it */
+    int md_read_pending;
     uint16_t width, height;
     int      valid;
 };

@@ -44,8 +44,13 @@ with open(O + "/md_timeline.txt", "w") as out:
     print("share of wall time with k mode-decision kernels running: " + ", ".join("%d: %.0f%%" % (k, 100.0 * v / tot) for k, v in sorted(hist.items())), file=out)
     durs = sorted((e - s) / 1e6 for s, e, _, _ in md)
     print("duration ms: min %.1f median %.1f max %.1f; sum %.0f over wall %.0f ms" % (durs[0], durs[len(durs) // 2], durs[-1], sum(durs), (end - t0) / 1e6), file=out)
-    busy = sorted(other)
     print("other kernels: %d launches, %.0f ms summed" % (len(other), sum((e - s) for s, e, _, _ in other) / 1e6), file=out)
+    byname = {}
+    for s, e, _, n in other:
+        d = byname.setdefault(n, [0, 0.0, 0.0])
+        d[0] += 1; d[1] += (e - s) / 1e6; d[2] = max(d[2], (e - s) / 1e6)
+    for n, d in sorted(byname.items(), key=lambda kv: -kv[1][1])[:12]:
+        print("    %-42s %5d launches %9.1f ms summed, longest %.2f ms" % (n, d[0], d[1], d[2]), file=out)
 print(open(O + "/md_timeline.txt").read())
 PY
 grep "mode decision" $O/report.txt | cut -c1-400
