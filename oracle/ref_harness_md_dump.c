@@ -149,6 +149,21 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
     }
     if (g_state < 0)
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);
+    {   /* SVT_REF_MD_FORCE="complex2:<m>,noise:<n>": per-LCU detector outcomes the synthetic clips never produce (LCU_COMPLEXITY_STATUS_2,
+         * EbSourceBasedOperationsProcess.c:967-993; CMPLX_NOISE, :135-160 - both need 1080p+ content classes) are set on every m-th / n-th LCU BEFORE the call, so that the
+         * record is the reference's own ModeDecisionLcu under those inputs (ProductIntraCandidateInjection's complexity branch, EbModeDecision.c:1147; the noise-class rule
+         * of the fast loop's chroma distortion, EbProductCodingLoop.c:2079-2094).  Only the recorded function's inputs are touched; the encode that follows is not used. */
+        static int f_cx = -1, f_nz;
+        if (f_cx < 0) {
+            const char *f = getenv("SVT_REF_MD_FORCE"), *q;
+            f_cx = (f && (q = strstr(f, "complex2:"))) ? atoi(q + 9) : 0;
+            f_nz = (f && (q = strstr(f, "noise:"))) ? atoi(q + 6) : 0;
+        }
+        if (f_cx > 0 && lcuAddr % (EB_U32)f_cx == 1)
+            pcs->ParentPcsPtr->complexLcuArray[lcuAddr] = LCU_COMPLEXITY_STATUS_2;
+        if (f_nz > 0 && lcuAddr % (EB_U32)f_nz == 0)
+            pcs->ParentPcsPtr->cmplxStatusLcu[lcuAddr] = CMPLX_NOISE;
+    }
     MdLcuRecord *r = (MdLcuRecord *)calloc(1, sizeof(*r));
     r->magic = MD_LCU_MAGIC, r->record_size = (uint32_t)sizeof(*r), r->picture_number = pcs->pictureNumber, r->lcu_index = lcuAddr;
     svt_md_fill_lcu(&r->lcu, scs, pcs, lcuPtr, contextPtr);

@@ -1624,6 +1624,7 @@ extern "C" int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmdM
 struct SvtAmdMdState {
     MdPictureDev d;
     uint8_t *d_src[3];
+    size_t src_cap[3];             /* bytes of d_src[k] (grown when a caller's row pitch needs more than the picture object's own) */
     SvtAmdOisLcuResult *d_ois;
     SvtAmdMdLcu *d_lcus;
     SvtAmdMdPicture *d_P;
@@ -1682,6 +1683,7 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     bool ok = hipMalloc((void **)&m->d.md_rec, pic->plane_bytes[0] / bps) == hipSuccess && hipMalloc((void **)&m->d.md_info, m->info_bytes) == hipSuccess;
     for (int k = 0; k < 3 && ok; k++) {
         ok = hipMalloc((void **)&m->d_src[k], pic->plane_bytes[k] / bps) == hipSuccess;
+        m->src_cap[k] = ok ? pic->plane_bytes[k] / bps : 0;
         if (bps == 2)
             ok = ok && hipMalloc((void **)&m->d_src16[k], pic->plane_bytes[k]) == hipSuccess;
     }
@@ -1731,12 +1733,15 @@ static int msb_view(hipStream_t st, const void *in16, uint8_t *out8, size_t samp
  * waiting for neighbours: six pictures' launches of 40 workgroups fill a 256-CU part, and whatever else the encoder needs meanwhile - the next pictures' motion
  * estimation and open-loop intra search, picture preparation, the runtime's copy kernels - then waits for a mode-decision launch to END (profiles/r05_a: with 12 - 16
  * pictures in the encoder's pool the closed loop fell from 57 to 25 fps, launches starting in bursts exactly when others finished).  The limit keeps about a fifth of the
- * CUs free: (CUs - CUs / 5) / workgroups per launch, 5 at 4K on an MI355X; SVT_AMD_MD_MAX_KERNELS overrides it.  A call waits for a free place AFTER its inputs are
+ * CUs free: (CUs - CUs / 16) / workgroups per launch = 6 at 4K on an MI355X (profiles/r05_b: 4 / 5 / 6 / unlimited = 61.8 / 69.7 / 71.6 / 54.0 fps); SVT_AMD_MD_MAX_KERNELS overrides it.  A call waits for a free place AFTER its inputs are
  * on the device and gives it back when its kernel has finished, before its records travel back. */
 namespace {
 std::mutex g_flight_mu;
 std::condition_variable g_flight_cv;
 int g_flights;
+unsigned long long g_flight_ticket;
+struct FlightWaiter { int prio; unsigned long long ticket; };
+std::vector<FlightWaiter> g_flight_wait;
 int md_flight_limit(int device, int grid)
 {
     static const int forced = getenv("SVT_AMD_MD_MAX_KERNELS") ? atoi(getenv("SVT_AMD_MD_MAX_KERNELS")) : 0;
@@ -1747,16 +1752,34 @@ int md_flight_limit(int device, int grid)
         hipDeviceProp_t pr;
         cus[device & 63] = hipGetDeviceProperties(&pr, device) == hipSuccess ? pr.multiProcessorCount : 256;
     }
-    const int c = cus[device & 63], n = (c - c / 5) / (grid > 0 ? grid : 1);
+    const int c = cus[device & 63], n = (c - c / 16) / (grid > 0 ? grid : 1);
     return n < 1 ? 1 : n;
 }
+/* a place among the launches on the device; among the calls that wait, the one of the lowest temporal layer goes first (the pictures other pictures wait for), then the
+ * one that came first */
 struct MdFlight {
     bool held = false;
-    void acquire(int limit)
+    void acquire(int limit, int prio)
     {
         std::unique_lock<std::mutex> l(g_flight_mu);
-        g_flight_cv.wait(l, [&] { return g_flights < limit; });
+        const FlightWaiter me = {prio, g_flight_ticket++};
+        g_flight_wait.push_back(me);
+        g_flight_cv.wait(l, [&] {
+            if (g_flights >= limit)
+                return false;
+            for (const FlightWaiter &w : g_flight_wait)
+                if (w.prio < me.prio || (w.prio == me.prio && w.ticket < me.ticket))
+                    return false;
+            return true;
+        });
+        for (size_t i = 0; i < g_flight_wait.size(); i++)
+            if (g_flight_wait[i].ticket == me.ticket) {
+                g_flight_wait.erase(g_flight_wait.begin() + (long)i);
+                break;
+            }
         g_flights++, held = true;
+        l.unlock();
+        g_flight_cv.notify_all(); /* the next in line may fit as well */
     }
     void release()
     {
@@ -1767,7 +1790,7 @@ struct MdFlight {
             g_flights--;
         }
         held = false;
-        g_flight_cv.notify_one();
+        g_flight_cv.notify_all();
     }
     ~MdFlight() { release(); }
 };
@@ -1860,9 +1883,24 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_up = t_begin, t_kernel = t_begin;
     const void *hs[3] = {src_y, src_cb, src_cr};
+    /* 8-bit source planes travel as ONE linear transfer each, in the host's row pitch (the device copy keeps that pitch): a strided copy is a shader kernel of the runtime
+     * (__amd_rocclr_copyBufferRect: 2 ms per plane, and 40 ms when the mode-decision launches of other pictures hold the CUs - profiles/r05_b), a linear one from page-locked
+     * memory is the DMA engine's */
+    const bool linear = bps == 1 && stride_y % 4 == 0 && stride_c % 4 == 0 && stride_y < 2 * pic->d.width + 256 && stride_c < pic->d.width + 256;
     for (int k = 0; k < 3; k++) {
         const uint32_t pw = k ? pic->d.width / 2 : pic->d.width, ph = k ? pic->d.height / 2 : pic->d.height;
-        if (bps == 1) {
+        if (linear) {
+            const size_t hstride = k ? stride_c : stride_y, need = hstride * (ph - 1) + pw;
+            if (m->src_cap[k] < need) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (m->d_src[k])
+                    (void)hipFree(m->d_src[k]);
+                m->d_src[k] = nullptr, m->src_cap[k] = 0;
+                HIP_TRY(hipMalloc((void **)&m->d_src[k], need + 64));
+                m->src_cap[k] = need;
+            }
+            HIP_TRY(hipMemcpyAsync(m->d_src[k], hs[k], need, hipMemcpyHostToDevice, st));
+        } else if (bps == 1) {
             HIP_TRY(hipMemcpy2DAsync(m->d_src[k], pic->d.pitch[k], hs[k], k ? stride_c : stride_y, pw, ph, hipMemcpyHostToDevice, st));
         } else { /* strides in samples */
             HIP_TRY(hipMemcpy2DAsync(m->d_src16[k], (size_t)pic->d.pitch[k] * 2, hs[k], (size_t)(k ? stride_c : stride_y) * 2, (size_t)pw * 2, ph, hipMemcpyHostToDevice, st));
@@ -1871,7 +1909,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         }
         m->d.src[k] = m->d_src[k], m->d.src16[k] = bps == 2 ? m->d_src16[k] : nullptr;
     }
-    m->d.src_pitch[0] = pic->d.pitch[0], m->d.src_pitch[1] = pic->d.pitch[1];
+    m->d.src_pitch[0] = linear ? stride_y : pic->d.pitch[0], m->d.src_pitch[1] = linear ? stride_c : pic->d.pitch[1];
     for (int l = 0; l < 2; l++) { /* the reference pictures as the mode decision reads them */
         m->d.mref[l] = pic->d.ref[l];
         if (bps == 2 && X && pic->has_ref[l])
@@ -1961,7 +1999,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         const int limit = md_flight_limit(ctx->device, grid);
         if (limit < 64) { /* the inputs first (a call that waits for a place holds no CU and no copy engine meanwhile) */
             HIP_TRY(hipStreamSynchronize(st));
-            flight.acquire(limit);
+            flight.acquire(limit, (int)P->temporal_layer);
         }
     }
     HIP_TRY(hipEventRecord(m->ev_k0, st));

@@ -46,6 +46,12 @@ CASES = {
     "bref_tiles_motion_640x384_m8": ("motion", 640, 384, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "34", "-tile_col_cnt", "2",
                                                                   "-tile_row_cnt", "2"], "ref"),
     "i_tiles_motion_640x384_m9": ("motion", 640, 384, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "33", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], None),
+    # detector outcomes no synthetic clip produces, set on every 3rd / 2nd LCU by the harness before the recorded call (SVT_REF_MD_FORCE, oracle/ref_harness_md_dump.c):
+    # LCU_COMPLEXITY_STATUS_2 LCUs (the complexity branch of the intra candidate injection) and CMPLX_NOISE LCUs (the noise-class rule of the fast loop's chroma distortion
+    # for 64x64 candidates that do not move: the zero-vector merge candidates of a static clip), in I, non-reference B and CHROMA_MODE_FULL reference B pictures
+    "i_forced_motion_416x240_m9": ("motion", 416, 240, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "32"], None, "complex2:3,noise:2"),
+    "b_forced_static_416x240_m8": ("static", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "nonref", "complex2:3,noise:2"),
+    "bref_forced_static_416x240_m8": ("static", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "ref", "complex2:3,noise:2"),
 }
 
 
@@ -89,13 +95,14 @@ def parse_dump(raw):
 
 
 def run_case(name):
-    kind, w, h, n, seed, args, keep = CASES[name]
+    kind, w, h, n, seed, args, keep = CASES[name][:7]
+    force = CASES[name][7] if len(CASES[name]) > 7 else None
     with tempfile.TemporaryDirectory() as td:
         yuv, dump = os.path.join(td, "clip.yuv"), os.path.join(td, "md.dump")
         S.write_clip(yuv, kind, w, h, n, seed)
         cmd = [S.REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-asm", "0", "-b", os.path.join(td, "out.265")] + args
         epdump = os.path.join(td, "ep.dump")
-        subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump, SVT_REF_ENCODEPASS_DUMP=epdump), check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(cmd, env=dict(os.environ, SVT_REF_MD_DUMP=dump, SVT_REF_ENCODEPASS_DUMP=epdump, **({"SVT_REF_MD_FORCE": force} if force else {})), check=True, stdout=subprocess.DEVNULL)
         pics, lcus = parse_dump(open(dump, "rb").read())
         import make_encodepass_golden as EPG
         ep_recs, _, _ = EPG.parse_dump(open(epdump, "rb").read(), S.EP_RECORD_DTYPE)

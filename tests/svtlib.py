@@ -283,6 +283,10 @@ def gen_luma(kind, w, h, t, seed):
     """One 8-bit luma frame of clip `kind` at time t."""
     if kind == "flat":
         return np.full((h, w), 128, np.uint8)
+    if kind == "static":
+        # the first frame of "motion" standing still under mild per-frame noise: zero vectors win and the zero-vector merge candidates carry real residual
+        frame_rng = np.random.default_rng(seed * 1000 + 77 + t)
+        return np.clip(gen_luma("motion", w, h, 0, seed).astype(np.int32) + frame_rng.integers(-2, 3, size=(h, w)), 0, 255).astype(np.uint8)
     rng = np.random.default_rng(seed)
     if kind == "noise":
         for _ in range(t):

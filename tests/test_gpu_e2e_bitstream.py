@@ -21,6 +21,8 @@ CASES = [
     ("noise", 320, 256, 6, ["-encMode", "4"]),
     ("motion", 1920, 1080, 6, ["-encMode", "9", "-pred-struct", "0"]),
     ("flat", 1024, 768, 5, ["-encMode", "7", "-rc", "1", "-tbr", "2000000"]),
+    # the same with one logical processor: the reference repeats itself there (oracle/_ref, six runs at -lp 1 and six at default threading on the 8-thread build host: one md5), so this leg takes no excuse
+    ("flat", 1024, 768, 5, ["-encMode", "7", "-rc", "1", "-tbr", "2000000", "-lp", "1"]),
     # all-intra 1080p encMode 10 (BASELINE configs[0]): OIS with 8x8 CUs on every picture, no ME at all
     ("motion", 1920, 1080, 4, ["-encMode", "10", "-intra-period", "0"]),
     # encMode 4 flat low-delay P: 35-mode OIS on P pictures, SSD sub-pel ME
@@ -69,16 +71,22 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
         S.write_clip(yuv, kind, w, h, n, 7)
     ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
     hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
-    if "-rc" in args:
-        # rate control is the one configuration whose QPs depend on WHEN something arrives: the rate-control kernel takes picture-manager tasks and packetization feedback
-        # in arrival order (Codec/EbRateControlProcess.c: RC_PICTURE_MANAGER_RESULT / RC_PACKETIZATION_FEEDBACK_RESULT) and a later picture's QP uses the sizes fed back so
-        # far.  One mismatch in about a dozen runs of this case was seen on the GPU box's 256 host threads (never in the full-suite runs before it, nor in six repeats
-        # after it); a mismatch therefore counts only when it persists: both encoders run again, up to three times in all.
-        for _ in range(2):
-            if hip_md5 == ref_md5:
+    if "-rc" in args and "-lp" not in args and hip_md5 != ref_md5:
+        # Rate control is the one configuration whose QPs can depend on WHEN something arrives: the rate-control kernel takes picture-manager tasks and packetization
+        # feedback in arrival order (Codec/EbRateControlProcess.c: RC_PICTURE_MANAGER_RESULT / RC_PACKETIZATION_FEEDBACK_RESULT) and a later picture's QP uses the sizes fed
+        # back so far.  A mismatch is excused ONLY when this very run proves the nondeterminism upstream: the unmodified reference, run again on the same clip, must
+        # itself produce more than one bitstream; then (and only then) the hooked encoder's bitstream has to be one the reference can produce.  A reference that repeats
+        # itself makes the first mismatch a failure of the bindings (no retry: VERDICT r4 / ADVICE r4).
+        ref_set = {ref_md5}
+        for k in range(5):
+            ref_set.add(_encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / ("ref%d.265" % k)))[0])
+        assert len(ref_set) > 1, "bitstream differs from the reference, and six reference runs of this clip all agree (%s): the bindings changed the result" % ref_md5
+        for k in range(4):
+            if hip_md5 in ref_set:
                 break
-            ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
             hip_md5, log = _encode(HIP_APP, yuv, w, h, n, args, str(tmp_path / "hip.265"))
+        assert hip_md5 in ref_set, "the reference itself produced %d different bitstreams for this clip; the hooked encoder's is none of them" % len(ref_set)
+        ref_md5 = hip_md5
     # every MotionEstimateLcu call is redirected at link time (--wrap); the hook announces itself
     assert "svt_hook_me: motion estimation on svt-hevc_amd" in log, "hook inactive:\n" + log[-1000:]
     # one device OIS call per picture; ME for every non-intra picture
@@ -538,8 +546,9 @@ def test_bitstream_and_recon_identical_with_device_resident_mode_decision(tmp_pa
         assert pics == n and lcus == n * nl and left == 0, rep
     elif isinstance(expect, tuple):
         assert inter >= 1 and pics == inter + 1 and lcus == pics * nl, rep   # the I picture + the P / B pictures inside the device call
-        if expect[1] is not None:   # at least these many (which reference pictures qualify depends on the LCU depth modes the reference derives)
-            assert pics >= expect[1] and inter >= expect[2], rep
+        print("MD_COUNTS", kind, w, h, n, pics, inter, left)   # (pytest -s: the exact counts of a run, for pinning)
+        if expect[1] is not None:   # exactly these: which pictures qualify follows from the LCU depth modes the reference derives for this clip - a fixed function of the clip
+            assert pics == expect[1] and inter == expect[2], rep
     else:
         assert pics == 0 and left >= 1, rep
     assert hip_md5 == ref_md5, "bitstream differs from the reference\n" + rep
@@ -562,5 +571,5 @@ def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(
     m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\)", rep)
     assert m, rep
     pics, inter, lcus = (int(v) for v in m.groups())
-    assert pics >= 13 and inter >= 12 and lcus == pics * S.lcu_count(3840, 2160), rep   # I + 8 layer-2 + 4 layer-1 pictures; the 4 base-layer B pictures: reference code
+    assert pics == 13 and inter == 12 and lcus == pics * S.lcu_count(3840, 2160), rep   # I + 8 layer-2 + 4 layer-1 pictures; the 4 base-layer B pictures: reference code
     assert r["bitstream_identical"], rep
