@@ -47,11 +47,11 @@ CASES = {
                                                                   "-tile_row_cnt", "2"], "ref"),
     "i_tiles_motion_640x384_m9": ("motion", 640, 384, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "33", "-tile_col_cnt", "2", "-tile_row_cnt", "2"], None),
     # detector outcomes no synthetic clip produces, set on every 3rd / 2nd LCU by the harness before the recorded call (SVT_REF_MD_FORCE, oracle/ref_harness_md_dump.c):
-    # LCU_COMPLEXITY_STATUS_2 LCUs (the complexity branch of the intra candidate injection) and CMPLX_NOISE LCUs (the noise-class rule of the fast loop's chroma distortion
+    # LCU_COMPLEXITY_STATUS_2 LCUs (the complexity branch of the intra candidate injection) and CMPLX_NOISE LCUs (every LCU of the reference B pictures; the noise-class rule of the fast loop's chroma distortion
     # for 64x64 candidates that do not move: the zero-vector merge candidates of a static clip), in I, non-reference B and CHROMA_MODE_FULL reference B pictures
     "i_forced_motion_416x240_m9": ("motion", 416, 240, 1, 7, ["-encMode", "9", "-intra-period", "0", "-q", "32"], None, "complex2:3,noise:2"),
     "b_forced_static_416x240_m8": ("static", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "nonref", "complex2:3,noise:2"),
-    "bref_forced_static_416x240_m8": ("static", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "ref", "complex2:3,noise:2"),
+    "bref_forced_static_416x240_m8": ("static", 416, 240, 9, 7, ["-encMode", "8", "-pred-struct", "2", "-hierarchical-levels", "3", "-q", "30"], "ref", "complex2:3,noise:1"),
 }
 
 
