@@ -22,13 +22,16 @@ timed region; `hbm_resident_fps` is the compute lane alone.
 Prints ONE JSON line (rank 0).
 
 `metric` / `value` = BASELINE.json's metric: ENCODED fps of the whole encoder with the HIP path bound in (integration/_build/
-SvtHevcEncApp_hip = the drop-in libSvtHevcEnc.so.1 + the reference's sample application) on BASELINE configs[2]'s command line, the
+SvtHevcEncApp_hip = the drop-in libSvtHevcEnc.so.1 + the reference's sample application) on BASELINE configs[2]'s command line, WITH THE CLOSED
+LOOP ON THE DEVICE (CLOSED_LOOP_ENV below: SVT_HOOK_MD=pb - motion estimation and open-loop intra search of every picture, mode decision, merge / skip
+decisions and encode pass of every open-loop P / B picture, one call per picture; `encoder_fps.coverage` says how many pictures that was), the
 application's own "Average Speed" (SURVEY 8d), GATED on the bitstream being md5-identical to the unmodified reference's
-(oracle/_ref/SvtHevcEncApp_ref) on the same clip: a differing bitstream reports value 0.  A "step" of that number = 8 encoded pictures
-(two mini-GOPs of the 3-layer random-access structure): --steps K encodes 8 K pictures (K = 20: 160 >= the 150 SURVEY 8d asks for);
-start-up is outside the clock (the application preloads the clip, -nb, and starts its clock after EbInitEncoder).  Which SVT_HOOK_*
-bindings were on is stated in `config.switches`.  `cpu_baseline` = the unmodified reference encoder (AVX2 tables, all host threads)
-on the same clip, plus a bounded `-lp 1` run for the per-core figure.
+(oracle/_ref/SvtHevcEncApp_ref) on the same clip in every run: a differing bitstream reports value 0.  `value` is the MEDIAN of RUNS = 3
+encodes (`encoder_fps.hip.fps_runs` holds all three).  A "step" of that number = 8 encoded pictures (two mini-GOPs of the 3-layer
+random-access structure): --steps K encodes 8 K pictures (K = 20: 160 >= the 150 SURVEY 8d asks for); start-up is outside the clock (the
+application preloads the clip, -nb, and starts its clock after EbInitEncoder).  `cpu_baseline.value` = the unmodified reference encoder (AVX2
+tables) on the same clip at ITS best threading on these hosts (-lp 32, median of 3; the default-threading run and a bounded `-lp 1` run are
+beside it); `vs_baseline` stays null (BASELINE.md holds no published number for this metric), `vs_cpu_baseline` = value / cpu_baseline.value.
 `front_half` keeps the hot-path throughput of the device front half (what `value` was in rounds 1-2) and `roofline` its dominant
 kernels; both are measured with --steps K batches-pairs of the loop described above, bracketed by barrier + synchronize.
 N > 1: one hooked encoder per rank on its own GPU (SVT_AMD_DEVICE = local rank, host threads divided), all started behind a barrier;
@@ -112,20 +115,87 @@ def cpu_baseline_reference(cfg, unique=8, frames=48):
 
 
 HIP_LP = 32   # logical processors the hooked encoder is run with (see encoded_fps_leg)
+# The configuration `value` is measured on: the closed loop on the device.  SVT_HOOK_MD=pb: mode decision + merge / skip decisions + encode pass of every open-loop P / B
+# picture (temporal layers 1 and 2 of BASELINE configs[2] = 3 of every 4 pictures) as ONE device call per picture, on top of the front half (motion estimation + open-loop
+# intra search of every picture).  The I pictures (one per second of video: 3 of 160) and the base-layer B pictures stay with the reference's code: a 4K closed-loop I
+# picture takes the device 0.45 s along its wavefront (35 intra candidates x 84 units per LCU; profiles/r05_c_md_bench_i_4k_stages.json) where 32 host threads take 0.06 s,
+# and everything waits for it - SVT_HOOK_MD=1 (I pictures on the device too) is measured beside it (`other_configurations`).  SVT_HOOK_PCS_POOL: PictureControlSet_t
+# objects of the encoder's EncDec pool (integration/svt_hook_encdec.c; the reference sizes it MAX(4, lp / 6) for host latencies) - DESIGN 5 has the sweep.
+CLOSED_LOOP_ENV = {"SVT_HOOK_MD": "pb", "SVT_HOOK_PCS_POOL": "8"}
+RUNS = 3          # `value` and the CPU baseline beside it are medians of this many encodes (84 vs 102 fps between boxes, and run to run on one)
+
+
+class GpuBusy:
+    """gpu_busy_percent of the device (amdgpu sysfs) sampled every 50 ms while an encoder child runs"""
+
+    def __init__(self, index):
+        import threading
+        self.path = None
+        for c in sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent")):
+            self.path = self.path or c
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+        if cands:
+            self.path = cands[min(index, len(cands) - 1)]
+        self.samples, self.stop = [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop.is_set():
+            try:
+                self.samples.append(int(open(self.path).read().strip()))
+            except Exception:  # noqa: BLE001
+                pass
+            self.stop.wait(0.05)
+
+    def __enter__(self):
+        if self.path:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.path:
+            self.thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        a = np.array(self.samples, np.float64)
+        return {"mean": round(float(a.mean()), 1), "max": float(a.max()), "samples": len(a), "source": self.path}
+
+
+def _median_run(runs):
+    """the run with the median fps of a list of run_app records (+ the spread)"""
+    ok = sorted((r for r in runs if r.get("fps")), key=lambda r: r["fps"])
+    if not ok:
+        return runs[0] if runs else {"fps": None, "md5": None}
+    m = dict(ok[len(ok) // 2])
+    m["fps_runs"] = [r["fps"] for r in runs if r.get("fps")]
+    m["fps_min"], m["fps_max"] = ok[0]["fps"], ok[-1]["fps"]
+    return m
+
+
+def _coverage(report_path):
+    import re
+    lines = [l.strip() for l in open(report_path) if "mode decision" in l] if os.path.exists(report_path) else []
+    m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\).*?; (\d+) pictures outside", " ".join(lines))
+    cover = {"pictures_on_device": int(m.group(1)), "p_b_pictures_on_device": int(m.group(2)), "pictures_left_to_the_reference_code": int(m.group(4))} if m else None
+    return cover, lines
 
 
 def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
-    """The BASELINE metric.  Rank 0 first encodes the clip with the unmodified reference (its md5 is the gate, its fps the CPU
-    baseline); then every rank runs the hooked encoder on its own GPU behind a barrier.  Returns (rank 0) the record of the JSON
-    line's `encoder_fps` with `value` = pictures of all ranks / slowest rank's encode time, 0 when any bitstream differs."""
+    """The BASELINE metric, on the CLOSED LOOP (CLOSED_LOOP_ENV).  Rank 0 first encodes the clip with the unmodified reference (its md5 is the gate); then every rank runs
+    the hooked encoder on its own GPU behind a barrier, RUNS times at N = 1.  Returns (rank 0) the record of the JSON line's `encoder_fps` with `value` = pictures of all
+    ranks / slowest rank's encode time of the MEDIAN run, 0 when any bitstream of any run differs.  Beside it (N = 1): the reference at the same -lp (its best threading;
+    median of RUNS - what cpu_baseline leads with), the hooked encoder with only the front half on the device (the configuration `value` was measured on up to round 4),
+    with the I pictures left to the host (SVT_HOOK_MD=pb), and at default threading."""
     import encoder_fps as E
     frames, unique = 8 * max(1, steps), 16
     w, h, depth, args = E.CONFIGS[enc_cfg]
     args = list(args) + ["-asm", "1"]
-    switches = {k: v for k, v in os.environ.items() if k.startswith("SVT_HOOK_")}
-    out = {"config": enc_cfg, "frames": frames, "unique_frames": unique, "args": " ".join(args), "host_threads": os.cpu_count(),
-           "switches": switches or "none set: motion estimation + open-loop intra search on the device (the bindings' default); the "
-                                   "EncDec bindings (SVT_HOOK_ENCODEPASS / _FULLLOOP / _INTRA / _INTER / _SAO / _MD) are off"}
+    user = {k: v for k, v in os.environ.items() if k.startswith("SVT_HOOK_") or k.startswith("SVT_AMD_")}
+    closed = dict(CLOSED_LOOP_ENV, **user)
+    out = {"config": enc_cfg, "frames": frames, "unique_frames": unique, "args": " ".join(args), "host_threads": os.cpu_count(), "switches": closed, "runs": RUNS if world == 1 else 1}
     td = tempfile.mkdtemp(prefix="svtenc_r%d_" % rank, dir="/tmp")
     try:
         yuv = os.path.join(td, "clip.yuv")
@@ -148,38 +218,58 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
             dist.broadcast(t, 0)
             ref_md5 = bytes(t.cpu().tolist()).decode() if int(t.sum()) else ""
             dist.barrier()
-        env = {"SVT_AMD_DEVICE": str(local_rank)}
+        env = dict(closed, SVT_AMD_DEVICE=str(local_rank))
         hargs = list(args)
-        # host threads of the encoder with the HIP path bound in (-lp, the application's own switch; the bitstream does not depend on it).  With motion
-        # estimation and the open-loop intra search on the device the host pipeline is fastest with about 32 logical processors - beyond that the
-        # reference's pipeline loses to its own thread count (profiles/r03_ab_fps_threads.txt: reference 46 / 70 / 78 / 71 / 61 / 55 / 51 fps at
-        # 8 / 16 / 32 / 48 / 64 / 128 / 256, hooked 65 / 86 / 100 / 94 / 69 / 72 / 63) - and N ranks share the host's threads anyway.
+        # host threads of the encoder with the HIP path bound in (-lp, the application's own switch; the bitstream does not depend on it): about 32 logical processors is
+        # where the reference's own pipeline is fastest on these hosts (profiles/r03_ab_fps_threads.txt: reference 46 / 70 / 78 / 71 / 61 / 55 / 51 fps at 8 / 16 / 32 / 48 /
+        # 64 / 128 / 256) - `cpu_baseline` leads with the reference AT THAT -lp - and N ranks share the host's threads anyway.
         ncpu = os.cpu_count() or 1
         lp = max(1, ncpu // world) if world > 1 else ncpu
         lp = min(lp, HIP_LP)
         if lp < ncpu:
             hargs += ["-lp", str(lp)]
         out["hip_threads"] = lp
-        try:
-            hip = E.run_app(E.HIP_APP, yuv, w, h, frames, hargs, os.path.join(td, "hip.265"), env=env, nb=unique)
-        except Exception as e:
-            hip = {"error": str(e)[-300:], "fps": None, "md5": None}
-        if rank == 0 and world == 1 and lp < ncpu:
-            # for the record: the reference at the same thread count (its best), and the hooked encoder at the default thread count
+        rp = os.path.join(td, "report.txt")
+        hips, busy = [], None
+        with GpuBusy(local_rank) as gb:
+            for k in range(RUNS if world == 1 else 1):
+                try:
+                    hips.append(E.run_app(E.HIP_APP, yuv, w, h, frames, hargs, os.path.join(td, "hip.265"), env=dict(env, **({"SVT_HOOK_REPORT": rp} if k == 0 else {})), nb=unique))
+                except Exception as e:
+                    hips.append({"error": str(e)[-300:], "fps": None, "md5": None})
+            busy = gb.summary()
+        hip = _median_run(hips)
+        out["gpu_busy"] = dict(busy, what="amdgpu gpu_busy_percent sampled every 50 ms over the %d closed-loop encodes (start-up and clip preload included)" % len(hips)) if busy else None
+        out["coverage"], out["report"] = _coverage(rp)
+        if rank == 0 and world == 1:
             try:
-                r2 = E.run_app(S.REF_APP, yuv, w, h, frames, hargs, os.path.join(td, "ref_lp.265"), nb=unique)
-                out["reference_same_threads"] = dict(r2, args="-lp %d" % lp, same_bitstream_as_default_threading=r2["md5"] == ref_md5)
-                h2 = E.run_app(E.HIP_APP, yuv, w, h, frames, list(args), os.path.join(td, "hip_all.265"), env=env, nb=unique)
-                out["hip_default_threads"] = dict(h2, threads=ncpu, bitstream_identical=h2["md5"] == ref_md5)
+                if lp < ncpu:
+                    r2 = _median_run([E.run_app(S.REF_APP, yuv, w, h, frames, hargs, os.path.join(td, "ref_lp.265"), nb=unique) for _ in range(RUNS)])
+                    out["reference_same_threads"] = dict(r2, args="-lp %d" % lp, same_bitstream_as_default_threading=r2["md5"] == ref_md5)
+                # the other configurations of the same encode, one run each
+                side = {}
+                for tag, e2, a2 in (("front_half_only", {k: v for k, v in env.items() if k not in ("SVT_HOOK_MD", "SVT_HOOK_PCS_POOL")}, hargs),
+                                    ("closed_loop_i_pictures_on_device", dict(env, SVT_HOOK_MD="1"), hargs),
+                                    ("closed_loop_default_threads", env, list(args))):
+                    try:
+                        r = E.run_app(E.HIP_APP, yuv, w, h, frames, a2, os.path.join(td, "side.265"), env=e2, nb=unique)
+                        side[tag] = {"fps": r["fps"], "bitstream_identical": r["md5"] == ref_md5}
+                    except Exception as e:
+                        side[tag] = {"error": str(e)[-300:]}
+                side["front_half_only"]["what"] = "no SVT_HOOK_MD: motion estimation + open-loop intra search on the device, the reference's own EncDec on the host threads (`value` of rounds 3-4)"
+                side["closed_loop_i_pictures_on_device"]["what"] = "SVT_HOOK_MD=1: the I pictures decided and encoded by the device call as well (a 4K closed-loop I picture takes it ~0.45 s along its wavefront)"
+                out["other_configurations"] = side
             except Exception as e:
                 out["reference_same_threads"] = {"error": str(e)[-300:]}
-        ok = bool(hip.get("md5")) and hip["md5"] == ref_md5
+        ok = all(bool(r.get("md5")) and r["md5"] == ref_md5 for r in hips)
         secs = frames / hip["fps"] if hip.get("fps") else float("inf")
         if world > 1:
             import torch.distributed as dist
             t = torch.tensor([secs if ok else float("inf")], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             secs = float(t.item())
+        elif not ok:
+            secs = float("inf")
         out["hip"] = hip
         out["bitstream_identical"] = secs != float("inf")
         out["value"] = round(world * frames / secs, 2) if secs != float("inf") else 0.0
@@ -188,40 +278,6 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
             if out.get("reference_same_threads", {}).get("fps"):
                 out["hip_over_reference_same_threads"] = round(hip["fps"] / out["reference_same_threads"]["fps"], 3)
         return out
-    finally:
-        shutil.rmtree(td, ignore_errors=True)
-
-
-def closed_loop_leg(enc_cfg, enc, frames=160):
-    """the hooked encoder with SVT_HOOK_MD=1 on the clip of `value` (fewer pictures): fps, md5 against the reference's bitstream of the same
-    `frames` pictures, and the binding's own report of what ran where"""
-    import encoder_fps as E
-    w, h, depth, args = E.CONFIGS[enc_cfg]
-    args = list(args) + ["-asm", "1"]
-    unique = 16
-    td = tempfile.mkdtemp(prefix="svtenc_md_", dir="/tmp")
-    try:
-        yuv = os.path.join(td, "clip.yuv")
-        (S.write_clip10_compressed if depth == 10 else S.write_clip)(yuv, "motion", w, h, unique, 7)
-        ref = E.run_app(S.REF_APP, yuv, w, h, frames, args, os.path.join(td, "ref.265"), nb=unique)
-        rp = os.path.join(td, "report.txt")
-        lp = min(HIP_LP, os.cpu_count() or 1)
-        ref_lp = E.run_app(S.REF_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "ref_lp.265"), nb=unique)
-        hip = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip.265"), env={"SVT_HOOK_MD": "1", "SVT_HOOK_REPORT": rp}, nb=unique)
-        # ... and with the I pictures left to the reference code: a 4K I picture's closed-loop decision (85 leaves x 35 candidates per LCU along the same wavefront) takes the
-        # device 0.45 s and every other picture waits for it
-        hip_pb = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", str(lp)], os.path.join(td, "hip_pb.265"), env={"SVT_HOOK_MD": "pb"}, nb=unique)
-        lines = [l.strip() for l in open(rp) if "mode decision" in l] if os.path.exists(rp) else []
-        import re
-        m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\).*?; (\d+) pictures outside", " ".join(lines))
-        cover = {"pictures_on_device": int(m.group(1)), "p_b_pictures_on_device": int(m.group(2)), "pictures_left_to_the_reference_code": int(m.group(4))} if m else None
-        return {"switches": {"SVT_HOOK_MD": "1"}, "frames": frames, "fps": hip["fps"], "reference_fps": ref["fps"], "reference_fps_same_threads": ref_lp["fps"],
-                "threads": "-lp %d" % lp, "bitstream_identical": hip["md5"] == ref["md5"], "coverage": cover, "report": lines,
-                "fps_p_b_pictures_only": hip_pb["fps"], "p_b_only_bitstream_identical": hip_pb["md5"] == ref["md5"],
-                "what": "motion estimation + open-loop intra search + mode decision + merge / skip decisions + encode pass of the I picture and of every open-loop P / B picture "
-                        "(temporal layers 1 and 2 of BASELINE configs[2]: CHROMA_MODE_FULL reference B pictures and non-reference B pictures) on the device, ONE call per "
-                        "picture; the base-layer B pictures (closed-loop intra, branch-and-depth-pillar LCUs) are the reference code's.  Not `value`: a device-decided "
-                        "picture stays 55 - 105 ms in the encoder's EncDec pool of max(4, lp / 6) pictures, longer than a host-decided one (DESIGN 3.11 / 5d)"}
     finally:
         shutil.rmtree(td, ignore_errors=True)
 
@@ -253,6 +309,42 @@ def md_kernel_leg(w, h):
     return out
 
 
+def md_kernel_pmc():
+    """HBM traffic of k_md_encode_picture, measured: tools/md_bench.py (the three open-loop B pictures of a 5-picture 4K encode, one call each + warm-up) under rocprofv3
+    --pmc FETCH_SIZE and, in a separate pass, WRITE_SIZE (the TCC block cannot hold both; KiB units; FETCH_SIZE doubled on gfx950 - MI355X_MICROARCH.md "HBM"), per
+    launch; the same rows carry the kernel's register / LDS / private-segment sizes."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out, meta = {}, None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="svtpmc_md_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", MD_BENCH_PICTURES="all", MD_BENCH_CLIP="motion")
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", td, "--", sys.executable, os.path.join(ROOT, "tools", "md_bench.py"),
+                                "3840", "2160", "7", "1", "inter", "5"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+            total, n = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if "k_md_encode_picture" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        total += float(row["Counter_Value"])
+                        n += 1
+                        meta = {"vgpr": int(row["VGPR_Count"]), "agpr": int(row.get("Accum_VGPR_Count") or 0), "sgpr": int(row["SGPR_Count"]),
+                                "lds_bytes_per_workgroup": int(row["LDS_Block_Size"]), "scratch_bytes_per_lane": int(row["Scratch_Size"])}
+            if not n:
+                return None, "no k_md_encode_picture dispatch in the %s pass" % counter
+            out[counter] = total * 1024.0 / n
+            out[counter + "_dispatches"] = n
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return dict({"fetch_bytes_raw": int(out["FETCH_SIZE"]), "write_bytes_raw": int(out["WRITE_SIZE"]), "fetch_bytes_corrected": int(2 * out["FETCH_SIZE"]),
+                 "per": "launch of k_md_encode_picture (mean over the %d dispatches of tools/md_bench.py: layer-1 and layer-2 B pictures)" % out["FETCH_SIZE_dispatches"]},
+                **(meta or {})), None
+
+
 def cpu_baseline_encoder(cfg, enc):
     """The reference encoder itself on this host's cores (AVX2 tables): the same clip and command line as `value` (timed by
     encoded_fps_leg), plus a bounded single-thread run (-lp 1) for the per-core figure SURVEY 8d asks for."""
@@ -260,13 +352,17 @@ def cpu_baseline_encoder(cfg, enc):
     if not enc or "reference" not in enc or not enc["reference"].get("fps"):
         raise RuntimeError("reference encoder run missing")
     w, h, depth, args = E.CONFIGS[cfg["enc"]]
-    out = {"value": enc["reference"]["fps"], "unit": "fps", "cores": os.cpu_count(), "kind": "reference",
-           "best_threading": ({"fps": enc["reference_same_threads"]["fps"], "args": enc["reference_same_threads"]["args"],
-                               "what": "the same reference run with the -lp the hooked encoder uses: the reference is faster with fewer threads than this "
-                                       "host has (profiles/r03_ab_fps_threads.txt)"} if enc.get("reference_same_threads", {}).get("fps") else None),
-           "sample": "%d %dx%d pictures (%d unique, looped), oracle/_ref/SvtHevcEncApp_ref -asm 1 (the reference compiled in place, AVX2 "
-                     "tables), default threading on all %d host threads, same command line as `value`: %s" %
-                     (enc["frames"], w, h, enc["unique_frames"], os.cpu_count(), enc["args"])}
+    best = enc.get("reference_same_threads", {})
+    sample = ("%d %dx%d pictures (%d unique, looped), oracle/_ref/SvtHevcEncApp_ref -asm 1 (the reference compiled in place, AVX2 tables), same command line as `value`: %s" %
+              (enc["frames"], w, h, enc["unique_frames"], enc["args"]))
+    if best.get("fps"):   # the reference at its best threading on these hosts (the -lp the hooked encoder runs with): the fair pair of `value`
+        out = {"value": best["fps"], "unit": "fps", "cores": enc["hip_threads"], "kind": "reference", "runs": best.get("fps_runs"),
+               "sample": sample + " " + best["args"] + ", median of %d encodes" % len(best.get("fps_runs") or [1]),
+               "default_threading": {"fps": enc["reference"]["fps"], "cores": os.cpu_count(),
+                                     "what": "the same run without -lp (all %d host threads): slower than with 32 - the reference's pipeline loses to its own thread count "
+                                             "(profiles/r03_ab_fps_threads.txt)" % os.cpu_count()}}
+    else:
+        out = {"value": enc["reference"]["fps"], "unit": "fps", "cores": os.cpu_count(), "kind": "reference", "sample": sample + ", default threading"}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         yuv = os.path.join(td, "c.yuv")
         (S.write_clip10_compressed if depth == 10 else S.write_clip)(yuv, "motion", w, h, 5, 7)
@@ -616,20 +712,20 @@ def main():
             "metric": "encoded fps, %s, bitstream md5-identical to the unmodified reference (BASELINE.json metric; whole encoder with the "
                       "HIP path bound in, application's Average Speed)" % cfg["name"],
             "value": value if value is not None else 0.0, "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(8e3 / value, 4) if value else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(8e3 / value, 4) if value else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "vs_cpu_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": cfg["name"] + ": whole encode of %s pictures (one step = 8 pictures), command line of BASELINE.md section 2" %
                                    (enc["frames"] if enc and "frames" in enc else "n/a"),
                        "width": W, "height": H, "mpix_per_s": round(value * W * H / 1e6, 1) if value else None,
                        "switches": enc.get("switches") if enc else None,
-                       "host_threads_of_the_encoder": ("-lp %d (of %d on this host); the reference's fps at default threading and at the same -lp are in "
-                                                       "encoder_fps / cpu_baseline" % (enc["hip_threads"], os.cpu_count())) if enc and enc.get("hip_threads") else None,
-                       "on_device": (["Decimation2D / GeneratePadding / half-pel planes (k_prep_fused)", "HME level 0 / 1, full-pel 85-PU search, sub-pel refinement, "
-                                      "bi-prediction search, MeCuResults (k_me<0>, k_me<1>)", "OpenLoopIntraSearchLcu (k_ois_picture)"] +
-                                     (["ModeDecisionLcu + EncodePass of the I picture and every open-loop P / B picture (k_md_encode_picture)"]
-                                      if os.environ.get("SVT_HOOK_MD") else [])) if enc else None,
-                       "on_host_in_this_run": ("EncDec (mode decision, encode pass, in-loop filters): the reference's own code; `closed_loop_on_device` is the same encode "
-                                               "with it on the device") if enc and not os.environ.get("SVT_HOOK_MD") else None,
+                       "host_threads_of_the_encoder": ("-lp %d (of %d on this host); the reference's fps at the same -lp (its best) and at default threading are in "
+                                                       "cpu_baseline / encoder_fps" % (enc["hip_threads"], os.cpu_count())) if enc and enc.get("hip_threads") else None,
+                       "on_device": ["Decimation2D / GeneratePadding / half-pel planes (k_prep_fused)", "HME level 0 / 1, full-pel 85-PU search, sub-pel refinement, "
+                                     "bi-prediction search, MeCuResults (k_me<0>, k_me<1>)", "OpenLoopIntraSearchLcu (k_ois_picture)",
+                                     "ModeDecisionLcu + merge / skip decisions (AddChromaEncDec) + EncodePass of every open-loop P / B picture - temporal layers 1 and 2 "
+                                     "(k_md_encode_picture, one launch per picture): %s" % (enc.get("coverage") if enc else None)] if enc else None,
+                       "on_host_in_this_run": ("EncDec of the I pictures and of the base-layer P / B pictures (closed-loop intra + branch-and-depth-pillar LCUs: the reference's "
+                                               "code, DESIGN 7) with their deblocking + SAO, entropy coding, picture management") if enc else None,
                        "parallelism": "one encoder per rank on its own GPU, no data-path collective" if world > 1 else "1 GPU"},
             "encoder_fps": enc,
             "front_half": {"what": "upload + picture preparation + open-loop motion estimation of %d LCUs against %d list(s) (HME L0 %dx%d + L1, "
@@ -670,16 +766,19 @@ def main():
                 res["cpu_baseline"]["front_half_one_core"] = cpu_baseline_reference(cfg)
             except Exception as e:  # the reference build is absent: say so, do not substitute
                 res["cpu_baseline"] = {"error": str(e)[-300:]}
-        if world == 1 and not a.no_encoder_fps and enc and enc.get("reference", {}).get("md5"):
-            # the closed loop on the device, measured beside `value` (not part of it): the same encode with SVT_HOOK_MD=pb - mode decision + encode pass of
-            # every non-reference P / B picture as ONE device call each, everything else as in `value`
-            try:
-                res["closed_loop_on_device"] = closed_loop_leg(cfg["enc"], enc)
-            except Exception as e:
-                res["closed_loop_on_device"] = {"error": str(e)[-300:]}
+        if res.get("cpu_baseline", {}).get("value") and value:
+            res["vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 3)
         if world == 1 and not a.no_encode_pass and os.path.exists(S.REF_APP):
             try:
                 res["roofline_md"] = md_kernel_leg(W, H)
+                if not a.no_pmc:
+                    tr, err = md_kernel_pmc()
+                    if tr:
+                        res["roofline_md"]["traffic"] = tr["fetch_bytes_corrected"] + tr["write_bytes_raw"]
+                        res["roofline_md"]["traffic_detail"] = tr
+                        res["roofline_md"]["lds_bytes_per_workgroup"] = tr.get("lds_bytes_per_workgroup")
+                    else:
+                        res["roofline_md"]["traffic_error"] = err
             except Exception as e:
                 res["roofline_md"] = {"error": str(e)[-300:]}
         if world == 1 and not a.no_encode_pass:

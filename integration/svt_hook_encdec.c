@@ -1138,6 +1138,14 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
         __atomic_add_fetch(&g_md_inter_pictures, 1, __ATOMIC_RELAXED);
     }
     e->md_ok = 1;
+    {
+        /* the call has returned: no kernel reads this picture's reference pictures any more (its LCUs are served from the records), so their cache slots are free to be
+         * recycled NOW - not when this PictureControlSet_t object meets its next picture (idle objects of a large pool kept up to two references pinned each and
+         * the cache grew instead of evicting) */
+        const int pins[2] = {e->ref_pins_plus1[0] - 1, e->ref_pins_plus1[1] - 1};
+        svt_hook_release_references(pins);
+        e->ref_pins_plus1[0] = e->ref_pins_plus1[1] = 0;
+    }
     if (!inter)
         t_dev = md_now() - t_c0;
     svt_hook_timeline("md_fill", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_in, t_p0);

@@ -508,8 +508,17 @@ static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
     const uint16_t mh = (uint16_t)((lumaHeight + 7) & ~7);
     SvtAmdContext *ctx = NULL;
     const char *step = "svt_amd_context_create";
-    if (!getenv("SVT_HOOK_KEEP_RUNTIME_ENV")) /* the encoder keeps up to NLANES + EP_LANES streams busy: a hardware queue each (the library's opt-in) */
+    /* the encoder keeps up to NLANES + EP_LANES streams busy: a hardware queue each (the library's opt-in).  The setting changes the process
+     * environment, so it belongs to EbInitEncoder time only - before the encoder's threads exist (setenv racing another thread's getenv is undefined) and before the
+     * process's first HIP call (it has no effect afterwards).  Under SVT_HOOK_LAZY_INIT this function runs on a kernel thread: the environment is left alone and the
+     * consequence is said out loud. */
+    if (getenv("SVT_HOOK_LAZY_INIT")) {
+        if (!getenv("GPU_MAX_HW_QUEUES"))
+            fprintf(stderr, "svt_hook_me: SVT_HOOK_LAZY_INIT: GPU_MAX_HW_QUEUES is not set and cannot be set from a worker thread - the lanes' streams share the runtime's "
+                            "default of 4 hardware queues (pictures in flight on the device will serialise; set GPU_MAX_HW_QUEUES=24 in the environment)\n");
+    } else if (!getenv("SVT_HOOK_KEEP_RUNTIME_ENV")) {
         (void)svt_amd_runtime_env_defaults();
+    }
     int rc = svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &ctx);
     for (int i = 0; i < NLANES && !rc; i++)
         step = "svt_amd_context_fork", rc = svt_amd_context_fork(ctx, &g_front[i].lane);
@@ -1432,8 +1441,14 @@ void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t
     for (int i = 0; i < REF_CACHE && !victim; i++)
         if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0] && !g_refs[i].pins) /* (a pinned copy of this very buffer + POC is what it was: keep it) */
             victim = &g_refs[i];
-    if (!victim)
+    if (!victim) {
+        /* a PINNED copy of this very buffer + POC (somebody still reads it) is superseded: it keeps its memory until its users let go, but no later lookup may match it
+         * - the fresh copy below is the one */
+        for (int i = 0; i < REF_CACHE; i++)
+            if (g_refs[i].buf == p->bufferY && g_refs[i].poc == poc && g_refs[i].d[0])
+                g_refs[i].buf = NULL;
         victim = ref_victim();
+    }
     const uint32_t rowsY = p->height + 2 * p->originY, rowsC = rowsY >> 1;
     const size_t need[3] = {(size_t)rowsY * p->strideY * bps, (size_t)rowsC * p->strideCb * bps, (size_t)rowsC * p->strideCr * bps};
     const void *src[3] = {dev->d_y, dev->d_cb, dev->d_cr};

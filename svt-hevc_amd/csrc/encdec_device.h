@@ -49,7 +49,23 @@ struct SvtAmdEncDecPicture {
     size_t refp_bytes[3];
     /* the mode decision's part (md_kernels.hip): neighbour maps, source planes, per-LCU arrays; allocated by the first svt_amd_md_encode_picture */
     struct SvtAmdMdState *md;
+    /* recorded behind every picture-level call that writes the picture's stages (encode pass, mode decision + encode pass, deblocking, SAO, an exchange that fills it):
+     * a reader on another context's stream - svt_amd_encdec_picture_import - orders itself behind it; `written`: the object holds an encoded picture at all */
+    hipEvent_t ev_written;
+    bool written;
 };
+/* the picture's stages are (being) written by work queued on ctx's stream */
+static inline int ep_picture_written(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic)
+{
+    if (!pic->ev_written && hipEventCreateWithFlags(&pic->ev_written, hipEventDisableTiming) != hipSuccess) {
+        pic->ev_written = nullptr;
+        return SVT_AMD_ERR_RESOURCES;
+    }
+    if (hipEventRecord(pic->ev_written, ctx->stream) != hipSuccess)
+        return SVT_AMD_ERR_DEVICE;
+    pic->written = true;
+    return SVT_AMD_OK;
+}
 void svt_amd_md_state_free(SvtAmdEncDecPicture *pic); /* md_kernels.hip */
 
 typedef SvtAmdLcuCu LcuCu;

@@ -187,6 +187,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
     if (pic->d_cost)
         (void)hipFree(pic->d_cost);
     svt_amd_md_state_free(pic);
+    if (pic->ev_written)
+        (void)hipEventDestroy(pic->ev_written);
     for (int k = 0; k < 3; k++) {
         if (pic->dbk[k])
             (void)hipFree(pic->dbk[k]);
@@ -289,6 +291,8 @@ static int encode_lcus(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     HIP_TRY(hipMemcpyAsync(d, works, wb, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_encode_lcu<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const WorkT *)d, (ResultT *)(d + wba));
     HIP_TRY(hipGetLastError());
+    if ((rc = ep_picture_written(ctx, pic)) != 0)
+        return rc;
     HIP_TRY(hipMemcpyAsync(results, d + wba, rb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
@@ -390,6 +394,11 @@ static int encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const ty
     grid = grid > n_active ? n_active : grid > 512 ? 512 : grid;
     hipLaunchKernelGGL(k_encode_picture<T>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, d_works, d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
+    {
+        const int rcw = ep_picture_written(ctx, pic);
+        if (rcw)
+            return rcw;
+    }
     if (results)
         HIP_TRY(hipMemcpyAsync(results, d_results, sizeof(ResultT) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     return SVT_AMD_OK;
@@ -512,23 +521,33 @@ extern "C" int svt_amd_encdec_picture_broadcast(SvtAmdContext *ctx, SvtAmdEncDec
     uint8_t *const *stage = rank != root ? pic->fin : pic->sao_done ? pic->fin : pic->deblocked ? pic->dbk : pic->d.rec;
     void *planes[3] = {stage[0], stage[1], stage[2]};
     rc = svt_amd_recon_broadcast(ctx, planes, pic->plane_bytes, world, rank, root);
-    if (rc == SVT_AMD_OK && rank != root)
+    if (rc == SVT_AMD_OK && rank != root) { /* the receiver's object now holds the root's finished picture: nothing of its own earlier picture is valid any more */
         pic->deblocked = pic->sao_done = true;
+        pic->epoch++;
+        rc = ep_picture_written(ctx, pic);
+    }
     return rc;
 }
 extern "C" int svt_amd_encdec_picture_import(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdEncDecPicture *from)
 {
     if (!ctx || !pic || !from || pic == from || pic->d.width != from->d.width || pic->d.height != from->d.height || pic->d.bps != from->d.bps)
         return SVT_AMD_ERR_BAD_PARAM;
+    if (!from->written || !from->ev_written) {
+        svt_amd_set_error("svt_amd_encdec_picture_import: the source object holds no encoded picture");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
     HIP_TRY(hipSetDevice(ctx->device));
-    const int rc = final_stage_planes(pic);
+    int rc = final_stage_planes(pic);
     if (rc)
         return rc;
+    /* behind whatever the owner's stream still has queued on the source picture (its encode pass / filters run on another context, possibly another device) */
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, from->ev_written, 0));
     uint8_t *const *stage = from->sao_done ? from->fin : from->deblocked ? from->dbk : from->d.rec;
-    for (int p = 0; p < 3; p++)
-        HIP_TRY(hipMemcpyAsync(pic->fin[p], stage[p], pic->plane_bytes[p], hipMemcpyDeviceToDevice, ctx->stream));
+    for (int p = 0; p < 3; p++) /* hipMemcpyDefault: the source may live on a peer device */
+        HIP_TRY(hipMemcpyAsync(pic->fin[p], stage[p], pic->plane_bytes[p], hipMemcpyDefault, ctx->stream));
     pic->deblocked = pic->sao_done = true;
-    return SVT_AMD_OK;
+    pic->epoch++; /* the per-LCU completion marks of the receiver's own earlier picture do not describe this one */
+    return ep_picture_written(ctx, pic);
 }
 extern "C" int svt_amd_encdec_picture_pack(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdRect *rects, int world, int r, void *d_slots,
                                            size_t slot_bytes, int to_slot)
@@ -636,6 +655,8 @@ static int picture_deblock(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const t
                                   d_qp, w8, prm->tc_offset, prm->beta_offset, prm->cb_qp_offset, prm->cr_qp_offset)) != 0)
         return rc;
     pic->deblocked = true;
+    if ((rc = ep_picture_written(ctx, pic)) != 0)
+        return rc;
     void *outs[3] = {out_y, out_cb, out_cr};
     for (int k = 0; k < 3; k++)
         if (outs[k]) {
@@ -775,7 +796,7 @@ static int picture_sao(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
         }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     pic->sao_done = pic->sao_done || apply;
-    return SVT_AMD_OK;
+    return ep_picture_written(ctx, pic);
 }
 
 /* PadRefAndSetFlags (Codec/EbEncDecProcess.c:1805; GeneratePadding / GeneratePadding16Bit): the finished picture inside a frame of

@@ -2017,6 +2017,8 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
                            (SvtAmdLcuResult16 *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev_k1, st));
+    if ((rc = ep_picture_written(ctx, pic)) != 0)
+        return rc;
     {   /* records read in place: the next motion-estimation / open-loop intra launch INTO those slots orders itself behind this kernel (context.hip slot_records_before_write) */
         SvtAmdContext *root = ctx->parent ? ctx->parent : ctx;
         const int rs[2] = {d_me_slot ? me_slot : -1, d_ois_slot ? ois_slot : -1};

@@ -65,6 +65,12 @@ def run(lib, g, reps=5, check=True):
         calls = float(pr[:, 15].sum()) / n
         stages = {nm: round(float(tot[i]) / n / calls, 0) for i, nm in enumerate(names)}   # shader clocks per LCU per call
         stages["sum_without_wait"] = round(float(tot[:12].sum()) / n / calls, 0)
+        stages["units_tested_per_lcu"] = round(float(pr[:, 14].sum()) / n / calls, 2)
+        stages["fast_loop_candidates_per_unit"] = round(float(pr[:, 13].sum()) / max(1.0, float(pr[:, 14].sum())), 2)
+        sub = np.zeros((n, 16), np.uint64)
+        lib.svt_amd_debug_md_profile_sub.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if lib.svt_amd_debug_md_profile_sub(ctx, pic, sub.ctypes.data) == 0:   # the finer marks (MD_SUB), shader clocks per tested unit
+            stages["sub_stage_clocks_per_unit"] = [round(float(v) / max(1.0, float(pr[:, 14].sum())), 0) for v in sub.sum(axis=0)]
     if check:
         compare_md(out, g["out"], "%dx%d" % (w, h))
     lib.svt_amd_encdec_picture_destroy(ctx, pic)
