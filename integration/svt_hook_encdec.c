@@ -695,6 +695,20 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
             if (!f->md_ok && !g_ep_own) { /* SVT_HOOK_MD alone, a picture outside the device's mode decision: the reference code's, EncodePass included */
                 __atomic_add_fetch(&g_ep_cpu_units, 1, __ATOMIC_RELAXED);
                 __real_EncodePass(scs, pcs, lcuPtr, tbAddr, lcuOriginX, lcuOriginY, lcuQp, enableSaoFlag, contextPtr);
+                if (svt_hook_timeline_enabled()) { /* the host's own pictures on the same time line: first counted LCU .. last LCU through EncodePass (the first LCUs of a
+                                                     * picture whose leading LCUs take the BDP path pass before the picture's entry exists and are not counted) */
+                    svt_hook_lock(&f->lock);
+                    if (f->tl_lcus == 0)
+                        f->tl_first = svt_hook_now();
+                    f->tl_lcus++;
+                    const double first = f->tl_first;
+                    const int last = tbAddr + 1 == (EB_U32)f->cap;
+                    if (last)
+                        f->tl_lcus = 0;
+                    svt_hook_unlock(&f->lock);
+                    if (last)
+                        svt_hook_timeline("encodepass", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, first, svt_hook_now());
+                }
                 return;
             }
         }

@@ -1951,7 +1951,38 @@ static void *kernel_thread(void *(*real)(void *), void *arg)
     return r;
 }
 void *__wrap_MotionEstimationKernel(void *inputPtr) { return kernel_thread(__real_MotionEstimationKernel, inputPtr); }
-void *__wrap_EncDecKernel(void *inputPtr) { return kernel_thread(__real_EncDecKernel, inputPtr); }
+static __thread int t_encdec_thread; /* SVT_HOOK_TIMELINE: GeneratePadding calls of EncDec threads are PadRefAndSetFlags's (the picture-analysis threads pad input pictures) */
+void *__wrap_EncDecKernel(void *inputPtr)
+{
+    t_encdec_thread = 1;
+    return kernel_thread(__real_EncDecKernel, inputPtr);
+}
+
+/* SVT_HOOK_TIMELINE only: what lies between a reference picture's last LCU and the next picture's first on the host - the tail EncDecKernel runs on ONE thread
+ * (ApplySaoOffsetsPicture, then PadRefAndSetFlags = three GeneratePadding calls, Codec/EbEncDecProcess.c:3081-3109) and the first LCU of every picture
+ * (ModeDecisionConfigureLcu of LCU 0).  Pass-throughs otherwise. */
+void __real_GeneratePadding(EB_BYTE srcPic, EB_U32 srcStride, EB_U32 originalSrcWidth, EB_U32 originalSrcHeight, EB_U32 paddingWidth, EB_U32 paddingHeight);
+void __wrap_GeneratePadding(EB_BYTE srcPic, EB_U32 srcStride, EB_U32 originalSrcWidth, EB_U32 originalSrcHeight, EB_U32 paddingWidth, EB_U32 paddingHeight)
+{
+    if (!t_encdec_thread || !svt_hook_timeline_enabled()) {
+        __real_GeneratePadding(srcPic, srcStride, originalSrcWidth, originalSrcHeight, paddingWidth, paddingHeight);
+        return;
+    }
+    const double t0 = svt_hook_now();
+    __real_GeneratePadding(srcPic, srcStride, originalSrcWidth, originalSrcHeight, paddingWidth, paddingHeight);
+    svt_hook_timeline("refpad", 0, (int)originalSrcWidth, (int)originalSrcHeight, t0, svt_hook_now());
+}
+void __real_ModeDecisionConfigureLcu(ModeDecisionContext_t *contextPtr, LargestCodingUnit_t *lcuPtr, PictureControlSet_t *pcs, SequenceControlSet_t *scs, EB_U8 pictureQp,
+                                     EB_U8 lcuQp);
+void __wrap_ModeDecisionConfigureLcu(ModeDecisionContext_t *contextPtr, LargestCodingUnit_t *lcuPtr, PictureControlSet_t *pcs, SequenceControlSet_t *scs, EB_U8 pictureQp,
+                                     EB_U8 lcuQp)
+{
+    if (lcuPtr->index == 0 && svt_hook_timeline_enabled()) {
+        const double t = svt_hook_now();
+        svt_hook_timeline("lcu0", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t, t);
+    }
+    __real_ModeDecisionConfigureLcu(contextPtr, lcuPtr, pcs, scs, pictureQp, lcuQp);
+}
 
 static void hook_report(void)
 {

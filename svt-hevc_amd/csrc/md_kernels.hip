@@ -1729,57 +1729,69 @@ static int msb_view(hipStream_t st, const void *in16, uint8_t *out8, size_t samp
     return SVT_AMD_OK;
 }
 
-/* How many k_md_encode_picture launches may be on the device at a time.  A workgroup of this kernel holds a whole CU (its LDS) for the life of the launch, most of it
- * waiting for neighbours: six pictures' launches of 40 workgroups fill a 256-CU part, and whatever else the encoder needs meanwhile - the next pictures' motion
- * estimation and open-loop intra search, picture preparation, the runtime's copy kernels - then waits for a mode-decision launch to END (profiles/r05_a: with 12 - 16
- * pictures in the encoder's pool the closed loop fell from 57 to 25 fps, launches starting in bursts exactly when others finished).  The limit keeps about a fifth of the
- * CUs free: (CUs - CUs / 16) / workgroups per launch = 6 at 4K on an MI355X (profiles/r05_b: 4 / 5 / 6 / unlimited = 61.8 / 69.7 / 71.6 / 54.0 fps); SVT_AMD_MD_MAX_KERNELS overrides it.  A call waits for a free place AFTER its inputs are
- * on the device and gives it back when its kernel has finished, before its records travel back. */
+/* How much of the device the k_md_encode_picture launches in flight may hold.  A workgroup of this kernel holds a whole CU (its LDS) for the life of the launch, most of it
+ * waiting for neighbours: whatever else the encoder needs meanwhile - the next pictures' motion estimation and open-loop intra search, picture preparation, the runtime's
+ * copy and fill kernels - waits for a mode-decision launch to END once they fill the part (profiles/r05_a: with 12 - 16 pictures in the encoder's pool the closed loop
+ * fell from 57 to 25 fps, launches starting in bursts exactly when others finished).  The launches therefore share a BUDGET of workgroups = CUs - CUs / 16 (240 on an
+ * MI355X): a call waits for its grid to fit AFTER its inputs are on the device (lowest temporal layer first among the waiters, then first come) and gives the workgroups
+ * back when its kernel has finished, before its records travel back.
+ * How wide a launch is decides how many pictures share the device: the wavefront of a 4K picture is 30 LCUs wide at its widest and 16 on average; 40 workgroups (the
+ * widest front + the encode passes behind it) give a lone picture its shortest kernel (51.5 ms for a layer-2 picture), 20 cost it 9 % (56.0 ms) and let twelve pictures
+ * run side by side - 148 instead of 96 pictures/s of device capacity (profiles/r05_k_md_flights_24q.txt), 93 - 96 instead of 79 fps of encode (r05_k_sweep_grid2.txt).
+ * A call therefore takes the wide grid only while the device is nearly idle (at most a third of the budget in use and nobody waiting) and the narrow one (half) otherwise.
+ * SVT_AMD_MD_MAX_KERNELS=<n> forces a plain count limit instead, SVT_AMD_MD_GRID=<n> a fixed width (measurement). */
 namespace {
 std::mutex g_flight_mu;
 std::condition_variable g_flight_cv;
-int g_flights;
+int g_flights, g_flight_wgs;
 unsigned long long g_flight_ticket;
 struct FlightWaiter { int prio; unsigned long long ticket; };
 std::vector<FlightWaiter> g_flight_wait;
-int md_flight_limit(int device, int grid)
+int md_forced_count_limit()
 {
     static const int forced = getenv("SVT_AMD_MD_MAX_KERNELS") ? atoi(getenv("SVT_AMD_MD_MAX_KERNELS")) : 0;
-    if (forced > 0)
-        return forced;
+    return forced;
+}
+int md_wg_budget(int device)
+{
     static int cus[64];
     if (!cus[device & 63]) {
         hipDeviceProp_t pr;
         cus[device & 63] = hipGetDeviceProperties(&pr, device) == hipSuccess ? pr.multiProcessorCount : 256;
     }
-    const int c = cus[device & 63], n = (c - c / 16) / (grid > 0 ? grid : 1);
-    return n < 1 ? 1 : n;
+    const int c = cus[device & 63];
+    return c - c / 16;
 }
-/* a place among the launches on the device; among the calls that wait, the one of the lowest temporal layer goes first (the pictures other pictures wait for), then the
- * one that came first */
 struct MdFlight {
-    bool held = false;
-    void acquire(int limit, int prio)
+    int held = 0; /* workgroups this call holds */
+    /* waits until the launch fits; returns the grid granted: `wide` when the device is nearly idle, `narrow` otherwise */
+    int acquire(int budget, int wide, int narrow, int prio)
     {
         std::unique_lock<std::mutex> l(g_flight_mu);
         const FlightWaiter me = {prio, g_flight_ticket++};
         g_flight_wait.push_back(me);
+        const int count_limit = md_forced_count_limit();
+        int grant = 0;
         g_flight_cv.wait(l, [&] {
-            if (g_flights >= limit)
-                return false;
             for (const FlightWaiter &w : g_flight_wait)
                 if (w.prio < me.prio || (w.prio == me.prio && w.ticket < me.ticket))
                     return false;
-            return true;
+            if (count_limit > 0) {
+                grant = wide;
+                return g_flights < count_limit;
+            }
+            grant = (g_flight_wait.size() == 1 && g_flight_wgs + wide <= budget / 3) ? wide : narrow;
+            return g_flight_wgs + grant <= budget || g_flights == 0;
         });
         for (size_t i = 0; i < g_flight_wait.size(); i++)
             if (g_flight_wait[i].ticket == me.ticket) {
                 g_flight_wait.erase(g_flight_wait.begin() + (long)i);
                 break;
             }
-        g_flights++, held = true;
+        g_flights++, g_flight_wgs += grant, held = grant;
         l.unlock();
         g_flight_cv.notify_all(); /* the next in line may fit as well */
+        return grant;
     }
     void release()
     {
@@ -1787,9 +1799,9 @@ struct MdFlight {
             return;
         {
             std::lock_guard<std::mutex> l(g_flight_mu);
-            g_flights--;
+            g_flights--, g_flight_wgs -= held;
         }
-        held = false;
+        held = 0;
         g_flight_cv.notify_all();
     }
     ~MdFlight() { release(); }
@@ -1986,22 +1998,20 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
      * passes behind it costs a lone picture 3 - 4 % and lets six pictures' launches run side by side (profiles/r04_w_md_flights_*: the kernel keeps its 51 ms with
      * twelve calls in flight, 100 pictures/s - given enough hardware queues, svt_amd_runtime_env_defaults). */
     int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2 + (wl + 7) / 8;
-    {   /* debug (SVT_AMD_MD_GRID): workgroups of the launch - how many a picture really needs decides how many pictures share the GPU */
+    int narrow = (grid + 1) / 2 < 8 ? 8 : (grid + 1) / 2; /* what the launch gets while other pictures share the device (MdFlight) */
+    {   /* measurement (SVT_AMD_MD_GRID): a fixed launch width */
         const char *fg = getenv("SVT_AMD_MD_GRID");
         const int forced = fg ? atoi(fg) : 0;
         if (forced > 0)
-            grid = forced;
+            grid = narrow = forced;
     }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
-    m->grid = grid;
+    narrow = narrow > grid ? grid : narrow;
     MdFlight flight;
-    {
-        const int limit = md_flight_limit(ctx->device, grid);
-        if (limit < 64) { /* the inputs first (a call that waits for a place holds no CU and no copy engine meanwhile) */
-            HIP_TRY(hipStreamSynchronize(st));
-            flight.acquire(limit, (int)P->temporal_layer);
-        }
-    }
+    /* the inputs first (a call that waits for its place holds no CU and no copy engine meanwhile) */
+    HIP_TRY(hipStreamSynchronize(st));
+    grid = flight.acquire(md_wg_budget(ctx->device), grid, narrow, (int)P->temporal_layer);
+    m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X && bps == 1)
         hipLaunchKernelGGL((k_md_encode_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true, uint8_t>), st, m->d, pic->d, (SvtAmdLcuWork *)m->d_works,
@@ -2032,7 +2042,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         HIP_TRY(hipStreamSynchronize(st));
         t_kernel = std::chrono::steady_clock::now();
     }
-    if (flight.held) { /* the place is free as soon as the kernel has finished: the records' way back needs no CU */
+    if (flight.held) { /* the workgroups are free as soon as the kernel has finished: the records' way back needs no CU */
         HIP_TRY(hipEventSynchronize(m->ev_k1));
         flight.release();
     }
