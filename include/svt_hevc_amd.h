@@ -1670,6 +1670,8 @@ SVT_AMD_API int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture
 SVT_AMD_API int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
 /* measurement: duration in ms (HIP events on the call's stream) and launch width (workgroups) of the picture object's last mode-decision kernel launch */
 SVT_AMD_API int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms, int *workgroups);
+/* diagnosis: the mode-decision launches that hold (or wait for) workgroups of the device budget right now (md_kernels.hip: MdFlight) */
+SVT_AMD_API int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, int *waiting);
 /* measurement: dynamic LDS bytes a workgroup of k_md_encode_picture<inter, sample bytes> is launched with (the whole LCU state: one workgroup per CU) */
 SVT_AMD_API int svt_amd_debug_md_kernel_lds_bytes(int inter, int bytes_per_sample);
 

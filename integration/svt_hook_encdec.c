@@ -46,7 +46,7 @@
 #include "svt_hook_internal.h"
 #include "svt_md_fill.h"
 
-#define EP_LANES 16    /* device contexts (stream + staging) EncDec threads share: one per picture whose device call is in flight */
+#define EP_LANES 24    /* device contexts (stream + staging) EncDec threads share: one per picture whose device call is in flight */
 #define EP_PICTURES 64 /* pictures in flight (PictureControlSet_t objects of the EncDec pool) */
 
 void __real_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
@@ -644,6 +644,7 @@ void __wrap_AddChromaEncDec(PictureControlSet_t *pictureControlSetPtr, LargestCo
     svt_hook_die("mode decision: EncodePass asks for the merge / skip costs of a unit the device did not decide");
 }
 
+static void watchdog_tick(void); /* SVT_HOOK_WATCHDOG, below */
 void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, LargestCodingUnit_t *lcuPtr, EB_U32 tbAddr, EB_U32 lcuOriginX,
                        EB_U32 lcuOriginY, EB_U32 lcuQp, EB_BOOL enableSaoFlag, EncDecContext_t *contextPtr)
 {
@@ -660,6 +661,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
         return;
     }
     svt_hook_note_callback(scs);
+    watchdog_tick();
     const int wide = contextPtr->is16bit != 0; /* 10-bit encode: 16-bit samples, EncodeLoop16bit */
     {   /* the common case of SVT_HOOK_MD: the picture's device call has returned - answered from its records without a global lock or a device lane (see entry_lookup) */
         EpPictureEntry *f = entry_lookup(scs, pcs, wide);
@@ -966,6 +968,63 @@ EB_ERRORTYPE __wrap_EncodeTuCalcCost(EncDecContext_t *contextPtr, EB_U32 *countN
 
 
 /* ---- SVT_HOOK_MD: ModeDecisionLcu (Codec/EbProductCodingLoop.c:4691) answered from ONE device call per picture -------------------- */
+/* SVT_HOOK_WATCHDOG=<seconds>: a thread that ends the process LOUDLY when no LCU has passed EncodePass for that long while pictures are inside the bindings - with
+ * what every picture object, lane and the device's launch budget hold at that moment.  A diagnosis tool for the bench and the sweeps (a wedged encoder must say why
+ * instead of eating the run's time limit); off unless asked for. */
+static unsigned long g_wd_progress;
+static int g_wd_state; /* 0 unknown, 1 running, -1 off */
+static void *watchdog_main(void *arg)
+{
+    const int limit = (int)(intptr_t)arg;
+    unsigned long last = __atomic_load_n(&g_wd_progress, __ATOMIC_RELAXED);
+    int idle = 0;
+    for (;;) {
+        struct timespec ts = {1, 0};
+        nanosleep(&ts, NULL);
+        const unsigned long now = __atomic_load_n(&g_wd_progress, __ATOMIC_RELAXED);
+        int busy = 0;
+        for (int i = 0; i < EP_PICTURES; i++) {
+            const EpPictureEntry *e = &g_ep_pic[i];
+            if (e->pcs && e->md_picture_plus1 && e->md_done_plus1 != e->md_picture_plus1)
+                busy++;
+        }
+        int fl = 0, wg = 0, wt = 0;
+        (void)svt_amd_debug_md_flights(&fl, &wg, &wt);
+        idle = (now == last && (busy || fl || wt)) ? idle + 1 : 0;
+        last = now;
+        if (idle < limit)
+            continue;
+        fprintf(stderr, "svt_hook_encdec: WATCHDOG: no LCU through EncodePass for %d s; device launches in flight %d holding %d workgroups, %d calls waiting\n", limit, fl, wg, wt);
+        for (int i = 0; i < EP_LANES; i++)
+            if (g_ep_lane_busy[i])
+                fprintf(stderr, "    lane %d busy\n", i);
+        for (int i = 0; i < EP_PICTURES; i++) {
+            const EpPictureEntry *e = &g_ep_pic[i];
+            if (e->pcs)
+                fprintf(stderr, "    picture object %d: picture %llu (tl %d, slice %d), md call for %llu, returned for %llu, ok %d, LCUs served %d\n", i,
+                        (unsigned long long)e->pcs->pictureNumber, (int)e->pcs->temporalLayerIndex, (int)e->pcs->sliceType,
+                        (unsigned long long)e->md_picture_plus1 - 1, (unsigned long long)e->md_done_plus1 - 1, e->md_ok, e->tl_lcus);
+        }
+        fflush(stderr);
+        abort();
+    }
+    return NULL;
+}
+static void watchdog_tick(void)
+{
+    __atomic_add_fetch(&g_wd_progress, 1, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&g_wd_state, __ATOMIC_ACQUIRE) == 0) {
+        int expect = 0;
+        const char *v = getenv("SVT_HOOK_WATCHDOG");
+        const int secs = v ? atoi(v) : 0;
+        if (__atomic_compare_exchange_n(&g_wd_state, &expect, secs > 0 ? 1 : -1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) && secs > 0) {
+            pthread_t th;
+            if (pthread_create(&th, NULL, watchdog_main, (void *)(intptr_t)secs) == 0)
+                pthread_detach(th);
+        }
+    }
+}
+
 /* The EncDec picture pool.  The reference sizes it for host latencies: pictureControlSetPoolInitCountChild = MAX(4, coreCount / 6) PictureControlSet_t objects
  * between the picture manager and packetization (Codec/EbEncHandle.c:1801, built at :818-829) - five at -lp 32.  A picture the device decides and encodes stays there
  * for its device call (50 - 120 ms at 4K where the host's wavefront takes 25 - 40), so the closed loop's rate is (objects in the pool) / (residence) and the pool, not the

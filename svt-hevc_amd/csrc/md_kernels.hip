@@ -2136,6 +2136,17 @@ extern "C" int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPictur
     return SVT_AMD_OK;
 }
 
+extern "C" int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, int *waiting)
+{
+    std::lock_guard<std::mutex> l(g_flight_mu);
+    if (in_flight)
+        *in_flight = g_flights;
+    if (workgroups_held)
+        *workgroups_held = g_flight_wgs;
+    if (waiting)
+        *waiting = (int)g_flight_wait.size();
+    return SVT_AMD_OK;
+}
 extern "C" int svt_amd_debug_md_kernel_lds_bytes(int inter, int bytes_per_sample)
 {
     if (bytes_per_sample == 2)

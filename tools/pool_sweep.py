@@ -36,9 +36,10 @@ with tempfile.TemporaryDirectory() as td:
                 rep = os.path.join(td, "report.txt")
                 env["SVT_HOOK_REPORT"] = rep
                 try:
-                    r = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", lp], os.path.join(td, "hip.265"), env=env, nb=16)
+                    r = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", lp], os.path.join(td, "hip.265"), env=dict({"SVT_HOOK_WATCHDOG": "15"}, **env), nb=16,
+                                  timeout=int(os.environ.get("SWEEP_TIMEOUT", "120")))
                 except Exception as ex:  # noqa: BLE001
-                    print(json.dumps({"lp": int(lp), "mode": mode, "pool": int(pool), "error": str(ex)[-600:]}), flush=True)
+                    print(json.dumps({"lp": int(lp), "mode": mode, "pool": int(pool), "error": str(ex)[-2500:]}), flush=True)
                     continue
                 cov = ""
                 if os.path.exists(rep):
