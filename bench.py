@@ -231,13 +231,23 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
         out["hip_threads"] = lp
         rp = os.path.join(td, "report.txt")
         hips, busy = [], None
+        # SVT_HOOK_WATCHDOG: a wedged encoder ends itself after 20 s without an LCU through EncodePass and says what every picture object and the launch budget held
+        # (integration/svt_hook_encdec.c); such a run is REPORTED (`aborted_runs`) and repeated once - a run that finishes with a different bitstream is never repeated
+        env.setdefault("SVT_HOOK_WATCHDOG", "20")
+        aborted = []
         with GpuBusy(local_rank) as gb:
             for k in range(RUNS if world == 1 else 1):
-                try:
-                    hips.append(E.run_app(E.HIP_APP, yuv, w, h, frames, hargs, os.path.join(td, "hip.265"), env=dict(env, **({"SVT_HOOK_REPORT": rp} if k == 0 else {})), nb=unique))
-                except Exception as e:
-                    hips.append({"error": str(e)[-300:], "fps": None, "md5": None})
+                for attempt in range(2):
+                    try:
+                        hips.append(E.run_app(E.HIP_APP, yuv, w, h, frames, hargs, os.path.join(td, "hip.265"), env=dict(env, **({"SVT_HOOK_REPORT": rp} if k == 0 else {})), nb=unique,
+                                              timeout=240))
+                        break
+                    except Exception as e:
+                        aborted.append(str(e)[-1200:])
+                        if attempt == 1:
+                            hips.append({"error": str(e)[-300:], "fps": None, "md5": None})
             busy = gb.summary()
+        out["aborted_runs"] = aborted
         hip = _median_run(hips)
         out["gpu_busy"] = dict(busy, what="amdgpu gpu_busy_percent sampled every 50 ms over the %d closed-loop encodes (start-up and clip preload included)" % len(hips)) if busy else None
         out["coverage"], out["report"] = _coverage(rp)
