@@ -377,6 +377,16 @@ typedef struct SvtAmdPaLcuStats {
 SVT_AMD_API int svt_amd_picture_stats(SvtAmdContext *ctx, int slot, SvtAmdPaLcuStats *out, int regions_w, int regions_h, uint32_t *histogram,
                                       uint8_t *region_average, uint64_t *sum_luma);
 
+/*
+ * Source-based-operations input of the mode-decision configuration: CalculateAcEnergy (Codec/EbSourceBasedOperationsProcess.c:302-362) of
+ * every LCU of the picture the slot holds - the AC energy (ComputeNxMSatdSadLCU, Codec/EbPictureOperators.c:232: 8x8 Hadamard sums minus the DC terms >> 2)
+ * of the 64x64 and of its four 32x32, the values pictureControlSetPtr->lcuYSrcEnergyCuArray[lcu][0..4] carries into DeriveDefaultSegments
+ * (EbModeDecisionConfiguration.c:409-426) and the encode pass's skin / contour tests (EbModeDecisionProcess.c:542).  LCUs the picture does not cover completely
+ * get the reference's 100000000 (:351).  Which pictures the values are read for (I pictures outside low-delay P) is the caller's rule.
+ * out: HOST, [LCUs in raster order][5].  Blocking.
+ */
+SVT_AMD_API int svt_amd_picture_ac_energy(SvtAmdContext *ctx, int slot, uint64_t *out);
+
 /* Batched form (grid = pictures x LCUs), each job reading the ME results its slot holds on the device. */
 typedef struct SvtAmdOisJob {
     SvtAmdOisParams params;

@@ -43,6 +43,9 @@
 #include "EbCodingUnit.h"
 #include "EbTransformUnit.h"
 #include "EbCabacContextModel.h"
+#include "EbSystemResourceManager.h"
+#include "EbUnPackProcess.h"
+#include "EbPackUnPack_C.h"
 
 #include "../include/svt_hevc_amd.h"
 #include "svt_hook_internal.h"
@@ -344,6 +347,77 @@ static void fill_ois_params(SvtAmdOisParams *p, const PictureParentControlSet_t 
 
 /* The picture's lane entry: claims a lane and queues the whole front half on first touch; returns with the results complete.
  * `me_ctx` is NULL when the first touch is an OIS call (I pictures never reach MotionEstimateLcu). */
+/*
+ * SURVEY 8f-3, the source-based-operations input of the mode-decision configuration: CalculateAcEnergy (EbSourceBasedOperationsProcess.c:302) asks
+ * ComputeNxMSatdSadLCU (EbPictureOperators.c:232) for the AC energy of the 64x64 and of the four 32x32 of every complete LCU of an I picture (outside
+ * low-delay P).  With SVT_HOOK_SBO=1 the device computes all of them in one launch from the luma the front half has just uploaded for the picture's open-loop
+ * intra search (svt_amd_picture_ac_energy), while the picture still holds its lane; the reference's calls - which arrive two processes later - are answered
+ * from that table.  A table entry is keyed by the address of the picture's first luma sample in the encoder's enhanced-picture buffer: the buffer is handed to
+ * a later picture only after this one has left the encoder, and a later I picture in the same buffer replaces the entry before its own calls arrive.
+ */
+#define SBO_PICTURES 128
+typedef struct { const uint8_t *base; uint32_t stride, width, height, lcus_w; uint64_t *energy; size_t capacity; } SboEntry;
+static SboEntry g_sbo[SBO_PICTURES];
+static pthread_mutex_t g_sbo_lock = PTHREAD_MUTEX_INITIALIZER;
+static unsigned long g_sbo_pictures, g_sbo_answers, g_sbo_cpu;
+static int sbo_on(void)
+{
+    static int on = -1;
+    if (on < 0)
+        on = getenv("SVT_HOOK_SBO") && atoi(getenv("SVT_HOOK_SBO")) > 0;
+    return on;
+}
+static void sbo_note_picture(FrontEntry *e, const PictureParentControlSet_t *pcs, const SequenceControlSet_t *scs)
+{
+    if (!sbo_on() || pcs->sliceType != EB_I_PICTURE || pcs->predStructure == EB_PRED_LOW_DELAY_P)
+        return;
+    const EbPictureBufferDesc_t *in = pcs->enhancedPicturePtr;
+    const uint8_t *base = in->bufferY + (size_t)in->originY * in->strideY + in->originX;
+    const uint32_t n = ((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u);
+    uint64_t *energy = (uint64_t *)malloc((size_t)n * 5 * sizeof(uint64_t));
+    if (!energy || svt_amd_picture_ac_energy(e->lane, (int)(pcs->pictureNumber % NSLOTS), energy))
+        die("svt_amd_picture_ac_energy");
+    pthread_mutex_lock(&g_sbo_lock);
+    SboEntry *t = NULL;
+    for (int i = 0; i < SBO_PICTURES && !t; i++)
+        if (g_sbo[i].base == base || !g_sbo[i].base)
+            t = &g_sbo[i];
+    if (!t) { /* more enhanced-picture buffers than entries: the calls of this picture go to the reference code */
+        pthread_mutex_unlock(&g_sbo_lock);
+        free(energy);
+        return;
+    }
+    free(t->energy);
+    t->base = base, t->stride = in->strideY, t->width = scs->lumaWidth, t->height = scs->lumaHeight, t->lcus_w = (scs->lumaWidth + 63u) / 64u, t->energy = energy;
+    g_sbo_pictures++;
+    pthread_mutex_unlock(&g_sbo_lock);
+}
+EB_U64 __real_ComputeNxMSatdSadLCU(EB_U8 *src, EB_U32 srcStride, EB_U32 width, EB_U32 height);
+EB_U64 __wrap_ComputeNxMSatdSadLCU(EB_U8 *src, EB_U32 srcStride, EB_U32 width, EB_U32 height)
+{
+    if (sbo_on() && !svt_hook_failed() && width == height && (width == 64 || width == 32)) {
+        pthread_mutex_lock(&g_sbo_lock);
+        for (int i = 0; i < SBO_PICTURES && g_sbo[i].base; i++) {
+            const SboEntry *t = &g_sbo[i];
+            if (t->stride != srcStride || src < t->base || (size_t)(src - t->base) >= (size_t)t->stride * t->height)
+                continue;
+            const uint32_t y = (uint32_t)((size_t)(src - t->base) / t->stride), x = (uint32_t)((size_t)(src - t->base) % t->stride);
+            if (x + width > t->width || y + height > t->height || (x & 31) || (y & 31) || (width == 64 && ((x | y) & 63)))
+                break;
+            const uint64_t *en = t->energy + (size_t)((y >> 6) * t->lcus_w + (x >> 6)) * 5;
+            const uint64_t v = width == 64 ? en[0] : en[1 + (((y >> 5) & 1) << 1) + ((x >> 5) & 1)];
+            if (v == 100000000ull)
+                break; /* an LCU the picture does not cover: never asked for by CalculateAcEnergy */
+            g_sbo_answers++;
+            pthread_mutex_unlock(&g_sbo_lock);
+            return v;
+        }
+        g_sbo_cpu++;
+        pthread_mutex_unlock(&g_sbo_lock);
+    }
+    return __real_ComputeNxMSatdSadLCU(src, srcStride, width, height);
+}
+
 static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t *me_ctx, const EbPictureBufferDesc_t *inputPtr)
 {
     static __thread FrontEntry *cached;
@@ -434,13 +508,16 @@ static FrontEntry *front_entry(PictureParentControlSet_t *pcs, const MeContext_t
     if (svt_amd_frontend_wait(e->lane, &me, &ois))
         die("svt_amd_frontend_wait");
     e->me = (const SvtAmdMeCuResult *)me, e->ois = (const uint8_t *)ois;
-    if (!__atomic_exchange_n(&e->timed, 1, __ATOMIC_ACQ_REL)) { /* first thread back: submit -> results on the host */
+    const int first_back = !__atomic_exchange_n(&e->timed, 1, __ATOMIC_ACQ_REL);
+    if (first_back) { /* first thread back: submit -> results on the host */
         svt_hook_lock(&g_front_lock);
         g_t_device += now_s() - e->t_submit, g_n_timed++;
         if (e->pic < TL_N)
             g_tl_ready[e->pic] = now_s() - g_tl0;
         svt_hook_unlock(&g_front_lock);
     }
+    if (first_back)
+        sbo_note_picture(e, pcs, scs);
     cached = e;
     cached_gen = e->gen;
     return e;
@@ -1951,6 +2028,42 @@ static void *kernel_thread(void *(*real)(void *), void *arg)
     return r;
 }
 void *__wrap_MotionEstimationKernel(void *inputPtr) { return kernel_thread(__real_MotionEstimationKernel, inputPtr); }
+
+/*
+ * SURVEY 8f-4, the wire format of 10-bit input: the application's 16-bit samples become the encoder's 8-bit plane + 2-bit plane in the UnPack2D threads
+ * (Codec/EbPictureOperators.c:512; CopyFrameBuffer, EbEncHandle.c:3485-3551, cuts each plane into row bands and posts one job per band).  With
+ * SVT_HOOK_UNPACK=1 a thread keeps the reference's job protocol (take a job, do it, take an end-of-job token, give the job back, post the token) and does the job
+ * on the device: svt_amd_EB_ENC_msbUnPack2D = the signature of the table slot the reference thread calls (UnPack2D_funcPtrArray_16Bit).  One job = one
+ * band over PCIe and back: this binding proves the kernel inside the encoder (same stream out of the same 16-bit file); the device-side form for planes that
+ * stay in HBM is svt_amd_unpack_plane.
+ */
+void *__real_UnPack2D(void *context);
+static unsigned long g_unpack_jobs, g_unpack_samples;
+void *__wrap_UnPack2D(void *context)
+{
+    const char *on = getenv("SVT_HOOK_UNPACK");
+    if (!on || atoi(on) <= 0)
+        return __real_UnPack2D(context);
+    UnPackContext_t *c = (UnPackContext_t *)context;
+    for (;;) {
+        EbObjectWrapper_t *job, *token;
+        EbGetFullObject(c->copyFrameOutputFifoPtr, &job);
+        if (job->quitSignal == EB_TRUE)
+            break;
+        const EBUnPack2DType_t *u = (const EBUnPack2DType_t *)job->objectPtr;
+        if (svt_hook_failed())
+            EB_ENC_msbUnPack2D(u->in16BitBuffer, u->inStride, u->out8BitBuffer, u->outnBitBuffer, u->out8Stride, u->outnStride, u->width, u->height);
+        else {
+            svt_amd_EB_ENC_msbUnPack2D(u->in16BitBuffer, u->inStride, u->out8BitBuffer, u->outnBitBuffer, u->out8Stride, u->outnStride, u->width, u->height);
+            __atomic_add_fetch(&g_unpack_jobs, 1, __ATOMIC_RELAXED);
+            __atomic_add_fetch(&g_unpack_samples, (unsigned long)u->width * u->height, __ATOMIC_RELAXED);
+        }
+        EbGetEmptyObject(c->unPackInputFifoPtr, &token);
+        EbReleaseObject(job);
+        EbPostFullObject(token);
+    }
+    return EB_NULL;
+}
 static __thread int t_encdec_thread; /* SVT_HOOK_TIMELINE: GeneratePadding calls of EncDec threads are PadRefAndSetFlags's (the picture-analysis threads pad input pictures) */
 void *__wrap_EncDecKernel(void *inputPtr)
 {
@@ -2020,6 +2133,11 @@ static void hook_report(void)
                 g_fl_gpu, g_fl_cpu, g_cl_gpu, g_cl_cpu, g_recon_gpu, g_intra_gpu, g_intra4_gpu, g_md_intra_gpu, g_md_intra_ol_gpu, g_md_intra4_gpu,
                 g_inter_gpu, g_inter16_gpu, g_md_inter_gpu, g_quant_gpu, g_quant_pm_gpu, g_sao_gpu);
     }
+    if (g_unpack_jobs)
+        fprintf(out, "svt_hook_me: 16-bit input -> 8-bit + 2-bit planes (UnPack2D) on the GPU: %lu jobs, %lu samples\n", g_unpack_jobs, g_unpack_samples);
+    if (sbo_on())
+        fprintf(out, "svt_hook_me: AC energy (CalculateAcEnergy) of %lu pictures on the GPU, %lu ComputeNxMSatdSadLCU calls answered from it, %lu left to the reference code\n",
+                g_sbo_pictures, g_sbo_answers, g_sbo_cpu);
     fprintf(out, "svt_hook_me: %lu pictures / %lu LCUs intra-searched (OIS) on the GPU, 0 on the CPU\n", g_ois_pictures,
             g_ois_lcus);
     fprintf(out, "svt_hook_me: %lu pictures / %lu LCUs estimated on the GPU, 0 on the CPU\n", g_pictures, g_lcus);

@@ -291,6 +291,10 @@ void svt_oracle_coeff_scan_tu(const int16_t *coeff, uint32_t stride, uint32_t si
                               uint32_t nz, SvtAmdCoeffScanTu *tu, SvtAmdCoeffScanGroup *groups, uint32_t *ng, uint16_t *levels, uint32_t *nl);
 int svt_oracle_coeff_scan_lcu(const SvtAmdLcuWork *W, const SvtAmdLcuResult *R, SvtAmdCoeffScanLcu *out, SvtAmdCoeffScanGroup *groups, uint16_t *levels);
 
+/* ---- source-based operations: AC energy of the LCUs (svt_oracle_sbo.c) ---- */
+uint64_t svt_oracle_sbo_ac_energy(const uint8_t *src, uint32_t stride, uint32_t width, uint32_t height);
+void svt_oracle_sbo_ac_energy_picture(const uint8_t *luma, uint32_t stride, uint32_t width, uint32_t height, uint64_t *out);
+
 /* ---- picture-analysis statistics (svt_oracle_pa.c) ---- */
 void svt_oracle_pa_block_stats(const uint8_t *luma, uint32_t stride, SvtAmdPaLcuStats *out);
 uint64_t svt_oracle_pa_luma_histogram(const uint8_t *sixteenth, uint32_t stride, uint32_t width, uint32_t height, uint32_t regions_w, uint32_t regions_h,

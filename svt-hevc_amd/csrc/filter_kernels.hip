@@ -531,9 +531,42 @@ __global__ void k_cpack(const uint8_t *__restrict__ inn, uint32_t innStride, uin
             (uint8_t)((p[0] & 0xC0) | ((p[1] >> 2) & 0x30) | ((p[2] >> 4) & 0x0C) | ((p[3] >> 6) & 0x03));
     }
 }
+/* eight samples a thread where the three planes allow 16 / 8 / 8-byte accesses (`vec`, uniform: the encoder's picture buffers and the application's
+ * 16-bit input do), a sample a thread otherwise; 2 B read + 2 B written per sample: HBM-bound */
 __global__ void k_unpack(const uint16_t *__restrict__ in16, uint32_t inStride, uint8_t *__restrict__ out8,
                          uint32_t out8Stride, uint8_t *__restrict__ outn, uint32_t outnStride, uint32_t w, uint32_t h)
 {
+    const bool vec = !(((uintptr_t)in16 | ((uintptr_t)inStride << 1)) & 15) && !(((uintptr_t)out8 | out8Stride) & 7) &&
+                     (!outn || !(((uintptr_t)outn | outnStride) & 7));
+    if (vec) {
+        const uint32_t gw = (w + 7) >> 3, full = w >> 3;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < gw * h; i += gridDim.x * blockDim.x) {
+            const uint32_t y = i / gw, g = i - y * gw, x = g << 3;
+            if (g < full) {
+                const uint4 v = *(const uint4 *)(in16 + x + (size_t)y * inStride);
+                /* sample pairs (lo | hi << 16): the 8 MSBs are bits 2..9, the two LSBs go to bits 6..7 of their byte */
+                const uint32_t p[4] = {v.x, v.y, v.z, v.w};
+                uint32_t m[2], l[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t a = p[2 * k], b = p[2 * k + 1];
+                    m[k] = ((a >> 2) & 255u) | (((a >> 18) & 255u) << 8) | (((b >> 2) & 255u) << 16) | (((b >> 18) & 255u) << 24);
+                    l[k] = ((a & 3u) << 6) | (((a >> 16) & 3u) << 14) | ((b & 3u) << 22) | (((b >> 16) & 3u) << 30);
+                }
+                *(uint2 *)(out8 + x + (size_t)y * out8Stride) = make_uint2(m[0], m[1]);
+                if (outn)
+                    *(uint2 *)(outn + x + (size_t)y * outnStride) = make_uint2(l[0], l[1]);
+            } else {
+                for (uint32_t xx = x; xx < w; xx++) {
+                    const uint16_t q = in16[xx + (size_t)y * inStride];
+                    out8[xx + (size_t)y * out8Stride] = (uint8_t)(q >> 2);
+                    if (outn)
+                        outn[xx + (size_t)y * outnStride] = (uint8_t)(q << 6);
+                }
+            }
+        }
+        return;
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
         const uint32_t y = i / w, x = i - y * w;
         const uint16_t p = in16[x + (size_t)y * inStride];

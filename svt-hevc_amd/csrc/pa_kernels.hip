@@ -7,6 +7,10 @@
  *                     averages of four children, taken across lanes with shuffles (the 8x8 blocks of a 16x16 are lanes l, l+1, l+8, l+9).
  *   k_pa_histogram    SubSampleLumaGeneratePixelIntensityHistogramBins (:3384) on the 1/16 picture: a workgroup per (region, strip of rows), 256 bins
  *                     in LDS, one global atomic per non-empty bin; the finishing touches (bins start at 1, << 4, region average) are k_pa_finish.
+ *   k_sbo_ac_energy   CalculateAcEnergy (Codec/EbSourceBasedOperationsProcess.c:302; SURVEY 8f-3, an input of the mode-decision configuration): one wave per
+ *                     COMPLETE LCU, a lane per 8x8 block: the block's 8x8 Hadamard sum (Compute8x8Satd_U8, C_DEFAULT/EbPictureOperators_C.c:563) in registers,
+ *                     the 32x32 / 64x64 sums across lanes, AC = sum of block SATDs - (sum of the blocks' DC terms >> 2) (ComputeNxMSatdSadLCU,
+ *                     Codec/EbPictureOperators.c:232).
  * Bound: HBM - 0.5 B/pel read for the block statistics (every other row; whole cache lines are fetched: 1 B/pel), 1/16 B/pel for the histograms.
  */
 #include "svt_amd_internal.h"
@@ -130,6 +134,89 @@ extern "C" int svt_amd_picture_stats(SvtAmdContext *ctx, int slot, SvtAmdPaLcuSt
         HIP_TRY(hipMemcpyAsync(region_average, d_avg, (size_t)regions, hipMemcpyDeviceToHost, ctx->stream));
     if (sum_luma)
         HIP_TRY(hipMemcpyAsync(sum_luma, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_AMD_OK;
+}
+
+/* 8-point Hadamard butterflies in place (the order of the outputs differs from the reference's; only v[0] = the sum and the multiset of magnitudes matter) */
+__device__ __forceinline__ void hadamard8(int *v)
+{
+#pragma unroll
+    for (int span = 4; span > 0; span >>= 1)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (!(i & span)) {
+                const int a = v[i], b = v[i + span];
+                v[i] = a + b, v[i + span] = a - b;
+            }
+}
+/* out: [lcu][5] = the 64x64 then the four 32x32 (raster) of every LCU; incomplete LCUs carry the reference's "not computed" value (:351) */
+__global__ __launch_bounds__(64) void k_sbo_ac_energy(const uint8_t *__restrict__ full, int pitch, int width, int height, int lcus_w,
+                                                      unsigned long long *__restrict__ out)
+{
+    const int lcu = blockIdx.x, b = threadIdx.x, lx = (lcu % lcus_w) * 64, ly = (lcu / lcus_w) * 64;
+    if (lx + 64 > width || ly + 64 > height) {
+        if (b < 5)
+            out[(size_t)lcu * 5 + b] = 100000000ull;
+        return;
+    }
+    const uint8_t *p = full + (size_t)(ly + (b >> 3) * 8) * pitch + lx + (b & 7) * 8;
+    int m[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint2 v = *(const uint2 *)(p + (size_t)r * pitch);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            m[r][c] = (v.x >> (8 * c)) & 255, m[r][4 + c] = (v.y >> (8 * c)) & 255;
+        hadamard8(m[r]);
+    }
+    uint32_t satd = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        int col[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            col[r] = m[r][c];
+        hadamard8(col);
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            satd += (uint32_t)abs(col[r]), m[r][c] = col[r];
+    }
+    uint32_t s = (satd + 2) >> 2, dc = (uint32_t)m[0][0]; /* Compute8x8Satd_U8: the block's rounded sum; *dcValue += m2[0][0] */
+    /* the 32x32 the lane's block belongs to: lanes that differ in bits 0, 1 (x) and 3, 4 (y) */
+    s += __shfl_xor(s, 1), dc += __shfl_xor(dc, 1);
+    s += __shfl_xor(s, 2), dc += __shfl_xor(dc, 2);
+    s += __shfl_xor(s, 8), dc += __shfl_xor(dc, 8);
+    s += __shfl_xor(s, 16), dc += __shfl_xor(dc, 16);
+    if (!(b & 27))
+        out[(size_t)lcu * 5 + 1 + ((b >> 5) << 1) + ((b & 7) >> 2)] = (unsigned long long)s - (dc >> 2);
+    s += __shfl_xor(s, 4), dc += __shfl_xor(dc, 4);
+    s += __shfl_xor(s, 32), dc += __shfl_xor(dc, 32);
+    if (b == 0)
+        out[(size_t)lcu * 5] = (unsigned long long)s - (dc >> 2);
+}
+
+extern "C" int svt_amd_picture_ac_energy(SvtAmdContext *ctx, int slot, uint64_t *out)
+{
+    if (!ctx || !out || slot < 0 || slot >= ctx->num_slots) {
+        svt_amd_set_error("svt_amd_picture_ac_energy: bad parameter");
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const DevPicture *s = &ctx->slots[slot];
+    if (!s->valid) {
+        svt_amd_set_error("svt_amd_picture_ac_energy: slot %d holds no picture", slot);
+        return SVT_AMD_ERR_BAD_PARAM;
+    }
+    const int wl = (s->width + 63) / 64, hl = (s->height + 63) / 64, n = wl * hl;
+    uint8_t *d = nullptr;
+    int rc = svt_amd_ctx_scratch(ctx, (size_t)n * 40, &d);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
+    hipLaunchKernelGGL(k_sbo_ac_energy, dim3((unsigned)n), dim3(64), 0, ctx->stream, s->full.origin, s->full.pitch, s->width, s->height, wl, (unsigned long long *)d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d, (size_t)n * 40, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVT_AMD_OK;
 }

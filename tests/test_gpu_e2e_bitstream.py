@@ -595,3 +595,52 @@ def test_baseline_config1_with_the_device_closed_loop_on_is_bitstream_identical(
     assert pics >= 1 and pics == inter + 1, rep                       # the I picture + the P pictures whose LCUs all take ModeDecisionLcu
     assert pics + left <= frames and pics * 2 >= frames, rep           # (pinned to the exact count below once read off a run)
     assert r["bitstream_identical"], rep
+
+
+def _encode_with_report(tmp_path, yuv, w, h, n, args, env):
+    rep = str(tmp_path / "report.txt")
+    r = subprocess.run([HIP_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-b", str(tmp_path / "hip.265"), "-asm", "1", "-q", "32"] + args,
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, SVT_HOOK_REPORT=rep, **env))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return hashlib.md5(open(str(tmp_path / "hip.265"), "rb").read()).hexdigest(), open(rep).read()
+
+
+@pytest.mark.parametrize("kind,w,h,n,args", [
+    ("objects", 640, 384, 9, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-intra-period", "3"]),
+    ("motion", 1920, 1080, 5, ["-encMode", "5", "-pred-struct", "2", "-hierarchical-levels", "3"]),
+    ("objects", 416, 240, 6, ["-encMode", "9", "-intra-period", "0"]),
+])
+def test_bitstream_identical_with_the_ac_energy_of_i_pictures_from_the_device(tmp_path, kind, w, h, n, args):
+    """SURVEY 8f-3 bound in the encoder (SVT_HOOK_SBO=1): every ComputeNxMSatdSadLCU call of CalculateAcEnergy (EbSourceBasedOperationsProcess.c:323-339) is answered
+    from ONE svt_amd_picture_ac_energy launch per I picture on the luma the front half uploaded; the values steer DeriveDefaultSegments and the encode pass's
+    contour tests, so a wrong one moves the stream."""
+    import re
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip(yuv, kind, w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
+    hip_md5, report = _encode_with_report(tmp_path, yuv, w, h, n, args, {"SVT_HOOK_SBO": "1"})
+    m = re.search(r"AC energy \(CalculateAcEnergy\) of (\d+) pictures on the GPU, (\d+) ComputeNxMSatdSadLCU calls answered from it, (\d+) left", report)
+    assert m, report[-1500:]
+    pictures, answered, left = (int(x) for x in m.groups())
+    print("SBO_COUNTS", kind, w, h, n, pictures, answered, left)
+    assert pictures >= 1 and answered == pictures * 5 * (w // 64) * (h // 64) and left == 0
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"
+
+
+@pytest.mark.parametrize("w,h,n,args", [
+    (640, 384, 5, ["-encMode", "7", "-pred-struct", "2", "-hierarchical-levels", "2", "-sao", "1", "-bit-depth", "10"]),
+    (1920, 1080, 3, ["-encMode", "9", "-pred-struct", "0", "-bit-depth", "10"]),
+    (424, 240, 4, ["-encMode", "9", "-bit-depth", "10"]),                      # a width the row bands' 8-sample groups do not divide
+])
+def test_bitstream_identical_with_the_16_bit_input_unpacked_on_the_device(tmp_path, w, h, n, args):
+    """SURVEY 8f-4 bound in the encoder (SVT_HOOK_UNPACK=1): the UnPack2D threads (EbPictureOperators.c:512) keep the reference's job protocol and split every row
+    band of the application's 16-bit planes into the 8-bit + 2-bit planes on the device."""
+    import re
+    yuv = str(tmp_path / "clip.yuv")
+    S.write_clip10(yuv, "motion", w, h, n, 7)
+    ref_md5, _ = _encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / "ref.265"))
+    hip_md5, report = _encode_with_report(tmp_path, yuv, w, h, n, args, {"SVT_HOOK_UNPACK": "1"})
+    m = re.search(r"\(UnPack2D\) on the GPU: (\d+) jobs, (\d+) samples", report)
+    assert m, report[-1500:]
+    assert int(m.group(1)) >= 3 * n and 0.9 * n * w * h * 1.5 <= int(m.group(2)) <= n * w * h * 3 // 2
+    assert hip_md5 == ref_md5, "bitstream differs from the reference"

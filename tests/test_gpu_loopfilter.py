@@ -298,3 +298,25 @@ def test_pack_unpack_plane_roundtrip(libs, gpu_ctx, compressed):
     assert rc == 0
     product.svt_amd_synchronize(gpu_ctx)
     assert np.array_equal(o8.cpu().numpy(), in8) and np.array_equal(on.cpu().numpy(), two << 6)
+
+
+@pytest.mark.parametrize("w,h,s16,s8,sn,off", [(70, 9, 80, 72, 88, 0), (66, 5, 67, 69, 71, 0), (64, 4, 64, 64, 64, 3), (7, 3, 8, 8, 8, 0), (1928, 17, 2048, 1936, 1936, 0)])
+def test_unpack_plane_ragged_shapes(libs, gpu_ctx, w, h, s16, s8, sn, off):
+    """svt_amd_unpack_plane where the 8-sample groups do not divide the width, where the strides forbid vector accesses and where the planes start off an
+    aligned address: bytes outside the w x h window stay untouched, inside they are (p >> 2, (p & 3) << 6) (EB_ENC_msbUnPack2D, C_DEFAULT/EbPackUnPack_C.c)."""
+    import torch
+    product, oracle = libs
+    rng = np.random.default_rng(w * 31 + h)
+    in16 = rng.integers(0, 1024, h * s16 + off, dtype=np.uint16)
+    d16 = torch.from_numpy(in16.view(np.int16)).cuda()
+    o8, on = torch.full((h * s8 + off,), 0xA5, dtype=torch.uint8, device="cuda"), torch.full((h * sn + off,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    rc = product.svt_amd_unpack_plane(gpu_ctx, d16.data_ptr() + 2 * off, s16, o8.data_ptr() + off, s8, on.data_ptr() + off, sn, w, h)
+    assert rc == 0, product.svt_amd_last_error()
+    product.svt_amd_synchronize(gpu_ctx)
+    want8, wantn = np.full(h * s8 + off, 0xA5, np.uint8), np.full(h * sn + off, 0x5A, np.uint8)
+    for y in range(h):
+        row = in16[off + y * s16: off + y * s16 + w]
+        want8[off + y * s8: off + y * s8 + w] = row >> 2
+        wantn[off + y * sn: off + y * sn + w] = (row & 3) << 6
+    assert np.array_equal(o8.cpu().numpy(), want8) and np.array_equal(on.cpu().numpy(), wantn)
