@@ -137,6 +137,12 @@ SVT_AMD_API const char *svt_amd_version(void);
  * (GPU_MAX_HW_QUEUES, unless the user set it) so that every lane's stream has a queue of its own.  Only has an effect BEFORE the process's first
  * HIP call; the library never changes the environment on its own. */
 SVT_AMD_API int svt_amd_runtime_env_defaults(void);
+/* OPT-IN device setting for hosts whose threads wait on the device while OTHER host threads have work to do (the encoder binding: up to a dozen EncDec threads
+ * wait 60 - 100 ms each for their picture's mode-decision kernel while the base-layer pictures are decided on the same 32 logical processors): the threads sleep
+ * in the HIP runtime's waits (hipDeviceScheduleBlockingSync) instead of spinning on a completion signal, which costs every wait a wake-up (tens of microseconds)
+ * and gives the cores back.  blocking = 0 restores the runtime's default.  A setting of the DEVICE, i.e. of every context of this process on it; best made before
+ * the device's first context (svt_amd_context_create). */
+SVT_AMD_API int svt_amd_host_wait_mode(int device_ordinal, int blocking);
 SVT_AMD_API const char *svt_amd_last_error(void);
 
 /*
@@ -1682,6 +1688,9 @@ SVT_AMD_API int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPic
 SVT_AMD_API int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms, int *workgroups);
 /* diagnosis: the mode-decision launches that hold (or wait for) workgroups of the device budget right now (md_kernels.hip: MdFlight) */
 SVT_AMD_API int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, int *waiting);
+/* Everything the first svt_amd_md_encode_picture[_inter / 16] call on a picture object would allocate (device state, page-locked staging, events), made NOW: for hosts that
+ * build their picture objects before their clock starts (the encoder binding at EbInitEncoder time) - allocations made while other pictures' kernels run wait for them. */
+SVT_AMD_API int svt_amd_md_picture_warmup(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic);
 /* measurement: dynamic LDS bytes a workgroup of k_md_encode_picture<inter, sample bytes> is launched with (the whole LCU state: one workgroup per CU) */
 SVT_AMD_API int svt_amd_debug_md_kernel_lds_bytes(int inter, int bytes_per_sample);
 

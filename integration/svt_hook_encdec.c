@@ -233,15 +233,20 @@ static EpPictureEntry *entry_lookup(const SequenceControlSet_t *scs, const Pictu
 }
 /* prepare == 0: only find (or create) the object; the caller decides whether the picture needs the device at all (SVT_HOOK_MD alone) and calls
  * picture_prepare itself under the entry's lock */
+static EpPictureEntry *picture_entry_of(SvtAmdContext *lane, uint32_t lumaWidth, uint32_t lumaHeight, const PictureControlSet_t *pcs, int wide, int prepare);
 static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlSet_t *scs, const PictureControlSet_t *pcs, int wide, int prepare)
+{
+    return picture_entry_of(lane, scs->lumaWidth, scs->lumaHeight, pcs, wide, prepare);
+}
+static EpPictureEntry *picture_entry_of(SvtAmdContext *lane, uint32_t lumaWidth, uint32_t lumaHeight, const PictureControlSet_t *pcs, int wide, int prepare)
 {
     EpPictureEntry *e = NULL;
     svt_hook_lock(&g_ep_lock);
     for (int i = 0; i < EP_PICTURES && !e; i++)
         if (g_ep_pic[i].pcs == pcs)
             e = &g_ep_pic[i];
-    const int ncap = (int)(((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u));
-    if (e && (e->cap != ncap || e->wide != wide || e->width != scs->lumaWidth || e->height != scs->lumaHeight)) {
+    const int ncap = (int)(((lumaWidth + 63u) / 64u) * ((lumaHeight + 63u) / 64u));
+    if (e && (e->cap != ncap || e->wide != wide || e->width != lumaWidth || e->height != lumaHeight)) {
         /* a PictureControlSet_t address of an earlier encoder instance with another picture format: nothing of the entry fits */
         entry_release(lane, e);
         e = NULL;
@@ -250,10 +255,10 @@ static EpPictureEntry *picture_entry(SvtAmdContext *lane, const SequenceControlS
         if (!g_ep_pic[i].pcs) {
             e = &g_ep_pic[i];
             pthread_mutex_init(&e->lock, NULL);
-            e->wide = wide, e->width = scs->lumaWidth, e->height = scs->lumaHeight;
-            if (svt_amd_encdec_picture_create(lane, (uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight, wide ? 2 : 1, &e->pic))
+            e->wide = wide, e->width = lumaWidth, e->height = lumaHeight;
+            if (svt_amd_encdec_picture_create(lane, (uint16_t)lumaWidth, (uint16_t)lumaHeight, wide ? 2 : 1, &e->pic))
                 svt_hook_die("svt_amd_encdec_picture_create");
-            e->cap = (int)(((scs->lumaWidth + 63u) / 64u) * ((scs->lumaHeight + 63u) / 64u));
+            e->cap = ncap;
             e->pending = malloc((wide ? sizeof(SvtAmdLcuBorder16) : sizeof(SvtAmdLcuBorder)) * (size_t)e->cap);
             if (!e->pending)
                 svt_hook_die("out of memory (encode-pass border list)");
@@ -1032,6 +1037,35 @@ static void watchdog_tick(void)
  * the bitstream does not depend on it (pictures are still released in decode order with their references complete).  The one-line change a maintainer makes in
  * LoadDefaultBufferConfigurationSettings is shown in INTEGRATION.md 1h. */
 #include "EbSystemResourceManager.h"
+/* First uses cost: a lane is a stream to create (20 - 30 ms while kernels run), a picture object and its mode-decision state are device allocations, the records of its
+ * device calls page-locked host memory - and any of them made while other pictures' kernels run waits for those (profiles/r05_aa).  The EncDec pictures are known when
+ * their pool is built (the binding below notes them); once the device is up - still inside EbInitEncoder, before the encode clock - every one of them gets its lane,
+ * picture object, state and records.  SVT_HOOK_NO_WARMUP=1 leaves all of it to the first pictures. */
+static void md_entry_buffers(SvtAmdContext *lane, EpPictureEntry *e);
+static const PictureControlSet_t *g_warm_pcs[EP_PICTURES];
+static int g_warm_n, g_warm_wide;
+static uint32_t g_warm_w, g_warm_h;
+void svt_hook_encdec_warmup(void)
+{
+    if (!g_warm_n || !getenv("SVT_HOOK_MD") || getenv("SVT_HOOK_NO_WARMUP") || (g_warm_w & 7) || (g_warm_h & 7))
+        return;
+    SvtAmdContext *root = svt_hook_device((uint16_t)g_warm_w, (uint16_t)g_warm_h);
+    const int n = g_warm_n < EP_LANES ? g_warm_n : EP_LANES;
+    SvtAmdContext *lanes[EP_LANES];
+    for (int i = 0; i < n; i++) /* all at once: a lane given back would be handed out again */
+        lanes[i] = lane_claim(root);
+    for (int i = 0; i < g_warm_n; i++) {
+        SvtAmdContext *lane = lanes[i % n];
+        EpPictureEntry *e = picture_entry_of(lane, g_warm_w, g_warm_h, g_warm_pcs[i], g_warm_wide, 0);
+        md_entry_buffers(lane, e);
+        if (svt_amd_md_picture_warmup(lane, e->pic))
+            svt_hook_die("svt_amd_md_picture_warmup");
+    }
+    for (int i = 0; i < n; i++)
+        lane_release(lanes[i]);
+    g_warm_n = 0;
+}
+EB_ERRORTYPE EbInputBufferHeaderCreator(EB_PTR *objectDblPtr, EB_PTR objectInitDataPtr); /* Codec/EbEncHandle.c:3902 (no header declares it) */
 EB_ERRORTYPE __real_EbSystemResourceCtor(EbSystemResource_t *resourcePtr, EB_U32 objectTotalCount, EB_U32 producerProcessTotalCount, EB_U32 consumerProcessTotalCount,
                                          EbFifo_t ***producerFifoPtrArrayPtr, EbFifo_t ***consumerFifoPtrArrayPtr, EB_BOOL fullFifoEnabled, EB_CREATOR objectCreator,
                                          EB_PTR objectInitDataPtr, EbDctor objectDestroyer);
@@ -1047,8 +1081,28 @@ EB_ERRORTYPE __wrap_EbSystemResourceCtor(EbSystemResource_t *resourcePtr, EB_U32
             objectTotalCount = (EB_U32)want;
         }
     }
-    return __real_EbSystemResourceCtor(resourcePtr, objectTotalCount, producerProcessTotalCount, consumerProcessTotalCount, producerFifoPtrArrayPtr, consumerFifoPtrArrayPtr,
-                                       fullFifoEnabled, objectCreator, objectInitDataPtr, objectDestroyer);
+    const EB_ERRORTYPE rc = __real_EbSystemResourceCtor(resourcePtr, objectTotalCount, producerProcessTotalCount, consumerProcessTotalCount, producerFifoPtrArrayPtr,
+                                                        consumerFifoPtrArrayPtr, fullFifoEnabled, objectCreator, objectInitDataPtr, objectDestroyer);
+    if (rc == EB_ErrorNone && objectCreator == PictureControlSetCreator && objectInitDataPtr) { /* svt_hook_encdec_warmup below */
+        const PictureControlSetInitData_t *init = (const PictureControlSetInitData_t *)objectInitDataPtr;
+        g_warm_n = 0, g_warm_w = init->pictureWidth, g_warm_h = init->pictureHeight, g_warm_wide = init->is16bit ? 1 : 0;
+        for (EB_U32 i = 0; i < resourcePtr->objectTotalCount && i < EP_PICTURES; i++)
+            g_warm_pcs[g_warm_n++] = (const PictureControlSet_t *)resourcePtr->wrapperPtrPool[i]->objectPtr;
+    }
+    /* the pools whose pictures cross PCIe when the mode decision runs on the device - source pictures (the application's input buffers the encoder keeps as
+     * enhancedPicturePtr) and reference pictures - are page-locked HERE, while the encoder is being built and the device is idle (svt_hook_me.c:svt_hook_pin_picture_at_init) */
+    if (rc == EB_ErrorNone && (getenv("SVT_HOOK_MD") || getenv("SVT_HOOK_ENCODEPASS")) && (objectCreator == EbInputBufferHeaderCreator || objectCreator == EbReferenceObjectCreator))
+        for (EB_U32 i = 0; i < resourcePtr->objectTotalCount; i++) {
+            void *obj = resourcePtr->wrapperPtrPool[i]->objectPtr;
+            if (objectCreator == EbInputBufferHeaderCreator) {
+                svt_hook_pin_picture_at_init((const EbPictureBufferDesc_t *)((EB_BUFFERHEADERTYPE *)obj)->pBuffer, 1);
+            } else {
+                const EbReferenceObject_t *r = (const EbReferenceObject_t *)obj;
+                svt_hook_pin_picture_at_init(r->referencePicture, 1);
+                svt_hook_pin_picture_at_init(r->referencePicture16bit, 2);
+            }
+        }
+    return rc;
 }
 
 EB_ERRORTYPE __real_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet_t *pcs, const MdcLcuData_t *const mdcResultTbPtr,
@@ -1095,6 +1149,22 @@ static void md_apply(LargestCodingUnit_t *lcuPtr, const SvtAmdMdLcuOut *o, EB_U8
     }
 }
 
+/* the page-locked records of an entry's device calls (first use, or the warm-up at EbInitEncoder time) */
+static void md_entry_buffers(SvtAmdContext *lane, EpPictureEntry *e)
+{
+    if (e->md_out)
+        return;
+    const size_t n = (size_t)e->cap;
+    const size_t wb = e->wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = e->wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
+    if (svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcuOut) * n, (void **)&e->md_out) || svt_amd_host_alloc(lane, wb * n, &e->md_works) ||
+        svt_amd_host_alloc(lane, rb * n, &e->md_res) || svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcu) * n, (void **)&e->md_lcus) ||
+        svt_amd_host_alloc(lane, sizeof(SvtAmdOisLcuResult) * n, (void **)&e->md_ois))
+        svt_hook_die("out of memory (mode-decision picture records)");
+    if (e->wide)
+        for (int k = 0; k < 3; k++)
+            if (svt_amd_host_alloc(lane, sizeof(uint16_t) * (size_t)(e->width >> (k ? 1 : 0)) * (e->height >> (k ? 1 : 0)), (void **)&e->md_src16[k]))
+                svt_hook_die("out of memory (10-bit source picture)");
+}
 /* the picture's ONE device call; under e->lock */
 static double g_md_t_fill, g_md_t_call, g_md_t_prepare; /* seconds of host work / of device calls / of picture_prepare inside md_picture, summed (under the entries' locks: racy sums, a report only) */
 static double md_now(void)
@@ -1122,17 +1192,7 @@ static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSe
         return;
     }
     const size_t n = (size_t)e->cap;
-    if (!e->md_out) {
-        const size_t wb = e->wide ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), rb = e->wide ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
-        if (svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcuOut) * n, (void **)&e->md_out) || svt_amd_host_alloc(lane, wb * n, &e->md_works) ||
-            svt_amd_host_alloc(lane, rb * n, &e->md_res) || svt_amd_host_alloc(lane, sizeof(SvtAmdMdLcu) * n, (void **)&e->md_lcus) ||
-            svt_amd_host_alloc(lane, sizeof(SvtAmdOisLcuResult) * n, (void **)&e->md_ois))
-            svt_hook_die("out of memory (mode-decision picture records)");
-        if (e->wide)
-            for (int k = 0; k < 3; k++)
-                if (svt_amd_host_alloc(lane, sizeof(uint16_t) * (size_t)(scs->lumaWidth >> (k ? 1 : 0)) * (scs->lumaHeight >> (k ? 1 : 0)), (void **)&e->md_src16[k]))
-                    svt_hook_die("out of memory (10-bit source picture)");
-    }
+    md_entry_buffers(lane, e);
     SvtAmdMdLcu *lcus = e->md_lcus;
     SvtAmdOisLcuResult *ois = e->md_ois;
     for (size_t i = 0; i < n; i++) {

@@ -39,6 +39,8 @@ void svt_hook_ep_quantize(EncDecContext_t *contextPtr, EB_S16 *quantCoeff, EB_S1
 /* EncodeGenerateRecon of the served LCU: the unit's reconstruction into the picture buffer */
 void svt_hook_ep_recon(EncDecContext_t *contextPtr, EB_U32 originX, EB_U32 originY, EB_U32 tuSize, EbPictureBufferDesc_t *recon);
 void svt_hook_encdec_report(FILE *out);
+/* EbInitEncoder time, device up: lanes, picture objects, mode-decision state and records of every EncDec picture of the pool (svt_hook_encdec.c) */
+void svt_hook_encdec_warmup(void);
 /* SVT_HOOK_ENCODEPASS_REFS: a picture whose LCUs were all encoded on the device is finished there too (deblocking, SAO, padding) and becomes
  * the reference picture of later pictures without an upload.  The SAO wraps tell the encode-pass binding which LCUs the reference ran the
  * decision for and with which rate inputs; the reference cache takes the finished picture. */
@@ -47,5 +49,7 @@ void svt_hook_ep_note_sao(const PictureControlSet_t *pcs, EB_U32 x, EB_U32 y, co
                           int mmSao, int is16);
 /* page-locks the planes of a pooled picture buffer of the encoder once (svt_hook_me.c) */
 void svt_hook_pin_picture(const EbPictureBufferDesc_t *p, size_t bps);
+/* the same at pool-construction time (EbInitEncoder): now if the device context exists, at device start-up otherwise */
+void svt_hook_pin_picture_at_init(const EbPictureBufferDesc_t *p, size_t bps);
 void svt_hook_register_device_reference(const EbPictureBufferDesc_t *p, uint64_t poc, size_t bps, const SvtAmdRefPicture *dev);
 #endif

@@ -130,6 +130,7 @@ static unsigned long counter_sum(int i)
 }
 static void hook_report(void);
 static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight);
+static void pin_deferred(void);
 
 /* SVT_HOOK_TIMELINE (svt_hook_internal.h) */
 #define TL_MAX 65536
@@ -596,6 +597,10 @@ static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
     } else if (!getenv("SVT_HOOK_KEEP_RUNTIME_ENV")) {
         (void)svt_amd_runtime_env_defaults();
     }
+    /* EncDec threads wait 60 - 100 ms for their picture's device call and motion-estimation threads 10 - 20 ms for their picture's lane while the base-layer pictures
+     * are decided by host threads on the same logical processors: waiting threads sleep (the library's opt-in; SVT_HOOK_WAIT=spin keeps the runtime's default) */
+    if (!(getenv("SVT_HOOK_WAIT") && !strcmp(getenv("SVT_HOOK_WAIT"), "spin")) && svt_amd_host_wait_mode(dev ? atoi(dev) : 0, 1))
+        fprintf(stderr, "svt_hook_me: svt_amd_host_wait_mode: %s (host threads will spin in their waits)\n", svt_amd_last_error());
     int rc = svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &ctx);
     for (int i = 0; i < NLANES && !rc; i++)
         step = "svt_amd_context_fork", rc = svt_amd_context_fork(ctx, &g_front[i].lane);
@@ -616,6 +621,9 @@ static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
         return 1;
     }
     g_ctx = ctx;
+    pin_deferred(); /* picture pools built before the device came up (the reference-picture pool, EbEncHandle.c:889) */
+    if (!getenv("SVT_HOOK_LAZY_INIT"))
+        svt_hook_encdec_warmup();
     g_nlcu = ((lumaWidth + 63u) / 64u) * ((lumaHeight + 63u) / 64u);
     g_verbose = getenv("SVT_HOOK_VERBOSE") != NULL;
     fprintf(stderr, "svt_hook_me: motion estimation on %s\n", svt_amd_version());
@@ -1410,21 +1418,61 @@ static int g_inter_state;
 /* Page-locks the planes of one of the encoder's pooled picture buffers (EbPictureBufferDescCtor / EbReconPictureBufferDescCtor allocate lumaSize / chromaSize
  * samples per plane, Codec/EbPictureBufferDesc.c:59-94, :149-166) for the life of the encoder: svt_amd_host_register remembers the range, a second call is a
  * lookup; hook_teardown releases them before EbDeinitEncoder frees the buffers.  SVT_HOOK_PIN_HOST=0 leaves the buffers pageable. */
-void svt_hook_pin_picture(const EbPictureBufferDesc_t *p, size_t bps)
+/* Page-locking a buffer is a call into the driver that updates the device's address space: made while mode-decision kernels of other pictures are running it can
+ * take hundreds of milliseconds, and the runtime's other calls queue behind it (profiles/r05_v: a picture's plane copies issued 720 ms apart).  The encoder's
+ * picture pools are therefore pinned where they are BUILT (EbInitEncoder: svt_hook_pin_pool from the EbSystemResourceCtor binding), not where a picture first uses
+ * one of their buffers; buffers built before the device context exists wait in a list that device start-up empties. */
+static struct { const EbPictureBufferDesc_t *p; size_t bps; } g_pin_later[1024];
+static int g_pin_later_n;
+static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
+static unsigned long g_pinned_at_init, g_pinned_late;
+static int g_pin_init_done; /* the pools have been built: a buffer first seen now is pinned inside the encode */
+static int pin_enabled(void)
 {
     static int state; /* 0 unknown, 1 on, -1 off */
     if (!state) {
         const char *v = getenv("SVT_HOOK_PIN_HOST");
         state = (v && !strcmp(v, "0")) ? -1 : 1;
     }
-    if (state < 0 || !g_ctx || !p)
-        return;
+    return state > 0;
+}
+static void pin_now(const EbPictureBufferDesc_t *p, size_t bps)
+{
     if (p->bufferY)
         (void)svt_amd_host_register(g_ctx, p->bufferY, (size_t)p->lumaSize * bps);
     if (p->bufferCb)
         (void)svt_amd_host_register(g_ctx, p->bufferCb, (size_t)p->chromaSize * bps);
     if (p->bufferCr)
         (void)svt_amd_host_register(g_ctx, p->bufferCr, (size_t)p->chromaSize * bps);
+}
+void svt_hook_pin_picture(const EbPictureBufferDesc_t *p, size_t bps)
+{
+    if (!pin_enabled() || !g_ctx || !p)
+        return;
+    pin_now(p, bps);
+}
+/* at pool-construction time: now if the device is up, when it comes up otherwise */
+void svt_hook_pin_picture_at_init(const EbPictureBufferDesc_t *p, size_t bps)
+{
+    if (!pin_enabled() || !p)
+        return;
+    pthread_mutex_lock(&g_pin_lock);
+    if (g_ctx) {
+        pin_now(p, bps);
+        g_pinned_at_init++;
+    } else if (g_pin_later_n < (int)(sizeof(g_pin_later) / sizeof(g_pin_later[0]))) {
+        g_pin_later[g_pin_later_n].p = p, g_pin_later[g_pin_later_n].bps = bps;
+        g_pin_later_n++;
+    }
+    pthread_mutex_unlock(&g_pin_lock);
+}
+static void pin_deferred(void) /* device start-up, g_ctx set */
+{
+    pthread_mutex_lock(&g_pin_lock);
+    for (int i = 0; i < g_pin_later_n; i++)
+        pin_now(g_pin_later[i].p, g_pin_later[i].bps), g_pinned_at_init++;
+    g_pin_later_n = 0;
+    pthread_mutex_unlock(&g_pin_lock);
 }
 
 /* must hold g_lock.  *slot = the cache slot, PINNED: the caller unpins it (ref_unpin / svt_hook_release_references) when it no longer reads the device copy */
@@ -2133,6 +2181,8 @@ static void hook_report(void)
                 g_fl_gpu, g_fl_cpu, g_cl_gpu, g_cl_cpu, g_recon_gpu, g_intra_gpu, g_intra4_gpu, g_md_intra_gpu, g_md_intra_ol_gpu, g_md_intra4_gpu,
                 g_inter_gpu, g_inter16_gpu, g_md_inter_gpu, g_quant_gpu, g_quant_pm_gpu, g_sao_gpu);
     }
+    if (g_pinned_at_init)
+        fprintf(out, "svt_hook_me: %lu picture buffers of the encoder's pools page-locked while the pools were built (EbInitEncoder)\n", g_pinned_at_init);
     if (g_unpack_jobs)
         fprintf(out, "svt_hook_me: 16-bit input -> 8-bit + 2-bit planes (UnPack2D) on the GPU: %lu jobs, %lu samples\n", g_unpack_jobs, g_unpack_samples);
     if (sbo_on())

@@ -136,7 +136,7 @@ static int context_common_create(SvtAmdContext *ctx)
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
-    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming | hipEventBlockingSync)); /* waited on for milliseconds by several host threads: they sleep */
     const int nlcu = ((ctx->max_w + 63) / 64) * ((ctx->max_h + 63) / 64);
     if (hipMalloc((void **)&ctx->d_me_scratch, (size_t)nlcu * sizeof(SvtAmdMeLcuResult)) != hipSuccess ||
         hipMalloc(&ctx->d_prep_jobs, 128 * SVT_AMD_MAX_BATCH) != hipSuccess ||
@@ -171,6 +171,12 @@ int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out)
  * starts, i.e. at the process's first HIP call - so this is a call the HOST makes, knowingly, before that (the encoder binding does, at
  * EbInitEncoder time: integration/svt_hook_me.c).  The library itself never touches the environment of the process that
  * loaded it; a setting the user made wins. */
+extern "C" int svt_amd_host_wait_mode(int device_ordinal, int blocking)
+{
+    HIP_TRY(hipSetDevice(device_ordinal));
+    HIP_TRY(hipSetDeviceFlags(blocking ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto));
+    return SVT_AMD_OK;
+}
 extern "C" int svt_amd_runtime_env_defaults(void) { return setenv("GPU_MAX_HW_QUEUES", "24", 0) == 0 ? SVT_AMD_OK : SVT_AMD_ERR_RESOURCES; }
 
 /* Job descriptors of a launch (a few KB) go host -> device through a pinned ring the GPU reads itself: a copy kernel on the
@@ -483,6 +489,21 @@ extern "C" int svt_amd_host_register(SvtAmdContext *ctx, const void *h_ptr, size
         (void)hipGetLastError();
     g_reg.push_back({h_ptr, bytes, e == hipSuccess});
     return SVT_AMD_OK;
+}
+/* the device's view of [h_ptr, h_ptr + bytes) if the range lies inside a page-locked registration, nullptr otherwise */
+const void *svt_amd_registered_device_ptr(const void *h_ptr, size_t bytes)
+{
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    for (const HostReg &r : g_reg)
+        if (r.ok && (const uint8_t *)h_ptr >= (const uint8_t *)r.p && (const uint8_t *)h_ptr + bytes <= (const uint8_t *)r.p + r.bytes) {
+            void *d = nullptr;
+            if (hipHostGetDevicePointer(&d, const_cast<void *>(r.p), 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            return (const uint8_t *)d + ((const uint8_t *)h_ptr - (const uint8_t *)r.p);
+        }
+    return nullptr;
 }
 extern "C" int svt_amd_host_unregister_all(SvtAmdContext *ctx)
 {

@@ -39,6 +39,7 @@ struct SvtAmdEncDecPicture {
     unsigned epoch;
     int nlcu;
     SvtAmdCabacCost *d_cost;
+    SvtAmdCabacCost *h_cost;   /* page-locked staging of the caller's (pageable) rate tables: the copy to d_cost stays asynchronous */
     bool has_ref[2], has_cost;
     /* the in-loop filters behind the encode pass: the deblocked picture and the picture after SAO live beside the un-deblocked one (the SAO
      * statistics need both, svt_amd_encdec_picture_sao); same pitches as rec[] */

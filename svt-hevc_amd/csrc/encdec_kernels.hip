@@ -118,7 +118,8 @@ static int picture_create(SvtAmdContext *ctx, uint16_t width, uint16_t height, i
     if (hipMalloc((void **)&p->d.mode_map, p->map_bytes) != hipSuccess)
         return SVT_AMD_ERR_RESOURCES;
     p->nlcu = ((width + 63) / 64) * ((height + 63) / 64);
-    if (hipMalloc((void **)&p->d_cost, sizeof(SvtAmdCabacCost)) != hipSuccess || rate_tables_once(ctx->device))
+    if (hipMalloc((void **)&p->d_cost, sizeof(SvtAmdCabacCost)) != hipSuccess || hipHostMalloc((void **)&p->h_cost, sizeof(SvtAmdCabacCost), hipHostMallocDefault) != hipSuccess ||
+        rate_tables_once(ctx->device))
         return SVT_AMD_ERR_RESOURCES;
     p->d.cost = p->d_cost;
     if (hipMalloc((void **)&p->d_sync, sizeof(unsigned) * (size_t)(1 + 2 * p->nlcu)) != hipSuccess)
@@ -186,6 +187,8 @@ extern "C" int svt_amd_encdec_picture_destroy(SvtAmdContext *ctx, SvtAmdEncDecPi
         (void)hipFree(pic->d.prof);
     if (pic->d_cost)
         (void)hipFree(pic->d_cost);
+    if (pic->h_cost)
+        (void)hipHostFree(pic->h_cost);
     svt_amd_md_state_free(pic);
     if (pic->ev_written)
         (void)hipEventDestroy(pic->ev_written);
@@ -228,7 +231,8 @@ extern "C" int svt_amd_encdec_picture_set_inter(SvtAmdContext *ctx, SvtAmdEncDec
         E.size[0] = (int32_t)(r->strideY * (r->height + 2 * r->originY)), E.size[1] = (int32_t)(r->strideC * ((r->height + 2 * r->originY) / 2));
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, ctx->stream)); /* pageable source: staged before the call returns */
+    memcpy(pic->h_cost, cost, sizeof(*cost)); /* a pageable source would make the copy a staged one the runtime completes inside the call, behind whatever its queue runs */
+    HIP_TRY(hipMemcpyAsync(pic->d_cost, pic->h_cost, sizeof(*cost), hipMemcpyHostToDevice, ctx->stream));
     pic->has_cost = true;
     return SVT_AMD_OK;
 }

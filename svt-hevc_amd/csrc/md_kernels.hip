@@ -54,6 +54,7 @@
 #define MD_LEAF_CALL __noinline__ /* the heavy leaves of the unit chain (interpolation, transform unit) as functions: one copy of their code and registers of their own */
 #endif
 #include <chrono>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include "md_logic.h"
@@ -1643,7 +1644,15 @@ struct SvtAmdMdState {
     SvtAmdMdInter *d_X;
     SvtAmdMeLcuResult *d_me;
     SvtAmdTmvpLcu *d_tmvp;
+    /* the call's small inputs (picture controls, inter controls, rate tables) come from the caller's stack / the encoder's heap: pageable memory, whose "asynchronous"
+     * copy is a staged one the runtime completes inside the call - behind whatever its queue is running (profiles/r05_v: plane copies of one call issued 720 ms apart
+     * while other pictures' mode-decision kernels ran).  They go through this page-locked block instead */
+    uint8_t *h_stage;
+    void *retired[8];              /* source planes outgrown by a caller's row pitch */
+    int n_retired;
 };
+static constexpr size_t MD_STAGE_P = 0, MD_STAGE_X = (sizeof(SvtAmdMdPicture) + 63) & ~(size_t)63, MD_STAGE_COST = MD_STAGE_X + ((sizeof(SvtAmdMdInter) + 63) & ~(size_t)63),
+                        MD_STAGE_BYTES = MD_STAGE_COST + ((sizeof(SvtAmdCabacCost) + 63) & ~(size_t)63);
 
 void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
 {
@@ -1656,10 +1665,14 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
+    for (int i = 0; i < m->n_retired; i++)
+        (void)hipFree(m->retired[i]);
     if (m->ev_k0)
         (void)hipEventDestroy(m->ev_k0);
     if (m->ev_k1)
         (void)hipEventDestroy(m->ev_k1);
+    if (m->h_stage)
+        (void)hipHostFree(m->h_stage);
     free(m);
     pic->md = nullptr;
 }
@@ -1682,8 +1695,12 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     m->work_bytes = bps == 2 ? sizeof(SvtAmdLcuWork16) : sizeof(SvtAmdLcuWork), m->result_bytes = bps == 2 ? sizeof(SvtAmdLcuResult16) : sizeof(SvtAmdLcuResult);
     bool ok = hipMalloc((void **)&m->d.md_rec, pic->plane_bytes[0] / bps) == hipSuccess && hipMalloc((void **)&m->d.md_info, m->info_bytes) == hipSuccess;
     for (int k = 0; k < 3 && ok; k++) {
-        ok = hipMalloc((void **)&m->d_src[k], pic->plane_bytes[k] / bps) == hipSuccess;
-        m->src_cap[k] = ok ? pic->plane_bytes[k] / bps : 0;
+        /* room for the caller's row pitch (an encoder's padded input pictures: width + up to 512 columns): growing the plane later means a hipFree, which waits for every
+         * kernel on the device - the other pictures' mode decisions - with the runtime's memory lock held (profiles/r05_aa: 90 - 300 ms, other threads' copies queueing behind it) */
+        const size_t roomy = (size_t)((pic->d.width + 512) >> (k ? 1 : 0)) * (pic->d.height >> (k ? 1 : 0)) + 64;
+        const size_t cap = roomy > pic->plane_bytes[k] / bps ? roomy : pic->plane_bytes[k] / bps;
+        ok = hipMalloc((void **)&m->d_src[k], cap) == hipSuccess;
+        m->src_cap[k] = ok ? cap - 64 : 0;
         if (bps == 2)
             ok = ok && hipMalloc((void **)&m->d_src16[k], pic->plane_bytes[k]) == hipSuccess;
     }
@@ -1695,7 +1712,8 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     ok = ok && hipMalloc((void **)&m->d.md_mv, m->mv_bytes) == hipSuccess && hipMalloc((void **)&m->d_X, sizeof(SvtAmdMdInter)) == hipSuccess &&
          hipMalloc((void **)&m->d_me, sizeof(SvtAmdMeLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_tmvp, sizeof(SvtAmdTmvpLcu) * (n + 1)) == hipSuccess;
     ok = ok && hipMalloc((void **)&m->d_md_done, sizeof(unsigned) * n) == hipSuccess && hipMemset(m->d_md_done, 0, sizeof(unsigned) * n) == hipSuccess;
-    ok = ok && hipEventCreate(&m->ev_k0) == hipSuccess && hipEventCreate(&m->ev_k1) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&m->h_stage, MD_STAGE_BYTES, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreate(&m->ev_k0) == hipSuccess && hipEventCreateWithFlags(&m->ev_k1, hipEventBlockingSync) == hipSuccess; /* ev_k1: the caller sleeps through the kernel */
     if (!ok) {
         svt_amd_set_error("hipMalloc (mode-decision picture state) failed");
         svt_amd_md_state_free(pic);
@@ -1719,6 +1737,18 @@ __global__ __launch_bounds__(256) void k_msb_view(const uint16_t *__restrict__ i
         for (size_t k = i; k < n; k++)
             out[k] = (uint8_t)(in[k] >> 2);
     }
+}
+/* a source plane from page-locked HOST memory into HBM by a kernel of the call's own stream (the device reads the host over PCIe): the runtime's
+ * hipMemcpyAsync of such a plane - a DMA-engine transfer - blocked the calling thread for one to four mode-decision kernel durations whenever other
+ * pictures' kernels were running (profiles/r05_y: 50 - 420 ms inside the call, a tenth of the calls); a launch never does.  src: any alignment; dst: 16 bytes */
+typedef uint4 __attribute__((aligned(1))) md_u128u;
+__global__ __launch_bounds__(256) void k_md_fetch_plane(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t bytes)
+{
+    const size_t n16 = bytes >> 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        *(uint4 *)(dst + i * 16) = *(const md_u128u *)(src + i * 16);
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15))
+        dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
 }
 static int msb_view(hipStream_t st, const void *in16, uint8_t *out8, size_t samples)
 {
@@ -1760,13 +1790,35 @@ int md_wg_budget(int device)
         cus[device & 63] = hipGetDeviceProperties(&pr, device) == hipSuccess ? pr.multiProcessorCount : 256;
     }
     const int c = cus[device & 63];
-    return c - c / 16;
+    static const int forced = getenv("SVT_AMD_MD_WG_BUDGET") ? atoi(getenv("SVT_AMD_MD_WG_BUDGET")) : 0; /* measurement */
+    return forced > 0 ? forced : c - c / 16;
+}
+/* SVT_AMD_MD_FLIGHT_STATS=<file> (measurement): one line appended when the process ends - calls, time spent waiting for a place, wide / narrow grants */
+struct FlightStats {
+    std::atomic<unsigned long long> calls{0}, wide{0}, wait_us{0}, run_us{0}, wgs_seen{0};
+    ~FlightStats()
+    {
+        const char *path = getenv("SVT_AMD_MD_FLIGHT_STATS");
+        FILE *f = calls && path ? fopen(path, "a") : nullptr;
+        if (!f)
+            return;
+        fprintf(f, "svt_amd: mode-decision launches: %llu calls (%llu at the wide grid), waiting for a place %.1f ms a call, launch -> kernel done %.1f ms a call, "
+                   "%.1f workgroups of other calls in flight at a grant (mean)\n", (unsigned long long)calls, (unsigned long long)wide, 1e-3 * (double)wait_us / (double)calls,
+                1e-3 * (double)run_us / (double)calls, (double)wgs_seen / (double)calls);
+        fclose(f);
+    }
+} g_flight_stats;
+double flight_now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 struct MdFlight {
     int held = 0; /* workgroups this call holds */
+    double t_granted = 0;
     /* waits until the launch fits; returns the grid granted: `wide` when the device is nearly idle, `narrow` otherwise */
     int acquire(int budget, int wide, int narrow, int prio)
     {
+        const double t0 = flight_now_us();
         std::unique_lock<std::mutex> l(g_flight_mu);
         const FlightWaiter me = {prio, g_flight_ticket++};
         g_flight_wait.push_back(me);
@@ -1788,8 +1840,11 @@ struct MdFlight {
                 g_flight_wait.erase(g_flight_wait.begin() + (long)i);
                 break;
             }
+        g_flight_stats.calls++, g_flight_stats.wide += grant == wide && wide != narrow, g_flight_stats.wgs_seen += (unsigned long long)g_flight_wgs;
         g_flights++, g_flight_wgs += grant, held = grant;
         l.unlock();
+        t_granted = flight_now_us();
+        g_flight_stats.wait_us += (unsigned long long)(t_granted - t0);
         g_flight_cv.notify_all(); /* the next in line may fit as well */
         return grant;
     }
@@ -1797,6 +1852,7 @@ struct MdFlight {
     {
         if (!held)
             return;
+        g_flight_stats.run_us += (unsigned long long)(flight_now_us() - t_granted);
         {
             std::lock_guard<std::mutex> l(g_flight_mu);
             g_flights--, g_flight_wgs -= held;
@@ -1806,6 +1862,37 @@ struct MdFlight {
     }
     ~MdFlight() { release(); }
 };
+}
+
+/* the kernel's dynamic LDS size, once per device */
+static int md_kernel_attributes(int device)
+{
+    static std::mutex mu;
+    static bool attr[64];
+    std::lock_guard<std::mutex> g(mu);
+    if (!attr[device & 63]) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint8_t>)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint8_t>)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint16_t>)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint16_t>)));
+        attr[device & 63] = true;
+    }
+    return SVT_AMD_OK;
+}
+/* everything the first svt_amd_md_encode_picture[_inter] call on this picture object would allocate (device state, page-locked staging, events), made now - by a host that
+ * builds its picture objects before the clock starts (the encoder binding: EbInitEncoder) */
+extern "C" int svt_amd_md_picture_warmup(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic)
+{
+    if (!ctx || !pic)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = rate_tables_once(ctx->device);
+    SvtAmdMdState *m = nullptr;
+    if (!rc)
+        rc = md_state(pic, &m);
+    if (!rc)
+        rc = md_kernel_attributes(ctx->device);
+    return rc;
 }
 
 /* bps: bytes per sample of the source planes, the work / result records and the picture object (1, or 2 = a 10-bit picture: the mode decision on the 8 MSBs of source
@@ -1892,8 +1979,21 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
             HIP_TRY(hipStreamWaitEvent(st, ev, 0));
     /* debug (SVT_AMD_MD_TIMING): host clock around the call's three parts, with a stream synchronisation after each - one line per call on stderr */
     static const bool timing = getenv("SVT_AMD_MD_TIMING") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    if (timing)
+        HIP_TRY(hipStreamSynchronize(st)); /* what the stream still had to do + the front half's records */
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_up = t_begin, t_kernel = t_begin;
+    auto t_tick = t_begin;
+    auto tick = [&](const char *what) { /* SVT_AMD_MD_TIMING: a host call of the upload section that took more than 5 ms names itself */
+        if (!timing)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double, std::milli>(now - t_tick).count();
+        if (d > 5.0)
+            fprintf(stderr, "svt_amd_md_encode_picture: %.1f ms inside the host call '%s'\n", d, what);
+        t_tick = now;
+    };
     const void *hs[3] = {src_y, src_cb, src_cr};
     /* 8-bit source planes travel as ONE linear transfer each, in the host's row pitch (the device copy keeps that pitch): a strided copy is a shader kernel of the runtime
      * (__amd_rocclr_copyBufferRect: 2 ms per plane, and 40 ms when the mode-decision launches of other pictures hold the CUs - profiles/r05_b), a linear one from page-locked
@@ -1905,13 +2005,22 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
             const size_t hstride = k ? stride_c : stride_y, need = hstride * (ph - 1) + pw;
             if (m->src_cap[k] < need) {
                 HIP_TRY(hipStreamSynchronize(st));
-                if (m->d_src[k])
+                if (m->d_src[k] && m->n_retired < 8)
+                    m->retired[m->n_retired++] = m->d_src[k]; /* freed with the state: a hipFree here would wait for every kernel on the device */
+                else if (m->d_src[k])
                     (void)hipFree(m->d_src[k]);
                 m->d_src[k] = nullptr, m->src_cap[k] = 0;
                 HIP_TRY(hipMalloc((void **)&m->d_src[k], need + 64));
                 m->src_cap[k] = need;
             }
-            HIP_TRY(hipMemcpyAsync(m->d_src[k], hs[k], need, hipMemcpyHostToDevice, st));
+            const uint8_t *dv = (const uint8_t *)svt_amd_registered_device_ptr(hs[k], need);
+            if (dv) {
+                hipLaunchKernelGGL(k_md_fetch_plane, dim3(k ? 32 : 96), dim3(256), 0, st, m->d_src[k], dv, need);
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipMemcpyAsync(m->d_src[k], hs[k], need, hipMemcpyHostToDevice, st));
+            }
+            tick(k ? "source chroma plane copy" : "source luma plane copy");
         } else if (bps == 1) {
             HIP_TRY(hipMemcpy2DAsync(m->d_src[k], pic->d.pitch[k], hs[k], k ? stride_c : stride_y, pw, ph, hipMemcpyHostToDevice, st));
         } else { /* strides in samples */
@@ -1940,22 +2049,30 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
             }
     }
     HIP_TRY(hipMemcpyAsync(m->d_lcus, lcus, sizeof(SvtAmdMdLcu) * (size_t)n, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(m->d_P, P, sizeof(*P), hipMemcpyHostToDevice, st));
+    tick("LCU controls copy");
+    memcpy(m->h_stage + MD_STAGE_P, P, sizeof(*P)); /* (the block is free: the previous call on this object returned after its stream had drained) */
+    HIP_TRY(hipMemcpyAsync(m->d_P, m->h_stage + MD_STAGE_P, sizeof(*P), hipMemcpyHostToDevice, st));
     if (cost) {
-        HIP_TRY(hipMemcpyAsync(pic->d_cost, cost, sizeof(*cost), hipMemcpyHostToDevice, st));
+        memcpy(m->h_stage + MD_STAGE_COST, cost, sizeof(*cost));
+        HIP_TRY(hipMemcpyAsync(pic->d_cost, m->h_stage + MD_STAGE_COST, sizeof(*cost), hipMemcpyHostToDevice, st));
         pic->has_cost = true;
     }
     m->d.X = nullptr, m->d.me = nullptr, m->d.tmvp = nullptr;
     if (X) {
-        HIP_TRY(hipMemcpyAsync(m->d_X, X, sizeof(*X), hipMemcpyHostToDevice, st));
+        memcpy(m->h_stage + MD_STAGE_X, X, sizeof(*X));
+        HIP_TRY(hipMemcpyAsync(m->d_X, m->h_stage + MD_STAGE_X, sizeof(*X), hipMemcpyHostToDevice, st));
+        tick("picture / inter controls copies");
         if (me)
             HIP_TRY(hipMemcpyAsync(m->d_me, me, sizeof(SvtAmdMeLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
+        tick("ME records copy");
         if (X->tmvp_enable) {
             HIP_TRY(hipMemcpyAsync(m->d_tmvp, tmvp, sizeof(SvtAmdTmvpLcu) * (size_t)n, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemsetAsync(m->d_tmvp + n, 0, sizeof(SvtAmdTmvpLcu), st));
+            tick("motion-field copy + fill");
         }
         m->d.X = m->d_X, m->d.me = me ? m->d_me : d_me_slot, m->d.tmvp = m->d_tmvp;
         HIP_TRY(hipMemsetAsync(m->d.md_mv, 0, m->mv_bytes, st));
+        tick("mv fill");
     }
     int n_active = n;
     const unsigned *d_order = pic->d_sync + 1 + n;
@@ -1975,20 +2092,12 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     HIP_TRY(hipMemsetAsync(m->d.md_info, 0xFF, m->info_bytes, st));
     HIP_TRY(hipMemsetAsync(m->d_results, 0, m->result_bytes * (size_t)n, st));
     HIP_TRY(hipMemsetAsync(m->d_works, 0, m->work_bytes * (size_t)n, st));
-    {
-        static std::mutex mu;
-        static bool attr[64];
-        std::lock_guard<std::mutex> g(mu);
-        if (!attr[ctx->device & 63]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint8_t>)));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint8_t>)));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint16_t>)));
-            HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint16_t>)));
-            attr[ctx->device & 63] = true;
-        }
-    }
+    tick("OIS copy + five fills");
+    if ((rc = md_kernel_attributes(ctx->device)) != 0)
+        return rc;
     if (timing) {
         HIP_TRY(hipStreamSynchronize(st));
+        tick("stream synchronisation after the uploads");
         t_up = std::chrono::steady_clock::now();
     }
     /* the wavefront is at most min((W/64 + 1) / 2, H/64) LCUs wide; the mode decision runs ahead of the encode pass, so twice that many workgroups
@@ -2004,6 +2113,9 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         const int forced = fg ? atoi(fg) : 0;
         if (forced > 0)
             grid = narrow = forced;
+        static const int fnarrow = getenv("SVT_AMD_MD_NARROW") ? atoi(getenv("SVT_AMD_MD_NARROW")) : 0;
+        if (fnarrow > 0)
+            narrow = fnarrow;
     }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
     narrow = narrow > grid ? grid : narrow;
@@ -2056,8 +2168,8 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "svt_amd_md_encode_picture%s: %d LCUs, inputs up %.2f ms, kernel %.2f ms, records down %.2f ms\n", X ? "_inter" : "", n_active, ms(t_begin, t_up),
-                ms(t_up, t_kernel), ms(t_kernel, t_end));
+        fprintf(stderr, "svt_amd_md_encode_picture%s: layer %d, %d LCUs, stream + front-half records ready %.2f ms, inputs up %.2f ms, kernel %.2f ms, records down %.2f ms\n", X ? "_inter" : "",
+                (int)P->temporal_layer, n_active, ms(t_call, t_begin), ms(t_begin, t_up), ms(t_up, t_kernel), ms(t_kernel, t_end));
     }
     return SVT_AMD_OK;
 }

@@ -119,6 +119,8 @@ struct SvtAmdContext {
 /* launch descriptors (job arrays) reach the device without the copy engines: see context.hip */
 int svt_amd_upload_descriptors(SvtAmdContext *ctx, void *d_dst, const void *src, size_t bytes);
 int svt_amd_ctx_scratch(SvtAmdContext *ctx, size_t bytes, uint8_t **out);
+/* context.hip: the device's view of a range inside a svt_amd_host_register'ed buffer, or nullptr */
+const void *svt_amd_registered_device_ptr(const void *h_ptr, size_t bytes);
 
 void svt_amd_set_error(const char *fmt, ...);
 #define HIP_TRY(expr)                                                                      \

@@ -35,6 +35,8 @@ with tempfile.TemporaryDirectory() as td:
                     env["SVT_HOOK_PCS_POOL"] = pool
                 rep = os.path.join(td, "report.txt")
                 env["SVT_HOOK_REPORT"] = rep
+                fst = os.path.join(td, "flights.txt")
+                env["SVT_AMD_MD_FLIGHT_STATS"] = fst
                 try:
                     r = E.run_app(E.HIP_APP, yuv, w, h, frames, args + ["-lp", lp], os.path.join(td, "hip.265"), env=dict({"SVT_HOOK_WATCHDOG": "15"}, **env), nb=16,
                                   timeout=int(os.environ.get("SWEEP_TIMEOUT", "120")))
@@ -47,5 +49,9 @@ with tempfile.TemporaryDirectory() as td:
                         if "mode decision:" in line and "pictures (" in line:
                             cov = line.split("mode decision:")[1].strip()[:120]
                     os.unlink(rep)
+                flights = ""
+                if os.path.exists(fst):
+                    flights = open(fst).read().strip().replace("svt_amd: mode-decision launches: ", "")
+                    os.unlink(fst)
                 print(json.dumps({"lp": int(lp), "mode": mode, "pool": int(pool), "extra": extra, "frames": frames, "fps": r["fps"], "identical": r["md5"] == ref[lp]["md5"],
-                                  "reference_fps": ref[lp]["fps"], "coverage": cov}), flush=True)
+                                  "reference_fps": ref[lp]["fps"], "coverage": cov, "flights": flights}), flush=True)

@@ -12,7 +12,8 @@ sys.path.insert(0, "tests")
 import svtlib as S
 S.write_clip("/tmp/md_clip.yuv", "motion", 3840, 2160, 16, 7)
 PY
-SVT_HOOK_MD=1 SVT_HOOK_REPORT=$O/report.txt timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- integration/_build/SvtHevcEncApp_hip -i /tmp/md_clip.yuv -w 3840 -h 2160 -n $N -nb 16 -b /tmp/md.265 -encMode 7 -pred-struct 2 -hierarchical-levels 2 -sao 1 -fps 60 -q 32 -asm 1 -lp $LP > $O/app.txt 2> $O/prof.err < /dev/null
+shift 3 2>/dev/null
+env SVT_HOOK_MD=${TL_MD:-pb} SVT_HOOK_REPORT=$O/report.txt "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- integration/_build/SvtHevcEncApp_hip -i /tmp/md_clip.yuv -w 3840 -h 2160 -n $N -nb 16 -b /tmp/md.265 -encMode 7 -pred-struct 2 -hierarchical-levels 2 -sao 1 -fps 60 -q 32 -asm 1 -lp $LP > $O/app.txt 2> $O/prof.err < /dev/null
 grep "Average Speed" $O/app.txt
 python - "$O" <<'PY'
 import csv, glob, sys
@@ -24,6 +25,10 @@ for f in glob.glob(O + "/tr/**/*kernel_trace.csv", recursive=True):
         rec = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), n[:40])
         (md if "k_md_encode_picture" in n else other).append(rec)
 md.sort()
+with open(O + "/events.txt", "w") as ev:   # every kernel of the run: start end (us since the first) queue name - for offline questions
+    allk = sorted(md + other)
+    for s_, e_, q_, n_ in allk:
+        print("%.1f %.1f %s %s" % ((s_ - allk[0][0]) / 1e3, (e_ - allk[0][0]) / 1e3, q_, n_.replace(" ", "_")), file=ev)
 if not md:
     print("no mode-decision kernel in the trace"); sys.exit(0)
 t0 = md[0][0]
