@@ -520,6 +520,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    # ---- the headline first (N = 1): md5-gated encoded fps of the whole encoder with the HIP path bound in.  The encoder is a child process with two dozen streams of its
+    # own; measured BEFORE this process opens the device, so that the two do not share the part's hardware queues (the same leg after the loops below: 87-97 fps where the
+    # stand-alone sweeps of the same binary read 103-117, profiles/r05_ah_bench.json).  N > 1 needs the process group for its barrier and runs it where it always did.
+    enc = None
+    if world == 1 and not a.inner and not a.no_encoder_fps:
+        enc = encoded_fps_leg(CONFIGS[a.config]["enc"], a.steps, rank, local_rank, world, None)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -700,8 +706,7 @@ def main():
     xchg = recon_exchange_leg(lib, root, rank, world, dev) if (world > 1 and not a.inner) else None
 
     # ---- the headline: md5-gated encoded fps of the whole encoder with the HIP path bound in -------------------------------------
-    enc = None
-    if not a.inner and not a.no_encoder_fps:
+    if world > 1 and not a.inner and not a.no_encoder_fps:
         enc = encoded_fps_leg(cfg["enc"], a.steps, rank, local_rank, world, dev)
 
     if rank == 0 and not a.inner:
