@@ -459,3 +459,61 @@ def test_md_encode_picture_inter16_decides_on_the_8_msbs_and_encodes_the_10_bit_
         lib.svt_amd_encdec_picture_destroy(ctx, pic)
     finally:
         lib.svt_amd_context_destroy(ctx)
+
+
+def test_md_after_the_warm_up_with_page_locked_padded_source_planes(product):
+    """What the encoder binding does since round 5: the picture object's mode-decision state is made BEFORE the first call (svt_amd_md_picture_warmup), the source planes
+    live in page-locked buffers with the encoder's row pitch (svt_amd_host_register: the call fetches them by a kernel of its own stream), host threads sleep in their waits
+    (svt_amd_host_wait_mode).  Decisions, work and result records must be those of the plain call on pageable, tightly pitched planes."""
+    lib = product
+    sig(lib)
+    vp = C.c_void_p
+    lib.svt_amd_md_picture_warmup.restype, lib.svt_amd_md_picture_warmup.argtypes = C.c_int, [vp, vp]
+    lib.svt_amd_host_register.restype, lib.svt_amd_host_register.argtypes = C.c_int, [vp, vp, C.c_size_t]
+    lib.svt_amd_host_unregister_all.restype, lib.svt_amd_host_unregister_all.argtypes = C.c_int, [vp]
+    lib.svt_amd_host_wait_mode.restype, lib.svt_amd_host_wait_mode.argtypes = C.c_int, [C.c_int, C.c_int]
+    g = dict(np.load(os.path.join(S.GOLDEN_DIR, "md_b_objects_416x240_m8.npz")))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    wait_rc = lib.svt_amd_host_wait_mode(0, 1)   # a process that has opened the device already (torch, earlier tests) may be refused the change: the call must say so, not crash
+    assert wait_rc in (0, S.ERR_DEVICE if hasattr(S, "ERR_DEVICE") else wait_rc), lib.svt_amd_last_error()
+    ctx, pic, pic2 = vp(), vp(), vp()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0 and lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic2)) == 0
+        want = md_encode_inter(lib, ctx, pic, g, 0, encode=True)
+        assert lib.svt_amd_md_picture_warmup(ctx, pic2) == 0, lib.svt_amd_last_error()
+        assert lib.svt_amd_md_picture_warmup(ctx, pic2) == 0                       # idempotent
+        # padded planes: 48 columns of padding left of the picture, a row pitch of w + 96 (w / 2 + 48 for chroma), the pictures' samples inside
+        pads = []
+        for n, pw, ph in (("src_y", w, h), ("src_cb", w // 2, h // 2), ("src_cr", w // 2, h // 2)):
+            buf = np.full((ph + 8, pw + 96 // (1 if n == "src_y" else 2)), 0x77, np.uint8)
+            off = 48 // (1 if n == "src_y" else 2)
+            buf[4:4 + ph, off:off + pw] = g[n][0]
+            assert lib.svt_amd_host_register(ctx, buf.ctypes.data, buf.nbytes) == 0
+            pads.append((buf, buf[4:, off:]))
+        P, lcus = np.ascontiguousarray(g["pic"][0:1]), np.ascontiguousarray(g["lcu"][0])
+        o = np.ascontiguousarray(g["ois"][0])
+        from test_oracle_md_golden import inter_inputs
+        import torch
+        X, me, tmvp, refs, planes = inter_inputs(g, 0)
+        dev = [[torch.from_numpy(a).cuda() for a in pl] for pl in planes]
+        torch.cuda.synchronize()
+        rs = [S.RefPicture(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), r.strideY, r.strideC, r.originX, r.originY, r.width, r.height) for d, r in zip(dev, refs)]
+        cost = np.ascontiguousarray(g["cost"][0])
+        assert lib.svt_amd_encdec_picture_set_inter(ctx, pic2, C.byref(rs[0]), C.byref(rs[1]), cost.ctypes.data) == 0, lib.svt_amd_last_error()
+        n = len(lcus)
+        out, works, res = np.zeros(n, S.MD_LCU_OUT_DTYPE), np.zeros(n, S.LCU_WORK_DTYPE), np.zeros(n, S.LCU_RESULT_DTYPE)
+        for rep in range(2):
+            rc = lib.svt_amd_md_encode_picture_inter(ctx, pic2, P.ctypes.data, X.ctypes.data, lcus.ctypes.data, pads[0][1].ctypes.data, pads[0][0].shape[1],
+                                                     pads[1][1].ctypes.data, pads[2][1].ctypes.data, pads[1][0].shape[1], o.ctypes.data, 0, me.ctypes.data, 0,
+                                                     tmvp.ctypes.data if tmvp is not None else None, out.ctypes.data, works.ctypes.data, res.ctypes.data)
+            assert rc == 0, lib.svt_amd_last_error()
+            compare_md(out, g["out"][0], "padded page-locked planes, call %d" % rep)       # the reference's own records (fields of leaves no call tested are unspecified)
+            assert np.array_equal(out["split"], want[0]["split"]) and np.array_equal(out["tested"], want[0]["tested"])
+            assert works.tobytes() == want[1].tobytes() and res.tobytes() == want[2].tobytes(), rep
+        assert lib.svt_amd_host_unregister_all(ctx) == 0
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+        lib.svt_amd_encdec_picture_destroy(ctx, pic2)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
+        lib.svt_amd_host_wait_mode(0, 0)
