@@ -154,11 +154,25 @@ void svt_hook_encdec_thread_exit(void)
     if (t_lane)
         lane_release(t_lane);
 }
+/* How many lanes there are: every lane is a stream, i.e. a hardware queue of the device, and the part schedules only so many at once - with the front half's lanes, the
+ * root context and the runtime's own, 16 EncDec lanes made EVERY kernel of the process 20 - 25 % slower from the first launch on (profiles/r05_ai: mode-decision kernels
+ * median 68 -> 90 ms at the same 10 - 12 launches side by side; r05_an: back to 75 ms with 12 + 3 lanes at pool 16).  12 by default (SVT_HOOK_EP_LANES): a picture beyond
+ * waits for a lane holding nothing on the device. */
+static int ep_lanes(void)
+{
+    static int n;
+    if (!n) {
+        const char *v = getenv("SVT_HOOK_EP_LANES");
+        const int want = v ? atoi(v) : 0;
+        n = (want >= 1 && want <= EP_LANES) ? want : 12;
+    }
+    return n;
+}
 static SvtAmdContext *lane_claim(SvtAmdContext *root)
 {
     svt_hook_lock(&g_ep_lock);
     for (;;) {
-        for (int i = 0; i < EP_LANES; i++)
+        for (int i = 0; i < ep_lanes(); i++)
             if (!g_ep_lane_busy[i]) {
                 if (!g_ep_lane[i] && svt_amd_context_fork(root, &g_ep_lane[i]))
                     svt_hook_die("svt_amd_context_fork (encode pass)");
@@ -1050,7 +1064,7 @@ void svt_hook_encdec_warmup(void)
     if (!g_warm_n || !getenv("SVT_HOOK_MD") || getenv("SVT_HOOK_NO_WARMUP") || (g_warm_w & 7) || (g_warm_h & 7))
         return;
     SvtAmdContext *root = svt_hook_device((uint16_t)g_warm_w, (uint16_t)g_warm_h);
-    const int n = g_warm_n < EP_LANES ? g_warm_n : EP_LANES;
+    const int n = g_warm_n < ep_lanes() ? g_warm_n : ep_lanes();
     SvtAmdContext *lanes[EP_LANES];
     for (int i = 0; i < n; i++) /* all at once: a lane given back would be handed out again */
         lanes[i] = lane_claim(root);
@@ -1173,20 +1187,27 @@ static double md_now(void)
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+/* picture-level part of the question "does this picture take the device call": needs no lane (a host-decided base-layer picture must not wait for one - the lanes are
+ * held by the pictures inside their 60 - 100 ms device calls, and the base layer is the encoder's serial chain) */
+static int md_picture_level_ok(SequenceControlSet_t *scs, PictureControlSet_t *pcs, ModeDecisionContext_t *md, SvtAmdMdPicture *P, SvtAmdMdInter *X)
+{
+    const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
+                      scs->staticConfig.rateControlMode != 0; /* per-LCU QP / lambda: not in SvtAmdMdPicture */
+    svt_md_fill_picture(P, scs, pcs, md);
+    const int inter = pcs->sliceType != EB_I_PICTURE;
+    if (inter)
+        svt_md_fill_inter(X, scs, pcs, md);
+    return !(tools || (!inter && g_md_skip_intra) || !(inter ? svt_amd_md_picture_supported_inter(P, X) : svt_amd_md_picture_supported(P)));
+}
 static void md_picture(SvtAmdContext *lane, EpPictureEntry *e, SequenceControlSet_t *scs, PictureControlSet_t *pcs, ModeDecisionContext_t *md)
 {
     const double t_in = md_now();
     double t_dev = 0;
     e->md_picture_plus1 = pcs->pictureNumber + 1, e->md_ok = 0;
-    const int tools = scs->staticConfig.improveSharpness || scs->staticConfig.bitRateReduction || scs->staticConfig.segmentOvEnabled ||
-                      scs->staticConfig.rateControlMode != 0; /* per-LCU QP / lambda: not in SvtAmdMdPicture */
     SvtAmdMdPicture P;
     SvtAmdMdInter X;
-    svt_md_fill_picture(&P, scs, pcs, md);
     const int inter = pcs->sliceType != EB_I_PICTURE;
-    if (inter)
-        svt_md_fill_inter(&X, scs, pcs, md);
-    if (tools || (!inter && g_md_skip_intra) || !(inter ? svt_amd_md_picture_supported_inter(&P, &X) : svt_amd_md_picture_supported(&P))) {
+    if (!md_picture_level_ok(scs, pcs, md, &P, &X)) {
         __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
         svt_hook_timeline("md_host", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_in, md_now());
         return;
@@ -1305,6 +1326,26 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
     if (e && __atomic_load_n(&e->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1) { /* the picture's device call has returned: no lock, no lane */
         ok = e->md_ok;
         goto decided;
+    }
+    if (e) { /* a warmed-up object: whether the picture takes the device call at all is settled without a lane */
+        svt_hook_lock(&e->lock);
+        if (e->md_picture_plus1 != pcs->pictureNumber + 1) {
+            SvtAmdMdPicture P;
+            SvtAmdMdInter X;
+            const double t_in = md_now();
+            if (!md_picture_level_ok(scs, pcs, contextPtr, &P, &X)) {
+                e->md_picture_plus1 = pcs->pictureNumber + 1, e->md_ok = 0;
+                __atomic_add_fetch(&g_md_left_pictures, 1, __ATOMIC_RELAXED);
+                svt_hook_timeline("md_host", pcs->pictureNumber, pcs->temporalLayerIndex, (int)pcs->sliceType, t_in, md_now());
+                __atomic_store_n(&e->md_done_plus1, pcs->pictureNumber + 1, __ATOMIC_RELEASE);
+            }
+        }
+        const int settled = e->md_picture_plus1 == pcs->pictureNumber + 1 && __atomic_load_n(&e->md_done_plus1, __ATOMIC_ACQUIRE) == pcs->pictureNumber + 1;
+        if (settled)
+            ok = e->md_ok;
+        svt_hook_unlock(&e->lock);
+        if (settled)
+            goto decided;
     }
     SvtAmdContext *root = svt_hook_device((uint16_t)scs->lumaWidth, (uint16_t)scs->lumaHeight);
     SvtAmdContext *lane = lane_claim(root);

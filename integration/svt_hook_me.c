@@ -51,7 +51,10 @@
 #include "svt_hook_internal.h"
 
 #define NSLOTS 48   /* device picture slots, keyed by pictureNumber % NSLOTS */
-#define NLANES 8    /* front-end lanes = pictures whose ME / OIS results are in flight or being served */
+#define NLANES_MAX 8
+static int g_nlanes = 4; /* front-end lanes = pictures whose ME / OIS results are in flight or being served (SVT_HOOK_FRONT_LANES=<1..8>).  A lane is a stream is a hardware queue,
+                          * and the device schedules only so many at once (svt_hook_encdec.c: ep_lanes): 4 serve > 1000 pictures/s (a picture holds its lane 4 ms) */
+#define NLANES g_nlanes
 
 /*
  * Front half, pipelined: a picture's first MotionEstimateLcu / OpenLoopIntraSearchLcu call claims a LANE (its own HIP stream
@@ -90,7 +93,7 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_mutex_t g_front_lock = PTHREAD_MUTEX_INITIALIZER; /* entry table + slot table */
 static pthread_cond_t g_front_cv = PTHREAD_COND_INITIALIZER;
 static SvtAmdContext *g_ctx;
-static FrontEntry g_front[NLANES];
+static FrontEntry g_front[NLANES_MAX];
 static uint64_t g_slot_pic[NSLOTS];
 static unsigned long g_ois_pictures, g_ois_lcus;
 static uint32_t g_nlcu;
@@ -601,6 +604,12 @@ static int ensure_context(uint16_t lumaWidth, uint16_t lumaHeight)
      * are decided by host threads on the same logical processors: waiting threads sleep (the library's opt-in; SVT_HOOK_WAIT=spin keeps the runtime's default) */
     if (!(getenv("SVT_HOOK_WAIT") && !strcmp(getenv("SVT_HOOK_WAIT"), "spin")) && svt_amd_host_wait_mode(dev ? atoi(dev) : 0, 1))
         fprintf(stderr, "svt_hook_me: svt_amd_host_wait_mode: %s (host threads will spin in their waits)\n", svt_amd_last_error());
+    {
+        const char *fl = getenv("SVT_HOOK_FRONT_LANES");
+        const int n = fl ? atoi(fl) : 0;
+        if (n >= 1 && n <= NLANES_MAX)
+            g_nlanes = n;
+    }
     int rc = svt_amd_context_create(dev ? atoi(dev) : 0, lumaWidth, mh, NSLOTS, &ctx);
     for (int i = 0; i < NLANES && !rc; i++)
         step = "svt_amd_context_fork", rc = svt_amd_context_fork(ctx, &g_front[i].lane);
