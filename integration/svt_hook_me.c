@@ -543,6 +543,17 @@ static void front_served(FrontEntry *e, unsigned *counter)
     svt_hook_unlock(&g_front_lock);
 }
 
+/* SVT_HOOK_FRONT_VERIFY=1: every MotionEstimateLcu / OpenLoopIntraSearchLcu call is answered by the device AND by the reference code, the two answers are compared and
+ * counted (the reference's stays).  A proof that does not depend on WHEN anything arrives - what a rate-controlled encode needs, whose bitstream does
+ * (tests/test_gpu_e2e_bitstream.py). */
+static unsigned long g_me_verified, g_me_mismatch, g_ois_verified, g_ois_mismatch;
+static int front_verify(void)
+{
+    static int on = -1;
+    if (on < 0)
+        on = getenv("SVT_HOOK_FRONT_VERIFY") != NULL;
+    return on;
+}
 EB_ERRORTYPE __real_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, EB_U32 lcuOriginX, EB_U32 lcuOriginY, MeContext_t *ctx,
                                       EbPictureBufferDesc_t *inputPtr);
 EB_ERRORTYPE __real_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U32 lcuIndex, MotionEstimationContext_t *ctx, EbPictureBufferDesc_t *inputPtr);
@@ -571,6 +582,28 @@ EB_ERRORTYPE __wrap_MotionEstimateLcu(PictureParentControlSet_t *pcs, EB_U32 lcu
         pcs->rcMEdistortion[lcuIndex] = 0;
         for (int i = 0; i < 16; i++)
             pcs->rcMEdistortion[lcuIndex] += pcs->meResults[lcuIndex][5 + i].distortionDirection[0].distortion;
+    }
+    if (front_verify()) { /* SVT_HOOK_FRONT_VERIFY: the reference code answers the same call; its answer stays in the picture, the two are compared */
+        MeCuResults_t dev[SVT_AMD_ME_PU_COUNT];
+        memcpy(dev, pcs->meResults[lcuIndex], sizeof(dev));
+        const EB_U32 rc_dev = scs->staticConfig.rateControlMode ? pcs->rcMEdistortion[lcuIndex] : 0;
+        (void)__real_MotionEstimateLcu(pcs, lcuIndex, lcuOriginX, lcuOriginY, ctx, inputPtr);
+        int bad = scs->staticConfig.rateControlMode && rc_dev != pcs->rcMEdistortion[lcuIndex];
+        for (int pu = 0; pu < SVT_AMD_ME_PU_COUNT && !bad; pu++) {
+            const MeCuResults_t *a = &dev[pu], *b = &pcs->meResults[lcuIndex][pu];
+            bad = a->xMvL0 != b->xMvL0 || a->yMvL0 != b->yMvL0 || a->totalMeCandidateIndex != b->totalMeCandidateIndex;
+            if (pcs->sliceType == EB_B_PICTURE)
+                bad = bad || a->xMvL1 != b->xMvL1 || a->yMvL1 != b->yMvL1;
+            for (int k = 0; k < b->totalMeCandidateIndex && !bad; k++)
+                bad = a->distortionDirection[k].distortion != b->distortionDirection[k].distortion || a->distortionDirection[k].direction != b->distortionDirection[k].direction;
+            if (bad && __atomic_load_n(&g_me_mismatch, __ATOMIC_RELAXED) < 4)
+                fprintf(stderr, "svt_hook_me: FRONT VERIFY picture %llu lcu %u unit %d: device (%d,%d)/(%d,%d) n %u d0 %u, reference (%d,%d)/(%d,%d) n %u d0 %u\n",
+                        (unsigned long long)pcs->pictureNumber, lcuIndex, pu, a->xMvL0, a->yMvL0, a->xMvL1, a->yMvL1, a->totalMeCandidateIndex, a->distortionDirection[0].distortion,
+                        b->xMvL0, b->yMvL0, b->xMvL1, b->yMvL1, b->totalMeCandidateIndex, b->distortionDirection[0].distortion);
+        }
+        __atomic_add_fetch(&g_me_verified, 1, __ATOMIC_RELAXED);
+        if (bad)
+            __atomic_add_fetch(&g_me_mismatch, 1, __ATOMIC_RELAXED);
     }
     __atomic_add_fetch(&g_lcus, 1, __ATOMIC_RELAXED);
     front_served(e, &e->me_left);
@@ -695,6 +728,27 @@ EB_ERRORTYPE __wrap_OpenLoopIntraSearchLcu(PictureParentControlSet_t *pcs, EB_U3
             else
                 b->totalIntraLumaMode[cu - 21] = total[cu];
         }
+    }
+    if (front_verify()) {
+        OisCu32Cu16Results_t da = *a;
+        OisCu8Results_t db = *b;
+        (void)__real_OpenLoopIntraSearchLcu(pcs, lcuIndex, ctx, inputPtr);
+        int bad = 0;
+        for (int cu = 1; cu < SVT_AMD_ME_PU_COUNT && !bad; cu++) { /* the fields the device's records carry for this unit are the fields the reference writes */
+            const OisCandidate_t *x = cu < 21 ? da.sortedOisCandidate[cu] : db.sortedOisCandidate[cu - 21], *y = cu < 21 ? a->sortedOisCandidate[cu] : b->sortedOisCandidate[cu - 21];
+            for (int k = 0; k < nc && !bad; k++) {
+                const uint32_t w = cand[cu * nc + k];
+                bad = ((w & SVT_AMD_OIS_W_DIST) && x[k].distortion != y[k].distortion) || ((w & SVT_AMD_OIS_W_VALID) && x[k].validDistortion != y[k].validDistortion) ||
+                      ((w & SVT_AMD_OIS_W_MODE) && x[k].intraMode != y[k].intraMode);
+            }
+            if (total[cu] != 0xFF)
+                bad = bad || (cu < 21 ? da.totalIntraLumaMode[cu] != a->totalIntraLumaMode[cu] : db.totalIntraLumaMode[cu - 21] != b->totalIntraLumaMode[cu - 21]);
+            if (bad && __atomic_load_n(&g_ois_mismatch, __ATOMIC_RELAXED) < 4)
+                fprintf(stderr, "svt_hook_me: FRONT VERIFY picture %llu lcu %u: open-loop intra search of unit %d differs\n", (unsigned long long)pcs->pictureNumber, lcuIndex, cu);
+        }
+        __atomic_add_fetch(&g_ois_verified, 1, __ATOMIC_RELAXED);
+        if (bad)
+            __atomic_add_fetch(&g_ois_mismatch, 1, __ATOMIC_RELAXED);
     }
     __atomic_add_fetch(&g_ois_lcus, 1, __ATOMIC_RELAXED);
     front_served(e, &e->ois_left);
@@ -2190,6 +2244,9 @@ static void hook_report(void)
                 g_fl_gpu, g_fl_cpu, g_cl_gpu, g_cl_cpu, g_recon_gpu, g_intra_gpu, g_intra4_gpu, g_md_intra_gpu, g_md_intra_ol_gpu, g_md_intra4_gpu,
                 g_inter_gpu, g_inter16_gpu, g_md_inter_gpu, g_quant_gpu, g_quant_pm_gpu, g_sao_gpu);
     }
+    if (front_verify())
+        fprintf(out, "svt_hook_me: front-half verification: %lu MotionEstimateLcu answers compared with the reference code's, %lu differ; %lu OpenLoopIntraSearchLcu answers compared, %lu differ\n",
+                g_me_verified, g_me_mismatch, g_ois_verified, g_ois_mismatch);
     if (g_pinned_at_init)
         fprintf(out, "svt_hook_me: %lu picture buffers of the encoder's pools page-locked while the pools were built (EbInitEncoder)\n", g_pinned_at_init);
     if (g_unpack_jobs)
