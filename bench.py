@@ -121,7 +121,7 @@ HIP_LP = 32   # logical processors the hooked encoder is run with (see encoded_f
 # picture takes the device 0.45 s along its wavefront (35 intra candidates x 84 units per LCU; profiles/r05_c_md_bench_i_4k_stages.json) where 32 host threads take 0.06 s,
 # and everything waits for it - SVT_HOOK_MD=1 (I pictures on the device too) is measured beside it (`other_configurations`).  SVT_HOOK_PCS_POOL: PictureControlSet_t
 # objects of the encoder's EncDec pool (integration/svt_hook_encdec.c; the reference sizes it MAX(4, lp / 6) for host latencies) - DESIGN 5 has the sweep.
-CLOSED_LOOP_ENV = {"SVT_HOOK_MD": "pb", "SVT_HOOK_PCS_POOL": "16"}
+CLOSED_LOOP_ENV = {"SVT_HOOK_MD": "pb", "SVT_HOOK_PCS_POOL": "16", "SVT_HOOK_EP_LANES": "12", "SVT_HOOK_FRONT_LANES": "4"}
 RUNS = 3          # `value` and the CPU baseline beside it are medians of this many encodes (84 vs 102 fps between boxes, and run to run on one)
 
 

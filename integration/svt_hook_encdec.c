@@ -156,15 +156,16 @@ void svt_hook_encdec_thread_exit(void)
 }
 /* How many lanes there are: every lane is a stream, i.e. a hardware queue of the device, and the part schedules only so many at once - with the front half's lanes, the
  * root context and the runtime's own, 16 EncDec lanes made EVERY kernel of the process 20 - 25 % slower from the first launch on (profiles/r05_ai: mode-decision kernels
- * median 68 -> 90 ms at the same 10 - 12 launches side by side; r05_an: back to 75 ms with 12 + 3 lanes at pool 16).  12 by default (SVT_HOOK_EP_LANES): a picture beyond
- * waits for a lane holding nothing on the device. */
+ * median 68 -> 90 ms at the same 10 - 12 launches side by side; r05_an: back to 75 ms with 12 + 3 lanes at pool 16).  SVT_HOOK_EP_LANES=<n> caps them (the closed-loop
+ * configuration bench.py measures: 12, with SVT_HOOK_FRONT_LANES=4); a picture beyond the cap waits for a lane holding nothing on the device.  Without the switch: EP_LANES,
+ * the count every end-to-end case of tests/ has run with. */
 static int ep_lanes(void)
 {
     static int n;
     if (!n) {
         const char *v = getenv("SVT_HOOK_EP_LANES");
         const int want = v ? atoi(v) : 0;
-        n = (want >= 1 && want <= EP_LANES) ? want : 12;
+        n = (want >= 1 && want <= EP_LANES) ? want : EP_LANES;
     }
     return n;
 }
@@ -1327,7 +1328,7 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
         ok = e->md_ok;
         goto decided;
     }
-    if (e) { /* a warmed-up object: whether the picture takes the device call at all is settled without a lane */
+    if (e && ep_lanes() < EP_LANES) { /* lanes are capped (SVT_HOOK_EP_LANES) and the object is warmed up: whether the picture takes the device call at all is settled without a lane */
         svt_hook_lock(&e->lock);
         if (e->md_picture_plus1 != pcs->pictureNumber + 1) {
             SvtAmdMdPicture P;

@@ -52,8 +52,9 @@
 
 #define NSLOTS 48   /* device picture slots, keyed by pictureNumber % NSLOTS */
 #define NLANES_MAX 8
-static int g_nlanes = 4; /* front-end lanes = pictures whose ME / OIS results are in flight or being served (SVT_HOOK_FRONT_LANES=<1..8>).  A lane is a stream is a hardware queue,
-                          * and the device schedules only so many at once (svt_hook_encdec.c: ep_lanes): 4 serve > 1000 pictures/s (a picture holds its lane 4 ms) */
+static int g_nlanes = NLANES_MAX; /* front-end lanes = pictures whose ME / OIS results are in flight or being served (SVT_HOOK_FRONT_LANES=<1..8>).  A lane is a stream is a hardware queue,
+                          * and the device schedules only so many at once (svt_hook_encdec.c: ep_lanes): 4 serve > 1000 pictures/s (a picture holds its lane 4 ms) - what the closed-loop
+                          * configuration of bench.py sets; 8 without the switch */
 #define NLANES g_nlanes
 
 /*
