@@ -463,19 +463,16 @@ def test_md_encode_picture_inter16_decides_on_the_8_msbs_and_encodes_the_10_bit_
 
 def test_md_after_the_warm_up_with_page_locked_padded_source_planes(product):
     """What the encoder binding does since round 5: the picture object's mode-decision state is made BEFORE the first call (svt_amd_md_picture_warmup), the source planes
-    live in page-locked buffers with the encoder's row pitch (svt_amd_host_register: the call fetches them by a kernel of its own stream), host threads sleep in their waits
-    (svt_amd_host_wait_mode).  Decisions, work and result records must be those of the plain call on pageable, tightly pitched planes."""
+    live in page-locked buffers with the encoder's row pitch (svt_amd_host_register: the call fetches them by a kernel of its own stream).  (svt_amd_host_wait_mode is a
+    setting of the DEVICE for the whole process: exercised by the encoder bindings in the end-to-end cases, not inside this test process.)  Decisions, work and result records must be those of the plain call on pageable, tightly pitched planes."""
     lib = product
     sig(lib)
     vp = C.c_void_p
     lib.svt_amd_md_picture_warmup.restype, lib.svt_amd_md_picture_warmup.argtypes = C.c_int, [vp, vp]
     lib.svt_amd_host_register.restype, lib.svt_amd_host_register.argtypes = C.c_int, [vp, vp, C.c_size_t]
     lib.svt_amd_host_unregister_all.restype, lib.svt_amd_host_unregister_all.argtypes = C.c_int, [vp]
-    lib.svt_amd_host_wait_mode.restype, lib.svt_amd_host_wait_mode.argtypes = C.c_int, [C.c_int, C.c_int]
     g = dict(np.load(os.path.join(S.GOLDEN_DIR, "md_b_objects_416x240_m8.npz")))
     w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
-    wait_rc = lib.svt_amd_host_wait_mode(0, 1)   # a process that has opened the device already (torch, earlier tests) may be refused the change: the call must say so, not crash
-    assert wait_rc in (0, S.ERR_DEVICE if hasattr(S, "ERR_DEVICE") else wait_rc), lib.svt_amd_last_error()
     ctx, pic, pic2 = vp(), vp(), vp()
     assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
     try:
@@ -516,4 +513,3 @@ def test_md_after_the_warm_up_with_page_locked_padded_source_planes(product):
         lib.svt_amd_encdec_picture_destroy(ctx, pic2)
     finally:
         lib.svt_amd_context_destroy(ctx)
-        lib.svt_amd_host_wait_mode(0, 0)
