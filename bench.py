@@ -125,6 +125,44 @@ CLOSED_LOOP_ENV = {"SVT_HOOK_MD": "pb", "SVT_HOOK_PCS_POOL": "16", "SVT_HOOK_EP_
 RUNS = 3          # `value` and the CPU baseline beside it are medians of this many encodes (84 vs 102 fps between boxes, and run to run on one)
 
 
+class FileSync:
+    """Barrier / all-gather of short strings between the ranks of ONE node through files - what the encoder leg needs (the reference's md5 to every rank, a start barrier, the
+    slowest rank's time) BEFORE any rank has opened its GPU: the leg's child encoders must not share the part's hardware queues with this process's streams (see main), and a
+    process group on the nccl backend opens the device.  Keyed by the launch (MASTER_PORT + the launcher's pid: all ranks of one torch.distributed.run share both)."""
+
+    def __init__(self, rank, world, root=None):
+        self.rank, self.world, self.n = rank, world, 0
+        key = "svtbench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("SVT_BENCH_SYNC_KEY", str(os.getppid())))
+        self.dir = os.path.join(root or tempfile.gettempdir(), key)
+        os.makedirs(self.dir, exist_ok=True)
+
+    def exchange(self, value, timeout_s=1800.0):
+        """every rank gives a string, every rank gets all of them in rank order; returns only when every rank has given its own (a barrier)"""
+        self.n += 1
+        path = lambda r: os.path.join(self.dir, "x%d_r%d" % (self.n, r))  # noqa: E731
+        with open(path(self.rank) + ".tmp", "w") as f:
+            f.write(str(value))
+        os.replace(path(self.rank) + ".tmp", path(self.rank))
+        t0 = time.monotonic()
+        while not all(os.path.exists(path(r)) for r in range(self.world)):
+            if time.monotonic() - t0 > timeout_s:
+                raise RuntimeError("FileSync: rank %d waited %.0f s for the other ranks at step %d (%s)" % (self.rank, timeout_s, self.n, self.dir))
+            time.sleep(0.02)
+        return [open(path(r)).read() for r in range(self.world)]
+
+    def close(self, timeout_s=600.0):
+        """rank 0 removes the directory - after every other rank has said that it will not look at it again"""
+        self.exchange("bye")
+        done = lambda r: os.path.join(self.dir, "done_r%d" % r)  # noqa: E731
+        if self.rank != 0:
+            open(done(self.rank), "w").close()
+            return
+        t0 = time.monotonic()
+        while not all(os.path.exists(done(r)) for r in range(1, self.world)) and time.monotonic() - t0 < timeout_s:
+            time.sleep(0.02)
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
 class GpuBusy:
     """gpu_busy_percent of the device (amdgpu sysfs) sampled every 50 ms while an encoder child runs"""
 
@@ -186,7 +224,7 @@ def _coverage(report_path):
     return cover, lines
 
 
-def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
+def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, sync):
     """The BASELINE metric, on the CLOSED LOOP (CLOSED_LOOP_ENV).  Rank 0 first encodes the clip with the unmodified reference (its md5 is the gate); then every rank runs
     the hooked encoder on its own GPU behind a barrier, RUNS times at N = 1.  Returns (rank 0) the record of the JSON line's `encoder_fps` with `value` = pictures of all
     ranks / slowest rank's encode time of the MEDIAN run, 0 when any bitstream of any run differs.  Beside it (N = 1): the reference at the same -lp (its best threading;
@@ -214,13 +252,7 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
             except Exception as e:
                 out["reference"] = {"error": str(e)[-300:]}
         if world > 1:
-            import torch.distributed as dist
-            t = torch.zeros(32, dtype=torch.uint8, device=dev)
-            if rank == 0 and ref_md5:
-                t = torch.tensor(list(ref_md5.encode()), dtype=torch.uint8, device=dev)
-            dist.broadcast(t, 0)
-            ref_md5 = bytes(t.cpu().tolist()).decode() if int(t.sum()) else ""
-            dist.barrier()
+            ref_md5 = sync.exchange(ref_md5 if rank == 0 else "")[0]      # rank 0's reference md5 to every rank; every rank's clip is written: the encoders start together
         env = dict(closed, SVT_AMD_DEVICE=str(local_rank))
         hargs = list(args)
         # host threads of the encoder with the HIP path bound in (-lp, the application's own switch; the bitstream does not depend on it): about 32 logical processors is
@@ -277,10 +309,7 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, dev):
         ok = all(bool(r.get("md5")) and r["md5"] == ref_md5 for r in hips)
         secs = frames / hip["fps"] if hip.get("fps") else float("inf")
         if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([secs if ok else float("inf")], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            secs = float(t.item())
+            secs = max(float(v) for v in sync.exchange(repr(secs if ok else float("inf"))))     # the slowest rank; inf when any rank's bitstream differs
         elif not ok:
             secs = float("inf")
         out["hip"] = hip
@@ -520,12 +549,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
-    # ---- the headline first (N = 1): md5-gated encoded fps of the whole encoder with the HIP path bound in.  The encoder is a child process with two dozen streams of its
+    # ---- the headline first: md5-gated encoded fps of the whole encoder with the HIP path bound in.  The encoder is a child process with two dozen streams of its
     # own; measured BEFORE this process opens the device, so that the two do not share the part's hardware queues (the same leg after the loops below: 87-97 fps where the
-    # stand-alone sweeps of the same binary read 103-117, profiles/r05_ah_bench.json).  N > 1 needs the process group for its barrier and runs it where it always did.
+    # stand-alone sweeps of the same binary read 103-117, profiles/r05_ah_bench_encoder_leg_last.json).  N > 1: the ranks meet through files (FileSync), not through the process
+    # group - the nccl backend opens the device.
     enc = None
-    if world == 1 and not a.inner and not a.no_encoder_fps:
-        enc = encoded_fps_leg(CONFIGS[a.config]["enc"], a.steps, rank, local_rank, world, None)
+    if not a.inner and not a.no_encoder_fps:
+        sync = FileSync(rank, world) if world > 1 else None
+        enc = encoded_fps_leg(CONFIGS[a.config]["enc"], a.steps, rank, local_rank, world, sync)
+        if sync:
+            sync.close()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -704,10 +737,6 @@ def main():
         res_steps = max(2, a.steps // 2)
 
     xchg = recon_exchange_leg(lib, root, rank, world, dev) if (world > 1 and not a.inner) else None
-
-    # ---- the headline: md5-gated encoded fps of the whole encoder with the HIP path bound in -------------------------------------
-    if world > 1 and not a.inner and not a.no_encoder_fps:
-        enc = encoded_fps_leg(cfg["enc"], a.steps, rank, local_rank, world, dev)
 
     if rank == 0 and not a.inner:
         fps = world * NL * B * a.steps / dt
