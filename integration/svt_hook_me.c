@@ -1489,8 +1489,7 @@ static int g_inter_state;
 static struct { const EbPictureBufferDesc_t *p; size_t bps; } g_pin_later[1024];
 static int g_pin_later_n;
 static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
-static unsigned long g_pinned_at_init, g_pinned_late;
-static int g_pin_init_done; /* the pools have been built: a buffer first seen now is pinned inside the encode */
+static unsigned long g_pinned_at_init;
 static int pin_enabled(void)
 {
     static int state; /* 0 unknown, 1 on, -1 off */
