@@ -1684,8 +1684,14 @@ SVT_AMD_API int svt_amd_md_lcus_supported(const SvtAmdMdPicture *P, const SvtAmd
  * switches the collection on) - see svt-hevc_amd/csrc/md_kernels.hip */
 SVT_AMD_API int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
 SVT_AMD_API int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
+/* ... and both sets of sums by the depth of the coding unit they were spent on: out[LCU][depth 0..3][32] */
+SVT_AMD_API int svt_amd_debug_md_profile_depth(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
+/* development builds (-DMD_TRACE) only, SVT_AMD_ERR_BAD_PARAM otherwise: lane-0 time stamps of the kernel's four waves along two units of one LCU (tools/md_trace.py) */
+SVT_AMD_API int svt_amd_debug_md_trace(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int lcu, int unit, unsigned long long *out);
 /* measurement: duration in ms (HIP events on the call's stream) and launch width (workgroups) of the picture object's last mode-decision kernel launch */
 SVT_AMD_API int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms, int *workgroups);
+/* ... and of the encode-pass kernel queued behind it by the same call */
+SVT_AMD_API int svt_amd_debug_md_ep_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms);
 /* diagnosis: the mode-decision launches that hold (or wait for) workgroups of the device budget right now (md_kernels.hip: MdFlight) */
 SVT_AMD_API int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, int *waiting);
 /* Everything the first svt_amd_md_encode_picture[_inter / 16] call on a picture object would allocate (device state, page-locked staging, events), made NOW: for hosts that

@@ -68,6 +68,8 @@ static inline int ep_picture_written(SvtAmdContext *ctx, SvtAmdEncDecPicture *pi
     return SVT_AMD_OK;
 }
 void svt_amd_md_state_free(SvtAmdEncDecPicture *pic); /* md_kernels.hip */
+/* encdec_kernels.hip: the encode pass of every LCU of the picture from work records the mode-decision kernel left in HBM, queued on ctx's stream behind it */
+int svt_amd_ep_launch_behind_md(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const void *d_works, void *d_results, int n_active, const unsigned *d_order, int inter, int tiles);
 
 typedef SvtAmdLcuCu LcuCu;
 /* the contract structs of a sample type */
@@ -109,6 +111,27 @@ struct EpLocal {
         return mode[p][(cy + 1) * 36 + cx + 1];
     }
 };
+
+/* development aid (builds with -DMD_TRACE only; tools/md_trace.py): time stamps of lane 0 of every wave at marks along the mode decision's unit chain, for ONE chosen
+ * LCU and two consecutive units - a poor man's thread trace that shows which wave the chain is waiting for at every barrier */
+#ifdef MD_TRACE
+#define MD_TRACE_N 128
+static __shared__ unsigned long long g_md_trace[4][MD_TRACE_N];
+static __shared__ int g_md_trace_n[4];
+static __shared__ int g_md_trace_on;
+#define MD_TR(id)                                                                                                                   \
+    do {                                                                                                                            \
+        if (g_md_trace_on && (threadIdx.x & 63) == 0) {                                                                             \
+            const int w_ = threadIdx.x >> 6, n_ = g_md_trace_n[w_];                                                                 \
+            if (n_ < MD_TRACE_N) {                                                                                                  \
+                g_md_trace[w_][n_] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFull);         \
+                g_md_trace_n[w_] = n_ + 1;                                                                                          \
+            }                                                                                                                       \
+        }                                                                                                                           \
+    } while (0)
+#else
+#define MD_TR(id) do { } while (0)
+#endif
 
 /* wave-level ordering of LDS traffic: what the lanes of this wave wrote is visible to its other lanes */
 #define EP_WAVE_SYNC()                                          \
@@ -437,6 +460,7 @@ __device__ __forceinline__ void ep_mc8_tile(EpMcScratch<uint8_t> &M, int lane, i
         }
     }
     EP_WAVE_SYNC();
+    MD_TR(43);
     /* vertical pass: a lane owns a column and RUN rows; the column of the transposed intermediate as packed pairs */
     constexpr int RUN = TN >= 8 ? (TN * TN) / 64 : 1, NIN = RUN + NT - 1, NW = (NIN + 2) / 2 + 1;
     const int x = lane & (TN - 1), y0 = (lane >> LGT) * RUN;
@@ -489,6 +513,7 @@ __device__ __forceinline__ void ep_inter_predict_core8(const EpRefPlanes *refs /
         for (int l = 0; l < 2; l++) {
             if (!(bi || inter_dir == l))
                 continue;
+            MD_TR(40);
             const EpRefPlanes R = refs[l]; /* one read of the whole record */
             const int qx = min(max(((abs_x + R.originX) << 2) + mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
             const int qy = min(max(((abs_y + R.originY) << 2) + mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
@@ -496,6 +521,7 @@ __device__ __forceinline__ void ep_inter_predict_core8(const EpRefPlanes *refs /
             const int fx = __builtin_amdgcn_readfirstlane(chroma ? qx & 7 : qx & 3), fy = __builtin_amdgcn_readfirstlane(chroma ? qy & 7 : qy & 3);
             const int cpr = (rows + 7) >> 3, nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
             bool staged = false;
+            MD_TR(41);
             EP_DBG_CLK(4);
 #ifdef EP_DEBUG_WINDOW_COUNTS
             if (lane == 0 && !chroma)
@@ -548,6 +574,7 @@ __device__ __forceinline__ void ep_inter_predict_core8(const EpRefPlanes *refs /
                 }
             }
             EP_WAVE_SYNC();
+            MD_TR(staged ? 42 : 46);
             EP_DBG_CLK(5);
             const int mode = !bi ? 0 : (second ? 2 : 1);
             uint8_t *td = dst + ty0 * pitch + tx0;
@@ -565,6 +592,7 @@ __device__ __forceinline__ void ep_inter_predict_core8(const EpRefPlanes *refs /
                 default: ep_mc8_tile<4, true>(M, lane, fx, fy, mode, td, pitch); break;
                 }
             }
+            MD_TR(44);
             EP_DBG_CLK(6);
             second = true;
         }

@@ -91,6 +91,23 @@ __global__ __launch_bounds__(256) void k_encode_picture(EpPicture P, const typen
 }
 
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
+/* the encode pass behind the mode-decision kernel of the same picture-level call (md_kernels.hip): d_works / d_results are the picture object's device arrays of the call's
+ * sample width; a P / B picture - most LCUs without an intra unit wait for nobody - as wide as the device holds, an I picture as wide as its wavefront */
+int svt_amd_ep_launch_behind_md(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const void *d_works, void *d_results, int n_active, const unsigned *d_order, int inter, int tiles)
+{
+    const int wl = (pic->d.width + 63) / 64, hl = (pic->d.height + 63) / 64;
+    int grid = inter ? 512 : ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 1;
+    grid = grid > n_active ? n_active : grid;
+    if (pic->d.bps == 2)
+        hipLaunchKernelGGL(k_encode_picture<uint16_t>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, (const SvtAmdLcuWork16 *)d_works, (SvtAmdLcuResult16 *)d_results, n_active, wl,
+                           pic->d_sync, pic->d_sync + 1, d_order, pic->epoch);
+    else
+        hipLaunchKernelGGL(k_encode_picture<uint8_t>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pic->d, (const SvtAmdLcuWork *)d_works, (SvtAmdLcuResult *)d_results, n_active, wl,
+                           pic->d_sync, pic->d_sync + 1, d_order, pic->epoch);
+    HIP_TRY(hipGetLastError());
+    return SVT_AMD_OK;
+}
+
 static int picture_create(SvtAmdContext *ctx, uint16_t width, uint16_t height, int bytes_per_sample, SvtAmdEncDecPicture **out)
 {
     if (!ctx || !out || width < 8 || height < 8 || (width & 7) || (height & 7) || (bytes_per_sample != 1 && bytes_per_sample != 2)) {

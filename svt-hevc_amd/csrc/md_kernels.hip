@@ -77,6 +77,7 @@ struct MdPictureDev {
     const SvtAmdMeLcuResult *me;
     const SvtAmdTmvpLcu *tmvp;
     int encode;                   /* 0: mode decision only (no work record, no encode pass) */
+    const SvtAmdCabacCost *cost;  /* the picture's coefficient-rate tables (the picture object's d_cost) */
     /* The mode decision works on 8-bit samples whatever the encoder's bit depth (Inter2Nx2NPuPredictionHevc narrows the 16-bit reference block it reads,
      * UnPackReferenceBlock, Codec/EbInterPrediction.c:414-457; the source is the picture's 8-bit plane): mref = the reference pictures as the mode decision reads them -
      * the picture object's own of an 8-bit picture, their 8-MSB views of a 10-bit one -, src16 = the 10-bit source the encode pass behind it codes (null: 8-bit). */
@@ -84,13 +85,15 @@ struct MdPictureDev {
     const uint16_t *src16[3];
     unsigned long long *prof;     /* debug (svt_amd_debug_md_profile): 16 shader-clock sums per LCU, or null */
     int prof_lcus;                /* LCUs of the picture: the sub-stage sums start behind the stage sums of all of them */
+    unsigned long long *trace;    /* debug (-DMD_TRACE builds, svt_amd_debug_md_trace): the time stamps of trace_lcu's units [trace_unit, trace_unit + 2), or null */
+    int trace_lcu, trace_unit;
 };
 /* stage clocks of the mode decision of one LCU, taken by lane 0 behind the barrier that ends the stage */
 #define MD_PROF(k)                                                          \
     do {                                                                    \
         if (D.prof && threadIdx.x == 0) {                                   \
             const unsigned long long c_ = __builtin_readcyclecounter();    \
-            M.prof[k] += c_ - M.prof_t, M.prof_t = c_, M.prof_s = c_;       \
+            M.prof[k] += c_ - M.prof_t, M.prof_d[M.prof_depth][k] += c_ - M.prof_t, M.prof_t = c_, M.prof_s = c_; \
         }                                                                   \
     } while (0)
 /* ... and finer marks inside a stage (svt_amd_debug_md_profile_sub): slot k of 16 gets the clocks since the previous mark of either kind */
@@ -98,7 +101,7 @@ struct MdPictureDev {
     do {                                                                    \
         if (D.prof && threadIdx.x == 0) {                                   \
             const unsigned long long c_ = __builtin_readcyclecounter();    \
-            M.prof[16 + (k)] += c_ - M.prof_s, M.prof_s = c_;               \
+            M.prof[16 + (k)] += c_ - M.prof_s, M.prof_d[M.prof_depth][16 + (k)] += c_ - M.prof_s, M.prof_s = c_; \
         }                                                                   \
     } while (0)
 
@@ -187,20 +190,14 @@ struct MdShared {
     uint32_t full_dist[MD_MAX_BUF];
     int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done, best_first, any_intra;
     unsigned long long prof[32], prof_t, prof_s;
+    unsigned long long prof_d[4][32]; /* the same sums by the depth of the unit they belong to (svt_amd_debug_md_profile_depth) */
+    int prof_depth;
     int16_t ref[132], reff[132], border[132];
     typename MdVariant<INTER>::type V;
     int16_t tiles[4][2 * TxRegTile<32>::UNIT];
     int16_t qbuf[4][32 * 32];
 };
 
-template <bool INTER, typename T>
-union MdEpShared {
-    MdShared<INTER> md;
-    struct {
-        EpShared<T> S;
-        EpLocal<T> L;
-    } ep;
-};
 
 /* the unit's intra reference, unfiltered (ref) and filtered (reff), by ONE wave: GenerateLumaIntraReferenceSamplesEncodePass with
  * constrainedIntraFlag 0 / strongIntraSmoothingFlag 1 as GenerateIntraLumaReferenceSamplesMd calls it (Codec/EbProductCodingLoop.c:280-295;
@@ -309,6 +306,7 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     MD_LDS(src), MD_LDS(pred), MD_LDS(tile), MD_LDS(qbuf), MD_LDS(&cost), MD_LDS(&rt);
     if (recon_coeff)
         MD_LDS(recon_coeff);
+    MD_TR(50);
     const int r = lane & (N - 1);
     const bool active = lane < N;
     int x[N];
@@ -326,7 +324,9 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
         for (int j = 0; j < N; j++)
             x[j] = 0;
     }
+    MD_TR(51);
     fwd_2d_regs<N>(x, tile + (lane / N) * TxRegTile<N>::UNIT, r, fs1, fs2, wrap); /* x[j] = coefficient (j, r) */
+    MD_TR(52);
     const int qpRem = qp % 6, qpPer = qp / 6;
     const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
     const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
@@ -354,14 +354,17 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
             nz += q != 0, d0 += (uint32_t)(df * df), d1 += (uint32_t)(v * v);
         }
     }
+    MD_TR(53);
     nz = md_wave_sum(nz), d0 = md_wave_sum(d0), d1 = md_wave_sum(d1); /* the lanes beyond the unit's rows hold zeros */
     EP_WAVE_SYNC(); /* qbuf is written */
+    MD_TR(54);
     const int lga = LG - pf, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
     const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
     /* nz is the whole unit's count and the same in every lane: a unit without levels (most merge candidates of a B picture at these QPs) has no bits to estimate */
     const uint32_t b32 = nz ? coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1), rt) : 0u;
     MdFl o;
     o.nz = nz, o.d0 = nz ? d0 : d1, o.d1 = d1, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
+    MD_TR(55);
     return o;
 }
 
@@ -527,7 +530,7 @@ __device__ __forceinline__ void md_chroma_tu(int lane, int T, const uint8_t *src
 /* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
 /* what the LCU's mode decision reads that no other LCU of the picture writes (its records, its source): into LDS BEFORE the workgroup waits for the LCU's neighbours */
 template <bool INTER>
-__device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
+__device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAmdMdPicture &P, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     const int t = threadIdx.x;
     auto &L = M.L;
@@ -537,9 +540,9 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
     static_assert(sizeof(SvtAmdCabacCost) % 4 == 0 && sizeof(SvtAmdMdPicture) % 4 == 0, "record sizes");
     for (int i = t; i < (int)(sizeof(SvtAmdMdPicture) / 4); i += 256)
         ((uint32_t *)&M.pic)[i] = ((const uint32_t *)D.P)[i];
-    if (E.cost)
+    if (D.cost)
         for (int i = t; i < (int)(sizeof(SvtAmdCabacCost) / 4); i += 256)
-            ((uint32_t *)&M.cost)[i] = ((const uint32_t *)E.cost)[i];
+            ((uint32_t *)&M.cost)[i] = ((const uint32_t *)D.cost)[i];
     static_assert(sizeof(RateTables) % 4 == 0, "record sizes");
     for (int i = t; i < (int)(sizeof(RateTables) / 4); i += 256)
         ((uint32_t *)&M.rt)[i] = ((const uint32_t *)&c_rt)[i];
@@ -591,7 +594,7 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const EpPic
 
 /* ModeDecisionLcu of one LCU (its inputs are in LDS: md_lcu_inputs): on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
 template <bool INTER>
-__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &Pg, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
+__device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPicture &Pg, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     /* the picture's controls as the unit loop reads them: the copies md_lcu_inputs left beside the LCU in LDS, not the records in HBM (a unit's scalar stages read dozens
      * of these fields one after the other - each a round trip of its own from global memory) */
@@ -669,11 +672,14 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
     const SvtAmdOisLcuResult *ois = &M.ois;
     const int pf = md_pf_mode(&P);
     for (;;) {
+        MD_TR(10);
         /* ---- lane 0: the unit, its contexts and its candidates ---- */
         if (t == 0) {
             const int cuIdx = M.cu_idx, leaf = M.lcu.leaf_index[cuIdx];
             const MdStats st = md_stats(leaf);
             M.leaf = leaf;
+            if (D.prof)
+                M.prof_depth = st.depth;
             M.S.local[leaf].tested = 1;
             M.S.cu[leaf].split = (uint8_t)((islice && st.depth == 0) ? 1 : M.lcu.leaf_split[cuIdx]);
             uint32_t l = L.info_at(st.x - 1, st.y), tp = L.info_at(st.x, st.y - 1);
@@ -692,6 +698,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     ncand = md_intra_candidates(&P, &M.lcu, ois, leaf, &st, M.cand);
             M.ncand = ncand; /* the intra candidates so far (P / B pictures: the lists below are made by three waves) */
         }
+        if (wave == 0)
+            MD_TR(11);
         MD_SUB(0);
         if constexpr (INTER) {
             /* GenerateL0L1AmvpMergeLists: the AMVP candidates of list 0, of list 1 and the merge candidates share their inputs and nothing else - and none of them needs
@@ -714,9 +722,12 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     M.V.nb[wave - 1][k] = u;
                 }
                 EP_WAVE_SYNC();
+                MD_TR(12);
                 if (lane == 0 && wave < 3) /* wave 1: both AMVP lists, wave 2: the merge candidates (the longest of the three) */
                     md_amvp_merge_lists_parts(&P, &M.V.X, M.V.nb[wave - 1], M.V.X.tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T,
                                               wave == 1 ? 3 : 4);
+                if (wave < 3)
+                    MD_TR(13);
                 /* ... and the fourth wave the unit's intra reference (only units below 64x64 have intra candidates) - source samples from HBM in the open-loop decision, a
                  * round trip under the other waves' chains */
                 if (wave == 3 && st.depth != 0) {
@@ -727,9 +738,12 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     if (M.lcu.chroma_encode_mode == 1 && open_loop)
                         md_build_refs_ol_chroma(D, M.V.refc, st.size, lcu_x + st.x, lcu_y + st.y, W, H, lane);
                 }
+                if (wave == 3)
+                    MD_TR(14);
             }
             MD_SUB(2);
             __syncthreads();
+            MD_TR(15);
             MD_SUB(3);
         }
         if constexpr (INTER) {
@@ -779,6 +793,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 if (lane == 0)
                     M.ncand = n0 + __popcll(km);
                 EP_WAVE_SYNC();
+                MD_TR(16);
             }
         }
         MD_SUB(4);
@@ -795,6 +810,8 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             const int width = st.depth == 0 ? 5 : 8;
             M.ncand = ncand, M.buffer_total = bufferTotal, M.max_buffers = bufferTotal + 1 < width ? bufferTotal + 1 : width;
         }
+        if (wave == 0)
+            MD_TR(17);
         MD_SUB(5);
         if (wave == 0) { /* a lane per candidate (MD_MAX_CAND <= 64): what the candidate list implies for the loops below */
             EP_WAVE_SYNC();
@@ -862,9 +879,11 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             }
             if (lane == 0)
                 M.best_first = bestFirst;
+            MD_TR(18);
         }
         MD_SUB(6);
         __syncthreads();
+        MD_TR(19);
         MD_PROF(1);
         const int leaf = M.leaf, ncand = M.ncand;
         const MdStats st = md_stats(leaf);
@@ -881,7 +900,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
         }
         MD_PROF(2);
         if (D.prof && t == 0)
-            M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1;
+            M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1, M.prof_d[M.prof_depth][13] += (unsigned long long)ncand, M.prof_d[M.prof_depth][14] += 1;
         /* ---- fast loop (ProductPerformFastLoop's second loop): ONE list of tasks = (candidate, plane, tile) dealt to the four waves ----
          * luma tasks first - a candidate of a 64x64 unit is motion-compensated in four 32x32 tiles, a task each (wave w takes tile w of EVERY candidate: all four waves work
          * whatever the number of candidates) -, then, in CHROMA_MODE_FULL LCUs, the Cb and the Cr block of every evaluated candidate.  A task predicts its block (inter:
@@ -903,6 +922,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     c = luma ? M.heavy[k] : M.V.heavyc[k];
                 else
                     c = M.heavy[k];
+                MD_TR(20);
                 const MdCand cd = M.cand[c];
                 uint32_t sad = 0;
                 if (cd.type == MD_INTER) {
@@ -910,6 +930,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                         const int sl = M.V.slot[c], n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
                         uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
                         md_predict_inter_plane(M.V.refs, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1, &M.V.rw);
+                        MD_TR(22);
                         MD_SUB(7);
                         if (luma && tiled64) {
                             const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
@@ -949,6 +970,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     }
                 }
                 sad = md_wave_sum(sad);
+                MD_TR(23);
                 MD_SUB(8);
                 if (lane == 0 && sad) {
                     if (luma)
@@ -956,9 +978,11 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     else if constexpr (INTER)
                         atomicAdd(&M.V.sadc[c], sad);
                 }
+                MD_TR(24);
             }
         }
         __syncthreads();
+        MD_TR(25);
         MD_PROF(3);
         /* ---- wave 0: fast costs (a lane per candidate: MD_MAX_CAND <= 64), candidate buffers (a lane per buffer), PreModeDecision ---- */
         if (wave == 0) {
@@ -983,6 +1007,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 }
                 M.costs[i] = cst, M.fast_rate[i] = rate;
             }
+            MD_TR(26);
             MD_SUB(9);
             /* md_fast_loop_buffers (md_logic.h; ProductPerformFastLoop's second loop, :1990-2179) with the buffers in lanes 0..7 instead of LDS: the candidates
              * arrive from the last to the first, each goes into the buffer with the highest cost (an unused one first) = the FIRST buffer holding the maximum
@@ -1016,6 +1041,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     highest = h;
                 }
             }
+            MD_TR(27);
             MD_SUB(10);
             if (lane < MD_MAX_BUF) {
                 M.B.fast_cost[lane] = bcost, M.B.full_cost[lane] = ~0ull, M.B.cand[lane] = (int16_t)bcand, M.B.pred[lane] = (int16_t)bpred;
@@ -1032,8 +1058,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 M.full_count = md_pre_mode_decision(&M.B, M.types, same ? bufferTotal : M.max_buffers, same, M.best);
                 M.nfull = M.full_count < bufferTotal ? M.full_count : bufferTotal;
             }
+            MD_TR(28);
         }
         __syncthreads();
+        MD_TR(29);
         MD_PROF(4);
         /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
         const int nfull = M.nfull;
@@ -1068,6 +1096,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             }
         }
         for (int f = wave; f < nfull && !split64; f += 4) {
+            MD_TR(30);
             const int b = M.best[f], ci = M.B.cand[b];
             const MdCand cd = M.cand[ci];
             /* the buffer's luma prediction: the candidate the fast loop predicted there, or - predictionIsReadyLuma == 0 - a fresh one */
@@ -1096,8 +1125,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
                 EP_WAVE_SYNC();
             }
+            MD_TR(31);
             MD_SUB(12);
             md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, rc, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, cd.type, cd.intra_mode, pf, M.fl[b]);
+            MD_TR(32);
             MD_SUB(13);
         }
         if constexpr (INTER) {
@@ -1167,7 +1198,9 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 }
             }
         }
+        MD_TR(33);
         __syncthreads();
+        MD_TR(34);
         MD_PROF(5);
         /* ---- wave 0: TuCalcCostLuma + the full cost of every surviving candidate (a lane each), then lane 0: ProductFullModeDecision, CheckHighCostPartition ---- */
         if (wave == 0) {
@@ -1233,6 +1266,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 if (P.full_loop_escape && !islice && ty == MD_INTER && cs < bestFullCost)
                     prevRootCbf = yc, bestFullCost = cs;
             }
+            MD_TR(35);
             MD_SUB(14);
             if (have && ((kept >> lane) & 1ull)) {
                 M.ycbf[b] = ycbf, M.full_dist[b] = (uint32_t)dist[0], M.B.full_cost[b] = full;
@@ -1277,8 +1311,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
             }
             if (exitParent >= 0 || open_loop)
                 M.update = M.S.cu[M.last].split == 0;
+            MD_TR(36);
         }
         __syncthreads();
+        MD_TR(37);
         MD_PROF(6);
         if constexpr (!INTER) {
             /* ---- wave 0: the winner's reconstruction ---- */
@@ -1332,7 +1368,9 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                     M.V.mvu[((ls.y >> 3) + e / c8 + 1) * 18 + (ls.x >> 3) + e % c8 + 1] = mu;
             }
         }
+        MD_TR(38);
         __syncthreads();
+        MD_TR(39);
         if (t == 0) {
             const int cur = M.leaf; /* the unit the loop stands on: the tested one, or the parent a partition exit fell back to */
             const MdStats cs = md_stats(cur);
@@ -1345,6 +1383,11 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
                 cuIdx += md_next_cu_step(&M.lcu, cuIdx, cs.depth);
             M.cu_idx = cuIdx;
             M.done = cuIdx >= M.lcu.leaf_count;
+#ifdef MD_TRACE
+            g_md_trace_on = D.trace && lcu == D.trace_lcu && cuIdx >= D.trace_unit && cuIdx < D.trace_unit + 2;
+            if (D.trace && lcu == D.trace_lcu)
+                D.trace[4 * (1 + MD_TRACE_N) + 3] += 0x10000ull + (g_md_trace_on ? 1 : 0) + ((unsigned long long)g_md_trace_n[0] << 32);
+#endif
         }
         __syncthreads();
         MD_PROF(8);
@@ -1392,7 +1435,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const EpPicture &E
 /* what EncodePass will do with the inter units of the LCU's final tree (Codec/EbCodingLoop.c:3838-3882): AMVP units as they are; merge units by the
  * merge / skip costs completed with chroma (AddChromaEncDec, Codec/EbProductCodingLoop.c:4158-4349: chroma prediction + chroma full loop +
  * MergeSkipFullCost), a wave per unit.  -> M.V.ep_kind[leaf] */
-__device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const EpPicture &E, const SvtAmdMdPicture &Pg, MdShared<true> &M, int lcu_x, int lcu_y)
+__device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const SvtAmdMdPicture &Pg, MdShared<true> &M, int lcu_x, int lcu_y)
 {
     const SvtAmdMdPicture &P = M.pic;
     (void)Pg;
@@ -1514,18 +1557,26 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
     }
 }
 
-/* ONE launch per picture: persistent workgroups draw LCUs as tickets in wavefront order (k_encode_picture's scheme, encdec_kernels.hip) */
-/* Two completion flags per LCU: md_done = the LCU's mode-decision state is in the picture's maps (what the mode decision of the right and the lower-left
- * LCU waits for), done = its encode pass is finished (what their encode pass waits for).  The mode decision of the picture therefore runs ahead of its
- * encode pass along the wavefront: the critical path of a picture is the mode-decision chain alone. */
+/* ONE launch per picture: persistent workgroups draw LCUs as tickets in wavefront order (k_encode_picture's scheme, encdec_kernels.hip).  md_done[lcu] = the LCU's
+ * mode-decision state is in the picture's maps: what the mode decision of the right and the lower-left LCU waits for.  Behind it, off the chain, the workgroup completes
+ * the merge / skip decisions with chroma and writes the LCU's work record; the ENCODE PASS of the picture is a kernel of its own (k_encode_picture, launched behind this
+ * one on the same stream: round 6 - inlined here it cost this kernel 904 B of private segment per lane, 43 K of its 64 K instructions and a quarter of every workgroup's
+ * time, for work that is off the picture's critical path and runs 2040 LCUs wide in ~1.5 ms when it is launched on its own).
+ * The picture's descriptor (MdPictureDev) comes by POINTER and is copied to LDS once per workgroup: passed by value, its run-time-indexed arrays (src[1 + p], mref[l])
+ * forced the whole record into the private segment (110 scratch stores in the prologue, a memory round trip at every use). */
 template <bool INTER, typename T>
-__global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPicture E, typename EpTypes<T>::Work *__restrict__ works, typename EpTypes<T>::Result *__restrict__ results,
-                                                           int nlcu, int wl, unsigned *ticket, unsigned *done, unsigned *md_done, const unsigned *__restrict__ order,
-                                                           unsigned epoch)
+__global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restrict__ Dp, typename EpTypes<T>::Work *__restrict__ works, int nlcu, int wl, unsigned *ticket,
+                                                    unsigned *md_done, const unsigned *__restrict__ order, unsigned epoch)
 {
     extern __shared__ __align__(16) unsigned char md_lds[];
-    MdEpShared<INTER, T> &U = *reinterpret_cast<MdEpShared<INTER, T> *>(md_lds);
+    MdShared<INTER> &M = *reinterpret_cast<MdShared<INTER> *>(md_lds);
     __shared__ unsigned s_ticket;
+    __shared__ MdPictureDev s_D;
+    static_assert(sizeof(MdPictureDev) % 8 == 0, "copied as 8-byte words");
+    for (int i = threadIdx.x; i < (int)(sizeof(MdPictureDev) / 8); i += 256)
+        reinterpret_cast<unsigned long long *>(&s_D)[i] = reinterpret_cast<const unsigned long long *>(Dp)[i];
+    __syncthreads();
+    const MdPictureDev &D = s_D;
     const SvtAmdMdPicture &P = *D.P;
     for (;;) {
         __syncthreads();
@@ -1538,29 +1589,48 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
         const int lx = lcu % wl, ly = lcu / wl;
         const SvtAmdMdLcu &Lc = D.lcus[lcu];
         unsigned long long c_ticket = 0;
-        md_lcu_inputs<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
+        md_lcu_inputs<INTER>(D, P, lcu, lx * 64, ly * 64, M);
         const int dep0 = Lc.tile_left ? -1 : lcu - 1;
         const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
         if (threadIdx.x == 0) {
             c_ticket = D.prof ? __builtin_readcyclecounter() : 0;
             if (dep0 >= 0)
                 while (__hip_atomic_load(&md_done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(2);
             if (dep1 >= 0)
                 while (__hip_atomic_load(&md_done[dep1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        unsigned long long c_wait = 0, c_md = 0, c_work = 0;
+        unsigned long long c_wait = 0, c_md = 0;
         if (D.prof && threadIdx.x == 0) {
             c_wait = __builtin_readcyclecounter();
             for (int k = 0; k < 32; k++)
-                U.md.prof[k] = 0;
-            U.md.prof_t = U.md.prof_s = c_wait;
+                M.prof[k] = 0;
+            for (int k = 0; k < 128; k++)
+                M.prof_d[0][k] = 0;
+            M.prof_depth = 0;
+            M.prof_t = M.prof_s = c_wait;
         }
-        md_lcu<INTER>(D, E, P, lcu, lx * 64, ly * 64, U.md);
+#ifdef MD_TRACE
+        if (threadIdx.x < 4)
+            g_md_trace_n[threadIdx.x] = 0;
+        if (threadIdx.x == 0)
+            g_md_trace_on = D.trace && lcu == D.trace_lcu && D.trace_unit == 0;
         __syncthreads();
+#endif
+        md_lcu<INTER>(D, P, lcu, lx * 64, ly * 64, M);
+        __syncthreads();
+#ifdef MD_TRACE
+        if (D.trace && lcu == D.trace_lcu) {
+            for (int i = threadIdx.x; i < 4 * (1 + MD_TRACE_N); i += 256) {
+                const int w_ = i / (1 + MD_TRACE_N), k_ = i - w_ * (1 + MD_TRACE_N);
+                D.trace[i] = k_ == 0 ? (unsigned long long)g_md_trace_n[w_] : g_md_trace[w_][k_ - 1];
+            }
+        }
+        __syncthreads();
+#endif
         if (threadIdx.x == 0) { /* the LCU's neighbour state is in the maps: the next LCUs' mode decisions may start */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_store(&md_done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1569,43 +1639,29 @@ __global__ __launch_bounds__(256) void k_md_encode_picture(MdPictureDev D, EpPic
             c_md = __builtin_readcyclecounter();
             unsigned long long *q = D.prof + 16 * (size_t)lcu;
             for (int k = 0; k < 9; k++)
-                q[k] += U.md.prof[k];
-            q[9] += c_md - U.md.prof_t;      /* the LCU's state leaving LDS */
+                q[k] += M.prof[k];
+            q[9] += c_md - M.prof_t;         /* the LCU's state leaving LDS */
             q[12] += c_wait - c_ticket;       /* waiting for the LCU's neighbours */
-            q[13] += U.md.prof[13], q[14] += U.md.prof[14]; /* candidates of the fast loops / units tested */
+            q[13] += M.prof[13], q[14] += M.prof[14]; /* candidates of the fast loops / units tested */
             unsigned long long *q2 = D.prof + 16 * (size_t)D.prof_lcus + 16 * (size_t)lcu; /* the sub-stage sums follow the stage sums of all LCUs */
             for (int k = 0; k < 16; k++)
-                q2[k] += U.md.prof[16 + k];
+                q2[k] += M.prof[16 + k];
+            unsigned long long *q3 = D.prof + 32 * (size_t)D.prof_lcus + 128 * (size_t)lcu; /* ... and both by depth */
+            for (int k = 0; k < 128; k++)
+                q3[k] += M.prof_d[0][k];
             q[15] += 1;
         }
         if (D.encode) {
             if constexpr (INTER)
-                md_ep_kinds(D, E, P, U.md, lx * 64, ly * 64);
-            md_make_work<INTER, T>(D, P, U.md, lx * 64, ly * 64, works[lcu]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads(); /* the work record is complete (the encode pass reads it back from memory) and the mode decision's LDS is free */
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (threadIdx.x == 0) /* the intra units of the encode pass read the neighbours' reconstruction and mode types */
-                ep_wait_neighbours(works[lcu], lcu, wl, done, epoch);
-            __syncthreads();
+                md_ep_kinds(D, P, M, lx * 64, ly * 64);
+            md_make_work<INTER, T>(D, P, M, lx * 64, ly * 64, works[lcu]);
             if (D.prof && threadIdx.x == 0)
-                c_work = __builtin_readcyclecounter();
-            ep_encode_lcu<T>(E, works[lcu], results[lcu], U.ep.S, U.ep.L);
-            __syncthreads();
-            if (D.prof && threadIdx.x == 0) {
-                unsigned long long *q = D.prof + 16 * (size_t)lcu;
-                q[10] += c_work - c_md, q[11] += __builtin_readcyclecounter() - c_work;
-            }
-        }
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(&done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                D.prof[16 * (size_t)lcu + 10] += __builtin_readcyclecounter() - c_md; /* merge / skip decisions with chroma + the work record */
         }
     }
 }
 
-static_assert(sizeof(MdEpShared<true, uint8_t>) <= 160 * 1024 && sizeof(MdEpShared<false, uint8_t>) <= 160 * 1024 && sizeof(MdEpShared<true, uint16_t>) <= 160 * 1024 &&
-                  sizeof(MdEpShared<false, uint16_t>) <= 160 * 1024,
+static_assert(sizeof(MdShared<true>) + sizeof(MdPictureDev) + 64 <= 160 * 1024 && sizeof(MdShared<false>) + sizeof(MdPictureDev) + 64 <= 160 * 1024,
               "the LCU state has to fit the 160 KB of LDS of a CU");
 
 /* ---- host side ------------------------------------------------------------------------------------------------------------- */
@@ -1637,8 +1693,12 @@ struct SvtAmdMdState {
     size_t ref8_bytes[2][3];
     size_t info_bytes, mv_bytes;
     unsigned long long *d_prof;
+    unsigned long long *d_trace;
+    int trace_lcu, trace_unit;
     unsigned *d_md_done;           /* epoch of the call whose mode decision finished the LCU */
-    hipEvent_t ev_k0, ev_k1;       /* around the last launch of k_md_encode_picture on the call's stream (svt_amd_debug_md_kernel_ms) */
+    unsigned *d_md_ticket;         /* the mode-decision kernel's ticket counter (the encode pass behind it draws from the picture object's own) */
+    MdPictureDev *d_D;             /* the descriptor the kernel reads (d, copied per call) */
+    hipEvent_t ev_k0, ev_k1, ev_k2; /* around the last launch of k_md_picture on the call's stream (svt_amd_debug_md_kernel_ms), and behind the encode pass that follows it */
     int grid;                      /* its workgroups */
     /* P / B pictures */
     SvtAmdMdInter *d_X;
@@ -1652,7 +1712,7 @@ struct SvtAmdMdState {
     int n_retired;
 };
 static constexpr size_t MD_STAGE_P = 0, MD_STAGE_X = (sizeof(SvtAmdMdPicture) + 63) & ~(size_t)63, MD_STAGE_COST = MD_STAGE_X + ((sizeof(SvtAmdMdInter) + 63) & ~(size_t)63),
-                        MD_STAGE_BYTES = MD_STAGE_COST + ((sizeof(SvtAmdCabacCost) + 63) & ~(size_t)63);
+                        MD_STAGE_D = MD_STAGE_COST + ((sizeof(SvtAmdCabacCost) + 63) & ~(size_t)63), MD_STAGE_BYTES = MD_STAGE_D + ((sizeof(MdPictureDev) + 63) & ~(size_t)63);
 
 void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
 {
@@ -1660,7 +1720,7 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
     if (!m)
         return;
     void *ptrs[] = {m->d.md_rec, m->d.md_info, m->d_src[0], m->d_src[1], m->d_src[2], m->d_ois, m->d_lcus, m->d_P, m->d_out, m->d_works, m->d_results,
-                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp, m->d_prof, m->d_md_done, m->d_src16[0], m->d_src16[1], m->d_src16[2],
+                    m->d.md_mv, m->d_X, m->d_me, m->d_tmvp, m->d_prof, m->d_trace, m->d_md_done, m->d_md_ticket, m->d_D, m->d_src16[0], m->d_src16[1], m->d_src16[2],
                     m->d_ref8[0][0], m->d_ref8[0][1], m->d_ref8[0][2], m->d_ref8[1][0], m->d_ref8[1][1], m->d_ref8[1][2]};
     for (void *q : ptrs)
         if (q)
@@ -1671,6 +1731,8 @@ void svt_amd_md_state_free(SvtAmdEncDecPicture *pic)
         (void)hipEventDestroy(m->ev_k0);
     if (m->ev_k1)
         (void)hipEventDestroy(m->ev_k1);
+    if (m->ev_k2)
+        (void)hipEventDestroy(m->ev_k2);
     if (m->h_stage)
         (void)hipHostFree(m->h_stage);
     free(m);
@@ -1712,8 +1774,10 @@ static int md_state(SvtAmdEncDecPicture *pic, SvtAmdMdState **out)
     ok = ok && hipMalloc((void **)&m->d.md_mv, m->mv_bytes) == hipSuccess && hipMalloc((void **)&m->d_X, sizeof(SvtAmdMdInter)) == hipSuccess &&
          hipMalloc((void **)&m->d_me, sizeof(SvtAmdMeLcuResult) * n) == hipSuccess && hipMalloc((void **)&m->d_tmvp, sizeof(SvtAmdTmvpLcu) * (n + 1)) == hipSuccess;
     ok = ok && hipMalloc((void **)&m->d_md_done, sizeof(unsigned) * n) == hipSuccess && hipMemset(m->d_md_done, 0, sizeof(unsigned) * n) == hipSuccess;
+    ok = ok && hipMalloc((void **)&m->d_md_ticket, 64) == hipSuccess && hipMalloc((void **)&m->d_D, sizeof(MdPictureDev)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&m->h_stage, MD_STAGE_BYTES, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&m->ev_k0) == hipSuccess && hipEventCreateWithFlags(&m->ev_k1, hipEventBlockingSync) == hipSuccess; /* ev_k1: the caller sleeps through the kernel */
+    ok = ok && hipEventCreate(&m->ev_k2) == hipSuccess;
     if (!ok) {
         svt_amd_set_error("hipMalloc (mode-decision picture state) failed");
         svt_amd_md_state_free(pic);
@@ -1871,10 +1935,12 @@ static int md_kernel_attributes(int device)
     static bool attr[64];
     std::lock_guard<std::mutex> g(mu);
     if (!attr[device & 63]) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint8_t>)));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint8_t>)));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<false, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<false, uint16_t>)));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_encode_picture<true, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdEpShared<true, uint16_t>)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<true, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<true>)));
+#ifndef MD_INTER8_ONLY /* (development builds, tools/exp_build.sh: one instantiation compiles in a quarter of the time) */
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<false, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<false>)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<false, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<false>)));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<true, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<true>)));
+#endif
         attr[device & 63] = true;
     }
     return SVT_AMD_OK;
@@ -2081,6 +2147,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         HIP_TRY(hipMemsetAsync(m->d_out, 0, sizeof(SvtAmdMdLcuOut) * (size_t)n, st));
     }
     m->d.prof = m->d_prof, m->d.prof_lcus = n;
+    m->d.trace = m->d_trace, m->d.trace_lcu = m->trace_lcu, m->d.trace_unit = m->trace_unit;
     m->d.encode = !X || works || results; /* P / B pictures: without a place for the work / result records, the mode decision alone */
     if (ois)
         HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -2119,6 +2186,10 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
     narrow = narrow > grid ? grid : narrow;
+    m->d.cost = pic->has_cost ? pic->d_cost : nullptr;
+    memcpy(m->h_stage + MD_STAGE_D, &m->d, sizeof(m->d));
+    HIP_TRY(hipMemcpyAsync(m->d_D, m->h_stage + MD_STAGE_D, sizeof(m->d), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(m->d_md_ticket, 0, sizeof(unsigned), st));
     MdFlight flight;
     /* the inputs first (a call that waits for its place holds no CU and no copy engine meanwhile) */
     HIP_TRY(hipStreamSynchronize(st));
@@ -2126,19 +2197,29 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X && bps == 1)
-        hipLaunchKernelGGL((k_md_encode_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true, uint8_t>), st, m->d, pic->d, (SvtAmdLcuWork *)m->d_works,
-                           (SvtAmdLcuResult *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
-    else if (bps == 1)
-        hipLaunchKernelGGL((k_md_encode_picture<false, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false, uint8_t>), st, m->d, pic->d, (SvtAmdLcuWork *)m->d_works,
-                           (SvtAmdLcuResult *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
-    else if (X)
-        hipLaunchKernelGGL((k_md_encode_picture<true, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<true, uint16_t>), st, m->d, pic->d, (SvtAmdLcuWork16 *)m->d_works,
-                           (SvtAmdLcuResult16 *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
+        hipLaunchKernelGGL((k_md_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<true>), st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+                           m->d_md_done, d_order, pic->epoch);
+#ifdef MD_INTER8_ONLY
     else
-        hipLaunchKernelGGL((k_md_encode_picture<false, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdEpShared<false, uint16_t>), st, m->d, pic->d, (SvtAmdLcuWork16 *)m->d_works,
-                           (SvtAmdLcuResult16 *)m->d_results, n_active, wl, pic->d_sync, pic->d_sync + 1, m->d_md_done, d_order, pic->epoch);
+        return SVT_AMD_ERR_BAD_PARAM;
+#else
+    else if (bps == 1)
+        hipLaunchKernelGGL((k_md_picture<false, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<false>), st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+                           m->d_md_done, d_order, pic->epoch);
+    else if (X)
+        hipLaunchKernelGGL((k_md_picture<true, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<true>), st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
+                           m->d_md_done, d_order, pic->epoch);
+    else
+        hipLaunchKernelGGL((k_md_picture<false, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<false>), st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
+                           m->d_md_done, d_order, pic->epoch);
+#endif
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev_k1, st));
+    /* the encode pass of the picture: its own kernel behind the decisions, on the same stream (every LCU's work record is in HBM; LCUs without intra units wait for nobody,
+     * so a P / B picture runs as wide as the device is) */
+    if (m->d.encode && (rc = svt_amd_ep_launch_behind_md(ctx, pic, m->d_works, m->d_results, n_active, d_order, X != nullptr, tiles)) != 0)
+        return rc;
+    HIP_TRY(hipEventRecord(m->ev_k2, st));
     if ((rc = ep_picture_written(ctx, pic)) != 0)
         return rc;
     {   /* records read in place: the next motion-estimation / open-loop intra launch INTO those slots orders itself behind this kernel (context.hip slot_records_before_write) */
@@ -2225,8 +2306,8 @@ extern "C" int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture 
         return rc;
     const size_t bytes = sizeof(unsigned long long) * 16 * (size_t)pic->nlcu;
     if (!m->d_prof) {
-        HIP_TRY(hipMalloc((void **)&m->d_prof, 2 * bytes)); /* stage sums of every LCU, then sub-stage sums of every LCU */
-        HIP_TRY(hipMemset(m->d_prof, 0, 2 * bytes));
+        HIP_TRY(hipMalloc((void **)&m->d_prof, 10 * bytes)); /* stage sums of every LCU, then sub-stage sums of every LCU, then both by unit depth (4 x 32 per LCU) */
+        HIP_TRY(hipMemset(m->d_prof, 0, 10 * bytes));
     }
     if (out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2248,6 +2329,17 @@ extern "C" int svt_amd_debug_md_kernel_ms(SvtAmdContext *ctx, SvtAmdEncDecPictur
     return SVT_AMD_OK;
 }
 
+/* measurement: duration of the encode-pass kernel that followed the picture object's last mode-decision launch (0 when the call asked for decisions only) */
+extern "C" int svt_amd_debug_md_ep_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, float *ms)
+{
+    if (!ctx || !pic || !pic->md || !ms)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(pic->md->ev_k2));
+    HIP_TRY(hipEventElapsedTime(ms, pic->md->ev_k1, pic->md->ev_k2));
+    return SVT_AMD_OK;
+}
+
 extern "C" int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, int *waiting)
 {
     std::lock_guard<std::mutex> l(g_flight_mu);
@@ -2262,8 +2354,8 @@ extern "C" int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, in
 extern "C" int svt_amd_debug_md_kernel_lds_bytes(int inter, int bytes_per_sample)
 {
     if (bytes_per_sample == 2)
-        return (int)(inter ? sizeof(MdEpShared<true, uint16_t>) : sizeof(MdEpShared<false, uint16_t>));
-    return (int)(inter ? sizeof(MdEpShared<true, uint8_t>) : sizeof(MdEpShared<false, uint8_t>));
+        return (int)(inter ? sizeof(MdShared<true>) : sizeof(MdShared<false>)) + (int)sizeof(MdPictureDev);
+    return (int)(inter ? sizeof(MdShared<true>) : sizeof(MdShared<false>)) + (int)sizeof(MdPictureDev);
 }
 
 /* debug: the finer marks of the mode-decision kernel (MD_SUB): 16 sums per LCU, collected together with svt_amd_debug_md_profile's (which switches the collection on) */
@@ -2275,6 +2367,46 @@ extern "C" int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPict
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t bytes = sizeof(unsigned long long) * 16 * (size_t)pic->nlcu;
     HIP_TRY(hipMemcpy(out, pic->md->d_prof + 16 * (size_t)pic->nlcu, bytes, hipMemcpyDeviceToHost));
+    return SVT_AMD_OK;
+}
+
+/* debug (-DMD_TRACE builds): lane-0 time stamps of the four waves along the unit chain of LCU `lcu`, units [unit, unit + 2) of its leaf list.  out == NULL: arms the picture
+ * object's later calls; with out: [4 waves][1 + 128] words - the count, then (mark << 48 | shader clock) */
+extern "C" int svt_amd_debug_md_trace(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int lcu, int unit, unsigned long long *out)
+{
+#ifdef MD_TRACE
+    if (!ctx || !pic)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    SvtAmdMdState *m = nullptr;
+    const int rc = md_state(pic, &m);
+    if (rc)
+        return rc;
+    const size_t bytes = sizeof(unsigned long long) * (4 * (1 + MD_TRACE_N) + 4);
+    if (!m->d_trace)
+        HIP_TRY(hipMalloc((void **)&m->d_trace, bytes));
+    if (out) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(out, m->d_trace, bytes, hipMemcpyDeviceToHost));
+    } else {
+        HIP_TRY(hipMemset(m->d_trace, 0, bytes));
+        m->trace_lcu = lcu, m->trace_unit = unit;
+    }
+    return SVT_AMD_OK;
+#else
+    (void)ctx, (void)pic, (void)lcu, (void)unit, (void)out;
+    return SVT_AMD_ERR_BAD_PARAM;
+#endif
+}
+
+/* debug: the stage and sub-stage sums by the depth of the unit they were spent on: [LCU][depth 0..3][32] (slots 0..15 as svt_amd_debug_md_profile, 16..31 as _sub) */
+extern "C" int svt_amd_debug_md_profile_depth(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out)
+{
+    if (!ctx || !pic || !pic->md || !pic->md->d_prof || !out)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, pic->md->d_prof + 32 * (size_t)pic->nlcu, sizeof(unsigned long long) * 128 * (size_t)pic->nlcu, hipMemcpyDeviceToHost));
     return SVT_AMD_OK;
 }
 
