@@ -141,8 +141,8 @@ struct MdInterShared {
     MdMvUnit mvu[9 * 18];          /* (cy + 1) * 18 + cx + 1: 8x8 cells, cy in [-1, 8), cx in [-1, 16] */
     SvtAmdMeCuResult me[SVT_AMD_ME_PU_COUNT]; /* the LCU's motion-estimation candidates */
     SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
-    MdMvUnit nb[2][5]; /* the spatial neighbours' motion, a copy per list-building wave */
-    MdInterLists T;
+    alignas(16) MdCand me_c[4], mg_c[5]; /* the unit's motion-estimation / merge candidates as their list-building waves leave them (wave 0 appends them to the intra candidates) */
+    int n_me, n_mg;
     alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
     uint8_t cpred[MD_PRED_SLOTS][64 * 64]; /* the fast loop's predictions of the first motion-compensated candidates, kept for the full loop */
     int8_t slot[MD_MAX_CAND];      /* candidate -> cpred slot, -1 = none */
@@ -152,6 +152,7 @@ struct MdInterShared {
     alignas(16) uint8_t cpred_c[MD_PRED_SLOTS][2][32 * 32]; /* the chroma predictions beside cpred, pitch = unit size / 2 */
     int16_t refc[2][132];          /* the unit's open-loop chroma intra references (Cb, Cr) in pu_predict's layout */
     uint32_t sadc[MD_MAX_CAND];    /* Cb + Cr SAD of the fast loop */
+    uint32_t sadc2[MD_MAX_CAND][2]; /* ... per plane, one owner per entry (md_units_inter) */
     uint8_t heavyc[MD_MAX_CAND];   /* the candidates whose chroma the fast loop predicts and measures, packed */
     int nheavyc;
     MdFl flc[MD_MAX_BUF][2][4];    /* the chroma full loop's sums per buffer, plane and transform unit */
@@ -176,9 +177,10 @@ struct MdShared {
     SvtAmdMdPicture pic;           /* the picture's controls and rate tables: the full costs index the tables by lane-dependent contexts (a load from HBM each otherwise) */
     RateTables rt;                 /* the estimator's scan / context tables (rate_device.h c_rt: 624 B of constant memory read per coefficient position) beside them */
     SvtAmdCabacCost cost;          /* the picture's coefficient-rate tables: read per coefficient in the full loops, so kept beside the LCU instead of in HBM */
-    MdCand cand[MD_MAX_CAND];
+    alignas(16) MdCand cand[MD_MAX_CAND];
     unsigned long long costs[MD_MAX_CAND], fast_rate[MD_MAX_CAND];
     uint32_t sad[MD_MAX_CAND];
+    uint32_t sadt[MD_MAX_CAND][4]; /* P / B pictures: the fast loop's luma SAD per candidate and tile (one owner per entry; [0] alone for units below 64x64) */
     uint8_t evaluated[MD_MAX_CAND];
     uint8_t heavy[MD_MAX_CAND];    /* the candidates the fast loop has to predict and measure, packed: the waves take them in turn */
     int nheavy;
@@ -292,6 +294,16 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
     return (dc + n) >> (lgn + 1);
 }
 
+/* the coefficient-bit estimator (rate_device.h) as ONE function for every transform size: inlined into the four sizes of md_full_loop_unit it was 2.5 K instructions four
+ * times over in a kernel whose unit loop does not fit the instruction cache (SQC_TC_INST_REQ: ~760 instruction lines from L2 per unit, profiles/r06_j) */
+__device__ __noinline__ uint32_t md_coeff_bits(const SvtAmdCabacCost *cost, const int16_t *qbuf, int N, int lga, uint32_t nz, int type, int intra_mode, int component, int lane, int S4,
+                                               const RateTables *rt)
+{
+    MD_LDS(cost), MD_LDS(qbuf), MD_LDS(rt);
+    const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
+    return coeff_bits_lanes(*cost, qbuf, (uint32_t)N, lga, ti, lane < S4, lane, lane & (S4 - 1), *rt);
+}
+
 /* One transform unit of ProductFullLoop (EbFullLoop.c:185-446) / FullLoop_R + CuFullDistortionFastTuMode_R (:579-1066) on lanes r = 0..N-1 of
  * the calling wave: residual -> EstimateTransform -> quantiser -> coefficient-domain distortion -> coefficient bits.  src / pred: the unit's
  * source and prediction (pitches in samples); recon_coeff: the de-quantised coefficients (N x N, pitch N) for PerformInverseTransformRecon, or
@@ -340,18 +352,20 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
 #pragma unroll
     for (int j = 0; j < N; j++) {
         const int v = x[j], sign = v < 0 ? -1 : 1;
+        /* the products of the quantiser fit 24 x 24 bits (coefficients are 16-bit values by the transforms' construction, the scaling factors below 2^15): v_mul_i32_i24 is
+         * a full-rate instruction, v_mul_lo_u32 a quarter-rate one - four of them per coefficient on one lane's chain */
         int tq = abs(v);
-        tq = (int)((uint32_t)tq * QF);
+        tq = (int)__umul24((uint32_t)tq, QF);
         tq = (int)((uint32_t)tq + offs);
         tq >>= shiftedQBits;
         const int q = clip16i(sign * tq);
-        const int c = clip16i(((q * shiftedFFunc) + iq_offset) >> shiftNum);
+        const int c = clip16i((__mul24(q, shiftedFFunc) + iq_offset) >> shiftNum);
         if (in_area && j < area) {
             qbuf[j * N + r] = (int16_t)q;
             if (recon_coeff)
                 recon_coeff[j * N + r] = (int16_t)c;
             const int df = (int16_t)(v - c);
-            nz += q != 0, d0 += (uint32_t)(df * df), d1 += (uint32_t)(v * v);
+            nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
         }
     }
     MD_TR(53);
@@ -359,9 +373,8 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     EP_WAVE_SYNC(); /* qbuf is written */
     MD_TR(54);
     const int lga = LG - pf, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
-    const SvtAmdTuInfo ti = {nz, (uint8_t)type, (uint8_t)intra_mode, 4 /* EB_INTRA_CHROMA_DM */, (uint8_t)component};
     /* nz is the whole unit's count and the same in every lane: a unit without levels (most merge candidates of a B picture at these QPs) has no bits to estimate */
-    const uint32_t b32 = nz ? coeff_bits_lanes(cost, qbuf, N, lga, ti, lane < S4, lane, lane & (S4 - 1), rt) : 0u;
+    const uint32_t b32 = nz ? md_coeff_bits(&cost, qbuf, N, lga, nz, type, intra_mode, component, lane, S4, &rt) : 0u;
     MdFl o;
     o.nz = nz, o.d0 = nz ? d0 : d1, o.d1 = d1, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
     MD_TR(55);
@@ -429,18 +442,122 @@ __device__ __forceinline__ unsigned long long md_readlane64(unsigned long long v
     return ((unsigned long long)hi << 32) | lo;
 }
 
-/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of plane p of a candidate (0 luma: N x N, 1 / 2 chroma: N/2 x N/2), by one wave, into dst with pitch = the block's width */
-__device__ MD_LEAF_CALL void md_predict_inter_plane(const EpRefPlanes *refs, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
-                                                    int tile_first, int tile_step, const EpRefWindows *rw)
+/* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of ONE TILE (TN x TN samples: the whole block of a unit up to 32x32 / its chroma block, a quarter of a 64x64
+ * unit's luma) of plane p of a candidate, by one wave, both lists: ep_inter_predict_core8 (encdec_device.h) with the tile size and the tap count decided at compile time -
+ * a function per size (the 16x16 and 8x8 blocks most units have need a fraction of the registers of the 32x32 form: no callee-saved register, so no private-segment traffic
+ * around the call), everything passed BY VALUE (a candidate passed by reference went through the private segment: a memory round trip of ~1.5 K clocks per call on the unit
+ * chain).  mv0 / mv1: x | y << 16.  td: the tile's first sample in the destination, pitch in samples. */
+template <int TN, bool CHROMA>
+__device__ MD_LEAF_CALL void md_predict_tile(const EpRefPlanes *refs, int abs_x, int abs_y, int inter_dir, uint32_t mv0, uint32_t mv1, int p, int lane, EpMcScratch<uint8_t> *Mp,
+                                             uint8_t *td, int pitch, int tx0, int ty0, const EpRefWindows *RW)
 {
-    int16_t mv[2][2];
-    mv[0][0] = c.mv[0].x, mv[0][1] = c.mv[0].y, mv[1][0] = c.mv[1].x, mv[1][1] = c.mv[1].y;
-    const int pitch = p ? N >> 1 : N;
-    /* a function's pointer arguments are generic: tell the compiler which of them point into LDS, or every access becomes a FLAT instruction (slower than ds_*, and it
-     * waits on both memory counters) */
-    MD_LDS(&mc), MD_LDS(dst), MD_LDS(rw), MD_LDS(refs); /* (the candidate is the caller's copy in registers / private memory) */
-    ep_inter_predict_core8(refs, x0, y0, N, c.dir, mv, p, lane, mc, dst, pitch, tile_first, tile_step, rw);
-    EP_WAVE_SYNC();
+    constexpr int WP = EpMcScratch<uint8_t>::WP;
+    constexpr int ntaps = CHROMA ? 4 : 8, first = CHROMA ? -1 : -3, rows = TN + ntaps - 1, cpr = (rows + 7) >> 3, nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
+    EpMcScratch<uint8_t> &M = *Mp;
+    MD_LDS(Mp), MD_LDS(td), MD_LDS(RW), MD_LDS(refs);
+    const bool bi = inter_dir == 2;
+    bool second = false;
+    for (int l = 0; l < 2; l++) {
+        if (!(bi || inter_dir == l))
+            continue;
+        MD_TR(40);
+        const EpRefPlanes R = refs[l]; /* one read of the whole record */
+        const uint32_t mvw = l ? mv1 : mv0;
+        const int mvx = (int)(int16_t)(mvw & 0xFFFF), mvy = (int)(int16_t)(mvw >> 16);
+        const int qx = min(max(((abs_x + R.originX) << 2) + mvx, (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
+        const int qy = min(max(((abs_y + R.originY) << 2) + mvy, (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
+        const int ix = (CHROMA ? qx >> 3 : qx >> 2) + tx0, iy = (CHROMA ? qy >> 3 : qy >> 2) + ty0;
+        const int fx = __builtin_amdgcn_readfirstlane(CHROMA ? qx & 7 : qx & 3), fy = __builtin_amdgcn_readfirstlane(CHROMA ? qy & 7 : qy & 3);
+        bool staged = false;
+        MD_TR(41);
+        if (RW && !CHROMA && RW->valid[l]) {
+            const int rx = ix + first - RW->x0[l], ry = iy + first - RW->y0[l];
+            if (rx >= 0 && ry >= 0 && rx + cpr * 8 <= EpRefWindows::P && ry + rows <= EpRefWindows::H) {
+                staged = true;
+#pragma unroll
+                for (int i0 = 0; i0 < nchunk; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < nchunk) {
+                        const int j = (i * inv) >> 16, m = i - j * cpr, o = (ry + j) * EpRefWindows::P + rx + m * 8, sh = o & 3;
+                        const uint32_t *wp = reinterpret_cast<const uint32_t *>(&RW->pix[l][o & ~3]);
+                        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        uint2 v;
+                        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh), v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                        *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v;
+                    }
+                }
+            }
+        }
+        if (!staged) {
+            const int stride = (int)R.stride[CHROMA], last = R.size[CHROMA] - 1;
+            const uint8_t *plane = (const uint8_t *)R.plane[p];
+            const int base0 = (iy + first) * stride + ix + first;
+            constexpr int NU = (nchunk + 63) / 64; /* every load of the window issued before the first store: one memory latency per window */
+            uint2 v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int i = u * 64 + lane;
+                if (i < nchunk) {
+                    const int j = (i * inv) >> 16, m = i - j * cpr, idx = base0 + j * stride + m * 8;
+                    if (idx >= 0 && idx + 8 <= last + 1) {
+                        __builtin_memcpy(&v[u], plane + idx, 8);
+                    } else {
+                        uint8_t e[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                            e[q] = plane[min(max(idx + q, 0), last)];
+                        __builtin_memcpy(&v[u], e, 8);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int i = u * 64 + lane;
+                if (i < nchunk) {
+                    const int j = (i * inv) >> 16, m = i - j * cpr;
+                    *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v[u];
+                }
+            }
+        }
+        EP_WAVE_SYNC();
+        MD_TR(staged ? 42 : 46);
+        ep_mc8_tile<TN, CHROMA>(M, lane, fx, fy, !bi ? 0 : (second ? 2 : 1), td, pitch);
+        MD_TR(44);
+        second = true;
+    }
+}
+/* ... of plane p (0 luma: N x N, 1 / 2 chroma: N/2 x N/2) of a candidate (direction, vectors x | y << 16) into dst with pitch = the block's width; tile_first / tile_step
+ * let several waves share the four 32x32 tiles of a 64x64 unit's luma */
+__device__ __forceinline__ void md_predict_inter_plane(const EpRefPlanes *refs, int dir, uint32_t mv0, uint32_t mv1, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc,
+                                                       uint8_t *dst, int tile_first, int tile_step, const EpRefWindows *rw)
+{
+    const int n = p ? N >> 1 : N, pitch = n;
+    if (!p) {
+        switch (n) {
+        case 64:
+            for (int ti = tile_first; ti < 4; ti += tile_step) {
+                const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
+                md_predict_tile<32, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst + ty0 * pitch + tx0, pitch, tx0, ty0, rw);
+            }
+            break;
+        case 32: md_predict_tile<32, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw); break;
+        case 16: md_predict_tile<16, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw); break;
+        default: md_predict_tile<8, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw); break;
+        }
+    } else {
+        switch (n) {
+        case 32: md_predict_tile<32, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
+        case 16: md_predict_tile<16, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
+        case 8: md_predict_tile<8, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
+        default: md_predict_tile<4, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
+        }
+    }
+}
+__device__ __forceinline__ uint32_t md_pack_mv(MdMv v) { return (uint32_t)(uint16_t)v.x | ((uint32_t)(uint16_t)v.y << 16); }
+__device__ __forceinline__ void md_predict_inter_plane(const EpRefPlanes *refs, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
+                                                       int tile_first, int tile_step, const EpRefWindows *rw)
+{
+    md_predict_inter_plane(refs, (int)c.dir, md_pack_mv(c.mv[0]), md_pack_mv(c.mv[1]), x0, y0, N, p, lane, mc, dst, tile_first, tile_step, rw);
 }
 /* IntraPredictionOl's chroma references of the unit (Codec/EbIntraPrediction.c:5065 UpdateChromaNeighborSamplesArrayOL): SOURCE chroma samples around the
  * unit, mid-grey beyond the picture.  By one wave; ref[p] in pu_predict's layout (n = N/2). */
@@ -525,6 +642,906 @@ __device__ __forceinline__ void md_chroma_tu(int lane, int T, const uint8_t *src
     dist[0] = ((unsigned long long)o.d0 + (1ull << (sh - 1))) >> sh, dist[1] = ((unsigned long long)o.d1 + (1ull << (sh - 1))) >> sh;
     *bits = (((unsigned long long)o.bits) << 10) >> 15;
     EP_WAVE_SYNC();
+}
+
+/* ---- the motion-vector lists of a unit on REGISTERS (round 6): GenerateL0L1AmvpMergeLists (Codec/EbAdaptiveMotionVectorPrediction.c:2117-3005) as md_logic.h restates it
+ * (md_amvp_merge_lists_parts - the text the CPU checker runs and the device tests compare with, reference records on both sides), specialised for what a picture fixes:
+ * the target picture of list l IS ref_poc[l], so "the neighbour's vector points to the target picture" is a compare of list indices (+ one flag: both lists hold the same
+ * picture), and the scale factor of a spatial neighbour that points to the other list's picture is a constant of the picture - the division of ScaleMV happens once per LCU
+ * (MdListConsts), not per neighbour.  The five neighbours arrive in registers (v_readlane), both lists are derived side by side: lane l of the wave works on list l. */
+struct MdListConsts {
+    int same01;      /* ref_poc[0] == ref_poc[1] */
+    int need[2];     /* a vector of the OTHER list's picture has to be scaled to reach list l's picture (td != tb) */
+    int scale[2];    /* ... by this factor (ScaleMV :28-52) */
+    int bslice;
+};
+__device__ __forceinline__ int md_scale_factor(int tb, int td) /* ScaleMV's factor; tb, td: int16 differences */
+{
+    tb = md_clip3(-128, 127, tb), td = md_clip3(-128, 127, td);
+    const int16_t temp = (int16_t)((0x4000 + ((td >> 1) < 0 ? -(td >> 1) : (td >> 1))) / td);
+    return md_clip3(-4096, 4095, (tb * temp + 32) >> 6);
+}
+__device__ __forceinline__ MdMv md_scale_by(MdMv v, int scale)
+{
+    MdMv o;
+    o.x = (int16_t)md_clip3(-32768, 32767, (scale * v.x + 127 + (scale * v.x < 0)) >> 8);
+    o.y = (int16_t)md_clip3(-32768, 32767, (scale * v.y + 127 + (scale * v.y < 0)) >> 8);
+    return o;
+}
+__device__ __forceinline__ MdListConsts md_list_consts(const SvtAmdMdPicture &P, const SvtAmdMdInter &X)
+{
+    MdListConsts k;
+    k.bslice = P.slice_type == 0;
+    k.same01 = X.ref_poc[0] == X.ref_poc[1];
+    for (int l = 0; l < 2; l++) {
+        const int16_t tb = (int16_t)(X.picture_number - X.ref_poc[l]), td = (int16_t)(X.picture_number - X.ref_poc[1 - l]);
+        k.need[l] = td != tb;
+        k.scale[l] = td != tb && td != 0 ? md_scale_factor(tb, td) : 0;
+    }
+    return k;
+}
+/* GetTemporalMVP_V2 / one list of GetTemporalMVPBPicture_V2 (md_temporal_mvp, md_logic.h) */
+__device__ __forceinline__ bool md_temporal_mvp_dev(const SvtAmdMdInter &X, const SvtAmdTmvpLcu *map, MdTmvpPos t, int targetList, MdMv *out)
+{
+    int colList = X.is_low_delay ? targetList : 1 - X.colocated_pu_ref_list;
+    const SvtAmdTmvpLcu *m = &map[t.bottom_right ? t.lcu_offset : 0];
+    if (!t.bottom_right && !m->available[t.unit])
+        return false;
+    const int pd = m->pred_dir[t.unit];
+    colList = pd == MD_BI ? colList : pd;
+    MdMv v;
+    v.x = m->mv[colList][t.unit][0], v.y = m->mv[colList][t.unit][1];
+    const int16_t td = (int16_t)(X.colocated_poc - m->ref_poc[colList][t.unit]), tb = (int16_t)(X.picture_number - X.ref_poc[targetList]);
+    if (td != tb)
+        v = md_scale_by(v, md_scale_factor(tb, td));
+    *out = v;
+    return true;
+}
+/* the AMVP candidates of list `list` (a per-lane value): GetSpatialMVPPosAx_V3 / GetNonScalingSpatialMVPPosBx_V3 / GetScalingSpatialMVPPosBx_V3 + the temporal candidate + the
+ * zero fill -> c[0..1], count */
+__device__ __forceinline__ int md_amvp_one_list(const MdListConsts &K, const SvtAmdMdInter &X, const MdMvUnit (&nb)[5], const SvtAmdTmvpLcu *map, MdTmvpPos tp, int list, MdMv c[3])
+{
+    /* non-scaling: the neighbour's vector that points to list `list`'s picture */
+    auto nonscale = [&](const MdMvUnit &u, MdMv *out) -> bool {
+        if (u.dir == MD_BI) {
+            *out = u.mv[0];
+            if (list)
+                *out = u.mv[1];
+            return true;
+        }
+        const bool ok = u.dir == list || K.same01;
+        if (ok)
+            *out = u.dir ? u.mv[1] : u.mv[0];
+        return ok;
+    };
+    /* scaling: always available */
+    auto scaled = [&](const MdMvUnit &u) -> MdMv {
+        const int l2 = u.dir == MD_BI ? list : u.dir;
+        MdMv v = l2 ? u.mv[1] : u.mv[0];
+        if (l2 != list && K.need[list ? 1 : 0])
+            v = md_scale_by(v, list ? K.scale[1] : K.scale[0]);
+        return v;
+    };
+    const MdMvUnit &A0 = nb[MD_A0], &A1 = nb[MD_A1], &B0 = nb[MD_B0], &B1 = nb[MD_B1], &B2 = nb[MD_B2];
+    MdMv zero;
+    zero.x = zero.y = 0;
+    c[0] = c[1] = c[2] = zero;
+    int num = 0;
+    bool ax = false;
+    MdMv v = zero;
+    if (A0.avail)
+        ax = nonscale(A0, &v);
+    if (!ax && A1.avail)
+        ax = nonscale(A1, &v);
+    if (!ax && (A0.avail || A1.avail))
+        v = scaled(A0.avail ? A0 : A1), ax = true;
+    if (ax)
+        c[0] = v, num = 1;
+    bool bx = false;
+    MdMv vb = zero;
+    if (B0.avail)
+        bx = nonscale(B0, &vb);
+    if (!bx && B1.avail)
+        bx = nonscale(B1, &vb);
+    if (!bx && B2.avail)
+        bx = nonscale(B2, &vb);
+    /* (a vector a failed test left behind is overwritten or never counted, exactly as in the reference's array) */
+    if (bx) {
+        if (num == 0)
+            c[0] = vb;
+        else
+            c[1] = vb;
+        num++;
+    }
+    if (!ax && (B0.avail || B1.avail || B2.avail)) {
+        const MdMv vs = scaled(B0.avail ? B0 : (B1.avail ? B1 : B2));
+        if (num == 0)
+            c[0] = vs;
+        else if (num == 1)
+            c[1] = vs;
+        else
+            c[2] = vs;
+        num++;
+    }
+    if (num == 2 && c[0].x == c[1].x && c[0].y == c[1].y)
+        num = 1;
+    if (map && num < 2) {
+        MdMv tv;
+        if (md_temporal_mvp_dev(X, map, tp, list, &tv)) {
+            if (num == 0)
+                c[0] = tv;
+            else
+                c[1] = tv;
+            num++;
+        }
+    }
+    if (num < 1 || (num == 1 && c[0].x != 0 && c[0].y != 0)) {
+        if (num == 0)
+            c[0] = zero;
+        else
+            c[1] = zero;
+        num++;
+    }
+    return num;
+}
+/* ChooseMVPIdx_V2 for one list (md_choose_mvp, md_logic.h): clips the candidate's vector of that list, picks the nearer predictor */
+__device__ __forceinline__ void md_choose_mvp_one(const SvtAmdMdPicture &P, uint32_t ox, uint32_t oy, const MdMv a[3], int count, MdMv *mv, uint8_t *idxOut, MdMv *mvp)
+{
+    md_clip_mv(&P, ox, oy, mv);
+    int idx = 0;
+    if (count == 2) {
+        const uint32_t d0 = (uint32_t)abs(a[0].x - mv->x) + (uint32_t)abs(a[0].y - mv->y), d1 = (uint32_t)abs(a[1].x - mv->x) + (uint32_t)abs(a[1].y - mv->y);
+        idx = d0 <= d1 ? 0 : 1;
+    } else if (count > 2) {
+        return;
+    }
+    *idxOut = (uint8_t)idx, *mvp = idx ? a[1] : a[0];
+}
+/* the merge candidates (md_amvp_merge_lists_parts part 4, :2649-2990): m[0..4], always totalMerge of them (the zero vectors fill the list).  t0 / t1 / tok: the temporal
+ * candidate's two vectors and whether list 0's exists (derived by the caller, a lane per list) */
+__device__ __forceinline__ void md_merge_list_regs(const MdListConsts &K, const MdMvUnit (&nb)[5], bool have_map, bool tok, MdMv t0, MdMv t1, int totalMerge, MdMergeCand m[5])
+{
+    const int bslice = K.bslice;
+    const MdMvUnit &A0 = nb[MD_A0], &A1 = nb[MD_A1], &B0 = nb[MD_B0], &B1 = nb[MD_B1], &B2 = nb[MD_B2];
+    int idx = 0;
+    auto add = [&](int dir, MdMv v0, MdMv v1) {
+        MdMergeCand e;
+        e.mv[0] = v0, e.mv[1] = v1, e.dir = (uint8_t)dir, e.pad[0] = e.pad[1] = e.pad[2] = 0;
+        if (idx < totalMerge) { /* (the reference leaves its loop as soon as the list is full) */
+            if (idx == 0)
+                m[0] = e;
+            else if (idx == 1)
+                m[1] = e;
+            else if (idx == 2)
+                m[2] = e;
+            else if (idx == 3)
+                m[3] = e;
+            else
+                m[4] = e;
+        }
+        idx++;
+    };
+    auto differs = [&](const MdMvUnit &a, const MdMvUnit &b) { return md_mv_differs(&a, &b, bslice) != 0; };
+    for (int k = 0; k < 5; k++)
+        m[k].mv[0].x = m[k].mv[0].y = m[k].mv[1].x = m[k].mv[1].y = 0, m[k].dir = 0, m[k].pad[0] = m[k].pad[1] = m[k].pad[2] = 0;
+    if (A1.avail)
+        add(bslice ? A1.dir : MD_L0, A1.mv[0], A1.mv[1]);
+    if (idx < totalMerge && B1.avail && (!A1.avail || differs(B1, A1)))
+        add(bslice ? B1.dir : MD_L0, B1.mv[0], B1.mv[1]);
+    if (idx < totalMerge && B0.avail && (!B1.avail || differs(B0, B1)))
+        add(bslice ? B0.dir : MD_L0, B0.mv[0], B0.mv[1]);
+    if (idx < totalMerge && A0.avail && (!A1.avail || differs(A0, A1)))
+        add(bslice ? A0.dir : MD_L0, A0.mv[0], A0.mv[1]);
+    if (idx < totalMerge && idx < 4 && B2.avail && (!A1.avail || differs(B2, A1)) && (!B1.avail || differs(B2, B1)))
+        add(bslice ? B2.dir : MD_L0, B2.mv[0], B2.mv[1]);
+    if (idx < totalMerge && have_map && tok) {
+        MdMv z;
+        z.x = z.y = 0;
+        if (bslice)
+            add(MD_BI, t0, t1);
+        else if (idx < 5)
+            add(MD_L0, t0, z);
+    }
+    if (idx < totalMerge && bslice) { /* combined bi-predictive candidates: mvMergeCandIndexArrayForFillingUp (:20-23) */
+        const int loopEnd = idx * (idx - 1);
+        auto at = [&](int i) -> MdMergeCand { return i == 0 ? m[0] : i == 1 ? m[1] : i == 2 ? m[2] : m[3]; };
+        for (int f = 0; idx < totalMerge && f < loopEnd; f++) {
+            const int i0 = f == 0 ? 0 : f == 1 ? 1 : f == 2 ? 0 : f == 3 ? 2 : f == 4 ? 1 : f == 5 ? 2 : f == 6 ? 0 : f == 7 ? 3 : f == 8 ? 1 : f == 9 ? 3 : f == 10 ? 2 : 3;
+            const int i1 = f == 0 ? 1 : f == 1 ? 0 : f == 2 ? 2 : f == 3 ? 0 : f == 4 ? 2 : f == 5 ? 1 : f == 6 ? 3 : f == 7 ? 0 : f == 8 ? 3 : f == 9 ? 1 : f == 10 ? 3 : 2;
+            const MdMergeCand c0 = at(i0), c1 = at(i1);
+            if (((c0.dir + 1) & 1) && ((c1.dir + 1) & 2) && (!K.same01 || c0.mv[0].x != c1.mv[1].x || c0.mv[0].y != c1.mv[1].y))
+                add(MD_BI, c0.mv[0], c1.mv[1]);
+        }
+    }
+    {
+        MdMv z;
+        z.x = z.y = 0;
+        for (int r = 0; r < 5 && idx < totalMerge; r++)
+            add(bslice ? MD_BI : MD_L0, z, z);
+    }
+}
+
+/* ---- the unit loop of P / B pictures (round 6) ---------------------------------------------------------------------------------------------------------------------------
+ * The decisions are those of md_lcu's loop below (which I pictures keep) - same md_logic.h rules, same leaves, same arithmetic - arranged for the one thing that bounds the
+ * picture: the length of a unit's dependency chain on ONE wave (a wave issues an instruction every ~4 clocks, an LDS round trip costs ~30 issue slots, a workgroup barrier
+ * with a single-lane stage behind it serialises four SIMDs).  Four barriers per unit instead of ten:
+ *   A  contexts + intra candidates (wave 0) | AMVP lists + motion-estimation candidates (wave 1) | merge list + merge candidates (wave 2) | intra references (wave 3)
+ *   -- barrier --
+ *   B  EVERY wave derives the unit's candidate list in its own registers (lane i = candidate i: first fast loop, evaluated flags, the task list as ballot masks) - nothing
+ *      to broadcast, no barrier - and runs its share of the fast-loop tasks
+ *   -- barrier --
+ *   C  EVERY wave: fast costs (lane per candidate), candidate-buffer replay, PreModeDecision - again redundantly, so each wave knows the survivors - then its share of the
+ *      full-loop tasks
+ *   -- barrier --
+ *   D  wave 0: full costs (lane per survivor), ProductFullModeDecision, CheckHighCostPartition, inter-depth decision, neighbour update, next unit
+ *   -- barrier --
+ * Candidates live in lane registers of every wave (a field of candidate c is a v_readlane away), not in LDS records read field by field. */
+__device__ __forceinline__ int md_nth_bit(unsigned long long m, int k) /* index of the k-th set bit (k < popcount) */
+{
+    for (int i = 0; i < k; i++)
+        m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+__device__ __forceinline__ uint32_t md_rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+union MdCandWords {
+    MdCand c;
+    uint32_t w[8];
+};
+static_assert(sizeof(MdCand) == 32, "a candidate is eight words: type | intra_mode | mpm | dist_ready, me_dist, dir | merge_flag | merge_index | mvp_idx[0], mvp_idx[1], mv[0], mv[1], mvp[0], mvp[1]");
+
+__device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, int lcu_x, int lcu_y, MdShared<true> &M)
+{
+    const SvtAmdMdPicture &P = M.pic; /* the rate tables (indexed by contexts): read where they are */
+    /* the picture's and the LCU's CONTROLS in registers: a copy of the records' scalar parts, made once per LCU (a control read from LDS is a ~120-clock round trip on
+     * a chain whose every stage tests a dozen of them).  Ph / Lh go to the rules that read controls only; the rate tables and the leaf list stay behind P / M.lcu. */
+    SvtAmdMdPicture Ph;
+    __builtin_memcpy(&Ph, &M.pic, offsetof(SvtAmdMdPicture, rates));
+    SvtAmdMdLcu Lh;
+    __builtin_memcpy(&Lh.tile_left, &M.lcu.tile_left, sizeof(SvtAmdMdLcu) - offsetof(SvtAmdMdLcu, tile_left));
+    Lh.leaf_count = M.lcu.leaf_count;
+    /* the wave index as a UNIFORM value (an SGPR): the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave, and makes every `if (wave == ..)` and
+     * every task loop a masked vector region otherwise */
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = t & 63;
+    auto &L = M.L;
+    const int W = (int)Ph.width, H = (int)Ph.height;
+    const int lh = min(64, H - lcu_y);
+    const SvtAmdOisLcuResult *ois = &M.ois;
+    const int pf = md_pf_mode(&Ph);
+    /* what the picture and the LCU fix, read once */
+    const bool cfull = Lh.chroma_encode_mode == 1; /* CHROMA_MODE_FULL: chroma in both loops of every candidate */
+    const bool tile_l = Lh.tile_left != 0, tile_t = Lh.tile_top != 0, tile_r = Lh.tile_right != 0;
+    const MdListConsts K = md_list_consts(Ph, M.V.X);
+    const bool tmvp_on = M.V.X.tmvp_enable != 0;
+    const unsigned long long lanebit = 1ull << lane, below = lanebit - 1ull;
+    for (;;) {
+        MD_TR(10);
+        /* ---- the unit (every thread alike) ---- */
+        const int cuIdx = M.cu_idx, leaf = M.lcu.leaf_index[cuIdx];
+        const MdStats st = md_stats(leaf);
+        const int N = st.size, lgN = st.lg, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
+        const int totalMerge = md_nmm(&Ph, N);
+        /* ================= A ================= */
+        if (wave == 0) {
+            if (lane == 0) {
+                M.leaf = leaf;
+                if (D.prof)
+                    M.prof_depth = st.depth;
+                M.S.local[leaf].tested = 1;
+                M.S.cu[leaf].split = M.lcu.leaf_split[cuIdx];
+                uint32_t l = L.info_at(st.x - 1, st.y), tp = L.info_at(st.x, st.y - 1);
+                if ((tile_l && st.x == 0) || (l & 0xFF) == 0xFE)
+                    l = 0xFFFFFFFFu;
+                if ((tile_t && st.y == 0) || (tp & 0xFF) == 0xFE)
+                    tp = 0xFFFFFFFFu;
+                MdNeighbors Nb;
+                Nb.left_mode = (uint8_t)l, Nb.left_intra = (uint8_t)(l >> 8), Nb.left_depth = (uint8_t)(l >> 16), Nb.left_skip = (uint8_t)(l >> 24);
+                Nb.top_mode = (uint8_t)tp, Nb.top_intra = (uint8_t)(tp >> 8), Nb.top_depth = (uint8_t)(tp >> 16), Nb.top_skip = (uint8_t)(tp >> 24);
+                md_context_generation(&M.S, leaf, st.y, &Nb);
+                M.S.cu[leaf].split = (uint8_t)md_skip_small_cu(&Ph, &Lh, &M.S, leaf, st.depth);
+                int ncand = 0;
+                if (st.depth != 0 && (st.depth == 3 || !Lh.restrict_intra_global_motion))
+                    if (!(Ph.limit_intra && st.x == 0 && st.y == 0))
+                        ncand = md_intra_candidates(&Ph, &M.lcu, ois, leaf, &st, M.cand);
+                M.ncand = ncand; /* the intra candidates; the other waves' follow */
+            }
+            MD_TR(11);
+            MD_SUB(0);
+        } else if (wave < 3) {
+            /* the five spatial neighbours (A0, A1, B0, B1, B2; availability as GenerateL0L1AmvpMergeLists derives it, :2256-2340): a lane each, then all five in registers */
+            uint32_t w0 = 0, w1 = 0, w2 = 0;
+            if (lane < 5) {
+                const int k = lane;
+                const bool left = tile_l && st.x == 0, top = tile_t && st.y == 0, right = tile_r && ((st.x + N) & 63) == 0;
+                const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
+                const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
+                if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(M.V.mv_at(px, py));
+                    w0 = q[0], w1 = q[1], w2 = (q[2] & 0xFFu) | 0x100u; /* mv[0], mv[1], dir | avail << 8 */
+                }
+            }
+            MdMvUnit nbr[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t a = md_rl(w0, k), b = md_rl(w1, k), c = md_rl(w2, k);
+                nbr[k].mv[0].x = (int16_t)(a & 0xFFFF), nbr[k].mv[0].y = (int16_t)(a >> 16), nbr[k].mv[1].x = (int16_t)(b & 0xFFFF), nbr[k].mv[1].y = (int16_t)(b >> 16);
+                nbr[k].dir = (uint8_t)(c & 0xFF), nbr[k].avail = (uint8_t)((c >> 8) & 1), nbr[k].pad[0] = nbr[k].pad[1] = 0;
+            }
+            MD_TR(12);
+            const SvtAmdTmvpLcu *map = tmvp_on ? M.V.tmvp : nullptr;
+            MdTmvpPos tp;
+            tp.bottom_right = 0, tp.lcu_offset = 0, tp.unit = 0, tp.pad = 0;
+            if (map)
+                tp = md_tmvp_position(&Ph, map, x0, y0, N);
+            const int list = lane & 1; /* list-specific work: lane l on list l */
+            bool keep = false;
+            MdCandWords cw;
+            cw.w[0] = MD_INTER, cw.w[1] = cw.w[2] = cw.w[3] = cw.w[4] = cw.w[5] = cw.w[6] = cw.w[7] = 0;
+            if (wave == 1) {
+                /* both AMVP lists side by side, then Me2Nx2NCandidatesInjection: a lane per motion-estimation candidate */
+                MdMv a[3];
+                const int num = md_amvp_one_list(K, M.V.X, nbr, map, tp, list, a);
+                const uint32_t pa0 = md_pack_mv(a[0]), pa1 = md_pack_mv(a[1]);
+                MD_TR(13);
+                const SvtAmdMeCuResult *me = &M.V.me[md_raster_index(&st)];
+                if (lane < 3 && lane < me->total_me_candidate_index) {
+                    const int dir = me->direction[lane];
+                    if (!(dir == MD_BI && Ph.depth_mode == 0 && Lh.lcu_md_mode == 10)) {
+                        keep = true;
+                        MdCand &c = cw.c;
+                        c.dist_ready = 1, c.me_dist = me->distortion[lane], c.dir = (uint8_t)dir;
+                        c.mv[0].x = me->x_mv_l0, c.mv[0].y = me->y_mv_l0, c.mv[1].x = me->x_mv_l1, c.mv[1].y = me->y_mv_l1;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < 2; l++) { /* ChooseMVPIdx_V2 with list l's candidates (lane l holds them) */
+                    MdMv al[3];
+                    const uint32_t q0 = md_rl(pa0, l), q1 = md_rl(pa1, l);
+                    const int cnt = (int)md_rl((uint32_t)num, l);
+                    al[0].x = (int16_t)(q0 & 0xFFFF), al[0].y = (int16_t)(q0 >> 16), al[1].x = (int16_t)(q1 & 0xFFFF), al[1].y = (int16_t)(q1 >> 16), al[2] = al[1];
+                    if (keep && (cw.c.dir == MD_BI || cw.c.dir == l))
+                        md_choose_mvp_one(Ph, (uint32_t)x0, (uint32_t)y0, al, cnt, &cw.c.mv[l], &cw.c.mvp_idx[l], &cw.c.mvp[l]);
+                }
+            } else {
+                /* the temporal candidate's two vectors side by side, the merge list, then ProductMergeSkip2Nx2NCandidatesInjection: a lane per merge candidate */
+                MdMv tv;
+                tv.x = tv.y = 0;
+                bool tok = false;
+                if (map && (list == 0 || K.bslice)) {
+                    tok = md_temporal_mvp_dev(M.V.X, map, tp, list, &tv);
+                    if (!tok)
+                        tv.x = tv.y = 0;
+                }
+                const uint32_t ptv = md_pack_mv(tv), q0 = md_rl(ptv, 0), q1 = md_rl(ptv, 1);
+                const bool tok0 = md_rl((uint32_t)tok, 0) != 0;
+                MdMv t0v, t1v;
+                t0v.x = (int16_t)(q0 & 0xFFFF), t0v.y = (int16_t)(q0 >> 16), t1v.x = (int16_t)(q1 & 0xFFFF), t1v.y = (int16_t)(q1 >> 16);
+                MdMergeCand mg[5];
+                md_merge_list_regs(K, nbr, map != nullptr, tok0, t0v, t1v, totalMerge, mg);
+                MD_TR(13);
+                const int k = lane;
+                if (k < 5 && k < totalMerge) {
+                    const MdMergeCand mc = k == 0 ? mg[0] : k == 1 ? mg[1] : k == 2 ? mg[2] : k == 3 ? mg[3] : mg[4];
+                    bool dup = false;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const MdMergeCand d = mg[j];
+                        const bool f0 = mc.mv[0].x == d.mv[0].x && mc.mv[0].y == d.mv[0].y;
+                        const bool f1 = mc.dir != MD_L0 && mc.mv[1].x == d.mv[1].x && mc.mv[1].y == d.mv[1].y;
+                        const bool same = mc.dir == MD_L0 ? f0 : (mc.dir == MD_L1 ? f1 : (f0 && f1));
+                        dup = dup || (j < k && mc.dir == d.dir && same);
+                    }
+                    if (!dup) {
+                        keep = true;
+                        cw.c.dir = mc.dir, cw.c.merge_flag = 1, cw.c.merge_index = (uint8_t)k, cw.c.mv[0] = mc.mv[0], cw.c.mv[1] = mc.mv[1];
+                    }
+                }
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                uint4 *dst = reinterpret_cast<uint4 *>(&(wave == 1 ? M.V.me_c : M.V.mg_c)[__popcll(km & below)]);
+                dst[0] = make_uint4(cw.w[0], cw.w[1], cw.w[2], cw.w[3]), dst[1] = make_uint4(cw.w[4], cw.w[5], cw.w[6], cw.w[7]);
+            }
+            if (lane == 0)
+                (wave == 1 ? M.V.n_me : M.V.n_mg) = __popcll(km);
+            MD_TR(16);
+        } else if (st.depth != 0) {
+            /* the unit's intra reference from SOURCE samples (IntraPredictionOl; only units below 64x64 have intra candidates) */
+            md_build_refs_ol(D, M, st, x0, y0, W, H, lane);
+            if (cfull)
+                md_build_refs_ol_chroma(D, M.V.refc, N, x0, y0, W, H, lane);
+            MD_TR(14);
+        }
+        MD_SUB(2);
+        __syncthreads();
+        MD_TR(15);
+        MD_SUB(3);
+        /* ================= B: the candidate list in the lanes of EVERY wave ================= */
+        const int ni = M.ncand, nme = M.V.n_me, nmg = M.V.n_mg, nc = ni + nme + nmg;
+        const bool in = lane < nc;
+        MdCandWords cw;
+        {
+            const MdCand *src = lane < ni ? &M.cand[lane] : lane < ni + nme ? &M.V.me_c[lane - ni] : &M.V.mg_c[in ? lane - ni - nme : 0];
+            const uint4 a = reinterpret_cast<const uint4 *>(src)[0], b = reinterpret_cast<const uint4 *>(src)[1];
+            cw.w[0] = a.x & 0xFF00FFFFu /* mpm = 0: no most-probable-mode search in P / B pictures */, cw.w[1] = a.y, cw.w[2] = a.z, cw.w[3] = a.w, cw.w[4] = b.x, cw.w[5] = b.y, cw.w[6] = b.z,
+            cw.w[7] = b.w;
+        }
+        const MdCand &c = cw.c;
+        const int ctype = in ? c.type : 0;
+        const MdCu cuv = M.S.cu[leaf]; /* the unit's contexts (wave 0 left them before the barrier) */
+        int bufferTotal = md_nfl(&Ph, &Lh, N);
+        bufferTotal = nc < bufferTotal ? nc : bufferTotal;
+        const int width = st.depth == 0 ? 5 : 8, max_buffers = bufferTotal + 1 < width ? bufferTotal + 1 : width;
+        const bool any_intra = ni != 0;
+        /* the first fast loop (EbProductCodingLoop.c:1948-1988): the best of the candidates whose distortion the open-loop stages left; the reference walks from the last
+         * candidate down with <=: the LOWEST index among equal costs */
+        int bestFirst = -1;
+        {
+            const bool ready = in && c.dist_ready;
+            unsigned long long cost = ~0ull;
+            if (ready) {
+                uint64_t r;
+                cost = c.type == MD_INTER ? md_inter_fast_cost(&Ph, &st, &cuv, &c, c.me_dist, &r) : md_intra_fast_cost_pslice(&Ph, &st, &cuv, c.intra_mode, c.me_dist, &r);
+            }
+            unsigned long long m = ~0ull, rm = __ballot(ready);
+            while (rm) {
+                const int l = __ffsll((long long)rm) - 1;
+                rm &= rm - 1;
+                const unsigned long long v = md_readlane64(cost, l);
+                if (bestFirst < 0 || v < m)
+                    m = v, bestFirst = l;
+            }
+        }
+        int evl = (int)(in && (!c.dist_ready || lane == bestFirst));
+        if (evl && lane == bestFirst && c.type == MD_INTRA)
+            evl = 3; /* the open-loop distortion stands, no luma prediction (:1660, :2042) */
+        /* what the fast loop has to predict + measure: the evaluated candidates except the open-loop intra candidate whose distortion stands (:2042) */
+        const bool heavy = in && evl && !(lane == bestFirst && c.type == MD_INTRA);
+        const unsigned long long hm = __ballot(heavy);
+        const bool hc = in && evl && cfull; /* CHROMA_MODE_FULL: the chroma pair of EVERY evaluated candidate */
+        const unsigned long long cm = __ballot(hc);
+        const unsigned long long qm = __ballot(evl && c.type == MD_INTER); /* the first MD_PRED_SLOTS inter candidates the loop evaluates keep their prediction for the full loop */
+        const int qrank = __popcll(qm & below);
+        const int slot = (in && evl && c.type == MD_INTER && qrank < MD_PRED_SLOTS) ? qrank : -1;
+        if (wave == 0 && in && lane >= ni) { /* the list as one array (wave 0's full costs read a survivor's record from it) */
+            uint4 *dst = reinterpret_cast<uint4 *>(&M.cand[lane]);
+            dst[0] = make_uint4(cw.w[0], cw.w[1], cw.w[2], cw.w[3]), dst[1] = make_uint4(cw.w[4], cw.w[5], cw.w[6], cw.w[7]);
+        }
+        MD_TR(18);
+        MD_SUB(6);
+        MD_PROF(1);
+        MD_PROF(2);
+        if (D.prof && t == 0)
+            M.prof[13] += (unsigned long long)nc, M.prof[14] += 1, M.prof_d[M.prof_depth][13] += (unsigned long long)nc, M.prof_d[M.prof_depth][14] += 1;
+        /* ---- fast loop (ProductPerformFastLoop's second loop): ONE list of tasks = (candidate, plane, tile) dealt to the four waves ---- */
+        const bool tiled64 = N == 64 && !any_intra;
+        {
+            const int nheavy = __popcll(hm), nhc = __popcll(cm);
+            const int nl = tiled64 ? nheavy * 4 : nheavy, ntask = nl + 2 * nhc;
+            for (int tk = wave; tk < ntask; tk += 4) {
+                MD_TR(20);
+                const bool luma = tk < nl;
+                const int k = luma ? (tiled64 ? tk >> 2 : tk) : (tk - nl) >> 1, ti = luma ? (tiled64 ? tk & 3 : 0) : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
+                const int ci = md_nth_bit(luma ? hm : cm, k);
+                const uint32_t cw0 = md_rl(cw.w[0], ci), cw2 = md_rl(cw.w[2], ci);
+                uint32_t sad = 0;
+                if ((cw0 & 0xFF) == MD_INTER) {
+                    const int sl = (int)md_rl((uint32_t)slot, ci), n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
+                    uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
+                    md_predict_inter_plane(M.V.refs, (int)(cw2 & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0,
+                                           tiled64 && luma ? 4 : 1, &M.V.rw);
+                    MD_TR(22);
+                    MD_SUB(7);
+                    if (luma && tiled64) {
+                        const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
+                        for (int e = 4 * lane; e < 32 * 32; e += 256) { /* v_sad_u8: four samples a word */
+                            const int y = ty0 + (e >> 5), x = tx0 + (e & 31);
+                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[y * 64 + x]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + y) * 64 + st.x + x]), sad);
+                        }
+                    } else if (luma) {
+                        for (int e = 4 * lane; e < N * N; e += 256)
+                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&L.src[(st.y + (e >> lgN)) * 64 + st.x + (e & (N - 1))]), sad);
+                    } else { /* chroma blocks are 4 .. 32 samples wide: rows of words */
+                        const uint8_t *sc = &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)];
+                        for (int e = 4 * lane; e < n * n; e += 256)
+                            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&sc[(e >> lgn) * 32 + (e & (n - 1))]), sad);
+                    }
+                } else if (luma) {
+                    const int mode = (int)((cw0 >> 8) & 0xFF);
+                    const int16_t *use = M.ref;
+                    const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
+                    for (int e = lane; e < N * N; e += 64) {
+                        const int y = e >> lgN, x = e & (N - 1);
+                        const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
+                        sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
+                    }
+                } else { /* IntraPredictionOl's chroma pair: the chroma mode is always DM (Codec/EbIntraPrediction.c:5530) */
+                    const int mode = (int)((cw0 >> 8) & 0xFF), n = N >> 1, lgn = lgN - 1;
+                    const int16_t *use = M.V.refc[pl - 1];
+                    const int dcv = mode == 1 ? md_dc_value(use, n, lgn, lane) : 0;
+                    const uint8_t *sc = &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)];
+                    for (int e = lane; e < n * n; e += 64) {
+                        const int y = e >> lgn, x = e & (n - 1);
+                        const int v = pu_predict(mode, n, lgn, use, x, y, dcv, false, 255);
+                        sad += (uint32_t)abs(v - (int)sc[y * 32 + x]);
+                    }
+                }
+                sad = md_wave_sum(sad);
+                MD_TR(23);
+                MD_SUB(8);
+                if (lane == 0) { /* every (candidate, plane, tile) has ONE owner: plain stores, nothing to initialise */
+                    if (luma)
+                        M.sadt[ci][ti] = sad;
+                    else
+                        M.V.sadc2[ci][pl - 1] = sad;
+                }
+                MD_TR(24);
+            }
+        }
+        __syncthreads();
+        MD_TR(25);
+        MD_PROF(3);
+        /* ================= C: fast costs (a lane per candidate), candidate buffers (a lane per buffer), PreModeDecision - in every wave ================= */
+        unsigned long long rate = 0, cst = ~0ull;
+        if (in && evl) {
+            uint64_t dist = 0, distc = 0;
+            if (heavy)
+                dist = tiled64 ? (uint64_t)M.sadt[lane][0] + M.sadt[lane][1] + M.sadt[lane][2] + M.sadt[lane][3] : (uint64_t)M.sadt[lane][0];
+            else
+                dist = c.me_dist;
+            uint32_t cwt = 0;
+            if (cfull) /* the chroma pair's SAD with the noise-class rule (:2079-2094) */
+                distc = md_fast_chroma_noise_rule(&Lh, N, &c, (uint64_t)M.V.sadc2[lane][0] + M.V.sadc2[lane][1]), cwt = M.V.X.chroma_weight;
+            cst = c.type == MD_INTER ? md_inter_fast_cost_c(&Ph, &st, &cuv, &c, dist, distc, cwt, !Lh.cmplx_noise, (uint64_t *)&rate)
+                                     : md_intra_fast_cost_pslice_c(&Ph, &st, &cuv, c.intra_mode, dist, distc, cwt, (uint64_t *)&rate);
+        }
+        MD_TR(26);
+        MD_SUB(9);
+        /* md_fast_loop_buffers (md_logic.h; ProductPerformFastLoop's second loop, :1990-2179) with the buffers in lanes 0..7: the candidates arrive from the last to the
+         * first, each goes into the buffer with the highest cost (an unused one first) = the FIRST buffer holding the maximum over [0, maxBuffers) */
+        unsigned long long bcost = ~0ull;
+        int bcand = -1, bpred = -1, evcount = 0;
+        {
+            int highest = 0;
+            const int maxb = max_buffers < 2 ? 2 : max_buffers;
+            for (int idx = nc - 1; idx >= 0; idx--) {
+                const unsigned long long cv = md_readlane64(cst, idx);
+                const int ev = __builtin_amdgcn_readlane(evl, idx);
+                if (lane == highest) {
+                    bcand = idx;
+                    if (ev) {
+                        bcost = cv;
+                        if (!(ev & 2))
+                            bpred = idx;
+                    }
+                }
+                evcount += ev != 0;
+                if (idx) {
+                    unsigned long long m = 0;
+                    int h = 0;
+#pragma unroll
+                    for (int b = 0; b < MD_MAX_BUF; b++)
+                        if (b < maxb) {
+                            const unsigned long long v = md_readlane64(bcost, b);
+                            if (b == 0 || v > m)
+                                m = v, h = b;
+                        }
+                    highest = h;
+                }
+            }
+        }
+        MD_TR(27);
+        MD_SUB(10);
+        /* PreModeDecision (md_pre_mode_decision, md_logic.h; Codec/EbModeDecision.c:300-383) on uniform values: the buffers' costs by v_readlane, the order as nibbles of a word */
+        uint32_t best = 0; /* best[f] = (best >> 4 f) & 15 */
+        int full_count, nfull;
+        /* lane b: the type of buffer b's candidate.  (The shuffle runs in EVERY lane: a lane that sits the instruction out returns zero to whoever reads it - and the
+         * candidates beyond the buffer count live in exactly the lanes that hold no buffer.) */
+        const int btype_any = __shfl(ctype, bcand < 0 ? 0 : bcand), btype = bcand >= 0 ? btype_any : 0;
+        {
+            int bt = evcount < bufferTotal ? evcount : bufferTotal;
+            const int same = evcount == bt, count = same ? bt : max_buffers;
+            const int fullRecon = same ? (count < 1 ? 1 : count) : (count - 1 < 1 ? 1 : count - 1);
+            if (count > 1) {
+                int skipIdx = -1;
+                if (!same) {
+                    unsigned long long hcost = md_readlane64(bcost, 0);
+                    skipIdx = 0;
+                    for (int i = 1; i < count; i++) {
+                        const unsigned long long v = md_readlane64(bcost, i);
+                        if (v >= hcost)
+                            hcost = v, skipIdx = i;
+                    }
+                }
+                int k = 0;
+                for (int i = 0; i < count; i++)
+                    if (i != skipIdx)
+                        best |= (uint32_t)i << (4 * k++);
+            }
+            const unsigned long long interm = __ballot(btype == MD_INTER) & 0xFFull, intram = __ballot(btype == MD_INTRA) & 0xFFull;
+            for (int i = 0; i < fullRecon - 1; i++) /* inter candidates first */
+                for (int j = i + 1; j < fullRecon; j++) {
+                    const uint32_t bi = (best >> (4 * i)) & 15u, bj = (best >> (4 * j)) & 15u;
+                    if (((intram >> bi) & 1ull) && ((interm >> bj) & 1ull))
+                        best = (best & ~((15u << (4 * i)) | (15u << (4 * j)))) | (bj << (4 * i)) | (bi << (4 * j));
+                }
+            full_count = fullRecon;
+            nfull = full_count < bt ? full_count : bt;
+        }
+        MD_TR(28);
+        MD_PROF(4);
+        /* ---- full loop: a wave per surviving candidate (PerformFullLoop, :4351) ---- */
+        /* a 64x64 unit has four 32x32 transform units per candidate: a wave per (candidate, transform unit).  The candidates of a 64x64 unit are motion-compensated. */
+        const bool split64 = N == 64 && nfull <= 4 && !any_intra;
+        bool fresh64 = false;
+        auto buf_cand = [&](int b) { return __builtin_amdgcn_readlane(bcand, b); };
+        auto buf_pred = [&](int b) { return __builtin_amdgcn_readlane(bpred, b); };
+        auto kept_pred = [&](int pci) { return (int)md_rl((uint32_t)slot, pci) >= 0 && __builtin_amdgcn_readlane(evl, pci) != 0; };
+        if (split64) {
+            for (int f = 0; f < nfull; f++) {
+                const int b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b), pci = buf_pred(b) < 0 ? ci : buf_pred(b);
+                if (!kept_pred(pci)) {
+                    fresh64 = true;
+                    if (wave == f)
+                        md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], pci) & 0xFF), md_rl(cw.w[4], pci), md_rl(cw.w[5], pci), x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1,
+                                               &M.V.rw);
+                }
+            }
+            if (fresh64)
+                __syncthreads();
+            for (int f = 0; f < nfull; f++) {
+                const int b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b), pci = buf_pred(b) < 0 ? ci : buf_pred(b);
+                const uint8_t *pred = kept_pred(pci) ? M.V.cpred[(int)md_rl((uint32_t)slot, pci)] : M.V.wpred[f];
+                const int tu = wave, off = ((tu & 1) << 5) + ((tu >> 1) << 5) * 64;
+                const uint32_t c0 = md_rl(cw.w[0], ci);
+                const MdFl o = md_full_loop_unit<32>(lane, &L.src[st.y * 64 + st.x] + off, 64, pred + off, 64, nullptr, M.tiles[wave], M.qbuf[wave], Ph.qp, Ph.slice_type, M.cost,
+                                                     (int)(c0 & 0xFF), (int)((c0 >> 8) & 0xFF), 0, pf, M.rt);
+                if (lane == 0)
+                    M.fl[b][tu] = o;
+                EP_WAVE_SYNC();
+            }
+        }
+        for (int f = wave; f < nfull && !split64; f += 4) {
+            MD_TR(30);
+            const int b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b);
+            const uint32_t c0 = md_rl(cw.w[0], ci);
+            const int cdtype = (int)(c0 & 0xFF), cdmode = (int)((c0 >> 8) & 0xFF);
+            /* the buffer's luma prediction: the candidate the fast loop predicted there, or - predictionIsReadyLuma == 0 - a fresh one */
+            const bool fresh = ci == bestFirst && cdtype == MD_INTRA && __builtin_amdgcn_readlane(evl, ci) != 0;
+            const int pci = (fresh || buf_pred(b) < 0) ? ci : buf_pred(b);
+            const uint32_t p0 = md_rl(cw.w[0], pci);
+            uint8_t *pred = M.V.wpred[wave];
+            if ((p0 & 0xFF) == MD_INTER) {
+                if (kept_pred(pci))
+                    pred = M.V.cpred[(int)md_rl((uint32_t)slot, pci)]; /* the fast loop's prediction of this candidate is still there */
+                else
+                    md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], pci) & 0xFF), md_rl(cw.w[4], pci), md_rl(cw.w[5], pci), x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
+            } else {
+                const int mode = (int)((p0 >> 8) & 0xFF);
+                const int16_t *use = M.ref;
+                const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
+                for (int e = lane; e < N * N; e += 64)
+                    pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
+                EP_WAVE_SYNC();
+            }
+            MD_TR(31);
+            MD_SUB(12);
+            md_full_loop_cand(lane, N, &L.src[st.y * 64 + st.x], pred, N, nullptr, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, cdtype, cdmode, pf, M.fl[b]);
+            MD_TR(32);
+            MD_SUB(13);
+        }
+        /* CHROMA_MODE_FULL (PerformFullLoop :4443-4560): the chroma pair of every survivor - ChromaPrediction (the candidate's OWN prediction: the fast loop's when it
+         * evaluated the candidate, a fresh one otherwise), FullLoop_R + CuFullDistortionFastTuMode_R - as tasks (survivor, plane) on the waves the luma units left idle */
+        if (cfull) {
+            if (fresh64) /* every wave is done with the fresh luma predictions in the waves' scratch before a chroma block lands there */
+                __syncthreads();
+            const int Cn = N >> 1, lgc = lgN - 1, Tc = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
+            unsigned mine = 0;
+            {
+                int load[4];
+#pragma unroll
+                for (int w_ = 0; w_ < 4; w_++)
+                    load[w_] = (!split64 && w_ < nfull) ? 3 : 0;
+                for (int tk = 0; tk < 2 * nfull; tk++) {
+                    int best_w = 0;
+#pragma unroll
+                    for (int w_ = 1; w_ < 4; w_++)
+                        if (load[w_] < load[best_w])
+                            best_w = w_;
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; w_++)
+                        if (w_ == best_w)
+                            load[w_] += 2;
+                    if (best_w == wave)
+                        mine |= 1u << tk;
+                }
+            }
+            for (int tk = 0; tk < 2 * nfull; tk++) {
+                if (!((mine >> tk) & 1u))
+                    continue;
+                const int f = tk >> 1, pl = tk & 1, b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b);
+                const uint32_t c0 = md_rl(cw.w[0], ci);
+                const int cdtype = (int)(c0 & 0xFF), cdmode = (int)((c0 >> 8) & 0xFF);
+                const uint8_t *pred;
+                if (cdtype == MD_INTER && kept_pred(ci)) {
+                    pred = M.V.cpred_c[(int)md_rl((uint32_t)slot, ci)][pl];
+                } else {
+                    uint8_t *pw = M.V.wpred_c(wave, pl);
+                    if (cdtype == MD_INTER) {
+                        md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], ci) & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw);
+                    } else {
+                        const int16_t *use = M.V.refc[pl];
+                        const int dcv = cdmode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
+                        for (int e = lane; e < Cn * Cn; e += 64)
+                            pw[e] = (uint8_t)pu_predict(cdmode, Cn, lgc, use, e & (Cn - 1), e >> lgc, dcv, false, 255);
+                        EP_WAVE_SYNC();
+                    }
+                    pred = pw;
+                }
+                for (int tu = 0; tu < ntu; tu++) {
+                    const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
+                    uint32_t nz;
+                    unsigned long long d[2], bt;
+                    md_chroma_tu(lane, Tc, &M.V.src_c[pl][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, cdtype, cdmode,
+                                 1 + pl, pf, &nz, d, &bt);
+                    if (lane == 0) {
+                        MdFl o;
+                        o.nz = nz, o.d0 = (uint32_t)d[0], o.d1 = (uint32_t)d[1], o.bits = (uint32_t)bt;
+                        M.V.flc[b][pl][tu] = o;
+                    }
+                }
+            }
+        }
+        MD_TR(33);
+        __syncthreads();
+        MD_TR(34);
+        MD_PROF(5);
+        /* ================= D (wave 0): TuCalcCostLuma + the full cost of every survivor (a lane each), ProductFullModeDecision, the depth decisions, the neighbour update ================= */
+        if (wave == 0) {
+            const bool have = lane < nfull;
+            const int b = (int)((best >> (4 * (have ? lane : 0))) & 15u);
+            const int ci = __shfl(bcand, b);
+            uint32_t ycbf = 0;
+            unsigned long long bits = 0, dist[2] = {0, 0}, full = 0;
+            uint64_t mc = 0, sc = 0;
+            const unsigned long long frate = __shfl(rate, have ? ci : 0); /* fastLumaRate of the survivor's candidate */
+            MdCandWords sv; /* the survivor's candidate record */
+            {
+                const uint4 a = reinterpret_cast<const uint4 *>(&M.cand[have ? ci : 0])[0], bq = reinterpret_cast<const uint4 *>(&M.cand[have ? ci : 0])[1];
+                sv.w[0] = a.x, sv.w[1] = a.y, sv.w[2] = a.z, sv.w[3] = a.w, sv.w[4] = bq.x, sv.w[5] = bq.y, sv.w[6] = bq.z, sv.w[7] = bq.w;
+            }
+            const int svtype = have ? sv.c.type : 0;
+            if (have) {
+                const MdCand &cs = sv.c;
+                if (N == 64) {
+                    for (int tu = 0; tu < 4; tu++)
+                        md_tu_calc_cost(P, M.fl[b][tu], cs.type, 64, 32, tu + 1, &ycbf, &bits, dist);
+                } else {
+                    md_tu_calc_cost(P, M.fl[b][0], cs.type, N, N, 0, &ycbf, &bits, dist);
+                }
+                bits = md_pf_coeff_bits(pf, Ph.qp, bits); /* (CHROMA_MODE_BEST and CHROMA_MODE_FULL LCUs: the only ones md_lcu_supported admits) */
+                if (cfull) { /* InterFullCost / MergeSkipFullCost / IntraFullCostPslice: the chroma loop's sums join the luma ones */
+                    const int ntu = N == 64 ? 4 : 1;
+                    uint32_t cbf[2] = {0, 0};
+                    uint64_t cbits[2] = {0, 0}, cdist[2][2] = {{0, 0}, {0, 0}};
+                    for (int pl = 0; pl < 2; pl++)
+                        for (int tu = 0; tu < ntu; tu++) {
+                            const MdFl o = M.V.flc[b][pl][tu];
+                            cbf[pl] |= (uint32_t)(o.nz != 0) << (ntu == 1 ? 0 : tu + 1);
+                            cbits[pl] += o.bits, cdist[pl][0] += o.d0, cdist[pl][1] += o.d1;
+                        }
+                    const uint64_t yd[2] = {dist[0], dist[1]};
+                    if (cs.type == MD_INTER)
+                        full = md_inter_full_cost(&P, M.V.X.chroma_weight, &cuv, &cs, N, ycbf, cbf, frate, yd, cdist, bits, cbits, &mc, &sc);
+                    else
+                        full = md_intra_full_cost_pslice(&P, M.V.X.chroma_weight, N, ycbf, cbf, frate, dist[0], cdist, bits, cbits);
+                } else if (cs.type == MD_INTER) {
+                    full = md_inter_full_luma_cost(&P, &cuv, &cs, N, ycbf, frate, (const uint64_t *)dist, bits, &mc, &sc);
+                } else {
+                    full = md_intra_full_luma_cost_pslice(&P, N, ycbf, frate, dist[0], bits);
+                }
+            }
+            /* the reference walks the candidates in order: an intra candidate after an inter one whose root cbf is 0 is not costed at all (full-loop escape, :4450-4460) and
+             * keeps whatever its buffer held (here: the all-ones cost of the buffer's initialisation) */
+            uint32_t prevRootCbf = 1;
+            unsigned long long bestFullCost = 0xFFFFFFFFull, kept = 0;
+            for (int g = 0; g < nfull; g++) {
+                const int ty = __builtin_amdgcn_readlane(svtype, g);
+                const uint32_t yc = md_rl(ycbf, g);
+                const unsigned long long cs_ = md_readlane64(full, g);
+                if (ty == MD_INTRA && prevRootCbf == 0)
+                    continue;
+                kept |= 1ull << g;
+                if (Ph.full_loop_escape && ty == MD_INTER && cs_ < bestFullCost)
+                    prevRootCbf = yc, bestFullCost = cs_;
+            }
+            MD_TR(35);
+            MD_SUB(14);
+            /* ProductFullModeDecision (:1995): the lowest full cost among the first full_count buffers of the order (the first of equal ones) */
+            const unsigned long long fcost = (have && ((kept >> lane) & 1ull)) ? full : ~0ull;
+            int wf = 0;
+            {
+                unsigned long long lowestCost = ~0ull;
+                for (int f = 0; f < full_count && f < nfull; f++) { /* (buffers beyond the survivors keep the all-ones cost: never lower) */
+                    const unsigned long long v = md_readlane64(fcost, f);
+                    if (v < lowestCost)
+                        wf = f, lowestCost = v;
+                }
+            }
+            /* the winner's lane hands its sums to lane 0 */
+            const unsigned long long w_cost = md_readlane64(fcost, wf), w_mc = md_readlane64(mc, wf), w_sc = md_readlane64(sc, wf), w_bits = md_readlane64(bits, wf),
+                                     w_d0 = md_readlane64(dist[0], wf), w_d1 = md_readlane64(dist[1], wf), w_rate = md_readlane64(frate, wf);
+            const uint32_t w_ycbf = md_rl(ycbf, wf), w_c0 = md_rl(sv.w[0], wf), w_c2 = md_rl(sv.w[2], wf), w_mv0 = md_rl(sv.w[4], wf), w_mv1 = md_rl(sv.w[5], wf);
+            const bool w_kept = ((kept >> wf) & 1ull) != 0;
+            if (lane == 0) {
+                const int wtype = (int)(w_c0 & 0xFF), wdir = (int)(w_c2 & 0xFF);
+                MdCu &u = M.S.cu[leaf];
+                /* (a winner the escape left uncosted keeps the buffer's initial values: zeros, as ProductResetModeDecision leaves them) */
+                M.S.local[leaf].cost = w_cost, M.S.local[leaf].full_distortion = w_kept ? (uint32_t)w_d0 : 0u;
+                u.pred_mode = (uint8_t)wtype, u.skip_flag = 0, u.intra_luma_mode = (uint8_t)(wtype == MD_INTRA ? ((w_c0 >> 8) & 0xFF) : 0x1F);
+                const uint32_t yc = w_kept ? w_ycbf : 0u;
+                u.ycbf = (uint8_t)(N == 64 ? (yc & 0x1E) : (yc & 1));
+                u.inter_dir = (uint8_t)(wtype == MD_INTER ? wdir : 3), u.merge_flag = (uint8_t)(wtype == MD_INTER ? ((w_c2 >> 8) & 0xFF) : 0), u.merge_index = (uint8_t)((w_c2 >> 16) & 0xFF);
+                u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0;
+                if (wtype == MD_INTER) {
+                    if (wdir != MD_L1)
+                        u.mv[0].x = (int16_t)(w_mv0 & 0xFFFF), u.mv[0].y = (int16_t)(w_mv0 >> 16);
+                    if (wdir != MD_L0)
+                        u.mv[1].x = (int16_t)(w_mv1 & 0xFFFF), u.mv[1].y = (int16_t)(w_mv1 >> 16);
+                }
+                u.merge_cost = w_kept ? w_mc : 0, u.skip_cost = w_kept ? w_sc : 0;
+                u.y_coeff_bits = w_kept ? w_bits : 0, u.y_dist[0] = w_kept ? w_d0 : 0, u.y_dist[1] = w_kept ? w_d1 : 0;
+                u.fast_luma_rate = w_rate, u.ycbf_mask = yc;
+                M.S.local[leaf].mdc_index = (uint8_t)cuIdx;
+                int cur = leaf, curIdx = cuIdx;
+                const int exitParent = md_check_high_cost_partition(&P, &Lh, &M.S, leaf);
+                int last;
+                if (exitParent >= 0) {
+                    cur = exitParent, curIdx = M.S.local[exitParent].mdc_index;
+                    M.S.cu[exitParent].split = 0;
+                    last = md_inter_depth_decision(&P, &M.S, exitParent, lcu_x, lcu_y, 1, 0);
+                } else { /* open loop: no reconstruction to wait for, the inter-depth decision follows at once */
+                    last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, md_stop_split(&Ph, &Lh, st.depth, w_kept ? (uint32_t)w_d0 : 0u));
+                }
+                M.last = last;
+                M.update = M.S.cu[last].split == 0;
+                /* the next unit (CalculateNextCuIndex :1261): the loop stands on `cur` - the tested unit, or the parent a partition exit fell back to */
+                int nextIdx = curIdx;
+                if (M.S.cu[cur].split || lh < 64)
+                    nextIdx++;
+                else
+                    nextIdx += md_next_cu_step(&M.lcu, curIdx, md_stats(cur).depth);
+                M.cu_idx = nextIdx;
+                M.done = nextIdx >= Lh.leaf_count;
+#ifdef MD_TRACE
+                g_md_trace_on = D.trace && lcu == D.trace_lcu && nextIdx >= D.trace_unit && nextIdx < D.trace_unit + 2;
+#endif
+            }
+            MD_TR(36);
+            EP_WAVE_SYNC();
+            MD_PROF(6);
+            /* ModeDecisionUpdateNeighborArrays of the unit the decision ended on (at most 256 cells: this wave's lanes) */
+            if (M.update) {
+                const int last = M.last;
+                const MdStats ls = md_stats(last);
+                const MdCu u = M.S.cu[last];
+                const uint32_t w = (uint32_t)u.pred_mode | ((uint32_t)u.intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) | ((uint32_t)u.skip_flag << 24);
+                const int cells = ls.size >> 2, lgc4 = ls.lg - 2;
+                for (int e = lane; e < cells * cells; e += 64)
+                    L.info[((ls.y >> 2) + (e >> lgc4) + 1) * 36 + (ls.x >> 2) + (e & (cells - 1)) + 1] = w;
+                const int c8 = ls.size >> 3, lgc8 = ls.lg - 3;
+                MdMvUnit mu;
+                mu.mv[0] = u.mv[0], mu.mv[1] = u.mv[1], mu.dir = u.inter_dir, mu.avail = 0, mu.pad[0] = mu.pad[1] = 0;
+                for (int e = lane; e < c8 * c8; e += 64)
+                    M.V.mvu[((ls.y >> 3) + (e >> lgc8) + 1) * 18 + (ls.x >> 3) + (e & (c8 - 1)) + 1] = mu;
+            }
+            MD_TR(38);
+        }
+        __syncthreads();
+        MD_TR(39);
+        MD_PROF(8);
+        if (M.done)
+            break;
+    }
 }
 
 /* ModeDecisionLcu of one LCU: on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
@@ -671,6 +1688,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
     MD_PROF(0);
     const SvtAmdOisLcuResult *ois = &M.ois;
     const int pf = md_pf_mode(&P);
+    constexpr bool NEW_INTER_LOOP = INTER; /* P / B pictures: md_units_inter (round 6); the loop below is the I pictures' */
+    if constexpr (NEW_INTER_LOOP)
+        md_units_inter(D, lcu, lcu_x, lcu_y, M);
+    else
     for (;;) {
         MD_TR(10);
         /* ---- lane 0: the unit, its contexts and its candidates ---- */
@@ -708,26 +1729,77 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
              * (no workgroup barrier between the fetch and the list), lane 0 then makes the wave's lists - four chains side by side instead of a barrier after the first. */
             if (wave >= 1) {
                 const MdStats st = md_stats(M.lcu.leaf_index[M.cu_idx]);
-                if (lane < 5 && wave < 3) {
-                    const int N = st.size, k = lane;
-                    const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
-                    const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
-                    const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
-                    MdMvUnit u;
-                    u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0, u.dir = 0, u.avail = 0, u.pad[0] = u.pad[1] = 0;
-                    if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
-                        u = *M.V.mv_at(px, py);
-                        u.avail = 1;
+                if (wave < 3) {
+                    /* the five spatial neighbours (A0, A1, B0, B1, B2): a lane each, then every lane of the wave holds all five IN REGISTERS (v_readlane) - the list code
+                     * below runs on registers in every lane alike, with no trip through LDS between the fetch and the lists */
+                    uint32_t w0 = 0, w1 = 0, w2 = 0;
+                    if (lane < 5) {
+                        const int N = st.size, k = lane;
+                        const bool left = M.lcu.tile_left && st.x == 0, top = M.lcu.tile_top && st.y == 0, right = M.lcu.tile_right && ((st.x + N) & 63) == 0;
+                        const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
+                        const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
+                        if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
+                            const uint32_t *q = reinterpret_cast<const uint32_t *>(M.V.mv_at(px, py));
+                            w0 = q[0], w1 = q[1], w2 = (q[2] & 0xFFu) | 0x100u; /* mv[0], mv[1], dir | avail << 8 */
+                        }
                     }
-                    M.V.nb[wave - 1][k] = u;
-                }
-                EP_WAVE_SYNC();
-                MD_TR(12);
-                if (lane == 0 && wave < 3) /* wave 1: both AMVP lists, wave 2: the merge candidates (the longest of the three) */
-                    md_amvp_merge_lists_parts(&P, &M.V.X, M.V.nb[wave - 1], M.V.X.tmvp_enable ? M.V.tmvp : nullptr, lcu_x + st.x, lcu_y + st.y, st.size, md_nmm(&P, st.size), &M.V.T,
-                                              wave == 1 ? 3 : 4);
-                if (wave < 3)
+                    MdMvUnit nbr[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w0, k), b = (uint32_t)__builtin_amdgcn_readlane((int)w1, k),
+                                       c = (uint32_t)__builtin_amdgcn_readlane((int)w2, k);
+                        nbr[k].mv[0].x = (int16_t)(a & 0xFFFF), nbr[k].mv[0].y = (int16_t)(a >> 16), nbr[k].mv[1].x = (int16_t)(b & 0xFFFF), nbr[k].mv[1].y = (int16_t)(b >> 16);
+                        nbr[k].dir = (uint8_t)(c & 0xFF), nbr[k].avail = (uint8_t)((c >> 8) & 1), nbr[k].pad[0] = nbr[k].pad[1] = 0;
+                    }
+                    MD_TR(12);
+                    MdInterLists T;
+                    T.amvp_count[0] = T.amvp_count[1] = 0, T.merge_count = 0, T.pad = 0;
+                    const int ox = lcu_x + st.x, oy = lcu_y + st.y, totalMerge = md_nmm(&P, st.size);
+                    /* wave 1: both AMVP lists, wave 2: the merge candidates (the longest of the three) */
+                    md_amvp_merge_lists_parts(&P, &M.V.X, nbr, M.V.X.tmvp_enable ? M.V.tmvp : nullptr, ox, oy, st.size, totalMerge, &T, wave == 1 ? 3 : 4);
                     MD_TR(13);
+                    bool keep = false;
+                    MdCand c;
+                    c.type = MD_INTER, c.intra_mode = 0, c.mpm = 0, c.dist_ready = 0, c.me_dist = 0, c.dir = 0, c.merge_flag = 0, c.merge_index = 0;
+                    c.mvp_idx[0] = c.mvp_idx[1] = 0, c.pad[0] = c.pad[1] = c.pad[2] = 0;
+                    c.mv[0].x = c.mv[0].y = c.mv[1].x = c.mv[1].y = 0, c.mvp[0].x = c.mvp[0].y = c.mvp[1].x = c.mvp[1].y = 0;
+                    if (wave == 1) { /* Me2Nx2NCandidatesInjection: a lane per motion-estimation candidate (md_inter_candidates, md_logic.h) */
+                        const SvtAmdMeCuResult *me = &M.V.me[md_raster_index(&st)];
+                        if (lane < 3 && lane < me->total_me_candidate_index) {
+                            const int dir = me->direction[lane];
+                            if (!(dir == MD_BI && P.depth_mode == 0 && M.lcu.lcu_md_mode == 10)) {
+                                keep = true;
+                                c.dist_ready = 1, c.me_dist = me->distortion[lane], c.dir = (uint8_t)dir;
+                                c.mv[0].x = me->x_mv_l0, c.mv[0].y = me->y_mv_l0, c.mv[1].x = me->x_mv_l1, c.mv[1].y = me->y_mv_l1;
+                                md_choose_mvp(&P, (uint32_t)ox, (uint32_t)oy, &T, &c);
+                            }
+                        }
+                    } else { /* ProductMergeSkip2Nx2NCandidatesInjection: a lane per merge candidate, duplicates of earlier ones dropped */
+                        const int k = lane;
+                        if (k < 5 && k < totalMerge && k < T.merge_count) {
+                            const MdMergeCand mc = k == 0 ? T.merge[0] : k == 1 ? T.merge[1] : k == 2 ? T.merge[2] : k == 3 ? T.merge[3] : T.merge[4];
+                            bool dup = false;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const MdMergeCand d = T.merge[j];
+                                const bool f0 = mc.mv[0].x == d.mv[0].x && mc.mv[0].y == d.mv[0].y;
+                                const bool f1 = mc.dir != MD_L0 && mc.mv[1].x == d.mv[1].x && mc.mv[1].y == d.mv[1].y;
+                                const bool same = mc.dir == MD_L0 ? f0 : (mc.dir == MD_L1 ? f1 : (f0 && f1));
+                                dup = dup || (j < k && mc.dir == d.dir && same);
+                            }
+                            if (!dup) {
+                                keep = true;
+                                c.dir = mc.dir, c.merge_flag = 1, c.merge_index = (uint8_t)k, c.mv[0] = mc.mv[0], c.mv[1] = mc.mv[1];
+                            }
+                        }
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    if (keep)
+                        (wave == 1 ? M.V.me_c : M.V.mg_c)[__popcll(km & ((1ull << lane) - 1ull))] = c;
+                    if (lane == 0)
+                        (wave == 1 ? M.V.n_me : M.V.n_mg) = __popcll(km);
+                    MD_TR(16);
+                }
                 /* ... and the fourth wave the unit's intra reference (only units below 64x64 have intra candidates) - source samples from HBM in the open-loop decision, a
                  * round trip under the other waves' chains */
                 if (wave == 3 && st.depth != 0) {
@@ -745,55 +1817,16 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
             __syncthreads();
             MD_TR(15);
             MD_SUB(3);
-        }
-        if constexpr (INTER) {
-            /* the inter candidates (md_inter_candidates, md_logic.h): the motion-estimation candidates and the merge candidates are independent of one another - lanes
-             * 0..2 and 3..7 of wave 0 make one each (md_choose_mvp / the duplicate check side by side) and a ballot puts the survivors in the scalar order */
+            /* wave 0 appends the two waves' candidates to the intra candidates: motion-estimation candidates first, merge candidates behind them (md_inter_candidates' order) */
             if (wave == 0) {
-                const MdStats st = md_stats(M.leaf);
-                const int n0 = M.ncand, totalMerge = md_nmm(&P, st.size);
-                const SvtAmdMeCuResult *me = &M.V.me[md_raster_index(&st)];
-                bool keep = false;
-                MdCand c;
-                c.type = MD_INTER, c.intra_mode = 0, c.mpm = 0, c.dist_ready = 0, c.me_dist = 0, c.dir = 0, c.merge_flag = 0, c.merge_index = 0;
-                c.mvp_idx[0] = c.mvp_idx[1] = 0, c.pad[0] = c.pad[1] = c.pad[2] = 0;
-                c.mv[0].x = c.mv[0].y = c.mv[1].x = c.mv[1].y = 0, c.mvp[0].x = c.mvp[0].y = c.mvp[1].x = c.mvp[1].y = 0;
-                if (lane < 3) {
-                    if (lane < me->total_me_candidate_index) {
-                        const int dir = me->direction[lane];
-                        if (!(dir == MD_BI && P.depth_mode == 0 && M.lcu.lcu_md_mode == 10)) {
-                            keep = true;
-                            c.dist_ready = 1, c.me_dist = me->distortion[lane], c.dir = (uint8_t)dir;
-                            c.mv[0].x = me->x_mv_l0, c.mv[0].y = me->y_mv_l0, c.mv[1].x = me->x_mv_l1, c.mv[1].y = me->y_mv_l1;
-                            md_choose_mvp(&P, (uint32_t)(lcu_x + st.x), (uint32_t)(lcu_y + st.y), &M.V.T, &c);
-                        }
-                    }
-                } else if (lane < 8) {
-                    const int k = lane - 3;
-                    if (k < totalMerge && k < M.V.T.merge_count) {
-                        const MdMergeCand mc = M.V.T.merge[k];
-                        bool dup = false;
-                        for (int j = 0; j < k; j++) {
-                            const MdMergeCand d = M.V.T.merge[j];
-                            const bool f0 = mc.mv[0].x == d.mv[0].x && mc.mv[0].y == d.mv[0].y;
-                            const bool f1 = mc.dir != MD_L0 && mc.mv[1].x == d.mv[1].x && mc.mv[1].y == d.mv[1].y;
-                            const bool same = mc.dir == MD_L0 ? f0 : (mc.dir == MD_L1 ? f1 : (f0 && f1));
-                            dup = dup || (mc.dir == d.dir && same);
-                        }
-                        if (!dup) {
-                            keep = true;
-                            c.dir = mc.dir, c.merge_flag = 1, c.merge_index = (uint8_t)k, c.mv[0] = mc.mv[0], c.mv[1] = mc.mv[1];
-                        }
-                    }
-                }
-                const unsigned long long km = __ballot(keep);
-                if (keep)
-                    M.cand[n0 + __popcll(km & ((1ull << lane) - 1ull))] = c;
-                EP_WAVE_SYNC();
+                const int n0 = M.ncand, nme = M.V.n_me, nmg = M.V.n_mg;
+                if (lane < nme)
+                    M.cand[n0 + lane] = M.V.me_c[lane];
+                else if (lane < nme + nmg)
+                    M.cand[n0 + lane] = M.V.mg_c[lane - nme];
                 if (lane == 0)
-                    M.ncand = n0 + __popcll(km);
+                    M.ncand = n0 + nme + nmg;
                 EP_WAVE_SYNC();
-                MD_TR(16);
             }
         }
         MD_SUB(4);
@@ -916,7 +1949,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
             const int T = tiled64 ? 4 : 1, nl = M.nheavy * T, ntask = nl + 2 * nhc;
             for (int tk = wave; tk < ntask; tk += 4) {
                 const bool luma = tk < nl;
-                const int k = luma ? tk / T : (tk - nl) >> 1, ti = luma ? tk - k * T : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
+                const int k = luma ? (tiled64 ? tk >> 2 : tk) : (tk - nl) >> 1, ti = luma ? (tiled64 ? tk & 3 : 0) : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
                 int c;
                 if constexpr (INTER)
                     c = luma ? M.heavy[k] : M.V.heavyc[k];
