@@ -294,6 +294,119 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
     return (dc + n) >> (lgn + 1);
 }
 
+/* ---- the 16x16 and 32x32 forward transforms of the full loops on the MATRIX CORES (round 6) ----------------------------------------------------------------------------
+ * Transform16x16 / Transform32x32Estimate (C_DEFAULT/EbTransforms_C.c: two partial-butterfly passes) are exact integer evaluations of C . X . C^T with a rounding shift
+ * after each pass (txfm_mfma.hip; the Estimate forms wrap the first butterfly levels to 16 bits, which no sum reaches while the pass's inputs stay below 2^14 (16x16) /
+ * 2^13 (32x32): checked per unit, the register butterflies take the unit otherwise - never on 8-bit video, where |T1| <= 16 . 90 . 255 >> 4).  Here the products run as
+ * v_mfma_f32_16x16x16_f16 / v_mfma_f32_32x32x8_f16 ON EXACT INTEGERS: residuals (|x| <= 255) and matrix entries (|c| <= 90) are f16 values, their sums of 16 / 32
+ * products stay below 2^24 (exact in the f32 accumulator); the 16-bit intermediate of pass 2 goes in as two exact planes T1 = 64 H + L (|H| <= 512, 0 <= L < 64).
+ * Why, on a path that is not FLOP-bound: the unit chain is bound by INSTRUCTIONS ISSUED PER WAVE.  The butterflies keep a row per lane - N lanes of 64 busy, ~560 issue
+ * slots for a 16x16 unit and ~800 for its quantiser; the matrix form keeps all 64 lanes busy (4 / 16 coefficients a lane, already where the quantiser wants them) in ~150.
+ * Pass 1 is computed transposed (T1^T = S . C^T) so that a lane's accumulator registers ARE its B operand of pass 2 (out = C . T1^T): no transpose, no LDS.
+ * The constant operand C (lane l: C_N[l % N][its K slots]) is the same for both passes; a workgroup keeps it in LDS (s_dct_op), filled once per launch. */
+typedef _Float16 md_v4h __attribute__((ext_vector_type(4)));
+typedef float md_v4f __attribute__((ext_vector_type(4)));
+typedef float md_v16f __attribute__((ext_vector_type(16)));
+static __shared__ uint32_t s_dct_op[10][64]; /* [0..1]: 16x16, [2 + 2 s .. 3 + 2 s]: 32x32 K-slice s; two dwords = four f16 */
+__device__ __forceinline__ void md_dct_operands_init()
+{
+    const int t = threadIdx.x;
+    if (t < 64) {
+        union { md_v4h h; uint32_t w[2]; } u;
+        for (int i = 0; i < 4; i++)
+            u.h[i] = (_Float16)(float)d_T32[2 * (t & 15)][4 * (t >> 4) + i];
+        s_dct_op[0][t] = u.w[0], s_dct_op[1][t] = u.w[1];
+        for (int sl = 0; sl < 4; sl++) {
+            for (int i = 0; i < 4; i++)
+                u.h[i] = (_Float16)(float)d_T32[t & 31][8 * sl + 4 * (t >> 5) + i];
+            s_dct_op[2 + 2 * sl][t] = u.w[0], s_dct_op[3 + 2 * sl][t] = u.w[1];
+        }
+    }
+}
+__device__ __forceinline__ md_v4h md_h4(int a, int b, int c, int d)
+{
+    md_v4h r;
+    r[0] = (_Float16)(float)a, r[1] = (_Float16)(float)b, r[2] = (_Float16)(float)c, r[3] = (_Float16)(float)d;
+    return r;
+}
+__device__ __forceinline__ md_v4h md_dct_op(int slot, int lane)
+{
+    union { md_v4h h; uint32_t w[2]; } u;
+    u.w[0] = s_dct_op[slot][lane], u.w[1] = s_dct_op[slot + 1][lane];
+    return u.h;
+}
+/* coefficients of the N x N unit (N = 16: 4 per lane, coefficient (4 (lane >> 4) + i, lane & 15); N = 32: 16 per lane, coefficient (mfma row(v, lane >> 5), lane & 31)) ->
+ * out[]; returns false (in every lane) when the unit leaves the wrap-free domain of the Estimate butterflies */
+template <int N>
+__device__ __forceinline__ bool md_fwd_mfma(int lane, const uint8_t *src, int srcPitch, const uint8_t *pred, int predPitch, int fs1, int fs2, int (&out)[N * N / 64])
+{
+    const int off1 = 1 << (fs1 - 1), off2 = 1 << (fs2 - 1);
+    if constexpr (N == 16) {
+        const int j = lane & 15, g = lane >> 4;
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(src + j * srcPitch + 4 * g), b = *reinterpret_cast<const uint32_t *>(pred + j * predPitch + 4 * g);
+        const md_v4h A = md_h4((int)(a & 0xFF) - (int)(b & 0xFF), (int)((a >> 8) & 0xFF) - (int)((b >> 8) & 0xFF), (int)((a >> 16) & 0xFF) - (int)((b >> 16) & 0xFF),
+                               (int)(a >> 24) - (int)(b >> 24));
+        const md_v4h C = md_dct_op(0, lane);
+        const md_v4f z = {0.f, 0.f, 0.f, 0.f};
+        const md_v4f t1 = __builtin_amdgcn_mfma_f32_16x16x16f16(A, C, z, 0, 0, 0); /* T1^T[4 g + i][lane & 15] */
+        int t[4];
+        bool wide = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            t[i] = (int)(int16_t)(((int)t1[i] + off1) >> fs1);
+            wide = wide || t[i] > 16383 || t[i] < -16383;
+        }
+        if (__ballot(wide))
+            return false;
+        const md_v4h H = md_h4(t[0] >> 6, t[1] >> 6, t[2] >> 6, t[3] >> 6), Lo = md_h4(t[0] & 63, t[1] & 63, t[2] & 63, t[3] & 63);
+        const md_v4f dh = __builtin_amdgcn_mfma_f32_16x16x16f16(C, H, z, 0, 0, 0), dl = __builtin_amdgcn_mfma_f32_16x16x16f16(C, Lo, z, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = (int)(int16_t)((((int)dh[i] << 6) + (int)dl[i] + off2) >> fs2);
+        return true;
+    } else {
+        static_assert(N == 32, "matrix-core forms: 16x16 and 32x32");
+        const int m = lane & 31, h = lane >> 5;
+        md_v16f acc;
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            acc[v] = 0.f;
+        md_v4h C[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(src + m * srcPitch + 8 * sl + 4 * h), b = *reinterpret_cast<const uint32_t *>(pred + m * predPitch + 8 * sl + 4 * h);
+            const md_v4h A = md_h4((int)(a & 0xFF) - (int)(b & 0xFF), (int)((a >> 8) & 0xFF) - (int)((b >> 8) & 0xFF), (int)((a >> 16) & 0xFF) - (int)((b >> 16) & 0xFF),
+                                   (int)(a >> 24) - (int)(b >> 24));
+            C[sl] = md_dct_op(2 + 2 * sl, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x8f16(A, C[sl], acc, 0, 0, 0);
+        }
+        int t[16];
+        bool wide = false;
+#pragma unroll
+        for (int v = 0; v < 16; v++) { /* T1^T[row(v, h)][m] */
+            t[v] = (int)(int16_t)(((int)acc[v] + off1) >> fs1);
+            wide = wide || t[v] > 8191 || t[v] < -8191;
+        }
+        if (__ballot(wide))
+            return false;
+        md_v16f dh, dl;
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            dh[v] = 0.f, dl[v] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) { /* the accumulator registers 4 sl .. 4 sl + 3 hold exactly K-slice sl of pass 2 */
+            const md_v4h H = md_h4(t[4 * sl] >> 6, t[4 * sl + 1] >> 6, t[4 * sl + 2] >> 6, t[4 * sl + 3] >> 6);
+            const md_v4h Lo = md_h4(t[4 * sl] & 63, t[4 * sl + 1] & 63, t[4 * sl + 2] & 63, t[4 * sl + 3] & 63);
+            dh = __builtin_amdgcn_mfma_f32_32x32x8f16(C[sl], H, dh, 0, 0, 0);
+            dl = __builtin_amdgcn_mfma_f32_32x32x8f16(C[sl], Lo, dl, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            out[v] = (int)(int16_t)((((int)dh[v] << 6) + (int)dl[v] + off2) >> fs2);
+        return true;
+    }
+}
+
 /* the coefficient-bit estimator (rate_device.h) as ONE function for every transform size: inlined into the four sizes of md_full_loop_unit it was 2.5 K instructions four
  * times over in a kernel whose unit loop does not fit the instruction cache (SQC_TC_INST_REQ: ~760 instruction lines from L2 per unit, profiles/r06_j) */
 __device__ __noinline__ uint32_t md_coeff_bits(const SvtAmdCabacCost *cost, const int16_t *qbuf, int N, int lga, uint32_t nz, int type, int intra_mode, int component, int lane, int S4,
@@ -319,6 +432,52 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     if (recon_coeff)
         MD_LDS(recon_coeff);
     MD_TR(50);
+    const int qpRem = qp % 6, qpPer = qp / 6;
+    const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
+    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    const int tshift = 7 - LG, shiftedQBits = 14 + qpPer + tshift;
+    const uint32_t offs = ((slice_type == 2 || slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
+    const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
+    const int area = N >> pf;
+    unsigned nz = 0, d0 = 0, d1 = 0;
+    auto quantise = [&](int v, bool inside, int &q, int &c) {
+        /* the products of the quantiser fit 24 x 24 bits (coefficients are 16-bit values, the scaling factors below 2^15): v_mul_i32_i24 is a full-rate instruction,
+         * v_mul_lo_u32 a quarter-rate one */
+        const int sign = v < 0 ? -1 : 1;
+        int tq = abs(v);
+        tq = (int)__umul24((uint32_t)tq, QF);
+        tq = (int)((uint32_t)tq + offs);
+        tq >>= shiftedQBits;
+        q = clip16i(sign * tq);
+        c = clip16i((__mul24(q, shiftedFFunc) + iq_offset) >> shiftNum);
+        if (inside) {
+            const int df = (int16_t)(v - c);
+            nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
+        }
+    };
+    bool on_matrix_cores = false;
+    if constexpr (N == 16 || N == 32) {
+        int co[N * N / 64];
+        on_matrix_cores = md_fwd_mfma<N>(lane, src, srcPitch, pred, predPitch, fs1, fs2, co); /* wave-uniform */
+        if (on_matrix_cores) {
+            MD_TR(52);
+            const int k = lane & (N - 1);
+#pragma unroll
+            for (int i = 0; i < N * N / 64; i++) {
+                const int k2 = N == 16 ? 4 * (lane >> 4) + i : (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); /* the accumulator's row */
+                const bool inside = k2 < area && k < area;
+                int q, c;
+                quantise(co[i], inside, q, c);
+                if (inside) {
+                    qbuf[k2 * N + k] = (int16_t)q;
+                    if (recon_coeff)
+                        recon_coeff[k2 * N + k] = (int16_t)c;
+                }
+            }
+        }
+    }
+    if (!on_matrix_cores) {
     const int r = lane & (N - 1);
     const bool active = lane < N;
     int x[N];
@@ -337,36 +496,72 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
             x[j] = 0;
     }
     MD_TR(51);
-    fwd_2d_regs<N>(x, tile + (lane / N) * TxRegTile<N>::UNIT, r, fs1, fs2, wrap); /* x[j] = coefficient (j, r) */
-    MD_TR(52);
-    const int qpRem = qp % 6, qpPer = qp / 6;
-    const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
-    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
-    const int tshift = 7 - LG, shiftedQBits = 14 + qpPer + tshift;
-    const uint32_t offs = ((slice_type == 2 || slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
-    const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
-    const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
-    const int area = N >> pf;
-    const bool in_area = active && r < area;
-    unsigned nz = 0, d0 = 0, d1 = 0;
+    /* the transform on the unit's N row-lanes (pass 1, transpose through LDS, pass 2), its coefficients straight into the quantiser's buffer (row-major, 16-bit: what the
+     * second pass produces) - and the QUANTISER ON ALL 64 LANES: a lane owns N*N/64 consecutive coefficients (16 / 4 / 1 of a 32x32 / 16x16 / 8x8 unit) instead of a whole
+     * column on N lanes: a 16x16 unit's quantiser is 4 coefficients deep per lane, not 16 (the unit chain is bound by instructions issued per wave). */
+    {
+        constexpr int P = TxRegTile<N>::PITCH;
+        int16_t *t_ = tile + (lane / N) * TxRegTile<N>::UNIT;
+        fwd_1d_regs<N>(x, fs1, wrap, [&](int k, int16_t v) { t_[k * P + r] = v; });
+        EP_WAVE_SYNC();
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-        const int v = x[j], sign = v < 0 ? -1 : 1;
-        /* the products of the quantiser fit 24 x 24 bits (coefficients are 16-bit values by the transforms' construction, the scaling factors below 2^15): v_mul_i32_i24 is
-         * a full-rate instruction, v_mul_lo_u32 a quarter-rate one - four of them per coefficient on one lane's chain */
-        int tq = abs(v);
-        tq = (int)__umul24((uint32_t)tq, QF);
-        tq = (int)((uint32_t)tq + offs);
-        tq >>= shiftedQBits;
-        const int q = clip16i(sign * tq);
-        const int c = clip16i((__mul24(q, shiftedFFunc) + iq_offset) >> shiftNum);
-        if (in_area && j < area) {
-            qbuf[j * N + r] = (int16_t)q;
-            if (recon_coeff)
-                recon_coeff[j * N + r] = (int16_t)c;
-            const int df = (int16_t)(v - c);
-            nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
+        for (int j = 0; j < N; j += 2) {
+            const uint32_t w = *(const uint32_t *)&t_[r * P + j];
+            x[j] = (int16_t)(w & 0xffffu), x[j + 1] = (int16_t)(w >> 16);
         }
+        fwd_1d_regs<N>(x, fs2, wrap, [&](int k, int16_t v) {
+            if (active)
+                qbuf[k * N + r] = v; /* coefficient (k, r) */
+        });
+        EP_WAVE_SYNC();
+    }
+    MD_TR(52);
+    {
+        constexpr int CPL = N * N >= 64 ? N * N / 64 : 1, LANES = N * N / CPL; /* coefficients per lane; the lanes that hold some */
+        const int e0 = lane * CPL;
+        const bool lane_in = lane < LANES && (e0 >> LG) < area; /* (a lane's coefficients share their row: CPL <= N) */
+        if (lane_in) {
+            int v_[CPL];
+            int16_t *qp_ = qbuf + e0;
+            if constexpr (CPL == 16) {
+                const uint4 a = reinterpret_cast<const uint4 *>(qp_)[0], b = reinterpret_cast<const uint4 *>(qp_)[1];
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    v_[2 * i] = (int16_t)(w[i] & 0xffffu), v_[2 * i + 1] = (int16_t)(w[i] >> 16);
+            } else if constexpr (CPL == 4) {
+                const uint2 a = *reinterpret_cast<const uint2 *>(qp_);
+                v_[0] = (int16_t)(a.x & 0xffffu), v_[1] = (int16_t)(a.x >> 16), v_[2] = (int16_t)(a.y & 0xffffu), v_[3] = (int16_t)(a.y >> 16);
+            } else {
+                v_[0] = qp_[0];
+            }
+            int q_[CPL], c_[CPL];
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const bool inside = ((e0 + i) & (N - 1)) < area;
+                int q, c;
+                quantise(v_[i], inside, q, c);
+                q_[i] = inside ? q : v_[i] /* outside the quantised area the buffer is never read */, c_[i] = c;
+            }
+            auto put = [&](int16_t *dst, const int (&val)[CPL]) {
+                if constexpr (CPL == 16) {
+                    uint32_t w[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        w[i] = (uint32_t)(uint16_t)val[2 * i] | ((uint32_t)(uint16_t)val[2 * i + 1] << 16);
+                    reinterpret_cast<uint4 *>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]), reinterpret_cast<uint4 *>(dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                } else if constexpr (CPL == 4) {
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)(uint16_t)val[0] | ((uint32_t)(uint16_t)val[1] << 16), (uint32_t)(uint16_t)val[2] | ((uint32_t)(uint16_t)val[3] << 16));
+                } else {
+                    dst[0] = (int16_t)val[0];
+                }
+            };
+            put(qp_, q_);
+            if (recon_coeff) { /* (outside the quantised area the reconstruction buffer keeps what it held: the closed-loop decision runs without partial frequencies) */
+                put(recon_coeff + e0, c_);
+            }
+        }
+    }
     }
     MD_TR(53);
     nz = md_wave_sum(nz), d0 = md_wave_sum(d0), d1 = md_wave_sum(d1); /* the lanes beyond the unit's rows hold zeros */
@@ -2609,6 +2804,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
     for (int i = threadIdx.x; i < (int)(sizeof(MdPictureDev) / 8); i += 256)
         reinterpret_cast<unsigned long long *>(&s_D)[i] = reinterpret_cast<const unsigned long long *>(Dp)[i];
     __syncthreads();
+    md_dct_operands_init();
     const MdPictureDev &D = s_D;
     const SvtAmdMdPicture &P = *D.P;
     for (;;) {
