@@ -1269,19 +1269,25 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         const bool any_intra = ni != 0;
         /* the first fast loop (EbProductCodingLoop.c:1948-1988): the best of the candidates whose distortion the open-loop stages left; the reference walks from the last
          * candidate down with <=: the LOWEST index among equal costs */
+        /* A candidate's fast cost is (distortion terms) + (lambda * rate + 2^22 >> 23), and the RATE is known before any distortion is: the rules of md_logic.h, called once
+         * per candidate with zero distortion, return exactly that rate term (and fastLumaRate).  Fast costs stay below 2^31 (SAD of at most 64 x 64 8-bit samples << 8, a
+         * chroma term of the same size, a rate term below 2^18): everything downstream - the first fast loop here, the fast costs, the candidate buffers and PreModeDecision
+         * behind the second barrier - runs on 32-bit values. */
+        unsigned long long rate = 0;
+        uint32_t rterm = 0;
+        if (in)
+            rterm = (uint32_t)(c.type == MD_INTER ? md_inter_fast_cost_c(&Ph, &st, &cuv, &c, 0, 0, 0, 1, (uint64_t *)&rate)
+                                                  : md_intra_fast_cost_pslice_c(&Ph, &st, &cuv, c.intra_mode, 0, 0, 0, (uint64_t *)&rate));
         int bestFirst = -1;
         {
             const bool ready = in && c.dist_ready;
-            unsigned long long cost = ~0ull;
-            if (ready) {
-                uint64_t r;
-                cost = c.type == MD_INTER ? md_inter_fast_cost(&Ph, &st, &cuv, &c, c.me_dist, &r) : md_intra_fast_cost_pslice(&Ph, &st, &cuv, c.intra_mode, c.me_dist, &r);
-            }
-            unsigned long long m = ~0ull, rm = __ballot(ready);
+            const uint32_t cost = ready ? (c.me_dist << 8) + rterm : 0xFFFFFFFFu;
+            uint32_t m = 0xFFFFFFFFu;
+            unsigned long long rm = __ballot(ready);
             while (rm) {
                 const int l = __ffsll((long long)rm) - 1;
                 rm &= rm - 1;
-                const unsigned long long v = md_readlane64(cost, l);
+                const uint32_t v = md_rl(cost, l);
                 if (bestFirst < 0 || v < m)
                     m = v, bestFirst = l;
             }
@@ -1376,30 +1382,37 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         MD_TR(25);
         MD_PROF(3);
         /* ================= C: fast costs (a lane per candidate), candidate buffers (a lane per buffer), PreModeDecision - in every wave ================= */
-        unsigned long long rate = 0, cst = ~0ull;
+        uint32_t cst = 0xFFFFFFFFu; /* (a candidate the loop does not evaluate: the all-ones cost of an unused buffer) */
         if (in && evl) {
-            uint64_t dist = 0, distc = 0;
+            uint32_t dist, distc = 0;
             if (heavy)
-                dist = tiled64 ? (uint64_t)M.sadt[lane][0] + M.sadt[lane][1] + M.sadt[lane][2] + M.sadt[lane][3] : (uint64_t)M.sadt[lane][0];
+                dist = tiled64 ? M.sadt[lane][0] + M.sadt[lane][1] + M.sadt[lane][2] + M.sadt[lane][3] : M.sadt[lane][0];
             else
                 dist = c.me_dist;
-            uint32_t cwt = 0;
-            if (cfull) /* the chroma pair's SAD with the noise-class rule (:2079-2094) */
-                distc = md_fast_chroma_noise_rule(&Lh, N, &c, (uint64_t)M.V.sadc2[lane][0] + M.V.sadc2[lane][1]), cwt = M.V.X.chroma_weight;
-            cst = c.type == MD_INTER ? md_inter_fast_cost_c(&Ph, &st, &cuv, &c, dist, distc, cwt, !Lh.cmplx_noise, (uint64_t *)&rate)
-                                     : md_intra_fast_cost_pslice_c(&Ph, &st, &cuv, c.intra_mode, dist, distc, cwt, (uint64_t *)&rate);
+            /* md_inter_fast_cost_c / md_intra_fast_cost_pslice_c (md_logic.h) with the rate term of the first barrier's side */
+            if (cfull) { /* the chroma pair's SAD with the noise-class rule (:2079-2094) */
+                distc = (uint32_t)md_fast_chroma_noise_rule(&Lh, N, &c, (uint64_t)M.V.sadc2[lane][0] + M.V.sadc2[lane][1]);
+                if (c.type == MD_INTER && c.merge_flag && Lh.cmplx_noise)
+                    cst = ((dist + distc) << 8) + rterm; /* weightChromaDistortion == 0: a merge candidate's chroma SAD is added unweighted */
+                else
+                    cst = (dist << 8) + (uint32_t)md_weighted_chroma(distc, M.V.X.chroma_weight) + rterm;
+            } else {
+                cst = (dist << 8) + rterm;
+            }
+        } else {
+            rate = 0; /* fastLumaRate of a candidate the loop does not evaluate (the reference never computes it) */
         }
         MD_TR(26);
         MD_SUB(9);
         /* md_fast_loop_buffers (md_logic.h; ProductPerformFastLoop's second loop, :1990-2179) with the buffers in lanes 0..7: the candidates arrive from the last to the
          * first, each goes into the buffer with the highest cost (an unused one first) = the FIRST buffer holding the maximum over [0, maxBuffers) */
-        unsigned long long bcost = ~0ull;
+        uint32_t bcost = 0xFFFFFFFFu;
         int bcand = -1, bpred = -1, evcount = 0;
         {
             int highest = 0;
             const int maxb = max_buffers < 2 ? 2 : max_buffers;
             for (int idx = nc - 1; idx >= 0; idx--) {
-                const unsigned long long cv = md_readlane64(cst, idx);
+                const uint32_t cv = md_rl(cst, idx);
                 const int ev = __builtin_amdgcn_readlane(evl, idx);
                 if (lane == highest) {
                     bcand = idx;
@@ -1411,12 +1424,12 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 }
                 evcount += ev != 0;
                 if (idx) {
-                    unsigned long long m = 0;
+                    uint32_t m = 0;
                     int h = 0;
 #pragma unroll
                     for (int b = 0; b < MD_MAX_BUF; b++)
                         if (b < maxb) {
-                            const unsigned long long v = md_readlane64(bcost, b);
+                            const uint32_t v = md_rl(bcost, b);
                             if (b == 0 || v > m)
                                 m = v, h = b;
                         }
@@ -1439,10 +1452,10 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             if (count > 1) {
                 int skipIdx = -1;
                 if (!same) {
-                    unsigned long long hcost = md_readlane64(bcost, 0);
+                    uint32_t hcost = md_rl(bcost, 0);
                     skipIdx = 0;
                     for (int i = 1; i < count; i++) {
-                        const unsigned long long v = md_readlane64(bcost, i);
+                        const uint32_t v = md_rl(bcost, i);
                         if (v >= hcost)
                             hcost = v, skipIdx = i;
                     }
