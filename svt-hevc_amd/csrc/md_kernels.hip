@@ -142,6 +142,7 @@ struct MdInterShared {
     SvtAmdMeCuResult me[SVT_AMD_ME_PU_COUNT]; /* the LCU's motion-estimation candidates */
     SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
     alignas(16) MdCand me_c[4], mg_c[5]; /* the unit's motion-estimation / merge candidates as their list-building waves leave them (wave 0 appends them to the intra candidates) */
+    uint2 me_rate[4];              /* ... and the motion-estimation candidates' rate term and fastLumaRate (they depend on the predictors only: derived beside the AMVP lists) */
     int n_me, n_mg;
     alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
     uint8_t cpred[MD_PRED_SLOTS][64 * 64]; /* the fast loop's predictions of the first motion-compensated candidates, kept for the full loop */
@@ -191,6 +192,7 @@ struct MdShared {
     unsigned long long merge_cost[MD_MAX_BUF], skip_cost[MD_MAX_BUF], y_bits[MD_MAX_BUF], y_dist[MD_MAX_BUF][2];
     uint32_t full_dist[MD_MAX_BUF];
     int leaf, cu_idx, ncand, buffer_total, nfull, full_count, max_buffers, lowest, do_recon, exited, last, update, done, best_first, any_intra;
+    uint8_t next_step[SVT_AMD_MD_LEAVES + 3]; /* CalculateNextCuIndex's step behind each entry of the leaf list when its unit is not split (md_next_cu_step), made with the LCU's inputs */
     unsigned long long prof[32], prof_t, prof_s;
     unsigned long long prof_d[4][32]; /* the same sums by the depth of the unit they belong to (svt_amd_debug_md_profile_depth) */
     int prof_depth;
@@ -1106,6 +1108,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
     const bool cfull = Lh.chroma_encode_mode == 1; /* CHROMA_MODE_FULL: chroma in both loops of every candidate */
     const bool tile_l = Lh.tile_left != 0, tile_t = Lh.tile_top != 0, tile_r = Lh.tile_right != 0;
     const MdListConsts K = md_list_consts(Ph, M.V.X);
+    const uint32_t sfb0 = P.rates.splitFlagBits[0], sfb1 = P.rates.splitFlagBits[1], sfb2 = P.rates.splitFlagBits[2]; /* SplitFlagRate of an unsplit unit, by context */
     const bool tmvp_on = M.V.X.tmvp_enable != 0;
     const unsigned long long lanebit = 1ull << lane, below = lanebit - 1ull;
     for (;;) {
@@ -1196,6 +1199,13 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     if (keep && (cw.c.dir == MD_BI || cw.c.dir == l))
                         md_choose_mvp_one(Ph, (uint32_t)x0, (uint32_t)y0, al, cnt, &cw.c.mv[l], &cw.c.mvp_idx[l], &cw.c.mvp[l]);
                 }
+                if (keep) { /* InterFastCost*sliceOpt's rate of a candidate that is not a merge candidate reads no context of the unit: this wave is not the longest of the four */
+                    MdCu none;
+                    none.skip_ctx = 0;
+                    uint64_t r64 = 0;
+                    const uint32_t rt32 = (uint32_t)md_inter_fast_cost_c(&Ph, &st, &none, &cw.c, 0, 0, 0, 1, &r64);
+                    M.V.me_rate[__popcll(__ballot(keep) & below)] = make_uint2(rt32, (uint32_t)r64);
+                }
             } else {
                 /* the temporal candidate's two vectors side by side, the merge list, then ProductMergeSkip2Nx2NCandidatesInjection: a lane per merge candidate */
                 MdMv tv;
@@ -1275,9 +1285,15 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
          * behind the second barrier - runs on 32-bit values. */
         unsigned long long rate = 0;
         uint32_t rterm = 0;
-        if (in)
-            rterm = (uint32_t)(c.type == MD_INTER ? md_inter_fast_cost_c(&Ph, &st, &cuv, &c, 0, 0, 0, 1, (uint64_t *)&rate)
-                                                  : md_intra_fast_cost_pslice_c(&Ph, &st, &cuv, c.intra_mode, 0, 0, 0, (uint64_t *)&rate));
+        if (in) {
+            if (lane >= ni && lane < ni + nme) { /* (derived beside the AMVP lists) */
+                const uint2 pr = M.V.me_rate[lane - ni];
+                rterm = pr.x, rate = pr.y;
+            } else {
+                rterm = (uint32_t)(c.type == MD_INTER ? md_inter_fast_cost_c(&Ph, &st, &cuv, &c, 0, 0, 0, 1, (uint64_t *)&rate)
+                                                      : md_intra_fast_cost_pslice_c(&Ph, &st, &cuv, c.intra_mode, 0, 0, 0, (uint64_t *)&rate));
+            }
+        }
         int bestFirst = -1;
         {
             const bool ready = in && c.dist_ready;
@@ -1700,13 +1716,38 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 u.y_coeff_bits = w_kept ? w_bits : 0, u.y_dist[0] = w_kept ? w_d0 : 0, u.y_dist[1] = w_kept ? w_d1 : 0;
                 u.fast_luma_rate = w_rate, u.ycbf_mask = yc;
                 M.S.local[leaf].mdc_index = (uint8_t)cuIdx;
-                int cur = leaf, curIdx = cuIdx;
-                const int exitParent = md_check_high_cost_partition(&P, &Lh, &M.S, leaf);
-                int last;
+                int cur = leaf, curIdx = cuIdx, last;
+                /* CheckHighCostPartition (md_check_high_cost_partition, md_logic.h) with everything it may read requested AT ONCE (the parent's record, the earlier siblings'
+                 * costs, the counters of the depth decision, the next-unit step): one LDS round trip where the rule's early exits make a chain of five */
+                const int off = md_depth_offset(st.depth), parent = st.parent;
+                const MdLocal pl = M.S.local[parent];
+                const uint64_t sib1 = M.S.local[leaf >= off ? leaf - off : 0].cost, sib2 = M.S.local[leaf >= 2 * off ? leaf - 2 * off : 0].cost;
+                const int split_now = u.split, g8 = M.S.g8, g16 = M.S.g16, step = M.next_step[cuIdx];
+                int exitParent = -1;
+                if (Lh.is_complete && st.depth != 0 && st.ordinal < 4 && !split_now && pl.tested) {
+                    const MdStats ps = md_stats(parent);
+                    const int ctx = (pl.left_mode > MD_INTRA ? 0 : pl.left_depth > ps.depth) + (pl.top_mode > MD_INTRA ? 0 : pl.top_depth > ps.depth);
+                    const uint64_t srate = ps.depth < 3 ? (ctx == 0 ? sfb0 : ctx == 1 ? sfb1 : sfb2) : 0;
+                    const uint64_t parentCost = pl.cost + (((uint64_t)Ph.full_lambda * srate + (1u << 22)) >> 23);
+                    const uint64_t children = w_cost + (st.ordinal >= 2 ? sib1 : 0) + (st.ordinal >= 3 ? sib2 : 0);
+                    if (children > parentCost)
+                        exitParent = parent;
+                }
                 if (exitParent >= 0) {
-                    cur = exitParent, curIdx = M.S.local[exitParent].mdc_index;
+                    cur = exitParent, curIdx = pl.mdc_index;
                     M.S.cu[exitParent].split = 0;
                     last = md_inter_depth_decision(&P, &M.S, exitParent, lcu_x, lcu_y, 1, 0);
+                } else if (st.ordinal < 4 || st.depth == 0) {
+                    /* ProductPerformInterDepthDecision (md_inter_depth_decision) of a unit that is not the last of its four siblings: no depth is compared, the unit becomes a
+                     * leaf when the leaf list or StopSplitCondition says so and the counters of finished blocks move */
+                    if (split_now == 0 || md_stop_split(&Ph, &Lh, st.depth, w_kept ? (uint32_t)w_d0 : 0u)) {
+                        u.split = 0;
+                        if (st.depth == 1)
+                            M.S.g16 = (uint8_t)(g16 + 1);
+                        else if (st.depth == 2)
+                            M.S.g8 = (uint8_t)(g8 + 1);
+                    }
+                    last = leaf;
                 } else { /* open loop: no reconstruction to wait for, the inter-depth decision follows at once */
                     last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, md_stop_split(&Ph, &Lh, st.depth, w_kept ? (uint32_t)w_d0 : 0u));
                 }
@@ -1717,7 +1758,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 if (M.S.cu[cur].split || lh < 64)
                     nextIdx++;
                 else
-                    nextIdx += md_next_cu_step(&M.lcu, curIdx, md_stats(cur).depth);
+                    nextIdx += cur == leaf ? step : (int)M.next_step[curIdx];
                 M.cu_idx = nextIdx;
                 M.done = nextIdx >= Lh.leaf_count;
 #ifdef MD_TRACE
@@ -1808,6 +1849,8 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAm
         md_construct_cu_array(&M.S, &M.lcu);
         M.cu_idx = 0, M.done = 0;
     }
+    if (t >= 64 && t < 64 + (int)M.lcu.leaf_count) /* (before the wait for the neighbours: off the chain) */
+        M.next_step[t - 64] = (uint8_t)md_next_cu_step(&M.lcu, t - 64, md_stats(M.lcu.leaf_index[t - 64]).depth);
     if constexpr (INTER) { /* still before the wait for the LCU's neighbours: the reference samples its candidates will most likely read */
         const SvtAmdMeCuResult me0 = M.V.me[0];
         int16_t cmv[2][2];
