@@ -88,10 +88,12 @@ struct MdPictureDev {
     unsigned long long *trace;    /* debug (-DMD_TRACE builds, svt_amd_debug_md_trace): the time stamps of trace_lcu's units [trace_unit, trace_unit + 2), or null */
     int trace_lcu, trace_unit;
 };
-/* stage clocks of the mode decision of one LCU, taken by lane 0 behind the barrier that ends the stage */
+/* stage clocks of the mode decision of one LCU, taken by lane 0 behind the barrier that ends the stage.  MD_PROF_ON: `prof_on`, a register copy of "D.prof != null" the
+ * functions that use the marks make once per LCU - the descriptor lives in LDS, and fifteen marks per unit each re-reading the pointer were fifteen LDS round trips per unit */
+#define MD_PROF_ON prof_on
 #define MD_PROF(k)                                                          \
     do {                                                                    \
-        if (D.prof && threadIdx.x == 0) {                                   \
+        if (MD_PROF_ON && threadIdx.x == 0) {                               \
             const unsigned long long c_ = __builtin_readcyclecounter();    \
             M.prof[k] += c_ - M.prof_t, M.prof_d[M.prof_depth][k] += c_ - M.prof_t, M.prof_t = c_, M.prof_s = c_; \
         }                                                                   \
@@ -99,7 +101,7 @@ struct MdPictureDev {
 /* ... and finer marks inside a stage (svt_amd_debug_md_profile_sub): slot k of 16 gets the clocks since the previous mark of either kind */
 #define MD_SUB(k)                                                           \
     do {                                                                    \
-        if (D.prof && threadIdx.x == 0) {                                   \
+        if (MD_PROF_ON && threadIdx.x == 0) {                               \
             const unsigned long long c_ = __builtin_readcyclecounter();    \
             M.prof[16 + (k)] += c_ - M.prof_s, M.prof_d[M.prof_depth][16 + (k)] += c_ - M.prof_s, M.prof_s = c_; \
         }                                                                   \
@@ -142,6 +144,8 @@ struct MdInterShared {
     SvtAmdMeCuResult me[SVT_AMD_ME_PU_COUNT]; /* the LCU's motion-estimation candidates */
     SvtAmdTmvpLcu tmvp[2];         /* the co-located picture's motion field at this LCU and the one to its right */
     alignas(16) MdCand me_c[4], mg_c[5]; /* the unit's motion-estimation / merge candidates as their list-building waves leave them (wave 0 appends them to the intra candidates) */
+    uint32_t nbtab[SVT_AMD_MD_LEAVES][5]; /* per entry of the leaf list, made with the LCU's inputs (off the chain): where its five spatial neighbours A0, A1, B0, B1, B2 lie - index into
+                                    * L.info | index into mvu << 10 | (inside what is decided before the unit, not across a tile edge) << 18 */
     uint2 me_rate[4];              /* ... and the motion-estimation candidates' rate term and fastLumaRate (they depend on the predictors only: derived beside the AMVP lists) */
     int n_me, n_mg;
     alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
@@ -1088,6 +1092,7 @@ static_assert(sizeof(MdCand) == 32, "a candidate is eight words: type | intra_mo
 
 __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, int lcu_x, int lcu_y, MdShared<true> &M)
 {
+    const bool prof_on = __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
     const SvtAmdMdPicture &P = M.pic; /* the rate tables (indexed by contexts): read where they are */
     /* the picture's and the LCU's CONTROLS in registers: a copy of the records' scalar parts, made once per LCU (a control read from LDS is a ~120-clock round trip on
      * a chain whose every stage tests a dozen of them).  Ph / Lh go to the rules that read controls only; the rate tables and the leaf list stay behind P / M.lcu. */
@@ -1122,7 +1127,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         if (wave == 0) {
             if (lane == 0) {
                 M.leaf = leaf;
-                if (D.prof)
+                if (prof_on)
                     M.prof_depth = st.depth;
                 M.S.local[leaf].tested = 1;
                 M.S.cu[leaf].split = M.lcu.leaf_split[cuIdx];
@@ -1148,12 +1153,9 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             /* the five spatial neighbours (A0, A1, B0, B1, B2; availability as GenerateL0L1AmvpMergeLists derives it, :2256-2340): a lane each, then all five in registers */
             uint32_t w0 = 0, w1 = 0, w2 = 0;
             if (lane < 5) {
-                const int k = lane;
-                const bool left = tile_l && st.x == 0, top = tile_t && st.y == 0, right = tile_r && ((st.x + N) & 63) == 0;
-                const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
-                const bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
-                if (ok && (L.info_at(px, py) & 0xFF) == MD_INTER) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(M.V.mv_at(px, py));
+                const uint32_t e = M.V.nbtab[cuIdx][lane];
+                if (((e >> 18) & 1u) && (L.info[e & 1023u] & 0xFF) == MD_INTER) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(&M.V.mvu[(e >> 10) & 255u]);
                     w0 = q[0], w1 = q[1], w2 = (q[2] & 0xFFu) | 0x100u; /* mv[0], mv[1], dir | avail << 8 */
                 }
             }
@@ -1327,7 +1329,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         MD_SUB(6);
         MD_PROF(1);
         MD_PROF(2);
-        if (D.prof && t == 0)
+        if (prof_on && t == 0)
             M.prof[13] += (unsigned long long)nc, M.prof[14] += 1, M.prof_d[M.prof_depth][13] += (unsigned long long)nc, M.prof_d[M.prof_depth][14] += 1;
         /* ---- fast loop (ProductPerformFastLoop's second loop): ONE list of tasks = (candidate, plane, tile) dealt to the four waves ---- */
         const bool tiled64 = N == 64 && !any_intra;
@@ -1851,6 +1853,24 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAm
     }
     if (t >= 64 && t < 64 + (int)M.lcu.leaf_count) /* (before the wait for the neighbours: off the chain) */
         M.next_step[t - 64] = (uint8_t)md_next_cu_step(&M.lcu, t - 64, md_stats(M.lcu.leaf_index[t - 64]).depth);
+    if constexpr (INTER) {
+        /* the spatial neighbours of every unit of the leaf list with the availability GenerateL0L1AmvpMergeLists derives from positions (EbAdaptiveMotionVectorPrediction.c:2256-2340:
+         * scan order, array bounds, tile edges); whether the neighbour is an inter unit is the one thing left to the unit's own time */
+        const bool tl = M.lcu.tile_left != 0, tt = M.lcu.tile_top != 0, tr = M.lcu.tile_right != 0;
+        for (int i = t; i < 5 * (int)M.lcu.leaf_count; i += 256) {
+            const int ci = i / 5, k = i - 5 * ci;
+            const MdStats st = md_stats(M.lcu.leaf_index[ci]);
+            const int N = st.size;
+            const bool left = tl && st.x == 0, top = tt && st.y == 0, right = tr && ((st.x + N) & 63) == 0;
+            const int px = k == 2 ? st.x + N : k == 3 ? st.x + N - 1 : st.x - 1, py = k == 0 ? st.y + N : k == 1 ? st.y + N - 1 : st.y - 1;
+            bool ok = k == 0 ? md_bottom_left_ok(&st) && !left : k == 1 ? !left : k == 2 ? md_top_right_ok(&st) && !top && !right : k == 3 ? !top : !left && !top;
+            const int cx = px >> 2, cy = py >> 2;
+            if (cy >= 16 || cx >= 32 || (cy >= 0 && cx >= 16)) /* (MdLocal8T::info_at: never written before this LCU's units) */
+                ok = false;
+            const int ii = ok ? (cy + 1) * 36 + cx + 1 : 0, mi = ok ? ((py >> 3) + 1) * 18 + (px >> 3) + 1 : 0;
+            M.V.nbtab[ci][k] = (uint32_t)ii | ((uint32_t)mi << 10) | ((uint32_t)ok << 18);
+        }
+    }
     if constexpr (INTER) { /* still before the wait for the LCU's neighbours: the reference samples its candidates will most likely read */
         const SvtAmdMeCuResult me0 = M.V.me[0];
         int16_t cmv[2][2];
@@ -1868,6 +1888,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
      * of these fields one after the other - each a round trip of its own from global memory) */
     const SvtAmdMdPicture &P = M.pic;
     (void)Pg;
+    const bool prof_on = __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     auto &L = M.L;
     const int W = (int)P.width, H = (int)P.height;
@@ -1950,7 +1971,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
             const int cuIdx = M.cu_idx, leaf = M.lcu.leaf_index[cuIdx];
             const MdStats st = md_stats(leaf);
             M.leaf = leaf;
-            if (D.prof)
+            if (prof_on)
                 M.prof_depth = st.depth;
             M.S.local[leaf].tested = 1;
             M.S.cu[leaf].split = (uint8_t)((islice && st.depth == 0) ? 1 : M.lcu.leaf_split[cuIdx]);
@@ -2183,7 +2204,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
             __syncthreads();
         }
         MD_PROF(2);
-        if (D.prof && t == 0)
+        if (prof_on && t == 0)
             M.prof[13] += (unsigned long long)ncand, M.prof[14] += 1, M.prof_d[M.prof_depth][13] += (unsigned long long)ncand, M.prof_d[M.prof_depth][14] += 1;
         /* ---- fast loop (ProductPerformFastLoop's second loop): ONE list of tasks = (candidate, plane, tile) dealt to the four waves ----
          * luma tasks first - a candidate of a 64x64 unit is motion-compensated in four 32x32 tiles, a task each (wave w takes tile w of EVERY candidate: all four waves work
@@ -2852,8 +2873,9 @@ template <bool INTER, typename T>
 __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restrict__ Dp, typename EpTypes<T>::Work *__restrict__ works, int nlcu, int wl, unsigned *ticket,
                                                     unsigned *md_done, const unsigned *__restrict__ order, unsigned epoch)
 {
-    extern __shared__ __align__(16) unsigned char md_lds[];
-    MdShared<INTER> &M = *reinterpret_cast<MdShared<INTER> *>(md_lds);
+    /* the LCU state as STATIC shared memory (its size is a compile-time constant): with `extern __shared__` every leaf function looked the dynamic segment's offset up
+     * in a table in memory at its entry (llvm.amdgcn.dynlds.offset.table: a scalar load and its latency per call), and no access had an absolute address */
+    __shared__ MdShared<INTER> M;
     __shared__ unsigned s_ticket;
     __shared__ MdPictureDev s_D;
     static_assert(sizeof(MdPictureDev) % 8 == 0, "copied as 8-byte words");
@@ -3220,12 +3242,7 @@ static int md_kernel_attributes(int device)
     static bool attr[64];
     std::lock_guard<std::mutex> g(mu);
     if (!attr[device & 63]) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<true, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<true>)));
-#ifndef MD_INTER8_ONLY /* (development builds, tools/exp_build.sh: one instantiation compiles in a quarter of the time) */
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<false, uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<false>)));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<false, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<false>)));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_md_picture<true, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MdShared<true>)));
-#endif
+        /* (the kernels' LCU state is static shared memory: nothing to raise) */
         attr[device & 63] = true;
     }
     return SVT_AMD_OK;
@@ -3482,20 +3499,20 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X && bps == 1)
-        hipLaunchKernelGGL((k_md_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<true>), st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
 #ifdef MD_INTER8_ONLY
     else
         return SVT_AMD_ERR_BAD_PARAM;
 #else
     else if (bps == 1)
-        hipLaunchKernelGGL((k_md_picture<false, uint8_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<false>), st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<false, uint8_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
     else if (X)
-        hipLaunchKernelGGL((k_md_picture<true, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<true>), st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<true, uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
     else
-        hipLaunchKernelGGL((k_md_picture<false, uint16_t>), dim3((unsigned)grid), dim3(256), sizeof(MdShared<false>), st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<false, uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
 #endif
     HIP_TRY(hipGetLastError());
