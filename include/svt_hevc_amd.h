@@ -1148,7 +1148,9 @@ SVT_AMD_API int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDec
  *   svt_amd_encdec_picture_broadcast - ncclBroadcast of the object's latest stage from rank `root` (communicator of svt_amd_comm_init); on the other ranks the planes
  *     land in the object's final stage, svt_amd_encdec_picture_reference then pads the picture there as on its owner;
  *   svt_amd_encdec_picture_import    - the same hand-over between two picture objects of one process (logical ranks on one device, a host with its own transport):
- *     a copy on ctx's stream; the owner's work on `from` must have completed (svt_amd_synchronize on its context);
+ *     a copy on ctx's stream, ordered BEHIND whatever last wrote `from` (the event recorded behind its encode pass, filter or exchange).  It does not hold `from`'s owner
+ *     back: the owner must not start its next picture on `from` before the importer's stream has passed the copy (svt_amd_lane_event_record / _wait, or
+ *     svt_amd_synchronize on the importer's context);
  *   svt_amd_recon_broadcast          - the collective on caller-owned planes (whole allocations of bytes[p] bytes, equal on every rank). */
 SVT_AMD_API int svt_amd_recon_broadcast(SvtAmdContext *ctx, void *const d_planes[3], const size_t bytes[3], int world, int rank, int root);
 SVT_AMD_API int svt_amd_encdec_picture_broadcast(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int world, int rank, int root);
@@ -1648,7 +1650,12 @@ SVT_AMD_API int svt_amd_md_picture_supported(const SvtAmdMdPicture *P);
  * included) and results (the encode pass's output contract) out - any of the three may be NULL.  src_y / src_cb / src_cr: HOST
  * planes of the picture's source (enhancedPicturePtr), sample (0,0), strides in samples.  ois: HOST array of the picture's
  * open-loop intra search results, or NULL - then the records svt_amd_ois_picture* left in HBM for `ois_slot` are read.  cost: the
- * picture's coefficient-rate tables (pcs->cabacCost).  Blocking. */
+ * picture's coefficient-rate tables (pcs->cabacCost).  Blocking.
+ * Source planes with rows contiguous in memory (stride_y < 2 * width + 256, multiples of 4) travel as ONE linear transfer each: the call then READS the
+ * caller's inter-row padding too - stride * (rows - 1) + width bytes from src_y / src_cb / src_cr must be readable (an encoder's padded picture buffer is;
+ * a plane assembled from separately allocated rows must be passed with a stride that fails the test, or copied first).
+ * Round 6: the call is two kernels on the context's stream - the decisions of every LCU (wavefront on the device), then the encode pass of every LCU from the work
+ * records the first left in HBM. */
 SVT_AMD_API int svt_amd_md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdMdPicture *P, const SvtAmdMdLcu *lcus,
                                           const uint8_t *src_y, uint32_t stride_y, const uint8_t *src_cb, const uint8_t *src_cr,
                                           uint32_t stride_c, const SvtAmdOisLcuResult *ois, int ois_slot, const SvtAmdCabacCost *cost,
@@ -1686,6 +1693,9 @@ SVT_AMD_API int svt_amd_debug_md_profile(SvtAmdContext *ctx, SvtAmdEncDecPicture
 SVT_AMD_API int svt_amd_debug_md_profile_sub(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
 /* ... and both sets of sums by the depth of the coding unit they were spent on: out[LCU][depth 0..3][32] */
 SVT_AMD_API int svt_amd_debug_md_profile_depth(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, unsigned long long *out);
+/* debug / test: the full loops' 16x16 and 32x32 forward transforms on the register butterflies (on != 0) instead of the matrix cores for the picture object's later calls:
+ * both paths must give the reference's decisions (tests/test_gpu_md.py) */
+SVT_AMD_API int svt_amd_debug_md_force_butterflies(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int on);
 /* development builds (-DMD_TRACE) only, SVT_AMD_ERR_BAD_PARAM otherwise: lane-0 time stamps of the kernel's four waves along two units of one LCU (tools/md_trace.py) */
 SVT_AMD_API int svt_amd_debug_md_trace(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int lcu, int unit, unsigned long long *out);
 /* measurement: duration in ms (HIP events on the call's stream) and launch width (workgroups) of the picture object's last mode-decision kernel launch */

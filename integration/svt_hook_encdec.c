@@ -163,7 +163,7 @@ static int ep_lanes(void)
 {
     static int n;
     if (!n) {
-        const char *v = getenv("SVT_HOOK_EP_LANES");
+        const char *v = svt_hook_cfg("SVT_HOOK_EP_LANES");
         const int want = v ? atoi(v) : 0;
         n = (want >= 1 && want <= EP_LANES) ? want : EP_LANES;
     }
@@ -671,7 +671,7 @@ void __wrap_EncodePass(SequenceControlSet_t *scs, PictureControlSet_t *pcs, Larg
     if (g_ep_state == 0) {
         g_ep_verify = getenv("SVT_HOOK_ENCODEPASS_VERIFY") != NULL;
         g_ep_refs = getenv("SVT_HOOK_ENCODEPASS_REFS") != NULL;
-        g_ep_state = (getenv("SVT_HOOK_ENCODEPASS") || getenv("SVT_HOOK_MD")) ? 1 : -1;
+        g_ep_state = (getenv("SVT_HOOK_ENCODEPASS") || svt_hook_cfg("SVT_HOOK_MD")) ? 1 : -1;
         g_ep_own = getenv("SVT_HOOK_ENCODEPASS") != NULL;
     }
     if (g_ep_state < 0 || svt_hook_failed() || contextPtr->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7)) {
@@ -1062,7 +1062,7 @@ static int g_warm_n, g_warm_wide;
 static uint32_t g_warm_w, g_warm_h;
 void svt_hook_encdec_warmup(void)
 {
-    if (!g_warm_n || !getenv("SVT_HOOK_MD") || getenv("SVT_HOOK_NO_WARMUP") || (g_warm_w & 7) || (g_warm_h & 7))
+    if (!g_warm_n || !svt_hook_cfg("SVT_HOOK_MD") || getenv("SVT_HOOK_NO_WARMUP") || (g_warm_w & 7) || (g_warm_h & 7))
         return;
     SvtAmdContext *root = svt_hook_device((uint16_t)g_warm_w, (uint16_t)g_warm_h);
     const int n = g_warm_n < ep_lanes() ? g_warm_n : ep_lanes();
@@ -1089,7 +1089,7 @@ EB_ERRORTYPE __wrap_EbSystemResourceCtor(EbSystemResource_t *resourcePtr, EB_U32
                                          EB_PTR objectInitDataPtr, EbDctor objectDestroyer)
 {
     if (objectCreator == PictureControlSetCreator) {
-        const char *v = getenv("SVT_HOOK_PCS_POOL");
+        const char *v = svt_hook_cfg("SVT_HOOK_PCS_POOL");
         const int want = v ? atoi(v) : 0;
         if (want > (int)objectTotalCount && want <= EP_PICTURES) {
             fprintf(stderr, "svt_hook_encdec: EncDec picture pool %u -> %d PictureControlSet_t objects (SVT_HOOK_PCS_POOL)\n", objectTotalCount, want);
@@ -1106,7 +1106,7 @@ EB_ERRORTYPE __wrap_EbSystemResourceCtor(EbSystemResource_t *resourcePtr, EB_U32
     }
     /* the pools whose pictures cross PCIe when the mode decision runs on the device - source pictures (the application's input buffers the encoder keeps as
      * enhancedPicturePtr) and reference pictures - are page-locked HERE, while the encoder is being built and the device is idle (svt_hook_me.c:svt_hook_pin_picture_at_init) */
-    if (rc == EB_ErrorNone && (getenv("SVT_HOOK_MD") || getenv("SVT_HOOK_ENCODEPASS")) && (objectCreator == EbInputBufferHeaderCreator || objectCreator == EbReferenceObjectCreator))
+    if (rc == EB_ErrorNone && (svt_hook_cfg("SVT_HOOK_MD") || getenv("SVT_HOOK_ENCODEPASS")) && (objectCreator == EbInputBufferHeaderCreator || objectCreator == EbReferenceObjectCreator))
         for (EB_U32 i = 0; i < resourcePtr->objectTotalCount; i++) {
             void *obj = resourcePtr->wrapperPtrPool[i]->objectPtr;
             if (objectCreator == EbInputBufferHeaderCreator) {
@@ -1315,8 +1315,8 @@ EB_ERRORTYPE __wrap_ModeDecisionLcu(SequenceControlSet_t *scs, PictureControlSet
 {
     if (g_md_state == 0) {
         g_md_verify = getenv("SVT_HOOK_MD_VERIFY") != NULL;
-        g_md_state = getenv("SVT_HOOK_MD") ? 1 : -1;
-        g_md_skip_intra = getenv("SVT_HOOK_MD") && !strcmp(getenv("SVT_HOOK_MD"), "pb"); /* SVT_HOOK_MD=pb: only P / B pictures go to the device */
+        g_md_state = svt_hook_cfg("SVT_HOOK_MD") ? 1 : -1;
+        g_md_skip_intra = svt_hook_cfg("SVT_HOOK_MD") && !strcmp(svt_hook_cfg("SVT_HOOK_MD"), "pb"); /* SVT_HOOK_MD=pb: only P / B pictures go to the device */
     }
     if (g_md_state < 0 || svt_hook_failed() || pcs->colorFormat != EB_YUV420 || (scs->lumaWidth & 7) || (scs->lumaHeight & 7))
         return __real_ModeDecisionLcu(scs, pcs, mdcResultTbPtr, lcuPtr, lcuOriginX, lcuOriginY, lcuAddr, contextPtr);

@@ -10,6 +10,11 @@
 #include "EbEncDecProcess.h"
 #include "../include/svt_hevc_amd.h"
 
+/* The bindings' CONFIGURATION: what the environment says where it says something, the product's defaults otherwise.  The defaults are the configuration bench.py
+ * measures and the end-to-end suite runs (the benchmarked configuration is the one a host gets by loading the library): the closed loop of P / B
+ * pictures on the device (SVT_HOOK_MD=pb), 16 picture control sets in the EncDec pool (SVT_HOOK_PCS_POOL), 12 EncDec lanes and 4 front-half lanes (= streams = hardware
+ * queues: SVT_HOOK_EP_LANES, SVT_HOOK_FRONT_LANES).  "0" or "off" in the environment switches a binding off; any other switch is NULL unless the environment sets it. */
+const char *svt_hook_cfg(const char *name);
 /* the root device context (created with the encoder, or here on first use) and the loud exit every binding shares */
 SvtAmdContext *svt_hook_device(uint16_t lumaWidth, uint16_t lumaHeight);
 void svt_hook_die(const char *what);

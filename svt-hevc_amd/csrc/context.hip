@@ -680,7 +680,11 @@ static void slot_records_reset(DevPicture *s)
 {
     __atomic_store_n(&s->me_lcus, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(&s->ois_lcus, 0u, __ATOMIC_RELEASE);
-    s->me_lo = s->me_hi = 0;
+    while (__atomic_exchange_n(&s->me_cov_lock, 1, __ATOMIC_ACQUIRE))
+        ;
+    memset(s->me_cov, 0, sizeof(s->me_cov));
+    s->me_cov_count = 0;
+    __atomic_store_n(&s->me_cov_lock, 0, __ATOMIC_RELEASE);
 }
 /* Before a kernel of this lane writes the slot's record buffers: a mode-decision kernel of another lane may still be reading the previous picture's records in place
  * (svt_amd_md_encode_picture_inter with me == NULL / ois == NULL records ev_md_read behind its launch). */
@@ -697,14 +701,16 @@ static int me_records_written(SvtAmdContext *ctx, int slot, const SvtAmdMeParams
 {
     DevPicture *s = &ctx->slots[slot];
     const uint32_t n = ((p->luma_width + 63u) / 64u) * ((p->luma_height + 63u) / 64u);
-    if (s->me_hi > s->me_lo && lcu_begin <= s->me_hi && lcu_end >= s->me_lo) { /* touches what is covered: one range */
-        s->me_lo = lcu_begin < s->me_lo ? lcu_begin : s->me_lo;
-        s->me_hi = lcu_end > s->me_hi ? lcu_end : s->me_hi;
-    } else {
-        s->me_lo = lcu_begin, s->me_hi = lcu_end;
-    }
+    uint32_t covered;
+    while (__atomic_exchange_n(&s->me_cov_lock, 1, __ATOMIC_ACQUIRE)) /* (two lanes may launch bands of one slot side by side) */
+        ;
+    for (uint32_t i = lcu_begin; i < lcu_end && i < n && i < 64u * 128u; i++)
+        if (!((s->me_cov[i >> 6] >> (i & 63)) & 1ull))
+            s->me_cov[i >> 6] |= 1ull << (i & 63), s->me_cov_count++;
+    covered = s->me_cov_count;
+    __atomic_store_n(&s->me_cov_lock, 0, __ATOMIC_RELEASE);
     HIP_TRY(hipEventRecord(s->ev_me, ctx->stream));
-    __atomic_store_n(&s->me_lcus, (s->me_lo == 0 && s->me_hi >= n) ? n : 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&s->me_lcus, covered >= n ? n : 0u, __ATOMIC_RELEASE);
     return SVT_AMD_OK;
 }
 static int ois_records_written(SvtAmdContext *ctx, int slot, const SvtAmdOisParams *p)

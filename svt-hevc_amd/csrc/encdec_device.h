@@ -115,7 +115,7 @@ struct EpLocal {
 /* development aid (builds with -DMD_TRACE only; tools/md_trace.py): time stamps of lane 0 of every wave at marks along the mode decision's unit chain, for ONE chosen
  * LCU and two consecutive units - a poor man's thread trace that shows which wave the chain is waiting for at every barrier */
 #ifdef MD_TRACE
-#define MD_TRACE_N 128
+#define MD_TRACE_N 120
 static __shared__ unsigned long long g_md_trace[4][MD_TRACE_N];
 static __shared__ int g_md_trace_n[4];
 static __shared__ int g_md_trace_on;

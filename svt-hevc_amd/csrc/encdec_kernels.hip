@@ -513,7 +513,10 @@ extern "C" int svt_amd_encdec_picture_exchange(SvtAmdContext *ctx, SvtAmdEncDecP
     uint8_t *const *stage = pic->sao_done ? pic->fin : pic->deblocked ? pic->dbk : pic->d.rec;
     void *planes[3] = {stage[0], stage[1], stage[2]};
     const uint32_t pitch[3] = {pic->d.pitch[0] * pic->d.bps, pic->d.pitch[1] * pic->d.bps, pic->d.pitch[2] * pic->d.bps};
-    return svt_amd_recon_exchange(ctx, planes, pitch, (int)pic->d.bps, rects, world, rank);
+    const int rc = svt_amd_recon_exchange(ctx, planes, pitch, (int)pic->d.bps, rects, world, rank);
+    /* "an exchange that fills it": a reader on another context's stream (svt_amd_encdec_picture_import) orders itself behind the all-gather, not behind whatever wrote the
+     * object before it */
+    return rc ? rc : ep_picture_written(ctx, pic);
 }
 /* Picture-level parallelism: the rank that owns a picture encodes all of it; its finished picture (latest stage) goes to every rank ONCE, before
  * svt_amd_encdec_picture_reference pads it there.  On the receiving ranks the planes land in the object's final stage (the object then counts as deblocked and
@@ -944,7 +947,7 @@ static int put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const typen
     hipLaunchKernelGGL(k_put_borders<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, pic->d, (const BorderT *)d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return SVT_AMD_OK;
+    return ep_picture_written(ctx, pic);
 }
 extern "C" int svt_amd_encdec_picture_put_borders(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const SvtAmdLcuBorder *borders, int n)
 {

@@ -85,6 +85,8 @@ struct MdPictureDev {
     const uint16_t *src16[3];
     unsigned long long *prof;     /* debug (svt_amd_debug_md_profile): 16 shader-clock sums per LCU, or null */
     int prof_lcus;                /* LCUs of the picture: the sub-stage sums start behind the stage sums of all of them */
+    int force_butterflies;        /* debug (svt_amd_debug_md_force_butterflies): the 16x16 / 32x32 forward transforms of the full loops on the register butterflies (the path a unit
+                                   * outside the matrix-core form's wrap-free domain takes) - the tests run the fixtures both ways */
     unsigned long long *trace;    /* debug (-DMD_TRACE builds, svt_amd_debug_md_trace): the time stamps of trace_lcu's units [trace_unit, trace_unit + 2), or null */
     int trace_lcu, trace_unit;
 };
@@ -313,10 +315,13 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
 typedef _Float16 md_v4h __attribute__((ext_vector_type(4)));
 typedef float md_v4f __attribute__((ext_vector_type(4)));
 typedef float md_v16f __attribute__((ext_vector_type(16)));
+static __shared__ int s_md_force_bfly;       /* debug (MdPictureDev.force_butterflies), set once per launch beside the operands below */
 static __shared__ uint32_t s_dct_op[10][64]; /* [0..1]: 16x16, [2 + 2 s .. 3 + 2 s]: 32x32 K-slice s; two dwords = four f16 */
-__device__ __forceinline__ void md_dct_operands_init()
+__device__ __forceinline__ void md_dct_operands_init(int force_butterflies)
 {
     const int t = threadIdx.x;
+    if (t == 64)
+        s_md_force_bfly = force_butterflies;
     if (t < 64) {
         union { md_v4h h; uint32_t w[2]; } u;
         for (int i = 0; i < 4; i++)
@@ -465,7 +470,7 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     bool on_matrix_cores = false;
     if constexpr (N == 16 || N == 32) {
         int co[N * N / 64];
-        on_matrix_cores = md_fwd_mfma<N>(lane, src, srcPitch, pred, predPitch, fs1, fs2, co); /* wave-uniform */
+        on_matrix_cores = !s_md_force_bfly && md_fwd_mfma<N>(lane, src, srcPitch, pred, predPitch, fs1, fs2, co); /* wave-uniform */
         if (on_matrix_cores) {
             MD_TR(52);
             const int k = lane & (N - 1);
@@ -1346,6 +1351,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 if ((cw0 & 0xFF) == MD_INTER) {
                     const int sl = (int)md_rl((uint32_t)slot, ci), n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
                     uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
+                    MD_TR(21);
                     md_predict_inter_plane(M.V.refs, (int)(cw2 & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0,
                                            tiled64 && luma ? 4 : 1, &M.V.rw);
                     MD_TR(22);
@@ -2882,7 +2888,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
     for (int i = threadIdx.x; i < (int)(sizeof(MdPictureDev) / 8); i += 256)
         reinterpret_cast<unsigned long long *>(&s_D)[i] = reinterpret_cast<const unsigned long long *>(Dp)[i];
     __syncthreads();
-    md_dct_operands_init();
+    md_dct_operands_init(Dp->force_butterflies);
     const MdPictureDev &D = s_D;
     const SvtAmdMdPicture &P = *D.P;
     for (;;) {
@@ -3002,6 +3008,7 @@ struct SvtAmdMdState {
     unsigned long long *d_prof;
     unsigned long long *d_trace;
     int trace_lcu, trace_unit;
+    int force_butterflies;
     unsigned *d_md_done;           /* epoch of the call whose mode decision finished the LCU */
     unsigned *d_md_ticket;         /* the mode-decision kernel's ticket counter (the encode pass behind it draws from the picture object's own) */
     MdPictureDev *d_D;             /* the descriptor the kernel reads (d, copied per call) */
@@ -3144,9 +3151,11 @@ static int msb_view(hipStream_t st, const void *in16, uint8_t *out8, size_t samp
 namespace {
 std::mutex g_flight_mu;
 std::condition_variable g_flight_cv;
-int g_flights, g_flight_wgs;
+/* per DEVICE: a process with contexts on several GPUs must not charge device B's launches against device A's compute units */
+struct FlightDevice { int flights = 0, wgs = 0, cus = 0; };
+FlightDevice g_flight_dev[64];
 unsigned long long g_flight_ticket;
-struct FlightWaiter { int prio; unsigned long long ticket; };
+struct FlightWaiter { int prio; unsigned long long ticket; int device; };
 std::vector<FlightWaiter> g_flight_wait;
 int md_forced_count_limit()
 {
@@ -3155,12 +3164,16 @@ int md_forced_count_limit()
 }
 int md_wg_budget(int device)
 {
-    static int cus[64];
-    if (!cus[device & 63]) {
-        hipDeviceProp_t pr;
-        cus[device & 63] = hipGetDeviceProperties(&pr, device) == hipSuccess ? pr.multiProcessorCount : 256;
+    int c;
+    {
+        std::lock_guard<std::mutex> l(g_flight_mu);
+        FlightDevice &fd = g_flight_dev[device & 63];
+        if (!fd.cus) {
+            hipDeviceProp_t pr;
+            fd.cus = hipGetDeviceProperties(&pr, device) == hipSuccess ? pr.multiProcessorCount : 256;
+        }
+        c = fd.cus;
     }
-    const int c = cus[device & 63];
     static const int forced = getenv("SVT_AMD_MD_WG_BUDGET") ? atoi(getenv("SVT_AMD_MD_WG_BUDGET")) : 0; /* measurement */
     return forced > 0 ? forced : c - c / 16;
 }
@@ -3185,34 +3198,42 @@ double flight_now_us()
 }
 struct MdFlight {
     int held = 0; /* workgroups this call holds */
+    int dev = 0;
     double t_granted = 0;
     /* waits until the launch fits; returns the grid granted: `wide` when the device is nearly idle, `narrow` otherwise */
-    int acquire(int budget, int wide, int narrow, int prio)
+    int acquire(int device, int budget, int wide, int narrow, int prio)
     {
         const double t0 = flight_now_us();
+        dev = device & 63;
         std::unique_lock<std::mutex> l(g_flight_mu);
-        const FlightWaiter me = {prio, g_flight_ticket++};
+        FlightDevice &fd = g_flight_dev[dev];
+        const FlightWaiter me = {prio, g_flight_ticket++, dev};
         g_flight_wait.push_back(me);
         const int count_limit = md_forced_count_limit();
         int grant = 0;
         g_flight_cv.wait(l, [&] {
-            for (const FlightWaiter &w : g_flight_wait)
+            int waiting_here = 0;
+            for (const FlightWaiter &w : g_flight_wait) {
+                if (w.device != dev)
+                    continue;
+                waiting_here++;
                 if (w.prio < me.prio || (w.prio == me.prio && w.ticket < me.ticket))
                     return false;
+            }
             if (count_limit > 0) {
                 grant = wide;
-                return g_flights < count_limit;
+                return fd.flights < count_limit;
             }
-            grant = (g_flight_wait.size() == 1 && g_flight_wgs + wide <= budget / 3) ? wide : narrow;
-            return g_flight_wgs + grant <= budget || g_flights == 0;
+            grant = (waiting_here == 1 && fd.wgs + wide <= budget / 3) ? wide : narrow;
+            return fd.wgs + grant <= budget || fd.flights == 0;
         });
         for (size_t i = 0; i < g_flight_wait.size(); i++)
             if (g_flight_wait[i].ticket == me.ticket) {
                 g_flight_wait.erase(g_flight_wait.begin() + (long)i);
                 break;
             }
-        g_flight_stats.calls++, g_flight_stats.wide += grant == wide && wide != narrow, g_flight_stats.wgs_seen += (unsigned long long)g_flight_wgs;
-        g_flights++, g_flight_wgs += grant, held = grant;
+        g_flight_stats.calls++, g_flight_stats.wide += grant == wide && wide != narrow, g_flight_stats.wgs_seen += (unsigned long long)fd.wgs;
+        fd.flights++, fd.wgs += grant, held = grant;
         l.unlock();
         t_granted = flight_now_us();
         g_flight_stats.wait_us += (unsigned long long)(t_granted - t0);
@@ -3226,7 +3247,7 @@ struct MdFlight {
         g_flight_stats.run_us += (unsigned long long)(flight_now_us() - t_granted);
         {
             std::lock_guard<std::mutex> l(g_flight_mu);
-            g_flights--, g_flight_wgs -= held;
+            g_flight_dev[dev].flights--, g_flight_dev[dev].wgs -= held;
         }
         held = 0;
         g_flight_cv.notify_all();
@@ -3450,6 +3471,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     }
     m->d.prof = m->d_prof, m->d.prof_lcus = n;
     m->d.trace = m->d_trace, m->d.trace_lcu = m->trace_lcu, m->d.trace_unit = m->trace_unit;
+    m->d.force_butterflies = m->force_butterflies;
     m->d.encode = !X || works || results; /* P / B pictures: without a place for the work / result records, the mode decision alone */
     if (ois)
         HIP_TRY(hipMemcpyAsync(m->d_ois, ois, sizeof(SvtAmdOisLcuResult) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -3485,6 +3507,9 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
         static const int fnarrow = getenv("SVT_AMD_MD_NARROW") ? atoi(getenv("SVT_AMD_MD_NARROW")) : 0;
         if (fnarrow > 0)
             narrow = fnarrow;
+        static const int fwide = getenv("SVT_AMD_MD_WIDE") ? atoi(getenv("SVT_AMD_MD_WIDE")) : 0;
+        if (fwide > 0)
+            grid = fwide;
     }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
     narrow = narrow > grid ? grid : narrow;
@@ -3495,7 +3520,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     MdFlight flight;
     /* the inputs first (a call that waits for its place holds no CU and no copy engine meanwhile) */
     HIP_TRY(hipStreamSynchronize(st));
-    grid = flight.acquire(md_wg_budget(ctx->device), grid, narrow, (int)P->temporal_layer);
+    grid = flight.acquire(ctx->device, md_wg_budget(ctx->device), grid, narrow, (int)P->temporal_layer);
     m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X && bps == 1)
@@ -3645,10 +3670,13 @@ extern "C" int svt_amd_debug_md_ep_ms(SvtAmdContext *ctx, SvtAmdEncDecPicture *p
 extern "C" int svt_amd_debug_md_flights(int *in_flight, int *workgroups_held, int *waiting)
 {
     std::lock_guard<std::mutex> l(g_flight_mu);
+    int fl = 0, wg = 0;
+    for (const FlightDevice &fd : g_flight_dev)
+        fl += fd.flights, wg += fd.wgs;
     if (in_flight)
-        *in_flight = g_flights;
+        *in_flight = fl;
     if (workgroups_held)
-        *workgroups_held = g_flight_wgs;
+        *workgroups_held = wg;
     if (waiting)
         *waiting = (int)g_flight_wait.size();
     return SVT_AMD_OK;
@@ -3699,6 +3727,21 @@ extern "C" int svt_amd_debug_md_trace(SvtAmdContext *ctx, SvtAmdEncDecPicture *p
     (void)ctx, (void)pic, (void)lcu, (void)unit, (void)out;
     return SVT_AMD_ERR_BAD_PARAM;
 #endif
+}
+
+/* debug: the picture object's later mode-decision calls run the 16x16 / 32x32 forward transforms of the full loops on the register butterflies (on != 0) instead of the
+ * matrix cores - the path a unit outside the matrix form's wrap-free domain takes, which no 8-bit picture reaches by itself */
+extern "C" int svt_amd_debug_md_force_butterflies(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, int on)
+{
+    if (!ctx || !pic)
+        return SVT_AMD_ERR_BAD_PARAM;
+    HIP_TRY(hipSetDevice(ctx->device));
+    SvtAmdMdState *m = nullptr;
+    const int rc = md_state(pic, &m);
+    if (rc)
+        return rc;
+    m->force_butterflies = on != 0;
+    return SVT_AMD_OK;
 }
 
 /* debug: the stage and sub-stage sums by the depth of the unit they were spent on: [LCU][depth 0..3][32] (slots 0..15 as svt_amd_debug_md_profile, 16..31 as _sub) */

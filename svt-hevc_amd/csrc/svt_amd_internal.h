@@ -41,7 +41,11 @@ struct DevPicture {
                                     * records where they are) waits on them */
     uint32_t me_lcus, ois_lcus;    /* LCUs of the picture whose records the buffers hold (0: none yet, or only a part of the picture: every upload into the slot resets
                                     * them; read / written across host threads with acquire / release) */
-    uint32_t me_lo, me_hi;         /* LCU range [lo, hi) of the slot's CURRENT picture that range launches have covered so far: me_lcus is set when it is the whole picture */
+    /* which LCUs of the slot's CURRENT picture the range launches since the last upload have covered - a bit per LCU (8K: 8,160), so bands may arrive in any order and
+     * from several lanes (me_cov_lock); me_lcus is set when every LCU is covered */
+    uint64_t me_cov[128];
+    uint32_t me_cov_count;
+    int me_cov_lock;
     hipEvent_t ev_md_read;         /* recorded behind a mode-decision kernel that reads d_me_out / d_ois_out in place: the next ME / OIS launch INTO the slot waits for it */
     int md_read_pending;
     uint16_t width, height;

@@ -53,7 +53,10 @@ def _encode(app, yuv, w, h, n, args, out):
     r = subprocess.run([app, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-b", out] +
                        ([] if "-asm" in args else ["-asm", "1"]) + ([] if "-q" in args else ["-q", "32"]) + args, capture_output=True, text=True,
                        timeout=120 if w * h * n <= 1920 * 1080 * 8 else 400,   # seconds: a wedged encoder must not eat the GPU session (the largest cases take < 60 s)
-                       env=dict(os.environ, SVT_HOOK_VERBOSE="1"))
+                       # the product's default is the CLOSED LOOP on the device (svt_hook_cfg: SVT_HOOK_MD=pb, pool 16, 12 + 4 lanes).  The cases of this file that
+                       # prove ONE binding at a time (front half, per-candidate full loops, reconstruction, prediction, SAO ...) switch it off unless they ask for it
+                       # themselves; the closed-loop cases below run with the defaults - the configuration bench.py measures
+                       env=dict({"SVT_HOOK_MD": "off"}, **dict(os.environ, SVT_HOOK_VERBOSE="1")))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), r.stderr
 
@@ -93,9 +96,15 @@ def test_bitstream_identical_with_gpu_me(tmp_path, kind, w, h, n, args):
         nl = S.lcu_count(w, h)
         assert (me_n, me_bad, ois_n, ois_bad) == ((n - 1) * nl, 0, n * nl, 0), m.group(0)
         if hip_md5 != ref_md5:
-            print("RC_TIMING: bitstreams differ under rate control (reference %s, hooked %s) with all %d + %d front-half answers equal to the reference code's" %
-                  (ref_md5, hip_md5, me_n, ois_n))
-            ref_md5 = hip_md5
+            # the md5 gate stays HARD unless the unmodified reference disagrees with ITSELF on this box (a reference-vs-reference control): five more reference
+            # encodes of the same clip; the hooked bitstream must be one the reference produced, or the reference must have produced more than one - and then the case is
+            # reported as an expected failure with both sets, never as a pass
+            ref_set = {ref_md5} | {_encode(S.REF_APP, yuv, w, h, n, args, str(tmp_path / ("ref%d.265" % k)))[0] for k in range(5)}
+            print("RC_TIMING: reference bitstreams %s, hooked %s (all %d + %d front-half answers equal to the reference code's)" % (sorted(ref_set), hip_md5, me_n, ois_n))
+            if hip_md5 not in ref_set:
+                assert len(ref_set) > 1, "bitstream differs from a reference that is deterministic here (%s vs %s)" % (hip_md5, ref_md5)
+                pytest.xfail("rate-controlled encode: the unmodified reference produced %d different bitstreams in 6 runs on this box; the hooked one is a further one" % len(ref_set))
+            hip_md5 = ref_md5 = next(iter(ref_set & {hip_md5}))
     # every MotionEstimateLcu call is redirected at link time (--wrap); the hook announces itself
     assert "svt_hook_me: motion estimation on svt-hevc_amd" in log, "hook inactive:\n" + log[-1000:]
     # one device OIS call per picture; ME for every non-intra picture
@@ -606,10 +615,31 @@ def test_baseline_config1_with_the_device_closed_loop_on_is_bitstream_identical(
     assert r["bitstream_identical"], rep
 
 
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_baseline_config2_with_the_library_defaults_is_bitstream_identical(tmp_path, cfg):
+    """What a host gets by LOADING the drop-in library and nothing else (no SVT_HOOK_* switch in the environment): the configuration bench.py measures - closed loop of the
+    P / B pictures on the device (SVT_HOOK_MD=pb), 16 picture control sets in the EncDec pool, 12 EncDec + 4 front-half lanes - at BASELINE configs[2] / [3], 33 pictures
+    at the bench's -lp 32: bitstream identical, 24 of 33 pictures (every layer-1 and layer-2 B picture) decided and encoded by the device call, the I picture and the
+    8 base-layer B pictures by the reference's code."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(S.ROOT, "tools"))
+    import encoder_fps as E
+    rp = str(tmp_path / "report.txt")
+    assert not [k for k in os.environ if k.startswith("SVT_HOOK_")], "this case runs the library's defaults"
+    r = E.measure(cfg, frames=33, extra=["-lp", "32"], hip_env={"SVT_HOOK_REPORT": rp}, tmpdir=str(tmp_path))
+    rep = open(rp).read()
+    m = re.search(r"mode decision: (\d+) pictures \((\d+) of them P / B; (\d+) LCUs\).*?; (\d+) pictures outside", rep)
+    assert m, rep
+    pics, inter, lcus, left = (int(v) for v in m.groups())
+    assert (pics, inter, left) == (24, 24, 8) and lcus == pics * S.lcu_count(3840, 2160), rep   # left: the 8 base-layer B pictures (the I picture is not offered to the device call at SVT_HOOK_MD=pb)
+    assert r["bitstream_identical"], rep
+
+
 def _encode_with_report(tmp_path, yuv, w, h, n, args, env):
     rep = str(tmp_path / "report.txt")
     r = subprocess.run([HIP_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-n", str(n), "-b", str(tmp_path / "hip.265"), "-asm", "1", "-q", "32"] + args,
-                       capture_output=True, text=True, timeout=300, env=dict(os.environ, SVT_HOOK_REPORT=rep, **env))
+                       capture_output=True, text=True, timeout=300, env=dict({"SVT_HOOK_MD": "off"}, **dict(os.environ, SVT_HOOK_REPORT=rep, **env)))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return hashlib.md5(open(str(tmp_path / "hip.265"), "rb").read()).hexdigest(), open(rep).read()
 

@@ -148,6 +148,31 @@ def test_md_of_p_and_b_pictures_matches_the_reference(product, name):
         lib.svt_amd_context_destroy(ctx)
 
 
+@pytest.mark.parametrize("name", [c for c in INTER_CASES if c.startswith(("b_motion", "bref_motion", "p_"))][:4])
+def test_md_of_p_and_b_pictures_with_the_transforms_on_the_register_butterflies(product, name):
+    """the full loops' 16x16 / 32x32 forward transforms run on the matrix cores (exact f16 x f16 -> f32 integer products) and fall back to the register butterflies for a
+    unit outside the Estimate butterflies' wrap-free domain - which no fixture reaches by itself.  svt_amd_debug_md_force_butterflies sends EVERY unit down that path: the
+    decisions must be the reference's both ways (so the two transform forms agree with each other on every unit of the fixtures)"""
+    lib = product
+    sig(lib)
+    lib.svt_amd_debug_md_force_butterflies.restype = C.c_int
+    lib.svt_amd_debug_md_force_butterflies.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    g = np.load(os.path.join(S.GOLDEN_DIR, "md_%s.npz" % name))
+    w, h = int(g["pic"][0]["width"]), int(g["pic"][0]["height"])
+    ctx, pic = C.c_void_p(), C.c_void_p()
+    assert lib.svt_amd_context_create(0, w, (h + 7) & ~7, 2, C.byref(ctx)) == 0, lib.svt_amd_last_error()
+    try:
+        assert lib.svt_amd_encdec_picture_create(ctx, w, h, 1, C.byref(pic)) == 0, lib.svt_amd_last_error()
+        for on in (1, 0):
+            assert lib.svt_amd_debug_md_force_butterflies(ctx, pic, on) == 0, lib.svt_amd_last_error()
+            for k in range(len(g["picture_number"])):
+                out, _, _ = md_encode_inter(lib, ctx, pic, g, k)
+                compare_md(out, g["out"][k], "%s picture %d, butterflies forced: %d" % (name, int(g["picture_number"][k]), on))
+        lib.svt_amd_encdec_picture_destroy(ctx, pic)
+    finally:
+        lib.svt_amd_context_destroy(ctx)
+
+
 @pytest.mark.parametrize("name", INTER_CASES)
 def test_md_and_encode_pass_of_p_and_b_pictures_in_one_call(product, oracle, name):
     """the same call with the encode pass behind the decisions: the work records (final tree, vectors, and for merge units the merge / skip decision

@@ -136,8 +136,11 @@ def run_inter(lib, g, reps=3, encode=True, check=True, profile=None):
         lib.svt_amd_debug_md_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         assert lib.svt_amd_debug_md_profile(ctx, pic, None) == 0
     lib.svt_amd_debug_md_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    ts, tested, units, kms = [], 0, 0, [[] for _ in g["picture_number"]]
+    ts, tested, units, kms, eps = [], 0, 0, [[] for _ in g["picture_number"]], [[] for _ in g["picture_number"]]
     wgs = C.c_int(0)
+    has_ep = hasattr(lib, "svt_amd_debug_md_ep_ms")
+    if has_ep:
+        lib.svt_amd_debug_md_ep_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     for k in range(len(g["picture_number"])):
         for rep in range(reps):
             t0 = time.perf_counter()
@@ -147,6 +150,10 @@ def run_inter(lib, g, reps=3, encode=True, check=True, profile=None):
                 ms = C.c_float(0)
                 assert lib.svt_amd_debug_md_kernel_ms(ctx, pic, C.byref(ms), C.byref(wgs)) == 0, lib.svt_amd_last_error()
                 kms[k].append(float(ms.value))
+                if has_ep and encode:
+                    e = C.c_float(0)
+                    assert lib.svt_amd_debug_md_ep_ms(ctx, pic, C.byref(e)) == 0, lib.svt_amd_last_error()
+                    eps[k].append(float(e.value))
         if check:
             compare_md(out, g["out"][k], "%dx%d picture %d" % (w, h, int(g["picture_number"][k])))
         tested += int(g["out"][k]["tested"].sum())
@@ -170,8 +177,9 @@ def run_inter(lib, g, reps=3, encode=True, check=True, profile=None):
     lib.svt_amd_context_destroy(ctx)
     per_pic = [{"picture": int(p), "temporal_layer": int(g["pic"][k]["temporal_layer"]), "is_reference": int(g["pic"][k]["is_reference"]),
                 "chroma_level": int(g["pic"][k]["chroma_level"]), "kernel_ms": round(float(np.median(kms[k])), 3) if kms[k] else None,
+                "encode_pass_kernel_ms": round(float(np.median(eps[k])), 3) if eps[k] else None,
                 "leaves_tested": int(g["out"][k]["tested"].sum())} for k, p in enumerate(g["picture_number"])]
-    return {"kernel": {"name": "k_md_encode_picture<true>", "workgroups": int(wgs.value), "ms_by_hip_events": per_pic},
+    return {"kernel": {"name": "k_md_picture<true> (+ k_encode_picture behind it on the same stream)", "workgroups": int(wgs.value), "ms_by_hip_events": per_pic},
             "stage_clocks_per_lcu": stages, "width": w, "height": h, "lcus": n, "pictures": [int(p) for p in g["picture_number"]], "leaves_tested_per_picture": tested // len(ts) * (reps - 1) if ts else 0,
             "final_units": units, "ms_per_picture_incl_host_copies": round(float(np.median(ts)), 2),
             "what": "svt_amd_md_encode_picture_inter (mode decision%s) of the recorded B pictures through the host-array ABI incl. reference-picture upload by the test; "

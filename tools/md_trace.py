@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import svtlib as S
 from test_gpu_md import md_encode_inter, sig
 
-N = 128
+N = 120
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 unit = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 g = dict(np.load(os.environ.get("MD_CHAIN_FX", os.path.join(ROOT, "tools", "_fx", "md4k.npz"))))
