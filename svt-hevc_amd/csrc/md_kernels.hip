@@ -903,91 +903,103 @@ __device__ __forceinline__ bool md_temporal_mvp_dev(const SvtAmdMdInter &X, cons
     *out = v;
     return true;
 }
-/* the AMVP candidates of list `list` (a per-lane value): GetSpatialMVPPosAx_V3 / GetNonScalingSpatialMVPPosBx_V3 / GetScalingSpatialMVPPosBx_V3 + the temporal candidate + the
- * zero fill -> c[0..1], count */
-__device__ __forceinline__ int md_amvp_one_list(const MdListConsts &K, const SvtAmdMdInter &X, const MdMvUnit (&nb)[5], const SvtAmdTmvpLcu *map, MdTmvpPos tp, int list, MdMv c[3])
+/* A neighbour's motion as THREE PACKED WORDS (mv[0], mv[1]: x | y << 16; dir | avail << 8) and the lists as words too: every selection below is a select between VALUES.
+ * (With MdMvUnit records, `scaled(A0.avail ? A0 : A1)` and `i == 0 ? m[0] : m[1]` are selects between ADDRESSES - the compiler then keeps the records in the private segment:
+ * 15 scratch stores per unit and list-building wave and memory-latency loads behind them, 130 MB of HBM writes per 4K picture, profiles/r06_aa.) */
+/* ... as fifteen VALUE parameters (an aggregate, however it is indexed, invites the optimiser to turn `b0 ? m0[B0] : m0[B1]` back into a load from a selected address) */
+#define MD_NB_PARAMS uint32_t A0m0, uint32_t A0m1, uint32_t A0da, uint32_t A1m0, uint32_t A1m1, uint32_t A1da, uint32_t B0m0, uint32_t B0m1, uint32_t B0da, \
+                     uint32_t B1m0, uint32_t B1m1, uint32_t B1da, uint32_t B2m0, uint32_t B2m1, uint32_t B2da
+#define MD_NB_ARGS(w0, w1, w2) md_rl(w0, MD_A0), md_rl(w1, MD_A0), md_rl(w2, MD_A0), md_rl(w0, MD_A1), md_rl(w1, MD_A1), md_rl(w2, MD_A1), md_rl(w0, MD_B0), md_rl(w1, MD_B0), \
+                               md_rl(w2, MD_B0), md_rl(w0, MD_B1), md_rl(w1, MD_B1), md_rl(w2, MD_B1), md_rl(w0, MD_B2), md_rl(w1, MD_B2), md_rl(w2, MD_B2)
+__device__ __forceinline__ MdMv md_unpack_mv(uint32_t w)
 {
+    MdMv v;
+    v.x = (int16_t)(w & 0xFFFF), v.y = (int16_t)(w >> 16);
+    return v;
+}
+/* the AMVP candidates of list `list` (a per-lane value): GetSpatialMVPPosAx_V3 / GetNonScalingSpatialMVPPosBx_V3 / GetScalingSpatialMVPPosBx_V3 + the temporal candidate + the
+ * zero fill -> c0, c1 (packed), count */
+__device__ __forceinline__ int md_amvp_one_list(const MdListConsts &K, const SvtAmdMdInter &X, MD_NB_PARAMS, const SvtAmdTmvpLcu *map, MdTmvpPos tp, int list, uint32_t *c0o, uint32_t *c1o)
+{
+    const int need = list ? K.need[1] : K.need[0], scale = list ? K.scale[1] : K.scale[0];
     /* non-scaling: the neighbour's vector that points to list `list`'s picture */
-    auto nonscale = [&](const MdMvUnit &u, MdMv *out) -> bool {
-        if (u.dir == MD_BI) {
-            *out = u.mv[0];
-            if (list)
-                *out = u.mv[1];
+    auto nonscale = [&](uint32_t m0, uint32_t m1, uint32_t da, uint32_t *out) -> bool {
+        const int dir = (int)(da & 0xFF);
+        if (dir == MD_BI) {
+            *out = list ? m1 : m0;
             return true;
         }
-        const bool ok = u.dir == list || K.same01;
+        const bool ok = dir == list || K.same01;
         if (ok)
-            *out = u.dir ? u.mv[1] : u.mv[0];
+            *out = dir ? m1 : m0;
         return ok;
     };
     /* scaling: always available */
-    auto scaled = [&](const MdMvUnit &u) -> MdMv {
-        const int l2 = u.dir == MD_BI ? list : u.dir;
-        MdMv v = l2 ? u.mv[1] : u.mv[0];
-        if (l2 != list && K.need[list ? 1 : 0])
-            v = md_scale_by(v, list ? K.scale[1] : K.scale[0]);
+    auto scaled = [&](uint32_t m0, uint32_t m1, uint32_t da) -> uint32_t {
+        const int dir = (int)(da & 0xFF), l2 = dir == MD_BI ? list : dir;
+        uint32_t v = l2 ? m1 : m0;
+        if (l2 != list && need)
+            v = md_pack_mv(md_scale_by(md_unpack_mv(v), scale));
         return v;
     };
-    const MdMvUnit &A0 = nb[MD_A0], &A1 = nb[MD_A1], &B0 = nb[MD_B0], &B1 = nb[MD_B1], &B2 = nb[MD_B2];
-    MdMv zero;
-    zero.x = zero.y = 0;
-    c[0] = c[1] = c[2] = zero;
+    const bool a0 = (A0da >> 8) & 1, a1 = (A1da >> 8) & 1, b0 = (B0da >> 8) & 1, b1 = (B1da >> 8) & 1, b2 = (B2da >> 8) & 1;
+    uint32_t c0 = 0, c1 = 0;
     int num = 0;
     bool ax = false;
-    MdMv v = zero;
-    if (A0.avail)
-        ax = nonscale(A0, &v);
-    if (!ax && A1.avail)
-        ax = nonscale(A1, &v);
-    if (!ax && (A0.avail || A1.avail))
-        v = scaled(A0.avail ? A0 : A1), ax = true;
+    uint32_t v = 0;
+    if (a0)
+        ax = nonscale(A0m0, A0m1, A0da, &v);
+    if (!ax && a1)
+        ax = nonscale(A1m0, A1m1, A1da, &v);
+    if (!ax && (a0 || a1))
+        v = scaled(a0 ? A0m0 : A1m0, a0 ? A0m1 : A1m1, a0 ? A0da : A1da), ax = true;
     if (ax)
-        c[0] = v, num = 1;
+        c0 = v, num = 1;
     bool bx = false;
-    MdMv vb = zero;
-    if (B0.avail)
-        bx = nonscale(B0, &vb);
-    if (!bx && B1.avail)
-        bx = nonscale(B1, &vb);
-    if (!bx && B2.avail)
-        bx = nonscale(B2, &vb);
+    uint32_t vb = 0;
+    if (b0)
+        bx = nonscale(B0m0, B0m1, B0da, &vb);
+    if (!bx && b1)
+        bx = nonscale(B1m0, B1m1, B1da, &vb);
+    if (!bx && b2)
+        bx = nonscale(B2m0, B2m1, B2da, &vb);
     /* (a vector a failed test left behind is overwritten or never counted, exactly as in the reference's array) */
     if (bx) {
         if (num == 0)
-            c[0] = vb;
+            c0 = vb;
         else
-            c[1] = vb;
+            c1 = vb;
         num++;
     }
-    if (!ax && (B0.avail || B1.avail || B2.avail)) {
-        const MdMv vs = scaled(B0.avail ? B0 : (B1.avail ? B1 : B2));
+    if (!ax && (b0 || b1 || b2)) { /* (ax false: no A neighbour, so at most one candidate so far) */
+        const uint32_t vs = scaled(b0 ? B0m0 : b1 ? B1m0 : B2m0, b0 ? B0m1 : b1 ? B1m1 : B2m1,
+                                   b0 ? B0da : b1 ? B1da : B2da);
         if (num == 0)
-            c[0] = vs;
-        else if (num == 1)
-            c[1] = vs;
+            c0 = vs;
         else
-            c[2] = vs;
+            c1 = vs;
         num++;
     }
-    if (num == 2 && c[0].x == c[1].x && c[0].y == c[1].y)
+    if (num == 2 && c0 == c1)
         num = 1;
     if (map && num < 2) {
         MdMv tv;
         if (md_temporal_mvp_dev(X, map, tp, list, &tv)) {
             if (num == 0)
-                c[0] = tv;
+                c0 = md_pack_mv(tv);
             else
-                c[1] = tv;
+                c1 = md_pack_mv(tv);
             num++;
         }
     }
-    if (num < 1 || (num == 1 && c[0].x != 0 && c[0].y != 0)) {
+    if (num < 1 || (num == 1 && (c0 & 0xFFFF) != 0 && (c0 >> 16) != 0)) {
         if (num == 0)
-            c[0] = zero;
+            c0 = 0;
         else
-            c[1] = zero;
+            c1 = 0;
         num++;
     }
+    *c0o = c0, *c1o = c1;
     return num;
 }
 /* ChooseMVPIdx_V2 for one list (md_choose_mvp, md_logic.h): clips the candidate's vector of that list, picks the nearer predictor */
@@ -1003,68 +1015,63 @@ __device__ __forceinline__ void md_choose_mvp_one(const SvtAmdMdPicture &P, uint
     }
     *idxOut = (uint8_t)idx, *mvp = idx ? a[1] : a[0];
 }
-/* the merge candidates (md_amvp_merge_lists_parts part 4, :2649-2990): m[0..4], always totalMerge of them (the zero vectors fill the list).  t0 / t1 / tok: the temporal
- * candidate's two vectors and whether list 0's exists (derived by the caller, a lane per list) */
-__device__ __forceinline__ void md_merge_list_regs(const MdListConsts &K, const MdMvUnit (&nb)[5], bool have_map, bool tok, MdMv t0, MdMv t1, int totalMerge, MdMergeCand m[5])
+/* the merge candidates (md_amvp_merge_lists_parts part 4, :2649-2990) as packed words g0[k] / g1[k] / gd[k] (mv[0], mv[1], dir), always totalMerge of them (the zero vectors
+ * fill the list).  t0 / t1 / tok: the temporal candidate's two vectors (packed) and whether list 0's exists (derived by the caller, a lane per list) */
+struct MdMerge5 {
+    uint32_t g0[5], g1[5], gd[5];
+};
+__device__ __forceinline__ void md_merge_list_regs(const MdListConsts &K, MD_NB_PARAMS, bool have_map, bool tok, uint32_t t0, uint32_t t1, int totalMerge, MdMerge5 &m)
 {
     const int bslice = K.bslice;
-    const MdMvUnit &A0 = nb[MD_A0], &A1 = nb[MD_A1], &B0 = nb[MD_B0], &B1 = nb[MD_B1], &B2 = nb[MD_B2];
     int idx = 0;
-    auto add = [&](int dir, MdMv v0, MdMv v1) {
-        MdMergeCand e;
-        e.mv[0] = v0, e.mv[1] = v1, e.dir = (uint8_t)dir, e.pad[0] = e.pad[1] = e.pad[2] = 0;
+    auto add = [&](uint32_t dir, uint32_t v0, uint32_t v1) {
         if (idx < totalMerge) { /* (the reference leaves its loop as soon as the list is full) */
-            if (idx == 0)
-                m[0] = e;
-            else if (idx == 1)
-                m[1] = e;
-            else if (idx == 2)
-                m[2] = e;
-            else if (idx == 3)
-                m[3] = e;
-            else
-                m[4] = e;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (idx == k)
+                    m.g0[k] = v0, m.g1[k] = v1, m.gd[k] = dir;
         }
         idx++;
     };
-    auto differs = [&](const MdMvUnit &a, const MdMvUnit &b) { return md_mv_differs(&a, &b, bslice) != 0; };
+    auto differs = [&](uint32_t am0, uint32_t am1, uint32_t ada, uint32_t bm0, uint32_t bm1, uint32_t bda) { /* md_mv_differs */
+        if (!bslice)
+            return am0 != bm0;
+        return (ada & 0xFF) != (bda & 0xFF) || am0 != bm0 || am1 != bm1;
+    };
+    auto dirof = [&](uint32_t da) { return bslice ? (da & 0xFFu) : (uint32_t)MD_L0; };
+    const bool a0 = (A0da >> 8) & 1, a1 = (A1da >> 8) & 1, b0 = (B0da >> 8) & 1, b1 = (B1da >> 8) & 1, b2 = (B2da >> 8) & 1;
+#pragma unroll
     for (int k = 0; k < 5; k++)
-        m[k].mv[0].x = m[k].mv[0].y = m[k].mv[1].x = m[k].mv[1].y = 0, m[k].dir = 0, m[k].pad[0] = m[k].pad[1] = m[k].pad[2] = 0;
-    if (A1.avail)
-        add(bslice ? A1.dir : MD_L0, A1.mv[0], A1.mv[1]);
-    if (idx < totalMerge && B1.avail && (!A1.avail || differs(B1, A1)))
-        add(bslice ? B1.dir : MD_L0, B1.mv[0], B1.mv[1]);
-    if (idx < totalMerge && B0.avail && (!B1.avail || differs(B0, B1)))
-        add(bslice ? B0.dir : MD_L0, B0.mv[0], B0.mv[1]);
-    if (idx < totalMerge && A0.avail && (!A1.avail || differs(A0, A1)))
-        add(bslice ? A0.dir : MD_L0, A0.mv[0], A0.mv[1]);
-    if (idx < totalMerge && idx < 4 && B2.avail && (!A1.avail || differs(B2, A1)) && (!B1.avail || differs(B2, B1)))
-        add(bslice ? B2.dir : MD_L0, B2.mv[0], B2.mv[1]);
+        m.g0[k] = m.g1[k] = m.gd[k] = 0;
+    if (a1)
+        add(dirof(A1da), A1m0, A1m1);
+    if (idx < totalMerge && b1 && (!a1 || differs(B1m0, B1m1, B1da, A1m0, A1m1, A1da)))
+        add(dirof(B1da), B1m0, B1m1);
+    if (idx < totalMerge && b0 && (!b1 || differs(B0m0, B0m1, B0da, B1m0, B1m1, B1da)))
+        add(dirof(B0da), B0m0, B0m1);
+    if (idx < totalMerge && a0 && (!a1 || differs(A0m0, A0m1, A0da, A1m0, A1m1, A1da)))
+        add(dirof(A0da), A0m0, A0m1);
+    if (idx < totalMerge && idx < 4 && b2 && (!a1 || differs(B2m0, B2m1, B2da, A1m0, A1m1, A1da)) && (!b1 || differs(B2m0, B2m1, B2da, B1m0, B1m1, B1da)))
+        add(dirof(B2da), B2m0, B2m1);
     if (idx < totalMerge && have_map && tok) {
-        MdMv z;
-        z.x = z.y = 0;
         if (bslice)
             add(MD_BI, t0, t1);
         else if (idx < 5)
-            add(MD_L0, t0, z);
+            add(MD_L0, t0, 0u);
     }
     if (idx < totalMerge && bslice) { /* combined bi-predictive candidates: mvMergeCandIndexArrayForFillingUp (:20-23) */
         const int loopEnd = idx * (idx - 1);
-        auto at = [&](int i) -> MdMergeCand { return i == 0 ? m[0] : i == 1 ? m[1] : i == 2 ? m[2] : m[3]; };
         for (int f = 0; idx < totalMerge && f < loopEnd; f++) {
             const int i0 = f == 0 ? 0 : f == 1 ? 1 : f == 2 ? 0 : f == 3 ? 2 : f == 4 ? 1 : f == 5 ? 2 : f == 6 ? 0 : f == 7 ? 3 : f == 8 ? 1 : f == 9 ? 3 : f == 10 ? 2 : 3;
             const int i1 = f == 0 ? 1 : f == 1 ? 0 : f == 2 ? 2 : f == 3 ? 0 : f == 4 ? 2 : f == 5 ? 1 : f == 6 ? 3 : f == 7 ? 0 : f == 8 ? 3 : f == 9 ? 1 : f == 10 ? 3 : 2;
-            const MdMergeCand c0 = at(i0), c1 = at(i1);
-            if (((c0.dir + 1) & 1) && ((c1.dir + 1) & 2) && (!K.same01 || c0.mv[0].x != c1.mv[1].x || c0.mv[0].y != c1.mv[1].y))
-                add(MD_BI, c0.mv[0], c1.mv[1]);
+            const uint32_t c0d = i0 == 0 ? m.gd[0] : i0 == 1 ? m.gd[1] : i0 == 2 ? m.gd[2] : m.gd[3], c0v = i0 == 0 ? m.g0[0] : i0 == 1 ? m.g0[1] : i0 == 2 ? m.g0[2] : m.g0[3];
+            const uint32_t c1d = i1 == 0 ? m.gd[0] : i1 == 1 ? m.gd[1] : i1 == 2 ? m.gd[2] : m.gd[3], c1v = i1 == 0 ? m.g1[0] : i1 == 1 ? m.g1[1] : i1 == 2 ? m.g1[2] : m.g1[3];
+            if (((c0d + 1) & 1) && ((c1d + 1) & 2) && (!K.same01 || c0v != c1v))
+                add(MD_BI, c0v, c1v);
         }
     }
-    {
-        MdMv z;
-        z.x = z.y = 0;
-        for (int r = 0; r < 5 && idx < totalMerge; r++)
-            add(bslice ? MD_BI : MD_L0, z, z);
-    }
+    for (int r = 0; r < 5 && idx < totalMerge; r++) /* zero vectors */
+        add(bslice ? MD_BI : MD_L0, 0u, 0u);
 }
 
 /* ---- the unit loop of P / B pictures (round 6) ---------------------------------------------------------------------------------------------------------------------------
@@ -1164,13 +1171,6 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     w0 = q[0], w1 = q[1], w2 = (q[2] & 0xFFu) | 0x100u; /* mv[0], mv[1], dir | avail << 8 */
                 }
             }
-            MdMvUnit nbr[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const uint32_t a = md_rl(w0, k), b = md_rl(w1, k), c = md_rl(w2, k);
-                nbr[k].mv[0].x = (int16_t)(a & 0xFFFF), nbr[k].mv[0].y = (int16_t)(a >> 16), nbr[k].mv[1].x = (int16_t)(b & 0xFFFF), nbr[k].mv[1].y = (int16_t)(b >> 16);
-                nbr[k].dir = (uint8_t)(c & 0xFF), nbr[k].avail = (uint8_t)((c >> 8) & 1), nbr[k].pad[0] = nbr[k].pad[1] = 0;
-            }
             MD_TR(12);
             const SvtAmdTmvpLcu *map = tmvp_on ? M.V.tmvp : nullptr;
             MdTmvpPos tp;
@@ -1183,9 +1183,8 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             cw.w[0] = MD_INTER, cw.w[1] = cw.w[2] = cw.w[3] = cw.w[4] = cw.w[5] = cw.w[6] = cw.w[7] = 0;
             if (wave == 1) {
                 /* both AMVP lists side by side, then Me2Nx2NCandidatesInjection: a lane per motion-estimation candidate */
-                MdMv a[3];
-                const int num = md_amvp_one_list(K, M.V.X, nbr, map, tp, list, a);
-                const uint32_t pa0 = md_pack_mv(a[0]), pa1 = md_pack_mv(a[1]);
+                uint32_t pa0, pa1;
+                const int num = md_amvp_one_list(K, M.V.X, MD_NB_ARGS(w0, w1, w2), map, tp, list, &pa0, &pa1);
                 MD_TR(13);
                 const SvtAmdMeCuResult *me = &M.V.me[md_raster_index(&st)];
                 if (lane < 3 && lane < me->total_me_candidate_index) {
@@ -1202,7 +1201,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     MdMv al[3];
                     const uint32_t q0 = md_rl(pa0, l), q1 = md_rl(pa1, l);
                     const int cnt = (int)md_rl((uint32_t)num, l);
-                    al[0].x = (int16_t)(q0 & 0xFFFF), al[0].y = (int16_t)(q0 >> 16), al[1].x = (int16_t)(q1 & 0xFFFF), al[1].y = (int16_t)(q1 >> 16), al[2] = al[1];
+                    al[0] = md_unpack_mv(q0), al[1] = md_unpack_mv(q1), al[2] = al[1];
                     if (keep && (cw.c.dir == MD_BI || cw.c.dir == l))
                         md_choose_mvp_one(Ph, (uint32_t)x0, (uint32_t)y0, al, cnt, &cw.c.mv[l], &cw.c.mvp_idx[l], &cw.c.mvp[l]);
                 }
@@ -1225,26 +1224,26 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 }
                 const uint32_t ptv = md_pack_mv(tv), q0 = md_rl(ptv, 0), q1 = md_rl(ptv, 1);
                 const bool tok0 = md_rl((uint32_t)tok, 0) != 0;
-                MdMv t0v, t1v;
-                t0v.x = (int16_t)(q0 & 0xFFFF), t0v.y = (int16_t)(q0 >> 16), t1v.x = (int16_t)(q1 & 0xFFFF), t1v.y = (int16_t)(q1 >> 16);
-                MdMergeCand mg[5];
-                md_merge_list_regs(K, nbr, map != nullptr, tok0, t0v, t1v, totalMerge, mg);
+                MdMerge5 mg;
+                md_merge_list_regs(K, MD_NB_ARGS(w0, w1, w2), map != nullptr, tok0, q0, q1, totalMerge, mg);
                 MD_TR(13);
                 const int k = lane;
                 if (k < 5 && k < totalMerge) {
-                    const MdMergeCand mc = k == 0 ? mg[0] : k == 1 ? mg[1] : k == 2 ? mg[2] : k == 3 ? mg[3] : mg[4];
+                    const uint32_t c0v = k == 0 ? mg.g0[0] : k == 1 ? mg.g0[1] : k == 2 ? mg.g0[2] : k == 3 ? mg.g0[3] : mg.g0[4];
+                    const uint32_t c1v = k == 0 ? mg.g1[0] : k == 1 ? mg.g1[1] : k == 2 ? mg.g1[2] : k == 3 ? mg.g1[3] : mg.g1[4];
+                    const uint32_t cd = k == 0 ? mg.gd[0] : k == 1 ? mg.gd[1] : k == 2 ? mg.gd[2] : k == 3 ? mg.gd[3] : mg.gd[4];
                     bool dup = false;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const MdMergeCand d = mg[j];
-                        const bool f0 = mc.mv[0].x == d.mv[0].x && mc.mv[0].y == d.mv[0].y;
-                        const bool f1 = mc.dir != MD_L0 && mc.mv[1].x == d.mv[1].x && mc.mv[1].y == d.mv[1].y;
-                        const bool same = mc.dir == MD_L0 ? f0 : (mc.dir == MD_L1 ? f1 : (f0 && f1));
-                        dup = dup || (j < k && mc.dir == d.dir && same);
+                        const bool f0 = c0v == mg.g0[j];
+                        const bool f1 = cd != MD_L0 && c1v == mg.g1[j];
+                        const bool same = cd == MD_L0 ? f0 : (cd == MD_L1 ? f1 : (f0 && f1));
+                        dup = dup || (j < k && cd == mg.gd[j] && same);
                     }
                     if (!dup) {
                         keep = true;
-                        cw.c.dir = mc.dir, cw.c.merge_flag = 1, cw.c.merge_index = (uint8_t)k, cw.c.mv[0] = mc.mv[0], cw.c.mv[1] = mc.mv[1];
+                        cw.w[2] = cd | (1u << 8) | ((uint32_t)k << 16); /* dir | merge_flag << 8 | merge_index << 16 */
+                        cw.w[4] = c0v, cw.w[5] = c1v;
                     }
                 }
             }

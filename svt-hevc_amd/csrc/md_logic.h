@@ -898,8 +898,8 @@ MD_FN uint64_t md_inter_fast_cost_c(const SvtAmdMdPicture *P, const MdStats *st,
     if (P->slice_type == 0) {
         const int bi = c->dir == MD_BI;
         rate += st->depth >= 3 ? (bi ? 136034u : 2742u) : md_sel3(st->depth, bi ? 36028u : 29856u, bi ? 59703u : 15752u, bi ? 84420u : 8692u);
-        if (c->dir != MD_BI)
-            rate += (c->dir ? 136034u : 2742u) + md_mvd_rate(c, c->dir);
+        if (c->dir != MD_BI) /* (constant list indices: a run-time index into the candidate record would pin it to memory on the device) */
+            rate += c->dir ? 136034u + md_mvd_rate(c, 1) : 2742u + md_mvd_rate(c, 0);
         else
             rate += (uint64_t)md_mvd_rate(c, 0) + md_mvd_rate(c, 1);
     } else {
