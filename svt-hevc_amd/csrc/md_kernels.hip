@@ -148,6 +148,7 @@ struct MdInterShared {
     alignas(16) MdCand me_c[4], mg_c[5]; /* the unit's motion-estimation / merge candidates as their list-building waves leave them (wave 0 appends them to the intra candidates) */
     uint32_t nbtab[SVT_AMD_MD_LEAVES][5]; /* per entry of the leaf list, made with the LCU's inputs (off the chain): where its five spatial neighbours A0, A1, B0, B1, B2 lie - index into
                                     * L.info | index into mvu << 10 | (inside what is decided before the unit, not across a tile edge) << 18 */
+    unsigned task_ctr;             /* md_units_inter's fast loop: the next task of the unit's list (the waves draw tasks as they finish: a bi-predicted block costs twice a uni-predicted one) */
     uint2 me_rate[4];              /* ... and the motion-estimation candidates' rate term and fastLumaRate (they depend on the predictors only: derived beside the AMVP lists) */
     int n_me, n_mg;
     alignas(16) uint8_t wpred[4][64 * 64];     /* a wave's prediction of the candidate it works on, pitch = unit size */
@@ -1158,6 +1159,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     if (!(Ph.limit_intra && st.x == 0 && st.y == 0))
                         ncand = md_intra_candidates(&Ph, &M.lcu, ois, leaf, &st, M.cand);
                 M.ncand = ncand; /* the intra candidates; the other waves' follow */
+                M.V.task_ctr = 0;
             }
             MD_TR(11);
             MD_SUB(0);
@@ -1340,7 +1342,18 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         {
             const int nheavy = __popcll(hm), nhc = __popcll(cm);
             const int nl = tiled64 ? nheavy * 4 : nheavy, ntask = nl + 2 * nhc;
-            for (int tk = wave; tk < ntask; tk += 4) {
+            /* up to four tasks: a wave each; more (CHROMA_MODE_FULL LCUs: eight to twelve): the waves DRAW them from a counter as they finish - the tasks differ by a factor of
+             * four (a bi-predicted luma block against a uni-predicted 4x4 chroma block), dealt round-robin the slowest wave set the stage's time */
+            const bool draw = ntask > 4;
+            for (int tk = wave;;) {
+                if (draw) {
+                    unsigned got = 0;
+                    if (lane == 0)
+                        got = atomicAdd(&M.V.task_ctr, 1u);
+                    tk = (int)md_rl(got, 0);
+                }
+                if (tk >= ntask)
+                    break;
                 MD_TR(20);
                 const bool luma = tk < nl;
                 const int k = luma ? (tiled64 ? tk >> 2 : tk) : (tk - nl) >> 1, ti = luma ? (tiled64 ? tk & 3 : 0) : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
@@ -1399,6 +1412,8 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                         M.V.sadc2[ci][pl - 1] = sad;
                 }
                 MD_TR(24);
+                if (!draw)
+                    break; /* (at most four tasks: this wave's one is done) */
             }
         }
         __syncthreads();
