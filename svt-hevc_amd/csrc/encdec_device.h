@@ -185,6 +185,14 @@ struct EpRefWindows {
     int valid[2];
     alignas(16) uint8_t pix[2][H * P + 16];
 };
+/* ... and the CHROMA samples around the same position, both planes (the mode decision of CHROMA_MODE_FULL LCUs predicts the chroma pair of every candidate in both of its
+ * loops: a window from HBM is a round trip of ~2 K clocks per list and plane on the unit chain).  Rows of words (P a multiple of 4): the filter reads them where they lie. */
+struct EpRefWindowsC {
+    static constexpr int R = 4, W = 32 + 2 * R + 3, P = 44, H = W;
+    int x0[2], y0[2]; /* padded-plane coordinates (chroma samples) of the window's first sample, per list */
+    int valid[2];
+    alignas(16) uint8_t pix[2][2][H * P + 20]; /* [list][Cb, Cr] */
+};
 /* by all 256 threads of the workgroup; mv[l] = the centre vector of list l in quarter samples */
 __device__ __forceinline__ void ep_ref_windows_fill(const EpRefPlanes *refs, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindows &RW, int t);
 
@@ -425,8 +433,11 @@ __device__ __forceinline__ int ep_sdot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(x, y, c, false);
 }
 /* both passes of one tile of TN x TN samples of one list: window in M.win -> dst / M.raw.  mode: 0 uni-prediction, 1 first list of a bi-predicted tile, 2 its second list */
-template <int TN, bool CHROMA>
-__device__ __forceinline__ void ep_mc8_tile(EpMcScratch<uint8_t> &M, int lane, int fx, int fy, int mode, uint8_t *dst, int pitch)
+/* DIRECT: the window is read where it lies - dwin + doff, rows dpitch bytes apart (dwin 4-byte aligned, dpitch a multiple of 4: the byte misalignment is the same for every
+ * row and segment, one v_alignbyte per word) - instead of from an 8-byte-aligned copy in M.win: a staged reference window (EpRefWindows) needs no copy pass */
+template <int TN, bool CHROMA, bool DIRECT = false>
+__device__ __forceinline__ void ep_mc8_tile(EpMcScratch<uint8_t> &M, int lane, int fx, int fy, int mode, uint8_t *dst, int pitch, const uint8_t *dwin = nullptr, int doff = 0,
+                                            int dpitch = 0)
 {
     constexpr int WP = EpMcScratch<uint8_t>::WP, TP = EpMcScratch<uint8_t>::TP;
     constexpr int NT = CHROMA ? 4 : 8, ROWS = TN + NT - 1, SEG = TN < 8 ? TN : 8, SPR = TN / SEG, ITEMS = ROWS * SPR;
@@ -440,11 +451,23 @@ __device__ __forceinline__ void ep_mc8_tile(EpMcScratch<uint8_t> &M, int lane, i
         const int i = i0 + lane;
         if (i < ITEMS) {
             const int j = SPR == 1 ? i : i / SPR, x0 = SPR == 1 ? 0 : (i - j * SPR) * SEG;
-            const uint32_t *wp = reinterpret_cast<const uint32_t *>(&M.win[j * WP + x0]);
             uint32_t w[4];
+            if (DIRECT) {
+                const int sh = __builtin_amdgcn_readfirstlane(doff & 3);
+                const uint32_t *wp = reinterpret_cast<const uint32_t *>(dwin + (doff & ~3) + j * dpitch + x0);
+                uint32_t r[5];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                w[k] = (k * 4 < SEG + NT - 1 ? wp[k] : 0u) ^ 0x80808080u;
+                for (int k = 0; k < 5; k++)
+                    r[k] = (k - 1) * 4 < SEG + NT - 1 ? wp[k] : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    w[k] = (k * 4 < SEG + NT - 1 ? __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) : 0u) ^ 0x80808080u;
+            } else {
+                const uint32_t *wp = reinterpret_cast<const uint32_t *>(&M.win[j * WP + x0]);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    w[k] = (k * 4 < SEG + NT - 1 ? wp[k] : 0u) ^ 0x80808080u;
+            }
 #pragma unroll
             for (int o = 0; o < SEG; o++) {
                 const uint32_t lo = (o & 3) ? __builtin_amdgcn_alignbyte(w[(o >> 2) + 1], w[o >> 2], o & 3) : w[o >> 2];
@@ -628,6 +651,40 @@ __device__ __forceinline__ void ep_ref_windows_fill(const EpRefPlanes *refs, int
                 __builtin_memcpy(&v, e, 8);
             }
             *reinterpret_cast<uint2 *>(&RW.pix[l][j * EpRefWindows::P + m * 8]) = v;
+        }
+        if (t == 0)
+            RW.x0[l] = x0, RW.y0[l] = y0, RW.valid[l] = 1;
+    }
+}
+
+__device__ __forceinline__ void ep_ref_windows_fill_chroma(const EpRefPlanes *refs, int lcu_x, int lcu_y, const bool use[2], const int16_t (*mv)[2], EpRefWindowsC &RW, int t)
+{
+    for (int l = 0; l < 2; l++) {
+        if (!use[l]) {
+            if (t == 0)
+                RW.valid[l] = 0;
+            continue;
+        }
+        const EpRefPlanes &R = refs[l];
+        const int qx = min(max(((lcu_x + R.originX) << 2) + mv[l][0], (R.originX - 71) << 2), (R.width + R.originX + 7) << 2);
+        const int qy = min(max(((lcu_y + R.originY) << 2) + mv[l][1], (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
+        const int x0 = (qx >> 3) - 1 - EpRefWindowsC::R, y0 = (qy >> 3) - 1 - EpRefWindowsC::R;
+        const int stride = (int)R.stride[1], last = R.size[1] - 1;
+        constexpr int WPR = EpRefWindowsC::P / 4, NW = EpRefWindowsC::H * WPR;
+        for (int i = t; i < 2 * NW; i += 256) {
+            const int pl = i >= NW, r = i - pl * NW, j = r / WPR, m = r - j * WPR, idx = (y0 + j) * stride + x0 + m * 4;
+            const uint8_t *plane = (const uint8_t *)R.plane[1 + pl];
+            uint32_t v;
+            if (idx >= 0 && idx + 4 <= last + 1) {
+                __builtin_memcpy(&v, plane + idx, 4);
+            } else { /* the core's clamped addressing */
+                uint8_t e[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    e[q] = plane[min(max(idx + q, 0), last)];
+                __builtin_memcpy(&v, e, 4);
+            }
+            *reinterpret_cast<uint32_t *>(&RW.pix[l][pl][j * EpRefWindowsC::P + m * 4]) = v;
         }
         if (t == 0)
             RW.x0[l] = x0, RW.y0[l] = y0, RW.valid[l] = 1;

@@ -93,20 +93,29 @@ struct MdPictureDev {
 /* stage clocks of the mode decision of one LCU, taken by lane 0 behind the barrier that ends the stage.  MD_PROF_ON: `prof_on`, a register copy of "D.prof != null" the
  * functions that use the marks make once per LCU - the descriptor lives in LDS, and fifteen marks per unit each re-reading the pointer were fifteen LDS round trips per unit */
 #define MD_PROF_ON prof_on
+/* the marks' bodies live in ONE function outside the unit loop: inlined, thirty marks were ~3 KB of instructions strewn over a loop whose code does not fit the
+ * instruction cache (a debug facility on the hot path of the product).  q: &M.prof[0]; the fields behind it are laid out as MdShared declares them. */
+__device__ __noinline__ void md_prof_mark(unsigned long long *q, int k, int sub)
+{
+    const unsigned long long c_ = __builtin_readcyclecounter();
+    unsigned long long *prof_t = q + 32, *prof_s = q + 33, *prof_d = q + 34;
+    const int depth = *reinterpret_cast<const int *>(q + 34 + 128);
+    if (sub) {
+        q[16 + k] += c_ - *prof_s, prof_d[depth * 32 + 16 + k] += c_ - *prof_s, *prof_s = c_;
+    } else {
+        q[k] += c_ - *prof_t, prof_d[depth * 32 + k] += c_ - *prof_t, *prof_t = c_, *prof_s = c_;
+    }
+}
 #define MD_PROF(k)                                                          \
     do {                                                                    \
-        if (MD_PROF_ON && threadIdx.x == 0) {                               \
-            const unsigned long long c_ = __builtin_readcyclecounter();    \
-            M.prof[k] += c_ - M.prof_t, M.prof_d[M.prof_depth][k] += c_ - M.prof_t, M.prof_t = c_, M.prof_s = c_; \
-        }                                                                   \
+        if (__builtin_expect(MD_PROF_ON, 0) && threadIdx.x == 0)            \
+            md_prof_mark(&M.prof[0], k, 0);                                 \
     } while (0)
 /* ... and finer marks inside a stage (svt_amd_debug_md_profile_sub): slot k of 16 gets the clocks since the previous mark of either kind */
 #define MD_SUB(k)                                                           \
     do {                                                                    \
-        if (MD_PROF_ON && threadIdx.x == 0) {                               \
-            const unsigned long long c_ = __builtin_readcyclecounter();    \
-            M.prof[16 + (k)] += c_ - M.prof_s, M.prof_d[M.prof_depth][16 + (k)] += c_ - M.prof_s, M.prof_s = c_; \
-        }                                                                   \
+        if (__builtin_expect(MD_PROF_ON, 0) && threadIdx.x == 0)            \
+            md_prof_mark(&M.prof[0], k, 1);                                 \
     } while (0)
 
 /* HASY: the closed-loop decision keeps the mode decision's luma reconstruction of the LCU (+ ring) here; the open-loop one (P / B pictures of this revision) never reads it */
@@ -148,6 +157,8 @@ struct MdInterShared {
     alignas(16) MdCand me_c[4], mg_c[5]; /* the unit's motion-estimation / merge candidates as their list-building waves leave them (wave 0 appends them to the intra candidates) */
     uint32_t nbtab[SVT_AMD_MD_LEAVES][5]; /* per entry of the leaf list, made with the LCU's inputs (off the chain): where its five spatial neighbours A0, A1, B0, B1, B2 lie - index into
                                     * L.info | index into mvu << 10 | (inside what is decided before the unit, not across a tile edge) << 18 */
+    uint4 unit_tab[SVT_AMD_MD_LEAVES]; /* per entry of the leaf list: MdStats of its unit (x, y), the unit's index (z): what every thread derives at the top of a unit, made with the LCU's inputs */
+    unsigned task_ctr2;            /* ... and of the chroma blocks of the full loop */
     unsigned task_ctr;             /* md_units_inter's fast loop: the next task of the unit's list (the waves draw tasks as they finish: a bi-predicted block costs twice a uni-predicted one) */
     uint2 me_rate[4];              /* ... and the motion-estimation candidates' rate term and fastLumaRate (they depend on the predictors only: derived beside the AMVP lists) */
     int n_me, n_mg;
@@ -168,6 +179,7 @@ struct MdInterShared {
                                     * function takes it by reference: a chain of loads per interpolation otherwise) */
     SvtAmdMdInter X;               /* the picture's inter controls beside the LCU: read per unit (a load from HBM each otherwise) */
     EpRefWindows rw;               /* the luma reference samples around the LCU displaced by the 64x64 unit's motion-estimation vectors, per list (encdec_device.h) */
+    EpRefWindowsC rwc;             /* ... and, for CHROMA_MODE_FULL LCUs (chroma in both loops of every candidate), the chroma samples around the same position */
     uint8_t ep_kind[SVT_AMD_MD_LEAVES]; /* SVT_AMD_EP_INTER_* of the final tree's inter units */
     uint8_t fin_leaf[SVT_AMD_LCU_MAX_CUS];
     int nfin;
@@ -203,11 +215,16 @@ struct MdShared {
     unsigned long long prof[32], prof_t, prof_s;
     unsigned long long prof_d[4][32]; /* the same sums by the depth of the unit they belong to (svt_amd_debug_md_profile_depth) */
     int prof_depth;
+    /* (md_prof_mark addresses prof_t .. prof_depth relative to prof[0]) */
     int16_t ref[132], reff[132], border[132];
     typename MdVariant<INTER>::type V;
-    int16_t tiles[4][2 * TxRegTile<32>::UNIT];
+    int16_t tiles[4][(INTER ? 1 : 2) * TxRegTile<32>::UNIT]; /* a wave's transpose tile (the I picture's inverse transforms run a unit per N lanes: two 32x32 units) */
     int16_t qbuf[4][32 * 32];
 };
+static_assert(offsetof(MdShared<true>, prof_t) == offsetof(MdShared<true>, prof) + 256 && offsetof(MdShared<true>, prof_s) == offsetof(MdShared<true>, prof) + 264 &&
+                  offsetof(MdShared<true>, prof_d) == offsetof(MdShared<true>, prof) + 272 && offsetof(MdShared<true>, prof_depth) == offsetof(MdShared<true>, prof) + 272 + 1024 &&
+                  offsetof(MdShared<false>, prof_depth) == offsetof(MdShared<false>, prof) + 272 + 1024,
+              "md_prof_mark's view of the profile fields");
 
 
 /* the unit's intra reference, unfiltered (ref) and filtered (reff), by ONE wave: GenerateLumaIntraReferenceSamplesEncodePass with
@@ -338,7 +355,7 @@ __device__ __forceinline__ void md_dct_operands_init(int force_butterflies)
 __device__ __forceinline__ md_v4h md_h4(int a, int b, int c, int d)
 {
     md_v4h r;
-    r[0] = (_Float16)(float)a, r[1] = (_Float16)(float)b, r[2] = (_Float16)(float)c, r[3] = (_Float16)(float)d;
+    r[0] = (_Float16)(short)a, r[1] = (_Float16)(short)b, r[2] = (_Float16)(short)c, r[3] = (_Float16)(short)d; /* v_cvt_f16_i16: |values| <= 512, exact */
     return r;
 }
 __device__ __forceinline__ md_v4h md_dct_op(int slot, int lane)
@@ -489,7 +506,7 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
             }
         }
     }
-    if (!on_matrix_cores) {
+    if (__builtin_expect(!on_matrix_cores, N < 16)) { /* (16x16 / 32x32: the fall-back of a unit outside the matrix form's domain - out of the way of the hot path's instruction stream) */
     const int r = lane & (N - 1);
     const bool active = lane < N;
     int x[N];
@@ -513,8 +530,11 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
      * column on N lanes: a 16x16 unit's quantiser is 4 coefficients deep per lane, not 16 (the unit chain is bound by instructions issued per wave). */
     {
         constexpr int P = TxRegTile<N>::PITCH;
-        int16_t *t_ = tile + (lane / N) * TxRegTile<N>::UNIT;
-        fwd_1d_regs<N>(x, fs1, wrap, [&](int k, int16_t v) { t_[k * P + r] = v; });
+        int16_t *t_ = tile; /* ONE unit per call, on lanes 0..N-1; the other lanes run along on zeros and leave no trace */
+        fwd_1d_regs<N>(x, fs1, wrap, [&](int k, int16_t v) {
+            if (active)
+                t_[k * P + r] = v;
+        });
         EP_WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < N; j += 2) {
@@ -649,6 +669,39 @@ __device__ __forceinline__ unsigned long long md_readlane64(unsigned long long v
     return ((unsigned long long)hi << 32) | lo;
 }
 
+/* a window of `rows` rows of `cpr` 8-byte chunks from a reference plane (the core's clamped addressing at the plane's ends) into the wave's scratch, rows WP apart: the
+ * fall-back of md_predict_tile for a window outside the staged samples - one copy of the code for every tile size */
+__device__ __noinline__ void md_window_from_plane(const uint8_t *plane, int stride, int last, int base0, int rows, int cpr, int lane, uint8_t *win)
+{
+    constexpr int WP = EpMcScratch<uint8_t>::WP;
+    MD_LDS(win);
+    const int nchunk = rows * cpr;
+    for (int i0 = 0; i0 < nchunk; i0 += 128) { /* two loads in flight per lane */
+        uint2 v[2];
+        int at[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = i0 + 64 * u + lane;
+            at[u] = -1;
+            if (i < nchunk) {
+                const int j = i / cpr, m = i - j * cpr, idx = base0 + j * stride + m * 8;
+                at[u] = j * WP + m * 8;
+                if (idx >= 0 && idx + 8 <= last + 1) {
+                    __builtin_memcpy(&v[u], plane + idx, 8);
+                } else {
+                    uint32_t lo = 0, hi = 0;
+                    for (int q = 0; q < 4; q++)
+                        lo |= (uint32_t)plane[min(max(idx + q, 0), last)] << (8 * q), hi |= (uint32_t)plane[min(max(idx + 4 + q, 0), last)] << (8 * q);
+                    v[u] = make_uint2(lo, hi);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (at[u] >= 0)
+                *reinterpret_cast<uint2 *>(&win[at[u]]) = v[u];
+    }
+}
 /* Inter2Nx2NPuPredictionHevc (Codec/EbInterPrediction.c:468) of ONE TILE (TN x TN samples: the whole block of a unit up to 32x32 / its chroma block, a quarter of a 64x64
  * unit's luma) of plane p of a candidate, by one wave, both lists: ep_inter_predict_core8 (encdec_device.h) with the tile size and the tap count decided at compile time -
  * a function per size (the 16x16 and 8x8 blocks most units have need a fraction of the registers of the 32x32 form: no callee-saved register, so no private-segment traffic
@@ -656,12 +709,12 @@ __device__ __forceinline__ unsigned long long md_readlane64(unsigned long long v
  * chain).  mv0 / mv1: x | y << 16.  td: the tile's first sample in the destination, pitch in samples. */
 template <int TN, bool CHROMA>
 __device__ MD_LEAF_CALL void md_predict_tile(const EpRefPlanes *refs, int abs_x, int abs_y, int inter_dir, uint32_t mv0, uint32_t mv1, int p, int lane, EpMcScratch<uint8_t> *Mp,
-                                             uint8_t *td, int pitch, int tx0, int ty0, const EpRefWindows *RW)
+                                             uint8_t *td, int pitch, int tx0, int ty0, const EpRefWindows *RW, const EpRefWindowsC *RWC)
 {
     constexpr int WP = EpMcScratch<uint8_t>::WP;
-    constexpr int ntaps = CHROMA ? 4 : 8, first = CHROMA ? -1 : -3, rows = TN + ntaps - 1, cpr = (rows + 7) >> 3, nchunk = rows * cpr, inv = (65536 + cpr - 1) / cpr;
+    constexpr int ntaps = CHROMA ? 4 : 8, first = CHROMA ? -1 : -3, rows = TN + ntaps - 1, cpr = (rows + 7) >> 3;
     EpMcScratch<uint8_t> &M = *Mp;
-    MD_LDS(Mp), MD_LDS(td), MD_LDS(RW), MD_LDS(refs);
+    MD_LDS(Mp), MD_LDS(td), MD_LDS(RW), MD_LDS(RWC), MD_LDS(refs);
     const bool bi = inter_dir == 2;
     bool second = false;
     for (int l = 0; l < 2; l++) {
@@ -675,60 +728,31 @@ __device__ MD_LEAF_CALL void md_predict_tile(const EpRefPlanes *refs, int abs_x,
         const int qy = min(max(((abs_y + R.originY) << 2) + mvy, (R.originY - 71) << 2), (R.height + R.originY + 7) << 2);
         const int ix = (CHROMA ? qx >> 3 : qx >> 2) + tx0, iy = (CHROMA ? qy >> 3 : qy >> 2) + ty0;
         const int fx = __builtin_amdgcn_readfirstlane(CHROMA ? qx & 7 : qx & 3), fy = __builtin_amdgcn_readfirstlane(CHROMA ? qy & 7 : qy & 3);
-        bool staged = false;
         MD_TR(41);
-        if (RW && !CHROMA && RW->valid[l]) {
-            const int rx = ix + first - RW->x0[l], ry = iy + first - RW->y0[l];
-            if (rx >= 0 && ry >= 0 && rx + cpr * 8 <= EpRefWindows::P && ry + rows <= EpRefWindows::H) {
-                staged = true;
-#pragma unroll
-                for (int i0 = 0; i0 < nchunk; i0 += 64) {
-                    const int i = i0 + lane;
-                    if (i < nchunk) {
-                        const int j = (i * inv) >> 16, m = i - j * cpr, o = (ry + j) * EpRefWindows::P + rx + m * 8, sh = o & 3;
-                        const uint32_t *wp = reinterpret_cast<const uint32_t *>(&RW->pix[l][o & ~3]);
-                        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-                        uint2 v;
-                        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh), v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                        *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v;
-                    }
-                }
+        /* where the filter reads the window: a staged one where it lies (EpRefWindows / EpRefWindowsC), any other from the scratch copy the fall-back below makes - ONE
+         * instance of the filter per tile size either way (two were ~1 K instructions more per function, in a loop whose code does not fit the instruction cache) */
+        /* (the window's place as a byte distance from the scratch copy's: all three live in the workgroup's LDS, 16-byte aligned; an integer, not a choice between pointers) */
+        int dbase = 0, doff = 0, dpitch = WP;
+        bool staged = false;
+        if (!CHROMA) {
+            if (RW && RW->valid[l]) {
+                const int rx = ix + first - RW->x0[l], ry = iy + first - RW->y0[l];
+                if (rx >= 0 && ry >= 0 && rx + rows <= EpRefWindows::P && ry + rows <= EpRefWindows::H)
+                    staged = true, dbase = (int)(RW->pix[l] - M.win), doff = ry * EpRefWindows::P + rx, dpitch = EpRefWindows::P;
+            }
+        } else {
+            if (RWC && RWC->valid[l]) {
+                const int rx = ix + first - RWC->x0[l], ry = iy + first - RWC->y0[l];
+                if (rx >= 0 && ry >= 0 && rx + rows <= EpRefWindowsC::P && ry + rows <= EpRefWindowsC::H)
+                    staged = true, dbase = (int)(RWC->pix[l][p - 1] - M.win), doff = ry * EpRefWindowsC::P + rx, dpitch = EpRefWindowsC::P;
             }
         }
-        if (!staged) {
-            const int stride = (int)R.stride[CHROMA], last = R.size[CHROMA] - 1;
-            const uint8_t *plane = (const uint8_t *)R.plane[p];
-            const int base0 = (iy + first) * stride + ix + first;
-            constexpr int NU = (nchunk + 63) / 64; /* every load of the window issued before the first store: one memory latency per window */
-            uint2 v[NU];
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int i = u * 64 + lane;
-                if (i < nchunk) {
-                    const int j = (i * inv) >> 16, m = i - j * cpr, idx = base0 + j * stride + m * 8;
-                    if (idx >= 0 && idx + 8 <= last + 1) {
-                        __builtin_memcpy(&v[u], plane + idx, 8);
-                    } else {
-                        uint8_t e[8];
-#pragma unroll
-                        for (int q = 0; q < 8; q++)
-                            e[q] = plane[min(max(idx + q, 0), last)];
-                        __builtin_memcpy(&v[u], e, 8);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int i = u * 64 + lane;
-                if (i < nchunk) {
-                    const int j = (i * inv) >> 16, m = i - j * cpr;
-                    *reinterpret_cast<uint2 *>(&M.win[j * WP + m * 8]) = v[u];
-                }
-            }
+        if (__builtin_expect(!staged, 0)) {
+            md_window_from_plane((const uint8_t *)R.plane[p], (int)R.stride[CHROMA], R.size[CHROMA] - 1, (iy + first) * (int)R.stride[CHROMA] + ix + first, rows, cpr, lane, M.win);
+            EP_WAVE_SYNC();
         }
-        EP_WAVE_SYNC();
-        MD_TR(staged ? 42 : 46);
-        ep_mc8_tile<TN, CHROMA>(M, lane, fx, fy, !bi ? 0 : (second ? 2 : 1), td, pitch);
+        MD_TR(42);
+        ep_mc8_tile<TN, CHROMA, true>(M, lane, fx, fy, !bi ? 0 : (second ? 2 : 1), td, pitch, M.win + dbase, doff, dpitch);
         MD_TR(44);
         second = true;
     }
@@ -736,7 +760,7 @@ __device__ MD_LEAF_CALL void md_predict_tile(const EpRefPlanes *refs, int abs_x,
 /* ... of plane p (0 luma: N x N, 1 / 2 chroma: N/2 x N/2) of a candidate (direction, vectors x | y << 16) into dst with pitch = the block's width; tile_first / tile_step
  * let several waves share the four 32x32 tiles of a 64x64 unit's luma */
 __device__ __forceinline__ void md_predict_inter_plane(const EpRefPlanes *refs, int dir, uint32_t mv0, uint32_t mv1, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc,
-                                                       uint8_t *dst, int tile_first, int tile_step, const EpRefWindows *rw)
+                                                       uint8_t *dst, int tile_first, int tile_step, const EpRefWindows *rw, const EpRefWindowsC *rwc = nullptr)
 {
     const int n = p ? N >> 1 : N, pitch = n;
     if (!p) {
@@ -744,27 +768,27 @@ __device__ __forceinline__ void md_predict_inter_plane(const EpRefPlanes *refs, 
         case 64:
             for (int ti = tile_first; ti < 4; ti += tile_step) {
                 const int ty0 = (ti >> 1) << 5, tx0 = (ti & 1) << 5;
-                md_predict_tile<32, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst + ty0 * pitch + tx0, pitch, tx0, ty0, rw);
+                md_predict_tile<32, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst + ty0 * pitch + tx0, pitch, tx0, ty0, rw, rwc);
             }
             break;
-        case 32: md_predict_tile<32, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw); break;
-        case 16: md_predict_tile<16, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw); break;
-        default: md_predict_tile<8, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw); break;
+        case 32: md_predict_tile<32, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
+        case 16: md_predict_tile<16, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
+        default: md_predict_tile<8, false>(refs, x0, y0, dir, mv0, mv1, 0, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
         }
     } else {
         switch (n) {
-        case 32: md_predict_tile<32, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
-        case 16: md_predict_tile<16, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
-        case 8: md_predict_tile<8, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
-        default: md_predict_tile<4, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw); break;
+        case 32: md_predict_tile<32, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
+        case 16: md_predict_tile<16, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
+        case 8: md_predict_tile<8, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
+        default: md_predict_tile<4, true>(refs, x0, y0, dir, mv0, mv1, p, lane, &mc, dst, pitch, 0, 0, rw, rwc); break;
         }
     }
 }
 __device__ __forceinline__ uint32_t md_pack_mv(MdMv v) { return (uint32_t)(uint16_t)v.x | ((uint32_t)(uint16_t)v.y << 16); }
 __device__ __forceinline__ void md_predict_inter_plane(const EpRefPlanes *refs, const MdCand &c, int x0, int y0, int N, int p, int lane, EpMcScratch<uint8_t> &mc, uint8_t *dst,
-                                                       int tile_first, int tile_step, const EpRefWindows *rw)
+                                                       int tile_first, int tile_step, const EpRefWindows *rw, const EpRefWindowsC *rwc = nullptr)
 {
-    md_predict_inter_plane(refs, (int)c.dir, md_pack_mv(c.mv[0]), md_pack_mv(c.mv[1]), x0, y0, N, p, lane, mc, dst, tile_first, tile_step, rw);
+    md_predict_inter_plane(refs, (int)c.dir, md_pack_mv(c.mv[0]), md_pack_mv(c.mv[1]), x0, y0, N, p, lane, mc, dst, tile_first, tile_step, rw, rwc);
 }
 /* IntraPredictionOl's chroma references of the unit (Codec/EbIntraPrediction.c:5065 UpdateChromaNeighborSamplesArrayOL): SOURCE chroma samples around the
  * unit, mid-grey beyond the picture.  By one wave; ref[p] in pu_predict's layout (n = N/2). */
@@ -1132,8 +1156,14 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
     for (;;) {
         MD_TR(10);
         /* ---- the unit (every thread alike) ---- */
-        const int cuIdx = M.cu_idx, leaf = M.lcu.leaf_index[cuIdx];
-        const MdStats st = md_stats(leaf);
+        const int cuIdx = M.cu_idx;
+        const uint4 ur = M.V.unit_tab[cuIdx]; /* (md_stats of the unit is ~40 instructions and a dependent read of the leaf list: tabulated with the LCU's inputs) */
+        const int leaf = (int)ur.z;
+        MdStats st;
+        {
+            const uint32_t w_[2] = {ur.x, ur.y};
+            __builtin_memcpy(&st, w_, 8);
+        }
         const int N = st.size, lgN = st.lg, x0 = lcu_x + st.x, y0 = lcu_y + st.y;
         const int totalMerge = md_nmm(&Ph, N);
         /* ================= A ================= */
@@ -1159,19 +1189,20 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     if (!(Ph.limit_intra && st.x == 0 && st.y == 0))
                         ncand = md_intra_candidates(&Ph, &M.lcu, ois, leaf, &st, M.cand);
                 M.ncand = ncand; /* the intra candidates; the other waves' follow */
-                M.V.task_ctr = 0;
+                M.V.task_ctr = 0, M.V.task_ctr2 = 0;
             }
             MD_TR(11);
             MD_SUB(0);
         } else if (wave < 3) {
             /* the five spatial neighbours (A0, A1, B0, B1, B2; availability as GenerateL0L1AmvpMergeLists derives it, :2256-2340): a lane each, then all five in registers */
             uint32_t w0 = 0, w1 = 0, w2 = 0;
-            if (lane < 5) {
+            if (lane < 5) { /* (the mode and the vectors are requested together: one LDS round trip behind the table's) */
                 const uint32_t e = M.V.nbtab[cuIdx][lane];
-                if (((e >> 18) & 1u) && (L.info[e & 1023u] & 0xFF) == MD_INTER) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(&M.V.mvu[(e >> 10) & 255u]);
-                    w0 = q[0], w1 = q[1], w2 = (q[2] & 0xFFu) | 0x100u; /* mv[0], mv[1], dir | avail << 8 */
-                }
+                const uint32_t inf = L.info[e & 1023u];
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(&M.V.mvu[(e >> 10) & 255u]);
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+                if (((e >> 18) & 1u) && (inf & 0xFF) == MD_INTER)
+                    w0 = q0, w1 = q1, w2 = (q2 & 0xFFu) | 0x100u; /* mv[0], mv[1], dir | avail << 8 */
             }
             MD_TR(12);
             const SvtAmdTmvpLcu *map = tmvp_on ? M.V.tmvp : nullptr;
@@ -1356,7 +1387,10 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     break;
                 MD_TR(20);
                 const bool luma = tk < nl;
-                const int k = luma ? (tiled64 ? tk >> 2 : tk) : (tk - nl) >> 1, ti = luma ? (tiled64 ? tk & 3 : 0) : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
+                /* drawn tasks run from the LAST candidate to the first: the list holds the intra candidates first, and their blocks are the short tasks - the long ones
+                 * (motion-compensated, two lists) start first, the short ones fill the waves' tails */
+                const int kq = luma ? (tiled64 ? tk >> 2 : tk) : (tk - nl) >> 1, ti = luma ? (tiled64 ? tk & 3 : 0) : 0, pl = luma ? 0 : 1 + ((tk - nl) & 1);
+                const int k = draw ? (luma ? nheavy : nhc) - 1 - kq : kq;
                 const int ci = md_nth_bit(luma ? hm : cm, k);
                 const uint32_t cw0 = md_rl(cw.w[0], ci), cw2 = md_rl(cw.w[2], ci);
                 uint32_t sad = 0;
@@ -1365,7 +1399,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
                     MD_TR(21);
                     md_predict_inter_plane(M.V.refs, (int)(cw2 & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0,
-                                           tiled64 && luma ? 4 : 1, &M.V.rw);
+                                           tiled64 && luma ? 4 : 1, &M.V.rw, &M.V.rwc);
                     MD_TR(22);
                     MD_SUB(7);
                     if (luma && tiled64) {
@@ -1449,6 +1483,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         {
             int highest = 0;
             const int maxb = max_buffers < 2 ? 2 : max_buffers;
+            const bool inb = lane < maxb;
             for (int idx = nc - 1; idx >= 0; idx--) {
                 const uint32_t cv = md_rl(cst, idx);
                 const int ev = __builtin_amdgcn_readlane(evl, idx);
@@ -1461,17 +1496,14 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     }
                 }
                 evcount += ev != 0;
-                if (idx) {
-                    uint32_t m = 0;
-                    int h = 0;
-#pragma unroll
-                    for (int b = 0; b < MD_MAX_BUF; b++)
-                        if (b < maxb) {
-                            const uint32_t v = md_rl(bcost, b);
-                            if (b == 0 || v > m)
-                                m = v, h = b;
-                        }
-                    highest = h;
+                if (idx) { /* the first of lanes [0, maxb) holding their maximum: three DPP steps over the eight lanes, one ballot */
+                    static_assert(MD_MAX_BUF == 8, "the buffers are the first eight lanes of a row");
+                    const uint32_t v = inb ? bcost : 0u;
+                    uint32_t m = v;
+                    m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));  /* quad_perm [1,0,3,2] */
+                    m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));  /* quad_perm [2,3,0,1] */
+                    m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false)); /* row_half_mirror */
+                    highest = __ffsll((long long)__ballot(inb && bcost == md_rl(m, 0))) - 1;
                 }
             }
         }
@@ -1529,7 +1561,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     fresh64 = true;
                     if (wave == f)
                         md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], pci) & 0xFF), md_rl(cw.w[4], pci), md_rl(cw.w[5], pci), x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1,
-                                               &M.V.rw);
+                                               &M.V.rw, &M.V.rwc);
                 }
             }
             if (fresh64)
@@ -1560,7 +1592,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 if (kept_pred(pci))
                     pred = M.V.cpred[(int)md_rl((uint32_t)slot, pci)]; /* the fast loop's prediction of this candidate is still there */
                 else
-                    md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], pci) & 0xFF), md_rl(cw.w[4], pci), md_rl(cw.w[5], pci), x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
+                    md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], pci) & 0xFF), md_rl(cw.w[4], pci), md_rl(cw.w[5], pci), x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw, &M.V.rwc);
             } else {
                 const int mode = (int)((p0 >> 8) & 0xFF);
                 const int16_t *use = M.ref;
@@ -1581,29 +1613,15 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             if (fresh64) /* every wave is done with the fresh luma predictions in the waves' scratch before a chroma block lands there */
                 __syncthreads();
             const int Cn = N >> 1, lgc = lgN - 1, Tc = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
-            unsigned mine = 0;
-            {
-                int load[4];
-#pragma unroll
-                for (int w_ = 0; w_ < 4; w_++)
-                    load[w_] = (!split64 && w_ < nfull) ? 3 : 0;
-                for (int tk = 0; tk < 2 * nfull; tk++) {
-                    int best_w = 0;
-#pragma unroll
-                    for (int w_ = 1; w_ < 4; w_++)
-                        if (load[w_] < load[best_w])
-                            best_w = w_;
-#pragma unroll
-                    for (int w_ = 0; w_ < 4; w_++)
-                        if (w_ == best_w)
-                            load[w_] += 2;
-                    if (best_w == wave)
-                        mine |= 1u << tk;
-                }
-            }
-            for (int tk = 0; tk < 2 * nfull; tk++) {
-                if (!((mine >> tk) & 1u))
-                    continue;
+            /* the waves DRAW the (survivor, plane) tasks as they get free: a luma unit with levels to price takes twice the time of one without, a wave without a luma
+             * unit starts at once - no fixed assignment fits */
+            for (;;) {
+                unsigned got = 0;
+                if (lane == 0)
+                    got = atomicAdd(&M.V.task_ctr2, 1u);
+                const int tk = (int)md_rl(got, 0);
+                if (tk >= 2 * nfull)
+                    break;
                 const int f = tk >> 1, pl = tk & 1, b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b);
                 const uint32_t c0 = md_rl(cw.w[0], ci);
                 const int cdtype = (int)(c0 & 0xFF), cdmode = (int)((c0 >> 8) & 0xFF);
@@ -1613,7 +1631,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 } else {
                     uint8_t *pw = M.V.wpred_c(wave, pl);
                     if (cdtype == MD_INTER) {
-                        md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], ci) & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw);
+                        md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], ci) & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw, &M.V.rwc);
                     } else {
                         const int16_t *use = M.V.refc[pl];
                         const int dcv = cdmode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
@@ -1718,8 +1736,9 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                                      w_d0 = md_readlane64(dist[0], wf), w_d1 = md_readlane64(dist[1], wf), w_rate = md_readlane64(frate, wf);
             const uint32_t w_ycbf = md_rl(ycbf, wf), w_c0 = md_rl(sv.w[0], wf), w_c2 = md_rl(sv.w[2], wf), w_mv0 = md_rl(sv.w[4], wf), w_mv1 = md_rl(sv.w[5], wf);
             const bool w_kept = ((kept >> wf) & 1ull) != 0;
+            const int wtype = (int)(w_c0 & 0xFF), wdir = (int)(w_c2 & 0xFF);
+            int last_v = leaf, upd_v = 0; /* (lane 0's; the wave reads them by v_readlane - a hand-over through LDS is two dependent round trips on the chain) */
             if (lane == 0) {
-                const int wtype = (int)(w_c0 & 0xFF), wdir = (int)(w_c2 & 0xFF);
                 MdCu &u = M.S.cu[leaf];
                 /* (a winner the escape left uncosted keeps the buffer's initial values: zeros, as ProductResetModeDecision leaves them) */
                 M.S.local[leaf].cost = w_cost, M.S.local[leaf].full_distortion = w_kept ? (uint32_t)w_d0 : 0u;
@@ -1773,8 +1792,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 } else { /* open loop: no reconstruction to wait for, the inter-depth decision follows at once */
                     last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, md_stop_split(&Ph, &Lh, st.depth, w_kept ? (uint32_t)w_d0 : 0u));
                 }
-                M.last = last;
-                M.update = M.S.cu[last].split == 0;
+                last_v = last, upd_v = M.S.cu[last].split == 0;
                 /* the next unit (CalculateNextCuIndex :1261): the loop stands on `cur` - the tested unit, or the parent a partition exit fell back to */
                 int nextIdx = curIdx;
                 if (M.S.cu[cur].split || lh < 64)
@@ -1791,19 +1809,29 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             EP_WAVE_SYNC();
             MD_PROF(6);
             /* ModeDecisionUpdateNeighborArrays of the unit the decision ended on (at most 256 cells: this wave's lanes) */
-            if (M.update) {
-                const int last = M.last;
-                const MdStats ls = md_stats(last);
-                const MdCu u = M.S.cu[last];
-                const uint32_t w = (uint32_t)u.pred_mode | ((uint32_t)u.intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) | ((uint32_t)u.skip_flag << 24);
+            if (md_rl((uint32_t)upd_v, 0)) {
+                const int last = (int)md_rl((uint32_t)last_v, 0);
+                uint32_t w, m0, m1, md;
+                MdStats ls = st;
+                if (last == leaf) { /* the unit just decided (most updates): its record is in this wave's registers */
+                    const bool wi = wtype == MD_INTER;
+                    w = (uint32_t)wtype | ((wtype == MD_INTRA ? (w_c0 >> 8) & 0xFFu : 0x1Fu) << 8) | ((uint32_t)st.depth << 16);
+                    m0 = wi && wdir != MD_L1 ? w_mv0 : 0u, m1 = wi && wdir != MD_L0 ? w_mv1 : 0u, md = wi ? (uint32_t)wdir : 3u;
+                } else {
+                    ls = md_stats(last);
+                    const MdCu u = M.S.cu[last];
+                    w = (uint32_t)u.pred_mode | ((uint32_t)u.intra_luma_mode << 8) | ((uint32_t)ls.depth << 16) | ((uint32_t)u.skip_flag << 24);
+                    m0 = md_pack_mv(u.mv[0]), m1 = md_pack_mv(u.mv[1]), md = u.inter_dir;
+                }
                 const int cells = ls.size >> 2, lgc4 = ls.lg - 2;
                 for (int e = lane; e < cells * cells; e += 64)
                     L.info[((ls.y >> 2) + (e >> lgc4) + 1) * 36 + (ls.x >> 2) + (e & (cells - 1)) + 1] = w;
                 const int c8 = ls.size >> 3, lgc8 = ls.lg - 3;
-                MdMvUnit mu;
-                mu.mv[0] = u.mv[0], mu.mv[1] = u.mv[1], mu.dir = u.inter_dir, mu.avail = 0, mu.pad[0] = mu.pad[1] = 0;
-                for (int e = lane; e < c8 * c8; e += 64)
-                    M.V.mvu[((ls.y >> 3) + (e >> lgc8) + 1) * 18 + (ls.x >> 3) + (e & (c8 - 1)) + 1] = mu;
+                static_assert(sizeof(MdMvUnit) == 12, "three words: mv[0], mv[1], dir | avail << 8");
+                for (int e = lane; e < c8 * c8; e += 64) {
+                    uint32_t *q = reinterpret_cast<uint32_t *>(&M.V.mvu[((ls.y >> 3) + (e >> lgc8) + 1) * 18 + (ls.x >> 3) + (e & (c8 - 1)) + 1]);
+                    q[0] = m0, q[1] = m1, q[2] = md;
+                }
             }
             MD_TR(38);
         }
@@ -1874,6 +1902,16 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAm
     if (t >= 64 && t < 64 + (int)M.lcu.leaf_count) /* (before the wait for the neighbours: off the chain) */
         M.next_step[t - 64] = (uint8_t)md_next_cu_step(&M.lcu, t - 64, md_stats(M.lcu.leaf_index[t - 64]).depth);
     if constexpr (INTER) {
+        static_assert(sizeof(MdStats) == 8, "two words");
+        if (t >= 128 && t < 128 + (int)M.lcu.leaf_count) {
+            const int lf = M.lcu.leaf_index[t - 128];
+            const MdStats s_ = md_stats(lf);
+            uint32_t w_[2];
+            __builtin_memcpy(w_, &s_, 8);
+            M.V.unit_tab[t - 128] = make_uint4(w_[0], w_[1], (uint32_t)lf, 0u);
+        }
+    }
+    if constexpr (INTER) {
         /* the spatial neighbours of every unit of the leaf list with the availability GenerateL0L1AmvpMergeLists derives from positions (EbAdaptiveMotionVectorPrediction.c:2256-2340:
          * scan order, array bounds, tile edges); whether the neighbour is an inter unit is the one thing left to the unit's own time */
         const bool tl = M.lcu.tile_left != 0, tt = M.lcu.tile_top != 0, tr = M.lcu.tile_right != 0;
@@ -1897,6 +1935,8 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAm
         cmv[0][0] = me0.x_mv_l0, cmv[0][1] = me0.y_mv_l0, cmv[1][0] = me0.x_mv_l1, cmv[1][1] = me0.y_mv_l1;
         const bool use[2] = {true, P.slice_type == 0};
         ep_ref_windows_fill(D.mref, lcu_x, lcu_y, use, cmv, M.V.rw, t);
+        const bool usec[2] = {M.lcu.chroma_encode_mode == 1, M.lcu.chroma_encode_mode == 1 && P.slice_type == 0};
+        ep_ref_windows_fill_chroma(D.mref, lcu_x, lcu_y, usec, cmv, M.V.rwc, t);
     }
 }
 
@@ -2254,7 +2294,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                     if constexpr (INTER) {
                         const int sl = M.V.slot[c], n = luma ? N : N >> 1, lgn = luma ? lgN : lgN - 1;
                         uint8_t *pr = luma ? (sl >= 0 ? M.V.cpred[sl] : M.V.wpred[wave]) : (sl >= 0 ? M.V.cpred_c[sl][pl - 1] : M.V.wpred_c(wave, pl - 1));
-                        md_predict_inter_plane(M.V.refs, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1, &M.V.rw);
+                        md_predict_inter_plane(M.V.refs, cd, x0, y0, N, pl, lane, M.V.mc[wave], pr, tiled64 && luma ? ti : 0, tiled64 && luma ? 4 : 1, &M.V.rw, &M.V.rwc);
                         MD_TR(22);
                         MD_SUB(7);
                         if (luma && tiled64) {
@@ -2402,7 +2442,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                     if (!(M.V.slot[pci] >= 0 && M.evaluated[pci])) {
                         sync = true;
                         if (wave == f)
-                            md_predict_inter_plane(M.V.refs, M.cand[pci], x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1, &M.V.rw);
+                            md_predict_inter_plane(M.V.refs, M.cand[pci], x0, y0, N, 0, lane, M.V.mc[wave], M.V.wpred[f], 0, 1, &M.V.rw, &M.V.rwc);
                     }
                 }
                 if (sync)
@@ -2440,7 +2480,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                     if (M.V.slot[pci] >= 0 && M.evaluated[pci])
                         pred = M.V.cpred[M.V.slot[pci]]; /* the fast loop's prediction of this candidate is still there */
                     else
-                        md_predict_inter_plane(M.V.refs, pc, x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
+                        md_predict_inter_plane(M.V.refs, pc, x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw, &M.V.rwc);
                 }
             } else {
                 const int mode = pc.intra_mode;
@@ -2497,7 +2537,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                     } else {
                         uint8_t *pw = M.V.wpred_c(wave, pl);
                         if (cd.type == MD_INTER) {
-                            md_predict_inter_plane(M.V.refs, cd, x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw);
+                            md_predict_inter_plane(M.V.refs, cd, x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw, &M.V.rwc);
                         } else {
                             const int mode = cd.intra_mode;
                             const int16_t *use = M.V.refc[pl];
@@ -2798,7 +2838,7 @@ __device__ __forceinline__ void md_ep_kinds(const MdPictureDev &D, const SvtAmdM
         cd.type = MD_INTER, cd.dir = u.inter_dir, cd.mv[0] = u.mv[0], cd.mv[1] = u.mv[1];
         for (int p = 0; p < 2; p++) {
             uint8_t *pred = M.V.wpred[wave] + p * 1024;
-            md_predict_inter_plane(M.V.refs, cd, lcu_x + st.x, lcu_y + st.y, N, 1 + p, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw);
+            md_predict_inter_plane(M.V.refs, cd, lcu_x + st.x, lcu_y + st.y, N, 1 + p, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw, &M.V.rwc);
             for (int tu = 0; tu < ntu; tu++) {
                 const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                 uint32_t nz;
