@@ -637,20 +637,33 @@ __device__ __forceinline__ void ep_ref_windows_fill(const EpRefPlanes *refs, int
         const int x0 = (qx >> 2) - 3 - EpRefWindows::R, y0 = (qy >> 2) - 3 - EpRefWindows::R;
         const int stride = (int)R.stride[0], last = R.size[0] - 1;
         const uint8_t *plane = (const uint8_t *)R.plane[0];
-        constexpr int CPR = EpRefWindows::P / 8, NCH = EpRefWindows::H * CPR;
-        for (int i = t; i < NCH; i += 256) {
-            const int j = i / CPR, m = i - j * CPR, idx = (y0 + j) * stride + x0 + m * 8;
-            uint2 v;
-            if (idx >= 0 && idx + 8 <= last + 1) {
-                __builtin_memcpy(&v, plane + idx, 8);
-            } else {
-                uint8_t e[8];
+        constexpr int CPR = EpRefWindows::P / 8, NCH = EpRefWindows::H * CPR, NU = (NCH + 255) / 256;
+        /* every load of a thread issued before its first store: ONE memory latency per window (the mode decision re-stages a window behind its wait for the neighbours,
+         * on the picture's critical path) */
+        uint2 v[NU];
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    e[q] = plane[min(max(idx + q, 0), last)];
-                __builtin_memcpy(&v, e, 8);
+        for (int u = 0; u < NU; u++) {
+            const int i = t + 256 * u;
+            v[u] = make_uint2(0u, 0u);
+            if (i < NCH) {
+                const int j = i / CPR, m = i - j * CPR, idx = (y0 + j) * stride + x0 + m * 8;
+                if (idx >= 0 && idx + 8 <= last + 1) {
+                    __builtin_memcpy(&v[u], plane + idx, 8);
+                } else {
+                    uint32_t lo = 0, hi = 0;
+                    for (int q = 0; q < 4; q++)
+                        lo |= (uint32_t)plane[min(max(idx + q, 0), last)] << (8 * q), hi |= (uint32_t)plane[min(max(idx + 4 + q, 0), last)] << (8 * q);
+                    v[u] = make_uint2(lo, hi);
+                }
             }
-            *reinterpret_cast<uint2 *>(&RW.pix[l][j * EpRefWindows::P + m * 8]) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int i = t + 256 * u;
+            if (i < NCH) {
+                const int j = i / CPR, m = i - j * CPR;
+                *reinterpret_cast<uint2 *>(&RW.pix[l][j * EpRefWindows::P + m * 8]) = v[u];
+            }
         }
         if (t == 0)
             RW.x0[l] = x0, RW.y0[l] = y0, RW.valid[l] = 1;

@@ -334,7 +334,7 @@ typedef _Float16 md_v4h __attribute__((ext_vector_type(4)));
 typedef float md_v4f __attribute__((ext_vector_type(4)));
 typedef float md_v16f __attribute__((ext_vector_type(16)));
 static __shared__ int s_md_force_bfly;       /* debug (MdPictureDev.force_butterflies), set once per launch beside the operands below */
-static __shared__ uint32_t s_dct_op[10][64]; /* [0..1]: 16x16, [2 + 2 s .. 3 + 2 s]: 32x32 K-slice s; two dwords = four f16 */
+static __shared__ uint32_t s_dct_op[12][64]; /* [0..1]: 16x16, [2 + 2 s .. 3 + 2 s]: 32x32 K-slice s, [10..11]: two 8x8 matrices on the diagonal of a 16x16 one; two dwords = four f16 */
 __device__ __forceinline__ void md_dct_operands_init(int force_butterflies)
 {
     const int t = threadIdx.x;
@@ -345,6 +345,11 @@ __device__ __forceinline__ void md_dct_operands_init(int force_butterflies)
         for (int i = 0; i < 4; i++)
             u.h[i] = (_Float16)(float)d_T32[2 * (t & 15)][4 * (t >> 4) + i];
         s_dct_op[0][t] = u.w[0], s_dct_op[1][t] = u.w[1];
+        for (int i = 0; i < 4; i++) { /* diag(C8, C8): the chroma pair of a 16x16 unit as ONE 16x16 product (md_chroma_pair8) */
+            const int r = t & 15, k = 4 * (t >> 4) + i;
+            u.h[i] = (_Float16)(float)((r >> 3) == (k >> 3) ? d_T32[4 * (r & 7)][k & 7] : 0);
+        }
+        s_dct_op[10][t] = u.w[0], s_dct_op[11][t] = u.w[1];
         for (int sl = 0; sl < 4; sl++) {
             for (int i = 0; i < 4; i++)
                 u.h[i] = (_Float16)(float)d_T32[t & 31][8 * sl + 4 * (t >> 5) + i];
@@ -606,6 +611,89 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
     o.nz = nz, o.d0 = nz ? d0 : d1, o.d1 = d1, o.bits = nz ? (uint32_t)__shfl((int)b32, 0) : 0u;
     MD_TR(55);
     return o;
+}
+
+/* BOTH 8x8 chroma transform units of a 16x16 unit's survivor (FullLoop_R + CuFullDistortionFastTuMode_R, one call per plane in md_chroma_tu) as ONE 16x16 product on the
+ * matrix cores: residual and transform matrix block-diagonal - diag(Cb, Cr), diag(C8, C8) - so that C X C^T = diag(C8 Cb C8^T, C8 Cr C8^T).  The register butterflies
+ * keep 8 of 64 lanes busy per plane (~1.3 K issue slots each); this form transforms and quantises both planes in ~250.  The 8-point Estimate transform has no 16-bit wrap
+ * level: exact for every input, no domain to check (|T1| <= 479 . 255 >> 2 < 2^15; H = T1 >> 6 within +-512, exact in f16).  src / pred: Cb's block, Cr's 1024 bytes
+ * behind (the LCU's chroma source planes and the candidates' chroma predictions both lie that way); out: M.V.flc[b][0] (Cr's sums: out[4]).  Same sums, same levels in
+ * qbuf (Cb's 64, then Cr's) as two md_chroma_tu calls. */
+__device__ MD_LEAF_CALL void md_chroma_pair8(int lane, const uint8_t *src, const uint8_t *pred, int16_t *qbuf, int qp, int slice_type, const SvtAmdCabacCost &cost, int type,
+                                             int intra_mode, int pf, const RateTables &rt, MdFl *out)
+{
+    constexpr int N = 8, LG = 3, fs1 = 2, fs2 = 9;
+    MD_LDS(src), MD_LDS(pred), MD_LDS(qbuf), MD_LDS(&cost), MD_LDS(&rt), MD_LDS(out);
+    const int pfc = pf == 2 ? 1 : pf; /* correctedPFMode (EbFullLoop.c:647-652) */
+    const int qpRem = qp % 6, qpPer = qp / 6;
+    const uint32_t QF = qpRem == 0 ? 26214u : qpRem == 1 ? 23302u : qpRem == 2 ? 20560u : qpRem == 3 ? 18396u : qpRem == 4 ? 16384u : 14564u;
+    const int FFv = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    const int tshift = 7 - LG, shiftedQBits = 14 + qpPer + tshift;
+    const uint32_t offs = ((slice_type == 2 || slice_type == 3) ? 171u : 85u) << (shiftedQBits - 9);
+    const int shiftedFFunc = qpPer > 8 ? FFv << (qpPer - 2) : FFv << qpPer;
+    const int shiftNum = qpPer > 8 ? 20 - 14 - tshift - 2 : 20 - 14 - tshift, iq_offset = 1 << (shiftNum - 1);
+    const int area = N >> pfc;
+    const int j = lane & 15, g = lane >> 4, plane = j >> 3;
+    const bool valid = (g >> 1) == plane; /* the lane's four K slots lie in its row's diagonal block */
+    const uint8_t *s_ = src + plane * 1024 + (j & 7) * 32 + 4 * (g & 1), *p_ = pred + plane * 1024 + (j & 7) * N + 4 * (g & 1);
+    const uint32_t a = valid ? *reinterpret_cast<const uint32_t *>(s_) : 0u, b = valid ? *reinterpret_cast<const uint32_t *>(p_) : 0u;
+    const md_v4h A = md_h4((int)(a & 0xFF) - (int)(b & 0xFF), (int)((a >> 8) & 0xFF) - (int)((b >> 8) & 0xFF), (int)((a >> 16) & 0xFF) - (int)((b >> 16) & 0xFF),
+                           (int)(a >> 24) - (int)(b >> 24));
+    const md_v4h C = md_dct_op(10, lane);
+    const md_v4f z = {0.f, 0.f, 0.f, 0.f};
+    const md_v4f t1 = __builtin_amdgcn_mfma_f32_16x16x16f16(A, C, z, 0, 0, 0);
+    int t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        t[i] = (int)(int16_t)(((int)t1[i] + (1 << (fs1 - 1))) >> fs1);
+    const md_v4h Hh = md_h4(t[0] >> 6, t[1] >> 6, t[2] >> 6, t[3] >> 6), Lo = md_h4(t[0] & 63, t[1] & 63, t[2] & 63, t[3] & 63);
+    const md_v4f dh = __builtin_amdgcn_mfma_f32_16x16x16f16(C, Hh, z, 0, 0, 0), dl = __builtin_amdgcn_mfma_f32_16x16x16f16(C, Lo, z, 0, 0, 0);
+    unsigned nz = 0, d0 = 0, d1 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = (int)(int16_t)((((int)dh[i] << 6) + (int)dl[i] + (1 << (fs2 - 1))) >> fs2);
+        const int k2 = 4 * g + i; /* coefficient (k2 & 7, j & 7) of plane j >> 3 where the lane is valid */
+        const bool inside = valid && (k2 & 7) < area && (j & 7) < area;
+        int tq = abs(v);
+        tq = (int)__umul24((uint32_t)tq, QF);
+        tq = (int)((uint32_t)tq + offs);
+        tq >>= shiftedQBits;
+        const int q = clip16i(v < 0 ? -tq : tq);
+        const int c = clip16i((__mul24(q, shiftedFFunc) + iq_offset) >> shiftNum);
+        if (inside) {
+            const int df = (int16_t)(v - c);
+            nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
+            qbuf[plane * 64 + (k2 & 7) * N + (j & 7)] = (int16_t)q;
+        }
+    }
+    /* the sums of each half of the wave (lanes 0..31: Cb's coefficients, 32..63: Cr's) */
+    auto halves = [&](unsigned v, unsigned &lo, unsigned &hi) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast15 into rows 1 and 3 */
+        lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    };
+    unsigned nzp[2], d0p[2], d1p[2];
+    halves(nz, nzp[0], nzp[1]), halves(d0, d0p[0], d0p[1]), halves(d1, d1p[0], d1p[1]);
+    EP_WAVE_SYNC(); /* qbuf is written */
+    const int lga = LG - pfc, S4 = lga <= 2 ? 1 : 1 << (2 * (lga - 2));
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        const uint32_t b32 = nzp[pl] ? md_coeff_bits(&cost, qbuf + pl * 64, N, lga, nzp[pl], type, intra_mode, 1 + pl, lane, S4, &rt) : 0u;
+        const uint32_t bits = nzp[pl] ? (uint32_t)__shfl((int)b32, 0) : 0u;
+        if (lane == 0) { /* md_chroma_tu's scaling of the sums: distortions >> 2 (7 - log2 N), bits << 10 >> 15 */
+            constexpr int sh = 2 * (7 - LG);
+            MdFl o;
+            o.nz = nzp[pl];
+            o.d0 = (uint32_t)(((unsigned long long)(nzp[pl] ? d0p[pl] : d1p[pl]) + (1ull << (sh - 1))) >> sh);
+            o.d1 = (uint32_t)(((unsigned long long)d1p[pl] + (1ull << (sh - 1))) >> sh);
+            o.bits = (uint32_t)((((unsigned long long)bits) << 10) >> 15);
+            out[4 * pl] = o;
+        }
+    }
+    EP_WAVE_SYNC();
 }
 
 /* PerformInverseTransformRecon of the winner (Codec/EbProductCodingLoop.c:1334-1414): EstimateInvTransform of the de-quantised
@@ -1613,40 +1701,52 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             if (fresh64) /* every wave is done with the fresh luma predictions in the waves' scratch before a chroma block lands there */
                 __syncthreads();
             const int Cn = N >> 1, lgc = lgN - 1, Tc = N == 64 ? 16 : Cn, ntu = N == 64 ? 4 : 1;
-            /* the waves DRAW the (survivor, plane) tasks as they get free: a luma unit with levels to price takes twice the time of one without, a wave without a luma
-             * unit starts at once - no fixed assignment fits */
+            /* the waves DRAW the chroma tasks as they get free: a luma unit with levels to price takes twice the time of one without, a wave without a luma unit starts at
+             * once - no fixed assignment fits.  A task = (survivor, plane); the 8x8 chroma pair of a 16x16 unit's survivor is ONE task on the matrix cores (md_chroma_pair8). */
+            const bool pair8 = N == 16 && !s_md_force_bfly;
+            const int ntk = pair8 ? nfull : 2 * nfull;
             for (;;) {
                 unsigned got = 0;
                 if (lane == 0)
                     got = atomicAdd(&M.V.task_ctr2, 1u);
                 const int tk = (int)md_rl(got, 0);
-                if (tk >= 2 * nfull)
+                if (tk >= ntk)
                     break;
-                const int f = tk >> 1, pl = tk & 1, b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b);
+                const int f = pair8 ? tk : tk >> 1, pl0 = pair8 ? 0 : tk & 1, pl1 = pair8 ? 2 : pl0 + 1, b = (int)((best >> (4 * f)) & 15u), ci = buf_cand(b);
                 const uint32_t c0 = md_rl(cw.w[0], ci);
                 const int cdtype = (int)(c0 & 0xFF), cdmode = (int)((c0 >> 8) & 0xFF);
-                const uint8_t *pred;
+                const uint8_t *pred; /* plane 0's block; plane 1's 1024 bytes behind */
                 if (cdtype == MD_INTER && kept_pred(ci)) {
-                    pred = M.V.cpred_c[(int)md_rl((uint32_t)slot, ci)][pl];
+                    pred = M.V.cpred_c[(int)md_rl((uint32_t)slot, ci)][0];
                 } else {
-                    uint8_t *pw = M.V.wpred_c(wave, pl);
-                    if (cdtype == MD_INTER) {
-                        md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], ci) & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw, &M.V.rwc);
-                    } else {
-                        const int16_t *use = M.V.refc[pl];
-                        const int dcv = cdmode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
-                        for (int e = lane; e < Cn * Cn; e += 64)
-                            pw[e] = (uint8_t)pu_predict(cdmode, Cn, lgc, use, e & (Cn - 1), e >> lgc, dcv, false, 255);
-                        EP_WAVE_SYNC();
+                    uint8_t *pw0 = M.V.wpred_c(wave, 0);
+                    for (int pl = pl0; pl < pl1; pl++) {
+                        uint8_t *pw = pw0 + pl * 1024;
+                        if (cdtype == MD_INTER) {
+                            md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], ci) & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw,
+                                                   &M.V.rwc);
+                        } else {
+                            const int16_t *use = M.V.refc[pl];
+                            const int dcv = cdmode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
+                            for (int e = lane; e < Cn * Cn; e += 64)
+                                pw[e] = (uint8_t)pu_predict(cdmode, Cn, lgc, use, e & (Cn - 1), e >> lgc, dcv, false, 255);
+                            EP_WAVE_SYNC();
+                        }
                     }
-                    pred = pw;
+                    pred = pw0;
                 }
+                if (pair8) {
+                    md_chroma_pair8(lane, &M.V.src_c[0][(st.y >> 1) * 32 + (st.x >> 1)], pred, M.qbuf[wave], (int)P.chroma_qp, (int)P.slice_type, M.cost, cdtype, cdmode, pf, M.rt,
+                                    &M.V.flc[b][0][0]);
+                    continue;
+                }
+                const int pl = pl0;
                 for (int tu = 0; tu < ntu; tu++) {
                     const int ox = ntu == 1 ? 0 : (tu & 1) << 4, oy = ntu == 1 ? 0 : (tu >> 1) << 4;
                     uint32_t nz;
                     unsigned long long d[2], bt;
-                    md_chroma_tu(lane, Tc, &M.V.src_c[pl][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt, cdtype, cdmode,
-                                 1 + pl, pf, &nz, d, &bt);
+                    md_chroma_tu(lane, Tc, &M.V.src_c[pl][((st.y >> 1) + oy) * 32 + (st.x >> 1) + ox], pred + pl * 1024 + oy * Cn + ox, Cn, M.tiles[wave], M.qbuf[wave], P, M.cost, M.rt,
+                                 cdtype, cdmode, 1 + pl, pf, &nz, d, &bt);
                     if (lane == 0) {
                         MdFl o;
                         o.nz = nz, o.d0 = (uint32_t)d[0], o.d1 = (uint32_t)d[1], o.bits = (uint32_t)bt;
