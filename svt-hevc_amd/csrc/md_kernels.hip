@@ -147,7 +147,11 @@ struct MdClosedLoop {
     int16_t recon_coeff[MD_MAX_BUF][32 * 32];
     uint8_t best_rec[4][64 * 64];
 };
+#ifdef MD_TRACE
+#define MD_PRED_SLOTS 4 /* (the trace buffer needs the room in LDS; a fifth kept candidate is predicted again by the full loop) */
+#else
 #define MD_PRED_SLOTS 5 /* one motion-estimation candidate + the merge candidates (two or three at the presets' mvMergeSkipModeCount) are evaluated per unit */
+#endif
 struct MdInterShared {
     /* a wave's chroma prediction of the candidate it works on: the first half of its luma scratch (a wave's tasks follow one another, the luma block is spent by then) */
     __device__ __forceinline__ uint8_t *wpred_c(int wave, int pl) { return wpred[wave] + pl * 1024; }
@@ -497,17 +501,25 @@ __device__ MD_LEAF_CALL MdFl md_full_loop_unit(int lane, const uint8_t *src, int
         if (on_matrix_cores) {
             MD_TR(52);
             const int k = lane & (N - 1);
+            /* the quantiser without a branch per coefficient (a lane's coefficients lie inside or outside the quantised area one by one: each test was an exec-mask
+             * region of its own): a coefficient outside contributes zeros to the sums and lands in a word of the buffer nobody reads */
+            const bool col_in = k < area;
 #pragma unroll
             for (int i = 0; i < N * N / 64; i++) {
                 const int k2 = N == 16 ? 4 * (lane >> 4) + i : (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); /* the accumulator's row */
-                const bool inside = k2 < area && k < area;
-                int q, c;
-                quantise(co[i], inside, q, c);
-                if (inside) {
-                    qbuf[k2 * N + k] = (int16_t)q;
-                    if (recon_coeff)
-                        recon_coeff[k2 * N + k] = (int16_t)c;
-                }
+                const bool inside = col_in && k2 < area;
+                const int v = inside ? co[i] : 0;
+                int tq = abs(v);
+                tq = (int)__umul24((uint32_t)tq, QF);
+                tq = (int)((uint32_t)tq + offs);
+                tq >>= shiftedQBits;
+                const int q = v < 0 ? -tq : tq; /* |q| <= 2^14: no clip */
+                const int c = clip16i((__mul24(q, shiftedFFunc) + iq_offset) >> shiftNum);
+                const int df = (int16_t)(v - c);
+                nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
+                qbuf[k2 * N + k] = (int16_t)q; /* (outside the area: zero, never read) */
+                if (recon_coeff && inside)
+                    recon_coeff[k2 * N + k] = (int16_t)c;
             }
         }
     }
@@ -651,20 +663,19 @@ __device__ MD_LEAF_CALL void md_chroma_pair8(int lane, const uint8_t *src, const
     unsigned nz = 0, d0 = 0, d1 = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int v = (int)(int16_t)((((int)dh[i] << 6) + (int)dl[i] + (1 << (fs2 - 1))) >> fs2);
         const int k2 = 4 * g + i; /* coefficient (k2 & 7, j & 7) of plane j >> 3 where the lane is valid */
         const bool inside = valid && (k2 & 7) < area && (j & 7) < area;
+        const int v = inside ? (int)(int16_t)((((int)dh[i] << 6) + (int)dl[i] + (1 << (fs2 - 1))) >> fs2) : 0; /* (no branch per coefficient: one outside adds zeros) */
         int tq = abs(v);
         tq = (int)__umul24((uint32_t)tq, QF);
         tq = (int)((uint32_t)tq + offs);
         tq >>= shiftedQBits;
-        const int q = clip16i(v < 0 ? -tq : tq);
+        const int q = v < 0 ? -tq : tq; /* |q| <= 2^14 */
         const int c = clip16i((__mul24(q, shiftedFFunc) + iq_offset) >> shiftNum);
-        if (inside) {
-            const int df = (int16_t)(v - c);
-            nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
+        const int df = (int16_t)(v - c);
+        nz += q != 0, d0 += (uint32_t)__mul24(df, df), d1 += (uint32_t)__mul24(v, v);
+        if (valid)
             qbuf[plane * 64 + (k2 & 7) * N + (j & 7)] = (int16_t)q;
-        }
     }
     /* the sums of each half of the wave (lanes 0..31: Cb's coefficients, 32..63: Cr's) */
     auto halves = [&](unsigned v, unsigned &lo, unsigned &hi) {
@@ -1241,10 +1252,13 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
     const uint32_t sfb0 = P.rates.splitFlagBits[0], sfb1 = P.rates.splitFlagBits[1], sfb2 = P.rates.splitFlagBits[2]; /* SplitFlagRate of an unsplit unit, by context */
     const bool tmvp_on = M.V.X.tmvp_enable != 0;
     const unsigned long long lanebit = 1ull << lane, below = lanebit - 1ull;
+    /* StopSplitCondition's thresholds of the three depths: what the picture and the LCU fix of md_stop_split (its tables are memory on the device: two dependent loads per
+     * call on wave 0's serial stretch of every unit otherwise) */
+    const uint32_t ss_thr0 = md_stop_split_threshold(&Ph, &Lh, 0), ss_thr1 = md_stop_split_threshold(&Ph, &Lh, 1), ss_thr2 = md_stop_split_threshold(&Ph, &Lh, 2);
+    int cuIdx = M.cu_idx;
     for (;;) {
         MD_TR(10);
         /* ---- the unit (every thread alike) ---- */
-        const int cuIdx = M.cu_idx;
         const uint4 ur = M.V.unit_tab[cuIdx]; /* (md_stats of the unit is ~40 instructions and a dependent read of the leaf list: tabulated with the LCU's inputs) */
         const int leaf = (int)ur.z;
         MdStats st;
@@ -1304,17 +1318,19 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
             cw.w[0] = MD_INTER, cw.w[1] = cw.w[2] = cw.w[3] = cw.w[4] = cw.w[5] = cw.w[6] = cw.w[7] = 0;
             if (wave == 1) {
                 /* both AMVP lists side by side, then Me2Nx2NCandidatesInjection: a lane per motion-estimation candidate */
+                /* the unit's motion-estimation record: requested BEFORE the lists are built (it depends on no neighbour), used behind them */
+                static_assert(sizeof(SvtAmdMeCuResult) == 24, "six words: vectors, distortions, directions | count");
+                const uint32_t *mew = reinterpret_cast<const uint32_t *>(&M.V.me[md_raster_index(&st)]);
+                const uint32_t me_v0 = mew[0], me_v1 = mew[1], me_dw = mew[5], me_dist = mew[2 + (lane < 3 ? lane : 0)];
                 uint32_t pa0, pa1;
                 const int num = md_amvp_one_list(K, M.V.X, MD_NB_ARGS(w0, w1, w2), map, tp, list, &pa0, &pa1);
                 MD_TR(13);
-                const SvtAmdMeCuResult *me = &M.V.me[md_raster_index(&st)];
-                if (lane < 3 && lane < me->total_me_candidate_index) {
-                    const int dir = me->direction[lane];
+                if (lane < 3 && lane < (int)(me_dw >> 24)) {
+                    const int dir = (int)((me_dw >> (8 * lane)) & 0xFFu);
                     if (!(dir == MD_BI && Ph.depth_mode == 0 && Lh.lcu_md_mode == 10)) {
                         keep = true;
-                        MdCand &c = cw.c;
-                        c.dist_ready = 1, c.me_dist = me->distortion[lane], c.dir = (uint8_t)dir;
-                        c.mv[0].x = me->x_mv_l0, c.mv[0].y = me->y_mv_l0, c.mv[1].x = me->x_mv_l1, c.mv[1].y = me->y_mv_l1;
+                        cw.w[0] = MD_INTER | (1u << 24); /* type | dist_ready << 24 */
+                        cw.w[1] = me_dist, cw.w[2] = (uint32_t)dir, cw.w[4] = me_v0, cw.w[5] = me_v1;
                     }
                 }
 #pragma unroll
@@ -1845,13 +1861,13 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 u.pred_mode = (uint8_t)wtype, u.skip_flag = 0, u.intra_luma_mode = (uint8_t)(wtype == MD_INTRA ? ((w_c0 >> 8) & 0xFF) : 0x1F);
                 const uint32_t yc = w_kept ? w_ycbf : 0u;
                 u.ycbf = (uint8_t)(N == 64 ? (yc & 0x1E) : (yc & 1));
-                u.inter_dir = (uint8_t)(wtype == MD_INTER ? wdir : 3), u.merge_flag = (uint8_t)(wtype == MD_INTER ? ((w_c2 >> 8) & 0xFF) : 0), u.merge_index = (uint8_t)((w_c2 >> 16) & 0xFF);
-                u.mv[0].x = u.mv[0].y = u.mv[1].x = u.mv[1].y = 0;
-                if (wtype == MD_INTER) {
-                    if (wdir != MD_L1)
-                        u.mv[0].x = (int16_t)(w_mv0 & 0xFFFF), u.mv[0].y = (int16_t)(w_mv0 >> 16);
-                    if (wdir != MD_L0)
-                        u.mv[1].x = (int16_t)(w_mv1 & 0xFFFF), u.mv[1].y = (int16_t)(w_mv1 >> 16);
+                { /* inter_dir | merge_flag | merge_index | pad, mv[0], mv[1]: three words of the record, three stores */
+                    static_assert(offsetof(MdCu, inter_dir) == 8 && offsetof(MdCu, merge_flag) == 9 && offsetof(MdCu, merge_index) == 10 && offsetof(MdCu, mv) == 12 && sizeof(MdMv) == 4,
+                                  "the unit's record, words 2..4");
+                    const bool wi = wtype == MD_INTER;
+                    uint32_t *q = reinterpret_cast<uint32_t *>(&u.inter_dir);
+                    q[0] = (wi ? (uint32_t)wdir : 3u) | ((wi ? (w_c2 >> 8) & 0xFFu : 0u) << 8) | (((w_c2 >> 16) & 0xFFu) << 16);
+                    q[1] = wi && wdir != MD_L1 ? w_mv0 : 0u, q[2] = wi && wdir != MD_L0 ? w_mv1 : 0u;
                 }
                 u.merge_cost = w_kept ? w_mc : 0, u.skip_cost = w_kept ? w_sc : 0;
                 u.y_coeff_bits = w_kept ? w_bits : 0, u.y_dist[0] = w_kept ? w_d0 : 0, u.y_dist[1] = w_kept ? w_d1 : 0;
@@ -1881,7 +1897,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 } else if (st.ordinal < 4 || st.depth == 0) {
                     /* ProductPerformInterDepthDecision (md_inter_depth_decision) of a unit that is not the last of its four siblings: no depth is compared, the unit becomes a
                      * leaf when the leaf list or StopSplitCondition says so and the counters of finished blocks move */
-                    if (split_now == 0 || md_stop_split(&Ph, &Lh, st.depth, w_kept ? (uint32_t)w_d0 : 0u)) {
+                    if (split_now == 0 || ((w_kept ? (uint32_t)w_d0 : 0u) < (st.depth == 0 ? ss_thr0 : st.depth == 1 ? ss_thr1 : st.depth == 2 ? ss_thr2 : 0u))) {
                         u.split = 0;
                         if (st.depth == 1)
                             M.S.g16 = (uint8_t)(g16 + 1);
@@ -1890,7 +1906,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                     }
                     last = leaf;
                 } else { /* open loop: no reconstruction to wait for, the inter-depth decision follows at once */
-                    last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, md_stop_split(&Ph, &Lh, st.depth, w_kept ? (uint32_t)w_d0 : 0u));
+                    last = md_inter_depth_decision(&P, &M.S, leaf, lcu_x, lcu_y, 0, ((w_kept ? (uint32_t)w_d0 : 0u) < (st.depth == 0 ? ss_thr0 : st.depth == 1 ? ss_thr1 : st.depth == 2 ? ss_thr2 : 0u)));
                 }
                 last_v = last, upd_v = M.S.cu[last].split == 0;
                 /* the next unit (CalculateNextCuIndex :1261): the loop stands on `cur` - the tested unit, or the parent a partition exit fell back to */
@@ -1938,7 +1954,8 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
         __syncthreads();
         MD_TR(39);
         MD_PROF(8);
-        if (M.done)
+        cuIdx = M.cu_idx; /* (the next unit, or the end of the leaf list: one LDS round trip for both) */
+        if (cuIdx >= (int)Lh.leaf_count)
             break;
     }
 }

@@ -1006,7 +1006,8 @@ MD_FN int md_skip_small_cu(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, const
 
 /* StopSplitCondition (Codec/EbFullLoop.c:1392-1455): depth thresholds on the unit's luma distortion; the tables (:14-70) depend on the
  * temporal layer only (layer <= hierarchical levels) */
-MD_FN int md_stop_split(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int depth, uint32_t fullDistortion)
+/* ... as a threshold of the unit's depth that the LCU fixes (0: the condition never holds): the device derives the three once per LCU */
+MD_FN uint32_t md_stop_split_threshold(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int depth)
 {
     const uint16_t d0[2][6] = {{1000, 4000, 9500, 3000, 3000, 3000}, {0, 1000, 7000, 9500, 9500, 9500}};
     const uint16_t d1[2][6] = {{0, 2000, 5500, 9500, 9500, 9500}, {0, 1500, 1500, 1500, 1500, 1500}};
@@ -1018,7 +1019,11 @@ MD_FN int md_stop_split(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int dept
     if (!L->is_complete || L->no_stop_split)
         return 0;
     const int e = L->edge_block != 0, t = P->temporal_layer > 5 ? 5 : P->temporal_layer;
-    return (depth == 0 && fullDistortion < d0[e][t]) || (depth == 1 && fullDistortion < d1[e][t]) || (depth == 2 && fullDistortion < d2[e][t]);
+    return depth == 0 ? d0[e][t] : depth == 1 ? d1[e][t] : depth == 2 ? d2[e][t] : 0u;
+}
+MD_FN int md_stop_split(const SvtAmdMdPicture *P, const SvtAmdMdLcu *L, int depth, uint32_t fullDistortion)
+{
+    return fullDistortion < md_stop_split_threshold(P, L, depth);
 }
 
 /* the transform-tree flag rates of a unit with chroma (shared by InterFullCost :1753-1950 and MergeSkipFullCost :2107-2355; rootCbf != 0): the luma part

@@ -154,8 +154,21 @@ __device__ __forceinline__ uint32_t coeff_bits_lanes(const SvtAmdCabacCost &c_co
                 const int k_low = (sub == 0 || (lone && !isLast)) ? 1 : 0;
                 int nnz = 0, phase = 0;
                 uint32_t lev = 0;
+                /* the highest position any lane of the wave has something to price at (its last significant coefficient in the TU's last sub-block, 15 in a coded
+                 * sub-block before it), wave-uniform: the positions above are skipped by a scalar branch.  A TU whose levels sit in the first few positions of the DC
+                 * sub-block - the common case of the mode decision's full loops - walks those few, not sixteen. */
+                int kmax;
+                {
+                    const int my_top = isLast ? posLast : 15;
+                    kmax = __ballot(my_top >= 8) != 0 ? 8 : 0;
+                    kmax += __ballot(my_top >= kmax + 4) != 0 ? 4 : 0;
+                    kmax += __ballot(my_top >= kmax + 2) != 0 ? 2 : 0;
+                    kmax += __ballot(my_top >= kmax + 1) != 0 ? 1 : 0;
+                }
 #pragma unroll
                 for (int k = 15; k >= 0; k--) {
+                    if (k > kmax)
+                        continue;
                     const uint32_t f = (sig >> k) & 1u;
                     bool take = (k == inferred);
                     if (k <= k_start && k >= k_low) {
