@@ -3372,7 +3372,9 @@ struct MdFlight {
     int dev = 0;
     double t_granted = 0;
     /* waits until the launch fits; returns the grid granted: `wide` when the device is nearly idle, `narrow` otherwise */
-    int acquire(int device, int budget, int wide, int narrow, int prio)
+    /* lone: the width of a launch that finds the device without any other mode-decision launch (two workgroups per LCU of the widest front); wide / narrow: round 5's pair for
+     * a device that is shared - the encoder's steady state is untouched by `lone` */
+    int acquire(int device, int budget, int lone, int wide, int narrow, int prio)
     {
         const double t0 = flight_now_us();
         dev = device & 63;
@@ -3395,7 +3397,7 @@ struct MdFlight {
                 grant = wide;
                 return fd.flights < count_limit;
             }
-            grant = (waiting_here == 1 && fd.wgs + wide <= budget / 3) ? wide : narrow;
+            grant = (waiting_here == 1 && fd.flights == 0) ? lone : (waiting_here == 1 && fd.wgs + wide <= budget / 3) ? wide : narrow;
             return fd.wgs + grant <= budget || fd.flights == 0;
         });
         for (size_t i = 0; i < g_flight_wait.size(); i++)
@@ -3403,7 +3405,7 @@ struct MdFlight {
                 g_flight_wait.erase(g_flight_wait.begin() + (long)i);
                 break;
             }
-        g_flight_stats.calls++, g_flight_stats.wide += grant == wide && wide != narrow, g_flight_stats.wgs_seen += (unsigned long long)fd.wgs;
+        g_flight_stats.calls++, g_flight_stats.wide += (grant == wide || grant == lone) && wide != narrow, g_flight_stats.wgs_seen += (unsigned long long)fd.wgs;
         fd.flights++, fd.wgs += grant, held = grant;
         l.unlock();
         t_granted = flight_now_us();
@@ -3668,21 +3670,29 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
      * The wavefront of a picture is (W/64 + 1) / 2 LCUs wide at its widest and 16 on average at 4K; one workgroup per LCU of the widest front plus a few for the encode
      * passes behind it costs a lone picture 3 - 4 % and lets six pictures' launches run side by side (profiles/r04_w_md_flights_*: the kernel keeps its 51 ms with
      * twelve calls in flight, 100 pictures/s - given enough hardware queues, svt_amd_runtime_env_defaults). */
-    int grid = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1) + 2 + (wl + 7) / 8;
+    /* Round 6: a lone picture on an idle device gets two workgroups per LCU of the widest front again - behind an LCU's decisions its workgroup spends ~15 % of the LCU's
+     * time on the merge / skip decisions with chroma and the work record, ahead of them on the next LCU's inputs, and with one workgroup per LCU of the front a ready LCU
+     * waits for a workgroup (4K: 40 / 48 / 56 / 64 workgroups = 27.1 / 27.05 / 26.85 / 26.7 ms for a layer-2 picture).  The widths a launch gets while other pictures' launches
+     * are on the device - the encoder's steady state - stay what round 5 measured best (40 / 20 at 4K). */
+    const int front = ((wl + 1) / 2 < hl ? (wl + 1) / 2 : hl) * (tiles > 0 ? tiles : 1);
+    int lone = 2 * front + 2;
+    int grid = front + 2 + (wl + 7) / 8;
     int narrow = (grid + 1) / 2 < 8 ? 8 : (grid + 1) / 2; /* what the launch gets while other pictures share the device (MdFlight) */
     {   /* measurement (SVT_AMD_MD_GRID): a fixed launch width */
         const char *fg = getenv("SVT_AMD_MD_GRID");
         const int forced = fg ? atoi(fg) : 0;
         if (forced > 0)
-            grid = narrow = forced;
+            lone = grid = narrow = forced;
         static const int fnarrow = getenv("SVT_AMD_MD_NARROW") ? atoi(getenv("SVT_AMD_MD_NARROW")) : 0;
         if (fnarrow > 0)
             narrow = fnarrow;
         static const int fwide = getenv("SVT_AMD_MD_WIDE") ? atoi(getenv("SVT_AMD_MD_WIDE")) : 0;
         if (fwide > 0)
-            grid = fwide;
+            lone = grid = fwide;
     }
     grid = grid > n_active ? n_active : grid > 224 ? 224 : grid;
+    lone = lone > n_active ? n_active : lone > 224 ? 224 : lone;
+    lone = lone < grid ? grid : lone;
     narrow = narrow > grid ? grid : narrow;
     m->d.cost = pic->has_cost ? pic->d_cost : nullptr;
     memcpy(m->h_stage + MD_STAGE_D, &m->d, sizeof(m->d));
@@ -3691,7 +3701,7 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     MdFlight flight;
     /* the inputs first (a call that waits for its place holds no CU and no copy engine meanwhile) */
     HIP_TRY(hipStreamSynchronize(st));
-    grid = flight.acquire(ctx->device, md_wg_budget(ctx->device), grid, narrow, (int)P->temporal_layer);
+    grid = flight.acquire(ctx->device, md_wg_budget(ctx->device), lone, grid, narrow, (int)P->temporal_layer);
     m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
     if (X && bps == 1)
