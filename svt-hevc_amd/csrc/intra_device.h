@@ -56,5 +56,72 @@ __device__ __forceinline__ int pu_predict(int mode, int N, int lg, const int16_t
     return ((32 - f) * s[0] + f * s[1] + 16) >> 5;
 }
 
+/* FOUR samples at once - (x .. x + 3, y) for the planar, DC and vertical-class modes (0, 1, 18..34), (x, y .. y + 3) for the horizontal-class modes (2..17): the samples of a
+ * run share the row's (column's) projection and weights, and a wave that predicts a sample per lane and step spends its time on exactly that set-up (the mode decision's
+ * loops are bound by instructions issued per wave).  Same values as pu_predict sample for sample; x (y) a multiple of 4, N >= 4. */
+__device__ __forceinline__ bool pu_horizontal_class(int mode) { return mode >= 2 && mode < 18; }
+__device__ __forceinline__ void pu_predict4(int mode, int N, int lg, const int16_t *r, int x, int y, int dc, bool lumaEdge, int maxv, int (&o)[4])
+{
+    const int16_t *left = r, *top = r + 2 * N + 1;
+    const int tl = r[2 * N];
+    if (mode == 0) {
+        const int l = left[y], tn = top[N], ln = left[N];
+        const int base = (N - 1 - y) , c0 = (y + 1) * ln + N;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = ((N - 1 - (x + k)) * l + (x + k + 1) * tn + base * top[x + k] + c0) >> (lg + 1);
+        return;
+    }
+    if (mode == 1) {
+        const bool edge = lumaEdge && N < 32;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = dc;
+        if (edge) {
+            if (y == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    o[k] = (top[x + k] + 3 * dc + 2) >> 2;
+                if (x == 0)
+                    o[0] = (left[0] + top[0] + 2 * dc + 2) >> 2;
+            } else if (x == 0) {
+                o[0] = (left[y] + 3 * dc + 2) >> 2;
+            }
+        }
+        return;
+    }
+    if (mode == 26) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = top[x + k];
+        if (lumaEdge && N < 32 && x == 0)
+            o[0] = min(maxv, max(0, top[0] + ((left[y] - tl) >> 1)));
+        return;
+    }
+    if (mode == 10) { /* (horizontal class: a run down the column) */
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = left[y + k];
+        if (lumaEdge && N < 32 && y == 0)
+            o[0] = min(maxv, max(0, left[0] + ((top[x] - tl) >> 1)));
+        return;
+    }
+    const bool vert = mode >= 18;
+    const int d = vert ? mode - 26 : 10 - mode;
+    const int a = d < 0 ? -pu_ang(-d) : pu_ang(d);
+    const int inv = d < 0 ? pu_inv(-d) : 0;
+    const int u = vert ? x : y, v = vert ? y : x; /* the run goes along u */
+    const int16_t *mainr = vert ? top : left, *side = vert ? left : top;
+    const int pos = (v + 1) * a, i = pos >> 5, f = pos & 31;
+    int s[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int idx = u + i + 1 + k;
+        s[k] = idx > 0 ? mainr[idx - 1] : idx == 0 ? tl : side[((-idx * inv + 128) >> 8) - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        o[k] = ((32 - f) * s[k] + f * s[k + 1] + 16) >> 5;
+}
 
 #endif

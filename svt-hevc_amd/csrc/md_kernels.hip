@@ -50,6 +50,9 @@
 #else
 #define MD_LDS(ptr) ((void)0)
 #endif
+#ifndef MD_RESTAGE_THR
+#define MD_RESTAGE_THR 16 /* quarter samples: a neighbour's vector this far from the staged window's centre re-stages the window behind the wait (md_lcu) */
+#endif
 #ifndef MD_LEAF_CALL
 #define MD_LEAF_CALL __noinline__ /* the heavy leaves of the unit chain (interpolation, transform unit) as functions: one copy of their code and registers of their own */
 #endif
@@ -322,6 +325,43 @@ __device__ __forceinline__ int md_dc_value(const int16_t *ref, int n, int lgn, i
     for (int o = 32; o > 0; o >>= 1)
         dc += __shfl_xor(dc, o);
     return (dc + n) >> (lgn + 1);
+}
+
+/* An intra-predicted block of n x n samples by one wave, FOUR samples a lane and step (pu_predict4: a run along the row for the planar, DC and vertical-class modes, down the
+ * column for the horizontal-class ones): stored to dst (pitch n) when dst is given, otherwise measured against src (pitch sp) - the lane's part of the SAD is returned.  One
+ * copy of the predictor for the eight places the mode decision predicts an intra block (a sample per lane and step there: ~200 issue slots per four samples, ~70 here). */
+__device__ MD_LEAF_CALL uint32_t md_intra_block(int mode, int n, int lgn, const int16_t *use, int luma_edge, int lane, const uint8_t *src, int sp, uint8_t *dst)
+{
+    MD_LDS(use);
+    if (src)
+        MD_LDS(src);
+    if (dst)
+        MD_LDS(dst);
+    const int dcv = mode == 1 ? md_dc_value(use, n, lgn, lane) : 0;
+    const bool hc = pu_horizontal_class(mode);
+    uint32_t sad = 0;
+    for (int g = lane; g < (n * n) >> 2; g += 64) {
+        const int a = 4 * (g & ((n >> 2) - 1)), b = g >> (lgn - 2);
+        const int x = hc ? b : a, y = hc ? a : b;
+        int o[4];
+        pu_predict4(mode, n, lgn, use, x, y, dcv, luma_edge != 0, 255, o);
+        if (!hc) {
+            const uint32_t w = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+            if (dst)
+                *reinterpret_cast<uint32_t *>(&dst[y * n + x]) = w;
+            else
+                sad = __builtin_amdgcn_sad_u8(w, *reinterpret_cast<const uint32_t *>(&src[y * sp + x]), sad);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (dst)
+                    dst[(y + k) * n + x] = (uint8_t)o[k];
+                else
+                    sad += (uint32_t)abs(o[k] - (int)src[(y + k) * sp + x]);
+            }
+        }
+    }
+    return sad;
 }
 
 /* ---- the 16x16 and 32x32 forward transforms of the full loops on the MATRIX CORES (round 6) ----------------------------------------------------------------------------
@@ -1521,24 +1561,9 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                             sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(&pr[e]), *reinterpret_cast<const uint32_t *>(&sc[(e >> lgn) * 32 + (e & (n - 1))]), sad);
                     }
                 } else if (luma) {
-                    const int mode = (int)((cw0 >> 8) & 0xFF);
-                    const int16_t *use = M.ref;
-                    const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
-                    for (int e = lane; e < N * N; e += 64) {
-                        const int y = e >> lgN, x = e & (N - 1);
-                        const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
-                        sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
-                    }
+                    sad = md_intra_block((int)((cw0 >> 8) & 0xFF), N, lgN, M.ref, 1, lane, &L.src[st.y * 64 + st.x], 64, nullptr);
                 } else { /* IntraPredictionOl's chroma pair: the chroma mode is always DM (Codec/EbIntraPrediction.c:5530) */
-                    const int mode = (int)((cw0 >> 8) & 0xFF), n = N >> 1, lgn = lgN - 1;
-                    const int16_t *use = M.V.refc[pl - 1];
-                    const int dcv = mode == 1 ? md_dc_value(use, n, lgn, lane) : 0;
-                    const uint8_t *sc = &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)];
-                    for (int e = lane; e < n * n; e += 64) {
-                        const int y = e >> lgn, x = e & (n - 1);
-                        const int v = pu_predict(mode, n, lgn, use, x, y, dcv, false, 255);
-                        sad += (uint32_t)abs(v - (int)sc[y * 32 + x]);
-                    }
+                    sad = md_intra_block((int)((cw0 >> 8) & 0xFF), N >> 1, lgN - 1, M.V.refc[pl - 1], 0, lane, &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)], 32, nullptr);
                 }
                 sad = md_wave_sum(sad);
                 MD_TR(23);
@@ -1698,11 +1723,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                 else
                     md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], pci) & 0xFF), md_rl(cw.w[4], pci), md_rl(cw.w[5], pci), x0, y0, N, 0, lane, M.V.mc[wave], pred, 0, 1, &M.V.rw, &M.V.rwc);
             } else {
-                const int mode = (int)((p0 >> 8) & 0xFF);
-                const int16_t *use = M.ref;
-                const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
-                for (int e = lane; e < N * N; e += 64)
-                    pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
+                md_intra_block((int)((p0 >> 8) & 0xFF), N, lgN, M.ref, 1, lane, nullptr, 0, pred);
                 EP_WAVE_SYNC();
             }
             MD_TR(31);
@@ -1742,10 +1763,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
                             md_predict_inter_plane(M.V.refs, (int)(md_rl(cw.w[2], ci) & 0xFF), md_rl(cw.w[4], ci), md_rl(cw.w[5], ci), x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw,
                                                    &M.V.rwc);
                         } else {
-                            const int16_t *use = M.V.refc[pl];
-                            const int dcv = cdmode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
-                            for (int e = lane; e < Cn * Cn; e += 64)
-                                pw[e] = (uint8_t)pu_predict(cdmode, Cn, lgc, use, e & (Cn - 1), e >> lgc, dcv, false, 255);
+                            md_intra_block(cdmode, Cn, lgc, M.V.refc[pl], 0, lane, nullptr, 0, pw);
                             EP_WAVE_SYNC();
                         }
                     }
@@ -2120,7 +2138,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
             const SvtAmdMeCuResult me0 = M.V.me[0];
             const int mex[2] = {me0.x_mv_l0, me0.x_mv_l1}, mey[2] = {me0.y_mv_l0, me0.y_mv_l1};
             for (int l = 0; l < (P.slice_type == 0 ? 2 : 1); l++)
-                if ((nbu.dir == MD_BI || nbu.dir == l) && (abs(nbu.mv[l].x - mex[l]) > 16 || abs(nbu.mv[l].y - mey[l]) > 16))
+                if ((nbu.dir == MD_BI || nbu.dir == l) && (abs(nbu.mv[l].x - mex[l]) > MD_RESTAGE_THR || abs(nbu.mv[l].y - mey[l]) > MD_RESTAGE_THR))
                     use[l] = true, cmv[l][0] = nbu.mv[l].x, cmv[l][1] = nbu.mv[l].y;
         }
         if (use[0] || use[1]) { /* (uniform: every thread read the same LDS words) */
@@ -2431,24 +2449,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                     }
                 } else if (luma) {
                     const int mode = cd.intra_mode;
-                    const int16_t *use = (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref;
-                    const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
-                    for (int e = lane; e < N * N; e += 64) {
-                        const int y = e >> lgN, x = e & (N - 1);
-                        const int v = pu_predict(mode, N, lgN, use, x, y, dcv, true, 255);
-                        sad += (uint32_t)abs(v - (int)L.src[(st.y + y) * 64 + st.x + x]);
-                    }
+                    sad = md_intra_block(mode, N, lgN, (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref, 1, lane, &L.src[st.y * 64 + st.x], 64, nullptr);
                 } else {
                     if constexpr (INTER) { /* IntraPredictionOl's chroma pair: the chroma mode is always DM (Codec/EbIntraPrediction.c:5530); kept for the full loop like the inter ones */
-                        const int mode = cd.intra_mode, n = N >> 1, lgn = lgN - 1;
-                        const int16_t *use = M.V.refc[pl - 1];
-                        const int dcv = mode == 1 ? md_dc_value(use, n, lgn, lane) : 0;
-                        const uint8_t *sc = &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)];
-                        for (int e = lane; e < n * n; e += 64) {
-                            const int y = e >> lgn, x = e & (n - 1);
-                            const int v = pu_predict(mode, n, lgn, use, x, y, dcv, false, 255);
-                            sad += (uint32_t)abs(v - (int)sc[y * 32 + x]);
-                        }
+                        sad = md_intra_block(cd.intra_mode, N >> 1, lgN - 1, M.V.refc[pl - 1], 0, lane, &M.V.src_c[pl - 1][(st.y >> 1) * 32 + (st.x >> 1)], 32, nullptr);
                     }
                 }
                 sad = md_wave_sum(sad);
@@ -2601,10 +2605,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                 }
             } else {
                 const int mode = pc.intra_mode;
-                const int16_t *use = (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref;
-                const int dcv = mode == 1 ? md_dc_value(use, N, lgN, lane) : 0;
-                for (int e = lane; e < N * N; e += 64)
-                    pred[e] = (uint8_t)pu_predict(mode, N, lgN, use, e & (N - 1), e >> lgN, dcv, true, 255);
+                md_intra_block(mode, N, lgN, (!open_loop && md_mode_filtered(mode, lgN)) ? M.reff : M.ref, 1, lane, nullptr, 0, pred);
                 EP_WAVE_SYNC();
             }
             MD_TR(31);
@@ -2656,11 +2657,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
                         if (cd.type == MD_INTER) {
                             md_predict_inter_plane(M.V.refs, cd, x0, y0, N, 1 + pl, lane, M.V.mc[wave], pw, 0, 1, &M.V.rw, &M.V.rwc);
                         } else {
-                            const int mode = cd.intra_mode;
-                            const int16_t *use = M.V.refc[pl];
-                            const int dcv = mode == 1 ? md_dc_value(use, Cn, lgc, lane) : 0;
-                            for (int e = lane; e < Cn * Cn; e += 64)
-                                pw[e] = (uint8_t)pu_predict(mode, Cn, lgc, use, e & (Cn - 1), e >> lgc, dcv, false, 255);
+                            md_intra_block(cd.intra_mode, Cn, lgc, M.V.refc[pl], 0, lane, nullptr, 0, pw);
                             EP_WAVE_SYNC();
                         }
                         pred = pw;
