@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p tools/_exp
-/opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 ${MD_OPT:--O3} -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -Wno-align-mismatch -Wno-unused-variable \
+/opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 ${MD_OPT:--O3} ${MD_SCHED--mllvm -amdgpu-sched-strategy=max-ilp} -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -Wno-align-mismatch -Wno-unused-variable \
     -c svt-hevc_amd/csrc/md_kernels.hip -o tools/_exp/md_$tag.o
 objs=$(ls svt-hevc_amd/build/*.o | grep -v md_kernels.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_exp/lib_$tag.so tools/_exp/md_$tag.o $objs
