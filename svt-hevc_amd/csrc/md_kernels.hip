@@ -1266,9 +1266,12 @@ union MdCandWords {
 };
 static_assert(sizeof(MdCand) == 32, "a candidate is eight words: type | intra_mode | mpm | dist_ready, me_dist, dir | merge_flag | merge_index | mvp_idx[0], mvp_idx[1], mv[0], mv[1], mvp[0], mvp[1]");
 
+/* PROF: whether the stage marks exist at all - the launches of a profiled call (svt_amd_debug_md_profile) take the instance with them, every other launch the one without:
+ * thirty tests of a flag per unit and wave, and their branches between the stages, are not on the product's path */
+template <bool PROF>
 __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, int lcu_x, int lcu_y, MdShared<true> &M)
 {
-    const bool prof_on = __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
+    const bool prof_on = PROF && __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
     const SvtAmdMdPicture &P = M.pic; /* the rate tables (indexed by contexts): read where they are */
     /* the picture's and the LCU's CONTROLS in registers: a copy of the records' scalar parts, made once per LCU (a control read from LDS is a ~120-clock round trip on
      * a chain whose every stage tests a dozen of them).  Ph / Lh go to the rules that read controls only; the rate tables and the leaf list stay behind P / M.lcu. */
@@ -2076,14 +2079,14 @@ __device__ __forceinline__ void md_lcu_inputs(const MdPictureDev &D, const SvtAm
 }
 
 /* ModeDecisionLcu of one LCU (its inputs are in LDS: md_lcu_inputs): on return M.S holds the decisions, the picture's maps the LCU's final neighbour state */
-template <bool INTER>
+template <bool INTER, bool PROF>
 __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPicture &Pg, int lcu, int lcu_x, int lcu_y, MdShared<INTER> &M)
 {
     /* the picture's controls as the unit loop reads them: the copies md_lcu_inputs left beside the LCU in LDS, not the records in HBM (a unit's scalar stages read dozens
      * of these fields one after the other - each a round trip of its own from global memory) */
     const SvtAmdMdPicture &P = M.pic;
     (void)Pg;
-    const bool prof_on = __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
+    const bool prof_on = PROF && __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     auto &L = M.L;
     const int W = (int)P.width, H = (int)P.height;
@@ -2157,7 +2160,7 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
     const int pf = md_pf_mode(&P);
     constexpr bool NEW_INTER_LOOP = INTER; /* P / B pictures: md_units_inter (round 6); the loop below is the I pictures' */
     if constexpr (NEW_INTER_LOOP)
-        md_units_inter(D, lcu, lcu_x, lcu_y, M);
+        md_units_inter<PROF>(D, lcu, lcu_x, lcu_y, M);
     else
     for (;;) {
         MD_TR(10);
@@ -3043,7 +3046,7 @@ __device__ __forceinline__ void md_make_work(const MdPictureDev &D, const SvtAmd
  * time, for work that is off the picture's critical path and runs 2040 LCUs wide in ~1.5 ms when it is launched on its own).
  * The picture's descriptor (MdPictureDev) comes by POINTER and is copied to LDS once per workgroup: passed by value, its run-time-indexed arrays (src[1 + p], mref[l])
  * forced the whole record into the private segment (110 scratch stores in the prologue, a memory round trip at every use). */
-template <bool INTER, typename T>
+template <bool INTER, typename T, bool PROF>
 __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restrict__ Dp, typename EpTypes<T>::Work *__restrict__ works, int nlcu, int wl, unsigned *ticket,
                                                     unsigned *md_done, const unsigned *__restrict__ order, unsigned epoch)
 {
@@ -3074,7 +3077,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
         const int dep0 = Lc.tile_left ? -1 : lcu - 1;
         const int dep1 = Lc.tile_top ? -1 : (Lc.tile_right || lx + 1 >= wl) ? lcu - wl : lcu - wl + 1;
         if (threadIdx.x == 0) {
-            c_ticket = D.prof ? __builtin_readcyclecounter() : 0;
+            c_ticket = (PROF && D.prof) ? __builtin_readcyclecounter() : 0;
             if (dep0 >= 0)
                 while (__hip_atomic_load(&md_done[dep0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
                     __builtin_amdgcn_s_sleep(2);
@@ -3085,7 +3088,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
         }
         __syncthreads();
         unsigned long long c_wait = 0, c_md = 0;
-        if (D.prof && threadIdx.x == 0) {
+        if (PROF && D.prof && threadIdx.x == 0) {
             c_wait = __builtin_readcyclecounter();
             for (int k = 0; k < 32; k++)
                 M.prof[k] = 0;
@@ -3101,7 +3104,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
             g_md_trace_on = D.trace && lcu == D.trace_lcu && D.trace_unit == 0;
         __syncthreads();
 #endif
-        md_lcu<INTER>(D, P, lcu, lx * 64, ly * 64, M);
+        md_lcu<INTER, PROF>(D, P, lcu, lx * 64, ly * 64, M);
         __syncthreads();
 #ifdef MD_TRACE
         if (D.trace && lcu == D.trace_lcu) {
@@ -3116,7 +3119,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_store(&md_done[lcu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (D.prof && threadIdx.x == 0) {
+        if (PROF && D.prof && threadIdx.x == 0) {
             c_md = __builtin_readcyclecounter();
             unsigned long long *q = D.prof + 16 * (size_t)lcu;
             for (int k = 0; k < 9; k++)
@@ -3136,7 +3139,7 @@ __global__ __launch_bounds__(256) void k_md_picture(const MdPictureDev *__restri
             if constexpr (INTER)
                 md_ep_kinds(D, P, M, lx * 64, ly * 64);
             md_make_work<INTER, T>(D, P, M, lx * 64, ly * 64, works[lcu]);
-            if (D.prof && threadIdx.x == 0)
+            if (PROF && D.prof && threadIdx.x == 0)
                 D.prof[16 * (size_t)lcu + 10] += __builtin_readcyclecounter() - c_md; /* merge / skip decisions with chroma + the work record */
         }
     }
@@ -3701,21 +3704,28 @@ static int md_encode_picture(SvtAmdContext *ctx, SvtAmdEncDecPicture *pic, const
     grid = flight.acquire(ctx->device, md_wg_budget(ctx->device), lone, grid, narrow, (int)P->temporal_layer);
     m->grid = grid;
     HIP_TRY(hipEventRecord(m->ev_k0, st));
-    if (X && bps == 1)
-        hipLaunchKernelGGL((k_md_picture<true, uint8_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+    const bool profiled = m->d.prof != nullptr; /* (the P / B kernels exist with and without the stage marks) */
+    if (X && bps == 1 && !profiled)
+        hipLaunchKernelGGL((k_md_picture<true, uint8_t, false>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+                           m->d_md_done, d_order, pic->epoch);
+    else if (X && bps == 1)
+        hipLaunchKernelGGL((k_md_picture<true, uint8_t, true>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
 #ifdef MD_INTER8_ONLY
     else
         return SVT_AMD_ERR_BAD_PARAM;
 #else
     else if (bps == 1)
-        hipLaunchKernelGGL((k_md_picture<false, uint8_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<false, uint8_t, true>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork *)m->d_works, n_active, wl, m->d_md_ticket,
+                           m->d_md_done, d_order, pic->epoch);
+    else if (X && !profiled)
+        hipLaunchKernelGGL((k_md_picture<true, uint16_t, false>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
     else if (X)
-        hipLaunchKernelGGL((k_md_picture<true, uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<true, uint16_t, true>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
     else
-        hipLaunchKernelGGL((k_md_picture<false, uint16_t>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
+        hipLaunchKernelGGL((k_md_picture<false, uint16_t, true>), dim3((unsigned)grid), dim3(256), 0, st, m->d_D, (SvtAmdLcuWork16 *)m->d_works, n_active, wl, m->d_md_ticket,
                            m->d_md_done, d_order, pic->epoch);
 #endif
     HIP_TRY(hipGetLastError());
