@@ -1268,7 +1268,9 @@ static_assert(sizeof(MdCand) == 32, "a candidate is eight words: type | intra_mo
 
 /* PROF: whether the stage marks exist at all - the launches of a profiled call (svt_amd_debug_md_profile) take the instance with them, every other launch the one without:
  * thirty tests of a flag per unit and wave, and their branches between the stages, are not on the product's path */
-template <bool PROF>
+/* CFULL: the LCU is CHROMA_MODE_FULL (chroma in both loops of every candidate) - an instance of the loop per chroma mode, chosen per LCU: the luma-only LCUs' instance carries
+ * none of the chroma tasks' code between its stages */
+template <bool PROF, bool CFULL>
 __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, int lcu_x, int lcu_y, MdShared<true> &M)
 {
     const bool prof_on = PROF && __builtin_amdgcn_readfirstlane((int)(D.prof != nullptr)) != 0;
@@ -1289,7 +1291,7 @@ __device__ __forceinline__ void md_units_inter(const MdPictureDev &D, int lcu, i
     const SvtAmdOisLcuResult *ois = &M.ois;
     const int pf = md_pf_mode(&Ph);
     /* what the picture and the LCU fix, read once */
-    const bool cfull = Lh.chroma_encode_mode == 1; /* CHROMA_MODE_FULL: chroma in both loops of every candidate */
+    constexpr bool cfull = CFULL; /* CHROMA_MODE_FULL (Lh.chroma_encode_mode == 1): chroma in both loops of every candidate */
     const bool tile_l = Lh.tile_left != 0, tile_t = Lh.tile_top != 0, tile_r = Lh.tile_right != 0;
     const MdListConsts K = md_list_consts(Ph, M.V.X);
     const uint32_t sfb0 = P.rates.splitFlagBits[0], sfb1 = P.rates.splitFlagBits[1], sfb2 = P.rates.splitFlagBits[2]; /* SplitFlagRate of an unsplit unit, by context */
@@ -2160,7 +2162,10 @@ __device__ __forceinline__ void md_lcu(const MdPictureDev &D, const SvtAmdMdPict
     const int pf = md_pf_mode(&P);
     constexpr bool NEW_INTER_LOOP = INTER; /* P / B pictures: md_units_inter (round 6); the loop below is the I pictures' */
     if constexpr (NEW_INTER_LOOP)
-        md_units_inter<PROF>(D, lcu, lcu_x, lcu_y, M);
+        if (M.lcu.chroma_encode_mode == 1)
+            md_units_inter<PROF, true>(D, lcu, lcu_x, lcu_y, M);
+        else
+            md_units_inter<PROF, false>(D, lcu, lcu_x, lcu_y, M);
     else
     for (;;) {
         MD_TR(10);
